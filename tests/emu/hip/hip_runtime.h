@@ -1,0 +1,157 @@
+// SIMT emulator for development WITHOUT a GPU.  TEST INFRASTRUCTURE ONLY.
+//
+// This header shadows <hip/hip_runtime.h> when the kernel sources under
+// dav1d_amd/csrc are compiled with g++ (-Itests/emu first on the include path)
+// into tests/emu/libdav1d_hip_emu.so.  Every thread of a workgroup runs as a
+// ucontext fiber on one OS thread; __syncthreads() and the wave-level cross-lane
+// operations are rendezvous points of the fiber scheduler (emu_rt.cpp).  The
+// point is to run the *unmodified* kernel source (indexing, LDS staging, lane
+// mapping) against the oracle on the CPU-only build container.  It is never
+// linked into, loaded by or substituted for the product library
+// (dav1d_amd/libdav1d_hip.so), bench.py or smoke().
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <cstring>
+#include <cstdlib>
+#include <cstdio>
+#include <functional>
+#include <algorithm>
+
+#define DAV1D_HIP_EMU 1
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3 { unsigned x, y, z; };
+
+extern uint3 threadIdx, blockIdx;
+extern dim3 blockDim, gridDim;
+
+#define __global__
+#define __device__
+#define __host__
+#define __shared__ static
+#define __constant__ static
+#define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
+#define __launch_bounds__(...)
+#ifndef __restrict__
+#define __restrict__
+#endif
+
+typedef int hipError_t;
+typedef struct emu_stream_st *hipStream_t;
+typedef struct emu_event_st *hipEvent_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorUnknown = 999 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost,
+                     hipMemcpyDeviceToDevice, hipMemcpyDefault };
+
+void emu_syncthreads();
+void emu_wave_sync();            // rendezvous of the live lanes of one 64-lane wave
+uint64_t *emu_wave_slots();      // 64 x 64-bit exchange slots of the calling wave
+void emu_launch(const std::function<void()> &body, dim3 grid, dim3 block);
+
+static inline void __syncthreads() { emu_syncthreads(); }
+
+static inline int emu_lane() {
+    return (int) ((threadIdx.x + threadIdx.y * blockDim.x +
+                   threadIdx.z * blockDim.x * blockDim.y) & 63);
+}
+
+template <typename T> static inline T emu_exchange(T v, int src_lane) {
+    static_assert(sizeof(T) <= 8, "exchange width");
+    uint64_t *s = emu_wave_slots();
+    uint64_t raw = 0;
+    memcpy(&raw, &v, sizeof(T));
+    s[emu_lane()] = raw;
+    emu_wave_sync();
+    raw = s[src_lane & 63];
+    T out;
+    memcpy(&out, &raw, sizeof(T));
+    emu_wave_sync();
+    return out;
+}
+template <typename T> static inline T __shfl(T v, int src, int width = 64) {
+    const int lane = emu_lane();
+    return emu_exchange(v, (lane & ~(width - 1)) | (src & (width - 1)));
+}
+template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64) {
+    return emu_exchange(v, emu_lane() ^ mask);
+}
+template <typename T> static inline T __shfl_down(T v, unsigned d, int width = 64) {
+    const int lane = emu_lane();
+    const int src = lane + (int) d;
+    return emu_exchange(v, ((src & ~(width - 1)) == (lane & ~(width - 1))) ? src : lane);
+}
+template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64) {
+    const int lane = emu_lane();
+    const int src = lane - (int) d;
+    return emu_exchange(v, (src >= 0 && (src & ~(width - 1)) == (lane & ~(width - 1))) ? src : lane);
+}
+static inline unsigned long long __ballot(int pred) {
+    uint64_t *s = emu_wave_slots();
+    s[emu_lane()] = pred ? 1 : 0;
+    emu_wave_sync();
+    unsigned long long m = 0;
+    // lanes that already exited keep a 0 in their slot (cleared at wave start)
+    for (int i = 0; i < 64; i++) m |= (unsigned long long) (s[i] & 1) << i;
+    emu_wave_sync();
+    s[emu_lane()] = 0;
+    return m;
+}
+static inline int __builtin_amdgcn_readfirstlane(int v) {
+    // emulation assumes wave-uniform control flow at the call site: lowest live lane
+    uint64_t *s = emu_wave_slots();
+    s[emu_lane()] = ((uint64_t) 1 << 63) | (uint32_t) v;
+    emu_wave_sync();
+    int out = v;
+    for (int i = 0; i < 64; i++) if (s[i] >> 63) { out = (int) (uint32_t) s[i]; break; }
+    emu_wave_sync();
+    s[emu_lane()] = 0;
+    return out;
+}
+static inline int __builtin_amdgcn_sdot2(uint32_t a, uint32_t b, int c, bool) {
+    return c + (int16_t) (a & 0xffff) * (int16_t) (b & 0xffff) +
+               (int16_t) (a >> 16) * (int16_t) (b >> 16);
+}
+static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
+    return (uint32_t) ((((uint64_t) hi << 32) | lo) >> (sh & 31));
+}
+static inline int __mul24(int a, int b) { return (int) ((int64_t) ((a << 8) >> 8) * ((b << 8) >> 8)); }
+static inline int __clz(int v) { return v ? __builtin_clz((unsigned) v) : 32; }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long) v); }
+using std::min;
+using std::max;
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    emu_launch([&]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block))
+
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+static inline hipError_t hipHostFree(void *p) { return hipFree(p); }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = 0) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t = 0) {
+    for (size_t y = 0; y < h; y++) memcpy((char *) d + y * dp, (const char *) s + y * sp, w);
+    return hipSuccess;
+}
+static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = 0) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = 0; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = 0; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = 0) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
