@@ -1,0 +1,95 @@
+"""ctypes binding of the C ABI in include/dav1d_hip.h.
+
+The product library is dav1d_amd/libdav1d_hip.so (built by dav1d_amd.build / __graft_entry__.build
+with hipcc for gfx950).  There is no CPU fallback: if the library is missing, or no
+MI355X-class device can be opened, loading / opening raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_PATH = os.path.join(HERE, "libdav1d_hip.so")
+
+
+class Plane(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("stride", C.c_ssize_t), ("w", C.c_int), ("h", C.c_int)]
+
+
+class Picture(C.Structure):
+    _fields_ = [("p", Plane * 3), ("bpc", C.c_int), ("layout", C.c_int),
+                ("alloc", C.c_void_p), ("alloc_size", C.c_size_t)]
+
+
+# numpy mirrors of the POD task descriptors (include/dav1d_hip.h)
+ITX_TASK = np.dtype([("dst_off", "<u4"), ("cf_off", "<u4"), ("eob", "<i2"), ("tx", "u1"), ("txtp", "u1"),
+                     ("plane", "u1"), ("pad", "u1", (3,))], align=False)
+MC_TASK = np.dtype([("dst_off", "<u4"), ("src_x", "<i4"), ("src_y", "<i4"), ("w", "u1"), ("h", "u1"),
+                    ("mx", "u1"), ("my", "u1"), ("filter_2d", "u1"), ("kind", "u1"), ("plane", "u1"),
+                    ("ref", "u1"), ("pad", "<u4")], align=False)
+COMP_TASK = np.dtype([("dst_off", "<u4"), ("tmp1_off", "<u4"), ("tmp2_off", "<u4"), ("mask_off", "<u4"),
+                      ("w", "u1"), ("h", "u1"), ("kind", "u1"), ("plane", "u1"), ("arg", "i1"), ("ss", "u1"),
+                      ("pad", "<u2")], align=False)
+assert ITX_TASK.itemsize == 16 and MC_TASK.itemsize == 24 and COMP_TASK.itemsize == 24
+
+# every symbol include/dav1d_hip.h declares (tests check the built library exports all of them)
+SYMBOLS = [
+    "dav1d_hip_open", "dav1d_hip_close", "dav1d_hip_sync", "dav1d_hip_stream", "dav1d_hip_version",
+    "dav1d_hip_malloc", "dav1d_hip_free", "dav1d_hip_memset", "dav1d_hip_upload", "dav1d_hip_download",
+    "dav1d_hip_picture_alloc", "dav1d_hip_picture_free", "dav1d_hip_plane_upload", "dav1d_hip_plane_download",
+    "dav1d_hip_itx_add_batch", "dav1d_hip_itx_list_create", "dav1d_hip_itx_list_destroy", "dav1d_hip_itx_list_run",
+    "dav1d_hip_mc_batch", "dav1d_hip_mc_list_create", "dav1d_hip_mc_list_destroy", "dav1d_hip_mc_list_run",
+    "dav1d_hip_comp_batch", "dav1d_hip_comp_list_create", "dav1d_hip_comp_list_destroy", "dav1d_hip_comp_list_run",
+    "dav1d_hip_dsp_init_8bpc", "dav1d_hip_dsp_init_16bpc",
+]
+
+
+class LibraryError(RuntimeError):
+    pass
+
+
+def load(path=None):
+    """dlopen the C-ABI library and declare prototypes.  Raises if it is absent."""
+    path = path or DEFAULT_PATH
+    if not os.path.exists(path):
+        raise LibraryError("HIP library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)" % path)
+    lib = C.CDLL(path)
+    vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
+    P = C.POINTER
+    protos = {
+        "dav1d_hip_open": (i, [P(vp), i, vp]),
+        "dav1d_hip_close": (None, [vp]),
+        "dav1d_hip_sync": (i, [vp]),
+        "dav1d_hip_stream": (vp, [vp]),
+        "dav1d_hip_version": (C.c_char_p, []),
+        "dav1d_hip_malloc": (i, [vp, P(vp), sz]),
+        "dav1d_hip_free": (i, [vp, vp]),
+        "dav1d_hip_memset": (i, [vp, vp, i, sz]),
+        "dav1d_hip_upload": (i, [vp, vp, vp, sz]),
+        "dav1d_hip_download": (i, [vp, vp, vp, sz]),
+        "dav1d_hip_picture_alloc": (i, [vp, P(Picture), i, i, i, i]),
+        "dav1d_hip_picture_free": (i, [vp, P(Picture)]),
+        "dav1d_hip_plane_upload": (i, [vp, P(Picture), i, vp, C.c_ssize_t, i]),
+        "dav1d_hip_plane_download": (i, [vp, P(Picture), i, vp, C.c_ssize_t, i]),
+        "dav1d_hip_itx_add_batch": (i, [vp, P(Picture), vp, sz, vp]),
+        "dav1d_hip_itx_list_create": (i, [vp, P(vp), vp, sz]),
+        "dav1d_hip_itx_list_destroy": (None, [vp, vp]),
+        "dav1d_hip_itx_list_run": (i, [vp, vp, P(Picture), vp]),
+        "dav1d_hip_mc_batch": (i, [vp, P(Picture), P(Picture), i, vp, sz, vp]),
+        "dav1d_hip_mc_list_create": (i, [vp, P(vp), vp, sz]),
+        "dav1d_hip_mc_list_destroy": (None, [vp, vp]),
+        "dav1d_hip_mc_list_run": (i, [vp, vp, P(Picture), P(Picture), i, vp]),
+        "dav1d_hip_comp_batch": (i, [vp, P(Picture), vp, sz, vp, vp]),
+        "dav1d_hip_comp_list_create": (i, [vp, P(vp), vp, sz]),
+        "dav1d_hip_comp_list_destroy": (None, [vp, vp]),
+        "dav1d_hip_comp_list_run": (i, [vp, vp, P(Picture), vp, vp]),
+        "dav1d_hip_dsp_init_8bpc": (i, [vp]),
+        "dav1d_hip_dsp_init_16bpc": (i, [vp, i]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib

@@ -1,0 +1,178 @@
+"""Thin object layer over the C ABI for Python callers (tests, bench.py, smoke()).
+
+It only moves numpy arrays / device pointers in and out of the C entry points of
+include/dav1d_hip.h; all reconstruction work happens in the HIP library.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ITX_TASK, MC_TASK, COMP_TASK, Picture  # noqa: F401  (re-exported)
+
+LAYOUT_I400, LAYOUT_I420, LAYOUT_I422, LAYOUT_I444 = 0, 1, 2, 3
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _chk(rc, what):
+    if rc:
+        raise HipError("%s failed: errno %d" % (what, -rc))
+
+
+class DeviceBuffer:
+    """A device allocation made through dav1d_hip_malloc."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        _chk(ctx.lib.dav1d_hip_malloc(ctx.h, C.byref(p), self.nbytes), "malloc")
+        self.ptr = p.value
+
+    def upload(self, arr, offset=0):
+        a = np.ascontiguousarray(arr)
+        assert offset + a.nbytes <= self.nbytes
+        _chk(self.ctx.lib.dav1d_hip_upload(self.ctx.h, self.ptr + offset, a.ctypes.data, a.nbytes), "upload")
+
+    def download(self, dtype, count=None, offset=0):
+        dt = np.dtype(dtype)
+        n = (self.nbytes - offset) // dt.itemsize if count is None else count
+        out = np.empty(n, dt)
+        _chk(self.ctx.lib.dav1d_hip_download(self.ctx.h, out.ctypes.data, self.ptr + offset, out.nbytes), "download")
+        return out
+
+    def zero(self):
+        _chk(self.ctx.lib.dav1d_hip_memset(self.ctx.h, self.ptr, 0, self.nbytes), "memset")
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.dav1d_hip_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class DevicePicture:
+    def __init__(self, ctx, w, h, layout, bpc):
+        self.ctx = ctx
+        self.pic = Picture()
+        _chk(ctx.lib.dav1d_hip_picture_alloc(ctx.h, C.byref(self.pic), w, h, layout, bpc), "picture_alloc")
+        self.w, self.h, self.layout, self.bpc = w, h, layout, bpc
+        self.dtype = np.uint8 if bpc == 8 else np.uint16
+
+    @property
+    def n_planes(self):
+        return 1 if self.layout == LAYOUT_I400 else 3
+
+    def padded_shape(self, plane):
+        ss_ver = 1 if plane and self.layout == LAYOUT_I420 else 0
+        ss_hor = 1 if plane and self.layout != LAYOUT_I444 else 0
+        return (((self.h + 127) & ~127) >> ss_ver, ((self.w + 127) & ~127) >> ss_hor)
+
+    def stride_px(self, plane):
+        return self.pic.p[plane].stride // np.dtype(self.dtype).itemsize
+
+    def upload(self, plane, arr):
+        """arr: 2-D array of the PADDED plane shape (rows x cols)."""
+        a = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert a.shape == self.padded_shape(plane), (a.shape, self.padded_shape(plane))
+        _chk(self.ctx.lib.dav1d_hip_plane_upload(self.ctx.h, C.byref(self.pic), plane, a.ctypes.data,
+                                                 a.strides[0], 1), "plane_upload")
+
+    def download(self, plane):
+        out = np.empty(self.padded_shape(plane), self.dtype)
+        _chk(self.ctx.lib.dav1d_hip_plane_download(self.ctx.h, C.byref(self.pic), plane, out.ctypes.data,
+                                                   out.strides[0], 1), "plane_download")
+        return out
+
+    def free(self):
+        self.ctx.lib.dav1d_hip_picture_free(self.ctx.h, C.byref(self.pic))
+
+
+class _List:
+    def __init__(self, ctx, kind, tasks, dtype):
+        self.ctx, self.kind = ctx, kind
+        t = np.ascontiguousarray(tasks, dtype=dtype)
+        self.n = len(t)
+        self.h = C.c_void_p()
+        _chk(getattr(ctx.lib, "dav1d_hip_%s_list_create" % kind)(ctx.h, C.byref(self.h), t.ctypes.data, len(t)),
+             kind + "_list_create")
+
+    def destroy(self):
+        if self.h:
+            getattr(self.ctx.lib, "dav1d_hip_%s_list_destroy" % self.kind)(self.ctx.h, self.h)
+            self.h = None
+
+
+class Context:
+    """dav1d_hip_open() wrapper.  `stream` is a raw hipStream_t (int) or None."""
+
+    def __init__(self, device=0, stream=None, lib_path=None):
+        self.lib = _lib.load(lib_path)
+        h = C.c_void_p()
+        rc = self.lib.dav1d_hip_open(C.byref(h), device, stream)
+        if rc:
+            raise HipError("dav1d_hip_open(device=%d) failed: errno %d (no usable MI355X device; there is no "
+                           "CPU fallback)" % (device, -rc))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.dav1d_hip_close(self.h)
+            self.h = None
+
+    def sync(self):
+        _chk(self.lib.dav1d_hip_sync(self.h), "sync")
+
+    def buffer(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def buffer_from(self, arr):
+        a = np.ascontiguousarray(arr)
+        b = DeviceBuffer(self, max(a.nbytes, 16))
+        if a.nbytes:
+            b.upload(a)
+        return b
+
+    def picture(self, w, h, layout, bpc):
+        return DevicePicture(self, w, h, layout, bpc)
+
+    # ---- batched entry points (host task arrays, device arenas)
+    def itx_add_batch(self, dst, tasks, coef):
+        t = np.ascontiguousarray(tasks, dtype=ITX_TASK)
+        _chk(self.lib.dav1d_hip_itx_add_batch(self.h, C.byref(dst.pic), t.ctypes.data, len(t), coef.ptr), "itx_add_batch")
+
+    def mc_batch(self, dst, refs, tasks, prep=None):
+        t = np.ascontiguousarray(tasks, dtype=MC_TASK)
+        arr = (Picture * len(refs))(*[r.pic for r in refs])
+        _chk(self.lib.dav1d_hip_mc_batch(self.h, C.byref(dst.pic), arr, len(refs), t.ctypes.data, len(t),
+                                         prep.ptr if prep else None), "mc_batch")
+
+    def comp_batch(self, dst, tasks, prep, mask=None):
+        t = np.ascontiguousarray(tasks, dtype=COMP_TASK)
+        _chk(self.lib.dav1d_hip_comp_batch(self.h, C.byref(dst.pic), t.ctypes.data, len(t), prep.ptr,
+                                           mask.ptr if mask else None), "comp_batch")
+
+    # ---- device-resident lists
+    def itx_list(self, tasks):
+        return _List(self, "itx", tasks, ITX_TASK)
+
+    def mc_list(self, tasks):
+        return _List(self, "mc", tasks, MC_TASK)
+
+    def comp_list(self, tasks):
+        return _List(self, "comp", tasks, COMP_TASK)
+
+    def run_itx_list(self, lst, dst, coef):
+        _chk(self.lib.dav1d_hip_itx_list_run(self.h, lst.h, C.byref(dst.pic), coef.ptr if hasattr(coef, "ptr") else coef),
+             "itx_list_run")
+
+    def run_mc_list(self, lst, dst, refs, prep=None):
+        arr = (Picture * len(refs))(*[r.pic for r in refs])
+        p = None if prep is None else (prep.ptr if hasattr(prep, "ptr") else prep)
+        _chk(self.lib.dav1d_hip_mc_list_run(self.h, lst.h, C.byref(dst.pic), arr, len(refs), p), "mc_list_run")
+
+    def run_comp_list(self, lst, dst, prep, mask=None):
+        p = prep.ptr if hasattr(prep, "ptr") else prep
+        m = None if mask is None else (mask.ptr if hasattr(mask, "ptr") else mask)
+        _chk(self.lib.dav1d_hip_comp_list_run(self.h, lst.h, C.byref(dst.pic), p, m), "comp_list_run")

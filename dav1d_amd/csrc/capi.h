@@ -1,0 +1,59 @@
+// Internal declarations shared by the C-ABI translation units (host side).
+#pragma once
+#include "common.h"
+#include <errno.h>
+#include <vector>
+
+struct Dav1dHipContext {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    // scratch used by the reference-signature single-call wrappers (dsp_table.hip)
+    void *scratch;
+    size_t scratch_size;
+};
+
+static inline int hip_rc(hipError_t e) {
+    if (e == hipSuccess) return 0;
+    if (e == hipErrorOutOfMemory) return -ENOMEM;
+    if (e == hipErrorInvalidValue) return -EINVAL;
+    return -EIO;
+}
+#define HIP_TRY(x) do { const int rc_ = hip_rc(x); if (rc_) return rc_; } while (0)
+
+static inline DevPlanes dev_planes(const Dav1dHipPicture *p) {
+    DevPlanes d;
+    const int bps = p->bpc > 8 ? 2 : 1;
+    for (int i = 0; i < 3; i++) {
+        d.data[i] = p->p[i].data;
+        d.stride[i] = (int) (p->p[i].stride / bps);
+        d.w[i] = p->p[i].w;
+        d.h[i] = p->p[i].h;
+    }
+    return d;
+}
+
+// kernel launchers (one per family translation unit)
+extern "C" int dav1d_hip_launch_itx_bin(const DevPlanes *dst, int bpc, int tx, const Dav1dHipItxTask *tasks,
+                                        int n, void *coef, void *stream);
+// Device-side unit of motion compensation: a tile of at most 16x16 cut out of a
+// Dav1dHipMcTask by the host (mc list creation), filter rows already resolved
+// (reference GET_H_FILTER / GET_V_FILTER, src/mc_tmpl.c:115-123).
+struct McTile {
+    uint32_t dst_off;     // of the TASK: PUT pixel offset in the dst plane; PREP int16 offset in the prep arena
+    int32_t  src_x, src_y;// of the tile's top-left in the reference plane
+    uint8_t  w, h;        // tile size, <= 16
+    uint8_t  mx, my;
+    uint8_t  fh, fv;      // row of av1_mc_subpel_filters (0..5) or 6 = bilinear
+    uint8_t  kind, plane;
+    uint8_t  ref;
+    uint8_t  bw;          // task width = row stride of a PREP block
+    uint8_t  ox, oy;      // tile origin inside the task's block
+};
+extern "C" int dav1d_hip_launch_mc_bin(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, int cls,
+                                       const McTile *tiles, int n, int16_t *prep, void *stream);
+extern "C" int dav1d_hip_launch_comp(const DevPlanes *dst, int bpc, const Dav1dHipCompTask *tasks, int n,
+                                     const int16_t *prep, uint8_t *mask, void *stream);
+
+Dav1dHipContext *dav1d_hip_default_context(void);
+int dav1d_hip_scratch(Dav1dHipContext *c, size_t bytes, void **out);

@@ -1,0 +1,414 @@
+// Host side of the C ABI declared in include/dav1d_hip.h: context, device memory,
+// pictures, task-list binning and the batched entry points.
+#include "capi.h"
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <new>
+
+extern "C" {
+
+// ------------------------------------------------------------------ context
+
+int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
+    if (!out) return -EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+        return -ENODEV;
+    if (hipSetDevice(device) != hipSuccess) return -ENODEV;
+    Dav1dHipContext *c = new (std::nothrow) Dav1dHipContext();
+    if (!c) return -ENOMEM;
+    c->device = device;
+    c->own_stream = stream == nullptr;
+    c->scratch = nullptr;
+    c->scratch_size = 0;
+    if (stream) c->stream = (hipStream_t) stream;
+    else if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return -ENODEV; }
+    *out = c;
+    return 0;
+}
+
+void dav1d_hip_close(Dav1dHipContext *c) {
+    if (!c) return;
+    hipStreamSynchronize(c->stream);
+    if (c->scratch) hipFree(c->scratch);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int dav1d_hip_sync(Dav1dHipContext *c) { return hip_rc(hipStreamSynchronize(c->stream)); }
+void *dav1d_hip_stream(Dav1dHipContext *c) { return (void *) c->stream; }
+const char *dav1d_hip_version(void) { return "dav1d_hip 0.1 (gfx950)"; }
+
+int dav1d_hip_malloc(Dav1dHipContext *c, void **dev, size_t bytes) {
+    (void) c;
+    return hip_rc(hipMalloc(dev, bytes ? bytes : 1));
+}
+int dav1d_hip_free(Dav1dHipContext *c, void *dev) {
+    hipStreamSynchronize(c->stream);
+    return hip_rc(hipFree(dev));
+}
+int dav1d_hip_memset(Dav1dHipContext *c, void *dev, int v, size_t bytes) {
+    return hip_rc(hipMemsetAsync(dev, v, bytes, c->stream));
+}
+int dav1d_hip_upload(Dav1dHipContext *c, void *dev, const void *host, size_t bytes) {
+    HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+    return hip_rc(hipStreamSynchronize(c->stream));
+}
+int dav1d_hip_download(Dav1dHipContext *c, void *host, const void *dev, size_t bytes) {
+    HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    return hip_rc(hipStreamSynchronize(c->stream));
+}
+
+// ----------------------------------------------------------------- pictures
+
+int dav1d_hip_picture_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic, int w, int h, int layout, int bpc) {
+    if (!pic || w <= 0 || h <= 0 || (bpc != 8 && bpc != 10 && bpc != 12) || layout < 0 || layout > 3)
+        return -EINVAL;
+    // geometry of the reference's default allocator, src/picture.c:46-78
+    const int hbd = bpc > 8;
+    const int aligned_w = (w + 127) & ~127, aligned_h = (h + 127) & ~127;
+    const int has_chroma = layout != DAV1D_HIP_LAYOUT_I400;
+    const int ss_ver = layout == DAV1D_HIP_LAYOUT_I420;
+    const int ss_hor = layout != DAV1D_HIP_LAYOUT_I444;
+    ptrdiff_t y_stride = (ptrdiff_t) aligned_w << hbd;
+    ptrdiff_t uv_stride = has_chroma ? y_stride >> ss_hor : 0;
+    if (!(y_stride & 1023)) y_stride += 64;
+    if (!(uv_stride & 1023) && has_chroma) uv_stride += 64;
+    const size_t y_sz = (size_t) y_stride * aligned_h;
+    const size_t uv_sz = (size_t) uv_stride * (aligned_h >> ss_ver);
+    const size_t total = y_sz + 2 * uv_sz + 64;
+    void *buf = nullptr;
+    HIP_TRY(hipMalloc(&buf, total));
+    HIP_TRY(hipMemsetAsync(buf, 0, total, c->stream));
+    memset(pic, 0, sizeof(*pic));
+    pic->alloc = buf;
+    pic->alloc_size = total;
+    pic->bpc = bpc;
+    pic->layout = layout;
+    pic->p[0].data = buf;
+    pic->p[0].stride = y_stride;
+    pic->p[0].w = w;
+    pic->p[0].h = h;
+    for (int i = 1; i < 3; i++) {
+        pic->p[i].data = has_chroma ? (uint8_t *) buf + y_sz + (i - 1) * uv_sz : nullptr;
+        pic->p[i].stride = uv_stride;
+        pic->p[i].w = has_chroma ? (w + ss_hor) >> ss_hor : 0;
+        pic->p[i].h = has_chroma ? (h + ss_ver) >> ss_ver : 0;
+    }
+    return 0;
+}
+
+int dav1d_hip_picture_free(Dav1dHipContext *c, Dav1dHipPicture *pic) {
+    if (!pic || !pic->alloc) return 0;
+    hipStreamSynchronize(c->stream);
+    const int rc = hip_rc(hipFree(pic->alloc));
+    memset(pic, 0, sizeof(*pic));
+    return rc;
+}
+
+static void plane_extent(const Dav1dHipPicture *pic, int plane, int padded, size_t *row_bytes, int *rows) {
+    const int bps = pic->bpc > 8 ? 2 : 1;
+    if (padded) {
+        const int ss_ver = plane && pic->layout == DAV1D_HIP_LAYOUT_I420;
+        const int ss_hor = plane && pic->layout != DAV1D_HIP_LAYOUT_I444;
+        const int aw = ((pic->p[0].w + 127) & ~127) >> ss_hor, ah = ((pic->p[0].h + 127) & ~127) >> ss_ver;
+        *row_bytes = (size_t) aw * bps;
+        *rows = ah;
+    } else {
+        *row_bytes = (size_t) pic->p[plane].w * bps;
+        *rows = pic->p[plane].h;
+    }
+}
+
+int dav1d_hip_plane_upload(Dav1dHipContext *c, const Dav1dHipPicture *pic, int plane,
+                           const void *host, ptrdiff_t host_stride, int padded) {
+    if (!pic || plane < 0 || plane > 2 || !pic->p[plane].data) return -EINVAL;
+    size_t rb; int rows;
+    plane_extent(pic, plane, padded, &rb, &rows);
+    HIP_TRY(hipMemcpy2DAsync(pic->p[plane].data, pic->p[plane].stride, host, host_stride, rb, rows,
+                             hipMemcpyHostToDevice, c->stream));
+    return hip_rc(hipStreamSynchronize(c->stream));
+}
+
+int dav1d_hip_plane_download(Dav1dHipContext *c, const Dav1dHipPicture *pic, int plane,
+                             void *host, ptrdiff_t host_stride, int padded) {
+    if (!pic || plane < 0 || plane > 2 || !pic->p[plane].data) return -EINVAL;
+    size_t rb; int rows;
+    plane_extent(pic, plane, padded, &rb, &rows);
+    HIP_TRY(hipMemcpy2DAsync(host, host_stride, pic->p[plane].data, pic->p[plane].stride, rb, rows,
+                             hipMemcpyDeviceToHost, c->stream));
+    return hip_rc(hipStreamSynchronize(c->stream));
+}
+
+} // extern "C"
+
+int dav1d_hip_scratch(Dav1dHipContext *c, size_t bytes, void **out) {
+    if (c->scratch_size < bytes) {
+        hipStreamSynchronize(c->stream);
+        if (c->scratch) hipFree(c->scratch);
+        c->scratch = nullptr;
+        c->scratch_size = 0;
+        size_t sz = bytes < (1u << 20) ? (1u << 20) : bytes;
+        HIP_TRY(hipMalloc(&c->scratch, sz));
+        c->scratch_size = sz;
+    }
+    *out = c->scratch;
+    return 0;
+}
+
+Dav1dHipContext *dav1d_hip_default_context(void) {
+    static std::mutex mtx;
+    static Dav1dHipContext *g = nullptr;
+    std::lock_guard<std::mutex> lk(mtx);
+    if (!g) {
+        const char *e = getenv("DAV1D_HIP_DEVICE");
+        if (dav1d_hip_open(&g, e ? atoi(e) : 0, nullptr)) g = nullptr;
+    }
+    return g;
+}
+
+// ---------------------------------------------------------------------- itx
+
+static const uint8_t k_tx_w[19] = { 4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64 };
+static const uint8_t k_tx_h[19] = { 4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16 };
+
+struct Dav1dHipItxList {
+    Dav1dHipItxTask *dev;
+    size_t n;
+    size_t off[20];   // bin b occupies [off[b], off[b+1])
+};
+
+// legal (size, type) pairs, reference src/itx_tmpl.c:160-178 / 264-291
+static bool itx_legal(int tx, int txtp) {
+    if (tx < 0 || tx >= 19 || txtp < 0 || txtp > 16) return false;
+    if (txtp == 16) return tx == 0;
+    const int w = k_tx_w[tx], h = k_tx_h[tx];
+    const int mx = w > h ? w : h;
+    if (mx == 64) return txtp == 0;
+    if (mx == 32) return txtp == 0 || txtp == 9;
+    if (w == 16 && h == 16) return txtp <= 11;
+    return true;
+}
+
+extern "C" {
+
+int dav1d_hip_itx_list_create(Dav1dHipContext *c, Dav1dHipItxList **out, const Dav1dHipItxTask *tasks, size_t n) {
+    if (!out || (!tasks && n)) return -EINVAL;
+    *out = nullptr;
+    Dav1dHipItxList *l = new (std::nothrow) Dav1dHipItxList();
+    if (!l) return -ENOMEM;
+    memset(l, 0, sizeof(*l));
+    l->n = n;
+    size_t cnt[19] = { 0 };
+    for (size_t i = 0; i < n; i++) {
+        const Dav1dHipItxTask &t = tasks[i];
+        if (!itx_legal(t.tx, t.txtp) || t.plane > 2 || t.eob < 0) { delete l; return -EINVAL; }
+        cnt[t.tx]++;
+    }
+    for (int b = 0; b < 19; b++) l->off[b + 1] = l->off[b] + cnt[b];
+    if (n) {
+        std::vector<Dav1dHipItxTask> sorted(n);
+        size_t pos[19];
+        for (int b = 0; b < 19; b++) pos[b] = l->off[b];
+        for (size_t i = 0; i < n; i++) sorted[pos[tasks[i].tx]++] = tasks[i];   // stable: keeps decode order inside a bin
+        if (hipMalloc((void **) &l->dev, n * sizeof(Dav1dHipItxTask)) != hipSuccess) { delete l; return -ENOMEM; }
+        const int rc = dav1d_hip_upload(c, l->dev, sorted.data(), n * sizeof(Dav1dHipItxTask));
+        if (rc) { hipFree(l->dev); delete l; return rc; }
+    }
+    *out = l;
+    return 0;
+}
+
+void dav1d_hip_itx_list_destroy(Dav1dHipContext *c, Dav1dHipItxList *l) {
+    if (!l) return;
+    hipStreamSynchronize(c->stream);
+    if (l->dev) hipFree(l->dev);
+    delete l;
+}
+
+int dav1d_hip_itx_list_run(Dav1dHipContext *c, const Dav1dHipItxList *l, const Dav1dHipPicture *dst, void *coef) {
+    if (!l || !dst) return -EINVAL;
+    const DevPlanes dp = dev_planes(dst);
+    for (int b = 0; b < 19; b++) {
+        const size_t cnt = l->off[b + 1] - l->off[b];
+        if (!cnt) continue;
+        const int rc = dav1d_hip_launch_itx_bin(&dp, dst->bpc, b, l->dev + l->off[b], (int) cnt, coef, c->stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int dav1d_hip_itx_add_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipItxTask *tasks,
+                            size_t n, void *coef) {
+    Dav1dHipItxList *l = nullptr;
+    int rc = dav1d_hip_itx_list_create(c, &l, tasks, n);
+    if (rc) return rc;
+    rc = dav1d_hip_itx_list_run(c, l, dst, coef);
+    dav1d_hip_itx_list_destroy(c, l);     // synchronises the stream
+    return rc;
+}
+
+} // extern "C"
+
+// ----------------------------------------------------------------------- mc
+
+struct Dav1dHipMcList {
+    McTile *dev;
+    size_t n;
+    size_t off[10];   // 9 tile-shape bins
+};
+
+static int tile_dim_class(int v) { return v <= 4 ? 0 : v <= 8 ? 1 : 2; }
+
+extern "C" {
+
+int dav1d_hip_mc_list_create(Dav1dHipContext *c, Dav1dHipMcList **out, const Dav1dHipMcTask *tasks, size_t n) {
+    if (!out || (!tasks && n)) return -EINVAL;
+    *out = nullptr;
+    std::vector<McTile> bins[9];
+    for (size_t i = 0; i < n; i++) {
+        const Dav1dHipMcTask &t = tasks[i];
+        if (t.w < 2 || t.w > 128 || t.h < 2 || t.h > 128 || (t.w & (t.w - 1)) || (t.h & (t.h - 1)) ||
+            t.mx > 15 || t.my > 15 || t.filter_2d > 9 || t.kind > 1 || t.plane > 2 || t.ref > 7)
+            return -EINVAL;
+        McTile m;
+        memset(&m, 0, sizeof(m));
+        m.dst_off = t.dst_off;
+        m.mx = t.mx; m.my = t.my;
+        m.kind = t.kind; m.plane = t.plane; m.ref = t.ref;
+        m.bw = t.w;   // 128 wraps to... handled below
+        if (t.filter_2d == 9) {
+            m.fh = m.fv = 6;
+        } else {
+            // enum Filter2d -> (h type, v type) with REGULAR 0, SMOOTH 1, SHARP 2
+            // (reference src/levels.h:184-196, src/mc_tmpl.c:395-403)
+            static const uint8_t ht[9] = { 0, 0, 0, 2, 2, 2, 1, 1, 1 };
+            static const uint8_t vt[9] = { 0, 1, 2, 0, 1, 2, 0, 1, 2 };
+            const int h_type = ht[t.filter_2d], v_type = vt[t.filter_2d];
+            m.fh = t.w > 4 ? h_type : 3 + (h_type & 1);
+            m.fv = t.h > 4 ? v_type : 3 + (v_type & 1);
+        }
+        const int tw = t.w < 16 ? t.w : 16, th = t.h < 16 ? t.h : 16;
+        const int cls = tile_dim_class(tw) * 3 + tile_dim_class(th);
+        for (int oy = 0; oy < t.h; oy += th)
+            for (int ox = 0; ox < t.w; ox += tw) {
+                m.w = tw; m.h = th;
+                m.ox = ox; m.oy = oy;
+                m.src_x = t.src_x + ox;
+                m.src_y = t.src_y + oy;
+                bins[cls].push_back(m);
+            }
+    }
+    Dav1dHipMcList *l = new (std::nothrow) Dav1dHipMcList();
+    if (!l) return -ENOMEM;
+    memset(l, 0, sizeof(*l));
+    std::vector<McTile> all;
+    for (int b = 0; b < 9; b++) {
+        l->off[b] = all.size();
+        all.insert(all.end(), bins[b].begin(), bins[b].end());
+    }
+    l->off[9] = all.size();
+    l->n = all.size();
+    if (l->n) {
+        if (hipMalloc((void **) &l->dev, l->n * sizeof(McTile)) != hipSuccess) { delete l; return -ENOMEM; }
+        const int rc = dav1d_hip_upload(c, l->dev, all.data(), l->n * sizeof(McTile));
+        if (rc) { hipFree(l->dev); delete l; return rc; }
+    }
+    *out = l;
+    return 0;
+}
+
+void dav1d_hip_mc_list_destroy(Dav1dHipContext *c, Dav1dHipMcList *l) {
+    if (!l) return;
+    hipStreamSynchronize(c->stream);
+    if (l->dev) hipFree(l->dev);
+    delete l;
+}
+
+int dav1d_hip_mc_list_run(Dav1dHipContext *c, const Dav1dHipMcList *l, const Dav1dHipPicture *dst,
+                          const Dav1dHipPicture *refs, int n_refs, int16_t *prep) {
+    if (!l || !dst || !refs || n_refs < 1 || n_refs > 8) return -EINVAL;
+    const DevPlanes dp = dev_planes(dst);
+    DevPlanes rp[8];
+    for (int i = 0; i < n_refs; i++) {
+        if (refs[i].bpc != dst->bpc) return -EINVAL;
+        rp[i] = dev_planes(&refs[i]);
+    }
+    for (int b = 0; b < 9; b++) {
+        const size_t cnt = l->off[b + 1] - l->off[b];
+        if (!cnt) continue;
+        const int rc = dav1d_hip_launch_mc_bin(&dp, rp, n_refs, dst->bpc, b, l->dev + l->off[b], (int) cnt, prep, c->stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int dav1d_hip_mc_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *refs, int n_refs,
+                       const Dav1dHipMcTask *tasks, size_t n, int16_t *prep) {
+    Dav1dHipMcList *l = nullptr;
+    int rc = dav1d_hip_mc_list_create(c, &l, tasks, n);
+    if (rc) return rc;
+    rc = dav1d_hip_mc_list_run(c, l, dst, refs, n_refs, prep);
+    dav1d_hip_mc_list_destroy(c, l);
+    return rc;
+}
+
+} // extern "C"
+
+// --------------------------------------------------------------------- comp
+
+struct Dav1dHipCompList {
+    Dav1dHipCompTask *dev;
+    size_t n;
+};
+
+extern "C" {
+
+int dav1d_hip_comp_list_create(Dav1dHipContext *c, Dav1dHipCompList **out, const Dav1dHipCompTask *tasks, size_t n) {
+    if (!out || (!tasks && n)) return -EINVAL;
+    *out = nullptr;
+    for (size_t i = 0; i < n; i++) {
+        const Dav1dHipCompTask &t = tasks[i];
+        if (t.w < 4 || t.w > 128 || t.h < 4 || t.h > 128 || (t.w & 1) || (t.h & 1) || t.kind > 3 || t.plane > 2 || t.ss > 2)
+            return -EINVAL;
+    }
+    Dav1dHipCompList *l = new (std::nothrow) Dav1dHipCompList();
+    if (!l) return -ENOMEM;
+    l->dev = nullptr;
+    l->n = n;
+    if (n) {
+        if (hipMalloc((void **) &l->dev, n * sizeof(Dav1dHipCompTask)) != hipSuccess) { delete l; return -ENOMEM; }
+        const int rc = dav1d_hip_upload(c, l->dev, tasks, n * sizeof(Dav1dHipCompTask));
+        if (rc) { hipFree(l->dev); delete l; return rc; }
+    }
+    *out = l;
+    return 0;
+}
+
+void dav1d_hip_comp_list_destroy(Dav1dHipContext *c, Dav1dHipCompList *l) {
+    if (!l) return;
+    hipStreamSynchronize(c->stream);
+    if (l->dev) hipFree(l->dev);
+    delete l;
+}
+
+int dav1d_hip_comp_list_run(Dav1dHipContext *c, const Dav1dHipCompList *l, const Dav1dHipPicture *dst,
+                            const int16_t *prep, uint8_t *mask) {
+    if (!l || !dst) return -EINVAL;
+    const DevPlanes dp = dev_planes(dst);
+    return dav1d_hip_launch_comp(&dp, dst->bpc, l->dev, (int) l->n, prep, mask, c->stream);
+}
+
+int dav1d_hip_comp_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipCompTask *tasks, size_t n,
+                         const int16_t *prep, uint8_t *mask) {
+    Dav1dHipCompList *l = nullptr;
+    int rc = dav1d_hip_comp_list_create(c, &l, tasks, n);
+    if (rc) return rc;
+    rc = dav1d_hip_comp_list_run(c, l, dst, prep, mask);
+    dav1d_hip_comp_list_destroy(c, l);
+    return rc;
+}
+
+} // extern "C"

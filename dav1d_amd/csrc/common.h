@@ -1,0 +1,45 @@
+// Shared device-side definitions of the reconstruction kernels (gfx950 / wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/dav1d_hip.h"
+
+// Planes of one picture as the kernels see them (strides in PIXELS, i.e. the
+// reference's PXSTRIDE(), include/common/bitdepth.h:53,78-81).
+struct DevPlanes {
+    void *data[3];
+    int stride[3];
+    int w[3], h[3];
+};
+
+#define WAVE 64
+
+namespace dv {
+
+__device__ __forceinline__ int iclip(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+// a.lo*b.lo + a.hi*b.hi + c on packed int16 pairs (v_dot2c_i32_i16 on gfx950)
+__device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c) {
+#ifdef DAV1D_HIP_EMU
+    return __builtin_amdgcn_sdot2(a, b, c, false);
+#else
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b), c, false);
+#endif
+}
+__device__ __forceinline__ uint32_t pack2(int lo, int hi) { return (uint32_t) (lo & 0xffff) | ((uint32_t) hi << 16); }
+
+// Launch-order -> work-order remap.  Workgroup b is observed to land on XCD b % 8
+// (MI355X_MICROARCH.md "Workgroup dispatch"); giving XCD k the k-th contiguous
+// eighth of the (raster-ordered) task list keeps neighbouring blocks of a picture,
+// which share 128-byte lines, inside one XCD's L2.  Speed only, never correctness.
+__device__ __forceinline__ unsigned xcd_chunk_id(unsigned b, unsigned nb) {
+    const unsigned per = nb >> 3;             // full groups of 8
+    if (b >= per * 8) return b;               // ragged tail keeps launch order
+    return (b & 7) * per + (b >> 3);
+}
+
+} // namespace dv

@@ -1,0 +1,241 @@
+// Batched inverse transform + add (itxfm_add) for gfx950.
+//
+// Contract per task = reference inv_txfm_add_c (src/itx_tmpl.c:43-124) and
+// inv_txfm_add_wht_wht_4x4_c (:184-203): dc-only shortcut, rect2 pre-scale, row
+// pass on c[x] = coeff[y + x*sh], intermediate round/clip, column pass, add to dst
+// with pixel clip, and the coefficient slab zeroed.
+//
+// Mapping: every lane evaluates complete 1-D transforms in registers (itx1d.h).
+// A W x H block owns LPB = max(min(H,32), W) lanes: in the row pass lane r
+// transforms row r, in the column pass lane c transforms column c; the transpose in
+// between goes through LDS with a padded row stride (conflict-free both ways).
+// 64/LPB blocks share one wave, so 4x4 blocks run 16 to a wave and 64x64 one.
+// The slab is fetched with 16-byte loads into LDS (and zeroed with 16-byte stores
+// in the same sweep); the row pass then reads it transposed from LDS.
+#include "common.h"
+#include "itx1d.h"
+
+namespace {
+
+enum { K_DCT = 0, K_ADST = 1, K_IDENTITY = 2, K_FLIPADST = 3, K_WHT = 4 };
+
+__host__ __device__ constexpr int tx_w(int tx) {
+    constexpr int w[19] = { 4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64 };
+    return w[tx];
+}
+__host__ __device__ constexpr int tx_h(int tx) {
+    constexpr int h[19] = { 4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16 };
+    return h[tx];
+}
+// intermediate shift per size (reference src/itx_tmpl.c:160-178)
+__host__ __device__ constexpr int tx_shift(int tx) {
+    constexpr int s[19] = { 0, 1, 2, 2, 2, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2 };
+    return s[tx];
+}
+__host__ __device__ constexpr int cmin(int a, int b) { return a < b ? a : b; }
+__host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// itxfm_add table index -> 1-D kind of the first (horizontal) and second (vertical)
+// pass.  The reference's table entry [A_B] is the function whose internal type is
+// B_A (src/itx_tmpl.c:233-262), and dav1d_tx1d_types[internal] = {first, second}
+// (src/itx_1d.c:1043-1060): net effect first = B, second = A; V_x = {IDENTITY, x},
+// H_x = {x, IDENTITY}.
+__device__ __forceinline__ void txtp_kinds(const int txtp, int &first, int &second) {
+    // packed 2 bits per entry: first | second << 2
+    //            DCT_DCT ADST_DCT DCT_ADST ADST_ADST FLIPADST_DCT DCT_FLIPADST FLIPADST_FLIPADST ADST_FLIPADST
+    // first        D       D        A        A         D            F            F                 F
+    // second       D       A        D        A         F            D            F                 A
+    //            FLIPADST_ADST IDTX V_DCT H_DCT V_ADST H_ADST V_FLIPADST H_FLIPADST
+    // first        A             I    I     D     I      A      I          F
+    // second       F             I    D     I     A      I      F          I
+    constexpr unsigned char tab[16] = {
+        0 | 0 << 2, 0 | 1 << 2, 1 | 0 << 2, 1 | 1 << 2, 0 | 3 << 2, 3 | 0 << 2, 3 | 3 << 2, 3 | 1 << 2,
+        1 | 3 << 2, 2 | 2 << 2, 2 | 0 << 2, 0 | 2 << 2, 2 | 1 << 2, 1 | 2 << 2, 2 | 3 << 2, 3 | 2 << 2,
+    };
+    // spelled as a switch-free lookup on an immediate table (stays in SGPR/const)
+    unsigned v = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) v = (txtp == i) ? tab[i] : v;
+    first = v & 3;
+    second = v >> 2;
+}
+
+template <int N>
+__device__ __forceinline__ void tx1d(const int kind, const int *in, int *out, const int lo, const int hi) {
+    if constexpr (N == 64) {
+        itx1d::idct<64>(in, out, lo, hi);
+    } else if constexpr (N == 32) {
+        if (kind == K_IDENTITY) itx1d::iidentity<32>(in, out);
+        else itx1d::idct<32>(in, out, lo, hi);
+    } else {
+        if (kind == K_DCT) itx1d::idct<N>(in, out, lo, hi);
+        else if (kind == K_IDENTITY) itx1d::iidentity<N>(in, out);
+        else {
+            if constexpr (N == 4) itx1d::iadst4(in, out);
+            else itx1d::iadst<N>(in, out, lo, hi);
+        }
+    }
+}
+
+template <int TX, typename pixel, typename coef>
+__global__ __launch_bounds__(64) void itx_add_kernel(const DevPlanes dst, const Dav1dHipItxTask *__restrict__ tasks,
+                                                     const int n, coef *__restrict__ cf, const int bitdepth_max)
+{
+    constexpr int W = tx_w(TX), H = tx_h(TX);
+    constexpr int SW = cmin(W, 32), SH = cmin(H, 32);
+    constexpr int LPB = cmax(SH, W);          // lanes per block
+    constexpr int BPW = 64 / LPB;             // blocks per wave
+    constexpr int TS = W + 1;                 // padded row stride of the transpose buffer
+    constexpr int SHIFT = tx_shift(TX);
+    constexpr bool RECT2 = (W * 2 == H) || (H * 2 == W);
+    constexpr int NCH = SW * SH * (int) sizeof(coef) / 16;   // 16-byte chunks per slab
+    constexpr bool HBD = sizeof(pixel) == 2;
+
+    __shared__ __attribute__((aligned(16))) coef slab_s[BPW * SW * SH];
+    __shared__ int tmp_s[BPW * SH * TS];
+
+    const int lane = threadIdx.x;
+    const int sub = lane / LPB, l = lane % LPB;
+    const int ti = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x) * BPW + sub;
+    const bool live = ti < n;
+
+    Dav1dHipItxTask t;
+    if (live) t = tasks[ti];
+    else { t.dst_off = 0; t.cf_off = 0; t.eob = 0; t.tx = TX; t.txtp = 0; t.plane = 0; }
+
+    const bool wht = TX == 0 && t.txtp == 16;
+    const bool dconly = live && t.txtp == 0 && t.eob < 1;
+    const bool full = live && !dconly;
+    int k1 = 0, k2 = 0;
+    txtp_kinds(t.txtp, k1, k2);
+
+    coef *const gcf = cf + t.cf_off;
+    coef *const slab = slab_s + sub * SW * SH;
+    int *const tmp = tmp_s + sub * SH * TS;
+
+    // ---- fetch + zero the slab (full blocks); dc-only blocks touch coeff[0] only
+    int dc = 0;
+    if (full) {
+        const int4 *g4 = reinterpret_cast<const int4 *>(gcf);
+        int4 *z4 = reinterpret_cast<int4 *>(gcf);
+        int4 *s4 = reinterpret_cast<int4 *>(slab);
+#pragma unroll
+        for (int i = l; i < NCH; i += LPB) {
+            s4[i] = g4[i];
+            z4[i] = make_int4(0, 0, 0, 0);
+        }
+    } else if (dconly && l == 0) {
+        dc = gcf[0];
+        gcf[0] = 0;
+    }
+    dc = __shfl(dc, sub * LPB);
+    __syncthreads();
+
+    int row_min, row_max, col_min, col_max;
+    if (HBD) {
+        row_min = (int) ((unsigned) ~bitdepth_max << 7);
+        col_min = (int) ((unsigned) ~bitdepth_max << 5);
+    } else {
+        row_min = col_min = -32768;
+    }
+    row_max = ~row_min;
+    col_max = ~col_min;
+
+    // ---- first pass: lane r = row r, W-point transform along x
+    if (full && l < SH) {
+        int in[W], out[W];
+#pragma unroll
+        for (int x = 0; x < W; x++) {
+            int v = 0;
+            if (x < SW) {
+                v = slab[x * SH + l];
+                if (RECT2) v = (v * 181 + 128) >> 8;
+            }
+            in[x] = v;
+        }
+        if (TX == 0 && wht) {
+#pragma unroll
+            for (int x = 0; x < W; x++) in[x] >>= 2;
+            if constexpr (W == 4) itx1d::iwht4(in, out);
+#pragma unroll
+            for (int x = 0; x < W; x++) tmp[l * TS + x] = out[x];
+        } else {
+            tx1d<W>(k1, in, out, row_min, row_max);
+            const int rnd = (1 << SHIFT) >> 1;
+            const bool flip = k1 == K_FLIPADST;
+#pragma unroll
+            for (int x = 0; x < W; x++) {
+                const int xo = flip ? W - 1 - x : x;
+                tmp[l * TS + xo] = dv::iclip((out[x] + rnd) >> SHIFT, col_min, col_max);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- second pass: lane c = column c, H-point transform along y, add to dst
+    if (live && l < W) {
+        pixel *d = reinterpret_cast<pixel *>(dst.data[t.plane]) + t.dst_off + l;
+        const int stride = dst.stride[t.plane];
+        if (dconly) {
+            if (RECT2) dc = (dc * 181 + 128) >> 8;
+            dc = (dc * 181 + 128) >> 8;
+            dc = (dc + ((1 << SHIFT) >> 1)) >> SHIFT;
+            dc = (dc * 181 + 128 + 2048) >> 12;
+#pragma unroll 8
+            for (int y = 0; y < H; y++)
+                d[y * stride] = (pixel) dv::iclip((int) d[y * stride] + dc, 0, bitdepth_max);
+        } else {
+            int in[H], out[H];
+#pragma unroll
+            for (int y = 0; y < H; y++) in[y] = y < SH ? tmp[y * TS + l] : 0;
+            if (TX == 0 && wht) {
+                if constexpr (H == 4) itx1d::iwht4(in, out);
+#pragma unroll
+                for (int y = 0; y < H; y++)
+                    d[y * stride] = (pixel) dv::iclip((int) d[y * stride] + out[y], 0, bitdepth_max);
+            } else {
+                tx1d<H>(k2, in, out, col_min, col_max);
+                const bool flip = k2 == K_FLIPADST;
+#pragma unroll
+                for (int y = 0; y < H; y++) {
+                    const int yo = flip ? H - 1 - y : y;
+                    d[yo * stride] = (pixel) dv::iclip((int) d[yo * stride] + ((out[y] + 8) >> 4), 0, bitdepth_max);
+                }
+            }
+        }
+    }
+}
+
+template <typename pixel, typename coef>
+hipError_t launch_tx(const int tx, const DevPlanes &dst, const Dav1dHipItxTask *tasks, const int n,
+                     coef *cf, const int bitdepth_max, hipStream_t stream)
+{
+#define CASE(T) case T: { \
+        constexpr int lpb = cmax(cmin(tx_h(T), 32), tx_w(T)); \
+        constexpr int bpw = 64 / lpb; \
+        const int grid = (n + bpw - 1) / bpw; \
+        hipLaunchKernelGGL((itx_add_kernel<T, pixel, coef>), dim3(grid), dim3(64), 0, stream, \
+                           dst, tasks, n, cf, bitdepth_max); \
+        break; }
+    switch (tx) {
+        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9)
+        CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18)
+        default: return hipErrorInvalidValue;
+    }
+#undef CASE
+    return hipGetLastError();
+}
+
+} // namespace
+
+// tasks[] (device) holds the tasks of ONE tx size; offsets are managed by capi.
+extern "C" int dav1d_hip_launch_itx_bin(const DevPlanes *dst, int bpc, int tx, const Dav1dHipItxTask *tasks,
+                                        int n, void *coef, void *stream)
+{
+    if (n <= 0) return 0;
+    const int bitdepth_max = (1 << bpc) - 1;
+    hipError_t e;
+    if (bpc == 8) e = launch_tx<uint8_t, int16_t>(tx, *dst, tasks, n, (int16_t *) coef, bitdepth_max, (hipStream_t) stream);
+    else          e = launch_tx<uint16_t, int32_t>(tx, *dst, tasks, n, (int32_t *) coef, bitdepth_max, (hipStream_t) stream);
+    return e == hipSuccess ? 0 : -5;
+}

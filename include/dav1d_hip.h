@@ -1,0 +1,271 @@
+/*
+ * dav1d_hip.h — C ABI of the MI355X (gfx950) block-reconstruction backend.
+ *
+ * This is the drop-in boundary for dav1d's post-entropy hot path: the seven
+ * Dav1dDSPContext function tables (reference src/internal.h:62-70) and the
+ * pass-2 reconstruction hand-off (reference src/internal.h:276-293).
+ *
+ * Two levels are exported, both plain C (pointers + sizes, no C++/torch types):
+ *
+ *   1. Batched entry points (dav1d_hip_*_batch): one call = one kernel family
+ *      over a flat list of POD task descriptors, all buffers device-resident.
+ *      This is what a pass-2 "lister" inside dav1d submits per tile-sbrow / frame.
+ *
+ *   2. A kernel-level drop-in table (Dav1dHipDSPContext, dav1d_hip_dsp_init_*):
+ *      function pointers with the reference's exact DSP signatures that stage
+ *      host memory through the same kernels one call at a time.  It exists so the
+ *      unmodified reference call sites / parity tests can run against the backend;
+ *      it is not the fast path.
+ *
+ * Conventions: every function returns 0 or a negative errno (like DAV1D_ERR(),
+ * reference include/dav1d/common.h); strides are in BYTES like the reference's
+ * ptrdiff_t strides; `bitdepth_max` is (1 << bpc) - 1 as in HIGHBD_DECL_SUFFIX
+ * (reference include/common/bitdepth.h:69).  pixel = uint8_t @8bpc, uint16_t @10/12bpc;
+ * coef = int16_t @8bpc, int32_t @10/12bpc (reference include/common/bitdepth.h:44-63).
+ */
+#ifndef DAV1D_HIP_H
+#define DAV1D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DAV1D_HIP_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ context */
+
+typedef struct Dav1dHipContext Dav1dHipContext;
+
+/* Opens the backend on HIP device `device`.  `stream` is a hipStream_t owned by the
+ * caller (e.g. torch.cuda.current_stream().cuda_stream) or NULL for a private
+ * stream.  All batched calls are asynchronous on that stream.
+ * Fails with -ENODEV if no gfx950 device is usable: there is no CPU fallback. */
+DAV1D_HIP_API int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream);
+DAV1D_HIP_API void dav1d_hip_close(Dav1dHipContext *c);
+DAV1D_HIP_API int dav1d_hip_sync(Dav1dHipContext *c);
+DAV1D_HIP_API void *dav1d_hip_stream(Dav1dHipContext *c);
+DAV1D_HIP_API const char *dav1d_hip_version(void);
+
+/* Device memory helpers (callers may equally pass memory from their own allocator). */
+DAV1D_HIP_API int dav1d_hip_malloc(Dav1dHipContext *c, void **dev, size_t bytes);
+DAV1D_HIP_API int dav1d_hip_free(Dav1dHipContext *c, void *dev);
+DAV1D_HIP_API int dav1d_hip_memset(Dav1dHipContext *c, void *dev, int v, size_t bytes);
+DAV1D_HIP_API int dav1d_hip_upload(Dav1dHipContext *c, void *dev, const void *host, size_t bytes);
+DAV1D_HIP_API int dav1d_hip_download(Dav1dHipContext *c, void *host, const void *dev, size_t bytes);
+
+/* ----------------------------------------------------------------- pictures */
+
+enum Dav1dHipPixelLayout { /* == enum Dav1dPixelLayout, reference include/dav1d/headers.h */
+    DAV1D_HIP_LAYOUT_I400 = 0,
+    DAV1D_HIP_LAYOUT_I420 = 1,
+    DAV1D_HIP_LAYOUT_I422 = 2,
+    DAV1D_HIP_LAYOUT_I444 = 3,
+};
+
+typedef struct Dav1dHipPlane {
+    void *data;        /* device pointer to pixel (0,0) */
+    ptrdiff_t stride;  /* bytes */
+    int w, h;          /* visible size in pixels */
+} Dav1dHipPlane;
+
+typedef struct Dav1dHipPicture {
+    Dav1dHipPlane p[3];
+    int bpc;           /* 8, 10 or 12 */
+    int layout;        /* enum Dav1dHipPixelLayout */
+    void *alloc;       /* base of the allocation (owned when made by picture_alloc) */
+    size_t alloc_size;
+} Dav1dHipPicture;
+
+/* Allocation with the reference's geometry (src/picture.c:46-78): dimensions padded
+ * to 128, stride = aligned_w << hbd, +64 B when a multiple of 1024. */
+DAV1D_HIP_API int dav1d_hip_picture_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic,
+                                          int w, int h, int layout, int bpc);
+DAV1D_HIP_API int dav1d_hip_picture_free(Dav1dHipContext *c, Dav1dHipPicture *pic);
+/* host <-> device plane copies; host_stride in bytes; copies the PADDED plane
+ * (aligned dimensions) when `padded` is non-zero, else the visible w x h. */
+DAV1D_HIP_API int dav1d_hip_plane_upload(Dav1dHipContext *c, const Dav1dHipPicture *pic, int plane,
+                                         const void *host, ptrdiff_t host_stride, int padded);
+DAV1D_HIP_API int dav1d_hip_plane_download(Dav1dHipContext *c, const Dav1dHipPicture *pic, int plane,
+                                           void *host, ptrdiff_t host_stride, int padded);
+
+/* ---------------------------------------------------------------------- itx */
+
+/* One inverse-transform-and-add, replaces one call of
+ *   dsp->itx.itxfm_add[tx][txtp](dst, stride, coeff, eob HIGHBD)      (reference
+ * src/recon_tmpl.c:811-816, 1924-1970; kernel src/itx_tmpl.c:43-124,184-203). */
+typedef struct Dav1dHipItxTask {
+    uint32_t dst_off;  /* pixel offset of the block's top-left inside its plane: y*(stride/sizeof(pixel)) + x */
+    uint32_t cf_off;   /* offset (in coefs) of the block's slab in the coefficient arena;
+                          slab = min(w,32)*min(h,32) coefs, column-major coeff[y + x*min(h,32)]
+                          (reference src/itx_tmpl.c:98-105); must be a multiple of 16 bytes */
+    int16_t  eob;      /* as passed to itxfm_add (>= 0) */
+    uint8_t  tx;       /* enum RectTxfmSize, reference src/levels.h:44-78 (0..18) */
+    uint8_t  txtp;     /* enum TxfmType index of the itxfm_add table, reference src/levels.h:80-100 (16 = WHT_WHT) */
+    uint8_t  plane;    /* 0..2 */
+    uint8_t  pad[3];
+} Dav1dHipItxTask;
+
+/* Runs `n` tasks (any order, any mix of sizes; dst rectangles must be disjoint).
+ * `tasks` is a HOST array (the CPU lister produces it), `coef` a DEVICE pointer to
+ * the coefficient arena; every consumed slab is zeroed exactly as the reference does
+ * (src/itx_tmpl.c:60,108: the whole slab, or coeff[0] on the dc-only path).  The
+ * call bins the tasks by tx size, uploads them, launches and waits. */
+DAV1D_HIP_API int dav1d_hip_itx_add_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst,
+                                          const Dav1dHipItxTask *tasks, size_t n, void *coef);
+
+/* A pre-binned, device-resident list (what the frame driver and bench use):
+ * sort + upload once, launch many times. */
+typedef struct Dav1dHipItxList Dav1dHipItxList;
+DAV1D_HIP_API int dav1d_hip_itx_list_create(Dav1dHipContext *c, Dav1dHipItxList **out,
+                                            const Dav1dHipItxTask *host_tasks, size_t n);
+DAV1D_HIP_API void dav1d_hip_itx_list_destroy(Dav1dHipContext *c, Dav1dHipItxList *l);
+DAV1D_HIP_API int dav1d_hip_itx_list_run(Dav1dHipContext *c, const Dav1dHipItxList *l,
+                                         const Dav1dHipPicture *dst, void *coef);
+
+/* ----------------------------------------------------------------------- mc */
+
+enum Dav1dHipMcKind {
+    DAV1D_HIP_MC_PUT  = 0,  /* dsp->mc.mc[filter_2d]   -> pixels into dst plane   (reference src/mc_tmpl.c:129-187, 434-489) */
+    DAV1D_HIP_MC_PREP = 1,  /* dsp->mc.mct[filter_2d]  -> int16 into the prep arena (reference src/mc_tmpl.c:246-305, 516-586) */
+};
+
+/* One motion-compensated prediction, replaces one call of mc() in the reference
+ * driver (src/recon_tmpl.c:938-1050): dsp->mc.emu_edge when the window leaves the
+ * reference plane (:967-978) followed by dsp->mc.mc / mct (:983-989).  Edge
+ * emulation is folded into the fetch: source coordinates are clamped to
+ * [0, ref_w-1] x [0, ref_h-1] (== emu_edge_c, reference src/mc_tmpl.c:868-916). */
+typedef struct Dav1dHipMcTask {
+    uint32_t dst_off;   /* PUT: pixel offset in dst plane; PREP: int16 offset in the prep arena (w*h contiguous, row stride w) */
+    int32_t  src_x;     /* integer position of the block's top-left in the reference plane (may be out of range) */
+    int32_t  src_y;
+    uint8_t  w, h;      /* 2..128 */
+    uint8_t  mx, my;    /* 0..15 sixteenth-pel phases as passed to mc_fn */
+    uint8_t  filter_2d; /* enum Filter2d, reference src/levels.h:184-196 (9 = bilinear) */
+    uint8_t  kind;      /* enum Dav1dHipMcKind */
+    uint8_t  plane;     /* plane index (same in dst and ref) */
+    uint8_t  ref;       /* index into the refs[] array passed to the batch call */
+    uint32_t pad;
+} Dav1dHipMcTask;
+
+/* `tasks` is a HOST array; `refs` is a host array of n_refs (<= 8) picture
+ * descriptors with device planes; `prep` is the DEVICE int16 arena PREP tasks write to. */
+DAV1D_HIP_API int dav1d_hip_mc_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst,
+                                     const Dav1dHipPicture *refs, int n_refs,
+                                     const Dav1dHipMcTask *tasks, size_t n, int16_t *prep);
+
+/* Pre-tiled, device-resident list: blocks are cut into <= 16x16 tiles and binned by
+ * tile shape once; run many times. */
+typedef struct Dav1dHipMcList Dav1dHipMcList;
+DAV1D_HIP_API int dav1d_hip_mc_list_create(Dav1dHipContext *c, Dav1dHipMcList **out,
+                                           const Dav1dHipMcTask *host_tasks, size_t n);
+DAV1D_HIP_API void dav1d_hip_mc_list_destroy(Dav1dHipContext *c, Dav1dHipMcList *l);
+DAV1D_HIP_API int dav1d_hip_mc_list_run(Dav1dHipContext *c, const Dav1dHipMcList *l,
+                                        const Dav1dHipPicture *dst, const Dav1dHipPicture *refs,
+                                        int n_refs, int16_t *prep);
+
+/* Compound combination of two prepared predictions, replaces dsp->mc.avg / w_avg /
+ * mask / w_mask (reference src/recon_tmpl.c:1802-1826; src/mc_tmpl.c:628-681,724-794). */
+enum Dav1dHipCompKind {
+    DAV1D_HIP_COMP_AVG = 0,
+    DAV1D_HIP_COMP_WAVG = 1,   /* arg = weight (jnt_weight) */
+    DAV1D_HIP_COMP_MASK = 2,   /* mask_off -> w*h bytes in the mask arena */
+    DAV1D_HIP_COMP_WMASK = 3,  /* arg = sign; ss = 0:444 1:422 2:420; mask_off -> output mask */
+};
+typedef struct Dav1dHipCompTask {
+    uint32_t dst_off;   /* pixel offset in dst plane */
+    uint32_t tmp1_off;  /* int16 offsets in the prep arena */
+    uint32_t tmp2_off;
+    uint32_t mask_off;  /* byte offset in the mask arena (MASK: input, WMASK: output) */
+    uint8_t  w, h;
+    uint8_t  kind;      /* enum Dav1dHipCompKind */
+    uint8_t  plane;
+    int8_t   arg;
+    uint8_t  ss;
+    uint16_t pad;
+} Dav1dHipCompTask;
+
+/* `tasks` HOST array; `prep` / `mask` DEVICE arenas. */
+DAV1D_HIP_API int dav1d_hip_comp_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst,
+                                       const Dav1dHipCompTask *tasks, size_t n,
+                                       const int16_t *prep, uint8_t *mask);
+typedef struct Dav1dHipCompList Dav1dHipCompList;
+DAV1D_HIP_API int dav1d_hip_comp_list_create(Dav1dHipContext *c, Dav1dHipCompList **out,
+                                             const Dav1dHipCompTask *host_tasks, size_t n);
+DAV1D_HIP_API void dav1d_hip_comp_list_destroy(Dav1dHipContext *c, Dav1dHipCompList *l);
+DAV1D_HIP_API int dav1d_hip_comp_list_run(Dav1dHipContext *c, const Dav1dHipCompList *l,
+                                          const Dav1dHipPicture *dst, const int16_t *prep, uint8_t *mask);
+
+/* ------------------------------------------------- reference-signature table */
+
+/* Function pointer types with the reference's exact signatures (16 bpc flavour
+ * carries the trailing bitdepth_max, 8 bpc does not; reference src/itx.h:37-40,
+ * src/mc.h:38-122).  Pointers are HOST pointers. */
+typedef void (*dav1d_hip_itxfm_fn8)(uint8_t *dst, ptrdiff_t stride, int16_t *coeff, int eob);
+typedef void (*dav1d_hip_itxfm_fn16)(uint16_t *dst, ptrdiff_t stride, int32_t *coeff, int eob, int bitdepth_max);
+typedef void (*dav1d_hip_mc_fn8)(uint8_t *dst, ptrdiff_t dst_stride, const uint8_t *src, ptrdiff_t src_stride,
+                                 int w, int h, int mx, int my);
+typedef void (*dav1d_hip_mc_fn16)(uint16_t *dst, ptrdiff_t dst_stride, const uint16_t *src, ptrdiff_t src_stride,
+                                  int w, int h, int mx, int my, int bitdepth_max);
+typedef void (*dav1d_hip_mct_fn8)(int16_t *tmp, const uint8_t *src, ptrdiff_t src_stride,
+                                  int w, int h, int mx, int my);
+typedef void (*dav1d_hip_mct_fn16)(int16_t *tmp, const uint16_t *src, ptrdiff_t src_stride,
+                                   int w, int h, int mx, int my, int bitdepth_max);
+typedef void (*dav1d_hip_avg_fn8)(uint8_t *dst, ptrdiff_t dst_stride, const int16_t *tmp1, const int16_t *tmp2, int w, int h);
+typedef void (*dav1d_hip_avg_fn16)(uint16_t *dst, ptrdiff_t dst_stride, const int16_t *tmp1, const int16_t *tmp2, int w, int h,
+                                   int bitdepth_max);
+typedef void (*dav1d_hip_w_avg_fn8)(uint8_t *dst, ptrdiff_t dst_stride, const int16_t *tmp1, const int16_t *tmp2, int w, int h,
+                                    int weight);
+typedef void (*dav1d_hip_w_avg_fn16)(uint16_t *dst, ptrdiff_t dst_stride, const int16_t *tmp1, const int16_t *tmp2, int w, int h,
+                                     int weight, int bitdepth_max);
+typedef void (*dav1d_hip_mask_fn8)(uint8_t *dst, ptrdiff_t dst_stride, const int16_t *tmp1, const int16_t *tmp2, int w, int h,
+                                   const uint8_t *mask);
+typedef void (*dav1d_hip_mask_fn16)(uint16_t *dst, ptrdiff_t dst_stride, const int16_t *tmp1, const int16_t *tmp2, int w, int h,
+                                    const uint8_t *mask, int bitdepth_max);
+typedef void (*dav1d_hip_w_mask_fn8)(uint8_t *dst, ptrdiff_t dst_stride, const int16_t *tmp1, const int16_t *tmp2, int w, int h,
+                                     uint8_t *mask, int sign);
+typedef void (*dav1d_hip_w_mask_fn16)(uint16_t *dst, ptrdiff_t dst_stride, const int16_t *tmp1, const int16_t *tmp2, int w, int h,
+                                      uint8_t *mask, int sign, int bitdepth_max);
+
+#define DAV1D_HIP_N_RECT_TX_SIZES 19
+#define DAV1D_HIP_N_TX_TYPES_PLUS_LL 17
+#define DAV1D_HIP_N_2D_FILTERS 10
+
+/* Mirrors of the reference's per-family tables (member names follow the reference
+ * structs: src/itx.h:70-72, src/mc.h:146-162).  Entries the backend does not
+ * provide yet are NULL. */
+typedef struct Dav1dHipInvTxfmDSPContext8 { dav1d_hip_itxfm_fn8 itxfm_add[DAV1D_HIP_N_RECT_TX_SIZES][DAV1D_HIP_N_TX_TYPES_PLUS_LL]; } Dav1dHipInvTxfmDSPContext8;
+typedef struct Dav1dHipInvTxfmDSPContext16 { dav1d_hip_itxfm_fn16 itxfm_add[DAV1D_HIP_N_RECT_TX_SIZES][DAV1D_HIP_N_TX_TYPES_PLUS_LL]; } Dav1dHipInvTxfmDSPContext16;
+typedef struct Dav1dHipMCDSPContext8 {
+    dav1d_hip_mc_fn8 mc[DAV1D_HIP_N_2D_FILTERS];
+    dav1d_hip_mct_fn8 mct[DAV1D_HIP_N_2D_FILTERS];
+    dav1d_hip_avg_fn8 avg;
+    dav1d_hip_w_avg_fn8 w_avg;
+    dav1d_hip_mask_fn8 mask;
+    dav1d_hip_w_mask_fn8 w_mask[3];
+} Dav1dHipMCDSPContext8;
+typedef struct Dav1dHipMCDSPContext16 {
+    dav1d_hip_mc_fn16 mc[DAV1D_HIP_N_2D_FILTERS];
+    dav1d_hip_mct_fn16 mct[DAV1D_HIP_N_2D_FILTERS];
+    dav1d_hip_avg_fn16 avg;
+    dav1d_hip_w_avg_fn16 w_avg;
+    dav1d_hip_mask_fn16 mask;
+    dav1d_hip_w_mask_fn16 w_mask[3];
+} Dav1dHipMCDSPContext16;
+
+typedef struct Dav1dHipDSPContext8 { Dav1dHipMCDSPContext8 mc; Dav1dHipInvTxfmDSPContext8 itx; } Dav1dHipDSPContext8;
+typedef struct Dav1dHipDSPContext16 { Dav1dHipMCDSPContext16 mc; Dav1dHipInvTxfmDSPContext16 itx; } Dav1dHipDSPContext16;
+
+/* Counterparts of dav1d_{itx,mc}_dsp_init_{8,16}bpc (reference src/decode.c:3387-3415,
+ * src/itx_tmpl.c:220-311, src/mc_tmpl.c:960-1006).  They bind the table to the
+ * process-wide default context (device 0 unless DAV1D_HIP_DEVICE is set), opened on
+ * first use; they return -ENODEV when that fails and leave the table zeroed. */
+DAV1D_HIP_API int dav1d_hip_dsp_init_8bpc(Dav1dHipDSPContext8 *c);
+DAV1D_HIP_API int dav1d_hip_dsp_init_16bpc(Dav1dHipDSPContext16 *c, int bpc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAV1D_HIP_H */

@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+# Every kernel parity test runs against two builds of the SAME kernel sources:
+#   emu -> tests/emu SIMT emulation compiled with g++ (CPU container, -m "not gpu")
+#   hip -> dav1d_amd/libdav1d_hip.so on cuda:0 through the C ABI (-m gpu)
+BACKENDS = [pytest.param("emu", id="emu"), pytest.param("hip", marks=pytest.mark.gpu, id="hip")]
+
+
+@pytest.fixture(scope="session", params=BACKENDS)
+def ctx(request):
+    import util
+    c = util.make_context(request.param)
+    c.backend = request.param
+    yield c
+    c.close()

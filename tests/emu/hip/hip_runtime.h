@@ -26,6 +26,13 @@ struct dim3 {
 };
 struct uint3 { unsigned x, y, z; };
 
+struct int4 { int x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+static inline int4 make_int4(int x, int y, int z, int w) { int4 v = { x, y, z, w }; return v; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 v = { x, y }; return v; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 v = { x, y, z, w }; return v; }
+
 extern uint3 threadIdx, blockIdx;
 extern dim3 blockDim, gridDim;
 
@@ -33,7 +40,7 @@ extern dim3 blockDim, gridDim;
 #define __device__
 #define __host__
 #define __shared__ static
-#define __constant__ static
+#define __constant__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)

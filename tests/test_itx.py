@@ -1,0 +1,82 @@
+"""itxfm_add parity: HIP kernels (through the C ABI) vs the reference C functions.
+
+Input generation follows tests/checkasm/itx.c:185-305 (forward float transform of a random
+residual, random eob per sub-size class so dc-only / partial paths are hit); both the pixels
+and the zeroed coefficient slabs are compared byte for byte."""
+import numpy as np
+import pytest
+
+import util
+from dav1d_amd import api
+
+
+def _build_case(rng, bpc, txs, per_type, layout=api.LAYOUT_I400, W=256, H=256):
+    """Tile a WxH plane with blocks of the requested tx sizes; returns tasks, coef arena, block list."""
+    tasks, coefs, blocks = [], [], []
+    cf_off = 0
+    x = y = 0
+    row_h = 0
+    for tx in txs:
+        w, h = util.TX_W[tx], util.TX_H[tx]
+        for txtp in util.legal_txtps(tx):
+            for rep in range(per_type):
+                for subsh in range(1 if txtp else 0, util.subsh_max(tx)):
+                    if txtp == util.WHT_WHT and subsh > 1:
+                        continue
+                    if x + w > W:
+                        x = 0; y += row_h; row_h = 0
+                    if y + h > H:
+                        return tasks, coefs, blocks, True
+                    cf, eob = util.gen_itx_coefs(rng, tx, txtp, bpc, subsh)
+                    tasks.append((x, y, cf_off, eob, tx, txtp))
+                    coefs.append(cf)
+                    blocks.append((x, y, w, h))
+                    cf_off += len(cf)
+                    x += w
+                    row_h = max(row_h, h)
+    return tasks, coefs, blocks, False
+
+
+def _run_case(ctx, oracle, bpc, txs, per_type, seed):
+    rng = np.random.default_rng(seed)
+    W = H = 256
+    tasks, coefs, blocks, trunc = _build_case(rng, bpc, txs, per_type, W=W, H=H)
+    assert tasks and not trunc
+    pd = util.pix_dtype(bpc)
+    plane = rng.integers(0, 1 << bpc, size=(H, W)).astype(pd)
+    arena = np.concatenate(coefs)
+    # ---- oracle, block by block, on host copies
+    ref_plane = plane.copy()
+    ref_arena = arena.copy()
+    for (x, y, cf_off, eob, tx, txtp) in tasks:
+        n = len(coefs[0]) * 0 + min(util.TX_W[tx], 32) * min(util.TX_H[tx], 32)
+        dst = ref_plane[y:, x:]
+        oracle.call(bpc, "itxfm_add", tx, txtp, dst.ctypes.data, ref_plane.strides[0],
+                    ref_arena[cf_off:cf_off + n].ctypes.data, eob)
+    # ---- backend through the C ABI
+    pic = ctx.picture(W, H, api.LAYOUT_I400, bpc)
+    pic.upload(0, plane)
+    dcoef = ctx.buffer_from(arena)
+    t = np.zeros(len(tasks), api.ITX_TASK)
+    sp = pic.stride_px(0)
+    for i, (x, y, cf_off, eob, tx, txtp) in enumerate(tasks):
+        t[i] = (y * sp + x, cf_off, eob, tx, txtp, 0, (0, 0, 0))
+    perm = rng.permutation(len(t))            # any order must give the same result
+    ctx.itx_add_batch(pic, t[perm], dcoef)
+    out = pic.download(0)
+    out_arena = dcoef.download(arena.dtype, len(arena))
+    pic.free(); dcoef.free()
+    bad = np.argwhere(out != ref_plane)
+    if len(bad):
+        yy, xx = bad[0]
+        blk = [b for b in zip(tasks, blocks) if b[1][0] <= xx < b[1][0] + b[1][2] and b[1][1] <= yy < b[1][1] + b[1][3]]
+        raise AssertionError("pixel mismatch at (%d,%d): got %d want %d; block %s" %
+                             (xx, yy, out[yy, xx], ref_plane[yy, xx], blk[:1]))
+    assert np.array_equal(out_arena, ref_arena), "coefficient slabs not zeroed like the reference"
+
+
+@pytest.mark.parametrize("bpc", [8, 10, 12])
+@pytest.mark.parametrize("tx", list(range(19)), ids=util.TX_NAMES)
+def test_itxfm_add_matches_reference(ctx, bpc, tx):
+    per_type = 1 if ctx.backend == "emu" else 2
+    _run_case(ctx, util.default_oracle(), bpc, [tx], per_type, seed=1000 + tx * 3 + bpc)
