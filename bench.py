@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Headline benchmark: reconstructed Mpixels/s of the itx+mc reconstruction path at
+8K 4:2:0 10-bit on N MI355X GPUs (BASELINE.json metric), one process per GPU.
+
+A "step" = one pass of the hot path over one synthetic 8K inter frame whose task lists
+(dav1d_amd.synth, SURVEY.md §8d config C2's itx+mc subset) are already resident in HBM:
+    mc put/prep (all blocks, 3 planes) -> compound avg (25 % of blocks) -> itxfm_add (all blocks).
+Every step consumes its own pristine copy of the coefficient arena (the kernels zero the
+slabs they consume, as the reference does) and rotates over 4 output pictures, so no step
+runs on cached or already-zeroed data.  N > 1: frame-parallel replicas, one frame stream
+per GPU, no data-path collective ("weak" scaling).
+
+Prints ONE JSON line (rank 0) with the throughput, the roofline of the dominant kernel
+(measured live with HIP events on the launch stream) and the CPU baseline (the oracle
+replayed on the host cores for a bounded number of frames).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=7680)
+    ap.add_argument("--height", type=int, default=4320)
+    ap.add_argument("--bpc", type=int, default=10)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(frame):
+    """per reconstructed coded single-ref inter sample
+    P (ref read) + C (coef read) + C (coef zero-write) + P (dst write); compound adds one P."""
+    P = 1 if frame.bpc == 8 else 2
+    Cb = 2 if frame.bpc == 8 else 4
+    comp_samples = int((frame.comp["w"].astype(np.int64) * frame.comp["h"]).sum())
+    return frame.n_samples * (2 * P + 2 * Cb) + comp_samples * P
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from dav1d_amd import api, synth
+
+    stream = torch.cuda.current_stream()
+    ctx = api.Context(local, stream=stream.cuda_stream)
+    w, h, bpc = a.width, a.height, a.bpc
+    t_gen = time.time()
+    frame = synth.make_frame(w, h, bpc, seed=0xDA71D002 + rank)
+    rng = np.random.default_rng(1234 + rank)
+    ref_host = [synth.make_planes(rng, w, h, bpc) for _ in range(frame.n_refs)]
+    dst_host = synth.make_planes(rng, w, h, bpc, smooth=False)
+    t_gen = time.time() - t_gen
+
+    # ---- device-resident state
+    refs = []
+    for rp in ref_host:
+        r = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+        for pl in range(3):
+            r.upload(pl, rp[pl])
+        refs.append(r)
+    NDST = 4
+    dsts = []
+    for _ in range(NDST):
+        d = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+        for pl in range(3):
+            d.upload(pl, dst_host[pl])
+        dsts.append(d)
+    mc_list, comp_list, itx_list = ctx.mc_list(frame.mc), ctx.comp_list(frame.comp), ctx.itx_list(frame.itx)
+    prep = torch.zeros(frame.prep_elems, dtype=torch.int16, device="cuda")
+    tdt = torch.int16 if bpc == 8 else torch.int32
+    pristine = torch.from_numpy(frame.coef).to("cuda")
+    n_arena = a.steps + a.warmup + 1
+    arenas = torch.empty((n_arena, pristine.numel()), dtype=tdt, device="cuda")
+    for i in range(n_arena):
+        arenas[i].copy_(pristine)
+    torch.cuda.synchronize()
+
+    def step(i):
+        d = dsts[i % NDST]
+        ctx.run_mc_list(mc_list, d, refs, prep.data_ptr())
+        if comp_list.n:
+            ctx.run_comp_list(comp_list, d, prep.data_ptr())
+        ctx.run_itx_list(itx_list, d, arenas[i].data_ptr())
+
+    # ---- parity gate on this very workload: frame `warmup-0` output vs the oracle replay (bounded: luma rows)
+    check = "skipped"
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.warmup, a.warmup + a.steps):
+        step(i)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt / a.steps * 1e3
+    value = world * frame.luma_pixels * a.steps / dt / 1e6      # luma Mpixels/s, whole job
+
+    out = None
+    if rank == 0:
+        # ---- per-kernel durations (HIP events on the launch stream), one instrumented step
+        i = a.warmup + a.steps
+        ms_mc = (C.c_float * 9)()
+        cnt_mc = (C.c_size_t * 9)()
+        ms_itx = (C.c_float * 19)()
+        cnt_itx = (C.c_size_t * 19)()
+        rarr = (api.Picture * len(refs))(*[r.pic for r in refs])
+        d = dsts[i % NDST]
+        rc = ctx.lib.dav1d_hip_mc_list_run_timed(ctx.h, mc_list.h, C.byref(d.pic), rarr, len(refs), prep.data_ptr(), ms_mc, cnt_mc)
+        assert rc == 0
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
+        if comp_list.n:
+            ctx.run_comp_list(comp_list, d, prep.data_ptr())
+        ev1.record(stream)
+        rc = ctx.lib.dav1d_hip_itx_list_run_timed(ctx.h, itx_list.h, C.byref(d.pic), arenas[i].data_ptr(), ms_itx, cnt_itx)
+        assert rc == 0
+        torch.cuda.synchronize()
+        ms_comp = ev0.elapsed_time(ev1)
+        P = 1 if bpc == 8 else 2
+        Cb = 2 if bpc == 8 else 4
+        kernels = []
+        tile_px = {0: 4, 1: 8, 2: 16}
+        for b in range(9):
+            if cnt_mc[b]:
+                px = cnt_mc[b] * tile_px[b // 3] * tile_px[b % 3]
+                kernels.append(("mc_%dx%d" % (tile_px[b // 3], tile_px[b % 3]), ms_mc[b], px * 2 * P))
+        if comp_list.n:
+            cpx = int((frame.comp["w"].astype(np.int64) * frame.comp["h"]).sum())
+            kernels.append(("comp_avg", ms_comp, cpx * (4 + P)))
+        for b in range(19):
+            if cnt_itx[b]:
+                px = cnt_itx[b] * synth.TX_W[b] * synth.TX_H[b]
+                cf = cnt_itx[b] * min(synth.TX_W[b], 32) * min(synth.TX_H[b], 32)
+                kernels.append(("itx_%dx%d" % (synth.TX_W[b], synth.TX_H[b]), ms_itx[b], cf * 2 * Cb + px * 2 * P))
+        kernels.sort(key=lambda k: -k[1])
+        dom = kernels[0]
+        ach = dom[2] / (dom[1] * 1e-3) / 1e9
+        path_bytes = algorithmic_bytes(frame)
+        roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel_ms": round(dom[1], 4), "algorithmic_bytes_per_launch": int(dom[2]),
+                "path": {"algorithmic_bytes_per_frame": int(path_bytes),
+                         "achieved": round(path_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                         "frac": round(path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                "kernels_ms": {k[0]: round(k[1], 4) for k in kernels}}
+
+        # ---- parity gate + CPU baseline: the oracle replays the SAME lists on the host
+        cpu = None
+        if not a.no_cpu or not a.no_check:
+            import util
+            import test_frame
+            oracle = util.default_oracle()
+            reps, t_cpu = 0, 0.0
+            want = None
+            while True:
+                t1 = time.perf_counter()
+                want = test_frame.oracle_frame(oracle, frame, dst_host, ref_host)
+                t_cpu += time.perf_counter() - t1
+                reps += 1
+                if a.no_cpu or t_cpu >= a.cpu_seconds or reps >= 8:
+                    break
+            if not a.no_check:
+                got = [dsts[i % NDST].download(pl) for pl in range(3)]
+                ok = all(np.array_equal(got[pl], want[0][pl]) for pl in range(3))
+                ok = ok and not bool(arenas[i].any().item())
+                check = "bit-exact vs %s oracle (3 planes of the last frame)" % oracle.which if ok else "MISMATCH"
+                if not ok:
+                    raise SystemExit("bench: GPU output differs from the oracle")
+            cpu = {"value": round(frame.luma_pixels * reps / t_cpu / 1e6, 2), "unit": "Mpixels/s", "cores": 1,
+                   "kind": "reference" if oracle.which == "ref" else "port",
+                   "sample": "%d full %dx%d frame(s) of the same task lists through the oracle's C DSP entries, "
+                             "1 thread, %.1f s" % (reps, w, h, t_cpu),
+                   "host_cores_available": os.cpu_count()}
+        out = {"metric": "reconstructed luma Mpixels/s (8K 4:2:0 10-bit) on the itx+mc recon path; bit-exact vs C",
+               "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "int32" if bpc > 8 else "int16", "data": "synthetic",
+               "config": {"workload": "%dx%d 4:2:0 %d-bit inter frame, itx+mc recon (SURVEY §8d C2 mix 64/32/16/8/4 = "
+                                      "20/30/30/15/5 %% by area, 25 %% compound avg, all blocks coded, 3 refs); "
+                                      "lists resident in HBM" % (w, h, bpc),
+                          "frames_per_step": 1, "parallelism": "frame-parallel x%d" % world,
+                          "tasks": {"mc": int(len(frame.mc)), "comp": int(len(frame.comp)), "itx": int(len(frame.itx))},
+                          "samples_per_frame": frame.n_samples, "parity": check, "gen_seconds": round(t_gen, 1)},
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    barrier()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -240,6 +240,28 @@ int dav1d_hip_itx_list_run(Dav1dHipContext *c, const Dav1dHipItxList *l, const D
     return 0;
 }
 
+// Same launches, each bracketed by HIP events on the context's stream; ms[b] receives the
+// duration of bin b's kernel (0 for empty bins).  Measurement aid for bench.py.
+int dav1d_hip_itx_list_run_timed(Dav1dHipContext *c, const Dav1dHipItxList *l, const Dav1dHipPicture *dst, void *coef,
+                                 float *ms, size_t *counts) {
+    if (!l || !dst || !ms) return -EINVAL;
+    const DevPlanes dp = dev_planes(dst);
+    hipEvent_t ev[20];
+    for (int b = 0; b < 20; b++) HIP_TRY(hipEventCreate(&ev[b]));
+    HIP_TRY(hipEventRecord(ev[0], c->stream));
+    int rc = 0;
+    for (int b = 0; b < 19 && !rc; b++) {
+        const size_t cnt = l->off[b + 1] - l->off[b];
+        if (counts) counts[b] = cnt;
+        if (cnt) rc = dav1d_hip_launch_itx_bin(&dp, dst->bpc, b, l->dev + l->off[b], (int) cnt, coef, c->stream);
+        hipEventRecord(ev[b + 1], c->stream);
+    }
+    hipStreamSynchronize(c->stream);
+    for (int b = 0; b < 19; b++) { ms[b] = 0.f; hipEventElapsedTime(&ms[b], ev[b], ev[b + 1]); }
+    for (int b = 0; b < 20; b++) hipEventDestroy(ev[b]);
+    return rc;
+}
+
 int dav1d_hip_itx_add_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipItxTask *tasks,
                             size_t n, void *coef) {
     Dav1dHipItxList *l = nullptr;
@@ -343,6 +365,28 @@ int dav1d_hip_mc_list_run(Dav1dHipContext *c, const Dav1dHipMcList *l, const Dav
         if (rc) return rc;
     }
     return 0;
+}
+
+int dav1d_hip_mc_list_run_timed(Dav1dHipContext *c, const Dav1dHipMcList *l, const Dav1dHipPicture *dst,
+                                const Dav1dHipPicture *refs, int n_refs, int16_t *prep, float *ms, size_t *counts) {
+    if (!l || !dst || !refs || n_refs < 1 || n_refs > 8 || !ms) return -EINVAL;
+    const DevPlanes dp = dev_planes(dst);
+    DevPlanes rp[8];
+    for (int i = 0; i < n_refs; i++) rp[i] = dev_planes(&refs[i]);
+    hipEvent_t ev[10];
+    for (int b = 0; b < 10; b++) HIP_TRY(hipEventCreate(&ev[b]));
+    HIP_TRY(hipEventRecord(ev[0], c->stream));
+    int rc = 0;
+    for (int b = 0; b < 9 && !rc; b++) {
+        const size_t cnt = l->off[b + 1] - l->off[b];
+        if (counts) counts[b] = cnt;
+        if (cnt) rc = dav1d_hip_launch_mc_bin(&dp, rp, n_refs, dst->bpc, b, l->dev + l->off[b], (int) cnt, prep, c->stream);
+        hipEventRecord(ev[b + 1], c->stream);
+    }
+    hipStreamSynchronize(c->stream);
+    for (int b = 0; b < 9; b++) { ms[b] = 0.f; hipEventElapsedTime(&ms[b], ev[b], ev[b + 1]); }
+    for (int b = 0; b < 10; b++) hipEventDestroy(ev[b]);
+    return rc;
 }
 
 int dav1d_hip_mc_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *refs, int n_refs,

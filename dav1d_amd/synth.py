@@ -1,0 +1,239 @@
+"""Synthetic per-frame task lists for the reconstruction hot path.
+
+No AV1 bitstreams are available, so bench.py and the frame-level tests build the
+lists a pass-2 lister would emit for one inter frame: a block grid drawn from a size
+mix, one or two motion vectors per block, dequantised coefficients in the valid
+dynamic range with an eob consistent with the default scan order.  Everything is
+derived from a seed (numpy PCG64), vectorised so that an 8K frame takes seconds.
+"""
+import os
+
+import numpy as np
+
+from ._lib import ITX_TASK, MC_TASK, COMP_TASK
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+TX_W = [4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64]
+TX_H = [4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16]
+SQ_TX = {4: 0, 8: 1, 16: 2, 32: 3, 64: 4}
+
+_scans = None
+
+
+def scans():
+    """Default scan order per tx size (AV1 spec tables; dumped once from the oracle build by
+    tests/util.py into dav1d_amd/data/scans.npz)."""
+    global _scans
+    if _scans is None:
+        z = np.load(os.path.join(HERE, "data", "scans.npz"))
+        _scans = [z["tx%d" % t].astype(np.int64) for t in range(19)]
+    return _scans
+
+
+def plane_geometry(w, h, bpc, layout=1):
+    """(stride in pixels, padded rows) per plane; mirrors dav1d_hip_picture_alloc /
+    reference src/picture.c:46-78."""
+    hbd = bpc > 8
+    aw, ah = (w + 127) & ~127, (h + 127) & ~127
+    ss_ver = 1 if layout == 1 else 0
+    ss_hor = 1 if layout != 3 else 0
+    ys = aw << hbd
+    uvs = ys >> ss_hor
+    if not (ys & 1023):
+        ys += 64
+    if not (uvs & 1023):
+        uvs += 64
+    bps = 2 if hbd else 1
+    return [(ys // bps, ah), (uvs // bps, ah >> ss_ver), (uvs // bps, ah >> ss_ver)]
+
+
+def _dct_mat(n):
+    i = np.arange(n)[:, None]
+    j = np.arange(n)[None, :]
+    m = np.cos(np.pi * (2 * j + 1) * i / (2.0 * n))
+    m[0] *= np.sqrt(0.5)
+    return m
+
+
+_SCALE = [4.0, 4.0 * np.sqrt(0.5), 2.0, 2.0 * np.sqrt(0.5), 1.0, 0.5 * np.sqrt(0.5), 0.25, 0.125 * np.sqrt(0.5), 0.0625]
+
+
+def gen_coefs(rng, tx, n, bpc, eob_class_p=(0.3, 0.4, 0.3)):
+    """n slabs for tx size `tx` (2-D scan class): forward float DCT of a random residual in
+    [-bitdepth_max, bitdepth_max] (like tests/checkasm/itx.c:185-242), rounded, everything after
+    a per-block eob zeroed in scan order.  eob classes: dc-only / <= 1/4 of the slab / anywhere.
+    Returns (coefs[n, sw*sh] in the reference's column-major slab layout, eob[n])."""
+    w, h = TX_W[tx], TX_H[tx]
+    sw, sh = min(w, 32), min(h, 32)
+    bdmax = (1 << bpc) - 1
+    cdt = np.int16 if bpc == 8 else np.int32
+    scale = _SCALE[int(np.log2(w * h)) - 4]
+    out = np.empty((n, sw * sh), cdt)
+    ncoef = sw * sh
+    cls = rng.choice(3, size=n, p=eob_class_p)
+    eob = np.where(cls == 0, 0, np.where(cls == 1, rng.integers(1, max(2, ncoef // 4), size=n),
+                                         rng.integers(1, ncoef, size=n))).astype(np.int64)
+    scan = scans()[tx]
+    inv = np.empty(ncoef, np.int64)
+    inv[scan] = np.arange(ncoef)          # position of raster index rc in scan order
+    mw, mh = _dct_mat(w)[:sw] * scale, _dct_mat(h)[:sh]
+    step = max(1, (1 << 22) // (w * h))
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        res = rng.integers(-bdmax, bdmax + 1, size=(e - s, h, w)).astype(np.float32)
+        t = np.einsum("nyx,kx->nyk", res, mw.astype(np.float32))      # rows -> [n, y, kx]
+        c = np.einsum("ly,nyk->nkl", mh.astype(np.float32), t)        # cols -> [n, kx, ky] == slab[x*sh + y]
+        c = np.floor(c + 0.5).reshape(e - s, ncoef)
+        c[inv[None, :] > eob[s:e, None]] = 0
+        out[s:e] = c.astype(cdt)
+    return out, eob
+
+
+class Frame:
+    """Host-side task lists + coefficient arena of one synthetic inter frame."""
+    pass
+
+
+def make_frame(w, h, bpc, seed, mix=(0.20, 0.30, 0.30, 0.15, 0.05), compound_frac=0.25, n_refs=3,
+               mv_range_px=64, edge_frac=0.05, region=64, alt_txtp_frac=0.3):
+    """Block-size mix by area over 64x64 regions: (64, 32, 16, 8, 4)."""
+    rng = np.random.default_rng(seed)
+    geo = plane_geometry(w, h, bpc, 1)
+    sizes = np.array([64, 32, 16, 8, 4])
+    rx = np.arange(0, w, region)
+    ry = np.arange(0, h, region)
+    gx, gy = np.meshgrid(rx, ry)
+    gx, gy = gx.ravel(), gy.ravel()
+    rcls = rng.choice(5, size=len(gx), p=mix)
+
+    mc_parts, comp_parts, itx_parts = [], [], []
+    coef_parts = []
+    cf_off = 0
+    prep_off = 0
+    n_samples = 0
+
+    for ci, s in enumerate(sizes):
+        sel = np.flatnonzero(rcls == ci)
+        if not len(sel):
+            continue
+        k = region // s
+        ox, oy = np.meshgrid(np.arange(k) * s, np.arange(k) * s)
+        # raster order inside the region, regions in raster order (decode order of a 1-tile frame)
+        bx = (gx[sel][:, None] + ox.ravel()[None, :]).ravel()
+        by = (gy[sel][:, None] + oy.ravel()[None, :]).ravel()
+        keep = (bx < w) & (by < h)
+        bx, by = bx[keep], by[keep]
+        nb = len(bx)
+        comp = (rng.random(nb) < compound_frac) & (s >= 8)
+        ref0 = rng.integers(0, n_refs, size=nb)
+        ref1 = (ref0 + 1 + rng.integers(0, max(1, n_refs - 1), size=nb)) % n_refs
+        mv = rng.integers(-mv_range_px * 8, mv_range_px * 8 + 1, size=(2, nb, 2))   # [ref, block, (y, x)] 1/8 pel
+        # a band of blocks points far outside the picture to exercise edge emulation
+        far = rng.random(nb) < edge_frac
+        mv[:, far, :] *= 24
+        filt = np.where(rng.random(nb) < 0.7, 0, rng.integers(0, 10, size=nb))
+
+        for pl in range(3):
+            ss = 1 if pl else 0
+            if s == 4 and pl:
+                # 4x4 luma: chroma is predicted / coded once per 8x8 (by its last 4x4)
+                m = ((bx & 4) != 0) & ((by & 4) != 0)
+                pbx, pby, pw = bx[m] >> 1 & ~3, by[m] >> 1 & ~3, 4
+                sub = m
+            else:
+                pbx, pby, pw = bx >> ss, by >> ss, s >> ss
+                sub = np.ones(nb, bool)
+            npl = len(pbx)
+            stride = geo[pl][0]
+            dst_off = (pby * stride + pbx).astype(np.uint32)
+            n_samples += npl * pw * pw
+            for r in range(2):
+                mvy, mvx = mv[r, sub, 0], mv[r, sub, 1]
+                use = np.ones(npl, bool) if r == 0 else comp[sub]
+                t = np.zeros(int(use.sum()), MC_TASK)
+                if ss:
+                    t["src_x"] = (pbx + (mvx >> 4))[use]
+                    t["src_y"] = (pby + (mvy >> 4))[use]
+                    t["mx"] = (mvx & 15)[use]
+                    t["my"] = (mvy & 15)[use]
+                else:
+                    t["src_x"] = (pbx + (mvx >> 3))[use]
+                    t["src_y"] = (pby + (mvy >> 3))[use]
+                    t["mx"] = ((mvx & 7) << 1)[use]
+                    t["my"] = ((mvy & 7) << 1)[use]
+                t["w"] = t["h"] = pw
+                t["filter_2d"] = filt[sub][use]
+                t["plane"] = pl
+                t["ref"] = (ref0 if r == 0 else ref1)[sub][use]
+                c_sub = comp[sub][use]
+                # single-reference blocks PUT straight into the picture; compound blocks PREP both
+                t["kind"] = np.where(c_sub, 1, 0)
+                nprep = int(c_sub.sum())
+                offs = prep_off + np.arange(nprep, dtype=np.int64) * pw * pw
+                d = dst_off[use].copy()
+                d[c_sub] = offs
+                t["dst_off"] = d
+                if r == 0:
+                    first_offs = offs
+                    prep_off += nprep * pw * pw
+                else:
+                    ct = np.zeros(nprep, COMP_TASK)
+                    ct["dst_off"] = dst_off[comp[sub]]
+                    ct["tmp1_off"] = first_offs
+                    ct["tmp2_off"] = offs
+                    ct["w"] = ct["h"] = pw
+                    ct["kind"] = 0
+                    ct["plane"] = pl
+                    comp_parts.append(ct)
+                    prep_off += nprep * pw * pw
+                mc_parts.append(t)
+            # residual: one transform block per prediction block (64x64 chroma -> 32x32 etc.)
+            tx = SQ_TX[pw]
+            cf, eob = gen_coefs(rng, tx, npl, bpc)
+            it = np.zeros(npl, ITX_TASK)
+            it["dst_off"] = dst_off
+            ncoef = cf.shape[1]
+            it["cf_off"] = cf_off + np.arange(npl, dtype=np.int64) * ncoef
+            it["eob"] = eob
+            it["tx"] = tx
+            txtp = np.zeros(npl, np.uint8)
+            if pw <= 16:
+                alt = (rng.random(npl) < alt_txtp_frac) & (eob > 0)
+                txtp[alt] = rng.integers(1, 10, size=int(alt.sum()))      # 2-D classes only (scan order stays valid)
+            elif pw == 32:
+                alt = (rng.random(npl) < alt_txtp_frac * 0.3) & (eob > 0)
+                txtp[alt] = 9
+            it["txtp"] = txtp
+            it["plane"] = pl
+            itx_parts.append(it)
+            coef_parts.append(cf.reshape(-1))
+            cf_off += npl * ncoef
+
+    f = Frame()
+    f.w, f.h, f.bpc, f.n_refs = w, h, bpc, n_refs
+    f.mc = np.concatenate(mc_parts)
+    f.comp = np.concatenate(comp_parts) if comp_parts else np.zeros(0, COMP_TASK)
+    f.itx = np.concatenate(itx_parts)
+    f.coef = np.concatenate(coef_parts)
+    f.prep_elems = max(int(prep_off), 8)
+    f.n_samples = int(n_samples)          # reconstructed samples (all planes)
+    f.luma_pixels = w * h
+    return f
+
+
+def make_planes(rng, w, h, bpc, smooth=True):
+    """Padded random reference planes (3x3 box-smoothed noise), list of 3 arrays."""
+    geo = plane_geometry(w, h, bpc, 1)
+    pd = np.uint8 if bpc == 8 else np.uint16
+    out = []
+    for pl in range(3):
+        rows = geo[pl][1]
+        cols = ((w + 127) & ~127) >> (1 if pl else 0)
+        a = rng.integers(0, 1 << bpc, size=(rows, cols), dtype=np.int32)
+        if smooth:
+            p = np.pad(a, 1, mode="edge")
+            a = (p[:-2, :-2] + p[:-2, 1:-1] + p[:-2, 2:] + p[1:-1, :-2] + p[1:-1, 1:-1] + p[1:-1, 2:] +
+                 p[2:, :-2] + p[2:, 1:-1] + p[2:, 2:] + 4) // 9
+        out.append(a.astype(pd))
+    return out

@@ -125,6 +125,12 @@ DAV1D_HIP_API void dav1d_hip_itx_list_destroy(Dav1dHipContext *c, Dav1dHipItxLis
 DAV1D_HIP_API int dav1d_hip_itx_list_run(Dav1dHipContext *c, const Dav1dHipItxList *l,
                                          const Dav1dHipPicture *dst, void *coef);
 
+/* Measurement aid: the same launches, each bracketed by HIP events on the context's
+ * stream; ms[19] / counts[19] receive per-tx-size kernel durations and task counts. */
+DAV1D_HIP_API int dav1d_hip_itx_list_run_timed(Dav1dHipContext *c, const Dav1dHipItxList *l,
+                                               const Dav1dHipPicture *dst, void *coef,
+                                               float *ms, size_t *counts);
+
 /* ----------------------------------------------------------------------- mc */
 
 enum Dav1dHipMcKind {
@@ -165,6 +171,12 @@ DAV1D_HIP_API void dav1d_hip_mc_list_destroy(Dav1dHipContext *c, Dav1dHipMcList 
 DAV1D_HIP_API int dav1d_hip_mc_list_run(Dav1dHipContext *c, const Dav1dHipMcList *l,
                                         const Dav1dHipPicture *dst, const Dav1dHipPicture *refs,
                                         int n_refs, int16_t *prep);
+
+/* Measurement aid, see dav1d_hip_itx_list_run_timed: ms[9] / counts[9] per tile-shape bin
+ * (bin = 3*class(w) + class(h), class 0: 4, 1: 8, 2: 16). */
+DAV1D_HIP_API int dav1d_hip_mc_list_run_timed(Dav1dHipContext *c, const Dav1dHipMcList *l,
+                                              const Dav1dHipPicture *dst, const Dav1dHipPicture *refs,
+                                              int n_refs, int16_t *prep, float *ms, size_t *counts);
 
 /* Compound combination of two prepared predictions, replaces dsp->mc.avg / w_avg /
  * mask / w_mask (reference src/recon_tmpl.c:1802-1826; src/mc_tmpl.c:628-681,724-794). */

@@ -1,0 +1,86 @@
+"""Whole-frame parity of the itx+mc reconstruction path: the synthetic pass-2 task lists of
+dav1d_amd.synth run (a) through the HIP backend via the C ABI and (b) through the oracle's
+DSP function pointers via oracle/replay.c; every output plane, the prep arena and the
+coefficient arena must be byte-identical."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import util
+from dav1d_amd import api, synth
+
+
+class RP(C.Structure):
+    _fields_ = [("data", C.c_void_p * 3), ("stride", C.c_ssize_t * 3), ("w", C.c_int * 3), ("h", C.c_int * 3)]
+
+
+def planes_struct(planes, w, h):
+    rp = RP()
+    for i, p in enumerate(planes):
+        rp.data[i] = p.ctypes.data
+        rp.stride[i] = p.strides[0]
+        rp.w[i] = w if i == 0 else (w + 1) >> 1
+        rp.h[i] = h if i == 0 else (h + 1) >> 1
+    return rp
+
+
+def oracle_frame(oracle, frame, dst_planes, ref_planes_list):
+    """Replays the frame on the host; returns (planes, prep, coef) after reconstruction."""
+    rl = util.replay_lib()
+    entry = C.cast(oracle._entry, C.c_void_p)
+    w, h, bpc = frame.w, frame.h, frame.bpc
+    dst = [p.copy() for p in dst_planes]
+    drp = planes_struct(dst, w, h)
+    refs = (RP * len(ref_planes_list))(*[planes_struct(r, w, h) for r in ref_planes_list])
+    prep = np.zeros(frame.prep_elems, np.int16)
+    coef = frame.coef.copy()
+    mask = np.zeros(16, np.uint8)
+    assert rl.dav1d_replay_mc(entry, bpc, C.byref(drp), refs, frame.mc.ctypes.data, len(frame.mc), prep.ctypes.data) == 0
+    assert rl.dav1d_replay_comp(entry, bpc, C.byref(drp), frame.comp.ctypes.data, len(frame.comp),
+                                prep.ctypes.data, mask.ctypes.data) == 0
+    assert rl.dav1d_replay_itx(entry, bpc, C.byref(drp), frame.itx.ctypes.data, len(frame.itx), coef.ctypes.data) == 0
+    return dst, prep, coef
+
+
+def hip_frame(ctx, frame, dst_planes, ref_planes_list):
+    w, h, bpc = frame.w, frame.h, frame.bpc
+    dst = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+    for pl in range(3):
+        dst.upload(pl, dst_planes[pl])
+    refs = []
+    for rp in ref_planes_list:
+        r = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+        for pl in range(3):
+            r.upload(pl, rp[pl])
+        refs.append(r)
+    prep = ctx.buffer(frame.prep_elems * 2)
+    prep.zero()
+    coef = ctx.buffer_from(frame.coef)
+    ctx.mc_batch(dst, refs, frame.mc, prep)
+    if len(frame.comp):
+        ctx.comp_batch(dst, frame.comp, prep, None)
+    ctx.itx_add_batch(dst, frame.itx, coef)
+    out = [dst.download(pl) for pl in range(3)]
+    oprep = prep.download(np.int16, frame.prep_elems)
+    ocoef = coef.download(frame.coef.dtype, len(frame.coef))
+    for o in [dst, prep, coef] + refs:
+        o.free()
+    return out, oprep, ocoef
+
+
+@pytest.mark.parametrize("bpc", [8, 10, 12])
+def test_frame_itx_mc_matches_oracle(ctx, bpc):
+    w, h = (192, 128) if ctx.backend == "emu" else (1024, 576)
+    frame = synth.make_frame(w, h, bpc, seed=31 + bpc, edge_frac=0.15)
+    rng = np.random.default_rng(3 + bpc)
+    refs = [synth.make_planes(rng, w, h, bpc, smooth=(i != 1)) for i in range(frame.n_refs)]
+    dst0 = synth.make_planes(rng, w, h, bpc, smooth=False)
+    want, want_prep, want_coef = oracle_frame(util.default_oracle(), frame, dst0, refs)
+    got, got_prep, got_coef = hip_frame(ctx, frame, dst0, refs)
+    for pl in range(3):
+        bad = np.argwhere(got[pl] != want[pl])
+        assert not len(bad), "plane %d differs at %s (%d px)" % (pl, bad[0], len(bad))
+    assert np.array_equal(got_prep, want_prep)
+    assert np.array_equal(got_coef, want_coef)
+    assert not want_coef.any(), "all consumed coefficient slabs end up zeroed"

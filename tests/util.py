@@ -84,6 +84,10 @@ PROTO = {
     "w_avg": [_vp, _pd, _vp, _vp, _i, _i, _i],
     "mask": [_vp, _pd, _vp, _vp, _i, _i, _vp],
     "w_mask": [_vp, _pd, _vp, _vp, _i, _i, _vp, _i],
+    "emu_edge": [_pd, _pd, _pd, _pd, _pd, _pd, _vp, _pd, _vp, _pd],
+    "blend": [_vp, _pd, _vp, _i, _i, _vp],
+    "blend_v": [_vp, _pd, _vp, _i, _i],
+    "blend_h": [_vp, _pd, _vp, _i, _i],
 }
 NO_HBD_SUFFIX = {"blend", "blend_v", "blend_h", "emu_edge"}
 
@@ -264,3 +268,18 @@ SUBSH_ITERS = [2, 2, 3, 5, 5]
 def subsh_max(tx):
     lw, lh = int(np.log2(TX_W[tx])) - 2, int(np.log2(TX_H[tx])) - 2
     return SUBSH_ITERS[max(lw, lh)]
+
+
+# ------------------------------------------------------------- task-list replay
+
+@functools.lru_cache(None)
+def replay_lib():
+    """oracle/replay.c: walks the flat task lists through an oracle's DSP entries on the CPU."""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "replay"], check=True, stdout=subprocess.DEVNULL)
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "libdav1d_replay.so"))
+    for n in ("dav1d_replay_itx", "dav1d_replay_mc", "dav1d_replay_comp"):
+        getattr(lib, n).restype = C.c_int
+    lib.dav1d_replay_itx.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.dav1d_replay_mc.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.dav1d_replay_comp.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    return lib
