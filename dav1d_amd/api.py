@@ -74,13 +74,18 @@ class DevicePicture:
 
     def upload(self, plane, arr):
         """arr: 2-D array of the PADDED plane shape (rows x cols)."""
-        a = np.ascontiguousarray(arr, dtype=self.dtype)
+        a = np.asarray(arr, dtype=self.dtype)
+        if a.strides[1] != a.itemsize:
+            a = np.ascontiguousarray(a)
         assert a.shape == self.padded_shape(plane), (a.shape, self.padded_shape(plane))
         _chk(self.ctx.lib.dav1d_hip_plane_upload(self.ctx.h, C.byref(self.pic), plane, a.ctypes.data,
                                                  a.strides[0], 1), "plane_upload")
 
     def download(self, plane):
-        out = np.empty(self.padded_shape(plane), self.dtype)
+        """Padded plane as a (rows x cols) view of a host array with the DEVICE row stride, so that
+        the same pixel offsets address host and device copies."""
+        rows, cols = self.padded_shape(plane)
+        out = np.zeros((rows, self.stride_px(plane)), self.dtype)[:, :cols]
         _chk(self.ctx.lib.dav1d_hip_plane_download(self.ctx.h, C.byref(self.pic), plane, out.ctypes.data,
                                                    out.strides[0], 1), "plane_download")
         return out

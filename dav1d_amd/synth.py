@@ -223,7 +223,9 @@ def make_frame(w, h, bpc, seed, mix=(0.20, 0.30, 0.30, 0.15, 0.05), compound_fra
 
 
 def make_planes(rng, w, h, bpc, smooth=True):
-    """Padded random reference planes (3x3 box-smoothed noise), list of 3 arrays."""
+    """Padded random reference planes (3x3 box-smoothed noise), list of 3 arrays.  Each array is a
+    (rows x cols) view into a buffer whose row stride equals the device picture's stride, so
+    task offsets (y * stride + x) address host and device copies alike."""
     geo = plane_geometry(w, h, bpc, 1)
     pd = np.uint8 if bpc == 8 else np.uint16
     out = []
@@ -235,5 +237,17 @@ def make_planes(rng, w, h, bpc, smooth=True):
             p = np.pad(a, 1, mode="edge")
             a = (p[:-2, :-2] + p[:-2, 1:-1] + p[:-2, 2:] + p[1:-1, :-2] + p[1:-1, 1:-1] + p[1:-1, 2:] +
                  p[2:, :-2] + p[2:, 1:-1] + p[2:, 2:] + 4) // 9
-        out.append(a.astype(pd))
+        base = np.zeros((rows, geo[pl][0]), pd)
+        base[:, :cols] = a
+        out.append(base[:, :cols])
+    return out
+
+
+def copy_planes(planes):
+    """Deep copy that keeps each plane's row stride."""
+    out = []
+    for p in planes:
+        base = np.zeros((p.shape[0], p.strides[0] // p.itemsize), p.dtype)
+        base[:, :p.shape[1]] = p
+        out.append(base[:, :p.shape[1]])
     return out

@@ -30,7 +30,7 @@ def oracle_frame(oracle, frame, dst_planes, ref_planes_list):
     rl = util.replay_lib()
     entry = C.cast(oracle._entry, C.c_void_p)
     w, h, bpc = frame.w, frame.h, frame.bpc
-    dst = [p.copy() for p in dst_planes]
+    dst = synth.copy_planes(dst_planes)
     drp = planes_struct(dst, w, h)
     refs = (RP * len(ref_planes_list))(*[planes_struct(r, w, h) for r in ref_planes_list])
     prep = np.zeros(frame.prep_elems, np.int16)
@@ -71,7 +71,7 @@ def hip_frame(ctx, frame, dst_planes, ref_planes_list):
 
 @pytest.mark.parametrize("bpc", [8, 10, 12])
 def test_frame_itx_mc_matches_oracle(ctx, bpc):
-    w, h = (192, 128) if ctx.backend == "emu" else (1024, 576)
+    w, h = (1024, 64) if ctx.backend == "emu" else (1024, 576)   # 1024: exercises the +64 B stride rule
     frame = synth.make_frame(w, h, bpc, seed=31 + bpc, edge_frac=0.15)
     rng = np.random.default_rng(3 + bpc)
     refs = [synth.make_planes(rng, w, h, bpc, smooth=(i != 1)) for i in range(frame.n_refs)]
