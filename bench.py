@@ -57,9 +57,8 @@ def main():
     a = parse()
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from dav1d_amd import dist as dd
+    rank, local, world = dd.env()
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -116,8 +115,7 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        dd.barrier(world)
 
     barrier()
     torch.cuda.synchronize()
@@ -127,13 +125,10 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = dd.max_over_ranks(dt, world, device="cuda")
 
     ms_per_step = dt / a.steps * 1e3
-    value = world * frame.luma_pixels * a.steps / dt / 1e6      # luma Mpixels/s, whole job
+    value = dd.job_throughput(frame.luma_pixels, a.steps, dt, world) / 1e6      # luma Mpixels/s, whole job
 
     out = None
     if rank == 0:

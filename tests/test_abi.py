@@ -1,0 +1,69 @@
+"""C-ABI surface: the built library loads, exports every symbol include/dav1d_hip.h declares,
+agrees with the Python struct mirrors, and refuses to run without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import util
+from dav1d_amd import _lib, build
+
+
+@pytest.fixture(scope="module")
+def so():
+    return build.build_hip()
+
+
+def test_header_symbols_are_all_exported(so):
+    hdr = open(os.path.join(util.ROOT, "include", "dav1d_hip.h")).read()
+    declared = set(re.findall(r"DAV1D_HIP_API\s+[\w\s\*]+?\b(dav1d_hip_\w+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = C.CDLL(so)
+    for s in declared:
+        assert hasattr(lib, s), s
+
+
+def test_struct_mirrors_match_header_sizes():
+    assert _lib.ITX_TASK.itemsize == 16
+    assert _lib.MC_TASK.itemsize == 24
+    assert _lib.COMP_TASK.itemsize == 24
+    assert C.sizeof(_lib.Plane) == 24 and C.sizeof(_lib.Picture) == 24 * 3 + 8 + 16
+
+
+def test_open_fails_loudly_without_device(so):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = _lib.load(so)
+    h = C.c_void_p()
+    assert lib.dav1d_hip_open(C.byref(h), 0, None) == -19     # -ENODEV
+    tab = (C.c_void_p * 1024)()
+    assert lib.dav1d_hip_dsp_init_16bpc(tab, 10) == -19
+    assert not any(tab)
+    from dav1d_amd import api
+    with pytest.raises(api.HipError):
+        api.Context(0)
+
+
+def test_missing_library_raises():
+    with pytest.raises(_lib.LibraryError):
+        _lib.load("/nonexistent/libdav1d_hip.so")
+
+
+def test_device_tables_equal_reference_tables():
+    """dav1d_amd/csrc/av1_tables.h (generated) vs the tables of the reference build."""
+    lib = util.ref_lib()
+    if lib is None:
+        pytest.skip("oracle/_ref not built")
+    txt = open(os.path.join(util.ROOT, "dav1d_amd", "csrc", "av1_tables.h")).read()
+    for m in re.finditer(r"AV1_TABLE_QUAL (\w+) av1_(\w+)\[(\d+)\] = \{[^\n]*\n(.*?)\};", txt, re.S):
+        ctype, name, n, body = m.group(1), m.group(2), int(m.group(3)), m.group(4)
+        vals = np.array([int(v) for v in body.replace("\n", " ").split(",") if v.strip()])
+        dt = {"int8_t": np.int8, "uint8_t": np.uint8, "int16_t": np.int16, "uint16_t": np.uint16}[ctype]
+        sz = C.c_size_t()
+        p = lib.dav1d_ref_table(name.encode(), C.byref(sz))
+        assert p and sz.value == n * np.dtype(dt).itemsize, name
+        ref = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(sz.value,)).view(dt)
+        assert np.array_equal(ref, vals.astype(dt)), name
