@@ -91,7 +91,7 @@ def main():
         for pl in range(3):
             d.upload(pl, dst_host[pl])
         dsts.append(d)
-    mc_list, comp_list, itx_list = ctx.mc_list(frame.mc), ctx.comp_list(frame.comp), ctx.itx_list(frame.itx)
+    inter_list, itx_list = ctx.inter_list(frame.mc, frame.comp), ctx.itx_list(frame.itx)
     prep = torch.zeros(frame.prep_elems, dtype=torch.int16, device="cuda")
     tdt = torch.int16 if bpc == 8 else torch.int32
     pristine = torch.from_numpy(frame.coef).to("cuda")
@@ -103,9 +103,7 @@ def main():
 
     def step(i):
         d = dsts[i % NDST]
-        ctx.run_mc_list(mc_list, d, refs, prep.data_ptr())
-        if comp_list.n:
-            ctx.run_comp_list(comp_list, d, prep.data_ptr())
+        ctx.run_inter_list(inter_list, d, refs, prep.data_ptr())
         ctx.run_itx_list(itx_list, d, arenas[i].data_ptr())
 
     # ---- parity gate on this very workload: frame `warmup-0` output vs the oracle replay (bounded: luma rows)
@@ -134,34 +132,38 @@ def main():
     if rank == 0:
         # ---- per-kernel durations (HIP events on the launch stream), one instrumented step
         i = a.warmup + a.steps
-        ms_mc = (C.c_float * 9)()
-        cnt_mc = (C.c_size_t * 9)()
+        ms_mc = (C.c_float * 10)()
+        cnt_mc = (C.c_size_t * 10)()
         ms_itx = (C.c_float * 19)()
         cnt_itx = (C.c_size_t * 19)()
         rarr = (api.Picture * len(refs))(*[r.pic for r in refs])
         d = dsts[i % NDST]
-        rc = ctx.lib.dav1d_hip_mc_list_run_timed(ctx.h, mc_list.h, C.byref(d.pic), rarr, len(refs), prep.data_ptr(), ms_mc, cnt_mc)
+        rc = ctx.lib.dav1d_hip_inter_list_run_timed(ctx.h, inter_list.h, C.byref(d.pic), rarr, len(refs), prep.data_ptr(), None,
+                                                    ms_mc, cnt_mc)
         assert rc == 0
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record(stream)
-        if comp_list.n:
-            ctx.run_comp_list(comp_list, d, prep.data_ptr())
-        ev1.record(stream)
         rc = ctx.lib.dav1d_hip_itx_list_run_timed(ctx.h, itx_list.h, C.byref(d.pic), arenas[i].data_ptr(), ms_itx, cnt_itx)
         assert rc == 0
         torch.cuda.synchronize()
-        ms_comp = ev0.elapsed_time(ev1)
         P = 1 if bpc == 8 else 2
         Cb = 2 if bpc == 8 else 4
         kernels = []
         tile_px = {0: 4, 1: 8, 2: 16}
+        def cls_of(wv, hv):
+            c = lambda v: np.where(v <= 4, 0, np.where(v <= 8, 1, 2))
+            return c(np.minimum(wv, 16)) * 3 + c(np.minimum(hv, 16))
+        mc_bytes = np.zeros(9, np.int64)
+        mpx = frame.mc["w"].astype(np.int64) * frame.mc["h"]
+        np.add.at(mc_bytes, cls_of(frame.mc["w"], frame.mc["h"]), np.where(frame.mc["kind"] == 0, 2 * P, P) * mpx)
+        if len(frame.comp):
+            cpx = frame.comp["w"].astype(np.int64) * frame.comp["h"]
+            np.add.at(mc_bytes, cls_of(frame.comp["w"], frame.comp["h"]), P * cpx)
         for b in range(9):
             if cnt_mc[b]:
-                px = cnt_mc[b] * tile_px[b // 3] * tile_px[b % 3]
-                kernels.append(("mc_%dx%d" % (tile_px[b // 3], tile_px[b % 3]), ms_mc[b], px * 2 * P))
-        if comp_list.n:
-            cpx = int((frame.comp["w"].astype(np.int64) * frame.comp["h"]).sum())
-            kernels.append(("comp_avg", ms_comp, cpx * (4 + P)))
+                # algorithmic bytes: one P written per output pixel, one P read per predicted pixel
+                # (tiles of fused compound blocks read two references: counted via the task lists below)
+                kernels.append(("mc_%dx%d" % (tile_px[b // 3], tile_px[b % 3]), ms_mc[b], int(mc_bytes[b])))
+        if cnt_mc[9]:
+            kernels.append(("comp_unfused", ms_mc[9], 0))
         for b in range(19):
             if cnt_itx[b]:
                 px = cnt_itx[b] * synth.TX_W[b] * synth.TX_H[b]

@@ -43,6 +43,8 @@ SYMBOLS = [
     "dav1d_hip_comp_batch", "dav1d_hip_comp_list_create", "dav1d_hip_comp_list_destroy", "dav1d_hip_comp_list_run",
     "dav1d_hip_dsp_init_8bpc", "dav1d_hip_dsp_init_16bpc",
     "dav1d_hip_itx_list_run_timed", "dav1d_hip_mc_list_run_timed",
+    "dav1d_hip_inter_list_create", "dav1d_hip_inter_list_destroy", "dav1d_hip_inter_list_run",
+    "dav1d_hip_inter_list_run_timed", "dav1d_hip_inter_list_fused",
 ]
 
 
@@ -88,6 +90,11 @@ def load(path=None):
         "dav1d_hip_comp_list_run": (i, [vp, vp, P(Picture), vp, vp]),
         "dav1d_hip_itx_list_run_timed": (i, [vp, vp, P(Picture), vp, P(C.c_float), P(sz)]),
         "dav1d_hip_mc_list_run_timed": (i, [vp, vp, P(Picture), P(Picture), i, vp, P(C.c_float), P(sz)]),
+        "dav1d_hip_inter_list_create": (i, [vp, P(vp), vp, sz, vp, sz]),
+        "dav1d_hip_inter_list_destroy": (None, [vp, vp]),
+        "dav1d_hip_inter_list_run": (i, [vp, vp, P(Picture), P(Picture), i, vp, vp]),
+        "dav1d_hip_inter_list_run_timed": (i, [vp, vp, P(Picture), P(Picture), i, vp, vp, P(C.c_float), P(sz)]),
+        "dav1d_hip_inter_list_fused": (sz, [vp]),
         "dav1d_hip_dsp_init_8bpc": (i, [vp]),
         "dav1d_hip_dsp_init_16bpc": (i, [vp, i]),
     }

@@ -109,6 +109,22 @@ class _List:
             self.h = None
 
 
+class _InterList:
+    def __init__(self, ctx, mc_tasks, comp_tasks):
+        self.ctx = ctx
+        m = np.ascontiguousarray(mc_tasks, dtype=MC_TASK)
+        k = np.ascontiguousarray(comp_tasks, dtype=COMP_TASK)
+        self.h = C.c_void_p()
+        _chk(ctx.lib.dav1d_hip_inter_list_create(ctx.h, C.byref(self.h), m.ctypes.data, len(m), k.ctypes.data, len(k)),
+             "inter_list_create")
+        self.n_fused = int(ctx.lib.dav1d_hip_inter_list_fused(self.h))
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.dav1d_hip_inter_list_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
 class Context:
     """dav1d_hip_open() wrapper.  `stream` is a raw hipStream_t (int) or None."""
 
@@ -167,6 +183,15 @@ class Context:
 
     def comp_list(self, tasks):
         return _List(self, "comp", tasks, COMP_TASK)
+
+    def inter_list(self, mc_tasks, comp_tasks):
+        return _InterList(self, mc_tasks, comp_tasks)
+
+    def run_inter_list(self, lst, dst, refs, prep=None, mask=None):
+        arr = (Picture * len(refs))(*[r.pic for r in refs])
+        p = None if prep is None else (prep.ptr if hasattr(prep, "ptr") else prep)
+        m = None if mask is None else (mask.ptr if hasattr(mask, "ptr") else mask)
+        _chk(self.lib.dav1d_hip_inter_list_run(self.h, lst.h, C.byref(dst.pic), arr, len(refs), p, m), "inter_list_run")
 
     def run_itx_list(self, lst, dst, coef):
         _chk(self.lib.dav1d_hip_itx_list_run(self.h, lst.h, C.byref(dst.pic), coef.ptr if hasattr(coef, "ptr") else coef),

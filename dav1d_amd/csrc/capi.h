@@ -39,16 +39,25 @@ extern "C" int dav1d_hip_launch_itx_bin(const DevPlanes *dst, int bpc, int tx, c
 // Device-side unit of motion compensation: a tile of at most 16x16 cut out of a
 // Dav1dHipMcTask by the host (mc list creation), filter rows already resolved
 // (reference GET_H_FILTER / GET_V_FILTER, src/mc_tmpl.c:115-123).
-struct McTile {
-    uint32_t dst_off;     // of the TASK: PUT pixel offset in the dst plane; PREP int16 offset in the prep arena
+// A tile carries one prediction (PUT / PREP) or, when the list builder could pair a
+// compound task with the two PREP tasks that feed it, both predictions plus the combine
+// (AVG / WAVG): the int16 intermediates then never leave registers.
+enum { MCT_PUT = 0, MCT_PREP = 1, MCT_AVG = 2, MCT_WAVG = 3 };
+struct McRef {
     int32_t  src_x, src_y;// of the tile's top-left in the reference plane
-    uint8_t  w, h;        // tile size, <= 16
     uint8_t  mx, my;
     uint8_t  fh, fv;      // row of av1_mc_subpel_filters (0..5) or 6 = bilinear
+    uint8_t  ref;         // index into the reference picture set
+    uint8_t  pad[3];
+};
+struct McTile {
+    uint32_t dst_off;     // of the TASK: pixel offset in the dst plane; PREP: int16 offset in the prep arena
+    uint8_t  w, h;        // tile size, <= 16
     uint8_t  kind, plane;
-    uint8_t  ref;
     uint8_t  bw;          // task width = row stride of a PREP block
     uint8_t  ox, oy;      // tile origin inside the task's block
+    int8_t   weight;      // WAVG
+    McRef    r[2];
 };
 extern "C" int dav1d_hip_launch_mc_bin(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, int cls,
                                        const McTile *tiles, int n, int16_t *prep, void *stream);

@@ -286,43 +286,52 @@ static int tile_dim_class(int v) { return v <= 4 ? 0 : v <= 8 ? 1 : 2; }
 
 extern "C" {
 
-int dav1d_hip_mc_list_create(Dav1dHipContext *c, Dav1dHipMcList **out, const Dav1dHipMcTask *tasks, size_t n) {
-    if (!out || (!tasks && n)) return -EINVAL;
-    *out = nullptr;
-    std::vector<McTile> bins[9];
-    for (size_t i = 0; i < n; i++) {
-        const Dav1dHipMcTask &t = tasks[i];
-        if (t.w < 2 || t.w > 128 || t.h < 2 || t.h > 128 || (t.w & (t.w - 1)) || (t.h & (t.h - 1)) ||
-            t.mx > 15 || t.my > 15 || t.filter_2d > 9 || t.kind > 1 || t.plane > 2 || t.ref > 7)
-            return -EINVAL;
-        McTile m;
-        memset(&m, 0, sizeof(m));
-        m.dst_off = t.dst_off;
-        m.mx = t.mx; m.my = t.my;
-        m.kind = t.kind; m.plane = t.plane; m.ref = t.ref;
-        m.bw = t.w;   // 128 wraps to... handled below
-        if (t.filter_2d == 9) {
-            m.fh = m.fv = 6;
-        } else {
-            // enum Filter2d -> (h type, v type) with REGULAR 0, SMOOTH 1, SHARP 2
-            // (reference src/levels.h:184-196, src/mc_tmpl.c:395-403)
-            static const uint8_t ht[9] = { 0, 0, 0, 2, 2, 2, 1, 1, 1 };
-            static const uint8_t vt[9] = { 0, 1, 2, 0, 1, 2, 0, 1, 2 };
-            const int h_type = ht[t.filter_2d], v_type = vt[t.filter_2d];
-            m.fh = t.w > 4 ? h_type : 3 + (h_type & 1);
-            m.fv = t.h > 4 ? v_type : 3 + (v_type & 1);
-        }
-        const int tw = t.w < 16 ? t.w : 16, th = t.h < 16 ? t.h : 16;
-        const int cls = tile_dim_class(tw) * 3 + tile_dim_class(th);
-        for (int oy = 0; oy < t.h; oy += th)
-            for (int ox = 0; ox < t.w; ox += tw) {
-                m.w = tw; m.h = th;
-                m.ox = ox; m.oy = oy;
-                m.src_x = t.src_x + ox;
-                m.src_y = t.src_y + oy;
-                bins[cls].push_back(m);
-            }
+} // extern "C" (helpers below are C++)
+
+static int mc_task_valid(const Dav1dHipMcTask &t) {
+    return !(t.w < 2 || t.w > 128 || t.h < 2 || t.h > 128 || (t.w & (t.w - 1)) || (t.h & (t.h - 1)) ||
+             t.mx > 15 || t.my > 15 || t.filter_2d > 9 || t.kind > 1 || t.plane > 2 || t.ref > 7);
+}
+
+static McRef mc_ref_of(const Dav1dHipMcTask &t) {
+    McRef r;
+    memset(&r, 0, sizeof(r));
+    r.src_x = t.src_x; r.src_y = t.src_y;
+    r.mx = t.mx; r.my = t.my; r.ref = t.ref;
+    if (t.filter_2d == 9) {
+        r.fh = r.fv = 6;
+    } else {
+        // enum Filter2d -> (h type, v type) with REGULAR 0, SMOOTH 1, SHARP 2 (reference src/levels.h:184-196,
+        // src/mc_tmpl.c:395-403); 4-tap rows for w <= 4 / h <= 4 (src/mc_tmpl.c:115-123)
+        static const uint8_t ht[9] = { 0, 0, 0, 2, 2, 2, 1, 1, 1 };
+        static const uint8_t vt[9] = { 0, 1, 2, 0, 1, 2, 0, 1, 2 };
+        const int h_type = ht[t.filter_2d], v_type = vt[t.filter_2d];
+        r.fh = t.w > 4 ? h_type : 3 + (h_type & 1);
+        r.fv = t.h > 4 ? v_type : 3 + (v_type & 1);
     }
+    return r;
+}
+
+// cut one prediction block (or a fused pair) into <= 16x16 tiles and bin them by tile shape
+static void push_tiles(std::vector<McTile> *bins, const Dav1dHipMcTask &t, int kind, uint32_t dst_off,
+                       const Dav1dHipMcTask *second, int weight) {
+    McTile m;
+    memset(&m, 0, sizeof(m));
+    m.dst_off = dst_off;
+    m.kind = kind; m.plane = t.plane; m.bw = t.w; m.weight = (int8_t) weight;
+    const McRef r0 = mc_ref_of(t), r1 = second ? mc_ref_of(*second) : r0;
+    const int tw = t.w < 16 ? t.w : 16, th = t.h < 16 ? t.h : 16;
+    const int cls = tile_dim_class(tw) * 3 + tile_dim_class(th);
+    for (int oy = 0; oy < t.h; oy += th)
+        for (int ox = 0; ox < t.w; ox += tw) {
+            m.w = tw; m.h = th; m.ox = ox; m.oy = oy;
+            m.r[0] = r0; m.r[0].src_x += ox; m.r[0].src_y += oy;
+            m.r[1] = r1; m.r[1].src_x += ox; m.r[1].src_y += oy;
+            bins[cls].push_back(m);
+        }
+}
+
+static int mc_list_from_bins(Dav1dHipContext *c, Dav1dHipMcList **out, std::vector<McTile> *bins) {
     Dav1dHipMcList *l = new (std::nothrow) Dav1dHipMcList();
     if (!l) return -ENOMEM;
     memset(l, 0, sizeof(*l));
@@ -340,6 +349,19 @@ int dav1d_hip_mc_list_create(Dav1dHipContext *c, Dav1dHipMcList **out, const Dav
     }
     *out = l;
     return 0;
+}
+
+extern "C" {
+
+int dav1d_hip_mc_list_create(Dav1dHipContext *c, Dav1dHipMcList **out, const Dav1dHipMcTask *tasks, size_t n) {
+    if (!out || (!tasks && n)) return -EINVAL;
+    *out = nullptr;
+    std::vector<McTile> bins[9];
+    for (size_t i = 0; i < n; i++) {
+        if (!mc_task_valid(tasks[i])) return -EINVAL;
+        push_tiles(bins, tasks[i], tasks[i].kind == DAV1D_HIP_MC_PUT ? MCT_PUT : MCT_PREP, tasks[i].dst_off, nullptr, 0);
+    }
+    return mc_list_from_bins(c, out, bins);
 }
 
 void dav1d_hip_mc_list_destroy(Dav1dHipContext *c, Dav1dHipMcList *l) {
@@ -454,5 +476,113 @@ int dav1d_hip_comp_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const D
     dav1d_hip_comp_list_destroy(c, l);
     return rc;
 }
+
+} // extern "C"
+
+// ------------------------------------------------------- inter list (mc + comp, fused)
+
+// All inter prediction of a frame / tile-sbrow: the PUT / PREP tasks plus the compound
+// tasks that consume the PREP outputs, exactly as the reference driver issues them
+// (src/recon_tmpl.c:1784-1826).  Where an AVG / W_AVG task reads two PREP blocks that no
+// other task reads, the three are fused into one tile kind (both predictions + combine in
+// registers, nothing written to the prep arena).  MASK / W_MASK compounds keep the
+// two-step form.
+#include <unordered_map>
+
+struct Dav1dHipInterList {
+    Dav1dHipMcList *mc;
+    Dav1dHipCompList *comp;
+    size_t n_fused;
+};
+
+extern "C" {
+
+int dav1d_hip_inter_list_create(Dav1dHipContext *c, Dav1dHipInterList **out, const Dav1dHipMcTask *mc, size_t n_mc,
+                                const Dav1dHipCompTask *comp, size_t n_comp) {
+    if (!out || (!mc && n_mc) || (!comp && n_comp)) return -EINVAL;
+    *out = nullptr;
+    // prep offset -> producing PREP task, and how many compound inputs read that offset
+    std::unordered_map<uint32_t, size_t> producer;
+    std::unordered_map<uint32_t, int> readers;
+    for (size_t i = 0; i < n_mc; i++) {
+        if (!mc_task_valid(mc[i])) return -EINVAL;
+        if (mc[i].kind == DAV1D_HIP_MC_PREP) producer[mc[i].dst_off] = i;
+    }
+    for (size_t i = 0; i < n_comp; i++) { readers[comp[i].tmp1_off]++; readers[comp[i].tmp2_off]++; }
+    std::vector<char> fused_prep(n_mc, 0);
+    std::vector<Dav1dHipCompTask> rest;
+    std::vector<McTile> bins[9];
+    size_t n_fused = 0;
+    for (size_t i = 0; i < n_comp; i++) {
+        const Dav1dHipCompTask &k = comp[i];
+        bool fuse = k.kind == DAV1D_HIP_COMP_AVG || k.kind == DAV1D_HIP_COMP_WAVG;
+        size_t a = 0, b = 0;
+        if (fuse) {
+            auto pa = producer.find(k.tmp1_off), pb = producer.find(k.tmp2_off);
+            fuse = pa != producer.end() && pb != producer.end() && k.tmp1_off != k.tmp2_off &&
+                   readers[k.tmp1_off] == 1 && readers[k.tmp2_off] == 1;
+            if (fuse) {
+                a = pa->second; b = pb->second;
+                fuse = mc[a].w == k.w && mc[a].h == k.h && mc[b].w == k.w && mc[b].h == k.h &&
+                       mc[a].plane == k.plane && mc[b].plane == k.plane;
+            }
+        }
+        if (fuse) {
+            push_tiles(bins, mc[a], k.kind == DAV1D_HIP_COMP_AVG ? MCT_AVG : MCT_WAVG, k.dst_off, &mc[b], k.arg);
+            fused_prep[a] = fused_prep[b] = 1;
+            n_fused++;
+        } else {
+            rest.push_back(k);
+        }
+    }
+    for (size_t i = 0; i < n_mc; i++)
+        if (!fused_prep[i])
+            push_tiles(bins, mc[i], mc[i].kind == DAV1D_HIP_MC_PUT ? MCT_PUT : MCT_PREP, mc[i].dst_off, nullptr, 0);
+    Dav1dHipInterList *l = new (std::nothrow) Dav1dHipInterList();
+    if (!l) return -ENOMEM;
+    l->mc = nullptr; l->comp = nullptr; l->n_fused = n_fused;
+    int rc = mc_list_from_bins(c, &l->mc, bins);
+    if (!rc) rc = dav1d_hip_comp_list_create(c, &l->comp, rest.data(), rest.size());
+    if (rc) { dav1d_hip_mc_list_destroy(c, l->mc); delete l; return rc; }
+    *out = l;
+    return 0;
+}
+
+void dav1d_hip_inter_list_destroy(Dav1dHipContext *c, Dav1dHipInterList *l) {
+    if (!l) return;
+    dav1d_hip_mc_list_destroy(c, l->mc);
+    dav1d_hip_comp_list_destroy(c, l->comp);
+    delete l;
+}
+
+int dav1d_hip_inter_list_run(Dav1dHipContext *c, const Dav1dHipInterList *l, const Dav1dHipPicture *dst,
+                             const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask) {
+    if (!l) return -EINVAL;
+    int rc = dav1d_hip_mc_list_run(c, l->mc, dst, refs, n_refs, prep);
+    if (!rc && l->comp->n) rc = dav1d_hip_comp_list_run(c, l->comp, dst, prep, mask);
+    return rc;
+}
+
+int dav1d_hip_inter_list_run_timed(Dav1dHipContext *c, const Dav1dHipInterList *l, const Dav1dHipPicture *dst,
+                                   const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask,
+                                   float *ms, size_t *counts) {
+    if (!l || !ms) return -EINVAL;
+    int rc = dav1d_hip_mc_list_run_timed(c, l->mc, dst, refs, n_refs, prep, ms, counts);
+    ms[9] = 0.f;
+    if (counts) counts[9] = l->comp->n;
+    if (!rc && l->comp->n) {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, c->stream);
+        rc = dav1d_hip_comp_list_run(c, l->comp, dst, prep, mask);
+        hipEventRecord(e1, c->stream);
+        hipStreamSynchronize(c->stream);
+        hipEventElapsedTime(&ms[9], e0, e1);
+        hipEventDestroy(e0); hipEventDestroy(e1);
+    }
+    return rc;
+}
+
+size_t dav1d_hip_inter_list_fused(const Dav1dHipInterList *l) { return l ? l->n_fused : 0; }
 
 } // extern "C"

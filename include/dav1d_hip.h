@@ -210,6 +210,27 @@ DAV1D_HIP_API void dav1d_hip_comp_list_destroy(Dav1dHipContext *c, Dav1dHipCompL
 DAV1D_HIP_API int dav1d_hip_comp_list_run(Dav1dHipContext *c, const Dav1dHipCompList *l,
                                           const Dav1dHipPicture *dst, const int16_t *prep, uint8_t *mask);
 
+/* All inter prediction of a frame or tile-sbrow in one list: the PUT / PREP tasks and the
+ * compound tasks that consume the PREP outputs, in the form the reference driver issues
+ * them (src/recon_tmpl.c:1784-1826).  The builder fuses every AVG / W_AVG task with the two
+ * PREP tasks that feed it (when nothing else reads them): such blocks are predicted twice
+ * and combined in registers and never touch the prep arena, which is scratch (its contents
+ * after a run are unspecified).  MASK / W_MASK compounds keep the two-step form. */
+typedef struct Dav1dHipInterList Dav1dHipInterList;
+DAV1D_HIP_API int dav1d_hip_inter_list_create(Dav1dHipContext *c, Dav1dHipInterList **out,
+                                              const Dav1dHipMcTask *host_mc, size_t n_mc,
+                                              const Dav1dHipCompTask *host_comp, size_t n_comp);
+DAV1D_HIP_API void dav1d_hip_inter_list_destroy(Dav1dHipContext *c, Dav1dHipInterList *l);
+DAV1D_HIP_API int dav1d_hip_inter_list_run(Dav1dHipContext *c, const Dav1dHipInterList *l,
+                                           const Dav1dHipPicture *dst, const Dav1dHipPicture *refs,
+                                           int n_refs, int16_t *prep, uint8_t *mask);
+/* ms[10] / counts[10]: the 9 tile-shape bins of the mc kernel, then the residual compound kernel */
+DAV1D_HIP_API int dav1d_hip_inter_list_run_timed(Dav1dHipContext *c, const Dav1dHipInterList *l,
+                                                 const Dav1dHipPicture *dst, const Dav1dHipPicture *refs,
+                                                 int n_refs, int16_t *prep, uint8_t *mask,
+                                                 float *ms, size_t *counts);
+DAV1D_HIP_API size_t dav1d_hip_inter_list_fused(const Dav1dHipInterList *l);
+
 /* ------------------------------------------------- reference-signature table */
 
 /* Function pointer types with the reference's exact signatures (16 bpc flavour

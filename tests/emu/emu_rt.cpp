@@ -83,7 +83,7 @@ void run_block(const std::function<void()> &body, dim3 block) {
             if (fibers[i].st == WAIT_BLOCK) waiting++;
         }
         if (alive && waiting == alive) {
-            for (int i = 0; i < n; i++) fibers[i].st = RUN;
+            for (int i = 0; i < n; i++) if (fibers[i].st == WAIT_BLOCK) fibers[i].st = RUN;
             progressed = true;
         }
         if (!progressed && live > 0) {

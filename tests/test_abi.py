@@ -60,6 +60,8 @@ def test_device_tables_equal_reference_tables():
     txt = open(os.path.join(util.ROOT, "dav1d_amd", "csrc", "av1_tables.h")).read()
     for m in re.finditer(r"AV1_TABLE_QUAL (\w+) av1_(\w+)\[(\d+)\] = \{[^\n]*\n(.*?)\};", txt, re.S):
         ctype, name, n, body = m.group(1), m.group(2), int(m.group(3)), m.group(4)
+        if name == "mc_taps_packed":
+            continue                      # derived table, checked in test_packed_taps_match_subpel_filters
         vals = np.array([int(v) for v in body.replace("\n", " ").split(",") if v.strip()])
         dt = {"int8_t": np.int8, "uint8_t": np.uint8, "int16_t": np.int16, "uint16_t": np.uint16}[ctype]
         sz = C.c_size_t()
@@ -67,3 +69,22 @@ def test_device_tables_equal_reference_tables():
         assert p and sz.value == n * np.dtype(dt).itemsize, name
         ref = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(sz.value,)).view(dt)
         assert np.array_equal(ref, vals.astype(dt)), name
+
+
+def test_packed_taps_match_subpel_filters():
+    """av1_mc_taps_packed (v_dot2 operand form) is a pure re-packing of av1_mc_subpel_filters."""
+    txt = open(os.path.join(util.ROOT, "dav1d_amd", "csrc", "av1_tables.h")).read()
+
+    def table(name):
+        body = re.search(r"av1_%s\[\d+\] = \{[^\n]*\n(.*?)\};" % name, txt, re.S).group(1)
+        return [int(v.strip().rstrip("u"), 0) for v in body.replace("\n", " ").split(",") if v.strip()]
+
+    filt = np.array(table("mc_subpel_filters")).reshape(6, 15, 8)
+    packed = np.array(table("mc_taps_packed"), dtype=np.uint32).reshape(7, 16, 9)
+    for fs in range(7):
+        for m in range(16):
+            f = [0, 0, 0, 1, 0, 0, 0, 0] if m == 0 else ([0, 0, 0, 16 - m, m, 0, 0, 0] if fs == 6 else list(filt[fs, m - 1]))
+            g = [0] + f + [0]
+            want = [(f[2 * k] & 0xffff) | ((f[2 * k + 1] & 0xffff) << 16) for k in range(4)] + \
+                   [(g[2 * k] & 0xffff) | ((g[2 * k + 1] & 0xffff) << 16) for k in range(5)]
+            assert list(packed[fs, m]) == want, (fs, m)

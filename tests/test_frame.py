@@ -43,7 +43,7 @@ def oracle_frame(oracle, frame, dst_planes, ref_planes_list):
     return dst, prep, coef
 
 
-def hip_frame(ctx, frame, dst_planes, ref_planes_list):
+def hip_frame(ctx, frame, dst_planes, ref_planes_list, fused=False):
     w, h, bpc = frame.w, frame.h, frame.bpc
     dst = ctx.picture(w, h, api.LAYOUT_I420, bpc)
     for pl in range(3):
@@ -57,9 +57,15 @@ def hip_frame(ctx, frame, dst_planes, ref_planes_list):
     prep = ctx.buffer(frame.prep_elems * 2)
     prep.zero()
     coef = ctx.buffer_from(frame.coef)
-    ctx.mc_batch(dst, refs, frame.mc, prep)
-    if len(frame.comp):
-        ctx.comp_batch(dst, frame.comp, prep, None)
+    if fused:
+        il = ctx.inter_list(frame.mc, frame.comp)
+        assert il.n_fused == len(frame.comp)        # the synthetic frames only hold avg compounds
+        ctx.run_inter_list(il, dst, refs, prep)
+        il.destroy()
+    else:
+        ctx.mc_batch(dst, refs, frame.mc, prep)
+        if len(frame.comp):
+            ctx.comp_batch(dst, frame.comp, prep, None)
     ctx.itx_add_batch(dst, frame.itx, coef)
     out = [dst.download(pl) for pl in range(3)]
     oprep = prep.download(np.int16, frame.prep_elems)
@@ -69,18 +75,20 @@ def hip_frame(ctx, frame, dst_planes, ref_planes_list):
     return out, oprep, ocoef
 
 
+@pytest.mark.parametrize("fused", [False, True], ids=["twostep", "fused"])
 @pytest.mark.parametrize("bpc", [8, 10, 12])
-def test_frame_itx_mc_matches_oracle(ctx, bpc):
+def test_frame_itx_mc_matches_oracle(ctx, bpc, fused):
     w, h = (1024, 64) if ctx.backend == "emu" else (1024, 576)   # 1024: exercises the +64 B stride rule
     frame = synth.make_frame(w, h, bpc, seed=31 + bpc, edge_frac=0.15)
     rng = np.random.default_rng(3 + bpc)
     refs = [synth.make_planes(rng, w, h, bpc, smooth=(i != 1)) for i in range(frame.n_refs)]
     dst0 = synth.make_planes(rng, w, h, bpc, smooth=False)
     want, want_prep, want_coef = oracle_frame(util.default_oracle(), frame, dst0, refs)
-    got, got_prep, got_coef = hip_frame(ctx, frame, dst0, refs)
+    got, got_prep, got_coef = hip_frame(ctx, frame, dst0, refs, fused)
     for pl in range(3):
         bad = np.argwhere(got[pl] != want[pl])
         assert not len(bad), "plane %d differs at %s (%d px)" % (pl, bad[0], len(bad))
-    assert np.array_equal(got_prep, want_prep)
+    if not fused:       # with fusion the prep arena is scratch: the int16 intermediates stay in registers
+        assert np.array_equal(got_prep, want_prep)
     assert np.array_equal(got_coef, want_coef)
     assert not want_coef.any(), "all consumed coefficient slabs end up zeroed"

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 csv outputs of tools/pmc_profile.sh into one table per kernel:
+average duration (kernel-trace stats) and per-launch counter averages."""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def short(name):
+    m = re.search(r"(mc_kernel|itx_add_kernel|comp_kernel|\w+_kernel)<([^>]*)>", name)
+    if m:
+        return "%s<%s>" % (m.group(1), m.group(2).replace("unsigned short", "u16").replace("unsigned char", "u8").replace(" ", ""))
+    return name[:40]
+
+
+stats = {}
+for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        stats[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["Percentage"]))
+cnt = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        cnt[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+names = sorted(stats, key=lambda k: -stats[k][2])
+print("%-44s %6s %10s %6s" % ("kernel", "calls", "avg_us", "pct"))
+for k in names:
+    print("%-44s %6d %10.1f %6.2f" % (k, *stats[k]))
+print()
+for k in names:
+    if k not in cnt:
+        continue
+    print(k)
+    for c in sorted(cnt[k]):
+        v = cnt[k][c]
+        print("    %-24s %16.1f  (n=%d)" % (c, sum(v) / len(v), len(v)))
