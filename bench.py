@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--height", type=int, default=4320)
     ap.add_argument("--bpc", type=int, default=10)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--mv-range", type=int, default=64, help="synthetic MV range in pixels (experiments)")
+    ap.add_argument("--edge-frac", type=float, default=0.05, help="fraction of blocks pointing outside the picture")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     return ap.parse_args()
@@ -71,7 +73,7 @@ def main():
     ctx = api.Context(local, stream=stream.cuda_stream)
     w, h, bpc = a.width, a.height, a.bpc
     t_gen = time.time()
-    frame = synth.make_frame(w, h, bpc, seed=0xDA71D002 + rank)
+    frame = synth.make_frame(w, h, bpc, seed=0xDA71D002 + rank, mv_range_px=a.mv_range, edge_frac=a.edge_frac)
     rng = np.random.default_rng(1234 + rank)
     ref_host = [synth.make_planes(rng, w, h, bpc) for _ in range(frame.n_refs)]
     dst_host = synth.make_planes(rng, w, h, bpc, smooth=False)
@@ -132,8 +134,8 @@ def main():
     if rank == 0:
         # ---- per-kernel durations (HIP events on the launch stream), one instrumented step
         i = a.warmup + a.steps
-        ms_mc = (C.c_float * 10)()
-        cnt_mc = (C.c_size_t * 10)()
+        ms_mc = (C.c_float * 16)()
+        cnt_mc = (C.c_size_t * 16)()
         ms_itx = (C.c_float * 19)()
         cnt_itx = (C.c_size_t * 19)()
         rarr = (api.Picture * len(refs))(*[r.pic for r in refs])
@@ -147,23 +149,24 @@ def main():
         P = 1 if bpc == 8 else 2
         Cb = 2 if bpc == 8 else 4
         kernels = []
-        tile_px = {0: 4, 1: 8, 2: 16}
+        tile_w = [4, 8, 16, 32, 64]
+        tile_h = [4, 8, 16]
         def cls_of(wv, hv):
-            c = lambda v: np.where(v <= 4, 0, np.where(v <= 8, 1, 2))
-            return c(np.minimum(wv, 16)) * 3 + c(np.minimum(hv, 16))
-        mc_bytes = np.zeros(9, np.int64)
+            c = lambda v: np.where(v <= 4, 0, np.where(v <= 8, 1, np.where(v <= 16, 2, np.where(v <= 32, 3, 4))))
+            return c(np.minimum(wv, 64)) * 3 + c(np.minimum(hv, 16))
+        mc_bytes = np.zeros(15, np.int64)
         mpx = frame.mc["w"].astype(np.int64) * frame.mc["h"]
         np.add.at(mc_bytes, cls_of(frame.mc["w"], frame.mc["h"]), np.where(frame.mc["kind"] == 0, 2 * P, P) * mpx)
         if len(frame.comp):
             cpx = frame.comp["w"].astype(np.int64) * frame.comp["h"]
             np.add.at(mc_bytes, cls_of(frame.comp["w"], frame.comp["h"]), P * cpx)
-        for b in range(9):
+        for b in range(15):
             if cnt_mc[b]:
                 # algorithmic bytes: one P written per output pixel, one P read per predicted pixel
                 # (tiles of fused compound blocks read two references: counted via the task lists below)
-                kernels.append(("mc_%dx%d" % (tile_px[b // 3], tile_px[b % 3]), ms_mc[b], int(mc_bytes[b])))
-        if cnt_mc[9]:
-            kernels.append(("comp_unfused", ms_mc[9], 0))
+                kernels.append(("mc_%dx%d" % (tile_w[b // 3], tile_h[b % 3]), ms_mc[b], int(mc_bytes[b])))
+        if cnt_mc[15]:
+            kernels.append(("comp_unfused", ms_mc[15], 0))
         for b in range(19):
             if cnt_itx[b]:
                 px = cnt_itx[b] * synth.TX_W[b] * synth.TX_H[b]

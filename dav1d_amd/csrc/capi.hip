@@ -279,10 +279,11 @@ int dav1d_hip_itx_add_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, cons
 struct Dav1dHipMcList {
     McTile *dev;
     size_t n;
-    size_t off[10];   // 9 tile-shape bins
+    size_t off[16];   // 15 tile-shape bins: 3 * class(w in 4..64) + class(h in 4..16)
 };
 
-static int tile_dim_class(int v) { return v <= 4 ? 0 : v <= 8 ? 1 : 2; }
+static int tile_dim_class(int v) { return v <= 4 ? 0 : v <= 8 ? 1 : v <= 16 ? 2 : v <= 32 ? 3 : 4; }
+#define MC_BINS 15
 
 extern "C" {
 
@@ -320,7 +321,7 @@ static void push_tiles(std::vector<McTile> *bins, const Dav1dHipMcTask &t, int k
     m.dst_off = dst_off;
     m.kind = kind; m.plane = t.plane; m.bw = t.w; m.weight = (int8_t) weight;
     const McRef r0 = mc_ref_of(t), r1 = second ? mc_ref_of(*second) : r0;
-    const int tw = t.w < 16 ? t.w : 16, th = t.h < 16 ? t.h : 16;
+    const int tw = t.w < 64 ? t.w : 64, th = t.h < 16 ? t.h : 16;   // strips of one block, up to 64x16
     const int cls = tile_dim_class(tw) * 3 + tile_dim_class(th);
     for (int oy = 0; oy < t.h; oy += th)
         for (int ox = 0; ox < t.w; ox += tw) {
@@ -336,11 +337,11 @@ static int mc_list_from_bins(Dav1dHipContext *c, Dav1dHipMcList **out, std::vect
     if (!l) return -ENOMEM;
     memset(l, 0, sizeof(*l));
     std::vector<McTile> all;
-    for (int b = 0; b < 9; b++) {
+    for (int b = 0; b < MC_BINS; b++) {
         l->off[b] = all.size();
         all.insert(all.end(), bins[b].begin(), bins[b].end());
     }
-    l->off[9] = all.size();
+    l->off[MC_BINS] = all.size();
     l->n = all.size();
     if (l->n) {
         if (hipMalloc((void **) &l->dev, l->n * sizeof(McTile)) != hipSuccess) { delete l; return -ENOMEM; }
@@ -356,7 +357,7 @@ extern "C" {
 int dav1d_hip_mc_list_create(Dav1dHipContext *c, Dav1dHipMcList **out, const Dav1dHipMcTask *tasks, size_t n) {
     if (!out || (!tasks && n)) return -EINVAL;
     *out = nullptr;
-    std::vector<McTile> bins[9];
+    std::vector<McTile> bins[MC_BINS];
     for (size_t i = 0; i < n; i++) {
         if (!mc_task_valid(tasks[i])) return -EINVAL;
         push_tiles(bins, tasks[i], tasks[i].kind == DAV1D_HIP_MC_PUT ? MCT_PUT : MCT_PREP, tasks[i].dst_off, nullptr, 0);
@@ -380,7 +381,7 @@ int dav1d_hip_mc_list_run(Dav1dHipContext *c, const Dav1dHipMcList *l, const Dav
         if (refs[i].bpc != dst->bpc) return -EINVAL;
         rp[i] = dev_planes(&refs[i]);
     }
-    for (int b = 0; b < 9; b++) {
+    for (int b = 0; b < MC_BINS; b++) {
         const size_t cnt = l->off[b + 1] - l->off[b];
         if (!cnt) continue;
         const int rc = dav1d_hip_launch_mc_bin(&dp, rp, n_refs, dst->bpc, b, l->dev + l->off[b], (int) cnt, prep, c->stream);
@@ -395,19 +396,19 @@ int dav1d_hip_mc_list_run_timed(Dav1dHipContext *c, const Dav1dHipMcList *l, con
     const DevPlanes dp = dev_planes(dst);
     DevPlanes rp[8];
     for (int i = 0; i < n_refs; i++) rp[i] = dev_planes(&refs[i]);
-    hipEvent_t ev[10];
-    for (int b = 0; b < 10; b++) HIP_TRY(hipEventCreate(&ev[b]));
+    hipEvent_t ev[MC_BINS + 1];
+    for (int b = 0; b <= MC_BINS; b++) HIP_TRY(hipEventCreate(&ev[b]));
     HIP_TRY(hipEventRecord(ev[0], c->stream));
     int rc = 0;
-    for (int b = 0; b < 9 && !rc; b++) {
+    for (int b = 0; b < MC_BINS && !rc; b++) {
         const size_t cnt = l->off[b + 1] - l->off[b];
         if (counts) counts[b] = cnt;
         if (cnt) rc = dav1d_hip_launch_mc_bin(&dp, rp, n_refs, dst->bpc, b, l->dev + l->off[b], (int) cnt, prep, c->stream);
         hipEventRecord(ev[b + 1], c->stream);
     }
     hipStreamSynchronize(c->stream);
-    for (int b = 0; b < 9; b++) { ms[b] = 0.f; hipEventElapsedTime(&ms[b], ev[b], ev[b + 1]); }
-    for (int b = 0; b < 10; b++) hipEventDestroy(ev[b]);
+    for (int b = 0; b < MC_BINS; b++) { ms[b] = 0.f; hipEventElapsedTime(&ms[b], ev[b], ev[b + 1]); }
+    for (int b = 0; b <= MC_BINS; b++) hipEventDestroy(ev[b]);
     return rc;
 }
 
@@ -511,7 +512,7 @@ int dav1d_hip_inter_list_create(Dav1dHipContext *c, Dav1dHipInterList **out, con
     for (size_t i = 0; i < n_comp; i++) { readers[comp[i].tmp1_off]++; readers[comp[i].tmp2_off]++; }
     std::vector<char> fused_prep(n_mc, 0);
     std::vector<Dav1dHipCompTask> rest;
-    std::vector<McTile> bins[9];
+    std::vector<McTile> bins[MC_BINS];
     size_t n_fused = 0;
     for (size_t i = 0; i < n_comp; i++) {
         const Dav1dHipCompTask &k = comp[i];
@@ -568,8 +569,8 @@ int dav1d_hip_inter_list_run_timed(Dav1dHipContext *c, const Dav1dHipInterList *
                                    float *ms, size_t *counts) {
     if (!l || !ms) return -EINVAL;
     int rc = dav1d_hip_mc_list_run_timed(c, l->mc, dst, refs, n_refs, prep, ms, counts);
-    ms[9] = 0.f;
-    if (counts) counts[9] = l->comp->n;
+    ms[MC_BINS] = 0.f;
+    if (counts) counts[MC_BINS] = l->comp->n;
     if (!rc && l->comp->n) {
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
@@ -577,7 +578,7 @@ int dav1d_hip_inter_list_run_timed(Dav1dHipContext *c, const Dav1dHipInterList *
         rc = dav1d_hip_comp_list_run(c, l->comp, dst, prep, mask);
         hipEventRecord(e1, c->stream);
         hipStreamSynchronize(c->stream);
-        hipEventElapsedTime(&ms[9], e0, e1);
+        hipEventElapsedTime(&ms[MC_BINS], e0, e1);
         hipEventDestroy(e0); hipEventDestroy(e1);
     }
     return rc;

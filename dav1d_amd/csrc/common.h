@@ -32,6 +32,19 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c) {
 }
 __device__ __forceinline__ uint32_t pack2(int lo, int hi) { return (uint32_t) (lo & 0xffff) | ((uint32_t) hi << 16); }
 
+// LDS hand-off between the lanes of ONE wave (no other wave reads the data): order the
+// accesses and let the wave's outstanding LDS operations land; no s_barrier involved, so
+// waves of a workgroup never wait for each other.
+__device__ __forceinline__ void wave_sync() {
+#ifdef DAV1D_HIP_EMU
+    emu_wave_sync();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 // Launch-order -> work-order remap.  Workgroup b is observed to land on XCD b % 8
 // (MI355X_MICROARCH.md "Workgroup dispatch"); giving XCD k the k-th contiguous
 // eighth of the (raster-ordered) task list keeps neighbouring blocks of a picture,

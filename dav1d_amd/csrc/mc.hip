@@ -8,14 +8,17 @@
 // fused tiles additionally apply avg_c / w_avg_c (src/mc_tmpl.c:628-660) to the two
 // prep results while they are still in registers.
 //
-// Mapping: the host cuts every prediction block into tiles of at most 16x16 and bins
-// them by tile shape (TW, TH) in {4,8,16}^2.  A tile owns LPT = TW*TH/4 lanes (one
-// lane per 4-pixel output strip), 64/LPT tiles share a wave (16x16: 1, 8x8: 4, 4x4: 16).
+// Mapping: the host cuts every prediction block into tiles of at most 64x16 (a strip of
+// one block: same motion vector, same taps, long contiguous source rows) and bins them by
+// tile shape (TW, TH), TW in {4..64}, TH in {4,8,16}.  A tile owns LPT = min(64, TW*TH/4)
+// lanes (each lane produces 1, 2 or 4 output strips of 4 pixels), 64/LPT tiles share a wave
+// (64x16: one tile, 4 strips per lane; 16x16: 1; 8x8: 4; 4x4: 16).
 // Per tile and reference:
 //   1. gather: the (TH+7) x (TW+8) window goes to LDS as int16, tile column 0 at window
 //      column 4 so every 4-pixel strip is 8-byte aligned.  Interior windows are fetched
-//      with 8-byte (4-pixel) loads; windows touching the picture edge fall back to
-//      per-pixel clamped loads (== emu_edge).
+//      with 16-byte (8-pixel) loads at arbitrary 2-byte alignment, all issued before the
+//      first is consumed; windows touching the picture edge fall back to per-pixel clamped
+//      loads (== emu_edge).
 //   2. horizontal pass: one work item = TWO rows x one 4-pixel strip: 2 x 3 ds_read_b64,
 //      v_dot2 on packed pixel pairs (even outputs use the taps packed (f0,f1)(f2,f3)..,
 //      odd outputs the taps packed (0,f0)(f1,f2)..(f7,0): no re-alignment of the data),
@@ -34,7 +37,8 @@ namespace {
 struct RefSet { DevPlanes r[8]; };
 
 struct __attribute__((packed, aligned(2))) U64u { uint32_t a, b; };   // 2-byte aligned 8-byte global load
-struct __attribute__((packed, aligned(1))) U32u { uint32_t a; };
+struct __attribute__((packed, aligned(1))) U64b { uint32_t a, b; };   // byte-aligned (8 bpc rows)
+struct __attribute__((packed, aligned(2))) U128u { uint32_t a, b, c, d; };   // 2-byte aligned 16-byte global load
 
 // taps of one direction packed for v_dot2: ev[k] = (f[2k], f[2k+1]), od[k] = (f[2k-1], f[2k]) with f[-1] = f[8] = 0
 struct Taps { uint32_t ev[4]; uint32_t od[5]; };
@@ -50,17 +54,21 @@ __device__ __forceinline__ Taps load_taps(const int set, const int m) {
     return t;
 }
 
+constexpr int mc_cmin(int a, int b) { return a < b ? a : b; }
+
 template <int TW, int TH, typename pixel>
 __global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSet refs, const McTile *__restrict__ tiles,
                                                 const int n, int16_t *__restrict__ prep, const int bitdepth_max)
 {
-    constexpr int LPT = TW * TH / 4;    // lanes per tile = output strips per tile
-    constexpr int G = 64 / LPT;         // tiles per wave
-    constexpr int WS = TW + 8;          // window row stride (int16)
-    constexpr int WR = TH + 8;          // window rows held (TH+7 used, +1 so row pairs are complete)
-    constexpr int NS = TW / 4;          // 4-pixel strips per row
-    constexpr int NCH = WS / 4;         // 4-pixel chunks per window row
-    constexpr int NPR = WR / 2;         // row pairs of the intermediate
+    constexpr int NS = TW / 4;                          // 4-pixel strips per row
+    constexpr int LPT = mc_cmin(64, TW * TH / 4);       // lanes per tile
+    constexpr int G = 64 / LPT;                         // tiles side by side in a wave
+    constexpr int R = TW * TH / 4 / LPT;                // output strips per lane (1, 2 or 4)
+    constexpr int WS = (TW + 8 + 7) & ~7;               // window row stride (int16), rows 16-byte aligned
+    constexpr int WR = TH + 8;                          // window rows held (TH+7 used, +1 so row pairs are complete)
+    constexpr int NCH = WS / 8;                         // 8-pixel (16-byte) chunks per window row
+    constexpr int NPR = WR / 2;                         // row pairs of the intermediate
+    constexpr int NLD = ((WR - 1) * NCH + LPT - 1) / LPT;   // window loads per lane
     constexpr bool HBD = sizeof(pixel) == 2;
 
     __shared__ __attribute__((aligned(16))) int16_t win_s[G * WR * WS];
@@ -74,40 +82,29 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSe
     const bool live = ti < n;
 
     McTile t;
-    if (G == 1) {
-        // one tile per wave: pull the record through readfirstlane so the compiler keeps it (and the
-        // taps, strides, branch conditions derived from it) in SGPRs
-        static_assert(sizeof(McTile) == 44, "McTile layout");
-        const uint32_t *tp = reinterpret_cast<const uint32_t *>(tiles + (live ? ti : 0));
-        uint32_t raw[11];
-#pragma unroll
-        for (int k = 0; k < 11; k++) raw[k] = (uint32_t) __builtin_amdgcn_readfirstlane((int) tp[k]);
-        __builtin_memcpy(&t, raw, sizeof(t));
-    } else if (live) t = tiles[ti];
-    else {
-        t.dst_off = 0; t.w = t.h = 0; t.kind = 0; t.plane = 0; t.bw = 0; t.ox = t.oy = 0; t.weight = 0;
-#pragma unroll
-        for (int k = 0; k < 2; k++) { t.r[k].src_x = t.r[k].src_y = 0; t.r[k].mx = t.r[k].my = 0; t.r[k].fh = t.r[k].fv = 0; t.r[k].ref = 0; }
-    }
+    if (G == 1) t = tiles[__builtin_amdgcn_readfirstlane(live ? ti : 0)];
+    else t = tiles[live ? ti : 0];
 
     int16_t *const win = win_s + sub * WR * WS;
     uint32_t *const mid = mid_s + sub * NPR * TW;
 
     const int ib = HBD ? 14 - (32 - __clz(bitdepth_max)) : 4;   // intermediate_bits
     const int bias = HBD ? 8192 : 0;                            // PREP_BIAS
-    const bool compound = t.kind >= MCT_AVG;
+    const bool compound = live && t.kind >= MCT_AVG;
     const bool as_prep = t.kind != MCT_PUT;                     // PREP and both inputs of a compound tile
 
-    // output strip of this lane in the vertical pass
-    const int vr = l / NS, vs = l % NS;
-    int acc0[4] = { 0, 0, 0, 0 };   // first prediction of a compound tile
-    int q[4] = { 0, 0, 0, 0 };
+    int acc0[R][4], q[R][4];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) acc0[r][x] = q[r][x] = 0;
 
-    // one prediction (gather -> h -> v) of this lane's strip into out[]; a lambda invoked once or
+    // one prediction (gather -> h -> v) of this lane's strips into q[]; a lambda invoked once or
     // twice rather than a loop over t.r[] so that the record is never indexed dynamically
-    auto predict = [&](const McRef rf, int (&out)[4]) {
+    auto predict = [&](const McRef rf) {
         const bool has_h = rf.mx != 0, has_v = rf.my != 0;
         const int fbits = rf.fh == 6 ? 4 : 6;
+        const Taps fh = load_taps(rf.fh, rf.mx), fv = load_taps(rf.fv, rf.my);
 
         // ---- 1. gather the window
         if (live) {
@@ -117,49 +114,57 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSe
             const int x0 = rf.src_x - 4, y0 = rf.src_y - 3;
             const bool interior = x0 >= 0 && y0 >= 0 && x0 + WS <= rw && y0 + WR - 1 <= rh;
             if (interior) {
+                // 16-byte (8-pixel) loads, rows at arbitrary 2-byte alignment; all of a lane's loads are
+                // issued before the first LDS write
                 const pixel *base = src + y0 * rs + x0;
+                uint4 ld[NLD];
 #pragma unroll
-                for (int i = l; i < (WR - 1) * NCH; i += LPT) {
-                    const int ry = i / NCH, ch = i % NCH;
-                    uint32_t lo, hi;
+                for (int k = 0; k < NLD; k++) {
+                    const int i = dv::imin(l + k * LPT, (WR - 1) * NCH - 1);
+                    const pixel *p = base + (i / NCH) * rs + 8 * (i % NCH);
                     if (HBD) {
-                        const U64u v = *reinterpret_cast<const U64u *>(base + ry * rs + 4 * ch);
-                        lo = v.a; hi = v.b;
+                        const U128u v = *reinterpret_cast<const U128u *>(p);
+                        ld[k] = make_uint4(v.a, v.b, v.c, v.d);
                     } else {
-                        const uint32_t v = reinterpret_cast<const U32u *>(base + ry * rs + 4 * ch)->a;
-                        lo = (v & 0xff) | ((v & 0xff00) << 8);
-                        hi = ((v >> 16) & 0xff) | ((v >> 8) & 0xff0000);
+                        const U64b v = *reinterpret_cast<const U64b *>(p);
+                        ld[k] = make_uint4((v.a & 0xff) | ((v.a & 0xff00) << 8), ((v.a >> 16) & 0xff) | ((v.a >> 8) & 0xff0000),
+                                           (v.b & 0xff) | ((v.b & 0xff00) << 8), ((v.b >> 16) & 0xff) | ((v.b >> 8) & 0xff0000));
                     }
-                    *reinterpret_cast<uint2 *>(win + ry * WS + 4 * ch) = make_uint2(lo, hi);
+                }
+#pragma unroll
+                for (int k = 0; k < NLD; k++) {
+                    const int i = l + k * LPT;
+                    if (i < (WR - 1) * NCH) *reinterpret_cast<uint4 *>(win + (i / NCH) * WS + 8 * (i % NCH)) = ld[k];
                 }
             } else {
                 // edge emulation: per-pixel clamped fetch, 8 independent loads in flight per lane
                 for (int i0 = l; i0 < (WR - 1) * WS; i0 += 8 * LPT) {
                     pixel v[8];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int i = dv::imin(i0 + u * LPT, (WR - 1) * WS - 1);
-                        const int ry = i / WS, cx = i % WS;
-                        const int sy = dv::iclip(y0 + ry, 0, rh - 1);
-                        const int sx = dv::iclip(x0 + cx, 0, rw - 1);
-                        v[u] = src[sy * rs + sx];
+                    for (int e = 0; e < 8; e++) {
+                        const int i = dv::imin(i0 + e * LPT, (WR - 1) * WS - 1);
+                        const int sy = dv::iclip(y0 + i / WS, 0, rh - 1);
+                        const int sx = dv::iclip(x0 + i % WS, 0, rw - 1);
+                        v[e] = src[sy * rs + sx];
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int i = i0 + u * LPT;
-                        if (i < (WR - 1) * WS) win[i] = (int16_t) v[u];
+                    for (int e = 0; e < 8; e++) {
+                        const int i = i0 + e * LPT;
+                        if (i < (WR - 1) * WS) win[i] = (int16_t) v[e];
                     }
                 }
             }
         }
-        __syncthreads();
+        dv::wave_sync();
 
         // ---- 2. horizontal pass: item = (row pair, strip) -> mid2[pair][4 cols] = (even row, odd row)
         if (live) {
-            const Taps fh = load_taps(rf.fh, rf.mx);
             const int sh1 = has_h ? fbits - ib : 0;
             const int rnd1 = (1 << sh1) >> 1;
-            for (int it = l; it < NPR * NS; it += LPT) {
+#pragma unroll
+            for (int it0 = 0; it0 < NPR * NS; it0 += LPT) {
+                const int it = it0 + l;
+                if (it >= NPR * NS) break;
                 const int pr = it / NS, s = it % NS;
                 int o[2][4];
 #pragma unroll
@@ -167,8 +172,8 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSe
                     const uint2 *wp = reinterpret_cast<const uint2 *>(win + (2 * pr + e) * WS + 4 * s);
                     const uint2 a = wp[0], b = wp[1], c = wp[2];
                     const uint32_t d[6] = { a.x, a.y, b.x, b.y, c.x, c.y };
-                    // out x sums f[k] * p[x + 1 + k], p[] = the 12 pixels of d[]
-                    int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+                    // out x sums f[k] * p[x + 1 + k], p[] = the 12 pixels of d[]; the rounding offset seeds the sum
+                    int s0 = rnd1, s1 = rnd1, s2 = rnd1, s3 = rnd1;
 #pragma unroll
                     for (int k = 0; k < 5; k++) { s0 = dv::dot2(d[k], fh.od[k], s0); s2 = dv::dot2(d[k + 1], fh.od[k], s2); }
 #pragma unroll
@@ -180,21 +185,21 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSe
 #pragma unroll
                     for (int e = 0; e < 2; e++)
 #pragma unroll
-                        for (int x = 0; x < 4; x++) o[e][x] = (o[e][x] + rnd1) >> sh1;
+                        for (int x = 0; x < 4; x++) o[e][x] >>= sh1;
                 } else {
                     // no vertical filter: finish the sample here (the vertical pass is then the unit tap)
 #pragma unroll
                     for (int e = 0; e < 2; e++)
 #pragma unroll
                         for (int x = 0; x < 4; x++) {
-                            int v = o[e][x];
+                            int v = o[e][x];            // = sum + rnd1
                             if (!as_prep) {
                                 if (has_h) {
-                                    if (fbits == 4) v = (((v + rnd1) >> sh1) + ((1 << ib) >> 1)) >> ib;   // src/mc_tmpl.c:467-476
-                                    else            v = (v + 32 + rnd1) >> 6;                              // src/mc_tmpl.c:165-171
+                                    if (fbits == 4) v = ((v >> sh1) + ((1 << ib) >> 1)) >> ib;   // src/mc_tmpl.c:467-476
+                                    else            v = (v + 32) >> 6;                          // src/mc_tmpl.c:165-171
                                 }
                             } else {
-                                v = has_h ? ((v + rnd1) >> sh1) - bias : (v << ib) - bias;                 // :283-291 / :61-72
+                                v = has_h ? (v >> sh1) - bias : (v << ib) - bias;               // :283-291 / :61-72
                             }
                             o[e][x] = v;
                         }
@@ -207,70 +212,84 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSe
                 *reinterpret_cast<uint4 *>(mid + pr * TW + 4 * s) = m;
             }
         }
-        __syncthreads();
+        dv::wave_sync();
 
-        // ---- 3. vertical pass: lane = (output row vr, strip vs)
+        // ---- 3. vertical pass: item = (output row, strip), R items per lane
         if (live) {
-            const Taps fv = load_taps(rf.fv, rf.my);
-            // rows vr .. vr+7 of the window = pairs j0 .. j0+4; odd vr starts in the middle of a pair
-            const int j0 = vr >> 1;
-            const bool odd = vr & 1;
-            uint32_t g[5];
-#pragma unroll
-            for (int k = 0; k < 5; k++) g[k] = odd ? fv.od[k] : (k < 4 ? fv.ev[k] : 0u);
-            int sum[4] = { 0, 0, 0, 0 };
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const int j = dv::imin(j0 + k, NPR - 1);     // the 5th pair of an even row is weight 0
-                const uint4 m = *reinterpret_cast<const uint4 *>(mid + j * TW + 4 * vs);
-                sum[0] = dv::dot2(m.x, g[k], sum[0]);
-                sum[1] = dv::dot2(m.y, g[k], sum[1]);
-                sum[2] = dv::dot2(m.z, g[k], sum[2]);
-                sum[3] = dv::dot2(m.w, g[k], sum[3]);
-            }
             int sh2, vb;
             if (!has_v) { sh2 = 0; vb = 0; }
             else if (!as_prep) { sh2 = has_h ? fbits + ib : fbits; vb = 0; }          // src/mc_tmpl.c:157-159,176-178
             else { sh2 = has_h ? fbits : fbits - ib; vb = bias; }                     // :272-277, :294-299
             const int rnd2 = (1 << sh2) >> 1;
 #pragma unroll
-            for (int x = 0; x < 4; x++) out[x] = ((sum[x] + rnd2) >> sh2) - vb;
+            for (int r = 0; r < R; r++) {
+                const int it = r * LPT + l;
+                const int vr = it / NS, vs = it % NS;
+                // rows vr .. vr+7 of the window = pairs j0 .. j0+4; odd vr starts in the middle of a pair
+                const int j0 = vr >> 1;
+                const bool odd = vr & 1;
+                int sum[4] = { rnd2, rnd2, rnd2, rnd2 };
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const uint32_t g = odd ? fv.od[k] : (k < 4 ? fv.ev[k] : 0u);
+                    const int j = dv::imin(j0 + k, NPR - 1);     // the 5th pair of an even row is weight 0
+                    const uint4 m = *reinterpret_cast<const uint4 *>(mid + j * TW + 4 * vs);
+                    sum[0] = dv::dot2(m.x, g, sum[0]);
+                    sum[1] = dv::dot2(m.y, g, sum[1]);
+                    sum[2] = dv::dot2(m.z, g, sum[2]);
+                    sum[3] = dv::dot2(m.w, g, sum[3]);
+                }
+#pragma unroll
+                for (int x = 0; x < 4; x++) q[r][x] = (sum[x] >> sh2) - vb;
+            }
         }
     };
 
-    predict(t.r[0], q);
+    predict(t.r[0]);
     if (compound) {
 #pragma unroll
-        for (int x = 0; x < 4; x++) acc0[x] = q[x];
-        __syncthreads();                        // the second gather overwrites win / mid
-        predict(t.r[1], q);
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) acc0[r][x] = q[r][x];
+        dv::wave_sync();                        // the second gather overwrites win / mid
+        predict(t.r[1]);
     }
 
     // ---- combine + store
-    if (live && vr < t.h) {
-        if (t.kind == MCT_AVG) {
+    if (live) {
 #pragma unroll
-            for (int x = 0; x < 4; x++) q[x] = (acc0[x] + q[x] + (1 << ib) + bias * 2) >> (ib + 1);          // avg_c
-        } else if (t.kind == MCT_WAVG) {
+        for (int r = 0; r < R; r++) {
+            const int it = r * LPT + l;
+            const int vr = it / NS, vs = it % NS;
+            if (vr >= t.h) continue;
+            int o[4];
+            if (t.kind == MCT_AVG) {
 #pragma unroll
-            for (int x = 0; x < 4; x++)
-                q[x] = (acc0[x] * t.weight + q[x] * (16 - t.weight) + (8 << ib) + bias * 16) >> (ib + 4);  // w_avg_c
-        }
-        const int nvalid = dv::imin(4, t.w - 4 * vs);
-        if (t.kind != MCT_PREP) {
+                for (int x = 0; x < 4; x++) o[x] = (acc0[r][x] + q[r][x] + (1 << ib) + bias * 2) >> (ib + 1);          // avg_c
+            } else if (t.kind == MCT_WAVG) {
 #pragma unroll
-            for (int x = 0; x < 4; x++) q[x] = dv::iclip(q[x], 0, bitdepth_max);
-            pixel *d = reinterpret_cast<pixel *>(dst.data[t.plane]) + t.dst_off + (t.oy + vr) * dst.stride[t.plane] + t.ox + 4 * vs;
-            if (nvalid == 4) {
-                if (HBD) *reinterpret_cast<uint2 *>(d) = make_uint2(dv::pack2(q[0], q[1]), dv::pack2(q[2], q[3]));
-                else *reinterpret_cast<uint32_t *>(d) = (uint32_t) q[0] | ((uint32_t) q[1] << 8) | ((uint32_t) q[2] << 16) | ((uint32_t) q[3] << 24);
-            } else if (nvalid > 0) {
-                for (int x = 0; x < nvalid; x++) d[x] = (pixel) q[x];
+                for (int x = 0; x < 4; x++)
+                    o[x] = (acc0[r][x] * t.weight + q[r][x] * (16 - t.weight) + (8 << ib) + bias * 16) >> (ib + 4);  // w_avg_c
+            } else {
+#pragma unroll
+                for (int x = 0; x < 4; x++) o[x] = q[r][x];
             }
-        } else {
-            int16_t *d = prep + t.dst_off + (t.oy + vr) * t.bw + t.ox + 4 * vs;
-            if (nvalid == 4) *reinterpret_cast<uint2 *>(d) = make_uint2(dv::pack2(q[0], q[1]), dv::pack2(q[2], q[3]));
-            else if (nvalid > 0) for (int x = 0; x < nvalid; x++) d[x] = (int16_t) q[x];
+            const int nvalid = dv::imin(4, t.w - 4 * vs);
+            if (t.kind != MCT_PREP) {
+#pragma unroll
+                for (int x = 0; x < 4; x++) o[x] = dv::iclip(o[x], 0, bitdepth_max);
+                pixel *d = reinterpret_cast<pixel *>(dst.data[t.plane]) + t.dst_off + (t.oy + vr) * dst.stride[t.plane] + t.ox + 4 * vs;
+                if (nvalid == 4) {
+                    if (HBD) *reinterpret_cast<uint2 *>(d) = make_uint2(dv::pack2(o[0], o[1]), dv::pack2(o[2], o[3]));
+                    else *reinterpret_cast<uint32_t *>(d) = (uint32_t) o[0] | ((uint32_t) o[1] << 8) | ((uint32_t) o[2] << 16) | ((uint32_t) o[3] << 24);
+                } else if (nvalid > 0) {
+                    for (int x = 0; x < nvalid; x++) d[x] = (pixel) o[x];
+                }
+            } else {
+                int16_t *d = prep + t.dst_off + (t.oy + vr) * t.bw + t.ox + 4 * vs;
+                if (nvalid == 4) *reinterpret_cast<uint2 *>(d) = make_uint2(dv::pack2(o[0], o[1]), dv::pack2(o[2], o[3]));
+                else if (nvalid > 0) for (int x = 0; x < nvalid; x++) d[x] = (int16_t) o[x];
+            }
         }
     }
 }
@@ -280,14 +299,18 @@ hipError_t launch_cls(const int cls, const DevPlanes &dst, const RefSet &refs, c
                       int16_t *prep, const int bitdepth_max, hipStream_t stream)
 {
 #define CASE(C, TW, TH) case C: { \
-        constexpr int g = 64 / (TW * TH / 4); \
+        constexpr int lpt = mc_cmin(64, TW * TH / 4); \
+        constexpr int g = 64 / lpt; \
         hipLaunchKernelGGL((mc_kernel<TW, TH, pixel>), dim3((n + g - 1) / g), dim3(64), 0, stream, \
                            dst, refs, tiles, n, prep, bitdepth_max); \
         break; }
+    // class = 3 * wclass + hclass, widths 4 8 16 32 64, heights 4 8 16
     switch (cls) {
         CASE(0, 4, 4) CASE(1, 4, 8) CASE(2, 4, 16)
         CASE(3, 8, 4) CASE(4, 8, 8) CASE(5, 8, 16)
         CASE(6, 16, 4) CASE(7, 16, 8) CASE(8, 16, 16)
+        CASE(9, 32, 4) CASE(10, 32, 8) CASE(11, 32, 16)
+        CASE(12, 64, 4) CASE(13, 64, 8) CASE(14, 64, 16)
         default: return hipErrorInvalidValue;
     }
 #undef CASE

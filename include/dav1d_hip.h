@@ -172,8 +172,8 @@ DAV1D_HIP_API int dav1d_hip_mc_list_run(Dav1dHipContext *c, const Dav1dHipMcList
                                         const Dav1dHipPicture *dst, const Dav1dHipPicture *refs,
                                         int n_refs, int16_t *prep);
 
-/* Measurement aid, see dav1d_hip_itx_list_run_timed: ms[9] / counts[9] per tile-shape bin
- * (bin = 3*class(w) + class(h), class 0: 4, 1: 8, 2: 16). */
+/* Measurement aid, see dav1d_hip_itx_list_run_timed: ms[15] / counts[15] per tile-shape bin
+ * (bin = 3*class(w) + class(h); w classes 4, 8, 16, 32, 64; h classes 4, 8, 16). */
 DAV1D_HIP_API int dav1d_hip_mc_list_run_timed(Dav1dHipContext *c, const Dav1dHipMcList *l,
                                               const Dav1dHipPicture *dst, const Dav1dHipPicture *refs,
                                               int n_refs, int16_t *prep, float *ms, size_t *counts);
@@ -224,7 +224,7 @@ DAV1D_HIP_API void dav1d_hip_inter_list_destroy(Dav1dHipContext *c, Dav1dHipInte
 DAV1D_HIP_API int dav1d_hip_inter_list_run(Dav1dHipContext *c, const Dav1dHipInterList *l,
                                            const Dav1dHipPicture *dst, const Dav1dHipPicture *refs,
                                            int n_refs, int16_t *prep, uint8_t *mask);
-/* ms[10] / counts[10]: the 9 tile-shape bins of the mc kernel, then the residual compound kernel */
+/* ms[16] / counts[16]: the 15 tile-shape bins of the mc kernel, then the residual compound kernel */
 DAV1D_HIP_API int dav1d_hip_inter_list_run_timed(Dav1dHipContext *c, const Dav1dHipInterList *l,
                                                  const Dav1dHipPicture *dst, const Dav1dHipPicture *refs,
                                                  int n_refs, int16_t *prep, uint8_t *mask,

@@ -108,6 +108,8 @@ static inline unsigned long long __ballot(int pred) {
     s[emu_lane()] = 0;
     return m;
 }
+static inline int __any(int pred) { return __ballot(pred) != 0; }
+static inline int __all(int pred) { return __ballot(!pred) == 0; }
 static inline int __builtin_amdgcn_readfirstlane(int v) {
     // emulation assumes wave-uniform control flow at the call site: lowest live lane
     uint64_t *s = emu_wave_slots();
