@@ -97,7 +97,7 @@ def main():
     prep = torch.zeros(frame.prep_elems, dtype=torch.int16, device="cuda")
     tdt = torch.int16 if bpc == 8 else torch.int32
     pristine = torch.from_numpy(frame.coef).to("cuda")
-    n_arena = a.steps + a.warmup + 1
+    n_arena = a.steps + a.warmup + 3
     arenas = torch.empty((n_arena, pristine.numel()), dtype=tdt, device="cuda")
     for i in range(n_arena):
         arenas[i].copy_(pristine)
@@ -140,12 +140,20 @@ def main():
         cnt_itx = (C.c_size_t * 19)()
         rarr = (api.Picture * len(refs))(*[r.pic for r in refs])
         d = dsts[i % NDST]
-        rc = ctx.lib.dav1d_hip_inter_list_run_timed(ctx.h, inter_list.h, C.byref(d.pic), rarr, len(refs), prep.data_ptr(), None,
-                                                    ms_mc, cnt_mc)
-        assert rc == 0
-        rc = ctx.lib.dav1d_hip_itx_list_run_timed(ctx.h, itx_list.h, C.byref(d.pic), arenas[i].data_ptr(), ms_itx, cnt_itx)
-        assert rc == 0
-        torch.cuda.synchronize()
+        # three instrumented passes (each on its own pristine arena), keep the per-kernel minimum:
+        # the serial, event-bracketed launches are sensitive to clock ramps after an idle gap
+        best_mc, best_itx = [1e9] * 16, [1e9] * 19
+        for rep in range(3):
+            rc = ctx.lib.dav1d_hip_inter_list_run_timed(ctx.h, inter_list.h, C.byref(d.pic), rarr, len(refs), prep.data_ptr(), None,
+                                                        ms_mc, cnt_mc)
+            assert rc == 0
+            rc = ctx.lib.dav1d_hip_itx_list_run_timed(ctx.h, itx_list.h, C.byref(d.pic), arenas[i + rep].data_ptr(), ms_itx, cnt_itx)
+            assert rc == 0
+            torch.cuda.synchronize()
+            best_mc = [min(x, y) for x, y in zip(best_mc, ms_mc)]
+            best_itx = [min(x, y) for x, y in zip(best_itx, ms_itx)]
+        ms_mc, ms_itx = best_mc, best_itx
+        i = i + 2
         P = 1 if bpc == 8 else 2
         Cb = 2 if bpc == 8 else 4
         kernels = []

@@ -11,6 +11,38 @@ struct Dav1dHipContext {
     // scratch used by the reference-signature single-call wrappers (dsp_table.hip)
     void *scratch;
     size_t scratch_size;
+    // The per-shape kernels of one family touch disjoint pixels, so they run concurrently on
+    // side streams (fork from / join into `stream` with events): the long-latency, small-grid
+    // shapes (64x64 transforms ...) overlap with the wide ones instead of serialising.
+    enum { N_SIDE = 6 };
+    hipStream_t side[N_SIDE];
+    hipEvent_t ev_fork, ev_join[N_SIDE];
+    bool concurrent;
+};
+
+// fork/join helper: launches issued through next() land round-robin on the side streams
+struct StreamFan {
+    Dav1dHipContext *c;
+    int used;
+    explicit StreamFan(Dav1dHipContext *ctx) : c(ctx), used(0) {
+        if (c->concurrent) (void) hipEventRecord(c->ev_fork, c->stream);
+    }
+    hipStream_t next() {
+        if (!c->concurrent) return c->stream;
+        const int i = used % Dav1dHipContext::N_SIDE;
+        if (used < Dav1dHipContext::N_SIDE) (void) hipStreamWaitEvent(c->side[i], c->ev_fork, 0);
+        used++;
+        return c->side[i];
+    }
+    void join() {
+        if (!c->concurrent) return;
+        const int n = used < Dav1dHipContext::N_SIDE ? used : Dav1dHipContext::N_SIDE;
+        for (int i = 0; i < n; i++) {
+            (void) hipEventRecord(c->ev_join[i], c->side[i]);
+            (void) hipStreamWaitEvent(c->stream, c->ev_join[i], 0);
+        }
+        used = 0;
+    }
 };
 
 static inline int hip_rc(hipError_t e) {

@@ -25,6 +25,13 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     c->scratch_size = 0;
     if (stream) c->stream = (hipStream_t) stream;
     else if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return -ENODEV; }
+    const char *ser = getenv("DAV1D_HIP_SERIAL");
+    c->concurrent = !(ser && atoi(ser));
+    for (int i = 0; i < Dav1dHipContext::N_SIDE; i++) {
+        if (hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
+    }
+    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
     *out = c;
     return 0;
 }
@@ -33,6 +40,8 @@ void dav1d_hip_close(Dav1dHipContext *c) {
     if (!c) return;
     hipStreamSynchronize(c->stream);
     if (c->scratch) hipFree(c->scratch);
+    for (int i = 0; i < Dav1dHipContext::N_SIDE; i++) { hipStreamSynchronize(c->side[i]); hipStreamDestroy(c->side[i]); hipEventDestroy(c->ev_join[i]); }
+    hipEventDestroy(c->ev_fork);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -231,13 +240,18 @@ void dav1d_hip_itx_list_destroy(Dav1dHipContext *c, Dav1dHipItxList *l) {
 int dav1d_hip_itx_list_run(Dav1dHipContext *c, const Dav1dHipItxList *l, const Dav1dHipPicture *dst, void *coef) {
     if (!l || !dst) return -EINVAL;
     const DevPlanes dp = dev_planes(dst);
-    for (int b = 0; b < 19; b++) {
+    // longest-running shapes first (64-point, then 32-point ...), each on its own side stream
+    static const uint8_t order[19] = { 4, 11, 12, 17, 18, 3, 9, 10, 15, 16, 2, 7, 8, 13, 14, 1, 5, 6, 0 };
+    StreamFan fan(c);
+    int rc = 0;
+    for (int k = 0; k < 19 && !rc; k++) {
+        const int b = order[k];
         const size_t cnt = l->off[b + 1] - l->off[b];
         if (!cnt) continue;
-        const int rc = dav1d_hip_launch_itx_bin(&dp, dst->bpc, b, l->dev + l->off[b], (int) cnt, coef, c->stream);
-        if (rc) return rc;
+        rc = dav1d_hip_launch_itx_bin(&dp, dst->bpc, b, l->dev + l->off[b], (int) cnt, coef, fan.next());
     }
-    return 0;
+    fan.join();
+    return rc;
 }
 
 // Same launches, each bracketed by HIP events on the context's stream; ms[b] receives the
@@ -381,13 +395,15 @@ int dav1d_hip_mc_list_run(Dav1dHipContext *c, const Dav1dHipMcList *l, const Dav
         if (refs[i].bpc != dst->bpc) return -EINVAL;
         rp[i] = dev_planes(&refs[i]);
     }
-    for (int b = 0; b < MC_BINS; b++) {
+    StreamFan fan(c);
+    int rc = 0;
+    for (int b = MC_BINS - 1; b >= 0 && !rc; b--) {
         const size_t cnt = l->off[b + 1] - l->off[b];
         if (!cnt) continue;
-        const int rc = dav1d_hip_launch_mc_bin(&dp, rp, n_refs, dst->bpc, b, l->dev + l->off[b], (int) cnt, prep, c->stream);
-        if (rc) return rc;
+        rc = dav1d_hip_launch_mc_bin(&dp, rp, n_refs, dst->bpc, b, l->dev + l->off[b], (int) cnt, prep, fan.next());
     }
-    return 0;
+    fan.join();
+    return rc;
 }
 
 int dav1d_hip_mc_list_run_timed(Dav1dHipContext *c, const Dav1dHipMcList *l, const Dav1dHipPicture *dst,

@@ -10,8 +10,9 @@
 // transforms row r, in the column pass lane c transforms column c; the transpose in
 // between goes through LDS with a padded row stride (conflict-free both ways).
 // 64/LPB blocks share one wave, so 4x4 blocks run 16 to a wave and 64x64 one.
-// The slab is fetched with 16-byte loads into LDS (and zeroed with 16-byte stores
-// in the same sweep); the row pass then reads it transposed from LDS.
+// The slab is fetched with 16-byte loads into LDS (zeroed with 16-byte stores in the same
+// sweep) together with the destination pixels the column pass will need much later; the
+// row pass reads it transposed, and the same LDS region then becomes the transpose buffer.
 #include "common.h"
 #include "itx1d.h"
 
@@ -88,20 +89,21 @@ __global__ __launch_bounds__(64) void itx_add_kernel(const DevPlanes dst, const 
     constexpr int TS = W + 1;                 // padded row stride of the transpose buffer
     constexpr int SHIFT = tx_shift(TX);
     constexpr bool RECT2 = (W * 2 == H) || (H * 2 == W);
-    constexpr int NCH = SW * SH * (int) sizeof(coef) / 16;   // 16-byte chunks per slab
     constexpr bool HBD = sizeof(pixel) == 2;
 
-    __shared__ __attribute__((aligned(16))) coef slab_s[BPW * SW * SH];
-    __shared__ int tmp_s[BPW * SH * TS];
+    constexpr int NCH = SW * SH * (int) sizeof(coef) / 16;   // 16-byte chunks per slab
+    // one LDS region per block, used twice: first the raw slab (landing zone of the 16-byte
+    // loads), then, once every lane holds its row in registers, the transposed intermediate
+    __shared__ __attribute__((aligned(16))) int tmp_s[BPW * SH * TS];
 
     const int lane = threadIdx.x;
-    const int sub = lane / LPB, l = lane % LPB;
+    const int sub = BPW == 1 ? 0 : lane / LPB, l = BPW == 1 ? lane : lane % LPB;
     const int ti = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x) * BPW + sub;
     const bool live = ti < n;
 
     Dav1dHipItxTask t;
-    if (live) t = tasks[ti];
-    else { t.dst_off = 0; t.cf_off = 0; t.eob = 0; t.tx = TX; t.txtp = 0; t.plane = 0; }
+    if (BPW == 1) t = tasks[__builtin_amdgcn_readfirstlane(live ? ti : 0)];   // one block per wave: record in SGPRs
+    else t = tasks[live ? ti : 0];
 
     const bool wht = TX == 0 && t.txtp == 16;
     const bool dconly = live && t.txtp == 0 && t.eob < 1;
@@ -110,26 +112,47 @@ __global__ __launch_bounds__(64) void itx_add_kernel(const DevPlanes dst, const 
     txtp_kinds(t.txtp, k1, k2);
 
     coef *const gcf = cf + t.cf_off;
-    coef *const slab = slab_s + sub * SW * SH;
     int *const tmp = tmp_s + sub * SH * TS;
+    pixel *const d = reinterpret_cast<pixel *>(dst.data[t.plane]) + t.dst_off + l;
+    const int stride = dst.stride[t.plane];
 
-    // ---- fetch + zero the slab (full blocks); dc-only blocks touch coeff[0] only
+    // ---- issue every global load up front: the row's coefficients (lane r = row r reads
+    // coeff[r + x*SH], consecutive lanes -> consecutive addresses) and, for the column pass later,
+    // this lane's column of destination pixels.  dc-only blocks touch coeff[0] only.
+    int in[W];
+    pixel dpx[H];
     int dc = 0;
+    const bool row_lane = full && l < SH;
+    static_assert(SW * SH * (int) sizeof(coef) <= SH * TS * (int) sizeof(int), "slab fits the transpose buffer");
     if (full) {
+        // 16-byte loads of the contiguous slab, zeroed in the same sweep (src/itx_tmpl.c:108)
         const int4 *g4 = reinterpret_cast<const int4 *>(gcf);
         int4 *z4 = reinterpret_cast<int4 *>(gcf);
-        int4 *s4 = reinterpret_cast<int4 *>(slab);
+        int4 *s4 = reinterpret_cast<int4 *>(tmp);
+        int4 v[(NCH + LPB - 1) / LPB];
 #pragma unroll
-        for (int i = l; i < NCH; i += LPB) {
-            s4[i] = g4[i];
-            z4[i] = make_int4(0, 0, 0, 0);
+        for (int k = 0; k < (NCH + LPB - 1) / LPB; k++) if (l + k * LPB < NCH) v[k] = g4[l + k * LPB];
+        if (l < W) {
+#pragma unroll
+            for (int y = 0; y < H; y++) dpx[y] = d[y * stride];
         }
-    } else if (dconly && l == 0) {
-        dc = gcf[0];
-        gcf[0] = 0;
+#pragma unroll
+        for (int k = 0; k < (NCH + LPB - 1) / LPB; k++) if (l + k * LPB < NCH) { s4[l + k * LPB] = v[k]; z4[l + k * LPB] = make_int4(0, 0, 0, 0); }
+    } else if (dconly) {
+        if (l == 0) { dc = gcf[0]; gcf[0] = 0; }            // src/itx_tmpl.c:59-60
+        if (l < W) {
+#pragma unroll
+            for (int y = 0; y < H; y++) dpx[y] = d[y * stride];
+        }
     }
     dc = __shfl(dc, sub * LPB);
-    __syncthreads();
+    dv::wave_sync();
+    if (row_lane) {
+        const coef *slab = reinterpret_cast<const coef *>(tmp);
+#pragma unroll
+        for (int x = 0; x < SW; x++) in[x] = slab[x * SH + l];
+    }
+    dv::wave_sync();     // every row is in registers: the region becomes the transpose buffer
 
     int row_min, row_max, col_min, col_max;
     if (HBD) {
@@ -142,15 +165,12 @@ __global__ __launch_bounds__(64) void itx_add_kernel(const DevPlanes dst, const 
     col_max = ~col_min;
 
     // ---- first pass: lane r = row r, W-point transform along x
-    if (full && l < SH) {
-        int in[W], out[W];
+    if (row_lane) {
+        int out[W];
 #pragma unroll
         for (int x = 0; x < W; x++) {
-            int v = 0;
-            if (x < SW) {
-                v = slab[x * SH + l];
-                if (RECT2) v = (v * 181 + 128) >> 8;
-            }
+            int v = x < SW ? in[x] : 0;
+            if (RECT2 && x < SW) v = (v * 181 + 128) >> 8;
             in[x] = v;
         }
         if (TX == 0 && wht) {
@@ -170,36 +190,37 @@ __global__ __launch_bounds__(64) void itx_add_kernel(const DevPlanes dst, const 
             }
         }
     }
-    __syncthreads();
+    dv::wave_sync();
 
     // ---- second pass: lane c = column c, H-point transform along y, add to dst
     if (live && l < W) {
-        pixel *d = reinterpret_cast<pixel *>(dst.data[t.plane]) + t.dst_off + l;
-        const int stride = dst.stride[t.plane];
         if (dconly) {
             if (RECT2) dc = (dc * 181 + 128) >> 8;
             dc = (dc * 181 + 128) >> 8;
             dc = (dc + ((1 << SHIFT) >> 1)) >> SHIFT;
             dc = (dc * 181 + 128 + 2048) >> 12;
-#pragma unroll 8
-            for (int y = 0; y < H; y++)
-                d[y * stride] = (pixel) dv::iclip((int) d[y * stride] + dc, 0, bitdepth_max);
-        } else {
-            int in[H], out[H];
 #pragma unroll
-            for (int y = 0; y < H; y++) in[y] = y < SH ? tmp[y * TS + l] : 0;
+            for (int y = 0; y < H; y++)
+                d[y * stride] = (pixel) dv::iclip((int) dpx[y] + dc, 0, bitdepth_max);
+        } else {
+            int cin[H], out[H];
+#pragma unroll
+            for (int y = 0; y < H; y++) cin[y] = y < SH ? tmp[y * TS + l] : 0;
             if (TX == 0 && wht) {
-                if constexpr (H == 4) itx1d::iwht4(in, out);
+                if constexpr (H == 4) itx1d::iwht4(cin, out);
 #pragma unroll
                 for (int y = 0; y < H; y++)
-                    d[y * stride] = (pixel) dv::iclip((int) d[y * stride] + out[y], 0, bitdepth_max);
+                    d[y * stride] = (pixel) dv::iclip((int) dpx[y] + out[y], 0, bitdepth_max);
             } else {
-                tx1d<H>(k2, in, out, col_min, col_max);
-                const bool flip = k2 == K_FLIPADST;
+                tx1d<H>(k2, cin, out, col_min, col_max);
+                if (k2 == K_FLIPADST) {
 #pragma unroll
-                for (int y = 0; y < H; y++) {
-                    const int yo = flip ? H - 1 - y : y;
-                    d[yo * stride] = (pixel) dv::iclip((int) d[yo * stride] + ((out[y] + 8) >> 4), 0, bitdepth_max);
+                    for (int y = 0; y < H; y++)
+                        d[y * stride] = (pixel) dv::iclip((int) dpx[y] + ((out[H - 1 - y] + 8) >> 4), 0, bitdepth_max);
+                } else {
+#pragma unroll
+                    for (int y = 0; y < H; y++)
+                        d[y * stride] = (pixel) dv::iclip((int) dpx[y] + ((out[y] + 8) >> 4), 0, bitdepth_max);
                 }
             }
         }
