@@ -55,6 +55,33 @@ def algorithmic_bytes(frame):
     return frame.n_samples * (2 * P + 2 * Cb) + comp_samples * P
 
 
+def pmc_traffic(kernel, w, h, bpc):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this very workload
+    (tools/pmc_profile.sh -> profiles/*/traffic.json: FETCH_SIZE x 2 (gfx950 correction for wide
+    reads, validated on the 179.5 MB arena copy in the same profile) + WRITE_SIZE); None when no
+    profile of the default workload is available or the workload differs."""
+    if (w, h, bpc) != (7680, 4320, 10):
+        return None
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")))
+    if not files:
+        return None
+    m = re.match(r"(mc|itx)_(\d+)x(\d+)", kernel)
+    if not m:
+        return None
+    d = json.load(open(files[-1]))
+    if m.group(1) == "mc":
+        key = "mc_kernel<%s,%s,u16>" % (m.group(2), m.group(3))
+    else:
+        from dav1d_amd import synth
+        tx = [i for i in range(19) if synth.TX_W[i] == int(m.group(2)) and synth.TX_H[i] == int(m.group(3))][0]
+        key = "itx_add_kernel<%d,u16,int>" % tx
+    if key not in d:
+        return None
+    return int(d[key]["fetch_bytes_x2"] + d[key]["write_bytes"])
+
+
 def main():
     a = parse()
     import torch
@@ -185,7 +212,7 @@ def main():
         ach = dom[2] / (dom[1] * 1e-3) / 1e9
         path_bytes = algorithmic_bytes(frame)
         roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom[0], w, h, bpc),
                 "kernel_ms": round(dom[1], 4), "algorithmic_bytes_per_launch": int(dom[2]),
                 "path": {"algorithmic_bytes_per_frame": int(path_bytes),
                          "achieved": round(path_bytes / (ms_per_step * 1e-3) / 1e9, 1),

@@ -8,6 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+export DAV1D_HIP_SERIAL=1   # per-kernel durations must not overlap: run the shapes back to back
 ARGS="--steps 3 --warmup 1 --no-cpu --no-check $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python "$ROOT/bench.py" $ARGS > "$OUT/stats.log" 2>&1
 i=0
