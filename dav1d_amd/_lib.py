@@ -31,6 +31,9 @@ MC_TASK = np.dtype([("dst_off", "<u4"), ("src_x", "<i4"), ("src_y", "<i4"), ("w"
 COMP_TASK = np.dtype([("dst_off", "<u4"), ("tmp1_off", "<u4"), ("tmp2_off", "<u4"), ("mask_off", "<u4"),
                       ("w", "u1"), ("h", "u1"), ("kind", "u1"), ("plane", "u1"), ("arg", "i1"), ("ss", "u1"),
                       ("pad", "<u2")], align=False)
+CDEF_TASK = np.dtype([("bx", "<u2"), ("by", "<u2"), ("y_pri", "u1"), ("y_sec", "u1"), ("uv_pri", "u1"), ("uv_sec", "u1"),
+                      ("edges", "u1"), ("flags", "u1"), ("dir", "u1"), ("plane", "u1"), ("pad", "u1", (4,))], align=False)
+assert CDEF_TASK.itemsize == 16
 assert ITX_TASK.itemsize == 16 and MC_TASK.itemsize == 24 and COMP_TASK.itemsize == 24
 
 # every symbol include/dav1d_hip.h declares (tests check the built library exports all of them)
@@ -45,6 +48,7 @@ SYMBOLS = [
     "dav1d_hip_itx_list_run_timed", "dav1d_hip_mc_list_run_timed",
     "dav1d_hip_inter_list_create", "dav1d_hip_inter_list_destroy", "dav1d_hip_inter_list_run",
     "dav1d_hip_inter_list_run_timed", "dav1d_hip_inter_list_fused",
+    "dav1d_hip_cdef_batch",
 ]
 
 
@@ -95,6 +99,7 @@ def load(path=None):
         "dav1d_hip_inter_list_run": (i, [vp, vp, P(Picture), P(Picture), i, vp, vp]),
         "dav1d_hip_inter_list_run_timed": (i, [vp, vp, P(Picture), P(Picture), i, vp, vp, P(C.c_float), P(sz)]),
         "dav1d_hip_inter_list_fused": (sz, [vp]),
+        "dav1d_hip_cdef_batch": (i, [vp, P(Picture), P(Picture), vp, sz, i, vp]),
         "dav1d_hip_dsp_init_8bpc": (i, [vp]),
         "dav1d_hip_dsp_init_16bpc": (i, [vp, i]),
     }

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import ITX_TASK, MC_TASK, COMP_TASK, Picture  # noqa: F401  (re-exported)
+from ._lib import ITX_TASK, MC_TASK, COMP_TASK, CDEF_TASK, Picture  # noqa: F401  (re-exported)
 
 LAYOUT_I400, LAYOUT_I420, LAYOUT_I422, LAYOUT_I444 = 0, 1, 2, 3
 
@@ -173,6 +173,11 @@ class Context:
         t = np.ascontiguousarray(tasks, dtype=COMP_TASK)
         _chk(self.lib.dav1d_hip_comp_batch(self.h, C.byref(dst.pic), t.ctypes.data, len(t), prep.ptr,
                                            mask.ptr if mask else None), "comp_batch")
+
+    def cdef_batch(self, dst, src, tasks, damping, dirvar=None):
+        t = np.ascontiguousarray(tasks, dtype=CDEF_TASK)
+        _chk(self.lib.dav1d_hip_cdef_batch(self.h, C.byref(dst.pic), C.byref(src.pic), t.ctypes.data, len(t), damping,
+                                           dirvar.ptr if dirvar else None), "cdef_batch")
 
     # ---- device-resident lists
     def itx_list(self, tasks):

@@ -96,5 +96,8 @@ extern "C" int dav1d_hip_launch_mc_bin(const DevPlanes *dst, const DevPlanes *re
 extern "C" int dav1d_hip_launch_comp(const DevPlanes *dst, int bpc, const Dav1dHipCompTask *tasks, int n,
                                      const int16_t *prep, uint8_t *mask, void *stream);
 
+extern "C" int dav1d_hip_launch_cdef(const DevPlanes *dst, const DevPlanes *src, int bpc, int layout,
+                                     const Dav1dHipCdefTask *tasks, int n, int damping, uint32_t *dirvar, void *stream);
+
 Dav1dHipContext *dav1d_hip_default_context(void);
 int dav1d_hip_scratch(Dav1dHipContext *c, size_t bytes, void **out);

@@ -603,3 +603,21 @@ int dav1d_hip_inter_list_run_timed(Dav1dHipContext *c, const Dav1dHipInterList *
 size_t dav1d_hip_inter_list_fused(const Dav1dHipInterList *l) { return l ? l->n_fused : 0; }
 
 } // extern "C"
+
+// --------------------------------------------------------------------- cdef
+
+extern "C" int dav1d_hip_cdef_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src,
+                                    const Dav1dHipCdefTask *tasks, size_t n, int damping, uint32_t *dirvar) {
+    if (!dst || !src || (!tasks && n) || dst->bpc != src->bpc || dst->layout != src->layout) return -EINVAL;
+    if (!n) return 0;
+    for (size_t i = 0; i < n; i++)
+        if (tasks[i].edges > 15 || tasks[i].plane > 2 || tasks[i].dir > 7) return -EINVAL;
+    Dav1dHipCdefTask *dev = nullptr;
+    if (hipMalloc((void **) &dev, n * sizeof(*dev)) != hipSuccess) return -ENOMEM;
+    int rc = dav1d_hip_upload(c, dev, tasks, n * sizeof(*dev));
+    const DevPlanes dp = dev_planes(dst), sp = dev_planes(src);
+    if (!rc) rc = dav1d_hip_launch_cdef(&dp, &sp, dst->bpc, dst->layout, dev, (int) n, damping, dirvar, c->stream);
+    hipStreamSynchronize(c->stream);
+    hipFree(dev);
+    return rc;
+}

@@ -231,6 +231,33 @@ DAV1D_HIP_API int dav1d_hip_inter_list_run_timed(Dav1dHipContext *c, const Dav1d
                                                  float *ms, size_t *counts);
 DAV1D_HIP_API size_t dav1d_hip_inter_list_fused(const Dav1dHipInterList *l);
 
+/* --------------------------------------------------------------------- cdef */
+
+/* One 8x8 luma unit of CDEF as the reference driver handles it
+ * (dav1d_cdef_brow, src/cdef_apply_tmpl.c:149-290): direction search on the luma block
+ * (dsp->cdef.dir), variance-adjusted primary strength, dsp->cdef.fb[0] on luma and
+ * dsp->cdef.fb[uv_idx] on both chroma blocks.  Out of place: `src` is the immutable
+ * pre-CDEF (deblocked) picture, `dst` receives the filtered units; `dst` must already
+ * hold a copy of `src` for the units that are not listed (skipped / zero strength). */
+enum { DAV1D_HIP_CDEF_HAVE_LEFT = 1, DAV1D_HIP_CDEF_HAVE_RIGHT = 2, DAV1D_HIP_CDEF_HAVE_TOP = 4,
+       DAV1D_HIP_CDEF_HAVE_BOTTOM = 8 };    /* == enum CdefEdgeFlags, src/cdef.h:36-41 */
+typedef struct Dav1dHipCdefTask {
+    uint16_t bx, by;     /* unit position in 8x8 luma units (RAW tasks: top-left in pixels of `plane`) */
+    uint8_t  y_pri;      /* (y_strength >> 2) << (bpc - 8), before the variance adjustment */
+    uint8_t  y_sec;      /* secondary strength incl. the 3 -> 4 fix-up, << (bpc - 8) */
+    uint8_t  uv_pri, uv_sec;
+    uint8_t  edges;      /* DAV1D_HIP_CDEF_HAVE_* */
+    uint8_t  flags;      /* bit 0 RAW: one dsp->cdef.fb call (pri = y_pri, sec = y_sec, `dir`, no search / adjust) on
+                            `plane`; bit 1: block is 4 wide, bit 2: block is 4 high (fb[1] = 4x8, fb[2] = 4x4) */
+    uint8_t  dir, plane; /* RAW only */
+    uint8_t  pad[4];
+} Dav1dHipCdefTask;
+
+/* `tasks` HOST array.  `damping` = frame cdef.damping + (bpc - 8) (chroma uses damping - 1).
+ * `dirvar`: optional DEVICE array of n words receiving dir | var << 3 of every non-RAW task. */
+DAV1D_HIP_API int dav1d_hip_cdef_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src,
+                                       const Dav1dHipCdefTask *tasks, size_t n, int damping, uint32_t *dirvar);
+
 /* ------------------------------------------------- reference-signature table */
 
 /* Function pointer types with the reference's exact signatures (16 bpc flavour

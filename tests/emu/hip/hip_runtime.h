@@ -108,6 +108,8 @@ static inline unsigned long long __ballot(int pred) {
     s[emu_lane()] = 0;
     return m;
 }
+static inline int atomicAdd(int *p, int v) { const int o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned *p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
 static inline int __any(int pred) { return __ballot(pred) != 0; }
 static inline int __all(int pred) { return __ballot(!pred) == 0; }
 static inline int __builtin_amdgcn_readfirstlane(int v) {

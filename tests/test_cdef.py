@@ -1,0 +1,128 @@
+"""CDEF parity: the batched HIP kernel (one task = one 8x8 luma unit, as the reference driver
+dav1d_cdef_brow handles it) vs the reference DSP functions cdef.dir / cdef.fb[*] driven the same
+way (src/cdef_apply_tmpl.c:149-290).  Fill classes, strengths and damping follow
+tests/checkasm/cdef.c:42-104."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import util
+from dav1d_amd import api, synth
+
+
+def _fill(rng, shape, bpc, cls):
+    mx = (1 << bpc) - 1
+    if cls == 0:
+        return rng.integers(0, 4, size=shape)
+    if cls == 1:
+        return mx - rng.integers(0, 4, size=shape)
+    return rng.integers(0, mx + 1, size=shape)
+
+
+def oracle_cdef_unit(oracle, bpc, src, dst, t, damping, layout=1):
+    """The reference driver's work for one unit, out of place: reads src planes, writes dst planes."""
+    bd8 = bpc - 8
+    ss_ver = 1 if layout == 1 else 0
+    ss_hor = 1 if layout != 3 else 0
+    x0, y0 = int(t["bx"]) * 8, int(t["by"]) * 8
+    edges = int(t["edges"])
+    pd = src[0].dtype
+    var = C.c_uint(0)
+    direction = 0
+    y_pri, y_sec, uv_pri, uv_sec = (int(t[k]) for k in ("y_pri", "y_sec", "uv_pri", "uv_sec"))
+    if y_pri or uv_pri:
+        blk = src[0][y0:, x0:]
+        direction = oracle.call(bpc, "cdef_dir", 0, 0, blk.ctypes.data, src[0].strides[0], C.byref(var))
+
+    def fb(pl, fb_idx, px0, py0, w, h, pri, sec, d, damp):
+        s, o = src[pl], dst[pl]
+        left = np.zeros((8, 2), pd)
+        if px0 >= 2:
+            left[:h] = s[py0:py0 + h, px0 - 2:px0]
+        blk = o[py0:, px0:]
+        top = s[max(py0 - 2, 0):, px0:]
+        bot = s[min(py0 + h, s.shape[0] - 1):, px0:]
+        # pointers may be offset by -2 columns inside the callee; the planes carry padding columns
+        oracle.call(bpc, "cdef_fb", fb_idx, 0, blk.ctypes.data, s.strides[0], left.ctypes.data,
+                    top.ctypes.data, bot.ctypes.data, pri, sec, d, damp, edges)
+
+    if y_pri:
+        v = var.value
+        adj = 0
+        if v:
+            i = min(int(v >> 6).bit_length() - 1, 12) if (v >> 6) else 0
+            adj = (y_pri * (4 + i) + 8) >> 4
+        if adj or y_sec:
+            fb(0, 0, x0, y0, 8, 8, adj, y_sec, direction, damping)
+    elif y_sec:
+        fb(0, 0, x0, y0, 8, 8, 0, y_sec, 0, damping)
+    if uv_pri or uv_sec:
+        uv_dirs = [7, 0, 2, 4, 5, 6, 6, 6] if layout == 2 else list(range(8))
+        uvdir = uv_dirs[direction] if uv_pri else 0
+        uv_idx = 3 - layout
+        for pl in (1, 2):
+            fb(pl, uv_idx, x0 >> ss_hor, y0 >> ss_ver, 8 >> ss_hor, 8 >> ss_ver, uv_pri, uv_sec, uvdir, damping - 1)
+    return direction, var.value
+
+
+@pytest.mark.parametrize("bpc", [8, 10, 12])
+def test_cdef_units_match_reference(ctx, bpc):
+    oracle = util.default_oracle()
+    if oracle.which != "ref":
+        pytest.skip("cdef is checked against the reference build (oracle/port has no cdef yet)")
+    rng = np.random.default_rng(600 + bpc)
+    w, h = (128, 64) if ctx.backend == "emu" else (512, 256)
+    bd8 = bpc - 8
+    src_pic = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+    dst_pic = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+    planes = synth.make_planes(rng, w, h, bpc, smooth=False)
+    # three fill classes in bands (tests/checkasm/cdef.c:63-66)
+    for pl, p in enumerate(planes):
+        third = p.shape[1] // 3
+        for c in range(3):
+            p[:, c * third:(c + 1) * third] = _fill(rng, p[:, c * third:(c + 1) * third].shape, bpc, c)
+    for pl in range(3):
+        src_pic.upload(pl, planes[pl])
+        dst_pic.upload(pl, planes[pl])
+    bw, bh = w // 8, h // 8
+    tasks = np.zeros(bw * bh, api.CDEF_TASK)
+    damping = int(rng.integers(3, 7)) + bd8
+    k = 0
+    for by in range(bh):
+        for bx in range(bw):
+            e = (1 if bx > 0 else 0) | (2 if bx < bw - 1 else 0) | (4 if by > 0 else 0) | (8 if by < bh - 1 else 0)
+            if rng.integers(0, 5) == 0:
+                e &= int(rng.integers(0, 16))          # pretend some neighbours are missing
+            y_lvl, uv_lvl = int(rng.integers(0, 64)), int(rng.integers(0, 64))
+            mode = rng.integers(0, 6)
+            if mode == 0:
+                y_lvl &= 3
+            elif mode == 1:
+                uv_lvl &= ~3
+            elif mode == 2:
+                y_lvl = 0
+            ysec, uvsec = y_lvl & 3, uv_lvl & 3
+            ysec += ysec == 3
+            uvsec += uvsec == 3
+            tasks[k] = (bx, by, (y_lvl >> 2) << bd8, ysec << bd8, (uv_lvl >> 2) << bd8, uvsec << bd8, e, 0, 0, 0, (0, 0, 0, 0))
+            k += 1
+    want = synth.copy_planes(planes)
+    want_dv = np.zeros(len(tasks), np.uint32)
+    for i, t in enumerate(tasks):
+        d, v = oracle_cdef_unit(oracle, bpc, planes, want, t, damping)
+        want_dv[i] = d | (v << 3)
+    dirvar = ctx.buffer(4 * len(tasks))
+    dirvar.zero()
+    ctx.cdef_batch(dst_pic, src_pic, tasks, damping, dirvar)
+    got_dv = dirvar.download(np.uint32, len(tasks))
+    for pl in range(3):
+        got = dst_pic.download(pl)
+        bad = np.argwhere(got != want[pl])
+        assert not len(bad), "plane %d differs at %s: got %d want %d; task %s" % (
+            pl, bad[0], got[tuple(bad[0])], want[pl][tuple(bad[0])],
+            tuple(tasks[(bad[0][0] >> (3 - (pl > 0))) * bw + (bad[0][1] >> (3 - (pl > 0)))]))
+    pri_any = (tasks["y_pri"] > 0) | (tasks["uv_pri"] > 0)
+    assert np.array_equal(got_dv[pri_any], want_dv[pri_any]), "cdef_dir direction / variance side output"
+    for o in (src_pic, dst_pic, dirvar):
+        o.free()

@@ -88,7 +88,10 @@ PROTO = {
     "blend": [_vp, _pd, _vp, _i, _i, _vp],
     "blend_v": [_vp, _pd, _vp, _i, _i],
     "blend_h": [_vp, _pd, _vp, _i, _i],
+    "cdef_dir": [_vp, _pd, _vp],
+    "cdef_fb": [_vp, _pd, _vp, _vp, _vp, _i, _i, _i, _i, _i],
 }
+RET_INT = {"cdef_dir"}
 NO_HBD_SUFFIX = {"blend", "blend_v", "blend_h", "emu_edge"}
 
 
@@ -112,7 +115,7 @@ class Oracle:
             args = list(PROTO[family])
             if bpc > 8 and family not in NO_HBD_SUFFIX:
                 args.append(_i)
-            self._cache[key] = C.CFUNCTYPE(None, *args)(p)
+            self._cache[key] = C.CFUNCTYPE(C.c_int if family in RET_INT else None, *args)(p)
         return self._cache[key]
 
     def call(self, bpc, family, i, j, *args):
@@ -120,7 +123,7 @@ class Oracle:
         a = [x.ctypes.data if isinstance(x, np.ndarray) else x for x in args]
         if bpc > 8 and family not in NO_HBD_SUFFIX:
             a.append((1 << bpc) - 1)
-        f(*a)
+        return f(*a)
 
 
 def available_oracles():
