@@ -33,6 +33,9 @@ COMP_TASK = np.dtype([("dst_off", "<u4"), ("tmp1_off", "<u4"), ("tmp2_off", "<u4
                       ("pad", "<u2")], align=False)
 CDEF_TASK = np.dtype([("bx", "<u2"), ("by", "<u2"), ("y_pri", "u1"), ("y_sec", "u1"), ("uv_pri", "u1"), ("uv_sec", "u1"),
                       ("edges", "u1"), ("flags", "u1"), ("dir", "u1"), ("plane", "u1"), ("pad", "u1", (4,))], align=False)
+LF_TASK = np.dtype([("dst_off", "<u4"), ("lvl_off", "<u4"), ("vmask", "<u4", (3,)), ("plane", "u1"), ("dir", "u1"),
+                    ("lvl_comp", "u1"), ("pad", "u1")], align=False)
+assert LF_TASK.itemsize == 24
 assert CDEF_TASK.itemsize == 16
 assert ITX_TASK.itemsize == 16 and MC_TASK.itemsize == 24 and COMP_TASK.itemsize == 24
 
@@ -48,7 +51,7 @@ SYMBOLS = [
     "dav1d_hip_itx_list_run_timed", "dav1d_hip_mc_list_run_timed",
     "dav1d_hip_inter_list_create", "dav1d_hip_inter_list_destroy", "dav1d_hip_inter_list_run",
     "dav1d_hip_inter_list_run_timed", "dav1d_hip_inter_list_fused",
-    "dav1d_hip_cdef_batch",
+    "dav1d_hip_cdef_batch", "dav1d_hip_lf_batch",
 ]
 
 
@@ -100,6 +103,7 @@ def load(path=None):
         "dav1d_hip_inter_list_run_timed": (i, [vp, vp, P(Picture), P(Picture), i, vp, vp, P(C.c_float), P(sz)]),
         "dav1d_hip_inter_list_fused": (sz, [vp]),
         "dav1d_hip_cdef_batch": (i, [vp, P(Picture), P(Picture), vp, sz, i, vp]),
+        "dav1d_hip_lf_batch": (i, [vp, P(Picture), vp, sz, vp, C.c_ssize_t, vp, vp]),
         "dav1d_hip_dsp_init_8bpc": (i, [vp]),
         "dav1d_hip_dsp_init_16bpc": (i, [vp, i]),
     }

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import ITX_TASK, MC_TASK, COMP_TASK, CDEF_TASK, Picture  # noqa: F401  (re-exported)
+from ._lib import ITX_TASK, MC_TASK, COMP_TASK, CDEF_TASK, LF_TASK, Picture  # noqa: F401  (re-exported)
 
 LAYOUT_I400, LAYOUT_I420, LAYOUT_I422, LAYOUT_I444 = 0, 1, 2, 3
 
@@ -178,6 +178,14 @@ class Context:
         t = np.ascontiguousarray(tasks, dtype=CDEF_TASK)
         _chk(self.lib.dav1d_hip_cdef_batch(self.h, C.byref(dst.pic), C.byref(src.pic), t.ctypes.data, len(t), damping,
                                            dirvar.ptr if dirvar else None), "cdef_batch")
+
+    def lf_batch(self, dst, tasks, lvl, b4_stride, lut_e, lut_i):
+        t = np.ascontiguousarray(tasks, dtype=LF_TASK)
+        e = np.ascontiguousarray(lut_e, dtype=np.uint8)
+        i = np.ascontiguousarray(lut_i, dtype=np.uint8)
+        assert len(e) == 64 and len(i) == 64
+        _chk(self.lib.dav1d_hip_lf_batch(self.h, C.byref(dst.pic), t.ctypes.data, len(t), lvl.ptr, b4_stride,
+                                         e.ctypes.data, i.ctypes.data), "lf_batch")
 
     # ---- device-resident lists
     def itx_list(self, tasks):

@@ -621,3 +621,31 @@ extern "C" int dav1d_hip_cdef_batch(Dav1dHipContext *c, const Dav1dHipPicture *d
     hipFree(dev);
     return rc;
 }
+
+// -------------------------------------------------------------- loop filter
+
+extern "C" int dav1d_hip_lf_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipLfTask *tasks, size_t n,
+                                  const uint8_t *lvl, ptrdiff_t b4_stride, const uint8_t lut_e[64], const uint8_t lut_i[64]) {
+    if (!dst || (!tasks && n) || !lvl || !lut_e || !lut_i) return -EINVAL;
+    if (!n) return 0;
+    std::vector<Dav1dHipLfTask> sorted;
+    sorted.reserve(n);
+    size_t n0 = 0;
+    for (int d = 0; d < 2; d++) {
+        for (size_t i = 0; i < n; i++) {
+            if (tasks[i].plane > 2 || tasks[i].dir > 1 || tasks[i].lvl_comp > 3) return -EINVAL;
+            if (tasks[i].dir == d) sorted.push_back(tasks[i]);
+        }
+        if (d == 0) n0 = sorted.size();
+    }
+    Dav1dHipLfTask *dev = nullptr;
+    if (hipMalloc((void **) &dev, n * sizeof(*dev)) != hipSuccess) return -ENOMEM;
+    int rc = dav1d_hip_upload(c, dev, sorted.data(), n * sizeof(*dev));
+    const DevPlanes dp = dev_planes(dst);
+    // pass 1: every vertical edge; pass 2 (same stream, so after pass 1): every horizontal edge
+    if (!rc) rc = dav1d_hip_launch_lf(&dp, dst->bpc, dev, (int) n0, lvl, (int) b4_stride, lut_e, lut_i, c->stream);
+    if (!rc) rc = dav1d_hip_launch_lf(&dp, dst->bpc, dev + n0, (int) (n - n0), lvl, (int) b4_stride, lut_e, lut_i, c->stream);
+    hipStreamSynchronize(c->stream);
+    hipFree(dev);
+    return rc;
+}

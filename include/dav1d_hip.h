@@ -258,6 +258,28 @@ typedef struct Dav1dHipCdefTask {
 DAV1D_HIP_API int dav1d_hip_cdef_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src,
                                        const Dav1dHipCdefTask *tasks, size_t n, int damping, uint32_t *dirvar);
 
+/* --------------------------------------------------------------- loop filter */
+
+/* One call of dsp->lf.loop_filter_sb[plane != 0][dir] as the sbrow drivers issue it
+ * (src/lf_apply_tmpl.c:176-311; kernels src/loopfilter_tmpl.c:37-257): a line of up to 32
+ * edge units (4 pixels each) in one superblock column (dir 0: edges between columns, units
+ * run down) or row (dir 1: edges between rows, units run across). */
+typedef struct Dav1dHipLfTask {
+    uint32_t dst_off;    /* pixel offset of the first unit's first pixel on the q side of the edge */
+    uint32_t lvl_off;    /* index of the first unit's entry in the level array (uint8_t[4] per 4x4, src/internal.h:297) */
+    uint32_t vmask[3];   /* unit u is filtered when bit u is set in any word; width 16 if set in [2] (luma), else 8 (chroma: 6) if set in [1], else 4 */
+    uint8_t  plane;      /* 0..2 */
+    uint8_t  dir;        /* 0: loop_filter_h_* (vertical edge), 1: loop_filter_v_* (horizontal edge) */
+    uint8_t  lvl_comp;   /* which of the 4 level bytes: 0 Y cols, 1 Y rows, 2 U, 3 V */
+    uint8_t  pad;
+} Dav1dHipLfTask;
+
+/* `tasks` HOST array (any order: all dir-0 tasks run, then all dir-1 tasks, which reproduces the
+ * reference's column-then-row order); `lvl` DEVICE level array with row stride `b4_stride` entries;
+ * lut_e / lut_i: the 64-entry E / I limit tables of Av1FilterLUT (src/lf_mask.h:36-40).  In place. */
+DAV1D_HIP_API int dav1d_hip_lf_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipLfTask *tasks, size_t n,
+                                     const uint8_t *lvl, ptrdiff_t b4_stride, const uint8_t lut_e[64], const uint8_t lut_i[64]);
+
 /* ------------------------------------------------- reference-signature table */
 
 /* Function pointer types with the reference's exact signatures (16 bpc flavour

@@ -88,6 +88,7 @@ PROTO = {
     "blend": [_vp, _pd, _vp, _i, _i, _vp],
     "blend_v": [_vp, _pd, _vp, _i, _i],
     "blend_h": [_vp, _pd, _vp, _i, _i],
+    "loop_filter_sb": [_vp, _pd, _vp, _vp, _pd, _vp, _i],
     "cdef_dir": [_vp, _pd, _vp],
     "cdef_fb": [_vp, _pd, _vp, _vp, _vp, _i, _i, _i, _i, _i],
 }
