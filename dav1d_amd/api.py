@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import ITX_TASK, MC_TASK, COMP_TASK, CDEF_TASK, LF_TASK, Picture  # noqa: F401  (re-exported)
+from ._lib import ITX_TASK, MC_TASK, COMP_TASK, CDEF_TASK, LF_TASK, IPRED_TASK, Picture  # noqa: F401  (re-exported)
 
 LAYOUT_I400, LAYOUT_I420, LAYOUT_I422, LAYOUT_I444 = 0, 1, 2, 3
 
@@ -186,6 +186,11 @@ class Context:
         assert len(e) == 64 and len(i) == 64
         _chk(self.lib.dav1d_hip_lf_batch(self.h, C.byref(dst.pic), t.ctypes.data, len(t), lvl.ptr, b4_stride,
                                          e.ctypes.data, i.ctypes.data), "lf_batch")
+
+    def ipred_batch(self, dst, tasks, pal_idx=None):
+        t = np.ascontiguousarray(tasks, dtype=IPRED_TASK)
+        _chk(self.lib.dav1d_hip_ipred_batch(self.h, C.byref(dst.pic), t.ctypes.data, len(t),
+                                            pal_idx.ptr if pal_idx else None), "ipred_batch")
 
     # ---- device-resident lists
     def itx_list(self, tasks):

@@ -102,5 +102,8 @@ extern "C" int dav1d_hip_launch_cdef(const DevPlanes *dst, const DevPlanes *src,
 extern "C" int dav1d_hip_launch_lf(const DevPlanes *dst, int bpc, const Dav1dHipLfTask *tasks, int n, const uint8_t *lvl,
                                    int b4_stride, const uint8_t *lut_e, const uint8_t *lut_i, void *stream);
 
+extern "C" int dav1d_hip_launch_ipred(const DevPlanes *dst, int bpc, int layout, const Dav1dHipIpredTask *tasks, int n,
+                                      const uint8_t *pal_idx, void *stream);
+
 Dav1dHipContext *dav1d_hip_default_context(void);
 int dav1d_hip_scratch(Dav1dHipContext *c, size_t bytes, void **out);

@@ -231,6 +231,38 @@ DAV1D_HIP_API int dav1d_hip_inter_list_run_timed(Dav1dHipContext *c, const Dav1d
                                                  float *ms, size_t *counts);
 DAV1D_HIP_API size_t dav1d_hip_inter_list_fused(const Dav1dHipInterList *l);
 
+/* -------------------------------------------------------------------- ipred */
+
+enum Dav1dHipIpredKind {
+    DAV1D_HIP_IPRED_PRED = 0,  /* dav1d_prepare_intra_edges + dsp->ipred.intra_pred[m]  (src/recon_tmpl.c:1256-1283) */
+    DAV1D_HIP_IPRED_CFL = 1,   /* prepare (DC_PRED) + dsp->ipred.cfl_ac[layout-1] + cfl_pred[m]  (src/recon_tmpl.c:1367-1393) */
+    DAV1D_HIP_IPRED_PAL = 2,   /* dsp->ipred.pal_pred  (src/recon_tmpl.c:1207-1224, 1395-1413) */
+};
+
+/* One intra prediction of one transform block.  Field names follow the arguments of
+ * dav1d_prepare_intra_edges (src/ipred_prepare_tmpl.c:75-88) and of the intra_pred entries
+ * (src/ipred.h:44-47).  Tasks of one batch must be independent: their edge pixels are final. */
+typedef struct Dav1dHipIpredTask {
+    uint32_t dst_off;    /* pixel offset of the block in its plane */
+    uint32_t aux_off;    /* CFL: pixel offset of the co-located luma block in plane 0; PAL: byte offset of the packed indices */
+    uint16_t x4, y4;     /* `x`, `y`: block position in 4-pixel units of the plane */
+    uint16_t w4, h4;     /* `w`, `h`: end of the tile in the same units */
+    uint8_t  tw, th;     /* transform block size in 4-pixel units */
+    uint8_t  mode;       /* enum IntraPredMode of the bitstream (0 DC .. 12 PAETH, src/levels.h:108-122), 13 = FILTER_PRED */
+    int8_t   angle;      /* angle delta (directional), filter index (FILTER_PRED) or alpha (CFL) */
+    uint8_t  flags;      /* 1 have_left, 2 have_top, 4 top has right, 8 left has bottom (edge_flags already selected for the
+                            layout), 16 seq_hdr->intra_edge_filter, 32 ANGLE_SMOOTH_EDGE_FLAG */
+    uint8_t  plane;
+    uint8_t  kind;       /* enum Dav1dHipIpredKind */
+    uint8_t  pad;
+    uint16_t max_w, max_h; /* PRED: max_width / max_height arguments in pixels; CFL: w_pad / h_pad in 4-pixel units */
+    uint16_t pal[8];     /* PAL: the palette */
+} Dav1dHipIpredTask;
+
+/* `tasks` HOST array; `pal_idx` DEVICE byte arena of packed palette indices (may be NULL). */
+DAV1D_HIP_API int dav1d_hip_ipred_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipIpredTask *tasks, size_t n,
+                                        const uint8_t *pal_idx);
+
 /* --------------------------------------------------------------------- cdef */
 
 /* One 8x8 luma unit of CDEF as the reference driver handles it

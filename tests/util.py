@@ -89,11 +89,15 @@ PROTO = {
     "blend_v": [_vp, _pd, _vp, _i, _i],
     "blend_h": [_vp, _pd, _vp, _i, _i],
     "loop_filter_sb": [_vp, _pd, _vp, _vp, _pd, _vp, _i],
+    "intra_pred": [_vp, _pd, _vp, _i, _i, _i, _i, _i],
+    "cfl_ac": [_vp, _vp, _pd, _i, _i, _i, _i],
+    "cfl_pred": [_vp, _pd, _vp, _i, _i, _vp, _i],
+    "pal_pred": [_vp, _pd, _vp, _vp, _i, _i],
     "cdef_dir": [_vp, _pd, _vp],
     "cdef_fb": [_vp, _pd, _vp, _vp, _vp, _i, _i, _i, _i, _i],
 }
 RET_INT = {"cdef_dir"}
-NO_HBD_SUFFIX = {"blend", "blend_v", "blend_h", "emu_edge"}
+NO_HBD_SUFFIX = {"blend", "blend_v", "blend_h", "emu_edge", "cfl_ac", "pal_pred"}
 
 
 class Oracle:
