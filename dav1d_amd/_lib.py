@@ -40,6 +40,9 @@ IPRED_TASK = np.dtype([("dst_off", "<u4"), ("aux_off", "<u4"), ("x4", "<u2"), ("
                        ("tw", "u1"), ("th", "u1"), ("mode", "u1"), ("angle", "i1"), ("flags", "u1"), ("plane", "u1"),
                        ("kind", "u1"), ("pad", "u1"), ("max_w", "<u2"), ("max_h", "<u2"), ("pal", "<u2", (8,))], align=False)
 assert IPRED_TASK.itemsize == 44
+LR_TASK = np.dtype([("x", "<u2"), ("y", "<u2"), ("w", "<u2"), ("h", "<u2"), ("plane", "u1"), ("edges", "u1"), ("type", "u1"),
+                    ("pad", "u1"), ("filter", "<i2", (2, 8))], align=False)
+assert LR_TASK.itemsize == 44
 assert CDEF_TASK.itemsize == 16
 assert ITX_TASK.itemsize == 16 and MC_TASK.itemsize == 24 and COMP_TASK.itemsize == 24
 
@@ -55,7 +58,7 @@ SYMBOLS = [
     "dav1d_hip_itx_list_run_timed", "dav1d_hip_mc_list_run_timed",
     "dav1d_hip_inter_list_create", "dav1d_hip_inter_list_destroy", "dav1d_hip_inter_list_run",
     "dav1d_hip_inter_list_run_timed", "dav1d_hip_inter_list_fused",
-    "dav1d_hip_cdef_batch", "dav1d_hip_lf_batch", "dav1d_hip_ipred_batch",
+    "dav1d_hip_cdef_batch", "dav1d_hip_lf_batch", "dav1d_hip_ipred_batch", "dav1d_hip_lr_batch",
 ]
 
 
@@ -109,6 +112,7 @@ def load(path=None):
         "dav1d_hip_cdef_batch": (i, [vp, P(Picture), P(Picture), vp, sz, i, vp]),
         "dav1d_hip_lf_batch": (i, [vp, P(Picture), vp, sz, vp, C.c_ssize_t, vp, vp]),
         "dav1d_hip_ipred_batch": (i, [vp, P(Picture), vp, sz, vp]),
+        "dav1d_hip_lr_batch": (i, [vp, P(Picture), P(Picture), P(Picture), vp, sz]),
         "dav1d_hip_dsp_init_8bpc": (i, [vp]),
         "dav1d_hip_dsp_init_16bpc": (i, [vp, i]),
     }

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import ITX_TASK, MC_TASK, COMP_TASK, CDEF_TASK, LF_TASK, IPRED_TASK, Picture  # noqa: F401  (re-exported)
+from ._lib import ITX_TASK, MC_TASK, COMP_TASK, CDEF_TASK, LF_TASK, IPRED_TASK, LR_TASK, Picture  # noqa: F401  (re-exported)
 
 LAYOUT_I400, LAYOUT_I420, LAYOUT_I422, LAYOUT_I444 = 0, 1, 2, 3
 
@@ -191,6 +191,11 @@ class Context:
         t = np.ascontiguousarray(tasks, dtype=IPRED_TASK)
         _chk(self.lib.dav1d_hip_ipred_batch(self.h, C.byref(dst.pic), t.ctypes.data, len(t),
                                             pal_idx.ptr if pal_idx else None), "ipred_batch")
+
+    def lr_batch(self, dst, src, lpf, tasks):
+        t = np.ascontiguousarray(tasks, dtype=LR_TASK)
+        _chk(self.lib.dav1d_hip_lr_batch(self.h, C.byref(dst.pic), C.byref(src.pic), C.byref(lpf.pic), t.ctypes.data, len(t)),
+             "lr_batch")
 
     # ---- device-resident lists
     def itx_list(self, tasks):

@@ -105,5 +105,8 @@ extern "C" int dav1d_hip_launch_lf(const DevPlanes *dst, int bpc, const Dav1dHip
 extern "C" int dav1d_hip_launch_ipred(const DevPlanes *dst, int bpc, int layout, const Dav1dHipIpredTask *tasks, int n,
                                       const uint8_t *pal_idx, void *stream);
 
+extern "C" int dav1d_hip_launch_wiener(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
+                                       const Dav1dHipLrTask *tasks, int n, void *stream);
+
 Dav1dHipContext *dav1d_hip_default_context(void);
 int dav1d_hip_scratch(Dav1dHipContext *c, size_t bytes, void **out);

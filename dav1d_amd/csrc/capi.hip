@@ -671,3 +671,24 @@ extern "C" int dav1d_hip_ipred_batch(Dav1dHipContext *c, const Dav1dHipPicture *
     hipFree(dev);
     return rc;
 }
+
+// --------------------------------------------------------- loop restoration
+
+extern "C" int dav1d_hip_lr_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src,
+                                  const Dav1dHipPicture *lpf, const Dav1dHipLrTask *tasks, size_t n) {
+    if (!dst || !src || !lpf || (!tasks && n) || dst->bpc != src->bpc || lpf->bpc != src->bpc) return -EINVAL;
+    if (!n) return 0;
+    for (size_t i = 0; i < n; i++) {
+        const Dav1dHipLrTask &t = tasks[i];
+        if (t.plane > 2 || t.edges > 15 || !t.w || t.w > 384 || !t.h || t.h > 64) return -EINVAL;
+        if (t.type > DAV1D_HIP_LR_WIENER5) return -ENOSYS;      // self-guided filters: not provided yet
+    }
+    Dav1dHipLrTask *dev = nullptr;
+    if (hipMalloc((void **) &dev, n * sizeof(*dev)) != hipSuccess) return -ENOMEM;
+    int rc = dav1d_hip_upload(c, dev, tasks, n * sizeof(*dev));
+    const DevPlanes dp = dev_planes(dst), sp = dev_planes(src), lp = dev_planes(lpf);
+    if (!rc) rc = dav1d_hip_launch_wiener(&dp, &sp, &lp, dst->bpc, dev, (int) n, c->stream);
+    hipStreamSynchronize(c->stream);
+    hipFree(dev);
+    return rc;
+}

@@ -312,6 +312,30 @@ typedef struct Dav1dHipLfTask {
 DAV1D_HIP_API int dav1d_hip_lf_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipLfTask *tasks, size_t n,
                                      const uint8_t *lvl, ptrdiff_t b4_stride, const uint8_t lut_e[64], const uint8_t lut_i[64]);
 
+/* --------------------------------------------------------- loop restoration */
+
+enum { DAV1D_HIP_LR_HAVE_LEFT = 1, DAV1D_HIP_LR_HAVE_RIGHT = 2, DAV1D_HIP_LR_HAVE_TOP = 4, DAV1D_HIP_LR_HAVE_BOTTOM = 8 };
+                                                                     /* == enum LrEdgeFlags, src/looprestoration.h:36-41 */
+enum Dav1dHipLrType { DAV1D_HIP_LR_WIENER7 = 0, DAV1D_HIP_LR_WIENER5 = 1 };   /* dsp->lr.wiener[0 / 1] */
+
+/* One call of a looprestorationfilter_fn on one restoration-unit stripe as lr_stripe() issues it
+ * (src/lr_apply_tmpl.c:36-97): w <= 384, h <= 64.  Out of place: `src` = loop-restoration input
+ * (CDEF output), `lpf` = deblocked (pre-CDEF) picture supplying the two rows above / below the
+ * stripe (what the reference saves into lr_lpf_line, src/lf_apply_tmpl.c:41-102), `dst` = output. */
+typedef struct Dav1dHipLrTask {
+    uint16_t x, y;       /* stripe position in pixels of `plane` */
+    uint16_t w, h;
+    uint8_t  plane;
+    uint8_t  edges;      /* DAV1D_HIP_LR_HAVE_* */
+    uint8_t  type;       /* enum Dav1dHipLrType */
+    uint8_t  pad;
+    int16_t  filter[2][8]; /* LooprestorationParams.filter as built by lr_stripe (:55-71): [0] horizontal, [1] vertical */
+} Dav1dHipLrTask;
+
+/* `tasks` HOST array. */
+DAV1D_HIP_API int dav1d_hip_lr_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src,
+                                     const Dav1dHipPicture *lpf, const Dav1dHipLrTask *tasks, size_t n);
+
 /* ------------------------------------------------- reference-signature table */
 
 /* Function pointer types with the reference's exact signatures (16 bpc flavour

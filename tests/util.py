@@ -93,6 +93,8 @@ PROTO = {
     "cfl_ac": [_vp, _vp, _pd, _i, _i, _i, _i],
     "cfl_pred": [_vp, _pd, _vp, _i, _i, _vp, _i],
     "pal_pred": [_vp, _pd, _vp, _vp, _i, _i],
+    "wiener": [_vp, _pd, _vp, _vp, _i, _i, _vp, _i],
+    "sgr": [_vp, _pd, _vp, _vp, _i, _i, _vp, _i],
     "cdef_dir": [_vp, _pd, _vp],
     "cdef_fb": [_vp, _pd, _vp, _vp, _vp, _i, _i, _i, _i, _i],
 }
