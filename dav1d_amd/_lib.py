@@ -59,7 +59,17 @@ SYMBOLS = [
     "dav1d_hip_inter_list_create", "dav1d_hip_inter_list_destroy", "dav1d_hip_inter_list_run",
     "dav1d_hip_inter_list_run_timed", "dav1d_hip_inter_list_fused",
     "dav1d_hip_cdef_batch", "dav1d_hip_lf_batch", "dav1d_hip_ipred_batch", "dav1d_hip_lr_batch",
+    "dav1d_hip_fg_apply", "dav1d_hip_fg_generate_grain",
 ]
+
+
+class FilmGrainData(C.Structure):      # == Dav1dFilmGrainData, reference include/dav1d/headers.h:315-333
+    _fields_ = [("seed", C.c_uint), ("num_y_points", C.c_int), ("y_points", (C.c_uint8 * 2) * 14),
+                ("chroma_scaling_from_luma", C.c_int), ("num_uv_points", C.c_int * 2), ("uv_points", ((C.c_uint8 * 2) * 10) * 2),
+                ("scaling_shift", C.c_int), ("ar_coeff_lag", C.c_int), ("ar_coeffs_y", C.c_int8 * 24),
+                ("ar_coeffs_uv", (C.c_int8 * 28) * 2), ("ar_coeff_shift", C.c_uint64), ("grain_scale_shift", C.c_int),
+                ("uv_mult", C.c_int * 2), ("uv_luma_mult", C.c_int * 2), ("uv_offset", C.c_int * 2),
+                ("overlap_flag", C.c_int), ("clip_to_restricted_range", C.c_int)]
 
 
 class LibraryError(RuntimeError):
@@ -113,6 +123,8 @@ def load(path=None):
         "dav1d_hip_lf_batch": (i, [vp, P(Picture), vp, sz, vp, C.c_ssize_t, vp, vp]),
         "dav1d_hip_ipred_batch": (i, [vp, P(Picture), vp, sz, vp]),
         "dav1d_hip_lr_batch": (i, [vp, P(Picture), P(Picture), P(Picture), vp, sz]),
+        "dav1d_hip_fg_apply": (i, [vp, P(Picture), P(Picture), P(FilmGrainData), i]),
+        "dav1d_hip_fg_generate_grain": (i, [vp, P(FilmGrainData), i, i, vp]),
         "dav1d_hip_dsp_init_8bpc": (i, [vp]),
         "dav1d_hip_dsp_init_16bpc": (i, [vp, i]),
     }

@@ -8,6 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from ._lib import FilmGrainData  # noqa: F401
 from ._lib import ITX_TASK, MC_TASK, COMP_TASK, CDEF_TASK, LF_TASK, IPRED_TASK, LR_TASK, Picture  # noqa: F401  (re-exported)
 
 LAYOUT_I400, LAYOUT_I420, LAYOUT_I422, LAYOUT_I444 = 0, 1, 2, 3
@@ -196,6 +197,14 @@ class Context:
         t = np.ascontiguousarray(tasks, dtype=LR_TASK)
         _chk(self.lib.dav1d_hip_lr_batch(self.h, C.byref(dst.pic), C.byref(src.pic), C.byref(lpf.pic), t.ctypes.data, len(t)),
              "lr_batch")
+
+    def fg_apply(self, dst, src, data, is_id=0):
+        _chk(self.lib.dav1d_hip_fg_apply(self.h, C.byref(dst.pic), C.byref(src.pic), C.byref(data), is_id), "fg_apply")
+
+    def fg_generate_grain(self, data, bpc, layout):
+        out = np.zeros((3, 74, 82), np.int16)
+        _chk(self.lib.dav1d_hip_fg_generate_grain(self.h, C.byref(data), bpc, layout, out.ctypes.data), "fg_generate_grain")
+        return out
 
     # ---- device-resident lists
     def itx_list(self, tasks):

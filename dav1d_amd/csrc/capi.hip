@@ -692,3 +692,75 @@ extern "C" int dav1d_hip_lr_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst
     hipFree(dev);
     return rc;
 }
+
+// --------------------------------------------------------------- film grain
+
+// generate_scaling, reference src/fg_apply_tmpl.c:41-95 (piecewise-linear LUT over the scaling points;
+// high bit depth interpolates between the 8-bit grid points)
+static void fg_generate_scaling(const int bitdepth, const uint8_t points[][2], const int num, uint8_t *scaling) {
+    const int shift_x = bitdepth - 8, scaling_size = 1 << bitdepth;
+    if (num == 0) { memset(scaling, 0, scaling_size); return; }
+    memset(scaling, points[0][1], (size_t) points[0][0] << shift_x);
+    for (int i = 0; i < num - 1; i++) {
+        const int bx = points[i][0], by = points[i][1], ex = points[i + 1][0], ey = points[i + 1][1];
+        const int dx = ex - bx, dy = ey - by;
+        const int delta = dy * ((0x10000 + (dx >> 1)) / dx);
+        for (int x = 0, d = 0x8000; x < dx; x++) { scaling[(bx + x) << shift_x] = (uint8_t) (by + (d >> 16)); d += delta; }
+    }
+    const int n = points[num - 1][0] << shift_x;
+    memset(&scaling[n], points[num - 1][1], scaling_size - n);
+    if (shift_x) {
+        const int pad = 1 << shift_x, rnd = pad >> 1;
+        for (int i = 0; i < num - 1; i++) {
+            const int bx = points[i][0] << shift_x, ex = points[i + 1][0] << shift_x, dx = ex - bx;
+            for (int x = 0; x < dx; x += pad) {
+                const int range = scaling[bx + x + pad] - scaling[bx + x];
+                for (int k = 1, r = rnd; k < pad; k++) { r += range; scaling[bx + x + k] = (uint8_t) (scaling[bx + x] + (r >> shift_x)); }
+            }
+        }
+    }
+}
+
+extern "C" int dav1d_hip_fg_generate_grain(Dav1dHipContext *c, const Dav1dHipFilmGrainData *data, int bpc, int layout, int16_t *host_lut) {
+    if (!data || !host_lut || (bpc != 8 && bpc != 10 && bpc != 12)) return -EINVAL;
+    const size_t bytes = 3 * 74 * 82 * sizeof(int16_t);
+    int16_t *dev = nullptr;
+    if (hipMalloc((void **) &dev, bytes) != hipSuccess) return -ENOMEM;
+    hipMemsetAsync(dev, 0, bytes, c->stream);
+    int rc = dav1d_hip_launch_fg_gen(dev, data, bpc, layout, c->stream);
+    if (!rc) rc = dav1d_hip_download(c, host_lut, dev, bytes);
+    hipFree(dev);
+    return rc;
+}
+
+extern "C" int dav1d_hip_fg_apply(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src,
+                                  const Dav1dHipFilmGrainData *data, int is_id) {
+    if (!dst || !src || !data || dst->bpc != src->bpc || dst->layout != src->layout) return -EINVAL;
+    const int bpc = src->bpc, scaling_size = 1 << bpc;
+    const size_t lut_bytes = 3 * 74 * 82 * sizeof(int16_t);
+    uint8_t *dev = nullptr;
+    if (hipMalloc((void **) &dev, lut_bytes + 3 * (size_t) scaling_size) != hipSuccess) return -ENOMEM;
+    std::vector<uint8_t> sc(3 * (size_t) scaling_size, 0);
+    if (data->num_y_points || data->chroma_scaling_from_luma) fg_generate_scaling(bpc, data->y_points, data->num_y_points, &sc[0]);
+    for (int i = 0; i < 2; i++)
+        if (data->num_uv_points[i]) fg_generate_scaling(bpc, data->uv_points[i], data->num_uv_points[i], &sc[(size_t) (1 + i) * scaling_size]);
+    hipMemsetAsync(dev, 0, lut_bytes, c->stream);
+    int rc = dav1d_hip_upload(c, dev + lut_bytes, sc.data(), sc.size());
+    if (!rc) rc = dav1d_hip_launch_fg_gen((int16_t *) dev, data, bpc, src->layout, c->stream);
+    // planes that get no grain are copied (dav1d_prep_grain, src/fg_apply_tmpl.c:127-163)
+    const int ss_ver = src->layout == DAV1D_HIP_LAYOUT_I420;
+    for (int pl = 0; pl < 3 && !rc; pl++) {
+        if (pl && src->layout == DAV1D_HIP_LAYOUT_I400) break;
+        const bool grain = pl ? (data->num_uv_points[pl - 1] || data->chroma_scaling_from_luma) : data->num_y_points != 0;
+        if (grain) continue;
+        const int rows = pl ? (src->p[0].h + ss_ver) >> ss_ver : src->p[0].h;
+        const size_t rb = (size_t) src->p[pl].w * (bpc > 8 ? 2 : 1);
+        rc = hip_rc(hipMemcpy2DAsync(dst->p[pl].data, dst->p[pl].stride, src->p[pl].data, src->p[pl].stride, rb, rows,
+                                     hipMemcpyDeviceToDevice, c->stream));
+    }
+    const DevPlanes dp = dev_planes(dst), sp = dev_planes(src);
+    if (!rc) rc = dav1d_hip_launch_fg_apply(&dp, &sp, (const int16_t *) dev, dev + lut_bytes, scaling_size, data, bpc, src->layout, is_id, c->stream);
+    hipStreamSynchronize(c->stream);
+    hipFree(dev);
+    return rc;
+}

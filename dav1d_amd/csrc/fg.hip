@@ -1,0 +1,259 @@
+// Film grain synthesis for gfx950.
+//
+// Contract = the reference's dav1d_apply_grain (src/fg_apply_tmpl.c:97-241) over its DSP
+// entries: generate_grain_y / generate_grain_uv (src/filmgrain_tmpl.c:50-154) build the
+// 73x82 (chroma: 38x44 when subsampled) grain templates, fgy_32x32xn / fguv_32x32xn
+// (:169-413) add scaled grain per 32x32 block with the 2-pixel overlap blends.
+//
+// Grain templates (one workgroup, one wave per plane): the 16-bit LFSR is linear, so the
+// state at the start of every template row is obtained by applying the "advance one row"
+// GF(2) matrix (built by stepping the 16 basis states) row after row; rows then draw their
+// Gaussian samples in parallel.  The auto-regressive filter runs as a wavefront: lane = row,
+// each row trails the row above by lag + 1 samples.
+// Application: one wave per 32x32 luma block (and its chroma blocks); the per-block random
+// offsets are the k-th outputs of the per-row LFSR, recomputed by every wave (<= 241 steps).
+#include "common.h"
+#include "capi.h"
+#include "av1_tables.h"
+#include <string.h>
+
+namespace {
+
+enum { GW = 82, GH = 73, SGW = 44, SGH = 38 };
+
+__device__ __forceinline__ unsigned lfsr_step(const unsigned r) {
+    const unsigned bit = ((r >> 0) ^ (r >> 1) ^ (r >> 3) ^ (r >> 12)) & 1;
+    return (r >> 1) | (bit << 15);
+}
+__device__ __forceinline__ int round2(const int x, const int shift) { return (x + ((1 << shift) >> 1)) >> shift; }
+
+struct FgParams {                 // the scalar part of Dav1dFilmGrainData the kernels need
+    unsigned seed;
+    int num_y_points, chroma_scaling_from_luma, num_uv_points[2];
+    int scaling_shift, ar_coeff_lag, ar_coeff_shift, grain_scale_shift;
+    int uv_mult[2], uv_luma_mult[2], uv_offset[2];
+    int overlap_flag, clip_to_restricted_range;
+    int8_t ar_coeffs_y[24];
+    int8_t ar_coeffs_uv[2][28];
+};
+
+// one wave builds template `pl` (0 luma, 1/2 chroma) in `lut` (int16 [74][82])
+__device__ void gen_template(int16_t *lut, const int16_t *lut_y, const FgParams &p, const int pl, const int subx, const int suby,
+                             const int bitdepth_min_8, uint16_t *cols, uint16_t *rowstart, const int lane)
+{
+    const int W = (pl && subx) ? SGW : GW, H = (pl && suby) ? SGH : GH;
+    const int shift = 4 - bitdepth_min_8 + p.grain_scale_shift;
+    const int grain_ctr = 128 << bitdepth_min_8, grain_min = -grain_ctr, grain_max = grain_ctr - 1;
+    unsigned seed = p.seed;
+    if (pl) seed ^= pl == 2 ? 0x49d8 : 0xb524;
+    // ---- "advance W steps" matrix, columns = images of the basis states
+    if (lane < 16) {
+        unsigned s = 1u << lane;
+        for (int i = 0; i < W; i++) s = lfsr_step(s);
+        cols[lane] = (uint16_t) s;
+    }
+    dv::wave_sync();
+    if (lane == 0) {
+        unsigned s = seed;
+        for (int y = 0; y < H; y++) {
+            rowstart[y] = (uint16_t) s;
+            unsigned n = 0;
+            for (int b = 0; b < 16; b++) if (s & (1u << b)) n ^= cols[b];
+            s = n;
+        }
+    }
+    dv::wave_sync();
+    for (int y = lane; y < H; y += 64) {
+        unsigned s = rowstart[y];
+        for (int x = 0; x < W; x++) {
+            s = lfsr_step(s);
+            lut[y * GW + x] = (int16_t) round2(av1_gaussian_sequence[(s >> 5) & 2047], shift);
+        }
+    }
+    dv::wave_sync();
+    // ---- auto-regressive filter as a wavefront over rows (src/filmgrain_tmpl.c:72-91, 123-153)
+    const int lag = p.ar_coeff_lag, pad = 3;
+    const int8_t *coef = pl ? p.ar_coeffs_uv[pl - 1] : p.ar_coeffs_y;
+    for (int y0 = pad; y0 < H; y0 += 64) {
+        const int rows = dv::imin(64, H - y0);
+        const int y = y0 + lane;
+        const int steps = (W - 2 * pad) + (rows - 1) * (lag + 1);
+        for (int s = 0; s < steps; s++) {
+            const int x = pad + s - lane * (lag + 1);
+            if (lane < rows && x >= pad && x < W - pad) {
+                int sum = 0, k = 0;
+                for (int dy = -lag; dy <= 0; dy++)
+                    for (int dx = -lag; dx <= lag; dx++) {
+                        if (!dx && !dy) break;
+                        sum += coef[k++] * lut[(y + dy) * GW + x + dx];
+                    }
+                if (pl && p.num_y_points) {
+                    int luma = 0;
+                    const int lx = ((x - pad) << subx) + pad, ly = ((y - pad) << suby) + pad;
+                    for (int i = 0; i <= suby; i++)
+                        for (int j = 0; j <= subx; j++) luma += lut_y[(ly + i) * GW + lx + j];
+                    sum += round2(luma, subx + suby) * coef[k];
+                }
+                lut[y * GW + x] = (int16_t) dv::iclip(lut[y * GW + x] + round2(sum, p.ar_coeff_shift), grain_min, grain_max);
+            }
+            dv::wave_sync();
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void fg_gen_kernel(int16_t *luts, const FgParams p, const int layout, const int bitdepth_min_8)
+{
+    __shared__ uint16_t cols[16], rowstart[GH];
+    __shared__ int16_t t_y[(GH + 1) * GW], t_c[(GH + 1) * GW];     // templates are built in LDS, then copied out
+    const int lane = threadIdx.x;
+    const int subx = layout != DAV1D_HIP_LAYOUT_I444, suby = layout == DAV1D_HIP_LAYOUT_I420;
+    for (int i = lane; i < (GH + 1) * GW; i += 64) t_y[i] = t_c[i] = 0;
+    dv::wave_sync();
+    gen_template(t_y, t_y, p, 0, subx, suby, bitdepth_min_8, cols, rowstart, lane);
+    dv::wave_sync();
+    for (int i = lane; i < (GH + 1) * GW; i += 64) luts[i] = t_y[i];
+    for (int pl = 1; pl <= 2; pl++) {
+        dv::wave_sync();
+        if (layout != DAV1D_HIP_LAYOUT_I400 && (p.num_uv_points[pl - 1] || p.chroma_scaling_from_luma)) {
+            gen_template(t_c, t_y, p, pl, subx, suby, bitdepth_min_8, cols, rowstart, lane);
+            dv::wave_sync();
+            for (int i = lane; i < (GH + 1) * GW; i += 64) luts[pl * (GH + 1) * GW + i] = t_c[i];
+        }
+    }
+}
+
+// sample_lut, src/filmgrain_tmpl.c:156-167
+__device__ __forceinline__ int sample_lut(const int16_t *lut, const int randval, const int subx, const int suby,
+                                          const int bx, const int by, const int x, const int y)
+{
+    const int offx = 3 + (2 >> subx) * (3 + (randval >> 4));
+    const int offy = 3 + (2 >> suby) * (3 + (randval & 0xF));
+    return lut[(offy + y + (32 >> suby) * by) * GW + offx + x + (32 >> subx) * bx];
+}
+
+template <typename pixel>
+__global__ __launch_bounds__(64) void fg_apply_kernel(const DevPlanes dst, const DevPlanes src, const int16_t *__restrict__ luts,
+                                                      const uint8_t *__restrict__ scaling, const int scaling_size, const FgParams p,
+                                                      const int layout, const int is_id, const int bitdepth_max)
+{
+    const int bxi = blockIdx.x, row_num = blockIdx.y, pl = blockIdx.z;
+    const int lane = threadIdx.x;
+    const int bitdepth_min_8 = (32 - __clz(bitdepth_max)) - 8;
+    const int grain_ctr = 128 << bitdepth_min_8, grain_min = -grain_ctr, grain_max = grain_ctr - 1;
+    const int sx = pl && layout != DAV1D_HIP_LAYOUT_I444, sy = pl && layout == DAV1D_HIP_LAYOUT_I420;
+    if (pl == 0 && !p.num_y_points) return;
+    if (pl && !(p.num_uv_points[pl - 1] || p.chroma_scaling_from_luma)) return;
+    const int uv = pl - 1;
+
+    int min_value = 0, max_value = bitdepth_max;
+    if (p.clip_to_restricted_range) {
+        min_value = 16 << bitdepth_min_8;
+        max_value = ((pl && !is_id) ? 240 : 235) << bitdepth_min_8;
+    }
+    // plane geometry
+    const int pw = pl ? (src.w[0] + sx) >> sx : src.w[0];          // cpw / out->p.w
+    const int ph_luma = src.h[0];
+    const int bh = pl ? (dv::imin(ph_luma - row_num * 32, 32) + sy) >> sy : dv::imin(ph_luma - row_num * 32, 32);
+    const int bstep = 32 >> sx;
+    const int bx = bxi * bstep;
+    if (bx >= pw || bh <= 0) return;
+    const int bw = dv::imin(bstep, pw - bx);
+
+    // per-block random offsets: k-th output of the row LFSRs (src/filmgrain_tmpl.c:192-214)
+    const int rows = 1 + (p.overlap_flag && row_num > 0);
+    int off[2][2] = { { 0, 0 }, { 0, 0 } };      // [col: 0 = this block, 1 = left block][row: 0 = this row, 1 = row above]
+    for (int i = 0; i < rows; i++) {
+        unsigned s = p.seed;
+        s ^= (((row_num - i) * 37 + 178) & 0xFF) << 8;
+        s ^= (((row_num - i) * 173 + 105) & 0xFF);
+        for (int k = 0; k <= bxi; k++) {
+            off[1][i] = off[0][i];
+            s = lfsr_step(s);
+            off[0][i] = (s >> 8) & 0xFF;
+        }
+    }
+    const int ystart = (p.overlap_flag && row_num) ? dv::imin(2 >> sy, bh) : 0;
+    const int xstart = (p.overlap_flag && bxi) ? dv::imin(2 >> sx, bw) : 0;
+    // overlap weights: full resolution {27,17},{17,27}; subsampled {23,22}
+    const int16_t *lut = luts + pl * (GH + 1) * GW;
+    const uint8_t *sc = scaling + (size_t) ((pl && !p.chroma_scaling_from_luma) ? pl : 0) * scaling_size;
+
+    const pixel *const sp = reinterpret_cast<const pixel *>(src.data[pl]);
+    pixel *const dp = reinterpret_cast<pixel *>(dst.data[pl]);
+    const pixel *const lp = reinterpret_cast<const pixel *>(src.data[0]);
+    const int y0 = pl ? (row_num * 32) >> sy : row_num * 32;
+
+    for (int i = lane; i < bw * bh; i += 64) {
+        const int y = i / bw, x = i % bw;
+        int grain = sample_lut(lut, off[0][0], sx, sy, 0, 0, x, y);
+        const int wxa = sx ? 23 : (x == 0 ? 27 : 17), wxb = sx ? 22 : (x == 0 ? 17 : 27);
+        const int wya = sy ? 23 : (y == 0 ? 27 : 17), wyb = sy ? 22 : (y == 0 ? 17 : 27);
+        if (x < xstart) {
+            const int old = sample_lut(lut, off[1][0], sx, sy, 1, 0, x, y);
+            grain = dv::iclip(round2(old * wxa + grain * wxb, 5), grain_min, grain_max);
+        }
+        if (y < ystart) {
+            int top = sample_lut(lut, off[0][1], sx, sy, 0, 1, x, y);
+            if (x < xstart) {
+                const int old = sample_lut(lut, off[1][1], sx, sy, 1, 1, x, y);
+                top = dv::iclip(round2(old * wxa + top * wxb, 5), grain_min, grain_max);
+            }
+            grain = dv::iclip(round2(top * wya + grain * wyb, 5), grain_min, grain_max);
+        }
+        const int s0 = sp[(y0 + y) * src.stride[pl] + bx + x];
+        int val;
+        if (pl == 0) {
+            val = s0;
+        } else {
+            // luma co-located average; the reference extends the luma row by one pixel for odd widths
+            // (src/fg_apply_tmpl.c:193-199)
+            const int lx = (bx + x) << sx, ly = (row_num * 32) + (y << sy);
+            const pixel *lrow = lp + ly * src.stride[0];
+            int avg = lrow[dv::imin(lx, src.w[0] - 1)];
+            if (sx) avg = (avg + lrow[dv::imin(lx + 1, src.w[0] - 1)] + 1) >> 1;
+            val = avg;
+            if (!p.chroma_scaling_from_luma) {
+                const int combined = avg * p.uv_luma_mult[uv] + s0 * p.uv_mult[uv];
+                val = dv::iclip((combined >> 6) + (p.uv_offset[uv] * (1 << bitdepth_min_8)), 0, bitdepth_max);
+            }
+        }
+        const int noise = round2(sc[val] * grain, p.scaling_shift);
+        dp[(y0 + y) * dst.stride[pl] + bx + x] = (pixel) dv::iclip(s0 + noise, min_value, max_value);
+    }
+}
+
+FgParams make_params(const Dav1dHipFilmGrainData *d) {
+    FgParams p;
+    memset(&p, 0, sizeof(p));
+    p.seed = d->seed; p.num_y_points = d->num_y_points; p.chroma_scaling_from_luma = d->chroma_scaling_from_luma;
+    p.scaling_shift = d->scaling_shift; p.ar_coeff_lag = d->ar_coeff_lag; p.ar_coeff_shift = (int) d->ar_coeff_shift;
+    p.grain_scale_shift = d->grain_scale_shift; p.overlap_flag = d->overlap_flag; p.clip_to_restricted_range = d->clip_to_restricted_range;
+    for (int i = 0; i < 2; i++) {
+        p.num_uv_points[i] = d->num_uv_points[i];
+        p.uv_mult[i] = d->uv_mult[i]; p.uv_luma_mult[i] = d->uv_luma_mult[i]; p.uv_offset[i] = d->uv_offset[i];
+        memcpy(p.ar_coeffs_uv[i], d->ar_coeffs_uv[i], 28);
+    }
+    memcpy(p.ar_coeffs_y, d->ar_coeffs_y, 24);
+    return p;
+}
+
+} // namespace
+
+extern "C" int dav1d_hip_launch_fg_gen(int16_t *luts, const Dav1dHipFilmGrainData *data, int bpc, int layout, void *stream)
+{
+    hipLaunchKernelGGL(fg_gen_kernel, dim3(1), dim3(64), 0, (hipStream_t) stream, luts, make_params(data), layout, bpc - 8);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int dav1d_hip_launch_fg_apply(const DevPlanes *dst, const DevPlanes *src, const int16_t *luts, const uint8_t *scaling,
+                                         int scaling_size, const Dav1dHipFilmGrainData *data, int bpc, int layout, int is_id, void *stream)
+{
+    const int bitdepth_max = (1 << bpc) - 1;
+    const dim3 grid((src->w[0] + 31) / 32, (src->h[0] + 31) / 32, layout == DAV1D_HIP_LAYOUT_I400 ? 1 : 3);
+    const FgParams p = make_params(data);
+    if (bpc == 8)
+        hipLaunchKernelGGL((fg_apply_kernel<uint8_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max);
+    else
+        hipLaunchKernelGGL((fg_apply_kernel<uint16_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max);
+    return hip_rc(hipGetLastError());
+}

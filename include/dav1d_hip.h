@@ -336,6 +336,40 @@ typedef struct Dav1dHipLrTask {
 DAV1D_HIP_API int dav1d_hip_lr_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src,
                                      const Dav1dHipPicture *lpf, const Dav1dHipLrTask *tasks, size_t n);
 
+/* --------------------------------------------------------------- film grain */
+
+/* Same members, order and types as Dav1dFilmGrainData (include/dav1d/headers.h:315-333), so a
+ * pointer to frame_hdr->film_grain.data can be passed as is. */
+typedef struct Dav1dHipFilmGrainData {
+    unsigned seed;
+    int num_y_points;
+    uint8_t y_points[14][2];
+    int chroma_scaling_from_luma;
+    int num_uv_points[2];
+    uint8_t uv_points[2][10][2];
+    int scaling_shift;
+    int ar_coeff_lag;
+    int8_t ar_coeffs_y[24];
+    int8_t ar_coeffs_uv[2][25 + 3];
+    uint64_t ar_coeff_shift;
+    int grain_scale_shift;
+    int uv_mult[2];
+    int uv_luma_mult[2];
+    int uv_offset[2];
+    int overlap_flag;
+    int clip_to_restricted_range;
+} Dav1dHipFilmGrainData;
+
+/* dav1d_apply_grain (src/fg_apply_tmpl.c:97-241; called from src/lib.c:485-524) on the device:
+ * grain templates (fg.generate_grain_y / _uv), scaling LUTs (generate_scaling), then
+ * fg.fgy_32x32xn / fg.fguv_32x32xn over every 32x32 block of `src` into `dst`; planes without grain
+ * are copied.  `is_id` = seq_hdr->mtrx == DAV1D_MC_IDENTITY. */
+DAV1D_HIP_API int dav1d_hip_fg_apply(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src,
+                                     const Dav1dHipFilmGrainData *data, int is_id);
+/* The grain templates alone (parity aid): host_lut receives grain_lut[3][73 + 1][82] as int16_t. */
+DAV1D_HIP_API int dav1d_hip_fg_generate_grain(Dav1dHipContext *c, const Dav1dHipFilmGrainData *data, int bpc, int layout,
+                                              int16_t *host_lut);
+
 /* ------------------------------------------------- reference-signature table */
 
 /* Function pointer types with the reference's exact signatures (16 bpc flavour

@@ -112,3 +112,53 @@ const uint8_t *dav1d_ref_last_nonzero_col_from_eob(const int tx) {
     dav1d_init_last_nonzero_col_from_eob_tables();
     return dav1d_last_nonzero_col_from_eob[tx];
 }
+
+/* ---- film grain: the reference's whole dav1d_apply_grain on caller-provided planes ---- */
+#include "src/fg_apply.h"
+int dav1d_ref_apply_grain(const int bpc, const Dav1dFilmGrainData *const data, const int w, const int h,
+                          const int layout, const int is_id, void *const out_data[3], void *const in_data[3],
+                          const ptrdiff_t y_stride, const ptrdiff_t uv_stride)
+{
+    Dav1dPicture in, out;
+    Dav1dSequenceHeader seq;
+    Dav1dFrameHeader fh;
+    memset(&in, 0, sizeof(in)); memset(&out, 0, sizeof(out)); memset(&seq, 0, sizeof(seq)); memset(&fh, 0, sizeof(fh));
+    seq.mtrx = is_id ? DAV1D_MC_IDENTITY : DAV1D_MC_BT709;
+    fh.film_grain.data = *data;
+    in.p.w = out.p.w = w; in.p.h = out.p.h = h;
+    in.p.layout = out.p.layout = layout; in.p.bpc = out.p.bpc = bpc;
+    in.seq_hdr = out.seq_hdr = &seq; in.frame_hdr = out.frame_hdr = &fh;
+    for (int i = 0; i < 3; i++) { in.data[i] = in_data[i]; out.data[i] = out_data[i]; }
+    in.stride[0] = out.stride[0] = y_stride; in.stride[1] = out.stride[1] = uv_stride;
+    if (bpc == 8) dav1d_apply_grain_8bpc(&ctx(8)->fg, &out, &in);
+    else dav1d_apply_grain_16bpc(&ctx(bpc)->fg, &out, &in);
+    return 0;
+}
+
+/* grain templates as int16 [3][73 + 1][82] */
+int dav1d_ref_generate_grain(const int bpc, const Dav1dFilmGrainData *const data, const int layout, int16_t *const out)
+{
+    Dav1dDSPContext *const c = ctx(bpc);
+    memset(out, 0, sizeof(int16_t) * 3 * 74 * 82);
+    if (bpc == 8) {
+        static int8_t lut[3][74][82];
+        memset(lut, 0, sizeof(lut));
+        ((void (*)(int8_t (*)[82], const Dav1dFilmGrainData *)) c->fg.generate_grain_y)(lut[0], data);
+        if (layout)
+            for (int pl = 0; pl < 2; pl++)
+                if (data->num_uv_points[pl] || data->chroma_scaling_from_luma)
+                    ((void (*)(int8_t (*)[82], const int8_t (*)[82], const Dav1dFilmGrainData *, intptr_t))
+                         c->fg.generate_grain_uv[layout - 1])(lut[1 + pl], (const int8_t (*)[82]) lut[0], data, pl);
+        for (int i = 0; i < 3 * 74 * 82; i++) out[i] = ((int8_t *) lut)[i];
+    } else {
+        const int bdmax = (1 << bpc) - 1;
+        int16_t (*lut)[74][82] = (int16_t (*)[74][82]) out;
+        ((void (*)(int16_t (*)[82], const Dav1dFilmGrainData *, int)) c->fg.generate_grain_y)(lut[0], data, bdmax);
+        if (layout)
+            for (int pl = 0; pl < 2; pl++)
+                if (data->num_uv_points[pl] || data->chroma_scaling_from_luma)
+                    ((void (*)(int16_t (*)[82], const int16_t (*)[82], const Dav1dFilmGrainData *, intptr_t, int))
+                         c->fg.generate_grain_uv[layout - 1])(lut[1 + pl], (const int16_t (*)[82]) lut[0], data, pl, bdmax);
+    }
+    return 0;
+}
