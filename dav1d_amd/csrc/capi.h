@@ -112,5 +112,8 @@ extern "C" int dav1d_hip_launch_fg_gen(int16_t *luts, const Dav1dHipFilmGrainDat
 extern "C" int dav1d_hip_launch_fg_apply(const DevPlanes *dst, const DevPlanes *src, const int16_t *luts, const uint8_t *scaling,
                                          int scaling_size, const Dav1dHipFilmGrainData *data, int bpc, int layout, int is_id, void *stream);
 
+extern "C" int dav1d_hip_launch_sgr(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
+                                    const Dav1dHipLrTask *tasks, int n, void *stream);
+
 Dav1dHipContext *dav1d_hip_default_context(void);
 int dav1d_hip_scratch(Dav1dHipContext *c, size_t bytes, void **out);

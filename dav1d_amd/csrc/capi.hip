@@ -681,13 +681,20 @@ extern "C" int dav1d_hip_lr_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst
     for (size_t i = 0; i < n; i++) {
         const Dav1dHipLrTask &t = tasks[i];
         if (t.plane > 2 || t.edges > 15 || !t.w || t.w > 384 || !t.h || t.h > 64) return -EINVAL;
-        if (t.type > DAV1D_HIP_LR_WIENER5) return -ENOSYS;      // self-guided filters: not provided yet
+        if (t.type > DAV1D_HIP_LR_SGR_MIX) return -EINVAL;
     }
+    // Wiener tasks first, self-guided tasks second: one launch each (tasks write disjoint stripes)
+    std::vector<Dav1dHipLrTask> sorted;
+    sorted.reserve(n);
+    for (size_t i = 0; i < n; i++) if (tasks[i].type <= DAV1D_HIP_LR_WIENER5) sorted.push_back(tasks[i]);
+    const size_t nw = sorted.size();
+    for (size_t i = 0; i < n; i++) if (tasks[i].type > DAV1D_HIP_LR_WIENER5) sorted.push_back(tasks[i]);
     Dav1dHipLrTask *dev = nullptr;
     if (hipMalloc((void **) &dev, n * sizeof(*dev)) != hipSuccess) return -ENOMEM;
-    int rc = dav1d_hip_upload(c, dev, tasks, n * sizeof(*dev));
+    int rc = dav1d_hip_upload(c, dev, sorted.data(), n * sizeof(*dev));
     const DevPlanes dp = dev_planes(dst), sp = dev_planes(src), lp = dev_planes(lpf);
-    if (!rc) rc = dav1d_hip_launch_wiener(&dp, &sp, &lp, dst->bpc, dev, (int) n, c->stream);
+    if (!rc) rc = dav1d_hip_launch_wiener(&dp, &sp, &lp, dst->bpc, dev, (int) nw, c->stream);
+    if (!rc) rc = dav1d_hip_launch_sgr(&dp, &sp, &lp, dst->bpc, dev + nw, (int) (n - nw), c->stream);
     hipStreamSynchronize(c->stream);
     hipFree(dev);
     return rc;

@@ -1,4 +1,4 @@
-// Batched loop restoration for gfx950 (Wiener).
+// Batched loop restoration for gfx950 (Wiener + self-guided).
 //
 // Contract per task = one call of dsp->lr.wiener[*] (wiener_c, reference
 // src/looprestoration_tmpl.c:44-387) on one restoration-unit stripe (w <= 384, h <= 64) with the
@@ -13,6 +13,7 @@
 // pixels) and keeps the last 7 results in registers for the vertical filter.
 #include "common.h"
 #include "capi.h"
+#include "av1_tables.h"
 
 namespace {
 
@@ -90,6 +91,134 @@ __global__ __launch_bounds__(64) void wiener_kernel(const DevPlanes dst, const D
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Self-guided restoration (sgr_5x5_c / sgr_3x3_c / sgr_mix_c, reference
+// src/looprestoration_tmpl.c:389-1363).  The reference streams rows through rotating pointer sets;
+// what it computes is: box sums (3x3 and / or 5x5) over a virtual image V whose rows < 0 / >= h come
+// from the two lpf rows (one more replica for 5x5) or replicate the stripe's first / last row, the
+// (A, B) surfaces of sgr_calc_row_ab on columns -1 .. w (5x5: odd rows only), and the 4/3- resp.
+// 6/5-weighted neighbourhoods of sgr_finish_filter_row1 / sgr_finish_filter2.
+// Mapping: one wave per 62 output columns of a task; lane = one column of the (A, B) surfaces
+// (62 outputs + 1 halo column each side).  A lane walks down the virtual rows keeping the
+// horizontal box sums of the last 3 / 5 rows in registers; finished (A, B) rows go to a small
+// LDS ring so that the output stage can read the neighbouring columns.
+struct AB { int a; int b; };
+
+__device__ __forceinline__ AB calc_ab(const int sumsq, const int sum, const int s, const int bitdepth_min_8, const int n, const int one_by_x)
+{
+    // sgr_calc_row_ab, src/looprestoration_tmpl.c:505-523
+    const int a = (sumsq + ((1 << (2 * bitdepth_min_8)) >> 1)) >> (2 * bitdepth_min_8);
+    const int b = (sum + ((1 << bitdepth_min_8) >> 1)) >> bitdepth_min_8;
+    const unsigned p = (unsigned) dv::imax(a * n - b * b, 0);
+    const unsigned z = (p * (unsigned) s + (1u << 19)) >> 20;
+    const unsigned x = av1_sgr_x_by_x[z < 255 ? z : 255];
+    AB r;
+    r.a = (int) ((x * (unsigned) sum * (unsigned) one_by_x + (1 << 11)) >> 12);
+    r.b = (int) x;
+    return r;
+}
+
+template <typename pixel>
+__global__ __launch_bounds__(64) void sgr_kernel(const DevPlanes dst, const DevPlanes src, const DevPlanes lpf,
+                                                 const Dav1dHipLrTask *__restrict__ tasks, const int n, const int bitdepth_max)
+{
+    __shared__ int a3[4][64], b3[4][64], a5[2][64], b5[2][64];
+    const int ti = blockIdx.y;
+    if (ti >= n) return;
+    const Dav1dHipLrTask t = tasks[__builtin_amdgcn_readfirstlane(ti)];
+    const int seg0 = blockIdx.x * 62;
+    if (seg0 >= t.w) return;
+    const int lane = threadIdx.x;
+    const int c = seg0 - 1 + lane;                      // (A, B) column of this lane, -1 .. w
+    const int bitdepth_min_8 = (32 - __clz(bitdepth_max)) - 8;
+    const int pl = t.plane, w = t.w, h = t.h, edges = t.edges;
+    const bool do5 = t.type != DAV1D_HIP_LR_SGR_3X3, do3 = t.type != DAV1D_HIP_LR_SGR_5X5;
+    const int s0 = t.filter[0][0], s1 = t.filter[0][1], w0 = t.filter[0][2], w1 = t.filter[0][3];
+    const pixel *const s = reinterpret_cast<const pixel *>(src.data[pl]);
+    const pixel *const l = reinterpret_cast<const pixel *>(lpf.data[pl]);
+    const int ss = src.stride[pl], ls = lpf.stride[pl];
+    // rows below the stripe: the reference only gets to them for long enough (5x5 / mix: even) stripes
+    bool use_bottom = (edges & 8) != 0;
+    if (do5) use_bottom = use_bottom && !(h & 1) && h >= ((edges & 4) ? 4 : 6);
+    else use_bottom = use_bottom && h >= 3;
+
+    int col[5];                                         // picture columns of c-2 .. c+2 with the edge rules of sgr_box*_row_h
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        int cc = c + i - 2;
+        if (cc < 0 && !(edges & 1)) cc = 0;
+        if (cc >= w && !(edges & 2)) cc = w - 1;
+        cc = dv::iclip(cc, -3, w + 2);                  // halo lanes beyond column w are never used
+        col[i] = t.x + cc;
+    }
+    int s3[3] = { 0, 0, 0 }, q3[3] = { 0, 0, 0 }, s5[5] = { 0, 0, 0, 0, 0 }, q5[5] = { 0, 0, 0, 0, 0 };
+    const bool out_lane = lane >= 1 && lane <= 62 && c < w;
+    pixel *const d = reinterpret_cast<pixel *>(dst.data[pl]) + t.y * dst.stride[pl] + t.x + c;
+
+    for (int r = -3; r < h + 3; r++) {
+        // ---- horizontal box sums of virtual row r
+        const pixel *row;
+        if (r < 0) {
+            if (edges & 4) row = l + (t.y - (r == -1 ? 1 : 2)) * ls;
+            else row = s + t.y * ss;
+        } else if (r >= h) {
+            if (use_bottom) row = l + (t.y + h + (r == h ? 0 : 1)) * ls;
+            else row = s + (t.y + h - 1) * ss;
+        } else row = s + (t.y + r) * ss;
+        const int p0 = row[col[0]], p1 = row[col[1]], p2 = row[col[2]], p3 = row[col[3]], p4 = row[col[4]];
+#pragma unroll
+        for (int i = 0; i < 2; i++) { s3[i] = s3[i + 1]; q3[i] = q3[i + 1]; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { s5[i] = s5[i + 1]; q5[i] = q5[i + 1]; }
+        s3[2] = p1 + p2 + p3;
+        q3[2] = p1 * p1 + p2 * p2 + p3 * p3;
+        s5[4] = s3[2] + p0 + p4;
+        q5[4] = q3[2] + p0 * p0 + p4 * p4;
+        // ---- (A, B) rows that just became complete
+        if (do3 && r >= 0 && r <= h + 1) {              // row j = r - 1 of the 3x3 surface
+            const AB v = calc_ab(q3[0] + q3[1] + q3[2], s3[0] + s3[1] + s3[2], s1, bitdepth_min_8, 9, 455);
+            a3[(r - 1) & 3][lane] = v.a; b3[(r - 1) & 3][lane] = v.b;
+        }
+        if (do5 && r >= 1 && ((r - 2) & 1)) {           // row j = r - 2 (odd) of the 5x5 surface
+            const AB v = calc_ab(q5[0] + q5[1] + q5[2] + q5[3] + q5[4], s5[0] + s5[1] + s5[2] + s5[3] + s5[4], s0, bitdepth_min_8, 25, 164);
+            a5[((r - 2) >> 1) & 1][lane] = v.a; b5[((r - 2) >> 1) & 1][lane] = v.b;
+        }
+        dv::wave_sync();
+        // ---- output row y = r - 3
+        const int y = r - 3;
+        if (y >= 0 && y < h && out_lane) {
+            const int px = s[(t.y + y) * ss + t.x + c];
+            int v = 0;
+            if (do3) {
+                const int *A0 = a3[(y - 1) & 3], *A1 = a3[y & 3], *A2 = a3[(y + 1) & 3];
+                const int *B0 = b3[(y - 1) & 3], *B1 = b3[y & 3], *B2 = b3[(y + 1) & 3];
+                const int i = lane;
+                const int a = (B1[i] + B1[i - 1] + B1[i + 1] + B0[i] + B2[i]) * 4 + (B0[i - 1] + B2[i - 1] + B0[i + 1] + B2[i + 1]) * 3;
+                const int b = (A1[i] + A1[i - 1] + A1[i + 1] + A0[i] + A2[i]) * 4 + (A0[i - 1] + A2[i - 1] + A0[i + 1] + A2[i + 1]) * 3;
+                v += w1 * ((b - a * px + (1 << 8)) >> 9);
+            }
+            if (do5) {
+                const int i = lane;
+                int t5;
+                if (!(y & 1)) {
+                    const int k0 = ((y - 1) >> 1) & 1, k1 = ((y + 1) >> 1) & 1;
+                    const int a = (b5[k0][i] + b5[k1][i]) * 6 + (b5[k0][i - 1] + b5[k1][i - 1] + b5[k0][i + 1] + b5[k1][i + 1]) * 5;
+                    const int b = (a5[k0][i] + a5[k1][i]) * 6 + (a5[k0][i - 1] + a5[k1][i - 1] + a5[k0][i + 1] + a5[k1][i + 1]) * 5;
+                    t5 = (b - a * px + (1 << 8)) >> 9;
+                } else {
+                    const int k = (y >> 1) & 1;
+                    const int a = b5[k][i] * 6 + (b5[k][i - 1] + b5[k][i + 1]) * 5;
+                    const int b = a5[k][i] * 6 + (a5[k][i - 1] + a5[k][i + 1]) * 5;
+                    t5 = (b - a * px + (1 << 7)) >> 8;
+                }
+                v += w0 * t5;
+            }
+            d[y * dst.stride[pl]] = (pixel) dv::iclip(px + ((v + (1 << 10)) >> 11), 0, bitdepth_max);
+        }
+        dv::wave_sync();
+    }
+}
+
 } // namespace
 
 extern "C" int dav1d_hip_launch_wiener(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
@@ -102,5 +231,18 @@ extern "C" int dav1d_hip_launch_wiener(const DevPlanes *dst, const DevPlanes *sr
         hipLaunchKernelGGL((wiener_kernel<uint8_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks, n, bitdepth_max);
     else
         hipLaunchKernelGGL((wiener_kernel<uint16_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks, n, bitdepth_max);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int dav1d_hip_launch_sgr(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
+                                    const Dav1dHipLrTask *tasks, int n, void *stream)
+{
+    if (n <= 0) return 0;
+    const int bitdepth_max = (1 << bpc) - 1;
+    const dim3 grid(7, n);          // 7 x 62 >= 384 columns
+    if (bpc == 8)
+        hipLaunchKernelGGL((sgr_kernel<uint8_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks, n, bitdepth_max);
+    else
+        hipLaunchKernelGGL((sgr_kernel<uint16_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks, n, bitdepth_max);
     return hip_rc(hipGetLastError());
 }

@@ -316,7 +316,8 @@ DAV1D_HIP_API int dav1d_hip_lf_batch(Dav1dHipContext *c, const Dav1dHipPicture *
 
 enum { DAV1D_HIP_LR_HAVE_LEFT = 1, DAV1D_HIP_LR_HAVE_RIGHT = 2, DAV1D_HIP_LR_HAVE_TOP = 4, DAV1D_HIP_LR_HAVE_BOTTOM = 8 };
                                                                      /* == enum LrEdgeFlags, src/looprestoration.h:36-41 */
-enum Dav1dHipLrType { DAV1D_HIP_LR_WIENER7 = 0, DAV1D_HIP_LR_WIENER5 = 1 };   /* dsp->lr.wiener[0 / 1] */
+enum Dav1dHipLrType { DAV1D_HIP_LR_WIENER7 = 0, DAV1D_HIP_LR_WIENER5 = 1,      /* dsp->lr.wiener[0 / 1] */
+                      DAV1D_HIP_LR_SGR_5X5 = 2, DAV1D_HIP_LR_SGR_3X3 = 3, DAV1D_HIP_LR_SGR_MIX = 4 };   /* dsp->lr.sgr[0 / 1 / 2] */
 
 /* One call of a looprestorationfilter_fn on one restoration-unit stripe as lr_stripe() issues it
  * (src/lr_apply_tmpl.c:36-97): w <= 384, h <= 64.  Out of place: `src` = loop-restoration input
@@ -329,7 +330,8 @@ typedef struct Dav1dHipLrTask {
     uint8_t  edges;      /* DAV1D_HIP_LR_HAVE_* */
     uint8_t  type;       /* enum Dav1dHipLrType */
     uint8_t  pad;
-    int16_t  filter[2][8]; /* LooprestorationParams.filter as built by lr_stripe (:55-71): [0] horizontal, [1] vertical */
+    int16_t  filter[2][8]; /* Wiener: LooprestorationParams.filter as built by lr_stripe (:55-71): [0] horizontal, [1] vertical;
+                              SGR: filter[0][0..3] = params.sgr.{s0, s1, w0, w1} (:72-82) */
 } Dav1dHipLrTask;
 
 /* `tasks` HOST array. */

@@ -75,3 +75,75 @@ def test_wiener_matches_reference(ctx, bpc):
         raise AssertionError("mismatch at (%d,%d): got %d want %d (%d px) task %s" % (xx, yy, got[yy, xx], want[yy, xx], len(bad), hit[:1]))
     for o in (src, lpf, dst):
         o.free()
+
+
+@pytest.mark.parametrize("bpc", [8, 10, 12])
+def test_sgr_matches_reference(ctx, bpc):
+    """sgr_5x5 / sgr_3x3 / sgr_mix with the parameter sets of dav1d_sgr_params and the weight ranges of
+    tests/checkasm/looprestoration.c:137-195."""
+    import ctypes as C
+    import struct
+    oracle = util.default_oracle()
+    if oracle.which != "ref":
+        pytest.skip("loop restoration is checked against the reference build")
+    sz = C.c_size_t()
+    p = util.ref_lib().dav1d_ref_table(b"sgr_params", C.byref(sz))
+    sgr_params = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint16)), shape=(16, 2)).copy()
+    rng = np.random.default_rng(2500 + bpc)
+    W, H = 1024, 512
+    src = ctx.picture(W, H, api.LAYOUT_I400, bpc)
+    lpf = ctx.picture(W, H, api.LAYOUT_I400, bpc)
+    dst = ctx.picture(W, H, api.LAYOUT_I400, bpc)
+    sp = synth.make_planes(rng, W, H, bpc, smooth=True)[0]
+    lp = synth.make_planes(rng, W, H, bpc, smooth=True)[0]
+    dp = synth.make_planes(rng, W, H, bpc, smooth=False)[0]
+    # some flat and some noisy areas so that the whole x_by_x range is exercised
+    sp[:, 300:500] = rng.integers(0, 1 << bpc, size=(sp.shape[0], 200))
+    sp[100:200, :] = sp[100, 0]
+    src.upload(0, sp); lpf.upload(0, lp); dst.upload(0, dp)
+    want = synth.copy_planes([dp])[0]
+    stride_px = src.stride_px(0)
+    t = np.zeros(64, api.LR_TASK)
+    k = 0
+    y = 8
+    while y + 70 < H:
+        x = 8
+        while x + 400 < W:
+            w = int(rng.choice([int(rng.integers(1, 385)), int(rng.integers(1, 12)), 384, 64]))
+            h = int(rng.choice([int(rng.integers(1, 65)), int(rng.integers(1, 9)), 64]))
+            set_idx = int(rng.integers(0, 16))
+            s0, s1 = int(sgr_params[set_idx][0]), int(sgr_params[set_idx][1])
+            typ = 2 + (1 if not s0 else 0 if not s1 else 2)          # 2: 5x5, 3: 3x3, 4: mix
+            w0 = int(rng.integers(-96, 32))
+            w1 = 128 - (w0 + int(rng.integers(-32, 96)))
+            f = np.zeros((2, 8), np.int16)
+            f[0, :4] = (s0, s1, w0, w1)
+            t[k] = (x, y, w, h, 0, k % 16 if k < 32 else int(rng.integers(0, 16)), typ, 0, f)
+            k += 1
+            x += 400
+        y += 72
+    t = t[:k]
+    bps = want.itemsize
+    lbase = lp.base
+    for i in range(len(t)):
+        x, y, w, h = (int(t[i][n]) for n in ("x", "y", "w", "h"))
+        work = synth.copy_planes([sp])[0]
+        left = np.ascontiguousarray(sp[y:y + h, x - 4:x])
+        L = np.zeros((8, stride_px), sp.dtype)
+        L[0], L[1], L[6], L[7] = lbase[y - 2], lbase[y - 1], lbase[y + h], lbase[y + h + 1]
+        s0, s1, w0, w1 = (int(v) for v in t[i]["filter"][0][:4])
+        params = np.frombuffer(struct.pack("<IIhh", s0, s1, w0, w1) + b"\\0" * 20, np.uint8).copy()
+        oracle.call(bpc, "sgr", int(t[i]["type"]) - 2, 0, work.ctypes.data + (y * stride_px + x) * bps, work.strides[0],
+                    left, L.ctypes.data + x * bps, w, h, params, int(t[i]["edges"]))
+        want[y:y + h, x:x + w] = work[y:y + h, x:x + w]
+    ctx.lr_batch(dst, src, lpf, t)
+    got = dst.download(0)
+    bad = np.argwhere(got != want)
+    if len(bad):
+        yy, xx = bad[0]
+        hit = [tuple(t[i])[:8] + (tuple(t[i]["filter"][0][:4]),) for i in range(len(t))
+               if t[i]["x"] <= xx < t[i]["x"] + t[i]["w"] and t[i]["y"] <= yy < t[i]["y"] + t[i]["h"]]
+        raise AssertionError("mismatch at (%d,%d): got %d want %d (%d px) task %s" % (xx, yy, got[yy, xx], want[yy, xx], len(bad), hit[:1]))
+    assert set(t["type"]) == {2, 3, 4}
+    for o in (src, lpf, dst):
+        o.free()
