@@ -43,6 +43,13 @@ assert IPRED_TASK.itemsize == 44
 LR_TASK = np.dtype([("x", "<u2"), ("y", "<u2"), ("w", "<u2"), ("h", "<u2"), ("plane", "u1"), ("edges", "u1"), ("type", "u1"),
                     ("pad", "u1"), ("filter", "<i2", (2, 8))], align=False)
 assert LR_TASK.itemsize == 44
+WARP_TASK = np.dtype([("dst_off", "<u4"), ("src_x", "<i4"), ("src_y", "<i4"), ("mx", "<i4"), ("my", "<i4"), ("abcd", "<i2", (4,)),
+                      ("tmp_stride", "<u2"), ("kind", "u1"), ("plane", "u1"), ("ref", "u1"), ("pad", "u1", (3,))], align=False)
+assert WARP_TASK.itemsize == 36
+MC_SCALED_TASK = np.dtype([("dst_off", "<u4"), ("src_x", "<i4"), ("src_y", "<i4"), ("mx", "<i2"), ("my", "<i2"), ("dx", "<i2"),
+                           ("dy", "<i2"), ("w", "u1"), ("h", "u1"), ("filter_2d", "u1"), ("kind", "u1"), ("plane", "u1"),
+                           ("ref", "u1"), ("pad", "u1", (2,))], align=False)
+assert MC_SCALED_TASK.itemsize == 28
 assert CDEF_TASK.itemsize == 16
 assert ITX_TASK.itemsize == 16 and MC_TASK.itemsize == 24 and COMP_TASK.itemsize == 24
 
@@ -60,6 +67,7 @@ SYMBOLS = [
     "dav1d_hip_inter_list_run_timed", "dav1d_hip_inter_list_fused",
     "dav1d_hip_cdef_batch", "dav1d_hip_lf_batch", "dav1d_hip_ipred_batch", "dav1d_hip_lr_batch",
     "dav1d_hip_fg_apply", "dav1d_hip_fg_generate_grain",
+    "dav1d_hip_warp_batch", "dav1d_hip_mc_scaled_batch", "dav1d_hip_resize", "dav1d_hip_emu_edge",
 ]
 
 
@@ -125,6 +133,11 @@ def load(path=None):
         "dav1d_hip_lr_batch": (i, [vp, P(Picture), P(Picture), P(Picture), vp, sz]),
         "dav1d_hip_fg_apply": (i, [vp, P(Picture), P(Picture), P(FilmGrainData), i]),
         "dav1d_hip_fg_generate_grain": (i, [vp, P(FilmGrainData), i, i, vp]),
+        "dav1d_hip_warp_batch": (i, [vp, P(Picture), P(Picture), i, vp, sz, vp]),
+        "dav1d_hip_mc_scaled_batch": (i, [vp, P(Picture), P(Picture), i, vp, sz, vp]),
+        "dav1d_hip_resize": (i, [vp, P(Picture), P(Picture), i, i, i, i, i, i, i]),
+        "dav1d_hip_emu_edge": (i, [vp, i, C.c_ssize_t, C.c_ssize_t, C.c_ssize_t, C.c_ssize_t, C.c_ssize_t, C.c_ssize_t, vp,
+                                   C.c_ssize_t, vp, C.c_ssize_t]),
         "dav1d_hip_dsp_init_8bpc": (i, [vp]),
         "dav1d_hip_dsp_init_16bpc": (i, [vp, i]),
     }

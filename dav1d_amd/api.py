@@ -9,7 +9,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import FilmGrainData  # noqa: F401
-from ._lib import ITX_TASK, MC_TASK, COMP_TASK, CDEF_TASK, LF_TASK, IPRED_TASK, LR_TASK, Picture  # noqa: F401  (re-exported)
+from ._lib import ITX_TASK, MC_TASK, COMP_TASK, CDEF_TASK, LF_TASK, IPRED_TASK, LR_TASK, WARP_TASK, MC_SCALED_TASK, Picture  # noqa: F401  (re-exported)
 
 LAYOUT_I400, LAYOUT_I420, LAYOUT_I422, LAYOUT_I444 = 0, 1, 2, 3
 
@@ -174,6 +174,27 @@ class Context:
         t = np.ascontiguousarray(tasks, dtype=COMP_TASK)
         _chk(self.lib.dav1d_hip_comp_batch(self.h, C.byref(dst.pic), t.ctypes.data, len(t), prep.ptr,
                                            mask.ptr if mask else None), "comp_batch")
+
+    def warp_batch(self, dst, refs, tasks, prep=None):
+        t = np.ascontiguousarray(tasks, dtype=WARP_TASK)
+        arr = (Picture * len(refs))(*[r.pic for r in refs])
+        _chk(self.lib.dav1d_hip_warp_batch(self.h, C.byref(dst.pic), arr, len(refs), t.ctypes.data, len(t),
+                                           prep.ptr if prep else None), "warp_batch")
+
+    def mc_scaled_batch(self, dst, refs, tasks, prep=None):
+        t = np.ascontiguousarray(tasks, dtype=MC_SCALED_TASK)
+        arr = (Picture * len(refs))(*[r.pic for r in refs])
+        _chk(self.lib.dav1d_hip_mc_scaled_batch(self.h, C.byref(dst.pic), arr, len(refs), t.ctypes.data, len(t),
+                                                prep.ptr if prep else None), "mc_scaled_batch")
+
+    def resize(self, dst, src, plane, dst_w, y0, h, src_w, dx, mx0):
+        _chk(self.lib.dav1d_hip_resize(self.h, C.byref(dst.pic), C.byref(src.pic), plane, dst_w, y0, h, src_w, dx, mx0), "resize")
+
+    def emu_edge(self, bpc, bw, bh, iw, ih, x, y, dst, dst_stride, ref, ref_stride):
+        """dst / ref: DeviceBuffer (or raw device address); strides in bytes."""
+        d = dst.ptr if hasattr(dst, "ptr") else dst
+        r = ref.ptr if hasattr(ref, "ptr") else ref
+        _chk(self.lib.dav1d_hip_emu_edge(self.h, bpc, bw, bh, iw, ih, x, y, d, dst_stride, r, ref_stride), "emu_edge")
 
     def cdef_batch(self, dst, src, tasks, damping, dirvar=None):
         t = np.ascontiguousarray(tasks, dtype=CDEF_TASK)

@@ -74,7 +74,7 @@ extern "C" int dav1d_hip_launch_itx_bin(const DevPlanes *dst, int bpc, int tx, c
 // A tile carries one prediction (PUT / PREP) or, when the list builder could pair a
 // compound task with the two PREP tasks that feed it, both predictions plus the combine
 // (AVG / WAVG): the int16 intermediates then never leave registers.
-enum { MCT_PUT = 0, MCT_PREP = 1, MCT_AVG = 2, MCT_WAVG = 3 };
+enum { MCT_PUT = 0, MCT_PREP = 1, MCT_AVG = 2, MCT_WAVG = 3, MCT_PUT_TMP = 4 };
 struct McRef {
     int32_t  src_x, src_y;// of the tile's top-left in the reference plane
     uint8_t  mx, my;
@@ -114,6 +114,15 @@ extern "C" int dav1d_hip_launch_fg_apply(const DevPlanes *dst, const DevPlanes *
 
 extern "C" int dav1d_hip_launch_sgr(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
                                     const Dav1dHipLrTask *tasks, int n, void *stream);
+
+extern "C" int dav1d_hip_launch_warp(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, const Dav1dHipWarpTask *tasks, int n,
+                                     int16_t *prep, void *stream);
+extern "C" int dav1d_hip_launch_mc_scaled(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc,
+                                          const Dav1dHipMcScaledTask *tasks, int n, int16_t *prep, void *stream);
+extern "C" int dav1d_hip_launch_resize(const DevPlanes *dst, const DevPlanes *src, int bpc, int plane, int dst_w, int y0, int h, int src_w,
+                                       int dx, int mx0, void *stream);
+extern "C" int dav1d_hip_launch_emu_edge(void *dst, ptrdiff_t dst_stride, const void *ref, ptrdiff_t ref_stride, int bw, int bh,
+                                         int iw, int ih, int x, int y, int bpc, void *stream);
 
 Dav1dHipContext *dav1d_hip_default_context(void);
 int dav1d_hip_scratch(Dav1dHipContext *c, size_t bytes, void **out);

@@ -305,7 +305,7 @@ extern "C" {
 
 static int mc_task_valid(const Dav1dHipMcTask &t) {
     return !(t.w < 2 || t.w > 128 || t.h < 2 || t.h > 128 || (t.w & (t.w - 1)) || (t.h & (t.h - 1)) ||
-             t.mx > 15 || t.my > 15 || t.filter_2d > 9 || t.kind > 1 || t.plane > 2 || t.ref > 7);
+             t.mx > 15 || t.my > 15 || t.filter_2d > 9 || t.kind > 2 || t.plane > 2 || t.ref > 7);
 }
 
 static McRef mc_ref_of(const Dav1dHipMcTask &t) {
@@ -374,7 +374,8 @@ int dav1d_hip_mc_list_create(Dav1dHipContext *c, Dav1dHipMcList **out, const Dav
     std::vector<McTile> bins[MC_BINS];
     for (size_t i = 0; i < n; i++) {
         if (!mc_task_valid(tasks[i])) return -EINVAL;
-        push_tiles(bins, tasks[i], tasks[i].kind == DAV1D_HIP_MC_PUT ? MCT_PUT : MCT_PREP, tasks[i].dst_off, nullptr, 0);
+        push_tiles(bins, tasks[i], tasks[i].kind == DAV1D_HIP_MC_PUT ? MCT_PUT : tasks[i].kind == DAV1D_HIP_MC_PREP ? MCT_PREP : MCT_PUT_TMP,
+                   tasks[i].dst_off, nullptr, 0);
     }
     return mc_list_from_bins(c, out, bins);
 }
@@ -445,6 +446,7 @@ int dav1d_hip_mc_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav
 struct Dav1dHipCompList {
     Dav1dHipCompTask *dev;
     size_t n;
+    size_t n_first;   // tasks [0, n_first) run in the first launch, the BLEND_V tasks after them in a second one
 };
 
 extern "C" {
@@ -454,16 +456,24 @@ int dav1d_hip_comp_list_create(Dav1dHipContext *c, Dav1dHipCompList **out, const
     *out = nullptr;
     for (size_t i = 0; i < n; i++) {
         const Dav1dHipCompTask &t = tasks[i];
-        if (t.w < 4 || t.w > 128 || t.h < 4 || t.h > 128 || (t.w & 1) || (t.h & 1) || t.kind > 3 || t.plane > 2 || t.ss > 2)
+        if (t.kind > 6 || t.plane > 2 || t.ss > 2 || t.w > 128 || t.h > 128 || t.w < 2 || t.h < 2 ||
+            (t.kind <= 3 && (t.w < 4 || t.h < 4 || (t.w & 1) || (t.h & 1))))
             return -EINVAL;
     }
     Dav1dHipCompList *l = new (std::nothrow) Dav1dHipCompList();
     if (!l) return -ENOMEM;
     l->dev = nullptr;
     l->n = n;
+    // obmc() blends the top neighbours' predictions (blend_h) before the left ones (blend_v) and the two overlap in the
+    // block's top-left corner (reference src/recon_tmpl.c:1066-1111): keep that order with a second launch
+    std::vector<Dav1dHipCompTask> sorted;
+    sorted.reserve(n);
+    for (size_t i = 0; i < n; i++) if (tasks[i].kind != DAV1D_HIP_COMP_BLEND_V) sorted.push_back(tasks[i]);
+    l->n_first = sorted.size();
+    for (size_t i = 0; i < n; i++) if (tasks[i].kind == DAV1D_HIP_COMP_BLEND_V) sorted.push_back(tasks[i]);
     if (n) {
         if (hipMalloc((void **) &l->dev, n * sizeof(Dav1dHipCompTask)) != hipSuccess) { delete l; return -ENOMEM; }
-        const int rc = dav1d_hip_upload(c, l->dev, tasks, n * sizeof(Dav1dHipCompTask));
+        const int rc = dav1d_hip_upload(c, l->dev, sorted.data(), n * sizeof(Dav1dHipCompTask));
         if (rc) { hipFree(l->dev); delete l; return rc; }
     }
     *out = l;
@@ -481,7 +491,9 @@ int dav1d_hip_comp_list_run(Dav1dHipContext *c, const Dav1dHipCompList *l, const
                             const int16_t *prep, uint8_t *mask) {
     if (!l || !dst) return -EINVAL;
     const DevPlanes dp = dev_planes(dst);
-    return dav1d_hip_launch_comp(&dp, dst->bpc, l->dev, (int) l->n, prep, mask, c->stream);
+    int rc = dav1d_hip_launch_comp(&dp, dst->bpc, l->dev, (int) l->n_first, prep, mask, c->stream);
+    if (!rc) rc = dav1d_hip_launch_comp(&dp, dst->bpc, l->dev + l->n_first, (int) (l->n - l->n_first), prep, mask, c->stream);
+    return rc;
 }
 
 int dav1d_hip_comp_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipCompTask *tasks, size_t n,
@@ -554,7 +566,8 @@ int dav1d_hip_inter_list_create(Dav1dHipContext *c, Dav1dHipInterList **out, con
     }
     for (size_t i = 0; i < n_mc; i++)
         if (!fused_prep[i])
-            push_tiles(bins, mc[i], mc[i].kind == DAV1D_HIP_MC_PUT ? MCT_PUT : MCT_PREP, mc[i].dst_off, nullptr, 0);
+            push_tiles(bins, mc[i], mc[i].kind == DAV1D_HIP_MC_PUT ? MCT_PUT : mc[i].kind == DAV1D_HIP_MC_PREP ? MCT_PREP : MCT_PUT_TMP,
+                       mc[i].dst_off, nullptr, 0);
     Dav1dHipInterList *l = new (std::nothrow) Dav1dHipInterList();
     if (!l) return -ENOMEM;
     l->mc = nullptr; l->comp = nullptr; l->n_fused = n_fused;
@@ -669,6 +682,74 @@ extern "C" int dav1d_hip_ipred_batch(Dav1dHipContext *c, const Dav1dHipPicture *
     if (!rc) rc = dav1d_hip_launch_ipred(&dp, dst->bpc, dst->layout, dev, (int) n, pal_idx, c->stream);
     hipStreamSynchronize(c->stream);
     hipFree(dev);
+    return rc;
+}
+
+// ------------------------------------------------- mc: warp, scaled, resize, emu_edge
+
+template <typename T, typename Launch>
+static int run_task_batch(Dav1dHipContext *c, const T *tasks, size_t n, Launch launch) {
+    T *dev = nullptr;
+    if (hipMalloc((void **) &dev, n * sizeof(T)) != hipSuccess) return -ENOMEM;
+    int rc = dav1d_hip_upload(c, dev, tasks, n * sizeof(T));
+    if (!rc) rc = launch(dev);
+    hipStreamSynchronize(c->stream);
+    hipFree(dev);
+    return rc;
+}
+
+extern "C" int dav1d_hip_warp_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *refs, int n_refs,
+                                    const Dav1dHipWarpTask *tasks, size_t n, int16_t *prep) {
+    if (!dst || !refs || n_refs < 1 || n_refs > 8 || (!tasks && n)) return -EINVAL;
+    if (!n) return 0;
+    for (size_t i = 0; i < n; i++) {
+        const Dav1dHipWarpTask &t = tasks[i];
+        if (t.kind > DAV1D_HIP_MC_PREP || t.plane > 2 || t.ref >= n_refs) return -EINVAL;
+        if (t.kind == DAV1D_HIP_MC_PREP && !prep) return -EINVAL;
+    }
+    DevPlanes rp[8];
+    for (int i = 0; i < n_refs; i++) { if (refs[i].bpc != dst->bpc) return -EINVAL; rp[i] = dev_planes(&refs[i]); }
+    const DevPlanes dp = dev_planes(dst);
+    return run_task_batch(c, tasks, n, [&](const Dav1dHipWarpTask *dev) {
+        return dav1d_hip_launch_warp(&dp, rp, n_refs, dst->bpc, dev, (int) n, prep, c->stream); });
+}
+
+extern "C" int dav1d_hip_mc_scaled_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *refs, int n_refs,
+                                         const Dav1dHipMcScaledTask *tasks, size_t n, int16_t *prep) {
+    if (!dst || !refs || n_refs < 1 || n_refs > 8 || (!tasks && n)) return -EINVAL;
+    if (!n) return 0;
+    for (size_t i = 0; i < n; i++) {
+        const Dav1dHipMcScaledTask &t = tasks[i];
+        if (t.kind > DAV1D_HIP_MC_PREP || t.plane > 2 || t.ref >= n_refs || t.filter_2d > 9) return -EINVAL;
+        if (t.w < 2 || t.w > 128 || t.h < 2 || t.h > 128 || t.mx < 0 || t.mx > 1023 || t.my < 0 || t.my > 1023 || t.dx < 0 || t.dy < 0)
+            return -EINVAL;
+        if (t.kind == DAV1D_HIP_MC_PREP && !prep) return -EINVAL;
+    }
+    DevPlanes rp[8];
+    for (int i = 0; i < n_refs; i++) { if (refs[i].bpc != dst->bpc) return -EINVAL; rp[i] = dev_planes(&refs[i]); }
+    const DevPlanes dp = dev_planes(dst);
+    return run_task_batch(c, tasks, n, [&](const Dav1dHipMcScaledTask *dev) {
+        return dav1d_hip_launch_mc_scaled(&dp, rp, n_refs, dst->bpc, dev, (int) n, prep, c->stream); });
+}
+
+extern "C" int dav1d_hip_resize(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src, int plane, int dst_w, int y0,
+                                int h, int src_w, int dx, int mx0) {
+    if (!dst || !src || dst->bpc != src->bpc || plane < 0 || plane > 2 || dst_w < 1 || src_w < 1 || h < 0 || y0 < 0) return -EINVAL;
+    if (mx0 < 0 || mx0 > 0x3fff || dx < 0) return -EINVAL;
+    if (!h) return 0;
+    const DevPlanes dp = dev_planes(dst), sp = dev_planes(src);
+    if (y0 + h > dp.h[plane] || y0 + h > sp.h[plane] || dst_w > dp.w[plane]) return -EINVAL;
+    const int rc = dav1d_hip_launch_resize(&dp, &sp, dst->bpc, plane, dst_w, y0, h, src_w, dx, mx0, c->stream);
+    hipStreamSynchronize(c->stream);
+    return rc;
+}
+
+extern "C" int dav1d_hip_emu_edge(Dav1dHipContext *c, int bpc, intptr_t bw, intptr_t bh, intptr_t iw, intptr_t ih, intptr_t x, intptr_t y,
+                                  void *dst, ptrdiff_t dst_stride, const void *ref, ptrdiff_t ref_stride) {
+    if (!dst || !ref || bw < 1 || bh < 1 || iw < 1 || ih < 1 || (bpc != 8 && bpc != 10 && bpc != 12)) return -EINVAL;
+    const int rc = dav1d_hip_launch_emu_edge(dst, dst_stride, ref, ref_stride, (int) bw, (int) bh, (int) iw, (int) ih, (int) x, (int) y, bpc,
+                                             c->stream);
+    hipStreamSynchronize(c->stream);
     return rc;
 }
 

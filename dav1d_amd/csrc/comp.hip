@@ -6,6 +6,7 @@
 // pixel quad so that the 4:2:0 mask sample falls out of a single lane.
 #include "common.h"
 #include "capi.h"
+#include "av1_tables.h"
 
 namespace {
 
@@ -25,6 +26,20 @@ __global__ __launch_bounds__(64) void comp_kernel(const DevPlanes dst, const Dav
     pixel *const d0 = reinterpret_cast<pixel *>(dst.data[t.plane]) + t.dst_off;
     const int stride = dst.stride[t.plane];
     const int16_t *const t1 = prep + t.tmp1_off, *const t2 = prep + t.tmp2_off;
+
+    if (t.kind >= DAV1D_HIP_COMP_BLEND) {
+        // blend_c / blend_v_c / blend_h_c, src/mc_tmpl.c:682-722
+        const pixel *const tmp = reinterpret_cast<const pixel *>(prep) + t.tmp1_off;
+        const int ww = t.kind == DAV1D_HIP_COMP_BLEND_V ? (w * 3) >> 2 : w, hh = t.kind == DAV1D_HIP_COMP_BLEND_H ? (h * 3) >> 2 : h;
+        for (int i = threadIdx.x; i < ww * hh; i += 64) {
+            const int y = i / ww, x = i - y * ww;
+            const int m = t.kind == DAV1D_HIP_COMP_BLEND ? mask[t.mask_off + y * w + x]
+                        : t.kind == DAV1D_HIP_COMP_BLEND_V ? av1_obmc_masks[w + x] : av1_obmc_masks[h + y];
+            const int a = d0[y * stride + x], b = tmp[y * w + x];
+            d0[y * stride + x] = (pixel) ((a * (64 - m) + b * m + 32) >> 6);
+        }
+        return;
+    }
 
     for (int i = threadIdx.x; i < qw * (h >> 1); i += 64) {
         const int qy = i / qw, qx = i - qy * qw;

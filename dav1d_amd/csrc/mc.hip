@@ -90,8 +90,8 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSe
 
     const int ib = HBD ? 14 - (32 - __clz(bitdepth_max)) : 4;   // intermediate_bits
     const int bias = HBD ? 8192 : 0;                            // PREP_BIAS
-    const bool compound = live && t.kind >= MCT_AVG;
-    const bool as_prep = t.kind != MCT_PUT;                     // PREP and both inputs of a compound tile
+    const bool compound = live && (t.kind == MCT_AVG || t.kind == MCT_WAVG);
+    const bool as_prep = t.kind != MCT_PUT && t.kind != MCT_PUT_TMP;   // PREP and both inputs of a compound tile
 
     int acc0[R][4], q[R][4];
 #pragma unroll
@@ -278,7 +278,10 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSe
             if (t.kind != MCT_PREP) {
 #pragma unroll
                 for (int x = 0; x < 4; x++) o[x] = dv::iclip(o[x], 0, bitdepth_max);
-                pixel *d = reinterpret_cast<pixel *>(dst.data[t.plane]) + t.dst_off + (t.oy + vr) * dst.stride[t.plane] + t.ox + 4 * vs;
+                // PUT_TMP: pixels into the scratch arena, row stride = block width (the reference's `lap` buffer of obmc())
+                pixel *d = t.kind == MCT_PUT_TMP
+                    ? reinterpret_cast<pixel *>(prep) + t.dst_off + (t.oy + vr) * t.bw + t.ox + 4 * vs
+                    : reinterpret_cast<pixel *>(dst.data[t.plane]) + t.dst_off + (t.oy + vr) * dst.stride[t.plane] + t.ox + 4 * vs;
                 if (nvalid == 4) {
                     if (HBD) *reinterpret_cast<uint2 *>(d) = make_uint2(dv::pack2(o[0], o[1]), dv::pack2(o[2], o[3]));
                     else *reinterpret_cast<uint32_t *>(d) = (uint32_t) o[0] | ((uint32_t) o[1] << 8) | ((uint32_t) o[2] << 16) | ((uint32_t) o[3] << 24);

@@ -1,0 +1,212 @@
+// The rarer motion-compensation entries for gfx950: warp8x8 / warp8x8t, the scaled put / prep
+// variants, super-resolution resize and stand-alone emu_edge.
+//
+// Contracts: warp_affine_8x8_c / warp_affine_8x8t_c (reference src/mc_tmpl.c:799-866) as driven by
+// warp_affine() (src/recon_tmpl.c:1115-1174); put/prep_8tap_scaled_c and put/prep_bilin_scaled_c
+// (src/mc_tmpl.c:189-244, 307-357, 491-626) as driven by the scaled branch of mc()
+// (src/recon_tmpl.c:990-1047); resize_c (src/mc_tmpl.c:918-944); emu_edge_c (:868-916).
+// These are per-pixel gathers with position-dependent filters, so the mapping is one lane per output
+// pixel reading its taps straight from (L1-resident) memory; edge emulation is a coordinate clamp.
+#include "common.h"
+#include "capi.h"
+#include "av1_tables.h"
+
+namespace {
+
+struct RefSet { DevPlanes r[8]; };
+
+template <typename pixel>
+__device__ __forceinline__ int ref_px(const pixel *p, const int stride, const int w, const int h, const int x, const int y) {
+    return p[dv::iclip(y, 0, h - 1) * stride + dv::iclip(x, 0, w - 1)];
+}
+
+// ------------------------------------------------------------------------------------------ warp
+template <typename pixel>
+__global__ __launch_bounds__(64) void warp_kernel(const DevPlanes dst, const RefSet refs, const Dav1dHipWarpTask *__restrict__ tasks,
+                                                  const int n, int16_t *__restrict__ prep, const int bitdepth_max)
+{
+    __shared__ int16_t mid[15 * 8];
+    const int ti = blockIdx.x;
+    if (ti >= n) return;
+    const Dav1dHipWarpTask t = tasks[__builtin_amdgcn_readfirstlane(ti)];
+    constexpr bool HBD = sizeof(pixel) == 2;
+    const int ib = HBD ? 14 - (32 - __clz(bitdepth_max)) : 4;
+    const DevPlanes &rp = refs.r[t.ref];
+    const pixel *src = reinterpret_cast<const pixel *>(rp.data[t.plane]);
+    const int rs = rp.stride[t.plane], rw = rp.w[t.plane], rh = rp.h[t.plane];
+    const int lane = threadIdx.x;
+    // 15 rows x 8 columns of horizontally filtered samples (src/mc_tmpl.c:808-820)
+    for (int i = lane; i < 15 * 8; i += 64) {
+        const int y = i >> 3, x = i & 7;
+        const int tmx = t.mx + y * t.abcd[1] + x * t.abcd[0];
+        const int8_t *f = &av1_mc_warp_filter[(64 + ((tmx + 512) >> 10)) * 8];
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) s += f[k] * ref_px(src, rs, rw, rh, t.src_x + x + k - 3, t.src_y + y - 3);
+        mid[i] = (int16_t) ((s + ((1 << (7 - ib)) >> 1)) >> (7 - ib));
+    }
+    dv::wave_sync();
+    {
+        const int y = lane >> 3, x = lane & 7;
+        const int tmy = t.my + y * t.abcd[3] + x * t.abcd[2];
+        const int8_t *f = &av1_mc_warp_filter[(64 + ((tmy + 512) >> 10)) * 8];
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) s += f[k] * mid[(y + k) * 8 + x];
+        if (t.kind == DAV1D_HIP_MC_PUT) {
+            const int v = (s + ((1 << (7 + ib)) >> 1)) >> (7 + ib);
+            reinterpret_cast<pixel *>(dst.data[t.plane])[t.dst_off + y * dst.stride[t.plane] + x] = (pixel) dv::iclip(v, 0, bitdepth_max);
+        } else {
+            prep[t.dst_off + y * t.tmp_stride + x] = (int16_t) (((s + 64) >> 7) - (HBD ? 8192 : 0));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- scaled put / prep
+template <typename pixel>
+__global__ __launch_bounds__(64) void mc_scaled_kernel(const DevPlanes dst, const RefSet refs, const Dav1dHipMcScaledTask *__restrict__ tasks,
+                                                       const int n, int16_t *__restrict__ prep, const int bitdepth_max)
+{
+    const int ti = blockIdx.x;
+    if (ti >= n) return;
+    const Dav1dHipMcScaledTask t = tasks[__builtin_amdgcn_readfirstlane(ti)];
+    constexpr bool HBD = sizeof(pixel) == 2;
+    const int ib = HBD ? 14 - (32 - __clz(bitdepth_max)) : 4;
+    const int bias = HBD ? 8192 : 0;
+    const DevPlanes &rp = refs.r[t.ref];
+    const pixel *src = reinterpret_cast<const pixel *>(rp.data[t.plane]);
+    const int rs = rp.stride[t.plane], rw = rp.w[t.plane], rh = rp.h[t.plane];
+    const bool bilin = t.filter_2d == 9;
+    // enum Filter2d -> (h, v) 8-tap families, 4-tap rows for w <= 4 / h <= 4 (src/mc_tmpl.c:115-123)
+    const unsigned long long ht = 0x111222000ull, vt = 0x210210210ull;      // nibble f of each = type of Filter2d f
+    const int h_type = (int) (ht >> (4 * t.filter_2d)) & 15, v_type = (int) (vt >> (4 * t.filter_2d)) & 15;
+    const int hset = t.w > 4 ? h_type : 3 + (h_type & 1), vset = t.h > 4 ? v_type : 3 + (v_type & 1);
+    for (int i = threadIdx.x; i < t.w * t.h; i += 64) {
+        const int y = i / t.w, x = i % t.w;
+        const int px = t.mx + x * t.dx, py = t.my + y * t.dy;
+        const int ioff = px >> 10, fxi = (px & 0x3ff) >> 6, src_y = py >> 10, fyi = (py & 0x3ff) >> 6;
+        int v;
+        if (bilin) {
+            // mid[r][x] = FILTER_BILIN_RND(src, ioff, fxi, 1, 4 - ib) on source rows src_y, src_y + 1
+            int m[2];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int a = ref_px(src, rs, rw, rh, t.src_x + ioff, t.src_y + src_y + r);
+                const int b = ref_px(src, rs, rw, rh, t.src_x + ioff + 1, t.src_y + src_y + r);
+                m[r] = (int16_t) ((16 * a + fxi * (b - a) + ((1 << (4 - ib)) >> 1)) >> (4 - ib));
+            }
+            const int s = 16 * m[0] + fyi * (m[1] - m[0]);
+            v = t.kind == DAV1D_HIP_MC_PUT ? (s + ((1 << (4 + ib)) >> 1)) >> (4 + ib) : ((s + 8) >> 4) - bias;
+        } else {
+            const int8_t *fh = fxi ? &av1_mc_subpel_filters[(hset * 15 + fxi - 1) * 8] : nullptr;
+            const int8_t *fv = fyi ? &av1_mc_subpel_filters[(vset * 15 + fyi - 1) * 8] : nullptr;
+            int mid[8];
+            // the vertical filter spans source rows src_y - 3 .. src_y + 4 (mid_ptrs[0..7])
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int sy = t.src_y + src_y + r - 3;
+                if (!fv && r != 3) { mid[r] = 0; continue; }
+                int s;
+                if (fh) {
+                    s = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) s += fh[k] * ref_px(src, rs, rw, rh, t.src_x + ioff + k - 3, sy);
+                    s = (s + ((1 << (6 - ib)) >> 1)) >> (6 - ib);
+                } else {
+                    s = ref_px(src, rs, rw, rh, t.src_x + ioff, sy) << ib;
+                }
+                mid[r] = (int16_t) s;
+            }
+            if (fv) {
+                int s = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) s += fv[k] * mid[k];
+                v = t.kind == DAV1D_HIP_MC_PUT ? (s + ((1 << (6 + ib)) >> 1)) >> (6 + ib) : ((s + 32) >> 6) - bias;
+            } else {
+                v = t.kind == DAV1D_HIP_MC_PUT ? (mid[3] + ((1 << ib) >> 1)) >> ib : mid[3] - bias;
+            }
+        }
+        if (t.kind == DAV1D_HIP_MC_PUT)
+            reinterpret_cast<pixel *>(dst.data[t.plane])[t.dst_off + y * dst.stride[t.plane] + x] = (pixel) dv::iclip(v, 0, bitdepth_max);
+        else
+            prep[t.dst_off + y * t.w + x] = (int16_t) v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ resize
+template <typename pixel>
+__global__ __launch_bounds__(256) void resize_kernel(const DevPlanes dst, const DevPlanes src, const int plane, const int dst_w, const int y0, const int h,
+                                                     const int src_w, const int dx, const int mx0, const int bitdepth_max)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = y0 + blockIdx.y;
+    if (x >= dst_w) return;
+    // position after x steps of "mx += dx; src_x += mx >> 14; mx &= 0x3fff" starting from (mx0, -1)
+    const long long pos = (long long) mx0 + (long long) x * dx;
+    const int src_x = -1 + (int) (pos >> 14), mx = (int) (pos & 0x3fff);
+    const int8_t *F = &av1_resize_filter[(mx >> 8) * 8];
+    const pixel *s = reinterpret_cast<const pixel *>(src.data[plane]) + y * src.stride[plane];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) sum += F[k] * s[dv::iclip(src_x + k - 3, 0, src_w - 1)];
+    reinterpret_cast<pixel *>(dst.data[plane])[y * dst.stride[plane] + x] = (pixel) dv::iclip((-sum + 64) >> 7, 0, bitdepth_max);
+}
+
+// ---------------------------------------------------------------------------------------- emu_edge
+template <typename pixel>
+__global__ __launch_bounds__(256) void emu_edge_kernel(pixel *dst, const int dst_stride, const pixel *ref, const int ref_stride,
+                                                       const int bw, const int bh, const int iw, const int ih, const int x0, const int y0)
+{
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < bw * bh; i += gridDim.x * 256) {
+        const int y = i / bw, x = i % bw;
+        dst[y * dst_stride + x] = ref[dv::iclip(y0 + y, 0, ih - 1) * ref_stride + dv::iclip(x0 + x, 0, iw - 1)];
+    }
+}
+
+RefSet make_refs(const DevPlanes *refs, int n_refs) {
+    RefSet rs;
+    for (int i = 0; i < 8; i++) rs.r[i] = refs[i < n_refs ? i : 0];
+    return rs;
+}
+
+} // namespace
+
+extern "C" int dav1d_hip_launch_warp(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, const Dav1dHipWarpTask *tasks, int n,
+                                     int16_t *prep, void *stream)
+{
+    if (n <= 0) return 0;
+    const int bm = (1 << bpc) - 1;
+    if (bpc == 8) hipLaunchKernelGGL((warp_kernel<uint8_t>), dim3(n), dim3(64), 0, (hipStream_t) stream, *dst, make_refs(refs, n_refs), tasks, n, prep, bm);
+    else hipLaunchKernelGGL((warp_kernel<uint16_t>), dim3(n), dim3(64), 0, (hipStream_t) stream, *dst, make_refs(refs, n_refs), tasks, n, prep, bm);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int dav1d_hip_launch_mc_scaled(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc,
+                                          const Dav1dHipMcScaledTask *tasks, int n, int16_t *prep, void *stream)
+{
+    if (n <= 0) return 0;
+    const int bm = (1 << bpc) - 1;
+    if (bpc == 8) hipLaunchKernelGGL((mc_scaled_kernel<uint8_t>), dim3(n), dim3(64), 0, (hipStream_t) stream, *dst, make_refs(refs, n_refs), tasks, n, prep, bm);
+    else hipLaunchKernelGGL((mc_scaled_kernel<uint16_t>), dim3(n), dim3(64), 0, (hipStream_t) stream, *dst, make_refs(refs, n_refs), tasks, n, prep, bm);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int dav1d_hip_launch_resize(const DevPlanes *dst, const DevPlanes *src, int bpc, int plane, int dst_w, int y0, int h, int src_w,
+                                       int dx, int mx0, void *stream)
+{
+    const int bm = (1 << bpc) - 1;
+    const dim3 grid((dst_w + 255) / 256, h);
+    if (bpc == 8) hipLaunchKernelGGL((resize_kernel<uint8_t>), grid, dim3(256), 0, (hipStream_t) stream, *dst, *src, plane, dst_w, y0, h, src_w, dx, mx0, bm);
+    else hipLaunchKernelGGL((resize_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t) stream, *dst, *src, plane, dst_w, y0, h, src_w, dx, mx0, bm);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int dav1d_hip_launch_emu_edge(void *dst, ptrdiff_t dst_stride, const void *ref, ptrdiff_t ref_stride, int bw, int bh,
+                                         int iw, int ih, int x, int y, int bpc, void *stream)
+{
+    const int blocks = (bw * bh + 255) / 256;
+    if (bpc == 8) hipLaunchKernelGGL((emu_edge_kernel<uint8_t>), dim3(blocks), dim3(256), 0, (hipStream_t) stream, (uint8_t *) dst, (int) dst_stride,
+                                     (const uint8_t *) ref, (int) ref_stride, bw, bh, iw, ih, x, y);
+    else hipLaunchKernelGGL((emu_edge_kernel<uint16_t>), dim3(blocks), dim3(256), 0, (hipStream_t) stream, (uint16_t *) dst, (int) (dst_stride / 2),
+                            (const uint16_t *) ref, (int) (ref_stride / 2), bw, bh, iw, ih, x, y);
+    return hip_rc(hipGetLastError());
+}

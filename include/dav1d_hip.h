@@ -136,6 +136,8 @@ DAV1D_HIP_API int dav1d_hip_itx_list_run_timed(Dav1dHipContext *c, const Dav1dHi
 enum Dav1dHipMcKind {
     DAV1D_HIP_MC_PUT  = 0,  /* dsp->mc.mc[filter_2d]   -> pixels into dst plane   (reference src/mc_tmpl.c:129-187, 434-489) */
     DAV1D_HIP_MC_PREP = 1,  /* dsp->mc.mct[filter_2d]  -> int16 into the prep arena (reference src/mc_tmpl.c:246-305, 516-586) */
+    DAV1D_HIP_MC_PUT_TMP = 2, /* dsp->mc.mc[filter_2d] -> pixels into the scratch arena (row stride w): the `lap` predictions of
+                                 obmc() (reference src/recon_tmpl.c:1052-1112); the arena is the `prep` pointer viewed as pixels */
 };
 
 /* One motion-compensated prediction, replaces one call of mc() in the reference
@@ -185,6 +187,12 @@ enum Dav1dHipCompKind {
     DAV1D_HIP_COMP_WAVG = 1,   /* arg = weight (jnt_weight) */
     DAV1D_HIP_COMP_MASK = 2,   /* mask_off -> w*h bytes in the mask arena */
     DAV1D_HIP_COMP_WMASK = 3,  /* arg = sign; ss = 0:444 1:422 2:420; mask_off -> output mask */
+    /* dsp->mc.blend / blend_v / blend_h (reference src/mc_tmpl.c:682-722): dst = (dst*(64-m) + tmp*m + 32) >> 6 with
+     * tmp = w*h pixels at tmp1_off of the scratch arena (see DAV1D_HIP_MC_PUT_TMP); used by OBMC and inter-intra */
+    DAV1D_HIP_COMP_BLEND = 4,   /* mask_off -> w*h mask bytes */
+    DAV1D_HIP_COMP_BLEND_V = 5, /* obmc mask along x, first 3w/4 columns; run after every other kind of the same batch / list
+                                   (the order obmc() needs where a block's blend_h and blend_v areas overlap) */
+    DAV1D_HIP_COMP_BLEND_H = 6, /* obmc mask along y, first 3h/4 rows */
 };
 typedef struct Dav1dHipCompTask {
     uint32_t dst_off;   /* pixel offset in dst plane */
@@ -262,6 +270,60 @@ typedef struct Dav1dHipIpredTask {
 /* `tasks` HOST array; `pal_idx` DEVICE byte arena of packed palette indices (may be NULL). */
 DAV1D_HIP_API int dav1d_hip_ipred_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipIpredTask *tasks, size_t n,
                                         const uint8_t *pal_idx);
+
+/* ------------------------------------------------- mc: warp, scaled, resize, emu_edge */
+
+/* One 8x8 block of a warped prediction: dsp->mc.warp8x8 (kind PUT, pixels into dst) or warp8x8t (kind PREP, int16
+ * into the prep arena with row stride tmp_stride) as issued by warp_affine() (reference src/recon_tmpl.c:1115-1174;
+ * kernels src/mc_tmpl.c:799-866).  src_x / src_y = (dx, dy) of that driver, the integer position of the block's
+ * top-left in the reference plane; the 15x15 window around it is fetched with clamped coordinates (== the driver's
+ * emu_edge call at :1150-1160).  mx / my are the driver's values (already masked with ~0x3f). */
+typedef struct Dav1dHipWarpTask {
+    uint32_t dst_off;     /* PUT: pixel offset in dst plane; PREP: int16 offset in the prep arena */
+    int32_t  src_x, src_y;
+    int32_t  mx, my;
+    int16_t  abcd[4];
+    uint16_t tmp_stride;  /* PREP: row stride of the int16 output in elements */
+    uint8_t  kind;        /* DAV1D_HIP_MC_PUT or DAV1D_HIP_MC_PREP */
+    uint8_t  plane;
+    uint8_t  ref;
+    uint8_t  pad[3];
+} Dav1dHipWarpTask;
+DAV1D_HIP_API int dav1d_hip_warp_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *refs,
+                                       int n_refs, const Dav1dHipWarpTask *tasks, size_t n, int16_t *prep);
+
+/* One prediction from a reference of different size: dsp->mc.mc_scaled[filter_2d] (PUT) / mct_scaled[filter_2d]
+ * (PREP) as issued by the scaled branch of mc() (reference src/recon_tmpl.c:990-1047; kernels src/mc_tmpl.c:189-244,
+ * 307-357, 491-626).  src_x / src_y = (left, top) of that driver: the integer position in the reference plane that
+ * the kernels' `src` pointer addresses; mx / my = (pos_x & 0x3ff, pos_y & 0x3ff); dx / dy = the 1/1024 pel steps
+ * (svc[refidx][0].step, [1].step).  The window is fetched with clamped coordinates (== emu_edge, :1020-1032). */
+typedef struct Dav1dHipMcScaledTask {
+    uint32_t dst_off;     /* PUT: pixel offset in dst plane; PREP: int16 offset in the prep arena (row stride w) */
+    int32_t  src_x, src_y;
+    int16_t  mx, my;      /* 0..1023 */
+    int16_t  dx, dy;      /* step in 1/1024 pel: 512..2048 in valid AV1 */
+    uint8_t  w, h;        /* 2..128 */
+    uint8_t  filter_2d;   /* enum Filter2d (9 = bilinear) */
+    uint8_t  kind;        /* DAV1D_HIP_MC_PUT or DAV1D_HIP_MC_PREP */
+    uint8_t  plane;
+    uint8_t  ref;
+    uint8_t  pad[2];
+} Dav1dHipMcScaledTask;
+DAV1D_HIP_API int dav1d_hip_mc_scaled_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *refs,
+                                            int n_refs, const Dav1dHipMcScaledTask *tasks, size_t n, int16_t *prep);
+
+/* Horizontal super-resolution of one plane, replaces the per-row loop over dsp->mc.resize in dav1d_resize()
+ * (reference src/recon_tmpl.c:2024-2049 -> src/mc_tmpl.c:918-944): dst rows y0..y0+h-1, dst_w pixels each, from the same
+ * rows of src (src_w pixels each); dx = f->resize_step[ss_hor], mx0 = f->resize_start[ss_hor]. */
+DAV1D_HIP_API int dav1d_hip_resize(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src,
+                                   int plane, int dst_w, int y0, int h, int src_w, int dx, int mx0);
+
+/* Stand-alone dsp->mc.emu_edge (reference src/mc_tmpl.c:868-916), same argument meaning: a bw x bh block whose
+ * top-left sits at (x, y) of an iw x ih plane starting at `ref`, edge pixels replicated; strides in bytes, both
+ * pointers DEVICE memory.  (The batched mc / warp / scaled paths never need it: they clamp coordinates.) */
+DAV1D_HIP_API int dav1d_hip_emu_edge(Dav1dHipContext *c, int bpc, intptr_t bw, intptr_t bh, intptr_t iw, intptr_t ih,
+                                     intptr_t x, intptr_t y, void *dst, ptrdiff_t dst_stride,
+                                     const void *ref, ptrdiff_t ref_stride);
 
 /* --------------------------------------------------------------------- cdef */
 

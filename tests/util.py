@@ -85,6 +85,11 @@ PROTO = {
     "mask": [_vp, _pd, _vp, _vp, _i, _i, _vp],
     "w_mask": [_vp, _pd, _vp, _vp, _i, _i, _vp, _i],
     "emu_edge": [_pd, _pd, _pd, _pd, _pd, _pd, _vp, _pd, _vp, _pd],
+    "mc_scaled": [_vp, _pd, _vp, _pd, _i, _i, _i, _i, _i, _i],
+    "mct_scaled": [_vp, _vp, _pd, _i, _i, _i, _i, _i, _i],
+    "warp8x8": [_vp, _pd, _vp, _pd, _vp, _i, _i],
+    "warp8x8t": [_vp, _pd, _vp, _pd, _vp, _i, _i],
+    "resize": [_vp, _pd, _vp, _pd, _i, _i, _i, _i, _i],
     "blend": [_vp, _pd, _vp, _i, _i, _vp],
     "blend_v": [_vp, _pd, _vp, _i, _i],
     "blend_h": [_vp, _pd, _vp, _i, _i],
