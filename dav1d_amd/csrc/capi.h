@@ -103,7 +103,7 @@ extern "C" int dav1d_hip_launch_lf(const DevPlanes *dst, int bpc, const Dav1dHip
                                    int b4_stride, const uint8_t *lut_e, const uint8_t *lut_i, void *stream);
 
 extern "C" int dav1d_hip_launch_ipred(const DevPlanes *dst, int bpc, int layout, const Dav1dHipIpredTask *tasks, int n,
-                                      const uint8_t *pal_idx, void *stream);
+                                      uint8_t *pal_idx, void *stream);
 
 extern "C" int dav1d_hip_launch_wiener(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
                                        const Dav1dHipLrTask *tasks, int n, void *stream);
@@ -112,6 +112,10 @@ extern "C" int dav1d_hip_launch_fg_gen(int16_t *luts, const Dav1dHipFilmGrainDat
 extern "C" int dav1d_hip_launch_fg_apply(const DevPlanes *dst, const DevPlanes *src, const int16_t *luts, const uint8_t *scaling,
                                          int scaling_size, const Dav1dHipFilmGrainData *data, int bpc, int layout, int is_id, void *stream);
 
+extern "C" int dav1d_hip_launch_fg_gen_part(int16_t *luts, const Dav1dHipFilmGrainData *data, int bpc, int layout, int part, void *stream);
+extern "C" int dav1d_hip_launch_fg_apply_rows(const DevPlanes *dst, const DevPlanes *src, const int16_t *luts, const uint8_t *scaling,
+                                              int scaling_size, const Dav1dHipFilmGrainData *data, int bpc, int layout, int is_id,
+                                              int row_num, int pl, void *stream);
 extern "C" int dav1d_hip_launch_sgr(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
                                     const Dav1dHipLrTask *tasks, int n, void *stream);
 

@@ -666,14 +666,16 @@ extern "C" int dav1d_hip_lf_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst
 // -------------------------------------------------------------------- ipred
 
 extern "C" int dav1d_hip_ipred_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipIpredTask *tasks, size_t n,
-                                     const uint8_t *pal_idx) {
+                                     uint8_t *pal_idx) {
     if (!dst || (!tasks && n)) return -EINVAL;
     if (!n) return 0;
     for (size_t i = 0; i < n; i++) {
         const Dav1dHipIpredTask &t = tasks[i];
-        if (t.plane > 2 || t.kind > 2 || t.mode > 13 || !t.tw || !t.th || t.tw > 16 || t.th > 16) return -EINVAL;
-        if (t.kind == DAV1D_HIP_IPRED_PAL && !pal_idx) return -EINVAL;
-        if ((t.kind == DAV1D_HIP_IPRED_CFL || t.mode == 13) && (t.tw > 8 || t.th > 8)) return -EINVAL;   // both are limited to 32x32
+        if (t.plane > 2 || t.kind > DAV1D_HIP_IPRED_DSP_CFL_PRED || t.mode > 13 || !t.tw || !t.th || t.tw > 16 || t.th > 16) return -EINVAL;
+        if (t.kind >= DAV1D_HIP_IPRED_PAL && !pal_idx) return -EINVAL;
+        const bool cfl = t.kind == DAV1D_HIP_IPRED_CFL || t.kind >= DAV1D_HIP_IPRED_DSP_CFL_AC;
+        if ((cfl || (t.kind != DAV1D_HIP_IPRED_PAL && t.mode == 13)) && (t.tw > 8 || t.th > 8)) return -EINVAL;   // both are limited to 32x32
+        if (t.kind == DAV1D_HIP_IPRED_DSP_CFL_PRED && t.mode != 0 && (t.mode < 3 || t.mode > 5)) return -EINVAL;
     }
     Dav1dHipIpredTask *dev = nullptr;
     if (hipMalloc((void **) &dev, n * sizeof(*dev)) != hipSuccess) return -ENOMEM;

@@ -101,7 +101,9 @@ __device__ void gen_template(int16_t *lut, const int16_t *lut_y, const FgParams 
     }
 }
 
-__global__ __launch_bounds__(64) void fg_gen_kernel(int16_t *luts, const FgParams p, const int layout, const int bitdepth_min_8)
+// part 0: the luma template and every chroma template dav1d_apply_grain would build; part -1: generate_grain_y alone;
+// part 1 / 2: generate_grain_uv for that plane alone, the luma template it filters against taken from luts[0]
+__global__ __launch_bounds__(64) void fg_gen_kernel(int16_t *luts, const FgParams p, const int layout, const int bitdepth_min_8, const int part)
 {
     __shared__ uint16_t cols[16], rowstart[GH];
     __shared__ int16_t t_y[(GH + 1) * GW], t_c[(GH + 1) * GW];     // templates are built in LDS, then copied out
@@ -109,12 +111,17 @@ __global__ __launch_bounds__(64) void fg_gen_kernel(int16_t *luts, const FgParam
     const int subx = layout != DAV1D_HIP_LAYOUT_I444, suby = layout == DAV1D_HIP_LAYOUT_I420;
     for (int i = lane; i < (GH + 1) * GW; i += 64) t_y[i] = t_c[i] = 0;
     dv::wave_sync();
-    gen_template(t_y, t_y, p, 0, subx, suby, bitdepth_min_8, cols, rowstart, lane);
-    dv::wave_sync();
-    for (int i = lane; i < (GH + 1) * GW; i += 64) luts[i] = t_y[i];
+    if (part > 0) {
+        for (int i = lane; i < (GH + 1) * GW; i += 64) t_y[i] = luts[i];
+    } else {
+        gen_template(t_y, t_y, p, 0, subx, suby, bitdepth_min_8, cols, rowstart, lane);
+        dv::wave_sync();
+        for (int i = lane; i < (GH + 1) * GW; i += 64) luts[i] = t_y[i];
+    }
+    if (part < 0) return;
     for (int pl = 1; pl <= 2; pl++) {
         dv::wave_sync();
-        if (layout != DAV1D_HIP_LAYOUT_I400 && (p.num_uv_points[pl - 1] || p.chroma_scaling_from_luma)) {
+        if (part ? pl == part : (layout != DAV1D_HIP_LAYOUT_I400 && (p.num_uv_points[pl - 1] || p.chroma_scaling_from_luma))) {
             gen_template(t_c, t_y, p, pl, subx, suby, bitdepth_min_8, cols, rowstart, lane);
             dv::wave_sync();
             for (int i = lane; i < (GH + 1) * GW; i += 64) luts[pl * (GH + 1) * GW + i] = t_c[i];
@@ -134,9 +141,12 @@ __device__ __forceinline__ int sample_lut(const int16_t *lut, const int randval,
 template <typename pixel>
 __global__ __launch_bounds__(64) void fg_apply_kernel(const DevPlanes dst, const DevPlanes src, const int16_t *__restrict__ luts,
                                                       const uint8_t *__restrict__ scaling, const int scaling_size, const FgParams p,
-                                                      const int layout, const int is_id, const int bitdepth_max)
+                                                      const int layout, const int is_id, const int bitdepth_max,
+                                                      const int row_base, const int only_pl)
 {
-    const int bxi = blockIdx.x, row_num = blockIdx.y, pl = blockIdx.z;
+    // row_base / only_pl: the table-level entries run one block row of one plane on pictures that hold just that row
+    const int bxi = blockIdx.x, row_num = row_base + blockIdx.y, pl = only_pl < 0 ? (int) blockIdx.z : only_pl;
+    const int prow = blockIdx.y;          // block row inside the pictures
     const int lane = threadIdx.x;
     const int bitdepth_min_8 = (32 - __clz(bitdepth_max)) - 8;
     const int grain_ctr = 128 << bitdepth_min_8, grain_min = -grain_ctr, grain_max = grain_ctr - 1;
@@ -153,7 +163,7 @@ __global__ __launch_bounds__(64) void fg_apply_kernel(const DevPlanes dst, const
     // plane geometry
     const int pw = pl ? (src.w[0] + sx) >> sx : src.w[0];          // cpw / out->p.w
     const int ph_luma = src.h[0];
-    const int bh = pl ? (dv::imin(ph_luma - row_num * 32, 32) + sy) >> sy : dv::imin(ph_luma - row_num * 32, 32);
+    const int bh = pl ? (dv::imin(ph_luma - prow * 32, 32) + sy) >> sy : dv::imin(ph_luma - prow * 32, 32);
     const int bstep = 32 >> sx;
     const int bx = bxi * bstep;
     if (bx >= pw || bh <= 0) return;
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(64) void fg_apply_kernel(const DevPlanes dst, const
     const pixel *const sp = reinterpret_cast<const pixel *>(src.data[pl]);
     pixel *const dp = reinterpret_cast<pixel *>(dst.data[pl]);
     const pixel *const lp = reinterpret_cast<const pixel *>(src.data[0]);
-    const int y0 = pl ? (row_num * 32) >> sy : row_num * 32;
+    const int y0 = pl ? (prow * 32) >> sy : prow * 32;
 
     for (int i = lane; i < bw * bh; i += 64) {
         const int y = i / bw, x = i % bw;
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(64) void fg_apply_kernel(const DevPlanes dst, const
         } else {
             // luma co-located average; the reference extends the luma row by one pixel for odd widths
             // (src/fg_apply_tmpl.c:193-199)
-            const int lx = (bx + x) << sx, ly = (row_num * 32) + (y << sy);
+            const int lx = (bx + x) << sx, ly = (prow * 32) + (y << sy);
             const pixel *lrow = lp + ly * src.stride[0];
             int avg = lrow[dv::imin(lx, src.w[0] - 1)];
             if (sx) avg = (avg + lrow[dv::imin(lx + 1, src.w[0] - 1)] + 1) >> 1;
@@ -241,7 +251,13 @@ FgParams make_params(const Dav1dHipFilmGrainData *d) {
 
 extern "C" int dav1d_hip_launch_fg_gen(int16_t *luts, const Dav1dHipFilmGrainData *data, int bpc, int layout, void *stream)
 {
-    hipLaunchKernelGGL(fg_gen_kernel, dim3(1), dim3(64), 0, (hipStream_t) stream, luts, make_params(data), layout, bpc - 8);
+    hipLaunchKernelGGL(fg_gen_kernel, dim3(1), dim3(64), 0, (hipStream_t) stream, luts, make_params(data), layout, bpc - 8, 0);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int dav1d_hip_launch_fg_gen_part(int16_t *luts, const Dav1dHipFilmGrainData *data, int bpc, int layout, int part, void *stream)
+{
+    hipLaunchKernelGGL(fg_gen_kernel, dim3(1), dim3(64), 0, (hipStream_t) stream, luts, make_params(data), layout, bpc - 8, part);
     return hip_rc(hipGetLastError());
 }
 
@@ -252,8 +268,23 @@ extern "C" int dav1d_hip_launch_fg_apply(const DevPlanes *dst, const DevPlanes *
     const dim3 grid((src->w[0] + 31) / 32, (src->h[0] + 31) / 32, layout == DAV1D_HIP_LAYOUT_I400 ? 1 : 3);
     const FgParams p = make_params(data);
     if (bpc == 8)
-        hipLaunchKernelGGL((fg_apply_kernel<uint8_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max);
+        hipLaunchKernelGGL((fg_apply_kernel<uint8_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max, 0, -1);
     else
-        hipLaunchKernelGGL((fg_apply_kernel<uint16_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max);
+        hipLaunchKernelGGL((fg_apply_kernel<uint16_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max, 0, -1);
+    return hip_rc(hipGetLastError());
+}
+
+// one block row (`row_num`) of one plane, the pictures holding only that row
+extern "C" int dav1d_hip_launch_fg_apply_rows(const DevPlanes *dst, const DevPlanes *src, const int16_t *luts, const uint8_t *scaling,
+                                              int scaling_size, const Dav1dHipFilmGrainData *data, int bpc, int layout, int is_id,
+                                              int row_num, int pl, void *stream)
+{
+    const int bitdepth_max = (1 << bpc) - 1;
+    const dim3 grid((src->w[0] + 31) / 32, 1, 1);
+    const FgParams p = make_params(data);
+    if (bpc == 8)
+        hipLaunchKernelGGL((fg_apply_kernel<uint8_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max, row_num, pl);
+    else
+        hipLaunchKernelGGL((fg_apply_kernel<uint16_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max, row_num, pl);
     return hip_rc(hipGetLastError());
 }

@@ -66,8 +66,9 @@ __device__ __forceinline__ int upsample_edge_at(const int16_t *in, const int j, 
 
 template <typename pixel>
 __global__ __launch_bounds__(64) void ipred_kernel(const DevPlanes dst, const Dav1dHipIpredTask *__restrict__ tasks, const int n,
-                                                   const uint8_t *__restrict__ pal_idx, const int layout, const int bitdepth_max)
+                                                   uint8_t *aux, const int layout, const int bitdepth_max)
 {
+    const uint8_t *const pal_idx = aux;
     __shared__ int16_t e1[ESZ], e2[ESZ];
     __shared__ int16_t blk[32 * 32];
 
@@ -97,10 +98,19 @@ __global__ __launch_bounds__(64) void ipred_kernel(const DevPlanes dst, const Da
 
     // ---------------------------------------------------------------- mode mapping (prepare_intra_edges, :89-116)
     const bool have_left = t.flags & 1, have_top = t.flags & 2;
-    const bool edge_filter = t.flags & 16;
-    const int is_sm = (t.flags >> 5) & 1;
+    bool edge_filter = t.flags & 16;
+    int is_sm = (t.flags >> 5) & 1;
     int mode, angle = 0;
-    if (t.kind == DAV1D_HIP_IPRED_CFL) {
+    // DSP-level kinds: the caller did prepare_intra_edges, `mode` is the table index and the edge array sits in `aux`
+    const bool dsp_edge = t.kind == DAV1D_HIP_IPRED_DSP || t.kind == DAV1D_HIP_IPRED_DSP_CFL_PRED;
+    const bool is_cfl = t.kind == DAV1D_HIP_IPRED_CFL || t.kind == DAV1D_HIP_IPRED_DSP_CFL_AC || t.kind == DAV1D_HIP_IPRED_DSP_CFL_PRED;
+    if (dsp_edge) {
+        mode = t.mode;
+        const int raw = t.pal[0];                     // the `angle` argument with its flag bits (src/ipred_prepare.h:92-93)
+        angle = raw & 511; is_sm = (raw >> 9) & 1; edge_filter = (raw >> 10) & 1;
+    } else if (t.kind == DAV1D_HIP_IPRED_DSP_CFL_AC) {
+        mode = M_DC_128;
+    } else if (t.kind == DAV1D_HIP_IPRED_CFL) {
         mode = have_left ? (have_top ? M_DC : M_LEFT_DC) : (have_top ? M_TOP_DC : M_DC_128);
     } else if (t.mode >= 1 && t.mode <= 8) {
         const int base = t.mode == 1 ? 90 : t.mode == 2 ? 180 : t.mode == 3 ? 45 : t.mode == 4 ? 135 : t.mode == 5 ? 113 :
@@ -127,6 +137,12 @@ __global__ __launch_bounds__(64) void ipred_kernel(const DevPlanes dst, const Da
 
     // ---------------------------------------------------------------- edge gathering (:118-201)
     const pixel *const dtop = d - stride;
+    if (dsp_edge) {
+        const pixel *const edge = reinterpret_cast<const pixel *>(aux) + t.aux_off;
+        const int m = dv::imin(w, h);
+        for (int k = -(h + m) + lane; k <= w + m; k += 64) E[k] = (int16_t) edge[k];
+    } else if (t.kind == DAV1D_HIP_IPRED_DSP_CFL_AC) {
+    } else {
     if (n_left) {
         const int sz = h;
         if (have_left) {
@@ -180,16 +196,21 @@ __global__ __launch_bounds__(64) void ipred_kernel(const DevPlanes dst, const Da
         if (mode == M_Z2 && t.tw + t.th >= 6 && edge_filter) v = ((E[-1] + E[1]) * 5 + v * 6 + 8) >> 4;
         E[0] = (int16_t) v;
     }
+    }
     dv::wave_sync();
 
     // ---------------------------------------------------------------- CfL: ac from luma, then dc + alpha * ac
-    if (t.kind == DAV1D_HIP_IPRED_CFL) {
+    if (is_cfl) {
+        int16_t *const ac_mem = reinterpret_cast<int16_t *>(aux) + ((uint32_t) t.pal[1] | ((uint32_t) t.pal[2] << 16));
         const int ss_hor = layout != DAV1D_HIP_LAYOUT_I444, ss_ver = layout == DAV1D_HIP_LAYOUT_I420;
         const pixel *ypx = reinterpret_cast<const pixel *>(dst.data[0]) + t.aux_off;
         const int ys = dst.stride[0];
         const int w_pad = t.max_w, h_pad = t.max_h;           // CfL tasks reuse the fields for w_pad / h_pad (4-px units)
         const int wv = w - 4 * w_pad, hv = h - 4 * h_pad;
         int part = 0;
+        if (t.kind == DAV1D_HIP_IPRED_DSP_CFL_PRED) {
+            for (int i = lane; i < w * h; i += 64) blk[i] = ac_mem[i];
+        } else
         for (int i = lane; i < w * h; i += 64) {
             const int y = i / w, x = i % w;
             const int xs = dv::imin(x, wv - 1), yy = dv::imin(y, hv - 1);     // padding replicates the last visible column / row
@@ -202,7 +223,11 @@ __global__ __launch_bounds__(64) void ipred_kernel(const DevPlanes dst, const Da
             part += v;
         }
         const int log2sz = __builtin_ctz(w) + __builtin_ctz(h);
-        const int mean = (wave_sum(part) + ((1 << log2sz) >> 1)) >> log2sz;
+        const int mean = t.kind == DAV1D_HIP_IPRED_DSP_CFL_PRED ? 0 : (wave_sum(part) + ((1 << log2sz) >> 1)) >> log2sz;
+        if (t.kind == DAV1D_HIP_IPRED_DSP_CFL_AC) {
+            for (int i = lane; i < w * h; i += 64) ac_mem[i] = (int16_t) (blk[i] - mean);
+            return;
+        }
         int dc;
         if (mode == M_DC_128) dc = (bitdepth_max + 1) >> 1;
         else {
@@ -398,7 +423,7 @@ __global__ __launch_bounds__(64) void ipred_kernel(const DevPlanes dst, const Da
 } // namespace
 
 extern "C" int dav1d_hip_launch_ipred(const DevPlanes *dst, int bpc, int layout, const Dav1dHipIpredTask *tasks, int n,
-                                      const uint8_t *pal_idx, void *stream)
+                                      uint8_t *pal_idx, void *stream)
 {
     if (n <= 0) return 0;
     const int bitdepth_max = (1 << bpc) - 1;

@@ -245,6 +245,13 @@ enum Dav1dHipIpredKind {
     DAV1D_HIP_IPRED_PRED = 0,  /* dav1d_prepare_intra_edges + dsp->ipred.intra_pred[m]  (src/recon_tmpl.c:1256-1283) */
     DAV1D_HIP_IPRED_CFL = 1,   /* prepare (DC_PRED) + dsp->ipred.cfl_ac[layout-1] + cfl_pred[m]  (src/recon_tmpl.c:1367-1393) */
     DAV1D_HIP_IPRED_PAL = 2,   /* dsp->ipred.pal_pred  (src/recon_tmpl.c:1207-1224, 1395-1413) */
+    /* Table-level kinds, one DSP entry each with the caller having run dav1d_prepare_intra_edges (used by the
+     * reference-signature table; `aux` is then a scratch arena holding the prepared edge array / the ac block): */
+    DAV1D_HIP_IPRED_DSP = 3,          /* intra_pred[mode]: mode = table index (0..13), pal[0] = the `angle` argument with its flag
+                                         bits, aux_off = pixel offset of `topleft` in aux (elements -(h+min(w,h)) .. w+min(w,h) are read) */
+    DAV1D_HIP_IPRED_DSP_CFL_AC = 4,   /* cfl_ac[layout - 1]: luma at aux_off of plane 0, max_w / max_h = w_pad / h_pad, output tw*4 x th*4
+                                         int16 (row stride = width) at int16 offset pal[1] | pal[2] << 16 of aux */
+    DAV1D_HIP_IPRED_DSP_CFL_PRED = 5, /* cfl_pred[mode] (mode 0, 3, 4, 5): edge as DSP, ac as CFL_AC's output, angle = alpha */
 };
 
 /* One intra prediction of one transform block.  Field names follow the arguments of
@@ -267,9 +274,10 @@ typedef struct Dav1dHipIpredTask {
     uint16_t pal[8];     /* PAL: the palette */
 } Dav1dHipIpredTask;
 
-/* `tasks` HOST array; `pal_idx` DEVICE byte arena of packed palette indices (may be NULL). */
+/* `tasks` HOST array; `aux` DEVICE byte arena: packed palette indices for PAL tasks, scratch for the table-level
+ * kinds (may be NULL when neither is used). */
 DAV1D_HIP_API int dav1d_hip_ipred_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipIpredTask *tasks, size_t n,
-                                        const uint8_t *pal_idx);
+                                        uint8_t *aux);
 
 /* ------------------------------------------------- mc: warp, scaled, resize, emu_edge */
 
@@ -436,68 +444,133 @@ DAV1D_HIP_API int dav1d_hip_fg_generate_grain(Dav1dHipContext *c, const Dav1dHip
 
 /* ------------------------------------------------- reference-signature table */
 
-/* Function pointer types with the reference's exact signatures (16 bpc flavour
- * carries the trailing bitdepth_max, 8 bpc does not; reference src/itx.h:37-40,
- * src/mc.h:38-122).  Pointers are HOST pointers. */
-typedef void (*dav1d_hip_itxfm_fn8)(uint8_t *dst, ptrdiff_t stride, int16_t *coeff, int eob);
-typedef void (*dav1d_hip_itxfm_fn16)(uint16_t *dst, ptrdiff_t stride, int32_t *coeff, int eob, int bitdepth_max);
-typedef void (*dav1d_hip_mc_fn8)(uint8_t *dst, ptrdiff_t dst_stride, const uint8_t *src, ptrdiff_t src_stride,
-                                 int w, int h, int mx, int my);
-typedef void (*dav1d_hip_mc_fn16)(uint16_t *dst, ptrdiff_t dst_stride, const uint16_t *src, ptrdiff_t src_stride,
-                                  int w, int h, int mx, int my, int bitdepth_max);
-typedef void (*dav1d_hip_mct_fn8)(int16_t *tmp, const uint8_t *src, ptrdiff_t src_stride,
-                                  int w, int h, int mx, int my);
-typedef void (*dav1d_hip_mct_fn16)(int16_t *tmp, const uint16_t *src, ptrdiff_t src_stride,
-                                   int w, int h, int mx, int my, int bitdepth_max);
-typedef void (*dav1d_hip_avg_fn8)(uint8_t *dst, ptrdiff_t dst_stride, const int16_t *tmp1, const int16_t *tmp2, int w, int h);
-typedef void (*dav1d_hip_avg_fn16)(uint16_t *dst, ptrdiff_t dst_stride, const int16_t *tmp1, const int16_t *tmp2, int w, int h,
-                                   int bitdepth_max);
-typedef void (*dav1d_hip_w_avg_fn8)(uint8_t *dst, ptrdiff_t dst_stride, const int16_t *tmp1, const int16_t *tmp2, int w, int h,
-                                    int weight);
-typedef void (*dav1d_hip_w_avg_fn16)(uint16_t *dst, ptrdiff_t dst_stride, const int16_t *tmp1, const int16_t *tmp2, int w, int h,
-                                     int weight, int bitdepth_max);
-typedef void (*dav1d_hip_mask_fn8)(uint8_t *dst, ptrdiff_t dst_stride, const int16_t *tmp1, const int16_t *tmp2, int w, int h,
-                                   const uint8_t *mask);
-typedef void (*dav1d_hip_mask_fn16)(uint16_t *dst, ptrdiff_t dst_stride, const int16_t *tmp1, const int16_t *tmp2, int w, int h,
-                                    const uint8_t *mask, int bitdepth_max);
-typedef void (*dav1d_hip_w_mask_fn8)(uint8_t *dst, ptrdiff_t dst_stride, const int16_t *tmp1, const int16_t *tmp2, int w, int h,
-                                     uint8_t *mask, int sign);
-typedef void (*dav1d_hip_w_mask_fn16)(uint16_t *dst, ptrdiff_t dst_stride, const int16_t *tmp1, const int16_t *tmp2, int w, int h,
-                                      uint8_t *mask, int sign, int bitdepth_max);
+/* The kernel-level drop-in: function pointer types with the reference's exact signatures and a table whose
+ * layout is the reference's Dav1dDSPContext (src/internal.h:62-70: fg, ipred, mc, itx, lf, cdef, lr; members in the
+ * order of src/filmgrain.h:74-80, src/ipred.h:81-90, src/mc.h:146-162, src/itx.h:70-72, src/loopfilter.h:45-53,
+ * src/cdef.h:64-67, src/looprestoration.h:72-75), so `&c->dsp[bits]` of the reference can be handed to
+ * dav1d_hip_dsp_init_* as is.  The 16 bpc flavour carries the trailing bitdepth_max (HIGHBD_DECL_SUFFIX), the 8 bpc
+ * one does not; pixel = uint8_t / uint16_t, coef = int16_t / int32_t, grain entry = int8_t / int16_t
+ * (include/common/bitdepth.h:44-63, src/filmgrain.h:36-44).  All pointers are HOST pointers: each call stages its
+ * rectangles on the device, runs the same kernels the batched API runs, and copies the result back. */
+#define DAV1D_HIP_ALIGN16 __attribute__((aligned(16)))
+typedef struct Dav1dHipFilterLUT {      /* == Av1FilterLUT, reference src/lf_mask.h:36-40 */
+    DAV1D_HIP_ALIGN16 uint8_t e[64];
+    DAV1D_HIP_ALIGN16 uint8_t i[64];
+    DAV1D_HIP_ALIGN16 uint64_t sharp[2];
+} Dav1dHipFilterLUT;
+typedef union Dav1dHipLrParams {        /* == LooprestorationParams, reference src/looprestoration.h:49-55 */
+    DAV1D_HIP_ALIGN16 int16_t filter[2][8];
+    struct { uint32_t s0, s1; int16_t w0, w1; } sgr;
+} Dav1dHipLrParams;
 
 #define DAV1D_HIP_N_RECT_TX_SIZES 19
 #define DAV1D_HIP_N_TX_TYPES_PLUS_LL 17
 #define DAV1D_HIP_N_2D_FILTERS 10
+#define DAV1D_HIP_N_IMPL_INTRA_PRED_MODES 14
+#define DAV1D_HIP_GRAIN_WIDTH 82
 
-/* Mirrors of the reference's per-family tables (member names follow the reference
- * structs: src/itx.h:70-72, src/mc.h:146-162).  Entries the backend does not
- * provide yet are NULL. */
-typedef struct Dav1dHipInvTxfmDSPContext8 { dav1d_hip_itxfm_fn8 itxfm_add[DAV1D_HIP_N_RECT_TX_SIZES][DAV1D_HIP_N_TX_TYPES_PLUS_LL]; } Dav1dHipInvTxfmDSPContext8;
-typedef struct Dav1dHipInvTxfmDSPContext16 { dav1d_hip_itxfm_fn16 itxfm_add[DAV1D_HIP_N_RECT_TX_SIZES][DAV1D_HIP_N_TX_TYPES_PLUS_LL]; } Dav1dHipInvTxfmDSPContext16;
-typedef struct Dav1dHipMCDSPContext8 {
-    dav1d_hip_mc_fn8 mc[DAV1D_HIP_N_2D_FILTERS];
-    dav1d_hip_mct_fn8 mct[DAV1D_HIP_N_2D_FILTERS];
-    dav1d_hip_avg_fn8 avg;
-    dav1d_hip_w_avg_fn8 w_avg;
-    dav1d_hip_mask_fn8 mask;
-    dav1d_hip_w_mask_fn8 w_mask[3];
-} Dav1dHipMCDSPContext8;
-typedef struct Dav1dHipMCDSPContext16 {
-    dav1d_hip_mc_fn16 mc[DAV1D_HIP_N_2D_FILTERS];
-    dav1d_hip_mct_fn16 mct[DAV1D_HIP_N_2D_FILTERS];
-    dav1d_hip_avg_fn16 avg;
-    dav1d_hip_w_avg_fn16 w_avg;
-    dav1d_hip_mask_fn16 mask;
-    dav1d_hip_w_mask_fn16 w_mask[3];
-} Dav1dHipMCDSPContext16;
+#define DAV1D_HIP_BD_NONE
+#define DAV1D_HIP_BD_MAX , int bitdepth_max
+#define DAV1D_HIP_DSP_TABLE(B, pixel, coef, entry, BD) \
+typedef void (*dav1d_hip_itxfm_fn##B)(pixel *dst, ptrdiff_t stride, coef *coeff, int eob BD); \
+typedef void (*dav1d_hip_mc_fn##B)(pixel *dst, ptrdiff_t dst_stride, const pixel *src, ptrdiff_t src_stride, int w, int h, int mx, int my BD); \
+typedef void (*dav1d_hip_mc_scaled_fn##B)(pixel *dst, ptrdiff_t dst_stride, const pixel *src, ptrdiff_t src_stride, int w, int h, \
+                                          int mx, int my, int dx, int dy BD); \
+typedef void (*dav1d_hip_mct_fn##B)(int16_t *tmp, const pixel *src, ptrdiff_t src_stride, int w, int h, int mx, int my BD); \
+typedef void (*dav1d_hip_mct_scaled_fn##B)(int16_t *tmp, const pixel *src, ptrdiff_t src_stride, int w, int h, int mx, int my, \
+                                           int dx, int dy BD); \
+typedef void (*dav1d_hip_avg_fn##B)(pixel *dst, ptrdiff_t dst_stride, const int16_t *tmp1, const int16_t *tmp2, int w, int h BD); \
+typedef void (*dav1d_hip_w_avg_fn##B)(pixel *dst, ptrdiff_t dst_stride, const int16_t *tmp1, const int16_t *tmp2, int w, int h, int weight BD); \
+typedef void (*dav1d_hip_mask_fn##B)(pixel *dst, ptrdiff_t dst_stride, const int16_t *tmp1, const int16_t *tmp2, int w, int h, \
+                                     const uint8_t *mask BD); \
+typedef void (*dav1d_hip_w_mask_fn##B)(pixel *dst, ptrdiff_t dst_stride, const int16_t *tmp1, const int16_t *tmp2, int w, int h, \
+                                       uint8_t *mask, int sign BD); \
+typedef void (*dav1d_hip_blend_fn##B)(pixel *dst, ptrdiff_t dst_stride, const pixel *tmp, int w, int h, const uint8_t *mask); \
+typedef void (*dav1d_hip_blend_dir_fn##B)(pixel *dst, ptrdiff_t dst_stride, const pixel *tmp, int w, int h); \
+typedef void (*dav1d_hip_warp8x8_fn##B)(pixel *dst, ptrdiff_t dst_stride, const pixel *src, ptrdiff_t src_stride, const int16_t *abcd, \
+                                        int mx, int my BD); \
+typedef void (*dav1d_hip_warp8x8t_fn##B)(int16_t *tmp, ptrdiff_t tmp_stride, const pixel *src, ptrdiff_t src_stride, const int16_t *abcd, \
+                                         int mx, int my BD); \
+typedef void (*dav1d_hip_emu_edge_fn##B)(intptr_t bw, intptr_t bh, intptr_t iw, intptr_t ih, intptr_t x, intptr_t y, \
+                                         pixel *dst, ptrdiff_t dst_stride, const pixel *src, ptrdiff_t src_stride); \
+typedef void (*dav1d_hip_resize_fn##B)(pixel *dst, ptrdiff_t dst_stride, const pixel *src, ptrdiff_t src_stride, int dst_w, int h, \
+                                       int src_w, int dx, int mx BD); \
+typedef void (*dav1d_hip_angular_ipred_fn##B)(pixel *dst, ptrdiff_t stride, const pixel *topleft, int width, int height, int angle, \
+                                              int max_width, int max_height BD); \
+typedef void (*dav1d_hip_cfl_ac_fn##B)(int16_t *ac, const pixel *y, ptrdiff_t stride, int w_pad, int h_pad, int cw, int ch); \
+typedef void (*dav1d_hip_cfl_pred_fn##B)(pixel *dst, ptrdiff_t stride, const pixel *topleft, int width, int height, const int16_t *ac, \
+                                         int alpha BD); \
+typedef void (*dav1d_hip_pal_pred_fn##B)(pixel *dst, ptrdiff_t stride, const pixel *pal, const uint8_t *idx, int w, int h); \
+typedef void (*dav1d_hip_loopfilter_sb_fn##B)(pixel *dst, ptrdiff_t stride, const uint32_t *mask, const uint8_t (*lvl)[4], \
+                                              ptrdiff_t lvl_stride, const Dav1dHipFilterLUT *lut, int w BD); \
+typedef int (*dav1d_hip_cdef_dir_fn##B)(const pixel *dst, ptrdiff_t dst_stride, unsigned *var BD); \
+typedef void (*dav1d_hip_cdef_fn##B)(pixel *dst, ptrdiff_t stride, const pixel (*left)[2], const pixel *top, const pixel *bottom, \
+                                     int pri_strength, int sec_strength, int dir, int damping, int edges BD); \
+typedef void (*dav1d_hip_lr_fn##B)(pixel *dst, ptrdiff_t dst_stride, const pixel (*left)[4], const pixel *lpf, int w, int h, \
+                                   const Dav1dHipLrParams *params, int edges BD); \
+typedef void (*dav1d_hip_generate_grain_y_fn##B)(entry buf[][DAV1D_HIP_GRAIN_WIDTH], const Dav1dHipFilmGrainData *data BD); \
+typedef void (*dav1d_hip_generate_grain_uv_fn##B)(entry buf[][DAV1D_HIP_GRAIN_WIDTH], const entry buf_y[][DAV1D_HIP_GRAIN_WIDTH], \
+                                                  const Dav1dHipFilmGrainData *data, intptr_t uv BD); \
+typedef void (*dav1d_hip_fgy_32x32xn_fn##B)(pixel *dst_row, const pixel *src_row, ptrdiff_t stride, const Dav1dHipFilmGrainData *data, \
+                                            size_t pw, const uint8_t *scaling, const entry grain_lut[][DAV1D_HIP_GRAIN_WIDTH], \
+                                            int bh, int row_num BD); \
+typedef void (*dav1d_hip_fguv_32x32xn_fn##B)(pixel *dst_row, const pixel *src_row, ptrdiff_t stride, const Dav1dHipFilmGrainData *data, \
+                                             size_t pw, const uint8_t *scaling, const entry grain_lut[][DAV1D_HIP_GRAIN_WIDTH], \
+                                             int bh, int row_num, const pixel *luma_row, ptrdiff_t luma_stride, int uv_pl, int is_id BD); \
+typedef struct Dav1dHipFilmGrainDSPContext##B { \
+    dav1d_hip_generate_grain_y_fn##B generate_grain_y; \
+    dav1d_hip_generate_grain_uv_fn##B generate_grain_uv[3]; \
+    dav1d_hip_fgy_32x32xn_fn##B fgy_32x32xn; \
+    dav1d_hip_fguv_32x32xn_fn##B fguv_32x32xn[3]; \
+} Dav1dHipFilmGrainDSPContext##B; \
+typedef struct Dav1dHipIntraPredDSPContext##B { \
+    dav1d_hip_angular_ipred_fn##B intra_pred[DAV1D_HIP_N_IMPL_INTRA_PRED_MODES]; \
+    dav1d_hip_cfl_ac_fn##B cfl_ac[3]; \
+    dav1d_hip_cfl_pred_fn##B cfl_pred[6];    /* DC_PRED, -, -, LEFT_DC_PRED, TOP_DC_PRED, DC_128_PRED */ \
+    dav1d_hip_pal_pred_fn##B pal_pred; \
+} Dav1dHipIntraPredDSPContext##B; \
+typedef struct Dav1dHipMCDSPContext##B { \
+    dav1d_hip_mc_fn##B mc[DAV1D_HIP_N_2D_FILTERS]; \
+    dav1d_hip_mc_scaled_fn##B mc_scaled[DAV1D_HIP_N_2D_FILTERS]; \
+    dav1d_hip_mct_fn##B mct[DAV1D_HIP_N_2D_FILTERS]; \
+    dav1d_hip_mct_scaled_fn##B mct_scaled[DAV1D_HIP_N_2D_FILTERS]; \
+    dav1d_hip_avg_fn##B avg; \
+    dav1d_hip_w_avg_fn##B w_avg; \
+    dav1d_hip_mask_fn##B mask; \
+    dav1d_hip_w_mask_fn##B w_mask[3]; \
+    dav1d_hip_blend_fn##B blend; \
+    dav1d_hip_blend_dir_fn##B blend_v; \
+    dav1d_hip_blend_dir_fn##B blend_h; \
+    dav1d_hip_warp8x8_fn##B warp8x8; \
+    dav1d_hip_warp8x8t_fn##B warp8x8t; \
+    dav1d_hip_emu_edge_fn##B emu_edge; \
+    dav1d_hip_resize_fn##B resize; \
+} Dav1dHipMCDSPContext##B; \
+typedef struct Dav1dHipInvTxfmDSPContext##B { \
+    dav1d_hip_itxfm_fn##B itxfm_add[DAV1D_HIP_N_RECT_TX_SIZES][DAV1D_HIP_N_TX_TYPES_PLUS_LL]; \
+} Dav1dHipInvTxfmDSPContext##B; \
+typedef struct Dav1dHipLoopFilterDSPContext##B { dav1d_hip_loopfilter_sb_fn##B loop_filter_sb[2][2]; } Dav1dHipLoopFilterDSPContext##B; \
+typedef struct Dav1dHipCdefDSPContext##B { dav1d_hip_cdef_dir_fn##B dir; dav1d_hip_cdef_fn##B fb[3]; } Dav1dHipCdefDSPContext##B; \
+typedef struct Dav1dHipLoopRestorationDSPContext##B { dav1d_hip_lr_fn##B wiener[2]; dav1d_hip_lr_fn##B sgr[3]; } \
+    Dav1dHipLoopRestorationDSPContext##B; \
+typedef struct Dav1dHipDSPContext##B { \
+    Dav1dHipFilmGrainDSPContext##B fg; \
+    Dav1dHipIntraPredDSPContext##B ipred; \
+    Dav1dHipMCDSPContext##B mc; \
+    Dav1dHipInvTxfmDSPContext##B itx; \
+    Dav1dHipLoopFilterDSPContext##B lf; \
+    Dav1dHipCdefDSPContext##B cdef; \
+    Dav1dHipLoopRestorationDSPContext##B lr; \
+} Dav1dHipDSPContext##B;
 
-typedef struct Dav1dHipDSPContext8 { Dav1dHipMCDSPContext8 mc; Dav1dHipInvTxfmDSPContext8 itx; } Dav1dHipDSPContext8;
-typedef struct Dav1dHipDSPContext16 { Dav1dHipMCDSPContext16 mc; Dav1dHipInvTxfmDSPContext16 itx; } Dav1dHipDSPContext16;
+DAV1D_HIP_DSP_TABLE(8, uint8_t, int16_t, int8_t, DAV1D_HIP_BD_NONE)
+DAV1D_HIP_DSP_TABLE(16, uint16_t, int32_t, int16_t, DAV1D_HIP_BD_MAX)
 
-/* Counterparts of dav1d_{itx,mc}_dsp_init_{8,16}bpc (reference src/decode.c:3387-3415,
- * src/itx_tmpl.c:220-311, src/mc_tmpl.c:960-1006).  They bind the table to the
- * process-wide default context (device 0 unless DAV1D_HIP_DEVICE is set), opened on
- * first use; they return -ENODEV when that fails and leave the table zeroed. */
+/* Counterparts of dav1d_{film_grain,intra_pred,mc,itx,loop_filter,cdef,loop_restoration}_dsp_init_{8,16}bpc (reference
+ * src/lib.c:83-117 / src/decode.c:3387-3415): every entry of the table is overwritten with the HIP-backed function
+ * (illegal itxfm_add combinations stay NULL, as in src/itx_tmpl.c:220-311).  They bind the table to the process-wide
+ * default context (device 0 unless DAV1D_HIP_DEVICE is set), opened on first use; they return -ENODEV when that
+ * fails and leave the table zeroed -- there is no CPU fallback. */
 DAV1D_HIP_API int dav1d_hip_dsp_init_8bpc(Dav1dHipDSPContext8 *c);
 DAV1D_HIP_API int dav1d_hip_dsp_init_16bpc(Dav1dHipDSPContext16 *c, int bpc);
 

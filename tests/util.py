@@ -138,6 +138,14 @@ class Oracle:
         return f(*a)
 
 
+def ref_table(name, dtype):
+    """A constant table of the reference build (oracle/ref_shim.c) as a numpy array."""
+    sz = C.c_size_t(0)
+    p = ref_lib().dav1d_ref_table(name.encode(), C.byref(sz))
+    assert p, name
+    return np.frombuffer((C.c_uint8 * sz.value).from_address(p), dtype=dtype).copy()
+
+
 def available_oracles():
     out = []
     if ref_lib() is not None:
