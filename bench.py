@@ -100,7 +100,8 @@ def main():
     ctx = api.Context(local, stream=stream.cuda_stream)
     w, h, bpc = a.width, a.height, a.bpc
     t_gen = time.time()
-    frame = synth.make_frame(w, h, bpc, seed=0xDA71D002 + rank, mv_range_px=a.mv_range, edge_frac=a.edge_frac)
+    frame = synth.make_frame(w, h, bpc, seed=0xDA71D002 + rank, mv_range_px=a.mv_range, edge_frac=a.edge_frac,
+                             n_refs=int(os.environ.get("BENCH_N_REFS", "3")))
     rng = np.random.default_rng(1234 + rank)
     ref_host = [synth.make_planes(rng, w, h, bpc) for _ in range(frame.n_refs)]
     dst_host = synth.make_planes(rng, w, h, bpc, smooth=False)

@@ -5,6 +5,8 @@
 #include <string.h>
 #include <mutex>
 #include <new>
+#include <algorithm>
+#include <vector>
 
 extern "C" {
 
@@ -350,6 +352,21 @@ static int mc_list_from_bins(Dav1dHipContext *c, Dav1dHipMcList **out, std::vect
     Dav1dHipMcList *l = new (std::nothrow) Dav1dHipMcList();
     if (!l) return -ENOMEM;
     memset(l, 0, sizeof(*l));
+    // Order the tiles of a bin by where they READ: (reference, plane, 64-row band, x).  The fetch of a tile is
+    // row-granular (a 128-byte line per window row), so tiles that land on the same lines should run back to back on
+    // one XCD while those lines sit in its L2; dst writes stay local because MVs are short.  Speed only.
+    static const int sort_mode = getenv("DAV1D_HIP_MC_SORT") ? atoi(getenv("DAV1D_HIP_MC_SORT")) : 1;
+    if (sort_mode) {
+        auto key = [](const McTile &t) -> uint64_t {
+            const McRef &r = t.r[0];
+            const uint64_t y = (uint64_t) (r.src_y + 4096) & 0xffff, x = (uint64_t) (r.src_x + 4096) & 0xffff;
+            if (sort_mode == 2) return ((uint64_t) r.ref << 56) | ((uint64_t) t.plane << 52) | ((x >> 9) << 40) | (y << 16) | x;
+            if (sort_mode == 3) return ((uint64_t) t.plane << 52) | ((y >> 6) << 32) | (x << 8) | r.ref;
+            return ((uint64_t) r.ref << 56) | ((uint64_t) t.plane << 52) | ((y >> 6) << 32) | x;
+        };
+        for (int b = 0; b < MC_BINS; b++)
+            std::stable_sort(bins[b].begin(), bins[b].end(), [&](const McTile &p, const McTile &q) { return key(p) < key(q); });
+    }
     std::vector<McTile> all;
     for (int b = 0; b < MC_BINS; b++) {
         l->off[b] = all.size();
@@ -517,6 +534,7 @@ int dav1d_hip_comp_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const D
 // registers, nothing written to the prep arena).  MASK / W_MASK compounds keep the
 // two-step form.
 #include <unordered_map>
+#include <algorithm>
 
 struct Dav1dHipInterList {
     Dav1dHipMcList *mc;

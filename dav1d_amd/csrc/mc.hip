@@ -82,8 +82,22 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSe
     const bool live = ti < n;
 
     McTile t;
-    if (G == 1) t = tiles[__builtin_amdgcn_readfirstlane(live ? ti : 0)];
-    else t = tiles[live ? ti : 0];
+    if (G == 1) {
+        t = tiles[__builtin_amdgcn_readfirstlane(live ? ti : 0)];
+    } else {
+        // the G records of the wave come in with one coalesced sweep and are handed to their lanes through LDS
+        constexpr int RW = sizeof(McTile) / 4;
+        __shared__ __attribute__((aligned(16))) uint32_t rec_s[G * RW];
+        const int t0 = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x) * G;
+        const uint32_t *recs = reinterpret_cast<const uint32_t *>(tiles + t0);
+        const int nw = dv::imin(G, n - t0) * RW;
+        for (int i = lane; i < nw; i += 64) rec_s[i] = recs[i];
+        dv::wave_sync();
+        const uint32_t *rp = rec_s + (live ? sub : 0) * RW;
+        uint32_t *tw_ = reinterpret_cast<uint32_t *>(&t);
+#pragma unroll
+        for (int i = 0; i < RW; i++) tw_[i] = rp[i];
+    }
 
     int16_t *const win = win_s + sub * WR * WS;
     uint32_t *const mid = mid_s + sub * NPR * TW;
@@ -105,6 +119,10 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSe
         const bool has_h = rf.mx != 0, has_v = rf.my != 0;
         const int fbits = rf.fh == 6 ? 4 : 6;
         const Taps fh = load_taps(rf.fh, rf.mx), fv = load_taps(rf.fv, rf.my);
+        // window rows the vertical taps can reach: the others only ever meet zero taps, so they are neither
+        // fetched nor filtered (6-tap regular, 4-tap smooth / small blocks, 2-tap bilinear, 1-tap full-pel)
+        const int vspan = av1_mc_tap_span[rf.fv * 16 + rf.my];
+        const int row_lo = vspan & 15, row_hi = TH - 1 + (vspan >> 4);
 
         // ---- 1. gather the window
         if (live) {
@@ -122,6 +140,8 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSe
                 for (int k = 0; k < NLD; k++) {
                     const int i = dv::imin(l + k * LPT, (WR - 1) * NCH - 1);
                     const pixel *p = base + (i / NCH) * rs + 8 * (i % NCH);
+                    ld[k] = make_uint4(0, 0, 0, 0);
+                    if (i / NCH < row_lo || i / NCH >= row_hi) continue;
                     if (HBD) {
                         const U128u v = *reinterpret_cast<const U128u *>(p);
                         ld[k] = make_uint4(v.a, v.b, v.c, v.d);
@@ -166,6 +186,7 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSe
                 const int it = it0 + l;
                 if (it >= NPR * NS) break;
                 const int pr = it / NS, s = it % NS;
+                if (2 * pr + 1 < row_lo || 2 * pr >= row_hi) continue;
                 int o[2][4];
 #pragma unroll
                 for (int e = 0; e < 2; e++) {

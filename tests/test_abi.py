@@ -60,7 +60,7 @@ def test_device_tables_equal_reference_tables():
     txt = open(os.path.join(util.ROOT, "dav1d_amd", "csrc", "av1_tables.h")).read()
     for m in re.finditer(r"AV1_TABLE_QUAL (\w+) av1_(\w+)\[(\d+)\] = \{[^\n]*\n(.*?)\};", txt, re.S):
         ctype, name, n, body = m.group(1), m.group(2), int(m.group(3)), m.group(4)
-        if name == "mc_taps_packed":
+        if name in ("mc_taps_packed", "mc_tap_span"):
             continue                      # derived table, checked in test_packed_taps_match_subpel_filters
         vals = np.array([int(v) for v in body.replace("\n", " ").split(",") if v.strip()])
         dt = {"int8_t": np.int8, "uint8_t": np.uint8, "int16_t": np.int16, "uint16_t": np.uint16}[ctype]
@@ -88,3 +88,9 @@ def test_packed_taps_match_subpel_filters():
             want = [(f[2 * k] & 0xffff) | ((f[2 * k + 1] & 0xffff) << 16) for k in range(4)] + \
                    [(g[2 * k] & 0xffff) | ((g[2 * k + 1] & 0xffff) << 16) for k in range(5)]
             assert list(packed[fs, m]) == want, (fs, m)
+    span = np.array(table("mc_tap_span")).reshape(7, 16)
+    for fs in range(7):
+        for m in range(16):
+            f = [0, 0, 0, 1, 0, 0, 0, 0] if m == 0 else ([0, 0, 0, 16 - m, m, 0, 0, 0] if fs == 6 else list(filt[fs, m - 1]))
+            lo, hi = span[fs, m] & 15, span[fs, m] >> 4
+            assert all(v == 0 for v in f[:lo]) and all(v == 0 for v in f[hi:]) and f[lo] and f[hi - 1], (fs, m)
