@@ -91,6 +91,14 @@ struct McTile {
     int8_t   weight;      // WAVG
     McRef    r[2];
 };
+// a wave-sized run of tiles of one shape inside the source-ordered tile list (all-shapes launch)
+struct McGroup {
+    uint32_t start;       // first tile
+    uint16_t n;           // tiles in the group, <= 64 / lanes-per-tile of the shape
+    uint16_t cls;         // tile-shape bin
+};
+extern "C" int dav1d_hip_launch_mc_all(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, const McTile *tiles,
+                                       const McGroup *groups, int n_groups, int16_t *prep, void *stream);
 extern "C" int dav1d_hip_launch_mc_bin(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, int cls,
                                        const McTile *tiles, int n, int16_t *prep, void *stream);
 extern "C" int dav1d_hip_launch_comp(const DevPlanes *dst, int bpc, const Dav1dHipCompTask *tasks, int n,

@@ -56,9 +56,17 @@ __device__ __forceinline__ Taps load_taps(const int set, const int m) {
 
 constexpr int mc_cmin(int a, int b) { return a < b ? a : b; }
 
+// LDS bytes one wave needs for tile shape (TW, TH): window + row-pair intermediate + the tile records
+template <int TW, int TH>
+constexpr int mc_lds_bytes() {
+    constexpr int LPT = mc_cmin(64, TW * TH / 4), G = 64 / LPT, WS = (TW + 8 + 7) & ~7, WR = TH + 8, NPR = WR / 2;
+    return G * WR * WS * 2 + G * NPR * TW * 4 + (G > 1 ? G * (int) sizeof(McTile) : 0);
+}
+
+// One wave's worth of tiles of shape (TW, TH): tiles[t0 .. t0 + nt), nt <= 64 / LPT.  `smem` = mc_lds_bytes<TW, TH>() of LDS.
 template <int TW, int TH, typename pixel>
-__global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSet refs, const McTile *__restrict__ tiles,
-                                                const int n, int16_t *__restrict__ prep, const int bitdepth_max)
+__device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs, const McTile *__restrict__ tiles, const int t0, const int nt,
+                                        int16_t *__restrict__ prep, const int bitdepth_max, uint4 *smem)
 {
     constexpr int NS = TW / 4;                          // 4-pixel strips per row
     constexpr int LPT = mc_cmin(64, TW * TH / 4);       // lanes per tile
@@ -71,15 +79,15 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSe
     constexpr int NLD = ((WR - 1) * NCH + LPT - 1) / LPT;   // window loads per lane
     constexpr bool HBD = sizeof(pixel) == 2;
 
-    __shared__ __attribute__((aligned(16))) int16_t win_s[G * WR * WS];
-    __shared__ __attribute__((aligned(16))) uint32_t mid_s[G * NPR * TW];
+    int16_t *const win_s = reinterpret_cast<int16_t *>(smem);
+    uint32_t *const mid_s = reinterpret_cast<uint32_t *>(win_s + G * WR * WS);
 
     const int lane = threadIdx.x;
     // G == 1: the whole wave works on one tile, so the record, the taps and all the control flow
     // derived from them are wave-uniform (scalar loads, SGPRs, s_cbranch instead of exec masking)
     const int sub = G == 1 ? 0 : lane / LPT, l = G == 1 ? lane : lane % LPT;
-    const int ti = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x) * G + sub;
-    const bool live = ti < n;
+    const int ti = t0 + sub;
+    const bool live = sub < nt;
 
     McTile t;
     if (G == 1) {
@@ -87,10 +95,9 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSe
     } else {
         // the G records of the wave come in with one coalesced sweep and are handed to their lanes through LDS
         constexpr int RW = sizeof(McTile) / 4;
-        __shared__ __attribute__((aligned(16))) uint32_t rec_s[G * RW];
-        const int t0 = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x) * G;
+        uint32_t *const rec_s = mid_s + G * NPR * TW;
         const uint32_t *recs = reinterpret_cast<const uint32_t *>(tiles + t0);
-        const int nw = dv::imin(G, n - t0) * RW;
+        const int nw = nt * RW;
         for (int i = lane; i < nw; i += 64) rec_s[i] = recs[i];
         dv::wave_sync();
         const uint32_t *rp = rec_s + (live ? sub : 0) * RW;
@@ -318,6 +325,49 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSe
     }
 }
 
+// one tile shape per launch: workgroup b of the XCD-chunked order handles tiles [b * G, b * G + G)
+template <int TW, int TH, typename pixel>
+__global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSet refs, const McTile *__restrict__ tiles,
+                                                const int n, int16_t *__restrict__ prep, const int bitdepth_max)
+{
+    constexpr int G = 64 / mc_cmin(64, TW * TH / 4);
+    __shared__ uint4 smem[(mc_lds_bytes<TW, TH>() + 15) / 16];
+    const int t0 = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x) * G;
+    if (t0 >= n) return;
+    mc_body<TW, TH, pixel>(dst, refs, tiles, t0, dv::imin(G, n - t0), prep, bitdepth_max, smem);
+}
+
+// every tile shape in one launch: the tiles are ordered by where they read (all shapes interleaved, see
+// mc_list_from_bins) and cut into wave-sized groups of one shape, so that the lines one shape pulls into an
+// XCD's L2 are still there when its neighbours of other shapes need them
+constexpr int mc_cmax(int a, int b) { return a > b ? a : b; }
+constexpr int MC_LDS_MAX =
+    mc_cmax(mc_cmax(mc_cmax(mc_lds_bytes<4, 4>(), mc_lds_bytes<4, 8>()), mc_cmax(mc_lds_bytes<4, 16>(), mc_lds_bytes<8, 4>())),
+    mc_cmax(mc_cmax(mc_cmax(mc_lds_bytes<8, 8>(), mc_lds_bytes<8, 16>()), mc_cmax(mc_lds_bytes<16, 4>(), mc_lds_bytes<16, 8>())),
+    mc_cmax(mc_cmax(mc_cmax(mc_lds_bytes<16, 16>(), mc_lds_bytes<32, 4>()), mc_cmax(mc_lds_bytes<32, 8>(), mc_lds_bytes<32, 16>())),
+            mc_cmax(mc_cmax(mc_lds_bytes<64, 4>(), mc_lds_bytes<64, 8>()), mc_lds_bytes<64, 16>()))));
+
+template <typename pixel>
+__global__ __launch_bounds__(64) void mc_all_kernel(const DevPlanes dst, const RefSet refs, const McTile *__restrict__ tiles,
+                                                    const McGroup *__restrict__ groups, const int n_groups,
+                                                    int16_t *__restrict__ prep, const int bitdepth_max)
+{
+    __shared__ uint4 smem[(MC_LDS_MAX + 15) / 16];
+    const int gi = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x);
+    if (gi >= n_groups) return;
+    const McGroup g = groups[__builtin_amdgcn_readfirstlane(gi)];
+    const int t0 = __builtin_amdgcn_readfirstlane((int) g.start), nt = __builtin_amdgcn_readfirstlane((int) g.n);
+#define CASE(C, TW, TH) case C: mc_body<TW, TH, pixel>(dst, refs, tiles, t0, nt, prep, bitdepth_max, smem); break;
+    switch (__builtin_amdgcn_readfirstlane((int) g.cls)) {
+        CASE(0, 4, 4) CASE(1, 4, 8) CASE(2, 4, 16)
+        CASE(3, 8, 4) CASE(4, 8, 8) CASE(5, 8, 16)
+        CASE(6, 16, 4) CASE(7, 16, 8) CASE(8, 16, 16)
+        CASE(9, 32, 4) CASE(10, 32, 8) CASE(11, 32, 16)
+        CASE(12, 64, 4) CASE(13, 64, 8) CASE(14, 64, 16)
+    }
+#undef CASE
+}
+
 template <typename pixel>
 hipError_t launch_cls(const int cls, const DevPlanes &dst, const RefSet &refs, const McTile *tiles, const int n,
                       int16_t *prep, const int bitdepth_max, hipStream_t stream)
@@ -354,4 +404,18 @@ extern "C" int dav1d_hip_launch_mc_bin(const DevPlanes *dst, const DevPlanes *re
     if (bpc == 8) e = launch_cls<uint8_t>(cls, *dst, rs, tiles, n, prep, bitdepth_max, (hipStream_t) stream);
     else          e = launch_cls<uint16_t>(cls, *dst, rs, tiles, n, prep, bitdepth_max, (hipStream_t) stream);
     return hip_rc(e);
+}
+
+extern "C" int dav1d_hip_launch_mc_all(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, const McTile *tiles,
+                                       const McGroup *groups, int n_groups, int16_t *prep, void *stream)
+{
+    if (n_groups <= 0) return 0;
+    RefSet rs;
+    for (int i = 0; i < 8; i++) rs.r[i] = refs[i < n_refs ? i : 0];
+    const int bitdepth_max = (1 << bpc) - 1;
+    if (bpc == 8)
+        hipLaunchKernelGGL((mc_all_kernel<uint8_t>), dim3(n_groups), dim3(64), 0, (hipStream_t) stream, *dst, rs, tiles, groups, n_groups, prep, bitdepth_max);
+    else
+        hipLaunchKernelGGL((mc_all_kernel<uint16_t>), dim3(n_groups), dim3(64), 0, (hipStream_t) stream, *dst, rs, tiles, groups, n_groups, prep, bitdepth_max);
+    return hip_rc(hipGetLastError());
 }

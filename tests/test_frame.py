@@ -92,3 +92,18 @@ def test_frame_itx_mc_matches_oracle(ctx, bpc, fused):
         assert np.array_equal(got_prep, want_prep)
     assert np.array_equal(got_coef, want_coef)
     assert not want_coef.any(), "all consumed coefficient slabs end up zeroed"
+
+
+def test_all_shapes_in_one_launch(ctx):
+    """DAV1D_HIP_MC_FUSED=1 (every tile shape in one source-ordered launch) must give the same pictures: the frame
+    tests again, in a child process that has the switch set before the library reads it."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("DAV1D_HIP_MC_FUSED"):
+        pytest.skip("already inside the child run")
+    env = dict(os.environ, DAV1D_HIP_MC_FUSED="1")
+    sel = "emu" if ctx.backend == "emu" else "hip"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", sel + " and fused", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
