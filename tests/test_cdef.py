@@ -69,8 +69,6 @@ def oracle_cdef_unit(oracle, bpc, src, dst, t, damping, layout=1):
 @pytest.mark.parametrize("bpc", [8, 10, 12])
 def test_cdef_units_match_reference(ctx, bpc):
     oracle = util.default_oracle()
-    if oracle.which != "ref":
-        pytest.skip("cdef is checked against the reference build (oracle/port has no cdef yet)")
     rng = np.random.default_rng(600 + bpc)
     w, h = (128, 64) if ctx.backend == "emu" else (512, 256)
     bd8 = bpc - 8

@@ -24,15 +24,6 @@ BASE = {
 COUNT = {"generate_grain_uv": 3, "fguv_32x32xn": 3, "intra_pred": 14, "cfl_ac": 3, "cfl_pred": 6, "mc": 10, "mc_scaled": 10,
          "mct": 10, "mct_scaled": 10, "w_mask": 3, "cdef_fb": 3, "wiener": 2, "sgr": 3}
 
-_vp, _i, _pd, _sz = C.c_void_p, C.c_int, C.c_ssize_t, C.c_size_t
-FG_PROTO = {
-    "generate_grain_y": [_vp, _vp],
-    "generate_grain_uv": [_vp, _vp, _vp, _pd],
-    "fgy_32x32xn": [_vp, _vp, _pd, _vp, _sz, _vp, _vp, _i, _i],
-    "fguv_32x32xn": [_vp, _vp, _pd, _vp, _sz, _vp, _vp, _i, _i, _vp, _pd, _i, _i],
-}
-util.PROTO.update(FG_PROTO)
-
 
 def slot(family, i=0, j=0):
     if family == "itxfm_add":

@@ -42,8 +42,6 @@ def structured_plane(rng, shape, bpc):
 @pytest.mark.parametrize("bpc", [8, 10, 12])
 def test_loop_filter_sb_matches_reference(ctx, bpc):
     oracle = util.default_oracle()
-    if oracle.which != "ref":
-        pytest.skip("loop filter is checked against the reference build (oracle/port has no loop filter yet)")
     rng = np.random.default_rng(800 + bpc)
     w, h = 256, 256
     pic = ctx.picture(w, h, api.LAYOUT_I420, bpc)

@@ -102,6 +102,10 @@ PROTO = {
     "sgr": [_vp, _pd, _vp, _vp, _i, _i, _vp, _i],
     "cdef_dir": [_vp, _pd, _vp],
     "cdef_fb": [_vp, _pd, _vp, _vp, _vp, _i, _i, _i, _i, _i],
+    "generate_grain_y": [_vp, _vp],
+    "generate_grain_uv": [_vp, _vp, _vp, _pd],
+    "fgy_32x32xn": [_vp, _vp, _pd, _vp, C.c_size_t, _vp, _vp, _i, _i],
+    "fguv_32x32xn": [_vp, _vp, _pd, _vp, C.c_size_t, _vp, _vp, _i, _i, _vp, _pd, _i, _i],
 }
 RET_INT = {"cdef_dir"}
 NO_HBD_SUFFIX = {"blend", "blend_v", "blend_h", "emu_edge", "cfl_ac", "pal_pred"}
@@ -158,7 +162,9 @@ def available_oracles():
 @functools.lru_cache(None)
 def default_oracle():
     """The checker used by the HIP parity tests: the real reference when its prebuilt
-    library travelled with the repo, else the C restatement."""
+    library travelled with the repo, else the C restatement (DAV1D_TEST_ORACLE=port forces the latter)."""
+    if os.environ.get("DAV1D_TEST_ORACLE") == "port":
+        return Oracle("port")
     return Oracle("ref") if ref_lib() is not None else Oracle("port")
 
 
