@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--edge-frac", type=float, default=0.05, help="fraction of blocks pointing outside the picture")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-full", action="store_true", help="skip the full-DSP-table leg (deblock, CDEF, restoration, film grain)")
     return ap.parse_args()
 
 
@@ -247,6 +248,64 @@ def main():
                    "sample": "%d full %dx%d frame(s) of the same task lists through the oracle's C DSP entries, "
                              "1 thread, %.1f s" % (reps, w, h, t_cpu),
                    "host_cores_available": os.cpu_count()}
+        # ---- full DSP table on the same frame (BASELINE configs[2]): recon above + deblock + CDEF + restoration + grain,
+        # one frame, kernel time per stage from HIP events, every stage checked against the oracle's replay
+        full = None
+        if not a.no_full:
+            post = synth.make_post_filters(frame, seed=0xF11 + rank)
+            want_post, t_post_cpu = [None] * 4, 0.0
+            if not a.no_check:
+                import test_postchain
+                t1 = time.perf_counter()
+                want_post = test_postchain.oracle_post(oracle, post, want[0], w, h, bpc)
+                t_post_cpu = time.perf_counter() - t1
+            else:
+                got = [dsts[i % NDST].download(pl) for pl in range(3)]
+            pics = [ctx.picture(w, h, api.LAYOUT_I420, bpc) for _ in range(4)]
+            dbl, cdf, res, grn = pics
+            for pl in range(3):
+                dbl.upload(pl, got[pl])
+            lvl = ctx.buffer_from(post.lvl)
+            stage_ms = {}
+            for rep in range(2):            # second pass = warm clocks; deblocking is in place, so re-seed its input
+                for pl in range(3):
+                    dbl.upload(pl, got[pl])
+                ctx.lf_batch(dbl, post.lf, lvl, post.b4_stride, post.lut_e, post.lut_i)
+                stage_ms["deblock"] = ctx.last_kernel_ms()
+                ctx.cdef_batch(cdf, dbl, post.cdef, post.cdef_damping)
+                stage_ms["cdef"] = ctx.last_kernel_ms()
+                ctx.lr_batch(res, cdf, dbl, post.lr)
+                stage_ms["restoration"] = ctx.last_kernel_ms()
+                ctx.fg_apply(grn, res, post.fg)
+                stage_ms["film_grain"] = ctx.last_kernel_ms()
+            names = ["deblock", "cdef", "restoration", "film_grain"]
+            okp = True
+            for pic, wantp, nm in zip(pics, want_post, names):
+                if wantp is None:
+                    continue
+                for pl in range(3):
+                    vh, vw = (h, w) if pl == 0 else (h // 2, w // 2)
+                    if not np.array_equal(pic.download(pl)[:vh, :vw], wantp[pl][:vh, :vw]):
+                        okp = False
+                        print("bench: full-table stage %s plane %d differs from the oracle" % (nm, pl), file=sys.stderr)
+            if not okp:
+                raise SystemExit("bench: full-table GPU output differs from the oracle")
+            for o in pics + [lvl]:
+                o.free()
+            P = 1 if bpc == 8 else 2
+            post_ms = sum(stage_ms.values())
+            full_ms = ms_per_step + post_ms
+            full_bytes = path_bytes + frame.n_samples * 2 * P * 4        # each post filter: one read + one write per sample
+            full = {"workload": "same frame through the full DSP table: itx+mc recon, deblock (levels 16-32, masks from the transform grid), "
+                                "CDEF (y 17 / uv 5, every 8x8), Wiener Y + SGR-mix UV (64-px units), film grain (lag 3, overlap)",
+                    "ms_per_frame": round(full_ms, 4), "value": round(frame.luma_pixels / (full_ms * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
+                    "stages_ms": dict({"recon_itx_mc": round(ms_per_step, 4)}, **{k: round(v, 4) for k, v in stage_ms.items()}),
+                    "tasks": {"lf": int(len(post.lf)), "cdef": int(len(post.cdef)), "lr": int(len(post.lr))},
+                    "algorithmic_bytes_per_frame": int(full_bytes),
+                    "achieved": round(full_bytes / (full_ms * 1e-3) / 1e9, 1), "frac": round(full_bytes / (full_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "parity": "skipped" if a.no_check else "every stage bit-exact vs %s oracle%s" % (
+                        oracle.which, "" if want_post[3] is not None else " (film grain unchecked: needs oracle/_ref)"),
+                    "cpu_post_filters_s": round(t_post_cpu, 2)}
         out = {"metric": "reconstructed luma Mpixels/s (8K 4:2:0 10-bit) on the itx+mc recon path; bit-exact vs C",
                "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -257,7 +316,7 @@ def main():
                           "frames_per_step": 1, "parallelism": "frame-parallel x%d" % world,
                           "tasks": {"mc": int(len(frame.mc)), "comp": int(len(frame.comp)), "itx": int(len(frame.itx))},
                           "samples_per_frame": frame.n_samples, "parity": check, "gen_seconds": round(t_gen, 1)},
-               "roofline": roof, "cpu_baseline": cpu}
+               "roofline": roof, "cpu_baseline": cpu, "full_table": full}
         print(json.dumps(out))
     barrier()
     if world > 1:

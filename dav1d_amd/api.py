@@ -159,6 +159,9 @@ class Context:
     def picture(self, w, h, layout, bpc):
         return DevicePicture(self, w, h, layout, bpc)
 
+    def last_kernel_ms(self):
+        return float(self.lib.dav1d_hip_last_kernel_ms(self.h))
+
     # ---- batched entry points (host task arrays, device arenas)
     def itx_add_batch(self, dst, tasks, coef):
         t = np.ascontiguousarray(tasks, dtype=ITX_TASK)

@@ -18,6 +18,21 @@ struct Dav1dHipContext {
     hipStream_t side[N_SIDE];
     hipEvent_t ev_fork, ev_join[N_SIDE];
     bool concurrent;
+    // measurement aid: device time of the kernel launches of the most recent *_batch call (dav1d_hip_last_kernel_ms)
+    hipEvent_t ev_t0, ev_t1;
+    float last_ms;
+};
+
+// brackets the launches of a batch call with events on the context's stream
+struct KernelTimer {
+    Dav1dHipContext *c;
+    explicit KernelTimer(Dav1dHipContext *ctx) : c(ctx) { (void) hipEventRecord(c->ev_t0, c->stream); }
+    void stop() {        // call after the launches, before the batch call's own synchronize
+        (void) hipEventRecord(c->ev_t1, c->stream);
+        (void) hipEventSynchronize(c->ev_t1);
+        c->last_ms = 0.f;
+        (void) hipEventElapsedTime(&c->last_ms, c->ev_t0, c->ev_t1);
+    }
 };
 
 // fork/join helper: launches issued through next() land round-robin on the side streams
@@ -118,12 +133,13 @@ extern "C" int dav1d_hip_launch_wiener(const DevPlanes *dst, const DevPlanes *sr
 
 extern "C" int dav1d_hip_launch_fg_gen(int16_t *luts, const Dav1dHipFilmGrainData *data, int bpc, int layout, void *stream);
 extern "C" int dav1d_hip_launch_fg_apply(const DevPlanes *dst, const DevPlanes *src, const int16_t *luts, const uint8_t *scaling,
-                                         int scaling_size, const Dav1dHipFilmGrainData *data, int bpc, int layout, int is_id, void *stream);
+                                         int scaling_size, const Dav1dHipFilmGrainData *data, int bpc, int layout, int is_id, uint8_t *offs,
+                                         void *stream);
 
 extern "C" int dav1d_hip_launch_fg_gen_part(int16_t *luts, const Dav1dHipFilmGrainData *data, int bpc, int layout, int part, void *stream);
 extern "C" int dav1d_hip_launch_fg_apply_rows(const DevPlanes *dst, const DevPlanes *src, const int16_t *luts, const uint8_t *scaling,
                                               int scaling_size, const Dav1dHipFilmGrainData *data, int bpc, int layout, int is_id,
-                                              int row_num, int pl, void *stream);
+                                              int row_num, int pl, uint8_t *offs, void *stream);
 extern "C" int dav1d_hip_launch_sgr(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
                                     const Dav1dHipLrTask *tasks, int n, void *stream);
 

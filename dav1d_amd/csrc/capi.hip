@@ -34,6 +34,8 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
             hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
     }
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
+    if (hipEventCreate(&c->ev_t0) != hipSuccess || hipEventCreate(&c->ev_t1) != hipSuccess) { delete c; return -ENODEV; }
+    c->last_ms = 0.f;
     *out = c;
     return 0;
 }
@@ -44,6 +46,7 @@ void dav1d_hip_close(Dav1dHipContext *c) {
     if (c->scratch) hipFree(c->scratch);
     for (int i = 0; i < Dav1dHipContext::N_SIDE; i++) { hipStreamSynchronize(c->side[i]); hipStreamDestroy(c->side[i]); hipEventDestroy(c->ev_join[i]); }
     hipEventDestroy(c->ev_fork);
+    hipEventDestroy(c->ev_t0); hipEventDestroy(c->ev_t1);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -51,6 +54,7 @@ void dav1d_hip_close(Dav1dHipContext *c) {
 int dav1d_hip_sync(Dav1dHipContext *c) { return hip_rc(hipStreamSynchronize(c->stream)); }
 void *dav1d_hip_stream(Dav1dHipContext *c) { return (void *) c->stream; }
 const char *dav1d_hip_version(void) { return "dav1d_hip 0.1 (gfx950)"; }
+float dav1d_hip_last_kernel_ms(Dav1dHipContext *c) { return c ? c->last_ms : 0.f; }
 
 int dav1d_hip_malloc(Dav1dHipContext *c, void **dev, size_t bytes) {
     (void) c;
@@ -698,7 +702,9 @@ extern "C" int dav1d_hip_cdef_batch(Dav1dHipContext *c, const Dav1dHipPicture *d
     if (hipMalloc((void **) &dev, n * sizeof(*dev)) != hipSuccess) return -ENOMEM;
     int rc = dav1d_hip_upload(c, dev, tasks, n * sizeof(*dev));
     const DevPlanes dp = dev_planes(dst), sp = dev_planes(src);
+    KernelTimer kt(c);
     if (!rc) rc = dav1d_hip_launch_cdef(&dp, &sp, dst->bpc, dst->layout, dev, (int) n, damping, dirvar, c->stream);
+    kt.stop();
     hipStreamSynchronize(c->stream);
     hipFree(dev);
     return rc;
@@ -725,8 +731,10 @@ extern "C" int dav1d_hip_lf_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst
     int rc = dav1d_hip_upload(c, dev, sorted.data(), n * sizeof(*dev));
     const DevPlanes dp = dev_planes(dst);
     // pass 1: every vertical edge; pass 2 (same stream, so after pass 1): every horizontal edge
+    KernelTimer kt(c);
     if (!rc) rc = dav1d_hip_launch_lf(&dp, dst->bpc, dev, (int) n0, lvl, (int) b4_stride, lut_e, lut_i, c->stream);
     if (!rc) rc = dav1d_hip_launch_lf(&dp, dst->bpc, dev + n0, (int) (n - n0), lvl, (int) b4_stride, lut_e, lut_i, c->stream);
+    kt.stop();
     hipStreamSynchronize(c->stream);
     hipFree(dev);
     return rc;
@@ -750,7 +758,9 @@ extern "C" int dav1d_hip_ipred_batch(Dav1dHipContext *c, const Dav1dHipPicture *
     if (hipMalloc((void **) &dev, n * sizeof(*dev)) != hipSuccess) return -ENOMEM;
     int rc = dav1d_hip_upload(c, dev, tasks, n * sizeof(*dev));
     const DevPlanes dp = dev_planes(dst);
+    KernelTimer kt(c);
     if (!rc) rc = dav1d_hip_launch_ipred(&dp, dst->bpc, dst->layout, dev, (int) n, pal_idx, c->stream);
+    kt.stop();
     hipStreamSynchronize(c->stream);
     hipFree(dev);
     return rc;
@@ -845,8 +855,10 @@ extern "C" int dav1d_hip_lr_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst
     if (hipMalloc((void **) &dev, n * sizeof(*dev)) != hipSuccess) return -ENOMEM;
     int rc = dav1d_hip_upload(c, dev, sorted.data(), n * sizeof(*dev));
     const DevPlanes dp = dev_planes(dst), sp = dev_planes(src), lp = dev_planes(lpf);
+    KernelTimer kt(c);
     if (!rc) rc = dav1d_hip_launch_wiener(&dp, &sp, &lp, dst->bpc, dev, (int) nw, c->stream);
     if (!rc) rc = dav1d_hip_launch_sgr(&dp, &sp, &lp, dst->bpc, dev + nw, (int) (n - nw), c->stream);
+    kt.stop();
     hipStreamSynchronize(c->stream);
     hipFree(dev);
     return rc;
@@ -896,15 +908,17 @@ extern "C" int dav1d_hip_fg_apply(Dav1dHipContext *c, const Dav1dHipPicture *dst
                                   const Dav1dHipFilmGrainData *data, int is_id) {
     if (!dst || !src || !data || dst->bpc != src->bpc || dst->layout != src->layout) return -EINVAL;
     const int bpc = src->bpc, scaling_size = 1 << bpc;
-    const size_t lut_bytes = 3 * 74 * 82 * sizeof(int16_t);
+    const size_t lut_bytes = (3 * 74 * 82 * sizeof(int16_t) + 255) & ~(size_t) 255;      // keeps the scaling tables 16-byte aligned
     uint8_t *dev = nullptr;
-    if (hipMalloc((void **) &dev, lut_bytes + 3 * (size_t) scaling_size) != hipSuccess) return -ENOMEM;
+    const size_t offs_bytes = (size_t) ((src->p[0].w + 31) / 32) * ((src->p[0].h + 31) / 32);
+    if (hipMalloc((void **) &dev, lut_bytes + 3 * (size_t) scaling_size + offs_bytes) != hipSuccess) return -ENOMEM;
     std::vector<uint8_t> sc(3 * (size_t) scaling_size, 0);
     if (data->num_y_points || data->chroma_scaling_from_luma) fg_generate_scaling(bpc, data->y_points, data->num_y_points, &sc[0]);
     for (int i = 0; i < 2; i++)
         if (data->num_uv_points[i]) fg_generate_scaling(bpc, data->uv_points[i], data->num_uv_points[i], &sc[(size_t) (1 + i) * scaling_size]);
     hipMemsetAsync(dev, 0, lut_bytes, c->stream);
     int rc = dav1d_hip_upload(c, dev + lut_bytes, sc.data(), sc.size());
+    KernelTimer kt(c);
     if (!rc) rc = dav1d_hip_launch_fg_gen((int16_t *) dev, data, bpc, src->layout, c->stream);
     // planes that get no grain are copied (dav1d_prep_grain, src/fg_apply_tmpl.c:127-163)
     const int ss_ver = src->layout == DAV1D_HIP_LAYOUT_I420;
@@ -918,7 +932,9 @@ extern "C" int dav1d_hip_fg_apply(Dav1dHipContext *c, const Dav1dHipPicture *dst
                                      hipMemcpyDeviceToDevice, c->stream));
     }
     const DevPlanes dp = dev_planes(dst), sp = dev_planes(src);
-    if (!rc) rc = dav1d_hip_launch_fg_apply(&dp, &sp, (const int16_t *) dev, dev + lut_bytes, scaling_size, data, bpc, src->layout, is_id, c->stream);
+    if (!rc) rc = dav1d_hip_launch_fg_apply(&dp, &sp, (const int16_t *) dev, dev + lut_bytes, scaling_size, data, bpc, src->layout, is_id,
+                                            dev + lut_bytes + 3 * (size_t) scaling_size, c->stream);
+    kt.stop();
     hipStreamSynchronize(c->stream);
     hipFree(dev);
     return rc;

@@ -308,7 +308,8 @@ void fg_row_call(int layout, int pl, pixel *dst_row, const pixel *src_row, ptrdi
     if (!pl) { if (!d.num_y_points) d.num_y_points = 1; }
     else if (!d.num_uv_points[pl - 1] && !d.chroma_scaling_from_luma) d.num_uv_points[pl - 1] = 1;
     const DevPlanes dp = dev_planes(&out), sp = dev_planes(&in);
-    if (dav1d_hip_launch_fg_apply_rows(&dp, &sp, luts, sc, scaling_size, &d, bpc, in.layout, is_id, row_num, pl, s.c->stream)) abort();
+    uint8_t *offs = (uint8_t *) s.take(2 * (size_t) ((lw + 31) / 32) + 16);
+    if (dav1d_hip_launch_fg_apply_rows(&dp, &sp, luts, sc, scaling_size, &d, bpc, in.layout, is_id, row_num, pl, offs, s.c->stream)) abort();
     down2d(s.c, dst_row, stride, out.p[pl].data, out.p[pl].stride, pw * sizeof(pixel), bh);
     s.sync();
 }

@@ -37,6 +37,47 @@ struct FgParams {                 // the scalar part of Dav1dFilmGrainData the k
     int8_t ar_coeffs_uv[2][28];
 };
 
+template <int LAG>
+__device__ void ar_filter(int16_t *lut, const int16_t *lut_y, const FgParams &p, const int pl, const int subx, const int suby,
+                          const int W, const int H, const int grain_min, const int grain_max, const int lane)
+{
+    constexpr int pad = 3, NC = 2 * LAG * (LAG + 1);        // taps before the current sample
+    int coef[NC + 1];
+    {
+        const int8_t *c = pl ? p.ar_coeffs_uv[pl - 1] : p.ar_coeffs_y;
+#pragma unroll
+        for (int k = 0; k <= NC; k++) coef[k] = c[k];
+    }
+    const bool with_luma = pl && p.num_y_points;
+    for (int y0 = pad; y0 < H; y0 += 64) {
+        const int rows = dv::imin(64, H - y0);
+        const int y = y0 + lane;
+        const int steps = (W - 2 * pad) + (rows - 1) * (LAG + 1);
+        for (int s = 0; s < steps; s++) {
+            const int x = pad + s - lane * (LAG + 1);
+            if (lane < rows && x >= pad && x < W - pad) {
+                int sum = 0, k = 0;
+#pragma unroll
+                for (int dy = -LAG; dy <= 0; dy++)
+#pragma unroll
+                    for (int dx = -LAG; dx <= LAG; dx++) {
+                        if (dy == 0 && dx >= 0) continue;
+                        sum += coef[k++] * lut[(y + dy) * GW + x + dx];
+                    }
+                if (with_luma) {
+                    int luma = 0;
+                    const int lx = ((x - pad) << subx) + pad, ly = ((y - pad) << suby) + pad;
+                    for (int i = 0; i <= suby; i++)
+                        for (int j = 0; j <= subx; j++) luma += lut_y[(ly + i) * GW + lx + j];
+                    sum += round2(luma, subx + suby) * coef[NC];
+                }
+                lut[y * GW + x] = (int16_t) dv::iclip(lut[y * GW + x] + round2(sum, p.ar_coeff_shift), grain_min, grain_max);
+            }
+            dv::wave_sync();
+        }
+    }
+}
+
 // one wave builds template `pl` (0 luma, 1/2 chroma) in `lut` (int16 [74][82])
 __device__ void gen_template(int16_t *lut, const int16_t *lut_y, const FgParams &p, const int pl, const int subx, const int suby,
                              const int bitdepth_min_8, uint16_t *cols, uint16_t *rowstart, const int lane)
@@ -71,38 +112,16 @@ __device__ void gen_template(int16_t *lut, const int16_t *lut_y, const FgParams 
         }
     }
     dv::wave_sync();
-    // ---- auto-regressive filter as a wavefront over rows (src/filmgrain_tmpl.c:72-91, 123-153)
-    const int lag = p.ar_coeff_lag, pad = 3;
-    const int8_t *coef = pl ? p.ar_coeffs_uv[pl - 1] : p.ar_coeffs_y;
-    for (int y0 = pad; y0 < H; y0 += 64) {
-        const int rows = dv::imin(64, H - y0);
-        const int y = y0 + lane;
-        const int steps = (W - 2 * pad) + (rows - 1) * (lag + 1);
-        for (int s = 0; s < steps; s++) {
-            const int x = pad + s - lane * (lag + 1);
-            if (lane < rows && x >= pad && x < W - pad) {
-                int sum = 0, k = 0;
-                for (int dy = -lag; dy <= 0; dy++)
-                    for (int dx = -lag; dx <= lag; dx++) {
-                        if (!dx && !dy) break;
-                        sum += coef[k++] * lut[(y + dy) * GW + x + dx];
-                    }
-                if (pl && p.num_y_points) {
-                    int luma = 0;
-                    const int lx = ((x - pad) << subx) + pad, ly = ((y - pad) << suby) + pad;
-                    for (int i = 0; i <= suby; i++)
-                        for (int j = 0; j <= subx; j++) luma += lut_y[(ly + i) * GW + lx + j];
-                    sum += round2(luma, subx + suby) * coef[k];
-                }
-                lut[y * GW + x] = (int16_t) dv::iclip(lut[y * GW + x] + round2(sum, p.ar_coeff_shift), grain_min, grain_max);
-            }
-            dv::wave_sync();
-        }
+    // ---- auto-regressive filter as a wavefront over rows (src/filmgrain_tmpl.c:72-91, 123-153); the lag is a
+    // compile-time constant of ar_filter so that the tap loops unroll and the coefficients stay in scalar registers
+    switch (p.ar_coeff_lag) {
+    case 0: ar_filter<0>(lut, lut_y, p, pl, subx, suby, W, H, grain_min, grain_max, lane); break;
+    case 1: ar_filter<1>(lut, lut_y, p, pl, subx, suby, W, H, grain_min, grain_max, lane); break;
+    case 2: ar_filter<2>(lut, lut_y, p, pl, subx, suby, W, H, grain_min, grain_max, lane); break;
+    default: ar_filter<3>(lut, lut_y, p, pl, subx, suby, W, H, grain_min, grain_max, lane); break;
     }
 }
 
-// part 0: the luma template and every chroma template dav1d_apply_grain would build; part -1: generate_grain_y alone;
-// part 1 / 2: generate_grain_uv for that plane alone, the luma template it filters against taken from luts[0]
 __global__ __launch_bounds__(64) void fg_gen_kernel(int16_t *luts, const FgParams p, const int layout, const int bitdepth_min_8, const int part)
 {
     __shared__ uint16_t cols[16], rowstart[GH];
@@ -138,11 +157,30 @@ __device__ __forceinline__ int sample_lut(const int16_t *lut, const int randval,
     return lut[(offy + y + (32 >> suby) * by) * GW + offx + x + (32 >> subx) * bx];
 }
 
+// Per-block random offsets (src/filmgrain_tmpl.c:192-214): block bx of block row r uses the (bx+1)-th output of an LFSR
+// seeded from r.  One lane walks one row's sequence once; the blocks then look their offsets up instead of each
+// re-running the generator from the start of the row.
+__global__ __launch_bounds__(64) void fg_offsets_kernel(uint8_t *__restrict__ offs, const unsigned seed, const int row0, const int nrows,
+                                                        const int nblk)
+{
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= nrows) return;
+    const int row_num = row0 + r;
+    unsigned s = seed;
+    s ^= ((row_num * 37 + 178) & 0xFF) << 8;
+    s ^= (row_num * 173 + 105) & 0xFF;
+    for (int k = 0; k < nblk; k++) {
+        s = lfsr_step(s);
+        offs[r * nblk + k] = (uint8_t) ((s >> 8) & 0xFF);
+    }
+}
+
 template <typename pixel>
 __global__ __launch_bounds__(64) void fg_apply_kernel(const DevPlanes dst, const DevPlanes src, const int16_t *__restrict__ luts,
                                                       const uint8_t *__restrict__ scaling, const int scaling_size, const FgParams p,
                                                       const int layout, const int is_id, const int bitdepth_max,
-                                                      const int row_base, const int only_pl)
+                                                      const int row_base, const int only_pl,
+                                                      const uint8_t *__restrict__ offs, const int offs_row0, const int offs_stride)
 {
     // row_base / only_pl: the table-level entries run one block row of one plane on pictures that hold just that row
     const int bxi = blockIdx.x, row_num = row_base + blockIdx.y, pl = only_pl < 0 ? (int) blockIdx.z : only_pl;
@@ -170,18 +208,11 @@ __global__ __launch_bounds__(64) void fg_apply_kernel(const DevPlanes dst, const
     const int bw = dv::imin(bstep, pw - bx);
 
     // per-block random offsets: k-th output of the row LFSRs (src/filmgrain_tmpl.c:192-214)
-    const int rows = 1 + (p.overlap_flag && row_num > 0);
-    int off[2][2] = { { 0, 0 }, { 0, 0 } };      // [col: 0 = this block, 1 = left block][row: 0 = this row, 1 = row above]
-    for (int i = 0; i < rows; i++) {
-        unsigned s = p.seed;
-        s ^= (((row_num - i) * 37 + 178) & 0xFF) << 8;
-        s ^= (((row_num - i) * 173 + 105) & 0xFF);
-        for (int k = 0; k <= bxi; k++) {
-            off[1][i] = off[0][i];
-            s = lfsr_step(s);
-            off[0][i] = (s >> 8) & 0xFF;
-        }
-    }
+    // the k-th outputs of the row LFSRs were tabulated by fg_offsets_kernel: [row][block]
+    const bool two_rows = p.overlap_flag && row_num > 0;
+    const uint8_t *orow = offs + (row_num - offs_row0) * offs_stride;
+    const int off_cur = orow[bxi], off_left = bxi ? orow[bxi - 1] : 0;
+    const int off_cur_up = two_rows ? orow[bxi - offs_stride] : 0, off_left_up = (two_rows && bxi) ? orow[bxi - 1 - offs_stride] : 0;
     const int ystart = (p.overlap_flag && row_num) ? dv::imin(2 >> sy, bh) : 0;
     const int xstart = (p.overlap_flag && bxi) ? dv::imin(2 >> sx, bw) : 0;
     // overlap weights: full resolution {27,17},{17,27}; subsampled {23,22}
@@ -193,42 +224,65 @@ __global__ __launch_bounds__(64) void fg_apply_kernel(const DevPlanes dst, const
     const pixel *const lp = reinterpret_cast<const pixel *>(src.data[0]);
     const int y0 = pl ? (prow * 32) >> sy : prow * 32;
 
-    for (int i = lane; i < bw * bh; i += 64) {
-        const int y = i / bw, x = i % bw;
-        int grain = sample_lut(lut, off[0][0], sx, sy, 0, 0, x, y);
-        const int wxa = sx ? 23 : (x == 0 ? 27 : 17), wxb = sx ? 22 : (x == 0 ? 17 : 27);
-        const int wya = sy ? 23 : (y == 0 ? 27 : 17), wyb = sy ? 22 : (y == 0 ? 17 : 27);
-        if (x < xstart) {
-            const int old = sample_lut(lut, off[1][0], sx, sy, 1, 0, x, y);
-            grain = dv::iclip(round2(old * wxa + grain * wxb, 5), grain_min, grain_max);
+    // the scaling table moves to LDS once per block: the per-pixel lookup then costs an LDS read instead of a second
+    // dependent trip to memory
+    __shared__ __attribute__((aligned(16))) uint8_t sc_s[4096];
+    for (int i = lane * 16; i < scaling_size; i += 64 * 16) *reinterpret_cast<uint4 *>(sc_s + i) = *reinterpret_cast<const uint4 *>(sc + i);
+    dv::wave_sync();
+
+    // lane = (column, row group): 2 rows of 32 or 4 rows of 16 pixels per pass, four passes in flight so that the
+    // source (and luma) loads of 4 pixels per lane are issued before the first is needed
+    const int lg = sx ? 4 : 5, rpp = 64 >> lg;
+    const int x = lane & (bstep - 1), yl = lane >> lg;
+    const int ss = src.stride[pl], ds = dst.stride[pl], ls = src.stride[0];
+    const int wxa = sx ? 23 : (x == 0 ? 27 : 17), wxb = sx ? 22 : (x == 0 ? 17 : 27);
+    for (int yb = 0; yb < bh; yb += 4 * rpp) {
+        int s0[4], lum[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int y = yb + j * rpp + yl;
+            const bool in = x < bw && y < bh;
+            s0[j] = in ? (int) sp[(y0 + y) * ss + bx + x] : 0;
+            lum[j] = 0;
+            if (pl && in) {
+                // luma co-located average; the reference extends the luma row by one pixel for odd widths
+                // (src/fg_apply_tmpl.c:193-199)
+                const int lx = (bx + x) << sx, ly = (prow * 32) + (y << sy);
+                const pixel *lrow = lp + ly * ls;
+                int avg = lrow[dv::imin(lx, src.w[0] - 1)];
+                if (sx) avg = (avg + lrow[dv::imin(lx + 1, src.w[0] - 1)] + 1) >> 1;
+                lum[j] = avg;
+            }
         }
-        if (y < ystart) {
-            int top = sample_lut(lut, off[0][1], sx, sy, 0, 1, x, y);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int y = yb + j * rpp + yl;
+            if (!(x < bw && y < bh)) continue;
+            int grain = sample_lut(lut, off_cur, sx, sy, 0, 0, x, y);
+            const int wya = sy ? 23 : (y == 0 ? 27 : 17), wyb = sy ? 22 : (y == 0 ? 17 : 27);
             if (x < xstart) {
-                const int old = sample_lut(lut, off[1][1], sx, sy, 1, 1, x, y);
-                top = dv::iclip(round2(old * wxa + top * wxb, 5), grain_min, grain_max);
+                const int old = sample_lut(lut, off_left, sx, sy, 1, 0, x, y);
+                grain = dv::iclip(round2(old * wxa + grain * wxb, 5), grain_min, grain_max);
             }
-            grain = dv::iclip(round2(top * wya + grain * wyb, 5), grain_min, grain_max);
-        }
-        const int s0 = sp[(y0 + y) * src.stride[pl] + bx + x];
-        int val;
-        if (pl == 0) {
-            val = s0;
-        } else {
-            // luma co-located average; the reference extends the luma row by one pixel for odd widths
-            // (src/fg_apply_tmpl.c:193-199)
-            const int lx = (bx + x) << sx, ly = (prow * 32) + (y << sy);
-            const pixel *lrow = lp + ly * src.stride[0];
-            int avg = lrow[dv::imin(lx, src.w[0] - 1)];
-            if (sx) avg = (avg + lrow[dv::imin(lx + 1, src.w[0] - 1)] + 1) >> 1;
-            val = avg;
-            if (!p.chroma_scaling_from_luma) {
-                const int combined = avg * p.uv_luma_mult[uv] + s0 * p.uv_mult[uv];
-                val = dv::iclip((combined >> 6) + (p.uv_offset[uv] * (1 << bitdepth_min_8)), 0, bitdepth_max);
+            if (y < ystart) {
+                int top = sample_lut(lut, off_cur_up, sx, sy, 0, 1, x, y);
+                if (x < xstart) {
+                    const int old = sample_lut(lut, off_left_up, sx, sy, 1, 1, x, y);
+                    top = dv::iclip(round2(old * wxa + top * wxb, 5), grain_min, grain_max);
+                }
+                grain = dv::iclip(round2(top * wya + grain * wyb, 5), grain_min, grain_max);
             }
+            int val = s0[j];
+            if (pl) {
+                val = lum[j];
+                if (!p.chroma_scaling_from_luma) {
+                    const int combined = lum[j] * p.uv_luma_mult[uv] + s0[j] * p.uv_mult[uv];
+                    val = dv::iclip((combined >> 6) + (p.uv_offset[uv] * (1 << bitdepth_min_8)), 0, bitdepth_max);
+                }
+            }
+            const int noise = round2(sc_s[val] * grain, p.scaling_shift);
+            dp[(y0 + y) * ds + bx + x] = (pixel) dv::iclip(s0[j] + noise, min_value, max_value);
         }
-        const int noise = round2(sc[val] * grain, p.scaling_shift);
-        dp[(y0 + y) * dst.stride[pl] + bx + x] = (pixel) dv::iclip(s0 + noise, min_value, max_value);
     }
 }
 
@@ -261,30 +315,37 @@ extern "C" int dav1d_hip_launch_fg_gen_part(int16_t *luts, const Dav1dHipFilmGra
     return hip_rc(hipGetLastError());
 }
 
+// offs: device scratch of at least ceil(w / 32) * ceil(h / 32) bytes for the offset table
 extern "C" int dav1d_hip_launch_fg_apply(const DevPlanes *dst, const DevPlanes *src, const int16_t *luts, const uint8_t *scaling,
-                                         int scaling_size, const Dav1dHipFilmGrainData *data, int bpc, int layout, int is_id, void *stream)
+                                         int scaling_size, const Dav1dHipFilmGrainData *data, int bpc, int layout, int is_id,
+                                         uint8_t *offs, void *stream)
 {
     const int bitdepth_max = (1 << bpc) - 1;
     const dim3 grid((src->w[0] + 31) / 32, (src->h[0] + 31) / 32, layout == DAV1D_HIP_LAYOUT_I400 ? 1 : 3);
     const FgParams p = make_params(data);
+    const int offs_row0 = 0, offs_stride = (int) grid.x;
+    hipLaunchKernelGGL(fg_offsets_kernel, dim3((grid.y + 63) / 64), dim3(64), 0, (hipStream_t) stream, offs, p.seed, 0, (int) grid.y, (int) grid.x);
     if (bpc == 8)
-        hipLaunchKernelGGL((fg_apply_kernel<uint8_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max, 0, -1);
+        hipLaunchKernelGGL((fg_apply_kernel<uint8_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max, 0, -1, offs, offs_row0, offs_stride);
     else
-        hipLaunchKernelGGL((fg_apply_kernel<uint16_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max, 0, -1);
+        hipLaunchKernelGGL((fg_apply_kernel<uint16_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max, 0, -1, offs, offs_row0, offs_stride);
     return hip_rc(hipGetLastError());
 }
 
 // one block row (`row_num`) of one plane, the pictures holding only that row
 extern "C" int dav1d_hip_launch_fg_apply_rows(const DevPlanes *dst, const DevPlanes *src, const int16_t *luts, const uint8_t *scaling,
                                               int scaling_size, const Dav1dHipFilmGrainData *data, int bpc, int layout, int is_id,
-                                              int row_num, int pl, void *stream)
+                                              int row_num, int pl, uint8_t *offs, void *stream)
 {
     const int bitdepth_max = (1 << bpc) - 1;
     const dim3 grid((src->w[0] + 31) / 32, 1, 1);
     const FgParams p = make_params(data);
+    // two table rows: the row above (its offsets feed the vertical overlap) and this one
+    const int offs_row0 = row_num - 1, offs_stride = (int) grid.x;
+    hipLaunchKernelGGL(fg_offsets_kernel, dim3(1), dim3(64), 0, (hipStream_t) stream, offs, p.seed, offs_row0, 2, (int) grid.x);
     if (bpc == 8)
-        hipLaunchKernelGGL((fg_apply_kernel<uint8_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max, row_num, pl);
+        hipLaunchKernelGGL((fg_apply_kernel<uint8_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max, row_num, pl, offs, offs_row0, offs_stride);
     else
-        hipLaunchKernelGGL((fg_apply_kernel<uint16_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max, row_num, pl);
+        hipLaunchKernelGGL((fg_apply_kernel<uint16_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max, row_num, pl, offs, offs_row0, offs_stride);
     return hip_rc(hipGetLastError());
 }

@@ -61,19 +61,25 @@ __device__ __forceinline__ void txtp_kinds(const int txtp, int &first, int &seco
     second = v >> 2;
 }
 
-template <int N>
-__device__ __forceinline__ void tx1d(const int kind, const int *in, int *out, const int lo, const int hi) {
+// Runs the 1-D transform `kind` and hands the result to `done`.  Every kind finishes inside its own branch: merging
+// the branches' output arrays instead makes the compiler keep part of them in scratch memory.
+template <int N, typename F>
+__device__ __forceinline__ void tx1d(const int kind, const int *in, const int lo, const int hi, F &&done) {
     if constexpr (N == 64) {
+        int out[N];
         itx1d::idct<64>(in, out, lo, hi);
+        done(out);
     } else if constexpr (N == 32) {
-        if (kind == K_IDENTITY) itx1d::iidentity<32>(in, out);
-        else itx1d::idct<32>(in, out, lo, hi);
+        if (kind == K_IDENTITY) { int out[N]; itx1d::iidentity<32>(in, out); done(out); }
+        else { int out[N]; itx1d::idct<32>(in, out, lo, hi); done(out); }
     } else {
-        if (kind == K_DCT) itx1d::idct<N>(in, out, lo, hi);
-        else if (kind == K_IDENTITY) itx1d::iidentity<N>(in, out);
+        if (kind == K_DCT) { int out[N]; itx1d::idct<N>(in, out, lo, hi); done(out); }
+        else if (kind == K_IDENTITY) { int out[N]; itx1d::iidentity<N>(in, out); done(out); }
         else {
+            int out[N];
             if constexpr (N == 4) itx1d::iadst4(in, out);
             else itx1d::iadst<N>(in, out, lo, hi);
+            done(out);
         }
     }
 }
@@ -180,14 +186,15 @@ __global__ __launch_bounds__(64) void itx_add_kernel(const DevPlanes dst, const 
 #pragma unroll
             for (int x = 0; x < W; x++) tmp[l * TS + x] = out[x];
         } else {
-            tx1d<W>(k1, in, out, row_min, row_max);
             const int rnd = (1 << SHIFT) >> 1;
             const bool flip = k1 == K_FLIPADST;
+            tx1d<W>(k1, in, row_min, row_max, [&](const int *res) {
 #pragma unroll
-            for (int x = 0; x < W; x++) {
-                const int xo = flip ? W - 1 - x : x;
-                tmp[l * TS + xo] = dv::iclip((out[x] + rnd) >> SHIFT, col_min, col_max);
-            }
+                for (int x = 0; x < W; x++) {
+                    const int xo = flip ? W - 1 - x : x;
+                    tmp[l * TS + xo] = dv::iclip((res[x] + rnd) >> SHIFT, col_min, col_max);
+                }
+            });
         }
     }
     dv::wave_sync();
@@ -212,16 +219,17 @@ __global__ __launch_bounds__(64) void itx_add_kernel(const DevPlanes dst, const 
                 for (int y = 0; y < H; y++)
                     d[y * stride] = (pixel) dv::iclip((int) dpx[y] + out[y], 0, bitdepth_max);
             } else {
-                tx1d<H>(k2, cin, out, col_min, col_max);
-                if (k2 == K_FLIPADST) {
+                tx1d<H>(k2, cin, col_min, col_max, [&](const int *res) {
+                    if (k2 == K_FLIPADST) {
 #pragma unroll
-                    for (int y = 0; y < H; y++)
-                        d[y * stride] = (pixel) dv::iclip((int) dpx[y] + ((out[H - 1 - y] + 8) >> 4), 0, bitdepth_max);
-                } else {
+                        for (int y = 0; y < H; y++)
+                            d[y * stride] = (pixel) dv::iclip((int) dpx[y] + ((res[H - 1 - y] + 8) >> 4), 0, bitdepth_max);
+                    } else {
 #pragma unroll
-                    for (int y = 0; y < H; y++)
-                        d[y * stride] = (pixel) dv::iclip((int) dpx[y] + ((out[y] + 8) >> 4), 0, bitdepth_max);
-                }
+                        for (int y = 0; y < H; y++)
+                            d[y * stride] = (pixel) dv::iclip((int) dpx[y] + ((res[y] + 8) >> 4), 0, bitdepth_max);
+                    }
+                });
             }
         }
     }

@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-from ._lib import ITX_TASK, MC_TASK, COMP_TASK
+from ._lib import ITX_TASK, MC_TASK, COMP_TASK, LF_TASK, CDEF_TASK, LR_TASK, FilmGrainData
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -212,6 +212,7 @@ def make_frame(w, h, bpc, seed, mix=(0.20, 0.30, 0.30, 0.15, 0.05), compound_fra
 
     f = Frame()
     f.w, f.h, f.bpc, f.n_refs = w, h, bpc, n_refs
+    f.region, f.region_cls, f.region_sizes = region, rcls.reshape(len(ry), len(rx)), sizes
     f.mc = np.concatenate(mc_parts)
     f.comp = np.concatenate(comp_parts) if comp_parts else np.zeros(0, COMP_TASK)
     f.itx = np.concatenate(itx_parts)
@@ -251,3 +252,162 @@ def copy_planes(planes):
         base[:, :p.shape[1]] = p
         out.append(base[:, :p.shape[1]])
     return out
+
+
+# ------------------------------------------------------------------ post-filter task lists for the same frame
+
+class PostFilters:
+    """Loop filter, CDEF, loop restoration and film grain inputs of one synthetic frame."""
+    pass
+
+
+def _pack_lines(bits, along_axis):
+    """bits[class][.., ..] boolean per 4x4 unit -> uint32 masks per run of 32 units along `along_axis`."""
+    out = []
+    for b in bits:
+        n = b.shape[along_axis]
+        pad = (-n) % 32
+        if pad:
+            padw = [(0, 0), (0, 0)]
+            padw[along_axis] = (0, pad)
+            b = np.pad(b, padw)
+        if along_axis == 0:
+            r = b.reshape(b.shape[0] // 32, 32, b.shape[1])          # [line, u, x]
+            m = (r.astype(np.uint64) << np.arange(32, dtype=np.uint64)[None, :, None]).sum(axis=1)   # [line, x]
+        else:
+            r = b.reshape(b.shape[0], b.shape[1] // 32, 32)          # [y, line, u]
+            m = (r.astype(np.uint64) << np.arange(32, dtype=np.uint64)[None, None, :]).sum(axis=2)   # [y, line]
+        out.append(m.astype(np.uint32))
+    return out
+
+
+def make_post_filters(frame, seed, layout=1):
+    """Deblocking masks follow the frame's transform grid (one transform per block; chroma = half size, at least 4):
+    an edge unit is filtered where a transform edge lies, with the width the smaller neighbour allows (16 / 8 / 4 on
+    luma, 6 / 4 on chroma), levels 16..32; CDEF on every 8x8 with y strength 17, uv strength 5; Wiener on Y and
+    SGR-mix on U / V in 64-pixel units and 64-row stripes (first stripe 8 rows short); film grain with 2 luma points,
+    lag 3, overlap."""
+    assert layout == 1
+    rng = np.random.default_rng(seed)
+    w, h, bpc = frame.w, frame.h, frame.bpc
+    bd8 = bpc - 8
+    geo = plane_geometry(w, h, bpc, layout)
+    reg = frame.region
+    size_of_region = frame.region_sizes[frame.region_cls]                 # luma transform size per 64x64 region
+    p = PostFilters()
+
+    # ---- loop filter
+    w4, h4 = w // 4, h // 4
+    b4_stride = (w4 + 31) & ~31
+    p.b4_stride = b4_stride
+    p.lvl = rng.integers(16, 33, size=((h4 + 31) & ~31, b4_stride, 4)).astype(np.uint8)
+    p.lut_e, p.lut_i = np.zeros(64, np.uint8), np.zeros(64, np.uint8)
+    for level in range(64):            # dav1d_calc_eih with sharpness 0 (reference src/lf_mask.c:385-410)
+        p.lut_i[level] = max(level, 1)
+        p.lut_e[level] = 2 * (level + 2) + max(level, 1)
+    tasks = []
+    for pl in range(3):
+        ss = 1 if pl else 0
+        pw4, ph4 = w4 >> ss, h4 >> ss
+        upr = (reg >> ss) // 4                                            # 4x4 units of this plane per region side
+        tsz = np.maximum(size_of_region >> ss, 4)
+        s_u = np.kron(tsz, np.ones((upr, upr), np.int64))[:ph4, :pw4]     # transform size at every unit
+        yy, xx = np.mgrid[0:ph4, 0:pw4]
+        for d in (0, 1):
+            pos = (xx if d == 0 else yy) * 4
+            here = s_u
+            prev = np.roll(s_u, 1, axis=1 if d == 0 else 0)
+            edge = (pos % here == 0) & (pos > 0)
+            m = np.minimum(here, prev)
+            if pl == 0:
+                cls = [edge, edge & (m >= 8), edge & (m >= 16)]            # vmask[0] any width, [1] >= 8, [2] 16
+            else:
+                cls = [edge, edge & (m >= 8)]
+            masks = _pack_lines(cls, 0 if d == 0 else 1)
+            any_m = masks[0]
+            li, lj = np.nonzero(any_m)                                    # d=0: (line = run of 32 rows, x4); d=1: (y4, line)
+            t = np.zeros(len(li), LF_TASK)
+            if d == 0:
+                y4, x4 = li * 32, lj
+            else:
+                y4, x4 = li, lj * 32
+            t["dst_off"] = (y4 * 4) * geo[pl][0] + x4 * 4
+            t["lvl_off"] = y4 * b4_stride + x4
+            for k in range(len(masks)):
+                t["vmask"][:, k] = masks[k][li, lj]
+            t["plane"], t["dir"] = pl, d
+            t["lvl_comp"] = (0 if d == 0 else 1) if pl == 0 else 1 + pl
+            tasks.append(t)
+    p.lf = np.concatenate(tasks)
+
+    # ---- cdef: every 8x8 unit, strengths as the frame header would give them (y 17 -> pri 4, sec 1; uv 5 -> pri 1, sec 1)
+    bw, bh = w // 8, h // 8
+    by, bx = np.mgrid[0:bh, 0:bw]
+    c = np.zeros(bw * bh, CDEF_TASK)
+    c["bx"], c["by"] = bx.ravel(), by.ravel()
+    c["y_pri"], c["y_sec"], c["uv_pri"], c["uv_sec"] = 4 << bd8, 1 << bd8, 1 << bd8, 1 << bd8
+    c["edges"] = ((bx > 0) * 1 + (bx < bw - 1) * 2 + (by > 0) * 4 + (by < bh - 1) * 8).ravel()
+    p.cdef = c
+    p.cdef_damping = 5 + bd8
+
+    # ---- loop restoration: 64-pixel units; stripes of 64 luma rows, the first one 8 rows short (src/lr_apply_tmpl.c:50-51)
+    lr = []
+    for pl in range(3):
+        ss = 1 if pl else 0
+        pw, ph = w >> ss, h >> ss
+        ys = [0]
+        first = (64 - 8) >> ss
+        y = first
+        while y < ph:
+            ys.append(y)
+            y += 64 >> ss
+        ys.append(ph)
+        xs = np.arange(0, pw, 64)
+        for si in range(len(ys) - 1):
+            y0, y1 = ys[si], ys[si + 1]
+            t = np.zeros(len(xs), LR_TASK)
+            t["x"], t["y"] = xs, y0
+            t["w"] = np.minimum(64, pw - xs)
+            t["h"] = y1 - y0
+            t["plane"] = pl
+            t["edges"] = (xs > 0) * 1 + (xs + 64 < pw) * 2 + (4 if y0 > 0 else 0) + (8 if y1 < ph else 0)
+            if pl == 0:
+                t["type"] = 0                                            # 7-tap Wiener, taps in the checkasm ranges
+                for d in range(2):
+                    f0 = rng.integers(-5, 11, size=len(xs))
+                    f1 = rng.integers(-23, 9, size=len(xs))
+                    f2 = rng.integers(-17, 47, size=len(xs))
+                    t["filter"][:, d, 0] = t["filter"][:, d, 6] = f0
+                    t["filter"][:, d, 1] = t["filter"][:, d, 5] = f1
+                    t["filter"][:, d, 2] = t["filter"][:, d, 4] = f2
+                    centre = -(f0 + f1 + f2) * 2
+                    t["filter"][:, d, 3] = centre + (128 if (d == 1 or bpc > 8) else 0)       # src/lr_apply_tmpl.c:55-66
+            else:
+                t["type"] = 4                                            # SGR mix, parameter set 0..9
+                sgr = np.array([(140, 3236), (112, 2158), (93, 1618), (80, 1438), (70, 1295), (58, 1177), (47, 1079), (37, 996),
+                                (30, 925), (25, 863)], np.int64)
+                k = rng.integers(0, 10, size=len(xs))
+                w0 = rng.integers(-96, 32, size=len(xs))
+                w1 = 160 - rng.integers(0, 128, size=len(xs)) - w0
+                t["filter"][:, 0, 0], t["filter"][:, 0, 1] = sgr[k, 0], sgr[k, 1]
+                t["filter"][:, 0, 2], t["filter"][:, 0, 3] = w0, w1
+            lr.append(t)
+    p.lr = np.concatenate(lr)
+
+    # ---- film grain
+    d = FilmGrainData()
+    d.seed = int(rng.integers(0, 1 << 16))
+    d.num_y_points = 2
+    d.y_points[0][0], d.y_points[0][1], d.y_points[1][0], d.y_points[1][1] = 16, 40, 235, 120
+    for i in range(2):
+        d.num_uv_points[i] = 2
+        d.uv_points[i][0][0], d.uv_points[i][0][1], d.uv_points[i][1][0], d.uv_points[i][1][1] = 16, 30, 240, 90
+        d.uv_mult[i], d.uv_luma_mult[i], d.uv_offset[i] = 64 + 8 * i, 32, 10 * (i + 1)
+        for k in range(25):
+            d.ar_coeffs_uv[i][k] = int(rng.integers(-32, 32))
+    d.scaling_shift, d.ar_coeff_lag, d.ar_coeff_shift, d.grain_scale_shift = 10, 3, 7, 0
+    for k in range(24):
+        d.ar_coeffs_y[k] = int(rng.integers(-32, 32))
+    d.overlap_flag, d.clip_to_restricted_range = 1, 0
+    p.fg = d
+    return p

@@ -134,3 +134,140 @@ int dav1d_replay_comp(entry_fn entry, int bpc, const ReplayPlanes *dst, const Da
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------ post filters
+ * The same marshalling for the in-loop filters: every task becomes the DSP call (or calls) the reference drivers
+ * would issue, on host planes.  Only driver-side glue is restated here (which rows go into `left` / `top` / `lpf`,
+ * the variance adjustment of the CDEF primary strength); the filters themselves are the oracle's. */
+#include <stdlib.h>
+
+typedef void (*lf8_fn)(uint8_t *, ptrdiff_t, const uint32_t *, const uint8_t (*)[4], ptrdiff_t, const void *, int);
+typedef void (*lf16_fn)(uint16_t *, ptrdiff_t, const uint32_t *, const uint8_t (*)[4], ptrdiff_t, const void *, int, int);
+
+/* dsp->lf.loop_filter_sb as dav1d_loopfilter_sbrow_cols / _rows call it (reference src/lf_apply_tmpl.c:176-311): every
+ * column-edge task, then every row-edge task.  lut = Av1FilterLUT { e[64], i[64], sharp[2] }. */
+int dav1d_replay_lf(entry_fn entry, int bpc, const ReplayPlanes *dst, const Dav1dHipLfTask *t, size_t n, const uint8_t *lvl,
+                    ptrdiff_t b4_stride, const void *lut)
+{
+    const int bdmax = (1 << bpc) - 1, bps = bpc > 8 ? 2 : 1;
+    for (int dir = 0; dir < 2; dir++)
+        for (size_t i = 0; i < n; i++) {
+            const Dav1dHipLfTask *k = &t[i];
+            if (k->dir != dir) continue;
+            void *fn = entry(bpc, "loop_filter_sb", k->plane != 0, dir);
+            if (!fn) return -1;
+            uint8_t *p = (uint8_t *) dst->data[k->plane] + (size_t) k->dst_off * bps;
+            const uint8_t (*l)[4] = (const uint8_t (*)[4]) (lvl + (size_t) k->lvl_off * 4 + k->lvl_comp);
+            if (bpc == 8) ((lf8_fn) fn)(p, dst->stride[k->plane], k->vmask, l, b4_stride, lut, 32);
+            else ((lf16_fn) fn)((uint16_t *) p, dst->stride[k->plane], k->vmask, l, b4_stride, lut, 32, bdmax);
+        }
+    return 0;
+}
+
+typedef int (*cdir8_fn)(const uint8_t *, ptrdiff_t, unsigned *);
+typedef int (*cdir16_fn)(const uint16_t *, ptrdiff_t, unsigned *, int);
+typedef void (*cfb8_fn)(uint8_t *, ptrdiff_t, const void *, const uint8_t *, const uint8_t *, int, int, int, int, int);
+typedef void (*cfb16_fn)(uint16_t *, ptrdiff_t, const void *, const uint16_t *, const uint16_t *, int, int, int, int, int, int);
+
+static void cdef_block(void *fn, int bpc, const ReplayPlanes *src, const ReplayPlanes *dst, int pl, int px0, int py0, int w, int h,
+                       int pri, int sec, int dir, int damping, int edges)
+{
+    const int bps = bpc > 8 ? 2 : 1, bdmax = (1 << bpc) - 1;
+    const ptrdiff_t st = src->stride[pl];
+    const uint8_t *s = (const uint8_t *) src->data[pl];
+    uint8_t left[8 * 2 * 2];
+    memset(left, 0, sizeof(left));
+    if (px0 >= 2) for (int y = 0; y < h; y++) memcpy(left + y * 2 * bps, s + (py0 + y) * st + (px0 - 2) * bps, 2 * bps);
+    /* rows above / below come from the unfiltered picture; when an edge flag is clear the pointer is never read */
+    const uint8_t *top = s + (py0 >= 2 ? py0 - 2 : 0) * st + px0 * bps;
+    const uint8_t *bot = s + (py0 + h < src->h[pl] ? py0 + h : src->h[pl] - 1) * st + px0 * bps;
+    uint8_t *blk = (uint8_t *) dst->data[pl] + py0 * dst->stride[pl] + px0 * bps;
+    if (bpc == 8) ((cfb8_fn) fn)(blk, dst->stride[pl], left, top, bot, pri, sec, dir, damping, edges);
+    else ((cfb16_fn) fn)((uint16_t *) blk, dst->stride[pl], left, (const uint16_t *) top, (const uint16_t *) bot, pri, sec, dir, damping, edges, bdmax);
+}
+
+/* One 8x8 unit of dav1d_cdef_brow (reference src/cdef_apply_tmpl.c:149-290), out of place: `dst` starts as a copy of
+ * `src`; direction search and variance adjustment (adjust_strength, :91-95) as the driver does them; the chroma
+ * direction remap of 4:2:2 (:115-117).  src and dst must share strides. */
+int dav1d_replay_cdef(entry_fn entry, int bpc, int layout, const ReplayPlanes *src, const ReplayPlanes *dst, const Dav1dHipCdefTask *t,
+                      size_t n, int damping)
+{
+    const int ss_ver = layout == 1, ss_hor = layout != 3 && layout != 0;
+    void *dirfn = entry(bpc, "cdef_dir", 0, 0), *fby = entry(bpc, "cdef_fb", 0, 0), *fbuv = layout ? entry(bpc, "cdef_fb", 3 - layout, 0) : NULL;
+    if (!dirfn || !fby) return -1;
+    static const uint8_t uv422[8] = { 7, 0, 2, 4, 5, 6, 6, 6 };
+    for (size_t i = 0; i < n; i++) {
+        const Dav1dHipCdefTask *k = &t[i];
+        if (k->flags & 1) continue;                          /* raw single-call tasks are not part of the frame flow */
+        const int x0 = k->bx * 8, y0 = k->by * 8;
+        int dir = 0;
+        unsigned var = 0;
+        if (k->y_pri || k->uv_pri) {
+            const uint8_t *blk = (const uint8_t *) src->data[0] + y0 * src->stride[0] + x0 * (bpc > 8 ? 2 : 1);
+            dir = bpc == 8 ? ((cdir8_fn) dirfn)(blk, src->stride[0], &var) : ((cdir16_fn) dirfn)((const uint16_t *) blk, src->stride[0], &var, (1 << bpc) - 1);
+        }
+        if (k->y_pri) {
+            int adj = 0;
+            if (var) {
+                int lg = 0;
+                for (unsigned v = var >> 6; v > 1; v >>= 1) lg++;
+                const int idx = (var >> 6) ? (lg < 12 ? lg : 12) : 0;
+                adj = (k->y_pri * (4 + idx) + 8) >> 4;
+            }
+            if (adj || k->y_sec) cdef_block(fby, bpc, src, dst, 0, x0, y0, 8, 8, adj, k->y_sec, dir, damping, k->edges);
+        } else if (k->y_sec) {
+            cdef_block(fby, bpc, src, dst, 0, x0, y0, 8, 8, 0, k->y_sec, 0, damping, k->edges);
+        }
+        if (fbuv && (k->uv_pri || k->uv_sec)) {
+            const int uvdir = k->uv_pri ? (layout == 2 ? uv422[dir] : dir) : 0;
+            for (int pl = 1; pl <= 2; pl++)
+                cdef_block(fbuv, bpc, src, dst, pl, x0 >> ss_hor, y0 >> ss_ver, 8 >> ss_hor, 8 >> ss_ver, k->uv_pri, k->uv_sec, uvdir,
+                           damping - 1, k->edges);
+        }
+    }
+    return 0;
+}
+
+typedef void (*lr8_fn)(uint8_t *, ptrdiff_t, const void *, const uint8_t *, int, int, const void *, int);
+typedef void (*lr16_fn)(uint16_t *, ptrdiff_t, const void *, const uint16_t *, int, int, const void *, int, int);
+
+/* One looprestorationfilter_fn call per task as lr_stripe() issues it (reference src/lr_apply_tmpl.c:36-97), out of place:
+ * `dst` starts as a copy of `src` (the tasks are walked in the order given, which must be raster order so that a unit's
+ * right neighbour is still unfiltered); `left` = the 4 columns left of the unit from `src`; the lpf buffer = rows y-2,
+ * y-1 at rows 0, 1 and rows y+h, y+h+1 at rows 6, 7 of an 8-row scratch with the plane's stride, from `lpf`. */
+int dav1d_replay_lr(entry_fn entry, int bpc, const ReplayPlanes *src, const ReplayPlanes *lpf, const ReplayPlanes *dst,
+                    const Dav1dHipLrTask *t, size_t n)
+{
+    const int bps = bpc > 8 ? 2 : 1, bdmax = (1 << bpc) - 1;
+    ptrdiff_t max_stride = 0;
+    for (int pl = 0; pl < 3; pl++) if (src->data[pl] && src->stride[pl] > max_stride) max_stride = src->stride[pl];
+    uint8_t *rows = malloc((size_t) 8 * max_stride + 64);
+    if (!rows) return -2;
+    for (size_t i = 0; i < n; i++) {
+        const Dav1dHipLrTask *k = &t[i];
+        const int pl = k->plane;
+        const ptrdiff_t st = dst->stride[pl];
+        if (src->stride[pl] != st || lpf->stride[pl] != st) { free(rows); return -3; }
+        void *fn = k->type <= DAV1D_HIP_LR_WIENER5 ? entry(bpc, "wiener", k->type, 0) : entry(bpc, "sgr", k->type - DAV1D_HIP_LR_SGR_5X5, 0);
+        if (!fn) { free(rows); return -1; }
+        uint8_t left[64 * 4 * 2];
+        memset(left, 0, sizeof(left));
+        if (k->x >= 4) for (int y = 0; y < k->h; y++) memcpy(left + y * 4 * bps, (const uint8_t *) src->data[pl] + (k->y + y) * st + (k->x - 4) * bps, 4 * bps);
+        const uint8_t *lp = (const uint8_t *) lpf->data[pl];
+        memset(rows, 0, (size_t) 8 * st);
+        if (k->y >= 2) { memcpy(rows, lp + (k->y - 2) * st, st); memcpy(rows + st, lp + (k->y - 1) * st, st); }
+        if (k->y + k->h + 1 < lpf->h[pl] + 8) {          /* planes are allocated with padding rows */
+            memcpy(rows + 6 * st, lp + (k->y + k->h) * st, st);
+            memcpy(rows + 7 * st, lp + (k->y + k->h + 1) * st, st);
+        }
+        union { int16_t filter[2][8]; struct { uint32_t s0, s1; int16_t w0, w1; } sgr; } prm;
+        memset(&prm, 0, sizeof(prm));
+        if (k->type <= DAV1D_HIP_LR_WIENER5) memcpy(prm.filter, k->filter, sizeof(prm.filter));
+        else { prm.sgr.s0 = (uint16_t) k->filter[0][0]; prm.sgr.s1 = (uint16_t) k->filter[0][1]; prm.sgr.w0 = k->filter[0][2]; prm.sgr.w1 = k->filter[0][3]; }
+        uint8_t *p = (uint8_t *) dst->data[pl] + k->y * st + k->x * bps;
+        if (bpc == 8) ((lr8_fn) fn)(p, st, left, rows + k->x * bps, k->w, k->h, &prm, k->edges);
+        else ((lr16_fn) fn)((uint16_t *) p, st, left, (const uint16_t *) (rows + k->x * bps), k->w, k->h, &prm, k->edges, bdmax);
+    }
+    free(rows);
+    return 0;
+}

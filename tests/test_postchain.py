@@ -1,0 +1,83 @@
+"""The in-loop filter chain of a whole frame -- deblocking, CDEF, loop restoration, film grain -- on the task lists
+dav1d_amd.synth derives from the frame's transform grid: HIP backend through the C ABI vs the oracle's DSP entries
+driven by oracle/replay.c the way the reference drivers drive them (src/lf_apply_tmpl.c, src/cdef_apply_tmpl.c,
+src/lr_apply_tmpl.c), stage by stage on identical inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import util
+from dav1d_amd import api, synth
+from test_frame import RP, planes_struct
+
+
+def oracle_post(oracle, post, recon, w, h, bpc, with_grain=True):
+    """recon planes -> (deblocked, cdef, restored, grain) planes on the host."""
+    rl = util.replay_lib()
+    entry = C.cast(oracle._entry, C.c_void_p)
+    lut = np.zeros(144, np.uint8)
+    lut[:64], lut[64:128] = post.lut_e, post.lut_i
+    d = synth.copy_planes(recon)
+    assert rl.dav1d_replay_lf(entry, bpc, C.byref(planes_struct(d, w, h)), post.lf.ctypes.data, len(post.lf), post.lvl.ctypes.data,
+                              post.b4_stride, lut.ctypes.data) == 0
+    c = synth.copy_planes(d)
+    assert rl.dav1d_replay_cdef(entry, bpc, 1, C.byref(planes_struct(d, w, h)), C.byref(planes_struct(c, w, h)), post.cdef.ctypes.data,
+                                len(post.cdef), post.cdef_damping) == 0
+    r = synth.copy_planes(c)
+    assert rl.dav1d_replay_lr(entry, bpc, C.byref(planes_struct(c, w, h)), C.byref(planes_struct(d, w, h)), C.byref(planes_struct(r, w, h)),
+                              post.lr.ctypes.data, len(post.lr)) == 0
+    g = None
+    if with_grain and util.ref_lib() is not None:
+        from test_filmgrain import _ref
+        g = synth.copy_planes(r)
+        src = synth.copy_planes(r)      # dav1d_apply_grain pads the luma of its input by one pixel (src/fg_apply_tmpl.c:193-199)
+        sp = (C.c_void_p * 3)(*[p.ctypes.data for p in src])
+        gp = (C.c_void_p * 3)(*[p.ctypes.data for p in g])
+        assert _ref().dav1d_ref_apply_grain(bpc, C.addressof(post.fg), w, h, 1, 0, gp, sp, g[0].strides[0], g[1].strides[0]) == 0
+    return d, c, r, g
+
+
+def hip_post(ctx, post, recon, w, h, bpc, with_grain=True):
+    pics = [ctx.picture(w, h, api.LAYOUT_I420, bpc) for _ in range(5)]
+    rec, dbl, cdf, res, grn = pics
+    for pl in range(3):
+        dbl.upload(pl, recon[pl])
+    lvl = ctx.buffer_from(post.lvl)
+    ctx.lf_batch(dbl, post.lf, lvl, post.b4_stride, post.lut_e, post.lut_i)
+    d = [dbl.download(pl) for pl in range(3)]
+    for pl in range(3):
+        cdf.upload(pl, d[pl])
+    ctx.cdef_batch(cdf, dbl, post.cdef, post.cdef_damping)
+    c = [cdf.download(pl) for pl in range(3)]
+    for pl in range(3):
+        res.upload(pl, c[pl])
+    ctx.lr_batch(res, cdf, dbl, post.lr)
+    r = [res.download(pl) for pl in range(3)]
+    g = None
+    if with_grain:
+        ctx.fg_apply(grn, res, post.fg)
+        g = [grn.download(pl) for pl in range(3)]
+    for o in pics + [lvl]:
+        o.free()
+    return d, c, r, g
+
+
+@pytest.mark.parametrize("bpc", [8, 10])
+def test_post_filter_chain_matches_oracle(ctx, bpc):
+    oracle = util.default_oracle()
+    w, h = (256, 192) if ctx.backend == "emu" else (1024, 576)
+    frame = synth.make_frame(w, h, bpc, seed=77 + bpc)
+    post = synth.make_post_filters(frame, seed=5 + bpc)
+    rng = np.random.default_rng(bpc)
+    recon = synth.make_planes(rng, w, h, bpc, smooth=True)
+    want = oracle_post(oracle, post, recon, w, h, bpc)
+    got = hip_post(ctx, post, recon, w, h, bpc)
+    for stage, a, b in zip(("deblock", "cdef", "restoration", "grain"), got, want):
+        if b is None:
+            continue
+        for pl in range(3):
+            vh, vw = (h, w) if pl == 0 else (h // 2, w // 2)
+            bad = np.argwhere(a[pl][:vh, :vw] != b[pl][:vh, :vw])
+            assert not len(bad), "%s plane %d differs at %s (%d px)" % (stage, pl, bad[0], len(bad))
+    assert any(np.any(got[0][pl] != recon[pl]) for pl in range(3)), "deblocking must change something"
