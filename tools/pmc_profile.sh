@@ -10,14 +10,14 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export DAV1D_HIP_SERIAL=1   # per-kernel durations must not overlap: run the shapes back to back
 ARGS="--steps 3 --warmup 1 --no-cpu --no-check $*"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python "$ROOT/bench.py" $ARGS > "$OUT/stats.log" 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python "$ROOT/bench.py" $ARGS > "$OUT/stats.log" 2>&1
 i=0
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM" \
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_INSTS_SMEM" \
            "FETCH_SIZE" \
            "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
     i=$((i+1))
-    timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pmc$i" -- python "$ROOT/bench.py" $ARGS > "$OUT/pmc$i.log" 2>&1
+    timeout 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pmc$i" -- python "$ROOT/bench.py" $ARGS > "$OUT/pmc$i.log" 2>&1
 done
 python "$ROOT/tools/pmc_summary.py" "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
