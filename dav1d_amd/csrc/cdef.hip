@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64) void cdef_kernel(const DevPlanes dst, const Dev
                                                   const int n, const int damping, const int layout, const int bitdepth_max,
                                                   uint32_t *__restrict__ dirvar)
 {
-    __shared__ int16_t tmp[144];
+    __shared__ int16_t tmp[144], tmp2[144];
     __shared__ int psum[2 * 8 + 2 * 15 + 4 * 11];    // hv[2][8], diag[2][15], alt[4][11]
     __shared__ unsigned cost_s[8];
 
@@ -174,14 +174,14 @@ __global__ __launch_bounds__(64) void cdef_kernel(const DevPlanes dst, const Dev
         } else if (sec) {
             run = true;
         }
-        const int x = lane % lw, y = lane / lw;
+        const int x = lane & (lw - 1), y = lane >> (lw == 4 ? 2 : 3);     // lw is 4 or 8
         if (run && y < lh) {
             const int v = cdef_px(tmp, x, y, pri, sec, d, damping, bitdepth_min_8);
             reinterpret_cast<pixel *>(dst.data[lpl])[(y0 + y) * dst.stride[lpl] + x0 + x] = (pixel) v;
         }
     }
 
-    // ---- chroma
+    // ---- chroma: both planes in one pass, U on the first w*h lanes, V on the next w*h (4:4:4: two passes of 64)
     if (!raw && (t.uv_pri || t.uv_sec) && layout != DAV1D_HIP_LAYOUT_I400) {
         const int ss_ver = layout == DAV1D_HIP_LAYOUT_I420, ss_hor = layout != DAV1D_HIP_LAYOUT_I444;
         const int w = 8 >> ss_hor, h = 8 >> ss_ver;
@@ -189,17 +189,17 @@ __global__ __launch_bounds__(64) void cdef_kernel(const DevPlanes dst, const Dev
         const unsigned uv422 = 0x66654207u;   // nibbles 7,0,2,4,5,6,6,6 for dir 0..7
         int uvdir = 0;
         if (t.uv_pri) uvdir = layout == DAV1D_HIP_LAYOUT_I422 ? (int) ((uv422 >> (4 * dir)) & 15) : dir;
-        for (int pl = 1; pl <= 2; pl++) {
-            dv::wave_sync();
-            const pixel *sp = reinterpret_cast<const pixel *>(src.data[pl]);
-            const int cx0 = x0 >> ss_hor, cy0 = y0 >> ss_ver;
-            load_window<pixel>(tmp, sp, src.stride[pl], cx0, cy0, w, h, edges, lane);
-            dv::wave_sync();
-            const int x = lane % w, y = lane / w;
-            if (y < h) {
-                const int v = cdef_px(tmp, x, y, t.uv_pri, t.uv_sec, uvdir, damping - 1, bitdepth_min_8);
-                reinterpret_cast<pixel *>(dst.data[pl])[(cy0 + y) * dst.stride[pl] + cx0 + x] = (pixel) v;
-            }
+        const int cx0 = x0 >> ss_hor, cy0 = y0 >> ss_ver;
+        dv::wave_sync();
+        load_window<pixel>(tmp, reinterpret_cast<const pixel *>(src.data[1]), src.stride[1], cx0, cy0, w, h, edges, lane);
+        load_window<pixel>(tmp2, reinterpret_cast<const pixel *>(src.data[2]), src.stride[2], cx0, cy0, w, h, edges, lane);
+        dv::wave_sync();
+        const int npx = w * h;                        // 16, 32 or 64 pixels per plane
+        for (int i = lane; i < 2 * npx; i += 64) {
+            const int pl = 1 + (i >= npx), k = i - (pl - 1) * npx;
+            const int x = k & (w - 1), y = k >> (3 - ss_hor);
+            const int v = cdef_px(pl == 1 ? tmp : tmp2, x, y, t.uv_pri, t.uv_sec, uvdir, damping - 1, bitdepth_min_8);
+            reinterpret_cast<pixel *>(dst.data[pl])[(cy0 + y) * dst.stride[pl] + cx0 + x] = (pixel) v;
         }
     }
 }
