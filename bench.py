@@ -306,7 +306,8 @@ def main():
                     "parity": "skipped" if a.no_check else "every stage bit-exact vs %s oracle%s" % (
                         oracle.which, "" if want_post[3] is not None else " (film grain unchecked: needs oracle/_ref)"),
                     "cpu_post_filters_s": round(t_post_cpu, 2)}
-        out = {"metric": "reconstructed luma Mpixels/s (8K 4:2:0 10-bit) on the itx+mc recon path; bit-exact vs C",
+        label = "8K" if (w, h) == (7680, 4320) else "4K" if (w, h) == (3840, 2160) else "%dx%d" % (w, h)
+        out = {"metric": "reconstructed luma Mpixels/s (%s 4:2:0 %d-bit) on the itx+mc recon path; bit-exact vs C" % (label, bpc),
                "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "int32" if bpc > 8 else "int16", "data": "synthetic",

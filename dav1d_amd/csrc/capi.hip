@@ -303,6 +303,7 @@ struct Dav1dHipMcList {
     McTile *dev_all;  // the same tiles, all shapes interleaved in source order (one launch for everything)
     McGroup *groups;
     size_t n_groups;
+    int max_ref;      // highest reference index any tile uses: checked against n_refs at run time
 };
 
 // DAV1D_HIP_MC_FUSED=1 runs every tile shape in one launch.  Measured on MI355X (8K 10-bit synthetic frame): the
@@ -390,6 +391,10 @@ static int mc_list_from_bins(Dav1dHipContext *c, Dav1dHipMcList **out, std::vect
     }
     l->off[MC_BINS] = all.size();
     l->n = all.size();
+    for (const McTile &t : all) {
+        const bool two = t.kind == MCT_AVG || t.kind == MCT_WAVG;
+        l->max_ref = std::max(l->max_ref, std::max((int) t.r[0].ref, two ? (int) t.r[1].ref : 0));
+    }
     if (l->n) {
         if (hipMalloc((void **) &l->dev, l->n * sizeof(McTile)) != hipSuccess) { delete l; return -ENOMEM; }
         int rc = dav1d_hip_upload(c, l->dev, all.data(), l->n * sizeof(McTile));
@@ -459,7 +464,7 @@ void dav1d_hip_mc_list_destroy(Dav1dHipContext *c, Dav1dHipMcList *l) {
 
 int dav1d_hip_mc_list_run(Dav1dHipContext *c, const Dav1dHipMcList *l, const Dav1dHipPicture *dst,
                           const Dav1dHipPicture *refs, int n_refs, int16_t *prep) {
-    if (!l || !dst || !refs || n_refs < 1 || n_refs > 8) return -EINVAL;
+    if (!l || !dst || !refs || n_refs < 1 || n_refs > 8 || (l->n && l->max_ref >= n_refs)) return -EINVAL;
     const DevPlanes dp = dev_planes(dst);
     DevPlanes rp[8];
     for (int i = 0; i < n_refs; i++) {
@@ -481,7 +486,7 @@ int dav1d_hip_mc_list_run(Dav1dHipContext *c, const Dav1dHipMcList *l, const Dav
 
 int dav1d_hip_mc_list_run_timed(Dav1dHipContext *c, const Dav1dHipMcList *l, const Dav1dHipPicture *dst,
                                 const Dav1dHipPicture *refs, int n_refs, int16_t *prep, float *ms, size_t *counts) {
-    if (!l || !dst || !refs || n_refs < 1 || n_refs > 8 || !ms) return -EINVAL;
+    if (!l || !dst || !refs || n_refs < 1 || n_refs > 8 || !ms || (l->n && l->max_ref >= n_refs)) return -EINVAL;
     const DevPlanes dp = dev_planes(dst);
     DevPlanes rp[8];
     for (int i = 0; i < n_refs; i++) rp[i] = dev_planes(&refs[i]);
