@@ -113,7 +113,7 @@ struct McGroup {
     uint16_t cls;         // tile-shape bin
 };
 extern "C" int dav1d_hip_launch_mc_all(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, const McTile *tiles,
-                                       const McGroup *groups, int n_groups, int16_t *prep, void *stream);
+                                       const McGroup *groups, int n_groups, int with_small, int16_t *prep, void *stream);
 extern "C" int dav1d_hip_launch_mc_bin(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, int cls,
                                        const McTile *tiles, int n, int16_t *prep, void *stream);
 extern "C" int dav1d_hip_launch_comp(const DevPlanes *dst, int bpc, const Dav1dHipCompTask *tasks, int n,

@@ -302,17 +302,18 @@ struct Dav1dHipMcList {
     size_t off[16];   // 15 tile-shape bins: 3 * class(w in 4..64) + class(h in 4..16)
     McTile *dev_all;  // the same tiles, all shapes interleaved in source order (one launch for everything)
     McGroup *groups;
-    size_t n_groups;
+    size_t n_groups, n_fused;
     int max_ref;      // highest reference index any tile uses: checked against n_refs at run time
 };
 
-// DAV1D_HIP_MC_FUSED=1 runs every tile shape in one launch.  Measured on MI355X (8K 10-bit synthetic frame): the
-// fetch traffic drops by a third (lines are shared across shapes while they sit in L2) but the launch is 10 % slower
-// than the per-shape launches, because every wave then pays the LDS / VGPR footprint of the hungriest shape; so
-// one launch per shape stays the default.
-static bool mc_all_shapes() {
-    static const bool on = getenv("DAV1D_HIP_MC_FUSED") && atoi(getenv("DAV1D_HIP_MC_FUSED")) != 0;
-    return on;
+// DAV1D_HIP_MC_FUSED: which tile shapes share one launch over a source-ordered list instead of one launch per shape.
+//   0  none;  2  the shapes that are at least 16 wide (bins 6 .. 14);  1  all of them.
+// Measured on MI355X (8K 10-bit synthetic frame): mode 1 cuts the fetch traffic by a third (lines are shared across
+// shapes while they sit in L2) but runs 10 % slower than per-shape launches, because every wave then pays the LDS / VGPR
+// footprint of the hungriest (small-tile) shape.
+static int mc_fused_min_bin() {
+    static const int mode = getenv("DAV1D_HIP_MC_FUSED") ? atoi(getenv("DAV1D_HIP_MC_FUSED")) : 0;
+    return mode == 1 ? 0 : mode == 2 ? 6 : 15;
 }
 
 static int tile_dim_class(int v) { return v <= 4 ? 0 : v <= 8 ? 1 : v <= 16 ? 2 : v <= 32 ? 3 : 4; }
@@ -402,20 +403,23 @@ static int mc_list_from_bins(Dav1dHipContext *c, Dav1dHipMcList **out, std::vect
         // All shapes in one list: cells of (reference, plane, 64-row band, 512-pixel strip) of the SOURCE position, shapes
         // kept together inside a cell so that a wave gets a full group of one shape; a group never leaves its cell.
         struct Ent { uint64_t key; uint32_t idx; };
-        std::vector<Ent> ord(l->n);
-        for (int b = 0; b < MC_BINS; b++)
+        const int fb = mc_fused_min_bin();
+        l->n_fused = l->n - l->off[fb];
+        std::vector<Ent> ord(l->n_fused);
+        for (int b = fb; b < MC_BINS; b++)
             for (size_t i = l->off[b]; i < l->off[b + 1]; i++) {
                 const McRef &r = all[i].r[0];
                 const uint64_t y = (uint64_t) (r.src_y + 4096) & 0xffff, x = (uint64_t) (r.src_x + 4096) & 0xffff;
-                ord[i].key = ((uint64_t) r.ref << 60) | ((uint64_t) all[i].plane << 58) | ((y >> 6) << 48) | ((x >> 9) << 42) |
+                Ent &e = ord[i - l->off[fb]];
+                e.key = ((uint64_t) r.ref << 60) | ((uint64_t) all[i].plane << 58) | ((y >> 6) << 48) | ((x >> 9) << 42) |
                              ((uint64_t) b << 38) | (x << 16) | y;
-                ord[i].idx = (uint32_t) i;
+                e.idx = (uint32_t) i;
             }
         std::sort(ord.begin(), ord.end(), [](const Ent &p, const Ent &q) { return p.key < q.key; });
-        std::vector<McTile> fused(l->n);
+        std::vector<McTile> fused(l->n_fused);
         std::vector<McGroup> groups;
         uint64_t cur = ~0ull;
-        for (size_t i = 0; i < l->n; i++) {
+        for (size_t i = 0; i < l->n_fused; i++) {
             fused[i] = all[ord[i].idx];
             const uint64_t cell_cls = ord[i].key >> 38;
             const int cls = (int) (cell_cls & 15);
@@ -429,10 +433,12 @@ static int mc_list_from_bins(Dav1dHipContext *c, Dav1dHipMcList **out, std::vect
             groups.back().n++;
         }
         l->n_groups = groups.size();
-        if (hipMalloc((void **) &l->dev_all, l->n * sizeof(McTile)) != hipSuccess ||
-            hipMalloc((void **) &l->groups, groups.size() * sizeof(McGroup)) != hipSuccess) rc = -ENOMEM;
-        if (!rc) rc = dav1d_hip_upload(c, l->dev_all, fused.data(), l->n * sizeof(McTile));
-        if (!rc) rc = dav1d_hip_upload(c, l->groups, groups.data(), groups.size() * sizeof(McGroup));
+        if (l->n_fused) {
+            if (hipMalloc((void **) &l->dev_all, l->n_fused * sizeof(McTile)) != hipSuccess ||
+                hipMalloc((void **) &l->groups, groups.size() * sizeof(McGroup)) != hipSuccess) rc = -ENOMEM;
+            if (!rc) rc = dav1d_hip_upload(c, l->dev_all, fused.data(), l->n_fused * sizeof(McTile));
+            if (!rc) rc = dav1d_hip_upload(c, l->groups, groups.data(), groups.size() * sizeof(McGroup));
+        }
         if (rc) { hipFree(l->dev); if (l->dev_all) hipFree(l->dev_all); if (l->groups) hipFree(l->groups); delete l; return rc; }
     }
     *out = l;
@@ -471,11 +477,11 @@ int dav1d_hip_mc_list_run(Dav1dHipContext *c, const Dav1dHipMcList *l, const Dav
         if (refs[i].bpc != dst->bpc) return -EINVAL;
         rp[i] = dev_planes(&refs[i]);
     }
-    if (mc_all_shapes())
-        return dav1d_hip_launch_mc_all(&dp, rp, n_refs, dst->bpc, l->dev_all, l->groups, (int) l->n_groups, prep, c->stream);
+    const int fb = mc_fused_min_bin();
     StreamFan fan(c);
     int rc = 0;
-    for (int b = MC_BINS - 1; b >= 0 && !rc; b--) {
+    if (l->n_fused) rc = dav1d_hip_launch_mc_all(&dp, rp, n_refs, dst->bpc, l->dev_all, l->groups, (int) l->n_groups, fb == 0, prep, fan.next());
+    for (int b = fb - 1; b >= 0 && !rc; b--) {
         const size_t cnt = l->off[b + 1] - l->off[b];
         if (!cnt) continue;
         rc = dav1d_hip_launch_mc_bin(&dp, rp, n_refs, dst->bpc, b, l->dev + l->off[b], (int) cnt, prep, fan.next());

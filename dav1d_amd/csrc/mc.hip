@@ -341,26 +341,34 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSe
 // mc_list_from_bins) and cut into wave-sized groups of one shape, so that the lines one shape pulls into an
 // XCD's L2 are still there when its neighbours of other shapes need them
 constexpr int mc_cmax(int a, int b) { return a > b ? a : b; }
+constexpr int MC_LDS_BIG =      // shapes at least 16 wide (classes 6 .. 14): one tile per wave, small LDS / VGPR footprints
+    mc_cmax(mc_cmax(mc_cmax(mc_lds_bytes<16, 4>(), mc_lds_bytes<16, 8>()), mc_cmax(mc_lds_bytes<16, 16>(), mc_lds_bytes<32, 4>())),
+    mc_cmax(mc_cmax(mc_lds_bytes<32, 8>(), mc_lds_bytes<32, 16>()), mc_cmax(mc_cmax(mc_lds_bytes<64, 4>(), mc_lds_bytes<64, 8>()), mc_lds_bytes<64, 16>())));
 constexpr int MC_LDS_MAX =
     mc_cmax(mc_cmax(mc_cmax(mc_lds_bytes<4, 4>(), mc_lds_bytes<4, 8>()), mc_cmax(mc_lds_bytes<4, 16>(), mc_lds_bytes<8, 4>())),
-    mc_cmax(mc_cmax(mc_cmax(mc_lds_bytes<8, 8>(), mc_lds_bytes<8, 16>()), mc_cmax(mc_lds_bytes<16, 4>(), mc_lds_bytes<16, 8>())),
-    mc_cmax(mc_cmax(mc_cmax(mc_lds_bytes<16, 16>(), mc_lds_bytes<32, 4>()), mc_cmax(mc_lds_bytes<32, 8>(), mc_lds_bytes<32, 16>())),
-            mc_cmax(mc_cmax(mc_lds_bytes<64, 4>(), mc_lds_bytes<64, 8>()), mc_lds_bytes<64, 16>()))));
+    mc_cmax(mc_cmax(mc_lds_bytes<8, 8>(), mc_lds_bytes<8, 16>()), MC_LDS_BIG));
 
-template <typename pixel>
+// SMALL = false: the kernel only knows the shapes that are at least 16 wide
+template <typename pixel, bool SMALL>
 __global__ __launch_bounds__(64) void mc_all_kernel(const DevPlanes dst, const RefSet refs, const McTile *__restrict__ tiles,
                                                     const McGroup *__restrict__ groups, const int n_groups,
                                                     int16_t *__restrict__ prep, const int bitdepth_max)
 {
-    __shared__ uint4 smem[(MC_LDS_MAX + 15) / 16];
+    __shared__ uint4 smem[((SMALL ? MC_LDS_MAX : MC_LDS_BIG) + 15) / 16];
     const int gi = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x);
     if (gi >= n_groups) return;
     const McGroup g = groups[__builtin_amdgcn_readfirstlane(gi)];
     const int t0 = __builtin_amdgcn_readfirstlane((int) g.start), nt = __builtin_amdgcn_readfirstlane((int) g.n);
 #define CASE(C, TW, TH) case C: mc_body<TW, TH, pixel>(dst, refs, tiles, t0, nt, prep, bitdepth_max, smem); break;
-    switch (__builtin_amdgcn_readfirstlane((int) g.cls)) {
-        CASE(0, 4, 4) CASE(1, 4, 8) CASE(2, 4, 16)
-        CASE(3, 8, 4) CASE(4, 8, 8) CASE(5, 8, 16)
+    const int cls = __builtin_amdgcn_readfirstlane((int) g.cls);
+    if (SMALL && cls < 6) {
+        switch (cls) {
+            CASE(0, 4, 4) CASE(1, 4, 8) CASE(2, 4, 16)
+            CASE(3, 8, 4) CASE(4, 8, 8) CASE(5, 8, 16)
+        }
+        return;
+    }
+    switch (cls) {
         CASE(6, 16, 4) CASE(7, 16, 8) CASE(8, 16, 16)
         CASE(9, 32, 4) CASE(10, 32, 8) CASE(11, 32, 16)
         CASE(12, 64, 4) CASE(13, 64, 8) CASE(14, 64, 16)
@@ -406,16 +414,19 @@ extern "C" int dav1d_hip_launch_mc_bin(const DevPlanes *dst, const DevPlanes *re
     return hip_rc(e);
 }
 
+// with_small = 0: the group list only holds shapes that are at least 16 wide
 extern "C" int dav1d_hip_launch_mc_all(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, const McTile *tiles,
-                                       const McGroup *groups, int n_groups, int16_t *prep, void *stream)
+                                       const McGroup *groups, int n_groups, int with_small, int16_t *prep, void *stream)
 {
     if (n_groups <= 0) return 0;
     RefSet rs;
     for (int i = 0; i < 8; i++) rs.r[i] = refs[i < n_refs ? i : 0];
     const int bitdepth_max = (1 << bpc) - 1;
-    if (bpc == 8)
-        hipLaunchKernelGGL((mc_all_kernel<uint8_t>), dim3(n_groups), dim3(64), 0, (hipStream_t) stream, *dst, rs, tiles, groups, n_groups, prep, bitdepth_max);
-    else
-        hipLaunchKernelGGL((mc_all_kernel<uint16_t>), dim3(n_groups), dim3(64), 0, (hipStream_t) stream, *dst, rs, tiles, groups, n_groups, prep, bitdepth_max);
+    const dim3 grid(n_groups), wave(64);
+    hipStream_t st = (hipStream_t) stream;
+    if (bpc == 8 && with_small) hipLaunchKernelGGL((mc_all_kernel<uint8_t, true>), grid, wave, 0, st, *dst, rs, tiles, groups, n_groups, prep, bitdepth_max);
+    else if (bpc == 8) hipLaunchKernelGGL((mc_all_kernel<uint8_t, false>), grid, wave, 0, st, *dst, rs, tiles, groups, n_groups, prep, bitdepth_max);
+    else if (with_small) hipLaunchKernelGGL((mc_all_kernel<uint16_t, true>), grid, wave, 0, st, *dst, rs, tiles, groups, n_groups, prep, bitdepth_max);
+    else hipLaunchKernelGGL((mc_all_kernel<uint16_t, false>), grid, wave, 0, st, *dst, rs, tiles, groups, n_groups, prep, bitdepth_max);
     return hip_rc(hipGetLastError());
 }

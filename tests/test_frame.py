@@ -94,15 +94,16 @@ def test_frame_itx_mc_matches_oracle(ctx, bpc, fused):
     assert not want_coef.any(), "all consumed coefficient slabs end up zeroed"
 
 
-def test_all_shapes_in_one_launch(ctx):
-    """DAV1D_HIP_MC_FUSED=1 (every tile shape in one source-ordered launch) must give the same pictures: the frame
-    tests again, in a child process that has the switch set before the library reads it."""
+@pytest.mark.parametrize("mode", ["1", "2"], ids=["all-shapes", "wide-shapes"])
+def test_shapes_sharing_one_launch(ctx, mode):
+    """DAV1D_HIP_MC_FUSED=1 / 2 (every tile shape / the shapes at least 16 wide in one source-ordered launch) must give
+    the same pictures: the frame tests again, in a child process that has the switch set before the library reads it."""
     import os
     import subprocess
     import sys
     if os.environ.get("DAV1D_HIP_MC_FUSED"):
         pytest.skip("already inside the child run")
-    env = dict(os.environ, DAV1D_HIP_MC_FUSED="1")
+    env = dict(os.environ, DAV1D_HIP_MC_FUSED=mode)
     sel = "emu" if ctx.backend == "emu" else "hip"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", sel + " and fused", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=900)
