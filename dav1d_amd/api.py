@@ -91,8 +91,19 @@ class DevicePicture:
                                                    out.strides[0], 1), "plane_download")
         return out
 
+    @classmethod
+    def view(cls, ctx, pic, w, h, layout, bpc):
+        """A non-owning wrapper around a Picture descriptor (e.g. the frame-owned output of FrameInFlight.end())."""
+        self = cls.__new__(cls)
+        self.ctx, self.pic = ctx, pic
+        self.w, self.h, self.layout, self.bpc = w, h, layout, bpc
+        self.dtype = np.uint8 if bpc == 8 else np.uint16
+        self.borrowed = True
+        return self
+
     def free(self):
-        self.ctx.lib.dav1d_hip_picture_free(self.ctx.h, C.byref(self.pic))
+        if not getattr(self, "borrowed", False):
+            self.ctx.lib.dav1d_hip_picture_free(self.ctx.h, C.byref(self.pic))
 
 
 class _List:
@@ -230,6 +241,9 @@ class Context:
         _chk(self.lib.dav1d_hip_fg_generate_grain(self.h, C.byref(data), bpc, layout, out.ctypes.data), "fg_generate_grain")
         return out
 
+    def frame(self, cur, refs):
+        return FrameInFlight(self, cur, refs)
+
     # ---- device-resident lists
     def itx_list(self, tasks):
         return _List(self, "itx", tasks, ITX_TASK)
@@ -262,3 +276,46 @@ class Context:
         p = prep.ptr if hasattr(prep, "ptr") else prep
         m = None if mask is None else (mask.ptr if hasattr(mask, "ptr") else mask)
         _chk(self.lib.dav1d_hip_comp_list_run(self.h, lst.h, C.byref(dst.pic), p, m), "comp_list_run")
+
+
+class FrameInFlight:
+    """dav1d_hip_frame_*: one frame in flight (driver-level boundary)."""
+
+    def __init__(self, ctx, cur, refs):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        arr = (Picture * max(len(refs), 1))(*[r.pic for r in refs])
+        _chk(ctx.lib.dav1d_hip_frame_begin(ctx.h, C.byref(self.h), C.byref(cur.pic), arr, len(refs)), "frame_begin")
+
+    def submit_tile_sbrow(self, mc, comp, itx):
+        m = np.ascontiguousarray(mc, dtype=MC_TASK)
+        c = np.ascontiguousarray(comp, dtype=COMP_TASK)
+        t = np.ascontiguousarray(itx, dtype=ITX_TASK)
+        _chk(self.ctx.lib.dav1d_hip_frame_submit_tile_sbrow(self.h, m.ctypes.data, len(m), c.ctypes.data, len(c), t.ctypes.data, len(t)),
+             "frame_submit_tile_sbrow")
+
+    def submit_filter_sbrow(self, lf, cdef, lr):
+        a = np.ascontiguousarray(lf, dtype=LF_TASK)
+        b = np.ascontiguousarray(cdef, dtype=CDEF_TASK)
+        c = np.ascontiguousarray(lr, dtype=LR_TASK)
+        _chk(self.ctx.lib.dav1d_hip_frame_submit_filter_sbrow(self.h, a.ctypes.data, len(a), b.ctypes.data, len(b), c.ctypes.data, len(c)),
+             "frame_submit_filter_sbrow")
+
+    def set_filters(self, lvl, b4_stride, lut_e, lut_i, cdef_damping, grain=None, is_id=0):
+        e = np.ascontiguousarray(lut_e, dtype=np.uint8)
+        i = np.ascontiguousarray(lut_i, dtype=np.uint8)
+        _chk(self.ctx.lib.dav1d_hip_frame_set_filters(self.h, lvl.ptr, b4_stride, e.ctypes.data, i.ctypes.data, cdef_damping,
+                                                      C.addressof(grain) if grain is not None else None, is_id), "frame_set_filters")
+
+    def end(self, coef, prep, mask=None, grain_out=None):
+        """Returns the Picture descriptor of the filtered (post CDEF / restoration) picture."""
+        filtered = Picture()
+        _chk(self.ctx.lib.dav1d_hip_frame_end(self.h, coef.ptr if coef is not None else None, prep.ptr if prep is not None else None,
+                                              mask.ptr if mask is not None else None, C.byref(filtered),
+                                              C.byref(grain_out.pic) if grain_out is not None else None), "frame_end")
+        return filtered
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.dav1d_hip_frame_destroy(self.h)
+            self.h = C.c_void_p()

@@ -445,6 +445,32 @@ DAV1D_HIP_API int dav1d_hip_fg_apply(Dav1dHipContext *c, const Dav1dHipPicture *
 DAV1D_HIP_API int dav1d_hip_fg_generate_grain(Dav1dHipContext *c, const Dav1dHipFilmGrainData *data, int bpc, int layout,
                                               int16_t *host_lut);
 
+/* ------------------------------------------------------------ one frame in flight */
+
+/* Driver-level boundary (reference: f->bd_fn.recon_b_intra / recon_b_inter / filter_sbrow_* called from the pass-2
+ * workers, src/internal.h:247-262, src/thread_task.c:733-851).  A lister that walks f->frame_thread.b[] like decode_b()'s
+ * pass-2 branch appends flat tasks per tile-sbrow / superblock row, from any worker thread; dav1d_hip_frame_end() runs
+ * the frame in the reference's stage order and returns when every stage has completed (src/thread_task.c:888-896 then
+ * publishes progress).  Intra blocks, warps and scaled references go through their own batch calls between
+ * frame_begin and frame_end (they need the caller's wavefront order). */
+typedef struct Dav1dHipFrame Dav1dHipFrame;
+DAV1D_HIP_API int dav1d_hip_frame_begin(Dav1dHipContext *c, Dav1dHipFrame **out, const Dav1dHipPicture *cur,
+                                        const Dav1dHipPicture *refs, int n_refs);
+DAV1D_HIP_API int dav1d_hip_frame_submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc,
+                                                    const Dav1dHipCompTask *comp, size_t n_comp,
+                                                    const Dav1dHipItxTask *itx, size_t n_itx);
+DAV1D_HIP_API int dav1d_hip_frame_submit_filter_sbrow(Dav1dHipFrame *f, const Dav1dHipLfTask *lf, size_t n_lf,
+                                                      const Dav1dHipCdefTask *cdef, size_t n_cdef,
+                                                      const Dav1dHipLrTask *lr, size_t n_lr);
+/* lvl: DEVICE level array; lut_e / lut_i: Av1FilterLUT tables; cdef_damping = frame damping + bpc - 8; grain may be NULL */
+DAV1D_HIP_API int dav1d_hip_frame_set_filters(Dav1dHipFrame *f, const uint8_t *lvl, ptrdiff_t b4_stride, const uint8_t lut_e[64],
+                                              const uint8_t lut_i[64], int cdef_damping, const Dav1dHipFilmGrainData *grain, int is_id);
+/* coef / prep / mask: DEVICE arenas.  `cur` ends up reconstructed and deblocked; *filtered describes the picture after
+ * CDEF + restoration (owned by the frame unless it is `cur`); grain_out (optional) receives the film grain output. */
+DAV1D_HIP_API int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask, Dav1dHipPicture *filtered,
+                                      const Dav1dHipPicture *grain_out);
+DAV1D_HIP_API void dav1d_hip_frame_destroy(Dav1dHipFrame *f);
+
 /* ------------------------------------------------- reference-signature table */
 
 /* The kernel-level drop-in: function pointer types with the reference's exact signatures and a table whose

@@ -1,0 +1,74 @@
+"""Driver-level boundary (dav1d_hip_frame_*): tasks submitted tile-sbrow by tile-sbrow from several threads, one
+dav1d_hip_frame_end() for the whole frame -- reconstruction, deblocking, CDEF, loop restoration, film grain -- against the
+oracle running the same stages through oracle/replay.c."""
+import threading
+
+import numpy as np
+import pytest
+
+import util
+from dav1d_amd import api, synth
+import test_frame
+import test_postchain
+
+
+@pytest.mark.parametrize("bpc", [8, 10])
+def test_frame_in_flight_matches_oracle(ctx, bpc):
+    oracle = util.default_oracle()
+    w, h = (256, 192) if ctx.backend == "emu" else (1024, 576)
+    frame = synth.make_frame(w, h, bpc, seed=31 + bpc, edge_frac=0.1)
+    post = synth.make_post_filters(frame, seed=9 + bpc)
+    rng = np.random.default_rng(5)
+    ref_host = [synth.make_planes(rng, w, h, bpc) for _ in range(frame.n_refs)]
+    dst_host = synth.make_planes(rng, w, h, bpc, smooth=False)
+    want_rec, _, _ = test_frame.oracle_frame(oracle, frame, dst_host, ref_host)
+    want = test_postchain.oracle_post(oracle, post, want_rec, w, h, bpc)
+
+    cur = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+    grain = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+    refs = []
+    for rp in ref_host:
+        r = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+        for pl in range(3):
+            r.upload(pl, rp[pl])
+        refs.append(r)
+    for pl in range(3):
+        cur.upload(pl, dst_host[pl])
+    prep = ctx.buffer(frame.prep_elems * 2)
+    prep.zero()
+    coef = ctx.buffer_from(frame.coef)
+    lvl = ctx.buffer_from(post.lvl)
+
+    f = ctx.frame(cur, refs)
+    f.set_filters(lvl, post.b4_stride, post.lut_e, post.lut_i, post.cdef_damping, post.fg, 0)
+    # "tile-sbrows": interleaved chunks of the lists, submitted from four threads; a compound task travels with the two
+    # PREP tasks it consumes only if they sit in the same list, so the compound list goes in with the first chunk
+    nchunk = 8
+    mc_chunks = np.array_split(frame.mc, nchunk)
+    itx_chunks = np.array_split(frame.itx, nchunk)
+    errs = []
+
+    def worker(k):
+        try:
+            f.submit_tile_sbrow(mc_chunks[k], frame.comp if k == 0 else frame.comp[:0], itx_chunks[k])
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(nchunk)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    # loop restoration units must keep raster order: one submission per plane and stripe row
+    f.submit_filter_sbrow(post.lf, post.cdef, post.lr)
+    filtered = f.end(coef, prep, None, grain)
+    out = api.DevicePicture.view(ctx, filtered, w, h, api.LAYOUT_I420, bpc)
+    for pl in range(3):
+        vh, vw = (h, w) if pl == 0 else (h // 2, w // 2)
+        assert np.array_equal(cur.download(pl)[:vh, :vw], want[0][pl][:vh, :vw]), ("deblocked", pl)
+        assert np.array_equal(out.download(pl)[:vh, :vw], want[2][pl][:vh, :vw]), ("restored", pl)
+        if want[3] is not None:
+            assert np.array_equal(grain.download(pl)[:vh, :vw], want[3][pl][:vh, :vw]), ("grain", pl)
+    f.destroy()
+    for o in [cur, grain, prep, coef, lvl] + refs:
+        o.free()
