@@ -252,21 +252,38 @@ def main():
         # one frame, kernel time per stage from HIP events, every stage checked against the oracle's replay
         full = None
         if not a.no_full:
+            import test_postchain
             post = synth.make_post_filters(frame, seed=0xF11 + rank)
+            intra = synth.make_intra_pass(frame, seed=0x1A7 + rank)
             want_post, t_post_cpu = [None] * 4, 0.0
-            if not a.no_check:
-                import test_postchain
-                t1 = time.perf_counter()
-                want_post = test_postchain.oracle_post(oracle, post, want[0], w, h, bpc)
-                t_post_cpu = time.perf_counter() - t1
-            else:
+            if a.no_check:
                 got = [dsts[i % NDST].download(pl) for pl in range(3)]
+            # intra pass (1/9 of the regions re-coded as intra, wavefront batches) on the reconstructed picture
+            rec = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+            for pl in range(3):
+                rec.upload(pl, got[pl])
+            ms_pred, ms_res = test_postchain.hip_intra(ctx, intra, rec)
+            got = [rec.download(pl) for pl in range(3)]
+            rec.free()
+            intra_ok = None
+            if not a.no_check:
+                t1 = time.perf_counter()
+                want_rec = synth.copy_planes(want[0])
+                if oracle.which == "ref":
+                    test_postchain.oracle_intra(oracle, intra, want_rec, w, h, bpc)
+                    intra_ok = all(np.array_equal(got[pl], want_rec[pl]) for pl in range(3))
+                    if not intra_ok:
+                        raise SystemExit("bench: intra pass differs from the oracle")
+                else:
+                    want_rec = got          # edge preparation is only available from the reference build
+                want_post = test_postchain.oracle_post(oracle, post, want_rec, w, h, bpc)
+                t_post_cpu = time.perf_counter() - t1
             pics = [ctx.picture(w, h, api.LAYOUT_I420, bpc) for _ in range(4)]
             dbl, cdf, res, grn = pics
             for pl in range(3):
                 dbl.upload(pl, got[pl])
             lvl = ctx.buffer_from(post.lvl)
-            stage_ms = {}
+            stage_ms = {"intra_pred": ms_pred, "intra_residual": ms_res}
             for rep in range(2):            # second pass = warm clocks; deblocking is in place, so re-seed its input
                 for pl in range(3):
                     dbl.upload(pl, got[pl])
@@ -295,16 +312,20 @@ def main():
             P = 1 if bpc == 8 else 2
             post_ms = sum(stage_ms.values())
             full_ms = ms_per_step + post_ms
-            full_bytes = path_bytes + frame.n_samples * 2 * P * 4        # each post filter: one read + one write per sample
-            full = {"workload": "same frame through the full DSP table: itx+mc recon, deblock (levels 16-32, masks from the transform grid), "
+            Cb = 2 if bpc == 8 else 4
+            # each post filter: one read + one write per sample; intra samples: coefficients + prediction write + residual RMW
+            full_bytes = path_bytes + frame.n_samples * 2 * P * 4 + intra.n_samples * (2 * Cb + 3 * P)
+            full = {"workload": "same frame through the full DSP table: itx+mc recon, intra pass (1/9 of the 64x64 regions re-coded as intra, "
+                                "%d wavefront batches of prediction + residual), deblock (levels 16-32, masks from the transform grid), " % len(intra.batches) +
                                 "CDEF (y 17 / uv 5, every 8x8), Wiener Y + SGR-mix UV (64-px units), film grain (lag 3, overlap)",
                     "ms_per_frame": round(full_ms, 4), "value": round(frame.luma_pixels / (full_ms * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
                     "stages_ms": dict({"recon_itx_mc": round(ms_per_step, 4)}, **{k: round(v, 4) for k, v in stage_ms.items()}),
-                    "tasks": {"lf": int(len(post.lf)), "cdef": int(len(post.cdef)), "lr": int(len(post.lr))},
+                    "tasks": {"ipred": intra.n_blocks, "lf": int(len(post.lf)), "cdef": int(len(post.cdef)), "lr": int(len(post.lr))},
                     "algorithmic_bytes_per_frame": int(full_bytes),
                     "achieved": round(full_bytes / (full_ms * 1e-3) / 1e9, 1), "frac": round(full_bytes / (full_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "parity": "skipped" if a.no_check else "every stage bit-exact vs %s oracle%s" % (
-                        oracle.which, "" if want_post[3] is not None else " (film grain unchecked: needs oracle/_ref)"),
+                    "parity": "skipped" if a.no_check else "every stage bit-exact vs %s oracle%s%s" % (
+                        oracle.which, "" if want_post[3] is not None else " (film grain unchecked: needs oracle/_ref)",
+                        "" if intra_ok else " (intra pass unchecked: needs oracle/_ref)"),
                     "cpu_post_filters_s": round(t_post_cpu, 2)}
         label = "8K" if (w, h) == (7680, 4320) else "4K" if (w, h) == (3840, 2160) else "%dx%d" % (w, h)
         out = {"metric": "reconstructed luma Mpixels/s (%s 4:2:0 %d-bit) on the itx+mc recon path; bit-exact vs C" % (label, bpc),

@@ -287,7 +287,9 @@ int dav1d_hip_itx_add_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, cons
     Dav1dHipItxList *l = nullptr;
     int rc = dav1d_hip_itx_list_create(c, &l, tasks, n);
     if (rc) return rc;
+    KernelTimer kt(c);
     rc = dav1d_hip_itx_list_run(c, l, dst, coef);
+    kt.stop();
     dav1d_hip_itx_list_destroy(c, l);     // synchronises the stream
     return rc;
 }

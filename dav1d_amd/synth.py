@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-from ._lib import ITX_TASK, MC_TASK, COMP_TASK, LF_TASK, CDEF_TASK, LR_TASK, FilmGrainData
+from ._lib import ITX_TASK, MC_TASK, COMP_TASK, LF_TASK, CDEF_TASK, LR_TASK, IPRED_TASK, FilmGrainData
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -410,4 +410,80 @@ def make_post_filters(frame, seed, layout=1):
         d.ar_coeffs_y[k] = int(rng.integers(-32, 32))
     d.overlap_flag, d.clip_to_restricted_range = 1, 0
     p.fg = d
+    return p
+
+
+# ------------------------------------------------------------------ an intra pass over part of the frame
+
+class IntraPass:
+    """Wavefront batches of intra blocks (prediction + residual) for a subset of the frame's 64x64 regions."""
+    pass
+
+
+def make_intra_pass(frame, seed, layout=1):
+    """Every third region in x and y (1/9 of the frame, never two neighbours) is re-coded as intra with the block size it
+    already has: the blocks of a region depend on their left / top / top-right neighbours, so block (i, j) of the region
+    grid goes into wave j + 2 i (the classic 2:1 wavefront); everything outside the region is final by then.  One batch
+    per wave: intra prediction of all its blocks in all planes, then their residuals.  Returns IntraPass with
+    .batches = [(ipred_tasks, itx_tasks)], .coef (its own coefficient arena)."""
+    assert layout == 1
+    rng = np.random.default_rng(seed)
+    w, h, bpc = frame.w, frame.h, frame.bpc
+    geo = plane_geometry(w, h, bpc, layout)
+    reg = frame.region
+    nry, nrx = frame.region_cls.shape
+    ry, rx = np.mgrid[0:nry, 0:nrx]
+    sel = (ry % 3 == 1) & (rx % 3 == 1)
+    waves = {}
+    coef_parts, cf_off = [], 0
+    for ci, s in enumerate(frame.region_sizes):
+        m = sel & (frame.region_cls == ci)
+        gy, gx = ry[m] * reg, rx[m] * reg
+        if not len(gx):
+            continue
+        for pl in range(3):
+            ss = 1 if pl else 0
+            pw = max(int(s) >> ss, 4)                      # block = transform size in this plane
+            k = (reg >> ss) // pw
+            pwid, phei = w >> ss, h >> ss
+            ii, jj = np.mgrid[0:k, 0:k]
+            bx = ((gx >> ss)[:, None] + (jj.ravel() * pw)[None, :]).ravel()
+            by = ((gy >> ss)[:, None] + (ii.ravel() * pw)[None, :]).ravel()
+            wi = np.tile((jj + 2 * ii).ravel(), len(gx))
+            jcol = np.tile(jj.ravel(), len(gx))
+            keep = (bx + pw <= pwid) & (by + pw <= phei)
+            bx, by, wi, jcol = bx[keep], by[keep], wi[keep], jcol[keep]
+            n = len(bx)
+            t = np.zeros(n, IPRED_TASK)
+            t["dst_off"] = by * geo[pl][0] + bx
+            t["x4"], t["y4"] = bx // 4, by // 4
+            t["w4"], t["h4"] = pwid // 4, phei // 4
+            t["tw"] = t["th"] = pw // 4
+            mode = rng.integers(0, 14, size=n)
+            if pw > 32:
+                mode[mode == 13] = 12                      # filter-intra stops at 32x32
+            t["mode"] = mode
+            directional = (mode >= 1) & (mode <= 8)
+            t["angle"] = np.where(directional, rng.integers(-3, 4, size=n), np.where(mode == 13, rng.integers(0, 5, size=n), 0))
+            flags = (bx > 0) * 1 + (by > 0) * 2 + 4 + (jcol == 0) * 8 + 16 + rng.integers(0, 2, size=n) * 32
+            t["flags"] = flags
+            t["plane"], t["kind"] = pl, 0
+            t["max_w"], t["max_h"] = pwid - bx, phei - by
+            tx = SQ_TX[pw]
+            cf, eob = gen_coefs(rng, tx, n, bpc)
+            it = np.zeros(n, ITX_TASK)
+            it["dst_off"] = t["dst_off"]
+            it["cf_off"] = cf_off + np.arange(n, dtype=np.int64) * cf.shape[1]
+            it["eob"], it["tx"], it["plane"] = eob, tx, pl
+            coef_parts.append(cf.reshape(-1))
+            cf_off += n * cf.shape[1]
+            for d in np.unique(wi):
+                q = wi == d
+                a, b = waves.setdefault(int(d), ([], []))
+                a.append(t[q]); b.append(it[q])
+    p = IntraPass()
+    p.batches = [(np.concatenate(waves[d][0]), np.concatenate(waves[d][1])) for d in sorted(waves)]
+    p.coef = np.concatenate(coef_parts) if coef_parts else np.zeros(16, np.int16 if bpc == 8 else np.int32)
+    p.n_blocks = int(sum(len(a) for a, _ in p.batches))
+    p.n_samples = int(sum(int((a["tw"].astype(np.int64) * 4 * a["th"] * 4).sum()) for a, _ in p.batches))
     return p

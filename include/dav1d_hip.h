@@ -49,7 +49,7 @@ DAV1D_HIP_API int dav1d_hip_sync(Dav1dHipContext *c);
 DAV1D_HIP_API void *dav1d_hip_stream(Dav1dHipContext *c);
 DAV1D_HIP_API const char *dav1d_hip_version(void);
 /* Measurement aid: device time (HIP events on the context's stream) of the kernel launches of the most recent
- * cdef / lf / ipred / lr / fg *_batch call on this context -- excludes the task upload the batch calls do. */
+ * itx_add / cdef / lf / ipred / lr / fg *_batch call on this context -- excludes the task upload the batch calls do. */
 DAV1D_HIP_API float dav1d_hip_last_kernel_ms(Dav1dHipContext *c);
 
 /* Device memory helpers (callers may equally pass memory from their own allocator). */

@@ -81,3 +81,58 @@ def test_post_filter_chain_matches_oracle(ctx, bpc):
             bad = np.argwhere(a[pl][:vh, :vw] != b[pl][:vh, :vw])
             assert not len(bad), "%s plane %d differs at %s (%d px)" % (stage, pl, bad[0], len(bad))
     assert any(np.any(got[0][pl] != recon[pl]) for pl in range(3)), "deblocking must change something"
+
+
+def oracle_intra(oracle, ip, planes, w, h, bpc):
+    """The intra pass on host planes (in place): per wave, prediction of every block through the reference's
+    dav1d_prepare_intra_edges + intra_pred entries, then the residuals through oracle/replay.c."""
+    import test_ipred
+    rl = util.replay_lib()
+    entry = C.cast(oracle._entry, C.c_void_p)
+    coef = ip.coef.copy()
+    rp = planes_struct(planes, w, h)
+    for pred, itx in ip.batches:
+        for k in range(len(pred)):
+            test_ipred.oracle_task(oracle, bpc, planes, pred[k], 1, None)
+        assert rl.dav1d_replay_itx(entry, bpc, C.byref(rp), itx.ctypes.data, len(itx), coef.ctypes.data) == 0
+    return coef
+
+
+def hip_intra(ctx, ip, pic):
+    """Returns (kernel ms of the predictions, kernel ms of the residuals)."""
+    coef = ctx.buffer_from(ip.coef)
+    ms_pred = ms_itx = 0.0
+    for pred, itx in ip.batches:
+        ctx.ipred_batch(pic, pred)
+        ms_pred += ctx.last_kernel_ms()
+        ctx.itx_add_batch(pic, itx, coef)
+        ms_itx += ctx.last_kernel_ms()
+    left = coef.download(ip.coef.dtype, len(ip.coef))
+    coef.free()
+    assert not left.any(), "every coefficient slab must come back zeroed"
+    return ms_pred, ms_itx
+
+
+@pytest.mark.parametrize("bpc", [8, 10])
+def test_intra_wavefront_pass_matches_oracle(ctx, bpc):
+    oracle = util.default_oracle()
+    if oracle.which != "ref":
+        pytest.skip("edge preparation is borrowed from the reference build (dav1d_prepare_intra_edges)")
+    w, h = (256, 192) if ctx.backend == "emu" else (1024, 576)
+    frame = synth.make_frame(w, h, bpc, seed=91 + bpc)
+    ip = synth.make_intra_pass(frame, seed=17 + bpc)
+    assert len(ip.batches) > 3 and ip.n_blocks > 20
+    rng = np.random.default_rng(bpc)
+    planes = synth.make_planes(rng, w, h, bpc, smooth=True)
+    pic = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+    for pl in range(3):
+        pic.upload(pl, planes[pl])
+    want = synth.copy_planes(planes)
+    oracle_intra(oracle, ip, want, w, h, bpc)
+    hip_intra(ctx, ip, pic)
+    for pl in range(3):
+        vh, vw = (h, w) if pl == 0 else (h // 2, w // 2)
+        bad = np.argwhere(pic.download(pl)[:vh, :vw] != want[pl][:vh, :vw])
+        assert not len(bad), "plane %d differs at %s (%d px)" % (pl, bad[0], len(bad))
+    assert any(np.any(want[pl] != planes[pl]) for pl in range(3))
+    pic.free()
