@@ -39,18 +39,19 @@ struct KernelTimer {
 struct StreamFan {
     Dav1dHipContext *c;
     int used;
-    explicit StreamFan(Dav1dHipContext *ctx) : c(ctx), used(0) {
-        if (c->concurrent) (void) hipEventRecord(c->ev_fork, c->stream);
+    bool on;      // small lists stay on the context's stream: forking costs more than their kernels run
+    explicit StreamFan(Dav1dHipContext *ctx, bool worth_it = true) : c(ctx), used(0), on(ctx->concurrent && worth_it) {
+        if (on) (void) hipEventRecord(c->ev_fork, c->stream);
     }
     hipStream_t next() {
-        if (!c->concurrent) return c->stream;
+        if (!on) return c->stream;
         const int i = used % Dav1dHipContext::N_SIDE;
         if (used < Dav1dHipContext::N_SIDE) (void) hipStreamWaitEvent(c->side[i], c->ev_fork, 0);
         used++;
         return c->side[i];
     }
     void join() {
-        if (!c->concurrent) return;
+        if (!on) return;
         const int n = used < Dav1dHipContext::N_SIDE ? used : Dav1dHipContext::N_SIDE;
         for (int i = 0; i < n; i++) {
             (void) hipEventRecord(c->ev_join[i], c->side[i]);

@@ -248,7 +248,7 @@ int dav1d_hip_itx_list_run(Dav1dHipContext *c, const Dav1dHipItxList *l, const D
     const DevPlanes dp = dev_planes(dst);
     // longest-running shapes first (64-point, then 32-point ...), each on its own side stream
     static const uint8_t order[19] = { 4, 11, 12, 17, 18, 3, 9, 10, 15, 16, 2, 7, 8, 13, 14, 1, 5, 6, 0 };
-    StreamFan fan(c);
+    StreamFan fan(c, l->n >= 16384);
     int rc = 0;
     for (int k = 0; k < 19 && !rc; k++) {
         const int b = order[k];
