@@ -1,6 +1,7 @@
 // Host side of the C ABI declared in include/dav1d_hip.h: context, device memory,
 // pictures, task-list binning and the batched entry points.
 #include "capi.h"
+#include "av1_scan_prefix.h"
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
@@ -220,6 +221,7 @@ int dav1d_hip_itx_list_create(Dav1dHipContext *c, Dav1dHipItxList **out, const D
     for (size_t i = 0; i < n; i++) {
         const Dav1dHipItxTask &t = tasks[i];
         if (!itx_legal(t.tx, t.txtp) || t.plane > 2 || t.eob < 0) { delete l; return -EINVAL; }
+        if (t.eob >= av1_scan_prefix_off[t.tx + 1] - av1_scan_prefix_off[t.tx]) { delete l; return -EINVAL; }
         cnt[t.tx]++;
     }
     for (int b = 0; b < 19; b++) l->off[b + 1] = l->off[b] + cnt[b];
@@ -227,7 +229,19 @@ int dav1d_hip_itx_list_create(Dav1dHipContext *c, Dav1dHipItxList **out, const D
         std::vector<Dav1dHipItxTask> sorted(n);
         size_t pos[19];
         for (int b = 0; b < 19; b++) pos[b] = l->off[b];
-        for (size_t i = 0; i < n; i++) sorted[pos[tasks[i].tx]++] = tasks[i];   // stable: keeps decode order inside a bin
+        for (size_t i = 0; i < n; i++) {
+            Dav1dHipItxTask &t = sorted[pos[tasks[i].tx]++] = tasks[i];          // stable: keeps decode order inside a bin
+            // How much of the slab can be non-zero: coefficients past the eob in scan order are zero by contract (the entropy
+            // decoder only writes scan positions <= eob, src/recon_tmpl.c:458-520, and itx leaves slabs zeroed), so the kernel
+            // reads and re-zeroes only the prefix [0, end).  2-D classes: the zig-zag's reach; H classes: the scan is the
+            // slab order itself; V classes: every column can be touched.  The device copy carries `end` in the pad bytes.
+            const int ncoef = av1_scan_prefix_off[t.tx + 1] - av1_scan_prefix_off[t.tx];
+            int end = ncoef;
+            if (t.txtp <= 9 || t.txtp == 16) end = av1_scan_prefix_end[av1_scan_prefix_off[t.tx] + t.eob];
+            else if (t.txtp == 11 || t.txtp == 13 || t.txtp == 15) end = t.eob + 1;
+            t.pad[0] = (uint8_t) (end & 255);
+            t.pad[1] = (uint8_t) (end >> 8);
+        }
         if (hipMalloc((void **) &l->dev, n * sizeof(Dav1dHipItxTask)) != hipSuccess) { delete l; return -ENOMEM; }
         const int rc = dav1d_hip_upload(c, l->dev, sorted.data(), n * sizeof(Dav1dHipItxTask));
         if (rc) { hipFree(l->dev); delete l; return rc; }

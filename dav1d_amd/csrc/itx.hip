@@ -135,15 +135,24 @@ __global__ __launch_bounds__(64) void itx_add_kernel(const DevPlanes dst, const 
         const int4 *g4 = reinterpret_cast<const int4 *>(gcf);
         int4 *z4 = reinterpret_cast<int4 *>(gcf);
         int4 *s4 = reinterpret_cast<int4 *>(tmp);
+        // only the part of the slab the scan can have reached (t.pad = prefix length in coefficients, filled in by the
+        // host from the eob); the rest is zero in memory by contract and is zero-filled in LDS without being fetched
+        const int nch = (((int) t.pad[0] | ((int) t.pad[1] << 8)) * (int) sizeof(coef) + 15) >> 4;
         int4 v[(NCH + LPB - 1) / LPB];
 #pragma unroll
-        for (int k = 0; k < (NCH + LPB - 1) / LPB; k++) if (l + k * LPB < NCH) v[k] = g4[l + k * LPB];
+        for (int k = 0; k < (NCH + LPB - 1) / LPB; k++) {
+            v[k] = make_int4(0, 0, 0, 0);
+            if (l + k * LPB < nch) v[k] = g4[l + k * LPB];
+        }
         if (l < W) {
 #pragma unroll
             for (int y = 0; y < H; y++) dpx[y] = d[y * stride];
         }
 #pragma unroll
-        for (int k = 0; k < (NCH + LPB - 1) / LPB; k++) if (l + k * LPB < NCH) { s4[l + k * LPB] = v[k]; z4[l + k * LPB] = make_int4(0, 0, 0, 0); }
+        for (int k = 0; k < (NCH + LPB - 1) / LPB; k++) {
+            if (l + k * LPB < NCH) s4[l + k * LPB] = v[k];
+            if (l + k * LPB < nch) z4[l + k * LPB] = make_int4(0, 0, 0, 0);
+        }
     } else if (dconly) {
         if (l == 0) { dc = gcf[0]; gcf[0] = 0; }            // src/itx_tmpl.c:59-60
         if (l < W) {
