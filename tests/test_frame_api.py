@@ -12,7 +12,7 @@ import test_frame
 import test_postchain
 
 
-@pytest.mark.parametrize("bpc", [8, 10])
+@pytest.mark.parametrize("bpc", [8, 10, 12])
 def test_frame_in_flight_matches_oracle(ctx, bpc):
     oracle = util.default_oracle()
     w, h = (256, 192) if ctx.backend == "emu" else (1024, 576)
