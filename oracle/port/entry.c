@@ -55,6 +55,26 @@ static void blendv16(void *d, ptrdiff_t ds, const void *t, int w, int h) { port_
 static void blendh8(void *d, ptrdiff_t ds, const void *t, int w, int h) { port_blend(2, d, ds, t, w, h, NULL, 0); }
 static void blendh16(void *d, ptrdiff_t ds, const void *t, int w, int h) { port_blend(2, d, ds, t, w, h, NULL, 1); }
 
+/* ---- warp, scaled mc, resize (src/mc.h:60-122) */
+static void warp8(void *d, ptrdiff_t ds, const void *s, ptrdiff_t ss, const int16_t *abcd, int mx, int my) { port_warp8x8(d, ds, NULL, 0, s, ss, abcd, mx, my, 255); }
+static void warp16(void *d, ptrdiff_t ds, const void *s, ptrdiff_t ss, const int16_t *abcd, int mx, int my, int bm) { port_warp8x8(d, ds, NULL, 0, s, ss, abcd, mx, my, bm); }
+static void warpt8(int16_t *t, ptrdiff_t ts, const void *s, ptrdiff_t ss, const int16_t *abcd, int mx, int my) { port_warp8x8(NULL, 0, t, ts, s, ss, abcd, mx, my, 255); }
+static void warpt16(int16_t *t, ptrdiff_t ts, const void *s, ptrdiff_t ss, const int16_t *abcd, int mx, int my, int bm) { port_warp8x8(NULL, 0, t, ts, s, ss, abcd, mx, my, bm); }
+#define MCS_W(f) \
+    static void mcs8_##f(void *d, ptrdiff_t ds, const void *s, ptrdiff_t ss, int w, int h, int mx, int my, int dx, int dy) { port_mc_scaled(d, ds, NULL, s, ss, w, h, mx, my, dx, dy, f, 255); } \
+    static void mcs16_##f(void *d, ptrdiff_t ds, const void *s, ptrdiff_t ss, int w, int h, int mx, int my, int dx, int dy, int bm) { port_mc_scaled(d, ds, NULL, s, ss, w, h, mx, my, dx, dy, f, bm); } \
+    static void mcts8_##f(int16_t *t, const void *s, ptrdiff_t ss, int w, int h, int mx, int my, int dx, int dy) { port_mc_scaled(NULL, 0, t, s, ss, w, h, mx, my, dx, dy, f, 255); } \
+    static void mcts16_##f(int16_t *t, const void *s, ptrdiff_t ss, int w, int h, int mx, int my, int dx, int dy, int bm) { port_mc_scaled(NULL, 0, t, s, ss, w, h, mx, my, dx, dy, f, bm); }
+FOR_F(MCS_W)
+#define S8(f) (void *) mcs8_##f,
+#define S16(f) (void *) mcs16_##f,
+#define ST8(f) (void *) mcts8_##f,
+#define ST16(f) (void *) mcts16_##f,
+static void *const mcs8_tab[10] = { FOR_F(S8) }, *const mcs16_tab[10] = { FOR_F(S16) };
+static void *const mcts8_tab[10] = { FOR_F(ST8) }, *const mcts16_tab[10] = { FOR_F(ST16) };
+static void resize8(void *d, ptrdiff_t ds, const void *s, ptrdiff_t ss, int dw, int h, int sw, int dx, int mx0) { port_resize(d, ds, s, ss, dw, h, sw, dx, mx0, 255); }
+static void resize16(void *d, ptrdiff_t ds, const void *s, ptrdiff_t ss, int dw, int h, int sw, int dx, int mx0, int bm) { port_resize(d, ds, s, ss, dw, h, sw, dx, mx0, bm); }
+
 /* ---- loop filter: loop_filter_sb[plane != 0][dir] (src/loopfilter.h:38-53); lut = Av1FilterLUT { e[64], i[64], .. } */
 #define LF_W(c, d) \
     static void lf8_##c##d(void *p, ptrdiff_t s, const uint32_t *m, const uint8_t (*l)[4], ptrdiff_t ls, const uint8_t *lut, int n) { (void) n; port_loop_filter_sb(c, d, p, s, m, l, ls, lut, 255); } \
@@ -169,6 +189,11 @@ void *dav1d_port_dsp_entry(const int bpc, const char *const family, const int i,
     if (F("blend")) return hbd ? (void *) blend16 : (void *) blend8;
     if (F("blend_v")) return hbd ? (void *) blendv16 : (void *) blendv8;
     if (F("blend_h")) return hbd ? (void *) blendh16 : (void *) blendh8;
+    if (F("mc_scaled")) return i >= 0 && i < 10 ? (hbd ? mcs16_tab[i] : mcs8_tab[i]) : NULL;
+    if (F("mct_scaled")) return i >= 0 && i < 10 ? (hbd ? mcts16_tab[i] : mcts8_tab[i]) : NULL;
+    if (F("warp8x8")) return hbd ? (void *) warp16 : (void *) warp8;
+    if (F("warp8x8t")) return hbd ? (void *) warpt16 : (void *) warpt8;
+    if (F("resize")) return hbd ? (void *) resize16 : (void *) resize8;
     if (F("loop_filter_sb")) {
         static void *const t8[2][2] = { { (void *) lf8_00, (void *) lf8_01 }, { (void *) lf8_10, (void *) lf8_11 } };
         static void *const t16[2][2] = { { (void *) lf16_00, (void *) lf16_01 }, { (void *) lf16_10, (void *) lf16_11 } };

@@ -125,3 +125,96 @@ void port_blend(int dir, void *dst, ptrdiff_t dst_stride, const void *tmp, int w
             px_set(dst, dst_stride, x, y, (a * (64 - m) + b * m + 32) >> 6, hbd);
         }
 }
+
+/* ---- warp8x8 / warp8x8t (reference src/mc_tmpl.c:799-866): 15 rows filtered horizontally with a per-pixel filter chosen by
+ * the affine position, then 8 rows vertically.  dst != NULL: pixels; tmp != NULL: int16 with PREP_BIAS. */
+void port_warp8x8(void *dst, ptrdiff_t dst_stride, int16_t *tmp, ptrdiff_t tmp_stride, const void *src, ptrdiff_t src_stride,
+                  const int16_t *abcd, int mx, int my, int bitdepth_max)
+{
+    const int hbd = bitdepth_max > 255;
+    const int ib = hbd ? 14 - bitdepth_of(bitdepth_max) : 4;
+    int16_t mid[15][8];
+    for (int y = 0; y < 15; y++)
+        for (int x = 0; x < 8; x++) {
+            const int tmx = mx + y * abcd[1] + x * abcd[0];
+            const int8_t *f = &av1_mc_warp_filter[(64 + ((tmx + 512) >> 10)) * 8];
+            int s = 0;
+            for (int k = 0; k < 8; k++) s += f[k] * px_get(src, src_stride, x + k - 3, y - 3, hbd);
+            mid[y][x] = (int16_t) ((s + ((1 << (7 - ib)) >> 1)) >> (7 - ib));
+        }
+    for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++) {
+            const int tmy = my + y * abcd[3] + x * abcd[2];
+            const int8_t *f = &av1_mc_warp_filter[(64 + ((tmy + 512) >> 10)) * 8];
+            int s = 0;
+            for (int k = 0; k < 8; k++) s += f[k] * mid[y + k][x];
+            if (dst) px_set(dst, dst_stride, x, y, port_iclip((s + ((1 << (7 + ib)) >> 1)) >> (7 + ib), 0, bitdepth_max), hbd);
+            else tmp[y * tmp_stride + x] = (int16_t) (((s + 64) >> 7) - (hbd ? 8192 : 0));
+        }
+}
+
+/* ---- put / prep with a scaled reference (reference src/mc_tmpl.c:189-244, 307-357, 491-626): output (x, y) samples the source at
+ * (mx + x*dx, my + y*dy) in 1/1024 pel; the 1/16-pel phase of each coordinate picks the filter row. */
+void port_mc_scaled(void *dst, ptrdiff_t dst_stride, int16_t *tmp, const void *src, ptrdiff_t src_stride, int w, int h,
+                    int mx, int my, int dx, int dy, int filter_2d, int bitdepth_max)
+{
+    static const uint8_t ht[9] = { 0, 0, 0, 2, 2, 2, 1, 1, 1 }, vt[9] = { 0, 1, 2, 0, 1, 2, 0, 1, 2 };
+    const int hbd = bitdepth_max > 255;
+    const int ib = hbd ? 14 - bitdepth_of(bitdepth_max) : 4;
+    const int bias = hbd ? 8192 : 0;
+    const int bilin = filter_2d == 9;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int px = mx + x * dx, py = my + y * dy;
+            const int sx = px >> 10, fx = (px & 0x3ff) >> 6, sy = py >> 10, fy = (py & 0x3ff) >> 6;
+            int v;
+            if (bilin) {
+                int m[2];
+                for (int r = 0; r < 2; r++) {
+                    const int a = px_get(src, src_stride, sx, sy + r, hbd), b = px_get(src, src_stride, sx + 1, sy + r, hbd);
+                    m[r] = (int16_t) ((16 * a + fx * (b - a) + ((1 << (4 - ib)) >> 1)) >> (4 - ib));
+                }
+                const int s = 16 * m[0] + fy * (m[1] - m[0]);
+                v = dst ? (s + ((1 << (4 + ib)) >> 1)) >> (4 + ib) : ((s + 8) >> 4) - bias;
+            } else {
+                int fh[8], fv[8], mid[8];
+                taps(fh, w > 4 ? ht[filter_2d] : 3 + (ht[filter_2d] & 1), fx);
+                taps(fv, h > 4 ? vt[filter_2d] : 3 + (vt[filter_2d] & 1), fy);
+                for (int r = 0; r < 8; r++) {
+                    int s;
+                    if (fx) {
+                        s = 0;
+                        for (int k = 0; k < 8; k++) s += fh[k] * px_get(src, src_stride, sx + k - 3, sy + r - 3, hbd);
+                        s = (s + ((1 << (6 - ib)) >> 1)) >> (6 - ib);
+                    } else s = px_get(src, src_stride, sx, sy + r - 3, hbd) << ib;
+                    mid[r] = (int16_t) s;
+                }
+                if (fy) {
+                    int s = 0;
+                    for (int k = 0; k < 8; k++) s += fv[k] * mid[k];
+                    v = dst ? (s + ((1 << (6 + ib)) >> 1)) >> (6 + ib) : ((s + 32) >> 6) - bias;
+                } else v = dst ? (mid[3] + ((1 << ib) >> 1)) >> ib : mid[3] - bias;
+            }
+            if (dst) px_set(dst, dst_stride, x, y, port_iclip(v, 0, bitdepth_max), hbd);
+            else tmp[y * w + x] = (int16_t) v;
+        }
+}
+
+/* ---- resize (reference src/mc_tmpl.c:918-944): horizontal 8-tap upscale, position in 1/16384 pel steps of dx starting at mx0 */
+void port_resize(void *dst, ptrdiff_t dst_stride, const void *src, ptrdiff_t src_stride, int dst_w, int h, int src_w, int dx, int mx0,
+                 int bitdepth_max)
+{
+    const int hbd = bitdepth_max > 255;
+    for (int y = 0; y < h; y++) {
+        int mx = mx0, sx = -1;
+        for (int x = 0; x < dst_w; x++) {
+            const int8_t *F = &av1_resize_filter[(mx >> 8) * 8];
+            int s = 0;
+            for (int k = 0; k < 8; k++) s += F[k] * px_get(src, src_stride, port_iclip(sx + k - 3, 0, src_w - 1), y, hbd);
+            px_set(dst, dst_stride, x, y, port_iclip((-s + 64) >> 7, 0, bitdepth_max), hbd);
+            mx += dx;
+            sx += mx >> 14;
+            mx &= 0x3fff;
+        }
+    }
+}

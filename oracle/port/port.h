@@ -24,6 +24,12 @@ void port_comp(int kind, int ss, void *dst, ptrdiff_t dst_stride, const int16_t 
 void port_emu_edge(intptr_t bw, intptr_t bh, intptr_t iw, intptr_t ih, intptr_t x, intptr_t y,
                    void *dst, ptrdiff_t dst_stride, const void *ref, ptrdiff_t ref_stride, int hbd);
 void port_blend(int dir, void *dst, ptrdiff_t dst_stride, const void *tmp, int w, int h, const uint8_t *mask, int hbd);
+void port_warp8x8(void *dst, ptrdiff_t dst_stride, int16_t *tmp, ptrdiff_t tmp_stride, const void *src, ptrdiff_t src_stride,
+                  const int16_t *abcd, int mx, int my, int bitdepth_max);
+void port_mc_scaled(void *dst, ptrdiff_t dst_stride, int16_t *tmp, const void *src, ptrdiff_t src_stride, int w, int h,
+                    int mx, int my, int dx, int dy, int filter_2d, int bitdepth_max);
+void port_resize(void *dst, ptrdiff_t dst_stride, const void *src, ptrdiff_t src_stride, int dst_w, int h, int src_w, int dx, int mx0,
+                 int bitdepth_max);
 void port_loop_filter_sb(int chroma, int dir, void *dst, ptrdiff_t stride, const uint32_t *vmask, const uint8_t (*l)[4],
                          ptrdiff_t b4_stride, const uint8_t *lut, int bitdepth_max);
 int port_cdef_dir(const void *img, ptrdiff_t stride, unsigned *var, int bitdepth_max);

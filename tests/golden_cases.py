@@ -293,6 +293,46 @@ def fg_case(oracle, bpc):
     return _digest(*outs)
 
 
+def mcx_case(oracle, bpc):
+    """warp8x8 / warp8x8t, scaled put / prep, resize (value ranges of tests/checkasm/mc.c:163-283, 565-771)."""
+    rng = np.random.default_rng(4100 + bpc)
+    pd = util.pix_dtype(bpc)
+    bps = pd().itemsize
+    src = _frame(rng, bpc, 300, 320)
+    outs = []
+    for it in range(24):
+        abcd = (rng.integers(0, 0x2000, size=4) - 0xa00).astype(np.int16)
+        mx, my = int(rng.integers(0, 0x2000)) - 0xa00, int(rng.integers(0, 0x2000)) - 0xa00
+        sp = _ptr(src, 20 + it, 24 + 3 * it)
+        d = np.zeros((8, 8), pd)
+        oracle.call(bpc, "warp8x8", 0, 0, d, 8 * bps, sp, src.strides[0], abcd, mx, my)
+        t = np.zeros((8, 8), np.int16)
+        oracle.call(bpc, "warp8x8t", 0, 0, t, 8, sp, src.strides[0], abcd, mx, my)
+        outs += [d, t]
+    for f in range(10):
+        for w, h in [(2, 2), (4, 8), (8, 4), (16, 32), (64, 16), (128, 8)]:
+            mx, my = int(rng.integers(0, 1024)), int(rng.integers(0, 1024))
+            dx = int(rng.choice([512, 1024, 2048, int(rng.integers(1, 2049))]))
+            dy = int(rng.choice([512, 1024, 2048, int(rng.integers(1, 2049))]))
+            sp = _ptr(src, 8, 8)
+            d = np.zeros((h, w + 1), pd)
+            oracle.call(bpc, "mc_scaled", f, 0, d, d.strides[0], sp, src.strides[0], w, h, mx, my, dx, dy)
+            outs.append(d)
+            if w >= 4:
+                t = np.zeros(w * h, np.int16)
+                oracle.call(bpc, "mct_scaled", f, 0, t, sp, src.strides[0], w, h, mx, my, dx, dy)
+                outs.append(t)
+    for it in range(6):
+        w_den = 9 + int(rng.integers(0, 8))
+        src_w = 16 + int(rng.integers(0, 300 - 16 + 1))
+        dst_w = w_den * src_w >> 3
+        dx = ((src_w << 14) + (dst_w >> 1)) // dst_w
+        d = np.zeros((20, dst_w + 2), pd)
+        oracle.call(bpc, "resize", 0, 0, d, d.strides[0], src, src.strides[0], dst_w, 20, src_w, dx, int(rng.integers(0, 0x4000)))
+        outs.append(d)
+    return _digest(*outs)
+
+
 def all_cases():
     """name -> callable(oracle)"""
     cases = {}
@@ -303,6 +343,7 @@ def all_cases():
             cases["mc/%dbpc/%s" % (bpc, nm)] = (lambda o, b=bpc, k=kind: mc_case(o, b, k))
         cases["comp/%dbpc" % bpc] = (lambda o, b=bpc: comp_case(o, b))
         cases["blend/%dbpc" % bpc] = (lambda o, b=bpc: blend_case(o, b))
+        cases["mcx/%dbpc" % bpc] = (lambda o, b=bpc: mcx_case(o, b))
         cases["lf/%dbpc" % bpc] = (lambda o, b=bpc: lf_case(o, b))
         cases["cdef/%dbpc" % bpc] = (lambda o, b=bpc: cdef_case(o, b))
         cases["lr/%dbpc" % bpc] = (lambda o, b=bpc: lr_case(o, b))
