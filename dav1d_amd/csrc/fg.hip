@@ -37,11 +37,16 @@ struct FgParams {                 // the scalar part of Dav1dFilmGrainData the k
     int8_t ar_coeffs_uv[2][28];
 };
 
+// The auto-regressive pass of one template as a wavefront: lane = row, row y trails row y-1 by LAG+1 columns, so everything a
+// sample needs is final when its turn comes (src/filmgrain_tmpl.c:72-91, 123-153).  LAG is a compile-time constant so that the
+// tap loops unroll and the coefficients live in scalar registers; a lane keeps its own last LAG results and a sliding
+// (2 LAG + 1)-wide window of each of the LAG rows above in registers, so a step reads LAG new samples from LDS, not
+// 2 LAG (LAG + 1).
 template <int LAG>
 __device__ void ar_filter(int16_t *lut, const int16_t *lut_y, const FgParams &p, const int pl, const int subx, const int suby,
                           const int W, const int H, const int grain_min, const int grain_max, const int lane)
 {
-    constexpr int pad = 3, NC = 2 * LAG * (LAG + 1);        // taps before the current sample
+    constexpr int pad = 3, NC = 2 * LAG * (LAG + 1), WW = 2 * LAG + 1;
     int coef[NC + 1];
     {
         const int8_t *c = pl ? p.ar_coeffs_uv[pl - 1] : p.ar_coeffs_y;
@@ -53,17 +58,47 @@ __device__ void ar_filter(int16_t *lut, const int16_t *lut_y, const FgParams &p,
         const int rows = dv::imin(64, H - y0);
         const int y = y0 + lane;
         const int steps = (W - 2 * pad) + (rows - 1) * (LAG + 1);
+        int win[LAG > 0 ? LAG : 1][WW], own[LAG > 0 ? LAG : 1];
+#pragma unroll
+        for (int k = 0; k < (LAG > 0 ? LAG : 1); k++) {
+            own[k] = 0;
+#pragma unroll
+            for (int j = 0; j < WW; j++) win[k][j] = 0;
+        }
         for (int s = 0; s < steps; s++) {
             const int x = pad + s - lane * (LAG + 1);
             if (lane < rows && x >= pad && x < W - pad) {
-                int sum = 0, k = 0;
+                if (x == pad) {
+                    // first sample of the row: fill the windows (columns 0 .. 2 LAG of the rows above, 0 .. LAG-1 of this row)
 #pragma unroll
-                for (int dy = -LAG; dy <= 0; dy++)
+                    for (int k = 0; k < LAG; k++) {
+                        own[k] = lut[y * GW + x - LAG + k];
 #pragma unroll
-                    for (int dx = -LAG; dx <= LAG; dx++) {
-                        if (dy == 0 && dx >= 0) continue;
-                        sum += coef[k++] * lut[(y + dy) * GW + x + dx];
+                        for (int j = 0; j < WW; j++) win[k][j] = lut[(y - LAG + k) * GW + x - LAG + j];
                     }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < LAG; k++) {
+#pragma unroll
+                        for (int j = 0; j + 1 < WW; j++) win[k][j] = win[k][j + 1];
+                        win[k][WW - 1] = lut[(y - LAG + k) * GW + x + LAG];
+                    }
+                }
+                // one partial sum per row: independent multiply-add chains instead of one 24-deep chain (a lone wave has
+                // nothing else to hide the ALU latency behind)
+                int part[LAG + 1];
+#pragma unroll
+                for (int k = 0; k < LAG; k++) {
+                    part[k] = 0;
+#pragma unroll
+                    for (int j = 0; j < WW; j++) part[k] += coef[k * WW + j] * win[k][j];
+                }
+                part[LAG] = 0;
+#pragma unroll
+                for (int j = 0; j < LAG; j++) part[LAG] += coef[LAG * WW + j] * own[j];
+                int sum = 0;
+#pragma unroll
+                for (int k = 0; k <= LAG; k++) sum += part[k];
                 if (with_luma) {
                     int luma = 0;
                     const int lx = ((x - pad) << subx) + pad, ly = ((y - pad) << suby) + pad;
@@ -71,7 +106,11 @@ __device__ void ar_filter(int16_t *lut, const int16_t *lut_y, const FgParams &p,
                         for (int j = 0; j <= subx; j++) luma += lut_y[(ly + i) * GW + lx + j];
                     sum += round2(luma, subx + suby) * coef[NC];
                 }
-                lut[y * GW + x] = (int16_t) dv::iclip(lut[y * GW + x] + round2(sum, p.ar_coeff_shift), grain_min, grain_max);
+                const int v = dv::iclip(lut[y * GW + x] + round2(sum, p.ar_coeff_shift), grain_min, grain_max);
+                lut[y * GW + x] = (int16_t) v;
+#pragma unroll
+                for (int j = 0; j + 1 < LAG; j++) own[j] = own[j + 1];
+                if (LAG > 0) own[LAG - 1] = v;
             }
             dv::wave_sync();
         }
@@ -80,7 +119,7 @@ __device__ void ar_filter(int16_t *lut, const int16_t *lut_y, const FgParams &p,
 
 // one wave builds template `pl` (0 luma, 1/2 chroma) in `lut` (int16 [74][82])
 __device__ void gen_template(int16_t *lut, const int16_t *lut_y, const FgParams &p, const int pl, const int subx, const int suby,
-                             const int bitdepth_min_8, uint16_t *cols, uint16_t *rowstart, const int lane)
+                             const int bitdepth_min_8, uint16_t *cols, uint16_t *rowstart, const int16_t *gauss, const int lane)
 {
     const int W = (pl && subx) ? SGW : GW, H = (pl && suby) ? SGH : GH;
     const int shift = 4 - bitdepth_min_8 + p.grain_scale_shift;
@@ -108,7 +147,7 @@ __device__ void gen_template(int16_t *lut, const int16_t *lut_y, const FgParams 
         unsigned s = rowstart[y];
         for (int x = 0; x < W; x++) {
             s = lfsr_step(s);
-            lut[y * GW + x] = (int16_t) round2(av1_gaussian_sequence[(s >> 5) & 2047], shift);
+            lut[y * GW + x] = (int16_t) round2(gauss[(s >> 5) & 2047], shift);
         }
     }
     dv::wave_sync();
@@ -122,18 +161,26 @@ __device__ void gen_template(int16_t *lut, const int16_t *lut_y, const FgParams 
     }
 }
 
-__global__ __launch_bounds__(64) void fg_gen_kernel(int16_t *luts, const FgParams p, const int layout, const int bitdepth_min_8, const int part)
+// part 3: like 1 / 2 with the plane taken from blockIdx.x and skipped when dav1d_apply_grain would not build it: both
+// chroma templates side by side, after a part -1 launch finished the luma template
+__global__ __launch_bounds__(64) void fg_gen_kernel(int16_t *luts, const FgParams p, const int layout, const int bitdepth_min_8, int part)
 {
     __shared__ uint16_t cols[16], rowstart[GH];
     __shared__ int16_t t_y[(GH + 1) * GW], t_c[(GH + 1) * GW];     // templates are built in LDS, then copied out
+    __shared__ int16_t gauss[2048];                                 // the Gaussian table: random lookups, so LDS not memory
     const int lane = threadIdx.x;
     const int subx = layout != DAV1D_HIP_LAYOUT_I444, suby = layout == DAV1D_HIP_LAYOUT_I420;
+    if (part == 3) {
+        part = 1 + blockIdx.x;
+        if (layout == DAV1D_HIP_LAYOUT_I400 || !(p.num_uv_points[part - 1] || p.chroma_scaling_from_luma)) return;
+    }
+    for (int i = lane; i < 2048; i += 64) gauss[i] = av1_gaussian_sequence[i];
     for (int i = lane; i < (GH + 1) * GW; i += 64) t_y[i] = t_c[i] = 0;
     dv::wave_sync();
     if (part > 0) {
         for (int i = lane; i < (GH + 1) * GW; i += 64) t_y[i] = luts[i];
     } else {
-        gen_template(t_y, t_y, p, 0, subx, suby, bitdepth_min_8, cols, rowstart, lane);
+        gen_template(t_y, t_y, p, 0, subx, suby, bitdepth_min_8, cols, rowstart, gauss, lane);
         dv::wave_sync();
         for (int i = lane; i < (GH + 1) * GW; i += 64) luts[i] = t_y[i];
     }
@@ -141,7 +188,7 @@ __global__ __launch_bounds__(64) void fg_gen_kernel(int16_t *luts, const FgParam
     for (int pl = 1; pl <= 2; pl++) {
         dv::wave_sync();
         if (part ? pl == part : (layout != DAV1D_HIP_LAYOUT_I400 && (p.num_uv_points[pl - 1] || p.chroma_scaling_from_luma))) {
-            gen_template(t_c, t_y, p, pl, subx, suby, bitdepth_min_8, cols, rowstart, lane);
+            gen_template(t_c, t_y, p, pl, subx, suby, bitdepth_min_8, cols, rowstart, gauss, lane);
             dv::wave_sync();
             for (int i = lane; i < (GH + 1) * GW; i += 64) luts[pl * (GH + 1) * GW + i] = t_c[i];
         }
@@ -305,7 +352,10 @@ FgParams make_params(const Dav1dHipFilmGrainData *d) {
 
 extern "C" int dav1d_hip_launch_fg_gen(int16_t *luts, const Dav1dHipFilmGrainData *data, int bpc, int layout, void *stream)
 {
-    hipLaunchKernelGGL(fg_gen_kernel, dim3(1), dim3(64), 0, (hipStream_t) stream, luts, make_params(data), layout, bpc - 8, 0);
+    // luma first, then both chroma templates side by side (they filter against the finished luma template)
+    hipLaunchKernelGGL(fg_gen_kernel, dim3(1), dim3(64), 0, (hipStream_t) stream, luts, make_params(data), layout, bpc - 8, -1);
+    if (layout != DAV1D_HIP_LAYOUT_I400)
+        hipLaunchKernelGGL(fg_gen_kernel, dim3(2), dim3(64), 0, (hipStream_t) stream, luts, make_params(data), layout, bpc - 8, 3);
     return hip_rc(hipGetLastError());
 }
 
