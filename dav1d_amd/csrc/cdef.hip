@@ -71,17 +71,22 @@ __device__ __forceinline__ int cdef_px(const int16_t *tmp, const int x, const in
     return (pri && sec) ? dv::iclip(v, (int) mn, mx) : v;
 }
 
-template <typename pixel>
+// The (w+4) x (h+4) neighbourhood of a block goes to LDS in 12-wide rows (the layout cdef_px and the direction tables
+// expect), INT16_MIN where `edges` says the neighbour does not exist.  WW = w + 4 is a compile-time constant, so the
+// entry -> (row, column) split is a shift or a multiply, and only the entries of the window are visited: 64 for a 4x4
+// block (one pass), 96 for 4x8, 144 for 8x8.
+template <typename pixel, int WW>
 __device__ __forceinline__ void load_window(int16_t *tmp, const pixel *src, const int stride, const int x0, const int y0,
-                                            const int w, const int h, const int edges, const int lane)
+                                            const int h, const int edges, const int lane)
 {
-    for (int i = lane; i < 144; i += 64) {
-        const int yy = i / 12 - 2, xx = i % 12 - 2;
-        int v = -32768;
-        const bool in_win = xx < w + 2 && yy < h + 2;
+    constexpr int w = WW - 4;
+    const int n = WW * (h + 4);
+    for (int i = lane; i < n; i += 64) {
+        const int yy = i / WW - 2, xx = i % WW - 2;
         const bool avail = (yy >= 0 || (edges & 4)) && (yy < h || (edges & 8)) && (xx >= 0 || (edges & 1)) && (xx < w || (edges & 2));
-        if (in_win && avail) v = src[(y0 + yy) * stride + x0 + xx];
-        tmp[i] = (int16_t) v;
+        int v = -32768;
+        if (avail) v = src[(y0 + yy) * stride + x0 + xx];
+        tmp[(yy + 2) * 12 + xx + 2] = (int16_t) v;
     }
 }
 
@@ -108,7 +113,8 @@ __global__ __launch_bounds__(64) void cdef_kernel(const DevPlanes dst, const Dev
     const int lw = raw_ ? (t.flags & 2 ? 4 : 8) : 8, lh = raw_ ? (t.flags & 4 ? 4 : 8) : 8;
     const pixel *sy = reinterpret_cast<const pixel *>(src.data[lpl]);
     const int x0 = raw_ ? t.bx : t.bx * 8, y0 = raw_ ? t.by : t.by * 8;   // raw: pixel coordinates
-    load_window<pixel>(tmp, sy, src.stride[lpl], x0, y0, lw, lh, edges, lane);
+    if (lw == 8) load_window<pixel, 12>(tmp, sy, src.stride[lpl], x0, y0, lh, edges, lane);
+    else load_window<pixel, 8>(tmp, sy, src.stride[lpl], x0, y0, lh, edges, lane);
     for (int i = lane; i < 90; i += 64) psum[i] = 0;
     dv::wave_sync();
 
@@ -191,8 +197,13 @@ __global__ __launch_bounds__(64) void cdef_kernel(const DevPlanes dst, const Dev
         if (t.uv_pri) uvdir = layout == DAV1D_HIP_LAYOUT_I422 ? (int) ((uv422 >> (4 * dir)) & 15) : dir;
         const int cx0 = x0 >> ss_hor, cy0 = y0 >> ss_ver;
         dv::wave_sync();
-        load_window<pixel>(tmp, reinterpret_cast<const pixel *>(src.data[1]), src.stride[1], cx0, cy0, w, h, edges, lane);
-        load_window<pixel>(tmp2, reinterpret_cast<const pixel *>(src.data[2]), src.stride[2], cx0, cy0, w, h, edges, lane);
+        if (w == 8) {
+            load_window<pixel, 12>(tmp, reinterpret_cast<const pixel *>(src.data[1]), src.stride[1], cx0, cy0, h, edges, lane);
+            load_window<pixel, 12>(tmp2, reinterpret_cast<const pixel *>(src.data[2]), src.stride[2], cx0, cy0, h, edges, lane);
+        } else {
+            load_window<pixel, 8>(tmp, reinterpret_cast<const pixel *>(src.data[1]), src.stride[1], cx0, cy0, h, edges, lane);
+            load_window<pixel, 8>(tmp2, reinterpret_cast<const pixel *>(src.data[2]), src.stride[2], cx0, cy0, h, edges, lane);
+        }
         dv::wave_sync();
         const int npx = w * h;                        // 16, 32 or 64 pixels per plane
         for (int i = lane; i < 2 * npx; i += 64) {
