@@ -17,6 +17,9 @@
 
 namespace {
 
+enum { LR_SEG = 64 };        // output rows per wave: the whole stripe (16-row segments were measured 20 % slower: 6 extra
+                             // rows of horizontal filtering per segment outweigh the shorter chains)
+
 template <typename pixel>
 __global__ __launch_bounds__(64) void wiener_kernel(const DevPlanes dst, const DevPlanes src, const DevPlanes lpf,
                                                     const Dav1dHipLrTask *__restrict__ tasks, const int n, const int bitdepth_max)
@@ -62,7 +65,11 @@ __global__ __launch_bounds__(64) void wiener_kernel(const DevPlanes dst, const D
     for (int i = 0; i < 7; i++) win[i] = 0;
     pixel *d = reinterpret_cast<pixel *>(dst.data[pl]) + t.y * dst.stride[pl] + t.x + xc;
 
-    for (int r = -3; r < h + 3; r++) {
+    // a wave filters SEG output rows: rows seg0 .. seg1-1 need the horizontally filtered virtual rows seg0-3 .. seg1+2, so
+    // splitting a stripe costs 6 extra rows per segment and buys shorter serial chains and SEG-fold more waves
+    const int seg0 = blockIdx.z * LR_SEG, seg1 = dv::imin(seg0 + LR_SEG, h);
+    if (seg0 >= h) return;
+    for (int r = seg0 - 3; r < seg1 + 3; r++) {
         // which picture row feeds virtual row r
         const pixel *row;
         if (r < 0) {
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(64) void wiener_kernel(const DevPlanes dst, const D
 #pragma unroll
         for (int i = 0; i < 6; i++) win[i] = win[i + 1];
         win[6] = sum;
-        if (r >= 3) {
+        if (r >= seg0 + 3) {
             int v = -round_offset;
 #pragma unroll
             for (int k = 0; k < 7; k++) v += win[k] * fv[k];
@@ -155,7 +162,9 @@ __global__ __launch_bounds__(64) void sgr_kernel(const DevPlanes dst, const DevP
     const bool out_lane = lane >= 1 && lane <= 62 && c < w;
     pixel *const d = reinterpret_cast<pixel *>(dst.data[pl]) + t.y * dst.stride[pl] + t.x + c;
 
-    for (int r = -3; r < h + 3; r++) {
+    const int rs0 = blockIdx.z * LR_SEG, rs1 = dv::imin(rs0 + LR_SEG, h);      // LR_SEG is even: the 5x5 surface lives on odd rows
+    if (rs0 >= h) return;
+    for (int r = rs0 - 3; r < rs1 + 3; r++) {
         // ---- horizontal box sums of virtual row r
         const pixel *row;
         if (r < 0) {
@@ -175,18 +184,18 @@ __global__ __launch_bounds__(64) void sgr_kernel(const DevPlanes dst, const DevP
         s5[4] = s3[2] + p0 + p4;
         q5[4] = q3[2] + p0 * p0 + p4 * p4;
         // ---- (A, B) rows that just became complete
-        if (do3 && r >= 0 && r <= h + 1) {              // row j = r - 1 of the 3x3 surface
+        if (do3 && r >= rs0 && r <= rs1 + 1) {        // row j = r - 1 of the 3x3 surface (rows rs0-1 .. rs1 feed this segment)
             const AB v = calc_ab(q3[0] + q3[1] + q3[2], s3[0] + s3[1] + s3[2], s1, bitdepth_min_8, 9, 455);
             a3[(r - 1) & 3][lane] = v.a; b3[(r - 1) & 3][lane] = v.b;
         }
-        if (do5 && r >= 1 && ((r - 2) & 1)) {           // row j = r - 2 (odd) of the 5x5 surface
+        if (do5 && r >= rs0 + 1 && ((r - 2) & 1)) {    // row j = r - 2 (odd) of the 5x5 surface
             const AB v = calc_ab(q5[0] + q5[1] + q5[2] + q5[3] + q5[4], s5[0] + s5[1] + s5[2] + s5[3] + s5[4], s0, bitdepth_min_8, 25, 164);
             a5[((r - 2) >> 1) & 1][lane] = v.a; b5[((r - 2) >> 1) & 1][lane] = v.b;
         }
         dv::wave_sync();
         // ---- output row y = r - 3
         const int y = r - 3;
-        if (y >= 0 && y < h && out_lane) {
+        if (y >= rs0 && y < rs1 && out_lane) {
             const int px = s[(t.y + y) * ss + t.x + c];
             int v = 0;
             if (do3) {
@@ -226,7 +235,7 @@ extern "C" int dav1d_hip_launch_wiener(const DevPlanes *dst, const DevPlanes *sr
 {
     if (n <= 0) return 0;
     const int bitdepth_max = (1 << bpc) - 1;
-    const dim3 grid(6, n);          // up to 384 columns per unit
+    const dim3 grid(6, n, (64 + LR_SEG - 1) / LR_SEG);          // up to 384 columns x 64 rows per unit
     if (bpc == 8)
         hipLaunchKernelGGL((wiener_kernel<uint8_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks, n, bitdepth_max);
     else
@@ -239,7 +248,7 @@ extern "C" int dav1d_hip_launch_sgr(const DevPlanes *dst, const DevPlanes *src, 
 {
     if (n <= 0) return 0;
     const int bitdepth_max = (1 << bpc) - 1;
-    const dim3 grid(7, n);          // 7 x 62 >= 384 columns
+    const dim3 grid(7, n, (64 + LR_SEG - 1) / LR_SEG);          // 7 x 62 >= 384 columns
     if (bpc == 8)
         hipLaunchKernelGGL((sgr_kernel<uint8_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks, n, bitdepth_max);
     else
