@@ -269,13 +269,10 @@ def main():
             if not a.no_check:
                 t1 = time.perf_counter()
                 want_rec = synth.copy_planes(want[0])
-                if oracle.which == "ref":
-                    test_postchain.oracle_intra(oracle, intra, want_rec, w, h, bpc)
-                    intra_ok = all(np.array_equal(got[pl], want_rec[pl]) for pl in range(3))
-                    if not intra_ok:
-                        raise SystemExit("bench: intra pass differs from the oracle")
-                else:
-                    want_rec = got          # edge preparation is only available from the reference build
+                test_postchain.oracle_intra(oracle, intra, want_rec, w, h, bpc)
+                intra_ok = all(np.array_equal(got[pl], want_rec[pl]) for pl in range(3))
+                if not intra_ok:
+                    raise SystemExit("bench: intra pass differs from the oracle")
                 want_post = test_postchain.oracle_post(oracle, post, want_rec, w, h, bpc)
                 t_post_cpu = time.perf_counter() - t1
             pics = [ctx.picture(w, h, api.LAYOUT_I420, bpc) for _ in range(4)]
@@ -323,9 +320,7 @@ def main():
                     "tasks": {"ipred": intra.n_blocks, "lf": int(len(post.lf)), "cdef": int(len(post.cdef)), "lr": int(len(post.lr))},
                     "algorithmic_bytes_per_frame": int(full_bytes),
                     "achieved": round(full_bytes / (full_ms * 1e-3) / 1e9, 1), "frac": round(full_bytes / (full_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "parity": "skipped" if a.no_check else "every stage bit-exact vs %s oracle%s%s" % (
-                        oracle.which, "" if want_post[3] is not None else " (film grain unchecked: needs oracle/_ref)",
-                        "" if intra_ok else " (intra pass unchecked: needs oracle/_ref)"),
+                    "parity": "skipped" if a.no_check else "every stage bit-exact vs %s oracle" % oracle.which,
                     "cpu_post_filters_s": round(t_post_cpu, 2)}
         label = "8K" if (w, h) == (7680, 4320) else "4K" if (w, h) == (3840, 2160) else "%dx%d" % (w, h)
         out = {"metric": "reconstructed luma Mpixels/s (%s 4:2:0 %d-bit) on the itx+mc recon path; bit-exact vs C" % (label, bpc),

@@ -126,3 +126,93 @@ void port_fg_row(const int pl, void *const dst_row, const void *const src_row, c
             }
     }
 }
+
+/* ---- the driver: dav1d_apply_grain (reference src/fg_apply_tmpl.c:41-241) on caller-provided planes.  Builds the grain
+ * templates and the scaling tables, copies the planes that get no grain, then walks the picture in rows of 32 lines. */
+
+/* generate_scaling (:41-95): piecewise-linear table through the (x, y) points; for more than 8 bits the 8-bit grid is
+ * spread out and the gaps are filled by interpolation */
+static void scaling_table(uint8_t *const lut, const int bd, const uint8_t pts[][2], const int num)
+{
+    const int shift = bd - 8, size = 1 << bd;
+    if (!num) { memset(lut, 0, size); return; }
+    memset(lut, pts[0][1], (size_t) pts[0][0] << shift);
+    for (int i = 0; i + 1 < num; i++) {
+        const int x0 = pts[i][0], y0 = pts[i][1], run = pts[i + 1][0] - x0, rise = pts[i + 1][1] - y0;
+        const int slope = rise * ((0x10000 + (run >> 1)) / run);
+        for (int k = 0, acc = 0x8000; k < run; k++, acc += slope) lut[(x0 + k) << shift] = (uint8_t) (y0 + (acc >> 16));
+    }
+    const int last = pts[num - 1][0] << shift;
+    memset(lut + last, pts[num - 1][1], size - last);
+    if (shift) {
+        const int pad = 1 << shift, half = pad >> 1;
+        for (int i = 0; i + 1 < num; i++) {
+            const int from = pts[i][0] << shift, to = pts[i + 1][0] << shift;
+            for (int x = 0; x < to - from; x += pad) {
+                const int span = lut[from + x + pad] - lut[from + x];
+                for (int n = 1, acc = half; n < pad; n++) { acc += span; lut[from + x + n] = (uint8_t) (lut[from + x] + (acc >> shift)); }
+            }
+        }
+    }
+}
+
+int dav1d_port_apply_grain(const int bpc, const PortFilmGrain *const d, const int w, const int h, const int layout, const int is_id,
+                           void *const out[3], void *const in[3], const ptrdiff_t y_stride, const ptrdiff_t uv_stride)
+{
+    const int bdmax = (1 << bpc) - 1, hbd = bpc > 8, bps = hbd ? 2 : 1;
+    const int sx = layout != 3 && layout != 0, sy = layout == 1;
+    static int grain[3][74][GW];
+    memset(grain, 0, sizeof(grain));
+    uint8_t *scaling = malloc((size_t) 3 << bpc);
+    if (!scaling) return -1;
+    port_generate_grain(grain[0], NULL, d, 0, 0, 0, bdmax);
+    for (int pl = 0; pl < 2; pl++)
+        if (layout && (d->num_uv_points[pl] || d->chroma_scaling_from_luma))
+            port_generate_grain(grain[1 + pl], (const int (*)[GW]) grain[0], d, 1 + pl, sx, sy, bdmax);
+    if (d->num_y_points || d->chroma_scaling_from_luma) scaling_table(scaling, bpc, d->y_points, d->num_y_points);
+    for (int pl = 0; pl < 2; pl++)
+        if (d->num_uv_points[pl]) scaling_table(scaling + ((size_t) (1 + pl) << bpc), bpc, d->uv_points[pl], d->num_uv_points[pl]);
+    /* planes without grain are copied (:127-163) */
+    if (!d->num_y_points) memcpy(out[0], in[0], (size_t) h * y_stride);
+    if (layout && !d->chroma_scaling_from_luma)
+        for (int pl = 0; pl < 2; pl++)
+            if (!d->num_uv_points[pl]) memcpy(out[1 + pl], in[1 + pl], (size_t) ((h + sy) >> sy) * uv_stride);
+    const int cpw = (w + sx) >> sx;
+    for (int row = 0; row * 32 < h; row++) {
+        const int lines = port_imin(h - row * 32, 32);
+        uint8_t *const luma = (uint8_t *) in[0] + (size_t) row * 32 * y_stride;
+        if (d->num_y_points)
+            port_fg_row(0, (uint8_t *) out[0] + (size_t) row * 32 * y_stride, luma, y_stride, d, w, scaling, (const int (*)[GW]) grain[0], lines,
+                        row, NULL, 0, 0, 0, is_id, bdmax);
+        if (!layout || (!d->num_uv_points[0] && !d->num_uv_points[1] && !d->chroma_scaling_from_luma)) continue;
+        const int bh = (lines + sy) >> sy;
+        if (w & sx)         /* odd width: the luma row gets one replicated pixel so that the 2:1 average has a partner (:193-199) */
+            for (int y = 0; y < bh; y++) {
+                uint8_t *p = luma + (size_t) (y << sy) * y_stride;
+                memcpy(p + (size_t) w * bps, p + (size_t) (w - 1) * bps, bps);
+            }
+        const size_t uv_off = (size_t) row * 32 * uv_stride >> sy;
+        for (int pl = 0; pl < 2; pl++) {
+            if (!d->chroma_scaling_from_luma && !d->num_uv_points[pl]) continue;
+            const uint8_t *sc = scaling + (d->chroma_scaling_from_luma ? 0 : (size_t) (1 + pl) << bpc);
+            port_fg_row(1 + pl, (uint8_t *) out[1 + pl] + uv_off, (const uint8_t *) in[1 + pl] + uv_off, uv_stride, d, cpw, sc,
+                        (const int (*)[GW]) grain[1 + pl], bh, row, luma, y_stride, sx, sy, is_id, bdmax);
+        }
+    }
+    free(scaling);
+    return 0;
+}
+
+/* grain templates as int16 [3][73 + 1][82], the chroma ones only where dav1d_apply_grain would build them */
+int dav1d_port_generate_grain(const int bpc, const PortFilmGrain *const d, const int layout, int16_t *const out)
+{
+    static int grain[3][74][GW];
+    memset(grain, 0, sizeof(grain));
+    const int sx = layout != 3 && layout != 0, sy = layout == 1, bdmax = (1 << bpc) - 1;
+    port_generate_grain(grain[0], NULL, d, 0, 0, 0, bdmax);
+    for (int pl = 0; pl < 2; pl++)
+        if (layout && (d->num_uv_points[pl] || d->chroma_scaling_from_luma))
+            port_generate_grain(grain[1 + pl], (const int (*)[GW]) grain[0], d, 1 + pl, sx, sy, bdmax);
+    for (int i = 0; i < 3 * 74 * GW; i++) out[i] = (int16_t) ((int *) grain)[i];
+    return 0;
+}

@@ -241,3 +241,108 @@ void port_pal_pred(void *const dst, const ptrdiff_t stride, const void *const pa
             }
         }
 }
+
+/* ---- dav1d_prepare_intra_edges (reference src/ipred_prepare_tmpl.c:75-204): maps the bitstream mode to a predictor and
+ * assembles the edge array that predictor reads -- left column, bottom-left extension, top row, top-right extension,
+ * corner -- from the picture around the block, with the reference's substitution rules where a neighbour is missing.
+ * Same arguments as the reference function (x, y, w, h in 4-pixel units; w / h = end of the tile). */
+static int needs(int mode, int what)      /* what: 0 left, 1 top, 2 corner, 3 top-right, 4 bottom-left (:50-73) */
+{
+    switch (what) {
+    case 0: return mode == M_DC || mode == M_HOR || mode == M_LEFT_DC || mode == M_Z2 || mode == M_Z3 || (mode >= M_SMOOTH && mode <= M_FILTER);
+    case 1: return mode == M_DC || mode == M_VERT || mode == M_TOP_DC || mode == M_Z1 || mode == M_Z2 || (mode >= M_SMOOTH && mode <= M_FILTER);
+    case 2: return mode == M_Z1 || mode == M_Z2 || mode == M_Z3 || mode == M_PAETH || mode == M_FILTER;
+    case 3: return mode == M_Z1;
+    default: return mode == M_Z3;
+    }
+}
+
+int port_prepare_intra_edges(const int x, const int have_left, const int y, const int have_top, const int w, const int h,
+                             const int edge_flags, const void *const dst, const ptrdiff_t stride, const void *const sb_edge,
+                             int mode, int *const angle, const int tw, const int th, const int filter_edge, void *const topleft_out,
+                             const int bitdepth_max)
+{
+    const int hbd = bitdepth_max > 255;
+    const ptrdiff_t sp = hbd ? stride / 2 : stride;
+    int bd = 0;
+    while (bitdepth_max >> bd) bd++;
+#define PX(i) (hbd ? (int) ((const uint16_t *) dst)[i] : (int) ((const uint8_t *) dst)[i])
+#define OUT(k, v) do { if (hbd) ((uint16_t *) topleft_out)[k] = (uint16_t) (v); else ((uint8_t *) topleft_out)[k] = (uint8_t) (v); } while (0)
+#define GET(k) (hbd ? (int) ((uint16_t *) topleft_out)[k] : (int) ((uint8_t *) topleft_out)[k])
+    /* bitstream mode -> predictor (:89-116) */
+    if (mode >= 1 && mode <= 8) {
+        static const uint8_t base[8] = { 90, 180, 45, 135, 113, 157, 203, 67 };
+        *angle = base[mode - 1] + 3 * *angle;
+        if (*angle <= 90) mode = (*angle < 90 && have_top) ? M_Z1 : M_VERT;
+        else if (*angle < 180) mode = M_Z2;
+        else mode = (*angle > 180 && have_left) ? M_Z3 : M_HOR;
+    } else if (mode == 0) {
+        mode = have_left ? (have_top ? M_DC : M_LEFT_DC) : (have_top ? M_TOP_DC : M_DC_128);
+    } else if (mode == 12) {
+        mode = have_left ? (have_top ? M_PAETH : M_HOR) : (have_top ? M_VERT : M_DC_128);
+    }
+    /* the row above: the picture, or the saved pre-filter row at the top of a superblock row */
+    ptrdiff_t top0 = -sp;                      /* index of the pixel above the block's first column */
+    const void *toprow = dst;
+    if (sb_edge) { toprow = sb_edge; top0 = x * 4; }
+#define TOP(i) (hbd ? (int) ((const uint16_t *) toprow)[top0 + (i)] : (int) ((const uint8_t *) toprow)[top0 + (i)])
+    if (needs(mode, 0)) {
+        const int sz = th * 4;
+        if (have_left) {
+            const int have = port_imin(sz, (h - y) * 4);
+            for (int i = 0; i < sz; i++) OUT(-1 - i, PX(port_imin(i, have - 1) * sp - 1));
+        } else {
+            const int v = have_top ? TOP(0) : ((1 << bd) >> 1) + 1;
+            for (int i = 0; i < sz; i++) OUT(-1 - i, v);
+        }
+        if (needs(mode, 4)) {
+            const int have_bl = (!have_left || y + th >= h) ? 0 : (edge_flags & 8);
+            if (have_bl) {
+                const int have = port_imin(sz, (h - y - th) * 4);
+                for (int i = 0; i < sz; i++) OUT(-sz - 1 - i, PX((sz + port_imin(i, have - 1)) * sp - 1));
+            } else {
+                const int v = GET(-sz);
+                for (int i = 0; i < sz; i++) OUT(-sz - 1 - i, v);
+            }
+        }
+    }
+    if (needs(mode, 1)) {
+        const int sz = tw * 4;
+        if (have_top) {
+            const int have = port_imin(sz, (w - x) * 4);
+            for (int i = 0; i < sz; i++) OUT(1 + i, TOP(port_imin(i, have - 1)));
+        } else {
+            const int v = have_left ? PX(-1) : ((1 << bd) >> 1) - 1;
+            for (int i = 0; i < sz; i++) OUT(1 + i, v);
+        }
+        if (needs(mode, 3)) {
+            const int have_tr = (!have_top || x + tw >= w) ? 0 : (edge_flags & 1);
+            if (have_tr) {
+                const int have = port_imin(sz, (w - x - tw) * 4);
+                for (int i = 0; i < sz; i++) OUT(1 + sz + i, TOP(sz + port_imin(i, have - 1)));
+            } else {
+                const int v = GET(sz);
+                for (int i = 0; i < sz; i++) OUT(1 + sz + i, v);
+            }
+        }
+    }
+    if (needs(mode, 2)) {
+        int v;
+        if (have_left) v = have_top ? TOP(-1) : PX(-1);
+        else v = have_top ? TOP(0) : (1 << bd) >> 1;
+        OUT(0, v);
+        if (mode == M_Z2 && tw + th >= 6 && filter_edge) OUT(0, ((GET(-1) + GET(1)) * 5 + v * 6 + 8) >> 4);
+    }
+#undef PX
+#undef OUT
+#undef GET
+#undef TOP
+    return mode;
+}
+
+int dav1d_prepare_intra_edges_8bpc(int x, int hl, int y, int ht, int w, int h, int ef, const void *dst, ptrdiff_t stride, const void *sb,
+                                   int mode, int *angle, int tw, int th, int fe, void *out)
+{ return port_prepare_intra_edges(x, hl, y, ht, w, h, ef, dst, stride, sb, mode, angle, tw, th, fe, out, 255); }
+int dav1d_prepare_intra_edges_16bpc(int x, int hl, int y, int ht, int w, int h, int ef, const void *dst, ptrdiff_t stride, const void *sb,
+                                    int mode, int *angle, int tw, int th, int fe, void *out, int bdmax)
+{ return port_prepare_intra_edges(x, hl, y, ht, w, h, ef, dst, stride, sb, mode, angle, tw, th, fe, out, bdmax); }

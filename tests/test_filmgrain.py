@@ -42,22 +42,28 @@ def random_fg(rng, bpc, variant):
     return d
 
 
-def _ref():
-    lib = util.ref_lib()
-    lib.dav1d_ref_apply_grain.restype = C.c_int
-    lib.dav1d_ref_apply_grain.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                          C.c_ssize_t, C.c_ssize_t]
-    lib.dav1d_ref_generate_grain.restype = C.c_int
-    lib.dav1d_ref_generate_grain.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]
-    return lib
+class _Driver:
+    """dav1d_apply_grain / the template generator of an oracle: the reference's own (oracle/ref_shim.c) or the
+    restatement's (oracle/port/fg_port.c), same arguments."""
+
+    def __init__(self, oracle):
+        pre = "dav1d_ref_" if oracle.which == "ref" else "dav1d_port_"
+        self.apply_grain = getattr(oracle.lib, pre + "apply_grain")
+        self.apply_grain.restype = C.c_int
+        self.apply_grain.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_ssize_t]
+        self.generate_grain = getattr(oracle.lib, pre + "generate_grain")
+        self.generate_grain.restype = C.c_int
+        self.generate_grain.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+
+
+def fg_driver(oracle=None):
+    return _Driver(oracle or util.default_oracle())
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("bpc", [8, 10, 12])
 def test_film_grain_matches_reference(ctx, bpc, variant):
-    if util.ref_lib() is None:
-        pytest.skip("film grain is checked against the reference build")
-    lib = _ref()
+    lib = fg_driver()
     rng = np.random.default_rng(3000 + 10 * bpc + variant)
     layout = api.LAYOUT_I420 if variant != 2 else api.LAYOUT_I444
     w, h = (160, 96) if ctx.backend == "emu" else (736, 416)
@@ -66,7 +72,7 @@ def test_film_grain_matches_reference(ctx, bpc, variant):
     data = random_fg(rng, bpc, variant)
     # templates
     want_lut = np.zeros((3, 74, 82), np.int16)
-    lib.dav1d_ref_generate_grain(bpc, C.byref(data), layout, want_lut.ctypes.data)
+    lib.generate_grain(bpc, C.byref(data), layout, want_lut.ctypes.data)
     got_lut = ctx.fg_generate_grain(data, bpc, layout)
     assert np.array_equal(got_lut[0], want_lut[0]), "luma grain template"
     assert np.array_equal(got_lut, want_lut), "chroma grain templates"
@@ -89,7 +95,7 @@ def test_film_grain_matches_reference(ctx, bpc, variant):
     inp = synth.copy_planes(planes)
     outp = (C.c_void_p * 3)(*[p.ctypes.data for p in want])
     inpp = (C.c_void_p * 3)(*[p.ctypes.data for p in inp])
-    lib.dav1d_ref_apply_grain(bpc, C.byref(data), w, h, layout, int(variant == 2), outp, inpp, want[0].strides[0], want[1].strides[0])
+    lib.apply_grain(bpc, C.byref(data), w, h, layout, int(variant == 2), outp, inpp, want[0].strides[0], want[1].strides[0])
     ctx.fg_apply(dst, src, data, int(variant == 2))
     ss_v, ss_h = (1 if layout == 1 else 0), (1 if layout != 3 else 0)
     for pl in range(3):

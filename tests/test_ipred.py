@@ -88,8 +88,6 @@ def gen_batches(rng, pic, bpc, n_batches):
 @pytest.mark.parametrize("bpc", [8, 10, 12])
 def test_intra_pred_matches_reference(ctx, bpc):
     oracle = util.default_oracle()
-    if oracle.which != "ref":
-        pytest.skip("ipred is checked against the reference build")
     rng = np.random.default_rng(1500 + bpc)
     W = H = 768
     pic = ctx.picture(W, H, api.LAYOUT_I400, bpc)
@@ -115,8 +113,6 @@ def test_intra_pred_matches_reference(ctx, bpc):
 @pytest.mark.parametrize("bpc", [8, 10, 12])
 def test_cfl_and_palette_match_reference(ctx, bpc):
     oracle = util.default_oracle()
-    if oracle.which != "ref":
-        pytest.skip("ipred is checked against the reference build")
     rng = np.random.default_rng(1700 + bpc)
     W = H = 768
     layout = api.LAYOUT_I420

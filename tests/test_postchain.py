@@ -28,13 +28,13 @@ def oracle_post(oracle, post, recon, w, h, bpc, with_grain=True):
     assert rl.dav1d_replay_lr(entry, bpc, C.byref(planes_struct(c, w, h)), C.byref(planes_struct(d, w, h)), C.byref(planes_struct(r, w, h)),
                               post.lr.ctypes.data, len(post.lr)) == 0
     g = None
-    if with_grain and util.ref_lib() is not None:
-        from test_filmgrain import _ref
+    if with_grain:
+        from test_filmgrain import fg_driver
         g = synth.copy_planes(r)
         src = synth.copy_planes(r)      # dav1d_apply_grain pads the luma of its input by one pixel (src/fg_apply_tmpl.c:193-199)
         sp = (C.c_void_p * 3)(*[p.ctypes.data for p in src])
         gp = (C.c_void_p * 3)(*[p.ctypes.data for p in g])
-        assert _ref().dav1d_ref_apply_grain(bpc, C.addressof(post.fg), w, h, 1, 0, gp, sp, g[0].strides[0], g[1].strides[0]) == 0
+        assert fg_driver(oracle).apply_grain(bpc, C.addressof(post.fg), w, h, 1, 0, gp, sp, g[0].strides[0], g[1].strides[0]) == 0
     return d, c, r, g
 
 
@@ -116,8 +116,6 @@ def hip_intra(ctx, ip, pic):
 @pytest.mark.parametrize("bpc", [8, 10, 12])
 def test_intra_wavefront_pass_matches_oracle(ctx, bpc):
     oracle = util.default_oracle()
-    if oracle.which != "ref":
-        pytest.skip("edge preparation is borrowed from the reference build (dav1d_prepare_intra_edges)")
     w, h = (256, 192) if ctx.backend == "emu" else (1024, 576)
     frame = synth.make_frame(w, h, bpc, seed=91 + bpc)
     ip = synth.make_intra_pass(frame, seed=17 + bpc)
