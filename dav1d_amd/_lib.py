@@ -24,7 +24,7 @@ class Picture(C.Structure):
 
 # numpy mirrors of the POD task descriptors (include/dav1d_hip.h)
 ITX_TASK = np.dtype([("dst_off", "<u4"), ("cf_off", "<u4"), ("eob", "<i2"), ("tx", "u1"), ("txtp", "u1"),
-                     ("plane", "u1"), ("pad", "u1", (3,))], align=False)
+                     ("plane", "u1"), ("flags", "u1"), ("rsv", "u1", (2,))], align=False)
 MC_TASK = np.dtype([("dst_off", "<u4"), ("src_x", "<i4"), ("src_y", "<i4"), ("w", "u1"), ("h", "u1"),
                     ("mx", "u1"), ("my", "u1"), ("filter_2d", "u1"), ("kind", "u1"), ("plane", "u1"),
                     ("ref", "u1"), ("pad", "<u4")], align=False)

@@ -220,7 +220,7 @@ int dav1d_hip_itx_list_create(Dav1dHipContext *c, Dav1dHipItxList **out, const D
     size_t cnt[19] = { 0 };
     for (size_t i = 0; i < n; i++) {
         const Dav1dHipItxTask &t = tasks[i];
-        if (!itx_legal(t.tx, t.txtp) || t.plane > 2 || t.eob < 0) { delete l; return -EINVAL; }
+        if (!itx_legal(t.tx, t.txtp) || t.plane > 2 || t.eob < 0 || t.flags > DAV1D_HIP_ITX_PACKED) { delete l; return -EINVAL; }
         if (t.eob >= av1_scan_prefix_off[t.tx + 1] - av1_scan_prefix_off[t.tx]) { delete l; return -EINVAL; }
         cnt[t.tx]++;
     }
@@ -239,8 +239,8 @@ int dav1d_hip_itx_list_create(Dav1dHipContext *c, Dav1dHipItxList **out, const D
             int end = ncoef;
             if (t.txtp <= 9 || t.txtp == 16) end = av1_scan_prefix_end[av1_scan_prefix_off[t.tx] + t.eob];
             else if (t.txtp == 11 || t.txtp == 13 || t.txtp == 15) end = t.eob + 1;
-            t.pad[0] = (uint8_t) (end & 255);
-            t.pad[1] = (uint8_t) (end >> 8);
+            t.rsv[0] = (uint8_t) (end & 255);
+            t.rsv[1] = (uint8_t) (end >> 8);
         }
         if (hipMalloc((void **) &l->dev, n * sizeof(Dav1dHipItxTask)) != hipSuccess) { delete l; return -ENOMEM; }
         const int rc = dav1d_hip_upload(c, l->dev, sorted.data(), n * sizeof(Dav1dHipItxTask));

@@ -15,6 +15,7 @@
 // row pass reads it transposed, and the same LDS region then becomes the transpose buffer.
 #include "common.h"
 #include "itx1d.h"
+#include "av1_scan_dev.h"
 
 namespace {
 
@@ -137,7 +138,8 @@ __global__ __launch_bounds__(64) void itx_add_kernel(const DevPlanes dst, const 
         int4 *s4 = reinterpret_cast<int4 *>(tmp);
         // only the part of the slab the scan can have reached (t.pad = prefix length in coefficients, filled in by the
         // host from the eob); the rest is zero in memory by contract and is zero-filled in LDS without being fetched
-        const int nch = (((int) t.pad[0] | ((int) t.pad[1] << 8)) * (int) sizeof(coef) + 15) >> 4;
+        const bool packed = t.flags & DAV1D_HIP_ITX_PACKED;
+        const int nch = packed ? 0 : (((int) t.rsv[0] | ((int) t.rsv[1] << 8)) * (int) sizeof(coef) + 15) >> 4;
         int4 v[(NCH + LPB - 1) / LPB];
 #pragma unroll
         for (int k = 0; k < (NCH + LPB - 1) / LPB; k++) {
@@ -153,8 +155,21 @@ __global__ __launch_bounds__(64) void itx_add_kernel(const DevPlanes dst, const 
             if (l + k * LPB < NCH) s4[l + k * LPB] = v[k];
             if (l + k * LPB < nch) z4[l + k * LPB] = make_int4(0, 0, 0, 0);
         }
+        if (packed) {
+            // sparse wire format: eob + 1 values in decode order are scattered to their slab positions (the slab in LDS was
+            // just zero-filled); positions as decode_coefs derives them (reference src/recon_tmpl.c:458-496, 548-575)
+            dv::wave_sync();
+            coef *const slab = reinterpret_cast<coef *>(tmp);
+            const int cls = (t.txtp == 11 || t.txtp == 13 || t.txtp == 15) ? 1 : (t.txtp == 10 || t.txtp == 12 || t.txtp == 14) ? 2 : 0;
+            const uint16_t *const scan = av1_scans + av1_scan_off[TX];
+            constexpr int LSW = SW == 4 ? 2 : SW == 8 ? 3 : SW == 16 ? 4 : 5;
+            for (int i = l; i <= t.eob; i += LPB) {
+                const int rc = cls == 0 ? (int) scan[i] : cls == 1 ? i : ((i & (SW - 1)) * SH + (i >> LSW));
+                slab[rc] = gcf[i];
+            }
+        }
     } else if (dconly) {
-        if (l == 0) { dc = gcf[0]; gcf[0] = 0; }            // src/itx_tmpl.c:59-60
+        if (l == 0) { dc = gcf[0]; if (!(t.flags & DAV1D_HIP_ITX_PACKED)) gcf[0] = 0; }            // src/itx_tmpl.c:59-60
         if (l < W) {
 #pragma unroll
             for (int y = 0; y < H; y++) dpx[y] = d[y * stride];

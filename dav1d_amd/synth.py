@@ -487,3 +487,32 @@ def make_intra_pass(frame, seed, layout=1):
     p.n_blocks = int(sum(len(a) for a, _ in p.batches))
     p.n_samples = int(sum(int((a["tw"].astype(np.int64) * 4 * a["th"] * 4).sum()) for a, _ in p.batches))
     return p
+
+
+def pack_frame_coefs(frame):
+    """The frame's dense coefficient arena -> the sparse wire format (DAV1D_HIP_ITX_PACKED): per block only the eob + 1
+    values in decode order.  Returns (itx tasks with PACKED set and cf_off into the packed arena, packed arena)."""
+    t = frame.itx.copy()
+    n = len(t)
+    lens = t["eob"].astype(np.int64) + 1
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    packed = np.empty(int(lens.sum()), frame.coef.dtype)
+    txtp = t["txtp"]
+    cls = np.where(np.isin(txtp, (11, 13, 15)), 1, np.where(np.isin(txtp, (10, 12, 14)), 2, 0))
+    for tx in np.unique(t["tx"]):
+        sw, sh = min(TX_W[tx], 32), min(TX_H[tx], 32)
+        nc = sw * sh
+        i = np.arange(nc)
+        order = [scans()[tx], i, (i & (sw - 1)) * sh + (i >> int(np.log2(sw)))]
+        for c in range(3):
+            sel = np.flatnonzero((t["tx"] == tx) & (cls == c))
+            if not len(sel):
+                continue
+            dense = frame.coef[(t["cf_off"][sel].astype(np.int64)[:, None] + order[c][None, :])]       # [blocks, scan position]
+            keep = i[None, :] <= t["eob"][sel].astype(np.int64)[:, None]
+            vals = dense[keep]                                                                        # row-major: block by block
+            dstpos = (offs[sel][:, None] + i[None, :])[keep]
+            packed[dstpos] = vals
+    t["cf_off"] = offs
+    t["flags"] = 1
+    return t, packed

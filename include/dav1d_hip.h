@@ -103,13 +103,22 @@ typedef struct Dav1dHipItxTask {
     uint32_t dst_off;  /* pixel offset of the block's top-left inside its plane: y*(stride/sizeof(pixel)) + x */
     uint32_t cf_off;   /* offset (in coefs) of the block's slab in the coefficient arena;
                           slab = min(w,32)*min(h,32) coefs, column-major coeff[y + x*min(h,32)]
-                          (reference src/itx_tmpl.c:98-105); must be a multiple of 16 bytes */
+                          (reference src/itx_tmpl.c:98-105); must be a multiple of 16 bytes
+                          (PACKED tasks: offset of the first of eob + 1 values, any alignment) */
     int16_t  eob;      /* as passed to itxfm_add (>= 0) */
     uint8_t  tx;       /* enum RectTxfmSize, reference src/levels.h:44-78 (0..18) */
     uint8_t  txtp;     /* enum TxfmType index of the itxfm_add table, reference src/levels.h:80-100 (16 = WHT_WHT) */
     uint8_t  plane;    /* 0..2 */
-    uint8_t  pad[3];
+    uint8_t  flags;    /* DAV1D_HIP_ITX_* */
+    uint8_t  rsv[2];   /* written by the library in its device copy; ignored on input */
 } Dav1dHipItxTask;
+
+/* flags.  PACKED: the block's coefficients are not a dense slab but the eob + 1 values the entropy decoder produced, in
+ * the order it produced them (scan position 0 .. eob: dav1d_scans[tx] for the 2-D transform classes, slab order for the H
+ * classes, column-interleaved for the V classes, reference src/recon_tmpl.c:458-520, 548-575), starting at cf_off of the
+ * arena; the arena is read-only for such tasks (nothing to re-zero).  This is the sparse wire format of SURVEY 8(f)#1:
+ * it shrinks the per-frame host -> device coefficient traffic from the full cf arena to the coefficients that exist. */
+enum { DAV1D_HIP_ITX_PACKED = 1 };
 
 /* Runs `n` tasks (any order, any mix of sizes; dst rectangles must be disjoint).
  * `tasks` is a HOST array (the CPU lister produces it), `coef` a DEVICE pointer to

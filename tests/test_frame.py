@@ -43,7 +43,7 @@ def oracle_frame(oracle, frame, dst_planes, ref_planes_list):
     return dst, prep, coef
 
 
-def hip_frame(ctx, frame, dst_planes, ref_planes_list, fused=False):
+def hip_frame(ctx, frame, dst_planes, ref_planes_list, fused=False, packed=False):
     w, h, bpc = frame.w, frame.h, frame.bpc
     dst = ctx.picture(w, h, api.LAYOUT_I420, bpc)
     for pl in range(3):
@@ -56,7 +56,8 @@ def hip_frame(ctx, frame, dst_planes, ref_planes_list, fused=False):
         refs.append(r)
     prep = ctx.buffer(frame.prep_elems * 2)
     prep.zero()
-    coef = ctx.buffer_from(frame.coef)
+    itx_tasks, coef_host = synth.pack_frame_coefs(frame) if packed else (frame.itx, frame.coef)
+    coef = ctx.buffer_from(coef_host)
     if fused:
         il = ctx.inter_list(frame.mc, frame.comp)
         assert il.n_fused == len(frame.comp)        # the synthetic frames only hold avg compounds
@@ -66,10 +67,13 @@ def hip_frame(ctx, frame, dst_planes, ref_planes_list, fused=False):
         ctx.mc_batch(dst, refs, frame.mc, prep)
         if len(frame.comp):
             ctx.comp_batch(dst, frame.comp, prep, None)
-    ctx.itx_add_batch(dst, frame.itx, coef)
+    ctx.itx_add_batch(dst, itx_tasks, coef)
     out = [dst.download(pl) for pl in range(3)]
     oprep = prep.download(np.int16, frame.prep_elems)
-    ocoef = coef.download(frame.coef.dtype, len(frame.coef))
+    ocoef = coef.download(coef_host.dtype, len(coef_host))
+    if packed:
+        assert np.array_equal(ocoef, coef_host), "a packed arena is read-only"
+        ocoef = np.zeros_like(frame.coef)
     for o in [dst, prep, coef] + refs:
         o.free()
     return out, oprep, ocoef
@@ -92,6 +96,21 @@ def test_frame_itx_mc_matches_oracle(ctx, bpc, fused):
         assert np.array_equal(got_prep, want_prep)
     assert np.array_equal(got_coef, want_coef)
     assert not want_coef.any(), "all consumed coefficient slabs end up zeroed"
+
+
+@pytest.mark.parametrize("bpc", [8, 10])
+def test_frame_from_packed_coefficients(ctx, bpc):
+    """The sparse coefficient wire format (DAV1D_HIP_ITX_PACKED) over a whole frame: same pictures as the dense arena."""
+    oracle = util.default_oracle()
+    w, h = (256, 128) if ctx.backend == "emu" else (1024, 512)
+    frame = synth.make_frame(w, h, bpc, seed=404 + bpc)
+    rng = np.random.default_rng(1)
+    refs = [synth.make_planes(rng, w, h, bpc) for _ in range(frame.n_refs)]
+    dst0 = synth.make_planes(rng, w, h, bpc, smooth=False)
+    want, _, _ = oracle_frame(oracle, frame, dst0, refs)
+    got, _, _ = hip_frame(ctx, frame, dst0, refs, fused=True, packed=True)
+    for pl in range(3):
+        assert np.array_equal(got[pl], want[pl]), pl
 
 
 @pytest.mark.parametrize("mode", ["1", "2"], ids=["all-shapes", "wide-shapes"])

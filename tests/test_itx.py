@@ -37,7 +37,7 @@ def _build_case(rng, bpc, txs, per_type, layout=api.LAYOUT_I400, W=256, H=256):
     return tasks, coefs, blocks, False
 
 
-def _run_case(ctx, oracle, bpc, txs, per_type, seed):
+def _run_case(ctx, oracle, bpc, txs, per_type, seed, packed=False):
     rng = np.random.default_rng(seed)
     W = H = 256
     tasks, coefs, blocks, trunc = _build_case(rng, bpc, txs, per_type, W=W, H=H)
@@ -56,11 +56,23 @@ def _run_case(ctx, oracle, bpc, txs, per_type, seed):
     # ---- backend through the C ABI
     pic = ctx.picture(W, H, api.LAYOUT_I400, bpc)
     pic.upload(0, plane)
-    dcoef = ctx.buffer_from(arena)
     t = np.zeros(len(tasks), api.ITX_TASK)
     sp = pic.stride_px(0)
-    for i, (x, y, cf_off, eob, tx, txtp) in enumerate(tasks):
-        t[i] = (y * sp + x, cf_off, eob, tx, txtp, 0, (0, 0, 0))
+    if packed:
+        # sparse wire format: only the eob + 1 coefficients of every block, in decode order, back to back
+        parts, off = [], 0
+        for i, (x, y, cf_off, eob, tx, txtp) in enumerate(tasks):
+            n = min(util.TX_W[tx], 32) * min(util.TX_H[tx], 32)
+            pk = util.pack_coefs(tx, txtp, arena[cf_off:cf_off + n], eob)
+            t[i] = (y * sp + x, off, eob, tx, txtp, 0, 1, (0, 0))
+            parts.append(pk)
+            off += len(pk)
+        arena = np.concatenate(parts)
+        ref_arena = arena.copy()              # read-only for the backend
+    else:
+        for i, (x, y, cf_off, eob, tx, txtp) in enumerate(tasks):
+            t[i] = (y * sp + x, cf_off, eob, tx, txtp, 0, 0, (0, 0))
+    dcoef = ctx.buffer_from(arena)
     perm = rng.permutation(len(t))            # any order must give the same result
     ctx.itx_add_batch(pic, t[perm], dcoef)
     out = pic.download(0)
@@ -72,7 +84,7 @@ def _run_case(ctx, oracle, bpc, txs, per_type, seed):
         blk = [b for b in zip(tasks, blocks) if b[1][0] <= xx < b[1][0] + b[1][2] and b[1][1] <= yy < b[1][1] + b[1][3]]
         raise AssertionError("pixel mismatch at (%d,%d): got %d want %d; block %s" %
                              (xx, yy, out[yy, xx], ref_plane[yy, xx], blk[:1]))
-    assert np.array_equal(out_arena, ref_arena), "coefficient slabs not zeroed like the reference"
+    assert np.array_equal(out_arena, ref_arena), "coefficient slabs not zeroed like the reference" if not packed else "packed arena modified"
 
 
 @pytest.mark.parametrize("bpc", [8, 10, 12])
@@ -80,3 +92,10 @@ def _run_case(ctx, oracle, bpc, txs, per_type, seed):
 def test_itxfm_add_matches_reference(ctx, bpc, tx):
     per_type = 1 if ctx.backend == "emu" else 2
     _run_case(ctx, util.default_oracle(), bpc, [tx], per_type, seed=1000 + tx * 3 + bpc)
+
+
+@pytest.mark.parametrize("bpc", [8, 10, 12])
+@pytest.mark.parametrize("tx", list(range(19)), ids=util.TX_NAMES)
+def test_itxfm_add_from_packed_coefficients(ctx, bpc, tx):
+    """DAV1D_HIP_ITX_PACKED: the same blocks fed as eob + 1 scan-order values each give the same pixels."""
+    _run_case(ctx, util.default_oracle(), bpc, [tx], 1, seed=5000 + tx * 3 + bpc, packed=True)

@@ -291,6 +291,23 @@ def gen_itx_coefs(rng, tx, txtp, bpc, subsh):
     return buf.astype(coef_dtype(bpc)), eob
 
 
+def pack_coefs(tx, txtp, dense, eob):
+    """Dense slab -> the eob + 1 values in decode order (the DAV1D_HIP_ITX_PACKED wire format): scan position i sits at
+    dav1d_scans[tx][i] for the 2-D classes, at i for the H classes, at (i & (sw-1)) * sh + (i >> log2(sw)) for the V classes
+    (reference src/recon_tmpl.c:458-496, 548-575)."""
+    w, h = TX_W[tx], TX_H[tx]
+    sw, sh = min(w, 32), min(h, 32)
+    i = np.arange(eob + 1)
+    cls = tx_class(txtp)
+    if cls == 0:
+        rc = scans()[tx][i].astype(np.int64)
+    elif cls == 1:
+        rc = i
+    else:
+        rc = (i & (sw - 1)) * sh + (i >> int(np.log2(sw)))
+    return dense[rc].copy()
+
+
 SUBSH_ITERS = [2, 2, 3, 5, 5]
 
 
