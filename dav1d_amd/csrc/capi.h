@@ -100,7 +100,7 @@ struct McRef {
 };
 struct McTile {
     uint32_t dst_off;     // of the TASK: pixel offset in the dst plane; PREP: int16 offset in the prep arena
-    uint8_t  w, h;        // tile size, <= 16
+    uint8_t  w, h;        // tile size, <= 64 x 16
     uint8_t  kind, plane;
     uint8_t  bw;          // task width = row stride of a PREP block
     uint8_t  ox, oy;      // tile origin inside the task's block

@@ -363,7 +363,7 @@ static McRef mc_ref_of(const Dav1dHipMcTask &t) {
     return r;
 }
 
-// cut one prediction block (or a fused pair) into <= 16x16 tiles and bin them by tile shape
+// cut one prediction block (or a fused pair) into <= 64x16 tiles and bin them by tile shape
 static void push_tiles(std::vector<McTile> *bins, const Dav1dHipMcTask &t, int kind, uint32_t dst_off,
                        const Dav1dHipMcTask *second, int weight) {
     McTile m;

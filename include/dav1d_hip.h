@@ -5,13 +5,16 @@
  * Dav1dDSPContext function tables (reference src/internal.h:62-70) and the
  * pass-2 reconstruction hand-off (reference src/internal.h:276-293).
  *
- * Two levels are exported, both plain C (pointers + sizes, no C++/torch types):
+ * Three levels are exported, all plain C (pointers + sizes, no C++/torch types):
  *
- *   1. Batched entry points (dav1d_hip_*_batch): one call = one kernel family
+ *   1. Batched entry points (dav1d_hip_*_batch, *_list_*): one call = one kernel family
  *      over a flat list of POD task descriptors, all buffers device-resident.
  *      This is what a pass-2 "lister" inside dav1d submits per tile-sbrow / frame.
  *
- *   2. A kernel-level drop-in table (Dav1dHipDSPContext, dav1d_hip_dsp_init_*):
+ *   2. One frame in flight (dav1d_hip_frame_*): the driver-level boundary -- tasks appended
+ *      per tile-sbrow from any worker thread, one call runs the frame's stages in order.
+ *
+ *   3. A kernel-level drop-in table (Dav1dHipDSPContext, dav1d_hip_dsp_init_*):
  *      function pointers with the reference's exact DSP signatures that stage
  *      host memory through the same kernels one call at a time.  It exists so the
  *      unmodified reference call sites / parity tests can run against the backend;
@@ -176,7 +179,7 @@ DAV1D_HIP_API int dav1d_hip_mc_batch(Dav1dHipContext *c, const Dav1dHipPicture *
                                      const Dav1dHipPicture *refs, int n_refs,
                                      const Dav1dHipMcTask *tasks, size_t n, int16_t *prep);
 
-/* Pre-tiled, device-resident list: blocks are cut into <= 16x16 tiles and binned by
+/* Pre-tiled, device-resident list: blocks are cut into <= 64x16 tiles and binned by
  * tile shape once; run many times. */
 typedef struct Dav1dHipMcList Dav1dHipMcList;
 DAV1D_HIP_API int dav1d_hip_mc_list_create(Dav1dHipContext *c, Dav1dHipMcList **out,
