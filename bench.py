@@ -281,7 +281,7 @@ def main():
             rec = ctx.picture(w, h, api.LAYOUT_I420, bpc)
             for pl in range(3):
                 rec.upload(pl, got[pl])
-            ms_pred, ms_res = test_postchain.hip_intra(ctx, intra, rec)
+            ms_intra = test_postchain.hip_intra(ctx, intra, rec, timed=True)
             got = [rec.download(pl) for pl in range(3)]
             rec.free()
             intra_ok = None
@@ -299,7 +299,7 @@ def main():
             for pl in range(3):
                 dbl.upload(pl, got[pl])
             lvl = ctx.buffer_from(post.lvl)
-            stage_ms = {"intra_pred": ms_pred, "intra_residual": ms_res}
+            stage_ms = {"intra_waves": ms_intra}
             for rep in range(2):            # second pass = warm clocks; deblocking is in place, so re-seed its input
                 for pl in range(3):
                     dbl.upload(pl, got[pl])

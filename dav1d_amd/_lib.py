@@ -68,6 +68,7 @@ SYMBOLS = [
     "dav1d_hip_cdef_batch", "dav1d_hip_lf_batch", "dav1d_hip_ipred_batch", "dav1d_hip_lr_batch",
     "dav1d_hip_fg_apply", "dav1d_hip_fg_generate_grain",
     "dav1d_hip_warp_batch", "dav1d_hip_mc_scaled_batch", "dav1d_hip_resize", "dav1d_hip_emu_edge",
+    "dav1d_hip_ipred_list_create", "dav1d_hip_ipred_list_run_batch", "dav1d_hip_ipred_list_destroy",
     "dav1d_hip_frame_begin", "dav1d_hip_frame_submit_tile_sbrow", "dav1d_hip_frame_submit_filter_sbrow",
     "dav1d_hip_frame_set_filters", "dav1d_hip_frame_end", "dav1d_hip_frame_destroy",
 ]
@@ -141,6 +142,9 @@ def load(path=None):
         "dav1d_hip_resize": (i, [vp, P(Picture), P(Picture), i, i, i, i, i, i, i]),
         "dav1d_hip_emu_edge": (i, [vp, i, C.c_ssize_t, C.c_ssize_t, C.c_ssize_t, C.c_ssize_t, C.c_ssize_t, C.c_ssize_t, vp,
                                    C.c_ssize_t, vp, C.c_ssize_t]),
+        "dav1d_hip_ipred_list_create": (i, [vp, P(vp), vp, vp, sz]),
+        "dav1d_hip_ipred_list_run_batch": (i, [vp, vp, sz, P(Picture), vp]),
+        "dav1d_hip_ipred_list_destroy": (None, [vp, vp]),
         "dav1d_hip_frame_begin": (i, [vp, P(vp), P(Picture), P(Picture), i]),
         "dav1d_hip_frame_submit_tile_sbrow": (i, [vp, vp, sz, vp, sz, vp, sz]),
         "dav1d_hip_frame_submit_filter_sbrow": (i, [vp, vp, sz, vp, sz, vp, sz]),

@@ -244,6 +244,9 @@ class Context:
     def frame(self, cur, refs):
         return FrameInFlight(self, cur, refs)
 
+    def ipred_list(self, batches):
+        return _IpredList(self, batches)
+
     # ---- device-resident lists
     def itx_list(self, tasks):
         return _List(self, "itx", tasks, ITX_TASK)
@@ -276,6 +279,26 @@ class Context:
         p = prep.ptr if hasattr(prep, "ptr") else prep
         m = None if mask is None else (mask.ptr if hasattr(mask, "ptr") else mask)
         _chk(self.lib.dav1d_hip_comp_list_run(self.h, lst.h, C.byref(dst.pic), p, m), "comp_list_run")
+
+
+class _IpredList:
+    """dav1d_hip_ipred_list_*: the intra batches of a wavefront, device resident."""
+
+    def __init__(self, ctx, batches):
+        self.ctx = ctx
+        self.n_batches = len(batches)
+        sizes = (C.c_size_t * max(len(batches), 1))(*[len(b) for b in batches])
+        allt = np.ascontiguousarray(np.concatenate(batches) if len(batches) else np.zeros(0, IPRED_TASK), dtype=IPRED_TASK)
+        self.h = C.c_void_p()
+        _chk(ctx.lib.dav1d_hip_ipred_list_create(ctx.h, C.byref(self.h), allt.ctypes.data, sizes, len(batches)), "ipred_list_create")
+
+    def run_batch(self, k, dst, aux=None):
+        _chk(self.ctx.lib.dav1d_hip_ipred_list_run_batch(self.ctx.h, self.h, k, C.byref(dst.pic), aux.ptr if aux else None), "ipred_list_run_batch")
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.dav1d_hip_ipred_list_destroy(self.ctx.h, self.h)
+            self.h = C.c_void_p()
 
 
 class FrameInFlight:

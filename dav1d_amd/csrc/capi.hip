@@ -769,18 +769,23 @@ extern "C" int dav1d_hip_lf_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst
 
 // -------------------------------------------------------------------- ipred
 
-extern "C" int dav1d_hip_ipred_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipIpredTask *tasks, size_t n,
-                                     uint8_t *pal_idx) {
-    if (!dst || (!tasks && n)) return -EINVAL;
-    if (!n) return 0;
+static int ipred_tasks_valid(const Dav1dHipIpredTask *tasks, size_t n, const uint8_t *aux) {
     for (size_t i = 0; i < n; i++) {
         const Dav1dHipIpredTask &t = tasks[i];
         if (t.plane > 2 || t.kind > DAV1D_HIP_IPRED_DSP_CFL_PRED || t.mode > 13 || !t.tw || !t.th || t.tw > 16 || t.th > 16) return -EINVAL;
-        if (t.kind >= DAV1D_HIP_IPRED_PAL && !pal_idx) return -EINVAL;
+        if (t.kind >= DAV1D_HIP_IPRED_PAL && !aux) return -EINVAL;
         const bool cfl = t.kind == DAV1D_HIP_IPRED_CFL || t.kind >= DAV1D_HIP_IPRED_DSP_CFL_AC;
         if ((cfl || (t.kind != DAV1D_HIP_IPRED_PAL && t.mode == 13)) && (t.tw > 8 || t.th > 8)) return -EINVAL;   // both are limited to 32x32
         if (t.kind == DAV1D_HIP_IPRED_DSP_CFL_PRED && t.mode != 0 && (t.mode < 3 || t.mode > 5)) return -EINVAL;
     }
+    return 0;
+}
+
+extern "C" int dav1d_hip_ipred_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipIpredTask *tasks, size_t n,
+                                     uint8_t *pal_idx) {
+    if (!dst || (!tasks && n)) return -EINVAL;
+    if (!n) return 0;
+    if (ipred_tasks_valid(tasks, n, pal_idx)) return -EINVAL;
     Dav1dHipIpredTask *dev = nullptr;
     if (hipMalloc((void **) &dev, n * sizeof(*dev)) != hipSuccess) return -ENOMEM;
     int rc = dav1d_hip_upload(c, dev, tasks, n * sizeof(*dev));
@@ -791,6 +796,56 @@ extern "C" int dav1d_hip_ipred_batch(Dav1dHipContext *c, const Dav1dHipPicture *
     hipStreamSynchronize(c->stream);
     hipFree(dev);
     return rc;
+}
+
+// Device-resident wavefront: the batches of an intra frame (or of the intra blocks of an inter frame) uploaded once; batch k
+// = tasks [start[k], start[k + 1]).  run_batch() only enqueues the launch, so a caller can interleave the residual lists of
+// every wave on the same stream without a host round trip per wave.
+struct Dav1dHipIpredList {
+    Dav1dHipIpredTask *dev;
+    std::vector<size_t> start;
+    bool needs_aux;
+};
+
+extern "C" int dav1d_hip_ipred_list_create(Dav1dHipContext *c, Dav1dHipIpredList **out, const Dav1dHipIpredTask *tasks,
+                                           const size_t *batch_sizes, size_t n_batches) {
+    if (!out || !batch_sizes) return -EINVAL;
+    *out = nullptr;
+    size_t n = 0;
+    for (size_t k = 0; k < n_batches; k++) n += batch_sizes[k];
+    if (n && !tasks) return -EINVAL;
+    uint8_t dummy = 0;
+    if (ipred_tasks_valid(tasks, n, &dummy)) return -EINVAL;
+    Dav1dHipIpredList *l = new (std::nothrow) Dav1dHipIpredList();
+    if (!l) return -ENOMEM;
+    l->dev = nullptr;
+    l->needs_aux = false;
+    for (size_t i = 0; i < n; i++) if (tasks[i].kind >= DAV1D_HIP_IPRED_PAL) l->needs_aux = true;
+    l->start.push_back(0);
+    for (size_t k = 0; k < n_batches; k++) l->start.push_back(l->start.back() + batch_sizes[k]);
+    if (n) {
+        if (hipMalloc((void **) &l->dev, n * sizeof(Dav1dHipIpredTask)) != hipSuccess) { delete l; return -ENOMEM; }
+        const int rc = dav1d_hip_upload(c, l->dev, tasks, n * sizeof(Dav1dHipIpredTask));
+        if (rc) { hipFree(l->dev); delete l; return rc; }
+    }
+    *out = l;
+    return 0;
+}
+
+extern "C" int dav1d_hip_ipred_list_run_batch(Dav1dHipContext *c, const Dav1dHipIpredList *l, size_t batch, const Dav1dHipPicture *dst,
+                                              uint8_t *aux) {
+    if (!l || !dst || batch + 1 >= l->start.size() || (l->needs_aux && !aux)) return -EINVAL;
+    const size_t n = l->start[batch + 1] - l->start[batch];
+    if (!n) return 0;
+    const DevPlanes dp = dev_planes(dst);
+    return dav1d_hip_launch_ipred(&dp, dst->bpc, dst->layout, l->dev + l->start[batch], (int) n, aux, c->stream);
+}
+
+extern "C" void dav1d_hip_ipred_list_destroy(Dav1dHipContext *c, Dav1dHipIpredList *l) {
+    if (!l) return;
+    hipStreamSynchronize(c->stream);
+    if (l->dev) hipFree(l->dev);
+    delete l;
 }
 
 // ------------------------------------------------- mc: warp, scaled, resize, emu_edge

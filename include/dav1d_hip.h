@@ -294,6 +294,16 @@ typedef struct Dav1dHipIpredTask {
 DAV1D_HIP_API int dav1d_hip_ipred_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipIpredTask *tasks, size_t n,
                                         uint8_t *aux);
 
+/* Device-resident wavefront of intra batches: uploaded once, batch k = the next batch_sizes[k] tasks of `tasks`.
+ * run_batch() only enqueues the kernel on the context's stream (no host synchronisation), so the residual lists
+ * (dav1d_hip_itx_list_run) of every wave can be interleaved on the same stream without a host round trip per wave. */
+typedef struct Dav1dHipIpredList Dav1dHipIpredList;
+DAV1D_HIP_API int dav1d_hip_ipred_list_create(Dav1dHipContext *c, Dav1dHipIpredList **out, const Dav1dHipIpredTask *tasks,
+                                              const size_t *batch_sizes, size_t n_batches);
+DAV1D_HIP_API int dav1d_hip_ipred_list_run_batch(Dav1dHipContext *c, const Dav1dHipIpredList *l, size_t batch,
+                                                 const Dav1dHipPicture *dst, uint8_t *aux);
+DAV1D_HIP_API void dav1d_hip_ipred_list_destroy(Dav1dHipContext *c, Dav1dHipIpredList *l);
+
 /* ------------------------------------------------- mc: warp, scaled, resize, emu_edge */
 
 /* One 8x8 block of a warped prediction: dsp->mc.warp8x8 (kind PUT, pixels into dst) or warp8x8t (kind PREP, int16

@@ -98,19 +98,38 @@ def oracle_intra(oracle, ip, planes, w, h, bpc):
     return coef
 
 
-def hip_intra(ctx, ip, pic):
-    """Returns (kernel ms of the predictions, kernel ms of the residuals)."""
+def hip_intra(ctx, ip, pic, timed=False):
+    """Runs the intra pass from device-resident lists, every wave enqueued back to back on the context's stream
+    (prediction of wave k, residuals of wave k, prediction of wave k + 1, ...), no host round trip in between.
+    timed (bench.py only; needs torch for the events): returns the device time of the whole pass in ms, else 0."""
+    import ctypes as C
     coef = ctx.buffer_from(ip.coef)
-    ms_pred = ms_itx = 0.0
-    for pred, itx in ip.batches:
-        ctx.ipred_batch(pic, pred)
-        ms_pred += ctx.last_kernel_ms()
-        ctx.itx_add_batch(pic, itx, coef)
-        ms_itx += ctx.last_kernel_ms()
+    plist = ctx.ipred_list([b[0] for b in ip.batches])
+    ilists = [ctx.itx_list(b[1]) for b in ip.batches]
+    lib = ctx.lib
+    lib.dav1d_hip_sync(ctx.h)
+    ev = None
+    if timed:
+        import torch
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        stream = torch.cuda.ExternalStream(lib.dav1d_hip_stream(ctx.h))
+        ev[0].record(stream)
+    for k in range(len(ip.batches)):
+        plist.run_batch(k, pic)
+        ctx.run_itx_list(ilists[k], pic, coef)
+    ms = 0.0
+    if ev:
+        ev[1].record(stream)
+        lib.dav1d_hip_sync(ctx.h)
+        ms = ev[0].elapsed_time(ev[1])
+    lib.dav1d_hip_sync(ctx.h)
     left = coef.download(ip.coef.dtype, len(ip.coef))
+    plist.destroy()
+    for l in ilists:
+        l.destroy()
     coef.free()
     assert not left.any(), "every coefficient slab must come back zeroed"
-    return ms_pred, ms_itx
+    return ms
 
 
 @pytest.mark.parametrize("bpc", [8, 10, 12])
