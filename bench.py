@@ -249,9 +249,9 @@ def main():
             reps, t_cpu = 0, 0.0
             want = None
             while True:
-                t1 = time.perf_counter()
-                want = test_frame.oracle_frame(oracle, frame, dst_host, ref_host)
-                t_cpu += time.perf_counter() - t1
+                tm = {}
+                want = test_frame.oracle_frame(oracle, frame, dst_host, ref_host, timing=tm)
+                t_cpu += tm["seconds"]
                 reps += 1
                 if a.no_cpu or t_cpu >= a.cpu_seconds or reps >= 8:
                     break
@@ -267,6 +267,23 @@ def main():
                    "sample": "%d full %dx%d frame(s) of the same task lists through the oracle's C DSP entries, "
                              "1 thread, %.1f s" % (reps, w, h, t_cpu),
                    "host_cores_available": os.cpu_count()}
+            if not a.no_cpu:
+                # the same replay spread over the host's cores; bounded like the 1-thread leg
+                nthr = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+                if nthr > 1:
+                    reps_mt, t_mt, same = 0, 0.0, True
+                    while t_mt < a.cpu_seconds / 4 and reps_mt < 16:
+                        tm = {}
+                        w_mt = test_frame.oracle_frame(oracle, frame, dst_host, ref_host, threads=nthr, timing=tm)
+                        t_mt += tm["seconds"]
+                        nthr = tm["threads"]
+                        reps_mt += 1
+                        if reps_mt == 1:
+                            same = all(np.array_equal(w_mt[0][pl], want[0][pl]) for pl in range(3))
+                    cpu["all_cores"] = {"value": round(frame.luma_pixels * reps_mt / t_mt / 1e6, 2), "unit": "Mpixels/s", "cores": nthr,
+                                        "sample": "%d frame(s), %d threads over the task lists (barrier between mc / compound / itx), %.1f s inside the replay"
+                                                  % (reps_mt, nthr, t_mt),
+                                        "equals_one_thread": bool(same)}
         # ---- full DSP table on the same frame (BASELINE configs[2]): recon above + deblock + CDEF + restoration + grain,
         # one frame, kernel time per stage from HIP events, every stage checked against the oracle's replay
         full = None

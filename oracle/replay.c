@@ -271,3 +271,71 @@ int dav1d_replay_lr(entry_fn entry, int bpc, const ReplayPlanes *src, const Repl
     free(rows);
     return 0;
 }
+
+/* ---- the same three lists over several host threads: the "all host cores" leg of bench.py's cpu_baseline
+ * (SURVEY.md 8d).  Phases run in the order of the single-thread replay (mc, compound, itx) with a barrier in between;
+ * inside a phase the threads pull chunks of consecutive tasks from a shared counter.  That is only valid when the tasks
+ * of one phase write disjoint rectangles (true for the synthetic inter frames: no mask / blend records) — the way
+ * dav1d's own workers run tile-sbrows of one pass concurrently (reference src/thread_task.c:733-851). */
+#include <pthread.h>
+#include <sched.h>
+
+typedef struct ReplayMt {
+    entry_fn entry; int bpc;
+    const ReplayPlanes *dst, *refs;
+    const Dav1dHipMcTask *mc; size_t n_mc;
+    const Dav1dHipCompTask *comp; size_t n_comp;
+    const Dav1dHipItxTask *itx; size_t n_itx;
+    int16_t *prep; void *coef;
+    size_t next[3];
+    int rc;
+    int n_thr;          /* threads that really run; published before `go` */
+    int go;
+    int arrived[3];     /* one counter per phase barrier */
+} ReplayMt;
+
+enum { REPLAY_CHUNK = 64 };
+
+static void *replay_worker(void *arg)
+{
+    ReplayMt *const m = arg;
+    const size_t n[3] = { m->n_mc, m->n_comp, m->n_itx };
+    uint8_t mask[16] = { 0 };
+    while (!__atomic_load_n(&m->go, __ATOMIC_ACQUIRE)) sched_yield();
+    const int n_thr = m->n_thr;
+    for (int ph = 0; ph < 3; ph++) {
+        for (;;) {
+            const size_t lo = __atomic_fetch_add(&m->next[ph], (size_t) REPLAY_CHUNK, __ATOMIC_RELAXED);
+            if (lo >= n[ph]) break;
+            const size_t cnt = n[ph] - lo < REPLAY_CHUNK ? n[ph] - lo : REPLAY_CHUNK;
+            int rc = ph == 0 ? dav1d_replay_mc(m->entry, m->bpc, m->dst, m->refs, m->mc + lo, cnt, m->prep)
+                   : ph == 1 ? dav1d_replay_comp(m->entry, m->bpc, m->dst, m->comp + lo, cnt, m->prep, mask)
+                             : dav1d_replay_itx(m->entry, m->bpc, m->dst, m->itx + lo, cnt, m->coef);
+            if (rc) __atomic_store_n(&m->rc, rc, __ATOMIC_RELAXED);
+        }
+        __atomic_fetch_add(&m->arrived[ph], 1, __ATOMIC_ACQ_REL);
+        while (__atomic_load_n(&m->arrived[ph], __ATOMIC_ACQUIRE) < n_thr) sched_yield();
+    }
+    return NULL;
+}
+
+int dav1d_replay_recon_mt(entry_fn entry, int bpc, const ReplayPlanes *dst, const ReplayPlanes *refs,
+                          const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
+                          const Dav1dHipItxTask *itx, size_t n_itx, int16_t *prep, void *coef, int n_threads)
+{
+    enum { MAX_THR = 1024 };
+    if (n_threads < 1 || n_threads > MAX_THR) return -22;
+    for (size_t i = 0; i < n_comp; i++)
+        if (comp[i].kind >= DAV1D_HIP_COMP_MASK) return -22;        /* mask outputs / blends are order dependent */
+    if (!entry(bpc, "mc", 0, 0)) return -1;                          /* the oracle fills its tables on the first call: do that here */
+    ReplayMt m = { entry, bpc, dst, refs, mc, n_mc, comp, n_comp, itx, n_itx, prep, coef, { 0, 0, 0 }, 0, 0, 0, { 0, 0, 0 } };
+    pthread_t th[MAX_THR];
+    int started = 0;
+    for (; started < n_threads - 1; started++)
+        if (pthread_create(&th[started], NULL, replay_worker, &m)) break;
+    m.n_thr = started + 1;                /* fewer than asked for if the host refused some */
+    __atomic_store_n(&m.go, 1, __ATOMIC_RELEASE);
+    replay_worker(&m);
+    for (int k = 0; k < started; k++) pthread_join(th[k], NULL);
+    return m.rc ? m.rc : m.n_thr;         /* > 0: the number of threads that ran */
+}

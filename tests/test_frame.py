@@ -25,8 +25,11 @@ def planes_struct(planes, w, h):
     return rp
 
 
-def oracle_frame(oracle, frame, dst_planes, ref_planes_list):
-    """Replays the frame on the host; returns (planes, prep, coef) after reconstruction."""
+def oracle_frame(oracle, frame, dst_planes, ref_planes_list, threads=1, timing=None):
+    """Replays the frame on the host; returns (planes, prep, coef) after reconstruction.  threads > 1: the phases of the
+    replay spread over host threads (oracle/replay.c dav1d_replay_recon_mt; avg / w_avg compounds only).  timing: dict that receives
+    the seconds spent inside the replay calls proper (without this harness's copies of the inputs)."""
+    import time
     rl = util.replay_lib()
     entry = C.cast(oracle._entry, C.c_void_p)
     w, h, bpc = frame.w, frame.h, frame.bpc
@@ -36,10 +39,22 @@ def oracle_frame(oracle, frame, dst_planes, ref_planes_list):
     prep = np.zeros(frame.prep_elems, np.int16)
     coef = frame.coef.copy()
     mask = np.zeros(16, np.uint8)
+    t0 = time.perf_counter()
+    if threads > 1:
+        rc = rl.dav1d_replay_recon_mt(entry, bpc, C.byref(drp), refs, frame.mc.ctypes.data, len(frame.mc), frame.comp.ctypes.data,
+                                      len(frame.comp), frame.itx.ctypes.data, len(frame.itx), prep.ctypes.data, coef.ctypes.data, threads)
+        assert rc > 0, rc
+        if timing is not None:
+            timing["seconds"] = time.perf_counter() - t0
+            timing["threads"] = rc
+        return dst, prep, coef
     assert rl.dav1d_replay_mc(entry, bpc, C.byref(drp), refs, frame.mc.ctypes.data, len(frame.mc), prep.ctypes.data) == 0
     assert rl.dav1d_replay_comp(entry, bpc, C.byref(drp), frame.comp.ctypes.data, len(frame.comp),
                                 prep.ctypes.data, mask.ctypes.data) == 0
     assert rl.dav1d_replay_itx(entry, bpc, C.byref(drp), frame.itx.ctypes.data, len(frame.itx), coef.ctypes.data) == 0
+    if timing is not None:
+        timing["seconds"] = time.perf_counter() - t0
+        timing["threads"] = 1
     return dst, prep, coef
 
 
@@ -96,6 +111,20 @@ def test_frame_itx_mc_matches_oracle(ctx, bpc, fused):
         assert np.array_equal(got_prep, want_prep)
     assert np.array_equal(got_coef, want_coef)
     assert not want_coef.any(), "all consumed coefficient slabs end up zeroed"
+
+
+def test_threaded_replay_equals_serial_replay():
+    """The all-cores leg of the CPU baseline must produce the pictures of the one-thread replay."""
+    oracle = util.default_oracle()
+    frame = synth.make_frame(512, 256, 10, seed=77)
+    rng = np.random.default_rng(5)
+    refs = [synth.make_planes(rng, 512, 256, 10) for _ in range(frame.n_refs)]
+    dst0 = synth.make_planes(rng, 512, 256, 10, smooth=False)
+    one = oracle_frame(oracle, frame, dst0, refs)
+    many = oracle_frame(oracle, frame, dst0, refs, threads=4)
+    for pl in range(3):
+        assert np.array_equal(one[0][pl], many[0][pl]), pl
+    assert np.array_equal(one[1], many[1]) and np.array_equal(one[2], many[2])
 
 
 @pytest.mark.parametrize("bpc", [8, 10])

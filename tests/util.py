@@ -328,6 +328,9 @@ def replay_lib():
     lib.dav1d_replay_itx.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.dav1d_replay_mc.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.dav1d_replay_comp.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.dav1d_replay_recon_mt.restype = C.c_int
+    lib.dav1d_replay_recon_mt.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                          C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
     for n in ("dav1d_replay_lf", "dav1d_replay_cdef", "dav1d_replay_lr"):
         getattr(lib, n).restype = C.c_int
     lib.dav1d_replay_lf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_ssize_t, C.c_void_p]
