@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--packed", action="store_true", help="feed the residuals in the sparse wire format (DAV1D_HIP_ITX_PACKED)")
     ap.add_argument("--no-full", action="store_true", help="skip the full-DSP-table leg (deblock, CDEF, restoration, film grain)")
+    ap.add_argument("--shard", choices=["frames", "tile-cols"], default="frames",
+                    help="N > 1: frames = one independent frame stream per GPU (weak scaling, no data-path collective); "
+                         "tile-cols = GPU g reconstructs tile column g of the SAME frame and one all-gather per frame rebuilds "
+                         "the picture everywhere (SURVEY 8e config C3, strong scaling)")
     return ap.parse_args()
 
 
@@ -102,9 +106,11 @@ def main():
     ctx = api.Context(local, stream=stream.cuda_stream)
     w, h, bpc = a.width, a.height, a.bpc
     t_gen = time.time()
-    frame = synth.make_frame(w, h, bpc, seed=0xDA71D002 + rank, mv_range_px=a.mv_range, edge_frac=a.edge_frac,
+    tile_cols = a.shard == "tile-cols"
+    srank = 0 if tile_cols else rank          # tile-column mode: every rank holds the same frame
+    frame = synth.make_frame(w, h, bpc, seed=0xDA71D002 + srank, mv_range_px=a.mv_range, edge_frac=a.edge_frac,
                              n_refs=int(os.environ.get("BENCH_N_REFS", "3")))
-    rng = np.random.default_rng(1234 + rank)
+    rng = np.random.default_rng(1234 + srank)
     ref_host = [synth.make_planes(rng, w, h, bpc) for _ in range(frame.n_refs)]
     dst_host = synth.make_planes(rng, w, h, bpc, smooth=False)
     t_gen = time.time() - t_gen
@@ -118,11 +124,20 @@ def main():
         refs.append(r)
     NDST = 4
     dsts = []
+    cols = dd.tile_columns(w, world) if tile_cols else None
     for _ in range(NDST):
-        d = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+        # tile-column mode: torch owns the picture memory so that RCCL can move the column strips
+        d = dd.SharedPicture(ctx, w, h, api.LAYOUT_I420, bpc, "cuda") if tile_cols else ctx.picture(w, h, api.LAYOUT_I420, bpc)
         for pl in range(3):
             d.upload(pl, dst_host[pl])
         dsts.append(d)
+    whole = frame
+    if tile_cols:
+        import copy
+        mine = dd.tasks_by_column(frame.mc, frame.comp, frame.itx, [dsts[0].view.stride_px(pl) for pl in range(3)], cols)[rank]
+        frame = copy.copy(whole)               # this rank's share of the lists; arenas and offsets stay the frame's
+        frame.mc, frame.comp, frame.itx = whole.mc[mine[0]], whole.comp[mine[1]], whole.itx[mine[2]]
+        frame.n_samples = int((np.asarray(synth.TX_W, np.int64)[frame.itx["tx"]] * np.asarray(synth.TX_H, np.int64)[frame.itx["tx"]]).sum())
     itx_tasks, coef_host = synth.pack_frame_coefs(frame) if a.packed else (frame.itx, frame.coef)
     inter_list, itx_list = ctx.inter_list(frame.mc, frame.comp), ctx.itx_list(itx_tasks)
     prep = torch.zeros(frame.prep_elems, dtype=torch.int16, device="cuda")
@@ -155,6 +170,8 @@ def main():
         d = dsts[i % NDST]
         ctx.run_inter_list(inter_list, d, refs, prep.data_ptr())
         ctx.run_itx_list(itx_list, d, arenas[i].data_ptr())
+        if tile_cols:
+            dd.allgather_tile_columns(d, cols, rank, world)
 
     # ---- parity gate on this very workload: frame `warmup-0` output vs the oracle replay (bounded: luma rows)
     check = "skipped"
@@ -176,7 +193,8 @@ def main():
     dt = dd.max_over_ranks(dt, world, device="cuda")
 
     ms_per_step = dt / a.steps * 1e3
-    value = dd.job_throughput(frame.luma_pixels, a.steps, dt, world) / 1e6      # luma Mpixels/s, whole job
+    # whole-job luma Mpixels/s: N frames per step (one per GPU) when sharded by frame, ONE frame per step over tile columns
+    value = (whole.luma_pixels * a.steps / dt if tile_cols else dd.job_throughput(frame.luma_pixels, a.steps, dt, world)) / 1e6
 
     out = None
     if rank == 0:
@@ -250,7 +268,7 @@ def main():
             want = None
             while True:
                 tm = {}
-                want = test_frame.oracle_frame(oracle, frame, dst_host, ref_host, timing=tm)
+                want = test_frame.oracle_frame(oracle, whole, dst_host, ref_host, timing=tm)
                 t_cpu += tm["seconds"]
                 reps += 1
                 if a.no_cpu or t_cpu >= a.cpu_seconds or reps >= 8:
@@ -274,7 +292,7 @@ def main():
                     reps_mt, t_mt, same = 0, 0.0, True
                     while t_mt < a.cpu_seconds / 4 and reps_mt < 16:
                         tm = {}
-                        w_mt = test_frame.oracle_frame(oracle, frame, dst_host, ref_host, threads=nthr, timing=tm)
+                        w_mt = test_frame.oracle_frame(oracle, whole, dst_host, ref_host, threads=nthr, timing=tm)
                         t_mt += tm["seconds"]
                         nthr = tm["threads"]
                         reps_mt += 1
@@ -287,7 +305,7 @@ def main():
         # ---- full DSP table on the same frame (BASELINE configs[2]): recon above + deblock + CDEF + restoration + grain,
         # one frame, kernel time per stage from HIP events, every stage checked against the oracle's replay
         full = None
-        if not a.no_full:
+        if not a.no_full and not tile_cols:      # the post filters cross tile edges: their halo exchange is a later row
             import test_postchain
             post = synth.make_post_filters(frame, seed=0xF11 + rank)
             intra = synth.make_intra_pass(frame, seed=0x1A7 + rank)
@@ -361,12 +379,12 @@ def main():
         label = "8K" if (w, h) == (7680, 4320) else "4K" if (w, h) == (3840, 2160) else "%dx%d" % (w, h)
         out = {"metric": "reconstructed luma Mpixels/s (%s 4:2:0 %d-bit) on the itx+mc recon path; bit-exact vs C" % (label, bpc),
                "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if tile_cols else "weak", "vs_baseline": None,
                "dtype": "int32" if bpc > 8 else "int16", "data": "synthetic",
                "config": {"workload": "%dx%d 4:2:0 %d-bit inter frame, itx+mc recon (SURVEY §8d C2 mix 64/32/16/8/4 = "
                                       "20/30/30/15/5 %% by area, 25 %% compound avg, all blocks coded, 3 refs); "
                                       "lists resident in HBM" % (w, h, bpc),
-                          "frames_per_step": 1, "parallelism": "frame-parallel x%d" % world,
+                          "frames_per_step": 1, "parallelism": ("tile-columns x%d + one all-gather per frame" if tile_cols else "frame-parallel x%d") % world,
                           "tasks": {"mc": int(len(frame.mc)), "comp": int(len(frame.comp)), "itx": int(len(frame.itx))},
                           "coef_format": "packed: eob + 1 scan-order values per block" if a.packed else "dense cf arena (reference layout)",
                           "coef_bytes_per_frame": int(coef_host.nbytes), "coef_h2d_ms_per_frame": h2d_ms,

@@ -36,3 +36,105 @@ def test_frame_parallel_world2_gloo(tmp_path):
     d = json.loads(line)
     assert d["t"] == 2.0 and d["v"] == 2 * 100.0 * 4 / 2.0
     assert d["frames"] == [[0, 2, 4, 6, 8], [1, 3, 5, 7]]
+
+
+TILE_COL_WORKER = """
+import sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import numpy as np
+import torch, torch.distributed as dist
+import util, test_frame
+from dav1d_amd import api, synth, dist as dd
+
+rank, local, world = dd.env()
+dist.init_process_group("gloo")
+W, H, BPC = 512, 128, 10
+ctx = util.make_context("emu")
+cols = dd.tile_columns(W, world)
+rng = np.random.default_rng(11)
+ref_host = [synth.make_planes(rng, W, H, BPC) for _ in range(3)]
+dst0 = synth.make_planes(rng, W, H, BPC, smooth=False)
+frames = [synth.make_frame(W, H, BPC, seed=900 + n, mv_range_px=48) for n in range(2)]
+
+# every rank holds all references; the picture being reconstructed becomes reference 0 of the next frame
+refs = []
+for r in ref_host:
+    p = dd.SharedPicture(ctx, W, H, api.LAYOUT_I420, BPC, "cpu")
+    for pl in range(3):
+        p.upload(pl, r[pl])
+    refs.append(p)
+prev = None
+for n, frame in enumerate(frames):
+    cur = dd.SharedPicture(ctx, W, H, api.LAYOUT_I420, BPC, "cpu")
+    for pl in range(3):
+        cur.upload(pl, dst0[pl])
+    stride_px = [cur.view.stride_px(pl) for pl in range(3)]
+    mine = dd.tasks_by_column(frame.mc, frame.comp, frame.itx, stride_px, cols)[rank]
+    rlist = [prev.view if (prev is not None and k == 0) else refs[k].view for k in range(3)]
+    prep = ctx.buffer(frame.prep_elems * 2); prep.zero()
+    coef = ctx.buffer_from(frame.coef)
+    ctx.mc_batch(cur.view, rlist, frame.mc[mine[0]], prep)
+    if len(mine[1]):
+        ctx.comp_batch(cur.view, frame.comp[mine[1]], prep, None)
+    ctx.itx_add_batch(cur.view, frame.itx[mine[2]], coef)
+    ctx.sync()
+    own = [cur.download(pl).copy() for pl in range(3)]
+    dd.allgather_tile_columns(cur, cols, rank, world)
+    prev = cur
+    counts = [len(mine[0]), len(mine[1]), len(mine[2])]
+
+# the oracle reconstructs both frames whole, on one rank
+if rank == 0:
+    oracle = util.default_oracle()
+    want_prev = None
+    for n, frame in enumerate(frames):
+        rl = [want_prev if (want_prev is not None and k == 0) else ref_host[k] for k in range(3)]
+        want, _, _ = test_frame.oracle_frame(oracle, frame, dst0, rl)
+        want_prev = want
+    got = [prev.download(pl) for pl in range(3)]
+    ok = all(np.array_equal(got[pl], want[pl]) for pl in range(3))
+    # what this rank alone produced must differ from the whole picture outside its column (the gather did the work)
+    partial = any(not np.array_equal(own[pl], want[pl]) for pl in range(3))
+    print(json.dumps({"ok": bool(ok), "partial": bool(partial), "cols": cols, "counts": counts}))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_tile_columns_world2_gloo(tmp_path):
+    """Tile-column sharding end to end on two CPU ranks: each reconstructs its column with the
+    SIMT-emulated kernels, one all-gather per frame rebuilds the picture, the second frame predicts from the gathered
+    picture; the result equals the oracle's whole-frame replay."""
+    import json
+    script = tmp_path / "tc.py"
+    script.write_text(TILE_COL_WORKER % {"root": util.ROOT, "tests": os.path.join(util.ROOT, "tests")})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29519", str(script)],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["ok"] and d["partial"], d
+    assert d["cols"] == [[0, 256], [256, 512]]
+    assert all(c > 0 for c in d["counts"])
+
+
+def test_tile_column_split_covers_every_task_once():
+    import numpy as np
+    from dav1d_amd import dist as dd, synth
+    frame = synth.make_frame(1024, 256, 8, seed=3)
+    stride_px = [g[0] for g in synth.plane_geometry(1024, 256, 8, 1)]
+    for n in (1, 2, 3, 4, 8):
+        cols = dd.tile_columns(1024, n)
+        assert len(cols) == n and cols[0][0] == 0 and cols[-1][1] == 1024
+        assert all(a[1] == b[0] for a, b in zip(cols, cols[1:])) and all(x0 % 128 == 0 for x0, _ in cols)
+        parts = dd.tasks_by_column(frame.mc, frame.comp, frame.itx, stride_px, cols)
+        for k, total in enumerate((len(frame.mc), len(frame.comp), len(frame.itx))):
+            idx = np.concatenate([p[k] for p in parts])
+            assert len(idx) == total and len(np.unique(idx)) == total
+        # destination rectangles stay inside their column
+        for c, (mi, ci, ii) in enumerate(parts):
+            t = frame.itx[ii]
+            x = (t["dst_off"].astype(np.int64) % np.asarray(stride_px)[t["plane"]]) << (t["plane"] > 0)
+            assert ((x >= cols[c][0]) & (x < cols[c][1])).all()
+    assert dd.uniform_tile_columns(7680, 8) == [(k * 1024, min((k + 1) * 1024, 7680)) for k in range(8)]   # 8,8,...,4 sb128
