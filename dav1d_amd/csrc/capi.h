@@ -96,7 +96,8 @@ struct McRef {
     uint8_t  mx, my;
     uint8_t  fh, fv;      // row of av1_mc_subpel_filters (0..5) or 6 = bilinear
     uint8_t  ref;         // index into the reference picture set
-    uint8_t  pad[3];
+    uint8_t  vspan;       // av1_mc_tap_span of (fv, my): the window rows the vertical taps reach (filled at list creation)
+    uint8_t  pad[2];
 };
 struct McTile {
     uint32_t dst_off;     // of the TASK: pixel offset in the dst plane; PREP: int16 offset in the prep arena

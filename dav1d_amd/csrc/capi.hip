@@ -242,6 +242,27 @@ int dav1d_hip_itx_list_create(Dav1dHipContext *c, Dav1dHipItxList **out, const D
             t.rsv[0] = (uint8_t) (end & 255);
             t.rsv[1] = (uint8_t) (end >> 8);
         }
+        // Blocks that share a wave should share their code path: a wave runs every 1-D kernel (and the dc-only shortcut) that
+        // any of its blocks needs, one after the other.  Inside windows of consecutive blocks (still close together in the
+        // picture, so the destination lines stay in L2) the blocks are grouped by (dc-only, first kind, second kind).  The
+        // blocks of one list write disjoint pixels, so their order is free.  Speed only.
+        static const int win_waves = getenv("DAV1D_HIP_ITX_SORT_WINDOW") ? atoi(getenv("DAV1D_HIP_ITX_SORT_WINDOW")) : 128;
+        if (win_waves > 0) {
+            static const uint8_t kinds[17] = {       // first | second << 2 per itxfm_add type (txtp_kinds() in itx.hip); 16 = WHT
+                0 | 0 << 2, 0 | 1 << 2, 1 | 0 << 2, 1 | 1 << 2, 0 | 3 << 2, 3 | 0 << 2, 3 | 3 << 2, 3 | 1 << 2,
+                1 | 3 << 2, 2 | 2 << 2, 2 | 0 << 2, 0 | 2 << 2, 2 | 1 << 2, 1 | 2 << 2, 2 | 3 << 2, 3 | 2 << 2, 16 };
+            auto key = [](const Dav1dHipItxTask &t) -> int { return t.txtp == 0 && t.eob < 1 ? 0 : 1 + kinds[t.txtp]; };
+            for (int b = 0; b < 19; b++) {
+                const int w = k_tx_w[b], h = k_tx_h[b];
+                const int lanes = std::max(std::min(h, 32), w);
+                const size_t win = (size_t) win_waves * (size_t) std::max(1, 64 / lanes);
+                for (size_t lo = l->off[b]; lo < l->off[b + 1]; lo += win) {
+                    const size_t hi = std::min(lo + win, l->off[b + 1]);
+                    std::stable_sort(sorted.begin() + lo, sorted.begin() + hi,
+                                     [&](const Dav1dHipItxTask &p, const Dav1dHipItxTask &q) { return key(p) < key(q); });
+                }
+            }
+        }
         if (hipMalloc((void **) &l->dev, n * sizeof(Dav1dHipItxTask)) != hipSuccess) { delete l; return -ENOMEM; }
         const int rc = dav1d_hip_upload(c, l->dev, sorted.data(), n * sizeof(Dav1dHipItxTask));
         if (rc) { hipFree(l->dev); delete l; return rc; }
@@ -320,6 +341,8 @@ struct Dav1dHipMcList {
     McGroup *groups;
     size_t n_groups, n_fused;
     int max_ref;      // highest reference index any tile uses: checked against n_refs at run time
+    McTile *host;     // host copy of `dev` in source order: regrouped per reference geometry at run time
+    uint64_t geo_sig; // geometry the device copy is grouped for (0 = not yet)
 };
 
 // DAV1D_HIP_MC_FUSED: which tile shapes share one launch over a source-ordered list instead of one launch per shape.
@@ -360,6 +383,7 @@ static McRef mc_ref_of(const Dav1dHipMcTask &t) {
         r.fh = t.w > 4 ? h_type : 3 + (h_type & 1);
         r.fv = t.h > 4 ? v_type : 3 + (v_type & 1);
     }
+    r.vspan = av1_mc_tap_span_host[r.fv * 16 + r.my];
     return r;
 }
 
@@ -415,7 +439,9 @@ static int mc_list_from_bins(Dav1dHipContext *c, Dav1dHipMcList **out, std::vect
     if (l->n) {
         if (hipMalloc((void **) &l->dev, l->n * sizeof(McTile)) != hipSuccess) { delete l; return -ENOMEM; }
         int rc = dav1d_hip_upload(c, l->dev, all.data(), l->n * sizeof(McTile));
+        if (!rc && !(l->host = (McTile *) malloc(l->n * sizeof(McTile)))) rc = -ENOMEM;
         if (rc) { hipFree(l->dev); delete l; return rc; }
+        memcpy(l->host, all.data(), l->n * sizeof(McTile));
         // All shapes in one list: cells of (reference, plane, 64-row band, 512-pixel strip) of the SOURCE position, shapes
         // kept together inside a cell so that a wave gets a full group of one shape; a group never leaves its cell.
         struct Ent { uint64_t key; uint32_t idx; };
@@ -455,10 +481,58 @@ static int mc_list_from_bins(Dav1dHipContext *c, Dav1dHipMcList **out, std::vect
             if (!rc) rc = dav1d_hip_upload(c, l->dev_all, fused.data(), l->n_fused * sizeof(McTile));
             if (!rc) rc = dav1d_hip_upload(c, l->groups, groups.data(), groups.size() * sizeof(McGroup));
         }
-        if (rc) { hipFree(l->dev); if (l->dev_all) hipFree(l->dev_all); if (l->groups) hipFree(l->groups); delete l; return rc; }
+        if (rc) { hipFree(l->dev); free(l->host); if (l->dev_all) hipFree(l->dev_all); if (l->groups) hipFree(l->groups); delete l; return rc; }
     }
     *out = l;
     return 0;
+}
+
+// Tiles that share a wave should share their code path: a wave runs the edge-emulating gather if ANY of its tiles leaves
+// the reference plane, and the second prediction if ANY of them is a fused compound.  Inside windows of consecutive tiles
+// (the source order, so the lines they read stay together) the tiles are grouped by (leaves the plane, kind).  Which tiles
+// leave the plane depends on the reference geometry, known only at run time: done on the first run and again whenever the
+// geometry changes.  The tiles of one list write disjoint rectangles (BLEND_V aside, which lives in the comp list), so
+// their order is free.  Speed only.
+static int mc_regroup(Dav1dHipContext *c, Dav1dHipMcList *l, const DevPlanes *rp, int n_refs) {
+    static const int win_waves = getenv("DAV1D_HIP_MC_GROUP_WINDOW") ? atoi(getenv("DAV1D_HIP_MC_GROUP_WINDOW")) : 128;
+    if (win_waves <= 0 || !l->n) return 0;
+    uint64_t sig = 0xcbf29ce484222325ull;
+    for (int r = 0; r < n_refs; r++)
+        for (int p = 0; p < 3; p++) { sig = (sig ^ (uint32_t) rp[r].w[p]) * 0x100000001b3ull; sig = (sig ^ (uint32_t) rp[r].h[p]) * 0x100000001b3ull; }
+    sig |= 1;
+    if (l->geo_sig == sig) return 0;
+    std::vector<McTile> g(l->host, l->host + l->n);
+    std::vector<uint8_t> key(l->n);
+    for (int b = 0; b < MC_BINS; b++) {
+        const int tw = 4 << (b / 3), th = 4 << (b % 3);
+        const int ws = tw == 4 ? 12 : (tw + 8 + 7) & ~7, ext_x = (ws + 7) / 8 * 8, ext_y = th + 7;   // mc.hip: NCH * 8, WR - 1
+        const int lanes = tw * th / 4 < 64 ? tw * th / 4 : 64;
+        const size_t win = (size_t) win_waves * (size_t) (64 / lanes);
+        if (64 / lanes < 2) continue;                    // one tile per wave: nothing to share
+        for (size_t i = l->off[b]; i < l->off[b + 1]; i++) {
+            const McTile &t = g[i];
+            const bool two = t.kind == MCT_AVG || t.kind == MCT_WAVG;
+            bool edge = false;
+            for (int k = 0; k < (two ? 2 : 1); k++) {
+                const McRef &r = t.r[k];
+                const int x0 = r.src_x - 4, y0 = r.src_y - 3;
+                edge |= x0 < 0 || y0 < 0 || x0 + ext_x > rp[r.ref].w[t.plane] || y0 + ext_y > rp[r.ref].h[t.plane];
+            }
+            key[i] = (uint8_t) ((edge ? 8 : 0) | t.kind);
+        }
+        std::vector<uint32_t> idx;
+        for (size_t lo = l->off[b]; lo < l->off[b + 1]; lo += win) {
+            const size_t hi = std::min(lo + win, l->off[b + 1]);
+            idx.resize(hi - lo);
+            for (size_t i = lo; i < hi; i++) idx[i - lo] = (uint32_t) i;
+            std::stable_sort(idx.begin(), idx.end(), [&](uint32_t p, uint32_t q) { return key[p] < key[q]; });
+            for (size_t i = lo; i < hi; i++) g[i] = l->host[idx[i - lo]];
+        }
+    }
+    hipStreamSynchronize(c->stream);                     // an earlier run may still be reading the old order
+    const int rc = dav1d_hip_upload(c, l->dev, g.data(), l->n * sizeof(McTile));
+    if (!rc) l->geo_sig = sig;
+    return rc;
 }
 
 extern "C" {
@@ -479,6 +553,7 @@ void dav1d_hip_mc_list_destroy(Dav1dHipContext *c, Dav1dHipMcList *l) {
     if (!l) return;
     hipStreamSynchronize(c->stream);
     if (l->dev) hipFree(l->dev);
+    free(l->host);
     if (l->dev_all) hipFree(l->dev_all);
     if (l->groups) hipFree(l->groups);
     delete l;
@@ -494,8 +569,9 @@ int dav1d_hip_mc_list_run(Dav1dHipContext *c, const Dav1dHipMcList *l, const Dav
         rp[i] = dev_planes(&refs[i]);
     }
     const int fb = mc_fused_min_bin();
+    int rc = mc_regroup(c, const_cast<Dav1dHipMcList *>(l), rp, n_refs);
+    if (rc) return rc;
     StreamFan fan(c);
-    int rc = 0;
     if (l->n_fused) rc = dav1d_hip_launch_mc_all(&dp, rp, n_refs, dst->bpc, l->dev_all, l->groups, (int) l->n_groups, fb == 0, prep, fan.next());
     for (int b = fb - 1; b >= 0 && !rc; b--) {
         const size_t cnt = l->off[b + 1] - l->off[b];
@@ -512,6 +588,7 @@ int dav1d_hip_mc_list_run_timed(Dav1dHipContext *c, const Dav1dHipMcList *l, con
     const DevPlanes dp = dev_planes(dst);
     DevPlanes rp[8];
     for (int i = 0; i < n_refs; i++) rp[i] = dev_planes(&refs[i]);
+    if (int rg = mc_regroup(c, const_cast<Dav1dHipMcList *>(l), rp, n_refs)) return rg;
     hipEvent_t ev[MC_BINS + 1];
     for (int b = 0; b <= MC_BINS; b++) HIP_TRY(hipEventCreate(&ev[b]));
     HIP_TRY(hipEventRecord(ev[0], c->stream));

@@ -35,6 +35,7 @@
 namespace {
 
 struct RefSet { DevPlanes r[8]; };
+static_assert(sizeof(DevPlanes) == 64 && sizeof(RefSet) == 512, "the waves copy the table to LDS dword by dword");
 
 struct __attribute__((packed, aligned(2))) U64u { uint32_t a, b; };   // 2-byte aligned 8-byte global load
 struct __attribute__((packed, aligned(1))) U64b { uint32_t a, b; };   // byte-aligned (8 bpc rows)
@@ -55,12 +56,15 @@ __device__ __forceinline__ Taps load_taps(const int set, const int m) {
 }
 
 constexpr int mc_cmin(int a, int b) { return a < b ? a : b; }
+// window row stride in pixels: TW + 8 columns rounded up to whole 16-byte chunks; 4-wide tiles keep exactly the 12 columns
+// the 4-tap / 8-tap rows reach (8-byte aligned rows are enough for the 8-byte reads of the horizontal pass)
+constexpr int mc_win_stride(int tw) { return tw == 4 ? 12 : (tw + 8 + 7) & ~7; }
 
 // LDS bytes one wave needs for tile shape (TW, TH): window + row-pair intermediate + the tile records
 template <int TW, int TH>
 constexpr int mc_lds_bytes() {
-    constexpr int LPT = mc_cmin(64, TW * TH / 4), G = 64 / LPT, WS = (TW + 8 + 7) & ~7, WR = TH + 8, NPR = WR / 2;
-    return G * WR * WS * 2 + G * NPR * TW * 4 + (G > 1 ? G * (int) sizeof(McTile) : 0);
+    constexpr int LPT = mc_cmin(64, TW * TH / 4), G = 64 / LPT, WS = mc_win_stride(TW), WR = TH + 8, NPR = WR / 2;
+    return G * WR * WS * 2 + G * NPR * TW * 4 + (G > 1 ? G * (int) sizeof(McTile) + (int) sizeof(RefSet) : 0);
 }
 
 // One wave's worth of tiles of shape (TW, TH): tiles[t0 .. t0 + nt), nt <= 64 / LPT.  `smem` = mc_lds_bytes<TW, TH>() of LDS.
@@ -72,9 +76,9 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
     constexpr int LPT = mc_cmin(64, TW * TH / 4);       // lanes per tile
     constexpr int G = 64 / LPT;                         // tiles side by side in a wave
     constexpr int R = TW * TH / 4 / LPT;                // output strips per lane (1, 2 or 4)
-    constexpr int WS = (TW + 8 + 7) & ~7;               // window row stride (int16), rows 16-byte aligned
+    constexpr int WS = mc_win_stride(TW);               // window row stride (int16)
     constexpr int WR = TH + 8;                          // window rows held (TH+7 used, +1 so row pairs are complete)
-    constexpr int NCH = WS / 8;                         // 8-pixel (16-byte) chunks per window row
+    constexpr int NCH = (WS + 7) / 8;                   // 8-pixel (16-byte) chunks fetched per window row
     constexpr int NPR = WR / 2;                         // row pairs of the intermediate
     constexpr int NLD = ((WR - 1) * NCH + LPT - 1) / LPT;   // window loads per lane
     constexpr bool HBD = sizeof(pixel) == 2;
@@ -99,6 +103,12 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
         const uint32_t *recs = reinterpret_cast<const uint32_t *>(tiles + t0);
         const int nw = nt * RW;
         for (int i = lane; i < nw; i += 64) rec_s[i] = recs[i];
+        // the reference plane table goes to LDS in the same round trip: the lanes index it by their own tile's reference,
+        // and a second, dependent trip to the kernel arguments would sit in front of every window fetch
+        uint32_t *const ref_s = rec_s + G * RW;
+        const uint32_t *rsrc = reinterpret_cast<const uint32_t *>(&refs);
+#pragma unroll
+        for (int i = 0; i < (int) sizeof(RefSet) / 4; i += 64) ref_s[i + lane] = rsrc[i + lane];
         dv::wave_sync();
         const uint32_t *rp = rec_s + (live ? sub : 0) * RW;
         uint32_t *tw_ = reinterpret_cast<uint32_t *>(&t);
@@ -128,16 +138,26 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
         const Taps fh = load_taps(rf.fh, rf.mx), fv = load_taps(rf.fv, rf.my);
         // window rows the vertical taps can reach: the others only ever meet zero taps, so they are neither
         // fetched nor filtered (6-tap regular, 4-tap smooth / small blocks, 2-tap bilinear, 1-tap full-pel)
-        const int vspan = av1_mc_tap_span[rf.fv * 16 + rf.my];
+        const int vspan = rf.vspan;
         const int row_lo = vspan & 15, row_hi = TH - 1 + (vspan >> 4);
 
         // ---- 1. gather the window
         if (live) {
-            const DevPlanes &rp = refs.r[rf.ref];
-            const pixel *src = reinterpret_cast<const pixel *>(rp.data[t.plane]);
-            const int rs = rp.stride[t.plane], rw = rp.w[t.plane], rh = rp.h[t.plane];
+            const pixel *src;
+            int rs, rw, rh;
+            if (G == 1) {
+                const DevPlanes &rp = refs.r[rf.ref];
+                src = reinterpret_cast<const pixel *>(rp.data[t.plane]);
+                rs = rp.stride[t.plane]; rw = rp.w[t.plane]; rh = rp.h[t.plane];
+            } else {
+                constexpr int RW = sizeof(McTile) / 4, DW = sizeof(DevPlanes) / 4;
+                const uint32_t *rt = mid_s + G * NPR * TW + G * RW + rf.ref * DW;      // == ref_s above
+                const uint32_t *pd = rt + 2 * t.plane;
+                src = reinterpret_cast<const pixel *>((uint64_t) pd[0] | ((uint64_t) pd[1] << 32));
+                rs = (int) rt[6 + t.plane]; rw = (int) rt[9 + t.plane]; rh = (int) rt[12 + t.plane];
+            }
             const int x0 = rf.src_x - 4, y0 = rf.src_y - 3;
-            const bool interior = x0 >= 0 && y0 >= 0 && x0 + WS <= rw && y0 + WR - 1 <= rh;
+            const bool interior = x0 >= 0 && y0 >= 0 && x0 + NCH * 8 <= rw && y0 + WR - 1 <= rh;
             if (interior) {
                 // 16-byte (8-pixel) loads, rows at arbitrary 2-byte alignment; all of a lane's loads are
                 // issued before the first LDS write
@@ -161,7 +181,14 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
 #pragma unroll
                 for (int k = 0; k < NLD; k++) {
                     const int i = l + k * LPT;
-                    if (i < (WR - 1) * NCH) *reinterpret_cast<uint4 *>(win + (i / NCH) * WS + 8 * (i % NCH)) = ld[k];
+                    if (i >= (WR - 1) * NCH) continue;
+                    int16_t *const wp = win + (i / NCH) * WS + 8 * (i % NCH);
+                    if (WS % 8 == 0) {
+                        *reinterpret_cast<uint4 *>(wp) = ld[k];
+                    } else {        // 12-column rows: 8-byte stores, the last chunk keeps only its first half
+                        *reinterpret_cast<uint2 *>(wp) = make_uint2(ld[k].x, ld[k].y);
+                        if (8 * (i % NCH) + 8 <= WS) *reinterpret_cast<uint2 *>(wp + 4) = make_uint2(ld[k].z, ld[k].w);
+                    }
                 }
             } else {
                 // edge emulation: per-pixel clamped fetch, 8 independent loads in flight per lane
