@@ -316,9 +316,19 @@ def main():
             rec = ctx.picture(w, h, api.LAYOUT_I420, bpc)
             for pl in range(3):
                 rec.upload(pl, got[pl])
-            ms_intra = test_postchain.hip_intra(ctx, intra, rec, timed=True)
+            rec2 = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+            for pl in range(3):
+                rec2.upload(pl, got[pl])
+            # the chain of ~200 small dependent launches twice: enqueued launch by launch, and recorded once + replayed as a
+            # HIP graph (dav1d_hip_graph_*); both must give the same picture, the faster one is the stage time
+            ms_intra_plain = test_postchain.hip_intra(ctx, intra, rec2, timed=True)
+            ms_intra_graph = test_postchain.hip_intra(ctx, intra, rec, timed=True, graph=True)
             got = [rec.download(pl) for pl in range(3)]
+            if not all(np.array_equal(got[pl], rec2.download(pl)) for pl in range(3)):
+                raise SystemExit("bench: graph replay of the intra pass differs from the enqueued launches")
+            ms_intra = min(ms_intra_plain, ms_intra_graph)
             rec.free()
+            rec2.free()
             intra_ok = None
             if not a.no_check:
                 t1 = time.perf_counter()
@@ -371,6 +381,8 @@ def main():
                                 "CDEF (y 17 / uv 5, every 8x8), Wiener Y + SGR-mix UV (64-px units), film grain (lag 3, overlap)",
                     "ms_per_frame": round(full_ms, 4), "value": round(frame.luma_pixels / (full_ms * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
                     "stages_ms": dict({"recon_itx_mc": round(ms_per_step, 4)}, **{k: round(v, 4) for k, v in stage_ms.items()}),
+                    "intra_launch_modes_ms": {"enqueued": round(ms_intra_plain, 4), "graph_replay": round(ms_intra_graph, 4),
+                                              "graph_nodes": int(test_postchain.hip_intra.last_nodes), "wavefront_steps": len(intra.batches)},
                     "tasks": {"ipred": intra.n_blocks, "lf": int(len(post.lf)), "cdef": int(len(post.cdef)), "lr": int(len(post.lr))},
                     "algorithmic_bytes_per_frame": int(full_bytes),
                     "achieved": round(full_bytes / (full_ms * 1e-3) / 1e9, 1), "frac": round(full_bytes / (full_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

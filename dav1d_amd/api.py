@@ -170,6 +170,21 @@ class Context:
     def picture(self, w, h, layout, bpc):
         return DevicePicture(self, w, h, layout, bpc)
 
+    def graph_begin(self):
+        """Start recording the list runs issued on this context (dav1d_hip_graph_begin)."""
+        _chk(self.lib.dav1d_hip_graph_begin(self.h), "graph_begin")
+
+    def graph_end(self):
+        g = C.c_void_p()
+        _chk(self.lib.dav1d_hip_graph_end(self.h, C.byref(g)), "graph_end")
+        return g
+
+    def graph_launch(self, g):
+        _chk(self.lib.dav1d_hip_graph_launch(self.h, g), "graph_launch")
+
+    def graph_destroy(self, g):
+        self.lib.dav1d_hip_graph_destroy(self.h, g)
+
     def last_kernel_ms(self):
         return float(self.lib.dav1d_hip_last_kernel_ms(self.h))
 

@@ -65,6 +65,7 @@ static inline int hip_rc(hipError_t e) {
     if (e == hipSuccess) return 0;
     if (e == hipErrorOutOfMemory) return -ENOMEM;
     if (e == hipErrorInvalidValue) return -EINVAL;
+    if (e == hipErrorNotSupported) return -ENOSYS;
     return -EIO;
 }
 #define HIP_TRY(x) do { const int rc_ = hip_rc(x); if (rc_) return rc_; } while (0)
@@ -82,6 +83,8 @@ static inline DevPlanes dev_planes(const Dav1dHipPicture *p) {
 }
 
 // kernel launchers (one per family translation unit)
+extern "C" int dav1d_hip_launch_itx_all(const DevPlanes *dst, int bpc, const Dav1dHipItxTask *tasks, const size_t *off,
+                                        void *coef, void *stream);
 extern "C" int dav1d_hip_launch_itx_bin(const DevPlanes *dst, int bpc, int tx, const Dav1dHipItxTask *tasks,
                                         int n, void *coef, void *stream);
 // Device-side unit of motion compensation: a tile of at most 16x16 cut out of a
@@ -127,7 +130,7 @@ extern "C" int dav1d_hip_launch_cdef(const DevPlanes *dst, const DevPlanes *src,
 extern "C" int dav1d_hip_launch_lf(const DevPlanes *dst, int bpc, const Dav1dHipLfTask *tasks, int n, const uint8_t *lvl,
                                    int b4_stride, const uint8_t *lut_e, const uint8_t *lut_i, void *stream);
 
-extern "C" int dav1d_hip_launch_ipred(const DevPlanes *dst, int bpc, int layout, const Dav1dHipIpredTask *tasks, int n,
+extern "C" int dav1d_hip_launch_ipred(const DevPlanes *dst, int bpc, int layout, const Dav1dHipIpredTask *tasks, int n, int n_big,
                                       uint8_t *pal_idx, void *stream);
 
 extern "C" int dav1d_hip_launch_wiener(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,

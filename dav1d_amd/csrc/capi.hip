@@ -54,6 +54,50 @@ void dav1d_hip_close(Dav1dHipContext *c) {
 
 int dav1d_hip_sync(Dav1dHipContext *c) { return hip_rc(hipStreamSynchronize(c->stream)); }
 void *dav1d_hip_stream(Dav1dHipContext *c) { return (void *) c->stream; }
+
+// ---- recorded launch sequences (hipGraph)
+struct Dav1dHipGraph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    size_t nodes;
+};
+
+int dav1d_hip_graph_begin(Dav1dHipContext *c) {
+    if (!c) return -EINVAL;
+    return hip_rc(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+}
+
+int dav1d_hip_graph_end(Dav1dHipContext *c, Dav1dHipGraph **out) {
+    if (!c || !out) return -EINVAL;
+    *out = nullptr;
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamEndCapture(c->stream, &graph));
+    if (!graph) return -EIO;
+    Dav1dHipGraph *g = new (std::nothrow) Dav1dHipGraph();
+    if (!g) { hipGraphDestroy(graph); return -ENOMEM; }
+    g->graph = graph;
+    g->nodes = 0;
+    (void) hipGraphGetNodes(graph, nullptr, &g->nodes);
+    const hipError_t e = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { hipGraphDestroy(graph); delete g; return hip_rc(e); }
+    *out = g;
+    return 0;
+}
+
+int dav1d_hip_graph_launch(Dav1dHipContext *c, const Dav1dHipGraph *g) {
+    if (!c || !g) return -EINVAL;
+    return hip_rc(hipGraphLaunch(g->exec, c->stream));
+}
+
+size_t dav1d_hip_graph_nodes(const Dav1dHipGraph *g) { return g ? g->nodes : 0; }
+
+void dav1d_hip_graph_destroy(Dav1dHipContext *c, Dav1dHipGraph *g) {
+    if (!g) return;
+    if (c) hipStreamSynchronize(c->stream);
+    hipGraphExecDestroy(g->exec);
+    hipGraphDestroy(g->graph);
+    delete g;
+}
 const char *dav1d_hip_version(void) { return "dav1d_hip 0.1 (gfx950)"; }
 float dav1d_hip_last_kernel_ms(Dav1dHipContext *c) { return c ? c->last_ms : 0.f; }
 
@@ -283,6 +327,9 @@ int dav1d_hip_itx_list_run(Dav1dHipContext *c, const Dav1dHipItxList *l, const D
     const DevPlanes dp = dev_planes(dst);
     // longest-running shapes first (64-point, then 32-point ...), each on its own side stream
     static const uint8_t order[19] = { 4, 11, 12, 17, 18, 3, 9, 10, 15, 16, 2, 7, 8, 13, 14, 1, 5, 6, 0 };
+    // short lists (the residuals of one intra wavefront step): every size in one launch
+    static const size_t one_launch_below = getenv("DAV1D_HIP_ITX_ONE_LAUNCH") ? (size_t) atol(getenv("DAV1D_HIP_ITX_ONE_LAUNCH")) : 4096;
+    if (l->n && l->n < one_launch_below) return dav1d_hip_launch_itx_all(&dp, dst->bpc, l->dev, l->off, coef, c->stream);
     StreamFan fan(c, l->n >= 16384);
     int rc = 0;
     for (int k = 0; k < 19 && !rc; k++) {
@@ -858,17 +905,31 @@ static int ipred_tasks_valid(const Dav1dHipIpredTask *tasks, size_t n, const uin
     return 0;
 }
 
+// Blocks of 1024 pixels or more whose predictor has no serial dependency are predicted by four workgroups each
+// (ipred.hip: IPRED_PARTS); they go first in a batch so that the grid holds exactly 4 * n_big + n_small workgroups.
+// The tasks of one batch are independent of each other, so their order is free.
+static bool ipred_task_big(const Dav1dHipIpredTask &t) {
+    if ((int) t.tw * t.th * 16 < 1024) return false;
+    if (t.kind == DAV1D_HIP_IPRED_PAL) return true;
+    return (t.kind == DAV1D_HIP_IPRED_PRED || t.kind == DAV1D_HIP_IPRED_DSP) && t.mode != 13;      // 13 = filter intra: serial
+}
+static size_t ipred_big_first(Dav1dHipIpredTask *t, size_t n) {
+    return (size_t) (std::stable_partition(t, t + n, ipred_task_big) - t);
+}
+
 extern "C" int dav1d_hip_ipred_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipIpredTask *tasks, size_t n,
                                      uint8_t *pal_idx) {
     if (!dst || (!tasks && n)) return -EINVAL;
     if (!n) return 0;
     if (ipred_tasks_valid(tasks, n, pal_idx)) return -EINVAL;
+    std::vector<Dav1dHipIpredTask> ordered(tasks, tasks + n);
+    const size_t n_big = ipred_big_first(ordered.data(), n);
     Dav1dHipIpredTask *dev = nullptr;
     if (hipMalloc((void **) &dev, n * sizeof(*dev)) != hipSuccess) return -ENOMEM;
-    int rc = dav1d_hip_upload(c, dev, tasks, n * sizeof(*dev));
+    int rc = dav1d_hip_upload(c, dev, ordered.data(), n * sizeof(*dev));
     const DevPlanes dp = dev_planes(dst);
     KernelTimer kt(c);
-    if (!rc) rc = dav1d_hip_launch_ipred(&dp, dst->bpc, dst->layout, dev, (int) n, pal_idx, c->stream);
+    if (!rc) rc = dav1d_hip_launch_ipred(&dp, dst->bpc, dst->layout, dev, (int) n, (int) n_big, pal_idx, c->stream);
     kt.stop();
     hipStreamSynchronize(c->stream);
     hipFree(dev);
@@ -880,7 +941,7 @@ extern "C" int dav1d_hip_ipred_batch(Dav1dHipContext *c, const Dav1dHipPicture *
 // every wave on the same stream without a host round trip per wave.
 struct Dav1dHipIpredList {
     Dav1dHipIpredTask *dev;
-    std::vector<size_t> start;
+    std::vector<size_t> start, n_big;     // batch k = tasks [start[k], start[k + 1]), its first n_big[k] are split four ways
     bool needs_aux;
 };
 
@@ -901,8 +962,10 @@ extern "C" int dav1d_hip_ipred_list_create(Dav1dHipContext *c, Dav1dHipIpredList
     l->start.push_back(0);
     for (size_t k = 0; k < n_batches; k++) l->start.push_back(l->start.back() + batch_sizes[k]);
     if (n) {
+        std::vector<Dav1dHipIpredTask> ordered(tasks, tasks + n);
+        for (size_t k = 0; k < n_batches; k++) l->n_big.push_back(ipred_big_first(ordered.data() + l->start[k], batch_sizes[k]));
         if (hipMalloc((void **) &l->dev, n * sizeof(Dav1dHipIpredTask)) != hipSuccess) { delete l; return -ENOMEM; }
-        const int rc = dav1d_hip_upload(c, l->dev, tasks, n * sizeof(Dav1dHipIpredTask));
+        const int rc = dav1d_hip_upload(c, l->dev, ordered.data(), n * sizeof(Dav1dHipIpredTask));
         if (rc) { hipFree(l->dev); delete l; return rc; }
     }
     *out = l;
@@ -915,7 +978,7 @@ extern "C" int dav1d_hip_ipred_list_run_batch(Dav1dHipContext *c, const Dav1dHip
     const size_t n = l->start[batch + 1] - l->start[batch];
     if (!n) return 0;
     const DevPlanes dp = dev_planes(dst);
-    return dav1d_hip_launch_ipred(&dp, dst->bpc, dst->layout, l->dev + l->start[batch], (int) n, aux, c->stream);
+    return dav1d_hip_launch_ipred(&dp, dst->bpc, dst->layout, l->dev + l->start[batch], (int) n, (int) l->n_big[batch], aux, c->stream);
 }
 
 extern "C" void dav1d_hip_ipred_list_destroy(Dav1dHipContext *c, Dav1dHipIpredList *l) {

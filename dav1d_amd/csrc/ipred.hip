@@ -64,15 +64,24 @@ __device__ __forceinline__ int upsample_edge_at(const int16_t *in, const int j, 
     return dv::iclip((s + 8) >> 4, 0, bitdepth_max);
 }
 
+constexpr int IPRED_PARTS = 4;
+
 template <typename pixel>
 __global__ __launch_bounds__(64) void ipred_kernel(const DevPlanes dst, const Dav1dHipIpredTask *__restrict__ tasks, const int n,
-                                                   uint8_t *aux, const int layout, const int bitdepth_max)
+                                                   const int n_big, uint8_t *aux, const int layout, const int bitdepth_max)
 {
     const uint8_t *const pal_idx = aux;
     __shared__ int16_t e1[ESZ], e2[ESZ];
     __shared__ int16_t blk[32 * 32];
 
-    const int ti = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x);
+    // The first n_big tasks of the batch (the host puts them there: blocks of 1024 pixels or more without a serial
+    // predictor) get IPRED_PARTS workgroups each — every one prepares the edge for itself and writes its share of the
+    // rows; a lone wave walking 4096 pixels is what the wavefront steps of an intra frame would wait for.  The rest: one
+    // workgroup per block.
+    const int b = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x);
+    const bool many = b < n_big * IPRED_PARTS;
+    const int part = many ? b % IPRED_PARTS : 0;
+    const int ti = many ? b / IPRED_PARTS : b - n_big * (IPRED_PARTS - 1);
     if (ti >= n) return;
     const int lane = threadIdx.x;
     const Dav1dHipIpredTask t = tasks[__builtin_amdgcn_readfirstlane(ti)];
@@ -81,17 +90,24 @@ __global__ __launch_bounds__(64) void ipred_kernel(const DevPlanes dst, const Da
     const int stride = dst.stride[t.plane];
     pixel *const d = reinterpret_cast<pixel *>(dst.data[t.plane]) + t.dst_off;
     const int w = t.tw * 4, h = t.th * 4;
+    const int lw = __builtin_ctz(w);     // block sides are powers of two: pixel i of the block is (i >> lw, i & (w - 1))
     int16_t *const E = e1 + EC;          // E[k] == topleft_out[k]
+    const bool split = many;
+    const int i_lo = split ? part * (w * h / IPRED_PARTS) : 0, i_hi = split ? i_lo + w * h / IPRED_PARTS : w * h;
 
     // ---------------------------------------------------------------- palette
     if (t.kind == DAV1D_HIP_IPRED_PAL) {
         // t.pal[] = 8 colours, indices packed two per byte (src/ipred_tmpl.c:717-730)
         const uint8_t *idx = pal_idx + t.aux_off;
-        for (int i = lane; i < (w >> 1) * h; i += 64) {
-            const int y = i / (w >> 1), x = (i % (w >> 1)) * 2;
+        for (int i = (i_lo >> 1) + lane; i < (i_hi >> 1); i += 64) {
+            const int y = i >> (lw - 1), x = (i & ((w >> 1) - 1)) * 2;
             const int v = idx[i];
-            d[y * stride + x] = (pixel) t.pal[v & 7];
-            d[y * stride + x + 1] = (pixel) t.pal[v >> 4];
+            // the palette sits in scalar registers: picked by compares, never indexed (indexing would spill it to scratch)
+            int c0 = t.pal[0], c1 = t.pal[0];
+#pragma unroll
+            for (int k = 1; k < 8; k++) { c0 = (v & 7) == k ? (int) t.pal[k] : c0; c1 = (v >> 4) == k ? (int) t.pal[k] : c1; }
+            d[y * stride + x] = (pixel) c0;
+            d[y * stride + x + 1] = (pixel) c1;
         }
         return;
     }
@@ -212,7 +228,7 @@ __global__ __launch_bounds__(64) void ipred_kernel(const DevPlanes dst, const Da
             for (int i = lane; i < w * h; i += 64) blk[i] = ac_mem[i];
         } else
         for (int i = lane; i < w * h; i += 64) {
-            const int y = i / w, x = i % w;
+            const int y = i >> lw, x = i & (w - 1);
             const int xs = dv::imin(x, wv - 1), yy = dv::imin(y, hv - 1);     // padding replicates the last visible column / row
             const pixel *p = ypx + (yy << ss_ver) * ys + (xs << ss_hor);
             int s = p[0];
@@ -248,7 +264,7 @@ __global__ __launch_bounds__(64) void ipred_kernel(const DevPlanes dst, const Da
             const int diff = alpha * (blk[i] - mean);
             const int ad = diff < 0 ? -diff : diff;
             const int m = (ad + 32) >> 6;
-            d[(i / w) * stride + i % w] = (pixel) dv::iclip(dc + (diff < 0 ? -m : m), 0, bitdepth_max);
+            d[(i >> lw) * stride + (i & (w - 1))] = (pixel) dv::iclip(dc + (diff < 0 ? -m : m), 0, bitdepth_max);
         }
         return;
     }
@@ -270,7 +286,7 @@ __global__ __launch_bounds__(64) void ipred_kernel(const DevPlanes dst, const Da
                 dc = (int) u;
             }
         }
-        for (int i = lane; i < w * h; i += 64) d[(i / w) * stride + i % w] = (pixel) dc;
+        for (int i = i_lo + lane; i < i_hi; i += 64) d[(i >> lw) * stride + (i & (w - 1))] = (pixel) dc;
         return;
     }
 
@@ -348,11 +364,14 @@ __global__ __launch_bounds__(64) void ipred_kernel(const DevPlanes dst, const Da
                 const int x = bx * 4, y = by * 2;
                 int p[7];
                 // p0 = topleft, p1..p4 = top, p5, p6 = left
+#pragma unroll
                 for (int q = 0; q < 5; q++) p[q] = y ? blk[(y - 1) * w + x - 1 + q] : E[x + q];
                 if (y && !x) p[0] = E[-y];
                 p[5] = x ? blk[y * w + x - 1] : E[-1 - y];
                 p[6] = x ? blk[(y + 1) * w + x - 1] : E[-2 - y];
+#pragma unroll
                 for (int yy = 0; yy < 2; yy++)
+#pragma unroll
                     for (int xx = 0; xx < 4; xx++) {
                         const int8_t *f = flt + (yy * 4 + xx) * 2;
                         const int acc = f[0] * p[0] + f[1] * p[1] + f[16] * p[2] + f[17] * p[3] + f[32] * p[4] + f[33] * p[5] + f[48] * p[6];
@@ -361,14 +380,14 @@ __global__ __launch_bounds__(64) void ipred_kernel(const DevPlanes dst, const Da
             }
             dv::wave_sync();
         }
-        for (int i = lane; i < w * h; i += 64) d[(i / w) * stride + i % w] = (pixel) blk[i];
+        for (int i = lane; i < w * h; i += 64) d[(i >> lw) * stride + (i & (w - 1))] = (pixel) blk[i];
         return;
     }
     dv::wave_sync();
 
     const int right = E[w], bottom = E[-h], tl = E[0];
-    for (int i = lane; i < w * h; i += 64) {
-        const int y = i / w, x = i % w;
+    for (int i = i_lo + lane; i < i_hi; i += 64) {
+        const int y = i >> lw, x = i & (w - 1);
         int v;
         switch (mode) {
         case M_VERT: v = E[1 + x]; break;
@@ -422,14 +441,16 @@ __global__ __launch_bounds__(64) void ipred_kernel(const DevPlanes dst, const Da
 
 } // namespace
 
-extern "C" int dav1d_hip_launch_ipred(const DevPlanes *dst, int bpc, int layout, const Dav1dHipIpredTask *tasks, int n,
+extern "C" int dav1d_hip_launch_ipred(const DevPlanes *dst, int bpc, int layout, const Dav1dHipIpredTask *tasks, int n, int n_big,
                                       uint8_t *pal_idx, void *stream)
 {
     if (n <= 0) return 0;
+    if (n_big < 0 || n_big > n) return -22;
+    const int grid = n + n_big * (IPRED_PARTS - 1);
     const int bitdepth_max = (1 << bpc) - 1;
     if (bpc == 8)
-        hipLaunchKernelGGL((ipred_kernel<uint8_t>), dim3(n), dim3(64), 0, (hipStream_t) stream, *dst, tasks, n, pal_idx, layout, bitdepth_max);
+        hipLaunchKernelGGL((ipred_kernel<uint8_t>), dim3(grid), dim3(64), 0, (hipStream_t) stream, *dst, tasks, n, n_big, pal_idx, layout, bitdepth_max);
     else
-        hipLaunchKernelGGL((ipred_kernel<uint16_t>), dim3(n), dim3(64), 0, (hipStream_t) stream, *dst, tasks, n, pal_idx, layout, bitdepth_max);
+        hipLaunchKernelGGL((ipred_kernel<uint16_t>), dim3(grid), dim3(64), 0, (hipStream_t) stream, *dst, tasks, n, n_big, pal_idx, layout, bitdepth_max);
     return hip_rc(hipGetLastError());
 }

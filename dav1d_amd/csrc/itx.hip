@@ -85,9 +85,17 @@ __device__ __forceinline__ void tx1d(const int kind, const int *in, const int lo
     }
 }
 
+// LDS ints one wave needs for transform size TX (all of its blocks)
+template <int TX>
+constexpr int itx_lds_ints() {
+    constexpr int W = tx_w(TX), H = tx_h(TX), SH = cmin(H, 32), LPB = cmax(SH, W);
+    return (64 / LPB) * SH * (W + 1);
+}
+
+// The wave `group` of the blocks of ONE transform size: blocks [group * BPW, group * BPW + BPW) of tasks[0 .. n).
 template <int TX, typename pixel, typename coef>
-__global__ __launch_bounds__(64) void itx_add_kernel(const DevPlanes dst, const Dav1dHipItxTask *__restrict__ tasks,
-                                                     const int n, coef *__restrict__ cf, const int bitdepth_max)
+__device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItxTask *__restrict__ tasks,
+                                         const int n, coef *__restrict__ cf, const int bitdepth_max, const int group, int *tmp_s)
 {
     constexpr int W = tx_w(TX), H = tx_h(TX);
     constexpr int SW = cmin(W, 32), SH = cmin(H, 32);
@@ -101,11 +109,11 @@ __global__ __launch_bounds__(64) void itx_add_kernel(const DevPlanes dst, const 
     constexpr int NCH = SW * SH * (int) sizeof(coef) / 16;   // 16-byte chunks per slab
     // one LDS region per block, used twice: first the raw slab (landing zone of the 16-byte
     // loads), then, once every lane holds its row in registers, the transposed intermediate
-    __shared__ __attribute__((aligned(16))) int tmp_s[BPW * SH * TS];
+    static_assert(BPW * SH * TS == itx_lds_ints<TX>(), "LDS sizing");
 
     const int lane = threadIdx.x;
     const int sub = BPW == 1 ? 0 : lane / LPB, l = BPW == 1 ? lane : lane % LPB;
-    const int ti = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x) * BPW + sub;
+    const int ti = group * BPW + sub;
     const bool live = ti < n;
 
     Dav1dHipItxTask t;
@@ -259,6 +267,43 @@ __global__ __launch_bounds__(64) void itx_add_kernel(const DevPlanes dst, const 
     }
 }
 
+template <int TX, typename pixel, typename coef>
+__global__ __launch_bounds__(64) void itx_add_kernel(const DevPlanes dst, const Dav1dHipItxTask *__restrict__ tasks,
+                                                     const int n, coef *__restrict__ cf, const int bitdepth_max)
+{
+    __shared__ __attribute__((aligned(16))) int tmp_s[itx_lds_ints<TX>()];
+    itx_body<TX, pixel, coef>(dst, tasks, n, cf, bitdepth_max, (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x), tmp_s);
+}
+
+// Every transform size in one launch, for the short lists of an intra wavefront step (a few hundred blocks of up to
+// five sizes: one launch instead of five keeps the dependent chain of the step short).  tasks[] is the size-binned
+// list; seg.off[b] = first task of size b, seg.grp[b] = first workgroup of size b.  LDS / registers are those of the
+// hungriest size, which does not matter for lists that cannot fill the chip anyway.
+struct ItxSegments { int off[20]; int grp[20]; };
+constexpr int itx_lds_ints_of(int tx) {
+    return (64 / cmax(cmin(tx_h(tx), 32), tx_w(tx))) * cmin(tx_h(tx), 32) * (tx_w(tx) + 1);
+}
+constexpr int itx_lds_max(int tx = 0) { return tx == 19 ? 0 : cmax(itx_lds_ints_of(tx), itx_lds_max(tx + 1)); }
+static_assert(itx_lds_ints_of(7) == itx_lds_ints<7>() && itx_lds_ints_of(4) == itx_lds_ints<4>(), "LDS sizing");
+
+template <typename pixel, typename coef>
+__global__ __launch_bounds__(64) void itx_multi_kernel(const DevPlanes dst, const Dav1dHipItxTask *__restrict__ tasks,
+                                                       const ItxSegments seg, coef *__restrict__ cf, const int bitdepth_max)
+{
+    __shared__ __attribute__((aligned(16))) int tmp_s[itx_lds_max()];
+    const int g = blockIdx.x;
+    int b = 0;
+#pragma unroll
+    for (int k = 1; k < 19; k++) b = g >= seg.grp[k] ? k : b;
+    const int first = seg.off[b], cnt = seg.off[b + 1] - first, group = g - seg.grp[b];
+#define CASE(T) case T: itx_body<T, pixel, coef>(dst, tasks + first, cnt, cf, bitdepth_max, group, tmp_s); break;
+    switch (b) {
+        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9)
+        CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18)
+    }
+#undef CASE
+}
+
 template <typename pixel, typename coef>
 hipError_t launch_tx(const int tx, const DevPlanes &dst, const Dav1dHipItxTask *tasks, const int n,
                      coef *cf, const int bitdepth_max, hipStream_t stream)
@@ -280,6 +325,31 @@ hipError_t launch_tx(const int tx, const DevPlanes &dst, const Dav1dHipItxTask *
 }
 
 } // namespace
+
+// tasks[] (device) = a whole size-binned list, off[b] .. off[b + 1] = the tasks of size b: one launch for all of them
+extern "C" int dav1d_hip_launch_itx_all(const DevPlanes *dst, int bpc, const Dav1dHipItxTask *tasks, const size_t *off,
+                                        void *coef, void *stream)
+{
+    ItxSegments seg;
+    int groups = 0;
+    for (int b = 0; b < 19; b++) {
+        const int lpb = cmax(cmin(tx_h(b), 32), tx_w(b)), bpw = 64 / lpb;
+        seg.off[b] = (int) off[b];
+        seg.grp[b] = groups;
+        groups += ((int) (off[b + 1] - off[b]) + bpw - 1) / bpw;
+    }
+    seg.off[19] = (int) off[19];
+    seg.grp[19] = groups;
+    if (!groups) return 0;
+    const int bitdepth_max = (1 << bpc) - 1;
+    if (bpc == 8)
+        hipLaunchKernelGGL((itx_multi_kernel<uint8_t, int16_t>), dim3(groups), dim3(64), 0, (hipStream_t) stream,
+                           *dst, tasks, seg, (int16_t *) coef, bitdepth_max);
+    else
+        hipLaunchKernelGGL((itx_multi_kernel<uint16_t, int32_t>), dim3(groups), dim3(64), 0, (hipStream_t) stream,
+                           *dst, tasks, seg, (int32_t *) coef, bitdepth_max);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
 
 // tasks[] (device) holds the tasks of ONE tx size; offsets are managed by capi.
 extern "C" int dav1d_hip_launch_itx_bin(const DevPlanes *dst, int bpc, int tx, const Dav1dHipItxTask *tasks,

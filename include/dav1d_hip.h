@@ -50,6 +50,20 @@ DAV1D_HIP_API int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream
 DAV1D_HIP_API void dav1d_hip_close(Dav1dHipContext *c);
 DAV1D_HIP_API int dav1d_hip_sync(Dav1dHipContext *c);
 DAV1D_HIP_API void *dav1d_hip_stream(Dav1dHipContext *c);
+
+/* Launch-bound sequences (the intra wavefront of a frame: ~100-200 small dependent launches; the reference runs the same
+ * chain block by block inside recon_b_intra, src/recon_tmpl.c:1176-1560) can be recorded once and replayed as one HIP
+ * graph.  Between begin and end, every *_list_run / *_run_batch call on this context is captured instead of executed; only
+ * calls that neither allocate, copy to/from the host nor synchronise may be made (the list-run entry points qualify; the
+ * *_batch conveniences and the first run of an mc list do not).  The graph replays the captured launches with the captured
+ * pointers: the pictures, arenas and lists they name must stay alive, and the contents they read are whatever is there at
+ * replay time.  -ENOSYS when the runtime cannot capture. */
+typedef struct Dav1dHipGraph Dav1dHipGraph;
+DAV1D_HIP_API int dav1d_hip_graph_begin(Dav1dHipContext *c);
+DAV1D_HIP_API int dav1d_hip_graph_end(Dav1dHipContext *c, Dav1dHipGraph **out);
+DAV1D_HIP_API int dav1d_hip_graph_launch(Dav1dHipContext *c, const Dav1dHipGraph *g);
+DAV1D_HIP_API size_t dav1d_hip_graph_nodes(const Dav1dHipGraph *g);      /* launches (and other nodes) recorded */
+DAV1D_HIP_API void dav1d_hip_graph_destroy(Dav1dHipContext *c, Dav1dHipGraph *g);
 DAV1D_HIP_API const char *dav1d_hip_version(void);
 /* Measurement aid: device time (HIP events on the context's stream) of the kernel launches of the most recent
  * itx_add / cdef / lf / ipred / lr / fg *_batch call on this context -- excludes the task upload the batch calls do. */

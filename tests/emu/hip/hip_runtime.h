@@ -51,7 +51,7 @@ extern dim3 blockDim, gridDim;
 typedef int hipError_t;
 typedef struct emu_stream_st *hipStream_t;
 typedef struct emu_event_st *hipEvent_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorUnknown = 999 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotSupported = 801, hipErrorUnknown = 999 };
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost,
                      hipMemcpyDeviceToDevice, hipMemcpyDefault };
 
@@ -169,4 +169,16 @@ static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = 0; return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+// stream capture: the emulator runs launches on the spot and cannot record them
+typedef struct emu_graph_st *hipGraph_t;
+typedef struct emu_graph_exec_st *hipGraphExec_t;
+typedef struct emu_graph_node_st *hipGraphNode_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
+static inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorNotSupported; }
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *g) { *g = 0; return hipErrorNotSupported; }
+static inline hipError_t hipGraphGetNodes(hipGraph_t, hipGraphNode_t *, size_t *n) { *n = 0; return hipErrorNotSupported; }
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t *, hipGraph_t, hipGraphNode_t *, char *, size_t) { return hipErrorNotSupported; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+static inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }

@@ -98,9 +98,10 @@ def oracle_intra(oracle, ip, planes, w, h, bpc):
     return coef
 
 
-def hip_intra(ctx, ip, pic, timed=False):
+def hip_intra(ctx, ip, pic, timed=False, graph=False):
     """Runs the intra pass from device-resident lists, every wave enqueued back to back on the context's stream
     (prediction of wave k, residuals of wave k, prediction of wave k + 1, ...), no host round trip in between.
+    graph: record the whole chain once (dav1d_hip_graph_*) and replay it as one HIP graph.
     timed (bench.py only; needs torch for the events): returns the device time of the whole pass in ms, else 0."""
     import ctypes as C
     coef = ctx.buffer_from(ip.coef)
@@ -108,15 +109,28 @@ def hip_intra(ctx, ip, pic, timed=False):
     ilists = [ctx.itx_list(b[1]) for b in ip.batches]
     lib = ctx.lib
     lib.dav1d_hip_sync(ctx.h)
+
+    def chain():
+        for k in range(len(ip.batches)):
+            plist.run_batch(k, pic)
+            ctx.run_itx_list(ilists[k], pic, coef)
+
+    g = None
+    if graph:
+        ctx.graph_begin()
+        chain()
+        g = ctx.graph_end()
+        hip_intra.last_nodes = int(lib.dav1d_hip_graph_nodes(g))
     ev = None
     if timed:
         import torch
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         stream = torch.cuda.ExternalStream(lib.dav1d_hip_stream(ctx.h))
         ev[0].record(stream)
-    for k in range(len(ip.batches)):
-        plist.run_batch(k, pic)
-        ctx.run_itx_list(ilists[k], pic, coef)
+    if g is not None:
+        ctx.graph_launch(g)
+    else:
+        chain()
     ms = 0.0
     if ev:
         ev[1].record(stream)
@@ -124,6 +138,8 @@ def hip_intra(ctx, ip, pic, timed=False):
         ms = ev[0].elapsed_time(ev[1])
     lib.dav1d_hip_sync(ctx.h)
     left = coef.download(ip.coef.dtype, len(ip.coef))
+    if g is not None:
+        ctx.graph_destroy(g)
     plist.destroy()
     for l in ilists:
         l.destroy()
@@ -153,3 +169,35 @@ def test_intra_wavefront_pass_matches_oracle(ctx, bpc):
         assert not len(bad), "plane %d differs at %s (%d px)" % (pl, bad[0], len(bad))
     assert any(np.any(want[pl] != planes[pl]) for pl in range(3))
     pic.free()
+
+
+@pytest.mark.gpu
+def test_intra_wavefront_pass_replayed_as_a_graph():
+    """The same chain recorded once and replayed through dav1d_hip_graph_*: identical picture."""
+    ctx = util.make_context("hip")
+    oracle = util.default_oracle()
+    bpc, w, h = 10, 1024, 576
+    frame = synth.make_frame(w, h, bpc, seed=191)
+    ip = synth.make_intra_pass(frame, seed=117)
+    rng = np.random.default_rng(4)
+    planes = synth.make_planes(rng, w, h, bpc, smooth=True)
+    pic = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+    for pl in range(3):
+        pic.upload(pl, planes[pl])
+    want = synth.copy_planes(planes)
+    oracle_intra(oracle, ip, want, w, h, bpc)
+    hip_intra(ctx, ip, pic, graph=True)
+    assert hip_intra.last_nodes >= len(ip.batches)
+    for pl in range(3):
+        vh, vw = (h, w) if pl == 0 else (h // 2, w // 2)
+        assert np.array_equal(pic.download(pl)[:vh, :vw], want[pl][:vh, :vw]), pl
+    pic.free()
+    ctx.close()
+
+
+def test_graph_capture_is_refused_where_it_cannot_work():
+    """The SIMT emulator runs launches on the spot: recording must fail loudly (-ENOSYS), not silently do nothing."""
+    ctx = util.make_context("emu")
+    with pytest.raises(api.HipError):
+        ctx.graph_begin()
+    ctx.close()
