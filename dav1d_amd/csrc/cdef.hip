@@ -90,14 +90,28 @@ __device__ __forceinline__ void load_window(int16_t *tmp, const pixel *src, cons
     }
 }
 
+// The same window when every neighbour exists and pixels are 16 bits wide: rows of WW * 2 bytes fetched as 8-byte pieces
+// (4-byte aligned in memory: block origins are multiples of 4 pixels, the window starts 2 pixels to the left), one piece
+// per lane, lanes [lane0, lane0 + (WW / 4) * (h + 4)).
+struct __attribute__((packed, aligned(4))) CdefU64 { uint32_t a, b; };
+template <int WW>
+__device__ __forceinline__ void load_window_fast(int16_t *tmp, const uint16_t *src, const int stride, const int x0, const int y0,
+                                                 const int h, const int item)
+{
+    constexpr int NP = WW / 4;
+    if (item < 0 || item >= NP * (h + 4)) return;
+    const int row = item / NP, part = item % NP;
+    const CdefU64 v = *reinterpret_cast<const CdefU64 *>(src + (y0 - 2 + row) * stride + x0 - 2 + 4 * part);
+    *reinterpret_cast<uint2 *>(tmp + row * 12 + 4 * part) = make_uint2(v.a, v.b);
+}
+
 template <typename pixel>
 __global__ __launch_bounds__(64) void cdef_kernel(const DevPlanes dst, const DevPlanes src, const Dav1dHipCdefTask *__restrict__ tasks,
                                                   const int n, const int damping, const int layout, const int bitdepth_max,
                                                   uint32_t *__restrict__ dirvar)
 {
-    __shared__ int16_t tmp[144], tmp2[144];
-    __shared__ int psum[2 * 8 + 2 * 15 + 4 * 11];    // hv[2][8], diag[2][15], alt[4][11]
-    __shared__ unsigned cost_s[8];
+    __shared__ __attribute__((aligned(8))) int16_t tmp[144], tmp2[144];
+    constexpr bool HBD = sizeof(pixel) == 2;
 
     const int ti = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x);
     if (ti >= n) return;
@@ -113,52 +127,73 @@ __global__ __launch_bounds__(64) void cdef_kernel(const DevPlanes dst, const Dev
     const int lw = raw_ ? (t.flags & 2 ? 4 : 8) : 8, lh = raw_ ? (t.flags & 4 ? 4 : 8) : 8;
     const pixel *sy = reinterpret_cast<const pixel *>(src.data[lpl]);
     const int x0 = raw_ ? t.bx : t.bx * 8, y0 = raw_ ? t.by : t.by * 8;   // raw: pixel coordinates
-    if (lw == 8) load_window<pixel, 12>(tmp, sy, src.stride[lpl], x0, y0, lh, edges, lane);
+    if (HBD && edges == 15 && lw == 8) load_window_fast<12>(tmp, reinterpret_cast<const uint16_t *>(sy), src.stride[lpl], x0, y0, lh, lane);
+    else if (lw == 8) load_window<pixel, 12>(tmp, sy, src.stride[lpl], x0, y0, lh, edges, lane);
     else load_window<pixel, 8>(tmp, sy, src.stride[lpl], x0, y0, lh, edges, lane);
-    for (int i = lane; i < 90; i += 64) psum[i] = 0;
     dv::wave_sync();
 
     // ---- direction search (only when a primary strength is in play, src/cdef_apply_tmpl.c:208-212)
+    // cdef_find_dir_c (src/cdef_tmpl.c:239-319) squares 90 partial sums of the block along 8 directions.  Here every
+    // 16-lane row of the wave owns one of the eight partial-sum arrays (two passes of four), lane r of a row gathers
+    // element r from the window in LDS (at most 8 steps of one or two pixels), squares and weighs it, and a butterfly
+    // over the row adds the array's cost.  No LDS atomics, no serial tail.
     int dir = 0;
     unsigned var = 0;
     const bool raw = t.flags & 1;      // DSP-level call: explicit dir / strengths, luma path only, no adjust
     if (!raw && (t.y_pri || t.uv_pri || dirvar)) {
-        const int x = lane & 7, y = lane >> 3;
-        const int px = (tmp[(y + 2) * 12 + x + 2] >> bitdepth_min_8) - 128;
-        int *hv = psum, *diag = psum + 16, *alt = psum + 46;
-        atomicAdd(&diag[0 * 15 + y + x], px);
-        atomicAdd(&alt[0 * 11 + y + (x >> 1)], px);
-        atomicAdd(&hv[0 * 8 + y], px);
-        atomicAdd(&alt[1 * 11 + 3 + y - (x >> 1)], px);
-        atomicAdd(&diag[1 * 15 + 7 + y - x], px);
-        atomicAdd(&alt[2 * 11 + 3 - (y >> 1) + x], px);
-        atomicAdd(&hv[1 * 8 + x], px);
-        atomicAdd(&alt[3 * 11 + (y >> 1) + x], px);
-        dv::wave_sync();
-        if (lane < 8) {
-            static const unsigned short div_table[7] = { 840, 420, 280, 210, 168, 140, 120 };
-            unsigned c = 0;
-            const int nn = lane;
-            if (nn == 2 || nn == 6) {
-                const int *p = hv + (nn == 6) * 8;
-                for (int k = 0; k < 8; k++) c += p[k] * p[k];
-                c *= 105;
-            } else if (nn == 0 || nn == 4) {
-                const int *p = diag + (nn == 4) * 15;
-                for (int k = 0; k < 7; k++) c += (p[k] * p[k] + p[14 - k] * p[14 - k]) * div_table[k];
-                c += p[7] * p[7] * 105;
+        const int r = lane & 15, g = lane >> 4;
+        unsigned cost[8];
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            // pixel of step k: x = cx + sx * k + hx * (k >> 1), y = k (hv[0]: y = r); `two`: also x + 1
+            //   pass 0: diag[0] (idx y + x), diag[1] (7 + y - x), alt[0] (y + (x >> 1)), alt[1] (3 + y - (x >> 1))
+            //   pass 1: alt[2] (3 - (y >> 1) + x), alt[3] ((y >> 1) + x), hv[0] (y), hv[1] (x)
+            int cx, sx, hx;
+            bool two = false, rows = false;
+            if (pass == 0) {
+                cx = g == 0 ? r : g == 1 ? 7 - r : g == 2 ? 2 * r : 6 - 2 * r;
+                sx = g == 0 ? -1 : g == 1 ? 1 : g == 2 ? -2 : 2;
+                hx = 0;
+                two = g >= 2;
             } else {
-                const int *p = alt + (nn >> 1) * 11;
-                for (int m = 0; m < 5; m++) c += p[3 + m] * p[3 + m];
-                c *= 105;
-                for (int m = 0; m < 3; m++) c += (p[m] * p[m] + p[10 - m] * p[10 - m]) * div_table[2 * m + 1];
+                cx = g == 0 ? r - 3 : g == 1 ? r : g == 2 ? 0 : r;
+                sx = g == 2 ? 1 : 0;
+                hx = g == 0 ? 1 : g == 1 ? -1 : 0;
+                rows = g == 2;
             }
-            cost_s[nn] = c;
+            int p = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int x = cx + sx * k + hx * (k >> 1), y = rows ? r : k;
+                if (x >= 0 && x < 8 && y < 8) {
+                    const int16_t *c = tmp + (y + 2) * 12 + x + 2;
+                    p += (c[0] >> bitdepth_min_8) - 128;
+                    if (two) p += (c[1] >> bitdepth_min_8) - 128;
+                }
+            }
+            // weights: 105 for the full-length lines, 840 / (k + 1) for the short ones (div_table, src/cdef_tmpl.c:279)
+            const bool is_diag = pass == 0 && g < 2, is_hv = pass == 1 && g >= 2;
+            int short_k = -1;                                   // index into div_table, -1 = weight 105
+            if (is_diag) short_k = r < 7 ? r : r > 7 ? 14 - r : -1;
+            else if (!is_hv) short_k = r < 3 ? 2 * r + 1 : r > 7 ? 2 * (10 - r) + 1 : -1;
+            const unsigned long long div_lo = 840ull | 420ull << 16 | 280ull << 32 | 210ull << 48, div_hi = 168ull | 140ull << 16 | 120ull << 32;
+            const unsigned wgt = short_k < 0 ? 105u : (unsigned) ((short_k < 4 ? div_lo >> (16 * short_k) : div_hi >> (16 * (short_k - 4))) & 0xffff);
+            unsigned c = (unsigned) (p * p) * wgt;
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) c += (unsigned) __shfl_xor((int) c, m);
+            // direction numbering: diag[0] 0, alt[0] 1, hv[0] 2, alt[1] 3, diag[1] 4, alt[2] 5, hv[1] 6, alt[3] 7
+            const unsigned c0 = (unsigned) __shfl((int) c, 0), c1 = (unsigned) __shfl((int) c, 16);
+            const unsigned c2 = (unsigned) __shfl((int) c, 32), c3 = (unsigned) __shfl((int) c, 48);
+            if (pass == 0) { cost[0] = c0; cost[4] = c1; cost[1] = c2; cost[3] = c3; }
+            else           { cost[5] = c0; cost[7] = c1; cost[2] = c2; cost[6] = c3; }
         }
-        dv::wave_sync();
-        unsigned best = cost_s[0];
-        for (int k = 1; k < 8; k++) if (cost_s[k] > best) { best = cost_s[k]; dir = k; }
-        var = (best - cost_s[dir ^ 4]) >> 10;
+        unsigned best = cost[0];
+#pragma unroll
+        for (int k = 1; k < 8; k++) if (cost[k] > best) { best = cost[k]; dir = k; }
+        unsigned opp = cost[4];                                 // cost[dir ^ 4], picked by compares (never indexed)
+#pragma unroll
+        for (int k = 1; k < 8; k++) opp = dir == k ? cost[k ^ 4] : opp;
+        var = (best - opp) >> 10;
         if (dirvar && lane == 0) dirvar[tis] = (uint32_t) dir | (var << 3);
     }
 
@@ -197,7 +232,11 @@ __global__ __launch_bounds__(64) void cdef_kernel(const DevPlanes dst, const Dev
         if (t.uv_pri) uvdir = layout == DAV1D_HIP_LAYOUT_I422 ? (int) ((uv422 >> (4 * dir)) & 15) : dir;
         const int cx0 = x0 >> ss_hor, cy0 = y0 >> ss_ver;
         dv::wave_sync();
-        if (w == 8) {
+        if (HBD && edges == 15 && w == 4) {
+            // 4-wide chroma: 2 pieces x (h + 4) rows per plane, U on lanes 0 .. 31, V on lanes 32 .. 63
+            load_window_fast<8>(lane < 32 ? tmp : tmp2, reinterpret_cast<const uint16_t *>(src.data[lane < 32 ? 1 : 2]),
+                                src.stride[lane < 32 ? 1 : 2], cx0, cy0, h, lane & 31);
+        } else if (w == 8) {
             load_window<pixel, 12>(tmp, reinterpret_cast<const pixel *>(src.data[1]), src.stride[1], cx0, cy0, h, edges, lane);
             load_window<pixel, 12>(tmp2, reinterpret_cast<const pixel *>(src.data[2]), src.stride[2], cx0, cy0, h, edges, lane);
         } else {
