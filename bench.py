@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--packed", action="store_true", help="feed the residuals in the sparse wire format (DAV1D_HIP_ITX_PACKED)")
     ap.add_argument("--no-full", action="store_true", help="skip the full-DSP-table leg (deblock, CDEF, restoration, film grain)")
+    ap.add_argument("--two-phase", action="store_true",
+                    help="run the step as dav1d_hip_inter_list_run + dav1d_hip_itx_list_run (every residual after every prediction) "
+                         "instead of the pipelined dav1d_hip_recon_list_run")
     ap.add_argument("--shard", choices=["frames", "tile-cols"], default="frames",
                     help="N > 1: frames = one independent frame stream per GPU (weak scaling, no data-path collective); "
                          "tile-cols = GPU g reconstructs tile column g of the SAME frame and one all-gather per frame rebuilds "
@@ -139,7 +142,8 @@ def main():
         frame.mc, frame.comp, frame.itx = whole.mc[mine[0]], whole.comp[mine[1]], whole.itx[mine[2]]
         frame.n_samples = int((np.asarray(synth.TX_W, np.int64)[frame.itx["tx"]] * np.asarray(synth.TX_H, np.int64)[frame.itx["tx"]]).sum())
     itx_tasks, coef_host = synth.pack_frame_coefs(frame) if a.packed else (frame.itx, frame.coef)
-    inter_list, itx_list = ctx.inter_list(frame.mc, frame.comp), ctx.itx_list(itx_tasks)
+    inter_list, itx_list = ctx.inter_list(frame.mc, frame.comp), ctx.itx_list(itx_tasks)      # also used by the per-kernel timing below
+    recon_list = None if a.two_phase else ctx.recon_list(dsts[0], frame.mc, frame.comp, itx_tasks)
     prep = torch.zeros(frame.prep_elems, dtype=torch.int16, device="cuda")
     tdt = torch.int16 if bpc == 8 else torch.int32
     pristine = torch.from_numpy(coef_host).to("cuda")
@@ -168,8 +172,11 @@ def main():
 
     def step(i):
         d = dsts[i % NDST]
-        ctx.run_inter_list(inter_list, d, refs, prep.data_ptr())
-        ctx.run_itx_list(itx_list, d, arenas[i].data_ptr())
+        if recon_list is not None:
+            recon_list.run(d, refs, prep.data_ptr(), arenas[i].data_ptr())
+        else:
+            ctx.run_inter_list(inter_list, d, refs, prep.data_ptr())
+            ctx.run_itx_list(itx_list, d, arenas[i].data_ptr())
         if tile_cols:
             dd.allgather_tile_columns(d, cols, rank, world)
 
@@ -402,6 +409,8 @@ def main():
                "config": {"workload": "%dx%d 4:2:0 %d-bit inter frame, itx+mc recon (SURVEY §8d C2 mix 64/32/16/8/4 = "
                                       "20/30/30/15/5 %% by area, 25 %% compound avg, all blocks coded, 3 refs); "
                                       "lists resident in HBM" % (w, h, bpc),
+                          "step": ("inter list, then itx list" if a.two_phase else
+                                   "recon list: residual launches wait only for the prediction launches under their blocks (2 streams)"),
                           "frames_per_step": 1, "parallelism": ("tile-columns x%d + one all-gather per frame" if tile_cols else "frame-parallel x%d") % world,
                           "tasks": {"mc": int(len(frame.mc)), "comp": int(len(frame.comp)), "itx": int(len(frame.itx))},
                           "coef_format": "packed: eob + 1 scan-order values per block" if a.packed else "dense cf arena (reference layout)",

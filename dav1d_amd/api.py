@@ -137,6 +137,31 @@ class _InterList:
             self.h = None
 
 
+class _ReconList:
+    """dav1d_hip_recon_list_*: predictions + residuals of a frame, pipelined per tile shape / transform size."""
+
+    def __init__(self, ctx, geometry, mc_tasks, comp_tasks, itx_tasks):
+        self.ctx = ctx
+        m = np.ascontiguousarray(mc_tasks, dtype=MC_TASK)
+        k = np.ascontiguousarray(comp_tasks, dtype=COMP_TASK)
+        t = np.ascontiguousarray(itx_tasks, dtype=ITX_TASK)
+        self.h = C.c_void_p()
+        _chk(ctx.lib.dav1d_hip_recon_list_create(ctx.h, C.byref(self.h), C.byref(geometry.pic), m.ctypes.data, len(m),
+                                                 k.ctypes.data, len(k), t.ctypes.data, len(t)), "recon_list_create")
+
+    def run(self, dst, refs, prep, coef, mask=None):
+        arr = (Picture * len(refs))(*[r.pic for r in refs])
+        p = None if prep is None else (prep.ptr if hasattr(prep, "ptr") else prep)
+        m = None if mask is None else (mask.ptr if hasattr(mask, "ptr") else mask)
+        _chk(self.ctx.lib.dav1d_hip_recon_list_run(self.ctx.h, self.h, C.byref(dst.pic), arr, len(refs), p, m,
+                                                   coef.ptr if hasattr(coef, "ptr") else coef), "recon_list_run")
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.dav1d_hip_recon_list_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
 class Context:
     """dav1d_hip_open() wrapper.  `stream` is a raw hipStream_t (int) or None."""
 
@@ -271,6 +296,9 @@ class Context:
 
     def comp_list(self, tasks):
         return _List(self, "comp", tasks, COMP_TASK)
+
+    def recon_list(self, geometry, mc_tasks, comp_tasks, itx_tasks):
+        return _ReconList(self, geometry, mc_tasks, comp_tasks, itx_tasks)
 
     def inter_list(self, mc_tasks, comp_tasks):
         return _InterList(self, mc_tasks, comp_tasks)

@@ -17,6 +17,7 @@ struct Dav1dHipContext {
     enum { N_SIDE = 6 };
     hipStream_t side[N_SIDE];
     hipEvent_t ev_fork, ev_join[N_SIDE];
+    hipEvent_t ev_bin[16];      // "this tile shape's predictions are in the picture" (recon list pipeline)
     bool concurrent;
     // measurement aid: device time of the kernel launches of the most recent *_batch call (dav1d_hip_last_kernel_ms)
     hipEvent_t ev_t0, ev_t1;

@@ -35,6 +35,8 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
             hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
     }
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
+    for (int i = 0; i < 16; i++)
+        if (hipEventCreateWithFlags(&c->ev_bin[i], hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
     if (hipEventCreate(&c->ev_t0) != hipSuccess || hipEventCreate(&c->ev_t1) != hipSuccess) { delete c; return -ENODEV; }
     c->last_ms = 0.f;
     *out = c;
@@ -47,6 +49,7 @@ void dav1d_hip_close(Dav1dHipContext *c) {
     if (c->scratch) hipFree(c->scratch);
     for (int i = 0; i < Dav1dHipContext::N_SIDE; i++) { hipStreamSynchronize(c->side[i]); hipStreamDestroy(c->side[i]); hipEventDestroy(c->ev_join[i]); }
     hipEventDestroy(c->ev_fork);
+    for (int i = 0; i < 16; i++) hipEventDestroy(c->ev_bin[i]);
     hipEventDestroy(c->ev_t0); hipEventDestroy(c->ev_t1);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -746,12 +749,42 @@ struct Dav1dHipInterList {
     Dav1dHipMcList *mc;
     Dav1dHipCompList *comp;
     size_t n_fused;
+    // with a picture geometry (recon lists): which launches write each 4x4 cell of a plane — bit b = the mc launch of tile
+    // shape b, bit 15 = the compound / blend launch
+    std::vector<uint16_t> writers[3];
+    int cell_stride[3], stride_px[3];
 };
+
+// marks the 4x4 cells of a w x h rectangle at pixel offset `off` of a plane
+static void mark_cells(Dav1dHipInterList *l, int plane, uint32_t off, int w, int h, uint16_t bit) {
+    const int sp = l->stride_px[plane], cs = l->cell_stride[plane];
+    if (sp <= 0) return;
+    const int x = (int) (off % (uint32_t) sp), y = (int) (off / (uint32_t) sp);
+    for (int cy = y >> 2; cy <= (y + h - 1) >> 2; cy++)
+        for (int cx = x >> 2; cx <= (x + w - 1) >> 2; cx++) {
+            const size_t i = (size_t) cy * cs + cx;
+            if (cx < cs && i < l->writers[plane].size()) l->writers[plane][i] |= bit;
+        }
+}
+
+extern "C" {
+
+} // extern "C"
+
+static int inter_list_create_geo(Dav1dHipContext *c, Dav1dHipInterList **out, const Dav1dHipMcTask *mc, size_t n_mc,
+                                 const Dav1dHipCompTask *comp, size_t n_comp, const Dav1dHipPicture *geom);
 
 extern "C" {
 
 int dav1d_hip_inter_list_create(Dav1dHipContext *c, Dav1dHipInterList **out, const Dav1dHipMcTask *mc, size_t n_mc,
                                 const Dav1dHipCompTask *comp, size_t n_comp) {
+    return inter_list_create_geo(c, out, mc, n_mc, comp, n_comp, nullptr);
+}
+
+} // extern "C"
+
+static int inter_list_create_geo(Dav1dHipContext *c, Dav1dHipInterList **out, const Dav1dHipMcTask *mc, size_t n_mc,
+                                 const Dav1dHipCompTask *comp, size_t n_comp, const Dav1dHipPicture *geom) {
     if (!out || (!mc && n_mc) || (!comp && n_comp)) return -EINVAL;
     *out = nullptr;
     // prep offset -> producing PREP task, and how many compound inputs read that offset
@@ -795,12 +828,29 @@ int dav1d_hip_inter_list_create(Dav1dHipContext *c, Dav1dHipInterList **out, con
     Dav1dHipInterList *l = new (std::nothrow) Dav1dHipInterList();
     if (!l) return -ENOMEM;
     l->mc = nullptr; l->comp = nullptr; l->n_fused = n_fused;
+    for (int p = 0; p < 3; p++) l->cell_stride[p] = l->stride_px[p] = 0;
+    if (geom) {
+        const int bps = geom->bpc > 8 ? 2 : 1;
+        for (int p = 0; p < 3; p++) {
+            if (!geom->p[p].data) continue;
+            l->stride_px[p] = (int) (geom->p[p].stride / bps);
+            l->cell_stride[p] = (l->stride_px[p] + 3) >> 2;
+            l->writers[p].assign((size_t) l->cell_stride[p] * (size_t) ((geom->p[p].h + 127 + 3) >> 2), 0);
+        }
+        for (int b = 0; b < MC_BINS; b++)
+            for (const McTile &t : bins[b])
+                if (t.kind == MCT_PUT || t.kind == MCT_AVG || t.kind == MCT_WAVG)
+                    mark_cells(l, t.plane, t.dst_off + (uint32_t) t.oy * (uint32_t) l->stride_px[t.plane] + t.ox, t.w, t.h, (uint16_t) (1u << b));
+        for (const Dav1dHipCompTask &k : rest) mark_cells(l, k.plane, k.dst_off, k.w, k.h, 1u << 15);
+    }
     int rc = mc_list_from_bins(c, &l->mc, bins);
     if (!rc) rc = dav1d_hip_comp_list_create(c, &l->comp, rest.data(), rest.size());
     if (rc) { dav1d_hip_mc_list_destroy(c, l->mc); delete l; return rc; }
     *out = l;
     return 0;
 }
+
+extern "C" {
 
 void dav1d_hip_inter_list_destroy(Dav1dHipContext *c, Dav1dHipInterList *l) {
     if (!l) return;
@@ -1161,3 +1211,130 @@ extern "C" int dav1d_hip_fg_apply(Dav1dHipContext *c, const Dav1dHipPicture *dst
     hipFree(dev);
     return rc;
 }
+
+// ------------------------------------------------------------------ recon list: predictions and residuals pipelined
+//
+// dav1d_hip_inter_list_run followed by dav1d_hip_itx_list_run makes every residual wait for every prediction.  The residual
+// launch of one transform size only needs the prediction launches whose tiles lie under its blocks; which ones those are is
+// worked out here once, on a 4x4-cell map of the picture.  At run time the prediction launches go down the context's stream
+// in the order largest tile shape first, each followed by an event; the residual launches go down a side stream, largest
+// transform first, each waiting for the events of its own predecessors only.  The memory-bound predictions of the small
+// shapes then overlap with the arithmetic-bound 64- and 32-point transforms instead of queueing in front of them.
+struct Dav1dHipReconList {
+    Dav1dHipInterList *inter;
+    Dav1dHipItxList *itx;
+    uint16_t dep[19];          // per transform size: bits of the launches (see Dav1dHipInterList::writers) it has to wait for
+    int stride_px[3];
+};
+
+extern "C" {
+
+int dav1d_hip_recon_list_create(Dav1dHipContext *c, Dav1dHipReconList **out, const Dav1dHipPicture *geometry,
+                                const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
+                                const Dav1dHipItxTask *itx, size_t n_itx) {
+    if (!c || !out || !geometry) return -EINVAL;
+    *out = nullptr;
+    Dav1dHipReconList *l = new (std::nothrow) Dav1dHipReconList();
+    if (!l) return -ENOMEM;
+    l->inter = nullptr; l->itx = nullptr;
+    int rc = inter_list_create_geo(c, &l->inter, mc, n_mc, comp, n_comp, geometry);
+    if (!rc) rc = dav1d_hip_itx_list_create(c, &l->itx, itx, n_itx);
+    if (rc) { if (l->inter) dav1d_hip_inter_list_destroy(c, l->inter); delete l; return rc; }
+    for (int b = 0; b < 19; b++) l->dep[b] = 0;
+    for (int p = 0; p < 3; p++) l->stride_px[p] = l->inter->stride_px[p];
+    for (size_t i = 0; i < n_itx; i++) {
+        const Dav1dHipItxTask &t = itx[i];
+        const int sp = l->stride_px[t.plane], cs = l->inter->cell_stride[t.plane];
+        if (sp <= 0) { l->dep[t.tx] = 0xffff; continue; }
+        const int x = (int) (t.dst_off % (uint32_t) sp), y = (int) (t.dst_off / (uint32_t) sp);
+        const std::vector<uint16_t> &wr = l->inter->writers[t.plane];
+        uint16_t m = 0;
+        for (int cy = y >> 2; cy <= (y + k_tx_h[t.tx] - 1) >> 2; cy++)
+            for (int cx = x >> 2; cx <= (x + k_tx_w[t.tx] - 1) >> 2; cx++) {
+                const size_t j = (size_t) cy * cs + cx;
+                m |= (cx < cs && j < wr.size()) ? wr[j] : (uint16_t) 0xffff;      // off the map: wait for everything
+            }
+        l->dep[t.tx] |= m;
+    }
+    // the maps are only needed for the dependency masks
+    for (int p = 0; p < 3; p++) std::vector<uint16_t>().swap(l->inter->writers[p]);
+    *out = l;
+    return 0;
+}
+
+void dav1d_hip_recon_list_destroy(Dav1dHipContext *c, Dav1dHipReconList *l) {
+    if (!l) return;
+    dav1d_hip_inter_list_destroy(c, l->inter);
+    dav1d_hip_itx_list_destroy(c, l->itx);
+    delete l;
+}
+
+int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, const Dav1dHipPicture *dst,
+                             const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask, void *coef) {
+    if (!c || !l || !dst || !refs) return -EINVAL;
+    const int bps = dst->bpc > 8 ? 2 : 1;
+    for (int p = 0; p < 3; p++)
+        if (l->stride_px[p] && dst->p[p].stride / bps != l->stride_px[p]) return -EINVAL;    // not the geometry the list was made for
+    const Dav1dHipMcList *ml = l->inter->mc;
+    // DAV1D_HIP_RECON_PIPELINE = smallest residual list worth two streams (0: always pipeline, -1: never); read per call so that
+    // tests can switch it
+    const char *env = getenv("DAV1D_HIP_RECON_PIPELINE");
+    const long min_tasks = env ? atol(env) : 16384;
+    if (min_tasks < 0 || !c->concurrent || mc_fused_min_bin() < MC_BINS || (long) l->itx->n < min_tasks) {
+        int rc = dav1d_hip_inter_list_run(c, l->inter, dst, refs, n_refs, prep, mask);
+        if (!rc) rc = dav1d_hip_itx_list_run(c, l->itx, dst, coef);
+        return rc;
+    }
+    if (n_refs < 1 || n_refs > 8 || (ml->n && ml->max_ref >= n_refs)) return -EINVAL;
+    const DevPlanes dp = dev_planes(dst);
+    DevPlanes rp[8];
+    for (int i = 0; i < n_refs; i++) {
+        if (refs[i].bpc != dst->bpc) return -EINVAL;
+        rp[i] = dev_planes(&refs[i]);
+    }
+    int rc = mc_regroup(c, const_cast<Dav1dHipMcList *>(ml), rp, n_refs);
+    if (rc) return rc;
+    // DAV1D_HIP_RECON_LANES: side streams the residual launches are dealt over.  Measured (8K 10-bit): 1 lane 0.379 ms,
+    // 2 lanes 0.394, 3 lanes 0.407, 5 lanes 0.420 per frame — residual launches running next to each other take bandwidth from
+    // the predictions they are waiting for; one in-order residual stream keeps the pipeline a pipeline.
+    const char *le = getenv("DAV1D_HIP_RECON_LANES");
+    const int n_lanes = le ? std::max(1, std::min((int) Dav1dHipContext::N_SIDE, atoi(le))) : 1;
+    hipStream_t sm = c->stream;
+    (void) hipEventRecord(c->ev_fork, sm);
+    for (int i = 0; i < n_lanes; i++) (void) hipStreamWaitEvent(c->side[i], c->ev_fork, 0);
+    uint16_t launched = 0;
+    for (int b = MC_BINS - 1; b >= 0 && !rc; b--) {
+        const size_t cnt = ml->off[b + 1] - ml->off[b];
+        if (!cnt) continue;
+        rc = dav1d_hip_launch_mc_bin(&dp, rp, n_refs, dst->bpc, b, ml->dev + ml->off[b], (int) cnt, prep, sm);
+        (void) hipEventRecord(c->ev_bin[b], sm);
+        launched |= (uint16_t) (1u << b);
+    }
+    if (!rc && l->inter->comp->n) {
+        rc = dav1d_hip_comp_list_run(c, l->inter->comp, dst, prep, mask);
+        (void) hipEventRecord(c->ev_bin[15], sm);
+        launched |= 1u << 15;
+    }
+    static const uint8_t order[19] = { 4, 11, 12, 17, 18, 3, 9, 10, 15, 16, 2, 7, 8, 13, 14, 1, 5, 6, 0 };
+    uint16_t waited[Dav1dHipContext::N_SIDE] = { 0 };
+    int lane = 0;
+    for (int k = 0; k < 19 && !rc; k++) {
+        const int b = order[k];
+        const size_t cnt = l->itx->off[b + 1] - l->itx->off[b];
+        if (!cnt) continue;
+        hipStream_t si = c->side[lane];
+        const uint16_t need = (uint16_t) (l->dep[b] & launched & ~waited[lane]);   // a lane is in order: one wait per event is enough
+        for (int e = 0; e < 16; e++)
+            if (need >> e & 1) (void) hipStreamWaitEvent(si, c->ev_bin[e], 0);
+        waited[lane] |= need;
+        rc = dav1d_hip_launch_itx_bin(&dp, dst->bpc, b, l->itx->dev + l->itx->off[b], (int) cnt, coef, si);
+        lane = (lane + 1) % n_lanes;
+    }
+    for (int i = 0; i < n_lanes; i++) {
+        (void) hipEventRecord(c->ev_join[i], c->side[i]);
+        (void) hipStreamWaitEvent(sm, c->ev_join[i], 0);
+    }
+    return rc;
+}
+
+} // extern "C"

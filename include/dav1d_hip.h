@@ -258,6 +258,19 @@ DAV1D_HIP_API int dav1d_hip_inter_list_create(Dav1dHipContext *c, Dav1dHipInterL
                                               const Dav1dHipMcTask *host_mc, size_t n_mc,
                                               const Dav1dHipCompTask *host_comp, size_t n_comp);
 DAV1D_HIP_API void dav1d_hip_inter_list_destroy(Dav1dHipContext *c, Dav1dHipInterList *l);
+
+/* Predictions and residuals of one frame (or tile-sbrow set) as ONE list: what dav1d_hip_inter_list_run followed by
+ * dav1d_hip_itx_list_run does, except that the residual launch of a transform size waits only for the prediction launches
+ * whose tiles lie under its blocks (worked out at creation on a 4x4-cell map of `geometry`, a picture of the size and strides
+ * the list will run on), so the memory-bound small predictions overlap with the arithmetic-bound large transforms.  The
+ * counterpart of the reference's per-block order mc -> itxfm_add inside recon_b_inter (src/recon_tmpl.c:1557-2000). */
+typedef struct Dav1dHipReconList Dav1dHipReconList;
+DAV1D_HIP_API int dav1d_hip_recon_list_create(Dav1dHipContext *c, Dav1dHipReconList **out, const Dav1dHipPicture *geometry,
+                                              const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
+                                              const Dav1dHipItxTask *itx, size_t n_itx);
+DAV1D_HIP_API int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, const Dav1dHipPicture *dst,
+                                           const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask, void *coef);
+DAV1D_HIP_API void dav1d_hip_recon_list_destroy(Dav1dHipContext *c, Dav1dHipReconList *l);
 DAV1D_HIP_API int dav1d_hip_inter_list_run(Dav1dHipContext *c, const Dav1dHipInterList *l,
                                            const Dav1dHipPicture *dst, const Dav1dHipPicture *refs,
                                            int n_refs, int16_t *prep, uint8_t *mask);

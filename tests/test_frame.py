@@ -59,7 +59,7 @@ def oracle_frame(oracle, frame, dst_planes, ref_planes_list, threads=1, timing=N
     return dst, prep, coef
 
 
-def hip_frame(ctx, frame, dst_planes, ref_planes_list, fused=False, packed=False):
+def hip_frame(ctx, frame, dst_planes, ref_planes_list, fused=False, packed=False, recon=False):
     w, h, bpc = frame.w, frame.h, frame.bpc
     dst = ctx.picture(w, h, api.LAYOUT_I420, bpc)
     for pl in range(3):
@@ -74,7 +74,11 @@ def hip_frame(ctx, frame, dst_planes, ref_planes_list, fused=False, packed=False
     prep.zero()
     itx_tasks, coef_host = synth.pack_frame_coefs(frame) if packed else (frame.itx, frame.coef)
     coef = ctx.buffer_from(coef_host)
-    if fused:
+    if recon:
+        rl = ctx.recon_list(dst, frame.mc, frame.comp, itx_tasks)
+        rl.run(dst, refs, prep, coef)
+        rl.destroy()
+    elif fused:
         il = ctx.inter_list(frame.mc, frame.comp)
         assert il.n_fused == len(frame.comp)        # the synthetic frames only hold avg compounds
         ctx.run_inter_list(il, dst, refs, prep)
@@ -83,7 +87,8 @@ def hip_frame(ctx, frame, dst_planes, ref_planes_list, fused=False, packed=False
         ctx.mc_batch(dst, refs, frame.mc, prep)
         if len(frame.comp):
             ctx.comp_batch(dst, frame.comp, prep, None)
-    ctx.itx_add_batch(dst, itx_tasks, coef)
+    if not recon:
+        ctx.itx_add_batch(dst, itx_tasks, coef)
     out = [dst.download(pl) for pl in range(3)]
     oprep = prep.download(np.int16, frame.prep_elems)
     ocoef = coef.download(coef_host.dtype, len(coef_host))
@@ -141,6 +146,39 @@ def test_frame_from_packed_coefficients(ctx, bpc):
     got, _, _ = hip_frame(ctx, frame, dst0, refs, fused=True, packed=True)
     for pl in range(3):
         assert np.array_equal(got[pl], want[pl]), pl
+
+
+@pytest.mark.parametrize("pipeline", ["0", "-1"], ids=["pipelined", "sequential"])
+@pytest.mark.parametrize("bpc", [8, 10])
+def test_recon_list_matches_oracle(ctx, bpc, pipeline, monkeypatch):
+    """dav1d_hip_recon_list_*: predictions and residuals as one list, the residual launch of a transform size waiting only
+    for the prediction launches under its blocks (two streams) — and the same list run strictly one phase after the other."""
+    monkeypatch.setenv("DAV1D_HIP_RECON_PIPELINE", pipeline)
+    w, h = (512, 128) if ctx.backend == "emu" else (1280, 1024)
+    frame = synth.make_frame(w, h, bpc, seed=515 + bpc, edge_frac=0.1)
+    rng = np.random.default_rng(9 + bpc)
+    refs = [synth.make_planes(rng, w, h, bpc) for _ in range(frame.n_refs)]
+    dst0 = synth.make_planes(rng, w, h, bpc, smooth=False)
+    want, _, want_coef = oracle_frame(util.default_oracle(), frame, dst0, refs)
+    got, _, got_coef = hip_frame(ctx, frame, dst0, refs, recon=True)
+    for pl in range(3):
+        bad = np.argwhere(got[pl] != want[pl])
+        assert not len(bad), "plane %d differs at %s (%d px)" % (pl, bad[0], len(bad))
+    assert np.array_equal(got_coef, want_coef)
+
+
+def test_recon_list_refuses_another_geometry(ctx):
+    frame = synth.make_frame(256, 128, 8, seed=2)
+    a = ctx.picture(256, 128, api.LAYOUT_I420, 8)
+    b = ctx.picture(1024, 128, api.LAYOUT_I420, 8)
+    rl = ctx.recon_list(a, frame.mc, frame.comp, frame.itx)
+    coef = ctx.buffer_from(frame.coef)
+    prep = ctx.buffer(max(frame.prep_elems, 8) * 2)
+    with pytest.raises(api.HipError):
+        rl.run(b, [b] * frame.n_refs, prep, coef)
+    rl.destroy()
+    for o in (a, b, coef, prep):
+        o.free()
 
 
 @pytest.mark.parametrize("mode", ["1", "2"], ids=["all-shapes", "wide-shapes"])
