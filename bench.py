@@ -264,6 +264,21 @@ def main():
                          "achieved": round(path_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                          "frac": round(path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                 "kernels_ms": {k[0]: round(k[1], 4) for k in kernels}}
+        # measured HBM bytes of the whole step (sum of the committed per-kernel PMC figures) next to the algorithmic ones:
+        # what the memory system really moved per frame, and the rate that is at this step time
+        tr = [pmc_traffic(k[0], w, h, bpc) for k in kernels]
+        if tr and all(v is not None for v in tr):
+            roof["path"]["hbm_traffic_bytes_per_frame"] = int(sum(tr))
+            roof["path"]["hbm_traffic_achieved"] = round(sum(tr) / (ms_per_step * 1e-3) / 1e9, 1)
+            roof["path"]["hbm_traffic_frac"] = round(sum(tr) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        # the dominant mc kernel's reads including the filter halo ((w + 7) x (h + 7) window per predicted block, which
+        # random motion vectors cannot share between blocks): the floor of its fetch traffic on this workload
+        if dom[0].startswith("mc_"):
+            b = [k[0] for k in kernels].index(dom[0])
+            tw_, th_ = (int(v) for v in dom[0][3:].split("x"))
+            sel_m = (np.minimum(frame.mc["w"], 64) == tw_) & (np.minimum(frame.mc["h"], 16) == th_)
+            n_tiles = int((((frame.mc["w"][sel_m].astype(np.int64) + tw_ - 1) // tw_) * ((frame.mc["h"][sel_m].astype(np.int64) + th_ - 1) // th_)).sum())
+            roof["window_bytes_per_launch"] = int(n_tiles * (tw_ + 7) * (th_ + 7) * P + dom[2] // 2)
 
         # ---- parity gate + CPU baseline: the oracle replays the SAME lists on the host
         cpu = None

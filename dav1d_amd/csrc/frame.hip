@@ -129,13 +129,17 @@ int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *ma
     Dav1dHipContext *c = f->c;
     int rc = 0;
     if (!f->mc.empty() || !f->comp.empty()) {
+        // predictions and residuals as one pipelined list (the residual launch of a transform size waits only for the
+        // prediction launches under its blocks)
         if (!f->n_refs) return -EINVAL;
-        Dav1dHipInterList *il = nullptr;
-        rc = dav1d_hip_inter_list_create(c, &il, f->mc.data(), f->mc.size(), f->comp.data(), f->comp.size());
-        if (!rc) rc = dav1d_hip_inter_list_run(c, il, &f->cur, f->refs, f->n_refs, prep, mask);
-        if (il) dav1d_hip_inter_list_destroy(c, il);
+        Dav1dHipReconList *rl = nullptr;
+        rc = dav1d_hip_recon_list_create(c, &rl, &f->cur, f->mc.data(), f->mc.size(), f->comp.data(), f->comp.size(),
+                                         f->itx.data(), f->itx.size());
+        if (!rc) rc = dav1d_hip_recon_list_run(c, rl, &f->cur, f->refs, f->n_refs, prep, mask, coef);
+        if (rl) dav1d_hip_recon_list_destroy(c, rl);
+    } else if (!f->itx.empty()) {
+        rc = dav1d_hip_itx_add_batch(c, &f->cur, f->itx.data(), f->itx.size(), coef);
     }
-    if (!rc && !f->itx.empty()) rc = dav1d_hip_itx_add_batch(c, &f->cur, f->itx.data(), f->itx.size(), coef);
     if (!rc && !f->lf.empty()) {
         if (!f->lvl) return -EINVAL;
         rc = dav1d_hip_lf_batch(c, &f->cur, f->lf.data(), f->lf.size(), f->lvl, f->b4_stride, f->lut_e, f->lut_i);
