@@ -203,6 +203,27 @@ def main():
     # whole-job luma Mpixels/s: N frames per step (one per GPU) when sharded by frame, ONE frame per step over tile columns
     value = (whole.luma_pixels * a.steps / dt if tile_cols else dd.job_throughput(frame.luma_pixels, a.steps, dt, world)) / 1e6
 
+    # ---- the same step fed with the sparse coefficient format (DAV1D_HIP_ITX_PACKED): reported next to `value`, which keeps
+    # the dense reference layout SURVEY 8d prices; rank 0 of a one-GPU run only, and checked against the same oracle pictures
+    packed_leg = None
+    if rank == 0 and world == 1 and not a.packed and not a.two_phase:
+        p_tasks, p_coef = synth.pack_frame_coefs(frame)
+        p_list = ctx.recon_list(dsts[0], frame.mc, frame.comp, p_tasks)
+        p_arena = torch.from_numpy(p_coef).to("cuda")
+        for i in range(a.warmup):
+            p_list.run(dsts[i % NDST], refs, prep.data_ptr(), p_arena.data_ptr())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            p_list.run(dsts[i % NDST], refs, prep.data_ptr(), p_arena.data_ptr())
+        torch.cuda.synchronize()
+        dt_p = time.perf_counter() - t0
+        p_out = [dsts[(a.steps - 1) % NDST].download(pl) for pl in range(3)]
+        packed_leg = {"ms_per_step": round(dt_p / a.steps * 1e3, 4), "value": round(frame.luma_pixels * a.steps / dt_p / 1e6, 1),
+                      "unit": "Mpixels/s", "coef_bytes_per_frame": int(p_coef.nbytes), "_pictures": p_out}
+        p_list.destroy()
+        del p_arena
+
     out = None
     if rank == 0:
         # ---- per-kernel durations (HIP events on the launch stream), one instrumented step
@@ -302,6 +323,10 @@ def main():
                 check = "bit-exact vs %s oracle (3 planes of the last frame)" % oracle.which if ok else "MISMATCH"
                 if not ok:
                     raise SystemExit("bench: GPU output differs from the oracle")
+                if packed_leg is not None:
+                    if not all(np.array_equal(packed_leg["_pictures"][pl], want[0][pl]) for pl in range(3)):
+                        raise SystemExit("bench: the packed-coefficient step differs from the oracle")
+                    packed_leg["parity"] = "bit-exact vs %s oracle" % oracle.which
             cpu = {"value": round(frame.luma_pixels * reps / t_cpu / 1e6, 2), "unit": "Mpixels/s", "cores": 1,
                    "kind": "reference" if oracle.which == "ref" else "port",
                    "sample": "%d full %dx%d frame(s) of the same task lists through the oracle's C DSP entries, "
@@ -432,6 +457,10 @@ def main():
                           "coef_bytes_per_frame": int(coef_host.nbytes), "coef_h2d_ms_per_frame": h2d_ms,
                           "samples_per_frame": frame.n_samples, "parity": check, "gen_seconds": round(t_gen, 1)},
                "roofline": roof, "cpu_baseline": cpu, "full_table": full}
+        if packed_leg is not None:
+            packed_leg.pop("_pictures", None)
+            packed_leg.setdefault("parity", "skipped")
+            out["packed_coefficients"] = packed_leg
         print(json.dumps(out))
     barrier()
     if world > 1:
