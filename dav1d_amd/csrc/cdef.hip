@@ -19,10 +19,12 @@ namespace {
 
 __device__ __forceinline__ int ulog2(unsigned v) { return 31 - __clz((int) v); }
 
-__device__ __forceinline__ int constrain(const int diff, const int threshold, const int shift) {
-    const int adiff = diff < 0 ? -diff : diff;
-    const int v = dv::imin(adiff, dv::imax(0, threshold - (adiff >> shift)));
-    return diff < 0 ? -v : v;
+// constrain() of src/cdef_tmpl.c:56-62 = clamp(diff, -lim, lim) with lim = max(0, threshold - (|diff| >> shift))
+__device__ __forceinline__ int constrain(const int p, const int px, const int threshold, const int shift) {
+    const int diff = p - px;
+    const int adiff = dv::imax(diff, -diff);
+    const int lim = dv::sub_floor0(threshold, adiff >> shift);
+    return dv::med3(diff, -lim, lim);
 }
 
 // filters pixel (x, y) of a block whose padded window sits in tmp (12-wide rows, origin at tmp[2*12+2])
@@ -42,8 +44,8 @@ __device__ __forceinline__ int cdef_px(const int16_t *tmp, const int x, const in
         for (int k = 0; k < 2; k++) {
             const int off = dirs[2 * 2 + k];
             const int p0 = c[off], p1 = c[-off];
-            sum += tap * constrain(p0 - px, pri, pri_shift);
-            sum += tap * constrain(p1 - px, pri, pri_shift);
+            sum += tap * constrain(p0, px, pri, pri_shift);
+            sum += tap * constrain(p1, px, pri, pri_shift);
             tap = (tap & 3) | 2;
             mn = min(mn, (unsigned) p0); mx = dv::imax(mx, p0);
             mn = min(mn, (unsigned) p1); mx = dv::imax(mx, p1);
@@ -56,10 +58,10 @@ __device__ __forceinline__ int cdef_px(const int16_t *tmp, const int x, const in
             const int off2 = dirs[4 * 2 + k], off3 = dirs[0 * 2 + k];
             const int s0 = c[off2], s1 = c[-off2], s2 = c[off3], s3 = c[-off3];
             const int tap = 2 - k;
-            sum += tap * constrain(s0 - px, sec, sec_shift);
-            sum += tap * constrain(s1 - px, sec, sec_shift);
-            sum += tap * constrain(s2 - px, sec, sec_shift);
-            sum += tap * constrain(s3 - px, sec, sec_shift);
+            sum += tap * constrain(s0, px, sec, sec_shift);
+            sum += tap * constrain(s1, px, sec, sec_shift);
+            sum += tap * constrain(s2, px, sec, sec_shift);
+            sum += tap * constrain(s3, px, sec, sec_shift);
             mn = min(mn, (unsigned) s0); mx = dv::imax(mx, s0);
             mn = min(mn, (unsigned) s1); mx = dv::imax(mx, s1);
             mn = min(mn, (unsigned) s2); mx = dv::imax(mx, s2);
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(64) void cdef_kernel(const DevPlanes dst, const Dev
                                                   uint32_t *__restrict__ dirvar)
 {
     __shared__ __attribute__((aligned(8))) int16_t tmp[144], tmp2[144];
+    __shared__ int16_t pdir[64];
     constexpr bool HBD = sizeof(pixel) == 2;
 
     const int ti = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x);
@@ -141,6 +144,12 @@ __global__ __launch_bounds__(64) void cdef_kernel(const DevPlanes dst, const Dev
     unsigned var = 0;
     const bool raw = t.flags & 1;      // DSP-level call: explicit dir / strengths, luma path only, no adjust
     if (!raw && (t.y_pri || t.uv_pri || dirvar)) {
+        // the samples the search sums, (px >> (bitdepth - 8)) - 128, once per pixel instead of once per gather
+        {
+            const int x = lane & 7, y = lane >> 3;
+            pdir[lane] = (int16_t) ((tmp[(y + 2) * 12 + x + 2] >> bitdepth_min_8) - 128);
+        }
+        dv::wave_sync();
         const int r = lane & 15, g = lane >> 4;
         unsigned cost[8];
 #pragma unroll
@@ -165,10 +174,10 @@ __global__ __launch_bounds__(64) void cdef_kernel(const DevPlanes dst, const Dev
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int x = cx + sx * k + hx * (k >> 1), y = rows ? r : k;
-                if (x >= 0 && x < 8 && y < 8) {
-                    const int16_t *c = tmp + (y + 2) * 12 + x + 2;
-                    p += (c[0] >> bitdepth_min_8) - 128;
-                    if (two) p += (c[1] >> bitdepth_min_8) - 128;
+                if ((unsigned) x < 8u && y < 8) {
+                    const int16_t *c = pdir + y * 8 + x;
+                    p += c[0];
+                    if (two) p += c[1];
                 }
             }
             // weights: 105 for the full-length lines, 840 / (k + 1) for the short ones (div_table, src/cdef_tmpl.c:279)

@@ -30,6 +30,25 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c) {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b), c, false);
 #endif
 }
+// single-instruction forms the compiler does not find on its own for runtime bounds
+__device__ __forceinline__ int med3(int v, int lo, int hi) {           // clamp(v, lo, hi) for lo <= hi
+#ifdef DAV1D_HIP_EMU
+    return v < lo ? lo : v > hi ? hi : v;
+#else
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+#endif
+}
+__device__ __forceinline__ int sub_floor0(int a, int b) {               // max(0, a - b) for a, b >= 0
+#ifdef DAV1D_HIP_EMU
+    return a > b ? a - b : 0;
+#else
+    int r;
+    asm("v_sub_u32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#endif
+}
 __device__ __forceinline__ uint32_t pack2(int lo, int hi) { return (uint32_t) (lo & 0xffff) | ((uint32_t) hi << 16); }
 
 // LDS hand-off between the lanes of ONE wave (no other wave reads the data): order the
