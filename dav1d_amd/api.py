@@ -381,6 +381,10 @@ class FrameInFlight:
                                               C.byref(grain_out.pic) if grain_out is not None else None), "frame_end")
         return filtered
 
+    def post_bands(self):
+        """Bands the post filters of the last end() were pipelined over (0: stage by stage)."""
+        return int(self.ctx.lib.dav1d_hip_frame_post_bands(self.h))
+
     def destroy(self):
         if self.h:
             self.ctx.lib.dav1d_hip_frame_destroy(self.h)

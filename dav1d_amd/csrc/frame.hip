@@ -6,6 +6,7 @@
 // Out-of-place stages land in pictures the frame owns; host code only: every kernel is reached through the batch API.
 #include "capi.h"
 #include <string.h>
+#include <stdlib.h>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -31,7 +32,160 @@ struct Dav1dHipFrame {
     int is_id;
     Dav1dHipPicture tmp[2];          // CDEF output, restoration output (allocated on first use)
     bool have_tmp[2];
+    int post_bands;                  // bands the post filters of the last dav1d_hip_frame_end ran in (0: stage by stage)
 };
+
+static int frame_tmp(Dav1dHipFrame *f, int i) {
+    if (f->have_tmp[i]) return 0;
+    const int rc = dav1d_hip_picture_alloc(f->c, &f->tmp[i], f->cur.p[0].w, f->cur.p[0].h, f->cur.layout, f->cur.bpc);
+    if (!rc) f->have_tmp[i] = true;
+    return rc;
+}
+
+// ---------------------------------------------------------------- post filters, pipelined over bands of superblock rows
+//
+// deblock -> CDEF -> restoration of a whole frame one after the other leaves the arithmetic-bound CDEF kernel and the
+// memory-bound deblocking / restoration kernels waiting for each other.  The reference overlaps them by superblock row
+// (filter_sbrow_* tasks, src/thread_task.c:783-851: CDEF of row n runs once deblocking of row n + 1 is done, restoration one
+// row behind that); the same here with bands of a few superblock rows: deblocking of band b on the context's stream, CDEF of
+// band b on a side stream once deblocking of band b + 1 is through (its horizontal edges still change the last rows of band
+// b), restoration of band b on a second side stream once CDEF of band b + 1 is through (it reads 3 rows below the band).
+// Out of place as before: CDEF writes tmp[0] from cur, restoration writes tmp[1].  Returns 1 when the frame does not qualify
+// (too small, a deblocking column task crossing a band, units not covering the frame): the caller then runs stage by stage.
+static int post_filters_pipelined(Dav1dHipFrame *f, const Dav1dHipPicture **last_out) {
+    Dav1dHipContext *c = f->c;
+    const bool has_lf = !f->lf.empty(), has_cdef = !f->cdef.empty(), has_lr = !f->lr.empty();
+    if (!c->concurrent || (int) has_lf + has_cdef + has_lr < 2) return 1;
+    // DAV1D_HIP_POST_BANDS = bands per frame.  Off unless asked for: measured on MI355X (8K 10-bit frame: deblock 0.15 + CDEF
+    // 0.58 + restoration 0.26 = 0.99 ms stage by stage) the banded pipeline takes 1.14 ms with 3 bands, 1.21 with 6, 1.78 with
+    // 17 — every cross-stream event costs a release / acquire of the caches, about 45 us per band, more than the overlap of
+    // the arithmetic-bound CDEF with its memory-bound neighbours returns.  (The recon list, 5 events per frame, does gain.)
+    const char *env = getenv("DAV1D_HIP_POST_BANDS");
+    const int want = env ? atoi(env) : 0;
+    if (want < 2) return 1;
+    const int H = f->cur.p[0].h, W = f->cur.p[0].w, layout = f->cur.layout, bps = f->cur.bpc > 8 ? 2 : 1;
+    const int ss_ver = layout == DAV1D_HIP_LAYOUT_I420, ss_hor = layout != DAV1D_HIP_LAYOUT_I444;
+    // band height: whole pairs of 128-row superblock rows (a chroma column task of 32 units covers 256 luma rows in 4:2:0)
+    const int sbpairs = (H + 255) / 256, band_h = 256 * ((sbpairs + want - 1) / want), nb = (H + band_h - 1) / band_h;
+    if (nb < 3) return 1;
+    auto band_of = [&](int luma_y) { const int b = luma_y / band_h; return b < 0 ? 0 : b >= nb ? nb - 1 : b; };
+    // ---- band of every task; anything irregular sends the frame down the stage-by-stage path
+    std::vector<int> lf_b(f->lf.size()), cdef_b(f->cdef.size()), lr_b(f->lr.size());
+    for (size_t i = 0; i < f->lf.size(); i++) {
+        const Dav1dHipLfTask &t = f->lf[i];
+        if (t.plane > 2 || t.dir > 1 || t.lvl_comp > 3) return -EINVAL;
+        const int sv = t.plane ? ss_ver : 0, stride = (int) (f->cur.p[t.plane].stride / bps);
+        if (stride <= 0) return -EINVAL;
+        const int y = (int) (t.dst_off / (uint32_t) stride) << sv;
+        lf_b[i] = band_of(y);
+        if (t.dir == 0) {        // a column of units running down: must end inside its band
+            const uint32_t m = t.vmask[0] | t.vmask[1] | t.vmask[2];
+            const int units = m ? 32 - __builtin_clz(m) : 0;
+            if (units && band_of(y + ((4 * units) << sv) - 1) != lf_b[i]) return 1;
+        }
+    }
+    if (has_cdef && f->cdef.size() != (size_t) ((W + 7) / 8) * (size_t) ((H + 7) / 8)) return 1;   // unlisted units would need the copy
+    for (size_t i = 0; i < f->cdef.size(); i++) {
+        const Dav1dHipCdefTask &t = f->cdef[i];
+        if (t.edges > 15 || t.plane > 2 || t.dir > 7) return -EINVAL;
+        if (t.flags & 1) return 1;
+        cdef_b[i] = band_of(t.by * 8);
+    }
+    long long area[3] = { 0, 0, 0 };
+    for (size_t i = 0; i < f->lr.size(); i++) {
+        const Dav1dHipLrTask &t = f->lr[i];
+        if (t.plane > 2 || t.edges > 15 || !t.w || t.w > 384 || !t.h || t.h > 64 || t.type > DAV1D_HIP_LR_SGR_MIX) return -EINVAL;
+        lr_b[i] = band_of((int) t.y << (t.plane ? ss_ver : 0));
+        area[t.plane] += (long long) t.w * t.h;
+    }
+    if (has_lr)
+        for (int p = 0; p < (layout == DAV1D_HIP_LAYOUT_I400 ? 1 : 3); p++)
+            if (area[p] != (long long) f->cur.p[p].w * f->cur.p[p].h) return 1;
+    (void) ss_hor;
+    // ---- ordered copies: lf (band, columns before rows), cdef (band), lr (band, Wiener before self-guided)
+    std::vector<Dav1dHipLfTask> lf_s(f->lf.size());
+    std::vector<Dav1dHipCdefTask> cdef_s(f->cdef.size());
+    std::vector<Dav1dHipLrTask> lr_s(f->lr.size());
+    std::vector<size_t> lf_off(2 * nb + 1, 0), cdef_off(nb + 1, 0), lr_off(2 * nb + 1, 0);
+    for (size_t i = 0; i < f->lf.size(); i++) lf_off[2 * lf_b[i] + f->lf[i].dir + 1]++;
+    for (size_t i = 0; i < f->cdef.size(); i++) cdef_off[cdef_b[i] + 1]++;
+    for (size_t i = 0; i < f->lr.size(); i++) lr_off[2 * lr_b[i] + (f->lr[i].type > DAV1D_HIP_LR_WIENER5) + 1]++;
+    for (int k = 0; k < 2 * nb; k++) { lf_off[k + 1] += lf_off[k]; lr_off[k + 1] += lr_off[k]; }
+    for (int k = 0; k < nb; k++) cdef_off[k + 1] += cdef_off[k];
+    {
+        std::vector<size_t> pos(lf_off.begin(), lf_off.end() - 1);
+        for (size_t i = 0; i < f->lf.size(); i++) lf_s[pos[2 * lf_b[i] + f->lf[i].dir]++] = f->lf[i];
+        pos.assign(cdef_off.begin(), cdef_off.end() - 1);
+        for (size_t i = 0; i < f->cdef.size(); i++) cdef_s[pos[cdef_b[i]]++] = f->cdef[i];
+        pos.assign(lr_off.begin(), lr_off.end() - 1);
+        for (size_t i = 0; i < f->lr.size(); i++) lr_s[pos[2 * lr_b[i] + (f->lr[i].type > DAV1D_HIP_LR_WIENER5)]++] = f->lr[i];
+    }
+    if (has_lf && !f->lvl) return -EINVAL;
+    int rc = 0;
+    if (has_cdef) rc = frame_tmp(f, 0);
+    if (!rc && has_lr) rc = frame_tmp(f, 1);
+    if (rc) return rc;
+    const size_t bytes_lf = lf_s.size() * sizeof(Dav1dHipLfTask), bytes_cdef = cdef_s.size() * sizeof(Dav1dHipCdefTask),
+                 bytes_lr = lr_s.size() * sizeof(Dav1dHipLrTask);
+    const size_t o_cdef = (bytes_lf + 255) & ~(size_t) 255, o_lr = (o_cdef + bytes_cdef + 255) & ~(size_t) 255;
+    uint8_t *dev = nullptr;
+    if (hipMalloc((void **) &dev, o_lr + bytes_lr + 256) != hipSuccess) return -ENOMEM;
+    if (bytes_lf) rc = dav1d_hip_upload(c, dev, lf_s.data(), bytes_lf);
+    if (!rc && bytes_cdef) rc = dav1d_hip_upload(c, dev + o_cdef, cdef_s.data(), bytes_cdef);
+    if (!rc && bytes_lr) rc = dav1d_hip_upload(c, dev + o_lr, lr_s.data(), bytes_lr);
+    const Dav1dHipLfTask *d_lf = reinterpret_cast<const Dav1dHipLfTask *>(dev);
+    const Dav1dHipCdefTask *d_cdef = reinterpret_cast<const Dav1dHipCdefTask *>(dev + o_cdef);
+    const Dav1dHipLrTask *d_lr = reinterpret_cast<const Dav1dHipLrTask *>(dev + o_lr);
+    std::vector<hipEvent_t> ev(2 * nb, nullptr);
+    for (int k = 0; k < 2 * nb && !rc; k++) rc = hip_rc(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+    const Dav1dHipPicture *cdef_out = has_cdef ? &f->tmp[0] : &f->cur;
+    if (!rc) {
+        const DevPlanes cur = dev_planes(&f->cur), t0 = dev_planes(&f->tmp[0]), t1 = dev_planes(&f->tmp[1]), co = dev_planes(cdef_out);
+        hipStream_t sa = c->stream, sb = c->side[0], sc = c->side[1];
+        (void) hipEventRecord(c->ev_t0, sa);          // dav1d_hip_last_kernel_ms(): device time of the pipelined section
+        (void) hipEventRecord(c->ev_fork, sa);
+        (void) hipStreamWaitEvent(sb, c->ev_fork, 0);
+        (void) hipStreamWaitEvent(sc, c->ev_fork, 0);
+        // the three stages are issued band by band, interleaved, so that no stream ever waits for an event that is recorded
+        // later in issue order than its own next launch needs
+        for (int b = 0; b < nb + 2 && !rc; b++) {
+            if (has_lf && b < nb) {
+                const size_t v0 = lf_off[2 * b], v1 = lf_off[2 * b + 1], v2 = lf_off[2 * b + 2];
+                if (v1 > v0) rc = dav1d_hip_launch_lf(&cur, f->cur.bpc, d_lf + v0, (int) (v1 - v0), f->lvl, (int) f->b4_stride, f->lut_e, f->lut_i, sa);
+                if (!rc && v2 > v1) rc = dav1d_hip_launch_lf(&cur, f->cur.bpc, d_lf + v1, (int) (v2 - v1), f->lvl, (int) f->b4_stride, f->lut_e, f->lut_i, sa);
+                (void) hipEventRecord(ev[b], sa);
+            }
+            const int bc = b - 1;                    // CDEF runs one band behind deblocking
+            if (has_cdef && bc >= 0 && bc < nb && !rc) {
+                if (has_lf) (void) hipStreamWaitEvent(sb, ev[bc + 1 < nb ? bc + 1 : nb - 1], 0);
+                const size_t n = cdef_off[bc + 1] - cdef_off[bc];
+                if (n) rc = dav1d_hip_launch_cdef(&t0, &cur, f->cur.bpc, layout, d_cdef + cdef_off[bc], (int) n, f->cdef_damping, nullptr, sb);
+                (void) hipEventRecord(ev[nb + bc], sb);
+            }
+            const int br = b - 2;                    // restoration one band behind CDEF
+            if (has_lr && br >= 0 && br < nb && !rc) {
+                const int dep = br + 1 < nb ? br + 1 : nb - 1;
+                if (has_cdef) (void) hipStreamWaitEvent(sc, ev[nb + dep], 0);
+                else if (has_lf) (void) hipStreamWaitEvent(sc, ev[dep], 0);
+                const size_t w0 = lr_off[2 * br], w1 = lr_off[2 * br + 1], w2 = lr_off[2 * br + 2];
+                if (w1 > w0) rc = dav1d_hip_launch_wiener(&t1, &co, &cur, f->cur.bpc, d_lr + w0, (int) (w1 - w0), sc);
+                if (!rc && w2 > w1) rc = dav1d_hip_launch_sgr(&t1, &co, &cur, f->cur.bpc, d_lr + w1, (int) (w2 - w1), sc);
+            }
+        }
+        (void) hipEventRecord(c->ev_join[0], sb);
+        (void) hipEventRecord(c->ev_join[1], sc);
+        (void) hipStreamWaitEvent(sa, c->ev_join[0], 0);
+        (void) hipStreamWaitEvent(sa, c->ev_join[1], 0);
+        (void) hipEventRecord(c->ev_t1, sa);
+    }
+    (void) hipStreamSynchronize(c->stream);
+    if (!rc) { c->last_ms = 0.f; (void) hipEventElapsedTime(&c->last_ms, c->ev_t0, c->ev_t1); }
+    for (hipEvent_t e : ev) if (e) (void) hipEventDestroy(e);
+    (void) hipFree(dev);
+    *last_out = has_lr ? &f->tmp[1] : cdef_out;
+    if (!rc) f->post_bands = nb;
+    return rc;
+}
 
 extern "C" {
 
@@ -51,6 +205,7 @@ int dav1d_hip_frame_begin(Dav1dHipContext *c, Dav1dHipFrame **out, const Dav1dHi
     f->have_grain = false;
     f->is_id = 0;
     f->have_tmp[0] = f->have_tmp[1] = false;
+    f->post_bands = 0;
     *out = f;
     return 0;
 }
@@ -97,13 +252,6 @@ int dav1d_hip_frame_set_filters(Dav1dHipFrame *f, const uint8_t *lvl, ptrdiff_t 
     return 0;
 }
 
-static int frame_tmp(Dav1dHipFrame *f, int i) {
-    if (f->have_tmp[i]) return 0;
-    const int rc = dav1d_hip_picture_alloc(f->c, &f->tmp[i], f->cur.p[0].w, f->cur.p[0].h, f->cur.layout, f->cur.bpc);
-    if (!rc) f->have_tmp[i] = true;
-    return rc;
-}
-
 static int copy_picture(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src) {
     if (dst->alloc_size && dst->alloc_size == src->alloc_size && dst->alloc && src->alloc)
         return hip_rc(hipMemcpyAsync(dst->alloc, src->alloc, src->alloc_size, hipMemcpyDeviceToDevice, c->stream));
@@ -140,28 +288,37 @@ int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *ma
     } else if (!f->itx.empty()) {
         rc = dav1d_hip_itx_add_batch(c, &f->cur, f->itx.data(), f->itx.size(), coef);
     }
-    if (!rc && !f->lf.empty()) {
-        if (!f->lvl) return -EINVAL;
-        rc = dav1d_hip_lf_batch(c, &f->cur, f->lf.data(), f->lf.size(), f->lvl, f->b4_stride, f->lut_e, f->lut_i);
-    }
     const Dav1dHipPicture *last = &f->cur;
-    if (!rc && !f->cdef.empty()) {
-        rc = frame_tmp(f, 0);
-        if (!rc) rc = copy_picture(c, &f->tmp[0], &f->cur);       // units that are not listed keep their pixels
-        if (!rc) rc = dav1d_hip_cdef_batch(c, &f->tmp[0], &f->cur, f->cdef.data(), f->cdef.size(), f->cdef_damping, nullptr);
-        last = &f->tmp[0];
-    }
-    if (!rc && !f->lr.empty()) {
-        rc = frame_tmp(f, 1);
-        if (!rc) rc = copy_picture(c, &f->tmp[1], last);
-        if (!rc) rc = dav1d_hip_lr_batch(c, &f->tmp[1], last, &f->cur, f->lr.data(), f->lr.size());
-        last = &f->tmp[1];
+    int piped = 1;
+    f->post_bands = 0;
+    if (!rc) piped = post_filters_pipelined(f, &last);
+    if (piped < 0) return piped;
+    if (piped == 1) {        // stage by stage
+        last = &f->cur;
+        if (!rc && !f->lf.empty()) {
+            if (!f->lvl) return -EINVAL;
+            rc = dav1d_hip_lf_batch(c, &f->cur, f->lf.data(), f->lf.size(), f->lvl, f->b4_stride, f->lut_e, f->lut_i);
+        }
+        if (!rc && !f->cdef.empty()) {
+            rc = frame_tmp(f, 0);
+            if (!rc) rc = copy_picture(c, &f->tmp[0], &f->cur);       // units that are not listed keep their pixels
+            if (!rc) rc = dav1d_hip_cdef_batch(c, &f->tmp[0], &f->cur, f->cdef.data(), f->cdef.size(), f->cdef_damping, nullptr);
+            last = &f->tmp[0];
+        }
+        if (!rc && !f->lr.empty()) {
+            rc = frame_tmp(f, 1);
+            if (!rc) rc = copy_picture(c, &f->tmp[1], last);
+            if (!rc) rc = dav1d_hip_lr_batch(c, &f->tmp[1], last, &f->cur, f->lr.data(), f->lr.size());
+            last = &f->tmp[1];
+        }
     }
     if (!rc && filtered) *filtered = *last;
     if (!rc && f->have_grain && grain_out) rc = dav1d_hip_fg_apply(c, grain_out, last, &f->grain, f->is_id);
     if (!rc) rc = dav1d_hip_sync(c);
     return rc;
 }
+
+int dav1d_hip_frame_post_bands(const Dav1dHipFrame *f) { return f ? f->post_bands : 0; }
 
 void dav1d_hip_frame_destroy(Dav1dHipFrame *f) {
     if (!f) return;

@@ -518,6 +518,11 @@ DAV1D_HIP_API int dav1d_hip_frame_set_filters(Dav1dHipFrame *f, const uint8_t *l
  * CDEF + restoration (owned by the frame unless it is `cur`); grain_out (optional) receives the film grain output. */
 DAV1D_HIP_API int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask, Dav1dHipPicture *filtered,
                                       const Dav1dHipPicture *grain_out);
+/* How the post filters of the last dav1d_hip_frame_end ran: the number of superblock-row bands deblocking, CDEF and
+ * restoration were pipelined over (three streams, CDEF one band behind deblocking, restoration one behind CDEF — the
+ * reference's filter_sbrow_* ordering, src/thread_task.c:783-851), or 0 when they ran stage by stage (small frames, units
+ * not covering the frame, or DAV1D_HIP_POST_BANDS unset: the banded mode is an opt-in experiment, see frame.hip). */
+DAV1D_HIP_API int dav1d_hip_frame_post_bands(const Dav1dHipFrame *f);
 DAV1D_HIP_API void dav1d_hip_frame_destroy(Dav1dHipFrame *f);
 
 /* ------------------------------------------------- reference-signature table */

@@ -13,9 +13,12 @@ import test_postchain
 
 
 @pytest.mark.parametrize("bpc", [8, 10, 12])
-def test_frame_in_flight_matches_oracle(ctx, bpc):
+@pytest.mark.parametrize("bands", [8, 0], ids=["banded", "staged"])
+def test_frame_in_flight_matches_oracle(ctx, bpc, bands, monkeypatch):
+    """bands: the post filters pipelined over superblock-row bands (three streams) / one stage after the other."""
+    monkeypatch.setenv("DAV1D_HIP_POST_BANDS", str(bands))
     oracle = util.default_oracle()
-    w, h = (256, 192) if ctx.backend == "emu" else (1024, 576)
+    w, h = (64, 768) if ctx.backend == "emu" else (1024, 1152)
     frame = synth.make_frame(w, h, bpc, seed=31 + bpc, edge_frac=0.1)
     post = synth.make_post_filters(frame, seed=9 + bpc)
     rng = np.random.default_rng(5)
@@ -62,6 +65,7 @@ def test_frame_in_flight_matches_oracle(ctx, bpc):
     # loop restoration units must keep raster order: one submission per plane and stripe row
     f.submit_filter_sbrow(post.lf, post.cdef, post.lr)
     filtered = f.end(coef, prep, None, grain)
+    assert f.post_bands() == (min(bands, (h + 255) // 256) if bands else 0)
     out = api.DevicePicture.view(ctx, filtered, w, h, api.LAYOUT_I420, bpc)
     for pl in range(3):
         vh, vw = (h, w) if pl == 0 else (h // 2, w // 2)
