@@ -1302,31 +1302,38 @@ int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, con
     hipStream_t sm = c->stream;
     (void) hipEventRecord(c->ev_fork, sm);
     for (int i = 0; i < n_lanes; i++) (void) hipStreamWaitEvent(c->side[i], c->ev_fork, 0);
-    uint16_t launched = 0;
-    for (int b = MC_BINS - 1; b >= 0 && !rc; b--) {
-        const size_t cnt = ml->off[b + 1] - ml->off[b];
-        if (!cnt) continue;
-        rc = dav1d_hip_launch_mc_bin(&dp, rp, n_refs, dst->bpc, b, ml->dev + ml->off[b], (int) cnt, prep, sm);
-        (void) hipEventRecord(c->ev_bin[b], sm);
-        launched |= (uint16_t) (1u << b);
-    }
-    if (!rc && l->inter->comp->n) {
-        rc = dav1d_hip_comp_list_run(c, l->inter->comp, dst, prep, mask);
-        (void) hipEventRecord(c->ev_bin[15], sm);
-        launched |= 1u << 15;
-    }
+    // The prediction launches run in order on one stream, so a residual launch only has to wait for the LAST launch it depends
+    // on — and only those launches get an event (a cross-stream event is a cache release / acquire: not free).
     static const uint8_t order[19] = { 4, 11, 12, 17, 18, 3, 9, 10, 15, 16, 2, 7, 8, 13, 14, 1, 5, 6, 0 };
-    uint16_t waited[Dav1dHipContext::N_SIDE] = { 0 };
+    int seq[16], n_seq = 0;                              // launch order of the prediction side: bins descending, then the compound launch
+    for (int b = MC_BINS - 1; b >= 0; b--) if (ml->off[b + 1] > ml->off[b]) seq[n_seq++] = b;
+    if (l->inter->comp->n) seq[n_seq++] = 15;
+    int last_dep[19];                                    // per transform size: position in seq[] of its last dependency, -1 none
+    bool wanted[16] = { false };
+    for (int b = 0; b < 19; b++) {
+        last_dep[b] = -1;
+        if (l->itx->off[b + 1] == l->itx->off[b]) continue;
+        for (int k = 0; k < n_seq; k++) if (l->dep[b] >> seq[k] & 1) last_dep[b] = k;
+        if (last_dep[b] >= 0) wanted[last_dep[b]] = true;
+    }
+    for (int k = 0; k < n_seq && !rc; k++) {
+        const int b = seq[k];
+        if (b == 15) rc = dav1d_hip_comp_list_run(c, l->inter->comp, dst, prep, mask);
+        else rc = dav1d_hip_launch_mc_bin(&dp, rp, n_refs, dst->bpc, b, ml->dev + ml->off[b], (int) (ml->off[b + 1] - ml->off[b]), prep, sm);
+        if (wanted[k]) (void) hipEventRecord(c->ev_bin[k], sm);
+    }
+    int waited[Dav1dHipContext::N_SIDE];
+    for (int i = 0; i < Dav1dHipContext::N_SIDE; i++) waited[i] = -1;
     int lane = 0;
     for (int k = 0; k < 19 && !rc; k++) {
         const int b = order[k];
         const size_t cnt = l->itx->off[b + 1] - l->itx->off[b];
         if (!cnt) continue;
         hipStream_t si = c->side[lane];
-        const uint16_t need = (uint16_t) (l->dep[b] & launched & ~waited[lane]);   // a lane is in order: one wait per event is enough
-        for (int e = 0; e < 16; e++)
-            if (need >> e & 1) (void) hipStreamWaitEvent(si, c->ev_bin[e], 0);
-        waited[lane] |= need;
+        if (last_dep[b] > waited[lane]) {                // a lane is in order too: an earlier wait covers everything before it
+            (void) hipStreamWaitEvent(si, c->ev_bin[last_dep[b]], 0);
+            waited[lane] = last_dep[b];
+        }
         rc = dav1d_hip_launch_itx_bin(&dp, dst->bpc, b, l->itx->dev + l->itx->off[b], (int) cnt, coef, si);
         lane = (lane + 1) % n_lanes;
     }
