@@ -276,6 +276,18 @@ class Context:
     def fg_apply(self, dst, src, data, is_id=0):
         _chk(self.lib.dav1d_hip_fg_apply(self.h, C.byref(dst.pic), C.byref(src.pic), C.byref(data), is_id), "fg_apply")
 
+    def fg_prepare(self, data, bpc, layout):
+        """dav1d_hip_fg_prepare: templates + scaling tables on a side stream; returns the handle for fg_apply_prepared."""
+        g = C.c_void_p()
+        _chk(self.lib.dav1d_hip_fg_prepare(self.h, C.byref(g), C.addressof(data), bpc, layout), "fg_prepare")
+        return g
+
+    def fg_apply_prepared(self, dst, src, g, is_id=0):
+        _chk(self.lib.dav1d_hip_fg_apply_prepared(self.h, C.byref(dst.pic), C.byref(src.pic), g, is_id), "fg_apply_prepared")
+
+    def fg_grain_destroy(self, g):
+        self.lib.dav1d_hip_fg_grain_destroy(self.h, g)
+
     def fg_generate_grain(self, data, bpc, layout):
         out = np.zeros((3, 74, 82), np.int16)
         _chk(self.lib.dav1d_hip_fg_generate_grain(self.h, C.byref(data), bpc, layout, out.ctypes.data), "fg_generate_grain")

@@ -1176,22 +1176,64 @@ extern "C" int dav1d_hip_fg_generate_grain(Dav1dHipContext *c, const Dav1dHipFil
     return rc;
 }
 
-extern "C" int dav1d_hip_fg_apply(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src,
-                                  const Dav1dHipFilmGrainData *data, int is_id) {
-    if (!dst || !src || !data || dst->bpc != src->bpc || dst->layout != src->layout) return -EINVAL;
-    const int bpc = src->bpc, scaling_size = 1 << bpc;
-    const size_t lut_bytes = (3 * 74 * 82 * sizeof(int16_t) + 255) & ~(size_t) 255;      // keeps the scaling tables 16-byte aligned
-    uint8_t *dev = nullptr;
-    const size_t offs_bytes = (size_t) ((src->p[0].w + 31) / 32) * ((src->p[0].h + 31) / 32);
-    if (hipMalloc((void **) &dev, lut_bytes + 3 * (size_t) scaling_size + offs_bytes) != hipSuccess) return -ENOMEM;
-    std::vector<uint8_t> sc(3 * (size_t) scaling_size, 0);
-    if (data->num_y_points || data->chroma_scaling_from_luma) fg_generate_scaling(bpc, data->y_points, data->num_y_points, &sc[0]);
+// Grain templates + scaling tables of one frame (dav1d_prep_grain, src/fg_apply_tmpl.c:97-163 up to the row loop): they depend
+// on the frame header only, so they are generated on a side stream as soon as the parameters are known — a lone wave per
+// template, ~0.23 ms of latency that then hides behind the reconstruction of the frame — and dav1d_hip_fg_apply_prepared
+// (the dav1d_apply_grain_row part) only waits for their event.
+struct Dav1dHipGrain {
+    uint8_t *dev;
+    size_t lut_bytes, scaling_size;
+    int bpc, layout;
+    Dav1dHipFilmGrainData data;
+    std::vector<uint8_t> sc;       // host copy of the scaling tables: kept alive for the asynchronous upload
+    hipEvent_t ready;
+    hipStream_t side;
+};
+
+static int fg_prepare_on(Dav1dHipContext *c, Dav1dHipGrain **out, const Dav1dHipFilmGrainData *data, int bpc, int layout, hipStream_t stream) {
+    if (!c || !out || !data || (bpc != 8 && bpc != 10 && bpc != 12) || layout < 0 || layout > 3) return -EINVAL;
+    *out = nullptr;
+    Dav1dHipGrain *g = new (std::nothrow) Dav1dHipGrain();
+    if (!g) return -ENOMEM;
+    g->dev = nullptr; g->bpc = bpc; g->layout = layout; g->data = *data;
+    g->scaling_size = (size_t) 1 << bpc;
+    g->lut_bytes = (3 * 74 * 82 * sizeof(int16_t) + 255) & ~(size_t) 255;      // keeps the scaling tables 16-byte aligned
+    g->side = stream;
+    if (hipEventCreateWithFlags(&g->ready, hipEventDisableTiming) != hipSuccess) { delete g; return -ENOMEM; }
+    if (hipMalloc((void **) &g->dev, g->lut_bytes + 3 * g->scaling_size) != hipSuccess) { hipEventDestroy(g->ready); delete g; return -ENOMEM; }
+    g->sc.assign(3 * g->scaling_size, 0);
+    if (data->num_y_points || data->chroma_scaling_from_luma) fg_generate_scaling(bpc, data->y_points, data->num_y_points, &g->sc[0]);
     for (int i = 0; i < 2; i++)
-        if (data->num_uv_points[i]) fg_generate_scaling(bpc, data->uv_points[i], data->num_uv_points[i], &sc[(size_t) (1 + i) * scaling_size]);
-    hipMemsetAsync(dev, 0, lut_bytes, c->stream);
-    int rc = dav1d_hip_upload(c, dev + lut_bytes, sc.data(), sc.size());
-    KernelTimer kt(c);
-    if (!rc) rc = dav1d_hip_launch_fg_gen((int16_t *) dev, data, bpc, src->layout, c->stream);
+        if (data->num_uv_points[i]) fg_generate_scaling(bpc, data->uv_points[i], data->num_uv_points[i], &g->sc[(size_t) (1 + i) * g->scaling_size]);
+    int rc = hip_rc(hipMemsetAsync(g->dev, 0, g->lut_bytes, g->side));
+    if (!rc) rc = hip_rc(hipMemcpyAsync(g->dev + g->lut_bytes, g->sc.data(), g->sc.size(), hipMemcpyHostToDevice, g->side));
+    if (!rc) rc = dav1d_hip_launch_fg_gen((int16_t *) g->dev, data, bpc, layout, g->side);
+    if (!rc) rc = hip_rc(hipEventRecord(g->ready, g->side));
+    if (rc) { hipStreamSynchronize(g->side); hipFree(g->dev); hipEventDestroy(g->ready); delete g; return rc; }
+    *out = g;
+    return 0;
+}
+
+extern "C" int dav1d_hip_fg_prepare(Dav1dHipContext *c, Dav1dHipGrain **out, const Dav1dHipFilmGrainData *data, int bpc, int layout) {
+    if (!c) return -EINVAL;
+    return fg_prepare_on(c, out, data, bpc, layout, c->concurrent ? c->side[Dav1dHipContext::N_SIDE - 1] : c->stream);
+}
+
+extern "C" void dav1d_hip_fg_grain_destroy(Dav1dHipContext *c, Dav1dHipGrain *g) {
+    if (!g) return;
+    hipStreamSynchronize(g->side);
+    if (c) hipStreamSynchronize(c->stream);
+    hipFree(g->dev);
+    hipEventDestroy(g->ready);
+    delete g;
+}
+
+// the application proper on the context's stream (no timing, no synchronisation); offs: scratch for the per-block offsets
+static int fg_apply_core(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src, const Dav1dHipGrain *g, int is_id,
+                         uint8_t *offs) {
+    const Dav1dHipFilmGrainData *data = &g->data;
+    const int bpc = src->bpc;
+    int rc = 0;
     // planes that get no grain are copied (dav1d_prep_grain, src/fg_apply_tmpl.c:127-163)
     const int ss_ver = src->layout == DAV1D_HIP_LAYOUT_I420;
     for (int pl = 0; pl < 3 && !rc; pl++) {
@@ -1204,11 +1246,45 @@ extern "C" int dav1d_hip_fg_apply(Dav1dHipContext *c, const Dav1dHipPicture *dst
                                      hipMemcpyDeviceToDevice, c->stream));
     }
     const DevPlanes dp = dev_planes(dst), sp = dev_planes(src);
-    if (!rc) rc = dav1d_hip_launch_fg_apply(&dp, &sp, (const int16_t *) dev, dev + lut_bytes, scaling_size, data, bpc, src->layout, is_id,
-                                            dev + lut_bytes + 3 * (size_t) scaling_size, c->stream);
+    if (!rc) rc = dav1d_hip_launch_fg_apply(&dp, &sp, (const int16_t *) g->dev, g->dev + g->lut_bytes, (int) g->scaling_size, data, bpc, src->layout,
+                                            is_id, offs, c->stream);
+    return rc;
+}
+
+static int fg_args_ok(const Dav1dHipPicture *dst, const Dav1dHipPicture *src) {
+    return dst && src && dst->bpc == src->bpc && dst->layout == src->layout;
+}
+
+extern "C" int dav1d_hip_fg_apply_prepared(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src,
+                                           const Dav1dHipGrain *g, int is_id) {
+    if (!c || !g || !fg_args_ok(dst, src) || src->bpc != g->bpc || src->layout != g->layout) return -EINVAL;
+    uint8_t *offs = nullptr;
+    const size_t offs_bytes = (size_t) ((src->p[0].w + 31) / 32) * ((src->p[0].h + 31) / 32);
+    if (hipMalloc((void **) &offs, offs_bytes + 16) != hipSuccess) return -ENOMEM;
+    int rc = hip_rc(hipStreamWaitEvent(c->stream, g->ready, 0));
+    KernelTimer kt(c);
+    if (!rc) rc = fg_apply_core(c, dst, src, g, is_id, offs);
     kt.stop();
     hipStreamSynchronize(c->stream);
-    hipFree(dev);
+    hipFree(offs);
+    return rc;
+}
+
+// dav1d_apply_grain in one call: templates and application back to back on the context's stream
+extern "C" int dav1d_hip_fg_apply(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src,
+                                  const Dav1dHipFilmGrainData *data, int is_id) {
+    if (!c || !data || !fg_args_ok(dst, src)) return -EINVAL;
+    uint8_t *offs = nullptr;
+    const size_t offs_bytes = (size_t) ((src->p[0].w + 31) / 32) * ((src->p[0].h + 31) / 32);
+    if (hipMalloc((void **) &offs, offs_bytes + 16) != hipSuccess) return -ENOMEM;
+    Dav1dHipGrain *g = nullptr;
+    KernelTimer kt(c);
+    int rc = fg_prepare_on(c, &g, data, src->bpc, src->layout, c->stream);
+    if (!rc) rc = fg_apply_core(c, dst, src, g, is_id, offs);
+    kt.stop();
+    hipStreamSynchronize(c->stream);
+    hipFree(offs);
+    dav1d_hip_fg_grain_destroy(c, g);
     return rc;
 }
 

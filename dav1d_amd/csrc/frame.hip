@@ -29,6 +29,7 @@ struct Dav1dHipFrame {
     int cdef_damping;
     bool have_grain;
     Dav1dHipFilmGrainData grain;
+    Dav1dHipGrain *prepared;         // templates + scaling tables, generated on a side stream from set_filters on
     int is_id;
     Dav1dHipPicture tmp[2];          // CDEF output, restoration output (allocated on first use)
     bool have_tmp[2];
@@ -203,6 +204,7 @@ int dav1d_hip_frame_begin(Dav1dHipContext *c, Dav1dHipFrame **out, const Dav1dHi
     f->b4_stride = 0;
     f->cdef_damping = 0;
     f->have_grain = false;
+    f->prepared = nullptr;
     f->is_id = 0;
     f->have_tmp[0] = f->have_tmp[1] = false;
     f->post_bands = 0;
@@ -247,7 +249,13 @@ int dav1d_hip_frame_set_filters(Dav1dHipFrame *f, const uint8_t *lvl, ptrdiff_t 
     if (lut_i) memcpy(f->lut_i, lut_i, 64);
     f->cdef_damping = cdef_damping;
     f->have_grain = grain != nullptr;
-    if (grain) f->grain = *grain;
+    if (f->prepared) { dav1d_hip_fg_grain_destroy(f->c, f->prepared); f->prepared = nullptr; }
+    if (grain) {
+        f->grain = *grain;
+        // the grain of the frame only depends on these parameters: start generating it now, next to the reconstruction
+        const int rc = dav1d_hip_fg_prepare(f->c, &f->prepared, grain, f->cur.bpc, f->cur.layout);
+        if (rc) return rc;
+    }
     f->is_id = is_id;
     return 0;
 }
@@ -313,7 +321,9 @@ int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *ma
         }
     }
     if (!rc && filtered) *filtered = *last;
-    if (!rc && f->have_grain && grain_out) rc = dav1d_hip_fg_apply(c, grain_out, last, &f->grain, f->is_id);
+    if (!rc && f->have_grain && grain_out)
+        rc = f->prepared ? dav1d_hip_fg_apply_prepared(c, grain_out, last, f->prepared, f->is_id)
+                         : dav1d_hip_fg_apply(c, grain_out, last, &f->grain, f->is_id);
     if (!rc) rc = dav1d_hip_sync(c);
     return rc;
 }
@@ -323,6 +333,7 @@ int dav1d_hip_frame_post_bands(const Dav1dHipFrame *f) { return f ? f->post_band
 void dav1d_hip_frame_destroy(Dav1dHipFrame *f) {
     if (!f) return;
     (void) hipStreamSynchronize(f->c->stream);
+    if (f->prepared) dav1d_hip_fg_grain_destroy(f->c, f->prepared);
     for (int i = 0; i < 2; i++) if (f->have_tmp[i]) dav1d_hip_picture_free(f->c, &f->tmp[i]);
     delete f;
 }

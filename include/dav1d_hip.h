@@ -490,6 +490,16 @@ typedef struct Dav1dHipFilmGrainData {
  * are copied.  `is_id` = seq_hdr->mtrx == DAV1D_MC_IDENTITY. */
 DAV1D_HIP_API int dav1d_hip_fg_apply(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src,
                                      const Dav1dHipFilmGrainData *data, int is_id);
+
+/* The same in the two halves the reference has (dav1d_prep_grain / dav1d_apply_grain_row, src/fg_apply_tmpl.c:97-241): the grain
+ * templates and scaling tables depend on the frame header only, so dav1d_hip_fg_prepare can be called as soon as the header is
+ * parsed — it enqueues their generation on a side stream and returns — and dav1d_hip_fg_apply_prepared, at the end of the
+ * frame, only waits for that event.  The ~0.23 ms the lone-wave template kernels take then hide behind the reconstruction. */
+typedef struct Dav1dHipGrain Dav1dHipGrain;
+DAV1D_HIP_API int dav1d_hip_fg_prepare(Dav1dHipContext *c, Dav1dHipGrain **out, const Dav1dHipFilmGrainData *data, int bpc, int layout);
+DAV1D_HIP_API int dav1d_hip_fg_apply_prepared(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src,
+                                              const Dav1dHipGrain *g, int is_id);
+DAV1D_HIP_API void dav1d_hip_fg_grain_destroy(Dav1dHipContext *c, Dav1dHipGrain *g);
 /* The grain templates alone (parity aid): host_lut receives grain_lut[3][73 + 1][82] as int16_t. */
 DAV1D_HIP_API int dav1d_hip_fg_generate_grain(Dav1dHipContext *c, const Dav1dHipFilmGrainData *data, int bpc, int layout,
                                               int16_t *host_lut);

@@ -96,12 +96,21 @@ def test_film_grain_matches_reference(ctx, bpc, variant):
     outp = (C.c_void_p * 3)(*[p.ctypes.data for p in want])
     inpp = (C.c_void_p * 3)(*[p.ctypes.data for p in inp])
     lib.apply_grain(bpc, C.byref(data), w, h, layout, int(variant == 2), outp, inpp, want[0].strides[0], want[1].strides[0])
-    ctx.fg_apply(dst, src, data, int(variant == 2))
     ss_v, ss_h = (1 if layout == 1 else 0), (1 if layout != 3 else 0)
-    for pl in range(3):
-        vh, vw = (h, w) if pl == 0 else ((h + ss_v) >> ss_v, (w + ss_h) >> ss_h)
-        got = dst.download(pl)[:vh, :vw]
-        bad = np.argwhere(got != want[pl][:vh, :vw])
-        assert not len(bad), "plane %d differs at %s: got %d want %d (%d px)" % (
-            pl, bad[0], got[tuple(bad[0])], want[pl][tuple(bad[0])], len(bad))
+    # one call (dav1d_apply_grain), then the two halves (prepare at "frame start", apply at the end)
+    for split in (False, True):
+        for pl in range(3):
+            dst.upload(pl, out0[pl])
+        if split:
+            g = ctx.fg_prepare(data, bpc, layout)
+            ctx.fg_apply_prepared(dst, src, g, int(variant == 2))
+            ctx.fg_grain_destroy(g)
+        else:
+            ctx.fg_apply(dst, src, data, int(variant == 2))
+        for pl in range(3):
+            vh, vw = (h, w) if pl == 0 else ((h + ss_v) >> ss_v, (w + ss_h) >> ss_h)
+            got = dst.download(pl)[:vh, :vw]
+            bad = np.argwhere(got != want[pl][:vh, :vw])
+            assert not len(bad), "plane %d differs at %s: got %d want %d (%d px, split=%s)" % (
+                pl, bad[0], got[tuple(bad[0])], want[pl][tuple(bad[0])], len(bad), split)
     src.free(); dst.free()
