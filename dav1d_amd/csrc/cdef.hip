@@ -73,6 +73,49 @@ __device__ __forceinline__ int cdef_px(const int16_t *tmp, const int x, const in
     return (pri && sec) ? dv::iclip(v, (int) mn, mx) : v;
 }
 
+// The same pixel by TWO neighbouring lanes (lane ^ 1): lane `half` takes the taps of distance half + 1 (one primary pair, two
+// secondary pairs: 6 of the 12), the partial sum and the range travel across the pair, both lanes end up with the result.
+// Used where a pass would leave half the wave idle (the 32 chroma pixels of a 4:2:0 unit).
+__device__ __forceinline__ int cdef_px_pair(const int16_t *tmp, const int x, const int y, const int half, const int pri, const int sec,
+                                            const int dir, const int damping, const int bitdepth_min_8)
+{
+    const int16_t *c = tmp + (y + 2) * 12 + x + 2;
+    const int px = c[0];
+    int sum = 0, mx = px;
+    unsigned mn = (unsigned) px;
+    const int8_t *dirs = &av1_cdef_directions[dir * 2];
+    if (pri) {
+        const int pri_tap = 4 - ((pri >> bitdepth_min_8) & 1);
+        const int pri_shift = dv::imax(0, damping - ulog2(pri));
+        const int tap = half ? ((pri_tap & 3) | 2) : pri_tap;
+        const int off = half ? dirs[2 * 2 + 1] : dirs[2 * 2 + 0];
+        const int p0 = c[off], p1 = c[-off];
+        sum += tap * constrain(p0, px, pri, pri_shift);
+        sum += tap * constrain(p1, px, pri, pri_shift);
+        mn = min(mn, (unsigned) p0); mx = dv::imax(mx, p0);
+        mn = min(mn, (unsigned) p1); mx = dv::imax(mx, p1);
+    }
+    if (sec) {
+        const int sec_shift = damping - ulog2(sec);
+        const int off2 = half ? dirs[4 * 2 + 1] : dirs[4 * 2 + 0], off3 = half ? dirs[0 * 2 + 1] : dirs[0 * 2 + 0];
+        const int s0 = c[off2], s1 = c[-off2], s2 = c[off3], s3 = c[-off3];
+        const int tap = 2 - half;
+        sum += tap * constrain(s0, px, sec, sec_shift);
+        sum += tap * constrain(s1, px, sec, sec_shift);
+        sum += tap * constrain(s2, px, sec, sec_shift);
+        sum += tap * constrain(s3, px, sec, sec_shift);
+        mn = min(mn, (unsigned) s0); mx = dv::imax(mx, s0);
+        mn = min(mn, (unsigned) s1); mx = dv::imax(mx, s1);
+        mn = min(mn, (unsigned) s2); mx = dv::imax(mx, s2);
+        mn = min(mn, (unsigned) s3); mx = dv::imax(mx, s3);
+    }
+    sum += __shfl_xor(sum, 1);
+    mn = min(mn, (unsigned) __shfl_xor((int) mn, 1));
+    mx = dv::imax(mx, __shfl_xor(mx, 1));
+    const int v = px + ((sum - (sum < 0) + 8) >> 4);
+    return (pri && sec) ? dv::iclip(v, (int) mn, mx) : v;
+}
+
 // The (w+4) x (h+4) neighbourhood of a block goes to LDS in 12-wide rows (the layout cdef_px and the direction tables
 // expect), INT16_MIN where `edges` says the neighbour does not exist.  WW = w + 4 is a compile-time constant, so the
 // entry -> (row, column) split is a shift or a multiply, and only the entries of the window are visited: 64 for a 4x4
@@ -254,6 +297,14 @@ __global__ __launch_bounds__(64) void cdef_kernel(const DevPlanes dst, const Dev
         }
         dv::wave_sync();
         const int npx = w * h;                        // 16, 32 or 64 pixels per plane
+        if (2 * npx == 32) {
+            // 4:2:0: 32 chroma pixels, two lanes each (see cdef_px_pair) — one full-width pass instead of a half-empty one
+            const int i = lane >> 1, half = lane & 1;
+            const int pl = 1 + (i >= 16), k = i & 15;
+            const int x = k & 3, y = k >> 2;
+            const int v = cdef_px_pair(pl == 1 ? tmp : tmp2, x, y, half, t.uv_pri, t.uv_sec, uvdir, damping - 1, bitdepth_min_8);
+            if (!half) reinterpret_cast<pixel *>(dst.data[pl])[(cy0 + y) * dst.stride[pl] + cx0 + x] = (pixel) v;
+        } else
         for (int i = lane; i < 2 * npx; i += 64) {
             const int pl = 1 + (i >= npx), k = i - (pl - 1) * npx;
             const int x = k & (w - 1), y = k >> (3 - ss_hor);
