@@ -18,7 +18,9 @@
 namespace {
 
 enum { LR_SEG = 64 };        // output rows per wave: the whole stripe (16-row segments were measured 20 % slower: 6 extra
-                             // rows of horizontal filtering per segment outweigh the shorter chains)
+                             // rows of horizontal filtering per segment outweigh the shorter chains).  Also measured and
+                             // dropped: fetching rows two iterations ahead (+6 %), one unaligned 8-pixel fetch per lane and
+                             // row instead of seven 1-pixel ones (+60 %: neighbouring lanes read overlapping 16-byte pieces)
 
 template <typename pixel>
 __global__ __launch_bounds__(64) void wiener_kernel(const DevPlanes dst, const DevPlanes src, const DevPlanes lpf,
