@@ -300,6 +300,9 @@ def main():
             sel_m = (np.minimum(frame.mc["w"], 64) == tw_) & (np.minimum(frame.mc["h"], 16) == th_)
             n_tiles = int((((frame.mc["w"][sel_m].astype(np.int64) + tw_ - 1) // tw_) * ((frame.mc["h"][sel_m].astype(np.int64) + th_ - 1) // th_)).sum())
             roof["window_bytes_per_launch"] = int(n_tiles * (tw_ + 7) * (th_ + 7) * P + dom[2] // 2)
+            roof["frac_incl_halo"] = round(roof["window_bytes_per_launch"] / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if roof["traffic"]:
+            roof["frac_measured_traffic"] = round(roof["traffic"] / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
 
         # ---- parity gate + CPU baseline: the oracle replays the SAME lists on the host
         cpu = None

@@ -188,7 +188,9 @@ typedef struct Dav1dHipMcTask {
 } Dav1dHipMcTask;
 
 /* `tasks` is a HOST array; `refs` is a host array of n_refs (<= 8) picture
- * descriptors with device planes; `prep` is the DEVICE int16 arena PREP tasks write to. */
+ * descriptors with device planes; `prep` is the DEVICE int16 arena PREP tasks write to.
+ * The tasks of one call / list write disjoint rectangles and run in no particular order (the library reorders them by
+ * where they read and by code path). */
 DAV1D_HIP_API int dav1d_hip_mc_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst,
                                      const Dav1dHipPicture *refs, int n_refs,
                                      const Dav1dHipMcTask *tasks, size_t n, int16_t *prep);
