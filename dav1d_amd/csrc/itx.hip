@@ -13,259 +13,10 @@
 // The slab is fetched with 16-byte loads into LDS (zeroed with 16-byte stores in the same
 // sweep) together with the destination pixels the column pass will need much later; the
 // row pass reads it transposed, and the same LDS region then becomes the transpose buffer.
-#include "common.h"
-#include "itx1d.h"
-#include "av1_scan_dev.h"
+#include "itx_body.h"
+#include "capi.h"
 
 namespace {
-
-enum { K_DCT = 0, K_ADST = 1, K_IDENTITY = 2, K_FLIPADST = 3, K_WHT = 4 };
-
-__host__ __device__ constexpr int tx_w(int tx) {
-    constexpr int w[19] = { 4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64 };
-    return w[tx];
-}
-__host__ __device__ constexpr int tx_h(int tx) {
-    constexpr int h[19] = { 4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16 };
-    return h[tx];
-}
-// intermediate shift per size (reference src/itx_tmpl.c:160-178)
-__host__ __device__ constexpr int tx_shift(int tx) {
-    constexpr int s[19] = { 0, 1, 2, 2, 2, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2 };
-    return s[tx];
-}
-__host__ __device__ constexpr int cmin(int a, int b) { return a < b ? a : b; }
-__host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
-
-// itxfm_add table index -> 1-D kind of the first (horizontal) and second (vertical)
-// pass.  The reference's table entry [A_B] is the function whose internal type is
-// B_A (src/itx_tmpl.c:233-262), and dav1d_tx1d_types[internal] = {first, second}
-// (src/itx_1d.c:1043-1060): net effect first = B, second = A; V_x = {IDENTITY, x},
-// H_x = {x, IDENTITY}.
-__device__ __forceinline__ void txtp_kinds(const int txtp, int &first, int &second) {
-    // packed 2 bits per entry: first | second << 2
-    //            DCT_DCT ADST_DCT DCT_ADST ADST_ADST FLIPADST_DCT DCT_FLIPADST FLIPADST_FLIPADST ADST_FLIPADST
-    // first        D       D        A        A         D            F            F                 F
-    // second       D       A        D        A         F            D            F                 A
-    //            FLIPADST_ADST IDTX V_DCT H_DCT V_ADST H_ADST V_FLIPADST H_FLIPADST
-    // first        A             I    I     D     I      A      I          F
-    // second       F             I    D     I     A      I      F          I
-    constexpr unsigned char tab[16] = {
-        0 | 0 << 2, 0 | 1 << 2, 1 | 0 << 2, 1 | 1 << 2, 0 | 3 << 2, 3 | 0 << 2, 3 | 3 << 2, 3 | 1 << 2,
-        1 | 3 << 2, 2 | 2 << 2, 2 | 0 << 2, 0 | 2 << 2, 2 | 1 << 2, 1 | 2 << 2, 2 | 3 << 2, 3 | 2 << 2,
-    };
-    // spelled as a switch-free lookup on an immediate table (stays in SGPR/const)
-    unsigned v = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) v = (txtp == i) ? tab[i] : v;
-    first = v & 3;
-    second = v >> 2;
-}
-
-// Runs the 1-D transform `kind` and hands the result to `done`.  Every kind finishes inside its own branch: merging
-// the branches' output arrays instead makes the compiler keep part of them in scratch memory.
-template <int N, typename F>
-__device__ __forceinline__ void tx1d(const int kind, const int *in, const int lo, const int hi, F &&done) {
-    if constexpr (N == 64) {
-        int out[N];
-        itx1d::idct<64>(in, out, lo, hi);
-        done(out);
-    } else if constexpr (N == 32) {
-        if (kind == K_IDENTITY) { int out[N]; itx1d::iidentity<32>(in, out); done(out); }
-        else { int out[N]; itx1d::idct<32>(in, out, lo, hi); done(out); }
-    } else {
-        if (kind == K_DCT) { int out[N]; itx1d::idct<N>(in, out, lo, hi); done(out); }
-        else if (kind == K_IDENTITY) { int out[N]; itx1d::iidentity<N>(in, out); done(out); }
-        else {
-            int out[N];
-            if constexpr (N == 4) itx1d::iadst4(in, out);
-            else itx1d::iadst<N>(in, out, lo, hi);
-            done(out);
-        }
-    }
-}
-
-// LDS ints one wave needs for transform size TX (all of its blocks)
-template <int TX>
-constexpr int itx_lds_ints() {
-    constexpr int W = tx_w(TX), H = tx_h(TX), SH = cmin(H, 32), LPB = cmax(SH, W);
-    return (64 / LPB) * SH * (W + 1);
-}
-
-// The wave `group` of the blocks of ONE transform size: blocks [group * BPW, group * BPW + BPW) of tasks[0 .. n).
-template <int TX, typename pixel, typename coef>
-__device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItxTask *__restrict__ tasks,
-                                         const int n, coef *__restrict__ cf, const int bitdepth_max, const int group, int *tmp_s)
-{
-    constexpr int W = tx_w(TX), H = tx_h(TX);
-    constexpr int SW = cmin(W, 32), SH = cmin(H, 32);
-    constexpr int LPB = cmax(SH, W);          // lanes per block
-    constexpr int BPW = 64 / LPB;             // blocks per wave
-    constexpr int TS = W + 1;                 // padded row stride of the transpose buffer
-    constexpr int SHIFT = tx_shift(TX);
-    constexpr bool RECT2 = (W * 2 == H) || (H * 2 == W);
-    constexpr bool HBD = sizeof(pixel) == 2;
-
-    constexpr int NCH = SW * SH * (int) sizeof(coef) / 16;   // 16-byte chunks per slab
-    // one LDS region per block, used twice: first the raw slab (landing zone of the 16-byte
-    // loads), then, once every lane holds its row in registers, the transposed intermediate
-    static_assert(BPW * SH * TS == itx_lds_ints<TX>(), "LDS sizing");
-
-    const int lane = threadIdx.x;
-    const int sub = BPW == 1 ? 0 : lane / LPB, l = BPW == 1 ? lane : lane % LPB;
-    const int ti = group * BPW + sub;
-    const bool live = ti < n;
-
-    Dav1dHipItxTask t;
-    if (BPW == 1) t = tasks[__builtin_amdgcn_readfirstlane(live ? ti : 0)];   // one block per wave: record in SGPRs
-    else t = tasks[live ? ti : 0];
-
-    const bool wht = TX == 0 && t.txtp == 16;
-    const bool dconly = live && t.txtp == 0 && t.eob < 1;
-    const bool full = live && !dconly;
-    int k1 = 0, k2 = 0;
-    txtp_kinds(t.txtp, k1, k2);
-
-    coef *const gcf = cf + t.cf_off;
-    int *const tmp = tmp_s + sub * SH * TS;
-    pixel *const d = reinterpret_cast<pixel *>(dst.data[t.plane]) + t.dst_off + l;
-    const int stride = dst.stride[t.plane];
-
-    // ---- issue every global load up front: the row's coefficients (lane r = row r reads
-    // coeff[r + x*SH], consecutive lanes -> consecutive addresses) and, for the column pass later,
-    // this lane's column of destination pixels.  dc-only blocks touch coeff[0] only.
-    int in[W];
-    pixel dpx[H];
-    int dc = 0;
-    const bool row_lane = full && l < SH;
-    static_assert(SW * SH * (int) sizeof(coef) <= SH * TS * (int) sizeof(int), "slab fits the transpose buffer");
-    if (full) {
-        // 16-byte loads of the contiguous slab, zeroed in the same sweep (src/itx_tmpl.c:108)
-        const int4 *g4 = reinterpret_cast<const int4 *>(gcf);
-        int4 *z4 = reinterpret_cast<int4 *>(gcf);
-        int4 *s4 = reinterpret_cast<int4 *>(tmp);
-        // only the part of the slab the scan can have reached (t.pad = prefix length in coefficients, filled in by the
-        // host from the eob); the rest is zero in memory by contract and is zero-filled in LDS without being fetched
-        const bool packed = t.flags & DAV1D_HIP_ITX_PACKED;
-        const int nch = packed ? 0 : (((int) t.rsv[0] | ((int) t.rsv[1] << 8)) * (int) sizeof(coef) + 15) >> 4;
-        int4 v[(NCH + LPB - 1) / LPB];
-#pragma unroll
-        for (int k = 0; k < (NCH + LPB - 1) / LPB; k++) {
-            v[k] = make_int4(0, 0, 0, 0);
-            if (l + k * LPB < nch) v[k] = g4[l + k * LPB];
-        }
-        if (l < W) {
-#pragma unroll
-            for (int y = 0; y < H; y++) dpx[y] = d[y * stride];
-        }
-#pragma unroll
-        for (int k = 0; k < (NCH + LPB - 1) / LPB; k++) {
-            if (l + k * LPB < NCH) s4[l + k * LPB] = v[k];
-            if (l + k * LPB < nch) z4[l + k * LPB] = make_int4(0, 0, 0, 0);
-        }
-        if (packed) {
-            // sparse wire format: eob + 1 values in decode order are scattered to their slab positions (the slab in LDS was
-            // just zero-filled); positions as decode_coefs derives them (reference src/recon_tmpl.c:458-496, 548-575)
-            dv::wave_sync();
-            coef *const slab = reinterpret_cast<coef *>(tmp);
-            const int cls = (t.txtp == 11 || t.txtp == 13 || t.txtp == 15) ? 1 : (t.txtp == 10 || t.txtp == 12 || t.txtp == 14) ? 2 : 0;
-            const uint16_t *const scan = av1_scans + av1_scan_off[TX];
-            constexpr int LSW = SW == 4 ? 2 : SW == 8 ? 3 : SW == 16 ? 4 : 5;
-            for (int i = l; i <= t.eob; i += LPB) {
-                const int rc = cls == 0 ? (int) scan[i] : cls == 1 ? i : ((i & (SW - 1)) * SH + (i >> LSW));
-                slab[rc] = gcf[i];
-            }
-        }
-    } else if (dconly) {
-        if (l == 0) { dc = gcf[0]; if (!(t.flags & DAV1D_HIP_ITX_PACKED)) gcf[0] = 0; }            // src/itx_tmpl.c:59-60
-        if (l < W) {
-#pragma unroll
-            for (int y = 0; y < H; y++) dpx[y] = d[y * stride];
-        }
-    }
-    dc = __shfl(dc, sub * LPB);
-    dv::wave_sync();
-    if (row_lane) {
-        const coef *slab = reinterpret_cast<const coef *>(tmp);
-#pragma unroll
-        for (int x = 0; x < SW; x++) in[x] = slab[x * SH + l];
-    }
-    dv::wave_sync();     // every row is in registers: the region becomes the transpose buffer
-
-    int row_min, row_max, col_min, col_max;
-    if (HBD) {
-        row_min = (int) ((unsigned) ~bitdepth_max << 7);
-        col_min = (int) ((unsigned) ~bitdepth_max << 5);
-    } else {
-        row_min = col_min = -32768;
-    }
-    row_max = ~row_min;
-    col_max = ~col_min;
-
-    // ---- first pass: lane r = row r, W-point transform along x
-    if (row_lane) {
-        int out[W];
-#pragma unroll
-        for (int x = 0; x < W; x++) {
-            int v = x < SW ? in[x] : 0;
-            if (RECT2 && x < SW) v = (v * 181 + 128) >> 8;
-            in[x] = v;
-        }
-        if (TX == 0 && wht) {
-#pragma unroll
-            for (int x = 0; x < W; x++) in[x] >>= 2;
-            if constexpr (W == 4) itx1d::iwht4(in, out);
-#pragma unroll
-            for (int x = 0; x < W; x++) tmp[l * TS + x] = out[x];
-        } else {
-            const int rnd = (1 << SHIFT) >> 1;
-            const bool flip = k1 == K_FLIPADST;
-            tx1d<W>(k1, in, row_min, row_max, [&](const int *res) {
-#pragma unroll
-                for (int x = 0; x < W; x++) {
-                    const int xo = flip ? W - 1 - x : x;
-                    tmp[l * TS + xo] = dv::iclip((res[x] + rnd) >> SHIFT, col_min, col_max);
-                }
-            });
-        }
-    }
-    dv::wave_sync();
-
-    // ---- second pass: lane c = column c, H-point transform along y, add to dst
-    if (live && l < W) {
-        if (dconly) {
-            if (RECT2) dc = (dc * 181 + 128) >> 8;
-            dc = (dc * 181 + 128) >> 8;
-            dc = (dc + ((1 << SHIFT) >> 1)) >> SHIFT;
-            dc = (dc * 181 + 128 + 2048) >> 12;
-#pragma unroll
-            for (int y = 0; y < H; y++)
-                d[y * stride] = (pixel) dv::iclip((int) dpx[y] + dc, 0, bitdepth_max);
-        } else {
-            int cin[H], out[H];
-#pragma unroll
-            for (int y = 0; y < H; y++) cin[y] = y < SH ? tmp[y * TS + l] : 0;
-            if (TX == 0 && wht) {
-                if constexpr (H == 4) itx1d::iwht4(cin, out);
-#pragma unroll
-                for (int y = 0; y < H; y++)
-                    d[y * stride] = (pixel) dv::iclip((int) dpx[y] + out[y], 0, bitdepth_max);
-            } else {
-                tx1d<H>(k2, cin, col_min, col_max, [&](const int *res) {
-                    if (k2 == K_FLIPADST) {
-#pragma unroll
-                        for (int y = 0; y < H; y++)
-                            d[y * stride] = (pixel) dv::iclip((int) dpx[y] + ((res[H - 1 - y] + 8) >> 4), 0, bitdepth_max);
-                    } else {
-#pragma unroll
-                        for (int y = 0; y < H; y++)
-                            d[y * stride] = (pixel) dv::iclip((int) dpx[y] + ((res[y] + 8) >> 4), 0, bitdepth_max);
-                    }
-                });
-            }
-        }
-    }
-}
 
 template <int TX, typename pixel, typename coef>
 __global__ __launch_bounds__(64) void itx_add_kernel(const DevPlanes dst, const Dav1dHipItxTask *__restrict__ tasks,

@@ -1,0 +1,329 @@
+// The motion-compensation work of one wave (gather -> horizontal -> vertical -> combine), shared by the per-shape kernels of
+// mc.hip and by the fused prediction + residual kernels of recon.hip.  See mc.hip for the description of the mapping.
+#pragma once
+#include "common.h"
+#include "capi.h"
+#include "av1_tables.h"
+
+namespace {
+
+struct RefSet { DevPlanes r[8]; };
+static_assert(sizeof(DevPlanes) == 64 && sizeof(RefSet) == 512, "the waves copy the table to LDS dword by dword");
+
+struct __attribute__((packed, aligned(2))) U64u { uint32_t a, b; };   // 2-byte aligned 8-byte global load
+struct __attribute__((packed, aligned(1))) U64b { uint32_t a, b; };   // byte-aligned (8 bpc rows)
+struct __attribute__((packed, aligned(2))) U128u { uint32_t a, b, c, d; };   // 2-byte aligned 16-byte global load
+
+// taps of one direction packed for v_dot2: ev[k] = (f[2k], f[2k+1]), od[k] = (f[2k-1], f[2k]) with f[-1] = f[8] = 0
+struct Taps { uint32_t ev[4]; uint32_t od[5]; };
+
+__device__ __forceinline__ Taps load_taps(const int set, const int m) {
+    // av1_mc_taps_packed[set 0..5 | 6 = bilinear][phase 0..15, 0 = unit tap][ev0..3, od0..4]
+    const uint32_t *p = &av1_mc_taps_packed[(set * 16 + m) * 9];
+    Taps t;
+#pragma unroll
+    for (int k = 0; k < 4; k++) t.ev[k] = p[k];
+#pragma unroll
+    for (int k = 0; k < 5; k++) t.od[k] = p[4 + k];
+    return t;
+}
+
+constexpr int mc_cmin(int a, int b) { return a < b ? a : b; }
+// window row stride in pixels: TW + 8 columns rounded up to whole 16-byte chunks; 4-wide tiles keep exactly the 12 columns
+// the 4-tap / 8-tap rows reach (8-byte aligned rows are enough for the 8-byte reads of the horizontal pass)
+constexpr int mc_win_stride(int tw) { return tw == 4 ? 12 : (tw + 8 + 7) & ~7; }
+
+// LDS bytes one wave needs for tile shape (TW, TH): window + row-pair intermediate + the tile records
+template <int TW, int TH>
+constexpr int mc_lds_bytes() {
+    constexpr int LPT = mc_cmin(64, TW * TH / 4), G = 64 / LPT, WS = mc_win_stride(TW), WR = TH + 8, NPR = WR / 2;
+    return G * WR * WS * 2 + G * NPR * TW * 4 + (G > 1 ? G * (int) sizeof(McTile) + (int) sizeof(RefSet) : 0);
+}
+
+// One wave's worth of tiles of shape (TW, TH): tiles[t0 .. t0 + nt), nt <= 64 / LPT.  `smem` = mc_lds_bytes<TW, TH>() of LDS.
+template <int TW, int TH, typename pixel>
+__device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs, const McTile *__restrict__ tiles, const int t0, const int nt,
+                                        int16_t *__restrict__ prep, const int bitdepth_max, uint4 *smem)
+{
+    constexpr int NS = TW / 4;                          // 4-pixel strips per row
+    constexpr int LPT = mc_cmin(64, TW * TH / 4);       // lanes per tile
+    constexpr int G = 64 / LPT;                         // tiles side by side in a wave
+    constexpr int R = TW * TH / 4 / LPT;                // output strips per lane (1, 2 or 4)
+    constexpr int WS = mc_win_stride(TW);               // window row stride (int16)
+    constexpr int WR = TH + 8;                          // window rows held (TH+7 used, +1 so row pairs are complete)
+    constexpr int NCH = (WS + 7) / 8;                   // 8-pixel (16-byte) chunks fetched per window row
+    constexpr int NPR = WR / 2;                         // row pairs of the intermediate
+    constexpr int NLD = ((WR - 1) * NCH + LPT - 1) / LPT;   // window loads per lane
+    constexpr bool HBD = sizeof(pixel) == 2;
+
+    int16_t *const win_s = reinterpret_cast<int16_t *>(smem);
+    uint32_t *const mid_s = reinterpret_cast<uint32_t *>(win_s + G * WR * WS);
+
+    const int lane = threadIdx.x;
+    // G == 1: the whole wave works on one tile, so the record, the taps and all the control flow
+    // derived from them are wave-uniform (scalar loads, SGPRs, s_cbranch instead of exec masking)
+    const int sub = G == 1 ? 0 : lane / LPT, l = G == 1 ? lane : lane % LPT;
+    const int ti = t0 + sub;
+    const bool live = sub < nt;
+
+    McTile t;
+    if (G == 1) {
+        t = tiles[__builtin_amdgcn_readfirstlane(live ? ti : 0)];
+    } else {
+        // the G records of the wave come in with one coalesced sweep and are handed to their lanes through LDS
+        constexpr int RW = sizeof(McTile) / 4;
+        uint32_t *const rec_s = mid_s + G * NPR * TW;
+        const uint32_t *recs = reinterpret_cast<const uint32_t *>(tiles + t0);
+        const int nw = nt * RW;
+        for (int i = lane; i < nw; i += 64) rec_s[i] = recs[i];
+        // the reference plane table goes to LDS in the same round trip: the lanes index it by their own tile's reference,
+        // and a second, dependent trip to the kernel arguments would sit in front of every window fetch
+        uint32_t *const ref_s = rec_s + G * RW;
+        const uint32_t *rsrc = reinterpret_cast<const uint32_t *>(&refs);
+#pragma unroll
+        for (int i = 0; i < (int) sizeof(RefSet) / 4; i += 64) ref_s[i + lane] = rsrc[i + lane];
+        dv::wave_sync();
+        const uint32_t *rp = rec_s + (live ? sub : 0) * RW;
+        uint32_t *tw_ = reinterpret_cast<uint32_t *>(&t);
+#pragma unroll
+        for (int i = 0; i < RW; i++) tw_[i] = rp[i];
+    }
+
+    int16_t *const win = win_s + sub * WR * WS;
+    uint32_t *const mid = mid_s + sub * NPR * TW;
+
+    const int ib = HBD ? 14 - (32 - __clz(bitdepth_max)) : 4;   // intermediate_bits
+    const int bias = HBD ? 8192 : 0;                            // PREP_BIAS
+    const bool compound = live && (t.kind == MCT_AVG || t.kind == MCT_WAVG);
+    const bool as_prep = t.kind != MCT_PUT && t.kind != MCT_PUT_TMP;   // PREP and both inputs of a compound tile
+
+    int acc0[R][4], q[R][4];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) acc0[r][x] = q[r][x] = 0;
+
+    // one prediction (gather -> h -> v) of this lane's strips into q[]; a lambda invoked once or
+    // twice rather than a loop over t.r[] so that the record is never indexed dynamically
+    auto predict = [&](const McRef rf) {
+        const bool has_h = rf.mx != 0, has_v = rf.my != 0;
+        const int fbits = rf.fh == 6 ? 4 : 6;
+        const Taps fh = load_taps(rf.fh, rf.mx), fv = load_taps(rf.fv, rf.my);
+        // window rows the vertical taps can reach: the others only ever meet zero taps, so they are neither
+        // fetched nor filtered (6-tap regular, 4-tap smooth / small blocks, 2-tap bilinear, 1-tap full-pel)
+        const int vspan = rf.vspan;
+        const int row_lo = vspan & 15, row_hi = TH - 1 + (vspan >> 4);
+
+        // ---- 1. gather the window
+        if (live) {
+            const pixel *src;
+            int rs, rw, rh;
+            if (G == 1) {
+                const DevPlanes &rp = refs.r[rf.ref];
+                src = reinterpret_cast<const pixel *>(rp.data[t.plane]);
+                rs = rp.stride[t.plane]; rw = rp.w[t.plane]; rh = rp.h[t.plane];
+            } else {
+                constexpr int RW = sizeof(McTile) / 4, DW = sizeof(DevPlanes) / 4;
+                const uint32_t *rt = mid_s + G * NPR * TW + G * RW + rf.ref * DW;      // == ref_s above
+                const uint32_t *pd = rt + 2 * t.plane;
+                src = reinterpret_cast<const pixel *>((uint64_t) pd[0] | ((uint64_t) pd[1] << 32));
+                rs = (int) rt[6 + t.plane]; rw = (int) rt[9 + t.plane]; rh = (int) rt[12 + t.plane];
+            }
+            const int x0 = rf.src_x - 4, y0 = rf.src_y - 3;
+            const bool interior = x0 >= 0 && y0 >= 0 && x0 + NCH * 8 <= rw && y0 + WR - 1 <= rh;
+            if (interior) {
+                // 16-byte (8-pixel) loads, rows at arbitrary 2-byte alignment; all of a lane's loads are
+                // issued before the first LDS write
+                const pixel *base = src + y0 * rs + x0;
+                uint4 ld[NLD];
+#pragma unroll
+                for (int k = 0; k < NLD; k++) {
+                    const int i = dv::imin(l + k * LPT, (WR - 1) * NCH - 1);
+                    const pixel *p = base + (i / NCH) * rs + 8 * (i % NCH);
+                    ld[k] = make_uint4(0, 0, 0, 0);
+                    if (i / NCH < row_lo || i / NCH >= row_hi) continue;
+                    if (HBD) {
+                        const U128u v = *reinterpret_cast<const U128u *>(p);
+                        ld[k] = make_uint4(v.a, v.b, v.c, v.d);
+                    } else {
+                        const U64b v = *reinterpret_cast<const U64b *>(p);
+                        ld[k] = make_uint4((v.a & 0xff) | ((v.a & 0xff00) << 8), ((v.a >> 16) & 0xff) | ((v.a >> 8) & 0xff0000),
+                                           (v.b & 0xff) | ((v.b & 0xff00) << 8), ((v.b >> 16) & 0xff) | ((v.b >> 8) & 0xff0000));
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NLD; k++) {
+                    const int i = l + k * LPT;
+                    if (i >= (WR - 1) * NCH) continue;
+                    int16_t *const wp = win + (i / NCH) * WS + 8 * (i % NCH);
+                    if (WS % 8 == 0) {
+                        *reinterpret_cast<uint4 *>(wp) = ld[k];
+                    } else {        // 12-column rows: 8-byte stores, the last chunk keeps only its first half
+                        *reinterpret_cast<uint2 *>(wp) = make_uint2(ld[k].x, ld[k].y);
+                        if (8 * (i % NCH) + 8 <= WS) *reinterpret_cast<uint2 *>(wp + 4) = make_uint2(ld[k].z, ld[k].w);
+                    }
+                }
+            } else {
+                // edge emulation: per-pixel clamped fetch, 8 independent loads in flight per lane
+                for (int i0 = l; i0 < (WR - 1) * WS; i0 += 8 * LPT) {
+                    pixel v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const int i = dv::imin(i0 + e * LPT, (WR - 1) * WS - 1);
+                        const int sy = dv::iclip(y0 + i / WS, 0, rh - 1);
+                        const int sx = dv::iclip(x0 + i % WS, 0, rw - 1);
+                        v[e] = src[sy * rs + sx];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const int i = i0 + e * LPT;
+                        if (i < (WR - 1) * WS) win[i] = (int16_t) v[e];
+                    }
+                }
+            }
+        }
+        dv::wave_sync();
+
+        // ---- 2. horizontal pass: item = (row pair, strip) -> mid2[pair][4 cols] = (even row, odd row)
+        if (live) {
+            const int sh1 = has_h ? fbits - ib : 0;
+            const int rnd1 = (1 << sh1) >> 1;
+#pragma unroll
+            for (int it0 = 0; it0 < NPR * NS; it0 += LPT) {
+                const int it = it0 + l;
+                if (it >= NPR * NS) break;
+                const int pr = it / NS, s = it % NS;
+                if (2 * pr + 1 < row_lo || 2 * pr >= row_hi) continue;
+                int o[2][4];
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const uint2 *wp = reinterpret_cast<const uint2 *>(win + (2 * pr + e) * WS + 4 * s);
+                    const uint2 a = wp[0], b = wp[1], c = wp[2];
+                    const uint32_t d[6] = { a.x, a.y, b.x, b.y, c.x, c.y };
+                    // out x sums f[k] * p[x + 1 + k], p[] = the 12 pixels of d[]; the rounding offset seeds the sum
+                    int s0 = rnd1, s1 = rnd1, s2 = rnd1, s3 = rnd1;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) { s0 = dv::dot2(d[k], fh.od[k], s0); s2 = dv::dot2(d[k + 1], fh.od[k], s2); }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { s1 = dv::dot2(d[k + 1], fh.ev[k], s1); s3 = dv::dot2(d[k + 2], fh.ev[k], s3); }
+                    o[e][0] = s0; o[e][1] = s1; o[e][2] = s2; o[e][3] = s3;
+                }
+                if (has_v) {
+                    // intermediate rounding, reference src/mc_tmpl.c:150-152 (8-tap) / 462-464 (bilinear)
+#pragma unroll
+                    for (int e = 0; e < 2; e++)
+#pragma unroll
+                        for (int x = 0; x < 4; x++) o[e][x] >>= sh1;
+                } else {
+                    // no vertical filter: finish the sample here (the vertical pass is then the unit tap)
+#pragma unroll
+                    for (int e = 0; e < 2; e++)
+#pragma unroll
+                        for (int x = 0; x < 4; x++) {
+                            int v = o[e][x];            // = sum + rnd1
+                            if (!as_prep) {
+                                if (has_h) {
+                                    if (fbits == 4) v = ((v >> sh1) + ((1 << ib) >> 1)) >> ib;   // src/mc_tmpl.c:467-476
+                                    else            v = (v + 32) >> 6;                          // src/mc_tmpl.c:165-171
+                                }
+                            } else {
+                                v = has_h ? (v >> sh1) - bias : (v << ib) - bias;               // :283-291 / :61-72
+                            }
+                            o[e][x] = v;
+                        }
+                }
+                uint4 m;
+                m.x = dv::pack2(o[0][0], o[1][0]);
+                m.y = dv::pack2(o[0][1], o[1][1]);
+                m.z = dv::pack2(o[0][2], o[1][2]);
+                m.w = dv::pack2(o[0][3], o[1][3]);
+                *reinterpret_cast<uint4 *>(mid + pr * TW + 4 * s) = m;
+            }
+        }
+        dv::wave_sync();
+
+        // ---- 3. vertical pass: item = (output row, strip), R items per lane
+        if (live) {
+            int sh2, vb;
+            if (!has_v) { sh2 = 0; vb = 0; }
+            else if (!as_prep) { sh2 = has_h ? fbits + ib : fbits; vb = 0; }          // src/mc_tmpl.c:157-159,176-178
+            else { sh2 = has_h ? fbits : fbits - ib; vb = bias; }                     // :272-277, :294-299
+            const int rnd2 = (1 << sh2) >> 1;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int it = r * LPT + l;
+                const int vr = it / NS, vs = it % NS;
+                // rows vr .. vr+7 of the window = pairs j0 .. j0+4; odd vr starts in the middle of a pair
+                const int j0 = vr >> 1;
+                const bool odd = vr & 1;
+                int sum[4] = { rnd2, rnd2, rnd2, rnd2 };
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const uint32_t g = odd ? fv.od[k] : (k < 4 ? fv.ev[k] : 0u);
+                    const int j = dv::imin(j0 + k, NPR - 1);     // the 5th pair of an even row is weight 0
+                    const uint4 m = *reinterpret_cast<const uint4 *>(mid + j * TW + 4 * vs);
+                    sum[0] = dv::dot2(m.x, g, sum[0]);
+                    sum[1] = dv::dot2(m.y, g, sum[1]);
+                    sum[2] = dv::dot2(m.z, g, sum[2]);
+                    sum[3] = dv::dot2(m.w, g, sum[3]);
+                }
+#pragma unroll
+                for (int x = 0; x < 4; x++) q[r][x] = (sum[x] >> sh2) - vb;
+            }
+        }
+    };
+
+    predict(t.r[0]);
+    if (compound) {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) acc0[r][x] = q[r][x];
+        dv::wave_sync();                        // the second gather overwrites win / mid
+        predict(t.r[1]);
+    }
+
+    // ---- combine + store
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int it = r * LPT + l;
+            const int vr = it / NS, vs = it % NS;
+            if (vr >= t.h) continue;
+            int o[4];
+            if (t.kind == MCT_AVG) {
+#pragma unroll
+                for (int x = 0; x < 4; x++) o[x] = (acc0[r][x] + q[r][x] + (1 << ib) + bias * 2) >> (ib + 1);          // avg_c
+            } else if (t.kind == MCT_WAVG) {
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                    o[x] = (acc0[r][x] * t.weight + q[r][x] * (16 - t.weight) + (8 << ib) + bias * 16) >> (ib + 4);  // w_avg_c
+            } else {
+#pragma unroll
+                for (int x = 0; x < 4; x++) o[x] = q[r][x];
+            }
+            const int nvalid = dv::imin(4, t.w - 4 * vs);
+            if (t.kind != MCT_PREP) {
+#pragma unroll
+                for (int x = 0; x < 4; x++) o[x] = dv::iclip(o[x], 0, bitdepth_max);
+                // PUT_TMP: pixels into the scratch arena, row stride = block width (the reference's `lap` buffer of obmc())
+                pixel *d = t.kind == MCT_PUT_TMP
+                    ? reinterpret_cast<pixel *>(prep) + t.dst_off + (t.oy + vr) * t.bw + t.ox + 4 * vs
+                    : reinterpret_cast<pixel *>(dst.data[t.plane]) + t.dst_off + (t.oy + vr) * dst.stride[t.plane] + t.ox + 4 * vs;
+                if (nvalid == 4) {
+                    if (HBD) *reinterpret_cast<uint2 *>(d) = make_uint2(dv::pack2(o[0], o[1]), dv::pack2(o[2], o[3]));
+                    else *reinterpret_cast<uint32_t *>(d) = (uint32_t) o[0] | ((uint32_t) o[1] << 8) | ((uint32_t) o[2] << 16) | ((uint32_t) o[3] << 24);
+                } else if (nvalid > 0) {
+                    for (int x = 0; x < nvalid; x++) d[x] = (pixel) o[x];
+                }
+            } else {
+                int16_t *d = prep + t.dst_off + (t.oy + vr) * t.bw + t.ox + 4 * vs;
+                if (nvalid == 4) *reinterpret_cast<uint2 *>(d) = make_uint2(dv::pack2(o[0], o[1]), dv::pack2(o[2], o[3]));
+                else if (nvalid > 0) for (int x = 0; x < nvalid; x++) d[x] = (int16_t) o[x];
+            }
+        }
+    }
+}
+
+
+} // namespace
