@@ -118,6 +118,8 @@ struct McGroup {
     uint16_t n;           // tiles in the group, <= 64 / lanes-per-tile of the shape
     uint16_t cls;         // tile-shape bin
 };
+extern "C" int dav1d_hip_launch_recon_fused(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, int cls, const McTile *tiles,
+                                            const Dav1dHipItxTask *tasks, int n, int16_t *prep, void *coef, void *stream);
 extern "C" int dav1d_hip_launch_mc_all(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, const McTile *tiles,
                                        const McGroup *groups, int n_groups, int with_small, int16_t *prep, void *stream);
 extern "C" int dav1d_hip_launch_mc_bin(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, int cls,

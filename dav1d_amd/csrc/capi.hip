@@ -257,6 +257,36 @@ static bool itx_legal(int tx, int txtp) {
 
 extern "C" {
 
+} // extern "C"
+
+static bool itx_task_ok(const Dav1dHipItxTask &t) {
+    if (!itx_legal(t.tx, t.txtp) || t.plane > 2 || t.eob < 0 || t.flags > DAV1D_HIP_ITX_PACKED) return false;
+    return t.eob < av1_scan_prefix_off[t.tx + 1] - av1_scan_prefix_off[t.tx];
+}
+
+// How much of the slab can be non-zero: coefficients past the eob in scan order are zero by contract (the entropy
+// decoder only writes scan positions <= eob, src/recon_tmpl.c:458-520, and itx leaves slabs zeroed), so the kernel
+// reads and re-zeroes only the prefix [0, end).  2-D classes: the zig-zag's reach; H classes: the scan is the
+// slab order itself; V classes: every column can be touched.  The device copy carries `end` in the pad bytes.
+static void itx_fill_prefix(Dav1dHipItxTask &t) {
+    const int ncoef = av1_scan_prefix_off[t.tx + 1] - av1_scan_prefix_off[t.tx];
+    int end = ncoef;
+    if (t.txtp <= 9 || t.txtp == 16) end = av1_scan_prefix_end[av1_scan_prefix_off[t.tx] + t.eob];
+    else if (t.txtp == 11 || t.txtp == 13 || t.txtp == 15) end = t.eob + 1;
+    t.rsv[0] = (uint8_t) (end & 255);
+    t.rsv[1] = (uint8_t) (end >> 8);
+}
+
+// code path of a transform block: dc-only shortcut, else its two 1-D kinds (txtp_kinds() in itx_body.h); 16 = WHT
+static int itx_path_key(const Dav1dHipItxTask &t) {
+    static const uint8_t kinds[17] = {
+        0 | 0 << 2, 0 | 1 << 2, 1 | 0 << 2, 1 | 1 << 2, 0 | 3 << 2, 3 | 0 << 2, 3 | 3 << 2, 3 | 1 << 2,
+        1 | 3 << 2, 2 | 2 << 2, 2 | 0 << 2, 0 | 2 << 2, 2 | 1 << 2, 1 | 2 << 2, 2 | 3 << 2, 3 | 2 << 2, 16 };
+    return t.txtp == 0 && t.eob < 1 ? 0 : 1 + kinds[t.txtp];
+}
+
+extern "C" {
+
 int dav1d_hip_itx_list_create(Dav1dHipContext *c, Dav1dHipItxList **out, const Dav1dHipItxTask *tasks, size_t n) {
     if (!out || (!tasks && n)) return -EINVAL;
     *out = nullptr;
@@ -267,8 +297,7 @@ int dav1d_hip_itx_list_create(Dav1dHipContext *c, Dav1dHipItxList **out, const D
     size_t cnt[19] = { 0 };
     for (size_t i = 0; i < n; i++) {
         const Dav1dHipItxTask &t = tasks[i];
-        if (!itx_legal(t.tx, t.txtp) || t.plane > 2 || t.eob < 0 || t.flags > DAV1D_HIP_ITX_PACKED) { delete l; return -EINVAL; }
-        if (t.eob >= av1_scan_prefix_off[t.tx + 1] - av1_scan_prefix_off[t.tx]) { delete l; return -EINVAL; }
+        if (!itx_task_ok(t)) { delete l; return -EINVAL; }
         cnt[t.tx]++;
     }
     for (int b = 0; b < 19; b++) l->off[b + 1] = l->off[b] + cnt[b];
@@ -278,16 +307,7 @@ int dav1d_hip_itx_list_create(Dav1dHipContext *c, Dav1dHipItxList **out, const D
         for (int b = 0; b < 19; b++) pos[b] = l->off[b];
         for (size_t i = 0; i < n; i++) {
             Dav1dHipItxTask &t = sorted[pos[tasks[i].tx]++] = tasks[i];          // stable: keeps decode order inside a bin
-            // How much of the slab can be non-zero: coefficients past the eob in scan order are zero by contract (the entropy
-            // decoder only writes scan positions <= eob, src/recon_tmpl.c:458-520, and itx leaves slabs zeroed), so the kernel
-            // reads and re-zeroes only the prefix [0, end).  2-D classes: the zig-zag's reach; H classes: the scan is the
-            // slab order itself; V classes: every column can be touched.  The device copy carries `end` in the pad bytes.
-            const int ncoef = av1_scan_prefix_off[t.tx + 1] - av1_scan_prefix_off[t.tx];
-            int end = ncoef;
-            if (t.txtp <= 9 || t.txtp == 16) end = av1_scan_prefix_end[av1_scan_prefix_off[t.tx] + t.eob];
-            else if (t.txtp == 11 || t.txtp == 13 || t.txtp == 15) end = t.eob + 1;
-            t.rsv[0] = (uint8_t) (end & 255);
-            t.rsv[1] = (uint8_t) (end >> 8);
+            itx_fill_prefix(t);
         }
         // Blocks that share a wave should share their code path: a wave runs every 1-D kernel (and the dc-only shortcut) that
         // any of its blocks needs, one after the other.  Inside windows of consecutive blocks (still close together in the
@@ -295,10 +315,7 @@ int dav1d_hip_itx_list_create(Dav1dHipContext *c, Dav1dHipItxList **out, const D
         // blocks of one list write disjoint pixels, so their order is free.  Speed only.
         static const int win_waves = getenv("DAV1D_HIP_ITX_SORT_WINDOW") ? atoi(getenv("DAV1D_HIP_ITX_SORT_WINDOW")) : 128;
         if (win_waves > 0) {
-            static const uint8_t kinds[17] = {       // first | second << 2 per itxfm_add type (txtp_kinds() in itx.hip); 16 = WHT
-                0 | 0 << 2, 0 | 1 << 2, 1 | 0 << 2, 1 | 1 << 2, 0 | 3 << 2, 3 | 0 << 2, 3 | 3 << 2, 3 | 1 << 2,
-                1 | 3 << 2, 2 | 2 << 2, 2 | 0 << 2, 0 | 2 << 2, 2 | 1 << 2, 1 | 2 << 2, 2 | 3 << 2, 3 | 2 << 2, 16 };
-            auto key = [](const Dav1dHipItxTask &t) -> int { return t.txtp == 0 && t.eob < 1 ? 0 : 1 + kinds[t.txtp]; };
+            auto key = [](const Dav1dHipItxTask &t) -> int { return itx_path_key(t); };
             for (int b = 0; b < 19; b++) {
                 const int w = k_tx_w[b], h = k_tx_h[b];
                 const int lanes = std::max(std::min(h, 32), w);
@@ -439,7 +456,7 @@ static McRef mc_ref_of(const Dav1dHipMcTask &t) {
 
 // cut one prediction block (or a fused pair) into <= 64x16 tiles and bin them by tile shape
 static void push_tiles(std::vector<McTile> *bins, const Dav1dHipMcTask &t, int kind, uint32_t dst_off,
-                       const Dav1dHipMcTask *second, int weight) {
+                       const Dav1dHipMcTask *second, int weight, std::vector<McTile> *single = nullptr) {
     McTile m;
     memset(&m, 0, sizeof(m));
     m.dst_off = dst_off;
@@ -452,7 +469,7 @@ static void push_tiles(std::vector<McTile> *bins, const Dav1dHipMcTask &t, int k
             m.w = tw; m.h = th; m.ox = ox; m.oy = oy;
             m.r[0] = r0; m.r[0].src_x += ox; m.r[0].src_y += oy;
             m.r[1] = r1; m.r[1].src_x += ox; m.r[1].src_y += oy;
-            bins[cls].push_back(m);
+            if (single) single->push_back(m); else bins[cls].push_back(m);
         }
 }
 
@@ -755,6 +772,25 @@ struct Dav1dHipInterList {
     int cell_stride[3], stride_px[3];
 };
 
+// Recon lists: a transform block that covers exactly one prediction block (same plane, position and size, square 4x4 ..
+// 64x64) is paired with it; the pair runs in one wave (recon.hip) and the prediction never reaches the picture on its own.
+struct ReconPairing {
+    std::unordered_map<uint64_t, uint32_t> by_pos;      // plane << 32 | dst_off -> index of the (square) transform task there
+    const Dav1dHipItxTask *itx;
+    std::vector<char> taken;                            // per transform task: paired
+    std::vector<McTile> tiles[5];                       // per size class: tiles of the paired blocks, block by block
+    std::vector<uint32_t> itx_idx[5];                   // per size class: the transform task of each block
+    int mask;                                           // size classes that pair (bit k: 4 << k pixels square)
+    // the transform task a prediction of this rectangle pairs with, or -1
+    long find(int plane, uint32_t dst_off, int w, int h) {
+        if (w != h) return -1;
+        auto it = by_pos.find((uint64_t) plane << 32 | dst_off);
+        if (it == by_pos.end() || taken[it->second]) return -1;
+        const Dav1dHipItxTask &t = itx[it->second];
+        return (t.tx <= 4 && (mask >> t.tx & 1) && (4 << t.tx) == w) ? (long) it->second : -1;
+    }
+};
+
 // marks the 4x4 cells of a w x h rectangle at pixel offset `off` of a plane
 static void mark_cells(Dav1dHipInterList *l, int plane, uint32_t off, int w, int h, uint16_t bit) {
     const int sp = l->stride_px[plane], cs = l->cell_stride[plane];
@@ -772,7 +808,7 @@ extern "C" {
 } // extern "C"
 
 static int inter_list_create_geo(Dav1dHipContext *c, Dav1dHipInterList **out, const Dav1dHipMcTask *mc, size_t n_mc,
-                                 const Dav1dHipCompTask *comp, size_t n_comp, const Dav1dHipPicture *geom);
+                                 const Dav1dHipCompTask *comp, size_t n_comp, const Dav1dHipPicture *geom, ReconPairing *pair = nullptr);
 
 extern "C" {
 
@@ -784,7 +820,7 @@ int dav1d_hip_inter_list_create(Dav1dHipContext *c, Dav1dHipInterList **out, con
 } // extern "C"
 
 static int inter_list_create_geo(Dav1dHipContext *c, Dav1dHipInterList **out, const Dav1dHipMcTask *mc, size_t n_mc,
-                                 const Dav1dHipCompTask *comp, size_t n_comp, const Dav1dHipPicture *geom) {
+                                 const Dav1dHipCompTask *comp, size_t n_comp, const Dav1dHipPicture *geom, ReconPairing *pair) {
     if (!out || (!mc && n_mc) || (!comp && n_comp)) return -EINVAL;
     *out = nullptr;
     // prep offset -> producing PREP task, and how many compound inputs read that offset
@@ -814,7 +850,10 @@ static int inter_list_create_geo(Dav1dHipContext *c, Dav1dHipInterList **out, co
             }
         }
         if (fuse) {
-            push_tiles(bins, mc[a], k.kind == DAV1D_HIP_COMP_AVG ? MCT_AVG : MCT_WAVG, k.dst_off, &mc[b], k.arg);
+            const long j = pair ? pair->find(k.plane, k.dst_off, k.w, k.h) : -1;
+            if (j >= 0) { pair->taken[j] = 1; pair->itx_idx[pair->itx[j].tx].push_back((uint32_t) j); }
+            push_tiles(bins, mc[a], k.kind == DAV1D_HIP_COMP_AVG ? MCT_AVG : MCT_WAVG, k.dst_off, &mc[b], k.arg,
+                       j >= 0 ? &pair->tiles[pair->itx[j].tx] : nullptr);
             fused_prep[a] = fused_prep[b] = 1;
             n_fused++;
         } else {
@@ -822,9 +861,12 @@ static int inter_list_create_geo(Dav1dHipContext *c, Dav1dHipInterList **out, co
         }
     }
     for (size_t i = 0; i < n_mc; i++)
-        if (!fused_prep[i])
+        if (!fused_prep[i]) {
+            const long j = (pair && mc[i].kind == DAV1D_HIP_MC_PUT) ? pair->find(mc[i].plane, mc[i].dst_off, mc[i].w, mc[i].h) : -1;
+            if (j >= 0) { pair->taken[j] = 1; pair->itx_idx[pair->itx[j].tx].push_back((uint32_t) j); }
             push_tiles(bins, mc[i], mc[i].kind == DAV1D_HIP_MC_PUT ? MCT_PUT : mc[i].kind == DAV1D_HIP_MC_PREP ? MCT_PREP : MCT_PUT_TMP,
-                       mc[i].dst_off, nullptr, 0);
+                       mc[i].dst_off, nullptr, 0, j >= 0 ? &pair->tiles[pair->itx[j].tx] : nullptr);
+        }
     Dav1dHipInterList *l = new (std::nothrow) Dav1dHipInterList();
     if (!l) return -ENOMEM;
     l->mc = nullptr; l->comp = nullptr; l->n_fused = n_fused;
@@ -1296,12 +1338,32 @@ extern "C" int dav1d_hip_fg_apply(Dav1dHipContext *c, const Dav1dHipPicture *dst
 // in the order largest tile shape first, each followed by an event; the residual launches go down a side stream, largest
 // transform first, each waiting for the events of its own predecessors only.  The memory-bound predictions of the small
 // shapes then overlap with the arithmetic-bound 64- and 32-point transforms instead of queueing in front of them.
+#ifndef RECON_FUSE_DEFAULT
+#define RECON_FUSE_DEFAULT 6
+#endif
 struct Dav1dHipReconList {
-    Dav1dHipInterList *inter;
-    Dav1dHipItxList *itx;
+    Dav1dHipInterList *inter;  // predictions that have no residual of their own shape (and everything when pairing is off)
+    Dav1dHipItxList *itx;      // residuals without a prediction of their own shape
     uint16_t dep[19];          // per transform size: bits of the launches (see Dav1dHipInterList::writers) it has to wait for
     int stride_px[3];
+    // paired blocks, per square size class 4x4 .. 64x64: tiles (1, 1, 1, 2, 4 per block) and transform tasks, device resident
+    McTile *f_tiles[5];
+    Dav1dHipItxTask *f_tasks[5];
+    size_t f_n[5];
+    int f_max_ref;
 };
+
+// DAV1D_HIP_RECON_FUSE: which square block sizes get paired (transform block + the prediction block of the same rectangle in
+// one wave, recon.hip): bit 0 4x4, bit 1 8x8, bit 2 16x16, bit 3 32x32, bit 4 64x64; 0 none.  Measured on MI355X (8K 10-bit
+// frame, ms per frame): none 0.362, 8x8 + 16x16 (6, the default) 0.311, 4x4 + 8x8 0.318, 4x4 + 8x8 + 16x16 0.335, 16x16 + 32x32
+// 0.333, all 0.411.  Kernel by kernel a pair beats prediction + residual only for the small sizes (4x4: 73 against 83 us,
+// 8x8: 76 against 84; 16x16: 90 against 79, 32x32: 101 against 69: the fused wave carries the LDS and registers of both
+// bodies); what pays is that the paired launches move a quarter less HBM traffic AND run next to the pipelined launches of
+// the other sizes on streams of their own.
+static int recon_fuse_mask() {
+    const char *e = getenv("DAV1D_HIP_RECON_FUSE");
+    return (e ? atoi(e) : RECON_FUSE_DEFAULT) & 31;
+}
 
 extern "C" {
 
@@ -1310,12 +1372,72 @@ int dav1d_hip_recon_list_create(Dav1dHipContext *c, Dav1dHipReconList **out, con
                                 const Dav1dHipItxTask *itx, size_t n_itx) {
     if (!c || !out || !geometry) return -EINVAL;
     *out = nullptr;
+    if ((!itx && n_itx) || n_itx > 0xffffffffu) return -EINVAL;
+    for (size_t i = 0; i < n_itx; i++) if (!itx_task_ok(itx[i])) return -EINVAL;
     Dav1dHipReconList *l = new (std::nothrow) Dav1dHipReconList();
     if (!l) return -ENOMEM;
     l->inter = nullptr; l->itx = nullptr;
-    int rc = inter_list_create_geo(c, &l->inter, mc, n_mc, comp, n_comp, geometry);
+    for (int k = 0; k < 5; k++) { l->f_tiles[k] = nullptr; l->f_tasks[k] = nullptr; l->f_n[k] = 0; }
+    l->f_max_ref = 0;
+    ReconPairing pair;
+    const bool fuse = recon_fuse_mask() != 0;
+    if (fuse) {
+        pair.mask = recon_fuse_mask();
+        pair.itx = itx;
+        pair.taken.assign(n_itx, 0);
+        for (size_t i = 0; i < n_itx; i++)
+            if (itx[i].tx <= 4 && (pair.mask >> itx[i].tx & 1)) pair.by_pos[(uint64_t) itx[i].plane << 32 | itx[i].dst_off] = (uint32_t) i;
+    }
+    int rc = inter_list_create_geo(c, &l->inter, mc, n_mc, comp, n_comp, geometry, fuse ? &pair : nullptr);
+    std::vector<Dav1dHipItxTask> rest;
+    if (!rc && fuse) {
+        rest.reserve(n_itx);
+        for (size_t i = 0; i < n_itx; i++) if (!pair.taken[i]) rest.push_back(itx[i]);
+        itx = rest.data();
+        n_itx = rest.size();
+    }
     if (!rc) rc = dav1d_hip_itx_list_create(c, &l->itx, itx, n_itx);
-    if (rc) { if (l->inter) dav1d_hip_inter_list_destroy(c, l->inter); delete l; return rc; }
+    // ---- the paired blocks of each size: ordered by where their first tile reads (as the tiles of mc lists are), then
+    // grouped by the transform's code path inside windows of 128 waves (as the blocks of itx lists are); uploaded
+    for (int k = 0; k < 5 && !rc && fuse; k++) {
+        const size_t nblk = pair.itx_idx[k].size();
+        if (!nblk) continue;
+        const int tpb = k < 3 ? 1 : k == 3 ? 2 : 4, bpw = k == 0 ? 16 : k == 1 ? 8 : k == 2 ? 4 : k == 3 ? 2 : 1;
+        if (pair.tiles[k].size() != nblk * tpb) { rc = -EINVAL; break; }
+        std::vector<uint32_t> ord(nblk);
+        std::vector<uint64_t> skey(nblk);
+        for (size_t i = 0; i < nblk; i++) {
+            ord[i] = (uint32_t) i;
+            const McTile &t = pair.tiles[k][i * tpb];
+            const uint64_t y = (uint64_t) (t.r[0].src_y + 4096) & 0xffff, x = (uint64_t) (t.r[0].src_x + 4096) & 0xffff;
+            skey[i] = ((uint64_t) t.r[0].ref << 56) | ((uint64_t) t.plane << 52) | ((y >> 6) << 32) | x;
+        }
+        std::stable_sort(ord.begin(), ord.end(), [&](uint32_t p, uint32_t q) { return skey[p] < skey[q]; });
+        const size_t win = (size_t) 128 * bpw;
+        for (size_t lo = 0; lo < nblk; lo += win)
+            std::stable_sort(ord.begin() + lo, ord.begin() + std::min(lo + win, nblk), [&](uint32_t p, uint32_t q) {
+                const McTile &tp = pair.tiles[k][p * tpb], &tq = pair.tiles[k][q * tpb];
+                const int kp = itx_path_key(pair.itx[pair.itx_idx[k][p]]) * 8 + tp.kind, kq = itx_path_key(pair.itx[pair.itx_idx[k][q]]) * 8 + tq.kind;
+                return kp < kq;
+            });
+        std::vector<McTile> tiles(nblk * tpb);
+        std::vector<Dav1dHipItxTask> tasks(nblk);
+        for (size_t i = 0; i < nblk; i++) {
+            for (int j = 0; j < tpb; j++) {
+                const McTile &t = tiles[i * tpb + j] = pair.tiles[k][(size_t) ord[i] * tpb + j];
+                const bool two = t.kind == MCT_AVG || t.kind == MCT_WAVG;
+                l->f_max_ref = std::max(l->f_max_ref, std::max((int) t.r[0].ref, two ? (int) t.r[1].ref : 0));
+            }
+            tasks[i] = pair.itx[pair.itx_idx[k][ord[i]]];
+            itx_fill_prefix(tasks[i]);
+        }
+        if (hipMalloc((void **) &l->f_tiles[k], tiles.size() * sizeof(McTile)) != hipSuccess ||
+            hipMalloc((void **) &l->f_tasks[k], tasks.size() * sizeof(Dav1dHipItxTask)) != hipSuccess) { rc = -ENOMEM; break; }
+        rc = dav1d_hip_upload(c, l->f_tiles[k], tiles.data(), tiles.size() * sizeof(McTile));
+        if (!rc) rc = dav1d_hip_upload(c, l->f_tasks[k], tasks.data(), tasks.size() * sizeof(Dav1dHipItxTask));
+        l->f_n[k] = nblk;
+    }
+    if (rc) { dav1d_hip_recon_list_destroy(c, l); return rc; }
     for (int b = 0; b < 19; b++) l->dep[b] = 0;
     for (int p = 0; p < 3; p++) l->stride_px[p] = l->inter->stride_px[p];
     for (size_t i = 0; i < n_itx; i++) {
@@ -1340,8 +1462,10 @@ int dav1d_hip_recon_list_create(Dav1dHipContext *c, Dav1dHipReconList **out, con
 
 void dav1d_hip_recon_list_destroy(Dav1dHipContext *c, Dav1dHipReconList *l) {
     if (!l) return;
-    dav1d_hip_inter_list_destroy(c, l->inter);
-    dav1d_hip_itx_list_destroy(c, l->itx);
+    if (l->inter) dav1d_hip_inter_list_destroy(c, l->inter);
+    if (l->itx) dav1d_hip_itx_list_destroy(c, l->itx);
+    hipStreamSynchronize(c->stream);
+    for (int k = 0; k < 5; k++) { if (l->f_tiles[k]) hipFree(l->f_tiles[k]); if (l->f_tasks[k]) hipFree(l->f_tasks[k]); }
     delete l;
 }
 
@@ -1351,25 +1475,66 @@ int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, con
     const int bps = dst->bpc > 8 ? 2 : 1;
     for (int p = 0; p < 3; p++)
         if (l->stride_px[p] && dst->p[p].stride / bps != l->stride_px[p]) return -EINVAL;    // not the geometry the list was made for
+    size_t n_paired = 0;
+    bool paired_on_side = false;
+    for (int k = 0; k < 5; k++) n_paired += l->f_n[k];
+    if (n_paired) {
+        // the paired blocks: one launch per size, largest first; independent of each other and of everything below
+        if (n_refs < 1 || n_refs > 8 || l->f_max_ref >= n_refs) return -EINVAL;
+        const DevPlanes dp = dev_planes(dst);
+        DevPlanes rp[8];
+        for (int i = 0; i < n_refs; i++) {
+            if (refs[i].bpc != dst->bpc) return -EINVAL;
+            rp[i] = dev_planes(&refs[i]);
+        }
+        // on side streams 2 and 3 (0 and 1 belong to the pipeline of the unpaired rest below, which runs next to them)
+        const bool side = c->concurrent && n_paired >= 16384;
+        int rc = 0, lane = 0;
+        if (side) {
+            (void) hipEventRecord(c->ev_fork, c->stream);
+            (void) hipStreamWaitEvent(c->side[2], c->ev_fork, 0);
+            (void) hipStreamWaitEvent(c->side[3], c->ev_fork, 0);
+        }
+        for (int k = 4; k >= 0 && !rc; k--)
+            if (l->f_n[k]) {
+                rc = dav1d_hip_launch_recon_fused(&dp, rp, n_refs, dst->bpc, k, l->f_tiles[k], l->f_tasks[k], (int) l->f_n[k], prep, coef,
+                                                  side ? c->side[2 + lane] : c->stream);
+                lane ^= 1;
+            }
+        if (side) {
+            (void) hipEventRecord(c->ev_join[2], c->side[2]);
+            (void) hipEventRecord(c->ev_join[3], c->side[3]);
+        }
+        if (rc) return rc;
+        paired_on_side = side;
+        if (!l->inter->mc->n && !l->inter->comp->n && !l->itx->n) {
+            if (side) { (void) hipStreamWaitEvent(c->stream, c->ev_join[2], 0); (void) hipStreamWaitEvent(c->stream, c->ev_join[3], 0); }
+            return 0;
+        }
+    }
     const Dav1dHipMcList *ml = l->inter->mc;
     // DAV1D_HIP_RECON_PIPELINE = smallest residual list worth two streams (0: always pipeline, -1: never); read per call so that
     // tests can switch it
     const char *env = getenv("DAV1D_HIP_RECON_PIPELINE");
     const long min_tasks = env ? atol(env) : 16384;
+    auto join_paired = [&]() {
+        if (paired_on_side) { (void) hipStreamWaitEvent(c->stream, c->ev_join[2], 0); (void) hipStreamWaitEvent(c->stream, c->ev_join[3], 0); }
+    };
     if (min_tasks < 0 || !c->concurrent || mc_fused_min_bin() < MC_BINS || (long) l->itx->n < min_tasks) {
         int rc = dav1d_hip_inter_list_run(c, l->inter, dst, refs, n_refs, prep, mask);
         if (!rc) rc = dav1d_hip_itx_list_run(c, l->itx, dst, coef);
+        join_paired();
         return rc;
     }
-    if (n_refs < 1 || n_refs > 8 || (ml->n && ml->max_ref >= n_refs)) return -EINVAL;
+    if (n_refs < 1 || n_refs > 8 || (ml->n && ml->max_ref >= n_refs)) { join_paired(); return -EINVAL; }
     const DevPlanes dp = dev_planes(dst);
     DevPlanes rp[8];
     for (int i = 0; i < n_refs; i++) {
-        if (refs[i].bpc != dst->bpc) return -EINVAL;
+        if (refs[i].bpc != dst->bpc) { join_paired(); return -EINVAL; }
         rp[i] = dev_planes(&refs[i]);
     }
     int rc = mc_regroup(c, const_cast<Dav1dHipMcList *>(ml), rp, n_refs);
-    if (rc) return rc;
+    if (rc) { join_paired(); return rc; }
     // DAV1D_HIP_RECON_LANES: side streams the residual launches are dealt over.  Measured (8K 10-bit): 1 lane 0.379 ms,
     // 2 lanes 0.394, 3 lanes 0.407, 5 lanes 0.420 per frame — residual launches running next to each other take bandwidth from
     // the predictions they are waiting for; one in-order residual stream keeps the pipeline a pipeline.
@@ -1423,6 +1588,7 @@ int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, con
         (void) hipEventRecord(c->ev_join[i], c->side[i]);
         (void) hipStreamWaitEvent(sm, c->ev_join[i], 0);
     }
+    join_paired();
     return rc;
 }
 

@@ -81,9 +81,12 @@ constexpr int itx_lds_ints() {
 }
 
 // The wave `group` of the blocks of ONE transform size: blocks [group * BPW, group * BPW + BPW) of tasks[0 .. n).
-template <int TX, typename pixel, typename coef>
+// PRED_LDS (fused prediction + residual kernels): the pixels the residual is added to come from pred_s (block `sub` of the
+// wave, W x H, row stride W) instead of the picture; the sum still goes to the picture.
+template <int TX, typename pixel, typename coef, bool PRED_LDS = false>
 __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItxTask *__restrict__ tasks,
-                                         const int n, coef *__restrict__ cf, const int bitdepth_max, const int group, int *tmp_s)
+                                         const int n, coef *__restrict__ cf, const int bitdepth_max, const int group, int *tmp_s,
+                                         const pixel *pred_s = nullptr)
 {
     constexpr int W = tx_w(TX), H = tx_h(TX);
     constexpr int SW = cmin(W, 32), SH = cmin(H, 32);
@@ -144,7 +147,7 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
         }
         if (l < W) {
 #pragma unroll
-            for (int y = 0; y < H; y++) dpx[y] = d[y * stride];
+            for (int y = 0; y < H; y++) dpx[y] = PRED_LDS ? pred_s[(sub * H + y) * W + l] : d[y * stride];
         }
 #pragma unroll
         for (int k = 0; k < (NCH + LPB - 1) / LPB; k++) {
@@ -168,7 +171,7 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
         if (l == 0) { dc = gcf[0]; if (!(t.flags & DAV1D_HIP_ITX_PACKED)) gcf[0] = 0; }            // src/itx_tmpl.c:59-60
         if (l < W) {
 #pragma unroll
-            for (int y = 0; y < H; y++) dpx[y] = d[y * stride];
+            for (int y = 0; y < H; y++) dpx[y] = PRED_LDS ? pred_s[(sub * H + y) * W + l] : d[y * stride];
         }
     }
     dc = __shfl(dc, sub * LPB);

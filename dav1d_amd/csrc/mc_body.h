@@ -41,9 +41,13 @@ constexpr int mc_lds_bytes() {
 }
 
 // One wave's worth of tiles of shape (TW, TH): tiles[t0 .. t0 + nt), nt <= 64 / LPT.  `smem` = mc_lds_bytes<TW, TH>() of LDS.
-template <int TW, int TH, typename pixel>
+// TO_LDS (fused prediction + residual kernels): pixels of PUT / AVG / WAVG tiles go to pred_s instead of the picture — block
+// (tile index - pred_tile0) >> pred_tpb_log2 of the wave, pred_w x pred_h pixels each, row stride pred_w.
+template <int TW, int TH, typename pixel, bool TO_LDS = false>
 __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs, const McTile *__restrict__ tiles, const int t0, const int nt,
-                                        int16_t *__restrict__ prep, const int bitdepth_max, uint4 *smem)
+                                        int16_t *__restrict__ prep, const int bitdepth_max, uint4 *smem,
+                                        pixel *pred_s = nullptr, const int pred_tile0 = 0, const int pred_tpb_log2 = 0,
+                                        const int pred_w = 0, const int pred_h = 0)
 {
     constexpr int NS = TW / 4;                          // 4-pixel strips per row
     constexpr int LPT = mc_cmin(64, TW * TH / 4);       // lanes per tile
@@ -105,7 +109,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
 
     // one prediction (gather -> h -> v) of this lane's strips into q[]; a lambda invoked once or
     // twice rather than a loop over t.r[] so that the record is never indexed dynamically
-    auto predict = [&](const McRef rf) {
+    auto predict = [&](const McRef rf, const bool act) {
         const bool has_h = rf.mx != 0, has_v = rf.my != 0;
         const int fbits = rf.fh == 6 ? 4 : 6;
         const Taps fh = load_taps(rf.fh, rf.mx), fv = load_taps(rf.fv, rf.my);
@@ -115,7 +119,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
         const int row_lo = vspan & 15, row_hi = TH - 1 + (vspan >> 4);
 
         // ---- 1. gather the window
-        if (live) {
+        if (act) {
             const pixel *src;
             int rs, rw, rh;
             if (G == 1) {
@@ -185,7 +189,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
         dv::wave_sync();
 
         // ---- 2. horizontal pass: item = (row pair, strip) -> mid2[pair][4 cols] = (even row, odd row)
-        if (live) {
+        if (act) {
             const int sh1 = has_h ? fbits - ib : 0;
             const int rnd1 = (1 << sh1) >> 1;
 #pragma unroll
@@ -243,7 +247,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
         dv::wave_sync();
 
         // ---- 3. vertical pass: item = (output row, strip), R items per lane
-        if (live) {
+        if (act) {
             int sh2, vb;
             if (!has_v) { sh2 = 0; vb = 0; }
             else if (!as_prep) { sh2 = has_h ? fbits + ib : fbits; vb = 0; }          // src/mc_tmpl.c:157-159,176-178
@@ -273,14 +277,18 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
         }
     };
 
-    predict(t.r[0]);
-    if (compound) {
+    predict(t.r[0], live);
+    // the second prediction of the compound tiles: entered by the whole wave (lanes of single-reference tiles idle through
+    // it) so that every lane passes the same LDS hand-off points, whatever follows this body
+    if (__any(compound)) {
+        if (compound) {
 #pragma unroll
-        for (int r = 0; r < R; r++)
+            for (int r = 0; r < R; r++)
 #pragma unroll
-            for (int x = 0; x < 4; x++) acc0[r][x] = q[r][x];
+                for (int x = 0; x < 4; x++) acc0[r][x] = q[r][x];
+        }
         dv::wave_sync();                        // the second gather overwrites win / mid
-        predict(t.r[1]);
+        predict(t.r[1], compound);
     }
 
     // ---- combine + store
@@ -309,6 +317,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
                 // PUT_TMP: pixels into the scratch arena, row stride = block width (the reference's `lap` buffer of obmc())
                 pixel *d = t.kind == MCT_PUT_TMP
                     ? reinterpret_cast<pixel *>(prep) + t.dst_off + (t.oy + vr) * t.bw + t.ox + 4 * vs
+                    : TO_LDS ? pred_s + ((ti - pred_tile0) >> pred_tpb_log2) * (pred_w * pred_h) + (t.oy + vr) * pred_w + t.ox + 4 * vs
                     : reinterpret_cast<pixel *>(dst.data[t.plane]) + t.dst_off + (t.oy + vr) * dst.stride[t.plane] + t.ox + 4 * vs;
                 if (nvalid == 4) {
                     if (HBD) *reinterpret_cast<uint2 *>(d) = make_uint2(dv::pack2(o[0], o[1]), dv::pack2(o[2], o[3]));

@@ -1,0 +1,87 @@
+// Prediction and residual of a block in one wave (gfx950).
+//
+// The reference reconstructs an inter block as mc() into the picture followed by itxfm_add() on the same pixels
+// (src/recon_tmpl.c:1557-2000).  Run as two launches, every predicted pixel is written to HBM once and read back once by
+// the residual launch — 4 of the 16 bytes per sample the pair moves.  Where a transform block covers exactly one prediction
+// block (same rectangle; the recon list pairs them up), the wave that owns the transform block first runs the
+// motion-compensation body for the block's tiles with the LDS as destination, then the inverse-transform body with the LDS
+// as the source of the pixels it adds to: the picture is written once.  Both bodies are the ones of mc.hip / itx.hip
+// (mc_body.h, itx_body.h), bit for bit.
+//
+// One kernel per square transform size (4x4 .. 64x64): a wave takes as many blocks as the transform body packs into a wave
+// (16, 8, 4, 2, 1) and predicts them tile group by tile group (tiles of <= 64x16, as in mc.hip).
+#include "mc_body.h"
+#include "itx_body.h"
+
+namespace {
+
+constexpr int rc_log2(int v) { return v <= 1 ? 0 : 1 + rc_log2(v >> 1); }
+
+template <int CLS, typename pixel, typename coef>
+__global__ __launch_bounds__(64) void recon_fused_kernel(const DevPlanes dst, const RefSet refs, const McTile *__restrict__ tiles,
+                                                         const Dav1dHipItxTask *__restrict__ tasks, const int n_blocks,
+                                                         int16_t *__restrict__ prep, coef *__restrict__ cf, const int bitdepth_max)
+{
+    constexpr int TX = CLS;                                  // TX_4X4 .. TX_64X64
+    constexpr int W = 4 << CLS;
+    constexpr int TW = mc_cmin(W, 64), TH = mc_cmin(W, 16);  // tile shape of mc.hip for a W x W block
+    constexpr int TPB = (W / TW) * (W / TH);                 // tiles per block: 1, 1, 1, 2, 4
+    constexpr int LPB = cmax(cmin(W, 32), W), BPW = 64 / LPB;   // blocks per wave of the transform body
+    constexpr int G = 64 / mc_cmin(64, TW * TH / 4);         // tiles per call of the prediction body
+    __shared__ uint4 smem_mc[(mc_lds_bytes<TW, TH>() + 15) / 16];
+    __shared__ __attribute__((aligned(16))) int smem_itx[itx_lds_ints<TX>()];
+    __shared__ __attribute__((aligned(16))) pixel pred[BPW * W * W];
+
+    const int group = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x);
+    const int block0 = group * BPW;
+    if (block0 >= n_blocks) return;
+    const int nb = dv::imin(BPW, n_blocks - block0);
+    const int tile0 = block0 * TPB, ntile = nb * TPB;
+    for (int c = 0; c < ntile; c += G) {
+        mc_body<TW, TH, pixel, true>(dst, refs, tiles, tile0 + c, dv::imin(G, ntile - c), prep, bitdepth_max, smem_mc,
+                                     pred, tile0, rc_log2(TPB), W, W);
+        dv::wave_sync();
+    }
+    itx_body<TX, pixel, coef, true>(dst, tasks, n_blocks, cf, bitdepth_max, group, smem_itx, pred);
+}
+
+template <int CLS, typename pixel, typename coef>
+void launch_cls(const DevPlanes &dst, const RefSet &refs, const McTile *tiles, const Dav1dHipItxTask *tasks, const int n,
+                int16_t *prep, coef *cf, const int bitdepth_max, hipStream_t stream)
+{
+    constexpr int W = 4 << CLS, LPB = cmax(cmin(W, 32), W), BPW = 64 / LPB;
+    hipLaunchKernelGGL((recon_fused_kernel<CLS, pixel, coef>), dim3((n + BPW - 1) / BPW), dim3(64), 0, stream,
+                       dst, refs, tiles, tasks, n, prep, cf, bitdepth_max);
+}
+
+template <typename pixel, typename coef>
+hipError_t launch_any(const int cls, const DevPlanes &dst, const RefSet &refs, const McTile *tiles, const Dav1dHipItxTask *tasks,
+                      const int n, int16_t *prep, coef *cf, const int bitdepth_max, hipStream_t stream)
+{
+    switch (cls) {
+    case 0: launch_cls<0, pixel, coef>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, stream); break;
+    case 1: launch_cls<1, pixel, coef>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, stream); break;
+    case 2: launch_cls<2, pixel, coef>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, stream); break;
+    case 3: launch_cls<3, pixel, coef>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, stream); break;
+    case 4: launch_cls<4, pixel, coef>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, stream); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+} // namespace
+
+// tiles[] / tasks[] (device): the n blocks of ONE square transform size cls = 0 (4x4) .. 4 (64x64); block i owns
+// tasks[i] and the (1, 1, 1, 2, 4) tiles starting at tiles[i * tiles_per_block].
+extern "C" int dav1d_hip_launch_recon_fused(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, int cls, const McTile *tiles,
+                                            const Dav1dHipItxTask *tasks, int n, int16_t *prep, void *coef, void *stream)
+{
+    if (n <= 0) return 0;
+    RefSet rs;
+    for (int i = 0; i < 8; i++) rs.r[i] = refs[i < n_refs ? i : 0];
+    const int bitdepth_max = (1 << bpc) - 1;
+    hipError_t e;
+    if (bpc == 8) e = launch_any<uint8_t, int16_t>(cls, *dst, rs, tiles, tasks, n, prep, (int16_t *) coef, bitdepth_max, (hipStream_t) stream);
+    else          e = launch_any<uint16_t, int32_t>(cls, *dst, rs, tiles, tasks, n, prep, (int32_t *) coef, bitdepth_max, (hipStream_t) stream);
+    return hip_rc(e);
+}

@@ -148,12 +148,14 @@ def test_frame_from_packed_coefficients(ctx, bpc):
         assert np.array_equal(got[pl], want[pl]), pl
 
 
+@pytest.mark.parametrize("fuse", ["0", "31", "6"], ids=["two-kernels", "all-paired", "default-paired"])
 @pytest.mark.parametrize("pipeline", ["0", "-1"], ids=["pipelined", "sequential"])
-@pytest.mark.parametrize("bpc", [8, 10])
-def test_recon_list_matches_oracle(ctx, bpc, pipeline, monkeypatch):
+@pytest.mark.parametrize("bpc", [8, 10, 12])
+def test_recon_list_matches_oracle(ctx, bpc, pipeline, fuse, monkeypatch):
     """dav1d_hip_recon_list_*: predictions and residuals as one list, the residual launch of a transform size waiting only
     for the prediction launches under its blocks (two streams) — and the same list run strictly one phase after the other."""
     monkeypatch.setenv("DAV1D_HIP_RECON_PIPELINE", pipeline)
+    monkeypatch.setenv("DAV1D_HIP_RECON_FUSE", fuse)      # paired: prediction + residual of a block in one wave (recon.hip)
     w, h = (512, 128) if ctx.backend == "emu" else (1280, 1024)
     frame = synth.make_frame(w, h, bpc, seed=515 + bpc, edge_frac=0.1)
     rng = np.random.default_rng(9 + bpc)
