@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--two-phase", action="store_true",
                     help="run the step as dav1d_hip_inter_list_run + dav1d_hip_itx_list_run (every residual after every prediction) "
                          "instead of the pipelined dav1d_hip_recon_list_run")
+    ap.add_argument("--step-only", action="store_true",
+                    help="run the warm-up and the timed steps and nothing else (no per-kernel timing, parity, CPU or full-table legs): "
+                         "what tools/pmc_profile.sh counts the step's HBM traffic on")
     ap.add_argument("--shard", choices=["frames", "tile-cols"], default="frames",
                     help="N > 1: frames = one independent frame stream per GPU (weak scaling, no data-path collective); "
                          "tile-cols = GPU g reconstructs tile column g of the SAME frame and one all-gather per frame rebuilds "
@@ -76,11 +79,13 @@ def pmc_traffic(kernel, w, h, bpc):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")))
     if not files:
         return None
-    m = re.match(r"(mc|itx)_(\d+)x(\d+)", kernel)
+    m = re.match(r"(mc|itx|recon)_(\d+)x(\d+)", kernel)
     if not m:
         return None
     d = json.load(open(files[-1]))
-    if m.group(1) == "mc":
+    if m.group(1) == "recon":
+        key = "recon_fused_kernel<%d,u16,int>" % (int(m.group(2)).bit_length() - 3)
+    elif m.group(1) == "mc":
         key = "mc_kernel<%s,%s,u16>" % (m.group(2), m.group(3))
     else:
         from dav1d_amd import synth
@@ -89,6 +94,18 @@ def pmc_traffic(kernel, w, h, bpc):
     if key not in d:
         return None
     return int(d[key]["fetch_bytes_x2"] + d[key]["write_bytes"])
+
+
+def step_traffic(w, h, bpc, a):
+    """HBM bytes one step of the default workload moves: (FETCH_SIZE x 2 + WRITE_SIZE) summed over every kernel of
+    `bench.py --step-only` under rocprofv3, divided by the steps it ran (tools/pmc_profile.sh -> profiles/*/step_traffic.json)."""
+    if (w, h, bpc) != (7680, 4320, 10) or a.packed or a.two_phase or a.shard != "frames":
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "step_traffic.json")))
+    if not files:
+        return None
+    return json.load(open(files[-1])).get("bytes_per_step")
 
 
 def main():
@@ -147,7 +164,7 @@ def main():
     prep = torch.zeros(frame.prep_elems, dtype=torch.int16, device="cuda")
     tdt = torch.int16 if bpc == 8 else torch.int32
     pristine = torch.from_numpy(coef_host).to("cuda")
-    n_arena = a.steps + a.warmup + 3
+    n_arena = a.steps + a.warmup + 8
     if a.packed:        # a packed arena is read-only: every step reads the same one
         arenas = [pristine] * n_arena
     else:
@@ -205,6 +222,14 @@ def main():
 
     # ---- the same step fed with the sparse coefficient format (DAV1D_HIP_ITX_PACKED): reported next to `value`, which keeps
     # the dense reference layout SURVEY 8d prices; rank 0 of a one-GPU run only, and checked against the same oracle pictures
+    if a.step_only:
+        if rank == 0:
+            print(json.dumps({"step_only": True, "ms_per_step": round(ms_per_step, 4), "value": round(value, 1), "steps": a.steps,
+                              "warmup": a.warmup}))
+        barrier()
+        if world > 1:
+            dist.destroy_process_group()
+        return
     packed_leg = None
     if rank == 0 and world == 1 and not a.packed and not a.two_phase:
         p_tasks, p_coef = synth.pack_frame_coefs(frame)
@@ -274,6 +299,36 @@ def main():
                 px = cnt_itx[b] * synth.TX_W[b] * synth.TX_H[b]
                 cf = cnt_itx[b] * min(synth.TX_W[b], 32) * min(synth.TX_H[b], 32)
                 kernels.append(("itx_%dx%d" % (synth.TX_W[b], synth.TX_H[b]), ms_itx[b], cf * 2 * Cb + px * 2 * P))
+        kernels_two_phase = sorted(kernels, key=lambda k: -k[1])
+        if recon_list is not None:
+            # the launches the step really makes (paired prediction + residual kernels for some sizes, the rest as prediction
+            # and residual launches), each on its own between events; algorithmic bytes: SURVEY 8d per sample
+            ms40, cnt40 = (C.c_float * 40)(), (C.c_size_t * 40)()
+            best40 = [1e9] * 40
+            for rep in range(3):
+                rc = ctx.lib.dav1d_hip_recon_list_run_timed(ctx.h, recon_list.h, C.byref(d.pic), rarr, len(refs), prep.data_ptr(), None,
+                                                            arenas[i + 3 + rep].data_ptr(), ms40, cnt40)
+                assert rc == 0
+                best40 = [min(x, y) for x, y in zip(best40, ms40)]
+            step_kernels = []
+            for k in range(5):
+                if cnt40[k]:
+                    W_ = 4 << k
+                    px = cnt40[k] * W_ * W_
+                    cfs = cnt40[k] * min(W_, 32) ** 2
+                    csel = (frame.comp["w"] == W_) & (frame.comp["h"] == W_) if len(frame.comp) else np.zeros(0, bool)
+                    step_kernels.append(("recon_%dx%d" % (W_, W_), best40[k], int(px * 2 * P + cfs * 2 * Cb + int(csel.sum()) * W_ * W_ * P)))
+            for b in range(15):
+                if cnt40[5 + b] and cnt_mc[b]:
+                    step_kernels.append(("mc_%dx%d" % (tile_w[b // 3], tile_h[b % 3]), best40[5 + b], int(mc_bytes[b] * cnt40[5 + b] / cnt_mc[b])))
+            if cnt40[20]:
+                step_kernels.append(("comp_unfused", best40[20], 0))
+            for b in range(19):
+                if cnt40[21 + b]:
+                    px = cnt40[21 + b] * synth.TX_W[b] * synth.TX_H[b]
+                    cfs = cnt40[21 + b] * min(synth.TX_W[b], 32) * min(synth.TX_H[b], 32)
+                    step_kernels.append(("itx_%dx%d" % (synth.TX_W[b], synth.TX_H[b]), best40[21 + b], cfs * 2 * Cb + px * 2 * P))
+            kernels = step_kernels
         kernels.sort(key=lambda k: -k[1])
         dom = kernels[0]
         ach = dom[2] / (dom[1] * 1e-3) / 1e9
@@ -284,14 +339,15 @@ def main():
                 "path": {"algorithmic_bytes_per_frame": int(path_bytes),
                          "achieved": round(path_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                          "frac": round(path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                "kernels_ms": {k[0]: round(k[1], 4) for k in kernels}}
+                "kernels_ms": {k[0]: round(k[1], 4) for k in kernels},
+                "kernels_two_phase_ms": {k[0]: round(k[1], 4) for k in kernels_two_phase}}
         # measured HBM bytes of the whole step (sum of the committed per-kernel PMC figures) next to the algorithmic ones:
         # what the memory system really moved per frame, and the rate that is at this step time
-        tr = [pmc_traffic(k[0], w, h, bpc) for k in kernels]
-        if tr and all(v is not None for v in tr):
-            roof["path"]["hbm_traffic_bytes_per_frame"] = int(sum(tr))
-            roof["path"]["hbm_traffic_achieved"] = round(sum(tr) / (ms_per_step * 1e-3) / 1e9, 1)
-            roof["path"]["hbm_traffic_frac"] = round(sum(tr) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        step_bytes = step_traffic(w, h, bpc, a)
+        if step_bytes:
+            roof["path"]["hbm_traffic_bytes_per_frame"] = int(step_bytes)
+            roof["path"]["hbm_traffic_achieved"] = round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1)
+            roof["path"]["hbm_traffic_frac"] = round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         # the dominant mc kernel's reads including the filter halo ((w + 7) x (h + 7) window per predicted block, which
         # random motion vectors cannot share between blocks): the floor of its fetch traffic on this workload
         if dom[0].startswith("mc_"):

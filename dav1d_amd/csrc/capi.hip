@@ -1592,4 +1592,48 @@ int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, con
     return rc;
 }
 
+// Measurement aid: the launches of a recon list one after the other on the context's stream, each bracketed by events.
+// ms / counts: [0..4] the paired launches by size class (blocks), [5..19] the prediction launches by tile shape (tiles), [20] the
+// compound / blend launch (tasks), [21..39] the residual launches by transform size (blocks).
+int dav1d_hip_recon_list_run_timed(Dav1dHipContext *c, const Dav1dHipReconList *l, const Dav1dHipPicture *dst,
+                                   const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask, void *coef,
+                                   float *ms, size_t *counts) {
+    if (!c || !l || !dst || !refs || !ms || !counts || n_refs < 1 || n_refs > 8) return -EINVAL;
+    const Dav1dHipMcList *ml = l->inter->mc;
+    if ((ml->n && ml->max_ref >= n_refs) || l->f_max_ref >= n_refs) return -EINVAL;
+    const DevPlanes dp = dev_planes(dst);
+    DevPlanes rp[8];
+    for (int i = 0; i < n_refs; i++) rp[i] = dev_planes(&refs[i]);
+    int rc = mc_regroup(c, const_cast<Dav1dHipMcList *>(ml), rp, n_refs);
+    if (rc) return rc;
+    enum { N = 40 };
+    hipEvent_t ev[N + 1];
+    for (int k = 0; k <= N; k++) HIP_TRY(hipEventCreate(&ev[k]));
+    HIP_TRY(hipEventRecord(ev[0], c->stream));
+    for (int k = 0; k < N && !rc; k++) {
+        size_t cnt = 0;
+        if (k < 5) {
+            cnt = l->f_n[k];
+            if (cnt) rc = dav1d_hip_launch_recon_fused(&dp, rp, n_refs, dst->bpc, k, l->f_tiles[k], l->f_tasks[k], (int) cnt, prep, coef, c->stream);
+        } else if (k < 20) {
+            const int b = k - 5;
+            cnt = ml->off[b + 1] - ml->off[b];
+            if (cnt) rc = dav1d_hip_launch_mc_bin(&dp, rp, n_refs, dst->bpc, b, ml->dev + ml->off[b], (int) cnt, prep, c->stream);
+        } else if (k == 20) {
+            cnt = l->inter->comp->n;
+            if (cnt) rc = dav1d_hip_comp_list_run(c, l->inter->comp, dst, prep, mask);
+        } else {
+            const int b = k - 21;
+            cnt = l->itx->off[b + 1] - l->itx->off[b];
+            if (cnt) rc = dav1d_hip_launch_itx_bin(&dp, dst->bpc, b, l->itx->dev + l->itx->off[b], (int) cnt, coef, c->stream);
+        }
+        counts[k] = cnt;
+        (void) hipEventRecord(ev[k + 1], c->stream);
+    }
+    (void) hipStreamSynchronize(c->stream);
+    for (int k = 0; k < N; k++) { ms[k] = 0.f; (void) hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]); }
+    for (int k = 0; k <= N; k++) (void) hipEventDestroy(ev[k]);
+    return rc;
+}
+
 } // extern "C"

@@ -273,6 +273,12 @@ DAV1D_HIP_API int dav1d_hip_recon_list_create(Dav1dHipContext *c, Dav1dHipReconL
 DAV1D_HIP_API int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, const Dav1dHipPicture *dst,
                                            const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask, void *coef);
 DAV1D_HIP_API void dav1d_hip_recon_list_destroy(Dav1dHipContext *c, Dav1dHipReconList *l);
+/* Measurement aid (bench.py): every launch of the list on its own, bracketed by events.  ms / counts hold 40 entries:
+ * [0..4] paired launches (prediction + residual in one wave) by square size 4x4 .. 64x64, [5..19] prediction launches by tile
+ * shape (3 * width class + height class), [20] the compound / blend launch, [21..39] residual launches by transform size. */
+DAV1D_HIP_API int dav1d_hip_recon_list_run_timed(Dav1dHipContext *c, const Dav1dHipReconList *l, const Dav1dHipPicture *dst,
+                                                 const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask, void *coef,
+                                                 float *ms, size_t *counts);
 DAV1D_HIP_API int dav1d_hip_inter_list_run(Dav1dHipContext *c, const Dav1dHipInterList *l,
                                            const Dav1dHipPicture *dst, const Dav1dHipPicture *refs,
                                            int n_refs, int16_t *prep, uint8_t *mask);

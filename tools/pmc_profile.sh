@@ -21,5 +21,10 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
     i=$((i+1))
     timeout 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pmc$i" -- python "$ROOT/bench.py" $ARGS > "$OUT/pmc$i.log" 2>&1
 done
-python "$ROOT/tools/pmc_summary.py" "$OUT" > "$OUT/summary.txt" 2>&1
+# the step as it really runs (pipelined + paired launches on several streams): HBM bytes of everything it launches
+unset DAV1D_HIP_SERIAL
+STEP_ARGS="--steps 4 --warmup 0 --step-only $*"
+timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/step_fetch" -- python "$ROOT/bench.py" $STEP_ARGS > "$OUT/step_fetch.log" 2>&1
+timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/step_write" -- python "$ROOT/bench.py" $STEP_ARGS > "$OUT/step_write.log" 2>&1
+python "$ROOT/tools/pmc_summary.py" "$OUT" --step 4 > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

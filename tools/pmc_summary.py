@@ -51,3 +51,32 @@ for k in names:
         w = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"]) * 1024
         traffic[k] = {"fetch_bytes_raw": f, "fetch_bytes_x2": 2 * f, "write_bytes": w, "avg_us": stats[k][1]}
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+
+# the step as it really runs: bytes of every kernel the `--step-only` passes launched (step_fetch / step_write), per step
+if "--step" in sys.argv:
+    n_steps = int(sys.argv[sys.argv.index("--step") + 1])
+    tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+    per_kernel = defaultdict(lambda: {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "launches": 0})
+    for d, cname in (("step_fetch", "FETCH_SIZE"), ("step_write", "WRITE_SIZE")):
+        for f in glob.glob(os.path.join(out, d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] != cname:
+                    continue
+                k = short(r["Kernel_Name"])
+                if not re.match(r"(mc_kernel|itx_add_kernel|recon_fused_kernel|comp_kernel|mc_all_kernel|itx_multi_kernel)", k):
+                    continue        # fills / copies of the harness are not the step
+                v = float(r["Counter_Value"]) * 1024
+                tot[cname] += v
+                per_kernel[k][cname] += v
+                if cname == "FETCH_SIZE":
+                    per_kernel[k]["launches"] += 1
+    if tot["FETCH_SIZE"] and tot["WRITE_SIZE"]:
+        step = {"steps": n_steps, "bytes_per_step": (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / n_steps,
+                "fetch_bytes_x2_per_step": 2 * tot["FETCH_SIZE"] / n_steps, "write_bytes_per_step": tot["WRITE_SIZE"] / n_steps,
+                "kernels": {k: {"launches_per_step": v["launches"] / n_steps,
+                                "bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) / max(v["launches"], 1)}
+                            for k, v in sorted(per_kernel.items())}}
+        json.dump(step, open(os.path.join(out, "step_traffic.json"), "w"), indent=1)
+        print()
+        print("step traffic: %.1f MB per step (fetch x2 %.1f MB + write %.1f MB)" % (step["bytes_per_step"] / 1e6,
+              step["fetch_bytes_x2_per_step"] / 1e6, step["write_bytes_per_step"] / 1e6))
