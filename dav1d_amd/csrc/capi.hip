@@ -1487,28 +1487,31 @@ int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, con
             if (refs[i].bpc != dst->bpc) return -EINVAL;
             rp[i] = dev_planes(&refs[i]);
         }
-        // on side streams 2 and 3 (0 and 1 belong to the pipeline of the unpaired rest below, which runs next to them)
+        // one after the other on a side stream of their own, next to the pipeline of the unpaired rest below (main stream:
+        // predictions, side stream 0: residuals).  Measured: the paired launches on one stream 0.317 ms per frame, on two
+        // streams that run side by side 0.334-0.343 — three launches at a time share the memory system better than four.
         const bool side = c->concurrent && n_paired >= 16384;
         int rc = 0, lane = 0;
+        const int ps[2] = { 2, 2 };
         if (side) {
             (void) hipEventRecord(c->ev_fork, c->stream);
-            (void) hipStreamWaitEvent(c->side[2], c->ev_fork, 0);
-            (void) hipStreamWaitEvent(c->side[3], c->ev_fork, 0);
+            (void) hipStreamWaitEvent(c->side[ps[0]], c->ev_fork, 0);
+            (void) hipStreamWaitEvent(c->side[ps[1]], c->ev_fork, 0);
         }
         for (int k = 4; k >= 0 && !rc; k--)
             if (l->f_n[k]) {
                 rc = dav1d_hip_launch_recon_fused(&dp, rp, n_refs, dst->bpc, k, l->f_tiles[k], l->f_tasks[k], (int) l->f_n[k], prep, coef,
-                                                  side ? c->side[2 + lane] : c->stream);
+                                                  side ? c->side[ps[lane]] : c->stream);
                 lane ^= 1;
             }
         if (side) {
-            (void) hipEventRecord(c->ev_join[2], c->side[2]);
-            (void) hipEventRecord(c->ev_join[3], c->side[3]);
+            (void) hipEventRecord(c->ev_join[1], c->side[ps[0]]);
+            (void) hipEventRecord(c->ev_join[2], c->side[ps[1]]);
         }
         if (rc) return rc;
         paired_on_side = side;
         if (!l->inter->mc->n && !l->inter->comp->n && !l->itx->n) {
-            if (side) { (void) hipStreamWaitEvent(c->stream, c->ev_join[2], 0); (void) hipStreamWaitEvent(c->stream, c->ev_join[3], 0); }
+            if (side) { (void) hipStreamWaitEvent(c->stream, c->ev_join[1], 0); (void) hipStreamWaitEvent(c->stream, c->ev_join[2], 0); }
             return 0;
         }
     }
@@ -1518,7 +1521,7 @@ int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, con
     const char *env = getenv("DAV1D_HIP_RECON_PIPELINE");
     const long min_tasks = env ? atol(env) : 16384;
     auto join_paired = [&]() {
-        if (paired_on_side) { (void) hipStreamWaitEvent(c->stream, c->ev_join[2], 0); (void) hipStreamWaitEvent(c->stream, c->ev_join[3], 0); }
+        if (paired_on_side) { (void) hipStreamWaitEvent(c->stream, c->ev_join[1], 0); (void) hipStreamWaitEvent(c->stream, c->ev_join[2], 0); }
     };
     if (min_tasks < 0 || !c->concurrent || mc_fused_min_bin() < MC_BINS || (long) l->itx->n < min_tasks) {
         int rc = dav1d_hip_inter_list_run(c, l->inter, dst, refs, n_refs, prep, mask);
@@ -1539,7 +1542,8 @@ int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, con
     // 2 lanes 0.394, 3 lanes 0.407, 5 lanes 0.420 per frame — residual launches running next to each other take bandwidth from
     // the predictions they are waiting for; one in-order residual stream keeps the pipeline a pipeline.
     const char *le = getenv("DAV1D_HIP_RECON_LANES");
-    const int n_lanes = le ? std::max(1, std::min((int) Dav1dHipContext::N_SIDE, atoi(le))) : 1;
+    const int n_lanes = paired_on_side ? 1      // side streams 1 and 2 carry the paired launches
+                      : le ? std::max(1, std::min((int) Dav1dHipContext::N_SIDE, atoi(le))) : 1;
     hipStream_t sm = c->stream;
     (void) hipEventRecord(c->ev_fork, sm);
     for (int i = 0; i < n_lanes; i++) (void) hipStreamWaitEvent(c->side[i], c->ev_fork, 0);
