@@ -169,6 +169,69 @@ def test_recon_list_matches_oracle(ctx, bpc, pipeline, fuse, monkeypatch):
     assert np.array_equal(got_coef, want_coef)
 
 
+@pytest.mark.parametrize("pipeline", ["0", "-1"], ids=["pipelined", "sequential"])
+def test_recon_list_with_transforms_smaller_than_their_prediction(ctx, pipeline, monkeypatch):
+    """Blocks whose residual is coded as four transforms of half the size cannot be paired with their prediction: they
+    take the prediction launch + residual launch route, where the 8x8 residual launch has to wait for the 16x16 prediction
+    launch — next to paired blocks of the same frame."""
+    import copy
+    monkeypatch.setenv("DAV1D_HIP_RECON_PIPELINE", pipeline)
+    bpc = 10
+    w, h = (512, 128) if ctx.backend == "emu" else (1280, 1024)
+    base = synth.make_frame(w, h, bpc, seed=808, edge_frac=0.05)
+    rng = np.random.default_rng(81)
+    stride = synth.plane_geometry(w, h, bpc, 1)[0][0]
+    pick = np.flatnonzero((base.itx["tx"] == 2) & (base.itx["plane"] == 0))[::2]       # every other 16x16 luma transform
+    cf, eob = synth.gen_coefs(rng, 1, 4 * len(pick), bpc)
+    small = np.zeros(4 * len(pick), base.itx.dtype)
+    off0 = len(base.coef)
+    for q, (dy, dx) in enumerate(((0, 0), (0, 8), (8, 0), (8, 8))):
+        part = small[q::4]
+        part["dst_off"] = base.itx["dst_off"][pick] + dy * stride + dx
+        part["cf_off"] = off0 + (np.arange(len(pick)) * 4 + q) * 64
+        part["eob"] = eob[q::4]
+        part["tx"], part["plane"] = 1, 0
+    order = np.argsort(np.arange(4 * len(pick)).reshape(4, -1).T.ravel(), kind="stable")   # [block][quarter] coefficient order
+    frame = copy.copy(base)
+    frame.itx = np.concatenate([np.delete(base.itx, pick), small])
+    slabs = np.zeros((4 * len(pick), 64), base.coef.dtype)
+    for q in range(4):
+        slabs[np.arange(len(pick)) * 4 + q] = cf[q::4]
+    frame.coef = np.concatenate([base.coef, slabs.ravel()])
+    del order
+    refs = [synth.make_planes(rng, w, h, bpc) for _ in range(frame.n_refs)]
+    dst0 = synth.make_planes(rng, w, h, bpc, smooth=False)
+    want, _, want_coef = oracle_frame(util.default_oracle(), frame, dst0, refs)
+    got, _, got_coef = hip_frame(ctx, frame, dst0, refs, recon=True)
+    for pl in range(3):
+        bad = np.argwhere(got[pl] != want[pl])
+        assert not len(bad), "plane %d differs at %s (%d px)" % (pl, bad[0], len(bad))
+    assert np.array_equal(got_coef, want_coef)
+
+
+def test_recon_list_with_nothing_or_only_one_side(ctx):
+    """Empty lists, predictions without residuals, residuals without predictions."""
+    bpc, w, h = 8, 256, 128
+    frame = synth.make_frame(w, h, bpc, seed=12)
+    rng = np.random.default_rng(3)
+    refs_h = [synth.make_planes(rng, w, h, bpc) for _ in range(frame.n_refs)]
+    dst0 = synth.make_planes(rng, w, h, bpc, smooth=False)
+    oracle = util.default_oracle()
+    import copy
+    for mode in ("empty", "mc-only", "itx-only"):
+        f = copy.copy(frame)
+        if mode != "mc-only":
+            f.itx = frame.itx if mode == "itx-only" else frame.itx[:0]
+        else:
+            f.itx = frame.itx[:0]
+        if mode != "mc-only":
+            f.mc, f.comp = frame.mc[:0], frame.comp[:0]
+        want, _, _ = oracle_frame(oracle, f, dst0, refs_h)
+        got, _, _ = hip_frame(ctx, f, dst0, refs_h, recon=True)
+        for pl in range(3):
+            assert np.array_equal(got[pl], want[pl]), (mode, pl)
+
+
 def test_recon_list_refuses_another_geometry(ctx):
     frame = synth.make_frame(256, 128, 8, seed=2)
     a = ctx.picture(256, 128, api.LAYOUT_I420, 8)
