@@ -1,0 +1,36 @@
+"""bench.py's output contract (one JSON line with the fields the driver reads), on a small frame so that it runs in seconds."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import util
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--width", "1280", "--height", "1024", "--cpu-seconds", "0.5"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and d["config"]["parity"].startswith("bit-exact")
+    roof = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in roof, k
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0 < roof["frac"] < 1
+    cpu = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cpu, k
+    assert cpu["kind"] in ("reference", "port") and cpu["cores"] == 1 and cpu["value"] > 0
+    assert d["value"] > cpu["value"]
+    assert d["full_table"]["parity"].startswith("every stage bit-exact")
