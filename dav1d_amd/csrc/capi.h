@@ -137,7 +137,7 @@ extern "C" int dav1d_hip_launch_ipred(const DevPlanes *dst, int bpc, int layout,
                                       uint8_t *pal_idx, void *stream);
 
 extern "C" int dav1d_hip_launch_wiener(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
-                                       const Dav1dHipLrTask *tasks, int n, void *stream);
+                                       const Dav1dHipLrTask *tasks, int n, int max_w, void *stream);
 
 extern "C" int dav1d_hip_launch_fg_gen(int16_t *luts, const Dav1dHipFilmGrainData *data, int bpc, int layout, void *stream);
 extern "C" int dav1d_hip_launch_fg_apply(const DevPlanes *dst, const DevPlanes *src, const int16_t *luts, const uint8_t *scaling,
@@ -149,7 +149,7 @@ extern "C" int dav1d_hip_launch_fg_apply_rows(const DevPlanes *dst, const DevPla
                                               int scaling_size, const Dav1dHipFilmGrainData *data, int bpc, int layout, int is_id,
                                               int row_num, int pl, uint8_t *offs, void *stream);
 extern "C" int dav1d_hip_launch_sgr(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
-                                    const Dav1dHipLrTask *tasks, int n, void *stream);
+                                    const Dav1dHipLrTask *tasks, int n, int max_w, void *stream);
 
 extern "C" int dav1d_hip_launch_warp(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, const Dav1dHipWarpTask *tasks, int n,
                                      int16_t *prep, void *stream);

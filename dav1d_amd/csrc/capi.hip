@@ -1170,8 +1170,10 @@ extern "C" int dav1d_hip_lr_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst
     int rc = dav1d_hip_upload(c, dev, sorted.data(), n * sizeof(*dev));
     const DevPlanes dp = dev_planes(dst), sp = dev_planes(src), lp = dev_planes(lpf);
     KernelTimer kt(c);
-    if (!rc) rc = dav1d_hip_launch_wiener(&dp, &sp, &lp, dst->bpc, dev, (int) nw, c->stream);
-    if (!rc) rc = dav1d_hip_launch_sgr(&dp, &sp, &lp, dst->bpc, dev + nw, (int) (n - nw), c->stream);
+    int max_w[2] = { 0, 0 };
+    for (size_t i = 0; i < n; i++) max_w[i >= nw] = std::max(max_w[i >= nw], (int) sorted[i].w);
+    if (!rc) rc = dav1d_hip_launch_wiener(&dp, &sp, &lp, dst->bpc, dev, (int) nw, max_w[0], c->stream);
+    if (!rc) rc = dav1d_hip_launch_sgr(&dp, &sp, &lp, dst->bpc, dev + nw, (int) (n - nw), max_w[1], c->stream);
     kt.stop();
     hipStreamSynchronize(c->stream);
     hipFree(dev);

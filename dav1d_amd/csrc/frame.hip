@@ -169,8 +169,8 @@ static int post_filters_pipelined(Dav1dHipFrame *f, const Dav1dHipPicture **last
                 if (has_cdef) (void) hipStreamWaitEvent(sc, ev[nb + dep], 0);
                 else if (has_lf) (void) hipStreamWaitEvent(sc, ev[dep], 0);
                 const size_t w0 = lr_off[2 * br], w1 = lr_off[2 * br + 1], w2 = lr_off[2 * br + 2];
-                if (w1 > w0) rc = dav1d_hip_launch_wiener(&t1, &co, &cur, f->cur.bpc, d_lr + w0, (int) (w1 - w0), sc);
-                if (!rc && w2 > w1) rc = dav1d_hip_launch_sgr(&t1, &co, &cur, f->cur.bpc, d_lr + w1, (int) (w2 - w1), sc);
+                if (w1 > w0) rc = dav1d_hip_launch_wiener(&t1, &co, &cur, f->cur.bpc, d_lr + w0, (int) (w1 - w0), 384, sc);
+                if (!rc && w2 > w1) rc = dav1d_hip_launch_sgr(&t1, &co, &cur, f->cur.bpc, d_lr + w1, (int) (w2 - w1), 384, sc);
             }
         }
         (void) hipEventRecord(c->ev_join[0], sb);

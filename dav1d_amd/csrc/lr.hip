@@ -232,12 +232,13 @@ __global__ __launch_bounds__(64) void sgr_kernel(const DevPlanes dst, const DevP
 
 } // namespace
 
+// max_w: width of the widest unit of the batch (<= 384): the grid covers that many columns, not 384 for everybody
 extern "C" int dav1d_hip_launch_wiener(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
-                                       const Dav1dHipLrTask *tasks, int n, void *stream)
+                                       const Dav1dHipLrTask *tasks, int n, int max_w, void *stream)
 {
     if (n <= 0) return 0;
     const int bitdepth_max = (1 << bpc) - 1;
-    const dim3 grid(6, n, (64 + LR_SEG - 1) / LR_SEG);          // up to 384 columns x 64 rows per unit
+    const dim3 grid(((max_w < 1 ? 1 : max_w > 384 ? 384 : max_w) + 63) / 64, n, (64 + LR_SEG - 1) / LR_SEG);   // 64 columns x 64 rows per wave
     if (bpc == 8)
         hipLaunchKernelGGL((wiener_kernel<uint8_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks, n, bitdepth_max);
     else
@@ -246,11 +247,11 @@ extern "C" int dav1d_hip_launch_wiener(const DevPlanes *dst, const DevPlanes *sr
 }
 
 extern "C" int dav1d_hip_launch_sgr(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
-                                    const Dav1dHipLrTask *tasks, int n, void *stream)
+                                    const Dav1dHipLrTask *tasks, int n, int max_w, void *stream)
 {
     if (n <= 0) return 0;
     const int bitdepth_max = (1 << bpc) - 1;
-    const dim3 grid(7, n, (64 + LR_SEG - 1) / LR_SEG);          // 7 x 62 >= 384 columns
+    const dim3 grid(((max_w < 1 ? 1 : max_w > 384 ? 384 : max_w) + 61) / 62, n, (64 + LR_SEG - 1) / LR_SEG);   // 62 output columns per wave
     if (bpc == 8)
         hipLaunchKernelGGL((sgr_kernel<uint8_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks, n, bitdepth_max);
     else
