@@ -130,7 +130,7 @@ extern "C" int dav1d_hip_launch_comp(const DevPlanes *dst, int bpc, const Dav1dH
 extern "C" int dav1d_hip_launch_cdef(const DevPlanes *dst, const DevPlanes *src, int bpc, int layout,
                                      const Dav1dHipCdefTask *tasks, int n, int damping, uint32_t *dirvar, void *stream);
 
-extern "C" int dav1d_hip_launch_lf(const DevPlanes *dst, int bpc, const Dav1dHipLfTask *tasks, int n, const uint8_t *lvl,
+extern "C" int dav1d_hip_launch_lf(const DevPlanes *dst, int bpc, int dir, const Dav1dHipLfTask *tasks, int n, const uint8_t *lvl,
                                    int b4_stride, const uint8_t *lut_e, const uint8_t *lut_i, void *stream);
 
 extern "C" int dav1d_hip_launch_ipred(const DevPlanes *dst, int bpc, int layout, const Dav1dHipIpredTask *tasks, int n, int n_big,

@@ -975,8 +975,8 @@ extern "C" int dav1d_hip_lf_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst
     const DevPlanes dp = dev_planes(dst);
     // pass 1: every vertical edge; pass 2 (same stream, so after pass 1): every horizontal edge
     KernelTimer kt(c);
-    if (!rc) rc = dav1d_hip_launch_lf(&dp, dst->bpc, dev, (int) n0, lvl, (int) b4_stride, lut_e, lut_i, c->stream);
-    if (!rc) rc = dav1d_hip_launch_lf(&dp, dst->bpc, dev + n0, (int) (n - n0), lvl, (int) b4_stride, lut_e, lut_i, c->stream);
+    if (!rc) rc = dav1d_hip_launch_lf(&dp, dst->bpc, 0, dev, (int) n0, lvl, (int) b4_stride, lut_e, lut_i, c->stream);
+    if (!rc) rc = dav1d_hip_launch_lf(&dp, dst->bpc, 1, dev + n0, (int) (n - n0), lvl, (int) b4_stride, lut_e, lut_i, c->stream);
     kt.stop();
     hipStreamSynchronize(c->stream);
     hipFree(dev);

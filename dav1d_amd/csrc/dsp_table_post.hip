@@ -113,7 +113,8 @@ void lf_call(int chroma, int dir, pixel *dst, ptrdiff_t stride, const uint32_t *
     if (!vm) return;
     const int units = 32 - __builtin_clz(vm);
     // how far the widest filter in play reaches on each side of the edge (src/loopfilter_tmpl.c:37-161)
-    const int reach = chroma ? (mask[1] ? 3 : 2) : (mask[2] ? 7 : mask[1] ? 4 : 2);
+    // (edges between columns: the kernel fetches the taps of a line as one 8-pixel or two 8-pixel pieces around the edge)
+    const int reach = dir ? (chroma ? (mask[1] ? 3 : 2) : (mask[2] ? 7 : mask[1] ? 4 : 2)) : ((!chroma && mask[2]) ? 8 : 4);
     const int along = 4 * units, across = 2 * reach;
     Stage s(1 << 20);
     Dav1dHipPicture pic = dir ? scratch_pic(s, along, across, bpc) : scratch_pic(s, across, along, bpc);

@@ -152,8 +152,8 @@ static int post_filters_pipelined(Dav1dHipFrame *f, const Dav1dHipPicture **last
         for (int b = 0; b < nb + 2 && !rc; b++) {
             if (has_lf && b < nb) {
                 const size_t v0 = lf_off[2 * b], v1 = lf_off[2 * b + 1], v2 = lf_off[2 * b + 2];
-                if (v1 > v0) rc = dav1d_hip_launch_lf(&cur, f->cur.bpc, d_lf + v0, (int) (v1 - v0), f->lvl, (int) f->b4_stride, f->lut_e, f->lut_i, sa);
-                if (!rc && v2 > v1) rc = dav1d_hip_launch_lf(&cur, f->cur.bpc, d_lf + v1, (int) (v2 - v1), f->lvl, (int) f->b4_stride, f->lut_e, f->lut_i, sa);
+                if (v1 > v0) rc = dav1d_hip_launch_lf(&cur, f->cur.bpc, 0, d_lf + v0, (int) (v1 - v0), f->lvl, (int) f->b4_stride, f->lut_e, f->lut_i, sa);
+                if (!rc && v2 > v1) rc = dav1d_hip_launch_lf(&cur, f->cur.bpc, 1, d_lf + v1, (int) (v2 - v1), f->lvl, (int) f->b4_stride, f->lut_e, f->lut_i, sa);
                 (void) hipEventRecord(ev[b], sa);
             }
             const int bc = b - 1;                    // CDEF runs one band behind deblocking
