@@ -296,6 +296,9 @@ class Context:
     def frame(self, cur, refs):
         return FrameInFlight(self, cur, refs)
 
+    def intra_list(self, batches):
+        return _IntraList(self, batches)
+
     def ipred_list(self, batches):
         return _IpredList(self, batches)
 
@@ -353,6 +356,31 @@ class _IpredList:
     def destroy(self):
         if self.h:
             self.ctx.lib.dav1d_hip_ipred_list_destroy(self.ctx.h, self.h)
+            self.h = C.c_void_p()
+
+
+class _IntraList:
+    """dav1d_hip_intra_list_*: predictions + residuals of every wavefront step (small blocks paired in one wave)."""
+
+    def __init__(self, ctx, batches):
+        """batches: [(ipred tasks, itx tasks)] per wavefront step."""
+        self.ctx = ctx
+        self.n_batches = len(batches)
+        ps = (C.c_size_t * max(len(batches), 1))(*[len(b[0]) for b in batches])
+        ts = (C.c_size_t * max(len(batches), 1))(*[len(b[1]) for b in batches])
+        allp = np.ascontiguousarray(np.concatenate([b[0] for b in batches]) if batches else np.zeros(0, IPRED_TASK), dtype=IPRED_TASK)
+        allt = np.ascontiguousarray(np.concatenate([b[1] for b in batches]) if batches else np.zeros(0, ITX_TASK), dtype=ITX_TASK)
+        self.h = C.c_void_p()
+        _chk(ctx.lib.dav1d_hip_intra_list_create(ctx.h, C.byref(self.h), allp.ctypes.data, ps, allt.ctypes.data, ts, len(batches)),
+             "intra_list_create")
+
+    def run_batch(self, k, dst, coef, aux=None):
+        _chk(self.ctx.lib.dav1d_hip_intra_list_run_batch(self.ctx.h, self.h, k, C.byref(dst.pic), coef.ptr if hasattr(coef, "ptr") else coef,
+                                                         aux.ptr if aux else None), "intra_list_run_batch")
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.dav1d_hip_intra_list_destroy(self.ctx.h, self.h)
             self.h = C.c_void_p()
 
 

@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["capi.hip", "frame.hip", "dsp_table.hip", "dsp_table_post.hip", "itx.hip", "mc.hip", "recon.hip", "mcx.hip", "comp.hip", "cdef.hip", "loopfilter.hip", "ipred.hip", "lr.hip", "fg.hip"]
+SOURCES = ["capi.hip", "frame.hip", "dsp_table.hip", "dsp_table_post.hip", "itx.hip", "mc.hip", "recon.hip", "intra_pair.hip", "mcx.hip", "comp.hip", "cdef.hip", "loopfilter.hip", "ipred.hip", "lr.hip", "fg.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 

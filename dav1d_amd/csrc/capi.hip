@@ -1642,4 +1642,110 @@ int dav1d_hip_recon_list_run_timed(Dav1dHipContext *c, const Dav1dHipReconList *
     return rc;
 }
 
+// ------------------------------------------------------------------ intra wavefront list
+//
+// The batches (wavefront steps) of an intra frame with both halves of every block: predictions and residuals.  A 4x4 or 8x8
+// block whose residual covers exactly its prediction runs as a pair in one wave (intra_pair.hip); the other blocks of the
+// step keep the prediction launch + residual launch route.  run_batch() only enqueues: at most three launches per step, one
+// for the steps that hold nothing but small blocks (the second half of every superblock's wavefront).
+struct Dav1dHipIntraList {
+    Dav1dHipIpredList *preds;                 // unpaired predictions, batch by batch
+    std::vector<Dav1dHipItxList *> itx;       // unpaired residuals, one list per batch
+    Dav1dHipIpredTask *p_dev;                 // paired blocks of all batches: predictions ...
+    Dav1dHipItxTask *t_dev;                   // ... and their residuals, same order
+    std::vector<size_t> pair_start;           // batch k = pairs [pair_start[k], pair_start[k + 1])
+    bool needs_aux;
+};
+
+void dav1d_hip_intra_list_destroy(Dav1dHipContext *c, Dav1dHipIntraList *l) {
+    if (!l) return;
+    if (l->preds) dav1d_hip_ipred_list_destroy(c, l->preds);
+    for (Dav1dHipItxList *t : l->itx) if (t) dav1d_hip_itx_list_destroy(c, t);
+    hipStreamSynchronize(c->stream);
+    if (l->p_dev) hipFree(l->p_dev);
+    if (l->t_dev) hipFree(l->t_dev);
+    delete l;
+}
+
+int dav1d_hip_intra_list_create(Dav1dHipContext *c, Dav1dHipIntraList **out, const Dav1dHipIpredTask *preds, const size_t *pred_sizes,
+                                const Dav1dHipItxTask *txs, const size_t *tx_sizes, size_t n_batches) {
+    if (!c || !out || !pred_sizes || !tx_sizes) return -EINVAL;
+    *out = nullptr;
+    size_t np = 0, nt = 0;
+    for (size_t k = 0; k < n_batches; k++) { np += pred_sizes[k]; nt += tx_sizes[k]; }
+    if ((np && !preds) || (nt && !txs)) return -EINVAL;
+    uint8_t dummy = 0;
+    if (ipred_tasks_valid(preds, np, &dummy)) return -EINVAL;
+    for (size_t i = 0; i < nt; i++) if (!itx_task_ok(txs[i])) return -EINVAL;
+    Dav1dHipIntraList *l = new (std::nothrow) Dav1dHipIntraList();
+    if (!l) return -ENOMEM;
+    l->preds = nullptr; l->p_dev = nullptr; l->t_dev = nullptr; l->needs_aux = false;
+    for (size_t i = 0; i < np; i++) if (preds[i].kind >= DAV1D_HIP_IPRED_PAL) l->needs_aux = true;
+    static const bool pairing = !(getenv("DAV1D_HIP_INTRA_PAIR") && !atoi(getenv("DAV1D_HIP_INTRA_PAIR")));
+    std::vector<Dav1dHipIpredTask> rest_p, pair_p;
+    std::vector<Dav1dHipItxTask> pair_t;
+    std::vector<size_t> rest_p_sizes;
+    int rc = 0;
+    size_t p0 = 0, t0 = 0;
+    l->pair_start.push_back(0);
+    for (size_t k = 0; k < n_batches && !rc; k++) {
+        std::unordered_map<uint64_t, size_t> tx_at;
+        for (size_t i = 0; i < tx_sizes[k]; i++) {
+            const Dav1dHipItxTask &t = txs[t0 + i];
+            if (pairing && t.tx <= 1) tx_at[(uint64_t) t.plane << 32 | t.dst_off] = i;
+        }
+        std::vector<char> taken(tx_sizes[k], 0);
+        size_t n_rest = 0;
+        for (size_t i = 0; i < pred_sizes[k]; i++) {
+            const Dav1dHipIpredTask &p = preds[p0 + i];
+            long j = -1;
+            if (p.tw == p.th && p.tw <= 2 && p.kind <= DAV1D_HIP_IPRED_PAL) {
+                auto it = tx_at.find((uint64_t) p.plane << 32 | p.dst_off);
+                if (it != tx_at.end() && !taken[it->second] && txs[t0 + it->second].tx == p.tw - 1) j = (long) it->second;
+            }
+            if (j >= 0) {
+                taken[j] = 1;
+                pair_p.push_back(p);
+                pair_t.push_back(txs[t0 + j]);
+                itx_fill_prefix(pair_t.back());
+            } else {
+                rest_p.push_back(p);
+                n_rest++;
+            }
+        }
+        rest_p_sizes.push_back(n_rest);
+        l->pair_start.push_back(pair_p.size());
+        std::vector<Dav1dHipItxTask> rest_t;
+        for (size_t i = 0; i < tx_sizes[k]; i++) if (!taken[i]) rest_t.push_back(txs[t0 + i]);
+        Dav1dHipItxList *tl = nullptr;
+        rc = dav1d_hip_itx_list_create(c, &tl, rest_t.data(), rest_t.size());
+        l->itx.push_back(tl);
+        p0 += pred_sizes[k]; t0 += tx_sizes[k];
+    }
+    if (!rc) rc = dav1d_hip_ipred_list_create(c, &l->preds, rest_p.data(), rest_p_sizes.data(), n_batches);
+    if (!rc && !pair_p.empty()) {
+        if (hipMalloc((void **) &l->p_dev, pair_p.size() * sizeof(Dav1dHipIpredTask)) != hipSuccess ||
+            hipMalloc((void **) &l->t_dev, pair_t.size() * sizeof(Dav1dHipItxTask)) != hipSuccess) rc = -ENOMEM;
+        if (!rc) rc = dav1d_hip_upload(c, l->p_dev, pair_p.data(), pair_p.size() * sizeof(Dav1dHipIpredTask));
+        if (!rc) rc = dav1d_hip_upload(c, l->t_dev, pair_t.data(), pair_t.size() * sizeof(Dav1dHipItxTask));
+    }
+    if (rc) { dav1d_hip_intra_list_destroy(c, l); return rc; }
+    *out = l;
+    return 0;
+}
+
+int dav1d_hip_intra_list_run_batch(Dav1dHipContext *c, const Dav1dHipIntraList *l, size_t batch, const Dav1dHipPicture *dst, void *coef,
+                                   uint8_t *aux) {
+    if (!c || !l || !dst || batch + 1 >= l->pair_start.size() || (l->needs_aux && !aux)) return -EINVAL;
+    const DevPlanes dp = dev_planes(dst);
+    int rc = 0;
+    const size_t n_pairs = l->pair_start[batch + 1] - l->pair_start[batch];
+    if (n_pairs)
+        rc = dav1d_hip_launch_intra_pairs(&dp, dst->bpc, dst->layout, l->p_dev + l->pair_start[batch], l->t_dev + l->pair_start[batch],
+                                          (int) n_pairs, aux, coef, c->stream);
+    if (!rc) rc = dav1d_hip_ipred_list_run_batch(c, l->preds, batch, dst, aux);
+    if (!rc && l->itx[batch]->n) rc = dav1d_hip_itx_list_run(c, l->itx[batch], dst, coef);
+    return rc;
+}
+
 } // extern "C"

@@ -1,0 +1,50 @@
+// Intra prediction and residual of a small block in one wave (gfx950).
+//
+// The reference reconstructs an intra transform block as prepare_intra_edges + intra_pred into the picture, then
+// itxfm_add on the same pixels (src/recon_tmpl.c:1207-1360).  The wavefront steps of an intra frame are chains of small
+// dependent launches, each paying its own launch-to-finish latency; for the 4x4 and 8x8 blocks — all there is in the
+// second half of the wavefront of a superblock — the two launches of a step become one: the wave predicts the block into
+// LDS (ipred_body.h, the body of ipred.hip) and adds the residual from there (itx_body.h, the body of itx.hip).
+#include "ipred_body.h"
+#include "itx_body.h"
+#include "capi.h"
+
+namespace {
+
+// pairs[i] = (prediction task, transform task) of block i; both describe the same rectangle, tx = TX_4X4 or TX_8X8
+template <typename pixel, typename coef>
+__global__ __launch_bounds__(64) void intra_pair_kernel(const DevPlanes dst, const Dav1dHipIpredTask *__restrict__ preds,
+                                                        const Dav1dHipItxTask *__restrict__ txs, const int n, uint8_t *aux,
+                                                        coef *__restrict__ cf, const int layout, const int bitdepth_max)
+{
+    __shared__ int16_t e1[ESZ], e2[ESZ];
+    __shared__ int16_t blk[32 * 32];
+    __shared__ __attribute__((aligned(16))) int smem_itx[cmax(itx_lds_ints<0>(), itx_lds_ints<1>())];
+    __shared__ __attribute__((aligned(16))) pixel pred[8 * 8];
+    const int bi = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x);
+    if (bi >= n) return;
+    const int bs = __builtin_amdgcn_readfirstlane(bi);
+    const Dav1dHipIpredTask t = preds[bs];
+    const int w = t.tw * 4;
+    ipred_body<pixel>(dst, t, 0, false, aux, layout, bitdepth_max, e1, e2, blk, pred, w);
+    dv::wave_sync();
+    // the transform body packs several blocks into a wave; here it gets a list of one: lanes past the first block idle
+    if (w == 4) itx_body<0, pixel, coef, true>(dst, txs + bs, 1, cf, bitdepth_max, 0, smem_itx, pred);
+    else        itx_body<1, pixel, coef, true>(dst, txs + bs, 1, cf, bitdepth_max, 0, smem_itx, pred);
+}
+
+} // namespace
+
+extern "C" int dav1d_hip_launch_intra_pairs(const DevPlanes *dst, int bpc, int layout, const Dav1dHipIpredTask *preds,
+                                            const Dav1dHipItxTask *txs, int n, uint8_t *aux, void *coef, void *stream)
+{
+    if (n <= 0) return 0;
+    const int bitdepth_max = (1 << bpc) - 1;
+    if (bpc == 8)
+        hipLaunchKernelGGL((intra_pair_kernel<uint8_t, int16_t>), dim3(n), dim3(64), 0, (hipStream_t) stream, *dst, preds, txs, n, aux,
+                           (int16_t *) coef, layout, bitdepth_max);
+    else
+        hipLaunchKernelGGL((intra_pair_kernel<uint16_t, int32_t>), dim3(n), dim3(64), 0, (hipStream_t) stream, *dst, preds, txs, n, aux,
+                           (int32_t *) coef, layout, bitdepth_max);
+    return hip_rc(hipGetLastError());
+}

@@ -339,6 +339,18 @@ DAV1D_HIP_API int dav1d_hip_ipred_list_run_batch(Dav1dHipContext *c, const Dav1d
                                                  const Dav1dHipPicture *dst, uint8_t *aux);
 DAV1D_HIP_API void dav1d_hip_ipred_list_destroy(Dav1dHipContext *c, Dav1dHipIpredList *l);
 
+/* The wavefront of an intra frame with both halves of every block: batch k = the predictions AND the residuals of the blocks
+ * of step k (pred_sizes[k] / tx_sizes[k] consecutive tasks of `preds` / `txs`).  What dav1d_hip_ipred_list_run_batch(k)
+ * followed by dav1d_hip_itx_list_run does, except that a 4x4 or 8x8 block whose residual covers exactly its prediction is
+ * predicted and reconstructed by one wave (the reference's order inside recon_b_intra, src/recon_tmpl.c:1207-1360): one
+ * launch instead of two for the steps that hold only small blocks.  run_batch only enqueues; it can be recorded into a graph. */
+typedef struct Dav1dHipIntraList Dav1dHipIntraList;
+DAV1D_HIP_API int dav1d_hip_intra_list_create(Dav1dHipContext *c, Dav1dHipIntraList **out, const Dav1dHipIpredTask *preds, const size_t *pred_sizes,
+                                              const Dav1dHipItxTask *txs, const size_t *tx_sizes, size_t n_batches);
+DAV1D_HIP_API int dav1d_hip_intra_list_run_batch(Dav1dHipContext *c, const Dav1dHipIntraList *l, size_t batch, const Dav1dHipPicture *dst,
+                                                 void *coef, uint8_t *aux);
+DAV1D_HIP_API void dav1d_hip_intra_list_destroy(Dav1dHipContext *c, Dav1dHipIntraList *l);
+
 /* ------------------------------------------------- mc: warp, scaled, resize, emu_edge */
 
 /* One 8x8 block of a warped prediction: dsp->mc.warp8x8 (kind PUT, pixels into dst) or warp8x8t (kind PREP, int16

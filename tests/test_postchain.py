@@ -98,22 +98,32 @@ def oracle_intra(oracle, ip, planes, w, h, bpc):
     return coef
 
 
-def hip_intra(ctx, ip, pic, timed=False, graph=False):
+def hip_intra(ctx, ip, pic, timed=False, graph=False, paired=True):
     """Runs the intra pass from device-resident lists, every wave enqueued back to back on the context's stream
     (prediction of wave k, residuals of wave k, prediction of wave k + 1, ...), no host round trip in between.
     graph: record the whole chain once (dav1d_hip_graph_*) and replay it as one HIP graph.
+    paired: through dav1d_hip_intra_list_* (4x4 / 8x8 blocks: prediction + residual in one wave) instead of the prediction
+    list + one residual list per step.
     timed (bench.py only; needs torch for the events): returns the device time of the whole pass in ms, else 0."""
     import ctypes as C
     coef = ctx.buffer_from(ip.coef)
-    plist = ctx.ipred_list([b[0] for b in ip.batches])
-    ilists = [ctx.itx_list(b[1]) for b in ip.batches]
     lib = ctx.lib
+    if paired:
+        xl = ctx.intra_list(ip.batches)
+        plist, ilists = None, []
+    else:
+        xl = None
+        plist = ctx.ipred_list([b[0] for b in ip.batches])
+        ilists = [ctx.itx_list(b[1]) for b in ip.batches]
     lib.dav1d_hip_sync(ctx.h)
 
     def chain():
         for k in range(len(ip.batches)):
-            plist.run_batch(k, pic)
-            ctx.run_itx_list(ilists[k], pic, coef)
+            if xl is not None:
+                xl.run_batch(k, pic, coef)
+            else:
+                plist.run_batch(k, pic)
+                ctx.run_itx_list(ilists[k], pic, coef)
 
     g = None
     if graph:
@@ -140,7 +150,10 @@ def hip_intra(ctx, ip, pic, timed=False, graph=False):
     left = coef.download(ip.coef.dtype, len(ip.coef))
     if g is not None:
         ctx.graph_destroy(g)
-    plist.destroy()
+    if xl is not None:
+        xl.destroy()
+    else:
+        plist.destroy()
     for l in ilists:
         l.destroy()
     coef.free()
@@ -148,8 +161,9 @@ def hip_intra(ctx, ip, pic, timed=False, graph=False):
     return ms
 
 
+@pytest.mark.parametrize("paired", [True, False], ids=["paired", "two-launches"])
 @pytest.mark.parametrize("bpc", [8, 10, 12])
-def test_intra_wavefront_pass_matches_oracle(ctx, bpc):
+def test_intra_wavefront_pass_matches_oracle(ctx, bpc, paired):
     oracle = util.default_oracle()
     w, h = (256, 192) if ctx.backend == "emu" else (1024, 576)
     frame = synth.make_frame(w, h, bpc, seed=91 + bpc)
@@ -162,7 +176,7 @@ def test_intra_wavefront_pass_matches_oracle(ctx, bpc):
         pic.upload(pl, planes[pl])
     want = synth.copy_planes(planes)
     oracle_intra(oracle, ip, want, w, h, bpc)
-    hip_intra(ctx, ip, pic)
+    hip_intra(ctx, ip, pic, paired=paired)
     for pl in range(3):
         vh, vw = (h, w) if pl == 0 else (h // 2, w // 2)
         bad = np.argwhere(pic.download(pl)[:vh, :vw] != want[pl][:vh, :vw])
