@@ -400,6 +400,12 @@ class FrameInFlight:
         _chk(self.ctx.lib.dav1d_hip_frame_submit_tile_sbrow(self.h, m.ctypes.data, len(m), c.ctypes.data, len(c), t.ctypes.data, len(t)),
              "frame_submit_tile_sbrow")
 
+    def submit_intra_step(self, step, ipred, itx, aux=None):
+        a = np.ascontiguousarray(ipred, dtype=IPRED_TASK)
+        t = np.ascontiguousarray(itx, dtype=ITX_TASK)
+        _chk(self.ctx.lib.dav1d_hip_frame_submit_intra_step(self.h, step, a.ctypes.data, len(a), t.ctypes.data, len(t),
+                                                            aux.ptr if aux is not None else None), "frame_submit_intra_step")
+
     def submit_filter_sbrow(self, lf, cdef, lr):
         a = np.ascontiguousarray(lf, dtype=LF_TASK)
         b = np.ascontiguousarray(cdef, dtype=CDEF_TASK)

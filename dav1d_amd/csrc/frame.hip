@@ -20,6 +20,11 @@ struct Dav1dHipFrame {
     std::vector<Dav1dHipMcTask> mc;
     std::vector<Dav1dHipCompTask> comp;
     std::vector<Dav1dHipItxTask> itx;
+    // intra blocks: step k of the wavefront = the blocks whose neighbours are final after steps 0 .. k - 1 (and after the
+    // inter blocks of the frame); predictions and residuals per step
+    std::vector<std::vector<Dav1dHipIpredTask>> ipred;
+    std::vector<std::vector<Dav1dHipItxTask>> intra_itx;
+    uint8_t *aux;                    // DEVICE arena of the palette indices the intra tasks point into (may be NULL)
     std::vector<Dav1dHipLfTask> lf;
     std::vector<Dav1dHipCdefTask> cdef;
     std::vector<Dav1dHipLrTask> lr;
@@ -203,6 +208,7 @@ int dav1d_hip_frame_begin(Dav1dHipContext *c, Dav1dHipFrame **out, const Dav1dHi
     f->lvl = nullptr;
     f->b4_stride = 0;
     f->cdef_damping = 0;
+    f->aux = nullptr;
     f->have_grain = false;
     f->prepared = nullptr;
     f->is_id = 0;
@@ -222,6 +228,23 @@ int dav1d_hip_frame_submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc
     f->mc.insert(f->mc.end(), mc, mc + n_mc);
     f->comp.insert(f->comp.end(), comp, comp + n_comp);
     f->itx.insert(f->itx.end(), itx, itx + n_itx);
+    return 0;
+}
+
+// Intra blocks (recon_b_intra, src/recon_tmpl.c:1176-1555) of wavefront step `step`: the transform blocks whose left / top /
+// top-right neighbours are complete once every inter block of the frame and every intra block of the steps before it is — the
+// lister derives the step from the block position inside its superblock and the superblock's own anti-diagonal, as the
+// reference's tile threads do with their sbrow progress.  ipred[i] predicts a block; the residuals of the step's blocks go in
+// `itx` (any order).  `aux`: DEVICE arena of packed palette indices the PAL tasks point into (NULL if none), the same for all
+// calls of a frame.  Thread-safe; steps may arrive in any order.
+int dav1d_hip_frame_submit_intra_step(Dav1dHipFrame *f, size_t step, const Dav1dHipIpredTask *ipred, size_t n_ipred,
+                                      const Dav1dHipItxTask *itx, size_t n_itx, uint8_t *aux) {
+    if (!f || (!ipred && n_ipred) || (!itx && n_itx) || step > 65535) return -EINVAL;
+    std::lock_guard<std::mutex> lk(f->mtx);
+    if (f->ipred.size() <= step) { f->ipred.resize(step + 1); f->intra_itx.resize(step + 1); }
+    f->ipred[step].insert(f->ipred[step].end(), ipred, ipred + n_ipred);
+    f->intra_itx[step].insert(f->intra_itx[step].end(), itx, itx + n_itx);
+    if (aux) f->aux = aux;
     return 0;
 }
 
@@ -295,6 +318,22 @@ int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *ma
         if (rl) dav1d_hip_recon_list_destroy(c, rl);
     } else if (!f->itx.empty()) {
         rc = dav1d_hip_itx_add_batch(c, &f->cur, f->itx.data(), f->itx.size(), coef);
+    }
+    // intra blocks, wavefront step by step (each step: a paired launch for the small blocks, a prediction and a residual
+    // launch for the others), enqueued back to back
+    if (!rc && !f->ipred.empty()) {
+        std::vector<Dav1dHipIpredTask> allp;
+        std::vector<Dav1dHipItxTask> allt;
+        std::vector<size_t> ps, ts;
+        for (size_t k = 0; k < f->ipred.size(); k++) {
+            ps.push_back(f->ipred[k].size()); ts.push_back(f->intra_itx[k].size());
+            allp.insert(allp.end(), f->ipred[k].begin(), f->ipred[k].end());
+            allt.insert(allt.end(), f->intra_itx[k].begin(), f->intra_itx[k].end());
+        }
+        Dav1dHipIntraList *xl = nullptr;
+        rc = dav1d_hip_intra_list_create(c, &xl, allp.data(), ps.data(), allt.data(), ts.data(), ps.size());
+        for (size_t k = 0; k < ps.size() && !rc; k++) rc = dav1d_hip_intra_list_run_batch(c, xl, k, &f->cur, coef, f->aux);
+        if (xl) dav1d_hip_intra_list_destroy(c, xl);
     }
     const Dav1dHipPicture *last = &f->cur;
     int piped = 1;

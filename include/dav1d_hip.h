@@ -538,6 +538,10 @@ DAV1D_HIP_API int dav1d_hip_frame_begin(Dav1dHipContext *c, Dav1dHipFrame **out,
 DAV1D_HIP_API int dav1d_hip_frame_submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc,
                                                     const Dav1dHipCompTask *comp, size_t n_comp,
                                                     const Dav1dHipItxTask *itx, size_t n_itx);
+/* Intra blocks of wavefront step `step` (their neighbours are final after the inter blocks of the frame and the intra blocks of
+ * the steps before): predictions + residuals; `aux` = DEVICE arena of packed palette indices (NULL if no PAL task).  Thread-safe. */
+DAV1D_HIP_API int dav1d_hip_frame_submit_intra_step(Dav1dHipFrame *f, size_t step, const Dav1dHipIpredTask *ipred, size_t n_ipred,
+                                                    const Dav1dHipItxTask *itx, size_t n_itx, uint8_t *aux);
 DAV1D_HIP_API int dav1d_hip_frame_submit_filter_sbrow(Dav1dHipFrame *f, const Dav1dHipLfTask *lf, size_t n_lf,
                                                       const Dav1dHipCdefTask *cdef, size_t n_cdef,
                                                       const Dav1dHipLrTask *lr, size_t n_lr);

@@ -25,6 +25,10 @@ def test_frame_in_flight_matches_oracle(ctx, bpc, bands, monkeypatch):
     ref_host = [synth.make_planes(rng, w, h, bpc) for _ in range(frame.n_refs)]
     dst_host = synth.make_planes(rng, w, h, bpc, smooth=False)
     want_rec, _, _ = test_frame.oracle_frame(oracle, frame, dst_host, ref_host)
+    # some regions are then re-coded as intra blocks (wavefront steps), on top of the inter reconstruction
+    ip = synth.make_intra_pass(frame, seed=77 + bpc)
+    want_rec = synth.copy_planes(want_rec)
+    test_postchain.oracle_intra(oracle, ip, want_rec, w, h, bpc)
     want = test_postchain.oracle_post(oracle, post, want_rec, w, h, bpc)
 
     cur = ctx.picture(w, h, api.LAYOUT_I420, bpc)
@@ -39,7 +43,7 @@ def test_frame_in_flight_matches_oracle(ctx, bpc, bands, monkeypatch):
         cur.upload(pl, dst_host[pl])
     prep = ctx.buffer(frame.prep_elems * 2)
     prep.zero()
-    coef = ctx.buffer_from(frame.coef)
+    coef = ctx.buffer_from(np.concatenate([frame.coef, ip.coef]))       # one arena: the intra residuals behind the inter ones
     lvl = ctx.buffer_from(post.lvl)
 
     f = ctx.frame(cur, refs)
@@ -62,6 +66,11 @@ def test_frame_in_flight_matches_oracle(ctx, bpc, bands, monkeypatch):
     for t in th:
         t.join()
     assert not errs, errs
+    for k in reversed(range(len(ip.batches))):                           # steps may arrive in any order
+        pt, it = ip.batches[k]
+        it = it.copy()
+        it["cf_off"] += len(frame.coef)
+        f.submit_intra_step(k, pt, it)
     # loop restoration units must keep raster order: one submission per plane and stripe row
     f.submit_filter_sbrow(post.lf, post.cdef, post.lr)
     filtered = f.end(coef, prep, None, grain)
