@@ -34,3 +34,16 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert cpu["kind"] in ("reference", "port") and cpu["cores"] == 1 and cpu["value"] > 0
     assert d["value"] > cpu["value"]
     assert d["full_table"]["parity"].startswith("every stage bit-exact")
+
+
+@pytest.mark.gpu
+def test_bench_tile_column_mode_on_one_gpu():
+    """--shard tile-cols with one rank: torch-owned pictures behind the C ABI, the column split (one column) and the gather
+    (a no-op) — the path the N > 1 tile-column runs take, bit-exact against the oracle."""
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--width", "1280", "--height", "1024", "--no-cpu", "--shard", "tile-cols"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["scaling"] == "strong" and "tile-columns" in d["config"]["parallelism"]
+    assert d["config"]["parity"].startswith("bit-exact")
