@@ -209,6 +209,23 @@ def test_recon_list_with_transforms_smaller_than_their_prediction(ctx, pipeline,
     assert np.array_equal(got_coef, want_coef)
 
 
+@pytest.mark.parametrize("size", [(200, 136), (72, 40), (1000, 72)], ids=["200x136", "72x40", "1000x72"])
+def test_recon_list_on_pictures_that_are_not_multiples_of_the_block_sizes(ctx, size):
+    """Visible sizes that cut blocks (they still lie inside the padded planes, as in the reference's allocation)."""
+    w, h = size
+    bpc = 10
+    frame = synth.make_frame(w, h, bpc, seed=w * 7 + h, edge_frac=0.2, mv_range_px=40)
+    rng = np.random.default_rng(w + h)
+    refs = [synth.make_planes(rng, w, h, bpc) for _ in range(frame.n_refs)]
+    dst0 = synth.make_planes(rng, w, h, bpc, smooth=False)
+    want, _, want_coef = oracle_frame(util.default_oracle(), frame, dst0, refs)
+    got, _, got_coef = hip_frame(ctx, frame, dst0, refs, recon=True)
+    for pl in range(3):
+        bad = np.argwhere(got[pl] != want[pl])
+        assert not len(bad), "plane %d differs at %s (%d px)" % (pl, bad[0], len(bad))
+    assert np.array_equal(got_coef, want_coef)
+
+
 def test_recon_list_with_nothing_or_only_one_side(ctx):
     """Empty lists, predictions without residuals, residuals without predictions."""
     bpc, w, h = 8, 256, 128
