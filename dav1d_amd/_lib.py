@@ -71,6 +71,9 @@ SYMBOLS = [
     "dav1d_hip_ipred_list_create", "dav1d_hip_ipred_list_run_batch", "dav1d_hip_ipred_list_destroy",
     "dav1d_hip_frame_begin", "dav1d_hip_frame_submit_tile_sbrow", "dav1d_hip_frame_submit_filter_sbrow",
     "dav1d_hip_frame_set_filters", "dav1d_hip_frame_end", "dav1d_hip_frame_destroy",
+    "dav1d_hip_frame_submit_step_blend", "dav1d_hip_frame_submit_warp", "dav1d_hip_frame_submit_scaled",
+    "dav1d_hip_lister_create", "dav1d_hip_lister_tile_sbrow", "dav1d_hip_lister_prep_elems", "dav1d_hip_lister_mask_bytes",
+    "dav1d_hip_lister_steps", "dav1d_hip_lister_const_masks", "dav1d_hip_lister_destroy", "dav1d_hip_synth_frame",
 ]
 
 
@@ -81,6 +84,28 @@ class FilmGrainData(C.Structure):      # == Dav1dFilmGrainData, reference includ
                 ("ar_coeffs_uv", (C.c_int8 * 28) * 2), ("ar_coeff_shift", C.c_uint64), ("grain_scale_shift", C.c_int),
                 ("uv_mult", C.c_int * 2), ("uv_luma_mult", C.c_int * 2), ("uv_offset", C.c_int * 2),
                 ("overlap_flag", C.c_int), ("clip_to_restricted_range", C.c_int)]
+
+
+class WarpParams(C.Structure):         # == Dav1dHipWarpParams / Dav1dWarpedMotionParams
+    _fields_ = [("type", C.c_int), ("matrix", C.c_int32 * 6), ("abcd", C.c_int16 * 4)]
+
+
+class FrameDesc(C.Structure):          # == Dav1dHipFrameDesc
+    _fields_ = [("w", C.c_int), ("h", C.c_int), ("layout", C.c_int), ("bpc", C.c_int), ("sb128", C.c_int),
+                ("intra_edge_filter", C.c_int), ("is_inter", C.c_int), ("n_tile_cols", C.c_int), ("n_tile_rows", C.c_int),
+                ("col_start_sb", C.c_uint16 * 65), ("row_start_sb", C.c_uint16 * 65), ("b4_stride", C.c_ssize_t),
+                ("b", C.c_void_p), ("cbi", C.c_void_p), ("tile_start_off", C.c_void_p), ("pal", C.c_void_p),
+                ("svc", ((C.c_int32 * 2) * 2) * 7), ("ref_w", C.c_int * 7), ("ref_h", C.c_int * 7), ("gmv", WarpParams * 7),
+                ("gmv_warp_allowed", C.c_uint8 * 7), ("jnt_weights", (C.c_uint8 * 7) * 7), ("cf_align64", C.c_int)]
+
+
+class SynthParams(C.Structure):        # == Dav1dHipSynthParams
+    _fields_ = [("seed", C.c_uint64), ("intra_pct", C.c_int), ("skip_pct", C.c_int), ("compound_pct", C.c_int),
+                ("masked_compound", C.c_int), ("global_pct", C.c_int), ("interintra_pct", C.c_int), ("obmc_pct", C.c_int),
+                ("warp_pct", C.c_int), ("cfl_pct", C.c_int), ("palette", C.c_int), ("filter_intra_pct", C.c_int),
+                ("tx_split_pct", C.c_int), ("alt_txtp_pct", C.c_int), ("eob_none_pct", C.c_int), ("mv_range", C.c_int),
+                ("far_mv_pct", C.c_int), ("n_refs", C.c_int), ("split_pct", C.c_int * 5), ("rect_pct", C.c_int),
+                ("fixed_bl", C.c_int), ("cf_align64", C.c_int)]
 
 
 class LibraryError(RuntimeError):
@@ -168,6 +193,17 @@ def load(path=None):
         "dav1d_hip_frame_set_filters": (i, [vp, vp, C.c_ssize_t, vp, vp, i, vp, i]),
         "dav1d_hip_frame_end": (i, [vp, vp, vp, vp, P(Picture), P(Picture)]),
         "dav1d_hip_frame_destroy": (None, [vp]),
+        "dav1d_hip_frame_submit_step_blend": (i, [vp, sz, vp, sz]),
+        "dav1d_hip_frame_submit_warp": (i, [vp, vp, sz]),
+        "dav1d_hip_frame_submit_scaled": (i, [vp, vp, sz]),
+        "dav1d_hip_lister_create": (i, [P(vp), P(FrameDesc), vp]),
+        "dav1d_hip_lister_tile_sbrow": (i, [vp, i, i, i]),
+        "dav1d_hip_lister_prep_elems": (sz, [vp]),
+        "dav1d_hip_lister_mask_bytes": (sz, [vp]),
+        "dav1d_hip_lister_steps": (sz, [vp]),
+        "dav1d_hip_lister_const_masks": (vp, [P(sz)]),
+        "dav1d_hip_lister_destroy": (None, [vp]),
+        "dav1d_hip_synth_frame": (i, [P(FrameDesc), P(SynthParams), vp, sz, sz, vp, sz]),
         "dav1d_hip_dsp_init_8bpc": (i, [vp]),
         "dav1d_hip_dsp_init_16bpc": (i, [vp, i]),
     }

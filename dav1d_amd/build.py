@@ -16,7 +16,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["capi.hip", "frame.hip", "dsp_table.hip", "dsp_table_post.hip", "itx.hip", "mc.hip", "recon.hip", "intra_pair.hip", "mcx.hip", "comp.hip", "cdef.hip", "loopfilter.hip", "ipred.hip", "lr.hip", "fg.hip"]
+# host side of the pass-2 hand-off: plain C99 (the lister, its AV1 geometry, the synthetic frame generator), compiled with gcc
+HOST_SOURCES = ["av1_host.c", "lister.c", "synth_frame.c"]
+HOST = os.path.join(HERE, "host")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CC = os.environ.get("CC", "gcc")
 
 
 def _newer(target, deps):
@@ -28,10 +32,22 @@ def _newer(target, deps):
 
 def _deps():
     out = [os.path.join(ROOT, "include", "dav1d_hip.h")]
-    for f in os.listdir(CSRC):
-        if f.endswith(".h"):
-            out.append(os.path.join(CSRC, f))
+    for d in (CSRC, HOST):
+        for f in os.listdir(d):
+            if f.endswith(".h"):
+                out.append(os.path.join(d, f))
     return out
+
+
+def _host_jobs(objdir, hdrs, force):
+    jobs, objs = [], []
+    for s in HOST_SOURCES:
+        src = os.path.join(HOST, s)
+        obj = os.path.join(objdir, "host_" + s.replace(".c", ".o"))
+        objs.append(obj)
+        if force or _newer(obj, [src] + hdrs):
+            jobs.append([CC, "-std=gnu99", "-O2", "-fPIC", "-fvisibility=hidden", "-Wall", "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
+    return jobs, objs
 
 
 def _run(cmd):
@@ -54,13 +70,15 @@ def build_hip(force=False, verbose=False):
         if force or _newer(obj, [src] + hdrs):
             jobs.append([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
                          "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
+    hjobs, hobjs = _host_jobs(objdir, hdrs, force)
+    jobs += hjobs
     with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
         for o in ex.map(_run, jobs):
             if verbose and o:
                 print(o)
-    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES] + hobjs
     if force or jobs or _newer(out, objs):
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-lpthread"])
     return out
 
 
@@ -79,6 +97,9 @@ def build_emu(force=False):
         if force or _newer(obj, [src] + hdrs):
             jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-w", "-I" + emu, "-I" + os.path.join(ROOT, "include"),
                          "-x", "c++", "-c", src, "-o", obj])
+    hjobs, hobjs = _host_jobs(objdir, hdrs, force)
+    jobs += hjobs
+    objs += hobjs
     with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
         list(ex.map(_run, jobs))
     if force or jobs or _newer(out, objs):

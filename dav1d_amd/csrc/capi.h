@@ -136,7 +136,7 @@ extern "C" int dav1d_hip_launch_lf(const DevPlanes *dst, int bpc, int dir, const
 extern "C" int dav1d_hip_launch_intra_pairs(const DevPlanes *dst, int bpc, int layout, const Dav1dHipIpredTask *preds,
                                             const Dav1dHipItxTask *txs, int n, uint8_t *aux, void *coef, void *stream);
 extern "C" int dav1d_hip_launch_ipred(const DevPlanes *dst, int bpc, int layout, const Dav1dHipIpredTask *tasks, int n, int n_big,
-                                      uint8_t *pal_idx, void *stream);
+                                      uint8_t *pal_idx, void *tmp, void *stream);
 
 extern "C" int dav1d_hip_launch_wiener(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
                                        const Dav1dHipLrTask *tasks, int n, int max_w, void *stream);
@@ -163,4 +163,10 @@ extern "C" int dav1d_hip_launch_emu_edge(void *dst, ptrdiff_t dst_stride, const 
                                          int iw, int ih, int x, int y, int bpc, void *stream);
 
 Dav1dHipContext *dav1d_hip_default_context(void);
+// the intra wavefront list with the blends of inter-intra blocks (frame driver)
+extern "C" int dav1d_hip_intra_list_create_blend(Dav1dHipContext *c, Dav1dHipIntraList **out, const Dav1dHipIpredTask *preds, const size_t *pred_sizes,
+                                                 const Dav1dHipItxTask *txs, const size_t *tx_sizes, const Dav1dHipCompTask *blends,
+                                                 const size_t *blend_sizes, size_t n_batches);
+extern "C" int dav1d_hip_intra_list_run_batch_blend(Dav1dHipContext *c, const Dav1dHipIntraList *l, size_t batch, const Dav1dHipPicture *dst,
+                                                    void *coef, uint8_t *aux, int16_t *prep, uint8_t *mask);
 int dav1d_hip_scratch(Dav1dHipContext *c, size_t bytes, void **out);

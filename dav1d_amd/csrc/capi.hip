@@ -430,7 +430,8 @@ extern "C" {
 } // extern "C" (helpers below are C++)
 
 static int mc_task_valid(const Dav1dHipMcTask &t) {
-    return !(t.w < 2 || t.w > 128 || t.h < 2 || t.h > 128 || (t.w & (t.w - 1)) || (t.h & (t.h - 1)) ||
+    // widths are powers of two; heights too, except the 3/4-height `lap` predictions of obmc() (6, 12, 24 rows)
+    return !(t.w < 2 || t.w > 128 || t.h < 2 || t.h > 128 || (t.w & (t.w - 1)) || (t.h & 1) ||
              t.mx > 15 || t.my > 15 || t.filter_2d > 9 || t.kind > 2 || t.plane > 2 || t.ref > 7);
 }
 
@@ -466,7 +467,7 @@ static void push_tiles(std::vector<McTile> *bins, const Dav1dHipMcTask &t, int k
     const int cls = tile_dim_class(tw) * 3 + tile_dim_class(th);
     for (int oy = 0; oy < t.h; oy += th)
         for (int ox = 0; ox < t.w; ox += tw) {
-            m.w = tw; m.h = th; m.ox = ox; m.oy = oy;
+            m.w = tw; m.h = std::min(th, t.h - oy); m.ox = ox; m.oy = oy;
             m.r[0] = r0; m.r[0].src_x += ox; m.r[0].src_y += oy;
             m.r[1] = r1; m.r[1].src_x += ox; m.r[1].src_y += oy;
             if (single) single->push_back(m); else bins[cls].push_back(m);
@@ -685,6 +686,7 @@ int dav1d_hip_mc_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav
 } // extern "C"
 
 // --------------------------------------------------------------------- comp
+#include <unordered_set>
 
 struct Dav1dHipCompList {
     Dav1dHipCompTask *dev;
@@ -709,11 +711,18 @@ int dav1d_hip_comp_list_create(Dav1dHipContext *c, Dav1dHipCompList **out, const
     l->n = n;
     // obmc() blends the top neighbours' predictions (blend_h) before the left ones (blend_v) and the two overlap in the
     // block's top-left corner (reference src/recon_tmpl.c:1066-1111): keep that order with a second launch
+    // The chroma planes of a COMP_INTER_SEG block are combined with the mask its luma W_MASK task wrote
+    // (src/recon_tmpl.c:1812-1818, 1882-1889): those MASK tasks wait for the second launch as well.
+    std::unordered_set<uint32_t> wmask_out;
+    for (size_t i = 0; i < n; i++) if (tasks[i].kind == DAV1D_HIP_COMP_WMASK) wmask_out.insert(tasks[i].mask_off);
+    auto second = [&](const Dav1dHipCompTask &t) {
+        return t.kind == DAV1D_HIP_COMP_BLEND_V || (t.kind == DAV1D_HIP_COMP_MASK && wmask_out.count(t.mask_off));
+    };
     std::vector<Dav1dHipCompTask> sorted;
     sorted.reserve(n);
-    for (size_t i = 0; i < n; i++) if (tasks[i].kind != DAV1D_HIP_COMP_BLEND_V) sorted.push_back(tasks[i]);
+    for (size_t i = 0; i < n; i++) if (!second(tasks[i])) sorted.push_back(tasks[i]);
     l->n_first = sorted.size();
-    for (size_t i = 0; i < n; i++) if (tasks[i].kind == DAV1D_HIP_COMP_BLEND_V) sorted.push_back(tasks[i]);
+    for (size_t i = 0; i < n; i++) if (second(tasks[i])) sorted.push_back(tasks[i]);
     if (n) {
         if (hipMalloc((void **) &l->dev, n * sizeof(Dav1dHipCompTask)) != hipSuccess) { delete l; return -ENOMEM; }
         const int rc = dav1d_hip_upload(c, l->dev, sorted.data(), n * sizeof(Dav1dHipCompTask));
@@ -781,9 +790,33 @@ struct ReconPairing {
     std::vector<McTile> tiles[5];                       // per size class: tiles of the paired blocks, block by block
     std::vector<uint32_t> itx_idx[5];                   // per size class: the transform task of each block
     int mask;                                           // size classes that pair (bit k: 4 << k pixels square)
+    int stride_px[3];                                   // picture strides (pixels) of the geometry the list is made for
+    std::vector<uint8_t> blend_cells[3];                // per plane: 4x4 cells a blend task writes
+    int cell_stride[3];
+    void block_blend(const Dav1dHipCompTask &k) {
+        const int sp = stride_px[k.plane];
+        if (sp <= 0) return;
+        const int x = (int) (k.dst_off % (uint32_t) sp), y = (int) (k.dst_off / (uint32_t) sp);
+        for (int cy = y >> 2; cy <= (y + k.h - 1) >> 2; cy++)
+            for (int cx = x >> 2; cx <= (x + k.w - 1) >> 2; cx++) {
+                const size_t i = (size_t) cy * cell_stride[k.plane] + cx;
+                if (cx < cell_stride[k.plane] && i < blend_cells[k.plane].size()) blend_cells[k.plane][i] = 1;
+            }
+    }
+    bool blended(int plane, uint32_t dst_off, int w, int h) const {
+        const int sp = stride_px[plane];
+        if (sp <= 0 || blend_cells[plane].empty()) return false;
+        const int x = (int) (dst_off % (uint32_t) sp), y = (int) (dst_off / (uint32_t) sp);
+        for (int cy = y >> 2; cy <= (y + h - 1) >> 2; cy++)
+            for (int cx = x >> 2; cx <= (x + w - 1) >> 2; cx++) {
+                const size_t i = (size_t) cy * cell_stride[plane] + cx;
+                if (cx < cell_stride[plane] && i < blend_cells[plane].size() && blend_cells[plane][i]) return true;
+            }
+        return false;
+    }
     // the transform task a prediction of this rectangle pairs with, or -1
     long find(int plane, uint32_t dst_off, int w, int h) {
-        if (w != h) return -1;
+        if (w != h || blended(plane, dst_off, w, h)) return -1;
         auto it = by_pos.find((uint64_t) plane << 32 | dst_off);
         if (it == by_pos.end() || taken[it->second]) return -1;
         const Dav1dHipItxTask &t = itx[it->second];
@@ -831,6 +864,11 @@ static int inter_list_create_geo(Dav1dHipContext *c, Dav1dHipInterList **out, co
         if (mc[i].kind == DAV1D_HIP_MC_PREP) producer[mc[i].dst_off] = i;
     }
     for (size_t i = 0; i < n_comp; i++) { readers[comp[i].tmp1_off]++; readers[comp[i].tmp2_off]++; }
+    // A block some BLEND / BLEND_H / BLEND_V task writes on top of (OBMC, src/recon_tmpl.c:1052-1112) must not be paired:
+    // the reference's order is prediction, blends, residual, and a paired wave would add the residual before the blends.
+    if (pair)
+        for (size_t i = 0; i < n_comp; i++)
+            if (comp[i].kind >= DAV1D_HIP_COMP_BLEND) pair->block_blend(comp[i]);
     std::vector<char> fused_prep(n_mc, 0);
     std::vector<Dav1dHipCompTask> rest;
     std::vector<McTile> bins[MC_BINS];
@@ -988,8 +1026,9 @@ extern "C" int dav1d_hip_lf_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst
 static int ipred_tasks_valid(const Dav1dHipIpredTask *tasks, size_t n, const uint8_t *aux) {
     for (size_t i = 0; i < n; i++) {
         const Dav1dHipIpredTask &t = tasks[i];
-        if (t.plane > 2 || t.kind > DAV1D_HIP_IPRED_DSP_CFL_PRED || t.mode > 13 || !t.tw || !t.th || t.tw > 16 || t.th > 16) return -EINVAL;
-        if (t.kind >= DAV1D_HIP_IPRED_PAL && !aux) return -EINVAL;
+        if (t.plane > 2 || t.kind > DAV1D_HIP_IPRED_PRED_TMP || t.mode > 13 || !t.tw || !t.th || t.tw > 16 || t.th > 16) return -EINVAL;
+        if (t.kind >= DAV1D_HIP_IPRED_PAL && t.kind != DAV1D_HIP_IPRED_PRED_TMP && !aux) return -EINVAL;
+        if (t.kind == DAV1D_HIP_IPRED_PRED_TMP && (t.tw > 8 || t.th > 8 || t.mode > 12)) return -EINVAL;
         const bool cfl = t.kind == DAV1D_HIP_IPRED_CFL || t.kind >= DAV1D_HIP_IPRED_DSP_CFL_AC;
         if ((cfl || (t.kind != DAV1D_HIP_IPRED_PAL && t.mode == 13)) && (t.tw > 8 || t.th > 8)) return -EINVAL;   // both are limited to 32x32
         if (t.kind == DAV1D_HIP_IPRED_DSP_CFL_PRED && t.mode != 0 && (t.mode < 3 || t.mode > 5)) return -EINVAL;
@@ -1021,7 +1060,7 @@ extern "C" int dav1d_hip_ipred_batch(Dav1dHipContext *c, const Dav1dHipPicture *
     int rc = dav1d_hip_upload(c, dev, ordered.data(), n * sizeof(*dev));
     const DevPlanes dp = dev_planes(dst);
     KernelTimer kt(c);
-    if (!rc) rc = dav1d_hip_launch_ipred(&dp, dst->bpc, dst->layout, dev, (int) n, (int) n_big, pal_idx, c->stream);
+    if (!rc) rc = dav1d_hip_launch_ipred(&dp, dst->bpc, dst->layout, dev, (int) n, (int) n_big, pal_idx, nullptr, c->stream);
     kt.stop();
     hipStreamSynchronize(c->stream);
     hipFree(dev);
@@ -1034,7 +1073,7 @@ extern "C" int dav1d_hip_ipred_batch(Dav1dHipContext *c, const Dav1dHipPicture *
 struct Dav1dHipIpredList {
     Dav1dHipIpredTask *dev;
     std::vector<size_t> start, n_big;     // batch k = tasks [start[k], start[k + 1]), its first n_big[k] are split four ways
-    bool needs_aux;
+    bool needs_aux, needs_tmp;
 };
 
 extern "C" int dav1d_hip_ipred_list_create(Dav1dHipContext *c, Dav1dHipIpredList **out, const Dav1dHipIpredTask *tasks,
@@ -1049,8 +1088,11 @@ extern "C" int dav1d_hip_ipred_list_create(Dav1dHipContext *c, Dav1dHipIpredList
     Dav1dHipIpredList *l = new (std::nothrow) Dav1dHipIpredList();
     if (!l) return -ENOMEM;
     l->dev = nullptr;
-    l->needs_aux = false;
-    for (size_t i = 0; i < n; i++) if (tasks[i].kind >= DAV1D_HIP_IPRED_PAL) l->needs_aux = true;
+    l->needs_aux = l->needs_tmp = false;
+    for (size_t i = 0; i < n; i++) {
+        if (tasks[i].kind >= DAV1D_HIP_IPRED_PAL && tasks[i].kind != DAV1D_HIP_IPRED_PRED_TMP) l->needs_aux = true;
+        if (tasks[i].kind == DAV1D_HIP_IPRED_PRED_TMP) l->needs_tmp = true;
+    }
     l->start.push_back(0);
     for (size_t k = 0; k < n_batches; k++) l->start.push_back(l->start.back() + batch_sizes[k]);
     if (n) {
@@ -1064,13 +1106,19 @@ extern "C" int dav1d_hip_ipred_list_create(Dav1dHipContext *c, Dav1dHipIpredList
     return 0;
 }
 
-extern "C" int dav1d_hip_ipred_list_run_batch(Dav1dHipContext *c, const Dav1dHipIpredList *l, size_t batch, const Dav1dHipPicture *dst,
-                                              uint8_t *aux) {
-    if (!l || !dst || batch + 1 >= l->start.size() || (l->needs_aux && !aux)) return -EINVAL;
+// tmp: the scratch (prep) arena PRED_TMP tasks write to; NULL when the list holds none
+static int ipred_list_run_batch_tmp(Dav1dHipContext *c, const Dav1dHipIpredList *l, size_t batch, const Dav1dHipPicture *dst, uint8_t *aux,
+                                    void *tmp) {
+    if (!l || !dst || batch + 1 >= l->start.size() || (l->needs_aux && !aux) || (l->needs_tmp && !tmp)) return -EINVAL;
     const size_t n = l->start[batch + 1] - l->start[batch];
     if (!n) return 0;
     const DevPlanes dp = dev_planes(dst);
-    return dav1d_hip_launch_ipred(&dp, dst->bpc, dst->layout, l->dev + l->start[batch], (int) n, (int) l->n_big[batch], aux, c->stream);
+    return dav1d_hip_launch_ipred(&dp, dst->bpc, dst->layout, l->dev + l->start[batch], (int) n, (int) l->n_big[batch], aux, tmp, c->stream);
+}
+
+extern "C" int dav1d_hip_ipred_list_run_batch(Dav1dHipContext *c, const Dav1dHipIpredList *l, size_t batch, const Dav1dHipPicture *dst,
+                                              uint8_t *aux) {
+    return ipred_list_run_batch_tmp(c, l, batch, dst, aux, nullptr);
 }
 
 extern "C" void dav1d_hip_ipred_list_destroy(Dav1dHipContext *c, Dav1dHipIpredList *l) {
@@ -1386,6 +1434,14 @@ int dav1d_hip_recon_list_create(Dav1dHipContext *c, Dav1dHipReconList **out, con
     if (fuse) {
         pair.mask = recon_fuse_mask();
         pair.itx = itx;
+        bool any_blend = false;
+        for (size_t i = 0; i < n_comp && !any_blend; i++) any_blend = comp[i].kind >= DAV1D_HIP_COMP_BLEND;
+        for (int p = 0; p < 3; p++) {
+            const int bps = geometry->bpc > 8 ? 2 : 1;
+            pair.stride_px[p] = geometry->p[p].data ? (int) (geometry->p[p].stride / bps) : 0;
+            pair.cell_stride[p] = (pair.stride_px[p] + 3) >> 2;
+            if (any_blend && pair.stride_px[p]) pair.blend_cells[p].assign((size_t) pair.cell_stride[p] * (size_t) ((geometry->p[p].h + 127 + 3) >> 2), 0);
+        }
         pair.taken.assign(n_itx, 0);
         for (size_t i = 0; i < n_itx; i++)
             if (itx[i].tx <= 4 && (pair.mask >> itx[i].tx & 1)) pair.by_pos[(uint64_t) itx[i].plane << 32 | itx[i].dst_off] = (uint32_t) i;
@@ -1654,6 +1710,8 @@ struct Dav1dHipIntraList {
     Dav1dHipIpredTask *p_dev;                 // paired blocks of all batches: predictions ...
     Dav1dHipItxTask *t_dev;                   // ... and their residuals, same order
     std::vector<size_t> pair_start;           // batch k = pairs [pair_start[k], pair_start[k + 1])
+    Dav1dHipCompTask *b_dev;                  // inter-intra blends of all batches (run between a batch's predictions and residuals)
+    std::vector<size_t> blend_start;          // batch k = blends [blend_start[k], blend_start[k + 1])
     bool needs_aux;
 };
 
@@ -1664,11 +1722,18 @@ void dav1d_hip_intra_list_destroy(Dav1dHipContext *c, Dav1dHipIntraList *l) {
     hipStreamSynchronize(c->stream);
     if (l->p_dev) hipFree(l->p_dev);
     if (l->t_dev) hipFree(l->t_dev);
+    if (l->b_dev) hipFree(l->b_dev);
     delete l;
 }
 
 int dav1d_hip_intra_list_create(Dav1dHipContext *c, Dav1dHipIntraList **out, const Dav1dHipIpredTask *preds, const size_t *pred_sizes,
                                 const Dav1dHipItxTask *txs, const size_t *tx_sizes, size_t n_batches) {
+    return dav1d_hip_intra_list_create_blend(c, out, preds, pred_sizes, txs, tx_sizes, nullptr, nullptr, n_batches);
+}
+
+int dav1d_hip_intra_list_create_blend(Dav1dHipContext *c, Dav1dHipIntraList **out, const Dav1dHipIpredTask *preds, const size_t *pred_sizes,
+                                      const Dav1dHipItxTask *txs, const size_t *tx_sizes, const Dav1dHipCompTask *blends,
+                                      const size_t *blend_sizes, size_t n_batches) {
     if (!c || !out || !pred_sizes || !tx_sizes) return -EINVAL;
     *out = nullptr;
     size_t np = 0, nt = 0;
@@ -1679,8 +1744,18 @@ int dav1d_hip_intra_list_create(Dav1dHipContext *c, Dav1dHipIntraList **out, con
     for (size_t i = 0; i < nt; i++) if (!itx_task_ok(txs[i])) return -EINVAL;
     Dav1dHipIntraList *l = new (std::nothrow) Dav1dHipIntraList();
     if (!l) return -ENOMEM;
-    l->preds = nullptr; l->p_dev = nullptr; l->t_dev = nullptr; l->needs_aux = false;
-    for (size_t i = 0; i < np; i++) if (preds[i].kind >= DAV1D_HIP_IPRED_PAL) l->needs_aux = true;
+    l->preds = nullptr; l->p_dev = nullptr; l->t_dev = nullptr; l->b_dev = nullptr; l->needs_aux = false;
+    for (size_t i = 0; i < np; i++) if (preds[i].kind >= DAV1D_HIP_IPRED_PAL && preds[i].kind != DAV1D_HIP_IPRED_PRED_TMP) l->needs_aux = true;
+    l->blend_start.push_back(0);
+    for (size_t k = 0; k < n_batches; k++) l->blend_start.push_back(l->blend_start.back() + (blend_sizes ? blend_sizes[k] : 0));
+    if (l->blend_start.back()) {
+        const size_t nb = l->blend_start.back();
+        for (size_t i = 0; i < nb; i++)
+            if (!blends || blends[i].kind != DAV1D_HIP_COMP_BLEND || blends[i].plane > 2 || blends[i].w < 4 || blends[i].h < 4) { delete l; return -EINVAL; }
+        if (hipMalloc((void **) &l->b_dev, nb * sizeof(Dav1dHipCompTask)) != hipSuccess) { delete l; return -ENOMEM; }
+        const int brc = dav1d_hip_upload(c, l->b_dev, blends, nb * sizeof(Dav1dHipCompTask));
+        if (brc) { hipFree(l->b_dev); delete l; return brc; }
+    }
     static const bool pairing = !(getenv("DAV1D_HIP_INTRA_PAIR") && !atoi(getenv("DAV1D_HIP_INTRA_PAIR")));
     std::vector<Dav1dHipIpredTask> rest_p, pair_p;
     std::vector<Dav1dHipItxTask> pair_t;
@@ -1736,14 +1811,23 @@ int dav1d_hip_intra_list_create(Dav1dHipContext *c, Dav1dHipIntraList **out, con
 
 int dav1d_hip_intra_list_run_batch(Dav1dHipContext *c, const Dav1dHipIntraList *l, size_t batch, const Dav1dHipPicture *dst, void *coef,
                                    uint8_t *aux) {
+    return dav1d_hip_intra_list_run_batch_blend(c, l, batch, dst, coef, aux, nullptr, nullptr);
+}
+
+// prep / mask: the scratch arena the PRED_TMP predictions of the batch go to and the blends read, and the mask arena
+int dav1d_hip_intra_list_run_batch_blend(Dav1dHipContext *c, const Dav1dHipIntraList *l, size_t batch, const Dav1dHipPicture *dst, void *coef,
+                                         uint8_t *aux, int16_t *prep, uint8_t *mask) {
     if (!c || !l || !dst || batch + 1 >= l->pair_start.size() || (l->needs_aux && !aux)) return -EINVAL;
+    const size_t n_blend = l->blend_start[batch + 1] - l->blend_start[batch];
+    if (n_blend && (!prep || !mask)) return -EINVAL;
     const DevPlanes dp = dev_planes(dst);
     int rc = 0;
     const size_t n_pairs = l->pair_start[batch + 1] - l->pair_start[batch];
     if (n_pairs)
         rc = dav1d_hip_launch_intra_pairs(&dp, dst->bpc, dst->layout, l->p_dev + l->pair_start[batch], l->t_dev + l->pair_start[batch],
                                           (int) n_pairs, aux, coef, c->stream);
-    if (!rc) rc = dav1d_hip_ipred_list_run_batch(c, l->preds, batch, dst, aux);
+    if (!rc) rc = ipred_list_run_batch_tmp(c, l->preds, batch, dst, aux, prep);
+    if (!rc && n_blend) rc = dav1d_hip_launch_comp(&dp, dst->bpc, l->b_dev + l->blend_start[batch], (int) n_blend, prep, mask, c->stream);
     if (!rc && l->itx[batch]->n) rc = dav1d_hip_itx_list_run(c, l->itx[batch], dst, coef);
     return rc;
 }

@@ -24,6 +24,9 @@ struct Dav1dHipFrame {
     // inter blocks of the frame); predictions and residuals per step
     std::vector<std::vector<Dav1dHipIpredTask>> ipred;
     std::vector<std::vector<Dav1dHipItxTask>> intra_itx;
+    std::vector<std::vector<Dav1dHipCompTask>> step_blend;      // inter-intra blends per step (between predictions and residuals)
+    std::vector<Dav1dHipWarpTask> warp;                         // warped predictions (step 0: they read reference pictures only)
+    std::vector<Dav1dHipMcScaledTask> scaled;                   // predictions from references of another size
     uint8_t *aux;                    // DEVICE arena of the palette indices the intra tasks point into (may be NULL)
     std::vector<Dav1dHipLfTask> lf;
     std::vector<Dav1dHipCdefTask> cdef;
@@ -31,6 +34,7 @@ struct Dav1dHipFrame {
     const uint8_t *lvl;
     ptrdiff_t b4_stride;
     uint8_t lut_e[64], lut_i[64];
+    bool have_lut;
     int cdef_damping;
     bool have_grain;
     Dav1dHipFilmGrainData grain;
@@ -126,7 +130,7 @@ static int post_filters_pipelined(Dav1dHipFrame *f, const Dav1dHipPicture **last
         pos.assign(lr_off.begin(), lr_off.end() - 1);
         for (size_t i = 0; i < f->lr.size(); i++) lr_s[pos[2 * lr_b[i] + (f->lr[i].type > DAV1D_HIP_LR_WIENER5)]++] = f->lr[i];
     }
-    if (has_lf && !f->lvl) return -EINVAL;
+    if (has_lf && (!f->lvl || !f->have_lut)) return -EINVAL;
     int rc = 0;
     if (has_cdef) rc = frame_tmp(f, 0);
     if (!rc && has_lr) rc = frame_tmp(f, 1);
@@ -206,6 +210,8 @@ int dav1d_hip_frame_begin(Dav1dHipContext *c, Dav1dHipFrame **out, const Dav1dHi
     for (int i = 0; i < n_refs; i++) f->refs[i] = refs[i];
     f->n_refs = n_refs;
     f->lvl = nullptr;
+    memset(f->lut_e, 0, 64); memset(f->lut_i, 0, 64);
+    f->have_lut = false;
     f->b4_stride = 0;
     f->cdef_damping = 0;
     f->aux = nullptr;
@@ -241,10 +247,43 @@ int dav1d_hip_frame_submit_intra_step(Dav1dHipFrame *f, size_t step, const Dav1d
                                       const Dav1dHipItxTask *itx, size_t n_itx, uint8_t *aux) {
     if (!f || (!ipred && n_ipred) || (!itx && n_itx) || step > 65535) return -EINVAL;
     std::lock_guard<std::mutex> lk(f->mtx);
-    if (f->ipred.size() <= step) { f->ipred.resize(step + 1); f->intra_itx.resize(step + 1); }
+    if (f->ipred.size() <= step) { f->ipred.resize(step + 1); f->intra_itx.resize(step + 1); f->step_blend.resize(step + 1); }
     f->ipred[step].insert(f->ipred[step].end(), ipred, ipred + n_ipred);
     f->intra_itx[step].insert(f->intra_itx[step].end(), itx, itx + n_itx);
     if (aux) f->aux = aux;
+    return 0;
+}
+
+// The blends of inter-intra blocks of wavefront step `step` (kind DAV1D_HIP_COMP_BLEND, tmp1_off = where the step's PRED_TMP task
+// wrote the intra prediction): run after the step's predictions and before its residuals — the reference's order inside
+// recon_b_inter (src/recon_tmpl.c:1606-1630: intra_pred into tmp, blend, later the residual).  Thread-safe.
+int dav1d_hip_frame_submit_step_blend(Dav1dHipFrame *f, size_t step, const Dav1dHipCompTask *blend, size_t n) {
+    if (!f || (!blend && n) || step > 65535 || !step) return -EINVAL;
+    std::lock_guard<std::mutex> lk(f->mtx);
+    if (f->ipred.size() <= step) { f->ipred.resize(step + 1); f->intra_itx.resize(step + 1); f->step_blend.resize(step + 1); }
+    f->step_blend[step].insert(f->step_blend[step].end(), blend, blend + n);
+    return 0;
+}
+
+// Warped predictions (warp_affine(), src/recon_tmpl.c:1115-1174) and predictions from references of another size (the scaled
+// branch of mc(), :990-1047) of any tile-sbrow: they read reference pictures only and run before the compound combinations.
+int dav1d_hip_frame_submit_warp(Dav1dHipFrame *f, const Dav1dHipWarpTask *t, size_t n) {
+    if (!f || (!t && n)) return -EINVAL;
+    std::lock_guard<std::mutex> lk(f->mtx);
+    f->warp.insert(f->warp.end(), t, t + n);
+    return 0;
+}
+int dav1d_hip_frame_submit_scaled(Dav1dHipFrame *f, const Dav1dHipMcScaledTask *t, size_t n) {
+    if (!f || (!t && n)) return -EINVAL;
+    std::lock_guard<std::mutex> lk(f->mtx);
+    f->scaled.insert(f->scaled.end(), t, t + n);
+    return 0;
+}
+
+// internal: the picture the frame reconstructs into (the lister needs its strides)
+int dav1d_hip_frame_picture(const Dav1dHipFrame *f, Dav1dHipPicture *out) {
+    if (!f || !out) return -EINVAL;
+    *out = f->cur;
     return 0;
 }
 
@@ -270,6 +309,7 @@ int dav1d_hip_frame_set_filters(Dav1dHipFrame *f, const uint8_t *lvl, ptrdiff_t 
     f->b4_stride = b4_stride;
     if (lut_e) memcpy(f->lut_e, lut_e, 64);
     if (lut_i) memcpy(f->lut_i, lut_i, 64);
+    f->have_lut = lut_e && lut_i;
     f->cdef_damping = cdef_damping;
     f->have_grain = grain != nullptr;
     if (f->prepared) { dav1d_hip_fg_grain_destroy(f->c, f->prepared); f->prepared = nullptr; }
@@ -307,6 +347,10 @@ int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *ma
     std::lock_guard<std::mutex> lk(f->mtx);
     Dav1dHipContext *c = f->c;
     int rc = 0;
+    // warped / scaled predictions first: the compound combinations of the list below read their PREP outputs
+    if (!f->warp.empty()) rc = dav1d_hip_warp_batch(c, &f->cur, f->refs, f->n_refs, f->warp.data(), f->warp.size(), prep);
+    if (!rc && !f->scaled.empty()) rc = dav1d_hip_mc_scaled_batch(c, &f->cur, f->refs, f->n_refs, f->scaled.data(), f->scaled.size(), prep);
+    if (rc) return rc;
     if (!f->mc.empty() || !f->comp.empty()) {
         // predictions and residuals as one pipelined list (the residual launch of a transform size waits only for the
         // prediction launches under its blocks)
@@ -324,15 +368,18 @@ int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *ma
     if (!rc && !f->ipred.empty()) {
         std::vector<Dav1dHipIpredTask> allp;
         std::vector<Dav1dHipItxTask> allt;
-        std::vector<size_t> ps, ts;
+        std::vector<Dav1dHipCompTask> allb;
+        std::vector<size_t> ps, ts, bs;
+        f->step_blend.resize(f->ipred.size());
         for (size_t k = 0; k < f->ipred.size(); k++) {
-            ps.push_back(f->ipred[k].size()); ts.push_back(f->intra_itx[k].size());
+            ps.push_back(f->ipred[k].size()); ts.push_back(f->intra_itx[k].size()); bs.push_back(f->step_blend[k].size());
             allp.insert(allp.end(), f->ipred[k].begin(), f->ipred[k].end());
             allt.insert(allt.end(), f->intra_itx[k].begin(), f->intra_itx[k].end());
+            allb.insert(allb.end(), f->step_blend[k].begin(), f->step_blend[k].end());
         }
         Dav1dHipIntraList *xl = nullptr;
-        rc = dav1d_hip_intra_list_create(c, &xl, allp.data(), ps.data(), allt.data(), ts.data(), ps.size());
-        for (size_t k = 0; k < ps.size() && !rc; k++) rc = dav1d_hip_intra_list_run_batch(c, xl, k, &f->cur, coef, f->aux);
+        rc = dav1d_hip_intra_list_create_blend(c, &xl, allp.data(), ps.data(), allt.data(), ts.data(), allb.data(), bs.data(), ps.size());
+        for (size_t k = 0; k < ps.size() && !rc; k++) rc = dav1d_hip_intra_list_run_batch_blend(c, xl, k, &f->cur, coef, f->aux, prep, mask);
         if (xl) dav1d_hip_intra_list_destroy(c, xl);
     }
     const Dav1dHipPicture *last = &f->cur;
@@ -343,7 +390,7 @@ int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *ma
     if (piped == 1) {        // stage by stage
         last = &f->cur;
         if (!rc && !f->lf.empty()) {
-            if (!f->lvl) return -EINVAL;
+            if (!f->lvl || !f->have_lut) return -EINVAL;
             rc = dav1d_hip_lf_batch(c, &f->cur, f->lf.data(), f->lf.size(), f->lvl, f->b4_stride, f->lut_e, f->lut_i);
         }
         if (!rc && !f->cdef.empty()) {

@@ -19,7 +19,7 @@ namespace {
 
 template <typename pixel>
 __global__ __launch_bounds__(64) void ipred_kernel(const DevPlanes dst, const Dav1dHipIpredTask *__restrict__ tasks, const int n,
-                                                   const int n_big, uint8_t *aux, const int layout, const int bitdepth_max)
+                                                   const int n_big, uint8_t *aux, void *tmp, const int layout, const int bitdepth_max)
 {
     __shared__ int16_t e1[ESZ], e2[ESZ];
     __shared__ int16_t blk[32 * 32];
@@ -34,22 +34,24 @@ __global__ __launch_bounds__(64) void ipred_kernel(const DevPlanes dst, const Da
     const int ti = many ? b / IPRED_PARTS : b - n_big * (IPRED_PARTS - 1);
     if (ti >= n) return;
     const Dav1dHipIpredTask t = tasks[__builtin_amdgcn_readfirstlane(ti)];
-    pixel *const d = reinterpret_cast<pixel *>(dst.data[t.plane]) + t.dst_off;
-    ipred_body<pixel>(dst, t, part, many, aux, layout, bitdepth_max, e1, e2, blk, d, dst.stride[t.plane]);
+    // PRED_TMP (the intra half of an inter-intra block): same edges, the prediction goes to the scratch arena, row stride = width
+    const bool to_tmp = t.kind == DAV1D_HIP_IPRED_PRED_TMP;
+    pixel *const d = to_tmp ? reinterpret_cast<pixel *>(tmp) + t.aux_off : reinterpret_cast<pixel *>(dst.data[t.plane]) + t.dst_off;
+    ipred_body<pixel>(dst, t, part, many, aux, layout, bitdepth_max, e1, e2, blk, d, to_tmp ? t.tw * 4 : dst.stride[t.plane]);
 }
 
 } // namespace
 
 extern "C" int dav1d_hip_launch_ipred(const DevPlanes *dst, int bpc, int layout, const Dav1dHipIpredTask *tasks, int n, int n_big,
-                                      uint8_t *pal_idx, void *stream)
+                                      uint8_t *pal_idx, void *tmp, void *stream)
 {
     if (n <= 0) return 0;
     if (n_big < 0 || n_big > n) return -22;
     const int grid = n + n_big * (IPRED_PARTS - 1);
     const int bitdepth_max = (1 << bpc) - 1;
     if (bpc == 8)
-        hipLaunchKernelGGL((ipred_kernel<uint8_t>), dim3(grid), dim3(64), 0, (hipStream_t) stream, *dst, tasks, n, n_big, pal_idx, layout, bitdepth_max);
+        hipLaunchKernelGGL((ipred_kernel<uint8_t>), dim3(grid), dim3(64), 0, (hipStream_t) stream, *dst, tasks, n, n_big, pal_idx, tmp, layout, bitdepth_max);
     else
-        hipLaunchKernelGGL((ipred_kernel<uint16_t>), dim3(grid), dim3(64), 0, (hipStream_t) stream, *dst, tasks, n, n_big, pal_idx, layout, bitdepth_max);
+        hipLaunchKernelGGL((ipred_kernel<uint16_t>), dim3(grid), dim3(64), 0, (hipStream_t) stream, *dst, tasks, n, n_big, pal_idx, tmp, layout, bitdepth_max);
     return hip_rc(hipGetLastError());
 }

@@ -302,6 +302,10 @@ enum Dav1dHipIpredKind {
     DAV1D_HIP_IPRED_DSP_CFL_AC = 4,   /* cfl_ac[layout - 1]: luma at aux_off of plane 0, max_w / max_h = w_pad / h_pad, output tw*4 x th*4
                                          int16 (row stride = width) at int16 offset pal[1] | pal[2] << 16 of aux */
     DAV1D_HIP_IPRED_DSP_CFL_PRED = 5, /* cfl_pred[mode] (mode 0, 3, 4, 5): edge as DSP, ac as CFL_AC's output, angle = alpha */
+    /* The intra half of an inter-intra block (src/recon_tmpl.c:1606-1630, 1751-1784): edges prepared from the block's place in
+     * the picture like PRED, prediction written to the scratch (prep) arena as pixels, row stride = block width, at pixel
+     * offset aux_off; a DAV1D_HIP_COMP_BLEND task of the same wavefront step blends it in.  Frame API only. */
+    DAV1D_HIP_IPRED_PRED_TMP = 6,
 };
 
 /* One intra prediction of one transform block.  Field names follow the arguments of
@@ -542,6 +546,12 @@ DAV1D_HIP_API int dav1d_hip_frame_submit_tile_sbrow(Dav1dHipFrame *f, const Dav1
  * the steps before): predictions + residuals; `aux` = DEVICE arena of packed palette indices (NULL if no PAL task).  Thread-safe. */
 DAV1D_HIP_API int dav1d_hip_frame_submit_intra_step(Dav1dHipFrame *f, size_t step, const Dav1dHipIpredTask *ipred, size_t n_ipred,
                                                     const Dav1dHipItxTask *itx, size_t n_itx, uint8_t *aux);
+/* Inter-intra blends of wavefront step `step` >= 1 (kind DAV1D_HIP_COMP_BLEND reading what the step's DAV1D_HIP_IPRED_PRED_TMP
+ * tasks wrote): run between the step's predictions and its residuals.  Thread-safe. */
+DAV1D_HIP_API int dav1d_hip_frame_submit_step_blend(Dav1dHipFrame *f, size_t step, const Dav1dHipCompTask *blend, size_t n);
+/* Warped predictions / predictions from references of another size of any tile-sbrow; run before the compound combinations. */
+DAV1D_HIP_API int dav1d_hip_frame_submit_warp(Dav1dHipFrame *f, const Dav1dHipWarpTask *t, size_t n);
+DAV1D_HIP_API int dav1d_hip_frame_submit_scaled(Dav1dHipFrame *f, const Dav1dHipMcScaledTask *t, size_t n);
 DAV1D_HIP_API int dav1d_hip_frame_submit_filter_sbrow(Dav1dHipFrame *f, const Dav1dHipLfTask *lf, size_t n_lf,
                                                       const Dav1dHipCdefTask *cdef, size_t n_cdef,
                                                       const Dav1dHipLrTask *lr, size_t n_lr);
@@ -558,6 +568,112 @@ DAV1D_HIP_API int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *pre
  * not covering the frame, or DAV1D_HIP_POST_BANDS unset: the banded mode is an opt-in experiment, see frame.hip). */
 DAV1D_HIP_API int dav1d_hip_frame_post_bands(const Dav1dHipFrame *f);
 DAV1D_HIP_API void dav1d_hip_frame_destroy(Dav1dHipFrame *f);
+
+/* ------------------------------------------------------------- pass-2 lister */
+
+/* The hand-off of dav1d's frame threading (reference src/internal.h:276-293): pass 1 (entropy decoding) leaves, per frame,
+ * an Av1Block per coded block, the eob / transform type of every transform block (cbi), the dequantised coefficients (cf)
+ * and the palettes; pass 2 walks them in decode order and reconstructs (decode_b()'s pass-2 branch, src/decode.c:706-806,
+ * calling f->bd_fn.recon_b_intra / recon_b_inter, src/recon_tmpl.c:1176-1985).  The lister below IS that walk: instead of
+ * calling the DSP table it appends the flat task records above to a Dav1dHipFrame.  Host C (dav1d_amd/host/lister.c). */
+
+/* == Av1Block, reference src/levels.h:262-287 (32 bytes; tests/test_lister.py pins size and member offsets against the
+ * reference build).  Stored at the block's top-left 4x4: f->frame_thread.b[by * b4_stride + bx]. */
+typedef struct Dav1dHipAv1Block {
+    uint8_t bl, bs, bp;
+    uint8_t intra, seg_id, skip_mode, skip, uvtx;
+    union {
+        struct {
+            uint8_t y_mode, uv_mode, tx, pal_sz[2];
+            int8_t y_angle, uv_angle, cfl_alpha[2];
+        } i;                                           /* intra */
+        struct {
+            union {
+                struct { int16_t mv[2][2]; /* [ref][y, x] */ uint8_t wedge_idx, mask_sign, interintra_mode; } m;
+                struct { int16_t mv2d[2]; int16_t matrix[4]; } w;      /* MM_WARP blocks */
+            } u;
+            uint8_t comp_type, inter_mode, motion_mode, drl_idx;
+            int8_t ref[2];
+            uint8_t max_ytx, filter2d, interintra_type, tx_split0;
+            uint16_t tx_split1;
+        } p;                                           /* inter */
+    } u;
+} Dav1dHipAv1Block;
+
+/* == Dav1dWarpedMotionParams, reference include/dav1d/headers.h:97-106 */
+typedef struct Dav1dHipWarpParams {
+    int type;                    /* enum Dav1dWarpedMotionType: 0 identity, 1 translation, 2 rot-zoom, 3 affine */
+    int32_t matrix[6];
+    union { struct { int16_t alpha, beta, gamma, delta; } p; int16_t abcd[4]; } u;
+} Dav1dHipWarpParams;
+
+/* Everything of a Dav1dFrameContext the walk reads, as plain values and HOST pointers (nothing is copied: the arrays must
+ * stay alive until the last lister call of the frame).  Member comments name the reference field. */
+typedef struct Dav1dHipFrameDesc {
+    int w, h;                    /* f->cur.p.w / h (the coded size; super-resolution is not handled: -ENOTSUP) */
+    int layout, bpc;             /* f->cur.p.layout / bpc */
+    int sb128;                   /* seq_hdr->sb128 */
+    int intra_edge_filter;       /* seq_hdr->intra_edge_filter */
+    int is_inter;                /* IS_INTER_OR_SWITCH(frame_hdr): 0 on key / intra-only frames (intra block copy: -ENOTSUP) */
+    int n_tile_cols, n_tile_rows;           /* frame_hdr->tiling.cols / rows */
+    uint16_t col_start_sb[65], row_start_sb[65];    /* frame_hdr->tiling.col_start_sb / row_start_sb */
+    ptrdiff_t b4_stride;         /* f->b4_stride */
+    const Dav1dHipAv1Block *b;   /* f->frame_thread.b */
+    const int16_t *cbi;          /* f->frame_thread.cbi: eob << 5 | txtp per transform block */
+    const unsigned *tile_start_off;         /* f->frame_thread.tile_start_off[tile]: start of the tile's share of cbi / cf / pal_idx */
+    const void *pal;             /* f->frame_thread.pal: pixel[3][8] per 8x8 (NULL without screen content tools) */
+    int32_t svc[7][2][2];        /* f->svc[ref][x / y]{ scale, step }: scale 0 = reference has the frame's size */
+    int ref_w[7], ref_h[7];      /* f->refp[i].p.p.w / h */
+    Dav1dHipWarpParams gmv[7];   /* frame_hdr->gmv */
+    uint8_t gmv_warp_allowed[7]; /* f->gmv_warp_allowed */
+    uint8_t jnt_weights[7][7];   /* f->jnt_weights */
+    int cf_align64;              /* 1 when the producer is an x86-64 build of dav1d: decode_sb() realigns the coefficient cursor to
+                                    64 bytes after every 8x8 split into 4x4s (#if ARCH_X86_64, src/decode.c:2209-2218) */
+} Dav1dHipFrameDesc;
+
+/* Byte offset of a tile's first coefficient in the cf arena, of its first cbi entry and of its first palette index byte, as
+ * setup_tile() derives them from tile_start_off (reference src/decode.c:2438-2452). */
+typedef struct Dav1dHipLister Dav1dHipLister;
+
+/* Scratch layout of a listed frame: the prep arena holds, in int16 units, the PREP blocks of compound predictions and (as
+ * pixels) the OBMC / inter-intra intermediates; the mask arena starts with the constant wedge / inter-intra masks
+ * (dav1d_hip_lister_const_masks: upload them once per arena) followed by the frame's segmentation masks.  Sizes are known
+ * once every tile-sbrow is listed. */
+DAV1D_HIP_API int dav1d_hip_lister_create(Dav1dHipLister **out, const Dav1dHipFrameDesc *desc, Dav1dHipFrame *frame);
+/* One tile-sbrow (what a DAV1D_TASK_TYPE_TILE_RECONSTRUCTION task runs, src/thread_task.c:733-752 -> dav1d_decode_tile_sbrow
+ * with pass 2).  Thread-safe across tiles; the superblock rows of one tile must be listed top to bottom. */
+DAV1D_HIP_API int dav1d_hip_lister_tile_sbrow(Dav1dHipLister *l, int tile_row, int tile_col, int sby);
+DAV1D_HIP_API size_t dav1d_hip_lister_prep_elems(const Dav1dHipLister *l);   /* int16 elements of the prep arena used so far */
+DAV1D_HIP_API size_t dav1d_hip_lister_mask_bytes(const Dav1dHipLister *l);   /* bytes of the mask arena used so far (constant part included) */
+DAV1D_HIP_API size_t dav1d_hip_lister_steps(const Dav1dHipLister *l);        /* wavefront steps the frame needs so far */
+DAV1D_HIP_API const uint8_t *dav1d_hip_lister_const_masks(size_t *bytes);    /* HOST blob to copy to the start of the mask arena */
+DAV1D_HIP_API void dav1d_hip_lister_destroy(Dav1dHipLister *l);
+/* Test aids (tests/test_host_tables.py pins the lister's derived AV1 geometry against the tables of the reference build). */
+DAV1D_HIP_API long dav1d_hip_lister_mask_offset(int which, int c, int bs, int sign, int idx);
+DAV1D_HIP_API void dav1d_hip_lister_tables(uint8_t *out);
+DAV1D_HIP_API int dav1d_hip_lister_block_warp(Dav1dHipWarpParams *wm, const int16_t *matrix, const int16_t *mv2d, int bw4, int bh4, int bx4, int by4);
+
+/* Input generator (tests / bench.py; not part of the decode path): fills the hand-off arrays `desc` points to the way pass 1 of
+ * dav1d would have — block decisions drawn from a seeded generator under the legality rules of the AV1 syntax, coefficients on
+ * the scan positions up to each block's eob — because no AV1 streams or encoders exist in the build / GPU environment.  The
+ * arrays must be sized as dav1d_decode_frame_init() sizes them (src/decode.c:2839-2895) and cf zeroed.  Percentages 0..100. */
+typedef struct Dav1dHipSynthParams {
+    uint64_t seed;
+    int intra_pct, skip_pct;                 /* intra blocks on inter frames; skip (no residual) blocks */
+    int compound_pct, masked_compound;       /* two-reference blocks; allow COMP_INTER_SEG / WEDGE among them */
+    int global_pct;                          /* GLOBALMV blocks (warped when desc->gmv_warp_allowed[ref]) */
+    int interintra_pct, obmc_pct, warp_pct;  /* single-reference tools */
+    int cfl_pct, palette, filter_intra_pct;  /* intra tools (palette: percentage among eligible blocks, needs desc->pal) */
+    int tx_split_pct, alt_txtp_pct;          /* transform splitting per tree node; non-DCT_DCT transform types */
+    int eob_none_pct;                        /* transform blocks without coefficients (eob = -1) */
+    int mv_range, far_mv_pct;                /* |mv| in 1/8 pel; vectors pointing far outside the picture (edge emulation) */
+    int n_refs;                              /* references in use, 1..7 */
+    int split_pct[5], rect_pct;              /* per block level 128 .. 8: split; among the rest: a non-square partition */
+    int fixed_bl;                            /* >= 0: every block is the square of that level (0 = 128x128 .. 4 = 8x8, 5 = 4x4) */
+    int cf_align64;                          /* == Dav1dHipFrameDesc.cf_align64 */
+} Dav1dHipSynthParams;
+DAV1D_HIP_API int dav1d_hip_synth_frame(const Dav1dHipFrameDesc *desc, const Dav1dHipSynthParams *sp, void *cf, size_t cf_bytes,
+                                        size_t cbi_entries, uint8_t *pal_idx, size_t pal_idx_bytes);
 
 /* ------------------------------------------------- reference-signature table */
 

@@ -1,0 +1,369 @@
+/* Frame-level parity harness, linked INTO the oracle build of the reference (oracle/_ref/libdav1d_ref.so).
+ * TEST INFRASTRUCTURE ONLY: nothing in the product library links or loads this.
+ *
+ * It builds a real Dav1dContext / Dav1dFrameContext / Dav1dTaskContext the way dav1d_submit_frame() does
+ * (reference src/decode.c:3290-3560), lets the reference's own dav1d_decode_frame_init() (:2750-3140) allocate every
+ * per-frame array, exposes those arrays so that a test can fill them with a synthetic pass-1 output, and then runs the
+ * reference's OWN pass 2 — dav1d_decode_tile_sbrow() with frame_thread.pass = 2 (:2594-2635), i.e. decode_sb / decode_b /
+ * dav1d_recon_b_intra / dav1d_recon_b_inter through the reference DSP table — and its OWN in-loop filters
+ * (dav1d_filter_sbrow_{8,16}bpc, src/recon_tmpl.c:2100-2109) on the CPU.  No codec logic is restated here: only the set-up
+ * of the context structs, the tile cursors of setup_tile() (:2438-2452, static in the reference) and, for the filter inputs,
+ * the per-block calls of dav1d_create_lf_mask_intra / _inter that pass 1 makes (:1216-1226, 1882-1900). */
+#include "config.h"
+#include <stdlib.h>
+#include <string.h>
+#include <stddef.h>
+#include <limits.h>
+#include "src/internal.h"
+#include "src/tables.h"
+#include "src/wedge.h"
+#include "src/intra_edge.h"
+#include "src/qm.h"
+#include "src/warpmv.h"
+#include "src/decode.h"
+#include "src/recon.h"
+#include "src/lf_mask.h"
+#include "src/env.h"
+
+typedef struct RefFrameParams {
+    int w, h, layout, bpc, sb128;
+    int is_inter;
+    int n_tile_cols, n_tile_rows;
+    uint16_t col_start_sb[65], row_start_sb[65];
+    int intra_edge_filter;
+    int allow_screen_content_tools;
+    int switchable_comp_refs;
+    int ref_w[7], ref_h[7];
+    int ref_poc[7], cur_poc, order_hint_n_bits;
+    int gmv_type[7];
+    int32_t gmv_matrix[7][6];
+    /* in-loop filters */
+    int lf_level_y[2], lf_level_u, lf_level_v, lf_sharpness;
+    int cdef_enabled, cdef_damping, cdef_n_bits;
+    int cdef_y_strength[8], cdef_uv_strength[8];
+    int lr_type[3], lr_unit_size[2];
+} RefFrameParams;
+
+typedef struct RefFrame {
+    Dav1dContext c;
+    Dav1dFrameContext f;
+    Dav1dSequenceHeader seq;
+    Dav1dFrameHeader fh, ref_fh[7];
+    Dav1dTaskContext *tc;
+    atomic_int flush_mem;
+    void *pic_mem[8];
+    size_t plane_bytes[8][3];
+    refmvs_temporal_block *mvs;
+    RefFrameParams p;
+    /* pass-1 stand-in state for the loop filter masks */
+    BlockContext *lf_a;       /* per 128-pixel column of the frame */
+    BlockContext lf_l;
+} RefFrame;
+
+static void once_init(void) {
+    static int done;
+    if (done) return;
+    dav1d_init_cpu();
+    dav1d_init_ii_wedge_masks();
+    dav1d_init_intra_edge_tree();
+    dav1d_init_qm_tables();
+    done = 1;
+}
+
+/* geometry of dav1d_default_picture_alloc(), src/picture.c:46-78 */
+static int alloc_picture(RefFrame *r, const int slot, Dav1dPicture *p, const int w, const int h, const int layout, const int bpc) {
+    const int hbd = bpc > 8;
+    const int aligned_w = (w + 127) & ~127, aligned_h = (h + 127) & ~127;
+    const int has_chroma = layout != DAV1D_PIXEL_LAYOUT_I400;
+    const int ss_ver = layout == DAV1D_PIXEL_LAYOUT_I420, ss_hor = layout != DAV1D_PIXEL_LAYOUT_I444;
+    ptrdiff_t y_stride = aligned_w << hbd;
+    ptrdiff_t uv_stride = has_chroma ? y_stride >> ss_hor : 0;
+    if (!(y_stride & 1023)) y_stride += DAV1D_PICTURE_ALIGNMENT;
+    if (!(uv_stride & 1023) && has_chroma) uv_stride += DAV1D_PICTURE_ALIGNMENT;
+    const size_t y_sz = y_stride * aligned_h, uv_sz = uv_stride * (aligned_h >> ss_ver);
+    void *buf = NULL;
+    if (posix_memalign(&buf, 64, y_sz + 2 * uv_sz + DAV1D_PICTURE_ALIGNMENT)) return -1;
+    memset(buf, 0, y_sz + 2 * uv_sz + DAV1D_PICTURE_ALIGNMENT);
+    memset(p, 0, sizeof(*p));
+    p->p.w = w; p->p.h = h; p->p.layout = layout; p->p.bpc = bpc;
+    p->stride[0] = y_stride; p->stride[1] = uv_stride;
+    p->data[0] = buf;
+    p->data[1] = has_chroma ? (uint8_t *) buf + y_sz : NULL;
+    p->data[2] = has_chroma ? (uint8_t *) buf + y_sz + uv_sz : NULL;
+    r->pic_mem[slot] = buf;
+    r->plane_bytes[slot][0] = y_sz; r->plane_bytes[slot][1] = r->plane_bytes[slot][2] = uv_sz;
+    return 0;
+}
+
+void dav1d_ref_frame_destroy(void *h);
+
+void *dav1d_ref_frame_create(const RefFrameParams *const p) {
+    once_init();
+    RefFrame *r = NULL;
+    if (posix_memalign((void **) &r, 64, sizeof(*r))) return NULL;
+    memset(r, 0, sizeof(*r));
+    r->p = *p;
+    Dav1dContext *const c = &r->c;
+    Dav1dFrameContext *const f = &r->f;
+    const int bits = p->bpc == 8 ? 0 : p->bpc == 10 ? 1 : 2;
+
+    /* the frame-threaded configuration that produces the two-pass hand-off (src/lib.c:140-301: n_fc > 1) */
+    c->n_fc = 2; c->n_tc = 2;
+    c->fc = f;
+    c->flush = &r->flush_mem;
+    c->inloop_filters = DAV1D_INLOOPFILTER_ALL;
+    if (posix_memalign((void **) &r->tc, 64, sizeof(*r->tc))) { free(r); return NULL; }
+    memset(r->tc, 0, sizeof(*r->tc));
+    c->tc = r->tc;
+    if (p->bpc == 8) {
+        dav1d_cdef_dsp_init_8bpc(&c->dsp[0].cdef); dav1d_intra_pred_dsp_init_8bpc(&c->dsp[0].ipred); dav1d_itx_dsp_init_8bpc(&c->dsp[0].itx, 8);
+        dav1d_loop_filter_dsp_init_8bpc(&c->dsp[0].lf); dav1d_loop_restoration_dsp_init_8bpc(&c->dsp[0].lr, 8); dav1d_mc_dsp_init_8bpc(&c->dsp[0].mc);
+        dav1d_film_grain_dsp_init_8bpc(&c->dsp[0].fg);
+    } else {
+        dav1d_cdef_dsp_init_16bpc(&c->dsp[bits].cdef); dav1d_intra_pred_dsp_init_16bpc(&c->dsp[bits].ipred); dav1d_itx_dsp_init_16bpc(&c->dsp[bits].itx, p->bpc);
+        dav1d_loop_filter_dsp_init_16bpc(&c->dsp[bits].lf); dav1d_loop_restoration_dsp_init_16bpc(&c->dsp[bits].lr, p->bpc); dav1d_mc_dsp_init_16bpc(&c->dsp[bits].mc);
+        dav1d_film_grain_dsp_init_16bpc(&c->dsp[bits].fg);
+    }
+    dav1d_refmvs_dsp_init(&c->refmvs_dsp);
+    dav1d_pal_dsp_init(&c->pal_dsp);
+
+    /* headers: the fields pass 2 and the in-loop filters read */
+    Dav1dSequenceHeader *const seq = &r->seq;
+    Dav1dFrameHeader *const fh = &r->fh;
+    seq->sb128 = p->sb128;
+    seq->hbd = bits;
+    seq->layout = p->layout;
+    seq->intra_edge_filter = p->intra_edge_filter;
+    seq->order_hint_n_bits = p->order_hint_n_bits;
+    seq->order_hint = p->order_hint_n_bits > 0;
+    seq->cdef = p->cdef_enabled;
+    seq->restoration = p->lr_type[0] || p->lr_type[1] || p->lr_type[2];
+    fh->frame_type = p->is_inter ? DAV1D_FRAME_TYPE_INTER : DAV1D_FRAME_TYPE_KEY;
+    fh->width[0] = fh->width[1] = p->w;
+    fh->height = p->h;
+    fh->frame_offset = p->cur_poc;
+    fh->allow_screen_content_tools = p->allow_screen_content_tools;
+    fh->switchable_comp_refs = p->switchable_comp_refs;
+    fh->tiling.cols = p->n_tile_cols; fh->tiling.rows = p->n_tile_rows;
+    for (int i = 0; i <= p->n_tile_cols; i++) fh->tiling.col_start_sb[i] = p->col_start_sb[i];
+    for (int i = 0; i <= p->n_tile_rows; i++) fh->tiling.row_start_sb[i] = p->row_start_sb[i];
+    fh->loopfilter.level_y[0] = p->lf_level_y[0]; fh->loopfilter.level_y[1] = p->lf_level_y[1];
+    fh->loopfilter.level_u = p->lf_level_u; fh->loopfilter.level_v = p->lf_level_v;
+    fh->loopfilter.sharpness = p->lf_sharpness;
+    fh->cdef.damping = p->cdef_damping; fh->cdef.n_bits = p->cdef_n_bits;
+    for (int i = 0; i < 8; i++) { fh->cdef.y_strength[i] = p->cdef_y_strength[i]; fh->cdef.uv_strength[i] = p->cdef_uv_strength[i]; }
+    for (int i = 0; i < 3; i++) fh->restoration.type[i] = p->lr_type[i];
+    fh->restoration.unit_size[0] = p->lr_unit_size[0]; fh->restoration.unit_size[1] = p->lr_unit_size[1];
+    fh->txfm_mode = DAV1D_TX_SWITCHABLE;
+    for (int i = 0; i < 7; i++) {
+        fh->gmv[i] = dav1d_default_wm_params;
+        fh->gmv[i].type = p->gmv_type[i];
+        if (p->gmv_type[i]) memcpy(fh->gmv[i].matrix, p->gmv_matrix[i], sizeof(fh->gmv[i].matrix));
+    }
+
+    f->c = c;
+    f->seq_hdr = seq;
+    f->frame_hdr = fh;
+    f->dsp = &c->dsp[bits];
+    f->lf.last_sharpness = -1;
+    /* bd_fn, src/decode.c:3419-3442 */
+    if (p->bpc == 8) {
+        f->bd_fn.recon_b_inter = dav1d_recon_b_inter_8bpc; f->bd_fn.recon_b_intra = dav1d_recon_b_intra_8bpc;
+        f->bd_fn.filter_sbrow = dav1d_filter_sbrow_8bpc; f->bd_fn.backup_ipred_edge = dav1d_backup_ipred_edge_8bpc;
+        f->bd_fn.read_coef_blocks = dav1d_read_coef_blocks_8bpc;
+    } else {
+        f->bd_fn.recon_b_inter = dav1d_recon_b_inter_16bpc; f->bd_fn.recon_b_intra = dav1d_recon_b_intra_16bpc;
+        f->bd_fn.filter_sbrow = dav1d_filter_sbrow_16bpc; f->bd_fn.backup_ipred_edge = dav1d_backup_ipred_edge_16bpc;
+        f->bd_fn.read_coef_blocks = dav1d_read_coef_blocks_16bpc;
+    }
+
+    /* pictures: current (no super-resolution: sr_cur is cur) and the seven references */
+    if (alloc_picture(r, 0, &f->cur, p->w, p->h, p->layout, p->bpc)) goto fail;
+    f->cur.seq_hdr = seq; f->cur.frame_hdr = fh;
+    f->sr_cur.p = f->cur;
+    if (p->is_inter)
+        for (int i = 0; i < 7; i++) {
+            if (alloc_picture(r, 1 + i, &f->refp[i].p, p->ref_w[i], p->ref_h[i], p->layout, p->bpc)) goto fail;
+            r->ref_fh[i].frame_offset = p->ref_poc[i];
+            r->ref_fh[i].width[0] = r->ref_fh[i].width[1] = p->ref_w[i];
+            r->ref_fh[i].height = p->ref_h[i];
+            f->refp[i].p.frame_hdr = &r->ref_fh[i];
+            f->refp[i].p.seq_hdr = seq;
+            f->refpoc[i] = p->ref_poc[i];
+            /* src/decode.c:3469-3487 */
+            if (p->w != p->ref_w[i] || p->h != p->ref_h[i]) {
+#define scale_fac(ref_sz, this_sz) ((((ref_sz) << 14) + ((this_sz) >> 1)) / (this_sz))
+                f->svc[i][0].scale = scale_fac(p->ref_w[i], p->w);
+                f->svc[i][1].scale = scale_fac(p->ref_h[i], p->h);
+                f->svc[i][0].step = (f->svc[i][0].scale + 8) >> 4;
+                f->svc[i][1].step = (f->svc[i][1].scale + 8) >> 4;
+#undef scale_fac
+            }
+            f->gmv_warp_allowed[i] = fh->gmv[i].type > DAV1D_WM_TYPE_TRANSLATION && !fh->force_integer_mv &&
+                                     !dav1d_get_shear_params(&fh->gmv[i]) && !f->svc[i][0].scale;
+        }
+
+    /* geometry, src/decode.c:3552-3562 */
+    f->w4 = (p->w + 3) >> 2; f->h4 = (p->h + 3) >> 2;
+    f->bw = ((p->w + 7) >> 3) << 1; f->bh = ((p->h + 7) >> 3) << 1;
+    f->sb128w = (f->bw + 31) >> 5; f->sb128h = (f->bh + 31) >> 5;
+    f->sb_shift = 4 + seq->sb128; f->sb_step = 16 << seq->sb128;
+    f->sbh = (f->bh + f->sb_step - 1) >> f->sb_shift;
+    f->b4_stride = (f->bw + 31) & ~31;
+    f->bitdepth_max = (1 << p->bpc) - 1;
+    if (p->is_inter) {
+        r->mvs = calloc((size_t) f->sb128h * 16 * (f->b4_stride >> 1), sizeof(*r->mvs));
+        f->mvs = r->mvs;
+    }
+    if (dav1d_decode_frame_init(f)) goto fail;
+    if (p->is_inter) memset(f->rf.r, 0, sizeof(*f->rf.r) * 35 * 2 * f->rf.n_blocks * 2);
+    memset(f->frame_thread.b, 0, sizeof(*f->frame_thread.b) * f->sb128w * f->sb128h * 32 * 32);
+    memset(f->lf.level, 0, sizeof(*f->lf.level) * f->sb128w * f->sb128h * 32 * 32 + 3);
+    memset(f->lf.lr_mask, 0, sizeof(*f->lf.lr_mask) * f->lf.lr_mask_sz);
+    memset(f->lf.tx_lpf_right_edge[0], 0, (size_t) f->lf.re_sz * 32 * 2);
+
+    /* setup_tile(), src/decode.c:2425-2509, minus the entropy decoder */
+    {
+        static const uint8_t ss_size_mul[4][2] = { { 4, 4 }, { 6, 5 }, { 8, 6 }, { 12, 8 } };
+        const uint8_t *const size_mul = ss_size_mul[p->layout];
+        for (int tr = 0, j = 0; tr < p->n_tile_rows; tr++)
+            for (int tcol = 0; tcol < p->n_tile_cols; tcol++, j++) {
+                Dav1dTileState *const ts = &f->ts[j];
+                const unsigned off = f->frame_thread.tile_start_off[j];
+                for (int q = 0; q < 2; q++) {
+                    ts->frame_thread[q].pal_idx = f->frame_thread.pal_idx ? &f->frame_thread.pal_idx[(size_t) off * size_mul[1] / 8] : NULL;
+                    ts->frame_thread[q].cbi = &f->frame_thread.cbi[(size_t) off * size_mul[0] / 64];
+                    ts->frame_thread[q].cf = (uint8_t *) f->frame_thread.cf + (((size_t) off * size_mul[0]) >> !seq->hbd);
+                }
+                ts->tiling.row = tr; ts->tiling.col = tcol;
+                ts->tiling.col_start = fh->tiling.col_start_sb[tcol] << f->sb_shift;
+                ts->tiling.col_end = imin(fh->tiling.col_start_sb[tcol + 1] << f->sb_shift, f->bw);
+                ts->tiling.row_start = fh->tiling.row_start_sb[tr] << f->sb_shift;
+                ts->tiling.row_end = imin(fh->tiling.row_start_sb[tr + 1] << f->sb_shift, f->bh);
+                ts->lflvl = f->lf.lvl;
+            }
+    }
+    r->lf_a = calloc((size_t) f->sb128w, sizeof(*r->lf_a));
+    return r;
+fail:
+    dav1d_ref_frame_destroy(r);
+    return NULL;
+}
+
+void dav1d_ref_frame_destroy(void *const h) {
+    RefFrame *const r = h;
+    if (!r) return;
+    for (int i = 0; i < 8; i++) free(r->pic_mem[i]);
+    free(r->tc);
+    free(r->mvs);
+    free(r->lf_a);
+    /* the per-frame arrays dav1d_decode_frame_init() allocated stay with the process: test infrastructure */
+    free(r);
+}
+
+/* named access to the arrays a test fills / reads */
+void *dav1d_ref_frame_ptr(void *const h, const char *const name, size_t *const bytes) {
+    RefFrame *const r = h;
+    Dav1dFrameContext *const f = &r->f;
+    const int num_sb128 = f->sb128w * f->sb128h;
+    size_t n = 0;
+    void *ptr = NULL;
+#define IS(s) (!strcmp(name, s))
+    if (IS("b")) { ptr = f->frame_thread.b; n = sizeof(Av1Block) * num_sb128 * 32 * 32; }
+    else if (IS("cbi")) { ptr = f->frame_thread.cbi; n = sizeof(int16_t) * (size_t) f->frame_thread.cbi_sz * 32 * 32 / 4; }
+    else if (IS("cf")) { ptr = f->frame_thread.cf; n = (size_t) f->frame_thread.cf_sz * 128 * 128 / 2; }
+    else if (IS("pal")) { ptr = f->frame_thread.pal; n = (size_t) f->frame_thread.pal_sz * 16 * 16 * 24; }
+    else if (IS("pal_idx")) { ptr = f->frame_thread.pal_idx; n = (size_t) f->frame_thread.pal_idx_sz * 128 * 128 / 8; }
+    else if (IS("tile_start_off")) { ptr = f->frame_thread.tile_start_off; n = sizeof(unsigned) * f->n_ts; }
+    else if (IS("svc")) { ptr = f->svc; n = sizeof(f->svc); }
+    else if (IS("gmv_warp_allowed")) { ptr = f->gmv_warp_allowed; n = sizeof(f->gmv_warp_allowed); }
+    else if (IS("jnt_weights")) { ptr = f->jnt_weights; n = sizeof(f->jnt_weights); }
+    else if (IS("gmv")) { ptr = r->fh.gmv; n = sizeof(r->fh.gmv); }
+    else if (IS("lf_mask")) { ptr = f->lf.mask; n = sizeof(*f->lf.mask) * num_sb128; }
+    else if (IS("lf_level")) { ptr = f->lf.level; n = sizeof(*f->lf.level) * num_sb128 * 32 * 32; }
+    else if (IS("lr_mask")) { ptr = f->lf.lr_mask; n = sizeof(*f->lf.lr_mask) * f->lf.lr_mask_sz; }
+    else if (IS("lim_lut")) { ptr = &f->lf.lim_lut; n = sizeof(f->lf.lim_lut); }
+    else if (IS("tx_lpf_right_edge0")) { ptr = f->lf.tx_lpf_right_edge[0]; n = (size_t) f->lf.re_sz * 32; }
+    else if (IS("tx_lpf_right_edge1")) { ptr = f->lf.tx_lpf_right_edge[1]; n = (size_t) f->lf.re_sz * 32; }
+    else if (!strncmp(name, "pic", 3) && name[3] >= '0' && name[3] <= '7' && name[4] == '_' && name[5] >= '0' && name[5] <= '2') {
+        /* pic<slot>_<plane>: slot 0 = the current picture, 1 + i = reference i */
+        const int slot = name[3] - '0', pl = name[5] - '0';
+        const Dav1dPicture *pic = slot ? &f->refp[slot - 1].p : &f->cur;
+        ptr = pic->data[pl]; n = r->plane_bytes[slot][pl];
+    }
+#undef IS
+    if (bytes) *bytes = n;
+    return ptr;
+}
+
+/* geometry a test needs: [0] b4_stride, [1] bw, [2] bh, [3] sb128w, [4] sbh, [5..6] cur strides, [7 + 2 i ..] ref strides */
+void dav1d_ref_frame_geometry(void *const h, int64_t *const out) {
+    RefFrame *const r = h;
+    const Dav1dFrameContext *const f = &r->f;
+    out[0] = f->b4_stride; out[1] = f->bw; out[2] = f->bh; out[3] = f->sb128w; out[4] = f->sbh;
+    out[5] = f->cur.stride[0]; out[6] = f->cur.stride[1];
+    for (int i = 0; i < 7; i++) { out[7 + 2 * i] = f->refp[i].p.stride[0]; out[8 + 2 * i] = f->refp[i].p.stride[1]; }
+}
+
+/* sizeof / offsetof of the reference's hand-off structs, for pinning the product's mirrors */
+void dav1d_ref_layouts(int *const out) {
+    int n = 0;
+    out[n++] = (int) sizeof(Av1Block);
+    out[n++] = (int) offsetof(Av1Block, bl); out[n++] = (int) offsetof(Av1Block, bs); out[n++] = (int) offsetof(Av1Block, bp);
+    out[n++] = (int) offsetof(Av1Block, intra); out[n++] = (int) offsetof(Av1Block, seg_id); out[n++] = (int) offsetof(Av1Block, skip_mode);
+    out[n++] = (int) offsetof(Av1Block, skip); out[n++] = (int) offsetof(Av1Block, uvtx);
+    out[n++] = (int) offsetof(Av1Block, y_mode); out[n++] = (int) offsetof(Av1Block, uv_mode); out[n++] = (int) offsetof(Av1Block, tx);
+    out[n++] = (int) offsetof(Av1Block, pal_sz); out[n++] = (int) offsetof(Av1Block, y_angle); out[n++] = (int) offsetof(Av1Block, uv_angle);
+    out[n++] = (int) offsetof(Av1Block, cfl_alpha);
+    out[n++] = (int) offsetof(Av1Block, mv); out[n++] = (int) offsetof(Av1Block, wedge_idx); out[n++] = (int) offsetof(Av1Block, mask_sign);
+    out[n++] = (int) offsetof(Av1Block, interintra_mode); out[n++] = (int) offsetof(Av1Block, mv2d); out[n++] = (int) offsetof(Av1Block, matrix);
+    out[n++] = (int) offsetof(Av1Block, comp_type); out[n++] = (int) offsetof(Av1Block, inter_mode); out[n++] = (int) offsetof(Av1Block, motion_mode);
+    out[n++] = (int) offsetof(Av1Block, drl_idx); out[n++] = (int) offsetof(Av1Block, ref); out[n++] = (int) offsetof(Av1Block, max_ytx);
+    out[n++] = (int) offsetof(Av1Block, filter2d); out[n++] = (int) offsetof(Av1Block, interintra_type); out[n++] = (int) offsetof(Av1Block, tx_split0);
+    out[n++] = (int) offsetof(Av1Block, tx_split1);
+    out[n++] = (int) sizeof(Dav1dWarpedMotionParams);
+    out[n++] = (int) offsetof(Dav1dWarpedMotionParams, type); out[n++] = (int) offsetof(Dav1dWarpedMotionParams, matrix);
+    out[n++] = (int) offsetof(Dav1dWarpedMotionParams, u);
+    out[n++] = (int) sizeof(Av1Filter); out[n++] = (int) sizeof(Av1Restoration); out[n++] = (int) sizeof(Av1RestorationUnit);
+    out[n++] = -1;
+}
+
+/* pass 2 of the whole frame: every tile-sbrow in the order a single worker would take them
+ * (dav1d_decode_frame_main, src/decode.c:3196-3240) */
+int dav1d_ref_frame_recon(void *const h) {
+    RefFrame *const r = h;
+    Dav1dFrameContext *const f = &r->f;
+    Dav1dTaskContext *const t = r->tc;
+    const Dav1dFrameHeader *const fh = &r->fh;
+    const int keyframe = !r->p.is_inter;
+    t->c = &r->c; t->f = f;
+    t->frame_thread.pass = 2;
+    /* reset_context(), src/decode.c:2385-2413, of the pass-2 half of f->a (dav1d_decode_frame_init_cdf, :3182-3188) */
+    for (int n = 0; n < f->a_sz; n++) {
+        memset(&f->a[n], 0, sizeof(f->a[n]));
+        memset(f->a[n].intra, keyframe, sizeof(f->a[n].intra));
+        memset(f->a[n].uvmode, DC_PRED, sizeof(f->a[n].uvmode));
+        if (keyframe) memset(f->a[n].mode, DC_PRED, sizeof(f->a[n].mode));
+    }
+    /* the tile cursors start over (a second run after the arrays changed) */
+    {
+        static const uint8_t ss_size_mul[4][2] = { { 4, 4 }, { 6, 5 }, { 8, 6 }, { 12, 8 } };
+        const uint8_t *const size_mul = ss_size_mul[r->p.layout];
+        for (int j = 0; j < f->n_ts; j++) {
+            const unsigned off = f->frame_thread.tile_start_off[j];
+            Dav1dTileState *const ts = &f->ts[j];
+            ts->frame_thread[0].pal_idx = f->frame_thread.pal_idx ? &f->frame_thread.pal_idx[(size_t) off * size_mul[1] / 8] : NULL;
+            ts->frame_thread[0].cbi = &f->frame_thread.cbi[(size_t) off * size_mul[0] / 64];
+            ts->frame_thread[0].cf = (uint8_t *) f->frame_thread.cf + (((size_t) off * size_mul[0]) >> !r->seq.hbd);
+        }
+    }
+    for (int tile_row = 0; tile_row < fh->tiling.rows; tile_row++)
+        for (int sby = fh->tiling.row_start_sb[tile_row]; sby < fh->tiling.row_start_sb[tile_row + 1]; sby++) {
+            t->by = sby << f->sb_shift;
+            for (int tile_col = 0; tile_col < fh->tiling.cols; tile_col++) {
+                t->ts = &f->ts[tile_row * fh->tiling.cols + tile_col];
+                if (dav1d_decode_tile_sbrow(t)) return -1;
+            }
+        }
+    return 0;
+}

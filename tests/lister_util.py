@@ -1,0 +1,275 @@
+"""Frame-level parity plumbing: the reference's own pass 2 (oracle/ref_frame.c inside oracle/_ref) against
+synthetic pass-1 output -> dav1d_hip_lister_* -> dav1d_hip_frame_* on the device (or the SIMT-emulated build).
+
+The reference side is TEST INFRASTRUCTURE: it owns the hand-off arrays (allocated by the reference's
+dav1d_decode_frame_init), the product's generator (dav1d_hip_synth_frame) fills them, the reference reconstructs
+from them on the CPU and the lister + kernels reconstruct from the very same arrays on the GPU."""
+import ctypes as C
+
+import numpy as np
+
+import util
+from dav1d_amd import _lib, api
+
+
+class RefFrameParams(C.Structure):
+    _fields_ = [("w", C.c_int), ("h", C.c_int), ("layout", C.c_int), ("bpc", C.c_int), ("sb128", C.c_int), ("is_inter", C.c_int),
+                ("n_tile_cols", C.c_int), ("n_tile_rows", C.c_int), ("col_start_sb", C.c_uint16 * 65), ("row_start_sb", C.c_uint16 * 65),
+                ("intra_edge_filter", C.c_int), ("allow_screen_content_tools", C.c_int), ("switchable_comp_refs", C.c_int),
+                ("ref_w", C.c_int * 7), ("ref_h", C.c_int * 7), ("ref_poc", C.c_int * 7), ("cur_poc", C.c_int),
+                ("order_hint_n_bits", C.c_int), ("gmv_type", C.c_int * 7), ("gmv_matrix", (C.c_int32 * 6) * 7),
+                ("lf_level_y", C.c_int * 2), ("lf_level_u", C.c_int), ("lf_level_v", C.c_int), ("lf_sharpness", C.c_int),
+                ("cdef_enabled", C.c_int), ("cdef_damping", C.c_int), ("cdef_n_bits", C.c_int), ("cdef_y_strength", C.c_int * 8),
+                ("cdef_uv_strength", C.c_int * 8), ("lr_type", C.c_int * 3), ("lr_unit_size", C.c_int * 2)]
+
+
+def ref_lib():
+    lib = util.ref_lib()
+    if lib is None:
+        return None
+    lib.dav1d_ref_frame_create.restype = C.c_void_p
+    lib.dav1d_ref_frame_create.argtypes = [C.POINTER(RefFrameParams)]
+    lib.dav1d_ref_frame_ptr.restype = C.c_void_p
+    lib.dav1d_ref_frame_ptr.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t)]
+    lib.dav1d_ref_frame_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    lib.dav1d_ref_frame_recon.argtypes = [C.c_void_p]
+    lib.dav1d_ref_frame_destroy.argtypes = [C.c_void_p]
+    lib.dav1d_ref_layouts.argtypes = [C.POINTER(C.c_int)]
+    return lib
+
+
+def uniform_tiles(n_sb, n_tiles):
+    """start of every tile in superblocks, uniform spacing (reference src/obu.c:637-644)"""
+    n_tiles = max(1, min(n_tiles, n_sb))
+    size = (n_sb + n_tiles - 1) // n_tiles
+    starts = list(range(0, n_sb, size))
+    return starts + [n_sb]
+
+
+class RefFrame:
+    """One synthetic frame inside a real Dav1dFrameContext of the reference build."""
+
+    def __init__(self, w, h, layout, bpc, is_inter=True, sb128=True, tile_cols=1, tile_rows=1, ref_sizes=None, gmv=None,
+                 intra_edge_filter=1, screen_content=0, order_hint_bits=5):
+        self.lib = ref_lib()
+        assert self.lib is not None, "the reference build oracle/_ref is required"
+        p = RefFrameParams()
+        p.w, p.h, p.layout, p.bpc, p.sb128, p.is_inter = w, h, layout, bpc, int(sb128), int(is_inter)
+        sb = 128 if sb128 else 64
+        cs = uniform_tiles((w + sb - 1) // sb, tile_cols)
+        rs = uniform_tiles((h + sb - 1) // sb, tile_rows)
+        p.n_tile_cols, p.n_tile_rows = len(cs) - 1, len(rs) - 1
+        for i, v in enumerate(cs):
+            p.col_start_sb[i] = v
+        for i, v in enumerate(rs):
+            p.row_start_sb[i] = v
+        p.intra_edge_filter = intra_edge_filter
+        p.allow_screen_content_tools = screen_content
+        p.switchable_comp_refs = int(is_inter)
+        p.order_hint_n_bits = order_hint_bits
+        p.cur_poc = 8
+        for i in range(7):
+            rw, rh = (ref_sizes[i] if ref_sizes else (w, h))
+            p.ref_w[i], p.ref_h[i] = rw, rh
+            p.ref_poc[i] = [7, 6, 4, 2, 9, 10, 12][i]
+            if gmv and gmv[i] is not None:
+                p.gmv_type[i] = gmv[i][0]
+                for k in range(6):
+                    p.gmv_matrix[i][k] = gmv[i][1][k]
+        self.p = p
+        self.h = self.lib.dav1d_ref_frame_create(C.byref(p))
+        assert self.h, "dav1d_ref_frame_create failed"
+        geo = (C.c_int64 * 21)()
+        self.lib.dav1d_ref_frame_geometry(self.h, geo)
+        self.b4_stride, self.bw, self.bh, self.sb128w, self.sbh = [int(geo[i]) for i in range(5)]
+        self.cur_stride = (int(geo[5]), int(geo[6]))
+        self.ref_stride = [(int(geo[7 + 2 * i]), int(geo[8 + 2 * i])) for i in range(7)]
+        self.w, self.ht, self.layout, self.bpc, self.is_inter = w, h, layout, bpc, is_inter
+        self.cols, self.rows = cs, rs
+
+    def ptr(self, name):
+        n = C.c_size_t()
+        p = self.lib.dav1d_ref_frame_ptr(self.h, name.encode(), C.byref(n))
+        return p, n.value
+
+    def array(self, name, dtype):
+        p, n = self.ptr(name)
+        if not p:
+            return None
+        dt = np.dtype(dtype)
+        return np.ctypeslib.as_array((C.c_uint8 * n).from_address(p)).view(dt)
+
+    def plane(self, slot, pl):
+        """(rows x stride) view of a plane of picture slot 0 (current) or 1 + i (reference i), in pixels"""
+        a = self.array("pic%d_%d" % (slot, pl), np.uint8 if self.bpc == 8 else np.uint16)
+        stride = (self.cur_stride if slot == 0 else self.ref_stride[slot - 1])[1 if pl else 0]
+        spx = stride // a.itemsize
+        return a[:(len(a) // spx) * spx].reshape(-1, spx)
+
+    def desc(self):
+        d = _lib.FrameDesc()
+        p = self.p
+        d.w, d.h, d.layout, d.bpc, d.sb128 = p.w, p.h, p.layout, p.bpc, p.sb128
+        d.intra_edge_filter, d.is_inter = p.intra_edge_filter, p.is_inter
+        d.n_tile_cols, d.n_tile_rows = p.n_tile_cols, p.n_tile_rows
+        for i in range(65):
+            d.col_start_sb[i] = p.col_start_sb[i]
+            d.row_start_sb[i] = p.row_start_sb[i]
+        d.b4_stride = self.b4_stride
+        d.b = self.ptr("b")[0]
+        d.cbi = self.ptr("cbi")[0]
+        d.tile_start_off = self.ptr("tile_start_off")[0]
+        d.pal = self.ptr("pal")[0]
+        svc = self.array("svc", np.int32).reshape(7, 2, 2)
+        gwa = self.array("gmv_warp_allowed", np.uint8)
+        jw = self.array("jnt_weights", np.uint8).reshape(7, 7)
+        gmv = self.array("gmv", np.uint8).reshape(7, -1)
+        for i in range(7):
+            for k in range(2):
+                d.svc[i][k][0], d.svc[i][k][1] = int(svc[i, k, 0]), int(svc[i, k, 1])
+            d.ref_w[i], d.ref_h[i] = p.ref_w[i], p.ref_h[i]
+            d.gmv_warp_allowed[i] = int(gwa[i])
+            for j in range(7):
+                d.jnt_weights[i][j] = int(jw[i, j])
+            C.memmove(C.addressof(d.gmv[i]), gmv[i].ctypes.data, C.sizeof(_lib.WarpParams))
+        d.cf_align64 = 1                     # the oracle build is an x86-64 build (oracle/ref_config.h)
+        return d
+
+    def recon(self):
+        rc = self.lib.dav1d_ref_frame_recon(self.h)
+        assert rc == 0, "reference pass 2 failed"
+
+    def destroy(self):
+        if self.h:
+            self.lib.dav1d_ref_frame_destroy(self.h)
+            self.h = None
+
+
+def default_synth(seed, **kw):
+    sp = _lib.SynthParams()
+    sp.seed = seed
+    sp.intra_pct, sp.skip_pct = 15, 20
+    sp.compound_pct, sp.masked_compound = 30, 1
+    sp.global_pct = 5
+    sp.interintra_pct, sp.obmc_pct, sp.warp_pct = 15, 20, 10
+    sp.cfl_pct, sp.palette, sp.filter_intra_pct = 30, 0, 25
+    sp.tx_split_pct, sp.alt_txtp_pct, sp.eob_none_pct = 30, 40, 10
+    sp.mv_range, sp.far_mv_pct, sp.n_refs = 256, 4, 7
+    for i, v in enumerate((95, 80, 60, 45, 30)):
+        sp.split_pct[i] = v
+    sp.rect_pct = 50
+    sp.fixed_bl = -1
+    sp.cf_align64 = 1
+    for k, v in kw.items():
+        if k == "split_pct":
+            for i, x in enumerate(v):
+                sp.split_pct[i] = x
+        else:
+            setattr(sp, k, v)
+    return sp
+
+
+def synth(ctx, rf, sp):
+    """run the product's generator on the reference-owned arrays"""
+    d = rf.desc()
+    cf, cf_bytes = rf.ptr("cf")
+    _, cbi_bytes = rf.ptr("cbi")
+    pal_idx, pal_idx_bytes = rf.ptr("pal_idx")
+    C.memset(cf, 0, cf_bytes)
+    rc = ctx.lib.dav1d_hip_synth_frame(C.byref(d), C.byref(sp), cf, cf_bytes, cbi_bytes // 2, pal_idx, pal_idx_bytes)
+    assert rc == 0, "dav1d_hip_synth_frame: %d" % rc
+    # the reference's itxfm_add consumes (zeroes) the coefficients: keep what pass 1 "produced" for the device side
+    rf.cf_copy = rf.array("cf", np.uint8).copy()
+    return d
+
+
+def fill_pictures(rf, seed):
+    """random (smoothed) reference pictures, random noise in the current picture's visible area is NOT needed: every
+    pixel of it is written by the reconstruction; padding starts as zero on both sides"""
+    rng = np.random.default_rng(seed)
+    n_pl = 1 if rf.layout == 0 else 3
+    if rf.is_inter:
+        for i in range(7):
+            for pl in range(n_pl):
+                a = rf.plane(1 + i, pl)
+                v = rng.integers(0, 1 << rf.bpc, size=a.shape, dtype=np.int32)
+                p = np.pad(v, 1, mode="edge")
+                v = (p[:-2, 1:-1] + p[2:, 1:-1] + p[1:-1, :-2] + p[1:-1, 2:] + 4 * p[1:-1, 1:-1] + 4) // 8
+                a[...] = v.astype(a.dtype)
+
+
+def run_hip(ctx, rf, d, threads=1):
+    """lister -> frame API -> kernels; returns the reconstructed planes (visible area) and the lister handle stats"""
+    n_pl = 1 if rf.layout == 0 else 3
+    cur = ctx.picture(rf.w, rf.ht, rf.layout, rf.bpc)
+    refs = []
+    if rf.is_inter:
+        for i in range(7):
+            r = ctx.picture(rf.p.ref_w[i], rf.p.ref_h[i], rf.layout, rf.bpc)
+            for pl in range(n_pl):
+                src = rf.plane(1 + i, pl)
+                rows, cols = r.padded_shape(pl)
+                r.upload(pl, np.ascontiguousarray(src[:rows, :cols]))
+            refs.append(r)
+    frame = ctx.frame(cur, refs)
+    lh = C.c_void_p()
+    rc = ctx.lib.dav1d_hip_lister_create(C.byref(lh), C.byref(d), frame.h)
+    assert rc == 0, "lister_create: %d" % rc
+    jobs = [(tr, tc) for tr in range(d.n_tile_rows) for tc in range(d.n_tile_cols)]
+
+    def one_tile(job):
+        tr, tc = job
+        for sby in range(d.row_start_sb[tr], d.row_start_sb[tr + 1]):
+            rc2 = ctx.lib.dav1d_hip_lister_tile_sbrow(lh, tr, tc, sby)
+            assert rc2 == 0, "lister_tile_sbrow(%d, %d, %d): %d" % (tr, tc, sby, rc2)
+    if threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(one_tile, jobs))
+    else:
+        for j in jobs:
+            one_tile(j)
+    prep_elems = ctx.lib.dav1d_hip_lister_prep_elems(lh)
+    mask_bytes = ctx.lib.dav1d_hip_lister_mask_bytes(lh)
+    steps = ctx.lib.dav1d_hip_lister_steps(lh)
+    # arenas: coefficients = the reference's cf array verbatim; aux = its packed palette indices
+    coef = ctx.buffer_from(rf.cf_copy)
+    prep = ctx.buffer(prep_elems * 2 + 64)
+    mask = ctx.buffer(mask_bytes + 64)
+    nb = C.c_size_t()
+    blob = ctx.lib.dav1d_hip_lister_const_masks(C.byref(nb))
+    mask.upload(np.ctypeslib.as_array((C.c_uint8 * nb.value).from_address(blob)))
+    aux = None
+    pi = rf.array("pal_idx", np.uint8)
+    if pi is not None and len(pi):
+        aux = ctx.buffer_from(pi)
+        frame.submit_intra_step(0, np.zeros(0, api.IPRED_TASK), np.zeros(0, api.ITX_TASK), aux)
+    frame.end(coef, prep, mask)
+    out = [cur.download(pl) for pl in range(n_pl)]
+    coef_after = coef.download(np.uint8)
+    ctx.lib.dav1d_hip_lister_destroy(lh)
+    frame.destroy()
+    for b in (coef, prep, mask, aux):
+        if b is not None:
+            b.free()
+    cur.free()
+    for r in refs:
+        r.free()
+    return out, dict(prep_elems=prep_elems, mask_bytes=mask_bytes, steps=steps, coef_after=coef_after)
+
+
+def compare(rf, got):
+    """visible area of every plane against the reference's reconstruction"""
+    n_pl = 1 if rf.layout == 0 else 3
+    ss_hor = 1 if rf.layout in (1, 2) else 0
+    ss_ver = 1 if rf.layout == 1 else 0
+    bad = []
+    for pl in range(n_pl):
+        w = rf.w if not pl else (rf.w + ss_hor) >> ss_hor
+        h = rf.ht if not pl else (rf.ht + ss_ver) >> ss_ver
+        want = rf.plane(0, pl)[:h, :w]
+        have = got[pl][:h, :w]
+        if not np.array_equal(want, have):
+            yy, xx = np.nonzero(want != have)
+            bad.append((pl, len(yy), int(yy[0]), int(xx[0]), int(want[yy[0], xx[0]]), int(have[yy[0], xx[0]])))
+    return bad
