@@ -74,6 +74,7 @@ SYMBOLS = [
     "dav1d_hip_frame_submit_step_blend", "dav1d_hip_frame_submit_warp", "dav1d_hip_frame_submit_scaled",
     "dav1d_hip_lister_create", "dav1d_hip_lister_tile_sbrow", "dav1d_hip_lister_prep_elems", "dav1d_hip_lister_mask_bytes",
     "dav1d_hip_lister_steps", "dav1d_hip_lister_const_masks", "dav1d_hip_lister_destroy", "dav1d_hip_synth_frame",
+    "dav1d_hip_lister_mask_offset", "dav1d_hip_lister_tables", "dav1d_hip_lister_block_warp",
 ]
 
 
@@ -204,6 +205,9 @@ def load(path=None):
         "dav1d_hip_lister_const_masks": (vp, [P(sz)]),
         "dav1d_hip_lister_destroy": (None, [vp]),
         "dav1d_hip_synth_frame": (i, [P(FrameDesc), P(SynthParams), vp, sz, sz, vp, sz]),
+        "dav1d_hip_lister_mask_offset": (C.c_long, [i, i, i, i, i]),
+        "dav1d_hip_lister_tables": (None, [vp]),
+        "dav1d_hip_lister_block_warp": (i, [P(WarpParams), vp, vp, i, i, i, i]),
         "dav1d_hip_dsp_init_8bpc": (i, [vp]),
         "dav1d_hip_dsp_init_16bpc": (i, [vp, i]),
     }

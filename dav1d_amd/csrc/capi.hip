@@ -1163,10 +1163,10 @@ extern "C" int dav1d_hip_mc_scaled_batch(Dav1dHipContext *c, const Dav1dHipPictu
     if (!n) return 0;
     for (size_t i = 0; i < n; i++) {
         const Dav1dHipMcScaledTask &t = tasks[i];
-        if (t.kind > DAV1D_HIP_MC_PREP || t.plane > 2 || t.ref >= n_refs || t.filter_2d > 9) return -EINVAL;
+        if (t.kind > DAV1D_HIP_MC_PUT_TMP || t.plane > 2 || t.ref >= n_refs || t.filter_2d > 9) return -EINVAL;
         if (t.w < 2 || t.w > 128 || t.h < 2 || t.h > 128 || t.mx < 0 || t.mx > 1023 || t.my < 0 || t.my > 1023 || t.dx < 0 || t.dy < 0)
             return -EINVAL;
-        if (t.kind == DAV1D_HIP_MC_PREP && !prep) return -EINVAL;
+        if (t.kind != DAV1D_HIP_MC_PUT && !prep) return -EINVAL;
     }
     DevPlanes rp[8];
     for (int i = 0; i < n_refs; i++) { if (refs[i].bpc != dst->bpc) return -EINVAL; rp[i] = dev_planes(&refs[i]); }

@@ -77,6 +77,7 @@ __global__ __launch_bounds__(64) void mc_scaled_kernel(const DevPlanes dst, cons
     const pixel *src = reinterpret_cast<const pixel *>(rp.data[t.plane]);
     const int rs = rp.stride[t.plane], rw = rp.w[t.plane], rh = rp.h[t.plane];
     const bool bilin = t.filter_2d == 9;
+    const bool as_put = t.kind != DAV1D_HIP_MC_PREP;
     // enum Filter2d -> (h, v) 8-tap families, 4-tap rows for w <= 4 / h <= 4 (src/mc_tmpl.c:115-123)
     const unsigned long long ht = 0x111222000ull, vt = 0x210210210ull;      // nibble f of each = type of Filter2d f
     const int h_type = (int) (ht >> (4 * t.filter_2d)) & 15, v_type = (int) (vt >> (4 * t.filter_2d)) & 15;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(64) void mc_scaled_kernel(const DevPlanes dst, cons
                 m[r] = (int16_t) ((16 * a + fxi * (b - a) + ((1 << (4 - ib)) >> 1)) >> (4 - ib));
             }
             const int s = 16 * m[0] + fyi * (m[1] - m[0]);
-            v = t.kind == DAV1D_HIP_MC_PUT ? (s + ((1 << (4 + ib)) >> 1)) >> (4 + ib) : ((s + 8) >> 4) - bias;
+            v = as_put ? (s + ((1 << (4 + ib)) >> 1)) >> (4 + ib) : ((s + 8) >> 4) - bias;
         } else {
             const int8_t *fh = fxi ? &av1_mc_subpel_filters[(hset * 15 + fxi - 1) * 8] : nullptr;
             const int8_t *fv = fyi ? &av1_mc_subpel_filters[(vset * 15 + fyi - 1) * 8] : nullptr;
@@ -121,13 +122,15 @@ __global__ __launch_bounds__(64) void mc_scaled_kernel(const DevPlanes dst, cons
                 int s = 0;
 #pragma unroll
                 for (int k = 0; k < 8; k++) s += fv[k] * mid[k];
-                v = t.kind == DAV1D_HIP_MC_PUT ? (s + ((1 << (6 + ib)) >> 1)) >> (6 + ib) : ((s + 32) >> 6) - bias;
+                v = as_put ? (s + ((1 << (6 + ib)) >> 1)) >> (6 + ib) : ((s + 32) >> 6) - bias;
             } else {
-                v = t.kind == DAV1D_HIP_MC_PUT ? (mid[3] + ((1 << ib) >> 1)) >> ib : mid[3] - bias;
+                v = as_put ? (mid[3] + ((1 << ib) >> 1)) >> ib : mid[3] - bias;
             }
         }
         if (t.kind == DAV1D_HIP_MC_PUT)
             reinterpret_cast<pixel *>(dst.data[t.plane])[t.dst_off + y * dst.stride[t.plane] + x] = (pixel) dv::iclip(v, 0, bitdepth_max);
+        else if (t.kind == DAV1D_HIP_MC_PUT_TMP)      // the `lap` prediction of obmc() from a scaled reference: pixels into the scratch arena
+            reinterpret_cast<pixel *>(prep)[t.dst_off + y * t.w + x] = (pixel) dv::iclip(v, 0, bitdepth_max);
         else
             prep[t.dst_off + y * t.w + x] = (int16_t) v;
     }

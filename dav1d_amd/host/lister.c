@@ -377,7 +377,6 @@ static void emit_mc(Walk *w, const int kind, const uint32_t off, const int bw4, 
         k->ref = (uint8_t) ref;
     } else {
         /* scaled reference, :990-1047 */
-        if (kind == DAV1D_HIP_MC_PUT_TMP) { w->err = -ENOTSUP; return; }     /* OBMC from a scaled reference */
         const int orig_pos_y = (by * v_mul << 4) + mv.y * (1 << !ss_ver);
         const int orig_pos_x = (bx * h_mul << 4) + mv.x * (1 << !ss_hor);
         int pos[2];

@@ -264,7 +264,7 @@ static void gen_block(Gen *g, const int bl, const int bs, const int bp, const in
                 const int k = rnd_n(&g->rng, 100);
                 /* warped motion needs a reference of the frame's own size (src/decode.c:1783-1785) */
                 const int ref_same = !g->d->svc[b->u.p.ref[0]][0][0] && !g->d->svc[b->u.p.ref[0]][1][0];
-                if (k < sp->obmc_pct && ref_same) {
+                if (k < sp->obmc_pct) {
                     b->u.p.motion_mode = H_MM_OBMC;
                 } else if (k < sp->obmc_pct + sp->warp_pct && ref_same) {
                     /* a local warp model: near-identity matrix with a valid shear, or "no valid model found" */

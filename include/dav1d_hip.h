@@ -388,7 +388,7 @@ typedef struct Dav1dHipMcScaledTask {
     int16_t  dx, dy;      /* step in 1/1024 pel: 512..2048 in valid AV1 */
     uint8_t  w, h;        /* 2..128 */
     uint8_t  filter_2d;   /* enum Filter2d (9 = bilinear) */
-    uint8_t  kind;        /* DAV1D_HIP_MC_PUT or DAV1D_HIP_MC_PREP */
+    uint8_t  kind;        /* DAV1D_HIP_MC_PUT, DAV1D_HIP_MC_PREP or DAV1D_HIP_MC_PUT_TMP */
     uint8_t  plane;
     uint8_t  ref;
     uint8_t  pad[2];

@@ -367,3 +367,23 @@ int dav1d_ref_frame_recon(void *const h) {
         }
     return 0;
 }
+
+/* t->warpmv of a MM_WARP block exactly as decode_b() rebuilds it in pass 2 (src/decode.c:743-757); returns what
+ * dav1d_get_shear_params() returned.  out = { matrix[6], alpha, beta, gamma, delta } */
+int dav1d_ref_block_warp(const int16_t *const matrix, const int16_t *const mv2d, const int bw4, const int bh4, const int bx, const int by,
+                         int32_t *const out)
+{
+    Dav1dWarpedMotionParams wm;
+    memset(&wm, 0, sizeof(wm));
+    wm.type = DAV1D_WM_TYPE_AFFINE;
+    wm.matrix[2] = matrix[0] + 0x10000;
+    wm.matrix[3] = matrix[1];
+    wm.matrix[4] = matrix[2];
+    wm.matrix[5] = matrix[3] + 0x10000;
+    const mv m = { .y = mv2d[0], .x = mv2d[1] };
+    dav1d_set_affine_mv2d(bw4, bh4, m, &wm, bx, by);
+    const int rc = dav1d_get_shear_params(&wm);
+    for (int i = 0; i < 6; i++) out[i] = wm.matrix[i];
+    out[6] = wm.u.p.alpha; out[7] = wm.u.p.beta; out[8] = wm.u.p.gamma; out[9] = wm.u.p.delta;
+    return rc;
+}

@@ -93,6 +93,8 @@ const void *dav1d_ref_table(const char *const name, size_t *const sz) {
     T("sgr_x_by_x", dav1d_sgr_x_by_x)
     T("txfm_dimensions", dav1d_txfm_dimensions)
     T("block_dimensions", dav1d_block_dimensions)
+    T("max_txfm_size_for_bs", dav1d_max_txfm_size_for_bs)
+    T("block_sizes", dav1d_block_sizes)
 #undef T
     return NULL;
 }

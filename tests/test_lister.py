@@ -1,0 +1,179 @@
+"""The pass-2 lister against the reference's OWN pass 2.
+
+One synthetic pass-1 output (Av1Block / cbi / cf / palettes, dav1d_hip_synth_frame) sits in the per-frame arrays of a real
+Dav1dFrameContext of the reference build (oracle/ref_frame.c).  The reference reconstructs from it on the CPU with
+dav1d_decode_tile_sbrow(pass 2) -> decode_sb -> decode_b -> dav1d_recon_b_intra / dav1d_recon_b_inter; the product lists
+the same arrays (dav1d_hip_lister_*), submits the tasks to a frame (dav1d_hip_frame_*) and runs the kernels.  Planes must be
+byte-identical.  Covers 8 / 10 / 12 bpc, 4:0:0 / 4:2:0 / 4:2:2 / 4:4:4, 64- and 128-pixel superblocks, tiles (listed from
+several threads), key frames, and every prediction tool: OBMC, compound avg / weighted / wedge / segment, local and global
+warps, inter-intra, scaled references, sub8x8 chroma, palette, CfL, filter-intra, transform splitting, all transform types."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import util
+import lister_util as lu
+from dav1d_amd import _lib
+
+pytestmark = pytest.mark.skipif(util.ref_lib() is None, reason="needs the reference build oracle/_ref")
+
+GMV = [None] * 7
+GMV[0] = (3, [12345, -23456, 65536 + 800, 300, -250, 65536 - 600])
+GMV[2] = (2, [-8000, 4000, 65536 + 500, 400, -400, 65536 + 500])
+GMV[4] = (1, [16000, -8000, 65536, 0, 0, 65536])
+
+
+def scaled_refs(w, h):
+    rs = [(w, h)] * 7
+    rs[1] = (2 * w, 2 * h)
+    rs[3] = (w * 3 // 4 & ~7, h * 3 // 4 & ~7)
+    rs[5] = (w * 3 // 2 & ~7, h + 8)
+    return rs
+
+
+def run_case(ctx, w, h, layout, bpc, seed, is_inter=True, tiles=(1, 1), threads=1, sb128=True, ref_sizes=None, gmv=None, **kw):
+    rf = lu.RefFrame(w, h, layout, bpc, is_inter=is_inter, tile_cols=tiles[0], tile_rows=tiles[1], sb128=sb128,
+                     screen_content=1 if kw.get("palette") else 0, ref_sizes=ref_sizes, gmv=gmv)
+    try:
+        sp = lu.default_synth(seed, **kw)
+        d = lu.synth(ctx, rf, sp)
+        lu.fill_pictures(rf, seed + 1)
+        rf.recon()
+        got, st = lu.run_hip(ctx, rf, d, threads)
+        bad = lu.compare(rf, got)
+        assert not bad, "planes differ from the reference's pass 2: (plane, pixels, first y, x, want, got) %s" % bad
+        # the coefficient arena is consumed exactly as the reference consumes it (itx zeroes what it read)
+        after_ref = rf.array("cf", np.uint8)
+        assert np.array_equal(st["coef_after"][:len(after_ref)], after_ref), "coefficient arena differs after the frame"
+        return st
+    finally:
+        rf.destroy()
+
+
+def test_hand_off_struct_layouts_match_the_reference():
+    lib = lu.ref_lib()
+    out = (C.c_int * 64)()
+    lib.dav1d_ref_layouts(out)
+    v = list(out)
+    v = v[:v.index(-1)]
+    B = _lib_av1block()
+    want = [C.sizeof(B)]
+    for path in ("bl", "bs", "bp", "intra", "seg_id", "skip_mode", "skip", "uvtx", "y_mode", "uv_mode", "tx", "pal_sz", "y_angle",
+                 "uv_angle", "cfl_alpha", "mv", "wedge_idx", "mask_sign", "interintra_mode", "mv2d", "matrix", "comp_type", "inter_mode",
+                 "motion_mode", "drl_idx", "ref", "max_ytx", "filter2d", "interintra_type", "tx_split0", "tx_split1"):
+        want.append(_offset(B, path))
+    want += [C.sizeof(_lib.WarpParams), _lib.WarpParams.type.offset, _lib.WarpParams.matrix.offset, _lib.WarpParams.abcd.offset]
+    assert v[:len(want)] == want
+
+
+class _Intra(C.Structure):
+    _fields_ = [("y_mode", C.c_uint8), ("uv_mode", C.c_uint8), ("tx", C.c_uint8), ("pal_sz", C.c_uint8 * 2), ("y_angle", C.c_int8),
+                ("uv_angle", C.c_int8), ("cfl_alpha", C.c_int8 * 2)]
+
+
+class _M(C.Structure):
+    _fields_ = [("mv", (C.c_int16 * 2) * 2), ("wedge_idx", C.c_uint8), ("mask_sign", C.c_uint8), ("interintra_mode", C.c_uint8)]
+
+
+class _W(C.Structure):
+    _fields_ = [("mv2d", C.c_int16 * 2), ("matrix", C.c_int16 * 4)]
+
+
+class _MU(C.Union):
+    _fields_ = [("m", _M), ("w", _W)]
+
+
+class _Inter(C.Structure):
+    _fields_ = [("u", _MU), ("comp_type", C.c_uint8), ("inter_mode", C.c_uint8), ("motion_mode", C.c_uint8), ("drl_idx", C.c_uint8),
+                ("ref", C.c_int8 * 2), ("max_ytx", C.c_uint8), ("filter2d", C.c_uint8), ("interintra_type", C.c_uint8),
+                ("tx_split0", C.c_uint8), ("tx_split1", C.c_uint16)]
+
+
+class _BU(C.Union):
+    _fields_ = [("i", _Intra), ("p", _Inter)]
+
+
+def _lib_av1block():
+    class B(C.Structure):          # mirrors Dav1dHipAv1Block of include/dav1d_hip.h member by member
+        _fields_ = [("bl", C.c_uint8), ("bs", C.c_uint8), ("bp", C.c_uint8), ("intra", C.c_uint8), ("seg_id", C.c_uint8),
+                    ("skip_mode", C.c_uint8), ("skip", C.c_uint8), ("uvtx", C.c_uint8), ("u", _BU)]
+    return B
+
+
+def _offset(B, name):
+    if hasattr(B, name):
+        return getattr(B, name).offset
+    base = B.u.offset
+    if hasattr(_Intra, name):
+        return base + getattr(_Intra, name).offset
+    if hasattr(_Inter, name):
+        return base + getattr(_Inter, name).offset
+    if hasattr(_M, name):
+        return base + getattr(_M, name).offset
+    return base + getattr(_W, name).offset
+
+
+PLAIN = dict(intra_pct=0, compound_pct=0, global_pct=0, interintra_pct=0, obmc_pct=0, warp_pct=0, tx_split_pct=0, alt_txtp_pct=0, rect_pct=0)
+
+# (name, w, h, layout, bpc, keyword arguments)
+TOOLS = [
+    ("plain", 256, 192, 1, 8, dict(PLAIN)),
+    ("partitions", 256, 192, 1, 8, dict(PLAIN, rect_pct=70)),
+    ("vartx_txtp", 256, 192, 1, 8, dict(PLAIN, tx_split_pct=40, alt_txtp_pct=60)),
+    ("compound", 256, 192, 1, 10, dict(PLAIN, compound_pct=70, masked_compound=1)),
+    ("obmc", 256, 192, 1, 8, dict(PLAIN, obmc_pct=70, rect_pct=40)),
+    ("local_warp", 256, 192, 1, 10, dict(PLAIN, warp_pct=70)),
+    ("interintra", 256, 192, 1, 8, dict(PLAIN, interintra_pct=80, intra_pct=10)),
+    ("intra_tools", 256, 192, 1, 10, dict(PLAIN, intra_pct=50, cfl_pct=50, filter_intra_pct=40, rect_pct=40)),
+]
+
+
+@pytest.mark.parametrize("name,w,h,layout,bpc,kw", TOOLS, ids=[t[0] for t in TOOLS])
+def test_tools_one_by_one(ctx, name, w, h, layout, bpc, kw):
+    run_case(ctx, w, h, layout, bpc, 3 + len(name), **kw)
+
+
+MIX = [
+    ("420_8", 256, 192, 1, 8, {}),
+    ("420_10", 256, 192, 1, 10, {}),
+    ("420_12_cut", 200, 136, 1, 12, {}),
+    ("444_8", 256, 192, 3, 8, {}),
+    ("444_10", 192, 192, 3, 10, {}),
+    ("422_10", 256, 192, 2, 10, {}),
+    ("400_8", 256, 192, 0, 8, {}),
+    ("tiles_2x2", 320, 200, 1, 8, dict(tiles=(2, 2))),
+    ("tiles_3_threads", 320, 200, 1, 10, dict(tiles=(3, 1), threads=3)),
+    ("sb64_tiles", 264, 136, 1, 8, dict(sb128=False, tiles=(2, 1))),
+    ("key_420_8", 256, 192, 1, 8, dict(is_inter=False)),
+    ("key_444_10", 192, 128, 3, 10, dict(is_inter=False)),
+    ("key_palette", 256, 192, 1, 8, dict(is_inter=False, palette=40)),
+    ("inter_palette_10", 256, 192, 1, 10, dict(palette=40, intra_pct=50)),
+    ("global_motion", 256, 192, 1, 8, dict(gmv=GMV, global_pct=40)),
+    ("global_motion_444", 192, 192, 3, 10, dict(gmv=GMV, global_pct=40)),
+    ("scaled_refs", 256, 192, 1, 8, dict(ref_sizes=scaled_refs(256, 192))),
+    ("scaled_refs_444_10", 192, 128, 3, 10, dict(ref_sizes=scaled_refs(192, 128))),
+]
+# the SIMT-emulated kernels are slow: the CPU run takes a cross-section, the GPU run everything
+MIX_CPU = {"420_8", "420_12_cut", "444_10", "422_10", "400_8", "tiles_3_threads", "sb64_tiles", "key_444_10", "key_palette",
+           "global_motion", "scaled_refs_444_10"}
+
+
+@pytest.mark.parametrize("name,w,h,layout,bpc,kw", MIX, ids=[t[0] for t in MIX])
+def test_every_tool_mixed(ctx, name, w, h, layout, bpc, kw):
+    if ctx.backend == "emu" and name not in MIX_CPU:
+        pytest.skip("GPU run only")
+    st = run_case(ctx, w, h, layout, bpc, 100 + MIX.index((name, w, h, layout, bpc, kw)), **kw)
+    if not kw.get("is_inter", True):
+        assert st["steps"] > 20          # a key frame is one long wavefront
+
+
+@pytest.mark.gpu
+def test_larger_frame_many_tiles_threads():
+    ctx = util.make_context("hip")
+    ctx.backend = "hip"
+    try:
+        run_case(ctx, 1920, 1080, 1, 10, 7, tiles=(4, 2), threads=8)
+        run_case(ctx, 1280, 720, 1, 8, 8, tiles=(2, 1), threads=2, is_inter=False)
+    finally:
+        ctx.close()
