@@ -74,7 +74,7 @@ SYMBOLS = [
     "dav1d_hip_frame_submit_step_blend", "dav1d_hip_frame_submit_warp", "dav1d_hip_frame_submit_scaled",
     "dav1d_hip_lister_create", "dav1d_hip_lister_tile_sbrow", "dav1d_hip_lister_prep_elems", "dav1d_hip_lister_mask_bytes",
     "dav1d_hip_lister_steps", "dav1d_hip_lister_const_masks", "dav1d_hip_lister_destroy", "dav1d_hip_synth_frame",
-    "dav1d_hip_lister_mask_offset", "dav1d_hip_lister_tables", "dav1d_hip_lister_block_warp",
+    "dav1d_hip_lister_mask_offset", "dav1d_hip_lister_tables", "dav1d_hip_lister_block_warp", "dav1d_hip_lister_filter_sbrow",
 ]
 
 
@@ -107,6 +107,13 @@ class SynthParams(C.Structure):        # == Dav1dHipSynthParams
                 ("tx_split_pct", C.c_int), ("alt_txtp_pct", C.c_int), ("eob_none_pct", C.c_int), ("mv_range", C.c_int),
                 ("far_mv_pct", C.c_int), ("n_refs", C.c_int), ("split_pct", C.c_int * 5), ("rect_pct", C.c_int),
                 ("fixed_bl", C.c_int), ("cf_align64", C.c_int)]
+
+
+class FilterDesc(C.Structure):         # == Dav1dHipFilterDesc
+    _fields_ = [("lf_level_y", C.c_int * 2), ("lf_level_u", C.c_int), ("lf_level_v", C.c_int), ("lf_mask", C.c_void_p),
+                ("tx_lpf_right_edge", C.c_void_p * 2), ("a_tx_lpf_y", C.c_void_p), ("a_tx_lpf_uv", C.c_void_p), ("a_stride", C.c_size_t),
+                ("cdef_enabled", C.c_int), ("cdef_damping", C.c_int), ("cdef_y_strength", C.c_uint8 * 8), ("cdef_uv_strength", C.c_uint8 * 8),
+                ("lr_type", C.c_int * 3), ("lr_unit_size", C.c_int * 2), ("lr_mask", C.c_void_p)]
 
 
 class LibraryError(RuntimeError):
@@ -207,6 +214,7 @@ def load(path=None):
         "dav1d_hip_synth_frame": (i, [P(FrameDesc), P(SynthParams), vp, sz, sz, vp, sz]),
         "dav1d_hip_lister_mask_offset": (C.c_long, [i, i, i, i, i]),
         "dav1d_hip_lister_tables": (None, [vp]),
+        "dav1d_hip_lister_filter_sbrow": (i, [vp, P(FilterDesc), i]),
         "dav1d_hip_lister_block_warp": (i, [P(WarpParams), vp, vp, i, i, i, i]),
         "dav1d_hip_dsp_init_8bpc": (i, [vp]),
         "dav1d_hip_dsp_init_16bpc": (i, [vp, i]),

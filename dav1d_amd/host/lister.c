@@ -13,6 +13,7 @@
  *     1 + the largest step among the cells its edges reach; everything else is step 0 (no dependency inside the frame).
  * Plain C99, no HIP: the frame's submit calls are the only way out. */
 #include "av1_host.h"
+#include "lister_priv.h"
 #include <errno.h>
 #include <stdlib.h>
 #include <string.h>
@@ -850,6 +851,16 @@ void dav1d_hip_lister_destroy(Dav1dHipLister *l) {
     for (int p = 0; p < 3; p++) free(l->step[p]);
     free(l->tiles);
     free(l);
+}
+
+void dav1d_hip_lister_geo(const Dav1dHipLister *l, ListerGeo *g) {
+    g->frame = l->frame;
+    g->w = l->d.w; g->h = l->d.h; g->layout = l->d.layout; g->bpc = l->d.bpc; g->sb128 = l->d.sb128;
+    g->ss_hor = l->ss_hor; g->ss_ver = l->ss_ver; g->bw = l->bw; g->bh = l->bh; g->sb_step = l->sb_step;
+    for (int p = 0; p < 3; p++) g->stride[p] = l->stride[p];
+    g->b4_stride = l->d.b4_stride;
+    g->n_tile_cols = l->d.n_tile_cols; g->n_tile_rows = l->d.n_tile_rows;
+    g->col_start_sb = l->d.col_start_sb; g->row_start_sb = l->d.row_start_sb;
 }
 
 size_t dav1d_hip_lister_prep_elems(const Dav1dHipLister *l) { return l ? (size_t) ((l->arena_bytes + 1) / 2 + 64) : 0; }

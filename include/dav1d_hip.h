@@ -648,6 +648,41 @@ DAV1D_HIP_API size_t dav1d_hip_lister_mask_bytes(const Dav1dHipLister *l);   /* 
 DAV1D_HIP_API size_t dav1d_hip_lister_steps(const Dav1dHipLister *l);        /* wavefront steps the frame needs so far */
 DAV1D_HIP_API const uint8_t *dav1d_hip_lister_const_masks(size_t *bytes);    /* HOST blob to copy to the start of the mask arena */
 DAV1D_HIP_API void dav1d_hip_lister_destroy(Dav1dHipLister *l);
+/* ---- the in-loop filters of a listed frame ----
+ * What pass 1 leaves for the filters (reference src/lf_mask.h:42-63): per 128x128 the deblocking edge masks, the CDEF index of
+ * its four 64x64s and the "has coefficients" mask of its 8x8s; per 128x128 and plane four restoration units; the level cache
+ * f->lf.level goes to the device as is (dav1d_hip_frame_set_filters).  dav1d_hip_lister_filter_sbrow restates the drivers that
+ * turn those into DSP calls — dav1d_loopfilter_sbrow_cols / _rows incl. the mask fix-ups at tile edges (src/lf_apply_tmpl.c:
+ * 313-466), dav1d_cdef_brow (src/cdef_apply_tmpl.c:97-308), dav1d_lr_sbrow (src/lr_apply_tmpl.c:36-202) — as task records. */
+typedef struct Dav1dHipRestorationUnit {       /* == Av1RestorationUnit */
+    uint8_t type;                /* 0 none, 2 Wiener, 3 + sgr_idx self-guided */
+    int8_t filter_h[3], filter_v[3], sgr_weights[2];
+} Dav1dHipRestorationUnit;
+typedef struct Dav1dHipAv1Filter {             /* == Av1Filter */
+    uint16_t filter_y[2][32][3][2];
+    uint16_t filter_uv[2][32][2][2];
+    int8_t cdef_idx[4];
+    uint16_t noskip_mask[16][2];
+} Dav1dHipAv1Filter;
+typedef struct Dav1dHipAv1Restoration { Dav1dHipRestorationUnit lr[3][4]; } Dav1dHipAv1Restoration;    /* == Av1Restoration */
+
+typedef struct Dav1dHipFilterDesc {
+    int lf_level_y[2], lf_level_u, lf_level_v;     /* frame_hdr->loopfilter.level_y / level_u / level_v */
+    const Dav1dHipAv1Filter *lf_mask;              /* f->lf.mask, [sb128 row * sb128w + sb128 column] */
+    const uint8_t *tx_lpf_right_edge[2];           /* f->lf.tx_lpf_right_edge */
+    const uint8_t *a_tx_lpf_y, *a_tx_lpf_uv;       /* f->a[0].tx_lpf_y / .tx_lpf_uv of the pass-1 above contexts ... */
+    size_t a_stride;                               /* ... sizeof(BlockContext) apart, [tile row * sb128w + sb128 column] */
+    int cdef_enabled;                              /* seq_hdr->cdef */
+    int cdef_damping;                              /* frame_hdr->cdef.damping */
+    uint8_t cdef_y_strength[8], cdef_uv_strength[8];   /* frame_hdr->cdef.y_strength / uv_strength */
+    int lr_type[3];                                /* frame_hdr->restoration.type: 0 = plane not restored */
+    int lr_unit_size[2];                           /* frame_hdr->restoration.unit_size (log2), luma / chroma */
+    const Dav1dHipAv1Restoration *lr_mask;         /* f->lf.lr_mask */
+} Dav1dHipFilterDesc;
+/* One superblock row of filter tasks (what dav1d_filter_sbrow would execute, src/recon_tmpl.c:2100-2109), submitted to the
+ * lister's frame.  Thread-safe; any order. */
+DAV1D_HIP_API int dav1d_hip_lister_filter_sbrow(Dav1dHipLister *l, const Dav1dHipFilterDesc *fd, int sby);
+
 /* Test aids (tests/test_host_tables.py pins the lister's derived AV1 geometry against the tables of the reference build). */
 DAV1D_HIP_API long dav1d_hip_lister_mask_offset(int which, int c, int bs, int sign, int idx);
 DAV1D_HIP_API void dav1d_hip_lister_tables(uint8_t *out);

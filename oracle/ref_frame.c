@@ -39,6 +39,8 @@ typedef struct RefFrameParams {
     int32_t gmv_matrix[7][6];
     /* in-loop filters */
     int lf_level_y[2], lf_level_u, lf_level_v, lf_sharpness;
+    int lf_mode_ref_delta_enabled;
+    int lf_ref_delta[8], lf_mode_delta[2];
     int cdef_enabled, cdef_damping, cdef_n_bits;
     int cdef_y_strength[8], cdef_uv_strength[8];
     int lr_type[3], lr_unit_size[2];
@@ -55,9 +57,10 @@ typedef struct RefFrame {
     size_t plane_bytes[8][3];
     refmvs_temporal_block *mvs;
     RefFrameParams p;
-    /* pass-1 stand-in state for the loop filter masks */
-    BlockContext *lf_a;       /* per 128-pixel column of the frame */
+    /* pass-1 stand-in state for the loop filter masks: the above contexts are the pass-1 half of f->a itself */
     BlockContext lf_l;
+    int cur_tile_row;
+    uint32_t rng;
 } RefFrame;
 
 static void once_init(void) {
@@ -150,6 +153,9 @@ void *dav1d_ref_frame_create(const RefFrameParams *const p) {
     fh->loopfilter.level_y[0] = p->lf_level_y[0]; fh->loopfilter.level_y[1] = p->lf_level_y[1];
     fh->loopfilter.level_u = p->lf_level_u; fh->loopfilter.level_v = p->lf_level_v;
     fh->loopfilter.sharpness = p->lf_sharpness;
+    fh->loopfilter.mode_ref_delta_enabled = p->lf_mode_ref_delta_enabled;
+    for (int i = 0; i < 8; i++) fh->loopfilter.mode_ref_deltas.ref_delta[i] = p->lf_ref_delta[i];
+    for (int i = 0; i < 2; i++) fh->loopfilter.mode_ref_deltas.mode_delta[i] = p->lf_mode_delta[i];
     fh->cdef.damping = p->cdef_damping; fh->cdef.n_bits = p->cdef_n_bits;
     for (int i = 0; i < 8; i++) { fh->cdef.y_strength[i] = p->cdef_y_strength[i]; fh->cdef.uv_strength[i] = p->cdef_uv_strength[i]; }
     for (int i = 0; i < 3; i++) fh->restoration.type[i] = p->lr_type[i];
@@ -243,7 +249,6 @@ void *dav1d_ref_frame_create(const RefFrameParams *const p) {
                 ts->lflvl = f->lf.lvl;
             }
     }
-    r->lf_a = calloc((size_t) f->sb128w, sizeof(*r->lf_a));
     return r;
 fail:
     dav1d_ref_frame_destroy(r);
@@ -256,7 +261,6 @@ void dav1d_ref_frame_destroy(void *const h) {
     for (int i = 0; i < 8; i++) free(r->pic_mem[i]);
     free(r->tc);
     free(r->mvs);
-    free(r->lf_a);
     /* the per-frame arrays dav1d_decode_frame_init() allocated stay with the process: test infrastructure */
     free(r);
 }
@@ -283,6 +287,7 @@ void *dav1d_ref_frame_ptr(void *const h, const char *const name, size_t *const b
     else if (IS("lf_level")) { ptr = f->lf.level; n = sizeof(*f->lf.level) * num_sb128 * 32 * 32; }
     else if (IS("lr_mask")) { ptr = f->lf.lr_mask; n = sizeof(*f->lf.lr_mask) * f->lf.lr_mask_sz; }
     else if (IS("lim_lut")) { ptr = &f->lf.lim_lut; n = sizeof(f->lf.lim_lut); }
+    else if (IS("a")) { ptr = f->a; n = sizeof(*f->a) * f->a_sz; }
     else if (IS("tx_lpf_right_edge0")) { ptr = f->lf.tx_lpf_right_edge[0]; n = (size_t) f->lf.re_sz * 32; }
     else if (IS("tx_lpf_right_edge1")) { ptr = f->lf.tx_lpf_right_edge[1]; n = (size_t) f->lf.re_sz * 32; }
     else if (!strncmp(name, "pic", 3) && name[3] >= '0' && name[3] <= '7' && name[4] == '_' && name[5] >= '0' && name[5] <= '2') {
@@ -325,6 +330,12 @@ void dav1d_ref_layouts(int *const out) {
     out[n++] = (int) offsetof(Dav1dWarpedMotionParams, type); out[n++] = (int) offsetof(Dav1dWarpedMotionParams, matrix);
     out[n++] = (int) offsetof(Dav1dWarpedMotionParams, u);
     out[n++] = (int) sizeof(Av1Filter); out[n++] = (int) sizeof(Av1Restoration); out[n++] = (int) sizeof(Av1RestorationUnit);
+    out[n++] = (int) offsetof(Av1Filter, filter_y); out[n++] = (int) offsetof(Av1Filter, filter_uv); out[n++] = (int) offsetof(Av1Filter, cdef_idx);
+    out[n++] = (int) offsetof(Av1Filter, noskip_mask);
+    out[n++] = (int) offsetof(Av1RestorationUnit, type); out[n++] = (int) offsetof(Av1RestorationUnit, filter_h);
+    out[n++] = (int) offsetof(Av1RestorationUnit, filter_v); out[n++] = (int) offsetof(Av1RestorationUnit, sgr_weights);
+    out[n++] = (int) sizeof(BlockContext); out[n++] = (int) offsetof(BlockContext, tx_lpf_y); out[n++] = (int) offsetof(BlockContext, tx_lpf_uv);
+    out[n++] = (int) sizeof(Av1FilterLUT); out[n++] = (int) offsetof(Av1FilterLUT, e); out[n++] = (int) offsetof(Av1FilterLUT, i);
     out[n++] = -1;
 }
 
@@ -339,7 +350,7 @@ int dav1d_ref_frame_recon(void *const h) {
     t->c = &r->c; t->f = f;
     t->frame_thread.pass = 2;
     /* reset_context(), src/decode.c:2385-2413, of the pass-2 half of f->a (dav1d_decode_frame_init_cdf, :3182-3188) */
-    for (int n = 0; n < f->a_sz; n++) {
+    for (int n = f->sb128w * fh->tiling.rows; n < f->a_sz; n++) {      /* the pass-1 half keeps what pass 1 left (tx_lpf_*) */
         memset(&f->a[n], 0, sizeof(f->a[n]));
         memset(f->a[n].intra, keyframe, sizeof(f->a[n].intra));
         memset(f->a[n].uvmode, DC_PRED, sizeof(f->a[n].uvmode));
@@ -386,4 +397,139 @@ int dav1d_ref_block_warp(const int16_t *const matrix, const int16_t *const mv2d,
     for (int i = 0; i < 6; i++) out[i] = wm.matrix[i];
     out[6] = wm.u.p.alpha; out[7] = wm.u.p.beta; out[8] = wm.u.p.gamma; out[9] = wm.u.p.delta;
     return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Filter inputs.  Pass 1 of the reference builds the deblocking masks, the level cache, noskip_mask and cdef_idx block by
+ * block while it parses (src/decode.c:938-956, 1216-1226, 1882-1900, 1945-1956, 2730-2740).  Here the reference's own
+ * block walk (decode_sb with pass == 2) visits every block with the two reconstruction hooks pointed at the functions
+ * below, which make the same calls of the reference's dav1d_create_lf_mask_intra / _inter with the same arguments. */
+static RefFrame *g_walk;       /* the hooks have no user pointer */
+
+static uint32_t walk_rnd(RefFrame *const r) { r->rng = r->rng * 1664525u + 1013904223u; return r->rng >> 8; }
+
+static void walk_common(Dav1dTaskContext *const t, const enum BlockSize bs, const Av1Block *const b) {
+    RefFrame *const r = g_walk;
+    const Dav1dFrameContext *const f = t->f;
+    Av1Filter *const lf_mask = f->lf.mask + (t->by >> 5) * f->sb128w + (t->bx >> 5);
+    const uint8_t *const b_dim = dav1d_block_dimensions[bs];
+    const int bx4 = t->bx & 31, by4 = t->by & 31, bw4 = b_dim[0], bh4 = b_dim[1];
+    /* cdef index of the 64x64(s) the block touches: read with the first block that has coefficients (:938-956) */
+    if (!b->skip) {
+        const int idx = ((t->bx & 16) >> 4) + ((t->by & 16) >> 3);
+        if (lf_mask->cdef_idx[idx] == -1) {
+            const int v = walk_rnd(r) & ((1 << f->frame_hdr->cdef.n_bits) - 1);
+            lf_mask->cdef_idx[idx] = v;
+            if (bw4 > 16) lf_mask->cdef_idx[idx + 1] = v;
+            if (bh4 > 16) lf_mask->cdef_idx[idx + 2] = v;
+            if (bw4 == 32 && bh4 == 32) lf_mask->cdef_idx[idx + 3] = v;
+        }
+        /* :1945-1956 */
+        uint16_t (*noskip_mask)[2] = &lf_mask->noskip_mask[by4 >> 1];
+        const unsigned mask = (~0U >> (32 - bw4)) << (bx4 & 15);
+        const int bx_idx = (bx4 & 16) >> 4;
+        for (int y = 0; y < bh4; y += 2, noskip_mask++) {
+            (*noskip_mask)[bx_idx] |= mask;
+            if (bw4 == 32) (*noskip_mask)[1] |= mask;
+        }
+    }
+}
+
+static void walk_intra(Dav1dTaskContext *const t, const enum BlockSize bs, const enum EdgeFlags flags, const Av1Block *const b) {
+    (void) flags;
+    RefFrame *const r = g_walk;
+    const Dav1dFrameContext *const f = t->f;
+    const Dav1dTileState *const ts = t->ts;
+    const int ss_ver = f->cur.p.layout == DAV1D_PIXEL_LAYOUT_I420, ss_hor = f->cur.p.layout != DAV1D_PIXEL_LAYOUT_I444;
+    const uint8_t *const b_dim = dav1d_block_dimensions[bs];
+    const int bx4 = t->bx & 31, by4 = t->by & 31, cbx4 = bx4 >> ss_hor, cby4 = by4 >> ss_ver;
+    const int has_chroma = f->cur.p.layout != DAV1D_PIXEL_LAYOUT_I400 && (b_dim[0] > ss_hor || t->bx & 1) && (b_dim[1] > ss_ver || t->by & 1);
+    BlockContext *const a = &f->a[r->cur_tile_row * f->sb128w + (t->bx >> 5)];
+    if (f->frame_hdr->loopfilter.level_y[0] || f->frame_hdr->loopfilter.level_y[1])
+        dav1d_create_lf_mask_intra(f->lf.mask + (t->by >> 5) * f->sb128w + (t->bx >> 5), f->lf.level, f->b4_stride,
+                                   (const uint8_t (*)[8][2]) &ts->lflvl[b->seg_id][0][0][0], t->bx, t->by, f->w4, f->h4, bs,
+                                   b->tx, b->uvtx, f->cur.p.layout, &a->tx_lpf_y[bx4], &r->lf_l.tx_lpf_y[by4],
+                                   has_chroma ? &a->tx_lpf_uv[cbx4] : NULL, has_chroma ? &r->lf_l.tx_lpf_uv[cby4] : NULL);
+    walk_common(t, bs, b);
+}
+
+static int walk_inter(Dav1dTaskContext *const t, const enum BlockSize bs, const Av1Block *const b) {
+    RefFrame *const r = g_walk;
+    const Dav1dFrameContext *const f = t->f;
+    const Dav1dTileState *const ts = t->ts;
+    const int ss_ver = f->cur.p.layout == DAV1D_PIXEL_LAYOUT_I420, ss_hor = f->cur.p.layout != DAV1D_PIXEL_LAYOUT_I444;
+    const uint8_t *const b_dim = dav1d_block_dimensions[bs];
+    const int bx4 = t->bx & 31, by4 = t->by & 31, cbx4 = bx4 >> ss_hor, cby4 = by4 >> ss_ver;
+    const int has_chroma = f->cur.p.layout != DAV1D_PIXEL_LAYOUT_I400 && (b_dim[0] > ss_hor || t->bx & 1) && (b_dim[1] > ss_ver || t->by & 1);
+    BlockContext *const a = &f->a[r->cur_tile_row * f->sb128w + (t->bx >> 5)];
+    if (f->frame_hdr->loopfilter.level_y[0] || f->frame_hdr->loopfilter.level_y[1]) {
+        const int is_comp = b->comp_type != COMP_INTER_NONE;
+        const int is_globalmv = b->inter_mode == (is_comp ? GLOBALMV_GLOBALMV : GLOBALMV);
+        const uint8_t (*const lf_lvls)[8][2] = (const uint8_t (*)[8][2]) &ts->lflvl[b->seg_id][0][b->ref[0] + 1][!is_globalmv];
+        const uint16_t tx_split[2] = { b->tx_split0, b->tx_split1 };
+        dav1d_create_lf_mask_inter(f->lf.mask + (t->by >> 5) * f->sb128w + (t->bx >> 5), f->lf.level, f->b4_stride, lf_lvls,
+                                   t->bx, t->by, f->w4, f->h4, b->skip, bs, b->max_ytx, tx_split, b->uvtx, f->cur.p.layout,
+                                   &a->tx_lpf_y[bx4], &r->lf_l.tx_lpf_y[by4],
+                                   has_chroma ? &a->tx_lpf_uv[cbx4] : NULL, has_chroma ? &r->lf_l.tx_lpf_uv[cby4] : NULL);
+    }
+    walk_common(t, bs, b);
+    return 0;
+}
+
+int dav1d_ref_frame_build_filter_inputs(void *const h, const unsigned seed) {
+    RefFrame *const r = h;
+    Dav1dFrameContext *const f = &r->f;
+    Dav1dTaskContext *const t = r->tc;
+    const Dav1dFrameHeader *const fh = &r->fh;
+    const int num_sb128 = f->sb128w * f->sb128h;
+    r->rng = seed * 2654435761u + 12345u;
+    memset(f->lf.mask, 0, sizeof(*f->lf.mask) * num_sb128);
+    for (int i = 0; i < num_sb128; i++) memset(f->lf.mask[i].cdef_idx, -1, 4);
+    memset(f->lf.level, 0, sizeof(*f->lf.level) * num_sb128 * 32 * 32);
+    /* reset_context() of the pass-1 half of f->a: tx_lpf_y = 2, tx_lpf_uv = 1 (:2401-2402) */
+    for (int n = 0; n < f->sb128w * fh->tiling.rows; n++) {
+        memset(f->a[n].tx_lpf_y, 2, sizeof(f->a[n].tx_lpf_y));
+        memset(f->a[n].tx_lpf_uv, 1, sizeof(f->a[n].tx_lpf_uv));
+    }
+    recon_b_intra_fn keep_intra = f->bd_fn.recon_b_intra;
+    recon_b_inter_fn keep_inter = f->bd_fn.recon_b_inter;
+    backup_ipred_edge_fn keep_edge = f->bd_fn.backup_ipred_edge;
+    f->bd_fn.recon_b_intra = walk_intra;
+    f->bd_fn.recon_b_inter = walk_inter;
+    g_walk = r;
+    t->c = &r->c; t->f = f;
+    t->frame_thread.pass = 2;
+    int rc = 0;
+    const int ss_ver = f->cur.p.layout == DAV1D_PIXEL_LAYOUT_I420;
+    for (int tile_row = 0; tile_row < fh->tiling.rows && !rc; tile_row++)
+        for (int sby = fh->tiling.row_start_sb[tile_row]; sby < fh->tiling.row_start_sb[tile_row + 1] && !rc; sby++) {
+            t->by = sby << f->sb_shift;
+            for (int tile_col = 0; tile_col < fh->tiling.cols && !rc; tile_col++) {
+                t->ts = &f->ts[tile_row * fh->tiling.cols + tile_col];
+                r->cur_tile_row = tile_row;
+                memset(r->lf_l.tx_lpf_y, 2, sizeof(r->lf_l.tx_lpf_y));
+                memset(r->lf_l.tx_lpf_uv, 1, sizeof(r->lf_l.tx_lpf_uv));
+                rc = dav1d_decode_tile_sbrow(t);
+                /* :2730-2740: the left context at the tile's right edge, for the mask fix-ups across tile columns */
+                int align_h = (f->bh + 31) & ~31;
+                memcpy(&f->lf.tx_lpf_right_edge[0][align_h * tile_col + t->by], &r->lf_l.tx_lpf_y[t->by & 16], f->sb_step);
+                align_h >>= ss_ver;
+                memcpy(&f->lf.tx_lpf_right_edge[1][align_h * tile_col + (t->by >> ss_ver)], &r->lf_l.tx_lpf_uv[(t->by & 16) >> ss_ver],
+                       f->sb_step >> ss_ver);
+            }
+        }
+    f->bd_fn.recon_b_intra = keep_intra;
+    f->bd_fn.recon_b_inter = keep_inter;
+    f->bd_fn.backup_ipred_edge = keep_edge;
+    return rc;
+}
+
+/* the reference's in-loop filters, superblock row by superblock row (dav1d_decode_frame_main, src/decode.c:3228-3232) */
+int dav1d_ref_frame_filter(void *const h) {
+    RefFrame *const r = h;
+    Dav1dFrameContext *const f = &r->f;
+    r->tc->c = &r->c; r->tc->f = f;
+    r->tc->top_pre_cdef_toggle = 0;
+    for (int sby = 0; sby < f->sbh; sby++) f->bd_fn.filter_sbrow(f, sby);
+    return 0;
 }

@@ -19,6 +19,7 @@ class RefFrameParams(C.Structure):
                 ("ref_w", C.c_int * 7), ("ref_h", C.c_int * 7), ("ref_poc", C.c_int * 7), ("cur_poc", C.c_int),
                 ("order_hint_n_bits", C.c_int), ("gmv_type", C.c_int * 7), ("gmv_matrix", (C.c_int32 * 6) * 7),
                 ("lf_level_y", C.c_int * 2), ("lf_level_u", C.c_int), ("lf_level_v", C.c_int), ("lf_sharpness", C.c_int),
+                ("lf_mode_ref_delta_enabled", C.c_int), ("lf_ref_delta", C.c_int * 8), ("lf_mode_delta", C.c_int * 2),
                 ("cdef_enabled", C.c_int), ("cdef_damping", C.c_int), ("cdef_n_bits", C.c_int), ("cdef_y_strength", C.c_int * 8),
                 ("cdef_uv_strength", C.c_int * 8), ("lr_type", C.c_int * 3), ("lr_unit_size", C.c_int * 2)]
 
@@ -35,6 +36,8 @@ def ref_lib():
     lib.dav1d_ref_frame_recon.argtypes = [C.c_void_p]
     lib.dav1d_ref_frame_destroy.argtypes = [C.c_void_p]
     lib.dav1d_ref_layouts.argtypes = [C.POINTER(C.c_int)]
+    lib.dav1d_ref_frame_build_filter_inputs.argtypes = [C.c_void_p, C.c_uint]
+    lib.dav1d_ref_frame_filter.argtypes = [C.c_void_p]
     return lib
 
 
@@ -50,7 +53,7 @@ class RefFrame:
     """One synthetic frame inside a real Dav1dFrameContext of the reference build."""
 
     def __init__(self, w, h, layout, bpc, is_inter=True, sb128=True, tile_cols=1, tile_rows=1, ref_sizes=None, gmv=None,
-                 intra_edge_filter=1, screen_content=0, order_hint_bits=5):
+                 intra_edge_filter=1, screen_content=0, order_hint_bits=5, filters=None):
         self.lib = ref_lib()
         assert self.lib is not None, "the reference build oracle/_ref is required"
         p = RefFrameParams()
@@ -76,6 +79,27 @@ class RefFrame:
                 p.gmv_type[i] = gmv[i][0]
                 for k in range(6):
                     p.gmv_matrix[i][k] = gmv[i][1][k]
+        if filters:
+            # filters: dict(lf=(y0, y1, u, v, sharpness, deltas?), cdef=(damping, n_bits, y_strengths, uv_strengths), lr=(types[3], unit_log2[2]))
+            if "lf" in filters:
+                y0, y1, u, v, sharp, deltas = filters["lf"]
+                p.lf_level_y[0], p.lf_level_y[1], p.lf_level_u, p.lf_level_v, p.lf_sharpness = y0, y1, u, v, sharp
+                if deltas:
+                    p.lf_mode_ref_delta_enabled = 1
+                    for i, d in enumerate((1, 0, -1, 0, -1, 2, -2, 1)):
+                        p.lf_ref_delta[i] = d
+                    p.lf_mode_delta[0], p.lf_mode_delta[1] = 1, -1
+            if "cdef" in filters:
+                damping, n_bits, ys, uvs = filters["cdef"]
+                p.cdef_enabled, p.cdef_damping, p.cdef_n_bits = 1, damping, n_bits
+                for i in range(1 << n_bits):
+                    p.cdef_y_strength[i], p.cdef_uv_strength[i] = ys[i], uvs[i]
+            if "lr" in filters:
+                types, units = filters["lr"]
+                for i in range(3):
+                    p.lr_type[i] = types[i]
+                p.lr_unit_size[0], p.lr_unit_size[1] = units
+        self.filters = filters
         self.p = p
         self.h = self.lib.dav1d_ref_frame_create(C.byref(p))
         assert self.h, "dav1d_ref_frame_create failed"
@@ -139,6 +163,61 @@ class RefFrame:
         rc = self.lib.dav1d_ref_frame_recon(self.h)
         assert rc == 0, "reference pass 2 failed"
 
+    def build_filter_inputs(self, seed):
+        """the deblocking masks / levels / cdef indices the reference's pass 1 would have built for the blocks in place, and
+        random restoration units"""
+        rc = self.lib.dav1d_ref_frame_build_filter_inputs(self.h, seed)
+        assert rc == 0
+        rng = np.random.default_rng(seed)
+        lrm = self.array("lr_mask", np.int8)
+        if lrm is not None and len(lrm):
+            u = lrm.reshape(-1, 3, 4, 9)           # Av1Restoration.lr[plane][unit]{type, filter_h[3], filter_v[3], sgr_weights[2]}
+            sgr = np.array([(140, 3236), (112, 2158), (93, 1618), (80, 1438), (70, 1295), (58, 1177), (47, 1079), (37, 996), (30, 925),
+                            (25, 863), (0, 2589), (0, 1618), (0, 1177), (0, 925), (56, 0), (22, 0)])
+            for pl in range(3):
+                ft = self.p.lr_type[pl]            # 0 none, 1 switchable, 2 Wiener, 3 self-guided
+                n = u.shape[0] * 4
+                kind = rng.integers(0, 3, size=n) if ft == 1 else np.where(rng.random(n) < 0.8, ft - 1, 0) if ft else np.zeros(n, np.int64)
+                idx = rng.integers(0, 16, size=n)
+                typ = np.where(kind == 0, 0, np.where(kind == 1, 2, 3 + idx))
+                uu = np.zeros((n, 9), np.int64)
+                uu[:, 0] = typ
+                for d in (1, 4):                   # filter_h, filter_v: the ranges of read_restoration_info(), src/decode.c:2531-2546
+                    uu[:, d + 0] = 0 if pl else rng.integers(-5, 11, size=n)
+                    uu[:, d + 1] = rng.integers(-23, 9, size=n)
+                    uu[:, d + 2] = rng.integers(-17, 47, size=n)
+                w0 = rng.integers(-96, 32, size=n)
+                w1 = rng.integers(-32, 96, size=n)
+                uu[:, 7] = np.where(sgr[idx, 0] != 0, w0, 0)
+                uu[:, 8] = np.where(sgr[idx, 1] != 0, w1, 95)
+                u[:, pl] = uu.reshape(-1, 4, 9).astype(np.int8)
+
+    def filter(self):
+        assert self.lib.dav1d_ref_frame_filter(self.h) == 0
+
+    def filter_desc(self):
+        fd = _lib.FilterDesc()
+        p = self.p
+        fd.lf_level_y[0], fd.lf_level_y[1], fd.lf_level_u, fd.lf_level_v = p.lf_level_y[0], p.lf_level_y[1], p.lf_level_u, p.lf_level_v
+        fd.lf_mask = self.ptr("lf_mask")[0]
+        fd.tx_lpf_right_edge[0] = self.ptr("tx_lpf_right_edge0")[0]
+        fd.tx_lpf_right_edge[1] = self.ptr("tx_lpf_right_edge1")[0]
+        lay = (C.c_int * 64)()
+        self.lib.dav1d_ref_layouts(lay)
+        v = list(lay)
+        v = v[:v.index(-1)]
+        a_sz, a_y, a_uv = v[-6], v[-5], v[-4]
+        a = self.ptr("a")[0]
+        fd.a_tx_lpf_y, fd.a_tx_lpf_uv, fd.a_stride = a + a_y, a + a_uv, a_sz
+        fd.cdef_enabled, fd.cdef_damping = p.cdef_enabled, p.cdef_damping
+        for i in range(8):
+            fd.cdef_y_strength[i], fd.cdef_uv_strength[i] = p.cdef_y_strength[i], p.cdef_uv_strength[i]
+        for i in range(3):
+            fd.lr_type[i] = p.lr_type[i]
+        fd.lr_unit_size[0], fd.lr_unit_size[1] = p.lr_unit_size[0], p.lr_unit_size[1]
+        fd.lr_mask = self.ptr("lr_mask")[0]
+        return fd
+
     def destroy(self):
         if self.h:
             self.lib.dav1d_ref_frame_destroy(self.h)
@@ -198,7 +277,7 @@ def fill_pictures(rf, seed):
                 a[...] = v.astype(a.dtype)
 
 
-def run_hip(ctx, rf, d, threads=1):
+def run_hip(ctx, rf, d, threads=1, with_filters=False):
     """lister -> frame API -> kernels; returns the reconstructed planes (visible area) and the lister handle stats"""
     n_pl = 1 if rf.layout == 0 else 3
     cur = ctx.picture(rf.w, rf.ht, rf.layout, rf.bpc)
@@ -244,12 +323,26 @@ def run_hip(ctx, rf, d, threads=1):
     if pi is not None and len(pi):
         aux = ctx.buffer_from(pi)
         frame.submit_intra_step(0, np.zeros(0, api.IPRED_TASK), np.zeros(0, api.ITX_TASK), aux)
-    frame.end(coef, prep, mask)
-    out = [cur.download(pl) for pl in range(n_pl)]
+    lvl = None
+    if with_filters:
+        fd = rf.filter_desc()
+        sbh = rf.sbh
+        for sby in range(sbh):
+            rc3 = ctx.lib.dav1d_hip_lister_filter_sbrow(lh, C.byref(fd), sby)
+            assert rc3 == 0, "lister_filter_sbrow(%d): %d" % (sby, rc3)
+        lvl = ctx.buffer_from(rf.array("lf_level", np.uint8))
+        lut = rf.array("lim_lut", np.uint8)          # Av1FilterLUT: e[64], i[64], sharp[2]
+        frame.set_filters(lvl, rf.b4_stride, lut[0:64], lut[64:128], rf.p.cdef_damping + rf.bpc - 8)
+    filtered = frame.end(coef, prep, mask)
+    if with_filters:
+        fpic = api.DevicePicture.view(ctx, filtered, rf.w, rf.ht, rf.layout, rf.bpc)
+        out = [fpic.download(pl) for pl in range(n_pl)]
+    else:
+        out = [cur.download(pl) for pl in range(n_pl)]
     coef_after = coef.download(np.uint8)
     ctx.lib.dav1d_hip_lister_destroy(lh)
     frame.destroy()
-    for b in (coef, prep, mask, aux):
+    for b in (coef, prep, mask, aux, lvl):
         if b is not None:
             b.free()
     cur.free()

@@ -1,0 +1,81 @@
+"""The filter lister (deblocking masks / CDEF indices / restoration units -> task records) against the reference's OWN
+in-loop filters: dav1d_filter_sbrow_{8,16}bpc (src/recon_tmpl.c:2100-2109: dav1d_loopfilter_sbrow_cols / _rows with the
+tile-edge mask fix-ups, dav1d_copy_lpf, dav1d_cdef_brow, dav1d_lr_sbrow) run superblock row by superblock row on a real
+Dav1dFrameContext whose masks and level cache were built by the reference's dav1d_create_lf_mask_intra / _inter for the very
+blocks of the frame.  The device side: dav1d_hip_lister_filter_sbrow -> dav1d_hip_frame_* -> kernels, after the lister-driven
+reconstruction of the same frame.  The final pictures must be byte-identical."""
+import numpy as np
+import pytest
+
+import util
+import lister_util as lu
+
+pytestmark = pytest.mark.skipif(util.ref_lib() is None, reason="needs the reference build oracle/_ref")
+
+LF = dict(lf=(20, 28, 16, 24, 0, False))
+LF_DELTAS = dict(lf=(12, 40, 30, 0, 3, True))
+CDEF = dict(cdef=(5, 2, [17, 33, 0, 63], [5, 0, 20, 48]))
+CDEF3 = dict(cdef=(3, 3, [4, 9, 62, 3, 0, 21, 40, 1], [0, 7, 12, 63, 16, 0, 2, 31]))
+LR_SW = dict(lr=([1, 1, 1], [6, 6]))
+LR_W_S = dict(lr=([2, 3, 0], [7, 6]))
+LR_BIG = dict(lr=([3, 1, 2], [8, 7]))
+ALL = dict(LF, **CDEF, **LR_SW)
+
+
+def run_case(ctx, w, h, layout, bpc, seed, filters, is_inter=True, tiles=(1, 1), sb128=True, **kw):
+    rf = lu.RefFrame(w, h, layout, bpc, is_inter=is_inter, tile_cols=tiles[0], tile_rows=tiles[1], sb128=sb128, filters=filters)
+    try:
+        sp = lu.default_synth(seed, **kw)
+        d = lu.synth(ctx, rf, sp)
+        lu.fill_pictures(rf, seed + 1)
+        rf.build_filter_inputs(seed)
+        rf.recon()
+        n_pl = 1 if layout == 0 else 3
+        before = [rf.plane(0, pl).copy() for pl in range(n_pl)]
+        rf.filter()
+        assert any(not np.array_equal(before[pl], rf.plane(0, pl)) for pl in range(n_pl)), "the filters changed nothing: vacuous case"
+        got, _ = lu.run_hip(ctx, rf, d, 1, with_filters=True)
+        bad = lu.compare(rf, got)
+        assert not bad, "filtered planes differ from dav1d_filter_sbrow: (plane, pixels, first y, x, want, got) %s" % bad
+    finally:
+        rf.destroy()
+
+
+CASES = [
+    ("deblock", 320, 200, 1, 8, LF, {}),
+    ("deblock_deltas_tiles", 320, 200, 1, 10, LF_DELTAS, dict(tiles=(2, 2))),
+    ("deblock_sb64_tiles", 264, 200, 1, 8, LF, dict(sb128=False, tiles=(2, 3))),
+    ("deblock_444", 256, 136, 3, 10, LF, dict(tiles=(2, 1))),
+    ("deblock_422", 256, 136, 2, 8, LF, {}),
+    ("deblock_400", 256, 136, 0, 8, LF, {}),
+    ("cdef", 320, 200, 1, 8, CDEF, {}),
+    ("cdef_8_strengths_12bit", 320, 200, 1, 12, CDEF3, {}),
+    ("cdef_444", 256, 136, 3, 10, CDEF, {}),
+    ("cdef_422", 256, 136, 2, 10, CDEF3, {}),
+    ("cdef_skips", 320, 200, 1, 8, CDEF, dict(skip_pct=85)),
+    ("lr_switchable", 320, 200, 1, 8, LR_SW, {}),
+    ("lr_wiener_sgr_128", 320, 264, 1, 10, LR_W_S, {}),
+    ("lr_256_units_444", 400, 264, 3, 8, LR_BIG, {}),
+    ("all_tiles", 320, 200, 1, 10, ALL, dict(tiles=(2, 2))),
+    ("all_key_frame", 320, 200, 1, 8, ALL, dict(is_inter=False)),
+    ("all_sb64_cut", 296, 168, 1, 10, ALL, dict(sb128=False, tiles=(2, 2))),
+]
+CPU = {"deblock_deltas_tiles", "deblock_sb64_tiles", "deblock_444", "deblock_400", "cdef_8_strengths_12bit", "cdef_422", "cdef_skips",
+       "lr_wiener_sgr_128", "lr_256_units_444", "all_tiles", "all_key_frame", "all_sb64_cut"}
+
+
+@pytest.mark.parametrize("name,w,h,layout,bpc,filters,kw", CASES, ids=[c[0] for c in CASES])
+def test_filters_match_dav1d_filter_sbrow(ctx, name, w, h, layout, bpc, filters, kw):
+    if ctx.backend == "emu" and name not in CPU:
+        pytest.skip("GPU run only")
+    run_case(ctx, w, h, layout, bpc, 40 + [c[0] for c in CASES].index(name), filters, **kw)
+
+
+@pytest.mark.gpu
+def test_filters_1080p():
+    ctx = util.make_context("hip")
+    ctx.backend = "hip"
+    try:
+        run_case(ctx, 1920, 1080, 1, 10, 77, ALL, tiles=(4, 2))
+    finally:
+        ctx.close()
