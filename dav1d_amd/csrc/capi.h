@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include <errno.h>
+#include <mutex>
 #include <vector>
 
 struct Dav1dHipContext {
@@ -22,6 +23,17 @@ struct Dav1dHipContext {
     // measurement aid: device time of the kernel launches of the most recent *_batch call (dav1d_hip_last_kernel_ms)
     hipEvent_t ev_t0, ev_t1;
     float last_ms;
+    // chunked frames (chunk.hip): pinned slabs recycled between frames, the device arenas of the frame in flight, a copy stream
+    struct Slab { uint8_t *host; size_t cap; };
+    std::mutex pool_mtx;
+    std::vector<Slab> free_slabs;
+    uint8_t *chunk_dev, *gather_dev, *segtab_dev;
+    size_t chunk_dev_cap, gather_cap, segtab_cap;
+    uint8_t *pending_slab;
+    size_t pending_slab_cap;
+    hipStream_t copy_stream;
+    hipEvent_t ev_copy;
+    std::mutex run_mtx;         // one multi-stream section (recon list run, banded post filters) at a time per context
 };
 
 // brackets the launches of a batch call with events on the context's stream

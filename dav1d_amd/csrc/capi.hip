@@ -1,6 +1,7 @@
 // Host side of the C ABI declared in include/dav1d_hip.h: context, device memory,
 // pictures, task-list binning and the batched entry points.
 #include "capi.h"
+#include "lists.h"
 #include "av1_scan_prefix.h"
 #include <stdlib.h>
 #include <string.h>
@@ -39,6 +40,10 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
         if (hipEventCreateWithFlags(&c->ev_bin[i], hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
     if (hipEventCreate(&c->ev_t0) != hipSuccess || hipEventCreate(&c->ev_t1) != hipSuccess) { delete c; return -ENODEV; }
     c->last_ms = 0.f;
+    c->chunk_dev = c->gather_dev = c->segtab_dev = c->pending_slab = nullptr;
+    c->chunk_dev_cap = c->gather_cap = c->segtab_cap = c->pending_slab_cap = 0;
+    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
     *out = c;
     return 0;
 }
@@ -51,6 +56,12 @@ void dav1d_hip_close(Dav1dHipContext *c) {
     hipEventDestroy(c->ev_fork);
     for (int i = 0; i < 16; i++) hipEventDestroy(c->ev_bin[i]);
     hipEventDestroy(c->ev_t0); hipEventDestroy(c->ev_t1);
+    hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); hipEventDestroy(c->ev_copy);
+    if (c->chunk_dev) hipFree(c->chunk_dev);
+    if (c->gather_dev) hipFree(c->gather_dev);
+    if (c->segtab_dev) hipFree(c->segtab_dev);
+    if (c->pending_slab) hipHostFree(c->pending_slab);
+    for (const Dav1dHipContext::Slab &sl : c->free_slabs) hipHostFree(sl.host);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -237,11 +248,6 @@ Dav1dHipContext *dav1d_hip_default_context(void) {
 static const uint8_t k_tx_w[19] = { 4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64 };
 static const uint8_t k_tx_h[19] = { 4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16 };
 
-struct Dav1dHipItxList {
-    Dav1dHipItxTask *dev;
-    size_t n;
-    size_t off[20];   // bin b occupies [off[b], off[b+1])
-};
 
 // legal (size, type) pairs, reference src/itx_tmpl.c:160-178 / 264-291
 static bool itx_legal(int tx, int txtp) {
@@ -259,7 +265,7 @@ extern "C" {
 
 } // extern "C"
 
-static bool itx_task_ok(const Dav1dHipItxTask &t) {
+bool itx_task_ok(const Dav1dHipItxTask &t) {
     if (!itx_legal(t.tx, t.txtp) || t.plane > 2 || t.eob < 0 || t.flags > DAV1D_HIP_ITX_PACKED) return false;
     return t.eob < av1_scan_prefix_off[t.tx + 1] - av1_scan_prefix_off[t.tx];
 }
@@ -268,7 +274,7 @@ static bool itx_task_ok(const Dav1dHipItxTask &t) {
 // decoder only writes scan positions <= eob, src/recon_tmpl.c:458-520, and itx leaves slabs zeroed), so the kernel
 // reads and re-zeroes only the prefix [0, end).  2-D classes: the zig-zag's reach; H classes: the scan is the
 // slab order itself; V classes: every column can be touched.  The device copy carries `end` in the pad bytes.
-static void itx_fill_prefix(Dav1dHipItxTask &t) {
+void itx_fill_prefix(Dav1dHipItxTask &t) {
     const int ncoef = av1_scan_prefix_off[t.tx + 1] - av1_scan_prefix_off[t.tx];
     int end = ncoef;
     if (t.txtp <= 9 || t.txtp == 16) end = av1_scan_prefix_end[av1_scan_prefix_off[t.tx] + t.eob];
@@ -278,7 +284,7 @@ static void itx_fill_prefix(Dav1dHipItxTask &t) {
 }
 
 // code path of a transform block: dc-only shortcut, else its two 1-D kinds (txtp_kinds() in itx_body.h); 16 = WHT
-static int itx_path_key(const Dav1dHipItxTask &t) {
+int itx_path_key(const Dav1dHipItxTask &t) {
     static const uint8_t kinds[17] = {
         0 | 0 << 2, 0 | 1 << 2, 1 | 0 << 2, 1 | 1 << 2, 0 | 3 << 2, 3 | 0 << 2, 3 | 3 << 2, 3 | 1 << 2,
         1 | 3 << 2, 2 | 2 << 2, 2 | 0 << 2, 0 | 2 << 2, 2 | 1 << 2, 1 | 2 << 2, 2 | 3 << 2, 3 | 2 << 2, 16 };
@@ -400,17 +406,6 @@ int dav1d_hip_itx_add_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, cons
 
 // ----------------------------------------------------------------------- mc
 
-struct Dav1dHipMcList {
-    McTile *dev;      // tiles bin by bin (one launch per tile shape)
-    size_t n;
-    size_t off[16];   // 15 tile-shape bins: 3 * class(w in 4..64) + class(h in 4..16)
-    McTile *dev_all;  // the same tiles, all shapes interleaved in source order (one launch for everything)
-    McGroup *groups;
-    size_t n_groups, n_fused;
-    int max_ref;      // highest reference index any tile uses: checked against n_refs at run time
-    McTile *host;     // host copy of `dev` in source order: regrouped per reference geometry at run time
-    uint64_t geo_sig; // geometry the device copy is grouped for (0 = not yet)
-};
 
 // DAV1D_HIP_MC_FUSED: which tile shapes share one launch over a source-ordered list instead of one launch per shape.
 //   0  none;  2  the shapes that are at least 16 wide (bins 6 .. 14);  1  all of them.
@@ -422,20 +417,19 @@ static int mc_fused_min_bin() {
     return mode == 1 ? 0 : mode == 2 ? 6 : 15;
 }
 
-static int tile_dim_class(int v) { return v <= 4 ? 0 : v <= 8 ? 1 : v <= 16 ? 2 : v <= 32 ? 3 : 4; }
-#define MC_BINS 15
+int tile_dim_class(int v) { return v <= 4 ? 0 : v <= 8 ? 1 : v <= 16 ? 2 : v <= 32 ? 3 : 4; }
 
 extern "C" {
 
 } // extern "C" (helpers below are C++)
 
-static int mc_task_valid(const Dav1dHipMcTask &t) {
+int mc_task_valid(const Dav1dHipMcTask &t) {
     // widths are powers of two; heights too, except the 3/4-height `lap` predictions of obmc() (6, 12, 24 rows)
     return !(t.w < 2 || t.w > 128 || t.h < 2 || t.h > 128 || (t.w & (t.w - 1)) || (t.h & 1) ||
              t.mx > 15 || t.my > 15 || t.filter_2d > 9 || t.kind > 2 || t.plane > 2 || t.ref > 7);
 }
 
-static McRef mc_ref_of(const Dav1dHipMcTask &t) {
+McRef mc_ref_of(const Dav1dHipMcTask &t) {
     McRef r;
     memset(&r, 0, sizeof(r));
     r.src_x = t.src_x; r.src_y = t.src_y;
@@ -456,8 +450,8 @@ static McRef mc_ref_of(const Dav1dHipMcTask &t) {
 }
 
 // cut one prediction block (or a fused pair) into <= 64x16 tiles and bin them by tile shape
-static void push_tiles(std::vector<McTile> *bins, const Dav1dHipMcTask &t, int kind, uint32_t dst_off,
-                       const Dav1dHipMcTask *second, int weight, std::vector<McTile> *single = nullptr) {
+void push_tiles(std::vector<McTile> *bins, const Dav1dHipMcTask &t, int kind, uint32_t dst_off,
+                       const Dav1dHipMcTask *second, int weight, std::vector<McTile> *single) {
     McTile m;
     memset(&m, 0, sizeof(m));
     m.dst_off = dst_off;
@@ -561,13 +555,17 @@ static int mc_list_from_bins(Dav1dHipContext *c, Dav1dHipMcList **out, std::vect
 // leave the plane depends on the reference geometry, known only at run time: done on the first run and again whenever the
 // geometry changes.  The tiles of one list write disjoint rectangles (BLEND_V aside, which lives in the comp list), so
 // their order is free.  Speed only.
-static int mc_regroup(Dav1dHipContext *c, Dav1dHipMcList *l, const DevPlanes *rp, int n_refs) {
-    static const int win_waves = getenv("DAV1D_HIP_MC_GROUP_WINDOW") ? atoi(getenv("DAV1D_HIP_MC_GROUP_WINDOW")) : 128;
-    if (win_waves <= 0 || !l->n) return 0;
+uint64_t dav1d_hip_mc_geo_sig(const DevPlanes *rp, int n_refs) {
     uint64_t sig = 0xcbf29ce484222325ull;
     for (int r = 0; r < n_refs; r++)
         for (int p = 0; p < 3; p++) { sig = (sig ^ (uint32_t) rp[r].w[p]) * 0x100000001b3ull; sig = (sig ^ (uint32_t) rp[r].h[p]) * 0x100000001b3ull; }
-    sig |= 1;
+    return sig | 1;
+}
+
+static int mc_regroup(Dav1dHipContext *c, Dav1dHipMcList *l, const DevPlanes *rp, int n_refs) {
+    static const int win_waves = getenv("DAV1D_HIP_MC_GROUP_WINDOW") ? atoi(getenv("DAV1D_HIP_MC_GROUP_WINDOW")) : 128;
+    if (win_waves <= 0 || !l->n) return 0;
+    const uint64_t sig = dav1d_hip_mc_geo_sig(rp, n_refs);
     if (l->geo_sig == sig) return 0;
     std::vector<McTile> g(l->host, l->host + l->n);
     std::vector<uint8_t> key(l->n);
@@ -688,11 +686,6 @@ int dav1d_hip_mc_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav
 // --------------------------------------------------------------------- comp
 #include <unordered_set>
 
-struct Dav1dHipCompList {
-    Dav1dHipCompTask *dev;
-    size_t n;
-    size_t n_first;   // tasks [0, n_first) run in the first launch, the BLEND_V tasks after them in a second one
-};
 
 extern "C" {
 
@@ -771,15 +764,6 @@ int dav1d_hip_comp_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const D
 #include <unordered_map>
 #include <algorithm>
 
-struct Dav1dHipInterList {
-    Dav1dHipMcList *mc;
-    Dav1dHipCompList *comp;
-    size_t n_fused;
-    // with a picture geometry (recon lists): which launches write each 4x4 cell of a plane — bit b = the mc launch of tile
-    // shape b, bit 15 = the compound / blend launch
-    std::vector<uint16_t> writers[3];
-    int cell_stride[3], stride_px[3];
-};
 
 // Recon lists: a transform block that covers exactly one prediction block (same plane, position and size, square 4x4 ..
 // 64x64) is paired with it; the pair runs in one wave (recon.hip) and the prediction never reaches the picture on its own.
@@ -1391,17 +1375,6 @@ extern "C" int dav1d_hip_fg_apply(Dav1dHipContext *c, const Dav1dHipPicture *dst
 #ifndef RECON_FUSE_DEFAULT
 #define RECON_FUSE_DEFAULT 6
 #endif
-struct Dav1dHipReconList {
-    Dav1dHipInterList *inter;  // predictions that have no residual of their own shape (and everything when pairing is off)
-    Dav1dHipItxList *itx;      // residuals without a prediction of their own shape
-    uint16_t dep[19];          // per transform size: bits of the launches (see Dav1dHipInterList::writers) it has to wait for
-    int stride_px[3];
-    // paired blocks, per square size class 4x4 .. 64x64: tiles (1, 1, 1, 2, 4 per block) and transform tasks, device resident
-    McTile *f_tiles[5];
-    Dav1dHipItxTask *f_tasks[5];
-    size_t f_n[5];
-    int f_max_ref;
-};
 
 // DAV1D_HIP_RECON_FUSE: which square block sizes get paired (transform block + the prediction block of the same rectangle in
 // one wave, recon.hip): bit 0 4x4, bit 1 8x8, bit 2 16x16, bit 3 32x32, bit 4 64x64; 0 none.  Measured on MI355X (8K 10-bit
@@ -1410,7 +1383,7 @@ struct Dav1dHipReconList {
 // 8x8: 76 against 84; 16x16: 90 against 79, 32x32: 101 against 69: the fused wave carries the LDS and registers of both
 // bodies); what pays is that the paired launches move a quarter less HBM traffic AND run next to the pipelined launches of
 // the other sizes on streams of their own.
-static int recon_fuse_mask() {
+int recon_fuse_mask() {
     const char *e = getenv("DAV1D_HIP_RECON_FUSE");
     return (e ? atoi(e) : RECON_FUSE_DEFAULT) & 31;
 }

@@ -1,0 +1,457 @@
+// Per-tile-sbrow preparation of the reconstruction lists, done on the SUBMITTING thread.
+//
+// Round 1 built the device lists of a frame inside dav1d_hip_frame_end(): validation, fusing compound pairs, cutting blocks
+// into tiles, binning, ordering, pairing, the dependency map and the upload, single-threaded, 0.16 us per task — 0.2 s for an
+// 8K frame that the device reconstructs in 0.3 ms.  Here the same work happens per chunk (the tasks of one
+// dav1d_hip_frame_submit_tile_sbrow() call) on whatever worker thread submits it — dav1d's pass-2 workers run tile-sbrows in
+// parallel (src/thread_task.c:733-752) — the finished chunk goes to pinned memory and is uploaded at once on a copy stream,
+// and frame_end() only has to (1) add up the per-bin counts, (2) launch one gather kernel that lines the chunks' segments up
+// into contiguous per-bin arrays, (3) launch the frame.  Everything a chunk needs to know about other chunks is nothing: the
+// tasks of a tile-sbrow write a rectangle of their own, so fusing, pairing and the prediction -> residual dependencies are
+// local to it.
+#include "capi.h"
+#include "lists.h"
+#include "chunk.h"
+#include <string.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <unordered_map>
+#include <new>
+
+uint64_t dav1d_hip_mc_geo_sig(const DevPlanes *rp, int n_refs);       // capi.hip: the key mc_regroup() remembers a grouping by
+
+namespace {
+
+// ------------------------------------------------------------------ pinned slabs, recycled through the context
+
+uint8_t *slab_get(Dav1dHipContext *c, size_t bytes, size_t *cap) {
+    {
+        std::lock_guard<std::mutex> lk(c->pool_mtx);
+        for (size_t i = 0; i < c->free_slabs.size(); i++)
+            if (c->free_slabs[i].cap >= bytes) {
+                const Dav1dHipContext::Slab s = c->free_slabs[i];
+                c->free_slabs[i] = c->free_slabs.back();
+                c->free_slabs.pop_back();
+                *cap = s.cap;
+                return s.host;
+            }
+    }
+    size_t want = 1 << 18;
+    while (want < bytes) want <<= 1;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, want, 0) != hipSuccess) return nullptr;
+    *cap = want;
+    return (uint8_t *) p;
+}
+
+void slab_put(Dav1dHipContext *c, uint8_t *host, size_t cap) {
+    if (!host) return;
+    std::lock_guard<std::mutex> lk(c->pool_mtx);
+    c->free_slabs.push_back({ host, cap });
+}
+
+inline uint64_t src_key(const McTile &t) {
+    const McRef &r = t.r[0];
+    const uint64_t y = (uint64_t) (r.src_y + 4096) & 0xffff, x = (uint64_t) (r.src_x + 4096) & 0xffff;
+    return ((uint64_t) r.ref << 56) | ((uint64_t) t.plane << 52) | ((y >> 6) << 32) | x;
+}
+
+// a plane-local map of 4x4 cells over the bounding box of a chunk's destination rectangles
+struct CellMap {
+    int x0, y0, w, h, stride;       // in cells; stride of the PLANE in pixels
+    std::vector<uint16_t> writers;  // bit b: the prediction launch of tile shape b writes the cell; bit 15: the compound / blend launch
+    std::vector<uint8_t> blend;     // a blend task writes the cell
+    bool empty() const { return w <= 0 || h <= 0; }
+    template <typename F> void each(uint32_t off, int bw, int bh, F f) {
+        const int px = (int) (off % (uint32_t) stride), py = (int) (off / (uint32_t) stride);
+        for (int cy = py >> 2; cy <= (py + bh - 1) >> 2; cy++)
+            for (int cx = px >> 2; cx <= (px + bw - 1) >> 2; cx++) {
+                if (cx < x0 || cy < y0 || cx >= x0 + w || cy >= y0 + h) continue;
+                f((size_t) (cy - y0) * w + (cx - x0));
+            }
+    }
+};
+
+} // namespace
+
+void Dav1dHipChunk::release(Dav1dHipContext *c) {
+    slab_put(c, host, cap);
+    host = nullptr;
+}
+
+// Everything dav1d_hip_recon_list_create() does for a whole frame, for the tasks of one tile-sbrow.
+int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHipPicture *geom, const Dav1dHipPicture *refs, int n_refs,
+                          const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
+                          const Dav1dHipItxTask *itx, size_t n_itx)
+{
+    *out = nullptr;
+    const int bps = geom->bpc > 8 ? 2 : 1;
+    int stride[3];
+    for (int p = 0; p < 3; p++) stride[p] = geom->p[p].data ? (int) (geom->p[p].stride / bps) : 0;
+    // ---- validation (what the list creators check)
+    for (size_t i = 0; i < n_mc; i++) if (!mc_task_valid(mc[i]) || !stride[mc[i].plane] || (mc[i].kind != DAV1D_HIP_MC_PUT_TMP && mc[i].kind > DAV1D_HIP_MC_PREP)) return -EINVAL;
+    for (size_t i = 0; i < n_comp; i++) {
+        const Dav1dHipCompTask &t = comp[i];
+        if (t.kind > 6 || t.plane > 2 || !stride[t.plane] || t.ss > 2 || t.w > 128 || t.h > 128 || t.w < 2 || t.h < 2 ||
+            (t.kind <= 3 && (t.w < 4 || t.h < 4 || (t.w & 1) || (t.h & 1)))) return -EINVAL;
+    }
+    for (size_t i = 0; i < n_itx; i++) if (!itx_task_ok(itx[i]) || !stride[itx[i].plane]) return -EINVAL;
+
+    static const uint8_t tx_w[19] = { 4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64 };
+    static const uint8_t tx_h[19] = { 4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16 };
+
+    // ---- bounding boxes of what the chunk writes, per plane, in 4x4 cells
+    CellMap cm[3];
+    for (int p = 0; p < 3; p++) { cm[p].x0 = cm[p].y0 = 1 << 30; cm[p].w = cm[p].h = 0; cm[p].stride = stride[p]; }
+    int x1[3] = { -1, -1, -1 }, y1[3] = { -1, -1, -1 };
+    auto grow = [&](int p, uint32_t off, int bw, int bh) {
+        const int px = (int) (off % (uint32_t) stride[p]), py = (int) (off / (uint32_t) stride[p]);
+        cm[p].x0 = std::min(cm[p].x0, px >> 2); cm[p].y0 = std::min(cm[p].y0, py >> 2);
+        x1[p] = std::max(x1[p], (px + bw - 1) >> 2); y1[p] = std::max(y1[p], (py + bh - 1) >> 2);
+    };
+    for (size_t i = 0; i < n_mc; i++) if (mc[i].kind == DAV1D_HIP_MC_PUT) grow(mc[i].plane, mc[i].dst_off, mc[i].w, mc[i].h);
+    for (size_t i = 0; i < n_comp; i++) grow(comp[i].plane, comp[i].dst_off, comp[i].w, comp[i].h);
+    for (size_t i = 0; i < n_itx; i++) grow(itx[i].plane, itx[i].dst_off, tx_w[itx[i].tx], tx_h[itx[i].tx]);
+    bool any_blend = false;
+    for (size_t i = 0; i < n_comp && !any_blend; i++) any_blend = comp[i].kind >= DAV1D_HIP_COMP_BLEND;
+    for (int p = 0; p < 3; p++) {
+        if (x1[p] < 0) { cm[p].w = cm[p].h = 0; continue; }
+        cm[p].w = x1[p] - cm[p].x0 + 1; cm[p].h = y1[p] - cm[p].y0 + 1;
+        cm[p].writers.assign((size_t) cm[p].w * cm[p].h, 0);
+        if (any_blend) cm[p].blend.assign((size_t) cm[p].w * cm[p].h, 0);
+    }
+    if (any_blend)
+        for (size_t i = 0; i < n_comp; i++)
+            if (comp[i].kind >= DAV1D_HIP_COMP_BLEND) {
+                CellMap &m = cm[comp[i].plane];
+                m.each(comp[i].dst_off, comp[i].w, comp[i].h, [&](size_t k) { m.blend[k] = 1; });
+            }
+
+    // ---- pairing: a square transform block that covers exactly one prediction block runs with it in one wave (recon.hip)
+    const int fuse_mask = recon_fuse_mask();
+    std::unordered_map<uint64_t, uint32_t> tx_at;
+    std::vector<char> taken(n_itx, 0);
+    if (fuse_mask) {
+        tx_at.reserve(n_itx);
+        for (size_t i = 0; i < n_itx; i++)
+            if (itx[i].tx <= 4 && (fuse_mask >> itx[i].tx & 1)) tx_at[(uint64_t) itx[i].plane << 32 | itx[i].dst_off] = (uint32_t) i;
+    }
+    std::vector<McTile> p_tiles[5];
+    std::vector<uint32_t> p_itx[5];
+    auto find_pair = [&](int plane, uint32_t off, int bw, int bh) -> long {
+        if (!fuse_mask || bw != bh) return -1;
+        auto it = tx_at.find((uint64_t) plane << 32 | off);
+        if (it == tx_at.end() || taken[it->second]) return -1;
+        const Dav1dHipItxTask &t = itx[it->second];
+        if (!(t.tx <= 4 && (4 << t.tx) == bw)) return -1;
+        if (any_blend) {           // OBMC: prediction, blends, THEN the residual (src/recon_tmpl.c:1052-1112)
+            bool hit = false;
+            CellMap &m = cm[plane];
+            m.each(off, bw, bh, [&](size_t k) { hit |= m.blend[k] != 0; });
+            if (hit) return -1;
+        }
+        return (long) it->second;
+    };
+
+    // ---- compound pairs whose two PREP blocks nothing else reads are predicted twice and combined in registers
+    std::unordered_map<uint32_t, uint32_t> producer;
+    std::unordered_map<uint32_t, int> readers;
+    if (n_comp) {
+        producer.reserve(n_mc);
+        for (size_t i = 0; i < n_mc; i++) if (mc[i].kind == DAV1D_HIP_MC_PREP) producer[mc[i].dst_off] = (uint32_t) i;
+        readers.reserve(2 * n_comp);
+        for (size_t i = 0; i < n_comp; i++) if (comp[i].kind <= DAV1D_HIP_COMP_WMASK) { readers[comp[i].tmp1_off]++; readers[comp[i].tmp2_off]++; }
+    }
+    std::vector<char> fused_prep(n_mc, 0);
+    std::vector<Dav1dHipCompTask> rest;
+    std::vector<McTile> bins[MC_BINS];
+    for (size_t i = 0; i < n_comp; i++) {
+        const Dav1dHipCompTask &k = comp[i];
+        bool fuse = k.kind == DAV1D_HIP_COMP_AVG || k.kind == DAV1D_HIP_COMP_WAVG;
+        uint32_t a = 0, b = 0;
+        if (fuse) {
+            auto pa = producer.find(k.tmp1_off), pb = producer.find(k.tmp2_off);
+            fuse = pa != producer.end() && pb != producer.end() && k.tmp1_off != k.tmp2_off && readers[k.tmp1_off] == 1 && readers[k.tmp2_off] == 1;
+            if (fuse) {
+                a = pa->second; b = pb->second;
+                fuse = mc[a].w == k.w && mc[a].h == k.h && mc[b].w == k.w && mc[b].h == k.h && mc[a].plane == k.plane && mc[b].plane == k.plane;
+            }
+        }
+        if (fuse) {
+            const long j = find_pair(k.plane, k.dst_off, k.w, k.h);
+            if (j >= 0) { taken[j] = 1; p_itx[itx[j].tx].push_back((uint32_t) j); }
+            push_tiles(bins, mc[a], k.kind == DAV1D_HIP_COMP_AVG ? MCT_AVG : MCT_WAVG, k.dst_off, &mc[b], k.arg, j >= 0 ? &p_tiles[itx[j].tx] : nullptr);
+            fused_prep[a] = fused_prep[b] = 1;
+        } else {
+            rest.push_back(k);
+        }
+    }
+    for (size_t i = 0; i < n_mc; i++)
+        if (!fused_prep[i]) {
+            const long j = mc[i].kind == DAV1D_HIP_MC_PUT ? find_pair(mc[i].plane, mc[i].dst_off, mc[i].w, mc[i].h) : -1;
+            if (j >= 0) { taken[j] = 1; p_itx[itx[j].tx].push_back((uint32_t) j); }
+            push_tiles(bins, mc[i], mc[i].kind == DAV1D_HIP_MC_PUT ? MCT_PUT : mc[i].kind == DAV1D_HIP_MC_PREP ? MCT_PREP : MCT_PUT_TMP,
+                       mc[i].dst_off, nullptr, 0, j >= 0 ? &p_tiles[itx[j].tx] : nullptr);
+        }
+
+    Dav1dHipChunk *ck = new (std::nothrow) Dav1dHipChunk();
+    if (!ck) return -ENOMEM;
+    memset(ck->seg, 0, sizeof(ck->seg));
+    memset(ck->dep, 0, sizeof(ck->dep));
+    ck->max_ref = 0; ck->host = nullptr; ck->cap = ck->used = 0; ck->dev_off = 0;
+    ck->order = ~0ull;
+
+    // ---- who writes which cell, then: which prediction launches each residual size has to wait for
+    for (int b = 0; b < MC_BINS; b++)
+        for (const McTile &t : bins[b])
+            if (t.kind == MCT_PUT || t.kind == MCT_AVG || t.kind == MCT_WAVG) {
+                CellMap &m = cm[t.plane];
+                m.each(t.dst_off + (uint32_t) t.oy * (uint32_t) stride[t.plane] + t.ox, t.w, t.h, [&](size_t k) { m.writers[k] |= (uint16_t) (1u << b); });
+            }
+    for (const Dav1dHipCompTask &k : rest) { CellMap &m = cm[k.plane]; m.each(k.dst_off, k.w, k.h, [&](size_t q) { m.writers[q] |= 1u << 15; }); }
+    std::vector<Dav1dHipItxTask> ibins[19];
+    for (size_t i = 0; i < n_itx; i++) {
+        const Dav1dHipItxTask &t = itx[i];
+        ck->order = std::min(ck->order, (uint64_t) t.plane << 40 | t.dst_off);
+        if (taken[i]) continue;
+        CellMap &m = cm[t.plane];
+        uint16_t d = 0;
+        m.each(t.dst_off, tx_w[t.tx], tx_h[t.tx], [&](size_t k) { d |= m.writers[k]; });
+        ck->dep[t.tx] |= d;
+        ibins[t.tx].push_back(t);
+        itx_fill_prefix(ibins[t.tx].back());
+    }
+    for (size_t i = 0; i < n_mc; i++) if (mc[i].kind == DAV1D_HIP_MC_PUT) ck->order = std::min(ck->order, (uint64_t) mc[i].plane << 40 | mc[i].dst_off);
+
+    // ---- order inside the chunk.  Predictions: by where they read (reference, plane, 64-row band, x), then inside windows of
+    // 128 waves' worth by (leaves the reference plane, kind) so that the tiles of a wave share their code path.  Residuals:
+    // inside windows by code path (dc-only, 1-D kinds).  Speed only: the tasks of a chunk write disjoint pixels.
+    DevPlanes rp[8];
+    for (int i = 0; i < n_refs; i++) rp[i] = dev_planes(&refs[i]);
+    static const int mc_win = getenv("DAV1D_HIP_MC_GROUP_WINDOW") ? atoi(getenv("DAV1D_HIP_MC_GROUP_WINDOW")) : 128;
+    static const int itx_win = getenv("DAV1D_HIP_ITX_SORT_WINDOW") ? atoi(getenv("DAV1D_HIP_ITX_SORT_WINDOW")) : 128;
+    for (int b = 0; b < MC_BINS; b++) {
+        std::vector<McTile> &v = bins[b];
+        if (v.empty()) continue;
+        std::stable_sort(v.begin(), v.end(), [](const McTile &p, const McTile &q) { return src_key(p) < src_key(q); });
+        const int tw = 4 << (b / 3), th = 4 << (b % 3);
+        const int lanes = tw * th / 4 < 64 ? tw * th / 4 : 64;
+        if (mc_win > 0 && 64 / lanes >= 2 && n_refs) {
+            const int ws = tw == 4 ? 12 : (tw + 8 + 7) & ~7, ext_x = (ws + 7) / 8 * 8, ext_y = th + 7;
+            auto key = [&](const McTile &t) -> int {
+                const bool two = t.kind == MCT_AVG || t.kind == MCT_WAVG;
+                bool edge = false;
+                for (int k = 0; k < (two ? 2 : 1); k++) {
+                    const McRef &r = t.r[k];
+                    if (r.ref >= n_refs) continue;
+                    const int xx = r.src_x - 4, yy = r.src_y - 3;
+                    edge |= xx < 0 || yy < 0 || xx + ext_x > rp[r.ref].w[t.plane] || yy + ext_y > rp[r.ref].h[t.plane];
+                }
+                return (edge ? 8 : 0) | t.kind;
+            };
+            const size_t win = (size_t) mc_win * (size_t) (64 / lanes);
+            for (size_t lo = 0; lo < v.size(); lo += win)
+                std::stable_sort(v.begin() + lo, v.begin() + std::min(lo + win, v.size()), [&](const McTile &p, const McTile &q) { return key(p) < key(q); });
+        }
+        for (const McTile &t : v) {
+            const bool two = t.kind == MCT_AVG || t.kind == MCT_WAVG;
+            ck->max_ref = std::max(ck->max_ref, std::max((int) t.r[0].ref, two ? (int) t.r[1].ref : 0));
+        }
+    }
+    if (itx_win > 0)
+        for (int b = 0; b < 19; b++) {
+            std::vector<Dav1dHipItxTask> &v = ibins[b];
+            const int lanes = std::max(std::min((int) tx_h[b], 32), (int) tx_w[b]);
+            const size_t win = (size_t) itx_win * (size_t) std::max(1, 64 / lanes);
+            for (size_t lo = 0; lo < v.size(); lo += win)
+                std::stable_sort(v.begin() + lo, v.begin() + std::min(lo + win, v.size()),
+                                 [](const Dav1dHipItxTask &p, const Dav1dHipItxTask &q) { return itx_path_key(p) < itx_path_key(q); });
+        }
+    // paired blocks: by where the first tile reads, then by (transform code path, prediction kind) inside windows
+    std::vector<McTile> pt_sorted[5];
+    std::vector<Dav1dHipItxTask> pk_sorted[5];
+    for (int k = 0; k < 5; k++) {
+        const size_t nblk = p_itx[k].size();
+        if (!nblk) continue;
+        const int tpb = k < 3 ? 1 : k == 3 ? 2 : 4, bpw = k == 0 ? 16 : k == 1 ? 8 : k == 2 ? 4 : k == 3 ? 2 : 1;
+        if (p_tiles[k].size() != nblk * tpb) { delete ck; return -EINVAL; }
+        std::vector<uint32_t> ord(nblk);
+        for (size_t i = 0; i < nblk; i++) ord[i] = (uint32_t) i;
+        std::stable_sort(ord.begin(), ord.end(), [&](uint32_t p, uint32_t q) { return src_key(p_tiles[k][(size_t) p * tpb]) < src_key(p_tiles[k][(size_t) q * tpb]); });
+        const size_t win = (size_t) 128 * bpw;
+        for (size_t lo = 0; lo < nblk; lo += win)
+            std::stable_sort(ord.begin() + lo, ord.begin() + std::min(lo + win, nblk), [&](uint32_t p, uint32_t q) {
+                const int kp = itx_path_key(itx[p_itx[k][p]]) * 8 + p_tiles[k][(size_t) p * tpb].kind;
+                const int kq = itx_path_key(itx[p_itx[k][q]]) * 8 + p_tiles[k][(size_t) q * tpb].kind;
+                return kp < kq;
+            });
+        pt_sorted[k].resize(nblk * tpb);
+        pk_sorted[k].resize(nblk);
+        for (size_t i = 0; i < nblk; i++) {
+            for (int j = 0; j < tpb; j++) {
+                const McTile &t = pt_sorted[k][i * tpb + j] = p_tiles[k][(size_t) ord[i] * tpb + j];
+                const bool two = t.kind == MCT_AVG || t.kind == MCT_WAVG;
+                ck->max_ref = std::max(ck->max_ref, std::max((int) t.r[0].ref, two ? (int) t.r[1].ref : 0));
+            }
+            pk_sorted[k][i] = itx[p_itx[k][ord[i]]];
+            itx_fill_prefix(pk_sorted[k][i]);
+        }
+    }
+    // compound / blend tasks: BLEND_V and the MASK tasks that read a mask a W_MASK task of the chunk writes go second
+    std::vector<Dav1dHipCompTask> c_first, c_second;
+    {
+        std::unordered_map<uint32_t, char> wmask_out;
+        for (const Dav1dHipCompTask &t : rest) if (t.kind == DAV1D_HIP_COMP_WMASK) wmask_out[t.mask_off] = 1;
+        for (const Dav1dHipCompTask &t : rest)
+            ((t.kind == DAV1D_HIP_COMP_BLEND_V || (t.kind == DAV1D_HIP_COMP_MASK && wmask_out.count(t.mask_off))) ? c_second : c_first).push_back(t);
+    }
+
+    // ---- one pinned blob: [mc bins][itx bins][paired tiles][paired residuals][comp first][comp second], 16-byte aligned segments
+    size_t total = 0;
+    auto place = [&](int id, size_t n, size_t esz) { ck->seg[id].off = (uint32_t) total; ck->seg[id].n = (uint32_t) n; total += (n * esz + 15) & ~(size_t) 15; };
+    for (int b = 0; b < MC_BINS; b++) place(CK_MC + b, bins[b].size(), sizeof(McTile));
+    for (int b = 0; b < 19; b++) place(CK_ITX + b, ibins[b].size(), sizeof(Dav1dHipItxTask));
+    for (int k = 0; k < 5; k++) place(CK_PTILE + k, pt_sorted[k].size(), sizeof(McTile));
+    for (int k = 0; k < 5; k++) place(CK_PTASK + k, pk_sorted[k].size(), sizeof(Dav1dHipItxTask));
+    place(CK_COMP, c_first.size(), sizeof(Dav1dHipCompTask));
+    place(CK_COMP + 1, c_second.size(), sizeof(Dav1dHipCompTask));
+    ck->used = total;
+    if (total) {
+        ck->host = slab_get(c, total, &ck->cap);
+        if (!ck->host) { delete ck; return -ENOMEM; }
+        auto put = [&](int id, const void *src, size_t esz) { if (ck->seg[id].n) memcpy(ck->host + ck->seg[id].off, src, (size_t) ck->seg[id].n * esz); };
+        for (int b = 0; b < MC_BINS; b++) put(CK_MC + b, bins[b].data(), sizeof(McTile));
+        for (int b = 0; b < 19; b++) put(CK_ITX + b, ibins[b].data(), sizeof(Dav1dHipItxTask));
+        for (int k = 0; k < 5; k++) put(CK_PTILE + k, pt_sorted[k].data(), sizeof(McTile));
+        for (int k = 0; k < 5; k++) put(CK_PTASK + k, pk_sorted[k].data(), sizeof(Dav1dHipItxTask));
+        put(CK_COMP, c_first.data(), sizeof(Dav1dHipCompTask));
+        put(CK_COMP + 1, c_second.data(), sizeof(Dav1dHipCompTask));
+    }
+    *out = ck;
+    return 0;
+}
+
+// ------------------------------------------------------------------ gather: chunk segments -> contiguous per-bin arrays
+
+namespace {
+struct GatherSeg { uint32_t src, dst, words, pad; };          // byte offsets in the chunk arena / the gathered arena, length in 32-bit words
+
+__global__ __launch_bounds__(256) void gather_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const GatherSeg *__restrict__ segs, const int n)
+{
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const GatherSeg s = segs[i];
+    const uint32_t *const a = reinterpret_cast<const uint32_t *>(src + s.src);
+    uint32_t *const d = reinterpret_cast<uint32_t *>(dst + s.dst);
+    for (uint32_t k = threadIdx.x; k < s.words; k += 256) d[k] = a[k];
+}
+} // namespace
+
+static int ensure_dev(uint8_t **p, size_t *cap, size_t want, hipStream_t sync_on) {
+    if (*cap >= want) return 0;
+    if (*p) { (void) hipStreamSynchronize(sync_on); (void) hipFree(*p); *p = nullptr; *cap = 0; }
+    size_t n = 1 << 22;
+    while (n < want) n <<= 1;
+    if (hipMalloc((void **) p, n) != hipSuccess) return -ENOMEM;
+    *cap = n;
+    return 0;
+}
+
+// Uploads the chunks (one copy each, on the context's copy stream), lines their segments up per bin with one gather launch and
+// fills the caller-provided list objects with views of the gathered arrays.  The lists own nothing (never destroy them).
+int dav1d_hip_chunks_to_recon_list(Dav1dHipContext *c, std::vector<Dav1dHipChunk *> &chunks, const Dav1dHipPicture *refs, int n_refs,
+                                   Dav1dHipReconList *l, Dav1dHipInterList *il, Dav1dHipMcList *ml, Dav1dHipCompList *cl, Dav1dHipItxList *xl)
+{
+    std::sort(chunks.begin(), chunks.end(), [](const Dav1dHipChunk *a, const Dav1dHipChunk *b) { return a->order < b->order; });
+    size_t esz[CK_N];
+    for (int a = 0; a < CK_N; a++) esz[a] = sizeof(Dav1dHipItxTask);
+    for (int b = 0; b < MC_BINS; b++) esz[CK_MC + b] = sizeof(McTile);
+    for (int k = 0; k < 5; k++) esz[CK_PTILE + k] = sizeof(McTile);
+    esz[CK_COMP] = esz[CK_COMP + 1] = sizeof(Dav1dHipCompTask);
+    size_t cnt[CK_N] = { 0 }, src_total = 0;
+    for (Dav1dHipChunk *ck : chunks) {
+        for (int a = 0; a < CK_N; a++) cnt[a] += ck->seg[a].n;
+        ck->dev_off = src_total;
+        src_total += (ck->used + 255) & ~(size_t) 255;
+    }
+    // gathered layout: the 15 prediction bins back to back, the 19 residual bins back to back, every paired array on its own,
+    // the two compound runs back to back; each group starts 256-byte aligned
+    size_t aoff[CK_N], end = 0;
+    auto group = [&](int first, int n) {
+        end = (end + 255) & ~(size_t) 255;
+        for (int a = first; a < first + n; a++) { aoff[a] = end; end += cnt[a] * esz[a]; }
+    };
+    group(CK_MC, MC_BINS);
+    group(CK_ITX, 19);
+    for (int k = 0; k < 5; k++) group(CK_PTILE + k, 1);
+    for (int k = 0; k < 5; k++) group(CK_PTASK + k, 1);
+    group(CK_COMP, 2);
+    int rc = ensure_dev(&c->chunk_dev, &c->chunk_dev_cap, src_total + 256, c->stream);
+    if (!rc) rc = ensure_dev(&c->gather_dev, &c->gather_cap, end + 256, c->stream);
+    if (rc) return rc;
+    size_t n_seg = 0;
+    for (Dav1dHipChunk *ck : chunks) for (int a = 0; a < CK_N; a++) n_seg += ck->seg[a].n != 0;
+    size_t tab_cap = 0;
+    uint8_t *tab_host = n_seg ? slab_get(c, n_seg * sizeof(GatherSeg), &tab_cap) : nullptr;
+    if (n_seg && !tab_host) return -ENOMEM;
+    rc = ensure_dev(&c->segtab_dev, &c->segtab_cap, n_seg * sizeof(GatherSeg) + 256, c->stream);
+    if (rc) { slab_put(c, tab_host, tab_cap); return rc; }
+    GatherSeg *tab = reinterpret_cast<GatherSeg *>(tab_host);
+    size_t run[CK_N] = { 0 }, k = 0;
+    for (Dav1dHipChunk *ck : chunks)
+        for (int a = 0; a < CK_N; a++)
+            if (ck->seg[a].n) {
+                tab[k].src = (uint32_t) (ck->dev_off + ck->seg[a].off);
+                tab[k].dst = (uint32_t) (aoff[a] + run[a] * esz[a]);
+                tab[k].words = (uint32_t) (ck->seg[a].n * esz[a] / 4);
+                tab[k].pad = 0;
+                run[a] += ck->seg[a].n;
+                k++;
+            }
+    // uploads on the copy stream (the context's stream may still be busy with the frame before), then the gather behind them
+    for (Dav1dHipChunk *ck : chunks)
+        if (ck->used && !rc) rc = hip_rc(hipMemcpyAsync(c->chunk_dev + ck->dev_off, ck->host, ck->used, hipMemcpyHostToDevice, c->copy_stream));
+    if (!rc && n_seg) rc = hip_rc(hipMemcpyAsync(c->segtab_dev, tab_host, n_seg * sizeof(GatherSeg), hipMemcpyHostToDevice, c->copy_stream));
+    if (!rc) rc = hip_rc(hipEventRecord(c->ev_copy, c->copy_stream));
+    if (!rc) rc = hip_rc(hipStreamWaitEvent(c->stream, c->ev_copy, 0));
+    if (!rc && n_seg) {
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned) n_seg), dim3(256), 0, c->stream, c->chunk_dev, c->gather_dev,
+                           reinterpret_cast<const GatherSeg *>(c->segtab_dev), (int) n_seg);
+        rc = hip_rc(hipGetLastError());
+    }
+    c->pending_slab = tab_host; c->pending_slab_cap = tab_cap;      // recycled once the frame has synchronised
+    if (rc) return rc;
+
+    // ---- the list views
+    memset(static_cast<void *>(ml), 0, sizeof(*ml));
+    ml->dev = reinterpret_cast<McTile *>(c->gather_dev + aoff[CK_MC]);
+    for (int b = 0; b < MC_BINS; b++) ml->off[b + 1] = ml->off[b] + cnt[CK_MC + b];
+    ml->n = ml->off[MC_BINS];
+    DevPlanes rp[8];
+    for (int i = 0; i < n_refs; i++) rp[i] = dev_planes(&refs[i]);
+    ml->geo_sig = dav1d_hip_mc_geo_sig(rp, n_refs);      // the chunks grouped their tiles for this geometry already
+    cl->dev = reinterpret_cast<Dav1dHipCompTask *>(c->gather_dev + aoff[CK_COMP]);
+    cl->n_first = cnt[CK_COMP];
+    cl->n = cnt[CK_COMP] + cnt[CK_COMP + 1];
+    memset(static_cast<void *>(xl), 0, sizeof(*xl));
+    xl->dev = reinterpret_cast<Dav1dHipItxTask *>(c->gather_dev + aoff[CK_ITX]);
+    for (int b = 0; b < 19; b++) xl->off[b + 1] = xl->off[b] + cnt[CK_ITX + b];
+    xl->n = xl->off[19];
+    il->mc = ml; il->comp = cl; il->n_fused = 0;
+    for (int p = 0; p < 3; p++) il->cell_stride[p] = il->stride_px[p] = 0;
+    l->inter = il; l->itx = xl;
+    l->f_max_ref = 0;
+    for (int b = 0; b < 19; b++) l->dep[b] = 0;
+    for (Dav1dHipChunk *ck : chunks) {
+        for (int b = 0; b < 19; b++) l->dep[b] |= ck->dep[b];
+        ml->max_ref = std::max(ml->max_ref, ck->max_ref);
+        l->f_max_ref = std::max(l->f_max_ref, ck->max_ref);
+    }
+    for (int q = 0; q < 5; q++) {
+        l->f_n[q] = cnt[CK_PTASK + q];
+        l->f_tiles[q] = cnt[CK_PTILE + q] ? reinterpret_cast<McTile *>(c->gather_dev + aoff[CK_PTILE + q]) : nullptr;
+        l->f_tasks[q] = cnt[CK_PTASK + q] ? reinterpret_cast<Dav1dHipItxTask *>(c->gather_dev + aoff[CK_PTASK + q]) : nullptr;
+    }
+    for (int p = 0; p < 3; p++) l->stride_px[p] = 0;        // the frame's own picture: no geometry to re-check at run time
+    return 0;
+}

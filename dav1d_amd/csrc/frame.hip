@@ -5,6 +5,7 @@
 //   inter prediction (+ fused compounds) -> residuals -> deblock (cols, rows) -> CDEF -> loop restoration -> film grain.
 // Out-of-place stages land in pictures the frame owns; host code only: every kernel is reached through the batch API.
 #include "capi.h"
+#include "chunk.h"
 #include <string.h>
 #include <stdlib.h>
 #include <mutex>
@@ -17,9 +18,7 @@ struct Dav1dHipFrame {
     Dav1dHipPicture refs[8];
     int n_refs;
     std::mutex mtx;
-    std::vector<Dav1dHipMcTask> mc;
-    std::vector<Dav1dHipCompTask> comp;
-    std::vector<Dav1dHipItxTask> itx;
+    std::vector<Dav1dHipChunk *> chunks;    // the tile-sbrows' inter predictions + residuals, preprocessed by their submitters (chunk.hip)
     // intra blocks: step k of the wavefront = the blocks whose neighbours are final after steps 0 .. k - 1 (and after the
     // inter blocks of the frame); predictions and residuals per step
     std::vector<std::vector<Dav1dHipIpredTask>> ipred;
@@ -230,10 +229,14 @@ int dav1d_hip_frame_begin(Dav1dHipContext *c, Dav1dHipFrame **out, const Dav1dHi
 int dav1d_hip_frame_submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
                                       const Dav1dHipItxTask *itx, size_t n_itx) {
     if (!f || (!mc && n_mc) || (!comp && n_comp) || (!itx && n_itx)) return -EINVAL;
+    if (!n_mc && !n_comp && !n_itx) return 0;
+    if ((n_mc || n_comp) && !f->n_refs) return -EINVAL;
+    // all the list preparation of this tile-sbrow happens here, on the submitting thread, without the frame's lock
+    Dav1dHipChunk *ck = nullptr;
+    const int rc = dav1d_hip_chunk_build(f->c, &ck, &f->cur, f->refs, f->n_refs, mc, n_mc, comp, n_comp, itx, n_itx);
+    if (rc) return rc;
     std::lock_guard<std::mutex> lk(f->mtx);
-    f->mc.insert(f->mc.end(), mc, mc + n_mc);
-    f->comp.insert(f->comp.end(), comp, comp + n_comp);
-    f->itx.insert(f->itx.end(), itx, itx + n_itx);
+    f->chunks.push_back(ck);
     return 0;
 }
 
@@ -342,26 +345,54 @@ static int copy_picture(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Da
 // the frame, valid until dav1d_hip_frame_destroy); when film grain parameters were set and `grain_out` is given, the grain
 // is applied from *filtered into grain_out (dav1d_apply_grain, src/lib.c:311-329).  Synchronous: every stage has
 // completed on return, so the caller can publish progress the way src/thread_task.c:888-896 does.
+static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask, Dav1dHipPicture *filtered, const Dav1dHipPicture *grain_out);
+
 int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask, Dav1dHipPicture *filtered, const Dav1dHipPicture *grain_out) {
     if (!f) return -EINVAL;
     std::lock_guard<std::mutex> lk(f->mtx);
+    Dav1dHipContext *c = f->c;
+    // the multi-stream sections below use the context's side streams and events: one frame (or list run) at a time per context
+    std::lock_guard<std::mutex> run_lk(c->run_mtx);
+    const int rc_run = frame_run(f, coef, prep, mask, filtered, grain_out);
+    // the frame has synchronised (or failed): the pinned chunk blobs go back to the context's pool
+    (void) hipStreamSynchronize(c->copy_stream);
+    for (Dav1dHipChunk *ck : f->chunks) { ck->release(c); delete ck; }
+    f->chunks.clear();
+    if (c->pending_slab) {
+        std::lock_guard<std::mutex> pl(c->pool_mtx);
+        c->free_slabs.push_back({ c->pending_slab, c->pending_slab_cap });
+        c->pending_slab = nullptr;
+    }
+    return rc_run;
+}
+
+} // extern "C"
+
+static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask, Dav1dHipPicture *filtered, const Dav1dHipPicture *grain_out) {
     Dav1dHipContext *c = f->c;
     int rc = 0;
     // warped / scaled predictions first: the compound combinations of the list below read their PREP outputs
     if (!f->warp.empty()) rc = dav1d_hip_warp_batch(c, &f->cur, f->refs, f->n_refs, f->warp.data(), f->warp.size(), prep);
     if (!rc && !f->scaled.empty()) rc = dav1d_hip_mc_scaled_batch(c, &f->cur, f->refs, f->n_refs, f->scaled.data(), f->scaled.size(), prep);
     if (rc) return rc;
-    if (!f->mc.empty() || !f->comp.empty()) {
+    if (!f->chunks.empty()) {
         // predictions and residuals as one pipelined list (the residual launch of a transform size waits only for the
-        // prediction launches under its blocks)
-        if (!f->n_refs) return -EINVAL;
-        Dav1dHipReconList *rl = nullptr;
-        rc = dav1d_hip_recon_list_create(c, &rl, &f->cur, f->mc.data(), f->mc.size(), f->comp.data(), f->comp.size(),
-                                         f->itx.data(), f->itx.size());
-        if (!rc) rc = dav1d_hip_recon_list_run(c, rl, &f->cur, f->refs, f->n_refs, prep, mask, coef);
-        if (rl) dav1d_hip_recon_list_destroy(c, rl);
-    } else if (!f->itx.empty()) {
-        rc = dav1d_hip_itx_add_batch(c, &f->cur, f->itx.data(), f->itx.size(), coef);
+        // prediction launches under its blocks), assembled from the chunks the submitting threads prepared: one upload per
+        // chunk, one gather launch, then the frame's launches
+        Dav1dHipReconList rl;
+        Dav1dHipInterList il;
+        Dav1dHipMcList ml;
+        Dav1dHipCompList cl;
+        Dav1dHipItxList xl;
+        rc = dav1d_hip_chunks_to_recon_list(c, f->chunks, f->refs, f->n_refs, &rl, &il, &ml, &cl, &xl);
+        if (!rc) {
+            if (ml.n || cl.n || rl.f_n[0] || rl.f_n[1] || rl.f_n[2] || rl.f_n[3] || rl.f_n[4]) {
+                if (!f->n_refs) rc = -EINVAL;
+                else rc = dav1d_hip_recon_list_run(c, &rl, &f->cur, f->refs, f->n_refs, prep, mask, coef);
+            } else if (xl.n) {
+                rc = dav1d_hip_itx_list_run(c, &xl, &f->cur, coef);
+            }
+        }
     }
     // intra blocks, wavefront step by step (each step: a paired launch for the small blocks, a prediction and a residual
     // launch for the others), enqueued back to back
@@ -411,8 +442,11 @@ int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *ma
         rc = f->prepared ? dav1d_hip_fg_apply_prepared(c, grain_out, last, f->prepared, f->is_id)
                          : dav1d_hip_fg_apply(c, grain_out, last, &f->grain, f->is_id);
     if (!rc) rc = dav1d_hip_sync(c);
+    else (void) dav1d_hip_sync(c);
     return rc;
 }
+
+extern "C" {
 
 int dav1d_hip_frame_post_bands(const Dav1dHipFrame *f) { return f ? f->post_bands : 0; }
 
@@ -420,6 +454,7 @@ void dav1d_hip_frame_destroy(Dav1dHipFrame *f) {
     if (!f) return;
     (void) hipStreamSynchronize(f->c->stream);
     if (f->prepared) dav1d_hip_fg_grain_destroy(f->c, f->prepared);
+    for (Dav1dHipChunk *ck : f->chunks) { ck->release(f->c); delete ck; }
     for (int i = 0; i < 2; i++) if (f->have_tmp[i]) dav1d_hip_picture_free(f->c, &f->tmp[i]);
     delete f;
 }

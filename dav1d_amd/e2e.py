@@ -1,0 +1,187 @@
+"""End-to-end leg of the benchmark: hand-off arrays -> pass-2 lister (host threads) -> device.
+
+What the headline `value` of bench.py leaves out by definition (lists resident in HBM) is measured here: one synthetic 8K
+frame's pass-1 output (Av1Block / cbi / cf, dav1d_hip_synth_frame) is listed by dav1d_hip_lister_tile_sbrow() from a pool of
+host threads (one per tile, as dav1d's pass-2 workers would), every submit prepares its chunk of the device lists on the
+submitting thread, the coefficient arena crosses the host link, and dav1d_hip_frame_end() launches the frame.
+
+    python -m dav1d_amd.e2e [--frames N] [--threads T] [--tile-cols C]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import _lib, api
+
+SIZE_MUL = [(4, 4), (6, 5), (8, 6), (12, 8)]      # ss_size_mul, reference src/decode.c:2416-2421
+
+
+class HandOff:
+    """The per-frame arrays of dav1d's frame threading, sized as dav1d_decode_frame_init() sizes them
+    (reference src/decode.c:2839-2895, 3002-3015), as numpy buffers."""
+
+    def __init__(self, w, h, layout, bpc, sb128=True, tile_cols=1, tile_rows=1):
+        self.w, self.h, self.layout, self.bpc, self.sb128 = w, h, layout, bpc, sb128
+        hbd = bpc > 8
+        self.bw, self.bh = ((w + 7) >> 3) << 1, ((h + 7) >> 3) << 1
+        self.sb128w, self.sb128h = (self.bw + 31) >> 5, (self.bh + 31) >> 5
+        n = self.sb128w * self.sb128h
+        sm = SIZE_MUL[layout]
+        self.b = np.zeros(n * 32 * 32 * 32, np.uint8)
+        self.cbi = np.zeros(n * sm[0] * 32 * 32 // 4, np.int16)
+        self.cf = np.zeros(((n * sm[0]) << hbd) * 128 * 128 // 2, np.uint8)
+        sb = 128 if sb128 else 64
+        sbw, sbh = (w + sb - 1) // sb, (h + sb - 1) // sb
+        self.sbh = sbh
+
+        def uniform(n_sb, k):
+            k = max(1, min(k, n_sb))
+            size = (n_sb + k - 1) // k
+            return list(range(0, n_sb, size)) + [n_sb]
+        self.cols, self.rows = uniform(sbw, tile_cols), uniform(sbh, tile_rows)
+        # f->frame_thread.tile_start_off, src/decode.c:2803-2813
+        sb_step4 = (32 if sb128 else 16) * 4
+        tso = []
+        for tr in range(len(self.rows) - 1):
+            row_off = self.rows[tr] * sb_step4 * self.sb128w * 128
+            b_diff = (self.rows[tr + 1] - self.rows[tr]) * sb_step4
+            for tc in range(len(self.cols) - 1):
+                tso.append(row_off + b_diff * self.cols[tc] * sb_step4)
+        self.tile_start_off = np.array(tso, np.uint32)
+        d = _lib.FrameDesc()
+        d.w, d.h, d.layout, d.bpc, d.sb128, d.intra_edge_filter, d.is_inter = w, h, layout, bpc, int(sb128), 1, 1
+        d.n_tile_cols, d.n_tile_rows = len(self.cols) - 1, len(self.rows) - 1
+        for i, v in enumerate(self.cols):
+            d.col_start_sb[i] = v
+        for i, v in enumerate(self.rows):
+            d.row_start_sb[i] = v
+        d.b4_stride = (self.bw + 31) & ~31
+        d.b, d.cbi, d.tile_start_off = self.b.ctypes.data, self.cbi.ctypes.data, self.tile_start_off.ctypes.data
+        d.cf_align64 = 1
+        for i in range(7):
+            d.ref_w[i], d.ref_h[i] = w, h
+        self.desc = d
+
+
+def c2_params(seed, n_refs=3):
+    """SURVEY 8d config C2's itx+mc subset as generator settings: block mix 64 / 32 / 16 / 8 / 4 = 20 / 30 / 30 / 15 / 5 % by area
+    (split probabilities per level: 1 - 0.2, 1 - 0.3 / 0.8, ...), 25 % compound average, every block coded, no intra blocks."""
+    sp = _lib.SynthParams()
+    sp.seed = seed
+    sp.intra_pct, sp.skip_pct = 0, 0
+    sp.compound_pct, sp.masked_compound = 25, 0
+    sp.tx_split_pct, sp.alt_txtp_pct, sp.eob_none_pct = 0, 30, 0
+    sp.mv_range, sp.far_mv_pct, sp.n_refs = 512, 5, n_refs
+    for i, v in enumerate((100, 80, 63, 50, 25)):
+        sp.split_pct[i] = v
+    sp.rect_pct = 0
+    sp.fixed_bl = -1
+    sp.cf_align64 = 1
+    return sp
+
+
+def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0xE2E, check=None, intra_pct=0):
+    """Returns the measurement dict.  check: optional callable(handoff, desc, planes) -> str used as the parity gate."""
+    layout = api.LAYOUT_I420
+    ho = HandOff(w, h, layout, bpc, True, tile_cols, 1)
+    sp = c2_params(seed)
+    sp.intra_pct = intra_pct
+    t0 = time.perf_counter()
+    rc = ctx.lib.dav1d_hip_synth_frame(C.byref(ho.desc), C.byref(sp), ho.cf.ctypes.data, ho.cf.nbytes, len(ho.cbi), None, 0)
+    assert rc == 0, rc
+    t_synth = time.perf_counter() - t0
+    rng = np.random.default_rng(seed)
+    refs = []
+    for _ in range(3):
+        r = ctx.picture(w, h, layout, bpc)
+        for pl in range(3):
+            rows, cols = r.padded_shape(pl)
+            r.upload(pl, rng.integers(0, 1 << bpc, size=(rows, cols), dtype=np.uint16).astype(r.dtype))
+        refs.append(r)
+    refs7 = [refs[i % 3] for i in range(7)]
+    cur = ctx.picture(w, h, layout, bpc)
+    n_tiles = ho.desc.n_tile_cols
+    threads = threads or n_tiles
+    coef = ctx.buffer(ho.cf.nbytes)
+    import torch
+    pinned = torch.from_numpy(ho.cf).pin_memory() if torch.cuda.is_available() else None
+    nb = C.c_size_t()
+    blob = ctx.lib.dav1d_hip_lister_const_masks(C.byref(nb))
+    prep = mask = None
+    res = {"list_ms": [], "h2d_ms": [], "frame_end_ms": [], "total_ms": []}
+    steps = 0
+    planes = None
+    with ThreadPoolExecutor(threads) as ex:
+        for it in range(frames):
+            t_a = time.perf_counter()
+            frame = ctx.frame(cur, refs7)
+            lh = C.c_void_p()
+            assert ctx.lib.dav1d_hip_lister_create(C.byref(lh), C.byref(ho.desc), frame.h) == 0
+
+            def tile(tc):
+                for sby in range(ho.sbh):
+                    rc2 = ctx.lib.dav1d_hip_lister_tile_sbrow(lh, 0, tc, sby)
+                    assert rc2 == 0, rc2
+            list(ex.map(tile, range(n_tiles)))
+            t_b = time.perf_counter()
+            if prep is None:
+                prep = ctx.buffer(ctx.lib.dav1d_hip_lister_prep_elems(lh) * 2 + 4096)
+                mask = ctx.buffer(ctx.lib.dav1d_hip_lister_mask_bytes(lh) + 4096)
+                mask.upload(np.ctypeslib.as_array((C.c_uint8 * nb.value).from_address(blob)))
+            # the coefficient arena crosses the host link every frame (the kernels consume = zero it)
+            if pinned is not None:
+                rc3 = ctx.lib.dav1d_hip_upload(ctx.h, coef.ptr, pinned.data_ptr(), ho.cf.nbytes)
+            else:
+                rc3 = ctx.lib.dav1d_hip_upload(ctx.h, coef.ptr, ho.cf.ctypes.data, ho.cf.nbytes)
+            assert rc3 == 0
+            t_c = time.perf_counter()
+            frame.end(coef, prep, mask)
+            t_d = time.perf_counter()
+            steps = ctx.lib.dav1d_hip_lister_steps(lh)
+            if it == frames - 1 and check is not None:
+                planes = [cur.download(pl) for pl in range(3)]
+            ctx.lib.dav1d_hip_lister_destroy(lh)
+            frame.destroy()
+            if it:          # the first frame pays the pools' allocations
+                res["list_ms"].append((t_b - t_a) * 1e3)
+                res["h2d_ms"].append((t_c - t_b) * 1e3)
+                res["frame_end_ms"].append((t_d - t_c) * 1e3)
+                res["total_ms"].append((t_d - t_a) * 1e3)
+    out = {k: round(float(np.median(v)), 3) for k, v in res.items() if v}
+    out["frames"] = frames - 1
+    out["host_threads"] = threads
+    out["tiles"] = n_tiles
+    out["wavefront_steps"] = int(steps)
+    out["coef_bytes_per_frame"] = int(ho.cf.nbytes)
+    out["value"] = round(w * h / (out["total_ms"] * 1e-3) / 1e6, 1) if "total_ms" in out else None
+    out["unit"] = "Mpixels/s"
+    out["synth_seconds"] = round(t_synth, 2)
+    out["workload"] = ("%dx%d 4:2:0 %d-bit inter frame from pass-1 hand-off arrays: lister on %d host threads (one per tile column), chunk "
+                       "preparation on the submitting threads, dense coefficient arena over the host link, frame_end" % (w, h, bpc, threads))
+    if check is not None and planes is not None:
+        out["parity"] = check(ho, planes, refs)
+    for o in refs + [cur, coef] + ([prep, mask] if prep is not None else []):
+        o.free()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=6)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--tile-cols", type=int, default=4)
+    ap.add_argument("--width", type=int, default=7680)
+    ap.add_argument("--height", type=int, default=4320)
+    ap.add_argument("--intra-pct", type=int, default=0)
+    a = ap.parse_args()
+    ctx = api.Context(0)
+    print(json.dumps(run(ctx, a.width, a.height, 10, a.frames, a.threads or None, a.tile_cols, intra_pct=a.intra_pct)))
+
+
+if __name__ == "__main__":
+    main()
