@@ -27,8 +27,11 @@ struct Dav1dHipContext {
     struct Slab { uint8_t *host; size_t cap; };
     std::mutex pool_mtx;
     std::vector<Slab> free_slabs;
-    uint8_t *chunk_dev, *gather_dev, *segtab_dev;
-    size_t chunk_dev_cap, gather_cap, segtab_cap;
+    struct Arena { uint8_t *dev; size_t cap; };
+    std::vector<Arena> free_arenas;            // chunk arenas of finished frames (a frame in flight owns one)
+    size_t arena_hint;                         // what the largest frame so far needed
+    uint8_t *gather_dev, *segtab_dev;
+    size_t gather_cap, segtab_cap;
     uint8_t *pending_slab;
     size_t pending_slab_cap;
     hipStream_t copy_stream;

@@ -40,8 +40,9 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
         if (hipEventCreateWithFlags(&c->ev_bin[i], hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
     if (hipEventCreate(&c->ev_t0) != hipSuccess || hipEventCreate(&c->ev_t1) != hipSuccess) { delete c; return -ENODEV; }
     c->last_ms = 0.f;
-    c->chunk_dev = c->gather_dev = c->segtab_dev = c->pending_slab = nullptr;
-    c->chunk_dev_cap = c->gather_cap = c->segtab_cap = c->pending_slab_cap = 0;
+    c->gather_dev = c->segtab_dev = c->pending_slab = nullptr;
+    c->gather_cap = c->segtab_cap = c->pending_slab_cap = 0;
+    c->arena_hint = 0;
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
     *out = c;
@@ -57,7 +58,7 @@ void dav1d_hip_close(Dav1dHipContext *c) {
     for (int i = 0; i < 16; i++) hipEventDestroy(c->ev_bin[i]);
     hipEventDestroy(c->ev_t0); hipEventDestroy(c->ev_t1);
     hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); hipEventDestroy(c->ev_copy);
-    if (c->chunk_dev) hipFree(c->chunk_dev);
+    for (const Dav1dHipContext::Arena &ar : c->free_arenas) hipFree(ar.dev);
     if (c->gather_dev) hipFree(c->gather_dev);
     if (c->segtab_dev) hipFree(c->segtab_dev);
     if (c->pending_slab) hipHostFree(c->pending_slab);

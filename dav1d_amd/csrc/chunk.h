@@ -13,7 +13,8 @@ struct Dav1dHipChunk {
     int max_ref;
     uint8_t *host;                               // pinned blob (a slab of the context's pool)
     size_t cap, used;
-    size_t dev_off;                              // where the blob sits in the context's chunk arena
+    size_t dev_off;                              // where the blob sits in the frame's chunk arena
+    bool uploaded;                               // ... once it has been sent there (at submit time when the arena had room)
     uint64_t order;                              // first destination position: chunks are lined up in picture order
     void release(Dav1dHipContext *c);
 };
@@ -21,5 +22,6 @@ struct Dav1dHipChunk {
 int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHipPicture *geom, const Dav1dHipPicture *refs, int n_refs,
                           const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
                           const Dav1dHipItxTask *itx, size_t n_itx);
-int dav1d_hip_chunks_to_recon_list(Dav1dHipContext *c, std::vector<Dav1dHipChunk *> &chunks, const Dav1dHipPicture *refs, int n_refs,
+int dav1d_hip_chunks_to_recon_list(Dav1dHipContext *c, std::vector<Dav1dHipChunk *> &chunks, uint8_t **arena, size_t *arena_cap,
+                                   const Dav1dHipPicture *refs, int n_refs,
                                    Dav1dHipReconList *l, Dav1dHipInterList *il, Dav1dHipMcList *ml, Dav1dHipCompList *cl, Dav1dHipItxList *xl);

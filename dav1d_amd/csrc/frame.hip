@@ -8,6 +8,7 @@
 #include "chunk.h"
 #include <string.h>
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -19,6 +20,9 @@ struct Dav1dHipFrame {
     int n_refs;
     std::mutex mtx;
     std::vector<Dav1dHipChunk *> chunks;    // the tile-sbrows' inter predictions + residuals, preprocessed by their submitters (chunk.hip)
+    uint8_t *arena;                         // device mirror of the chunks' blobs: each chunk is uploaded as soon as it is submitted
+    size_t arena_cap;
+    std::atomic<size_t> arena_used;
     // intra blocks: step k of the wavefront = the blocks whose neighbours are final after steps 0 .. k - 1 (and after the
     // inter blocks of the frame); predictions and residuals per step
     std::vector<std::vector<Dav1dHipIpredTask>> ipred;
@@ -219,6 +223,23 @@ int dav1d_hip_frame_begin(Dav1dHipContext *c, Dav1dHipFrame **out, const Dav1dHi
     f->is_id = 0;
     f->have_tmp[0] = f->have_tmp[1] = false;
     f->post_bands = 0;
+    // a chunk arena sized for the largest frame this context has seen (grown at frame end when it turns out too small)
+    f->arena = nullptr; f->arena_cap = 0; f->arena_used = 0;
+    {
+        std::lock_guard<std::mutex> lk(c->pool_mtx);
+        for (size_t i = 0; i < c->free_arenas.size(); i++)
+            if (c->free_arenas[i].cap >= c->arena_hint) {
+                f->arena = c->free_arenas[i].dev; f->arena_cap = c->free_arenas[i].cap;
+                c->free_arenas[i] = c->free_arenas.back();
+                c->free_arenas.pop_back();
+                break;
+            }
+    }
+    if (!f->arena) {
+        size_t want = (size_t) 1 << 24;
+        while (want < c->arena_hint + (c->arena_hint >> 2)) want <<= 1;
+        if (hipMalloc((void **) &f->arena, want) == hipSuccess) f->arena_cap = want; else f->arena = nullptr;
+    }
     *out = f;
     return 0;
 }
@@ -235,6 +256,14 @@ int dav1d_hip_frame_submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc
     Dav1dHipChunk *ck = nullptr;
     const int rc = dav1d_hip_chunk_build(f->c, &ck, &f->cur, f->refs, f->n_refs, mc, n_mc, comp, n_comp, itx, n_itx);
     if (rc) return rc;
+    // up it goes, while the other tile-sbrows are still being listed
+    if (ck->used) {
+        const size_t sz = (ck->used + 255) & ~(size_t) 255, off = f->arena_used.fetch_add(sz);
+        if (f->arena && off + sz <= f->arena_cap) {
+            ck->dev_off = off;
+            ck->uploaded = hipMemcpyAsync(f->arena + off, ck->host, ck->used, hipMemcpyHostToDevice, f->c->copy_stream) == hipSuccess;
+        }
+    }
     std::lock_guard<std::mutex> lk(f->mtx);
     f->chunks.push_back(ck);
     return 0;
@@ -358,6 +387,7 @@ int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *ma
     (void) hipStreamSynchronize(c->copy_stream);
     for (Dav1dHipChunk *ck : f->chunks) { ck->release(c); delete ck; }
     f->chunks.clear();
+    f->arena_used = 0;
     if (c->pending_slab) {
         std::lock_guard<std::mutex> pl(c->pool_mtx);
         c->free_slabs.push_back({ c->pending_slab, c->pending_slab_cap });
@@ -384,7 +414,7 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
         Dav1dHipMcList ml;
         Dav1dHipCompList cl;
         Dav1dHipItxList xl;
-        rc = dav1d_hip_chunks_to_recon_list(c, f->chunks, f->refs, f->n_refs, &rl, &il, &ml, &cl, &xl);
+        rc = dav1d_hip_chunks_to_recon_list(c, f->chunks, &f->arena, &f->arena_cap, f->refs, f->n_refs, &rl, &il, &ml, &cl, &xl);
         if (!rc) {
             if (ml.n || cl.n || rl.f_n[0] || rl.f_n[1] || rl.f_n[2] || rl.f_n[3] || rl.f_n[4]) {
                 if (!f->n_refs) rc = -EINVAL;
@@ -454,7 +484,12 @@ void dav1d_hip_frame_destroy(Dav1dHipFrame *f) {
     if (!f) return;
     (void) hipStreamSynchronize(f->c->stream);
     if (f->prepared) dav1d_hip_fg_grain_destroy(f->c, f->prepared);
+    (void) hipStreamSynchronize(f->c->copy_stream);
     for (Dav1dHipChunk *ck : f->chunks) { ck->release(f->c); delete ck; }
+    if (f->arena) {
+        std::lock_guard<std::mutex> lk(f->c->pool_mtx);
+        f->c->free_arenas.push_back({ f->arena, f->arena_cap });
+    }
     for (int i = 0; i < 2; i++) if (f->have_tmp[i]) dav1d_hip_picture_free(f->c, &f->tmp[i]);
     delete f;
 }
