@@ -1374,16 +1374,15 @@ extern "C" int dav1d_hip_fg_apply(Dav1dHipContext *c, const Dav1dHipPicture *dst
 // transform first, each waiting for the events of its own predecessors only.  The memory-bound predictions of the small
 // shapes then overlap with the arithmetic-bound 64- and 32-point transforms instead of queueing in front of them.
 #ifndef RECON_FUSE_DEFAULT
-#define RECON_FUSE_DEFAULT 6
+#define RECON_FUSE_DEFAULT 14
 #endif
 
 // DAV1D_HIP_RECON_FUSE: which square block sizes get paired (transform block + the prediction block of the same rectangle in
 // one wave, recon.hip): bit 0 4x4, bit 1 8x8, bit 2 16x16, bit 3 32x32, bit 4 64x64; 0 none.  Measured on MI355X (8K 10-bit
-// frame, ms per frame): none 0.362, 8x8 + 16x16 (6, the default) 0.311, 4x4 + 8x8 0.318, 4x4 + 8x8 + 16x16 0.335, 16x16 + 32x32
-// 0.333, all 0.411.  Kernel by kernel a pair beats prediction + residual only for the small sizes (4x4: 73 against 83 us,
-// 8x8: 76 against 84; 16x16: 90 against 79, 32x32: 101 against 69: the fused wave carries the LDS and registers of both
-// bodies); what pays is that the paired launches move a quarter less HBM traffic AND run next to the pipelined launches of
-// the other sizes on streams of their own.
+// frame, ms per frame, round 2 after the paired kernel's LDS regions were overlaid): 8x8 + 16x16 (6) 0.325-0.339,
+// 8x8 + 16x16 + 32x32 (14, the default) 0.317-0.327.  Round 1 (three separate LDS arrays): none 0.362, 6 0.311 (older clock),
+// 4x4 + 8x8 0.318, all 0.411.  What pays is that the paired launches move a quarter less HBM traffic AND run next to the
+// pipelined launches of the other sizes on streams of their own; 4x4 and 64x64 pairs lose to their separate kernels.
 int recon_fuse_mask() {
     const char *e = getenv("DAV1D_HIP_RECON_FUSE");
     return (e ? atoi(e) : RECON_FUSE_DEFAULT) & 31;

@@ -102,7 +102,7 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
     // loads), then, once every lane holds its row in registers, the transposed intermediate
     static_assert(BPW * SH * TS == itx_lds_ints<TX>(), "LDS sizing");
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;       // the body belongs to one wave (recon.hip runs several side by side in a workgroup)
     const int sub = BPW == 1 ? 0 : lane / LPB, l = BPW == 1 ? lane : lane % LPB;
     const int ti = group * BPW + sub;
     const bool live = ti < n;
@@ -129,6 +129,14 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
     pixel dpx[H];
     int dc = 0;
     const bool row_lane = full && l < SH;
+    if (PRED_LDS) {
+        // the predicted pixels leave the LDS before anything of this body is stored there: recon.hip lets the two regions overlap
+        if (live && l < W) {
+#pragma unroll
+            for (int y = 0; y < H; y++) dpx[y] = pred_s[(sub * H + y) * W + l];
+        }
+        dv::wave_sync();
+    }
     static_assert(SW * SH * (int) sizeof(coef) <= SH * TS * (int) sizeof(int), "slab fits the transpose buffer");
     if (full) {
         // 16-byte loads of the contiguous slab, zeroed in the same sweep (src/itx_tmpl.c:108)
@@ -145,9 +153,9 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
             v[k] = make_int4(0, 0, 0, 0);
             if (l + k * LPB < nch) v[k] = g4[l + k * LPB];
         }
-        if (l < W) {
+        if (!PRED_LDS && l < W) {
 #pragma unroll
-            for (int y = 0; y < H; y++) dpx[y] = PRED_LDS ? pred_s[(sub * H + y) * W + l] : d[y * stride];
+            for (int y = 0; y < H; y++) dpx[y] = d[y * stride];
         }
 #pragma unroll
         for (int k = 0; k < (NCH + LPB - 1) / LPB; k++) {
@@ -169,9 +177,9 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
         }
     } else if (dconly) {
         if (l == 0) { dc = gcf[0]; if (!(t.flags & DAV1D_HIP_ITX_PACKED)) gcf[0] = 0; }            // src/itx_tmpl.c:59-60
-        if (l < W) {
+        if (!PRED_LDS && l < W) {
 #pragma unroll
-            for (int y = 0; y < H; y++) dpx[y] = PRED_LDS ? pred_s[(sub * H + y) * W + l] : d[y * stride];
+            for (int y = 0; y < H; y++) dpx[y] = d[y * stride];
         }
     }
     dc = __shfl(dc, sub * LPB);

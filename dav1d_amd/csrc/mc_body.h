@@ -63,7 +63,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
     int16_t *const win_s = reinterpret_cast<int16_t *>(smem);
     uint32_t *const mid_s = reinterpret_cast<uint32_t *>(win_s + G * WR * WS);
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;       // the body belongs to one wave (recon.hip runs several side by side in a workgroup)
     // G == 1: the whole wave works on one tile, so the record, the taps and all the control flow
     // derived from them are wave-uniform (scalar loads, SGPRs, s_cbranch instead of exec masking)
     const int sub = G == 1 ? 0 : lane / LPT, l = G == 1 ? lane : lane % LPT;

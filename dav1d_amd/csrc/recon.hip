@@ -15,10 +15,14 @@
 
 namespace {
 
+#ifndef RECON_WAVES
+#define RECON_WAVES 1
+#endif
+
 constexpr int rc_log2(int v) { return v <= 1 ? 0 : 1 + rc_log2(v >> 1); }
 
 template <int CLS, typename pixel, typename coef>
-__global__ __launch_bounds__(64) void recon_fused_kernel(const DevPlanes dst, const RefSet refs, const McTile *__restrict__ tiles,
+__global__ __launch_bounds__(64, RECON_WAVES) void recon_fused_kernel(const DevPlanes dst, const RefSet refs, const McTile *__restrict__ tiles,
                                                          const Dav1dHipItxTask *__restrict__ tasks, const int n_blocks,
                                                          int16_t *__restrict__ prep, coef *__restrict__ cf, const int bitdepth_max)
 {
@@ -28,9 +32,17 @@ __global__ __launch_bounds__(64) void recon_fused_kernel(const DevPlanes dst, co
     constexpr int TPB = (W / TW) * (W / TH);                 // tiles per block: 1, 1, 1, 2, 4
     constexpr int LPB = cmax(cmin(W, 32), W), BPW = 64 / LPB;   // blocks per wave of the transform body
     constexpr int G = 64 / mc_cmin(64, TW * TH / 4);         // tiles per call of the prediction body
-    __shared__ uint4 smem_mc[(mc_lds_bytes<TW, TH>() + 15) / 16];
-    __shared__ __attribute__((aligned(16))) int smem_itx[itx_lds_ints<TX>()];
-    __shared__ __attribute__((aligned(16))) pixel pred[BPW * W * W];
+    // One LDS buffer, used twice: [prediction window + intermediate | the predicted blocks] while the blocks are predicted, then
+    // [slabs / transpose buffer of the transform] — the transform body has the predicted pixels in registers before it stores
+    // its first slab chunk, so the regions may overlap.  Fewer LDS bytes per wave = more resident waves per CU, which is what
+    // these kernels are short of (16x16: 8320 -> 4352 bytes, 5 -> 6 waves per SIMD, 89 -> 76 us per 8K frame).
+    constexpr int MC_B = (mc_lds_bytes<TW, TH>() + 15) / 16 * 16, PRED_B = BPW * W * W * (int) sizeof(pixel);
+    constexpr int ITX_B = itx_lds_ints<TX>() * 4;
+    constexpr int LDS_B = cmax(MC_B + PRED_B, ITX_B);
+    __shared__ uint4 smem[(LDS_B + 15) / 16];
+    uint4 *const smem_mc = smem;
+    pixel *const pred = reinterpret_cast<pixel *>(reinterpret_cast<char *>(smem) + MC_B);
+    int *const smem_itx = reinterpret_cast<int *>(smem);
 
     const int group = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x);
     const int block0 = group * BPW;

@@ -8,7 +8,7 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(mc_kernel|itx_add_kernel|comp_kernel)<([^>]*)>", name)
+    m = re.search(r"(mc_kernel|itx_add_kernel|comp_kernel|recon_fused_kernel)<([^>]*)>", name)
     return (m.group(1).replace("_kernel", "") + "<" + m.group(2).replace("unsigned short", "u16").replace(" ", "") + ">") if m else name[:40]
 
 
@@ -27,7 +27,7 @@ def main():
         cur.append(e)
     steps.append(cur)
     for si, st in enumerate(steps[-3:]):
-        st = [e for e in st if e[2].startswith(("mc", "itx", "comp"))]
+        st = [e for e in st if e[2].startswith(("mc", "itx", "comp", "recon"))]
         if not st:
             continue
         t0, t1 = min(e[0] for e in st), max(e[1] for e in st)
