@@ -20,6 +20,7 @@ struct Dav1dHipContext {
     hipEvent_t ev_fork, ev_join[N_SIDE];
     hipEvent_t ev_bin[16];      // "this tile shape's predictions are in the picture" (recon list pipeline)
     bool concurrent;
+    bool cdef_unit_kernel;      // $DAV1D_HIP_CDEF_UNIT=1 at open: one wave per 8x8 unit (the round-1 kernel) instead of strips; A/B aid
     // measurement aid: device time of the kernel launches of the most recent *_batch call (dav1d_hip_last_kernel_ms)
     hipEvent_t ev_t0, ev_t1;
     float last_ms;
@@ -142,8 +143,25 @@ extern "C" int dav1d_hip_launch_mc_bin(const DevPlanes *dst, const DevPlanes *re
 extern "C" int dav1d_hip_launch_comp(const DevPlanes *dst, int bpc, const Dav1dHipCompTask *tasks, int n,
                                      const int16_t *prep, uint8_t *mask, void *stream);
 
+// raw_only: tasks without the RAW flag are left alone (they are run by groups, below)
 extern "C" int dav1d_hip_launch_cdef(const DevPlanes *dst, const DevPlanes *src, int bpc, int layout,
-                                     const Dav1dHipCdefTask *tasks, int n, int damping, uint32_t *dirvar, void *stream);
+                                     const Dav1dHipCdefTask *tasks, int n, int damping, uint32_t *dirvar, int raw_only, void *stream);
+
+// Up to 16 listed units of ONE unit row, tasks[first .. first + n) in rising bx, all within [bx0, bx0 + span): what one wave of
+// the strip kernel filters from a shared window.  edges: LEFT of the first unit, RIGHT of the last, TOP / BOTTOM of all.
+struct CdefGroup {
+    uint32_t first;
+    uint16_t bx0, by;
+    uint8_t n, span, edges, pad;
+};
+// appends the groups of tasks[0 .. n) (indices offset by `base`) in list order; returns the number of RAW tasks met
+size_t dav1d_hip_cdef_make_groups(const Dav1dHipCdefTask *tasks, size_t n, size_t base, std::vector<CdefGroup> &out);
+bool dav1d_hip_cdef_strip_ok(const DevPlanes *dst, const DevPlanes *src, int bpc);
+extern "C" int dav1d_hip_launch_cdef_groups(const DevPlanes *dst, const DevPlanes *src, int bpc, int layout, const Dav1dHipCdefTask *tasks,
+                                            const CdefGroup *groups, int n_groups, int damping, uint32_t *dirvar, void *stream);
+// tasks + ready-made groups (host arrays) -> upload, strip kernel (+ the unit kernel for RAW tasks), synchronize
+int dav1d_hip_cdef_run_groups(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src, const Dav1dHipCdefTask *tasks,
+                              size_t n, const CdefGroup *groups, size_t n_groups, size_t n_raw, int damping, uint32_t *dirvar);
 
 extern "C" int dav1d_hip_launch_lf(const DevPlanes *dst, int bpc, int dir, const Dav1dHipLfTask *tasks, int n, const uint8_t *lvl,
                                    int b4_stride, const uint8_t *lut_e, const uint8_t *lut_i, void *stream);

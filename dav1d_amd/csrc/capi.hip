@@ -31,6 +31,8 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     else if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return -ENODEV; }
     const char *ser = getenv("DAV1D_HIP_SERIAL");
     c->concurrent = !(ser && atoi(ser));
+    const char *cu = getenv("DAV1D_HIP_CDEF_UNIT");
+    c->cdef_unit_kernel = cu && atoi(cu);
     for (int i = 0; i < Dav1dHipContext::N_SIDE; i++) {
         if (hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
@@ -958,18 +960,43 @@ size_t dav1d_hip_inter_list_fused(const Dav1dHipInterList *l) { return l ? l->n_
 
 // --------------------------------------------------------------------- cdef
 
+int dav1d_hip_cdef_run_groups(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src, const Dav1dHipCdefTask *tasks,
+                              size_t n, const CdefGroup *groups, size_t n_groups, size_t n_raw, int damping, uint32_t *dirvar) {
+    const size_t tb = (n * sizeof(Dav1dHipCdefTask) + 255) & ~(size_t) 255;
+    uint8_t *dev = nullptr;
+    if (hipMalloc((void **) &dev, tb + n_groups * sizeof(CdefGroup) + 256) != hipSuccess) return -ENOMEM;
+    int rc = dav1d_hip_upload(c, dev, tasks, n * sizeof(Dav1dHipCdefTask));
+    if (!rc && n_groups) rc = dav1d_hip_upload(c, dev + tb, groups, n_groups * sizeof(CdefGroup));
+    const DevPlanes dp = dev_planes(dst), sp = dev_planes(src);
+    const Dav1dHipCdefTask *d_tasks = reinterpret_cast<const Dav1dHipCdefTask *>(dev);
+    KernelTimer kt(c);
+    if (!rc) rc = dav1d_hip_launch_cdef_groups(&dp, &sp, dst->bpc, dst->layout, d_tasks, reinterpret_cast<const CdefGroup *>(dev + tb),
+                                               (int) n_groups, damping, dirvar, c->stream);
+    if (!rc && n_raw) rc = dav1d_hip_launch_cdef(&dp, &sp, dst->bpc, dst->layout, d_tasks, (int) n, damping, dirvar, 1, c->stream);
+    kt.stop();
+    hipStreamSynchronize(c->stream);
+    hipFree(dev);
+    return rc;
+}
+
 extern "C" int dav1d_hip_cdef_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src,
                                     const Dav1dHipCdefTask *tasks, size_t n, int damping, uint32_t *dirvar) {
     if (!dst || !src || (!tasks && n) || dst->bpc != src->bpc || dst->layout != src->layout) return -EINVAL;
     if (!n) return 0;
     for (size_t i = 0; i < n; i++)
         if (tasks[i].edges > 15 || tasks[i].plane > 2 || tasks[i].dir > 7) return -EINVAL;
+    const DevPlanes dp = dev_planes(dst), sp = dev_planes(src);
+    if (dav1d_hip_cdef_strip_ok(&dp, &sp, dst->bpc) && !c->cdef_unit_kernel) {
+        // units that sit side by side share a wave (strip kernel); DSP-level RAW tasks keep the one-unit kernel
+        std::vector<CdefGroup> groups;
+        const size_t n_raw = dav1d_hip_cdef_make_groups(tasks, n, 0, groups);
+        return dav1d_hip_cdef_run_groups(c, dst, src, tasks, n, groups.data(), groups.size(), n_raw, damping, dirvar);
+    }
     Dav1dHipCdefTask *dev = nullptr;
     if (hipMalloc((void **) &dev, n * sizeof(*dev)) != hipSuccess) return -ENOMEM;
     int rc = dav1d_hip_upload(c, dev, tasks, n * sizeof(*dev));
-    const DevPlanes dp = dev_planes(dst), sp = dev_planes(src);
     KernelTimer kt(c);
-    if (!rc) rc = dav1d_hip_launch_cdef(&dp, &sp, dst->bpc, dst->layout, dev, (int) n, damping, dirvar, c->stream);
+    if (!rc) rc = dav1d_hip_launch_cdef(&dp, &sp, dst->bpc, dst->layout, dev, (int) n, damping, dirvar, 0, c->stream);
     kt.stop();
     hipStreamSynchronize(c->stream);
     hipFree(dev);

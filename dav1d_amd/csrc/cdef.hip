@@ -153,7 +153,7 @@ __device__ __forceinline__ void load_window_fast(int16_t *tmp, const uint16_t *s
 template <typename pixel>
 __global__ __launch_bounds__(64) void cdef_kernel(const DevPlanes dst, const DevPlanes src, const Dav1dHipCdefTask *__restrict__ tasks,
                                                   const int n, const int damping, const int layout, const int bitdepth_max,
-                                                  uint32_t *__restrict__ dirvar)
+                                                  uint32_t *__restrict__ dirvar, const int raw_only)
 {
     __shared__ __attribute__((aligned(8))) int16_t tmp[144], tmp2[144];
     __shared__ int16_t pdir[64];
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(64) void cdef_kernel(const DevPlanes dst, const Dev
     const int lane = threadIdx.x;
     const int tis = __builtin_amdgcn_readfirstlane(ti);
     const Dav1dHipCdefTask t = tasks[tis];
+    if (raw_only && !(t.flags & 1)) return;
     const int bitdepth_min_8 = (32 - __clz(bitdepth_max)) - 8;
     const int edges = t.edges;
 
@@ -314,16 +315,375 @@ __global__ __launch_bounds__(64) void cdef_kernel(const DevPlanes dst, const Dev
     }
 }
 
+
+// =====================================================================================================================
+// Strip kernel: one wave = up to 16 horizontally adjacent 8x8 units of one unit row (a CdefGroup), every plane.
+//
+// * One window per plane in LDS shared by the 16 units (128 + 2 * 8 columns x (8 + 4) rows for luma), loaded as aligned
+//   W-pixel pieces; a piece is either inside the picture or — where the group's edge flags say so — the INT16_MIN sentinel.
+// * Direction search (cdef_find_dir_c, src/cdef_tmpl.c:239-319) for the 16 units at once: the 90 partial sums of a unit are
+//   a 0/1 incidence matrix (which pixel feeds which line of which direction) times its 64 samples, and the samples
+//   (px >> (bitdepth - 8)) - 128 are int8, so seven v_mfma_i32_16x16x64_i8 (one per 16-line tile: two diagonals, four
+//   "alt" families, rows + columns) give all 16 x 90 sums exactly; squaring, weighting by 840 / line length and the
+//   arg-max stay on the VALU, four lines of one unit per lane.
+// * Filter (cdef_filter_block_c, src/cdef_tmpl.c:103-237) on pixel PAIRS in packed 16-bit arithmetic (the sums fit: |sum|
+//   <= 12 * 240 + 12 * 64): lane l filters rows [q * H / 4, (q + 1) * H / 4) of unit u = l >> 2, q = l & 3; strengths,
+//   direction and shifts are per-lane values, so units with different parameters share the wave.
+// =====================================================================================================================
+
+struct alignas(16) CdefDirTab {
+    uint8_t m[7][16][64];       // [tile][line][pixel y * 8 + x]
+    uint16_t w[7][16];          // 840 / (pixels on the line), 0 for the unused lines of a tile
+};
+// line of pixel (x, y) in tile t: the index expressions of cdef_find_dir_c (src/cdef_tmpl.c:255-270)
+constexpr int cdef_line(const int t, const int x, const int y) {
+    return t == 0 ? y + x : t == 1 ? 7 + y - x : t == 2 ? y + (x >> 1) : t == 3 ? 3 + y - (x >> 1) :
+           t == 4 ? 3 - (y >> 1) + x : t == 5 ? (y >> 1) + x : y;
+}
+constexpr CdefDirTab make_cdef_dir_tab() {
+    CdefDirTab d = {};
+    for (int t = 0; t < 7; t++) {
+        int cnt[16] = {};
+        for (int y = 0; y < 8; y++)
+            for (int x = 0; x < 8; x++) {
+                const int i = cdef_line(t, x, y);
+                d.m[t][i][y * 8 + x] = 1; cnt[i]++;
+                if (t == 6) { d.m[t][8 + x][y * 8 + x] = 1; cnt[8 + x]++; }      // tile 6: rows 0..7 = hv[0], 8..15 = hv[1]
+            }
+        for (int i = 0; i < 16; i++) d.w[t][i] = cnt[i] ? (uint16_t) (840 / cnt[i]) : 0;
+    }
+    return d;
+}
+__device__ const CdefDirTab cdef_dir_tab = make_cdef_dir_tab();
+// (dy, dx) of the two taps of a direction, from the 12-wide offsets of av1_cdef_directions (entries 2 .. 9 are directions 0 .. 7)
+constexpr uint32_t cdef_dir_yx(const int dir) {
+    uint32_t v = 0;
+    for (int k = 0; k < 2; k++) {
+        const int off = av1_cdef_directions[(dir + 2) * 2 + k];
+        const int dy = (off + 6 + 120) / 12 - 10, dx = off - 12 * dy;
+        v |= (uint32_t) ((dy & 0xff) | (dx & 0xff) << 8) << (16 * k);
+    }
+    return v;
+}
+__device__ const uint32_t cdef_dir_yx_tab[8] = { cdef_dir_yx(0), cdef_dir_yx(1), cdef_dir_yx(2), cdef_dir_yx(3),
+                                                 cdef_dir_yx(4), cdef_dir_yx(5), cdef_dir_yx(6), cdef_dir_yx(7) };
+
+template <typename pixel, int W>
+__device__ __forceinline__ void cdef_load_piece(uint16_t *dstp, const pixel *srcp, const bool ok) {
+    constexpr bool HBD = sizeof(pixel) == 2;
+    if (W == 8) {
+        uint4 v = make_uint4(0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u);
+        if (ok) {
+            if (HBD) v = *reinterpret_cast<const uint4 *>(srcp);
+            else {
+                const uint2 b = *reinterpret_cast<const uint2 *>(srcp);
+                v = make_uint4((b.x & 0xff) | (b.x & 0xff00) << 8, (b.x >> 16 & 0xff) | (b.x >> 24) << 16,
+                               (b.y & 0xff) | (b.y & 0xff00) << 8, (b.y >> 16 & 0xff) | (b.y >> 24) << 16);
+            }
+        }
+        *reinterpret_cast<uint4 *>(dstp) = v;
+    } else {
+        uint2 v = make_uint2(0x80008000u, 0x80008000u);
+        if (ok) {
+            if (HBD) v = *reinterpret_cast<const uint2 *>(srcp);
+            else {
+                const uint32_t b = *reinterpret_cast<const uint32_t *>(srcp);
+                v = make_uint2((b & 0xff) | (b & 0xff00) << 8, (b >> 16 & 0xff) | (b >> 24) << 16);
+            }
+        }
+        *reinterpret_cast<uint2 *>(dstp) = v;
+    }
+}
+
+// Window of one plane: rows y0 - 2 .. y0 + H + 1, 18 pieces of W pixels per row (piece p = picture columns x0 + (p - 1) * W ..),
+// of which 0 .. span + 1 are filled.  Unit u's pixels start at window column (u + 1) * W.
+template <typename pixel, int W, int H>
+__device__ __forceinline__ void cdef_load_window(uint16_t *win, const pixel *src, const int stride, const int x0, const int y0,
+                                                 const int span, const int edges, const int lane)
+{
+    constexpr int NPR = 18;
+    for (int i = lane; i < (H + 4) * NPR; i += 64) {
+        const int row = i / NPR, p = i - row * NPR;
+        if (p > span + 1) continue;
+        const bool ok = (row >= 2 || (edges & 4)) && (row < H + 2 || (edges & 8)) && (p > 0 || (edges & 1)) && (p <= span || (edges & 2));
+        cdef_load_piece<pixel, W>(win + (row * NPR + p) * W, src + (y0 + row - 2) * stride + x0 + (p - 1) * W, ok);
+    }
+}
+
+struct CdefTapSet { uint32_t thr2, sh2, tap2[2], yx; };      // one strength: threshold, shift, the two tap weights, (dy, dx) x 2
+
+// 12 taps on RPL rows of W pixels (W / 2 packed pairs per row); `base` = window index (pixels) of the lane's first pixel
+template <int W, int RPL>
+__device__ __forceinline__ void cdef_filter_rows(const uint16_t *win, const int base, const bool any_pri, const bool any_sec,
+                                                 const CdefTapSet pri, const CdefTapSet sec0, const CdefTapSet sec1,
+                                                 const bool clamp_range, uint32_t (&out)[RPL][W / 2])
+{
+    constexpr int NP = W / 2, WS = 18 * W;
+    const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win);
+#pragma unroll
+    for (int r = 0; r < RPL; r++) {
+        const int b = base + r * WS;
+        uint32_t px[NP], sum[NP], mn[NP], mx[NP];
+#pragma unroll
+        for (int j = 0; j < NP; j++) { px[j] = w32[(b >> 1) + j]; sum[j] = 0; mn[j] = mx[j] = px[j]; }
+        auto tap = [&](const CdefTapSet &ts, const int k, const int sign) {
+            const int dy = (int) (int8_t) (ts.yx >> (16 * k)), dx = (int) (int8_t) (ts.yx >> (16 * k + 8));
+            const int idx = b + sign * (dy * WS + dx);
+            const uint32_t *q = w32 + (idx >> 1);
+            const uint32_t shv = (uint32_t) (idx & 1) << 4;
+            uint32_t d[NP + 1];
+#pragma unroll
+            for (int j = 0; j <= NP; j++) d[j] = q[j];
+#pragma unroll
+            for (int j = 0; j < NP; j++) {
+                const uint32_t p = __builtin_amdgcn_alignbit(d[j + 1], d[j], shv);
+                // constrain(), src/cdef_tmpl.c:56-62, two pixels at a time
+                const uint32_t d1 = dv::pk_sub(p, px[j]), d2 = dv::pk_sub(px[j], p);
+                const uint32_t ad = dv::pk_max_i16(d1, d2);
+                const uint32_t lim = dv::pk_sub_u16_sat(ts.thr2, dv::pk_lshr(ad, ts.sh2));
+                const uint32_t c = dv::pk_min_i16(dv::pk_max_i16(d1, dv::pk_sub(0u, lim)), lim);
+                sum[j] = dv::pk_mad(c, ts.tap2[k], sum[j]);
+                mn[j] = dv::pk_min_u16(mn[j], p);
+                mx[j] = dv::pk_max_i16(mx[j], p);
+            }
+        };
+        if (any_pri) { tap(pri, 0, 1); tap(pri, 0, -1); tap(pri, 1, 1); tap(pri, 1, -1); }
+        if (any_sec) {
+            tap(sec0, 0, 1); tap(sec0, 0, -1); tap(sec1, 0, 1); tap(sec1, 0, -1);
+            tap(sec0, 1, 1); tap(sec0, 1, -1); tap(sec1, 1, 1); tap(sec1, 1, -1);
+        }
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            // px + ((sum - (sum < 0) + 8) >> 4)
+            uint32_t s = dv::pk_add(sum[j], dv::pk_ashr(sum[j], dv::rep2(15)));
+            s = dv::pk_ashr(dv::pk_add(s, dv::rep2(8)), dv::rep2(4));
+            const uint32_t v = dv::pk_add(px[j], s);
+            // only the primary + secondary path clamps to the local range (src/cdef_tmpl.c:165 vs :185,209)
+            out[r][j] = clamp_range ? dv::pk_min_i16(dv::pk_max_i16(v, mn[j]), mx[j]) : v;
+        }
+    }
+}
+
+__device__ __forceinline__ CdefTapSet cdef_tapset(const int strength, const int shift, const int tap0, const int tap1, const uint32_t yx) {
+    CdefTapSet t;
+    t.thr2 = dv::rep2(strength); t.sh2 = dv::rep2(shift); t.tap2[0] = dv::rep2(tap0); t.tap2[1] = dv::rep2(tap1); t.yx = yx;
+    return t;
+}
+
+// filter + store of one plane for the lane's (unit u, quarter q)
+template <typename pixel, int W, int H>
+__device__ __forceinline__ void cdef_plane(const uint16_t *win, const uint32_t *dir_yx, pixel *dstp, const int stride, const int x0, const int y0,
+                                           const int u, const int q, const int pri, const int sec, const int dir, const int damping,
+                                           const int bitdepth_min_8, const bool run)
+{
+    constexpr int RPL = H / 4, NP = W / 2, WS = 18 * W;
+    const bool any_pri = __any(run && pri), any_sec = __any(run && sec);
+    const int pri_tap = 4 - ((pri >> bitdepth_min_8) & 1);
+    const CdefTapSet tp = cdef_tapset(pri, pri ? dv::imax(0, damping - ulog2(pri)) : 0, pri_tap, (pri_tap & 3) | 2, dir_yx[dir]);
+    const int sec_shift = sec ? damping - ulog2(sec) : 0;
+    const CdefTapSet ts0 = cdef_tapset(sec, sec_shift, 2, 1, dir_yx[(dir + 2) & 7]);
+    const CdefTapSet ts1 = cdef_tapset(sec, sec_shift, 2, 1, dir_yx[(dir + 6) & 7]);
+    uint32_t out[RPL][NP];
+    const int row0 = q * RPL;
+    cdef_filter_rows<W, RPL>(win, (row0 + 2) * WS + (u + 1) * W, any_pri, any_sec, tp, ts0, ts1, pri && sec, out);
+    if (!run) return;
+#pragma unroll
+    for (int r = 0; r < RPL; r++) {
+        pixel *d = dstp + (y0 + row0 + r) * stride + x0 + u * W;
+        if (sizeof(pixel) == 2) {
+            if (W == 8) *reinterpret_cast<uint4 *>(d) = make_uint4(out[r][0], out[r][1], out[r][NP - 2], out[r][NP - 1]);
+            else *reinterpret_cast<uint2 *>(d) = make_uint2(out[r][0], out[r][1]);
+        } else {
+            // low bytes of the four halves of two registers
+            const uint32_t lo = __builtin_amdgcn_perm(out[r][1], out[r][0], 0x06040200u);
+            if (W == 8) *reinterpret_cast<uint2 *>(d) = make_uint2(lo, __builtin_amdgcn_perm(out[r][NP - 1], out[r][NP - 2], 0x06040200u));
+            else *reinterpret_cast<uint32_t *>(d) = lo;
+        }
+    }
+}
+
+template <typename pixel>
+__global__ __launch_bounds__(64) void cdef_strip_kernel(const DevPlanes dst, const DevPlanes src, const Dav1dHipCdefTask *__restrict__ tasks,
+                                                        const CdefGroup *__restrict__ groups, const int n_groups, const int damping,
+                                                        const int layout, const int bitdepth_max, uint32_t *__restrict__ dirvar)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t win[12 * 18 * 8];
+    __shared__ uint32_t traw[16][2], upar[16][2], dir_yx[8];
+
+    const int gi = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x);
+    if (gi >= n_groups) return;
+    const int lane = threadIdx.x;
+    const CdefGroup g = groups[__builtin_amdgcn_readfirstlane(gi)];
+    const int bitdepth_min_8 = (32 - __clz(bitdepth_max)) - 8;
+    const int edges = g.edges, span = g.span;
+    const int x0 = g.bx0 * 8, y0 = g.by * 8;
+
+    if (lane < 16) { traw[lane][0] = 0; traw[lane][1] = 0; }
+    if (lane < 8) dir_yx[lane] = cdef_dir_yx_tab[lane];
+    dv::wave_sync();
+    if (lane < g.n) {
+        const Dav1dHipCdefTask t = tasks[g.first + lane];
+        const int slot = t.bx - g.bx0;
+        traw[slot][0] = (uint32_t) t.y_pri | (uint32_t) t.y_sec << 8 | (uint32_t) t.uv_pri << 16 | (uint32_t) t.uv_sec << 24;
+        traw[slot][1] = 0x100u | (uint32_t) lane;                       // present, rank in the group
+    }
+    cdef_load_window<pixel, 8, 8>(win, reinterpret_cast<const pixel *>(src.data[0]), src.stride[0], x0, y0, span, edges, lane);
+    dv::wave_sync();
+
+    // ---- direction search for unit n = lane & 15 (every lane of the four 16-lane rows ends up with the unit's eight costs)
+    {
+        const int n = lane & 15, gq = lane >> 4;
+        const uint32_t raw0 = traw[n][0], raw1 = traw[n][1];
+        const int y_pri = raw0 & 0xff, y_sec = raw0 >> 8 & 0xff, uv_pri = raw0 >> 16 & 0xff, uv_sec = raw0 >> 24;
+        const bool present = raw1 >> 8 & 1;
+        int dir = 0;
+        unsigned var = 0;
+        if (__any(present && (y_pri || uv_pri)) || dirvar) {
+            // B operand: samples 16 * gq .. + 15 of unit n = its rows 2 * gq, 2 * gq + 1, as int8
+            uint32_t bq[4];
+            const uint32_t sh2 = dv::rep2(bitdepth_min_8);
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(win + (2 * gq + r + 2) * 144 + (n + 1) * 8);
+                bq[2 * r + 0] = __builtin_amdgcn_perm(dv::pk_lshr(v.y, sh2), dv::pk_lshr(v.x, sh2), 0x06040200u) ^ 0x80808080u;
+                bq[2 * r + 1] = __builtin_amdgcn_perm(dv::pk_lshr(v.w, sh2), dv::pk_lshr(v.z, sh2), 0x06040200u) ^ 0x80808080u;
+            }
+            const uint4 b = make_uint4(bq[0], bq[1], bq[2], bq[3]);
+            unsigned cost[8];
+#pragma unroll
+            for (int t = 0; t < 7; t++) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(&cdef_dir_tab.m[t][n][16 * gq]);
+                int acc[4] = { 0, 0, 0, 0 };
+                dv::mfma_i32_16x16x64_i8(a, b, acc);
+                const uint2 wq = *reinterpret_cast<const uint2 *>(&cdef_dir_tab.w[t][4 * gq]);
+                unsigned c = (unsigned) (acc[0] * acc[0]) * (wq.x & 0xffff) + (unsigned) (acc[1] * acc[1]) * (wq.x >> 16) +
+                             (unsigned) (acc[2] * acc[2]) * (wq.y & 0xffff) + (unsigned) (acc[3] * acc[3]) * (wq.y >> 16);
+                c += (unsigned) __shfl_xor((int) c, 16);
+                if (t < 6) {
+                    c += (unsigned) __shfl_xor((int) c, 32);
+                    // direction numbering: diag[0] 0, alt[0] 1, hv[0] 2, alt[1] 3, diag[1] 4, alt[2] 5, hv[1] 6, alt[3] 7
+                    cost[t == 0 ? 0 : t == 1 ? 4 : t == 2 ? 1 : t == 3 ? 3 : t == 4 ? 5 : 7] = c;
+                } else {
+                    const unsigned o = (unsigned) __shfl_xor((int) c, 32);
+                    cost[2] = gq < 2 ? c : o;
+                    cost[6] = gq < 2 ? o : c;
+                }
+            }
+            unsigned best = cost[0];
+#pragma unroll
+            for (int k = 1; k < 8; k++) if (cost[k] > best) { best = cost[k]; dir = k; }
+            unsigned opp = cost[4];                                 // cost[dir ^ 4], picked by compares (never indexed)
+#pragma unroll
+            for (int k = 1; k < 8; k++) opp = dir == k ? cost[k ^ 4] : opp;
+            var = (best - opp) >> 10;
+            if (dirvar && lane < 16 && present) dirvar[g.first + (raw1 & 0xff)] = (uint32_t) dir | (var << 3);
+        }
+        if (lane < 16) {
+            // luma: adjust_strength, src/cdef_apply_tmpl.c:91-95; direction 0 without a primary strength (:218-230)
+            int pri = 0, d = 0;
+            bool run = false;
+            if (y_pri) {
+                if (var) {
+                    const int i = (var >> 6) ? dv::imin(ulog2(var >> 6), 12) : 0;
+                    pri = (y_pri * (4 + i) + 8) >> 4;
+                }
+                d = dir;
+                run = pri || y_sec;
+            } else if (y_sec) run = true;
+            // chroma: 4:2:2 remaps the direction (src/cdef_apply_tmpl.c:115-117)
+            const unsigned uv422 = 0x66654207u;   // nibbles 7,0,2,4,5,6,6,6 for dir 0..7
+            int uvdir = 0;
+            if (uv_pri) uvdir = layout == DAV1D_HIP_LAYOUT_I422 ? (int) ((uv422 >> (4 * dir)) & 15) : dir;
+            upar[n][0] = (uint32_t) pri | (uint32_t) y_sec << 8 | (uint32_t) d << 16 | (uint32_t) (present && run) << 24;
+            upar[n][1] = (uint32_t) uv_pri | (uint32_t) uv_sec << 8 | (uint32_t) uvdir << 16 | (uint32_t) (present && (uv_pri || uv_sec)) << 24;
+        }
+    }
+    dv::wave_sync();
+
+    const int u = lane >> 2, q = lane & 3;
+    const uint32_t p0 = upar[u][0], p1 = upar[u][1];
+    cdef_plane<pixel, 8, 8>(win, dir_yx, reinterpret_cast<pixel *>(dst.data[0]), dst.stride[0], x0, y0, u, q, p0 & 0xff, p0 >> 8 & 0xff,
+                            p0 >> 16 & 0xff, damping, bitdepth_min_8, p0 >> 24 & 1);
+    if (layout == DAV1D_HIP_LAYOUT_I400 || !__any(p1 >> 24 & 1)) return;
+    const int ss_ver = layout == DAV1D_HIP_LAYOUT_I420, ss_hor = layout != DAV1D_HIP_LAYOUT_I444;
+    const int cx0 = x0 >> ss_hor, cy0 = y0 >> ss_ver;
+    for (int pl = 1; pl < 3; pl++) {
+        const pixel *sp = reinterpret_cast<const pixel *>(src.data[pl]);
+        pixel *dp = reinterpret_cast<pixel *>(dst.data[pl]);
+        dv::wave_sync();
+        if (!ss_hor) cdef_load_window<pixel, 8, 8>(win, sp, src.stride[pl], cx0, cy0, span, edges, lane);
+        else if (!ss_ver) cdef_load_window<pixel, 4, 8>(win, sp, src.stride[pl], cx0, cy0, span, edges, lane);
+        else cdef_load_window<pixel, 4, 4>(win, sp, src.stride[pl], cx0, cy0, span, edges, lane);
+        dv::wave_sync();
+        const int pri = p1 & 0xff, sec = p1 >> 8 & 0xff, d = p1 >> 16 & 0xff;
+        const bool run = p1 >> 24 & 1;
+        if (!ss_hor) cdef_plane<pixel, 8, 8>(win, dir_yx, dp, dst.stride[pl], cx0, cy0, u, q, pri, sec, d, damping - 1, bitdepth_min_8, run);
+        else if (!ss_ver) cdef_plane<pixel, 4, 8>(win, dir_yx, dp, dst.stride[pl], cx0, cy0, u, q, pri, sec, d, damping - 1, bitdepth_min_8, run);
+        else cdef_plane<pixel, 4, 4>(win, dir_yx, dp, dst.stride[pl], cx0, cy0, u, q, pri, sec, d, damping - 1, bitdepth_min_8, run);
+    }
+}
+
 } // namespace
 
 extern "C" int dav1d_hip_launch_cdef(const DevPlanes *dst, const DevPlanes *src, int bpc, int layout,
-                                     const Dav1dHipCdefTask *tasks, int n, int damping, uint32_t *dirvar, void *stream)
+                                     const Dav1dHipCdefTask *tasks, int n, int damping, uint32_t *dirvar, int raw_only, void *stream)
 {
     if (n <= 0) return 0;
     const int bitdepth_max = (1 << bpc) - 1;
     if (bpc == 8)
-        hipLaunchKernelGGL((cdef_kernel<uint8_t>), dim3(n), dim3(64), 0, (hipStream_t) stream, *dst, *src, tasks, n, damping, layout, bitdepth_max, dirvar);
+        hipLaunchKernelGGL((cdef_kernel<uint8_t>), dim3(n), dim3(64), 0, (hipStream_t) stream, *dst, *src, tasks, n, damping, layout, bitdepth_max, dirvar, raw_only);
     else
-        hipLaunchKernelGGL((cdef_kernel<uint16_t>), dim3(n), dim3(64), 0, (hipStream_t) stream, *dst, *src, tasks, n, damping, layout, bitdepth_max, dirvar);
+        hipLaunchKernelGGL((cdef_kernel<uint16_t>), dim3(n), dim3(64), 0, (hipStream_t) stream, *dst, *src, tasks, n, damping, layout, bitdepth_max, dirvar, raw_only);
     return hip_rc(hipGetLastError());
+}
+
+extern "C" int dav1d_hip_launch_cdef_groups(const DevPlanes *dst, const DevPlanes *src, int bpc, int layout, const Dav1dHipCdefTask *tasks,
+                                            const CdefGroup *groups, int n_groups, int damping, uint32_t *dirvar, void *stream)
+{
+    if (n_groups <= 0) return 0;
+    const int bitdepth_max = (1 << bpc) - 1;
+    if (bpc == 8)
+        hipLaunchKernelGGL((cdef_strip_kernel<uint8_t>), dim3(n_groups), dim3(64), 0, (hipStream_t) stream, *dst, *src, tasks, groups, n_groups, damping, layout, bitdepth_max, dirvar);
+    else
+        hipLaunchKernelGGL((cdef_strip_kernel<uint16_t>), dim3(n_groups), dim3(64), 0, (hipStream_t) stream, *dst, *src, tasks, groups, n_groups, damping, layout, bitdepth_max, dirvar);
+    return hip_rc(hipGetLastError());
+}
+
+// The strip kernel moves whole 16-byte (luma, 4:4:4 chroma) / 8-byte pieces: planes and strides have to be aligned for it
+// (pictures from dav1d_hip_picture_alloc are: 64-byte strides and plane starts).
+bool dav1d_hip_cdef_strip_ok(const DevPlanes *dst, const DevPlanes *src, int bpc) {
+    const int bps = bpc > 8 ? 2 : 1;
+    for (int p = 0; p < 3; p++) {
+        if (!src->data[p]) continue;
+        if (((uintptr_t) src->data[p] | (uintptr_t) dst->data[p]) & 15) return false;
+        if (((size_t) src->stride[p] * bps | (size_t) dst->stride[p] * bps) & 15) return false;
+    }
+    return true;
+}
+
+size_t dav1d_hip_cdef_make_groups(const Dav1dHipCdefTask *tasks, size_t n, size_t base, std::vector<CdefGroup> &out) {
+    size_t n_raw = 0;
+    bool open = false;
+    CdefGroup g = {};
+    int last_bx = 0, last_edges = 0;
+    for (size_t i = 0; i < n; i++) {
+        const Dav1dHipCdefTask &t = tasks[i];
+        if (t.flags & 1) { n_raw++; if (open) { out.push_back(g); open = false; } continue; }
+        // a unit joins the open group when it lies further right in the same row within 16 units of the group's first one, shares
+        // the rows above / below, has a left neighbour, and the unit before it has a right neighbour
+        const bool joins = open && t.by == g.by && t.bx > last_bx && t.bx - g.bx0 < 16 && g.n < 16 && (t.edges & 12) == (g.edges & 12) &&
+                           (t.edges & 1) && (last_edges & 2);
+        if (!joins) {
+            if (open) out.push_back(g);
+            g.first = (uint32_t) (base + i); g.bx0 = t.bx; g.by = t.by; g.n = 0; g.pad = 0;
+            g.edges = (uint8_t) (t.edges & 13);
+            open = true;
+        }
+        g.n++;
+        g.span = (uint8_t) (t.bx - g.bx0 + 1);
+        g.edges = (uint8_t) ((g.edges & 13) | (t.edges & 2));
+        last_bx = t.bx; last_edges = t.edges;
+    }
+    if (open) out.push_back(g);
+    return n_raw;
 }

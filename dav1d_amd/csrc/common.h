@@ -51,6 +51,59 @@ __device__ __forceinline__ int sub_floor0(int a, int b) {               // max(0
 }
 __device__ __forceinline__ uint32_t pack2(int lo, int hi) { return (uint32_t) (lo & 0xffff) | ((uint32_t) hi << 16); }
 
+// ---- two 16-bit values per 32-bit register (v_pk_* on gfx950); `2` = one value per half
+#ifdef DAV1D_HIP_EMU
+#define DV_PK2(expr_lo, expr_hi) ((uint32_t) ((expr_lo) & 0xffff) | ((uint32_t) ((expr_hi) & 0xffff) << 16))
+#define DV_LO(v) ((int) (int16_t) ((v) & 0xffff))
+#define DV_HI(v) ((int) (int16_t) ((v) >> 16))
+#define DV_ULO(v) ((int) ((v) & 0xffff))
+#define DV_UHI(v) ((int) ((v) >> 16))
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return DV_PK2(DV_LO(a) + DV_LO(b), DV_HI(a) + DV_HI(b)); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return DV_PK2(DV_LO(a) - DV_LO(b), DV_HI(a) - DV_HI(b)); }
+__device__ __forceinline__ uint32_t pk_sub_u16_sat(uint32_t a, uint32_t b) {      // max(0, a - b) on unsigned halves
+    return DV_PK2(DV_ULO(a) > DV_ULO(b) ? DV_ULO(a) - DV_ULO(b) : 0, DV_UHI(a) > DV_UHI(b) ? DV_UHI(a) - DV_UHI(b) : 0);
+}
+__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) { return DV_PK2(imin(DV_LO(a), DV_LO(b)), imin(DV_HI(a), DV_HI(b))); }
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) { return DV_PK2(imax(DV_LO(a), DV_LO(b)), imax(DV_HI(a), DV_HI(b))); }
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) { return DV_PK2(imin(DV_ULO(a), DV_ULO(b)), imin(DV_UHI(a), DV_UHI(b))); }
+__device__ __forceinline__ uint32_t pk_lshr(uint32_t v, uint32_t sh2) { return DV_PK2(DV_ULO(v) >> (sh2 & 15), DV_UHI(v) >> ((sh2 >> 16) & 15)); }
+__device__ __forceinline__ uint32_t pk_ashr(uint32_t v, uint32_t sh2) { return DV_PK2(DV_LO(v) >> (sh2 & 15), DV_HI(v) >> ((sh2 >> 16) & 15)); }
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) {  // a * b + c, low 16 bits per half
+    return DV_PK2(DV_LO(a) * DV_LO(b) + DV_LO(c), DV_HI(a) * DV_HI(b) + DV_HI(c));
+}
+#else
+typedef short pk_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short pk_u2 __attribute__((ext_vector_type(2)));
+#define DV_S2(v) __builtin_bit_cast(dv::pk_s2, (uint32_t) (v))
+#define DV_U2(v) __builtin_bit_cast(dv::pk_u2, (uint32_t) (v))
+#define DV_R(v) __builtin_bit_cast(uint32_t, (v))
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return DV_R(DV_S2(a) + DV_S2(b)); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return DV_R(DV_S2(a) - DV_S2(b)); }
+__device__ __forceinline__ uint32_t pk_sub_u16_sat(uint32_t a, uint32_t b) { return DV_R(__builtin_elementwise_sub_sat(DV_U2(a), DV_U2(b))); }
+__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) { return DV_R(__builtin_elementwise_min(DV_S2(a), DV_S2(b))); }
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) { return DV_R(__builtin_elementwise_max(DV_S2(a), DV_S2(b))); }
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) { return DV_R(__builtin_elementwise_min(DV_U2(a), DV_U2(b))); }
+__device__ __forceinline__ uint32_t pk_lshr(uint32_t v, uint32_t sh2) { return DV_R(DV_U2(v) >> DV_U2(sh2)); }
+__device__ __forceinline__ uint32_t pk_ashr(uint32_t v, uint32_t sh2) { return DV_R(DV_S2(v) >> DV_S2(sh2)); }
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) { return DV_R(DV_S2(a) * DV_S2(b) + DV_S2(c)); }
+#endif
+__device__ __forceinline__ uint32_t rep2(int v) { return (uint32_t) (v & 0xffff) * 0x10001u; }   // the same value in both halves
+
+// D = A x B + C on the matrix cores, int8 operands: A 16 x 64, B 64 x 16, C / D 16 x 16 int32 (v_mfma_i32_16x16x64_i8).
+// Lane l supplies 16 bytes of row l & 15 of A and 16 bytes of column l & 15 of B, both for the SAME 16 values of k (chosen
+// by l >> 4 and the byte position), and gets D[4 * (l >> 4) + r][l & 15] in c[r].
+__device__ __forceinline__ void mfma_i32_16x16x64_i8(const uint4 a, const uint4 b, int c[4]) {
+#ifdef DAV1D_HIP_EMU
+    emu_mfma_i32_16x16x64_i8(&a.x, &b.x, c);
+#else
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i acc = { c[0], c[1], c[2], c[3] };
+    const v4i va = { (int) a.x, (int) a.y, (int) a.z, (int) a.w }, vb = { (int) b.x, (int) b.y, (int) b.z, (int) b.w };
+    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(va, vb, acc, 0, 0, 0);
+    c[0] = acc[0]; c[1] = acc[1]; c[2] = acc[2]; c[3] = acc[3];
+#endif
+}
+
 // LDS hand-off between the lanes of ONE wave (no other wave reads the data): order the
 // accesses and let the wave's outstanding LDS operations land; no s_barrier involved, so
 // waves of a workgroup never wait for each other.

@@ -172,7 +172,7 @@ static int post_filters_pipelined(Dav1dHipFrame *f, const Dav1dHipPicture **last
             if (has_cdef && bc >= 0 && bc < nb && !rc) {
                 if (has_lf) (void) hipStreamWaitEvent(sb, ev[bc + 1 < nb ? bc + 1 : nb - 1], 0);
                 const size_t n = cdef_off[bc + 1] - cdef_off[bc];
-                if (n) rc = dav1d_hip_launch_cdef(&t0, &cur, f->cur.bpc, layout, d_cdef + cdef_off[bc], (int) n, f->cdef_damping, nullptr, sb);
+                if (n) rc = dav1d_hip_launch_cdef(&t0, &cur, f->cur.bpc, layout, d_cdef + cdef_off[bc], (int) n, f->cdef_damping, nullptr, 0, sb);
                 (void) hipEventRecord(ev[nb + bc], sb);
             }
             const int br = b - 2;                    // restoration one band behind CDEF

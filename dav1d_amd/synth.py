@@ -223,16 +223,16 @@ def make_frame(w, h, bpc, seed, mix=(0.20, 0.30, 0.30, 0.15, 0.05), compound_fra
     return f
 
 
-def make_planes(rng, w, h, bpc, smooth=True):
-    """Padded random reference planes (3x3 box-smoothed noise), list of 3 arrays.  Each array is a
+def make_planes(rng, w, h, bpc, smooth=True, layout=1):
+    """Padded random reference planes (3x3 box-smoothed noise), list of 3 arrays (1 for 4:0:0).  Each array is a
     (rows x cols) view into a buffer whose row stride equals the device picture's stride, so
     task offsets (y * stride + x) address host and device copies alike."""
-    geo = plane_geometry(w, h, bpc, 1)
+    geo = plane_geometry(w, h, bpc, layout)
     pd = np.uint8 if bpc == 8 else np.uint16
     out = []
-    for pl in range(3):
+    for pl in range(1 if layout == 0 else 3):
         rows = geo[pl][1]
-        cols = ((w + 127) & ~127) >> (1 if pl else 0)
+        cols = ((w + 127) & ~127) >> (1 if pl and layout != 3 else 0)
         a = rng.integers(0, 1 << bpc, size=(rows, cols), dtype=np.int32)
         if smooth:
             p = np.pad(a, 1, mode="edge")

@@ -130,6 +130,35 @@ static inline int __builtin_amdgcn_sdot2(uint32_t a, uint32_t b, int c, bool) {
 static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
     return (uint32_t) ((((uint64_t) hi << 32) | lo) >> (sh & 31));
 }
+static inline uint32_t __builtin_amdgcn_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
+    // v_perm_b32: result byte i = byte sel[i] of the 8 bytes { s1 (0..3), s0 (4..7) }; selector values above 7 are not used here
+    const uint64_t both = ((uint64_t) s0 << 32) | s1;
+    uint32_t out = 0;
+    for (int i = 0; i < 4; i++) out |= (uint32_t) ((both >> (8 * ((sel >> (8 * i)) & 7))) & 0xff) << (8 * i);
+    return out;
+}
+// v_mfma_i32_16x16x64_i8 as dv::mfma_i32_16x16x64_i8 describes it: every lane publishes its operand bytes, then computes its four
+// results from the operands of the lanes that hold the matching row of A / column of B.
+static inline void emu_mfma_i32_16x16x64_i8(const uint32_t *a, const uint32_t *b, int *c) {
+    uint32_t A[64][4], B[64][4];
+    uint64_t *s = emu_wave_slots();
+    for (int k = 0; k < 4; k++) {
+        s[emu_lane()] = ((uint64_t) b[k] << 32) | a[k];
+        emu_wave_sync();
+        for (int i = 0; i < 64; i++) { A[i][k] = (uint32_t) s[i]; B[i][k] = (uint32_t) (s[i] >> 32); }
+        emu_wave_sync();
+    }
+    s[emu_lane()] = 0;
+    const int l = emu_lane(), col = l & 15;
+    for (int r = 0; r < 4; r++) {
+        const int row = 4 * (l >> 4) + r;
+        int acc = c[r];
+        for (int g = 0; g < 4; g++)
+            for (int k = 0; k < 16; k++)
+                acc += (int) (int8_t) (A[row + 16 * g][k >> 2] >> (8 * (k & 3))) * (int) (int8_t) (B[col + 16 * g][k >> 2] >> (8 * (k & 3)));
+        c[r] = acc;
+    }
+}
 static inline int __mul24(int a, int b) { return (int) ((int64_t) ((a << 8) >> 8) * ((b << 8) >> 8)); }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned) v) : 32; }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
