@@ -396,23 +396,31 @@ __device__ __forceinline__ void cdef_load_piece(uint16_t *dstp, const pixel *src
 }
 
 // Window of one plane: rows y0 - 2 .. y0 + H + 1, 18 pieces of W pixels per row (piece p = picture columns x0 + (p - 1) * W ..),
-// of which 0 .. span + 1 are filled.  Unit u's pixels start at window column (u + 1) * W.
+// of which 0 .. span + 1 are filled.  Unit u's pixels start at window column (u + 1) * W.  Lanes 0 .. 53 take three rows of 18
+// pieces per pass: a lane keeps its piece and its row within the pass, only the row advances.
 template <typename pixel, int W, int H>
 __device__ __forceinline__ void cdef_load_window(uint16_t *win, const pixel *src, const int stride, const int x0, const int y0,
                                                  const int span, const int edges, const int lane)
 {
     constexpr int NPR = 18;
-    for (int i = lane; i < (H + 4) * NPR; i += 64) {
-        const int row = i / NPR, p = i - row * NPR;
-        if (p > span + 1) continue;
-        const bool ok = (row >= 2 || (edges & 4)) && (row < H + 2 || (edges & 8)) && (p > 0 || (edges & 1)) && (p <= span || (edges & 2));
-        cdef_load_piece<pixel, W>(win + (row * NPR + p) * W, src + (y0 + row - 2) * stride + x0 + (p - 1) * W, ok);
+    const int r3 = lane / NPR, p = lane - r3 * NPR;
+    if (lane >= 3 * NPR || p > span + 1) return;
+    const bool col_ok = (p > 0 || (edges & 1)) && (p <= span || (edges & 2));
+    const pixel *sp = src + (y0 + r3 - 2) * stride + x0 + (p - 1) * W;
+    uint16_t *wp = win + (r3 * NPR + p) * W;
+#pragma unroll
+    for (int it = 0; it < (H + 4 + 2) / 3; it++) {
+        const int row = it * 3 + r3;
+        if ((H + 4) % 3 && row >= H + 4) break;
+        const bool ok = col_ok && (row >= 2 || (edges & 4)) && (row < H + 2 || (edges & 8));
+        cdef_load_piece<pixel, W>(wp + it * 3 * NPR * W, sp + it * 3 * stride, ok);
     }
 }
 
-struct CdefTapSet { uint32_t thr2, sh2, tap2[2], yx; };      // one strength: threshold, shift, the two tap weights, (dy, dx) x 2
+struct CdefTapSet { uint32_t thr2, sh2, tap2[2]; int off[2]; };      // one strength: threshold, shift, the two tap weights and offsets
 
-// 12 taps on RPL rows of W pixels (W / 2 packed pairs per row); `base` = window index (pixels) of the lane's first pixel
+// 12 taps on RPL rows of W pixels (W / 2 packed pairs per row); `base` = window index (pixels) of the lane's first pixel.
+// Taps outside, rows inside: the address and the odd-column shift of a tap are worked out once for all rows.
 template <int W, int RPL>
 __device__ __forceinline__ void cdef_filter_rows(const uint16_t *win, const int base, const bool any_pri, const bool any_sec,
                                                  const CdefTapSet pri, const CdefTapSet sec0, const CdefTapSet sec1,
@@ -420,53 +428,57 @@ __device__ __forceinline__ void cdef_filter_rows(const uint16_t *win, const int 
 {
     constexpr int NP = W / 2, WS = 18 * W;
     const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win);
+    uint32_t px[RPL][NP], sum[RPL][NP], mn[RPL][NP], mx[RPL][NP];
 #pragma unroll
-    for (int r = 0; r < RPL; r++) {
-        const int b = base + r * WS;
-        uint32_t px[NP], sum[NP], mn[NP], mx[NP];
+    for (int r = 0; r < RPL; r++)
 #pragma unroll
-        for (int j = 0; j < NP; j++) { px[j] = w32[(b >> 1) + j]; sum[j] = 0; mn[j] = mx[j] = px[j]; }
-        auto tap = [&](const CdefTapSet &ts, const int k, const int sign) {
-            const int dy = (int) (int8_t) (ts.yx >> (16 * k)), dx = (int) (int8_t) (ts.yx >> (16 * k + 8));
-            const int idx = b + sign * (dy * WS + dx);
-            const uint32_t *q = w32 + (idx >> 1);
-            const uint32_t shv = (uint32_t) (idx & 1) << 4;
+        for (int j = 0; j < NP; j++) { px[r][j] = w32[(base >> 1) + r * (WS / 2) + j]; sum[r][j] = 0; mn[r][j] = mx[r][j] = px[r][j]; }
+    auto tap = [&](const CdefTapSet &ts, const int k, const int idx) {
+        const uint32_t *q = w32 + (idx >> 1);
+        const uint32_t shv = (uint32_t) (idx & 1) << 4;
+#pragma unroll
+        for (int r = 0; r < RPL; r++) {
             uint32_t d[NP + 1];
 #pragma unroll
-            for (int j = 0; j <= NP; j++) d[j] = q[j];
+            for (int j = 0; j <= NP; j++) d[j] = q[r * (WS / 2) + j];
 #pragma unroll
             for (int j = 0; j < NP; j++) {
                 const uint32_t p = __builtin_amdgcn_alignbit(d[j + 1], d[j], shv);
                 // constrain(), src/cdef_tmpl.c:56-62, two pixels at a time
-                const uint32_t d1 = dv::pk_sub(p, px[j]), d2 = dv::pk_sub(px[j], p);
+                const uint32_t d1 = dv::pk_sub(p, px[r][j]), d2 = dv::pk_sub(px[r][j], p);
                 const uint32_t ad = dv::pk_max_i16(d1, d2);
                 const uint32_t lim = dv::pk_sub_u16_sat(ts.thr2, dv::pk_lshr(ad, ts.sh2));
                 const uint32_t c = dv::pk_min_i16(dv::pk_max_i16(d1, dv::pk_sub(0u, lim)), lim);
-                sum[j] = dv::pk_mad(c, ts.tap2[k], sum[j]);
-                mn[j] = dv::pk_min_u16(mn[j], p);
-                mx[j] = dv::pk_max_i16(mx[j], p);
+                sum[r][j] = dv::pk_mad(c, ts.tap2[k], sum[r][j]);
+                mn[r][j] = dv::pk_min_u16(mn[r][j], p);
+                mx[r][j] = dv::pk_max_i16(mx[r][j], p);
             }
-        };
-        if (any_pri) { tap(pri, 0, 1); tap(pri, 0, -1); tap(pri, 1, 1); tap(pri, 1, -1); }
-        if (any_sec) {
-            tap(sec0, 0, 1); tap(sec0, 0, -1); tap(sec1, 0, 1); tap(sec1, 0, -1);
-            tap(sec0, 1, 1); tap(sec0, 1, -1); tap(sec1, 1, 1); tap(sec1, 1, -1);
         }
+    };
+    if (any_pri) { tap(pri, 0, base + pri.off[0]); tap(pri, 0, base - pri.off[0]); tap(pri, 1, base + pri.off[1]); tap(pri, 1, base - pri.off[1]); }
+    if (any_sec) {
+        tap(sec0, 0, base + sec0.off[0]); tap(sec0, 0, base - sec0.off[0]); tap(sec1, 0, base + sec1.off[0]); tap(sec1, 0, base - sec1.off[0]);
+        tap(sec0, 1, base + sec0.off[1]); tap(sec0, 1, base - sec0.off[1]); tap(sec1, 1, base + sec1.off[1]); tap(sec1, 1, base - sec1.off[1]);
+    }
+#pragma unroll
+    for (int r = 0; r < RPL; r++)
 #pragma unroll
         for (int j = 0; j < NP; j++) {
             // px + ((sum - (sum < 0) + 8) >> 4)
-            uint32_t s = dv::pk_add(sum[j], dv::pk_ashr(sum[j], dv::rep2(15)));
+            uint32_t s = dv::pk_add(sum[r][j], dv::pk_ashr(sum[r][j], dv::rep2(15)));
             s = dv::pk_ashr(dv::pk_add(s, dv::rep2(8)), dv::rep2(4));
-            const uint32_t v = dv::pk_add(px[j], s);
+            const uint32_t v = dv::pk_add(px[r][j], s);
             // only the primary + secondary path clamps to the local range (src/cdef_tmpl.c:165 vs :185,209)
-            out[r][j] = clamp_range ? dv::pk_min_i16(dv::pk_max_i16(v, mn[j]), mx[j]) : v;
+            out[r][j] = clamp_range ? dv::pk_min_i16(dv::pk_max_i16(v, mn[r][j]), mx[r][j]) : v;
         }
-    }
 }
 
+template <int WS>
 __device__ __forceinline__ CdefTapSet cdef_tapset(const int strength, const int shift, const int tap0, const int tap1, const uint32_t yx) {
     CdefTapSet t;
-    t.thr2 = dv::rep2(strength); t.sh2 = dv::rep2(shift); t.tap2[0] = dv::rep2(tap0); t.tap2[1] = dv::rep2(tap1); t.yx = yx;
+    t.thr2 = dv::rep2(strength); t.sh2 = dv::rep2(shift); t.tap2[0] = dv::rep2(tap0); t.tap2[1] = dv::rep2(tap1);
+#pragma unroll
+    for (int k = 0; k < 2; k++) t.off[k] = (int) (int8_t) (yx >> (16 * k)) * WS + (int) (int8_t) (yx >> (16 * k + 8));
     return t;
 }
 
@@ -479,10 +491,10 @@ __device__ __forceinline__ void cdef_plane(const uint16_t *win, const uint32_t *
     constexpr int RPL = H / 4, NP = W / 2, WS = 18 * W;
     const bool any_pri = __any(run && pri), any_sec = __any(run && sec);
     const int pri_tap = 4 - ((pri >> bitdepth_min_8) & 1);
-    const CdefTapSet tp = cdef_tapset(pri, pri ? dv::imax(0, damping - ulog2(pri)) : 0, pri_tap, (pri_tap & 3) | 2, dir_yx[dir]);
+    const CdefTapSet tp = cdef_tapset<WS>(pri, pri ? dv::imax(0, damping - ulog2(pri)) : 0, pri_tap, (pri_tap & 3) | 2, dir_yx[dir]);
     const int sec_shift = sec ? damping - ulog2(sec) : 0;
-    const CdefTapSet ts0 = cdef_tapset(sec, sec_shift, 2, 1, dir_yx[(dir + 2) & 7]);
-    const CdefTapSet ts1 = cdef_tapset(sec, sec_shift, 2, 1, dir_yx[(dir + 6) & 7]);
+    const CdefTapSet ts0 = cdef_tapset<WS>(sec, sec_shift, 2, 1, dir_yx[(dir + 2) & 7]);
+    const CdefTapSet ts1 = cdef_tapset<WS>(sec, sec_shift, 2, 1, dir_yx[(dir + 6) & 7]);
     uint32_t out[RPL][NP];
     const int row0 = q * RPL;
     cdef_filter_rows<W, RPL>(win, (row0 + 2) * WS + (u + 1) * W, any_pri, any_sec, tp, ts0, ts1, pri && sec, out);
@@ -502,12 +514,15 @@ __device__ __forceinline__ void cdef_plane(const uint16_t *win, const uint32_t *
     }
 }
 
-template <typename pixel>
+// CW x CH = chroma unit (8x8 4:4:4, 4x8 4:2:2, 4x4 4:2:0; CW = 0: no chroma).  The three windows have LDS of their own, so
+// every load of the wave is in flight before the first wait.
+template <typename pixel, int CW, int CH>
 __global__ __launch_bounds__(64) void cdef_strip_kernel(const DevPlanes dst, const DevPlanes src, const Dav1dHipCdefTask *__restrict__ tasks,
                                                         const CdefGroup *__restrict__ groups, const int n_groups, const int damping,
                                                         const int layout, const int bitdepth_max, uint32_t *__restrict__ dirvar)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t win[12 * 18 * 8];
+    constexpr int CWIN = CW ? (CH + 4) * 18 * CW : 8;
+    __shared__ __attribute__((aligned(16))) uint16_t win[12 * 18 * 8], cwin[2][CWIN];
     __shared__ uint32_t traw[16][2], upar[16][2], dir_yx[8];
 
     const int gi = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x);
@@ -521,13 +536,22 @@ __global__ __launch_bounds__(64) void cdef_strip_kernel(const DevPlanes dst, con
     if (lane < 16) { traw[lane][0] = 0; traw[lane][1] = 0; }
     if (lane < 8) dir_yx[lane] = cdef_dir_yx_tab[lane];
     dv::wave_sync();
+    bool uv = false;
     if (lane < g.n) {
         const Dav1dHipCdefTask t = tasks[g.first + lane];
         const int slot = t.bx - g.bx0;
         traw[slot][0] = (uint32_t) t.y_pri | (uint32_t) t.y_sec << 8 | (uint32_t) t.uv_pri << 16 | (uint32_t) t.uv_sec << 24;
         traw[slot][1] = 0x100u | (uint32_t) lane;                       // present, rank in the group
+        uv = t.uv_pri || t.uv_sec;
     }
+    const bool any_uv = CW && __any(uv);
+    constexpr int ss_hor = CW == 4, ss_ver = CH == 4;
+    const int cx0 = x0 >> ss_hor, cy0 = y0 >> ss_ver;
     cdef_load_window<pixel, 8, 8>(win, reinterpret_cast<const pixel *>(src.data[0]), src.stride[0], x0, y0, span, edges, lane);
+    if (CW && any_uv) {
+        cdef_load_window<pixel, CW ? CW : 8, CW ? CH : 8>(cwin[0], reinterpret_cast<const pixel *>(src.data[1]), src.stride[1], cx0, cy0, span, edges, lane);
+        cdef_load_window<pixel, CW ? CW : 8, CW ? CH : 8>(cwin[1], reinterpret_cast<const pixel *>(src.data[2]), src.stride[2], cx0, cy0, span, edges, lane);
+    }
     dv::wave_sync();
 
     // ---- direction search for unit n = lane & 15 (every lane of the four 16-lane rows ends up with the unit's eight costs)
@@ -556,8 +580,9 @@ __global__ __launch_bounds__(64) void cdef_strip_kernel(const DevPlanes dst, con
                 int acc[4] = { 0, 0, 0, 0 };
                 dv::mfma_i32_16x16x64_i8(a, b, acc);
                 const uint2 wq = *reinterpret_cast<const uint2 *>(&cdef_dir_tab.w[t][4 * gq]);
-                unsigned c = (unsigned) (acc[0] * acc[0]) * (wq.x & 0xffff) + (unsigned) (acc[1] * acc[1]) * (wq.x >> 16) +
-                             (unsigned) (acc[2] * acc[2]) * (wq.y & 0xffff) + (unsigned) (acc[3] * acc[3]) * (wq.y >> 16);
+                // |sum| <= 16 * 128 and weight <= 840: 24-bit multiplies (full rate) are exact here
+                unsigned c = dv::mul_u24((unsigned) dv::mul_i24(acc[0], acc[0]), wq.x & 0xffff) + dv::mul_u24((unsigned) dv::mul_i24(acc[1], acc[1]), wq.x >> 16) +
+                             dv::mul_u24((unsigned) dv::mul_i24(acc[2], acc[2]), wq.y & 0xffff) + dv::mul_u24((unsigned) dv::mul_i24(acc[3], acc[3]), wq.y >> 16);
                 c += (unsigned) __shfl_xor((int) c, 16);
                 if (t < 6) {
                     c += (unsigned) __shfl_xor((int) c, 32);
@@ -604,23 +629,13 @@ __global__ __launch_bounds__(64) void cdef_strip_kernel(const DevPlanes dst, con
     const uint32_t p0 = upar[u][0], p1 = upar[u][1];
     cdef_plane<pixel, 8, 8>(win, dir_yx, reinterpret_cast<pixel *>(dst.data[0]), dst.stride[0], x0, y0, u, q, p0 & 0xff, p0 >> 8 & 0xff,
                             p0 >> 16 & 0xff, damping, bitdepth_min_8, p0 >> 24 & 1);
-    if (layout == DAV1D_HIP_LAYOUT_I400 || !__any(p1 >> 24 & 1)) return;
-    const int ss_ver = layout == DAV1D_HIP_LAYOUT_I420, ss_hor = layout != DAV1D_HIP_LAYOUT_I444;
-    const int cx0 = x0 >> ss_hor, cy0 = y0 >> ss_ver;
-    for (int pl = 1; pl < 3; pl++) {
-        const pixel *sp = reinterpret_cast<const pixel *>(src.data[pl]);
-        pixel *dp = reinterpret_cast<pixel *>(dst.data[pl]);
-        dv::wave_sync();
-        if (!ss_hor) cdef_load_window<pixel, 8, 8>(win, sp, src.stride[pl], cx0, cy0, span, edges, lane);
-        else if (!ss_ver) cdef_load_window<pixel, 4, 8>(win, sp, src.stride[pl], cx0, cy0, span, edges, lane);
-        else cdef_load_window<pixel, 4, 4>(win, sp, src.stride[pl], cx0, cy0, span, edges, lane);
-        dv::wave_sync();
-        const int pri = p1 & 0xff, sec = p1 >> 8 & 0xff, d = p1 >> 16 & 0xff;
-        const bool run = p1 >> 24 & 1;
-        if (!ss_hor) cdef_plane<pixel, 8, 8>(win, dir_yx, dp, dst.stride[pl], cx0, cy0, u, q, pri, sec, d, damping - 1, bitdepth_min_8, run);
-        else if (!ss_ver) cdef_plane<pixel, 4, 8>(win, dir_yx, dp, dst.stride[pl], cx0, cy0, u, q, pri, sec, d, damping - 1, bitdepth_min_8, run);
-        else cdef_plane<pixel, 4, 4>(win, dir_yx, dp, dst.stride[pl], cx0, cy0, u, q, pri, sec, d, damping - 1, bitdepth_min_8, run);
-    }
+    if (!CW || !any_uv) return;
+    const int pri = p1 & 0xff, sec = p1 >> 8 & 0xff, d = p1 >> 16 & 0xff;
+    const bool run = p1 >> 24 & 1;
+#pragma unroll
+    for (int pl = 1; pl < 3; pl++)
+        cdef_plane<pixel, CW ? CW : 8, CW ? CH : 8>(cwin[pl - 1], dir_yx, reinterpret_cast<pixel *>(dst.data[pl]), dst.stride[pl], cx0, cy0, u, q,
+                                                      pri, sec, d, damping - 1, bitdepth_min_8, run);
 }
 
 } // namespace
@@ -637,15 +652,26 @@ extern "C" int dav1d_hip_launch_cdef(const DevPlanes *dst, const DevPlanes *src,
     return hip_rc(hipGetLastError());
 }
 
+template <typename pixel>
+static void launch_strips(const DevPlanes *dst, const DevPlanes *src, int layout, const Dav1dHipCdefTask *tasks, const CdefGroup *groups,
+                          int n_groups, int damping, int bitdepth_max, uint32_t *dirvar, hipStream_t stream)
+{
+#define STRIPS(CW, CH) hipLaunchKernelGGL((cdef_strip_kernel<pixel, CW, CH>), dim3(n_groups), dim3(64), 0, stream, *dst, *src, tasks, groups, \
+                                          n_groups, damping, layout, bitdepth_max, dirvar)
+    if (layout == DAV1D_HIP_LAYOUT_I420) STRIPS(4, 4);
+    else if (layout == DAV1D_HIP_LAYOUT_I422) STRIPS(4, 8);
+    else if (layout == DAV1D_HIP_LAYOUT_I444) STRIPS(8, 8);
+    else STRIPS(0, 0);
+#undef STRIPS
+}
+
 extern "C" int dav1d_hip_launch_cdef_groups(const DevPlanes *dst, const DevPlanes *src, int bpc, int layout, const Dav1dHipCdefTask *tasks,
                                             const CdefGroup *groups, int n_groups, int damping, uint32_t *dirvar, void *stream)
 {
     if (n_groups <= 0) return 0;
     const int bitdepth_max = (1 << bpc) - 1;
-    if (bpc == 8)
-        hipLaunchKernelGGL((cdef_strip_kernel<uint8_t>), dim3(n_groups), dim3(64), 0, (hipStream_t) stream, *dst, *src, tasks, groups, n_groups, damping, layout, bitdepth_max, dirvar);
-    else
-        hipLaunchKernelGGL((cdef_strip_kernel<uint16_t>), dim3(n_groups), dim3(64), 0, (hipStream_t) stream, *dst, *src, tasks, groups, n_groups, damping, layout, bitdepth_max, dirvar);
+    if (bpc == 8) launch_strips<uint8_t>(dst, src, layout, tasks, groups, n_groups, damping, bitdepth_max, dirvar, (hipStream_t) stream);
+    else launch_strips<uint16_t>(dst, src, layout, tasks, groups, n_groups, damping, bitdepth_max, dirvar, (hipStream_t) stream);
     return hip_rc(hipGetLastError());
 }
 

@@ -87,7 +87,32 @@ __device__ __forceinline__ uint32_t pk_lshr(uint32_t v, uint32_t sh2) { return D
 __device__ __forceinline__ uint32_t pk_ashr(uint32_t v, uint32_t sh2) { return DV_R(DV_S2(v) >> DV_S2(sh2)); }
 __device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) { return DV_R(DV_S2(a) * DV_S2(b) + DV_S2(c)); }
 #endif
-__device__ __forceinline__ uint32_t rep2(int v) { return (uint32_t) (v & 0xffff) * 0x10001u; }   // the same value in both halves
+// full-rate 24-bit multiplies (v_mul_i32_i24 / v_mul_u32_u24): exact when both operands fit 24 bits
+__device__ __forceinline__ int mul_i24(int a, int b) {
+#ifdef DAV1D_HIP_EMU
+    return a * b;
+#else
+    int r;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#endif
+}
+__device__ __forceinline__ unsigned mul_u24(unsigned a, unsigned b) {
+#ifdef DAV1D_HIP_EMU
+    return a * b;
+#else
+    unsigned r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#endif
+}
+__device__ __forceinline__ uint32_t rep2(int v) {                     // the same value in both halves
+#ifdef DAV1D_HIP_EMU
+    return (uint32_t) (v & 0xffff) * 0x10001u;
+#else
+    return __builtin_amdgcn_perm((uint32_t) v, (uint32_t) v, 0x05040100u);
+#endif
+}
 
 // D = A x B + C on the matrix cores, int8 operands: A 16 x 64, B 64 x 16, C / D 16 x 16 int32 (v_mfma_i32_16x16x64_i8).
 // Lane l supplies 16 bytes of row l & 15 of A and 16 bytes of column l & 15 of B, both for the SAME 16 values of k (chosen

@@ -160,6 +160,7 @@ static inline void emu_mfma_i32_16x16x64_i8(const uint32_t *a, const uint32_t *b
     }
 }
 static inline int __mul24(int a, int b) { return (int) ((int64_t) ((a << 8) >> 8) * ((b << 8) >> 8)); }
+static inline unsigned __umul24(unsigned a, unsigned b) { return (unsigned) ((uint64_t) (a & 0xffffff) * (b & 0xffffff)); }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned) v) : 32; }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long) v); }
