@@ -538,36 +538,20 @@ def main():
         # ---- end to end: the same kind of frame from dav1d's pass-1 hand-off arrays (Av1Block / cbi / cf) through the pass-2
         # lister on host threads, the chunk preparation, the coefficient upload and frame_end; checked against the reference's OWN
         # pass 2 (dav1d_decode_tile_sbrow on a real Dav1dFrameContext, oracle/ref_frame.c) when the reference build is there
-        e2e_leg = None
+        e2e_leg = key_leg = None
         if world == 1 and not a.no_e2e:
             from dav1d_amd import e2e
 
-            def e2e_check(ho, planes, ref_pics):
+            def e2e_check(ho, planes, ref_pics, is_inter=True):
                 import lister_util as lu
-                if lu.ref_lib() is None:
-                    return "skipped (no reference build)"
-                rf = lu.RefFrame(ho.w, ho.h, ho.layout, ho.bpc, is_inter=True, sb128=True, tile_cols=ho.desc.n_tile_cols, tile_rows=1)
                 try:
-                    for name, src in (("b", ho.b), ("cbi", ho.cbi.view(np.uint8)), ("cf", ho.cf)):
-                        dst = rf.array(name, np.uint8)
-                        assert len(dst) == len(src), (name, len(dst), len(src))
-                        dst[:] = src
-                    assert np.array_equal(rf.array("tile_start_off", np.uint32)[:len(ho.tile_start_off)], ho.tile_start_off)
-                    for i in range(7):
-                        for pl in range(3):
-                            hostp = ref_pics[i % 3].download(pl)
-                            dstp = rf.plane(1 + i, pl)
-                            dstp[:hostp.shape[0], :hostp.shape[1]] = hostp
-                    t0 = time.perf_counter()
-                    rf.recon()
-                    t_ref = time.perf_counter() - t0
-                    bad = lu.compare(rf, planes)
-                    if bad:
-                        raise SystemExit("bench: end-to-end leg differs from the reference's pass 2: %s" % bad)
-                    return "bit-exact vs the reference's own pass 2 (dav1d_decode_tile_sbrow, 1 thread: %.2f s for this frame)" % t_ref
-                finally:
-                    rf.destroy()
+                    return lu.check_handoff_against_reference(ho, planes, ref_pics, is_inter)
+                except AssertionError as e:
+                    raise SystemExit("bench: end-to-end leg differs from the reference's pass 2: %s" % e)
             e2e_leg = e2e.run(ctx, w, h, bpc, frames=6, threads=None, tile_cols=a.e2e_tile_cols, check=None if a.no_check else e2e_check)
+            # the key-frame worst case (reference src/recon_tmpl.c:1239-1333, every block through the intra wavefront): same route
+            key_leg = e2e.run(ctx, w, h, bpc, frames=4, threads=None, tile_cols=a.e2e_tile_cols, key_frame=True, seed=0xE2F,
+                              check=None if a.no_check else (lambda ho, planes, refs: e2e_check(ho, planes, refs, is_inter=False)))
         label = "8K" if (w, h) == (7680, 4320) else "4K" if (w, h) == (3840, 2160) else "%dx%d" % (w, h)
         out = {"metric": "reconstructed luma Mpixels/s (%s 4:2:0 %d-bit) on the itx+mc recon path; bit-exact vs C" % (label, bpc),
                "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -583,7 +567,7 @@ def main():
                           "coef_format": "packed: eob + 1 scan-order values per block" if a.packed else "dense cf arena (reference layout)",
                           "coef_bytes_per_frame": int(coef_host.nbytes), "coef_h2d_ms_per_frame": h2d_ms,
                           "samples_per_frame": frame.n_samples, "parity": check, "gen_seconds": round(t_gen, 1)},
-               "roofline": roof, "cpu_baseline": cpu, "full_table": full, "end_to_end": e2e_leg}
+               "roofline": roof, "cpu_baseline": cpu, "full_table": full, "end_to_end": e2e_leg, "all_intra": key_leg}
         if packed_leg is not None:
             packed_leg.pop("_pictures", None)
             packed_leg.setdefault("parity", "skipped")

@@ -302,6 +302,9 @@ class Context:
     def ipred_list(self, batches):
         return _IpredList(self, batches)
 
+    def intra_flow(self, batches):
+        return _IntraFlow(self, batches)
+
     # ---- device-resident lists
     def itx_list(self, tasks):
         return _List(self, "itx", tasks, ITX_TASK)
@@ -381,6 +384,35 @@ class _IntraList:
     def destroy(self):
         if self.h:
             self.ctx.lib.dav1d_hip_intra_list_destroy(self.ctx.h, self.h)
+            self.h = C.c_void_p()
+
+
+class _IntraFlow:
+    """dav1d_hip_intra_flow_*: the whole wavefront as one launch."""
+
+    def __init__(self, ctx, batches):
+        self.ctx = ctx
+        ps = (C.c_size_t * max(len(batches), 1))(*[len(b[0]) for b in batches])
+        ts = (C.c_size_t * max(len(batches), 1))(*[len(b[1]) for b in batches])
+        allp = np.ascontiguousarray(np.concatenate([b[0] for b in batches]) if batches else np.zeros(0, IPRED_TASK), dtype=IPRED_TASK)
+        allt = np.ascontiguousarray(np.concatenate([b[1] for b in batches]) if batches else np.zeros(0, ITX_TASK), dtype=ITX_TASK)
+        self.h = C.c_void_p()
+        _chk(ctx.lib.dav1d_hip_intra_flow_create(ctx.h, C.byref(self.h), allp.ctypes.data, ps, allt.ctypes.data, ts, len(batches)),
+             "intra_flow_create")
+        self.n_units = int(ctx.lib.dav1d_hip_intra_flow_units(self.h))
+
+    def run(self, dst, coef, aux=None):
+        _chk(self.ctx.lib.dav1d_hip_intra_flow_run(self.ctx.h, self.h, C.byref(dst.pic), coef.ptr if hasattr(coef, "ptr") else coef,
+                                                   aux.ptr if aux else None), "intra_flow_run")
+
+    def status(self):
+        out = (C.c_uint32 * 3)()
+        _chk(self.ctx.lib.dav1d_hip_intra_flow_status(self.ctx.h, self.h, out), "intra_flow_status")
+        return tuple(int(v) for v in out)
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.dav1d_hip_intra_flow_destroy(self.ctx.h, self.h)
             self.h = C.c_void_p()
 
 

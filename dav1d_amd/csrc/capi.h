@@ -20,6 +20,9 @@ struct Dav1dHipContext {
     hipEvent_t ev_fork, ev_join[N_SIDE];
     hipEvent_t ev_bin[16];      // "this tile shape's predictions are in the picture" (recon list pipeline)
     bool concurrent;
+    int flow_min_steps;         // wavefronts of at least this many steps run as one dataflow launch ($DAV1D_HIP_FLOW_MIN_STEPS, 0 = never)
+    int flow_mode;              // $DAV1D_HIP_FLOW_MODE at open: hand-off variant of the intra dataflow launch (intra_flow.hip)
+    int flow_groups;            // workgroups of the intra dataflow launch ($DAV1D_HIP_FLOW_GROUPS at open, default 256 = one per CU: more waves mostly poll)
     bool cdef_unit_kernel;      // $DAV1D_HIP_CDEF_UNIT=1 at open: one wave per 8x8 unit (the round-1 kernel) instead of strips; A/B aid
     // measurement aid: device time of the kernel launches of the most recent *_batch call (dav1d_hip_last_kernel_ms)
     hipEvent_t ev_t0, ev_t1;
@@ -142,6 +145,29 @@ extern "C" int dav1d_hip_launch_mc_bin(const DevPlanes *dst, const DevPlanes *re
                                        const McTile *tiles, int n, int16_t *prep, void *stream);
 extern "C" int dav1d_hip_launch_comp(const DevPlanes *dst, int bpc, const Dav1dHipCompTask *tasks, int n,
                                      const int16_t *prep, uint8_t *mask, void *stream);
+
+// One unit of the intra dataflow launch (intra_flow.hip): prediction and / or residual of one transform block, records included
+// so that a wave has everything about a unit after ONE scalar fetch.
+struct IntraUnit {
+    uint32_t need;              // units that have to be finished before this one starts (= units in earlier steps)
+    uint32_t has;               // bit 0: p holds a prediction, bit 1: t holds a residual
+    uint32_t pad[2];
+    Dav1dHipIpredTask p;
+    Dav1dHipItxTask t;
+    uint32_t pad2;
+};
+static_assert(sizeof(IntraUnit) == 80, "unit record layout");
+extern "C" int dav1d_hip_launch_intra_flow(const DevPlanes *dst, int bpc, int layout, const IntraUnit *units, int n_units, uint8_t *aux,
+                                           void *coef, uint32_t *ctr, int max_groups, int mode, void *stream);
+struct Dav1dHipIntraFlow;
+// batches (wavefront steps) of predictions + residuals -> device-resident unit list; -ENOTSUP when the list holds a task
+// kind the dataflow launch does not run (PRED_TMP for inter-intra, DSP-level kinds): the caller keeps the stepped route
+extern "C" int dav1d_hip_intra_flow_create(Dav1dHipContext *c, Dav1dHipIntraFlow **out, const Dav1dHipIpredTask *preds, const size_t *pred_sizes,
+                                           const Dav1dHipItxTask *txs, const size_t *tx_sizes, size_t n_batches);
+extern "C" int dav1d_hip_intra_flow_run(Dav1dHipContext *c, const Dav1dHipIntraFlow *l, const Dav1dHipPicture *dst, void *coef, uint8_t *aux);
+extern "C" void dav1d_hip_intra_flow_destroy(Dav1dHipContext *c, Dav1dHipIntraFlow *l);
+extern "C" size_t dav1d_hip_intra_flow_units(const Dav1dHipIntraFlow *l);
+extern "C" int dav1d_hip_intra_flow_status(Dav1dHipContext *c, const Dav1dHipIntraFlow *l, uint32_t out[3]);
 
 // raw_only: tasks without the RAW flag are left alone (they are run by groups, below)
 extern "C" int dav1d_hip_launch_cdef(const DevPlanes *dst, const DevPlanes *src, int bpc, int layout,

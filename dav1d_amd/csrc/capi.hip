@@ -33,6 +33,12 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     c->concurrent = !(ser && atoi(ser));
     const char *cu = getenv("DAV1D_HIP_CDEF_UNIT");
     c->cdef_unit_kernel = cu && atoi(cu);
+    const char *fg = getenv("DAV1D_HIP_FLOW_GROUPS");
+    c->flow_groups = fg && atoi(fg) > 0 ? atoi(fg) : 256;
+    const char *fm = getenv("DAV1D_HIP_FLOW_MODE");
+    c->flow_mode = fm ? atoi(fm) : 0;
+    const char *fs = getenv("DAV1D_HIP_FLOW_MIN_STEPS");
+    c->flow_min_steps = fs ? atoi(fs) : 200;
     for (int i = 0; i < Dav1dHipContext::N_SIDE; i++) {
         if (hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
@@ -1807,6 +1813,127 @@ int dav1d_hip_intra_list_create_blend(Dav1dHipContext *c, Dav1dHipIntraList **ou
     if (rc) { dav1d_hip_intra_list_destroy(c, l); return rc; }
     *out = l;
     return 0;
+}
+
+// ------------------------------------------------------------------ intra dataflow launch (intra_flow.hip)
+struct Dav1dHipIntraFlow {
+    IntraUnit *units;
+    uint32_t *ctr;
+    size_t n_units, n_steps;
+    bool needs_aux;
+};
+
+void dav1d_hip_intra_flow_destroy(Dav1dHipContext *c, Dav1dHipIntraFlow *l) {
+    if (!l) return;
+    hipStreamSynchronize(c->stream);
+    if (l->units) hipFree(l->units);
+    if (l->ctr) hipFree(l->ctr);
+    delete l;
+}
+size_t dav1d_hip_intra_flow_units(const Dav1dHipIntraFlow *l) { return l ? l->n_units : 0; }
+// after a run: tickets drawn, units finished, waves that gave up waiting (0 unless something is broken); synchronizes
+int dav1d_hip_intra_flow_status(Dav1dHipContext *c, const Dav1dHipIntraFlow *l, uint32_t out[3]) {
+    if (!c || !l || !out) return -EINVAL;
+    uint32_t w[65];      // ticket, done, error live in words 0 / 32 / 64 (intra_flow.hip)
+    const int rc = dav1d_hip_download(c, w, l->ctr, sizeof(w));
+    out[0] = w[0]; out[1] = w[32]; out[2] = w[64];
+    return rc;
+}
+
+int dav1d_hip_intra_flow_create(Dav1dHipContext *c, Dav1dHipIntraFlow **out, const Dav1dHipIpredTask *preds, const size_t *pred_sizes,
+                                const Dav1dHipItxTask *txs, const size_t *tx_sizes, size_t n_batches) {
+    if (!c || !out || !pred_sizes || !tx_sizes) return -EINVAL;
+    *out = nullptr;
+    size_t np = 0, nt = 0;
+    for (size_t k = 0; k < n_batches; k++) { np += pred_sizes[k]; nt += tx_sizes[k]; }
+    if ((np && !preds) || (nt && !txs)) return -EINVAL;
+    uint8_t dummy = 0;
+    if (ipred_tasks_valid(preds, np, &dummy)) return -EINVAL;
+    for (size_t i = 0; i < nt; i++) if (!itx_task_ok(txs[i])) return -EINVAL;
+    bool needs_aux = false;
+    for (size_t i = 0; i < np; i++) {
+        const int k = preds[i].kind;
+        if (k != DAV1D_HIP_IPRED_PRED && k != DAV1D_HIP_IPRED_CFL && k != DAV1D_HIP_IPRED_PAL) return -ENOTSUP;
+        if (k == DAV1D_HIP_IPRED_PAL) needs_aux = true;
+    }
+    if (np >= 0xffffffffu || nt >= 0xffffffffu) return -ENOTSUP;
+    // units step by step: a prediction with the residual of the same rectangle (that is how the reference walks an intra block:
+    // predict a transform block, add its residual, next one), the predictions without one, then the residuals without a
+    // prediction of their own — those wait for every prediction of their step (a palette block: one prediction, many residuals)
+    std::vector<IntraUnit> units;
+    units.reserve(np + nt / 4);
+    auto unit = [&](const Dav1dHipIpredTask *p, const Dav1dHipItxTask *t, uint32_t need) {
+        IntraUnit u;
+        memset(&u, 0, sizeof(u));
+        u.need = need;
+        if (p) { u.p = *p; u.has |= 1; }
+        if (t) { u.t = *t; itx_fill_prefix(u.t); u.has |= 2; }
+        units.push_back(u);
+    };
+    size_t p0 = 0, t0 = 0;
+    std::vector<uint32_t> slot;        // open-addressed map (plane, dst_off) -> transform task of the batch
+    std::vector<char> taken;
+    size_t n_steps = 0;
+    for (size_t k = 0; k < n_batches; k++) {
+        const size_t ntk = tx_sizes[k], npk = pred_sizes[k];
+        size_t cap = 16;
+        while (cap < 2 * ntk + 2) cap <<= 1;
+        slot.assign(cap, 0xffffffffu);
+        taken.assign(ntk, 0);
+        auto hash = [&](uint32_t plane, uint32_t off) { return (size_t) ((off * 2654435761u) ^ (plane * 0x9e3779b9u)) & (cap - 1); };
+        for (size_t i = 0; i < ntk; i++) {
+            const Dav1dHipItxTask &t = txs[t0 + i];
+            size_t h = hash(t.plane, t.dst_off);
+            while (slot[h] != 0xffffffffu) h = (h + 1) & (cap - 1);
+            slot[h] = (uint32_t) i;
+        }
+        const uint32_t need0 = (uint32_t) units.size();
+        for (size_t i = 0; i < npk; i++) {
+            const Dav1dHipIpredTask &p = preds[p0 + i];
+            uint32_t j = 0xffffffffu;
+            for (size_t h = hash(p.plane, p.dst_off); slot[h] != 0xffffffffu; h = (h + 1) & (cap - 1)) {
+                const Dav1dHipItxTask &t = txs[t0 + slot[h]];
+                if (t.plane == p.plane && t.dst_off == p.dst_off && !taken[slot[h]] && k_tx_w[t.tx] == p.tw * 4 && k_tx_h[t.tx] == p.th * 4) {
+                    j = slot[h];
+                    break;
+                }
+            }
+            if (j != 0xffffffffu) taken[j] = 1;
+            unit(&p, j == 0xffffffffu ? nullptr : &txs[t0 + j], need0);
+        }
+        const uint32_t need1 = (uint32_t) units.size();
+        for (size_t i = 0; i < ntk; i++)
+            if (!taken[i]) unit(nullptr, &txs[t0 + i], need1);
+        n_steps += (units.size() > need0) + (units.size() > need1 && need1 > need0);
+        p0 += npk; t0 += ntk;
+    }
+    Dav1dHipIntraFlow *l = new (std::nothrow) Dav1dHipIntraFlow();
+    if (!l) return -ENOMEM;
+    memset(l, 0, sizeof(*l));
+    l->n_units = units.size();
+    l->n_steps = n_steps;
+    l->needs_aux = needs_aux;
+    int rc = 0;
+    if (hipMalloc((void **) &l->ctr, 512) != hipSuccess) rc = -ENOMEM;
+    if (!rc && !units.empty()) {
+        // one record past the end: the waves fetch a unit ahead
+        if (hipMalloc((void **) &l->units, (units.size() + 1) * sizeof(IntraUnit)) != hipSuccess) rc = -ENOMEM;
+        if (!rc) rc = dav1d_hip_upload(c, l->units, units.data(), units.size() * sizeof(IntraUnit));
+    }
+    if (rc) { dav1d_hip_intra_flow_destroy(c, l); return rc; }
+    *out = l;
+    return 0;
+}
+
+// enqueues: counters to zero, then the launch
+int dav1d_hip_intra_flow_run(Dav1dHipContext *c, const Dav1dHipIntraFlow *l, const Dav1dHipPicture *dst, void *coef, uint8_t *aux) {
+    if (!c || !l || !dst || (l->needs_aux && !aux)) return -EINVAL;
+    if (!l->n_units) return 0;
+    if (hipMemsetAsync(l->ctr, 0, 512, c->stream) != hipSuccess) return -EIO;
+    const DevPlanes dp = dev_planes(dst);
+    // 8 one-wave workgroups per CU: more waves only poll
+    return dav1d_hip_launch_intra_flow(&dp, dst->bpc, dst->layout, l->units, (int) l->n_units, aux, coef, l->ctr, c->flow_groups, c->flow_mode,
+                                       c->stream);
 }
 
 int dav1d_hip_intra_list_run_batch(Dav1dHipContext *c, const Dav1dHipIntraList *l, size_t batch, const Dav1dHipPicture *dst, void *coef,

@@ -129,6 +129,77 @@ __device__ __forceinline__ void mfma_i32_16x16x64_i8(const uint4 a, const uint4 
 #endif
 }
 
+// ---- data handed from one workgroup to another INSIDE a launch (intra_flow.hip).  A CU's vector L1 is never refreshed by
+// another CU's stores and the per-XCD L2s are not coherent with each other for ordinary accesses; relaxed atomics at agent
+// scope (global_load / global_store ... sc1) are: the producer stores its pixels with st_coherent, waits for the stores
+// (stores_done) and bumps a counter; the consumer polls the counter and reads the pixels with ld_coherent.
+template <typename T>
+__device__ __forceinline__ T ld_coherent(const T *p) {
+#ifdef DAV1D_HIP_EMU
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void st_coherent(T *p, const T v) {
+#ifdef DAV1D_HIP_EMU
+    *p = v;
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void stores_done() {       // every vector memory operation of this wave has been acknowledged
+#ifndef DAV1D_HIP_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ unsigned ld_rmw(unsigned *p) {          // the value as the atomic unit sees it (fetch-add of 0)
+#ifdef DAV1D_HIP_EMU
+    return *p;
+#else
+    return __hip_atomic_fetch_add(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void fence_release_agent() {
+#ifndef DAV1D_HIP_EMU
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ void fence_acquire_agent() {
+#ifndef DAV1D_HIP_EMU
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+}
+__device__ __forceinline__ void nap_long() {
+#ifndef DAV1D_HIP_EMU
+    __builtin_amdgcn_s_sleep(127);
+#endif
+}
+__device__ __forceinline__ void nap() {
+#ifndef DAV1D_HIP_EMU
+    __builtin_amdgcn_s_sleep(2);
+#endif
+}
+// start fetching the line at p (the value is not used; the wave does not wait for it here)
+__device__ __forceinline__ void touch(const void *p) {
+#ifndef DAV1D_HIP_EMU
+    const int v = *reinterpret_cast<const volatile int *>(p);
+    asm volatile("" :: "v"(v));
+#else
+    (void) p;
+#endif
+}
+// picture pixels behind operator[]: plain loads, or coherent ones when another workgroup of the same launch wrote them
+template <typename pixel, bool COH>
+struct PxRead {
+    const pixel *p;
+    __device__ __forceinline__ pixel operator[](const int i) const { return COH ? ld_coherent(p + i) : p[i]; }
+    __device__ __forceinline__ PxRead operator+(const int k) const { return PxRead{ p + k }; }
+    __device__ __forceinline__ PxRead operator-(const int k) const { return PxRead{ p - k }; }
+};
+
 // LDS hand-off between the lanes of ONE wave (no other wave reads the data): order the
 // accesses and let the wave's outstanding LDS operations land; no s_barrier involved, so
 // waves of a workgroup never wait for each other.

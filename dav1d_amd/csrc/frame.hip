@@ -5,6 +5,7 @@
 //   inter prediction (+ fused compounds) -> residuals -> deblock (cols, rows) -> CDEF -> loop restoration -> film grain.
 // Out-of-place stages land in pictures the frame owns; host code only: every kernel is reached through the batch API.
 #include "capi.h"
+#include <chrono>
 #include "chunk.h"
 #include <string.h>
 #include <stdlib.h>
@@ -438,10 +439,38 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
             allt.insert(allt.end(), f->intra_itx[k].begin(), f->intra_itx[k].end());
             allb.insert(allb.end(), f->step_blend[k].begin(), f->step_blend[k].end());
         }
-        Dav1dHipIntraList *xl = nullptr;
-        rc = dav1d_hip_intra_list_create_blend(c, &xl, allp.data(), ps.data(), allt.data(), ts.data(), allb.data(), bs.data(), ps.size());
-        for (size_t k = 0; k < ps.size() && !rc; k++) rc = dav1d_hip_intra_list_run_batch_blend(c, xl, k, &f->cur, coef, f->aux, prep, mask);
-        if (xl) dav1d_hip_intra_list_destroy(c, xl);
+        // A long wavefront (a key frame: thousands of steps, most of them narrow) goes down as ONE launch whose waves hand the
+        // steps to each other (intra_flow.hip); a short one (the intra blocks of an inter frame: tens of steps, the first ones
+        // wide) stays with up to three launches per step, which keep more waves in flight per step.  c->flow_min_steps = the
+        // border ($DAV1D_HIP_FLOW_MIN_STEPS at open, default 200; 0 = always the launches).
+        static const bool trace = getenv("DAV1D_HIP_TRACE_INTRA") != nullptr;
+        const auto t_a = std::chrono::steady_clock::now();
+        Dav1dHipIntraFlow *fl = nullptr;
+        if (allb.empty() && c->flow_min_steps > 0 && ps.size() >= (size_t) c->flow_min_steps) {
+            const int frc = dav1d_hip_intra_flow_create(c, &fl, allp.data(), ps.data(), allt.data(), ts.data(), ps.size());
+            if (frc && frc != -ENOTSUP) rc = frc;
+        }
+        if (fl) {
+            const auto t_b = std::chrono::steady_clock::now();
+            (void) dav1d_hip_sync(c);
+            const auto t_c = std::chrono::steady_clock::now();
+            rc = dav1d_hip_intra_flow_run(c, fl, &f->cur, coef, f->aux);
+            uint32_t st[3] = { 0, 0, 0 };
+            if (!rc) rc = dav1d_hip_intra_flow_status(c, fl, st);
+            if (trace) {
+                const auto t_d = std::chrono::steady_clock::now();
+                fprintf(stderr, "intra flow: %zu steps, %zu units; create %.2f ms, earlier work %.2f ms, launch to finish %.2f ms\n", ps.size(),
+                        dav1d_hip_intra_flow_units(fl), std::chrono::duration<double, std::milli>(t_b - t_a).count(),
+                        std::chrono::duration<double, std::milli>(t_c - t_b).count(), std::chrono::duration<double, std::milli>(t_d - t_c).count());
+            }
+            if (!rc && (st[2] || st[1] != dav1d_hip_intra_flow_units(fl))) rc = -EIO;      // a wave gave up waiting: never in a sound run
+            dav1d_hip_intra_flow_destroy(c, fl);
+        } else if (!rc) {
+            Dav1dHipIntraList *xl = nullptr;
+            rc = dav1d_hip_intra_list_create_blend(c, &xl, allp.data(), ps.data(), allt.data(), ts.data(), allb.data(), bs.data(), ps.size());
+            for (size_t k = 0; k < ps.size() && !rc; k++) rc = dav1d_hip_intra_list_run_batch_blend(c, xl, k, &f->cur, coef, f->aux, prep, mask);
+            if (xl) dav1d_hip_intra_list_destroy(c, xl);
+        }
     }
     const Dav1dHipPicture *last = &f->cur;
     int piped = 1;

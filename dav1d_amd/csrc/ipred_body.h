@@ -57,7 +57,8 @@ constexpr int IPRED_PARTS = 4;
 // t: the block's task; split / part: this workgroup predicts part `part` of IPRED_PARTS of the block's pixels (split) or all
 // of them; e1, e2 (ESZ int16 each), blk (32 x 32 int16): LDS of the wave; o / ostride: where the predicted pixels go — the
 // block's place in the picture, or an LDS tile (row stride = block width) when a residual is added by the same wave.
-template <typename pixel>
+// COH: the pixels read from the picture (edges, CfL's luma) were written by other workgroups of the SAME launch (intra_flow.hip)
+template <typename pixel, bool COH = false>
 __device__ __forceinline__ void ipred_body(const DevPlanes &dst, const Dav1dHipIpredTask &t, const int part, const bool split,
                                            uint8_t *aux, const int layout, const int bitdepth_max,
                                            int16_t *e1, int16_t *e2, int16_t *blk, pixel *const o, const int ostride)
@@ -67,7 +68,7 @@ __device__ __forceinline__ void ipred_body(const DevPlanes &dst, const Dav1dHipI
     constexpr bool HBD = sizeof(pixel) == 2;
     const int bitdepth = 32 - __clz(bitdepth_max);
     const int stride = dst.stride[t.plane];
-    const pixel *const d = reinterpret_cast<const pixel *>(dst.data[t.plane]) + t.dst_off;
+    const dv::PxRead<pixel, COH> d = { reinterpret_cast<const pixel *>(dst.data[t.plane]) + t.dst_off };
     const int w = t.tw * 4, h = t.th * 4;
     const int lw = __builtin_ctz(w);     // block sides are powers of two: pixel i of the block is (i >> lw, i & (w - 1))
     int16_t *const E = e1 + EC;          // E[k] == topleft_out[k]
@@ -130,7 +131,7 @@ __device__ __forceinline__ void ipred_body(const DevPlanes &dst, const Dav1dHipI
     const bool n_tr = mode == M_Z1, n_bl = mode == M_Z3;
 
     // ---------------------------------------------------------------- edge gathering (:118-201)
-    const pixel *const dtop = d - stride;
+    const dv::PxRead<pixel, COH> dtop = d - stride;
     if (dsp_edge) {
         const pixel *const edge = reinterpret_cast<const pixel *>(aux) + t.aux_off;
         const int m = dv::imin(w, h);
@@ -197,7 +198,7 @@ __device__ __forceinline__ void ipred_body(const DevPlanes &dst, const Dav1dHipI
     if (is_cfl) {
         int16_t *const ac_mem = reinterpret_cast<int16_t *>(aux) + ((uint32_t) t.pal[1] | ((uint32_t) t.pal[2] << 16));
         const int ss_hor = layout != DAV1D_HIP_LAYOUT_I444, ss_ver = layout == DAV1D_HIP_LAYOUT_I420;
-        const pixel *ypx = reinterpret_cast<const pixel *>(dst.data[0]) + t.aux_off;
+        const dv::PxRead<pixel, COH> ypx = { reinterpret_cast<const pixel *>(dst.data[0]) + t.aux_off };
         const int ys = dst.stride[0];
         const int w_pad = t.max_w, h_pad = t.max_h;           // CfL tasks reuse the fields for w_pad / h_pad (4-px units)
         const int wv = w - 4 * w_pad, hv = h - 4 * h_pad;
@@ -208,7 +209,7 @@ __device__ __forceinline__ void ipred_body(const DevPlanes &dst, const Dav1dHipI
         for (int i = lane; i < w * h; i += 64) {
             const int y = i >> lw, x = i & (w - 1);
             const int xs = dv::imin(x, wv - 1), yy = dv::imin(y, hv - 1);     // padding replicates the last visible column / row
-            const pixel *p = ypx + (yy << ss_ver) * ys + (xs << ss_hor);
+            const dv::PxRead<pixel, COH> p = ypx + ((yy << ss_ver) * ys + (xs << ss_hor));
             int s = p[0];
             if (ss_hor) s += p[1];
             if (ss_ver) { s += p[ys]; if (ss_hor) s += p[ys + 1]; }

@@ -73,6 +73,12 @@ __device__ __forceinline__ void tx1d(const int kind, const int *in, const int lo
     }
 }
 
+template <bool COH, typename pixel>
+__device__ __forceinline__ void put_px(pixel *p, const pixel v) {
+    if (COH) dv::st_coherent(p, v);
+    else *p = v;
+}
+
 // LDS ints one wave needs for transform size TX (all of its blocks)
 template <int TX>
 constexpr int itx_lds_ints() {
@@ -83,7 +89,8 @@ constexpr int itx_lds_ints() {
 // The wave `group` of the blocks of ONE transform size: blocks [group * BPW, group * BPW + BPW) of tasks[0 .. n).
 // PRED_LDS (fused prediction + residual kernels): the pixels the residual is added to come from pred_s (block `sub` of the
 // wave, W x H, row stride W) instead of the picture; the sum still goes to the picture.
-template <int TX, typename pixel, typename coef, bool PRED_LDS = false>
+// COH: the result is read by other workgroups of the SAME launch (intra_flow.hip): coherent stores.
+template <int TX, typename pixel, typename coef, bool PRED_LDS = false, bool COH = false>
 __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItxTask *__restrict__ tasks,
                                          const int n, coef *__restrict__ cf, const int bitdepth_max, const int group, int *tmp_s,
                                          const pixel *pred_s = nullptr)
@@ -239,7 +246,7 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
             dc = (dc * 181 + 128 + 2048) >> 12;
 #pragma unroll
             for (int y = 0; y < H; y++)
-                d[y * stride] = (pixel) dv::iclip((int) dpx[y] + dc, 0, bitdepth_max);
+                put_px<COH>(d + y * stride, (pixel) dv::iclip((int) dpx[y] + dc, 0, bitdepth_max));
         } else {
             int cin[H], out[H];
 #pragma unroll
@@ -248,17 +255,17 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
                 if constexpr (H == 4) itx1d::iwht4(cin, out);
 #pragma unroll
                 for (int y = 0; y < H; y++)
-                    d[y * stride] = (pixel) dv::iclip((int) dpx[y] + out[y], 0, bitdepth_max);
+                    put_px<COH>(d + y * stride, (pixel) dv::iclip((int) dpx[y] + out[y], 0, bitdepth_max));
             } else {
                 tx1d<H>(k2, cin, col_min, col_max, [&](const int *res) {
                     if (k2 == K_FLIPADST) {
 #pragma unroll
                         for (int y = 0; y < H; y++)
-                            d[y * stride] = (pixel) dv::iclip((int) dpx[y] + ((res[H - 1 - y] + 8) >> 4), 0, bitdepth_max);
+                            put_px<COH>(d + y * stride, (pixel) dv::iclip((int) dpx[y] + ((res[H - 1 - y] + 8) >> 4), 0, bitdepth_max));
                     } else {
 #pragma unroll
                         for (int y = 0; y < H; y++)
-                            d[y * stride] = (pixel) dv::iclip((int) dpx[y] + ((res[y] + 8) >> 4), 0, bitdepth_max);
+                            put_px<COH>(d + y * stride, (pixel) dv::iclip((int) dpx[y] + ((res[y] + 8) >> 4), 0, bitdepth_max));
                     }
                 });
             }

@@ -113,16 +113,19 @@ __global__ __launch_bounds__(64) void wiener_kernel(const DevPlanes dst, const D
 // LDS ring so that the output stage can read the neighbouring columns.
 struct AB { int a; int b; };
 
-__device__ __forceinline__ AB calc_ab(const int sumsq, const int sum, const int s, const int bitdepth_min_8, const int n, const int one_by_x)
+__device__ __forceinline__ AB calc_ab(const int sumsq, const int sum, const int s, const int bitdepth_min_8, const int n, const int one_by_x,
+                                      const uint8_t *x_by_x /* LDS copy of av1_sgr_x_by_x */)
 {
-    // sgr_calc_row_ab, src/looprestoration_tmpl.c:505-523
+    // sgr_calc_row_ab, src/looprestoration_tmpl.c:505-523.  Ranges (12-bit worst case): a <= 25 * 255^2 < 2^21, b <= 25 * 255 < 2^13,
+    // x <= 255, sum <= 25 * 4095 < 2^17: those products take the full-rate 24-bit multiplier; p * s and (x * sum) * one_by_x need
+    // the 32-bit one (they wrap mod 2^32 exactly as the reference's unsigned arithmetic does).
     const int a = (sumsq + ((1 << (2 * bitdepth_min_8)) >> 1)) >> (2 * bitdepth_min_8);
     const int b = (sum + ((1 << bitdepth_min_8) >> 1)) >> bitdepth_min_8;
-    const unsigned p = (unsigned) dv::imax(a * n - b * b, 0);
+    const unsigned p = (unsigned) dv::imax((int) dv::mul_u24((unsigned) a, (unsigned) n) - (int) dv::mul_u24((unsigned) b, (unsigned) b), 0);
     const unsigned z = (p * (unsigned) s + (1u << 19)) >> 20;
-    const unsigned x = av1_sgr_x_by_x[z < 255 ? z : 255];
+    const unsigned x = x_by_x[z < 255 ? z : 255];
     AB r;
-    r.a = (int) ((x * (unsigned) sum * (unsigned) one_by_x + (1 << 11)) >> 12);
+    r.a = (int) ((dv::mul_u24(x, (unsigned) sum) * (unsigned) one_by_x + (1 << 11)) >> 12);
     r.b = (int) x;
     return r;
 }
@@ -132,12 +135,15 @@ __global__ __launch_bounds__(64) void sgr_kernel(const DevPlanes dst, const DevP
                                                  const Dav1dHipLrTask *__restrict__ tasks, const int n, const int bitdepth_max)
 {
     __shared__ int a3[4][64], b3[4][64], a5[2][64], b5[2][64];
+    __shared__ __attribute__((aligned(4))) uint8_t x_by_x[256];
     const int ti = blockIdx.y;
     if (ti >= n) return;
     const Dav1dHipLrTask t = tasks[__builtin_amdgcn_readfirstlane(ti)];
     const int seg0 = blockIdx.x * 62;
     if (seg0 >= t.w) return;
     const int lane = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; k++) x_by_x[4 * lane + k] = av1_sgr_x_by_x[4 * lane + k];      // first read comes after the loop's first wave_sync
     const int c = seg0 - 1 + lane;                      // (A, B) column of this lane, -1 .. w
     const int bitdepth_min_8 = (32 - __clz(bitdepth_max)) - 8;
     const int pl = t.plane, w = t.w, h = t.h, edges = t.edges;
@@ -187,11 +193,11 @@ __global__ __launch_bounds__(64) void sgr_kernel(const DevPlanes dst, const DevP
         q5[4] = q3[2] + p0 * p0 + p4 * p4;
         // ---- (A, B) rows that just became complete
         if (do3 && r >= rs0 && r <= rs1 + 1) {        // row j = r - 1 of the 3x3 surface (rows rs0-1 .. rs1 feed this segment)
-            const AB v = calc_ab(q3[0] + q3[1] + q3[2], s3[0] + s3[1] + s3[2], s1, bitdepth_min_8, 9, 455);
+            const AB v = calc_ab(q3[0] + q3[1] + q3[2], s3[0] + s3[1] + s3[2], s1, bitdepth_min_8, 9, 455, x_by_x);
             a3[(r - 1) & 3][lane] = v.a; b3[(r - 1) & 3][lane] = v.b;
         }
         if (do5 && r >= rs0 + 1 && ((r - 2) & 1)) {    // row j = r - 2 (odd) of the 5x5 surface
-            const AB v = calc_ab(q5[0] + q5[1] + q5[2] + q5[3] + q5[4], s5[0] + s5[1] + s5[2] + s5[3] + s5[4], s0, bitdepth_min_8, 25, 164);
+            const AB v = calc_ab(q5[0] + q5[1] + q5[2] + q5[3] + q5[4], s5[0] + s5[1] + s5[2] + s5[3] + s5[4], s0, bitdepth_min_8, 25, 164, x_by_x);
             a5[((r - 2) >> 1) & 1][lane] = v.a; b5[((r - 2) >> 1) & 1][lane] = v.b;
         }
         dv::wave_sync();

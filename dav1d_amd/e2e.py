@@ -118,12 +118,14 @@ def c2_params(seed, n_refs=3):
     return sp
 
 
-def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0xE2E, check=None, intra_pct=0):
+def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0xE2E, check=None, intra_pct=0, key_frame=False):
     """Returns the measurement dict.  check: optional callable(handoff, desc, planes) -> str used as the parity gate."""
     layout = api.LAYOUT_I420
     ho = HandOff(w, h, layout, bpc, True, tile_cols, 1)
     sp = c2_params(seed)
-    sp.intra_pct = intra_pct
+    sp.intra_pct = 100 if key_frame else intra_pct
+    if key_frame:
+        ho.desc.is_inter = 0
     t0 = time.perf_counter()
     rc = ctx.lib.dav1d_hip_synth_frame(C.byref(ho.desc), C.byref(sp), ho.cf.ctypes.data, ho.cf.nbytes, len(ho.cbi), None, 0)
     assert rc == 0, rc
@@ -196,9 +198,10 @@ def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0
     out["value"] = round(w * h / (out["total_ms"] * 1e-3) / 1e6, 1) if "total_ms" in out else None
     out["unit"] = "Mpixels/s"
     out["synth_seconds"] = round(t_synth, 2)
-    out["workload"] = ("%dx%d 4:2:0 %d-bit inter frame from pass-1 hand-off arrays: lister on %d host threads (one per tile column), chunk "
+    kind = "key frame (every block intra)" if key_frame else "inter frame" if not intra_pct else "inter frame, %d %% intra blocks" % intra_pct
+    out["workload"] = ("%dx%d 4:2:0 %d-bit " + kind + " from pass-1 hand-off arrays: lister on %d host threads (one per tile column), chunk "
                        "preparation + upload on the submitting threads, dense coefficient arena over the host link meanwhile (h2d_ms), "
-                       "frame_end = gather + the frame's launches + sync" % (w, h, bpc, threads))
+                       "frame_end = gather + the frame's launches + sync") % (w, h, bpc, threads)
     if check is not None and planes is not None:
         out["parity"] = check(ho, planes, refs)
     for o in refs + [cur, coef] + ([prep, mask] if prep is not None else []):
@@ -214,9 +217,10 @@ def main():
     ap.add_argument("--width", type=int, default=7680)
     ap.add_argument("--height", type=int, default=4320)
     ap.add_argument("--intra-pct", type=int, default=0)
+    ap.add_argument("--key-frame", type=int, default=0)
     a = ap.parse_args()
     ctx = api.Context(0)
-    print(json.dumps(run(ctx, a.width, a.height, 10, a.frames, a.threads or None, a.tile_cols, intra_pct=a.intra_pct)))
+    print(json.dumps(run(ctx, a.width, a.height, 10, a.frames, a.threads or None, a.tile_cols, intra_pct=a.intra_pct, key_frame=bool(a.key_frame))))
 
 
 if __name__ == "__main__":

@@ -355,6 +355,20 @@ DAV1D_HIP_API int dav1d_hip_intra_list_run_batch(Dav1dHipContext *c, const Dav1d
                                                  void *coef, uint8_t *aux);
 DAV1D_HIP_API void dav1d_hip_intra_list_destroy(Dav1dHipContext *c, Dav1dHipIntraList *l);
 
+/* The same wavefront as ONE launch: the batches become a list of units (prediction + residual of one transform block)
+ * sorted by step; the waves of the launch draw units in that order and a unit starts once every unit of the earlier steps
+ * has finished (a counter in device memory), so a step boundary is a hand-off between running waves instead of a kernel
+ * boundary.  Same results as the batch-by-batch routes.  create: -ENOTSUP when a task kind is not handled here (PRED_TMP of
+ * inter-intra blocks, the DSP-level kinds) — use dav1d_hip_intra_list_* then.  run only enqueues. */
+typedef struct Dav1dHipIntraFlow Dav1dHipIntraFlow;
+DAV1D_HIP_API int dav1d_hip_intra_flow_create(Dav1dHipContext *c, Dav1dHipIntraFlow **out, const Dav1dHipIpredTask *preds, const size_t *pred_sizes,
+                                              const Dav1dHipItxTask *txs, const size_t *tx_sizes, size_t n_batches);
+DAV1D_HIP_API int dav1d_hip_intra_flow_run(Dav1dHipContext *c, const Dav1dHipIntraFlow *l, const Dav1dHipPicture *dst, void *coef, uint8_t *aux);
+DAV1D_HIP_API void dav1d_hip_intra_flow_destroy(Dav1dHipContext *c, Dav1dHipIntraFlow *l);
+DAV1D_HIP_API size_t dav1d_hip_intra_flow_units(const Dav1dHipIntraFlow *l);
+/* after a run (synchronizes): out = { tickets drawn, units finished, waves that gave up waiting (0 unless something is broken) } */
+DAV1D_HIP_API int dav1d_hip_intra_flow_status(Dav1dHipContext *c, const Dav1dHipIntraFlow *l, uint32_t out[3]);
+
 /* ------------------------------------------------- mc: warp, scaled, resize, emu_edge */
 
 /* One 8x8 block of a warped prediction: dsp->mc.warp8x8 (kind PUT, pixels into dst) or warp8x8t (kind PREP, int16

@@ -366,3 +366,34 @@ def compare(rf, got):
             yy, xx = np.nonzero(want != have)
             bad.append((pl, len(yy), int(yy[0]), int(xx[0]), int(want[yy[0], xx[0]]), int(have[yy[0], xx[0]])))
     return bad
+
+
+def check_handoff_against_reference(ho, planes, ref_pics, is_inter=True):
+    """The parity gate of the end-to-end route (dav1d_amd/e2e.py): the hand-off arrays `ho` go into a real Dav1dFrameContext,
+    the reference's OWN pass 2 (dav1d_decode_tile_sbrow, oracle/ref_frame.c) reconstructs the frame on the CPU, and the
+    planes the device produced must equal it.  Returns a description, raises AssertionError on a difference."""
+    import time
+    if ref_lib() is None:
+        return "skipped (no reference build)"
+    rf = RefFrame(ho.w, ho.h, ho.layout, ho.bpc, is_inter=is_inter, sb128=bool(ho.sb128), tile_cols=ho.desc.n_tile_cols,
+                  tile_rows=ho.desc.n_tile_rows)
+    try:
+        for name, src in (("b", ho.b), ("cbi", ho.cbi.view(np.uint8)), ("cf", ho.cf)):
+            dst = rf.array(name, np.uint8)
+            assert len(dst) == len(src), (name, len(dst), len(src))
+            dst[:] = src
+        assert np.array_equal(rf.array("tile_start_off", np.uint32)[:len(ho.tile_start_off)], ho.tile_start_off)
+        if is_inter:
+            for i in range(7):
+                for pl in range(3):
+                    hostp = ref_pics[i % len(ref_pics)].download(pl)
+                    dstp = rf.plane(1 + i, pl)
+                    dstp[:hostp.shape[0], :hostp.shape[1]] = hostp
+        t0 = time.perf_counter()
+        rf.recon()
+        t_ref = time.perf_counter() - t0
+        bad = compare(rf, planes)
+        assert not bad, bad
+        return "bit-exact vs the reference's own pass 2 (dav1d_decode_tile_sbrow, 1 thread: %.2f s for this frame)" % t_ref
+    finally:
+        rf.destroy()
