@@ -45,7 +45,9 @@ def parse():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--packed", action="store_true", help="feed the residuals in the sparse wire format (DAV1D_HIP_ITX_PACKED)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (hand-off arrays -> lister -> device)")
-    ap.add_argument("--e2e-tile-cols", type=int, default=8, help="tile columns (= listing threads) of the end-to-end leg")
+    ap.add_argument("--e2e-tile-cols", type=int, default=16, help="tile columns of the end-to-end leg (one listing thread per tile)")
+    ap.add_argument("--e2e-tile-rows", type=int, default=8, help="tile rows of the end-to-end leg")
+    ap.add_argument("--no-c1", action="store_true", help="skip the 4K 8-bit (BASELINE configs[1]) line that the default run appends")
     ap.add_argument("--no-full", action="store_true", help="skip the full-DSP-table leg (deblock, CDEF, restoration, film grain)")
     ap.add_argument("--two-phase", action="store_true",
                     help="run the step as dav1d_hip_inter_list_run + dav1d_hip_itx_list_run (every residual after every prediction) "
@@ -416,6 +418,27 @@ def main():
                                         "sample": "%d frame(s), %d threads over the task lists (barrier between mc / compound / itx), "
                                                   "%.1f s inside the replay" % (best[2], best[1], best[3]),
                                         "mpixels_per_s_by_threads": tried, "equals_one_thread": bool(same)}
+        # ---- the reference itself as the CPU peer: its own pass 2 (dav1d_decode_tile_sbrow, C DSP functions) on the same kind of
+        # frame from hand-off arrays, tiles on a pool of workers (oracle/ref_frame.c dav1d_ref_frame_recon_mt); and whether the
+        # assembly path could have been built here
+        if cpu is not None and not a.no_cpu and rank == 0 and world == 1:
+            import shutil
+            import lister_util as lu
+            try:
+                ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+                thr = sorted({t for t in (1, 16, 32, 64, 128) if t <= max(1, ncpu)})
+                rates = lu.reference_pass2_rate(ctx, w, h, bpc, 16, 8, threads=thr)
+                if rates:
+                    bt = max(rates, key=lambda k: rates[k])
+                    cpu["reference_pass2"] = {"value": rates[bt], "unit": "Mpixels/s", "cores": int(bt), "kind": "reference",
+                                              "sample": "1 frame per thread count, %dx%d %d-bit inter frame in 16 x 8 tiles, the reference's "
+                                                        "dav1d_decode_tile_sbrow (pass 2, C DSP) with one worker per tile in flight" % (w, h, bpc),
+                                              "mpixels_per_s_by_threads": {str(k): v for k, v in rates.items()}}
+            except Exception as e:       # the peer is a reported baseline, never a reason to lose the line
+                cpu["reference_pass2"] = {"error": str(e)[:200]}
+            cpu["avx2"] = ("unavailable: no nasm on this host (the reference's src/x86/*.asm cannot be assembled; SURVEY 8c)"
+                           if shutil.which("nasm") is None else
+                           "nasm present but the assembly build is not wired up (oracle/Makefile builds the C path only)")
         # ---- full DSP table on the same frame (BASELINE configs[2]): recon above + deblock + CDEF + restoration + grain,
         # one frame, kernel time per stage from HIP events, every stage checked against the oracle's replay
         full = None
@@ -548,9 +571,10 @@ def main():
                     return lu.check_handoff_against_reference(ho, planes, ref_pics, is_inter)
                 except AssertionError as e:
                     raise SystemExit("bench: end-to-end leg differs from the reference's pass 2: %s" % e)
-            e2e_leg = e2e.run(ctx, w, h, bpc, frames=6, threads=None, tile_cols=a.e2e_tile_cols, check=None if a.no_check else e2e_check)
+            e2e_leg = e2e.run(ctx, w, h, bpc, frames=6, threads=None, tile_cols=a.e2e_tile_cols, tile_rows=a.e2e_tile_rows,
+                              check=None if a.no_check else e2e_check)
             # the key-frame worst case (reference src/recon_tmpl.c:1239-1333, every block through the intra wavefront): same route
-            key_leg = e2e.run(ctx, w, h, bpc, frames=4, threads=None, tile_cols=a.e2e_tile_cols, key_frame=True, seed=0xE2F,
+            key_leg = e2e.run(ctx, w, h, bpc, frames=4, threads=None, tile_cols=a.e2e_tile_cols, tile_rows=a.e2e_tile_rows, key_frame=True, seed=0xE2F,
                               check=None if a.no_check else (lambda ho, planes, refs: e2e_check(ho, planes, refs, is_inter=False)))
         label = "8K" if (w, h) == (7680, 4320) else "4K" if (w, h) == (3840, 2160) else "%dx%d" % (w, h)
         out = {"metric": "reconstructed luma Mpixels/s (%s 4:2:0 %d-bit) on the itx+mc recon path; bit-exact vs C" % (label, bpc),
@@ -568,6 +592,20 @@ def main():
                           "coef_bytes_per_frame": int(coef_host.nbytes), "coef_h2d_ms_per_frame": h2d_ms,
                           "samples_per_frame": frame.n_samples, "parity": check, "gen_seconds": round(t_gen, 1)},
                "roofline": roof, "cpu_baseline": cpu, "full_table": full, "end_to_end": e2e_leg, "all_intra": key_leg}
+        # BASELINE configs[1] (4K 8-bit, the reference's CPU-runnable size) next to the headline: the same bench in a child process,
+        # its digest under "config_c1_4k_8bit"
+        if world == 1 and not a.no_c1 and not a.step_only and (w, h, bpc) == (7680, 4320, 10):
+            import subprocess
+            try:
+                child = subprocess.run([sys.executable, os.path.abspath(__file__), "--width", "3840", "--height", "2160", "--bpc", "8", "--no-c1",
+                                        "--no-full", "--no-e2e", "--no-cpu", "--steps", str(a.steps), "--warmup", str(a.warmup)],
+                                       capture_output=True, text=True, timeout=600)
+                cj = json.loads(child.stdout.strip().splitlines()[-1])
+                out["config_c1_4k_8bit"] = {"metric": cj["metric"], "value": cj["value"], "unit": cj["unit"], "ms_per_step": cj["ms_per_step"],
+                                            "dtype": cj["dtype"], "roofline": {k: cj["roofline"].get(k) for k in ("kernel", "frac", "path")},
+                                            "parity": cj["config"]["parity"], "workload": cj["config"]["workload"]}
+            except Exception as e:
+                out["config_c1_4k_8bit"] = {"error": str(e)[:200]}
         if packed_leg is not None:
             packed_leg.pop("_pictures", None)
             packed_leg.setdefault("parity", "skipped")

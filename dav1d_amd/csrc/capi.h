@@ -160,6 +160,9 @@ static_assert(sizeof(IntraUnit) == 80, "unit record layout");
 extern "C" int dav1d_hip_launch_intra_flow(const DevPlanes *dst, int bpc, int layout, const IntraUnit *units, int n_units, uint8_t *aux,
                                            void *coef, uint32_t *ctr, int max_groups, int mode, void *stream);
 struct Dav1dHipIntraFlow;
+extern "C" int dav1d_hip_intra_units_build(const Dav1dHipIpredTask *preds, const uint32_t *pred_end, const Dav1dHipItxTask *txs, const uint32_t *tx_end,
+                                size_t n_steps, std::vector<IntraUnit> &units, std::vector<uint32_t> &ua_end, std::vector<uint32_t> &ub_end);
+extern "C" int dav1d_hip_intra_flow_from_units(Dav1dHipContext *c, Dav1dHipIntraFlow **out, const IntraUnit *units, size_t n);
 // batches (wavefront steps) of predictions + residuals -> device-resident unit list; -ENOTSUP when the list holds a task
 // kind the dataflow launch does not run (PRED_TMP for inter-intra, DSP-level kinds): the caller keeps the stepped route
 extern "C" int dav1d_hip_intra_flow_create(Dav1dHipContext *c, Dav1dHipIntraFlow **out, const Dav1dHipIpredTask *preds, const size_t *pred_sizes,

@@ -1840,89 +1840,113 @@ int dav1d_hip_intra_flow_status(Dav1dHipContext *c, const Dav1dHipIntraFlow *l, 
     return rc;
 }
 
-int dav1d_hip_intra_flow_create(Dav1dHipContext *c, Dav1dHipIntraFlow **out, const Dav1dHipIpredTask *preds, const size_t *pred_sizes,
-                                const Dav1dHipItxTask *txs, const size_t *tx_sizes, size_t n_batches) {
-    if (!c || !out || !pred_sizes || !tx_sizes) return -EINVAL;
-    *out = nullptr;
-    size_t np = 0, nt = 0;
-    for (size_t k = 0; k < n_batches; k++) { np += pred_sizes[k]; nt += tx_sizes[k]; }
-    if ((np && !preds) || (nt && !txs)) return -EINVAL;
+// Units of one set of tasks sorted by step (*_end[s] = end of step s): per step first the predictions, each with the residual
+// of the same rectangle when there is one (that is how the reference walks an intra block: predict a transform block, add
+// its residual, next one), then the residuals without a prediction of their own — those wait for every prediction of their
+// step (a palette block: one prediction, many residuals).  need is left 0.  -ENOTSUP: a task kind the dataflow launch
+// does not run (PRED_TMP of inter-intra blocks, the DSP-level kinds).
+int dav1d_hip_intra_units_build(const Dav1dHipIpredTask *preds, const uint32_t *pred_end, const Dav1dHipItxTask *txs, const uint32_t *tx_end,
+                                size_t n_steps, std::vector<IntraUnit> &units, std::vector<uint32_t> &ua_end, std::vector<uint32_t> &ub_end) {
+    const size_t np = n_steps ? pred_end[n_steps - 1] : 0, nt = n_steps ? tx_end[n_steps - 1] : 0;
     uint8_t dummy = 0;
     if (ipred_tasks_valid(preds, np, &dummy)) return -EINVAL;
     for (size_t i = 0; i < nt; i++) if (!itx_task_ok(txs[i])) return -EINVAL;
-    bool needs_aux = false;
     for (size_t i = 0; i < np; i++) {
         const int k = preds[i].kind;
         if (k != DAV1D_HIP_IPRED_PRED && k != DAV1D_HIP_IPRED_CFL && k != DAV1D_HIP_IPRED_PAL) return -ENOTSUP;
-        if (k == DAV1D_HIP_IPRED_PAL) needs_aux = true;
     }
-    if (np >= 0xffffffffu || nt >= 0xffffffffu) return -ENOTSUP;
-    // units step by step: a prediction with the residual of the same rectangle (that is how the reference walks an intra block:
-    // predict a transform block, add its residual, next one), the predictions without one, then the residuals without a
-    // prediction of their own — those wait for every prediction of their step (a palette block: one prediction, many residuals)
-    std::vector<IntraUnit> units;
+    units.clear();
     units.reserve(np + nt / 4);
-    auto unit = [&](const Dav1dHipIpredTask *p, const Dav1dHipItxTask *t, uint32_t need) {
+    ua_end.assign(n_steps, 0); ub_end.assign(n_steps, 0);
+    auto unit = [&](const Dav1dHipIpredTask *p, const Dav1dHipItxTask *t) {
         IntraUnit u;
         memset(&u, 0, sizeof(u));
-        u.need = need;
         if (p) { u.p = *p; u.has |= 1; }
         if (t) { u.t = *t; itx_fill_prefix(u.t); u.has |= 2; }
         units.push_back(u);
     };
-    size_t p0 = 0, t0 = 0;
-    std::vector<uint32_t> slot;        // open-addressed map (plane, dst_off) -> transform task of the batch
+    std::vector<uint32_t> slot;        // open-addressed map (plane, dst_off) -> transform task of the step
     std::vector<char> taken;
-    size_t n_steps = 0;
-    for (size_t k = 0; k < n_batches; k++) {
-        const size_t ntk = tx_sizes[k], npk = pred_sizes[k];
-        size_t cap = 16;
-        while (cap < 2 * ntk + 2) cap <<= 1;
-        slot.assign(cap, 0xffffffffu);
-        taken.assign(ntk, 0);
-        auto hash = [&](uint32_t plane, uint32_t off) { return (size_t) ((off * 2654435761u) ^ (plane * 0x9e3779b9u)) & (cap - 1); };
-        for (size_t i = 0; i < ntk; i++) {
-            const Dav1dHipItxTask &t = txs[t0 + i];
-            size_t h = hash(t.plane, t.dst_off);
-            while (slot[h] != 0xffffffffu) h = (h + 1) & (cap - 1);
-            slot[h] = (uint32_t) i;
-        }
-        const uint32_t need0 = (uint32_t) units.size();
-        for (size_t i = 0; i < npk; i++) {
-            const Dav1dHipIpredTask &p = preds[p0 + i];
-            uint32_t j = 0xffffffffu;
-            for (size_t h = hash(p.plane, p.dst_off); slot[h] != 0xffffffffu; h = (h + 1) & (cap - 1)) {
-                const Dav1dHipItxTask &t = txs[t0 + slot[h]];
-                if (t.plane == p.plane && t.dst_off == p.dst_off && !taken[slot[h]] && k_tx_w[t.tx] == p.tw * 4 && k_tx_h[t.tx] == p.th * 4) {
-                    j = slot[h];
-                    break;
-                }
+    for (size_t k = 0; k < n_steps; k++) {
+        const size_t p0 = k ? pred_end[k - 1] : 0, t0 = k ? tx_end[k - 1] : 0;
+        const size_t npk = pred_end[k] - p0, ntk = tx_end[k] - t0;
+        if (npk || ntk) {
+            size_t cap = 16;
+            while (cap < 2 * ntk + 2) cap <<= 1;
+            slot.assign(cap, 0xffffffffu);
+            taken.assign(ntk, 0);
+            auto hash = [&](uint32_t plane, uint32_t off) { return (size_t) ((off * 2654435761u) ^ (plane * 0x9e3779b9u)) & (cap - 1); };
+            for (size_t i = 0; i < ntk; i++) {
+                const Dav1dHipItxTask &t = txs[t0 + i];
+                size_t h = hash(t.plane, t.dst_off);
+                while (slot[h] != 0xffffffffu) h = (h + 1) & (cap - 1);
+                slot[h] = (uint32_t) i;
             }
-            if (j != 0xffffffffu) taken[j] = 1;
-            unit(&p, j == 0xffffffffu ? nullptr : &txs[t0 + j], need0);
+            for (size_t i = 0; i < npk; i++) {
+                const Dav1dHipIpredTask &p = preds[p0 + i];
+                uint32_t j = 0xffffffffu;
+                for (size_t h = hash(p.plane, p.dst_off); slot[h] != 0xffffffffu; h = (h + 1) & (cap - 1)) {
+                    const Dav1dHipItxTask &t = txs[t0 + slot[h]];
+                    if (t.plane == p.plane && t.dst_off == p.dst_off && !taken[slot[h]] && k_tx_w[t.tx] == p.tw * 4 && k_tx_h[t.tx] == p.th * 4) {
+                        j = slot[h];
+                        break;
+                    }
+                }
+                if (j != 0xffffffffu) taken[j] = 1;
+                unit(&p, j == 0xffffffffu ? nullptr : &txs[t0 + j]);
+            }
+            ua_end[k] = (uint32_t) units.size();
+            for (size_t i = 0; i < ntk; i++) if (!taken[i]) unit(nullptr, &txs[t0 + i]);
+        } else {
+            ua_end[k] = (uint32_t) units.size();
         }
-        const uint32_t need1 = (uint32_t) units.size();
-        for (size_t i = 0; i < ntk; i++)
-            if (!taken[i]) unit(nullptr, &txs[t0 + i], need1);
-        n_steps += (units.size() > need0) + (units.size() > need1 && need1 > need0);
-        p0 += npk; t0 += ntk;
+        ub_end[k] = (uint32_t) units.size();
     }
+    return 0;
+}
+
+// units (host, need set, sorted) -> device-resident list
+int dav1d_hip_intra_flow_from_units(Dav1dHipContext *c, Dav1dHipIntraFlow **out, const IntraUnit *units, size_t n) {
+    if (!c || !out || (!units && n)) return -EINVAL;
+    *out = nullptr;
     Dav1dHipIntraFlow *l = new (std::nothrow) Dav1dHipIntraFlow();
     if (!l) return -ENOMEM;
     memset(l, 0, sizeof(*l));
-    l->n_units = units.size();
-    l->n_steps = n_steps;
-    l->needs_aux = needs_aux;
+    l->n_units = n;
+    for (size_t i = 0; i < n && !l->needs_aux; i++) if ((units[i].has & 1) && units[i].p.kind == DAV1D_HIP_IPRED_PAL) l->needs_aux = true;
     int rc = 0;
     if (hipMalloc((void **) &l->ctr, 512) != hipSuccess) rc = -ENOMEM;
-    if (!rc && !units.empty()) {
+    if (!rc && n) {
         // one record past the end: the waves fetch a unit ahead
-        if (hipMalloc((void **) &l->units, (units.size() + 1) * sizeof(IntraUnit)) != hipSuccess) rc = -ENOMEM;
-        if (!rc) rc = dav1d_hip_upload(c, l->units, units.data(), units.size() * sizeof(IntraUnit));
+        if (hipMalloc((void **) &l->units, (n + 1) * sizeof(IntraUnit)) != hipSuccess) rc = -ENOMEM;
+        if (!rc) rc = dav1d_hip_upload(c, l->units, units, n * sizeof(IntraUnit));
     }
     if (rc) { dav1d_hip_intra_flow_destroy(c, l); return rc; }
     *out = l;
     return 0;
+}
+
+int dav1d_hip_intra_flow_create(Dav1dHipContext *c, Dav1dHipIntraFlow **out, const Dav1dHipIpredTask *preds, const size_t *pred_sizes,
+                                const Dav1dHipItxTask *txs, const size_t *tx_sizes, size_t n_batches) {
+    if (!c || !out || !pred_sizes || !tx_sizes) return -EINVAL;
+    *out = nullptr;
+    std::vector<uint32_t> pe(n_batches), te(n_batches), ua, ub;
+    size_t np = 0, nt = 0;
+    for (size_t k = 0; k < n_batches; k++) {
+        np += pred_sizes[k]; nt += tx_sizes[k];
+        if (np >= 0xffffffffu || nt >= 0xffffffffu) return -ENOTSUP;
+        pe[k] = (uint32_t) np; te[k] = (uint32_t) nt;
+    }
+    if ((np && !preds) || (nt && !txs)) return -EINVAL;
+    std::vector<IntraUnit> units;
+    const int rc = dav1d_hip_intra_units_build(preds, pe.data(), txs, te.data(), n_batches, units, ua, ub);
+    if (rc) return rc;
+    for (size_t k = 0, i = 0; k < n_batches; k++) {
+        const uint32_t need_a = (uint32_t) i, need_b = ua[k];
+        for (; i < ua[k]; i++) units[i].need = need_a;
+        for (; i < ub[k]; i++) units[i].need = need_b;
+    }
+    return dav1d_hip_intra_flow_from_units(c, out, units.data(), units.size());
 }
 
 // enqueues: counters to zero, then the launch

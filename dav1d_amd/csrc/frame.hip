@@ -26,9 +26,19 @@ struct Dav1dHipFrame {
     std::atomic<size_t> arena_used;
     // intra blocks: step k of the wavefront = the blocks whose neighbours are final after steps 0 .. k - 1 (and after the
     // inter blocks of the frame); predictions and residuals per step
-    std::vector<std::vector<Dav1dHipIpredTask>> ipred;
-    std::vector<std::vector<Dav1dHipItxTask>> intra_itx;
-    std::vector<std::vector<Dav1dHipCompTask>> step_blend;      // inter-intra blends per step (between predictions and residuals)
+    // One entry per submission (a tile-sbrow's blocks), tasks sorted by step with the end offset of every step; built — and
+    // for the dataflow launch paired into units — on the submitting thread, merged step by step at frame end.
+    struct StepChunk {
+        std::vector<Dav1dHipIpredTask> ip;
+        std::vector<Dav1dHipItxTask> ix;
+        std::vector<Dav1dHipCompTask> bl;           // inter-intra blends (between a step's predictions and its residuals)
+        std::vector<uint32_t> ip_end, ix_end, bl_end;       // [step] -> end offset of the step in ip / ix / bl
+        std::vector<IntraUnit> units;               // per step: the units with a prediction, then the residuals on their own
+        std::vector<uint32_t> ua_end, ub_end;       // [step] -> end of the step's first / second kind in units
+        bool flow_ok;                               // every task is of a kind the dataflow launch runs
+    };
+    std::vector<StepChunk *> step_chunks;
+    size_t n_steps;                                 // 1 + highest step submitted
     std::vector<Dav1dHipWarpTask> warp;                         // warped predictions (step 0: they read reference pictures only)
     std::vector<Dav1dHipMcScaledTask> scaled;                   // predictions from references of another size
     uint8_t *aux;                    // DEVICE arena of the palette indices the intra tasks point into (may be NULL)
@@ -219,6 +229,7 @@ int dav1d_hip_frame_begin(Dav1dHipContext *c, Dav1dHipFrame **out, const Dav1dHi
     f->b4_stride = 0;
     f->cdef_damping = 0;
     f->aux = nullptr;
+    f->n_steps = 0;
     f->have_grain = false;
     f->prepared = nullptr;
     f->is_id = 0;
@@ -279,12 +290,11 @@ int dav1d_hip_frame_submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc
 int dav1d_hip_frame_submit_intra_step(Dav1dHipFrame *f, size_t step, const Dav1dHipIpredTask *ipred, size_t n_ipred,
                                       const Dav1dHipItxTask *itx, size_t n_itx, uint8_t *aux) {
     if (!f || (!ipred && n_ipred) || (!itx && n_itx) || step > 65535) return -EINVAL;
-    std::lock_guard<std::mutex> lk(f->mtx);
-    if (f->ipred.size() <= step) { f->ipred.resize(step + 1); f->intra_itx.resize(step + 1); f->step_blend.resize(step + 1); }
-    f->ipred[step].insert(f->ipred[step].end(), ipred, ipred + n_ipred);
-    f->intra_itx[step].insert(f->intra_itx[step].end(), itx, itx + n_itx);
-    if (aux) f->aux = aux;
-    return 0;
+    std::vector<size_t> pe(step + 1, 0), xe(step + 1, 0), be(step + 1, 0);
+    pe[step] = n_ipred; xe[step] = n_itx;
+    const int rc = dav1d_hip_frame_submit_intra_sorted(f, step + 1, ipred, pe.data(), itx, xe.data(), nullptr, be.data());
+    if (!rc && aux) { std::lock_guard<std::mutex> lk(f->mtx); f->aux = aux; }
+    return rc;
 }
 
 // The blends of inter-intra blocks of wavefront step `step` (kind DAV1D_HIP_COMP_BLEND, tmp1_off = where the step's PRED_TMP task
@@ -292,9 +302,40 @@ int dav1d_hip_frame_submit_intra_step(Dav1dHipFrame *f, size_t step, const Dav1d
 // recon_b_inter (src/recon_tmpl.c:1606-1630: intra_pred into tmp, blend, later the residual).  Thread-safe.
 int dav1d_hip_frame_submit_step_blend(Dav1dHipFrame *f, size_t step, const Dav1dHipCompTask *blend, size_t n) {
     if (!f || (!blend && n) || step > 65535 || !step) return -EINVAL;
+    std::vector<size_t> pe(step + 1, 0), xe(step + 1, 0), be(step + 1, 0);
+    be[step] = n;
+    return dav1d_hip_frame_submit_intra_sorted(f, step + 1, nullptr, pe.data(), nullptr, xe.data(), blend, be.data());
+}
+
+// All intra steps of one submitter in one call: tasks sorted by step, *_end[s] = end offset of step s in its array (steps
+// 0 .. n_steps - 1; step 0 stays empty: it is the inter blocks').  One lock per call instead of one per step, and the pairing
+// of predictions with their residuals (dataflow launch, intra_flow.hip) happens here, on the submitting thread.
+int dav1d_hip_frame_submit_intra_sorted(Dav1dHipFrame *f, size_t n_steps, const Dav1dHipIpredTask *ip, const size_t *ip_end,
+                                        const Dav1dHipItxTask *ix, const size_t *ix_end, const Dav1dHipCompTask *bl, const size_t *bl_end) {
+    if (!f || !n_steps || n_steps > 65536 || !ip_end || !ix_end || !bl_end) return -EINVAL;
+    const size_t np = ip_end[n_steps - 1], nx = ix_end[n_steps - 1], nb = bl_end[n_steps - 1];
+    if ((np && !ip) || (nx && !ix) || (nb && !bl) || np >= 0xffffffffu || nx >= 0xffffffffu) return -EINVAL;
+    if (!np && !nx && !nb) return 0;
+    Dav1dHipFrame::StepChunk *ck = new (std::nothrow) Dav1dHipFrame::StepChunk();
+    if (!ck) return -ENOMEM;
+    ck->ip.assign(ip, ip + np); ck->ix.assign(ix, ix + nx); ck->bl.assign(bl, bl + nb);
+    ck->ip_end.resize(n_steps); ck->ix_end.resize(n_steps); ck->bl_end.resize(n_steps);
+    for (size_t s = 0; s < n_steps; s++) {
+        if (ip_end[s] > np || ix_end[s] > nx || bl_end[s] > nb || (s && (ip_end[s] < ip_end[s - 1] || ix_end[s] < ix_end[s - 1] || bl_end[s] < bl_end[s - 1]))) {
+            delete ck;
+            return -EINVAL;
+        }
+        ck->ip_end[s] = (uint32_t) ip_end[s]; ck->ix_end[s] = (uint32_t) ix_end[s]; ck->bl_end[s] = (uint32_t) bl_end[s];
+    }
+    ck->flow_ok = nb == 0 && f->c->flow_min_steps > 0;
+    if (ck->flow_ok) {
+        int rc = dav1d_hip_intra_units_build(ck->ip.data(), ck->ip_end.data(), ck->ix.data(), ck->ix_end.data(), n_steps, ck->units, ck->ua_end, ck->ub_end);
+        if (rc == -ENOTSUP) { ck->flow_ok = false; ck->units.clear(); rc = 0; }
+        if (rc) { delete ck; return rc; }
+    }
     std::lock_guard<std::mutex> lk(f->mtx);
-    if (f->ipred.size() <= step) { f->ipred.resize(step + 1); f->intra_itx.resize(step + 1); f->step_blend.resize(step + 1); }
-    f->step_blend[step].insert(f->step_blend[step].end(), blend, blend + n);
+    f->step_chunks.push_back(ck);
+    if (n_steps > f->n_steps) f->n_steps = n_steps;
     return 0;
 }
 
@@ -388,6 +429,9 @@ int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *ma
     (void) hipStreamSynchronize(c->copy_stream);
     for (Dav1dHipChunk *ck : f->chunks) { ck->release(c); delete ck; }
     f->chunks.clear();
+    for (Dav1dHipFrame::StepChunk *sc : f->step_chunks) delete sc;
+    f->step_chunks.clear();
+    f->n_steps = 0;
     f->arena_used = 0;
     if (c->pending_slab) {
         std::lock_guard<std::mutex> pl(c->pool_mtx);
@@ -427,45 +471,64 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
     }
     // intra blocks, wavefront step by step (each step: a paired launch for the small blocks, a prediction and a residual
     // launch for the others), enqueued back to back
-    if (!rc && !f->ipred.empty()) {
-        std::vector<Dav1dHipIpredTask> allp;
-        std::vector<Dav1dHipItxTask> allt;
-        std::vector<Dav1dHipCompTask> allb;
-        std::vector<size_t> ps, ts, bs;
-        f->step_blend.resize(f->ipred.size());
-        for (size_t k = 0; k < f->ipred.size(); k++) {
-            ps.push_back(f->ipred[k].size()); ts.push_back(f->intra_itx[k].size()); bs.push_back(f->step_blend[k].size());
-            allp.insert(allp.end(), f->ipred[k].begin(), f->ipred[k].end());
-            allt.insert(allt.end(), f->intra_itx[k].begin(), f->intra_itx[k].end());
-            allb.insert(allb.end(), f->step_blend[k].begin(), f->step_blend[k].end());
-        }
-        // A long wavefront (a key frame: thousands of steps, most of them narrow) goes down as ONE launch whose waves hand the
-        // steps to each other (intra_flow.hip); a short one (the intra blocks of an inter frame: tens of steps, the first ones
-        // wide) stays with up to three launches per step, which keep more waves in flight per step.  c->flow_min_steps = the
-        // border ($DAV1D_HIP_FLOW_MIN_STEPS at open, default 200; 0 = always the launches).
+    if (!rc && !f->step_chunks.empty()) {
         static const bool trace = getenv("DAV1D_HIP_TRACE_INTRA") != nullptr;
         const auto t_a = std::chrono::steady_clock::now();
-        Dav1dHipIntraFlow *fl = nullptr;
-        if (allb.empty() && c->flow_min_steps > 0 && ps.size() >= (size_t) c->flow_min_steps) {
-            const int frc = dav1d_hip_intra_flow_create(c, &fl, allp.data(), ps.data(), allt.data(), ts.data(), ps.size());
-            if (frc && frc != -ENOTSUP) rc = frc;
-        }
-        if (fl) {
+        const size_t ns = f->n_steps;
+        bool flow = c->flow_min_steps > 0 && ns >= (size_t) c->flow_min_steps;
+        for (const Dav1dHipFrame::StepChunk *ck : f->step_chunks) flow = flow && ck->flow_ok;
+        if (flow) {
+            // A long wavefront (a key frame: hundreds to thousands of steps, most of them narrow) goes down as ONE launch whose
+            // waves hand the steps to each other (intra_flow.hip).  The chunks' units, merged step by step: first the units with
+            // a prediction of every chunk, then the residuals on their own; `need` = where the group starts.
+            std::vector<size_t> na(ns + 1, 0), nb(ns + 1, 0);
+            for (const Dav1dHipFrame::StepChunk *ck : f->step_chunks)
+                for (size_t s = 0; s < ck->ua_end.size(); s++) {
+                    const uint32_t b0 = s ? ck->ub_end[s - 1] : 0;
+                    na[s] += ck->ua_end[s] - b0; nb[s] += ck->ub_end[s] - ck->ua_end[s];
+                }
+            std::vector<size_t> oa(ns + 1, 0), ob(ns + 1, 0);
+            size_t total = 0;
+            for (size_t s = 0; s < ns; s++) { oa[s] = total; ob[s] = total + na[s]; total += na[s] + nb[s]; }
+            std::vector<IntraUnit> all(total);
+            std::vector<size_t> pa(oa), pb(ob);
+            for (const Dav1dHipFrame::StepChunk *ck : f->step_chunks)
+                for (size_t s = 0; s < ck->ua_end.size(); s++) {
+                    const uint32_t b0 = s ? ck->ub_end[s - 1] : 0, a1 = ck->ua_end[s], b1 = ck->ub_end[s];
+                    if (a1 > b0) { memcpy(&all[pa[s]], &ck->units[b0], (a1 - b0) * sizeof(IntraUnit)); for (uint32_t i = b0; i < a1; i++) all[pa[s]++].need = (uint32_t) oa[s]; }
+                    if (b1 > a1) { memcpy(&all[pb[s]], &ck->units[a1], (b1 - a1) * sizeof(IntraUnit)); for (uint32_t i = a1; i < b1; i++) all[pb[s]++].need = (uint32_t) ob[s]; }
+                }
+            Dav1dHipIntraFlow *fl = nullptr;
+            rc = dav1d_hip_intra_flow_from_units(c, &fl, all.data(), all.size());
             const auto t_b = std::chrono::steady_clock::now();
-            (void) dav1d_hip_sync(c);
-            const auto t_c = std::chrono::steady_clock::now();
-            rc = dav1d_hip_intra_flow_run(c, fl, &f->cur, coef, f->aux);
+            if (!rc) rc = dav1d_hip_intra_flow_run(c, fl, &f->cur, coef, f->aux);
             uint32_t st[3] = { 0, 0, 0 };
             if (!rc) rc = dav1d_hip_intra_flow_status(c, fl, st);
+            if (!rc && (st[2] || st[1] != all.size())) rc = -EIO;      // a wave gave up waiting: never in a sound run
             if (trace) {
                 const auto t_d = std::chrono::steady_clock::now();
-                fprintf(stderr, "intra flow: %zu steps, %zu units; create %.2f ms, earlier work %.2f ms, launch to finish %.2f ms\n", ps.size(),
-                        dav1d_hip_intra_flow_units(fl), std::chrono::duration<double, std::milli>(t_b - t_a).count(),
-                        std::chrono::duration<double, std::milli>(t_c - t_b).count(), std::chrono::duration<double, std::milli>(t_d - t_c).count());
+                fprintf(stderr, "intra flow: %zu steps, %zu units; merge + upload %.2f ms, launch to finish %.2f ms\n", ns, all.size(),
+                        std::chrono::duration<double, std::milli>(t_b - t_a).count(), std::chrono::duration<double, std::milli>(t_d - t_b).count());
             }
-            if (!rc && (st[2] || st[1] != dav1d_hip_intra_flow_units(fl))) rc = -EIO;      // a wave gave up waiting: never in a sound run
-            dav1d_hip_intra_flow_destroy(c, fl);
-        } else if (!rc) {
+            if (fl) dav1d_hip_intra_flow_destroy(c, fl);
+        } else {
+            // A short wavefront (the intra blocks of an inter frame: tens of steps, the first ones wide) runs as up to three
+            // launches per step (a paired launch for the small blocks, a prediction and a residual launch for the others),
+            // which keep more waves in flight per step; so does any frame with inter-intra blends.  c->flow_min_steps = the
+            // border ($DAV1D_HIP_FLOW_MIN_STEPS at open, default 200; 0 = always the launches).
+            std::vector<Dav1dHipIpredTask> allp;
+            std::vector<Dav1dHipItxTask> allt;
+            std::vector<Dav1dHipCompTask> allb;
+            std::vector<size_t> ps(ns, 0), ts(ns, 0), bs(ns, 0);
+            for (size_t s = 0; s < ns; s++)
+                for (const Dav1dHipFrame::StepChunk *ck : f->step_chunks) {
+                    if (s >= ck->ip_end.size()) continue;
+                    const uint32_t p0 = s ? ck->ip_end[s - 1] : 0, x0 = s ? ck->ix_end[s - 1] : 0, b0 = s ? ck->bl_end[s - 1] : 0;
+                    allp.insert(allp.end(), ck->ip.begin() + p0, ck->ip.begin() + ck->ip_end[s]);
+                    allt.insert(allt.end(), ck->ix.begin() + x0, ck->ix.begin() + ck->ix_end[s]);
+                    allb.insert(allb.end(), ck->bl.begin() + b0, ck->bl.begin() + ck->bl_end[s]);
+                    ps[s] += ck->ip_end[s] - p0; ts[s] += ck->ix_end[s] - x0; bs[s] += ck->bl_end[s] - b0;
+                }
             Dav1dHipIntraList *xl = nullptr;
             rc = dav1d_hip_intra_list_create_blend(c, &xl, allp.data(), ps.data(), allt.data(), ts.data(), allb.data(), bs.data(), ps.size());
             for (size_t k = 0; k < ps.size() && !rc; k++) rc = dav1d_hip_intra_list_run_batch_blend(c, xl, k, &f->cur, coef, f->aux, prep, mask);
@@ -515,6 +578,7 @@ void dav1d_hip_frame_destroy(Dav1dHipFrame *f) {
     if (f->prepared) dav1d_hip_fg_grain_destroy(f->c, f->prepared);
     (void) hipStreamSynchronize(f->c->copy_stream);
     for (Dav1dHipChunk *ck : f->chunks) { ck->release(f->c); delete ck; }
+    for (Dav1dHipFrame::StepChunk *sc : f->step_chunks) delete sc;
     if (f->arena) {
         std::lock_guard<std::mutex> lk(f->c->pool_mtx);
         f->c->free_arenas.push_back({ f->arena, f->arena_cap });

@@ -118,10 +118,10 @@ def c2_params(seed, n_refs=3):
     return sp
 
 
-def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0xE2E, check=None, intra_pct=0, key_frame=False):
+def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0xE2E, check=None, intra_pct=0, key_frame=False, tile_rows=1):
     """Returns the measurement dict.  check: optional callable(handoff, desc, planes) -> str used as the parity gate."""
     layout = api.LAYOUT_I420
-    ho = HandOff(w, h, layout, bpc, True, tile_cols, 1)
+    ho = HandOff(w, h, layout, bpc, True, tile_cols, tile_rows)
     sp = c2_params(seed)
     sp.intra_pct = 100 if key_frame else intra_pct
     if key_frame:
@@ -140,7 +140,8 @@ def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0
         refs.append(r)
     refs7 = [refs[i % 3] for i in range(7)]
     cur = ctx.picture(w, h, layout, bpc)
-    n_tiles = ho.desc.n_tile_cols
+    n_tcols, n_trows = ho.desc.n_tile_cols, ho.desc.n_tile_rows
+    n_tiles = n_tcols * n_trows
     threads = threads or n_tiles
     coef = ctx.buffer(ho.cf.nbytes)
     import torch
@@ -158,9 +159,10 @@ def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0
             lh = C.c_void_p()
             assert ctx.lib.dav1d_hip_lister_create(C.byref(lh), C.byref(ho.desc), frame.h) == 0
 
-            def tile(tc):
-                for sby in range(ho.sbh):
-                    rc2 = ctx.lib.dav1d_hip_lister_tile_sbrow(lh, 0, tc, sby)
+            def tile(k):
+                tr, tc = divmod(k, n_tcols)
+                for sby in range(ho.rows[tr], ho.rows[tr + 1]):
+                    rc2 = ctx.lib.dav1d_hip_lister_tile_sbrow(lh, tr, tc, sby)
                     assert rc2 == 0, rc2
             # the coefficient arena crosses the host link every frame (the kernels consume = zero it), while the listing runs
             def h2d():
@@ -199,9 +201,9 @@ def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0
     out["unit"] = "Mpixels/s"
     out["synth_seconds"] = round(t_synth, 2)
     kind = "key frame (every block intra)" if key_frame else "inter frame" if not intra_pct else "inter frame, %d %% intra blocks" % intra_pct
-    out["workload"] = ("%dx%d 4:2:0 %d-bit " + kind + " from pass-1 hand-off arrays: lister on %d host threads (one per tile column), chunk "
+    out["workload"] = ("%dx%d 4:2:0 %d-bit " + kind + " from pass-1 hand-off arrays: lister on %d host threads over %d x %d tiles, chunk "
                        "preparation + upload on the submitting threads, dense coefficient arena over the host link meanwhile (h2d_ms), "
-                       "frame_end = gather + the frame's launches + sync") % (w, h, bpc, threads)
+                       "frame_end = gather + the frame's launches + sync") % (w, h, bpc, threads, n_tcols, n_trows)
     if check is not None and planes is not None:
         out["parity"] = check(ho, planes, refs)
     for o in refs + [cur, coef] + ([prep, mask] if prep is not None else []):
@@ -214,13 +216,14 @@ def main():
     ap.add_argument("--frames", type=int, default=6)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--tile-cols", type=int, default=4)
+    ap.add_argument("--tile-rows", type=int, default=1)
     ap.add_argument("--width", type=int, default=7680)
     ap.add_argument("--height", type=int, default=4320)
     ap.add_argument("--intra-pct", type=int, default=0)
     ap.add_argument("--key-frame", type=int, default=0)
     a = ap.parse_args()
     ctx = api.Context(0)
-    print(json.dumps(run(ctx, a.width, a.height, 10, a.frames, a.threads or None, a.tile_cols, intra_pct=a.intra_pct, key_frame=bool(a.key_frame))))
+    print(json.dumps(run(ctx, a.width, a.height, 10, a.frames, a.threads or None, a.tile_cols, intra_pct=a.intra_pct, key_frame=bool(a.key_frame), tile_rows=a.tile_rows)))
 
 
 if __name__ == "__main__":

@@ -910,14 +910,8 @@ static int submit_steps(Dav1dHipLister *l, Out *o) {
     for (size_t i = 0; i < o->ipred.n; i++) ip[ci[o->ipred_step.p[i]]++] = o->ipred.p[i];
     for (size_t i = 0; i < o->blend.n; i++) bl[cb[o->blend_step.p[i]]++] = o->blend.p[i];
     for (size_t i = 0; i < o->sitx.n; i++) ix[cx[o->sitx_step.p[i]]++] = o->sitx.p[i];
-    int rc = 0;
-    size_t i0 = 0, b0 = 0, x0 = 0;
-    for (unsigned s = 1; s <= hi && !rc; s++) {
-        const size_t i1 = ci[s], b1 = cb[s], x1 = cx[s];
-        if (i1 > i0 || x1 > x0) rc = dav1d_hip_frame_submit_intra_step(l->frame, s, ip + i0, i1 - i0, ix + x0, x1 - x0, NULL);
-        if (!rc && b1 > b0) rc = dav1d_hip_frame_submit_step_blend(l->frame, s, bl + b0, b1 - b0);
-        i0 = i1; b0 = b1; x0 = x1;
-    }
+    /* after the fill, ci[s] / cb[s] / cx[s] = end of step s: exactly what the one-call submission takes */
+    const int rc = dav1d_hip_frame_submit_intra_sorted(l->frame, (size_t) hi + 1, ip, ci, ix, cx, bl, cb);
     free(cnt); free(ip); free(bl); free(ix);
     return rc;
 }

@@ -560,6 +560,12 @@ DAV1D_HIP_API int dav1d_hip_frame_submit_tile_sbrow(Dav1dHipFrame *f, const Dav1
  * the steps before): predictions + residuals; `aux` = DEVICE arena of packed palette indices (NULL if no PAL task).  Thread-safe. */
 DAV1D_HIP_API int dav1d_hip_frame_submit_intra_step(Dav1dHipFrame *f, size_t step, const Dav1dHipIpredTask *ipred, size_t n_ipred,
                                                     const Dav1dHipItxTask *itx, size_t n_itx, uint8_t *aux);
+/* Every intra step of one submitter (a tile-sbrow) in ONE call: the tasks sorted by step, *_end[s] = end offset of step s in its
+ * array, steps 0 .. n_steps - 1 (step 0 stays empty: it belongs to the inter blocks); blends = the step's inter-intra blends
+ * (dav1d_hip_frame_submit_step_blend).  What the pass-2 lister calls: one lock per tile-sbrow instead of one per step. */
+DAV1D_HIP_API int dav1d_hip_frame_submit_intra_sorted(Dav1dHipFrame *f, size_t n_steps, const Dav1dHipIpredTask *ipred, const size_t *ipred_end,
+                                                      const Dav1dHipItxTask *itx, const size_t *itx_end, const Dav1dHipCompTask *blend,
+                                                      const size_t *blend_end);
 /* Inter-intra blends of wavefront step `step` >= 1 (kind DAV1D_HIP_COMP_BLEND reading what the step's DAV1D_HIP_IPRED_PRED_TMP
  * tasks wrote): run between the step's predictions and its residuals.  Thread-safe. */
 DAV1D_HIP_API int dav1d_hip_frame_submit_step_blend(Dav1dHipFrame *f, size_t step, const Dav1dHipCompTask *blend, size_t n);

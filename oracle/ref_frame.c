@@ -379,6 +379,82 @@ int dav1d_ref_frame_recon(void *const h) {
     return 0;
 }
 
+/* The same pass 2 on n_threads workers, the split dav1d's frame threading makes (tile-sbrow tasks, src/thread_task.c:693-760):
+ * a worker takes the next tile whose turn it is and runs its superblock rows top to bottom; tiles do not depend on each
+ * other in pass 2 (prediction never crosses a tile edge; the reference pictures are complete).  Every worker has a
+ * Dav1dTaskContext of its own, as dav1d's worker threads do. */
+#include <pthread.h>
+typedef struct MtJob {
+    RefFrame *r;
+    int next;                /* next tile, under mu */
+    int failed;
+    pthread_mutex_t mu;
+} MtJob;
+
+static void *mt_worker(void *const arg) {
+    MtJob *const job = arg;
+    RefFrame *const r = job->r;
+    Dav1dFrameContext *const f = &r->f;
+    const Dav1dFrameHeader *const fh = &r->fh;
+    Dav1dTaskContext *t = NULL;
+    if (posix_memalign((void **) &t, 64, sizeof(*t))) { job->failed = 1; return NULL; }
+    memset(t, 0, sizeof(*t));
+    t->c = &r->c; t->f = f;
+    t->frame_thread.pass = 2;
+    for (;;) {
+        pthread_mutex_lock(&job->mu);
+        const int tile = job->next < f->n_ts ? job->next++ : -1;
+        pthread_mutex_unlock(&job->mu);
+        if (tile < 0) break;
+        const int tile_row = tile / fh->tiling.cols;
+        t->ts = &f->ts[tile];
+        for (int sby = fh->tiling.row_start_sb[tile_row]; sby < fh->tiling.row_start_sb[tile_row + 1]; sby++) {
+            t->by = sby << f->sb_shift;
+            if (dav1d_decode_tile_sbrow(t)) { job->failed = 1; break; }
+        }
+    }
+    free(t);
+    return NULL;
+}
+
+int dav1d_ref_frame_recon_mt(void *const h, int n_threads) {
+    RefFrame *const r = h;
+    Dav1dFrameContext *const f = &r->f;
+    const Dav1dFrameHeader *const fh = &r->fh;
+    const int keyframe = !r->p.is_inter;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > f->n_ts) n_threads = f->n_ts;
+    for (int n = f->sb128w * fh->tiling.rows; n < f->a_sz; n++) {
+        memset(&f->a[n], 0, sizeof(f->a[n]));
+        memset(f->a[n].intra, keyframe, sizeof(f->a[n].intra));
+        memset(f->a[n].uvmode, DC_PRED, sizeof(f->a[n].uvmode));
+        if (keyframe) memset(f->a[n].mode, DC_PRED, sizeof(f->a[n].mode));
+    }
+    {
+        static const uint8_t ss_size_mul[4][2] = { { 4, 4 }, { 6, 5 }, { 8, 6 }, { 12, 8 } };
+        const uint8_t *const size_mul = ss_size_mul[r->p.layout];
+        for (int j = 0; j < f->n_ts; j++) {
+            const unsigned off = f->frame_thread.tile_start_off[j];
+            Dav1dTileState *const ts = &f->ts[j];
+            ts->frame_thread[0].pal_idx = f->frame_thread.pal_idx ? &f->frame_thread.pal_idx[(size_t) off * size_mul[1] / 8] : NULL;
+            ts->frame_thread[0].cbi = &f->frame_thread.cbi[(size_t) off * size_mul[0] / 64];
+            ts->frame_thread[0].cf = (uint8_t *) f->frame_thread.cf + (((size_t) off * size_mul[0]) >> !r->seq.hbd);
+        }
+    }
+    MtJob job = { .r = r, .next = 0, .failed = 0 };
+    pthread_mutex_init(&job.mu, NULL);
+    pthread_t *const th = malloc(sizeof(*th) * (size_t) n_threads);
+    if (!th) return -1;
+    int started = 0;
+    for (; started < n_threads; started++)
+        if (pthread_create(&th[started], NULL, mt_worker, &job)) break;
+    if (!started) mt_worker(&job);
+    for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
+    free(th);
+    pthread_mutex_destroy(&job.mu);
+    return job.failed ? -1 : 0;
+}
+
 /* t->warpmv of a MM_WARP block exactly as decode_b() rebuilds it in pass 2 (src/decode.c:743-757); returns what
  * dav1d_get_shear_params() returned.  out = { matrix[6], alpha, beta, gamma, delta } */
 int dav1d_ref_block_warp(const int16_t *const matrix, const int16_t *const mv2d, const int bw4, const int bh4, const int bx, const int by,

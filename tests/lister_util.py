@@ -34,6 +34,8 @@ def ref_lib():
     lib.dav1d_ref_frame_ptr.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t)]
     lib.dav1d_ref_frame_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     lib.dav1d_ref_frame_recon.argtypes = [C.c_void_p]
+    if hasattr(lib, "dav1d_ref_frame_recon_mt"):
+        lib.dav1d_ref_frame_recon_mt.argtypes = [C.c_void_p, C.c_int]
     lib.dav1d_ref_frame_destroy.argtypes = [C.c_void_p]
     lib.dav1d_ref_layouts.argtypes = [C.POINTER(C.c_int)]
     lib.dav1d_ref_frame_build_filter_inputs.argtypes = [C.c_void_p, C.c_uint]
@@ -159,8 +161,9 @@ class RefFrame:
         d.cf_align64 = 1                     # the oracle build is an x86-64 build (oracle/ref_config.h)
         return d
 
-    def recon(self):
-        rc = self.lib.dav1d_ref_frame_recon(self.h)
+    def recon(self, threads=1):
+        """pass 2 of the frame: dav1d_decode_tile_sbrow over every tile; threads > 1: one worker per tile in flight"""
+        rc = self.lib.dav1d_ref_frame_recon(self.h) if threads <= 1 else self.lib.dav1d_ref_frame_recon_mt(self.h, threads)
         assert rc == 0, "reference pass 2 failed"
 
     def build_filter_inputs(self, seed):
@@ -395,5 +398,31 @@ def check_handoff_against_reference(ho, planes, ref_pics, is_inter=True):
         bad = compare(rf, planes)
         assert not bad, bad
         return "bit-exact vs the reference's own pass 2 (dav1d_decode_tile_sbrow, 1 thread: %.2f s for this frame)" % t_ref
+    finally:
+        rf.destroy()
+
+
+def reference_pass2_rate(lib_ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=(32, 64, 128), seed=0xCB0):
+    """The CPU peer of the end-to-end route: the reference's OWN pass 2 (dav1d_decode_tile_sbrow on a real Dav1dFrameContext,
+    C DSP functions of this build) on the same kind of synthetic inter frame, split into tile_cols x tile_rows tiles and run
+    by a pool of workers, one tile each at a time — the split dav1d's frame threading makes in pass 2.  Returns
+    {threads: Mpixels/s}.  lib_ctx: anything with .lib = the product library (for the frame generator)."""
+    import time
+    from dav1d_amd import e2e
+    if ref_lib() is None:
+        return None
+    rf = RefFrame(w, h, 1, bpc, is_inter=True, sb128=True, tile_cols=tile_cols, tile_rows=tile_rows)
+    try:
+        sp = e2e.c2_params(seed)
+        synth(lib_ctx, rf, sp)
+        fill_pictures(rf, seed)
+        cf = rf.array("cf", np.uint8)
+        out = {}
+        for t in threads:
+            cf[:] = rf.cf_copy
+            t0 = time.perf_counter()
+            rf.recon(t)
+            out[int(t)] = round(w * h / (time.perf_counter() - t0) / 1e6, 1)
+        return out
     finally:
         rf.destroy()

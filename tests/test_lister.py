@@ -177,3 +177,26 @@ def test_larger_frame_many_tiles_threads():
         run_case(ctx, 1280, 720, 1, 8, 8, tiles=(2, 1), threads=2, is_inter=False)
     finally:
         ctx.close()
+
+
+def test_reference_pass2_on_worker_threads_equals_one_thread():
+    """oracle/ref_frame.c dav1d_ref_frame_recon_mt (the CPU peer bench.py times): tiles on a pool of workers give the picture
+    the single-threaded walk gives."""
+    if lu.ref_lib() is None:
+        pytest.skip("no reference build (oracle/_ref)")
+    import util
+    ctx = util.make_context("emu")
+    from dav1d_amd import e2e
+    outs = []
+    for threads in (1, 6):
+        rf = lu.RefFrame(640, 384, 1, 10, is_inter=True, sb128=True, tile_cols=4, tile_rows=3)
+        sp = e2e.c2_params(5)
+        sp.intra_pct = 20
+        lu.synth(ctx, rf, sp)
+        lu.fill_pictures(rf, 9)
+        rf.recon(threads)
+        outs.append([rf.plane(0, pl).copy() for pl in range(3)])
+        rf.destroy()
+    for pl in range(3):
+        assert np.array_equal(outs[0][pl], outs[1][pl])
+    ctx.close()
