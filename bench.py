@@ -59,6 +59,9 @@ def parse():
                     help="N > 1: frames = one independent frame stream per GPU (weak scaling, no data-path collective); "
                          "tile-cols = GPU g reconstructs tile column g of the SAME frame and one all-gather per frame rebuilds "
                          "the picture everywhere (SURVEY 8e config C3, strong scaling)")
+    ap.add_argument("--tc-filters", action="store_true",
+                    help="tile-cols only: the step also runs deblocking, CDEF and loop restoration of the rank's column after a halo "
+                         "exchange of 16 luma columns with its neighbours (dav1d_amd/dist.py), and gathers the FILTERED columns")
     return ap.parse_args()
 
 
@@ -191,6 +194,16 @@ def main():
         h2d_ms = round(best, 3)
         del pinned
 
+    tc_post = None
+    if tile_cols and a.tc_filters:
+        # this rank's share of the frame's in-loop filter tasks (margins included) and the two extra pictures of the chain
+        post_all = synth.make_post_filters(whole, seed=0xF11)
+        lf_c, cdef_c, lr_c = dd.post_tasks_of_column(post_all.lf, post_all.cdef, post_all.lr,
+                                                     [dsts[0].view.stride_px(pl) for pl in range(3)], cols[rank])
+        tc_post = {"all": post_all, "lf": lf_c, "cdef": cdef_c, "lr": lr_c, "lvl": ctx.buffer_from(post_all.lvl),
+                   "cdf": dd.SharedPicture(ctx, w, h, api.LAYOUT_I420, bpc, "cuda"), "res": dd.SharedPicture(ctx, w, h, api.LAYOUT_I420, bpc, "cuda")}
+    final_pic = {}
+
     def step(i):
         d = dsts[i % NDST]
         if recon_list is not None:
@@ -198,7 +211,20 @@ def main():
         else:
             ctx.run_inter_list(inter_list, d, refs, prep.data_ptr())
             ctx.run_itx_list(itx_list, d, arenas[i].data_ptr())
-        if tile_cols:
+        if tile_cols and tc_post is not None:
+            ctx.sync()
+            dd.exchange_halo(d, cols, rank, world)
+            pa, cdf, res = tc_post["all"], tc_post["cdf"], tc_post["res"]
+            ctx.lf_batch(d.view, tc_post["lf"], tc_post["lvl"], pa.b4_stride, pa.lut_e, pa.lut_i)
+            for pl in range(3):
+                cdf.planes[pl].copy_(d.planes[pl])
+            ctx.cdef_batch(cdf.view, d.view, tc_post["cdef"], pa.cdef_damping)
+            for pl in range(3):
+                res.planes[pl].copy_(cdf.planes[pl])
+            ctx.lr_batch(res.view, cdf.view, d.view, tc_post["lr"])
+            dd.allgather_tile_columns(res, cols, rank, world)
+            final_pic[0] = res
+        elif tile_cols:
             dd.allgather_tile_columns(d, cols, rank, world)
 
     # ---- parity gate on this very workload: frame `warmup-0` output vs the oracle replay (bounded: luma rows)
@@ -379,7 +405,16 @@ def main():
                 reps += 1
                 if a.no_cpu or t_cpu >= a.cpu_seconds or reps >= 8:
                     break
-            if not a.no_check:
+            if not a.no_check and tc_post is not None:
+                # tile columns with in-loop filters: the gathered picture against the oracle's whole-frame chain
+                import test_postchain
+                _, _, r_, _ = test_postchain.oracle_post(oracle, tc_post["all"], want[0], w, h, bpc, with_grain=False)
+                got = [final_pic[0].download(pl) for pl in range(3)]
+                ok = all(np.array_equal(got[pl][:(h >> (pl > 0)), :(w >> (pl > 0))], r_[pl][:(h >> (pl > 0)), :(w >> (pl > 0))]) for pl in range(3))
+                check = "bit-exact vs %s oracle after deblock + CDEF + restoration (gathered columns)" % oracle.which if ok else "MISMATCH"
+                if not ok:
+                    raise SystemExit("bench: the filtered tile columns differ from the oracle's whole-frame chain")
+            elif not a.no_check:
                 got = [dsts[i % NDST].download(pl) for pl in range(3)]
                 ok = all(np.array_equal(got[pl], want[0][pl]) for pl in range(3))
                 ok = ok and (a.packed or not bool(arenas[i].any().item()))
@@ -586,7 +621,8 @@ def main():
                                       "lists resident in HBM" % (w, h, bpc),
                           "step": ("inter list, then itx list" if a.two_phase else
                                    "recon list: residual launches wait only for the prediction launches under their blocks (2 streams)"),
-                          "frames_per_step": 1, "parallelism": ("tile-columns x%d + one all-gather per frame" if tile_cols else "frame-parallel x%d") % world,
+                          "frames_per_step": 1, "parallelism": (("tile-columns x%d, in-loop filters per column after a 16-column halo exchange, one all-gather of the filtered columns per frame"
+                                                            if a.tc_filters else "tile-columns x%d + one all-gather per frame") if tile_cols else "frame-parallel x%d") % world,
                           "tasks": {"mc": int(len(frame.mc)), "comp": int(len(frame.comp)), "itx": int(len(frame.itx))},
                           "coef_format": "packed: eob + 1 scan-order values per block" if a.packed else "dense cf arena (reference layout)",
                           "coef_bytes_per_frame": int(coef_host.nbytes), "coef_h2d_ms_per_frame": h2d_ms,

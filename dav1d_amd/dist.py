@@ -144,7 +144,7 @@ def allgather_tile_columns(pic, cols, rank, world, ss_hor=1):
     wmax = max(x1 - x0 for x0, x1 in cols)
     shapes = [(p.shape[0], wmax >> (ss_hor if pl else 0)) for pl, p in enumerate(pic.planes)]
     per = sum(r * c for r, c in shapes)
-    send = torch.zeros(per, dtype=pic.tdtype, device=pic.store.device)
+    send = _buf(("col_send", per), per, pic.tdtype, pic.store.device)      # staging kept between frames (strips are not contiguous)
 
     def strips(buf, k):
         out, off = [], 0
@@ -157,10 +157,125 @@ def allgather_tile_columns(pic, cols, rank, world, ss_hor=1):
 
     for pl, (v, a, b) in enumerate(strips(send, rank)):
         v.copy_(pic.planes[pl][:, a:b])
-    recv = torch.empty(world * per, dtype=pic.tdtype, device=pic.store.device)
+    recv = _buf(("col_recv", per, world), world * per, pic.tdtype, pic.store.device)
     dist.all_gather_into_tensor(recv.view(torch.uint8), send.view(torch.uint8))    # bytes: every backend moves uint8
     for k in range(world):
         if k == rank:
             continue
         for pl, (v, a, b) in enumerate(strips(recv[k * per:(k + 1) * per], k)):
             pic.planes[pl][:, a:b].copy_(v)
+
+
+# ---- tile-column mode, in-loop filters: deblocking, CDEF and loop restoration read across the tile edge ------------
+#
+# What rank g needs from its neighbours so that everything it produces INSIDE its column [x0, x1) is exact:
+#   loop restoration at x >= x0 reads CDEF output from x0 - 3;
+#   CDEF output at x0 - 3 lies in the 8x8 unit [x0 - 8, x0): its direction search reads the unit's deblocked pixels, its taps
+#     deblocked pixels from x0 - 5;
+#   deblocked pixels in [x0 - 8, x0) come from the vertical edges at x0 - 8 (at most the 8-wide filter there: a 16-wide one needs
+#     16-pixel transforms on both sides, i.e. an edge at a multiple of 16), x0 - 4 and x0, which read reconstructed pixels from
+#     x0 - 12 on; horizontal edges work down a column and spread nothing sideways.
+# So HALO = 16 luma columns (8 chroma) of RECONSTRUCTED pixels per side are exchanged once per frame, every rank then runs the
+# filter tasks that touch [x0 - 8, x1 + 8) (deblocking, CDEF) or are cropped to [x0, x1) (restoration) — a few per cent of work
+# done twice instead of a second and third exchange — and the final all-gather moves finished columns only.
+HALO = 16
+
+_buffers = {}
+
+
+def _buf(key, n, dtype, device):
+    import torch
+    b = _buffers.get(key)
+    if b is None or b.numel() < n or b.dtype != dtype or b.device != torch.device(device):
+        b = torch.empty(n, dtype=dtype, device=device)
+        _buffers[key] = b
+    return b[:n]
+
+
+def exchange_halo(pic, cols, rank, world, ss_hor=1, halo=HALO):
+    """After rank g reconstructed column g of `pic`: its neighbours' outermost `halo` luma columns (all planes) arrive next to
+    it.  One small all-gather (2 strips per rank: gloo and RCCL alike move it as bytes; 2 x 16 columns of an 8K frame are
+    0.4 MB per rank), staging buffers kept between frames."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return
+    assert len(cols) == world
+    shapes = [(p.shape[0], halo >> (ss_hor if pl else 0)) for pl, p in enumerate(pic.planes)]
+    per = sum(r * c for r, c in shapes)
+    dev = pic.store.device
+    send = _buf(("halo_send", id(pic.store.device), per), 2 * per, pic.tdtype, dev)
+    recv = _buf(("halo_recv", id(pic.store.device), per, world), 2 * per * world, pic.tdtype, dev)
+    x0, x1 = cols[rank]
+
+    def parts(buf, side):
+        out, off = [], side * per
+        for pl, (r, c) in enumerate(shapes):
+            out.append(buf[off:off + r * c].view(r, c))
+            off += r * c
+        return out
+
+    for pl, v in enumerate(parts(send, 0)):                 # my left edge (goes to rank - 1's right halo)
+        s = ss_hor if pl else 0
+        v.copy_(pic.planes[pl][:, x0 >> s:(x0 >> s) + v.shape[1]])
+    for pl, v in enumerate(parts(send, 1)):                 # my right edge (goes to rank + 1's left halo)
+        s = ss_hor if pl else 0
+        v.copy_(pic.planes[pl][:, (x1 >> s) - v.shape[1]:x1 >> s])
+    dist.all_gather_into_tensor(recv.view(torch.uint8), send.view(torch.uint8))
+    if rank > 0:                                            # left neighbour's right edge -> [x0 - halo, x0)
+        for pl, v in enumerate(parts(recv[(rank - 1) * 2 * per:rank * 2 * per], 1)):
+            s = ss_hor if pl else 0
+            pic.planes[pl][:, (x0 >> s) - v.shape[1]:x0 >> s].copy_(v)
+    if rank + 1 < world:                                    # right neighbour's left edge -> [x1, x1 + halo)
+        for pl, v in enumerate(parts(recv[(rank + 1) * 2 * per:(rank + 2) * 2 * per], 0)):
+            s = ss_hor if pl else 0
+            pic.planes[pl][:, x1 >> s:(x1 >> s) + v.shape[1]].copy_(v)
+
+
+def post_tasks_of_column(lf, cdef, lr, stride_px, col, ss_hor=1):
+    """The in-loop filter tasks rank g runs for column `col` = (x0, x1) (see the derivation above): deblocking and CDEF tasks
+    that touch [x0 - 8, x1 + 8), restoration units cropped to [x0, x1).  Returns (lf tasks, cdef tasks, lr tasks)."""
+    import numpy as np
+    x0, x1 = col
+    stride = np.asarray(stride_px, np.int64)
+    pl = lf["plane"].astype(np.int64)
+    sh = np.where(pl > 0, ss_hor, 0)
+    x = (lf["dst_off"].astype(np.int64) % stride[pl]) << sh              # luma x of the task's first unit
+    span = np.where(lf["dir"] == 0, 1, 128 << sh)                        # dir 1: a line of up to 32 units runs across
+    keep = (x + span > x0 - 9) & (x <= x1 + 8)               # edges at x0 - 8 .. x1 + 8; lines that cross that range
+    lf_c = lf[keep]
+    cx = cdef["bx"].astype(np.int64) * 8
+    raw = (cdef["flags"] & 1) != 0
+    cdef_c = cdef[~raw & (cx + 8 > x0 - 8) & (cx < x1 + 8)]
+    out = []
+    for t in lr:
+        s = ss_hor if t["plane"] else 0
+        a, b = x0 >> s, x1 >> s
+        lo, hi = max(int(t["x"]), a), min(int(t["x"]) + int(t["w"]), b)
+        if lo >= hi:
+            continue
+        u = t.copy()
+        e = int(t["edges"])
+        if lo > int(t["x"]):
+            e |= 1                                                       # cropped on the left: the pixels beyond exist
+        if hi < int(t["x"]) + int(t["w"]):
+            e |= 2
+        u["x"], u["w"], u["edges"] = lo, hi - lo, e
+        out.append(u)
+    lr_c = np.array(out, dtype=lr.dtype) if out else lr[:0]
+    return lf_c, cdef_c, lr_c
+
+
+# ---- frame-parallel mode with dependent frames ------------------------------------------------------------------------------------
+# dav1d's frame threads let frame n + 1 start while frame n is still being decoded and make each of its blocks wait until the
+# reference rows it reads have been published (src/thread_task.c:416-433, progress per superblock row).  Across GPUs the unit
+# of publication is the whole picture: the rank that finished frame n sends it once, every rank that predicts from it receives
+# it into its own copy (RCCL broadcast over xGMI; one 8K 10-bit picture is 100 MB = about 0.7 ms per link).
+
+def broadcast_picture(pic, src_rank, world):
+    """Every rank ends up with rank `src_rank`'s planes of `pic` (a SharedPicture: one contiguous tensor, so ONE broadcast)."""
+    if world == 1:
+        return
+    import torch
+    import torch.distributed as dist
+    dist.broadcast(pic.store.view(torch.uint8) if pic.store.dtype != torch.uint8 else pic.store, src=src_rank)

@@ -47,3 +47,16 @@ def test_bench_tile_column_mode_on_one_gpu():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["scaling"] == "strong" and "tile-columns" in d["config"]["parallelism"]
     assert d["config"]["parity"].startswith("bit-exact")
+
+
+@pytest.mark.gpu
+def test_bench_tile_column_mode_with_in_loop_filters_on_one_gpu():
+    """--shard tile-cols --tc-filters with one rank: the halo exchange is a no-op, the rank's share of the filter tasks is all of
+    them, and the gathered picture equals the oracle's deblock + CDEF + restoration of the whole frame."""
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--width", "1280", "--height", "1024", "--no-cpu", "--shard", "tile-cols", "--tc-filters"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "in-loop filters per column" in d["config"]["parallelism"]
+    assert d["config"]["parity"].startswith("bit-exact") and "restoration" in d["config"]["parity"]

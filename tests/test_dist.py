@@ -119,6 +119,161 @@ def test_tile_columns_world2_gloo(tmp_path):
     assert all(c > 0 for c in d["counts"])
 
 
+POST_WORKER = """
+import sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import numpy as np
+import torch, torch.distributed as dist
+import util, test_frame, test_postchain
+from dav1d_amd import api, synth, dist as dd
+
+rank, local, world = dd.env()
+dist.init_process_group("gloo")
+W, H, BPC = 512, 192, 10
+ctx = util.make_context("emu")
+cols = dd.tile_columns(W, world)
+rng = np.random.default_rng(21)
+ref_host = [synth.make_planes(rng, W, H, BPC) for _ in range(3)]
+dst0 = synth.make_planes(rng, W, H, BPC, smooth=False)
+frame = synth.make_frame(W, H, BPC, seed=933, mv_range_px=48)
+post = synth.make_post_filters(frame, seed=41)
+
+refs = []
+for r in ref_host:
+    p = dd.SharedPicture(ctx, W, H, api.LAYOUT_I420, BPC, "cpu")
+    for pl in range(3):
+        p.upload(pl, r[pl])
+    refs.append(p)
+cur, cdf, res = (dd.SharedPicture(ctx, W, H, api.LAYOUT_I420, BPC, "cpu") for _ in range(3))
+for pl in range(3):
+    cur.upload(pl, dst0[pl])
+stride_px = [cur.view.stride_px(pl) for pl in range(3)]
+mine = dd.tasks_by_column(frame.mc, frame.comp, frame.itx, stride_px, cols)[rank]
+prep = ctx.buffer(frame.prep_elems * 2); prep.zero()
+coef = ctx.buffer_from(frame.coef)
+ctx.mc_batch(cur.view, [r.view for r in refs], frame.mc[mine[0]], prep)
+if len(mine[1]):
+    ctx.comp_batch(cur.view, frame.comp[mine[1]], prep, None)
+ctx.itx_add_batch(cur.view, frame.itx[mine[2]], coef)
+ctx.sync()
+# the in-loop filters of this rank's column: neighbours' edge columns first, then deblocking (in place), CDEF, restoration
+dd.exchange_halo(cur, cols, rank, world)
+lf_c, cdef_c, lr_c = dd.post_tasks_of_column(post.lf, post.cdef, post.lr, stride_px, cols[rank])
+lvl = ctx.buffer_from(post.lvl)
+ctx.lf_batch(cur.view, lf_c, lvl, post.b4_stride, post.lut_e, post.lut_i)
+for pl in range(3):
+    cdf.planes[pl].copy_(cur.planes[pl])
+ctx.cdef_batch(cdf.view, cur.view, cdef_c, post.cdef_damping)
+for pl in range(3):
+    res.planes[pl].copy_(cdf.planes[pl])
+ctx.lr_batch(res.view, cdf.view, cur.view, lr_c)
+ctx.sync()
+dd.allgather_tile_columns(res, cols, rank, world)
+share = [len(lf_c) / len(post.lf), len(cdef_c) / len(post.cdef), len(lr_c) / max(1, len(post.lr))]
+if rank == 0:
+    oracle = util.default_oracle()
+    want, _, _ = test_frame.oracle_frame(oracle, frame, dst0, ref_host)
+    d, c, r, _ = test_postchain.oracle_post(oracle, post, want, W, H, BPC, with_grain=False)
+    got = [res.download(pl) for pl in range(3)]
+    bad = []
+    for pl in range(3):
+        vh, vw = (H, W) if pl == 0 else (H // 2, W // 2)
+        if not np.array_equal(got[pl][:vh, :vw], r[pl][:vh, :vw]):
+            yy, xx = np.nonzero(got[pl][:vh, :vw] != r[pl][:vh, :vw])
+            bad.append((pl, int(yy[0]), int(xx[0]), int(len(yy)), int(xx.min()), int(xx.max())))
+    changed = any(np.any(r[pl] != want[pl]) for pl in range(3))
+    print(json.dumps({"ok": not bad, "bad": bad, "cols": cols, "share": share, "filters_changed_pixels": bool(changed)}))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_tile_columns_with_in_loop_filters_world2_gloo(tmp_path):
+    """Tile-column sharding with deblocking, CDEF and restoration across the tile edge: each rank reconstructs its
+    column, receives 16 luma columns of its neighbour's reconstruction, filters its own column (+ the margin the chain
+    needs), and the gathered result equals the oracle's whole-frame chain on one rank."""
+    import json
+    script = tmp_path / "post.py"
+    script.write_text(POST_WORKER % {"root": util.ROOT, "tests": os.path.join(util.ROOT, "tests")})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29523", str(script)],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["ok"] and d["filters_changed_pixels"], d
+    assert all(0.5 <= s < 0.75 for s in d["share"]), d          # a little more than half the tasks per rank: the margins
+
+
+DEP_WORKER = """
+import sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import numpy as np
+import torch, torch.distributed as dist
+import util, test_frame
+from dav1d_amd import api, synth, dist as dd
+
+rank, local, world = dd.env()
+dist.init_process_group("gloo")
+W, H, BPC, N = 256, 128, 10, 4
+ctx = util.make_context("emu")
+rng = np.random.default_rng(31)
+ref_host = [synth.make_planes(rng, W, H, BPC) for _ in range(3)]
+dst0 = synth.make_planes(rng, W, H, BPC, smooth=False)
+frames = [synth.make_frame(W, H, BPC, seed=700 + n, mv_range_px=32) for n in range(N)]
+refs = []
+for r in ref_host:
+    p = dd.SharedPicture(ctx, W, H, api.LAYOUT_I420, BPC, "cpu")
+    for pl in range(3):
+        p.upload(pl, r[pl])
+    refs.append(p)
+# frame n is reconstructed by rank n %% world and predicts (reference 0) from frame n - 1, which another rank produced:
+# the owner publishes the finished picture, everybody receives it
+pics = [dd.SharedPicture(ctx, W, H, api.LAYOUT_I420, BPC, "cpu") for _ in range(N)]
+mine = dd.frames_of_rank(N, rank, world)
+for n, frame in enumerate(frames):
+    cur = pics[n]
+    if n in mine:
+        for pl in range(3):
+            cur.upload(pl, dst0[pl])
+        rlist = [pics[n - 1].view if (n and k == 0) else refs[k].view for k in range(3)]
+        prep = ctx.buffer(frame.prep_elems * 2); prep.zero()
+        coef = ctx.buffer_from(frame.coef)
+        ctx.mc_batch(cur.view, rlist, frame.mc, prep)
+        if len(frame.comp):
+            ctx.comp_batch(cur.view, frame.comp, prep, None)
+        ctx.itx_add_batch(cur.view, frame.itx, coef)
+        ctx.sync()
+    dd.broadcast_picture(cur, n %% world, world)
+if rank == 0:
+    oracle = util.default_oracle()
+    want_prev = None
+    for n, frame in enumerate(frames):
+        rl = [want_prev if (want_prev is not None and k == 0) else ref_host[k] for k in range(3)]
+        want, _, _ = test_frame.oracle_frame(oracle, frame, dst0, rl)
+        want_prev = want
+    got = [pics[N - 1].download(pl) for pl in range(3)]
+    print(json.dumps({"ok": bool(all(np.array_equal(got[pl], want[pl]) for pl in range(3))), "mine": mine}))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_frame_parallel_dependent_frames_world2_gloo(tmp_path):
+    """Frame-parallel sharding where every frame predicts from the previous one (decoded on the other rank): the owner
+    broadcasts the finished picture (dist.broadcast_picture), the chain of four frames equals the oracle's."""
+    import json
+    script = tmp_path / "dep.py"
+    script.write_text(DEP_WORKER % {"root": util.ROOT, "tests": os.path.join(util.ROOT, "tests")})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29527", str(script)],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["ok"] and d["mine"] == [0, 2], d
+
+
 def test_tile_column_split_covers_every_task_once():
     import numpy as np
     from dav1d_amd import dist as dd, synth
