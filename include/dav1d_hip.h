@@ -703,6 +703,33 @@ typedef struct Dav1dHipFilterDesc {
  * lister's frame.  Thread-safe; any order. */
 DAV1D_HIP_API int dav1d_hip_lister_filter_sbrow(Dav1dHipLister *l, const Dav1dHipFilterDesc *fd, int sby);
 
+/* ---- deblocking masks and levels from the hand-off arrays (what pass 1 builds with dav1d_create_lf_mask_intra / _inter,
+ * reference src/lf_mask.c:259-383, src/decode.c:1216-1226, 1882-1900, 1945-1956, 2730-2740), built on the device.
+ * dav1d_hip_lf_rects (host walk, host/lf_rects.c): one rectangle per transform block — a whole skipped inter block counts as
+ * one — in 4x4 units of its plane.  dav1d_hip_lf_masks_build (csrc/lfmask.hip): the rectangles painted into a cell map, the
+ * masks, noskip_mask, level cache and tile-edge contexts read off it; outputs have the reference's layouts, so they go
+ * straight into Dav1dHipFilterDesc / dav1d_hip_frame_set_filters. */
+enum { DAV1D_HIP_LF_RECT_LUMA = 0, DAV1D_HIP_LF_RECT_CHROMA = 1, DAV1D_HIP_LF_RECT_NOSKIP = 2 };
+typedef struct Dav1dHipLfRect {
+    uint16_t x4, y4;     /* position, 4x4 units of the rectangle's plane (NOSKIP: luma units) */
+    uint8_t  w4, h4;     /* size in the same units, clipped to the frame (NOSKIP: the unclipped block) */
+    uint8_t  cls;        /* bits 0-1: min(2, log2(width / 4)) (chroma: min(1, .)), bits 2-3: the same for the height,
+                            bit 4: the left side is an edge the filter visits, bit 5: the top side is */
+    uint8_t  kind;       /* DAV1D_HIP_LF_RECT_* */
+    uint8_t  lvl[2];     /* level cache entries [0], [1] (luma) / [2], [3] (chroma) of the covered cells */
+    uint8_t  pad[2];
+} Dav1dHipLfRect;
+/* lflvl = ts->lflvl (== f->lf.lvl without delta_lf): [segment][0 y-vert, 1 y-hor, 2 u, 3 v][reference + 1][mode is not GLOBALMV].
+ * *out is malloc'ed; release it with dav1d_hip_lf_rects_free. */
+DAV1D_HIP_API int dav1d_hip_lf_rects(const Dav1dHipFrameDesc *d, const uint8_t lflvl[8][4][8][2], Dav1dHipLfRect **out, size_t *n);
+DAV1D_HIP_API void dav1d_hip_lf_rects_free(Dav1dHipLfRect *p);
+/* masks_out: HOST, one Av1Filter per 128x128 (filter_y, filter_uv, noskip_mask written; cdef_idx zeroed: it comes from the
+ * bitstream).  level_dev: DEVICE level cache (uint8_t[4] per 4x4, pitch d->b4_stride).  right_edge[0 luma, 1 chroma]: HOST,
+ * == f->lf.tx_lpf_right_edge.  a_y / a_uv: HOST, 32 bytes per (tile row, sb128 column) == the tx_lpf_y / tx_lpf_uv members of
+ * the pass-1 above contexts (Dav1dHipFilterDesc.a_stride = 32). */
+DAV1D_HIP_API int dav1d_hip_lf_masks_build(Dav1dHipContext *c, const Dav1dHipFrameDesc *d, const Dav1dHipLfRect *rects, size_t n_rects,
+                                           Dav1dHipAv1Filter *masks_out, uint8_t *level_dev, uint8_t *right_edge[2], uint8_t *a_y, uint8_t *a_uv);
+
 /* Test aids (tests/test_host_tables.py pins the lister's derived AV1 geometry against the tables of the reference build). */
 DAV1D_HIP_API long dav1d_hip_lister_mask_offset(int which, int c, int bs, int sign, int idx);
 DAV1D_HIP_API void dav1d_hip_lister_tables(uint8_t *out);

@@ -284,6 +284,7 @@ void *dav1d_ref_frame_ptr(void *const h, const char *const name, size_t *const b
     else if (IS("jnt_weights")) { ptr = f->jnt_weights; n = sizeof(f->jnt_weights); }
     else if (IS("gmv")) { ptr = r->fh.gmv; n = sizeof(r->fh.gmv); }
     else if (IS("lf_mask")) { ptr = f->lf.mask; n = sizeof(*f->lf.mask) * num_sb128; }
+    else if (IS("lflvl")) { ptr = f->lf.lvl; n = sizeof(f->lf.lvl); }
     else if (IS("lf_level")) { ptr = f->lf.level; n = sizeof(*f->lf.level) * num_sb128 * 32 * 32; }
     else if (IS("lr_mask")) { ptr = f->lf.lr_mask; n = sizeof(*f->lf.lr_mask) * f->lf.lr_mask_sz; }
     else if (IS("lim_lut")) { ptr = &f->lf.lim_lut; n = sizeof(f->lf.lim_lut); }

@@ -110,6 +110,7 @@ static inline unsigned long long __ballot(int pred) {
 }
 static inline int atomicAdd(int *p, int v) { const int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned *p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
+static inline unsigned atomicOr(unsigned *p, unsigned v) { const unsigned o = *p; *p = o | v; return o; }
 static inline int __any(int pred) { return __ballot(pred) != 0; }
 static inline int __all(int pred) { return __ballot(!pred) == 0; }
 static inline int __builtin_amdgcn_readfirstlane(int v) {

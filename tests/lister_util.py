@@ -280,7 +280,7 @@ def fill_pictures(rf, seed):
                 a[...] = v.astype(a.dtype)
 
 
-def run_hip(ctx, rf, d, threads=1, with_filters=False):
+def run_hip(ctx, rf, d, threads=1, with_filters=False, own_masks=False):
     """lister -> frame API -> kernels; returns the reconstructed planes (visible area) and the lister handle stats"""
     n_pl = 1 if rf.layout == 0 else 3
     cur = ctx.picture(rf.w, rf.ht, rf.layout, rf.bpc)
@@ -330,10 +330,36 @@ def run_hip(ctx, rf, d, threads=1, with_filters=False):
     if with_filters:
         fd = rf.filter_desc()
         sbh = rf.sbh
+        keep = None
+        if own_masks:
+            # masks, noskip_mask, level cache and tile-edge contexts built by the product (dav1d_hip_lf_rects + _lf_masks_build)
+            # instead of taken from the reference's pass 1; cdef_idx comes from the bitstream, so it is carried over
+            lflvl = rf.array("lflvl", np.uint8)
+            rects_p, n = C.c_void_p(), C.c_size_t()
+            assert ctx.lib.dav1d_hip_lf_rects(C.byref(d), lflvl.ctypes.data, C.byref(rects_p), C.byref(n)) == 0
+            bw, bh = ((rf.w + 7) >> 3) << 1, ((rf.ht + 7) >> 3) << 1
+            sb128w, sb128h, align_h = (bw + 31) >> 5, (bh + 31) >> 5, (bh + 31) & ~31
+            ref_masks = rf.array("lf_mask", np.uint8).reshape(sb128w * sb128h, 1348)
+            masks = np.zeros((sb128w * sb128h, 1348), np.uint8)
+            lvl = ctx.buffer(sb128h * 32 * d.b4_stride * 4 + 64)
+            lvl.zero()
+            r_y, r_uv = np.zeros(align_h * d.n_tile_cols, np.uint8), np.zeros(align_h * d.n_tile_cols, np.uint8)
+            a_y, a_uv = np.zeros(d.n_tile_rows * sb128w * 32, np.uint8), np.zeros(d.n_tile_rows * sb128w * 32, np.uint8)
+            right = (C.c_void_p * 2)(r_y.ctypes.data, r_uv.ctypes.data)
+            rc4 = ctx.lib.dav1d_hip_lf_masks_build(ctx.h, C.byref(d), rects_p, n.value, masks.ctypes.data, lvl.ptr, right,
+                                                   a_y.ctypes.data, a_uv.ctypes.data)
+            ctx.lib.dav1d_hip_lf_rects_free(rects_p)
+            assert rc4 == 0, rc4
+            masks[:, 1280:1284] = ref_masks[:, 1280:1284]
+            fd.lf_mask = masks.ctypes.data
+            fd.tx_lpf_right_edge[0], fd.tx_lpf_right_edge[1] = r_y.ctypes.data, r_uv.ctypes.data
+            fd.a_tx_lpf_y, fd.a_tx_lpf_uv, fd.a_stride = a_y.ctypes.data, a_uv.ctypes.data, 32
+            keep = (masks, r_y, r_uv, a_y, a_uv)
         for sby in range(sbh):
             rc3 = ctx.lib.dav1d_hip_lister_filter_sbrow(lh, C.byref(fd), sby)
             assert rc3 == 0, "lister_filter_sbrow(%d): %d" % (sby, rc3)
-        lvl = ctx.buffer_from(rf.array("lf_level", np.uint8))
+        if not own_masks:
+            lvl = ctx.buffer_from(rf.array("lf_level", np.uint8))
         lut = rf.array("lim_lut", np.uint8)          # Av1FilterLUT: e[64], i[64], sharp[2]
         frame.set_filters(lvl, rf.b4_stride, lut[0:64], lut[64:128], rf.p.cdef_damping + rf.bpc - 8)
     filtered = frame.end(coef, prep, mask)

@@ -22,7 +22,7 @@ LR_BIG = dict(lr=([3, 1, 2], [8, 7]))
 ALL = dict(LF, **CDEF, **LR_SW)
 
 
-def run_case(ctx, w, h, layout, bpc, seed, filters, is_inter=True, tiles=(1, 1), sb128=True, **kw):
+def run_case(ctx, w, h, layout, bpc, seed, filters, is_inter=True, tiles=(1, 1), sb128=True, own_masks=False, **kw):
     rf = lu.RefFrame(w, h, layout, bpc, is_inter=is_inter, tile_cols=tiles[0], tile_rows=tiles[1], sb128=sb128, filters=filters)
     try:
         sp = lu.default_synth(seed, **kw)
@@ -34,7 +34,7 @@ def run_case(ctx, w, h, layout, bpc, seed, filters, is_inter=True, tiles=(1, 1),
         before = [rf.plane(0, pl).copy() for pl in range(n_pl)]
         rf.filter()
         assert any(not np.array_equal(before[pl], rf.plane(0, pl)) for pl in range(n_pl)), "the filters changed nothing: vacuous case"
-        got, _ = lu.run_hip(ctx, rf, d, 1, with_filters=True)
+        got, _ = lu.run_hip(ctx, rf, d, 1, with_filters=True, own_masks=own_masks)
         bad = lu.compare(rf, got)
         assert not bad, "filtered planes differ from dav1d_filter_sbrow: (plane, pixels, first y, x, want, got) %s" % bad
     finally:
@@ -79,3 +79,14 @@ def test_filters_1080p():
         run_case(ctx, 1920, 1080, 1, 10, 77, ALL, tiles=(4, 2))
     finally:
         ctx.close()
+
+
+OWN = [("all_tiles", 320, 200, 1, 10, ALL, dict(tiles=(2, 2))), ("deltas_444_tiles", 256, 136, 3, 10, dict(LF_DELTAS, **CDEF), dict(tiles=(2, 2))),
+       ("key_frame_sb64", 296, 168, 1, 8, ALL, dict(is_inter=False, sb128=False, tiles=(2, 2)))]
+
+
+@pytest.mark.parametrize("name,w,h,layout,bpc,filters,kw", OWN, ids=[c[0] for c in OWN])
+def test_filters_from_masks_the_product_built_itself(ctx, name, w, h, layout, bpc, filters, kw):
+    """The same chain with nothing of the reference's pass 1 but cdef_idx (which the bitstream carries): deblocking masks,
+    noskip_mask, level cache and the tile-edge contexts come from dav1d_hip_lf_rects + dav1d_hip_lf_masks_build."""
+    run_case(ctx, w, h, layout, bpc, 90 + [c[0] for c in OWN].index(name), filters, own_masks=True, **kw)
