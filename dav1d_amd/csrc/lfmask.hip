@@ -15,6 +15,8 @@
 // written and read about twice, 4 bytes of levels per cell written: ~15 MB for an 8K frame.
 #include "common.h"
 #include "capi.h"
+#include <string.h>
+#include <vector>
 
 namespace {
 
