@@ -642,6 +642,18 @@ def main():
                                             "parity": cj["config"]["parity"], "workload": cj["config"]["workload"]}
             except Exception as e:
                 out["config_c1_4k_8bit"] = {"error": str(e)[:200]}
+        # $DAV1D_STREAMS: real AV1 streams on the GPU box.  Decoding one needs dav1d's pass 1 (OBU parsing + entropy
+        # decoding), which stays in dav1d by design and is not built here; the hook reports what it found
+        sdir = os.environ.get("DAV1D_STREAMS")
+        if sdir:
+            import glob
+            import shutil
+            files = sorted(glob.glob(os.path.join(sdir, "**", "*.ivf"), recursive=True) + glob.glob(os.path.join(sdir, "**", "*.obu"), recursive=True))
+            out["streams"] = {"dir": sdir, "files": len(files), "dav1d_cli": shutil.which("dav1d"),
+                              "status": "not run: stream-level md5 / fps / argon need a dav1d build bound to libdav1d_hip (INTEGRATION.md); "
+                                        "this repository holds the pass-2 backend and its hand-off, not pass 1"}
+        else:
+            out["streams"] = {"status": "no $DAV1D_STREAMS supplied"}
         if packed_leg is not None:
             packed_leg.pop("_pictures", None)
             packed_leg.setdefault("parity", "skipped")
