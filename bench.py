@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (hand-off arrays -> lister -> device)")
     ap.add_argument("--e2e-tile-cols", type=int, default=16, help="tile columns of the end-to-end leg (one listing thread per tile)")
     ap.add_argument("--e2e-tile-rows", type=int, default=8, help="tile rows of the end-to-end leg")
+    ap.add_argument("--e2e-threads", type=int, default=32, help="listing threads of the end-to-end legs (0: one per tile); 32 measured best on the 256-thread host")
     ap.add_argument("--no-c1", action="store_true", help="skip the 4K 8-bit (BASELINE configs[1]) line that the default run appends")
     ap.add_argument("--no-full", action="store_true", help="skip the full-DSP-table leg (deblock, CDEF, restoration, film grain)")
     ap.add_argument("--two-phase", action="store_true",
@@ -606,10 +607,10 @@ def main():
                     return lu.check_handoff_against_reference(ho, planes, ref_pics, is_inter)
                 except AssertionError as e:
                     raise SystemExit("bench: end-to-end leg differs from the reference's pass 2: %s" % e)
-            e2e_leg = e2e.run(ctx, w, h, bpc, frames=6, threads=None, tile_cols=a.e2e_tile_cols, tile_rows=a.e2e_tile_rows,
+            e2e_leg = e2e.run(ctx, w, h, bpc, frames=6, threads=a.e2e_threads or None, tile_cols=a.e2e_tile_cols, tile_rows=a.e2e_tile_rows,
                               check=None if a.no_check else e2e_check)
             # the key-frame worst case (reference src/recon_tmpl.c:1239-1333, every block through the intra wavefront): same route
-            key_leg = e2e.run(ctx, w, h, bpc, frames=4, threads=None, tile_cols=a.e2e_tile_cols, tile_rows=a.e2e_tile_rows, key_frame=True, seed=0xE2F,
+            key_leg = e2e.run(ctx, w, h, bpc, frames=4, threads=a.e2e_threads or None, tile_cols=a.e2e_tile_cols, tile_rows=a.e2e_tile_rows, key_frame=True, seed=0xE2F,
                               check=None if a.no_check else (lambda ho, planes, refs: e2e_check(ho, planes, refs, is_inter=False)))
         label = "8K" if (w, h) == (7680, 4320) else "4K" if (w, h) == (3840, 2160) else "%dx%d" % (w, h)
         out = {"metric": "reconstructed luma Mpixels/s (%s 4:2:0 %d-bit) on the itx+mc recon path; bit-exact vs C" % (label, bpc),
