@@ -459,6 +459,22 @@ class FrameInFlight:
                                               C.byref(grain_out.pic) if grain_out is not None else None), "frame_end")
         return filtered
 
+    def end_async(self, coef, prep, mask=None, grain_out=None, done=None):
+        """dav1d_hip_frame_end_async: returns at once; done(rc) is called on the library's thread when the frame is final."""
+        cb_t = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
+        self._cb = cb_t((lambda cookie, rc, pic: done(rc)) if done else (lambda cookie, rc, pic: None))
+        _chk(self.ctx.lib.dav1d_hip_frame_end_async(self.h, coef.ptr if coef is not None else None, prep.ptr if prep is not None else None,
+                                                    mask.ptr if mask is not None else None,
+                                                    C.byref(grain_out.pic) if grain_out is not None else None, self._cb, None), "frame_end_async")
+
+    def progress(self):
+        return int(self.ctx.lib.dav1d_hip_frame_progress(self.h))
+
+    def wait(self):
+        filtered = Picture()
+        _chk(self.ctx.lib.dav1d_hip_frame_wait(self.h, C.byref(filtered)), "frame_wait")
+        return filtered
+
     def post_bands(self):
         """Bands the post filters of the last end() were pipelined over (0: stage by stage)."""
         return int(self.ctx.lib.dav1d_hip_frame_post_bands(self.h))

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <atomic>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <vector>
 
@@ -57,6 +58,10 @@ struct Dav1dHipFrame {
     Dav1dHipPicture tmp[2];          // CDEF output, restoration output (allocated on first use)
     bool have_tmp[2];
     int post_bands;                  // bands the post filters of the last dav1d_hip_frame_end ran in (0: stage by stage)
+    std::thread worker;              // dav1d_hip_frame_end_async
+    std::atomic<int> progress_rows;
+    int async_rc;
+    Dav1dHipPicture async_filtered;
 };
 
 static int frame_tmp(Dav1dHipFrame *f, int i) {
@@ -235,6 +240,9 @@ int dav1d_hip_frame_begin(Dav1dHipContext *c, Dav1dHipFrame **out, const Dav1dHi
     f->is_id = 0;
     f->have_tmp[0] = f->have_tmp[1] = false;
     f->post_bands = 0;
+    f->progress_rows.store(0);
+    f->async_rc = 0;
+    memset(&f->async_filtered, 0, sizeof(f->async_filtered));
     // a chunk arena sized for the largest frame this context has seen (grown at frame end when it turns out too small)
     f->arena = nullptr; f->arena_cap = 0; f->arena_used = 0;
     {
@@ -572,8 +580,42 @@ extern "C" {
 
 int dav1d_hip_frame_post_bands(const Dav1dHipFrame *f) { return f ? f->post_bands : 0; }
 
+// ---- asynchronous frame end + progress (reference src/thread_task.c:888-896 publishes f->sr_cur.progress[1] when a frame's
+// rows are final; :393-439 check_tile waits on it).  The stages of a frame run over the WHOLE picture one after the other here, so
+// rows become final together: progress is 0 until the frame is through and the picture height afterwards.  What the calling
+// thread gets is that it does not have to wait: dav1d_hip_frame_end_async hands the blocking dav1d_hip_frame_end to a thread of
+// the library and returns; the callback (optional) runs on that thread when the frame is final — the place to store
+// progress[1] and wake the dependent frames' tasks.
+int dav1d_hip_frame_end_async(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask, const Dav1dHipPicture *grain_out,
+                              void (*done)(void *cookie, int rc, const Dav1dHipPicture *filtered), void *cookie) {
+    if (!f) return -EINVAL;
+    if (f->worker.joinable()) return -EBUSY;
+    f->async_rc = 1;                                  // running
+    f->progress_rows.store(0);
+    const Dav1dHipPicture g = grain_out ? *grain_out : Dav1dHipPicture();
+    const bool have_g = grain_out != nullptr;
+    f->worker = std::thread([f, coef, prep, mask, g, have_g, done, cookie]() {
+        (void) hipSetDevice(f->c->device);
+        const int rc = dav1d_hip_frame_end(f, coef, prep, mask, &f->async_filtered, have_g ? &g : nullptr);
+        f->async_rc = rc;
+        if (!rc) f->progress_rows.store(f->cur.p[0].h);
+        if (done) done(cookie, rc, &f->async_filtered);
+    });
+    return 0;
+}
+// rows of the picture that are final (all in-loop filters applied): 0 or the picture height
+int dav1d_hip_frame_progress(const Dav1dHipFrame *f) { return f ? f->progress_rows.load() : -EINVAL; }
+// waits for the frame handed to dav1d_hip_frame_end_async; returns its result, *filtered as dav1d_hip_frame_end
+int dav1d_hip_frame_wait(Dav1dHipFrame *f, Dav1dHipPicture *filtered) {
+    if (!f) return -EINVAL;
+    if (f->worker.joinable()) f->worker.join();
+    if (filtered) *filtered = f->async_filtered;
+    return f->async_rc == 1 ? -EINVAL : f->async_rc;
+}
+
 void dav1d_hip_frame_destroy(Dav1dHipFrame *f) {
     if (!f) return;
+    if (f->worker.joinable()) f->worker.join();
     (void) hipStreamSynchronize(f->c->stream);
     if (f->prepared) dav1d_hip_fg_grain_destroy(f->c, f->prepared);
     (void) hipStreamSynchronize(f->c->copy_stream);

@@ -587,6 +587,14 @@ DAV1D_HIP_API int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *pre
  * reference's filter_sbrow_* ordering, src/thread_task.c:783-851), or 0 when they ran stage by stage (small frames, units
  * not covering the frame, or DAV1D_HIP_POST_BANDS unset: the banded mode is an opt-in experiment, see frame.hip). */
 DAV1D_HIP_API int dav1d_hip_frame_post_bands(const Dav1dHipFrame *f);
+/* The same without blocking the caller: the frame runs on a thread of the library; `done` (optional) is called on that thread
+ * when every row of the frame is final — where a dav1d build stores f->sr_cur.progress[1] and signals the task threads
+ * (reference src/thread_task.c:888-896; :393-439 is the waiting side).  dav1d_hip_frame_progress: rows that are final (the
+ * stages run over whole pictures, so this is 0 or the picture height); dav1d_hip_frame_wait joins and returns the result. */
+DAV1D_HIP_API int dav1d_hip_frame_end_async(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask, const Dav1dHipPicture *grain_out,
+                                            void (*done)(void *cookie, int rc, const Dav1dHipPicture *filtered), void *cookie);
+DAV1D_HIP_API int dav1d_hip_frame_progress(const Dav1dHipFrame *f);
+DAV1D_HIP_API int dav1d_hip_frame_wait(Dav1dHipFrame *f, Dav1dHipPicture *filtered);
 DAV1D_HIP_API void dav1d_hip_frame_destroy(Dav1dHipFrame *f);
 
 /* ------------------------------------------------------------- pass-2 lister */

@@ -13,9 +13,13 @@ import test_postchain
 
 
 @pytest.mark.parametrize("bpc", [8, 10, 12])
-@pytest.mark.parametrize("bands", [8, 0], ids=["banded", "staged"])
+@pytest.mark.parametrize("bands", [8, 0, -1], ids=["banded", "staged", "staged-async-end"])
 def test_frame_in_flight_matches_oracle(ctx, bpc, bands, monkeypatch):
-    """bands: the post filters pipelined over superblock-row bands (three streams) / one stage after the other."""
+    """bands: the post filters pipelined over superblock-row bands (three streams) / one stage after the other; -1: the latter
+    through dav1d_hip_frame_end_async (the frame runs on a thread of the library, completion arrives through the callback and
+    dav1d_hip_frame_progress — the hook for dav1d's progress publication, src/thread_task.c:888-896)."""
+    async_end = bands < 0
+    bands = max(bands, 0)
     monkeypatch.setenv("DAV1D_HIP_POST_BANDS", str(bands))
     oracle = util.default_oracle()
     w, h = (64, 768) if ctx.backend == "emu" else (1024, 1152)
@@ -73,7 +77,14 @@ def test_frame_in_flight_matches_oracle(ctx, bpc, bands, monkeypatch):
         f.submit_intra_step(k, pt, it)
     # loop restoration units must keep raster order: one submission per plane and stripe row
     f.submit_filter_sbrow(post.lf, post.cdef, post.lr)
-    filtered = f.end(coef, prep, None, grain)
+    if async_end:
+        seen = []
+        assert f.progress() == 0
+        f.end_async(coef, prep, None, grain, done=lambda rc: seen.append((rc, f.progress())))
+        filtered = f.wait()
+        assert seen == [(0, h)] and f.progress() == h, seen
+    else:
+        filtered = f.end(coef, prep, None, grain)
     assert f.post_bands() == (min(bands, (h + 255) // 256) if bands else 0)
     out = api.DevicePicture.view(ctx, filtered, w, h, api.LAYOUT_I420, bpc)
     for pl in range(3):
