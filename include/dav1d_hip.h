@@ -738,6 +738,21 @@ DAV1D_HIP_API void dav1d_hip_lf_rects_free(Dav1dHipLfRect *p);
 DAV1D_HIP_API int dav1d_hip_lf_masks_build(Dav1dHipContext *c, const Dav1dHipFrameDesc *d, const Dav1dHipLfRect *rects, size_t n_rects,
                                            Dav1dHipAv1Filter *masks_out, uint8_t *level_dev, uint8_t *right_edge[2], uint8_t *a_y, uint8_t *a_uv);
 
+/* ---- the data-parallel members of Dav1dRefmvsDSPContext (reference src/refmvs.c:763-803 save_tmvs, :914-923 splat_mv) on a
+ * frame-level map of refmvs_block records in DEVICE memory: r[y4 * stride4 + x4], 12 bytes each ({ mv[2] (y, x int16 each),
+ * int8 ref[2], bs, mf }), instead of the reference's ring of rows. */
+typedef struct Dav1dHipSplatTask {
+    uint16_t bx4, by4;       /* block position, 4x4 units */
+    uint8_t  bw4, bh4;       /* size, 4x4 units (clipped to the frame by the caller, as decode_b does) */
+    uint8_t  pad[2];
+    uint32_t rmv[3];         /* the refmvs_block to splat, as its 12 bytes */
+} Dav1dHipSplatTask;
+DAV1D_HIP_API int dav1d_hip_refmvs_splat_batch(Dav1dHipContext *c, void *r_dev, ptrdiff_t stride4, const Dav1dHipSplatTask *tasks, size_t n);
+/* rp_dev: refmvs_temporal_block records (5 bytes: mv, ref), rp_stride per 8x8 row; ref_sign and the rectangle as the reference's
+ * save_tmvs arguments (8x8 units). */
+DAV1D_HIP_API int dav1d_hip_refmvs_save_tmvs(Dav1dHipContext *c, void *rp_dev, ptrdiff_t rp_stride, const void *r_dev, ptrdiff_t stride4,
+                                             const uint8_t ref_sign[7], int col_start8, int col_end8, int row_start8, int row_end8);
+
 /* Test aids (tests/test_host_tables.py pins the lister's derived AV1 geometry against the tables of the reference build). */
 DAV1D_HIP_API long dav1d_hip_lister_mask_offset(int which, int c, int bs, int sign, int idx);
 DAV1D_HIP_API void dav1d_hip_lister_tables(uint8_t *out);

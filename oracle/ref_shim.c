@@ -164,3 +164,17 @@ int dav1d_ref_generate_grain(const int bpc, const Dav1dFilmGrainData *const data
     }
     return 0;
 }
+
+/* Dav1dRefmvsDSPContext of the reference build (C path): save_tmvs and splat_mv through thin calls */
+#include "src/refmvs.h"
+void dav1d_ref_refmvs_splat(refmvs_block **rr, const refmvs_block *rmv, int bx4, int bw4, int bh4) {
+    Dav1dRefmvsDSPContext c;
+    dav1d_refmvs_dsp_init(&c);
+    c.splat_mv(rr, rmv, bx4, bw4, bh4);
+}
+void dav1d_ref_refmvs_save_tmvs(refmvs_temporal_block *rp, ptrdiff_t stride, refmvs_block *const *rr, const uint8_t *ref_sign,
+                                int col_end8, int row_end8, int col_start8, int row_start8) {
+    Dav1dRefmvsDSPContext c;
+    dav1d_refmvs_dsp_init(&c);
+    c.save_tmvs(rp, stride, rr, ref_sign, col_end8, row_end8, col_start8, row_start8);
+}
