@@ -22,7 +22,7 @@ struct Dav1dHipContext {
     bool concurrent;
     int flow_min_steps;         // wavefronts of at least this many steps run as one dataflow launch ($DAV1D_HIP_FLOW_MIN_STEPS, 0 = never)
     int flow_mode;              // $DAV1D_HIP_FLOW_MODE at open: hand-off variant of the intra dataflow launch (intra_flow.hip)
-    int flow_groups;            // workgroups of the intra dataflow launch ($DAV1D_HIP_FLOW_GROUPS at open, default 256 = one per CU: more waves mostly poll)
+    int flow_groups;            // workgroups of the intra dataflow launch ($DAV1D_HIP_FLOW_GROUPS at open, default 512; every wave has to be resident: units are dealt out round-robin)
     bool cdef_unit_kernel;      // $DAV1D_HIP_CDEF_UNIT=1 at open: one wave per 8x8 unit (the round-1 kernel) instead of strips; A/B aid
     // measurement aid: device time of the kernel launches of the most recent *_batch call (dav1d_hip_last_kernel_ms)
     hipEvent_t ev_t0, ev_t1;
@@ -149,20 +149,23 @@ extern "C" int dav1d_hip_launch_comp(const DevPlanes *dst, int bpc, const Dav1dH
 // One unit of the intra dataflow launch (intra_flow.hip): prediction and / or residual of one transform block, records included
 // so that a wave has everything about a unit after ONE scalar fetch.
 struct IntraUnit {
-    uint32_t need;              // units that have to be finished before this one starts (= units in earlier steps)
+    uint32_t need;              // host side: units in earlier groups (a group = the units of one step that may run together);
+                                // equal values mark a group.  The device copy also carries what the waves use:
     uint32_t has;               // bit 0: p holds a prediction, bit 1: t holds a residual
-    uint32_t pad[2];
+    uint32_t grp;               // dense index of the unit's group
+    uint32_t prev_n;            // units in the group before it (0 for the first): that many completions open this group
     Dav1dHipIpredTask p;
     Dav1dHipItxTask t;
     uint32_t pad2;
 };
 static_assert(sizeof(IntraUnit) == 80, "unit record layout");
+enum { FLOW_SUB = 8, FLOW_SUB_STRIDE = 32 };       // completion counters per group, words between them (a 128-byte line each)
 extern "C" int dav1d_hip_launch_intra_flow(const DevPlanes *dst, int bpc, int layout, const IntraUnit *units, int n_units, uint8_t *aux,
-                                           void *coef, uint32_t *ctr, int max_groups, int mode, void *stream);
+                                           void *coef, uint32_t *ctr, int n_waves, int mode, void *stream);
 struct Dav1dHipIntraFlow;
 extern "C" int dav1d_hip_intra_units_build(const Dav1dHipIpredTask *preds, const uint32_t *pred_end, const Dav1dHipItxTask *txs, const uint32_t *tx_end,
                                 size_t n_steps, std::vector<IntraUnit> &units, std::vector<uint32_t> &ua_end, std::vector<uint32_t> &ub_end);
-extern "C" int dav1d_hip_intra_flow_from_units(Dav1dHipContext *c, Dav1dHipIntraFlow **out, const IntraUnit *units, size_t n);
+extern "C" int dav1d_hip_intra_flow_from_units(Dav1dHipContext *c, Dav1dHipIntraFlow **out, IntraUnit *units, size_t n);
 // batches (wavefront steps) of predictions + residuals -> device-resident unit list; -ENOTSUP when the list holds a task
 // kind the dataflow launch does not run (PRED_TMP for inter-intra, DSP-level kinds): the caller keeps the stepped route
 extern "C" int dav1d_hip_intra_flow_create(Dav1dHipContext *c, Dav1dHipIntraFlow **out, const Dav1dHipIpredTask *preds, const size_t *pred_sizes,

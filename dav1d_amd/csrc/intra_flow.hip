@@ -9,19 +9,22 @@
 //
 // Here the whole pass is a list of UNITS sorted by step, one unit = prediction + residual of one transform block (or only
 // one of the two), worked off by a grid of one-wave workgroups inside a single launch:
-//   * a wave draws the next unit with an atomic ticket, loads its task records, and waits until `done` (the count of
-//     finished units) has reached the unit's `need` = the number of units in earlier steps.  Tickets are handed out in
-//     list order, so a waiting wave only ever waits for units held by waves that are already running: no residency
-//     requirement, no deadlock, and a grid of any size works;
+//   * the units are dealt to the waves round-robin (wave w works on units w, w + G, w + 2 G, ...; every wave of the launch has to
+//     be resident, which the launch function guarantees by sizing the grid from the occupancy query), and a unit starts once
+//     the group before it — the units of the previous step — has finished: every group has eight completion counters in
+//     cache lines of their own, a finishing wave bumps one of them, a waiting wave sums the eight.  One shared "done" word and
+//     one shared ticket word, as the first version had, cap the launch at what ONE address takes in atomics (about 25 ns
+//     each: 37 ms for the 615 K units of an 8K key frame, whatever the number of waves);
 //   * the prediction goes to an LDS tile, the residual is added from there (ipred_body.h + itx_body.h, the bodies of the
-//     stand-alone kernels), the pixels leave with agent-scope stores, and once those are acknowledged the wave bumps
-//     `done`.  Edge pixels are read with agent-scope loads: per-XCD L2s and per-CU L1s are not coherent for plain accesses
+//     stand-alone kernels), the pixels leave with agent-scope stores, and once those are acknowledged the wave bumps its
+//     counter.  Edge pixels are read with agent-scope loads: per-XCD L2s and per-CU L1s are not coherent for plain accesses
 //     within a launch (MI355X_MICROARCH.md, "inter-workgroup visibility").
 // A step boundary then costs a counter hand-off (about a microsecond) instead of a kernel boundary plus the fill and drain
 // of a small grid.
 #include "ipred_body.h"
 #include "itx_body.h"
 #include "capi.h"
+#include <type_traits>
 
 namespace {
 
@@ -30,13 +33,12 @@ constexpr int flow_itx_lds_of(int tx) {
 }
 constexpr int flow_itx_lds_max(int tx = 0) { return tx == 19 ? 0 : cmax(flow_itx_lds_of(tx), flow_itx_lds_max(tx + 1)); }
 
-enum { FLOW_TICKET = 0, FLOW_DONE = 32, FLOW_ERROR = 64 };   // == capi.hip
-enum { FLOW_SPIN_LIMIT = 1 << 20 };       // polls before a wave gives up and raises ctr[2] (a bug, never a normal run)
+enum { FLOW_SPIN_LIMIT = 1 << 20 };       // polls before a wave gives up and raises the error word (a bug, never a normal run)
 
 template <typename pixel, typename coef>
 __global__ __launch_bounds__(64, 4) void intra_flow_kernel(const DevPlanes dst, const IntraUnit *__restrict__ units, const int n_units,
                                                            uint8_t *aux, coef *__restrict__ cf, const int layout, const int bitdepth_max,
-                                                           uint32_t *ctr /* words 0 / 32 / 64 (lines of their own): next ticket, done, error */,
+                                                           uint32_t *ctr /* word 0: error; from word 32: FLOW_SUB counters per group */,
                                                            const int mode)
 {
     __shared__ int16_t e1[ESZ], e2[ESZ];
@@ -48,40 +50,32 @@ __global__ __launch_bounds__(64, 4) void intra_flow_kernel(const DevPlanes dst, 
     pixel *const tile = reinterpret_cast<pixel *>(smem);
     int *const smem_itx = reinterpret_cast<int *>(smem);
     const int lane = threadIdx.x;
+    const int wave = blockIdx.x, n_waves = gridDim.x;
+    uint32_t *const cnt = ctr + 32;
 
-    // The next ticket is drawn when the unit's last stores are on their way, so that the round trip of the draw hides behind
-    // the wait for their acknowledgement; drawing earlier would park a unit behind a busy wave while other waves idle
-    // (measured on an 8K key frame: 94 ms against 77).
-    auto draw = [&]() {
-        int t = 0;
-        if (lane == 0) t = (int) atomicAdd(&ctr[FLOW_TICKET], 1u);
-        return t;                       // lane 0's value; readfirstlane where it is used
-    };
-    int ticket = __builtin_amdgcn_readfirstlane(draw());
-    while (ticket < n_units) {
-        const IntraUnit *const up = units + ticket;
+    for (int ui = wave; ui < n_units; ui += n_waves) {
+        const IntraUnit *const up = units + ui;
         const IntraUnit u = *up;
+        if (ui + n_waves < n_units) dv::touch(units + ui + n_waves);            // the wave's next record, on its way
         const bool has_pred = u.has & 1, has_tx = u.has & 2;
         if (has_tx) {
             // ... and the first lines of this unit's coefficients
             const int nb = ((int) u.t.rsv[0] | (int) u.t.rsv[1] << 8) * (int) sizeof(coef);
             if (lane * 64 < nb) dv::touch(reinterpret_cast<const char *>(cf + u.t.cf_off) + lane * 64);
         }
-        if (u.need) {
-            // mode bit 0: poll through the atomic unit; bit 1: agent-scope fences around the hand-off as well
+        if (u.prev_n) {
+            // the group before this one is through when its counters add up to its size (mode bit 1: fences as well; A/B aid)
+            const uint32_t *const prev = cnt + (size_t) (u.grp - 1) * (FLOW_SUB * FLOW_SUB_STRIDE);
             int spins = 0;
             for (;;) {
-                unsigned v = 0;
-                if (mode & 1) v = (unsigned) __builtin_amdgcn_readfirstlane((int) dv::ld_rmw(&ctr[FLOW_DONE]));
-                else v = dv::ld_coherent(&ctr[FLOW_DONE]);
-                if (v >= u.need) break;
-                // a wave that is steps ahead of the front leaves the counter's line alone for a while: thousands of waves polling
-                // one word slow every hand-off down (measured: 52 us per step on an 8K key frame with 2048 pollers, 22 with 256)
-                const unsigned gap = u.need - v;
-                if (gap > 1024) dv::nap_long();
-                if (gap > 128) dv::nap_long();
+                unsigned v = lane < FLOW_SUB ? dv::ld_coherent(prev + lane * FLOW_SUB_STRIDE) : 0u;
+#pragma unroll
+                for (int m = 1; m < FLOW_SUB; m <<= 1) v += (unsigned) __shfl_xor((int) v, m);
+                v = (unsigned) __builtin_amdgcn_readfirstlane((int) v);
+                if (v >= u.prev_n) break;
+                if (2 * v < u.prev_n) dv::nap_long();           // far from done: leave the lines alone for a while
                 dv::nap();
-                if (++spins > FLOW_SPIN_LIMIT) { if (lane == 0) atomicAdd(&ctr[FLOW_ERROR], 1u); break; }
+                if (++spins > FLOW_SPIN_LIMIT) { if (lane == 0) atomicAdd(&ctr[0], 1u); break; }
             }
             if (mode & 2) dv::fence_acquire_agent();
         }
@@ -104,32 +98,49 @@ __global__ __launch_bounds__(64, 4) void intra_flow_kernel(const DevPlanes dst, 
                 CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18)
             }
 #undef CASE
-        } else {
-            for (int i = lane; i < w * h; i += 64) dv::st_coherent(d + (i / w) * stride + (i % w), tile[i]);
         }
-        const int next_raw = draw();
+        dv::wave_sync();
+        // the reconstructed tile leaves the LDS four pixels per store (blocks are at least four pixels wide and four-pixel aligned)
+        {
+            typedef typename std::conditional<sizeof(pixel) == 2, uint64_t, uint32_t>::type quad;
+            const int wq = w >> 2;
+            for (int i = lane; i < wq * h; i += 64) {
+                const int y = i / wq, x = (i - y * wq) * 4;
+                dv::st_coherent(reinterpret_cast<quad *>(d + y * stride + x), *reinterpret_cast<const quad *>(tile + y * w + x));
+            }
+        }
         dv::stores_done();
         if (mode & 2) dv::fence_release_agent();
-        const int next_ticket = __builtin_amdgcn_readfirstlane(next_raw);
-        dv::touch(units + (next_ticket < n_units ? next_ticket : n_units));            // the next record, on its way
         dv::wave_sync();                 // the LDS is free for the next unit
-        if (lane == 0) atomicAdd(&ctr[FLOW_DONE], 1u);
-        // a convergence point between this lane-0 region and the next one (the ticket draw at the top of the loop): without it
-        // the compiler threads lane 0 from here straight into that region and the wave falls apart (observed: the kernel of the
-        // first version never ended)
+        if (lane == 0) atomicAdd(cnt + ((size_t) u.grp * FLOW_SUB + (wave & (FLOW_SUB - 1))) * FLOW_SUB_STRIDE, 1u);
+        // a convergence point after the lane-0 region (the first version of this kernel, with a lane-0 ticket draw at the top of
+        // the loop, was threaded by the compiler from one such region into the next and never ended)
         dv::wave_sync();
-        ticket = next_ticket;
     }
 }
 
 } // namespace
 
 extern "C" int dav1d_hip_launch_intra_flow(const DevPlanes *dst, int bpc, int layout, const IntraUnit *units, int n_units, uint8_t *aux,
-                                           void *coef, uint32_t *ctr, int max_groups, int mode, void *stream)
+                                           void *coef, uint32_t *ctr, int n_waves, int mode, void *stream)
 {
     if (n_units <= 0) return 0;
     const int bitdepth_max = (1 << bpc) - 1;
-    const int grid = n_units < max_groups ? n_units : max_groups;
+    // every wave of the grid has to be resident (units are dealt round-robin, a unit waits for units other waves hold): never
+    // more waves than the device runs at once for this kernel
+    int grid = n_units < n_waves ? n_units : n_waves;
+#ifdef DAV1D_HIP_EMU
+    grid = 1;                               // the emulator runs workgroups one after the other
+#else
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    const void *fn = bpc == 8 ? (const void *) intra_flow_kernel<uint8_t, int16_t> : (const void *) intra_flow_kernel<uint16_t, int32_t>;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0) != hipSuccess || per_cu < 1) return -EIO;
+    // one block per CU less than the query says (MI355X_MICROARCH.md: the API over-reports by one near SGPR limits)
+    const int cap = prop.multiProcessorCount * (per_cu > 1 ? per_cu - 1 : 1);
+    if (grid > cap) grid = cap;
+#endif
     if (bpc == 8)
         hipLaunchKernelGGL((intra_flow_kernel<uint8_t, int16_t>), dim3(grid), dim3(64), 0, (hipStream_t) stream, *dst, units, n_units, aux,
                            (int16_t *) coef, layout, bitdepth_max, ctr, mode);

@@ -73,12 +73,6 @@ __device__ __forceinline__ void tx1d(const int kind, const int *in, const int lo
     }
 }
 
-template <bool COH, typename pixel>
-__device__ __forceinline__ void put_px(pixel *p, const pixel v) {
-    if (COH) dv::st_coherent(p, v);
-    else *p = v;
-}
-
 // LDS ints one wave needs for transform size TX (all of its blocks)
 template <int TX>
 constexpr int itx_lds_ints() {
@@ -89,7 +83,7 @@ constexpr int itx_lds_ints() {
 // The wave `group` of the blocks of ONE transform size: blocks [group * BPW, group * BPW + BPW) of tasks[0 .. n).
 // PRED_LDS (fused prediction + residual kernels): the pixels the residual is added to come from pred_s (block `sub` of the
 // wave, W x H, row stride W) instead of the picture; the sum still goes to the picture.
-// COH: the result is read by other workgroups of the SAME launch (intra_flow.hip): coherent stores.
+// COH (with PRED_LDS): the result goes back to the LDS tile instead of the picture; the caller (intra_flow.hip) writes it out.
 template <int TX, typename pixel, typename coef, bool PRED_LDS = false, bool COH = false>
 __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItxTask *__restrict__ tasks,
                                          const int n, coef *__restrict__ cf, const int bitdepth_max, const int group, int *tmp_s,
@@ -237,7 +231,17 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
     }
     dv::wave_sync();
 
-    // ---- second pass: lane c = column c, H-point transform along y, add to dst
+    // ---- second pass: lane c = column c, H-point transform along y, add to dst.  COH: the sums go back to the LDS tile the
+    // prediction came from (the caller writes it out with wide coherent stores); the tile shares its memory with tmp, so every
+    // lane has its column of tmp in registers before the first lane writes
+    int cin[H];
+    if (live && l < W && !dconly) {
+#pragma unroll
+        for (int y = 0; y < H; y++) cin[y] = y < SH ? tmp[y * TS + l] : 0;
+    }
+    if (COH) dv::wave_sync();
+    pixel *const o = COH ? const_cast<pixel *>(pred_s) + sub * H * W + l : d;
+    const int ostride = COH ? W : stride;
     if (live && l < W) {
         if (dconly) {
             if (RECT2) dc = (dc * 181 + 128) >> 8;
@@ -246,26 +250,24 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
             dc = (dc * 181 + 128 + 2048) >> 12;
 #pragma unroll
             for (int y = 0; y < H; y++)
-                put_px<COH>(d + y * stride, (pixel) dv::iclip((int) dpx[y] + dc, 0, bitdepth_max));
+                o[y * ostride] = ((pixel) dv::iclip((int) dpx[y] + dc, 0, bitdepth_max));
         } else {
-            int cin[H], out[H];
-#pragma unroll
-            for (int y = 0; y < H; y++) cin[y] = y < SH ? tmp[y * TS + l] : 0;
+            int out[H];
             if (TX == 0 && wht) {
                 if constexpr (H == 4) itx1d::iwht4(cin, out);
 #pragma unroll
                 for (int y = 0; y < H; y++)
-                    put_px<COH>(d + y * stride, (pixel) dv::iclip((int) dpx[y] + out[y], 0, bitdepth_max));
+                    o[y * ostride] = ((pixel) dv::iclip((int) dpx[y] + out[y], 0, bitdepth_max));
             } else {
                 tx1d<H>(k2, cin, col_min, col_max, [&](const int *res) {
                     if (k2 == K_FLIPADST) {
 #pragma unroll
                         for (int y = 0; y < H; y++)
-                            put_px<COH>(d + y * stride, (pixel) dv::iclip((int) dpx[y] + ((res[H - 1 - y] + 8) >> 4), 0, bitdepth_max));
+                            o[y * ostride] = ((pixel) dv::iclip((int) dpx[y] + ((res[H - 1 - y] + 8) >> 4), 0, bitdepth_max));
                     } else {
 #pragma unroll
                         for (int y = 0; y < H; y++)
-                            put_px<COH>(d + y * stride, (pixel) dv::iclip((int) dpx[y] + ((res[y] + 8) >> 4), 0, bitdepth_max));
+                            o[y * ostride] = ((pixel) dv::iclip((int) dpx[y] + ((res[y] + 8) >> 4), 0, bitdepth_max));
                     }
                 });
             }
