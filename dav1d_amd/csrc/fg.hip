@@ -277,36 +277,63 @@ __global__ __launch_bounds__(64) void fg_apply_kernel(const DevPlanes dst, const
     for (int i = lane * 16; i < scaling_size; i += 64 * 16) *reinterpret_cast<uint4 *>(sc_s + i) = *reinterpret_cast<const uint4 *>(sc + i);
     dv::wave_sync();
 
-    // lane = (column, row group): 2 rows of 32 or 4 rows of 16 pixels per pass, four passes in flight so that the
-    // source (and luma) loads of 4 pixels per lane are issued before the first is needed
-    const int lg = sx ? 4 : 5, rpp = 64 >> lg;
-    const int x = lane & (bstep - 1), yl = lane >> lg;
+    // lane = (group of four columns, row): 8 rows of 32 or 16 rows of 16 pixels per pass; a lane fetches its four source pixels
+    // (and, for chroma, the eight luma pixels under them) with one load each and stores four pixels at once — round 1 moved one
+    // pixel per lane and instruction (0.16 ms per 8K frame, latency-bound)
+    const int qpr = bstep >> 2, rpp = 64 / qpr;        // lanes per row, rows per pass
+    const int x0 = (lane % qpr) * 4, yl = lane / qpr;
     const int ss = src.stride[pl], ds = dst.stride[pl], ls = src.stride[0];
-    const int wxa = sx ? 23 : (x == 0 ? 27 : 17), wxb = sx ? 22 : (x == 0 ? 17 : 27);
-    for (int yb = 0; yb < bh; yb += 4 * rpp) {
-        int s0[4], lum[4];
+    constexpr bool HBD = sizeof(pixel) == 2;
+    for (int yb = 0; yb < bh; yb += rpp) {
+        const int y = yb + yl;
+        if (y >= bh || x0 >= bw) continue;
+        const bool whole = x0 + 4 <= bw;
+        int s0[4], lum[4] = { 0, 0, 0, 0 };
+        const pixel *srow = sp + (y0 + y) * ss + bx + x0;
+        if (whole) {
+            if (HBD) { const uint2 v = *reinterpret_cast<const uint2 *>(srow); s0[0] = v.x & 0xffff; s0[1] = v.x >> 16; s0[2] = v.y & 0xffff; s0[3] = v.y >> 16; }
+            else { const uint32_t v = *reinterpret_cast<const uint32_t *>(srow); s0[0] = v & 0xff; s0[1] = v >> 8 & 0xff; s0[2] = v >> 16 & 0xff; s0[3] = v >> 24; }
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int y = yb + j * rpp + yl;
-            const bool in = x < bw && y < bh;
-            s0[j] = in ? (int) sp[(y0 + y) * ss + bx + x] : 0;
-            lum[j] = 0;
-            if (pl && in) {
-                // luma co-located average; the reference extends the luma row by one pixel for odd widths
-                // (src/fg_apply_tmpl.c:193-199)
-                const int lx = (bx + x) << sx, ly = (prow * 32) + (y << sy);
-                const pixel *lrow = lp + ly * ls;
-                int avg = lrow[dv::imin(lx, src.w[0] - 1)];
-                if (sx) avg = (avg + lrow[dv::imin(lx + 1, src.w[0] - 1)] + 1) >> 1;
-                lum[j] = avg;
+            for (int k = 0; k < 4; k++) s0[k] = x0 + k < bw ? (int) srow[k] : 0;
+        }
+        if (pl) {
+            // luma co-located average; the reference extends the luma row by one pixel for odd widths (src/fg_apply_tmpl.c:193-199)
+            const int lx = (bx + x0) << sx, ly = (prow * 32) + (y << sy);
+            const pixel *lrow = lp + ly * ls;
+            if (whole && lx + (4 << sx) <= src.w[0]) {
+                int l8[8];
+                if (HBD) {
+                    const uint2 a = *reinterpret_cast<const uint2 *>(lrow + lx);
+                    l8[0] = a.x & 0xffff; l8[1] = a.x >> 16; l8[2] = a.y & 0xffff; l8[3] = a.y >> 16;
+                    if (sx) { const uint2 b = *reinterpret_cast<const uint2 *>(lrow + lx + 4); l8[4] = b.x & 0xffff; l8[5] = b.x >> 16; l8[6] = b.y & 0xffff; l8[7] = b.y >> 16; }
+                } else {
+                    const uint32_t a = *reinterpret_cast<const uint32_t *>(lrow + lx);
+                    l8[0] = a & 0xff; l8[1] = a >> 8 & 0xff; l8[2] = a >> 16 & 0xff; l8[3] = a >> 24;
+                    if (sx) { const uint32_t b = *reinterpret_cast<const uint32_t *>(lrow + lx + 4); l8[4] = b & 0xff; l8[5] = b >> 8 & 0xff; l8[6] = b >> 16 & 0xff; l8[7] = b >> 24; }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) lum[k] = sx ? (l8[2 * k] + l8[2 * k + 1] + 1) >> 1 : l8[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (x0 + k >= bw) continue;
+                    const int lxk = (bx + x0 + k) << sx;
+                    int avg = lrow[dv::imin(lxk, src.w[0] - 1)];
+                    if (sx) avg = (avg + lrow[dv::imin(lxk + 1, src.w[0] - 1)] + 1) >> 1;
+                    lum[k] = avg;
+                }
             }
         }
+        int res[4];
+        const int wya = sy ? 23 : (y == 0 ? 27 : 17), wyb = sy ? 22 : (y == 0 ? 17 : 27);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int y = yb + j * rpp + yl;
-            if (!(x < bw && y < bh)) continue;
+        for (int k = 0; k < 4; k++) {
+            const int x = x0 + k;
+            res[k] = 0;
+            if (x >= bw) continue;
+            const int wxa = sx ? 23 : (x == 0 ? 27 : 17), wxb = sx ? 22 : (x == 0 ? 17 : 27);
             int grain = sample_lut(lut, off_cur, sx, sy, 0, 0, x, y);
-            const int wya = sy ? 23 : (y == 0 ? 27 : 17), wyb = sy ? 22 : (y == 0 ? 17 : 27);
             if (x < xstart) {
                 const int old = sample_lut(lut, off_left, sx, sy, 1, 0, x, y);
                 grain = dv::iclip(round2(old * wxa + grain * wxb, 5), grain_min, grain_max);
@@ -319,16 +346,24 @@ __global__ __launch_bounds__(64) void fg_apply_kernel(const DevPlanes dst, const
                 }
                 grain = dv::iclip(round2(top * wya + grain * wyb, 5), grain_min, grain_max);
             }
-            int val = s0[j];
+            int val = s0[k];
             if (pl) {
-                val = lum[j];
+                val = lum[k];
                 if (!p.chroma_scaling_from_luma) {
-                    const int combined = lum[j] * p.uv_luma_mult[uv] + s0[j] * p.uv_mult[uv];
+                    const int combined = lum[k] * p.uv_luma_mult[uv] + s0[k] * p.uv_mult[uv];
                     val = dv::iclip((combined >> 6) + (p.uv_offset[uv] * (1 << bitdepth_min_8)), 0, bitdepth_max);
                 }
             }
             const int noise = round2(sc_s[val] * grain, p.scaling_shift);
-            dp[(y0 + y) * ds + bx + x] = (pixel) dv::iclip(s0[j] + noise, min_value, max_value);
+            res[k] = dv::iclip(s0[k] + noise, min_value, max_value);
+        }
+        pixel *drow = dp + (y0 + y) * ds + bx + x0;
+        if (whole) {
+            if (HBD) *reinterpret_cast<uint2 *>(drow) = make_uint2((uint32_t) res[0] | (uint32_t) res[1] << 16, (uint32_t) res[2] | (uint32_t) res[3] << 16);
+            else *reinterpret_cast<uint32_t *>(drow) = (uint32_t) res[0] | (uint32_t) res[1] << 8 | (uint32_t) res[2] << 16 | (uint32_t) res[3] << 24;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (x0 + k < bw) drow[k] = (pixel) res[k];
         }
     }
 }
