@@ -182,15 +182,25 @@ __device__ __forceinline__ void nap() {
     __builtin_amdgcn_s_sleep(2);
 #endif
 }
-// start fetching the line at p (the value is not used; the wave does not wait for it here)
-__device__ __forceinline__ void touch(const void *p) {
+// Prefetch in two halves: fetch_begin issues the load of the line at p, fetch_end (any time later) is where the compiler has to
+// have the value — put work between them and the trip to memory runs under it.  (A single "touch" whose value is consumed on the
+// spot makes the wave wait right there: measured, no gain.)
+__device__ __forceinline__ int fetch_begin(const void *p) {
 #ifndef DAV1D_HIP_EMU
-    const int v = *reinterpret_cast<const volatile int *>(p);
-    asm volatile("" :: "v"(v));
+    return *reinterpret_cast<const volatile int *>(p);
 #else
     (void) p;
+    return 0;
 #endif
 }
+__device__ __forceinline__ void fetch_end(const int v) {
+#ifndef DAV1D_HIP_EMU
+    asm volatile("" :: "v"(v));
+#else
+    (void) v;
+#endif
+}
+__device__ __forceinline__ void touch(const void *p) { fetch_end(fetch_begin(p)); }
 // picture pixels behind operator[]: plain loads, or coherent ones when another workgroup of the same launch wrote them
 template <typename pixel, bool COH>
 struct PxRead {

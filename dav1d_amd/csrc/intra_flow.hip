@@ -56,13 +56,13 @@ __global__ __launch_bounds__(64, 4) void intra_flow_kernel(const DevPlanes dst, 
     for (int ui = wave; ui < n_units; ui += n_waves) {
         const IntraUnit *const up = units + ui;
         const IntraUnit u = *up;
-        if (ui + n_waves < n_units) dv::touch(units + ui + n_waves);            // the wave's next record, on its way
+        // the wave's next record and the first lines of this unit's coefficients set off now; the values are claimed after the
+        // prediction, so the trips to memory run under the wait for the step and the prediction
         const bool has_pred = u.has & 1, has_tx = u.has & 2;
-        if (has_tx) {
-            // ... and the first lines of this unit's coefficients
-            const int nb = ((int) u.t.rsv[0] | (int) u.t.rsv[1] << 8) * (int) sizeof(coef);
-            if (lane * 64 < nb) dv::touch(reinterpret_cast<const char *>(cf + u.t.cf_off) + lane * 64);
-        }
+        const int keep0 = dv::fetch_begin(units + (ui + n_waves < n_units ? ui + n_waves : ui));
+        const int nb = has_tx ? ((int) u.t.rsv[0] | (int) u.t.rsv[1] << 8) * (int) sizeof(coef) : 0;
+        const int keep1 = dv::fetch_begin(has_tx ? reinterpret_cast<const char *>(cf + u.t.cf_off) + (lane * 64 < nb ? lane * 64 : 0)
+                                                 : reinterpret_cast<const char *>(units + ui));
         if (u.prev_n) {
             // the group before this one is through when its counters add up to its size (mode bit 1: fences as well; A/B aid)
             const uint32_t *const prev = cnt + (size_t) (u.grp - 1) * (FLOW_SUB * FLOW_SUB_STRIDE);
@@ -90,6 +90,8 @@ __global__ __launch_bounds__(64, 4) void intra_flow_kernel(const DevPlanes dst, 
             // a residual on its own (the blocks of a palette block, ...): the pixels it is added to come from the picture
             for (int i = lane; i < w * h; i += 64) tile[i] = dv::ld_coherent(d + (i / w) * stride + (i % w));
         }
+        dv::fetch_end(keep0);
+        dv::fetch_end(keep1);
         dv::wave_sync();
         if (has_tx) {
 #define CASE(T) case T: itx_body<T, pixel, coef, true, true>(dst, &up->t, 1, cf, bitdepth_max, 0, smem_itx, tile); break;

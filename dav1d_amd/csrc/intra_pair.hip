@@ -25,8 +25,15 @@ __global__ __launch_bounds__(64) void intra_pair_kernel(const DevPlanes dst, con
     if (bi >= n) return;
     const int bs = __builtin_amdgcn_readfirstlane(bi);
     const Dav1dHipIpredTask t = preds[bs];
+    // the residual's record and the first lines of its coefficients set off now: their trip to memory overlaps the prediction's
+    // (record -> edge pixels -> predictor) instead of following it; a step of the wavefront is this chain of latencies
+    const Dav1dHipItxTask tt = txs[bs];
+    const int nb = ((int) tt.rsv[0] | (int) tt.rsv[1] << 8) * (int) sizeof(coef);
+    const int lane64 = (int) threadIdx.x * 64 < nb ? (int) threadIdx.x * 64 : 0;
+    const int keep = dv::fetch_begin(reinterpret_cast<const char *>(cf + tt.cf_off) + lane64);
     const int w = t.tw * 4;
     ipred_body<pixel>(dst, t, 0, false, aux, layout, bitdepth_max, e1, e2, blk, pred, w);
+    dv::fetch_end(keep);
     dv::wave_sync();
     // the transform body packs several blocks into a wave; here it gets a list of one: lanes past the first block idle
     if (w == 4) itx_body<0, pixel, coef, true>(dst, txs + bs, 1, cf, bitdepth_max, 0, smem_itx, pred);
