@@ -556,8 +556,9 @@ def main():
             fr = ctx.frame(dbl, [])
             fr.set_filters(lvl, post.b4_stride, post.lut_e, post.lut_i, post.cdef_damping, None, 0)
             fr.submit_filter_sbrow(post.lf, post.cdef, post.lr)
-            os.environ["DAV1D_HIP_POST_BANDS"] = os.environ.get("DAV1D_HIP_POST_BANDS", "4")     # off by default in the library
+            ctx.set_option("post_bands", int(os.environ.get("DAV1D_HIP_POST_BANDS", "4")))     # off by default in the library
             filt = fr.end(None, None, None, None)
+            ctx.set_option("post_bands", 0)
             if fr.post_bands():
                 fo = api.DevicePicture.view(ctx, filt, w, h, api.LAYOUT_I420, bpc)
                 for pl in range(3):

@@ -179,6 +179,10 @@ class Context:
             self.lib.dav1d_hip_close(self.h)
             self.h = None
 
+    def set_option(self, name, value):
+        """dav1d_hip_set_option: a tuning knob of this context (see include/dav1d_hip.h)"""
+        _chk(self.lib.dav1d_hip_set_option(self.h, name.encode(), int(value)), "set_option(%s)" % name)
+
     def sync(self):
         _chk(self.lib.dav1d_hip_sync(self.h), "sync")
 

@@ -23,6 +23,10 @@ struct Dav1dHipContext {
     int flow_min_steps;         // wavefronts of at least this many steps run as one dataflow launch ($DAV1D_HIP_FLOW_MIN_STEPS, 0 = never)
     int flow_mode;              // $DAV1D_HIP_FLOW_MODE at open: hand-off variant of the intra dataflow launch (intra_flow.hip)
     int flow_groups;            // workgroups of the intra dataflow launch ($DAV1D_HIP_FLOW_GROUPS at open, default 512; every wave has to be resident: units are dealt out round-robin)
+    int recon_fuse;             // bit mask of the square block sizes that run paired (DAV1D_HIP_RECON_FUSE)
+    long recon_pipeline;        // smallest residual list a recon list pipelines on two streams (DAV1D_HIP_RECON_PIPELINE)
+    int recon_lanes;            // side streams of the residual launches (DAV1D_HIP_RECON_LANES)
+    int post_bands;             // bands of the pipelined post filters, 0 = stage by stage (DAV1D_HIP_POST_BANDS)
     bool cdef_unit_kernel;      // $DAV1D_HIP_CDEF_UNIT=1 at open: one wave per 8x8 unit (the round-1 kernel) instead of strips; A/B aid
     // measurement aid: device time of the kernel launches of the most recent *_batch call (dav1d_hip_last_kernel_ms)
     hipEvent_t ev_t0, ev_t1;

@@ -1,6 +1,10 @@
 // Host side of the C ABI declared in include/dav1d_hip.h: context, device memory,
 // pictures, task-list binning and the batched entry points.
 #include "capi.h"
+
+#ifndef RECON_FUSE_DEFAULT
+#define RECON_FUSE_DEFAULT 14       // which square block sizes run paired by default: see recon_fuse_mask() below
+#endif
 #include "lists.h"
 #include "av1_scan_prefix.h"
 #include <stdlib.h>
@@ -29,6 +33,19 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     c->scratch_size = 0;
     if (stream) c->stream = (hipStream_t) stream;
     else if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return -ENODEV; }
+    // the library holds gfx950 code only: any other device cannot run it
+#ifndef DAV1D_HIP_EMU
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6)) { delete c; return -ENODEV; }
+    }
+#endif
+    // tuning knobs: context state, the environment only supplies the defaults at open (dav1d_hip_set_option changes them later)
+    auto env_int = [](const char *name, long dflt) { const char *e = getenv(name); return e ? atol(e) : dflt; };
+    c->recon_fuse = (int) env_int("DAV1D_HIP_RECON_FUSE", RECON_FUSE_DEFAULT);
+    c->recon_pipeline = env_int("DAV1D_HIP_RECON_PIPELINE", 16384);
+    c->recon_lanes = (int) env_int("DAV1D_HIP_RECON_LANES", 1);
+    c->post_bands = (int) env_int("DAV1D_HIP_POST_BANDS", 0);
     const char *ser = getenv("DAV1D_HIP_SERIAL");
     c->concurrent = !(ser && atoi(ser));
     const char *cu = getenv("DAV1D_HIP_CDEF_UNIT");
@@ -121,6 +138,22 @@ void dav1d_hip_graph_destroy(Dav1dHipContext *c, Dav1dHipGraph *g) {
     hipGraphDestroy(g->graph);
     delete g;
 }
+// knobs by name (the environment variables of DESIGN.md without the DAV1D_HIP_ prefix, lower case); -EINVAL for an unknown name
+int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value) {
+    if (!c || !name) return -EINVAL;
+    if (!strcmp(name, "recon_fuse")) c->recon_fuse = (int) value;
+    else if (!strcmp(name, "recon_pipeline")) c->recon_pipeline = value;
+    else if (!strcmp(name, "recon_lanes")) c->recon_lanes = (int) value;
+    else if (!strcmp(name, "post_bands")) c->post_bands = (int) value;
+    else if (!strcmp(name, "serial")) c->concurrent = !value;
+    else if (!strcmp(name, "cdef_unit")) c->cdef_unit_kernel = value != 0;
+    else if (!strcmp(name, "flow_groups")) c->flow_groups = value > 0 ? (int) value : c->flow_groups;
+    else if (!strcmp(name, "flow_mode")) c->flow_mode = (int) value;
+    else if (!strcmp(name, "flow_min_steps")) c->flow_min_steps = (int) value;
+    else return -EINVAL;
+    return 0;
+}
+
 const char *dav1d_hip_version(void) { return "dav1d_hip 0.1 (gfx950)"; }
 float dav1d_hip_last_kernel_ms(Dav1dHipContext *c) { return c ? c->last_ms : 0.f; }
 
@@ -1406,9 +1439,6 @@ extern "C" int dav1d_hip_fg_apply(Dav1dHipContext *c, const Dav1dHipPicture *dst
 // in the order largest tile shape first, each followed by an event; the residual launches go down a side stream, largest
 // transform first, each waiting for the events of its own predecessors only.  The memory-bound predictions of the small
 // shapes then overlap with the arithmetic-bound 64- and 32-point transforms instead of queueing in front of them.
-#ifndef RECON_FUSE_DEFAULT
-#define RECON_FUSE_DEFAULT 14
-#endif
 
 // DAV1D_HIP_RECON_FUSE: which square block sizes get paired (transform block + the prediction block of the same rectangle in
 // one wave, recon.hip): bit 0 4x4, bit 1 8x8, bit 2 16x16, bit 3 32x32, bit 4 64x64; 0 none.  Measured on MI355X (8K 10-bit
@@ -1416,10 +1446,7 @@ extern "C" int dav1d_hip_fg_apply(Dav1dHipContext *c, const Dav1dHipPicture *dst
 // 8x8 + 16x16 + 32x32 (14, the default) 0.317-0.327.  Round 1 (three separate LDS arrays): none 0.362, 6 0.311 (older clock),
 // 4x4 + 8x8 0.318, all 0.411.  What pays is that the paired launches move a quarter less HBM traffic AND run next to the
 // pipelined launches of the other sizes on streams of their own; 4x4 and 64x64 pairs lose to their separate kernels.
-int recon_fuse_mask() {
-    const char *e = getenv("DAV1D_HIP_RECON_FUSE");
-    return (e ? atoi(e) : RECON_FUSE_DEFAULT) & 31;
-}
+int recon_fuse_mask(const Dav1dHipContext *c) { return c->recon_fuse & 31; }
 
 extern "C" {
 
@@ -1436,9 +1463,9 @@ int dav1d_hip_recon_list_create(Dav1dHipContext *c, Dav1dHipReconList **out, con
     for (int k = 0; k < 5; k++) { l->f_tiles[k] = nullptr; l->f_tasks[k] = nullptr; l->f_n[k] = 0; }
     l->f_max_ref = 0;
     ReconPairing pair;
-    const bool fuse = recon_fuse_mask() != 0;
+    const bool fuse = recon_fuse_mask(c) != 0;
     if (fuse) {
-        pair.mask = recon_fuse_mask();
+        pair.mask = recon_fuse_mask(c);
         pair.itx = itx;
         bool any_blend = false;
         for (size_t i = 0; i < n_comp && !any_blend; i++) any_blend = comp[i].kind >= DAV1D_HIP_COMP_BLEND;
@@ -1580,10 +1607,8 @@ int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, con
         }
     }
     const Dav1dHipMcList *ml = l->inter->mc;
-    // DAV1D_HIP_RECON_PIPELINE = smallest residual list worth two streams (0: always pipeline, -1: never); read per call so that
-    // tests can switch it
-    const char *env = getenv("DAV1D_HIP_RECON_PIPELINE");
-    const long min_tasks = env ? atol(env) : 16384;
+    // c->recon_pipeline = smallest residual list worth two streams (0: always pipeline, -1: never)
+    const long min_tasks = c->recon_pipeline;
     auto join_paired = [&]() {
         if (paired_on_side) { (void) hipStreamWaitEvent(c->stream, c->ev_join[1], 0); (void) hipStreamWaitEvent(c->stream, c->ev_join[2], 0); }
     };
@@ -1605,9 +1630,8 @@ int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, con
     // DAV1D_HIP_RECON_LANES: side streams the residual launches are dealt over.  Measured (8K 10-bit): 1 lane 0.379 ms,
     // 2 lanes 0.394, 3 lanes 0.407, 5 lanes 0.420 per frame — residual launches running next to each other take bandwidth from
     // the predictions they are waiting for; one in-order residual stream keeps the pipeline a pipeline.
-    const char *le = getenv("DAV1D_HIP_RECON_LANES");
     const int n_lanes = paired_on_side ? 1      // side streams 1 and 2 carry the paired launches
-                      : le ? std::max(1, std::min((int) Dav1dHipContext::N_SIDE, atoi(le))) : 1;
+                      : std::max(1, std::min((int) Dav1dHipContext::N_SIDE, c->recon_lanes));
     hipStream_t sm = c->stream;
     (void) hipEventRecord(c->ev_fork, sm);
     for (int i = 0; i < n_lanes; i++) (void) hipStreamWaitEvent(c->side[i], c->ev_fork, 0);

@@ -176,7 +176,7 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
             }
 
     // ---- pairing: a square transform block that covers exactly one prediction block runs with it in one wave (recon.hip)
-    const int fuse_mask = recon_fuse_mask();
+    const int fuse_mask = recon_fuse_mask(c);
     std::vector<char> taken(n_itx, 0);
     if (fuse_mask) {
         for (int p = 0; p < 3; p++) if (!cm[p].empty()) cm[p].tx_at.assign((size_t) cm[p].w * cm[p].h, 0);

@@ -89,8 +89,7 @@ static int post_filters_pipelined(Dav1dHipFrame *f, const Dav1dHipPicture **last
     // 0.58 + restoration 0.26 = 0.99 ms stage by stage) the banded pipeline takes 1.14 ms with 3 bands, 1.21 with 6, 1.78 with
     // 17 — every cross-stream event costs a release / acquire of the caches, about 45 us per band, more than the overlap of
     // the arithmetic-bound CDEF with its memory-bound neighbours returns.  (The recon list, 5 events per frame, does gain.)
-    const char *env = getenv("DAV1D_HIP_POST_BANDS");
-    const int want = env ? atoi(env) : 0;
+    const int want = c->post_bands;
     if (want < 2) return 1;
     const int H = f->cur.p[0].h, W = f->cur.p[0].w, layout = f->cur.layout, bps = f->cur.bpc > 8 ? 2 : 1;
     const int ss_ver = layout == DAV1D_HIP_LAYOUT_I420, ss_hor = layout != DAV1D_HIP_LAYOUT_I444;

@@ -59,5 +59,5 @@ int mc_task_valid(const Dav1dHipMcTask &t);
 McRef mc_ref_of(const Dav1dHipMcTask &t);
 void push_tiles(std::vector<McTile> *bins, const Dav1dHipMcTask &t, int kind, uint32_t dst_off, const Dav1dHipMcTask *second, int weight,
                 std::vector<McTile> *single = nullptr);
-int recon_fuse_mask();
+int recon_fuse_mask(const Dav1dHipContext *c);
 int tile_dim_class(int v);

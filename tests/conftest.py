@@ -24,3 +24,13 @@ def ctx(request):
     c.backend = request.param
     yield c
     c.close()
+
+
+@pytest.fixture(autouse=True)
+def _default_options(request):
+    """Tests that turn a context's tuning knobs (ctx.set_option) get the library's defaults back afterwards: the context is shared."""
+    yield
+    if "ctx" in request.fixturenames:
+        c = request.getfixturevalue("ctx")
+        for name, value in (("recon_fuse", 14), ("recon_pipeline", 16384), ("recon_lanes", 1), ("post_bands", 0)):
+            c.set_option(name, value)

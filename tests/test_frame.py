@@ -154,8 +154,8 @@ def test_frame_from_packed_coefficients(ctx, bpc):
 def test_recon_list_matches_oracle(ctx, bpc, pipeline, fuse, monkeypatch):
     """dav1d_hip_recon_list_*: predictions and residuals as one list, the residual launch of a transform size waiting only
     for the prediction launches under its blocks (two streams) — and the same list run strictly one phase after the other."""
-    monkeypatch.setenv("DAV1D_HIP_RECON_PIPELINE", pipeline)
-    monkeypatch.setenv("DAV1D_HIP_RECON_FUSE", fuse)      # paired: prediction + residual of a block in one wave (recon.hip)
+    ctx.set_option("recon_pipeline", pipeline)
+    ctx.set_option("recon_fuse", fuse)      # paired: prediction + residual of a block in one wave (recon.hip)
     w, h = (512, 128) if ctx.backend == "emu" else (1280, 1024)
     frame = synth.make_frame(w, h, bpc, seed=515 + bpc, edge_frac=0.1)
     rng = np.random.default_rng(9 + bpc)
@@ -175,7 +175,7 @@ def test_recon_list_with_transforms_smaller_than_their_prediction(ctx, pipeline,
     take the prediction launch + residual launch route, where the 8x8 residual launch has to wait for the 16x16 prediction
     launch — next to paired blocks of the same frame."""
     import copy
-    monkeypatch.setenv("DAV1D_HIP_RECON_PIPELINE", pipeline)
+    ctx.set_option("recon_pipeline", pipeline)
     bpc = 10
     w, h = (512, 128) if ctx.backend == "emu" else (1280, 1024)
     base = synth.make_frame(w, h, bpc, seed=808, edge_frac=0.05)

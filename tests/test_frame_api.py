@@ -20,7 +20,8 @@ def test_frame_in_flight_matches_oracle(ctx, bpc, bands, monkeypatch):
     dav1d_hip_frame_progress — the hook for dav1d's progress publication, src/thread_task.c:888-896)."""
     async_end = bands < 0
     bands = max(bands, 0)
-    monkeypatch.setenv("DAV1D_HIP_POST_BANDS", str(bands))
+    ctx.set_option("post_bands", bands)
+
     oracle = util.default_oracle()
     w, h = (64, 768) if ctx.backend == "emu" else (1024, 1152)
     frame = synth.make_frame(w, h, bpc, seed=31 + bpc, edge_frac=0.1)
