@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64, 4) void intra_flow_kernel(const DevPlanes dst, 
     __shared__ uint4 smem[(cmax(TILE_B, ITX_B) + 15) / 16];
     pixel *const tile = reinterpret_cast<pixel *>(smem);
     int *const smem_itx = reinterpret_cast<int *>(smem);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x, n_waves = gridDim.x;
     uint32_t *const cnt = ctr + 32;
 

@@ -64,7 +64,7 @@ __device__ __forceinline__ void ipred_body(const DevPlanes &dst, const Dav1dHipI
                                            int16_t *e1, int16_t *e2, int16_t *blk, pixel *const o, const int ostride)
 {
     const uint8_t *const pal_idx = aux;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;        // the body belongs to one wave (the intra kernels run four side by side in a workgroup)
     constexpr bool HBD = sizeof(pixel) == 2;
     const int bitdepth = 32 - __clz(bitdepth_max);
     const int stride = dst.stride[t.plane];
