@@ -202,6 +202,9 @@ int dav1d_hip_cdef_run_groups(Dav1dHipContext *c, const Dav1dHipPicture *dst, co
 extern "C" int dav1d_hip_launch_lf(const DevPlanes *dst, int bpc, int dir, const Dav1dHipLfTask *tasks, int n, const uint8_t *lvl,
                                    int b4_stride, const uint8_t *lut_e, const uint8_t *lut_i, void *stream);
 
+extern "C" int dav1d_hip_launch_intra_step(const DevPlanes *dst, int bpc, int layout, const Dav1dHipIpredTask *tasks, int n, int n_big,
+                                           const Dav1dHipIpredTask *preds, const Dav1dHipItxTask *txs, int n_pairs, uint8_t *aux, void *tmp,
+                                           void *coef, void *stream);
 extern "C" int dav1d_hip_launch_intra_pairs(const DevPlanes *dst, int bpc, int layout, const Dav1dHipIpredTask *preds,
                                             const Dav1dHipItxTask *txs, int n, uint8_t *aux, void *coef, void *stream);
 extern "C" int dav1d_hip_launch_ipred(const DevPlanes *dst, int bpc, int layout, const Dav1dHipIpredTask *tasks, int n, int n_big,

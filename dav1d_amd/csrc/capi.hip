@@ -2019,10 +2019,19 @@ int dav1d_hip_intra_list_run_batch_blend(Dav1dHipContext *c, const Dav1dHipIntra
     const DevPlanes dp = dev_planes(dst);
     int rc = 0;
     const size_t n_pairs = l->pair_start[batch + 1] - l->pair_start[batch];
-    if (n_pairs)
-        rc = dav1d_hip_launch_intra_pairs(&dp, dst->bpc, dst->layout, l->p_dev + l->pair_start[batch], l->t_dev + l->pair_start[batch],
-                                          (int) n_pairs, aux, coef, c->stream);
-    if (!rc) rc = ipred_list_run_batch_tmp(c, l->preds, batch, dst, aux, prep);
+    const Dav1dHipIpredList *pl = l->preds;
+    const size_t n_rest = pl ? pl->start[batch + 1] - pl->start[batch] : 0;
+    if (n_pairs && n_rest) {
+        // the pairs and the other predictions of the step are independent: one launch, side by side (intra_pair.hip)
+        if ((pl->needs_aux && !aux) || (pl->needs_tmp && !prep)) return -EINVAL;
+        rc = dav1d_hip_launch_intra_step(&dp, dst->bpc, dst->layout, pl->dev + pl->start[batch], (int) n_rest, (int) pl->n_big[batch],
+                                         l->p_dev + l->pair_start[batch], l->t_dev + l->pair_start[batch], (int) n_pairs, aux, prep, coef, c->stream);
+    } else {
+        if (n_pairs)
+            rc = dav1d_hip_launch_intra_pairs(&dp, dst->bpc, dst->layout, l->p_dev + l->pair_start[batch], l->t_dev + l->pair_start[batch],
+                                              (int) n_pairs, aux, coef, c->stream);
+        if (!rc) rc = ipred_list_run_batch_tmp(c, l->preds, batch, dst, aux, prep);
+    }
     if (!rc && n_blend) rc = dav1d_hip_launch_comp(&dp, dst->bpc, l->b_dev + l->blend_start[batch], (int) n_blend, prep, mask, c->stream);
     if (!rc && l->itx[batch]->n) rc = dav1d_hip_itx_list_run(c, l->itx[batch], dst, coef);
     return rc;
