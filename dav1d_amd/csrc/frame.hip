@@ -153,14 +153,27 @@ static int post_filters_pipelined(Dav1dHipFrame *f, const Dav1dHipPicture **last
     if (has_cdef) rc = frame_tmp(f, 0);
     if (!rc && has_lr) rc = frame_tmp(f, 1);
     if (rc) return rc;
+    // CDEF: units that sit side by side share a wave (cdef.hip, strip kernel); the groups of every band, band after band
+    std::vector<CdefGroup> cgroups;
+    std::vector<size_t> cg_off(nb + 1, 0);
+    const DevPlanes cur_p = dev_planes(&f->cur);
+    const bool strips = has_cdef && !c->cdef_unit_kernel && dav1d_hip_cdef_strip_ok(&cur_p, &cur_p, f->cur.bpc);
+    if (strips)
+        for (int k = 0; k < nb; k++) {
+            (void) dav1d_hip_cdef_make_groups(cdef_s.data() + cdef_off[k], cdef_off[k + 1] - cdef_off[k], cdef_off[k], cgroups);
+            cg_off[k + 1] = cgroups.size();
+        }
     const size_t bytes_lf = lf_s.size() * sizeof(Dav1dHipLfTask), bytes_cdef = cdef_s.size() * sizeof(Dav1dHipCdefTask),
                  bytes_lr = lr_s.size() * sizeof(Dav1dHipLrTask);
     const size_t o_cdef = (bytes_lf + 255) & ~(size_t) 255, o_lr = (o_cdef + bytes_cdef + 255) & ~(size_t) 255;
     uint8_t *dev = nullptr;
-    if (hipMalloc((void **) &dev, o_lr + bytes_lr + 256) != hipSuccess) return -ENOMEM;
+    const size_t o_cg = (o_lr + bytes_lr + 255) & ~(size_t) 255, bytes_cg = cgroups.size() * sizeof(CdefGroup);
+    if (hipMalloc((void **) &dev, o_cg + bytes_cg + 256) != hipSuccess) return -ENOMEM;
     if (bytes_lf) rc = dav1d_hip_upload(c, dev, lf_s.data(), bytes_lf);
     if (!rc && bytes_cdef) rc = dav1d_hip_upload(c, dev + o_cdef, cdef_s.data(), bytes_cdef);
     if (!rc && bytes_lr) rc = dav1d_hip_upload(c, dev + o_lr, lr_s.data(), bytes_lr);
+    if (!rc && bytes_cg) rc = dav1d_hip_upload(c, dev + o_cg, cgroups.data(), bytes_cg);
+    const CdefGroup *d_cg = reinterpret_cast<const CdefGroup *>(dev + o_cg);
     const Dav1dHipLfTask *d_lf = reinterpret_cast<const Dav1dHipLfTask *>(dev);
     const Dav1dHipCdefTask *d_cdef = reinterpret_cast<const Dav1dHipCdefTask *>(dev + o_cdef);
     const Dav1dHipLrTask *d_lr = reinterpret_cast<const Dav1dHipLrTask *>(dev + o_lr);
@@ -187,7 +200,21 @@ static int post_filters_pipelined(Dav1dHipFrame *f, const Dav1dHipPicture **last
             if (has_cdef && bc >= 0 && bc < nb && !rc) {
                 if (has_lf) (void) hipStreamWaitEvent(sb, ev[bc + 1 < nb ? bc + 1 : nb - 1], 0);
                 const size_t n = cdef_off[bc + 1] - cdef_off[bc];
-                if (n) rc = dav1d_hip_launch_cdef(&t0, &cur, f->cur.bpc, layout, d_cdef + cdef_off[bc], (int) n, f->cdef_damping, nullptr, 0, sb);
+                // a listed unit whose strengths come out as zero (adjusted primary 0 and no secondary) is not written by the kernel:
+                // the band's rows of the deblocked picture go to the output first
+                for (int pl = 0; pl < 3 && !rc; pl++) {
+                    if (!f->cur.p[pl].data) continue;
+                    const int sv = pl ? ss_ver : 0;
+                    const int r0 = (bc * band_h) >> sv, r1 = std::min(((bc + 1) * band_h) >> sv, f->cur.p[pl].h);
+                    if (r1 > r0)
+                        rc = hip_rc(hipMemcpy2DAsync((uint8_t *) f->tmp[0].p[pl].data + (size_t) r0 * f->tmp[0].p[pl].stride, f->tmp[0].p[pl].stride,
+                                                     (const uint8_t *) f->cur.p[pl].data + (size_t) r0 * f->cur.p[pl].stride, f->cur.p[pl].stride,
+                                                     (size_t) f->cur.p[pl].w * bps, r1 - r0, hipMemcpyDeviceToDevice, sb));
+                }
+                if (rc) break;
+                if (n && strips) rc = dav1d_hip_launch_cdef_groups(&t0, &cur, f->cur.bpc, layout, d_cdef, d_cg + cg_off[bc], (int) (cg_off[bc + 1] - cg_off[bc]),
+                                                                   f->cdef_damping, nullptr, sb);
+                else if (n) rc = dav1d_hip_launch_cdef(&t0, &cur, f->cur.bpc, layout, d_cdef + cdef_off[bc], (int) n, f->cdef_damping, nullptr, 0, sb);
                 (void) hipEventRecord(ev[nb + bc], sb);
             }
             const int br = b - 2;                    // restoration one band behind CDEF
