@@ -223,7 +223,8 @@ extern "C" int dav1d_hip_launch_fg_apply_rows(const DevPlanes *dst, const DevPla
                                               int scaling_size, const Dav1dHipFilmGrainData *data, int bpc, int layout, int is_id,
                                               int row_num, int pl, uint8_t *offs, void *stream);
 extern "C" int dav1d_hip_launch_sgr(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
-                                    const Dav1dHipLrTask *tasks, int n, int max_w, void *stream);
+                                    const Dav1dHipLrTask *tasks, const void *waves, int n_waves, void *stream);
+void dav1d_hip_sgr_make_rows(Dav1dHipLrTask *tasks, size_t n, std::vector<uint32_t> &waves);
 
 extern "C" int dav1d_hip_launch_warp(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, const Dav1dHipWarpTask *tasks, int n,
                                      int16_t *prep, void *stream);

@@ -1264,15 +1264,21 @@ extern "C" int dav1d_hip_lr_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst
     for (size_t i = 0; i < n; i++) if (tasks[i].type <= DAV1D_HIP_LR_WIENER5) sorted.push_back(tasks[i]);
     const size_t nw = sorted.size();
     for (size_t i = 0; i < n; i++) if (tasks[i].type > DAV1D_HIP_LR_WIENER5) sorted.push_back(tasks[i]);
-    Dav1dHipLrTask *dev = nullptr;
-    if (hipMalloc((void **) &dev, n * sizeof(*dev)) != hipSuccess) return -ENOMEM;
+    // self-guided: the units of a row share waves (lr.hip)
+    std::vector<uint32_t> waves;
+    dav1d_hip_sgr_make_rows(sorted.data() + nw, n - nw, waves);
+    const size_t o_waves = (n * sizeof(Dav1dHipLrTask) + 15) & ~(size_t) 15;
+    uint8_t *devb = nullptr;
+    if (hipMalloc((void **) &devb, o_waves + waves.size() * 4 + 16) != hipSuccess) return -ENOMEM;
+    Dav1dHipLrTask *const dev = reinterpret_cast<Dav1dHipLrTask *>(devb);
     int rc = dav1d_hip_upload(c, dev, sorted.data(), n * sizeof(*dev));
+    if (!rc && !waves.empty()) rc = dav1d_hip_upload(c, devb + o_waves, waves.data(), waves.size() * 4);
     const DevPlanes dp = dev_planes(dst), sp = dev_planes(src), lp = dev_planes(lpf);
     KernelTimer kt(c);
-    int max_w[2] = { 0, 0 };
-    for (size_t i = 0; i < n; i++) max_w[i >= nw] = std::max(max_w[i >= nw], (int) sorted[i].w);
-    if (!rc) rc = dav1d_hip_launch_wiener(&dp, &sp, &lp, dst->bpc, dev, (int) nw, max_w[0], c->stream);
-    if (!rc) rc = dav1d_hip_launch_sgr(&dp, &sp, &lp, dst->bpc, dev + nw, (int) (n - nw), max_w[1], c->stream);
+    int max_w = 0;
+    for (size_t i = 0; i < nw; i++) max_w = std::max(max_w, (int) sorted[i].w);
+    if (!rc) rc = dav1d_hip_launch_wiener(&dp, &sp, &lp, dst->bpc, dev, (int) nw, max_w, c->stream);
+    if (!rc) rc = dav1d_hip_launch_sgr(&dp, &sp, &lp, dst->bpc, dev + nw, devb + o_waves, (int) (waves.size() / 4), c->stream);
     kt.stop();
     hipStreamSynchronize(c->stream);
     hipFree(dev);

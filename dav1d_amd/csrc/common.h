@@ -87,18 +87,71 @@ __device__ __forceinline__ uint32_t pk_lshr(uint32_t v, uint32_t sh2) { return D
 __device__ __forceinline__ uint32_t pk_ashr(uint32_t v, uint32_t sh2) { return DV_R(DV_S2(v) >> DV_S2(sh2)); }
 __device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) { return DV_R(DV_S2(a) * DV_S2(b) + DV_S2(c)); }
 #endif
+// clamp with lo <= hi as one instruction (v_med3_i32); the compiler only forms it when both bounds are literals, and the
+// select form of iclip() above costs three
+__device__ __forceinline__ int clamp3(int v, int lo, int hi) {
+#ifdef DAV1D_HIP_EMU
+    if (lo > hi) __builtin_trap();
+    return v < lo ? lo : v > hi ? hi : v;
+#else
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+#endif
+}
 // full-rate 24-bit multiplies (v_mul_i32_i24 / v_mul_u32_u24): exact when both operands fit 24 bits
 __device__ __forceinline__ int mul_i24(int a, int b) {
 #ifdef DAV1D_HIP_EMU
-    return a * b;
+    if (a < -(1 << 23) || a >= (1 << 23) || b < -(1 << 23) || b >= (1 << 23)) __builtin_trap();
+    return (int) ((unsigned) a * (unsigned) b);
 #else
     int r;
     asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 #endif
 }
+// a * b + c, all three per-lane values
+__device__ __forceinline__ int mad_i24(int a, int b, int c) {
+#ifdef DAV1D_HIP_EMU
+    if (a < -(1 << 23) || a >= (1 << 23) || b < -(1 << 23) || b >= (1 << 23)) __builtin_trap();
+    return (int) ((unsigned) a * (unsigned) b + (unsigned) c);
+#else
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#endif
+}
+// i / D for 0 <= i < 4096 and a compile-time D <= 64 without the 32-bit multiplier: M = floor(2^18 / D) + 1 overshoots
+// 2^18 / D by less than D / 2^18 per unit of i, i.e. by less than 1 / D in total, which cannot carry into the quotient
+template <int D> __device__ __forceinline__ int div_small(int i) {
+    static_assert(D >= 1 && D <= 64, "divisor");
+#ifdef DAV1D_HIP_EMU
+    if (i < 0 || i >= 4096) __builtin_trap();
+    return i / D;
+#else
+    if constexpr ((D & (D - 1)) == 0) return i >> (31 - __builtin_clz(D));
+    else {
+        unsigned r;
+        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(i), "v"((1u << 18) / D + 1));
+        return (int) (r >> 18);
+    }
+#endif
+}
+// a * k + c on the same multiplier (v_mad_i32_i24), k a compile-time constant (it travels in an SGPR: anything that is not
+// wave-uniform must not be passed here).  The emulated build checks the 24-bit range of the operands instead of wrapping them.
+__device__ __forceinline__ int mad_i24k(int a, int k, int c) {
+#ifdef DAV1D_HIP_EMU
+    if (a < -(1 << 23) || a >= (1 << 23) || k < -(1 << 23) || k >= (1 << 23)) __builtin_trap();
+    return (int) ((unsigned) a * (unsigned) k + (unsigned) c);
+#else
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c));
+    return r;
+#endif
+}
 __device__ __forceinline__ unsigned mul_u24(unsigned a, unsigned b) {
 #ifdef DAV1D_HIP_EMU
+    if (a >= (1u << 24) || b >= (1u << 24)) __builtin_trap();
     return a * b;
 #else
     unsigned r;

@@ -163,16 +163,25 @@ static int post_filters_pipelined(Dav1dHipFrame *f, const Dav1dHipPicture **last
             (void) dav1d_hip_cdef_make_groups(cdef_s.data() + cdef_off[k], cdef_off[k + 1] - cdef_off[k], cdef_off[k], cgroups);
             cg_off[k + 1] = cgroups.size();
         }
+    // self-guided restoration: the units of a row share waves (lr.hip); rows and waves per band
+    std::vector<uint32_t> sgr_waves;
+    std::vector<size_t> sw_off(nb + 1, 0);
+    for (int k = 0; k < nb; k++) {
+        dav1d_hip_sgr_make_rows(lr_s.data() + lr_off[2 * k + 1], lr_off[2 * k + 2] - lr_off[2 * k + 1], sgr_waves);
+        sw_off[k + 1] = sgr_waves.size() / 4;
+    }
     const size_t bytes_lf = lf_s.size() * sizeof(Dav1dHipLfTask), bytes_cdef = cdef_s.size() * sizeof(Dav1dHipCdefTask),
                  bytes_lr = lr_s.size() * sizeof(Dav1dHipLrTask);
     const size_t o_cdef = (bytes_lf + 255) & ~(size_t) 255, o_lr = (o_cdef + bytes_cdef + 255) & ~(size_t) 255;
     uint8_t *dev = nullptr;
     const size_t o_cg = (o_lr + bytes_lr + 255) & ~(size_t) 255, bytes_cg = cgroups.size() * sizeof(CdefGroup);
-    if (hipMalloc((void **) &dev, o_cg + bytes_cg + 256) != hipSuccess) return -ENOMEM;
+    const size_t o_sw = (o_cg + bytes_cg + 255) & ~(size_t) 255;
+    if (hipMalloc((void **) &dev, o_sw + sgr_waves.size() * 4 + 256) != hipSuccess) return -ENOMEM;
     if (bytes_lf) rc = dav1d_hip_upload(c, dev, lf_s.data(), bytes_lf);
     if (!rc && bytes_cdef) rc = dav1d_hip_upload(c, dev + o_cdef, cdef_s.data(), bytes_cdef);
     if (!rc && bytes_lr) rc = dav1d_hip_upload(c, dev + o_lr, lr_s.data(), bytes_lr);
     if (!rc && bytes_cg) rc = dav1d_hip_upload(c, dev + o_cg, cgroups.data(), bytes_cg);
+    if (!rc && !sgr_waves.empty()) rc = dav1d_hip_upload(c, dev + o_sw, sgr_waves.data(), sgr_waves.size() * 4);
     const CdefGroup *d_cg = reinterpret_cast<const CdefGroup *>(dev + o_cg);
     const Dav1dHipLfTask *d_lf = reinterpret_cast<const Dav1dHipLfTask *>(dev);
     const Dav1dHipCdefTask *d_cdef = reinterpret_cast<const Dav1dHipCdefTask *>(dev + o_cdef);
@@ -224,7 +233,7 @@ static int post_filters_pipelined(Dav1dHipFrame *f, const Dav1dHipPicture **last
                 else if (has_lf) (void) hipStreamWaitEvent(sc, ev[dep], 0);
                 const size_t w0 = lr_off[2 * br], w1 = lr_off[2 * br + 1], w2 = lr_off[2 * br + 2];
                 if (w1 > w0) rc = dav1d_hip_launch_wiener(&t1, &co, &cur, f->cur.bpc, d_lr + w0, (int) (w1 - w0), 384, sc);
-                if (!rc && w2 > w1) rc = dav1d_hip_launch_sgr(&t1, &co, &cur, f->cur.bpc, d_lr + w1, (int) (w2 - w1), 384, sc);
+                if (!rc && w2 > w1) rc = dav1d_hip_launch_sgr(&t1, &co, &cur, f->cur.bpc, d_lr + w1, dev + o_sw + 16 * sw_off[br], (int) (sw_off[br + 1] - sw_off[br]), sc);
             }
         }
         (void) hipEventRecord(c->ev_join[0], sb);

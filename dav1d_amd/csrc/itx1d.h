@@ -13,6 +13,7 @@
 // live in VGPRs and every constant becomes an immediate.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "common.h"
 
 namespace itx1d {
 
@@ -32,7 +33,7 @@ __device__ constexpr int brev(int v, int bits) {
     return r;
 }
 
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return dv::clamp3(v, lo, hi); }
 
 // Round2(ka*a + kb*b, 12) for |ka|,|kb| <= 4096 without leaving 32 bits when
 // |a|,|b| < 2^19: multipliers above 2048 in magnitude are folded by +-4096 and the
@@ -41,10 +42,16 @@ __device__ __forceinline__ int rot(int a, int b, int ka, int kb) {
     const int qa = ka > 2048 ? 1 : ka < -2048 ? -1 : 0;
     const int qb = kb > 2048 ? 1 : kb < -2048 ? -1 : 0;
     const int fa = ka - 4096 * qa, fb = kb - 4096 * qb;
-    return ((a * fa + b * fb + 2048) >> 12) + qa * a + qb * b;
+    // the operands are far inside 24 bits (coefficients are clamped to bitdepth + 8 bits on the way in, Hadamard outputs to the same
+    // range, a rotation adds one bit): the full-rate 24-bit multiply-add gives the low 32 bits of the same products; a 32-bit
+    // v_mul_lo_u32 takes four times as long, and these multiplies are most of what a transform is
+    int acc = 2048;
+    if (fb) acc = dv::mad_i24k(b, fb, acc);
+    if (fa) acc = dv::mad_i24k(a, fa, acc);
+    return (acc >> 12) + qa * a + qb * b;
 }
 // Round2(v * 2896, 12) == (v * 181 + 128) >> 8 (2896 = 181 * 16)
-__device__ __forceinline__ int rot45(int v) { return (v * 181 + 128) >> 8; }
+__device__ __forceinline__ int rot45(int v) { return dv::mad_i24k(v, 181, 128) >> 8; }
 
 // ---------------------------------------------------------------- inverse DCT-II
 template <int N>
@@ -118,12 +125,13 @@ __device__ __forceinline__ void iadst4(const int *in, int *out) {
     const int a = in[0], b = in[1], c = in[2], d = in[3];
     // Round2(1321 a + 3344 b + 3803 c + 2482 d, 12) etc.; multipliers above 2048 are
     // folded by 4096 as in rot() so that four 19-bit operands stay inside 32 bits
-    out[0] = ((1321 * a + (3344 - 4096) * b + (3803 - 4096) * c + (2482 - 4096) * d + 2048) >> 12)
+    using dv::mad_i24k;
+    out[0] = (mad_i24k(a, 1321, mad_i24k(b, 3344 - 4096, mad_i24k(c, 3803 - 4096, mad_i24k(d, 2482 - 4096, 2048)))) >> 12)
              + b + c + d;
-    out[1] = (((2482 - 4096) * a + (3344 - 4096) * b - 1321 * c - (3803 - 4096) * d + 2048) >> 12)
+    out[1] = (mad_i24k(a, 2482 - 4096, mad_i24k(b, 3344 - 4096, mad_i24k(c, -1321, mad_i24k(d, -(3803 - 4096), 2048)))) >> 12)
              + a + b - d;
-    out[2] = (209 * (a - c + d) + 128) >> 8;
-    out[3] = (((3803 - 4096) * a - (3344 - 4096) * b + (2482 - 4096) * c - 1321 * d + 2048) >> 12)
+    out[2] = mad_i24k(a - c + d, 209, 128) >> 8;
+    out[3] = (mad_i24k(a, 3803 - 4096, mad_i24k(b, -(3344 - 4096), mad_i24k(c, 2482 - 4096, mad_i24k(d, -1321, 2048)))) >> 12)
              + a - b + c;
 }
 
@@ -202,9 +210,9 @@ __device__ __forceinline__ void iidentity(const int *in, int *out) {
 #pragma unroll
     for (int i = 0; i < N; i++) {
         const int v = in[i];
-        if (N == 4)       out[i] = v + ((v * 1697 + 2048) >> 12);
+        if (N == 4)       out[i] = v + (dv::mad_i24k(v, 1697, 2048) >> 12);
         else if (N == 8)  out[i] = 2 * v;
-        else if (N == 16) out[i] = 2 * v + ((v * 1697 + 1024) >> 11);
+        else if (N == 16) out[i] = 2 * v + (dv::mad_i24k(v, 1697, 1024) >> 11);
         else              out[i] = 4 * v;
     }
 }

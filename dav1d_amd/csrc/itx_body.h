@@ -208,7 +208,7 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
 #pragma unroll
         for (int x = 0; x < W; x++) {
             int v = x < SW ? in[x] : 0;
-            if (RECT2 && x < SW) v = (v * 181 + 128) >> 8;
+            if (RECT2 && x < SW) v = dv::mad_i24k(v, 181, 128) >> 8;
             in[x] = v;
         }
         if (TX == 0 && wht) {
@@ -224,7 +224,7 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
 #pragma unroll
                 for (int x = 0; x < W; x++) {
                     const int xo = flip ? W - 1 - x : x;
-                    tmp[l * TS + xo] = dv::iclip((res[x] + rnd) >> SHIFT, col_min, col_max);
+                    tmp[l * TS + xo] = dv::clamp3((res[x] + rnd) >> SHIFT, col_min, col_max);
                 }
             });
         }
@@ -250,24 +250,24 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
             dc = (dc * 181 + 128 + 2048) >> 12;
 #pragma unroll
             for (int y = 0; y < H; y++)
-                o[y * ostride] = ((pixel) dv::iclip((int) dpx[y] + dc, 0, bitdepth_max));
+                o[y * ostride] = ((pixel) dv::clamp3((int) dpx[y] + dc, 0, bitdepth_max));
         } else {
             int out[H];
             if (TX == 0 && wht) {
                 if constexpr (H == 4) itx1d::iwht4(cin, out);
 #pragma unroll
                 for (int y = 0; y < H; y++)
-                    o[y * ostride] = ((pixel) dv::iclip((int) dpx[y] + out[y], 0, bitdepth_max));
+                    o[y * ostride] = ((pixel) dv::clamp3((int) dpx[y] + out[y], 0, bitdepth_max));
             } else {
                 tx1d<H>(k2, cin, col_min, col_max, [&](const int *res) {
                     if (k2 == K_FLIPADST) {
 #pragma unroll
                         for (int y = 0; y < H; y++)
-                            o[y * ostride] = ((pixel) dv::iclip((int) dpx[y] + ((res[H - 1 - y] + 8) >> 4), 0, bitdepth_max));
+                            o[y * ostride] = ((pixel) dv::clamp3((int) dpx[y] + ((res[H - 1 - y] + 8) >> 4), 0, bitdepth_max));
                     } else {
 #pragma unroll
                         for (int y = 0; y < H; y++)
-                            o[y * ostride] = ((pixel) dv::iclip((int) dpx[y] + ((res[y] + 8) >> 4), 0, bitdepth_max));
+                            o[y * ostride] = ((pixel) dv::clamp3((int) dpx[y] + ((res[y] + 8) >> 4), 0, bitdepth_max));
                     }
                 });
             }

@@ -14,6 +14,8 @@
 #include "common.h"
 #include "capi.h"
 #include "av1_tables.h"
+#include <vector>
+#include <algorithm>
 
 namespace {
 
@@ -130,31 +132,54 @@ __device__ __forceinline__ AB calc_ab(const int sumsq, const int sum, const int 
     return r;
 }
 
+// One wave = 64 consecutive "virtual columns" of a ROW of units (tasks of the same plane, y and height, any x): a unit of width w
+// takes w + 2 virtual columns (its (A, B) columns -1 .. w), the units of a row follow each other without gaps, and consecutive
+// waves overlap by two lanes, so that every virtual column is an interior lane (1 .. 62) of exactly one wave.  Round 1 cut
+// every unit into waves of its own: a 64-pixel unit needs 66 (A, B) columns = two waves, the second one with 2 of 64 lanes at
+// work; a row of sixty such units now takes 64 waves instead of 120.  The unit a lane works for — its position, width, edge
+// flags, filter type and strengths — is per-lane data; what the waves of a row share is the plane, y and the height.
+struct SgrWave { uint32_t first, end; int32_t v0; uint32_t pad; };      // tasks [first, end) = the row; lane 0 is virtual column v0 of task `first`
+
 template <typename pixel>
 __global__ __launch_bounds__(64) void sgr_kernel(const DevPlanes dst, const DevPlanes src, const DevPlanes lpf,
-                                                 const Dav1dHipLrTask *__restrict__ tasks, const int n, const int bitdepth_max)
+                                                 const Dav1dHipLrTask *__restrict__ tasks, const SgrWave *__restrict__ waves, const int n_waves,
+                                                 const int bitdepth_max)
 {
     __shared__ int a3[4][64], b3[4][64], a5[2][64], b5[2][64];
     __shared__ __attribute__((aligned(4))) uint8_t x_by_x[256];
-    const int ti = blockIdx.y;
-    if (ti >= n) return;
-    const Dav1dHipLrTask t = tasks[__builtin_amdgcn_readfirstlane(ti)];
-    const int seg0 = blockIdx.x * 62;
-    if (seg0 >= t.w) return;
+    if ((int) blockIdx.x >= n_waves) return;
+    const SgrWave wv = waves[blockIdx.x];
     const int lane = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < 4; k++) x_by_x[4 * lane + k] = av1_sgr_x_by_x[4 * lane + k];      // first read comes after the loop's first wave_sync
-    const int c = seg0 - 1 + lane;                      // (A, B) column of this lane, -1 .. w
+    // which unit of the row this lane works for
+    uint32_t ti = wv.first;
+    int v = wv.v0 + lane;
+    bool valid = true;
+    for (int it = 0; it < 64; it++) {
+        if (ti >= wv.end) { valid = false; break; }
+        const int wt = tasks[ti].w;
+        if (v < wt + 2) break;
+        v -= wt + 2;
+        ti++;
+    }
+    if (ti >= wv.end) { valid = false; ti = wv.end - 1; }
+    const Dav1dHipLrTask t = tasks[ti];
+    const Dav1dHipLrTask t0 = tasks[wv.first];                     // the row's plane, y, height (the same for every unit of it)
+    const int c = v - 1;                                                // (A, B) column of this lane inside its unit, -1 .. w
     const int bitdepth_min_8 = (32 - __clz(bitdepth_max)) - 8;
-    const int pl = t.plane, w = t.w, h = t.h, edges = t.edges;
-    const bool do5 = t.type != DAV1D_HIP_LR_SGR_3X3, do3 = t.type != DAV1D_HIP_LR_SGR_5X5;
+    const int pl = __builtin_amdgcn_readfirstlane((int) t0.plane), h = __builtin_amdgcn_readfirstlane((int) t0.h),
+              ty = __builtin_amdgcn_readfirstlane((int) t0.y);
+    const int w = t.w, edges = t.edges;
+    const bool do5 = valid && t.type != DAV1D_HIP_LR_SGR_3X3, do3 = valid && t.type != DAV1D_HIP_LR_SGR_5X5;
+    const bool any5 = __any(do5), any3 = __any(do3);
     const int s0 = t.filter[0][0], s1 = t.filter[0][1], w0 = t.filter[0][2], w1 = t.filter[0][3];
     const pixel *const s = reinterpret_cast<const pixel *>(src.data[pl]);
     const pixel *const l = reinterpret_cast<const pixel *>(lpf.data[pl]);
     const int ss = src.stride[pl], ls = lpf.stride[pl];
     // rows below the stripe: the reference only gets to them for long enough (5x5 / mix: even) stripes
     bool use_bottom = (edges & 8) != 0;
-    if (do5) use_bottom = use_bottom && !(h & 1) && h >= ((edges & 4) ? 4 : 6);
+    if (t.type != DAV1D_HIP_LR_SGR_3X3) use_bottom = use_bottom && !(h & 1) && h >= ((edges & 4) ? 4 : 6);
     else use_bottom = use_bottom && h >= 3;
 
     int col[5];                                         // picture columns of c-2 .. c+2 with the edge rules of sgr_box*_row_h
@@ -167,21 +192,20 @@ __global__ __launch_bounds__(64) void sgr_kernel(const DevPlanes dst, const DevP
         col[i] = t.x + cc;
     }
     int s3[3] = { 0, 0, 0 }, q3[3] = { 0, 0, 0 }, s5[5] = { 0, 0, 0, 0, 0 }, q5[5] = { 0, 0, 0, 0, 0 };
-    const bool out_lane = lane >= 1 && lane <= 62 && c < w;
-    pixel *const d = reinterpret_cast<pixel *>(dst.data[pl]) + t.y * dst.stride[pl] + t.x + c;
+    const bool out_lane = valid && lane >= 1 && lane <= 62 && c >= 0 && c < w;
+    pixel *const d = reinterpret_cast<pixel *>(dst.data[pl]) + ty * dst.stride[pl] + t.x + c;
 
-    const int rs0 = blockIdx.z * LR_SEG, rs1 = dv::imin(rs0 + LR_SEG, h);      // LR_SEG is even: the 5x5 surface lives on odd rows
-    if (rs0 >= h) return;
+    const int rs0 = 0, rs1 = h;
     for (int r = rs0 - 3; r < rs1 + 3; r++) {
-        // ---- horizontal box sums of virtual row r
+        // ---- horizontal box sums of virtual row r (which picture row feeds it depends on the lane's unit: its edge flags)
         const pixel *row;
         if (r < 0) {
-            if (edges & 4) row = l + (t.y - (r == -1 ? 1 : 2)) * ls;
-            else row = s + t.y * ss;
+            if (edges & 4) row = l + (ty - (r == -1 ? 1 : 2)) * ls;
+            else row = s + ty * ss;
         } else if (r >= h) {
-            if (use_bottom) row = l + (t.y + h + (r == h ? 0 : 1)) * ls;
-            else row = s + (t.y + h - 1) * ss;
-        } else row = s + (t.y + r) * ss;
+            if (use_bottom) row = l + (ty + h + (r == h ? 0 : 1)) * ls;
+            else row = s + (ty + h - 1) * ss;
+        } else row = s + (ty + r) * ss;
         const int p0 = row[col[0]], p1 = row[col[1]], p2 = row[col[2]], p3 = row[col[3]], p4 = row[col[4]];
 #pragma unroll
         for (int i = 0; i < 2; i++) { s3[i] = s3[i + 1]; q3[i] = q3[i + 1]; }
@@ -192,27 +216,27 @@ __global__ __launch_bounds__(64) void sgr_kernel(const DevPlanes dst, const DevP
         s5[4] = s3[2] + p0 + p4;
         q5[4] = q3[2] + p0 * p0 + p4 * p4;
         // ---- (A, B) rows that just became complete
-        if (do3 && r >= rs0 && r <= rs1 + 1) {        // row j = r - 1 of the 3x3 surface (rows rs0-1 .. rs1 feed this segment)
-            const AB v = calc_ab(q3[0] + q3[1] + q3[2], s3[0] + s3[1] + s3[2], s1, bitdepth_min_8, 9, 455, x_by_x);
-            a3[(r - 1) & 3][lane] = v.a; b3[(r - 1) & 3][lane] = v.b;
+        if (any3 && r >= rs0 && r <= rs1 + 1) {       // row j = r - 1 of the 3x3 surface (rows rs0-1 .. rs1 feed this segment)
+            const AB ab = calc_ab(q3[0] + q3[1] + q3[2], s3[0] + s3[1] + s3[2], s1, bitdepth_min_8, 9, 455, x_by_x);
+            a3[(r - 1) & 3][lane] = ab.a; b3[(r - 1) & 3][lane] = ab.b;
         }
-        if (do5 && r >= rs0 + 1 && ((r - 2) & 1)) {    // row j = r - 2 (odd) of the 5x5 surface
-            const AB v = calc_ab(q5[0] + q5[1] + q5[2] + q5[3] + q5[4], s5[0] + s5[1] + s5[2] + s5[3] + s5[4], s0, bitdepth_min_8, 25, 164, x_by_x);
-            a5[((r - 2) >> 1) & 1][lane] = v.a; b5[((r - 2) >> 1) & 1][lane] = v.b;
+        if (any5 && r >= rs0 + 1 && ((r - 2) & 1)) {    // row j = r - 2 (odd) of the 5x5 surface
+            const AB ab = calc_ab(q5[0] + q5[1] + q5[2] + q5[3] + q5[4], s5[0] + s5[1] + s5[2] + s5[3] + s5[4], s0, bitdepth_min_8, 25, 164, x_by_x);
+            a5[((r - 2) >> 1) & 1][lane] = ab.a; b5[((r - 2) >> 1) & 1][lane] = ab.b;
         }
         dv::wave_sync();
         // ---- output row y = r - 3
         const int y = r - 3;
         if (y >= rs0 && y < rs1 && out_lane) {
-            const int px = s[(t.y + y) * ss + t.x + c];
-            int v = 0;
+            const int px = s[(ty + y) * ss + t.x + c];
+            int acc = 0;
             if (do3) {
                 const int *A0 = a3[(y - 1) & 3], *A1 = a3[y & 3], *A2 = a3[(y + 1) & 3];
                 const int *B0 = b3[(y - 1) & 3], *B1 = b3[y & 3], *B2 = b3[(y + 1) & 3];
                 const int i = lane;
                 const int a = (B1[i] + B1[i - 1] + B1[i + 1] + B0[i] + B2[i]) * 4 + (B0[i - 1] + B2[i - 1] + B0[i + 1] + B2[i + 1]) * 3;
                 const int b = (A1[i] + A1[i - 1] + A1[i + 1] + A0[i] + A2[i]) * 4 + (A0[i - 1] + A2[i - 1] + A0[i + 1] + A2[i + 1]) * 3;
-                v += w1 * ((b - a * px + (1 << 8)) >> 9);
+                acc += w1 * ((b - a * px + (1 << 8)) >> 9);
             }
             if (do5) {
                 const int i = lane;
@@ -228,9 +252,9 @@ __global__ __launch_bounds__(64) void sgr_kernel(const DevPlanes dst, const DevP
                     const int b = a5[k][i] * 6 + (a5[k][i - 1] + a5[k][i + 1]) * 5;
                     t5 = (b - a * px + (1 << 7)) >> 8;
                 }
-                v += w0 * t5;
+                acc += w0 * t5;
             }
-            d[y * dst.stride[pl]] = (pixel) dv::iclip(px + ((v + (1 << 10)) >> 11), 0, bitdepth_max);
+            d[y * dst.stride[pl]] = (pixel) dv::iclip(px + ((acc + (1 << 10)) >> 11), 0, bitdepth_max);
         }
         dv::wave_sync();
     }
@@ -252,15 +276,41 @@ extern "C" int dav1d_hip_launch_wiener(const DevPlanes *dst, const DevPlanes *sr
     return hip_rc(hipGetLastError());
 }
 
+// tasks: DEVICE, the self-guided tasks sorted into rows (dav1d_hip_sgr_make_rows); waves: DEVICE wave descriptors
 extern "C" int dav1d_hip_launch_sgr(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
-                                    const Dav1dHipLrTask *tasks, int n, int max_w, void *stream)
+                                    const Dav1dHipLrTask *tasks, const void *waves, int n_waves, void *stream)
 {
-    if (n <= 0) return 0;
+    if (n_waves <= 0) return 0;
     const int bitdepth_max = (1 << bpc) - 1;
-    const dim3 grid(((max_w < 1 ? 1 : max_w > 384 ? 384 : max_w) + 61) / 62, n, (64 + LR_SEG - 1) / LR_SEG);   // 62 output columns per wave
     if (bpc == 8)
-        hipLaunchKernelGGL((sgr_kernel<uint8_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks, n, bitdepth_max);
+        hipLaunchKernelGGL((sgr_kernel<uint8_t>), dim3(n_waves), dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks,
+                           (const SgrWave *) waves, n_waves, bitdepth_max);
     else
-        hipLaunchKernelGGL((sgr_kernel<uint16_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks, n, bitdepth_max);
+        hipLaunchKernelGGL((sgr_kernel<uint16_t>), dim3(n_waves), dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks,
+                           (const SgrWave *) waves, n_waves, bitdepth_max);
     return hip_rc(hipGetLastError());
+}
+
+// Self-guided tasks -> rows (same plane, y, height; sorted by x, in place) and the waves that cover them, appended to `waves` as
+// 16-byte descriptors { first task, end task, virtual column of lane 0 inside the first task, 0 }; task indices count from tasks[0].
+void dav1d_hip_sgr_make_rows(Dav1dHipLrTask *tasks, size_t n, std::vector<uint32_t> &waves) {
+    std::stable_sort(tasks, tasks + n, [](const Dav1dHipLrTask &a, const Dav1dHipLrTask &b) {
+        if (a.plane != b.plane) return a.plane < b.plane;
+        if (a.y != b.y) return a.y < b.y;
+        if (a.h != b.h) return a.h < b.h;
+        return a.x < b.x;
+    });
+    for (size_t r0 = 0; r0 < n;) {
+        size_t r1 = r0 + 1;
+        while (r1 < n && tasks[r1].plane == tasks[r0].plane && tasks[r1].y == tasks[r0].y && tasks[r1].h == tasks[r0].h) r1++;
+        long total = 0;
+        for (size_t i = r0; i < r1; i++) total += tasks[i].w + 2;
+        size_t ti = r0;
+        long start = 0;                 // virtual position where task ti begins
+        for (long p0 = 0; p0 + 2 < total; p0 += 62) {
+            while (p0 >= start + tasks[ti].w + 2) { start += tasks[ti].w + 2; ti++; }
+            waves.push_back((uint32_t) ti); waves.push_back((uint32_t) r1); waves.push_back((uint32_t) (int32_t) (p0 - start)); waves.push_back(0);
+        }
+        r0 = r1;
+    }
 }

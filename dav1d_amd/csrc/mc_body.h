@@ -143,9 +143,10 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
 #pragma unroll
                 for (int k = 0; k < NLD; k++) {
                     const int i = dv::imin(l + k * LPT, (WR - 1) * NCH - 1);
-                    const pixel *p = base + (i / NCH) * rs + 8 * (i % NCH);
+                    const int wr = dv::div_small<NCH>(i);               // row and 8-pixel piece of the window; the offset stays in 32 bits
+                    const pixel *p = base + (dv::mul_i24(wr, rs) + 8 * (i - wr * NCH));
                     ld[k] = make_uint4(0, 0, 0, 0);
-                    if (i / NCH < row_lo || i / NCH >= row_hi) continue;
+                    if (wr < row_lo || wr >= row_hi) continue;
                     if (HBD) {
                         const U128u v = *reinterpret_cast<const U128u *>(p);
                         ld[k] = make_uint4(v.a, v.b, v.c, v.d);
@@ -159,12 +160,13 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
                 for (int k = 0; k < NLD; k++) {
                     const int i = l + k * LPT;
                     if (i >= (WR - 1) * NCH) continue;
-                    int16_t *const wp = win + (i / NCH) * WS + 8 * (i % NCH);
+                    const int wr = dv::div_small<NCH>(i);
+                    int16_t *const wp = win + wr * WS + 8 * (i - wr * NCH);
                     if (WS % 8 == 0) {
                         *reinterpret_cast<uint4 *>(wp) = ld[k];
                     } else {        // 12-column rows: 8-byte stores, the last chunk keeps only its first half
                         *reinterpret_cast<uint2 *>(wp) = make_uint2(ld[k].x, ld[k].y);
-                        if (8 * (i % NCH) + 8 <= WS) *reinterpret_cast<uint2 *>(wp + 4) = make_uint2(ld[k].z, ld[k].w);
+                        if (8 * (i - wr * NCH) + 8 <= WS) *reinterpret_cast<uint2 *>(wp + 4) = make_uint2(ld[k].z, ld[k].w);
                     }
                 }
             } else {
@@ -305,7 +307,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
             } else if (t.kind == MCT_WAVG) {
 #pragma unroll
                 for (int x = 0; x < 4; x++)
-                    o[x] = (acc0[r][x] * t.weight + q[r][x] * (16 - t.weight) + (8 << ib) + bias * 16) >> (ib + 4);  // w_avg_c
+                    o[x] = dv::mad_i24(acc0[r][x], t.weight, dv::mad_i24(q[r][x], 16 - t.weight, (8 << ib) + bias * 16)) >> (ib + 4);  // w_avg_c
             } else {
 #pragma unroll
                 for (int x = 0; x < 4; x++) o[x] = q[r][x];
@@ -313,7 +315,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
             const int nvalid = dv::imin(4, t.w - 4 * vs);
             if (t.kind != MCT_PREP) {
 #pragma unroll
-                for (int x = 0; x < 4; x++) o[x] = dv::iclip(o[x], 0, bitdepth_max);
+                for (int x = 0; x < 4; x++) o[x] = dv::clamp3(o[x], 0, bitdepth_max);
                 // PUT_TMP: pixels into the scratch arena, row stride = block width (the reference's `lap` buffer of obmc())
                 pixel *d = t.kind == MCT_PUT_TMP
                     ? reinterpret_cast<pixel *>(prep) + t.dst_off + (t.oy + vr) * t.bw + t.ox + 4 * vs

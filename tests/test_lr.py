@@ -75,16 +75,22 @@ def test_wiener_matches_reference(ctx, bpc):
         o.free()
 
 
-@pytest.mark.parametrize("bpc", [8, 10, 12])
-def test_sgr_matches_reference(ctx, bpc):
-    """sgr_5x5 / sgr_3x3 / sgr_mix with the parameter sets of dav1d_sgr_params and the weight ranges of
-    tests/checkasm/looprestoration.c:137-195."""
-    import ctypes as C
+def _sgr_task(rng, sgr_params, x, y, w, h, edges):
+    set_idx = int(rng.integers(0, 16))
+    s0, s1 = int(sgr_params[set_idx][0]), int(sgr_params[set_idx][1])
+    typ = 2 + (1 if not s0 else 0 if not s1 else 2)          # 2: 5x5, 3: 3x3, 4: mix
+    w0 = int(rng.integers(-96, 32))
+    w1 = 128 - (w0 + int(rng.integers(-32, 96)))
+    f = np.zeros((2, 8), np.int16)
+    f[0, :4] = (s0, s1, w0, w1)
+    return (x, y, w, h, 0, edges, typ, 0, f)
+
+
+def _check_sgr(ctx, bpc, rng, make_tasks):
     import struct
     oracle = util.default_oracle()
     import golden_cases
     sgr_params = np.array(golden_cases.SGR_PARAMS, np.uint16)      # == av1_sgr_params, checked against the reference in test_abi
-    rng = np.random.default_rng(2500 + bpc)
     W, H = 1024, 512
     src = ctx.picture(W, H, api.LAYOUT_I400, bpc)
     lpf = ctx.picture(W, H, api.LAYOUT_I400, bpc)
@@ -98,26 +104,10 @@ def test_sgr_matches_reference(ctx, bpc):
     src.upload(0, sp); lpf.upload(0, lp); dst.upload(0, dp)
     want = synth.copy_planes([dp])[0]
     stride_px = src.stride_px(0)
-    t = np.zeros(64, api.LR_TASK)
-    k = 0
-    y = 8
-    while y + 70 < H:
-        x = 8
-        while x + 400 < W:
-            w = int(rng.choice([int(rng.integers(1, 385)), int(rng.integers(1, 12)), 384, 64]))
-            h = int(rng.choice([int(rng.integers(1, 65)), int(rng.integers(1, 9)), 64]))
-            set_idx = int(rng.integers(0, 16))
-            s0, s1 = int(sgr_params[set_idx][0]), int(sgr_params[set_idx][1])
-            typ = 2 + (1 if not s0 else 0 if not s1 else 2)          # 2: 5x5, 3: 3x3, 4: mix
-            w0 = int(rng.integers(-96, 32))
-            w1 = 128 - (w0 + int(rng.integers(-32, 96)))
-            f = np.zeros((2, 8), np.int16)
-            f[0, :4] = (s0, s1, w0, w1)
-            t[k] = (x, y, w, h, 0, k % 16 if k < 32 else int(rng.integers(0, 16)), typ, 0, f)
-            k += 1
-            x += 400
-        y += 72
-    t = t[:k]
+    rows = make_tasks(rng, sgr_params, W, H)
+    t = np.zeros(len(rows), api.LR_TASK)
+    for i, v in enumerate(rows):
+        t[i] = v
     bps = want.itemsize
     lbase = lp.base
     for i in range(len(t)):
@@ -127,7 +117,7 @@ def test_sgr_matches_reference(ctx, bpc):
         L = np.zeros((8, stride_px), sp.dtype)
         L[0], L[1], L[6], L[7] = lbase[y - 2], lbase[y - 1], lbase[y + h], lbase[y + h + 1]
         s0, s1, w0, w1 = (int(v) for v in t[i]["filter"][0][:4])
-        params = np.frombuffer(struct.pack("<IIhh", s0, s1, w0, w1) + b"\\0" * 20, np.uint8).copy()
+        params = np.frombuffer(struct.pack("<IIhh", s0, s1, w0, w1) + b"\0" * 20, np.uint8).copy()
         oracle.call(bpc, "sgr", int(t[i]["type"]) - 2, 0, work.ctypes.data + (y * stride_px + x) * bps, work.strides[0],
                     left, L.ctypes.data + x * bps, w, h, params, int(t[i]["edges"]))
         want[y:y + h, x:x + w] = work[y:y + h, x:x + w]
@@ -142,3 +132,45 @@ def test_sgr_matches_reference(ctx, bpc):
     assert set(t["type"]) == {2, 3, 4}
     for o in (src, lpf, dst):
         o.free()
+
+
+@pytest.mark.parametrize("bpc", [8, 10, 12])
+def test_sgr_matches_reference(ctx, bpc):
+    """sgr_5x5 / sgr_3x3 / sgr_mix with the parameter sets of dav1d_sgr_params and the weight ranges of
+    tests/checkasm/looprestoration.c:137-195."""
+    def make(rng, sgr_params, W, H):
+        out = []
+        y = 8
+        while y + 70 < H:
+            x = 8
+            while x + 400 < W:
+                w = int(rng.choice([int(rng.integers(1, 385)), int(rng.integers(1, 12)), 384, 64]))
+                h = int(rng.choice([int(rng.integers(1, 65)), int(rng.integers(1, 9)), 64]))
+                k = len(out)
+                out.append(_sgr_task(rng, sgr_params, x, y, w, h, k % 16 if k < 32 else int(rng.integers(0, 16))))
+                x += 400
+            y += 72
+        return out
+    _check_sgr(ctx, bpc, np.random.default_rng(2500 + bpc), make)
+
+
+@pytest.mark.parametrize("bpc", [8, 10])
+def test_sgr_units_of_a_row_share_waves(ctx, bpc):
+    """Rows of units with the same y and height — adjacent, with gaps, one to seventy pixels wide, of all three filter types and with
+    every edge combination side by side: the kernel lays the units of a row out in one run of columns and cuts the run into waves
+    (lr.hip), so a wave holds the end of one unit, whole small units and the start of the next."""
+    def make(rng, sgr_params, W, H):
+        out = []
+        y = 8
+        while y + 70 < H:
+            h = int(rng.choice([64, 64, 56, int(rng.integers(1, 65)), 2, 5]))
+            x = 8
+            while True:
+                w = int(rng.choice([64, 64, 32, int(rng.integers(1, 8)), int(rng.integers(1, 71)), 1, 60, 61, 62, 63]))
+                if x + w + 8 > W:
+                    break
+                out.append(_sgr_task(rng, sgr_params, x, y, w, h, int(rng.integers(0, 16))))
+                x += w + int(rng.choice([0, 0, 0, 3, 17]))
+            y += 72
+        return out
+    _check_sgr(ctx, bpc, np.random.default_rng(2600 + bpc), make)
