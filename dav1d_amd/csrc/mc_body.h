@@ -29,9 +29,11 @@ __device__ __forceinline__ Taps load_taps(const int set, const int m) {
 }
 
 constexpr int mc_cmin(int a, int b) { return a < b ? a : b; }
-// window row stride in pixels: TW + 8 columns rounded up to whole 16-byte chunks; 4-wide tiles keep exactly the 12 columns
-// the 4-tap / 8-tap rows reach (8-byte aligned rows are enough for the 8-byte reads of the horizontal pass)
-constexpr int mc_win_stride(int tw) { return tw == 4 ? 12 : (tw + 8 + 7) & ~7; }
+// window row stride in pixels: TW + 8 columns rounded up to whole 16-byte chunks.  4-wide tiles: blocks of width 4 are only ever
+// filtered with the 4-tap sets, bilinear or the unit tap (reference src/mc_tmpl.c GET_H_FILTER: w > 4 ? type : 3 + (type & 1);
+// the host builds the tiles by the same rule, capi.hip), whose taps 0, 1, 6 and 7 are zero: the 4 outputs of a row reach the 7
+// columns src_x - 1 .. src_x + 5, so the window starts at src_x - 2 and is one 16-byte piece per row
+constexpr int mc_win_stride(int tw) { return tw == 4 ? 8 : (tw + 8 + 7) & ~7; }
 
 // LDS bytes one wave needs for tile shape (TW, TH): window + row-pair intermediate + the tile records
 template <int TW, int TH>
@@ -58,6 +60,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
     constexpr int NCH = (WS + 7) / 8;                   // 8-pixel (16-byte) chunks fetched per window row
     constexpr int NPR = WR / 2;                         // row pairs of the intermediate
     constexpr int NLD = ((WR - 1) * NCH + LPT - 1) / LPT;   // window loads per lane
+    constexpr bool NARROW = TW == 4;                        // window columns start at src_x - 2 instead of src_x - 4, taps 2 .. 5 only
     constexpr bool HBD = sizeof(pixel) == 2;
 
     int16_t *const win_s = reinterpret_cast<int16_t *>(smem);
@@ -133,7 +136,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
                 src = reinterpret_cast<const pixel *>((uint64_t) pd[0] | ((uint64_t) pd[1] << 32));
                 rs = (int) rt[6 + t.plane]; rw = (int) rt[9 + t.plane]; rh = (int) rt[12 + t.plane];
             }
-            const int x0 = rf.src_x - 4, y0 = rf.src_y - 3;
+            const int x0 = rf.src_x - (NARROW ? 2 : 4), y0 = rf.src_y - 3;
             const bool interior = x0 >= 0 && y0 >= 0 && x0 + NCH * 8 <= rw && y0 + WR - 1 <= rh;
             if (interior) {
                 // 16-byte (8-pixel) loads, rows at arbitrary 2-byte alignment; all of a lane's loads are
@@ -204,14 +207,25 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
                     const uint2 *wp = reinterpret_cast<const uint2 *>(win + (2 * pr + e) * WS + 4 * s);
-                    const uint2 a = wp[0], b = wp[1], c = wp[2];
-                    const uint32_t d[6] = { a.x, a.y, b.x, b.y, c.x, c.y };
-                    // out x sums f[k] * p[x + 1 + k], p[] = the 12 pixels of d[]; the rounding offset seeds the sum
                     int s0 = rnd1, s1 = rnd1, s2 = rnd1, s3 = rnd1;
+                    if constexpr (NARROW) {
+                        // out x sums f[k] * p[x - 1 + k] over k = 2 .. 5, p[] = the 8 pixels of the row: the tap pairs (f1, f2) (f3, f4)
+                        // (f5, f6) and (f2, f3) (f4, f5) of the 8-tap layout meet pixel pairs two columns further left
+                        const uint2 a = wp[0], b = wp[1];
+                        const uint32_t d[4] = { a.x, a.y, b.x, b.y };
 #pragma unroll
-                    for (int k = 0; k < 5; k++) { s0 = dv::dot2(d[k], fh.od[k], s0); s2 = dv::dot2(d[k + 1], fh.od[k], s2); }
+                        for (int k = 0; k < 3; k++) { s0 = dv::dot2(d[k], fh.od[k + 1], s0); s2 = dv::dot2(d[k + 1], fh.od[k + 1], s2); }
 #pragma unroll
-                    for (int k = 0; k < 4; k++) { s1 = dv::dot2(d[k + 1], fh.ev[k], s1); s3 = dv::dot2(d[k + 2], fh.ev[k], s3); }
+                        for (int k = 0; k < 2; k++) { s1 = dv::dot2(d[k + 1], fh.ev[k + 1], s1); s3 = dv::dot2(d[k + 2], fh.ev[k + 1], s3); }
+                    } else {
+                        const uint2 a = wp[0], b = wp[1], c = wp[2];
+                        const uint32_t d[6] = { a.x, a.y, b.x, b.y, c.x, c.y };
+                        // out x sums f[k] * p[x + 1 + k], p[] = the 12 pixels of d[]; the rounding offset seeds the sum
+#pragma unroll
+                        for (int k = 0; k < 5; k++) { s0 = dv::dot2(d[k], fh.od[k], s0); s2 = dv::dot2(d[k + 1], fh.od[k], s2); }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { s1 = dv::dot2(d[k + 1], fh.ev[k], s1); s3 = dv::dot2(d[k + 2], fh.ev[k], s3); }
+                    }
                     o[e][0] = s0; o[e][1] = s1; o[e][2] = s2; o[e][3] = s3;
                 }
                 if (has_v) {
