@@ -89,15 +89,15 @@ __global__ __launch_bounds__(64) void wiener_kernel(const DevPlanes dst, const D
         if (!HBD) sum += row[t.x + xc] * 128;
 #pragma unroll
         for (int i = 0; i < 7; i++) sum += row[col[i]] * fh[i];
-        sum = dv::iclip((sum + rounding_off_h) >> round_bits_h, 0, clip_limit - 1);
+        sum = dv::clamp3((sum + rounding_off_h) >> round_bits_h, 0, clip_limit - 1);
 #pragma unroll
         for (int i = 0; i < 6; i++) win[i] = win[i + 1];
         win[6] = sum;
         if (r >= seg0 + 3) {
             int v = -round_offset;
 #pragma unroll
-            for (int k = 0; k < 7; k++) v += win[k] * fv[k];
-            if (active) d[(r - 3) * dst.stride[pl]] = (pixel) dv::iclip((v + rounding_off_v) >> round_bits_v, 0, bitdepth_max);
+            for (int k = 0; k < 7; k++) v = dv::mad_i24(win[k], fv[k], v);       // win < 2^16 (clip_limit), 16-bit taps: the full-rate multiplier
+            if (active) d[(r - 3) * dst.stride[pl]] = (pixel) dv::clamp3((v + rounding_off_v) >> round_bits_v, 0, bitdepth_max);
         }
     }
 }
@@ -236,7 +236,8 @@ __global__ __launch_bounds__(64) void sgr_kernel(const DevPlanes dst, const DevP
                 const int i = lane;
                 const int a = (B1[i] + B1[i - 1] + B1[i + 1] + B0[i] + B2[i]) * 4 + (B0[i - 1] + B2[i - 1] + B0[i + 1] + B2[i + 1]) * 3;
                 const int b = (A1[i] + A1[i - 1] + A1[i + 1] + A0[i] + A2[i]) * 4 + (A0[i - 1] + A2[i - 1] + A0[i + 1] + A2[i + 1]) * 3;
-                acc += w1 * ((b - a * px + (1 << 8)) >> 9);
+                // a <= 32 * 255, px < 2^12, |(b - a * px) >> 9| < 2^17, 8-bit weights: every product fits the 24-bit multiplier
+                acc = dv::mad_i24(w1, (b - (int) dv::mul_u24((unsigned) a, (unsigned) px) + (1 << 8)) >> 9, acc);
             }
             if (do5) {
                 const int i = lane;
@@ -245,16 +246,16 @@ __global__ __launch_bounds__(64) void sgr_kernel(const DevPlanes dst, const DevP
                     const int k0 = ((y - 1) >> 1) & 1, k1 = ((y + 1) >> 1) & 1;
                     const int a = (b5[k0][i] + b5[k1][i]) * 6 + (b5[k0][i - 1] + b5[k1][i - 1] + b5[k0][i + 1] + b5[k1][i + 1]) * 5;
                     const int b = (a5[k0][i] + a5[k1][i]) * 6 + (a5[k0][i - 1] + a5[k1][i - 1] + a5[k0][i + 1] + a5[k1][i + 1]) * 5;
-                    t5 = (b - a * px + (1 << 8)) >> 9;
+                    t5 = (b - (int) dv::mul_u24((unsigned) a, (unsigned) px) + (1 << 8)) >> 9;
                 } else {
                     const int k = (y >> 1) & 1;
                     const int a = b5[k][i] * 6 + (b5[k][i - 1] + b5[k][i + 1]) * 5;
                     const int b = a5[k][i] * 6 + (a5[k][i - 1] + a5[k][i + 1]) * 5;
-                    t5 = (b - a * px + (1 << 7)) >> 8;
+                    t5 = (b - (int) dv::mul_u24((unsigned) a, (unsigned) px) + (1 << 7)) >> 8;
                 }
-                acc += w0 * t5;
+                acc = dv::mad_i24(w0, t5, acc);
             }
-            d[y * dst.stride[pl]] = (pixel) dv::iclip(px + ((acc + (1 << 10)) >> 11), 0, bitdepth_max);
+            d[y * dst.stride[pl]] = (pixel) dv::clamp3(px + ((acc + (1 << 10)) >> 11), 0, bitdepth_max);
         }
         dv::wave_sync();
     }
