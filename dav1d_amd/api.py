@@ -9,7 +9,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import FilmGrainData  # noqa: F401
-from ._lib import ITX_TASK, MC_TASK, COMP_TASK, CDEF_TASK, LF_TASK, IPRED_TASK, LR_TASK, WARP_TASK, MC_SCALED_TASK, Picture  # noqa: F401  (re-exported)
+from ._lib import ITX_TASK, MC_TASK, COMP_TASK, CDEF_TASK, LF_TASK, IPRED_TASK, LR_TASK, WARP_TASK, MC_SCALED_TASK, Picture, HostPicture  # noqa: F401  (re-exported)
 
 LAYOUT_I400, LAYOUT_I420, LAYOUT_I422, LAYOUT_I444 = 0, 1, 2, 3
 
@@ -420,6 +420,40 @@ class _IntraFlow:
             self.h = C.c_void_p()
 
 
+class HostPictureBuf:
+    """dav1d_hip_host_picture_*: pinned host planes + the device picture of the same geometry (the buffers behind a
+    Dav1dPicAllocator, reference include/dav1d/picture.h)."""
+
+    def __init__(self, ctx, w, h, layout, bpc):
+        self.ctx = ctx
+        self.hp = HostPicture()
+        _chk(ctx.lib.dav1d_hip_host_picture_alloc(ctx.h, C.byref(self.hp), w, h, layout, bpc), "host_picture_alloc")
+        self.w, self.h, self.layout, self.bpc = w, h, layout, bpc
+
+    @property
+    def dev(self):
+        return self.hp.dev
+
+    def fetch(self, src=None, row0=0, row1=1 << 30):
+        _chk(self.ctx.lib.dav1d_hip_host_picture_fetch(self.ctx.h, C.byref(self.hp), C.byref(src) if src is not None else None, row0, row1),
+             "host_picture_fetch")
+
+    def wait(self):
+        _chk(self.ctx.lib.dav1d_hip_host_picture_wait(self.ctx.h), "host_picture_wait")
+
+    def plane(self, pl):
+        """numpy view of host plane pl (visible w x h)."""
+        p = self.hp.dev.p[pl]
+        dt = np.uint16 if self.bpc > 8 else np.uint8
+        stride = self.hp.stride[1 if pl else 0]
+        buf = (C.c_uint8 * (stride * p.h)).from_address(self.hp.data[pl])
+        return np.frombuffer(buf, dtype=dt).reshape(p.h, stride // dt().itemsize)[:, :p.w]
+
+    def release(self):
+        if self.hp.alloc:
+            _chk(self.ctx.lib.dav1d_hip_host_picture_release(self.ctx.h, C.byref(self.hp)), "host_picture_release")
+
+
 class FrameInFlight:
     """dav1d_hip_frame_*: one frame in flight (driver-level boundary)."""
 
@@ -473,6 +507,13 @@ class FrameInFlight:
 
     def progress(self):
         return int(self.ctx.lib.dav1d_hip_frame_progress(self.h))
+
+    def set_progress_callback(self, fn):
+        """dav1d_hip_frame_set_progress_callback: fn(rows, picture) on the thread that ends the frame, every time more rows of the
+        filtered picture are final (a Picture descriptor valid during the call)."""
+        cb_t = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(Picture))
+        self._pcb = cb_t(lambda cookie, rows, pic: fn(rows, pic.contents)) if fn else C.cast(None, cb_t)
+        _chk(self.ctx.lib.dav1d_hip_frame_set_progress_callback(self.h, self._pcb, None), "frame_set_progress_callback")
 
     def wait(self):
         filtered = Picture()

@@ -216,6 +216,66 @@ int dav1d_hip_picture_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic, int w, int
     return 0;
 }
 
+// Host side of a Dav1dPicAllocator: pinned planes with the geometry of the device picture (= the reference's default allocator,
+// src/picture.c:46-82)
+int dav1d_hip_host_picture_alloc(Dav1dHipContext *c, Dav1dHipHostPicture *hp, int w, int h, int layout, int bpc) {
+    if (!c || !hp) return -EINVAL;
+    memset(hp, 0, sizeof(*hp));
+    const int rc = dav1d_hip_picture_alloc(c, &hp->dev, w, h, layout, bpc);
+    if (rc) return rc;
+    void *buf = nullptr;
+    if (hipHostMalloc(&buf, hp->dev.alloc_size, hipHostMallocDefault) != hipSuccess) {
+        (void) dav1d_hip_picture_free(c, &hp->dev);
+        memset(hp, 0, sizeof(*hp));
+        return -ENOMEM;
+    }
+    hp->alloc = buf;
+    hp->alloc_size = hp->dev.alloc_size;
+    for (int i = 0; i < 3; i++)
+        hp->data[i] = hp->dev.p[i].data ? (uint8_t *) buf + ((const uint8_t *) hp->dev.p[i].data - (const uint8_t *) hp->dev.alloc) : nullptr;
+    hp->stride[0] = hp->dev.p[0].stride;
+    hp->stride[1] = hp->dev.p[1].stride;
+    return 0;
+}
+
+int dav1d_hip_host_picture_release(Dav1dHipContext *c, Dav1dHipHostPicture *hp) {
+    if (!c || !hp) return -EINVAL;
+    (void) hipStreamSynchronize(c->copy_stream);
+    int rc = 0;
+    if (hp->alloc) rc = hip_rc(hipHostFree(hp->alloc));
+    const int rc2 = dav1d_hip_picture_free(c, &hp->dev);
+    memset(hp, 0, sizeof(*hp));
+    return rc ? rc : rc2;
+}
+
+int dav1d_hip_host_picture_fetch(Dav1dHipContext *c, const Dav1dHipHostPicture *hp, const Dav1dHipPicture *src, int row0, int row1) {
+    if (!c || !hp || !hp->alloc) return -EINVAL;
+    if (!src) src = &hp->dev;
+    if (src->bpc != hp->dev.bpc || src->layout != hp->dev.layout || src->p[0].w != hp->dev.p[0].w || src->p[0].h != hp->dev.p[0].h) return -EINVAL;
+    if (row0 < 0) row0 = 0;
+    if (row1 > src->p[0].h) row1 = src->p[0].h;
+    if (row1 <= row0) return 0;
+    const int ss_ver = src->layout == DAV1D_HIP_LAYOUT_I420, bps = src->bpc > 8 ? 2 : 1;
+    for (int pl = 0; pl < 3; pl++) {
+        if (!src->p[pl].data || !hp->data[pl]) continue;
+        const int sv = pl ? ss_ver : 0;
+        // chroma rows under luma rows [row0, row1): a band boundary is even, the last band ends with the picture
+        const int r0 = row0 >> sv, r1 = row1 >= src->p[0].h ? src->p[pl].h : row1 >> sv;
+        if (r1 <= r0) continue;
+        const ptrdiff_t hs = hp->stride[pl ? 1 : 0];
+        const hipError_t e = hipMemcpy2DAsync((uint8_t *) hp->data[pl] + (size_t) r0 * hs, hs,
+                                              (const uint8_t *) src->p[pl].data + (size_t) r0 * src->p[pl].stride, src->p[pl].stride,
+                                              (size_t) src->p[pl].w * bps, r1 - r0, hipMemcpyDeviceToHost, c->copy_stream);
+        if (e != hipSuccess) return hip_rc(e);
+    }
+    return 0;
+}
+
+int dav1d_hip_host_picture_wait(Dav1dHipContext *c) {
+    if (!c) return -EINVAL;
+    return hip_rc(hipStreamSynchronize(c->copy_stream));
+}
+
 int dav1d_hip_picture_free(Dav1dHipContext *c, Dav1dHipPicture *pic) {
     if (!pic || !pic->alloc) return 0;
     hipStreamSynchronize(c->stream);

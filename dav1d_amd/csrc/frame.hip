@@ -60,6 +60,14 @@ struct Dav1dHipFrame {
     int post_bands;                  // bands the post filters of the last dav1d_hip_frame_end ran in (0: stage by stage)
     std::thread worker;              // dav1d_hip_frame_end_async
     std::atomic<int> progress_rows;
+    void (*progress_cb)(void *cookie, int rows, const Dav1dHipPicture *pic) = nullptr;
+    void *progress_cookie = nullptr;
+    // rows of the filtered picture that are final: stored for dav1d_hip_frame_progress, handed to the callback
+    void publish(int rows, const Dav1dHipPicture *pic) {
+        if (rows <= progress_rows.load()) return;
+        progress_rows.store(rows);
+        if (progress_cb) progress_cb(progress_cookie, rows, pic);
+    }
     int async_rc;
     Dav1dHipPicture async_filtered;
 };
@@ -186,8 +194,18 @@ static int post_filters_pipelined(Dav1dHipFrame *f, const Dav1dHipPicture **last
     const Dav1dHipLfTask *d_lf = reinterpret_cast<const Dav1dHipLfTask *>(dev);
     const Dav1dHipCdefTask *d_cdef = reinterpret_cast<const Dav1dHipCdefTask *>(dev + o_cdef);
     const Dav1dHipLrTask *d_lr = reinterpret_cast<const Dav1dHipLrTask *>(dev + o_lr);
-    std::vector<hipEvent_t> ev(2 * nb, nullptr);
-    for (int k = 0; k < 2 * nb && !rc; k++) rc = hip_rc(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+    std::vector<hipEvent_t> ev(3 * nb, nullptr);       // [0, nb): deblocked, [nb, 2nb): CDEF done, [2nb, 3nb): the band's last stage done
+    for (int k = 0; k < 3 * nb && !rc; k++) rc = hip_rc(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+    // luma rows that are final once the last stage of band b is through: restoration stripes start 8 rows above the 64-row grid, so
+    // a band's last stripe reaches into the next band's rows and the first rows of a band belong to the band before it
+    std::vector<int> final_rows(nb, H);
+    for (int b = nb - 2; b >= 0; b--) final_rows[b] = std::min(final_rows[b + 1], (b + 1) * band_h);
+    if (has_lr) {
+        std::vector<int> first_y(nb + 1, H);
+        for (size_t i = 0; i < f->lr.size(); i++)
+            first_y[lr_b[i]] = std::min(first_y[lr_b[i]], (int) f->lr[i].y << (f->lr[i].plane ? ss_ver : 0));
+        for (int b = nb - 1; b >= 0; b--) { first_y[b] = std::min(first_y[b], first_y[b + 1]); final_rows[b] = first_y[b + 1]; }
+    }
     const Dav1dHipPicture *cdef_out = has_cdef ? &f->tmp[0] : &f->cur;
     if (!rc) {
         const DevPlanes cur = dev_planes(&f->cur), t0 = dev_planes(&f->tmp[0]), t1 = dev_planes(&f->tmp[1]), co = dev_planes(cdef_out);
@@ -225,6 +243,7 @@ static int post_filters_pipelined(Dav1dHipFrame *f, const Dav1dHipPicture **last
                                                                    f->cdef_damping, nullptr, sb);
                 else if (n) rc = dav1d_hip_launch_cdef(&t0, &cur, f->cur.bpc, layout, d_cdef + cdef_off[bc], (int) n, f->cdef_damping, nullptr, 0, sb);
                 (void) hipEventRecord(ev[nb + bc], sb);
+                if (!has_lr) (void) hipEventRecord(ev[2 * nb + bc], sb);
             }
             const int br = b - 2;                    // restoration one band behind CDEF
             if (has_lr && br >= 0 && br < nb && !rc) {
@@ -234,6 +253,7 @@ static int post_filters_pipelined(Dav1dHipFrame *f, const Dav1dHipPicture **last
                 const size_t w0 = lr_off[2 * br], w1 = lr_off[2 * br + 1], w2 = lr_off[2 * br + 2];
                 if (w1 > w0) rc = dav1d_hip_launch_wiener(&t1, &co, &cur, f->cur.bpc, d_lr + w0, (int) (w1 - w0), 384, sc);
                 if (!rc && w2 > w1) rc = dav1d_hip_launch_sgr(&t1, &co, &cur, f->cur.bpc, d_lr + w1, dev + o_sw + 16 * sw_off[br], (int) (sw_off[br + 1] - sw_off[br]), sc);
+                (void) hipEventRecord(ev[2 * nb + br], sc);
             }
         }
         (void) hipEventRecord(c->ev_join[0], sb);
@@ -241,6 +261,13 @@ static int post_filters_pipelined(Dav1dHipFrame *f, const Dav1dHipPicture **last
         (void) hipStreamWaitEvent(sa, c->ev_join[0], 0);
         (void) hipStreamWaitEvent(sa, c->ev_join[1], 0);
         (void) hipEventRecord(c->ev_t1, sa);
+    }
+    // the bands come through in order: every band's rows are published as soon as its last stage is (reference
+    // src/thread_task.c:888-896, once per superblock row there)
+    const Dav1dHipPicture *const out_pic = has_lr ? &f->tmp[1] : cdef_out;
+    for (int b = 0; b < nb && !rc; b++) {
+        if (hipEventSynchronize(ev[2 * nb + b]) != hipSuccess) break;
+        if (b + 1 < nb) f->publish(final_rows[b], out_pic);         // the last band is published with the frame (frame_run)
     }
     (void) hipStreamSynchronize(c->stream);
     if (!rc) { c->last_ms = 0.f; (void) hipEventElapsedTime(&c->last_ms, c->ev_t0, c->ev_t1); }
@@ -608,10 +635,19 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
                          : dav1d_hip_fg_apply(c, grain_out, last, &f->grain, f->is_id);
     if (!rc) rc = dav1d_hip_sync(c);
     else (void) dav1d_hip_sync(c);
+    if (!rc) f->publish(f->cur.p[0].h, last);
     return rc;
 }
 
 extern "C" {
+
+int dav1d_hip_frame_set_progress_callback(Dav1dHipFrame *f, void (*progress)(void *cookie, int rows, const Dav1dHipPicture *pic), void *cookie) {
+    if (!f) return -EINVAL;
+    if (f->worker.joinable()) return -EBUSY;
+    f->progress_cb = progress;
+    f->progress_cookie = cookie;
+    return 0;
+}
 
 int dav1d_hip_frame_post_bands(const Dav1dHipFrame *f) { return f ? f->post_bands : 0; }
 
@@ -633,12 +669,11 @@ int dav1d_hip_frame_end_async(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8
         (void) hipSetDevice(f->c->device);
         const int rc = dav1d_hip_frame_end(f, coef, prep, mask, &f->async_filtered, have_g ? &g : nullptr);
         f->async_rc = rc;
-        if (!rc) f->progress_rows.store(f->cur.p[0].h);
         if (done) done(cookie, rc, &f->async_filtered);
     });
     return 0;
 }
-// rows of the picture that are final (all in-loop filters applied): 0 or the picture height
+// rows of the picture that are final (all in-loop filters applied)
 int dav1d_hip_frame_progress(const Dav1dHipFrame *f) { return f ? f->progress_rows.load() : -EINVAL; }
 // waits for the frame handed to dav1d_hip_frame_end_async; returns its result, *filtered as dav1d_hip_frame_end
 int dav1d_hip_frame_wait(Dav1dHipFrame *f, Dav1dHipPicture *filtered) {

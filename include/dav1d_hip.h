@@ -108,6 +108,25 @@ typedef struct Dav1dHipPicture {
 DAV1D_HIP_API int dav1d_hip_picture_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic,
                                           int w, int h, int layout, int bpc);
 DAV1D_HIP_API int dav1d_hip_picture_free(Dav1dHipContext *c, Dav1dHipPicture *pic);
+/* The buffers behind a Dav1dPicAllocator (reference include/dav1d/picture.h:89-133, default implementation
+ * src/picture.c:46-82): a decoded picture the application reads on the host — pinned memory, planes and strides laid out by the
+ * rules of dav1d_default_picture_alloc (dimensions rounded up to 128, 64 more bytes of stride where it would be a multiple of
+ * 1024, 64 bytes of slack at the end) — paired with the device picture the frame is reconstructed into, which has the same
+ * geometry.  alloc_picture_callback stores data[] / stride[] in the Dav1dPicture and the struct in allocator_data;
+ * release_picture_callback hands it back (INTEGRATION.md shows both).  dav1d_hip_host_picture_fetch copies luma rows
+ * [row0, row1) and the chroma rows under them from `src` (NULL: hp->dev; or the picture a frame reported as filtered) to the host
+ * planes on the context's copy stream and returns; dav1d_hip_host_picture_wait waits for the copies issued so far. */
+typedef struct Dav1dHipHostPicture {
+    void *data[3];             /* pinned host planes */
+    ptrdiff_t stride[2];       /* bytes: luma, chroma */
+    Dav1dHipPicture dev;       /* device picture of the same geometry */
+    void *alloc;               /* base of the host allocation */
+    size_t alloc_size;
+} Dav1dHipHostPicture;
+DAV1D_HIP_API int dav1d_hip_host_picture_alloc(Dav1dHipContext *c, Dav1dHipHostPicture *hp, int w, int h, int layout, int bpc);
+DAV1D_HIP_API int dav1d_hip_host_picture_release(Dav1dHipContext *c, Dav1dHipHostPicture *hp);
+DAV1D_HIP_API int dav1d_hip_host_picture_fetch(Dav1dHipContext *c, const Dav1dHipHostPicture *hp, const Dav1dHipPicture *src, int row0, int row1);
+DAV1D_HIP_API int dav1d_hip_host_picture_wait(Dav1dHipContext *c);
 /* host <-> device plane copies; host_stride in bytes; copies the PADDED plane
  * (aligned dimensions) when `padded` is non-zero, else the visible w x h. */
 DAV1D_HIP_API int dav1d_hip_plane_upload(Dav1dHipContext *c, const Dav1dHipPicture *pic, int plane,
@@ -593,12 +612,22 @@ DAV1D_HIP_API int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *pre
 DAV1D_HIP_API int dav1d_hip_frame_post_bands(const Dav1dHipFrame *f);
 /* The same without blocking the caller: the frame runs on a thread of the library; `done` (optional) is called on that thread
  * when every row of the frame is final — where a dav1d build stores f->sr_cur.progress[1] and signals the task threads
- * (reference src/thread_task.c:888-896; :393-439 is the waiting side).  dav1d_hip_frame_progress: rows that are final (the
- * stages run over whole pictures, so this is 0 or the picture height); dav1d_hip_frame_wait joins and returns the result. */
+ * (reference src/thread_task.c:888-896; :393-439 is the waiting side).  dav1d_hip_frame_progress: rows that are final (see
+ * dav1d_hip_frame_set_progress_callback for their granularity); dav1d_hip_frame_wait joins and returns the result. */
 DAV1D_HIP_API int dav1d_hip_frame_end_async(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask, const Dav1dHipPicture *grain_out,
                                             void (*done)(void *cookie, int rc, const Dav1dHipPicture *filtered), void *cookie);
 DAV1D_HIP_API int dav1d_hip_frame_progress(const Dav1dHipFrame *f);
 DAV1D_HIP_API int dav1d_hip_frame_wait(Dav1dHipFrame *f, Dav1dHipPicture *filtered);
+/* Row-granular progress, the reference's per-superblock-row publication (src/thread_task.c:888-896: after a row's last filter,
+ * `atomic_store(&f->sr_cur.progress[1], y)` and a broadcast): `progress` is called on the thread that ends the frame whenever
+ * more rows of the filtered picture have become final — `rows` luma rows from the top, living in `pic` (the picture
+ * dav1d_hip_frame_end reports as *filtered) — and once more with the picture height when the frame is through.  Rows arrive in
+ * steps of a band when the in-loop filters run banded (option post_bands >= 3: bands of whole 256-row superblock-row pairs, each
+ * followed through deblocking, CDEF and restoration; the band's event is waited for before the call), in one step otherwise.
+ * Set before dav1d_hip_frame_end / _end_async; the callback may copy the rows out (dav1d_hip_host_picture_fetch) but must not
+ * submit to the frame. */
+DAV1D_HIP_API int dav1d_hip_frame_set_progress_callback(Dav1dHipFrame *f, void (*progress)(void *cookie, int rows, const Dav1dHipPicture *pic),
+                                                        void *cookie);
 DAV1D_HIP_API void dav1d_hip_frame_destroy(Dav1dHipFrame *f);
 
 /* ------------------------------------------------------------- pass-2 lister */

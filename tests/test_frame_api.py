@@ -13,13 +13,16 @@ import test_postchain
 
 
 @pytest.mark.parametrize("bpc", [8, 10, 12])
-@pytest.mark.parametrize("bands", [8, 0, -1], ids=["banded", "staged", "staged-async-end"])
+@pytest.mark.parametrize("bands", [8, 0, -1, -8], ids=["banded", "staged", "staged-async-end", "banded-async-progress"])
 def test_frame_in_flight_matches_oracle(ctx, bpc, bands, monkeypatch):
     """bands: the post filters pipelined over superblock-row bands (three streams) / one stage after the other; -1: the latter
     through dav1d_hip_frame_end_async (the frame runs on a thread of the library, completion arrives through the callback and
-    dav1d_hip_frame_progress — the hook for dav1d's progress publication, src/thread_task.c:888-896)."""
+    dav1d_hip_frame_progress — the hook for dav1d's progress publication, src/thread_task.c:888-896); -8: banded and
+    asynchronous with the row-granular progress callback — every time rows are published they are copied out of the filtered
+    picture to pinned host planes (dav1d_hip_host_picture_*, the buffers behind a Dav1dPicAllocator) while the bands below are
+    still being filtered, and what was copied must be the final picture."""
     async_end = bands < 0
-    bands = max(bands, 0)
+    bands = 0 if bands == -1 else abs(bands)
     ctx.set_option("post_bands", bands)
 
     oracle = util.default_oracle()
@@ -78,12 +81,26 @@ def test_frame_in_flight_matches_oracle(ctx, bpc, bands, monkeypatch):
         f.submit_intra_step(k, pt, it)
     # loop restoration units must keep raster order: one submission per plane and stripe row
     f.submit_filter_sbrow(post.lf, post.cdef, post.lr)
+    host = None
     if async_end:
-        seen = []
+        seen, steps = [], []
         assert f.progress() == 0
+        if bands:
+            host = api.HostPictureBuf(ctx, w, h, api.LAYOUT_I420, bpc)
+
+            def on_rows(rows, pic):
+                host.fetch(pic, steps[-1] if steps else 0, rows)          # rows [previous, rows) are final: out they go
+                steps.append(rows)
+            f.set_progress_callback(on_rows)
         f.end_async(coef, prep, None, grain, done=lambda rc: seen.append((rc, f.progress())))
         filtered = f.wait()
         assert seen == [(0, h)] and f.progress() == h, seen
+        if bands:
+            nb = min(bands, (h + 255) // 256)
+            assert len(steps) == nb and steps == sorted(set(steps)) and steps[-1] == h, steps
+            # restoration stripes start 8 rows above the 64-row grid: a band's last stripe ends 56 rows into the next band
+            assert all(r % 256 == 56 for r in steps[:-1]), steps
+            host.wait()
     else:
         filtered = f.end(coef, prep, None, grain)
     assert f.post_bands() == (min(bands, (h + 255) // 256) if bands else 0)
@@ -94,6 +111,11 @@ def test_frame_in_flight_matches_oracle(ctx, bpc, bands, monkeypatch):
         assert np.array_equal(out.download(pl)[:vh, :vw], want[2][pl][:vh, :vw]), ("restored", pl)
         if want[3] is not None:
             assert np.array_equal(grain.download(pl)[:vh, :vw], want[3][pl][:vh, :vw]), ("grain", pl)
+        if host is not None:
+            assert np.array_equal(host.plane(pl)[:vh, :vw], want[2][pl][:vh, :vw]), ("rows copied out as they were published", pl)
+    if host is not None:
+        assert host.hp.stride[0] == cur.pic.p[0].stride and host.hp.stride[1] == cur.pic.p[1].stride
+        host.release()
     f.destroy()
     for o in [cur, grain, prep, coef, lvl] + refs:
         o.free()
