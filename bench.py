@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--edge-frac", type=float, default=0.05, help="fraction of blocks pointing outside the picture")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-inflight", action="store_true", help="skip the frames-in-flight leg of the full table")
     ap.add_argument("--packed", action="store_true", help="feed the residuals in the sparse wire format (DAV1D_HIP_ITX_PACKED)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (hand-off arrays -> lister -> device)")
     ap.add_argument("--e2e-tile-cols", type=int, default=16, help="tile columns of the end-to-end leg (one listing thread per tile)")
@@ -114,6 +115,103 @@ def step_traffic(w, h, bpc, a):
     if not files:
         return None
     return json.load(open(files[-1])).get("bytes_per_step")
+
+
+def frames_in_flight(api, device, frame, itx_tasks, coef_host, intra, post, ref_host, dst_host, w, h, bpc, want_res, n_ctx_list=(1, 2, 4, 8), n_frames=4):
+    """The full DSP table as dav1d's frame threading would drive it: n contexts (one per frame in flight, own streams), each
+    running whole frames — recon list, intra waves, deblock, CDEF, restoration, film grain — from device-resident lists, one host
+    thread per context.  Wall clock over n_frames frames per context, everything included (task-list uploads of the in-loop
+    filters, stream synchronisation between stages).  One frame in flight leaves the GPU to the ~50 dependent launches of the
+    intra waves for a third of the time; a second frame fills it.  The frames do not reference each other (in a stream, frames
+    in flight reference pictures that are already final, src/thread_task.c:416-433).  Every context's last picture is compared
+    with the stage-by-stage result that was checked against the oracle."""
+    import threading
+    out = {}
+    states = []
+
+    def make(k):
+        ctx = api.Context(device)
+        st = {"ctx": ctx}
+        st["refs"] = []
+        for rp in ref_host:
+            r = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+            for pl in range(3):
+                r.upload(pl, rp[pl])
+            st["refs"].append(r)
+        st["pics"] = [ctx.picture(w, h, api.LAYOUT_I420, bpc) for _ in range(4)]         # reconstructed / deblocked, CDEF, restored, grain
+        st["recon"] = ctx.recon_list(st["pics"][0], frame.mc, frame.comp, itx_tasks)
+        st["intra"] = ctx.intra_list(intra.batches)
+        st["prep"] = ctx.buffer(frame.prep_elems * 2)
+        st["prep"].zero()
+        st["coef"] = [ctx.buffer_from(coef_host) for _ in range(n_frames)]                # the residual launches zero what they read
+        st["icoef"] = [ctx.buffer_from(intra.coef) for _ in range(n_frames)]
+        st["lvl"] = ctx.buffer_from(post.lvl)
+        st["grain"] = ctx.fg_prepare(post.fg, bpc, api.LAYOUT_I420) if post.fg is not None else None
+        ctx.sync()
+        return st
+
+    def one_frame(st, i):
+        ctx = st["ctx"]
+        rec, cdf, res, grn = st["pics"]
+        st["recon"].run(rec, st["refs"], st["prep"], st["coef"][i])
+        for k in range(len(intra.batches)):
+            st["intra"].run_batch(k, rec, st["icoef"][i])
+        ctx.lf_batch(rec, post.lf, st["lvl"], post.b4_stride, post.lut_e, post.lut_i)
+        ctx.cdef_batch(cdf, rec, post.cdef, post.cdef_damping)
+        ctx.lr_batch(res, cdf, rec, post.lr)
+        if st["grain"] is not None:
+            ctx.fg_apply_prepared(grn, res, st["grain"])
+        ctx.sync()
+
+    def reset(st):
+        for pl in range(3):
+            st["pics"][0].upload(pl, dst_host[pl])
+        for b in st["coef"]:
+            b.upload(coef_host)
+        for b in st["icoef"]:
+            b.upload(intra.coef)
+        st["ctx"].sync()
+
+    try:
+        for n in n_ctx_list:
+            while len(states) < n:
+                states.append(make(len(states)))
+            for st in states[:n]:
+                reset(st)
+            errs = []
+
+            def work(st):
+                try:
+                    for i in range(n_frames):       # the blocks cover the picture: every frame rewrites all of it
+                        one_frame(st, i)
+                except Exception as e:      # noqa: BLE001
+                    errs.append(e)
+            th = [threading.Thread(target=work, args=(st,)) for st in states[:n]]
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            dt = time.perf_counter() - t0
+            if errs:
+                raise errs[0]
+            for st in states[:n]:
+                for pl in range(3):
+                    vh, vw = (h, w) if pl == 0 else (h // 2, w // 2)
+                    if not np.array_equal(st["pics"][2].download(pl)[:vh, :vw], want_res[pl][:vh, :vw]):
+                        raise SystemExit("bench: %d frames in flight: restored picture differs from the checked stage-by-stage result" % n)
+            out[str(n)] = round(dt / (n * n_frames) * 1e3, 4)
+    finally:
+        for st in states:
+            ctx = st["ctx"]
+            if st.get("grain") is not None:
+                ctx.fg_grain_destroy(st["grain"])
+            st["recon"].destroy()
+            st["intra"].destroy()
+            for o in st["refs"] + st["pics"] + st["coef"] + st["icoef"] + [st["prep"], st["lvl"]]:
+                o.free()
+            ctx.close()
+    return out
 
 
 def main():
@@ -568,6 +666,16 @@ def main():
                 post_piped = {"ms": round(ctx.last_kernel_ms(), 4), "bands": fr.post_bands(),
                               "stage_by_stage_ms": round(stage_ms["deblock"] + stage_ms["cdef"] + stage_ms["restoration"], 4)}
             fr.destroy()
+            in_flight = None
+            if not a.no_inflight and rank == 0 and world == 1 and not a.packed:
+                res_host = [res.download(pl) for pl in range(3)]
+                try:
+                    in_flight = frames_in_flight(api, local, frame, itx_tasks, coef_host, intra, post, ref_host, dst_host, w, h, bpc, res_host)
+                except SystemExit:
+                    raise
+                except Exception as e:       # noqa: BLE001  (a reported extra, never a reason to lose the line)
+                    in_flight = {"error": str(e)[:200]}
+                del res_host
             if grain_handle is not None:
                 ctx.fg_grain_destroy(grain_handle)
             for o in pics + [lvl]:
@@ -588,6 +696,10 @@ def main():
                     "film_grain_modes_ms": {"templates_then_apply_in_one_call": round(fg_one_call_ms, 4),
                                             "apply_with_templates_prepared_on_a_side_stream": round(stage_ms["film_grain"], 4)},
                     "post_filters_pipelined": post_piped,
+                    # wall clock per frame, everything included, with 1, 2, 4 and 8 frames in flight on this GPU (one context and host
+                    # thread per frame, the way dav1d's frame threading would drive the backend); ms_per_frame above is the sum of
+                    # the stages' device times of ONE frame
+                    "wall_ms_per_frame_by_frames_in_flight": in_flight,
                     "intra_launch_modes_ms": {"enqueued": round(ms_intra_plain, 4), "graph_replay": round(ms_intra_graph, 4),
                                               "graph_nodes": int(test_postchain.hip_intra.last_nodes), "wavefront_steps": len(intra.batches)},
                     "tasks": {"ipred": intra.n_blocks, "lf": int(len(post.lf)), "cdef": int(len(post.cdef)), "lr": int(len(post.lr))},

@@ -37,6 +37,7 @@ struct Dav1dHipContext {
     std::vector<Slab> free_slabs;
     struct Arena { uint8_t *dev; size_t cap; };
     std::vector<Arena> free_arenas;            // chunk arenas of finished frames (a frame in flight owns one)
+    std::vector<Arena> free_task_bufs;         // task-list buffers of the *_batch calls (TaskBuf below)
     size_t arena_hint;                         // what the largest frame so far needed
     uint8_t *gather_dev, *segtab_dev;
     size_t gather_cap, segtab_cap;
@@ -46,6 +47,40 @@ struct Dav1dHipContext {
     hipEvent_t ev_copy;
     std::mutex run_mtx;         // one multi-stream section (recon list run, banded post filters) at a time per context
 };
+
+// Device memory for the task list of one *_batch call, taken from a pool of the context.  hipMalloc + hipFree per call was the
+// obvious form and is fine for one context; hipFree waits for the whole device, so with several contexts at work (frames in
+// flight) every call of one frame stalled the others.  The pool only grows; dav1d_hip_close frees it.
+struct TaskBuf {
+    Dav1dHipContext *c;
+    uint8_t *p = nullptr;
+    size_t cap = 0;
+    TaskBuf(Dav1dHipContext *ctx, size_t bytes) : c(ctx) {
+        {
+            std::lock_guard<std::mutex> lk(c->pool_mtx);
+            int best = -1;
+            for (int i = 0; i < (int) c->free_task_bufs.size(); i++)
+                if (c->free_task_bufs[i].cap >= bytes && (best < 0 || c->free_task_bufs[i].cap < c->free_task_bufs[best].cap)) best = i;
+            if (best >= 0) {
+                p = c->free_task_bufs[best].dev; cap = c->free_task_bufs[best].cap;
+                c->free_task_bufs.erase(c->free_task_bufs.begin() + best);
+                return;
+            }
+        }
+        size_t want = 1 << 16;
+        while (want < bytes) want <<= 1;
+        void *q = nullptr;
+        if (hipMalloc(&q, want) == hipSuccess) { p = (uint8_t *) q; cap = want; }
+    }
+    ~TaskBuf() {
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(c->pool_mtx);
+        c->free_task_bufs.push_back({ p, cap });
+    }
+    TaskBuf(const TaskBuf &) = delete;
+    TaskBuf &operator=(const TaskBuf &) = delete;
+};
+
 
 // brackets the launches of a batch call with events on the context's stream
 struct KernelTimer {

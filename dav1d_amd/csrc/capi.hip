@@ -84,6 +84,7 @@ void dav1d_hip_close(Dav1dHipContext *c) {
     hipEventDestroy(c->ev_t0); hipEventDestroy(c->ev_t1);
     hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); hipEventDestroy(c->ev_copy);
     for (const Dav1dHipContext::Arena &ar : c->free_arenas) hipFree(ar.dev);
+    for (const Dav1dHipContext::Arena &ar : c->free_task_bufs) hipFree(ar.dev);
     if (c->gather_dev) hipFree(c->gather_dev);
     if (c->segtab_dev) hipFree(c->segtab_dev);
     if (c->pending_slab) hipHostFree(c->pending_slab);
@@ -1062,8 +1063,9 @@ size_t dav1d_hip_inter_list_fused(const Dav1dHipInterList *l) { return l ? l->n_
 int dav1d_hip_cdef_run_groups(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src, const Dav1dHipCdefTask *tasks,
                               size_t n, const CdefGroup *groups, size_t n_groups, size_t n_raw, int damping, uint32_t *dirvar) {
     const size_t tb = (n * sizeof(Dav1dHipCdefTask) + 255) & ~(size_t) 255;
-    uint8_t *dev = nullptr;
-    if (hipMalloc((void **) &dev, tb + n_groups * sizeof(CdefGroup) + 256) != hipSuccess) return -ENOMEM;
+    TaskBuf dev_buf(c, tb + n_groups * sizeof(CdefGroup) + 256);
+    uint8_t *const dev = reinterpret_cast<uint8_t *>(dev_buf.p);
+    if (!dev) return -ENOMEM;
     int rc = dav1d_hip_upload(c, dev, tasks, n * sizeof(Dav1dHipCdefTask));
     if (!rc && n_groups) rc = dav1d_hip_upload(c, dev + tb, groups, n_groups * sizeof(CdefGroup));
     const DevPlanes dp = dev_planes(dst), sp = dev_planes(src);
@@ -1074,7 +1076,6 @@ int dav1d_hip_cdef_run_groups(Dav1dHipContext *c, const Dav1dHipPicture *dst, co
     if (!rc && n_raw) rc = dav1d_hip_launch_cdef(&dp, &sp, dst->bpc, dst->layout, d_tasks, (int) n, damping, dirvar, 1, c->stream);
     kt.stop();
     hipStreamSynchronize(c->stream);
-    hipFree(dev);
     return rc;
 }
 
@@ -1091,14 +1092,14 @@ extern "C" int dav1d_hip_cdef_batch(Dav1dHipContext *c, const Dav1dHipPicture *d
         const size_t n_raw = dav1d_hip_cdef_make_groups(tasks, n, 0, groups);
         return dav1d_hip_cdef_run_groups(c, dst, src, tasks, n, groups.data(), groups.size(), n_raw, damping, dirvar);
     }
-    Dav1dHipCdefTask *dev = nullptr;
-    if (hipMalloc((void **) &dev, n * sizeof(*dev)) != hipSuccess) return -ENOMEM;
+    TaskBuf dev_buf(c, n * sizeof(Dav1dHipCdefTask));
+    Dav1dHipCdefTask *const dev = reinterpret_cast<Dav1dHipCdefTask *>(dev_buf.p);
+    if (!dev) return -ENOMEM;
     int rc = dav1d_hip_upload(c, dev, tasks, n * sizeof(*dev));
     KernelTimer kt(c);
     if (!rc) rc = dav1d_hip_launch_cdef(&dp, &sp, dst->bpc, dst->layout, dev, (int) n, damping, dirvar, 0, c->stream);
     kt.stop();
     hipStreamSynchronize(c->stream);
-    hipFree(dev);
     return rc;
 }
 
@@ -1118,8 +1119,9 @@ extern "C" int dav1d_hip_lf_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst
         }
         if (d == 0) n0 = sorted.size();
     }
-    Dav1dHipLfTask *dev = nullptr;
-    if (hipMalloc((void **) &dev, n * sizeof(*dev)) != hipSuccess) return -ENOMEM;
+    TaskBuf dev_buf(c, n * sizeof(Dav1dHipLfTask));
+    Dav1dHipLfTask *const dev = reinterpret_cast<Dav1dHipLfTask *>(dev_buf.p);
+    if (!dev) return -ENOMEM;
     int rc = dav1d_hip_upload(c, dev, sorted.data(), n * sizeof(*dev));
     const DevPlanes dp = dev_planes(dst);
     // pass 1: every vertical edge; pass 2 (same stream, so after pass 1): every horizontal edge
@@ -1128,7 +1130,6 @@ extern "C" int dav1d_hip_lf_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst
     if (!rc) rc = dav1d_hip_launch_lf(&dp, dst->bpc, 1, dev + n0, (int) (n - n0), lvl, (int) b4_stride, lut_e, lut_i, c->stream);
     kt.stop();
     hipStreamSynchronize(c->stream);
-    hipFree(dev);
     return rc;
 }
 
@@ -1166,15 +1167,15 @@ extern "C" int dav1d_hip_ipred_batch(Dav1dHipContext *c, const Dav1dHipPicture *
     if (ipred_tasks_valid(tasks, n, pal_idx)) return -EINVAL;
     std::vector<Dav1dHipIpredTask> ordered(tasks, tasks + n);
     const size_t n_big = ipred_big_first(ordered.data(), n);
-    Dav1dHipIpredTask *dev = nullptr;
-    if (hipMalloc((void **) &dev, n * sizeof(*dev)) != hipSuccess) return -ENOMEM;
+    TaskBuf dev_buf(c, n * sizeof(Dav1dHipIpredTask));
+    Dav1dHipIpredTask *const dev = reinterpret_cast<Dav1dHipIpredTask *>(dev_buf.p);
+    if (!dev) return -ENOMEM;
     int rc = dav1d_hip_upload(c, dev, ordered.data(), n * sizeof(*dev));
     const DevPlanes dp = dev_planes(dst);
     KernelTimer kt(c);
     if (!rc) rc = dav1d_hip_launch_ipred(&dp, dst->bpc, dst->layout, dev, (int) n, (int) n_big, pal_idx, nullptr, c->stream);
     kt.stop();
     hipStreamSynchronize(c->stream);
-    hipFree(dev);
     return rc;
 }
 
@@ -1243,12 +1244,12 @@ extern "C" void dav1d_hip_ipred_list_destroy(Dav1dHipContext *c, Dav1dHipIpredLi
 
 template <typename T, typename Launch>
 static int run_task_batch(Dav1dHipContext *c, const T *tasks, size_t n, Launch launch) {
-    T *dev = nullptr;
-    if (hipMalloc((void **) &dev, n * sizeof(T)) != hipSuccess) return -ENOMEM;
+    TaskBuf dev_buf(c, n * sizeof(T));
+    T *const dev = reinterpret_cast<T *>(dev_buf.p);
+    if (!dev) return -ENOMEM;
     int rc = dav1d_hip_upload(c, dev, tasks, n * sizeof(T));
     if (!rc) rc = launch(dev);
     hipStreamSynchronize(c->stream);
-    hipFree(dev);
     return rc;
 }
 
@@ -1328,8 +1329,9 @@ extern "C" int dav1d_hip_lr_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst
     std::vector<uint32_t> waves;
     dav1d_hip_sgr_make_rows(sorted.data() + nw, n - nw, waves);
     const size_t o_waves = (n * sizeof(Dav1dHipLrTask) + 15) & ~(size_t) 15;
-    uint8_t *devb = nullptr;
-    if (hipMalloc((void **) &devb, o_waves + waves.size() * 4 + 16) != hipSuccess) return -ENOMEM;
+    TaskBuf devb_buf(c, o_waves + waves.size() * 4 + 16);
+    uint8_t *const devb = reinterpret_cast<uint8_t *>(devb_buf.p);
+    if (!devb) return -ENOMEM;
     Dav1dHipLrTask *const dev = reinterpret_cast<Dav1dHipLrTask *>(devb);
     int rc = dav1d_hip_upload(c, dev, sorted.data(), n * sizeof(*dev));
     if (!rc && !waves.empty()) rc = dav1d_hip_upload(c, devb + o_waves, waves.data(), waves.size() * 4);
@@ -1341,7 +1343,6 @@ extern "C" int dav1d_hip_lr_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst
     if (!rc) rc = dav1d_hip_launch_sgr(&dp, &sp, &lp, dst->bpc, dev + nw, devb + o_waves, (int) (waves.size() / 4), c->stream);
     kt.stop();
     hipStreamSynchronize(c->stream);
-    hipFree(dev);
     return rc;
 }
 
@@ -1376,12 +1377,12 @@ static void fg_generate_scaling(const int bitdepth, const uint8_t points[][2], c
 extern "C" int dav1d_hip_fg_generate_grain(Dav1dHipContext *c, const Dav1dHipFilmGrainData *data, int bpc, int layout, int16_t *host_lut) {
     if (!data || !host_lut || (bpc != 8 && bpc != 10 && bpc != 12)) return -EINVAL;
     const size_t bytes = 3 * 74 * 82 * sizeof(int16_t);
-    int16_t *dev = nullptr;
-    if (hipMalloc((void **) &dev, bytes) != hipSuccess) return -ENOMEM;
+    TaskBuf dev_buf(c, bytes);
+    int16_t *const dev = reinterpret_cast<int16_t *>(dev_buf.p);
+    if (!dev) return -ENOMEM;
     hipMemsetAsync(dev, 0, bytes, c->stream);
     int rc = dav1d_hip_launch_fg_gen(dev, data, bpc, layout, c->stream);
     if (!rc) rc = dav1d_hip_download(c, host_lut, dev, bytes);
-    hipFree(dev);
     return rc;
 }
 
@@ -1467,15 +1468,15 @@ static int fg_args_ok(const Dav1dHipPicture *dst, const Dav1dHipPicture *src) {
 extern "C" int dav1d_hip_fg_apply_prepared(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src,
                                            const Dav1dHipGrain *g, int is_id) {
     if (!c || !g || !fg_args_ok(dst, src) || src->bpc != g->bpc || src->layout != g->layout) return -EINVAL;
-    uint8_t *offs = nullptr;
     const size_t offs_bytes = (size_t) ((src->p[0].w + 31) / 32) * ((src->p[0].h + 31) / 32);
-    if (hipMalloc((void **) &offs, offs_bytes + 16) != hipSuccess) return -ENOMEM;
+    TaskBuf offs_buf(c, offs_bytes + 16);
+    uint8_t *const offs = reinterpret_cast<uint8_t *>(offs_buf.p);
+    if (!offs) return -ENOMEM;
     int rc = hip_rc(hipStreamWaitEvent(c->stream, g->ready, 0));
     KernelTimer kt(c);
     if (!rc) rc = fg_apply_core(c, dst, src, g, is_id, offs);
     kt.stop();
     hipStreamSynchronize(c->stream);
-    hipFree(offs);
     return rc;
 }
 
@@ -1483,16 +1484,16 @@ extern "C" int dav1d_hip_fg_apply_prepared(Dav1dHipContext *c, const Dav1dHipPic
 extern "C" int dav1d_hip_fg_apply(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src,
                                   const Dav1dHipFilmGrainData *data, int is_id) {
     if (!c || !data || !fg_args_ok(dst, src)) return -EINVAL;
-    uint8_t *offs = nullptr;
     const size_t offs_bytes = (size_t) ((src->p[0].w + 31) / 32) * ((src->p[0].h + 31) / 32);
-    if (hipMalloc((void **) &offs, offs_bytes + 16) != hipSuccess) return -ENOMEM;
+    TaskBuf offs_buf(c, offs_bytes + 16);
+    uint8_t *const offs = reinterpret_cast<uint8_t *>(offs_buf.p);
+    if (!offs) return -ENOMEM;
     Dav1dHipGrain *g = nullptr;
     KernelTimer kt(c);
     int rc = fg_prepare_on(c, &g, data, src->bpc, src->layout, c->stream);
     if (!rc) rc = fg_apply_core(c, dst, src, g, is_id, offs);
     kt.stop();
     hipStreamSynchronize(c->stream);
-    hipFree(offs);
     dav1d_hip_fg_grain_destroy(c, g);
     return rc;
 }

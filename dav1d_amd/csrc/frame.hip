@@ -181,10 +181,11 @@ static int post_filters_pipelined(Dav1dHipFrame *f, const Dav1dHipPicture **last
     const size_t bytes_lf = lf_s.size() * sizeof(Dav1dHipLfTask), bytes_cdef = cdef_s.size() * sizeof(Dav1dHipCdefTask),
                  bytes_lr = lr_s.size() * sizeof(Dav1dHipLrTask);
     const size_t o_cdef = (bytes_lf + 255) & ~(size_t) 255, o_lr = (o_cdef + bytes_cdef + 255) & ~(size_t) 255;
-    uint8_t *dev = nullptr;
     const size_t o_cg = (o_lr + bytes_lr + 255) & ~(size_t) 255, bytes_cg = cgroups.size() * sizeof(CdefGroup);
     const size_t o_sw = (o_cg + bytes_cg + 255) & ~(size_t) 255;
-    if (hipMalloc((void **) &dev, o_sw + sgr_waves.size() * 4 + 256) != hipSuccess) return -ENOMEM;
+    TaskBuf dev_buf(c, o_sw + sgr_waves.size() * 4 + 256);
+    uint8_t *const dev = dev_buf.p;
+    if (!dev) return -ENOMEM;
     if (bytes_lf) rc = dav1d_hip_upload(c, dev, lf_s.data(), bytes_lf);
     if (!rc && bytes_cdef) rc = dav1d_hip_upload(c, dev + o_cdef, cdef_s.data(), bytes_cdef);
     if (!rc && bytes_lr) rc = dav1d_hip_upload(c, dev + o_lr, lr_s.data(), bytes_lr);
@@ -272,7 +273,6 @@ static int post_filters_pipelined(Dav1dHipFrame *f, const Dav1dHipPicture **last
     (void) hipStreamSynchronize(c->stream);
     if (!rc) { c->last_ms = 0.f; (void) hipEventElapsedTime(&c->last_ms, c->ev_t0, c->ev_t1); }
     for (hipEvent_t e : ev) if (e) (void) hipEventDestroy(e);
-    (void) hipFree(dev);
     *last_out = has_lr ? &f->tmp[1] : cdef_out;
     if (!rc) f->post_bands = nb;
     return rc;
