@@ -22,7 +22,7 @@ namespace {
 constexpr int rc_log2(int v) { return v <= 1 ? 0 : 1 + rc_log2(v >> 1); }
 
 template <int CLS, typename pixel, typename coef>
-__global__ __launch_bounds__(64, RECON_WAVES) void recon_fused_kernel(const DevPlanes dst, const RefSet refs, const McTile *__restrict__ tiles,
+__global__ __launch_bounds__(64, CLS == 1 ? 6 : RECON_WAVES) void recon_fused_kernel(const DevPlanes dst, const RefSet refs, const McTile *__restrict__ tiles,
                                                          const Dav1dHipItxTask *__restrict__ tasks, const int n_blocks,
                                                          int16_t *__restrict__ prep, coef *__restrict__ cf, const int bitdepth_max)
 {
