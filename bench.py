@@ -143,8 +143,8 @@ def frames_in_flight(api, device, frame, itx_tasks, coef_host, intra, post, ref_
         st["intra"] = ctx.intra_list(intra.batches)
         st["prep"] = ctx.buffer(frame.prep_elems * 2)
         st["prep"].zero()
-        st["coef"] = [ctx.buffer_from(coef_host) for _ in range(n_frames)]                # the residual launches zero what they read
-        st["icoef"] = [ctx.buffer_from(intra.coef) for _ in range(n_frames)]
+        st["coef"] = [ctx.buffer_from(coef_host) for _ in range(n_frames + 1)]            # the residual launches zero what they read
+        st["icoef"] = [ctx.buffer_from(intra.coef) for _ in range(n_frames + 1)]          # (the last one is the warm-up frame's)
         st["lvl"] = ctx.buffer_from(post.lvl)
         st["grain"] = ctx.fg_prepare(post.fg, bpc, api.LAYOUT_I420) if post.fg is not None else None
         ctx.sync()
@@ -178,6 +178,7 @@ def frames_in_flight(api, device, frame, itx_tasks, coef_host, intra, post, ref_
                 states.append(make(len(states)))
             for st in states[:n]:
                 reset(st)
+                one_frame(st, n_frames)             # warm-up: first-use allocations of the context's pools, code objects
             errs = []
 
             def work(st):
