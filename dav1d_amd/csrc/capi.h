@@ -26,6 +26,7 @@ struct Dav1dHipContext {
     int recon_fuse;             // bit mask of the square block sizes that run paired (DAV1D_HIP_RECON_FUSE)
     long recon_pipeline;        // smallest residual list a recon list pipelines on two streams (DAV1D_HIP_RECON_PIPELINE)
     int recon_lanes;            // side streams of the residual launches (DAV1D_HIP_RECON_LANES)
+    int recon_coop_below;       // paired kernels: launches of fewer groups than this take the cooperative form (recon.hip; DAV1D_HIP_RECON_COOP_BELOW)
     int post_bands;             // bands of the pipelined post filters, 0 = stage by stage (DAV1D_HIP_POST_BANDS)
     bool cdef_unit_kernel;      // $DAV1D_HIP_CDEF_UNIT=1 at open: one wave per 8x8 unit (the round-1 kernel) instead of strips; A/B aid
     // measurement aid: device time of the kernel launches of the most recent *_batch call (dav1d_hip_last_kernel_ms)
@@ -177,7 +178,7 @@ struct McGroup {
     uint16_t cls;         // tile-shape bin
 };
 extern "C" int dav1d_hip_launch_recon_fused(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, int cls, const McTile *tiles,
-                                            const Dav1dHipItxTask *tasks, int n, int16_t *prep, void *coef, void *stream);
+                                            const Dav1dHipItxTask *tasks, int n, int16_t *prep, void *coef, int coop_below, void *stream);
 extern "C" int dav1d_hip_launch_mc_all(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, const McTile *tiles,
                                        const McGroup *groups, int n_groups, int with_small, int16_t *prep, void *stream);
 extern "C" int dav1d_hip_launch_mc_bin(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, int cls,

@@ -45,6 +45,7 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     c->recon_fuse = (int) env_int("DAV1D_HIP_RECON_FUSE", RECON_FUSE_DEFAULT);
     c->recon_pipeline = env_int("DAV1D_HIP_RECON_PIPELINE", 16384);
     c->recon_lanes = (int) env_int("DAV1D_HIP_RECON_LANES", 1);
+    c->recon_coop_below = (int) env_int("DAV1D_HIP_RECON_COOP_BELOW", 4096);
     c->post_bands = (int) env_int("DAV1D_HIP_POST_BANDS", 0);
     const char *ser = getenv("DAV1D_HIP_SERIAL");
     c->concurrent = !(ser && atoi(ser));
@@ -145,6 +146,7 @@ int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value) {
     if (!strcmp(name, "recon_fuse")) c->recon_fuse = (int) value;
     else if (!strcmp(name, "recon_pipeline")) c->recon_pipeline = value;
     else if (!strcmp(name, "recon_lanes")) c->recon_lanes = (int) value;
+    else if (!strcmp(name, "recon_coop_below")) c->recon_coop_below = (int) value;
     else if (!strcmp(name, "post_bands")) c->post_bands = (int) value;
     else if (!strcmp(name, "serial")) c->concurrent = !value;
     else if (!strcmp(name, "cdef_unit")) c->cdef_unit_kernel = value != 0;
@@ -1661,7 +1663,7 @@ int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, con
         }
         for (int k = 4; k >= 0 && !rc; k--)
             if (l->f_n[k]) {
-                rc = dav1d_hip_launch_recon_fused(&dp, rp, n_refs, dst->bpc, k, l->f_tiles[k], l->f_tasks[k], (int) l->f_n[k], prep, coef,
+                rc = dav1d_hip_launch_recon_fused(&dp, rp, n_refs, dst->bpc, k, l->f_tiles[k], l->f_tasks[k], (int) l->f_n[k], prep, coef, c->recon_coop_below,
                                                   side ? c->side[ps[lane]] : c->stream);
                 lane ^= 1;
             }
@@ -1776,7 +1778,7 @@ int dav1d_hip_recon_list_run_timed(Dav1dHipContext *c, const Dav1dHipReconList *
         size_t cnt = 0;
         if (k < 5) {
             cnt = l->f_n[k];
-            if (cnt) rc = dav1d_hip_launch_recon_fused(&dp, rp, n_refs, dst->bpc, k, l->f_tiles[k], l->f_tasks[k], (int) cnt, prep, coef, c->stream);
+            if (cnt) rc = dav1d_hip_launch_recon_fused(&dp, rp, n_refs, dst->bpc, k, l->f_tiles[k], l->f_tasks[k], (int) cnt, prep, coef, c->recon_coop_below, c->stream);
         } else if (k < 20) {
             const int b = k - 5;
             cnt = ml->off[b + 1] - ml->off[b];

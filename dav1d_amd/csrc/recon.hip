@@ -21,10 +21,25 @@ namespace {
 
 constexpr int rc_log2(int v) { return v <= 1 ? 0 : 1 + rc_log2(v >> 1); }
 
-template <int CLS, typename pixel, typename coef>
-__global__ __launch_bounds__(64, CLS == 1 ? 6 : RECON_WAVES) void recon_fused_kernel(const DevPlanes dst, const RefSet refs, const McTile *__restrict__ tiles,
-                                                         const Dav1dHipItxTask *__restrict__ tasks, const int n_blocks,
-                                                         int16_t *__restrict__ prep, coef *__restrict__ cf, const int bitdepth_max)
+// Waves per workgroup of the cooperative form: the prediction body takes G tiles per call, a wave's blocks have BPW * TPB of them.
+// Where that is more than one call (8x8: 2; 16x16, 32x32, 64x64: 4) the calls are independent chains of record -> window fetch ->
+// two filter passes; the cooperative form gives every call a wave of its own (the fetches of all of a group's tiles in flight
+// together, the transform one fetch latency after launch instead of four) and the other waves end at the barrier.  Measured on
+// MI355X: with enough groups to fill the chip several times over (an 8K frame: 6,500 - 19,000 groups per size) the one-wave
+// form is 5 - 10 % faster, the SIMDs are busy either way and the extra waves cost LDS and a barrier; with few groups (a 4K frame:
+// 1,600 - 4,800, one or two per SIMD) a kernel lasts as long as its longest wave and the cooperative form shortens that.
+// The launch picks by group count (option recon_coop_below).
+template <int CLS> constexpr int recon_waves() {
+    constexpr int W = 4 << CLS, TW = mc_cmin(W, 64), TH = mc_cmin(W, 16), TPB = (W / TW) * (W / TH);
+    constexpr int LPB = cmax(cmin(W, 32), W), BPW = 64 / LPB, G = 64 / mc_cmin(64, TW * TH / 4);
+    return (BPW * TPB + G - 1) / G;
+}
+
+template <int CLS, typename pixel, typename coef, bool COOP>
+__global__ __launch_bounds__(COOP ? 64 * recon_waves<CLS>() : 64, COOP ? 1 : CLS == 1 ? 6 : RECON_WAVES)
+void recon_fused_kernel(const DevPlanes dst, const RefSet refs, const McTile *__restrict__ tiles,
+                        const Dav1dHipItxTask *__restrict__ tasks, const int n_blocks,
+                        int16_t *__restrict__ prep, coef *__restrict__ cf, const int bitdepth_max)
 {
     constexpr int TX = CLS;                                  // TX_4X4 .. TX_64X64
     constexpr int W = 4 << CLS;
@@ -32,16 +47,18 @@ __global__ __launch_bounds__(64, CLS == 1 ? 6 : RECON_WAVES) void recon_fused_ke
     constexpr int TPB = (W / TW) * (W / TH);                 // tiles per block: 1, 1, 1, 2, 4
     constexpr int LPB = cmax(cmin(W, 32), W), BPW = 64 / LPB;   // blocks per wave of the transform body
     constexpr int G = 64 / mc_cmin(64, TW * TH / 4);         // tiles per call of the prediction body
-    // One LDS buffer, used twice: [prediction window + intermediate | the predicted blocks] while the blocks are predicted, then
-    // [slabs / transpose buffer of the transform] — the transform body has the predicted pixels in registers before it stores
-    // its first slab chunk, so the regions may overlap.  Fewer LDS bytes per wave = more resident waves per CU, which is what
-    // these kernels are short of (16x16: 8320 -> 4352 bytes, 5 -> 6 waves per SIMD, 89 -> 76 us per 8K frame).
+    constexpr int NW = COOP ? recon_waves<CLS>() : 1;
+    // One LDS buffer, used twice: [prediction windows + intermediates, one set per wave | the predicted blocks] while the blocks
+    // are predicted, then [slabs / transpose buffer of the transform] — the transform body has the predicted pixels in registers
+    // before it stores its first slab chunk, so the regions may overlap.  Fewer LDS bytes per wave = more resident waves per CU,
+    // which is what these kernels are short of (16x16: 8320 -> 4352 bytes, 5 -> 6 waves per SIMD, 89 -> 76 us per 8K frame).
     constexpr int MC_B = (mc_lds_bytes<TW, TH>() + 15) / 16 * 16, PRED_B = BPW * W * W * (int) sizeof(pixel);
     constexpr int ITX_B = itx_lds_ints<TX>() * 4;
-    constexpr int LDS_B = cmax(MC_B + PRED_B, ITX_B);
+    constexpr int LDS_B = cmax(NW * MC_B + PRED_B, ITX_B);
     __shared__ uint4 smem[(LDS_B + 15) / 16];
-    uint4 *const smem_mc = smem;
-    pixel *const pred = reinterpret_cast<pixel *>(reinterpret_cast<char *>(smem) + MC_B);
+    const int wave = NW == 1 ? 0 : (int) (threadIdx.x >> 6);
+    uint4 *const smem_mc = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(smem) + wave * MC_B);
+    pixel *const pred = reinterpret_cast<pixel *>(reinterpret_cast<char *>(smem) + NW * MC_B);
     int *const smem_itx = reinterpret_cast<int *>(smem);
 
     const int group = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x);
@@ -49,33 +66,47 @@ __global__ __launch_bounds__(64, CLS == 1 ? 6 : RECON_WAVES) void recon_fused_ke
     if (block0 >= n_blocks) return;
     const int nb = dv::imin(BPW, n_blocks - block0);
     const int tile0 = block0 * TPB, ntile = nb * TPB;
-    for (int c = 0; c < ntile; c += G) {
-        mc_body<TW, TH, pixel, true>(dst, refs, tiles, tile0 + c, dv::imin(G, ntile - c), prep, bitdepth_max, smem_mc,
-                                     pred, tile0, rc_log2(TPB), W, W);
-        dv::wave_sync();
+    if constexpr (NW == 1) {
+        for (int c = 0; c < ntile; c += G) {
+            mc_body<TW, TH, pixel, true>(dst, refs, tiles, tile0 + c, dv::imin(G, ntile - c), prep, bitdepth_max, smem_mc,
+                                         pred, tile0, rc_log2(TPB), W, W);
+            dv::wave_sync();
+        }
+    } else {
+        const int c = wave * G;
+        if (c < ntile)
+            mc_body<TW, TH, pixel, true>(dst, refs, tiles, tile0 + c, dv::imin(G, ntile - c), prep, bitdepth_max, smem_mc,
+                                         pred, tile0, rc_log2(TPB), W, W);
+        __syncthreads();
+        if (wave) return;
     }
     itx_body<TX, pixel, coef, true>(dst, tasks, n_blocks, cf, bitdepth_max, group, smem_itx, pred);
 }
 
 template <int CLS, typename pixel, typename coef>
 void launch_cls(const DevPlanes &dst, const RefSet &refs, const McTile *tiles, const Dav1dHipItxTask *tasks, const int n,
-                int16_t *prep, coef *cf, const int bitdepth_max, hipStream_t stream)
+                int16_t *prep, coef *cf, const int bitdepth_max, const int coop_below, hipStream_t stream)
 {
     constexpr int W = 4 << CLS, LPB = cmax(cmin(W, 32), W), BPW = 64 / LPB;
-    hipLaunchKernelGGL((recon_fused_kernel<CLS, pixel, coef>), dim3((n + BPW - 1) / BPW), dim3(64), 0, stream,
-                       dst, refs, tiles, tasks, n, prep, cf, bitdepth_max);
+    const int groups = (n + BPW - 1) / BPW;
+    if (recon_waves<CLS>() > 1 && groups < coop_below)
+        hipLaunchKernelGGL((recon_fused_kernel<CLS, pixel, coef, true>), dim3(groups), dim3(64 * recon_waves<CLS>()), 0, stream,
+                           dst, refs, tiles, tasks, n, prep, cf, bitdepth_max);
+    else
+        hipLaunchKernelGGL((recon_fused_kernel<CLS, pixel, coef, false>), dim3(groups), dim3(64), 0, stream,
+                           dst, refs, tiles, tasks, n, prep, cf, bitdepth_max);
 }
 
 template <typename pixel, typename coef>
 hipError_t launch_any(const int cls, const DevPlanes &dst, const RefSet &refs, const McTile *tiles, const Dav1dHipItxTask *tasks,
-                      const int n, int16_t *prep, coef *cf, const int bitdepth_max, hipStream_t stream)
+                      const int n, int16_t *prep, coef *cf, const int bitdepth_max, const int coop_below, hipStream_t stream)
 {
     switch (cls) {
-    case 0: launch_cls<0, pixel, coef>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, stream); break;
-    case 1: launch_cls<1, pixel, coef>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, stream); break;
-    case 2: launch_cls<2, pixel, coef>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, stream); break;
-    case 3: launch_cls<3, pixel, coef>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, stream); break;
-    case 4: launch_cls<4, pixel, coef>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, stream); break;
+    case 0: launch_cls<0, pixel, coef>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, stream); break;
+    case 1: launch_cls<1, pixel, coef>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, stream); break;
+    case 2: launch_cls<2, pixel, coef>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, stream); break;
+    case 3: launch_cls<3, pixel, coef>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, stream); break;
+    case 4: launch_cls<4, pixel, coef>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, stream); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -86,14 +117,14 @@ hipError_t launch_any(const int cls, const DevPlanes &dst, const RefSet &refs, c
 // tiles[] / tasks[] (device): the n blocks of ONE square transform size cls = 0 (4x4) .. 4 (64x64); block i owns
 // tasks[i] and the (1, 1, 1, 2, 4) tiles starting at tiles[i * tiles_per_block].
 extern "C" int dav1d_hip_launch_recon_fused(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, int cls, const McTile *tiles,
-                                            const Dav1dHipItxTask *tasks, int n, int16_t *prep, void *coef, void *stream)
+                                            const Dav1dHipItxTask *tasks, int n, int16_t *prep, void *coef, int coop_below, void *stream)
 {
     if (n <= 0) return 0;
     RefSet rs;
     for (int i = 0; i < 8; i++) rs.r[i] = refs[i < n_refs ? i : 0];
     const int bitdepth_max = (1 << bpc) - 1;
     hipError_t e;
-    if (bpc == 8) e = launch_any<uint8_t, int16_t>(cls, *dst, rs, tiles, tasks, n, prep, (int16_t *) coef, bitdepth_max, (hipStream_t) stream);
-    else          e = launch_any<uint16_t, int32_t>(cls, *dst, rs, tiles, tasks, n, prep, (int32_t *) coef, bitdepth_max, (hipStream_t) stream);
+    if (bpc == 8) e = launch_any<uint8_t, int16_t>(cls, *dst, rs, tiles, tasks, n, prep, (int16_t *) coef, bitdepth_max, coop_below, (hipStream_t) stream);
+    else          e = launch_any<uint16_t, int32_t>(cls, *dst, rs, tiles, tasks, n, prep, (int32_t *) coef, bitdepth_max, coop_below, (hipStream_t) stream);
     return hip_rc(e);
 }

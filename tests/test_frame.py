@@ -148,13 +148,16 @@ def test_frame_from_packed_coefficients(ctx, bpc):
         assert np.array_equal(got[pl], want[pl]), pl
 
 
-@pytest.mark.parametrize("fuse", ["0", "31", "6"], ids=["two-kernels", "all-paired", "default-paired"])
+@pytest.mark.parametrize("fuse", ["0", "31", "6", "31-one-wave"], ids=["two-kernels", "all-paired", "default-paired", "all-paired-one-wave"])
 @pytest.mark.parametrize("pipeline", ["0", "-1"], ids=["pipelined", "sequential"])
 @pytest.mark.parametrize("bpc", [8, 10, 12])
 def test_recon_list_matches_oracle(ctx, bpc, pipeline, fuse, monkeypatch):
     """dav1d_hip_recon_list_*: predictions and residuals as one list, the residual launch of a transform size waiting only
     for the prediction launches under its blocks (two streams) — and the same list run strictly one phase after the other."""
     ctx.set_option("recon_pipeline", pipeline)
+    if fuse.endswith("-one-wave"):          # the paired kernels as one wave per group (what large frames get) instead of the
+        fuse = fuse.split("-")[0]           # cooperative form frames of this size get by default
+        ctx.set_option("recon_coop_below", 0)
     ctx.set_option("recon_fuse", fuse)      # paired: prediction + residual of a block in one wave (recon.hip)
     w, h = (512, 128) if ctx.backend == "emu" else (1280, 1024)
     frame = synth.make_frame(w, h, bpc, seed=515 + bpc, edge_frac=0.1)
