@@ -22,6 +22,9 @@ stats = {}
 for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         stats[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["Percentage"]))
+for f in glob.glob(os.path.join(out, "stats_full", "**", "*kernel_stats.csv"), recursive=True):      # stages outside the recon step
+    for r in csv.DictReader(open(f)):
+        stats.setdefault(short(r["Name"]), (int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
 cnt = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
