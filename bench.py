@@ -100,6 +100,8 @@ def pmc_traffic(kernel, w, h, bpc):
         from dav1d_amd import synth
         tx = [i for i in range(19) if synth.TX_W[i] == int(m.group(2)) and synth.TX_H[i] == int(m.group(3))][0]
         key = "itx_add_kernel<%d,u16,int>" % tx
+    if key not in d and key[:-1] + ",false>" in d:        # the paired kernels carry their form (one wave / cooperative) in the name
+        key = key[:-1] + ",false>"
     if key not in d:
         return None
     return int(d[key]["fetch_bytes_x2"] + d[key]["write_bytes"])
