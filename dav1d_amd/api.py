@@ -20,7 +20,13 @@ class HipError(RuntimeError):
 
 def _chk(rc, what):
     if rc:
-        raise HipError("%s failed: errno %d" % (what, -rc))
+        why = ""
+        if rc in (-5, -12, -38):          # -EIO / -ENOMEM / -ENOSYS: a HIP call was behind it
+            try:
+                why = " (HIP: %s)" % _lib.load().dav1d_hip_last_hip_error(None).decode()
+            except Exception:           # noqa: BLE001
+                pass
+        raise HipError("%s failed: errno %d%s" % (what, -rc, why))
 
 
 class DeviceBuffer:

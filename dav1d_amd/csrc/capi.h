@@ -121,8 +121,12 @@ struct StreamFan {
     }
 };
 
+// the HIP error behind the last non-zero return on this thread (dav1d_hip_last_hip_error): the C ABI speaks errno, and -EIO alone
+// does not say whether a launch was refused, a kernel faulted or a copy failed
+extern "C" { extern thread_local int dav1d_hip_tls_last_error; }
 static inline int hip_rc(hipError_t e) {
     if (e == hipSuccess) return 0;
+    dav1d_hip_tls_last_error = (int) e;
     if (e == hipErrorOutOfMemory) return -ENOMEM;
     if (e == hipErrorInvalidValue) return -EINVAL;
     if (e == hipErrorNotSupported) return -ENOSYS;

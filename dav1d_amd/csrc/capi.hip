@@ -171,6 +171,13 @@ int dav1d_hip_free(Dav1dHipContext *c, void *dev) {
 int dav1d_hip_memset(Dav1dHipContext *c, void *dev, int v, size_t bytes) {
     return hip_rc(hipMemsetAsync(dev, v, bytes, c->stream));
 }
+thread_local int dav1d_hip_tls_last_error = 0;
+const char *dav1d_hip_last_hip_error(int *code) {
+    const int e = dav1d_hip_tls_last_error;
+    if (code) *code = e;
+    return e ? hipGetErrorString((hipError_t) e) : "no error";
+}
+
 int dav1d_hip_upload(Dav1dHipContext *c, void *dev, const void *host, size_t bytes) {
     HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
     return hip_rc(hipStreamSynchronize(c->stream));

@@ -77,6 +77,10 @@ DAV1D_HIP_API float dav1d_hip_last_kernel_ms(Dav1dHipContext *c);
 DAV1D_HIP_API int dav1d_hip_malloc(Dav1dHipContext *c, void **dev, size_t bytes);
 DAV1D_HIP_API int dav1d_hip_free(Dav1dHipContext *c, void *dev);
 DAV1D_HIP_API int dav1d_hip_memset(Dav1dHipContext *c, void *dev, int v, size_t bytes);
+/* Every entry point returns 0 or a negative errno.  When the cause was a HIP call (-EIO, -ENOMEM, -ENOSYS ...), this returns
+ * the text of the last HIP error seen on the calling thread ("no error" if none) and its hipError_t value in *code (NULL: not
+ * wanted).  Asynchronous faults of a kernel surface at the next synchronising call of the context. */
+DAV1D_HIP_API const char *dav1d_hip_last_hip_error(int *code);
 DAV1D_HIP_API int dav1d_hip_upload(Dav1dHipContext *c, void *dev, const void *host, size_t bytes);
 DAV1D_HIP_API int dav1d_hip_download(Dav1dHipContext *c, void *host, const void *dev, size_t bytes);
 

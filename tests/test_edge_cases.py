@@ -92,3 +92,12 @@ def test_ragged_pictures_follow_the_reference_geometry(ctx, w, h):
         pic.upload(1, a)
         assert np.array_equal(pic.download(1), a)
         pic.free()
+
+
+def test_last_hip_error_is_reported_as_text(ctx):
+    """dav1d_hip_last_hip_error: the C ABI speaks errno; the HIP error behind an -EIO / -ENOMEM is kept per thread as text."""
+    import ctypes as C
+    code = C.c_int(-1)
+    msg = ctx.lib.dav1d_hip_last_hip_error(C.byref(code))
+    assert isinstance(msg, bytes) and len(msg) > 0
+    assert (code.value == 0) == (msg == b"no error")
