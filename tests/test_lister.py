@@ -179,6 +179,24 @@ def test_larger_frame_many_tiles_threads():
         ctx.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,layout,bpc,kw", [
+    (3840, 2160, 3, 10, dict(tiles=(4, 2), threads=8)),                 # 4:4:4 at 4K
+    (2560, 1440, 2, 8, dict(tiles=(2, 2), threads=4)),                  # 4:2:2
+    (3840, 2160, 1, 12, dict(tiles=(4, 2), threads=8, gmv=GMV, global_pct=20)),
+    (1920, 1080, 3, 8, dict(tiles=(2, 1), threads=2, is_inter=False, palette=30)),
+], ids=["444_10_4k", "422_8_1440p", "420_12_4k_gmv", "key_444_8_1080p_palette"])
+def test_every_tool_at_frame_scale(w, h, layout, bpc, kw):
+    """The mix of every tool (OBMC, warp, masks, inter-intra, palette, CfL, rectangular transforms ...) on whole pictures of the
+    other chroma layouts and bit depths, hand-off arrays through the lister threads to pixels, against the reference's own pass 2."""
+    ctx = util.make_context("hip")
+    ctx.backend = "hip"
+    try:
+        run_case(ctx, w, h, layout, bpc, 40 + layout + bpc, **kw)
+    finally:
+        ctx.close()
+
+
 def test_reference_pass2_on_worker_threads_equals_one_thread():
     """oracle/ref_frame.c dav1d_ref_frame_recon_mt (the CPU peer bench.py times): tiles on a pool of workers give the picture
     the single-threaded walk gives."""
