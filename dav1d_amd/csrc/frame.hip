@@ -40,6 +40,8 @@ struct Dav1dHipFrame {
     };
     std::vector<StepChunk *> step_chunks;
     size_t n_steps;                                 // 1 + highest step submitted
+    std::vector<Dav1dHipMcTask> step_copy;                      // intra block copies: predictions from the frame's own pixels ...
+    std::vector<uint16_t> step_copy_step;                       // ... and the wavefront step each of them runs in
     std::vector<Dav1dHipWarpTask> warp;                         // warped predictions (step 0: they read reference pictures only)
     std::vector<Dav1dHipMcScaledTask> scaled;                   // predictions from references of another size
     uint8_t *aux;                    // DEVICE arena of the palette indices the intra tasks point into (may be NULL)
@@ -367,6 +369,21 @@ int dav1d_hip_frame_submit_intra_step(Dav1dHipFrame *f, size_t step, const Dav1d
     return rc;
 }
 
+int dav1d_hip_frame_submit_step_copy(Dav1dHipFrame *f, const Dav1dHipMcTask *tasks, const uint16_t *steps, size_t n) {
+    if (!f || ((!tasks || !steps) && n)) return -EINVAL;
+    for (size_t i = 0; i < n; i++)
+        if (!steps[i] || tasks[i].kind != DAV1D_HIP_MC_PUT || tasks[i].plane > 2 || !f->cur.p[tasks[i].plane].data) return -EINVAL;
+    std::lock_guard<std::mutex> lk(f->mtx);
+    for (size_t i = 0; i < n; i++) {
+        Dav1dHipMcTask t = tasks[i];
+        t.ref = 0;                                   // the one "reference" these are run with is the frame's own picture
+        f->step_copy.push_back(t);
+        f->step_copy_step.push_back(steps[i]);
+        f->n_steps = std::max(f->n_steps, (size_t) steps[i] + 1);
+    }
+    return 0;
+}
+
 // The blends of inter-intra blocks of wavefront step `step` (kind DAV1D_HIP_COMP_BLEND, tmp1_off = where the step's PRED_TMP task
 // wrote the intra prediction): run after the step's predictions and before its residuals — the reference's order inside
 // recon_b_inter (src/recon_tmpl.c:1606-1630: intra_pred into tmp, blend, later the residual).  Thread-safe.
@@ -547,6 +564,7 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
         const size_t ns = f->n_steps;
         bool flow = c->flow_min_steps > 0 && ns >= (size_t) c->flow_min_steps;
         for (const Dav1dHipFrame::StepChunk *ck : f->step_chunks) flow = flow && ck->flow_ok;
+        flow = flow && f->step_copy.empty();          // intra block copies are launches of their own between the steps
         if (flow) {
             // A long wavefront (a key frame: hundreds to thousands of steps, most of them narrow) goes down as ONE launch whose
             // waves hand the steps to each other (intra_flow.hip).  The chunks' units, merged step by step: first the units with
@@ -599,9 +617,30 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
                     allb.insert(allb.end(), ck->bl.begin() + b0, ck->bl.begin() + ck->bl_end[s]);
                     ps[s] += ck->ip_end[s] - p0; ts[s] += ck->ix_end[s] - x0; bs[s] += ck->bl_end[s] - b0;
                 }
+            // intra block copies by step: the frame's own picture as the one reference, its size rounded up to whole 8x8 blocks
+            // (what mc() bounds an intrabc source by: f->bw * 4 >> ss_hor, src/recon_tmpl.c:960-966)
+            std::vector<Dav1dHipMcTask> cp(f->step_copy.size());
+            std::vector<size_t> cp_end(ns + 1, 0);
+            if (!cp.empty()) {
+                for (uint16_t s : f->step_copy_step) cp_end[(size_t) s + 1 <= ns ? s + 1 : ns]++;
+                for (size_t s = 0; s < ns; s++) cp_end[s + 1] += cp_end[s];
+                std::vector<size_t> pos(cp_end.begin(), cp_end.end() - 1);
+                for (size_t i = 0; i < cp.size(); i++) cp[pos[f->step_copy_step[i]]++] = f->step_copy[i];
+            }
+            Dav1dHipPicture self = f->cur;
+            {
+                const int ssh = f->cur.layout != DAV1D_HIP_LAYOUT_I444, ssv = f->cur.layout == DAV1D_HIP_LAYOUT_I420;
+                const int w8 = (f->cur.p[0].w + 7) & ~7, h8 = (f->cur.p[0].h + 7) & ~7;
+                self.p[0].w = w8; self.p[0].h = h8;
+                for (int p = 1; p < 3; p++) if (self.p[p].data) { self.p[p].w = w8 >> ssh; self.p[p].h = h8 >> ssv; }
+            }
             Dav1dHipIntraList *xl = nullptr;
             rc = dav1d_hip_intra_list_create_blend(c, &xl, allp.data(), ps.data(), allt.data(), ts.data(), allb.data(), bs.data(), ps.size());
-            for (size_t k = 0; k < ps.size() && !rc; k++) rc = dav1d_hip_intra_list_run_batch_blend(c, xl, k, &f->cur, coef, f->aux, prep, mask);
+            for (size_t k = 0; k < ps.size() && !rc; k++) {
+                if (!cp.empty() && cp_end[k + 1] > cp_end[k])
+                    rc = dav1d_hip_mc_batch(c, &f->cur, &self, 1, cp.data() + cp_end[k], cp_end[k + 1] - cp_end[k], prep);
+                if (!rc) rc = dav1d_hip_intra_list_run_batch_blend(c, xl, k, &f->cur, coef, f->aux, prep, mask);
+            }
             if (xl) dav1d_hip_intra_list_destroy(c, xl);
         }
     }

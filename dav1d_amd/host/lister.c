@@ -63,6 +63,7 @@ typedef struct Out {
     VEC(Dav1dHipIpredTask) ipred; VEC(uint16_t) ipred_step;
     VEC(Dav1dHipCompTask) blend;  VEC(uint16_t) blend_step;
     VEC(Dav1dHipItxTask) sitx;    VEC(uint16_t) sitx_step;
+    VEC(Dav1dHipMcTask) smc;      VEC(uint16_t) smc_step;       /* intra block copies: predictions from the frame's own pixels */
 } Out;
 
 typedef struct Walk {
@@ -522,6 +523,8 @@ static unsigned list_interintra(Walk *w, const int bs, const Dav1dHipAv1Block *b
     return s;
 }
 
+static void list_inter_residuals(Walk *w, int bs, const Dav1dHipAv1Block *b, int bx, int by, const unsigned step[3]);
+
 /* recon_b_inter(), src/recon_tmpl.c:1557-1985, for inter frames */
 static void list_inter(Walk *w, const int bs, const Dav1dHipAv1Block *b, const int bx, const int by) {
     Dav1dHipLister *l = w->l;
@@ -652,8 +655,19 @@ static void list_inter(Walk *w, const int bs, const Dav1dHipAv1Block *b, const i
         }
     }
 
+    list_inter_residuals(w, bs, b, bx, by, step);
+}
+
+/* residuals of an inter (or intra-block-copy) block: per 64x64 of the block, the luma transform tree, then both chroma planes
+ * (src/recon_tmpl.c:1916-1981); step[pl] = wavefront step of the plane's residuals */
+static void list_inter_residuals(Walk *w, const int bs, const Dav1dHipAv1Block *b, const int bx, const int by, const unsigned step[3]) {
+    Dav1dHipLister *l = w->l;
+    const int ss_hor = l->ss_hor, ss_ver = l->ss_ver, layout = l->d.layout;
+    const uint8_t *b_dim = h_bs_dim[bs];
+    const int bw4 = b_dim[0], bh4 = b_dim[1];
+    const int w4 = imin(bw4, l->bw - bx), h4 = imin(bh4, l->bh - by);
+    const int has_chroma = layout != DAV1D_HIP_LAYOUT_I400 && (bw4 > ss_hor || (bx & 1)) && (bh4 > ss_ver || (by & 1));
     if (b->skip) return;
-    /* residuals: per 64x64 of the block, the luma transform tree, then both chroma planes (:1916-1981) */
     const int cw4 = (w4 + ss_hor) >> ss_hor, ch4 = (h4 + ss_ver) >> ss_ver;
     const HostTx *uvtx = &h_tx[b->uvtx], *ytx = &h_tx[b->u.p.max_ytx];
     for (int init_y = 0; init_y < bh4; init_y += 16)
@@ -672,6 +686,68 @@ static void list_inter(Walk *w, const int bs, const Dav1dHipAv1Block *b, const i
         }
 }
 
+/* Intra block copy: recon_b_inter() on key / intra-only frames (src/recon_tmpl.c:1583-1597).  The prediction is mc() from the
+ * frame's own reconstruction with the bilinear filter — luma at integer positions; chroma of a subsampled layout lands on half
+ * positions for odd vectors, and a 4-wide / 4-high luma block predicts the chroma of its whole 8x8 with its own vector
+ * (`bw4 << (bw4 == ss_hor)` from `bx & ~ss_hor`).  The pixels it reads were written by blocks earlier in decode order of the same
+ * tile: the block's wavefront step is 1 + the largest step among the cells of the source rectangles, its residuals run in the same
+ * step after the copy, and its own cells carry that step for whoever predicts from them next. */
+static unsigned src_step(const Walk *w, const int pl, const int x_px, const int y_px, const int w_px, const int h_px) {
+    const Dav1dHipLister *l = w->l;
+    const int sh = pl ? l->ss_hor : 0, sv = pl ? l->ss_ver : 0;
+    const int cw = (l->bw + sh) >> sh, ch = (l->bh + sv) >> sv;                     /* cells of the plane */
+    const int x0 = iclip(x_px >> 2, 0, cw - 1), x1 = iclip((x_px + w_px) >> 2, 0, cw - 1);    /* one pixel more: the bilinear taps */
+    const int y0 = iclip(y_px >> 2, 0, ch - 1), y1 = iclip((y_px + h_px) >> 2, 0, ch - 1);
+    const uint16_t *m = l->step[pl];
+    const int st = l->step_stride[pl];
+    unsigned s = 0;
+    for (int y = y0; y <= y1; y++)
+        for (int x = x0; x <= x1; x++) s = m[y * st + x] > s ? m[y * st + x] : s;
+    return s;
+}
+
+static void list_intrabc(Walk *w, const int bs, const Dav1dHipAv1Block *b, const int bx, const int by) {
+    Dav1dHipLister *l = w->l;
+    const int ss_hor = l->ss_hor, ss_ver = l->ss_ver, layout = l->d.layout;
+    const uint8_t *b_dim = h_bs_dim[bs];
+    const int bw4 = b_dim[0], bh4 = b_dim[1];
+    const int has_chroma = layout != DAV1D_HIP_LAYOUT_I400 && (bw4 > ss_hor || (bx & 1)) && (bh4 > ss_ver || (by & 1));
+    const Mv mv = mv_of(b->u.p.u.m.mv[0]);
+    const size_t n0 = w->o->mc.n;
+    /* the three predictions, emitted like any mc() call (reference 0 stands for the frame itself), then moved to the stepped list */
+    emit_mc(w, DAV1D_HIP_MC_PUT, dst_off(l, 0, bx * 4, by * 4), bw4, bh4, bx, by, 0, mv, 0, 9 /* FILTER_2D_BILINEAR */);
+    if (has_chroma)
+        for (int pl = 1; pl < 3; pl++)
+            emit_mc(w, DAV1D_HIP_MC_PUT, dst_off(l, 1, 4 * (bx >> ss_hor), 4 * (by >> ss_ver)), bw4 << (bw4 == ss_hor), bh4 << (bh4 == ss_ver),
+                    bx & ~ss_hor, by & ~ss_ver, pl, mv, 0, 9);
+    if (w->o->mc.n - n0 != (size_t) (has_chroma ? 3 : 1)) { w->err = -EINVAL; return; }       /* a scaled "reference 0": not here */
+    unsigned s = 0;
+    for (size_t i = n0; i < w->o->mc.n; i++) {
+        const Dav1dHipMcTask *k = &w->o->mc.p[i];
+        const int sh = k->plane ? ss_hor : 0, sv = k->plane ? ss_ver : 0;
+        /* the source must lie inside the coded area (is_mv_valid keeps it inside the tile); nothing is emulated here */
+        if (k->src_x < 0 || k->src_y < 0 || k->src_x + k->w + !!k->mx > (l->bw * 4) >> sh || k->src_y + k->h + !!k->my > (l->bh * 4) >> sv) {
+            w->err = -EINVAL;
+            return;
+        }
+        const unsigned q = src_step(w, k->plane, k->src_x, k->src_y, k->w, k->h);
+        if (q > s) s = q;
+    }
+    s++;
+    for (size_t i = n0; i < w->o->mc.n; i++) {
+        *VPUSH(w->o->smc, Dav1dHipMcTask) = w->o->mc.p[i];
+        *VPUSH(w->o->smc_step, uint16_t) = (uint16_t) s;
+    }
+    w->o->mc.n = n0;
+    const unsigned step[3] = { s, s, s };
+    list_inter_residuals(w, bs, b, bx, by, step);
+    set_step(w, 0, bx, by, bw4, bh4, s);
+    if (has_chroma) {
+        const int cbw4 = (bw4 + ss_hor) >> ss_hor, cbh4 = (bh4 + ss_ver) >> ss_ver;
+        for (int pl = 1; pl < 3; pl++) set_step(w, pl, bx >> ss_hor, by >> ss_ver, cbw4, cbh4, s);
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------ the walk */
 
 /* decode_b(), pass-2 branch (src/decode.c:706-806) */
@@ -681,7 +757,8 @@ static void list_block(Walk *w, const int bs, const int edge_flags, const int bx
     const Dav1dHipAv1Block *b = &l->d.b[bi];
     if (b->intra) list_intra(w, bs, edge_flags, b, bx, by);
     else if (l->d.is_inter) list_inter(w, bs, b, bx, by);
-    else { w->err = -ENOTSUP; return; }          /* intra block copy */
+    else list_intrabc(w, bs, b, bx, by);         /* an inter-coded block of a key / intra-only frame: intra block copy */
+    if (w->err) return;
     /* what later blocks need to know about this one: its identity along the bottom row and the right column */
     const int bw4 = h_bs_dim[bs][0], bh4 = h_bs_dim[bs][1];
     const int xe = imin(bx + bw4, l->bw), ye = imin(by + bh4, l->bh);
@@ -936,7 +1013,9 @@ int dav1d_hip_lister_tile_sbrow(Dav1dHipLister *l, const int tile_row, const int
     if (!rc) rc = dav1d_hip_frame_submit_tile_sbrow(l->frame, o.mc.p, o.mc.n, o.comp.p, o.comp.n, o.itx.p, o.itx.n);
     if (!rc && o.warp.n) rc = dav1d_hip_frame_submit_warp(l->frame, o.warp.p, o.warp.n);
     if (!rc && o.scaled.n) rc = dav1d_hip_frame_submit_scaled(l->frame, o.scaled.p, o.scaled.n);
+    if (!rc && o.smc.n) rc = dav1d_hip_frame_submit_step_copy(l->frame, o.smc.p, o.smc_step.p, o.smc.n);
     if (!rc) rc = submit_steps(l, &o);
+    free(o.smc.p); free(o.smc_step.p);
     free(o.mc.p); free(o.comp.p); free(o.warp.p); free(o.scaled.p); free(o.itx.p);
     free(o.ipred.p); free(o.ipred_step.p); free(o.blend.p); free(o.blend_step.p); free(o.sitx.p); free(o.sitx_step.p);
     if (!rc) cur->next_sby = sby + 1;

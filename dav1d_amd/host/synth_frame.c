@@ -191,6 +191,30 @@ static void gen_block(Gen *g, const int bl, const int bs, const int bp, const in
     b->bl = (uint8_t) bl; b->bs = (uint8_t) bs; b->bp = (uint8_t) bp;
     b->skip = (uint8_t) pct(&g->rng, sp->skip_pct);
     b->intra = (uint8_t) (!g->d->is_inter || pct(&g->rng, sp->intra_pct));
+    int bc_dx = 0, bc_dy = 0;
+    if (!g->d->is_inter && sp->intrabc_pct && imax(bw4, bh4) <= 16 && pct(&g->rng, sp->intrabc_pct)) {
+        /* Intra block copy: a source for the block — and for the chroma of the whole 8x8 a 4-wide / 4-high block carries, one more
+         * pixel to the right and below for the bilinear taps of half positions — inside the tile, in the superblock rows above this
+         * one or at least 256 pixels to the left of this superblock: decoded before this block whatever the partition order
+         * (the stream-level rule, is_mv_valid, is narrower).  Vectors are whole pixels, at most 4095 of them. */
+        const int sb4 = g->d->sb128 ? 32 : 16;
+        const int ex0 = (bx & ~ss_hor) * 4, ey0 = (by & ~ss_ver) * 4;
+        const int ew = (((bx + bw4) * 4 + 7 * ss_hor) & ~(7 * ss_hor)) - ex0 + 1, eh = (((by + bh4) * 4 + 7 * ss_ver) & ~(7 * ss_ver)) - ey0 + 1;
+        const int tx0 = g->col_start * 4, tx1 = imin(g->col_end, g->bw) * 4, ty0 = g->row_start * 4, ty1 = imin(g->row_end, g->bh) * 4;
+        const int sb_top = (by & ~(sb4 - 1)) * 4, sb_left = (bx & ~(sb4 - 1)) * 4, sb_bot = imin(sb_top + sb4 * 4, ty1);
+        int sx = -1, sy = -1;
+        for (int tries = 0; tries < 8 && sx < 0; tries++) {
+            if (rnd_n(&g->rng, 2) && sb_top - ty0 >= eh && tx1 - tx0 >= ew) {              /* above */
+                sy = rnd_range(&g->rng, imax(ty0, ey0 - 4000), sb_top - eh);
+                sx = rnd_range(&g->rng, imax(tx0, ex0 - 4000), imin(tx1 - ew, ex0 + 4000));
+            } else if (sb_left - 256 - tx0 >= ew && sb_bot - ty0 >= eh) {                  /* to the left */
+                sx = rnd_range(&g->rng, imax(tx0, ex0 - 4000), sb_left - 256 - ew);
+                sy = rnd_range(&g->rng, imax(ty0, ey0 - 4000), imin(sb_bot - eh, ey0 + 4000));
+            }
+            if (sx >= 0 && (sx > sb_left - 256 - ew && sy > sb_top - eh)) sx = sy = -1;         /* ranges that came out empty */
+        }
+        if (sx >= 0) { b->intra = 0; bc_dx = sx - ex0; bc_dy = sy - ey0; }
+    }
     if (b->intra) {
         b->u.i.y_mode = (uint8_t) rnd_n(&g->rng, 13);
         if (pct(&g->rng, 30)) b->u.i.y_mode = H_DC_PRED;
@@ -227,6 +251,27 @@ static void gen_block(Gen *g, const int bl, const int bs, const int bp, const in
                 if (pct(&g->rng, sp->tx_split_pct)) tx = h_tx[tx].sub;
         b->u.i.tx = (uint8_t) tx;
         b->uvtx = h_max_tx_for_bs[bs][layout];
+    } else if (!g->d->is_inter) {
+        /* intra block copy: reference "0" = the frame itself, one whole-pixel vector, bilinear, no inter tools (src/decode.c:1258-1330) */
+        b->u.p.ref[0] = 0; b->u.p.ref[1] = -1;
+        b->u.p.u.m.mv[0][0] = (int16_t) (bc_dy * 8);
+        b->u.p.u.m.mv[0][1] = (int16_t) (bc_dx * 8);
+        b->u.p.comp_type = H_COMP_INTER_NONE;
+        b->u.p.inter_mode = 3;
+        b->u.p.filter2d = 9;                                               /* FILTER_2D_BILINEAR */
+        uint16_t masks[2] = { 0, 0 };
+        b->u.p.max_ytx = h_max_tx_for_bs[bs][0];
+        b->uvtx = h_max_tx_for_bs[bs][layout];
+        if (!b->skip && b->u.p.max_ytx == H_TX_4X4) {
+            b->uvtx = H_TX_4X4;
+        } else if (!b->skip && sp->tx_split_pct) {
+            const HostTx *ytx = &h_tx[b->u.p.max_ytx];
+            for (int y = 0, y_off = 0; y < bh4; y += ytx->h, y_off++)
+                for (int x = 0, x_off = 0; x < bw4; x += ytx->w, x_off++)
+                    gen_tx_split(g, masks, b->u.p.max_ytx, 0, x_off, y_off, bx + x, by + y);
+        }
+        b->u.p.tx_split0 = (uint8_t) masks[0];
+        b->u.p.tx_split1 = masks[1];
     } else {
         const int n_refs = imax(1, imin(sp->n_refs, 7));
         int is_comp = imin(bw4, bh4) > 1 && n_refs > 1 && pct(&g->rng, sp->compound_pct);

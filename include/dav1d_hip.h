@@ -596,6 +596,12 @@ DAV1D_HIP_API int dav1d_hip_frame_submit_intra_sorted(Dav1dHipFrame *f, size_t n
 /* Inter-intra blends of wavefront step `step` >= 1 (kind DAV1D_HIP_COMP_BLEND reading what the step's DAV1D_HIP_IPRED_PRED_TMP
  * tasks wrote): run between the step's predictions and its residuals.  Thread-safe. */
 DAV1D_HIP_API int dav1d_hip_frame_submit_step_blend(Dav1dHipFrame *f, size_t step, const Dav1dHipCompTask *blend, size_t n);
+/* Intra block copy (recon_b_inter on key / intra-only frames, reference src/recon_tmpl.c:1583-1597): predictions that read the
+ * frame's OWN reconstruction.  tasks[i] is an ordinary prediction record (kind DAV1D_HIP_MC_PUT, filter_2d 9 = bilinear, `ref`
+ * ignored: the source is the picture the frame is reconstructed into, bounded by its size rounded up to whole 8x8 blocks) that
+ * runs in wavefront step steps[i] >= 1 — after every block of the earlier steps is final, before the step's residuals.  Frames that
+ * carry such tasks run their wavefront as launches per step (not as the dataflow launch).  Thread-safe. */
+DAV1D_HIP_API int dav1d_hip_frame_submit_step_copy(Dav1dHipFrame *f, const Dav1dHipMcTask *tasks, const uint16_t *steps, size_t n);
 /* Warped predictions / predictions from references of another size of any tile-sbrow; run before the compound combinations. */
 DAV1D_HIP_API int dav1d_hip_frame_submit_warp(Dav1dHipFrame *f, const Dav1dHipWarpTask *t, size_t n);
 DAV1D_HIP_API int dav1d_hip_frame_submit_scaled(Dav1dHipFrame *f, const Dav1dHipMcScaledTask *t, size_t n);
@@ -679,7 +685,7 @@ typedef struct Dav1dHipFrameDesc {
     int layout, bpc;             /* f->cur.p.layout / bpc */
     int sb128;                   /* seq_hdr->sb128 */
     int intra_edge_filter;       /* seq_hdr->intra_edge_filter */
-    int is_inter;                /* IS_INTER_OR_SWITCH(frame_hdr): 0 on key / intra-only frames (intra block copy: -ENOTSUP) */
+    int is_inter;                /* IS_INTER_OR_SWITCH(frame_hdr): 0 on key / intra-only frames (their inter-coded blocks are intra block copies) */
     int n_tile_cols, n_tile_rows;           /* frame_hdr->tiling.cols / rows */
     uint16_t col_start_sb[65], row_start_sb[65];    /* frame_hdr->tiling.col_start_sb / row_start_sb */
     ptrdiff_t b4_stride;         /* f->b4_stride */
@@ -813,6 +819,8 @@ typedef struct Dav1dHipSynthParams {
     int split_pct[5], rect_pct;              /* per block level 128 .. 8: split; among the rest: a non-square partition */
     int fixed_bl;                            /* >= 0: every block is the square of that level (0 = 128x128 .. 4 = 8x8, 5 = 4x4) */
     int cf_align64;                          /* == Dav1dHipFrameDesc.cf_align64 */
+    int intrabc_pct;                         /* key / intra-only frames: blocks (up to 64x64) coded as intra block copies where a source
+                                                rectangle exists in the tile's superblock rows above or 256 pixels to the left */
 } Dav1dHipSynthParams;
 DAV1D_HIP_API int dav1d_hip_synth_frame(const Dav1dHipFrameDesc *desc, const Dav1dHipSynthParams *sp, void *cf, size_t cf_bytes,
                                         size_t cbi_entries, uint8_t *pal_idx, size_t pal_idx_bytes);

@@ -38,6 +38,9 @@ def run_case(ctx, w, h, layout, bpc, seed, is_inter=True, tiles=(1, 1), threads=
     try:
         sp = lu.default_synth(seed, **kw)
         d = lu.synth(ctx, rf, sp)
+        if kw.get("intrabc_pct"):       # the case is about intra block copies: there must be some (Av1Block byte 3 = intra, byte 1 = bs)
+            blk = rf.array("b", np.uint8).reshape(-1, 32)
+            assert int(((blk[:, 3] == 0) & ((blk[:, 0] | blk[:, 1]) != 0)).sum()) > 50
         lu.fill_pictures(rf, seed + 1)
         rf.recon()
         got, st = lu.run_hip(ctx, rf, d, threads)
@@ -148,6 +151,11 @@ MIX = [
     ("key_420_8", 256, 192, 1, 8, dict(is_inter=False)),
     ("key_444_10", 192, 128, 3, 10, dict(is_inter=False)),
     ("key_palette", 256, 192, 1, 8, dict(is_inter=False, palette=40)),
+    # intra block copy (recon_b_inter on a key frame, src/recon_tmpl.c:1583-1597): sources above and to the left, odd vectors
+    # (chroma half positions in 4:2:0 / 4:2:2), 4-wide / 4-high blocks carrying the chroma of their 8x8, several tiles
+    ("key_intrabc_420_8", 512, 320, 1, 8, dict(is_inter=False, intrabc_pct=45, tiles=(2, 1))),
+    ("key_intrabc_444_10", 384, 256, 3, 10, dict(is_inter=False, intrabc_pct=60)),
+    ("key_intrabc_422_12_sb64", 520, 264, 2, 12, dict(is_inter=False, intrabc_pct=50, sb128=False, palette=20)),
     ("inter_palette_10", 256, 192, 1, 10, dict(palette=40, intra_pct=50)),
     ("global_motion", 256, 192, 1, 8, dict(gmv=GMV, global_pct=40)),
     ("global_motion_444", 192, 192, 3, 10, dict(gmv=GMV, global_pct=40)),
@@ -156,6 +164,7 @@ MIX = [
 ]
 # the SIMT-emulated kernels are slow: the CPU run takes a cross-section, the GPU run everything
 MIX_CPU = {"420_8", "420_12_cut", "444_10", "422_10", "400_8", "tiles_3_threads", "sb64_tiles", "key_444_10", "key_palette",
+           "key_intrabc_420_8", "key_intrabc_444_10", "key_intrabc_422_12_sb64",
            "global_motion", "scaled_refs_444_10"}
 
 
