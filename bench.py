@@ -472,6 +472,9 @@ def main():
                          "achieved": round(path_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                          "frac": round(path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                 "kernels_ms": {k[0]: round(k[1], 4) for k in kernels},
+                # every kernel of the step against the same roofline (algorithmic bytes of its launch / its time / peak): the
+                # dominant one above is the longest, not the best or the worst
+                "kernels_frac": {k[0]: round(k[2] / (k[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k in kernels if k[1] > 0 and k[2] > 0},
                 "kernels_two_phase_ms": {k[0]: round(k[1], 4) for k in kernels_two_phase}}
         # measured HBM bytes of the whole step (sum of the committed per-kernel PMC figures) next to the algorithmic ones:
         # what the memory system really moved per frame, and the rate that is at this step time
