@@ -59,6 +59,9 @@ struct Dav1dHipFrame {
     int is_id;
     Dav1dHipPicture tmp[2];          // CDEF output, restoration output (allocated on first use)
     bool have_tmp[2];
+    int sr_w;                        // super-resolution: width after the upscale between CDEF and restoration (0: none)
+    Dav1dHipPicture sr[3];           // upscaled: CDEF output, deblocked rows (restoration's stripe borders), restoration output
+    bool have_sr[3];
     int post_bands;                  // bands the post filters of the last dav1d_hip_frame_end ran in (0: stage by stage)
     std::thread worker;              // dav1d_hip_frame_end_async
     std::atomic<int> progress_rows;
@@ -95,6 +98,7 @@ static int post_filters_pipelined(Dav1dHipFrame *f, const Dav1dHipPicture **last
     Dav1dHipContext *c = f->c;
     const bool has_lf = !f->lf.empty(), has_cdef = !f->cdef.empty(), has_lr = !f->lr.empty();
     if (!c->concurrent || (int) has_lf + has_cdef + has_lr < 2) return 1;
+    if (f->sr_w) return 1;                 // super-resolution: the upscale sits between CDEF and restoration, stage by stage
     // DAV1D_HIP_POST_BANDS = bands per frame.  Off unless asked for: measured on MI355X (8K 10-bit frame: deblock 0.15 + CDEF
     // 0.58 + restoration 0.26 = 0.99 ms stage by stage) the banded pipeline takes 1.14 ms with 3 bands, 1.21 with 6, 1.78 with
     // 17 — every cross-stream event costs a release / acquire of the caches, about 45 us per band, more than the overlap of
@@ -303,6 +307,8 @@ int dav1d_hip_frame_begin(Dav1dHipContext *c, Dav1dHipFrame **out, const Dav1dHi
     f->prepared = nullptr;
     f->is_id = 0;
     f->have_tmp[0] = f->have_tmp[1] = false;
+    f->sr_w = 0;
+    f->have_sr[0] = f->have_sr[1] = f->have_sr[2] = false;
     f->post_bands = 0;
     f->progress_rows.store(0);
     f->async_rc = 0;
@@ -661,11 +667,50 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
             if (!rc) rc = dav1d_hip_cdef_batch(c, &f->tmp[0], &f->cur, f->cdef.data(), f->cdef.size(), f->cdef_damping, nullptr);
             last = &f->tmp[0];
         }
+        const Dav1dHipPicture *lpf = &f->cur;        // the deblocked picture: what restoration reads across its stripe borders
+        if (!rc && f->sr_w) {
+            // Super-resolution (dav1d_filter_sbrow_resize, src/recon_tmpl.c:2053-2086; backup_lpf's resize, src/lf_apply_tmpl.c:
+            // 40-100): every row of the CDEF output — and of the deblocked picture, for the rows restoration reads at its stripe
+            // borders — upscaled horizontally.  Step and first position: AV1 spec 7.16 (dav1d_submit_frame, src/decode.c:3531-3539);
+            // the source width is the coded width rounded up to whole 8x8 blocks (4 * f->bw), whose columns the frame did write.
+            const int ssh = f->cur.layout != DAV1D_HIP_LAYOUT_I444;
+            const int in_w[2] = { f->cur.p[0].w, (f->cur.p[0].w + ssh) >> ssh }, out_w[2] = { f->sr_w, (f->sr_w + ssh) >> ssh };
+            const int src_w[2] = { (f->cur.p[0].w + 7) & ~7, (((f->cur.p[0].w + 7) & ~7) + ssh) >> ssh };
+            int step[2], start[2];
+            for (int i = 0; i < 2; i++) {
+                step[i] = ((in_w[i] << 14) + (out_w[i] >> 1)) / out_w[i];
+                const int err = out_w[i] * step[i] - (in_w[i] << 14);
+                start[i] = ((-((out_w[i] - in_w[i]) << 13) + (out_w[i] >> 1)) / out_w[i] + 128 - err / 2) & 0x3fff;
+            }
+            const bool want_lpf = !f->lr.empty();
+            for (int k = 0; k < 2 && !rc; k++) {
+                if (k == 1 && !want_lpf) break;
+                if (!f->have_sr[k]) {
+                    rc = dav1d_hip_picture_alloc(c, &f->sr[k], f->sr_w, f->cur.p[0].h, f->cur.layout, f->cur.bpc);
+                    if (!rc) f->have_sr[k] = true;
+                }
+                const Dav1dHipPicture *from = k ? &f->cur : last;
+                for (int pl = 0; pl < 3 && !rc; pl++)
+                    if (f->cur.p[pl].data)
+                        rc = dav1d_hip_resize(c, &f->sr[k], from, pl, out_w[!!pl], 0, f->cur.p[pl].h, src_w[!!pl], step[!!pl], start[!!pl]);
+            }
+            last = &f->sr[0];
+            lpf = &f->sr[1];
+        }
         if (!rc && !f->lr.empty()) {
-            rc = frame_tmp(f, 1);
-            if (!rc) rc = copy_picture(c, &f->tmp[1], last);
-            if (!rc) rc = dav1d_hip_lr_batch(c, &f->tmp[1], last, &f->cur, f->lr.data(), f->lr.size());
-            last = &f->tmp[1];
+            Dav1dHipPicture *out = &f->tmp[1];
+            if (f->sr_w) {
+                if (!f->have_sr[2]) {
+                    rc = dav1d_hip_picture_alloc(c, &f->sr[2], f->sr_w, f->cur.p[0].h, f->cur.layout, f->cur.bpc);
+                    if (!rc) f->have_sr[2] = true;
+                }
+                out = &f->sr[2];
+            } else {
+                rc = frame_tmp(f, 1);
+            }
+            if (!rc) rc = copy_picture(c, out, last);
+            if (!rc) rc = dav1d_hip_lr_batch(c, out, last, lpf, f->lr.data(), f->lr.size());
+            last = out;
         }
     }
     if (!rc && filtered) *filtered = *last;
@@ -679,6 +724,15 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
 }
 
 extern "C" {
+
+int dav1d_hip_frame_set_super_res(Dav1dHipFrame *f, int sr_w) {
+    if (!f || sr_w < 0) return -EINVAL;
+    if (f->worker.joinable()) return -EBUSY;
+    // AV1: the upscaled width is at most twice the coded one (denominators 9 .. 16 over 8), never smaller
+    if (sr_w && (sr_w < f->cur.p[0].w || sr_w > 2 * f->cur.p[0].w)) return -EINVAL;
+    f->sr_w = sr_w == f->cur.p[0].w ? 0 : sr_w;
+    return 0;
+}
 
 int dav1d_hip_frame_set_progress_callback(Dav1dHipFrame *f, void (*progress)(void *cookie, int rows, const Dav1dHipPicture *pic), void *cookie) {
     if (!f) return -EINVAL;
@@ -735,6 +789,7 @@ void dav1d_hip_frame_destroy(Dav1dHipFrame *f) {
         f->c->free_arenas.push_back({ f->arena, f->arena_cap });
     }
     for (int i = 0; i < 2; i++) if (f->have_tmp[i]) dav1d_hip_picture_free(f->c, &f->tmp[i]);
+    for (int i = 0; i < 3; i++) if (f->have_sr[i]) dav1d_hip_picture_free(f->c, &f->sr[i]);
     delete f;
 }
 

@@ -200,11 +200,12 @@ static void list_lr_unit(const ListerGeo *g, FOut *o, const int x, int y, const 
 static void list_lr(const ListerGeo *g, const Dav1dHipFilterDesc *fd, FOut *o, const int sby) {
     const int sbh = (g->bh + g->sb_step - 1) / g->sb_step;
     const int not_last = sby + 1 < sbh, offset_y = 8 * !!sby;
-    const int sr_sb128w = (g->w + 127) >> 7;
+    const int sr_w = fd->sr_w > 0 ? fd->sr_w : g->w;            /* restoration works on the upscaled frame */
+    const int sr_sb128w = (sr_w + 127) >> 7;
     for (int plane = 0; plane < (g->layout == DAV1D_HIP_LAYOUT_I400 ? 1 : 3); plane++) {
         if (!fd->lr_type[plane]) continue;
         const int ss_ver = plane && g->ss_ver, ss_hor = plane && g->ss_hor;
-        const int h = (g->h + ss_ver) >> ss_ver, w = (g->w + ss_hor) >> ss_hor;
+        const int h = (g->h + ss_ver) >> ss_ver, w = (sr_w + ss_hor) >> ss_hor;
         const int next_row_y = (sby + 1) << ((6 - ss_ver) + g->sb128);
         const int row_h = imin(next_row_y - (8 >> ss_ver) * not_last, h);
         const int y = (sby << ((6 - ss_ver) + g->sb128)) - (offset_y >> ss_ver);

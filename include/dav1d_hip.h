@@ -608,6 +608,12 @@ DAV1D_HIP_API int dav1d_hip_frame_submit_scaled(Dav1dHipFrame *f, const Dav1dHip
 DAV1D_HIP_API int dav1d_hip_frame_submit_filter_sbrow(Dav1dHipFrame *f, const Dav1dHipLfTask *lf, size_t n_lf,
                                                       const Dav1dHipCdefTask *cdef, size_t n_cdef,
                                                       const Dav1dHipLrTask *lr, size_t n_lr);
+/* Super-resolution (reference src/recon_tmpl.c:2053-2086 dav1d_filter_sbrow_resize, src/lf_apply_tmpl.c:40-100 backup_lpf): the frame
+ * is reconstructed, deblocked and CDEF-filtered at its coded width; between CDEF and restoration every row is upscaled to sr_w
+ * pixels by the 8-tap resampler (mc.resize; step and first position from the two widths, AV1 spec 7.16), and so are the deblocked
+ * rows restoration reads at its stripe borders.  The restoration tasks of such a frame are in upscaled coordinates
+ * (Dav1dHipFilterDesc.sr_w); *filtered and grain_out of dav1d_hip_frame_end are sr_w wide.  Call before dav1d_hip_frame_end. */
+DAV1D_HIP_API int dav1d_hip_frame_set_super_res(Dav1dHipFrame *f, int sr_w);
 /* lvl: DEVICE level array; lut_e / lut_i: Av1FilterLUT tables; cdef_damping = frame damping + bpc - 8; grain may be NULL */
 DAV1D_HIP_API int dav1d_hip_frame_set_filters(Dav1dHipFrame *f, const uint8_t *lvl, ptrdiff_t b4_stride, const uint8_t lut_e[64],
                                               const uint8_t lut_i[64], int cdef_damping, const Dav1dHipFilmGrainData *grain, int is_id);
@@ -681,7 +687,7 @@ typedef struct Dav1dHipWarpParams {
 /* Everything of a Dav1dFrameContext the walk reads, as plain values and HOST pointers (nothing is copied: the arrays must
  * stay alive until the last lister call of the frame).  Member comments name the reference field. */
 typedef struct Dav1dHipFrameDesc {
-    int w, h;                    /* f->cur.p.w / h (the coded size; super-resolution is not handled: -ENOTSUP) */
+    int w, h;                    /* f->cur.p.w / h: the coded size (super-resolution upscales after CDEF: dav1d_hip_frame_set_super_res) */
     int layout, bpc;             /* f->cur.p.layout / bpc */
     int sb128;                   /* seq_hdr->sb128 */
     int intra_edge_filter;       /* seq_hdr->intra_edge_filter */
@@ -749,6 +755,8 @@ typedef struct Dav1dHipFilterDesc {
     int lr_type[3];                                /* frame_hdr->restoration.type: 0 = plane not restored */
     int lr_unit_size[2];                           /* frame_hdr->restoration.unit_size (log2), luma / chroma */
     const Dav1dHipAv1Restoration *lr_mask;         /* f->lf.lr_mask */
+    int sr_w;                                      /* super-resolution: frame_hdr->width[1], the width restoration works at and
+                                                      lr_mask is laid out for (f->sr_sb128w); 0 or the coded width: none */
 } Dav1dHipFilterDesc;
 /* One superblock row of filter tasks (what dav1d_filter_sbrow would execute, src/recon_tmpl.c:2100-2109), submitted to the
  * lister's frame.  Thread-safe; any order. */

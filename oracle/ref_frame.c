@@ -44,6 +44,7 @@ typedef struct RefFrameParams {
     int cdef_enabled, cdef_damping, cdef_n_bits;
     int cdef_y_strength[8], cdef_uv_strength[8];
     int lr_type[3], lr_unit_size[2];
+    int sr_w;                     /* super-resolution: width of the upscaled frame (0 or w: none) */
 } RefFrameParams;
 
 typedef struct RefFrame {
@@ -53,8 +54,8 @@ typedef struct RefFrame {
     Dav1dFrameHeader fh, ref_fh[7];
     Dav1dTaskContext *tc;
     atomic_int flush_mem;
-    void *pic_mem[8];
-    size_t plane_bytes[8][3];
+    void *pic_mem[9];             /* 0 current, 1 + i reference i, 8 the upscaled current picture (super-resolution) */
+    size_t plane_bytes[9][3];
     refmvs_temporal_block *mvs;
     RefFrameParams p;
     /* pass-1 stand-in state for the loop filter masks: the above contexts are the pass-1 half of f->a itself */
@@ -143,6 +144,12 @@ void *dav1d_ref_frame_create(const RefFrameParams *const p) {
     seq->restoration = p->lr_type[0] || p->lr_type[1] || p->lr_type[2];
     fh->frame_type = p->is_inter ? DAV1D_FRAME_TYPE_INTER : DAV1D_FRAME_TYPE_KEY;
     fh->width[0] = fh->width[1] = p->w;
+    if (p->sr_w && p->sr_w != p->w) {
+        /* super-resolution: the frame is coded p->w wide and upscaled to p->sr_w between CDEF and restoration */
+        fh->width[1] = p->sr_w;
+        fh->super_res.enabled = 1;
+        fh->super_res.width_scale_denominator = (8 * p->sr_w + p->w / 2) / p->w;       /* parse-side only; the filters use the widths */
+    }
     fh->height = p->h;
     fh->frame_offset = p->cur_poc;
     fh->allow_screen_content_tools = p->allow_screen_content_tools;
@@ -187,6 +194,20 @@ void *dav1d_ref_frame_create(const RefFrameParams *const p) {
     if (alloc_picture(r, 0, &f->cur, p->w, p->h, p->layout, p->bpc)) goto fail;
     f->cur.seq_hdr = seq; f->cur.frame_hdr = fh;
     f->sr_cur.p = f->cur;
+    if (fh->super_res.enabled) {
+        /* dav1d_submit_frame(), src/decode.c:3524-3540: a picture of its own for the upscaled frame, the step and the first
+         * position of the horizontal resampler (AV1 spec 7.16) per plane class */
+        if (alloc_picture(r, 8, &f->sr_cur.p, p->sr_w, p->h, p->layout, p->bpc)) goto fail;
+        f->sr_cur.p.seq_hdr = seq; f->sr_cur.p.frame_hdr = fh;
+        const int ss_hor = p->layout != DAV1D_PIXEL_LAYOUT_I444;
+        const int in_w[2] = { p->w, (p->w + ss_hor) >> ss_hor }, out_w[2] = { p->sr_w, (p->sr_w + ss_hor) >> ss_hor };
+        for (int i = 0; i < 2; i++) {
+            const int step = ((in_w[i] << 14) + (out_w[i] >> 1)) / out_w[i];
+            const int err = out_w[i] * step - (in_w[i] << 14);
+            f->resize_step[i] = step;
+            f->resize_start[i] = ((-((out_w[i] - in_w[i]) << 13) + (out_w[i] >> 1)) / out_w[i] + 128 - err / 2) & 0x3fff;
+        }
+    }
     if (p->is_inter)
         for (int i = 0; i < 7; i++) {
             if (alloc_picture(r, 1 + i, &f->refp[i].p, p->ref_w[i], p->ref_h[i], p->layout, p->bpc)) goto fail;
@@ -258,7 +279,7 @@ fail:
 void dav1d_ref_frame_destroy(void *const h) {
     RefFrame *const r = h;
     if (!r) return;
-    for (int i = 0; i < 8; i++) free(r->pic_mem[i]);
+    for (int i = 0; i < 9; i++) free(r->pic_mem[i]);
     free(r->tc);
     free(r->mvs);
     /* the per-frame arrays dav1d_decode_frame_init() allocated stay with the process: test infrastructure */
@@ -291,12 +312,13 @@ void *dav1d_ref_frame_ptr(void *const h, const char *const name, size_t *const b
     else if (IS("a")) { ptr = f->a; n = sizeof(*f->a) * f->a_sz; }
     else if (IS("tx_lpf_right_edge0")) { ptr = f->lf.tx_lpf_right_edge[0]; n = (size_t) f->lf.re_sz * 32; }
     else if (IS("tx_lpf_right_edge1")) { ptr = f->lf.tx_lpf_right_edge[1]; n = (size_t) f->lf.re_sz * 32; }
-    else if (!strncmp(name, "pic", 3) && name[3] >= '0' && name[3] <= '7' && name[4] == '_' && name[5] >= '0' && name[5] <= '2') {
-        /* pic<slot>_<plane>: slot 0 = the current picture, 1 + i = reference i */
+    else if (!strncmp(name, "pic", 3) && name[3] >= '0' && name[3] <= '8' && name[4] == '_' && name[5] >= '0' && name[5] <= '2') {
+        /* pic<slot>_<plane>: slot 0 = the current picture, 1 + i = reference i, 8 = the upscaled current picture */
         const int slot = name[3] - '0', pl = name[5] - '0';
-        const Dav1dPicture *pic = slot ? &f->refp[slot - 1].p : &f->cur;
-        ptr = pic->data[pl]; n = r->plane_bytes[slot][pl];
+        const Dav1dPicture *pic = slot == 8 ? &f->sr_cur.p : slot ? &f->refp[slot - 1].p : &f->cur;
+        ptr = pic->data[pl]; n = slot == 8 && !r->pic_mem[8] ? 0 : r->plane_bytes[slot][pl];
     }
+    else if (IS("resize")) { ptr = f->resize_step; n = sizeof(f->resize_step) + sizeof(f->resize_start); }
 #undef IS
     if (bytes) *bytes = n;
     return ptr;
@@ -309,6 +331,7 @@ void dav1d_ref_frame_geometry(void *const h, int64_t *const out) {
     out[0] = f->b4_stride; out[1] = f->bw; out[2] = f->bh; out[3] = f->sb128w; out[4] = f->sbh;
     out[5] = f->cur.stride[0]; out[6] = f->cur.stride[1];
     for (int i = 0; i < 7; i++) { out[7 + 2 * i] = f->refp[i].p.stride[0]; out[8 + 2 * i] = f->refp[i].p.stride[1]; }
+    out[21] = f->sr_cur.p.stride[0]; out[22] = f->sr_cur.p.stride[1]; out[23] = f->sr_sb128w;
 }
 
 /* sizeof / offsetof of the reference's hand-off structs, for pinning the product's mirrors */

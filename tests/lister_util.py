@@ -21,7 +21,7 @@ class RefFrameParams(C.Structure):
                 ("lf_level_y", C.c_int * 2), ("lf_level_u", C.c_int), ("lf_level_v", C.c_int), ("lf_sharpness", C.c_int),
                 ("lf_mode_ref_delta_enabled", C.c_int), ("lf_ref_delta", C.c_int * 8), ("lf_mode_delta", C.c_int * 2),
                 ("cdef_enabled", C.c_int), ("cdef_damping", C.c_int), ("cdef_n_bits", C.c_int), ("cdef_y_strength", C.c_int * 8),
-                ("cdef_uv_strength", C.c_int * 8), ("lr_type", C.c_int * 3), ("lr_unit_size", C.c_int * 2)]
+                ("cdef_uv_strength", C.c_int * 8), ("lr_type", C.c_int * 3), ("lr_unit_size", C.c_int * 2), ("sr_w", C.c_int)]
 
 
 def ref_lib():
@@ -55,7 +55,7 @@ class RefFrame:
     """One synthetic frame inside a real Dav1dFrameContext of the reference build."""
 
     def __init__(self, w, h, layout, bpc, is_inter=True, sb128=True, tile_cols=1, tile_rows=1, ref_sizes=None, gmv=None,
-                 intra_edge_filter=1, screen_content=0, order_hint_bits=5, filters=None):
+                 intra_edge_filter=1, screen_content=0, order_hint_bits=5, filters=None, sr_w=0):
         self.lib = ref_lib()
         assert self.lib is not None, "the reference build oracle/_ref is required"
         p = RefFrameParams()
@@ -101,12 +101,15 @@ class RefFrame:
                 for i in range(3):
                     p.lr_type[i] = types[i]
                 p.lr_unit_size[0], p.lr_unit_size[1] = units
+        p.sr_w = sr_w if sr_w and sr_w != w else 0
+        self.sr_w = p.sr_w
         self.filters = filters
         self.p = p
         self.h = self.lib.dav1d_ref_frame_create(C.byref(p))
         assert self.h, "dav1d_ref_frame_create failed"
-        geo = (C.c_int64 * 21)()
+        geo = (C.c_int64 * 24)()
         self.lib.dav1d_ref_frame_geometry(self.h, geo)
+        self.sr_stride = (int(geo[21]), int(geo[22]))
         self.b4_stride, self.bw, self.bh, self.sb128w, self.sbh = [int(geo[i]) for i in range(5)]
         self.cur_stride = (int(geo[5]), int(geo[6]))
         self.ref_stride = [(int(geo[7 + 2 * i]), int(geo[8 + 2 * i])) for i in range(7)]
@@ -128,7 +131,7 @@ class RefFrame:
     def plane(self, slot, pl):
         """(rows x stride) view of a plane of picture slot 0 (current) or 1 + i (reference i), in pixels"""
         a = self.array("pic%d_%d" % (slot, pl), np.uint8 if self.bpc == 8 else np.uint16)
-        stride = (self.cur_stride if slot == 0 else self.ref_stride[slot - 1])[1 if pl else 0]
+        stride = (self.cur_stride if slot == 0 else self.sr_stride if slot == 8 else self.ref_stride[slot - 1])[1 if pl else 0]
         spx = stride // a.itemsize
         return a[:(len(a) // spx) * spx].reshape(-1, spx)
 
@@ -197,6 +200,7 @@ class RefFrame:
 
     def filter(self):
         assert self.lib.dav1d_ref_frame_filter(self.h) == 0
+        self.filtered_is_upscaled = bool(self.sr_w)      # the final picture is sr_cur (slot 8) then
 
     def filter_desc(self):
         fd = _lib.FilterDesc()
@@ -219,6 +223,7 @@ class RefFrame:
             fd.lr_type[i] = p.lr_type[i]
         fd.lr_unit_size[0], fd.lr_unit_size[1] = p.lr_unit_size[0], p.lr_unit_size[1]
         fd.lr_mask = self.ptr("lr_mask")[0]
+        fd.sr_w = self.sr_w
         return fd
 
     def destroy(self):
@@ -362,9 +367,11 @@ def run_hip(ctx, rf, d, threads=1, with_filters=False, own_masks=False):
             lvl = ctx.buffer_from(rf.array("lf_level", np.uint8))
         lut = rf.array("lim_lut", np.uint8)          # Av1FilterLUT: e[64], i[64], sharp[2]
         frame.set_filters(lvl, rf.b4_stride, lut[0:64], lut[64:128], rf.p.cdef_damping + rf.bpc - 8)
+        if rf.sr_w:
+            assert ctx.lib.dav1d_hip_frame_set_super_res(frame.h, rf.sr_w) == 0
     filtered = frame.end(coef, prep, mask)
     if with_filters:
-        fpic = api.DevicePicture.view(ctx, filtered, rf.w, rf.ht, rf.layout, rf.bpc)
+        fpic = api.DevicePicture.view(ctx, filtered, rf.sr_w or rf.w, rf.ht, rf.layout, rf.bpc)
         out = [fpic.download(pl) for pl in range(n_pl)]
     else:
         out = [cur.download(pl) for pl in range(n_pl)]
@@ -386,10 +393,12 @@ def compare(rf, got):
     ss_hor = 1 if rf.layout in (1, 2) else 0
     ss_ver = 1 if rf.layout == 1 else 0
     bad = []
+    slot = 8 if getattr(rf, "sr_w", 0) and getattr(rf, "filtered_is_upscaled", False) else 0
+    fw = rf.sr_w if slot == 8 else rf.w
     for pl in range(n_pl):
-        w = rf.w if not pl else (rf.w + ss_hor) >> ss_hor
+        w = fw if not pl else (fw + ss_hor) >> ss_hor
         h = rf.ht if not pl else (rf.ht + ss_ver) >> ss_ver
-        want = rf.plane(0, pl)[:h, :w]
+        want = rf.plane(slot, pl)[:h, :w]
         have = got[pl][:h, :w]
         if not np.array_equal(want, have):
             yy, xx = np.nonzero(want != have)

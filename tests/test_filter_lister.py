@@ -22,8 +22,8 @@ LR_BIG = dict(lr=([3, 1, 2], [8, 7]))
 ALL = dict(LF, **CDEF, **LR_SW)
 
 
-def run_case(ctx, w, h, layout, bpc, seed, filters, is_inter=True, tiles=(1, 1), sb128=True, own_masks=False, **kw):
-    rf = lu.RefFrame(w, h, layout, bpc, is_inter=is_inter, tile_cols=tiles[0], tile_rows=tiles[1], sb128=sb128, filters=filters)
+def run_case(ctx, w, h, layout, bpc, seed, filters, is_inter=True, tiles=(1, 1), sb128=True, own_masks=False, sr_w=0, **kw):
+    rf = lu.RefFrame(w, h, layout, bpc, is_inter=is_inter, tile_cols=tiles[0], tile_rows=tiles[1], sb128=sb128, filters=filters, sr_w=sr_w)
     try:
         sp = lu.default_synth(seed, **kw)
         d = lu.synth(ctx, rf, sp)
@@ -33,7 +33,10 @@ def run_case(ctx, w, h, layout, bpc, seed, filters, is_inter=True, tiles=(1, 1),
         n_pl = 1 if layout == 0 else 3
         before = [rf.plane(0, pl).copy() for pl in range(n_pl)]
         rf.filter()
-        assert any(not np.array_equal(before[pl], rf.plane(0, pl)) for pl in range(n_pl)), "the filters changed nothing: vacuous case"
+        if not sr_w:
+            assert any(not np.array_equal(before[pl], rf.plane(0, pl)) for pl in range(n_pl)), "the filters changed nothing: vacuous case"
+        else:
+            assert rf.plane(8, 0)[:h, :sr_w].any(), "the upscaled picture is empty: vacuous case"
         got, _ = lu.run_hip(ctx, rf, d, 1, with_filters=True, own_masks=own_masks)
         bad = lu.compare(rf, got)
         assert not bad, "filtered planes differ from dav1d_filter_sbrow: (plane, pixels, first y, x, want, got) %s" % bad
@@ -59,9 +62,16 @@ CASES = [
     ("all_tiles", 320, 200, 1, 10, ALL, dict(tiles=(2, 2))),
     ("all_key_frame", 320, 200, 1, 8, ALL, dict(is_inter=False)),
     ("all_sb64_cut", 296, 168, 1, 10, ALL, dict(sb128=False, tiles=(2, 2))),
+    # super-resolution (dav1d_filter_sbrow_resize between CDEF and restoration; restoration units, their lr_mask and the stripe
+    # border rows in the upscaled frame): denominators 9 .. 16 of the coded width
+    ("superres_all_420_8", 320, 200, 1, 8, ALL, dict(sr_w=480, tiles=(2, 1))),
+    ("superres_cdef_only_444_10", 256, 136, 3, 10, CDEF, dict(sr_w=288)),
+    ("superres_lr_big_units_10", 320, 264, 1, 10, dict(LF, **LR_BIG), dict(sr_w=640)),
+    ("superres_key_422_12", 264, 136, 2, 12, ALL, dict(sr_w=400, is_inter=False)),
 ]
 CPU = {"deblock_deltas_tiles", "deblock_sb64_tiles", "deblock_444", "deblock_400", "cdef_8_strengths_12bit", "cdef_422", "cdef_skips",
-       "lr_wiener_sgr_128", "lr_256_units_444", "all_tiles", "all_key_frame", "all_sb64_cut"}
+       "lr_wiener_sgr_128", "lr_256_units_444", "all_tiles", "all_key_frame", "all_sb64_cut", "superres_all_420_8",
+       "superres_cdef_only_444_10", "superres_lr_big_units_10", "superres_key_422_12"}
 
 
 @pytest.mark.parametrize("name,w,h,layout,bpc,filters,kw", CASES, ids=[c[0] for c in CASES])
