@@ -68,10 +68,11 @@ CASES = [
     ("superres_cdef_only_444_10", 256, 136, 3, 10, CDEF, dict(sr_w=288)),
     ("superres_lr_big_units_10", 320, 264, 1, 10, dict(LF, **LR_BIG), dict(sr_w=640)),
     ("superres_key_422_12", 264, 136, 2, 12, ALL, dict(sr_w=400, is_inter=False)),
+    ("superres_width_not_8n", 324, 200, 1, 8, ALL, dict(sr_w=486)),     # the resampler reads the columns up to the 8x8 block grid
 ]
 CPU = {"deblock_deltas_tiles", "deblock_sb64_tiles", "deblock_444", "deblock_400", "cdef_8_strengths_12bit", "cdef_422", "cdef_skips",
        "lr_wiener_sgr_128", "lr_256_units_444", "all_tiles", "all_key_frame", "all_sb64_cut", "superres_all_420_8",
-       "superres_cdef_only_444_10", "superres_lr_big_units_10", "superres_key_422_12"}
+       "superres_cdef_only_444_10", "superres_lr_big_units_10", "superres_key_422_12", "superres_width_not_8n"}
 
 
 @pytest.mark.parametrize("name,w,h,layout,bpc,filters,kw", CASES, ids=[c[0] for c in CASES])
