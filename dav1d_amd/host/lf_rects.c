@@ -18,6 +18,8 @@ typedef struct RectOut { Dav1dHipLfRect *p; size_t n, cap; int err; } RectOut;
 typedef struct LfWalk {
     const Dav1dHipFrameDesc *d;
     const uint8_t (*lflvl)[4][8][2];
+    const uint8_t (*sb_lflvl)[8][4][8][2];       /* delta_lf: one table per superblock, raster order (NULL: the frame's table) */
+    int sb_shift, sbw;
     RectOut *o;
     int w4, h4, bw, bh, ss_hor, ss_ver;
 } LfWalk;
@@ -83,7 +85,9 @@ static void lf_block(const LfWalk *w, const int bs, const int bx, const int by) 
         ref = b->u.p.ref[0] + 1;
         nz = b->u.p.inter_mode != (is_comp ? H_GLOBALMV_GLOBALMV : H_GLOBALMV);
     }
-    const uint8_t (*lv)[8][2] = w->lflvl[b->seg_id];
+    /* delta_lf: the levels of a block come from the table its superblock was parsed with (ts->lflvlmem, src/decode.c:1180-1206) */
+    const uint8_t (*const tab)[4][8][2] = w->sb_lflvl ? w->sb_lflvl[(by >> w->sb_shift) * w->sbw + (bx >> w->sb_shift)] : w->lflvl;
+    const uint8_t (*lv)[8][2] = tab[b->seg_id];
     const int l0 = lv[0][ref][nz], l1 = lv[1][ref][nz], l2 = lv[2][ref][nz], l3 = lv[3][ref][nz];
     if (bw4 > 0 && bh4 > 0) {
         if (!inter) tiles(w, DAV1D_HIP_LF_RECT_LUMA, b->u.i.tx, bx, by, bw4, bh4, 2, l0, l1);
@@ -163,12 +167,20 @@ static void walk(const LfWalk *w, const int bl, const int bx, const int by) {
 
 /* every block of the frame -> rectangles (malloc'ed array in *out, the caller frees it) */
 int dav1d_hip_lf_rects(const Dav1dHipFrameDesc *d, const uint8_t lflvl[8][4][8][2], Dav1dHipLfRect **out, size_t *n) {
+    return dav1d_hip_lf_rects_sb(d, lflvl, NULL, out, n);
+}
+
+int dav1d_hip_lf_rects_sb(const Dav1dHipFrameDesc *d, const uint8_t lflvl[8][4][8][2], const uint8_t (*sb_lflvl)[8][4][8][2],
+                          Dav1dHipLfRect **out, size_t *n) {
     if (!d || !lflvl || !out || !n || !d->b || d->layout < 0 || d->layout > 3) return -EINVAL;
     h_tables_init();
     RectOut o;
     memset(&o, 0, sizeof(o));
     LfWalk w;
     w.d = d; w.lflvl = lflvl; w.o = &o;
+    w.sb_lflvl = sb_lflvl;
+    w.sb_shift = d->sb128 ? 5 : 4;
+    w.sbw = ((((d->w + 7) >> 3) << 1) + (1 << w.sb_shift) - 1) >> w.sb_shift;
     w.w4 = (d->w + 3) >> 2; w.h4 = (d->h + 3) >> 2;
     w.bw = ((d->w + 7) >> 3) << 1; w.bh = ((d->h + 7) >> 3) << 1;
     w.ss_hor = d->layout != DAV1D_HIP_LAYOUT_I444; w.ss_ver = d->layout == DAV1D_HIP_LAYOUT_I420;

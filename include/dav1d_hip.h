@@ -781,6 +781,12 @@ typedef struct Dav1dHipLfRect {
 /* lflvl = ts->lflvl (== f->lf.lvl without delta_lf): [segment][0 y-vert, 1 y-hor, 2 u, 3 v][reference + 1][mode is not GLOBALMV].
  * *out is malloc'ed; release it with dav1d_hip_lf_rects_free. */
 DAV1D_HIP_API int dav1d_hip_lf_rects(const Dav1dHipFrameDesc *d, const uint8_t lflvl[8][4][8][2], Dav1dHipLfRect **out, size_t *n);
+/* The same with delta_lf (frame_hdr->delta.lf.present): pass 1 recomputes the level table whenever a superblock brings new deltas
+ * (dav1d_calc_lf_values into ts->lflvlmem, reference src/decode.c:1180-1206), so a block's levels come from the table its
+ * superblock was parsed with.  sb_lflvl[sb row * sbw + sb column] = that table (sbw = superblock columns of the frame; the glue
+ * keeps a copy of ts->lflvlmem per superblock); NULL = dav1d_hip_lf_rects. */
+DAV1D_HIP_API int dav1d_hip_lf_rects_sb(const Dav1dHipFrameDesc *d, const uint8_t lflvl[8][4][8][2], const uint8_t (*sb_lflvl)[8][4][8][2],
+                                        Dav1dHipLfRect **out, size_t *n);
 DAV1D_HIP_API void dav1d_hip_lf_rects_free(Dav1dHipLfRect *p);
 /* masks_out: HOST, one Av1Filter per 128x128 (filter_y, filter_uv, noskip_mask written; cdef_idx zeroed: it comes from the
  * bitstream).  level_dev: DEVICE level cache (uint8_t[4] per 4x4, pitch d->b4_stride).  right_edge[0 luma, 1 chroma]: HOST,

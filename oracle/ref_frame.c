@@ -45,6 +45,7 @@ typedef struct RefFrameParams {
     int cdef_y_strength[8], cdef_uv_strength[8];
     int lr_type[3], lr_unit_size[2];
     int sr_w;                     /* super-resolution: width of the upscaled frame (0 or w: none) */
+    int delta_lf;                 /* 1: delta_lf present — every superblock gets level deltas of its own (2: one delta for all four levels) */
 } RefFrameParams;
 
 typedef struct RefFrame {
@@ -62,6 +63,10 @@ typedef struct RefFrame {
     BlockContext lf_l;
     int cur_tile_row;
     uint32_t rng;
+    /* delta_lf: the level table pass 1 would have had in ts->lflvlmem while it parsed superblock [sb row * sbw + sb column]
+     * (dav1d_calc_lf_values with the superblock's deltas, src/decode.c:1180-1206) */
+    uint8_t (*sb_lflvl)[8][4][8][2];
+    int sbw;
 } RefFrame;
 
 static void once_init(void) {
@@ -282,6 +287,7 @@ void dav1d_ref_frame_destroy(void *const h) {
     for (int i = 0; i < 9; i++) free(r->pic_mem[i]);
     free(r->tc);
     free(r->mvs);
+    free(r->sb_lflvl);
     /* the per-frame arrays dav1d_decode_frame_init() allocated stay with the process: test infrastructure */
     free(r);
 }
@@ -306,6 +312,7 @@ void *dav1d_ref_frame_ptr(void *const h, const char *const name, size_t *const b
     else if (IS("gmv")) { ptr = r->fh.gmv; n = sizeof(r->fh.gmv); }
     else if (IS("lf_mask")) { ptr = f->lf.mask; n = sizeof(*f->lf.mask) * num_sb128; }
     else if (IS("lflvl")) { ptr = f->lf.lvl; n = sizeof(f->lf.lvl); }
+    else if (IS("sb_lflvl")) { ptr = r->sb_lflvl; n = r->sb_lflvl ? sizeof(*r->sb_lflvl) * (size_t) r->sbw * f->sbh : 0; }
     else if (IS("lf_level")) { ptr = f->lf.level; n = sizeof(*f->lf.level) * num_sb128 * 32 * 32; }
     else if (IS("lr_mask")) { ptr = f->lf.lr_mask; n = sizeof(*f->lf.lr_mask) * f->lf.lr_mask_sz; }
     else if (IS("lim_lut")) { ptr = &f->lf.lim_lut; n = sizeof(f->lf.lim_lut); }
@@ -535,6 +542,13 @@ static void walk_common(Dav1dTaskContext *const t, const enum BlockSize bs, cons
     }
 }
 
+/* ts->lflvl as pass 1 had it at this block: the frame's table, or the superblock's own with delta_lf */
+static const uint8_t (*walk_lflvl(const RefFrame *const r, const Dav1dTaskContext *const t))[4][8][2] {
+    if (!r->sb_lflvl) return t->ts->lflvl;
+    const Dav1dFrameContext *const f = t->f;
+    return (const uint8_t (*)[4][8][2]) r->sb_lflvl[(t->by >> f->sb_shift) * r->sbw + (t->bx >> f->sb_shift)];
+}
+
 static void walk_intra(Dav1dTaskContext *const t, const enum BlockSize bs, const enum EdgeFlags flags, const Av1Block *const b) {
     (void) flags;
     RefFrame *const r = g_walk;
@@ -547,7 +561,7 @@ static void walk_intra(Dav1dTaskContext *const t, const enum BlockSize bs, const
     BlockContext *const a = &f->a[r->cur_tile_row * f->sb128w + (t->bx >> 5)];
     if (f->frame_hdr->loopfilter.level_y[0] || f->frame_hdr->loopfilter.level_y[1])
         dav1d_create_lf_mask_intra(f->lf.mask + (t->by >> 5) * f->sb128w + (t->bx >> 5), f->lf.level, f->b4_stride,
-                                   (const uint8_t (*)[8][2]) &ts->lflvl[b->seg_id][0][0][0], t->bx, t->by, f->w4, f->h4, bs,
+                                   (const uint8_t (*)[8][2]) &walk_lflvl(r, t)[b->seg_id][0][0][0], t->bx, t->by, f->w4, f->h4, bs,
                                    b->tx, b->uvtx, f->cur.p.layout, &a->tx_lpf_y[bx4], &r->lf_l.tx_lpf_y[by4],
                                    has_chroma ? &a->tx_lpf_uv[cbx4] : NULL, has_chroma ? &r->lf_l.tx_lpf_uv[cby4] : NULL);
     walk_common(t, bs, b);
@@ -565,7 +579,7 @@ static int walk_inter(Dav1dTaskContext *const t, const enum BlockSize bs, const 
     if (f->frame_hdr->loopfilter.level_y[0] || f->frame_hdr->loopfilter.level_y[1]) {
         const int is_comp = b->comp_type != COMP_INTER_NONE;
         const int is_globalmv = b->inter_mode == (is_comp ? GLOBALMV_GLOBALMV : GLOBALMV);
-        const uint8_t (*const lf_lvls)[8][2] = (const uint8_t (*)[8][2]) &ts->lflvl[b->seg_id][0][b->ref[0] + 1][!is_globalmv];
+        const uint8_t (*const lf_lvls)[8][2] = (const uint8_t (*)[8][2]) &walk_lflvl(r, t)[b->seg_id][0][b->ref[0] + 1][!is_globalmv];
         const uint16_t tx_split[2] = { b->tx_split0, b->tx_split1 };
         dav1d_create_lf_mask_inter(f->lf.mask + (t->by >> 5) * f->sb128w + (t->bx >> 5), f->lf.level, f->b4_stride, lf_lvls,
                                    t->bx, t->by, f->w4, f->h4, b->skip, bs, b->max_ytx, tx_split, b->uvtx, f->cur.p.layout,
@@ -583,6 +597,21 @@ int dav1d_ref_frame_build_filter_inputs(void *const h, const unsigned seed) {
     const Dav1dFrameHeader *const fh = &r->fh;
     const int num_sb128 = f->sb128w * f->sb128h;
     r->rng = seed * 2654435761u + 12345u;
+    if (r->p.delta_lf) {
+        /* one set of deltas per superblock, as read_delta_lf leaves them in ts->last_delta_lf (multiples of 1 << res_log2 inside
+         * +-63), turned into level tables by the reference's own dav1d_calc_lf_values */
+        r->fh.delta.lf.present = 1;
+        r->fh.delta.lf.multi = r->p.delta_lf == 1;
+        r->sbw = (f->bw + f->sb_step - 1) >> f->sb_shift;
+        free(r->sb_lflvl);
+        r->sb_lflvl = calloc((size_t) r->sbw * f->sbh, sizeof(*r->sb_lflvl));
+        if (!r->sb_lflvl) return -1;
+        for (int i = 0; i < r->sbw * f->sbh; i++) {
+            int8_t delta[4];
+            for (int k = 0; k < 4; k++) delta[k] = (int8_t) ((int) (walk_rnd(r) % 97) - 48);
+            dav1d_calc_lf_values(r->sb_lflvl[i], &r->fh, delta);
+        }
+    }
     memset(f->lf.mask, 0, sizeof(*f->lf.mask) * num_sb128);
     for (int i = 0; i < num_sb128; i++) memset(f->lf.mask[i].cdef_idx, -1, 4);
     memset(f->lf.level, 0, sizeof(*f->lf.level) * num_sb128 * 32 * 32);

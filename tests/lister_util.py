@@ -21,7 +21,7 @@ class RefFrameParams(C.Structure):
                 ("lf_level_y", C.c_int * 2), ("lf_level_u", C.c_int), ("lf_level_v", C.c_int), ("lf_sharpness", C.c_int),
                 ("lf_mode_ref_delta_enabled", C.c_int), ("lf_ref_delta", C.c_int * 8), ("lf_mode_delta", C.c_int * 2),
                 ("cdef_enabled", C.c_int), ("cdef_damping", C.c_int), ("cdef_n_bits", C.c_int), ("cdef_y_strength", C.c_int * 8),
-                ("cdef_uv_strength", C.c_int * 8), ("lr_type", C.c_int * 3), ("lr_unit_size", C.c_int * 2), ("sr_w", C.c_int)]
+                ("cdef_uv_strength", C.c_int * 8), ("lr_type", C.c_int * 3), ("lr_unit_size", C.c_int * 2), ("sr_w", C.c_int), ("delta_lf", C.c_int)]
 
 
 def ref_lib():
@@ -55,7 +55,7 @@ class RefFrame:
     """One synthetic frame inside a real Dav1dFrameContext of the reference build."""
 
     def __init__(self, w, h, layout, bpc, is_inter=True, sb128=True, tile_cols=1, tile_rows=1, ref_sizes=None, gmv=None,
-                 intra_edge_filter=1, screen_content=0, order_hint_bits=5, filters=None, sr_w=0):
+                 intra_edge_filter=1, screen_content=0, order_hint_bits=5, filters=None, sr_w=0, delta_lf=0):
         self.lib = ref_lib()
         assert self.lib is not None, "the reference build oracle/_ref is required"
         p = RefFrameParams()
@@ -101,6 +101,7 @@ class RefFrame:
                 for i in range(3):
                     p.lr_type[i] = types[i]
                 p.lr_unit_size[0], p.lr_unit_size[1] = units
+        p.delta_lf = delta_lf
         p.sr_w = sr_w if sr_w and sr_w != w else 0
         self.sr_w = p.sr_w
         self.filters = filters
@@ -341,7 +342,9 @@ def run_hip(ctx, rf, d, threads=1, with_filters=False, own_masks=False):
             # instead of taken from the reference's pass 1; cdef_idx comes from the bitstream, so it is carried over
             lflvl = rf.array("lflvl", np.uint8)
             rects_p, n = C.c_void_p(), C.c_size_t()
-            assert ctx.lib.dav1d_hip_lf_rects(C.byref(d), lflvl.ctypes.data, C.byref(rects_p), C.byref(n)) == 0
+            sbt = rf.array("sb_lflvl", np.uint8)            # delta_lf: one level table per superblock
+            assert ctx.lib.dav1d_hip_lf_rects_sb(C.byref(d), lflvl.ctypes.data, sbt.ctypes.data if sbt is not None and len(sbt) else None,
+                                                 C.byref(rects_p), C.byref(n)) == 0
             bw, bh = ((rf.w + 7) >> 3) << 1, ((rf.ht + 7) >> 3) << 1
             sb128w, sb128h, align_h = (bw + 31) >> 5, (bh + 31) >> 5, (bh + 31) & ~31
             ref_masks = rf.array("lf_mask", np.uint8).reshape(sb128w * sb128h, 1348)

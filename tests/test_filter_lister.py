@@ -22,8 +22,9 @@ LR_BIG = dict(lr=([3, 1, 2], [8, 7]))
 ALL = dict(LF, **CDEF, **LR_SW)
 
 
-def run_case(ctx, w, h, layout, bpc, seed, filters, is_inter=True, tiles=(1, 1), sb128=True, own_masks=False, sr_w=0, **kw):
-    rf = lu.RefFrame(w, h, layout, bpc, is_inter=is_inter, tile_cols=tiles[0], tile_rows=tiles[1], sb128=sb128, filters=filters, sr_w=sr_w)
+def run_case(ctx, w, h, layout, bpc, seed, filters, is_inter=True, tiles=(1, 1), sb128=True, own_masks=False, sr_w=0, delta_lf=0, **kw):
+    rf = lu.RefFrame(w, h, layout, bpc, is_inter=is_inter, tile_cols=tiles[0], tile_rows=tiles[1], sb128=sb128, filters=filters, sr_w=sr_w,
+                     delta_lf=delta_lf)
     try:
         sp = lu.default_synth(seed, **kw)
         d = lu.synth(ctx, rf, sp)
@@ -69,10 +70,11 @@ CASES = [
     ("superres_lr_big_units_10", 320, 264, 1, 10, dict(LF, **LR_BIG), dict(sr_w=640)),
     ("superres_key_422_12", 264, 136, 2, 12, ALL, dict(sr_w=400, is_inter=False)),
     ("superres_width_not_8n", 324, 200, 1, 8, ALL, dict(sr_w=486)),     # the resampler reads the columns up to the 8x8 block grid
+    ("delta_lf_pass1_masks", 520, 264, 1, 8, ALL, dict(delta_lf=1)),     # levels that differ from superblock to superblock
 ]
 CPU = {"deblock_deltas_tiles", "deblock_sb64_tiles", "deblock_444", "deblock_400", "cdef_8_strengths_12bit", "cdef_422", "cdef_skips",
        "lr_wiener_sgr_128", "lr_256_units_444", "all_tiles", "all_key_frame", "all_sb64_cut", "superres_all_420_8",
-       "superres_cdef_only_444_10", "superres_lr_big_units_10", "superres_key_422_12", "superres_width_not_8n"}
+       "superres_cdef_only_444_10", "superres_lr_big_units_10", "superres_key_422_12", "superres_width_not_8n", "delta_lf_pass1_masks"}
 
 
 @pytest.mark.parametrize("name,w,h,layout,bpc,filters,kw", CASES, ids=[c[0] for c in CASES])
@@ -93,7 +95,8 @@ def test_filters_1080p():
 
 
 OWN = [("all_tiles", 320, 200, 1, 10, ALL, dict(tiles=(2, 2))), ("deltas_444_tiles", 256, 136, 3, 10, dict(LF_DELTAS, **CDEF), dict(tiles=(2, 2))),
-       ("key_frame_sb64", 296, 168, 1, 8, ALL, dict(is_inter=False, sb128=False, tiles=(2, 2)))]
+       ("key_frame_sb64", 296, 168, 1, 8, ALL, dict(is_inter=False, sb128=False, tiles=(2, 2))),
+       ("delta_lf_tiles", 520, 264, 1, 10, dict(LF_DELTAS, **CDEF), dict(delta_lf=1, tiles=(2, 1)))]
 
 
 @pytest.mark.parametrize("name,w,h,layout,bpc,filters,kw", OWN, ids=[c[0] for c in OWN])

@@ -32,6 +32,9 @@ CASES = [
     ("400", 256, 136, 0, 8, LF, {}),
     ("key_frame", 320, 200, 1, 8, LF_DELTAS, dict(is_inter=False, tiles=(1, 2))),
     ("skips_and_splits", 384, 264, 1, 10, LF, dict(skip_pct=50, tx_split_pct=60, tiles=(3, 2))),
+    # delta_lf: every superblock parsed with level deltas of its own (four of them / one for all), tables from dav1d_calc_lf_values
+    ("delta_lf_multi", 520, 392, 1, 8, LF_DELTAS, dict(delta_lf=1, tiles=(2, 2))),
+    ("delta_lf_single_sb64_444", 328, 264, 3, 10, LF, dict(delta_lf=2, sb128=False)),
 ]
 
 
@@ -40,7 +43,7 @@ def test_device_built_masks_equal_the_reference_builders(ctx, name, w, h, layout
     kw = dict(kw)
     tiles = kw.pop("tiles", (1, 1))
     rf = lu.RefFrame(w, h, layout, bpc, is_inter=kw.pop("is_inter", True), tile_cols=tiles[0], tile_rows=tiles[1], sb128=kw.pop("sb128", True),
-                     filters=filters)
+                     filters=filters, delta_lf=kw.pop("delta_lf", 0))
     try:
         sp = lu.default_synth(77, **kw)
         d = lu.synth(ctx, rf, sp)
@@ -50,7 +53,11 @@ def test_device_built_masks_equal_the_reference_builders(ctx, name, w, h, layout
         assert len(lflvl) == 8 * 4 * 8 * 2 and lflvl.any()
         # ---- ours
         rects_p, n = C.c_void_p(), C.c_size_t()
-        assert ctx.lib.dav1d_hip_lf_rects(C.byref(d), lflvl.ctypes.data, C.byref(rects_p), C.byref(n)) == 0
+        sbt = rf.array("sb_lflvl", np.uint8)
+        if rf.p.delta_lf:
+            assert sbt is not None and len(sbt) and len(np.unique(sbt.reshape(-1, 512), axis=0)) > 1, "one table for every superblock: vacuous case"
+        assert ctx.lib.dav1d_hip_lf_rects_sb(C.byref(d), lflvl.ctypes.data, sbt.ctypes.data if sbt is not None and len(sbt) else None,
+                                             C.byref(rects_p), C.byref(n)) == 0
         assert n.value > 0
         ss_hor, ss_ver = int(layout != 3), int(layout == 1)
         w4, h4 = (w + 3) >> 2, (h + 3) >> 2
