@@ -119,6 +119,32 @@ def step_traffic(w, h, bpc, a):
     return json.load(open(files[-1])).get("bytes_per_step")
 
 
+def device_probe(torch):
+    """What this particular box is: boxes of one pool have measured 10-15 % apart on every kernel of the step (and 2.7x on the
+    64x64 transform launch) with the same build; the compute units, the clocks the runtime reports and a plain 1 GiB
+    device-to-device copy timed here let a reader tell a slow box from a slow kernel."""
+    try:
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+        n = 1 << 28
+        a = torch.empty(n, dtype=torch.int32, device="cuda")
+        b = torch.empty(n, dtype=torch.int32, device="cuda")
+        a.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 1e9
+        for _ in range(4):
+            e0.record()
+            b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        del a, b
+        return {"name": pr.name, "compute_units": int(pr.multi_processor_count), "clock_mhz": int(getattr(pr, "clock_rate", 0) // 1000),
+                "memory_clock_mhz": int(getattr(pr, "memory_clock_rate", 0) // 1000),
+                "copy_1gib_gbs": round(2 * 4 * n / (best * 1e-3) / 1e9, 1)}       # read + write
+    except Exception as e:       # noqa: BLE001
+        return {"error": str(e)[:120]}
+
+
 def frames_in_flight(api, device, frame, itx_tasks, coef_host, intra, post, ref_host, dst_host, w, h, bpc, want_res, n_ctx_list=(1, 2, 4, 8), n_frames=4):
     """The full DSP table as dav1d's frame threading would drive it: n contexts (one per frame in flight, own streams), each
     running whole frames — recon list, intra waves, deblock, CDEF, restoration, film grain — from device-resident lists, one host
@@ -747,7 +773,8 @@ def main():
                           "coef_format": "packed: eob + 1 scan-order values per block" if a.packed else "dense cf arena (reference layout)",
                           "coef_bytes_per_frame": int(coef_host.nbytes), "coef_h2d_ms_per_frame": h2d_ms,
                           "samples_per_frame": frame.n_samples, "parity": check, "gen_seconds": round(t_gen, 1)},
-               "roofline": roof, "cpu_baseline": cpu, "full_table": full, "end_to_end": e2e_leg, "all_intra": key_leg}
+               "roofline": roof, "cpu_baseline": cpu, "full_table": full, "end_to_end": e2e_leg, "all_intra": key_leg,
+               "device": device_probe(torch)}
         # BASELINE configs[1] (4K 8-bit, the reference's CPU-runnable size) next to the headline: the same bench in a child process,
         # its digest under "config_c1_4k_8bit"
         if world == 1 and not a.no_c1 and not a.step_only and (w, h, bpc) == (7680, 4320, 10):
