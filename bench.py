@@ -121,7 +121,7 @@ def step_traffic(w, h, bpc, a):
 
 def device_probe(torch):
     """What this particular box is: boxes of one pool have measured 10-15 % apart on every kernel of the step (and 2.7x on the
-    64x64 transform launch) with the same build; the compute units, the clocks the runtime reports and a plain 1 GiB
+    64x64 transform launch) with the same build; the compute units the runtime reports and a plain 1 GiB
     device-to-device copy timed here let a reader tell a slow box from a slow kernel."""
     try:
         pr = torch.cuda.get_device_properties(torch.cuda.current_device())
@@ -138,8 +138,7 @@ def device_probe(torch):
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1))
         del a, b
-        return {"name": pr.name, "compute_units": int(pr.multi_processor_count), "clock_mhz": int(getattr(pr, "clock_rate", 0) // 1000),
-                "memory_clock_mhz": int(getattr(pr, "memory_clock_rate", 0) // 1000),
+        return {"name": pr.name, "compute_units": int(pr.multi_processor_count),
                 "copy_1gib_gbs": round(2 * 4 * n / (best * 1e-3) / 1e9, 1)}       # read + write
     except Exception as e:       # noqa: BLE001
         return {"error": str(e)[:120]}

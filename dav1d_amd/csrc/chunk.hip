@@ -405,6 +405,10 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
     return 0;
 }
 
+// the pinned slabs for other users of the library (frame.hip: the merged units of a dataflow launch)
+uint8_t *dav1d_hip_slab_get(Dav1dHipContext *c, size_t bytes, size_t *cap) { return slab_get(c, bytes, cap); }
+void dav1d_hip_slab_put(Dav1dHipContext *c, uint8_t *host, size_t cap) { slab_put(c, host, cap); }
+
 // ------------------------------------------------------------------ gather: chunk segments -> contiguous per-bin arrays
 
 namespace {

@@ -584,24 +584,54 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
             std::vector<size_t> oa(ns + 1, 0), ob(ns + 1, 0);
             size_t total = 0;
             for (size_t s = 0; s < ns; s++) { oa[s] = total; ob[s] = total + na[s]; total += na[s] + nb[s]; }
-            std::vector<IntraUnit> all(total);
-            std::vector<size_t> pa(oa), pb(ob);
-            for (const Dav1dHipFrame::StepChunk *ck : f->step_chunks)
-                for (size_t s = 0; s < ck->ua_end.size(); s++) {
-                    const uint32_t b0 = s ? ck->ub_end[s - 1] : 0, a1 = ck->ua_end[s], b1 = ck->ub_end[s];
-                    if (a1 > b0) { memcpy(&all[pa[s]], &ck->units[b0], (a1 - b0) * sizeof(IntraUnit)); for (uint32_t i = b0; i < a1; i++) all[pa[s]++].need = (uint32_t) oa[s]; }
-                    if (b1 > a1) { memcpy(&all[pb[s]], &ck->units[a1], (b1 - a1) * sizeof(IntraUnit)); for (uint32_t i = a1; i < b1; i++) all[pb[s]++].need = (uint32_t) ob[s]; }
+            // where every chunk's share of every step goes (a running position per step, chunk after chunk), then the copies —
+            // 50 MB for an 8K key frame — on a few threads into pinned memory: the upload is one DMA from there
+            const size_t nck = f->step_chunks.size();
+            std::vector<uint32_t> da(nck * ns, 0), db(nck * ns, 0);
+            {
+                std::vector<size_t> pa(oa), pb(ob);
+                for (size_t k = 0; k < nck; k++) {
+                    const Dav1dHipFrame::StepChunk *ck = f->step_chunks[k];
+                    for (size_t s = 0; s < ck->ua_end.size(); s++) {
+                        const uint32_t b0 = s ? ck->ub_end[s - 1] : 0, a1 = ck->ua_end[s], b1 = ck->ub_end[s];
+                        da[k * ns + s] = (uint32_t) pa[s]; pa[s] += a1 - b0;
+                        db[k * ns + s] = (uint32_t) pb[s]; pb[s] += b1 - a1;
+                    }
                 }
+            }
+            size_t slab_cap = 0;
+            IntraUnit *const all = total ? reinterpret_cast<IntraUnit *>(dav1d_hip_slab_get(c, total * sizeof(IntraUnit), &slab_cap)) : nullptr;
+            if (total && !all) return -ENOMEM;
+            auto copy_chunks = [&](size_t k0, size_t k1) {
+                for (size_t k = k0; k < k1; k++) {
+                    const Dav1dHipFrame::StepChunk *ck = f->step_chunks[k];
+                    for (size_t s = 0; s < ck->ua_end.size(); s++) {
+                        const uint32_t b0 = s ? ck->ub_end[s - 1] : 0, a1 = ck->ua_end[s], b1 = ck->ub_end[s];
+                        IntraUnit *pa = all + da[k * ns + s], *pb = all + db[k * ns + s];
+                        if (a1 > b0) { memcpy(pa, &ck->units[b0], (a1 - b0) * sizeof(IntraUnit)); for (uint32_t i = 0; i < a1 - b0; i++) pa[i].need = (uint32_t) oa[s]; }
+                        if (b1 > a1) { memcpy(pb, &ck->units[a1], (b1 - a1) * sizeof(IntraUnit)); for (uint32_t i = 0; i < b1 - a1; i++) pb[i].need = (uint32_t) ob[s]; }
+                    }
+                }
+            };
+            {
+                const unsigned hw = std::thread::hardware_concurrency();
+                const size_t nt = std::max<size_t>(1, std::min<size_t>({ (size_t) 8, hw ? hw : 1, nck / 16 + 1 }));
+                std::vector<std::thread> th;
+                for (size_t t = 1; t < nt; t++) th.emplace_back(copy_chunks, nck * t / nt, nck * (t + 1) / nt);
+                copy_chunks(0, nck / nt);
+                for (std::thread &x : th) x.join();
+            }
             Dav1dHipIntraFlow *fl = nullptr;
-            rc = dav1d_hip_intra_flow_from_units(c, &fl, all.data(), all.size());
+            rc = dav1d_hip_intra_flow_from_units(c, &fl, all, total);
+            if (all) dav1d_hip_slab_put(c, reinterpret_cast<uint8_t *>(all), slab_cap);         // the upload has synchronised
             const auto t_b = std::chrono::steady_clock::now();
             if (!rc) rc = dav1d_hip_intra_flow_run(c, fl, &f->cur, coef, f->aux);
             uint32_t st[3] = { 0, 0, 0 };
             if (!rc) rc = dav1d_hip_intra_flow_status(c, fl, st);
-            if (!rc && (st[2] || st[1] != all.size())) rc = -EIO;      // a wave gave up waiting: never in a sound run
+            if (!rc && (st[2] || st[1] != total)) rc = -EIO;      // a wave gave up waiting: never in a sound run
             if (trace) {
                 const auto t_d = std::chrono::steady_clock::now();
-                fprintf(stderr, "intra flow: %zu steps, %zu units; merge + upload %.2f ms, launch to finish %.2f ms\n", ns, all.size(),
+                fprintf(stderr, "intra flow: %zu steps, %zu units; merge + upload %.2f ms, launch to finish %.2f ms\n", ns, total,
                         std::chrono::duration<double, std::milli>(t_b - t_a).count(), std::chrono::duration<double, std::milli>(t_d - t_b).count());
             }
             if (fl) dav1d_hip_intra_flow_destroy(c, fl);

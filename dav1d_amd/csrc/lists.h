@@ -61,3 +61,5 @@ void push_tiles(std::vector<McTile> *bins, const Dav1dHipMcTask &t, int kind, ui
                 std::vector<McTile> *single = nullptr);
 int recon_fuse_mask(const Dav1dHipContext *c);
 int tile_dim_class(int v);
+uint8_t *dav1d_hip_slab_get(Dav1dHipContext *c, size_t bytes, size_t *cap);      // chunk.hip: pinned host memory, recycled through the context
+void dav1d_hip_slab_put(Dav1dHipContext *c, uint8_t *host, size_t cap);
