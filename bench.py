@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (hand-off arrays -> lister -> device)")
     ap.add_argument("--e2e-tile-cols", type=int, default=16, help="tile columns of the end-to-end leg (one listing thread per tile)")
     ap.add_argument("--e2e-tile-rows", type=int, default=8, help="tile rows of the end-to-end leg")
-    ap.add_argument("--e2e-threads", type=int, default=32, help="listing threads of the end-to-end legs (0: one per tile); 32 measured best on the 256-thread host")
+    ap.add_argument("--e2e-threads", type=int, default=64, help="listing threads (of the library, dav1d_hip_lister_run) of the end-to-end legs (0: one per tile); the host side stops scaling around 32-64 threads on the 256-thread host: it is bound by the host memory system")
     ap.add_argument("--no-c1", action="store_true", help="skip the 4K 8-bit (BASELINE configs[1]) line that the default run appends")
     ap.add_argument("--no-full", action="store_true", help="skip the full-DSP-table leg (deblock, CDEF, restoration, film grain)")
     ap.add_argument("--two-phase", action="store_true",

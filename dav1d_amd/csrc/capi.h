@@ -26,6 +26,7 @@ struct Dav1dHipContext {
     int recon_fuse;             // bit mask of the square block sizes that run paired (DAV1D_HIP_RECON_FUSE)
     long recon_pipeline;        // smallest residual list a recon list pipelines on two streams (DAV1D_HIP_RECON_PIPELINE)
     int recon_lanes;            // side streams of the residual launches (DAV1D_HIP_RECON_LANES)
+    int chunk_upload;           // 0: a frame's chunks go up as one transfer at frame end; 1: each chunk as it is submitted (DAV1D_HIP_CHUNK_UPLOAD)
     int recon_coop_below;       // paired kernels: launches of fewer groups than this take the cooperative form (recon.hip; DAV1D_HIP_RECON_COOP_BELOW)
     int post_bands;             // bands of the pipelined post filters, 0 = stage by stage (DAV1D_HIP_POST_BANDS)
     bool cdef_unit_kernel;      // $DAV1D_HIP_CDEF_UNIT=1 at open: one wave per 8x8 unit (the round-1 kernel) instead of strips; A/B aid

@@ -45,6 +45,7 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     c->recon_fuse = (int) env_int("DAV1D_HIP_RECON_FUSE", RECON_FUSE_DEFAULT);
     c->recon_pipeline = env_int("DAV1D_HIP_RECON_PIPELINE", 16384);
     c->recon_lanes = (int) env_int("DAV1D_HIP_RECON_LANES", 1);
+    c->chunk_upload = (int) env_int("DAV1D_HIP_CHUNK_UPLOAD", 0);
     c->recon_coop_below = (int) env_int("DAV1D_HIP_RECON_COOP_BELOW", 4096);
     c->post_bands = (int) env_int("DAV1D_HIP_POST_BANDS", 0);
     const char *ser = getenv("DAV1D_HIP_SERIAL");
@@ -146,6 +147,7 @@ int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value) {
     if (!strcmp(name, "recon_fuse")) c->recon_fuse = (int) value;
     else if (!strcmp(name, "recon_pipeline")) c->recon_pipeline = value;
     else if (!strcmp(name, "recon_lanes")) c->recon_lanes = (int) value;
+    else if (!strcmp(name, "chunk_upload")) c->chunk_upload = (int) value;
     else if (!strcmp(name, "recon_coop_below")) c->recon_coop_below = (int) value;
     else if (!strcmp(name, "post_bands")) c->post_bands = (int) value;
     else if (!strcmp(name, "serial")) c->concurrent = !value;

@@ -22,9 +22,14 @@ struct Dav1dHipFrame {
     int n_refs;
     std::mutex mtx;
     std::vector<Dav1dHipChunk *> chunks;    // the tile-sbrows' inter predictions + residuals, preprocessed by their submitters (chunk.hip)
-    uint8_t *arena;                         // device mirror of the chunks' blobs: each chunk is uploaded as soon as it is submitted
+    uint8_t *arena;                         // device home of the chunks' blobs
     size_t arena_cap;
     std::atomic<size_t> arena_used;
+    // Pinned twin of the arena: a submitter copies its chunk's blob to the offset it drew and is done; the frame goes up as ONE
+    // transfer at frame end (30 MB for an 8K frame: half a millisecond).  One hipMemcpyAsync per chunk — 1,800 calls per 8K frame,
+    // serialised inside the runtime at about 4 us each — was what the listing threads queued on (c->chunk_upload: 1 = that way).
+    uint8_t *harena;
+    size_t harena_cap;
     // intra blocks: step k of the wavefront = the blocks whose neighbours are final after steps 0 .. k - 1 (and after the
     // inter blocks of the frame); predictions and residuals per step
     // One entry per submission (a tile-sbrow's blocks), tasks sorted by step with the end offset of every step; built — and
@@ -330,6 +335,8 @@ int dav1d_hip_frame_begin(Dav1dHipContext *c, Dav1dHipFrame **out, const Dav1dHi
         while (want < c->arena_hint + (c->arena_hint >> 2)) want <<= 1;
         if (hipMalloc((void **) &f->arena, want) == hipSuccess) f->arena_cap = want; else f->arena = nullptr;
     }
+    f->harena = nullptr; f->harena_cap = 0;
+    if (f->arena && !c->chunk_upload) f->harena = dav1d_hip_slab_get(c, f->arena_cap, &f->harena_cap);
     *out = f;
     return 0;
 }
@@ -351,7 +358,8 @@ int dav1d_hip_frame_submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc
         const size_t sz = (ck->used + 255) & ~(size_t) 255, off = f->arena_used.fetch_add(sz);
         if (f->arena && off + sz <= f->arena_cap) {
             ck->dev_off = off;
-            ck->uploaded = hipMemcpyAsync(f->arena + off, ck->host, ck->used, hipMemcpyHostToDevice, f->c->copy_stream) == hipSuccess;
+            if (f->harena && off + sz <= f->harena_cap) { memcpy(f->harena + off, ck->host, ck->used); ck->uploaded = true; }     // goes up with the frame
+            else ck->uploaded = hipMemcpyAsync(f->arena + off, ck->host, ck->used, hipMemcpyHostToDevice, f->c->copy_stream) == hipSuccess;
         }
     }
     std::lock_guard<std::mutex> lk(f->mtx);
@@ -552,7 +560,12 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
         Dav1dHipMcList ml;
         Dav1dHipCompList cl;
         Dav1dHipItxList xl;
-        rc = dav1d_hip_chunks_to_recon_list(c, f->chunks, &f->arena, &f->arena_cap, f->refs, f->n_refs, &rl, &il, &ml, &cl, &xl);
+        if (f->harena) {
+            // the blobs the submitters left in the pinned twin: one transfer (the gather launch waits for the copy stream)
+            const size_t used = std::min(std::min(f->arena_used.load(), f->arena_cap), f->harena_cap);
+            if (used) rc = hip_rc(hipMemcpyAsync(f->arena, f->harena, used, hipMemcpyHostToDevice, c->copy_stream));
+        }
+        if (!rc) rc = dav1d_hip_chunks_to_recon_list(c, f->chunks, &f->arena, &f->arena_cap, f->refs, f->n_refs, &rl, &il, &ml, &cl, &xl);
         if (!rc) {
             if (ml.n || cl.n || rl.f_n[0] || rl.f_n[1] || rl.f_n[2] || rl.f_n[3] || rl.f_n[4]) {
                 if (!f->n_refs) rc = -EINVAL;
@@ -814,6 +827,7 @@ void dav1d_hip_frame_destroy(Dav1dHipFrame *f) {
     (void) hipStreamSynchronize(f->c->copy_stream);
     for (Dav1dHipChunk *ck : f->chunks) { ck->release(f->c); delete ck; }
     for (Dav1dHipFrame::StepChunk *sc : f->step_chunks) delete sc;
+    if (f->harena) dav1d_hip_slab_put(f->c, f->harena, f->harena_cap);
     if (f->arena) {
         std::lock_guard<std::mutex> lk(f->c->pool_mtx);
         f->c->free_arenas.push_back({ f->arena, f->arena_cap });

@@ -118,7 +118,8 @@ def c2_params(seed, n_refs=3):
     return sp
 
 
-def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0xE2E, check=None, intra_pct=0, key_frame=False, tile_rows=1):
+def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0xE2E, check=None, intra_pct=0, key_frame=False, tile_rows=1,
+        native_threads=True):
     """Returns the measurement dict.  check: optional callable(handoff, desc, planes) -> str used as the parity gate."""
     layout = api.LAYOUT_I420
     ho = HandOff(w, h, layout, bpc, True, tile_cols, tile_rows)
@@ -171,7 +172,12 @@ def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0
                 assert ctx.lib.dav1d_hip_upload(ctx.h, coef.ptr, src, ho.cf.nbytes) == 0
                 return (time.perf_counter() - t) * 1e3
             up = ex2.submit(h2d)
-            list(ex.map(tile, range(n_tiles)))
+            if native_threads:
+                # the library's own threads walk the tiles (dav1d_hip_lister_run): no interpreter lock between the tile-sbrows
+                rc2 = ctx.lib.dav1d_hip_lister_run(lh, threads)
+                assert rc2 == 0, rc2
+            else:
+                list(ex.map(tile, range(n_tiles)))
             t_b = time.perf_counter()
             h2d_ms = up.result()
             if prep is None:
@@ -201,7 +207,7 @@ def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0
     out["unit"] = "Mpixels/s"
     out["synth_seconds"] = round(t_synth, 2)
     kind = "key frame (every block intra)" if key_frame else "inter frame" if not intra_pct else "inter frame, %d %% intra blocks" % intra_pct
-    out["workload"] = ("%dx%d 4:2:0 %d-bit " + kind + " from pass-1 hand-off arrays: lister on %d host threads over %d x %d tiles, chunk "
+    out["workload"] = ("%dx%d 4:2:0 %d-bit " + kind + " from pass-1 hand-off arrays: lister on %d host threads" + (" of the library" if native_threads else "") + " over %d x %d tiles, chunk "
                        "preparation + upload on the submitting threads, dense coefficient arena over the host link meanwhile (h2d_ms), "
                        "frame_end = gather + the frame's launches + sync") % (w, h, bpc, threads, n_tcols, n_trows)
     if check is not None and planes is not None:

@@ -15,6 +15,7 @@
 #include "av1_host.h"
 #include "lister_priv.h"
 #include <errno.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1020,4 +1021,41 @@ int dav1d_hip_lister_tile_sbrow(Dav1dHipLister *l, const int tile_row, const int
     free(o.ipred.p); free(o.ipred_step.p); free(o.blend.p); free(o.blend_step.p); free(o.sitx.p); free(o.sitx_step.p);
     if (!rc) cur->next_sby = sby + 1;
     return rc;
+}
+
+/* Every tile of the frame on n_threads threads of the library: tiles are handed out in raster order under a mutex, a thread walks
+ * its tile's superblock rows top to bottom (dav1d_hip_lister_tile_sbrow).  A caller with a thread pool of its own — dav1d's task
+ * threads — calls dav1d_hip_lister_tile_sbrow itself; this is for callers without one (and for timing the host side without a
+ * foreign runtime's locks in the way). */
+typedef struct RunAll { Dav1dHipLister *l; pthread_mutex_t mtx; int next, err; } RunAll;
+static void *run_worker(void *arg) {
+    RunAll *r = (RunAll *) arg;
+    const int n_tiles = r->l->d.n_tile_cols * r->l->d.n_tile_rows;
+    for (;;) {
+        pthread_mutex_lock(&r->mtx);
+        const int k = r->err ? n_tiles : r->next++;
+        pthread_mutex_unlock(&r->mtx);
+        if (k >= n_tiles) break;
+        const int tr = k / r->l->d.n_tile_cols, tc = k % r->l->d.n_tile_cols;
+        int rc = 0;
+        for (int sby = r->l->d.row_start_sb[tr]; sby < r->l->d.row_start_sb[tr + 1] && !rc; sby++) rc = dav1d_hip_lister_tile_sbrow(r->l, tr, tc, sby);
+        if (rc) { pthread_mutex_lock(&r->mtx); if (!r->err) r->err = rc; pthread_mutex_unlock(&r->mtx); }
+    }
+    return NULL;
+}
+int dav1d_hip_lister_run(Dav1dHipLister *l, int n_threads) {
+    if (!l || n_threads < 1) return -EINVAL;
+    const int n_tiles = l->d.n_tile_cols * l->d.n_tile_rows;
+    if (n_threads > n_tiles) n_threads = n_tiles;
+    if (n_threads > 256) n_threads = 256;
+    RunAll r;
+    r.l = l; r.next = 0; r.err = 0;
+    pthread_mutex_init(&r.mtx, NULL);
+    pthread_t th[256];
+    int started = 0;
+    for (int i = 1; i < n_threads; i++) { if (pthread_create(&th[started], NULL, run_worker, &r)) break; started++; }
+    run_worker(&r);
+    for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
+    pthread_mutex_destroy(&r.mtx);
+    return r.err;
 }

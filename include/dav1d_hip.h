@@ -720,6 +720,9 @@ DAV1D_HIP_API int dav1d_hip_lister_create(Dav1dHipLister **out, const Dav1dHipFr
 /* One tile-sbrow (what a DAV1D_TASK_TYPE_TILE_RECONSTRUCTION task runs, src/thread_task.c:733-752 -> dav1d_decode_tile_sbrow
  * with pass 2).  Thread-safe across tiles; the superblock rows of one tile must be listed top to bottom. */
 DAV1D_HIP_API int dav1d_hip_lister_tile_sbrow(Dav1dHipLister *l, int tile_row, int tile_col, int sby);
+/* All tiles of the frame on n_threads threads of the library (tiles in raster order, each walked top to bottom) — for callers
+ * without a thread pool of their own; dav1d's task threads call dav1d_hip_lister_tile_sbrow instead. */
+DAV1D_HIP_API int dav1d_hip_lister_run(Dav1dHipLister *l, int n_threads);
 DAV1D_HIP_API size_t dav1d_hip_lister_prep_elems(const Dav1dHipLister *l);   /* int16 elements of the prep arena used so far */
 DAV1D_HIP_API size_t dav1d_hip_lister_mask_bytes(const Dav1dHipLister *l);   /* bytes of the mask arena used so far (constant part included) */
 DAV1D_HIP_API size_t dav1d_hip_lister_steps(const Dav1dHipLister *l);        /* wavefront steps the frame needs so far */

@@ -32,7 +32,10 @@ with ThreadPoolExecutor(threads) as ex:
             tr, tc = divmod(k, n_tcols)
             for sby in range(ho.rows[tr], ho.rows[tr + 1]):
                 assert ctx.lib.dav1d_hip_lister_tile_sbrow(lh, tr, tc, sby) == 0
-        list(ex.map(tile, range(n_tcols * n_trows)))
+        if os.environ.get("LISTER_NATIVE"):
+            assert ctx.lib.dav1d_hip_lister_run(lh, threads) == 0
+        else:
+            list(ex.map(tile, range(n_tcols * n_trows)))
         ts.append((time.perf_counter() - t0) * 1e3)
         ctx.lib.dav1d_hip_lister_destroy(lh)
         frame.destroy()
