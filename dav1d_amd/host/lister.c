@@ -37,6 +37,7 @@ typedef struct TileCursor {
     size_t cf;         /* next BYTE of f->frame_thread.cf */
     size_t pal_idx;    /* next byte of f->frame_thread.pal_idx */
     int next_sby;
+    uint64_t win[2][2];           /* [prep, mask][next, end]: the tile's window of the shared arenas (a tile is walked by one thread at a time) */
 } TileCursor;
 
 struct Dav1dHipLister {
@@ -48,10 +49,17 @@ struct Dav1dHipLister {
     uint16_t *step[3];            /* [4x4 cell of the plane] -> wavefront step of the transform block that wrote it */
     int step_stride[3];
     TileCursor *tiles;
-    uint64_t arena_bytes;         /* prep arena cursor (atomic) */
-    uint64_t mask_bytes;          /* mask arena cursor (atomic), starts behind the constant masks */
-    uint32_t max_step;            /* atomic */
     int cf_align64;
+    /* The shared counters live on cache lines of their own: every walking thread reads the fields above for every block, and a
+     * counter bumped on the same line sent that line around all of them (the walk of an 8K frame took 9 ms on 32 threads and
+     * 22 ms on one).  The arena cursors are bumped once per WINDOW a tile-sbrow draws, not once per compound block. */
+    char pad0[64];
+    uint64_t arena_bytes;         /* prep arena cursor (atomic) */
+    char pad1[56];
+    uint64_t mask_bytes;          /* mask arena cursor (atomic), starts behind the constant masks */
+    char pad2[56];
+    uint32_t max_step;            /* atomic */
+    char pad3[60];
 };
 
 /* one tile-sbrow's worth of output */
@@ -71,17 +79,31 @@ typedef struct Walk {
     Dav1dHipLister *l;
     Out *o;
     TileCursor *cur;
+    unsigned seen_step;                               /* largest step this walk has reported to the lister */
     int col_start, col_end, row_start, row_end;       /* tile, 4-pixel units */
     int err;
 } Walk;
+
+static uint64_t arena_alloc(Walk *w, const int which, uint64_t *cursor, const uint64_t bytes) {
+    const uint64_t need = (bytes + 31) & ~(uint64_t) 31;
+    uint64_t (*win)[2] = w->cur->win;
+    if (win[which][0] + need > win[which][1]) {
+        const uint64_t grab = need > (1u << 17) ? need : (1u << 17);
+        win[which][0] = __atomic_fetch_add(cursor, grab, __ATOMIC_RELAXED);
+        win[which][1] = win[which][0] + grab;
+    }
+    const uint64_t at = win[which][0];
+    win[which][0] += need;
+    return at;
+}
 
 static int imin(const int a, const int b) { return a < b ? a : b; }
 static int imax(const int a, const int b) { return a > b ? a : b; }
 static int iclip(const int v, const int lo, const int hi) { return v < lo ? lo : v > hi ? hi : v; }
 
-static uint64_t arena_alloc(uint64_t *cursor, const uint64_t bytes) {
-    return __atomic_fetch_add(cursor, (bytes + 31) & ~(uint64_t) 31, __ATOMIC_RELAXED);
-}
+/* bytes of the prep (which = 0) / mask (1) arena for this walk: from its tile's window, which is refilled from the shared cursor
+ * 128 KB at a time (what a tile leaves unused at the end of the frame is less than that) */
+static uint64_t arena_alloc(struct Walk *w, const int which, uint64_t *cursor, const uint64_t bytes);
 
 static void note_step(Dav1dHipLister *l, const uint32_t s) {
     uint32_t cur = __atomic_load_n(&l->max_step, __ATOMIC_RELAXED);
@@ -115,7 +137,7 @@ static void set_step(const Walk *w, const int pl, const int x4, const int y4, co
     const int st = l->step_stride[pl];
     for (int y = y4; y < y_hi; y++)
         for (int x = x4; x < x_hi; x++) m[y * st + x] = (uint16_t) s;
-    note_step(w->l, s);
+    if (s > ((Walk *) w)->seen_step) { ((Walk *) w)->seen_step = s; note_step(w->l, s); }
 }
 
 /* ------------------------------------------------------------------------------------------------ neighbours */
@@ -461,7 +483,7 @@ static void list_obmc(Walk *w, const uint32_t doff, const int bs, const int pl, 
             if (!a->intra) {
                 const int ow4 = imin(step4, b_dim[0]), oh4 = imin(b_dim[1], 16) >> 1;
                 const int lw = ow4 * h_mul, lh = ((oh4 * 3 + 3) >> 2) * v_mul;
-                const uint64_t ab = arena_alloc(&l->arena_bytes, (uint64_t) lw * lh * l->psz);
+                const uint64_t ab = arena_alloc(w, 0, &l->arena_bytes, (uint64_t) lw * lh * l->psz);
                 emit_mc(w, DAV1D_HIP_MC_PUT_TMP, (uint32_t) (ab / l->psz), ow4, (oh4 * 3 + 3) >> 2, bx + x, by, pl, mv_of(a->u.p.u.m.mv[0]),
                         a->u.p.ref[0], a->u.p.filter2d);
                 Dav1dHipCompTask *k = new_comp(w, DAV1D_HIP_COMP_BLEND_H, pl, doff + (uint32_t) (x * h_mul), h_mul * ow4, v_mul * oh4);
@@ -478,7 +500,7 @@ static void list_obmc(Walk *w, const uint32_t doff, const int bs, const int pl, 
             if (!lf->intra) {
                 const int ow4 = imin(b_dim[0], 16) >> 1, oh4 = imin(step4, b_dim[1]);
                 const int lw = ow4 * h_mul, lh = oh4 * v_mul;
-                const uint64_t ab = arena_alloc(&l->arena_bytes, (uint64_t) lw * lh * l->psz);
+                const uint64_t ab = arena_alloc(w, 0, &l->arena_bytes, (uint64_t) lw * lh * l->psz);
                 emit_mc(w, DAV1D_HIP_MC_PUT_TMP, (uint32_t) (ab / l->psz), ow4, oh4, bx, by + y, pl, mv_of(lf->u.p.u.m.mv[0]),
                         lf->u.p.ref[0], lf->u.p.filter2d);
                 Dav1dHipCompTask *k = new_comp(w, DAV1D_HIP_COMP_BLEND_V, pl, doff + (uint32_t) (y * v_mul * l->stride[pl]), h_mul * ow4, v_mul * oh4);
@@ -497,7 +519,7 @@ static unsigned list_interintra(Walk *w, const int bs, const Dav1dHipAv1Block *b
     const int pw4 = pl ? (bw4 + ss_hor) >> ss_hor : bw4, ph4 = pl ? (bh4 + ss_ver) >> ss_ver : bh4;
     const int x4 = bx >> ss_hor, y4 = by >> ss_ver;
     const unsigned s = dep_step(w, pl, x4, y4, pw4, ph4);
-    const uint64_t ab = arena_alloc(&l->arena_bytes, (uint64_t) pw4 * ph4 * 16 * l->psz);
+    const uint64_t ab = arena_alloc(w, 0, &l->arena_bytes, (uint64_t) pw4 * ph4 * 16 * l->psz);
     Dav1dHipIpredTask *k = new_ipred(w, s);
     k->kind = DAV1D_HIP_IPRED_PRED_TMP;
     k->plane = (uint8_t) pl;
@@ -614,7 +636,7 @@ static void list_inter(Walk *w, const int bs, const Dav1dHipAv1Block *b, const i
             uint32_t tmp[2];
             for (int i = 0; i < 2; i++) {
                 const int ref = b->u.p.ref[i];
-                const uint64_t ab = arena_alloc(&l->arena_bytes, (uint64_t) pw * ph * 2);
+                const uint64_t ab = arena_alloc(w, 0, &l->arena_bytes, (uint64_t) pw * ph * 2);
                 tmp[i] = (uint32_t) (ab / 2);
                 if (b->u.p.inter_mode == H_GLOBALMV_GLOBALMV && l->d.gmv_warp_allowed[ref] && (!pl || imin(cbw4, cbh4) > 1))
                     emit_warp(w, DAV1D_HIP_MC_PREP, tmp[i], pw, bs, bx, by, pl, ref, &l->d.gmv[ref]);
@@ -636,7 +658,7 @@ static void list_inter(Walk *w, const int bs, const Dav1dHipAv1Block *b, const i
             case H_COMP_INTER_SEG:
                 if (!pl) {
                     const int mw = bw4 * 4 >> (chr_layout_idx != 0), mh = bh4 * 4 >> (chr_layout_idx == 2);
-                    mask_off = (uint32_t) arena_alloc(&l->mask_bytes, (uint64_t) mw * mh);
+                    mask_off = (uint32_t) arena_alloc(w, 1, &l->mask_bytes, (uint64_t) mw * mh);
                     k = new_comp(w, DAV1D_HIP_COMP_WMASK, 0, doff, pw, ph);
                     k->arg = (int8_t) sign;
                     k->ss = (uint8_t) chr_layout_idx;
@@ -1003,6 +1025,7 @@ int dav1d_hip_lister_tile_sbrow(Dav1dHipLister *l, const int tile_row, const int
     memset(&o, 0, sizeof(o));
     Walk w;
     w.l = l; w.o = &o; w.cur = cur; w.err = 0;
+    w.seen_step = 0;
     w.col_start = l->d.col_start_sb[tile_col] << sb_shift;
     w.col_end = imin(l->d.col_start_sb[tile_col + 1] << sb_shift, l->bw);
     w.row_start = l->d.row_start_sb[tile_row] << sb_shift;
