@@ -181,8 +181,7 @@ def frames_in_flight(api, device, frame, itx_tasks, coef_host, intra, post, ref_
         ctx = st["ctx"]
         rec, cdf, res, grn = st["pics"]
         st["recon"].run(rec, st["refs"], st["prep"], st["coef"][i])
-        for k in range(len(intra.batches)):
-            st["intra"].run_batch(k, rec, st["icoef"][i])
+        st["intra"].run_all(rec, st["icoef"][i])
         ctx.lf_batch(rec, post.lf, st["lvl"], post.b4_stride, post.lut_e, post.lut_i)
         ctx.cdef_batch(cdf, rec, post.cdef, post.cdef_damping)
         ctx.lr_batch(res, cdf, rec, post.lr)

@@ -391,6 +391,10 @@ class _IntraList:
         _chk(self.ctx.lib.dav1d_hip_intra_list_run_batch(self.ctx.h, self.h, k, C.byref(dst.pic), coef.ptr if hasattr(coef, "ptr") else coef,
                                                          aux.ptr if aux else None), "intra_list_run_batch")
 
+    def run_all(self, dst, coef, aux=None):
+        _chk(self.ctx.lib.dav1d_hip_intra_list_run_all(self.ctx.h, self.h, C.byref(dst.pic), coef.ptr if hasattr(coef, "ptr") else coef,
+                                                       aux.ptr if aux else None), "intra_list_run_all")
+
     def destroy(self):
         if self.h:
             self.ctx.lib.dav1d_hip_intra_list_destroy(self.ctx.h, self.h)

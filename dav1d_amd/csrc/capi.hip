@@ -2091,6 +2091,14 @@ int dav1d_hip_intra_list_run_batch(Dav1dHipContext *c, const Dav1dHipIntraList *
     return dav1d_hip_intra_list_run_batch_blend(c, l, batch, dst, coef, aux, nullptr, nullptr);
 }
 
+// every batch of the list, in order, back to back on the context's stream (what a frame does; one call instead of one per step)
+int dav1d_hip_intra_list_run_all(Dav1dHipContext *c, const Dav1dHipIntraList *l, const Dav1dHipPicture *dst, void *coef, uint8_t *aux) {
+    if (!c || !l) return -EINVAL;
+    int rc = 0;
+    for (size_t k = 0; k + 1 < l->pair_start.size() && !rc; k++) rc = dav1d_hip_intra_list_run_batch_blend(c, l, k, dst, coef, aux, nullptr, nullptr);
+    return rc;
+}
+
 // prep / mask: the scratch arena the PRED_TMP predictions of the batch go to and the blends read, and the mask arena
 int dav1d_hip_intra_list_run_batch_blend(Dav1dHipContext *c, const Dav1dHipIntraList *l, size_t batch, const Dav1dHipPicture *dst, void *coef,
                                          uint8_t *aux, int16_t *prep, uint8_t *mask) {

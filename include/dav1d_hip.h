@@ -380,6 +380,9 @@ DAV1D_HIP_API int dav1d_hip_intra_list_create(Dav1dHipContext *c, Dav1dHipIntraL
                                               const Dav1dHipItxTask *txs, const size_t *tx_sizes, size_t n_batches);
 DAV1D_HIP_API int dav1d_hip_intra_list_run_batch(Dav1dHipContext *c, const Dav1dHipIntraList *l, size_t batch, const Dav1dHipPicture *dst,
                                                  void *coef, uint8_t *aux);
+/* all batches of the list in order, enqueued back to back (no synchronisation in between) */
+DAV1D_HIP_API int dav1d_hip_intra_list_run_all(Dav1dHipContext *c, const Dav1dHipIntraList *l, const Dav1dHipPicture *dst, void *coef,
+                                               uint8_t *aux);
 DAV1D_HIP_API void dav1d_hip_intra_list_destroy(Dav1dHipContext *c, Dav1dHipIntraList *l);
 
 /* The same wavefront as ONE launch: the batches become a list of units (prediction + residual of one transform block)

@@ -126,6 +126,9 @@ def hip_intra(ctx, ip, pic, timed=False, graph=False, paired=True, flow=False):
         if fl is not None:
             fl.run(pic, coef)
             return
+        if xl is not None and not graph:
+            xl.run_all(pic, coef)              # dav1d_hip_intra_list_run_all: the batches in order, one call
+            return
         for k in range(len(ip.batches)):
             if xl is not None:
                 xl.run_batch(k, pic, coef)
