@@ -740,7 +740,7 @@ def main():
         # ---- end to end: the same kind of frame from dav1d's pass-1 hand-off arrays (Av1Block / cbi / cf) through the pass-2
         # lister on host threads, the chunk preparation, the coefficient upload and frame_end; checked against the reference's OWN
         # pass 2 (dav1d_decode_tile_sbrow on a real Dav1dFrameContext, oracle/ref_frame.c) when the reference build is there
-        e2e_leg = key_leg = None
+        e2e_leg = key_leg = full_route = None
         if world == 1 and not a.no_e2e:
             from dav1d_amd import e2e
 
@@ -755,6 +755,16 @@ def main():
             # the key-frame worst case (reference src/recon_tmpl.c:1239-1333, every block through the intra wavefront): same route
             key_leg = e2e.run(ctx, w, h, bpc, frames=4, threads=a.e2e_threads or None, tile_cols=a.e2e_tile_cols, tile_rows=a.e2e_tile_rows, key_frame=True, seed=0xE2F,
                               check=None if a.no_check else (lambda ho, planes, refs: e2e_check(ho, planes, refs, is_inter=False)))
+            # the whole frame — reconstruction AND in-loop filters — from pass 1's outputs, checked against the reference's own
+            # dav1d_decode_tile_sbrow + dav1d_filter_sbrow (needs the reference build oracle/_ref for the filter inputs and the check)
+            if not a.no_check:
+                import lister_util as lu
+                try:
+                    full_route = lu.full_route_rate(ctx, w, h, bpc, a.e2e_tile_cols, a.e2e_tile_rows, threads=a.e2e_threads or 64, frames=5)
+                except AssertionError as e:
+                    raise SystemExit("bench: full end-to-end leg differs from the reference: %s" % e)
+                except Exception as e:       # noqa: BLE001  (a reported extra)
+                    full_route = {"error": str(e)[:200]}
         label = "8K" if (w, h) == (7680, 4320) else "4K" if (w, h) == (3840, 2160) else "%dx%d" % (w, h)
         out = {"metric": "reconstructed luma Mpixels/s (%s 4:2:0 %d-bit) on the itx+mc recon path; bit-exact vs C" % (label, bpc),
                "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -771,7 +781,7 @@ def main():
                           "coef_format": "packed: eob + 1 scan-order values per block" if a.packed else "dense cf arena (reference layout)",
                           "coef_bytes_per_frame": int(coef_host.nbytes), "coef_h2d_ms_per_frame": h2d_ms,
                           "samples_per_frame": frame.n_samples, "parity": check, "gen_seconds": round(t_gen, 1)},
-               "roofline": roof, "cpu_baseline": cpu, "full_table": full, "end_to_end": e2e_leg, "all_intra": key_leg,
+               "roofline": roof, "cpu_baseline": cpu, "full_table": full, "end_to_end": e2e_leg, "all_intra": key_leg, "end_to_end_full_table": full_route,
                "device": None if a.no_check else device_probe(torch)}       # (not under the profiler: its copies would sit in the kernel statistics)
         # BASELINE configs[1] (4K 8-bit, the reference's CPU-runnable size) next to the headline: the same bench in a child process,
         # its digest under "config_c1_4k_8bit"

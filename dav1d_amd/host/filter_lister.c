@@ -7,6 +7,7 @@
 #include "av1_host.h"
 #include "lister_priv.h"
 #include <errno.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -251,4 +252,38 @@ int dav1d_hip_lister_filter_sbrow(Dav1dHipLister *l, const Dav1dHipFilterDesc *f
     const int rc = dav1d_hip_frame_submit_filter_sbrow(g.frame, o.lf.p, o.lf.n, o.cdef.p, o.cdef.n, o.lr.p, o.lr.n);
     free(o.lf.p); free(o.cdef.p); free(o.lr.p);
     return rc;
+}
+
+/* Every superblock row of the frame's filter tasks on n_threads threads of the library (rows handed out under a mutex) — the
+ * counterpart of dav1d_hip_lister_run for callers without a thread pool of their own. */
+typedef struct FRunAll { Dav1dHipLister *l; const Dav1dHipFilterDesc *fd; pthread_mutex_t mtx; int next, n, err; } FRunAll;
+static void *frun_worker(void *arg) {
+    FRunAll *r = (FRunAll *) arg;
+    for (;;) {
+        pthread_mutex_lock(&r->mtx);
+        const int k = r->err ? r->n : r->next++;
+        pthread_mutex_unlock(&r->mtx);
+        if (k >= r->n) break;
+        const int rc = dav1d_hip_lister_filter_sbrow(r->l, r->fd, k);
+        if (rc) { pthread_mutex_lock(&r->mtx); if (!r->err) r->err = rc; pthread_mutex_unlock(&r->mtx); }
+    }
+    return NULL;
+}
+int dav1d_hip_lister_filter_run(Dav1dHipLister *l, const Dav1dHipFilterDesc *fd, int n_threads) {
+    if (!l || !fd || n_threads < 1) return -EINVAL;
+    ListerGeo g;
+    dav1d_hip_lister_geo(l, &g);
+    FRunAll r;
+    r.l = l; r.fd = fd; r.next = 0; r.err = 0;
+    r.n = (g.bh + g.sb_step - 1) / g.sb_step;
+    if (n_threads > r.n) n_threads = r.n;
+    if (n_threads > 256) n_threads = 256;
+    pthread_mutex_init(&r.mtx, NULL);
+    pthread_t th[256];
+    int started = 0;
+    for (int i = 1; i < n_threads; i++) { if (pthread_create(&th[started], NULL, frun_worker, &r)) break; started++; }
+    frun_worker(&r);
+    for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
+    pthread_mutex_destroy(&r.mtx);
+    return r.err;
 }

@@ -767,6 +767,8 @@ typedef struct Dav1dHipFilterDesc {
 /* One superblock row of filter tasks (what dav1d_filter_sbrow would execute, src/recon_tmpl.c:2100-2109), submitted to the
  * lister's frame.  Thread-safe; any order. */
 DAV1D_HIP_API int dav1d_hip_lister_filter_sbrow(Dav1dHipLister *l, const Dav1dHipFilterDesc *fd, int sby);
+/* every superblock row of the frame on n_threads threads of the library (see dav1d_hip_lister_run) */
+DAV1D_HIP_API int dav1d_hip_lister_filter_run(Dav1dHipLister *l, const Dav1dHipFilterDesc *fd, int n_threads);
 
 /* ---- deblocking masks and levels from the hand-off arrays (what pass 1 builds with dav1d_create_lf_mask_intra / _inter,
  * reference src/lf_mask.c:259-383, src/decode.c:1216-1226, 1882-1900, 1945-1956, 2730-2740), built on the device.

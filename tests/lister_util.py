@@ -464,3 +464,101 @@ def reference_pass2_rate(lib_ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=
         return out
     finally:
         rf.destroy()
+
+
+def full_route_rate(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=64, frames=5, seed=0xF0E):
+    """The whole frame from dav1d's hand-off to final pixels, timed: pass-1 arrays (Av1Block / cbi / cf) and pass 1's filter inputs
+    (Av1Filter masks, level cache, cdef_idx, restoration units — built here by the reference's own dav1d_create_lf_mask_* on a real
+    Dav1dFrameContext) -> lister threads -> filter lister threads -> dav1d_hip_frame_end (reconstruction, deblocking, CDEF,
+    restoration).  Per frame the dense coefficient arena and the level cache cross the host link while the listing runs.  The
+    final picture is compared with the reference's dav1d_decode_tile_sbrow + dav1d_filter_sbrow of the same frame.  Returns the
+    measurement dict, or None without the reference build."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    from dav1d_amd import e2e
+    if ref_lib() is None:
+        return None
+    filters = dict(lf=(20, 28, 16, 24, 0, False), cdef=(5, 2, [17, 33, 0, 63], [5, 0, 20, 48]), lr=([1, 1, 1], [6, 6]))
+    rf = RefFrame(w, h, 1, bpc, is_inter=True, sb128=True, tile_cols=tile_cols, tile_rows=tile_rows, filters=filters)
+    try:
+        sp = e2e.c2_params(seed)
+        d = synth(ctx, rf, sp)
+        fill_pictures(rf, seed + 1)
+        rf.build_filter_inputs(seed)
+        t0 = time.perf_counter()
+        rf.recon(min(threads, 64))
+        t_ref_recon = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        rf.filter()
+        t_ref_filter = time.perf_counter() - t0
+        n_pl = 3
+        cur = ctx.picture(w, h, 1, bpc)
+        refs = []
+        for i in range(7):
+            r = ctx.picture(rf.p.ref_w[i], rf.p.ref_h[i], 1, bpc)
+            for pl in range(n_pl):
+                rows, cols = r.padded_shape(pl)
+                r.upload(pl, np.ascontiguousarray(rf.plane(1 + i, pl)[:rows, :cols]))
+            refs.append(r)
+        coef = ctx.buffer(len(rf.cf_copy))
+        lvl_host = rf.array("lf_level", np.uint8)
+        lvl = ctx.buffer(len(lvl_host))
+        lut = rf.array("lim_lut", np.uint8)
+        fd = rf.filter_desc()
+        nb = C.c_size_t()
+        blob = ctx.lib.dav1d_hip_lister_const_masks(C.byref(nb))
+        prep = mask = None
+        res = {"list_ms": [], "filter_list_ms": [], "h2d_ms": [], "frame_end_ms": [], "total_ms": []}
+        planes = None
+        with ThreadPoolExecutor(1) as ex2:
+            for it in range(frames):
+                t_a = time.perf_counter()
+                frame = ctx.frame(cur, refs)
+                lh = C.c_void_p()
+                assert ctx.lib.dav1d_hip_lister_create(C.byref(lh), C.byref(d), frame.h) == 0
+
+                def h2d():
+                    t = time.perf_counter()
+                    coef.upload(rf.cf_copy)
+                    lvl.upload(lvl_host)
+                    return (time.perf_counter() - t) * 1e3
+                up = ex2.submit(h2d)
+                assert ctx.lib.dav1d_hip_lister_run(lh, threads) == 0
+                t_b = time.perf_counter()
+                assert ctx.lib.dav1d_hip_lister_filter_run(lh, C.byref(fd), threads) == 0
+                t_c = time.perf_counter()
+                h2d_ms = up.result()
+                if prep is None:
+                    prep = ctx.buffer(ctx.lib.dav1d_hip_lister_prep_elems(lh) * 2 + 4096)
+                    mask = ctx.buffer(ctx.lib.dav1d_hip_lister_mask_bytes(lh) + 4096)
+                    mask.upload(np.ctypeslib.as_array((C.c_uint8 * nb.value).from_address(blob)))
+                frame.set_filters(lvl, rf.b4_stride, lut[0:64], lut[64:128], rf.p.cdef_damping + bpc - 8)
+                t_d = time.perf_counter()
+                filtered = frame.end(coef, prep, mask)
+                t_e = time.perf_counter()
+                if it == frames - 1:
+                    fpic = api.DevicePicture.view(ctx, filtered, w, h, 1, bpc)
+                    planes = [fpic.download(pl) for pl in range(n_pl)]
+                ctx.lib.dav1d_hip_lister_destroy(lh)
+                frame.destroy()
+                if it:
+                    res["list_ms"].append((t_b - t_a) * 1e3)
+                    res["filter_list_ms"].append((t_c - t_b) * 1e3)
+                    res["h2d_ms"].append(h2d_ms)
+                    res["frame_end_ms"].append((t_e - t_d) * 1e3)
+                    res["total_ms"].append((t_e - t_a) * 1e3)
+        bad = compare(rf, planes)
+        if bad:
+            raise AssertionError("full route: filtered planes differ from the reference's: %s" % bad)
+        out = {k: round(float(np.median(v)), 3) for k, v in res.items() if v}
+        out.update(frames=frames - 1, host_threads=threads, tiles=tile_cols * tile_rows,
+                   value=round(w * h / (out["total_ms"] * 1e-3) / 1e6, 1), unit="Mpixels/s",
+                   parity="bit-exact vs the reference's dav1d_decode_tile_sbrow + dav1d_filter_sbrow (%.2f s + %.2f s on this host)" % (t_ref_recon, t_ref_filter),
+                   workload="%dx%d 4:2:0 %d-bit inter frame, hand-off arrays + pass 1's filter inputs -> %d library threads listing blocks, then "
+                            "filter tasks -> reconstruction, deblocking (levels 20/28/16/24), CDEF (4 strength pairs), switchable restoration "
+                            "(64-pixel units); coefficients (dense) and level cache cross the host link every frame" % (w, h, bpc, threads))
+        for o in refs + [cur, coef, lvl] + ([prep, mask] if prep is not None else []):
+            o.free()
+        return out
+    finally:
+        rf.destroy()
