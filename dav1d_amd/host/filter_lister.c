@@ -249,8 +249,9 @@ int dav1d_hip_lister_filter_sbrow(Dav1dHipLister *l, const Dav1dHipFilterDesc *f
     list_deblock(&g, fd, &o, sby);
     list_cdef(&g, fd, &o, sby);
     list_lr(&g, fd, &o, sby);
-    const int rc = dav1d_hip_frame_submit_filter_sbrow(g.frame, o.lf.p, o.lf.n, o.cdef.p, o.cdef.n, o.lr.p, o.lr.n);
-    free(o.lf.p); free(o.cdef.p); free(o.lr.p);
+    /* the arrays go to the frame as they are (it frees them): no copy, no growing vector under the frame's lock */
+    const int rc = dav1d_hip_frame_submit_filter_owned(g.frame, o.lf.p, o.lf.n, o.cdef.p, o.cdef.n, o.lr.p, o.lr.n);
+    if (rc) { free(o.lf.p); free(o.cdef.p); free(o.lr.p); }
     return rc;
 }
 
