@@ -56,7 +56,14 @@ struct Dav1dHipFrame {
     // filter tasks as their submitters handed them over (malloc'ed arrays, owned): strung together at frame end.  Appending to the
     // three vectors above under the frame's lock — 11 MB per 8K frame, reallocations included — made the filter listing threads
     // queue (5 ms on 64 threads).
-    struct FilterPiece { Dav1dHipLfTask *lf; size_t n_lf; Dav1dHipCdefTask *cdef; size_t n_cdef; Dav1dHipLrTask *lr; size_t n_lr; };
+    // What can be done per piece is done by the thread that submits it: the checks of the batch calls, the deblocking tasks
+    // partitioned into vertical edges first, the CDEF units grouped for the strip kernel (group.first relative to the piece).
+    struct FilterPiece {
+        Dav1dHipLfTask *lf; size_t n_lf, n_lf0;              // [0, n_lf0): dir 0 (edges between columns), the rest dir 1
+        Dav1dHipCdefTask *cdef; size_t n_cdef, n_raw;
+        std::vector<CdefGroup> *groups;
+        Dav1dHipLrTask *lr; size_t n_lr;
+    };
     std::vector<FilterPiece> filter_pieces;
     const uint8_t *lvl;
     ptrdiff_t b4_stride;
@@ -473,8 +480,33 @@ int dav1d_hip_frame_picture(const Dav1dHipFrame *f, Dav1dHipPicture *out) {
 int dav1d_hip_frame_submit_filter_owned(Dav1dHipFrame *f, Dav1dHipLfTask *lf, size_t n_lf, Dav1dHipCdefTask *cdef, size_t n_cdef,
                                         Dav1dHipLrTask *lr, size_t n_lr) {
     if (!f || (!lf && n_lf) || (!cdef && n_cdef) || (!lr && n_lr)) return -EINVAL;
+    // the checks of dav1d_hip_lf_batch / _cdef_batch / _lr_batch, here and in parallel instead of at frame end
+    unsigned bad = 0;
+    size_t n0 = 0;
+    for (size_t i = 0; i < n_lf; i++) { bad |= (unsigned) (lf[i].plane > 2) | (unsigned) (lf[i].dir > 1) | (unsigned) (lf[i].lvl_comp > 3); n0 += lf[i].dir == 0; }
+    for (size_t i = 0; i < n_cdef; i++) bad |= (unsigned) (cdef[i].edges > 15) | (unsigned) (cdef[i].plane > 2) | (unsigned) (cdef[i].dir > 7);
+    for (size_t i = 0; i < n_lr; i++)
+        bad |= (unsigned) (lr[i].plane > 2) | (unsigned) (lr[i].edges > 15) | (unsigned) (!lr[i].w) | (unsigned) (lr[i].w > 384) | (unsigned) (!lr[i].h) |
+               (unsigned) (lr[i].h > 64) | (unsigned) (lr[i].type > DAV1D_HIP_LR_SGR_MIX);
+    if (bad) return -EINVAL;
+    Dav1dHipFrame::FilterPiece p = { lf, n_lf, n0, cdef, n_cdef, 0, nullptr, lr, n_lr };
+    if (n_lf && n0 && n0 < n_lf) {
+        // vertical edges first (stable): the two deblocking launches read the halves
+        Dav1dHipLfTask *q = (Dav1dHipLfTask *) malloc(n_lf * sizeof(*q));
+        if (!q) return -ENOMEM;
+        size_t a = 0, b = n0;
+        for (size_t i = 0; i < n_lf; i++) q[lf[i].dir ? b++ : a++] = lf[i];
+        memcpy(lf, q, n_lf * sizeof(*q));                 // the caller's array stays the piece's array (it is handed over either way)
+        free(q);
+    }
+    if (n_cdef) {
+        p.groups = new (std::nothrow) std::vector<CdefGroup>();
+        if (!p.groups) return -ENOMEM;
+        p.groups->reserve(n_cdef / 8 + 16);
+        p.n_raw = dav1d_hip_cdef_make_groups(cdef, n_cdef, 0, *p.groups);
+    }
     std::lock_guard<std::mutex> lk(f->mtx);
-    f->filter_pieces.push_back({ lf, n_lf, cdef, n_cdef, lr, n_lr });
+    f->filter_pieces.push_back(p);
     return 0;
 }
 
@@ -505,8 +537,107 @@ static void frame_merge_filter_pieces(Dav1dHipFrame *f) {
         f->cdef.insert(f->cdef.end(), p.cdef, p.cdef + p.n_cdef);
         f->lr.insert(f->lr.end(), p.lr, p.lr + p.n_lr);
         free(p.lf); free(p.cdef); free(p.lr);
+        delete p.groups;
     }
     f->filter_pieces.clear();
+}
+
+static int copy_picture(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src);
+
+// Deblocking and CDEF of a frame straight from the pieces: the tasks copied piece after piece into pinned memory (the larger
+// arrays on a few threads), one upload each, the launches of dav1d_hip_lf_batch / dav1d_hip_cdef_run_groups.  *did_cdef: the
+// CDEF output is in f->tmp[0].
+static int frame_filters_from_pieces(Dav1dHipFrame *f, bool *did_cdef) {
+    Dav1dHipContext *c = f->c;
+    *did_cdef = false;
+    size_t n_lf = 0, n_lf0 = 0, n_cdef = 0, n_groups = 0, n_raw = 0;
+    for (const Dav1dHipFrame::FilterPiece &p : f->filter_pieces) {
+        n_lf += p.n_lf; n_lf0 += p.n_lf0; n_cdef += p.n_cdef; n_raw += p.n_raw;
+        if (p.groups) n_groups += p.groups->size();
+    }
+    int rc = 0;
+    const DevPlanes cur = dev_planes(&f->cur);
+    if (n_lf) {
+        if (!f->lvl || !f->have_lut) return -EINVAL;
+        size_t cap = 0;
+        Dav1dHipLfTask *host = reinterpret_cast<Dav1dHipLfTask *>(dav1d_hip_slab_get(c, n_lf * sizeof(Dav1dHipLfTask), &cap));
+        if (!host) return -ENOMEM;
+        size_t a = 0, b = n_lf0;
+        for (const Dav1dHipFrame::FilterPiece &p : f->filter_pieces) {
+            if (p.n_lf0) memcpy(host + a, p.lf, p.n_lf0 * sizeof(*host));
+            if (p.n_lf > p.n_lf0) memcpy(host + b, p.lf + p.n_lf0, (p.n_lf - p.n_lf0) * sizeof(*host));
+            a += p.n_lf0; b += p.n_lf - p.n_lf0;
+        }
+        TaskBuf dev_buf(c, n_lf * sizeof(Dav1dHipLfTask));
+        Dav1dHipLfTask *const dev = reinterpret_cast<Dav1dHipLfTask *>(dev_buf.p);
+        if (!dev) rc = -ENOMEM;
+        if (!rc) rc = dav1d_hip_upload(c, dev, host, n_lf * sizeof(*dev));
+        if (!rc) rc = dav1d_hip_launch_lf(&cur, f->cur.bpc, 0, dev, (int) n_lf0, f->lvl, (int) f->b4_stride, f->lut_e, f->lut_i, c->stream);
+        if (!rc) rc = dav1d_hip_launch_lf(&cur, f->cur.bpc, 1, dev + n_lf0, (int) (n_lf - n_lf0), f->lvl, (int) f->b4_stride, f->lut_e, f->lut_i, c->stream);
+        (void) hipStreamSynchronize(c->stream);
+        dav1d_hip_slab_put(c, reinterpret_cast<uint8_t *>(host), cap);
+        if (rc) return rc;
+    }
+    if (n_cdef) {
+        rc = frame_tmp(f, 0);
+        if (!rc) rc = copy_picture(c, &f->tmp[0], &f->cur);       // units that are not listed keep their pixels
+        if (rc) return rc;
+        const DevPlanes t0 = dev_planes(&f->tmp[0]);
+        const bool strips = !c->cdef_unit_kernel && dav1d_hip_cdef_strip_ok(&t0, &cur, f->cur.bpc);
+        const size_t tb = (n_cdef * sizeof(Dav1dHipCdefTask) + 255) & ~(size_t) 255;
+        size_t cap = 0;
+        uint8_t *host = dav1d_hip_slab_get(c, tb + n_groups * sizeof(CdefGroup) + 256, &cap);
+        if (!host) return -ENOMEM;
+        Dav1dHipCdefTask *ht = reinterpret_cast<Dav1dHipCdefTask *>(host);
+        CdefGroup *hg = reinterpret_cast<CdefGroup *>(host + tb);
+        // where every piece goes, then the copies on a few threads (8 MB of unit records for an 8K frame)
+        const size_t np = f->filter_pieces.size();
+        std::vector<size_t> t_off(np + 1, 0), g_off(np + 1, 0);
+        for (size_t k = 0; k < np; k++) {
+            t_off[k + 1] = t_off[k] + f->filter_pieces[k].n_cdef;
+            g_off[k + 1] = g_off[k] + (f->filter_pieces[k].groups ? f->filter_pieces[k].groups->size() : 0);
+        }
+        auto copy_pieces = [&](size_t k0, size_t k1) {
+            for (size_t k = k0; k < k1; k++) {
+                const Dav1dHipFrame::FilterPiece &p = f->filter_pieces[k];
+                if (p.n_cdef) memcpy(ht + t_off[k], p.cdef, p.n_cdef * sizeof(*ht));
+                if (p.groups)
+                    for (size_t i = 0; i < p.groups->size(); i++) { CdefGroup g = (*p.groups)[i]; g.first += (uint32_t) t_off[k]; hg[g_off[k] + i] = g; }
+            }
+        };
+        {
+            const unsigned hw = std::thread::hardware_concurrency();
+            const size_t nt = std::max<size_t>(1, std::min<size_t>({ (size_t) 4, hw ? hw : 1, np / 4 + 1 }));
+            std::vector<std::thread> th;
+            for (size_t t = 1; t < nt; t++) th.emplace_back(copy_pieces, np * t / nt, np * (t + 1) / nt);
+            copy_pieces(0, np / nt);
+            for (std::thread &x : th) x.join();
+        }
+        TaskBuf dev_buf(c, tb + n_groups * sizeof(CdefGroup) + 256);
+        uint8_t *const dev = dev_buf.p;
+        if (!dev) rc = -ENOMEM;
+        if (!rc) rc = dav1d_hip_upload(c, dev, host, tb + n_groups * sizeof(CdefGroup));
+        const Dav1dHipCdefTask *d_tasks = reinterpret_cast<const Dav1dHipCdefTask *>(dev);
+        if (!rc && strips) {
+            rc = dav1d_hip_launch_cdef_groups(&t0, &cur, f->cur.bpc, f->cur.layout, d_tasks, reinterpret_cast<const CdefGroup *>(dev + tb), (int) n_groups,
+                                              f->cdef_damping, nullptr, c->stream);
+            if (!rc && n_raw) rc = dav1d_hip_launch_cdef(&t0, &cur, f->cur.bpc, f->cur.layout, d_tasks, (int) n_cdef, f->cdef_damping, nullptr, 1, c->stream);
+        } else if (!rc) {
+            rc = dav1d_hip_launch_cdef(&t0, &cur, f->cur.bpc, f->cur.layout, d_tasks, (int) n_cdef, f->cdef_damping, nullptr, 0, c->stream);
+        }
+        (void) hipStreamSynchronize(c->stream);
+        dav1d_hip_slab_put(c, host, cap);
+        if (rc) return rc;
+        *did_cdef = true;
+    }
+    // restoration units: few; they go through the merged vector and dav1d_hip_lr_batch
+    for (Dav1dHipFrame::FilterPiece &p : f->filter_pieces) {
+        f->lr.insert(f->lr.end(), p.lr, p.lr + p.n_lr);
+        free(p.lf); free(p.cdef); free(p.lr);
+        delete p.groups;
+    }
+    f->filter_pieces.clear();
+    return 0;
 }
 
 // Frame-level filter parameters: the level array (DEVICE, f->lf.level layout), the E / I tables of Av1FilterLUT, the frame's
@@ -582,7 +713,7 @@ int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *ma
 static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask, Dav1dHipPicture *filtered, const Dav1dHipPicture *grain_out) {
     Dav1dHipContext *c = f->c;
     int rc = 0;
-    frame_merge_filter_pieces(f);
+    if (c->post_bands >= 2) frame_merge_filter_pieces(f);          // the banded route works on the merged lists
     // warped / scaled predictions first: the compound combinations of the list below read their PREP outputs
     if (!f->warp.empty()) rc = dav1d_hip_warp_batch(c, &f->cur, f->refs, f->n_refs, f->warp.data(), f->warp.size(), prep);
     if (!rc && !f->scaled.empty()) rc = dav1d_hip_mc_scaled_batch(c, &f->cur, f->refs, f->n_refs, f->scaled.data(), f->scaled.size(), prep);
@@ -736,6 +867,11 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
     if (piped < 0) return piped;
     if (piped == 1) {        // stage by stage
         last = &f->cur;
+        if (!rc && !f->filter_pieces.empty()) {
+            bool did_cdef = false;
+            rc = frame_filters_from_pieces(f, &did_cdef);
+            if (did_cdef) last = &f->tmp[0];
+        }
         if (!rc && !f->lf.empty()) {
             if (!f->lvl || !f->have_lut) return -EINVAL;
             rc = dav1d_hip_lf_batch(c, &f->cur, f->lf.data(), f->lf.size(), f->lvl, f->b4_stride, f->lut_e, f->lut_i);
@@ -863,7 +999,7 @@ void dav1d_hip_frame_destroy(Dav1dHipFrame *f) {
     (void) hipStreamSynchronize(f->c->copy_stream);
     for (Dav1dHipChunk *ck : f->chunks) { ck->release(f->c); delete ck; }
     for (Dav1dHipFrame::StepChunk *sc : f->step_chunks) delete sc;
-    for (Dav1dHipFrame::FilterPiece &p : f->filter_pieces) { free(p.lf); free(p.cdef); free(p.lr); }
+    for (Dav1dHipFrame::FilterPiece &p : f->filter_pieces) { free(p.lf); free(p.cdef); free(p.lr); delete p.groups; }
     if (f->harena) dav1d_hip_slab_put(f->c, f->harena, f->harena_cap);
     if (f->arena) {
         std::lock_guard<std::mutex> lk(f->c->pool_mtx);
