@@ -510,7 +510,7 @@ def full_route_rate(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=64, frame
         prep = mask = None
         res = {"list_ms": [], "filter_list_ms": [], "h2d_ms": [], "frame_end_ms": [], "total_ms": []}
         planes = None
-        with ThreadPoolExecutor(2) as ex2:
+        with ThreadPoolExecutor(1) as ex2:
             for it in range(frames):
                 t_a = time.perf_counter()
                 frame = ctx.frame(cur, refs)
@@ -523,16 +523,9 @@ def full_route_rate(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=64, frame
                     lvl.upload(lvl_host)
                     return (time.perf_counter() - t) * 1e3
                 up = ex2.submit(h2d)
-
-                def filt():          # the filter tasks only read pass 1's arrays: listed next to the blocks, not after them
-                    t = time.perf_counter()
-                    rcf = ctx.lib.dav1d_hip_lister_filter_run(lh, C.byref(fd), max(threads // 2, 1))
-                    return rcf, (time.perf_counter() - t) * 1e3
-                fl = ex2.submit(filt)
                 assert ctx.lib.dav1d_hip_lister_run(lh, threads) == 0
                 t_b = time.perf_counter()
-                rcf, filt_ms = fl.result()
-                assert rcf == 0, rcf
+                assert ctx.lib.dav1d_hip_lister_filter_run(lh, C.byref(fd), threads) == 0
                 t_c = time.perf_counter()
                 h2d_ms = up.result()
                 if prep is None:
@@ -550,7 +543,7 @@ def full_route_rate(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=64, frame
                 frame.destroy()
                 if it:
                     res["list_ms"].append((t_b - t_a) * 1e3)
-                    res["filter_list_ms"].append(filt_ms)
+                    res["filter_list_ms"].append((t_c - t_b) * 1e3)
                     res["h2d_ms"].append(h2d_ms)
                     res["frame_end_ms"].append((t_e - t_d) * 1e3)
                     res["total_ms"].append((t_e - t_a) * 1e3)
@@ -561,7 +554,7 @@ def full_route_rate(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=64, frame
         out.update(frames=frames - 1, host_threads=threads, tiles=tile_cols * tile_rows,
                    value=round(w * h / (out["total_ms"] * 1e-3) / 1e6, 1), unit="Mpixels/s",
                    parity="bit-exact vs the reference's dav1d_decode_tile_sbrow + dav1d_filter_sbrow (%.2f s + %.2f s on this host)" % (t_ref_recon, t_ref_filter),
-                   workload="%dx%d 4:2:0 %d-bit inter frame, hand-off arrays + pass 1's filter inputs -> %d library threads listing blocks and, next to them, "
+                   workload="%dx%d 4:2:0 %d-bit inter frame, hand-off arrays + pass 1's filter inputs -> %d library threads listing blocks, then "
                             "filter tasks -> reconstruction, deblocking (levels 20/28/16/24), CDEF (4 strength pairs), switchable restoration "
                             "(64-pixel units); coefficients (dense) and level cache cross the host link every frame" % (w, h, bpc, threads))
         for o in refs + [cur, coef, lvl] + ([prep, mask] if prep is not None else []):
