@@ -608,6 +608,9 @@ DAV1D_HIP_API int dav1d_hip_frame_submit_step_copy(Dav1dHipFrame *f, const Dav1d
 /* Warped predictions / predictions from references of another size of any tile-sbrow; run before the compound combinations. */
 DAV1D_HIP_API int dav1d_hip_frame_submit_warp(Dav1dHipFrame *f, const Dav1dHipWarpTask *t, size_t n);
 DAV1D_HIP_API int dav1d_hip_frame_submit_scaled(Dav1dHipFrame *f, const Dav1dHipMcScaledTask *t, size_t n);
+/* In-loop filter tasks of a superblock row (or any other share of the frame; any order, any thread).  The tasks are checked
+ * here (-EINVAL), and what can be prepared per share is — deblocking tasks ordered vertical edges first, CDEF units of a row that
+ * sit side by side grouped for the strip kernel — so keep the units of one row of 8x8 blocks in one call, in raster order. */
 DAV1D_HIP_API int dav1d_hip_frame_submit_filter_sbrow(Dav1dHipFrame *f, const Dav1dHipLfTask *lf, size_t n_lf,
                                                       const Dav1dHipCdefTask *cdef, size_t n_cdef,
                                                       const Dav1dHipLrTask *lr, size_t n_lr);
