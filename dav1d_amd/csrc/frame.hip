@@ -30,6 +30,7 @@ struct Dav1dHipFrame {
     // serialised inside the runtime at about 4 us each — was what the listing threads queued on (c->chunk_upload: 1 = that way).
     uint8_t *harena;
     size_t harena_cap;
+    size_t harena_flushed;                  // bytes of the twin already on their way to the device (dav1d_hip_frame_flush)
     // intra blocks: step k of the wavefront = the blocks whose neighbours are final after steps 0 .. k - 1 (and after the
     // inter blocks of the frame); predictions and residuals per step
     // One entry per submission (a tile-sbrow's blocks), tasks sorted by step with the end offset of every step; built — and
@@ -347,7 +348,7 @@ int dav1d_hip_frame_begin(Dav1dHipContext *c, Dav1dHipFrame **out, const Dav1dHi
         while (want < c->arena_hint + (c->arena_hint >> 2)) want <<= 1;
         if (hipMalloc((void **) &f->arena, want) == hipSuccess) f->arena_cap = want; else f->arena = nullptr;
     }
-    f->harena = nullptr; f->harena_cap = 0;
+    f->harena = nullptr; f->harena_cap = 0; f->harena_flushed = 0;
     if (f->arena && !c->chunk_upload) f->harena = dav1d_hip_slab_get(c, f->arena_cap, &f->harena_cap);
     *out = f;
     return 0;
@@ -684,6 +685,7 @@ static int copy_picture(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Da
 // is applied from *filtered into grain_out (dav1d_apply_grain, src/lib.c:311-329).  Synchronous: every stage has
 // completed on return, so the caller can publish progress the way src/thread_task.c:888-896 does.
 static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask, Dav1dHipPicture *filtered, const Dav1dHipPicture *grain_out);
+static int frame_flush_locked(Dav1dHipFrame *f);
 
 int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask, Dav1dHipPicture *filtered, const Dav1dHipPicture *grain_out) {
     if (!f) return -EINVAL;
@@ -700,6 +702,7 @@ int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *ma
     f->step_chunks.clear();
     f->n_steps = 0;
     f->arena_used = 0;
+    f->harena_flushed = 0;
     if (c->pending_slab) {
         std::lock_guard<std::mutex> pl(c->pool_mtx);
         c->free_slabs.push_back({ c->pending_slab, c->pending_slab_cap });
@@ -727,11 +730,7 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
         Dav1dHipMcList ml;
         Dav1dHipCompList cl;
         Dav1dHipItxList xl;
-        if (f->harena) {
-            // the blobs the submitters left in the pinned twin: one transfer (the gather launch waits for the copy stream)
-            const size_t used = std::min(std::min(f->arena_used.load(), f->arena_cap), f->harena_cap);
-            if (used) rc = hip_rc(hipMemcpyAsync(f->arena, f->harena, used, hipMemcpyHostToDevice, c->copy_stream));
-        }
+        if (f->harena) rc = frame_flush_locked(f);       // what dav1d_hip_frame_flush has not sent yet (the gather launch waits for the copy stream)
         if (!rc) rc = dav1d_hip_chunks_to_recon_list(c, f->chunks, &f->arena, &f->arena_cap, f->refs, f->n_refs, &rl, &il, &ml, &cl, &xl);
         if (!rc) {
             if (ml.n || cl.n || rl.f_n[0] || rl.f_n[1] || rl.f_n[2] || rl.f_n[3] || rl.f_n[4]) {
@@ -939,6 +938,27 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
 }
 
 extern "C" {
+
+// The chunk blobs in the pinned twin that are not on their way yet: one transfer on the copy stream.  Only complete blobs may go:
+// the caller guarantees that no submission is in progress (dav1d_hip_frame_flush is called between the listing and the frame end).
+static int frame_flush_locked(Dav1dHipFrame *f) {
+    if (!f->harena) return 0;
+    const size_t used = std::min(std::min(f->arena_used.load(), f->arena_cap), f->harena_cap);
+    if (used <= f->harena_flushed) return 0;
+    const int rc = hip_rc(hipMemcpyAsync(f->arena + f->harena_flushed, f->harena + f->harena_flushed, used - f->harena_flushed, hipMemcpyHostToDevice,
+                                         f->c->copy_stream));
+    if (!rc) f->harena_flushed = used;
+    return rc;
+}
+
+// Optional, once every tile-sbrow submitted so far has returned: start the transfer of the chunks now instead of at frame end (it
+// then runs under whatever the caller does next — the filter listing, the tail of the coefficient upload).  Not thread-safe
+// against submissions in progress.
+int dav1d_hip_frame_flush(Dav1dHipFrame *f) {
+    if (!f) return -EINVAL;
+    std::lock_guard<std::mutex> lk(f->mtx);
+    return frame_flush_locked(f);
+}
 
 int dav1d_hip_frame_set_super_res(Dav1dHipFrame *f, int sr_w) {
     if (!f || sr_w < 0) return -EINVAL;

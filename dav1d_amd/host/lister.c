@@ -1080,5 +1080,6 @@ int dav1d_hip_lister_run(Dav1dHipLister *l, int n_threads) {
     run_worker(&r);
     for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
     pthread_mutex_destroy(&r.mtx);
+    if (!r.err) (void) dav1d_hip_frame_flush(l->frame);         /* every tile is in: the lists start their way to the device */
     return r.err;
 }

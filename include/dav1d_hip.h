@@ -608,6 +608,10 @@ DAV1D_HIP_API int dav1d_hip_frame_submit_step_copy(Dav1dHipFrame *f, const Dav1d
 /* Warped predictions / predictions from references of another size of any tile-sbrow; run before the compound combinations. */
 DAV1D_HIP_API int dav1d_hip_frame_submit_warp(Dav1dHipFrame *f, const Dav1dHipWarpTask *t, size_t n);
 DAV1D_HIP_API int dav1d_hip_frame_submit_scaled(Dav1dHipFrame *f, const Dav1dHipMcScaledTask *t, size_t n);
+/* Optional: once every dav1d_hip_frame_submit_tile_sbrow issued so far has returned (all tiles listed), start moving the prepared
+ * lists to the device now rather than at dav1d_hip_frame_end; the transfer then runs under whatever the caller does next.  Must
+ * not race with a submission in progress.  dav1d_hip_lister_run does this by itself when its threads have joined. */
+DAV1D_HIP_API int dav1d_hip_frame_flush(Dav1dHipFrame *f);
 /* In-loop filter tasks of a superblock row (or any other share of the frame; any order, any thread).  The tasks are checked
  * here (-EINVAL), and what can be prepared per share is — deblocking tasks ordered vertical edges first, CDEF units of a row that
  * sit side by side grouped for the strip kernel — so keep the units of one row of 8x8 blocks in one call, in raster order. */
