@@ -155,8 +155,9 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
                         ld[k] = make_uint4(v.a, v.b, v.c, v.d);
                     } else {
                         const U64b v = *reinterpret_cast<const U64b *>(p);
-                        ld[k] = make_uint4((v.a & 0xff) | ((v.a & 0xff00) << 8), ((v.a >> 16) & 0xff) | ((v.a >> 8) & 0xff0000),
-                                           (v.b & 0xff) | ((v.b & 0xff00) << 8), ((v.b >> 16) & 0xff) | ((v.b >> 8) & 0xff0000));
+                        // bytes -> 16-bit lanes: one byte permute per pair of pixels (selector 0x0c = a zero byte)
+                        ld[k] = make_uint4(__builtin_amdgcn_perm(0u, v.a, 0x0c010c00u), __builtin_amdgcn_perm(0u, v.a, 0x0c030c02u),
+                                           __builtin_amdgcn_perm(0u, v.b, 0x0c010c00u), __builtin_amdgcn_perm(0u, v.b, 0x0c030c02u));
                     }
                 }
 #pragma unroll

@@ -132,10 +132,15 @@ static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint3
     return (uint32_t) ((((uint64_t) hi << 32) | lo) >> (sh & 31));
 }
 static inline uint32_t __builtin_amdgcn_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
-    // v_perm_b32: result byte i = byte sel[i] of the 8 bytes { s1 (0..3), s0 (4..7) }; selector values above 7 are not used here
+    // v_perm_b32: result byte i = byte sel[i] of the 8 bytes { s1 (0..3), s0 (4..7) }; selector 12 = 0x00, 13 and above = 0xff
+    // (8 .. 11, the sign replications, are not used here)
     const uint64_t both = ((uint64_t) s0 << 32) | s1;
     uint32_t out = 0;
-    for (int i = 0; i < 4; i++) out |= (uint32_t) ((both >> (8 * ((sel >> (8 * i)) & 7))) & 0xff) << (8 * i);
+    for (int i = 0; i < 4; i++) {
+        const unsigned k = (sel >> (8 * i)) & 0xff;
+        const uint32_t byte = k < 8 ? (uint32_t) ((both >> (8 * k)) & 0xff) : k == 12 ? 0u : k >= 13 ? 0xffu : (abort(), 0u);
+        out |= byte << (8 * i);
+    }
     return out;
 }
 // v_mfma_i32_16x16x64_i8 as dv::mfma_i32_16x16x64_i8 describes it: every lane publishes its operand bytes, then computes its four
