@@ -101,7 +101,8 @@ class FrameDesc(C.Structure):          # == Dav1dHipFrameDesc
                 ("col_start_sb", C.c_uint16 * 65), ("row_start_sb", C.c_uint16 * 65), ("b4_stride", C.c_ssize_t),
                 ("b", C.c_void_p), ("cbi", C.c_void_p), ("tile_start_off", C.c_void_p), ("pal", C.c_void_p),
                 ("svc", ((C.c_int32 * 2) * 2) * 7), ("ref_w", C.c_int * 7), ("ref_h", C.c_int * 7), ("gmv", WarpParams * 7),
-                ("gmv_warp_allowed", C.c_uint8 * 7), ("jnt_weights", (C.c_uint8 * 7) * 7), ("cf_align64", C.c_int)]
+                ("gmv_warp_allowed", C.c_uint8 * 7), ("jnt_weights", (C.c_uint8 * 7) * 7), ("cf_align64", C.c_int),
+                ("lossless", C.c_uint8 * 8)]
 
 
 class SynthParams(C.Structure):        # == Dav1dHipSynthParams
@@ -110,7 +111,8 @@ class SynthParams(C.Structure):        # == Dav1dHipSynthParams
                 ("warp_pct", C.c_int), ("cfl_pct", C.c_int), ("palette", C.c_int), ("filter_intra_pct", C.c_int),
                 ("tx_split_pct", C.c_int), ("alt_txtp_pct", C.c_int), ("eob_none_pct", C.c_int), ("mv_range", C.c_int),
                 ("far_mv_pct", C.c_int), ("n_refs", C.c_int), ("split_pct", C.c_int * 5), ("rect_pct", C.c_int),
-                ("fixed_bl", C.c_int), ("cf_align64", C.c_int), ("intrabc_pct", C.c_int)]
+                ("fixed_bl", C.c_int), ("cf_align64", C.c_int), ("intrabc_pct", C.c_int), ("n_segs", C.c_int),
+                ("skip_mode_pct", C.c_int)]
 
 
 class FilterDesc(C.Structure):         # == Dav1dHipFilterDesc

@@ -27,14 +27,18 @@ namespace {
 uint8_t *slab_get(Dav1dHipContext *c, size_t bytes, size_t *cap) {
     {
         std::lock_guard<std::mutex> lk(c->pool_mtx);
+        // best fit: a 256 KB chunk blob must not walk off with the 16 - 64 MB twin of the arena that the next frame_begin wants
+        // (a fresh hipHostMalloc of that size is a millisecond-class stall, and the pool would grow with every overlap)
+        int best = -1;
         for (size_t i = 0; i < c->free_slabs.size(); i++)
-            if (c->free_slabs[i].cap >= bytes) {
-                const Dav1dHipContext::Slab s = c->free_slabs[i];
-                c->free_slabs[i] = c->free_slabs.back();
-                c->free_slabs.pop_back();
-                *cap = s.cap;
-                return s.host;
-            }
+            if (c->free_slabs[i].cap >= bytes && (best < 0 || c->free_slabs[i].cap < c->free_slabs[best].cap)) best = (int) i;
+        if (best >= 0) {
+            const Dav1dHipContext::Slab s = c->free_slabs[best];
+            c->free_slabs[best] = c->free_slabs.back();
+            c->free_slabs.pop_back();
+            *cap = s.cap;
+            return s.host;
+        }
     }
     size_t want = 1 << 18;
     while (want < bytes) want <<= 1;

@@ -671,8 +671,12 @@ static int copy_picture(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Da
     const int bps = src->bpc > 8 ? 2 : 1;
     for (int pl = 0; pl < 3; pl++) {
         if (!src->p[pl].data) continue;
+        // whole 8-pixel column groups (inside both strides): the super-resolution upscale resamples from the 8x8 block grid, and
+        // columns [w, round8(w)) of an 8x8 unit CDEF leaves alone must be the deblocked ones here as in the whole-allocation copy
+        size_t row_bytes = (size_t) ((src->p[pl].w + 7) & ~7) * bps;
+        row_bytes = std::min(row_bytes, (size_t) std::min(src->p[pl].stride, dst->p[pl].stride));
         const int rc = hip_rc(hipMemcpy2DAsync(dst->p[pl].data, dst->p[pl].stride, src->p[pl].data, src->p[pl].stride,
-                                               (size_t) src->p[pl].w * bps, src->p[pl].h, hipMemcpyDeviceToDevice, c->stream));
+                                               row_bytes, src->p[pl].h, hipMemcpyDeviceToDevice, c->stream));
         if (rc) return rc;
     }
     return 0;
@@ -742,8 +746,9 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
         }
     }
     // intra blocks, wavefront step by step (each step: a paired launch for the small blocks, a prediction and a residual
-    // launch for the others), enqueued back to back
-    if (!rc && !f->step_chunks.empty()) {
+    // launch for the others), enqueued back to back.  A frame may hold step copies (intra block copies) without any intra-step
+    // submission (direct callers of the C API): they run all the same.
+    if (!rc && (!f->step_chunks.empty() || !f->step_copy.empty())) {
         static const bool trace = getenv("DAV1D_HIP_TRACE_INTRA") != nullptr;
         const auto t_a = std::chrono::steady_clock::now();
         const size_t ns = f->n_steps;

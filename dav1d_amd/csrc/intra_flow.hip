@@ -75,7 +75,10 @@ __global__ __launch_bounds__(64, 4) void intra_flow_kernel(const DevPlanes dst, 
                 if (v >= u.prev_n) break;
                 if (2 * v < u.prev_n) dv::nap_long();           // far from done: leave the lines alone for a while
                 dv::nap();
-                if (++spins > FLOW_SPIN_LIMIT) { if (lane == 0) atomicAdd(&ctr[0], 1u); break; }
+                // never met in a run that works: the wave raises the error word and LEAVES — reconstructing a unit whose edges are not there
+                // yet would put wrong pixels into the picture; without its completions the other waves give up the same way and the
+                // frame comes back -EIO
+                if (++spins > FLOW_SPIN_LIMIT) { if (lane == 0) atomicAdd(&ctr[0], 1u); return; }
             }
             if (mode & 2) dv::fence_acquire_agent();
         }
@@ -121,6 +124,13 @@ __global__ __launch_bounds__(64, 4) void intra_flow_kernel(const DevPlanes dst, 
     }
 }
 
+#ifndef DAV1D_HIP_EMU
+// per device: the grid the kernel may have (8 / 16 bpc) and the end of the most recent dataflow launch
+enum { FLOW_MAX_DEVICES = 64 };
+struct FlowDevice { std::mutex mtx; int cap[2] = { 0, 0 }; hipEvent_t done = nullptr; bool any = false; };
+FlowDevice flow_devices[FLOW_MAX_DEVICES];
+#endif
+
 } // namespace
 
 extern "C" int dav1d_hip_launch_intra_flow(const DevPlanes *dst, int bpc, int layout, const IntraUnit *units, int n_units, uint8_t *aux,
@@ -134,14 +144,25 @@ extern "C" int dav1d_hip_launch_intra_flow(const DevPlanes *dst, int bpc, int la
 #ifdef DAV1D_HIP_EMU
     grid = 1;                               // the emulator runs workgroups one after the other
 #else
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    const void *fn = bpc == 8 ? (const void *) intra_flow_kernel<uint8_t, int16_t> : (const void *) intra_flow_kernel<uint16_t, int32_t>;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0) != hipSuccess || per_cu < 1) return -EIO;
-    // one block per CU less than the query says (MI355X_MICROARCH.md: the API over-reports by one near SGPR limits)
-    const int cap = prop.multiProcessorCount * (per_cu > 1 ? per_cu - 1 : 1);
-    if (grid > cap) grid = cap;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FLOW_MAX_DEVICES) return -EIO;
+    FlowDevice &fd = flow_devices[dev];
+    std::lock_guard<std::mutex> lk(fd.mtx);
+    if (!fd.cap[bpc != 8]) {                // asked once per device and kernel, not on every launch
+        int per_cu = 0, cus = 0;
+        const void *fn = bpc == 8 ? (const void *) intra_flow_kernel<uint8_t, int16_t> : (const void *) intra_flow_kernel<uint16_t, int32_t>;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0) != hipSuccess || per_cu < 1 || cus < 1) return -EIO;
+        // one block per CU less than the query says (MI355X_MICROARCH.md: the API over-reports by one near SGPR limits)
+        fd.cap[bpc != 8] = cus * (per_cu > 1 ? per_cu - 1 : 1);
+    }
+    if (grid > fd.cap[bpc != 8]) grid = fd.cap[bpc != 8];
+    // The occupancy figure is that of an EMPTY device.  Other kernels only delay the residency of this grid (they end without
+    // waiting for it), but a second dataflow launch — another context's key frame, frames in flight — could hold the slots this one
+    // needs while waiting for slots this one holds.  So the dataflow launches of a device form a chain: each waits for the one
+    // before it, whatever stream and context it came from (a device-side wait, the host does not block).
+    if (!fd.done && hipEventCreateWithFlags(&fd.done, hipEventDisableTiming) != hipSuccess) return -EIO;
+    if (fd.any && hipStreamWaitEvent((hipStream_t) stream, fd.done, 0) != hipSuccess) return -EIO;
 #endif
     if (bpc == 8)
         hipLaunchKernelGGL((intra_flow_kernel<uint8_t, int16_t>), dim3(grid), dim3(64), 0, (hipStream_t) stream, *dst, units, n_units, aux,
@@ -149,5 +170,12 @@ extern "C" int dav1d_hip_launch_intra_flow(const DevPlanes *dst, int bpc, int la
     else
         hipLaunchKernelGGL((intra_flow_kernel<uint16_t, int32_t>), dim3(grid), dim3(64), 0, (hipStream_t) stream, *dst, units, n_units, aux,
                            (int32_t *) coef, layout, bitdepth_max, ctr, mode);
-    return hip_rc(hipGetLastError());
+    const int rc = hip_rc(hipGetLastError());
+#ifndef DAV1D_HIP_EMU
+    if (!rc) {
+        if (hipEventRecord(fd.done, (hipStream_t) stream) != hipSuccess) return -EIO;
+        fd.any = true;
+    }
+#endif
+    return rc;
 }

@@ -15,11 +15,14 @@
 #include "../csrc/av1_tables.h"
 
 #define VEC(T) struct { T *p; size_t n, cap; }
-#define VPUSH(v, T) ((v).n == (v).cap ? fl_grow((void **) &(v).p, &(v).cap, sizeof(T)) : 0, &(v).p[(v).n++])
+/* out of memory: the push lands in a scratch element and the entry point returns -ENOMEM (see lister.c) */
+static __thread int fl_oom;
+static __thread uint64_t fl_sink[16];
+#define VPUSH(v, T) (((v).n == (v).cap && fl_grow((void **) &(v).p, &(v).cap, sizeof(T))) ? (T *) (void *) fl_sink : &(v).p[(v).n++])
 static int fl_grow(void **p, size_t *cap, const size_t esz) {
     const size_t nc = *cap ? *cap * 2 : 256;
     void *q = realloc(*p, nc * esz);
-    if (!q) abort();
+    if (!q) { fl_oom = 1; return 1; }
     *p = q; *cap = nc;
     return 0;
 }
@@ -246,9 +249,11 @@ int dav1d_hip_lister_filter_sbrow(Dav1dHipLister *l, const Dav1dHipFilterDesc *f
     if (g.n_tile_rows > 1 && (fd->lf_level_y[0] || fd->lf_level_y[1]) && (!fd->a_tx_lpf_y || !fd->a_tx_lpf_uv)) return -EINVAL;
     FOut o;
     memset(&o, 0, sizeof(o));
+    fl_oom = 0;
     list_deblock(&g, fd, &o, sby);
     list_cdef(&g, fd, &o, sby);
     list_lr(&g, fd, &o, sby);
+    if (fl_oom) { free(o.lf.p); free(o.cdef.p); free(o.lr.p); return -ENOMEM; }
     /* the arrays go to the frame as they are (it frees them): no copy, no growing vector under the frame's lock */
     const int rc = dav1d_hip_frame_submit_filter_owned(g.frame, o.lf.p, o.lf.n, o.cdef.p, o.cdef.n, o.lr.p, o.lr.n);
     if (rc) { free(o.lf.p); free(o.cdef.p); free(o.lr.p); }

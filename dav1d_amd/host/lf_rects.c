@@ -92,7 +92,8 @@ static void lf_block(const LfWalk *w, const int bs, const int bx, const int by) 
     if (bw4 > 0 && bh4 > 0) {
         if (!inter) tiles(w, DAV1D_HIP_LF_RECT_LUMA, b->u.i.tx, bx, by, bw4, bh4, 2, l0, l1);
         else if (b->skip) {
-            const HostTx *t = &h_tx[b->u.p.max_ytx];
+            /* a lossless segment: 4x4 whatever the record says (src/decode.c:1890-1893; a skipped block's max_ytx is the block's largest) */
+            const HostTx *t = &h_tx[d->lossless[b->seg_id & 7] ? H_TX_4X4 : b->u.p.max_ytx];
             push(w->o, DAV1D_HIP_LF_RECT_LUMA, bx, by, bw4, bh4, imin_(2, t->lw), imin_(2, t->lh), 3, l0, l1);
         } else {
             const HostTx *t = &h_tx[b->u.p.max_ytx];
@@ -111,7 +112,7 @@ static void lf_block(const LfWalk *w, const int bs, const int bx, const int by) 
     const int cbh4 = imin_(((w->h4 + ss_ver) >> ss_ver) - (by >> ss_ver), (h_bs_dim[bs][1] + ss_ver) >> ss_ver);
     if (cbw4 <= 0 || cbh4 <= 0) return;
     if (inter && b->skip) {
-        const HostTx *t = &h_tx[b->uvtx];
+        const HostTx *t = &h_tx[d->lossless[b->seg_id & 7] ? H_TX_4X4 : b->uvtx];
         push(w->o, DAV1D_HIP_LF_RECT_CHROMA, bx >> ss_hor, by >> ss_ver, cbw4, cbh4, imin_(1, t->lw), imin_(1, t->lh), 3, l2, l3);
     } else {
         tiles(w, DAV1D_HIP_LF_RECT_CHROMA, b->uvtx, bx >> ss_hor, by >> ss_ver, cbw4, cbh4, 1, l2, l3);

@@ -23,11 +23,16 @@
 int dav1d_hip_frame_picture(const Dav1dHipFrame *f, Dav1dHipPicture *out);
 
 #define VEC(T) struct { T *p; size_t n, cap; }
-#define VPUSH(v, T) ((v).n == (v).cap ? vgrow((void **) &(v).p, &(v).cap, sizeof(T)) : 0, &(v).p[(v).n++])
+/* A vector that cannot grow hands out a scratch element and raises the calling thread's flag: the walk goes on writing into
+ * the scratch (nothing is read back from a pushed element), and the entry point that started it returns -ENOMEM (SURVEY 8b:
+ * library errors are negative errno, never an abort of the host process). */
+static __thread int v_oom;
+static __thread uint64_t v_sink[16];          /* >= the largest task record */
+#define VPUSH(v, T) (((v).n == (v).cap && vgrow((void **) &(v).p, &(v).cap, sizeof(T))) ? (T *) (void *) v_sink : &(v).p[(v).n++])
 static int vgrow(void **p, size_t *cap, const size_t esz) {
     const size_t nc = *cap ? *cap * 2 : 256;
     void *q = realloc(*p, nc * esz);
-    if (!q) abort();
+    if (!q) { v_oom = 1; return 1; }
     *p = q; *cap = nc;
     return 0;
 }
@@ -84,6 +89,8 @@ typedef struct Walk {
     int err;
 } Walk;
 
+/* bytes of the prep (which = 0) / mask (1) arena for this walk: from its tile's window, which is refilled from the shared cursor
+ * 128 KB at a time (what a tile leaves unused at the end of the frame is less than that) */
 static uint64_t arena_alloc(Walk *w, const int which, uint64_t *cursor, const uint64_t bytes) {
     const uint64_t need = (bytes + 31) & ~(uint64_t) 31;
     uint64_t (*win)[2] = w->cur->win;
@@ -100,10 +107,6 @@ static uint64_t arena_alloc(Walk *w, const int which, uint64_t *cursor, const ui
 static int imin(const int a, const int b) { return a < b ? a : b; }
 static int imax(const int a, const int b) { return a > b ? a : b; }
 static int iclip(const int v, const int lo, const int hi) { return v < lo ? lo : v > hi ? hi : v; }
-
-/* bytes of the prep (which = 0) / mask (1) arena for this walk: from its tile's window, which is refilled from the shared cursor
- * 128 KB at a time (what a tile leaves unused at the end of the frame is less than that) */
-static uint64_t arena_alloc(struct Walk *w, const int which, uint64_t *cursor, const uint64_t bytes);
 
 static void note_step(Dav1dHipLister *l, const uint32_t s) {
     uint32_t cur = __atomic_load_n(&l->max_step, __ATOMIC_RELAXED);
@@ -135,6 +138,9 @@ static void set_step(const Walk *w, const int pl, const int x4, const int y4, co
     const int x_hi = imin(x4 + tw, (l->bw + sh) >> sh), y_hi = imin(y4 + th, (l->bh + sv) >> sv);
     uint16_t *m = l->step[pl];
     const int st = l->step_stride[pl];
+    /* steps travel as uint16_t (the cell map, the *_step vectors, dav1d_hip_frame_submit_intra_sorted): a wavefront deeper than
+     * that — no legal frame size gets there with tiles of at most 4096 x 2304 luma samples — is refused, not wrapped */
+    if (s > 65535) { ((Walk *) w)->err = -ERANGE; return; }
     for (int y = y4; y < y_hi; y++)
         for (int x = x4; x < x_hi; x++) m[y * st + x] = (uint16_t) s;
     if (s > ((Walk *) w)->seen_step) { ((Walk *) w)->seen_step = s; note_step(w->l, s); }
@@ -1031,9 +1037,10 @@ int dav1d_hip_lister_tile_sbrow(Dav1dHipLister *l, const int tile_row, const int
     w.row_start = l->d.row_start_sb[tile_row] << sb_shift;
     w.row_end = imin(l->d.row_start_sb[tile_row + 1] << sb_shift, l->bh);
     const int by = sby << sb_shift;
-    for (int bx = w.col_start; bx < w.col_end && !w.err; bx += l->sb_step)
+    v_oom = 0;
+    for (int bx = w.col_start; bx < w.col_end && !w.err && !v_oom; bx += l->sb_step)
         walk_sb(&w, l->d.sb128 ? H_BL_128X128 : H_BL_64X64, bx, by, 1, 0);
-    int rc = w.err;
+    int rc = v_oom ? -ENOMEM : w.err;
     if (!rc) rc = dav1d_hip_frame_submit_tile_sbrow(l->frame, o.mc.p, o.mc.n, o.comp.p, o.comp.n, o.itx.p, o.itx.n);
     if (!rc && o.warp.n) rc = dav1d_hip_frame_submit_warp(l->frame, o.warp.p, o.warp.n);
     if (!rc && o.scaled.n) rc = dav1d_hip_frame_submit_scaled(l->frame, o.scaled.p, o.scaled.n);

@@ -42,6 +42,7 @@ typedef struct Gen {
     size_t cur_cbi, cur_cf, cur_pal_idx;             /* cursors of the tile being generated */
     size_t end_cbi, end_cf, end_pal_idx;             /* capacity checks */
     int col_start, col_end, row_start, row_end;
+    int cur_lossless;                                /* the block being generated lies in a lossless segment: 4x4 WHT only */
     int err;
 } Gen;
 
@@ -70,7 +71,7 @@ static void gen_tx(Gen *g, const int tx, const int intra) {
     const int sw = imin(t->w, 8) * 4, sh = imin(t->h, 8) * 4, ncoef = sw * sh;
     const size_t bytes = (size_t) ncoef * g->csz;
     if (g->cur_cbi + 1 > g->end_cbi || g->cur_cf + bytes > g->end_cf) { g->err = -ENOSPC; return; }
-    int eob, txtp = pick_txtp(g, tx, intra);
+    int eob, txtp = g->cur_lossless ? 16 /* WHT_WHT, src/recon_tmpl.c:347-360 */ : pick_txtp(g, tx, intra);
     const int cls = rnd_n(&g->rng, 100);
     if (cls < g->sp->eob_none_pct) eob = -1;
     else if (cls < g->sp->eob_none_pct + 30) eob = 0;
@@ -191,6 +192,14 @@ static void gen_block(Gen *g, const int bl, const int bs, const int bp, const in
     b->bl = (uint8_t) bl; b->bs = (uint8_t) bs; b->bp = (uint8_t) bp;
     b->skip = (uint8_t) pct(&g->rng, sp->skip_pct);
     b->intra = (uint8_t) (!g->d->is_inter || pct(&g->rng, sp->intra_pct));
+    /* segmentation (src/decode.c:808-870): nothing of pass 2 depends on the segment; the deblocking levels and the lossless rule of
+     * the mask builders (src/decode.c:1216-1226, 1882-1900) do */
+    if (sp->n_segs > 1) b->seg_id = (uint8_t) rnd_n(&g->rng, imin(sp->n_segs, 8));
+    const int lossless = g->d->lossless[b->seg_id];
+    g->cur_lossless = lossless;
+    /* skip_mode (src/decode.c:872-886, 1399-1404): two fixed references averaged, no residual */
+    const int skip_mode = g->d->is_inter && !b->intra && imin(bw4, bh4) > 1 && imax(1, imin(sp->n_refs, 7)) > 1 && pct(&g->rng, sp->skip_mode_pct);
+    if (skip_mode) { b->skip_mode = 1; b->skip = 1; }
     int bc_dx = 0, bc_dy = 0;
     if (!g->d->is_inter && sp->intrabc_pct && imax(bw4, bh4) <= 16 && pct(&g->rng, sp->intrabc_pct)) {
         /* Intra block copy: a source for the block — and for the chroma of the whole 8x8 a 4-wide / 4-high block carries, one more
@@ -220,7 +229,7 @@ static void gen_block(Gen *g, const int bl, const int bs, const int bp, const in
         if (pct(&g->rng, 30)) b->u.i.y_mode = H_DC_PRED;
         if (b_dim[2] + b_dim[3] >= 2 && is_directional(b->u.i.y_mode)) b->u.i.y_angle = (int8_t) rnd_range(&g->rng, -3, 3);
         if (has_chroma) {
-            const int cfl_ok = (cfl_allowed >> bs) & 1;
+            const int cfl_ok = lossless ? cbw4 == 1 && cbh4 == 1 : (cfl_allowed >> bs) & 1;       /* src/decode.c:1072-1074 */
             b->u.i.uv_mode = (uint8_t) rnd_n(&g->rng, 13);
             if (pct(&g->rng, 25)) b->u.i.uv_mode = H_DC_PRED;
             if (cfl_ok && pct(&g->rng, sp->cfl_pct)) {
@@ -251,6 +260,7 @@ static void gen_block(Gen *g, const int bl, const int bs, const int bp, const in
                 if (pct(&g->rng, sp->tx_split_pct)) tx = h_tx[tx].sub;
         b->u.i.tx = (uint8_t) tx;
         b->uvtx = h_max_tx_for_bs[bs][layout];
+        if (lossless) b->u.i.tx = b->uvtx = H_TX_4X4;                       /* src/decode.c:1186-1188 */
     } else if (!g->d->is_inter) {
         /* intra block copy: reference "0" = the frame itself, one whole-pixel vector, bilinear, no inter tools (src/decode.c:1258-1330) */
         b->u.p.ref[0] = 0; b->u.p.ref[1] = -1;
@@ -262,8 +272,8 @@ static void gen_block(Gen *g, const int bl, const int bs, const int bp, const in
         uint16_t masks[2] = { 0, 0 };
         b->u.p.max_ytx = h_max_tx_for_bs[bs][0];
         b->uvtx = h_max_tx_for_bs[bs][layout];
-        if (!b->skip && b->u.p.max_ytx == H_TX_4X4) {
-            b->uvtx = H_TX_4X4;
+        if (!b->skip && (lossless || b->u.p.max_ytx == H_TX_4X4)) {         /* src/decode.c:456-459 */
+            b->u.p.max_ytx = b->uvtx = H_TX_4X4;
         } else if (!b->skip && sp->tx_split_pct) {
             const HostTx *ytx = &h_tx[b->u.p.max_ytx];
             for (int y = 0, y_off = 0; y < bh4; y += ytx->h, y_off++)
@@ -274,7 +284,7 @@ static void gen_block(Gen *g, const int bl, const int bs, const int bp, const in
         b->u.p.tx_split1 = masks[1];
     } else {
         const int n_refs = imax(1, imin(sp->n_refs, 7));
-        int is_comp = imin(bw4, bh4) > 1 && n_refs > 1 && pct(&g->rng, sp->compound_pct);
+        int is_comp = skip_mode || (imin(bw4, bh4) > 1 && n_refs > 1 && pct(&g->rng, sp->compound_pct));
         b->u.p.ref[0] = (int8_t) rnd_n(&g->rng, n_refs);
         b->u.p.ref[1] = -1;
         for (int i = 0; i < 2; i++) {
@@ -292,6 +302,7 @@ static void gen_block(Gen *g, const int bl, const int bs, const int bp, const in
             b->u.p.comp_type = k < 40 ? H_COMP_INTER_AVG : k < 60 ? H_COMP_INTER_WEIGHTED_AVG : k < 80 ? H_COMP_INTER_SEG : H_COMP_INTER_WEDGE;
             if (!sp->masked_compound && b->u.p.comp_type >= H_COMP_INTER_SEG) b->u.p.comp_type = H_COMP_INTER_AVG;
             if (b->u.p.comp_type == H_COMP_INTER_WEDGE && !((wedge_allowed >> bs) & 1)) b->u.p.comp_type = H_COMP_INTER_SEG;
+            if (skip_mode) b->u.p.comp_type = H_COMP_INTER_AVG;
             b->u.p.u.m.wedge_idx = (uint8_t) rnd_n(&g->rng, 16);
             b->u.p.u.m.mask_sign = (uint8_t) rnd_n(&g->rng, 2);
             b->u.p.inter_mode = 7;
@@ -334,8 +345,8 @@ static void gen_block(Gen *g, const int bl, const int bs, const int bp, const in
         uint16_t masks[2] = { 0, 0 };
         b->u.p.max_ytx = h_max_tx_for_bs[bs][0];
         b->uvtx = h_max_tx_for_bs[bs][layout];
-        if (!b->skip && b->u.p.max_ytx == H_TX_4X4) {
-            b->uvtx = H_TX_4X4;
+        if (!b->skip && (lossless || b->u.p.max_ytx == H_TX_4X4)) {         /* src/decode.c:456-459 */
+            b->u.p.max_ytx = b->uvtx = H_TX_4X4;
         } else if (!b->skip && sp->tx_split_pct) {
             const HostTx *ytx = &h_tx[b->u.p.max_ytx];
             for (int y = 0, y_off = 0; y < bh4; y += ytx->h, y_off++)

@@ -650,8 +650,10 @@ DAV1D_HIP_API int dav1d_hip_frame_wait(Dav1dHipFrame *f, Dav1dHipPicture *filter
  * dav1d_hip_frame_end reports as *filtered) — and once more with the picture height when the frame is through.  Rows arrive in
  * steps of a band when the in-loop filters run banded (option post_bands >= 3: bands of whole 256-row superblock-row pairs, each
  * followed through deblocking, CDEF and restoration; the band's event is waited for before the call), in one step otherwise.
- * Set before dav1d_hip_frame_end / _end_async; the callback may copy the rows out (dav1d_hip_host_picture_fetch) but must not
- * submit to the frame. */
+ * Set before dav1d_hip_frame_end / _end_async.  The callback runs with the frame's and the context's locks held: it may copy the
+ * rows out (dav1d_hip_host_picture_fetch, dav1d_hip_download) and signal other threads, but it must not call any
+ * dav1d_hip_frame_* entry point of this frame (submit, flush, wait, destroy) nor start a list run / frame end on the same
+ * context — those would wait for the locks the caller of the callback holds. */
 DAV1D_HIP_API int dav1d_hip_frame_set_progress_callback(Dav1dHipFrame *f, void (*progress)(void *cookie, int rows, const Dav1dHipPicture *pic),
                                                         void *cookie);
 DAV1D_HIP_API void dav1d_hip_frame_destroy(Dav1dHipFrame *f);
@@ -716,6 +718,9 @@ typedef struct Dav1dHipFrameDesc {
     uint8_t jnt_weights[7][7];   /* f->jnt_weights */
     int cf_align64;              /* 1 when the producer is an x86-64 build of dav1d: decode_sb() realigns the coefficient cursor to
                                     64 bytes after every 8x8 split into 4x4s (#if ARCH_X86_64, src/decode.c:2209-2218) */
+    uint8_t lossless[8];         /* frame_hdr->segmentation.lossless[seg_id]: the deblocking masks of an inter block of such a
+                                    segment are built with 4x4 transforms whatever b->max_ytx / uvtx say (src/decode.c:1890-1893;
+                                    a skipped block keeps the block's largest sizes in its record, :456-470) */
 } Dav1dHipFrameDesc;
 
 /* Byte offset of a tile's first coefficient in the cf arena, of its first cbi entry and of its first palette index byte, as
@@ -850,6 +855,9 @@ typedef struct Dav1dHipSynthParams {
     int cf_align64;                          /* == Dav1dHipFrameDesc.cf_align64 */
     int intrabc_pct;                         /* key / intra-only frames: blocks (up to 64x64) coded as intra block copies where a source
                                                 rectangle exists in the tile's superblock rows above or 256 pixels to the left */
+    int n_segs;                              /* segmentation: seg_id drawn from 0 .. n_segs - 1 per block (0 / 1: every block in segment 0) */
+    int skip_mode_pct;                       /* inter frames: blocks coded with skip_mode (two fixed references averaged, no residual,
+                                                src/decode.c:1399-1404) */
 } Dav1dHipSynthParams;
 DAV1D_HIP_API int dav1d_hip_synth_frame(const Dav1dHipFrameDesc *desc, const Dav1dHipSynthParams *sp, void *cf, size_t cf_bytes,
                                         size_t cbi_entries, uint8_t *pal_idx, size_t pal_idx_bytes);

@@ -46,6 +46,10 @@ typedef struct RefFrameParams {
     int lr_type[3], lr_unit_size[2];
     int sr_w;                     /* super-resolution: width of the upscaled frame (0 or w: none) */
     int delta_lf;                 /* 1: delta_lf present — every superblock gets level deltas of its own (2: one delta for all four levels) */
+    /* segmentation: per-segment deblocking level deltas (seg_data.d[s].delta_lf_y_v, _y_h, _u, _v) and lossless segments */
+    int seg_enabled;
+    int seg_delta_lf[8][4];
+    int seg_lossless[8];
 } RefFrameParams;
 
 typedef struct RefFrame {
@@ -173,6 +177,17 @@ void *dav1d_ref_frame_create(const RefFrameParams *const p) {
     for (int i = 0; i < 3; i++) fh->restoration.type[i] = p->lr_type[i];
     fh->restoration.unit_size[0] = p->lr_unit_size[0]; fh->restoration.unit_size[1] = p->lr_unit_size[1];
     fh->txfm_mode = DAV1D_TX_SWITCHABLE;
+    if (p->seg_enabled) {
+        fh->segmentation.enabled = 1;
+        for (int s = 0; s < 8; s++) {
+            Dav1dSegmentationData *const sd = &fh->segmentation.seg_data.d[s];
+            sd->delta_lf_y_v = p->seg_delta_lf[s][0]; sd->delta_lf_y_h = p->seg_delta_lf[s][1];
+            sd->delta_lf_u = p->seg_delta_lf[s][2]; sd->delta_lf_v = p->seg_delta_lf[s][3];
+            sd->ref = -1;
+            fh->segmentation.lossless[s] = p->seg_lossless[s];
+            fh->segmentation.qidx[s] = p->seg_lossless[s] ? 0 : 100;
+        }
+    }
     for (int i = 0; i < 7; i++) {
         fh->gmv[i] = dav1d_default_wm_params;
         fh->gmv[i].type = p->gmv_type[i];
@@ -581,8 +596,11 @@ static int walk_inter(Dav1dTaskContext *const t, const enum BlockSize bs, const 
         const int is_globalmv = b->inter_mode == (is_comp ? GLOBALMV_GLOBALMV : GLOBALMV);
         const uint8_t (*const lf_lvls)[8][2] = (const uint8_t (*)[8][2]) &walk_lflvl(r, t)[b->seg_id][0][b->ref[0] + 1][!is_globalmv];
         const uint16_t tx_split[2] = { b->tx_split0, b->tx_split1 };
+        /* the caller's own adjustment for lossless segments, src/decode.c:1889-1893 */
+        enum RectTxfmSize ytx = b->max_ytx, uvtx = b->uvtx;
+        if (f->frame_hdr->segmentation.lossless[b->seg_id]) { ytx = (enum RectTxfmSize) TX_4X4; uvtx = (enum RectTxfmSize) TX_4X4; }
         dav1d_create_lf_mask_inter(f->lf.mask + (t->by >> 5) * f->sb128w + (t->bx >> 5), f->lf.level, f->b4_stride, lf_lvls,
-                                   t->bx, t->by, f->w4, f->h4, b->skip, bs, b->max_ytx, tx_split, b->uvtx, f->cur.p.layout,
+                                   t->bx, t->by, f->w4, f->h4, b->skip, bs, ytx, tx_split, uvtx, f->cur.p.layout,
                                    &a->tx_lpf_y[bx4], &r->lf_l.tx_lpf_y[by4],
                                    has_chroma ? &a->tx_lpf_uv[cbx4] : NULL, has_chroma ? &r->lf_l.tx_lpf_uv[cby4] : NULL);
     }

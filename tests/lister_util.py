@@ -21,7 +21,8 @@ class RefFrameParams(C.Structure):
                 ("lf_level_y", C.c_int * 2), ("lf_level_u", C.c_int), ("lf_level_v", C.c_int), ("lf_sharpness", C.c_int),
                 ("lf_mode_ref_delta_enabled", C.c_int), ("lf_ref_delta", C.c_int * 8), ("lf_mode_delta", C.c_int * 2),
                 ("cdef_enabled", C.c_int), ("cdef_damping", C.c_int), ("cdef_n_bits", C.c_int), ("cdef_y_strength", C.c_int * 8),
-                ("cdef_uv_strength", C.c_int * 8), ("lr_type", C.c_int * 3), ("lr_unit_size", C.c_int * 2), ("sr_w", C.c_int), ("delta_lf", C.c_int)]
+                ("cdef_uv_strength", C.c_int * 8), ("lr_type", C.c_int * 3), ("lr_unit_size", C.c_int * 2), ("sr_w", C.c_int), ("delta_lf", C.c_int),
+                ("seg_enabled", C.c_int), ("seg_delta_lf", (C.c_int * 4) * 8), ("seg_lossless", C.c_int * 8)]
 
 
 def ref_lib():
@@ -55,7 +56,7 @@ class RefFrame:
     """One synthetic frame inside a real Dav1dFrameContext of the reference build."""
 
     def __init__(self, w, h, layout, bpc, is_inter=True, sb128=True, tile_cols=1, tile_rows=1, ref_sizes=None, gmv=None,
-                 intra_edge_filter=1, screen_content=0, order_hint_bits=5, filters=None, sr_w=0, delta_lf=0):
+                 intra_edge_filter=1, screen_content=0, order_hint_bits=5, filters=None, sr_w=0, delta_lf=0, segments=None):
         self.lib = ref_lib()
         assert self.lib is not None, "the reference build oracle/_ref is required"
         p = RefFrameParams()
@@ -102,6 +103,15 @@ class RefFrame:
                     p.lr_type[i] = types[i]
                 p.lr_unit_size[0], p.lr_unit_size[1] = units
         p.delta_lf = delta_lf
+        if segments:
+            # segments: dict(delta_lf=[[y_v, y_h, u, v]] * n, lossless=[0 / 1] * n): segmentation with per-segment level deltas
+            # (Dav1dSegmentationData.delta_lf_*) and lossless segments (frame_hdr->segmentation.lossless)
+            p.seg_enabled = 1
+            for s_, dl in enumerate(segments.get("delta_lf", [])):
+                for k in range(4):
+                    p.seg_delta_lf[s_][k] = dl[k]
+            for s_, v in enumerate(segments.get("lossless", [])):
+                p.seg_lossless[s_] = int(v)
         p.sr_w = sr_w if sr_w and sr_w != w else 0
         self.sr_w = p.sr_w
         self.filters = filters
@@ -163,6 +173,8 @@ class RefFrame:
                 d.jnt_weights[i][j] = int(jw[i, j])
             C.memmove(C.addressof(d.gmv[i]), gmv[i].ctypes.data, C.sizeof(_lib.WarpParams))
         d.cf_align64 = 1                     # the oracle build is an x86-64 build (oracle/ref_config.h)
+        for s_ in range(8):
+            d.lossless[s_] = p.seg_lossless[s_]
         return d
 
     def recon(self, threads=1):

@@ -20,11 +20,13 @@ LR_SW = dict(lr=([1, 1, 1], [6, 6]))
 LR_W_S = dict(lr=([2, 3, 0], [7, 6]))
 LR_BIG = dict(lr=([3, 1, 2], [8, 7]))
 ALL = dict(LF, **CDEF, **LR_SW)
+SEGMENTS = dict(delta_lf=[[0, 0, 0, 0], [10, -8, 6, -4], [-12, 5, 0, 9], [20, 20, -10, -10]], lossless=[0, 1, 0, 1])
 
 
-def run_case(ctx, w, h, layout, bpc, seed, filters, is_inter=True, tiles=(1, 1), sb128=True, own_masks=False, sr_w=0, delta_lf=0, **kw):
+def run_case(ctx, w, h, layout, bpc, seed, filters, is_inter=True, tiles=(1, 1), sb128=True, own_masks=False, sr_w=0, delta_lf=0, segments=None,
+             **kw):
     rf = lu.RefFrame(w, h, layout, bpc, is_inter=is_inter, tile_cols=tiles[0], tile_rows=tiles[1], sb128=sb128, filters=filters, sr_w=sr_w,
-                     delta_lf=delta_lf)
+                     delta_lf=delta_lf, segments=segments)
     try:
         sp = lu.default_synth(seed, **kw)
         d = lu.synth(ctx, rf, sp)
@@ -71,10 +73,12 @@ CASES = [
     ("superres_key_422_12", 264, 136, 2, 12, ALL, dict(sr_w=400, is_inter=False)),
     ("superres_width_not_8n", 324, 200, 1, 8, ALL, dict(sr_w=486)),     # the resampler reads the columns up to the 8x8 block grid
     ("delta_lf_pass1_masks", 520, 264, 1, 8, ALL, dict(delta_lf=1)),     # levels that differ from superblock to superblock
+    ("segments_lossless_pass1_masks", 328, 200, 1, 10, ALL, dict(segments=SEGMENTS, n_segs=4, skip_pct=40, skip_mode_pct=15)),
 ]
 CPU = {"deblock_deltas_tiles", "deblock_sb64_tiles", "deblock_444", "deblock_400", "cdef_8_strengths_12bit", "cdef_422", "cdef_skips",
        "lr_wiener_sgr_128", "lr_256_units_444", "all_tiles", "all_key_frame", "all_sb64_cut", "superres_all_420_8",
-       "superres_cdef_only_444_10", "superres_lr_big_units_10", "superres_key_422_12", "superres_width_not_8n", "delta_lf_pass1_masks"}
+       "superres_cdef_only_444_10", "superres_lr_big_units_10", "superres_key_422_12", "superres_width_not_8n", "delta_lf_pass1_masks",
+       "segments_lossless_pass1_masks"}
 
 
 @pytest.mark.parametrize("name,w,h,layout,bpc,filters,kw", CASES, ids=[c[0] for c in CASES])
@@ -96,7 +100,11 @@ def test_filters_1080p():
 
 OWN = [("all_tiles", 320, 200, 1, 10, ALL, dict(tiles=(2, 2))), ("deltas_444_tiles", 256, 136, 3, 10, dict(LF_DELTAS, **CDEF), dict(tiles=(2, 2))),
        ("key_frame_sb64", 296, 168, 1, 8, ALL, dict(is_inter=False, sb128=False, tiles=(2, 2))),
-       ("delta_lf_tiles", 520, 264, 1, 10, dict(LF_DELTAS, **CDEF), dict(delta_lf=1, tiles=(2, 1)))]
+       ("delta_lf_tiles", 520, 264, 1, 10, dict(LF_DELTAS, **CDEF), dict(delta_lf=1, tiles=(2, 1))),
+       # segments with levels of their own, two of them lossless, skipped and skip_mode blocks among them: the whole chain from masks the
+       # product built with Dav1dHipFrameDesc.lossless
+       ("segments_lossless_tiles", 392, 264, 1, 10, ALL, dict(segments=SEGMENTS, n_segs=4, skip_pct=40, skip_mode_pct=15, tiles=(2, 2))),
+       ("segments_lossless_444_8", 256, 136, 3, 8, dict(LF_DELTAS, **CDEF), dict(segments=SEGMENTS, n_segs=4, skip_pct=35))]
 
 
 @pytest.mark.parametrize("name,w,h,layout,bpc,filters,kw", OWN, ids=[c[0] for c in OWN])

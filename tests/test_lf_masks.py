@@ -22,6 +22,9 @@ assert LF_RECT.itemsize == 12
 
 LF = dict(lf=(20, 28, 16, 24, 0, False))
 LF_DELTAS = dict(lf=(12, 40, 30, 9, 3, True))
+# segmentation: four segments with level deltas of their own, two of them lossless (4x4 WHT blocks; the mask builder's caller
+# substitutes TX_4X4 for the sizes of their inter blocks, src/decode.c:1889-1893)
+SEGMENTS = dict(delta_lf=[[0, 0, 0, 0], [10, -8, 6, -4], [-12, 5, 0, 9], [20, 20, -10, -10]], lossless=[0, 1, 0, 1])
 
 CASES = [
     ("420_8", 320, 200, 1, 8, LF, {}),
@@ -35,6 +38,9 @@ CASES = [
     # delta_lf: every superblock parsed with level deltas of its own (four of them / one for all), tables from dav1d_calc_lf_values
     ("delta_lf_multi", 520, 392, 1, 8, LF_DELTAS, dict(delta_lf=1, tiles=(2, 2))),
     ("delta_lf_single_sb64_444", 328, 264, 3, 10, LF, dict(delta_lf=2, sb128=False)),
+    ("segments_lossless_skips", 392, 264, 1, 10, LF, dict(segments=SEGMENTS, n_segs=4, skip_pct=45, skip_mode_pct=15, tiles=(2, 2))),
+    ("segments_lossless_444_sb64_deltas", 264, 200, 3, 8, LF_DELTAS, dict(segments=SEGMENTS, n_segs=4, skip_pct=30, sb128=False)),
+    ("segments_lossless_key_422", 260, 140, 2, 10, LF, dict(segments=SEGMENTS, n_segs=3, is_inter=False)),
 ]
 
 
@@ -43,7 +49,7 @@ def test_device_built_masks_equal_the_reference_builders(ctx, name, w, h, layout
     kw = dict(kw)
     tiles = kw.pop("tiles", (1, 1))
     rf = lu.RefFrame(w, h, layout, bpc, is_inter=kw.pop("is_inter", True), tile_cols=tiles[0], tile_rows=tiles[1], sb128=kw.pop("sb128", True),
-                     filters=filters, delta_lf=kw.pop("delta_lf", 0))
+                     filters=filters, delta_lf=kw.pop("delta_lf", 0), segments=kw.pop("segments", None))
     try:
         sp = lu.default_synth(77, **kw)
         d = lu.synth(ctx, rf, sp)
@@ -59,6 +65,16 @@ def test_device_built_masks_equal_the_reference_builders(ctx, name, w, h, layout
         assert ctx.lib.dav1d_hip_lf_rects_sb(C.byref(d), lflvl.ctypes.data, sbt.ctypes.data if sbt is not None and len(sbt) else None,
                                              C.byref(rects_p), C.byref(n)) == 0
         assert n.value > 0
+        if rf.p.seg_enabled:
+            # not a vacuous case: segments carry different levels, and (inter frames) skipped inter blocks of lossless segments exist
+            # whose recorded transform size is not 4x4 (Av1Block bytes: 3 intra, 4 seg_id, 6 skip, 7 uvtx; block origins have bl | bs != 0)
+            assert len(np.unique(lflvl.reshape(8, -1)[:4], axis=0)) == 4
+            blk = rf.array("b", np.uint8).reshape(-1, 32)
+            at_origin = (blk[:, 0] | blk[:, 1]) != 0
+            assert len(np.unique(blk[at_origin, 4])) == sp.n_segs
+            if rf.is_inter:
+                hit = at_origin & (blk[:, 3] == 0) & (blk[:, 6] == 1) & (np.asarray(rf.p.seg_lossless[:])[blk[:, 4] & 7] == 1) & (blk[:, 7] != 0)
+                assert int(hit.sum()) > 10, "no skipped inter block in a lossless segment"
         ss_hor, ss_ver = int(layout != 3), int(layout == 1)
         w4, h4 = (w + 3) >> 2, (h + 3) >> 2
         bw, bh = ((w + 7) >> 3) << 1, ((h + 7) >> 3) << 1

@@ -32,9 +32,9 @@ def scaled_refs(w, h):
     return rs
 
 
-def run_case(ctx, w, h, layout, bpc, seed, is_inter=True, tiles=(1, 1), threads=1, sb128=True, ref_sizes=None, gmv=None, **kw):
+def run_case(ctx, w, h, layout, bpc, seed, is_inter=True, tiles=(1, 1), threads=1, sb128=True, ref_sizes=None, gmv=None, segments=None, **kw):
     rf = lu.RefFrame(w, h, layout, bpc, is_inter=is_inter, tile_cols=tiles[0], tile_rows=tiles[1], sb128=sb128,
-                     screen_content=1 if kw.get("palette") else 0, ref_sizes=ref_sizes, gmv=gmv)
+                     screen_content=1 if kw.get("palette") else 0, ref_sizes=ref_sizes, gmv=gmv, segments=segments)
     try:
         sp = lu.default_synth(seed, **kw)
         d = lu.synth(ctx, rf, sp)
@@ -117,6 +117,8 @@ def _offset(B, name):
     return base + getattr(_W, name).offset
 
 
+SEGMENTS = dict(delta_lf=[[0, 0, 0, 0], [10, -8, 6, -4], [-12, 5, 0, 9], [20, 20, -10, -10]], lossless=[0, 1, 0, 1])
+
 PLAIN = dict(intra_pct=0, compound_pct=0, global_pct=0, interintra_pct=0, obmc_pct=0, warp_pct=0, tx_split_pct=0, alt_txtp_pct=0, rect_pct=0)
 
 # (name, w, h, layout, bpc, keyword arguments)
@@ -161,11 +163,16 @@ MIX = [
     ("global_motion_444", 192, 192, 3, 10, dict(gmv=GMV, global_pct=40)),
     ("scaled_refs", 256, 192, 1, 8, dict(ref_sizes=scaled_refs(256, 192))),
     ("scaled_refs_444_10", 192, 128, 3, 10, dict(ref_sizes=scaled_refs(192, 128))),
+    # segmentation: seg_id varies from block to block, two lossless segments (their blocks: 4x4 Walsh-Hadamard transforms only,
+    # src/recon_tmpl.c:347-360, src/decode.c:456-459, 1186-1188), skip_mode blocks (src/decode.c:1399-1404)
+    ("segments_lossless_420_10", 256, 192, 1, 10, dict(segments=SEGMENTS, n_segs=4, skip_mode_pct=15)),
+    ("segments_lossless_key_444_8", 192, 128, 3, 8, dict(segments=SEGMENTS, n_segs=4, is_inter=False)),
+    ("segments_lossless_422_12_tiles", 264, 136, 2, 12, dict(segments=SEGMENTS, n_segs=3, skip_mode_pct=25, tiles=(2, 1))),
 ]
 # the SIMT-emulated kernels are slow: the CPU run takes a cross-section, the GPU run everything
 MIX_CPU = {"420_8", "420_12_cut", "444_10", "422_10", "400_8", "tiles_3_threads", "sb64_tiles", "key_444_10", "key_palette",
            "key_intrabc_420_8", "key_intrabc_444_10", "key_intrabc_422_12_sb64",
-           "global_motion", "scaled_refs_444_10"}
+           "global_motion", "scaled_refs_444_10", "segments_lossless_420_10", "segments_lossless_key_444_8", "segments_lossless_422_12_tiles"}
 
 
 @pytest.mark.parametrize("name,w,h,layout,bpc,kw", MIX, ids=[t[0] for t in MIX])
