@@ -87,6 +87,14 @@ class DevicePicture:
         assert a.shape == self.padded_shape(plane), (a.shape, self.padded_shape(plane))
         _chk(self.ctx.lib.dav1d_hip_plane_upload(self.ctx.h, C.byref(self.pic), plane, a.ctypes.data,
                                                  a.strides[0], 1), "plane_upload")
+        # the raster planes changed behind the tiled twin's back (Dav1dHipPicture.twin_ok is the caller's to keep)
+        self.pic.twin_ok = 0
+        if getattr(self.ctx, "auto_retile", False) and plane == self.n_planes - 1:
+            self.retile()
+
+    def retile(self):
+        """(Re)build the tiled twin from the raster planes: motion compensation then reads this picture through it."""
+        _chk(self.ctx.lib.dav1d_hip_picture_retile(self.ctx.h, C.byref(self.pic)), "picture_retile")
 
     def download(self, plane):
         """Padded plane as a (rows x cols) view of a host array with the DEVICE row stride, so that

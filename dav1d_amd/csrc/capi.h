@@ -29,6 +29,9 @@ struct Dav1dHipContext {
     int chunk_upload;           // 0: a frame's chunks go up as one transfer at frame end; 1: each chunk as it is submitted (DAV1D_HIP_CHUNK_UPLOAD)
     int recon_coop_below;       // paired kernels: launches of fewer groups than this take the cooperative form (recon.hip; DAV1D_HIP_RECON_COOP_BELOW)
     int post_bands;             // bands of the pipelined post filters, 0 = stage by stage (DAV1D_HIP_POST_BANDS)
+    int recon_pair_streams;     // side streams the paired launches of a recon list are dealt over (DAV1D_HIP_RECON_PAIR_STREAMS, 1 or 2)
+    int ref_twin;               // tiled twins of reference pictures ($DAV1D_HIP_REF_TWIN): 0 never read, 1 (default) read when a picture has a valid
+                                // one (dav1d_hip_picture_retile), 2 also made for every picture of dav1d_hip_picture_alloc and by dav1d_hip_frame_end
     bool cdef_unit_kernel;      // $DAV1D_HIP_CDEF_UNIT=1 at open: one wave per 8x8 unit (the round-1 kernel) instead of strips; A/B aid
     // measurement aid: device time of the kernel launches of the most recent *_batch call (dav1d_hip_last_kernel_ms)
     hipEvent_t ev_t0, ev_t1;
@@ -144,7 +147,28 @@ static inline DevPlanes dev_planes(const Dav1dHipPicture *p) {
         d.w[i] = p->p[i].w;
         d.h[i] = p->p[i].h;
     }
+    d.tiled = 0;
     return d;
+}
+static inline bool picture_twin_usable(const Dav1dHipPicture *p) {
+    if (!p->twin_ok) return false;
+    const int bps = p->bpc > 8 ? 2 : 1;
+    for (int i = 0; i < 3; i++)
+        if (p->p[i].data && (!p->twin[i] || (p->p[i].stride / bps) % 8)) return false;
+    return true;
+}
+// The planes motion compensation reads its references through: the tiled twins when the context uses them and EVERY reference
+// of the call has a valid one (a launch is one kernel variant: all tiled or all raster), the raster planes otherwise.
+static inline void ref_planes(const Dav1dHipContext *c, const Dav1dHipPicture *refs, int n_refs, DevPlanes *rp) {
+    bool tiled = c->ref_twin != 0 && n_refs > 0;
+    for (int i = 0; i < n_refs && tiled; i++) tiled = picture_twin_usable(&refs[i]);
+    for (int i = 0; i < n_refs; i++) {
+        rp[i] = dev_planes(&refs[i]);
+        if (tiled) {
+            for (int pl = 0; pl < 3; pl++) rp[i].data[pl] = refs[i].p[pl].data ? refs[i].twin[pl] : nullptr;
+            rp[i].tiled = 1;
+        }
+    }
 }
 
 // kernel launchers (one per family translation unit)
@@ -165,7 +189,8 @@ struct McRef {
     uint8_t  fh, fv;      // row of av1_mc_subpel_filters (0..5) or 6 = bilinear
     uint8_t  ref;         // index into the reference picture set
     uint8_t  vspan;       // av1_mc_tap_span of (fv, my): the window rows the vertical taps reach (filled at list creation)
-    uint8_t  pad[2];
+    uint8_t  hspan;       // the same of (fh, mx): the window columns the horizontal taps reach, origin src_x - 3 (tiled references)
+    uint8_t  pad;
 };
 struct McTile {
     uint32_t dst_off;     // of the TASK: pixel offset in the dst plane; PREP: int16 offset in the prep arena

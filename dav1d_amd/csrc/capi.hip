@@ -48,6 +48,8 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     c->chunk_upload = (int) env_int("DAV1D_HIP_CHUNK_UPLOAD", 0);
     c->recon_coop_below = (int) env_int("DAV1D_HIP_RECON_COOP_BELOW", 4096);
     c->post_bands = (int) env_int("DAV1D_HIP_POST_BANDS", 0);
+    c->ref_twin = (int) env_int("DAV1D_HIP_REF_TWIN", 1);
+    c->recon_pair_streams = (int) env_int("DAV1D_HIP_RECON_PAIR_STREAMS", 1);
     const char *ser = getenv("DAV1D_HIP_SERIAL");
     c->concurrent = !(ser && atoi(ser));
     const char *cu = getenv("DAV1D_HIP_CDEF_UNIT");
@@ -150,6 +152,8 @@ int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value) {
     else if (!strcmp(name, "chunk_upload")) c->chunk_upload = (int) value;
     else if (!strcmp(name, "recon_coop_below")) c->recon_coop_below = (int) value;
     else if (!strcmp(name, "post_bands")) c->post_bands = (int) value;
+    else if (!strcmp(name, "ref_twin")) c->ref_twin = (int) value;
+    else if (!strcmp(name, "recon_pair_streams")) c->recon_pair_streams = (int) value;
     else if (!strcmp(name, "serial")) c->concurrent = !value;
     else if (!strcmp(name, "cdef_unit")) c->cdef_unit_kernel = value != 0;
     else if (!strcmp(name, "flow_groups")) c->flow_groups = value > 0 ? (int) value : c->flow_groups;
@@ -225,7 +229,48 @@ int dav1d_hip_picture_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic, int w, int
         pic->p[i].w = has_chroma ? (w + ss_hor) >> ss_hor : 0;
         pic->p[i].h = has_chroma ? (h + ss_ver) >> ss_ver : 0;
     }
+    if (c->ref_twin >= 2) {
+        const int rc = dav1d_hip_picture_twin_alloc(c, pic);
+        if (rc) { (void) hipFree(buf); memset(pic, 0, sizeof(*pic)); return rc; }
+    }
     return 0;
+}
+
+// Storage for the tiled twin: per plane stride x (height rounded up to 8 rows) bytes, the planes one after the other.
+int dav1d_hip_picture_twin_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic) {
+    if (!c || !pic || !pic->p[0].data) return -EINVAL;
+    if (pic->twin_alloc) return 0;
+    const int bps = pic->bpc > 8 ? 2 : 1;
+    size_t off[3] = { 0, 0, 0 }, total = 0;
+    for (int i = 0; i < 3; i++) {
+        if (!pic->p[i].data) continue;
+        if (pic->p[i].stride <= 0 || (pic->p[i].stride / bps) % 8 || pic->p[i].stride % 16) return -EINVAL;
+        off[i] = total;
+        // a plane of picture_alloc is padded to 128 rows: the twin mirrors what can be addressed (rows up to the next multiple of 8)
+        total += (size_t) pic->p[i].stride * (size_t) ((pic->p[i].h + 7) & ~7);
+        total = (total + 255) & ~(size_t) 255;
+    }
+    void *buf = nullptr;
+    HIP_TRY(hipMalloc(&buf, total + 256));
+    HIP_TRY(hipMemsetAsync(buf, 0, total + 256, c->stream));
+    pic->twin_alloc = buf;
+    for (int i = 0; i < 3; i++) pic->twin[i] = pic->p[i].data ? (uint8_t *) buf + off[i] : nullptr;
+    pic->twin_ok = 0;
+    return 0;
+}
+
+extern "C" int dav1d_hip_launch_retile(const DevPlanes *src, void *const twin[3], int bpc, void *stream);
+
+int dav1d_hip_picture_retile(Dav1dHipContext *c, Dav1dHipPicture *pic) {
+    if (!c || !pic) return -EINVAL;
+    if (!pic->twin_alloc && !pic->twin[0]) {
+        const int rc = dav1d_hip_picture_twin_alloc(c, pic);
+        if (rc) return rc;
+    }
+    const DevPlanes sp = dev_planes(pic);
+    const int rc = dav1d_hip_launch_retile(&sp, pic->twin, pic->bpc, c->stream);
+    if (!rc) pic->twin_ok = 1;
+    return rc;
 }
 
 // Host side of a Dav1dPicAllocator: pinned planes with the geometry of the device picture (= the reference's default allocator,
@@ -289,9 +334,10 @@ int dav1d_hip_host_picture_wait(Dav1dHipContext *c) {
 }
 
 int dav1d_hip_picture_free(Dav1dHipContext *c, Dav1dHipPicture *pic) {
-    if (!pic || !pic->alloc) return 0;
+    if (!pic || (!pic->alloc && !pic->twin_alloc)) return 0;
     hipStreamSynchronize(c->stream);
-    const int rc = hip_rc(hipFree(pic->alloc));
+    int rc = pic->alloc ? hip_rc(hipFree(pic->alloc)) : 0;
+    if (pic->twin_alloc) { const int rc2 = hip_rc(hipFree(pic->twin_alloc)); if (!rc) rc = rc2; }
     memset(pic, 0, sizeof(*pic));
     return rc;
 }
@@ -560,6 +606,7 @@ McRef mc_ref_of(const Dav1dHipMcTask &t) {
         r.fv = t.h > 4 ? v_type : 3 + (v_type & 1);
     }
     r.vspan = av1_mc_tap_span_host[r.fv * 16 + r.my];
+    r.hspan = av1_mc_tap_span_host[r.fh * 16 + r.mx];
     return r;
 }
 
@@ -698,7 +745,7 @@ static int mc_regroup(Dav1dHipContext *c, Dav1dHipMcList *l, const DevPlanes *rp
                 const int x0 = r.src_x - 4, y0 = r.src_y - 3;
                 edge |= x0 < 0 || y0 < 0 || x0 + ext_x > rp[r.ref].w[t.plane] || y0 + ext_y > rp[r.ref].h[t.plane];
             }
-            key[i] = (uint8_t) ((edge ? 8 : 0) | t.kind);
+            key[i] = (uint8_t) ((edge ? 16 : 0) | t.kind << 1 | (t.r[0].src_x & 1));       // the column parity: see the paired blocks of recon lists
         }
         std::vector<uint32_t> idx;
         for (size_t lo = l->off[b]; lo < l->off[b + 1]; lo += win) {
@@ -744,10 +791,9 @@ int dav1d_hip_mc_list_run(Dav1dHipContext *c, const Dav1dHipMcList *l, const Dav
     if (!l || !dst || !refs || n_refs < 1 || n_refs > 8 || (l->n && l->max_ref >= n_refs)) return -EINVAL;
     const DevPlanes dp = dev_planes(dst);
     DevPlanes rp[8];
-    for (int i = 0; i < n_refs; i++) {
-        if (refs[i].bpc != dst->bpc) return -EINVAL;
-        rp[i] = dev_planes(&refs[i]);
-    }
+    for (int i = 0; i < n_refs; i++) if (refs[i].bpc != dst->bpc) return -EINVAL;
+    if (l->n_fused) { for (int i = 0; i < n_refs; i++) rp[i] = dev_planes(&refs[i]); }       // the all-shapes launch reads raster planes
+    else ref_planes(c, refs, n_refs, rp);
     const int fb = mc_fused_min_bin();
     int rc = mc_regroup(c, const_cast<Dav1dHipMcList *>(l), rp, n_refs);
     if (rc) return rc;
@@ -767,7 +813,7 @@ int dav1d_hip_mc_list_run_timed(Dav1dHipContext *c, const Dav1dHipMcList *l, con
     if (!l || !dst || !refs || n_refs < 1 || n_refs > 8 || !ms || (l->n && l->max_ref >= n_refs)) return -EINVAL;
     const DevPlanes dp = dev_planes(dst);
     DevPlanes rp[8];
-    for (int i = 0; i < n_refs; i++) rp[i] = dev_planes(&refs[i]);
+    ref_planes(c, refs, n_refs, rp);
     if (int rg = mc_regroup(c, const_cast<Dav1dHipMcList *>(l), rp, n_refs)) return rg;
     hipEvent_t ev[MC_BINS + 1];
     for (int b = 0; b <= MC_BINS; b++) HIP_TRY(hipEventCreate(&ev[b]));
@@ -1589,7 +1635,10 @@ int dav1d_hip_recon_list_create(Dav1dHipContext *c, Dav1dHipReconList **out, con
         for (size_t lo = 0; lo < nblk; lo += win)
             std::stable_sort(ord.begin() + lo, ord.begin() + std::min(lo + win, nblk), [&](uint32_t p, uint32_t q) {
                 const McTile &tp = pair.tiles[k][p * tpb], &tq = pair.tiles[k][q * tpb];
-                const int kp = itx_path_key(pair.itx[pair.itx_idx[k][p]]) * 8 + tp.kind, kq = itx_path_key(pair.itx[pair.itx_idx[k][q]]) * 8 + tq.kind;
+                // ... and the parity of the first reference column: with tiled references the horizontal pass picks its tap pairs by it
+                // (mc_body.h, TILED), and a wave whose tiles agree runs one of the two forms instead of both
+                const int kp = (itx_path_key(pair.itx[pair.itx_idx[k][p]]) * 8 + tp.kind) * 2 + (tp.r[0].src_x & 1);
+                const int kq = (itx_path_key(pair.itx[pair.itx_idx[k][q]]) * 8 + tq.kind) * 2 + (tq.r[0].src_x & 1);
                 return kp < kq;
             });
         std::vector<McTile> tiles(nblk * tpb);
@@ -1655,16 +1704,15 @@ int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, con
         if (n_refs < 1 || n_refs > 8 || l->f_max_ref >= n_refs) return -EINVAL;
         const DevPlanes dp = dev_planes(dst);
         DevPlanes rp[8];
-        for (int i = 0; i < n_refs; i++) {
-            if (refs[i].bpc != dst->bpc) return -EINVAL;
-            rp[i] = dev_planes(&refs[i]);
-        }
+        for (int i = 0; i < n_refs; i++) if (refs[i].bpc != dst->bpc) return -EINVAL;
+        ref_planes(c, refs, n_refs, rp);
         // one after the other on a side stream of their own, next to the pipeline of the unpaired rest below (main stream:
         // predictions, side stream 0: residuals).  Measured: the paired launches on one stream 0.317 ms per frame, on two
         // streams that run side by side 0.334-0.343 — three launches at a time share the memory system better than four.
         const bool side = c->concurrent && n_paired >= 16384;
         int rc = 0, lane = 0;
-        const int ps[2] = { 2, 2 };
+        // c->recon_pair_streams: 1 = the paired launches one after the other on ONE side stream, 2 = dealt over two
+        const int ps[2] = { 2, c->recon_pair_streams >= 2 ? 3 : 2 };
         if (side) {
             (void) hipEventRecord(c->ev_fork, c->stream);
             (void) hipStreamWaitEvent(c->side[ps[0]], c->ev_fork, 0);
@@ -1702,10 +1750,8 @@ int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, con
     if (n_refs < 1 || n_refs > 8 || (ml->n && ml->max_ref >= n_refs)) { join_paired(); return -EINVAL; }
     const DevPlanes dp = dev_planes(dst);
     DevPlanes rp[8];
-    for (int i = 0; i < n_refs; i++) {
-        if (refs[i].bpc != dst->bpc) { join_paired(); return -EINVAL; }
-        rp[i] = dev_planes(&refs[i]);
-    }
+    for (int i = 0; i < n_refs; i++) if (refs[i].bpc != dst->bpc) { join_paired(); return -EINVAL; }
+    ref_planes(c, refs, n_refs, rp);
     int rc = mc_regroup(c, const_cast<Dav1dHipMcList *>(ml), rp, n_refs);
     if (rc) { join_paired(); return rc; }
     // DAV1D_HIP_RECON_LANES: side streams the residual launches are dealt over.  Measured (8K 10-bit): 1 lane 0.379 ms,
@@ -1776,7 +1822,7 @@ int dav1d_hip_recon_list_run_timed(Dav1dHipContext *c, const Dav1dHipReconList *
     if ((ml->n && ml->max_ref >= n_refs) || l->f_max_ref >= n_refs) return -EINVAL;
     const DevPlanes dp = dev_planes(dst);
     DevPlanes rp[8];
-    for (int i = 0; i < n_refs; i++) rp[i] = dev_planes(&refs[i]);
+    ref_planes(c, refs, n_refs, rp);
     int rc = mc_regroup(c, const_cast<Dav1dHipMcList *>(ml), rp, n_refs);
     if (rc) return rc;
     enum { N = 40 };

@@ -72,7 +72,7 @@ template <typename T> void sort_by_key(std::vector<T> &v, const std::vector<uint
     v.swap(t);
 }
 
-// inside consecutive windows of `win` elements: stable counting sort by a small key (< 64)
+// inside consecutive windows of `win` elements: stable counting sort by a one-byte key
 template <typename T> void group_in_windows(std::vector<T> &v, const std::vector<uint8_t> &key, size_t win) {
     const size_t n = v.size();
     if (n < 2 || !win) return;
@@ -80,11 +80,11 @@ template <typename T> void group_in_windows(std::vector<T> &v, const std::vector
     std::vector<uint8_t> kt(std::min(win, n));
     for (size_t lo = 0; lo < n; lo += win) {
         const size_t m = std::min(win, n - lo);
-        uint32_t cnt[65] = { 0 };
+        uint32_t cnt[257] = { 0 };
         bool same = true;
         for (size_t i = 0; i < m; i++) { cnt[key[lo + i] + 1]++; same &= key[lo + i] == key[lo]; }
         if (same) continue;
-        for (int k = 0; k < 64; k++) cnt[k + 1] += cnt[k];
+        for (int k = 0; k < 256; k++) cnt[k + 1] += cnt[k];
         for (size_t i = 0; i < m; i++) t[cnt[key[lo + i]]++] = v[lo + i];
         for (size_t i = 0; i < m; i++) v[lo + i] = t[i];
     }
@@ -323,7 +323,7 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
                     const int xx = r.src_x - 4, yy = r.src_y - 3;
                     edge |= xx < 0 || yy < 0 || xx + ext_x > rp[r.ref].w[t.plane] || yy + ext_y > rp[r.ref].h[t.plane];
                 }
-                return (edge ? 8 : 0) | t.kind;
+                return (edge ? 16 : 0) | t.kind << 1 | (t.r[0].src_x & 1);      // the column parity: the tiled form of the horizontal pass (mc_body.h)
             };
             std::vector<uint8_t> gk(v.size());
             for (size_t i = 0; i < v.size(); i++) gk[i] = (uint8_t) key(v[i]);
@@ -359,7 +359,8 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
             std::vector<uint8_t> gk(nblk);
             for (size_t i = 0; i < nblk; i++) {
                 const int kind = p_tiles[k][(size_t) ord[i] * tpb].kind;
-                gk[i] = (uint8_t) (itx_path_key(itx[p_itx[k][ord[i]]]) * 3 + (kind == MCT_AVG ? 1 : kind == MCT_WAVG ? 2 : 0));
+                gk[i] = (uint8_t) ((itx_path_key(itx[p_itx[k][ord[i]]]) * 3 + (kind == MCT_AVG ? 1 : kind == MCT_WAVG ? 2 : 0)) * 2 +
+                                   (p_tiles[k][(size_t) ord[i] * tpb].r[0].src_x & 1));
             }
             group_in_windows(ord, gk, (size_t) 128 * bpw);
         }

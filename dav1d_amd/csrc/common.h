@@ -11,7 +11,9 @@ struct DevPlanes {
     void *data[3];
     int stride[3];
     int w[3], h[3];
+    int tiled;          // data[] are the planes of the picture's tiled twin (8x8 tiles, mc_body.h); only ever set on references
 };
+static_assert(sizeof(DevPlanes) == 64, "kernel argument layout");
 
 #define WAVE 64
 
@@ -121,12 +123,12 @@ __device__ __forceinline__ int mad_i24(int a, int b, int c) {
     return r;
 #endif
 }
-// i / D for 0 <= i < 4096 and a compile-time D <= 64 without the 32-bit multiplier: M = floor(2^18 / D) + 1 overshoots
-// 2^18 / D by less than D / 2^18 per unit of i, i.e. by less than 1 / D in total, which cannot carry into the quotient
+// i / D for a compile-time D <= 128 and 0 <= i with i * D < 2^18 (D <= 64: i < 4096) without the 32-bit multiplier: with
+// M = floor(2^18 / D) + 1, i * M / 2^18 exceeds i / D by at most i / 2^18 < 1 / D, which cannot carry into the quotient
 template <int D> __device__ __forceinline__ int div_small(int i) {
-    static_assert(D >= 1 && D <= 64, "divisor");
+    static_assert(D >= 1 && D <= 128, "divisor");
 #ifdef DAV1D_HIP_EMU
-    if (i < 0 || i >= 4096) __builtin_trap();
+    if (i < 0 || i * D >= (1 << 18)) __builtin_trap();
     return i / D;
 #else
     if constexpr ((D & (D - 1)) == 0) return i >> (31 - __builtin_clz(D));

@@ -932,6 +932,8 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
             last = out;
         }
     }
+    // the picture later frames predict from gets its tiled twin (Dav1dHipPicture.twin: what their motion compensation reads)
+    if (!rc && c->ref_twin >= 2 && last->twin[0]) rc = dav1d_hip_picture_retile(c, const_cast<Dav1dHipPicture *>(last));
     if (!rc && filtered) *filtered = *last;
     if (!rc && f->have_grain && grain_out)
         rc = f->prepared ? dav1d_hip_fg_apply_prepared(c, grain_out, last, f->prepared, f->is_id)

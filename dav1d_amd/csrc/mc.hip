@@ -33,15 +33,16 @@
 namespace {
 
 // one tile shape per launch: workgroup b of the XCD-chunked order handles tiles [b * G, b * G + G)
-template <int TW, int TH, typename pixel>
+// TILED: the references are read through their tiled twins (refs.r[].data point there; mc_body.h)
+template <int TW, int TH, typename pixel, bool TILED>
 __global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSet refs, const McTile *__restrict__ tiles,
                                                 const int n, int16_t *__restrict__ prep, const int bitdepth_max)
 {
     constexpr int G = 64 / mc_cmin(64, TW * TH / 4);
-    __shared__ uint4 smem[(mc_lds_bytes<TW, TH>() + 15) / 16];
+    __shared__ uint4 smem[(mc_lds_bytes<TW, TH, TILED>() + 15) / 16];
     const int t0 = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x) * G;
     if (t0 >= n) return;
-    mc_body<TW, TH, pixel>(dst, refs, tiles, t0, dv::imin(G, n - t0), prep, bitdepth_max, smem);
+    mc_body<TW, TH, pixel, false, TILED>(dst, refs, tiles, t0, dv::imin(G, n - t0), prep, bitdepth_max, smem);
 }
 
 // every tile shape in one launch: the tiles are ordered by where they read (all shapes interleaved, see
@@ -83,14 +84,14 @@ __global__ __launch_bounds__(64) void mc_all_kernel(const DevPlanes dst, const R
 #undef CASE
 }
 
-template <typename pixel>
+template <typename pixel, bool TILED>
 hipError_t launch_cls(const int cls, const DevPlanes &dst, const RefSet &refs, const McTile *tiles, const int n,
                       int16_t *prep, const int bitdepth_max, hipStream_t stream)
 {
 #define CASE(C, TW, TH) case C: { \
         constexpr int lpt = mc_cmin(64, TW * TH / 4); \
         constexpr int g = 64 / lpt; \
-        hipLaunchKernelGGL((mc_kernel<TW, TH, pixel>), dim3((n + g - 1) / g), dim3(64), 0, stream, \
+        hipLaunchKernelGGL((mc_kernel<TW, TH, pixel, TILED>), dim3((n + g - 1) / g), dim3(64), 0, stream, \
                            dst, refs, tiles, n, prep, bitdepth_max); \
         break; }
     // class = 3 * wclass + hclass, widths 4 8 16 32 64, heights 4 8 16
@@ -115,9 +116,13 @@ extern "C" int dav1d_hip_launch_mc_bin(const DevPlanes *dst, const DevPlanes *re
     RefSet rs;
     for (int i = 0; i < 8; i++) rs.r[i] = refs[i < n_refs ? i : 0];
     const int bitdepth_max = (1 << bpc) - 1;
+    const int tiled = refs_tiled(refs, n_refs);
+    if (tiled < 0) return -EINVAL;
     hipError_t e;
-    if (bpc == 8) e = launch_cls<uint8_t>(cls, *dst, rs, tiles, n, prep, bitdepth_max, (hipStream_t) stream);
-    else          e = launch_cls<uint16_t>(cls, *dst, rs, tiles, n, prep, bitdepth_max, (hipStream_t) stream);
+    if (bpc == 8) e = tiled ? launch_cls<uint8_t, true>(cls, *dst, rs, tiles, n, prep, bitdepth_max, (hipStream_t) stream)
+                            : launch_cls<uint8_t, false>(cls, *dst, rs, tiles, n, prep, bitdepth_max, (hipStream_t) stream);
+    else          e = tiled ? launch_cls<uint16_t, true>(cls, *dst, rs, tiles, n, prep, bitdepth_max, (hipStream_t) stream)
+                            : launch_cls<uint16_t, false>(cls, *dst, rs, tiles, n, prep, bitdepth_max, (hipStream_t) stream);
     return hip_rc(e);
 }
 
@@ -126,6 +131,7 @@ extern "C" int dav1d_hip_launch_mc_all(const DevPlanes *dst, const DevPlanes *re
                                        const McGroup *groups, int n_groups, int with_small, int16_t *prep, void *stream)
 {
     if (n_groups <= 0) return 0;
+    if (refs_tiled(refs, n_refs) != 0) return -EINVAL;       // the all-shapes launch (an experiment, off by default) reads raster planes
     RefSet rs;
     for (int i = 0; i < 8; i++) rs.r[i] = refs[i < n_refs ? i : 0];
     const int bitdepth_max = (1 << bpc) - 1;

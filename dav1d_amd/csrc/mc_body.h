@@ -4,10 +4,17 @@
 #include "common.h"
 #include "capi.h"
 #include "av1_tables.h"
+#include <type_traits>
 
 namespace {
 
 struct RefSet { DevPlanes r[8]; };
+// 1 / 0: every reference of the call is handed over as its tiled twin / as raster planes; -1: a mix, which no kernel variant reads
+inline int refs_tiled(const DevPlanes *refs, const int n_refs) {
+    int t = 0;
+    for (int i = 0; i < n_refs; i++) t += refs[i].tiled != 0;
+    return t == 0 ? 0 : t == n_refs ? 1 : -1;
+}
 static_assert(sizeof(DevPlanes) == 64 && sizeof(RefSet) == 512, "the waves copy the table to LDS dword by dword");
 
 struct __attribute__((packed, aligned(2))) U64u { uint32_t a, b; };   // 2-byte aligned 8-byte global load
@@ -34,18 +41,30 @@ constexpr int mc_cmin(int a, int b) { return a < b ? a : b; }
 // the host builds the tiles by the same rule, capi.hip), whose taps 0, 1, 6 and 7 are zero: the 4 outputs of a row reach the 7
 // columns src_x - 1 .. src_x + 5, so the window starts at src_x - 2 and is one 16-byte piece per row
 constexpr int mc_win_stride(int tw) { return tw == 4 ? 8 : (tw + 8 + 7) & ~7; }
+// The same for a reference stored as 8x8 tiles (TILED, see "tiled twin" below): the window is made of whole tile rows — aligned
+// 8-pixel pieces — so it starts at the piece that holds the first column the taps reach (src_x - 3; 4-wide tiles src_x - 1) and
+// holds one piece more than the span needs: TW + 7 (7) columns at any of 8 offsets
+constexpr int mc_win_stride_tiled(int tw) { return tw == 4 ? 16 : tw + 16; }
 
 // LDS bytes one wave needs for tile shape (TW, TH): window + row-pair intermediate + the tile records
-template <int TW, int TH>
+template <int TW, int TH, bool TILED = false>
 constexpr int mc_lds_bytes() {
-    constexpr int LPT = mc_cmin(64, TW * TH / 4), G = 64 / LPT, WS = mc_win_stride(TW), WR = TH + 8, NPR = WR / 2;
+    constexpr int LPT = mc_cmin(64, TW * TH / 4), G = 64 / LPT, WS = TILED ? mc_win_stride_tiled(TW) : mc_win_stride(TW), WR = TH + 8, NPR = WR / 2;
     return G * WR * WS * 2 + G * NPR * TW * 4 + (G > 1 ? G * (int) sizeof(McTile) + (int) sizeof(RefSet) : 0);
 }
 
 // One wave's worth of tiles of shape (TW, TH): tiles[t0 .. t0 + nt), nt <= 64 / LPT.  `smem` = mc_lds_bytes<TW, TH>() of LDS.
 // TO_LDS (fused prediction + residual kernels): pixels of PUT / AVG / WAVG tiles go to pred_s instead of the picture — block
 // (tile index - pred_tile0) >> pred_tpb_log2 of the wave, pred_w x pred_h pixels each, row stride pred_w.
-template <int TW, int TH, typename pixel, bool TO_LDS = false>
+//
+// TILED (the "tiled twin" of a reference picture, written by dav1d_hip_picture_retile / the frame's last stage): refs.r[].data
+// point to planes of the same size and stride whose pixels are stored as 8x8 tiles, 64 consecutive pixels each (128 bytes at
+// 10 / 12 bits: one memory line), tile (tx, ty) at pixel offset ty * 8 * stride + tx * 64, row r of the tile at + 8 r.  A window
+// of (TW + 7) x (TH + 7) pixels at an arbitrary position then touches (1 + (TW + 6) / 8) x (1 + (TH + 6) / 8) lines instead of one
+// or two per ROW (a raster row of 48 bytes costs 1.4 lines: measured, profiles/r02_calib_fetch_size.txt) — for an 8x8 block 7.6
+// lines instead of 18.  The gather fetches whole tile rows (aligned 16-byte pieces; 8 consecutive lanes = the 8 rows of one tile =
+// one line), and the horizontal pass picks its taps by the parity of the window's offset inside the piece instead of shifting data.
+template <int TW, int TH, typename pixel, bool TO_LDS = false, bool TILED = false>
 __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs, const McTile *__restrict__ tiles, const int t0, const int nt,
                                         int16_t *__restrict__ prep, const int bitdepth_max, uint4 *smem,
                                         pixel *pred_s = nullptr, const int pred_tile0 = 0, const int pred_tpb_log2 = 0,
@@ -55,7 +74,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
     constexpr int LPT = mc_cmin(64, TW * TH / 4);       // lanes per tile
     constexpr int G = 64 / LPT;                         // tiles side by side in a wave
     constexpr int R = TW * TH / 4 / LPT;                // output strips per lane (1, 2 or 4)
-    constexpr int WS = mc_win_stride(TW);               // window row stride (int16)
+    constexpr int WS = TILED ? mc_win_stride_tiled(TW) : mc_win_stride(TW);    // window row stride (int16)
     constexpr int WR = TH + 8;                          // window rows held (TH+7 used, +1 so row pairs are complete)
     constexpr int NCH = (WS + 7) / 8;                   // 8-pixel (16-byte) chunks fetched per window row
     constexpr int NPR = WR / 2;                         // row pairs of the intermediate
@@ -120,6 +139,8 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
         // fetched nor filtered (6-tap regular, 4-tap smooth / small blocks, 2-tap bilinear, 1-tap full-pel)
         const int vspan = rf.vspan;
         const int row_lo = vspan & 15, row_hi = TH - 1 + (vspan >> 4);
+        // TILED: the window starts at the aligned piece that holds its first tap column; `toff` = that column's offset in the piece
+        const int tx0 = rf.src_x - (NARROW ? 1 : 3), xa = tx0 & ~7, toff = tx0 & 7;
 
         // ---- 1. gather the window
         if (act) {
@@ -136,6 +157,70 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
                 src = reinterpret_cast<const pixel *>((uint64_t) pd[0] | ((uint64_t) pd[1] << 32));
                 rs = (int) rt[6 + t.plane]; rw = (int) rt[9 + t.plane]; rh = (int) rt[12 + t.plane];
             }
+            if constexpr (TILED) {
+                // columns the horizontal taps reach (the span table again, origin src_x - 3) and rows the vertical ones do: the window
+                // is "inside" when those are — the rest of it is neither fetched nor met by a non-zero tap
+                const int c_first = rf.src_x - 3 + (rf.hspan & 15), c_last = rf.src_x - 3 + TW - 2 + (rf.hspan >> 4);
+                const int y0 = rf.src_y - 3;
+                const bool interior = c_first >= 0 && c_last < rw && y0 + row_lo >= 0 && y0 + row_hi <= rh;
+                if (interior) {
+                    // Lanes in a grid of rows x pieces, both powers of two (no division): lane -> (row lr of its row group, piece
+                    // column lp), the loops step over row groups and piece columns.  Consecutive lanes walk down the rows of one
+                    // tile column: 8 of them share a 128-byte line.  Tiles of 4 rows only ever meet the 4-tap / bilinear / unit
+                    // sets vertically (blocks of height <= 4, reference GET_V_FILTER): rows 2 .. TH + 4 of the window.
+                    constexpr int R0 = TH == 4 ? 2 : 0, NR = TH == 4 ? TH + 3 : WR - 1;
+                    constexpr int RG = NR <= 8 ? 8 : NR <= 16 ? 16 : 32;                 // lanes of a row group
+                    constexpr int RPAR = mc_cmin(LPT, RG), NRI = (NR + RPAR - 1) / RPAR;
+                    constexpr int PG = LPT >= RG ? LPT / RG : 1, NPI = (NCH + PG - 1) / PG;
+                    typedef typename std::conditional<HBD, uint4, uint2>::type piece_t;
+                    const int lr = l & (RPAR - 1), lp = PG > 1 ? l / RG : 0;
+                    piece_t ld[NRI][NPI];
+                    bool ok[NRI][NPI];
+#pragma unroll
+                    for (int ri = 0; ri < NRI; ri++) {
+                        const int wr = R0 + lr + ri * RPAR, y = y0 + wr;
+                        const bool row_ok = lr + ri * RPAR < NR && wr >= row_lo && wr < row_hi;
+                        const pixel *prow = src + (dv::mul_i24(y & ~7, rs) + ((y & 7) << 3));
+#pragma unroll
+                        for (int pi = 0; pi < NPI; pi++) {
+                            const int pc = lp + pi * PG, x = xa + 8 * pc;
+                            ok[ri][pi] = row_ok && pc < NCH && x + 7 >= c_first && x <= c_last;
+                            if (ok[ri][pi]) ld[ri][pi] = *reinterpret_cast<const piece_t *>(prow + (x << 3));
+                        }
+                    }
+                    // pieces that were not fetched are not stored either: what they would hold only ever meets zero taps
+#pragma unroll
+                    for (int ri = 0; ri < NRI; ri++)
+#pragma unroll
+                        for (int pi = 0; pi < NPI; pi++) {
+                            if (!ok[ri][pi]) continue;
+                            const int wr = R0 + lr + ri * RPAR, pc = lp + pi * PG;
+                            uint4 v;
+                            if constexpr (HBD) v = ld[ri][pi];
+                            else v = make_uint4(__builtin_amdgcn_perm(0u, ld[ri][pi].x, 0x0c010c00u), __builtin_amdgcn_perm(0u, ld[ri][pi].x, 0x0c030c02u),
+                                                __builtin_amdgcn_perm(0u, ld[ri][pi].y, 0x0c010c00u), __builtin_amdgcn_perm(0u, ld[ri][pi].y, 0x0c030c02u));
+                            *reinterpret_cast<uint4 *>(win + wr * WS + 8 * pc) = v;
+                        }
+                } else {
+                    // edge emulation through the tile addressing: per-pixel clamped fetch, 8 independent loads in flight per lane
+                    for (int i0 = l; i0 < (WR - 1) * WS; i0 += 8 * LPT) {
+                        pixel v[8];
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            const int i = dv::imin(i0 + e * LPT, (WR - 1) * WS - 1);
+                            const int wr = dv::div_small<WS>(i);
+                            const int sy = dv::iclip(y0 + wr, 0, rh - 1);
+                            const int sx = dv::iclip(xa + (i - wr * WS), 0, rw - 1);
+                            v[e] = src[dv::mul_i24(sy & ~7, rs) + ((sx >> 3) << 6) + ((sy & 7) << 3) + (sx & 7)];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            const int i = i0 + e * LPT;
+                            if (i < (WR - 1) * WS) win[i] = (int16_t) v[e];
+                        }
+                    }
+                }
+            } else {
             const int x0 = rf.src_x - (NARROW ? 2 : 4), y0 = rf.src_y - 3;
             const bool interior = x0 >= 0 && y0 >= 0 && x0 + NCH * 8 <= rw && y0 + WR - 1 <= rh;
             if (interior) {
@@ -191,6 +276,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
                     }
                 }
             }
+            }
         }
         dv::wave_sync();
 
@@ -209,7 +295,41 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
                 for (int e = 0; e < 2; e++) {
                     const uint2 *wp = reinterpret_cast<const uint2 *>(win + (2 * pr + e) * WS + 4 * s);
                     int s0 = rnd1, s1 = rnd1, s2 = rnd1, s3 = rnd1;
-                    if constexpr (NARROW) {
+                    if constexpr (TILED) {
+                        // Output x of this strip sums f[k] * p[c + k] from window column c = toff + 4 s + x on.  c even: the pixel
+                        // pairs of the row's dwords meet the tap pairs (f0, f1) (f2, f3) .. = ev[]; c odd: (0, f0) (f1, f2) .. = od[]
+                        // one dword earlier.  Whether the strip's first column is even is a property of the tile (lists group
+                        // tiles by it so that a wave rarely holds both kinds).
+                        const uint32_t *dw = reinterpret_cast<const uint32_t *>(win + (2 * pr + e) * WS) + ((toff >> 1) + 2 * s);
+                        if constexpr (NARROW) {
+                            // taps 2 .. 5 only: the sums start one tap pair (two columns) into the 8-tap layout
+                            const uint32_t d0 = dw[0], d1 = dw[1], d2 = dw[2], d3 = dw[3];
+                            if (!(toff & 1)) {
+                                s0 = dv::dot2(d0, fh.ev[1], dv::dot2(d1, fh.ev[2], s0));
+                                s1 = dv::dot2(d0, fh.od[1], dv::dot2(d1, fh.od[2], dv::dot2(d2, fh.od[3], s1)));
+                                s2 = dv::dot2(d1, fh.ev[1], dv::dot2(d2, fh.ev[2], s2));
+                                s3 = dv::dot2(d1, fh.od[1], dv::dot2(d2, fh.od[2], dv::dot2(d3, fh.od[3], s3)));
+                            } else {
+                                s0 = dv::dot2(d0, fh.od[1], dv::dot2(d1, fh.od[2], dv::dot2(d2, fh.od[3], s0)));
+                                s1 = dv::dot2(d1, fh.ev[1], dv::dot2(d2, fh.ev[2], s1));
+                                s2 = dv::dot2(d1, fh.od[1], dv::dot2(d2, fh.od[2], dv::dot2(d3, fh.od[3], s2)));
+                                s3 = dv::dot2(d2, fh.ev[1], dv::dot2(d3, fh.ev[2], s3));
+                            }
+                        } else {
+                            const uint32_t d[6] = { dw[0], dw[1], dw[2], dw[3], dw[4], dw[5] };
+                            if (!(toff & 1)) {
+#pragma unroll
+                                for (int k = 0; k < 4; k++) { s0 = dv::dot2(d[k], fh.ev[k], s0); s2 = dv::dot2(d[k + 1], fh.ev[k], s2); }
+#pragma unroll
+                                for (int k = 0; k < 5; k++) { s1 = dv::dot2(d[k], fh.od[k], s1); s3 = dv::dot2(d[k + 1], fh.od[k], s3); }
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 5; k++) { s0 = dv::dot2(d[k], fh.od[k], s0); s2 = dv::dot2(d[k + 1], fh.od[k], s2); }
+#pragma unroll
+                                for (int k = 0; k < 4; k++) { s1 = dv::dot2(d[k + 1], fh.ev[k], s1); s3 = dv::dot2(d[k + 2], fh.ev[k], s3); }
+                            }
+                        }
+                    } else if constexpr (NARROW) {
                         // out x sums f[k] * p[x - 1 + k] over k = 2 .. 5, p[] = the 8 pixels of the row: the tap pairs (f1, f2) (f3, f4)
                         // (f5, f6) and (f2, f3) (f4, f5) of the 8-tap layout meet pixel pairs two columns further left
                         const uint2 a = wp[0], b = wp[1];

@@ -10,6 +10,7 @@
 #include "common.h"
 #include "capi.h"
 #include "av1_tables.h"
+#include <type_traits>
 
 namespace {
 
@@ -211,5 +212,44 @@ extern "C" int dav1d_hip_launch_emu_edge(void *dst, ptrdiff_t dst_stride, const 
                                      (const uint8_t *) ref, (int) ref_stride, bw, bh, iw, ih, x, y);
     else hipLaunchKernelGGL((emu_edge_kernel<uint16_t>), dim3(blocks), dim3(256), 0, (hipStream_t) stream, (uint16_t *) dst, (int) (dst_stride / 2),
                             (const uint16_t *) ref, (int) (ref_stride / 2), bw, bh, iw, ih, x, y);
+    return hip_rc(hipGetLastError());
+}
+
+
+// ------------------------------------------------------------------------------------------ tiled twin
+// Raster plane -> 8x8 tiles of 64 consecutive pixels (Dav1dHipPicture.twin; what reads it: mc_body.h, TILED).  One wave moves 8
+// rows x 64 pixels: lane l reads the 8 pixels (r = l >> 3, c = l & 7) of its row segment — the 8 lanes of a row read 128 (64)
+// contiguous bytes — and writes row r of tile c: the wave's stores cover 8 whole tiles, 1 KB (512 bytes) of contiguous memory.
+namespace {
+template <typename pixel>
+__global__ __launch_bounds__(64) void retile_kernel(const pixel *__restrict__ src, pixel *__restrict__ twin, const int stride, const int h,
+                                                    const int n_xg)
+{
+    typedef typename std::conditional<sizeof(pixel) == 2, uint4, uint2>::type piece_t;
+    const int g = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x);
+    const int ty = g / n_xg, xg = g - ty * n_xg;
+    const int lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
+    const int x = xg * 64 + c * 8;
+    if (x >= stride) return;
+    // rows below the plane (a caller-wrapped picture need not have them): the last row again
+    const int y = dv::imin(ty * 8 + r, h - 1);
+    const piece_t v = *reinterpret_cast<const piece_t *>(src + (size_t) y * stride + x);
+    *reinterpret_cast<piece_t *>(twin + (size_t) ty * 8 * stride + (size_t) (x >> 3) * 64 + r * 8) = v;
+}
+} // namespace
+
+extern "C" int dav1d_hip_launch_retile(const DevPlanes *src, void *const twin[3], int bpc, void *stream) {
+    for (int pl = 0; pl < 3; pl++) {
+        if (!src->data[pl]) continue;
+        if (!twin[pl] || src->stride[pl] % 8 || src->h[pl] <= 0) return -EINVAL;
+        const int n_xg = (src->stride[pl] + 63) / 64, n_ty = (src->h[pl] + 7) / 8;
+        const dim3 grid((unsigned) n_xg * (unsigned) n_ty), wave(64);
+        if (bpc == 8)
+            hipLaunchKernelGGL((retile_kernel<uint8_t>), grid, wave, 0, (hipStream_t) stream, (const uint8_t *) src->data[pl], (uint8_t *) twin[pl],
+                               src->stride[pl], src->h[pl], n_xg);
+        else
+            hipLaunchKernelGGL((retile_kernel<uint16_t>), grid, wave, 0, (hipStream_t) stream, (const uint16_t *) src->data[pl], (uint16_t *) twin[pl],
+                               src->stride[pl], src->h[pl], n_xg);
+    }
     return hip_rc(hipGetLastError());
 }

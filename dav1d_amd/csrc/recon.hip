@@ -35,7 +35,7 @@ template <int CLS> constexpr int recon_waves() {
     return (BPW * TPB + G - 1) / G;
 }
 
-template <int CLS, typename pixel, typename coef, bool COOP>
+template <int CLS, typename pixel, typename coef, bool COOP, bool TILED>
 __global__ __launch_bounds__(COOP ? 64 * recon_waves<CLS>() : 64, COOP ? 1 : CLS == 1 ? 6 : RECON_WAVES)
 void recon_fused_kernel(const DevPlanes dst, const RefSet refs, const McTile *__restrict__ tiles,
                         const Dav1dHipItxTask *__restrict__ tasks, const int n_blocks,
@@ -52,7 +52,7 @@ void recon_fused_kernel(const DevPlanes dst, const RefSet refs, const McTile *__
     // are predicted, then [slabs / transpose buffer of the transform] — the transform body has the predicted pixels in registers
     // before it stores its first slab chunk, so the regions may overlap.  Fewer LDS bytes per wave = more resident waves per CU,
     // which is what these kernels are short of (16x16: 8320 -> 4352 bytes, 5 -> 6 waves per SIMD, 89 -> 76 us per 8K frame).
-    constexpr int MC_B = (mc_lds_bytes<TW, TH>() + 15) / 16 * 16, PRED_B = BPW * W * W * (int) sizeof(pixel);
+    constexpr int MC_B = (mc_lds_bytes<TW, TH, TILED>() + 15) / 16 * 16, PRED_B = BPW * W * W * (int) sizeof(pixel);
     constexpr int ITX_B = itx_lds_ints<TX>() * 4;
     constexpr int LDS_B = cmax(NW * MC_B + PRED_B, ITX_B);
     __shared__ uint4 smem[(LDS_B + 15) / 16];
@@ -68,14 +68,14 @@ void recon_fused_kernel(const DevPlanes dst, const RefSet refs, const McTile *__
     const int tile0 = block0 * TPB, ntile = nb * TPB;
     if constexpr (NW == 1) {
         for (int c = 0; c < ntile; c += G) {
-            mc_body<TW, TH, pixel, true>(dst, refs, tiles, tile0 + c, dv::imin(G, ntile - c), prep, bitdepth_max, smem_mc,
+            mc_body<TW, TH, pixel, true, TILED>(dst, refs, tiles, tile0 + c, dv::imin(G, ntile - c), prep, bitdepth_max, smem_mc,
                                          pred, tile0, rc_log2(TPB), W, W);
             dv::wave_sync();
         }
     } else {
         const int c = wave * G;
         if (c < ntile)
-            mc_body<TW, TH, pixel, true>(dst, refs, tiles, tile0 + c, dv::imin(G, ntile - c), prep, bitdepth_max, smem_mc,
+            mc_body<TW, TH, pixel, true, TILED>(dst, refs, tiles, tile0 + c, dv::imin(G, ntile - c), prep, bitdepth_max, smem_mc,
                                          pred, tile0, rc_log2(TPB), W, W);
         __syncthreads();
         if (wave) return;
@@ -83,30 +83,30 @@ void recon_fused_kernel(const DevPlanes dst, const RefSet refs, const McTile *__
     itx_body<TX, pixel, coef, true>(dst, tasks, n_blocks, cf, bitdepth_max, group, smem_itx, pred);
 }
 
-template <int CLS, typename pixel, typename coef>
+template <int CLS, typename pixel, typename coef, bool TILED>
 void launch_cls(const DevPlanes &dst, const RefSet &refs, const McTile *tiles, const Dav1dHipItxTask *tasks, const int n,
                 int16_t *prep, coef *cf, const int bitdepth_max, const int coop_below, hipStream_t stream)
 {
     constexpr int W = 4 << CLS, LPB = cmax(cmin(W, 32), W), BPW = 64 / LPB;
     const int groups = (n + BPW - 1) / BPW;
     if (recon_waves<CLS>() > 1 && groups < coop_below)
-        hipLaunchKernelGGL((recon_fused_kernel<CLS, pixel, coef, true>), dim3(groups), dim3(64 * recon_waves<CLS>()), 0, stream,
+        hipLaunchKernelGGL((recon_fused_kernel<CLS, pixel, coef, true, TILED>), dim3(groups), dim3(64 * recon_waves<CLS>()), 0, stream,
                            dst, refs, tiles, tasks, n, prep, cf, bitdepth_max);
     else
-        hipLaunchKernelGGL((recon_fused_kernel<CLS, pixel, coef, false>), dim3(groups), dim3(64), 0, stream,
+        hipLaunchKernelGGL((recon_fused_kernel<CLS, pixel, coef, false, TILED>), dim3(groups), dim3(64), 0, stream,
                            dst, refs, tiles, tasks, n, prep, cf, bitdepth_max);
 }
 
-template <typename pixel, typename coef>
+template <typename pixel, typename coef, bool TILED>
 hipError_t launch_any(const int cls, const DevPlanes &dst, const RefSet &refs, const McTile *tiles, const Dav1dHipItxTask *tasks,
                       const int n, int16_t *prep, coef *cf, const int bitdepth_max, const int coop_below, hipStream_t stream)
 {
     switch (cls) {
-    case 0: launch_cls<0, pixel, coef>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, stream); break;
-    case 1: launch_cls<1, pixel, coef>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, stream); break;
-    case 2: launch_cls<2, pixel, coef>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, stream); break;
-    case 3: launch_cls<3, pixel, coef>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, stream); break;
-    case 4: launch_cls<4, pixel, coef>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, stream); break;
+    case 0: launch_cls<0, pixel, coef, TILED>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, stream); break;
+    case 1: launch_cls<1, pixel, coef, TILED>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, stream); break;
+    case 2: launch_cls<2, pixel, coef, TILED>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, stream); break;
+    case 3: launch_cls<3, pixel, coef, TILED>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, stream); break;
+    case 4: launch_cls<4, pixel, coef, TILED>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, stream); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -123,8 +123,13 @@ extern "C" int dav1d_hip_launch_recon_fused(const DevPlanes *dst, const DevPlane
     RefSet rs;
     for (int i = 0; i < 8; i++) rs.r[i] = refs[i < n_refs ? i : 0];
     const int bitdepth_max = (1 << bpc) - 1;
+    const int tiled = refs_tiled(refs, n_refs);
+    if (tiled < 0) return -EINVAL;
+    hipStream_t st = (hipStream_t) stream;
     hipError_t e;
-    if (bpc == 8) e = launch_any<uint8_t, int16_t>(cls, *dst, rs, tiles, tasks, n, prep, (int16_t *) coef, bitdepth_max, coop_below, (hipStream_t) stream);
-    else          e = launch_any<uint16_t, int32_t>(cls, *dst, rs, tiles, tasks, n, prep, (int32_t *) coef, bitdepth_max, coop_below, (hipStream_t) stream);
+    if (bpc == 8) e = tiled ? launch_any<uint8_t, int16_t, true>(cls, *dst, rs, tiles, tasks, n, prep, (int16_t *) coef, bitdepth_max, coop_below, st)
+                            : launch_any<uint8_t, int16_t, false>(cls, *dst, rs, tiles, tasks, n, prep, (int16_t *) coef, bitdepth_max, coop_below, st);
+    else          e = tiled ? launch_any<uint16_t, int32_t, true>(cls, *dst, rs, tiles, tasks, n, prep, (int32_t *) coef, bitdepth_max, coop_below, st)
+                            : launch_any<uint16_t, int32_t, false>(cls, *dst, rs, tiles, tasks, n, prep, (int32_t *) coef, bitdepth_max, coop_below, st);
     return hip_rc(e);
 }

@@ -105,6 +105,16 @@ typedef struct Dav1dHipPicture {
     int layout;        /* enum Dav1dHipPixelLayout */
     void *alloc;       /* base of the allocation (owned when made by picture_alloc) */
     size_t alloc_size;
+    /* Optional "tiled twin": the same pixels once more, stored as 8x8 tiles (64 consecutive pixels per tile: one 128-byte memory
+     * line at 10 / 12 bits; tile (tx, ty) of a plane at pixel offset ty * 8 * stride_in_pixels + tx * 64, row r of it 8 r further),
+     * each plane with the size and stride of its raster plane.  Motion compensation reads a reference through its twin when
+     * EVERY reference of the call has one that is valid (twin_ok): a prediction window then touches a third to a half of the
+     * memory lines it touches in raster order.  dav1d_hip_picture_retile fills it; dav1d_hip_frame_end /
+     * dav1d_hip_recon_list_run do so for the picture they produce when it has the storage.  Whoever changes the raster planes by
+     * other means clears twin_ok (or retiles).  twin_alloc: the storage (owned when made by the library). */
+    void *twin[3];
+    void *twin_alloc;
+    int twin_ok;
 } Dav1dHipPicture;
 
 /* Allocation with the reference's geometry (src/picture.c:46-78): dimensions padded
@@ -112,6 +122,14 @@ typedef struct Dav1dHipPicture {
 DAV1D_HIP_API int dav1d_hip_picture_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic,
                                           int w, int h, int layout, int bpc);
 DAV1D_HIP_API int dav1d_hip_picture_free(Dav1dHipContext *c, Dav1dHipPicture *pic);
+/* The tiled twin of a picture (see Dav1dHipPicture.twin).  Context option "ref_twin" ($DAV1D_HIP_REF_TWIN): 0 = twins are never
+ * read; 1 (default) = motion compensation reads references through valid twins, which the caller makes (dav1d_hip_picture_retile
+ * once a picture is final); 2 = dav1d_hip_picture_alloc also makes the storage along with the planes and dav1d_hip_frame_end
+ * retiles the picture it produces.  _twin_alloc adds the storage to a picture that has none (also to a caller-wrapped one: strides
+ * must be multiples of 8 pixels, plane heights are rounded up to 8 rows).  _retile copies the raster planes into the twin on the
+ * context's stream (asynchronous, like every launch) and sets twin_ok. */
+DAV1D_HIP_API int dav1d_hip_picture_twin_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic);
+DAV1D_HIP_API int dav1d_hip_picture_retile(Dav1dHipContext *c, Dav1dHipPicture *pic);
 /* The buffers behind a Dav1dPicAllocator (reference include/dav1d/picture.h:89-133, default implementation
  * src/picture.c:46-82): a decoded picture the application reads on the host — pinned memory, planes and strides laid out by the
  * rules of dav1d_default_picture_alloc (dimensions rounded up to 128, 64 more bytes of stride where it would be a multiple of

@@ -34,3 +34,13 @@ def _default_options(request):
         c = request.getfixturevalue("ctx")
         for name, value in (("recon_fuse", 14), ("recon_pipeline", 16384), ("recon_lanes", 1), ("recon_coop_below", 4096), ("chunk_upload", 0), ("post_bands", 0)):
             c.set_option(name, value)
+
+
+@pytest.fixture(params=[False, True], ids=["raster-refs", "tiled-refs"])
+def twin_refs(request, ctx):
+    """Tests that name this fixture run twice: with reference pictures read in raster order, and with every uploaded picture
+    retiled (api.DevicePicture.upload -> dav1d_hip_picture_retile) so that motion compensation reads references through their tiled
+    twins (Dav1dHipPicture.twin, the TILED kernel variants of mc.hip / recon.hip).  Both must give the oracle's pixels."""
+    ctx.auto_retile = request.param
+    yield request.param
+    ctx.auto_retile = False

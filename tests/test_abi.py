@@ -29,7 +29,7 @@ def test_struct_mirrors_match_header_sizes():
     assert _lib.ITX_TASK.itemsize == 16
     assert _lib.MC_TASK.itemsize == 24
     assert _lib.COMP_TASK.itemsize == 24
-    assert C.sizeof(_lib.Plane) == 24 and C.sizeof(_lib.Picture) == 24 * 3 + 8 + 16
+    assert C.sizeof(_lib.Plane) == 24 and C.sizeof(_lib.Picture) == 24 * 3 + 8 + 16 + 3 * 8 + 8 + 8      # planes, bpc + layout, alloc, twin[3], twin_alloc, twin_ok (+ padding)
 
 
 def test_open_fails_loudly_without_device(so):

@@ -8,7 +8,7 @@ from dav1d_amd import e2e
 
 
 @pytest.mark.parametrize("key_frame", [False, True], ids=["inter", "key"])
-def test_end_to_end_route_matches_reference_pass2(ctx, key_frame):
+def test_end_to_end_route_matches_reference_pass2(ctx, key_frame, twin_refs):
     if lu.ref_lib() is None:
         pytest.skip("no reference build (oracle/_ref)")
     w, h = (384, 256) if ctx.backend == "emu" else (1920, 1080)

@@ -102,7 +102,7 @@ def hip_frame(ctx, frame, dst_planes, ref_planes_list, fused=False, packed=False
 
 @pytest.mark.parametrize("fused", [False, True], ids=["twostep", "fused"])
 @pytest.mark.parametrize("bpc", [8, 10, 12])
-def test_frame_itx_mc_matches_oracle(ctx, bpc, fused):
+def test_frame_itx_mc_matches_oracle(ctx, bpc, fused, twin_refs):
     w, h = (1024, 64) if ctx.backend == "emu" else (1024, 576)   # 1024: exercises the +64 B stride rule
     frame = synth.make_frame(w, h, bpc, seed=31 + bpc, edge_frac=0.15)
     rng = np.random.default_rng(3 + bpc)
@@ -151,7 +151,7 @@ def test_frame_from_packed_coefficients(ctx, bpc):
 @pytest.mark.parametrize("fuse", ["0", "31", "6", "31-one-wave"], ids=["two-kernels", "all-paired", "default-paired", "all-paired-one-wave"])
 @pytest.mark.parametrize("pipeline", ["0", "-1"], ids=["pipelined", "sequential"])
 @pytest.mark.parametrize("bpc", [8, 10, 12])
-def test_recon_list_matches_oracle(ctx, bpc, pipeline, fuse, monkeypatch):
+def test_recon_list_matches_oracle(ctx, bpc, pipeline, fuse, monkeypatch, twin_refs):
     """dav1d_hip_recon_list_*: predictions and residuals as one list, the residual launch of a transform size waiting only
     for the prediction launches under its blocks (two streams) — and the same list run strictly one phase after the other."""
     ctx.set_option("recon_pipeline", pipeline)
@@ -213,7 +213,7 @@ def test_recon_list_with_transforms_smaller_than_their_prediction(ctx, pipeline,
 
 
 @pytest.mark.parametrize("size", [(200, 136), (72, 40), (1000, 72)], ids=["200x136", "72x40", "1000x72"])
-def test_recon_list_on_pictures_that_are_not_multiples_of_the_block_sizes(ctx, size):
+def test_recon_list_on_pictures_that_are_not_multiples_of_the_block_sizes(ctx, size, twin_refs):
     """Visible sizes that cut blocks (they still lie inside the padded planes, as in the reference's allocation)."""
     w, h = size
     bpc = 10

@@ -135,7 +135,7 @@ TOOLS = [
 
 
 @pytest.mark.parametrize("name,w,h,layout,bpc,kw", TOOLS, ids=[t[0] for t in TOOLS])
-def test_tools_one_by_one(ctx, name, w, h, layout, bpc, kw):
+def test_tools_one_by_one(ctx, name, w, h, layout, bpc, kw, twin_refs):
     run_case(ctx, w, h, layout, bpc, 3 + len(name), **kw)
 
 

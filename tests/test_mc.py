@@ -74,9 +74,12 @@ def _gen_tasks(rng, n, vis_w, vis_h, DW, DH, kind, sizes):
     return t[:k], pos, prep_off
 
 
+@pytest.mark.parametrize("twin", [False, True], ids=["raster", "tiled"])
 @pytest.mark.parametrize("bpc", [8, 10, 12])
 @pytest.mark.parametrize("kind", [0, 1], ids=["put", "prep"])
-def test_mc_matches_reference(ctx, bpc, kind):
+def test_mc_matches_reference(ctx, bpc, kind, twin):
+    """twin: the reference picture is read through its tiled twin (8x8 tiles, dav1d_hip_picture_retile) — the same pixels must
+    come out, windows that leave the picture on any side included."""
     oracle = util.default_oracle()
     rng = np.random.default_rng(77 + bpc * 2 + kind)
     vis_w, vis_h = 200, 150                      # visible size; allocation is padded to 256 x 256
@@ -85,6 +88,9 @@ def test_mc_matches_reference(ctx, bpc, kind):
     ref = ctx.picture(vis_w, vis_h, api.LAYOUT_I400, bpc)
     refplane = rng.integers(0, 1 << bpc, size=ref.padded_shape(0)).astype(pd)   # padding is NOT edge-replicated
     ref.upload(0, refplane)
+    if twin:
+        ref.retile()
+        assert ref.pic.twin_ok and ref.pic.twin[0]
     dst = ctx.picture(DW, DH, api.LAYOUT_I400, bpc)
     dplane = rng.integers(0, 1 << bpc, size=dst.padded_shape(0)).astype(pd)
     dst.upload(0, dplane)
