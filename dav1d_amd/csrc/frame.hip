@@ -354,6 +354,24 @@ int dav1d_hip_frame_begin(Dav1dHipContext *c, Dav1dHipFrame **out, const Dav1dHi
     return 0;
 }
 
+// The references again, before the frame is ended: dav1d's frame threading lists frame n + 1 while frame n is still being filtered
+// (src/thread_task.c:393-439 lets a tile task start once the rows it reads are final), and which picture holds frame n's final
+// pixels — `cur` itself or a picture the frame owns (*filtered of dav1d_hip_frame_end) — is only known when frame n ends.
+// Geometry, bit depth and layout must be those given to dav1d_hip_frame_begin: the lists were prepared for them.
+int dav1d_hip_frame_set_refs(Dav1dHipFrame *f, const Dav1dHipPicture *refs, int n_refs) {
+    if (!f || !refs || n_refs != f->n_refs) return -EINVAL;
+    if (f->worker.joinable()) return -EBUSY;
+    std::lock_guard<std::mutex> lk(f->mtx);
+    for (int i = 0; i < n_refs; i++) {
+        if (refs[i].bpc != f->refs[i].bpc || refs[i].layout != f->refs[i].layout) return -EINVAL;
+        for (int p = 0; p < 3; p++)
+            if (refs[i].p[p].w != f->refs[i].p[p].w || refs[i].p[p].h != f->refs[i].p[p].h || refs[i].p[p].stride != f->refs[i].p[p].stride ||
+                !refs[i].p[p].data != !f->refs[i].p[p].data) return -EINVAL;
+    }
+    for (int i = 0; i < n_refs; i++) f->refs[i] = refs[i];
+    return 0;
+}
+
 // Reconstruction tasks of one tile-sbrow (what decode_b()'s pass-2 branch would have executed, src/decode.c:706-806).
 // Thread-safe; the order between tile-sbrows is free: inter tasks of a frame write disjoint pixels, and every residual
 // is added after every prediction.

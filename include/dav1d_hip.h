@@ -601,6 +601,10 @@ DAV1D_HIP_API int dav1d_hip_fg_generate_grain(Dav1dHipContext *c, const Dav1dHip
 typedef struct Dav1dHipFrame Dav1dHipFrame;
 DAV1D_HIP_API int dav1d_hip_frame_begin(Dav1dHipContext *c, Dav1dHipFrame **out, const Dav1dHipPicture *cur,
                                         const Dav1dHipPicture *refs, int n_refs);
+/* The references once more, any time before dav1d_hip_frame_end: same geometry as at dav1d_hip_frame_begin, other memory.  For
+ * frame threading: frame n + 1 is listed while frame n is still in flight, and the picture that holds frame n's final pixels
+ * (*filtered of its dav1d_hip_frame_end: `cur` or a picture that frame owns) is known only when frame n ends. */
+DAV1D_HIP_API int dav1d_hip_frame_set_refs(Dav1dHipFrame *f, const Dav1dHipPicture *refs, int n_refs);
 DAV1D_HIP_API int dav1d_hip_frame_submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc,
                                                     const Dav1dHipCompTask *comp, size_t n_comp,
                                                     const Dav1dHipItxTask *itx, size_t n_itx);

@@ -1,0 +1,741 @@
+/* The backend inside dav1d's own task loop.  TEST INFRASTRUCTURE ONLY: linked into oracle/_ref_hooked/libdav1d_hooked.so, the
+ * reference build with src/thread_task.c patched at the hook points of INTEGRATION.md 2 (oracle/hooked/thread_task.patch).
+ *
+ * What runs here is dav1d: dav1d_open() creates the context, its frame contexts (n_fc >= 3) and its worker threads
+ * (dav1d_worker_task); every frame goes through the reference's dav1d_submit_frame(), dav1d_decode_frame_init(), the task
+ * queues of src/thread_task.c with their inter-frame dependencies (check_tile), dav1d_decode_frame_exit() and the output queue
+ * drained by dav1d_get_picture().  There are no AV1 streams in either box, so the ONE thing that is replaced in both modes is the
+ * entropy decoder: the frame headers are built here instead of parsed, and pass 1's output (Av1Block / cbi / cf, the deblocking
+ * masks built by the reference's own dav1d_create_lf_mask_*, cdef indices, restoration units) is injected when a frame's
+ * arrays exist (Dav1dHooks.after_init), the pass-1 tile tasks return at once.
+ *   mode 0: pass 2 and the in-loop filters are the reference's own code on its worker threads — the peer.
+ *   mode 1: the glue of INTEGRATION.md: Dav1dPicAllocator on dav1d_hip_host_picture_*, hip_frame_desc(), the pass-2 tile task
+ *           calls dav1d_hip_lister_tile_sbrow, the filter tasks dav1d_hip_lister_filter_sbrow, the end of the frame
+ *           dav1d_hip_frame_end on a thread of the harness, which then publishes the frame's rows (dav1d_hooked_frame_done).
+ * Frames form a chain: a key frame, then inter frames that each predict from the three frames before them. */
+#include "config.h"
+#include <dlfcn.h>
+#include <errno.h>
+#include <limits.h>
+#include <pthread.h>
+#include <stdatomic.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "dav1d/dav1d.h"
+#include "common/frame.h"
+#include "src/internal.h"
+#include "src/tables.h"
+#include "src/decode.h"
+#include "src/lf_mask.h"
+#include "src/ref.h"
+#include "src/picture.h"
+#include "src/warpmv.h"
+#include "hooked/hooks.h"
+#include "dav1d_hip.h"
+
+typedef struct HookedParams {
+    int w, h, layout, bpc, sb128;
+    int n_tile_cols, n_tile_rows;
+    uint16_t col_start_sb[65], row_start_sb[65];
+    int n_threads, frame_delay, n_frames;
+    int lf_level_y[2], lf_level_u, lf_level_v, lf_sharpness;
+    int cdef_enabled, cdef_damping, cdef_n_bits;
+    int cdef_y_strength[8], cdef_uv_strength[8];
+    int lr_type[3], lr_unit_size[2];
+    int mode;                  /* 0 the reference's pass 2 + filters, 1 the HIP backend */
+    int free_listing;          /* mode 1: 1 = a frame is listed without waiting for its references (their pixels are only needed when
+                                  the frame ends, and the frames end in order); 0 = dav1d's own rule with every reference fully needed */
+    int device;
+    int keep_output;           /* copy every output picture (for comparisons) */
+    Dav1dHipSynthParams synth; /* block decisions of the generated frames; seed + frame number per frame */
+} HookedParams;
+
+/* the entry points of include/dav1d_hip.h, resolved from the library the caller names (libdav1d_hip.so, or the SIMT-emulated
+ * build of the same sources on a machine without a GPU) */
+typedef struct Hip {
+    void *dl;
+    int (*open)(Dav1dHipContext **, int, void *);
+    void (*close)(Dav1dHipContext *);
+    int (*sync)(Dav1dHipContext *);
+    int (*malloc_)(Dav1dHipContext *, void **, size_t);
+    int (*free_)(Dav1dHipContext *, void *);
+    int (*upload)(Dav1dHipContext *, void *, const void *, size_t);
+    int (*host_picture_alloc)(Dav1dHipContext *, Dav1dHipHostPicture *, int, int, int, int);
+    int (*host_picture_release)(Dav1dHipContext *, Dav1dHipHostPicture *);
+    int (*host_picture_fetch)(Dav1dHipContext *, const Dav1dHipHostPicture *, const Dav1dHipPicture *, int, int);
+    int (*host_picture_wait)(Dav1dHipContext *);
+    int (*frame_begin)(Dav1dHipContext *, Dav1dHipFrame **, const Dav1dHipPicture *, const Dav1dHipPicture *, int);
+    int (*frame_set_refs)(Dav1dHipFrame *, const Dav1dHipPicture *, int);
+    int (*frame_set_filters)(Dav1dHipFrame *, const uint8_t *, ptrdiff_t, const uint8_t *, const uint8_t *, int, const Dav1dHipFilmGrainData *, int);
+    int (*frame_end)(Dav1dHipFrame *, void *, int16_t *, uint8_t *, Dav1dHipPicture *, const Dav1dHipPicture *);
+    void (*frame_destroy)(Dav1dHipFrame *);
+    int (*lister_create)(Dav1dHipLister **, const Dav1dHipFrameDesc *, Dav1dHipFrame *);
+    int (*lister_tile_sbrow)(Dav1dHipLister *, int, int, int);
+    int (*lister_filter_sbrow)(Dav1dHipLister *, const Dav1dHipFilterDesc *, int);
+    size_t (*lister_prep_elems)(const Dav1dHipLister *);
+    size_t (*lister_mask_bytes)(const Dav1dHipLister *);
+    const uint8_t *(*lister_const_masks)(size_t *);
+    void (*lister_destroy)(Dav1dHipLister *);
+    int (*synth_frame)(const Dav1dHipFrameDesc *, const Dav1dHipSynthParams *, void *, size_t, size_t, uint8_t *, size_t);
+} Hip;
+
+/* what the allocator hangs on a Dav1dPicture in mode 1 */
+typedef struct HookedPic {
+    Dav1dHipHostPicture hp;
+    Dav1dHipFrame *frame;        /* the frame that produced the picture: owns `ref` when that is not hp.dev */
+    Dav1dHipPicture ref;         /* where the final pixels are: what later frames predict from */
+} HookedPic;
+
+/* per frame context */
+typedef struct FcState {
+    Dav1dHipFrameDesc desc;
+    Dav1dHipFilterDesc fd;
+    Dav1dHipFrame *frame;
+    Dav1dHipLister *lister;
+    atomic_int *filter_listed;   /* [sby]: the filter tasks of the row are listed */
+    int sbh_cap;
+    void *coef, *lvl, *prep, *mask;
+    size_t coef_cap, lvl_cap, prep_cap, mask_cap;
+    int err;
+} FcState;
+
+typedef struct Hooked {
+    HookedParams p;
+    Hip hip;
+    Dav1dHipContext *ctx;
+    Dav1dContext *c;
+    unsigned n_fc;
+    Dav1dRef *seq_ref;
+    FcState *fcs;
+    /* frames whose last task is through, waiting for their turn on the GPU thread (frames end in submission order) */
+    pthread_t gpu_thread;
+    pthread_mutex_t q_mtx;
+    pthread_cond_t q_cond;
+    Dav1dFrameContext **q_frame;          /* [frame number] */
+    int q_next, q_stop;
+    /* outputs */
+    uint8_t **out_plane;                  /* [frame * 3 + plane]: tight rows */
+    int n_out;
+    double seconds;
+    int failed;
+} Hooked;
+
+static Hooked *g_h;                       /* one harness at a time: the hooks carry no user pointer */
+
+/* ------------------------------------------------------------------------------------------------ INTEGRATION.md 2, verbatim */
+static void hip_frame_desc(Dav1dHipFrameDesc *d, const Dav1dFrameContext *f) {
+    memset(d, 0, sizeof(*d));
+    d->w = f->cur.p.w; d->h = f->cur.p.h; d->layout = f->cur.p.layout; d->bpc = f->cur.p.bpc;
+    d->sb128 = f->seq_hdr->sb128; d->intra_edge_filter = f->seq_hdr->intra_edge_filter;
+    d->is_inter = IS_INTER_OR_SWITCH(f->frame_hdr);
+    d->n_tile_cols = f->frame_hdr->tiling.cols; d->n_tile_rows = f->frame_hdr->tiling.rows;
+    memcpy(d->col_start_sb, f->frame_hdr->tiling.col_start_sb, sizeof(d->col_start_sb));
+    memcpy(d->row_start_sb, f->frame_hdr->tiling.row_start_sb, sizeof(d->row_start_sb));
+    d->b4_stride = f->b4_stride;
+    d->b = (const Dav1dHipAv1Block *) f->frame_thread.b;           /* same 32-byte layout, pinned by tests/test_lister.py */
+    d->cbi = (const int16_t *) f->frame_thread.cbi;
+    d->tile_start_off = f->frame_thread.tile_start_off;
+    d->pal = f->frame_thread.pal;
+    memcpy(d->svc, f->svc, sizeof(d->svc));
+    for (int i = 0; i < 7; i++) { d->ref_w[i] = f->refp[i].p.p.w; d->ref_h[i] = f->refp[i].p.p.h; }
+    memcpy(d->gmv, f->frame_hdr->gmv, sizeof(d->gmv));             /* Dav1dHipWarpParams == Dav1dWarpedMotionParams */
+    memcpy(d->gmv_warp_allowed, f->gmv_warp_allowed, sizeof(d->gmv_warp_allowed));
+    memcpy(d->jnt_weights, f->jnt_weights, sizeof(d->jnt_weights));
+    d->cf_align64 = ARCH_X86_64;                                   /* the cf cursor realignment of src/decode.c:2209-2218 */
+    memcpy(d->lossless, f->frame_hdr->segmentation.lossless, sizeof(d->lossless));   /* mask builder: src/decode.c:1889-1893 */
+}
+
+static void hip_filter_desc(Dav1dHipFilterDesc *fd, const Dav1dFrameContext *f) {
+    memset(fd, 0, sizeof(*fd));
+    fd->lf_level_y[0] = f->frame_hdr->loopfilter.level_y[0]; fd->lf_level_y[1] = f->frame_hdr->loopfilter.level_y[1];
+    fd->lf_level_u = f->frame_hdr->loopfilter.level_u; fd->lf_level_v = f->frame_hdr->loopfilter.level_v;
+    fd->lf_mask = (const Dav1dHipAv1Filter *) f->lf.mask;
+    fd->tx_lpf_right_edge[0] = f->lf.tx_lpf_right_edge[0]; fd->tx_lpf_right_edge[1] = f->lf.tx_lpf_right_edge[1];
+    fd->a_tx_lpf_y = f->a[0].tx_lpf_y; fd->a_tx_lpf_uv = f->a[0].tx_lpf_uv; fd->a_stride = sizeof(BlockContext);
+    fd->cdef_enabled = f->seq_hdr->cdef; fd->cdef_damping = f->frame_hdr->cdef.damping;
+    for (int i = 0; i < 8; i++) { fd->cdef_y_strength[i] = f->frame_hdr->cdef.y_strength[i]; fd->cdef_uv_strength[i] = f->frame_hdr->cdef.uv_strength[i]; }
+    for (int i = 0; i < 3; i++) fd->lr_type[i] = f->frame_hdr->restoration.type[i];
+    fd->lr_unit_size[0] = f->frame_hdr->restoration.unit_size[0]; fd->lr_unit_size[1] = f->frame_hdr->restoration.unit_size[1];
+    fd->lr_mask = (const Dav1dHipAv1Restoration *) f->lf.lr_mask;
+    fd->sr_w = 0;
+}
+
+static int hip_alloc_picture(Dav1dPicture *const p, void *const cookie) {
+    Hooked *const h = cookie;
+    HookedPic *const hp = calloc(1, sizeof(*hp));
+    if (!hp) return DAV1D_ERR(ENOMEM);
+    const int rc = h->hip.host_picture_alloc(h->ctx, &hp->hp, p->p.w, p->p.h, p->p.layout, p->p.bpc);   /* layouts share their values */
+    if (rc) { free(hp); return rc; }
+    for (int i = 0; i < 3; i++) p->data[i] = hp->hp.data[i];
+    p->stride[0] = hp->hp.stride[0]; p->stride[1] = hp->hp.stride[1];
+    p->allocator_data = hp;
+    hp->ref = hp->hp.dev;
+    return 0;
+}
+static void hip_release_picture(Dav1dPicture *const p, void *const cookie) {
+    Hooked *const h = cookie;
+    HookedPic *const hp = p->allocator_data;
+    if (hp->frame) h->hip.frame_destroy(hp->frame);
+    h->hip.host_picture_release(h->ctx, &hp->hp);
+    free(hp);
+}
+
+/* ------------------------------------------------------------------------------------------------ pass-1 stand-in: filter inputs
+ * The reference's own block walk (decode_sb with pass == 2) visits every block with the two reconstruction hooks pointed at the
+ * functions below, which make the calls of dav1d_create_lf_mask_intra / _inter that pass 1 makes (src/decode.c:1216-1226,
+ * 1882-1900) and the cdef_idx / noskip_mask updates (:938-956, 1945-1956) — as oracle/ref_frame.c does for single frames. */
+typedef struct WalkState { BlockContext lf_l; int cur_tile_row; uint32_t rng; } WalkState;
+static __thread WalkState *g_walk;
+
+static uint32_t walk_rnd(WalkState *const r) { r->rng = r->rng * 1664525u + 1013904223u; return r->rng >> 8; }
+
+static void walk_common(Dav1dTaskContext *const t, const enum BlockSize bs, const Av1Block *const b) {
+    WalkState *const r = g_walk;
+    const Dav1dFrameContext *const f = t->f;
+    Av1Filter *const lf_mask = f->lf.mask + (t->by >> 5) * f->sb128w + (t->bx >> 5);
+    const uint8_t *const b_dim = dav1d_block_dimensions[bs];
+    const int bx4 = t->bx & 31, by4 = t->by & 31, bw4 = b_dim[0], bh4 = b_dim[1];
+    if (!b->skip) {
+        const int idx = ((t->bx & 16) >> 4) + ((t->by & 16) >> 3);
+        if (lf_mask->cdef_idx[idx] == -1) {
+            const int v = walk_rnd(r) & ((1 << f->frame_hdr->cdef.n_bits) - 1);
+            lf_mask->cdef_idx[idx] = v;
+            if (bw4 > 16) lf_mask->cdef_idx[idx + 1] = v;
+            if (bh4 > 16) lf_mask->cdef_idx[idx + 2] = v;
+            if (bw4 == 32 && bh4 == 32) lf_mask->cdef_idx[idx + 3] = v;
+        }
+        uint16_t (*noskip_mask)[2] = &lf_mask->noskip_mask[by4 >> 1];
+        const unsigned mask = (~0U >> (32 - bw4)) << (bx4 & 15);
+        const int bx_idx = (bx4 & 16) >> 4;
+        for (int y = 0; y < bh4; y += 2, noskip_mask++) {
+            (*noskip_mask)[bx_idx] |= mask;
+            if (bw4 == 32) (*noskip_mask)[1] |= mask;
+        }
+    }
+}
+
+static void walk_intra(Dav1dTaskContext *const t, const enum BlockSize bs, const enum EdgeFlags flags, const Av1Block *const b) {
+    (void) flags;
+    WalkState *const r = g_walk;
+    const Dav1dFrameContext *const f = t->f;
+    const int ss_ver = f->cur.p.layout == DAV1D_PIXEL_LAYOUT_I420, ss_hor = f->cur.p.layout != DAV1D_PIXEL_LAYOUT_I444;
+    const uint8_t *const b_dim = dav1d_block_dimensions[bs];
+    const int bx4 = t->bx & 31, by4 = t->by & 31, cbx4 = bx4 >> ss_hor, cby4 = by4 >> ss_ver;
+    const int has_chroma = f->cur.p.layout != DAV1D_PIXEL_LAYOUT_I400 && (b_dim[0] > ss_hor || t->bx & 1) && (b_dim[1] > ss_ver || t->by & 1);
+    BlockContext *const a = &f->a[r->cur_tile_row * f->sb128w + (t->bx >> 5)];
+    if (f->frame_hdr->loopfilter.level_y[0] || f->frame_hdr->loopfilter.level_y[1])
+        dav1d_create_lf_mask_intra(f->lf.mask + (t->by >> 5) * f->sb128w + (t->bx >> 5), f->lf.level, f->b4_stride,
+                                   (const uint8_t (*)[8][2]) &t->ts->lflvl[b->seg_id][0][0][0], t->bx, t->by, f->w4, f->h4, bs,
+                                   b->tx, b->uvtx, f->cur.p.layout, &a->tx_lpf_y[bx4], &r->lf_l.tx_lpf_y[by4],
+                                   has_chroma ? &a->tx_lpf_uv[cbx4] : NULL, has_chroma ? &r->lf_l.tx_lpf_uv[cby4] : NULL);
+    walk_common(t, bs, b);
+}
+
+static int walk_inter(Dav1dTaskContext *const t, const enum BlockSize bs, const Av1Block *const b) {
+    WalkState *const r = g_walk;
+    const Dav1dFrameContext *const f = t->f;
+    const int ss_ver = f->cur.p.layout == DAV1D_PIXEL_LAYOUT_I420, ss_hor = f->cur.p.layout != DAV1D_PIXEL_LAYOUT_I444;
+    const uint8_t *const b_dim = dav1d_block_dimensions[bs];
+    const int bx4 = t->bx & 31, by4 = t->by & 31, cbx4 = bx4 >> ss_hor, cby4 = by4 >> ss_ver;
+    const int has_chroma = f->cur.p.layout != DAV1D_PIXEL_LAYOUT_I400 && (b_dim[0] > ss_hor || t->bx & 1) && (b_dim[1] > ss_ver || t->by & 1);
+    BlockContext *const a = &f->a[r->cur_tile_row * f->sb128w + (t->bx >> 5)];
+    if (f->frame_hdr->loopfilter.level_y[0] || f->frame_hdr->loopfilter.level_y[1]) {
+        const int is_comp = b->comp_type != COMP_INTER_NONE;
+        const int is_globalmv = b->inter_mode == (is_comp ? GLOBALMV_GLOBALMV : GLOBALMV);
+        const uint8_t (*const lf_lvls)[8][2] = (const uint8_t (*)[8][2]) &t->ts->lflvl[b->seg_id][0][b->ref[0] + 1][!is_globalmv];
+        const uint16_t tx_split[2] = { b->tx_split0, b->tx_split1 };
+        enum RectTxfmSize ytx = b->max_ytx, uvtx = b->uvtx;
+        if (f->frame_hdr->segmentation.lossless[b->seg_id]) { ytx = (enum RectTxfmSize) TX_4X4; uvtx = (enum RectTxfmSize) TX_4X4; }
+        dav1d_create_lf_mask_inter(f->lf.mask + (t->by >> 5) * f->sb128w + (t->bx >> 5), f->lf.level, f->b4_stride, lf_lvls,
+                                   t->bx, t->by, f->w4, f->h4, b->skip, bs, ytx, tx_split, uvtx, f->cur.p.layout,
+                                   &a->tx_lpf_y[bx4], &r->lf_l.tx_lpf_y[by4],
+                                   has_chroma ? &a->tx_lpf_uv[cbx4] : NULL, has_chroma ? &r->lf_l.tx_lpf_uv[cby4] : NULL);
+    }
+    walk_common(t, bs, b);
+    return 0;
+}
+
+static int build_filter_inputs(Dav1dFrameContext *const f, const unsigned seed) {
+    const Dav1dFrameHeader *const fh = f->frame_hdr;
+    const int num_sb128 = f->sb128w * f->sb128h;
+    WalkState ws;
+    memset(&ws, 0, sizeof(ws));
+    ws.rng = seed * 2654435761u + 12345u;
+    Dav1dTaskContext *t = NULL;
+    if (posix_memalign((void **) &t, 64, sizeof(*t))) return -1;
+    memset(t, 0, sizeof(*t));
+    memset(f->lf.mask, 0, sizeof(*f->lf.mask) * num_sb128);
+    for (int i = 0; i < num_sb128; i++) memset(f->lf.mask[i].cdef_idx, -1, 4);
+    memset(f->lf.level, 0, sizeof(*f->lf.level) * num_sb128 * 32 * 32);
+    /* reset_context() of the pass-1 half of f->a: tx_lpf_y = 2, tx_lpf_uv = 1 (src/decode.c:2401-2402) */
+    for (int n = 0; n < f->sb128w * fh->tiling.rows; n++) {
+        memset(f->a[n].tx_lpf_y, 2, sizeof(f->a[n].tx_lpf_y));
+        memset(f->a[n].tx_lpf_uv, 1, sizeof(f->a[n].tx_lpf_uv));
+    }
+    const recon_b_intra_fn keep_intra = f->bd_fn.recon_b_intra;
+    const recon_b_inter_fn keep_inter = f->bd_fn.recon_b_inter;
+    f->bd_fn.recon_b_intra = walk_intra;
+    f->bd_fn.recon_b_inter = walk_inter;
+    g_walk = &ws;
+    t->c = f->c; t->f = f;
+    t->frame_thread.pass = 2;
+    int rc = 0;
+    const int ss_ver = f->cur.p.layout == DAV1D_PIXEL_LAYOUT_I420;
+    for (int tile_row = 0; tile_row < fh->tiling.rows && !rc; tile_row++)
+        for (int sby = fh->tiling.row_start_sb[tile_row]; sby < fh->tiling.row_start_sb[tile_row + 1] && !rc; sby++) {
+            t->by = sby << f->sb_shift;
+            for (int tile_col = 0; tile_col < fh->tiling.cols && !rc; tile_col++) {
+                t->ts = &f->ts[tile_row * fh->tiling.cols + tile_col];
+                ws.cur_tile_row = tile_row;
+                memset(ws.lf_l.tx_lpf_y, 2, sizeof(ws.lf_l.tx_lpf_y));
+                memset(ws.lf_l.tx_lpf_uv, 1, sizeof(ws.lf_l.tx_lpf_uv));
+                rc = dav1d_decode_tile_sbrow(t);
+                /* src/decode.c:2730-2740: the left context at the tile's right edge, for the mask fix-ups across tile columns */
+                int align_h = (f->bh + 31) & ~31;
+                memcpy(&f->lf.tx_lpf_right_edge[0][align_h * tile_col + t->by], &ws.lf_l.tx_lpf_y[t->by & 16], f->sb_step);
+                align_h >>= ss_ver;
+                memcpy(&f->lf.tx_lpf_right_edge[1][align_h * tile_col + (t->by >> ss_ver)], &ws.lf_l.tx_lpf_uv[(t->by & 16) >> ss_ver],
+                       f->sb_step >> ss_ver);
+            }
+        }
+    f->bd_fn.recon_b_intra = keep_intra;
+    f->bd_fn.recon_b_inter = keep_inter;
+    g_walk = NULL;
+    /* the walk moved the pass-2 tile cursors and contexts: back to the start of the frame (setup_tile, src/decode.c:2438-2452;
+     * reset_context of the pass-2 half, :3182-3188) */
+    {
+        static const uint8_t ss_size_mul[4][2] = { { 4, 4 }, { 6, 5 }, { 8, 6 }, { 12, 8 } };
+        const uint8_t *const size_mul = ss_size_mul[f->cur.p.layout];
+        const int hbd = f->cur.p.bpc > 8;
+        for (int j = 0; j < fh->tiling.cols * fh->tiling.rows; j++) {
+            const unsigned off = f->frame_thread.tile_start_off[j];
+            Dav1dTileState *const ts = &f->ts[j];
+            for (int q = 0; q < 2; q++) {
+                ts->frame_thread[q].pal_idx = f->frame_thread.pal_idx ? &f->frame_thread.pal_idx[(size_t) off * size_mul[1] / 8] : NULL;
+                ts->frame_thread[q].cbi = &f->frame_thread.cbi[(size_t) off * size_mul[0] / 64];
+                ts->frame_thread[q].cf = (uint8_t *) f->frame_thread.cf + (((size_t) off * size_mul[0]) >> !hbd);
+            }
+        }
+        const int keyframe = IS_KEY_OR_INTRA(fh);
+        for (int n = f->sb128w * fh->tiling.rows; n < f->sb128w * fh->tiling.rows * 2; n++) {
+            memset(&f->a[n], 0, sizeof(f->a[n]));
+            memset(f->a[n].intra, keyframe, sizeof(f->a[n].intra));
+            memset(f->a[n].uvmode, DC_PRED, sizeof(f->a[n].uvmode));
+            if (keyframe) memset(f->a[n].mode, DC_PRED, sizeof(f->a[n].mode));
+        }
+    }
+    /* restoration units: what read_restoration_info() parses (src/decode.c:2511-2592), drawn in its ranges */
+    if (f->lf.lr_mask && f->lf.restore_planes) {
+        static const uint8_t sgr_s[16][2] = { { 1, 1 }, { 1, 1 }, { 1, 1 }, { 1, 1 }, { 1, 1 }, { 1, 1 }, { 1, 1 }, { 1, 1 }, { 1, 1 }, { 1, 1 },
+                                              { 0, 1 }, { 0, 1 }, { 0, 1 }, { 0, 1 }, { 1, 0 }, { 1, 0 } };
+        for (int i = 0; i < f->lf.lr_mask_sz; i++)
+            for (int pl = 0; pl < 3; pl++) {
+                const int ft = fh->restoration.type[pl];
+                for (int u = 0; u < 4; u++) {
+                    Av1RestorationUnit *const lr = &f->lf.lr_mask[i].lr[pl][u];
+                    memset(lr, 0, sizeof(*lr));
+                    int kind = 0;                                        /* 0 none, 1 Wiener, 2 self-guided */
+                    if (ft == DAV1D_RESTORATION_SWITCHABLE) kind = walk_rnd(&ws) % 3;
+                    else if (ft == DAV1D_RESTORATION_WIENER) kind = walk_rnd(&ws) % 5 ? 1 : 0;
+                    else if (ft == DAV1D_RESTORATION_SGRPROJ) kind = walk_rnd(&ws) % 5 ? 2 : 0;
+                    const int idx = walk_rnd(&ws) & 15;
+                    lr->type = kind == 0 ? DAV1D_RESTORATION_NONE : kind == 1 ? DAV1D_RESTORATION_WIENER : DAV1D_RESTORATION_SGRPROJ + idx;
+                    lr->filter_h[0] = lr->filter_v[0] = 0;
+                    if (!pl) { lr->filter_h[0] = (int) (walk_rnd(&ws) % 16) - 5; lr->filter_v[0] = (int) (walk_rnd(&ws) % 16) - 5; }
+                    lr->filter_h[1] = (int) (walk_rnd(&ws) % 32) - 23; lr->filter_v[1] = (int) (walk_rnd(&ws) % 32) - 23;
+                    lr->filter_h[2] = (int) (walk_rnd(&ws) % 64) - 17; lr->filter_v[2] = (int) (walk_rnd(&ws) % 64) - 17;
+                    lr->sgr_weights[0] = sgr_s[idx][0] ? (int) (walk_rnd(&ws) % 128) - 96 : 0;
+                    lr->sgr_weights[1] = sgr_s[idx][1] ? (int) (walk_rnd(&ws) % 128) - 32 : 95;
+                }
+            }
+    }
+    free(t);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------ the hooks */
+static FcState *state_of(const Dav1dFrameContext *const f) { return &g_h->fcs[f - f->c->fc]; }
+
+static void note_error(Dav1dFrameContext *const f, const int rc) {
+    if (rc) { atomic_store(&f->task_thread.error, -1); g_h->failed = 1; }
+}
+
+static void once_per_row(const Dav1dFrameContext *const f, const int sby) {
+    FcState *const s = state_of(f);
+    if (atomic_exchange(&s->filter_listed[sby], 1)) return;
+    note_error((Dav1dFrameContext *) f, g_h->hip.lister_filter_sbrow(s->lister, &s->fd, sby));     /* instead of filter_sbrow* */
+}
+static void hk_filter_f(Dav1dFrameContext *const f, const int sby) { once_per_row(f, sby); }
+static void hk_filter_t(Dav1dTaskContext *const tc, const int sby) { once_per_row(tc->f, sby); }
+
+static int grow(Hooked *const h, void **const p, size_t *const cap, const size_t bytes) {
+    if (*cap >= bytes) return 0;
+    if (*p) h->hip.free_(h->ctx, *p);
+    *p = NULL; *cap = 0;
+    size_t want = 1 << 16;
+    while (want < bytes) want <<= 1;
+    const int rc = h->hip.malloc_(h->ctx, p, want);
+    if (!rc) *cap = want;
+    return rc;
+}
+
+static int hk_after_init(Dav1dFrameContext *const f) {
+    Hooked *const h = g_h;
+    FcState *const s = state_of(f);
+    const Dav1dFrameHeader *const fh = f->frame_hdr;
+    const int n_tiles = fh->tiling.cols * fh->tiling.rows;
+    /* ---- pass 1's output, generated: block records, cbi, coefficients, palettes */
+    hip_frame_desc(&s->desc, f);
+    const size_t cf_bytes = (size_t) f->frame_thread.cf_sz * 128 * 128 / 2;
+    const size_t cbi_entries = (size_t) f->frame_thread.cbi_sz * 32 * 32 / 4;
+    const size_t pal_idx_bytes = (size_t) f->frame_thread.pal_idx_sz * 128 * 128 / 8;
+    memset(f->frame_thread.cf, 0, cf_bytes);
+    memset(f->frame_thread.b, 0, sizeof(*f->frame_thread.b) * f->sb128w * f->sb128h * 32 * 32);
+    Dav1dHipSynthParams sp = h->p.synth;
+    sp.seed += 7919u * (uint64_t) fh->frame_offset;
+    sp.cf_align64 = ARCH_X86_64;
+    int rc = h->hip.synth_frame(&s->desc, &sp, f->frame_thread.cf, cf_bytes, cbi_entries, f->frame_thread.pal_idx, pal_idx_bytes);
+    if (rc) return DAV1D_ERR(EINVAL);
+    /* ---- ... and what pass 1 builds for the in-loop filters (no delta_lf here: every tile uses the frame's level table,
+     * src/decode.c:1018-1021) */
+    for (int j = 0; j < n_tiles; j++) f->ts[j].lflvl = f->lf.lvl;
+    if (build_filter_inputs(f, (unsigned) (sp.seed & 0xffffff) + 3)) return DAV1D_ERR(EINVAL);
+    /* ---- the rows of its references a tile-sbrow needs (decode_b's lowest_pixel bookkeeping, src/decode.c:1957-1990): all of them,
+     * or none when the listing may run ahead (the pixels are read when the frame ends, and frames end in order) */
+    if (IS_INTER_OR_SWITCH(fh))
+        for (int j = 0; j < n_tiles; j++) {
+            Dav1dTileState *const ts = &f->ts[j];
+            const int rows = (ts->tiling.row_end - ts->tiling.row_start + f->sb_step - 1) >> f->sb_shift;
+            for (int r = 0; r < rows; r++)
+                for (int n = 0; n < 7; n++) {
+                    const int need = h->p.mode == 1 && h->p.free_listing ? INT_MIN : f->refp[n].p.p.h;
+                    ts->lowest_pixel[r][n][0] = need;
+                    ts->lowest_pixel[r][n][1] = need == INT_MIN ? INT_MIN : need >> (f->cur.p.layout == DAV1D_PIXEL_LAYOUT_I420);
+                }
+        }
+    if (h->p.mode != 1) return 0;
+    /* ---- frame + lister, the filter stages pointed at the filter lister */
+    HookedPic *const cur = f->sr_cur.p.allocator_data;
+    Dav1dHipPicture refs[7];
+    const int n_refs = IS_INTER_OR_SWITCH(fh) ? 7 : 0;
+    for (int i = 0; i < n_refs; i++) refs[i] = ((HookedPic *) f->refp[i].p.allocator_data)->hp.dev;     /* geometry; the final ones at the end */
+    rc = h->hip.frame_begin(h->ctx, &s->frame, &cur->hp.dev, refs, n_refs);
+    if (!rc) rc = h->hip.lister_create(&s->lister, &s->desc, s->frame);
+    if (rc) return DAV1D_ERR(ENOMEM);
+    hip_filter_desc(&s->fd, f);
+    if (f->sbh > s->sbh_cap) {
+        free(s->filter_listed);
+        s->filter_listed = calloc((size_t) f->sbh, sizeof(*s->filter_listed));
+        if (!s->filter_listed) return DAV1D_ERR(ENOMEM);
+        s->sbh_cap = f->sbh;
+    }
+    for (int i = 0; i < f->sbh; i++) atomic_store(&s->filter_listed[i], 0);
+    f->bd_fn.filter_sbrow_deblock_cols = hk_filter_f;
+    f->bd_fn.filter_sbrow_deblock_rows = hk_filter_f;
+    f->bd_fn.filter_sbrow_cdef = hk_filter_t;
+    f->bd_fn.filter_sbrow_resize = hk_filter_f;
+    f->bd_fn.filter_sbrow_lr = hk_filter_f;
+    s->err = 0;
+    return 0;
+}
+
+static int hk_entropy(Dav1dTaskContext *const t) { (void) t; return 0; }       /* pass 1 was injected */
+
+static int hk_recon(Dav1dTaskContext *const t) {
+    /* instead of dav1d_decode_tile_sbrow(tc) */
+    const Dav1dFrameContext *const f = t->f;
+    const int rc = g_h->hip.lister_tile_sbrow(state_of(f)->lister, t->ts->tiling.row, t->ts->tiling.col, t->by >> f->sb_shift);
+    if (rc) g_h->failed = 1;
+    return rc ? 1 : 0;
+}
+
+/* the frame's tasks are through (a worker thread, the scheduler's lock held): its turn on the GPU thread comes */
+static void hk_frame_complete(Dav1dFrameContext *const f) {
+    Hooked *const h = g_h;
+    pthread_mutex_lock(&h->q_mtx);
+    h->q_frame[f->frame_hdr->frame_offset] = f;
+    pthread_cond_broadcast(&h->q_cond);
+    pthread_mutex_unlock(&h->q_mtx);
+}
+
+static int finish_frame(Hooked *const h, Dav1dFrameContext *const f) {
+    FcState *const s = state_of(f);
+    HookedPic *const cur = f->sr_cur.p.allocator_data;
+    const Hip *const hip = &h->hip;
+    int rc = 0;
+    if (IS_INTER_OR_SWITCH(f->frame_hdr)) {
+        Dav1dHipPicture refs[7];
+        for (int i = 0; i < 7; i++) refs[i] = ((HookedPic *) f->refp[i].p.allocator_data)->ref;        /* where those frames' final pixels are */
+        rc = hip->frame_set_refs(s->frame, refs, 7);
+    }
+    const size_t cf_bytes = (size_t) f->frame_thread.cf_sz * 128 * 128 / 2;
+    const size_t lvl_bytes = sizeof(*f->lf.level) * (size_t) f->sb128w * f->sb128h * 32 * 32;
+    size_t n_const = 0;
+    const uint8_t *const blob = hip->lister_const_masks(&n_const);
+    if (!rc) rc = grow(h, &s->coef, &s->coef_cap, cf_bytes + 64);
+    if (!rc) rc = grow(h, &s->lvl, &s->lvl_cap, lvl_bytes + 64);
+    if (!rc) rc = grow(h, &s->prep, &s->prep_cap, hip->lister_prep_elems(s->lister) * 2 + 4096);
+    const size_t mask_cap_before = s->mask_cap;
+    if (!rc) rc = grow(h, &s->mask, &s->mask_cap, hip->lister_mask_bytes(s->lister) + 4096);
+    if (!rc && s->mask_cap != mask_cap_before) rc = hip->upload(h->ctx, s->mask, blob, n_const);
+    if (!rc) rc = hip->upload(h->ctx, s->coef, f->frame_thread.cf, cf_bytes);
+    if (!rc) rc = hip->upload(h->ctx, s->lvl, f->lf.level, lvl_bytes);
+    if (!rc) rc = hip->frame_set_filters(s->frame, s->lvl, f->b4_stride, f->lf.lim_lut.e, f->lf.lim_lut.i,
+                                         f->frame_hdr->cdef.damping + f->cur.p.bpc - 8, NULL, 0);
+    Dav1dHipPicture filtered;
+    memset(&filtered, 0, sizeof(filtered));
+    if (!rc) rc = hip->frame_end(s->frame, s->coef, s->prep, s->mask, &filtered, NULL);
+    hip->lister_destroy(s->lister);
+    s->lister = NULL;
+    if (!rc) {
+        cur->ref = filtered;                      /* later frames predict from this; the frame object lives as long as the picture */
+        cur->frame = s->frame;
+        rc = hip->host_picture_fetch(h->ctx, &cur->hp, &filtered, 0, f->cur.p.h);
+        if (!rc) rc = hip->host_picture_wait(h->ctx);
+    } else {
+        hip->frame_destroy(s->frame);
+    }
+    s->frame = NULL;
+    return rc;
+}
+
+static void *gpu_thread(void *const arg) {
+    Hooked *const h = arg;
+    for (;;) {
+        pthread_mutex_lock(&h->q_mtx);
+        while (!h->q_stop && !(h->q_next < h->p.n_frames && h->q_frame[h->q_next])) pthread_cond_wait(&h->q_cond, &h->q_mtx);
+        if (h->q_stop) { pthread_mutex_unlock(&h->q_mtx); break; }
+        Dav1dFrameContext *const f = h->q_frame[h->q_next++];
+        pthread_mutex_unlock(&h->q_mtx);
+        const int rc = finish_frame(h, f);
+        if (rc) h->failed = 1;
+        dav1d_hooked_frame_done(f, rc ? DAV1D_ERR(EIO) : 0);
+    }
+    return NULL;
+}
+
+static const Dav1dHooks hooks_cpu = { hk_after_init, hk_entropy, NULL, NULL };
+static const Dav1dHooks hooks_hip = { hk_after_init, hk_entropy, hk_recon, hk_frame_complete };
+
+/* ------------------------------------------------------------------------------------------------ headers */
+static void fill_seq(Dav1dSequenceHeader *const seq, const HookedParams *const p) {
+    memset(seq, 0, sizeof(*seq));
+    seq->profile = p->layout == DAV1D_PIXEL_LAYOUT_I444 ? 1 : p->layout == DAV1D_PIXEL_LAYOUT_I422 || p->bpc == 12 ? 2 : 0;
+    seq->max_width = p->w; seq->max_height = p->h;
+    seq->layout = p->layout;
+    seq->hbd = p->bpc == 8 ? 0 : p->bpc == 10 ? 1 : 2;
+    seq->monochrome = p->layout == DAV1D_PIXEL_LAYOUT_I400;
+    seq->ss_hor = p->layout != DAV1D_PIXEL_LAYOUT_I444; seq->ss_ver = p->layout == DAV1D_PIXEL_LAYOUT_I420;
+    seq->sb128 = p->sb128;
+    seq->intra_edge_filter = 1;
+    seq->inter_intra = seq->masked_compound = seq->warped_motion = seq->dual_filter = seq->filter_intra = 1;
+    seq->order_hint = 1; seq->order_hint_n_bits = 7;
+    seq->jnt_comp = 1;
+    seq->cdef = p->cdef_enabled;
+    seq->restoration = p->lr_type[0] || p->lr_type[1] || p->lr_type[2];
+    seq->num_operating_points = 1;
+}
+
+static void fill_frame(Dav1dFrameHeader *const fh, const HookedParams *const p, const int k) {
+    memset(fh, 0, sizeof(*fh));
+    fh->frame_type = k ? DAV1D_FRAME_TYPE_INTER : DAV1D_FRAME_TYPE_KEY;
+    fh->show_frame = fh->showable_frame = 1;
+    fh->error_resilient_mode = !k;
+    fh->width[0] = fh->width[1] = fh->render_width = p->w;
+    fh->height = fh->render_height = p->h;
+    fh->super_res.width_scale_denominator = 8;
+    fh->frame_offset = k;
+    fh->primary_ref_frame = DAV1D_PRIMARY_REF_NONE;
+    fh->refresh_frame_flags = k ? 1 << (k & 7) : 0xff;
+    /* the three frames before this one, round and round: frame j >= 1 sits in slot j & 7 (until frame j + 8 takes the slot), the key
+     * frame in every slot it has not been pushed out of — slot 0 as long as it is referenced (k <= 3) */
+    for (int i = 0; i < 7; i++) {
+        int j = k - 1 - i % 3;
+        if (j < 0) j = 0;
+        fh->refidx[i] = j & 7;
+    }
+    fh->hp = 1;
+    fh->subpel_filter_mode = DAV1D_FILTER_SWITCHABLE;
+    fh->switchable_motion_mode = 1;
+    fh->warp_motion = 1;
+    fh->switchable_comp_refs = !!k;
+    fh->txfm_mode = DAV1D_TX_SWITCHABLE;
+    fh->tiling.uniform = 1;
+    fh->tiling.cols = p->n_tile_cols; fh->tiling.rows = p->n_tile_rows;
+    for (int i = 0; i <= p->n_tile_cols; i++) fh->tiling.col_start_sb[i] = p->col_start_sb[i];
+    for (int i = 0; i <= p->n_tile_rows; i++) fh->tiling.row_start_sb[i] = p->row_start_sb[i];
+    fh->quant.yac = 100;
+    fh->loopfilter.level_y[0] = p->lf_level_y[0]; fh->loopfilter.level_y[1] = p->lf_level_y[1];
+    fh->loopfilter.level_u = p->lf_level_u; fh->loopfilter.level_v = p->lf_level_v;
+    fh->loopfilter.sharpness = p->lf_sharpness;
+    fh->cdef.damping = p->cdef_damping; fh->cdef.n_bits = p->cdef_n_bits;
+    for (int i = 0; i < 8; i++) { fh->cdef.y_strength[i] = p->cdef_y_strength[i]; fh->cdef.uv_strength[i] = p->cdef_uv_strength[i]; }
+    for (int i = 0; i < 3; i++) fh->restoration.type[i] = p->lr_type[i];
+    fh->restoration.unit_size[0] = p->lr_unit_size[0]; fh->restoration.unit_size[1] = p->lr_unit_size[1];
+    for (int i = 0; i < 7; i++) fh->gmv[i] = dav1d_default_wm_params;
+}
+
+/* ------------------------------------------------------------------------------------------------ outputs */
+static void keep_picture(Hooked *const h, const Dav1dPicture *const pic) {
+    const int k = pic->frame_hdr->frame_offset;
+    if (k < 0 || k >= h->p.n_frames) return;
+    h->n_out++;
+    if (!h->p.keep_output) return;
+    const int bps = pic->p.bpc > 8 ? 2 : 1;
+    const int ss_hor = pic->p.layout != DAV1D_PIXEL_LAYOUT_I444, ss_ver = pic->p.layout == DAV1D_PIXEL_LAYOUT_I420;
+    for (int pl = 0; pl < (pic->p.layout == DAV1D_PIXEL_LAYOUT_I400 ? 1 : 3); pl++) {
+        const int w = pl ? (pic->p.w + ss_hor) >> ss_hor : pic->p.w, hh = pl ? (pic->p.h + ss_ver) >> ss_ver : pic->p.h;
+        uint8_t *const dst = malloc((size_t) w * hh * bps);
+        if (!dst) { h->failed = 1; return; }
+        for (int y = 0; y < hh; y++) memcpy(dst + (size_t) y * w * bps, (const uint8_t *) pic->data[pl] + (ptrdiff_t) y * pic->stride[!!pl], (size_t) w * bps);
+        free(h->out_plane[k * 3 + pl]);
+        h->out_plane[k * 3 + pl] = dst;
+    }
+}
+
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+
+/* ------------------------------------------------------------------------------------------------ entry points */
+#define SYM(field, name) do { *(void **) &h->hip.field = dlsym(h->hip.dl, name); if (!h->hip.field) goto fail; } while (0)
+
+void dav1d_hooked_close(void *handle);
+
+void *dav1d_hooked_open(const HookedParams *const p, const char *const hip_lib) {
+    Hooked *const h = calloc(1, sizeof(*h));
+    if (!h) return NULL;
+    h->p = *p;
+    pthread_mutex_init(&h->q_mtx, NULL);
+    pthread_cond_init(&h->q_cond, NULL);
+    h->hip.dl = dlopen(hip_lib, RTLD_NOW | RTLD_LOCAL);
+    if (!h->hip.dl) goto fail;
+    SYM(open, "dav1d_hip_open"); SYM(close, "dav1d_hip_close"); SYM(sync, "dav1d_hip_sync"); SYM(malloc_, "dav1d_hip_malloc"); SYM(free_, "dav1d_hip_free");
+    SYM(upload, "dav1d_hip_upload"); SYM(host_picture_alloc, "dav1d_hip_host_picture_alloc"); SYM(host_picture_release, "dav1d_hip_host_picture_release");
+    SYM(host_picture_fetch, "dav1d_hip_host_picture_fetch"); SYM(host_picture_wait, "dav1d_hip_host_picture_wait");
+    SYM(frame_begin, "dav1d_hip_frame_begin"); SYM(frame_set_refs, "dav1d_hip_frame_set_refs"); SYM(frame_set_filters, "dav1d_hip_frame_set_filters");
+    SYM(frame_end, "dav1d_hip_frame_end"); SYM(frame_destroy, "dav1d_hip_frame_destroy");
+    SYM(lister_create, "dav1d_hip_lister_create"); SYM(lister_tile_sbrow, "dav1d_hip_lister_tile_sbrow"); SYM(lister_filter_sbrow, "dav1d_hip_lister_filter_sbrow");
+    SYM(lister_prep_elems, "dav1d_hip_lister_prep_elems"); SYM(lister_mask_bytes, "dav1d_hip_lister_mask_bytes");
+    SYM(lister_const_masks, "dav1d_hip_lister_const_masks"); SYM(lister_destroy, "dav1d_hip_lister_destroy"); SYM(synth_frame, "dav1d_hip_synth_frame");
+    if (p->mode == 1 && h->hip.open(&h->ctx, p->device, NULL)) goto fail;
+    Dav1dSettings s;
+    dav1d_default_settings(&s);
+    s.n_threads = p->n_threads;
+    s.max_frame_delay = p->frame_delay;
+    s.apply_grain = 0;
+    if (p->mode == 1) {
+        s.allocator.cookie = h;
+        s.allocator.alloc_picture_callback = hip_alloc_picture;
+        s.allocator.release_picture_callback = hip_release_picture;
+    }
+    if (dav1d_open(&h->c, &s)) goto fail;
+    if (h->c->n_fc < 2) goto fail;                       /* the two-pass hand-off only exists with frame threading */
+    h->n_fc = h->c->n_fc;
+    h->fcs = calloc(h->n_fc, sizeof(*h->fcs));
+    h->q_frame = calloc((size_t) p->n_frames + 1, sizeof(*h->q_frame));
+    h->out_plane = calloc((size_t) p->n_frames * 3 + 3, sizeof(*h->out_plane));
+    if (!h->fcs || !h->q_frame || !h->out_plane) goto fail;
+    h->seq_ref = dav1d_ref_create(ALLOC_OBU_HDR, sizeof(Dav1dSequenceHeader));
+    if (!h->seq_ref) goto fail;
+    fill_seq(h->seq_ref->data, p);
+    return h;
+fail:
+    dav1d_hooked_close(h);
+    return NULL;
+}
+
+int dav1d_hooked_n_fc(void *const handle) { return handle ? (int) ((Hooked *) handle)->n_fc : 0; }
+
+/* the whole chain: returns 0 and the wall-clock seconds from the first dav1d_submit_frame to the last picture out */
+int dav1d_hooked_run(void *const handle, double *const seconds) {
+    Hooked *const h = handle;
+    Dav1dContext *const c = h->c;
+    const HookedParams *const p = &h->p;
+    const int n_tiles = p->n_tile_cols * p->n_tile_rows;
+    g_h = h;
+    dav1d_hooks = p->mode == 1 ? &hooks_hip : &hooks_cpu;
+    h->q_next = 0; h->q_stop = 0; h->n_out = 0; h->failed = 0;
+    memset(h->q_frame, 0, sizeof(*h->q_frame) * ((size_t) p->n_frames + 1));
+    int have_thread = 0;
+    if (p->mode == 1) { if (pthread_create(&h->gpu_thread, NULL, gpu_thread, h)) return -1; have_thread = 1; }
+    int rc = 0;
+    const double t0 = now_s();
+    for (int k = 0; k < p->n_frames && !rc; k++) {
+        /* what dav1d_parse_obus leaves behind for dav1d_submit_frame (src/obu.c:1220 ff.): sequence and frame header, tile groups */
+        c->seq_hdr_ref = h->seq_ref; c->seq_hdr = h->seq_ref->data;
+        if (!k) dav1d_ref_inc(h->seq_ref);
+        c->frame_hdr_ref = dav1d_ref_create(ALLOC_OBU_HDR, sizeof(Dav1dFrameHeader));
+        if (!c->frame_hdr_ref) { rc = -1; break; }
+        c->frame_hdr = c->frame_hdr_ref->data;
+        fill_frame(c->frame_hdr, p, k);
+        if (c->n_tile_data_alloc < n_tiles) {
+            c->tile = dav1d_realloc(ALLOC_TILE, c->tile, sizeof(*c->tile) * n_tiles);
+            if (!c->tile) { rc = -1; break; }
+            c->n_tile_data_alloc = n_tiles;
+        }
+        memset(c->tile, 0, sizeof(*c->tile) * n_tiles);
+        for (int j = 0; j < n_tiles; j++) c->tile[j].start = c->tile[j].end = j;     /* one empty tile group per tile: no bytes to parse */
+        c->n_tile_data = n_tiles;
+        c->n_tiles = n_tiles;
+        rc = dav1d_submit_frame(c);
+        if (rc) break;
+        if (c->out.p.data[0]) { keep_picture(h, &c->out.p); dav1d_thread_picture_unref(&c->out); }
+    }
+    /* drain */
+    c->drain = 1;
+    for (;;) {
+        Dav1dPicture pic;
+        memset(&pic, 0, sizeof(pic));
+        const int r = dav1d_get_picture(c, &pic);
+        if (r) { if (r != DAV1D_ERR(EAGAIN) && !rc) rc = r; break; }
+        keep_picture(h, &pic);
+        dav1d_picture_unref(&pic);
+    }
+    h->seconds = now_s() - t0;
+    if (have_thread) {
+        pthread_mutex_lock(&h->q_mtx);
+        h->q_stop = 1;
+        pthread_cond_broadcast(&h->q_cond);
+        pthread_mutex_unlock(&h->q_mtx);
+        pthread_join(h->gpu_thread, NULL);
+    }
+    dav1d_hooks = NULL;
+    if (seconds) *seconds = h->seconds;
+    if (!rc && (h->failed || h->n_out != p->n_frames)) rc = -2;
+    return rc;
+}
+
+const void *dav1d_hooked_plane(void *const handle, const int frame, const int plane) {
+    Hooked *const h = handle;
+    return frame >= 0 && frame < h->p.n_frames && plane >= 0 && plane < 3 ? h->out_plane[frame * 3 + plane] : NULL;
+}
+
+void dav1d_hooked_close(void *const handle) {
+    Hooked *const h = handle;
+    if (!h) return;
+    if (h->c) {
+        /* the references of the last frames still hold pictures: dav1d_close releases them through the allocator */
+        dav1d_close(&h->c);
+    }
+    if (h->fcs) {
+        for (unsigned i = 0; i < h->n_fc; i++) {
+            FcState *const s = &h->fcs[i];
+            if (h->ctx) {
+                if (s->coef) h->hip.free_(h->ctx, s->coef);
+                if (s->lvl) h->hip.free_(h->ctx, s->lvl);
+                if (s->prep) h->hip.free_(h->ctx, s->prep);
+                if (s->mask) h->hip.free_(h->ctx, s->mask);
+            }
+            free(s->filter_listed);
+        }
+        free(h->fcs);
+    }
+    if (h->seq_ref) dav1d_ref_dec(&h->seq_ref);
+    if (h->ctx) h->hip.close(h->ctx);
+    if (h->out_plane) { for (int i = 0; i < h->p.n_frames * 3; i++) free(h->out_plane[i]); free(h->out_plane); }
+    free(h->q_frame);
+    if (h->hip.dl) dlclose(h->hip.dl);
+    pthread_mutex_destroy(&h->q_mtx);
+    pthread_cond_destroy(&h->q_cond);
+    free(h);
+}

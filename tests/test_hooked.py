@@ -1,0 +1,41 @@
+"""The backend inside dav1d's own task loop: dav1d_open / dav1d_submit_frame / dav1d_worker_task threads /
+check_tile dependencies / dav1d_get_picture are the reference's, src/thread_task.c carries the hook points of INTEGRATION.md 2
+(oracle/hooked/thread_task.patch), and a chain of frames — a key frame, then inter frames predicting from the three frames before
+them — is decoded twice from the same injected pass-1 output: by the reference's own pass 2 + in-loop filters on its worker
+threads, and by the glue of INTEGRATION.md (allocator on dav1d_hip_host_picture_*, dav1d_hip_lister_tile_sbrow /
+_filter_sbrow from the tile and filter tasks, dav1d_hip_frame_end when the frame's tasks are through).  Every output picture must be
+identical."""
+import numpy as np
+import pytest
+
+import util
+import hooked_util as hk
+from dav1d_amd import _lib
+
+pytestmark = pytest.mark.skipif(hk.lib() is None, reason="needs oracle/_ref_hooked (the reference build with the hook patch)")
+
+
+def hip_lib_path(ctx):
+    return util.emu_lib_path() if ctx.backend == "emu" else _lib.DEFAULT_PATH
+
+
+CASES = [
+    ("420_10_filters", 384, 256, 10, dict(tiles=(2, 1))),
+    ("420_8_tiles_2x2_no_filters", 320, 200, 8, dict(tiles=(2, 2), filters=None)),
+    ("444_12_sb64_dav1d_dependencies", 256, 136, 12, dict(layout=3, sb128=False, tiles=(1, 1), free_listing=0)),
+]
+
+
+@pytest.mark.parametrize("name,w,h,bpc,kw", CASES, ids=[c[0] for c in CASES])
+def test_chain_through_the_task_loop_equals_dav1d(ctx, name, w, h, bpc, kw):
+    n_frames = 6 if ctx.backend == "emu" else 9
+    kw = dict(kw)
+    want_s, n_fc, want = hk.run(hk.params(w, h, bpc, n_frames, mode=0, **kw), hip_lib_path(ctx))
+    assert n_fc >= 3
+    got_s, _, got = hk.run(hk.params(w, h, bpc, n_frames, mode=1, **kw), hip_lib_path(ctx))
+    for k in range(n_frames):
+        for pl in range(len(want[k])):
+            bad = np.argwhere(want[k][pl] != got[k][pl])
+            assert not len(bad), "frame %d plane %d differs at %s (%d pixels)" % (k, pl, bad[0], len(bad))
+    # the chain is a chain: frames differ from each other, and an inter frame is not what the key frame was
+    assert not np.array_equal(want[0][0], want[1][0]) and not np.array_equal(want[1][0], want[n_frames - 1][0])
