@@ -765,6 +765,24 @@ def main():
                     raise SystemExit("bench: full end-to-end leg differs from the reference: %s" % e)
                 except Exception as e:       # noqa: BLE001  (a reported extra)
                     full_route = {"error": str(e)[:200]}
+        # ---- the backend inside dav1d's OWN task loop (oracle/_ref_hooked: the reference with src/thread_task.c patched at the hook
+        # points of INTEGRATION.md 2; dav1d_open, dav1d_submit_frame, the worker threads, check_tile, dav1d_get_picture are dav1d's):
+        # a chain of dependent 8K frames at BASELINE configs[2]'s 4 tile columns, every picture checked against dav1d's own pass 2 +
+        # filters under the same loop
+        task_loop = None
+        if world == 1 and not a.no_e2e and not a.no_check:
+            try:
+                import hooked_util as hk
+                from dav1d_amd import _lib as _l
+                if hk.lib() is None:
+                    task_loop = {"status": "skipped: oracle/_ref_hooked is not built (needs /root/reference at build time)"}
+                else:
+                    ctx.sync()
+                    task_loop = hk.task_loop_rate(_l.DEFAULT_PATH, w, h, bpc, tiles=(4, 1), threads=min(64, os.cpu_count() or 8), frame_delay=8, frames=24, check_frames=3)
+            except AssertionError as e:
+                raise SystemExit("bench: the dav1d task loop leg differs from dav1d's own pass 2 + filters: %s" % e)
+            except Exception as e:       # noqa: BLE001  (a reported extra)
+                task_loop = {"error": str(e)[:200]}
         label = "8K" if (w, h) == (7680, 4320) else "4K" if (w, h) == (3840, 2160) else "%dx%d" % (w, h)
         out = {"metric": "reconstructed luma Mpixels/s (%s 4:2:0 %d-bit) on the itx+mc recon path; bit-exact vs C" % (label, bpc),
                "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -781,7 +799,7 @@ def main():
                           "coef_format": "packed: eob + 1 scan-order values per block" if a.packed else "dense cf arena (reference layout)",
                           "coef_bytes_per_frame": int(coef_host.nbytes), "coef_h2d_ms_per_frame": h2d_ms,
                           "samples_per_frame": frame.n_samples, "parity": check, "gen_seconds": round(t_gen, 1)},
-               "roofline": roof, "cpu_baseline": cpu, "full_table": full, "end_to_end": e2e_leg, "all_intra": key_leg, "end_to_end_full_table": full_route,
+               "roofline": roof, "cpu_baseline": cpu, "full_table": full, "end_to_end": e2e_leg, "all_intra": key_leg, "end_to_end_full_table": full_route, "dav1d_task_loop": task_loop,
                "device": None if a.no_check else device_probe(torch)}       # (not under the profiler: its copies would sit in the kernel statistics)
         # BASELINE configs[1] (4K 8-bit, the reference's CPU-runnable size) next to the headline: the same bench in a child process,
         # its digest under "config_c1_4k_8bit"

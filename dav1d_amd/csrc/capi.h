@@ -43,6 +43,8 @@ struct Dav1dHipContext {
     struct Arena { uint8_t *dev; size_t cap; };
     std::vector<Arena> free_arenas;            // chunk arenas of finished frames (a frame in flight owns one)
     std::vector<Arena> free_task_bufs;         // task-list buffers of the *_batch calls (TaskBuf below)
+    std::vector<Dav1dHipPicture> free_pictures; // the frames' own pictures (CDEF / restoration outputs) between frames: hipMalloc and
+                                               // above all hipFree (it waits for the device) stay out of the per-frame path
     size_t arena_hint;                         // what the largest frame so far needed
     uint8_t *gather_dev, *segtab_dev;
     size_t gather_cap, segtab_cap;
@@ -302,6 +304,9 @@ extern "C" int dav1d_hip_launch_emu_edge(void *dst, ptrdiff_t dst_stride, const 
                                          int iw, int ih, int x, int y, int bpc, void *stream);
 
 Dav1dHipContext *dav1d_hip_default_context(void);
+// a picture for a frame's own use from the context's pool (zeroed like a fresh one) / back to it
+extern "C" int dav1d_hip_picture_take(Dav1dHipContext *c, Dav1dHipPicture *pic, int w, int h, int layout, int bpc);
+extern "C" void dav1d_hip_picture_give(Dav1dHipContext *c, Dav1dHipPicture *pic);
 // the intra wavefront list with the blends of inter-intra blocks (frame driver)
 extern "C" int dav1d_hip_intra_list_create_blend(Dav1dHipContext *c, Dav1dHipIntraList **out, const Dav1dHipIpredTask *preds, const size_t *pred_sizes,
                                                  const Dav1dHipItxTask *txs, const size_t *tx_sizes, const Dav1dHipCompTask *blends,

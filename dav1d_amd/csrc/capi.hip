@@ -89,6 +89,7 @@ void dav1d_hip_close(Dav1dHipContext *c) {
     hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); hipEventDestroy(c->ev_copy);
     for (const Dav1dHipContext::Arena &ar : c->free_arenas) hipFree(ar.dev);
     for (const Dav1dHipContext::Arena &ar : c->free_task_bufs) hipFree(ar.dev);
+    for (Dav1dHipPicture &q : c->free_pictures) { if (q.alloc) hipFree(q.alloc); if (q.twin_alloc) hipFree(q.twin_alloc); }
     if (c->gather_dev) hipFree(c->gather_dev);
     if (c->segtab_dev) hipFree(c->segtab_dev);
     if (c->pending_slab) hipHostFree(c->pending_slab);
@@ -234,6 +235,33 @@ int dav1d_hip_picture_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic, int w, int
         if (rc) { (void) hipFree(buf); memset(pic, 0, sizeof(*pic)); return rc; }
     }
     return 0;
+}
+
+int dav1d_hip_picture_take(Dav1dHipContext *c, Dav1dHipPicture *pic, int w, int h, int layout, int bpc) {
+    {
+        std::lock_guard<std::mutex> lk(c->pool_mtx);
+        for (size_t i = 0; i < c->free_pictures.size(); i++) {
+            const Dav1dHipPicture &q = c->free_pictures[i];
+            if (q.p[0].w == w && q.p[0].h == h && q.layout == layout && q.bpc == bpc && !q.twin_alloc == !(c->ref_twin >= 2)) {
+                *pic = q;
+                c->free_pictures[i] = c->free_pictures.back();
+                c->free_pictures.pop_back();
+                pic->twin_ok = 0;
+                // as a fresh allocation would be: zero, padding included
+                return hip_rc(hipMemsetAsync(pic->alloc, 0, pic->alloc_size, c->stream));
+            }
+        }
+    }
+    return dav1d_hip_picture_alloc(c, pic, w, h, layout, bpc);
+}
+
+void dav1d_hip_picture_give(Dav1dHipContext *c, Dav1dHipPicture *pic) {
+    if (!pic->alloc) return;
+    {
+        std::lock_guard<std::mutex> lk(c->pool_mtx);
+        if (c->free_pictures.size() < 16) { c->free_pictures.push_back(*pic); memset(pic, 0, sizeof(*pic)); return; }
+    }
+    (void) dav1d_hip_picture_free(c, pic);
 }
 
 // Storage for the tiled twin: per plane stride x (height rounded up to 8 rows) bytes, the planes one after the other.

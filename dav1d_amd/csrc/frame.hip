@@ -97,7 +97,7 @@ struct Dav1dHipFrame {
 
 static int frame_tmp(Dav1dHipFrame *f, int i) {
     if (f->have_tmp[i]) return 0;
-    const int rc = dav1d_hip_picture_alloc(f->c, &f->tmp[i], f->cur.p[0].w, f->cur.p[0].h, f->cur.layout, f->cur.bpc);
+    const int rc = dav1d_hip_picture_take(f->c, &f->tmp[i], f->cur.p[0].w, f->cur.p[0].h, f->cur.layout, f->cur.bpc);
     if (!rc) f->have_tmp[i] = true;
     return rc;
 }
@@ -1050,7 +1050,7 @@ void dav1d_hip_frame_destroy(Dav1dHipFrame *f) {
         std::lock_guard<std::mutex> lk(f->c->pool_mtx);
         f->c->free_arenas.push_back({ f->arena, f->arena_cap });
     }
-    for (int i = 0; i < 2; i++) if (f->have_tmp[i]) dav1d_hip_picture_free(f->c, &f->tmp[i]);
+    for (int i = 0; i < 2; i++) if (f->have_tmp[i]) dav1d_hip_picture_give(f->c, &f->tmp[i]);
     for (int i = 0; i < 3; i++) if (f->have_sr[i]) dav1d_hip_picture_free(f->c, &f->sr[i]);
     delete f;
 }

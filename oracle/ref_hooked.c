@@ -48,8 +48,20 @@ typedef struct HookedParams {
                                   the frame ends, and the frames end in order); 0 = dav1d's own rule with every reference fully needed */
     int device;
     int keep_output;           /* copy every output picture (for comparisons) */
+    int inject;                /* 0: pass 1's output is generated when a frame's arrays exist (inside the run); 1: ... and a copy is kept in the
+                                  store; 2: taken from the store of an earlier run (the generator and the mask-building walk — one thread
+                                  per frame here, where dav1d spreads entropy decoding over all of them — stay out of the timed chain) */
     Dav1dHipSynthParams synth; /* block decisions of the generated frames; seed + frame number per frame */
 } HookedParams;
+
+/* pass 1's output of one frame, as dav1d_decode_frame_init() sizes the arrays */
+typedef struct StoredFrame {
+    void *b, *cbi, *cf, *pal, *pal_idx;
+    size_t b_bytes, cbi_bytes, cf_bytes, pal_bytes, pal_idx_bytes;
+    void *lf_mask, *lf_level, *lr_mask, *re0, *re1, *a;
+    size_t lf_mask_bytes, lf_level_bytes, lr_mask_bytes, re_bytes, a_bytes;
+} StoredFrame;
+typedef struct Store { int n; StoredFrame *fr; } Store;
 
 /* the entry points of include/dav1d_hip.h, resolved from the library the caller names (libdav1d_hip.so, or the SIMT-emulated
  * build of the same sources on a machine without a GPU) */
@@ -61,6 +73,7 @@ typedef struct Hip {
     int (*malloc_)(Dav1dHipContext *, void **, size_t);
     int (*free_)(Dav1dHipContext *, void *);
     int (*upload)(Dav1dHipContext *, void *, const void *, size_t);
+    int (*memset_)(Dav1dHipContext *, void *, int, size_t);
     int (*host_picture_alloc)(Dav1dHipContext *, Dav1dHipHostPicture *, int, int, int, int);
     int (*host_picture_release)(Dav1dHipContext *, Dav1dHipHostPicture *);
     int (*host_picture_fetch)(Dav1dHipContext *, const Dav1dHipHostPicture *, const Dav1dHipPicture *, int, int);
@@ -98,6 +111,9 @@ typedef struct FcState {
     void *coef, *lvl, *prep, *mask;
     size_t coef_cap, lvl_cap, prep_cap, mask_cap;
     int err;
+    /* inject == 2, mode 1: the frame context's own arrays while the stored ones stand in for them */
+    void *own_b, *own_cbi, *own_cf;
+    int swapped;
 } FcState;
 
 typedef struct Hooked {
@@ -108,20 +124,43 @@ typedef struct Hooked {
     unsigned n_fc;
     Dav1dRef *seq_ref;
     FcState *fcs;
-    /* frames whose last task is through, waiting for their turn on the GPU thread (frames end in submission order) */
-    pthread_t gpu_thread;
+    Store *store;
+    /* Frames whose last task is through (q_frame[frame number]) go through three threads of the harness: coefficients and level
+     * cache to the device (any order, a context and stream of its own), dav1d_hip_frame_end (in submission order: a frame's
+     * references are final when it ends), the copy of the picture to the host planes + dav1d_hooked_frame_done (in order). */
+    Dav1dHipContext *ctx_up;
+    pthread_t up_thread, gpu_thread, out_thread;
     pthread_mutex_t q_mtx;
     pthread_cond_t q_cond;
     Dav1dFrameContext **q_frame;          /* [frame number] */
-    int q_next, q_stop;
+    uint8_t *q_state;                     /* [frame number]: 0 not yet, 1 tasks through, 2 uploaded (or failed), 3 ended */
+    int *q_rc;
+    Dav1dHipPicture *q_filtered;
+    double *q_done_t;                     /* when dav1d_hooked_frame_done returned */
+    int q_up_next, q_gpu_next, q_out_next, q_stop;
+    /* pictures between uses (dav1d's default allocator pools them too, src/picture.c:46-82 + src/mem.c) */
+    struct HookedPic *free_pics[32];
+    int n_free_pics, closing;
+    pthread_mutex_t pic_mtx;
     /* outputs */
     uint8_t **out_plane;                  /* [frame * 3 + plane]: tight rows */
     int n_out;
     double seconds;
     int failed;
+    /* where the time goes (seconds, summed over frames): [0] picture allocation, [1] after_init, [2] listing (tile tasks), [3] filter
+     * listing, [4] waiting for a frame's turn, [5] uploads, [6] dav1d_hip_frame_end, [7] fetch to the host planes, [8] picture release */
+    double stat[16];
+    double frame_end_s[64];               /* dav1d_hip_frame_end of frame k */
+    pthread_mutex_t stat_mtx;
 } Hooked;
 
 static Hooked *g_h;                       /* one harness at a time: the hooks carry no user pointer */
+
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+static void stat_add(Hooked *const h, const int i, const double t0) {
+    const double dt = now_s() - t0;
+    pthread_mutex_lock(&h->stat_mtx); h->stat[i] += dt; pthread_mutex_unlock(&h->stat_mtx);
+}
 
 /* ------------------------------------------------------------------------------------------------ INTEGRATION.md 2, verbatim */
 static void hip_frame_desc(Dav1dHipFrameDesc *d, const Dav1dFrameContext *f) {
@@ -163,9 +202,26 @@ static void hip_filter_desc(Dav1dHipFilterDesc *fd, const Dav1dFrameContext *f) 
 
 static int hip_alloc_picture(Dav1dPicture *const p, void *const cookie) {
     Hooked *const h = cookie;
-    HookedPic *const hp = calloc(1, sizeof(*hp));
-    if (!hp) return DAV1D_ERR(ENOMEM);
-    const int rc = h->hip.host_picture_alloc(h->ctx, &hp->hp, p->p.w, p->p.h, p->p.layout, p->p.bpc);   /* layouts share their values */
+    const double t0 = now_s();
+    HookedPic *hp = NULL;
+    pthread_mutex_lock(&h->pic_mtx);
+    for (int i = 0; i < h->n_free_pics; i++) {
+        const Dav1dHipPicture *const d = &h->free_pics[i]->hp.dev;
+        if (d->p[0].w == p->p.w && d->p[0].h == p->p.h && d->layout == (int) p->p.layout && d->bpc == p->p.bpc) {
+            hp = h->free_pics[i];
+            h->free_pics[i] = h->free_pics[--h->n_free_pics];
+            break;
+        }
+    }
+    pthread_mutex_unlock(&h->pic_mtx);
+    int rc = 0;
+    if (hp) rc = h->hip.memset_(h->ctx, hp->hp.dev.alloc, 0, hp->hp.dev.alloc_size);       /* as a fresh one: zero, padding included */
+    if (!hp) {
+        hp = calloc(1, sizeof(*hp));
+        if (!hp) return DAV1D_ERR(ENOMEM);
+        rc = h->hip.host_picture_alloc(h->ctx, &hp->hp, p->p.w, p->p.h, p->p.layout, p->p.bpc);   /* layouts share their values */
+    }
+    stat_add(h, 0, t0);
     if (rc) { free(hp); return rc; }
     for (int i = 0; i < 3; i++) p->data[i] = hp->hp.data[i];
     p->stride[0] = hp->hp.stride[0]; p->stride[1] = hp->hp.stride[1];
@@ -176,9 +232,17 @@ static int hip_alloc_picture(Dav1dPicture *const p, void *const cookie) {
 static void hip_release_picture(Dav1dPicture *const p, void *const cookie) {
     Hooked *const h = cookie;
     HookedPic *const hp = p->allocator_data;
+    const double t0 = now_s();
     if (hp->frame) h->hip.frame_destroy(hp->frame);
+    hp->frame = NULL;
+    hp->ref = hp->hp.dev;
+    hp->ref.twin_ok = hp->hp.dev.twin_ok = 0;
+    pthread_mutex_lock(&h->pic_mtx);
+    if (!h->closing && h->n_free_pics < 32) { h->free_pics[h->n_free_pics++] = hp; pthread_mutex_unlock(&h->pic_mtx); stat_add(h, 8, t0); return; }
+    pthread_mutex_unlock(&h->pic_mtx);
     h->hip.host_picture_release(h->ctx, &hp->hp);
     free(hp);
+    stat_add(h, 8, t0);
 }
 
 /* ------------------------------------------------------------------------------------------------ pass-1 stand-in: filter inputs
@@ -364,7 +428,9 @@ static void note_error(Dav1dFrameContext *const f, const int rc) {
 static void once_per_row(const Dav1dFrameContext *const f, const int sby) {
     FcState *const s = state_of(f);
     if (atomic_exchange(&s->filter_listed[sby], 1)) return;
+    const double t0 = now_s();
     note_error((Dav1dFrameContext *) f, g_h->hip.lister_filter_sbrow(s->lister, &s->fd, sby));     /* instead of filter_sbrow* */
+    stat_add(g_h, 3, t0);
 }
 static void hk_filter_f(Dav1dFrameContext *const f, const int sby) { once_per_row(f, sby); }
 static void hk_filter_t(Dav1dTaskContext *const tc, const int sby) { once_per_row(tc->f, sby); }
@@ -380,27 +446,78 @@ static int grow(Hooked *const h, void **const p, size_t *const cap, const size_t
     return rc;
 }
 
+static int hk_after_init_(Dav1dFrameContext *const f);
 static int hk_after_init(Dav1dFrameContext *const f) {
+    const double t0 = now_s();
+    const int rc = hk_after_init_(f);
+    stat_add(g_h, 1, t0);
+    return rc;
+}
+static int hk_after_init_(Dav1dFrameContext *const f) {
     Hooked *const h = g_h;
     FcState *const s = state_of(f);
     const Dav1dFrameHeader *const fh = f->frame_hdr;
     const int n_tiles = fh->tiling.cols * fh->tiling.rows;
-    /* ---- pass 1's output, generated: block records, cbi, coefficients, palettes */
-    hip_frame_desc(&s->desc, f);
     const size_t cf_bytes = (size_t) f->frame_thread.cf_sz * 128 * 128 / 2;
     const size_t cbi_entries = (size_t) f->frame_thread.cbi_sz * 32 * 32 / 4;
     const size_t pal_idx_bytes = (size_t) f->frame_thread.pal_idx_sz * 128 * 128 / 8;
-    memset(f->frame_thread.cf, 0, cf_bytes);
-    memset(f->frame_thread.b, 0, sizeof(*f->frame_thread.b) * f->sb128w * f->sb128h * 32 * 32);
-    Dav1dHipSynthParams sp = h->p.synth;
-    sp.seed += 7919u * (uint64_t) fh->frame_offset;
-    sp.cf_align64 = ARCH_X86_64;
-    int rc = h->hip.synth_frame(&s->desc, &sp, f->frame_thread.cf, cf_bytes, cbi_entries, f->frame_thread.pal_idx, pal_idx_bytes);
-    if (rc) return DAV1D_ERR(EINVAL);
-    /* ---- ... and what pass 1 builds for the in-loop filters (no delta_lf here: every tile uses the frame's level table,
-     * src/decode.c:1018-1021) */
-    for (int j = 0; j < n_tiles; j++) f->ts[j].lflvl = f->lf.lvl;
-    if (build_filter_inputs(f, (unsigned) (sp.seed & 0xffffff) + 3)) return DAV1D_ERR(EINVAL);
+    const size_t b_bytes = sizeof(*f->frame_thread.b) * (size_t) f->sb128w * f->sb128h * 32 * 32;
+    const size_t pal_bytes = (size_t) f->frame_thread.pal_sz * 16 * 16 * 24;
+    const int num_sb128 = f->sb128w * f->sb128h;
+    const size_t re_bytes = (size_t) f->lf.re_sz * 32;
+    const size_t a_bytes = sizeof(*f->a) * (size_t) f->sb128w * fh->tiling.rows;           /* the pass-1 half */
+    int rc = 0;
+    for (int j = 0; j < n_tiles; j++) f->ts[j].lflvl = f->lf.lvl;       /* no delta_lf here: the frame's level table, src/decode.c:1018-1021 */
+    StoredFrame *const sf = h->store && fh->frame_offset < h->store->n ? &h->store->fr[fh->frame_offset] : NULL;
+    if (h->p.inject == 2) {
+        /* ---- pass 1's output from the store: the three large arrays stand in for the frame context's own where nothing writes them
+         * (mode 1; the reference's pass 2 consumes cf, so mode 0 takes copies), the small ones are copied */
+        if (!sf || !sf->b || sf->b_bytes != b_bytes || sf->cf_bytes != cf_bytes || sf->cbi_bytes != cbi_entries * 2) return DAV1D_ERR(EINVAL);
+        if (h->p.mode == 1) {
+            s->own_b = f->frame_thread.b; s->own_cbi = f->frame_thread.cbi; s->own_cf = f->frame_thread.cf;
+            f->frame_thread.b = sf->b; f->frame_thread.cbi = sf->cbi; f->frame_thread.cf = sf->cf;
+            s->swapped = 1;
+        } else {
+            memcpy(f->frame_thread.b, sf->b, b_bytes); memcpy(f->frame_thread.cbi, sf->cbi, sf->cbi_bytes); memcpy(f->frame_thread.cf, sf->cf, cf_bytes);
+        }
+        if (sf->pal_bytes) memcpy(f->frame_thread.pal, sf->pal, sf->pal_bytes);
+        if (sf->pal_idx_bytes) memcpy(f->frame_thread.pal_idx, sf->pal_idx, sf->pal_idx_bytes);
+        memcpy(f->lf.mask, sf->lf_mask, sf->lf_mask_bytes);
+        memcpy(f->lf.level, sf->lf_level, sf->lf_level_bytes);
+        if (sf->lr_mask_bytes) memcpy(f->lf.lr_mask, sf->lr_mask, sf->lr_mask_bytes);
+        memcpy(f->lf.tx_lpf_right_edge[0], sf->re0, sf->re_bytes); memcpy(f->lf.tx_lpf_right_edge[1], sf->re1, sf->re_bytes);
+        memcpy(f->a, sf->a, sf->a_bytes);
+        hip_frame_desc(&s->desc, f);
+    } else {
+        /* ---- pass 1's output, generated: block records, cbi, coefficients, palettes */
+        hip_frame_desc(&s->desc, f);
+        memset(f->frame_thread.cf, 0, cf_bytes);
+        memset(f->frame_thread.b, 0, b_bytes);
+        Dav1dHipSynthParams sp = h->p.synth;
+        sp.seed += 7919u * (uint64_t) fh->frame_offset;
+        sp.cf_align64 = ARCH_X86_64;
+        rc = h->hip.synth_frame(&s->desc, &sp, f->frame_thread.cf, cf_bytes, cbi_entries, f->frame_thread.pal_idx, pal_idx_bytes);
+        if (rc) return DAV1D_ERR(EINVAL);
+        /* ---- ... and what pass 1 builds for the in-loop filters */
+        if (build_filter_inputs(f, (unsigned) (sp.seed & 0xffffff) + 3)) return DAV1D_ERR(EINVAL);
+        if (h->p.inject == 1 && sf) {
+#define KEEP(dst, n_dst, src, n) do { free(dst); dst = NULL; n_dst = 0; if ((n) && (src)) { dst = malloc(n); if (!dst) return DAV1D_ERR(ENOMEM); memcpy(dst, src, n); n_dst = n; } } while (0)
+            KEEP(sf->b, sf->b_bytes, f->frame_thread.b, b_bytes);
+            KEEP(sf->cbi, sf->cbi_bytes, f->frame_thread.cbi, cbi_entries * 2);
+            KEEP(sf->cf, sf->cf_bytes, f->frame_thread.cf, cf_bytes);
+            KEEP(sf->pal, sf->pal_bytes, f->frame_thread.pal, pal_bytes);
+            KEEP(sf->pal_idx, sf->pal_idx_bytes, f->frame_thread.pal_idx, pal_idx_bytes);
+            KEEP(sf->lf_mask, sf->lf_mask_bytes, f->lf.mask, sizeof(*f->lf.mask) * (size_t) num_sb128);
+            KEEP(sf->lf_level, sf->lf_level_bytes, f->lf.level, sizeof(*f->lf.level) * (size_t) num_sb128 * 32 * 32);
+            KEEP(sf->lr_mask, sf->lr_mask_bytes, f->lf.lr_mask, sizeof(*f->lf.lr_mask) * (size_t) f->lf.lr_mask_sz);
+            size_t dummy;
+            KEEP(sf->re0, sf->re_bytes, f->lf.tx_lpf_right_edge[0], re_bytes);
+            KEEP(sf->re1, dummy, f->lf.tx_lpf_right_edge[1], re_bytes);
+            KEEP(sf->a, sf->a_bytes, f->a, a_bytes);
+            (void) dummy;
+#undef KEEP
+        }
+    }
     /* ---- the rows of its references a tile-sbrow needs (decode_b's lowest_pixel bookkeeping, src/decode.c:1957-1990): all of them,
      * or none when the listing may run ahead (the pixels are read when the frame ends, and frames end in order) */
     if (IS_INTER_OR_SWITCH(fh))
@@ -445,7 +562,9 @@ static int hk_entropy(Dav1dTaskContext *const t) { (void) t; return 0; }       /
 static int hk_recon(Dav1dTaskContext *const t) {
     /* instead of dav1d_decode_tile_sbrow(tc) */
     const Dav1dFrameContext *const f = t->f;
+    const double t0 = now_s();
     const int rc = g_h->hip.lister_tile_sbrow(state_of(f)->lister, t->ts->tiling.row, t->ts->tiling.col, t->by >> f->sb_shift);
+    stat_add(g_h, 2, t0);
     if (rc) g_h->failed = 1;
     return rc ? 1 : 0;
 }
@@ -455,44 +574,55 @@ static void hk_frame_complete(Dav1dFrameContext *const f) {
     Hooked *const h = g_h;
     pthread_mutex_lock(&h->q_mtx);
     h->q_frame[f->frame_hdr->frame_offset] = f;
+    h->q_state[f->frame_hdr->frame_offset] = 1;
     pthread_cond_broadcast(&h->q_cond);
     pthread_mutex_unlock(&h->q_mtx);
 }
 
-static int finish_frame(Hooked *const h, Dav1dFrameContext *const f) {
+/* stage 1 (any order): what the frame's launches read from the host side */
+static int stage_upload(Hooked *const h, Dav1dFrameContext *const f) {
+    FcState *const s = state_of(f);
+    const Hip *const hip = &h->hip;
+    const size_t cf_bytes = (size_t) f->frame_thread.cf_sz * 128 * 128 / 2;
+    const size_t lvl_bytes = sizeof(*f->lf.level) * (size_t) f->sb128w * f->sb128h * 32 * 32;
+    size_t n_const = 0;
+    const uint8_t *const blob = hip->lister_const_masks(&n_const);
+    const double t0 = now_s();
+    int rc = grow(h, &s->coef, &s->coef_cap, cf_bytes + 64);
+    if (!rc) rc = grow(h, &s->lvl, &s->lvl_cap, lvl_bytes + 64);
+    if (!rc) rc = grow(h, &s->prep, &s->prep_cap, hip->lister_prep_elems(s->lister) * 2 + 4096);
+    const size_t mask_cap_before = s->mask_cap;
+    if (!rc) rc = grow(h, &s->mask, &s->mask_cap, hip->lister_mask_bytes(s->lister) + 4096);
+    if (!rc && s->mask_cap != mask_cap_before) rc = hip->upload(h->ctx_up, s->mask, blob, n_const);
+    if (!rc) rc = hip->upload(h->ctx_up, s->coef, f->frame_thread.cf, cf_bytes);
+    if (!rc) rc = hip->upload(h->ctx_up, s->lvl, f->lf.level, lvl_bytes);
+    stat_add(h, 5, t0);
+    return rc;
+}
+
+/* stage 2 (in submission order): INTEGRATION.md 2, "when the last task of the frame is in" */
+static int stage_end(Hooked *const h, Dav1dFrameContext *const f, Dav1dHipPicture *const filtered) {
     FcState *const s = state_of(f);
     HookedPic *const cur = f->sr_cur.p.allocator_data;
     const Hip *const hip = &h->hip;
     int rc = 0;
+    const double t0 = now_s();
     if (IS_INTER_OR_SWITCH(f->frame_hdr)) {
         Dav1dHipPicture refs[7];
         for (int i = 0; i < 7; i++) refs[i] = ((HookedPic *) f->refp[i].p.allocator_data)->ref;        /* where those frames' final pixels are */
         rc = hip->frame_set_refs(s->frame, refs, 7);
     }
-    const size_t cf_bytes = (size_t) f->frame_thread.cf_sz * 128 * 128 / 2;
-    const size_t lvl_bytes = sizeof(*f->lf.level) * (size_t) f->sb128w * f->sb128h * 32 * 32;
-    size_t n_const = 0;
-    const uint8_t *const blob = hip->lister_const_masks(&n_const);
-    if (!rc) rc = grow(h, &s->coef, &s->coef_cap, cf_bytes + 64);
-    if (!rc) rc = grow(h, &s->lvl, &s->lvl_cap, lvl_bytes + 64);
-    if (!rc) rc = grow(h, &s->prep, &s->prep_cap, hip->lister_prep_elems(s->lister) * 2 + 4096);
-    const size_t mask_cap_before = s->mask_cap;
-    if (!rc) rc = grow(h, &s->mask, &s->mask_cap, hip->lister_mask_bytes(s->lister) + 4096);
-    if (!rc && s->mask_cap != mask_cap_before) rc = hip->upload(h->ctx, s->mask, blob, n_const);
-    if (!rc) rc = hip->upload(h->ctx, s->coef, f->frame_thread.cf, cf_bytes);
-    if (!rc) rc = hip->upload(h->ctx, s->lvl, f->lf.level, lvl_bytes);
     if (!rc) rc = hip->frame_set_filters(s->frame, s->lvl, f->b4_stride, f->lf.lim_lut.e, f->lf.lim_lut.i,
                                          f->frame_hdr->cdef.damping + f->cur.p.bpc - 8, NULL, 0);
-    Dav1dHipPicture filtered;
-    memset(&filtered, 0, sizeof(filtered));
-    if (!rc) rc = hip->frame_end(s->frame, s->coef, s->prep, s->mask, &filtered, NULL);
+    memset(filtered, 0, sizeof(*filtered));
+    if (!rc) rc = hip->frame_end(s->frame, s->coef, s->prep, s->mask, filtered, NULL);
+    if (f->frame_hdr->frame_offset < 64) h->frame_end_s[f->frame_hdr->frame_offset] = now_s() - t0;
+    stat_add(h, 6, t0);
     hip->lister_destroy(s->lister);
     s->lister = NULL;
     if (!rc) {
-        cur->ref = filtered;                      /* later frames predict from this; the frame object lives as long as the picture */
+        cur->ref = *filtered;                     /* later frames predict from this; the frame object lives as long as the picture */
         cur->frame = s->frame;
-        rc = hip->host_picture_fetch(h->ctx, &cur->hp, &filtered, 0, f->cur.p.h);
-        if (!rc) rc = hip->host_picture_wait(h->ctx);
     } else {
         hip->frame_destroy(s->frame);
     }
@@ -500,17 +630,44 @@ static int finish_frame(Hooked *const h, Dav1dFrameContext *const f) {
     return rc;
 }
 
-static void *gpu_thread(void *const arg) {
-    Hooked *const h = arg;
+/* stage 3 (in order): the picture to the host planes the application sees, then the frame is done as far as dav1d is concerned */
+static void stage_out(Hooked *const h, Dav1dFrameContext *const f, int rc, const Dav1dHipPicture *const filtered) {
+    FcState *const s = state_of(f);
+    HookedPic *const cur = f->sr_cur.p.allocator_data;
+    const double t0 = now_s();
+    if (!rc) rc = h->hip.host_picture_fetch(h->ctx, &cur->hp, filtered, 0, f->cur.p.h);
+    if (!rc) rc = h->hip.host_picture_wait(h->ctx);
+    stat_add(h, 7, t0);
+    if (s->swapped) {          /* the frame context gets its own arrays back before dav1d sees the frame again */
+        f->frame_thread.b = s->own_b; f->frame_thread.cbi = s->own_cbi; f->frame_thread.cf = s->own_cf;
+        s->swapped = 0;
+    }
+    if (rc) h->failed = 1;
+    const int k = f->frame_hdr->frame_offset;
+    dav1d_hooked_frame_done(f, rc ? DAV1D_ERR(EIO) : 0);
+    h->q_done_t[k] = now_s();
+}
+
+static void *stage_thread(void *const arg) {
+    Hooked *const h = ((void **) arg)[0];
+    const int stage = (int) (intptr_t) ((void **) arg)[1];
+    int *const next = stage == 1 ? &h->q_up_next : stage == 2 ? &h->q_gpu_next : &h->q_out_next;
     for (;;) {
+        const double t_wait = now_s();
         pthread_mutex_lock(&h->q_mtx);
-        while (!h->q_stop && !(h->q_next < h->p.n_frames && h->q_frame[h->q_next])) pthread_cond_wait(&h->q_cond, &h->q_mtx);
+        while (!h->q_stop && !(*next < h->p.n_frames && h->q_state[*next] >= stage)) pthread_cond_wait(&h->q_cond, &h->q_mtx);
         if (h->q_stop) { pthread_mutex_unlock(&h->q_mtx); break; }
-        Dav1dFrameContext *const f = h->q_frame[h->q_next++];
+        const int k = (*next)++;
+        Dav1dFrameContext *const f = h->q_frame[k];
         pthread_mutex_unlock(&h->q_mtx);
-        const int rc = finish_frame(h, f);
-        if (rc) h->failed = 1;
-        dav1d_hooked_frame_done(f, rc ? DAV1D_ERR(EIO) : 0);
+        if (stage == 2) stat_add(h, 4, t_wait);
+        if (stage == 1) h->q_rc[k] = stage_upload(h, f);
+        else if (stage == 2) { if (!h->q_rc[k]) h->q_rc[k] = stage_end(h, f, &h->q_filtered[k]); else { h->hip.lister_destroy(state_of(f)->lister); state_of(f)->lister = NULL; h->hip.frame_destroy(state_of(f)->frame); state_of(f)->frame = NULL; } }
+        else stage_out(h, f, h->q_rc[k], &h->q_filtered[k]);
+        pthread_mutex_lock(&h->q_mtx);
+        if (stage < 3) h->q_state[k] = (uint8_t) (stage + 1);
+        pthread_cond_broadcast(&h->q_cond);
+        pthread_mutex_unlock(&h->q_mtx);
     }
     return NULL;
 }
@@ -594,30 +751,52 @@ static void keep_picture(Hooked *const h, const Dav1dPicture *const pic) {
     }
 }
 
-static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
-
 /* ------------------------------------------------------------------------------------------------ entry points */
 #define SYM(field, name) do { *(void **) &h->hip.field = dlsym(h->hip.dl, name); if (!h->hip.field) goto fail; } while (0)
 
 void dav1d_hooked_close(void *handle);
 
-void *dav1d_hooked_open(const HookedParams *const p, const char *const hip_lib) {
+void *dav1d_hooked_store_create(const int n_frames) {
+    Store *const st = calloc(1, sizeof(*st));
+    if (!st) return NULL;
+    st->fr = calloc((size_t) n_frames, sizeof(*st->fr));
+    if (!st->fr) { free(st); return NULL; }
+    st->n = n_frames;
+    return st;
+}
+void dav1d_hooked_store_destroy(void *const store) {
+    Store *const st = store;
+    if (!st) return;
+    for (int i = 0; i < st->n; i++) {
+        StoredFrame *const f = &st->fr[i];
+        free(f->b); free(f->cbi); free(f->cf); free(f->pal); free(f->pal_idx); free(f->lf_mask); free(f->lf_level); free(f->lr_mask);
+        free(f->re0); free(f->re1); free(f->a);
+    }
+    free(st->fr);
+    free(st);
+}
+
+void *dav1d_hooked_open(const HookedParams *const p, const char *const hip_lib, void *const store) {
     Hooked *const h = calloc(1, sizeof(*h));
     if (!h) return NULL;
     h->p = *p;
+    h->store = store;
+    if (p->inject && !store) { free(h); return NULL; }
     pthread_mutex_init(&h->q_mtx, NULL);
+    pthread_mutex_init(&h->stat_mtx, NULL);
     pthread_cond_init(&h->q_cond, NULL);
     h->hip.dl = dlopen(hip_lib, RTLD_NOW | RTLD_LOCAL);
     if (!h->hip.dl) goto fail;
     SYM(open, "dav1d_hip_open"); SYM(close, "dav1d_hip_close"); SYM(sync, "dav1d_hip_sync"); SYM(malloc_, "dav1d_hip_malloc"); SYM(free_, "dav1d_hip_free");
-    SYM(upload, "dav1d_hip_upload"); SYM(host_picture_alloc, "dav1d_hip_host_picture_alloc"); SYM(host_picture_release, "dav1d_hip_host_picture_release");
+    SYM(upload, "dav1d_hip_upload"); SYM(memset_, "dav1d_hip_memset"); SYM(host_picture_alloc, "dav1d_hip_host_picture_alloc"); SYM(host_picture_release, "dav1d_hip_host_picture_release");
     SYM(host_picture_fetch, "dav1d_hip_host_picture_fetch"); SYM(host_picture_wait, "dav1d_hip_host_picture_wait");
     SYM(frame_begin, "dav1d_hip_frame_begin"); SYM(frame_set_refs, "dav1d_hip_frame_set_refs"); SYM(frame_set_filters, "dav1d_hip_frame_set_filters");
     SYM(frame_end, "dav1d_hip_frame_end"); SYM(frame_destroy, "dav1d_hip_frame_destroy");
     SYM(lister_create, "dav1d_hip_lister_create"); SYM(lister_tile_sbrow, "dav1d_hip_lister_tile_sbrow"); SYM(lister_filter_sbrow, "dav1d_hip_lister_filter_sbrow");
     SYM(lister_prep_elems, "dav1d_hip_lister_prep_elems"); SYM(lister_mask_bytes, "dav1d_hip_lister_mask_bytes");
     SYM(lister_const_masks, "dav1d_hip_lister_const_masks"); SYM(lister_destroy, "dav1d_hip_lister_destroy"); SYM(synth_frame, "dav1d_hip_synth_frame");
-    if (p->mode == 1 && h->hip.open(&h->ctx, p->device, NULL)) goto fail;
+    pthread_mutex_init(&h->pic_mtx, NULL);
+    if (p->mode == 1 && (h->hip.open(&h->ctx, p->device, NULL) || h->hip.open(&h->ctx_up, p->device, NULL))) goto fail;
     Dav1dSettings s;
     dav1d_default_settings(&s);
     s.n_threads = p->n_threads;
@@ -633,8 +812,12 @@ void *dav1d_hooked_open(const HookedParams *const p, const char *const hip_lib) 
     h->n_fc = h->c->n_fc;
     h->fcs = calloc(h->n_fc, sizeof(*h->fcs));
     h->q_frame = calloc((size_t) p->n_frames + 1, sizeof(*h->q_frame));
+    h->q_state = calloc((size_t) p->n_frames + 1, 1);
+    h->q_rc = calloc((size_t) p->n_frames + 1, sizeof(*h->q_rc));
+    h->q_filtered = calloc((size_t) p->n_frames + 1, sizeof(*h->q_filtered));
+    h->q_done_t = calloc((size_t) p->n_frames + 1, sizeof(*h->q_done_t));
     h->out_plane = calloc((size_t) p->n_frames * 3 + 3, sizeof(*h->out_plane));
-    if (!h->fcs || !h->q_frame || !h->out_plane) goto fail;
+    if (!h->fcs || !h->q_frame || !h->out_plane || !h->q_state || !h->q_rc || !h->q_filtered || !h->q_done_t) goto fail;
     h->seq_ref = dav1d_ref_create(ALLOC_OBU_HDR, sizeof(Dav1dSequenceHeader));
     if (!h->seq_ref) goto fail;
     fill_seq(h->seq_ref->data, p);
@@ -644,6 +827,14 @@ fail:
     return NULL;
 }
 
+void dav1d_hooked_stats(void *const handle, double *const out) { memcpy(out, ((Hooked *) handle)->stat, sizeof(((Hooked *) handle)->stat)); }
+void dav1d_hooked_frame_end_seconds(void *const handle, double *const out) { memcpy(out, ((Hooked *) handle)->frame_end_s, sizeof(((Hooked *) handle)->frame_end_s)); }
+/* seconds between the completion of frame `from` and of the last frame (mode 1): the chain without its key frame and warm-up */
+double dav1d_hooked_tail_seconds(void *const handle, const int from) {
+    Hooked *const h = handle;
+    if (from < 0 || from >= h->p.n_frames - 1 || !h->q_done_t[from] || !h->q_done_t[h->p.n_frames - 1]) return 0.;
+    return h->q_done_t[h->p.n_frames - 1] - h->q_done_t[from];
+}
 int dav1d_hooked_n_fc(void *const handle) { return handle ? (int) ((Hooked *) handle)->n_fc : 0; }
 
 /* the whole chain: returns 0 and the wall-clock seconds from the first dav1d_submit_frame to the last picture out */
@@ -654,10 +845,18 @@ int dav1d_hooked_run(void *const handle, double *const seconds) {
     const int n_tiles = p->n_tile_cols * p->n_tile_rows;
     g_h = h;
     dav1d_hooks = p->mode == 1 ? &hooks_hip : &hooks_cpu;
-    h->q_next = 0; h->q_stop = 0; h->n_out = 0; h->failed = 0;
+    h->q_up_next = h->q_gpu_next = h->q_out_next = 0; h->q_stop = 0; h->n_out = 0; h->failed = 0;
+    memset(h->q_state, 0, (size_t) p->n_frames + 1);
+    memset(h->q_rc, 0, sizeof(*h->q_rc) * ((size_t) p->n_frames + 1));
+    memset(h->stat, 0, sizeof(h->stat));
     memset(h->q_frame, 0, sizeof(*h->q_frame) * ((size_t) p->n_frames + 1));
     int have_thread = 0;
-    if (p->mode == 1) { if (pthread_create(&h->gpu_thread, NULL, gpu_thread, h)) return -1; have_thread = 1; }
+    void *targ[3][2] = { { h, (void *) (intptr_t) 1 }, { h, (void *) (intptr_t) 2 }, { h, (void *) (intptr_t) 3 } };
+    if (p->mode == 1) {
+        if (pthread_create(&h->up_thread, NULL, stage_thread, targ[0]) || pthread_create(&h->gpu_thread, NULL, stage_thread, targ[1]) ||
+            pthread_create(&h->out_thread, NULL, stage_thread, targ[2])) return -1;
+        have_thread = 1;
+    }
     int rc = 0;
     const double t0 = now_s();
     for (int k = 0; k < p->n_frames && !rc; k++) {
@@ -697,7 +896,9 @@ int dav1d_hooked_run(void *const handle, double *const seconds) {
         h->q_stop = 1;
         pthread_cond_broadcast(&h->q_cond);
         pthread_mutex_unlock(&h->q_mtx);
+        pthread_join(h->up_thread, NULL);
         pthread_join(h->gpu_thread, NULL);
+        pthread_join(h->out_thread, NULL);
     }
     dav1d_hooks = NULL;
     if (seconds) *seconds = h->seconds;
@@ -713,10 +914,13 @@ const void *dav1d_hooked_plane(void *const handle, const int frame, const int pl
 void dav1d_hooked_close(void *const handle) {
     Hooked *const h = handle;
     if (!h) return;
+    h->closing = 1;
     if (h->c) {
         /* the references of the last frames still hold pictures: dav1d_close releases them through the allocator */
         dav1d_close(&h->c);
     }
+    for (int i = 0; i < h->n_free_pics; i++) { h->hip.host_picture_release(h->ctx, &h->free_pics[i]->hp); free(h->free_pics[i]); }
+    h->n_free_pics = 0;
     if (h->fcs) {
         for (unsigned i = 0; i < h->n_fc; i++) {
             FcState *const s = &h->fcs[i];
@@ -731,9 +935,10 @@ void dav1d_hooked_close(void *const handle) {
         free(h->fcs);
     }
     if (h->seq_ref) dav1d_ref_dec(&h->seq_ref);
+    if (h->ctx_up) h->hip.close(h->ctx_up);
     if (h->ctx) h->hip.close(h->ctx);
     if (h->out_plane) { for (int i = 0; i < h->p.n_frames * 3; i++) free(h->out_plane[i]); free(h->out_plane); }
-    free(h->q_frame);
+    free(h->q_frame); free(h->q_state); free(h->q_rc); free(h->q_filtered); free(h->q_done_t);
     if (h->hip.dl) dlclose(h->hip.dl);
     pthread_mutex_destroy(&h->q_mtx);
     pthread_cond_destroy(&h->q_cond);

@@ -19,7 +19,8 @@ class HookedParams(C.Structure):
                 ("lf_level_y", C.c_int * 2), ("lf_level_u", C.c_int), ("lf_level_v", C.c_int), ("lf_sharpness", C.c_int),
                 ("cdef_enabled", C.c_int), ("cdef_damping", C.c_int), ("cdef_n_bits", C.c_int), ("cdef_y_strength", C.c_int * 8),
                 ("cdef_uv_strength", C.c_int * 8), ("lr_type", C.c_int * 3), ("lr_unit_size", C.c_int * 2),
-                ("mode", C.c_int), ("free_listing", C.c_int), ("device", C.c_int), ("keep_output", C.c_int), ("synth", _lib.SynthParams)]
+                ("mode", C.c_int), ("free_listing", C.c_int), ("device", C.c_int), ("keep_output", C.c_int), ("inject", C.c_int),
+                ("synth", _lib.SynthParams)]
 
 
 def lib():
@@ -27,11 +28,18 @@ def lib():
         return None
     l = C.CDLL(HOOKED_SO)
     l.dav1d_hooked_open.restype = C.c_void_p
-    l.dav1d_hooked_open.argtypes = [C.POINTER(HookedParams), C.c_char_p]
+    l.dav1d_hooked_open.argtypes = [C.POINTER(HookedParams), C.c_char_p, C.c_void_p]
+    l.dav1d_hooked_store_create.restype = C.c_void_p
+    l.dav1d_hooked_store_create.argtypes = [C.c_int]
+    l.dav1d_hooked_store_destroy.argtypes = [C.c_void_p]
     l.dav1d_hooked_run.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     l.dav1d_hooked_plane.restype = C.c_void_p
     l.dav1d_hooked_plane.argtypes = [C.c_void_p, C.c_int, C.c_int]
     l.dav1d_hooked_n_fc.argtypes = [C.c_void_p]
+    l.dav1d_hooked_tail_seconds.restype = C.c_double
+    l.dav1d_hooked_tail_seconds.argtypes = [C.c_void_p, C.c_int]
+    l.dav1d_hooked_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    l.dav1d_hooked_frame_end_seconds.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     l.dav1d_hooked_close.argtypes = [C.c_void_p]
     return l
 
@@ -68,17 +76,40 @@ def params(w, h, bpc, n_frames, mode, layout=1, sb128=True, tiles=(2, 1), thread
     return p
 
 
-def run(p, hip_lib_path):
+class Store:
+    """pass 1's output of the frames of a chain, kept between runs (HookedParams.inject: 1 fills it, 2 replays it)"""
+
+    def __init__(self, n_frames):
+        self.l = lib()
+        self.h = self.l.dav1d_hooked_store_create(n_frames)
+        assert self.h
+
+    def destroy(self):
+        if self.h:
+            self.l.dav1d_hooked_store_destroy(self.h)
+            self.h = None
+
+
+def run(p, hip_lib_path, store=None, inject=0):
     """One chain through dav1d's task loop; returns (seconds, n_fc, [frame][plane] arrays or None)."""
     l = lib()
     assert l is not None, "oracle/_ref_hooked is not built"
-    h = l.dav1d_hooked_open(C.byref(p), hip_lib_path.encode())
+    p.inject = inject if store is not None else 0
+    h = l.dav1d_hooked_open(C.byref(p), hip_lib_path.encode(), store.h if store is not None else None)
     assert h, "dav1d_hooked_open failed"
     try:
         sec = C.c_double()
         rc = l.dav1d_hooked_run(h, C.byref(sec))
         assert rc == 0, "dav1d_hooked_run: %d" % rc
         n_fc = l.dav1d_hooked_n_fc(h)
+        st = (C.c_double * 16)()
+        l.dav1d_hooked_stats(h, st)
+        run.last_stats = dict(zip(("picture_alloc", "after_init", "listing", "filter_listing", "gpu_thread_idle", "uploads", "frame_end", "fetch", "picture_release"),
+                                  [round(v * 1e3 / max(1, p.n_frames), 2) for v in st[:9]]))
+        run.last_tail = (lambda frm: l.dav1d_hooked_tail_seconds(h, frm))(getattr(run, "tail_from", 0)) if p.mode == 1 else 0.
+        fe = (C.c_double * 64)()
+        l.dav1d_hooked_frame_end_seconds(h, fe)
+        run.last_frame_end_ms = [round(v * 1e3, 2) for v in fe[:min(64, p.n_frames)]]
         frames = None
         if p.keep_output:
             dt = np.uint8 if p.bpc == 8 else np.uint16
@@ -96,3 +127,48 @@ def run(p, hip_lib_path):
         return sec.value, n_fc, frames
     finally:
         l.dav1d_hooked_close(h)
+
+
+def task_loop_rate(hip_lib_path, w, h, bpc, tiles=(4, 1), threads=64, frame_delay=8, frames=24, check_frames=4, seed=0x7A5C, intra_pct=10):
+    """bench.py's dav1d_task_loop leg: a chain of dependent frames (a key frame, then inter frames of the C2 block mix predicting from
+    the three frames before them; deblocking, CDEF and switchable restoration on) through dav1d's OWN task loop — dav1d_submit_frame,
+    its worker threads, check_tile, dav1d_get_picture — with the backend plugged in at the hook points of INTEGRATION.md 2.  First a
+    short chain is decoded both ways and compared picture by picture (the peer: the reference's pass 2 + filters on the same worker
+    threads, C only); then the chain is timed, first frame submitted to last picture out."""
+    from dav1d_amd import e2e
+    sp = e2e.c2_params(seed)
+    sp.intra_pct = intra_pct
+    common = dict(tiles=tiles, threads=threads, frame_delay=frame_delay, synth=sp)
+    store = Store(frames)
+    try:
+        # the peer generates (and keeps) pass 1's output of the first frames; everything after replays the store, so that the generator and
+        # the mask-building walk (one thread per frame in this harness) stay out of the timed chains
+        _, n_fc, want = run(params(w, h, bpc, check_frames, mode=0, **common), hip_lib_path, store, inject=1)
+        _, _, got = run(params(w, h, bpc, check_frames, mode=1, **common), hip_lib_path, store, inject=2)
+        for k in range(check_frames):
+            for pl in range(3):
+                if not np.array_equal(want[k][pl], got[k][pl]):
+                    raise AssertionError("dav1d task loop: frame %d plane %d differs from dav1d's own pass 2 + filters" % (k, pl))
+        del want, got
+        run(params(w, h, bpc, frames, mode=0, keep_output=False, **common), hip_lib_path, store, inject=1)      # fills the store for every frame
+        run.tail_from = min(frame_delay, frames - 2)
+        t_s, _, _ = run(params(w, h, bpc, frames, mode=1, keep_output=False, **common), hip_lib_path, store, inject=2)
+        tail_s, tail_n = run.last_tail, frames - 1 - run.tail_from
+        stages = dict(run.last_stats)
+        stages["frame_end_ms_by_frame"] = list(run.last_frame_end_ms)
+        cpu_s, _, _ = run(params(w, h, bpc, check_frames, mode=0, keep_output=False, **common), hip_lib_path, store, inject=2)
+    finally:
+        store.destroy()
+    return {"frames": frames, "fps": round(frames / t_s, 1), "ms_per_frame": round(t_s / frames * 1e3, 2),
+            "value": round(w * h * frames / t_s / 1e6, 1), "unit": "Mpixels/s",
+            "steady_state": {"frames": tail_n, "fps": round(tail_n / tail_s, 1) if tail_s else None, "ms_per_frame": round(tail_s / tail_n * 1e3, 2) if tail_s else None,
+                             "value": round(w * h * tail_n / tail_s / 1e6, 1) if tail_s else None,
+                             "what": "the inter frames after the first %d (key frame, first-use allocations and pipeline fill left out): completion of frame %d to "
+                                     "completion of the last" % (run.tail_from + 1, run.tail_from)}, "n_fc": n_fc, "worker_threads": threads,
+            "tile_cols": tiles[0], "tile_rows": tiles[1], "ms_per_frame_by_stage_summed_over_threads": stages,
+            "peer_fps": round(check_frames / cpu_s, 2), "peer": "the reference's pass 2 + in-loop filters (C, no assembly) under the same task loop, %d worker threads, "
+                                                               "%d frames" % (threads, check_frames),
+            "parity": "bit-exact vs dav1d's own pass 2 + filters under the same task loop (%d frames)" % check_frames,
+            "workload": "%dx%d 4:2:0 %d-bit: key frame + inter frames (C2 mix, 10 %% intra, 3 references = the 3 frames before), deblock + CDEF + switchable "
+                        "restoration; pass 1's output injected from memory (no AV1 streams exist here); dav1d_open(n_threads=%d, max_frame_delay=%d), src/thread_task.c with the "
+                        "hook points of INTEGRATION.md 2; listing runs ahead, frames end in order on one GPU thread" % (w, h, bpc, threads, frame_delay)}
