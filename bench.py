@@ -61,6 +61,12 @@ def parse():
                     help="N > 1: frames = one independent frame stream per GPU (weak scaling, no data-path collective); "
                          "tile-cols = GPU g reconstructs tile column g of the SAME frame and one all-gather per frame rebuilds "
                          "the picture everywhere (SURVEY 8e config C3, strong scaling)")
+    ap.add_argument("--config", choices=["c2", "c4"], default="c2",
+                    help="c2 (default): the itx+mc recon step of the headline; c4 (BASELINE configs[4]): every rank takes a frame of its own through the "
+                         "FULL table (recon, deblock, CDEF, restoration) and film grain per step (dav1d_amd.dist.C4Workload)")
+    ap.add_argument("--dependent", action="store_true",
+                    help="with --config c4: reference 0 of a rank's frame is the picture rank - 1 produced one step earlier; every owner broadcasts "
+                         "its finished picture to all ranks after its step (RCCL broadcast, the publication rule of src/thread_task.c:416-433)")
     ap.add_argument("--tc-filters", action="store_true",
                     help="tile-cols only: the step also runs deblocking, CDEF and loop restoration of the rank's column after a halo "
                          "exchange of 16 luma columns with its neighbours (dav1d_amd/dist.py), and gathers the FILTERED columns")
@@ -267,6 +273,66 @@ def main():
     ref_host = [synth.make_planes(rng, w, h, bpc) for _ in range(frame.n_refs)]
     dst_host = synth.make_planes(rng, w, h, bpc, smooth=False)
     t_gen = time.time() - t_gen
+
+    if a.config == "c4":
+        # BASELINE configs[4]: frames in flight one per GPU, full table + film grain (+ dependent frames): its own short path
+        post = synth.make_post_filters(frame, seed=0xF11 + srank)
+        dev = "cuda"
+        wl = dd.C4Workload(ctx, frame, post, ref_host, dst_host, rank, world, dev, a.dependent)
+        tdt = torch.int16 if bpc == 8 else torch.int32
+        pristine = torch.from_numpy(frame.coef).to(dev)
+        n_arena = a.steps + a.warmup + 1
+        arenas = torch.empty((n_arena, pristine.numel()), dtype=tdt, device=dev)
+        for i in range(n_arena):
+            arenas[i].copy_(pristine)
+        torch.cuda.synchronize()
+        for i in range(a.warmup):
+            wl.step(arenas[i].data_ptr())
+        torch.cuda.synchronize()
+        dd.barrier(world)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.warmup, a.warmup + a.steps):
+            wl.step(arenas[i].data_ptr())
+        torch.cuda.synchronize()
+        dd.barrier(world)
+        dt = dd.max_over_ranks(time.perf_counter() - t0, world, device="cuda")
+        parity = "skipped"
+        if rank == 0 and not a.no_check and not a.dependent:
+            # this rank's last frame against the oracle's replay of the same lists (independent frames: every step gives the same picture)
+            import util
+            import test_frame
+            import test_postchain
+            oracle = util.default_oracle()
+            rec, _, _ = test_frame.oracle_frame(oracle, frame, dst_host, ref_host, threads=min(64, os.cpu_count() or 1))
+            _, _, want_res, want_grn = test_postchain.oracle_post(oracle, post, rec, w, h, bpc)
+            got_res, got_grn = wl.outputs()
+            for pl in range(3):
+                vh, vw = (h, w) if pl == 0 else (h // 2, w // 2)
+                if not np.array_equal(got_res[pl][:vh, :vw], want_res[pl][:vh, :vw]) or not np.array_equal(got_grn[pl][:vh, :vw], want_grn[pl][:vh, :vw]):
+                    raise SystemExit("bench --config c4: plane %d differs from the oracle" % pl)
+            parity = "bit-exact vs %s oracle (restoration output and film grain output of rank 0's last frame)" % oracle.which
+        if rank == 0:
+            P, Cb = (1, 2) if bpc == 8 else (2, 4)
+            full_bytes = algorithmic_bytes(frame) + 8 * P * frame.n_samples        # + deblock, CDEF, restoration, grain: 2 P each
+            ms = dt / a.steps * 1e3
+            print(json.dumps({
+                "metric": "reconstructed luma Mpixels/s (%dx%d 4:2:0 %d-bit), full DSP table + film grain, one frame per GPU per step" % (w, h, bpc),
+                "value": round(dd.job_throughput(frame.luma_pixels, a.steps, dt, world) / 1e6, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "int32" if bpc > 8 else "int16", "data": "synthetic",
+                "config": {"workload": "BASELINE configs[4]: %dx%d 4:2:0 %d-bit, recon list + deblock + CDEF + restoration + film grain on every rank's own frame; %s"
+                                       % (w, h, bpc, "reference 0 = the picture of rank - 1 from the step before: every owner broadcasts its restored picture to all "
+                                          "ranks after its step (one RCCL broadcast per owner)" if a.dependent else "independent frames (closed GOPs): no data-path collective"),
+                           "parallelism": "frame-parallel x%d%s" % (world, ", dependent" if a.dependent else ""), "parity": parity},
+                "roofline": {"bound": "hbm", "achieved": round(full_bytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(full_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                             "what": "whole step on algorithmic bytes (28 B per coded inter sample at 10 bits), wall clock incl. the host side of the batch calls"},
+                "cpu_baseline": None}))
+        dd.barrier(world)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     # ---- device-resident state
     refs = []
@@ -765,6 +831,30 @@ def main():
                     raise SystemExit("bench: full end-to-end leg differs from the reference: %s" % e)
                 except Exception as e:       # noqa: BLE001  (a reported extra)
                     full_route = {"error": str(e)[:200]}
+        # ---- BASELINE configs[2] says 4 tile columns: the end-to-end legs again with the frame cut that way (a tile's superblock rows are
+        # listed top to bottom, so 4 tiles are 4 listing threads), next to the many-tile runs above
+        e2e_c2 = full_route_c2 = None
+        if world == 1 and not a.no_e2e:
+            from dav1d_amd import e2e
+            e2e_c2 = e2e.run(ctx, w, h, bpc, frames=4, threads=4, tile_cols=4, tile_rows=1, check=None if a.no_check else e2e_check)
+            if not a.no_check:
+                import lister_util as lu
+                try:
+                    full_route_c2 = lu.full_route_rate(ctx, w, h, bpc, 4, 1, threads=4, frames=4)
+                except AssertionError as e:
+                    raise SystemExit("bench: full end-to-end leg (4 tile columns) differs from the reference: %s" % e)
+                except Exception as e:       # noqa: BLE001
+                    full_route_c2 = {"error": str(e)[:200]}
+        # ---- BASELINE configs[0]: 1080p 8-bit on ONE host thread (the reference C), and the same reference code with the HIP DSP table
+        c0 = None
+        if world == 1 and not a.no_cpu and not a.no_check and (w, h, bpc) == (7680, 4320, 10):
+            try:
+                import lister_util as lu
+                c0 = lu.c0_line(ctx, strict=False)        # a bring-up path, reported: the line says so if the pictures ever differ
+            except AssertionError as e:
+                raise SystemExit("bench: %s" % e)
+            except Exception as e:       # noqa: BLE001
+                c0 = {"error": str(e)[:200]}
         # ---- the backend inside dav1d's OWN task loop (oracle/_ref_hooked: the reference with src/thread_task.c patched at the hook
         # points of INTEGRATION.md 2; dav1d_open, dav1d_submit_frame, the worker threads, check_tile, dav1d_get_picture are dav1d's):
         # a chain of dependent 8K frames at BASELINE configs[2]'s 4 tile columns, every picture checked against dav1d's own pass 2 +
@@ -799,7 +889,8 @@ def main():
                           "coef_format": "packed: eob + 1 scan-order values per block" if a.packed else "dense cf arena (reference layout)",
                           "coef_bytes_per_frame": int(coef_host.nbytes), "coef_h2d_ms_per_frame": h2d_ms,
                           "samples_per_frame": frame.n_samples, "parity": check, "gen_seconds": round(t_gen, 1)},
-               "roofline": roof, "cpu_baseline": cpu, "full_table": full, "end_to_end": e2e_leg, "all_intra": key_leg, "end_to_end_full_table": full_route, "dav1d_task_loop": task_loop,
+               "roofline": roof, "cpu_baseline": cpu, "full_table": full, "end_to_end": e2e_leg, "all_intra": key_leg, "end_to_end_full_table": full_route, "end_to_end_4_tile_columns": e2e_c2, "end_to_end_full_table_4_tile_columns": full_route_c2,
+               "dav1d_task_loop": task_loop, "config_c0_1080p_8bit": c0,
                "device": None if a.no_check else device_probe(torch)}       # (not under the profiler: its copies would sit in the kernel statistics)
         # BASELINE configs[1] (4K 8-bit, the reference's CPU-runnable size) next to the headline: the same bench in a child process,
         # its digest under "config_c1_4k_8bit"

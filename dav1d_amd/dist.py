@@ -279,3 +279,71 @@ def broadcast_picture(pic, src_rank, world):
     import torch
     import torch.distributed as dist
     dist.broadcast(pic.store.view(torch.uint8) if pic.store.dtype != torch.uint8 else pic.store, src=src_rank)
+
+
+# ---- config C4 of SURVEY 8d / BASELINE configs[4]: frames in flight one per GPU, the FULL table (reconstruction, deblocking, CDEF,
+# restoration) and film grain on every frame.  One step = every rank takes its next frame through all of it.  Two flavours:
+#   independent (closed GOPs): no data-path collective at all;
+#   dependent: reference 0 of a rank's frame in step s is the picture rank - 1 produced in step s - 1 (the publication rule of
+#   src/thread_task.c:416-433 at picture granularity): after its frame is through, every owner broadcasts the picture later frames
+#   predict from (the restoration output; film grain is output-only, src/lib.c:311-329) and every rank keeps a copy.
+# bench.py --config c4 [--dependent] runs it on GPUs over RCCL, tests/test_dist.py on two CPU ranks over gloo (SIMT-emulated kernels).
+
+class C4Workload:
+    def __init__(self, ctx, frame, post, ref_host, dst_host, rank, world, device, dependent):
+        from . import api
+        self.ctx, self.frame, self.post, self.rank, self.world, self.dependent = ctx, frame, post, rank, world, dependent
+        w, h, bpc = frame.w, frame.h, frame.bpc
+        self.w, self.h, self.bpc = w, h, bpc
+
+        def pic():
+            return SharedPicture(ctx, w, h, api.LAYOUT_I420, bpc, device)
+        self.refs = []
+        for rp in ref_host:
+            p = pic()
+            for pl in range(3):
+                p.upload(pl, rp[pl])
+            self.refs.append(p)
+        self.cur, self.cdf, self.grn = pic(), pic(), pic()
+        if dst_host is not None:           # what lies in the picture before the frame (every visible pixel is written by the frame)
+            for pl in range(3):
+                self.cur.upload(pl, dst_host[pl])
+        # the restoration outputs: one per owner in dependent mode (ring[o] = the latest picture of rank o, kept on every rank)
+        self.ring = [pic() for _ in range(world if dependent else 1)]
+        self.have_prev = False
+        self.lvl = ctx.buffer_from(post.lvl)
+        self.prep = ctx.buffer(frame.prep_elems * 2 + 64)
+        self.recon = ctx.recon_list(self.cur.view, frame.mc, frame.comp, frame.itx)
+        self.coefs = None
+
+    def refs_now(self):
+        views = [r.view for r in self.refs]
+        if self.dependent and self.have_prev:
+            views[0] = self.ring[(self.rank - 1) % self.world].view
+        return views
+
+    def step(self, coef):
+        """coef: a pristine DEVICE coefficient arena for this step (pointer or Buffer)"""
+        ctx, post = self.ctx, self.post
+        cur, cdf = self.cur, self.cdf
+        res = self.ring[self.rank if self.dependent else 0]
+        self.prep.zero()
+        self.recon.run(cur.view, self.refs_now(), self.prep, coef)
+        ctx.lf_batch(cur.view, post.lf, self.lvl, post.b4_stride, post.lut_e, post.lut_i)
+        for pl in range(3):
+            cdf.planes[pl].copy_(cur.planes[pl])
+        ctx.cdef_batch(cdf.view, cur.view, post.cdef, post.cdef_damping)
+        for pl in range(3):
+            res.planes[pl].copy_(cdf.planes[pl])
+        ctx.lr_batch(res.view, cdf.view, cur.view, post.lr)
+        ctx.fg_apply(self.grn.view, res.view, post.fg)
+        if self.dependent:
+            ctx.sync()
+            for o in range(self.world):
+                broadcast_picture(self.ring[o], o, self.world)
+            self.have_prev = True
+
+    def outputs(self):
+        """(restored planes, grain planes) of this rank's latest frame"""
+        res = self.ring[self.rank if self.dependent else 0]
+        return [res.download(pl) for pl in range(3)], [self.grn.download(pl) for pl in range(3)]

@@ -307,6 +307,17 @@ void dav1d_ref_frame_destroy(void *const h) {
     free(r);
 }
 
+/* The kernel-level drop-in of INTEGRATION.md 1: the frame's DSP table (421 function pointers, src/internal.h:62-70) is overwritten
+ * with a table of the same layout — the one dav1d_hip_dsp_init_{8,16}bpc fills — so that the reference's own pass 2 and in-loop
+ * filters make every DSP call through it. */
+int dav1d_ref_frame_use_dsp(void *const h, const void *const table, const size_t bytes) {
+    RefFrame *const r = h;
+    const int bits = r->p.bpc == 8 ? 0 : r->p.bpc == 10 ? 1 : 2;
+    if (bytes != sizeof(r->c.dsp[bits])) return -1;
+    memcpy(&r->c.dsp[bits], table, bytes);
+    return 0;
+}
+
 /* named access to the arrays a test fills / reads */
 void *dav1d_ref_frame_ptr(void *const h, const char *const name, size_t *const bytes) {
     RefFrame *const r = h;

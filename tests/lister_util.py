@@ -574,3 +574,55 @@ def full_route_rate(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=64, frame
         return out
     finally:
         rf.destroy()
+
+
+def c0_line(ctx, w=1920, h=1080, bpc=8, seed=0xC0, strict=True):
+    """BASELINE configs[0] (1080p 8-bit, 64-pixel superblocks, one tile, ONE CPU thread; the Chimera stream itself does not
+    exist here, a synthetic inter frame of every tool stands in): the reference's own pass 2 + in-loop filters on one thread — the
+    plumbing baseline — and the SAME reference code with its DSP table replaced by the reference-signature table of the HIP library
+    (dav1d_hip_dsp_init_8bpc, INTEGRATION.md 1: every DSP call staged to the device, run by the batched kernel on one task, copied
+    back).  Both pictures must be identical."""
+    import time
+    if ref_lib() is None:
+        return None
+    filters = dict(lf=(20, 28, 16, 24, 0, False), cdef=(5, 2, [17, 33, 0, 63], [5, 0, 20, 48]), lr=([1, 1, 1], [6, 6]))
+    out = {}
+    pics = []
+    n_slots = 421
+    for leg in ("reference C, 1 thread", "reference drivers + HIP DSP table"):
+        rf = RefFrame(w, h, 1, bpc, is_inter=True, sb128=False, tile_cols=1, tile_rows=1, filters=filters)
+        try:
+            sp = default_synth(seed, n_refs=3, far_mv_pct=2)
+            synth(ctx, rf, sp)
+            fill_pictures(rf, seed + 1)
+            rf.build_filter_inputs(seed)
+            if leg != "reference C, 1 thread":
+                tab = (C.c_void_p * n_slots)()
+                rc = ctx.lib.dav1d_hip_dsp_init_8bpc(tab) if bpc == 8 else ctx.lib.dav1d_hip_dsp_init_16bpc(tab, bpc)
+                assert rc == 0, rc
+                rf.lib.dav1d_ref_frame_use_dsp.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+                assert rf.lib.dav1d_ref_frame_use_dsp(rf.h, tab, C.sizeof(tab)) == 0
+            t0 = time.perf_counter()
+            rf.recon(1)
+            t1 = time.perf_counter()
+            rf.filter()
+            t2 = time.perf_counter()
+            pics.append([rf.plane(0, pl).copy() for pl in range(3)])
+            out[leg] = {"value": round(w * h / (t2 - t0) / 1e6, 2), "unit": "Mpixels/s", "recon_s": round(t1 - t0, 3), "filters_s": round(t2 - t1, 3)}
+        finally:
+            rf.destroy()
+    parity = "bit-exact: the picture through the HIP DSP table equals the reference C picture"
+    for pl in range(3):
+        if not np.array_equal(pics[0][pl], pics[1][pl]):
+            bad = np.argwhere(pics[0][pl] != pics[1][pl])
+            parity = ("MISMATCH: plane %d through the HIP DSP table differs from the reference C: %d pixels, first (y, x) %s, rows %d..%d, columns %d..%d"
+                      % (pl, len(bad), bad[0].tolist(), bad[:, 0].min(), bad[:, 0].max(), bad[:, 1].min(), bad[:, 1].max()))
+            if strict:
+                raise AssertionError("C0: " + parity)
+            break
+    return {"workload": "%dx%d 4:2:0 %d-bit inter frame, 64-pixel superblocks, one tile, every prediction tool, deblock + CDEF + restoration; "
+                        "dav1d_decode_tile_sbrow + dav1d_filter_sbrow on ONE host thread" % (w, h, bpc),
+            "cpu_c_1_thread": out["reference C, 1 thread"],
+            "dsp_table_drop_in": dict(out["reference drivers + HIP DSP table"], what="the same reference code, every DSP call through dav1d_hip_dsp_init's table "
+                                      "(one staged task per call: the bring-up path, not the fast one)"),
+            "parity": parity}

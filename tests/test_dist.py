@@ -274,6 +274,84 @@ def test_frame_parallel_dependent_frames_world2_gloo(tmp_path):
     assert d["ok"] and d["mine"] == [0, 2], d
 
 
+C4_WORKER = """
+import sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import numpy as np
+import torch, torch.distributed as dist
+import util, test_frame, test_postchain
+from dav1d_amd import api, synth, dist as dd
+
+rank, local, world = dd.env()
+dist.init_process_group("gloo")
+W, H, BPC, STEPS = 256, 128, 10, 3
+DEP = %(dependent)d
+ctx = util.make_context("emu")
+rng = np.random.default_rng(41)
+ref_host = [synth.make_planes(rng, W, H, BPC) for _ in range(3)]
+dst0 = synth.make_planes(rng, W, H, BPC, smooth=False)
+# every rank has a frame of its own (BASELINE configs[4]: frames in flight, one per GPU); the lists of all ranks are built everywhere
+# so that rank 0 can replay the whole job on the oracle
+frames = [synth.make_frame(W, H, BPC, seed=1200 + r, mv_range_px=32) for r in range(world)]
+posts = [synth.make_post_filters(frames[r], seed=50 + r) for r in range(world)]
+wl = dd.C4Workload(ctx, frames[rank], posts[rank], ref_host, dst0, rank, world, "cpu", bool(DEP))
+for s in range(STEPS):
+    coef = ctx.buffer_from(frames[rank].coef)
+    wl.step(coef)
+    ctx.sync()
+    coef.free()
+res, grn = wl.outputs()
+mine = {"res": [p.tolist() for p in res], "grn": [p.tolist() for p in grn]} if False else None
+# rank 0 replays every rank's chain on the oracle and compares its own outputs; the other ranks send theirs over
+got = [None] * world
+dist.all_gather_object(got, (rank, [p.copy() for p in res], [p.copy() for p in grn]))
+if rank == 0:
+    oracle = util.default_oracle()
+    prev = [None] * world                       # restoration output of rank r in the previous step
+    for s in range(STEPS):
+        cur = []
+        for r in range(world):
+            rl = list(ref_host)
+            if DEP and s:
+                rl[0] = prev[(r - 1) %% world]
+            rec, _, _ = test_frame.oracle_frame(oracle, frames[r], dst0, rl)
+            d, c, rs, g = test_postchain.oracle_post(oracle, posts[r], rec, W, H, BPC)
+            cur.append((rs, g))
+        prev = [c[0] for c in cur]
+    ok = True
+    for r, res_r, grn_r in got:
+        for pl in range(3):
+            vh, vw = (H, W) if pl == 0 else (H // 2, W // 2)
+            ok &= bool(np.array_equal(res_r[pl][:vh, :vw], cur[r][0][pl][:vh, :vw]))
+            ok &= bool(np.array_equal(grn_r[pl][:vh, :vw], cur[r][1][pl][:vh, :vw]))
+    differs = bool(any(not np.array_equal(got[0][1][pl], got[1][1][pl]) for pl in range(3)))
+    print(json.dumps({"ok": ok, "ranks_differ": differs, "steps": STEPS, "dependent": DEP}))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+import pytest
+
+
+@pytest.mark.parametrize("dependent", [0, 1], ids=["independent", "dependent"])
+def test_c4_full_table_and_film_grain_world2_gloo(tmp_path, dependent):
+    """BASELINE configs[4] on two CPU ranks (dav1d_amd.dist.C4Workload, what `bench.py --config c4 [--dependent]` times on GPUs): every rank
+    takes a frame of its own through reconstruction, deblocking, CDEF, restoration and film grain, step after step; in the dependent
+    flavour reference 0 of a rank's frame is the picture the OTHER rank produced one step earlier (broadcast_picture).  Restoration and
+    grain outputs of both ranks after three steps equal the oracle's replay of the whole job."""
+    import json
+    script = tmp_path / "c4.py"
+    script.write_text(C4_WORKER % {"root": util.ROOT, "tests": os.path.join(util.ROOT, "tests"), "dependent": dependent})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29531 + dependent), str(script)],
+                       capture_output=True, text=True, env=env, timeout=1500)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["ok"] and d["ranks_differ"], d
+
+
 def test_tile_column_split_covers_every_task_once():
     import numpy as np
     from dav1d_amd import dist as dd, synth
