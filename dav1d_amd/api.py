@@ -92,9 +92,11 @@ class DevicePicture:
         if getattr(self.ctx, "auto_retile", False) and plane == self.n_planes - 1:
             self.retile()
 
-    def retile(self):
-        """(Re)build the tiled twin from the raster planes: motion compensation then reads this picture through it."""
-        _chk(self.ctx.lib.dav1d_hip_picture_retile(self.ctx.h, C.byref(self.pic)), "picture_retile")
+    def retile(self, overlapped=False):
+        """(Re)build the tiled twin from the raster planes: motion compensation then reads this picture through it.  overlapped: on a
+        side stream, next to whatever is enqueued afterwards (dav1d_hip_picture_retile_overlapped)."""
+        fn = self.ctx.lib.dav1d_hip_picture_retile_overlapped if overlapped else self.ctx.lib.dav1d_hip_picture_retile
+        _chk(fn(self.ctx.h, C.byref(self.pic)), "picture_retile")
 
     def download(self, plane):
         """Padded plane as a (rows x cols) view of a host array with the DEVICE row stride, so that
@@ -169,6 +171,15 @@ class _ReconList:
         m = None if mask is None else (mask.ptr if hasattr(mask, "ptr") else mask)
         _chk(self.ctx.lib.dav1d_hip_recon_list_run(self.ctx.h, self.h, C.byref(dst.pic), arr, len(refs), p, m,
                                                    coef.ptr if hasattr(coef, "ptr") else coef), "recon_list_run")
+
+    def run_twin(self, dst, refs, prep, coef, mask=None):
+        """dav1d_hip_recon_list_run_twin: the frame's pixels also end up in dst's tiled twin (written by the launches themselves when
+        they can, by a retile pass otherwise); dst.pic.twin_ok is set."""
+        arr = (Picture * len(refs))(*[r.pic for r in refs])
+        p = None if prep is None else (prep.ptr if hasattr(prep, "ptr") else prep)
+        m = None if mask is None else (mask.ptr if hasattr(mask, "ptr") else mask)
+        _chk(self.ctx.lib.dav1d_hip_recon_list_run_twin(self.ctx.h, self.h, C.byref(dst.pic), arr, len(refs), p, m,
+                                                        coef.ptr if hasattr(coef, "ptr") else coef), "recon_list_run_twin")
 
     def destroy(self):
         if self.h:

@@ -52,6 +52,8 @@ struct Dav1dHipContext {
     size_t pending_slab_cap;
     hipStream_t copy_stream;
     hipEvent_t ev_copy;
+    hipEvent_t ev_retile;       // the end of the most recent overlapped retile (dav1d_hip_picture_retile_overlapped) ...
+    bool retile_pending;        // ... which the next launches that read twins have to wait for
     std::mutex run_mtx;         // one multi-stream section (recon list run, banded post filters) at a time per context
 };
 
@@ -161,9 +163,13 @@ static inline bool picture_twin_usable(const Dav1dHipPicture *p) {
 }
 // The planes motion compensation reads its references through: the tiled twins when the context uses them and EVERY reference
 // of the call has a valid one (a launch is one kernel variant: all tiled or all raster), the raster planes otherwise.
-static inline void ref_planes(const Dav1dHipContext *c, const Dav1dHipPicture *refs, int n_refs, DevPlanes *rp) {
+static inline void ref_planes(Dav1dHipContext *c, const Dav1dHipPicture *refs, int n_refs, DevPlanes *rp) {
     bool tiled = c->ref_twin != 0 && n_refs > 0;
     for (int i = 0; i < n_refs && tiled; i++) tiled = picture_twin_usable(&refs[i]);
+    if (tiled && c->retile_pending) {          // a twin of this context may still be on its way on the side stream
+        (void) hipStreamWaitEvent(c->stream, c->ev_retile, 0);
+        c->retile_pending = false;
+    }
     for (int i = 0; i < n_refs; i++) {
         rp[i] = dev_planes(&refs[i]);
         if (tiled) {
@@ -211,6 +217,13 @@ struct McGroup {
 };
 extern "C" int dav1d_hip_launch_recon_fused(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, int cls, const McTile *tiles,
                                             const Dav1dHipItxTask *tasks, int n, int16_t *prep, void *coef, int coop_below, void *stream);
+extern "C" int dav1d_hip_launch_recon_fused_out(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, int cls, const McTile *tiles,
+                                                const Dav1dHipItxTask *tasks, int n, int16_t *prep, void *coef, int coop_below, int wide,
+                                                const DevPlanes *dst_twin, void *stream);
+extern "C" int dav1d_hip_launch_mc_bin_twin(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, int cls,
+                                            const McTile *tiles, int n, int16_t *prep, const DevPlanes *dst_twin, void *stream);
+extern "C" int dav1d_hip_launch_itx_bin_out(const DevPlanes *dst, int bpc, int tx, const Dav1dHipItxTask *tasks, int n, void *coef, int wide,
+                                            const DevPlanes *dst_twin, void *stream);
 extern "C" int dav1d_hip_launch_mc_all(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, const McTile *tiles,
                                        const McGroup *groups, int n_groups, int with_small, int16_t *prep, void *stream);
 extern "C" int dav1d_hip_launch_mc_bin(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, int cls,

@@ -68,6 +68,8 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     for (int i = 0; i < 16; i++)
         if (hipEventCreateWithFlags(&c->ev_bin[i], hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
     if (hipEventCreate(&c->ev_t0) != hipSuccess || hipEventCreate(&c->ev_t1) != hipSuccess) { delete c; return -ENODEV; }
+    if (hipEventCreateWithFlags(&c->ev_retile, hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
+    c->retile_pending = false;
     c->last_ms = 0.f;
     c->gather_dev = c->segtab_dev = c->pending_slab = nullptr;
     c->gather_cap = c->segtab_cap = c->pending_slab_cap = 0;
@@ -85,7 +87,7 @@ void dav1d_hip_close(Dav1dHipContext *c) {
     for (int i = 0; i < Dav1dHipContext::N_SIDE; i++) { hipStreamSynchronize(c->side[i]); hipStreamDestroy(c->side[i]); hipEventDestroy(c->ev_join[i]); }
     hipEventDestroy(c->ev_fork);
     for (int i = 0; i < 16; i++) hipEventDestroy(c->ev_bin[i]);
-    hipEventDestroy(c->ev_t0); hipEventDestroy(c->ev_t1);
+    hipEventDestroy(c->ev_t0); hipEventDestroy(c->ev_t1); hipEventDestroy(c->ev_retile);
     hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); hipEventDestroy(c->ev_copy);
     for (const Dav1dHipContext::Arena &ar : c->free_arenas) hipFree(ar.dev);
     for (const Dav1dHipContext::Arena &ar : c->free_task_bufs) hipFree(ar.dev);
@@ -98,7 +100,10 @@ void dav1d_hip_close(Dav1dHipContext *c) {
     delete c;
 }
 
-int dav1d_hip_sync(Dav1dHipContext *c) { return hip_rc(hipStreamSynchronize(c->stream)); }
+int dav1d_hip_sync(Dav1dHipContext *c) {
+    if (c->retile_pending) { (void) hipEventSynchronize(c->ev_retile); c->retile_pending = false; }
+    return hip_rc(hipStreamSynchronize(c->stream));
+}
 void *dav1d_hip_stream(Dav1dHipContext *c) { return (void *) c->stream; }
 
 // ---- recorded launch sequences (hipGraph)
@@ -264,6 +269,8 @@ void dav1d_hip_picture_give(Dav1dHipContext *c, Dav1dHipPicture *pic) {
     (void) dav1d_hip_picture_free(c, pic);
 }
 
+extern "C" int dav1d_hip_launch_retile(const DevPlanes *src, void *const twin[3], int bpc, void *stream);
+
 // Storage for the tiled twin: per plane stride x (height rounded up to 8 rows) bytes, the planes one after the other.
 int dav1d_hip_picture_twin_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic) {
     if (!c || !pic || !pic->p[0].data) return -EINVAL;
@@ -288,6 +295,28 @@ int dav1d_hip_picture_twin_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic) {
 }
 
 extern "C" int dav1d_hip_launch_retile(const DevPlanes *src, void *const twin[3], int bpc, void *stream);
+
+// The same on a side stream of the context: the copy starts when the work enqueued so far is through and runs NEXT TO whatever the
+// caller enqueues afterwards (the next frame's launches: they are bound by request latency and arithmetic, the copy by bandwidth).
+// Launches of this context that read twins wait for it (ref_planes); dav1d_hip_sync does too.
+int dav1d_hip_picture_retile_overlapped(Dav1dHipContext *c, Dav1dHipPicture *pic) {
+    if (!c || !pic) return -EINVAL;
+    if (!c->concurrent) return dav1d_hip_picture_retile(c, pic);
+    if (!pic->twin_alloc && !pic->twin[0]) {
+        const int rc = dav1d_hip_picture_twin_alloc(c, pic);
+        if (rc) return rc;
+    }
+    hipStream_t side = c->side[Dav1dHipContext::N_SIDE - 1];
+    HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+    HIP_TRY(hipStreamWaitEvent(side, c->ev_fork, 0));
+    const DevPlanes sp = dev_planes(pic);
+    const int rc = dav1d_hip_launch_retile(&sp, pic->twin, pic->bpc, side);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(c->ev_retile, side));
+    c->retile_pending = true;
+    pic->twin_ok = 1;
+    return 0;
+}
 
 int dav1d_hip_picture_retile(Dav1dHipContext *c, Dav1dHipPicture *pic) {
     if (!c || !pic) return -EINVAL;
@@ -1614,7 +1643,9 @@ int dav1d_hip_recon_list_create(Dav1dHipContext *c, Dav1dHipReconList **out, con
     for (size_t i = 0; i < n_itx; i++) if (!itx_task_ok(itx[i])) return -EINVAL;
     Dav1dHipReconList *l = new (std::nothrow) Dav1dHipReconList();
     if (!l) return -ENOMEM;
-    l->inter = nullptr; l->itx = nullptr;
+    const Dav1dHipItxTask *const itx_all = itx;
+    const size_t n_itx_all = n_itx;
+    l->inter = nullptr; l->itx = nullptr; l->wide_ok = false;
     for (int k = 0; k < 5; k++) { l->f_tiles[k] = nullptr; l->f_tasks[k] = nullptr; l->f_n[k] = 0; }
     l->f_max_ref = 0;
     ReconPairing pair;
@@ -1689,6 +1720,12 @@ int dav1d_hip_recon_list_create(Dav1dHipContext *c, Dav1dHipReconList **out, con
     if (rc) { dav1d_hip_recon_list_destroy(c, l); return rc; }
     for (int b = 0; b < 19; b++) l->dep[b] = 0;
     for (int p = 0; p < 3; p++) l->stride_px[p] = l->inter->stride_px[p];
+    l->wide_ok = true;
+    for (size_t i = 0; i < n_itx_all && l->wide_ok; i++) {
+        const Dav1dHipItxTask &t = itx_all[i];
+        const int sp = l->stride_px[t.plane];
+        l->wide_ok = sp > 0 && (int) (t.dst_off % (uint32_t) sp) % std::min((int) k_tx_w[t.tx], 8) == 0 && sp % 8 == 0;
+    }
     for (size_t i = 0; i < n_itx; i++) {
         const Dav1dHipItxTask &t = itx[i];
         const int sp = l->stride_px[t.plane], cs = l->inter->cell_stride[t.plane];
@@ -1718,8 +1755,43 @@ void dav1d_hip_recon_list_destroy(Dav1dHipContext *c, Dav1dHipReconList *l) {
     delete l;
 }
 
+static int recon_list_run_impl(Dav1dHipContext *c, const Dav1dHipReconList *l, const Dav1dHipPicture *dst, const Dav1dHipPicture *refs, int n_refs,
+                               int16_t *prep, uint8_t *mask, void *coef, bool wide, const DevPlanes *dst_twin);
+
 int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, const Dav1dHipPicture *dst,
                              const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask, void *coef) {
+    return recon_list_run_impl(c, l, dst, refs, n_refs, prep, mask, coef, false, nullptr);
+}
+
+// The same, and the picture's tiled twin (Dav1dHipPicture.twin) holds the frame's pixels afterwards: the step of a frame whose in-loop
+// filters are off, as later frames will predict from it.  When every launch of the list can write the twin along with the raster
+// planes — tiled references, blocks on the 8-pixel grid, no mask / blend tasks (those go through a kernel that only knows raster
+// planes) — it is written by the launches themselves (the paired kernels and the residual kernels through tile_write_out, the
+// prediction kernels strip by strip); otherwise the list runs as always and dav1d_hip_picture_retile follows.  Sets dst->twin_ok.
+int dav1d_hip_recon_list_run_twin(Dav1dHipContext *c, const Dav1dHipReconList *l, Dav1dHipPicture *dst,
+                                  const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask, void *coef) {
+    if (!c || !l || !dst || !refs) return -EINVAL;
+    if (!dst->twin[0] && !dst->twin_alloc) { const int rc = dav1d_hip_picture_twin_alloc(c, dst); if (rc) return rc; }
+    bool direct = c->ref_twin != 0 && l->wide_ok && !l->inter->comp->n && mc_fused_min_bin() >= MC_BINS;
+    const int bps = dst->bpc > 8 ? 2 : 1;
+    for (int p = 0; p < 3 && direct; p++)
+        if (dst->p[p].data) direct = dst->twin[p] && !((uintptr_t) dst->p[p].data & 15) && !((uintptr_t) dst->twin[p] & 15) && dst->p[p].stride % 16 == 0 &&
+                                     (dst->p[p].stride / bps) % 8 == 0;
+    for (int i = 0; i < n_refs && direct; i++) direct = picture_twin_usable(&refs[i]);
+    dst->twin_ok = 0;
+    if (direct) {
+        DevPlanes tw = dev_planes(dst);
+        for (int p = 0; p < 3; p++) tw.data[p] = dst->p[p].data ? dst->twin[p] : nullptr;
+        const int rc = recon_list_run_impl(c, l, dst, refs, n_refs, prep, mask, coef, true, &tw);
+        if (!rc) dst->twin_ok = 1;
+        return rc;
+    }
+    const int rc = recon_list_run_impl(c, l, dst, refs, n_refs, prep, mask, coef, false, nullptr);
+    return rc ? rc : dav1d_hip_picture_retile(c, dst);
+}
+
+static int recon_list_run_impl(Dav1dHipContext *c, const Dav1dHipReconList *l, const Dav1dHipPicture *dst, const Dav1dHipPicture *refs, int n_refs,
+                               int16_t *prep, uint8_t *mask, void *coef, const bool wide, const DevPlanes *dst_twin) {
     if (!c || !l || !dst || !refs) return -EINVAL;
     const int bps = dst->bpc > 8 ? 2 : 1;
     for (int p = 0; p < 3; p++)
@@ -1748,8 +1820,8 @@ int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, con
         }
         for (int k = 4; k >= 0 && !rc; k--)
             if (l->f_n[k]) {
-                rc = dav1d_hip_launch_recon_fused(&dp, rp, n_refs, dst->bpc, k, l->f_tiles[k], l->f_tasks[k], (int) l->f_n[k], prep, coef, c->recon_coop_below,
-                                                  side ? c->side[ps[lane]] : c->stream);
+                rc = dav1d_hip_launch_recon_fused_out(&dp, rp, n_refs, dst->bpc, k, l->f_tiles[k], l->f_tasks[k], (int) l->f_n[k], prep, coef, c->recon_coop_below,
+                                                      wide, dst_twin, side ? c->side[ps[lane]] : c->stream);
                 lane ^= 1;
             }
         if (side) {
@@ -1769,7 +1841,7 @@ int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, con
     auto join_paired = [&]() {
         if (paired_on_side) { (void) hipStreamWaitEvent(c->stream, c->ev_join[1], 0); (void) hipStreamWaitEvent(c->stream, c->ev_join[2], 0); }
     };
-    if (min_tasks < 0 || !c->concurrent || mc_fused_min_bin() < MC_BINS || (long) l->itx->n < min_tasks) {
+    if (!dst_twin && (min_tasks < 0 || !c->concurrent || mc_fused_min_bin() < MC_BINS || (long) l->itx->n < min_tasks)) {
         int rc = dav1d_hip_inter_list_run(c, l->inter, dst, refs, n_refs, prep, mask);
         if (!rc) rc = dav1d_hip_itx_list_run(c, l->itx, dst, coef);
         join_paired();
@@ -1809,6 +1881,7 @@ int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, con
     for (int k = 0; k < n_seq && !rc; k++) {
         const int b = seq[k];
         if (b == 15) rc = dav1d_hip_comp_list_run(c, l->inter->comp, dst, prep, mask);
+        else if (dst_twin) rc = dav1d_hip_launch_mc_bin_twin(&dp, rp, n_refs, dst->bpc, b, ml->dev + ml->off[b], (int) (ml->off[b + 1] - ml->off[b]), prep, dst_twin, sm);
         else rc = dav1d_hip_launch_mc_bin(&dp, rp, n_refs, dst->bpc, b, ml->dev + ml->off[b], (int) (ml->off[b + 1] - ml->off[b]), prep, sm);
         if (wanted[k]) (void) hipEventRecord(c->ev_bin[k], sm);
     }
@@ -1828,7 +1901,7 @@ int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, con
             (void) hipStreamWaitEvent(si, c->ev_bin[last_dep[b]], 0);
             waited[lane] = last_dep[b];
         }
-        rc = dav1d_hip_launch_itx_bin(&dp, dst->bpc, b, l->itx->dev + l->itx->off[b], (int) cnt, coef, si);
+        rc = dav1d_hip_launch_itx_bin_out(&dp, dst->bpc, b, l->itx->dev + l->itx->off[b], (int) cnt, coef, wide, dst_twin, si);
         lane = (lane + 1) % n_lanes;
     }
     for (int i = 0; i < n_lanes; i++) {

@@ -265,6 +265,17 @@ struct PxRead {
     __device__ __forceinline__ PxRead operator-(const int k) const { return PxRead{ p - k }; }
 };
 
+// x, y of a pixel offset in a plane (off < 2^28, stride < 2^15) without the integer divider: one float quotient, corrected
+__device__ __forceinline__ void off_to_xy(const uint32_t off, const int stride, int &x, int &y) {
+    int q = (int) ((float) off / (float) stride);
+    int r = (int) off - q * stride;
+    if (r < 0) { q--; r += stride; }
+    if (r < 0) { q--; r += stride; }
+    if (r >= stride) { q++; r -= stride; }
+    if (r >= stride) { q++; r -= stride; }
+    x = r; y = q;
+}
+
 // LDS hand-off between the lanes of ONE wave (no other wave reads the data): order the
 // accesses and let the wave's outstanding LDS operations land; no s_barrier involved, so
 // waves of a workgroup never wait for each other.

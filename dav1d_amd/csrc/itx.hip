@@ -15,6 +15,7 @@
 // row pass reads it transposed, and the same LDS region then becomes the transpose buffer.
 #include "itx_body.h"
 #include "capi.h"
+#include <string.h>
 
 namespace {
 
@@ -24,6 +25,25 @@ __global__ __launch_bounds__(64) void itx_add_kernel(const DevPlanes dst, const 
 {
     __shared__ __attribute__((aligned(16))) int tmp_s[itx_lds_ints<TX>()];
     itx_body<TX, pixel, coef>(dst, tasks, n, cf, bitdepth_max, (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x), tmp_s);
+}
+
+// The same with the sums leaving through an LDS tile in row pieces (tile_write_out, itx_body.h) — to the raster planes and, when
+// `twin` has planes, to the picture's tiled twin.  The tile shares its memory with the transpose buffer: every lane has its column in
+// registers before the first sum is written (itx_body's COH form).
+template <int TX, typename pixel, typename coef>
+__global__ __launch_bounds__(64) void itx_add_wide_kernel(const DevPlanes dst, const Dav1dHipItxTask *__restrict__ tasks,
+                                                          const int n, coef *__restrict__ cf, const int bitdepth_max, const DevPlanes twin)
+{
+    constexpr int W = tx_w(TX), H = tx_h(TX), LPB = cmax(cmin(H, 32), W), BPW = 64 / LPB;
+    static_assert(BPW * W * H * (int) sizeof(pixel) <= itx_lds_ints<TX>() * 4, "the tile fits the transpose buffer");
+    __shared__ __attribute__((aligned(16))) int tmp_s[itx_lds_ints<TX>()];
+    pixel *const tile = reinterpret_cast<pixel *>(tmp_s);
+    const int group = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x);
+    const int block0 = group * BPW;
+    if (block0 >= n) return;
+    itx_body<TX, pixel, coef, false, true>(dst, tasks, n, cf, bitdepth_max, group, tmp_s, tile);
+    dv::wave_sync();
+    tile_write_out<W, H, BPW, pixel>(tile, tasks + block0, dv::imin(BPW, n - block0), dst, twin, twin.data[0] != nullptr);
 }
 
 // Every transform size in one launch, for the short lists of an intra wavefront step (a few hundred blocks of up to
@@ -53,6 +73,26 @@ __global__ __launch_bounds__(64) void itx_multi_kernel(const DevPlanes dst, cons
         CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18)
     }
 #undef CASE
+}
+
+template <typename pixel, typename coef>
+hipError_t launch_tx_wide(const int tx, const DevPlanes &dst, const Dav1dHipItxTask *tasks, const int n,
+                          coef *cf, const int bitdepth_max, const DevPlanes &twin, hipStream_t stream)
+{
+#define CASE(T) case T: { \
+        constexpr int lpb = cmax(cmin(tx_h(T), 32), tx_w(T)); \
+        constexpr int bpw = 64 / lpb; \
+        const int grid = (n + bpw - 1) / bpw; \
+        hipLaunchKernelGGL((itx_add_wide_kernel<T, pixel, coef>), dim3(grid), dim3(64), 0, stream, \
+                           dst, tasks, n, cf, bitdepth_max, twin); \
+        break; }
+    switch (tx) {
+        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9)
+        CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18)
+        default: return hipErrorInvalidValue;
+    }
+#undef CASE
+    return hipGetLastError();
 }
 
 template <typename pixel, typename coef>
@@ -111,5 +151,21 @@ extern "C" int dav1d_hip_launch_itx_bin(const DevPlanes *dst, int bpc, int tx, c
     hipError_t e;
     if (bpc == 8) e = launch_tx<uint8_t, int16_t>(tx, *dst, tasks, n, (int16_t *) coef, bitdepth_max, (hipStream_t) stream);
     else          e = launch_tx<uint16_t, int32_t>(tx, *dst, tasks, n, (int32_t *) coef, bitdepth_max, (hipStream_t) stream);
+    return e == hipSuccess ? 0 : -5;
+}
+
+// the same with wide stores (wide != 0) and, optionally, the tiled twin of dst written along (dst_twin != NULL, needs wide)
+extern "C" int dav1d_hip_launch_itx_bin_out(const DevPlanes *dst, int bpc, int tx, const Dav1dHipItxTask *tasks, int n, void *coef, int wide,
+                                            const DevPlanes *dst_twin, void *stream)
+{
+    if (!wide) return dst_twin ? -EINVAL : dav1d_hip_launch_itx_bin(dst, bpc, tx, tasks, n, coef, stream);
+    if (n <= 0) return 0;
+    const int bitdepth_max = (1 << bpc) - 1;
+    DevPlanes twin;
+    memset(&twin, 0, sizeof(twin));
+    if (dst_twin) twin = *dst_twin;
+    hipError_t e;
+    if (bpc == 8) e = launch_tx_wide<uint8_t, int16_t>(tx, *dst, tasks, n, (int16_t *) coef, bitdepth_max, twin, (hipStream_t) stream);
+    else          e = launch_tx_wide<uint16_t, int32_t>(tx, *dst, tasks, n, (int32_t *) coef, bitdepth_max, twin, (hipStream_t) stream);
     return e == hipSuccess ? 0 : -5;
 }

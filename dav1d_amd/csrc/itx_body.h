@@ -4,6 +4,7 @@
 #include "common.h"
 #include "itx1d.h"
 #include "av1_scan_dev.h"
+#include <type_traits>
 
 namespace {
 
@@ -275,5 +276,51 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
     }
 }
 
+
+// ---- reconstructed blocks from an LDS tile to the picture in wide pieces (and, optionally, to the picture's tiled twin)
+//
+// The column pass leaves a lane with a COLUMN of its block: written from there, a W x H block costs H two-byte stores per lane.
+// Through the tile (itx_body's COH form: the sums go back to LDS, [block][row][W pixels]) every lane instead takes row pieces of
+// up to 8 pixels — 16 bytes at 10 / 12 bits — and stores each once to the raster plane and, when the picture has a tiled twin
+// (Dav1dHipPicture.twin: 8x8 tiles of 64 consecutive pixels, mc_body.h), once to the twin: a piece is a whole tile row there, an
+// 8x8 block one 128-byte line.
+
+template <int W, int H, int BPW, typename pixel>
+__device__ __forceinline__ void tile_write_out(const pixel *tile, const Dav1dHipItxTask *__restrict__ tasks, const int nb,
+                                               const DevPlanes &dst, const DevPlanes &twin, const bool has_twin)
+{
+    constexpr int CP = W < 8 ? W : 8;                   // pixels per piece: inside one row of one 8x8 tile
+    constexpr int CPR = W / CP, PER_BLOCK = H * CPR, NCHK = BPW * PER_BLOCK;
+    constexpr int BYTES = CP * (int) sizeof(pixel);
+    typedef typename std::conditional<BYTES == 16, uint4, typename std::conditional<BYTES == 8, uint2, uint32_t>::type>::type piece_t;
+    static_assert(BYTES == 4 || BYTES == 8 || BYTES == 16, "piece size");
+    const int lane = threadIdx.x & 63;
+    // lane b knows block b: plane and position, handed to the lanes that store the block's pieces by wave shuffles
+    int bx = 0, by = 0, bpl = 0;
+    if (lane < nb) {
+        const Dav1dHipItxTask t = tasks[lane];
+        bpl = t.plane;
+        dv::off_to_xy(t.dst_off, bpl == 0 ? dst.stride[0] : bpl == 1 ? dst.stride[1] : dst.stride[2], bx, by);
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < NCHK; i0 += 64) {
+        const int i = i0 + lane;
+        const int b = BPW == 1 ? 0 : (i / PER_BLOCK) & (BPW - 1), rem = i - (i / PER_BLOCK) * PER_BLOCK;
+        const int y = rem / CPR, c = rem - y * CPR;
+        const int x0 = BPW == 1 ? __builtin_amdgcn_readfirstlane(bx) : __shfl(bx, b);
+        const int y0 = BPW == 1 ? __builtin_amdgcn_readfirstlane(by) : __shfl(by, b);
+        const int pl = BPW == 1 ? __builtin_amdgcn_readfirstlane(bpl) : __shfl(bpl, b);
+        if (i >= NCHK || i / PER_BLOCK >= nb) continue;
+        const piece_t v = *reinterpret_cast<const piece_t *>(tile + (b * H + y) * W + c * CP);
+        const int X = x0 + c * CP, Y = y0 + y;
+        const int stride = pl == 0 ? dst.stride[0] : pl == 1 ? dst.stride[1] : dst.stride[2];
+        pixel *const base = reinterpret_cast<pixel *>(pl == 0 ? dst.data[0] : pl == 1 ? dst.data[1] : dst.data[2]);
+        *reinterpret_cast<piece_t *>(base + (dv::mul_i24(Y, stride) + X)) = v;
+        if (has_twin) {      // (kernel arguments are never indexed by a run-time value nor have their address taken: either sends them to scratch memory)
+            pixel *const tb = reinterpret_cast<pixel *>(pl == 0 ? twin.data[0] : pl == 1 ? twin.data[1] : twin.data[2]);
+            *reinterpret_cast<piece_t *>(tb + (dv::mul_i24(Y & ~7, stride) + ((X >> 3) << 6) + ((Y & 7) << 3) + (X & 7))) = v;
+        }
+    }
+}
 
 } // namespace

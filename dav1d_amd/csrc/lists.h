@@ -50,6 +50,8 @@ struct Dav1dHipReconList {
     Dav1dHipItxTask *f_tasks[5];
     size_t f_n[5];
     int f_max_ref;
+    bool wide_ok;              // every transform block starts at a multiple of min(its width, 8) pixels: the blocks may leave through
+                               // tile_write_out (itx_body.h) in aligned row pieces.  Always so for AV1 geometry; checked because lists are an API
 };
 
 bool itx_task_ok(const Dav1dHipItxTask &t);

@@ -45,6 +45,18 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSe
     mc_body<TW, TH, pixel, false, TILED>(dst, refs, tiles, t0, dv::imin(G, n - t0), prep, bitdepth_max, smem);
 }
 
+// TILED references and the picture's own tiled twin written along with the raster planes (mc_body.h, TWIN)
+template <int TW, int TH, typename pixel>
+__global__ __launch_bounds__(64) void mc_twin_kernel(const DevPlanes dst, const RefSet refs, const McTile *__restrict__ tiles,
+                                                     const int n, int16_t *__restrict__ prep, const int bitdepth_max, const DevPlanes twin)
+{
+    constexpr int G = 64 / mc_cmin(64, TW * TH / 4);
+    __shared__ uint4 smem[(mc_lds_bytes<TW, TH, true>() + 15) / 16];
+    const int t0 = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x) * G;
+    if (t0 >= n) return;
+    mc_body<TW, TH, pixel, false, true, true>(dst, refs, tiles, t0, dv::imin(G, n - t0), prep, bitdepth_max, smem, nullptr, 0, 0, 0, 0, twin);
+}
+
 // every tile shape in one launch: the tiles are ordered by where they read (all shapes interleaved, see
 // mc_list_from_bins) and cut into wave-sized groups of one shape, so that the lines one shape pulls into an
 // XCD's L2 are still there when its neighbours of other shapes need them
@@ -107,6 +119,46 @@ hipError_t launch_cls(const int cls, const DevPlanes &dst, const RefSet &refs, c
     return hipGetLastError();
 }
 
+template <typename pixel>
+hipError_t launch_cls_twin(const int cls, const DevPlanes &dst, const RefSet &refs, const McTile *tiles, const int n,
+                           int16_t *prep, const int bitdepth_max, const DevPlanes &twin, hipStream_t stream)
+{
+#define CASE(C, TW, TH) case C: { \
+        constexpr int lpt = mc_cmin(64, TW * TH / 4); \
+        constexpr int g = 64 / lpt; \
+        hipLaunchKernelGGL((mc_twin_kernel<TW, TH, pixel>), dim3((n + g - 1) / g), dim3(64), 0, stream, \
+                           dst, refs, tiles, n, prep, bitdepth_max, twin); \
+        break; }
+    switch (cls) {
+        CASE(0, 4, 4) CASE(1, 4, 8) CASE(2, 4, 16)
+        CASE(3, 8, 4) CASE(4, 8, 8) CASE(5, 8, 16)
+        CASE(6, 16, 4) CASE(7, 16, 8) CASE(8, 16, 16)
+        CASE(9, 32, 4) CASE(10, 32, 8) CASE(11, 32, 16)
+        CASE(12, 64, 4) CASE(13, 64, 8) CASE(14, 64, 16)
+        default: return hipErrorInvalidValue;
+    }
+#undef CASE
+    return hipGetLastError();
+}
+
+} // namespace
+
+// with the tiled twin of dst written along (tiled references only: the twin form exists for the TILED kernels)
+extern "C" int dav1d_hip_launch_mc_bin_twin(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, int cls,
+                                            const McTile *tiles, int n, int16_t *prep, const DevPlanes *dst_twin, void *stream)
+{
+    if (n <= 0) return 0;
+    if (!dst_twin || refs_tiled(refs, n_refs) != 1) return -EINVAL;
+    RefSet rs;
+    for (int i = 0; i < 8; i++) rs.r[i] = refs[i < n_refs ? i : 0];
+    const int bitdepth_max = (1 << bpc) - 1;
+    hipError_t e;
+    if (bpc == 8) e = launch_cls_twin<uint8_t>(cls, *dst, rs, tiles, n, prep, bitdepth_max, *dst_twin, (hipStream_t) stream);
+    else          e = launch_cls_twin<uint16_t>(cls, *dst, rs, tiles, n, prep, bitdepth_max, *dst_twin, (hipStream_t) stream);
+    return hip_rc(e);
+}
+
+namespace {
 } // namespace
 
 extern "C" int dav1d_hip_launch_mc_bin(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, int cls,

@@ -64,11 +64,13 @@ constexpr int mc_lds_bytes() {
 // or two per ROW (a raster row of 48 bytes costs 1.4 lines: measured, profiles/r02_calib_fetch_size.txt) — for an 8x8 block 7.6
 // lines instead of 18.  The gather fetches whole tile rows (aligned 16-byte pieces; 8 consecutive lanes = the 8 rows of one tile =
 // one line), and the horizontal pass picks its taps by the parity of the window's offset inside the piece instead of shifting data.
-template <int TW, int TH, typename pixel, bool TO_LDS = false, bool TILED = false>
+// TWIN: pixels that go to the picture (PUT / AVG / WAVG tiles outside the paired kernels) go to the planes of its tiled twin as well
+// (`twin`: same strides; every 4-pixel strip lies inside one tile row).
+template <int TW, int TH, typename pixel, bool TO_LDS = false, bool TILED = false, bool TWIN = false>
 __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs, const McTile *__restrict__ tiles, const int t0, const int nt,
                                         int16_t *__restrict__ prep, const int bitdepth_max, uint4 *smem,
                                         pixel *pred_s = nullptr, const int pred_tile0 = 0, const int pred_tpb_log2 = 0,
-                                        const int pred_w = 0, const int pred_h = 0)
+                                        const int pred_w = 0, const int pred_h = 0, const DevPlanes &twin = DevPlanes())
 {
     constexpr int NS = TW / 4;                          // 4-pixel strips per row
     constexpr int LPT = mc_cmin(64, TW * TH / 4);       // lanes per tile
@@ -429,6 +431,9 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
     }
 
     // ---- combine + store
+    int tbx = 0, tby = 0;          // TWIN: the block's position in its plane
+    const int tstride = t.plane == 0 ? dst.stride[0] : t.plane == 1 ? dst.stride[1] : dst.stride[2];
+    if (TWIN && live && t.kind != MCT_PREP && t.kind != MCT_PUT_TMP) dv::off_to_xy(t.dst_off, tstride, tbx, tby);
     if (live) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -461,6 +466,17 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
                     else *reinterpret_cast<uint32_t *>(d) = (uint32_t) o[0] | ((uint32_t) o[1] << 8) | ((uint32_t) o[2] << 16) | ((uint32_t) o[3] << 24);
                 } else if (nvalid > 0) {
                     for (int x = 0; x < nvalid; x++) d[x] = (pixel) o[x];
+                }
+                if (TWIN && !TO_LDS && t.kind != MCT_PUT_TMP && nvalid > 0) {
+                    const int X = tbx + t.ox + 4 * vs, Y = tby + t.oy + vr;
+                    pixel *const td = reinterpret_cast<pixel *>(t.plane == 0 ? twin.data[0] : t.plane == 1 ? twin.data[1] : twin.data[2]) +
+                                      (dv::mul_i24(Y & ~7, tstride) + ((X >> 3) << 6) + ((Y & 7) << 3) + (X & 7));
+                    if (nvalid == 4) {
+                        if (HBD) *reinterpret_cast<uint2 *>(td) = make_uint2(dv::pack2(o[0], o[1]), dv::pack2(o[2], o[3]));
+                        else *reinterpret_cast<uint32_t *>(td) = (uint32_t) o[0] | ((uint32_t) o[1] << 8) | ((uint32_t) o[2] << 16) | ((uint32_t) o[3] << 24);
+                    } else {
+                        for (int x = 0; x < nvalid; x++) td[x] = (pixel) o[x];
+                    }
                 }
             } else {
                 int16_t *d = prep + t.dst_off + (t.oy + vr) * t.bw + t.ox + 4 * vs;

@@ -226,15 +226,26 @@ __global__ __launch_bounds__(64) void retile_kernel(const pixel *__restrict__ sr
                                                     const int n_xg)
 {
     typedef typename std::conditional<sizeof(pixel) == 2, uint4, uint2>::type piece_t;
+    constexpr int ROWS = 8;                   // tile rows (of 8 picture rows) per wave: 8 KB (4 KB) in flight per wave
     const int g = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x);
-    const int ty = g / n_xg, xg = g - ty * n_xg;
+    const int tyg = g / n_xg, xg = g - tyg * n_xg;
     const int lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
     const int x = xg * 64 + c * 8;
     if (x >= stride) return;
-    // rows below the plane (a caller-wrapped picture need not have them): the last row again
-    const int y = dv::imin(ty * 8 + r, h - 1);
-    const piece_t v = *reinterpret_cast<const piece_t *>(src + (size_t) y * stride + x);
-    *reinterpret_cast<piece_t *>(twin + (size_t) ty * 8 * stride + (size_t) (x >> 3) * 64 + r * 8) = v;
+    const int n_ty = (h + 7) >> 3;
+    piece_t v[ROWS];
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        const int ty = tyg * ROWS + k;
+        // rows below the plane (a caller-wrapped picture need not have them): the last row again
+        const int y = dv::imin(ty * 8 + r, h - 1);
+        v[k] = *reinterpret_cast<const piece_t *>(src + (size_t) y * stride + x);
+    }
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        const int ty = tyg * ROWS + k;
+        if (ty < n_ty) *reinterpret_cast<piece_t *>(twin + (size_t) ty * 8 * stride + (size_t) (x >> 3) * 64 + r * 8) = v[k];
+    }
 }
 } // namespace
 
@@ -242,7 +253,7 @@ extern "C" int dav1d_hip_launch_retile(const DevPlanes *src, void *const twin[3]
     for (int pl = 0; pl < 3; pl++) {
         if (!src->data[pl]) continue;
         if (!twin[pl] || src->stride[pl] % 8 || src->h[pl] <= 0) return -EINVAL;
-        const int n_xg = (src->stride[pl] + 63) / 64, n_ty = (src->h[pl] + 7) / 8;
+        const int n_xg = (src->stride[pl] + 63) / 64, n_ty = ((src->h[pl] + 7) / 8 + 7) / 8;      // 8 tile rows per wave
         const dim3 grid((unsigned) n_xg * (unsigned) n_ty), wave(64);
         if (bpc == 8)
             hipLaunchKernelGGL((retile_kernel<uint8_t>), grid, wave, 0, (hipStream_t) stream, (const uint8_t *) src->data[pl], (uint8_t *) twin[pl],

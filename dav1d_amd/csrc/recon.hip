@@ -12,6 +12,7 @@
 // (16, 8, 4, 2, 1) and predicts them tile group by tile group (tiles of <= 64x16, as in mc.hip).
 #include "mc_body.h"
 #include "itx_body.h"
+#include <string.h>
 
 namespace {
 
@@ -35,11 +36,13 @@ template <int CLS> constexpr int recon_waves() {
     return (BPW * TPB + G - 1) / G;
 }
 
-template <int CLS, typename pixel, typename coef, bool COOP, bool TILED>
+// WIDE: the reconstructed blocks leave through the LDS tile in row pieces of up to 16 bytes (tile_write_out, itx_body.h) instead of
+// two bytes per lane and row — and go to the picture's tiled twin as well when `twin` has planes (twin.data[0] != nullptr).
+template <int CLS, typename pixel, typename coef, bool COOP, bool TILED, bool WIDE>
 __global__ __launch_bounds__(COOP ? 64 * recon_waves<CLS>() : 64, COOP ? 1 : CLS == 1 ? 6 : RECON_WAVES)
 void recon_fused_kernel(const DevPlanes dst, const RefSet refs, const McTile *__restrict__ tiles,
                         const Dav1dHipItxTask *__restrict__ tasks, const int n_blocks,
-                        int16_t *__restrict__ prep, coef *__restrict__ cf, const int bitdepth_max)
+                        int16_t *__restrict__ prep, coef *__restrict__ cf, const int bitdepth_max, const DevPlanes twin)
 {
     constexpr int TX = CLS;                                  // TX_4X4 .. TX_64X64
     constexpr int W = 4 << CLS;
@@ -80,56 +83,84 @@ void recon_fused_kernel(const DevPlanes dst, const RefSet refs, const McTile *__
         __syncthreads();
         if (wave) return;
     }
-    itx_body<TX, pixel, coef, true>(dst, tasks, n_blocks, cf, bitdepth_max, group, smem_itx, pred);
+    if constexpr (WIDE) {
+        itx_body<TX, pixel, coef, true, true>(dst, tasks, n_blocks, cf, bitdepth_max, group, smem_itx, pred);
+        dv::wave_sync();
+        tile_write_out<W, W, BPW, pixel>(pred, tasks + block0, nb, dst, twin, twin.data[0] != nullptr);
+    } else {
+        itx_body<TX, pixel, coef, true>(dst, tasks, n_blocks, cf, bitdepth_max, group, smem_itx, pred);
+    }
 }
 
-template <int CLS, typename pixel, typename coef, bool TILED>
+template <int CLS, typename pixel, typename coef, bool TILED, bool WIDE>
 void launch_cls(const DevPlanes &dst, const RefSet &refs, const McTile *tiles, const Dav1dHipItxTask *tasks, const int n,
-                int16_t *prep, coef *cf, const int bitdepth_max, const int coop_below, hipStream_t stream)
+                int16_t *prep, coef *cf, const int bitdepth_max, const int coop_below, const DevPlanes &twin, hipStream_t stream)
 {
     constexpr int W = 4 << CLS, LPB = cmax(cmin(W, 32), W), BPW = 64 / LPB;
     const int groups = (n + BPW - 1) / BPW;
     if (recon_waves<CLS>() > 1 && groups < coop_below)
-        hipLaunchKernelGGL((recon_fused_kernel<CLS, pixel, coef, true, TILED>), dim3(groups), dim3(64 * recon_waves<CLS>()), 0, stream,
-                           dst, refs, tiles, tasks, n, prep, cf, bitdepth_max);
+        hipLaunchKernelGGL((recon_fused_kernel<CLS, pixel, coef, true, TILED, WIDE>), dim3(groups), dim3(64 * recon_waves<CLS>()), 0, stream,
+                           dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, twin);
     else
-        hipLaunchKernelGGL((recon_fused_kernel<CLS, pixel, coef, false, TILED>), dim3(groups), dim3(64), 0, stream,
-                           dst, refs, tiles, tasks, n, prep, cf, bitdepth_max);
+        hipLaunchKernelGGL((recon_fused_kernel<CLS, pixel, coef, false, TILED, WIDE>), dim3(groups), dim3(64), 0, stream,
+                           dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, twin);
 }
 
-template <typename pixel, typename coef, bool TILED>
+template <typename pixel, typename coef, bool TILED, bool WIDE>
 hipError_t launch_any(const int cls, const DevPlanes &dst, const RefSet &refs, const McTile *tiles, const Dav1dHipItxTask *tasks,
-                      const int n, int16_t *prep, coef *cf, const int bitdepth_max, const int coop_below, hipStream_t stream)
+                      const int n, int16_t *prep, coef *cf, const int bitdepth_max, const int coop_below, const DevPlanes &twin, hipStream_t stream)
 {
     switch (cls) {
-    case 0: launch_cls<0, pixel, coef, TILED>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, stream); break;
-    case 1: launch_cls<1, pixel, coef, TILED>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, stream); break;
-    case 2: launch_cls<2, pixel, coef, TILED>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, stream); break;
-    case 3: launch_cls<3, pixel, coef, TILED>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, stream); break;
-    case 4: launch_cls<4, pixel, coef, TILED>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, stream); break;
+    case 0: launch_cls<0, pixel, coef, TILED, WIDE>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, twin, stream); break;
+    case 1: launch_cls<1, pixel, coef, TILED, WIDE>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, twin, stream); break;
+    case 2: launch_cls<2, pixel, coef, TILED, WIDE>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, twin, stream); break;
+    case 3: launch_cls<3, pixel, coef, TILED, WIDE>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, twin, stream); break;
+    case 4: launch_cls<4, pixel, coef, TILED, WIDE>(dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, twin, stream); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
+template <typename pixel, typename coef>
+hipError_t launch_variant(const bool tiled, const bool wide, const int cls, const DevPlanes &dst, const RefSet &refs, const McTile *tiles,
+                          const Dav1dHipItxTask *tasks, const int n, int16_t *prep, coef *cf, const int bitdepth_max, const int coop_below,
+                          const DevPlanes &twin, hipStream_t st)
+{
+    if (tiled) return wide ? launch_any<pixel, coef, true, true>(cls, dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, twin, st)
+                           : launch_any<pixel, coef, true, false>(cls, dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, twin, st);
+    return wide ? launch_any<pixel, coef, false, true>(cls, dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, twin, st)
+                : launch_any<pixel, coef, false, false>(cls, dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, twin, st);
+}
+
 } // namespace
 
 // tiles[] / tasks[] (device): the n blocks of ONE square transform size cls = 0 (4x4) .. 4 (64x64); block i owns
-// tasks[i] and the (1, 1, 1, 2, 4) tiles starting at tiles[i * tiles_per_block].
-extern "C" int dav1d_hip_launch_recon_fused(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, int cls, const McTile *tiles,
-                                            const Dav1dHipItxTask *tasks, int n, int16_t *prep, void *coef, int coop_below, void *stream)
+// tasks[i] and the (1, 1, 1, 2, 4) tiles starting at tiles[i * tiles_per_block].  wide: the blocks leave through tile_write_out
+// (planes and strides must be 16-byte aligned: the caller checks); dst_twin (with wide; may be NULL): the planes of dst's tiled twin,
+// written along with the raster planes.
+extern "C" int dav1d_hip_launch_recon_fused_out(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, int cls, const McTile *tiles,
+                                                const Dav1dHipItxTask *tasks, int n, int16_t *prep, void *coef, int coop_below, int wide,
+                                                const DevPlanes *dst_twin, void *stream)
 {
     if (n <= 0) return 0;
+    if (dst_twin && !wide) return -EINVAL;
     RefSet rs;
     for (int i = 0; i < 8; i++) rs.r[i] = refs[i < n_refs ? i : 0];
     const int bitdepth_max = (1 << bpc) - 1;
     const int tiled = refs_tiled(refs, n_refs);
     if (tiled < 0) return -EINVAL;
+    DevPlanes twin;
+    memset(&twin, 0, sizeof(twin));
+    if (dst_twin) twin = *dst_twin;
     hipStream_t st = (hipStream_t) stream;
     hipError_t e;
-    if (bpc == 8) e = tiled ? launch_any<uint8_t, int16_t, true>(cls, *dst, rs, tiles, tasks, n, prep, (int16_t *) coef, bitdepth_max, coop_below, st)
-                            : launch_any<uint8_t, int16_t, false>(cls, *dst, rs, tiles, tasks, n, prep, (int16_t *) coef, bitdepth_max, coop_below, st);
-    else          e = tiled ? launch_any<uint16_t, int32_t, true>(cls, *dst, rs, tiles, tasks, n, prep, (int32_t *) coef, bitdepth_max, coop_below, st)
-                            : launch_any<uint16_t, int32_t, false>(cls, *dst, rs, tiles, tasks, n, prep, (int32_t *) coef, bitdepth_max, coop_below, st);
+    if (bpc == 8) e = launch_variant<uint8_t, int16_t>(tiled, wide, cls, *dst, rs, tiles, tasks, n, prep, (int16_t *) coef, bitdepth_max, coop_below, twin, st);
+    else          e = launch_variant<uint16_t, int32_t>(tiled, wide, cls, *dst, rs, tiles, tasks, n, prep, (int32_t *) coef, bitdepth_max, coop_below, twin, st);
     return hip_rc(e);
+}
+
+extern "C" int dav1d_hip_launch_recon_fused(const DevPlanes *dst, const DevPlanes *refs, int n_refs, int bpc, int cls, const McTile *tiles,
+                                            const Dav1dHipItxTask *tasks, int n, int16_t *prep, void *coef, int coop_below, void *stream)
+{
+    return dav1d_hip_launch_recon_fused_out(dst, refs, n_refs, bpc, cls, tiles, tasks, n, prep, coef, coop_below, 0, nullptr, stream);
 }

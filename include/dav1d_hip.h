@@ -130,6 +130,10 @@ DAV1D_HIP_API int dav1d_hip_picture_free(Dav1dHipContext *c, Dav1dHipPicture *pi
  * context's stream (asynchronous, like every launch) and sets twin_ok. */
 DAV1D_HIP_API int dav1d_hip_picture_twin_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic);
 DAV1D_HIP_API int dav1d_hip_picture_retile(Dav1dHipContext *c, Dav1dHipPicture *pic);
+/* ... on a side stream of the context: starts when what is enqueued so far is through, runs next to what is enqueued afterwards
+ * (the copy is bound by bandwidth, a frame's launches by request latency and arithmetic).  Launches of THIS context that read
+ * twins, and dav1d_hip_sync, wait for it; other contexts must not read the twin before this context has synchronised. */
+DAV1D_HIP_API int dav1d_hip_picture_retile_overlapped(Dav1dHipContext *c, Dav1dHipPicture *pic);
 /* The buffers behind a Dav1dPicAllocator (reference include/dav1d/picture.h:89-133, default implementation
  * src/picture.c:46-82): a decoded picture the application reads on the host — pinned memory, planes and strides laid out by the
  * rules of dav1d_default_picture_alloc (dimensions rounded up to 128, 64 more bytes of stride where it would be a multiple of
@@ -317,6 +321,12 @@ DAV1D_HIP_API int dav1d_hip_recon_list_create(Dav1dHipContext *c, Dav1dHipReconL
                                               const Dav1dHipItxTask *itx, size_t n_itx);
 DAV1D_HIP_API int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, const Dav1dHipPicture *dst,
                                            const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask, void *coef);
+/* The same for a frame whose in-loop filters are off and that later frames predict from: afterwards dst's tiled twin
+ * (Dav1dHipPicture.twin; the storage is made when missing) holds the frame's pixels and dst->twin_ok is set.  With tiled references,
+ * blocks on AV1's grid and no mask / blend tasks the launches write the twin along with the raster planes (no extra pass over the
+ * picture); otherwise the list runs as dav1d_hip_recon_list_run does and dav1d_hip_picture_retile follows. */
+DAV1D_HIP_API int dav1d_hip_recon_list_run_twin(Dav1dHipContext *c, const Dav1dHipReconList *l, Dav1dHipPicture *dst,
+                                                const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask, void *coef);
 DAV1D_HIP_API void dav1d_hip_recon_list_destroy(Dav1dHipContext *c, Dav1dHipReconList *l);
 /* Measurement aid (bench.py): every launch of the list on its own, bracketed by events.  ms / counts hold 40 entries:
  * [0..4] paired launches (prediction + residual in one wave) by square size 4x4 .. 64x64, [5..19] prediction launches by tile

@@ -59,7 +59,7 @@ def oracle_frame(oracle, frame, dst_planes, ref_planes_list, threads=1, timing=N
     return dst, prep, coef
 
 
-def hip_frame(ctx, frame, dst_planes, ref_planes_list, fused=False, packed=False, recon=False):
+def hip_frame(ctx, frame, dst_planes, ref_planes_list, fused=False, packed=False, recon=False, twin_out=False):
     w, h, bpc = frame.w, frame.h, frame.bpc
     dst = ctx.picture(w, h, api.LAYOUT_I420, bpc)
     for pl in range(3):
@@ -76,7 +76,12 @@ def hip_frame(ctx, frame, dst_planes, ref_planes_list, fused=False, packed=False
     coef = ctx.buffer_from(coef_host)
     if recon:
         rl = ctx.recon_list(dst, frame.mc, frame.comp, itx_tasks)
-        rl.run(dst, refs, prep, coef)
+        if twin_out:
+            rl.run_twin(dst, refs, prep, coef)
+            assert dst.pic.twin_ok
+            hip_frame.last_twin = [read_twin(ctx, dst, pl) for pl in range(3)]
+        else:
+            rl.run(dst, refs, prep, coef)
         rl.destroy()
     elif fused:
         il = ctx.inter_list(frame.mc, frame.comp)
@@ -98,6 +103,45 @@ def hip_frame(ctx, frame, dst_planes, ref_planes_list, fused=False, packed=False
     for o in [dst, prep, coef] + refs:
         o.free()
     return out, oprep, ocoef
+
+
+def read_twin(ctx, pic, plane):
+    """the tiled twin of a plane back in raster order (rows x stride), for comparisons"""
+    stride = pic.stride_px(plane)
+    rows = pic.padded_shape(plane)[0]
+    bps = np.dtype(pic.dtype).itemsize
+    ctx.sync()
+    raw = np.zeros(stride * ((pic.pic.p[plane].h + 7) & ~7), pic.dtype)
+    assert ctx.lib.dav1d_hip_download(ctx.h, raw.ctypes.data, pic.pic.twin[plane], raw.nbytes) == 0
+    t = raw.reshape(-1, stride // 8, 8, 8)             # [tile row][tile column][row in tile][column in tile]
+    return t.transpose(0, 2, 1, 3).reshape(-1, stride)[:rows]
+
+
+@pytest.mark.parametrize("refs_tiled", [True, False], ids=["launches-write-the-twin", "retile-after"])
+@pytest.mark.parametrize("bpc", [8, 10, 12])
+def test_recon_list_leaves_the_tiled_twin_of_its_picture(ctx, bpc, refs_tiled):
+    """dav1d_hip_recon_list_run_twin: the picture of a frame without in-loop filters as later frames will read it.  With tiled
+    references the paired, prediction and residual launches write the twin themselves (wide row pieces through tile_write_out, strips
+    from the prediction kernels); with raster references a retile pass follows.  Raster planes equal the oracle's, and the twin,
+    untiled, equals the raster planes over the visible area."""
+    ctx.auto_retile = refs_tiled
+    try:
+        w, h = (512, 128) if ctx.backend == "emu" else (1280, 1024)
+        frame = synth.make_frame(w, h, bpc, seed=915 + bpc, edge_frac=0.1)
+        rng = np.random.default_rng(19 + bpc)
+        refs = [synth.make_planes(rng, w, h, bpc) for _ in range(frame.n_refs)]
+        dst0 = synth.make_planes(rng, w, h, bpc, smooth=False)
+        want, _, want_coef = oracle_frame(util.default_oracle(), frame, dst0, refs)
+        got, _, got_coef = hip_frame(ctx, frame, dst0, refs, recon=True, twin_out=True)
+    finally:
+        ctx.auto_retile = False
+    assert np.array_equal(got_coef, want_coef)
+    for pl in range(3):
+        assert np.array_equal(got[pl], want[pl]), "plane %d differs from the oracle" % pl
+        vh, vw = (h, w) if pl == 0 else (h // 2, w // 2)
+        tw = hip_frame.last_twin[pl]
+        bad = np.argwhere(tw[:vh, :vw] != want[pl][:vh, :vw])
+        assert not len(bad), "twin of plane %d differs at %s (%d px)" % (pl, bad[0], len(bad))
 
 
 @pytest.mark.parametrize("fused", [False, True], ids=["twostep", "fused"])

@@ -66,7 +66,7 @@ def main():
     pics = {}
     only = [m for m in a.only.split(",") if m]
     retiled = False
-    for mode in ("raster", "tiled", "tiled+retile_dst"):
+    for mode in ("raster", "tiled", "tiled+retile_dst", "tiled+retile_dst_overlapped", "tiled+twin_written_by_the_launches"):
         if only and mode not in only:
             continue
         if mode != "raster" and not retiled:
@@ -75,21 +75,39 @@ def main():
             torch.cuda.synchronize()
             retiled = True
         fresh()
+        direct = mode.endswith("launches")
         for i in range(3):
-            rl.run(dsts[i % 4], refs, prep.data_ptr(), arenas[i].data_ptr())
+            (rl.run_twin if direct else rl.run)(dsts[i % 4], refs, prep.data_ptr(), arenas[i].data_ptr())
             if mode.endswith("dst"):
                 dsts[i % 4].retile()
+            elif mode.endswith("overlapped"):
+                dsts[i % 4].retile(True)
+        ctx.sync()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(3, 3 + a.steps):
-            rl.run(dsts[i % 4], refs, prep.data_ptr(), arenas[i].data_ptr())
+            (rl.run_twin if direct else rl.run)(dsts[i % 4], refs, prep.data_ptr(), arenas[i].data_ptr())
             if mode.endswith("dst"):
                 dsts[i % 4].retile()
+            elif mode.endswith("overlapped"):
+                dsts[i % 4].retile(True)
+        ctx.sync()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.steps * 1e3
         out[mode] = {"ms_per_step": round(dt, 4)}
         pics[mode] = [dsts[(2 + a.steps) % 4].download(pl) for pl in range(3)]
-        if a.no_kernels:
+        if direct:
+            # the twin the launches wrote, against a retile of the same picture
+            d = dsts[(2 + a.steps) % 4]
+            import ctypes as CC
+            nb = d.pic.p[0].stride * ((h + 7) & ~7)
+            t1 = np.zeros(nb, np.uint8); t2 = np.zeros(nb, np.uint8)
+            ctx.lib.dav1d_hip_sync(ctx.h)
+            ctx.lib.dav1d_hip_download(ctx.h, t1.ctypes.data, d.pic.twin[0], nb)
+            d.retile(); ctx.lib.dav1d_hip_sync(ctx.h)
+            ctx.lib.dav1d_hip_download(ctx.h, t2.ctypes.data, d.pic.twin[0], nb)
+            out[mode]["twin_equals_retile"] = bool(np.array_equal(t1, t2))
+        if a.no_kernels or direct:
             continue
         # per-kernel
         fresh()
@@ -116,6 +134,8 @@ def main():
     out["retile_ms"] = round(best, 4)
     if "raster" in pics and "tiled" in pics:
         out["parity_tiled_vs_raster"] = all(np.array_equal(pics["raster"][pl], pics["tiled"][pl]) for pl in range(3))
+    if "raster" in pics and "tiled+twin_written_by_the_launches" in pics:
+        out["parity_direct_vs_raster"] = all(np.array_equal(pics["raster"][pl], pics["tiled+twin_written_by_the_launches"][pl]) for pl in range(3))
     out["opts"] = a.opt + (["fuse=%d" % a.fuse] if a.fuse >= 0 else [])
     print(json.dumps(out))
 
