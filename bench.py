@@ -404,8 +404,7 @@ def main():
             ctx.run_inter_list(inter_list, d, refs, prep.data_ptr())
             ctx.run_itx_list(itx_list, d, arenas[i].data_ptr())
         if tile_cols and tc_post is not None:
-            ctx.sync()
-            dd.exchange_halo(d, cols, rank, world)
+            dd.exchange_halo(d, cols, rank, world)       # enqueued on the context's stream behind the reconstruction (dav1d_hip_peer_exchange_halo)
             pa, cdf, res = tc_post["all"], tc_post["cdf"], tc_post["res"]
             ctx.lf_batch(d.view, tc_post["lf"], tc_post["lvl"], pa.b4_stride, pa.lut_e, pa.lut_i)
             for pl in range(3):

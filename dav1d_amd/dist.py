@@ -1,6 +1,7 @@
-"""Multi-GPU plumbing of the frame-parallel mode: one process per GPU, frames
-sharded round-robin, no data-path collective.  torch.distributed (RCCL on GPUs, gloo in CPU tests)
-carries only the barrier and the max-over-ranks of the timed region."""
+"""Multi-GPU launch plumbing: one process per GPU.  The data-path collectives — picture broadcast for frames decoded
+elsewhere, the all-gather of tile columns, the halo exchange before the in-loop filters — are C entry points of the library
+(dav1d_hip_peer_*, csrc/peer.hip, RCCL over xGMI; a shared-memory stand-in in the SIMT-emulated build); torch.distributed (RCCL on GPUs,
+gloo in CPU tests) only carries the rendezvous of the peer id, the barrier and the max-over-ranks of the timed region."""
 import os
 
 
@@ -133,37 +134,66 @@ class SharedPicture:
         return a[:, :self.view.padded_shape(plane)[1]]
 
 
+# ---- the data-path collectives live behind the C ABI (csrc/peer.hip: dav1d_hip_peer_* on RCCL; one Dav1dHipPeer per process) -------
+# What stays here is launch plumbing: the rendezvous of the 128-byte id over torch.distributed and thin wrappers.
+
+_peers = {}
+
+
+def peer_of(ctx, rank, world):
+    """The process's Dav1dHipPeer for this context (made on first use: rank 0's id travels through torch.distributed once)."""
+    import ctypes as C
+    key = (id(ctx), rank, world)
+    p = _peers.get(key)
+    if p is None:
+        import torch.distributed as dist
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            rc = ctx.lib.dav1d_hip_peer_unique_id(ident)
+            if rc:
+                raise RuntimeError("dav1d_hip_peer_unique_id: %d" % rc)
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=0)
+        ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        rc = ctx.lib.dav1d_hip_peer_open(ctx.h, C.byref(h), ident, rank, world)
+        if rc:
+            raise RuntimeError("dav1d_hip_peer_open: %d" % rc)
+        p = h
+        _peers[key] = (h, ctx)
+        return p
+    return p[0]
+
+
+def close_peers():
+    """dav1d_hip_peer_close for every peer this process opened (before the contexts go)"""
+    for h, ctx in list(_peers.values()):
+        ctx.lib.dav1d_hip_peer_close(h)
+    _peers.clear()
+
+
+def _pic_of(pic):
+    return pic.pic if hasattr(pic, "pic") else pic
+
+
+def _ctx_of(pic):
+    return pic.view.ctx if hasattr(pic, "view") else pic.ctx
+
+
 def allgather_tile_columns(pic, cols, rank, world, ss_hor=1):
-    """After rank g reconstructed column g of `pic`: ONE all-gather per frame (all planes of a strip packed into one
-    message, strips padded to the widest column — SURVEY §8e) and every rank holds the whole picture."""
-    import torch
-    import torch.distributed as dist
+    """After rank g reconstructed column g of `pic`: ONE all-gather per frame (all planes of a strip packed into one message by a
+    strided copy kernel, strips padded to the widest column — SURVEY 8e) and every rank holds the whole picture
+    (dav1d_hip_peer_allgather_columns)."""
+    import ctypes as C
     if world == 1:
         return
     assert len(cols) == world, "one tile column per rank"
-    wmax = max(x1 - x0 for x0, x1 in cols)
-    shapes = [(p.shape[0], wmax >> (ss_hor if pl else 0)) for pl, p in enumerate(pic.planes)]
-    per = sum(r * c for r, c in shapes)
-    send = _buf(("col_send", per), per, pic.tdtype, pic.store.device)      # staging kept between frames (strips are not contiguous)
-
-    def strips(buf, k):
-        out, off = [], 0
-        x0, x1 = cols[k]
-        for pl, (r, c) in enumerate(shapes):
-            s = ss_hor if pl else 0
-            out.append((buf[off:off + r * c].view(r, c)[:, :(x1 - x0) >> s], x0 >> s, x1 >> s))
-            off += r * c
-        return out
-
-    for pl, (v, a, b) in enumerate(strips(send, rank)):
-        v.copy_(pic.planes[pl][:, a:b])
-    recv = _buf(("col_recv", per, world), world * per, pic.tdtype, pic.store.device)
-    dist.all_gather_into_tensor(recv.view(torch.uint8), send.view(torch.uint8))    # bytes: every backend moves uint8
-    for k in range(world):
-        if k == rank:
-            continue
-        for pl, (v, a, b) in enumerate(strips(recv[k * per:(k + 1) * per], k)):
-            pic.planes[pl][:, a:b].copy_(v)
+    ctx = _ctx_of(pic)
+    x0 = (C.c_int * world)(*[c[0] for c in cols])
+    x1 = (C.c_int * world)(*[c[1] for c in cols])
+    rc = ctx.lib.dav1d_hip_peer_allgather_columns(peer_of(ctx, rank, world), C.byref(_pic_of(pic)), x0, x1)
+    if rc:
+        raise RuntimeError("dav1d_hip_peer_allgather_columns: %d" % rc)
 
 
 # ---- tile-column mode, in-loop filters (SURVEY §8e): deblocking, CDEF and loop restoration read across the tile edge ------------
@@ -180,56 +210,20 @@ def allgather_tile_columns(pic, cols, rank, world, ss_hor=1):
 # done twice instead of a second and third exchange — and the final all-gather moves finished columns only.
 HALO = 16
 
-_buffers = {}
-
-
-def _buf(key, n, dtype, device):
-    import torch
-    b = _buffers.get(key)
-    if b is None or b.numel() < n or b.dtype != dtype or b.device != torch.device(device):
-        b = torch.empty(n, dtype=dtype, device=device)
-        _buffers[key] = b
-    return b[:n]
-
-
 def exchange_halo(pic, cols, rank, world, ss_hor=1, halo=HALO):
-    """After rank g reconstructed column g of `pic`: its neighbours' outermost `halo` luma columns (all planes) arrive next to
-    it.  One small all-gather (2 strips per rank: gloo and RCCL alike move it as bytes; 2 x 16 columns of an 8K frame are
-    0.4 MB per rank), staging buffers kept between frames."""
-    import torch
-    import torch.distributed as dist
+    """After rank g reconstructed column g of `pic`: its neighbours' outermost `halo` luma columns (all planes) arrive next to it
+    (dav1d_hip_peer_exchange_halo: both edge strips of a rank in one message, one small all-gather; 2 x 16 columns of an 8K frame are
+    0.4 MB per rank)."""
+    import ctypes as C
     if world == 1:
         return
     assert len(cols) == world
-    shapes = [(p.shape[0], halo >> (ss_hor if pl else 0)) for pl, p in enumerate(pic.planes)]
-    per = sum(r * c for r, c in shapes)
-    dev = pic.store.device
-    send = _buf(("halo_send", id(pic.store.device), per), 2 * per, pic.tdtype, dev)
-    recv = _buf(("halo_recv", id(pic.store.device), per, world), 2 * per * world, pic.tdtype, dev)
-    x0, x1 = cols[rank]
-
-    def parts(buf, side):
-        out, off = [], side * per
-        for pl, (r, c) in enumerate(shapes):
-            out.append(buf[off:off + r * c].view(r, c))
-            off += r * c
-        return out
-
-    for pl, v in enumerate(parts(send, 0)):                 # my left edge (goes to rank - 1's right halo)
-        s = ss_hor if pl else 0
-        v.copy_(pic.planes[pl][:, x0 >> s:(x0 >> s) + v.shape[1]])
-    for pl, v in enumerate(parts(send, 1)):                 # my right edge (goes to rank + 1's left halo)
-        s = ss_hor if pl else 0
-        v.copy_(pic.planes[pl][:, (x1 >> s) - v.shape[1]:x1 >> s])
-    dist.all_gather_into_tensor(recv.view(torch.uint8), send.view(torch.uint8))
-    if rank > 0:                                            # left neighbour's right edge -> [x0 - halo, x0)
-        for pl, v in enumerate(parts(recv[(rank - 1) * 2 * per:rank * 2 * per], 1)):
-            s = ss_hor if pl else 0
-            pic.planes[pl][:, (x0 >> s) - v.shape[1]:x0 >> s].copy_(v)
-    if rank + 1 < world:                                    # right neighbour's left edge -> [x1, x1 + halo)
-        for pl, v in enumerate(parts(recv[(rank + 1) * 2 * per:(rank + 2) * 2 * per], 0)):
-            s = ss_hor if pl else 0
-            pic.planes[pl][:, x1 >> s:(x1 >> s) + v.shape[1]].copy_(v)
+    ctx = _ctx_of(pic)
+    x0 = (C.c_int * world)(*[c[0] for c in cols])
+    x1 = (C.c_int * world)(*[c[1] for c in cols])
+    rc = ctx.lib.dav1d_hip_peer_exchange_halo(peer_of(ctx, rank, world), C.byref(_pic_of(pic)), x0, x1, halo)
+    if rc:
+        raise RuntimeError("dav1d_hip_peer_exchange_halo: %d" % rc)
 
 
 def post_tasks_of_column(lf, cdef, lr, stride_px, col, ss_hor=1):
@@ -272,13 +266,18 @@ def post_tasks_of_column(lf, cdef, lr, stride_px, col, ss_hor=1):
 # of publication is the whole picture: the rank that finished frame n sends it once, every rank that predicts from it receives
 # it into its own copy (RCCL broadcast over xGMI; one 8K 10-bit picture is 100 MB = about 0.7 ms per link).
 
-def broadcast_picture(pic, src_rank, world):
-    """Every rank ends up with rank `src_rank`'s planes of `pic` (a SharedPicture: one contiguous tensor, so ONE broadcast)."""
+def broadcast_picture(pic, src_rank, world, rank=None):
+    """Every rank ends up with rank `src_rank`'s planes of `pic` (dav1d_hip_peer_broadcast_picture: one ncclBroadcast for a picture of
+    the library's allocator, one per plane for caller-owned planes)."""
+    import ctypes as C
     if world == 1:
         return
-    import torch
-    import torch.distributed as dist
-    dist.broadcast(pic.store.view(torch.uint8) if pic.store.dtype != torch.uint8 else pic.store, src=src_rank)
+    ctx = _ctx_of(pic)
+    if rank is None:
+        rank = env()[0]
+    rc = ctx.lib.dav1d_hip_peer_broadcast_picture(peer_of(ctx, rank, world), C.byref(_pic_of(pic)), src_rank)
+    if rc:
+        raise RuntimeError("dav1d_hip_peer_broadcast_picture: %d" % rc)
 
 
 # ---- config C4 of SURVEY 8d / BASELINE configs[4]: frames in flight one per GPU, the FULL table (reconstruction, deblocking, CDEF,
@@ -338,7 +337,6 @@ class C4Workload:
         ctx.lr_batch(res.view, cdf.view, cur.view, post.lr)
         ctx.fg_apply(self.grn.view, res.view, post.fg)
         if self.dependent:
-            ctx.sync()
             for o in range(self.world):
                 broadcast_picture(self.ring[o], o, self.world)
             self.have_prev = True

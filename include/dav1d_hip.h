@@ -894,6 +894,31 @@ typedef struct Dav1dHipSynthParams {
 DAV1D_HIP_API int dav1d_hip_synth_frame(const Dav1dHipFrameDesc *desc, const Dav1dHipSynthParams *sp, void *cf, size_t cf_bytes,
                                         size_t cbi_entries, uint8_t *pal_idx, size_t pal_idx_bytes);
 
+/* ------------------------------------------------- multi-GPU (RCCL over xGMI), one process per GPU
+ *
+ * The data-path collectives of the two shardings (one Dav1dFrameContext per frame thread on the reference side, src/internal.h:
+ * 247-262, src/lib.c:140-301 n_fc): frames in flight one per GPU, where a frame that predicts from a frame decoded on another GPU
+ * needs that picture (the publication rule of src/thread_task.c:416-433 at picture granularity) -> _broadcast_picture; tile columns one
+ * per GPU (tiles are independent for reconstruction, src/recon_tmpl.c:1264-1268, not for inter prediction and the in-loop
+ * filters, src/lf_apply_tmpl.c:330-398) -> _allgather_columns once per frame, _exchange_halo before the filters.  Rendezvous: rank
+ * 0 makes a 128-byte id (dav1d_hip_peer_unique_id), the host hands it to every process by its own means (a file, a socket, MPI,
+ * torch.distributed ...), every process opens its peer with the same id.  Everything is enqueued on the context's stream. */
+typedef struct Dav1dHipPeer Dav1dHipPeer;
+DAV1D_HIP_API int dav1d_hip_peer_unique_id(uint8_t id[128]);
+DAV1D_HIP_API int dav1d_hip_peer_open(Dav1dHipContext *c, Dav1dHipPeer **out, const uint8_t id[128], int rank, int world);
+DAV1D_HIP_API void dav1d_hip_peer_close(Dav1dHipPeer *p);
+DAV1D_HIP_API int dav1d_hip_peer_rank(const Dav1dHipPeer *p);
+DAV1D_HIP_API int dav1d_hip_peer_world(const Dav1dHipPeer *p);
+/* every rank ends up with `owner`'s pixels of `pic` (same geometry everywhere; one ncclBroadcast for a picture of
+ * dav1d_hip_picture_alloc) */
+DAV1D_HIP_API int dav1d_hip_peer_broadcast_picture(Dav1dHipPeer *p, Dav1dHipPicture *pic, int owner);
+/* rank g reconstructed luma columns [x0[g], x1[g]) (even; chroma follows the layout): afterwards every rank holds all of them.  One
+ * strided pack kernel, ONE ncclAllGather of the strips (padded to the widest), scatter kernels straight into the planes. */
+DAV1D_HIP_API int dav1d_hip_peer_allgather_columns(Dav1dHipPeer *p, Dav1dHipPicture *pic, const int *x0, const int *x1);
+/* the `halo` luma columns on either side of this rank's column from the neighbours that reconstructed them (in-loop filters across
+ * the tile edge; 16 covers deblocking + CDEF + restoration) */
+DAV1D_HIP_API int dav1d_hip_peer_exchange_halo(Dav1dHipPeer *p, Dav1dHipPicture *pic, const int *x0, const int *x1, int halo);
+
 /* ------------------------------------------------- reference-signature table */
 
 /* The kernel-level drop-in: function pointer types with the reference's exact signatures and a table whose

@@ -352,6 +352,31 @@ def test_c4_full_table_and_film_grain_world2_gloo(tmp_path, dependent):
     assert d["ok"] and d["ranks_differ"], d
 
 
+@pytest.mark.gpu
+def test_peer_opens_on_rccl_with_one_rank():
+    """The C peer entry points on the real thing: librccl.so is found and resolved at run time, ncclGetUniqueId / ncclCommInitRank
+    work on the GPU box (one rank: the collectives themselves are no-ops), the picture calls keep their contracts."""
+    import ctypes as C
+    from dav1d_amd import api
+    ctx = util.make_context("hip")
+    try:
+        ident = (C.c_uint8 * 128)()
+        assert ctx.lib.dav1d_hip_peer_unique_id(ident) == 0 and any(ident)
+        h = C.c_void_p()
+        assert ctx.lib.dav1d_hip_peer_open(ctx.h, C.byref(h), ident, 0, 1) == 0
+        assert ctx.lib.dav1d_hip_peer_rank(h) == 0 and ctx.lib.dav1d_hip_peer_world(h) == 1
+        pic = ctx.picture(256, 128, api.LAYOUT_I420, 10)
+        x0, x1 = (C.c_int * 1)(0), (C.c_int * 1)(256)
+        assert ctx.lib.dav1d_hip_peer_broadcast_picture(h, C.byref(pic.pic), 0) == 0
+        assert ctx.lib.dav1d_hip_peer_allgather_columns(h, C.byref(pic.pic), x0, x1) == 0
+        assert ctx.lib.dav1d_hip_peer_exchange_halo(h, C.byref(pic.pic), x0, x1, 16) == 0
+        assert ctx.lib.dav1d_hip_peer_broadcast_picture(h, C.byref(pic.pic), 3) == -22
+        ctx.lib.dav1d_hip_peer_close(h)
+        pic.free()
+    finally:
+        ctx.close()
+
+
 def test_tile_column_split_covers_every_task_once():
     import numpy as np
     from dav1d_amd import dist as dd, synth
