@@ -352,29 +352,40 @@ def test_c4_full_table_and_film_grain_world2_gloo(tmp_path, dependent):
     assert d["ok"] and d["ranks_differ"], d
 
 
+RCCL_ONE_RANK = """
+import sys, ctypes as C
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import util
+from dav1d_amd import api
+ctx = util.make_context("hip")
+ident = (C.c_uint8 * 128)()
+assert ctx.lib.dav1d_hip_peer_unique_id(ident) == 0 and any(ident)
+h = C.c_void_p()
+rc = ctx.lib.dav1d_hip_peer_open(ctx.h, C.byref(h), ident, 0, 1)
+assert rc == 0, rc
+assert ctx.lib.dav1d_hip_peer_rank(h) == 0 and ctx.lib.dav1d_hip_peer_world(h) == 1
+pic = ctx.picture(256, 128, api.LAYOUT_I420, 10)
+x0, x1 = (C.c_int * 1)(0), (C.c_int * 1)(256)
+assert ctx.lib.dav1d_hip_peer_broadcast_picture(h, C.byref(pic.pic), 0) == 0
+assert ctx.lib.dav1d_hip_peer_allgather_columns(h, C.byref(pic.pic), x0, x1) == 0
+assert ctx.lib.dav1d_hip_peer_exchange_halo(h, C.byref(pic.pic), x0, x1, 16) == 0
+assert ctx.lib.dav1d_hip_peer_broadcast_picture(h, C.byref(pic.pic), 3) == -22
+ctx.lib.dav1d_hip_peer_close(h)
+pic.free()
+ctx.close()
+print("RCCL_ONE_RANK_OK")
+"""
+
+
 @pytest.mark.gpu
-def test_peer_opens_on_rccl_with_one_rank():
-    """The C peer entry points on the real thing: librccl.so is found and resolved at run time, ncclGetUniqueId / ncclCommInitRank
-    work on the GPU box (one rank: the collectives themselves are no-ops), the picture calls keep their contracts."""
-    import ctypes as C
-    from dav1d_amd import api
-    ctx = util.make_context("hip")
-    try:
-        ident = (C.c_uint8 * 128)()
-        assert ctx.lib.dav1d_hip_peer_unique_id(ident) == 0 and any(ident)
-        h = C.c_void_p()
-        assert ctx.lib.dav1d_hip_peer_open(ctx.h, C.byref(h), ident, 0, 1) == 0
-        assert ctx.lib.dav1d_hip_peer_rank(h) == 0 and ctx.lib.dav1d_hip_peer_world(h) == 1
-        pic = ctx.picture(256, 128, api.LAYOUT_I420, 10)
-        x0, x1 = (C.c_int * 1)(0), (C.c_int * 1)(256)
-        assert ctx.lib.dav1d_hip_peer_broadcast_picture(h, C.byref(pic.pic), 0) == 0
-        assert ctx.lib.dav1d_hip_peer_allgather_columns(h, C.byref(pic.pic), x0, x1) == 0
-        assert ctx.lib.dav1d_hip_peer_exchange_halo(h, C.byref(pic.pic), x0, x1, 16) == 0
-        assert ctx.lib.dav1d_hip_peer_broadcast_picture(h, C.byref(pic.pic), 3) == -22
-        ctx.lib.dav1d_hip_peer_close(h)
-        pic.free()
-    finally:
-        ctx.close()
+def test_peer_opens_on_rccl_with_one_rank(tmp_path):
+    """The C peer entry points on the real thing, in a process of their own as every rank of a multi-GPU job is: librccl.so is found and
+    resolved at run time, ncclGetUniqueId / ncclCommInitRank work on the GPU box (one rank: the collectives themselves are no-ops), the
+    picture calls keep their contracts."""
+    script = tmp_path / "one.py"
+    script.write_text(RCCL_ONE_RANK % {"root": util.ROOT, "tests": os.path.join(util.ROOT, "tests")})
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_ONE_RANK_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
 
 
 def test_tile_column_split_covers_every_task_once():
