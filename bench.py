@@ -844,6 +844,25 @@ def main():
                     raise SystemExit("bench: full end-to-end leg (4 tile columns) differs from the reference: %s" % e)
                 except Exception as e:       # noqa: BLE001
                     full_route_c2 = {"error": str(e)[:200]}
+        # ---- frames in flight (round 3): frame n + 1 is listed while frame n runs on the device, the packing lister sends the
+        # coefficients that exist instead of the dense arena.  ms_per_frame = sustained over the frames after the warm-up.
+        sustained = None
+        if world == 1 and not a.no_e2e:
+            from dav1d_amd import e2e
+            sustained = {}
+            try:
+                sustained["recon"] = e2e.run_sustained(ctx, w, h, bpc, frames=12, threads=a.e2e_threads or 64, tile_cols=a.e2e_tile_cols, tile_rows=a.e2e_tile_rows,
+                                                       check=None if a.no_check else e2e_check)
+                sustained["recon_4_tile_columns"] = e2e.run_sustained(ctx, w, h, bpc, frames=6, threads=4, tile_cols=4, tile_rows=1,
+                                                                      check=None if a.no_check else e2e_check)
+                if not a.no_check:
+                    import lister_util as lu
+                    sustained["full_table"] = lu.full_route_sustained(ctx, w, h, bpc, a.e2e_tile_cols, a.e2e_tile_rows, threads=a.e2e_threads or 64, frames=12)
+                    sustained["full_table_4_tile_columns"] = lu.full_route_sustained(ctx, w, h, bpc, 4, 1, threads=4, frames=6)
+            except AssertionError as e:
+                raise SystemExit("bench: frames-in-flight leg differs from the reference: %s" % e)
+            except Exception as e:       # noqa: BLE001  (a reported extra)
+                sustained["error"] = str(e)[:200]
         # ---- BASELINE configs[0]: 1080p 8-bit on ONE host thread (the reference C), and the same reference code with the HIP DSP table
         c0 = None
         if world == 1 and not a.no_cpu and not a.no_check and (w, h, bpc) == (7680, 4320, 10):
@@ -889,7 +908,7 @@ def main():
                           "coef_bytes_per_frame": int(coef_host.nbytes), "coef_h2d_ms_per_frame": h2d_ms,
                           "samples_per_frame": frame.n_samples, "parity": check, "gen_seconds": round(t_gen, 1)},
                "roofline": roof, "cpu_baseline": cpu, "full_table": full, "end_to_end": e2e_leg, "all_intra": key_leg, "end_to_end_full_table": full_route, "end_to_end_4_tile_columns": e2e_c2, "end_to_end_full_table_4_tile_columns": full_route_c2,
-               "dav1d_task_loop": task_loop, "config_c0_1080p_8bit": c0,
+               "end_to_end_frames_in_flight": sustained, "dav1d_task_loop": task_loop, "config_c0_1080p_8bit": c0,
                "device": None if a.no_check else device_probe(torch)}       # (not under the profiler: its copies would sit in the kernel statistics)
         # BASELINE configs[1] (4K 8-bit, the reference's CPU-runnable size) next to the headline: the same bench in a child process,
         # its digest under "config_c1_4k_8bit"

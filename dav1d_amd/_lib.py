@@ -74,7 +74,7 @@ SYMBOLS = [
     "dav1d_hip_fg_apply", "dav1d_hip_fg_generate_grain",
     "dav1d_hip_warp_batch", "dav1d_hip_mc_scaled_batch", "dav1d_hip_resize", "dav1d_hip_emu_edge",
     "dav1d_hip_ipred_list_create", "dav1d_hip_ipred_list_run_batch", "dav1d_hip_ipred_list_destroy",
-    "dav1d_hip_frame_begin", "dav1d_hip_frame_submit_tile_sbrow", "dav1d_hip_frame_submit_filter_sbrow",
+    "dav1d_hip_frame_begin", "dav1d_hip_frame_submit_tile_sbrow", "dav1d_hip_frame_submit_coefs", "dav1d_hip_frame_coef_bytes", "dav1d_hip_frame_submit_filter_sbrow",
     "dav1d_hip_frame_set_filters", "dav1d_hip_frame_end", "dav1d_hip_frame_destroy",
     "dav1d_hip_frame_submit_step_blend", "dav1d_hip_frame_submit_warp", "dav1d_hip_frame_submit_scaled",
     "dav1d_hip_lister_create", "dav1d_hip_lister_tile_sbrow", "dav1d_hip_lister_run", "dav1d_hip_lister_filter_run", "dav1d_hip_lister_prep_elems", "dav1d_hip_lister_mask_bytes",
@@ -103,7 +103,7 @@ class FrameDesc(C.Structure):          # == Dav1dHipFrameDesc
                 ("b", C.c_void_p), ("cbi", C.c_void_p), ("tile_start_off", C.c_void_p), ("pal", C.c_void_p),
                 ("svc", ((C.c_int32 * 2) * 2) * 7), ("ref_w", C.c_int * 7), ("ref_h", C.c_int * 7), ("gmv", WarpParams * 7),
                 ("gmv_warp_allowed", C.c_uint8 * 7), ("jnt_weights", (C.c_uint8 * 7) * 7), ("cf_align64", C.c_int),
-                ("lossless", C.c_uint8 * 8)]
+                ("lossless", C.c_uint8 * 8), ("cf", C.c_void_p)]
 
 
 class SynthParams(C.Structure):        # == Dav1dHipSynthParams
@@ -243,6 +243,8 @@ def load(path=None):
         "dav1d_hip_ipred_list_destroy": (None, [vp, vp]),
         "dav1d_hip_frame_begin": (i, [vp, P(vp), P(Picture), P(Picture), i]),
         "dav1d_hip_frame_submit_tile_sbrow": (i, [vp, vp, sz, vp, sz, vp, sz]),
+        "dav1d_hip_frame_submit_coefs": (i, [vp, vp, sz, vp]),
+        "dav1d_hip_frame_coef_bytes": (sz, [vp]),
         "dav1d_hip_frame_submit_filter_sbrow": (i, [vp, vp, sz, vp, sz, vp, sz]),
         "dav1d_hip_frame_set_filters": (i, [vp, vp, C.c_ssize_t, vp, vp, i, vp, i]),
         "dav1d_hip_frame_end": (i, [vp, vp, vp, vp, P(Picture), P(Picture)]),

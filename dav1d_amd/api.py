@@ -192,6 +192,7 @@ class Context:
 
     def __init__(self, device=0, stream=None, lib_path=None):
         self.lib = _lib.load(lib_path)
+        self.device, self.lib_path = device, lib_path
         h = C.c_void_p()
         rc = self.lib.dav1d_hip_open(C.byref(h), device, stream)
         if rc:

@@ -46,7 +46,7 @@ def _host_jobs(objdir, hdrs, force):
         obj = os.path.join(objdir, "host_" + s.replace(".c", ".o"))
         objs.append(obj)
         if force or _newer(obj, [src] + hdrs):
-            jobs.append([CC, "-std=gnu99", "-O2", "-fPIC", "-fvisibility=hidden", "-Wall", "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
+            jobs.append([CC, "-std=gnu99", "-O2", "-fPIC", "-fvisibility=hidden", "-Wall"] + os.environ.get("DAV1D_HIP_HOST_CFLAGS", "").split() + ["-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
     return jobs, objs
 
 
@@ -95,7 +95,7 @@ def build_emu(force=False):
         obj = os.path.join(objdir, os.path.basename(src).rsplit(".", 1)[0] + ".o")
         objs.append(obj)
         if force or _newer(obj, [src] + hdrs):
-            jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-w", "-I" + emu, "-I" + os.path.join(ROOT, "include"),
+            jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-w"] + os.environ.get("DAV1D_HIP_EMU_CXXFLAGS", "").split() + ["-I" + emu, "-I" + os.path.join(ROOT, "include"),
                          "-x", "c++", "-c", src, "-o", obj])
     hjobs, hobjs = _host_jobs(objdir, hdrs, force)
     jobs += hjobs

@@ -74,6 +74,7 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     c->gather_dev = c->segtab_dev = c->pending_slab = nullptr;
     c->gather_cap = c->segtab_cap = c->pending_slab_cap = 0;
     c->arena_hint = 0;
+    c->carena_hint = 0;
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
     *out = c;

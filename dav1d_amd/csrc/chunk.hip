@@ -132,10 +132,24 @@ void Dav1dHipChunk::release(Dav1dHipContext *c) {
 }
 
 // Everything dav1d_hip_recon_list_create() does for a whole frame, for the tasks of one tile-sbrow.
+#ifdef CHUNK_PROF
+#include <time.h>
+#include <stdio.h>
+static uint64_t cprof[16], cprof_n[4];
+static uint64_t cnow() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (uint64_t) ts.tv_sec * 1000000000ull + ts.tv_nsec; }
+#define P(i) { const uint64_t t_ = cnow(); __atomic_fetch_add(&cprof[i], t_ - tp_, __ATOMIC_RELAXED); tp_ = t_; }
+extern "C" void dav1d_hip_chunk_prof() { for (int i = 0; i < 10; i++) { fprintf(stderr, "%d:%.1f ", i, cprof[i] * 1e-6); cprof[i] = 0; } fprintf(stderr, " mc %llu comp %llu itx %llu\n", (unsigned long long) cprof_n[0], (unsigned long long) cprof_n[1], (unsigned long long) cprof_n[2]); cprof_n[0] = cprof_n[1] = cprof_n[2] = 0; }
+#else
+#define P(i)
+#endif
 int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHipPicture *geom, const Dav1dHipPicture *refs, int n_refs,
                           const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
                           const Dav1dHipItxTask *itx, size_t n_itx)
 {
+#ifdef CHUNK_PROF
+    uint64_t tp_ = cnow();
+    cprof_n[0] += n_mc; cprof_n[1] += n_comp; cprof_n[2] += n_itx;
+#endif
     *out = nullptr;
     const int bps = geom->bpc > 8 ? 2 : 1;
     int stride[3];
@@ -149,6 +163,7 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
     }
     for (size_t i = 0; i < n_itx; i++) if (!itx_task_ok(itx[i]) || !stride[itx[i].plane]) return -EINVAL;
 
+    P(0);
     static const uint8_t tx_w[19] = { 4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64 };
     static const uint8_t tx_h[19] = { 4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16 };
 
@@ -179,6 +194,7 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
                 m.each(comp[i].dst_off, comp[i].w, comp[i].h, [&](size_t k) { m.blend[k] = 1; });
             }
 
+    P(1);
     // ---- pairing: a square transform block that covers exactly one prediction block runs with it in one wave (recon.hip)
     const int fuse_mask = recon_fuse_mask(c);
     std::vector<char> taken(n_itx, 0);
@@ -208,6 +224,7 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
         return (long) q - 1;
     };
 
+    P(2);
     // ---- compound pairs whose two PREP blocks nothing else reads are predicted twice and combined in registers
     size_t n_prep = 0;
     for (size_t i = 0; i < n_mc; i++) n_prep += mc[i].kind == DAV1D_HIP_MC_PREP;
@@ -258,6 +275,7 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
                        mc[i].dst_off, nullptr, 0, j >= 0 ? &p_tiles[itx[j].tx] : nullptr);
         }
 
+    P(3);
     Dav1dHipChunk *ck = new (std::nothrow) Dav1dHipChunk();
     if (!ck) return -ENOMEM;
     memset(ck->seg, 0, sizeof(ck->seg));
@@ -287,6 +305,7 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
     }
     for (size_t i = 0; i < n_mc; i++) if (mc[i].kind == DAV1D_HIP_MC_PUT) ck->order = std::min(ck->order, (uint64_t) mc[i].plane << 40 | mc[i].dst_off);
 
+    P(4);
     // ---- order inside the chunk.  Predictions: by where they read (reference, plane, 64-row band, x), then inside windows of
     // 128 waves' worth by (leaves the reference plane, kind) so that the tiles of a wave share their code path.  Residuals:
     // inside windows by code path (dc-only, 1-D kinds).  Speed only: the tasks of a chunk write disjoint pixels.
@@ -334,6 +353,7 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
             ck->max_ref = std::max(ck->max_ref, std::max((int) t.r[0].ref, two ? (int) t.r[1].ref : 0));
         }
     }
+    P(5);
     if (itx_win > 0)
         for (int b = 0; b < 19; b++) {
             std::vector<Dav1dHipItxTask> &v = ibins[b];
@@ -342,6 +362,7 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
             for (size_t i = 0; i < v.size(); i++) gk[i] = (uint8_t) itx_path_key(v[i]);
             group_in_windows(v, gk, (size_t) itx_win * (size_t) std::max(1, 64 / lanes));
         }
+    P(6);
     // paired blocks: by where the first tile reads, then by (transform code path, prediction kind) inside windows
     std::vector<McTile> pt_sorted[5];
     std::vector<Dav1dHipItxTask> pk_sorted[5];
@@ -376,6 +397,7 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
             itx_fill_prefix(pk_sorted[k][i]);
         }
     }
+    P(7);
     // compound / blend tasks: BLEND_V and the MASK tasks that read a mask a W_MASK task of the chunk writes go second
     std::vector<Dav1dHipCompTask> c_first, c_second;
     {
@@ -385,6 +407,7 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
             ((t.kind == DAV1D_HIP_COMP_BLEND_V || (t.kind == DAV1D_HIP_COMP_MASK && wmask_out.count(t.mask_off))) ? c_second : c_first).push_back(t);
     }
 
+    P(8);
     // ---- one pinned blob: [mc bins][itx bins][paired tiles][paired residuals][comp first][comp second], 16-byte aligned segments
     size_t total = 0;
     auto place = [&](int id, size_t n, size_t esz) { ck->seg[id].off = (uint32_t) total; ck->seg[id].n = (uint32_t) n; total += (n * esz + 15) & ~(size_t) 15; };
@@ -406,6 +429,7 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
         put(CK_COMP, c_first.data(), sizeof(Dav1dHipCompTask));
         put(CK_COMP + 1, c_second.data(), sizeof(Dav1dHipCompTask));
     }
+    P(9);
     *out = ck;
     return 0;
 }

@@ -31,6 +31,19 @@ struct Dav1dHipFrame {
     uint8_t *harena;
     size_t harena_cap;
     size_t harena_flushed;                  // bytes of the twin already on their way to the device (dav1d_hip_frame_flush)
+    // The frame's own coefficient arena (dav1d_hip_frame_submit_coefs): the eob + 1 values per transform block a packing lister
+    // gathered, drawn segment by segment by the submitting threads.  The device side is sized for the frame's dense bound (no
+    // packed frame can need more: a block's values fit its slab), the pinned twin for what frames have needed so far; a segment
+    // that does not fit the twin is kept (late) and sent on its own at frame end.
+    uint8_t *carena;
+    size_t carena_cap;
+    uint8_t *hcarena;
+    size_t hcarena_cap, hcarena_flushed;
+    std::atomic<size_t> carena_used;        // bytes
+    std::once_flag carena_once;
+    struct LateCoefs { size_t off, bytes; void *copy; };
+    std::vector<LateCoefs> late_coefs;
+    std::atomic<int> saw_dense, saw_packed; // kinds of residual tasks submitted so far
     // intra blocks: step k of the wavefront = the blocks whose neighbours are final after steps 0 .. k - 1 (and after the
     // inter blocks of the frame); predictions and residuals per step
     // One entry per submission (a tile-sbrow's blocks), tasks sorted by step with the end offset of every step; built — and
@@ -335,19 +348,22 @@ int dav1d_hip_frame_begin(Dav1dHipContext *c, Dav1dHipFrame **out, const Dav1dHi
     f->arena = nullptr; f->arena_cap = 0; f->arena_used = 0;
     {
         std::lock_guard<std::mutex> lk(c->pool_mtx);
+        int best = -1;              // best fit: the coefficient arenas of packed frames live in the same pool and are much larger
         for (size_t i = 0; i < c->free_arenas.size(); i++)
-            if (c->free_arenas[i].cap >= c->arena_hint) {
-                f->arena = c->free_arenas[i].dev; f->arena_cap = c->free_arenas[i].cap;
-                c->free_arenas[i] = c->free_arenas.back();
-                c->free_arenas.pop_back();
-                break;
-            }
+            if (c->free_arenas[i].cap >= c->arena_hint && (best < 0 || c->free_arenas[i].cap < c->free_arenas[best].cap)) best = (int) i;
+        if (best >= 0) {
+            f->arena = c->free_arenas[best].dev; f->arena_cap = c->free_arenas[best].cap;
+            c->free_arenas[best] = c->free_arenas.back();
+            c->free_arenas.pop_back();
+        }
     }
     if (!f->arena) {
         size_t want = (size_t) 1 << 24;
         while (want < c->arena_hint + (c->arena_hint >> 2)) want <<= 1;
         if (hipMalloc((void **) &f->arena, want) == hipSuccess) f->arena_cap = want; else f->arena = nullptr;
     }
+    f->carena = f->hcarena = nullptr; f->carena_cap = f->hcarena_cap = f->hcarena_flushed = 0; f->carena_used = 0;
+    f->saw_dense = 0; f->saw_packed = 0;
     f->harena = nullptr; f->harena_cap = 0; f->harena_flushed = 0;
     if (f->arena && !c->chunk_upload) f->harena = dav1d_hip_slab_get(c, f->arena_cap, &f->harena_cap);
     *out = f;
@@ -372,6 +388,62 @@ int dav1d_hip_frame_set_refs(Dav1dHipFrame *f, const Dav1dHipPicture *refs, int 
     return 0;
 }
 
+static void note_kinds(Dav1dHipFrame *f, const Dav1dHipItxTask *itx, size_t n) {
+    unsigned packed = 0, dense = 0;
+    for (size_t i = 0; i < n; i++) { const unsigned p = itx[i].flags & DAV1D_HIP_ITX_PACKED; packed |= p; dense |= p ^ 1u; }
+    if (packed) f->saw_packed.store(1, std::memory_order_relaxed);
+    if (dense) f->saw_dense.store(1, std::memory_order_relaxed);
+}
+
+// bytes of a dense coefficient arena of this picture: no packed frame holds more values than that
+static size_t dense_coef_bytes(const Dav1dHipPicture *p) {
+    size_t n = 0;
+    for (int pl = 0; pl < 3; pl++)
+        if (p->p[pl].data) n += (size_t) ((p->p[pl].w + 63) & ~63) * (size_t) ((p->p[pl].h + 63) & ~63);
+    return n * (p->bpc > 8 ? 4 : 2);
+}
+
+// The values of the caller's PACKED residual tasks (a tile-sbrow's worth): copied into the frame's coefficient arena; *base = what
+// to add to the tasks' cf_off.  The arena travels with the frame (dav1d_hip_frame_flush / dav1d_hip_frame_end with coef = NULL).
+int dav1d_hip_frame_submit_coefs(Dav1dHipFrame *f, const void *vals, size_t n, uint32_t *base) {
+    if (!f || !base || (!vals && n)) return -EINVAL;
+    Dav1dHipContext *c = f->c;
+    const size_t csz = f->cur.bpc > 8 ? 4 : 2;
+    std::call_once(f->carena_once, [&]() {
+        const size_t want = dense_coef_bytes(&f->cur) + 4096;
+        {
+            std::lock_guard<std::mutex> lk(c->pool_mtx);
+            int best = -1;
+            for (size_t i = 0; i < c->free_arenas.size(); i++)
+                if (c->free_arenas[i].cap >= want && (best < 0 || c->free_arenas[i].cap < c->free_arenas[best].cap)) best = (int) i;
+            if (best >= 0) {
+                f->carena = c->free_arenas[best].dev; f->carena_cap = c->free_arenas[best].cap;
+                c->free_arenas[best] = c->free_arenas.back();
+                c->free_arenas.pop_back();
+            }
+        }
+        if (!f->carena && hipMalloc((void **) &f->carena, want) == hipSuccess) f->carena_cap = want;
+        if (f->carena) {
+            const size_t twin = std::min(f->carena_cap, std::max(c->carena_hint + (c->carena_hint >> 2), want / 4));
+            f->hcarena = dav1d_hip_slab_get(c, twin, &f->hcarena_cap);
+        }
+    });
+    if (!f->carena) return -ENOMEM;
+    const size_t bytes = (n * csz + 63) & ~(size_t) 63, off = f->carena_used.fetch_add(bytes);
+    if (off + bytes > f->carena_cap || (off + bytes) / csz > 0xffffffffu) return -EINVAL;      // more values than the frame has coefficients
+    *base = (uint32_t) (off / csz);
+    if (!n) return 0;
+    if (f->hcarena && off + bytes <= f->hcarena_cap) { memcpy(f->hcarena + off, vals, n * csz); return 0; }
+    void *copy = malloc(n * csz);
+    if (!copy) return -ENOMEM;
+    memcpy(copy, vals, n * csz);
+    std::lock_guard<std::mutex> lk(f->mtx);
+    f->late_coefs.push_back({ off, n * csz, copy });
+    return 0;
+}
+
+size_t dav1d_hip_frame_coef_bytes(const Dav1dHipFrame *f) { return f ? f->carena_used.load() : 0; }
+
 // Reconstruction tasks of one tile-sbrow (what decode_b()'s pass-2 branch would have executed, src/decode.c:706-806).
 // Thread-safe; the order between tile-sbrows is free: inter tasks of a frame write disjoint pixels, and every residual
 // is added after every prediction.
@@ -380,6 +452,7 @@ int dav1d_hip_frame_submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc
     if (!f || (!mc && n_mc) || (!comp && n_comp) || (!itx && n_itx)) return -EINVAL;
     if (!n_mc && !n_comp && !n_itx) return 0;
     if ((n_mc || n_comp) && !f->n_refs) return -EINVAL;
+    note_kinds(f, itx, n_itx);
     // all the list preparation of this tile-sbrow happens here, on the submitting thread, without the frame's lock
     Dav1dHipChunk *ck = nullptr;
     const int rc = dav1d_hip_chunk_build(f->c, &ck, &f->cur, f->refs, f->n_refs, mc, n_mc, comp, n_comp, itx, n_itx);
@@ -448,6 +521,7 @@ int dav1d_hip_frame_submit_intra_sorted(Dav1dHipFrame *f, size_t n_steps, const 
     const size_t np = ip_end[n_steps - 1], nx = ix_end[n_steps - 1], nb = bl_end[n_steps - 1];
     if ((np && !ip) || (nx && !ix) || (nb && !bl) || np >= 0xffffffffu || nx >= 0xffffffffu) return -EINVAL;
     if (!np && !nx && !nb) return 0;
+    note_kinds(f, ix, nx);
     Dav1dHipFrame::StepChunk *ck = new (std::nothrow) Dav1dHipFrame::StepChunk();
     if (!ck) return -ENOMEM;
     ck->ip.assign(ip, ip + np); ck->ix.assign(ix, ix + nx); ck->bl.assign(bl, bl + nb);
@@ -725,6 +799,12 @@ int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *ma
     f->n_steps = 0;
     f->arena_used = 0;
     f->harena_flushed = 0;
+    c->carena_hint = std::max(c->carena_hint, f->carena_used.load());
+    f->carena_used = 0;
+    f->hcarena_flushed = 0;
+    f->saw_dense = 0; f->saw_packed = 0;
+    for (Dav1dHipFrame::LateCoefs &lc : f->late_coefs) free(lc.copy);
+    f->late_coefs.clear();
     if (c->pending_slab) {
         std::lock_guard<std::mutex> pl(c->pool_mtx);
         c->free_slabs.push_back({ c->pending_slab, c->pending_slab_cap });
@@ -738,6 +818,18 @@ int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *ma
 static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask, Dav1dHipPicture *filtered, const Dav1dHipPicture *grain_out) {
     Dav1dHipContext *c = f->c;
     int rc = 0;
+    if (f->saw_packed.load()) {
+        // a packed frame: every residual task points into the frame's own coefficient arena (a dense arena next to it is not
+        // supported: the kernels take one base).  What the flushes have not sent goes now, the late segments behind it.
+        if (coef || f->saw_dense.load() || !f->carena) return -EINVAL;
+        rc = frame_flush_locked(f);
+        for (const Dav1dHipFrame::LateCoefs &lc : f->late_coefs)
+            if (!rc) rc = hip_rc(hipMemcpyAsync(f->carena + lc.off, lc.copy, lc.bytes, hipMemcpyHostToDevice, c->copy_stream));
+        if (!rc) rc = hip_rc(hipEventRecord(c->ev_copy, c->copy_stream));
+        if (!rc) rc = hip_rc(hipStreamWaitEvent(c->stream, c->ev_copy, 0));
+        if (rc) return rc;
+        coef = f->carena;
+    }
     if (c->post_bands >= 2) frame_merge_filter_pieces(f);          // the banded route works on the merged lists
     // warped / scaled predictions first: the compound combinations of the list below read their PREP outputs
     if (!f->warp.empty()) rc = dav1d_hip_warp_batch(c, &f->cur, f->refs, f->n_refs, f->warp.data(), f->warp.size(), prep);
@@ -967,11 +1059,21 @@ extern "C" {
 // The chunk blobs in the pinned twin that are not on their way yet: one transfer on the copy stream.  Only complete blobs may go:
 // the caller guarantees that no submission is in progress (dav1d_hip_frame_flush is called between the listing and the frame end).
 static int frame_flush_locked(Dav1dHipFrame *f) {
-    if (!f->harena) return 0;
+    int rc = 0;
+    if (f->hcarena) {
+        // segments are drawn whole: one that crosses the end of the twin went the late way, everything below `used` that is in the twin is complete
+        const size_t used = std::min(f->carena_used.load(), f->hcarena_cap);
+        if (used > f->hcarena_flushed) {
+            rc = hip_rc(hipMemcpyAsync(f->carena + f->hcarena_flushed, f->hcarena + f->hcarena_flushed, used - f->hcarena_flushed, hipMemcpyHostToDevice,
+                                       f->c->copy_stream));
+            if (!rc) f->hcarena_flushed = used;
+        }
+    }
+    if (!f->harena || rc) return rc;
     const size_t used = std::min(std::min(f->arena_used.load(), f->arena_cap), f->harena_cap);
     if (used <= f->harena_flushed) return 0;
-    const int rc = hip_rc(hipMemcpyAsync(f->arena + f->harena_flushed, f->harena + f->harena_flushed, used - f->harena_flushed, hipMemcpyHostToDevice,
-                                         f->c->copy_stream));
+    rc = hip_rc(hipMemcpyAsync(f->arena + f->harena_flushed, f->harena + f->harena_flushed, used - f->harena_flushed, hipMemcpyHostToDevice,
+                               f->c->copy_stream));
     if (!rc) f->harena_flushed = used;
     return rc;
 }
@@ -1046,9 +1148,12 @@ void dav1d_hip_frame_destroy(Dav1dHipFrame *f) {
     for (Dav1dHipFrame::StepChunk *sc : f->step_chunks) delete sc;
     for (Dav1dHipFrame::FilterPiece &p : f->filter_pieces) { free(p.lf); free(p.cdef); free(p.lr); delete p.groups; }
     if (f->harena) dav1d_hip_slab_put(f->c, f->harena, f->harena_cap);
-    if (f->arena) {
+    if (f->hcarena) dav1d_hip_slab_put(f->c, f->hcarena, f->hcarena_cap);
+    for (Dav1dHipFrame::LateCoefs &lc : f->late_coefs) free(lc.copy);
+    if (f->arena || f->carena) {
         std::lock_guard<std::mutex> lk(f->c->pool_mtx);
-        f->c->free_arenas.push_back({ f->arena, f->arena_cap });
+        if (f->arena) f->c->free_arenas.push_back({ f->arena, f->arena_cap });
+        if (f->carena) f->c->free_arenas.push_back({ f->carena, f->carena_cap });
     }
     for (int i = 0; i < 2; i++) if (f->have_tmp[i]) dav1d_hip_picture_give(f->c, &f->tmp[i]);
     for (int i = 0; i < 3; i++) if (f->have_sr[i]) dav1d_hip_picture_free(f->c, &f->sr[i]);

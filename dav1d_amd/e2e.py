@@ -217,6 +217,145 @@ def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0
     return out
 
 
+def run_pipelined(ctx, desc, cf_frames, w, h, layout, bpc, refs, threads, depth=2, warm=2, filters=None):
+    """Frames in flight, as dav1d's frame threading has them: frame n + 1 is listed (host threads) while frame n is on the device.
+
+    cf_frames: one HOST coefficient arena per frame (f->frame_thread.cf of that frame's context; the packing lister consumes it:
+    Dav1dHipFrameDesc.cf).  `depth` frames own a picture, a prep and a mask arena each.  filters: None, or dict(fd=FilterDesc,
+    lvl_host=level cache, b4_stride, lut_e, lut_i, damping) — the frame then runs its in-loop filters too (the level cache goes
+    up per frame on a context of its own, so that the copy does not queue behind the frame on the device).
+    The listing thread (this one) and the ending thread hand frames over a queue; a picture slot is reused when its frame is
+    through.  Returns (stats, planes of the last frame): ms_per_frame is the sustained rate between the ends of frame warm - 1
+    and the last one; list / end times are per-frame medians of the two threads' own clocks."""
+    import queue
+    import threading
+    lib = ctx.lib
+    frames = len(cf_frames)
+    up_ctx = api.Context(ctx.device, lib_path=ctx.lib_path) if filters else None
+    slots = []
+    for _ in range(depth):
+        slots.append(dict(cur=ctx.picture(w, h, layout, bpc), prep=None, mask=None,
+                          lvl=ctx.buffer(len(filters["lvl_host"])) if filters else None))
+    free_slots = queue.Queue()
+    for sl in slots:
+        free_slots.put(sl)
+    todo = queue.Queue()
+    nb = C.c_size_t()
+    blob = lib.dav1d_hip_lister_const_masks(C.byref(nb))
+    const_masks = np.ctypeslib.as_array((C.c_uint8 * nb.value).from_address(blob))
+    t_end, end_ms, err = [], [], []
+    last = {}
+
+    def ender():
+        while True:
+            job = todo.get()
+            if job is None:
+                return
+            frame, lh, sl, it = job
+            try:
+                t = time.perf_counter()
+                filtered = frame.end(None, sl["prep"], sl["mask"])
+                now = time.perf_counter()
+                t_end.append(now)
+                end_ms.append((now - t) * 1e3)
+                if it == frames - 1:
+                    pic = api.DevicePicture.view(ctx, filtered, w, h, layout, bpc) if filters else sl["cur"]
+                    last["planes"] = [pic.download(pl) for pl in range(1 if layout == 0 else 3)]
+            except Exception as e:          # noqa: BLE001 - reported by the caller
+                err.append(e)
+            lib.dav1d_hip_lister_destroy(lh)
+            frame.destroy()
+            free_slots.put(sl)
+    th = threading.Thread(target=ender)
+    th.start()
+    list_ms, flist_ms, wait_ms = [], [], []
+    d = _lib.FrameDesc.from_buffer_copy(desc)
+    try:
+        for it in range(frames):
+            t0 = time.perf_counter()
+            sl = free_slots.get()
+            t_a = time.perf_counter()
+            frame = ctx.frame(sl["cur"], refs)
+            d.cf = cf_frames[it].ctypes.data
+            lh = C.c_void_p()
+            assert lib.dav1d_hip_lister_create(C.byref(lh), C.byref(d), frame.h) == 0
+            if filters:
+                assert lib.dav1d_hip_upload(up_ctx.h, sl["lvl"].ptr, filters["lvl_host"].ctypes.data, len(filters["lvl_host"])) == 0
+            rc = lib.dav1d_hip_lister_run(lh, threads)
+            assert rc == 0, rc
+            t_b = time.perf_counter()
+            if filters:
+                assert lib.dav1d_hip_lister_filter_run(lh, C.byref(filters["fd"]), threads) == 0
+                frame.set_filters(sl["lvl"], filters["b4_stride"], filters["lut_e"], filters["lut_i"], filters["damping"])
+            t_c = time.perf_counter()
+            coef_bytes = int(lib.dav1d_hip_frame_coef_bytes(frame.h))
+            need_prep, need_mask = lib.dav1d_hip_lister_prep_elems(lh) * 2 + 4096, lib.dav1d_hip_lister_mask_bytes(lh) + 4096
+            if sl["prep"] is None or sl["prep"].nbytes < need_prep:
+                sl["prep"] = ctx.buffer(need_prep + need_prep // 4)
+            if sl["mask"] is None or sl["mask"].nbytes < need_mask:
+                sl["mask"] = ctx.buffer(need_mask + need_mask // 4)
+                assert lib.dav1d_hip_upload((up_ctx or ctx).h, sl["mask"].ptr, const_masks.ctypes.data, nb.value) == 0
+            todo.put((frame, lh, sl, it))
+            if it >= warm:
+                wait_ms.append((t_a - t0) * 1e3)
+                list_ms.append((t_b - t_a) * 1e3)
+                flist_ms.append((t_c - t_b) * 1e3)
+    finally:
+        todo.put(None)
+        th.join()
+    if err:
+        raise err[0]
+    n = frames - warm
+    out = {"ms_per_frame": round((t_end[-1] - t_end[warm - 1]) / n * 1e3, 3), "frames": n, "frames_in_flight": depth,
+           "list_ms": round(float(np.median(list_ms)), 3), "frame_end_ms": round(float(np.median(end_ms[warm:])), 3),
+           "slot_wait_ms": round(float(np.median(wait_ms)), 3), "host_threads": threads,
+           "packed_coef_bytes_per_frame": coef_bytes}
+    if filters:
+        out["filter_list_ms"] = round(float(np.median(flist_ms)), 3)
+    out["value"] = round(w * h / (out["ms_per_frame"] * 1e-3) / 1e6, 1)
+    out["unit"] = "Mpixels/s"
+    for sl in slots:
+        for k in ("cur", "prep", "mask", "lvl"):
+            if sl[k] is not None:
+                sl[k].free()
+    if up_ctx:
+        up_ctx.close()
+    return out, last.get("planes")
+
+
+def run_sustained(ctx, w=7680, h=4320, bpc=10, frames=10, threads=None, tile_cols=4, tile_rows=1, seed=0xE2E, check=None, depth=2, warm=2):
+    """The reconstruction route with frames in flight (run_pipelined): the synthetic inter frame of run(), every frame with a
+    coefficient arena of its own that the packing lister consumes; nothing dense crosses the host link."""
+    layout = api.LAYOUT_I420
+    ho = HandOff(w, h, layout, bpc, True, tile_cols, tile_rows)
+    sp = c2_params(seed)
+    rc = ctx.lib.dav1d_hip_synth_frame(C.byref(ho.desc), C.byref(sp), ho.cf.ctypes.data, ho.cf.nbytes, len(ho.cbi), None, 0)
+    assert rc == 0, rc
+    rng = np.random.default_rng(seed)
+    refs = []
+    for _ in range(3):
+        r = ctx.picture(w, h, layout, bpc)
+        for pl in range(3):
+            rows, cols = r.padded_shape(pl)
+            r.upload(pl, rng.integers(0, 1 << bpc, size=(rows, cols), dtype=np.uint16).astype(r.dtype))
+        refs.append(r)
+    n_tiles = ho.desc.n_tile_cols * ho.desc.n_tile_rows
+    threads = threads or n_tiles
+    cfs = [ho.cf.copy() for _ in range(frames)]
+    out, planes = run_pipelined(ctx, ho.desc, cfs, w, h, layout, bpc, [refs[i % 3] for i in range(7)], threads, depth, warm)
+    out["tiles"] = n_tiles
+    out["host_arena_left_zero"] = not any(bool(c.any()) for c in cfs)
+    out["workload"] = ("%dx%d 4:2:0 %d-bit inter frame from pass-1 hand-off arrays, %d frames in flight: the packing lister on %d library "
+                       "threads over %d x %d tiles (eob + 1 values per block into the frame's pinned arena, host arena zeroed), chunk "
+                       "preparation on the listing threads, frame_end (transfer + gather + launches + sync) of frame n under the "
+                       "listing of frame n + 1" % (w, h, bpc, depth, threads, ho.desc.n_tile_cols, ho.desc.n_tile_rows))
+    if check is not None and planes is not None:
+        out["parity"] = check(ho, planes, refs)
+    for o in refs:
+        o.free()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=6)
@@ -227,8 +366,12 @@ def main():
     ap.add_argument("--height", type=int, default=4320)
     ap.add_argument("--intra-pct", type=int, default=0)
     ap.add_argument("--key-frame", type=int, default=0)
+    ap.add_argument("--sustained", type=int, default=0, help="frames in flight (0: one frame at a time, dense coefficients)")
     a = ap.parse_args()
     ctx = api.Context(0)
+    if a.sustained:
+        print(json.dumps(run_sustained(ctx, a.width, a.height, 10, a.frames, a.threads or None, a.tile_cols, a.tile_rows, depth=a.sustained)))
+        return
     print(json.dumps(run(ctx, a.width, a.height, 10, a.frames, a.threads or None, a.tile_cols, intra_pct=a.intra_pct, key_frame=bool(a.key_frame), tile_rows=a.tile_rows)))
 
 

@@ -19,6 +19,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#define __device__
+#include "../csrc/av1_scan_dev.h"      /* dav1d_scans, flattened (generated from the reference build's tables by tools/gen_tables.py) */
+#undef __device__
+
 /* internal entry points of the frame driver (csrc/frame.hip) */
 int dav1d_hip_frame_picture(const Dav1dHipFrame *f, Dav1dHipPicture *out);
 
@@ -78,6 +82,7 @@ typedef struct Out {
     VEC(Dav1dHipCompTask) blend;  VEC(uint16_t) blend_step;
     VEC(Dav1dHipItxTask) sitx;    VEC(uint16_t) sitx_step;
     VEC(Dav1dHipMcTask) smc;      VEC(uint16_t) smc_step;       /* intra block copies: predictions from the frame's own pixels */
+    uint8_t *pack; size_t npack, pack_cap;                     /* packing lister: the tile-sbrow's coefficient values (npack of them) */
 } Out;
 
 typedef struct Walk {
@@ -186,6 +191,40 @@ static uint32_t dst_off(const Dav1dHipLister *l, const int pl, const int x_px, c
     return (uint32_t) ((size_t) y_px * l->stride[pl] + x_px);
 }
 
+/* Packing (Dav1dHipFrameDesc.cf): the eob + 1 values of one block, in the order decode_coefs() produced them — scan position i
+ * sits at dav1d_scans[tx][i] for the 2-D transform classes, at i for the horizontal 1-D classes, column-interleaved for the
+ * vertical ones (src/recon_tmpl.c:458-520, 548-575) — move to the tile-sbrow's value buffer; where they were becomes zero, as
+ * the reference's inverse transform leaves its slab (src/itx_tmpl.c:60,108).  Returns the offset of the first value. */
+static uint32_t pack_block(Walk *w, const int tx, const int txtp, const int eob, const size_t cf_byte) {
+    const Dav1dHipLister *l = w->l;
+    Out *o = w->o;
+    const size_t n = (size_t) eob + 1;
+    if (o->npack + n > o->pack_cap) {
+        size_t nc = o->pack_cap ? o->pack_cap * 2 : 1 << 16;
+        while (nc < o->npack + n) nc *= 2;
+        void *q = realloc(o->pack, nc * (size_t) l->csz);
+        if (!q) { v_oom = 1; return 0; }
+        o->pack = (uint8_t *) q; o->pack_cap = nc;
+    }
+    const HostTx *t = &h_tx[tx];
+    const int sw = imin(t->w, 8) * 4, sh = imin(t->h, 8) * 4, lsw = sw == 4 ? 2 : sw == 8 ? 3 : sw == 16 ? 4 : 5;      /* HostTx.w / h: 4-pixel units */
+    /* TxfmType: H_DCT 10, V_DCT 11, H_ADST 12, V_ADST 13, H_FLIPADST 14, V_FLIPADST 15 (src/levels.h:80-100); the transposed storage
+     * of the coefficient slab makes the V_ kinds the row-contiguous ones (src/recon_tmpl.c:458-496) */
+    const int cls = (txtp == 11 || txtp == 13 || txtp == 15) ? 1 : (txtp == 10 || txtp == 12 || txtp == 14) ? 2 : 0;
+    const uint16_t *scan = av1_scans + av1_scan_off[tx];
+    const uint32_t at = (uint32_t) o->npack;
+#define PACK_LOOP(T) do { \
+        T *src = (T *) ((uint8_t *) l->d.cf + cf_byte), *dst = (T *) o->pack + o->npack; \
+        if (cls == 0) for (size_t i = 0; i < n; i++) { const int rc = scan[i]; dst[i] = src[rc]; src[rc] = 0; } \
+        else if (cls == 1) { memcpy(dst, src, n * sizeof(T)); memset(src, 0, n * sizeof(T)); } \
+        else for (size_t i = 0; i < n; i++) { const int rc = ((int) i & (sw - 1)) * sh + ((int) i >> lsw); dst[i] = src[rc]; src[rc] = 0; } \
+    } while (0)
+    if (l->hbd) PACK_LOOP(int32_t); else PACK_LOOP(int16_t);
+#undef PACK_LOOP
+    o->npack += n;
+    return at;
+}
+
 /* one transform block: the next cbi entry, its slab, the task (src/recon_tmpl.c:796-816, 1292-1330, 1924-1970) */
 static void emit_tx(Walk *w, const int pl, const int tx, const int x_px, const int y_px, const unsigned step) {
     Dav1dHipLister *l = w->l;
@@ -199,6 +238,7 @@ static void emit_tx(Walk *w, const int pl, const int tx, const int x_px, const i
     memset(k, 0, sizeof(*k));
     k->dst_off = dst_off(l, pl, x_px, y_px);
     k->cf_off = (uint32_t) (cf / l->csz);
+    if (l->d.cf) { k->cf_off = pack_block(w, tx, txtp, eob, cf); k->flags = DAV1D_HIP_ITX_PACKED; }
     k->eob = (int16_t) eob;
     k->tx = (uint8_t) tx;
     k->txtp = (uint8_t) txtp;
@@ -951,8 +991,15 @@ int dav1d_hip_lister_create(Dav1dHipLister **out, const Dav1dHipFrameDesc *d, Da
     return 0;
 }
 
+#ifdef LISTER_PROF
+void dav1d_hip_lister_prof(void);
+#endif
 void dav1d_hip_lister_destroy(Dav1dHipLister *l) {
     if (!l) return;
+#ifdef LISTER_PROF
+    dav1d_hip_lister_prof();
+    { extern void dav1d_hip_chunk_prof(void); dav1d_hip_chunk_prof(); }
+#endif
     free(l->owner);
     for (int p = 0; p < 3; p++) free(l->step[p]);
     free(l->tiles);
@@ -994,6 +1041,19 @@ int dav1d_hip_lister_block_warp(Dav1dHipWarpParams *wm, const int16_t *matrix, c
     return h_shear_params(wm);
 }
 const uint8_t *dav1d_hip_lister_const_masks(size_t *bytes) { const HostMasks *m = h_masks(); if (bytes) *bytes = m->size; return m->blob; }
+
+#ifdef LISTER_PROF
+#include <time.h>
+#include <stdio.h>
+static uint64_t prof_ns[4];
+static uint64_t prof_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (uint64_t) ts.tv_sec * 1000000000ull + ts.tv_nsec; }
+#define PROF_T(v) const uint64_t v = prof_now()
+#define PROF_ADD(i, d) __atomic_fetch_add(&prof_ns[i], (d), __ATOMIC_RELAXED)
+void dav1d_hip_lister_prof(void) { fprintf(stderr, "lister: walk %.2f ms, submit %.2f ms\n", prof_ns[0] * 1e-6, prof_ns[1] * 1e-6); prof_ns[0] = prof_ns[1] = 0; }
+#else
+#define PROF_T(v)
+#define PROF_ADD(i, d)
+#endif
 
 /* stable counting sort of stepped records by step, then one submit per step */
 static int submit_steps(Dav1dHipLister *l, Out *o) {
@@ -1038,15 +1098,26 @@ int dav1d_hip_lister_tile_sbrow(Dav1dHipLister *l, const int tile_row, const int
     w.row_end = imin(l->d.row_start_sb[tile_row + 1] << sb_shift, l->bh);
     const int by = sby << sb_shift;
     v_oom = 0;
+    PROF_T(t0);
     for (int bx = w.col_start; bx < w.col_end && !w.err && !v_oom; bx += l->sb_step)
         walk_sb(&w, l->d.sb128 ? H_BL_128X128 : H_BL_64X64, bx, by, 1, 0);
     int rc = v_oom ? -ENOMEM : w.err;
+    if (!rc && l->d.cf && (o.itx.n || o.sitx.n)) {
+        /* the tile-sbrow's values join the frame's coefficient arena; the tasks counted from the start of the buffer */
+        uint32_t base = 0;
+        rc = dav1d_hip_frame_submit_coefs(l->frame, o.pack, o.npack, &base);
+        for (size_t i = 0; i < o.itx.n; i++) o.itx.p[i].cf_off += base;
+        for (size_t i = 0; i < o.sitx.n; i++) o.sitx.p[i].cf_off += base;
+    }
+    PROF_T(t1);
     if (!rc) rc = dav1d_hip_frame_submit_tile_sbrow(l->frame, o.mc.p, o.mc.n, o.comp.p, o.comp.n, o.itx.p, o.itx.n);
+    PROF_T(t2);
+    PROF_ADD(0, t1 - t0); PROF_ADD(1, t2 - t1);
     if (!rc && o.warp.n) rc = dav1d_hip_frame_submit_warp(l->frame, o.warp.p, o.warp.n);
     if (!rc && o.scaled.n) rc = dav1d_hip_frame_submit_scaled(l->frame, o.scaled.p, o.scaled.n);
     if (!rc && o.smc.n) rc = dav1d_hip_frame_submit_step_copy(l->frame, o.smc.p, o.smc_step.p, o.smc.n);
     if (!rc) rc = submit_steps(l, &o);
-    free(o.smc.p); free(o.smc_step.p);
+    free(o.smc.p); free(o.smc_step.p); free(o.pack);
     free(o.mc.p); free(o.comp.p); free(o.warp.p); free(o.scaled.p); free(o.itx.p);
     free(o.ipred.p); free(o.ipred_step.p); free(o.blend.p); free(o.blend_step.p); free(o.sitx.p); free(o.sitx_step.p);
     if (!rc) cur->next_sby = sby + 1;

@@ -618,6 +618,14 @@ DAV1D_HIP_API int dav1d_hip_frame_set_refs(Dav1dHipFrame *f, const Dav1dHipPictu
 DAV1D_HIP_API int dav1d_hip_frame_submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc,
                                                     const Dav1dHipCompTask *comp, size_t n_comp,
                                                     const Dav1dHipItxTask *itx, size_t n_itx);
+/* The values DAV1D_HIP_ITX_PACKED residual tasks of this frame refer to, a share at a time (a tile-sbrow's): n values (int32 at
+ * more than 8 bits per component, int16 at 8) are copied into the frame's own coefficient arena; *base = the offset, in values, to
+ * add to the cf_off of the tasks that index `vals` from 0.  Such a frame is ended with coef = NULL (a frame holds packed tasks or
+ * dense ones, not both: -EINVAL at dav1d_hip_frame_end); the arena goes to the device with the prepared lists
+ * (dav1d_hip_frame_flush, dav1d_hip_frame_end).  Thread-safe. */
+DAV1D_HIP_API int dav1d_hip_frame_submit_coefs(Dav1dHipFrame *f, const void *vals, size_t n, uint32_t *base);
+/* bytes of that arena in use so far (what will cross the host link for the frame's residuals) */
+DAV1D_HIP_API size_t dav1d_hip_frame_coef_bytes(const Dav1dHipFrame *f);
 /* Intra blocks of wavefront step `step` (their neighbours are final after the inter blocks of the frame and the intra blocks of
  * the steps before): predictions + residuals; `aux` = DEVICE arena of packed palette indices (NULL if no PAL task).  Thread-safe. */
 DAV1D_HIP_API int dav1d_hip_frame_submit_intra_step(Dav1dHipFrame *f, size_t step, const Dav1dHipIpredTask *ipred, size_t n_ipred,
@@ -753,6 +761,14 @@ typedef struct Dav1dHipFrameDesc {
     uint8_t lossless[8];         /* frame_hdr->segmentation.lossless[seg_id]: the deblocking masks of an inter block of such a
                                     segment are built with 4x4 transforms whatever b->max_ytx / uvtx say (src/decode.c:1890-1893;
                                     a skipped block keeps the block's largest sizes in its record, :456-470) */
+    void *cf;                    /* f->frame_thread.cf (HOST, writable) or NULL.  NULL: the residual tasks point into a dense copy of
+                                    the arena that the caller sends to the device itself (dav1d_hip_frame_end's `coef`).  Otherwise
+                                    the lister PACKS: per transform block it gathers the eob + 1 values the entropy decoder
+                                    produced (scan order, see DAV1D_HIP_ITX_PACKED) into the frame's own coefficient arena
+                                    (dav1d_hip_frame_submit_coefs) and zeroes them where they were — what the reference's
+                                    itxfm_add does to the slab it consumed (src/itx_tmpl.c:60,108): when the last tile-sbrow is
+                                    listed, cf is ready for the next frame's pass 1, and only the values that exist cross the
+                                    host link.  dav1d_hip_frame_end is then called with coef = NULL. */
 } Dav1dHipFrameDesc;
 
 /* Byte offset of a tile's first coefficient in the cf arena, of its first cbi entry and of its first palette index byte, as

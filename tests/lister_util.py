@@ -298,8 +298,10 @@ def fill_pictures(rf, seed):
                 a[...] = v.astype(a.dtype)
 
 
-def run_hip(ctx, rf, d, threads=1, with_filters=False, own_masks=False):
-    """lister -> frame API -> kernels; returns the reconstructed planes (visible area) and the lister handle stats"""
+def run_hip(ctx, rf, d, threads=1, with_filters=False, own_masks=False, packed=False):
+    """lister -> frame API -> kernels; returns the reconstructed planes (visible area) and the lister handle stats.
+    packed: the lister gathers the coefficients that exist out of the host arena (Dav1dHipFrameDesc.cf) into the frame's own
+    coefficient arena, zeroing them in place; no dense arena goes to the device."""
     n_pl = 1 if rf.layout == 0 else 3
     cur = ctx.picture(rf.w, rf.ht, rf.layout, rf.bpc)
     refs = []
@@ -313,7 +315,12 @@ def run_hip(ctx, rf, d, threads=1, with_filters=False, own_masks=False):
             refs.append(r)
     frame = ctx.frame(cur, refs)
     lh = C.c_void_p()
+    host_cf = None
+    if packed:
+        host_cf = rf.cf_copy.copy()
+        d.cf = host_cf.ctypes.data
     rc = ctx.lib.dav1d_hip_lister_create(C.byref(lh), C.byref(d), frame.h)
+    d.cf = None
     assert rc == 0, "lister_create: %d" % rc
     jobs = [(tr, tc) for tr in range(d.n_tile_rows) for tc in range(d.n_tile_cols)]
 
@@ -333,7 +340,7 @@ def run_hip(ctx, rf, d, threads=1, with_filters=False, own_masks=False):
     mask_bytes = ctx.lib.dav1d_hip_lister_mask_bytes(lh)
     steps = ctx.lib.dav1d_hip_lister_steps(lh)
     # arenas: coefficients = the reference's cf array verbatim; aux = its packed palette indices
-    coef = ctx.buffer_from(rf.cf_copy)
+    coef = None if packed else ctx.buffer_from(rf.cf_copy)
     prep = ctx.buffer(prep_elems * 2 + 64)
     mask = ctx.buffer(mask_bytes + 64)
     nb = C.c_size_t()
@@ -390,7 +397,7 @@ def run_hip(ctx, rf, d, threads=1, with_filters=False, own_masks=False):
         out = [fpic.download(pl) for pl in range(n_pl)]
     else:
         out = [cur.download(pl) for pl in range(n_pl)]
-    coef_after = coef.download(np.uint8)
+    coef_after = host_cf if packed else coef.download(np.uint8)
     ctx.lib.dav1d_hip_lister_destroy(lh)
     frame.destroy()
     for b in (coef, prep, mask, aux, lvl):
@@ -570,6 +577,51 @@ def full_route_rate(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=64, frame
                             "filter tasks -> reconstruction, deblocking (levels 20/28/16/24), CDEF (4 strength pairs), switchable restoration "
                             "(64-pixel units); coefficients (dense) and level cache cross the host link every frame" % (w, h, bpc, threads))
         for o in refs + [cur, coef, lvl] + ([prep, mask] if prep is not None else []):
+            o.free()
+        return out
+    finally:
+        rf.destroy()
+
+
+def full_route_sustained(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=64, frames=10, depth=2, warm=2, seed=0xF0E):
+    """full_route_rate with frames in flight (dav1d_amd.e2e.run_pipelined): frame n + 1 is listed — blocks by the packing lister,
+    then the filter tasks — while frame n runs on the device; per frame only the coefficients that exist, the prepared lists and the
+    level cache cross the host link.  The last frame's final picture is compared with the reference's dav1d_decode_tile_sbrow +
+    dav1d_filter_sbrow.  Returns the measurement dict, or None without the reference build."""
+    from dav1d_amd import e2e
+    if ref_lib() is None:
+        return None
+    filters = dict(lf=(20, 28, 16, 24, 0, False), cdef=(5, 2, [17, 33, 0, 63], [5, 0, 20, 48]), lr=([1, 1, 1], [6, 6]))
+    rf = RefFrame(w, h, 1, bpc, is_inter=True, sb128=True, tile_cols=tile_cols, tile_rows=tile_rows, filters=filters)
+    try:
+        sp = e2e.c2_params(seed)
+        d = synth(ctx, rf, sp)
+        fill_pictures(rf, seed + 1)
+        rf.build_filter_inputs(seed)
+        rf.recon(min(threads, 64))
+        rf.filter()
+        refs = []
+        for i in range(7):
+            r = ctx.picture(rf.p.ref_w[i], rf.p.ref_h[i], 1, bpc)
+            for pl in range(3):
+                rows, cols = r.padded_shape(pl)
+                r.upload(pl, np.ascontiguousarray(rf.plane(1 + i, pl)[:rows, :cols]))
+            refs.append(r)
+        lut = rf.array("lim_lut", np.uint8)
+        flt = dict(fd=rf.filter_desc(), lvl_host=rf.array("lf_level", np.uint8), b4_stride=rf.b4_stride, lut_e=lut[0:64], lut_i=lut[64:128],
+                   damping=rf.p.cdef_damping + bpc - 8)
+        cfs = [rf.cf_copy.copy() for _ in range(frames)]
+        out, planes = e2e.run_pipelined(ctx, d, cfs, w, h, 1, bpc, refs, threads, depth, warm, filters=flt)
+        bad = compare(rf, planes)
+        if bad:
+            raise AssertionError("full route, frames in flight: filtered planes differ from the reference's: %s" % bad)
+        out.update(tiles=tile_cols * tile_rows, host_arena_left_zero=not any(bool(c.any()) for c in cfs),
+                   parity="bit-exact vs the reference's dav1d_decode_tile_sbrow + dav1d_filter_sbrow (last of the frames)",
+                   workload="%dx%d 4:2:0 %d-bit inter frame, %d x %d tiles, %d frames in flight: hand-off arrays + pass 1's filter inputs -> %d library "
+                            "threads (packing lister, then filter tasks) while the frame before runs reconstruction, deblocking, CDEF, switchable "
+                            "restoration; eob + 1 values per block, the prepared lists and the level cache cross the host link" %
+                            (w, h, bpc, tile_cols, tile_rows, depth, threads))
+        for o in refs:
             o.free()
         return out
     finally:

@@ -28,3 +28,48 @@ def test_full_route_with_filters_matches_the_reference(ctx):
     w, h = (384, 264) if ctx.backend == "emu" else (1920, 1080)
     out = lu.full_route_rate(ctx, w, h, 10, tile_cols=2, tile_rows=2, threads=4, frames=3)
     assert out and out["parity"].startswith("bit-exact") and out["total_ms"] > 0
+
+
+def test_frames_in_flight_with_the_packing_lister(ctx):
+    """e2e.run_sustained / lister_util.full_route_sustained (bench.py's *_sustained legs): frame n + 1 is listed while frame n runs on the
+    device; the packing lister (Dav1dHipFrameDesc.cf) moves the coefficients that exist into the frame's own arena and leaves the host
+    arena zero, nothing dense crosses the host link; the last frame of the run equals the reference's."""
+    if lu.ref_lib() is None:
+        pytest.skip("no reference build (oracle/_ref)")
+    w, h = (384, 256) if ctx.backend == "emu" else (1920, 1080)
+    out = e2e.run_sustained(ctx, w, h, 10, frames=4, threads=3, tile_cols=2, tile_rows=2, seed=78, warm=1,
+                            check=lambda ho, planes, refs: lu.check_handoff_against_reference(ho, planes, refs))
+    assert out["parity"].startswith("bit-exact"), out["parity"]
+    assert out["host_arena_left_zero"] and 0 < out["packed_coef_bytes_per_frame"] < w * h * 6 // 2
+    out = lu.full_route_sustained(ctx, w, h + 8, 10, tile_cols=2, tile_rows=2, threads=4, frames=4, warm=1)
+    assert out and out["parity"].startswith("bit-exact") and out["host_arena_left_zero"]
+
+
+def test_packed_and_dense_residuals_do_not_mix_in_a_frame(ctx):
+    """a frame's residual tasks all point into the frame's own coefficient arena (dav1d_hip_frame_submit_coefs) or all into the
+    caller's dense one: dav1d_hip_frame_end refuses the mix and a packed frame that is handed a dense arena."""
+    import ctypes as C
+    import numpy as np
+    from dav1d_amd import api
+    cur = ctx.picture(64, 64, api.LAYOUT_I420, 8)
+    frame = ctx.frame(cur, [])
+    vals = np.array([64, 0, 0, 3], np.int16)
+    base = C.c_uint32(123)
+    assert ctx.lib.dav1d_hip_frame_submit_coefs(frame.h, vals.ctypes.data, len(vals), C.byref(base)) == 0 and base.value == 0
+    assert ctx.lib.dav1d_hip_frame_submit_coefs(frame.h, vals.ctypes.data, len(vals), C.byref(base)) == 0 and base.value == 32   # 64-byte segments
+    assert ctx.lib.dav1d_hip_frame_coef_bytes(frame.h) == 128
+    t = np.zeros(2, api.ITX_TASK)
+    t["tx"], t["eob"], t["flags"], t["cf_off"] = 0, 3, [1, 0], [0, 0]
+    t["dst_off"] = [0, 8]
+    assert ctx.lib.dav1d_hip_frame_submit_tile_sbrow(frame.h, None, 0, None, 0, t.ctypes.data, 2) == 0
+    dense = ctx.buffer(4096)
+    dense.zero()
+    assert ctx.lib.dav1d_hip_frame_end(frame.h, None, None, None, None, None) == -22
+    frame.destroy()
+    frame = ctx.frame(cur, [])
+    assert ctx.lib.dav1d_hip_frame_submit_coefs(frame.h, vals.ctypes.data, len(vals), C.byref(base)) == 0
+    assert ctx.lib.dav1d_hip_frame_submit_tile_sbrow(frame.h, None, 0, None, 0, t[:1].ctypes.data, 1) == 0
+    assert ctx.lib.dav1d_hip_frame_end(frame.h, dense.ptr, None, None, None, None) == -22
+    frame.destroy()
+    dense.free()
+    cur.free()

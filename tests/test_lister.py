@@ -32,7 +32,8 @@ def scaled_refs(w, h):
     return rs
 
 
-def run_case(ctx, w, h, layout, bpc, seed, is_inter=True, tiles=(1, 1), threads=1, sb128=True, ref_sizes=None, gmv=None, segments=None, **kw):
+def run_case(ctx, w, h, layout, bpc, seed, is_inter=True, tiles=(1, 1), threads=1, sb128=True, ref_sizes=None, gmv=None, segments=None,
+             packed=False, **kw):
     rf = lu.RefFrame(w, h, layout, bpc, is_inter=is_inter, tile_cols=tiles[0], tile_rows=tiles[1], sb128=sb128,
                      screen_content=1 if kw.get("palette") else 0, ref_sizes=ref_sizes, gmv=gmv, segments=segments)
     try:
@@ -43,7 +44,7 @@ def run_case(ctx, w, h, layout, bpc, seed, is_inter=True, tiles=(1, 1), threads=
             assert int(((blk[:, 3] == 0) & ((blk[:, 0] | blk[:, 1]) != 0)).sum()) > 50
         lu.fill_pictures(rf, seed + 1)
         rf.recon()
-        got, st = lu.run_hip(ctx, rf, d, threads)
+        got, st = lu.run_hip(ctx, rf, d, threads, packed=packed)
         bad = lu.compare(rf, got)
         assert not bad, "planes differ from the reference's pass 2: (plane, pixels, first y, x, want, got) %s" % bad
         # the coefficient arena is consumed exactly as the reference consumes it (itx zeroes what it read)
@@ -184,6 +185,21 @@ def test_every_tool_mixed(ctx, name, w, h, layout, bpc, kw):
         assert st["steps"] > 20          # a key frame is one long wavefront
 
 
+# The packing lister (Dav1dHipFrameDesc.cf): the same pixels from eob + 1 values per block, and the host arena left as the reference's
+# inverse transforms leave it (zero).  The CPU run takes one case per coefficient order and pixel type; the GPU run the whole mix.
+PACKED_CPU = {"420_10", "444_8", "tiles_3_threads", "key_444_10", "key_intrabc_420_8", "segments_lossless_420_10"}
+
+
+@pytest.mark.parametrize("name,w,h,layout,bpc,kw", MIX + [("vartx_txtp", 256, 192, 1, 8, dict(PLAIN, tx_split_pct=40, alt_txtp_pct=60)),
+                                                         ("vartx_txtp_10", 256, 192, 1, 10, dict(PLAIN, tx_split_pct=40, alt_txtp_pct=80))],
+                         ids=[t[0] for t in MIX] + ["vartx_txtp", "vartx_txtp_10"])
+def test_packing_lister(ctx, name, w, h, layout, bpc, kw):
+    if ctx.backend == "emu" and name not in PACKED_CPU and not name.startswith("vartx"):
+        pytest.skip("GPU run only")
+    st = run_case(ctx, w, h, layout, bpc, 300 + len(name), packed=True, **kw)
+    assert not st["coef_after"].any()
+
+
 @pytest.mark.gpu
 def test_larger_frame_many_tiles_threads():
     ctx = util.make_context("hip")
@@ -191,6 +207,7 @@ def test_larger_frame_many_tiles_threads():
     try:
         run_case(ctx, 1920, 1080, 1, 10, 7, tiles=(4, 2), threads=8)
         run_case(ctx, 1280, 720, 1, 8, 8, tiles=(2, 1), threads=2, is_inter=False)
+        run_case(ctx, 1920, 1080, 1, 10, 9, tiles=(4, 2), threads=8, packed=True)
     finally:
         ctx.close()
 

@@ -1,10 +1,34 @@
-"""End-to-end route with different lister thread pools / upload modes (run on the GPU box)."""
-import sys, os
+"""Frames-in-flight legs of bench.py on their own (no headline step): python tools/e2e_probe.py [--frames N] [--threads T] [--depth D]"""
+import argparse
+import json
+import os
+import sys
+
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from dav1d_amd import api, e2e
-ctx = api.Context(0)
-for up in (1, 0):
-    ctx.set_option("chunk_upload", up)
-    for native, thr in ((False, 32), (True, 32), (True, 64), (True, 105)):
-        r = e2e.run(ctx, frames=5, threads=thr, tile_cols=16, tile_rows=8, native_threads=native)
-        print("per-chunk upload" if up else "one upload      ", "native" if native else "python", thr, {k: r[k] for k in ("list_ms", "frame_end_ms", "total_ms", "value")})
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=12)
+    ap.add_argument("--threads", type=int, default=64)
+    ap.add_argument("--depth", type=int, default=2)
+    ap.add_argument("--tiles", default="16x8")
+    ap.add_argument("--no-full", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    a = ap.parse_args()
+    from dav1d_amd import api, e2e
+    import lister_util as lu
+    ctx = api.Context(0)
+    tc, tr = (int(v) for v in a.tiles.split("x"))
+    chk = None if a.no_check else (lambda ho, planes, refs: lu.check_handoff_against_reference(ho, planes, refs))
+    out = {"recon": e2e.run_sustained(ctx, 7680, 4320, 10, frames=a.frames, threads=a.threads, tile_cols=tc, tile_rows=tr, depth=a.depth, check=chk)}
+    if not a.no_full:
+        out["full_table"] = lu.full_route_sustained(ctx, 7680, 4320, 10, tc, tr, threads=a.threads, frames=a.frames, depth=a.depth)
+    for v in out.values():
+        v.pop("workload", None)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
