@@ -39,7 +39,7 @@ struct Dav1dHipContext {
     // chunked frames (chunk.hip): pinned slabs recycled between frames, the device arenas of the frame in flight, a copy stream
     struct Slab { uint8_t *host; size_t cap; };
     std::mutex pool_mtx;
-    std::vector<Slab> free_slabs;
+    std::vector<Slab> free_slabs[48];          // by size class: slab capacities are powers of two, class = log2(cap)
     struct Arena { uint8_t *dev; size_t cap; };
     std::vector<Arena> free_arenas;            // chunk arenas of finished frames (a frame in flight owns one)
     std::vector<Arena> free_task_bufs;         // task-list buffers of the *_batch calls (TaskBuf below)

@@ -96,7 +96,7 @@ void dav1d_hip_close(Dav1dHipContext *c) {
     if (c->gather_dev) hipFree(c->gather_dev);
     if (c->segtab_dev) hipFree(c->segtab_dev);
     if (c->pending_slab) hipHostFree(c->pending_slab);
-    for (const Dav1dHipContext::Slab &sl : c->free_slabs) hipHostFree(sl.host);
+    for (const std::vector<Dav1dHipContext::Slab> &cls : c->free_slabs) for (const Dav1dHipContext::Slab &sl : cls) hipHostFree(sl.host);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }

@@ -24,24 +24,26 @@ namespace {
 
 // ------------------------------------------------------------------ pinned slabs, recycled through the context
 
+// capacities are powers of two (>= 256 KB): one free list per size, so that a 256 KB chunk blob never walks off with the 64 MB twin
+// of an arena (a fresh hipHostMalloc of that size is a millisecond-class stall) and a request costs no search — with best fit over
+// ONE list, the 1,800 requests of an 8K frame each scanned the few thousand slabs of the pool under its lock
+static int slab_class(size_t cap) { int k = 0; while (((size_t) 1 << k) < cap) k++; return k < 47 ? k : 47; }
+
 uint8_t *slab_get(Dav1dHipContext *c, size_t bytes, size_t *cap) {
+    size_t want = 1 << 18;
+    while (want < bytes) want <<= 1;
     {
         std::lock_guard<std::mutex> lk(c->pool_mtx);
-        // best fit: a 256 KB chunk blob must not walk off with the 16 - 64 MB twin of the arena that the next frame_begin wants
-        // (a fresh hipHostMalloc of that size is a millisecond-class stall, and the pool would grow with every overlap)
-        int best = -1;
-        for (size_t i = 0; i < c->free_slabs.size(); i++)
-            if (c->free_slabs[i].cap >= bytes && (best < 0 || c->free_slabs[i].cap < c->free_slabs[best].cap)) best = (int) i;
-        if (best >= 0) {
-            const Dav1dHipContext::Slab s = c->free_slabs[best];
-            c->free_slabs[best] = c->free_slabs.back();
-            c->free_slabs.pop_back();
+        // the exact class, else the next two up (a slab four times too large is still a better deal than a new allocation)
+        for (int k = slab_class(want), e = std::min(k + 3, 48); k < e; k++) {
+            std::vector<Dav1dHipContext::Slab> &v = c->free_slabs[k];
+            if (v.empty()) continue;
+            const Dav1dHipContext::Slab s = v.back();
+            v.pop_back();
             *cap = s.cap;
             return s.host;
         }
     }
-    size_t want = 1 << 18;
-    while (want < bytes) want <<= 1;
     void *p = nullptr;
     if (hipHostMalloc(&p, want, 0) != hipSuccess) return nullptr;
     *cap = want;
@@ -51,33 +53,37 @@ uint8_t *slab_get(Dav1dHipContext *c, size_t bytes, size_t *cap) {
 void slab_put(Dav1dHipContext *c, uint8_t *host, size_t cap) {
     if (!host) return;
     std::lock_guard<std::mutex> lk(c->pool_mtx);
-    c->free_slabs.push_back({ host, cap });
+    c->free_slabs[slab_class(cap)].push_back({ host, cap });
 }
 
-inline uint64_t src_key(const McTile &t) {
+// where a tile reads: (reference, plane, 64-row band, x) in 31 bits
+inline uint32_t src_key(const McTile &t) {
     const McRef &r = t.r[0];
-    const uint64_t y = (uint64_t) (r.src_y + 4096) & 0xffff, x = (uint64_t) (r.src_x + 4096) & 0xffff;
-    return ((uint64_t) r.ref << 56) | ((uint64_t) t.plane << 52) | ((y >> 6) << 32) | x;
+    const uint32_t y = (uint32_t) (r.src_y + 4096) & 0xffff, x = (uint32_t) (r.src_x + 4096) & 0xffff;
+    return ((uint32_t) (r.ref & 7) << 28) | ((uint32_t) (t.plane & 3) << 26) | ((y >> 6) << 16) | x;
 }
 
-// v ordered by key[i] (ties: original order); keys are computed once per element, not once per comparison
-template <typename T> void sort_by_key(std::vector<T> &v, const std::vector<uint64_t> &key) {
+// v ordered by key[i] (ties: original order); key and position travel as one 64-bit word through the sort
+template <typename T> void sort_by_key(std::vector<T> &v, const std::vector<uint32_t> &key) {
     const size_t n = v.size();
     if (n < 2) return;
-    std::vector<std::pair<uint64_t, uint32_t>> o(n);
-    for (size_t i = 0; i < n; i++) o[i] = { key[i], (uint32_t) i };
+    static thread_local std::vector<uint64_t> o;
+    static thread_local std::vector<T> t;
+    o.resize(n); t.resize(n);
+    bool sorted = true;
+    for (size_t i = 0; i < n; i++) { o[i] = (uint64_t) key[i] << 32 | (uint32_t) i; sorted &= !i || key[i] >= key[i - 1]; }
+    if (sorted) return;
     std::sort(o.begin(), o.end());
-    std::vector<T> t(n);
-    for (size_t i = 0; i < n; i++) t[i] = v[o[i].second];
-    v.swap(t);
+    for (size_t i = 0; i < n; i++) t[i] = v[(uint32_t) o[i]];
+    for (size_t i = 0; i < n; i++) v[i] = t[i];
 }
 
 // inside consecutive windows of `win` elements: stable counting sort by a one-byte key
 template <typename T> void group_in_windows(std::vector<T> &v, const std::vector<uint8_t> &key, size_t win) {
     const size_t n = v.size();
     if (n < 2 || !win) return;
-    std::vector<T> t(std::min(win, n));
-    std::vector<uint8_t> kt(std::min(win, n));
+    static thread_local std::vector<T> t;
+    t.resize(std::min(win, n));
     for (size_t lo = 0; lo < n; lo += win) {
         const size_t m = std::min(win, n - lo);
         uint32_t cnt[257] = { 0 };
@@ -90,11 +96,25 @@ template <typename T> void group_in_windows(std::vector<T> &v, const std::vector
     }
 }
 
+// pixel offset -> (x, y) of a plane: two hardware divisions per conversion were a quarter of the chunk preparation (a few
+// conversions per task, 1.6 M tasks per 8K frame); the quotient from a double product is exact after one correction step
+struct PlaneDiv {
+    uint32_t d;
+    double inv;
+    void set(int stride) { d = (uint32_t) (stride > 0 ? stride : 1); inv = 1.0 / (double) d; }
+    inline void xy(uint32_t off, int &x, int &y) const {
+        uint32_t q = (uint32_t) ((double) off * inv);
+        int64_t r = (int64_t) off - (int64_t) q * d;
+        if (r < 0) { q--; r += d; } else if (r >= (int64_t) d) { q++; r -= d; }
+        x = (int) r; y = (int) q;
+    }
+};
+
 // open-addressing map uint32 -> uint32 for the PREP producers of a chunk (keys: arena offsets)
 struct FlatMap {
     std::vector<uint32_t> k, v;
     uint32_t mask;
-    explicit FlatMap(size_t n) { size_t c = 16; while (c < 2 * n + 2) c <<= 1; k.assign(c, 0xffffffffu); v.assign(c, 0); mask = (uint32_t) c - 1; }
+    void reset(size_t n) { size_t c = 16; while (c < 2 * n + 2) c <<= 1; k.assign(c, 0xffffffffu); v.assign(c, 0); mask = (uint32_t) c - 1; }
     uint32_t *slot(uint32_t key, bool insert) {
         uint32_t h = (key * 2654435761u) & mask;
         while (k[h] != 0xffffffffu && k[h] != key) h = (h + 1) & mask;
@@ -106,22 +126,40 @@ struct FlatMap {
 // a plane-local map of 4x4 cells over the bounding box of a chunk's destination rectangles
 struct CellMap {
     int x0, y0, w, h, stride;       // in cells; stride of the PLANE in pixels
+    PlaneDiv dv;
     std::vector<uint16_t> writers;  // bit b: the prediction launch of tile shape b writes the cell; bit 15: the compound / blend launch
     std::vector<uint8_t> blend;     // a blend task writes the cell
     std::vector<uint32_t> tx_at;    // 1 + index of the (pairable) square transform block whose top-left cell this is
     size_t cell_of(uint32_t off) const {
-        const int px = (int) (off % (uint32_t) stride), py = (int) (off / (uint32_t) stride);
+        int px, py;
+        dv.xy(off, px, py);
         return (size_t) ((py >> 2) - y0) * w + ((px >> 2) - x0);
     }
     bool empty() const { return w <= 0 || h <= 0; }
     template <typename F> void each(uint32_t off, int bw, int bh, F f) {
-        const int px = (int) (off % (uint32_t) stride), py = (int) (off / (uint32_t) stride);
+        int px, py;
+        dv.xy(off, px, py);
         for (int cy = py >> 2; cy <= (py + bh - 1) >> 2; cy++)
             for (int cx = px >> 2; cx <= (px + bw - 1) >> 2; cx++) {
                 if (cx < x0 || cy < y0 || cx >= x0 + w || cy >= y0 + h) continue;
                 f((size_t) (cy - y0) * w + (cx - x0));
             }
     }
+};
+
+// What a chunk preparation needs besides its output, kept per thread: dav1d's workers (and the library's pool threads) prepare
+// a tile-sbrow after the other, and two dozen vectors allocated, faulted in page by page and handed back for each of the 1,800
+// chunks of an 8K frame were a third of the preparation time.
+struct ChunkScratch {
+    CellMap cm[3];
+    std::vector<char> taken, fused_prep;
+    std::vector<McTile> p_tiles[5], bins[MC_BINS], pt_sorted[5];
+    std::vector<uint32_t> p_itx[5], ord;
+    std::vector<Dav1dHipCompTask> rest, c_first, c_second;
+    std::vector<Dav1dHipItxTask> ibins[19], pk_sorted[5];
+    std::vector<uint8_t> gk;
+    std::vector<uint32_t> sk;
+    FlatMap producer, readers;
 };
 
 } // namespace
@@ -138,13 +176,13 @@ void Dav1dHipChunk::release(Dav1dHipContext *c) {
 static uint64_t cprof[16], cprof_n[4];
 static uint64_t cnow() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (uint64_t) ts.tv_sec * 1000000000ull + ts.tv_nsec; }
 #define P(i) { const uint64_t t_ = cnow(); __atomic_fetch_add(&cprof[i], t_ - tp_, __ATOMIC_RELAXED); tp_ = t_; }
-extern "C" void dav1d_hip_chunk_prof() { for (int i = 0; i < 10; i++) { fprintf(stderr, "%d:%.1f ", i, cprof[i] * 1e-6); cprof[i] = 0; } fprintf(stderr, " mc %llu comp %llu itx %llu\n", (unsigned long long) cprof_n[0], (unsigned long long) cprof_n[1], (unsigned long long) cprof_n[2]); cprof_n[0] = cprof_n[1] = cprof_n[2] = 0; }
+extern "C" void dav1d_hip_chunk_prof() { for (int i = 0; i < 14; i++) { fprintf(stderr, "%d:%.1f ", i, cprof[i] * 1e-6); cprof[i] = 0; } fprintf(stderr, " mc %llu comp %llu itx %llu\n", (unsigned long long) cprof_n[0], (unsigned long long) cprof_n[1], (unsigned long long) cprof_n[2]); cprof_n[0] = cprof_n[1] = cprof_n[2] = 0; }
 #else
 #define P(i)
 #endif
 int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHipPicture *geom, const Dav1dHipPicture *refs, int n_refs,
                           const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
-                          const Dav1dHipItxTask *itx, size_t n_itx)
+                          const Dav1dHipItxTask *itx, size_t n_itx, Dav1dHipChunkPlace place_blob, void *cookie)
 {
 #ifdef CHUNK_PROF
     uint64_t tp_ = cnow();
@@ -168,11 +206,13 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
     static const uint8_t tx_h[19] = { 4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16 };
 
     // ---- bounding boxes of what the chunk writes, per plane, in 4x4 cells
-    CellMap cm[3];
-    for (int p = 0; p < 3; p++) { cm[p].x0 = cm[p].y0 = 1 << 30; cm[p].w = cm[p].h = 0; cm[p].stride = stride[p]; }
+    static thread_local ChunkScratch scr;
+    CellMap (&cm)[3] = scr.cm;
+    for (int p = 0; p < 3; p++) { cm[p].blend.clear(); cm[p].tx_at.clear(); cm[p].x0 = cm[p].y0 = 1 << 30; cm[p].w = cm[p].h = 0; cm[p].stride = stride[p]; cm[p].dv.set(stride[p]); }
     int x1[3] = { -1, -1, -1 }, y1[3] = { -1, -1, -1 };
     auto grow = [&](int p, uint32_t off, int bw, int bh) {
-        const int px = (int) (off % (uint32_t) stride[p]), py = (int) (off / (uint32_t) stride[p]);
+        int px, py;
+        cm[p].dv.xy(off, px, py);
         cm[p].x0 = std::min(cm[p].x0, px >> 2); cm[p].y0 = std::min(cm[p].y0, py >> 2);
         x1[p] = std::max(x1[p], (px + bw - 1) >> 2); y1[p] = std::max(y1[p], (py + bh - 1) >> 2);
     };
@@ -197,21 +237,27 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
     P(1);
     // ---- pairing: a square transform block that covers exactly one prediction block runs with it in one wave (recon.hip)
     const int fuse_mask = recon_fuse_mask(c);
-    std::vector<char> taken(n_itx, 0);
+    std::vector<char> &taken = scr.taken;
+    taken.assign(n_itx, 0);
     if (fuse_mask) {
         for (int p = 0; p < 3; p++) if (!cm[p].empty()) cm[p].tx_at.assign((size_t) cm[p].w * cm[p].h, 0);
         for (size_t i = 0; i < n_itx; i++)
-            if (itx[i].tx <= 4 && (fuse_mask >> itx[i].tx & 1) && !(itx[i].dst_off % (uint32_t) stride[itx[i].plane] & 3) &&
-                !(itx[i].dst_off / (uint32_t) stride[itx[i].plane] & 3))
-                cm[itx[i].plane].tx_at[cm[itx[i].plane].cell_of(itx[i].dst_off)] = (uint32_t) i + 1;
+            if (itx[i].tx <= 4 && (fuse_mask >> itx[i].tx & 1)) {
+                CellMap &m = cm[itx[i].plane];
+                int px, py;
+                m.dv.xy(itx[i].dst_off, px, py);
+                if (!((px | py) & 3)) m.tx_at[(size_t) ((py >> 2) - m.y0) * m.w + ((px >> 2) - m.x0)] = (uint32_t) i + 1;
+            }
     }
-    std::vector<McTile> p_tiles[5];
-    std::vector<uint32_t> p_itx[5];
+    std::vector<McTile> (&p_tiles)[5] = scr.p_tiles;
+    std::vector<uint32_t> (&p_itx)[5] = scr.p_itx;
+    for (int k = 0; k < 5; k++) { p_tiles[k].clear(); p_itx[k].clear(); }
     auto find_pair = [&](int plane, uint32_t off, int bw, int bh) -> long {
         if (!fuse_mask || bw != bh || bw < 4) return -1;
-        const int px = (int) (off % (uint32_t) stride[plane]), py = (int) (off / (uint32_t) stride[plane]);
+        int px, py;
+        cm[plane].dv.xy(off, px, py);
         if ((px | py) & 3) return -1;
-        const uint32_t q = cm[plane].tx_at[cm[plane].cell_of(off)];
+        const uint32_t q = cm[plane].tx_at[(size_t) ((py >> 2) - cm[plane].y0) * cm[plane].w + ((px >> 2) - cm[plane].x0)];
         if (!q || taken[q - 1]) return -1;
         const Dav1dHipItxTask &t = itx[q - 1];
         if (!(t.tx <= 4 && (4 << t.tx) == bw) || t.dst_off != off) return -1;
@@ -228,24 +274,31 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
     // ---- compound pairs whose two PREP blocks nothing else reads are predicted twice and combined in registers
     size_t n_prep = 0;
     for (size_t i = 0; i < n_mc; i++) n_prep += mc[i].kind == DAV1D_HIP_MC_PREP;
-    FlatMap producer(n_comp ? n_prep : 0), readers(n_comp ? 2 * n_comp : 0);      // arena offset -> 1 + task index / number of readers
+    FlatMap &producer = scr.producer, &readers = scr.readers;      // arena offset -> 1 + task index / number of readers
+    producer.reset(n_comp ? n_prep : 0); readers.reset(n_comp ? 2 * n_comp : 0);
     if (n_comp) {
         for (size_t i = 0; i < n_mc; i++) if (mc[i].kind == DAV1D_HIP_MC_PREP) *producer.slot(mc[i].dst_off, true) = (uint32_t) i + 1;
         for (size_t i = 0; i < n_comp; i++)
             if (comp[i].kind <= DAV1D_HIP_COMP_WMASK) { ++*readers.slot(comp[i].tmp1_off, true); ++*readers.slot(comp[i].tmp2_off, true); }
     }
-    std::vector<char> fused_prep(n_mc, 0);
-    std::vector<Dav1dHipCompTask> rest;
-    std::vector<McTile> bins[MC_BINS];
+    P(12);
+    std::vector<char> &fused_prep = scr.fused_prep;
+    fused_prep.assign(n_mc, 0);
+    std::vector<Dav1dHipCompTask> &rest = scr.rest;
+    rest.clear();
+    std::vector<McTile> (&bins)[MC_BINS] = scr.bins;
+    for (int b = 0; b < MC_BINS; b++) bins[b].clear();
+    P(13);
     {
         size_t est[MC_BINS] = { 0 };
         for (size_t i = 0; i < n_mc; i++) {
             const int tw = mc[i].w < 64 ? mc[i].w : 64, th = mc[i].h < 16 ? mc[i].h : 16;
-            est[tile_dim_class(tw) * 3 + tile_dim_class(th)] += (size_t) ((mc[i].w + tw - 1) / tw) * ((mc[i].h + th - 1) / th);
+            est[tile_dim_class(tw) * 3 + tile_dim_class(th)] += (size_t) ((mc[i].w + 63) >> 6) * ((mc[i].h + 15) >> 4);      // a reserve() hint
         }
         for (int b = 0; b < MC_BINS; b++) bins[b].reserve(est[b]);
         rest.reserve(n_comp / 4 + 16);
     }
+    P(10);
     for (size_t i = 0; i < n_comp; i++) {
         const Dav1dHipCompTask &k = comp[i];
         bool fuse = k.kind == DAV1D_HIP_COMP_AVG || k.kind == DAV1D_HIP_COMP_WAVG;
@@ -267,6 +320,7 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
             rest.push_back(k);
         }
     }
+    P(11);
     for (size_t i = 0; i < n_mc; i++)
         if (!fused_prep[i]) {
             const long j = mc[i].kind == DAV1D_HIP_MC_PUT ? find_pair(mc[i].plane, mc[i].dst_off, mc[i].w, mc[i].h) : -1;
@@ -291,7 +345,8 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
                 m.each(t.dst_off + (uint32_t) t.oy * (uint32_t) stride[t.plane] + t.ox, t.w, t.h, [&](size_t k) { m.writers[k] |= (uint16_t) (1u << b); });
             }
     for (const Dav1dHipCompTask &k : rest) { CellMap &m = cm[k.plane]; m.each(k.dst_off, k.w, k.h, [&](size_t q) { m.writers[q] |= 1u << 15; }); }
-    std::vector<Dav1dHipItxTask> ibins[19];
+    std::vector<Dav1dHipItxTask> (&ibins)[19] = scr.ibins;
+    for (int b = 0; b < 19; b++) ibins[b].clear();
     for (size_t i = 0; i < n_itx; i++) {
         const Dav1dHipItxTask &t = itx[i];
         ck->order = std::min(ck->order, (uint64_t) t.plane << 40 | t.dst_off);
@@ -321,11 +376,13 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
         // (measured on MI355X, 8K 10-bit: mode 1 makes the frame 2.5 % faster on the device and the listing 20 % slower on the host)
         static const int sort_mode = getenv("DAV1D_HIP_CHUNK_SORT") ? atoi(getenv("DAV1D_HIP_CHUNK_SORT")) : 2;
         if (sort_mode == 1) {
-            std::vector<uint64_t> sk(v.size());
+            std::vector<uint32_t> &sk = scr.sk;
+            sk.resize(v.size());
             for (size_t i = 0; i < v.size(); i++) sk[i] = src_key(v[i]);
             sort_by_key(v, sk);
         } else if (sort_mode == 2) {
-            std::vector<uint8_t> gk(v.size());
+            std::vector<uint8_t> &gk = scr.gk;
+            gk.resize(v.size());
             for (size_t i = 0; i < v.size(); i++) gk[i] = (uint8_t) ((v[i].r[0].ref & 7) * 3 + v[i].plane);
             group_in_windows(v, gk, v.size());
         }
@@ -344,7 +401,8 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
                 }
                 return (edge ? 16 : 0) | t.kind << 1 | (t.r[0].src_x & 1);      // the column parity: the tiled form of the horizontal pass (mc_body.h)
             };
-            std::vector<uint8_t> gk(v.size());
+            std::vector<uint8_t> &gk = scr.gk;
+            gk.resize(v.size());
             for (size_t i = 0; i < v.size(); i++) gk[i] = (uint8_t) key(v[i]);
             group_in_windows(v, gk, (size_t) mc_win * (size_t) (64 / lanes));
         }
@@ -358,26 +416,31 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
         for (int b = 0; b < 19; b++) {
             std::vector<Dav1dHipItxTask> &v = ibins[b];
             const int lanes = std::max(std::min((int) tx_h[b], 32), (int) tx_w[b]);
-            std::vector<uint8_t> gk(v.size());
+            std::vector<uint8_t> &gk = scr.gk;
+            gk.resize(v.size());
             for (size_t i = 0; i < v.size(); i++) gk[i] = (uint8_t) itx_path_key(v[i]);
             group_in_windows(v, gk, (size_t) itx_win * (size_t) std::max(1, 64 / lanes));
         }
     P(6);
     // paired blocks: by where the first tile reads, then by (transform code path, prediction kind) inside windows
-    std::vector<McTile> pt_sorted[5];
-    std::vector<Dav1dHipItxTask> pk_sorted[5];
+    std::vector<McTile> (&pt_sorted)[5] = scr.pt_sorted;
+    std::vector<Dav1dHipItxTask> (&pk_sorted)[5] = scr.pk_sorted;
+    for (int k = 0; k < 5; k++) { pt_sorted[k].clear(); pk_sorted[k].clear(); }
     for (int k = 0; k < 5; k++) {
         const size_t nblk = p_itx[k].size();
         if (!nblk) continue;
         const int tpb = k < 3 ? 1 : k == 3 ? 2 : 4, bpw = k == 0 ? 16 : k == 1 ? 8 : k == 2 ? 4 : k == 3 ? 2 : 1;
         if (p_tiles[k].size() != nblk * tpb) { delete ck; return -EINVAL; }
-        std::vector<uint32_t> ord(nblk);
+        std::vector<uint32_t> &ord = scr.ord;
+        ord.resize(nblk);
         for (size_t i = 0; i < nblk; i++) ord[i] = (uint32_t) i;
         {
-            std::vector<uint64_t> sk(nblk);
+            std::vector<uint32_t> &sk = scr.sk;
+            sk.resize(nblk);
             for (size_t i = 0; i < nblk; i++) sk[i] = src_key(p_tiles[k][i * tpb]);
             sort_by_key(ord, sk);
-            std::vector<uint8_t> gk(nblk);
+            std::vector<uint8_t> &gk = scr.gk;
+            gk.resize(nblk);
             for (size_t i = 0; i < nblk; i++) {
                 const int kind = p_tiles[k][(size_t) ord[i] * tpb].kind;
                 gk[i] = (uint8_t) ((itx_path_key(itx[p_itx[k][ord[i]]]) * 3 + (kind == MCT_AVG ? 1 : kind == MCT_WAVG ? 2 : 0)) * 2 +
@@ -399,8 +462,9 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
     }
     P(7);
     // compound / blend tasks: BLEND_V and the MASK tasks that read a mask a W_MASK task of the chunk writes go second
-    std::vector<Dav1dHipCompTask> c_first, c_second;
-    {
+    std::vector<Dav1dHipCompTask> &c_first = scr.c_first, &c_second = scr.c_second;
+    c_first.clear(); c_second.clear();
+    if (!rest.empty()) {
         std::unordered_map<uint32_t, char> wmask_out;
         for (const Dav1dHipCompTask &t : rest) if (t.kind == DAV1D_HIP_COMP_WMASK) wmask_out[t.mask_off] = 1;
         for (const Dav1dHipCompTask &t : rest)
@@ -419,9 +483,14 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
     place(CK_COMP + 1, c_second.size(), sizeof(Dav1dHipCompTask));
     ck->used = total;
     if (total) {
-        ck->host = slab_get(c, total, &ck->cap);
-        if (!ck->host) { delete ck; return -ENOMEM; }
-        auto put = [&](int id, const void *src, size_t esz) { if (ck->seg[id].n) memcpy(ck->host + ck->seg[id].off, src, (size_t) ck->seg[id].n * esz); };
+        uint8_t *dst = place_blob ? place_blob(cookie, total, &ck->dev_off) : nullptr;
+        if (dst) {
+            ck->uploaded = true;                 // part of the twin: goes up with it
+        } else {
+            dst = ck->host = slab_get(c, total, &ck->cap);
+            if (!ck->host) { delete ck; return -ENOMEM; }
+        }
+        auto put = [&](int id, const void *src, size_t esz) { if (ck->seg[id].n) memcpy(dst + ck->seg[id].off, src, (size_t) ck->seg[id].n * esz); };
         for (int b = 0; b < MC_BINS; b++) put(CK_MC + b, bins[b].data(), sizeof(McTile));
         for (int b = 0; b < 19; b++) put(CK_ITX + b, ibins[b].data(), sizeof(Dav1dHipItxTask));
         for (int k = 0; k < 5; k++) put(CK_PTILE + k, pt_sorted[k].data(), sizeof(McTile));
@@ -464,6 +533,24 @@ static int ensure_dev(uint8_t **p, size_t *cap, size_t want, hipStream_t sync_on
     return 0;
 }
 
+int dav1d_hip_chunks_send_late(Dav1dHipContext *c, std::vector<Dav1dHipChunk *> &chunks, uint8_t **arena, size_t *arena_cap, size_t need, bool *regrown) {
+    *regrown = false;
+    if (need + 256 > *arena_cap) {
+        (void) hipStreamSynchronize(c->copy_stream);
+        const int rc = ensure_dev(arena, arena_cap, need + 256, c->stream);
+        if (rc) return rc;
+        *regrown = true;
+    }
+    for (Dav1dHipChunk *ck : chunks) {
+        if (!ck->used || !ck->host || (ck->uploaded && !*regrown)) continue;
+        if (ck->dev_off + ck->used > *arena_cap) return -EINVAL;
+        const int rc = hip_rc(hipMemcpyAsync(*arena + ck->dev_off, ck->host, ck->used, hipMemcpyHostToDevice, c->copy_stream));
+        if (rc) return rc;
+        ck->uploaded = true;
+    }
+    return 0;
+}
+
 // Uploads the chunks (one copy each, on the context's copy stream), lines their segments up per bin with one gather launch and
 // fills the caller-provided list objects with views of the gathered arrays.  The lists own nothing (never destroy them).
 int dav1d_hip_chunks_to_recon_list(Dav1dHipContext *c, std::vector<Dav1dHipChunk *> &chunks, uint8_t **arena, size_t *arena_cap,
@@ -485,20 +572,8 @@ int dav1d_hip_chunks_to_recon_list(Dav1dHipContext *c, std::vector<Dav1dHipChunk
     }
     c->arena_hint = std::max(c->arena_hint, src_total);
     int rc = 0;
-    if (!all_up) {
-        // some chunk did not fit the frame's arena when it was submitted: a bigger arena, every chunk uploaded again
-        (void) hipStreamSynchronize(c->copy_stream);
-        rc = ensure_dev(arena, arena_cap, src_total + 256, c->stream);
-        if (rc) return rc;
-        size_t off = 0;
-        for (Dav1dHipChunk *ck : chunks) {
-            ck->dev_off = off;
-            off += (ck->used + 255) & ~(size_t) 255;
-            if (ck->used && !rc) rc = hip_rc(hipMemcpyAsync(*arena + ck->dev_off, ck->host, ck->used, hipMemcpyHostToDevice, c->copy_stream));
-            ck->uploaded = true;
-        }
-        if (rc) return rc;
-    }
+    if (!all_up) return -EINVAL;                 // dav1d_hip_chunks_send_late comes first
+    (void) arena; (void) arena_cap;
     // gathered layout: the 15 prediction bins back to back, the 19 residual bins back to back, every paired array on its own,
     // the two compound runs back to back; each group starts 256-byte aligned
     size_t aoff[CK_N], end = 0;

@@ -455,17 +455,18 @@ int dav1d_hip_frame_submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc
     note_kinds(f, itx, n_itx);
     // all the list preparation of this tile-sbrow happens here, on the submitting thread, without the frame's lock
     Dav1dHipChunk *ck = nullptr;
-    const int rc = dav1d_hip_chunk_build(f->c, &ck, &f->cur, f->refs, f->n_refs, mc, n_mc, comp, n_comp, itx, n_itx);
+    // the blob's place in the arena is drawn when its size is known; it is written straight into the arena's pinned twin
+    auto place = [](void *cookie, size_t bytes, size_t *dev_off) -> uint8_t * {
+        Dav1dHipFrame *fr = (Dav1dHipFrame *) cookie;
+        const size_t sz = (bytes + 255) & ~(size_t) 255, off = fr->arena_used.fetch_add(sz);
+        *dev_off = off;
+        return fr->harena && off + sz <= fr->harena_cap && off + sz <= fr->arena_cap ? fr->harena + off : nullptr;
+    };
+    const int rc = dav1d_hip_chunk_build(f->c, &ck, &f->cur, f->refs, f->n_refs, mc, n_mc, comp, n_comp, itx, n_itx, place, f);
     if (rc) return rc;
-    // up it goes, while the other tile-sbrows are still being listed
-    if (ck->used) {
-        const size_t sz = (ck->used + 255) & ~(size_t) 255, off = f->arena_used.fetch_add(sz);
-        if (f->arena && off + sz <= f->arena_cap) {
-            ck->dev_off = off;
-            if (f->harena && off + sz <= f->harena_cap) { memcpy(f->harena + off, ck->host, ck->used); ck->uploaded = true; }     // goes up with the frame
-            else ck->uploaded = hipMemcpyAsync(f->arena + off, ck->host, ck->used, hipMemcpyHostToDevice, f->c->copy_stream) == hipSuccess;
-        }
-    }
+    // c->chunk_upload (no twin): up it goes on its own, while the other tile-sbrows are still being listed
+    if (ck->used && ck->host && !f->harena && f->arena && ck->dev_off + ck->used <= f->arena_cap)
+        ck->uploaded = hipMemcpyAsync(f->arena + ck->dev_off, ck->host, ck->used, hipMemcpyHostToDevice, f->c->copy_stream) == hipSuccess;
     std::lock_guard<std::mutex> lk(f->mtx);
     f->chunks.push_back(ck);
     return 0;
@@ -806,8 +807,7 @@ int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *ma
     for (Dav1dHipFrame::LateCoefs &lc : f->late_coefs) free(lc.copy);
     f->late_coefs.clear();
     if (c->pending_slab) {
-        std::lock_guard<std::mutex> pl(c->pool_mtx);
-        c->free_slabs.push_back({ c->pending_slab, c->pending_slab_cap });
+        dav1d_hip_slab_put(c, c->pending_slab, c->pending_slab_cap);
         c->pending_slab = nullptr;
     }
     return rc_run;
@@ -844,7 +844,12 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
         Dav1dHipMcList ml;
         Dav1dHipCompList cl;
         Dav1dHipItxList xl;
-        if (f->harena) rc = frame_flush_locked(f);       // what dav1d_hip_frame_flush has not sent yet (the gather launch waits for the copy stream)
+        // a chunk that found no room in the twin (the first frames of a size: the arena is sized by what frames have needed) sits in
+        // a slab of its own: the arena grows to what was drawn, the twin goes up again if it did, the late chunks follow
+        bool regrown = false;
+        rc = dav1d_hip_chunks_send_late(c, f->chunks, &f->arena, &f->arena_cap, f->arena_used.load(), &regrown);
+        if (regrown) f->harena_flushed = 0;
+        if (!rc && f->harena) rc = frame_flush_locked(f);       // what dav1d_hip_frame_flush has not sent yet (the gather launch waits for the copy stream)
         if (!rc) rc = dav1d_hip_chunks_to_recon_list(c, f->chunks, &f->arena, &f->arena_cap, f->refs, f->n_refs, &rl, &il, &ml, &cl, &xl);
         if (!rc) {
             if (ml.n || cl.n || rl.f_n[0] || rl.f_n[1] || rl.f_n[2] || rl.f_n[3] || rl.f_n[4]) {

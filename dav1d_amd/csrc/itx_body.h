@@ -164,19 +164,6 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
             if (l + k * LPB < NCH) s4[l + k * LPB] = v[k];
             if (l + k * LPB < nch) z4[l + k * LPB] = make_int4(0, 0, 0, 0);
         }
-        if (packed) {
-            // sparse wire format: eob + 1 values in decode order are scattered to their slab positions (the slab in LDS was
-            // just zero-filled); positions as decode_coefs derives them (reference src/recon_tmpl.c:458-496, 548-575)
-            dv::wave_sync();
-            coef *const slab = reinterpret_cast<coef *>(tmp);
-            const int cls = (t.txtp == 11 || t.txtp == 13 || t.txtp == 15) ? 1 : (t.txtp == 10 || t.txtp == 12 || t.txtp == 14) ? 2 : 0;
-            const uint16_t *const scan = av1_scans + av1_scan_off[TX];
-            constexpr int LSW = SW == 4 ? 2 : SW == 8 ? 3 : SW == 16 ? 4 : 5;
-            for (int i = l; i <= t.eob; i += LPB) {
-                const int rc = cls == 0 ? (int) scan[i] : cls == 1 ? i : ((i & (SW - 1)) * SH + (i >> LSW));
-                slab[rc] = gcf[i];
-            }
-        }
     } else if (dconly) {
         if (l == 0) { dc = gcf[0]; if (!(t.flags & DAV1D_HIP_ITX_PACKED)) gcf[0] = 0; }            // src/itx_tmpl.c:59-60
         if (!PRED_LDS && l < W) {
@@ -186,6 +173,19 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
     }
     dc = __shfl(dc, sub * LPB);
     dv::wave_sync();
+    if (full && (t.flags & DAV1D_HIP_ITX_PACKED)) {
+        // sparse wire format: eob + 1 values in decode order are scattered to their slab positions (the slab in LDS was
+        // just zero-filled); positions as decode_coefs derives them (reference src/recon_tmpl.c:458-496, 548-575)
+        coef *const slab = reinterpret_cast<coef *>(tmp);
+        const int cls = (t.txtp == 11 || t.txtp == 13 || t.txtp == 15) ? 1 : (t.txtp == 10 || t.txtp == 12 || t.txtp == 14) ? 2 : 0;
+        const uint16_t *const scan = av1_scans + av1_scan_off[TX];
+        constexpr int LSW = SW == 4 ? 2 : SW == 8 ? 3 : SW == 16 ? 4 : 5;
+        for (int i = l; i <= t.eob; i += LPB) {
+            const int rc = cls == 0 ? (int) scan[i] : cls == 1 ? i : ((i & (SW - 1)) * SH + (i >> LSW));
+            slab[rc] = gcf[i];
+        }
+    }
+    dv::wave_sync();     // (every lane of the wave passes the two points above and this one: blocks of a wave differ in their paths)
     if (row_lane) {
         const coef *slab = reinterpret_cast<const coef *>(tmp);
 #pragma unroll

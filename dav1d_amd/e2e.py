@@ -232,6 +232,16 @@ def run_pipelined(ctx, desc, cf_frames, w, h, layout, bpc, refs, threads, depth=
     lib = ctx.lib
     frames = len(cf_frames)
     up_ctx = api.Context(ctx.device, lib_path=ctx.lib_path) if filters else None
+    lvl_keep = None
+    if filters:
+        # the level cache leaves from page-locked memory, as a picture allocator callback of the integration would provide it
+        try:
+            import torch
+            if torch.cuda.is_available():
+                lvl_keep = torch.from_numpy(np.ascontiguousarray(filters["lvl_host"])).pin_memory()
+                filters = dict(filters, lvl_host=lvl_keep.numpy())
+        except ImportError:
+            pass
     slots = []
     for _ in range(depth):
         slots.append(dict(cur=ctx.picture(w, h, layout, bpc), prep=None, mask=None,
@@ -243,7 +253,7 @@ def run_pipelined(ctx, desc, cf_frames, w, h, layout, bpc, refs, threads, depth=
     nb = C.c_size_t()
     blob = lib.dav1d_hip_lister_const_masks(C.byref(nb))
     const_masks = np.ctypeslib.as_array((C.c_uint8 * nb.value).from_address(blob))
-    t_end, end_ms, err = [], [], []
+    t_end, end_ms, err, destroy_ms, begin_ms, t_listed = [], [], [], [], [], []
     last = {}
 
     def ender():
@@ -263,8 +273,10 @@ def run_pipelined(ctx, desc, cf_frames, w, h, layout, bpc, refs, threads, depth=
                     last["planes"] = [pic.download(pl) for pl in range(1 if layout == 0 else 3)]
             except Exception as e:          # noqa: BLE001 - reported by the caller
                 err.append(e)
+            t = time.perf_counter()
             lib.dav1d_hip_lister_destroy(lh)
             frame.destroy()
+            destroy_ms.append((time.perf_counter() - t) * 1e3)
             free_slots.put(sl)
     th = threading.Thread(target=ender)
     th.start()
@@ -279,6 +291,7 @@ def run_pipelined(ctx, desc, cf_frames, w, h, layout, bpc, refs, threads, depth=
             d.cf = cf_frames[it].ctypes.data
             lh = C.c_void_p()
             assert lib.dav1d_hip_lister_create(C.byref(lh), C.byref(d), frame.h) == 0
+            begin_ms.append((time.perf_counter() - t_a) * 1e3)
             if filters:
                 assert lib.dav1d_hip_upload(up_ctx.h, sl["lvl"].ptr, filters["lvl_host"].ctypes.data, len(filters["lvl_host"])) == 0
             rc = lib.dav1d_hip_lister_run(lh, threads)
@@ -296,6 +309,7 @@ def run_pipelined(ctx, desc, cf_frames, w, h, layout, bpc, refs, threads, depth=
                 sl["mask"] = ctx.buffer(need_mask + need_mask // 4)
                 assert lib.dav1d_hip_upload((up_ctx or ctx).h, sl["mask"].ptr, const_masks.ctypes.data, nb.value) == 0
             todo.put((frame, lh, sl, it))
+            t_listed.append(time.perf_counter())
             if it >= warm:
                 wait_ms.append((t_a - t0) * 1e3)
                 list_ms.append((t_b - t_a) * 1e3)
@@ -312,6 +326,10 @@ def run_pipelined(ctx, desc, cf_frames, w, h, layout, bpc, refs, threads, depth=
            "packed_coef_bytes_per_frame": coef_bytes}
     if filters:
         out["filter_list_ms"] = round(float(np.median(flist_ms)), 3)
+    if os.environ.get("DAV1D_HIP_E2E_TRACE"):
+        r = lambda v: [round(float(x), 2) for x in v]
+        out["trace"] = {"list": r(list_ms), "end": r(end_ms), "destroy": r(destroy_ms), "begin": r(begin_ms),
+                        "listed_at": r((np.array(t_listed) - t_listed[0]) * 1e3), "ended_at": r((np.array(t_end) - t_listed[0]) * 1e3)}
     out["value"] = round(w * h / (out["ms_per_frame"] * 1e-3) / 1e6, 1)
     out["unit"] = "Mpixels/s"
     for sl in slots:

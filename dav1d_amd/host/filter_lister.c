@@ -237,7 +237,8 @@ static void list_lr(const ListerGeo *g, const Dav1dHipFilterDesc *fd, FOut *o, c
     }
 }
 
-int dav1d_hip_lister_filter_sbrow(Dav1dHipLister *l, const Dav1dHipFilterDesc *fd, const int sby) {
+/* parts: 1 = deblocking, 2 = CDEF, 4 = restoration — the three lists of a superblock row are independent of each other */
+static int filter_sbrow_parts(Dav1dHipLister *l, const Dav1dHipFilterDesc *fd, const int sby, const int parts) {
     if (!l || !fd || sby < 0) return -EINVAL;
     ListerGeo g;
     dav1d_hip_lister_geo(l, &g);
@@ -250,15 +251,18 @@ int dav1d_hip_lister_filter_sbrow(Dav1dHipLister *l, const Dav1dHipFilterDesc *f
     FOut o;
     memset(&o, 0, sizeof(o));
     fl_oom = 0;
-    list_deblock(&g, fd, &o, sby);
-    list_cdef(&g, fd, &o, sby);
-    list_lr(&g, fd, &o, sby);
+    if (parts & 1) list_deblock(&g, fd, &o, sby);
+    if (parts & 2) list_cdef(&g, fd, &o, sby);
+    if (parts & 4) list_lr(&g, fd, &o, sby);
     if (fl_oom) { free(o.lf.p); free(o.cdef.p); free(o.lr.p); return -ENOMEM; }
+    if (!o.lf.n && !o.cdef.n && !o.lr.n) { free(o.lf.p); free(o.cdef.p); free(o.lr.p); return 0; }
     /* the arrays go to the frame as they are (it frees them): no copy, no growing vector under the frame's lock */
     const int rc = dav1d_hip_frame_submit_filter_owned(g.frame, o.lf.p, o.lf.n, o.cdef.p, o.cdef.n, o.lr.p, o.lr.n);
     if (rc) { free(o.lf.p); free(o.cdef.p); free(o.lr.p); }
     return rc;
 }
+
+int dav1d_hip_lister_filter_sbrow(Dav1dHipLister *l, const Dav1dHipFilterDesc *fd, const int sby) { return filter_sbrow_parts(l, fd, sby, 7); }
 
 /* Every superblock row of the frame's filter tasks on n_threads threads of the library (rows handed out under a mutex) — the
  * counterpart of dav1d_hip_lister_run for callers without a thread pool of their own. */
@@ -270,7 +274,8 @@ static void *frun_worker(void *arg) {
         const int k = r->err ? r->n : r->next++;
         pthread_mutex_unlock(&r->mtx);
         if (k >= r->n) break;
-        const int rc = dav1d_hip_lister_filter_sbrow(r->l, r->fd, k);
+        /* a unit of work is one of the three lists of a row: an 8K frame has 34 superblock rows, too few for the threads at hand */
+        const int rc = filter_sbrow_parts(r->l, r->fd, k / 3, 1 << (k % 3));
         if (rc) { pthread_mutex_lock(&r->mtx); if (!r->err) r->err = rc; pthread_mutex_unlock(&r->mtx); }
     }
     return NULL;
@@ -281,15 +286,11 @@ int dav1d_hip_lister_filter_run(Dav1dHipLister *l, const Dav1dHipFilterDesc *fd,
     dav1d_hip_lister_geo(l, &g);
     FRunAll r;
     r.l = l; r.fd = fd; r.next = 0; r.err = 0;
-    r.n = (g.bh + g.sb_step - 1) / g.sb_step;
+    r.n = 3 * ((g.bh + g.sb_step - 1) / g.sb_step);
     if (n_threads > r.n) n_threads = r.n;
     if (n_threads > 256) n_threads = 256;
     pthread_mutex_init(&r.mtx, NULL);
-    pthread_t th[256];
-    int started = 0;
-    for (int i = 1; i < n_threads; i++) { if (pthread_create(&th[started], NULL, frun_worker, &r)) break; started++; }
-    frun_worker(&r);
-    for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
+    dav1d_hip_host_pool_run(frun_worker, &r, n_threads);
     pthread_mutex_destroy(&r.mtx);
     return r.err;
 }

@@ -1082,15 +1082,45 @@ static int submit_steps(Dav1dHipLister *l, Out *o) {
     return rc;
 }
 
+/* A thread's task vectors live as long as the thread (dav1d's workers, the library's pool): a tile-sbrow starts with the capacity the
+ * last one grew to instead of growing a dozen vectors from nothing — 1,800 times per 8K frame, each growth step of the larger ones
+ * a trip to the kernel's address-space lock that every other listing thread waits on. */
+static pthread_key_t out_key;
+static pthread_once_t out_once = PTHREAD_ONCE_INIT;
+static __thread Out *out_tls;
+static void out_free(void *p) {
+    Out *o = (Out *) p;
+    if (!o) return;
+    free(o->smc.p); free(o->smc_step.p); free(o->pack);
+    free(o->mc.p); free(o->comp.p); free(o->warp.p); free(o->scaled.p); free(o->itx.p);
+    free(o->ipred.p); free(o->ipred_step.p); free(o->blend.p); free(o->blend_step.p); free(o->sitx.p); free(o->sitx_step.p);
+    free(o);
+}
+static void out_key_make(void) { (void) pthread_key_create(&out_key, out_free); }
+static Out *out_get(void) {
+    Out *o = out_tls;
+    if (!o) {
+        pthread_once(&out_once, out_key_make);
+        o = (Out *) calloc(1, sizeof(*o));
+        if (!o) return NULL;
+        out_tls = o;
+        (void) pthread_setspecific(out_key, o);
+    }
+    o->mc.n = o->comp.n = o->warp.n = o->scaled.n = o->itx.n = o->ipred.n = o->ipred_step.n = o->blend.n = o->blend_step.n = 0;
+    o->sitx.n = o->sitx_step.n = o->smc.n = o->smc_step.n = 0;
+    o->npack = 0;
+    return o;
+}
+
 int dav1d_hip_lister_tile_sbrow(Dav1dHipLister *l, const int tile_row, const int tile_col, const int sby) {
     if (!l || tile_row < 0 || tile_row >= l->d.n_tile_rows || tile_col < 0 || tile_col >= l->d.n_tile_cols) return -EINVAL;
     TileCursor *cur = &l->tiles[tile_row * l->d.n_tile_cols + tile_col];
     if (sby != cur->next_sby || sby >= l->d.row_start_sb[tile_row + 1]) return -EINVAL;      /* top to bottom inside a tile */
     const int sb_shift = l->d.sb128 ? 5 : 4;
-    Out o;
-    memset(&o, 0, sizeof(o));
+    Out *const op = out_get();
+    if (!op) return -ENOMEM;
     Walk w;
-    w.l = l; w.o = &o; w.cur = cur; w.err = 0;
+    w.l = l; w.o = op; w.cur = cur; w.err = 0;
     w.seen_step = 0;
     w.col_start = l->d.col_start_sb[tile_col] << sb_shift;
     w.col_end = imin(l->d.col_start_sb[tile_col + 1] << sb_shift, l->bw);
@@ -1102,26 +1132,84 @@ int dav1d_hip_lister_tile_sbrow(Dav1dHipLister *l, const int tile_row, const int
     for (int bx = w.col_start; bx < w.col_end && !w.err && !v_oom; bx += l->sb_step)
         walk_sb(&w, l->d.sb128 ? H_BL_128X128 : H_BL_64X64, bx, by, 1, 0);
     int rc = v_oom ? -ENOMEM : w.err;
-    if (!rc && l->d.cf && (o.itx.n || o.sitx.n)) {
+    if (!rc && l->d.cf && (op->itx.n || op->sitx.n)) {
         /* the tile-sbrow's values join the frame's coefficient arena; the tasks counted from the start of the buffer */
         uint32_t base = 0;
-        rc = dav1d_hip_frame_submit_coefs(l->frame, o.pack, o.npack, &base);
-        for (size_t i = 0; i < o.itx.n; i++) o.itx.p[i].cf_off += base;
-        for (size_t i = 0; i < o.sitx.n; i++) o.sitx.p[i].cf_off += base;
+        rc = dav1d_hip_frame_submit_coefs(l->frame, op->pack, op->npack, &base);
+        for (size_t i = 0; i < op->itx.n; i++) op->itx.p[i].cf_off += base;
+        for (size_t i = 0; i < op->sitx.n; i++) op->sitx.p[i].cf_off += base;
     }
     PROF_T(t1);
-    if (!rc) rc = dav1d_hip_frame_submit_tile_sbrow(l->frame, o.mc.p, o.mc.n, o.comp.p, o.comp.n, o.itx.p, o.itx.n);
+    if (!rc) rc = dav1d_hip_frame_submit_tile_sbrow(l->frame, op->mc.p, op->mc.n, op->comp.p, op->comp.n, op->itx.p, op->itx.n);
     PROF_T(t2);
     PROF_ADD(0, t1 - t0); PROF_ADD(1, t2 - t1);
-    if (!rc && o.warp.n) rc = dav1d_hip_frame_submit_warp(l->frame, o.warp.p, o.warp.n);
-    if (!rc && o.scaled.n) rc = dav1d_hip_frame_submit_scaled(l->frame, o.scaled.p, o.scaled.n);
-    if (!rc && o.smc.n) rc = dav1d_hip_frame_submit_step_copy(l->frame, o.smc.p, o.smc_step.p, o.smc.n);
-    if (!rc) rc = submit_steps(l, &o);
-    free(o.smc.p); free(o.smc_step.p); free(o.pack);
-    free(o.mc.p); free(o.comp.p); free(o.warp.p); free(o.scaled.p); free(o.itx.p);
-    free(o.ipred.p); free(o.ipred_step.p); free(o.blend.p); free(o.blend_step.p); free(o.sitx.p); free(o.sitx_step.p);
+    if (!rc && op->warp.n) rc = dav1d_hip_frame_submit_warp(l->frame, op->warp.p, op->warp.n);
+    if (!rc && op->scaled.n) rc = dav1d_hip_frame_submit_scaled(l->frame, op->scaled.p, op->scaled.n);
+    if (!rc && op->smc.n) rc = dav1d_hip_frame_submit_step_copy(l->frame, op->smc.p, op->smc_step.p, op->smc.n);
+    if (!rc) rc = submit_steps(l, op);
     if (!rc) cur->next_sby = sby + 1;
     return rc;
+}
+
+/* ---- the library's host threads */
+static struct HostPool {
+    pthread_mutex_t m;
+    pthread_cond_t work, done, idle;
+    void *(*fn)(void *);
+    void *arg;
+    int created, want, claimed, finished, busy;
+    unsigned gen;
+} h_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, NULL, 0, 0, 0, 0, 0, 0 };
+
+static void *pool_thread(void *unused) {
+    (void) unused;
+    unsigned seen = 0;
+    pthread_mutex_lock(&h_pool.m);
+    for (;;) {
+        while (h_pool.gen == seen || h_pool.claimed >= h_pool.want) { seen = h_pool.gen; pthread_cond_wait(&h_pool.work, &h_pool.m); }
+        seen = h_pool.gen;
+        h_pool.claimed++;
+        void *(*fn)(void *) = h_pool.fn;
+        void *arg = h_pool.arg;
+        pthread_mutex_unlock(&h_pool.m);
+        fn(arg);
+        pthread_mutex_lock(&h_pool.m);
+        if (++h_pool.finished == h_pool.want) pthread_cond_signal(&h_pool.done);
+    }
+    return NULL;
+}
+
+void dav1d_hip_host_pool_run(void *(*fn)(void *), void *arg, int n) {
+    if (n > 1) {
+        pthread_mutex_lock(&h_pool.m);
+        while (h_pool.busy) pthread_cond_wait(&h_pool.idle, &h_pool.m);
+        h_pool.busy = 1;
+        while (h_pool.created < n - 1) {
+            pthread_t t;
+            pthread_attr_t at;
+            pthread_attr_init(&at);
+            pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+            const int rc = pthread_create(&t, &at, pool_thread, NULL);
+            pthread_attr_destroy(&at);
+            if (rc) break;
+            h_pool.created++;
+        }
+        h_pool.fn = fn; h_pool.arg = arg;
+        h_pool.want = h_pool.created < n - 1 ? h_pool.created : n - 1;
+        h_pool.claimed = h_pool.finished = 0;
+        h_pool.gen++;
+        pthread_cond_broadcast(&h_pool.work);
+        pthread_mutex_unlock(&h_pool.m);
+    }
+    fn(arg);
+    if (n > 1) {
+        pthread_mutex_lock(&h_pool.m);
+        while (h_pool.finished < h_pool.want) pthread_cond_wait(&h_pool.done, &h_pool.m);
+        h_pool.want = 0;
+        h_pool.busy = 0;
+        pthread_cond_signal(&h_pool.idle);
+        pthread_mutex_unlock(&h_pool.m);
+    }
 }
 
 /* Every tile of the frame on n_threads threads of the library: tiles are handed out in raster order under a mutex, a thread walks
@@ -1152,11 +1240,7 @@ int dav1d_hip_lister_run(Dav1dHipLister *l, int n_threads) {
     RunAll r;
     r.l = l; r.next = 0; r.err = 0;
     pthread_mutex_init(&r.mtx, NULL);
-    pthread_t th[256];
-    int started = 0;
-    for (int i = 1; i < n_threads; i++) { if (pthread_create(&th[started], NULL, run_worker, &r)) break; started++; }
-    run_worker(&r);
-    for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
+    dav1d_hip_host_pool_run(run_worker, &r, n_threads);
     pthread_mutex_destroy(&r.mtx);
     if (!r.err) (void) dav1d_hip_frame_flush(l->frame);         /* every tile is in: the lists start their way to the device */
     return r.err;

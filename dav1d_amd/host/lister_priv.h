@@ -15,4 +15,7 @@ void dav1d_hip_lister_geo(const Dav1dHipLister *l, ListerGeo *out);
 /* frame.hip: filter tasks handed over as malloc'ed arrays the frame frees (no copy under the frame's lock) */
 int dav1d_hip_frame_submit_filter_owned(Dav1dHipFrame *f, Dav1dHipLfTask *lf, size_t n_lf, Dav1dHipCdefTask *cdef, size_t n_cdef,
                                         Dav1dHipLrTask *lr, size_t n_lr);
+/* lister.c: fn(arg) on n threads at once — the caller and n - 1 threads of a pool the library keeps (created on first use, parked on
+ * a condition variable between jobs; one job at a time per process).  Starting 63 threads per frame took the caller a millisecond. */
+void dav1d_hip_host_pool_run(void *(*fn)(void *), void *arg, int n);
 #endif

@@ -51,6 +51,9 @@ typedef struct HookedParams {
     int inject;                /* 0: pass 1's output is generated when a frame's arrays exist (inside the run); 1: ... and a copy is kept in the
                                   store; 2: taken from the store of an earlier run (the generator and the mask-building walk — one thread
                                   per frame here, where dav1d spreads entropy decoding over all of them — stay out of the timed chain) */
+    int pack;                  /* mode 1: the lister packs (Dav1dHipFrameDesc.cf = f->frame_thread.cf): the coefficients that exist travel with
+                                  the frame's lists, cf is left zero as the reference's inverse transforms leave it, no dense arena goes to
+                                  the device.  With inject = 2 the arrays of the STORE are what gets consumed: replay such a store last. */
     Dav1dHipSynthParams synth; /* block decisions of the generated frames; seed + frame number per frame */
 } HookedParams;
 
@@ -538,6 +541,7 @@ static int hk_after_init_(Dav1dFrameContext *const f) {
     const int n_refs = IS_INTER_OR_SWITCH(fh) ? 7 : 0;
     for (int i = 0; i < n_refs; i++) refs[i] = ((HookedPic *) f->refp[i].p.allocator_data)->hp.dev;     /* geometry; the final ones at the end */
     rc = h->hip.frame_begin(h->ctx, &s->frame, &cur->hp.dev, refs, n_refs);
+    if (h->p.pack) s->desc.cf = f->frame_thread.cf;
     if (!rc) rc = h->hip.lister_create(&s->lister, &s->desc, s->frame);
     if (rc) return DAV1D_ERR(ENOMEM);
     hip_filter_desc(&s->fd, f);
@@ -588,13 +592,13 @@ static int stage_upload(Hooked *const h, Dav1dFrameContext *const f) {
     size_t n_const = 0;
     const uint8_t *const blob = hip->lister_const_masks(&n_const);
     const double t0 = now_s();
-    int rc = grow(h, &s->coef, &s->coef_cap, cf_bytes + 64);
+    int rc = h->p.pack ? 0 : grow(h, &s->coef, &s->coef_cap, cf_bytes + 64);
     if (!rc) rc = grow(h, &s->lvl, &s->lvl_cap, lvl_bytes + 64);
     if (!rc) rc = grow(h, &s->prep, &s->prep_cap, hip->lister_prep_elems(s->lister) * 2 + 4096);
     const size_t mask_cap_before = s->mask_cap;
     if (!rc) rc = grow(h, &s->mask, &s->mask_cap, hip->lister_mask_bytes(s->lister) + 4096);
     if (!rc && s->mask_cap != mask_cap_before) rc = hip->upload(h->ctx_up, s->mask, blob, n_const);
-    if (!rc) rc = hip->upload(h->ctx_up, s->coef, f->frame_thread.cf, cf_bytes);
+    if (!rc && !h->p.pack) rc = hip->upload(h->ctx_up, s->coef, f->frame_thread.cf, cf_bytes);
     if (!rc) rc = hip->upload(h->ctx_up, s->lvl, f->lf.level, lvl_bytes);
     stat_add(h, 5, t0);
     return rc;
@@ -615,7 +619,7 @@ static int stage_end(Hooked *const h, Dav1dFrameContext *const f, Dav1dHipPictur
     if (!rc) rc = hip->frame_set_filters(s->frame, s->lvl, f->b4_stride, f->lf.lim_lut.e, f->lf.lim_lut.i,
                                          f->frame_hdr->cdef.damping + f->cur.p.bpc - 8, NULL, 0);
     memset(filtered, 0, sizeof(*filtered));
-    if (!rc) rc = hip->frame_end(s->frame, s->coef, s->prep, s->mask, filtered, NULL);
+    if (!rc) rc = hip->frame_end(s->frame, h->p.pack ? NULL : s->coef, s->prep, s->mask, filtered, NULL);
     if (f->frame_hdr->frame_offset < 64) h->frame_end_s[f->frame_hdr->frame_offset] = now_s() - t0;
     stat_add(h, 6, t0);
     hip->lister_destroy(s->lister);

@@ -19,7 +19,7 @@ class HookedParams(C.Structure):
                 ("lf_level_y", C.c_int * 2), ("lf_level_u", C.c_int), ("lf_level_v", C.c_int), ("lf_sharpness", C.c_int),
                 ("cdef_enabled", C.c_int), ("cdef_damping", C.c_int), ("cdef_n_bits", C.c_int), ("cdef_y_strength", C.c_int * 8),
                 ("cdef_uv_strength", C.c_int * 8), ("lr_type", C.c_int * 3), ("lr_unit_size", C.c_int * 2),
-                ("mode", C.c_int), ("free_listing", C.c_int), ("device", C.c_int), ("keep_output", C.c_int), ("inject", C.c_int),
+                ("mode", C.c_int), ("free_listing", C.c_int), ("device", C.c_int), ("keep_output", C.c_int), ("inject", C.c_int), ("pack", C.c_int),
                 ("synth", _lib.SynthParams)]
 
 
@@ -48,7 +48,7 @@ FILTERS = dict(lf=(20, 28, 16, 24, 0), cdef=(5, 2, [17, 33, 0, 63], [5, 0, 20, 4
 
 
 def params(w, h, bpc, n_frames, mode, layout=1, sb128=True, tiles=(2, 1), threads=4, frame_delay=3, filters=FILTERS, seed=5, free_listing=1,
-           keep_output=True, synth=None):
+           keep_output=True, synth=None, pack=True):
     p = HookedParams()
     p.w, p.h, p.layout, p.bpc, p.sb128 = w, h, layout, bpc, int(sb128)
     sb = 128 if sb128 else 64
@@ -72,6 +72,7 @@ def params(w, h, bpc, n_frames, mode, layout=1, sb128=True, tiles=(2, 1), thread
             p.lr_type[i] = filters["lr"][0][i]
         p.lr_unit_size[0], p.lr_unit_size[1] = filters["lr"][1]
     p.mode, p.free_listing, p.device, p.keep_output = mode, free_listing, 0, int(keep_output)
+    p.pack = int(bool(pack) and mode == 1)
     p.synth = synth if synth is not None else lu.default_synth(seed, n_refs=3, far_mv_pct=2)
     return p
 
@@ -151,12 +152,13 @@ def task_loop_rate(hip_lib_path, w, h, bpc, tiles=(4, 1), threads=64, frame_dela
                     raise AssertionError("dav1d task loop: frame %d plane %d differs from dav1d's own pass 2 + filters" % (k, pl))
         del want, got
         run(params(w, h, bpc, frames, mode=0, keep_output=False, **common), hip_lib_path, store, inject=1)      # fills the store for every frame
+        cpu_s, _, _ = run(params(w, h, bpc, check_frames, mode=0, keep_output=False, **common), hip_lib_path, store, inject=2)
+        # last: the packing lister consumes the store's coefficient arrays (as dav1d's pass 2 consumes f->frame_thread.cf)
         run.tail_from = min(frame_delay, frames - 2)
         t_s, _, _ = run(params(w, h, bpc, frames, mode=1, keep_output=False, **common), hip_lib_path, store, inject=2)
         tail_s, tail_n = run.last_tail, frames - 1 - run.tail_from
         stages = dict(run.last_stats)
         stages["frame_end_ms_by_frame"] = list(run.last_frame_end_ms)
-        cpu_s, _, _ = run(params(w, h, bpc, check_frames, mode=0, keep_output=False, **common), hip_lib_path, store, inject=2)
     finally:
         store.destroy()
     return {"frames": frames, "fps": round(frames / t_s, 1), "ms_per_frame": round(t_s / frames * 1e3, 2),

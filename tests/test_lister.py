@@ -200,6 +200,14 @@ def test_packing_lister(ctx, name, w, h, layout, bpc, kw):
     assert not st["coef_after"].any()
 
 
+@pytest.mark.parametrize("bpc", [8, 10])
+def test_packing_lister_key_frame_through_the_dataflow_launch(ctx, bpc):
+    """a key frame deep enough for the one-launch wavefront (intra_flow.hip, more than flow_min_steps steps): its units carry PACKED
+    residuals; lanes of a wave that hold no block (one unit per wave) and lanes that do pass the same barriers (itx_body.h)"""
+    st = run_case(ctx, 384, 256, 1, bpc, 5, is_inter=False, tiles=(2, 1), packed=True)
+    assert st["steps"] >= 200 and not st["coef_after"].any()
+
+
 @pytest.mark.gpu
 def test_larger_frame_many_tiles_threads():
     ctx = util.make_context("hip")
