@@ -320,7 +320,9 @@ def run_pipelined(ctx, desc, cf_frames, w, h, layout, bpc, refs, threads, depth=
     if err:
         raise err[0]
     n = frames - warm
+    gaps = np.diff(np.array(t_end[warm - 1:])) * 1e3
     out = {"ms_per_frame": round((t_end[-1] - t_end[warm - 1]) / n * 1e3, 3), "frames": n, "frames_in_flight": depth,
+           "ms_between_frame_ends": {"median": round(float(np.median(gaps)), 3), "max": round(float(gaps.max()), 3)},
            "list_ms": round(float(np.median(list_ms)), 3), "frame_end_ms": round(float(np.median(end_ms[warm:])), 3),
            "slot_wait_ms": round(float(np.median(wait_ms)), 3), "host_threads": threads,
            "packed_coef_bytes_per_frame": coef_bytes}

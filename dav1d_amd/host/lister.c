@@ -352,6 +352,16 @@ static void list_intra(Walk *w, const int bs, const int edge_flags, const Dav1dH
                     if (!b->u.i.cfl_alpha[pl]) continue;
                     unsigned s = dep_step(w, 1 + pl, cx0, cy0, uv_t_dim->w, uv_t_dim->h);
                     if (s <= luma_step) s = luma_step + 1;          /* reads the reconstructed luma of this block */
+                    /* ... and, for a block that carries the chroma of its 8x8 from an odd row / column, the luma of the block above /
+                     * to the left as well (cfl_ac starts at bx & ~ss_hor, by & ~ss_ver, src/recon_tmpl.c:1367-1381).  Its own luma
+                     * prediction normally waits for those cells anyway; a palette block's does not (no edges). */
+                    {
+                        const uint16_t *m = l->step[0];
+                        const int st = l->step_stride[0];
+                        for (int yy = by & ~ss_ver; yy < by + h4; yy++)
+                            for (int xx = bx & ~ss_hor; xx < bx + w4; xx++)
+                                if (m[yy * st + xx] >= s) s = m[yy * st + xx] + 1u;
+                    }
                     cfl_step[pl] = s;
                     Dav1dHipIpredTask *k = new_ipred(w, s);
                     k->kind = DAV1D_HIP_IPRED_CFL;

@@ -200,6 +200,14 @@ def test_packing_lister(ctx, name, w, h, layout, bpc, kw):
     assert not st["coef_after"].any()
 
 
+def test_cfl_of_a_palette_block_waits_for_the_luma_it_borrows(ctx):
+    """A 16x4 block on an odd row carries the chroma of its 8x8: CfL averages the luma of the block above as well
+    (src/recon_tmpl.c:1367-1381).  With a palette as its own luma prediction (no edges, wavefront step 1) nothing else orders it
+    behind that block: the lister has to (seed 311 puts such a block into the bottom right corner of the picture)."""
+    for packed in (False, True):
+        run_case(ctx, 128, 64, 1, 8, 311, is_inter=False, palette=40, packed=packed)
+
+
 @pytest.mark.parametrize("bpc", [8, 10])
 def test_packing_lister_key_frame_through_the_dataflow_launch(ctx, bpc):
     """a key frame deep enough for the one-launch wavefront (intra_flow.hip, more than flow_min_steps steps): its units carry PACKED
