@@ -77,7 +77,7 @@ SYMBOLS = [
     "dav1d_hip_frame_begin", "dav1d_hip_frame_submit_tile_sbrow", "dav1d_hip_frame_submit_coefs", "dav1d_hip_frame_coef_bytes", "dav1d_hip_frame_submit_filter_sbrow",
     "dav1d_hip_frame_set_filters", "dav1d_hip_frame_end", "dav1d_hip_frame_destroy",
     "dav1d_hip_frame_submit_step_blend", "dav1d_hip_frame_submit_warp", "dav1d_hip_frame_submit_scaled",
-    "dav1d_hip_lister_create", "dav1d_hip_lister_tile_sbrow", "dav1d_hip_lister_run", "dav1d_hip_lister_filter_run", "dav1d_hip_lister_prep_elems", "dav1d_hip_lister_mask_bytes",
+    "dav1d_hip_lister_create", "dav1d_hip_lister_tile_sbrow", "dav1d_hip_lister_run", "dav1d_hip_lister_filter_run", "dav1d_hip_lister_run_frame", "dav1d_hip_lister_prep_elems", "dav1d_hip_lister_mask_bytes",
     "dav1d_hip_lister_steps", "dav1d_hip_lister_const_masks", "dav1d_hip_lister_destroy", "dav1d_hip_synth_frame",
     "dav1d_hip_lister_mask_offset", "dav1d_hip_lister_tables", "dav1d_hip_lister_block_warp", "dav1d_hip_lister_filter_sbrow",
 ]
@@ -256,6 +256,7 @@ def load(path=None):
         "dav1d_hip_lister_tile_sbrow": (i, [vp, i, i, i]),
         "dav1d_hip_lister_run": (i, [vp, i]),
         "dav1d_hip_lister_filter_run": (i, [vp, vp, i]),
+        "dav1d_hip_lister_run_frame": (i, [vp, vp, i]),
         "dav1d_hip_lister_prep_elems": (sz, [vp]),
         "dav1d_hip_lister_mask_bytes": (sz, [vp]),
         "dav1d_hip_lister_steps": (sz, [vp]),

@@ -435,10 +435,20 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
         ord.resize(nblk);
         for (size_t i = 0; i < nblk; i++) ord[i] = (uint32_t) i;
         {
-            std::vector<uint32_t> &sk = scr.sk;
-            sk.resize(nblk);
-            for (size_t i = 0; i < nblk; i++) sk[i] = src_key(p_tiles[k][i * tpb]);
-            sort_by_key(ord, sk);
+            // DAV1D_HIP_PAIR_SORT: 1 = by where the first tile reads (reference, plane, 64-row band, x); 2 (default) = by (reference, plane)
+            // only — a chunk is one row of superblocks listed in decode order, which already runs from left to right
+            static const int pair_sort = getenv("DAV1D_HIP_PAIR_SORT") ? atoi(getenv("DAV1D_HIP_PAIR_SORT")) : 2;
+            if (pair_sort == 1) {
+                std::vector<uint32_t> &sk = scr.sk;
+                sk.resize(nblk);
+                for (size_t i = 0; i < nblk; i++) sk[i] = src_key(p_tiles[k][i * tpb]);
+                sort_by_key(ord, sk);
+            } else if (pair_sort == 2) {
+                std::vector<uint8_t> &rk = scr.gk;
+                rk.resize(nblk);
+                for (size_t i = 0; i < nblk; i++) { const McTile &t0 = p_tiles[k][i * tpb]; rk[i] = (uint8_t) ((t0.r[0].ref & 7) * 3 + t0.plane); }
+                group_in_windows(ord, rk, nblk);
+            }
             std::vector<uint8_t> &gk = scr.gk;
             gk.resize(nblk);
             for (size_t i = 0; i < nblk; i++) {

@@ -294,11 +294,10 @@ def run_pipelined(ctx, desc, cf_frames, w, h, layout, bpc, refs, threads, depth=
             begin_ms.append((time.perf_counter() - t_a) * 1e3)
             if filters:
                 assert lib.dav1d_hip_upload(up_ctx.h, sl["lvl"].ptr, filters["lvl_host"].ctypes.data, len(filters["lvl_host"])) == 0
-            rc = lib.dav1d_hip_lister_run(lh, threads)
+            rc = lib.dav1d_hip_lister_run_frame(lh, C.byref(filters["fd"]), threads) if filters else lib.dav1d_hip_lister_run(lh, threads)
             assert rc == 0, rc
             t_b = time.perf_counter()
             if filters:
-                assert lib.dav1d_hip_lister_filter_run(lh, C.byref(filters["fd"]), threads) == 0
                 frame.set_filters(sl["lvl"], filters["b4_stride"], filters["lut_e"], filters["lut_i"], filters["damping"])
             t_c = time.perf_counter()
             coef_bytes = int(lib.dav1d_hip_frame_coef_bytes(frame.h))
@@ -326,8 +325,6 @@ def run_pipelined(ctx, desc, cf_frames, w, h, layout, bpc, refs, threads, depth=
            "list_ms": round(float(np.median(list_ms)), 3), "frame_end_ms": round(float(np.median(end_ms[warm:])), 3),
            "slot_wait_ms": round(float(np.median(wait_ms)), 3), "host_threads": threads,
            "packed_coef_bytes_per_frame": coef_bytes}
-    if filters:
-        out["filter_list_ms"] = round(float(np.median(flist_ms)), 3)
     if os.environ.get("DAV1D_HIP_E2E_TRACE"):
         r = lambda v: [round(float(x), 2) for x in v]
         out["trace"] = {"list": r(list_ms), "end": r(end_ms), "destroy": r(destroy_ms), "begin": r(begin_ms),

@@ -264,6 +264,13 @@ static int filter_sbrow_parts(Dav1dHipLister *l, const Dav1dHipFilterDesc *fd, c
 
 int dav1d_hip_lister_filter_sbrow(Dav1dHipLister *l, const Dav1dHipFilterDesc *fd, const int sby) { return filter_sbrow_parts(l, fd, sby, 7); }
 
+int dav1d_hip_lister_filter_units(const Dav1dHipLister *l) {
+    ListerGeo g;
+    dav1d_hip_lister_geo(l, &g);
+    return 3 * ((g.bh + g.sb_step - 1) / g.sb_step);
+}
+int dav1d_hip_lister_filter_unit(Dav1dHipLister *l, const Dav1dHipFilterDesc *fd, const int unit) { return filter_sbrow_parts(l, fd, unit / 3, 1 << (unit % 3)); }
+
 /* Every superblock row of the frame's filter tasks on n_threads threads of the library (rows handed out under a mutex) — the
  * counterpart of dav1d_hip_lister_run for callers without a thread pool of their own. */
 typedef struct FRunAll { Dav1dHipLister *l; const Dav1dHipFilterDesc *fd; pthread_mutex_t mtx; int next, n, err; } FRunAll;

@@ -55,6 +55,7 @@ struct Dav1dHipLister {
     int ss_hor, ss_ver, bw, bh, sb_step, hbd, csz /* bytes per coef */, psz /* bytes per pixel */;
     int stride[3];                /* picture strides in pixels */
     uint32_t *owner;              /* [4x4 cell] -> by * b4_stride + bx of the block whose bottom row / right column it is */
+    size_t map_bytes;             /* of one step map (the owner map is twice that) */
     uint16_t *step[3];            /* [4x4 cell of the plane] -> wavefront step of the transform block that wrote it */
     int step_stride[3];
     TileCursor *tiles;
@@ -955,6 +956,24 @@ static void walk_sb(Walk *w, const int bl, const int bx, const int by, const int
 
 /* ------------------------------------------------------------------------------------------------ entry points */
 
+/* the cell maps of finished listers, kept for the next frame of the size (a few per process) */
+static struct { pthread_mutex_t m; struct { void *p; size_t bytes; } e[16]; int n; } map_pool = { PTHREAD_MUTEX_INITIALIZER, { { NULL, 0 } }, 0 };
+static void *map_get(const size_t bytes) {
+    void *p = NULL;
+    pthread_mutex_lock(&map_pool.m);
+    for (int i = 0; i < map_pool.n; i++)
+        if (map_pool.e[i].bytes == bytes) { p = map_pool.e[i].p; map_pool.e[i] = map_pool.e[--map_pool.n]; break; }
+    pthread_mutex_unlock(&map_pool.m);
+    return p ? p : malloc(bytes);
+}
+static void map_put(void *p, const size_t bytes) {
+    if (!p) return;
+    pthread_mutex_lock(&map_pool.m);
+    if (map_pool.n < 16) { map_pool.e[map_pool.n].p = p; map_pool.e[map_pool.n].bytes = bytes; map_pool.n++; p = NULL; }
+    pthread_mutex_unlock(&map_pool.m);
+    free(p);
+}
+
 int dav1d_hip_lister_create(Dav1dHipLister **out, const Dav1dHipFrameDesc *d, Dav1dHipFrame *frame) {
     if (!out || !d || !frame || !d->b || !d->cbi || !d->tile_start_off) return -EINVAL;
     *out = NULL;
@@ -978,11 +997,14 @@ int dav1d_hip_lister_create(Dav1dHipLister **out, const Dav1dHipFrameDesc *d, Da
     l->psz = l->hbd ? 2 : 1;
     l->cf_align64 = d->cf_align64;
     for (int p = 0; p < 3; p++) l->stride[p] = cur.p[p].data ? (int) (cur.p[p].stride / l->psz) : 0;
+    /* the cell maps: recycled from frame to frame, NOT cleared here — 20 MB for an 8K frame, cleared (or faulted in page by page) on the
+     * thread that begins the frame while the listing threads wait for it; a tile's first tile-sbrow clears the tile's share instead */
     const size_t rows = (size_t) ((l->bh + 31) & ~31);
-    l->owner = (uint32_t *) calloc(rows * (size_t) d->b4_stride, sizeof(uint32_t));
+    l->map_bytes = rows * (size_t) d->b4_stride * sizeof(uint16_t);
+    l->owner = (uint32_t *) map_get(2 * l->map_bytes);
     for (int p = 0; p < 3; p++) {
         l->step_stride[p] = (int) d->b4_stride;
-        l->step[p] = (uint16_t *) calloc(rows * (size_t) d->b4_stride, sizeof(uint16_t));
+        l->step[p] = (uint16_t *) map_get(l->map_bytes);
     }
     const int n_tiles = d->n_tile_cols * d->n_tile_rows;
     l->tiles = (TileCursor *) calloc((size_t) n_tiles, sizeof(TileCursor));
@@ -1010,8 +1032,8 @@ void dav1d_hip_lister_destroy(Dav1dHipLister *l) {
     dav1d_hip_lister_prof();
     { extern void dav1d_hip_chunk_prof(void); dav1d_hip_chunk_prof(); }
 #endif
-    free(l->owner);
-    for (int p = 0; p < 3; p++) free(l->step[p]);
+    map_put(l->owner, 2 * l->map_bytes);
+    for (int p = 0; p < 3; p++) map_put(l->step[p], l->map_bytes);
     free(l->tiles);
     free(l);
 }
@@ -1137,6 +1159,18 @@ int dav1d_hip_lister_tile_sbrow(Dav1dHipLister *l, const int tile_row, const int
     w.row_start = l->d.row_start_sb[tile_row] << sb_shift;
     w.row_end = imin(l->d.row_start_sb[tile_row + 1] << sb_shift, l->bh);
     const int by = sby << sb_shift;
+    if (sby == l->d.row_start_sb[tile_row]) {
+        /* the tile's share of the cell maps: zero = "final before the wavefront starts" (what an inter block's cells stay at), and
+         * dep_step() looks at cells of rows that are listed later (the bottom-left extension of an edge) */
+        const int y_end = imin(((l->d.row_start_sb[tile_row + 1] << sb_shift) + 31) & ~31, (l->bh + 31) & ~31);
+        const size_t x0 = (size_t) w.col_start, nx = (size_t) (imin(l->d.col_start_sb[tile_col + 1] << sb_shift, (int) l->d.b4_stride) - w.col_start);
+        for (int y = w.row_start; y < y_end; y++) memset(l->owner + (size_t) y * l->d.b4_stride + x0, 0, nx * sizeof(uint32_t));
+        for (int p = 0; p < 3; p++) {            /* the chroma maps count in cells of their plane */
+            const int sh = p ? l->ss_hor : 0, sv = p ? l->ss_ver : 0;
+            const size_t px0 = x0 >> sh, pnx = ((x0 + nx + sh) >> sh) - px0;
+            for (int y = w.row_start >> sv; y < (y_end + sv) >> sv; y++) memset(l->step[p] + (size_t) y * l->step_stride[p] + px0, 0, pnx * sizeof(uint16_t));
+        }
+    }
     v_oom = 0;
     PROF_T(t0);
     for (int bx = w.col_start; bx < w.col_end && !w.err && !v_oom; bx += l->sb_step)
@@ -1226,15 +1260,21 @@ void dav1d_hip_host_pool_run(void *(*fn)(void *), void *arg, int n) {
  * its tile's superblock rows top to bottom (dav1d_hip_lister_tile_sbrow).  A caller with a thread pool of its own — dav1d's task
  * threads — calls dav1d_hip_lister_tile_sbrow itself; this is for callers without one (and for timing the host side without a
  * foreign runtime's locks in the way). */
-typedef struct RunAll { Dav1dHipLister *l; pthread_mutex_t mtx; int next, err; } RunAll;
+typedef struct RunAll { Dav1dHipLister *l; const Dav1dHipFilterDesc *fd; pthread_mutex_t mtx; int next, n_filter, err; } RunAll;
 static void *run_worker(void *arg) {
     RunAll *r = (RunAll *) arg;
     const int n_tiles = r->l->d.n_tile_cols * r->l->d.n_tile_rows;
     for (;;) {
         pthread_mutex_lock(&r->mtx);
-        const int k = r->err ? n_tiles : r->next++;
+        const int k = r->err ? n_tiles + r->n_filter : r->next++;
         pthread_mutex_unlock(&r->mtx);
-        if (k >= n_tiles) break;
+        if (k >= n_tiles + r->n_filter) break;
+        if (k >= n_tiles) {
+            /* the filter lists of the frame (dav1d_hip_lister_run_frame): short units that fill the threads' time once the tiles are handed out */
+            const int rc = dav1d_hip_lister_filter_unit(r->l, r->fd, k - n_tiles);
+            if (rc) { pthread_mutex_lock(&r->mtx); if (!r->err) r->err = rc; pthread_mutex_unlock(&r->mtx); }
+            continue;
+        }
         const int tr = k / r->l->d.n_tile_cols, tc = k % r->l->d.n_tile_cols;
         int rc = 0;
         for (int sby = r->l->d.row_start_sb[tr]; sby < r->l->d.row_start_sb[tr + 1] && !rc; sby++) rc = dav1d_hip_lister_tile_sbrow(r->l, tr, tc, sby);
@@ -1248,10 +1288,26 @@ int dav1d_hip_lister_run(Dav1dHipLister *l, int n_threads) {
     if (n_threads > n_tiles) n_threads = n_tiles;
     if (n_threads > 256) n_threads = 256;
     RunAll r;
-    r.l = l; r.next = 0; r.err = 0;
+    r.l = l; r.fd = NULL; r.next = 0; r.n_filter = 0; r.err = 0;
     pthread_mutex_init(&r.mtx, NULL);
     dav1d_hip_host_pool_run(run_worker, &r, n_threads);
     pthread_mutex_destroy(&r.mtx);
     if (!r.err) (void) dav1d_hip_frame_flush(l->frame);         /* every tile is in: the lists start their way to the device */
+    return r.err;
+}
+/* dav1d_hip_lister_run and dav1d_hip_lister_filter_run as ONE job: the tiles first, the filter lists (three per superblock row) behind
+ * them in the same queue — a thread that is through with its tiles takes filter lists instead of waiting for the slowest tile. */
+int dav1d_hip_lister_run_frame(Dav1dHipLister *l, const Dav1dHipFilterDesc *fd, int n_threads) {
+    if (!l || !fd || n_threads < 1) return -EINVAL;
+    RunAll r;
+    r.l = l; r.fd = fd; r.next = 0; r.err = 0;
+    r.n_filter = dav1d_hip_lister_filter_units(l);
+    const int n_units = l->d.n_tile_cols * l->d.n_tile_rows + r.n_filter;
+    if (n_threads > n_units) n_threads = n_units;
+    if (n_threads > 256) n_threads = 256;
+    pthread_mutex_init(&r.mtx, NULL);
+    dav1d_hip_host_pool_run(run_worker, &r, n_threads);
+    pthread_mutex_destroy(&r.mtx);
+    if (!r.err) (void) dav1d_hip_frame_flush(l->frame);
     return r.err;
 }

@@ -18,4 +18,7 @@ int dav1d_hip_frame_submit_filter_owned(Dav1dHipFrame *f, Dav1dHipLfTask *lf, si
 /* lister.c: fn(arg) on n threads at once — the caller and n - 1 threads of a pool the library keeps (created on first use, parked on
  * a condition variable between jobs; one job at a time per process).  Starting 63 threads per frame took the caller a millisecond. */
 void dav1d_hip_host_pool_run(void *(*fn)(void *), void *arg, int n);
+/* filter_lister.c: the filter tasks of a frame as independent units of work (a superblock row's deblocking, CDEF or restoration list) */
+int dav1d_hip_lister_filter_units(const Dav1dHipLister *l);
+int dav1d_hip_lister_filter_unit(Dav1dHipLister *l, const Dav1dHipFilterDesc *fd, int unit);
 #endif

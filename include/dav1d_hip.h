@@ -829,6 +829,9 @@ typedef struct Dav1dHipFilterDesc {
 DAV1D_HIP_API int dav1d_hip_lister_filter_sbrow(Dav1dHipLister *l, const Dav1dHipFilterDesc *fd, int sby);
 /* every superblock row of the frame on n_threads threads of the library (see dav1d_hip_lister_run) */
 DAV1D_HIP_API int dav1d_hip_lister_filter_run(Dav1dHipLister *l, const Dav1dHipFilterDesc *fd, int n_threads);
+/* dav1d_hip_lister_run and dav1d_hip_lister_filter_run as one job of n_threads threads: the tiles first, the filter lists of the
+ * superblock rows behind them in the same queue (they fill the time threads would otherwise wait for the slowest tile) */
+DAV1D_HIP_API int dav1d_hip_lister_run_frame(Dav1dHipLister *l, const Dav1dHipFilterDesc *fd, int n_threads);
 
 /* ---- deblocking masks and levels from the hand-off arrays (what pass 1 builds with dav1d_create_lf_mask_intra / _inter,
  * reference src/lf_mask.c:259-383, src/decode.c:1216-1226, 1882-1900, 1945-1956, 2730-2740), built on the device.
