@@ -851,13 +851,13 @@ def main():
             from dav1d_amd import e2e
             sustained = {}
             try:
-                sustained["recon"] = e2e.run_sustained(ctx, w, h, bpc, frames=12, threads=a.e2e_threads or 64, tile_cols=a.e2e_tile_cols, tile_rows=a.e2e_tile_rows,
+                sustained["recon"] = e2e.run_sustained(ctx, w, h, bpc, frames=16, threads=a.e2e_threads or None, tile_cols=a.e2e_tile_cols, tile_rows=a.e2e_tile_rows,
                                                        check=None if a.no_check else e2e_check)
                 sustained["recon_4_tile_columns"] = e2e.run_sustained(ctx, w, h, bpc, frames=6, threads=4, tile_cols=4, tile_rows=1,
                                                                       check=None if a.no_check else e2e_check)
                 if not a.no_check:
                     import lister_util as lu
-                    sustained["full_table"] = lu.full_route_sustained(ctx, w, h, bpc, a.e2e_tile_cols, a.e2e_tile_rows, threads=a.e2e_threads or 64, frames=12)
+                    sustained["full_table"] = lu.full_route_sustained(ctx, w, h, bpc, a.e2e_tile_cols, a.e2e_tile_rows, threads=a.e2e_threads or None, frames=16)
                     sustained["full_table_4_tile_columns"] = lu.full_route_sustained(ctx, w, h, bpc, 4, 1, threads=4, frames=6)
             except AssertionError as e:
                 raise SystemExit("bench: frames-in-flight leg differs from the reference: %s" % e)

@@ -217,6 +217,37 @@ def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0
     return out
 
 
+def cpu_quota():
+    """(cores the container may use per scheduling period or None, throttled periods so far or None): cgroup v2 cpu.max / cpu.stat"""
+    cores = thr = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        cores = None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            if line.startswith("nr_throttled"):
+                thr = int(line.split()[1])
+    except (OSError, ValueError):
+        pass
+    return cores, thr
+
+
+def host_threads(n_units, asked=None):
+    """Listing threads for the end-to-end legs: what was asked for, else as many as the host lets run at once — the CPU quota of the
+    container when there is one (more threads than that are throttled as a group: 16 cores' worth per 100 ms on the MI355X boxes of
+    this pool, after which every thread of the process stops until the period is over), else the CPUs this process may run on, 64 at most."""
+    if asked:
+        return min(asked, n_units)
+    cores, _ = cpu_quota()
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = min(64, avail)
+    if cores:
+        n = max(1, min(n, int(cores * 1.5)))        # a little over the quota: threads also wait (locks, the queue's tail)
+    return max(1, min(n, n_units))
+
+
 def run_pipelined(ctx, desc, cf_frames, w, h, layout, bpc, refs, threads, depth=2, warm=2, filters=None):
     """Frames in flight, as dav1d's frame threading has them: frame n + 1 is listed (host threads) while frame n is on the device.
 
@@ -282,8 +313,11 @@ def run_pipelined(ctx, desc, cf_frames, w, h, layout, bpc, refs, threads, depth=
     th.start()
     list_ms, flist_ms, wait_ms = [], [], []
     d = _lib.FrameDesc.from_buffer_copy(desc)
+    cpu0 = thr0 = None
     try:
         for it in range(frames):
+            if it == warm:
+                cpu0, (_, thr0) = time.process_time(), cpu_quota()
             t0 = time.perf_counter()
             sl = free_slots.get()
             t_a = time.perf_counter()
@@ -319,12 +353,17 @@ def run_pipelined(ctx, desc, cf_frames, w, h, layout, bpc, refs, threads, depth=
     if err:
         raise err[0]
     n = frames - warm
+    cpu1, (quota, thr1) = time.process_time(), cpu_quota()
     gaps = np.diff(np.array(t_end[warm - 1:])) * 1e3
     out = {"ms_per_frame": round((t_end[-1] - t_end[warm - 1]) / n * 1e3, 3), "frames": n, "frames_in_flight": depth,
            "ms_between_frame_ends": {"median": round(float(np.median(gaps)), 3), "max": round(float(gaps.max()), 3)},
            "list_ms": round(float(np.median(list_ms)), 3), "frame_end_ms": round(float(np.median(end_ms[warm:])), 3),
            "slot_wait_ms": round(float(np.median(wait_ms)), 3), "host_threads": threads,
-           "packed_coef_bytes_per_frame": coef_bytes}
+           "packed_coef_bytes_per_frame": coef_bytes,
+           # what the host side costs: CPU time of the whole process (listing threads, the ending thread, this harness) per frame.  Where
+           # the container has a CPU quota, sustained ms_per_frame cannot go below this divided by the quota, however many threads run.
+           "host_cpu_ms_per_frame": round((cpu1 - cpu0) / n * 1e3, 1) if cpu0 is not None else None,
+           "host_cpu_quota_cores": quota, "throttled_periods_during_run": (thr1 - thr0) if thr0 is not None and thr1 is not None else None}
     if os.environ.get("DAV1D_HIP_E2E_TRACE"):
         r = lambda v: [round(float(x), 2) for x in v]
         out["trace"] = {"list": r(list_ms), "end": r(end_ms), "destroy": r(destroy_ms), "begin": r(begin_ms),
@@ -357,7 +396,7 @@ def run_sustained(ctx, w=7680, h=4320, bpc=10, frames=10, threads=None, tile_col
             r.upload(pl, rng.integers(0, 1 << bpc, size=(rows, cols), dtype=np.uint16).astype(r.dtype))
         refs.append(r)
     n_tiles = ho.desc.n_tile_cols * ho.desc.n_tile_rows
-    threads = threads or n_tiles
+    threads = host_threads(n_tiles, threads)
     cfs = [ho.cf.copy() for _ in range(frames)]
     out, planes = run_pipelined(ctx, ho.desc, cfs, w, h, layout, bpc, [refs[i % 3] for i in range(7)], threads, depth, warm)
     out["tiles"] = n_tiles

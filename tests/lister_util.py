@@ -583,7 +583,7 @@ def full_route_rate(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=64, frame
         rf.destroy()
 
 
-def full_route_sustained(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=64, frames=10, depth=2, warm=2, seed=0xF0E):
+def full_route_sustained(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=None, frames=10, depth=2, warm=2, seed=0xF0E):
     """full_route_rate with frames in flight (dav1d_amd.e2e.run_pipelined): frame n + 1 is listed — blocks by the packing lister,
     then the filter tasks — while frame n runs on the device; per frame only the coefficients that exist, the prepared lists and the
     level cache cross the host link.  The last frame's final picture is compared with the reference's dav1d_decode_tile_sbrow +
@@ -598,6 +598,7 @@ def full_route_sustained(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=64, 
         d = synth(ctx, rf, sp)
         fill_pictures(rf, seed + 1)
         rf.build_filter_inputs(seed)
+        threads = e2e.host_threads(tile_cols * tile_rows + 3 * rf.sbh, threads)
         rf.recon(min(threads, 64))
         rf.filter()
         refs = []
