@@ -26,9 +26,11 @@ typedef uint8_t *(*Dav1dHipChunkPlace)(void *cookie, size_t bytes, size_t *dev_o
 int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHipPicture *geom, const Dav1dHipPicture *refs, int n_refs,
                           const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
                           const Dav1dHipItxTask *itx, size_t n_itx, Dav1dHipChunkPlace place, void *cookie);
-// the frame's arena grown to `need` bytes if it is smaller (contents lost: *regrown = true, the caller sends its twin again), then
-// every chunk that lives in a slab of its own sent to its place (copy stream)
-int dav1d_hip_chunks_send_late(Dav1dHipContext *c, std::vector<Dav1dHipChunk *> &chunks, uint8_t **arena, size_t *arena_cap, size_t need, bool *regrown);
+// The frame's arena grown to `need` bytes if it is smaller (contents lost: *regrown = true, the caller sends its twin again).  Then, AFTER
+// the twin has gone (a late chunk may start inside the range the twin covers: the twin's bytes there are not the chunk's), every chunk
+// that lives in a slab of its own is sent to its place (copy stream; `regrown`: also those that had been sent before).
+int dav1d_hip_chunks_grow_arena(Dav1dHipContext *c, uint8_t **arena, size_t *arena_cap, size_t need, bool *regrown);
+int dav1d_hip_chunks_send_late(Dav1dHipContext *c, std::vector<Dav1dHipChunk *> &chunks, uint8_t *arena, size_t arena_cap, bool regrown);
 int dav1d_hip_chunks_to_recon_list(Dav1dHipContext *c, std::vector<Dav1dHipChunk *> &chunks, uint8_t **arena, size_t *arena_cap,
                                    const Dav1dHipPicture *refs, int n_refs,
                                    Dav1dHipReconList *l, Dav1dHipInterList *il, Dav1dHipMcList *ml, Dav1dHipCompList *cl, Dav1dHipItxList *xl);

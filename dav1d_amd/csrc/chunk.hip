@@ -543,18 +543,20 @@ static int ensure_dev(uint8_t **p, size_t *cap, size_t want, hipStream_t sync_on
     return 0;
 }
 
-int dav1d_hip_chunks_send_late(Dav1dHipContext *c, std::vector<Dav1dHipChunk *> &chunks, uint8_t **arena, size_t *arena_cap, size_t need, bool *regrown) {
+int dav1d_hip_chunks_grow_arena(Dav1dHipContext *c, uint8_t **arena, size_t *arena_cap, size_t need, bool *regrown) {
     *regrown = false;
-    if (need + 256 > *arena_cap) {
-        (void) hipStreamSynchronize(c->copy_stream);
-        const int rc = ensure_dev(arena, arena_cap, need + 256, c->stream);
-        if (rc) return rc;
-        *regrown = true;
-    }
+    if (need + 256 <= *arena_cap) return 0;
+    (void) hipStreamSynchronize(c->copy_stream);
+    const int rc = ensure_dev(arena, arena_cap, need + 256, c->stream);
+    if (!rc) *regrown = true;
+    return rc;
+}
+
+int dav1d_hip_chunks_send_late(Dav1dHipContext *c, std::vector<Dav1dHipChunk *> &chunks, uint8_t *arena, size_t arena_cap, bool regrown) {
     for (Dav1dHipChunk *ck : chunks) {
-        if (!ck->used || !ck->host || (ck->uploaded && !*regrown)) continue;
-        if (ck->dev_off + ck->used > *arena_cap) return -EINVAL;
-        const int rc = hip_rc(hipMemcpyAsync(*arena + ck->dev_off, ck->host, ck->used, hipMemcpyHostToDevice, c->copy_stream));
+        if (!ck->used || !ck->host || (ck->uploaded && !regrown)) continue;
+        if (ck->dev_off + ck->used > arena_cap) return -EINVAL;
+        const int rc = hip_rc(hipMemcpyAsync(arena + ck->dev_off, ck->host, ck->used, hipMemcpyHostToDevice, c->copy_stream));
         if (rc) return rc;
         ck->uploaded = true;
     }

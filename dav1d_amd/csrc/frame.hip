@@ -358,7 +358,7 @@ int dav1d_hip_frame_begin(Dav1dHipContext *c, Dav1dHipFrame **out, const Dav1dHi
         }
     }
     if (!f->arena) {
-        size_t want = (size_t) 1 << 24;
+        size_t want = c->arena_min;
         while (want < c->arena_hint + (c->arena_hint >> 2)) want <<= 1;
         if (hipMalloc((void **) &f->arena, want) == hipSuccess) f->arena_cap = want; else f->arena = nullptr;
     }
@@ -847,9 +847,10 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
         // a chunk that found no room in the twin (the first frames of a size: the arena is sized by what frames have needed) sits in
         // a slab of its own: the arena grows to what was drawn, the twin goes up again if it did, the late chunks follow
         bool regrown = false;
-        rc = dav1d_hip_chunks_send_late(c, f->chunks, &f->arena, &f->arena_cap, f->arena_used.load(), &regrown);
+        rc = dav1d_hip_chunks_grow_arena(c, &f->arena, &f->arena_cap, f->arena_used.load(), &regrown);
         if (regrown) f->harena_flushed = 0;
         if (!rc && f->harena) rc = frame_flush_locked(f);       // what dav1d_hip_frame_flush has not sent yet (the gather launch waits for the copy stream)
+        if (!rc) rc = dav1d_hip_chunks_send_late(c, f->chunks, f->arena, f->arena_cap, regrown);      // after the twin: see chunk.h
         if (!rc) rc = dav1d_hip_chunks_to_recon_list(c, f->chunks, &f->arena, &f->arena_cap, f->refs, f->n_refs, &rl, &il, &ml, &cl, &xl);
         if (!rc) {
             if (ml.n || cl.n || rl.f_n[0] || rl.f_n[1] || rl.f_n[2] || rl.f_n[3] || rl.f_n[4]) {

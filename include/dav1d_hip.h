@@ -66,7 +66,7 @@ DAV1D_HIP_API size_t dav1d_hip_graph_nodes(const Dav1dHipGraph *g);      /* laun
 DAV1D_HIP_API void dav1d_hip_graph_destroy(Dav1dHipContext *c, Dav1dHipGraph *g);
 /* Tuning knobs are context state; the environment variables DESIGN.md lists only supply the defaults when the context is opened.
  * name = the variable without its DAV1D_HIP_ prefix, lower case ("recon_fuse", "recon_pipeline", "recon_lanes", "post_bands",
- * "serial", "cdef_unit", "flow_groups", "flow_mode", "flow_min_steps"); -EINVAL for an unknown name. */
+ * "serial", "cdef_unit", "flow_groups", "flow_mode", "flow_min_steps", "chunk_arena_min"); -EINVAL for an unknown name. */
 DAV1D_HIP_API int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value);
 DAV1D_HIP_API const char *dav1d_hip_version(void);
 /* Measurement aid: device time (HIP events on the context's stream) of the kernel launches of the most recent

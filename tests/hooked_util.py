@@ -72,7 +72,7 @@ def params(w, h, bpc, n_frames, mode, layout=1, sb128=True, tiles=(2, 1), thread
             p.lr_type[i] = filters["lr"][0][i]
         p.lr_unit_size[0], p.lr_unit_size[1] = filters["lr"][1]
     p.mode, p.free_listing, p.device, p.keep_output = mode, free_listing, 0, int(keep_output)
-    p.pack = int(bool(pack) and mode == 1)
+    p.pack = int(bool(pack) and mode == 1 and os.environ.get("DAV1D_HOOKED_PACK", "1") != "0")
     p.synth = synth if synth is not None else lu.default_synth(seed, n_refs=3, far_mv_pct=2)
     return p
 
@@ -149,7 +149,9 @@ def task_loop_rate(hip_lib_path, w, h, bpc, tiles=(4, 1), threads=64, frame_dela
         for k in range(check_frames):
             for pl in range(3):
                 if not np.array_equal(want[k][pl], got[k][pl]):
-                    raise AssertionError("dav1d task loop: frame %d plane %d differs from dav1d's own pass 2 + filters" % (k, pl))
+                    bad = np.argwhere(want[k][pl] != got[k][pl])
+                    raise AssertionError("dav1d task loop: frame %d plane %d differs from dav1d's own pass 2 + filters: %d pixels, first at (y, x) = %s, "
+                                         "rows %d..%d, columns %d..%d" % (k, pl, len(bad), tuple(bad[0]), bad[:, 0].min(), bad[:, 0].max(), bad[:, 1].min(), bad[:, 1].max()))
         del want, got
         run(params(w, h, bpc, frames, mode=0, keep_output=False, **common), hip_lib_path, store, inject=1)      # fills the store for every frame
         cpu_s, _, _ = run(params(w, h, bpc, check_frames, mode=0, keep_output=False, **common), hip_lib_path, store, inject=2)

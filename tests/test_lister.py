@@ -208,6 +208,22 @@ def test_cfl_of_a_palette_block_waits_for_the_luma_it_borrows(ctx):
         run_case(ctx, 128, 64, 1, 8, 311, is_inter=False, palette=40, packed=packed)
 
 
+@pytest.mark.parametrize("packed", [False, True], ids=["dense", "packed"])
+def test_chunks_that_do_not_fit_the_frames_arena(ctx, packed):
+    """The first frame of a size finds the chunk arena sized by guesswork (option chunk_arena_min makes the guess tiny here): the
+    tile-sbrows whose prepared lists do not fit its pinned twin keep them in slabs of their own, the arena grows at frame end, the twin
+    goes up first and the late chunks after it — one of them starts inside the range the twin covers."""
+    c2 = util.make_context(ctx.backend)
+    c2.backend = ctx.backend
+    try:
+        c2.set_option("chunk_arena_min", 32768)
+        run_case(c2, 512, 384, 1, 10, 77, tiles=(2, 1), threads=2, packed=packed, **PLAIN)
+        c2.set_option("chunk_arena_min", 4096)
+        run_case(c2, 384, 256, 1, 8, 78, packed=packed)
+    finally:
+        c2.close()
+
+
 @pytest.mark.parametrize("bpc", [8, 10])
 def test_packing_lister_key_frame_through_the_dataflow_launch(ctx, bpc):
     """a key frame deep enough for the one-launch wavefront (intra_flow.hip, more than flow_min_steps steps): its units carry PACKED
