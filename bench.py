@@ -106,10 +106,11 @@ def pmc_traffic(kernel, w, h, bpc):
         from dav1d_amd import synth
         tx = [i for i in range(19) if synth.TX_W[i] == int(m.group(2)) and synth.TX_H[i] == int(m.group(3))][0]
         key = "itx_add_kernel<%d,u16,int>" % tx
-    if key not in d and key[:-1] + ",false>" in d:        # the paired kernels carry their form (one wave / cooperative) in the name
-        key = key[:-1] + ",false>"
-    if key not in d:
-        return None
+    if key not in d:        # the kernels carry their variants in the name (cooperative / tiled references / wide stores): the plain one has them all off
+        cand = [k for k in d if k.startswith(key[:-1] + ",") and set(k[len(key):-1].split(",")) <= {"false"}]
+        if not cand:
+            return None
+        key = cand[0]
     return int(d[key]["fetch_bytes_x2"] + d[key]["write_bytes"])
 
 
@@ -830,6 +831,16 @@ def main():
                     raise SystemExit("bench: full end-to-end leg differs from the reference: %s" % e)
                 except Exception as e:       # noqa: BLE001  (a reported extra)
                     full_route = {"error": str(e)[:200]}
+        # ---- row-granular progress (reference src/thread_task.c:888-896 publishes per superblock row): what a listener costs
+        row_progress = None
+        if world == 1 and not a.no_e2e and not a.no_check:
+            try:
+                import lister_util as lu
+                row_progress = lu.row_progress_cost(ctx, w, h, bpc, a.e2e_tile_cols, a.e2e_tile_rows, threads=a.e2e_threads or 64)
+            except AssertionError as e:
+                raise SystemExit("bench: row progress leg differs from the reference: %s" % e)
+            except Exception as e:       # noqa: BLE001
+                row_progress = {"error": str(e)[:200]}
         # ---- BASELINE configs[2] says 4 tile columns: the end-to-end legs again with the frame cut that way (a tile's superblock rows are
         # listed top to bottom, so 4 tiles are 4 listing threads), next to the many-tile runs above
         e2e_c2 = full_route_c2 = None
@@ -912,7 +923,7 @@ def main():
                           "coef_bytes_per_frame": int(coef_host.nbytes), "coef_h2d_ms_per_frame": h2d_ms,
                           "samples_per_frame": frame.n_samples, "parity": check, "gen_seconds": round(t_gen, 1)},
                "roofline": roof, "cpu_baseline": cpu, "full_table": full, "end_to_end": e2e_leg, "all_intra": key_leg, "end_to_end_full_table": full_route, "end_to_end_4_tile_columns": e2e_c2, "end_to_end_full_table_4_tile_columns": full_route_c2,
-               "end_to_end_frames_in_flight": sustained, "dav1d_task_loop": task_loop, "config_c0_1080p_8bit": c0,
+               "end_to_end_frames_in_flight": sustained, "row_progress": row_progress, "dav1d_task_loop": task_loop, "config_c0_1080p_8bit": c0,
                "device": None if a.no_check else device_probe(torch)}       # (not under the profiler: its copies would sit in the kernel statistics)
         # BASELINE configs[1] (4K 8-bit, the reference's CPU-runnable size) next to the headline: the same bench in a child process,
         # its digest under "config_c1_4k_8bit"

@@ -775,6 +775,72 @@ static int copy_picture(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Da
     return 0;
 }
 
+// Row-granular progress without banding the whole frame (the reference publishes f->sr_cur.progress[1] after the last filter of every
+// superblock row, src/thread_task.c:888-896; post_filters_pipelined() above follows every band through all three stages on three
+// streams and pays 70 % for it).  Here only the LAST stage of a frame is cut: restoration runs as one Wiener + one self-guided launch
+// per band of 256 luma rows on the frame's stream, back to back (no host round trip, no cross-stream event), an event behind each
+// band; the host waits for the events in order and publishes.  Rows are final up to where the NEXT band's first stripe begins
+// (restoration stripes start 8 rows above the 64-row grid, src/lr_apply_tmpl.c:176-199).
+static int frame_lr_banded(Dav1dHipFrame *f, const Dav1dHipPicture *out, const Dav1dHipPicture *in, const Dav1dHipPicture *lpf) {
+    Dav1dHipContext *c = f->c;
+    const int H = f->cur.p[0].h, ss_ver = f->cur.layout == DAV1D_HIP_LAYOUT_I420;
+    const int band_h = 256, nb = (H + band_h - 1) / band_h;
+    const size_t n = f->lr.size();
+    if (nb < 2 || !n) return dav1d_hip_lr_batch(c, out, in, lpf, f->lr.data(), n);
+    std::vector<int> band(n);
+    std::vector<size_t> off(2 * nb + 1, 0);
+    std::vector<int> first_y(nb + 1, H);
+    for (size_t i = 0; i < n; i++) {
+        const Dav1dHipLrTask &t = f->lr[i];
+        if (t.plane > 2 || t.edges > 15 || !t.w || t.w > 384 || !t.h || t.h > 64 || t.type > DAV1D_HIP_LR_SGR_MIX) return -EINVAL;
+        const int y = (int) t.y << (t.plane ? ss_ver : 0);
+        band[i] = std::min(y / band_h, nb - 1);
+        first_y[band[i]] = std::min(first_y[band[i]], y);
+        off[2 * band[i] + (t.type > DAV1D_HIP_LR_WIENER5) + 1]++;
+    }
+    for (int k = 0; k < 2 * nb; k++) off[k + 1] += off[k];
+    std::vector<Dav1dHipLrTask> sorted(n);
+    {
+        std::vector<size_t> pos(off.begin(), off.end() - 1);
+        for (size_t i = 0; i < n; i++) sorted[pos[2 * band[i] + (f->lr[i].type > DAV1D_HIP_LR_WIENER5)]++] = f->lr[i];
+    }
+    for (int b = nb - 1; b >= 0; b--) first_y[b] = std::min(first_y[b], first_y[b + 1]);
+    std::vector<uint32_t> waves;
+    std::vector<size_t> w_off(nb + 1, 0);
+    for (int b = 0; b < nb; b++) {
+        dav1d_hip_sgr_make_rows(sorted.data() + off[2 * b + 1], off[2 * b + 2] - off[2 * b + 1], waves);
+        w_off[b + 1] = waves.size() / 4;
+    }
+    const size_t o_waves = (n * sizeof(Dav1dHipLrTask) + 15) & ~(size_t) 15;
+    TaskBuf devb_buf(c, o_waves + waves.size() * 4 + 16);
+    uint8_t *const devb = devb_buf.p;
+    if (!devb) return -ENOMEM;
+    Dav1dHipLrTask *const dev = reinterpret_cast<Dav1dHipLrTask *>(devb);
+    int rc = dav1d_hip_upload(c, dev, sorted.data(), n * sizeof(*dev));
+    if (!rc && !waves.empty()) rc = dav1d_hip_upload(c, devb + o_waves, waves.data(), waves.size() * 4);
+    const DevPlanes dp = dev_planes(out), sp = dev_planes(in), lp = dev_planes(lpf);
+    std::vector<hipEvent_t> ev(nb, nullptr);
+    for (int b = 0; b < nb && !rc; b++) rc = hip_rc(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
+    int launched = 0;
+    for (int b = 0; b < nb && !rc; b++) {
+        const size_t w0 = off[2 * b], w1 = off[2 * b + 1], w2 = off[2 * b + 2];
+        int max_w = 0;
+        for (size_t i = w0; i < w1; i++) max_w = std::max(max_w, (int) sorted[i].w);
+        if (w1 > w0) rc = dav1d_hip_launch_wiener(&dp, &sp, &lp, out->bpc, dev + w0, (int) (w1 - w0), max_w, c->stream);
+        if (!rc && w2 > w1) rc = dav1d_hip_launch_sgr(&dp, &sp, &lp, out->bpc, dev + w1, devb + o_waves + 16 * w_off[b], (int) (w_off[b + 1] - w_off[b]), c->stream);
+        if (!rc) rc = hip_rc(hipEventRecord(ev[b], c->stream));
+        if (!rc) launched++;
+    }
+    // the bands come through in order; the last one is published with the frame (frame_run)
+    for (int b = 0; b + 1 < launched; b++) {
+        if (hipEventSynchronize(ev[b]) != hipSuccess) { rc = rc ? rc : -EIO; break; }
+        f->publish(first_y[b + 1], out);
+    }
+    (void) hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : ev) if (e) (void) hipEventDestroy(e);
+    return rc;
+}
+
 // Runs the frame.  coef / prep / mask: the DEVICE arenas the task offsets refer to.  On return `cur` holds the
 // reconstructed AND deblocked picture (deblocking is in place, as in the reference); *filtered receives a descriptor of
 // the picture after CDEF and loop restoration (it is `cur` itself when neither stage has tasks; otherwise a picture owned by
@@ -1044,7 +1110,9 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
                 rc = frame_tmp(f, 1);
             }
             if (!rc) rc = copy_picture(c, out, last);
-            if (!rc) rc = dav1d_hip_lr_batch(c, out, last, lpf, f->lr.data(), f->lr.size());
+            // somebody listens for rows (dav1d_hip_frame_set_progress_callback): the LAST stage runs in bands of rows, each followed by
+            // an event, and the rows are published band by band while the later bands still run
+            if (!rc) rc = f->progress_cb && !f->sr_w ? frame_lr_banded(f, out, last, lpf) : dav1d_hip_lr_batch(c, out, last, lpf, f->lr.data(), f->lr.size());
             last = out;
         }
     }

@@ -485,7 +485,7 @@ def reference_pass2_rate(lib_ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=
         rf.destroy()
 
 
-def full_route_rate(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=64, frames=5, seed=0xF0E):
+def full_route_rate(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=64, frames=5, seed=0xF0E, progress=None):
     """The whole frame from dav1d's hand-off to final pixels, timed: pass-1 arrays (Av1Block / cbi / cf) and pass 1's filter inputs
     (Av1Filter masks, level cache, cdef_idx, restoration units — built here by the reference's own dav1d_create_lf_mask_* on a real
     Dav1dFrameContext) -> lister threads -> filter lister threads -> dav1d_hip_frame_end (reconstruction, deblocking, CDEF,
@@ -552,6 +552,8 @@ def full_route_rate(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=64, frame
                     mask = ctx.buffer(ctx.lib.dav1d_hip_lister_mask_bytes(lh) + 4096)
                     mask.upload(np.ctypeslib.as_array((C.c_uint8 * nb.value).from_address(blob)))
                 frame.set_filters(lvl, rf.b4_stride, lut[0:64], lut[64:128], rf.p.cdef_damping + bpc - 8)
+                if progress is not None:
+                    frame.set_progress_callback(lambda rows, pic: progress.append((it, rows)))      # a listener: the last stage runs in row bands
                 t_d = time.perf_counter()
                 filtered = frame.end(coef, prep, mask)
                 t_e = time.perf_counter()
@@ -581,6 +583,24 @@ def full_route_rate(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=64, frame
         return out
     finally:
         rf.destroy()
+
+
+def row_progress_cost(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=64, frames=7):
+    """What row-granular progress costs (dav1d_hip_frame_set_progress_callback on the stage-by-stage schedule: the last stage in bands of
+    256 rows, an event behind each, rows published while the later bands run): dav1d_hip_frame_end of the same frame with and without
+    a listener, pictures checked against the reference both times."""
+    calls = []
+    a = full_route_rate(ctx, w, h, bpc, tile_cols, tile_rows, threads, frames)
+    b = full_route_rate(ctx, w, h, bpc, tile_cols, tile_rows, threads, frames, progress=calls)
+    if not a or not b:
+        return None
+    per_frame = {}
+    for it, rows in calls:
+        per_frame.setdefault(it, []).append(rows)
+    last = per_frame[max(per_frame)]
+    return {"frame_end_ms": a["frame_end_ms"], "frame_end_ms_with_listener": b["frame_end_ms"],
+            "cost_pct": round((b["frame_end_ms"] / a["frame_end_ms"] - 1) * 100, 1), "publications_per_frame": len(last),
+            "rows_published": last, "parity": b["parity"]}
 
 
 def full_route_sustained(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=None, frames=10, depth=2, warm=2, seed=0xF0E):

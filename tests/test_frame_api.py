@@ -13,16 +13,18 @@ import test_postchain
 
 
 @pytest.mark.parametrize("bpc", [8, 10, 12])
-@pytest.mark.parametrize("bands", [8, 0, -1, -8], ids=["banded", "staged", "staged-async-end", "banded-async-progress"])
+@pytest.mark.parametrize("bands", [8, 0, -1, -8, -100], ids=["banded", "staged", "staged-async-end", "banded-async-progress", "staged-async-progress"])
 def test_frame_in_flight_matches_oracle(ctx, bpc, bands, monkeypatch):
     """bands: the post filters pipelined over superblock-row bands (three streams) / one stage after the other; -1: the latter
     through dav1d_hip_frame_end_async (the frame runs on a thread of the library, completion arrives through the callback and
     dav1d_hip_frame_progress — the hook for dav1d's progress publication, src/thread_task.c:888-896); -8: banded and
     asynchronous with the row-granular progress callback — every time rows are published they are copied out of the filtered
     picture to pinned host planes (dav1d_hip_host_picture_*, the buffers behind a Dav1dPicAllocator) while the bands below are
-    still being filtered, and what was copied must be the final picture."""
+    still being filtered, and what was copied must be the final picture; -100: the same listener on the stage-by-stage schedule —
+    only the LAST stage (restoration) runs in bands of 256 rows with an event behind each (frame_lr_banded, frame.hip)."""
     async_end = bands < 0
-    bands = 0 if bands == -1 else abs(bands)
+    last_stage_rows = bands == -100
+    bands = 0 if bands in (-1, -100) else abs(bands)
     ctx.set_option("post_bands", bands)
 
     oracle = util.default_oracle()
@@ -85,7 +87,7 @@ def test_frame_in_flight_matches_oracle(ctx, bpc, bands, monkeypatch):
     if async_end:
         seen, steps = [], []
         assert f.progress() == 0
-        if bands:
+        if bands or last_stage_rows:
             host = api.HostPictureBuf(ctx, w, h, api.LAYOUT_I420, bpc)
 
             def on_rows(rows, pic):
@@ -95,8 +97,8 @@ def test_frame_in_flight_matches_oracle(ctx, bpc, bands, monkeypatch):
         f.end_async(coef, prep, None, grain, done=lambda rc: seen.append((rc, f.progress())))
         filtered = f.wait()
         assert seen == [(0, h)] and f.progress() == h, seen
-        if bands:
-            nb = min(bands, (h + 255) // 256)
+        if bands or last_stage_rows:
+            nb = min(bands, (h + 255) // 256) if bands else (h + 255) // 256
             assert len(steps) == nb and steps == sorted(set(steps)) and steps[-1] == h, steps
             # restoration stripes start 8 rows above the 64-row grid: a band's last stripe ends 56 rows into the next band
             assert all(r % 256 == 56 for r in steps[:-1]), steps
