@@ -831,6 +831,49 @@ def main():
                     raise SystemExit("bench: full end-to-end leg differs from the reference: %s" % e)
                 except Exception as e:       # noqa: BLE001  (a reported extra)
                     full_route = {"error": str(e)[:200]}
+        # ---- splat_mv / save_tmvs of the frame's blocks on a frame-level refmvs map (csrc/refmvs.hip; bit-exact against the
+        # reference's functions in tests/test_refmvs.py).  Timed, not wired into a decode loop: pass 1 needs the rows on the host for its own
+        # motion vector prediction, so the device copy would be a second splat, not a saved one.
+        refmvs_leg = None
+        if world == 1 and not a.no_full and (w, h, bpc) == (7680, 4320, 10):
+            try:
+                import ctypes as C
+                SPLAT = np.dtype([("bx4", "<u2"), ("by4", "<u2"), ("bw4", "u1"), ("bh4", "u1"), ("pad", "u1", 2), ("rmv", "<u4", 3)])
+                ystride = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+                sp_px = ystride.pic.p[0].stride // 2
+                ystride.free()
+                blk = [(t["dst_off"], t["w"], t["h"]) for t in (frame.mc[(frame.mc["plane"] == 0) & (frame.mc["kind"] == 0)], frame.comp[frame.comp["plane"] == 0])]
+                off = np.concatenate([b[0] for b in blk]).astype(np.int64)
+                bw = np.concatenate([b[1] for b in blk]).astype(np.int64)
+                bh = np.concatenate([b[2] for b in blk]).astype(np.int64)
+                tasks = np.zeros(len(off), SPLAT)
+                tasks["bx4"], tasks["by4"] = (off % sp_px) // 4, (off // sp_px) // 4
+                tasks["bw4"], tasks["bh4"] = np.minimum(bw // 4, 32), np.minimum(bh // 4, 32)
+                rgen = np.random.default_rng(3)
+                tasks["rmv"][:, 0] = rgen.integers(0, 1 << 32, len(off), dtype=np.uint64).astype(np.uint32) & 0x03ff03ff
+                tasks["rmv"][:, 2] = 1 | (0xff << 8) | (12 << 16)
+                stride4, h4 = (w + 127) // 128 * 32, (h + 127) // 128 * 32
+                rmap = ctx.buffer(stride4 * h4 * 12)
+                rmap.zero()
+                rp_stride = ((w + 127) & ~127) >> 3
+                rp = ctx.buffer(rp_stride * (h // 8) * 5 + 64)
+                sign = np.array([1, 0, 1, 1, 0, 1, 0], np.uint8)
+                ms = []
+                for _ in range(4):
+                    ctx.sync()
+                    t0 = time.perf_counter()
+                    assert ctx.lib.dav1d_hip_refmvs_splat_batch(ctx.h, rmap.ptr, stride4, tasks.ctypes.data, len(tasks)) == 0
+                    ctx.sync()
+                    t1 = time.perf_counter()
+                    assert ctx.lib.dav1d_hip_refmvs_save_tmvs(ctx.h, rp.ptr, rp_stride, rmap.ptr, stride4, sign.ctypes.data, 0, w // 8, 0, h // 8) == 0
+                    ctx.sync()
+                    ms.append(((t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3))
+                refmvs_leg = {"blocks": int(len(tasks)), "splat_ms_with_task_upload": round(min(m[0] for m in ms), 3), "save_tmvs_ms": round(min(m[1] for m in ms), 3),
+                              "map_bytes": int(stride4 * h4 * 12), "parity": "tests/test_refmvs.py (bit-exact vs the reference's splat_mv / save_tmvs)"}
+                rmap.free()
+                rp.free()
+            except Exception as e:       # noqa: BLE001  (a reported extra)
+                refmvs_leg = {"error": str(e)[:200]}
         # ---- row-granular progress (reference src/thread_task.c:888-896 publishes per superblock row): what a listener costs
         row_progress = None
         if world == 1 and not a.no_e2e and not a.no_check:
@@ -923,7 +966,7 @@ def main():
                           "coef_bytes_per_frame": int(coef_host.nbytes), "coef_h2d_ms_per_frame": h2d_ms,
                           "samples_per_frame": frame.n_samples, "parity": check, "gen_seconds": round(t_gen, 1)},
                "roofline": roof, "cpu_baseline": cpu, "full_table": full, "end_to_end": e2e_leg, "all_intra": key_leg, "end_to_end_full_table": full_route, "end_to_end_4_tile_columns": e2e_c2, "end_to_end_full_table_4_tile_columns": full_route_c2,
-               "end_to_end_frames_in_flight": sustained, "row_progress": row_progress, "dav1d_task_loop": task_loop, "config_c0_1080p_8bit": c0,
+               "end_to_end_frames_in_flight": sustained, "row_progress": row_progress, "refmvs": refmvs_leg, "dav1d_task_loop": task_loop, "config_c0_1080p_8bit": c0,
                "device": None if a.no_check else device_probe(torch)}       # (not under the profiler: its copies would sit in the kernel statistics)
         # BASELINE configs[1] (4K 8-bit, the reference's CPU-runnable size) next to the headline: the same bench in a child process,
         # its digest under "config_c1_4k_8bit"

@@ -46,6 +46,7 @@ struct Dav1dHipContext {
     std::vector<Dav1dHipPicture> free_pictures; // the frames' own pictures (CDEF / restoration outputs) between frames: hipMalloc and
                                                // above all hipFree (it waits for the device) stay out of the per-frame path
     size_t arena_hint;                         // what the largest frame so far needed
+    int chunk_order;                           // option chunk_order: the prepared lists of a tile-sbrow ordered for the device (1) or left in decode order (0)
     size_t arena_min;                          // size of a frame's chunk arena before anything is known (option chunk_arena_min; tests make it tiny)
     size_t carena_hint;                        // bytes of packed coefficients the largest frame so far carried (sizes the pinned twin)
     uint8_t *gather_dev, *segtab_dev;

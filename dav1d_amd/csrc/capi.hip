@@ -75,6 +75,7 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     c->gather_cap = c->segtab_cap = c->pending_slab_cap = 0;
     c->arena_hint = 0;
     c->arena_min = (size_t) 1 << 24;
+    c->chunk_order = (int) env_int("DAV1D_HIP_CHUNK_ORDER", 0);
     c->carena_hint = 0;
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
@@ -167,6 +168,7 @@ int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value) {
     else if (!strcmp(name, "flow_groups")) c->flow_groups = value > 0 ? (int) value : c->flow_groups;
     else if (!strcmp(name, "flow_mode")) c->flow_mode = (int) value;
     else if (!strcmp(name, "flow_min_steps")) c->flow_min_steps = (int) value;
+    else if (!strcmp(name, "chunk_order")) c->chunk_order = value != 0;
     else if (!strcmp(name, "chunk_arena_min")) { if (value < 4096) return -EINVAL; c->arena_min = (size_t) 1 << 12; while (c->arena_min < (size_t) value) c->arena_min <<= 1; c->arena_hint = 0; }
     else return -EINVAL;
     return 0;

@@ -447,8 +447,19 @@ size_t dav1d_hip_frame_coef_bytes(const Dav1dHipFrame *f) { return f ? f->carena
 // Reconstruction tasks of one tile-sbrow (what decode_b()'s pass-2 branch would have executed, src/decode.c:706-806).
 // Thread-safe; the order between tile-sbrows is free: inter tasks of a frame write disjoint pixels, and every residual
 // is added after every prediction.
+static int submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
+                            const Dav1dHipItxTask *itx, size_t n_itx, bool trusted);
 int dav1d_hip_frame_submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
                                       const Dav1dHipItxTask *itx, size_t n_itx) {
+    return submit_tile_sbrow(f, mc, n_mc, comp, n_comp, itx, n_itx, false);
+}
+// internal (host/lister.c): the same for records the library made itself — they are not validated a second time
+int dav1d_hip_frame_submit_tile_sbrow_own(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
+                                          const Dav1dHipItxTask *itx, size_t n_itx) {
+    return submit_tile_sbrow(f, mc, n_mc, comp, n_comp, itx, n_itx, true);
+}
+static int submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
+                            const Dav1dHipItxTask *itx, size_t n_itx, bool trusted) {
     if (!f || (!mc && n_mc) || (!comp && n_comp) || (!itx && n_itx)) return -EINVAL;
     if (!n_mc && !n_comp && !n_itx) return 0;
     if ((n_mc || n_comp) && !f->n_refs) return -EINVAL;
@@ -462,7 +473,7 @@ int dav1d_hip_frame_submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc
         *dev_off = off;
         return fr->harena && off + sz <= fr->harena_cap && off + sz <= fr->arena_cap ? fr->harena + off : nullptr;
     };
-    const int rc = dav1d_hip_chunk_build(f->c, &ck, &f->cur, f->refs, f->n_refs, mc, n_mc, comp, n_comp, itx, n_itx, place, f);
+    const int rc = dav1d_hip_chunk_build(f->c, &ck, &f->cur, f->refs, f->n_refs, mc, n_mc, comp, n_comp, itx, n_itx, place, f, trusted);
     if (rc) return rc;
     // c->chunk_upload (no twin): up it goes on its own, while the other tile-sbrows are still being listed
     if (ck->used && ck->host && !f->harena && f->arena && ck->dev_off + ck->used <= f->arena_cap)

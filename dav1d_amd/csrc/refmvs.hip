@@ -59,15 +59,17 @@ int dav1d_hip_refmvs_splat_batch(Dav1dHipContext *c, void *r, ptrdiff_t stride4,
     if (!c || !r || stride4 <= 0 || (!tasks && n) || n > 0x7fffffff) return -EINVAL;
     if (!n) return 0;
     for (size_t i = 0; i < n; i++) if (!tasks[i].bw4 || !tasks[i].bh4 || tasks[i].bw4 > 32 || tasks[i].bh4 > 32 || tasks[i].bx4 + tasks[i].bw4 > stride4) return -EINVAL;
-    Dav1dHipSplatTask *dev = nullptr;
-    if (hipMalloc((void **) &dev, n * sizeof(*dev)) != hipSuccess) return -ENOMEM;
+    // the task array goes through the context's pool of task buffers (no allocation per call once the pool is warm) and the launch is
+    // left on the context's stream: whoever reads the map next does so on that stream, or calls dav1d_hip_sync
+    TaskBuf buf(c, n * sizeof(Dav1dHipSplatTask));
+    Dav1dHipSplatTask *const dev = reinterpret_cast<Dav1dHipSplatTask *>(buf.p);
+    if (!dev) return -ENOMEM;
     int rc = dav1d_hip_upload(c, dev, tasks, n * sizeof(*dev));
     if (!rc) {
         hipLaunchKernelGGL(splat_mv_kernel, dim3((unsigned) n), dim3(64), 0, c->stream, (uint32_t *) r, (int) stride4, dev, (int) n);
         rc = hip_rc(hipGetLastError());
     }
-    (void) hipStreamSynchronize(c->stream);
-    (void) hipFree(dev);
+    // the buffer returns to the pool when this scope ends: the next user of it uploads on the same stream, behind the launch
     return rc;
 }
 
@@ -83,9 +85,7 @@ int dav1d_hip_refmvs_save_tmvs(Dav1dHipContext *c, void *rp, ptrdiff_t rp_stride
     s.s[7] = 0;
     hipLaunchKernelGGL(save_tmvs_kernel, dim3((unsigned) ((col_end8 - col_start8 + 255) / 256), (unsigned) (row_end8 - row_start8)), dim3(256), 0, c->stream,
                        (uint8_t *) rp, (int) rp_stride, (const uint32_t *) r, (int) stride4, s, col_start8, col_end8, row_start8, row_end8);
-    const int rc = hip_rc(hipGetLastError());
-    (void) hipStreamSynchronize(c->stream);
-    return rc;
+    return hip_rc(hipGetLastError());       // stream-ordered: no host wait (dav1d_hip_sync, or a download on the context's stream)
 }
 
 } // extern "C"

@@ -25,6 +25,8 @@
 
 /* internal entry points of the frame driver (csrc/frame.hip) */
 int dav1d_hip_frame_picture(const Dav1dHipFrame *f, Dav1dHipPicture *out);
+int dav1d_hip_frame_submit_tile_sbrow_own(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
+                                          const Dav1dHipItxTask *itx, size_t n_itx);
 
 #define VEC(T) struct { T *p; size_t n, cap; }
 /* A vector that cannot grow hands out a scratch element and raises the calling thread's flag: the walk goes on writing into
@@ -1184,7 +1186,7 @@ int dav1d_hip_lister_tile_sbrow(Dav1dHipLister *l, const int tile_row, const int
         for (size_t i = 0; i < op->sitx.n; i++) op->sitx.p[i].cf_off += base;
     }
     PROF_T(t1);
-    if (!rc) rc = dav1d_hip_frame_submit_tile_sbrow(l->frame, op->mc.p, op->mc.n, op->comp.p, op->comp.n, op->itx.p, op->itx.n);
+    if (!rc) rc = dav1d_hip_frame_submit_tile_sbrow_own(l->frame, op->mc.p, op->mc.n, op->comp.p, op->comp.n, op->itx.p, op->itx.n);
     PROF_T(t2);
     PROF_ADD(0, t1 - t0); PROF_ADD(1, t2 - t1);
     if (!rc && op->warp.n) rc = dav1d_hip_frame_submit_warp(l->frame, op->warp.p, op->warp.n);

@@ -66,7 +66,9 @@ DAV1D_HIP_API size_t dav1d_hip_graph_nodes(const Dav1dHipGraph *g);      /* laun
 DAV1D_HIP_API void dav1d_hip_graph_destroy(Dav1dHipContext *c, Dav1dHipGraph *g);
 /* Tuning knobs are context state; the environment variables DESIGN.md lists only supply the defaults when the context is opened.
  * name = the variable without its DAV1D_HIP_ prefix, lower case ("recon_fuse", "recon_pipeline", "recon_lanes", "post_bands",
- * "serial", "cdef_unit", "flow_groups", "flow_mode", "flow_min_steps", "chunk_arena_min"); -EINVAL for an unknown name. */
+ * "serial", "cdef_unit", "flow_groups", "flow_mode", "flow_min_steps", "chunk_arena_min",
+ * "chunk_order": 1 = the prepared lists of a tile-sbrow are ordered for the device — by code path and reference, a few per cent on the
+ * launches for a tenth more host time per frame; 0, the default, leaves decode order); -EINVAL for an unknown name. */
 DAV1D_HIP_API int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value);
 DAV1D_HIP_API const char *dav1d_hip_version(void);
 /* Measurement aid: device time (HIP events on the context's stream) of the kernel launches of the most recent
@@ -878,6 +880,8 @@ typedef struct Dav1dHipSplatTask {
     uint8_t  pad[2];
     uint32_t rmv[3];         /* the refmvs_block to splat, as its 12 bytes */
 } Dav1dHipSplatTask;
+/* Both calls enqueue on the context's stream and return (no host wait, no allocation once the context's pools are warm): results are
+ * there for whatever runs on that stream next, or after dav1d_hip_sync. */
 DAV1D_HIP_API int dav1d_hip_refmvs_splat_batch(Dav1dHipContext *c, void *r_dev, ptrdiff_t stride4, const Dav1dHipSplatTask *tasks, size_t n);
 /* rp_dev: refmvs_temporal_block records (5 bytes: mv, ref), rp_stride per 8x8 row; ref_sign and the rectangle as the reference's
  * save_tmvs arguments (8x8 units). */

@@ -180,6 +180,7 @@ MIX_CPU = {"420_8", "420_12_cut", "444_10", "422_10", "400_8", "tiles_3_threads"
 def test_every_tool_mixed(ctx, name, w, h, layout, bpc, kw):
     if ctx.backend == "emu" and name not in MIX_CPU:
         pytest.skip("GPU run only")
+    ctx.set_option("chunk_order", MIX.index((name, w, h, layout, bpc, kw)) & 1)      # every other case with the lists ordered for the device
     st = run_case(ctx, w, h, layout, bpc, 100 + MIX.index((name, w, h, layout, bpc, kw)), **kw)
     if not kw.get("is_inter", True):
         assert st["steps"] > 20          # a key frame is one long wavefront
