@@ -837,7 +837,6 @@ def main():
         refmvs_leg = None
         if world == 1 and not a.no_full and (w, h, bpc) == (7680, 4320, 10):
             try:
-                import ctypes as C
                 SPLAT = np.dtype([("bx4", "<u2"), ("by4", "<u2"), ("bw4", "u1"), ("bh4", "u1"), ("pad", "u1", 2), ("rmv", "<u4", 3)])
                 ystride = ctx.picture(w, h, api.LAYOUT_I420, bpc)
                 sp_px = ystride.pic.p[0].stride // 2
