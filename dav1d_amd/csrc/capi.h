@@ -46,6 +46,8 @@ struct Dav1dHipContext {
     std::vector<Dav1dHipPicture> free_pictures; // the frames' own pictures (CDEF / restoration outputs) between frames: hipMalloc and
                                                // above all hipFree (it waits for the device) stay out of the per-frame path
     size_t arena_hint;                         // what the largest frame so far needed
+    uint32_t *band_cnt = nullptr, *band_flags = nullptr;   // frame_lr_banded (frame.hip): 64 counters + 64 targets on the device, 64 words of pinned host memory
+    uint32_t band_seq = 0;
     int chunk_order;                           // option chunk_order: the prepared lists of a tile-sbrow ordered for the device (1) or left in decode order (0)
     size_t arena_min;                          // size of a frame's chunk arena before anything is known (option chunk_arena_min; tests make it tiny)
     size_t carena_hint;                        // bytes of packed coefficients the largest frame so far carried (sizes the pinned twin)
@@ -294,6 +296,13 @@ extern "C" int dav1d_hip_launch_intra_pairs(const DevPlanes *dst, int bpc, int l
 extern "C" int dav1d_hip_launch_ipred(const DevPlanes *dst, int bpc, int layout, const Dav1dHipIpredTask *tasks, int n, int n_big,
                                       uint8_t *pal_idx, void *tmp, void *stream);
 
+// Completion of row bands signalled from INSIDE a launch (frame_lr_banded, frame.hip): every workgroup that has stored its pixels bumps its
+// band's counter; the one that completes a band writes `seq` to the band's word in pinned host memory.  cnt == nullptr: off.
+struct BandSignal { uint32_t *cnt; const uint32_t *target; uint32_t *host_flags; uint32_t seq; };
+extern "C" int dav1d_hip_launch_wiener_sig(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
+                                           const Dav1dHipLrTask *tasks, int n, int max_w, const BandSignal *sig, void *stream);
+extern "C" int dav1d_hip_launch_sgr_sig(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
+                                        const Dav1dHipLrTask *tasks, const void *waves, int n_waves, const BandSignal *sig, void *stream);
 extern "C" int dav1d_hip_launch_wiener(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
                                        const Dav1dHipLrTask *tasks, int n, int max_w, void *stream);
 

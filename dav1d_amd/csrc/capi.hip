@@ -92,6 +92,8 @@ void dav1d_hip_close(Dav1dHipContext *c) {
     for (int i = 0; i < 16; i++) hipEventDestroy(c->ev_bin[i]);
     hipEventDestroy(c->ev_t0); hipEventDestroy(c->ev_t1); hipEventDestroy(c->ev_retile);
     hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); hipEventDestroy(c->ev_copy);
+    if (c->band_cnt) (void) hipFree(c->band_cnt);
+    if (c->band_flags) (void) hipHostFree(c->band_flags);
     for (const Dav1dHipContext::Arena &ar : c->free_arenas) hipFree(ar.dev);
     for (const Dav1dHipContext::Arena &ar : c->free_task_bufs) hipFree(ar.dev);
     for (Dav1dHipPicture &q : c->free_pictures) { if (q.alloc) hipFree(q.alloc); if (q.twin_alloc) hipFree(q.twin_alloc); }

@@ -788,18 +788,27 @@ static int copy_picture(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Da
 
 // Row-granular progress without banding the whole frame (the reference publishes f->sr_cur.progress[1] after the last filter of every
 // superblock row, src/thread_task.c:888-896; post_filters_pipelined() above follows every band through all three stages on three
-// streams and pays 70 % for it).  Here only the LAST stage of a frame is cut: restoration runs as one Wiener + one self-guided launch
-// per band of 256 luma rows on the frame's stream, back to back (no host round trip, no cross-stream event), an event behind each
-// band; the host waits for the events in order and publishes.  Rows are final up to where the NEXT band's first stripe begins
-// (restoration stripes start 8 rows above the 64-row grid, src/lr_apply_tmpl.c:176-199).
+// streams and pays 70 % for it).  Here only the LAST stage of a frame tells where it is, and from INSIDE its two launches: the
+// restoration tasks are ordered by band of 256 luma rows, every workgroup that has written its pixels bumps its band's counter, and
+// the one that completes a band writes to a word of pinned host memory the ending thread polls (lr.hip band_done).  Cutting the stage
+// into a launch pair per band with an event behind each — the obvious way — was measured at 8K: 34 launches of 43 us each (a band
+// does not fill the device, a launch's time is one workgroup's latency) against 126 us for the two, +58 % on the frame.
+// Rows are final up to where the NEXT band's first stripe begins (restoration stripes start 8 rows above the 64-row grid,
+// src/lr_apply_tmpl.c:176-199).
 static int frame_lr_banded(Dav1dHipFrame *f, const Dav1dHipPicture *out, const Dav1dHipPicture *in, const Dav1dHipPicture *lpf) {
     Dav1dHipContext *c = f->c;
     const int H = f->cur.p[0].h, ss_ver = f->cur.layout == DAV1D_HIP_LAYOUT_I420;
     const int band_h = 256, nb = (H + band_h - 1) / band_h;
     const size_t n = f->lr.size();
-    if (nb < 2 || !n) return dav1d_hip_lr_batch(c, out, in, lpf, f->lr.data(), n);
+    if (nb < 2 || nb > 64 || !n) return dav1d_hip_lr_batch(c, out, in, lpf, f->lr.data(), n);
+    if (!c->band_cnt) {
+        if (hipMalloc((void **) &c->band_cnt, 128 * sizeof(uint32_t)) != hipSuccess) { c->band_cnt = nullptr; return -ENOMEM; }
+        if (hipHostMalloc((void **) &c->band_flags, 64 * sizeof(uint32_t), 0) != hipSuccess) { c->band_flags = nullptr; return -ENOMEM; }
+        memset(c->band_flags, 0, 64 * sizeof(uint32_t));
+    }
+    // tasks: [Wiener, band by band][self-guided, band by band, each band's units sorted into rows]
     std::vector<int> band(n);
-    std::vector<size_t> off(2 * nb + 1, 0);
+    std::vector<size_t> off(2 * nb + 1, 0);       // [kind * nb + band]
     std::vector<int> first_y(nb + 1, H);
     for (size_t i = 0; i < n; i++) {
         const Dav1dHipLrTask &t = f->lr[i];
@@ -807,48 +816,62 @@ static int frame_lr_banded(Dav1dHipFrame *f, const Dav1dHipPicture *out, const D
         const int y = (int) t.y << (t.plane ? ss_ver : 0);
         band[i] = std::min(y / band_h, nb - 1);
         first_y[band[i]] = std::min(first_y[band[i]], y);
-        off[2 * band[i] + (t.type > DAV1D_HIP_LR_WIENER5) + 1]++;
+        off[(t.type > DAV1D_HIP_LR_WIENER5) * nb + band[i] + 1]++;
     }
     for (int k = 0; k < 2 * nb; k++) off[k + 1] += off[k];
     std::vector<Dav1dHipLrTask> sorted(n);
     {
         std::vector<size_t> pos(off.begin(), off.end() - 1);
-        for (size_t i = 0; i < n; i++) sorted[pos[2 * band[i] + (f->lr[i].type > DAV1D_HIP_LR_WIENER5)]++] = f->lr[i];
+        for (size_t i = 0; i < n; i++) {
+            Dav1dHipLrTask &d = sorted[pos[(f->lr[i].type > DAV1D_HIP_LR_WIENER5) * nb + band[i]]++] = f->lr[i];
+            d.pad = (uint8_t) band[i];
+        }
     }
     for (int b = nb - 1; b >= 0; b--) first_y[b] = std::min(first_y[b], first_y[b + 1]);
-    std::vector<uint32_t> waves;
-    std::vector<size_t> w_off(nb + 1, 0);
+    const size_t nw = off[nb];                     // Wiener tasks
+    std::vector<uint32_t> tail;                    // the wave descriptors, then the 64 band targets: one upload
+    std::vector<uint32_t> target(64, 0);
+    int max_w = 0;
+    for (size_t i = 0; i < nw; i++) { max_w = std::max(max_w, (int) sorted[i].w); target[sorted[i].pad] += (uint32_t) ((sorted[i].w + 63) / 64); }
     for (int b = 0; b < nb; b++) {
-        dav1d_hip_sgr_make_rows(sorted.data() + off[2 * b + 1], off[2 * b + 2] - off[2 * b + 1], waves);
-        w_off[b + 1] = waves.size() / 4;
+        const size_t s0 = off[nb + b], s1 = off[nb + b + 1], w0 = tail.size();
+        dav1d_hip_sgr_make_rows(sorted.data() + s0, s1 - s0, tail);
+        for (size_t k = w0; k < tail.size(); k += 4) {          // the band's descriptors count from its first task: from the first self-guided task instead
+            tail[k] += (uint32_t) (s0 - nw); tail[k + 1] += (uint32_t) (s0 - nw); tail[k + 3] = (uint32_t) b;
+        }
+        target[b] += (uint32_t) ((tail.size() - w0) / 4);
     }
+    const size_t n_waves = tail.size() / 4;
+    tail.insert(tail.end(), target.begin(), target.end());
     const size_t o_waves = (n * sizeof(Dav1dHipLrTask) + 15) & ~(size_t) 15;
-    TaskBuf devb_buf(c, o_waves + waves.size() * 4 + 16);
+    TaskBuf devb_buf(c, o_waves + tail.size() * 4 + 16);
     uint8_t *const devb = devb_buf.p;
     if (!devb) return -ENOMEM;
     Dav1dHipLrTask *const dev = reinterpret_cast<Dav1dHipLrTask *>(devb);
     int rc = dav1d_hip_upload(c, dev, sorted.data(), n * sizeof(*dev));
-    if (!rc && !waves.empty()) rc = dav1d_hip_upload(c, devb + o_waves, waves.data(), waves.size() * 4);
+    if (!rc) rc = dav1d_hip_upload(c, devb + o_waves, tail.data(), tail.size() * 4);
+    if (!rc) rc = hip_rc(hipMemsetAsync(c->band_cnt, 0, 64 * sizeof(uint32_t), c->stream));
+    const uint32_t seq = ++c->band_seq ? c->band_seq : ++c->band_seq;        // never 0: the flags start at 0
+    const BandSignal sig = { c->band_cnt, reinterpret_cast<const uint32_t *>(devb + o_waves + n_waves * 16), c->band_flags, seq };
     const DevPlanes dp = dev_planes(out), sp = dev_planes(in), lp = dev_planes(lpf);
-    std::vector<hipEvent_t> ev(nb, nullptr);
-    for (int b = 0; b < nb && !rc; b++) rc = hip_rc(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
-    int launched = 0;
-    for (int b = 0; b < nb && !rc; b++) {
-        const size_t w0 = off[2 * b], w1 = off[2 * b + 1], w2 = off[2 * b + 2];
-        int max_w = 0;
-        for (size_t i = w0; i < w1; i++) max_w = std::max(max_w, (int) sorted[i].w);
-        if (w1 > w0) rc = dav1d_hip_launch_wiener(&dp, &sp, &lp, out->bpc, dev + w0, (int) (w1 - w0), max_w, c->stream);
-        if (!rc && w2 > w1) rc = dav1d_hip_launch_sgr(&dp, &sp, &lp, out->bpc, dev + w1, devb + o_waves + 16 * w_off[b], (int) (w_off[b + 1] - w_off[b]), c->stream);
-        if (!rc) rc = hip_rc(hipEventRecord(ev[b], c->stream));
-        if (!rc) launched++;
-    }
-    // the bands come through in order; the last one is published with the frame (frame_run)
-    for (int b = 0; b + 1 < launched; b++) {
-        if (hipEventSynchronize(ev[b]) != hipSuccess) { rc = rc ? rc : -EIO; break; }
-        f->publish(first_y[b + 1], out);
+    if (!rc) rc = dav1d_hip_launch_wiener_sig(&dp, &sp, &lp, out->bpc, dev, (int) nw, max_w, &sig, c->stream);
+    if (!rc) rc = dav1d_hip_launch_sgr_sig(&dp, &sp, &lp, out->bpc, dev + nw, devb + o_waves, (int) n_waves, &sig, c->stream);
+    // the bands come through (roughly) in order; the last one is published with the frame (frame_run).  A band without tasks has
+    // nothing to wait for beyond the bands before it.
+    if (!rc) {
+        volatile uint32_t *const flags = c->band_flags;
+        bool all_done = false;
+        for (int b = 0; b + 1 < nb; b++) {
+            for (unsigned spin = 0; target[b] && flags[b] != seq && !all_done; spin++) {
+                if ((spin & 63) == 63) all_done = hipStreamQuery(c->stream) == hipSuccess;          // (also the way out should a launch have failed)
+                else std::this_thread::yield();
+            }
+            if (all_done && flags[b] != seq && target[b]) break;
+            std::atomic_thread_fence(std::memory_order_acquire);
+            f->publish(first_y[b + 1], out);
+        }
     }
     (void) hipStreamSynchronize(c->stream);
-    for (hipEvent_t e : ev) if (e) (void) hipEventDestroy(e);
     return rc;
 }
 

@@ -24,9 +24,26 @@ enum { LR_SEG = 64 };        // output rows per wave: the whole stripe (16-row s
                              // dropped: fetching rows two iterations ahead (+6 %), one unaligned 8-pixel fetch per lane and
                              // row instead of seven 1-pixel ones (+60 %: neighbouring lanes read overlapping 16-byte pieces)
 
+// this wave's pixels are out (written back as far as the device's memory: the per-XCD L2s do not see each other's lines otherwise), its
+// band's counter goes up, and whoever completes the band tells the host
+__device__ __forceinline__ void band_done(const BandSignal &sg, const int band) {
+    if (!sg.cnt) return;
+    dv::fence_release_agent();
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned old = atomicAdd(sg.cnt + band, 1u);
+        if (old + 1 == sg.target[band]) {
+#ifdef DAV1D_HIP_EMU
+            sg.host_flags[band] = sg.seq;
+#else
+            __hip_atomic_store(sg.host_flags + band, sg.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+        }
+    }
+}
+
 template <typename pixel>
 __global__ __launch_bounds__(64) void wiener_kernel(const DevPlanes dst, const DevPlanes src, const DevPlanes lpf,
-                                                    const Dav1dHipLrTask *__restrict__ tasks, const int n, const int bitdepth_max)
+                                                    const Dav1dHipLrTask *__restrict__ tasks, const int n, const int bitdepth_max, const BandSignal sig)
 {
     constexpr bool HBD = sizeof(pixel) == 2;
     const int ti = blockIdx.y;
@@ -100,6 +117,7 @@ __global__ __launch_bounds__(64) void wiener_kernel(const DevPlanes dst, const D
             if (active) d[(r - 3) * dst.stride[pl]] = (pixel) dv::clamp3((v + rounding_off_v) >> round_bits_v, 0, bitdepth_max);
         }
     }
+    band_done(sig, t.pad);        // (the library's device copy carries the band in the record's spare byte)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -143,7 +161,7 @@ struct SgrWave { uint32_t first, end; int32_t v0; uint32_t pad; };      // tasks
 template <typename pixel>
 __global__ __launch_bounds__(64) void sgr_kernel(const DevPlanes dst, const DevPlanes src, const DevPlanes lpf,
                                                  const Dav1dHipLrTask *__restrict__ tasks, const SgrWave *__restrict__ waves, const int n_waves,
-                                                 const int bitdepth_max)
+                                                 const int bitdepth_max, const BandSignal sig)
 {
     __shared__ int a3[4][64], b3[4][64], a5[2][64], b5[2][64];
     __shared__ __attribute__((aligned(4))) uint8_t x_by_x[256];
@@ -259,37 +277,50 @@ __global__ __launch_bounds__(64) void sgr_kernel(const DevPlanes dst, const DevP
         }
         dv::wave_sync();
     }
+    band_done(sig, (int) wv.pad);
 }
 
 } // namespace
 
 // max_w: width of the widest unit of the batch (<= 384): the grid covers that many columns, not 384 for everybody
-extern "C" int dav1d_hip_launch_wiener(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
-                                       const Dav1dHipLrTask *tasks, int n, int max_w, void *stream)
+extern "C" int dav1d_hip_launch_wiener_sig(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
+                                           const Dav1dHipLrTask *tasks, int n, int max_w, const BandSignal *sig, void *stream)
 {
     if (n <= 0) return 0;
     const int bitdepth_max = (1 << bpc) - 1;
+    const BandSignal sg = sig ? *sig : BandSignal{ nullptr, nullptr, nullptr, 0 };
     const dim3 grid(((max_w < 1 ? 1 : max_w > 384 ? 384 : max_w) + 63) / 64, n, (64 + LR_SEG - 1) / LR_SEG);   // 64 columns x 64 rows per wave
     if (bpc == 8)
-        hipLaunchKernelGGL((wiener_kernel<uint8_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks, n, bitdepth_max);
+        hipLaunchKernelGGL((wiener_kernel<uint8_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks, n, bitdepth_max, sg);
     else
-        hipLaunchKernelGGL((wiener_kernel<uint16_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks, n, bitdepth_max);
+        hipLaunchKernelGGL((wiener_kernel<uint16_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks, n, bitdepth_max, sg);
     return hip_rc(hipGetLastError());
+}
+extern "C" int dav1d_hip_launch_wiener(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
+                                       const Dav1dHipLrTask *tasks, int n, int max_w, void *stream)
+{
+    return dav1d_hip_launch_wiener_sig(dst, src, lpf, bpc, tasks, n, max_w, nullptr, stream);
 }
 
 // tasks: DEVICE, the self-guided tasks sorted into rows (dav1d_hip_sgr_make_rows); waves: DEVICE wave descriptors
-extern "C" int dav1d_hip_launch_sgr(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
-                                    const Dav1dHipLrTask *tasks, const void *waves, int n_waves, void *stream)
+extern "C" int dav1d_hip_launch_sgr_sig(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
+                                        const Dav1dHipLrTask *tasks, const void *waves, int n_waves, const BandSignal *sig, void *stream)
 {
     if (n_waves <= 0) return 0;
     const int bitdepth_max = (1 << bpc) - 1;
+    const BandSignal sg = sig ? *sig : BandSignal{ nullptr, nullptr, nullptr, 0 };
     if (bpc == 8)
         hipLaunchKernelGGL((sgr_kernel<uint8_t>), dim3(n_waves), dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks,
-                           (const SgrWave *) waves, n_waves, bitdepth_max);
+                           (const SgrWave *) waves, n_waves, bitdepth_max, sg);
     else
         hipLaunchKernelGGL((sgr_kernel<uint16_t>), dim3(n_waves), dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks,
-                           (const SgrWave *) waves, n_waves, bitdepth_max);
+                           (const SgrWave *) waves, n_waves, bitdepth_max, sg);
     return hip_rc(hipGetLastError());
+}
+extern "C" int dav1d_hip_launch_sgr(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
+                                    const Dav1dHipLrTask *tasks, const void *waves, int n_waves, void *stream)
+{
+    return dav1d_hip_launch_sgr_sig(dst, src, lpf, bpc, tasks, waves, n_waves, nullptr, stream);
 }
 
 // Self-guided tasks -> rows (same plane, y, height; sorted by x, in place) and the waves that cover them, appended to `waves` as

@@ -692,9 +692,10 @@ DAV1D_HIP_API int dav1d_hip_frame_wait(Dav1dHipFrame *f, Dav1dHipPicture *filter
  * dav1d_hip_frame_end reports as *filtered) — and once more with the picture height when the frame is through.  Rows arrive in
  * steps of a band when the in-loop filters run banded (option post_bands >= 3: bands of whole 256-row superblock-row pairs, each
  * followed through deblocking, CDEF and restoration; the band's event is waited for before the call).  On the default schedule (one
- * stage after the other over the whole frame) a listener makes the LAST stage — loop restoration — run as one launch pair per band of
- * 256 luma rows, an event behind each: rows arrive in steps of 256 (17 publications for a 4320-row frame) while the later bands are
- * still being restored, at 1 - 3 % of the frame's time; a frame without restoration tasks publishes once.
+ * stage after the other over the whole frame) a listener makes the LAST stage — loop restoration — report from inside its launches:
+ * its tasks are ordered by band of 256 luma rows, the workgroups count their band's completions and the last one of a band writes to
+ * pinned host memory the ending thread polls; rows arrive in steps of 256 (17 publications for a 4320-row frame) while the later bands
+ * are still being restored, at no measurable cost to the frame.  A frame without restoration tasks publishes once.
  * Set before dav1d_hip_frame_end / _end_async.  The callback runs with the frame's and the context's locks held: it may copy the
  * rows out (dav1d_hip_host_picture_fetch, dav1d_hip_download) and signal other threads, but it must not call any
  * dav1d_hip_frame_* entry point of this frame (submit, flush, wait, destroy) nor start a list run / frame end on the same
