@@ -681,6 +681,7 @@ def main():
                 got = [dsts[i % NDST].download(pl) for pl in range(3)]
             # intra pass (1/9 of the regions re-coded as intra, wavefront batches) on the reconstructed picture
             rec = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+            rec0 = [np.array(g, copy=True) for g in got]
             for pl in range(3):
                 rec.upload(pl, got[pl])
             rec2 = ctx.picture(w, h, api.LAYOUT_I420, bpc)
@@ -693,7 +694,17 @@ def main():
             got = [rec.download(pl) for pl in range(3)]
             if not all(np.array_equal(got[pl], rec2.download(pl)) for pl in range(3)):
                 raise SystemExit("bench: graph replay of the intra pass differs from the enqueued launches")
-            ms_intra = min(ms_intra_plain, ms_intra_graph)
+            # ... and superblock by superblock (dav1d_hip_intra_sb_*: a workgroup per superblock, a launch per level): what a frame of
+            # the driver-level API runs by default
+            for pl in range(3):
+                rec2.upload(pl, rec0[pl])
+            test_postchain.hip_intra(ctx, intra, rec2, timed=True, sb=True)       # warm-up (first use of the kernel)
+            for pl in range(3):
+                rec2.upload(pl, rec0[pl])
+            ms_intra_sb = test_postchain.hip_intra(ctx, intra, rec2, timed=True, sb=True)
+            if not all(np.array_equal(got[pl], rec2.download(pl)) for pl in range(3)):
+                raise SystemExit("bench: the superblock route of the intra pass differs from the launches per step")
+            ms_intra = min(ms_intra_plain, ms_intra_graph, ms_intra_sb)
             rec.free()
             rec2.free()
             intra_ok = None
@@ -797,7 +808,9 @@ def main():
                     # the stages' device times of ONE frame
                     "wall_ms_per_frame_by_frames_in_flight": in_flight,
                     "intra_launch_modes_ms": {"enqueued": round(ms_intra_plain, 4), "graph_replay": round(ms_intra_graph, 4),
-                                              "graph_nodes": int(test_postchain.hip_intra.last_nodes), "wavefront_steps": len(intra.batches)},
+                                              "graph_nodes": int(test_postchain.hip_intra.last_nodes), "wavefront_steps": len(intra.batches),
+                                              "superblocks": round(ms_intra_sb, 4), "superblock_levels": int(test_postchain.hip_intra.sb_levels),
+                                              "superblocks_with_intra_units": int(test_postchain.hip_intra.sb_superblocks)},
                     "tasks": {"ipred": intra.n_blocks, "lf": int(len(post.lf)), "cdef": int(len(post.cdef)), "lr": int(len(post.lr))},
                     "algorithmic_bytes_per_frame": int(full_bytes),
                     "achieved": round(full_bytes / (full_ms * 1e-3) / 1e9, 1), "frac": round(full_bytes / (full_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

@@ -335,6 +335,9 @@ class Context:
     def intra_flow(self, batches):
         return _IntraFlow(self, batches)
 
+    def intra_sb(self, batches, geometry, sb128=False, col_start_sb=None, row_start_sb=None):
+        return _IntraSb(self, batches, geometry, sb128, col_start_sb, row_start_sb)
+
     # ---- device-resident lists
     def itx_list(self, tasks):
         return _List(self, "itx", tasks, ITX_TASK)
@@ -447,6 +450,39 @@ class _IntraFlow:
     def destroy(self):
         if self.h:
             self.ctx.lib.dav1d_hip_intra_flow_destroy(self.ctx.h, self.h)
+            self.h = C.c_void_p()
+
+
+class _IntraSb:
+    """dav1d_hip_intra_sb_*: the wavefront superblock by superblock (a workgroup per superblock, a launch per level).
+    col_start_sb / row_start_sb: the tile starts in superblocks, last entry = the end (None: one tile)."""
+
+    def __init__(self, ctx, batches, geometry, sb128=False, col_start_sb=None, row_start_sb=None):
+        self.ctx = ctx
+        ps = (C.c_size_t * max(len(batches), 1))(*[len(b[0]) for b in batches])
+        ts = (C.c_size_t * max(len(batches), 1))(*[len(b[1]) for b in batches])
+        allp = np.ascontiguousarray(np.concatenate([b[0] for b in batches]) if batches else np.zeros(0, IPRED_TASK), dtype=IPRED_TASK)
+        allt = np.ascontiguousarray(np.concatenate([b[1] for b in batches]) if batches else np.zeros(0, ITX_TASK), dtype=ITX_TASK)
+        sb = 128 if sb128 else 64
+        w, h = int(geometry.pic.p[0].w), int(geometry.pic.p[0].h)
+        cols = list(col_start_sb) if col_start_sb is not None else [0, (w + sb - 1) // sb]
+        rows = list(row_start_sb) if row_start_sb is not None else [0, (h + sb - 1) // sb]
+        ca = (C.c_uint16 * len(cols))(*cols)
+        ra = (C.c_uint16 * len(rows))(*rows)
+        self.h = C.c_void_p()
+        _chk(ctx.lib.dav1d_hip_intra_sb_create(ctx.h, C.byref(self.h), allp.ctypes.data, ps, allt.ctypes.data, ts, len(batches),
+                                               C.byref(geometry.pic), int(bool(sb128)), len(cols) - 1, ca, len(rows) - 1, ra),
+             "intra_sb_create")
+        self.n_levels = int(ctx.lib.dav1d_hip_intra_sb_levels(self.h))
+        self.n_superblocks = int(ctx.lib.dav1d_hip_intra_sb_superblocks(self.h))
+
+    def run(self, dst, coef, aux=None):
+        _chk(self.ctx.lib.dav1d_hip_intra_sb_run(self.ctx.h, self.h, C.byref(dst.pic), coef.ptr if hasattr(coef, "ptr") else coef,
+                                                 aux.ptr if aux else None), "intra_sb_run")
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.dav1d_hip_intra_sb_destroy(self.ctx.h, self.h)
             self.h = C.c_void_p()
 
 

@@ -23,6 +23,10 @@ struct Dav1dHipContext {
     int flow_min_steps;         // wavefronts of at least this many steps run as one dataflow launch ($DAV1D_HIP_FLOW_MIN_STEPS, 0 = never)
     int flow_mode;              // $DAV1D_HIP_FLOW_MODE at open: hand-off variant of the intra dataflow launch (intra_flow.hip)
     int flow_groups;            // workgroups of the intra dataflow launch ($DAV1D_HIP_FLOW_GROUPS at open, default 512; every wave has to be resident: units are dealt out round-robin)
+    int intra_sb;               // the intra wavefront superblock by superblock (intra_sb.hip; $DAV1D_HIP_INTRA_SB / option intra_sb): 0 never,
+                                // 1 for wavefronts of at least flow_min_steps steps, 2 (default) for every frame whose tiling is known
+    int intra_sb_lds;           // 1 (default): the superblock's pixels stay in LDS where that form exists ($DAV1D_HIP_INTRA_SB_LDS / option intra_sb_lds)
+    int intra_sb_waves;         // waves per workgroup of that route, 4 or 8 ($DAV1D_HIP_INTRA_SB_WAVES / option intra_sb_waves)
     int recon_fuse;             // bit mask of the square block sizes that run paired (DAV1D_HIP_RECON_FUSE)
     long recon_pipeline;        // smallest residual list a recon list pipelines on two streams (DAV1D_HIP_RECON_PIPELINE)
     int recon_lanes;            // side streams of the residual launches (DAV1D_HIP_RECON_LANES)
@@ -50,6 +54,7 @@ struct Dav1dHipContext {
     uint32_t band_seq = 0;
     int chunk_order;                           // option chunk_order: the prepared lists of a tile-sbrow ordered for the device (1) or left in decode order (0)
     size_t arena_min;                          // size of a frame's chunk arena before anything is known (option chunk_arena_min; tests make it tiny)
+    size_t uarena_hint = 0;                    // bytes of intra units the largest frame so far carried (sizes a frame's pinned unit arena)
     size_t carena_hint;                        // bytes of packed coefficients the largest frame so far carried (sizes the pinned twin)
     uint8_t *gather_dev, *segtab_dev;
     size_t gather_cap, segtab_cap;
@@ -264,6 +269,25 @@ extern "C" int dav1d_hip_intra_flow_run(Dav1dHipContext *c, const Dav1dHipIntraF
 extern "C" void dav1d_hip_intra_flow_destroy(Dav1dHipContext *c, Dav1dHipIntraFlow *l);
 extern "C" size_t dav1d_hip_intra_flow_units(const Dav1dHipIntraFlow *l);
 extern "C" int dav1d_hip_intra_flow_status(Dav1dHipContext *c, const Dav1dHipIntraFlow *l, uint32_t out[3]);
+
+// ---- the intra wavefront superblock by superblock (intra_sb.hip): one workgroup per superblock, a launch per level
+struct SbRegion { uint32_t first, n; uint16_t x0, y0; uint32_t pad; };   // device: the superblock's units, units[first .. first + n), and its luma origin
+struct SbPart { uint32_t sb, first, n; };          // host: superblock number (raster, frame-wide) and its run in a sorted unit array
+struct SbTiling {                                   // the frame's tiles in superblocks (frame_hdr->tiling.col_start_sb / row_start_sb)
+    int sb_log2, sbw, sbh, n_cols, n_rows;
+    uint16_t col_start[65], row_start[65];
+};
+int dav1d_hip_sb_tiling_make(SbTiling *tl, int w, int h, int sb128, int n_cols, const uint16_t *col_start_sb, int n_rows, const uint16_t *row_start_sb);
+int dav1d_hip_sbw_sort(std::vector<IntraUnit> &units, const std::vector<uint32_t> &ua_end, const std::vector<uint32_t> &ub_end,
+                            const SbTiling &tl, const int strides[3], int ss_hor, int ss_ver, std::vector<SbPart> &parts, IntraUnit *out);
+int dav1d_hip_sbw_levels(const SbTiling &tl, const uint32_t *sbs, size_t n, const uint8_t *dep, std::vector<int> &level_of_sb, std::vector<uint32_t> &level);
+extern "C" int dav1d_hip_launch_intra_sb(const DevPlanes *dst, int bpc, int layout, const IntraUnit *units, const SbRegion *regions, int n_regions,
+                                         uint8_t *aux, void *coef, int waves, int sb_log2, int lds, void *stream);
+// regions sorted by level + where each level starts, from the parts of any number of unit arrays laid end to end (base[k] = where
+// array k starts): host-side plan of a frame's launches
+struct SbPlan { std::vector<SbRegion> regions; std::vector<uint32_t> level_start; /* n_levels + 1 */ };
+int dav1d_hip_sbw_plan(const SbTiling &tl, const std::vector<const std::vector<SbPart> *> &parts, const std::vector<size_t> &base, const uint8_t *dep,
+                       SbPlan &plan);
 
 // raw_only: tasks without the RAW flag are left alone (they are run by groups, below)
 extern "C" int dav1d_hip_launch_cdef(const DevPlanes *dst, const DevPlanes *src, int bpc, int layout,

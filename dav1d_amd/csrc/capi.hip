@@ -60,6 +60,10 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     c->flow_mode = fm ? atoi(fm) : 0;
     const char *fs = getenv("DAV1D_HIP_FLOW_MIN_STEPS");
     c->flow_min_steps = fs ? atoi(fs) : 200;
+    const char *isb = getenv("DAV1D_HIP_INTRA_SB");
+    c->intra_sb = isb ? atoi(isb) : 2;
+    c->intra_sb_waves = (int) env_int("DAV1D_HIP_INTRA_SB_WAVES", 8);
+    c->intra_sb_lds = (int) env_int("DAV1D_HIP_INTRA_SB_LDS", 1);
     for (int i = 0; i < Dav1dHipContext::N_SIDE; i++) {
         if (hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
@@ -170,6 +174,9 @@ int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value) {
     else if (!strcmp(name, "flow_groups")) c->flow_groups = value > 0 ? (int) value : c->flow_groups;
     else if (!strcmp(name, "flow_mode")) c->flow_mode = (int) value;
     else if (!strcmp(name, "flow_min_steps")) c->flow_min_steps = (int) value;
+    else if (!strcmp(name, "intra_sb")) c->intra_sb = (int) value;
+    else if (!strcmp(name, "intra_sb_waves")) c->intra_sb_waves = value >= 8 ? 8 : 4;
+    else if (!strcmp(name, "intra_sb_lds")) c->intra_sb_lds = value != 0;
     else if (!strcmp(name, "chunk_order")) c->chunk_order = value != 0;
     else if (!strcmp(name, "chunk_arena_min")) { if (value < 4096) return -EINVAL; c->arena_min = (size_t) 1 << 12; while (c->arena_min < (size_t) value) c->arena_min <<= 1; c->arena_hint = 0; }
     else return -EINVAL;
@@ -2238,6 +2245,84 @@ int dav1d_hip_intra_flow_run(Dav1dHipContext *c, const Dav1dHipIntraFlow *l, con
     // 8 one-wave workgroups per CU: more waves only poll
     return dav1d_hip_launch_intra_flow(&dp, dst->bpc, dst->layout, l->units, (int) l->n_units, aux, coef, l->ctr, c->flow_groups, c->flow_mode,
                                        c->stream);
+}
+
+// ------------------------------------------------------------------ intra wavefront superblock by superblock (intra_sb.hip)
+struct Dav1dHipIntraSb {
+    IntraUnit *units;
+    SbRegion *regions;
+    std::vector<uint32_t> level_start;
+    size_t n_units, n_regions;
+    int sb_log2;
+    bool needs_aux;
+};
+
+void dav1d_hip_intra_sb_destroy(Dav1dHipContext *c, Dav1dHipIntraSb *l) {
+    if (!l) return;
+    hipStreamSynchronize(c->stream);
+    if (l->units) hipFree(l->units);
+    if (l->regions) hipFree(l->regions);
+    delete l;
+}
+size_t dav1d_hip_intra_sb_levels(const Dav1dHipIntraSb *l) { return l && !l->level_start.empty() ? l->level_start.size() - 1 : 0; }
+size_t dav1d_hip_intra_sb_superblocks(const Dav1dHipIntraSb *l) { return l ? l->n_regions : 0; }
+
+int dav1d_hip_intra_sb_create(Dav1dHipContext *c, Dav1dHipIntraSb **out, const Dav1dHipIpredTask *preds, const size_t *pred_sizes,
+                              const Dav1dHipItxTask *txs, const size_t *tx_sizes, size_t n_batches, const Dav1dHipPicture *geometry,
+                              int sb128, int n_tile_cols, const uint16_t *col_start_sb, int n_tile_rows, const uint16_t *row_start_sb) {
+    if (!c || !out || !pred_sizes || !tx_sizes || !geometry) return -EINVAL;
+    *out = nullptr;
+    SbTiling tl;
+    int rc = dav1d_hip_sb_tiling_make(&tl, geometry->p[0].w, geometry->p[0].h, sb128, n_tile_cols, col_start_sb, n_tile_rows, row_start_sb);
+    if (rc) return rc;
+    std::vector<uint32_t> pe(n_batches), te(n_batches), ua, ub;
+    size_t np = 0, nt = 0;
+    for (size_t k = 0; k < n_batches; k++) {
+        np += pred_sizes[k]; nt += tx_sizes[k];
+        if (np >= 0xffffffffu || nt >= 0xffffffffu) return -ENOTSUP;
+        pe[k] = (uint32_t) np; te[k] = (uint32_t) nt;
+    }
+    if ((np && !preds) || (nt && !txs)) return -EINVAL;
+    std::vector<IntraUnit> units;
+    rc = dav1d_hip_intra_units_build(preds, pe.data(), txs, te.data(), n_batches, units, ua, ub);
+    if (rc) return rc;
+    const DevPlanes dp = dev_planes(geometry);
+    std::vector<SbPart> parts;
+    std::vector<IntraUnit> sorted(units.size());
+    rc = dav1d_hip_sbw_sort(units, ua, ub, tl, dp.stride, geometry->layout != DAV1D_HIP_LAYOUT_I444, geometry->layout == DAV1D_HIP_LAYOUT_I420, parts, sorted.data());
+    if (rc) return rc;
+    units.swap(sorted);
+    SbPlan plan;
+    rc = dav1d_hip_sbw_plan(tl, { &parts }, { 0 }, nullptr, plan);
+    if (rc) return rc;
+    Dav1dHipIntraSb *l = new (std::nothrow) Dav1dHipIntraSb();
+    if (!l) return -ENOMEM;
+    l->units = nullptr; l->regions = nullptr;
+    l->n_units = units.size(); l->n_regions = plan.regions.size();
+    l->level_start = plan.level_start;
+    l->sb_log2 = tl.sb_log2;
+    l->needs_aux = false;
+    for (const IntraUnit &u : units) if ((u.has & 1) && u.p.kind == DAV1D_HIP_IPRED_PAL) { l->needs_aux = true; break; }
+    if (l->n_units) {
+        if (hipMalloc((void **) &l->units, (l->n_units + 1) * sizeof(IntraUnit)) != hipSuccess) rc = -ENOMEM;
+        if (!rc && hipMalloc((void **) &l->regions, l->n_regions * sizeof(SbRegion)) != hipSuccess) rc = -ENOMEM;
+        if (!rc) rc = dav1d_hip_upload(c, l->units, units.data(), l->n_units * sizeof(IntraUnit));
+        if (!rc) rc = dav1d_hip_upload(c, l->regions, plan.regions.data(), l->n_regions * sizeof(SbRegion));
+    }
+    if (rc) { dav1d_hip_intra_sb_destroy(c, l); return rc; }
+    *out = l;
+    return 0;
+}
+
+// enqueues one launch per level on the context's stream
+int dav1d_hip_intra_sb_run(Dav1dHipContext *c, const Dav1dHipIntraSb *l, const Dav1dHipPicture *dst, void *coef, uint8_t *aux) {
+    if (!c || !l || !dst || (l->needs_aux && !aux)) return -EINVAL;
+    const DevPlanes dp = dev_planes(dst);
+    int rc = 0;
+    for (size_t k = 0; k + 1 < l->level_start.size() && !rc; k++)
+        rc = dav1d_hip_launch_intra_sb(&dp, dst->bpc, dst->layout, l->units, l->regions + l->level_start[k],
+                                       (int) (l->level_start[k + 1] - l->level_start[k]), aux, coef, c->intra_sb_waves, l->sb_log2, c->intra_sb_lds, c->stream);
+    return rc;
 }
 
 int dav1d_hip_intra_list_run_batch(Dav1dHipContext *c, const Dav1dHipIntraList *l, size_t batch, const Dav1dHipPicture *dst, void *coef,

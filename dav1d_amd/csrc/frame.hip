@@ -56,7 +56,21 @@ struct Dav1dHipFrame {
         std::vector<IntraUnit> units;               // per step: the units with a prediction, then the residuals on their own
         std::vector<uint32_t> ua_end, ub_end;       // [step] -> end of the step's first / second kind in units
         bool flow_ok;                               // every task is of a kind the dataflow launch runs
+        std::vector<SbPart> parts;                  // sb_sorted: units are sorted by (superblock, step, kind), one part per superblock
+        bool sb_sorted;
+        IntraUnit *sorted;                          // ... and sit here: in the frame's pinned unit arena (in_arena) or in `units`
+        size_t n_sorted;
+        bool in_arena, has_pal;
     };
+    // The sorted units of the superblock route go straight into pinned memory, drawn chunk by chunk by the submitting threads (sized
+    // by what frames have needed so far; a chunk that does not fit keeps its units and is copied at frame end): the upload is one
+    // transfer from there.
+    uint8_t *huarena = nullptr;
+    size_t huarena_cap = 0;
+    std::atomic<size_t> uarena_used { 0 };
+    SbTiling tiling;                                // dav1d_hip_frame_set_tiling: what the superblock wavefront (intra_sb.hip) needs
+    bool have_tiling;
+    std::vector<uint8_t> sb_dep;                    // [superblock] -> neighbours its blocks read (dav1d_hip_frame_set_sb_deps; 15 until told)
     std::vector<StepChunk *> step_chunks;
     size_t n_steps;                                 // 1 + highest step submitted
     std::vector<Dav1dHipMcTask> step_copy;                      // intra block copies: predictions from the frame's own pixels ...
@@ -334,6 +348,7 @@ int dav1d_hip_frame_begin(Dav1dHipContext *c, Dav1dHipFrame **out, const Dav1dHi
     f->cdef_damping = 0;
     f->aux = nullptr;
     f->n_steps = 0;
+    f->have_tiling = false;
     f->have_grain = false;
     f->prepared = nullptr;
     f->is_id = 0;
@@ -551,9 +566,59 @@ int dav1d_hip_frame_submit_intra_sorted(Dav1dHipFrame *f, size_t n_steps, const 
         if (rc == -ENOTSUP) { ck->flow_ok = false; ck->units.clear(); rc = 0; }
         if (rc) { delete ck; return rc; }
     }
+    ck->sb_sorted = false;
+    if (ck->flow_ok && f->have_tiling && f->c->intra_sb > 0) {
+        // the superblock wavefront takes the units superblock by superblock: sorted here, on the submitting thread
+        const DevPlanes dp = dev_planes(&f->cur);
+        const size_t n = ck->units.size(), bytes = n * sizeof(IntraUnit);
+        {
+            std::lock_guard<std::mutex> lk(f->mtx);
+            if (!f->huarena) {
+                const size_t want = std::max<size_t>(f->c->uarena_hint + (f->c->uarena_hint >> 2), std::min<size_t>(f->c->arena_min, (size_t) 1 << 20));
+                f->huarena = dav1d_hip_slab_get(f->c, want, &f->huarena_cap);
+                if (!f->huarena) f->huarena_cap = 0;
+            }
+        }
+        const size_t off = f->uarena_used.fetch_add(bytes);
+        ck->in_arena = f->huarena && off + bytes <= f->huarena_cap;
+        std::vector<IntraUnit> own;
+        if (!ck->in_arena) own.resize(n);
+        ck->sorted = ck->in_arena ? reinterpret_cast<IntraUnit *>(f->huarena + off) : own.data();
+        ck->n_sorted = n;
+        const int rc = dav1d_hip_sbw_sort(ck->units, ck->ua_end, ck->ub_end, f->tiling, dp.stride, f->cur.layout != DAV1D_HIP_LAYOUT_I444,
+                                          f->cur.layout == DAV1D_HIP_LAYOUT_I420, ck->parts, ck->sorted);
+        if (rc) { delete ck; return rc; }
+        ck->has_pal = false;
+        for (size_t i = 0; i < n && !ck->has_pal; i++) ck->has_pal = (ck->units[i].has & 1) && ck->units[i].p.kind == DAV1D_HIP_IPRED_PAL;
+        if (ck->in_arena) { std::vector<IntraUnit>().swap(ck->units); }
+        else { ck->units.swap(own); ck->sorted = ck->units.data(); }
+        ck->sb_sorted = true;
+    }
     std::lock_guard<std::mutex> lk(f->mtx);
     f->step_chunks.push_back(ck);
     if (n_steps > f->n_steps) f->n_steps = n_steps;
+    return 0;
+}
+
+// The frame's tiles in superblocks (frame_hdr->tiling, seq_hdr->sb128): with them the intra blocks of the frame run superblock by
+// superblock (intra_sb.hip) instead of step by step.  Before the first intra submission; the listers call it.
+int dav1d_hip_frame_set_tiling(Dav1dHipFrame *f, int sb128, int n_tile_cols, const uint16_t *col_start_sb, int n_tile_rows, const uint16_t *row_start_sb) {
+    if (!f) return -EINVAL;
+    std::lock_guard<std::mutex> lk(f->mtx);
+    if (!f->step_chunks.empty()) return -EINVAL;
+    const int rc = dav1d_hip_sb_tiling_make(&f->tiling, f->cur.p[0].w, f->cur.p[0].h, sb128, n_tile_cols, col_start_sb, n_tile_rows, row_start_sb);
+    f->have_tiling = !rc;
+    if (!rc) f->sb_dep.assign((size_t) f->tiling.sbw * f->tiling.sbh, 15);
+    return rc;
+}
+
+// Which neighbouring superblocks the intra blocks of superblocks [first, first + n) (raster numbers, frame-wide) read pixels of that
+// intra blocks of THIS frame wrote: bit 0 left, 1 top-left, 2 top, 3 top-right.  Without it every neighbour that holds intra units
+// counts (correct, but an inter frame's scattered intra blocks then queue behind each other for nothing).  Callers write disjoint
+// ranges (a tile-sbrow each); no lock.
+int dav1d_hip_frame_set_sb_deps(Dav1dHipFrame *f, uint32_t first, size_t n, const uint8_t *mask) {
+    if (!f || !mask || !f->have_tiling || (size_t) first + n > f->sb_dep.size()) return -EINVAL;
+    memcpy(f->sb_dep.data() + first, mask, n);
     return 0;
 }
 
@@ -897,6 +962,8 @@ int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *ma
     f->chunks.clear();
     for (Dav1dHipFrame::StepChunk *sc : f->step_chunks) delete sc;
     f->step_chunks.clear();
+    if (f->huarena) { dav1d_hip_slab_put(c, f->huarena, f->huarena_cap); f->huarena = nullptr; f->huarena_cap = 0; }
+    f->uarena_used = 0;
     f->n_steps = 0;
     f->arena_used = 0;
     f->harena_flushed = 0;
@@ -971,7 +1038,76 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
         bool flow = c->flow_min_steps > 0 && ns >= (size_t) c->flow_min_steps;
         for (const Dav1dHipFrame::StepChunk *ck : f->step_chunks) flow = flow && ck->flow_ok;
         flow = flow && f->step_copy.empty();          // intra block copies are launches of their own between the steps
-        if (flow) {
+        // superblock by superblock (intra_sb.hip) when every submission was sorted for it (the frame's tiling is known, no inter-intra
+        // blends, no intra block copies): option intra_sb = 2 for every frame, 1 for the long wavefronts only
+        bool sbw = f->have_tiling && f->step_copy.empty() && !f->step_chunks.empty() && (c->intra_sb >= 2 || (c->intra_sb == 1 && flow));
+        bool any_sorted = false;
+        for (const Dav1dHipFrame::StepChunk *ck : f->step_chunks) { sbw = sbw && ck->flow_ok && ck->sb_sorted; any_sorted = any_sorted || ck->sb_sorted; }
+        if (any_sorted) flow = false;                  // the dataflow launch wants the units in step order
+        if (sbw) {
+            // the chunks' units: those in the pinned arena form its prefix [0, in_arena) in the order they were drawn; the others (the
+            // arena is sized by what earlier frames needed) follow, copied into a slab that then holds everything
+            const size_t nck = f->step_chunks.size();
+            std::vector<const std::vector<SbPart> *> parts(nck);
+            std::vector<size_t> base(nck);
+            size_t in_arena = 0, late = 0;
+            bool needs_aux = false;
+            for (size_t k = 0; k < nck; k++) {
+                const Dav1dHipFrame::StepChunk *ck = f->step_chunks[k];
+                parts[k] = &ck->parts;
+                needs_aux = needs_aux || ck->has_pal;
+                if (ck->in_arena) { base[k] = (size_t) (ck->sorted - reinterpret_cast<IntraUnit *>(f->huarena)); in_arena = std::max(in_arena, base[k] + ck->n_sorted); }
+                else late += ck->n_sorted;
+            }
+            const size_t total = in_arena + late;
+            c->uarena_hint = std::max(c->uarena_hint, total * sizeof(IntraUnit));
+            size_t slab_cap = 0;
+            uint8_t *slab = nullptr;
+            const uint8_t *host = f->huarena;
+            if (late) {
+                slab = dav1d_hip_slab_get(c, total * sizeof(IntraUnit), &slab_cap);
+                if (!slab) rc = -ENOMEM;
+                else {
+                    if (in_arena) memcpy(slab, f->huarena, in_arena * sizeof(IntraUnit));
+                    size_t at = in_arena;
+                    for (size_t k = 0; k < nck; k++) {
+                        const Dav1dHipFrame::StepChunk *ck = f->step_chunks[k];
+                        if (ck->in_arena) continue;
+                        memcpy(slab + at * sizeof(IntraUnit), ck->sorted, ck->n_sorted * sizeof(IntraUnit));
+                        base[k] = at; at += ck->n_sorted;
+                    }
+                    host = slab;
+                }
+            }
+            SbPlan plan;
+            if (!rc) rc = dav1d_hip_sbw_plan(f->tiling, parts, base, f->sb_dep.empty() ? nullptr : f->sb_dep.data(), plan);
+            if (!rc && needs_aux && !f->aux) rc = -EINVAL;
+            const size_t ub = total * sizeof(IntraUnit), rb = plan.regions.size() * sizeof(SbRegion);
+            if (!rc && total) {
+                TaskBuf dev_buf(c, ub + rb + 256);
+                uint8_t *const dev = dev_buf.p;
+                if (!dev) rc = -ENOMEM;
+                if (!rc) rc = hip_rc(hipMemcpyAsync(dev, host, ub, hipMemcpyHostToDevice, c->stream));
+                if (!rc) rc = dav1d_hip_upload(c, dev + ub, plan.regions.data(), rb);
+                const auto t_b = std::chrono::steady_clock::now();
+                const DevPlanes dp = dev_planes(&f->cur);
+                for (size_t l = 0; l + 1 < plan.level_start.size() && !rc; l++)
+                    rc = dav1d_hip_launch_intra_sb(&dp, f->cur.bpc, f->cur.layout, reinterpret_cast<const IntraUnit *>(dev),
+                                                   reinterpret_cast<const SbRegion *>(dev + ub) + plan.level_start[l],
+                                                   (int) (plan.level_start[l + 1] - plan.level_start[l]), f->aux, coef, c->intra_sb_waves, f->tiling.sb_log2,
+                                                   c->intra_sb_lds, c->stream);
+                // the device copy of the units goes back to the pool when this scope ends: the launches have to be through by then
+                const int rs = hip_rc(hipStreamSynchronize(c->stream));
+                if (!rc) rc = rs;
+                if (trace) {
+                    const auto t_d = std::chrono::steady_clock::now();
+                    fprintf(stderr, "intra sb: %zu steps, %zu units (%zu late) in %zu superblocks, %zu levels; plan + upload %.2f ms, launches to finish %.2f ms\n", ns,
+                            total, late, plan.regions.size(), plan.level_start.size() - 1, std::chrono::duration<double, std::milli>(t_b - t_a).count(),
+                            std::chrono::duration<double, std::milli>(t_d - t_b).count());
+                }
+            }
+            if (slab) dav1d_hip_slab_put(c, slab, slab_cap);
+        } else if (flow) {
             // A long wavefront (a key frame: hundreds to thousands of steps, most of them narrow) goes down as ONE launch whose
             // waves hand the steps to each other (intra_flow.hip).  The chunks' units, merged step by step: first the units with
             // a prediction of every chunk, then the residuals on their own; `need` = where the group starts.
@@ -1256,6 +1392,7 @@ void dav1d_hip_frame_destroy(Dav1dHipFrame *f) {
     for (Dav1dHipFrame::StepChunk *sc : f->step_chunks) delete sc;
     for (Dav1dHipFrame::FilterPiece &p : f->filter_pieces) { free(p.lf); free(p.cdef); free(p.lr); delete p.groups; }
     if (f->harena) dav1d_hip_slab_put(f->c, f->harena, f->harena_cap);
+    if (f->huarena) dav1d_hip_slab_put(f->c, f->huarena, f->huarena_cap);
     if (f->hcarena) dav1d_hip_slab_put(f->c, f->hcarena, f->hcarena_cap);
     for (Dav1dHipFrame::LateCoefs &lc : f->late_coefs) free(lc.copy);
     if (f->arena || f->carena) {

@@ -1,0 +1,421 @@
+// The intra wavefront superblock by superblock (gfx950).
+//
+// What the reference does with an intra block — prepare_intra_edges + intra_pred, then itxfm_add on the same pixels, transform
+// block after transform block in decode order (src/recon_tmpl.c:1207-1360) — has two scales of dependency.  INSIDE a superblock
+// a transform block reads what its neighbours of the same superblock wrote a moment ago (a 64x64 superblock of 4x4 blocks is a
+// chain of 46 such steps); BETWEEN superblocks only the left, top-left, top and top-right neighbours of the same tile are ever
+// read (the reference decodes a tile's superblocks in raster order and edge availability stops at the tile,
+// src/decode.c:2117-2375, src/ipred_prepare_tmpl.c:82-116).  The step-granular routes (a launch per step, intra_pair.hip; one
+// launch with a counter hand-off per step, intra_flow.hip) pay a device-wide hand-off — a kernel boundary, or a coherent trip
+// to memory and back — for every one of the several hundred steps of a key frame's tiles.
+//
+// Here ONE WORKGROUP owns a superblock: its waves work the superblock's units (prediction + residual of one transform block)
+// off step by step with a workgroup barrier in between, the pixels handed over through the XCD's L2 (plain stores,
+// acknowledged, then loads that bypass the CU's L1).  Superblocks are sorted into LEVELS — level(sb) = 1 + the highest level
+// among its four neighbours that hold intra units — and a level is a launch: 8 + 2 x 10 levels for a tile of 8 x 10
+// superblocks instead of several hundred steps, all tiles side by side.  An inter frame's scattered intra superblocks are one
+// or two levels.
+#include "ipred_body.h"
+#include "itx_body.h"
+#include "capi.h"
+#include <type_traits>
+#include <algorithm>
+#include <string.h>
+
+namespace {
+
+constexpr int sb_itx_lds_of(int tx) {
+    return (64 / cmax(cmin(tx_h(tx), 32), tx_w(tx))) * cmin(tx_h(tx), 32) * (tx_w(tx) + 1);
+}
+constexpr int sb_itx_lds_max(int tx = 0) { return tx == 19 ? 0 : cmax(sb_itx_lds_of(tx), sb_itx_lds_max(tx + 1)); }
+
+
+// units[r.first .. r.first + r.n): the superblock's units sorted by (step, predictions first); every unit carries the size of
+// its group (prev_n), the first unit of a group is the one that is read.
+template <typename pixel, typename coef, int SB_WAVES>
+__global__ __launch_bounds__(SB_WAVES * 64, 2) void intra_sb_kernel(const DevPlanes dst, const IntraUnit *__restrict__ units,
+                                                                     const SbRegion *__restrict__ regions, uint8_t *aux,
+                                                                     coef *__restrict__ cf, const int layout, const int bitdepth_max)
+{
+    __shared__ int16_t e1_s[SB_WAVES][ESZ], e2_s[SB_WAVES][ESZ];
+    __shared__ int16_t blk_s[SB_WAVES][32 * 32];
+    // the predicted tile and the transform's slabs share their LDS (itx_body.h, PRED_LDS)
+    constexpr int TILE_B = 64 * 64 * (int) sizeof(pixel), ITX_B = sb_itx_lds_max() * 4;
+    constexpr int SMEM_V = (cmax(TILE_B, ITX_B) + 15) / 16;
+    __shared__ uint4 smem_s[SB_WAVES][SMEM_V];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
+    int16_t *const e1 = e1_s[wv], *const e2 = e2_s[wv], *const blk = blk_s[wv];
+    pixel *const tile = reinterpret_cast<pixel *>(smem_s[wv]);
+    int *const smem_itx = reinterpret_cast<int *>(smem_s[wv]);
+
+    const SbRegion r = regions[blockIdx.x];
+    const IntraUnit *const ru = units + r.first;
+    uint32_t g0 = 0;
+    uint32_t gn = r.n ? ru[0].prev_n : 0;           // the same word for every wave: the barriers below are met by all of them
+    while (g0 < r.n) {
+        // the size of the group after this one sets off now (volatile: issued here, claimed at the end)
+        const uint32_t nx = g0 + gn < r.n ? g0 + gn : g0;
+        const uint32_t gn_next = *reinterpret_cast<const volatile uint32_t *>(&ru[nx].prev_n);
+        for (uint32_t k = wv; k < gn; k += SB_WAVES) {
+            const IntraUnit *const up = ru + g0 + k;
+            const IntraUnit u = *up;
+            // the wave's next record (same group or the next) and the first lines of this unit's coefficients set off now; the values
+            // are claimed after the prediction
+            const uint32_t nk = k + SB_WAVES < gn ? g0 + k + SB_WAVES : (g0 + gn + wv < r.n ? g0 + gn + wv : g0 + k);
+            const int keep0 = dv::fetch_begin(ru + nk);
+            const bool has_pred = u.has & 1, has_tx = u.has & 2;
+            const int nb = has_tx ? ((int) u.t.rsv[0] | (int) u.t.rsv[1] << 8) * (int) sizeof(coef) : 0;
+            const int keep1 = dv::fetch_begin(has_tx ? reinterpret_cast<const char *>(cf + u.t.cf_off) + (lane * 64 < nb ? lane * 64 : 0)
+                                                     : reinterpret_cast<const char *>(up));
+            const int plane = has_pred ? u.p.plane : u.t.plane;
+            const uint32_t dst_off = has_pred ? u.p.dst_off : u.t.dst_off;
+            const int w = has_pred ? u.p.tw * 4 : tx_w(u.t.tx), h = has_pred ? u.p.th * 4 : tx_h(u.t.tx);
+            pixel *const d = reinterpret_cast<pixel *>(dst.data[plane]) + dst_off;
+            const int stride = dst.stride[plane];
+            if (has_pred) {
+                ipred_body<pixel, true>(dst, u.p, 0, false, aux, layout, bitdepth_max, e1, e2, blk, tile, w);
+            } else {
+                // a residual on its own (the blocks of a palette block, ...): the pixels it is added to come from the picture
+                for (int i = lane; i < w * h; i += 64) tile[i] = dv::ld_coherent(d + (i / w) * stride + (i % w));
+            }
+            dv::fetch_end(keep0);
+            dv::fetch_end(keep1);
+            dv::wave_sync();
+            if (has_tx) {
+#define CASE(T) case T: itx_body<T, pixel, coef, true, true>(dst, &up->t, 1, cf, bitdepth_max, 0, smem_itx, tile); break;
+                switch (u.t.tx) {
+                    CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9)
+                    CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18)
+                }
+#undef CASE
+            }
+            dv::wave_sync();
+            // the reconstructed tile leaves the LDS four pixels per store (blocks are at least four pixels wide and four-pixel
+            // aligned); plain stores: the line stays in this XCD's L2, where the next group of the workgroup reads it
+            {
+                typedef typename std::conditional<sizeof(pixel) == 2, uint64_t, uint32_t>::type quad;
+                const int wq = w >> 2;
+                for (int i = lane; i < wq * h; i += 64) {
+                    const int y = i / wq, x = (i - y * wq) * 4;
+                    *reinterpret_cast<quad *>(d + y * stride + x) = *reinterpret_cast<const quad *>(tile + y * w + x);
+                }
+            }
+            dv::wave_sync();                 // the LDS is free for the wave's next unit
+        }
+        dv::stores_done();                   // this wave's pixels have reached the L2 ...
+        __syncthreads();                     // ... and so have the other waves': the next group may read them
+        g0 += gn;
+        gn = gn_next;
+    }
+}
+
+// ---- the same with the superblock's pixels RESIDENT IN LDS (4:2:0 / 4:0:0).
+//
+// The workgroup keeps an image of its superblock per plane: the pixels as they are in the picture when the launch starts (the
+// inter blocks of the frame are there already), one column to the left, one row above that reaches a superblock's width further
+// to the right (the top-right extension of the blocks on the superblock's top row).  Element (x, y) of the superblock, x in
+// [-PAD, 2W), y in [-1, H), sits at (y + 1) * S + x + PAD with S = 2W + PAD (PAD = the pixels of a 16-byte chunk): rows start 16-byte aligned, the image is filled with
+// 16-byte loads.  The prediction body (ipred_body.h) reads the edges through ordinary pointers: it is handed a DevPlanes that
+// describes the IMAGES (generic pointers into LDS) and a task whose offsets are the block's place in the image.  A finished
+// unit goes to the image (for its neighbours) and to the picture (stores nobody waits for): a step of the superblock then
+// costs LDS round trips and a workgroup barrier instead of trips to the L2 and back.
+template <typename pixel, int SBL2>
+struct SbImage {
+    static constexpr int W = 1 << SBL2, H = 1 << SBL2, CW = W >> 1, CH = H >> 1;
+    static constexpr int PAD = 16 / (int) sizeof(pixel);                 // pixels left of the superblock: one 16-byte chunk (it holds column -1)
+    static constexpr int SY = 2 * W + PAD, SC = 2 * CW + PAD;
+    static constexpr int NY = (H + 1) * SY, NC = (CH + 1) * SC;
+};
+
+template <typename pixel, int SBL2>
+__device__ __forceinline__ void sb_image_load(pixel *img, const int S, const int W, const int H, const pixel *plane, const int stride,
+                                               const int px0, const int py0, const int rows_ok /* rows of the plane that exist */)
+{
+    constexpr int PPC = 16 / (int) sizeof(pixel);         // pixels per 16-byte chunk
+    // rows -1 .. H - 1, chunks from x = -PPC (holds column -1) to 2W (a decoder only ever reads right of the superblock in the row above
+    // it; the other rows are filled as well — pixels as they are when the launch starts): a chunk is loaded when it lies inside the
+    // plane's allocation (x in [0, stride), y in [0, rows_ok)); what is not is never read by a block whose edge flags are right
+    const int cpr = (2 * W) / PPC + 1;                     // chunks per row incl. the one left of the superblock
+    for (int i = threadIdx.x; i < (H + 1) * cpr; i += blockDim.x) {
+        const int r = i / cpr, c = i - r * cpr;
+        const int y = r - 1, x = (c - 1) * PPC;
+        const int gx = px0 + x, gy = py0 + y;
+        if (gx < 0 || gy < 0 || gx + PPC > stride || gy >= rows_ok) continue;
+        *reinterpret_cast<uint4 *>(img + (y + 1) * S + x + PPC) = *reinterpret_cast<const uint4 *>(plane + (size_t) gy * stride + gx);
+    }
+}
+
+template <typename pixel, typename coef, int SBL2, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void intra_sbl_kernel(const DevPlanes dst, const IntraUnit *__restrict__ units,
+                                                            const SbRegion *__restrict__ regions, uint8_t *aux,
+                                                            coef *__restrict__ cf, const int layout, const int bitdepth_max)
+{
+    typedef SbImage<pixel, SBL2> G;
+    __shared__ int16_t e1_s[NW][ESZ], e2_s[NW][ESZ];
+    __shared__ int16_t blk_s[NW][32 * 32];
+    constexpr int TILE_B = 64 * 64 * (int) sizeof(pixel), ITX_B = sb_itx_lds_max() * 4;
+    constexpr int SMEM_V = (cmax(TILE_B, ITX_B) + 15) / 16;
+    __shared__ uint4 smem_s[NW][SMEM_V];
+    __shared__ __attribute__((aligned(16))) pixel img_y[G::NY];
+    __shared__ __attribute__((aligned(16))) pixel img_u[G::NC], img_v[G::NC];
+    __shared__ DevPlanes img;                      // the images as the prediction body sees "the picture"
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
+    int16_t *const e1 = e1_s[wv], *const e2 = e2_s[wv], *const blk = blk_s[wv];
+    pixel *const tile = reinterpret_cast<pixel *>(smem_s[wv]);
+    int *const smem_itx = reinterpret_cast<int *>(smem_s[wv]);
+
+    const SbRegion r = regions[blockIdx.x];
+    const IntraUnit *const ru = units + r.first;
+    const bool chroma = layout != DAV1D_HIP_LAYOUT_I400;
+    const int x0 = r.x0, y0 = r.y0;
+    // rows that exist: the picture's height rounded up to whole 8x8 blocks (what the frame's blocks may write)
+    sb_image_load<pixel, SBL2>(img_y, G::SY, G::W, G::H, reinterpret_cast<const pixel *>(dst.data[0]), dst.stride[0], x0, y0, (dst.h[0] + 7) & ~7);
+    if (chroma) {
+        const int ch = ((dst.h[0] + 7) & ~7) >> 1;
+        sb_image_load<pixel, SBL2>(img_u, G::SC, G::CW, G::CH, reinterpret_cast<const pixel *>(dst.data[1]), dst.stride[1], x0 >> 1, y0 >> 1, ch);
+        sb_image_load<pixel, SBL2>(img_v, G::SC, G::CW, G::CH, reinterpret_cast<const pixel *>(dst.data[2]), dst.stride[2], x0 >> 1, y0 >> 1, ch);
+    }
+    if (threadIdx.x == 0) {
+        img.data[0] = img_y; img.data[1] = img_u; img.data[2] = img_v;
+        img.stride[0] = G::SY; img.stride[1] = img.stride[2] = G::SC;
+        for (int p = 0; p < 3; p++) { img.w[p] = dst.w[p]; img.h[p] = dst.h[p]; }
+        img.tiled = 0;
+    }
+    __syncthreads();
+
+    uint32_t g0 = 0;
+    uint32_t gn = r.n ? ru[0].prev_n : 0;
+    while (g0 < r.n) {
+        // the size of the group after this one sets off now
+        const uint32_t nx = g0 + gn < r.n ? g0 + gn : g0;
+        const uint32_t gn_next = *reinterpret_cast<const volatile uint32_t *>(&ru[nx].prev_n);      // (volatile: issued here, claimed at the end)
+        for (uint32_t k = wv; k < gn; k += NW) {
+            const IntraUnit *const up = ru + g0 + k;
+            IntraUnit u = *up;
+            // the wave's next record (same group or the next) and the first lines of this unit's coefficients set off now
+            const uint32_t nk = k + NW < gn ? g0 + k + NW : (g0 + gn + wv < r.n ? g0 + gn + wv : g0 + k);
+            const int keep0 = dv::fetch_begin(ru + nk);
+            const bool has_pred = u.has & 1, has_tx = u.has & 2;
+            const int nb = has_tx ? ((int) u.t.rsv[0] | (int) u.t.rsv[1] << 8) * (int) sizeof(coef) : 0;
+            const int keep1 = dv::fetch_begin(has_tx ? reinterpret_cast<const char *>(cf + u.t.cf_off) + (lane * 64 < nb ? lane * 64 : 0)
+                                                     : reinterpret_cast<const char *>(up));
+            const int plane = has_pred ? u.p.plane : u.t.plane;
+            const uint32_t dst_off = has_pred ? u.p.dst_off : u.t.dst_off;
+            const int w = has_pred ? u.p.tw * 4 : tx_w(u.t.tx), h = has_pred ? u.p.th * 4 : tx_h(u.t.tx);
+            // the unit's place in its plane (host: need = y << 16 | x) and in the image of that plane
+            const int ux = (int) (u.need & 0xffff), uy = (int) (u.need >> 16);
+            const int lx = ux - (plane ? x0 >> 1 : x0), ly = uy - (plane ? y0 >> 1 : y0);
+            const int S = plane ? G::SC : G::SY;
+            pixel *const im = (plane == 0 ? img_y : plane == 1 ? img_u : img_v) + (ly + 1) * S + lx + G::PAD;
+            if (has_pred) {
+                u.p.dst_off = (uint32_t) ((ly + 1) * S + lx + G::PAD);
+                if (u.p.kind == DAV1D_HIP_IPRED_CFL)          // the co-located luma block (host/lister.c: the block's own luma origin)
+                    u.p.aux_off = (uint32_t) (((uy << 1) - y0 + 1) * G::SY + ((ux << 1) - x0) + G::PAD);
+                ipred_body<pixel, false>(img, u.p, 0, false, aux, layout, bitdepth_max, e1, e2, blk, tile, w);
+            } else {
+                // a residual on its own (the blocks of a palette block, ...): the pixels it is added to come from the image
+                for (int i = lane; i < w * h; i += 64) tile[i] = im[(i / w) * S + (i % w)];
+            }
+            dv::fetch_end(keep0);
+            dv::fetch_end(keep1);
+            dv::wave_sync();
+            if (has_tx) {
+#define CASE(T) case T: itx_body<T, pixel, coef, true, true>(dst, &up->t, 1, cf, bitdepth_max, 0, smem_itx, tile); break;
+                switch (u.t.tx) {
+                    CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9)
+                    CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18)
+                }
+#undef CASE
+            }
+            dv::wave_sync();
+            // the reconstructed tile goes to the image and to the picture, four pixels per store
+            {
+                typedef typename std::conditional<sizeof(pixel) == 2, uint64_t, uint32_t>::type quad;
+                pixel *const d = reinterpret_cast<pixel *>(plane == 0 ? dst.data[0] : plane == 1 ? dst.data[1] : dst.data[2]) + dst_off;
+                const int stride = plane == 0 ? dst.stride[0] : plane == 1 ? dst.stride[1] : dst.stride[2];
+                const int wq = w >> 2;
+                for (int i = lane; i < wq * h; i += 64) {
+                    const int y = i / wq, x = (i - y * wq) * 4;
+                    const quad v = *reinterpret_cast<const quad *>(tile + y * w + x);
+                    *reinterpret_cast<quad *>(im + y * S + x) = v;
+                    *reinterpret_cast<quad *>(d + y * stride + x) = v;
+                }
+            }
+            dv::wave_sync();                 // the wave's LDS is free for its next unit
+        }
+        __syncthreads();                     // the group's pixels are in the image
+        g0 += gn;
+        gn = gn_next;
+    }
+}
+
+} // namespace
+
+// waves: workgroup size in waves of the L2 hand-off form, 4 or 8.  lds: the LDS-resident form where it exists (4:2:0 / 4:0:0 pictures).
+extern "C" int dav1d_hip_launch_intra_sb(const DevPlanes *dst, int bpc, int layout, const IntraUnit *units, const SbRegion *regions, int n_regions,
+                                         uint8_t *aux, void *coef, int waves, int sb_log2, int lds, void *stream)
+{
+    if (n_regions <= 0) return 0;
+    const int bitdepth_max = (1 << bpc) - 1;
+    if (lds && (layout == DAV1D_HIP_LAYOUT_I420 || layout == DAV1D_HIP_LAYOUT_I400) && (sb_log2 == 6 || sb_log2 == 7)) {
+        // 64-pixel superblocks leave room for eight waves' worth of scratch next to the image, 128-pixel ones for four (160 KB of LDS per CU)
+#define SBL_LAUNCH(P, Cf, L2, NW) hipLaunchKernelGGL((intra_sbl_kernel<P, Cf, L2, NW>), dim3(n_regions), dim3(NW * 64), 0, (hipStream_t) stream, *dst, units, \
+                                                     regions, aux, (Cf *) coef, layout, bitdepth_max)
+        if (bpc == 8) { if (sb_log2 == 7) SBL_LAUNCH(uint8_t, int16_t, 7, 4); else SBL_LAUNCH(uint8_t, int16_t, 6, 8); }
+        else { if (sb_log2 == 7) SBL_LAUNCH(uint16_t, int32_t, 7, 4); else SBL_LAUNCH(uint16_t, int32_t, 6, 8); }
+#undef SBL_LAUNCH
+        return hip_rc(hipGetLastError());
+    }
+#define SB_LAUNCH(P, Cf, NW) hipLaunchKernelGGL((intra_sb_kernel<P, Cf, NW>), dim3(n_regions), dim3(NW * 64), 0, (hipStream_t) stream, *dst, units, regions, \
+                                                aux, (Cf *) coef, layout, bitdepth_max)
+    if (bpc == 8) { if (waves >= 8) SB_LAUNCH(uint8_t, int16_t, 8); else SB_LAUNCH(uint8_t, int16_t, 4); }
+    else { if (waves >= 8) SB_LAUNCH(uint16_t, int32_t, 8); else SB_LAUNCH(uint16_t, int32_t, 4); }
+#undef SB_LAUNCH
+    return hip_rc(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------- host side
+
+// Units sorted by step (dav1d_hip_intra_units_build: per step the units with a prediction [.. ua_end[s]), then the residuals on
+// their own [.. ub_end[s])) -> the same units sorted by (superblock, step, kind), with the size of its group in every unit and
+// one SbPart per superblock met.  strides: of the picture's planes in pixels.  out: room for units.size() records (the frame's
+// pinned unit arena, or any array); units itself only gets its `need` fields written.
+int dav1d_hip_sbw_sort(std::vector<IntraUnit> &units, const std::vector<uint32_t> &ua_end, const std::vector<uint32_t> &ub_end,
+                            const SbTiling &tl, const int strides[3], const int ss_hor, const int ss_ver, std::vector<SbPart> &parts, IntraUnit *out)
+{
+    parts.clear();
+    const size_t n = units.size();
+    if (!n) return 0;
+    if (tl.sb_log2 != 6 && tl.sb_log2 != 7) return -EINVAL;
+    const int sbw = tl.sbw;
+    std::vector<uint32_t> sb(n), key(n);
+    uint32_t lo = 0xffffffffu, hi = 0;
+    size_t s = 0;
+    for (size_t i = 0; i < n; i++) {
+        while (s < ub_end.size() && i >= ub_end[s]) s++;
+        if (s >= ub_end.size()) return -EINVAL;
+        const IntraUnit &u = units[i];
+        int x, y, pl;
+        if (u.has & 1) { pl = u.p.plane; x = u.p.x4 * 4; y = u.p.y4 * 4; }
+        else { pl = u.t.plane; if (pl > 2 || strides[pl] <= 0) return -EINVAL; x = (int) (u.t.dst_off % (uint32_t) strides[pl]); y = (int) (u.t.dst_off / (uint32_t) strides[pl]); }
+        if (x > 0xffff || y > 0xffff) return -EINVAL;
+        units[i].need = (uint32_t) y << 16 | (uint32_t) x;          // the unit's place in its plane (the LDS-resident kernel)
+        if (pl) { x <<= ss_hor; y <<= ss_ver; }
+        const int sx = x >> tl.sb_log2, sy = y >> tl.sb_log2;
+        if (sx >= sbw || sy >= tl.sbh) return -EINVAL;
+        sb[i] = (uint32_t) (sy * sbw + sx);
+        key[i] = (uint32_t) s * 2 + (i >= ua_end[s]);
+        lo = std::min(lo, sb[i]); hi = std::max(hi, sb[i]);
+    }
+    // stable counting sort by superblock (the units of a submission sit in a short run of superblock numbers)
+    const size_t span = (size_t) hi - lo + 1;
+    std::vector<uint32_t> cnt(span + 1, 0);
+    for (size_t i = 0; i < n; i++) cnt[sb[i] - lo + 1]++;
+    for (size_t k = 0; k < span; k++) cnt[k + 1] += cnt[k];
+    std::vector<uint32_t> okey(n);
+    {
+        std::vector<uint32_t> pos(cnt.begin(), cnt.end() - 1);
+        for (size_t i = 0; i < n; i++) { const uint32_t p = pos[sb[i] - lo]++; out[p] = units[i]; okey[p] = key[i]; }
+    }
+    for (size_t k = 0; k < span; k++) {
+        const uint32_t a = cnt[k], b = cnt[k + 1];
+        if (a == b) continue;
+        parts.push_back({ (uint32_t) (lo + k), a, b - a });
+        for (uint32_t i = a; i < b; ) {
+            uint32_t j = i + 1;
+            while (j < b && okey[j] == okey[i]) j++;
+            for (uint32_t q = i; q < j; q++) { out[q].prev_n = j - i; out[q].grp = okey[i]; }
+            i = j;
+        }
+    }
+    return 0;
+}
+
+// level[k] of parts' superblocks: 0 where no neighbour (left, top-left, top, top-right, inside the same tile) holds units, else one
+// more than the highest of theirs.  sbs: the superblock numbers (any order, each once); out: the level of each.  Returns the number
+// of levels.
+// dep: per superblock of the frame, which neighbours its blocks' edges reach into (bit 0 left, 1 top-left, 2 top, 3 top-right), or
+// nullptr: all four.
+int dav1d_hip_sbw_levels(const SbTiling &tl, const uint32_t *sbs, size_t n, const uint8_t *dep, std::vector<int> &level_of_sb, std::vector<uint32_t> &level)
+{
+    const int sbw = tl.sbw, sbh = tl.sbh;
+    level_of_sb.assign((size_t) sbw * sbh, -1);
+    for (size_t i = 0; i < n; i++) {
+        if (sbs[i] >= (uint32_t) (sbw * sbh)) return -EINVAL;
+        level_of_sb[sbs[i]] = 0;
+    }
+    int top = 0;
+    for (int tr = 0; tr < tl.n_rows; tr++)
+        for (int tc = 0; tc < tl.n_cols; tc++) {
+            const int x0 = tl.col_start[tc], x1 = std::min<int>(tl.col_start[tc + 1], sbw);
+            const int y0 = tl.row_start[tr], y1 = std::min<int>(tl.row_start[tr + 1], sbh);
+            for (int y = y0; y < y1; y++)
+                for (int x = x0; x < x1; x++) {
+                    int &lv = level_of_sb[(size_t) y * sbw + x];
+                    if (lv < 0) continue;
+                    int m = -1;
+                    const int dm = dep ? dep[(size_t) y * sbw + x] : 15;
+                    if (x > x0 && (dm & 1)) m = std::max(m, level_of_sb[(size_t) y * sbw + x - 1]);
+                    if (y > y0) {
+                        if (dm & 4) m = std::max(m, level_of_sb[(size_t) (y - 1) * sbw + x]);
+                        if (x > x0 && (dm & 2)) m = std::max(m, level_of_sb[(size_t) (y - 1) * sbw + x - 1]);
+                        if (x + 1 < x1 && (dm & 8)) m = std::max(m, level_of_sb[(size_t) (y - 1) * sbw + x + 1]);
+                    }
+                    lv = m + 1;
+                    top = std::max(top, lv + 1);
+                }
+        }
+    level.resize(n);
+    for (size_t i = 0; i < n; i++) level[i] = (uint32_t) level_of_sb[sbs[i]];
+    return top;
+}
+
+int dav1d_hip_sb_tiling_make(SbTiling *tl, int w, int h, int sb128, int n_cols, const uint16_t *col_start_sb, int n_rows, const uint16_t *row_start_sb)
+{
+    if (!tl || w < 1 || h < 1 || n_cols < 1 || n_cols > 64 || n_rows < 1 || n_rows > 64 || !col_start_sb || !row_start_sb) return -EINVAL;
+    tl->sb_log2 = sb128 ? 7 : 6;
+    tl->sbw = (w + (1 << tl->sb_log2) - 1) >> tl->sb_log2;
+    tl->sbh = (h + (1 << tl->sb_log2) - 1) >> tl->sb_log2;
+    tl->n_cols = n_cols; tl->n_rows = n_rows;
+    for (int i = 0; i <= n_cols; i++) { if (i && col_start_sb[i] <= col_start_sb[i - 1]) return -EINVAL; tl->col_start[i] = col_start_sb[i]; }
+    for (int i = 0; i <= n_rows; i++) { if (i && row_start_sb[i] <= row_start_sb[i - 1]) return -EINVAL; tl->row_start[i] = row_start_sb[i]; }
+    if (tl->col_start[0] || tl->row_start[0] || tl->col_start[n_cols] < tl->sbw || tl->row_start[n_rows] < tl->sbh) return -EINVAL;
+    return 0;
+}
+
+// The launches of a frame: every superblock that holds units, sorted by level.  A superblock met in two arrays (never by the
+// listers: a superblock belongs to one tile-sbrow) is refused.
+int dav1d_hip_sbw_plan(const SbTiling &tl, const std::vector<const std::vector<SbPart> *> &parts, const std::vector<size_t> &base, const uint8_t *dep,
+                       SbPlan &plan)
+{
+    plan.regions.clear(); plan.level_start.clear();
+    if (parts.size() != base.size()) return -EINVAL;
+    std::vector<uint32_t> sbs;
+    std::vector<SbRegion> reg;
+    for (size_t k = 0; k < parts.size(); k++)
+        for (const SbPart &p : *parts[k]) {
+            if (base[k] + p.first + p.n > 0xffffffffu) return -ENOTSUP;
+            sbs.push_back(p.sb);
+            reg.push_back({ (uint32_t) (base[k] + p.first), p.n, (uint16_t) ((p.sb % (uint32_t) tl.sbw) << tl.sb_log2), (uint16_t) ((p.sb / (uint32_t) tl.sbw) << tl.sb_log2), 0 });
+        }
+    std::vector<int> level_of_sb;
+    std::vector<uint32_t> level;
+    {
+        std::vector<uint32_t> seen(sbs);
+        std::sort(seen.begin(), seen.end());
+        if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) return -EINVAL;
+    }
+    const int nl = dav1d_hip_sbw_levels(tl, sbs.data(), sbs.size(), dep, level_of_sb, level);
+    if (nl < 0) return nl;
+    plan.level_start.assign((size_t) nl + 1, 0);
+    for (size_t i = 0; i < level.size(); i++) plan.level_start[level[i] + 1]++;
+    for (int l = 0; l < nl; l++) plan.level_start[l + 1] += plan.level_start[l];
+    plan.regions.resize(reg.size());
+    // within a level the superblocks with the most units first: the launch ends with its longest workgroup, which should not be
+    // the last one to start
+    std::vector<uint32_t> order(reg.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t) i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return level[a] != level[b] ? level[a] < level[b] : reg[a].n > reg[b].n; });
+    for (size_t i = 0; i < order.size(); i++) plan.regions[i] = reg[order[i]];
+    return 0;
+}

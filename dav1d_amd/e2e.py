@@ -206,7 +206,7 @@ def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0
     out["value"] = round(w * h / (out["total_ms"] * 1e-3) / 1e6, 1) if "total_ms" in out else None
     out["unit"] = "Mpixels/s"
     out["synth_seconds"] = round(t_synth, 2)
-    kind = "key frame (every block intra)" if key_frame else "inter frame" if not intra_pct else "inter frame, %d %% intra blocks" % intra_pct
+    kind = "key frame (every block intra)" if key_frame else "inter frame" if not intra_pct else "inter frame, %d %%%% intra blocks" % intra_pct
     out["workload"] = ("%dx%d 4:2:0 %d-bit " + kind + " from pass-1 hand-off arrays: lister on %d host threads" + (" of the library" if native_threads else "") + " over %d x %d tiles, chunk "
                        "preparation + upload on the submitting threads, dense coefficient arena over the host link meanwhile (h2d_ms), "
                        "frame_end = gather + the frame's launches + sync") % (w, h, bpc, threads, n_tcols, n_trows)

@@ -25,6 +25,7 @@
 
 /* internal entry points of the frame driver (csrc/frame.hip) */
 int dav1d_hip_frame_picture(const Dav1dHipFrame *f, Dav1dHipPicture *out);
+int dav1d_hip_frame_set_sb_deps(Dav1dHipFrame *f, uint32_t first, size_t n, const uint8_t *mask);
 int dav1d_hip_frame_submit_tile_sbrow_own(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
                                           const Dav1dHipItxTask *itx, size_t n_itx);
 
@@ -62,6 +63,9 @@ struct Dav1dHipLister {
     int step_stride[3];
     TileCursor *tiles;
     int cf_align64;
+    uint8_t *sb_dep;              /* [superblock, raster] -> neighbouring superblocks its intra blocks read intra pixels of (bit 0 left, 1 top-left,
+                                     2 top, 3 top-right): the levels of the superblock wavefront (csrc/intra_sb.hip) */
+    int sbw;
     /* The shared counters live on cache lines of their own: every walking thread reads the fields above for every block, and a
      * counter bumped on the same line sent that line around all of them (the walk of an 8K frame took 9 ms on 32 threads and
      * 22 ms on one).  The arena cursors are bumped once per WINDOW a tile-sbrow draws, not once per compound block. */
@@ -137,6 +141,25 @@ static unsigned dep_step(const Walk *w, const int pl, const int x4, const int y4
         for (int x = imax(x4 - 1, x_lo); x < imin(x4 + 2 * tw, x_hi); x++) s = m[(y4 - 1) * st + x] > s ? m[(y4 - 1) * st + x] : s;
     if (x4 > x_lo)
         for (int y = y4; y < imin(y4 + 2 * th, y_hi); y++) s = m[y * st + x4 - 1] > s ? m[y * st + x4 - 1] : s;
+    /* a block on the top row or the left column of its superblock: which neighbouring superblocks hold the intra-written cells (step
+     * > 0) among those just scanned.  Cells of superblocks that are decoded later (right of the top-right corner inside the
+     * superblock's own row, below the bottom-left corner) hold 0. */
+    const int cx = l->sb_step >> sh, cy = l->sb_step >> sv;          /* cells of this plane per superblock */
+    const int on_top = y4 % cy == 0, on_left = x4 % cx == 0;
+    if (s && (on_top || on_left)) {
+        unsigned bits = 0;
+        if (y4 > y_lo)
+            for (int x = imax(x4 - 1, x_lo); x < imin(x4 + 2 * tw, x_hi); x++)
+                if (m[(y4 - 1) * st + x]) {
+                    const int dx = x / cx - x4 / cx;
+                    if (on_top) bits |= dx < 0 ? 2 : dx == 0 ? 4 : 8;
+                    else if (dx < 0) bits |= 1;
+                }
+        if (x4 > x_lo && on_left)
+            for (int y = y4; y < imin(y4 + 2 * th, y_hi); y++)
+                if (m[y * st + x4 - 1] && y / cy == y4 / cy) bits |= 1;
+        if (bits) l->sb_dep[(size_t) (y4 / cy) * l->sbw + x4 / cx] |= (uint8_t) bits;
+    }
     return s + 1;
 }
 
@@ -994,6 +1017,8 @@ int dav1d_hip_lister_create(Dav1dHipLister **out, const Dav1dHipFrameDesc *d, Da
     l->ss_hor = d->layout != DAV1D_HIP_LAYOUT_I444;
     l->bw = ((d->w + 7) >> 3) << 1; l->bh = ((d->h + 7) >> 3) << 1;      /* f->bw / f->bh: whole 8x8s, src/decode.c:3543-3544 */
     l->sb_step = d->sb128 ? 32 : 16;
+    l->sbw = (d->w + l->sb_step * 4 - 1) / (l->sb_step * 4);
+    l->sb_dep = (uint8_t *) calloc((size_t) l->sbw * (size_t) ((d->h + l->sb_step * 4 - 1) / (l->sb_step * 4)) + 1, 1);
     l->hbd = d->bpc > 8;
     l->csz = l->hbd ? 4 : 2;
     l->psz = l->hbd ? 2 : 1;
@@ -1010,7 +1035,7 @@ int dav1d_hip_lister_create(Dav1dHipLister **out, const Dav1dHipFrameDesc *d, Da
     }
     const int n_tiles = d->n_tile_cols * d->n_tile_rows;
     l->tiles = (TileCursor *) calloc((size_t) n_tiles, sizeof(TileCursor));
-    if (!l->owner || !l->step[0] || !l->step[1] || !l->step[2] || !l->tiles) { dav1d_hip_lister_destroy(l); return -ENOMEM; }
+    if (!l->owner || !l->step[0] || !l->step[1] || !l->step[2] || !l->tiles || !l->sb_dep) { dav1d_hip_lister_destroy(l); return -ENOMEM; }
     /* setup_tile(), src/decode.c:2438-2452: where a tile's share of cbi / cf / pal_idx starts */
     static const uint8_t size_mul[4][2] = { { 4, 4 }, { 6, 5 }, { 8, 6 }, { 12, 8 } };
     for (int t = 0; t < n_tiles; t++) {
@@ -1021,6 +1046,9 @@ int dav1d_hip_lister_create(Dav1dHipLister **out, const Dav1dHipFrameDesc *d, Da
         l->tiles[t].next_sby = d->row_start_sb[t / d->n_tile_cols];
     }
     l->mask_bytes = h_masks()->size;
+    /* the frame learns its tiles: intra blocks then run superblock by superblock (csrc/intra_sb.hip).  A frame that already holds intra
+     * submissions (a second lister on one frame) keeps what it has. */
+    (void) dav1d_hip_frame_set_tiling(frame, d->sb128, d->n_tile_cols, d->col_start_sb, d->n_tile_rows, d->row_start_sb);
     *out = l;
     return 0;
 }
@@ -1037,6 +1065,7 @@ void dav1d_hip_lister_destroy(Dav1dHipLister *l) {
     map_put(l->owner, 2 * l->map_bytes);
     for (int p = 0; p < 3; p++) map_put(l->step[p], l->map_bytes);
     free(l->tiles);
+    free(l->sb_dep);
     free(l);
 }
 
@@ -1192,6 +1221,11 @@ int dav1d_hip_lister_tile_sbrow(Dav1dHipLister *l, const int tile_row, const int
     if (!rc && op->warp.n) rc = dav1d_hip_frame_submit_warp(l->frame, op->warp.p, op->warp.n);
     if (!rc && op->scaled.n) rc = dav1d_hip_frame_submit_scaled(l->frame, op->scaled.p, op->scaled.n);
     if (!rc && op->smc.n) rc = dav1d_hip_frame_submit_step_copy(l->frame, op->smc.p, op->smc_step.p, op->smc.n);
+    if (!rc && (op->ipred.n || op->sitx.n)) {
+        /* what this row of superblocks reads of its neighbours (dep_step): a frame without a tiling has no use for it */
+        const int sbx0 = w.col_start / l->sb_step, sbx1 = (w.col_end + l->sb_step - 1) / l->sb_step;
+        (void) dav1d_hip_frame_set_sb_deps(l->frame, (uint32_t) (sby * l->sbw + sbx0), (size_t) (sbx1 - sbx0), l->sb_dep + (size_t) sby * l->sbw + sbx0);
+    }
     if (!rc) rc = submit_steps(l, op);
     if (!rc) cur->next_sby = sby + 1;
     return rc;

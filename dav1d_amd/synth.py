@@ -451,8 +451,9 @@ def make_intra_pass(frame, seed, layout=1):
             by = ((gy >> ss)[:, None] + (ii.ravel() * pw)[None, :]).ravel()
             wi = np.tile((jj + 2 * ii).ravel(), len(gx))
             jcol = np.tile(jj.ravel(), len(gx))
+            irow = np.tile(ii.ravel(), len(gx))
             keep = (bx + pw <= pwid) & (by + pw <= phei)
-            bx, by, wi, jcol = bx[keep], by[keep], wi[keep], jcol[keep]
+            bx, by, wi, jcol, irow = bx[keep], by[keep], wi[keep], jcol[keep], irow[keep]
             n = len(bx)
             t = np.zeros(n, IPRED_TASK)
             t["dst_off"] = by * geo[pl][0] + bx
@@ -465,7 +466,10 @@ def make_intra_pass(frame, seed, layout=1):
             t["mode"] = mode
             directional = (mode >= 1) & (mode <= 8)
             t["angle"] = np.where(directional, rng.integers(-3, 4, size=n), np.where(mode == 13, rng.integers(0, 5, size=n), 0))
-            flags = (bx > 0) * 1 + (by > 0) * 2 + 4 + (jcol == 0) * 8 + 16 + rng.integers(0, 2, size=n) * 32
+            # edge availability as a decoder with 64x64 superblocks has it: the top-right neighbour is there for the region's top
+            # row (the row above is final) and inside the region (an earlier wave), not right of the region below its top row
+            # (that superblock comes later); the bottom-left one only for the region's left column above its last row
+            flags = (bx > 0) * 1 + (by > 0) * 2 + ((irow == 0) | (jcol + 1 < k)) * 4 + ((jcol == 0) & (irow + 1 < k)) * 8 + 16 + rng.integers(0, 2, size=n) * 32
             t["flags"] = flags
             t["plane"], t["kind"] = pl, 0
             t["max_w"], t["max_h"] = pwid - bx, phei - by

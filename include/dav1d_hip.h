@@ -67,6 +67,8 @@ DAV1D_HIP_API void dav1d_hip_graph_destroy(Dav1dHipContext *c, Dav1dHipGraph *g)
 /* Tuning knobs are context state; the environment variables DESIGN.md lists only supply the defaults when the context is opened.
  * name = the variable without its DAV1D_HIP_ prefix, lower case ("recon_fuse", "recon_pipeline", "recon_lanes", "post_bands",
  * "serial", "cdef_unit", "flow_groups", "flow_mode", "flow_min_steps", "chunk_arena_min",
+ * "intra_sb": the intra blocks of a frame superblock by superblock — 2, the default: every frame whose tiling is known; 1: only
+ * wavefronts of at least flow_min_steps steps; 0: never,
  * "chunk_order": 1 = the prepared lists of a tile-sbrow are ordered for the device — by code path and reference, a few per cent on the
  * launches for a tenth more host time per frame; 0, the default, leaves decode order); -EINVAL for an unknown name. */
 DAV1D_HIP_API int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value);
@@ -429,6 +431,23 @@ DAV1D_HIP_API size_t dav1d_hip_intra_flow_units(const Dav1dHipIntraFlow *l);
 /* after a run (synchronizes): out = { tickets drawn, units finished, waves that gave up waiting (0 unless something is broken) } */
 DAV1D_HIP_API int dav1d_hip_intra_flow_status(Dav1dHipContext *c, const Dav1dHipIntraFlow *l, uint32_t out[3]);
 
+/* The same wavefront SUPERBLOCK BY SUPERBLOCK: a workgroup owns a superblock and works its units off step by step behind
+ * workgroup barriers; superblocks are ordered in levels — a superblock's level is one more than the highest among its left,
+ * top-left, top and top-right neighbours of the same tile that hold intra units (all the reference's decode order lets a
+ * block read: src/decode.c:2117-2375, src/ipred_prepare_tmpl.c:82-116) — and a level is one launch.  The batches must be the
+ * steps of a wavefront in which a block's step exceeds the step of every block it reads INSIDE its superblock (the listers'
+ * and any decode-order-consistent numbering do).  geometry: a picture of the frame's size / layout / strides; sb128 and the
+ * tile starts as in Dav1dHipFrameDesc.  -ENOTSUP for the task kinds dav1d_hip_intra_flow_create refuses.  run only enqueues. */
+typedef struct Dav1dHipIntraSb Dav1dHipIntraSb;
+DAV1D_HIP_API int dav1d_hip_intra_sb_create(Dav1dHipContext *c, Dav1dHipIntraSb **out, const Dav1dHipIpredTask *preds, const size_t *pred_sizes,
+                                            const Dav1dHipItxTask *txs, const size_t *tx_sizes, size_t n_batches,
+                                            const Dav1dHipPicture *geometry, int sb128, int n_tile_cols, const uint16_t *col_start_sb,
+                                            int n_tile_rows, const uint16_t *row_start_sb);
+DAV1D_HIP_API int dav1d_hip_intra_sb_run(Dav1dHipContext *c, const Dav1dHipIntraSb *l, const Dav1dHipPicture *dst, void *coef, uint8_t *aux);
+DAV1D_HIP_API void dav1d_hip_intra_sb_destroy(Dav1dHipContext *c, Dav1dHipIntraSb *l);
+DAV1D_HIP_API size_t dav1d_hip_intra_sb_levels(const Dav1dHipIntraSb *l);          /* launches per run */
+DAV1D_HIP_API size_t dav1d_hip_intra_sb_superblocks(const Dav1dHipIntraSb *l);     /* superblocks that hold units */
+
 /* ------------------------------------------------- mc: warp, scaled, resize, emu_edge */
 
 /* One 8x8 block of a warped prediction: dsp->mc.warp8x8 (kind PUT, pixels into dst) or warp8x8t (kind PREP, int16
@@ -638,6 +657,12 @@ DAV1D_HIP_API int dav1d_hip_frame_submit_intra_step(Dav1dHipFrame *f, size_t ste
 DAV1D_HIP_API int dav1d_hip_frame_submit_intra_sorted(Dav1dHipFrame *f, size_t n_steps, const Dav1dHipIpredTask *ipred, const size_t *ipred_end,
                                                       const Dav1dHipItxTask *itx, const size_t *itx_end, const Dav1dHipCompTask *blend,
                                                       const size_t *blend_end);
+/* The frame's tiles in superblocks (seq_hdr->sb128, frame_hdr->tiling.cols / col_start_sb / rows / row_start_sb, as in
+ * Dav1dHipFrameDesc).  With them the frame's intra blocks run superblock by superblock (dav1d_hip_intra_sb_*) instead of step by
+ * step — provided no submission carries inter-intra blends or intra block copies.  Before the first intra submission (-EINVAL
+ * after it); dav1d_hip_lister_create calls it. */
+DAV1D_HIP_API int dav1d_hip_frame_set_tiling(Dav1dHipFrame *f, int sb128, int n_tile_cols, const uint16_t *col_start_sb, int n_tile_rows,
+                                             const uint16_t *row_start_sb);
 /* Inter-intra blends of wavefront step `step` >= 1 (kind DAV1D_HIP_COMP_BLEND reading what the step's DAV1D_HIP_IPRED_PRED_TMP
  * tasks wrote): run between the step's predictions and its residuals.  Thread-safe. */
 DAV1D_HIP_API int dav1d_hip_frame_submit_step_blend(Dav1dHipFrame *f, size_t step, const Dav1dHipCompTask *blend, size_t n);

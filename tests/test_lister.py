@@ -229,8 +229,37 @@ def test_chunks_that_do_not_fit_the_frames_arena(ctx, packed):
 def test_packing_lister_key_frame_through_the_dataflow_launch(ctx, bpc):
     """a key frame deep enough for the one-launch wavefront (intra_flow.hip, more than flow_min_steps steps): its units carry PACKED
     residuals; lanes of a wave that hold no block (one unit per wave) and lanes that do pass the same barriers (itx_body.h)"""
-    st = run_case(ctx, 384, 256, 1, bpc, 5, is_inter=False, tiles=(2, 1), packed=True)
+    c2 = util.make_context(ctx.backend)
+    c2.backend = ctx.backend
+    try:
+        c2.set_option("intra_sb", 0)            # (the default route of a frame with a tiling is superblock by superblock, below)
+        st = run_case(c2, 384, 256, 1, bpc, 5, is_inter=False, tiles=(2, 1), packed=True)
+    finally:
+        c2.close()
     assert st["steps"] >= 200 and not st["coef_after"].any()
+
+
+@pytest.mark.parametrize("lds", [1, 0], ids=["lds-resident", "l2-handoff"])
+@pytest.mark.parametrize("sb128", [True, False], ids=["sb128", "sb64"])
+@pytest.mark.parametrize("bpc", [8, 10])
+def test_key_frame_superblock_by_superblock(ctx, bpc, sb128, lds):
+    """The intra wavefront as one workgroup per superblock and one launch per level of superblocks (intra_sb.hip), both forms of the
+    hand-off inside a superblock, 64- and 128-pixel superblocks, several tiles (levels stop at tile edges), palette blocks (residuals
+    without a prediction of their own) and CfL; the first frame finds the pinned unit arena too small (chunk_arena_min), so some
+    tile-sbrows' units take the late path.  Inter frames with scattered intra blocks run the same route (levels from what the blocks
+    really read of their neighbours)."""
+    c2 = util.make_context(ctx.backend)
+    c2.backend = ctx.backend
+    try:
+        c2.set_option("intra_sb", 2)
+        c2.set_option("intra_sb_lds", lds)
+        c2.set_option("chunk_arena_min", 4096)
+        st = run_case(c2, 448, 320, 1, bpc, 21 + bpc, is_inter=False, tiles=(2, 2), threads=2, sb128=sb128, palette=15, packed=True)
+        assert st["steps"] >= 50 and not st["coef_after"].any()
+        run_case(c2, 448, 320, 1, bpc, 22 + bpc, is_inter=False, tiles=(1, 1), sb128=sb128)
+        run_case(c2, 448, 320, 1, bpc, 23 + bpc, is_inter=True, tiles=(2, 1), threads=2, sb128=sb128, **dict(PLAIN, intra_pct=25))
+    finally:
+        c2.close()
 
 
 @pytest.mark.gpu

@@ -98,19 +98,25 @@ def oracle_intra(oracle, ip, planes, w, h, bpc):
     return coef
 
 
-def hip_intra(ctx, ip, pic, timed=False, graph=False, paired=True, flow=False):
+def hip_intra(ctx, ip, pic, timed=False, graph=False, paired=True, flow=False, sb=False):
     """Runs the intra pass from device-resident lists, every wave enqueued back to back on the context's stream
     (prediction of wave k, residuals of wave k, prediction of wave k + 1, ...), no host round trip in between.
     graph: record the whole chain once (dav1d_hip_graph_*) and replay it as one HIP graph.
     paired: through dav1d_hip_intra_list_* (4x4 / 8x8 blocks: prediction + residual in one wave) instead of the prediction
     list + one residual list per step.
     flow: through dav1d_hip_intra_flow_* — the whole pass as one launch, steps handed over between running waves.
+    sb: through dav1d_hip_intra_sb_* — a workgroup per superblock, a launch per level of superblocks.
     timed (bench.py only; needs torch for the events): returns the device time of the whole pass in ms, else 0."""
     import ctypes as C
     coef = ctx.buffer_from(ip.coef)
     lib = ctx.lib
     fl = None
-    if flow:
+    sl = None
+    if sb:
+        sl = ctx.intra_sb(ip.batches, pic)
+        hip_intra.sb_levels, hip_intra.sb_superblocks = sl.n_levels, sl.n_superblocks
+        xl, plist, ilists = None, None, []
+    elif flow:
         fl = ctx.intra_flow(ip.batches)
         xl, plist, ilists = None, None, []
     elif paired:
@@ -123,6 +129,9 @@ def hip_intra(ctx, ip, pic, timed=False, graph=False, paired=True, flow=False):
     lib.dav1d_hip_sync(ctx.h)
 
     def chain():
+        if sl is not None:
+            sl.run(pic, coef)
+            return
         if fl is not None:
             fl.run(pic, coef)
             return
@@ -161,7 +170,9 @@ def hip_intra(ctx, ip, pic, timed=False, graph=False, paired=True, flow=False):
     left = coef.download(ip.coef.dtype, len(ip.coef))
     if g is not None:
         ctx.graph_destroy(g)
-    if fl is not None:
+    if sl is not None:
+        sl.destroy()
+    elif fl is not None:
         hip_intra.flow_status = fl.status()
         fl.destroy()
         assert hip_intra.flow_status == (hip_intra.flow_status[0], fl.n_units, 0), hip_intra.flow_status
@@ -176,7 +187,7 @@ def hip_intra(ctx, ip, pic, timed=False, graph=False, paired=True, flow=False):
     return ms
 
 
-@pytest.mark.parametrize("paired", [True, False, "flow"], ids=["paired", "two-launches", "one-launch"])
+@pytest.mark.parametrize("paired", [True, False, "flow", "sb"], ids=["paired", "two-launches", "one-launch", "superblocks"])
 @pytest.mark.parametrize("bpc", [8, 10, 12])
 def test_intra_wavefront_pass_matches_oracle(ctx, bpc, paired):
     oracle = util.default_oracle()
@@ -191,7 +202,7 @@ def test_intra_wavefront_pass_matches_oracle(ctx, bpc, paired):
         pic.upload(pl, planes[pl])
     want = synth.copy_planes(planes)
     oracle_intra(oracle, ip, want, w, h, bpc)
-    hip_intra(ctx, ip, pic, paired=paired is True, flow=paired == "flow")
+    hip_intra(ctx, ip, pic, paired=paired is True, flow=paired == "flow", sb=paired == "sb")
     for pl in range(3):
         vh, vw = (h, w) if pl == 0 else (h // 2, w // 2)
         bad = np.argwhere(pic.download(pl)[:vh, :vw] != want[pl][:vh, :vw])
