@@ -25,8 +25,9 @@ struct Dav1dHipContext {
     int flow_groups;            // workgroups of the intra dataflow launch ($DAV1D_HIP_FLOW_GROUPS at open, default 512; every wave has to be resident: units are dealt out round-robin)
     int intra_sb;               // the intra wavefront superblock by superblock (intra_sb.hip; $DAV1D_HIP_INTRA_SB / option intra_sb): 0 never,
                                 // 1 for wavefronts of at least flow_min_steps steps, 2 (default) for every frame whose tiling is known
-    int intra_sb_lds;           // 1 (default): the superblock's pixels stay in LDS where that form exists ($DAV1D_HIP_INTRA_SB_LDS / option intra_sb_lds)
-    int intra_sb_waves;         // waves per workgroup of that route, 4 or 8 ($DAV1D_HIP_INTRA_SB_WAVES / option intra_sb_waves)
+    int intra_sb_lds;           // 1: the superblock's pixels stay in LDS where that form exists (4:2:0); 0 (default): handed over through the L2 — measured
+                                // equal or a little faster ($DAV1D_HIP_INTRA_SB_LDS / option intra_sb_lds)
+    int intra_sb_waves;         // waves per workgroup of that route: 4, 8 or 0 = the kernel form's own choice ($DAV1D_HIP_INTRA_SB_WAVES / option intra_sb_waves)
     int recon_fuse;             // bit mask of the square block sizes that run paired (DAV1D_HIP_RECON_FUSE)
     long recon_pipeline;        // smallest residual list a recon list pipelines on two streams (DAV1D_HIP_RECON_PIPELINE)
     int recon_lanes;            // side streams of the residual launches (DAV1D_HIP_RECON_LANES)
@@ -271,15 +272,22 @@ extern "C" size_t dav1d_hip_intra_flow_units(const Dav1dHipIntraFlow *l);
 extern "C" int dav1d_hip_intra_flow_status(Dav1dHipContext *c, const Dav1dHipIntraFlow *l, uint32_t out[3]);
 
 // ---- the intra wavefront superblock by superblock (intra_sb.hip): one workgroup per superblock, a launch per level
-struct SbRegion { uint32_t first, n; uint16_t x0, y0; uint32_t pad; };   // device: the superblock's units, units[first .. first + n), and its luma origin
+struct SbRegion { uint32_t first, n; uint16_t x0, y0; uint32_t pad; };   // device: the superblock's records (header, then units) [first, first + n), its luma origin
 struct SbPart { uint32_t sb, first, n; };          // host: superblock number (raster, frame-wide) and its run in a sorted unit array
 struct SbTiling {                                   // the frame's tiles in superblocks (frame_hdr->tiling.col_start_sb / row_start_sb)
     int sb_log2, sbw, sbh, n_cols, n_rows;
     uint16_t col_start[65], row_start[65];
 };
 int dav1d_hip_sb_tiling_make(SbTiling *tl, int w, int h, int sb128, int n_cols, const uint16_t *col_start_sb, int n_rows, const uint16_t *row_start_sb);
-int dav1d_hip_sbw_sort(std::vector<IntraUnit> &units, const std::vector<uint32_t> &ua_end, const std::vector<uint32_t> &ub_end,
-                            const SbTiling &tl, const int strides[3], int ss_hor, int ss_ver, std::vector<SbPart> &parts, IntraUnit *out);
+enum : uint32_t { SB_NONE = 0xffffffffu };
+struct SbSort {
+    std::vector<uint32_t> pos, key;                 // per unit: its record in the output, its (step, kind) key
+    std::vector<SbPart> parts;                      // per superblock: number, its HEADER record in the output, its units (they follow the header)
+    size_t n_records;                               // units + superblocks
+};
+int dav1d_hip_sbw_prepare(std::vector<IntraUnit> &units, const std::vector<uint32_t> &ua_end, const std::vector<uint32_t> &ub_end,
+                          const SbTiling &tl, const int strides[3], int ss_hor, int ss_ver, SbSort &st);
+void dav1d_hip_sbw_emit(const std::vector<IntraUnit> &units, const SbSort &st, IntraUnit *out);
 int dav1d_hip_sbw_levels(const SbTiling &tl, const uint32_t *sbs, size_t n, const uint8_t *dep, std::vector<int> &level_of_sb, std::vector<uint32_t> &level);
 extern "C" int dav1d_hip_launch_intra_sb(const DevPlanes *dst, int bpc, int layout, const IntraUnit *units, const SbRegion *regions, int n_regions,
                                          uint8_t *aux, void *coef, int waves, int sb_log2, int lds, void *stream);

@@ -62,8 +62,8 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     c->flow_min_steps = fs ? atoi(fs) : 200;
     const char *isb = getenv("DAV1D_HIP_INTRA_SB");
     c->intra_sb = isb ? atoi(isb) : 2;
-    c->intra_sb_waves = (int) env_int("DAV1D_HIP_INTRA_SB_WAVES", 8);
-    c->intra_sb_lds = (int) env_int("DAV1D_HIP_INTRA_SB_LDS", 1);
+    c->intra_sb_waves = (int) env_int("DAV1D_HIP_INTRA_SB_WAVES", 0);
+    c->intra_sb_lds = (int) env_int("DAV1D_HIP_INTRA_SB_LDS", 0);
     for (int i = 0; i < Dav1dHipContext::N_SIDE; i++) {
         if (hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
@@ -175,7 +175,7 @@ int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value) {
     else if (!strcmp(name, "flow_mode")) c->flow_mode = (int) value;
     else if (!strcmp(name, "flow_min_steps")) c->flow_min_steps = (int) value;
     else if (!strcmp(name, "intra_sb")) c->intra_sb = (int) value;
-    else if (!strcmp(name, "intra_sb_waves")) c->intra_sb_waves = value >= 8 ? 8 : 4;
+    else if (!strcmp(name, "intra_sb_waves")) c->intra_sb_waves = value >= 8 ? 8 : value >= 4 ? 4 : 0;
     else if (!strcmp(name, "intra_sb_lds")) c->intra_sb_lds = value != 0;
     else if (!strcmp(name, "chunk_order")) c->chunk_order = value != 0;
     else if (!strcmp(name, "chunk_arena_min")) { if (value < 4096) return -EINVAL; c->arena_min = (size_t) 1 << 12; while (c->arena_min < (size_t) value) c->arena_min <<= 1; c->arena_hint = 0; }
@@ -2287,11 +2287,15 @@ int dav1d_hip_intra_sb_create(Dav1dHipContext *c, Dav1dHipIntraSb **out, const D
     rc = dav1d_hip_intra_units_build(preds, pe.data(), txs, te.data(), n_batches, units, ua, ub);
     if (rc) return rc;
     const DevPlanes dp = dev_planes(geometry);
-    std::vector<SbPart> parts;
-    std::vector<IntraUnit> sorted(units.size());
-    rc = dav1d_hip_sbw_sort(units, ua, ub, tl, dp.stride, geometry->layout != DAV1D_HIP_LAYOUT_I444, geometry->layout == DAV1D_HIP_LAYOUT_I420, parts, sorted.data());
+    SbSort st;
+    rc = dav1d_hip_sbw_prepare(units, ua, ub, tl, dp.stride, geometry->layout != DAV1D_HIP_LAYOUT_I444, geometry->layout == DAV1D_HIP_LAYOUT_I420, st);
     if (rc) return rc;
+    std::vector<IntraUnit> sorted(st.n_records);
+    dav1d_hip_sbw_emit(units, st, sorted.data());
+    bool has_pal = false;
+    for (const IntraUnit &u : units) if ((u.has & 1) && u.p.kind == DAV1D_HIP_IPRED_PAL) { has_pal = true; break; }
     units.swap(sorted);
+    const std::vector<SbPart> &parts = st.parts;
     SbPlan plan;
     rc = dav1d_hip_sbw_plan(tl, { &parts }, { 0 }, nullptr, plan);
     if (rc) return rc;
@@ -2301,8 +2305,7 @@ int dav1d_hip_intra_sb_create(Dav1dHipContext *c, Dav1dHipIntraSb **out, const D
     l->n_units = units.size(); l->n_regions = plan.regions.size();
     l->level_start = plan.level_start;
     l->sb_log2 = tl.sb_log2;
-    l->needs_aux = false;
-    for (const IntraUnit &u : units) if ((u.has & 1) && u.p.kind == DAV1D_HIP_IPRED_PAL) { l->needs_aux = true; break; }
+    l->needs_aux = has_pal;
     if (l->n_units) {
         if (hipMalloc((void **) &l->units, (l->n_units + 1) * sizeof(IntraUnit)) != hipSuccess) rc = -ENOMEM;
         if (!rc && hipMalloc((void **) &l->regions, l->n_regions * sizeof(SbRegion)) != hipSuccess) rc = -ENOMEM;

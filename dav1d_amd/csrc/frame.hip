@@ -570,7 +570,11 @@ int dav1d_hip_frame_submit_intra_sorted(Dav1dHipFrame *f, size_t n_steps, const 
     if (ck->flow_ok && f->have_tiling && f->c->intra_sb > 0) {
         // the superblock wavefront takes the units superblock by superblock: sorted here, on the submitting thread
         const DevPlanes dp = dev_planes(&f->cur);
-        const size_t n = ck->units.size(), bytes = n * sizeof(IntraUnit);
+        SbSort st;
+        const int rc = dav1d_hip_sbw_prepare(ck->units, ck->ua_end, ck->ub_end, f->tiling, dp.stride, f->cur.layout != DAV1D_HIP_LAYOUT_I444,
+                                             f->cur.layout == DAV1D_HIP_LAYOUT_I420, st);
+        if (rc) { delete ck; return rc; }
+        const size_t n = st.n_records, bytes = n * sizeof(IntraUnit);
         {
             std::lock_guard<std::mutex> lk(f->mtx);
             if (!f->huarena) {
@@ -585,11 +589,10 @@ int dav1d_hip_frame_submit_intra_sorted(Dav1dHipFrame *f, size_t n_steps, const 
         if (!ck->in_arena) own.resize(n);
         ck->sorted = ck->in_arena ? reinterpret_cast<IntraUnit *>(f->huarena + off) : own.data();
         ck->n_sorted = n;
-        const int rc = dav1d_hip_sbw_sort(ck->units, ck->ua_end, ck->ub_end, f->tiling, dp.stride, f->cur.layout != DAV1D_HIP_LAYOUT_I444,
-                                          f->cur.layout == DAV1D_HIP_LAYOUT_I420, ck->parts, ck->sorted);
-        if (rc) { delete ck; return rc; }
+        dav1d_hip_sbw_emit(ck->units, st, ck->sorted);
+        ck->parts.swap(st.parts);
         ck->has_pal = false;
-        for (size_t i = 0; i < n && !ck->has_pal; i++) ck->has_pal = (ck->units[i].has & 1) && ck->units[i].p.kind == DAV1D_HIP_IPRED_PAL;
+        for (size_t i = 0; i < ck->units.size() && !ck->has_pal; i++) ck->has_pal = (ck->units[i].has & 1) && ck->units[i].p.kind == DAV1D_HIP_IPRED_PAL;
         if (ck->in_arena) { std::vector<IntraUnit>().swap(ck->units); }
         else { ck->units.swap(own); ck->sorted = ck->units.data(); }
         ck->sb_sorted = true;

@@ -30,8 +30,11 @@ constexpr int sb_itx_lds_of(int tx) {
 constexpr int sb_itx_lds_max(int tx = 0) { return tx == 19 ? 0 : cmax(sb_itx_lds_of(tx), sb_itx_lds_max(tx + 1)); }
 
 
-// units[r.first .. r.first + r.n): the superblock's units sorted by (step, predictions first); every unit carries the size of
-// its group (prev_n), the first unit of a group is the one that is read.
+// the unit the same wave works on after `u` (host: dav1d_hip_sbw_emit)
+template <int NW> __device__ __forceinline__ uint32_t sb_next(const IntraUnit &u) { return NW == 4 ? u.pad2 : u.prev_n; }
+
+// records [r.first, r.first + r.n): the superblock's header, then its units sorted by (step, predictions first); grp = the unit's
+// group, groups are separated by workgroup barriers.
 template <typename pixel, typename coef, int SB_WAVES>
 __global__ __launch_bounds__(SB_WAVES * 64, 2) void intra_sb_kernel(const DevPlanes dst, const IntraUnit *__restrict__ units,
                                                                      const SbRegion *__restrict__ regions, uint8_t *aux,
@@ -49,24 +52,31 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void intra_sb_kernel(const DevPla
     int *const smem_itx = reinterpret_cast<int *>(smem_s[wv]);
 
     const SbRegion r = regions[blockIdx.x];
-    const IntraUnit *const ru = units + r.first;
-    uint32_t g0 = 0;
-    uint32_t gn = r.n ? ru[0].prev_n : 0;           // the same word for every wave: the barriers below are met by all of them
-    while (g0 < r.n) {
-        // the size of the group after this one sets off now (volatile: issued here, claimed at the end)
-        const uint32_t nx = g0 + gn < r.n ? g0 + gn : g0;
-        const uint32_t gn_next = *reinterpret_cast<const volatile uint32_t *>(&ru[nx].prev_n);
-        for (uint32_t k = wv; k < gn; k += SB_WAVES) {
-            const IntraUnit *const up = ru + g0 + k;
-            const IntraUnit u = *up;
-            // the wave's next record (same group or the next) and the first lines of this unit's coefficients set off now; the values
-            // are claimed after the prediction
-            const uint32_t nk = k + SB_WAVES < gn ? g0 + k + SB_WAVES : (g0 + gn + wv < r.n ? g0 + gn + wv : g0 + k);
-            const int keep0 = dv::fetch_begin(ru + nk);
+    const IntraUnit *const ru = units + r.first, *const us = ru + 1;       // header record, then the units
+    const uint32_t *const hdr = reinterpret_cast<const uint32_t *>(ru);
+    const uint32_t n_groups = (uint32_t) __builtin_amdgcn_readfirstlane((int) hdr[0]);
+    // this wave's chain of units (sb_next: the host linked them), two records ahead: while unit `u` is worked on, the record of the
+    // next one (un) is in registers — its coefficients set off — and the one after that (u2) is on its way
+    uint32_t ci = (uint32_t) __builtin_amdgcn_readfirstlane((int) hdr[(SB_WAVES == 4 ? 2 : 6) + wv]);
+    IntraUnit u, un;
+    if (ci != SB_NONE) u = us[ci];
+    uint32_t ni = ci != SB_NONE ? (uint32_t) __builtin_amdgcn_readfirstlane((int) sb_next<SB_WAVES>(u)) : SB_NONE;
+    if (ni != SB_NONE) un = us[ni];
+    for (uint32_t g = 0; g < n_groups; g++) {
+        while (ci != SB_NONE && (uint32_t) __builtin_amdgcn_readfirstlane((int) u.grp) == g) {
+            const IntraUnit *const up = us + ci;
+            uint32_t n2 = SB_NONE;
+            IntraUnit u2;
+            int keepn = 0;
+            if (ni != SB_NONE) {
+                n2 = (uint32_t) __builtin_amdgcn_readfirstlane((int) sb_next<SB_WAVES>(un));
+                if (n2 != SB_NONE) u2 = us[n2];
+                if (un.has & 2) {
+                    const int nbn = ((int) un.t.rsv[0] | (int) un.t.rsv[1] << 8) * (int) sizeof(coef);
+                    keepn = dv::fetch_begin(reinterpret_cast<const char *>(cf + un.t.cf_off) + (lane * 64 < nbn ? lane * 64 : 0));
+                }
+            }
             const bool has_pred = u.has & 1, has_tx = u.has & 2;
-            const int nb = has_tx ? ((int) u.t.rsv[0] | (int) u.t.rsv[1] << 8) * (int) sizeof(coef) : 0;
-            const int keep1 = dv::fetch_begin(has_tx ? reinterpret_cast<const char *>(cf + u.t.cf_off) + (lane * 64 < nb ? lane * 64 : 0)
-                                                     : reinterpret_cast<const char *>(up));
             const int plane = has_pred ? u.p.plane : u.t.plane;
             const uint32_t dst_off = has_pred ? u.p.dst_off : u.t.dst_off;
             const int w = has_pred ? u.p.tw * 4 : tx_w(u.t.tx), h = has_pred ? u.p.th * 4 : tx_h(u.t.tx);
@@ -78,8 +88,6 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void intra_sb_kernel(const DevPla
                 // a residual on its own (the blocks of a palette block, ...): the pixels it is added to come from the picture
                 for (int i = lane; i < w * h; i += 64) tile[i] = dv::ld_coherent(d + (i / w) * stride + (i % w));
             }
-            dv::fetch_end(keep0);
-            dv::fetch_end(keep1);
             dv::wave_sync();
             if (has_tx) {
 #define CASE(T) case T: itx_body<T, pixel, coef, true, true>(dst, &up->t, 1, cf, bitdepth_max, 0, smem_itx, tile); break;
@@ -100,12 +108,12 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void intra_sb_kernel(const DevPla
                     *reinterpret_cast<quad *>(d + y * stride + x) = *reinterpret_cast<const quad *>(tile + y * w + x);
                 }
             }
+            dv::fetch_end(keepn);
             dv::wave_sync();                 // the LDS is free for the wave's next unit
+            ci = ni; u = un; ni = n2; un = u2;
         }
         dv::stores_done();                   // this wave's pixels have reached the L2 ...
         __syncthreads();                     // ... and so have the other waves': the next group may read them
-        g0 += gn;
-        gn = gn_next;
     }
 }
 
@@ -146,7 +154,7 @@ __device__ __forceinline__ void sb_image_load(pixel *img, const int S, const int
 }
 
 template <typename pixel, typename coef, int SBL2, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void intra_sbl_kernel(const DevPlanes dst, const IntraUnit *__restrict__ units,
+__global__ __launch_bounds__(NW * 64, SBL2 == 6 ? 2 : 1) void intra_sbl_kernel(const DevPlanes dst, const IntraUnit *__restrict__ units,
                                                             const SbRegion *__restrict__ regions, uint8_t *aux,
                                                             coef *__restrict__ cf, const int layout, const int bitdepth_max)
 {
@@ -183,22 +191,30 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void intra_sbl_kernel(const DevPla
     }
     __syncthreads();
 
-    uint32_t g0 = 0;
-    uint32_t gn = r.n ? ru[0].prev_n : 0;
-    while (g0 < r.n) {
-        // the size of the group after this one sets off now
-        const uint32_t nx = g0 + gn < r.n ? g0 + gn : g0;
-        const uint32_t gn_next = *reinterpret_cast<const volatile uint32_t *>(&ru[nx].prev_n);      // (volatile: issued here, claimed at the end)
-        for (uint32_t k = wv; k < gn; k += NW) {
-            const IntraUnit *const up = ru + g0 + k;
-            IntraUnit u = *up;
-            // the wave's next record (same group or the next) and the first lines of this unit's coefficients set off now
-            const uint32_t nk = k + NW < gn ? g0 + k + NW : (g0 + gn + wv < r.n ? g0 + gn + wv : g0 + k);
-            const int keep0 = dv::fetch_begin(ru + nk);
+    const IntraUnit *const us = ru + 1;                                    // (ru[0] is the header record)
+    const uint32_t *const hdr = reinterpret_cast<const uint32_t *>(ru);
+    const uint32_t n_groups = (uint32_t) __builtin_amdgcn_readfirstlane((int) hdr[0]);
+    // this wave's chain of units, two records ahead (see intra_sb_kernel)
+    uint32_t ci = (uint32_t) __builtin_amdgcn_readfirstlane((int) hdr[(NW == 4 ? 2 : 6) + wv]);
+    IntraUnit u, un;
+    if (ci != SB_NONE) u = us[ci];
+    uint32_t ni = ci != SB_NONE ? (uint32_t) __builtin_amdgcn_readfirstlane((int) sb_next<NW>(u)) : SB_NONE;
+    if (ni != SB_NONE) un = us[ni];
+    for (uint32_t g = 0; g < n_groups; g++) {
+        while (ci != SB_NONE && (uint32_t) __builtin_amdgcn_readfirstlane((int) u.grp) == g) {
+            const IntraUnit *const up = us + ci;
+            uint32_t n2 = SB_NONE;
+            IntraUnit u2;
+            int keepn = 0;
+            if (ni != SB_NONE) {
+                n2 = (uint32_t) __builtin_amdgcn_readfirstlane((int) sb_next<NW>(un));
+                if (n2 != SB_NONE) u2 = us[n2];
+                if (un.has & 2) {
+                    const int nbn = ((int) un.t.rsv[0] | (int) un.t.rsv[1] << 8) * (int) sizeof(coef);
+                    keepn = dv::fetch_begin(reinterpret_cast<const char *>(cf + un.t.cf_off) + (lane * 64 < nbn ? lane * 64 : 0));
+                }
+            }
             const bool has_pred = u.has & 1, has_tx = u.has & 2;
-            const int nb = has_tx ? ((int) u.t.rsv[0] | (int) u.t.rsv[1] << 8) * (int) sizeof(coef) : 0;
-            const int keep1 = dv::fetch_begin(has_tx ? reinterpret_cast<const char *>(cf + u.t.cf_off) + (lane * 64 < nb ? lane * 64 : 0)
-                                                     : reinterpret_cast<const char *>(up));
             const int plane = has_pred ? u.p.plane : u.t.plane;
             const uint32_t dst_off = has_pred ? u.p.dst_off : u.t.dst_off;
             const int w = has_pred ? u.p.tw * 4 : tx_w(u.t.tx), h = has_pred ? u.p.th * 4 : tx_h(u.t.tx);
@@ -208,16 +224,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void intra_sbl_kernel(const DevPla
             const int S = plane ? G::SC : G::SY;
             pixel *const im = (plane == 0 ? img_y : plane == 1 ? img_u : img_v) + (ly + 1) * S + lx + G::PAD;
             if (has_pred) {
-                u.p.dst_off = (uint32_t) ((ly + 1) * S + lx + G::PAD);
-                if (u.p.kind == DAV1D_HIP_IPRED_CFL)          // the co-located luma block (host/lister.c: the block's own luma origin)
-                    u.p.aux_off = (uint32_t) (((uy << 1) - y0 + 1) * G::SY + ((ux << 1) - x0) + G::PAD);
-                ipred_body<pixel, false>(img, u.p, 0, false, aux, layout, bitdepth_max, e1, e2, blk, tile, w);
+                Dav1dHipIpredTask tp = u.p;
+                tp.dst_off = (uint32_t) ((ly + 1) * S + lx + G::PAD);
+                if (tp.kind == DAV1D_HIP_IPRED_CFL)          // the co-located luma block (host/lister.c: the block's own luma origin)
+                    tp.aux_off = (uint32_t) (((uy << 1) - y0 + 1) * G::SY + ((ux << 1) - x0) + G::PAD);
+                ipred_body<pixel, false>(img, tp, 0, false, aux, layout, bitdepth_max, e1, e2, blk, tile, w);
             } else {
                 // a residual on its own (the blocks of a palette block, ...): the pixels it is added to come from the image
                 for (int i = lane; i < w * h; i += 64) tile[i] = im[(i / w) * S + (i % w)];
             }
-            dv::fetch_end(keep0);
-            dv::fetch_end(keep1);
             dv::wave_sync();
             if (has_tx) {
 #define CASE(T) case T: itx_body<T, pixel, coef, true, true>(dst, &up->t, 1, cf, bitdepth_max, 0, smem_itx, tile); break;
@@ -241,35 +256,44 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void intra_sbl_kernel(const DevPla
                     *reinterpret_cast<quad *>(d + y * stride + x) = v;
                 }
             }
+            dv::fetch_end(keepn);
             dv::wave_sync();                 // the wave's LDS is free for its next unit
+            ci = ni; u = un; ni = n2; un = u2;
         }
         __syncthreads();                     // the group's pixels are in the image
-        g0 += gn;
-        gn = gn_next;
     }
 }
 
 } // namespace
 
-// waves: workgroup size in waves of the L2 hand-off form, 4 or 8.  lds: the LDS-resident form where it exists (4:2:0 / 4:0:0 pictures).
+// waves: workgroup size in waves, 4 or 8 (0: the form's own choice).  lds: the LDS-resident form where it exists (4:2:0 / 4:0:0 pictures).
 extern "C" int dav1d_hip_launch_intra_sb(const DevPlanes *dst, int bpc, int layout, const IntraUnit *units, const SbRegion *regions, int n_regions,
                                          uint8_t *aux, void *coef, int waves, int sb_log2, int lds, void *stream)
 {
     if (n_regions <= 0) return 0;
     const int bitdepth_max = (1 << bpc) - 1;
     if (lds && (layout == DAV1D_HIP_LAYOUT_I420 || layout == DAV1D_HIP_LAYOUT_I400) && (sb_log2 == 6 || sb_log2 == 7)) {
-        // 64-pixel superblocks leave room for eight waves' worth of scratch next to the image, 128-pixel ones for four (160 KB of LDS per CU)
+        // 128-pixel superblocks: the image leaves room for four waves' worth of scratch (160 KB of LDS per CU).  64-pixel ones: four
+        // waves and two workgroups per CU (waves = 0 or 4: a superblock's steps are mostly narrower than four units, two superblocks
+        // in flight keep the CU busier), or eight waves and one workgroup (waves = 8)
 #define SBL_LAUNCH(P, Cf, L2, NW) hipLaunchKernelGGL((intra_sbl_kernel<P, Cf, L2, NW>), dim3(n_regions), dim3(NW * 64), 0, (hipStream_t) stream, *dst, units, \
                                                      regions, aux, (Cf *) coef, layout, bitdepth_max)
-        if (bpc == 8) { if (sb_log2 == 7) SBL_LAUNCH(uint8_t, int16_t, 7, 4); else SBL_LAUNCH(uint8_t, int16_t, 6, 8); }
-        else { if (sb_log2 == 7) SBL_LAUNCH(uint16_t, int32_t, 7, 4); else SBL_LAUNCH(uint16_t, int32_t, 6, 8); }
+        if (bpc == 8) {
+            if (sb_log2 == 7) SBL_LAUNCH(uint8_t, int16_t, 7, 4);
+            else if (waves >= 8) SBL_LAUNCH(uint8_t, int16_t, 6, 8);
+            else SBL_LAUNCH(uint8_t, int16_t, 6, 4);
+        } else {
+            if (sb_log2 == 7) SBL_LAUNCH(uint16_t, int32_t, 7, 4);
+            else if (waves >= 8) SBL_LAUNCH(uint16_t, int32_t, 6, 8);
+            else SBL_LAUNCH(uint16_t, int32_t, 6, 4);
+        }
 #undef SBL_LAUNCH
         return hip_rc(hipGetLastError());
     }
 #define SB_LAUNCH(P, Cf, NW) hipLaunchKernelGGL((intra_sb_kernel<P, Cf, NW>), dim3(n_regions), dim3(NW * 64), 0, (hipStream_t) stream, *dst, units, regions, \
                                                 aux, (Cf *) coef, layout, bitdepth_max)
-    if (bpc == 8) { if (waves >= 8) SB_LAUNCH(uint8_t, int16_t, 8); else SB_LAUNCH(uint8_t, int16_t, 4); }
-    else { if (waves >= 8) SB_LAUNCH(uint16_t, int32_t, 8); else SB_LAUNCH(uint16_t, int32_t, 4); }
+    if (bpc == 8) { if (waves == 4) SB_LAUNCH(uint8_t, int16_t, 4); else SB_LAUNCH(uint8_t, int16_t, 8); }
+    else { if (waves == 4) SB_LAUNCH(uint16_t, int32_t, 4); else SB_LAUNCH(uint16_t, int32_t, 8); }
 #undef SB_LAUNCH
     return hip_rc(hipGetLastError());
 }
@@ -277,18 +301,23 @@ extern "C" int dav1d_hip_launch_intra_sb(const DevPlanes *dst, int bpc, int layo
 // ---------------------------------------------------------------------------------------------------- host side
 
 // Units sorted by step (dav1d_hip_intra_units_build: per step the units with a prediction [.. ua_end[s]), then the residuals on
-// their own [.. ub_end[s])) -> the same units sorted by (superblock, step, kind), with the size of its group in every unit and
-// one SbPart per superblock met.  strides: of the picture's planes in pixels.  out: room for units.size() records (the frame's
-// pinned unit arena, or any array); units itself only gets its `need` fields written.
-int dav1d_hip_sbw_sort(std::vector<IntraUnit> &units, const std::vector<uint32_t> &ua_end, const std::vector<uint32_t> &ub_end,
-                            const SbTiling &tl, const int strides[3], const int ss_hor, const int ss_ver, std::vector<SbPart> &parts, IntraUnit *out)
+// their own [.. ub_end[s])) -> one run of records per superblock met: a HEADER record, then the superblock's units sorted by (step,
+// kind).  A unit carries the dense index of its group (grp) and the index of the unit the same wave works on next — units of a
+// group are dealt to the waves round-robin — for workgroups of four (pad2) and eight waves (prev_n); the header (read as 32-bit
+// words) holds the number of groups [0], 0 in the place of `has` [1] and the first unit of every wave, [2 .. 5] for four waves,
+// [6 .. 13] for eight.  With the chains a wave has the record after next in flight and the coefficients of its next unit on their
+// way while it works (intra_sb_kernel).  strides: of the picture's planes in pixels.  prepare() says how many records there will
+// be (st.n_records = units + superblocks), emit() writes them to `out` (the frame's pinned unit arena, or any array).
+int dav1d_hip_sbw_prepare(std::vector<IntraUnit> &units, const std::vector<uint32_t> &ua_end, const std::vector<uint32_t> &ub_end,
+                          const SbTiling &tl, const int strides[3], const int ss_hor, const int ss_ver, SbSort &st)
 {
-    parts.clear();
+    st.parts.clear(); st.pos.clear(); st.key.clear(); st.n_records = 0;
     const size_t n = units.size();
     if (!n) return 0;
     if (tl.sb_log2 != 6 && tl.sb_log2 != 7) return -EINVAL;
     const int sbw = tl.sbw;
-    std::vector<uint32_t> sb(n), key(n);
+    std::vector<uint32_t> sb(n);
+    st.key.resize(n); st.pos.resize(n);
     uint32_t lo = 0xffffffffu, hi = 0;
     size_t s = 0;
     for (size_t i = 0; i < n; i++) {
@@ -304,31 +333,57 @@ int dav1d_hip_sbw_sort(std::vector<IntraUnit> &units, const std::vector<uint32_t
         const int sx = x >> tl.sb_log2, sy = y >> tl.sb_log2;
         if (sx >= sbw || sy >= tl.sbh) return -EINVAL;
         sb[i] = (uint32_t) (sy * sbw + sx);
-        key[i] = (uint32_t) s * 2 + (i >= ua_end[s]);
+        st.key[i] = (uint32_t) s * 2 + (i >= ua_end[s]);
         lo = std::min(lo, sb[i]); hi = std::max(hi, sb[i]);
     }
-    // stable counting sort by superblock (the units of a submission sit in a short run of superblock numbers)
+    // stable counting sort by superblock (the units of a submission sit in a short run of superblock numbers); superblock j of
+    // the submission starts j records later than its units alone would: its header and those of the superblocks before it
     const size_t span = (size_t) hi - lo + 1;
     std::vector<uint32_t> cnt(span + 1, 0);
     for (size_t i = 0; i < n; i++) cnt[sb[i] - lo + 1]++;
     for (size_t k = 0; k < span; k++) cnt[k + 1] += cnt[k];
-    std::vector<uint32_t> okey(n);
-    {
-        std::vector<uint32_t> pos(cnt.begin(), cnt.end() - 1);
-        for (size_t i = 0; i < n; i++) { const uint32_t p = pos[sb[i] - lo]++; out[p] = units[i]; okey[p] = key[i]; }
+    std::vector<uint32_t> hdrs(span, 0);
+    for (size_t k = 0, j = 0; k < span; k++) {
+        if (cnt[k] == cnt[k + 1]) continue;
+        st.parts.push_back({ (uint32_t) (lo + k), (uint32_t) (cnt[k] + j), cnt[k + 1] - cnt[k] });
+        hdrs[k] = (uint32_t) ++j;
     }
-    for (size_t k = 0; k < span; k++) {
-        const uint32_t a = cnt[k], b = cnt[k + 1];
-        if (a == b) continue;
-        parts.push_back({ (uint32_t) (lo + k), a, b - a });
-        for (uint32_t i = a; i < b; ) {
+    {
+        std::vector<uint32_t> at(cnt.begin(), cnt.end() - 1);
+        for (size_t i = 0; i < n; i++) st.pos[i] = at[sb[i] - lo]++ + hdrs[sb[i] - lo];
+    }
+    st.n_records = n + st.parts.size();
+    return 0;
+}
+
+void dav1d_hip_sbw_emit(const std::vector<IntraUnit> &units, const SbSort &st, IntraUnit *out)
+{
+    const size_t n = units.size();
+    std::vector<uint32_t> okey(st.n_records, 0);
+    for (size_t i = 0; i < n; i++) { out[st.pos[i]] = units[i]; okey[st.pos[i]] = st.key[i]; }
+    for (const SbPart &p : st.parts) {
+        IntraUnit *const hdr = out + p.first, *const us = hdr + 1;
+        const uint32_t *const k = okey.data() + p.first + 1;
+        memset(hdr, 0, sizeof(*hdr));
+        uint32_t *const hw = reinterpret_cast<uint32_t *>(hdr);
+        uint32_t last4[4], last8[8];
+        for (int w = 0; w < 4; w++) { last4[w] = SB_NONE; hw[2 + w] = SB_NONE; }
+        for (int w = 0; w < 8; w++) { last8[w] = SB_NONE; hw[6 + w] = SB_NONE; }
+        uint32_t groups = 0;
+        for (uint32_t i = 0; i < p.n; groups++) {
             uint32_t j = i + 1;
-            while (j < b && okey[j] == okey[i]) j++;
-            for (uint32_t q = i; q < j; q++) { out[q].prev_n = j - i; out[q].grp = okey[i]; }
+            while (j < p.n && k[j] == k[i]) j++;
+            for (uint32_t q = i; q < j; q++) {
+                us[q].grp = groups; us[q].prev_n = SB_NONE; us[q].pad2 = SB_NONE;
+                const uint32_t w4 = (q - i) & 3, w8 = (q - i) & 7;
+                if (last4[w4] == SB_NONE) hw[2 + w4] = q; else us[last4[w4]].pad2 = q;
+                if (last8[w8] == SB_NONE) hw[6 + w8] = q; else us[last8[w8]].prev_n = q;
+                last4[w4] = q; last8[w8] = q;
+            }
             i = j;
         }
+        hw[0] = groups;
     }
-    return 0;
 }
 
 // level[k] of parts' superblocks: 0 where no neighbour (left, top-left, top, top-right, inside the same tile) holds units, else one
@@ -394,9 +449,9 @@ int dav1d_hip_sbw_plan(const SbTiling &tl, const std::vector<const std::vector<S
     std::vector<SbRegion> reg;
     for (size_t k = 0; k < parts.size(); k++)
         for (const SbPart &p : *parts[k]) {
-            if (base[k] + p.first + p.n > 0xffffffffu) return -ENOTSUP;
+            if (base[k] + p.first + p.n + 1 > 0xffffffffu) return -ENOTSUP;
             sbs.push_back(p.sb);
-            reg.push_back({ (uint32_t) (base[k] + p.first), p.n, (uint16_t) ((p.sb % (uint32_t) tl.sbw) << tl.sb_log2), (uint16_t) ((p.sb / (uint32_t) tl.sbw) << tl.sb_log2), 0 });
+            reg.push_back({ (uint32_t) (base[k] + p.first), p.n + 1, (uint16_t) ((p.sb % (uint32_t) tl.sbw) << tl.sb_log2), (uint16_t) ((p.sb / (uint32_t) tl.sbw) << tl.sb_log2), 0 });
         }
     std::vector<int> level_of_sb;
     std::vector<uint32_t> level;

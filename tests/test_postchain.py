@@ -187,7 +187,7 @@ def hip_intra(ctx, ip, pic, timed=False, graph=False, paired=True, flow=False, s
     return ms
 
 
-@pytest.mark.parametrize("paired", [True, False, "flow", "sb"], ids=["paired", "two-launches", "one-launch", "superblocks"])
+@pytest.mark.parametrize("paired", [True, False, "flow", "sb", "sb-lds"], ids=["paired", "two-launches", "one-launch", "superblocks", "superblocks-lds"])
 @pytest.mark.parametrize("bpc", [8, 10, 12])
 def test_intra_wavefront_pass_matches_oracle(ctx, bpc, paired):
     oracle = util.default_oracle()
@@ -202,7 +202,12 @@ def test_intra_wavefront_pass_matches_oracle(ctx, bpc, paired):
         pic.upload(pl, planes[pl])
     want = synth.copy_planes(planes)
     oracle_intra(oracle, ip, want, w, h, bpc)
-    hip_intra(ctx, ip, pic, paired=paired is True, flow=paired == "flow", sb=paired == "sb")
+    if paired == "sb-lds":
+        ctx.set_option("intra_sb_lds", 1)
+    try:
+        hip_intra(ctx, ip, pic, paired=paired is True, flow=paired == "flow", sb=paired in ("sb", "sb-lds"))
+    finally:
+        ctx.set_option("intra_sb_lds", 0)
     for pl in range(3):
         vh, vw = (h, w) if pl == 0 else (h // 2, w // 2)
         bad = np.argwhere(pic.download(pl)[:vh, :vw] != want[pl][:vh, :vw])

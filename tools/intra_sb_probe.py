@@ -54,8 +54,10 @@ def main():
         planes = synth.make_planes(rng, w, h, 10, smooth=True)
         pics = {}
         res = {}
-        for name, kw in (("enqueued", {}), ("graph", {"graph": True}), ("superblocks_lds", {"sb": True}), ("superblocks_l2", {"sb": True})):
-            ctx.lib.dav1d_hip_set_option(ctx.h, b"intra_sb_lds", 0 if name.endswith("l2") else 1)
+        for name, kw in (("enqueued", {}), ("graph", {"graph": True}), ("superblocks_lds_w4", {"sb": True}), ("superblocks_lds_w8", {"sb": True}),
+                         ("superblocks_l2_w4", {"sb": True}), ("superblocks_l2_w8", {"sb": True})):
+            ctx.lib.dav1d_hip_set_option(ctx.h, b"intra_sb_lds", 0 if "_l2" in name else 1)
+            ctx.lib.dav1d_hip_set_option(ctx.h, b"intra_sb_waves", 8 if name.endswith("w8") else 4)
             for rep in range(2):
                 pic = ctx.picture(w, h, api.LAYOUT_I420, 10)
                 for pl in range(3):
