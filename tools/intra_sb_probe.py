@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--tiles", default="16x8")
     ap.add_argument("--modes", default="2,0")
     ap.add_argument("--lds", default="1,0", help="intra_sb_lds values to try with intra_sb = 2")
+    ap.add_argument("--waves", default="0", help="intra_sb_waves values to try with intra_sb = 2 (0: the default)")
     ap.add_argument("--no-pass", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--sizes", action="store_true", help="the intra pass with every region of ONE block size, per size: time per step of each route")
@@ -38,11 +39,13 @@ def main():
     ctx.backend = "hip"
     out = {}
     ldss = [int(v) for v in a.lds.split(",")]
-    combos = [(m, l) for m in [int(v) for v in a.modes.split(",")] for l in (ldss if m else ldss[:1])]
-    for mode, lds in ([] if a.no_e2e else combos):
+    wvs = [int(v) for v in a.waves.split(",")]
+    combos = [(m, l, wv) for m in [int(v) for v in a.modes.split(",")] for l in (ldss if m else ldss[:1]) for wv in (wvs if m and not l else wvs[:1])]
+    for mode, lds, wv in ([] if a.no_e2e else combos):
         assert ctx.lib.dav1d_hip_set_option(ctx.h, b"intra_sb", mode) == 0
         assert ctx.lib.dav1d_hip_set_option(ctx.h, b"intra_sb_lds", lds) == 0
-        tag = "intra_sb_%d_lds_%d" % (mode, lds) if mode else "intra_sb_0"
+        assert ctx.lib.dav1d_hip_set_option(ctx.h, b"intra_sb_waves", wv) == 0
+        tag = "intra_sb_%d_lds_%d_w%d" % (mode, lds, wv) if mode else "intra_sb_0"
         chk = None if a.no_check else (lambda ho, planes, refs: lu.check_handoff_against_reference(ho, planes, refs, is_inter=False))
         out["key_frame_" + tag] = e2e.run(ctx, w, h, 10, frames=4, threads=64, tile_cols=tc, tile_rows=tr, key_frame=True, seed=0xE2F, check=chk)
         chk = None if a.no_check else (lambda ho, planes, refs: lu.check_handoff_against_reference(ho, planes, refs, is_inter=True))
@@ -54,10 +57,10 @@ def main():
         planes = synth.make_planes(rng, w, h, 10, smooth=True)
         pics = {}
         res = {}
-        for name, kw in (("enqueued", {}), ("graph", {"graph": True}), ("superblocks_lds_w4", {"sb": True}), ("superblocks_lds_w8", {"sb": True}),
+        for name, kw in (("enqueued", {}), ("graph", {"graph": True}), ("superblocks_lds_w8", {"sb": True}),
                          ("superblocks_l2_w4", {"sb": True}), ("superblocks_l2_w8", {"sb": True})):
             ctx.lib.dav1d_hip_set_option(ctx.h, b"intra_sb_lds", 0 if "_l2" in name else 1)
-            ctx.lib.dav1d_hip_set_option(ctx.h, b"intra_sb_waves", 8 if name.endswith("w8") else 4)
+            ctx.lib.dav1d_hip_set_option(ctx.h, b"intra_sb_waves", int(name.rsplit("w", 1)[1]) if "_w" in name else 0)
             for rep in range(2):
                 pic = ctx.picture(w, h, api.LAYOUT_I420, 10)
                 for pl in range(3):
