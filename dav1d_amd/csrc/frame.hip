@@ -214,12 +214,13 @@ static int post_filters_pipelined(Dav1dHipFrame *f, const Dav1dHipPicture **last
     if (rc) return rc;
     // CDEF: units that sit side by side share a wave (cdef.hip, strip kernel); the groups of every band, band after band
     std::vector<CdefGroup> cgroups;
-    std::vector<size_t> cg_off(nb + 1, 0);
+    std::vector<size_t> cg_off(nb + 1, 0), raw_in_band(nb, 0);
     const DevPlanes cur_p = dev_planes(&f->cur);
     const bool strips = has_cdef && !c->cdef_unit_kernel && dav1d_hip_cdef_strip_ok(&cur_p, &cur_p, f->cur.bpc);
     if (strips)
         for (int k = 0; k < nb; k++) {
-            (void) dav1d_hip_cdef_make_groups(cdef_s.data() + cdef_off[k], cdef_off[k + 1] - cdef_off[k], cdef_off[k], cgroups);
+            // (tasks with the RAW flag — DSP-level callers — are not grouped: the band runs them through the unit kernel as well)
+            raw_in_band[k] = dav1d_hip_cdef_make_groups(cdef_s.data() + cdef_off[k], cdef_off[k + 1] - cdef_off[k], cdef_off[k], cgroups);
             cg_off[k + 1] = cgroups.size();
         }
     // self-guided restoration: the units of a row share waves (lr.hip); rows and waves per band
@@ -256,7 +257,12 @@ static int post_filters_pipelined(Dav1dHipFrame *f, const Dav1dHipPicture **last
         std::vector<int> first_y(nb + 1, H);
         for (size_t i = 0; i < f->lr.size(); i++)
             first_y[lr_b[i]] = std::min(first_y[lr_b[i]], (int) f->lr[i].y << (f->lr[i].plane ? ss_ver : 0));
-        for (int b = nb - 1; b >= 0; b--) { first_y[b] = std::min(first_y[b], first_y[b + 1]); final_rows[b] = first_y[b + 1]; }
+        // (when the NEXT band lists no unit, first_y comes from a later band: the rows are capped by what CDEF has finished when this
+        // band's restoration ends — it waited for CDEF of the next band, whose last 8 rows the band after that may still change)
+        for (int b = nb - 1; b >= 0; b--) {
+            first_y[b] = std::min(first_y[b], first_y[b + 1]);
+            final_rows[b] = b + 1 == nb ? H : std::min(first_y[b + 1], std::min(H, (b + 2) * band_h) - 8);
+        }
     }
     const Dav1dHipPicture *cdef_out = has_cdef ? &f->tmp[0] : &f->cur;
     if (!rc) {
@@ -291,9 +297,12 @@ static int post_filters_pipelined(Dav1dHipFrame *f, const Dav1dHipPicture **last
                                                      (size_t) f->cur.p[pl].w * bps, r1 - r0, hipMemcpyDeviceToDevice, sb));
                 }
                 if (rc) break;
-                if (n && strips) rc = dav1d_hip_launch_cdef_groups(&t0, &cur, f->cur.bpc, layout, d_cdef, d_cg + cg_off[bc], (int) (cg_off[bc + 1] - cg_off[bc]),
-                                                                   f->cdef_damping, nullptr, sb);
-                else if (n) rc = dav1d_hip_launch_cdef(&t0, &cur, f->cur.bpc, layout, d_cdef + cdef_off[bc], (int) n, f->cdef_damping, nullptr, 0, sb);
+                if (n && strips) {
+                    rc = dav1d_hip_launch_cdef_groups(&t0, &cur, f->cur.bpc, layout, d_cdef, d_cg + cg_off[bc], (int) (cg_off[bc + 1] - cg_off[bc]),
+                                                      f->cdef_damping, nullptr, sb);
+                    if (!rc && raw_in_band[bc])
+                        rc = dav1d_hip_launch_cdef(&t0, &cur, f->cur.bpc, layout, d_cdef + cdef_off[bc], (int) n, f->cdef_damping, nullptr, 1, sb);
+                } else if (n) rc = dav1d_hip_launch_cdef(&t0, &cur, f->cur.bpc, layout, d_cdef + cdef_off[bc], (int) n, f->cdef_damping, nullptr, 0, sb);
                 (void) hipEventRecord(ev[nb + bc], sb);
                 if (!has_lr) (void) hipEventRecord(ev[2 * nb + bc], sb);
             }
