@@ -25,6 +25,8 @@ struct Dav1dHipContext {
     int flow_groups;            // workgroups of the intra dataflow launch ($DAV1D_HIP_FLOW_GROUPS at open, default 512; every wave has to be resident: units are dealt out round-robin)
     int intra_sb;               // the intra wavefront superblock by superblock (intra_sb.hip; $DAV1D_HIP_INTRA_SB / option intra_sb): 0 never,
                                 // 1 for wavefronts of at least flow_min_steps steps, 2 (default) for every frame whose tiling is known
+    int intra_sb_flow;          // 1 (default): every level of a frame's superblocks in ONE launch, a superblock waiting for the flags of the neighbours it reads
+                                // ($DAV1D_HIP_INTRA_SB_FLOW / option intra_sb_flow); 0: a launch per level
     int intra_sb_lds;           // 1: the superblock's pixels stay in LDS where that form exists (4:2:0); 0 (default): handed over through the L2 — measured
                                 // equal or a little faster ($DAV1D_HIP_INTRA_SB_LDS / option intra_sb_lds)
     int intra_sb_waves;         // waves per workgroup of that route: 4, 8 or 0 = the kernel form's own choice ($DAV1D_HIP_INTRA_SB_WAVES / option intra_sb_waves)
@@ -272,7 +274,7 @@ extern "C" size_t dav1d_hip_intra_flow_units(const Dav1dHipIntraFlow *l);
 extern "C" int dav1d_hip_intra_flow_status(Dav1dHipContext *c, const Dav1dHipIntraFlow *l, uint32_t out[3]);
 
 // ---- the intra wavefront superblock by superblock (intra_sb.hip): one workgroup per superblock, a launch per level
-struct SbRegion { uint32_t first, n; uint16_t x0, y0; uint32_t pad; };   // device: the superblock's records (header, then units) [first, first + n), its luma origin
+struct SbRegion { uint32_t first, n; uint16_t x0, y0; uint32_t pad; uint32_t dep[4]; };   // device: the superblock's records (header, then units) [first, first + n), its luma origin
 struct SbPart { uint32_t sb, first, n; };          // host: superblock number (raster, frame-wide) and its run in a sorted unit array
 struct SbTiling {                                   // the frame's tiles in superblocks (frame_hdr->tiling.col_start_sb / row_start_sb)
     int sb_log2, sbw, sbh, n_cols, n_rows;
@@ -290,7 +292,7 @@ int dav1d_hip_sbw_prepare(std::vector<IntraUnit> &units, const std::vector<uint3
 void dav1d_hip_sbw_emit(const std::vector<IntraUnit> &units, const SbSort &st, IntraUnit *out);
 int dav1d_hip_sbw_levels(const SbTiling &tl, const uint32_t *sbs, size_t n, const uint8_t *dep, std::vector<int> &level_of_sb, std::vector<uint32_t> &level);
 extern "C" int dav1d_hip_launch_intra_sb(const DevPlanes *dst, int bpc, int layout, const IntraUnit *units, const SbRegion *regions, int n_regions,
-                                         uint8_t *aux, void *coef, int waves, int sb_log2, int lds, void *stream);
+                                         uint8_t *aux, void *coef, int waves, int sb_log2, int lds, uint32_t *flags, void *stream);
 // regions sorted by level + where each level starts, from the parts of any number of unit arrays laid end to end (base[k] = where
 // array k starts): host-side plan of a frame's launches
 struct SbPlan { std::vector<SbRegion> regions; std::vector<uint32_t> level_start; /* n_levels + 1 */ };

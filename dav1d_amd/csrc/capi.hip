@@ -64,6 +64,7 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     c->intra_sb = isb ? atoi(isb) : 2;
     c->intra_sb_waves = (int) env_int("DAV1D_HIP_INTRA_SB_WAVES", 0);
     c->intra_sb_lds = (int) env_int("DAV1D_HIP_INTRA_SB_LDS", 0);
+    c->intra_sb_flow = (int) env_int("DAV1D_HIP_INTRA_SB_FLOW", 1);
     for (int i = 0; i < Dav1dHipContext::N_SIDE; i++) {
         if (hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
@@ -177,6 +178,7 @@ int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value) {
     else if (!strcmp(name, "intra_sb")) c->intra_sb = (int) value;
     else if (!strcmp(name, "intra_sb_waves")) c->intra_sb_waves = value >= 8 ? 8 : value >= 4 ? 4 : 0;
     else if (!strcmp(name, "intra_sb_lds")) c->intra_sb_lds = value != 0;
+    else if (!strcmp(name, "intra_sb_flow")) c->intra_sb_flow = value != 0;
     else if (!strcmp(name, "chunk_order")) c->chunk_order = value != 0;
     else if (!strcmp(name, "chunk_arena_min")) { if (value < 4096) return -EINVAL; c->arena_min = (size_t) 1 << 12; while (c->arena_min < (size_t) value) c->arena_min <<= 1; c->arena_hint = 0; }
     else return -EINVAL;
@@ -2251,6 +2253,7 @@ int dav1d_hip_intra_flow_run(Dav1dHipContext *c, const Dav1dHipIntraFlow *l, con
 struct Dav1dHipIntraSb {
     IntraUnit *units;
     SbRegion *regions;
+    uint32_t *flags;            // n_regions + 1 words for the one-launch form
     std::vector<uint32_t> level_start;
     size_t n_units, n_regions;
     int sb_log2;
@@ -2262,6 +2265,7 @@ void dav1d_hip_intra_sb_destroy(Dav1dHipContext *c, Dav1dHipIntraSb *l) {
     hipStreamSynchronize(c->stream);
     if (l->units) hipFree(l->units);
     if (l->regions) hipFree(l->regions);
+    if (l->flags) hipFree(l->flags);
     delete l;
 }
 size_t dav1d_hip_intra_sb_levels(const Dav1dHipIntraSb *l) { return l && !l->level_start.empty() ? l->level_start.size() - 1 : 0; }
@@ -2301,7 +2305,7 @@ int dav1d_hip_intra_sb_create(Dav1dHipContext *c, Dav1dHipIntraSb **out, const D
     if (rc) return rc;
     Dav1dHipIntraSb *l = new (std::nothrow) Dav1dHipIntraSb();
     if (!l) return -ENOMEM;
-    l->units = nullptr; l->regions = nullptr;
+    l->units = nullptr; l->regions = nullptr; l->flags = nullptr;
     l->n_units = units.size(); l->n_regions = plan.regions.size();
     l->level_start = plan.level_start;
     l->sb_log2 = tl.sb_log2;
@@ -2309,6 +2313,7 @@ int dav1d_hip_intra_sb_create(Dav1dHipContext *c, Dav1dHipIntraSb **out, const D
     if (l->n_units) {
         if (hipMalloc((void **) &l->units, (l->n_units + 1) * sizeof(IntraUnit)) != hipSuccess) rc = -ENOMEM;
         if (!rc && hipMalloc((void **) &l->regions, l->n_regions * sizeof(SbRegion)) != hipSuccess) rc = -ENOMEM;
+        if (!rc && hipMalloc((void **) &l->flags, (l->n_regions + 1) * sizeof(uint32_t)) != hipSuccess) rc = -ENOMEM;
         if (!rc) rc = dav1d_hip_upload(c, l->units, units.data(), l->n_units * sizeof(IntraUnit));
         if (!rc) rc = dav1d_hip_upload(c, l->regions, plan.regions.data(), l->n_regions * sizeof(SbRegion));
     }
@@ -2317,14 +2322,20 @@ int dav1d_hip_intra_sb_create(Dav1dHipContext *c, Dav1dHipIntraSb **out, const D
     return 0;
 }
 
-// enqueues one launch per level on the context's stream
+// enqueues the launches on the context's stream: one per level, or (option intra_sb_flow, L2 hand-off form, more than one level) ONE
+// for all of them with the superblocks waiting for their neighbours' flags
 int dav1d_hip_intra_sb_run(Dav1dHipContext *c, const Dav1dHipIntraSb *l, const Dav1dHipPicture *dst, void *coef, uint8_t *aux) {
     if (!c || !l || !dst || (l->needs_aux && !aux)) return -EINVAL;
     const DevPlanes dp = dev_planes(dst);
     int rc = 0;
+    if (c->intra_sb_flow && !c->intra_sb_lds && l->level_start.size() > 2) {
+        if (hipMemsetAsync(l->flags, 0, (l->n_regions + 1) * sizeof(uint32_t), c->stream) != hipSuccess) return -EIO;
+        return dav1d_hip_launch_intra_sb(&dp, dst->bpc, dst->layout, l->units, l->regions, (int) l->n_regions, aux, coef, c->intra_sb_waves, l->sb_log2, 0,
+                                         l->flags, c->stream);
+    }
     for (size_t k = 0; k + 1 < l->level_start.size() && !rc; k++)
         rc = dav1d_hip_launch_intra_sb(&dp, dst->bpc, dst->layout, l->units, l->regions + l->level_start[k],
-                                       (int) (l->level_start[k + 1] - l->level_start[k]), aux, coef, c->intra_sb_waves, l->sb_log2, c->intra_sb_lds, c->stream);
+                                       (int) (l->level_start[k + 1] - l->level_start[k]), aux, coef, c->intra_sb_waves, l->sb_log2, c->intra_sb_lds, nullptr, c->stream);
     return rc;
 }
 

@@ -1096,18 +1096,30 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
             if (!rc && needs_aux && !f->aux) rc = -EINVAL;
             const size_t ub = total * sizeof(IntraUnit), rb = plan.regions.size() * sizeof(SbRegion);
             if (!rc && total) {
-                TaskBuf dev_buf(c, ub + rb + 256);
+                const bool one_launch = c->intra_sb_flow && !c->intra_sb_lds && plan.level_start.size() > 2;
+                const size_t fb = (plan.regions.size() + 1) * sizeof(uint32_t), o_flags = (ub + rb + 255) & ~(size_t) 255;
+                TaskBuf dev_buf(c, o_flags + fb + 256);
                 uint8_t *const dev = dev_buf.p;
                 if (!dev) rc = -ENOMEM;
                 if (!rc) rc = hip_rc(hipMemcpyAsync(dev, host, ub, hipMemcpyHostToDevice, c->stream));
+                if (!rc && one_launch) rc = hip_rc(hipMemsetAsync(dev + o_flags, 0, fb, c->stream));
                 if (!rc) rc = dav1d_hip_upload(c, dev + ub, plan.regions.data(), rb);
                 const auto t_b = std::chrono::steady_clock::now();
                 const DevPlanes dp = dev_planes(&f->cur);
+                if (one_launch) {
+                    // every level in one launch: superblocks wait for the flags of the neighbours they read (intra_sb.hip)
+                    if (!rc) rc = dav1d_hip_launch_intra_sb(&dp, f->cur.bpc, f->cur.layout, reinterpret_cast<const IntraUnit *>(dev),
+                                                            reinterpret_cast<const SbRegion *>(dev + ub), (int) plan.regions.size(), f->aux, coef,
+                                                            c->intra_sb_waves, f->tiling.sb_log2, 0, reinterpret_cast<uint32_t *>(dev + o_flags), c->stream);
+                    uint32_t gave_up = 0;
+                    if (!rc) rc = dav1d_hip_download(c, &gave_up, dev + o_flags + plan.regions.size() * sizeof(uint32_t), sizeof(gave_up));
+                    if (!rc && gave_up) rc = -EIO;
+                } else
                 for (size_t l = 0; l + 1 < plan.level_start.size() && !rc; l++)
                     rc = dav1d_hip_launch_intra_sb(&dp, f->cur.bpc, f->cur.layout, reinterpret_cast<const IntraUnit *>(dev),
                                                    reinterpret_cast<const SbRegion *>(dev + ub) + plan.level_start[l],
                                                    (int) (plan.level_start[l + 1] - plan.level_start[l]), f->aux, coef, c->intra_sb_waves, f->tiling.sb_log2,
-                                                   c->intra_sb_lds, c->stream);
+                                                   c->intra_sb_lds, nullptr, c->stream);
                 // the device copy of the units goes back to the pool when this scope ends: the launches have to be through by then
                 const int rs = hip_rc(hipStreamSynchronize(c->stream));
                 if (!rc) rc = rs;

@@ -27,6 +27,7 @@ namespace {
 constexpr int sb_itx_lds_of(int tx) {
     return (64 / cmax(cmin(tx_h(tx), 32), tx_w(tx))) * cmin(tx_h(tx), 32) * (tx_w(tx) + 1);
 }
+enum { SB_SPIN_LIMIT = 1 << 18 };        // naps of ~2 µs before a waiting workgroup gives up (a bug, never a normal run)
 constexpr int sb_itx_lds_max(int tx = 0) { return tx == 19 ? 0 : cmax(sb_itx_lds_of(tx), sb_itx_lds_max(tx + 1)); }
 
 
@@ -38,7 +39,9 @@ template <int NW> __device__ __forceinline__ uint32_t sb_next(const IntraUnit &u
 template <typename pixel, typename coef, int SB_WAVES>
 __global__ __launch_bounds__(SB_WAVES * 64, 2) void intra_sb_kernel(const DevPlanes dst, const IntraUnit *__restrict__ units,
                                                                      const SbRegion *__restrict__ regions, uint8_t *aux,
-                                                                     coef *__restrict__ cf, const int layout, const int bitdepth_max)
+                                                                     coef *__restrict__ cf, const int layout, const int bitdepth_max,
+                                                                     uint32_t *flags /* ONE launch for every level: a word per superblock (+ the error word behind them), or nullptr */,
+                                                                     const int n_regions)
 {
     __shared__ int16_t e1_s[SB_WAVES][ESZ], e2_s[SB_WAVES][ESZ];
     __shared__ int16_t blk_s[SB_WAVES][32 * 32];
@@ -52,6 +55,27 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void intra_sb_kernel(const DevPla
     int *const smem_itx = reinterpret_cast<int *>(smem_s[wv]);
 
     const SbRegion r = regions[blockIdx.x];
+    if (flags) {
+        // Every level in one launch: the superblocks this one reads from (r.dep, all earlier in the array) have to be through.
+        // Workgroups are dispatched in the order of their index, so whoever is waited for is running or done — no workgroup waits for
+        // one that cannot start.  The neighbours' pixels were stored plainly and written back by the release fence at their end;
+        // here one lane polls, then an acquire fence, and the edge reads are loads that bypass the L1 anyway.
+        if (threadIdx.x == 0) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (r.dep[k] == SB_NONE) continue;
+                int spins = 0;
+                while (dv::ld_coherent(flags + r.dep[k]) == 0u) {
+                    dv::nap_long();
+                    if (++spins > SB_SPIN_LIMIT) { ok = false; break; }
+                }
+            }
+            if (!ok) atomicAdd(flags + n_regions, 1u);          // never in a sound run: the frame comes back -EIO
+            dv::fence_acquire_agent();
+        }
+        __syncthreads();
+    }
     const IntraUnit *const ru = units + r.first, *const us = ru + 1;       // header record, then the units
     const uint32_t *const hdr = reinterpret_cast<const uint32_t *>(ru);
     const uint32_t n_groups = (uint32_t) __builtin_amdgcn_readfirstlane((int) hdr[0]);
@@ -114,6 +138,10 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void intra_sb_kernel(const DevPla
         }
         dv::stores_done();                   // this wave's pixels have reached the L2 ...
         __syncthreads();                     // ... and so have the other waves': the next group may read them
+    }
+    if (flags && threadIdx.x == 0) {
+        dv::fence_release_agent();           // the XCD's L2 writes the superblock's pixels back: other XCDs may read them
+        dv::st_coherent(flags + blockIdx.x, 1u);
     }
 }
 
@@ -266,13 +294,15 @@ __global__ __launch_bounds__(NW * 64, SBL2 == 6 ? 2 : 1) void intra_sbl_kernel(c
 
 } // namespace
 
+// flags != nullptr: regions[0 .. n_regions) are EVERY level of the frame in level order and run as one launch (L2 hand-off form only;
+// flags = n_regions + 1 zeroed words, the last one counts workgroups that gave up waiting).
 // waves: workgroup size in waves, 4 or 8 (0: the form's own choice).  lds: the LDS-resident form where it exists (4:2:0 / 4:0:0 pictures).
 extern "C" int dav1d_hip_launch_intra_sb(const DevPlanes *dst, int bpc, int layout, const IntraUnit *units, const SbRegion *regions, int n_regions,
-                                         uint8_t *aux, void *coef, int waves, int sb_log2, int lds, void *stream)
+                                         uint8_t *aux, void *coef, int waves, int sb_log2, int lds, uint32_t *flags, void *stream)
 {
     if (n_regions <= 0) return 0;
     const int bitdepth_max = (1 << bpc) - 1;
-    if (lds && (layout == DAV1D_HIP_LAYOUT_I420 || layout == DAV1D_HIP_LAYOUT_I400) && (sb_log2 == 6 || sb_log2 == 7)) {
+    if (lds && !flags && (layout == DAV1D_HIP_LAYOUT_I420 || layout == DAV1D_HIP_LAYOUT_I400) && (sb_log2 == 6 || sb_log2 == 7)) {
         // 128-pixel superblocks: the image leaves room for four waves' worth of scratch (160 KB of LDS per CU).  64-pixel ones: four
         // waves and two workgroups per CU (waves = 0 or 4: a superblock's steps are mostly narrower than four units, two superblocks
         // in flight keep the CU busier), or eight waves and one workgroup (waves = 8)
@@ -291,7 +321,7 @@ extern "C" int dav1d_hip_launch_intra_sb(const DevPlanes *dst, int bpc, int layo
         return hip_rc(hipGetLastError());
     }
 #define SB_LAUNCH(P, Cf, NW) hipLaunchKernelGGL((intra_sb_kernel<P, Cf, NW>), dim3(n_regions), dim3(NW * 64), 0, (hipStream_t) stream, *dst, units, regions, \
-                                                aux, (Cf *) coef, layout, bitdepth_max)
+                                                aux, (Cf *) coef, layout, bitdepth_max, flags, n_regions)
     if (bpc == 8) { if (waves == 4) SB_LAUNCH(uint8_t, int16_t, 4); else SB_LAUNCH(uint8_t, int16_t, 8); }
     else { if (waves == 4) SB_LAUNCH(uint16_t, int32_t, 4); else SB_LAUNCH(uint16_t, int32_t, 8); }
 #undef SB_LAUNCH
@@ -451,7 +481,7 @@ int dav1d_hip_sbw_plan(const SbTiling &tl, const std::vector<const std::vector<S
         for (const SbPart &p : *parts[k]) {
             if (base[k] + p.first + p.n + 1 > 0xffffffffu) return -ENOTSUP;
             sbs.push_back(p.sb);
-            reg.push_back({ (uint32_t) (base[k] + p.first), p.n + 1, (uint16_t) ((p.sb % (uint32_t) tl.sbw) << tl.sb_log2), (uint16_t) ((p.sb / (uint32_t) tl.sbw) << tl.sb_log2), 0 });
+            reg.push_back({ (uint32_t) (base[k] + p.first), p.n + 1, (uint16_t) ((p.sb % (uint32_t) tl.sbw) << tl.sb_log2), (uint16_t) ((p.sb / (uint32_t) tl.sbw) << tl.sb_log2), 0, { SB_NONE, SB_NONE, SB_NONE, SB_NONE } });
         }
     std::vector<int> level_of_sb;
     std::vector<uint32_t> level;
@@ -472,5 +502,28 @@ int dav1d_hip_sbw_plan(const SbTiling &tl, const std::vector<const std::vector<S
     for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t) i;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return level[a] != level[b] ? level[a] < level[b] : reg[a].n > reg[b].n; });
     for (size_t i = 0; i < order.size(); i++) plan.regions[i] = reg[order[i]];
+    // whom a superblock waits for when the levels run as ONE launch (intra_sb_kernel, flags): the positions, in this order, of the
+    // neighbours that set its level — the same rule as dav1d_hip_sbw_levels, so each of them sits earlier in the array
+    std::vector<uint32_t> where((size_t) tl.sbw * tl.sbh, SB_NONE);
+    for (size_t i = 0; i < order.size(); i++) where[sbs[order[i]]] = (uint32_t) i;
+    std::vector<int> tile_x0(tl.sbw, 0), tile_x1(tl.sbw, 0), tile_y0(tl.sbh, 0);
+    for (int tc = 0; tc < tl.n_cols; tc++)
+        for (int x = tl.col_start[tc]; x < std::min<int>(tl.col_start[tc + 1], tl.sbw); x++) { tile_x0[x] = tl.col_start[tc]; tile_x1[x] = std::min<int>(tl.col_start[tc + 1], tl.sbw); }
+    for (int tr = 0; tr < tl.n_rows; tr++)
+        for (int y = tl.row_start[tr]; y < std::min<int>(tl.row_start[tr + 1], tl.sbh); y++) tile_y0[y] = tl.row_start[tr];
+    for (size_t i = 0; i < order.size(); i++) {
+        SbRegion &r = plan.regions[i];
+        const uint32_t sb = sbs[order[i]];
+        const int x = (int) (sb % (uint32_t) tl.sbw), y = (int) (sb / (uint32_t) tl.sbw);
+        const int dm = dep ? dep[sb] : 15;
+        for (int k = 0; k < 4; k++) r.dep[k] = SB_NONE;
+        if (x > tile_x0[x] && (dm & 1)) r.dep[0] = where[sb - 1];
+        if (y > tile_y0[y]) {
+            if (x > tile_x0[x] && (dm & 2)) r.dep[1] = where[sb - tl.sbw - 1];
+            if (dm & 4) r.dep[2] = where[sb - tl.sbw];
+            if (x + 1 < tile_x1[x] && (dm & 8)) r.dep[3] = where[sb - tl.sbw + 1];
+        }
+        for (int k = 0; k < 4; k++) if (r.dep[k] != SB_NONE && r.dep[k] >= i) return -EINVAL;      // (cannot happen: levels rise along every dependency)
+    }
     return 0;
 }

@@ -239,7 +239,7 @@ def test_packing_lister_key_frame_through_the_dataflow_launch(ctx, bpc):
     assert st["steps"] >= 200 and not st["coef_after"].any()
 
 
-@pytest.mark.parametrize("lds", [1, 0], ids=["lds-resident", "l2-handoff"])
+@pytest.mark.parametrize("lds", [1, 0, 2], ids=["lds-resident", "l2-handoff", "l2-one-launch"])
 @pytest.mark.parametrize("sb128", [True, False], ids=["sb128", "sb64"])
 @pytest.mark.parametrize("bpc", [8, 10])
 def test_key_frame_superblock_by_superblock(ctx, bpc, sb128, lds):
@@ -252,7 +252,8 @@ def test_key_frame_superblock_by_superblock(ctx, bpc, sb128, lds):
     c2.backend = ctx.backend
     try:
         c2.set_option("intra_sb", 2)
-        c2.set_option("intra_sb_lds", lds)
+        c2.set_option("intra_sb_lds", int(lds == 1))
+        c2.set_option("intra_sb_flow", int(lds == 2))         # every level in one launch, superblocks waiting for their neighbours' flags
         c2.set_option("chunk_arena_min", 4096)
         st = run_case(c2, 448, 320, 1, bpc, 21 + bpc, is_inter=False, tiles=(2, 2), threads=2, sb128=sb128, palette=15, packed=True)
         assert st["steps"] >= 50 and not st["coef_after"].any()

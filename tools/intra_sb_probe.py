@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--modes", default="2,0")
     ap.add_argument("--lds", default="1,0", help="intra_sb_lds values to try with intra_sb = 2")
     ap.add_argument("--waves", default="0", help="intra_sb_waves values to try with intra_sb = 2 (0: the default)")
+    ap.add_argument("--flow", default="0", help="intra_sb_flow values to try (1: every level in one launch)")
     ap.add_argument("--no-pass", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--sizes", action="store_true", help="the intra pass with every region of ONE block size, per size: time per step of each route")
@@ -40,12 +41,15 @@ def main():
     out = {}
     ldss = [int(v) for v in a.lds.split(",")]
     wvs = [int(v) for v in a.waves.split(",")]
-    combos = [(m, l, wv) for m in [int(v) for v in a.modes.split(",")] for l in (ldss if m else ldss[:1]) for wv in (wvs if m and not l else wvs[:1])]
-    for mode, lds, wv in ([] if a.no_e2e else combos):
+    flows = [int(v) for v in a.flow.split(",")]
+    combos = [(m, l, wv, fl) for m in [int(v) for v in a.modes.split(",")] for l in (ldss if m else ldss[:1]) for wv in (wvs if m and not l else wvs[:1])
+              for fl in (flows if m and not l else [0])]
+    for mode, lds, wv, fl in ([] if a.no_e2e else combos):
+        assert ctx.lib.dav1d_hip_set_option(ctx.h, b"intra_sb_flow", fl) == 0
         assert ctx.lib.dav1d_hip_set_option(ctx.h, b"intra_sb", mode) == 0
         assert ctx.lib.dav1d_hip_set_option(ctx.h, b"intra_sb_lds", lds) == 0
         assert ctx.lib.dav1d_hip_set_option(ctx.h, b"intra_sb_waves", wv) == 0
-        tag = "intra_sb_%d_lds_%d_w%d" % (mode, lds, wv) if mode else "intra_sb_0"
+        tag = "intra_sb_%d_lds_%d_w%d_flow%d" % (mode, lds, wv, fl) if mode else "intra_sb_0"
         chk = None if a.no_check else (lambda ho, planes, refs: lu.check_handoff_against_reference(ho, planes, refs, is_inter=False))
         out["key_frame_" + tag] = e2e.run(ctx, w, h, 10, frames=4, threads=64, tile_cols=tc, tile_rows=tr, key_frame=True, seed=0xE2F, check=chk)
         chk = None if a.no_check else (lambda ho, planes, refs: lu.check_handoff_against_reference(ho, planes, refs, is_inter=True))
