@@ -14,6 +14,7 @@
 // offsets are the k-th outputs of the per-row LFSR, recomputed by every wave (<= 241 steps).
 #include "common.h"
 #include "capi.h"
+#include <type_traits>
 #include "av1_tables.h"
 #include <string.h>
 
@@ -223,16 +224,18 @@ __global__ __launch_bounds__(64) void fg_offsets_kernel(uint8_t *__restrict__ of
 }
 
 template <typename pixel>
-__global__ __launch_bounds__(64) void fg_apply_kernel(const DevPlanes dst, const DevPlanes src, const int16_t *__restrict__ luts,
+__global__ __launch_bounds__(256) void fg_apply_kernel(const DevPlanes dst, const DevPlanes src, const int16_t *__restrict__ luts,
                                                       const uint8_t *__restrict__ scaling, const int scaling_size, const FgParams p,
                                                       const int layout, const int is_id, const int bitdepth_max,
                                                       const int row_base, const int only_pl,
                                                       const uint8_t *__restrict__ offs, const int offs_row0, const int offs_stride)
 {
     // row_base / only_pl: the table-level entries run one block row of one plane on pictures that hold just that row
-    const int bxi = blockIdx.x, row_num = row_base + blockIdx.y, pl = only_pl < 0 ? (int) blockIdx.z : only_pl;
+    // four waves = four neighbouring blocks of a block row: they share ONE copy of the scaling table in LDS (a copy per 32x32 block
+    // was twice the block's own pixels in table traffic)
+    const int bxi = (int) blockIdx.x * 4 + ((int) threadIdx.x >> 6), row_num = row_base + blockIdx.y, pl = only_pl < 0 ? (int) blockIdx.z : only_pl;
     const int prow = blockIdx.y;          // block row inside the pictures
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int bitdepth_min_8 = (32 - __clz(bitdepth_max)) - 8;
     const int grain_ctr = 128 << bitdepth_min_8, grain_min = -grain_ctr, grain_max = grain_ctr - 1;
     const int sx = pl && layout != DAV1D_HIP_LAYOUT_I444, sy = pl && layout == DAV1D_HIP_LAYOUT_I420;
@@ -251,31 +254,34 @@ __global__ __launch_bounds__(64) void fg_apply_kernel(const DevPlanes dst, const
     const int bh = pl ? (dv::imin(ph_luma - prow * 32, 32) + sy) >> sy : dv::imin(ph_luma - prow * 32, 32);
     const int bstep = 32 >> sx;
     const int bx = bxi * bstep;
-    if (bx >= pw || bh <= 0) return;
-    const int bw = dv::imin(bstep, pw - bx);
+    if (bh <= 0) return;                                  // (the whole workgroup)
+    const bool active = bx < pw;                          // a wave past the end of the row still helps with the table
+    const int bw = active ? dv::imin(bstep, pw - bx) : 0;
 
     // per-block random offsets: k-th output of the row LFSRs (src/filmgrain_tmpl.c:192-214)
     // the k-th outputs of the row LFSRs were tabulated by fg_offsets_kernel: [row][block]
     const bool two_rows = p.overlap_flag && row_num > 0;
     const uint8_t *orow = offs + (row_num - offs_row0) * offs_stride;
-    const int off_cur = orow[bxi], off_left = bxi ? orow[bxi - 1] : 0;
-    const int off_cur_up = two_rows ? orow[bxi - offs_stride] : 0, off_left_up = (two_rows && bxi) ? orow[bxi - 1 - offs_stride] : 0;
+    const int bxo = active ? bxi : 0;
+    const int off_cur = orow[bxo], off_left = bxo ? orow[bxo - 1] : 0;
+    const int off_cur_up = two_rows ? orow[bxo - offs_stride] : 0, off_left_up = (two_rows && bxo) ? orow[bxo - 1 - offs_stride] : 0;
     const int ystart = (p.overlap_flag && row_num) ? dv::imin(2 >> sy, bh) : 0;
     const int xstart = (p.overlap_flag && bxi) ? dv::imin(2 >> sx, bw) : 0;
     // overlap weights: full resolution {27,17},{17,27}; subsampled {23,22}
     const int16_t *lut = luts + pl * (GH + 1) * GW;
     const uint8_t *sc = scaling + (size_t) ((pl && !p.chroma_scaling_from_luma) ? pl : 0) * scaling_size;
 
-    const pixel *const sp = reinterpret_cast<const pixel *>(src.data[pl]);
-    pixel *const dp = reinterpret_cast<pixel *>(dst.data[pl]);
-    const pixel *const lp = reinterpret_cast<const pixel *>(src.data[0]);
+    const pixel *__restrict__ const sp = reinterpret_cast<const pixel *>(src.data[pl]);
+    pixel *__restrict__ const dp = reinterpret_cast<pixel *>(dst.data[pl]);
+    const pixel *__restrict__ const lp = reinterpret_cast<const pixel *>(src.data[0]);
     const int y0 = pl ? (prow * 32) >> sy : prow * 32;
 
     // the scaling table moves to LDS once per block: the per-pixel lookup then costs an LDS read instead of a second
     // dependent trip to memory
     __shared__ __attribute__((aligned(16))) uint8_t sc_s[4096];
-    for (int i = lane * 16; i < scaling_size; i += 64 * 16) *reinterpret_cast<uint4 *>(sc_s + i) = *reinterpret_cast<const uint4 *>(sc + i);
-    dv::wave_sync();
+    for (int i = (int) threadIdx.x * 16; i < scaling_size; i += 256 * 16) *reinterpret_cast<uint4 *>(sc_s + i) = *reinterpret_cast<const uint4 *>(sc + i);
+    __syncthreads();
+    if (!active) return;
 
     // lane = (group of four columns, row): 8 rows of 32 or 16 rows of 16 pixels per pass; a lane fetches its four source pixels
     // (and, for chroma, the eight luma pixels under them) with one load each and stores four pixels at once — round 1 moved one
@@ -284,15 +290,36 @@ __global__ __launch_bounds__(64) void fg_apply_kernel(const DevPlanes dst, const
     const int x0 = (lane % qpr) * 4, yl = lane / qpr;
     const int ss = src.stride[pl], ds = dst.stride[pl], ls = src.stride[0];
     constexpr bool HBD = sizeof(pixel) == 2;
-    for (int yb = 0; yb < bh; yb += rpp) {
+    // every pass's wide loads are issued before the first pass computes (at most four passes: 32 rows, at least 8 per pass): a wave is
+    // one trip to memory long instead of one per pass
+    typedef typename std::conditional<HBD, uint2, uint32_t>::type quad_t;
+    quad_t pre_s[4], pre_la[4], pre_lb[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int y = q * rpp + yl;
+        pre_s[q] = quad_t(); pre_la[q] = quad_t(); pre_lb[q] = quad_t();
+        if (q * rpp >= bh || y >= bh || x0 + 4 > bw) continue;
+        pre_s[q] = *reinterpret_cast<const quad_t *>(sp + (y0 + y) * ss + bx + x0);
+        if (pl) {
+            const int lx = (bx + x0) << sx, ly = (prow * 32) + (y << sy);
+            if (lx + (4 << sx) <= src.w[0]) {
+                pre_la[q] = *reinterpret_cast<const quad_t *>(lp + ly * ls + lx);
+                if (sx) pre_lb[q] = *reinterpret_cast<const quad_t *>(lp + ly * ls + lx + 4);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int yb = q * rpp;
+        if (yb >= bh) continue;
         const int y = yb + yl;
         if (y >= bh || x0 >= bw) continue;
         const bool whole = x0 + 4 <= bw;
         int s0[4], lum[4] = { 0, 0, 0, 0 };
         const pixel *srow = sp + (y0 + y) * ss + bx + x0;
         if (whole) {
-            if (HBD) { const uint2 v = *reinterpret_cast<const uint2 *>(srow); s0[0] = v.x & 0xffff; s0[1] = v.x >> 16; s0[2] = v.y & 0xffff; s0[3] = v.y >> 16; }
-            else { const uint32_t v = *reinterpret_cast<const uint32_t *>(srow); s0[0] = v & 0xff; s0[1] = v >> 8 & 0xff; s0[2] = v >> 16 & 0xff; s0[3] = v >> 24; }
+            if constexpr (HBD) { const uint2 v = pre_s[q]; s0[0] = v.x & 0xffff; s0[1] = v.x >> 16; s0[2] = v.y & 0xffff; s0[3] = v.y >> 16; }
+            else { const uint32_t v = pre_s[q]; s0[0] = v & 0xff; s0[1] = v >> 8 & 0xff; s0[2] = v >> 16 & 0xff; s0[3] = v >> 24; }
         } else {
 #pragma unroll
             for (int k = 0; k < 4; k++) s0[k] = x0 + k < bw ? (int) srow[k] : 0;
@@ -303,14 +330,14 @@ __global__ __launch_bounds__(64) void fg_apply_kernel(const DevPlanes dst, const
             const pixel *lrow = lp + ly * ls;
             if (whole && lx + (4 << sx) <= src.w[0]) {
                 int l8[8];
-                if (HBD) {
-                    const uint2 a = *reinterpret_cast<const uint2 *>(lrow + lx);
+                if constexpr (HBD) {
+                    const uint2 a = pre_la[q];
                     l8[0] = a.x & 0xffff; l8[1] = a.x >> 16; l8[2] = a.y & 0xffff; l8[3] = a.y >> 16;
-                    if (sx) { const uint2 b = *reinterpret_cast<const uint2 *>(lrow + lx + 4); l8[4] = b.x & 0xffff; l8[5] = b.x >> 16; l8[6] = b.y & 0xffff; l8[7] = b.y >> 16; }
+                    if (sx) { const uint2 b = pre_lb[q]; l8[4] = b.x & 0xffff; l8[5] = b.x >> 16; l8[6] = b.y & 0xffff; l8[7] = b.y >> 16; }
                 } else {
-                    const uint32_t a = *reinterpret_cast<const uint32_t *>(lrow + lx);
+                    const uint32_t a = pre_la[q];
                     l8[0] = a & 0xff; l8[1] = a >> 8 & 0xff; l8[2] = a >> 16 & 0xff; l8[3] = a >> 24;
-                    if (sx) { const uint32_t b = *reinterpret_cast<const uint32_t *>(lrow + lx + 4); l8[4] = b & 0xff; l8[5] = b >> 8 & 0xff; l8[6] = b >> 16 & 0xff; l8[7] = b >> 24; }
+                    if (sx) { const uint32_t b = pre_lb[q]; l8[4] = b & 0xff; l8[5] = b >> 8 & 0xff; l8[6] = b >> 16 & 0xff; l8[7] = b >> 24; }
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k++) lum[k] = sx ? (l8[2 * k] + l8[2 * k + 1] + 1) >> 1 : l8[k];
@@ -406,14 +433,15 @@ extern "C" int dav1d_hip_launch_fg_apply(const DevPlanes *dst, const DevPlanes *
                                          uint8_t *offs, void *stream)
 {
     const int bitdepth_max = (1 << bpc) - 1;
-    const dim3 grid((src->w[0] + 31) / 32, (src->h[0] + 31) / 32, layout == DAV1D_HIP_LAYOUT_I400 ? 1 : 3);
+    const int nbx = (src->w[0] + 31) / 32;
+    const dim3 grid((nbx + 3) / 4, (src->h[0] + 31) / 32, layout == DAV1D_HIP_LAYOUT_I400 ? 1 : 3);        // four blocks of a row per workgroup
     const FgParams p = make_params(data);
-    const int offs_row0 = 0, offs_stride = (int) grid.x;
-    hipLaunchKernelGGL(fg_offsets_kernel, dim3((grid.y + 63) / 64), dim3(64), 0, (hipStream_t) stream, offs, p.seed, 0, (int) grid.y, (int) grid.x);
+    const int offs_row0 = 0, offs_stride = nbx;
+    hipLaunchKernelGGL(fg_offsets_kernel, dim3((grid.y + 63) / 64), dim3(64), 0, (hipStream_t) stream, offs, p.seed, 0, (int) grid.y, nbx);
     if (bpc == 8)
-        hipLaunchKernelGGL((fg_apply_kernel<uint8_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max, 0, -1, offs, offs_row0, offs_stride);
+        hipLaunchKernelGGL((fg_apply_kernel<uint8_t>), grid, dim3(256), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max, 0, -1, offs, offs_row0, offs_stride);
     else
-        hipLaunchKernelGGL((fg_apply_kernel<uint16_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max, 0, -1, offs, offs_row0, offs_stride);
+        hipLaunchKernelGGL((fg_apply_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max, 0, -1, offs, offs_row0, offs_stride);
     return hip_rc(hipGetLastError());
 }
 
@@ -423,14 +451,15 @@ extern "C" int dav1d_hip_launch_fg_apply_rows(const DevPlanes *dst, const DevPla
                                               int row_num, int pl, uint8_t *offs, void *stream)
 {
     const int bitdepth_max = (1 << bpc) - 1;
-    const dim3 grid((src->w[0] + 31) / 32, 1, 1);
+    const int nbx = (src->w[0] + 31) / 32;
+    const dim3 grid((nbx + 3) / 4, 1, 1);
     const FgParams p = make_params(data);
     // two table rows: the row above (its offsets feed the vertical overlap) and this one
-    const int offs_row0 = row_num - 1, offs_stride = (int) grid.x;
-    hipLaunchKernelGGL(fg_offsets_kernel, dim3(1), dim3(64), 0, (hipStream_t) stream, offs, p.seed, offs_row0, 2, (int) grid.x);
+    const int offs_row0 = row_num - 1, offs_stride = nbx;
+    hipLaunchKernelGGL(fg_offsets_kernel, dim3(1), dim3(64), 0, (hipStream_t) stream, offs, p.seed, offs_row0, 2, nbx);
     if (bpc == 8)
-        hipLaunchKernelGGL((fg_apply_kernel<uint8_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max, row_num, pl, offs, offs_row0, offs_stride);
+        hipLaunchKernelGGL((fg_apply_kernel<uint8_t>), grid, dim3(256), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max, row_num, pl, offs, offs_row0, offs_stride);
     else
-        hipLaunchKernelGGL((fg_apply_kernel<uint16_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max, row_num, pl, offs, offs_row0, offs_stride);
+        hipLaunchKernelGGL((fg_apply_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t) stream, *dst, *src, luts, scaling, scaling_size, p, layout, is_id, bitdepth_max, row_num, pl, offs, offs_row0, offs_stride);
     return hip_rc(hipGetLastError());
 }
