@@ -256,11 +256,19 @@ __device__ __forceinline__ void fetch_end(const int v) {
 #endif
 }
 __device__ __forceinline__ void touch(const void *p) { fetch_end(fetch_begin(p)); }
-// picture pixels behind operator[]: plain loads, or coherent ones when another workgroup of the same launch wrote them
-template <typename pixel, bool COH>
+// picture pixels behind operator[]: plain loads (COH 0), coherent ones when another workgroup of the same launch wrote them (1), or — the
+// "picture" being an image kept in LDS whose generic address travels in a DevPlanes (intra_sb.hip) — LDS reads (2): through the generic
+// pointer the compiler would issue flat loads, which wait for the vector memory path as well as for the LDS
+template <typename pixel, int COH>
 struct PxRead {
     const pixel *p;
-    __device__ __forceinline__ pixel operator[](const int i) const { return COH ? ld_coherent(p + i) : p[i]; }
+    __device__ __forceinline__ pixel operator[](const int i) const {
+#ifndef DAV1D_HIP_EMU
+        if constexpr (COH == 2) return ((__attribute__((address_space(3))) const pixel *) p)[i];
+#endif
+        if constexpr (COH == 1) return ld_coherent(p + i);
+        return p[i];
+    }
     __device__ __forceinline__ PxRead operator+(const int k) const { return PxRead{ p + k }; }
     __device__ __forceinline__ PxRead operator-(const int k) const { return PxRead{ p - k }; }
 };

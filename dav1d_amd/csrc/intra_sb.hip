@@ -256,7 +256,7 @@ __global__ __launch_bounds__(NW * 64, SBL2 == 6 ? 2 : 1) void intra_sbl_kernel(c
                 tp.dst_off = (uint32_t) ((ly + 1) * S + lx + G::PAD);
                 if (tp.kind == DAV1D_HIP_IPRED_CFL)          // the co-located luma block (host/lister.c: the block's own luma origin)
                     tp.aux_off = (uint32_t) (((uy << 1) - y0 + 1) * G::SY + ((ux << 1) - x0) + G::PAD);
-                ipred_body<pixel, false>(img, tp, 0, false, aux, layout, bitdepth_max, e1, e2, blk, tile, w);
+                ipred_body<pixel, 2>(img, tp, 0, false, aux, layout, bitdepth_max, e1, e2, blk, tile, w);
             } else {
                 // a residual on its own (the blocks of a palette block, ...): the pixels it is added to come from the image
                 for (int i = lane; i < w * h; i += 64) tile[i] = im[(i / w) * S + (i % w)];

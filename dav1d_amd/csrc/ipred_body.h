@@ -57,8 +57,9 @@ constexpr int IPRED_PARTS = 4;
 // t: the block's task; split / part: this workgroup predicts part `part` of IPRED_PARTS of the block's pixels (split) or all
 // of them; e1, e2 (ESZ int16 each), blk (32 x 32 int16): LDS of the wave; o / ostride: where the predicted pixels go — the
 // block's place in the picture, or an LDS tile (row stride = block width) when a residual is added by the same wave.
-// COH: the pixels read from the picture (edges, CfL's luma) were written by other workgroups of the SAME launch (intra_flow.hip)
-template <typename pixel, bool COH = false>
+// COH 1: the pixels read from the picture (edges, CfL's luma) were written by other workgroups of the SAME launch (intra_flow.hip);
+// COH 2: `dst` describes images kept in LDS (intra_sb.hip)
+template <typename pixel, int COH = 0>
 __device__ __forceinline__ void ipred_body(const DevPlanes &dst, const Dav1dHipIpredTask &t, const int part, const bool split,
                                            uint8_t *aux, const int layout, const int bitdepth_max,
                                            int16_t *e1, int16_t *e2, int16_t *blk, pixel *const o, const int ostride)
