@@ -282,7 +282,9 @@ def test_larger_frame_many_tiles_threads():
     (3840, 2160, 1, 12, dict(tiles=(4, 2), threads=8, gmv=GMV, global_pct=20)),
     (1920, 1080, 3, 8, dict(tiles=(2, 1), threads=2, is_inter=False, palette=30)),
     (1920, 1080, 1, 10, dict(tiles=(2, 2), threads=4, is_inter=False, intrabc_pct=30)),
-], ids=["444_10_4k", "422_8_1440p", "420_12_4k_gmv", "key_444_8_1080p_palette", "key_420_10_1080p_intrabc"])
+    (3840, 2160, 1, 10, dict(tiles=(4, 2), threads=8, is_inter=False, sb128=False)),      # 2040 superblocks of 64 pixels, 22 levels in one launch
+    (3840, 2160, 2, 8, dict(tiles=(2, 2), threads=4, is_inter=False, sb128=True, palette=20)),
+], ids=["444_10_4k", "422_8_1440p", "420_12_4k_gmv", "key_444_8_1080p_palette", "key_420_10_1080p_intrabc", "key_420_10_4k_sb64", "key_422_8_4k_sb128_palette"])
 def test_every_tool_at_frame_scale(w, h, layout, bpc, kw):
     """The mix of every tool (OBMC, warp, masks, inter-intra, palette, CfL, rectangular transforms ...) on whole pictures of the
     other chroma layouts and bit depths, hand-off arrays through the lister threads to pixels, against the reference's own pass 2."""
