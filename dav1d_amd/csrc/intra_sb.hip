@@ -12,9 +12,12 @@
 // Here ONE WORKGROUP owns a superblock: its waves work the superblock's units (prediction + residual of one transform block)
 // off step by step with a workgroup barrier in between, the pixels handed over through the XCD's L2 (plain stores,
 // acknowledged, then loads that bypass the CU's L1).  Superblocks are sorted into LEVELS — level(sb) = 1 + the highest level
-// among its four neighbours that hold intra units — and a level is a launch: 8 + 2 x 10 levels for a tile of 8 x 10
-// superblocks instead of several hundred steps, all tiles side by side.  An inter frame's scattered intra superblocks are one
-// or two levels.
+// among those of its four neighbours whose intra pixels its blocks read (the lister records that per superblock) — 8 + 2 x 10
+// levels for a tile of 8 x 10 superblocks instead of several hundred steps, all tiles side by side; an inter frame's scattered
+// intra superblocks are a few levels.  The levels run as ONE launch: workgroups in level order, a superblock waiting for the
+// flags of the neighbours it reads (release / acquire fences at superblock granularity) — or, on request, as a launch per level.
+// Measured on MI355X: an 8K key frame 27.4 ms as one dataflow launch -> 12.5 ms as 12 level launches -> 10.3 ms as
+// one launch of superblocks.
 #include "ipred_body.h"
 #include "itx_body.h"
 #include "capi.h"
@@ -27,9 +30,8 @@ namespace {
 constexpr int sb_itx_lds_of(int tx) {
     return (64 / cmax(cmin(tx_h(tx), 32), tx_w(tx))) * cmin(tx_h(tx), 32) * (tx_w(tx) + 1);
 }
-enum { SB_SPIN_LIMIT = 1 << 18 };        // naps of ~2 µs before a waiting workgroup gives up (a bug, never a normal run)
 constexpr int sb_itx_lds_max(int tx = 0) { return tx == 19 ? 0 : cmax(sb_itx_lds_of(tx), sb_itx_lds_max(tx + 1)); }
-
+enum { SB_SPIN_LIMIT = 1 << 18 };        // naps of ~3 µs before a waiting workgroup gives up (a bug, never a normal run)
 
 // the unit the same wave works on after `u` (host: dav1d_hip_sbw_emit)
 template <int NW> __device__ __forceinline__ uint32_t sb_next(const IntraUnit &u) { return NW == 4 ? u.pad2 : u.prev_n; }
@@ -151,10 +153,11 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void intra_sb_kernel(const DevPla
 // inter blocks of the frame are there already), one column to the left, one row above that reaches a superblock's width further
 // to the right (the top-right extension of the blocks on the superblock's top row).  Element (x, y) of the superblock, x in
 // [-PAD, 2W), y in [-1, H), sits at (y + 1) * S + x + PAD with S = 2W + PAD (PAD = the pixels of a 16-byte chunk): rows start 16-byte aligned, the image is filled with
-// 16-byte loads.  The prediction body (ipred_body.h) reads the edges through ordinary pointers: it is handed a DevPlanes that
-// describes the IMAGES (generic pointers into LDS) and a task whose offsets are the block's place in the image.  A finished
+// 16-byte loads.  The prediction body (ipred_body.h) is handed a DevPlanes that describes the IMAGES (their generic addresses;
+// dv::PxRead mode 2 turns them back into LDS reads) and a task whose offsets are the block's place in the image.  A finished
 // unit goes to the image (for its neighbours) and to the picture (stores nobody waits for): a step of the superblock then
-// costs LDS round trips and a workgroup barrier instead of trips to the L2 and back.
+// costs LDS round trips and a workgroup barrier instead of trips to the L2 and back.  Measured: no faster than the L2 hand-off
+// (what a unit costs is its own chain of LDS round trips and arithmetic, not the edge reads); an option, a launch per level.
 template <typename pixel, int SBL2>
 struct SbImage {
     static constexpr int W = 1 << SBL2, H = 1 << SBL2, CW = W >> 1, CH = H >> 1;
