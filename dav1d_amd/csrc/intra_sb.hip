@@ -62,21 +62,31 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void intra_sb_kernel(const DevPla
         // Workgroups are dispatched in the order of their index, so whoever is waited for is running or done — no workgroup waits for
         // one that cannot start.  The neighbours' pixels were stored plainly and written back by the release fence at their end;
         // here one lane polls, then an acquire fence, and the edge reads are loads that bypass the L1 anyway.
+        __shared__ int give_up;
         if (threadIdx.x == 0) {
             bool ok = true;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                if (r.dep[k] == SB_NONE) continue;
+                if (r.dep[k] == SB_NONE || !ok) continue;
                 int spins = 0;
-                while (dv::ld_coherent(flags + r.dep[k]) == 0u) {
+                for (;;) {
+                    const uint32_t v = dv::ld_coherent(flags + r.dep[k]);
+                    if (v == 1u) break;
+                    if (v == 2u || ++spins > SB_SPIN_LIMIT) { ok = false; break; }       // a neighbour gave up, or never came: so does this one
                     dv::nap_long();
-                    if (++spins > SB_SPIN_LIMIT) { ok = false; break; }
                 }
             }
-            if (!ok) atomicAdd(flags + n_regions, 1u);          // never in a sound run: the frame comes back -EIO
+            if (!ok) {
+                // never in a sound run.  The superblock is NOT reconstructed from neighbours that are not there; its flag says so, which
+                // lets everything behind it leave at once instead of timing out one after the other, and the frame comes back -EIO
+                atomicAdd(flags + n_regions, 1u);
+                dv::st_coherent(flags + blockIdx.x, 2u);
+            }
+            give_up = !ok;
             dv::fence_acquire_agent();
         }
         __syncthreads();
+        if (give_up) return;
     }
     const IntraUnit *const ru = units + r.first, *const us = ru + 1;       // header record, then the units
     const uint32_t *const hdr = reinterpret_cast<const uint32_t *>(ru);
