@@ -249,7 +249,8 @@ extern "C" int dav1d_hip_launch_comp(const DevPlanes *dst, int bpc, const Dav1dH
 struct IntraUnit {
     uint32_t need;              // host side: units in earlier groups (a group = the units of one step that may run together);
                                 // equal values mark a group.  The device copy also carries what the waves use:
-    uint32_t has;               // bit 0: p holds a prediction, bit 1: t holds a residual
+    uint32_t has;               // bit 0: p holds a prediction, bit 1: t holds a residual, bit 2 (superblock route): the prediction is the intra half of an
+                                // inter-intra block, blended into the picture's pixels with the mask at p.aux_off
     uint32_t grp;               // dense index of the unit's group
     uint32_t prev_n;            // units in the group before it (0 for the first): that many completions open this group
     Dav1dHipIpredTask p;
@@ -262,7 +263,8 @@ extern "C" int dav1d_hip_launch_intra_flow(const DevPlanes *dst, int bpc, int la
                                            void *coef, uint32_t *ctr, int n_waves, int mode, void *stream);
 struct Dav1dHipIntraFlow;
 extern "C" int dav1d_hip_intra_units_build(const Dav1dHipIpredTask *preds, const uint32_t *pred_end, const Dav1dHipItxTask *txs, const uint32_t *tx_end,
-                                size_t n_steps, std::vector<IntraUnit> &units, std::vector<uint32_t> &ua_end, std::vector<uint32_t> &ub_end);
+                                size_t n_steps, std::vector<IntraUnit> &units, std::vector<uint32_t> &ua_end, std::vector<uint32_t> &ub_end,
+                                const Dav1dHipCompTask *blends, const uint32_t *blend_end);
 extern "C" int dav1d_hip_intra_flow_from_units(Dav1dHipContext *c, Dav1dHipIntraFlow **out, IntraUnit *units, size_t n);
 // batches (wavefront steps) of predictions + residuals -> device-resident unit list; -ENOTSUP when the list holds a task
 // kind the dataflow launch does not run (PRED_TMP for inter-intra, DSP-level kinds): the caller keeps the stepped route
@@ -292,7 +294,7 @@ int dav1d_hip_sbw_prepare(std::vector<IntraUnit> &units, const std::vector<uint3
 void dav1d_hip_sbw_emit(const std::vector<IntraUnit> &units, const SbSort &st, IntraUnit *out);
 int dav1d_hip_sbw_levels(const SbTiling &tl, const uint32_t *sbs, size_t n, const uint8_t *dep, std::vector<int> &level_of_sb, std::vector<uint32_t> &level);
 extern "C" int dav1d_hip_launch_intra_sb(const DevPlanes *dst, int bpc, int layout, const IntraUnit *units, const SbRegion *regions, int n_regions,
-                                         uint8_t *aux, void *coef, int waves, int sb_log2, int lds, uint32_t *flags, void *stream);
+                                         uint8_t *aux, const uint8_t *mask, void *coef, int waves, int sb_log2, int lds, uint32_t *flags, void *stream);
 // regions sorted by level + where each level starts, from the parts of any number of unit arrays laid end to end (base[k] = where
 // array k starts): host-side plan of a frame's launches
 struct SbPlan { std::vector<SbRegion> regions; std::vector<uint32_t> level_start; /* n_levels + 1 */ };

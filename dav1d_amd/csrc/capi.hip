@@ -2119,14 +2119,22 @@ int dav1d_hip_intra_flow_status(Dav1dHipContext *c, const Dav1dHipIntraFlow *l, 
 // step (a palette block: one prediction, many residuals).  need is left 0.  -ENOTSUP: a task kind the dataflow launch
 // does not run (PRED_TMP of inter-intra blocks, the DSP-level kinds).
 int dav1d_hip_intra_units_build(const Dav1dHipIpredTask *preds, const uint32_t *pred_end, const Dav1dHipItxTask *txs, const uint32_t *tx_end,
-                                size_t n_steps, std::vector<IntraUnit> &units, std::vector<uint32_t> &ua_end, std::vector<uint32_t> &ub_end) {
+                                size_t n_steps, std::vector<IntraUnit> &units, std::vector<uint32_t> &ua_end, std::vector<uint32_t> &ub_end,
+                                const Dav1dHipCompTask *blends, const uint32_t *blend_end) {
     const size_t np = n_steps ? pred_end[n_steps - 1] : 0, nt = n_steps ? tx_end[n_steps - 1] : 0;
     uint8_t dummy = 0;
     if (ipred_tasks_valid(preds, np, &dummy)) return -EINVAL;
     for (size_t i = 0; i < nt; i++) if (!itx_task_ok(txs[i])) return -EINVAL;
+    // inter-intra blocks (kind PRED_TMP + a BLEND of the same rectangle in the same step) only where the caller brings the blends: the
+    // unit then carries the blend — its mask offset in the place of the scratch offset nobody needs when the prediction stays in LDS
     for (size_t i = 0; i < np; i++) {
         const int k = preds[i].kind;
+        if (k == DAV1D_HIP_IPRED_PRED_TMP && blends) continue;
         if (k != DAV1D_HIP_IPRED_PRED && k != DAV1D_HIP_IPRED_CFL && k != DAV1D_HIP_IPRED_PAL) return -ENOTSUP;
+    }
+    if (blends) {
+        const size_t nb = n_steps ? blend_end[n_steps - 1] : 0;
+        for (size_t i = 0; i < nb; i++) if (blends[i].kind != DAV1D_HIP_COMP_BLEND || blends[i].plane > 2) return -ENOTSUP;
     }
     units.clear();
     units.reserve(np + nt / 4);
@@ -2167,6 +2175,16 @@ int dav1d_hip_intra_units_build(const Dav1dHipIpredTask *preds, const uint32_t *
                 }
                 if (j != 0xffffffffu) taken[j] = 1;
                 unit(&p, j == 0xffffffffu ? nullptr : &txs[t0 + j]);
+                if (p.kind == DAV1D_HIP_IPRED_PRED_TMP) {
+                    // its blend: the one of the step with the same rectangle
+                    const size_t b0 = k ? blend_end[k - 1] : 0, b1 = blend_end[k];
+                    const Dav1dHipCompTask *bl = nullptr;
+                    for (size_t q = b0; q < b1 && !bl; q++)
+                        if (blends[q].plane == p.plane && blends[q].dst_off == p.dst_off && blends[q].w == p.tw * 4 && blends[q].h == p.th * 4) bl = &blends[q];
+                    if (!bl) return -EINVAL;
+                    units.back().has |= 4;
+                    units.back().p.aux_off = bl->mask_off;
+                }
             }
             // units of a group are independent: put those that run the same code (transform size, then predictor) next to each
             // other, so that the waves of a CU — which are dealt consecutive units — share instruction cache lines.  The launch's
@@ -2228,7 +2246,7 @@ int dav1d_hip_intra_flow_create(Dav1dHipContext *c, Dav1dHipIntraFlow **out, con
     }
     if ((np && !preds) || (nt && !txs)) return -EINVAL;
     std::vector<IntraUnit> units;
-    const int rc = dav1d_hip_intra_units_build(preds, pe.data(), txs, te.data(), n_batches, units, ua, ub);
+    const int rc = dav1d_hip_intra_units_build(preds, pe.data(), txs, te.data(), n_batches, units, ua, ub, nullptr, nullptr);
     if (rc) return rc;
     for (size_t k = 0, i = 0; k < n_batches; k++) {
         const uint32_t need_a = (uint32_t) i, need_b = ua[k];
@@ -2288,7 +2306,7 @@ int dav1d_hip_intra_sb_create(Dav1dHipContext *c, Dav1dHipIntraSb **out, const D
     }
     if ((np && !preds) || (nt && !txs)) return -EINVAL;
     std::vector<IntraUnit> units;
-    rc = dav1d_hip_intra_units_build(preds, pe.data(), txs, te.data(), n_batches, units, ua, ub);
+    rc = dav1d_hip_intra_units_build(preds, pe.data(), txs, te.data(), n_batches, units, ua, ub, nullptr, nullptr);
     if (rc) return rc;
     const DevPlanes dp = dev_planes(geometry);
     SbSort st;
@@ -2330,12 +2348,12 @@ int dav1d_hip_intra_sb_run(Dav1dHipContext *c, const Dav1dHipIntraSb *l, const D
     int rc = 0;
     if (c->intra_sb_flow && !c->intra_sb_lds && l->level_start.size() > 2) {
         if (hipMemsetAsync(l->flags, 0, (l->n_regions + 1) * sizeof(uint32_t), c->stream) != hipSuccess) return -EIO;
-        return dav1d_hip_launch_intra_sb(&dp, dst->bpc, dst->layout, l->units, l->regions, (int) l->n_regions, aux, coef, c->intra_sb_waves, l->sb_log2, 0,
+        return dav1d_hip_launch_intra_sb(&dp, dst->bpc, dst->layout, l->units, l->regions, (int) l->n_regions, aux, nullptr, coef, c->intra_sb_waves, l->sb_log2, 0,
                                          l->flags, c->stream);
     }
     for (size_t k = 0; k + 1 < l->level_start.size() && !rc; k++)
         rc = dav1d_hip_launch_intra_sb(&dp, dst->bpc, dst->layout, l->units, l->regions + l->level_start[k],
-                                       (int) (l->level_start[k + 1] - l->level_start[k]), aux, coef, c->intra_sb_waves, l->sb_log2, c->intra_sb_lds, nullptr, c->stream);
+                                       (int) (l->level_start[k + 1] - l->level_start[k]), aux, nullptr, coef, c->intra_sb_waves, l->sb_log2, c->intra_sb_lds, nullptr, c->stream);
     return rc;
 }
 

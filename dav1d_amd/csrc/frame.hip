@@ -60,7 +60,7 @@ struct Dav1dHipFrame {
         bool sb_sorted;
         IntraUnit *sorted;                          // ... and sit here: in the frame's pinned unit arena (in_arena) or in `units`
         size_t n_sorted;
-        bool in_arena, has_pal;
+        bool in_arena, has_pal, has_blend;
     };
     // The sorted units of the superblock route go straight into pinned memory, drawn chunk by chunk by the submitting threads (sized
     // by what frames have needed so far; a chunk that does not fit keeps its units and is copied at frame end): the upload is one
@@ -569,9 +569,14 @@ int dav1d_hip_frame_submit_intra_sorted(Dav1dHipFrame *f, size_t n_steps, const 
         }
         ck->ip_end[s] = (uint32_t) ip_end[s]; ck->ix_end[s] = (uint32_t) ix_end[s]; ck->bl_end[s] = (uint32_t) bl_end[s];
     }
-    ck->flow_ok = nb == 0 && f->c->flow_min_steps > 0;
+    // units (prediction + residual of a transform block): for the dataflow launch (no inter-intra blends) and for the superblock route
+    // (which blends inside the unit)
+    ck->has_blend = nb != 0;
+    const bool want_sb = f->have_tiling && f->c->intra_sb > 0;
+    ck->flow_ok = (nb == 0 && f->c->flow_min_steps > 0) || want_sb;
     if (ck->flow_ok) {
-        int rc = dav1d_hip_intra_units_build(ck->ip.data(), ck->ip_end.data(), ck->ix.data(), ck->ix_end.data(), n_steps, ck->units, ck->ua_end, ck->ub_end);
+        int rc = dav1d_hip_intra_units_build(ck->ip.data(), ck->ip_end.data(), ck->ix.data(), ck->ix_end.data(), n_steps, ck->units, ck->ua_end, ck->ub_end,
+                                             nb && want_sb ? ck->bl.data() : nullptr, ck->bl_end.data());
         if (rc == -ENOTSUP) { ck->flow_ok = false; ck->units.clear(); rc = 0; }
         if (rc) { delete ck; return rc; }
     }
@@ -1048,10 +1053,11 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
         const auto t_a = std::chrono::steady_clock::now();
         const size_t ns = f->n_steps;
         bool flow = c->flow_min_steps > 0 && ns >= (size_t) c->flow_min_steps;
-        for (const Dav1dHipFrame::StepChunk *ck : f->step_chunks) flow = flow && ck->flow_ok;
+        bool any_blend = false;
+        for (const Dav1dHipFrame::StepChunk *ck : f->step_chunks) { flow = flow && ck->flow_ok && !ck->has_blend; any_blend = any_blend || ck->has_blend; }
         flow = flow && f->step_copy.empty();          // intra block copies are launches of their own between the steps
-        // superblock by superblock (intra_sb.hip) when every submission was sorted for it (the frame's tiling is known, no inter-intra
-        // blends, no intra block copies): option intra_sb = 2 for every frame, 1 for the long wavefronts only
+        // superblock by superblock (intra_sb.hip) when every submission was sorted for it (the frame's tiling is known, no intra block
+        // copies; inter-intra blends are part of their units): option intra_sb = 2 for every frame, 1 for the long wavefronts only
         bool sbw = f->have_tiling && f->step_copy.empty() && !f->step_chunks.empty() && (c->intra_sb >= 2 || (c->intra_sb == 1 && flow));
         bool any_sorted = false;
         for (const Dav1dHipFrame::StepChunk *ck : f->step_chunks) { sbw = sbw && ck->flow_ok && ck->sb_sorted; any_sorted = any_sorted || ck->sb_sorted; }
@@ -1094,9 +1100,11 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
             SbPlan plan;
             if (!rc) rc = dav1d_hip_sbw_plan(f->tiling, parts, base, f->sb_dep.empty() ? nullptr : f->sb_dep.data(), plan);
             if (!rc && needs_aux && !f->aux) rc = -EINVAL;
+            if (!rc && any_blend && !mask) rc = -EINVAL;
             const size_t ub = total * sizeof(IntraUnit), rb = plan.regions.size() * sizeof(SbRegion);
             if (!rc && total) {
-                const bool one_launch = c->intra_sb_flow && !c->intra_sb_lds && plan.level_start.size() > 2;
+                const int lds = c->intra_sb_lds && !any_blend;          // (the LDS-resident form does not blend)
+                const bool one_launch = c->intra_sb_flow && !lds && plan.level_start.size() > 2;
                 const size_t fb = (plan.regions.size() + 1) * sizeof(uint32_t), o_flags = (ub + rb + 255) & ~(size_t) 255;
                 TaskBuf dev_buf(c, o_flags + fb + 256);
                 uint8_t *const dev = dev_buf.p;
@@ -1109,7 +1117,7 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
                 if (one_launch) {
                     // every level in one launch: superblocks wait for the flags of the neighbours they read (intra_sb.hip)
                     if (!rc) rc = dav1d_hip_launch_intra_sb(&dp, f->cur.bpc, f->cur.layout, reinterpret_cast<const IntraUnit *>(dev),
-                                                            reinterpret_cast<const SbRegion *>(dev + ub), (int) plan.regions.size(), f->aux, coef,
+                                                            reinterpret_cast<const SbRegion *>(dev + ub), (int) plan.regions.size(), f->aux, mask, coef,
                                                             c->intra_sb_waves, f->tiling.sb_log2, 0, reinterpret_cast<uint32_t *>(dev + o_flags), c->stream);
                     uint32_t gave_up = 0;
                     if (!rc) rc = dav1d_hip_download(c, &gave_up, dev + o_flags + plan.regions.size() * sizeof(uint32_t), sizeof(gave_up));
@@ -1118,8 +1126,8 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
                 for (size_t l = 0; l + 1 < plan.level_start.size() && !rc; l++)
                     rc = dav1d_hip_launch_intra_sb(&dp, f->cur.bpc, f->cur.layout, reinterpret_cast<const IntraUnit *>(dev),
                                                    reinterpret_cast<const SbRegion *>(dev + ub) + plan.level_start[l],
-                                                   (int) (plan.level_start[l + 1] - plan.level_start[l]), f->aux, coef, c->intra_sb_waves, f->tiling.sb_log2,
-                                                   c->intra_sb_lds, nullptr, c->stream);
+                                                   (int) (plan.level_start[l + 1] - plan.level_start[l]), f->aux, mask, coef, c->intra_sb_waves, f->tiling.sb_log2,
+                                                   lds, nullptr, c->stream);
                 // the device copy of the units goes back to the pool when this scope ends: the launches have to be through by then
                 const int rs = hip_rc(hipStreamSynchronize(c->stream));
                 if (!rc) rc = rs;

@@ -41,6 +41,7 @@ template <int NW> __device__ __forceinline__ uint32_t sb_next(const IntraUnit &u
 template <typename pixel, typename coef, int SB_WAVES>
 __global__ __launch_bounds__(SB_WAVES * 64, 2) void intra_sb_kernel(const DevPlanes dst, const IntraUnit *__restrict__ units,
                                                                      const SbRegion *__restrict__ regions, uint8_t *aux,
+                                                                     const uint8_t *__restrict__ mask /* inter-intra masks (may be nullptr without such units) */,
                                                                      coef *__restrict__ cf, const int layout, const int bitdepth_max,
                                                                      uint32_t *flags /* ONE launch for every level: a word per superblock (+ the error word behind them), or nullptr */,
                                                                      const int n_regions)
@@ -120,6 +121,16 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void intra_sb_kernel(const DevPla
             const int stride = dst.stride[plane];
             if (has_pred) {
                 ipred_body<pixel, true>(dst, u.p, 0, false, aux, layout, bitdepth_max, e1, e2, blk, tile, w);
+                if (u.has & 4) {
+                    // the intra half of an inter-intra block (src/recon_tmpl.c:1606-1630, 1751-1784): blended into the inter prediction, which
+                    // an earlier launch left in the picture (blend_c, src/mc_tmpl.c:682-695); the mask is that of the whole block
+                    dv::wave_sync();
+                    const uint8_t *const m = mask + u.p.aux_off;
+                    for (int i = lane; i < w * h; i += 64) {
+                        const int a = d[(i / w) * stride + (i % w)], b = tile[i], mm = m[i];
+                        tile[i] = (pixel) ((a * (64 - mm) + b * mm + 32) >> 6);
+                    }
+                }
             } else {
                 // a residual on its own (the blocks of a palette block, ...): the pixels it is added to come from the picture
                 for (int i = lane; i < w * h; i += 64) tile[i] = dv::ld_coherent(d + (i / w) * stride + (i % w));
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(NW * 64, SBL2 == 6 ? 2 : 1) void intra_sbl_kernel(c
 // flags = n_regions + 1 zeroed words, the last one counts workgroups that gave up waiting).
 // waves: workgroup size in waves, 4 or 8 (0: the form's own choice).  lds: the LDS-resident form where it exists (4:2:0 / 4:0:0 pictures).
 extern "C" int dav1d_hip_launch_intra_sb(const DevPlanes *dst, int bpc, int layout, const IntraUnit *units, const SbRegion *regions, int n_regions,
-                                         uint8_t *aux, void *coef, int waves, int sb_log2, int lds, uint32_t *flags, void *stream)
+                                         uint8_t *aux, const uint8_t *mask, void *coef, int waves, int sb_log2, int lds, uint32_t *flags, void *stream)
 {
     if (n_regions <= 0) return 0;
     const int bitdepth_max = (1 << bpc) - 1;
@@ -334,7 +345,7 @@ extern "C" int dav1d_hip_launch_intra_sb(const DevPlanes *dst, int bpc, int layo
         return hip_rc(hipGetLastError());
     }
 #define SB_LAUNCH(P, Cf, NW) hipLaunchKernelGGL((intra_sb_kernel<P, Cf, NW>), dim3(n_regions), dim3(NW * 64), 0, (hipStream_t) stream, *dst, units, regions, \
-                                                aux, (Cf *) coef, layout, bitdepth_max, flags, n_regions)
+                                                aux, mask, (Cf *) coef, layout, bitdepth_max, flags, n_regions)
     if (bpc == 8) { if (waves == 4) SB_LAUNCH(uint8_t, int16_t, 4); else SB_LAUNCH(uint8_t, int16_t, 8); }
     else { if (waves == 4) SB_LAUNCH(uint16_t, int32_t, 4); else SB_LAUNCH(uint16_t, int32_t, 8); }
 #undef SB_LAUNCH

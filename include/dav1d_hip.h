@@ -660,8 +660,8 @@ DAV1D_HIP_API int dav1d_hip_frame_submit_intra_sorted(Dav1dHipFrame *f, size_t n
                                                       const Dav1dHipItxTask *itx, const size_t *itx_end, const Dav1dHipCompTask *blend,
                                                       const size_t *blend_end);
 /* The frame's tiles in superblocks (seq_hdr->sb128, frame_hdr->tiling.cols / col_start_sb / rows / row_start_sb, as in
- * Dav1dHipFrameDesc).  With them the frame's intra blocks run superblock by superblock (dav1d_hip_intra_sb_*) instead of step by
- * step — provided no submission carries inter-intra blends or intra block copies.  Before the first intra submission (-EINVAL
+ * Dav1dHipFrameDesc).  With them the frame's intra blocks — the intra halves of inter-intra blocks and their blends included — run
+ * superblock by superblock (dav1d_hip_intra_sb_*) instead of step by step, provided no submission carries intra block copies.  Before the first intra submission (-EINVAL
  * after it); dav1d_hip_lister_create calls it. */
 DAV1D_HIP_API int dav1d_hip_frame_set_tiling(Dav1dHipFrame *f, int sb128, int n_tile_cols, const uint16_t *col_start_sb, int n_tile_rows,
                                              const uint16_t *row_start_sb);
