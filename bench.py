@@ -819,7 +819,7 @@ def main():
         # ---- end to end: the same kind of frame from dav1d's pass-1 hand-off arrays (Av1Block / cbi / cf) through the pass-2
         # lister on host threads, the chunk preparation, the coefficient upload and frame_end; checked against the reference's OWN
         # pass 2 (dav1d_decode_tile_sbrow on a real Dav1dFrameContext, oracle/ref_frame.c) when the reference build is there
-        e2e_leg = key_leg = full_route = None
+        e2e_leg = key_leg = full_route = e2e_packed = key_packed = None
         if world == 1 and not a.no_e2e:
             from dav1d_amd import e2e
 
@@ -834,6 +834,12 @@ def main():
             # the key-frame worst case (reference src/recon_tmpl.c:1239-1333, every block through the intra wavefront): same route
             key_leg = e2e.run(ctx, w, h, bpc, frames=4, threads=a.e2e_threads or None, tile_cols=a.e2e_tile_cols, tile_rows=a.e2e_tile_rows, key_frame=True, seed=0xE2F,
                               check=None if a.no_check else (lambda ho, planes, refs: e2e_check(ho, planes, refs, is_inter=False)))
+            # the same two legs through the PACKING lister (Dav1dHipFrameDesc.cf: eob + 1 values per block into the frame's own arena; what
+            # INTEGRATION.md recommends and the frames-in-flight legs below use): the 200 MB dense upload is gone from the frame's time
+            e2e_packed = e2e.run(ctx, w, h, bpc, frames=5, threads=a.e2e_threads or None, tile_cols=a.e2e_tile_cols, tile_rows=a.e2e_tile_rows, packed=True,
+                                 check=None if a.no_check else e2e_check)
+            key_packed = e2e.run(ctx, w, h, bpc, frames=4, threads=a.e2e_threads or None, tile_cols=a.e2e_tile_cols, tile_rows=a.e2e_tile_rows, key_frame=True,
+                                 seed=0xE2F, packed=True, check=None if a.no_check else (lambda ho, planes, refs: e2e_check(ho, planes, refs, is_inter=False)))
             # the whole frame — reconstruction AND in-loop filters — from pass 1's outputs, checked against the reference's own
             # dav1d_decode_tile_sbrow + dav1d_filter_sbrow (needs the reference build oracle/_ref for the filter inputs and the check)
             if not a.no_check:
@@ -977,7 +983,7 @@ def main():
                           "coef_format": "packed: eob + 1 scan-order values per block" if a.packed else "dense cf arena (reference layout)",
                           "coef_bytes_per_frame": int(coef_host.nbytes), "coef_h2d_ms_per_frame": h2d_ms,
                           "samples_per_frame": frame.n_samples, "parity": check, "gen_seconds": round(t_gen, 1)},
-               "roofline": roof, "cpu_baseline": cpu, "full_table": full, "end_to_end": e2e_leg, "all_intra": key_leg, "end_to_end_full_table": full_route, "end_to_end_4_tile_columns": e2e_c2, "end_to_end_full_table_4_tile_columns": full_route_c2,
+               "roofline": roof, "cpu_baseline": cpu, "full_table": full, "end_to_end": e2e_leg, "all_intra": key_leg, "end_to_end_packing_lister": e2e_packed, "all_intra_packing_lister": key_packed, "end_to_end_full_table": full_route, "end_to_end_4_tile_columns": e2e_c2, "end_to_end_full_table_4_tile_columns": full_route_c2,
                "end_to_end_frames_in_flight": sustained, "row_progress": row_progress, "refmvs": refmvs_leg, "dav1d_task_loop": task_loop, "config_c0_1080p_8bit": c0,
                "device": None if a.no_check else device_probe(torch)}       # (not under the profiler: its copies would sit in the kernel statistics)
         # BASELINE configs[1] (4K 8-bit, the reference's CPU-runnable size) next to the headline: the same bench in a child process,

@@ -119,8 +119,10 @@ def c2_params(seed, n_refs=3):
 
 
 def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0xE2E, check=None, intra_pct=0, key_frame=False, tile_rows=1,
-        native_threads=True):
-    """Returns the measurement dict.  check: optional callable(handoff, desc, planes) -> str used as the parity gate."""
+        native_threads=True, packed=False):
+    """Returns the measurement dict.  check: optional callable(handoff, desc, planes) -> str used as the parity gate.
+    packed: the packing lister (Dav1dHipFrameDesc.cf: the eob + 1 values per block go to the frame's own arena, the host arena is
+    left zeroed) instead of the dense arena crossing the host link; every frame gets a fresh copy of pass 1's coefficients."""
     layout = api.LAYOUT_I420
     ho = HandOff(w, h, layout, bpc, True, tile_cols, tile_rows)
     sp = c2_params(seed)
@@ -144,9 +146,11 @@ def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0
     n_tcols, n_trows = ho.desc.n_tile_cols, ho.desc.n_tile_rows
     n_tiles = n_tcols * n_trows
     threads = threads or n_tiles
-    coef = ctx.buffer(ho.cf.nbytes)
+    coef = ctx.buffer(ho.cf.nbytes if not packed else 4096)
     import torch
-    pinned = torch.from_numpy(ho.cf).pin_memory() if torch.cuda.is_available() else None
+    pinned = torch.from_numpy(ho.cf).pin_memory() if torch.cuda.is_available() and not packed else None
+    cf_copies = [np.array(ho.cf, copy=True) for _ in range(frames)] if packed else None
+    packed_bytes = 0
     nb = C.c_size_t()
     blob = ctx.lib.dav1d_hip_lister_const_masks(C.byref(nb))
     prep = mask = None
@@ -158,7 +162,11 @@ def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0
             t_a = time.perf_counter()
             frame = ctx.frame(cur, refs7)
             lh = C.c_void_p()
-            assert ctx.lib.dav1d_hip_lister_create(C.byref(lh), C.byref(ho.desc), frame.h) == 0
+            desc = ho.desc
+            if packed:
+                desc = _lib.FrameDesc.from_buffer_copy(ho.desc)
+                desc.cf = cf_copies[it].ctypes.data
+            assert ctx.lib.dav1d_hip_lister_create(C.byref(lh), C.byref(desc), frame.h) == 0
 
             def tile(k):
                 tr, tc = divmod(k, n_tcols)
@@ -167,6 +175,8 @@ def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0
                     assert rc2 == 0, rc2
             # the coefficient arena crosses the host link every frame (the kernels consume = zero it), while the listing runs
             def h2d():
+                if packed:
+                    return 0.0
                 t = time.perf_counter()
                 src = pinned.data_ptr() if pinned is not None else ho.cf.ctypes.data
                 assert ctx.lib.dav1d_hip_upload(ctx.h, coef.ptr, src, ho.cf.nbytes) == 0
@@ -185,7 +195,9 @@ def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0
                 mask = ctx.buffer(ctx.lib.dav1d_hip_lister_mask_bytes(lh) + 4096)
                 mask.upload(np.ctypeslib.as_array((C.c_uint8 * nb.value).from_address(blob)))
             t_c = time.perf_counter()
-            frame.end(coef, prep, mask)
+            if packed:
+                packed_bytes = int(ctx.lib.dav1d_hip_frame_coef_bytes(frame.h))
+            frame.end(None if packed else coef, prep, mask)
             t_d = time.perf_counter()
             steps = ctx.lib.dav1d_hip_lister_steps(lh)
             if it == frames - 1 and check is not None:
@@ -202,13 +214,13 @@ def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0
     out["host_threads"] = threads
     out["tiles"] = n_tiles
     out["wavefront_steps"] = int(steps)
-    out["coef_bytes_per_frame"] = int(ho.cf.nbytes)
+    out["coef_bytes_per_frame"] = int(packed_bytes if packed else ho.cf.nbytes)
     out["value"] = round(w * h / (out["total_ms"] * 1e-3) / 1e6, 1) if "total_ms" in out else None
     out["unit"] = "Mpixels/s"
     out["synth_seconds"] = round(t_synth, 2)
     kind = "key frame (every block intra)" if key_frame else "inter frame" if not intra_pct else "inter frame, %d %%%% intra blocks" % intra_pct
     out["workload"] = ("%dx%d 4:2:0 %d-bit " + kind + " from pass-1 hand-off arrays: lister on %d host threads" + (" of the library" if native_threads else "") + " over %d x %d tiles, chunk "
-                       "preparation + upload on the submitting threads, dense coefficient arena over the host link meanwhile (h2d_ms), "
+                       "preparation + upload on the submitting threads, " + ("the packing lister's values (eob + 1 per block) in the frame's own arena, " if packed else "dense coefficient arena over the host link meanwhile (h2d_ms), ") +
                        "frame_end = gather + the frame's launches + sync") % (w, h, bpc, threads, n_tcols, n_trows)
     if check is not None and planes is not None:
         out["parity"] = check(ho, planes, refs)

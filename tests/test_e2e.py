@@ -7,12 +7,13 @@ import lister_util as lu
 from dav1d_amd import e2e
 
 
+@pytest.mark.parametrize("packed", [False, True], ids=["dense-upload", "packing-lister"])
 @pytest.mark.parametrize("key_frame", [False, True], ids=["inter", "key"])
-def test_end_to_end_route_matches_reference_pass2(ctx, key_frame, twin_refs):
+def test_end_to_end_route_matches_reference_pass2(ctx, key_frame, packed, twin_refs):
     if lu.ref_lib() is None:
         pytest.skip("no reference build (oracle/_ref)")
     w, h = (384, 256) if ctx.backend == "emu" else (1920, 1080)
-    out = e2e.run(ctx, w, h, 10, frames=2, threads=3, tile_cols=2, tile_rows=2, seed=77, key_frame=key_frame,
+    out = e2e.run(ctx, w, h, 10, frames=2, threads=3, tile_cols=2, tile_rows=2, seed=77, key_frame=key_frame, packed=packed,
                   check=lambda ho, planes, refs: lu.check_handoff_against_reference(ho, planes, refs, is_inter=not key_frame))
     assert out["parity"].startswith("bit-exact"), out["parity"]
     assert out["wavefront_steps"] >= (2 if key_frame else 0)
