@@ -259,6 +259,13 @@ def test_key_frame_superblock_by_superblock(ctx, bpc, sb128, lds):
         assert st["steps"] >= 50 and not st["coef_after"].any()
         run_case(c2, 448, 320, 1, bpc, 22 + bpc, is_inter=False, tiles=(1, 1), sb128=sb128)
         run_case(c2, 448, 320, 1, bpc, 23 + bpc, is_inter=True, tiles=(2, 1), threads=2, sb128=sb128, **dict(PLAIN, intra_pct=25))
+        if lds == 0 and sb128:
+            # inter-intra blocks are units of the route too (prediction, blend with the inter prediction, residual) ...
+            run_case(c2, 448, 320, 1, bpc, 24 + bpc, is_inter=True, tiles=(2, 1), threads=2, **dict(PLAIN, intra_pct=20, interintra_pct=40))
+            # ... and with intra_sb = 1 only the long wavefronts take it: the short one of this frame runs launch by launch from the
+            # same submissions
+            c2.set_option("intra_sb", 1)
+            run_case(c2, 448, 320, 1, bpc, 23 + bpc, is_inter=True, tiles=(2, 1), threads=2, **dict(PLAIN, intra_pct=25))
     finally:
         c2.close()
 
