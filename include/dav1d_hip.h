@@ -436,7 +436,8 @@ DAV1D_HIP_API int dav1d_hip_intra_flow_status(Dav1dHipContext *c, const Dav1dHip
 /* The same wavefront SUPERBLOCK BY SUPERBLOCK: a workgroup owns a superblock and works its units off step by step behind
  * workgroup barriers; superblocks are ordered in levels — a superblock's level is one more than the highest among its left,
  * top-left, top and top-right neighbours of the same tile that hold intra units (all the reference's decode order lets a
- * block read: src/decode.c:2117-2375, src/ipred_prepare_tmpl.c:82-116) — and a level is one launch.  The batches must be the
+ * block read: src/decode.c:2117-2375, src/ipred_prepare_tmpl.c:82-116).  The levels run as ONE launch in which a superblock
+ * waits for the neighbours it reads (option intra_sb_flow, default), or as a launch per level.  The batches must be the
  * steps of a wavefront in which a block's step exceeds the step of every block it reads INSIDE its superblock (the listers'
  * and any decode-order-consistent numbering do).  geometry: a picture of the frame's size / layout / strides; sb128 and the
  * tile starts as in Dav1dHipFrameDesc.  -ENOTSUP for the task kinds dav1d_hip_intra_flow_create refuses.  run only enqueues. */
@@ -447,7 +448,7 @@ DAV1D_HIP_API int dav1d_hip_intra_sb_create(Dav1dHipContext *c, Dav1dHipIntraSb 
                                             int n_tile_rows, const uint16_t *row_start_sb);
 DAV1D_HIP_API int dav1d_hip_intra_sb_run(Dav1dHipContext *c, const Dav1dHipIntraSb *l, const Dav1dHipPicture *dst, void *coef, uint8_t *aux);
 DAV1D_HIP_API void dav1d_hip_intra_sb_destroy(Dav1dHipContext *c, Dav1dHipIntraSb *l);
-DAV1D_HIP_API size_t dav1d_hip_intra_sb_levels(const Dav1dHipIntraSb *l);          /* launches per run */
+DAV1D_HIP_API size_t dav1d_hip_intra_sb_levels(const Dav1dHipIntraSb *l);          /* levels of superblocks (launches per run with intra_sb_flow = 0) */
 DAV1D_HIP_API size_t dav1d_hip_intra_sb_superblocks(const Dav1dHipIntraSb *l);     /* superblocks that hold units */
 
 /* ------------------------------------------------- mc: warp, scaled, resize, emu_edge */
