@@ -928,6 +928,9 @@ def main():
                 sustained["recon"] = e2e.run_sustained(ctx, w, h, bpc, frames=24, threads=None, tile_cols=a.e2e_tile_cols, tile_rows=a.e2e_tile_rows,
                                                        check=None if a.no_check else e2e_check)
                 sustained["recon_burst_64_threads"] = e2e.run_sustained(ctx, w, h, bpc, frames=16, threads=64, tile_cols=a.e2e_tile_cols, tile_rows=a.e2e_tile_rows)
+                # key frames the same way: the listing of frame n + 1 under the superblock launch of frame n
+                sustained["all_intra"] = e2e.run_sustained(ctx, w, h, bpc, frames=8, threads=64, tile_cols=a.e2e_tile_cols, tile_rows=a.e2e_tile_rows, seed=0xE2F,
+                                                           key_frame=True, check=None if a.no_check else (lambda ho, planes, refs: e2e_check(ho, planes, refs, is_inter=False)))
                 sustained["recon_4_tile_columns"] = e2e.run_sustained(ctx, w, h, bpc, frames=6, threads=4, tile_cols=4, tile_rows=1,
                                                                       check=None if a.no_check else e2e_check)
                 if not a.no_check:

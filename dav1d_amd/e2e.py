@@ -391,12 +391,17 @@ def run_pipelined(ctx, desc, cf_frames, w, h, layout, bpc, refs, threads, depth=
     return out, last.get("planes")
 
 
-def run_sustained(ctx, w=7680, h=4320, bpc=10, frames=10, threads=None, tile_cols=4, tile_rows=1, seed=0xE2E, check=None, depth=2, warm=2):
-    """The reconstruction route with frames in flight (run_pipelined): the synthetic inter frame of run(), every frame with a
-    coefficient arena of its own that the packing lister consumes; nothing dense crosses the host link."""
+def run_sustained(ctx, w=7680, h=4320, bpc=10, frames=10, threads=None, tile_cols=4, tile_rows=1, seed=0xE2E, check=None, depth=2, warm=2,
+                  key_frame=False):
+    """The reconstruction route with frames in flight (run_pipelined): the synthetic inter frame of run() (key_frame: its key frame,
+    every block intra), every frame with a coefficient arena of its own that the packing lister consumes; nothing dense crosses the
+    host link."""
     layout = api.LAYOUT_I420
     ho = HandOff(w, h, layout, bpc, True, tile_cols, tile_rows)
     sp = c2_params(seed)
+    if key_frame:
+        sp.intra_pct = 100
+        ho.desc.is_inter = 0
     rc = ctx.lib.dav1d_hip_synth_frame(C.byref(ho.desc), C.byref(sp), ho.cf.ctypes.data, ho.cf.nbytes, len(ho.cbi), None, 0)
     assert rc == 0, rc
     rng = np.random.default_rng(seed)
@@ -413,10 +418,10 @@ def run_sustained(ctx, w=7680, h=4320, bpc=10, frames=10, threads=None, tile_col
     out, planes = run_pipelined(ctx, ho.desc, cfs, w, h, layout, bpc, [refs[i % 3] for i in range(7)], threads, depth, warm)
     out["tiles"] = n_tiles
     out["host_arena_left_zero"] = not any(bool(c.any()) for c in cfs)
-    out["workload"] = ("%dx%d 4:2:0 %d-bit inter frame from pass-1 hand-off arrays, %d frames in flight: the packing lister on %d library "
+    out["workload"] = ("%dx%d 4:2:0 %d-bit %s frame from pass-1 hand-off arrays, %d frames in flight: the packing lister on %d library "
                        "threads over %d x %d tiles (eob + 1 values per block into the frame's pinned arena, host arena zeroed), chunk "
                        "preparation on the listing threads, frame_end (transfer + gather + launches + sync) of frame n under the "
-                       "listing of frame n + 1" % (w, h, bpc, depth, threads, ho.desc.n_tile_cols, ho.desc.n_tile_rows))
+                       "listing of frame n + 1" % (w, h, bpc, "key" if key_frame else "inter", depth, threads, ho.desc.n_tile_cols, ho.desc.n_tile_rows))
     if check is not None and planes is not None:
         out["parity"] = check(ho, planes, refs)
     for o in refs:
