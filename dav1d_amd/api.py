@@ -480,6 +480,11 @@ class _IntraSb:
         _chk(self.ctx.lib.dav1d_hip_intra_sb_run(self.ctx.h, self.h, C.byref(dst.pic), coef.ptr if hasattr(coef, "ptr") else coef,
                                                  aux.ptr if aux else None), "intra_sb_run")
 
+    def status(self):
+        """dav1d_hip_intra_sb_status: waits for the run; raises when superblocks of the one-launch form were left unreconstructed"""
+        n = C.c_uint32()
+        _chk(self.ctx.lib.dav1d_hip_intra_sb_status(self.ctx.h, self.h, C.byref(n)), "intra_sb_status (%d superblocks gave up)" % n.value)
+
     def destroy(self):
         if self.h:
             self.ctx.lib.dav1d_hip_intra_sb_destroy(self.ctx.h, self.h)
@@ -525,9 +530,15 @@ class FrameInFlight:
 
     def __init__(self, ctx, cur, refs):
         self.ctx = ctx
+        self.cur = cur
         self.h = C.c_void_p()
         arr = (Picture * max(len(refs), 1))(*[r.pic for r in refs])
         _chk(ctx.lib.dav1d_hip_frame_begin(ctx.h, C.byref(self.h), C.byref(cur.pic), arr, len(refs)), "frame_begin")
+
+    def _cur_written(self, filtered):
+        # the frame wrote cur's raster planes: its tiled twin is valid only if the frame itself retiled it (option ref_twin = 2)
+        same = filtered is not None and filtered.p[0].data == self.cur.pic.p[0].data
+        self.cur.pic.twin_ok = filtered.twin_ok if same else 0
 
     def submit_tile_sbrow(self, mc, comp, itx):
         m = np.ascontiguousarray(mc, dtype=MC_TASK)
@@ -561,6 +572,7 @@ class FrameInFlight:
         _chk(self.ctx.lib.dav1d_hip_frame_end(self.h, coef.ptr if coef is not None else None, prep.ptr if prep is not None else None,
                                               mask.ptr if mask is not None else None, C.byref(filtered),
                                               C.byref(grain_out.pic) if grain_out is not None else None), "frame_end")
+        self._cur_written(filtered)
         return filtered
 
     def end_async(self, coef, prep, mask=None, grain_out=None, done=None):
@@ -584,6 +596,7 @@ class FrameInFlight:
     def wait(self):
         filtered = Picture()
         _chk(self.ctx.lib.dav1d_hip_frame_wait(self.h, C.byref(filtered)), "frame_wait")
+        self._cur_written(filtered)
         return filtered
 
     def post_bands(self):

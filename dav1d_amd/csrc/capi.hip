@@ -2357,6 +2357,20 @@ int dav1d_hip_intra_sb_run(Dav1dHipContext *c, const Dav1dHipIntraSb *l, const D
     return rc;
 }
 
+// after dav1d_hip_intra_sb_run: waits for the stream; workgroups of the one-launch form that gave up waiting for a neighbour (none in
+// a sound run, see include/dav1d_hip.h) left their superblocks unreconstructed -> -EIO
+int dav1d_hip_intra_sb_status(Dav1dHipContext *c, const Dav1dHipIntraSb *l, uint32_t *gave_up) {
+    if (!c || !l) return -EINVAL;
+    uint32_t n = 0;
+    if (gave_up) *gave_up = 0;
+    if (!l->flags || !l->n_units) return dav1d_hip_sync(c);
+    const int rc = dav1d_hip_download(c, &n, l->flags + l->n_regions, sizeof(n));
+    if (rc) return rc;
+    if (!(c->intra_sb_flow && !c->intra_sb_lds && l->level_start.size() > 2)) n = 0;      // the flags are only written by the one-launch form
+    if (gave_up) *gave_up = n;
+    return n ? -EIO : 0;
+}
+
 int dav1d_hip_intra_list_run_batch(Dav1dHipContext *c, const Dav1dHipIntraList *l, size_t batch, const Dav1dHipPicture *dst, void *coef,
                                    uint8_t *aux) {
     return dav1d_hip_intra_list_run_batch_blend(c, l, batch, dst, coef, aux, nullptr, nullptr);

@@ -936,19 +936,26 @@ static int frame_lr_banded(Dav1dHipFrame *f, const Dav1dHipPicture *out, const D
     const uint32_t seq = ++c->band_seq ? c->band_seq : ++c->band_seq;        // never 0: the flags start at 0
     const BandSignal sig = { c->band_cnt, reinterpret_cast<const uint32_t *>(devb + o_waves + n_waves * 16), c->band_flags, seq };
     const DevPlanes dp = dev_planes(out), sp = dev_planes(in), lp = dev_planes(lpf);
+    // "everything before restoration is through" (reconstruction, deblocking, CDEF, the copy of the units that are not listed): what a
+    // band WITHOUT restoration tasks has to wait for before its rows count as final
+    if (!rc) rc = hip_rc(hipEventRecord(c->ev_fork, c->stream));
     if (!rc) rc = dav1d_hip_launch_wiener_sig(&dp, &sp, &lp, out->bpc, dev, (int) nw, max_w, &sig, c->stream);
     if (!rc) rc = dav1d_hip_launch_sgr_sig(&dp, &sp, &lp, out->bpc, dev + nw, devb + o_waves, (int) n_waves, &sig, c->stream);
     // the bands come through (roughly) in order; the last one is published with the frame (frame_run).  A band without tasks has
     // nothing to wait for beyond the bands before it.
     if (!rc) {
         volatile uint32_t *const flags = c->band_flags;
-        bool all_done = false;
+        bool all_done = false, waited = false;
         for (int b = 0; b + 1 < nb; b++) {
             for (unsigned spin = 0; target[b] && flags[b] != seq && !all_done; spin++) {
                 if ((spin & 63) == 63) all_done = hipStreamQuery(c->stream) == hipSuccess;          // (also the way out should a launch have failed)
                 else std::this_thread::yield();
             }
             if (all_done && flags[b] != seq && target[b]) break;
+            // a band's flag says "the restoration workgroups of this band have written their pixels", which orders it behind the
+            // earlier stages only for bands that HAVE such workgroups: the leading bands without any wait for the stages themselves
+            if (target[b]) waited = true;
+            else if (!waited) { if (hipEventSynchronize(c->ev_fork) != hipSuccess) break; waited = true; }
             std::atomic_thread_fence(std::memory_order_acquire);
             f->publish(first_y[b + 1], out);
         }
@@ -1002,6 +1009,11 @@ int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *ma
 static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask, Dav1dHipPicture *filtered, const Dav1dHipPicture *grain_out) {
     Dav1dHipContext *c = f->c;
     int rc = 0;
+    // the raster planes of every picture this frame writes change below: whatever tiled twin a recycled picture still carries is
+    // stale from here on (*filtered is a copy of one of these descriptors, so it reports twin_ok = 0 unless the frame retiles it)
+    f->cur.twin_ok = 0;
+    for (int k = 0; k < 2; k++) f->tmp[k].twin_ok = 0;
+    for (int k = 0; k < 3; k++) f->sr[k].twin_ok = 0;
     if (f->saw_packed.load()) {
         // a packed frame: every residual task points into the frame's own coefficient arena (a dense arena next to it is not
         // supported: the kernels take one base).  What the flushes have not sent goes now, the late segments behind it.

@@ -1193,7 +1193,9 @@ int dav1d_hip_lister_tile_sbrow(Dav1dHipLister *l, const int tile_row, const int
     if (sby == l->d.row_start_sb[tile_row]) {
         /* the tile's share of the cell maps: zero = "final before the wavefront starts" (what an inter block's cells stay at), and
          * dep_step() looks at cells of rows that are listed later (the bottom-left extension of an edge) */
-        const int y_end = imin(((l->d.row_start_sb[tile_row + 1] << sb_shift) + 31) & ~31, (l->bh + 31) & ~31);
+        /* ... of THIS tile only: the rows of the tile below belong to whoever lists that tile's first superblock row, which may
+         * have happened already (tile-sbrows of different tiles come in any order); only the last tile row owns the padding rows */
+        const int y_end = tile_row + 1 < l->d.n_tile_rows ? imin(l->d.row_start_sb[tile_row + 1] << sb_shift, (l->bh + 31) & ~31) : (l->bh + 31) & ~31;
         const size_t x0 = (size_t) w.col_start, nx = (size_t) (imin(l->d.col_start_sb[tile_col + 1] << sb_shift, (int) l->d.b4_stride) - w.col_start);
         for (int y = w.row_start; y < y_end; y++) memset(l->owner + (size_t) y * l->d.b4_stride + x0, 0, nx * sizeof(uint32_t));
         for (int p = 0; p < 3; p++) {            /* the chroma maps count in cells of their plane */

@@ -447,6 +447,15 @@ DAV1D_HIP_API int dav1d_hip_intra_sb_create(Dav1dHipContext *c, Dav1dHipIntraSb 
                                             const Dav1dHipPicture *geometry, int sb128, int n_tile_cols, const uint16_t *col_start_sb,
                                             int n_tile_rows, const uint16_t *row_start_sb);
 DAV1D_HIP_API int dav1d_hip_intra_sb_run(Dav1dHipContext *c, const Dav1dHipIntraSb *l, const Dav1dHipPicture *dst, void *coef, uint8_t *aux);
+/* The one-launch form (option intra_sb_flow) is a dataflow inside ONE grid: a workgroup spins on the flags of workgroups with LOWER
+ * indices.  That makes forward progress only because (a) the hardware dispatches the workgroups of a grid in index order and (b) a
+ * workgroup that has been dispatched keeps its compute unit until it ends (no preemption of a running wave by this process's own
+ * launches) — true of gfx950 with the ROCm 7 firmware, NOT promised by the HIP programming model.  Should either stop holding, a
+ * waiting workgroup gives up after about 0.8 s (SB_SPIN_LIMIT in csrc/intra_sb.hip), marks itself so that its dependants give up
+ * too, and counts itself: dav1d_hip_frame_end then fails the frame with -EIO, and after dav1d_hip_intra_sb_run the caller asks
+ * dav1d_hip_intra_sb_status (synchronizes): 0, or -EIO with *gave_up = superblocks left unreconstructed.  The launch-per-level form
+ * (intra_sb_flow = 0) relies on neither assumption. */
+DAV1D_HIP_API int dav1d_hip_intra_sb_status(Dav1dHipContext *c, const Dav1dHipIntraSb *l, uint32_t *gave_up);
 DAV1D_HIP_API void dav1d_hip_intra_sb_destroy(Dav1dHipContext *c, Dav1dHipIntraSb *l);
 DAV1D_HIP_API size_t dav1d_hip_intra_sb_levels(const Dav1dHipIntraSb *l);          /* levels of superblocks (launches per run with intra_sb_flow = 0) */
 DAV1D_HIP_API size_t dav1d_hip_intra_sb_superblocks(const Dav1dHipIntraSb *l);     /* superblocks that hold units */

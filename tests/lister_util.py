@@ -298,7 +298,7 @@ def fill_pictures(rf, seed):
                 a[...] = v.astype(a.dtype)
 
 
-def run_hip(ctx, rf, d, threads=1, with_filters=False, own_masks=False, packed=False):
+def run_hip(ctx, rf, d, threads=1, with_filters=False, own_masks=False, packed=False, interleave=False):
     """lister -> frame API -> kernels; returns the reconstructed planes (visible area) and the lister handle stats.
     packed: the lister gathers the coefficients that exist out of the host arena (Dav1dHipFrameDesc.cf) into the frame's own
     coefficient arena, zeroing them in place; no dense arena goes to the device."""
@@ -329,7 +329,20 @@ def run_hip(ctx, rf, d, threads=1, with_filters=False, own_masks=False, packed=F
         for sby in range(d.row_start_sb[tr], d.row_start_sb[tr + 1]):
             rc2 = ctx.lib.dav1d_hip_lister_tile_sbrow(lh, tr, tc, sby)
             assert rc2 == 0, "lister_tile_sbrow(%d, %d, %d): %d" % (tr, tc, sby, rc2)
-    if threads > 1:
+    if interleave:
+        # tile-sbrows of different tiles come in any order (dav1d's task scheduling): the k-th superblock row of every tile, lowest
+        # tile row first, then the (k + 1)-th
+        k, left = 0, True
+        while left:
+            left = False
+            for tr, tc in reversed(jobs):
+                sby = d.row_start_sb[tr] + k
+                if sby < d.row_start_sb[tr + 1]:
+                    left = True
+                    rc2 = ctx.lib.dav1d_hip_lister_tile_sbrow(lh, tr, tc, sby)
+                    assert rc2 == 0, "lister_tile_sbrow(%d, %d, %d): %d" % (tr, tc, sby, rc2)
+            k += 1
+    elif threads > 1:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(threads) as ex:
             list(ex.map(one_tile, jobs))

@@ -33,7 +33,7 @@ def scaled_refs(w, h):
 
 
 def run_case(ctx, w, h, layout, bpc, seed, is_inter=True, tiles=(1, 1), threads=1, sb128=True, ref_sizes=None, gmv=None, segments=None,
-             packed=False, **kw):
+             packed=False, interleave=False, **kw):
     rf = lu.RefFrame(w, h, layout, bpc, is_inter=is_inter, tile_cols=tiles[0], tile_rows=tiles[1], sb128=sb128,
                      screen_content=1 if kw.get("palette") else 0, ref_sizes=ref_sizes, gmv=gmv, segments=segments)
     try:
@@ -44,7 +44,7 @@ def run_case(ctx, w, h, layout, bpc, seed, is_inter=True, tiles=(1, 1), threads=
             assert int(((blk[:, 3] == 0) & ((blk[:, 0] | blk[:, 1]) != 0)).sum()) > 50
         lu.fill_pictures(rf, seed + 1)
         rf.recon()
-        got, st = lu.run_hip(ctx, rf, d, threads, packed=packed)
+        got, st = lu.run_hip(ctx, rf, d, threads, packed=packed, interleave=interleave)
         bad = lu.compare(rf, got)
         assert not bad, "planes differ from the reference's pass 2: (plane, pixels, first y, x, want, got) %s" % bad
         # the coefficient arena is consumed exactly as the reference consumes it (itx zeroes what it read)
@@ -268,6 +268,14 @@ def test_key_frame_superblock_by_superblock(ctx, bpc, sb128, lds):
             run_case(c2, 448, 320, 1, bpc, 23 + bpc, is_inter=True, tiles=(2, 1), threads=2, **dict(PLAIN, intra_pct=25))
     finally:
         c2.close()
+
+
+def test_tile_sbrows_interleaved_across_tile_rows_with_an_odd_row_boundary(ctx):
+    """dav1d's scheduler lists tile-sbrows of different tiles in any order.  64-pixel superblocks, two tile rows meeting at superblock
+    row 3 (48 cells: not a multiple of the 32 cells the maps are padded to): the first superblock row of the LOWER tile is listed before
+    the upper tile's, whose clearing of its share of the cell maps must stop at its own last row (lister.c)."""
+    for is_inter, kw in ((False, dict(palette=10)), (True, dict(PLAIN, intra_pct=30))):
+        run_case(ctx, 448, 320, 1, 10, 77, is_inter=is_inter, tiles=(2, 2), sb128=False, interleave=True, **kw)
 
 
 @pytest.mark.gpu

@@ -171,6 +171,7 @@ def hip_intra(ctx, ip, pic, timed=False, graph=False, paired=True, flow=False, s
     if g is not None:
         ctx.graph_destroy(g)
     if sl is not None:
+        sl.status()                            # no superblock of the one-launch form gave up waiting for a neighbour
         sl.destroy()
     elif fl is not None:
         hip_intra.flow_status = fl.status()
