@@ -310,7 +310,7 @@ extern "C" int dav1d_hip_launch_cdef(const DevPlanes *dst, const DevPlanes *src,
 struct CdefGroup {
     uint32_t first;
     uint16_t bx0, by;
-    uint8_t n, span, edges, pad;
+    uint8_t n, span, edges, pad;      // pad: the units' DAV1D_HIP_CDEF_BOT_REP_* flags
 };
 // appends the groups of tasks[0 .. n) (indices offset by `base`) in list order; returns the number of RAW tasks met
 size_t dav1d_hip_cdef_make_groups(const Dav1dHipCdefTask *tasks, size_t n, size_t base, std::vector<CdefGroup> &out);

@@ -122,7 +122,7 @@ __device__ __forceinline__ int cdef_px_pair(const int16_t *tmp, const int x, con
 // block (one pass), 96 for 4x8, 144 for 8x8.
 template <typename pixel, int WW>
 __device__ __forceinline__ void load_window(int16_t *tmp, const pixel *src, const int stride, const int x0, const int y0,
-                                            const int h, const int edges, const int lane)
+                                            const int h, const int edges, const int lane, const bool rep_bot = false)
 {
     constexpr int w = WW - 4;
     const int n = WW * (h + 4);
@@ -130,7 +130,8 @@ __device__ __forceinline__ void load_window(int16_t *tmp, const pixel *src, cons
         const int yy = i / WW - 2, xx = i % WW - 2;
         const bool avail = (yy >= 0 || (edges & 4)) && (yy < h || (edges & 8)) && (xx >= 0 || (edges & 1)) && (xx < w || (edges & 2));
         int v = -32768;
-        if (avail) v = src[(y0 + yy) * stride + x0 + xx];
+        // rep_bot: the second row below the block is the first one once more (DAV1D_HIP_CDEF_BOT_REP_*)
+        if (avail) v = src[(y0 + (rep_bot && yy == h + 1 ? h : yy)) * stride + x0 + xx];
         tmp[(yy + 2) * 12 + xx + 2] = (int16_t) v;
     }
 }
@@ -174,8 +175,9 @@ __global__ __launch_bounds__(64) void cdef_kernel(const DevPlanes dst, const Dev
     const int lw = raw_ ? (t.flags & 2 ? 4 : 8) : 8, lh = raw_ ? (t.flags & 4 ? 4 : 8) : 8;
     const pixel *sy = reinterpret_cast<const pixel *>(src.data[lpl]);
     const int x0 = raw_ ? t.bx : t.bx * 8, y0 = raw_ ? t.by : t.by * 8;   // raw: pixel coordinates
-    if (HBD && edges == 15 && lw == 8) load_window_fast<12>(tmp, reinterpret_cast<const uint16_t *>(sy), src.stride[lpl], x0, y0, lh, lane);
-    else if (lw == 8) load_window<pixel, 12>(tmp, sy, src.stride[lpl], x0, y0, lh, edges, lane);
+    const bool rep_y = !raw_ && (t.flags & DAV1D_HIP_CDEF_BOT_REP_Y), rep_uv = !raw_ && (t.flags & DAV1D_HIP_CDEF_BOT_REP_UV);
+    if (HBD && edges == 15 && lw == 8 && !rep_y) load_window_fast<12>(tmp, reinterpret_cast<const uint16_t *>(sy), src.stride[lpl], x0, y0, lh, lane);
+    else if (lw == 8) load_window<pixel, 12>(tmp, sy, src.stride[lpl], x0, y0, lh, edges, lane, rep_y);
     else load_window<pixel, 8>(tmp, sy, src.stride[lpl], x0, y0, lh, edges, lane);
     dv::wave_sync();
 
@@ -285,16 +287,16 @@ __global__ __launch_bounds__(64) void cdef_kernel(const DevPlanes dst, const Dev
         if (t.uv_pri) uvdir = layout == DAV1D_HIP_LAYOUT_I422 ? (int) ((uv422 >> (4 * dir)) & 15) : dir;
         const int cx0 = x0 >> ss_hor, cy0 = y0 >> ss_ver;
         dv::wave_sync();
-        if (HBD && edges == 15 && w == 4) {
+        if (HBD && edges == 15 && w == 4 && !rep_uv) {
             // 4-wide chroma: 2 pieces x (h + 4) rows per plane, U on lanes 0 .. 31, V on lanes 32 .. 63
             load_window_fast<8>(lane < 32 ? tmp : tmp2, reinterpret_cast<const uint16_t *>(src.data[lane < 32 ? 1 : 2]),
                                 src.stride[lane < 32 ? 1 : 2], cx0, cy0, h, lane & 31);
         } else if (w == 8) {
-            load_window<pixel, 12>(tmp, reinterpret_cast<const pixel *>(src.data[1]), src.stride[1], cx0, cy0, h, edges, lane);
-            load_window<pixel, 12>(tmp2, reinterpret_cast<const pixel *>(src.data[2]), src.stride[2], cx0, cy0, h, edges, lane);
+            load_window<pixel, 12>(tmp, reinterpret_cast<const pixel *>(src.data[1]), src.stride[1], cx0, cy0, h, edges, lane, rep_uv);
+            load_window<pixel, 12>(tmp2, reinterpret_cast<const pixel *>(src.data[2]), src.stride[2], cx0, cy0, h, edges, lane, rep_uv);
         } else {
-            load_window<pixel, 8>(tmp, reinterpret_cast<const pixel *>(src.data[1]), src.stride[1], cx0, cy0, h, edges, lane);
-            load_window<pixel, 8>(tmp2, reinterpret_cast<const pixel *>(src.data[2]), src.stride[2], cx0, cy0, h, edges, lane);
+            load_window<pixel, 8>(tmp, reinterpret_cast<const pixel *>(src.data[1]), src.stride[1], cx0, cy0, h, edges, lane, rep_uv);
+            load_window<pixel, 8>(tmp2, reinterpret_cast<const pixel *>(src.data[2]), src.stride[2], cx0, cy0, h, edges, lane, rep_uv);
         }
         dv::wave_sync();
         const int npx = w * h;                        // 16, 32 or 64 pixels per plane
@@ -400,7 +402,7 @@ __device__ __forceinline__ void cdef_load_piece(uint16_t *dstp, const pixel *src
 // pieces per pass: a lane keeps its piece and its row within the pass, only the row advances.
 template <typename pixel, int W, int H>
 __device__ __forceinline__ void cdef_load_window(uint16_t *win, const pixel *src, const int stride, const int x0, const int y0,
-                                                 const int span, const int edges, const int lane)
+                                                 const int span, const int edges, const int lane, const bool rep_bot)
 {
     constexpr int NPR = 18;
     const int r3 = lane / NPR, p = lane - r3 * NPR;
@@ -413,7 +415,8 @@ __device__ __forceinline__ void cdef_load_window(uint16_t *win, const pixel *src
         const int row = it * 3 + r3;
         if ((H + 4) % 3 && row >= H + 4) break;
         const bool ok = col_ok && (row >= 2 || (edges & 4)) && (row < H + 2 || (edges & 8));
-        cdef_load_piece<pixel, W>(wp + it * 3 * NPR * W, sp + it * 3 * stride, ok);
+        // rep_bot: the window's last row (the second below the units) is the one before it once more (DAV1D_HIP_CDEF_BOT_REP_*)
+        cdef_load_piece<pixel, W>(wp + it * 3 * NPR * W, sp + (it * 3 - (rep_bot && row == H + 3)) * stride, ok);
     }
 }
 
@@ -547,10 +550,11 @@ __global__ __launch_bounds__(64) void cdef_strip_kernel(const DevPlanes dst, con
     const bool any_uv = CW && __any(uv);
     constexpr int ss_hor = CW == 4, ss_ver = CH == 4;
     const int cx0 = x0 >> ss_hor, cy0 = y0 >> ss_ver;
-    cdef_load_window<pixel, 8, 8>(win, reinterpret_cast<const pixel *>(src.data[0]), src.stride[0], x0, y0, span, edges, lane);
+    const bool rep_y = g.pad & DAV1D_HIP_CDEF_BOT_REP_Y, rep_uv = g.pad & DAV1D_HIP_CDEF_BOT_REP_UV;      // (the group carries its units' flags)
+    cdef_load_window<pixel, 8, 8>(win, reinterpret_cast<const pixel *>(src.data[0]), src.stride[0], x0, y0, span, edges, lane, rep_y);
     if (CW && any_uv) {
-        cdef_load_window<pixel, CW ? CW : 8, CW ? CH : 8>(cwin[0], reinterpret_cast<const pixel *>(src.data[1]), src.stride[1], cx0, cy0, span, edges, lane);
-        cdef_load_window<pixel, CW ? CW : 8, CW ? CH : 8>(cwin[1], reinterpret_cast<const pixel *>(src.data[2]), src.stride[2], cx0, cy0, span, edges, lane);
+        cdef_load_window<pixel, CW ? CW : 8, CW ? CH : 8>(cwin[0], reinterpret_cast<const pixel *>(src.data[1]), src.stride[1], cx0, cy0, span, edges, lane, rep_uv);
+        cdef_load_window<pixel, CW ? CW : 8, CW ? CH : 8>(cwin[1], reinterpret_cast<const pixel *>(src.data[2]), src.stride[2], cx0, cy0, span, edges, lane, rep_uv);
     }
     dv::wave_sync();
 
@@ -697,11 +701,12 @@ size_t dav1d_hip_cdef_make_groups(const Dav1dHipCdefTask *tasks, size_t n, size_
         if (t.flags & 1) { n_raw++; if (open) { out.push_back(g); open = false; } continue; }
         // a unit joins the open group when it lies further right in the same row within 16 units of the group's first one, shares
         // the rows above / below, has a left neighbour, and the unit before it has a right neighbour
+        const uint8_t rep = t.flags & (DAV1D_HIP_CDEF_BOT_REP_Y | DAV1D_HIP_CDEF_BOT_REP_UV);
         const bool joins = open && t.by == g.by && t.bx > last_bx && t.bx - g.bx0 < 16 && g.n < 16 && (t.edges & 12) == (g.edges & 12) &&
-                           (t.edges & 1) && (last_edges & 2);
+                           (t.edges & 1) && (last_edges & 2) && rep == g.pad;
         if (!joins) {
             if (open) out.push_back(g);
-            g.first = (uint32_t) (base + i); g.bx0 = t.bx; g.by = t.by; g.n = 0; g.pad = 0;
+            g.first = (uint32_t) (base + i); g.bx0 = t.bx; g.by = t.by; g.n = 0; g.pad = rep;
             g.edges = (uint8_t) (t.edges & 13);
             open = true;
         }

@@ -97,7 +97,8 @@ __global__ __launch_bounds__(64) void wiener_kernel(const DevPlanes dst, const D
             if (edges & 4) row = l + (t.y - (r == -1 ? 1 : 2)) * ls;
             else row = s + t.y * ss;
         } else if (r >= h) {
-            if (use_bottom) row = l + (t.y + h + (r == h ? 0 : 1)) * ls;
+            // (a row beyond the plane's last is that last row once more: backup_lpf's n_lines, src/lf_apply_tmpl.c:77-97)
+            if (use_bottom) row = l + dv::imin(t.y + h + (r == h ? 0 : 1), lpf.h[pl] - 1) * ls;
             else row = s + (t.y + h - 1) * ss;
         } else {
             row = s + (t.y + r) * ss;
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(64) void sgr_kernel(const DevPlanes dst, const DevP
             if (edges & 4) row = l + (ty - (r == -1 ? 1 : 2)) * ls;
             else row = s + ty * ss;
         } else if (r >= h) {
-            if (use_bottom) row = l + (ty + h + (r == h ? 0 : 1)) * ls;
+            if (use_bottom) row = l + dv::imin(ty + h + (r == h ? 0 : 1), lpf.h[pl] - 1) * ls;
             else row = s + (ty + h - 1) * ss;
         } else row = s + (ty + r) * ss;
         const int p0 = row[col[0]], p1 = row[col[1]], p2 = row[col[2]], p3 = row[col[3]], p4 = row[col[4]];

@@ -140,6 +140,15 @@ static void list_cdef(const ListerGeo *g, const Dav1dHipFilterDesc *fd, FOut *o,
     for (int by = start; by < end; by += 2) {
         const Dav1dHipAv1Filter *const row = fd->lf_mask + (size_t) (by >> 5) * sb128w;
         const int by_idx = (by & 30) >> 1;
+        /* The last unit row of a superblock row's own band (dav1d_filter_sbrow_cdef leaves the 8 rows under it to the next
+         * superblock row: src/recon_tmpl.c:2027-2051) reads its two bottom rows from the lines backup_lpf() saved, and backup_lpf
+         * stores the picture's last row twice when it is the first of the two (src/lf_apply_tmpl.c:77-97, n_lines) */
+        int rep = 0;
+        if (!((by + 4) % sbsz) && by + 4 < g->bh) {
+            const int yb = (by + 2) * 4;
+            if (yb + 1 == g->h) rep |= DAV1D_HIP_CDEF_BOT_REP_Y;
+            if (g->layout && (yb >> g->ss_ver) + 1 == (g->h + g->ss_ver) >> g->ss_ver) rep |= DAV1D_HIP_CDEF_BOT_REP_UV;
+        }
         for (int sbx = 0; sbx * 16 < g->bw; sbx++) {
             const Dav1dHipAv1Filter *const m = &row[sbx >> 1];
             const int cdef_idx = m->cdef_idx[((by & 16) >> 3) + (sbx & 1)];
@@ -155,6 +164,7 @@ static void list_cdef(const ListerGeo *g, const Dav1dHipFilterDesc *fd, FOut *o,
                 k->bx = (uint16_t) (bx >> 1); k->by = (uint16_t) (by >> 1);
                 k->y_pri = (uint8_t) ((y_lvl >> 2) << bd8); k->y_sec = (uint8_t) (y_sec << bd8);
                 k->uv_pri = (uint8_t) ((uv_lvl >> 2) << bd8); k->uv_sec = (uint8_t) (uv_sec << bd8);
+                k->flags = (uint8_t) rep;
                 k->edges = (uint8_t) ((bx > 0 ? DAV1D_HIP_CDEF_HAVE_LEFT : 0) | (bx + 2 < g->bw ? DAV1D_HIP_CDEF_HAVE_RIGHT : 0) |
                                       (by > 0 ? DAV1D_HIP_CDEF_HAVE_TOP : 0) | (by + 2 < g->bh ? DAV1D_HIP_CDEF_HAVE_BOTTOM : 0));
             }

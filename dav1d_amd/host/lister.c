@@ -830,11 +830,12 @@ static void list_intrabc(Walk *w, const int bs, const Dav1dHipAv1Block *b, const
     for (size_t i = n0; i < w->o->mc.n; i++) {
         const Dav1dHipMcTask *k = &w->o->mc.p[i];
         const int sh = k->plane ? ss_hor : 0, sv = k->plane ? ss_ver : 0;
-        /* the source must lie inside the coded area (is_mv_valid keeps it inside the tile); nothing is emulated here */
-        if (k->src_x < 0 || k->src_y < 0 || k->src_x + k->w + !!k->mx > (l->bw * 4) >> sh || k->src_y + k->h + !!k->my > (l->bh * 4) >> sv) {
-            w->err = -EINVAL;
-            return;
-        }
+        /* decode_b keeps the source inside the tile with the tile's right edge rounded UP to the block's width and the bottom at the
+         * end of the superblock row (src/decode.c:1296-1336), so a window may leave the coded area to the right / below: the
+         * reference emulates the edge of the f->bw * 4 x f->bh * 4 area then (mc() with refp == &f->sr_cur, src/recon_tmpl.c:
+         * 960-978), the stepped copies clamp their coordinates to the same area (dav1d_hip_frame_submit_step_copy).  The cells the
+         * clamped window reads are what the step waits for (src_step clips likewise). */
+        (void) sh; (void) sv;
         const unsigned q = src_step(w, k->plane, k->src_x, k->src_y, k->w, k->h);
         if (q > s) s = q;
     }

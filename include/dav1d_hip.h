@@ -522,6 +522,7 @@ DAV1D_HIP_API int dav1d_hip_emu_edge(Dav1dHipContext *c, int bpc, intptr_t bw, i
  * dsp->cdef.fb[uv_idx] on both chroma blocks.  Out of place: `src` is the immutable
  * pre-CDEF (deblocked) picture, `dst` receives the filtered units; `dst` must already
  * hold a copy of `src` for the units that are not listed (skipped / zero strength). */
+enum { DAV1D_HIP_CDEF_RAW = 1, DAV1D_HIP_CDEF_W4 = 2, DAV1D_HIP_CDEF_H4 = 4, DAV1D_HIP_CDEF_BOT_REP_Y = 8, DAV1D_HIP_CDEF_BOT_REP_UV = 16 };   /* Dav1dHipCdefTask.flags */
 enum { DAV1D_HIP_CDEF_HAVE_LEFT = 1, DAV1D_HIP_CDEF_HAVE_RIGHT = 2, DAV1D_HIP_CDEF_HAVE_TOP = 4,
        DAV1D_HIP_CDEF_HAVE_BOTTOM = 8 };    /* == enum CdefEdgeFlags, src/cdef.h:36-41 */
 typedef struct Dav1dHipCdefTask {
@@ -531,7 +532,12 @@ typedef struct Dav1dHipCdefTask {
     uint8_t  uv_pri, uv_sec;
     uint8_t  edges;      /* DAV1D_HIP_CDEF_HAVE_* */
     uint8_t  flags;      /* bit 0 RAW: one dsp->cdef.fb call (pri = y_pri, sec = y_sec, `dir`, no search / adjust) on
-                            `plane`; bit 1: block is 4 wide, bit 2: block is 4 high (fb[1] = 4x8, fb[2] = 4x4) */
+                            `plane`; bit 1: block is 4 wide, bit 2: block is 4 high (fb[1] = 4x8, fb[2] = 4x4);
+                            bit 3 (DAV1D_HIP_CDEF_BOT_REP_Y) / bit 4 (_UV): of the two rows below the unit, the SECOND is a copy
+                            of the first, in luma / in chroma.  With frame threading the last unit row of a superblock row's band
+                            takes its two bottom rows from the deblocked lines backup_lpf() saved (src/cdef_apply_tmpl.c:222-232),
+                            and where the picture's last row is the first of them, backup_lpf stores it twice
+                            (`n_lines = 4 - (row + stripe_h + 1 == h)`, src/lf_apply_tmpl.c:77-97) */
     uint8_t  dir, plane; /* RAW only */
     uint8_t  pad[4];
 } Dav1dHipCdefTask;
@@ -574,6 +580,8 @@ enum Dav1dHipLrType { DAV1D_HIP_LR_WIENER7 = 0, DAV1D_HIP_LR_WIENER5 = 1,      /
  * (src/lr_apply_tmpl.c:36-97): w <= 384, h <= 64.  Out of place: `src` = loop-restoration input
  * (CDEF output), `lpf` = deblocked (pre-CDEF) picture supplying the two rows above / below the
  * stripe (what the reference saves into lr_lpf_line, src/lf_apply_tmpl.c:41-102), `dst` = output. */
+/* (A row "below the stripe" that lies beyond the plane's last row is that last row once more: backup_lpf() stores the picture's last
+ * row twice where it is the first of the two, src/lf_apply_tmpl.c:77-97.) */
 typedef struct Dav1dHipLrTask {
     uint16_t x, y;       /* stripe position in pixels of `plane` */
     uint16_t w, h;

@@ -19,6 +19,7 @@
 #include <limits.h>
 #include <pthread.h>
 #include <stdatomic.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -31,6 +32,7 @@
 #include "src/ref.h"
 #include "src/picture.h"
 #include "src/warpmv.h"
+#include "src/thread_task.h"
 #include "hooked/hooks.h"
 #include "dav1d_hip.h"
 
@@ -55,6 +57,14 @@ typedef struct HookedParams {
                                   the frame's lists, cf is left zero as the reference's inverse transforms leave it, no dense arena goes to
                                   the device.  With inject = 2 the arrays of the STORE are what gets consumed: replay such a store last. */
     Dav1dHipSynthParams synth; /* block decisions of the generated frames; seed + frame number per frame */
+    int stream;                /* 1: NOTHING is injected.  The harness is handed an AV1 bitstream (tests/av1_obu.py: real headers, tile payloads of
+                                  seeded random bytes) and drives dav1d's public API with it — dav1d_send_data / dav1d_get_picture, dav1d_parse_obus,
+                                  dav1d_submit_frame, and the reference's own pass 1 (dav1d_msac_*, decode_b, decode_coefs, read_restoration_info,
+                                  dav1d_create_lf_mask_*) on its worker threads.  mode 0 is then dav1d itself, no hook installed but an error
+                                  recorder around the pass-1 tile call; mode 1 the glue of INTEGRATION.md behind dav1d's real pass 1 */
+    int apply_grain;           /* stream mode: film grain on the output pictures — mode 0: Dav1dSettings.apply_grain (dav1d_apply_grain on the
+                                  host); mode 1: apply_grain = 0 and the "application" applies it on the device (dav1d_hip_fg_apply on the picture
+                                  dav1d returns, frame_hdr->film_grain.data), as GPU video outputs do */
 } HookedParams;
 
 /* pass 1's output of one frame, as dav1d_decode_frame_init() sizes the arrays */
@@ -94,6 +104,12 @@ typedef struct Hip {
     const uint8_t *(*lister_const_masks)(size_t *);
     void (*lister_destroy)(Dav1dHipLister *);
     int (*synth_frame)(const Dav1dHipFrameDesc *, const Dav1dHipSynthParams *, void *, size_t, size_t, uint8_t *, size_t);
+    int (*frame_submit_intra_step)(Dav1dHipFrame *, size_t, const Dav1dHipIpredTask *, size_t, const Dav1dHipItxTask *, size_t, uint8_t *);
+    int (*frame_set_super_res)(Dav1dHipFrame *, int);
+    int (*fg_apply)(Dav1dHipContext *, const Dav1dHipPicture *, const Dav1dHipPicture *, const Dav1dHipFilmGrainData *, int);
+    int (*picture_alloc)(Dav1dHipContext *, Dav1dHipPicture *, int, int, int, int);
+    int (*picture_free)(Dav1dHipContext *, Dav1dHipPicture *);
+    int (*plane_download)(Dav1dHipContext *, const Dav1dHipPicture *, int, void *, ptrdiff_t, int);
 } Hip;
 
 /* what the allocator hangs on a Dav1dPicture in mode 1 */
@@ -101,6 +117,7 @@ typedef struct HookedPic {
     Dav1dHipHostPicture hp;
     Dav1dHipFrame *frame;        /* the frame that produced the picture: owns `ref` when that is not hp.dev */
     Dav1dHipPicture ref;         /* where the final pixels are: what later frames predict from */
+    atomic_int final;            /* the frame that produced the picture has ended (well or badly): `ref` is settled */
 } HookedPic;
 
 /* per frame context */
@@ -117,7 +134,27 @@ typedef struct FcState {
     /* inject == 2, mode 1: the frame context's own arrays while the stored ones stand in for them */
     void *own_b, *own_cbi, *own_cf;
     int swapped;
+    /* the frame's way through the three stage threads: 0 idle, 1 tasks through, 2 uploaded (or failed), 3 ended */
+    Dav1dFrameContext *q_f;
+    int q_state, q_rc;
+    uint64_t q_arrival;
+    Dav1dHipPicture q_filtered;
+    void *pal_idx;               /* device copy of f->frame_thread.pal_idx (palette frames) */
+    size_t pal_idx_cap;
 } FcState;
+
+typedef struct OutPic { int w, h, layout, bpc, frame_offset, grain; uint8_t *plane[3]; } OutPic;
+
+/* which tools pass 1's output of a stream really holds (blocks counted by the reference's own decode_sb walk, count_walk below) */
+enum { HIST_FRAMES_KEY, HIST_FRAMES_INTER, HIST_FRAMES_INTRA_ONLY, HIST_FRAMES_SUPER_RES, HIST_FRAMES_SCALED_REFS, HIST_FRAMES_INTRABC,
+       HIST_FRAMES_FILM_GRAIN, HIST_FRAMES_DELTA_LF, HIST_FRAMES_SEGMENTED, HIST_FRAMES_LOSSLESS,
+       HIST_B_INTRA, HIST_B_INTER, HIST_B_INTRABC, HIST_B_SKIP, HIST_B_SKIP_MODE, HIST_B_SEG_NONZERO,
+       HIST_B_PALETTE_Y, HIST_B_PALETTE_UV, HIST_B_CFL, HIST_B_FILTER_INTRA, HIST_B_DIRECTIONAL, HIST_B_ANGLE_DELTA, HIST_B_SMOOTH, HIST_B_PAETH,
+       HIST_B_COMP_AVG, HIST_B_COMP_WAVG, HIST_B_COMP_SEG, HIST_B_COMP_WEDGE, HIST_B_INTERINTRA, HIST_B_INTERINTRA_WEDGE, HIST_B_OBMC,
+       HIST_B_LOCAL_WARP, HIST_B_GLOBALMV, HIST_B_GLOBAL_WARP, HIST_B_SCALED_REF, HIST_B_FILTER_NOT_REGULAR, HIST_B_DUAL_FILTER,
+       HIST_B_TX_SPLIT, HIST_B_TX64, HIST_B_LOSSLESS, HIST_B_SUB8X8_CHROMA, HIST_B_128, HIST_B_4XN,
+       HIST_TX_BLOCKS, HIST_TX_NON_DCT, HIST_TX_EOB0, HIST_TX_NO_COEFS,
+       HIST_LR_WIENER, HIST_LR_SGR, HIST_CDEF_NONZERO_IDX, HIST_N };
 
 typedef struct Hooked {
     HookedParams p;
@@ -128,19 +165,27 @@ typedef struct Hooked {
     Dav1dRef *seq_ref;
     FcState *fcs;
     Store *store;
-    /* Frames whose last task is through (q_frame[frame number]) go through three threads of the harness: coefficients and level
-     * cache to the device (any order, a context and stream of its own), dav1d_hip_frame_end (in submission order: a frame's
-     * references are final when it ends), the copy of the picture to the host planes + dav1d_hooked_frame_done (in order). */
-    Dav1dHipContext *ctx_up;
+    /* Frames whose last task is through go through three threads of the harness (FcState.q_state): coefficients, palette indices and
+     * level cache to the device (any order, a context and stream of its own), dav1d_hip_frame_end (oldest first among the frames
+     * whose references have ended: where a reference's final pixels are is known when that frame ends), the copy of the picture
+     * to the host planes + dav1d_hooked_frame_done. */
+    Dav1dHipContext *ctx_up, *ctx_out;
     pthread_t up_thread, gpu_thread, out_thread;
     pthread_mutex_t q_mtx;
     pthread_cond_t q_cond;
-    Dav1dFrameContext **q_frame;          /* [frame number] */
-    uint8_t *q_state;                     /* [frame number]: 0 not yet, 1 tasks through, 2 uploaded (or failed), 3 ended */
-    int *q_rc;
-    Dav1dHipPicture *q_filtered;
-    double *q_done_t;                     /* when dav1d_hooked_frame_done returned */
-    int q_up_next, q_gpu_next, q_out_next, q_stop;
+    uint64_t q_arrivals;
+    double *q_done_t;                     /* chain mode, [frame number]: when dav1d_hooked_frame_done returned */
+    int q_stop;
+    /* stream mode */
+    struct OutPic *out_pics;              /* what dav1d_get_picture handed out, in that order */
+    int n_out_pics, cap_out_pics;
+    const uint8_t *const *tu;             /* the temporal units of the run (tile data points into them) */
+    const size_t *tu_size;
+    int n_tu;
+    int n_errors;                         /* pictures dav1d reported an error for */
+    struct TileError { int tu; size_t off; int overread; } tile_err[64];
+    int n_tile_err;
+    uint64_t hist[HIST_N];
     /* pictures between uses (dav1d's default allocator pools them too, src/picture.c:46-82 + src/mem.c) */
     struct HookedPic *free_pics[32];
     int n_free_pics, closing;
@@ -158,6 +203,22 @@ typedef struct Hooked {
 } Hooked;
 
 static Hooked *g_h;                       /* one harness at a time: the hooks carry no user pointer */
+
+/* DAV1D_HOOKED_BACKTRACE=1: a crash inside the harness, dav1d or the backend prints where (there is no debugger on the boxes) */
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+static void crash_handler(const int sig) {
+    void *bt[64];
+    const int n = backtrace(bt, 64);
+    backtrace_symbols_fd(bt, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+static void crash_handler_install(void) {
+    const char *const e = getenv("DAV1D_HOOKED_BACKTRACE");
+    if (e && *e == '1') { signal(SIGSEGV, crash_handler); signal(SIGABRT, crash_handler); signal(SIGBUS, crash_handler); }
+}
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
 static void stat_add(Hooked *const h, const int i, const double t0) {
@@ -200,7 +261,7 @@ static void hip_filter_desc(Dav1dHipFilterDesc *fd, const Dav1dFrameContext *f) 
     for (int i = 0; i < 3; i++) fd->lr_type[i] = f->frame_hdr->restoration.type[i];
     fd->lr_unit_size[0] = f->frame_hdr->restoration.unit_size[0]; fd->lr_unit_size[1] = f->frame_hdr->restoration.unit_size[1];
     fd->lr_mask = (const Dav1dHipAv1Restoration *) f->lf.lr_mask;
-    fd->sr_w = 0;
+    fd->sr_w = f->frame_hdr->width[0] != f->frame_hdr->width[1] ? f->sr_cur.p.p.w : 0;      /* restoration works on the upscaled frame */
 }
 
 static int hip_alloc_picture(Dav1dPicture *const p, void *const cookie) {
@@ -230,6 +291,7 @@ static int hip_alloc_picture(Dav1dPicture *const p, void *const cookie) {
     p->stride[0] = hp->hp.stride[0]; p->stride[1] = hp->hp.stride[1];
     p->allocator_data = hp;
     hp->ref = hp->hp.dev;
+    atomic_store(&hp->final, 0);
     return 0;
 }
 static void hip_release_picture(Dav1dPicture *const p, void *const cookie) {
@@ -425,7 +487,7 @@ static int build_filter_inputs(Dav1dFrameContext *const f, const unsigned seed) 
 static FcState *state_of(const Dav1dFrameContext *const f) { return &g_h->fcs[f - f->c->fc]; }
 
 static void note_error(Dav1dFrameContext *const f, const int rc) {
-    if (rc) { atomic_store(&f->task_thread.error, -1); g_h->failed = 1; }
+    if (rc) { atomic_store(&f->task_thread.error, -1); g_h->failed = 1; fprintf(stderr, "hooked: dav1d_hip_lister_filter_sbrow = %d\n", rc); }
 }
 
 static void once_per_row(const Dav1dFrameContext *const f, const int sby) {
@@ -470,9 +532,18 @@ static int hk_after_init_(Dav1dFrameContext *const f) {
     const size_t re_bytes = (size_t) f->lf.re_sz * 32;
     const size_t a_bytes = sizeof(*f->a) * (size_t) f->sb128w * fh->tiling.rows;           /* the pass-1 half */
     int rc = 0;
-    for (int j = 0; j < n_tiles; j++) f->ts[j].lflvl = f->lf.lvl;       /* no delta_lf here: the frame's level table, src/decode.c:1018-1021 */
-    StoredFrame *const sf = h->store && fh->frame_offset < h->store->n ? &h->store->fr[fh->frame_offset] : NULL;
-    if (h->p.inject == 2) {
+    if (h->p.mode == 1 && (s->lister || s->frame)) {        /* a frame that failed after this point left them behind */
+        if (s->lister) h->hip.lister_destroy(s->lister);
+        if (s->frame) h->hip.frame_destroy(s->frame);
+        s->lister = NULL; s->frame = NULL;
+    }
+    StoredFrame *const sf = !h->p.stream && h->store && fh->frame_offset < h->store->n ? &h->store->fr[fh->frame_offset] : NULL;
+    if (h->p.stream) {
+        /* ---- nothing to inject: dav1d's own pass 1 fills the arrays from the tile data (dav1d_decode_tile_sbrow in hk_entropy) */
+        if (h->p.mode != 1) return 0;
+        hip_frame_desc(&s->desc, f);
+    } else if (h->p.inject == 2) {
+        for (int j = 0; j < n_tiles; j++) f->ts[j].lflvl = f->lf.lvl;       /* no delta_lf here: the frame's level table, src/decode.c:1018-1021 */
         /* ---- pass 1's output from the store: the three large arrays stand in for the frame context's own where nothing writes them
          * (mode 1; the reference's pass 2 consumes cf, so mode 0 takes copies), the small ones are copied */
         if (!sf || !sf->b || sf->b_bytes != b_bytes || sf->cf_bytes != cf_bytes || sf->cbi_bytes != cbi_entries * 2) return DAV1D_ERR(EINVAL);
@@ -492,6 +563,7 @@ static int hk_after_init_(Dav1dFrameContext *const f) {
         memcpy(f->a, sf->a, sf->a_bytes);
         hip_frame_desc(&s->desc, f);
     } else {
+        for (int j = 0; j < n_tiles; j++) f->ts[j].lflvl = f->lf.lvl;
         /* ---- pass 1's output, generated: block records, cbi, coefficients, palettes */
         hip_frame_desc(&s->desc, f);
         memset(f->frame_thread.cf, 0, cf_bytes);
@@ -523,7 +595,7 @@ static int hk_after_init_(Dav1dFrameContext *const f) {
     }
     /* ---- the rows of its references a tile-sbrow needs (decode_b's lowest_pixel bookkeeping, src/decode.c:1957-1990): all of them,
      * or none when the listing may run ahead (the pixels are read when the frame ends, and frames end in order) */
-    if (IS_INTER_OR_SWITCH(fh))
+    if (IS_INTER_OR_SWITCH(fh) && !h->p.stream)
         for (int j = 0; j < n_tiles; j++) {
             Dav1dTileState *const ts = &f->ts[j];
             const int rows = (ts->tiling.row_end - ts->tiling.row_start + f->sb_step - 1) >> f->sb_shift;
@@ -536,13 +608,14 @@ static int hk_after_init_(Dav1dFrameContext *const f) {
         }
     if (h->p.mode != 1) return 0;
     /* ---- frame + lister, the filter stages pointed at the filter lister */
-    HookedPic *const cur = f->sr_cur.p.allocator_data;
+    HookedPic *const cur = f->cur.allocator_data;        /* the picture of the CODED size (f->sr_cur's is the upscaled one under super-resolution) */
     Dav1dHipPicture refs[7];
     const int n_refs = IS_INTER_OR_SWITCH(fh) ? 7 : 0;
     for (int i = 0; i < n_refs; i++) refs[i] = ((HookedPic *) f->refp[i].p.allocator_data)->hp.dev;     /* geometry; the final ones at the end */
     rc = h->hip.frame_begin(h->ctx, &s->frame, &cur->hp.dev, refs, n_refs);
     if (h->p.pack) s->desc.cf = f->frame_thread.cf;
     if (!rc) rc = h->hip.lister_create(&s->lister, &s->desc, s->frame);
+    if (!rc && fh->width[0] != fh->width[1]) rc = h->hip.frame_set_super_res(s->frame, f->sr_cur.p.p.w);
     if (rc) return DAV1D_ERR(ENOMEM);
     hip_filter_desc(&s->fd, f);
     if (f->sbh > s->sbh_cap) {
@@ -561,7 +634,32 @@ static int hk_after_init_(Dav1dFrameContext *const f) {
     return 0;
 }
 
-static int hk_entropy(Dav1dTaskContext *const t) { (void) t; return 0; }       /* pass 1 was injected */
+/* Pass 1.  Chain mode: the hand-off arrays were injected, nothing to do.  Stream mode: dav1d's own entropy decoding of the tile's
+ * superblock row, src/decode.c:2594-2748 (this wrapper only records WHERE a tile failed, for the writer of the random payloads,
+ * and — mode 1, listing ahead of the references — forgets the reference rows decode_b noted, src/decode.c:1957-1990). */
+static int hk_entropy(Dav1dTaskContext *const t) {
+    Hooked *const h = g_h;
+    if (!h->p.stream) return 0;
+    const int rc = dav1d_decode_tile_sbrow(t);
+    const Dav1dFrameContext *const f = t->f;
+    Dav1dTileState *const ts = t->ts;
+    if (rc) {
+        const uint8_t *pos = ts->msac.buf_pos < ts->msac.buf_end ? ts->msac.buf_pos : ts->msac.buf_end;
+        pthread_mutex_lock(&h->stat_mtx);
+        for (int i = 0; i < h->n_tu && h->n_tile_err < 64; i++)
+            if (pos >= h->tu[i] && pos <= h->tu[i] + h->tu_size[i]) {
+                h->tile_err[h->n_tile_err].tu = i;
+                h->tile_err[h->n_tile_err].off = (size_t) (pos - h->tu[i]);
+                h->tile_err[h->n_tile_err++].overread = ts->msac.cnt <= -15;
+                break;
+            }
+        pthread_mutex_unlock(&h->stat_mtx);
+    } else if (h->p.mode == 1 && h->p.free_listing && IS_INTER_OR_SWITCH(f->frame_hdr)) {
+        const int sby = (t->by - ts->tiling.row_start) >> f->sb_shift;
+        for (int n = 0; n < 7; n++) ts->lowest_pixel[sby][n][0] = ts->lowest_pixel[sby][n][1] = INT_MIN;
+    }
+    return rc;
+}
 
 static int hk_recon(Dav1dTaskContext *const t) {
     /* instead of dav1d_decode_tile_sbrow(tc) */
@@ -569,18 +667,163 @@ static int hk_recon(Dav1dTaskContext *const t) {
     const double t0 = now_s();
     const int rc = g_h->hip.lister_tile_sbrow(state_of(f)->lister, t->ts->tiling.row, t->ts->tiling.col, t->by >> f->sb_shift);
     stat_add(g_h, 2, t0);
-    if (rc) g_h->failed = 1;
+    if (rc) { g_h->failed = 1; fprintf(stderr, "hooked: dav1d_hip_lister_tile_sbrow(tile %d, %d, sby %d) = %d\n", t->ts->tiling.row, t->ts->tiling.col, t->by >> f->sb_shift, rc); }
     return rc ? 1 : 0;
 }
 
-/* the frame's tasks are through (a worker thread, the scheduler's lock held): its turn on the GPU thread comes */
+/* the frame's tasks are through (a worker thread, the scheduler's lock held): its turn on the stage threads comes */
 static void hk_frame_complete(Dav1dFrameContext *const f) {
     Hooked *const h = g_h;
+    FcState *const s = state_of(f);
     pthread_mutex_lock(&h->q_mtx);
-    h->q_frame[f->frame_hdr->frame_offset] = f;
-    h->q_state[f->frame_hdr->frame_offset] = 1;
+    s->q_f = f;
+    s->q_rc = 0;
+    s->q_arrival = ++h->q_arrivals;
+    s->q_state = 1;
     pthread_cond_broadcast(&h->q_cond);
     pthread_mutex_unlock(&h->q_mtx);
+}
+
+/* ---- which tools the frame's blocks use: the reference's own block walk (decode_sb with pass == 2) over pass 1's output with the two
+ * reconstruction hooks pointed at counters.  Stream mode, mode 1, after the frame's listing: nothing else uses the pass-2 cursors. */
+static __thread uint64_t *g_hist;
+static void count_common(const Dav1dTaskContext *const t, const enum BlockSize bs, const Av1Block *const b) {
+    const Dav1dFrameContext *const f = t->f;
+    const uint8_t *const b_dim = dav1d_block_dimensions[bs];
+    uint64_t *const hs = g_hist;
+    hs[HIST_B_SKIP] += b->skip;
+    hs[HIST_B_SEG_NONZERO] += !!b->seg_id;
+    hs[HIST_B_LOSSLESS] += f->frame_hdr->segmentation.lossless[b->seg_id];
+    hs[HIST_B_128] += b_dim[0] == 32 || b_dim[1] == 32;
+    hs[HIST_B_4XN] += b_dim[0] == 1 || b_dim[1] == 1;
+    const int ss_ver = f->cur.p.layout == DAV1D_PIXEL_LAYOUT_I420, ss_hor = f->cur.p.layout != DAV1D_PIXEL_LAYOUT_I444;
+    hs[HIST_B_SUB8X8_CHROMA] += f->cur.p.layout != DAV1D_PIXEL_LAYOUT_I400 && ((b_dim[0] == 1 && ss_hor) || (b_dim[1] == 1 && ss_ver));
+}
+static void count_intra(Dav1dTaskContext *const t, const enum BlockSize bs, const enum EdgeFlags flags, const Av1Block *const b) {
+    (void) flags;
+    uint64_t *const hs = g_hist;
+    hs[HIST_B_INTRA]++;
+    hs[HIST_B_PALETTE_Y] += !!b->pal_sz[0];
+    hs[HIST_B_PALETTE_UV] += !!b->pal_sz[1];
+    hs[HIST_B_CFL] += b->uv_mode == CFL_PRED;
+    hs[HIST_B_FILTER_INTRA] += b->y_mode == FILTER_PRED;
+    hs[HIST_B_DIRECTIONAL] += b->y_mode >= VERT_PRED && b->y_mode <= VERT_LEFT_PRED;
+    hs[HIST_B_ANGLE_DELTA] += b->y_mode >= VERT_PRED && b->y_mode <= VERT_LEFT_PRED && b->y_angle;
+    hs[HIST_B_SMOOTH] += b->y_mode >= SMOOTH_PRED && b->y_mode <= SMOOTH_H_PRED;
+    hs[HIST_B_PAETH] += b->y_mode == PAETH_PRED;
+    hs[HIST_B_TX64] += b->tx == TX_64X64 || b->tx == RTX_64X32 || b->tx == RTX_32X64 || b->tx == RTX_64X16 || b->tx == RTX_16X64;
+    count_common(t, bs, b);
+}
+static int count_inter(Dav1dTaskContext *const t, const enum BlockSize bs, const Av1Block *const b) {
+    const Dav1dFrameContext *const f = t->f;
+    uint64_t *const hs = g_hist;
+    if (!IS_INTER_OR_SWITCH(f->frame_hdr)) { hs[HIST_B_INTRABC]++; count_common(t, bs, b); return 0; }
+    hs[HIST_B_INTER]++;
+    hs[HIST_B_SKIP_MODE] += b->skip_mode;
+    const int is_comp = b->comp_type != COMP_INTER_NONE;
+    hs[HIST_B_COMP_AVG] += b->comp_type == COMP_INTER_AVG;
+    hs[HIST_B_COMP_WAVG] += b->comp_type == COMP_INTER_WEIGHTED_AVG;
+    hs[HIST_B_COMP_SEG] += b->comp_type == COMP_INTER_SEG;
+    hs[HIST_B_COMP_WEDGE] += b->comp_type == COMP_INTER_WEDGE;
+    if (!is_comp) {
+        hs[HIST_B_INTERINTRA] += !!b->interintra_type;
+        hs[HIST_B_INTERINTRA_WEDGE] += b->interintra_type == INTER_INTRA_WEDGE;
+        hs[HIST_B_OBMC] += b->motion_mode == MM_OBMC;
+        hs[HIST_B_LOCAL_WARP] += b->motion_mode == MM_WARP;
+    }
+    const int is_gmv = b->inter_mode == (is_comp ? GLOBALMV_GLOBALMV : GLOBALMV);
+    hs[HIST_B_GLOBALMV] += is_gmv;
+    hs[HIST_B_GLOBAL_WARP] += is_gmv && f->gmv_warp_allowed[b->ref[0]] && imin(dav1d_block_dimensions[bs][0], dav1d_block_dimensions[bs][1]) > 1;
+    hs[HIST_B_SCALED_REF] += !!f->svc[b->ref[0]][0].scale || (is_comp && f->svc[b->ref[1]][0].scale);
+    hs[HIST_B_FILTER_NOT_REGULAR] += b->filter2d != FILTER_2D_8TAP_REGULAR;
+    hs[HIST_B_DUAL_FILTER] += dav1d_filter_dir[b->filter2d][0] != dav1d_filter_dir[b->filter2d][1];
+    hs[HIST_B_TX_SPLIT] += b->tx_split0 || b->tx_split1;
+    hs[HIST_B_TX64] += b->max_ytx == TX_64X64 || b->max_ytx == RTX_64X32 || b->max_ytx == RTX_32X64 || b->max_ytx == RTX_64X16 || b->max_ytx == RTX_16X64;
+    count_common(t, bs, b);
+    return 0;
+}
+static void restore_pass2_cursors(Dav1dFrameContext *const f) {
+    /* back to the start of the frame (setup_tile, src/decode.c:2438-2452; reset_context of the pass-2 half, :3182-3188) */
+    static const uint8_t ss_size_mul[4][2] = { { 4, 4 }, { 6, 5 }, { 8, 6 }, { 12, 8 } };
+    const Dav1dFrameHeader *const fh = f->frame_hdr;
+    const uint8_t *const size_mul = ss_size_mul[f->cur.p.layout];
+    const int hbd = f->cur.p.bpc > 8;
+    for (int j = 0; j < fh->tiling.cols * fh->tiling.rows; j++) {
+        const unsigned off = f->frame_thread.tile_start_off[j];
+        Dav1dTileState *const ts = &f->ts[j];
+        /* (the cursors of pass 2 are [0], those of pass 1 [1]: ts->frame_thread[pass & 1]) */
+        ts->frame_thread[0].pal_idx = f->frame_thread.pal_idx ? &f->frame_thread.pal_idx[(size_t) off * size_mul[1] / 8] : NULL;
+        ts->frame_thread[0].cbi = &f->frame_thread.cbi[(size_t) off * size_mul[0] / 64];
+        ts->frame_thread[0].cf = (uint8_t *) f->frame_thread.cf + (((size_t) off * size_mul[0]) >> !hbd);
+    }
+}
+static void count_frame(Hooked *const h, Dav1dFrameContext *const f) {
+    const Dav1dFrameHeader *const fh = f->frame_hdr;
+    uint64_t hs[HIST_N];
+    memset(hs, 0, sizeof(hs));
+    hs[fh->frame_type == DAV1D_FRAME_TYPE_KEY ? HIST_FRAMES_KEY : fh->frame_type == DAV1D_FRAME_TYPE_INTRA ? HIST_FRAMES_INTRA_ONLY : HIST_FRAMES_INTER]++;
+    hs[HIST_FRAMES_SUPER_RES] += fh->width[0] != fh->width[1];
+    int scaled = 0;
+    if (IS_INTER_OR_SWITCH(fh)) for (int i = 0; i < 7; i++) scaled |= !!f->svc[i][0].scale;
+    hs[HIST_FRAMES_SCALED_REFS] += scaled;
+    hs[HIST_FRAMES_INTRABC] += fh->allow_intrabc;
+    hs[HIST_FRAMES_FILM_GRAIN] += fh->film_grain.present;
+    hs[HIST_FRAMES_DELTA_LF] += fh->delta.lf.present;
+    hs[HIST_FRAMES_SEGMENTED] += fh->segmentation.enabled;
+    hs[HIST_FRAMES_LOSSLESS] += fh->all_lossless;
+    /* transform blocks: the cbi entries pass 1 wrote, tile by tile (its cursor stands behind the last one) */
+    {
+        static const uint8_t ss_size_mul[4][2] = { { 4, 4 }, { 6, 5 }, { 8, 6 }, { 12, 8 } };
+        for (int j = 0; j < fh->tiling.cols * fh->tiling.rows; j++) {
+            const int16_t *c0 = &f->frame_thread.cbi[(size_t) f->frame_thread.tile_start_off[j] * ss_size_mul[f->cur.p.layout][0] / 64];
+            const int16_t *const c1 = f->ts[j].frame_thread[1].cbi;
+            for (; c0 < c1; c0++) {
+                const int eob = *c0 >> 5, txtp = *c0 & 31;
+                hs[HIST_TX_BLOCKS]++;
+                hs[HIST_TX_NO_COEFS] += eob < 0;
+                hs[HIST_TX_EOB0] += eob == 0;
+                hs[HIST_TX_NON_DCT] += eob >= 0 && txtp != DCT_DCT;
+            }
+        }
+    }
+    if (f->lf.lr_mask && f->lf.restore_planes)
+        for (int i = 0; i < f->lf.lr_mask_sz; i++)
+            for (int pl = 0; pl < 3; pl++)
+                for (int u = 0; u < 4; u++) {
+                    const int ty = f->lf.lr_mask[i].lr[pl][u].type;
+                    hs[HIST_LR_WIENER] += ty == DAV1D_RESTORATION_WIENER;
+                    hs[HIST_LR_SGR] += ty >= DAV1D_RESTORATION_SGRPROJ;
+                }
+    for (int i = 0; i < f->sb128w * f->sb128h; i++)
+        for (int q = 0; q < 4; q++) hs[HIST_CDEF_NONZERO_IDX] += f->lf.mask[i].cdef_idx[q] > 0;
+    Dav1dTaskContext *t = NULL;
+    if (!posix_memalign((void **) &t, 64, sizeof(*t))) {
+        memset(t, 0, sizeof(*t));
+        const recon_b_intra_fn keep_intra = f->bd_fn.recon_b_intra;
+        const recon_b_inter_fn keep_inter = f->bd_fn.recon_b_inter;
+        f->bd_fn.recon_b_intra = count_intra;
+        f->bd_fn.recon_b_inter = count_inter;
+        g_hist = hs;
+        t->c = f->c; t->f = f;
+        t->frame_thread.pass = 2;
+        int rc = 0;
+        for (int tile_row = 0; tile_row < fh->tiling.rows && !rc; tile_row++)
+            for (int sby = fh->tiling.row_start_sb[tile_row]; sby < fh->tiling.row_start_sb[tile_row + 1] && !rc; sby++) {
+                t->by = sby << f->sb_shift;
+                for (int tile_col = 0; tile_col < fh->tiling.cols && !rc; tile_col++) {
+                    t->ts = &f->ts[tile_row * fh->tiling.cols + tile_col];
+                    rc = dav1d_decode_tile_sbrow(t);
+                }
+            }
+        g_hist = NULL;
+        f->bd_fn.recon_b_intra = keep_intra;
+        f->bd_fn.recon_b_inter = keep_inter;
+        restore_pass2_cursors(f);
+        free(t);
+    }
+    pthread_mutex_lock(&h->stat_mtx);
+    for (int i = 0; i < HIST_N; i++) h->hist[i] += hs[i];
+    pthread_mutex_unlock(&h->stat_mtx);
 }
 
 /* stage 1 (any order): what the frame's launches read from the host side */
@@ -589,6 +832,7 @@ static int stage_upload(Hooked *const h, Dav1dFrameContext *const f) {
     const Hip *const hip = &h->hip;
     const size_t cf_bytes = (size_t) f->frame_thread.cf_sz * 128 * 128 / 2;
     const size_t lvl_bytes = sizeof(*f->lf.level) * (size_t) f->sb128w * f->sb128h * 32 * 32;
+    const size_t pal_idx_bytes = f->frame_hdr->allow_screen_content_tools ? (size_t) f->frame_thread.pal_idx_sz * 128 * 128 / 8 : 0;
     size_t n_const = 0;
     const uint8_t *const blob = hip->lister_const_masks(&n_const);
     const double t0 = now_s();
@@ -598,20 +842,43 @@ static int stage_upload(Hooked *const h, Dav1dFrameContext *const f) {
     const size_t mask_cap_before = s->mask_cap;
     if (!rc) rc = grow(h, &s->mask, &s->mask_cap, hip->lister_mask_bytes(s->lister) + 4096);
     if (!rc && s->mask_cap != mask_cap_before) rc = hip->upload(h->ctx_up, s->mask, blob, n_const);
-    if (!rc && !h->p.pack) rc = hip->upload(h->ctx_up, s->coef, f->frame_thread.cf, cf_bytes);
+    if (!rc && !h->p.pack) {
+        rc = hip->upload(h->ctx_up, s->coef, f->frame_thread.cf, cf_bytes);
+        /* the arena has been consumed: the next frame's pass 1 finds it zero, as after the reference's inverse transforms
+         * (src/itx_tmpl.c:60,108).  (The packing lister does that itself, block by block.) */
+        if (h->p.stream) memset(f->frame_thread.cf, 0, cf_bytes);
+    }
     if (!rc) rc = hip->upload(h->ctx_up, s->lvl, f->lf.level, lvl_bytes);
+    if (!rc && pal_idx_bytes && f->frame_thread.pal_idx) {
+        /* palette indices (pal_pred's `idx`, src/recon_tmpl.c:1207-1224): the arena PAL tasks point into */
+        rc = grow(h, &s->pal_idx, &s->pal_idx_cap, pal_idx_bytes + 64);
+        if (!rc) rc = hip->upload(h->ctx_up, s->pal_idx, f->frame_thread.pal_idx, pal_idx_bytes);
+        if (!rc) rc = hip->frame_submit_intra_step(s->frame, 0, NULL, 0, NULL, 0, s->pal_idx);
+    }
     stat_add(h, 5, t0);
     return rc;
 }
 
-/* stage 2 (in submission order): INTEGRATION.md 2, "when the last task of the frame is in" */
+/* have the frames this one predicts from ended?  (-1: one of them failed) */
+static int refs_final(const Dav1dFrameContext *const f) {
+    if (!IS_INTER_OR_SWITCH(f->frame_hdr)) return 1;
+    int all = 1;
+    for (int i = 0; i < 7; i++) {
+        if (atomic_load(&f->refp[i].progress[1]) == FRAME_ERROR) return -1;
+        all &= atomic_load(&((HookedPic *) f->refp[i].p.allocator_data)->final);
+    }
+    return all;
+}
+
+/* stage 2: INTEGRATION.md 2, "when the last task of the frame is in" */
 static int stage_end(Hooked *const h, Dav1dFrameContext *const f, Dav1dHipPicture *const filtered) {
     FcState *const s = state_of(f);
-    HookedPic *const cur = f->sr_cur.p.allocator_data;
+    HookedPic *const out = f->sr_cur.p.allocator_data;     /* the picture dav1d hands on: reference and output */
     const Hip *const hip = &h->hip;
-    int rc = 0;
+    int rc = refs_final(f) < 0 ? -EIO : 0;
     const double t0 = now_s();
-    if (IS_INTER_OR_SWITCH(f->frame_hdr)) {
+    if (h->p.stream) count_frame(h, f);
+    if (!rc && IS_INTER_OR_SWITCH(f->frame_hdr)) {
         Dav1dHipPicture refs[7];
         for (int i = 0; i < 7; i++) refs[i] = ((HookedPic *) f->refp[i].p.allocator_data)->ref;        /* where those frames' final pixels are */
         rc = hip->frame_set_refs(s->frame, refs, 7);
@@ -620,13 +887,13 @@ static int stage_end(Hooked *const h, Dav1dFrameContext *const f, Dav1dHipPictur
                                          f->frame_hdr->cdef.damping + f->cur.p.bpc - 8, NULL, 0);
     memset(filtered, 0, sizeof(*filtered));
     if (!rc) rc = hip->frame_end(s->frame, h->p.pack ? NULL : s->coef, s->prep, s->mask, filtered, NULL);
-    if (f->frame_hdr->frame_offset < 64) h->frame_end_s[f->frame_hdr->frame_offset] = now_s() - t0;
+    if (!h->p.stream && f->frame_hdr->frame_offset < 64) h->frame_end_s[f->frame_hdr->frame_offset] = now_s() - t0;
     stat_add(h, 6, t0);
     hip->lister_destroy(s->lister);
     s->lister = NULL;
     if (!rc) {
-        cur->ref = *filtered;                     /* later frames predict from this; the frame object lives as long as the picture */
-        cur->frame = s->frame;
+        out->ref = *filtered;                     /* later frames predict from this; the frame object lives as long as the picture */
+        out->frame = s->frame;
     } else {
         hip->frame_destroy(s->frame);
     }
@@ -634,44 +901,61 @@ static int stage_end(Hooked *const h, Dav1dFrameContext *const f, Dav1dHipPictur
     return rc;
 }
 
-/* stage 3 (in order): the picture to the host planes the application sees, then the frame is done as far as dav1d is concerned */
+/* stage 3: the picture to the host planes the application sees, then the frame is done as far as dav1d is concerned */
 static void stage_out(Hooked *const h, Dav1dFrameContext *const f, int rc, const Dav1dHipPicture *const filtered) {
     FcState *const s = state_of(f);
-    HookedPic *const cur = f->sr_cur.p.allocator_data;
+    HookedPic *const out = f->sr_cur.p.allocator_data;
     const double t0 = now_s();
-    if (!rc) rc = h->hip.host_picture_fetch(h->ctx, &cur->hp, filtered, 0, f->cur.p.h);
+    if (!rc) rc = h->hip.host_picture_fetch(h->ctx, &out->hp, filtered, 0, f->sr_cur.p.p.h);
     if (!rc) rc = h->hip.host_picture_wait(h->ctx);
     stat_add(h, 7, t0);
     if (s->swapped) {          /* the frame context gets its own arrays back before dav1d sees the frame again */
         f->frame_thread.b = s->own_b; f->frame_thread.cbi = s->own_cbi; f->frame_thread.cf = s->own_cf;
         s->swapped = 0;
     }
-    if (rc) h->failed = 1;
+    if (rc) { h->failed = 1; fprintf(stderr, "hooked: frame (order hint %d, type %d, %dx%d) failed in the backend: %d\n", f->frame_hdr->frame_offset, f->frame_hdr->frame_type, f->cur.p.w, f->cur.p.h, rc); }
     const int k = f->frame_hdr->frame_offset;
+    const int chain = !h->p.stream;
     dav1d_hooked_frame_done(f, rc ? DAV1D_ERR(EIO) : 0);
-    h->q_done_t[k] = now_s();
+    if (chain && k < h->p.n_frames) h->q_done_t[k] = now_s();
 }
 
 static void *stage_thread(void *const arg) {
     Hooked *const h = ((void **) arg)[0];
     const int stage = (int) (intptr_t) ((void **) arg)[1];
-    int *const next = stage == 1 ? &h->q_up_next : stage == 2 ? &h->q_gpu_next : &h->q_out_next;
     for (;;) {
         const double t_wait = now_s();
+        FcState *s = NULL;
         pthread_mutex_lock(&h->q_mtx);
-        while (!h->q_stop && !(*next < h->p.n_frames && h->q_state[*next] >= stage)) pthread_cond_wait(&h->q_cond, &h->q_mtx);
+        for (;;) {
+            if (h->q_stop) break;
+            s = NULL;
+            for (unsigned i = 0; i < h->n_fc; i++) {
+                FcState *const c = &h->fcs[i];
+                if (c->q_state != stage || (s && s->q_arrival < c->q_arrival)) continue;
+                if (stage == 2 && !refs_final(c->q_f)) continue;        /* its references have not all ended yet */
+                s = c;
+            }
+            if (s) break;
+            pthread_cond_wait(&h->q_cond, &h->q_mtx);
+        }
         if (h->q_stop) { pthread_mutex_unlock(&h->q_mtx); break; }
-        const int k = (*next)++;
-        Dav1dFrameContext *const f = h->q_frame[k];
+        Dav1dFrameContext *const f = s->q_f;
         pthread_mutex_unlock(&h->q_mtx);
         if (stage == 2) stat_add(h, 4, t_wait);
-        if (stage == 1) h->q_rc[k] = stage_upload(h, f);
-        else if (stage == 2) { if (!h->q_rc[k]) h->q_rc[k] = stage_end(h, f, &h->q_filtered[k]); else { h->hip.lister_destroy(state_of(f)->lister); state_of(f)->lister = NULL; h->hip.frame_destroy(state_of(f)->frame); state_of(f)->frame = NULL; } }
-        else stage_out(h, f, h->q_rc[k], &h->q_filtered[k]);
+        if (stage == 1) s->q_rc = stage_upload(h, f);
+        else if (stage == 2) {
+            if (!s->q_rc) s->q_rc = stage_end(h, f, &s->q_filtered);
+            else { h->hip.lister_destroy(s->lister); s->lister = NULL; h->hip.frame_destroy(s->frame); s->frame = NULL; }
+        }
         pthread_mutex_lock(&h->q_mtx);
-        if (stage < 3) h->q_state[k] = (uint8_t) (stage + 1);
+        if (stage == 2) atomic_store(&((HookedPic *) f->sr_cur.p.allocator_data)->final, 1);      /* well or badly: nobody waits for it any longer */
+        s->q_state = stage < 3 ? stage + 1 : 0;        /* (stage 3 first, its work after: dav1d may reuse the frame context from there on) */
+        const int rc = s->q_rc;
+        const Dav1dHipPicture filtered = s->q_filtered;
         pthread_cond_broadcast(&h->q_cond);
         pthread_mutex_unlock(&h->q_mtx);
+        if (stage == 3) stage_out(h, f, rc, &filtered);
     }
     return NULL;
 }
@@ -755,6 +1039,49 @@ static void keep_picture(Hooked *const h, const Dav1dPicture *const pic) {
     }
 }
 
+/* stream mode: every picture dav1d_get_picture hands out, in that order, as tight planes.  Film grain (HookedParams.apply_grain): mode 0
+ * gets it from dav1d (dav1d_apply_grain behind output_image, src/lib.c:311-329); in mode 1 dav1d was opened with apply_grain = 0 and the
+ * grain goes on here, on the device, from the picture's own header — what an application with a GPU output path does. */
+static int pic_has_grain(const Dav1dPicture *const pic) {          /* has_grain(), src/lib.c:303-309 */
+    const Dav1dFilmGrainData *const fg = &pic->frame_hdr->film_grain.data;
+    return fg->num_y_points || fg->num_uv_points[0] || fg->num_uv_points[1] || (fg->clip_to_restricted_range && fg->chroma_scaling_from_luma);
+}
+static void keep_stream_picture(Hooked *const h, const Dav1dPicture *const pic) {
+    if (h->n_out_pics == h->cap_out_pics) {
+        const int cap = h->cap_out_pics ? 2 * h->cap_out_pics : 64;
+        OutPic *const np = realloc(h->out_pics, (size_t) cap * sizeof(*np));
+        if (!np) { h->failed = 1; return; }
+        h->out_pics = np; h->cap_out_pics = cap;
+    }
+    OutPic *const o = &h->out_pics[h->n_out_pics];
+    memset(o, 0, sizeof(*o));
+    o->w = pic->p.w; o->h = pic->p.h; o->layout = pic->p.layout; o->bpc = pic->p.bpc; o->frame_offset = pic->frame_hdr->frame_offset;
+    const int bps = pic->p.bpc > 8 ? 2 : 1, n_pl = pic->p.layout == DAV1D_PIXEL_LAYOUT_I400 ? 1 : 3;
+    const int ss_hor = pic->p.layout != DAV1D_PIXEL_LAYOUT_I444, ss_ver = pic->p.layout == DAV1D_PIXEL_LAYOUT_I420;
+    const int grain_here = h->p.mode == 1 && h->p.apply_grain && pic_has_grain(pic);
+    o->grain = h->p.apply_grain && pic_has_grain(pic);
+    Dav1dHipPicture g;
+    memset(&g, 0, sizeof(g));
+    int rc = 0;
+    if (grain_here) {
+        const HookedPic *const hp = pic->allocator_data;
+        rc = h->hip.picture_alloc(h->ctx_out, &g, pic->p.w, pic->p.h, pic->p.layout, pic->p.bpc);
+        if (!rc) rc = h->hip.fg_apply(h->ctx_out, &g, &hp->ref, (const Dav1dHipFilmGrainData *) &pic->frame_hdr->film_grain.data,
+                                      pic->seq_hdr->mtrx == DAV1D_MC_IDENTITY);
+    }
+    for (int pl = 0; pl < n_pl && !rc; pl++) {
+        const int w = pl ? (pic->p.w + ss_hor) >> ss_hor : pic->p.w, hh = pl ? (pic->p.h + ss_ver) >> ss_ver : pic->p.h;
+        uint8_t *const dst = malloc((size_t) w * hh * bps);
+        if (!dst) { rc = -ENOMEM; break; }
+        if (grain_here) rc = h->hip.plane_download(h->ctx_out, &g, pl, dst, (ptrdiff_t) w * bps, 0);
+        else for (int y = 0; y < hh; y++) memcpy(dst + (size_t) y * w * bps, (const uint8_t *) pic->data[pl] + (ptrdiff_t) y * pic->stride[!!pl], (size_t) w * bps);
+        o->plane[pl] = dst;
+    }
+    if (grain_here) { if (!rc) rc = h->hip.sync(h->ctx_out); h->hip.picture_free(h->ctx_out, &g); }
+    if (rc) h->failed = 1;
+    h->n_out_pics++;
+}
+
 /* ------------------------------------------------------------------------------------------------ entry points */
 #define SYM(field, name) do { *(void **) &h->hip.field = dlsym(h->hip.dl, name); if (!h->hip.field) goto fail; } while (0)
 
@@ -783,6 +1110,7 @@ void dav1d_hooked_store_destroy(void *const store) {
 void *dav1d_hooked_open(const HookedParams *const p, const char *const hip_lib, void *const store) {
     Hooked *const h = calloc(1, sizeof(*h));
     if (!h) return NULL;
+    crash_handler_install();
     h->p = *p;
     h->store = store;
     if (p->inject && !store) { free(h); return NULL; }
@@ -799,13 +1127,16 @@ void *dav1d_hooked_open(const HookedParams *const p, const char *const hip_lib, 
     SYM(lister_create, "dav1d_hip_lister_create"); SYM(lister_tile_sbrow, "dav1d_hip_lister_tile_sbrow"); SYM(lister_filter_sbrow, "dav1d_hip_lister_filter_sbrow");
     SYM(lister_prep_elems, "dav1d_hip_lister_prep_elems"); SYM(lister_mask_bytes, "dav1d_hip_lister_mask_bytes");
     SYM(lister_const_masks, "dav1d_hip_lister_const_masks"); SYM(lister_destroy, "dav1d_hip_lister_destroy"); SYM(synth_frame, "dav1d_hip_synth_frame");
+    SYM(frame_submit_intra_step, "dav1d_hip_frame_submit_intra_step"); SYM(frame_set_super_res, "dav1d_hip_frame_set_super_res");
+    SYM(fg_apply, "dav1d_hip_fg_apply"); SYM(picture_alloc, "dav1d_hip_picture_alloc"); SYM(picture_free, "dav1d_hip_picture_free");
+    SYM(plane_download, "dav1d_hip_plane_download");
     pthread_mutex_init(&h->pic_mtx, NULL);
-    if (p->mode == 1 && (h->hip.open(&h->ctx, p->device, NULL) || h->hip.open(&h->ctx_up, p->device, NULL))) goto fail;
+    if (p->mode == 1 && (h->hip.open(&h->ctx, p->device, NULL) || h->hip.open(&h->ctx_up, p->device, NULL) || h->hip.open(&h->ctx_out, p->device, NULL))) goto fail;
     Dav1dSettings s;
     dav1d_default_settings(&s);
     s.n_threads = p->n_threads;
     s.max_frame_delay = p->frame_delay;
-    s.apply_grain = 0;
+    s.apply_grain = p->stream && p->mode == 0 && p->apply_grain;
     if (p->mode == 1) {
         s.allocator.cookie = h;
         s.allocator.alloc_picture_callback = hip_alloc_picture;
@@ -815,13 +1146,9 @@ void *dav1d_hooked_open(const HookedParams *const p, const char *const hip_lib, 
     if (h->c->n_fc < 2) goto fail;                       /* the two-pass hand-off only exists with frame threading */
     h->n_fc = h->c->n_fc;
     h->fcs = calloc(h->n_fc, sizeof(*h->fcs));
-    h->q_frame = calloc((size_t) p->n_frames + 1, sizeof(*h->q_frame));
-    h->q_state = calloc((size_t) p->n_frames + 1, 1);
-    h->q_rc = calloc((size_t) p->n_frames + 1, sizeof(*h->q_rc));
-    h->q_filtered = calloc((size_t) p->n_frames + 1, sizeof(*h->q_filtered));
     h->q_done_t = calloc((size_t) p->n_frames + 1, sizeof(*h->q_done_t));
     h->out_plane = calloc((size_t) p->n_frames * 3 + 3, sizeof(*h->out_plane));
-    if (!h->fcs || !h->q_frame || !h->out_plane || !h->q_state || !h->q_rc || !h->q_filtered || !h->q_done_t) goto fail;
+    if (!h->fcs || !h->out_plane || !h->q_done_t) goto fail;
     h->seq_ref = dav1d_ref_create(ALLOC_OBU_HDR, sizeof(Dav1dSequenceHeader));
     if (!h->seq_ref) goto fail;
     fill_seq(h->seq_ref->data, p);
@@ -849,11 +1176,10 @@ int dav1d_hooked_run(void *const handle, double *const seconds) {
     const int n_tiles = p->n_tile_cols * p->n_tile_rows;
     g_h = h;
     dav1d_hooks = p->mode == 1 ? &hooks_hip : &hooks_cpu;
-    h->q_up_next = h->q_gpu_next = h->q_out_next = 0; h->q_stop = 0; h->n_out = 0; h->failed = 0;
-    memset(h->q_state, 0, (size_t) p->n_frames + 1);
-    memset(h->q_rc, 0, sizeof(*h->q_rc) * ((size_t) p->n_frames + 1));
+    if (p->stream) return -1;
+    h->q_stop = 0; h->n_out = 0; h->failed = 0;
+    for (unsigned i = 0; i < h->n_fc; i++) h->fcs[i].q_state = 0;
     memset(h->stat, 0, sizeof(h->stat));
-    memset(h->q_frame, 0, sizeof(*h->q_frame) * ((size_t) p->n_frames + 1));
     int have_thread = 0;
     void *targ[3][2] = { { h, (void *) (intptr_t) 1 }, { h, (void *) (intptr_t) 2 }, { h, (void *) (intptr_t) 3 } };
     if (p->mode == 1) {
@@ -910,6 +1236,98 @@ int dav1d_hooked_run(void *const handle, double *const seconds) {
     return rc;
 }
 
+/* ---- stream mode: an AV1 bitstream through dav1d's public API (the loop of tools/dav1d.c:  dav1d_send_data / dav1d_get_picture until the
+ * input is used up, then draining).  tu[i] / tu_size[i]: the temporal units, which must stay alive and unchanged during the call (the
+ * tile data is referenced in place, dav1d_data_wrap).  Returns 0 when dav1d accepted every unit; the pictures it produced, the
+ * pictures it reported an error for and the tiles whose entropy decoding failed are read with the functions below. */
+static void no_free(const uint8_t *const data, void *const cookie) { (void) data; (void) cookie; }
+
+int dav1d_hooked_stream_run(void *const handle, const uint8_t *const *const tu, const size_t *const tu_size, const int n_tu, double *const seconds) {
+    Hooked *const h = handle;
+    Dav1dContext *const c = h->c;
+    const HookedParams *const p = &h->p;
+    if (!p->stream) return -1;
+    g_h = h;
+    dav1d_hooks = p->mode == 1 ? &hooks_hip : &hooks_cpu;
+    h->q_stop = 0; h->failed = 0; h->n_errors = 0; h->n_tile_err = 0;
+    h->tu = tu; h->tu_size = tu_size; h->n_tu = n_tu;
+    for (unsigned i = 0; i < h->n_fc; i++) h->fcs[i].q_state = 0;
+    memset(h->stat, 0, sizeof(h->stat));
+    memset(h->hist, 0, sizeof(h->hist));
+    for (int i = 0; i < h->n_out_pics; i++) for (int pl = 0; pl < 3; pl++) free(h->out_pics[i].plane[pl]);
+    h->n_out_pics = 0;
+    int have_thread = 0;
+    void *targ[3][2] = { { h, (void *) (intptr_t) 1 }, { h, (void *) (intptr_t) 2 }, { h, (void *) (intptr_t) 3 } };
+    if (p->mode == 1) {
+        if (pthread_create(&h->up_thread, NULL, stage_thread, targ[0]) || pthread_create(&h->gpu_thread, NULL, stage_thread, targ[1]) ||
+            pthread_create(&h->out_thread, NULL, stage_thread, targ[2])) return -1;
+        have_thread = 1;
+    }
+    int rc = 0;
+    const double t0 = now_s();
+    for (int k = 0; k < n_tu && !rc; k++) {
+        Dav1dData data;
+        memset(&data, 0, sizeof(data));
+        if (dav1d_data_wrap(&data, tu[k], tu_size[k], no_free, NULL)) { rc = -1; break; }
+        do {
+            int r = dav1d_send_data(c, &data);
+            if (r < 0 && r != DAV1D_ERR(EAGAIN)) { h->n_errors++; dav1d_data_unref(&data); break; }      /* a unit the parser rejects */
+            Dav1dPicture pic;
+            memset(&pic, 0, sizeof(pic));
+            r = dav1d_get_picture(c, &pic);
+            if (!r) { keep_stream_picture(h, &pic); dav1d_picture_unref(&pic); }
+            else if (r != DAV1D_ERR(EAGAIN)) h->n_errors++;                                              /* a frame that failed to decode */
+        } while (data.sz > 0);
+    }
+    for (;;) {          /* drain */
+        Dav1dPicture pic;
+        memset(&pic, 0, sizeof(pic));
+        const int r = dav1d_get_picture(c, &pic);
+        if (r == DAV1D_ERR(EAGAIN)) break;
+        if (r) { h->n_errors++; continue; }
+        keep_stream_picture(h, &pic);
+        dav1d_picture_unref(&pic);
+    }
+    h->seconds = now_s() - t0;
+    if (have_thread) {
+        pthread_mutex_lock(&h->q_mtx);
+        h->q_stop = 1;
+        pthread_cond_broadcast(&h->q_cond);
+        pthread_mutex_unlock(&h->q_mtx);
+        pthread_join(h->up_thread, NULL);
+        pthread_join(h->gpu_thread, NULL);
+        pthread_join(h->out_thread, NULL);
+    }
+    dav1d_hooks = NULL;
+    h->tu = NULL; h->tu_size = NULL; h->n_tu = 0;
+    if (seconds) *seconds = h->seconds;
+    if (!rc && h->failed) rc = -2;           /* the BACKEND failed (a frame dav1d itself rejects is not that: n_errors) */
+    return rc;
+}
+int dav1d_hooked_stream_pictures(void *const handle) { return ((Hooked *) handle)->n_out_pics; }
+int dav1d_hooked_stream_errors(void *const handle) { return ((Hooked *) handle)->n_errors; }
+/* info: w, h, layout, bpc, frame_offset (the order hint), film grain applied */
+const void *dav1d_hooked_stream_picture(void *const handle, const int i, const int plane, int info[6]) {
+    Hooked *const h = handle;
+    if (i < 0 || i >= h->n_out_pics || plane < 0 || plane > 2) return NULL;
+    const OutPic *const o = &h->out_pics[i];
+    if (info) { info[0] = o->w; info[1] = o->h; info[2] = o->layout; info[3] = o->bpc; info[4] = o->frame_offset; info[5] = o->grain; }
+    return o->plane[plane];
+}
+/* tiles whose pass 1 failed: out[3 * i] = temporal unit, [3 * i + 1] = byte offset in it the symbol decoder had reached, [3 * i + 2] = 1 if it
+ * ran out of data (src/decode.c:2743) */
+int dav1d_hooked_stream_tile_errors(void *const handle, long *const out, const int cap) {
+    Hooked *const h = handle;
+    const int n = h->n_tile_err < cap ? h->n_tile_err : cap;
+    for (int i = 0; i < n; i++) { out[3 * i] = h->tile_err[i].tu; out[3 * i + 1] = (long) h->tile_err[i].off; out[3 * i + 2] = h->tile_err[i].overread; }
+    return h->n_tile_err;
+}
+int dav1d_hooked_stream_histogram(void *const handle, uint64_t *const out, const int cap) {
+    Hooked *const h = handle;
+    for (int i = 0; i < HIST_N && i < cap; i++) out[i] = h->hist[i];
+    return HIST_N;
+}
+
 const void *dav1d_hooked_plane(void *const handle, const int frame, const int plane) {
     Hooked *const h = handle;
     return frame >= 0 && frame < h->p.n_frames && plane >= 0 && plane < 3 ? h->out_plane[frame * 3 + plane] : NULL;
@@ -933,16 +1351,22 @@ void dav1d_hooked_close(void *const handle) {
                 if (s->lvl) h->hip.free_(h->ctx, s->lvl);
                 if (s->prep) h->hip.free_(h->ctx, s->prep);
                 if (s->mask) h->hip.free_(h->ctx, s->mask);
+                if (s->pal_idx) h->hip.free_(h->ctx, s->pal_idx);
+                if (s->lister) h->hip.lister_destroy(s->lister);
+                if (s->frame) h->hip.frame_destroy(s->frame);
             }
             free(s->filter_listed);
         }
         free(h->fcs);
     }
     if (h->seq_ref) dav1d_ref_dec(&h->seq_ref);
+    if (h->ctx_out) h->hip.close(h->ctx_out);
     if (h->ctx_up) h->hip.close(h->ctx_up);
     if (h->ctx) h->hip.close(h->ctx);
     if (h->out_plane) { for (int i = 0; i < h->p.n_frames * 3; i++) free(h->out_plane[i]); free(h->out_plane); }
-    free(h->q_frame); free(h->q_state); free(h->q_rc); free(h->q_filtered); free(h->q_done_t);
+    for (int i = 0; i < h->n_out_pics; i++) for (int pl = 0; pl < 3; pl++) free(h->out_pics[i].plane[pl]);
+    free(h->out_pics);
+    free(h->q_done_t);
     if (h->hip.dl) dlclose(h->hip.dl);
     pthread_mutex_destroy(&h->q_mtx);
     pthread_cond_destroy(&h->q_cond);

@@ -170,7 +170,7 @@ typedef void (*cfb8_fn)(uint8_t *, ptrdiff_t, const void *, const uint8_t *, con
 typedef void (*cfb16_fn)(uint16_t *, ptrdiff_t, const void *, const uint16_t *, const uint16_t *, int, int, int, int, int, int);
 
 static void cdef_block(void *fn, int bpc, const ReplayPlanes *src, const ReplayPlanes *dst, int pl, int px0, int py0, int w, int h,
-                       int pri, int sec, int dir, int damping, int edges)
+                       int pri, int sec, int dir, int damping, int edges, int rep_bot)
 {
     const int bps = bpc > 8 ? 2 : 1, bdmax = (1 << bpc) - 1;
     const ptrdiff_t st = src->stride[pl];
@@ -181,9 +181,20 @@ static void cdef_block(void *fn, int bpc, const ReplayPlanes *src, const ReplayP
     /* rows above / below come from the unfiltered picture; when an edge flag is clear the pointer is never read */
     const uint8_t *top = s + (py0 >= 2 ? py0 - 2 : 0) * st + px0 * bps;
     const uint8_t *bot = s + (py0 + h < src->h[pl] ? py0 + h : src->h[pl] - 1) * st + px0 * bps;
+    uint8_t *bot2 = NULL;              /* DAV1D_HIP_CDEF_BOT_REP_*: the first row below, twice (what backup_lpf saved), rows dst-stride apart */
+    if (rep_bot) {
+        const ptrdiff_t ds = dst->stride[pl];
+        const int lo = px0 >= 2 ? 2 : 0;
+        bot2 = malloc((size_t) ds + (size_t) (w + 4) * bps + 64);
+        if (bot2) {
+            for (int r = 0; r < 2; r++) memcpy(bot2 + r * ds + (2 - lo) * bps, s + (py0 + h) * st + (px0 - lo) * bps, (size_t) (w + 2 + lo) * bps);
+            bot = bot2 + 2 * bps;
+        }
+    }
     uint8_t *blk = (uint8_t *) dst->data[pl] + py0 * dst->stride[pl] + px0 * bps;
     if (bpc == 8) ((cfb8_fn) fn)(blk, dst->stride[pl], left, top, bot, pri, sec, dir, damping, edges);
     else ((cfb16_fn) fn)((uint16_t *) blk, dst->stride[pl], left, (const uint16_t *) top, (const uint16_t *) bot, pri, sec, dir, damping, edges, bdmax);
+    free(bot2);
 }
 
 /* One 8x8 unit of dav1d_cdef_brow (reference src/cdef_apply_tmpl.c:149-290), out of place: `dst` starts as a copy of
@@ -214,15 +225,15 @@ int dav1d_replay_cdef(entry_fn entry, int bpc, int layout, const ReplayPlanes *s
                 const int idx = (var >> 6) ? (lg < 12 ? lg : 12) : 0;
                 adj = (k->y_pri * (4 + idx) + 8) >> 4;
             }
-            if (adj || k->y_sec) cdef_block(fby, bpc, src, dst, 0, x0, y0, 8, 8, adj, k->y_sec, dir, damping, k->edges);
+            if (adj || k->y_sec) cdef_block(fby, bpc, src, dst, 0, x0, y0, 8, 8, adj, k->y_sec, dir, damping, k->edges, k->flags & DAV1D_HIP_CDEF_BOT_REP_Y);
         } else if (k->y_sec) {
-            cdef_block(fby, bpc, src, dst, 0, x0, y0, 8, 8, 0, k->y_sec, 0, damping, k->edges);
+            cdef_block(fby, bpc, src, dst, 0, x0, y0, 8, 8, 0, k->y_sec, 0, damping, k->edges, k->flags & DAV1D_HIP_CDEF_BOT_REP_Y);
         }
         if (fbuv && (k->uv_pri || k->uv_sec)) {
             const int uvdir = k->uv_pri ? (layout == 2 ? uv422[dir] : dir) : 0;
             for (int pl = 1; pl <= 2; pl++)
                 cdef_block(fbuv, bpc, src, dst, pl, x0 >> ss_hor, y0 >> ss_ver, 8 >> ss_hor, 8 >> ss_ver, k->uv_pri, k->uv_sec, uvdir,
-                           damping - 1, k->edges);
+                           damping - 1, k->edges, k->flags & DAV1D_HIP_CDEF_BOT_REP_UV);
         }
     }
     return 0;
@@ -258,7 +269,8 @@ int dav1d_replay_lr(entry_fn entry, int bpc, const ReplayPlanes *src, const Repl
         if (k->y >= 2) { memcpy(rows, lp + (k->y - 2) * st, st); memcpy(rows + st, lp + (k->y - 1) * st, st); }
         if (k->y + k->h + 1 < lpf->h[pl] + 8) {          /* planes are allocated with padding rows */
             memcpy(rows + 6 * st, lp + (k->y + k->h) * st, st);
-            memcpy(rows + 7 * st, lp + (k->y + k->h + 1) * st, st);
+            /* backup_lpf() stores the picture's last row twice where it is the first of the two (src/lf_apply_tmpl.c:77-97) */
+            memcpy(rows + 7 * st, lp + (k->y + k->h + 1 < lpf->h[pl] ? k->y + k->h + 1 : lpf->h[pl] - 1) * st, st);
         }
         union { int16_t filter[2][8]; struct { uint32_t s0, s1; int16_t w0, w1; } sgr; } prm;
         memset(&prm, 0, sizeof(prm));

@@ -1,6 +1,7 @@
 // Fiber scheduler behind tests/emu/hip/hip_runtime.h.  TEST INFRASTRUCTURE ONLY.
 #include "hip/hip_runtime.h"
 #include <ucontext.h>
+#include <mutex>
 #include <vector>
 
 uint3 threadIdx, blockIdx;
@@ -99,7 +100,12 @@ void emu_syncthreads() { fibers[cur].st = WAIT_BLOCK; yield_to_sched(); }
 void emu_wave_sync() { fibers[cur].st = WAIT_WAVE; yield_to_sched(); }
 uint64_t *emu_wave_slots() { return wave_slots[fibers[cur].wave]; }
 
+// one launch at a time: the scheduler's state (and threadIdx / blockIdx) is global, and host threads with contexts of their own do
+// launch side by side (a frame ending on one thread, film grain going onto an output picture on another)
+static std::mutex launch_mtx;
+
 void emu_launch(const std::function<void()> &body, dim3 grid, dim3 block) {
+    std::lock_guard<std::mutex> lk(launch_mtx);
     blockDim = block;
     gridDim = grid;
     for (unsigned z = 0; z < grid.z; z++)
