@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--e2e-tile-cols", type=int, default=16, help="tile columns of the end-to-end leg (one listing thread per tile)")
     ap.add_argument("--e2e-tile-rows", type=int, default=8, help="tile rows of the end-to-end leg")
     ap.add_argument("--e2e-threads", type=int, default=64, help="listing threads (of the library, dav1d_hip_lister_run) of the one-frame-at-a-time end-to-end legs (0: one per tile).  The MI355X boxes of this pool give the container 16 cores' worth of CPU time per 100 ms (cgroup cpu.max): a burst on 64 threads runs at full speed until that is spent, then every thread stops for the rest of the period — the frames-in-flight legs report both ways")
+    ap.add_argument("--stream-frames", type=int, default=16, help="frames of the AV1 stream of the dav1d_task_loop_real_pass1 leg (every one compared with dav1d's)")
     ap.add_argument("--no-c1", action="store_true", help="skip the 4K 8-bit (BASELINE configs[1]) line that the default run appends")
     ap.add_argument("--no-full", action="store_true", help="skip the full-DSP-table leg (deblock, CDEF, restoration, film grain)")
     ap.add_argument("--two-phase", action="store_true",
@@ -970,6 +971,23 @@ def main():
                 raise SystemExit("bench: the dav1d task loop leg differs from dav1d's own pass 2 + filters: %s" % e)
             except Exception as e:       # noqa: BLE001  (a reported extra)
                 task_loop = {"error": str(e)[:200]}
+        # ---- ... and behind dav1d's REAL pass 1: an AV1 stream (tests/av1_obu.py: real headers, every tool, random tile payloads) through
+        # dav1d_send_data / dav1d_parse_obus / msac / decode_b unmodified; EVERY picture of the chain compared with dav1d's own
+        task_loop_stream = None
+        if world == 1 and not a.no_e2e and not a.no_check:
+            try:
+                import stream_util as sut
+                from dav1d_amd import _lib as _l
+                if sut.lib() is None:
+                    task_loop_stream = {"status": "skipped: oracle/_ref_hooked is not built (needs /root/reference at build time)"}
+                else:
+                    ctx.sync()
+                    task_loop_stream = sut.task_loop_rate(_l.DEFAULT_PATH, w, h, bpc, tiles_log2=(2, 0), threads=min(64, os.cpu_count() or 8), frame_delay=8,
+                                                          frames=a.stream_frames)
+            except AssertionError as e:
+                raise SystemExit("bench: the dav1d task loop leg behind dav1d's real pass 1 differs from dav1d: %s" % e)
+            except Exception as e:       # noqa: BLE001  (a reported extra)
+                task_loop_stream = {"error": str(e)[:200]}
         label = "8K" if (w, h) == (7680, 4320) else "4K" if (w, h) == (3840, 2160) else "%dx%d" % (w, h)
         out = {"metric": "reconstructed luma Mpixels/s (%s 4:2:0 %d-bit) on the itx+mc recon path; bit-exact vs C" % (label, bpc),
                "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -987,7 +1005,7 @@ def main():
                           "coef_bytes_per_frame": int(coef_host.nbytes), "coef_h2d_ms_per_frame": h2d_ms,
                           "samples_per_frame": frame.n_samples, "parity": check, "gen_seconds": round(t_gen, 1)},
                "roofline": roof, "cpu_baseline": cpu, "full_table": full, "end_to_end": e2e_leg, "all_intra": key_leg, "end_to_end_packing_lister": e2e_packed, "all_intra_packing_lister": key_packed, "end_to_end_full_table": full_route, "end_to_end_4_tile_columns": e2e_c2, "end_to_end_full_table_4_tile_columns": full_route_c2,
-               "end_to_end_frames_in_flight": sustained, "row_progress": row_progress, "refmvs": refmvs_leg, "dav1d_task_loop": task_loop, "config_c0_1080p_8bit": c0,
+               "end_to_end_frames_in_flight": sustained, "row_progress": row_progress, "refmvs": refmvs_leg, "dav1d_task_loop": task_loop, "dav1d_task_loop_real_pass1": task_loop_stream, "config_c0_1080p_8bit": c0,
                "device": None if a.no_check else device_probe(torch)}       # (not under the profiler: its copies would sit in the kernel statistics)
         # BASELINE configs[1] (4K 8-bit, the reference's CPU-runnable size) next to the headline: the same bench in a child process,
         # its digest under "config_c1_4k_8bit"

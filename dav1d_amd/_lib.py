@@ -78,7 +78,7 @@ SYMBOLS = [
     "dav1d_hip_frame_set_filters", "dav1d_hip_frame_end", "dav1d_hip_frame_destroy",
     "dav1d_hip_frame_submit_step_blend", "dav1d_hip_frame_submit_warp", "dav1d_hip_frame_submit_scaled",
     "dav1d_hip_lister_create", "dav1d_hip_lister_tile_sbrow", "dav1d_hip_lister_run", "dav1d_hip_lister_filter_run", "dav1d_hip_lister_run_frame", "dav1d_hip_lister_prep_elems", "dav1d_hip_lister_mask_bytes",
-    "dav1d_hip_lister_steps", "dav1d_hip_lister_const_masks", "dav1d_hip_lister_destroy", "dav1d_hip_synth_frame",
+    "dav1d_hip_lister_steps", "dav1d_hip_lister_const_masks", "dav1d_hip_lister_destroy",
     "dav1d_hip_lister_mask_offset", "dav1d_hip_lister_tables", "dav1d_hip_lister_block_warp", "dav1d_hip_lister_filter_sbrow",
 ]
 
@@ -104,16 +104,6 @@ class FrameDesc(C.Structure):          # == Dav1dHipFrameDesc
                 ("svc", ((C.c_int32 * 2) * 2) * 7), ("ref_w", C.c_int * 7), ("ref_h", C.c_int * 7), ("gmv", WarpParams * 7),
                 ("gmv_warp_allowed", C.c_uint8 * 7), ("jnt_weights", (C.c_uint8 * 7) * 7), ("cf_align64", C.c_int),
                 ("lossless", C.c_uint8 * 8), ("cf", C.c_void_p)]
-
-
-class SynthParams(C.Structure):        # == Dav1dHipSynthParams
-    _fields_ = [("seed", C.c_uint64), ("intra_pct", C.c_int), ("skip_pct", C.c_int), ("compound_pct", C.c_int),
-                ("masked_compound", C.c_int), ("global_pct", C.c_int), ("interintra_pct", C.c_int), ("obmc_pct", C.c_int),
-                ("warp_pct", C.c_int), ("cfl_pct", C.c_int), ("palette", C.c_int), ("filter_intra_pct", C.c_int),
-                ("tx_split_pct", C.c_int), ("alt_txtp_pct", C.c_int), ("eob_none_pct", C.c_int), ("mv_range", C.c_int),
-                ("far_mv_pct", C.c_int), ("n_refs", C.c_int), ("split_pct", C.c_int * 5), ("rect_pct", C.c_int),
-                ("fixed_bl", C.c_int), ("cf_align64", C.c_int), ("intrabc_pct", C.c_int), ("n_segs", C.c_int),
-                ("skip_mode_pct", C.c_int)]
 
 
 class FilterDesc(C.Structure):         # == Dav1dHipFilterDesc
@@ -269,7 +259,6 @@ def load(path=None):
         "dav1d_hip_lister_steps": (sz, [vp]),
         "dav1d_hip_lister_const_masks": (vp, [P(sz)]),
         "dav1d_hip_lister_destroy": (None, [vp]),
-        "dav1d_hip_synth_frame": (i, [P(FrameDesc), P(SynthParams), vp, sz, sz, vp, sz]),
         "dav1d_hip_lister_mask_offset": (C.c_long, [i, i, i, i, i]),
         "dav1d_hip_lister_tables": (None, [vp]),
         "dav1d_hip_lister_filter_sbrow": (i, [vp, P(FilterDesc), i]),

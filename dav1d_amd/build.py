@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["capi.hip", "chunk.hip", "frame.hip", "dsp_table.hip", "dsp_table_post.hip", "itx.hip", "mc.hip", "recon.hip", "intra_pair.hip", "intra_flow.hip", "intra_sb.hip", "lfmask.hip", "refmvs.hip", "peer.hip", "mcx.hip", "comp.hip", "cdef.hip", "loopfilter.hip", "ipred.hip", "lr.hip", "fg.hip"]
-# host side of the pass-2 hand-off: plain C99 (the lister, its AV1 geometry, the synthetic frame generator), compiled with gcc
-HOST_SOURCES = ["av1_host.c", "lister.c", "filter_lister.c", "lf_rects.c", "synth_frame.c"]
+# host side of the pass-2 hand-off: plain C99 (the lister, its AV1 geometry), compiled with gcc
+HOST_SOURCES = ["av1_host.c", "lister.c", "filter_lister.c", "lf_rects.c"]
 HOST = os.path.join(HERE, "host")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CC = os.environ.get("CC", "gcc")

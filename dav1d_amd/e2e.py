@@ -1,7 +1,7 @@
 """End-to-end leg of the benchmark: hand-off arrays -> pass-2 lister (host threads) -> device.
 
 What the headline `value` of bench.py leaves out by definition (lists resident in HBM) is measured here: one synthetic 8K
-frame's pass-1 output (Av1Block / cbi / cf, dav1d_hip_synth_frame) is listed by dav1d_hip_lister_tile_sbrow() from a pool of
+frame's pass-1 output (Av1Block / cbi / cf, dav1d_synth_frame) is listed by dav1d_hip_lister_tile_sbrow() from a pool of
 host threads (one per tile, as dav1d's pass-2 workers would), every submit prepares its chunk of the device lists on the
 submitting thread, the coefficient arena crosses the host link, and dav1d_hip_frame_end() launches the frame.
 
@@ -17,6 +17,11 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 from . import _lib, api
+
+# the generator of synthetic pass-1 output is test infrastructure with a library of its own (tests/synth/libdav1d_synth.so)
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import synth_lib  # noqa: E402
 
 SIZE_MUL = [(4, 4), (6, 5), (8, 6), (12, 8)]      # ss_size_mul, reference src/decode.c:2416-2421
 
@@ -104,7 +109,7 @@ class HandOff:
 def c2_params(seed, n_refs=3):
     """SURVEY 8d config C2's itx+mc subset as generator settings: block mix 64 / 32 / 16 / 8 / 4 = 20 / 30 / 30 / 15 / 5 % by area
     (split probabilities per level: 1 - 0.2, 1 - 0.3 / 0.8, ...), 25 % compound average, every block coded, no intra blocks."""
-    sp = _lib.SynthParams()
+    sp = synth_lib.SynthParams()
     sp.seed = seed
     sp.intra_pct, sp.skip_pct = 0, 0
     sp.compound_pct, sp.masked_compound = 25, 0
@@ -130,7 +135,7 @@ def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0
     if key_frame:
         ho.desc.is_inter = 0
     t0 = time.perf_counter()
-    rc = ctx.lib.dav1d_hip_synth_frame(C.byref(ho.desc), C.byref(sp), ho.cf.ctypes.data, ho.cf.nbytes, len(ho.cbi), None, 0)
+    rc = synth_lib.synth_frame(ho.desc, sp, ho.cf.ctypes.data, ho.cf.nbytes, len(ho.cbi), None, 0)
     assert rc == 0, rc
     t_synth = time.perf_counter() - t0
     rng = np.random.default_rng(seed)
@@ -402,7 +407,7 @@ def run_sustained(ctx, w=7680, h=4320, bpc=10, frames=10, threads=None, tile_col
     if key_frame:
         sp.intra_pct = 100
         ho.desc.is_inter = 0
-    rc = ctx.lib.dav1d_hip_synth_frame(C.byref(ho.desc), C.byref(sp), ho.cf.ctypes.data, ho.cf.nbytes, len(ho.cbi), None, 0)
+    rc = synth_lib.synth_frame(ho.desc, sp, ho.cf.ctypes.data, ho.cf.nbytes, len(ho.cbi), None, 0)
     assert rc == 0, rc
     rng = np.random.default_rng(seed)
     refs = []

@@ -35,6 +35,7 @@
 #include "src/thread_task.h"
 #include "hooked/hooks.h"
 #include "dav1d_hip.h"
+#include "dav1d_synth.h"
 
 typedef struct HookedParams {
     int w, h, layout, bpc, sb128;
@@ -56,7 +57,7 @@ typedef struct HookedParams {
     int pack;                  /* mode 1: the lister packs (Dav1dHipFrameDesc.cf = f->frame_thread.cf): the coefficients that exist travel with
                                   the frame's lists, cf is left zero as the reference's inverse transforms leave it, no dense arena goes to
                                   the device.  With inject = 2 the arrays of the STORE are what gets consumed: replay such a store last. */
-    Dav1dHipSynthParams synth; /* block decisions of the generated frames; seed + frame number per frame */
+    Dav1dSynthParams synth; /* block decisions of the generated frames; seed + frame number per frame */
     int stream;                /* 1: NOTHING is injected.  The harness is handed an AV1 bitstream (tests/av1_obu.py: real headers, tile payloads of
                                   seeded random bytes) and drives dav1d's public API with it — dav1d_send_data / dav1d_get_picture, dav1d_parse_obus,
                                   dav1d_submit_frame, and the reference's own pass 1 (dav1d_msac_*, decode_b, decode_coefs, read_restoration_info,
@@ -79,7 +80,9 @@ typedef struct Store { int n; StoredFrame *fr; } Store;
 /* the entry points of include/dav1d_hip.h, resolved from the library the caller names (libdav1d_hip.so, or the SIMT-emulated
  * build of the same sources on a machine without a GPU) */
 typedef struct Hip {
-    void *dl;
+    void *dl, *synth_dl;
+    /* chain mode: the generator of synthetic pass-1 output (tests/synth/libdav1d_synth.so, test infrastructure like this file) */
+    int (*synth_frame)(const Dav1dHipFrameDesc *, const Dav1dSynthParams *, void *, size_t, size_t, uint8_t *, size_t);
     int (*open)(Dav1dHipContext **, int, void *);
     void (*close)(Dav1dHipContext *);
     int (*sync)(Dav1dHipContext *);
@@ -103,7 +106,6 @@ typedef struct Hip {
     size_t (*lister_mask_bytes)(const Dav1dHipLister *);
     const uint8_t *(*lister_const_masks)(size_t *);
     void (*lister_destroy)(Dav1dHipLister *);
-    int (*synth_frame)(const Dav1dHipFrameDesc *, const Dav1dHipSynthParams *, void *, size_t, size_t, uint8_t *, size_t);
     int (*frame_submit_intra_step)(Dav1dHipFrame *, size_t, const Dav1dHipIpredTask *, size_t, const Dav1dHipItxTask *, size_t, uint8_t *);
     int (*frame_set_super_res)(Dav1dHipFrame *, int);
     int (*fg_apply)(Dav1dHipContext *, const Dav1dHipPicture *, const Dav1dHipPicture *, const Dav1dHipFilmGrainData *, int);
@@ -143,7 +145,7 @@ typedef struct FcState {
     size_t pal_idx_cap;
 } FcState;
 
-typedef struct OutPic { int w, h, layout, bpc, frame_offset, grain; uint8_t *plane[3]; } OutPic;
+typedef struct OutPic { int w, h, layout, bpc, frame_offset, grain; uint8_t *plane[3]; uint64_t hash[3]; double t; } OutPic;
 
 /* which tools pass 1's output of a stream really holds (blocks counted by the reference's own decode_sb walk, count_walk below) */
 enum { HIST_FRAMES_KEY, HIST_FRAMES_INTER, HIST_FRAMES_INTRA_ONLY, HIST_FRAMES_SUPER_RES, HIST_FRAMES_SCALED_REFS, HIST_FRAMES_INTRABC,
@@ -568,7 +570,7 @@ static int hk_after_init_(Dav1dFrameContext *const f) {
         hip_frame_desc(&s->desc, f);
         memset(f->frame_thread.cf, 0, cf_bytes);
         memset(f->frame_thread.b, 0, b_bytes);
-        Dav1dHipSynthParams sp = h->p.synth;
+        Dav1dSynthParams sp = h->p.synth;
         sp.seed += 7919u * (uint64_t) fh->frame_offset;
         sp.cf_align64 = ARCH_X86_64;
         rc = h->hip.synth_frame(&s->desc, &sp, f->frame_thread.cf, cf_bytes, cbi_entries, f->frame_thread.pal_idx, pal_idx_bytes);
@@ -1046,6 +1048,11 @@ static int pic_has_grain(const Dav1dPicture *const pic) {          /* has_grain(
     const Dav1dFilmGrainData *const fg = &pic->frame_hdr->film_grain.data;
     return fg->num_y_points || fg->num_uv_points[0] || fg->num_uv_points[1] || (fg->clip_to_restricted_range && fg->chroma_scaling_from_luma);
 }
+static uint64_t hash_bytes(uint64_t x, const uint8_t *p, size_t n) {
+    for (; n >= 8; n -= 8, p += 8) { uint64_t v; memcpy(&v, p, 8); x = (x ^ v) * 0x9E3779B97F4A7C15ull; x ^= x >> 29; }
+    for (; n; n--, p++) { x = (x ^ *p) * 0x100000001B3ull; }
+    return x;
+}
 static void keep_stream_picture(Hooked *const h, const Dav1dPicture *const pic) {
     if (h->n_out_pics == h->cap_out_pics) {
         const int cap = h->cap_out_pics ? 2 * h->cap_out_pics : 64;
@@ -1075,8 +1082,11 @@ static void keep_stream_picture(Hooked *const h, const Dav1dPicture *const pic) 
         if (!dst) { rc = -ENOMEM; break; }
         if (grain_here) rc = h->hip.plane_download(h->ctx_out, &g, pl, dst, (ptrdiff_t) w * bps, 0);
         else for (int y = 0; y < hh; y++) memcpy(dst + (size_t) y * w * bps, (const uint8_t *) pic->data[pl] + (ptrdiff_t) y * pic->stride[!!pl], (size_t) w * bps);
-        o->plane[pl] = dst;
+        o->hash[pl] = hash_bytes(0xDA71Dull + (uint64_t) pl, dst, (size_t) w * hh * bps);
+        if (h->p.keep_output == 2) free(dst);           /* digests only (long chains of large pictures) */
+        else o->plane[pl] = dst;
     }
+    o->t = now_s();
     if (grain_here) { if (!rc) rc = h->hip.sync(h->ctx_out); h->hip.picture_free(h->ctx_out, &g); }
     if (rc) h->failed = 1;
     h->n_out_pics++;
@@ -1126,7 +1136,21 @@ void *dav1d_hooked_open(const HookedParams *const p, const char *const hip_lib, 
     SYM(frame_end, "dav1d_hip_frame_end"); SYM(frame_destroy, "dav1d_hip_frame_destroy");
     SYM(lister_create, "dav1d_hip_lister_create"); SYM(lister_tile_sbrow, "dav1d_hip_lister_tile_sbrow"); SYM(lister_filter_sbrow, "dav1d_hip_lister_filter_sbrow");
     SYM(lister_prep_elems, "dav1d_hip_lister_prep_elems"); SYM(lister_mask_bytes, "dav1d_hip_lister_mask_bytes");
-    SYM(lister_const_masks, "dav1d_hip_lister_const_masks"); SYM(lister_destroy, "dav1d_hip_lister_destroy"); SYM(synth_frame, "dav1d_hip_synth_frame");
+    SYM(lister_const_masks, "dav1d_hip_lister_const_masks"); SYM(lister_destroy, "dav1d_hip_lister_destroy");
+    if (!p->stream) {
+        /* ../../tests/synth/libdav1d_synth.so, seen from where this library lies (oracle/_ref_hooked/) */
+        Dl_info me;
+        char path[4096];
+        if (!dladdr((void *) dav1d_hooked_close, &me) || !me.dli_fname || strlen(me.dli_fname) > sizeof(path) - 64) goto fail;
+        strcpy(path, me.dli_fname);
+        char *slash = strrchr(path, '/');
+        if (!slash) goto fail;
+        strcpy(slash, "/../../tests/synth/libdav1d_synth.so");
+        h->hip.synth_dl = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!h->hip.synth_dl) goto fail;
+        *(void **) &h->hip.synth_frame = dlsym(h->hip.synth_dl, "dav1d_synth_frame");
+        if (!h->hip.synth_frame) goto fail;
+    }
     SYM(frame_submit_intra_step, "dav1d_hip_frame_submit_intra_step"); SYM(frame_set_super_res, "dav1d_hip_frame_set_super_res");
     SYM(fg_apply, "dav1d_hip_fg_apply"); SYM(picture_alloc, "dav1d_hip_picture_alloc"); SYM(picture_free, "dav1d_hip_picture_free");
     SYM(plane_download, "dav1d_hip_plane_download");
@@ -1314,6 +1338,13 @@ const void *dav1d_hooked_stream_picture(void *const handle, const int i, const i
     if (info) { info[0] = o->w; info[1] = o->h; info[2] = o->layout; info[3] = o->bpc; info[4] = o->frame_offset; info[5] = o->grain; }
     return o->plane[plane];
 }
+/* out[0..2] = digests of the planes (keep_output = 2 keeps nothing else), returns the time the picture came out of dav1d_get_picture */
+double dav1d_hooked_stream_picture_digest(void *const handle, const int i, uint64_t out[3]) {
+    Hooked *const h = handle;
+    if (i < 0 || i >= h->n_out_pics) return 0.;
+    for (int pl = 0; pl < 3; pl++) out[pl] = h->out_pics[i].hash[pl];
+    return h->out_pics[i].t;
+}
 /* tiles whose pass 1 failed: out[3 * i] = temporal unit, [3 * i + 1] = byte offset in it the symbol decoder had reached, [3 * i + 2] = 1 if it
  * ran out of data (src/decode.c:2743) */
 int dav1d_hooked_stream_tile_errors(void *const handle, long *const out, const int cap) {
@@ -1367,6 +1398,7 @@ void dav1d_hooked_close(void *const handle) {
     for (int i = 0; i < h->n_out_pics; i++) for (int pl = 0; pl < 3; pl++) free(h->out_pics[i].plane[pl]);
     free(h->out_pics);
     free(h->q_done_t);
+    if (h->hip.synth_dl) dlclose(h->hip.synth_dl);
     if (h->hip.dl) dlclose(h->hip.dl);
     pthread_mutex_destroy(&h->q_mtx);
     pthread_cond_destroy(&h->q_cond);

@@ -258,6 +258,9 @@ class Knobs:
         self.use_ref_frame_mvs = 0.6
         self.max_tiles = (2, 2)            # log2 of the most tile columns / rows a frame gets
         self.bytes_per_pixel = 1.0         # tile payload (the decoder must never run dry: src/decode.c:2743)
+        self.seg_pin = 0                   # inter frames: segmentation on with this many of the 8 segments carrying the reference feature
+                                           # (their blocks are inter blocks of that reference whatever the payload says, src/decode.c:
+                                           # 1241-1262): random payloads alone decode to ~3/4 intra blocks (the intra flag's context feeds itself)
         self.__dict__.update(kw)
 
 
@@ -429,7 +432,8 @@ class StreamWriter:
 
     def _segmentation(self, b, fr, pri):
         k = self.k
-        fr.seg_enabled = int(self.p(k.segmentation))
+        pin = k.seg_pin if fr.frame_type == INTER else 0
+        fr.seg_enabled = int(self.p(k.segmentation) or pin > 0)
         b.bit(fr.seg_enabled)
         fr.seg = None
         if not fr.seg_enabled:
@@ -443,7 +447,7 @@ class StreamWriter:
             if update_map:
                 temporal = int(self.p(0.5))
                 b.bit(temporal)
-            update_data = int(self.p(0.7) or pri.seg is None)
+            update_data = int(self.p(0.7) or pri.seg is None or pin > 0)
             b.bit(update_data)
         fr.seg_update_map, fr.seg_temporal, fr.seg_update_data = update_map, temporal, update_data
         if update_data:
@@ -463,8 +467,8 @@ class StreamWriter:
                 d["delta_q"] = feat(9, -255, 255)
                 for j in range(4):
                     d["lf"][j] = feat(7, -63, 63)
-                if on and self.p(0.15):
-                    d["ref"] = self.ri(0, 7)
+                if i < pin or (on and self.p(0.15) and not pin):
+                    d["ref"] = 1 + i % 7 if i < pin else self.ri(0, 7)
                     b.bit(1)
                     b.f(3, d["ref"])
                 else:

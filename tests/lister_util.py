@@ -2,13 +2,14 @@
 synthetic pass-1 output -> dav1d_hip_lister_* -> dav1d_hip_frame_* on the device (or the SIMT-emulated build).
 
 The reference side is TEST INFRASTRUCTURE: it owns the hand-off arrays (allocated by the reference's
-dav1d_decode_frame_init), the product's generator (dav1d_hip_synth_frame) fills them, the reference reconstructs
+dav1d_decode_frame_init), the generator of tests/synth (dav1d_synth_frame) fills them, the reference reconstructs
 from them on the CPU and the lister + kernels reconstruct from the very same arrays on the GPU."""
 import ctypes as C
 
 import numpy as np
 
 import util
+import synth_lib
 from dav1d_amd import _lib, api
 
 
@@ -246,7 +247,7 @@ class RefFrame:
 
 
 def default_synth(seed, **kw):
-    sp = _lib.SynthParams()
+    sp = synth_lib.SynthParams()
     sp.seed = seed
     sp.intra_pct, sp.skip_pct = 15, 20
     sp.compound_pct, sp.masked_compound = 30, 1
@@ -276,8 +277,8 @@ def synth(ctx, rf, sp):
     _, cbi_bytes = rf.ptr("cbi")
     pal_idx, pal_idx_bytes = rf.ptr("pal_idx")
     C.memset(cf, 0, cf_bytes)
-    rc = ctx.lib.dav1d_hip_synth_frame(C.byref(d), C.byref(sp), cf, cf_bytes, cbi_bytes // 2, pal_idx, pal_idx_bytes)
-    assert rc == 0, "dav1d_hip_synth_frame: %d" % rc
+    rc = synth_lib.synth_frame(d, sp, cf, cf_bytes, cbi_bytes // 2, pal_idx, pal_idx_bytes)
+    assert rc == 0, "dav1d_synth_frame: %d" % rc
     # the reference's itxfm_add consumes (zeroes) the coefficients: keep what pass 1 "produced" for the device side
     rf.cf_copy = rf.array("cf", np.uint8).copy()
     return d

@@ -6,14 +6,16 @@
  * (src/decode.c:683-2115 decides the syntax elements, dav1d_read_coef_blocks src/recon_tmpl.c:824-936 the order of the
  * coefficient arrays).  Block decisions are drawn from a seeded generator under the legality rules of the AV1 syntax (which
  * tool may appear on which block size), so that every combination the reconstruction can meet does occur.
- * This is an input generator like dav1d_amd/synth.py, not part of the decode path.  Plain C99. */
-#include "av1_host.h"
+ * This is an input generator like dav1d_amd/synth.py, not part of the decode path and not part of the product library: TEST
+ * INFRASTRUCTURE, built into tests/synth/libdav1d_synth.so.  Plain C99. */
+#include "../../dav1d_amd/host/av1_host.h"
+#include "dav1d_synth.h"
 #include <errno.h>
 #include <stdlib.h>
 #include <string.h>
 
 #define __device__
-#include "../csrc/av1_scan_dev.h"
+#include "../../dav1d_amd/csrc/av1_scan_dev.h"
 #undef __device__
 
 typedef struct Rng { uint32_t s[4]; } Rng;
@@ -33,7 +35,7 @@ static int imax(const int a, const int b) { return a > b ? a : b; }
 
 typedef struct Gen {
     const Dav1dHipFrameDesc *d;
-    const Dav1dHipSynthParams *sp;
+    const Dav1dSynthParams *sp;
     Dav1dHipAv1Block *b;
     int16_t *cbi;
     uint8_t *cf, *pal, *pal_idx;
@@ -181,7 +183,7 @@ static int is_directional(const int m) { return m >= H_VERT_PRED && m <= H_VERT_
 
 /* decode_b() of pass 1 with the symbol decoder replaced by the generator (src/decode.c:808-1960) */
 static void gen_block(Gen *g, const int bl, const int bs, const int bp, const int bx, const int by) {
-    const Dav1dHipSynthParams *sp = g->sp;
+    const Dav1dSynthParams *sp = g->sp;
     Dav1dHipAv1Block *b = &g->b[(size_t) by * g->d->b4_stride + bx];
     const int ss_hor = g->ss_hor, ss_ver = g->ss_ver, layout = g->d->layout;
     const uint8_t *b_dim = h_bs_dim[bs];
@@ -425,7 +427,7 @@ static void gen_sb(Gen *g, const int bl, const int bx, const int by) {
 
 /* Fills b / cbi / cf / pal / pal_idx (the arrays desc points to, sized as dav1d_decode_frame_init() sizes them, cf zeroed)
  * for the whole frame.  cf_bytes / cbi_entries / pal_idx_bytes: the capacities, for overflow checks. */
-int dav1d_hip_synth_frame(const Dav1dHipFrameDesc *d, const Dav1dHipSynthParams *sp, void *cf, size_t cf_bytes, size_t cbi_entries,
+int dav1d_synth_frame(const Dav1dHipFrameDesc *d, const Dav1dSynthParams *sp, void *cf, size_t cf_bytes, size_t cbi_entries,
                           uint8_t *pal_idx, size_t pal_idx_bytes)
 {
     if (!d || !sp || !d->b || !d->cbi || !cf || !d->tile_start_off) return -EINVAL;

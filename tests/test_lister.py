@@ -1,6 +1,6 @@
 """The pass-2 lister against the reference's OWN pass 2.
 
-One synthetic pass-1 output (Av1Block / cbi / cf / palettes, dav1d_hip_synth_frame) sits in the per-frame arrays of a real
+One synthetic pass-1 output (Av1Block / cbi / cf / palettes, dav1d_synth_frame) sits in the per-frame arrays of a real
 Dav1dFrameContext of the reference build (oracle/ref_frame.c).  The reference reconstructs from it on the CPU with
 dav1d_decode_tile_sbrow(pass 2) -> decode_sb -> decode_b -> dav1d_recon_b_intra / dav1d_recon_b_inter; the product lists
 the same arrays (dav1d_hip_lister_*), submits the tasks to a frame (dav1d_hip_frame_*) and runs the kernels.  Planes must be

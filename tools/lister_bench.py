@@ -8,6 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import util
 from dav1d_amd import api, e2e
+import synth_lib
 
 a = [int(v) for v in sys.argv[1:]]
 w, h, threads, frames, tcols, trows = (a + [3840, 2160, 8, 5, 4, 2][len(a):])[:6]
@@ -15,7 +16,7 @@ ctx = util.make_ctx() if hasattr(util, "make_ctx") else api.Context(0, lib_path=
 layout, bpc = api.LAYOUT_I420, 10
 ho = e2e.HandOff(w, h, layout, bpc, True, tcols, trows)
 sp = e2e.c2_params(0xE2E)
-assert ctx.lib.dav1d_hip_synth_frame(C.byref(ho.desc), C.byref(sp), ho.cf.ctypes.data, ho.cf.nbytes, len(ho.cbi), None, 0) == 0
+assert synth_lib.synth_frame(ho.desc, sp, ho.cf.ctypes.data, ho.cf.nbytes, len(ho.cbi), None, 0) == 0
 refs = [ctx.picture(w, h, layout, bpc) for _ in range(3)]
 refs7 = [refs[i % 3] for i in range(7)]
 cur = ctx.picture(w, h, layout, bpc)
