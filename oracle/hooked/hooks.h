@@ -26,4 +26,6 @@ typedef struct Dav1dHooks {
 
 extern const Dav1dHooks *dav1d_hooks;                 /* NULL: the unpatched behaviour */
 void dav1d_hooked_frame_done(Dav1dFrameContext *f, int retval);
+/* the first `rows` luma rows of the frame's picture are final (src/thread_task.c:888-896 for a backend that finishes frames itself) */
+void dav1d_hooked_rows_done(Dav1dFrameContext *f, unsigned rows);
 #endif

@@ -63,6 +63,10 @@ typedef struct HookedParams {
                                   dav1d_submit_frame, and the reference's own pass 1 (dav1d_msac_*, decode_b, decode_coefs, read_restoration_info,
                                   dav1d_create_lf_mask_*) on its worker threads.  mode 0 is then dav1d itself, no hook installed but an error
                                   recorder around the pass-1 tile call; mode 1 the glue of INTEGRATION.md behind dav1d's real pass 1 */
+    int row_progress;          /* mode 1: rows are published as the frame's last stage completes them (dav1d_hip_frame_set_progress_callback ->
+                                  dav1d_hooked_rows_done: the store of src/thread_task.c:888-896), not only when the frame has ended.  With
+                                  free_listing = 0 the tile tasks of the next frames then really wait in check_tile() for the rows of their
+                                  references (decode_b's lowest_pixel bookkeeping) and start while this frame's filters still run */
     int apply_grain;           /* stream mode: film grain on the output pictures — mode 0: Dav1dSettings.apply_grain (dav1d_apply_grain on the
                                   host); mode 1: apply_grain = 0 and the "application" applies it on the device (dav1d_hip_fg_apply on the picture
                                   dav1d returns, frame_hdr->film_grain.data), as GPU video outputs do */
@@ -112,6 +116,7 @@ typedef struct Hip {
     int (*picture_alloc)(Dav1dHipContext *, Dav1dHipPicture *, int, int, int, int);
     int (*picture_free)(Dav1dHipContext *, Dav1dHipPicture *);
     int (*plane_download)(Dav1dHipContext *, const Dav1dHipPicture *, int, void *, ptrdiff_t, int);
+    int (*frame_set_progress_callback)(Dav1dHipFrame *, void (*)(void *, int, const Dav1dHipPicture *), void *);
 } Hip;
 
 /* what the allocator hangs on a Dav1dPicture in mode 1 */
@@ -185,6 +190,7 @@ typedef struct Hooked {
     const size_t *tu_size;
     int n_tu;
     int n_errors;                         /* pictures dav1d reported an error for */
+    atomic_int n_row_publications;
     struct TileError { int tu; size_t off; int overread; } tile_err[64];
     int n_tile_err;
     uint64_t hist[HIST_N];
@@ -872,6 +878,14 @@ static int refs_final(const Dav1dFrameContext *const f) {
     return all;
 }
 
+/* INTEGRATION.md 2, progress: rows of the frame's picture have become final on the device */
+static void rows_final(void *const cookie, const int rows, const Dav1dHipPicture *const pic) {
+    (void) pic;
+    Dav1dFrameContext *const f = cookie;
+    g_h->n_row_publications++;
+    dav1d_hooked_rows_done(f, (unsigned) rows);
+}
+
 /* stage 2: INTEGRATION.md 2, "when the last task of the frame is in" */
 static int stage_end(Hooked *const h, Dav1dFrameContext *const f, Dav1dHipPicture *const filtered) {
     FcState *const s = state_of(f);
@@ -888,6 +902,7 @@ static int stage_end(Hooked *const h, Dav1dFrameContext *const f, Dav1dHipPictur
     if (!rc) rc = hip->frame_set_filters(s->frame, s->lvl, f->b4_stride, f->lf.lim_lut.e, f->lf.lim_lut.i,
                                          f->frame_hdr->cdef.damping + f->cur.p.bpc - 8, NULL, 0);
     memset(filtered, 0, sizeof(*filtered));
+    if (!rc && h->p.row_progress) rc = hip->frame_set_progress_callback(s->frame, rows_final, f);
     if (!rc) rc = hip->frame_end(s->frame, h->p.pack ? NULL : s->coef, s->prep, s->mask, filtered, NULL);
     if (!h->p.stream && f->frame_hdr->frame_offset < 64) h->frame_end_s[f->frame_hdr->frame_offset] = now_s() - t0;
     stat_add(h, 6, t0);
@@ -1153,7 +1168,7 @@ void *dav1d_hooked_open(const HookedParams *const p, const char *const hip_lib, 
     }
     SYM(frame_submit_intra_step, "dav1d_hip_frame_submit_intra_step"); SYM(frame_set_super_res, "dav1d_hip_frame_set_super_res");
     SYM(fg_apply, "dav1d_hip_fg_apply"); SYM(picture_alloc, "dav1d_hip_picture_alloc"); SYM(picture_free, "dav1d_hip_picture_free");
-    SYM(plane_download, "dav1d_hip_plane_download");
+    SYM(plane_download, "dav1d_hip_plane_download"); SYM(frame_set_progress_callback, "dav1d_hip_frame_set_progress_callback");
     pthread_mutex_init(&h->pic_mtx, NULL);
     if (p->mode == 1 && (h->hip.open(&h->ctx, p->device, NULL) || h->hip.open(&h->ctx_up, p->device, NULL) || h->hip.open(&h->ctx_out, p->device, NULL))) goto fail;
     Dav1dSettings s;
@@ -1190,6 +1205,7 @@ double dav1d_hooked_tail_seconds(void *const handle, const int from) {
     if (from < 0 || from >= h->p.n_frames - 1 || !h->q_done_t[from] || !h->q_done_t[h->p.n_frames - 1]) return 0.;
     return h->q_done_t[h->p.n_frames - 1] - h->q_done_t[from];
 }
+int dav1d_hooked_row_publications(void *const handle) { return handle ? atomic_load(&((Hooked *) handle)->n_row_publications) : 0; }
 int dav1d_hooked_n_fc(void *const handle) { return handle ? (int) ((Hooked *) handle)->n_fc : 0; }
 
 /* the whole chain: returns 0 and the wall-clock seconds from the first dav1d_submit_frame to the last picture out */

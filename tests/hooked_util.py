@@ -21,7 +21,7 @@ class HookedParams(C.Structure):
                 ("cdef_enabled", C.c_int), ("cdef_damping", C.c_int), ("cdef_n_bits", C.c_int), ("cdef_y_strength", C.c_int * 8),
                 ("cdef_uv_strength", C.c_int * 8), ("lr_type", C.c_int * 3), ("lr_unit_size", C.c_int * 2),
                 ("mode", C.c_int), ("free_listing", C.c_int), ("device", C.c_int), ("keep_output", C.c_int), ("inject", C.c_int), ("pack", C.c_int),
-                ("synth", synth_lib.SynthParams), ("stream", C.c_int), ("apply_grain", C.c_int)]
+                ("synth", synth_lib.SynthParams), ("stream", C.c_int), ("row_progress", C.c_int), ("apply_grain", C.c_int)]
 
 
 def lib():
@@ -37,6 +37,7 @@ def lib():
     l.dav1d_hooked_plane.restype = C.c_void_p
     l.dav1d_hooked_plane.argtypes = [C.c_void_p, C.c_int, C.c_int]
     l.dav1d_hooked_n_fc.argtypes = [C.c_void_p]
+    l.dav1d_hooked_row_publications.argtypes = [C.c_void_p]
     l.dav1d_hooked_tail_seconds.restype = C.c_double
     l.dav1d_hooked_tail_seconds.argtypes = [C.c_void_p, C.c_int]
     l.dav1d_hooked_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
@@ -49,7 +50,7 @@ FILTERS = dict(lf=(20, 28, 16, 24, 0), cdef=(5, 2, [17, 33, 0, 63], [5, 0, 20, 4
 
 
 def params(w, h, bpc, n_frames, mode, layout=1, sb128=True, tiles=(2, 1), threads=4, frame_delay=3, filters=FILTERS, seed=5, free_listing=1,
-           keep_output=True, synth=None, pack=True):
+           keep_output=True, synth=None, pack=True, row_progress=0):
     p = HookedParams()
     p.w, p.h, p.layout, p.bpc, p.sb128 = w, h, layout, bpc, int(sb128)
     sb = 128 if sb128 else 64
@@ -73,6 +74,7 @@ def params(w, h, bpc, n_frames, mode, layout=1, sb128=True, tiles=(2, 1), thread
             p.lr_type[i] = filters["lr"][0][i]
         p.lr_unit_size[0], p.lr_unit_size[1] = filters["lr"][1]
     p.mode, p.free_listing, p.device, p.keep_output = mode, free_listing, 0, int(keep_output)
+    p.row_progress = int(row_progress)
     p.pack = int(bool(pack) and mode == 1 and os.environ.get("DAV1D_HOOKED_PACK", "1") != "0")
     p.synth = synth if synth is not None else lu.default_synth(seed, n_refs=3, far_mv_pct=2)
     return p
@@ -104,6 +106,7 @@ def run(p, hip_lib_path, store=None, inject=0):
         rc = l.dav1d_hooked_run(h, C.byref(sec))
         assert rc == 0, "dav1d_hooked_run: %d" % rc
         n_fc = l.dav1d_hooked_n_fc(h)
+        run.last_row_publications = l.dav1d_hooked_row_publications(h)
         st = (C.c_double * 16)()
         l.dav1d_hooked_stats(h, st)
         run.last_stats = dict(zip(("picture_alloc", "after_init", "listing", "filter_listing", "gpu_thread_idle", "uploads", "frame_end", "fetch", "picture_release"),

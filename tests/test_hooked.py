@@ -23,6 +23,9 @@ CASES = [
     ("420_10_filters", 384, 256, 10, dict(tiles=(2, 1))),
     ("420_8_tiles_2x2_no_filters", 320, 200, 8, dict(tiles=(2, 2), filters=None)),
     ("444_12_sb64_dav1d_dependencies", 256, 136, 12, dict(layout=3, sb128=False, tiles=(1, 1), free_listing=0)),
+    # rows published band by band from inside the frame's last stage (dav1d_hip_frame_set_progress_callback -> the store of
+    # src/thread_task.c:888-896), and dav1d's own rule for when a tile task may start: check_tile() waits for the rows of the references
+    ("420_10_rows_published_per_band_dav1d_dependencies", 320, 1100, 10, dict(tiles=(1, 1), free_listing=0, row_progress=1)),
 ]
 
 
@@ -37,5 +40,7 @@ def test_chain_through_the_task_loop_equals_dav1d(ctx, name, w, h, bpc, kw):
         for pl in range(len(want[k])):
             bad = np.argwhere(want[k][pl] != got[k][pl])
             assert not len(bad), "frame %d plane %d differs at %s (%d pixels)" % (k, pl, bad[0], len(bad))
+    if kw.get("row_progress"):
+        assert hk.run.last_row_publications >= n_frames, hk.run.last_row_publications      # bands of 256 rows: several per frame
     # the chain is a chain: frames differ from each other, and an inter frame is not what the key frame was
     assert not np.array_equal(want[0][0], want[1][0]) and not np.array_equal(want[1][0], want[n_frames - 1][0])

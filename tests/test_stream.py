@@ -58,7 +58,7 @@ def run_seed(ctx, seed, n_frames=7, knobs=None, **dec):
     units = [u["data"] for u in sw.units]
     want = su.decode(units, 0, lib)
     assert not want["errors"] and len(want["pictures"]) >= n_frames - 2
-    got = su.decode(units, 1, lib, free_listing=seed & 1, pack=not seed & 16, **dec)
+    got = su.decode(units, 1, lib, free_listing=seed & 1, pack=not seed & 16, row_progress=(seed >> 5) & 1, **dec)
     diff = su.compare(want, got)
     assert diff is None, "seed %d (%s %d-bit %dx%d sb%d): %s" % (seed, LAYOUTS[layout], bpc, w, h, 128 if sb128 else 64, diff)
     TOTAL.update(got["hist"])
