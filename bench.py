@@ -68,6 +68,15 @@ def parse():
     ap.add_argument("--dependent", action="store_true",
                     help="with --config c4: reference 0 of a rank's frame is the picture rank - 1 produced one step earlier; every owner broadcasts "
                          "its finished picture to all ranks after its step (RCCL broadcast, the publication rule of src/thread_task.c:416-433)")
+    ap.add_argument("--mix", choices=["c2", "c1"], default="c2",
+                    help="block mix of the synthetic frame: c2 = SURVEY 8d's C2 mix (64/32/16/8/4 = 20/30/30/15/5 %% by area, 25 %% compound); "
+                         "c1 = SURVEY 8d's C1 spec (every block 16x16: TX_16X16 luma / TX_8X8 chroma, single reference)")
+    ap.add_argument("--emu", action="store_true",
+                    help="CPU run on the SIMT-emulated build of the same kernel sources (tests/emu), torch.distributed over gloo: what "
+                         "tests/test_dist.py uses to run `bench.py --gpus 2` without a GPU (tiny sizes; no timing means anything)")
+    ap.add_argument("--one-leg", action="store_true",
+                    help="N > 1: only the leg the other flags select (default: three legs in one line — frame-parallel replicas, tile columns "
+                         "with in-loop filters (C3), dependent frames with film grain (C4))")
     ap.add_argument("--tc-filters", action="store_true",
                     help="tile-cols only: the step also runs deblocking, CDEF and loop restoration of the rank's column after a halo "
                          "exchange of 16 luma columns with its neighbours (dav1d_amd/dist.py), and gathers the FILTERED columns")
@@ -249,27 +258,118 @@ def frames_in_flight(api, device, frame, itx_tasks, coef_host, intra, post, ref_
     return out
 
 
+class _NoEvent:
+    def __init__(self, enable_timing=False):
+        pass
+
+    def record(self, stream=None):
+        pass
+
+    def elapsed_time(self, other):
+        return 1e-3
+
+
+def _emu_torch(torch):
+    """--emu: the torch.cuda calls of this file become no-ops (the kernels run on the CPU inside the emulated library)"""
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.set_device = lambda *a, **k: None
+    torch.cuda.is_available = lambda: True
+    torch.cuda.Event = _NoEvent
+
+
+def respawn_under_launcher(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: the same command line once per GPU under torch.distributed.run
+    (one process per GPU, RCCL rendezvous on 127.0.0.1)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.execv(sys.executable, cmd)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_launcher(a)
     import torch
     import torch.distributed as dist
     from dav1d_amd import dist as dd
     rank, local, world = dd.env()
-    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d (or without a launcher: bench.py starts one)" % a.gpus
+    if a.emu:
+        _emu_torch(torch)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    from dav1d_amd import api, synth
+        if a.emu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    ranks_seen = 1
+    if world > 1:
+        t = torch.ones(1, dtype=torch.int32, device=DEV(a))
+        dist.all_reduce(t)                       # RCCL (gloo with --emu): how many ranks really take part
+        ranks_seen = int(t.item())
+    if world > 1 and not a.one_leg and a.shard == "frames" and a.config == "c2" and not a.step_only:
+        # ---- three legs in one line: replicas (the headline step on every GPU), C3, C4
+        import copy
+        primary = run_job(a, rank, local, world)
+        a3 = copy.copy(a)
+        a3.shard, a3.tc_filters, a3.no_cpu = "tile-cols", True, True
+        c3 = run_job(a3, rank, local, world)
+        a4 = copy.copy(a)
+        a4.config, a4.dependent, a4.no_cpu = "c4", True, True
+        c4 = run_job(a4, rank, local, world)
+        if rank == 0:
+            def digest(line):
+                return {"metric": line["metric"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"], "scaling": line["scaling"],
+                        "parallelism": line["config"].get("parallelism"), "parity": line["config"].get("parity"),
+                        "roofline_frac": (line.get("roofline") or {}).get("frac"), "n_ranks_seen": ranks_seen}
+            primary["legs"] = {"replicas": digest(primary), "c3_tile_columns_with_in_loop_filters": digest(c3), "c4_dependent_frames_full_table_film_grain": digest(c4)}
+            primary["n_ranks_seen"] = ranks_seen
+            print(json.dumps(primary))
+    else:
+        line = run_job(a, rank, local, world)
+        if rank == 0 and line is not None:
+            line["n_ranks_seen"] = ranks_seen
+            print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dd.close_peers()
+        dist.destroy_process_group()
 
-    stream = torch.cuda.current_stream()
-    ctx = api.Context(local, stream=stream.cuda_stream)
+
+def DEV(a):
+    return "cpu" if a.emu else "cuda"
+
+
+def run_job(a, rank, local, world):
+    """One measurement (the mode `a` selects) on the process group main() set up; returns the JSON line on rank 0, None elsewhere."""
+    import torch
+    from dav1d_amd import dist as dd
+    from dav1d_amd import api, synth
+    dev = DEV(a)
+
+    if a.emu:
+        a.no_full = a.no_e2e = a.no_c1 = a.no_inflight = True         # (legs that time GPU streams)
+        import util
+        ctx = util.make_context("emu")
+        stream = None
+    else:
+        stream = torch.cuda.current_stream()
+        ctx = api.Context(local, stream=stream.cuda_stream)
     w, h, bpc = a.width, a.height, a.bpc
     t_gen = time.time()
     tile_cols = a.shard == "tile-cols"
-    srank = 0 if tile_cols else rank          # tile-column mode: every rank holds the same frame
-    frame = synth.make_frame(w, h, bpc, seed=0xDA71D002 + srank, mv_range_px=a.mv_range, edge_frac=a.edge_frac,
+    # tile-column mode: every rank holds the same frame; dependent C4 frames likewise (rank 0 replays the whole chain on the oracle, and
+    # the chain still tells a stale broadcast from a fresh one: every step's picture differs from the one before)
+    srank = 0 if tile_cols or (a.config == "c4" and a.dependent) else rank
+    mix_kw = dict(mix=(0.0, 0.0, 1.0, 0.0, 0.0), compound_frac=0.0) if a.mix == "c1" else {}
+    frame = synth.make_frame(w, h, bpc, seed=0xDA71D002 + srank, mv_range_px=a.mv_range, edge_frac=a.edge_frac, **mix_kw,
                              n_refs=int(os.environ.get("BENCH_N_REFS", "3")))
     rng = np.random.default_rng(1234 + srank)
     ref_host = [synth.make_planes(rng, w, h, bpc) for _ in range(frame.n_refs)]
@@ -279,7 +379,6 @@ def main():
     if a.config == "c4":
         # BASELINE configs[4]: frames in flight one per GPU, full table + film grain (+ dependent frames): its own short path
         post = synth.make_post_filters(frame, seed=0xF11 + srank)
-        dev = "cuda"
         wl = dd.C4Workload(ctx, frame, post, ref_host, dst_host, rank, world, dev, a.dependent)
         tdt = torch.int16 if bpc == 8 else torch.int32
         pristine = torch.from_numpy(frame.coef).to(dev)
@@ -291,6 +390,29 @@ def main():
         for i in range(a.warmup):
             wl.step(arenas[i].data_ptr())
         torch.cuda.synchronize()
+        parity = "skipped"
+        if rank == 0 and not a.no_check and a.dependent and a.warmup:
+            # the chain so far (every rank runs the same frame, reference 0 = what rank - 1 restored one step earlier) against the
+            # oracle's replay of the same number of steps
+            import util
+            import test_frame
+            import test_postchain
+            oracle = util.default_oracle()
+            prev = None
+            for sidx in range(a.warmup):
+                rl = list(ref_host)
+                if sidx:
+                    rl[0] = prev
+                rec, _, _ = test_frame.oracle_frame(oracle, frame, dst_host, rl, threads=min(64, os.cpu_count() or 1))
+                _, _, want_res, want_grn = test_postchain.oracle_post(oracle, post, rec, w, h, bpc)
+                prev = want_res
+            got_res, got_grn = wl.outputs()
+            for pl in range(3):
+                vh, vw = (h, w) if pl == 0 else (h // 2, w // 2)
+                if not np.array_equal(got_res[pl][:vh, :vw], want_res[pl][:vh, :vw]) or not np.array_equal(got_grn[pl][:vh, :vw], want_grn[pl][:vh, :vw]):
+                    raise SystemExit("bench --config c4 --dependent: plane %d differs from the oracle's chain after %d steps" % (pl, a.warmup))
+            parity = ("bit-exact vs %s oracle: restoration and film grain output of rank 0 after a chain of %d dependent steps (reference 0 of every step = "
+                      "the picture rank - 1 broadcast one step earlier)" % (oracle.which, a.warmup))
         dd.barrier(world)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -298,8 +420,7 @@ def main():
             wl.step(arenas[i].data_ptr())
         torch.cuda.synchronize()
         dd.barrier(world)
-        dt = dd.max_over_ranks(time.perf_counter() - t0, world, device="cuda")
-        parity = "skipped"
+        dt = dd.max_over_ranks(time.perf_counter() - t0, world, device=dev)
         if rank == 0 and not a.no_check and not a.dependent:
             # this rank's last frame against the oracle's replay of the same lists (independent frames: every step gives the same picture)
             import util
@@ -314,11 +435,12 @@ def main():
                 if not np.array_equal(got_res[pl][:vh, :vw], want_res[pl][:vh, :vw]) or not np.array_equal(got_grn[pl][:vh, :vw], want_grn[pl][:vh, :vw]):
                     raise SystemExit("bench --config c4: plane %d differs from the oracle" % pl)
             parity = "bit-exact vs %s oracle (restoration output and film grain output of rank 0's last frame)" % oracle.which
+        line = None
         if rank == 0:
             P, Cb = (1, 2) if bpc == 8 else (2, 4)
             full_bytes = algorithmic_bytes(frame) + 8 * P * frame.n_samples        # + deblock, CDEF, restoration, grain: 2 P each
             ms = dt / a.steps * 1e3
-            print(json.dumps({
+            line = ({
                 "metric": "reconstructed luma Mpixels/s (%dx%d 4:2:0 %d-bit), full DSP table + film grain, one frame per GPU per step" % (w, h, bpc),
                 "value": round(dd.job_throughput(frame.luma_pixels, a.steps, dt, world) / 1e6, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps,
                 "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -330,11 +452,9 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": round(full_bytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(full_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                              "what": "whole step on algorithmic bytes (28 B per coded inter sample at 10 bits), wall clock incl. the host side of the batch calls"},
-                "cpu_baseline": None}))
+                "cpu_baseline": None})
         dd.barrier(world)
-        if world > 1:
-            dist.destroy_process_group()
-        return
+        return line
 
     # ---- device-resident state
     refs = []
@@ -348,7 +468,7 @@ def main():
     cols = dd.tile_columns(w, world) if tile_cols else None
     for _ in range(NDST):
         # tile-column mode: torch owns the picture memory so that RCCL can move the column strips
-        d = dd.SharedPicture(ctx, w, h, api.LAYOUT_I420, bpc, "cuda") if tile_cols else ctx.picture(w, h, api.LAYOUT_I420, bpc)
+        d = dd.SharedPicture(ctx, w, h, api.LAYOUT_I420, bpc, dev) if tile_cols else ctx.picture(w, h, api.LAYOUT_I420, bpc)
         for pl in range(3):
             d.upload(pl, dst_host[pl])
         dsts.append(d)
@@ -362,20 +482,20 @@ def main():
     itx_tasks, coef_host = synth.pack_frame_coefs(frame) if a.packed else (frame.itx, frame.coef)
     inter_list, itx_list = ctx.inter_list(frame.mc, frame.comp), ctx.itx_list(itx_tasks)      # also used by the per-kernel timing below
     recon_list = None if a.two_phase else ctx.recon_list(dsts[0], frame.mc, frame.comp, itx_tasks)
-    prep = torch.zeros(frame.prep_elems, dtype=torch.int16, device="cuda")
+    prep = torch.zeros(frame.prep_elems, dtype=torch.int16, device=dev)
     tdt = torch.int16 if bpc == 8 else torch.int32
-    pristine = torch.from_numpy(coef_host).to("cuda")
+    pristine = torch.from_numpy(coef_host).to(dev)
     n_arena = a.steps + a.warmup + 8
     if a.packed:        # a packed arena is read-only: every step reads the same one
         arenas = [pristine] * n_arena
     else:
-        arenas = torch.empty((n_arena, pristine.numel()), dtype=tdt, device="cuda")
+        arenas = torch.empty((n_arena, pristine.numel()), dtype=tdt, device=dev)
         for i in range(n_arena):
             arenas[i].copy_(pristine)
     torch.cuda.synchronize()
     # what the boundary costs when the residuals arrive from the host every frame (reported next to `value`, never in it)
     h2d_ms = None
-    if rank == 0:
+    if rank == 0 and not a.emu:
         pinned = torch.from_numpy(coef_host).pin_memory()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         best = 1e9
@@ -395,7 +515,7 @@ def main():
         lf_c, cdef_c, lr_c = dd.post_tasks_of_column(post_all.lf, post_all.cdef, post_all.lr,
                                                      [dsts[0].view.stride_px(pl) for pl in range(3)], cols[rank])
         tc_post = {"all": post_all, "lf": lf_c, "cdef": cdef_c, "lr": lr_c, "lvl": ctx.buffer_from(post_all.lvl),
-                   "cdf": dd.SharedPicture(ctx, w, h, api.LAYOUT_I420, bpc, "cuda"), "res": dd.SharedPicture(ctx, w, h, api.LAYOUT_I420, bpc, "cuda")}
+                   "cdf": dd.SharedPicture(ctx, w, h, api.LAYOUT_I420, bpc, dev), "res": dd.SharedPicture(ctx, w, h, api.LAYOUT_I420, bpc, dev)}
     final_pic = {}
 
     def step(i):
@@ -437,7 +557,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    dt = dd.max_over_ranks(dt, world, device="cuda")
+    dt = dd.max_over_ranks(dt, world, device=dev)
 
     ms_per_step = dt / a.steps * 1e3
     # whole-job luma Mpixels/s: N frames per step (one per GPU) when sharded by frame, ONE frame per step over tile columns
@@ -446,18 +566,13 @@ def main():
     # ---- the same step fed with the sparse coefficient format (DAV1D_HIP_ITX_PACKED): reported next to `value`, which keeps
     # the dense reference layout SURVEY 8d prices; rank 0 of a one-GPU run only, and checked against the same oracle pictures
     if a.step_only:
-        if rank == 0:
-            print(json.dumps({"step_only": True, "ms_per_step": round(ms_per_step, 4), "value": round(value, 1), "steps": a.steps,
-                              "warmup": a.warmup}))
         barrier()
-        if world > 1:
-            dist.destroy_process_group()
-        return
+        return {"step_only": True, "ms_per_step": round(ms_per_step, 4), "value": round(value, 1), "steps": a.steps, "warmup": a.warmup} if rank == 0 else None
     packed_leg = None
     if rank == 0 and world == 1 and not a.packed and not a.two_phase:
         p_tasks, p_coef = synth.pack_frame_coefs(frame)
         p_list = ctx.recon_list(dsts[0], frame.mc, frame.comp, p_tasks)
-        p_arena = torch.from_numpy(p_coef).to("cuda")
+        p_arena = torch.from_numpy(p_coef).to(dev)
         for i in range(a.warmup):
             p_list.run(dsts[i % NDST], refs, prep.data_ptr(), p_arena.data_ptr())
         torch.cuda.synchronize()
@@ -554,6 +669,9 @@ def main():
             kernels = step_kernels
         kernels.sort(key=lambda k: -k[1])
         dom = kernels[0]
+        if a.emu:
+            kernels = [(k[0], max(k[1], 1e-6), k[2]) for k in kernels]       # the emulated events measure nothing
+            dom = kernels[0]
         ach = dom[2] / (dom[1] * 1e-3) / 1e9
         path_bytes = algorithmic_bytes(frame)
         roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -585,6 +703,17 @@ def main():
             roof["frac_incl_halo"] = round(roof["window_bytes_per_launch"] / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if roof["traffic"]:
             roof["frac_measured_traffic"] = round(roof["traffic"] / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        # scalars next to the nested objects (a reader that keeps only flat values still sees the whole path and the 4x4 class)
+        roof["path_frac"] = roof["path"]["frac"]
+        roof["path_achieved"] = roof["path"]["achieved"]
+        roof["path_ms"] = round(ms_per_step, 4)
+        k44 = [k for k in kernels if k[0] in ("mc_4x4", "itx_4x4", "recon_4x4")]
+        if k44:
+            roof["class_4x4_frac"] = round(sum(k[2] for k in k44) / (sum(k[1] for k in k44) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            roof["class_4x4_ms"] = round(sum(k[1] for k in k44), 4)
+        # where `traffic` comes from: PMC counters cannot be read from inside a run (rocprofv3 wraps the process), so the figure is the
+        # committed pass of tools/pmc_profile.sh over this very command — the profile's own directory says which box and build it saw
+        roof["traffic_source"] = "profiles/*/traffic.json (rocprofv3 --pmc FETCH_SIZE WRITE_SIZE over `bench.py --step-only`, FETCH_SIZE x 2 as calibrated in profiles/r02_calib_fetch_size.txt); not counted in this run"
 
         # ---- parity gate + CPU baseline: the oracle replays the SAME lists on the host
         cpu = None
@@ -988,14 +1117,25 @@ def main():
                 raise SystemExit("bench: the dav1d task loop leg behind dav1d's real pass 1 differs from dav1d: %s" % e)
             except Exception as e:       # noqa: BLE001  (a reported extra)
                 task_loop_stream = {"error": str(e)[:200]}
+        if full is not None and isinstance(full, dict):
+            for kk in ("ms_per_frame", "frac", "achieved"):
+                if kk in full:
+                    roof["full_table_" + kk] = full[kk]
+        if cpu is not None:
+            if isinstance(cpu.get("all_cores"), dict):
+                cpu["all_cores_value"], cpu["all_cores_cores"] = cpu["all_cores"].get("value"), cpu["all_cores"].get("cores")
+            if isinstance(cpu.get("reference_pass2"), dict) and "value" in cpu["reference_pass2"]:
+                cpu["reference_pass2_value"], cpu["reference_pass2_cores"] = cpu["reference_pass2"]["value"], cpu["reference_pass2"]["cores"]
         label = "8K" if (w, h) == (7680, 4320) else "4K" if (w, h) == (3840, 2160) else "%dx%d" % (w, h)
         out = {"metric": "reconstructed luma Mpixels/s (%s 4:2:0 %d-bit) on the itx+mc recon path; bit-exact vs C" % (label, bpc),
                "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if tile_cols else "weak", "vs_baseline": None,
                "dtype": "int32" if bpc > 8 else "int16", "data": "synthetic",
-               "config": {"workload": "%dx%d 4:2:0 %d-bit inter frame, itx+mc recon (SURVEY §8d C2 mix 64/32/16/8/4 = "
-                                      "20/30/30/15/5 %% by area, 25 %% compound avg, all blocks coded, 3 refs); "
-                                      "lists resident in HBM" % (w, h, bpc),
+               "config": {"workload": ("%dx%d 4:2:0 %d-bit inter frame, itx+mc recon (SURVEY §8d C1 spec: every block 16x16, TX_16X16 luma / TX_8X8 "
+                                       "chroma, single reference, all blocks coded, 3 refs); lists resident in HBM" if a.mix == "c1" else
+                                       "%dx%d 4:2:0 %d-bit inter frame, itx+mc recon (SURVEY §8d C2 mix 64/32/16/8/4 = "
+                                       "20/30/30/15/5 %% by area, 25 %% compound avg, all blocks coded, 3 refs); "
+                                       "lists resident in HBM") % (w, h, bpc),
                           "step": ("inter list, then itx list" if a.two_phase else
                                    "recon list: residual launches wait only for the prediction launches under their blocks (2 streams)"),
                           "frames_per_step": 1, "parallelism": (("tile-columns x%d, in-loop filters per column after a 16-column halo exchange, one all-gather of the filtered columns per frame"
@@ -1011,16 +1151,17 @@ def main():
         # its digest under "config_c1_4k_8bit"
         if world == 1 and not a.no_c1 and not a.step_only and (w, h, bpc) == (7680, 4320, 10):
             import subprocess
-            try:
-                child = subprocess.run([sys.executable, os.path.abspath(__file__), "--width", "3840", "--height", "2160", "--bpc", "8", "--no-c1",
-                                        "--no-full", "--no-e2e", "--no-cpu", "--steps", str(a.steps), "--warmup", str(a.warmup)],
-                                       capture_output=True, text=True, timeout=600)
-                cj = json.loads(child.stdout.strip().splitlines()[-1])
-                out["config_c1_4k_8bit"] = {"metric": cj["metric"], "value": cj["value"], "unit": cj["unit"], "ms_per_step": cj["ms_per_step"],
-                                            "dtype": cj["dtype"], "roofline": {k: cj["roofline"].get(k) for k in ("kernel", "frac", "path")},
-                                            "parity": cj["config"]["parity"], "workload": cj["config"]["workload"]}
-            except Exception as e:
-                out["config_c1_4k_8bit"] = {"error": str(e)[:200]}
+            for key, mix in (("config_c1_4k_8bit", "c1"), ("config_c1_4k_8bit_c2_mix", "c2")):
+                try:
+                    child = subprocess.run([sys.executable, os.path.abspath(__file__), "--width", "3840", "--height", "2160", "--bpc", "8", "--no-c1", "--mix", mix,
+                                            "--no-full", "--no-e2e", "--no-cpu", "--steps", str(a.steps), "--warmup", str(a.warmup)],
+                                           capture_output=True, text=True, timeout=600)
+                    cj = json.loads(child.stdout.strip().splitlines()[-1])
+                    out[key] = {"metric": cj["metric"], "value": cj["value"], "unit": cj["unit"], "ms_per_step": cj["ms_per_step"],
+                                "dtype": cj["dtype"], "roofline": {k: cj["roofline"].get(k) for k in ("kernel", "frac", "path")},
+                                "parity": cj["config"]["parity"], "workload": cj["config"]["workload"]}
+                except Exception as e:
+                    out[key] = {"error": str(e)[:200]}
         # $DAV1D_STREAMS: real AV1 streams on the GPU box.  Decoding one needs dav1d's pass 1 (OBU parsing + entropy
         # decoding), which stays in dav1d by design and is not built here; the hook reports what it found
         sdir = os.environ.get("DAV1D_STREAMS")
@@ -1037,10 +1178,8 @@ def main():
             packed_leg.pop("_pictures", None)
             packed_leg.setdefault("parity", "skipped")
             out["packed_coefficients"] = packed_leg
-        print(json.dumps(out))
     barrier()
-    if world > 1:
-        dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

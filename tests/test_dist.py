@@ -407,3 +407,28 @@ def test_tile_column_split_covers_every_task_once():
             x = (t["dst_off"].astype(np.int64) % np.asarray(stride_px)[t["plane"]]) << (t["plane"] > 0)
             assert ((x >= cols[c][0]) & (x < cols[c][1])).all()
     assert dd.uniform_tile_columns(7680, 8) == [(k * 1024, min((k + 1) * 1024, 7680)) for k in range(8)]   # 8,8,...,4 sb128
+
+
+def test_bench_py_starts_its_own_launcher_and_reports_three_legs_world2_gloo():
+    """`python bench.py --gpus 2` with NO launcher around it (it died on an assert): bench.py re-executes itself under
+    torch.distributed.run, one process per rank, and the N > 1 line carries three legs — frame-parallel replicas, tile columns with
+    in-loop filters (C3: halo exchange + all-gather through dav1d_hip_peer_*), dependent frames with the full table and film grain
+    (C4: picture broadcasts) — each with its own parity string against the oracle and the number of ranks the collective saw.
+    --emu: the same code on the SIMT-emulated kernels over gloo (tiny frame; the timings mean nothing)."""
+    import json
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--emu", "--width", "256", "--height", "128",
+                        "--steps", "2", "--warmup", "2", "--cpu-seconds", "0.1"], capture_output=True, text=True, env=env, timeout=1500, cwd="/tmp")
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["scaling"] == "weak"
+    legs = d["legs"]
+    assert set(legs) == {"replicas", "c3_tile_columns_with_in_loop_filters", "c4_dependent_frames_full_table_film_grain"}
+    for name, leg in legs.items():
+        assert leg["parity"].startswith("bit-exact"), (name, leg["parity"])
+        assert leg["n_ranks_seen"] == 2 and leg["value"] >= 0
+    assert legs["c3_tile_columns_with_in_loop_filters"]["scaling"] == "strong"
