@@ -532,13 +532,18 @@ def run_job(a, rank, local, world):
             for pl in range(3):
                 cdf.planes[pl].copy_(d.planes[pl])
             ctx.cdef_batch(cdf.view, d.view, tc_post["cdef"], pa.cdef_damping)
+            dd.wait_gathers(res, rank, world)                 # (one restoration picture: the gather of the frame before has to be through;
+                                                              #  it ran next to this frame's reconstruction, deblocking and CDEF)
             for pl in range(3):
                 res.planes[pl].copy_(cdf.planes[pl])
             ctx.lr_batch(res.view, cdf.view, d.view, tc_post["lr"])
-            dd.allgather_tile_columns(res, cols, rank, world)
+            dd.allgather_tile_columns(res, cols, rank, world, overlap=True)
             final_pic[0] = res
         elif tile_cols:
-            dd.allgather_tile_columns(d, cols, rank, world)
+            # on the peer's side stream: the next frame's reconstruction (other pictures) is enqueued before this gather completes; the
+            # context's stream only waits for the gather of the picture it is about to overwrite (NDST frames back)
+            dd.wait_gathers(d, rank, world, lag=NDST - 2)
+            dd.allgather_tile_columns(d, cols, rank, world, overlap=True)
 
     # ---- parity gate on this very workload: frame `warmup-0` output vs the oracle replay (bounded: luma rows)
     check = "skipped"

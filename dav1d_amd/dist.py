@@ -180,7 +180,17 @@ def _ctx_of(pic):
     return pic.view.ctx if hasattr(pic, "view") else pic.ctx
 
 
-def allgather_tile_columns(pic, cols, rank, world, ss_hor=1):
+def wait_gathers(pic, rank, world, lag=0):
+    """dav1d_hip_peer_wait: the context's stream waits for the overlapped gathers issued so far (all but the `lag` most recent)"""
+    if world == 1:
+        return
+    ctx = _ctx_of(pic)
+    rc = ctx.lib.dav1d_hip_peer_wait(peer_of(ctx, rank, world), lag)
+    if rc:
+        raise RuntimeError("dav1d_hip_peer_wait: %d" % rc)
+
+
+def allgather_tile_columns(pic, cols, rank, world, ss_hor=1, overlap=False):
     """After rank g reconstructed column g of `pic`: ONE all-gather per frame (all planes of a strip packed into one message by a
     strided copy kernel, strips padded to the widest column — SURVEY 8e) and every rank holds the whole picture
     (dav1d_hip_peer_allgather_columns)."""
@@ -191,7 +201,10 @@ def allgather_tile_columns(pic, cols, rank, world, ss_hor=1):
     ctx = _ctx_of(pic)
     x0 = (C.c_int * world)(*[c[0] for c in cols])
     x1 = (C.c_int * world)(*[c[1] for c in cols])
-    rc = ctx.lib.dav1d_hip_peer_allgather_columns(peer_of(ctx, rank, world), C.byref(_pic_of(pic)), x0, x1)
+    # overlap: on the peer's side stream, next to what is enqueued afterwards (the next frame's reconstruction); wait_gathers() before
+    # anything reads the gathered picture
+    fn = ctx.lib.dav1d_hip_peer_allgather_columns_async if overlap else ctx.lib.dav1d_hip_peer_allgather_columns
+    rc = fn(peer_of(ctx, rank, world), C.byref(_pic_of(pic)), x0, x1)
     if rc:
         raise RuntimeError("dav1d_hip_peer_allgather_columns: %d" % rc)
 
@@ -212,8 +225,8 @@ HALO = 16
 
 def exchange_halo(pic, cols, rank, world, ss_hor=1, halo=HALO):
     """After rank g reconstructed column g of `pic`: its neighbours' outermost `halo` luma columns (all planes) arrive next to it
-    (dav1d_hip_peer_exchange_halo: both edge strips of a rank in one message, one small all-gather; 2 x 16 columns of an 8K frame are
-    0.4 MB per rank)."""
+    (dav1d_hip_peer_exchange_halo: neighbour to neighbour, an ncclSend / ncclRecv pair per side inside one group; 16 columns of an 8K
+    frame are 0.2 MB per side)."""
     import ctypes as C
     if world == 1:
         return

@@ -961,8 +961,15 @@ DAV1D_HIP_API int dav1d_hip_peer_broadcast_picture(Dav1dHipPeer *p, Dav1dHipPict
  * strided pack kernel, ONE ncclAllGather of the strips (padded to the widest), scatter kernels straight into the planes. */
 DAV1D_HIP_API int dav1d_hip_peer_allgather_columns(Dav1dHipPeer *p, Dav1dHipPicture *pic, const int *x0, const int *x1);
 /* the `halo` luma columns on either side of this rank's column from the neighbours that reconstructed them (in-loop filters across
- * the tile edge; 16 covers deblocking + CDEF + restoration) */
+ * the tile edge; 16 covers deblocking + CDEF + restoration): neighbour to neighbour, an ncclSend / ncclRecv pair per side in one group */
 DAV1D_HIP_API int dav1d_hip_peer_exchange_halo(Dav1dHipPeer *p, Dav1dHipPicture *pic, const int *x0, const int *x1, int halo);
+/* dav1d_hip_peer_allgather_columns on the peer's side stream: it starts when what the context's stream holds so far is through (the frame
+ * that wrote the columns) and runs next to what the caller enqueues afterwards — the next frame's reconstruction, which predicts from
+ * other pictures.  dav1d_hip_peer_wait(p, lag): the context's stream waits for the asynchronous gathers issued so far but the `lag` (0 .. 7) most
+ * recent ones — 0 before the first launch that reads `pic`; k for a caller that recycles a picture k + 1 frames later.
+ * Column checks of all three calls (-EINVAL): even, one after the other, inside the plane, at least `halo` wide. */
+DAV1D_HIP_API int dav1d_hip_peer_allgather_columns_async(Dav1dHipPeer *p, Dav1dHipPicture *pic, const int *x0, const int *x1);
+DAV1D_HIP_API int dav1d_hip_peer_wait(Dav1dHipPeer *p, int lag);
 
 /* ------------------------------------------------- reference-signature table */
 

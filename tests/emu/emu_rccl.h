@@ -85,3 +85,37 @@ static inline ncclResult_t ncclBroadcast(const void *send, void *recv, size_t co
     }
     return ncclSuccess;
 }
+// Point-to-point inside a group (the halo exchange): sends are parked until ncclGroupEnd, which every rank of the communicator
+// enters (the callers here do: a rank without a neighbour on one side simply has fewer operations): each rank writes its messages
+// into its own slot, one segment per destination, all meet, each reads the segments addressed to it, all meet again.
+struct EmuP2P { int peer; void *ptr; size_t n; bool send; };
+static thread_local EmuP2P emu_p2p[16];
+static thread_local int emu_p2p_n;
+static thread_local ncclComm_t emu_p2p_comm;
+static inline ncclResult_t ncclGroupStart(void) { emu_p2p_n = 0; emu_p2p_comm = nullptr; return ncclSuccess; }
+static inline ncclResult_t ncclSend(const void *buf, size_t count, ncclDataType_t, int peer, ncclComm_t c, void *) {
+    if (emu_p2p_n >= 16) return ncclSystemError;
+    emu_p2p[emu_p2p_n++] = EmuP2P{ peer, const_cast<void *>(buf), count, true };
+    emu_p2p_comm = c;
+    return ncclSuccess;
+}
+static inline ncclResult_t ncclRecv(void *buf, size_t count, ncclDataType_t, int peer, ncclComm_t c, void *) {
+    if (emu_p2p_n >= 16) return ncclSystemError;
+    emu_p2p[emu_p2p_n++] = EmuP2P{ peer, buf, count, false };
+    emu_p2p_comm = c;
+    return ncclSuccess;
+}
+static inline ncclResult_t emu_nccl_group_end(ncclComm_t c) {
+    const size_t seg = c->slot_bytes / 8;
+    for (int i = 0; i < emu_p2p_n; i++)
+        if (emu_p2p[i].send) {
+            if (emu_p2p[i].n > seg) return ncclSystemError;
+            memcpy(c->slots + (size_t) c->rank * c->slot_bytes + (size_t) emu_p2p[i].peer * seg, emu_p2p[i].ptr, emu_p2p[i].n);
+        }
+    emu_nccl_post(c, nullptr, 0);
+    for (int i = 0; i < emu_p2p_n; i++)
+        if (!emu_p2p[i].send) memcpy(emu_p2p[i].ptr, c->slots + (size_t) emu_p2p[i].peer * c->slot_bytes + (size_t) c->rank * seg, emu_p2p[i].n);
+    emu_nccl_leave(c);
+    emu_p2p_n = 0;
+    return ncclSuccess;
+}

@@ -432,3 +432,29 @@ def test_bench_py_starts_its_own_launcher_and_reports_three_legs_world2_gloo():
         assert leg["parity"].startswith("bit-exact"), (name, leg["parity"])
         assert leg["n_ranks_seen"] == 2 and leg["value"] >= 0
     assert legs["c3_tile_columns_with_in_loop_filters"]["scaling"] == "strong"
+
+
+def test_peer_calls_check_their_columns():
+    """a column narrower than the halo, odd or overlapping columns, columns outside the plane are refused with -EINVAL
+    (they made the strip kernels read or write out of bounds) — on one emulated rank, before anything is exchanged."""
+    import ctypes as C
+    from dav1d_amd import api
+    ctx = util.make_context("emu")
+    try:
+        ident = (C.c_uint8 * 128)()
+        assert ctx.lib.dav1d_hip_peer_unique_id(ident) == 0
+        h = C.c_void_p()
+        assert ctx.lib.dav1d_hip_peer_open(ctx.h, C.byref(h), ident, 0, 1) == 0
+        pic = ctx.picture(256, 128, api.LAYOUT_I420, 10)
+
+        def cols(a, b):
+            return (C.c_int * 1)(a), (C.c_int * 1)(b)
+        for a, b, halo, want in ((0, 256, 16, 0), (0, 8, 16, -22), (1, 255, 16, -22), (-16, 128, 16, -22), (0, 512, 16, -22), (128, 64, 16, -22)):
+            x0, x1 = cols(a, b)
+            assert ctx.lib.dav1d_hip_peer_exchange_halo(h, C.byref(pic.pic), x0, x1, halo) == want, (a, b)
+            assert ctx.lib.dav1d_hip_peer_allgather_columns(h, C.byref(pic.pic), x0, x1) == (0 if (a, b) == (0, 8) else want), (a, b)
+        assert ctx.lib.dav1d_hip_peer_wait(h, 0) == 0 and ctx.lib.dav1d_hip_peer_wait(h, 9) == -22
+        ctx.lib.dav1d_hip_peer_close(h)
+        pic.free()
+    finally:
+        ctx.close()
