@@ -282,6 +282,7 @@ struct SbTiling {                                   // the frame's tiles in supe
     int sb_log2, sbw, sbh, n_cols, n_rows;
     uint16_t col_start[65], row_start[65];
 };
+void dav1d_hip_sbw_set_fine(int on);
 int dav1d_hip_sb_tiling_make(SbTiling *tl, int w, int h, int sb128, int n_cols, const uint16_t *col_start_sb, int n_rows, const uint16_t *row_start_sb);
 enum : uint32_t { SB_NONE = 0xffffffffu };
 struct SbSort {

@@ -179,6 +179,7 @@ int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value) {
     else if (!strcmp(name, "intra_sb_waves")) c->intra_sb_waves = value >= 8 ? 8 : value >= 4 ? 4 : 0;
     else if (!strcmp(name, "intra_sb_lds")) c->intra_sb_lds = value != 0;
     else if (!strcmp(name, "intra_sb_flow")) c->intra_sb_flow = value != 0;
+    else if (!strcmp(name, "intra_sb_fine")) dav1d_hip_sbw_set_fine(value != 0);
     else if (!strcmp(name, "chunk_order")) c->chunk_order = value != 0;
     else if (!strcmp(name, "chunk_arena_min")) { if (value < 4096) return -EINVAL; c->arena_min = (size_t) 1 << 12; while (c->arena_min < (size_t) value) c->arena_min <<= 1; c->arena_hint = 0; }
     else return -EINVAL;

@@ -1006,9 +1006,19 @@ int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *ma
 
 } // extern "C"
 
+// DAV1D_HIP_TRACE_FRAME=1: where a frame's time on the ending thread goes (host wall clock incl. the waits it makes), one line per frame
+struct FrameTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    double ms[8];
+    FrameTrace() : on(getenv("DAV1D_HIP_TRACE_FRAME") != nullptr), t(std::chrono::steady_clock::now()) { for (double &v : ms) v = 0; }
+    void mark(int k) { if (!on) return; const auto n = std::chrono::steady_clock::now(); ms[k] += std::chrono::duration<double, std::milli>(n - t).count(); t = n; }
+};
+
 static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask, Dav1dHipPicture *filtered, const Dav1dHipPicture *grain_out) {
     Dav1dHipContext *c = f->c;
     int rc = 0;
+    FrameTrace tr;
     // the raster planes of every picture this frame writes change below: whatever tiled twin a recycled picture still carries is
     // stale from here on (*filtered is a copy of one of these descriptors, so it reports twin_ok = 0 unless the frame retiles it)
     f->cur.twin_ok = 0;
@@ -1026,11 +1036,13 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
         if (rc) return rc;
         coef = f->carena;
     }
+    tr.mark(0);
     if (c->post_bands >= 2) frame_merge_filter_pieces(f);          // the banded route works on the merged lists
     // warped / scaled predictions first: the compound combinations of the list below read their PREP outputs
     if (!f->warp.empty()) rc = dav1d_hip_warp_batch(c, &f->cur, f->refs, f->n_refs, f->warp.data(), f->warp.size(), prep);
     if (!rc && !f->scaled.empty()) rc = dav1d_hip_mc_scaled_batch(c, &f->cur, f->refs, f->n_refs, f->scaled.data(), f->scaled.size(), prep);
     if (rc) return rc;
+    tr.mark(1);
     if (!f->chunks.empty()) {
         // predictions and residuals as one pipelined list (the residual launch of a transform size waits only for the
         // prediction launches under its blocks), assembled from the chunks the submitting threads prepared: one upload per
@@ -1057,6 +1069,7 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
             }
         }
     }
+    tr.mark(2);
     // intra blocks, wavefront step by step (each step: a paired launch for the small blocks, a prediction and a residual
     // launch for the others), enqueued back to back.  A frame may hold step copies (intra block copies) without any intra-step
     // submission (direct callers of the C API): they run all the same.
@@ -1260,6 +1273,7 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
             if (xl) dav1d_hip_intra_list_destroy(c, xl);
         }
     }
+    tr.mark(3);
     const Dav1dHipPicture *last = &f->cur;
     int piped = 1;
     f->post_bands = 0;
@@ -1336,9 +1350,13 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
     if (!rc && f->have_grain && grain_out)
         rc = f->prepared ? dav1d_hip_fg_apply_prepared(c, grain_out, last, f->prepared, f->is_id)
                          : dav1d_hip_fg_apply(c, grain_out, last, &f->grain, f->is_id);
+    tr.mark(4);
     if (!rc) rc = dav1d_hip_sync(c);
     else (void) dav1d_hip_sync(c);
+    tr.mark(5);
     if (!rc) f->publish(f->cur.p[0].h, last);
+    if (tr.on) fprintf(stderr, "frame_run %dx%d: coefs/flush %.2f  warp+scaled %.2f  chunks->lists+recon %.2f  intra %.2f  post filters %.2f  final sync %.2f ms  (chunks %zu, step chunks %zu, warp %zu, scaled %zu)\n",
+                       f->cur.p[0].w, f->cur.p[0].h, tr.ms[0], tr.ms[1], tr.ms[2], tr.ms[3], tr.ms[4], tr.ms[5], f->chunks.size(), f->step_chunks.size(), f->warp.size(), f->scaled.size());
     return rc;
 }
 

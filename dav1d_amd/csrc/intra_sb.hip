@@ -23,6 +23,7 @@
 #include "capi.h"
 #include <type_traits>
 #include <algorithm>
+#include <atomic>
 #include <string.h>
 
 namespace {
@@ -58,12 +59,20 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void intra_sb_kernel(const DevPla
     int *const smem_itx = reinterpret_cast<int *>(smem_s[wv]);
 
     const SbRegion r = regions[blockIdx.x];
-    if (flags) {
+    // FINE (one launch, every prediction stamped by the lister): nobody waits for whole superblocks.  flags[sb] = progress << 2 | state
+    // (state 1 finished, 2 gave up; progress P = every unit of a step < P has its pixels out).  A unit whose prediction reads intra pixels
+    // of other superblocks waits, itself, until those have published a progress above the step it needs; units on a superblock's right /
+    // bottom border store coherently and the superblock publishes behind their groups.
+    const bool fine = flags && reinterpret_cast<const uint32_t *>(units + r.first)[15] == 1u;
+    __shared__ int give_up;
+    if (flags && fine) {
+        if (threadIdx.x == 0) give_up = 0;
+        __syncthreads();
+    } else if (flags) {
         // Every level in one launch: the superblocks this one reads from (r.dep, all earlier in the array) have to be through.
         // Workgroups are dispatched in the order of their index, so whoever is waited for is running or done — no workgroup waits for
         // one that cannot start.  The neighbours' pixels were stored plainly and written back by the release fence at their end;
         // here one lane polls, then an acquire fence, and the edge reads are loads that bypass the L1 anyway.
-        __shared__ int give_up;
         if (threadIdx.x == 0) {
             bool ok = true;
 #pragma unroll
@@ -71,7 +80,7 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void intra_sb_kernel(const DevPla
                 if (r.dep[k] == SB_NONE || !ok) continue;
                 int spins = 0;
                 for (;;) {
-                    const uint32_t v = dv::ld_coherent(flags + r.dep[k]);
+                    const uint32_t v = dv::ld_coherent(flags + r.dep[k]) & 3u;
                     if (v == 1u) break;
                     if (v == 2u || ++spins > SB_SPIN_LIMIT) { ok = false; break; }       // a neighbour gave up, or never came: so does this one
                     dv::nap_long();
@@ -100,8 +109,10 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void intra_sb_kernel(const DevPla
     uint32_t ni = ci != SB_NONE ? (uint32_t) __builtin_amdgcn_readfirstlane((int) sb_next<SB_WAVES>(u)) : SB_NONE;
     if (ni != SB_NONE) un = us[ni];
     for (uint32_t g = 0; g < n_groups; g++) {
-        while (ci != SB_NONE && (uint32_t) __builtin_amdgcn_readfirstlane((int) u.grp) == g) {
+        uint32_t pub = 0;                    // (wave 0 holds the first unit of every group: it knows what to publish behind it)
+        while (ci != SB_NONE && ((uint32_t) __builtin_amdgcn_readfirstlane((int) u.grp) & 0xffffu) == g) {
             const IntraUnit *const up = us + ci;
+            pub = (uint32_t) __builtin_amdgcn_readfirstlane((int) u.grp) >> 16;
             uint32_t n2 = SB_NONE;
             IntraUnit u2;
             int keepn = 0;
@@ -112,6 +123,38 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void intra_sb_kernel(const DevPla
                     const int nbn = ((int) un.t.rsv[0] | (int) un.t.rsv[1] << 8) * (int) sizeof(coef);
                     keepn = dv::fetch_begin(reinterpret_cast<const char *>(cf + un.t.cf_off) + (lane * 64 < nbn ? lane * 64 : 0));
                 }
+            }
+            bool skip = false;
+            if (fine && (u.has & 1) && u.p.kind != DAV1D_HIP_IPRED_PAL) {
+                // the neighbouring superblocks this prediction reads intra pixels of: wait (one lane) until each has published a progress
+                // above the step it needs, or has finished
+                const uint32_t nmask = (uint32_t) __builtin_amdgcn_readfirstlane((int) u.p.pal[6]) & 15u;
+                const uint32_t nstep = (uint32_t) __builtin_amdgcn_readfirstlane((int) u.p.pal[7]);
+                if (nmask) {
+                    int bad = 0;
+                    if (lane == 0) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            if (!(nmask >> k & 1) || r.dep[k] == SB_NONE || bad) continue;
+                            int spins = 0;
+                            for (;;) {
+                                const uint32_t v = dv::ld_coherent(flags + r.dep[k]);
+                                if ((v & 3u) == 1u || (v >> 2) > nstep) break;
+                                if ((v & 3u) == 2u || ++spins > (SB_SPIN_LIMIT << 3) || *(volatile int *) &give_up) { bad = 1; break; }
+                                dv::nap();
+                            }
+                        }
+                        if (bad) give_up = 1;
+                    }
+                    bad = __shfl(bad, 0);
+                    skip = bad != 0;
+                    dv::fence_acquire_agent();
+                }
+            }
+            if (skip) {          // never in a sound run: the unit is NOT reconstructed from pixels that are not there
+                dv::fetch_end(keepn);
+                ci = ni; u = un; ni = n2; un = u2;
+                continue;
             }
             const bool has_pred = u.has & 1, has_tx = u.has & 2;
             const int plane = has_pred ? u.p.plane : u.t.plane;
@@ -150,21 +193,32 @@ __global__ __launch_bounds__(SB_WAVES * 64, 2) void intra_sb_kernel(const DevPla
             {
                 typedef typename std::conditional<sizeof(pixel) == 2, uint64_t, uint32_t>::type quad;
                 const int wq = w >> 2;
+                // (border units of the FINE form: agent-scope stores, written through to where the other XCDs' agent-scope loads look)
+                const bool coh = fine && (u.has & 8);
                 for (int i = lane; i < wq * h; i += 64) {
                     const int y = i / wq, x = (i - y * wq) * 4;
-                    *reinterpret_cast<quad *>(d + y * stride + x) = *reinterpret_cast<const quad *>(tile + y * w + x);
+                    const quad v = *reinterpret_cast<const quad *>(tile + y * w + x);
+                    if (coh) dv::st_coherent(reinterpret_cast<quad *>(d + y * stride + x), v);
+                    else *reinterpret_cast<quad *>(d + y * stride + x) = v;
                 }
             }
             dv::fetch_end(keepn);
             dv::wave_sync();                 // the LDS is free for the wave's next unit
             ci = ni; u = un; ni = n2; un = u2;
         }
-        dv::stores_done();                   // this wave's pixels have reached the L2 ...
+        dv::stores_done();                   // this wave's pixels have reached the L2 (the coherent ones: memory) ...
         __syncthreads();                     // ... and so have the other waves': the next group may read them
+        if (fine) {
+            if (*(volatile int *) &give_up) {
+                if (threadIdx.x == 0) { atomicAdd(flags + n_regions, 1u); dv::st_coherent(flags + blockIdx.x, 2u); }
+                return;
+            }
+            if (threadIdx.x == 0 && pub) dv::st_coherent(flags + blockIdx.x, pub << 2);
+        }
     }
     if (flags && threadIdx.x == 0) {
         dv::fence_release_agent();           // the XCD's L2 writes the superblock's pixels back: other XCDs may read them
-        dv::st_coherent(flags + blockIdx.x, 1u);
+        dv::st_coherent(flags + blockIdx.x, 0xfffffffdu);       // progress: everything; state: finished
     }
 }
 
@@ -253,7 +307,7 @@ __global__ __launch_bounds__(NW * 64, SBL2 == 6 ? 2 : 1) void intra_sbl_kernel(c
     uint32_t ni = ci != SB_NONE ? (uint32_t) __builtin_amdgcn_readfirstlane((int) sb_next<NW>(u)) : SB_NONE;
     if (ni != SB_NONE) un = us[ni];
     for (uint32_t g = 0; g < n_groups; g++) {
-        while (ci != SB_NONE && (uint32_t) __builtin_amdgcn_readfirstlane((int) u.grp) == g) {
+        while (ci != SB_NONE && ((uint32_t) __builtin_amdgcn_readfirstlane((int) u.grp) & 0xffffu) == g) {
             const IntraUnit *const up = us + ci;
             uint32_t n2 = SB_NONE;
             IntraUnit u2;
@@ -383,9 +437,14 @@ int dav1d_hip_sbw_prepare(std::vector<IntraUnit> &units, const std::vector<uint3
         else { pl = u.t.plane; if (pl > 2 || strides[pl] <= 0) return -EINVAL; x = (int) (u.t.dst_off % (uint32_t) strides[pl]); y = (int) (u.t.dst_off / (uint32_t) strides[pl]); }
         if (x > 0xffff || y > 0xffff) return -EINVAL;
         units[i].need = (uint32_t) y << 16 | (uint32_t) x;          // the unit's place in its plane (the LDS-resident kernel)
-        if (pl) { x <<= ss_hor; y <<= ss_ver; }
+        const int uw = (u.has & 1) ? u.p.tw * 4 : tx_w(u.t.tx), uh = (u.has & 1) ? u.p.th * 4 : tx_h(u.t.tx);
+        int x1 = x + uw, y1 = y + uh;
+        if (pl) { x <<= ss_hor; y <<= ss_ver; x1 <<= ss_hor; y1 <<= ss_ver; }
         const int sx = x >> tl.sb_log2, sy = y >> tl.sb_log2;
         if (sx >= sbw || sy >= tl.sbh) return -EINVAL;
+        // a unit that touches its superblock's last column or last row writes pixels the superblocks to the right / below may read:
+        // its stores go out coherently and the superblock publishes its progress behind its group (intra_sb_kernel)
+        if (x1 >= (sx + 1) << tl.sb_log2 || y1 >= (sy + 1) << tl.sb_log2) units[i].has |= 8; else units[i].has &= ~8u;
         sb[i] = (uint32_t) (sy * sbw + sx);
         st.key[i] = (uint32_t) s * 2 + (i >= ua_end[s]);
         lo = std::min(lo, sb[i]); hi = std::max(hi, sb[i]);
@@ -410,6 +469,10 @@ int dav1d_hip_sbw_prepare(std::vector<IntraUnit> &units, const std::vector<uint3
     return 0;
 }
 
+// option intra_sb_fine (process-wide; A/B aid): 0 = superblocks wait for whole neighbouring superblocks even when the lister's stamps are there
+static std::atomic<int> g_sbw_fine{1};
+void dav1d_hip_sbw_set_fine(int on) { g_sbw_fine.store(on); }
+
 void dav1d_hip_sbw_emit(const std::vector<IntraUnit> &units, const SbSort &st, IntraUnit *out)
 {
     const size_t n = units.size();
@@ -424,11 +487,19 @@ void dav1d_hip_sbw_emit(const std::vector<IntraUnit> &units, const SbSort &st, I
         for (int w = 0; w < 4; w++) { last4[w] = SB_NONE; hw[2 + w] = SB_NONE; }
         for (int w = 0; w < 8; w++) { last8[w] = SB_NONE; hw[6 + w] = SB_NONE; }
         uint32_t groups = 0;
+        bool fine = true;           // every prediction of the superblock says where it reaches into other superblocks (the lister's stamp)
+        for (uint32_t i = 0; i < p.n; i++)
+            if ((us[i].has & 1) && us[i].p.kind != DAV1D_HIP_IPRED_PAL && !(us[i].p.pal[6] & 0x8000)) fine = false;
         for (uint32_t i = 0; i < p.n; groups++) {
             uint32_t j = i + 1;
             while (j < p.n && k[j] == k[i]) j++;
+            // what the superblock publishes when this group is through: "every unit of a step below <the next group's step> is done" —
+            // only behind groups that hold a unit on the superblock's right / bottom border (nobody reads the others from outside)
+            bool border = false;
+            for (uint32_t q = i; q < j; q++) border = border || (us[q].has & 8);
+            const uint32_t pub = border && j < p.n ? std::min<uint32_t>(k[j] >> 1, 0xffffu) : 0;
             for (uint32_t q = i; q < j; q++) {
-                us[q].grp = groups; us[q].prev_n = SB_NONE; us[q].pad2 = SB_NONE;
+                us[q].grp = groups | pub << 16; us[q].prev_n = SB_NONE; us[q].pad2 = SB_NONE;
                 const uint32_t w4 = (q - i) & 3, w8 = (q - i) & 7;
                 if (last4[w4] == SB_NONE) hw[2 + w4] = q; else us[last4[w4]].pad2 = q;
                 if (last8[w8] == SB_NONE) hw[6 + w8] = q; else us[last8[w8]].prev_n = q;
@@ -437,6 +508,7 @@ void dav1d_hip_sbw_emit(const std::vector<IntraUnit> &units, const SbSort &st, I
             i = j;
         }
         hw[0] = groups;
+        hw[15] = fine && groups < 0xffffu && g_sbw_fine.load() ? 1u : 0u;
     }
 }
 

@@ -99,6 +99,9 @@ typedef struct Walk {
     unsigned seen_step;                               /* largest step this walk has reported to the lister */
     int col_start, col_end, row_start, row_end;       /* tile, 4-pixel units */
     int err;
+    /* what the latest dep_step() found in OTHER superblocks: the highest step among the intra-written cells it read there and which
+     * neighbours they lie in (bit 0 left, 1 top-left, 2 top, 3 top-right); new_ipred() stamps it on the task it makes */
+    unsigned xs_step, xs_mask;
 } Walk;
 
 /* bytes of the prep (which = 0) / mask (1) arena for this walk: from its tile's window, which is refilled from the shared cursor
@@ -146,20 +149,25 @@ static unsigned dep_step(const Walk *w, const int pl, const int x4, const int y4
      * superblock's own row, below the bottom-left corner) hold 0. */
     const int cx = l->sb_step >> sh, cy = l->sb_step >> sv;          /* cells of this plane per superblock */
     const int on_top = y4 % cy == 0, on_left = x4 % cx == 0;
+    unsigned xs = 0, bits = 0;
     if (s && (on_top || on_left)) {
-        unsigned bits = 0;
         if (y4 > y_lo)
-            for (int x = imax(x4 - 1, x_lo); x < imin(x4 + 2 * tw, x_hi); x++)
-                if (m[(y4 - 1) * st + x]) {
+            for (int x = imax(x4 - 1, x_lo); x < imin(x4 + 2 * tw, x_hi); x++) {
+                const unsigned v = m[(y4 - 1) * st + x];
+                if (v) {
                     const int dx = x / cx - x4 / cx;
-                    if (on_top) bits |= dx < 0 ? 2 : dx == 0 ? 4 : 8;
-                    else if (dx < 0) bits |= 1;
+                    if (on_top) { bits |= dx < 0 ? 2 : dx == 0 ? 4 : 8; if (v > xs) xs = v; }
+                    else if (dx < 0) { bits |= 1; if (v > xs) xs = v; }
                 }
+            }
         if (x4 > x_lo && on_left)
-            for (int y = y4; y < imin(y4 + 2 * th, y_hi); y++)
-                if (m[y * st + x4 - 1] && y / cy == y4 / cy) bits |= 1;
+            for (int y = y4; y < imin(y4 + 2 * th, y_hi); y++) {
+                const unsigned v = m[y * st + x4 - 1];
+                if (v && y / cy == y4 / cy) { bits |= 1; if (v > xs) xs = v; }
+            }
         if (bits) l->sb_dep[(size_t) (y4 / cy) * l->sbw + x4 / cx] |= (uint8_t) bits;
     }
+    ((Walk *) w)->xs_step = xs; ((Walk *) w)->xs_mask = bits;
     return s + 1;
 }
 
@@ -299,6 +307,12 @@ static Dav1dHipIpredTask *new_ipred(Walk *w, const unsigned step) {
     Dav1dHipIpredTask *k = VPUSH(w->o->ipred, Dav1dHipIpredTask);
     memset(k, 0, sizeof(*k));
     *VPUSH(w->o->ipred_step, uint16_t) = (uint16_t) step;
+    /* where the prediction reaches into other superblocks (Dav1dHipIpredTask.pal of the kinds that carry no palette: include/
+     * dav1d_hip.h): the superblock route then waits for exactly these units of its neighbours instead of for whole superblocks.
+     * (A palette prediction reads no neighbour and overwrites the fields with its colours.) */
+    k->pal[6] = (uint16_t) (0x8000u | w->xs_mask);
+    k->pal[7] = (uint16_t) w->xs_step;
+    w->xs_step = w->xs_mask = 0;
     return k;
 }
 
@@ -1185,7 +1199,7 @@ int dav1d_hip_lister_tile_sbrow(Dav1dHipLister *l, const int tile_row, const int
     if (!op) return -ENOMEM;
     Walk w;
     w.l = l; w.o = op; w.cur = cur; w.err = 0;
-    w.seen_step = 0;
+    w.seen_step = 0; w.xs_step = w.xs_mask = 0;
     w.col_start = l->d.col_start_sb[tile_col] << sb_shift;
     w.col_end = imin(l->d.col_start_sb[tile_col + 1] << sb_shift, l->bw);
     w.row_start = l->d.row_start_sb[tile_row] << sb_shift;

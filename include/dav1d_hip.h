@@ -386,7 +386,11 @@ typedef struct Dav1dHipIpredTask {
     uint8_t  kind;       /* enum Dav1dHipIpredKind */
     uint8_t  pad;
     uint16_t max_w, max_h; /* PRED: max_width / max_height arguments in pixels; CFL: w_pad / h_pad in 4-pixel units */
-    uint16_t pal[8];     /* PAL: the palette */
+    uint16_t pal[8];     /* PAL: the palette.  PRED / CFL / PRED_TMP tasks of a frame (optional, the pass-2 lister sets it): pal[6] = 0x8000 |
+                            mask of the neighbouring superblocks (bit 0 left, 1 top-left, 2 top, 3 top-right) in which the prediction reads
+                            pixels written by INTRA blocks of this frame, pal[7] = the highest wavefront step among those blocks.  With it on
+                            every prediction of a superblock, the superblock route waits per block for exactly that
+                            instead of for whole neighbouring superblocks; 0 = not known */
 } Dav1dHipIpredTask;
 
 /* `tasks` HOST array; `aux` DEVICE byte arena: packed palette indices for PAL tasks, scratch for the table-level
