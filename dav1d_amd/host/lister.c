@@ -16,6 +16,7 @@
 #include "lister_priv.h"
 #include <errno.h>
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -982,7 +983,11 @@ static void walk_sb(Walk *w, const int bl, const int bx, const int by, const int
             list_block(w, sz[bp][0], H_EDGE_ALL_TR, bx + hsz, by);
             if (bx + (hsz * 3 >> 1) < l->bw) list_block(w, sz[bp][0], n.v[1], bx + (hsz * 3 >> 1), by);
             break;
-        default: w->err = -EINVAL;
+        default:
+            if (getenv("DAV1D_HIP_TRACE_LISTER"))
+                fprintf(stderr, "lister: block at (%d, %d) level %d: bl %d bs %d bp %d intra %d (frame %dx%d, bw %d bh %d, b4_stride %d)\n", bx, by, bl, b->bl, b->bs, b->bp, b->intra,
+                        l->d.w, l->d.h, l->bw, l->bh, (int) l->d.b4_stride);
+            w->err = -EINVAL;
         }
     } else if (have_h_split) {
         if (b->bl != bl) { CHILD(0, bx, by); CHILD(1, bx + hsz, by); }
@@ -1027,6 +1032,12 @@ int dav1d_hip_lister_create(Dav1dHipLister **out, const Dav1dHipFrameDesc *d, Da
     Dav1dHipLister *l = (Dav1dHipLister *) calloc(1, sizeof(*l));
     if (!l) return -ENOMEM;
     l->d = *d;
+    if (!d->is_inter) {
+        /* key / intra-only frames have no references: whatever the caller's f->svc / refp still hold from the frame context's last
+         * inter frame is not looked at (an intra block copy predicts from the frame itself, never scaled: src/recon_tmpl.c:1584-1597) */
+        memset(l->d.svc, 0, sizeof(l->d.svc));
+        memset(l->d.gmv_warp_allowed, 0, sizeof(l->d.gmv_warp_allowed));
+    }
     l->frame = frame;
     l->ss_ver = d->layout == DAV1D_HIP_LAYOUT_I420;
     l->ss_hor = d->layout != DAV1D_HIP_LAYOUT_I444;
@@ -1245,6 +1256,9 @@ int dav1d_hip_lister_tile_sbrow(Dav1dHipLister *l, const int tile_row, const int
     }
     if (!rc) rc = submit_steps(l, op);
     if (!rc) cur->next_sby = sby + 1;
+    if (rc && getenv("DAV1D_HIP_TRACE_LISTER"))
+        fprintf(stderr, "lister: tile (%d, %d) sby %d: rc %d (walk err %d, oom %d; %zu mc %zu comp %zu warp %zu scaled %zu itx %zu ipred %zu sitx %zu smc)\n", tile_row, tile_col, sby, rc,
+                w.err, v_oom, op->mc.n, op->comp.n, op->warp.n, op->scaled.n, op->itx.n, op->ipred.n, op->sitx.n, op->smc.n);
     return rc;
 }
 

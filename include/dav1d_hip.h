@@ -806,7 +806,8 @@ typedef struct Dav1dHipFrameDesc {
     const int16_t *cbi;          /* f->frame_thread.cbi: eob << 5 | txtp per transform block */
     const unsigned *tile_start_off;         /* f->frame_thread.tile_start_off[tile]: start of the tile's share of cbi / cf / pal_idx */
     const void *pal;             /* f->frame_thread.pal: pixel[3][8] per 8x8 (NULL without screen content tools) */
-    int32_t svc[7][2][2];        /* f->svc[ref][x / y]{ scale, step }: scale 0 = reference has the frame's size */
+    int32_t svc[7][2][2];        /* f->svc[ref][x / y]{ scale, step }: scale 0 = reference has the frame's size.  Not looked at (like ref_w / ref_h /
+                                    gmv_warp_allowed) when !is_inter: a frame context keeps these from its last inter frame */
     int ref_w[7], ref_h[7];      /* f->refp[i].p.p.w / h */
     Dav1dHipWarpParams gmv[7];   /* frame_hdr->gmv */
     uint8_t gmv_warp_allowed[7]; /* f->gmv_warp_allowed */
