@@ -39,6 +39,7 @@ struct Dav1dHipContext {
     int recon_pair_streams;     // side streams the paired launches of a recon list are dealt over (DAV1D_HIP_RECON_PAIR_STREAMS, 1 or 2)
     int ref_twin;               // tiled twins of reference pictures ($DAV1D_HIP_REF_TWIN): 0 never read, 1 (default) read when a picture has a valid
                                 // one (dav1d_hip_picture_retile), 2 also made for every picture of dav1d_hip_picture_alloc and by dav1d_hip_frame_end
+    bool cdef_full_copy;        // option filter_full_copy / $DAV1D_HIP_FILTER_FULL_COPY=1: CDEF and restoration start from a copy of the whole picture (A/B aid)
     bool cdef_unit_kernel;      // $DAV1D_HIP_CDEF_UNIT=1 at open: one wave per 8x8 unit (the round-1 kernel) instead of strips; A/B aid
     // measurement aid: device time of the kernel launches of the most recent *_batch call (dav1d_hip_last_kernel_ms)
     hipEvent_t ev_t0, ev_t1;
@@ -316,6 +317,8 @@ struct CdefGroup {
 // appends the groups of tasks[0 .. n) (indices offset by `base`) in list order; returns the number of RAW tasks met
 size_t dav1d_hip_cdef_make_groups(const Dav1dHipCdefTask *tasks, size_t n, size_t base, std::vector<CdefGroup> &out);
 bool dav1d_hip_cdef_strip_ok(const DevPlanes *dst, const DevPlanes *src, int bpc);
+extern "C" int dav1d_hip_launch_cdef_fill_unlisted(const DevPlanes *dst, const DevPlanes *src, int bpc, int layout, const Dav1dHipCdefTask *tasks,
+                                                   int n, uint32_t *bitmap, int w8, int h8, void *stream);
 extern "C" int dav1d_hip_launch_cdef_groups(const DevPlanes *dst, const DevPlanes *src, int bpc, int layout, const Dav1dHipCdefTask *tasks,
                                             const CdefGroup *groups, int n_groups, int damping, uint32_t *dirvar, void *stream);
 // tasks + ready-made groups (host arrays) -> upload, strip kernel (+ the unit kernel for RAW tasks), synchronize

@@ -11,6 +11,7 @@
 // neighbourhood from the immutable pre-CDEF picture `src` and writes `dst`, so all units of
 // a frame are independent.  Mapping: one wave per unit, one lane per luma pixel; the window
 // goes to LDS as int16 with the INT16_MIN sentinel where the frame edge cuts it off.
+#include <type_traits>
 #include "common.h"
 #include "capi.h"
 #include "av1_tables.h"
@@ -489,7 +490,7 @@ __device__ __forceinline__ CdefTapSet cdef_tapset(const int strength, const int 
 template <typename pixel, int W, int H>
 __device__ __forceinline__ void cdef_plane(const uint16_t *win, const uint32_t *dir_yx, pixel *dstp, const int stride, const int x0, const int y0,
                                            const int u, const int q, const int pri, const int sec, const int dir, const int damping,
-                                           const int bitdepth_min_8, const bool run)
+                                           const int bitdepth_min_8, const bool run, const bool present)
 {
     constexpr int RPL = H / 4, NP = W / 2, WS = 18 * W;
     const bool any_pri = __any(run && pri), any_sec = __any(run && sec);
@@ -501,7 +502,9 @@ __device__ __forceinline__ void cdef_plane(const uint16_t *win, const uint32_t *
     uint32_t out[RPL][NP];
     const int row0 = q * RPL;
     cdef_filter_rows<W, RPL>(win, (row0 + 2) * WS + (u + 1) * W, any_pri, any_sec, tp, ts0, ts1, pri && sec, out);
-    if (!run) return;
+    // a listed unit that does not filter this plane has both strengths 0 here: its sums are 0 and `out` is the window's centre, so
+    // every listed unit is WRITTEN and dst needs no copy of src underneath (frame.hip fills the unlisted units, cdef_fill_unlisted)
+    if (!present) return;
 #pragma unroll
     for (int r = 0; r < RPL; r++) {
         pixel *d = dstp + (y0 + row0 + r) * stride + x0 + u * W;
@@ -623,8 +626,9 @@ __global__ __launch_bounds__(64) void cdef_strip_kernel(const DevPlanes dst, con
             const unsigned uv422 = 0x66654207u;   // nibbles 7,0,2,4,5,6,6,6 for dir 0..7
             int uvdir = 0;
             if (uv_pri) uvdir = layout == DAV1D_HIP_LAYOUT_I422 ? (int) ((uv422 >> (4 * dir)) & 15) : dir;
-            upar[n][0] = (uint32_t) pri | (uint32_t) y_sec << 8 | (uint32_t) d << 16 | (uint32_t) (present && run) << 24;
-            upar[n][1] = (uint32_t) uv_pri | (uint32_t) uv_sec << 8 | (uint32_t) uvdir << 16 | (uint32_t) (present && (uv_pri || uv_sec)) << 24;
+            const uint32_t pb = (uint32_t) present << 25;
+            upar[n][0] = (uint32_t) (run ? pri : 0) | (uint32_t) (run ? y_sec : 0) << 8 | (uint32_t) d << 16 | (uint32_t) (present && run) << 24 | pb;
+            upar[n][1] = (uint32_t) uv_pri | (uint32_t) uv_sec << 8 | (uint32_t) uvdir << 16 | (uint32_t) (present && (uv_pri || uv_sec)) << 24 | pb;
         }
     }
     dv::wave_sync();
@@ -632,14 +636,67 @@ __global__ __launch_bounds__(64) void cdef_strip_kernel(const DevPlanes dst, con
     const int u = lane >> 2, q = lane & 3;
     const uint32_t p0 = upar[u][0], p1 = upar[u][1];
     cdef_plane<pixel, 8, 8>(win, dir_yx, reinterpret_cast<pixel *>(dst.data[0]), dst.stride[0], x0, y0, u, q, p0 & 0xff, p0 >> 8 & 0xff,
-                            p0 >> 16 & 0xff, damping, bitdepth_min_8, p0 >> 24 & 1);
-    if (!CW || !any_uv) return;
+                            p0 >> 16 & 0xff, damping, bitdepth_min_8, p0 >> 24 & 1, p0 >> 25 & 1);
+    if (!CW) return;
+    if (!any_uv) {
+        // no unit of the strip filters chroma (no window was loaded): the listed units' chroma blocks go across as they are
+        if (!(p0 >> 25 & 1)) return;
+        constexpr int CWc = CW ? CW : 8, RPL = (CW ? CH : 8) / 4;
+        typedef typename std::conditional<CWc * sizeof(pixel) == 16, uint4, typename std::conditional<CWc * sizeof(pixel) == 8, uint2, uint32_t>::type>::type piece;
+#pragma unroll
+        for (int pl = 1; pl < 3; pl++)
+#pragma unroll
+            for (int r = 0; r < RPL; r++) {
+                const ptrdiff_t so = (ptrdiff_t) (cy0 + q * RPL + r) * src.stride[pl] + cx0 + u * CWc, dof = (ptrdiff_t) (cy0 + q * RPL + r) * dst.stride[pl] + cx0 + u * CWc;
+                *reinterpret_cast<piece *>(reinterpret_cast<pixel *>(dst.data[pl]) + dof) = *reinterpret_cast<const piece *>(reinterpret_cast<const pixel *>(src.data[pl]) + so);
+            }
+        return;
+    }
     const int pri = p1 & 0xff, sec = p1 >> 8 & 0xff, d = p1 >> 16 & 0xff;
     const bool run = p1 >> 24 & 1;
 #pragma unroll
     for (int pl = 1; pl < 3; pl++)
         cdef_plane<pixel, CW ? CW : 8, CW ? CH : 8>(cwin[pl - 1], dir_yx, reinterpret_cast<pixel *>(dst.data[pl]), dst.stride[pl], cx0, cy0, u, q,
-                                                      pri, sec, d, damping - 1, bitdepth_min_8, run);
+                                                      pri, sec, d, damping - 1, bitdepth_min_8, run, p1 >> 25 & 1);
+}
+
+// The units CDEF does NOT list (skipped blocks, zero strengths) keep the deblocked pixels: instead of copying the whole picture under
+// the filtered units (100 MB for an 8K frame), the listed units are marked in a bitmap of 8x8 units and only the others are copied.
+__global__ __launch_bounds__(256) void cdef_mark_kernel(const Dav1dHipCdefTask *__restrict__ tasks, const int n, uint32_t *__restrict__ bitmap, const int w8) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const Dav1dHipCdefTask t = tasks[i];
+    if (t.flags & DAV1D_HIP_CDEF_RAW) return;
+    const int idx = t.by * w8 + t.bx;
+    atomicOr(&bitmap[idx >> 5], 1u << (idx & 31));
+}
+
+// 256 threads = 32 units of a unit row x 8 pixel rows
+template <typename pixel>
+__global__ __launch_bounds__(256) void cdef_fill_unlisted_kernel(const DevPlanes dst, const DevPlanes src, const uint32_t *__restrict__ bitmap,
+                                                                 const int w8, const int layout)
+{
+    const int bx = blockIdx.x * 32 + (threadIdx.x & 31), by = blockIdx.y, r = threadIdx.x >> 5;
+    if (bx >= w8) return;
+    const int idx = by * w8 + bx;
+    if (bitmap[idx >> 5] >> (idx & 31) & 1) return;
+    typedef typename std::conditional<sizeof(pixel) == 2, uint4, uint2>::type row8;
+    typedef typename std::conditional<sizeof(pixel) == 2, uint2, uint32_t>::type row4;
+    {
+        const ptrdiff_t so = (ptrdiff_t) (by * 8 + r) * src.stride[0] + bx * 8, dof = (ptrdiff_t) (by * 8 + r) * dst.stride[0] + bx * 8;
+        *reinterpret_cast<row8 *>(reinterpret_cast<pixel *>(dst.data[0]) + dof) = *reinterpret_cast<const row8 *>(reinterpret_cast<const pixel *>(src.data[0]) + so);
+    }
+    if (layout == DAV1D_HIP_LAYOUT_I400) return;
+    const int ss_hor = layout != DAV1D_HIP_LAYOUT_I444, ss_ver = layout == DAV1D_HIP_LAYOUT_I420;
+    if (r >= 8 >> ss_ver) return;
+#pragma unroll
+    for (int pl = 1; pl < 3; pl++) {
+        const int y = by * (8 >> ss_ver) + r, x = bx * (8 >> ss_hor);
+        const pixel *s = reinterpret_cast<const pixel *>(src.data[pl]) + (ptrdiff_t) y * src.stride[pl] + x;
+        pixel *d = reinterpret_cast<pixel *>(dst.data[pl]) + (ptrdiff_t) y * dst.stride[pl] + x;
+        if (ss_hor) *reinterpret_cast<row4 *>(d) = *reinterpret_cast<const row4 *>(s);
+        else *reinterpret_cast<row8 *>(d) = *reinterpret_cast<const row8 *>(s);
+    }
 }
 
 } // namespace
@@ -676,6 +733,20 @@ extern "C" int dav1d_hip_launch_cdef_groups(const DevPlanes *dst, const DevPlane
     const int bitdepth_max = (1 << bpc) - 1;
     if (bpc == 8) launch_strips<uint8_t>(dst, src, layout, tasks, groups, n_groups, damping, bitdepth_max, dirvar, (hipStream_t) stream);
     else launch_strips<uint16_t>(dst, src, layout, tasks, groups, n_groups, damping, bitdepth_max, dirvar, (hipStream_t) stream);
+    return hip_rc(hipGetLastError());
+}
+
+// bitmap: DEVICE, (w8 * h8 + 31) / 32 words, cleared here.  The same alignment conditions as the strip kernel (dav1d_hip_cdef_strip_ok).
+extern "C" int dav1d_hip_launch_cdef_fill_unlisted(const DevPlanes *dst, const DevPlanes *src, int bpc, int layout, const Dav1dHipCdefTask *tasks,
+                                                   int n, uint32_t *bitmap, int w8, int h8, void *stream)
+{
+    if (w8 <= 0 || h8 <= 0) return 0;
+    const size_t words = ((size_t) w8 * h8 + 31) / 32;
+    if (hipMemsetAsync(bitmap, 0, words * 4, (hipStream_t) stream) != hipSuccess) return hip_rc(hipGetLastError());
+    if (n > 0) hipLaunchKernelGGL(cdef_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t) stream, tasks, n, bitmap, w8);
+    const dim3 grid((w8 + 31) / 32, h8);
+    if (bpc == 8) hipLaunchKernelGGL((cdef_fill_unlisted_kernel<uint8_t>), grid, dim3(256), 0, (hipStream_t) stream, *dst, *src, bitmap, w8, layout);
+    else hipLaunchKernelGGL((cdef_fill_unlisted_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t) stream, *dst, *src, bitmap, w8, layout);
     return hip_rc(hipGetLastError());
 }
 

@@ -730,6 +730,7 @@ static void frame_merge_filter_pieces(Dav1dHipFrame *f) {
 }
 
 static int copy_picture(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src);
+static int copy_unrestored_planes(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src, const std::vector<Dav1dHipLrTask> &lr);
 
 // Deblocking and CDEF of a frame straight from the pieces: the tasks copied piece after piece into pinned memory (the larger
 // arrays on a few threads), one upload each, the launches of dav1d_hip_lf_batch / dav1d_hip_cdef_run_groups.  *did_cdef: the
@@ -767,11 +768,21 @@ static int frame_filters_from_pieces(Dav1dHipFrame *f, bool *did_cdef) {
     }
     if (n_cdef) {
         rc = frame_tmp(f, 0);
-        if (!rc) rc = copy_picture(c, &f->tmp[0], &f->cur);       // units that are not listed keep their pixels
         if (rc) return rc;
         const DevPlanes t0 = dev_planes(&f->tmp[0]);
         const bool strips = !c->cdef_unit_kernel && dav1d_hip_cdef_strip_ok(&t0, &cur, f->cur.bpc);
+        // Units that are not listed keep their pixels.  The strip kernel writes every unit it is given (also the planes it does not
+        // filter), so only the UNLISTED units have to be brought over: none when the list covers the frame, the ones a bitmap of the
+        // listed units leaves out otherwise (cdef.hip cdef_fill_unlisted_kernel) — not a copy of the whole picture under the filter
+        // (100 MB of traffic for an 8K frame, 40 us).  The unit-per-wave kernel and DSP-level (RAW) tasks keep the copy.
+        const int w8 = (f->cur.p[0].w + 7) >> 3, h8 = (f->cur.p[0].h + 7) >> 3;
+        const bool fill = strips && !n_raw && !c->cdef_full_copy;
+        const bool covered = fill && n_cdef == (size_t) w8 * h8;
+        const size_t bm_bytes = fill && !covered ? (((size_t) w8 * h8 + 31) / 32 * 4 + 255) & ~(size_t) 255 : 0;
+        if (!fill) rc = copy_picture(c, &f->tmp[0], &f->cur);
+        if (rc) return rc;
         const size_t tb = (n_cdef * sizeof(Dav1dHipCdefTask) + 255) & ~(size_t) 255;
+        const size_t gb = (n_groups * sizeof(CdefGroup) + 255) & ~(size_t) 255;
         size_t cap = 0;
         uint8_t *host = dav1d_hip_slab_get(c, tb + n_groups * sizeof(CdefGroup) + 256, &cap);
         if (!host) return -ENOMEM;
@@ -800,11 +811,14 @@ static int frame_filters_from_pieces(Dav1dHipFrame *f, bool *did_cdef) {
             copy_pieces(0, np / nt);
             for (std::thread &x : th) x.join();
         }
-        TaskBuf dev_buf(c, tb + n_groups * sizeof(CdefGroup) + 256);
+        TaskBuf dev_buf(c, tb + gb + bm_bytes + 256);
         uint8_t *const dev = dev_buf.p;
         if (!dev) rc = -ENOMEM;
         if (!rc) rc = dav1d_hip_upload(c, dev, host, tb + n_groups * sizeof(CdefGroup));
         const Dav1dHipCdefTask *d_tasks = reinterpret_cast<const Dav1dHipCdefTask *>(dev);
+        if (!rc && bm_bytes)
+            rc = dav1d_hip_launch_cdef_fill_unlisted(&t0, &cur, f->cur.bpc, f->cur.layout, d_tasks, (int) n_cdef,
+                                                     reinterpret_cast<uint32_t *>(dev + tb + gb), w8, h8, c->stream);
         if (!rc && strips) {
             rc = dav1d_hip_launch_cdef_groups(&t0, &cur, f->cur.bpc, f->cur.layout, d_tasks, reinterpret_cast<const CdefGroup *>(dev + tb), (int) n_groups,
                                               f->cdef_damping, nullptr, c->stream);
@@ -848,6 +862,20 @@ int dav1d_hip_frame_set_filters(Dav1dHipFrame *f, const uint8_t *lvl, ptrdiff_t 
         if (rc) return rc;
     }
     f->is_id = is_id;
+    return 0;
+}
+
+static int copy_unrestored_planes(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src, const std::vector<Dav1dHipLrTask> &lr) {
+    if (c->cdef_full_copy) return copy_picture(c, dst, src);
+    uint64_t area[3] = { 0, 0, 0 };
+    for (const Dav1dHipLrTask &t : lr) if (t.plane < 3) area[t.plane] += (uint64_t) t.w * t.h;
+    const int bps = src->bpc > 8 ? 2 : 1;
+    for (int pl = 0; pl < 3; pl++) {
+        if (!src->p[pl].data || area[pl] == (uint64_t) src->p[pl].w * src->p[pl].h) continue;
+        const int rc = hip_rc(hipMemcpy2DAsync(dst->p[pl].data, dst->p[pl].stride, src->p[pl].data, src->p[pl].stride,
+                                               (size_t) src->p[pl].w * bps, src->p[pl].h, hipMemcpyDeviceToDevice, c->stream));
+        if (rc) return rc;
+    }
     return 0;
 }
 
@@ -1337,7 +1365,9 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
             } else {
                 rc = frame_tmp(f, 1);
             }
-            if (!rc) rc = copy_picture(c, out, last);
+            // restoration units of type NONE are not listed and keep their pixels: a plane whose listed stripes cover it needs nothing
+            // underneath, the others are copied plane by plane
+            if (!rc) rc = copy_unrestored_planes(c, out, last, f->lr);
             // somebody listens for rows (dav1d_hip_frame_set_progress_callback): the LAST stage runs in bands of rows, each followed by
             // an event, and the rows are published band by band while the later bands still run
             if (!rc) rc = f->progress_cb && !f->sr_w ? frame_lr_banded(f, out, last, lpf) : dav1d_hip_lr_batch(c, out, last, lpf, f->lr.data(), f->lr.size());

@@ -104,6 +104,14 @@ def test_screen_content_stream_palette_and_intra_block_copy(ctx):
     assert got["hist"]["b_palette_y"] > 0 and got["hist"]["b_intrabc"] > 0, got["hist"]
 
 
+def test_filters_over_a_full_copy_give_the_same_pictures(ctx, monkeypatch):
+    """CDEF and restoration normally bring over only the units they do not list (cdef.hip cdef_fill_unlisted_kernel, frame.hip
+    copy_unrestored_planes); the A/B switch puts the whole-picture copy back underneath: both are dav1d's pictures"""
+    monkeypatch.setenv("DAV1D_HIP_FILTER_FULL_COPY", "1")
+    for seed in (3, 11):
+        run_seed(ctx, seed, n_frames=5)
+
+
 @pytest.mark.gpu
 def test_sweep_of_streams_on_the_gpu():
     """>= 200 seeds over 8 / 10 / 12 bit x 4:0:0 / 4:2:0 / 4:2:2 / 4:4:4 x 64- / 128-pixel superblocks x 1 - 4 tile columns / rows
