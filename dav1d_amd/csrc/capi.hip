@@ -82,6 +82,7 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     c->arena_hint = 0;
     c->arena_min = (size_t) 1 << 24;
     c->chunk_order = (int) env_int("DAV1D_HIP_CHUNK_ORDER", 0);
+    c->chunk_hints = (int) env_int("DAV1D_HIP_CHUNK_HINTS", 1);
     c->carena_hint = 0;
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
@@ -183,6 +184,7 @@ int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value) {
     else if (!strcmp(name, "intra_sb_flow")) c->intra_sb_flow = value != 0;
     else if (!strcmp(name, "intra_sb_fine")) dav1d_hip_sbw_set_fine(value != 0);
     else if (!strcmp(name, "chunk_order")) c->chunk_order = value != 0;
+    else if (!strcmp(name, "chunk_hints")) c->chunk_hints = value != 0;
     else if (!strcmp(name, "chunk_arena_min")) { if (value < 4096) return -EINVAL; c->arena_min = (size_t) 1 << 12; while (c->arena_min < (size_t) value) c->arena_min <<= 1; c->arena_hint = 0; }
     else return -EINVAL;
     return 0;

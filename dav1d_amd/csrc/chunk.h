@@ -25,7 +25,8 @@ struct Dav1dHipChunk {
 typedef uint8_t *(*Dav1dHipChunkPlace)(void *cookie, size_t bytes, size_t *dev_off);
 int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHipPicture *geom, const Dav1dHipPicture *refs, int n_refs,
                           const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
-                          const Dav1dHipItxTask *itx, size_t n_itx, Dav1dHipChunkPlace place, void *cookie, bool trusted = false);
+                          const Dav1dHipItxTask *itx, size_t n_itx, Dav1dHipChunkPlace place, void *cookie, bool trusted = false,
+                          const uint16_t *itx_dep = nullptr);
 // The frame's arena grown to `need` bytes if it is smaller (contents lost: *regrown = true, the caller sends its twin again).  Then, AFTER
 // the twin has gone (a late chunk may start inside the range the twin covers: the twin's bytes there are not the chunk's), every chunk
 // that lives in a slab of its own is sent to its place (copy stream; `regrown`: also those that had been sent before).

@@ -12,6 +12,7 @@
 #include "capi.h"
 #include "lists.h"
 #include "chunk.h"
+#include "av1_scan_prefix.h"
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -169,6 +170,227 @@ void Dav1dHipChunk::release(Dav1dHipContext *c) {
     host = nullptr;
 }
 
+
+// ------------------------------------------------------------------ the library's own lister: no maps, no intermediate vectors
+//
+// dav1d_hip_chunk_build() below rediscovers, through maps of 4x4 cells and hash tables of arena offsets, what the walk that made the
+// records knew when it made them: which transform block covers exactly one prediction, which two PREP blocks one average consumes,
+// which launches write under a residual.  host/lister.c writes those three facts into the records (Walk.bdep / cand, lister.c) and the
+// preparation becomes two passes over them: count, then cut the tiles straight into the pinned blob.  Measured on the C2 8K frame
+// (923 K prediction, 106 K compound, 622 K transform records): 90 -> [see DESIGN.md 5] CPU-ms per frame.
+namespace {
+struct PairedBlock { uint32_t src, itx; };           // src: index of the PUT task, or 0x80000000 | index of the compound task
+struct HintScratch {
+    std::vector<uint8_t> taken, role, gk;
+    std::vector<PairedBlock> pb[5], tmp;
+};
+
+inline int n_tiles(const int w, const int h) { return ((w + 63) >> 6) * ((h + 15) >> 4); }
+inline int bin_of(const int w, const int h) { return tile_dim_class(w < 64 ? w : 64) * 3 + tile_dim_class(h < 16 ? h : 16); }
+
+// mc_ref_of (capi.hip) in line: a million calls per 8K frame
+inline McRef ref_of(const Dav1dHipMcTask &t) {
+    McRef r;
+    r.src_x = t.src_x; r.src_y = t.src_y;
+    r.mx = t.mx; r.my = t.my; r.ref = t.ref; r.pad = 0;
+    if (t.filter_2d == 9) {
+        r.fh = r.fv = 6;
+    } else {
+        // enum Filter2d -> (h type, v type), 4-tap rows for w <= 4 / h <= 4 (see mc_ref_of)
+        const int h_type = (0x15a80u >> (2 * t.filter_2d)) & 3, v_type = (0x24924u >> (2 * t.filter_2d)) & 3;
+        r.fh = (uint8_t) (t.w > 4 ? h_type : 3 + (h_type & 1));
+        r.fv = (uint8_t) (t.h > 4 ? v_type : 3 + (v_type & 1));
+    }
+    r.vspan = av1_mc_tap_span_host[r.fv * 16 + r.my];
+    r.hspan = av1_mc_tap_span_host[r.fh * 16 + r.mx];
+    return r;
+}
+
+inline McTile *cut_tiles(McTile *dst, const Dav1dHipMcTask &t, const int kind, const uint32_t dst_off, const Dav1dHipMcTask *second, const int weight) {
+    McTile m;
+    m.dst_off = dst_off;
+    m.kind = (uint8_t) kind; m.plane = t.plane; m.bw = t.w; m.weight = (int8_t) weight;
+    const McRef r0 = ref_of(t), r1 = second ? ref_of(*second) : r0;
+    const int tw = t.w < 64 ? t.w : 64, th = t.h < 16 ? t.h : 16;
+    for (int oy = 0; oy < t.h; oy += th)
+        for (int ox = 0; ox < t.w; ox += tw) {
+            m.w = (uint8_t) tw; m.h = (uint8_t) std::min(th, t.h - oy); m.ox = (uint8_t) ox; m.oy = (uint8_t) oy;
+            m.r[0] = r0; m.r[0].src_x += ox; m.r[0].src_y += oy;
+            m.r[1] = r1; m.r[1].src_x += ox; m.r[1].src_y += oy;
+            *dst++ = m;
+        }
+    return dst;
+}
+} // namespace
+
+static int chunk_build_hinted(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHipMcTask *mc, const size_t n_mc, const Dav1dHipCompTask *comp,
+                              const size_t n_comp, const Dav1dHipItxTask *itx, const size_t n_itx, const uint16_t *itx_dep,
+                              Dav1dHipChunkPlace place_blob, void *cookie)
+{
+    static thread_local HintScratch hs_tls;
+    HintScratch &hs = hs_tls;                  // (one trip through the thread-local lookup, not one per use)
+    const int fuse_mask = recon_fuse_mask(c);
+    std::vector<uint8_t> &taken = hs.taken, &role = hs.role;
+    taken.assign(n_itx, 0);
+    role.assign(n_mc, 0);                      // 1: a PREP an averaged pair consumes (its tiles are cut with the pair); 2: a PUT that runs with
+                                               // its transform block; 3: a PREP of an averaged pair that does
+    for (int k = 0; k < 5; k++) hs.pb[k].clear();
+    size_t cnt[CK_N] = { 0 };
+    uint64_t order = ~0ull;
+    int max_ref = 0;
+    bool any_wmask = false;
+    // the transform block a prediction runs in one wave with: named by the lister, taken when the size class is switched on
+    auto partner = [&](const Dav1dHipMcTask &t, const int w, const int h, const uint32_t off) -> long {
+        const uint32_t j = t.pad;
+        if (!j || j > n_itx || w != h) return -1;
+        const Dav1dHipItxTask &x = itx[j - 1];
+        if (x.tx > 4 || (4 << x.tx) != w || x.dst_off != off || x.plane != t.plane || !(fuse_mask >> x.tx & 1) || taken[j - 1]) return -1;
+        return (long) j - 1;
+    };
+    // ---- pass 1: what goes where
+    for (size_t i = 0; i < n_comp; i++) {
+        const Dav1dHipCompTask &k = comp[i];
+        if (k.kind <= DAV1D_HIP_COMP_WAVG && k.mask_off) {
+            const size_t a = (size_t) k.mask_off - 1;
+            if (a + 1 >= n_mc || mc[a].kind != DAV1D_HIP_MC_PREP || mc[a + 1].kind != DAV1D_HIP_MC_PREP || mc[a].w != k.w || mc[a].h != k.h ||
+                mc[a + 1].w != k.w || mc[a + 1].h != k.h || role[a] || role[a + 1]) return -EINVAL;
+            role[a] = role[a + 1] = 1;
+            const long j = partner(mc[a], k.w, k.h, k.dst_off);
+            if (j >= 0) {
+                taken[j] = 1;
+                role[a] = role[a + 1] = 3;
+                hs.pb[itx[j].tx].push_back({ 0x80000000u | (uint32_t) i, (uint32_t) j });
+            } else {
+                cnt[CK_MC + bin_of(k.w, k.h)] += (size_t) n_tiles(k.w, k.h);
+            }
+        } else {
+            any_wmask |= k.kind == DAV1D_HIP_COMP_WMASK;
+        }
+    }
+    for (size_t i = 0; i < n_mc; i++) {
+        const Dav1dHipMcTask &t = mc[i];
+        max_ref = std::max(max_ref, (int) t.ref);
+        if (role[i]) continue;
+        if (t.kind == DAV1D_HIP_MC_PUT) {
+            order = std::min(order, (uint64_t) t.plane << 40 | t.dst_off);
+            const long j = partner(t, t.w, t.h, t.dst_off);
+            if (j >= 0) {
+                taken[j] = 1;
+                role[i] = 2;
+                hs.pb[itx[j].tx].push_back({ (uint32_t) i, (uint32_t) j });
+                continue;
+            }
+        }
+        cnt[CK_MC + bin_of(t.w, t.h)] += (size_t) n_tiles(t.w, t.h);
+    }
+    Dav1dHipChunk *ck = new (std::nothrow) Dav1dHipChunk();
+    if (!ck) return -ENOMEM;
+    memset(ck->seg, 0, sizeof(ck->seg));
+    memset(ck->dep, 0, sizeof(ck->dep));
+    ck->host = nullptr; ck->cap = ck->used = 0; ck->dev_off = 0; ck->uploaded = false;
+    for (size_t i = 0; i < n_itx; i++) {
+        const Dav1dHipItxTask &t = itx[i];
+        order = std::min(order, (uint64_t) t.plane << 40 | t.dst_off);
+        if (taken[i]) continue;
+        ck->dep[t.tx] |= itx_dep[i];
+        cnt[CK_ITX + t.tx]++;
+    }
+    ck->order = order;
+    ck->max_ref = max_ref;
+    // compound / blend tasks that stay tasks: BLEND_V and the MASK tasks that read a mask a W_MASK task of the chunk writes go second
+    std::unordered_map<uint32_t, char> wmask_out;
+    if (any_wmask) for (size_t i = 0; i < n_comp; i++) if (comp[i].kind == DAV1D_HIP_COMP_WMASK) wmask_out[comp[i].mask_off] = 1;
+    auto second = [&](const Dav1dHipCompTask &t) { return t.kind == DAV1D_HIP_COMP_BLEND_V || (t.kind == DAV1D_HIP_COMP_MASK && any_wmask && wmask_out.count(t.mask_off)); };
+    for (size_t i = 0; i < n_comp; i++) {
+        const Dav1dHipCompTask &k = comp[i];
+        if (k.kind <= DAV1D_HIP_COMP_WAVG && k.mask_off) continue;
+        cnt[CK_COMP + (second(k) ? 1 : 0)]++;
+    }
+    // paired blocks inside windows of 128 waves by code path (transform kinds, prediction kind, column parity of the source): the
+    // blocks of a wave share their branch of recon_fused_kernel
+    for (int k = 0; k < 5; k++) {
+        std::vector<PairedBlock> &v = hs.pb[k];
+        const int tpb = k < 3 ? 1 : k == 3 ? 2 : 4, bpw = k == 0 ? 16 : k == 1 ? 8 : k == 2 ? 4 : k == 3 ? 2 : 1;
+        cnt[CK_PTILE + k] = v.size() * tpb;
+        cnt[CK_PTASK + k] = v.size();
+        if (v.size() < 2) continue;
+        hs.gk.resize(v.size());
+        for (size_t i = 0; i < v.size(); i++) {
+            const bool two = v[i].src >> 31;
+            const Dav1dHipCompTask *q = two ? &comp[v[i].src & 0x7fffffffu] : nullptr;
+            const Dav1dHipMcTask &t0 = two ? mc[q->mask_off - 1] : mc[v[i].src];
+            hs.gk[i] = (uint8_t) ((itx_path_key(itx[v[i].itx]) * 3 + (!two ? 0 : q->kind == DAV1D_HIP_COMP_AVG ? 1 : 2)) * 2 + (t0.src_x & 1));
+        }
+        group_in_windows(v, hs.gk, (size_t) 128 * bpw);
+    }
+    // ---- the blob: [mc bins][itx bins][paired tiles][paired residuals][comp first][comp second], 16-byte aligned segments
+    size_t total = 0;
+    auto place = [&](int id, size_t esz) { ck->seg[id].off = (uint32_t) total; ck->seg[id].n = (uint32_t) cnt[id]; total += (cnt[id] * esz + 15) & ~(size_t) 15; };
+    for (int b = 0; b < MC_BINS; b++) place(CK_MC + b, sizeof(McTile));
+    for (int b = 0; b < 19; b++) place(CK_ITX + b, sizeof(Dav1dHipItxTask));
+    for (int k = 0; k < 5; k++) place(CK_PTILE + k, sizeof(McTile));
+    for (int k = 0; k < 5; k++) place(CK_PTASK + k, sizeof(Dav1dHipItxTask));
+    place(CK_COMP, sizeof(Dav1dHipCompTask));
+    place(CK_COMP + 1, sizeof(Dav1dHipCompTask));
+    ck->used = total;
+    if (!total) { *out = ck; return 0; }
+    uint8_t *dst = place_blob ? place_blob(cookie, total, &ck->dev_off) : nullptr;
+    if (dst) {
+        ck->uploaded = true;                 // part of the twin: goes up with it
+    } else {
+        dst = ck->host = slab_get(c, total, &ck->cap);
+        if (!ck->host) { delete ck; return -ENOMEM; }
+    }
+    // ---- pass 2: cut and copy
+    McTile *mcur[MC_BINS];
+    for (int b = 0; b < MC_BINS; b++) mcur[b] = reinterpret_cast<McTile *>(dst + ck->seg[CK_MC + b].off);
+    Dav1dHipCompTask *ccur[2] = { reinterpret_cast<Dav1dHipCompTask *>(dst + ck->seg[CK_COMP].off), reinterpret_cast<Dav1dHipCompTask *>(dst + ck->seg[CK_COMP + 1].off) };
+    for (size_t i = 0; i < n_comp; i++) {
+        const Dav1dHipCompTask &k = comp[i];
+        if (k.kind <= DAV1D_HIP_COMP_WAVG && k.mask_off) {
+            const size_t a = (size_t) k.mask_off - 1;
+            if (role[a] == 3) continue;      // paired: below
+            McTile *&p = mcur[bin_of(k.w, k.h)];
+            p = cut_tiles(p, mc[a], k.kind == DAV1D_HIP_COMP_AVG ? MCT_AVG : MCT_WAVG, k.dst_off, &mc[a + 1], k.arg);
+        } else {
+            Dav1dHipCompTask *&p = ccur[second(k) ? 1 : 0];
+            *p++ = k;
+        }
+    }
+    for (size_t i = 0; i < n_mc; i++) {
+        const Dav1dHipMcTask &t = mc[i];
+        if (role[i]) continue;
+        McTile *&p = mcur[bin_of(t.w, t.h)];
+        p = cut_tiles(p, t, t.kind == DAV1D_HIP_MC_PUT ? MCT_PUT : t.kind == DAV1D_HIP_MC_PREP ? MCT_PREP : MCT_PUT_TMP, t.dst_off, nullptr, 0);
+    }
+    Dav1dHipItxTask *icur[19];
+    for (int b = 0; b < 19; b++) icur[b] = reinterpret_cast<Dav1dHipItxTask *>(dst + ck->seg[CK_ITX + b].off);
+    for (size_t i = 0; i < n_itx; i++)
+        if (!taken[i]) {
+            Dav1dHipItxTask *p = icur[itx[i].tx]++;
+            *p = itx[i];
+            itx_fill_prefix(*p);
+        }
+    for (int k = 0; k < 5; k++) {
+        McTile *pt = reinterpret_cast<McTile *>(dst + ck->seg[CK_PTILE + k].off);
+        Dav1dHipItxTask *pk = reinterpret_cast<Dav1dHipItxTask *>(dst + ck->seg[CK_PTASK + k].off);
+        for (const PairedBlock &b : hs.pb[k]) {
+            if (b.src >> 31) {
+                const Dav1dHipCompTask &q = comp[b.src & 0x7fffffffu];
+                const size_t a = (size_t) q.mask_off - 1;
+                pt = cut_tiles(pt, mc[a], q.kind == DAV1D_HIP_COMP_AVG ? MCT_AVG : MCT_WAVG, q.dst_off, &mc[a + 1], q.arg);
+            } else {
+                pt = cut_tiles(pt, mc[b.src], MCT_PUT, mc[b.src].dst_off, nullptr, 0);
+            }
+            *pk = itx[b.itx];
+            itx_fill_prefix(*pk);
+            pk++;
+        }
+    }
+    *out = ck;
+    return 0;
+}
+
 // Everything dav1d_hip_recon_list_create() does for a whole frame, for the tasks of one tile-sbrow.
 #ifdef CHUNK_PROF
 #include <time.h>
@@ -182,8 +404,13 @@ extern "C" void dav1d_hip_chunk_prof() { for (int i = 0; i < 14; i++) { fprintf(
 #endif
 int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHipPicture *geom, const Dav1dHipPicture *refs, int n_refs,
                           const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
-                          const Dav1dHipItxTask *itx, size_t n_itx, Dav1dHipChunkPlace place_blob, void *cookie, bool trusted)
+                          const Dav1dHipItxTask *itx, size_t n_itx, Dav1dHipChunkPlace place_blob, void *cookie, bool trusted, const uint16_t *itx_dep)
 {
+    // records of the library's own lister carry what the maps below would find (chunk_build_hinted); option chunk_order = 1 and
+    // chunk_hints = 0 keep the general preparation
+    if (trusted && (itx_dep || !n_itx) && !c->chunk_order && c->chunk_hints) {
+        return chunk_build_hinted(c, out, mc, n_mc, comp, n_comp, itx, n_itx, itx_dep, place_blob, cookie);
+    }
 #ifdef CHUNK_PROF
     uint64_t tp_ = cnow();
     cprof_n[0] += n_mc; cprof_n[1] += n_comp; cprof_n[2] += n_itx;

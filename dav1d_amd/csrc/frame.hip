@@ -472,18 +472,18 @@ size_t dav1d_hip_frame_coef_bytes(const Dav1dHipFrame *f) { return f ? f->carena
 // Thread-safe; the order between tile-sbrows is free: inter tasks of a frame write disjoint pixels, and every residual
 // is added after every prediction.
 static int submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
-                            const Dav1dHipItxTask *itx, size_t n_itx, bool trusted);
+                            const Dav1dHipItxTask *itx, size_t n_itx, bool trusted, const uint16_t *itx_dep = nullptr);
 int dav1d_hip_frame_submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
                                       const Dav1dHipItxTask *itx, size_t n_itx) {
     return submit_tile_sbrow(f, mc, n_mc, comp, n_comp, itx, n_itx, false);
 }
 // internal (host/lister.c): the same for records the library made itself — they are not validated a second time
 int dav1d_hip_frame_submit_tile_sbrow_own(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
-                                          const Dav1dHipItxTask *itx, size_t n_itx) {
-    return submit_tile_sbrow(f, mc, n_mc, comp, n_comp, itx, n_itx, true);
+                                          const Dav1dHipItxTask *itx, size_t n_itx, const uint16_t *itx_dep) {
+    return submit_tile_sbrow(f, mc, n_mc, comp, n_comp, itx, n_itx, true, itx_dep);
 }
 static int submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
-                            const Dav1dHipItxTask *itx, size_t n_itx, bool trusted) {
+                            const Dav1dHipItxTask *itx, size_t n_itx, bool trusted, const uint16_t *itx_dep) {
     if (!f || (!mc && n_mc) || (!comp && n_comp) || (!itx && n_itx)) return -EINVAL;
     if (!n_mc && !n_comp && !n_itx) return 0;
     if ((n_mc || n_comp) && !f->n_refs) return -EINVAL;
@@ -497,7 +497,7 @@ static int submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t 
         *dev_off = off;
         return fr->harena && off + sz <= fr->harena_cap && off + sz <= fr->arena_cap ? fr->harena + off : nullptr;
     };
-    const int rc = dav1d_hip_chunk_build(f->c, &ck, &f->cur, f->refs, f->n_refs, mc, n_mc, comp, n_comp, itx, n_itx, place, f, trusted);
+    const int rc = dav1d_hip_chunk_build(f->c, &ck, &f->cur, f->refs, f->n_refs, mc, n_mc, comp, n_comp, itx, n_itx, place, f, trusted, itx_dep);
     if (rc) return rc;
     // c->chunk_upload (no twin): up it goes on its own, while the other tile-sbrows are still being listed
     if (ck->used && ck->host && !f->harena && f->arena && ck->dev_off + ck->used <= f->arena_cap)
@@ -896,6 +896,14 @@ static int copy_picture(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Da
     return 0;
 }
 
+struct FrameTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    double ms[8];
+    FrameTrace() : on(getenv("DAV1D_HIP_TRACE_FRAME") != nullptr), t(std::chrono::steady_clock::now()) { for (double &v : ms) v = 0; }
+    void mark(int k) { if (!on) return; const auto n = std::chrono::steady_clock::now(); ms[k] += std::chrono::duration<double, std::milli>(n - t).count(); t = n; }
+};
+
 // Row-granular progress without banding the whole frame (the reference publishes f->sr_cur.progress[1] after the last filter of every
 // superblock row, src/thread_task.c:888-896; post_filters_pipelined() above follows every band through all three stages on three
 // streams and pays 70 % for it).  Here only the LAST stage of a frame tells where it is, and from INSIDE its two launches: the
@@ -911,6 +919,7 @@ static int frame_lr_banded(Dav1dHipFrame *f, const Dav1dHipPicture *out, const D
     const int band_h = 256, nb = (H + band_h - 1) / band_h;
     const size_t n = f->lr.size();
     if (nb < 2 || nb > 64 || !n) return dav1d_hip_lr_batch(c, out, in, lpf, f->lr.data(), n);
+    FrameTrace tr;
     if (!c->band_cnt) {
         if (hipMalloc((void **) &c->band_cnt, 128 * sizeof(uint32_t)) != hipSuccess) { c->band_cnt = nullptr; return -ENOMEM; }
         if (hipHostMalloc((void **) &c->band_flags, 64 * sizeof(uint32_t), 0) != hipSuccess) { c->band_flags = nullptr; return -ENOMEM; }
@@ -958,6 +967,7 @@ static int frame_lr_banded(Dav1dHipFrame *f, const Dav1dHipPicture *out, const D
     uint8_t *const devb = devb_buf.p;
     if (!devb) return -ENOMEM;
     Dav1dHipLrTask *const dev = reinterpret_cast<Dav1dHipLrTask *>(devb);
+    tr.mark(0);
     int rc = dav1d_hip_upload(c, dev, sorted.data(), n * sizeof(*dev));
     if (!rc) rc = dav1d_hip_upload(c, devb + o_waves, tail.data(), tail.size() * 4);
     if (!rc) rc = hip_rc(hipMemsetAsync(c->band_cnt, 0, 64 * sizeof(uint32_t), c->stream));
@@ -969,6 +979,7 @@ static int frame_lr_banded(Dav1dHipFrame *f, const Dav1dHipPicture *out, const D
     if (!rc) rc = hip_rc(hipEventRecord(c->ev_fork, c->stream));
     if (!rc) rc = dav1d_hip_launch_wiener_sig(&dp, &sp, &lp, out->bpc, dev, (int) nw, max_w, &sig, c->stream);
     if (!rc) rc = dav1d_hip_launch_sgr_sig(&dp, &sp, &lp, out->bpc, dev + nw, devb + o_waves, (int) n_waves, &sig, c->stream);
+    tr.mark(1);
     // the bands come through (roughly) in order; the last one is published with the frame (frame_run).  A band without tasks has
     // nothing to wait for beyond the bands before it.
     if (!rc) {
@@ -988,7 +999,11 @@ static int frame_lr_banded(Dav1dHipFrame *f, const Dav1dHipPicture *out, const D
             f->publish(first_y[b + 1], out);
         }
     }
+    tr.mark(2);
     (void) hipStreamSynchronize(c->stream);
+    tr.mark(3);
+    if (tr.on) fprintf(stderr, "frame_lr_banded: host lists %.3f  uploads + launches %.3f  bands published %.3f  tail sync %.3f ms (%zu tasks, %d bands)\n",
+                       tr.ms[0], tr.ms[1], tr.ms[2], tr.ms[3], n, nb);
     return rc;
 }
 
@@ -1035,13 +1050,6 @@ int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *ma
 } // extern "C"
 
 // DAV1D_HIP_TRACE_FRAME=1: where a frame's time on the ending thread goes (host wall clock incl. the waits it makes), one line per frame
-struct FrameTrace {
-    bool on;
-    std::chrono::steady_clock::time_point t;
-    double ms[8];
-    FrameTrace() : on(getenv("DAV1D_HIP_TRACE_FRAME") != nullptr), t(std::chrono::steady_clock::now()) { for (double &v : ms) v = 0; }
-    void mark(int k) { if (!on) return; const auto n = std::chrono::steady_clock::now(); ms[k] += std::chrono::duration<double, std::milli>(n - t).count(); t = n; }
-};
 
 static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask, Dav1dHipPicture *filtered, const Dav1dHipPicture *grain_out) {
     Dav1dHipContext *c = f->c;

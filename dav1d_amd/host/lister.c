@@ -28,7 +28,7 @@
 int dav1d_hip_frame_picture(const Dav1dHipFrame *f, Dav1dHipPicture *out);
 int dav1d_hip_frame_set_sb_deps(Dav1dHipFrame *f, uint32_t first, size_t n, const uint8_t *mask);
 int dav1d_hip_frame_submit_tile_sbrow_own(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
-                                          const Dav1dHipItxTask *itx, size_t n_itx);
+                                          const Dav1dHipItxTask *itx, size_t n_itx, const uint16_t *itx_dep);
 
 #define VEC(T) struct { T *p; size_t n, cap; }
 /* A vector that cannot grow hands out a scratch element and raises the calling thread's flag: the walk goes on writing into
@@ -36,7 +36,10 @@ int dav1d_hip_frame_submit_tile_sbrow_own(Dav1dHipFrame *f, const Dav1dHipMcTask
  * library errors are negative errno, never an abort of the host process). */
 static __thread int v_oom;
 static __thread uint64_t v_sink[16];          /* >= the largest task record */
-#define VPUSH(v, T) (((v).n == (v).cap && vgrow((void **) &(v).p, &(v).cap, sizeof(T))) ? (T *) (void *) v_sink : &(v).p[(v).n++])
+/* (the scratch is reached through a function of its own: as an operand of the conditional below, the thread-local address was
+ * looked up — a call of __tls_get_addr in a shared library — on EVERY push, 4 % of the walk) */
+static __attribute__((noinline, cold)) void *vsink(void) { return v_sink; }
+#define VPUSH(v, T) (((v).n == (v).cap && vgrow((void **) &(v).p, &(v).cap, sizeof(T))) ? (T *) vsink() : &(v).p[(v).n++])
 static int vgrow(void **p, size_t *cap, const size_t esz) {
     const size_t nc = *cap ? *cap * 2 : 256;
     void *q = realloc(*p, nc * esz);
@@ -86,6 +89,7 @@ typedef struct Out {
     VEC(Dav1dHipWarpTask) warp;
     VEC(Dav1dHipMcScaledTask) scaled;
     VEC(Dav1dHipItxTask) itx;                         /* step 0 */
+    VEC(uint16_t) itx_dep;                            /* per `itx` entry: the launches that predict under it (see Walk.bdep) */
     VEC(Dav1dHipIpredTask) ipred; VEC(uint16_t) ipred_step;
     VEC(Dav1dHipCompTask) blend;  VEC(uint16_t) blend_step;
     VEC(Dav1dHipItxTask) sitx;    VEC(uint16_t) sitx_step;
@@ -103,7 +107,20 @@ typedef struct Walk {
     /* what the latest dep_step() found in OTHER superblocks: the highest step among the intra-written cells it read there and which
      * neighbours they lie in (bit 0 left, 1 top-left, 2 top, 3 top-right); new_ipred() stamps it on the task it makes */
     unsigned xs_step, xs_mask;
+    /* What the walk knows about an inter block while it lists it and the chunk preparation (csrc/chunk.hip) would otherwise have to
+     * find again through maps of 4x4 cells: bdep[pl] = the launches that write the block's pixels of plane pl before its residuals
+     * (bit b: the prediction launch of tile shape b, bit 15: the compound / blend launch); cand[pl] = 1 + index in Out.mc of the ONE
+     * prediction (a PUT, or the first of the two PREPs of an averaged pair) that covers the block of plane pl, to be run in one wave
+     * with a transform block of exactly its square size (recon.hip) — emit_tx() writes 1 + that block's index into the prediction's
+     * `pad`.  An averaged pair names its first PREP in Dav1dHipCompTask.mask_off (1 + index; the second follows it). */
+    int hint_on;
+    unsigned bdep[3];
+    size_t cand[3];
+    uint32_t cand_off[3];
+    int cand_dim[3];
 } Walk;
+
+
 
 /* bytes of the prep (which = 0) / mask (1) arena for this walk: from its tile's window, which is refilled from the shared cursor
  * 128 KB at a time (what a tile leaves unused at the end of the frame is less than that) */
@@ -123,6 +140,11 @@ static uint64_t arena_alloc(Walk *w, const int which, uint64_t *cursor, const ui
 static int imin(const int a, const int b) { return a < b ? a : b; }
 static int imax(const int a, const int b) { return a > b ? a : b; }
 static int iclip(const int v, const int lo, const int hi) { return v < lo ? lo : v > hi ? hi : v; }
+/* bin of the <= 64x16 tiles a prediction block is cut into (csrc/capi.hip push_tiles): 3 * class(w) + class(h) */
+static int tile_bin(const int w_px, const int h_px) {
+    const int tw = imin(w_px, 64), th = imin(h_px, 16);
+    return (tw <= 4 ? 0 : tw <= 8 ? 1 : tw <= 16 ? 2 : tw <= 32 ? 3 : 4) * 3 + (th <= 4 ? 0 : th <= 8 ? 1 : 2);
+}
 
 static void note_step(Dav1dHipLister *l, const uint32_t s) {
     uint32_t cur = __atomic_load_n(&l->max_step, __ATOMIC_RELAXED);
@@ -278,7 +300,13 @@ static void emit_tx(Walk *w, const int pl, const int tx, const int x_px, const i
     k->tx = (uint8_t) tx;
     k->txtp = (uint8_t) txtp;
     k->plane = (uint8_t) pl;
-    if (step) *VPUSH(w->o->sitx_step, uint16_t) = (uint16_t) step;
+    if (step) { *VPUSH(w->o->sitx_step, uint16_t) = (uint16_t) step; return; }
+    *VPUSH(w->o->itx_dep, uint16_t) = (uint16_t) (w->hint_on ? w->bdep[pl] : 0xffff);
+    if (w->hint_on && w->cand[pl]) {
+        if (tx <= 4 && (4 << tx) == w->cand_dim[pl] && k->dst_off == w->cand_off[pl] && w->o->itx.n && k == &w->o->itx.p[w->o->itx.n - 1])
+            w->o->mc.p[w->cand[pl] - 1].pad = (uint32_t) w->o->itx.n;          /* 1 + index of k */
+        w->cand[pl] = 0;
+    }
 }
 
 /* read_coef_tree(), src/recon_tmpl.c:731-822: the luma transform blocks of one inter block in tree order */
@@ -497,6 +525,11 @@ static void emit_mc(Walk *w, const int kind, const uint32_t off, const int bw4, 
         k->kind = (uint8_t) kind;
         k->plane = (uint8_t) pl;
         k->ref = (uint8_t) ref;
+        if (w->hint_on && kind == DAV1D_HIP_MC_PUT) {
+            w->bdep[pl] |= 1u << tile_bin(k->w, k->h);
+            w->cand[pl] = k->w == k->h && k->w >= 4 ? w->o->mc.n : 0;
+            w->cand_off[pl] = off; w->cand_dim[pl] = k->w;
+        }
     } else {
         /* scaled reference, :990-1047 */
         const int orig_pos_y = (by * v_mul << 4) + mv.y * (1 << !ss_ver);
@@ -585,6 +618,7 @@ static void list_obmc(Walk *w, const uint32_t doff, const int bs, const int pl, 
                         a->u.p.ref[0], a->u.p.filter2d);
                 Dav1dHipCompTask *k = new_comp(w, DAV1D_HIP_COMP_BLEND_H, pl, doff + (uint32_t) (x * h_mul), h_mul * ow4, v_mul * oh4);
                 k->tmp1_off = (uint32_t) (ab / l->psz);
+                w->cand[pl] = 0; w->bdep[pl] |= 1u << 15;       /* prediction, blends, THEN the residual */
                 i++;
             }
             x += step4;
@@ -602,6 +636,7 @@ static void list_obmc(Walk *w, const uint32_t doff, const int bs, const int pl, 
                         lf->u.p.ref[0], lf->u.p.filter2d);
                 Dav1dHipCompTask *k = new_comp(w, DAV1D_HIP_COMP_BLEND_V, pl, doff + (uint32_t) (y * v_mul * l->stride[pl]), h_mul * ow4, v_mul * oh4);
                 k->tmp1_off = (uint32_t) (ab / l->psz);
+                w->cand[pl] = 0; w->bdep[pl] |= 1u << 15;
                 i++;
             }
             y += step4;
@@ -659,6 +694,8 @@ static void list_inter(Walk *w, const int bs, const Dav1dHipAv1Block *b, const i
     const uint32_t uvdst = has_chroma ? dst_off(l, 1, 4 * (bx >> ss_hor), 4 * (by >> ss_ver)) : 0;
     const int filter_2d = b->u.p.filter2d;
     unsigned step[3] = { 0, 0, 0 };                     /* wavefront step of the residuals per plane */
+    w->hint_on = 1;
+    for (int pl = 0; pl < 3; pl++) { w->bdep[pl] = 0; w->cand[pl] = 0; }
 
     if (b->u.p.comp_type == H_COMP_INTER_NONE) {
         const int ref = b->u.p.ref[0];
@@ -731,6 +768,7 @@ static void list_inter(Walk *w, const int bs, const Dav1dHipAv1Block *b, const i
             const int sh = pl && ss_hor, sv = pl && ss_ver;
             const int pw = bw4 * 4 >> sh, ph = bh4 * 4 >> sv;
             uint32_t tmp[2];
+            const size_t n0 = w->o->mc.n;
             for (int i = 0; i < 2; i++) {
                 const int ref = b->u.p.ref[i];
                 const uint64_t ab = arena_alloc(w, 0, &l->arena_bytes, (uint64_t) pw * ph * 2);
@@ -741,16 +779,27 @@ static void list_inter(Walk *w, const int bs, const Dav1dHipAv1Block *b, const i
                     emit_mc(w, DAV1D_HIP_MC_PREP, tmp[i], bw4, bh4, bx, by, pl, mv_of(b->u.p.u.m.mv[i]), ref, filter_2d);
             }
             const uint32_t doff = pl ? uvdst : ydst;
+            /* both halves plain translations of unscaled references: the pair can be predicted twice and averaged in registers */
+            const int plain = w->o->mc.n == n0 + 2;
             Dav1dHipCompTask *k;
             switch (b->u.p.comp_type) {
             case H_COMP_INTER_AVG:
-                k = new_comp(w, DAV1D_HIP_COMP_AVG, pl, doff, pw, ph);
-                k->tmp1_off = tmp[0]; k->tmp2_off = tmp[1];
-                break;
             case H_COMP_INTER_WEIGHTED_AVG:
-                k = new_comp(w, DAV1D_HIP_COMP_WAVG, pl, doff, pw, ph);
+                if (b->u.p.comp_type == H_COMP_INTER_AVG) {
+                    k = new_comp(w, DAV1D_HIP_COMP_AVG, pl, doff, pw, ph);
+                } else {
+                    k = new_comp(w, DAV1D_HIP_COMP_WAVG, pl, doff, pw, ph);
+                    k->arg = (int8_t) l->d.jnt_weights[b->u.p.ref[0]][b->u.p.ref[1]];
+                }
                 k->tmp1_off = tmp[0]; k->tmp2_off = tmp[1];
-                k->arg = (int8_t) l->d.jnt_weights[b->u.p.ref[0]][b->u.p.ref[1]];
+                if (plain) {
+                    k->mask_off = (uint32_t) n0 + 1;
+                    w->bdep[pl] |= 1u << tile_bin(pw, ph);
+                    w->cand[pl] = pw == ph && pw >= 4 ? n0 + 1 : 0;
+                    w->cand_off[pl] = doff; w->cand_dim[pl] = pw;
+                } else {
+                    w->bdep[pl] |= 1u << 15;
+                }
                 break;
             case H_COMP_INTER_SEG:
                 if (!pl) {
@@ -764,18 +813,21 @@ static void list_inter(Walk *w, const int bs, const Dav1dHipAv1Block *b, const i
                 }
                 k->tmp1_off = tmp[sign]; k->tmp2_off = tmp[!sign];
                 k->mask_off = mask_off;
+                w->bdep[pl] |= 1u << 15;
                 break;
             default: /* H_COMP_INTER_WEDGE */
                 k = new_comp(w, DAV1D_HIP_COMP_MASK, pl, doff, pw, ph);
                 k->tmp1_off = tmp[sign]; k->tmp2_off = tmp[!sign];
                 k->mask_off = pl ? hm->wedge[chr_layout_idx][bs - H_BS_32x32][sign][b->u.p.u.m.wedge_idx]
                                  : hm->wedge[0][bs - H_BS_32x32][0][b->u.p.u.m.wedge_idx];
+                w->bdep[pl] |= 1u << 15;
                 break;
             }
         }
     }
 
     list_inter_residuals(w, bs, b, bx, by, step);
+    w->hint_on = 0;
 }
 
 /* residuals of an inter (or intra-block-copy) block: per 64x64 of the block, the luma transform tree, then both chroma planes
@@ -1181,7 +1233,7 @@ static void out_free(void *p) {
     Out *o = (Out *) p;
     if (!o) return;
     free(o->smc.p); free(o->smc_step.p); free(o->pack);
-    free(o->mc.p); free(o->comp.p); free(o->warp.p); free(o->scaled.p); free(o->itx.p);
+    free(o->mc.p); free(o->comp.p); free(o->warp.p); free(o->scaled.p); free(o->itx.p); free(o->itx_dep.p);
     free(o->ipred.p); free(o->ipred_step.p); free(o->blend.p); free(o->blend_step.p); free(o->sitx.p); free(o->sitx_step.p);
     free(o);
 }
@@ -1195,7 +1247,7 @@ static Out *out_get(void) {
         out_tls = o;
         (void) pthread_setspecific(out_key, o);
     }
-    o->mc.n = o->comp.n = o->warp.n = o->scaled.n = o->itx.n = o->ipred.n = o->ipred_step.n = o->blend.n = o->blend_step.n = 0;
+    o->mc.n = o->comp.n = o->warp.n = o->scaled.n = o->itx.n = o->itx_dep.n = o->ipred.n = o->ipred_step.n = o->blend.n = o->blend_step.n = 0;
     o->sitx.n = o->sitx_step.n = o->smc.n = o->smc_step.n = 0;
     o->npack = 0;
     return o;
@@ -1211,6 +1263,8 @@ int dav1d_hip_lister_tile_sbrow(Dav1dHipLister *l, const int tile_row, const int
     Walk w;
     w.l = l; w.o = op; w.cur = cur; w.err = 0;
     w.seen_step = 0; w.xs_step = w.xs_mask = 0;
+    w.hint_on = 0;
+    for (int pl = 0; pl < 3; pl++) { w.bdep[pl] = 0; w.cand[pl] = 0; w.cand_off[pl] = 0; w.cand_dim[pl] = 0; }
     w.col_start = l->d.col_start_sb[tile_col] << sb_shift;
     w.col_end = imin(l->d.col_start_sb[tile_col + 1] << sb_shift, l->bw);
     w.row_start = l->d.row_start_sb[tile_row] << sb_shift;
@@ -1243,7 +1297,7 @@ int dav1d_hip_lister_tile_sbrow(Dav1dHipLister *l, const int tile_row, const int
         for (size_t i = 0; i < op->sitx.n; i++) op->sitx.p[i].cf_off += base;
     }
     PROF_T(t1);
-    if (!rc) rc = dav1d_hip_frame_submit_tile_sbrow_own(l->frame, op->mc.p, op->mc.n, op->comp.p, op->comp.n, op->itx.p, op->itx.n);
+    if (!rc) rc = dav1d_hip_frame_submit_tile_sbrow_own(l->frame, op->mc.p, op->mc.n, op->comp.p, op->comp.n, op->itx.p, op->itx.n, op->itx_dep.n == op->itx.n ? op->itx_dep.p : NULL);
     PROF_T(t2);
     PROF_ADD(0, t1 - t0); PROF_ADD(1, t2 - t1);
     if (!rc && op->warp.n) rc = dav1d_hip_frame_submit_warp(l->frame, op->warp.p, op->warp.n);
