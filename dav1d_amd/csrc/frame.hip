@@ -926,9 +926,17 @@ static int frame_lr_banded(Dav1dHipFrame *f, const Dav1dHipPicture *out, const D
         memset(c->band_flags, 0, 64 * sizeof(uint32_t));
     }
     // tasks: [Wiener, band by band][self-guided, band by band, each band's units sorted into rows]
-    std::vector<int> band(n);
-    std::vector<size_t> off(2 * nb + 1, 0);       // [kind * nb + band]
-    std::vector<int> first_y(nb + 1, H);
+    // (the lists live with the thread: vectors of this size come from mmap and are faulted in page by page on every call — most of
+    // the 0.14 ms this preparation took of a 2 ms frame)
+    static thread_local std::vector<int> band;
+    static thread_local std::vector<size_t> off;
+    static thread_local std::vector<int> first_y;
+    static thread_local std::vector<Dav1dHipLrTask> sorted;
+    static thread_local std::vector<uint32_t> tail, target;
+    static thread_local std::vector<size_t> pos;
+    band.resize(n);
+    off.assign(2 * nb + 1, 0);                    // [kind * nb + band]
+    first_y.assign(nb + 1, H);
     for (size_t i = 0; i < n; i++) {
         const Dav1dHipLrTask &t = f->lr[i];
         if (t.plane > 2 || t.edges > 15 || !t.w || t.w > 384 || !t.h || t.h > 64 || t.type > DAV1D_HIP_LR_SGR_MIX) return -EINVAL;
@@ -938,9 +946,9 @@ static int frame_lr_banded(Dav1dHipFrame *f, const Dav1dHipPicture *out, const D
         off[(t.type > DAV1D_HIP_LR_WIENER5) * nb + band[i] + 1]++;
     }
     for (int k = 0; k < 2 * nb; k++) off[k + 1] += off[k];
-    std::vector<Dav1dHipLrTask> sorted(n);
+    sorted.resize(n);
     {
-        std::vector<size_t> pos(off.begin(), off.end() - 1);
+        pos.assign(off.begin(), off.end() - 1);
         for (size_t i = 0; i < n; i++) {
             Dav1dHipLrTask &d = sorted[pos[(f->lr[i].type > DAV1D_HIP_LR_WIENER5) * nb + band[i]]++] = f->lr[i];
             d.pad = (uint8_t) band[i];
@@ -948,8 +956,8 @@ static int frame_lr_banded(Dav1dHipFrame *f, const Dav1dHipPicture *out, const D
     }
     for (int b = nb - 1; b >= 0; b--) first_y[b] = std::min(first_y[b], first_y[b + 1]);
     const size_t nw = off[nb];                     // Wiener tasks
-    std::vector<uint32_t> tail;                    // the wave descriptors, then the 64 band targets: one upload
-    std::vector<uint32_t> target(64, 0);
+    tail.clear();                                  // the wave descriptors, then the 64 band targets: one upload
+    target.assign(64, 0);
     int max_w = 0;
     for (size_t i = 0; i < nw; i++) { max_w = std::max(max_w, (int) sorted[i].w); target[sorted[i].pad] += (uint32_t) ((sorted[i].w + 63) / 64); }
     for (int b = 0; b < nb; b++) {
@@ -987,8 +995,8 @@ static int frame_lr_banded(Dav1dHipFrame *f, const Dav1dHipPicture *out, const D
         bool all_done = false, waited = false;
         for (int b = 0; b + 1 < nb; b++) {
             for (unsigned spin = 0; target[b] && flags[b] != seq && !all_done; spin++) {
-                if ((spin & 63) == 63) all_done = hipStreamQuery(c->stream) == hipSuccess;          // (also the way out should a launch have failed)
-                else std::this_thread::yield();
+                if ((spin & 4095) == 4095) all_done = hipStreamQuery(c->stream) == hipSuccess;      // (also the way out should a launch have failed)
+                else __builtin_ia32_pause();
             }
             if (all_done && flags[b] != seq && target[b]) break;
             // a band's flag says "the restoration workgroups of this band have written their pixels", which orders it behind the

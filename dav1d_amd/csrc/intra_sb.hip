@@ -26,6 +26,11 @@
 #include <atomic>
 #include <string.h>
 
+// workgroups of four waves a CU is asked to hold (register budget 512 / (4 x this) per lane; the LDS of a workgroup allows three)
+#ifndef SB_MIN_BLOCKS
+#define SB_MIN_BLOCKS 2
+#endif
+
 namespace {
 
 constexpr int sb_itx_lds_of(int tx) {
@@ -40,7 +45,7 @@ template <int NW> __device__ __forceinline__ uint32_t sb_next(const IntraUnit &u
 // records [r.first, r.first + r.n): the superblock's header, then its units sorted by (step, predictions first); grp = the unit's
 // group, groups are separated by workgroup barriers.
 template <typename pixel, typename coef, int SB_WAVES>
-__global__ __launch_bounds__(SB_WAVES * 64, 2) void intra_sb_kernel(const DevPlanes dst, const IntraUnit *__restrict__ units,
+__global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) void intra_sb_kernel(const DevPlanes dst, const IntraUnit *__restrict__ units,
                                                                      const SbRegion *__restrict__ regions, uint8_t *aux,
                                                                      const uint8_t *__restrict__ mask /* inter-intra masks (may be nullptr without such units) */,
                                                                      coef *__restrict__ cf, const int layout, const int bitdepth_max,

@@ -26,9 +26,12 @@ enum { LR_SEG = 64 };        // output rows per wave: the whole stripe (16-row s
 
 // this wave's pixels are out (written back as far as the device's memory: the per-XCD L2s do not see each other's lines otherwise), its
 // band's counter goes up, and whoever completes the band tells the host
+// (The pixels of a signalling launch leave through agent-scope stores — written through this XCD's L2 — so that "out" only takes waiting
+// for the wave's own stores.  A release fence here instead writes back EVERY dirty line of the XCD's L2, once per wave: measured at 8K
+// that was most of the 0.2 ms a frame with a listener cost more than one without.)
 __device__ __forceinline__ void band_done(const BandSignal &sg, const int band) {
     if (!sg.cnt) return;
-    dv::fence_release_agent();
+    dv::stores_done();
     if ((threadIdx.x & 63) == 0) {
         const unsigned old = atomicAdd(sg.cnt + band, 1u);
         if (old + 1 == sg.target[band]) {
@@ -115,7 +118,8 @@ __global__ __launch_bounds__(64) void wiener_kernel(const DevPlanes dst, const D
             int v = -round_offset;
 #pragma unroll
             for (int k = 0; k < 7; k++) v = dv::mad_i24(win[k], fv[k], v);       // win < 2^16 (clip_limit), 16-bit taps: the full-rate multiplier
-            if (active) d[(r - 3) * dst.stride[pl]] = (pixel) dv::clamp3((v + rounding_off_v) >> round_bits_v, 0, bitdepth_max);
+            const pixel px_out = (pixel) dv::clamp3((v + rounding_off_v) >> round_bits_v, 0, bitdepth_max);
+            if (active) { if (sig.cnt) dv::st_coherent(d + (r - 3) * dst.stride[pl], px_out); else d[(r - 3) * dst.stride[pl]] = px_out; }
         }
     }
     band_done(sig, t.pad);        // (the library's device copy carries the band in the record's spare byte)
@@ -274,7 +278,8 @@ __global__ __launch_bounds__(64) void sgr_kernel(const DevPlanes dst, const DevP
                 }
                 acc = dv::mad_i24(w0, t5, acc);
             }
-            d[y * dst.stride[pl]] = (pixel) dv::clamp3(px + ((acc + (1 << 10)) >> 11), 0, bitdepth_max);
+            const pixel px_out = (pixel) dv::clamp3(px + ((acc + (1 << 10)) >> 11), 0, bitdepth_max);
+            if (sig.cnt) dv::st_coherent(d + y * dst.stride[pl], px_out); else d[y * dst.stride[pl]] = px_out;
         }
         dv::wave_sync();
     }

@@ -4,7 +4,7 @@ import json, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 from dav1d_amd import api, e2e
 import lister_util as lu
-ctx = api.Context(0); ctx.backend = "hip"
+ctx = api.Context(0, lib_path=os.environ["DAV1D_HIP_LIB"]) if os.environ.get("DAV1D_HIP_LIB") else api.Context(0); ctx.backend = "hip"
 out = {}
 check = "--no-check" not in sys.argv
 for fine in (1, 0):
