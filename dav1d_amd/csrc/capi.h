@@ -39,6 +39,7 @@ struct Dav1dHipContext {
     int recon_pair_streams;     // side streams the paired launches of a recon list are dealt over (DAV1D_HIP_RECON_PAIR_STREAMS, 1 or 2)
     int ref_twin;               // tiled twins of reference pictures ($DAV1D_HIP_REF_TWIN): 0 never read, 1 (default) read when a picture has a valid
                                 // one (dav1d_hip_picture_retile), 2 also made for every picture of dav1d_hip_picture_alloc and by dav1d_hip_frame_end
+    bool cdef_rows;             // option cdef_rows (default 1) / $DAV1D_HIP_CDEF_ROWS: the filter lister hands over one record per unit row of a 64-pixel column and the device makes the unit records (cdef.hip cdef_expand_kernel)
     bool cdef_full_copy;        // option filter_full_copy / $DAV1D_HIP_FILTER_FULL_COPY=1: CDEF and restoration start from a copy of the whole picture (A/B aid)
     bool cdef_unit_kernel;      // $DAV1D_HIP_CDEF_UNIT=1 at open: one wave per 8x8 unit (the round-1 kernel) instead of strips; A/B aid
     // measurement aid: device time of the kernel launches of the most recent *_batch call (dav1d_hip_last_kernel_ms)
@@ -318,6 +319,8 @@ struct CdefGroup {
 // appends the groups of tasks[0 .. n) (indices offset by `base`) in list order; returns the number of RAW tasks met
 size_t dav1d_hip_cdef_make_groups(const Dav1dHipCdefTask *tasks, size_t n, size_t base, std::vector<CdefGroup> &out);
 bool dav1d_hip_cdef_strip_ok(const DevPlanes *dst, const DevPlanes *src, int bpc);
+extern "C" int dav1d_hip_launch_cdef_expand(const void *rows, int w64, int h8, int bw4, int bh4, int w8, Dav1dHipCdefTask *tasks, void *groups,
+                                            uint32_t *bitmap, void *stream);
 extern "C" int dav1d_hip_launch_cdef_fill_unlisted(const DevPlanes *dst, const DevPlanes *src, int bpc, int layout, const Dav1dHipCdefTask *tasks,
                                                    int n, uint32_t *bitmap, int w8, int h8, void *stream);
 extern "C" int dav1d_hip_launch_cdef_groups(const DevPlanes *dst, const DevPlanes *src, int bpc, int layout, const Dav1dHipCdefTask *tasks,

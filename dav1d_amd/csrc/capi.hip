@@ -55,6 +55,7 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     const char *cu = getenv("DAV1D_HIP_CDEF_UNIT");
     c->cdef_unit_kernel = cu && atoi(cu);
     c->cdef_full_copy = env_int("DAV1D_HIP_FILTER_FULL_COPY", 0) != 0;
+    c->cdef_rows = env_int("DAV1D_HIP_CDEF_ROWS", 1) != 0;
     const char *fg = getenv("DAV1D_HIP_FLOW_GROUPS");
     c->flow_groups = fg && atoi(fg) > 0 ? atoi(fg) : 512;
     const char *fm = getenv("DAV1D_HIP_FLOW_MODE");
@@ -175,6 +176,7 @@ int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value) {
     else if (!strcmp(name, "serial")) c->concurrent = !value;
     else if (!strcmp(name, "cdef_unit")) c->cdef_unit_kernel = value != 0;
     else if (!strcmp(name, "filter_full_copy")) c->cdef_full_copy = value != 0;
+    else if (!strcmp(name, "cdef_rows")) c->cdef_rows = value != 0;
     else if (!strcmp(name, "flow_groups")) c->flow_groups = value > 0 ? (int) value : c->flow_groups;
     else if (!strcmp(name, "flow_mode")) c->flow_mode = (int) value;
     else if (!strcmp(name, "flow_min_steps")) c->flow_min_steps = (int) value;

@@ -14,6 +14,7 @@
 #include <type_traits>
 #include "common.h"
 #include "capi.h"
+#include "cdef_rows.h"
 #include "av1_tables.h"
 
 namespace {
@@ -535,6 +536,7 @@ __global__ __launch_bounds__(64) void cdef_strip_kernel(const DevPlanes dst, con
     if (gi >= n_groups) return;
     const int lane = threadIdx.x;
     const CdefGroup g = groups[__builtin_amdgcn_readfirstlane(gi)];
+    if (!g.n) return;                 // (the slots of cdef_expand_kernel that hold no unit)
     const int bitdepth_min_8 = (32 - __clz(bitdepth_max)) - 8;
     const int edges = g.edges, span = g.span;
     const int x0 = g.bx0 * 8, y0 = g.by * 8;
@@ -736,14 +738,67 @@ extern "C" int dav1d_hip_launch_cdef_groups(const DevPlanes *dst, const DevPlane
     return hip_rc(hipGetLastError());
 }
 
-// bitmap: DEVICE, (w8 * h8 + 31) / 32 words, cleared here.  The same alignment conditions as the strip kernel (dav1d_hip_cdef_strip_ok).
+// The unit records of a frame, made on the device from one record per unit row of a 64-pixel column (cdef_rows.h): thread g = by8 * P + p
+// (P = pairs of 64-pixel columns) takes the up to 16 listed units of columns 2p, 2p + 1 in unit row by8 and writes them to tasks[16 g ..]
+// with groups[g] over them (n = 0: nothing there) — the arrays the host used to build, group and upload (518,400 records = 8 MB for
+// an 8K frame).  bitmap (or nullptr): the listed units are marked for cdef_fill_unlisted_kernel.
+__global__ __launch_bounds__(256) void cdef_expand_kernel(const Dav1dHipCdefRow *__restrict__ rows, const int w64, const int h8, const int bw4, const int bh4,
+                                                          const int w8, Dav1dHipCdefTask *__restrict__ tasks, CdefGroup *__restrict__ groups,
+                                                          uint32_t *__restrict__ bitmap)
+{
+    const int P = (w64 + 1) >> 1;
+    const int gi = blockIdx.x * 256 + threadIdx.x;
+    if (gi >= P * h8) return;
+    const int by = gi / P, px = gi - by * P;
+    Dav1dHipCdefRow r[2];
+    r[0] = rows[(size_t) by * w64 + 2 * px];
+    if (2 * px + 1 < w64) r[1] = rows[(size_t) by * w64 + 2 * px + 1]; else r[1].mask = 0;
+    const uint32_t m = (uint32_t) r[0].mask | (uint32_t) r[1].mask << 8;
+    CdefGroup g;
+    g.first = (uint32_t) gi * 16u; g.by = (uint16_t) by; g.n = (uint8_t) __builtin_popcount(m);
+    g.bx0 = 0; g.span = 0; g.edges = 0; g.pad = 0;
+    if (m) {
+        const int first = __builtin_ctz(m), last = 31 - __builtin_clz(m);
+        g.bx0 = (uint16_t) (16 * px + first); g.span = (uint8_t) (last - first + 1);
+        const int tb = (by > 0 ? DAV1D_HIP_CDEF_HAVE_TOP : 0) | (2 * by + 2 < bh4 ? DAV1D_HIP_CDEF_HAVE_BOTTOM : 0);
+        g.pad = r[first >> 3].flags;
+        g.edges = (uint8_t) (tb | (g.bx0 > 0 ? DAV1D_HIP_CDEF_HAVE_LEFT : 0) | (2 * (16 * px + last) + 2 < bw4 ? DAV1D_HIP_CDEF_HAVE_RIGHT : 0));
+        Dav1dHipCdefTask *t = tasks + (size_t) gi * 16;
+        for (uint32_t mm = m; mm; mm &= mm - 1) {
+            const int k = __builtin_ctz(mm), bx = 16 * px + k;
+            const Dav1dHipCdefRow &q = r[k >> 3];
+            Dav1dHipCdefTask o;
+            o.bx = (uint16_t) bx; o.by = (uint16_t) by;
+            o.y_pri = q.y_pri; o.y_sec = q.y_sec; o.uv_pri = q.uv_pri; o.uv_sec = q.uv_sec;
+            o.edges = (uint8_t) (tb | (bx > 0 ? DAV1D_HIP_CDEF_HAVE_LEFT : 0) | (2 * bx + 2 < bw4 ? DAV1D_HIP_CDEF_HAVE_RIGHT : 0));
+            o.flags = q.flags;
+            o.plane = 0; o.dir = 0; o.pad[0] = o.pad[1] = o.pad[2] = o.pad[3] = 0;
+            *t++ = o;
+            if (bitmap) { const int idx = by * w8 + bx; atomicOr(&bitmap[idx >> 5], 1u << (idx & 31)); }
+        }
+    }
+    groups[gi] = g;
+}
+
+extern "C" int dav1d_hip_launch_cdef_expand(const void *rows, int w64, int h8, int bw4, int bh4, int w8, Dav1dHipCdefTask *tasks, void *groups,
+                                            uint32_t *bitmap, void *stream)
+{
+    const int n = ((w64 + 1) >> 1) * h8;
+    if (n <= 0) return 0;
+    if (bitmap && hipMemsetAsync(bitmap, 0, (((size_t) w8 * h8 + 31) / 32) * 4, (hipStream_t) stream) != hipSuccess) return hip_rc(hipGetLastError());
+    hipLaunchKernelGGL(cdef_expand_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t) stream, (const Dav1dHipCdefRow *) rows, w64, h8, bw4, bh4, w8,
+                       tasks, (CdefGroup *) groups, bitmap);
+    return hip_rc(hipGetLastError());
+}
+
+// bitmap: DEVICE, (w8 * h8 + 31) / 32 words, cleared here (tasks == nullptr: marked already, by cdef_expand_kernel).  The same alignment conditions as the strip kernel (dav1d_hip_cdef_strip_ok).
 extern "C" int dav1d_hip_launch_cdef_fill_unlisted(const DevPlanes *dst, const DevPlanes *src, int bpc, int layout, const Dav1dHipCdefTask *tasks,
                                                    int n, uint32_t *bitmap, int w8, int h8, void *stream)
 {
     if (w8 <= 0 || h8 <= 0) return 0;
     const size_t words = ((size_t) w8 * h8 + 31) / 32;
-    if (hipMemsetAsync(bitmap, 0, words * 4, (hipStream_t) stream) != hipSuccess) return hip_rc(hipGetLastError());
-    if (n > 0) hipLaunchKernelGGL(cdef_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t) stream, tasks, n, bitmap, w8);
+    if (tasks && hipMemsetAsync(bitmap, 0, words * 4, (hipStream_t) stream) != hipSuccess) return hip_rc(hipGetLastError());
+    if (tasks && n > 0) hipLaunchKernelGGL(cdef_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t) stream, tasks, n, bitmap, w8);
     const dim3 grid((w8 + 31) / 32, h8);
     if (bpc == 8) hipLaunchKernelGGL((cdef_fill_unlisted_kernel<uint8_t>), grid, dim3(256), 0, (hipStream_t) stream, *dst, *src, bitmap, w8, layout);
     else hipLaunchKernelGGL((cdef_fill_unlisted_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t) stream, *dst, *src, bitmap, w8, layout);

@@ -6,6 +6,7 @@
 // Out-of-place stages land in pictures the frame owns; host code only: every kernel is reached through the batch API.
 #include "capi.h"
 #include <chrono>
+#include "cdef_rows.h"
 #include "chunk.h"
 #include <string.h>
 #include <stdlib.h>
@@ -93,6 +94,13 @@ struct Dav1dHipFrame {
         Dav1dHipLrTask *lr; size_t n_lr;
     };
     std::vector<FilterPiece> filter_pieces;
+    // CDEF as one record per unit row of a 64-pixel column (cdef_rows.h), written by the filter lister's threads straight into this
+    // pinned table and cut into unit records on the device (cdef.hip cdef_expand_kernel); state: 0 not asked yet, 1 in use, -1 refused
+    Dav1dHipCdefRow *cdef_rows = nullptr;
+    size_t cdef_rows_cap = 0;
+    int cdef_rows_state = 0, cdef_w64 = 0, cdef_h8 = 0;
+    bool cdef_rows_dirty = false;
+    std::atomic<size_t> cdef_row_units{0};
     const uint8_t *lvl;
     ptrdiff_t b4_stride;
     uint8_t lut_e[64], lut_i[64];
@@ -713,8 +721,63 @@ int dav1d_hip_frame_submit_filter_sbrow(Dav1dHipFrame *f, const Dav1dHipLfTask *
     return rc;
 }
 
+// internal (host/filter_lister.c): the frame's table of CDEF unit rows, or nullptr when this frame takes unit records
+extern "C" Dav1dHipCdefRow *dav1d_hip_frame_cdef_rows(Dav1dHipFrame *f, int *stride) {
+    if (!f) return nullptr;
+    std::lock_guard<std::mutex> lk(f->mtx);
+    if (!f->cdef_rows_state) {
+        Dav1dHipContext *c = f->c;
+        const DevPlanes cur = dev_planes(&f->cur);
+        f->cdef_rows_state = -1;
+        if (c->cdef_rows && c->post_bands < 2 && !c->cdef_unit_kernel && dav1d_hip_cdef_strip_ok(&cur, &cur, f->cur.bpc)) {
+            f->cdef_w64 = (f->cur.p[0].w + 63) >> 6; f->cdef_h8 = (f->cur.p[0].h + 7) >> 3;
+            const size_t bytes = (size_t) f->cdef_w64 * f->cdef_h8 * sizeof(Dav1dHipCdefRow);
+            f->cdef_rows = reinterpret_cast<Dav1dHipCdefRow *>(dav1d_hip_slab_get(c, bytes, &f->cdef_rows_cap));
+            if (f->cdef_rows) { memset(f->cdef_rows, 0, bytes); f->cdef_rows_state = 1; }
+        }
+    }
+    if (f->cdef_rows_state != 1) return nullptr;
+    if (f->cdef_rows_dirty) { memset(f->cdef_rows, 0, (size_t) f->cdef_w64 * f->cdef_h8 * sizeof(Dav1dHipCdefRow)); f->cdef_rows_dirty = false; }
+    *stride = f->cdef_w64;
+    return f->cdef_rows;
+}
+extern "C" void dav1d_hip_frame_cdef_rows_add(Dav1dHipFrame *f, size_t n_units) { if (f) f->cdef_row_units.fetch_add(n_units); }
+
+// the table as unit records, on the host (the routes that work on merged task lists; mixed submissions): a piece like any other
+static int frame_cdef_rows_to_piece(Dav1dHipFrame *f) {
+    const size_t n = f->cdef_row_units.load();
+    if (f->cdef_rows_state != 1 || !n) return 0;
+    Dav1dHipCdefTask *t = (Dav1dHipCdefTask *) malloc(n * sizeof(*t));
+    if (!t) return -ENOMEM;
+    const int bw4 = 2 * ((f->cur.p[0].w + 7) >> 3), bh4 = 2 * ((f->cur.p[0].h + 7) >> 3);      // f->bw, f->bh of the reference: whole 8x8 blocks
+    size_t k = 0;
+    for (int by = 0; by < f->cdef_h8; by++)
+        for (int sbx = 0; sbx < f->cdef_w64; sbx++) {
+            const Dav1dHipCdefRow &q = f->cdef_rows[(size_t) by * f->cdef_w64 + sbx];
+            for (unsigned m = q.mask; m && k < n; m &= m - 1) {
+                const int bx = 8 * sbx + __builtin_ctz(m);
+                Dav1dHipCdefTask &o = t[k++];
+                memset(&o, 0, sizeof(o));
+                o.bx = (uint16_t) bx; o.by = (uint16_t) by;
+                o.y_pri = q.y_pri; o.y_sec = q.y_sec; o.uv_pri = q.uv_pri; o.uv_sec = q.uv_sec;
+                o.flags = q.flags;
+                o.edges = (uint8_t) ((bx > 0 ? DAV1D_HIP_CDEF_HAVE_LEFT : 0) | (2 * bx + 2 < bw4 ? DAV1D_HIP_CDEF_HAVE_RIGHT : 0) |
+                                     (by > 0 ? DAV1D_HIP_CDEF_HAVE_TOP : 0) | (2 * by + 2 < bh4 ? DAV1D_HIP_CDEF_HAVE_BOTTOM : 0));
+            }
+        }
+    Dav1dHipFrame::FilterPiece p = { nullptr, 0, 0, t, k, 0, nullptr, nullptr, 0 };
+    p.groups = new (std::nothrow) std::vector<CdefGroup>();
+    if (!p.groups) { free(t); return -ENOMEM; }
+    p.n_raw = dav1d_hip_cdef_make_groups(t, k, 0, *p.groups);
+    f->filter_pieces.push_back(p);
+    f->cdef_row_units.store(0);
+    memset(f->cdef_rows, 0, (size_t) f->cdef_w64 * f->cdef_h8 * sizeof(Dav1dHipCdefRow));
+    return 0;
+}
+
 // the pieces -> f->lf / f->cdef / f->lr (once, at frame end; submission order)
 static void frame_merge_filter_pieces(Dav1dHipFrame *f) {
+    (void) frame_cdef_rows_to_piece(f);
     if (f->filter_pieces.empty()) return;
     size_t a = f->lf.size(), b = f->cdef.size(), d = f->lr.size();
     for (const Dav1dHipFrame::FilterPiece &p : f->filter_pieces) { a += p.n_lf; b += p.n_cdef; d += p.n_lr; }
@@ -738,6 +801,13 @@ static int copy_unrestored_planes(Dav1dHipContext *c, const Dav1dHipPicture *dst
 static int frame_filters_from_pieces(Dav1dHipFrame *f, bool *did_cdef) {
     Dav1dHipContext *c = f->c;
     *did_cdef = false;
+    // CDEF came as unit rows: expanded on the device below — unless unit records were submitted as well (one list then, made here)
+    bool rows = f->cdef_rows_state == 1 && f->cdef_row_units.load() > 0;
+    if (rows) {
+        bool mixed = false;
+        for (const Dav1dHipFrame::FilterPiece &p : f->filter_pieces) mixed |= p.n_cdef != 0;
+        if (mixed) { const int rc = frame_cdef_rows_to_piece(f); if (rc) return rc; rows = false; }
+    }
     size_t n_lf = 0, n_lf0 = 0, n_cdef = 0, n_groups = 0, n_raw = 0;
     for (const Dav1dHipFrame::FilterPiece &p : f->filter_pieces) {
         n_lf += p.n_lf; n_lf0 += p.n_lf0; n_cdef += p.n_cdef; n_raw += p.n_raw;
@@ -766,7 +836,34 @@ static int frame_filters_from_pieces(Dav1dHipFrame *f, bool *did_cdef) {
         dav1d_hip_slab_put(c, reinterpret_cast<uint8_t *>(host), cap);
         if (rc) return rc;
     }
-    if (n_cdef) {
+    if (rows) {
+        rc = frame_tmp(f, 0);
+        if (rc) return rc;
+        const DevPlanes t0 = dev_planes(&f->tmp[0]);
+        const int w64 = f->cdef_w64, h8 = f->cdef_h8, w8 = (f->cur.p[0].w + 7) >> 3;
+        const size_t n_units = f->cdef_row_units.load(), n_slots = (size_t) ((w64 + 1) >> 1) * h8;
+        const bool covered = !c->cdef_full_copy && n_units == (size_t) w8 * h8;
+        if (c->cdef_full_copy) rc = copy_picture(c, &f->tmp[0], &f->cur);
+        if (rc) return rc;
+        const size_t rb = ((size_t) w64 * h8 * sizeof(Dav1dHipCdefRow) + 255) & ~(size_t) 255, tb = n_slots * 16 * sizeof(Dav1dHipCdefTask);
+        const size_t gb = (n_slots * sizeof(CdefGroup) + 255) & ~(size_t) 255;
+        const size_t bm_bytes = covered || c->cdef_full_copy ? 0 : (((size_t) w8 * h8 + 31) / 32 * 4 + 255) & ~(size_t) 255;
+        TaskBuf dev_buf(c, rb + tb + gb + bm_bytes + 256);
+        uint8_t *const dev = dev_buf.p;
+        if (!dev) return -ENOMEM;
+        rc = dav1d_hip_upload(c, dev, f->cdef_rows, (size_t) w64 * h8 * sizeof(Dav1dHipCdefRow));
+        Dav1dHipCdefTask *const d_tasks = reinterpret_cast<Dav1dHipCdefTask *>(dev + rb);
+        uint32_t *const d_bm = bm_bytes ? reinterpret_cast<uint32_t *>(dev + rb + tb + gb) : nullptr;
+        if (!rc) rc = dav1d_hip_launch_cdef_expand(dev, w64, h8, 2 * w8, 2 * h8, w8, d_tasks, dev + rb + tb, d_bm, c->stream);
+        if (!rc && d_bm) rc = dav1d_hip_launch_cdef_fill_unlisted(&t0, &cur, f->cur.bpc, f->cur.layout, nullptr, 0, d_bm, w8, h8, c->stream);
+        if (!rc) rc = dav1d_hip_launch_cdef_groups(&t0, &cur, f->cur.bpc, f->cur.layout, d_tasks, reinterpret_cast<const CdefGroup *>(dev + rb + tb), (int) n_slots,
+                                                   f->cdef_damping, nullptr, c->stream);
+        (void) hipStreamSynchronize(c->stream);
+        f->cdef_row_units.store(0);              // consumed, like the pieces; the table is wiped before anybody writes to it again
+        f->cdef_rows_dirty = true;
+        if (rc) return rc;
+        *did_cdef = true;
+    } else if (n_cdef) {
         rc = frame_tmp(f, 0);
         if (rc) return rc;
         const DevPlanes t0 = dev_planes(&f->tmp[0]);
@@ -1325,7 +1422,7 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
     if (piped < 0) return piped;
     if (piped == 1) {        // stage by stage
         last = &f->cur;
-        if (!rc && !f->filter_pieces.empty()) {
+        if (!rc && (!f->filter_pieces.empty() || (f->cdef_rows_state == 1 && f->cdef_row_units.load() > 0))) {
             bool did_cdef = false;
             rc = frame_filters_from_pieces(f, &did_cdef);
             if (did_cdef) last = &f->tmp[0];
@@ -1499,6 +1596,7 @@ void dav1d_hip_frame_destroy(Dav1dHipFrame *f) {
     for (Dav1dHipChunk *ck : f->chunks) { ck->release(f->c); delete ck; }
     for (Dav1dHipFrame::StepChunk *sc : f->step_chunks) delete sc;
     for (Dav1dHipFrame::FilterPiece &p : f->filter_pieces) { free(p.lf); free(p.cdef); free(p.lr); delete p.groups; }
+    if (f->cdef_rows) dav1d_hip_slab_put(f->c, reinterpret_cast<uint8_t *>(f->cdef_rows), f->cdef_rows_cap);
     if (f->harena) dav1d_hip_slab_put(f->c, f->harena, f->harena_cap);
     if (f->huarena) dav1d_hip_slab_put(f->c, f->huarena, f->huarena_cap);
     if (f->hcarena) dav1d_hip_slab_put(f->c, f->hcarena, f->hcarena_cap);

@@ -34,15 +34,22 @@ namespace {
 
 // one tile shape per launch: workgroup b of the XCD-chunked order handles tiles [b * G, b * G + G)
 // TILED: the references are read through their tiled twins (refs.r[].data point there; mc_body.h)
+// MC_WAVES waves to a workgroup, each with a group of tiles and LDS of its own (they never meet): a launch of an 8K frame's 4x4 tiles is
+// 20,000 groups, and what bounds it is how fast workgroups are handed out, not how many fit
+#ifndef MC_WAVES
+#define MC_WAVES 1
+#endif
 template <int TW, int TH, typename pixel, bool TILED>
-__global__ __launch_bounds__(64) void mc_kernel(const DevPlanes dst, const RefSet refs, const McTile *__restrict__ tiles,
+__global__ __launch_bounds__(64 * MC_WAVES) void mc_kernel(const DevPlanes dst, const RefSet refs, const McTile *__restrict__ tiles,
                                                 const int n, int16_t *__restrict__ prep, const int bitdepth_max)
 {
     constexpr int G = 64 / mc_cmin(64, TW * TH / 4);
-    __shared__ uint4 smem[(mc_lds_bytes<TW, TH, TILED>() + 15) / 16];
-    const int t0 = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x) * G;
+    constexpr int SMEM_V = (mc_lds_bytes<TW, TH, TILED>() + 15) / 16;
+    __shared__ uint4 smem[MC_WAVES][SMEM_V];
+    const int wv = MC_WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
+    const int t0 = ((int) dv::xcd_chunk_id(blockIdx.x, gridDim.x) * MC_WAVES + wv) * G;
     if (t0 >= n) return;
-    mc_body<TW, TH, pixel, false, TILED>(dst, refs, tiles, t0, dv::imin(G, n - t0), prep, bitdepth_max, smem);
+    mc_body<TW, TH, pixel, false, TILED>(dst, refs, tiles, t0, dv::imin(G, n - t0), prep, bitdepth_max, smem[wv]);
 }
 
 // TILED references and the picture's own tiled twin written along with the raster planes (mc_body.h, TWIN)
@@ -103,7 +110,7 @@ hipError_t launch_cls(const int cls, const DevPlanes &dst, const RefSet &refs, c
 #define CASE(C, TW, TH) case C: { \
         constexpr int lpt = mc_cmin(64, TW * TH / 4); \
         constexpr int g = 64 / lpt; \
-        hipLaunchKernelGGL((mc_kernel<TW, TH, pixel, TILED>), dim3((n + g - 1) / g), dim3(64), 0, stream, \
+        hipLaunchKernelGGL((mc_kernel<TW, TH, pixel, TILED>), dim3(((n + g - 1) / g + MC_WAVES - 1) / MC_WAVES), dim3(64 * MC_WAVES), 0, stream, \
                            dst, refs, tiles, n, prep, bitdepth_max); \
         break; }
     // class = 3 * wclass + hclass, widths 4 8 16 32 64, heights 4 8 16

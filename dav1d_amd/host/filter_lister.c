@@ -6,6 +6,7 @@
  * parameters, is restated.  Plain C99. */
 #include "av1_host.h"
 #include "lister_priv.h"
+#include "../csrc/cdef_rows.h"
 #include <errno.h>
 #include <pthread.h>
 #include <stdlib.h>
@@ -137,6 +138,10 @@ static void list_cdef(const ListerGeo *g, const Dav1dHipFilterDesc *fd, FOut *o,
     const int sbsz = g->sb128 ? 32 : 16, bd8 = g->bpc - 8;
     const int sb128w = (g->bw + 31) >> 5;
     const int start = sby * sbsz, end = imin(start + sbsz, g->bh);
+    /* the frame's table of unit rows (NULL: the frame wants unit records) */
+    int rows_stride = 0;
+    size_t n_units = 0;
+    Dav1dHipCdefRow *const rows = dav1d_hip_frame_cdef_rows(g->frame, &rows_stride);
     for (int by = start; by < end; by += 2) {
         const Dav1dHipAv1Filter *const row = fd->lf_mask + (size_t) (by >> 5) * sb128w;
         const int by_idx = (by & 30) >> 1;
@@ -157,6 +162,21 @@ static void list_cdef(const ListerGeo *g, const Dav1dHipFilterDesc *fd, FOut *o,
             const int y_lvl = fd->cdef_y_strength[cdef_idx], uv_lvl = fd->cdef_uv_strength[cdef_idx];
             int y_sec = y_lvl & 3, uv_sec = uv_lvl & 3;
             y_sec += y_sec == 3; uv_sec += uv_sec == 3;
+            if (rows) {
+                /* one record for the eight units: the device cuts it into unit records (cdef.hip cdef_expand_kernel) */
+                unsigned mask = 0;
+                for (int u = 0, bx = sbx * 16; u < 8 && bx < g->bw; u++, bx += 2)
+                    if (noskip & (3u << (bx & 30))) mask |= 1u << u;
+                if (!mask) continue;
+                Dav1dHipCdefRow *k = &rows[(size_t) (by >> 1) * rows_stride + sbx];
+                k->y_pri = (uint8_t) ((y_lvl >> 2) << bd8); k->y_sec = (uint8_t) (y_sec << bd8);
+                k->uv_pri = (uint8_t) ((uv_lvl >> 2) << bd8); k->uv_sec = (uint8_t) (uv_sec << bd8);
+                k->flags = (uint8_t) rep;
+                k->pad = 0;
+                k->mask = (uint8_t) mask;
+                n_units += (size_t) __builtin_popcount(mask);
+                continue;
+            }
             for (int bx = sbx * 16; bx < imin((sbx + 1) * 16, g->bw); bx += 2) {
                 if (!(noskip & (3u << (bx & 30)))) continue;
                 Dav1dHipCdefTask *k = VPUSH(o->cdef, Dav1dHipCdefTask);
@@ -170,6 +190,7 @@ static void list_cdef(const ListerGeo *g, const Dav1dHipFilterDesc *fd, FOut *o,
             }
         }
     }
+    if (rows && n_units) dav1d_hip_frame_cdef_rows_add(g->frame, n_units);
 }
 
 /* lr_stripe, src/lr_apply_tmpl.c:36-97 */

@@ -15,6 +15,12 @@ void dav1d_hip_lister_geo(const Dav1dHipLister *l, ListerGeo *out);
 /* frame.hip: filter tasks handed over as malloc'ed arrays the frame frees (no copy under the frame's lock) */
 int dav1d_hip_frame_submit_filter_owned(Dav1dHipFrame *f, Dav1dHipLfTask *lf, size_t n_lf, Dav1dHipCdefTask *cdef, size_t n_cdef,
                                         Dav1dHipLrTask *lr, size_t n_lr);
+/* frame.hip: the frame's dense table of CDEF unit rows ([by8 * stride + 64-pixel column], cdef_rows.h; zeroed) for the filter lister to
+ * fill in — every entry by one thread — or NULL when the frame takes unit records (banded post filters, unaligned planes, option
+ * cdef_rows 0); _add: so many units were marked in it. */
+struct Dav1dHipCdefRow;
+struct Dav1dHipCdefRow *dav1d_hip_frame_cdef_rows(Dav1dHipFrame *f, int *stride);
+void dav1d_hip_frame_cdef_rows_add(Dav1dHipFrame *f, size_t n_units);
 /* lister.c: fn(arg) on n threads at once — the caller and n - 1 threads of a pool the library keeps (created on first use, parked on
  * a condition variable between jobs; one job at a time per process).  Starting 63 threads per frame took the caller a millisecond. */
 void dav1d_hip_host_pool_run(void *(*fn)(void *), void *arg, int n);

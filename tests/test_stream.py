@@ -112,6 +112,14 @@ def test_filters_over_a_full_copy_give_the_same_pictures(ctx, monkeypatch):
         run_seed(ctx, seed, n_frames=5)
 
 
+def test_cdef_from_unit_records_gives_the_same_pictures(ctx, monkeypatch):
+    """by default the filter lister hands CDEF over as one record per unit row of a 64-pixel column and the device makes the unit records
+    (cdef.hip cdef_expand_kernel); DAV1D_HIP_CDEF_ROWS=0 keeps the host-made unit records: both are dav1d's pictures"""
+    monkeypatch.setenv("DAV1D_HIP_CDEF_ROWS", "0")
+    for seed in (5, 12):
+        run_seed(ctx, seed, n_frames=5)
+
+
 @pytest.mark.gpu
 def test_sweep_of_streams_on_the_gpu():
     """>= 200 seeds over 8 / 10 / 12 bit x 4:0:0 / 4:2:0 / 4:2:2 / 4:4:4 x 64- / 128-pixel superblocks x 1 - 4 tile columns / rows
