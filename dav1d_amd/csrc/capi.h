@@ -292,18 +292,23 @@ struct SbSort {
     std::vector<uint32_t> pos, key;                 // per unit: its record in the output, its (step, kind) key
     std::vector<SbPart> parts;                      // per superblock: number, its HEADER record in the output, its units (they follow the header)
     size_t n_records;                               // units + superblocks
+    std::vector<uint64_t> copy_deps;                // intra block copies: (superblock << 32 | superblock its source window lies in), other superblocks only
 };
 int dav1d_hip_sbw_prepare(std::vector<IntraUnit> &units, const std::vector<uint32_t> &ua_end, const std::vector<uint32_t> &ub_end,
                           const SbTiling &tl, const int strides[3], int ss_hor, int ss_ver, SbSort &st);
 void dav1d_hip_sbw_emit(const std::vector<IntraUnit> &units, const SbSort &st, IntraUnit *out);
-int dav1d_hip_sbw_levels(const SbTiling &tl, const uint32_t *sbs, size_t n, const uint8_t *dep, std::vector<int> &level_of_sb, std::vector<uint32_t> &level);
+// extra (or nullptr): further (superblock << 32 | superblock it waits for) pairs, sorted — the sources of intra block copies
+int dav1d_hip_sbw_levels(const SbTiling &tl, const uint32_t *sbs, size_t n, const uint8_t *dep, std::vector<int> &level_of_sb, std::vector<uint32_t> &level,
+                         const std::vector<uint64_t> *extra = nullptr);
+// where (with flags; DEVICE, one word per superblock of the frame, raster): the superblock's place in `regions` or SB_NONE; sbw: superblocks per row
 extern "C" int dav1d_hip_launch_intra_sb(const DevPlanes *dst, int bpc, int layout, const IntraUnit *units, const SbRegion *regions, int n_regions,
-                                         uint8_t *aux, const uint8_t *mask, void *coef, int waves, int sb_log2, int lds, uint32_t *flags, void *stream);
+                                         uint8_t *aux, const uint8_t *mask, void *coef, int waves, int sb_log2, int lds, uint32_t *flags, void *stream,
+                                         const uint32_t *where = nullptr, int sbw = 0);
 // regions sorted by level + where each level starts, from the parts of any number of unit arrays laid end to end (base[k] = where
 // array k starts): host-side plan of a frame's launches
-struct SbPlan { std::vector<SbRegion> regions; std::vector<uint32_t> level_start; /* n_levels + 1 */ };
+struct SbPlan { std::vector<SbRegion> regions; std::vector<uint32_t> level_start; /* n_levels + 1 */ std::vector<uint32_t> where; /* superblock -> its region */ };
 int dav1d_hip_sbw_plan(const SbTiling &tl, const std::vector<const std::vector<SbPart> *> &parts, const std::vector<size_t> &base, const uint8_t *dep,
-                       SbPlan &plan);
+                       SbPlan &plan, const std::vector<uint64_t> *extra = nullptr);
 
 // raw_only: tasks without the RAW flag are left alone (they are run by groups, below)
 extern "C" int dav1d_hip_launch_cdef(const DevPlanes *dst, const DevPlanes *src, int bpc, int layout,

@@ -1278,7 +1278,8 @@ extern "C" int dav1d_hip_lf_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst
 static int ipred_tasks_valid(const Dav1dHipIpredTask *tasks, size_t n, const uint8_t *aux) {
     for (size_t i = 0; i < n; i++) {
         const Dav1dHipIpredTask &t = tasks[i];
-        if (t.plane > 2 || t.kind > DAV1D_HIP_IPRED_PRED_TMP || t.mode > 13 || !t.tw || !t.th || t.tw > 16 || t.th > 16) return -EINVAL;
+        if (t.plane > 2 || t.kind > DAV1D_HIP_IPRED_COPY || t.mode > 13 || !t.tw || !t.th || t.tw > 16 || t.th > 16) return -EINVAL;
+        if (t.kind == DAV1D_HIP_IPRED_COPY) { if ((t.pal[2] & 0xf0f0) != 0) return -EINVAL; continue; }
         if (t.kind >= DAV1D_HIP_IPRED_PAL && t.kind != DAV1D_HIP_IPRED_PRED_TMP && !aux) return -EINVAL;
         if (t.kind == DAV1D_HIP_IPRED_PRED_TMP && (t.tw > 8 || t.th > 8 || t.mode > 12)) return -EINVAL;
         const bool cfl = t.kind == DAV1D_HIP_IPRED_CFL || t.kind >= DAV1D_HIP_IPRED_DSP_CFL_AC;
@@ -1342,7 +1343,7 @@ extern "C" int dav1d_hip_ipred_list_create(Dav1dHipContext *c, Dav1dHipIpredList
     l->dev = nullptr;
     l->needs_aux = l->needs_tmp = false;
     for (size_t i = 0; i < n; i++) {
-        if (tasks[i].kind >= DAV1D_HIP_IPRED_PAL && tasks[i].kind != DAV1D_HIP_IPRED_PRED_TMP) l->needs_aux = true;
+        if (tasks[i].kind >= DAV1D_HIP_IPRED_PAL && tasks[i].kind < DAV1D_HIP_IPRED_PRED_TMP) l->needs_aux = true;
         if (tasks[i].kind == DAV1D_HIP_IPRED_PRED_TMP) l->needs_tmp = true;
     }
     l->start.push_back(0);
@@ -2026,7 +2027,7 @@ int dav1d_hip_intra_list_create_blend(Dav1dHipContext *c, Dav1dHipIntraList **ou
     Dav1dHipIntraList *l = new (std::nothrow) Dav1dHipIntraList();
     if (!l) return -ENOMEM;
     l->preds = nullptr; l->p_dev = nullptr; l->t_dev = nullptr; l->b_dev = nullptr; l->needs_aux = false;
-    for (size_t i = 0; i < np; i++) if (preds[i].kind >= DAV1D_HIP_IPRED_PAL && preds[i].kind != DAV1D_HIP_IPRED_PRED_TMP) l->needs_aux = true;
+    for (size_t i = 0; i < np; i++) if (preds[i].kind >= DAV1D_HIP_IPRED_PAL && preds[i].kind < DAV1D_HIP_IPRED_PRED_TMP) l->needs_aux = true;
     l->blend_start.push_back(0);
     for (size_t k = 0; k < n_batches; k++) l->blend_start.push_back(l->blend_start.back() + (blend_sizes ? blend_sizes[k] : 0));
     if (l->blend_start.back()) {
@@ -2137,7 +2138,7 @@ int dav1d_hip_intra_units_build(const Dav1dHipIpredTask *preds, const uint32_t *
     for (size_t i = 0; i < np; i++) {
         const int k = preds[i].kind;
         if (k == DAV1D_HIP_IPRED_PRED_TMP && blends) continue;
-        if (k != DAV1D_HIP_IPRED_PRED && k != DAV1D_HIP_IPRED_CFL && k != DAV1D_HIP_IPRED_PAL) return -ENOTSUP;
+        if (k != DAV1D_HIP_IPRED_PRED && k != DAV1D_HIP_IPRED_CFL && k != DAV1D_HIP_IPRED_PAL && k != DAV1D_HIP_IPRED_COPY) return -ENOTSUP;
     }
     if (blends) {
         const size_t nb = n_steps ? blend_end[n_steps - 1] : 0;

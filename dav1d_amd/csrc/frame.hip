@@ -58,6 +58,7 @@ struct Dav1dHipFrame {
         std::vector<uint32_t> ua_end, ub_end;       // [step] -> end of the step's first / second kind in units
         bool flow_ok;                               // every task is of a kind the dataflow launch runs
         std::vector<SbPart> parts;                  // sb_sorted: units are sorted by (superblock, step, kind), one part per superblock
+        std::vector<uint64_t> copy_deps;            // intra block copies: (superblock << 32 | superblock under its source window)
         bool sb_sorted;
         IntraUnit *sorted;                          // ... and sit here: in the frame's pinned unit arena (in_arena) or in `units`
         size_t n_sorted;
@@ -613,6 +614,7 @@ int dav1d_hip_frame_submit_intra_sorted(Dav1dHipFrame *f, size_t n_steps, const 
         ck->n_sorted = n;
         dav1d_hip_sbw_emit(ck->units, st, ck->sorted);
         ck->parts.swap(st.parts);
+        ck->copy_deps.swap(st.copy_deps);
         ck->has_pal = false;
         for (size_t i = 0; i < ck->units.size() && !ck->has_pal; i++) ck->has_pal = (ck->units[i].has & 1) && ck->units[i].p.kind == DAV1D_HIP_IPRED_PAL;
         if (ck->in_arena) { std::vector<IntraUnit>().swap(ck->units); }
@@ -1264,27 +1266,34 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
                 }
             }
             SbPlan plan;
-            if (!rc) rc = dav1d_hip_sbw_plan(f->tiling, parts, base, f->sb_dep.empty() ? nullptr : f->sb_dep.data(), plan);
+            std::vector<uint64_t> copy_deps;          // intra block copies: superblock -> the superblocks under its source windows
+            for (const Dav1dHipFrame::StepChunk *ck : f->step_chunks) copy_deps.insert(copy_deps.end(), ck->copy_deps.begin(), ck->copy_deps.end());
+            std::sort(copy_deps.begin(), copy_deps.end());
+            copy_deps.erase(std::unique(copy_deps.begin(), copy_deps.end()), copy_deps.end());
+            if (!rc) rc = dav1d_hip_sbw_plan(f->tiling, parts, base, f->sb_dep.empty() ? nullptr : f->sb_dep.data(), plan, copy_deps.empty() ? nullptr : &copy_deps);
             if (!rc && needs_aux && !f->aux) rc = -EINVAL;
             if (!rc && any_blend && !mask) rc = -EINVAL;
             const size_t ub = total * sizeof(IntraUnit), rb = plan.regions.size() * sizeof(SbRegion);
             if (!rc && total) {
-                const int lds = c->intra_sb_lds && !any_blend;          // (the LDS-resident form does not blend)
+                const int lds = c->intra_sb_lds && !any_blend && copy_deps.empty();          // (the LDS-resident form neither blends nor copies)
                 const bool one_launch = c->intra_sb_flow && !lds && plan.level_start.size() > 2;
                 const size_t fb = (plan.regions.size() + 1) * sizeof(uint32_t), o_flags = (ub + rb + 255) & ~(size_t) 255;
-                TaskBuf dev_buf(c, o_flags + fb + 256);
+                const size_t o_where = (o_flags + fb + 255) & ~(size_t) 255, wb = one_launch ? plan.where.size() * sizeof(uint32_t) : 0;
+                TaskBuf dev_buf(c, o_where + wb + 256);
                 uint8_t *const dev = dev_buf.p;
                 if (!dev) rc = -ENOMEM;
                 if (!rc) rc = hip_rc(hipMemcpyAsync(dev, host, ub, hipMemcpyHostToDevice, c->stream));
                 if (!rc && one_launch) rc = hip_rc(hipMemsetAsync(dev + o_flags, 0, fb, c->stream));
                 if (!rc) rc = dav1d_hip_upload(c, dev + ub, plan.regions.data(), rb);
+                if (!rc && wb) rc = dav1d_hip_upload(c, dev + o_where, plan.where.data(), wb);
                 const auto t_b = std::chrono::steady_clock::now();
                 const DevPlanes dp = dev_planes(&f->cur);
                 if (one_launch) {
                     // every level in one launch: superblocks wait for the flags of the neighbours they read (intra_sb.hip)
                     if (!rc) rc = dav1d_hip_launch_intra_sb(&dp, f->cur.bpc, f->cur.layout, reinterpret_cast<const IntraUnit *>(dev),
                                                             reinterpret_cast<const SbRegion *>(dev + ub), (int) plan.regions.size(), f->aux, mask, coef,
-                                                            c->intra_sb_waves, f->tiling.sb_log2, 0, reinterpret_cast<uint32_t *>(dev + o_flags), c->stream);
+                                                            c->intra_sb_waves, f->tiling.sb_log2, 0, reinterpret_cast<uint32_t *>(dev + o_flags), c->stream,
+                                                            reinterpret_cast<const uint32_t *>(dev + o_where), f->tiling.sbw);
                     uint32_t gave_up = 0;
                     if (!rc) rc = dav1d_hip_download(c, &gave_up, dev + o_flags + plan.regions.size() * sizeof(uint32_t), sizeof(gave_up));
                     if (!rc && gave_up) rc = -EIO;

@@ -50,7 +50,8 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
                                                                      const uint8_t *__restrict__ mask /* inter-intra masks (may be nullptr without such units) */,
                                                                      coef *__restrict__ cf, const int layout, const int bitdepth_max,
                                                                      uint32_t *flags /* ONE launch for every level: a word per superblock (+ the error word behind them), or nullptr */,
-                                                                     const int n_regions)
+                                                                     const int n_regions, const uint32_t *__restrict__ where /* superblock (raster) -> its region; with flags */,
+                                                                     const int sbw, const int sb_log2)
 {
     __shared__ int16_t e1_s[SB_WAVES][ESZ], e2_s[SB_WAVES][ESZ];
     __shared__ int16_t blk_s[SB_WAVES][32 * 32];
@@ -156,6 +157,35 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
                     dv::fence_acquire_agent();
                 }
             }
+            if (flags && where && (u.has & 1) && u.p.kind == DAV1D_HIP_IPRED_COPY && !skip) {
+                // an intra block copy: the superblocks under its source window (any earlier ones of the tile, not just the four neighbours)
+                // have to be THROUGH: a superblock writes only its border units through to memory as it goes, what a copy reads from its
+                // inside is out of the XCD's L2 with the release at its end (progress beyond pal[7] would not be enough)
+                const int pl = u.p.plane, ssh = pl && layout != DAV1D_HIP_LAYOUT_I444, ssv = pl && layout == DAV1D_HIP_LAYOUT_I420;
+                const int iw = ((dst.w[0] + 7) & ~7) >> ssh, ih = ((dst.h[0] + 7) & ~7) >> ssv;
+                const int sx = (int) (int16_t) u.p.pal[0], sy = (int) (int16_t) u.p.pal[1];
+                const int bx0 = (dv::iclip(sx, 0, iw - 1) << ssh) >> sb_log2, bx1 = (dv::iclip(sx + u.p.tw * 4 - 1 + ((u.p.pal[2] & 15) != 0), 0, iw - 1) << ssh) >> sb_log2;
+                const int by0 = (dv::iclip(sy, 0, ih - 1) << ssv) >> sb_log2, by1 = (dv::iclip(sy + u.p.th * 4 - 1 + ((u.p.pal[2] >> 8) != 0), 0, ih - 1) << ssv) >> sb_log2;
+                int bad = 0;
+                if (lane == 0) {
+                    for (int k = 0; k < 4 && !bad; k++) {
+                        if ((k & 1 && bx1 == bx0) || (k & 2 && by1 == by0)) continue;
+                        const uint32_t at = where[(k & 2 ? by1 : by0) * sbw + (k & 1 ? bx1 : bx0)];
+                        if (at == SB_NONE || at >= blockIdx.x) continue;        // (nothing written there by this pass; never itself or a later one)
+                        int spins = 0;
+                        for (;;) {
+                            const uint32_t v = dv::ld_coherent(flags + at);
+                            if ((v & 3u) == 1u) break;
+                            if ((v & 3u) == 2u || ++spins > (SB_SPIN_LIMIT << 3) || *(volatile int *) &give_up) { bad = 1; break; }
+                            dv::nap();
+                        }
+                    }
+                    if (bad) give_up = 1;
+                }
+                bad = __shfl(bad, 0);
+                skip = bad != 0;
+                dv::fence_acquire_agent();
+            }
             if (skip) {          // never in a sound run: the unit is NOT reconstructed from pixels that are not there
                 dv::fetch_end(keepn);
                 ci = ni; u = un; ni = n2; un = u2;
@@ -213,12 +243,12 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
         }
         dv::stores_done();                   // this wave's pixels have reached the L2 (the coherent ones: memory) ...
         __syncthreads();                     // ... and so have the other waves': the next group may read them
-        if (fine) {
+        if (flags) {
             if (*(volatile int *) &give_up) {
                 if (threadIdx.x == 0) { atomicAdd(flags + n_regions, 1u); dv::st_coherent(flags + blockIdx.x, 2u); }
                 return;
             }
-            if (threadIdx.x == 0 && pub) dv::st_coherent(flags + blockIdx.x, pub << 2);
+            if (fine && threadIdx.x == 0 && pub) dv::st_coherent(flags + blockIdx.x, pub << 2);
         }
     }
     if (flags && threadIdx.x == 0) {
@@ -381,7 +411,8 @@ __global__ __launch_bounds__(NW * 64, SBL2 == 6 ? 2 : 1) void intra_sbl_kernel(c
 // flags = n_regions + 1 zeroed words, the last one counts workgroups that gave up waiting).
 // waves: workgroup size in waves, 4 or 8 (0: the form's own choice).  lds: the LDS-resident form where it exists (4:2:0 / 4:0:0 pictures).
 extern "C" int dav1d_hip_launch_intra_sb(const DevPlanes *dst, int bpc, int layout, const IntraUnit *units, const SbRegion *regions, int n_regions,
-                                         uint8_t *aux, const uint8_t *mask, void *coef, int waves, int sb_log2, int lds, uint32_t *flags, void *stream)
+                                         uint8_t *aux, const uint8_t *mask, void *coef, int waves, int sb_log2, int lds, uint32_t *flags, void *stream,
+                                         const uint32_t *where, int sbw)
 {
     if (n_regions <= 0) return 0;
     const int bitdepth_max = (1 << bpc) - 1;
@@ -404,7 +435,7 @@ extern "C" int dav1d_hip_launch_intra_sb(const DevPlanes *dst, int bpc, int layo
         return hip_rc(hipGetLastError());
     }
 #define SB_LAUNCH(P, Cf, NW) hipLaunchKernelGGL((intra_sb_kernel<P, Cf, NW>), dim3(n_regions), dim3(NW * 64), 0, (hipStream_t) stream, *dst, units, regions, \
-                                                aux, mask, (Cf *) coef, layout, bitdepth_max, flags, n_regions)
+                                                aux, mask, (Cf *) coef, layout, bitdepth_max, flags, n_regions, where, sbw, sb_log2)
     if (bpc == 8) { if (waves == 4) SB_LAUNCH(uint8_t, int16_t, 4); else SB_LAUNCH(uint8_t, int16_t, 8); }
     else { if (waves == 4) SB_LAUNCH(uint16_t, int32_t, 4); else SB_LAUNCH(uint16_t, int32_t, 8); }
 #undef SB_LAUNCH
@@ -424,7 +455,7 @@ extern "C" int dav1d_hip_launch_intra_sb(const DevPlanes *dst, int bpc, int layo
 int dav1d_hip_sbw_prepare(std::vector<IntraUnit> &units, const std::vector<uint32_t> &ua_end, const std::vector<uint32_t> &ub_end,
                           const SbTiling &tl, const int strides[3], const int ss_hor, const int ss_ver, SbSort &st)
 {
-    st.parts.clear(); st.pos.clear(); st.key.clear(); st.n_records = 0;
+    st.parts.clear(); st.pos.clear(); st.key.clear(); st.n_records = 0; st.copy_deps.clear();
     const size_t n = units.size();
     if (!n) return 0;
     if (tl.sb_log2 != 6 && tl.sb_log2 != 7) return -EINVAL;
@@ -451,6 +482,21 @@ int dav1d_hip_sbw_prepare(std::vector<IntraUnit> &units, const std::vector<uint3
         // its stores go out coherently and the superblock publishes its progress behind its group (intra_sb_kernel)
         if (x1 >= (sx + 1) << tl.sb_log2 || y1 >= (sy + 1) << tl.sb_log2) units[i].has |= 8; else units[i].has &= ~8u;
         sb[i] = (uint32_t) (sy * sbw + sx);
+        if ((u.has & 1) && u.p.kind == DAV1D_HIP_IPRED_COPY) {
+            // the superblocks under the copy's source window (the same arithmetic as the kernel's wait): whom this superblock's level
+            // has to lie above
+            const int ssh = pl ? ss_hor : 0, ssv = pl ? ss_ver : 0;
+            const int iw = (tl.sbw << tl.sb_log2) >> ssh, ih = (tl.sbh << tl.sb_log2) >> ssv;      // (an upper bound of the coded area is enough here)
+            const int cx = (int) (int16_t) u.p.pal[0], cy = (int) (int16_t) u.p.pal[1];
+            const int bx0 = (std::min(std::max(cx, 0), iw - 1) << ssh) >> tl.sb_log2, bx1 = (std::min(std::max(cx + u.p.tw * 4 - 1 + ((u.p.pal[2] & 15) != 0), 0), iw - 1) << ssh) >> tl.sb_log2;
+            const int by0 = (std::min(std::max(cy, 0), ih - 1) << ssv) >> tl.sb_log2, by1 = (std::min(std::max(cy + u.p.th * 4 - 1 + ((u.p.pal[2] >> 8) != 0), 0), ih - 1) << ssv) >> tl.sb_log2;
+            for (int k = 0; k < 4; k++) {
+                if ((k & 1 && bx1 == bx0) || (k & 2 && by1 == by0)) continue;
+                const uint32_t src = (uint32_t) ((k & 2 ? by1 : by0) * sbw + (k & 1 ? bx1 : bx0));
+                const uint64_t pr = (uint64_t) sb[i] << 32 | src;
+                if (src != sb[i] && (st.copy_deps.empty() || st.copy_deps.back() != pr)) st.copy_deps.push_back(pr);
+            }
+        }
         st.key[i] = (uint32_t) s * 2 + (i >= ua_end[s]);
         lo = std::min(lo, sb[i]); hi = std::max(hi, sb[i]);
     }
@@ -522,7 +568,8 @@ void dav1d_hip_sbw_emit(const std::vector<IntraUnit> &units, const SbSort &st, I
 // of levels.
 // dep: per superblock of the frame, which neighbours its blocks' edges reach into (bit 0 left, 1 top-left, 2 top, 3 top-right), or
 // nullptr: all four.
-int dav1d_hip_sbw_levels(const SbTiling &tl, const uint32_t *sbs, size_t n, const uint8_t *dep, std::vector<int> &level_of_sb, std::vector<uint32_t> &level)
+int dav1d_hip_sbw_levels(const SbTiling &tl, const uint32_t *sbs, size_t n, const uint8_t *dep, std::vector<int> &level_of_sb, std::vector<uint32_t> &level,
+                         const std::vector<uint64_t> *extra)
 {
     const int sbw = tl.sbw, sbh = tl.sbh;
     level_of_sb.assign((size_t) sbw * sbh, -1);
@@ -546,6 +593,14 @@ int dav1d_hip_sbw_levels(const SbTiling &tl, const uint32_t *sbs, size_t n, cons
                         if (dm & 4) m = std::max(m, level_of_sb[(size_t) (y - 1) * sbw + x]);
                         if (x > x0 && (dm & 2)) m = std::max(m, level_of_sb[(size_t) (y - 1) * sbw + x - 1]);
                         if (x + 1 < x1 && (dm & 8)) m = std::max(m, level_of_sb[(size_t) (y - 1) * sbw + x + 1]);
+                    }
+                    if (extra) {
+                        // sources of intra block copies: earlier superblocks of the same tile (decode order), so their levels stand
+                        const uint64_t me = (uint64_t) ((size_t) y * sbw + x) << 32;
+                        for (auto it = std::lower_bound(extra->begin(), extra->end(), me); it != extra->end() && (*it >> 32) == (me >> 32); ++it) {
+                            const uint32_t src = (uint32_t) *it;
+                            if (src < (uint32_t) (sbw * sbh)) m = std::max(m, level_of_sb[src]);
+                        }
                     }
                     lv = m + 1;
                     top = std::max(top, lv + 1);
@@ -572,7 +627,7 @@ int dav1d_hip_sb_tiling_make(SbTiling *tl, int w, int h, int sb128, int n_cols, 
 // The launches of a frame: every superblock that holds units, sorted by level.  A superblock met in two arrays (never by the
 // listers: a superblock belongs to one tile-sbrow) is refused.
 int dav1d_hip_sbw_plan(const SbTiling &tl, const std::vector<const std::vector<SbPart> *> &parts, const std::vector<size_t> &base, const uint8_t *dep,
-                       SbPlan &plan)
+                       SbPlan &plan, const std::vector<uint64_t> *extra)
 {
     plan.regions.clear(); plan.level_start.clear();
     if (parts.size() != base.size()) return -EINVAL;
@@ -591,7 +646,7 @@ int dav1d_hip_sbw_plan(const SbTiling &tl, const std::vector<const std::vector<S
         std::sort(seen.begin(), seen.end());
         if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) return -EINVAL;
     }
-    const int nl = dav1d_hip_sbw_levels(tl, sbs.data(), sbs.size(), dep, level_of_sb, level);
+    const int nl = dav1d_hip_sbw_levels(tl, sbs.data(), sbs.size(), dep, level_of_sb, level, extra);
     if (nl < 0) return nl;
     plan.level_start.assign((size_t) nl + 1, 0);
     for (size_t i = 0; i < level.size(); i++) plan.level_start[level[i] + 1]++;
@@ -605,8 +660,14 @@ int dav1d_hip_sbw_plan(const SbTiling &tl, const std::vector<const std::vector<S
     for (size_t i = 0; i < order.size(); i++) plan.regions[i] = reg[order[i]];
     // whom a superblock waits for when the levels run as ONE launch (intra_sb_kernel, flags): the positions, in this order, of the
     // neighbours that set its level — the same rule as dav1d_hip_sbw_levels, so each of them sits earlier in the array
-    std::vector<uint32_t> where((size_t) tl.sbw * tl.sbh, SB_NONE);
+    std::vector<uint32_t> &where = plan.where;
+    where.assign((size_t) tl.sbw * tl.sbh, SB_NONE);
     for (size_t i = 0; i < order.size(); i++) where[sbs[order[i]]] = (uint32_t) i;
+    if (extra)          // a copy's source has to sit earlier in the array (the wait inside one launch relies on it)
+        for (const uint64_t pr : *extra) {
+            const uint32_t a = where[pr >> 32], b = (uint32_t) pr < where.size() ? where[(uint32_t) pr] : SB_NONE;
+            if (a != SB_NONE && b != SB_NONE && b >= a) return -EINVAL;
+        }
     std::vector<int> tile_x0(tl.sbw, 0), tile_x1(tl.sbw, 0), tile_y0(tl.sbh, 0);
     for (int tc = 0; tc < tl.n_cols; tc++)
         for (int x = tl.col_start[tc]; x < std::min<int>(tl.col_start[tc + 1], tl.sbw); x++) { tile_x0[x] = tl.col_start[tc]; tile_x1[x] = std::min<int>(tl.col_start[tc + 1], tl.sbw); }

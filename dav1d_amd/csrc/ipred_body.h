@@ -92,6 +92,40 @@ __device__ __forceinline__ void ipred_body(const DevPlanes &dst, const Dav1dHipI
         return;
     }
 
+    // ---------------------------------------------------------------- intra block copy: put_bilin_c (src/mc_tmpl.c:434-489) on the frame itself
+    if (t.kind == DAV1D_HIP_IPRED_COPY) {
+        const int ss_hor = t.plane && layout != DAV1D_HIP_LAYOUT_I444, ss_ver = t.plane && layout == DAV1D_HIP_LAYOUT_I420;
+        // mc() bounds the source by the coded area in whole 8x8 luma blocks (f->bw * 4 >> ss_hor, src/recon_tmpl.c:960-978)
+        const int iw = ((dst.w[0] + 7) & ~7) >> ss_hor, ih = ((dst.h[0] + 7) & ~7) >> ss_ver;
+        const int sx = (int) (int16_t) t.pal[0], sy = (int) (int16_t) t.pal[1], mx = t.pal[2] & 15, my = (t.pal[2] >> 8) & 15;
+        const dv::PxRead<pixel, COH> P = { reinterpret_cast<const pixel *>(dst.data[t.plane]) };
+        const int ib = HBD ? 14 - bitdepth : 4;                 // get_intermediate_bits
+        auto px = [&](const int xx, const int yy) -> int { return (int) P[dv::iclip(yy, 0, ih - 1) * stride + dv::iclip(xx, 0, iw - 1)]; };
+        for (int i = i_lo + lane; i < i_hi; i += 64) {
+            const int y = i >> lw, x = i & (w - 1);
+            const int X = sx + x, Y = sy + y;
+            int v;
+            if (mx) {
+                const int a0 = px(X, Y), a1 = px(X + 1, Y);
+                const int m0 = (16 * a0 + mx * (a1 - a0) + ((1 << (4 - ib)) >> 1)) >> (4 - ib);
+                if (my) {
+                    const int b0 = px(X, Y + 1), b1 = px(X + 1, Y + 1);
+                    const int m1 = (16 * b0 + mx * (b1 - b0) + ((1 << (4 - ib)) >> 1)) >> (4 - ib);
+                    v = (16 * m0 + my * (m1 - m0) + ((1 << (4 + ib)) >> 1)) >> (4 + ib);
+                } else {
+                    v = (m0 + ((1 << ib) >> 1)) >> ib;
+                }
+            } else if (my) {
+                const int a0 = px(X, Y), b0 = px(X, Y + 1);
+                v = (16 * a0 + my * (b0 - a0) + 8) >> 4;
+            } else {
+                v = px(X, Y);
+            }
+            o[y * ostride + x] = (pixel) dv::iclip(v, 0, bitdepth_max);
+        }
+        return;
+    }
+
     // ---------------------------------------------------------------- mode mapping (prepare_intra_edges, :89-116)
     const bool have_left = t.flags & 1, have_top = t.flags & 2;
     bool edge_filter = t.flags & 16;

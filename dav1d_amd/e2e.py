@@ -124,7 +124,7 @@ def c2_params(seed, n_refs=3):
 
 
 def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0xE2E, check=None, intra_pct=0, key_frame=False, tile_rows=1,
-        native_threads=True, packed=False):
+        native_threads=True, packed=False, intrabc_pct=0):
     """Returns the measurement dict.  check: optional callable(handoff, desc, planes) -> str used as the parity gate.
     packed: the packing lister (Dav1dHipFrameDesc.cf: the eob + 1 values per block go to the frame's own arena, the host arena is
     left zeroed) instead of the dense arena crossing the host link; every frame gets a fresh copy of pass 1's coefficients."""
@@ -132,6 +132,7 @@ def run(ctx, w=7680, h=4320, bpc=10, frames=6, threads=None, tile_cols=4, seed=0
     ho = HandOff(w, h, layout, bpc, True, tile_cols, tile_rows)
     sp = c2_params(seed)
     sp.intra_pct = 100 if key_frame else intra_pct
+    sp.intrabc_pct = intrabc_pct          # key frames: that share of the blocks are intra block copies (screen content)
     if key_frame:
         ho.desc.is_inter = 0
     t0 = time.perf_counter()

@@ -907,9 +907,27 @@ static void list_intrabc(Walk *w, const int bs, const Dav1dHipAv1Block *b, const
         if (q > s) s = q;
     }
     s++;
+    /* the copies join the predictions of step s (DAV1D_HIP_IPRED_COPY), in pieces of up to 64x64: on every route of the intra wavefront
+     * they run where an intra prediction of that step would — the superblock route included, which waits for the superblocks under the
+     * source window to have passed step s - 1 */
     for (size_t i = n0; i < w->o->mc.n; i++) {
-        *VPUSH(w->o->smc, Dav1dHipMcTask) = w->o->mc.p[i];
-        *VPUSH(w->o->smc_step, uint16_t) = (uint16_t) s;
+        const Dav1dHipMcTask m = w->o->mc.p[i];
+        const int pl = m.plane, ssh = pl ? ss_hor : 0, ssv = pl ? ss_ver : 0;
+        const int px0 = (int) (m.dst_off % (uint32_t) l->stride[pl]), py0 = (int) (m.dst_off / (uint32_t) l->stride[pl]);
+        if ((m.w & 3) || (m.h & 3) || (px0 & 3) || (py0 & 3) || m.src_x < -32768 || m.src_x > 32767 - 128 || m.src_y < -32768 || m.src_y > 32767 - 128) { w->err = -EINVAL; return; }
+        for (int oy = 0; oy < m.h; oy += 64)
+            for (int ox = 0; ox < m.w; ox += 64) {
+                Dav1dHipIpredTask *k = new_ipred(w, s);
+                k->kind = DAV1D_HIP_IPRED_COPY;
+                k->plane = (uint8_t) pl;
+                k->dst_off = m.dst_off + (uint32_t) oy * (uint32_t) l->stride[pl] + (uint32_t) ox;
+                k->x4 = (uint16_t) ((px0 + ox) >> 2); k->y4 = (uint16_t) ((py0 + oy) >> 2);
+                k->w4 = (uint16_t) (w->col_end >> ssh); k->h4 = (uint16_t) (w->row_end >> ssv);
+                k->tw = (uint8_t) (imin(64, m.w - ox) >> 2); k->th = (uint8_t) (imin(64, m.h - oy) >> 2);
+                k->pal[0] = (uint16_t) (int16_t) (m.src_x + ox); k->pal[1] = (uint16_t) (int16_t) (m.src_y + oy);
+                k->pal[2] = (uint16_t) (m.mx | m.my << 8);
+                k->pal[6] = 0x8000u; k->pal[7] = (uint16_t) (s - 1);
+            }
     }
     w->o->mc.n = n0;
     const unsigned step[3] = { s, s, s };

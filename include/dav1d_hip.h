@@ -367,6 +367,13 @@ enum Dav1dHipIpredKind {
      * the picture like PRED, prediction written to the scratch (prep) arena as pixels, row stride = block width, at pixel
      * offset aux_off; a DAV1D_HIP_COMP_BLEND task of the same wavefront step blends it in.  Frame API only. */
     DAV1D_HIP_IPRED_PRED_TMP = 6,
+    /* Intra block copy (recon_b_inter on key / intra-only frames, src/recon_tmpl.c:1583-1597: mc() from the frame's own reconstruction
+     * with the bilinear filter): the tw x th block is copied from position ((int16) pal[0], (int16) pal[1]) of its own plane, pixels of
+     * the source window outside the coded area (whole 8x8 luma blocks) replicated as mc()'s emu_edge does, with the sixteenth-pel phases
+     * pal[2] & 15 (x) and pal[2] >> 8 (y) — 0, or 8 in a subsampled chroma plane under an odd vector.  A prediction like any other of
+     * its wavefront step: what it reads was written by earlier steps.  pal[7] = the highest step among the blocks it reads (pal[6] =
+     * 0x8000): the superblock route waits for the superblocks under the source window to have passed it.  Blocks of up to 64x64. */
+    DAV1D_HIP_IPRED_COPY = 7,
 };
 
 /* One intra prediction of one transform block.  Field names follow the arguments of

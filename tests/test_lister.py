@@ -259,6 +259,9 @@ def test_key_frame_superblock_by_superblock(ctx, bpc, sb128, lds):
         assert st["steps"] >= 50 and not st["coef_after"].any()
         run_case(c2, 448, 320, 1, bpc, 22 + bpc, is_inter=False, tiles=(1, 1), sb128=sb128)
         run_case(c2, 448, 320, 1, bpc, 23 + bpc, is_inter=True, tiles=(2, 1), threads=2, sb128=sb128, **dict(PLAIN, intra_pct=25))
+        # intra block copies are predictions of the route (DAV1D_HIP_IPRED_COPY): a superblock's level lies above those of the superblocks
+        # under its copies' source windows, and in one launch the copy waits for them (the LDS-resident form leaves such frames to the L2 form)
+        run_case(c2, 512, 320, 1, bpc, 25 + bpc, is_inter=False, tiles=(2, 1), threads=2, sb128=sb128, intrabc_pct=50, palette=10)
         if lds == 0 and sb128:
             # inter-intra blocks are units of the route too (prediction, blend with the inter prediction, residual) ...
             run_case(c2, 448, 320, 1, bpc, 24 + bpc, is_inter=True, tiles=(2, 1), threads=2, **dict(PLAIN, intra_pct=20, interintra_pct=40))

@@ -9,7 +9,8 @@ out = {}
 check = "--no-check" not in sys.argv
 for fine in (1, 0):
     assert ctx.lib.dav1d_hip_set_option(ctx.h, b"intra_sb_fine", fine) == 0
-    for name, kw, inter in (("key_frame", dict(key_frame=True, seed=0xE2F), False), ("inter_10pct_intra", dict(intra_pct=10, seed=0xE30), True)):
+    for name, kw, inter in (("key_frame", dict(key_frame=True, seed=0xE2F), False), ("inter_10pct_intra", dict(intra_pct=10, seed=0xE30), True),
+                            ("key_frame_40pct_intrabc", dict(key_frame=True, intrabc_pct=40, seed=0xE31), False)):
         chk = (lambda ho, planes, refs, inter=inter: lu.check_handoff_against_reference(ho, planes, refs, is_inter=inter)) if check else None
         r = e2e.run(ctx, 7680, 4320, 10, frames=4, threads=64, tile_cols=16, tile_rows=8, check=chk, **kw)
         out["%s_fine%d" % (name, fine)] = {k: r.get(k) for k in ("ms_per_frame", "frame_end_ms", "list_ms", "parity", "value")}
