@@ -95,6 +95,16 @@ struct Dav1dHipFrame {
         Dav1dHipLrTask *lr; size_t n_lr;
     };
     std::vector<FilterPiece> filter_pieces;
+    // the host half of the restoration stage (frame_lr_plan): made while the earlier stages' launches run
+    struct LrPlan {
+        bool valid = false, banded = false;
+        int nb = 0, max_w = 0;
+        size_t nw = 0, n_waves = 0;
+        std::vector<Dav1dHipLrTask> sorted;
+        std::vector<uint32_t> tail, target;
+        std::vector<int> first_y, band;
+        std::vector<size_t> off, pos;
+    } lrplan;
     // CDEF as one record per unit row of a 64-pixel column (cdef_rows.h), written by the filter lister's threads straight into this
     // pinned table and cut into unit records on the device (cdef.hip cdef_expand_kernel); state: 0 not asked yet, 1 in use, -1 refused
     Dav1dHipCdefRow *cdef_rows = nullptr;
@@ -795,6 +805,7 @@ static void frame_merge_filter_pieces(Dav1dHipFrame *f) {
 }
 
 static int copy_picture(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src);
+static int frame_lr_plan(Dav1dHipFrame *f);
 static int copy_unrestored_planes(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src, const std::vector<Dav1dHipLrTask> &lr);
 
 // Deblocking and CDEF of a frame straight from the pieces: the tasks copied piece after piece into pinned memory (the larger
@@ -810,6 +821,9 @@ static int frame_filters_from_pieces(Dav1dHipFrame *f, bool *did_cdef) {
         for (const Dav1dHipFrame::FilterPiece &p : f->filter_pieces) mixed |= p.n_cdef != 0;
         if (mixed) { const int rc = frame_cdef_rows_to_piece(f); if (rc) return rc; rows = false; }
     }
+    // restoration units: few; they go through the merged vector, and their host-side preparation (frame_lr_plan) runs below while the
+    // device works on the stages before
+    for (Dav1dHipFrame::FilterPiece &p : f->filter_pieces) { f->lr.insert(f->lr.end(), p.lr, p.lr + p.n_lr); p.n_lr = 0; }
     size_t n_lf = 0, n_lf0 = 0, n_cdef = 0, n_groups = 0, n_raw = 0;
     for (const Dav1dHipFrame::FilterPiece &p : f->filter_pieces) {
         n_lf += p.n_lf; n_lf0 += p.n_lf0; n_cdef += p.n_cdef; n_raw += p.n_raw;
@@ -834,6 +848,7 @@ static int frame_filters_from_pieces(Dav1dHipFrame *f, bool *did_cdef) {
         if (!rc) rc = dav1d_hip_upload(c, dev, host, n_lf * sizeof(*dev));
         if (!rc) rc = dav1d_hip_launch_lf(&cur, f->cur.bpc, 0, dev, (int) n_lf0, f->lvl, (int) f->b4_stride, f->lut_e, f->lut_i, c->stream);
         if (!rc) rc = dav1d_hip_launch_lf(&cur, f->cur.bpc, 1, dev + n_lf0, (int) (n_lf - n_lf0), f->lvl, (int) f->b4_stride, f->lut_e, f->lut_i, c->stream);
+        if (!rc) rc = frame_lr_plan(f);          // (host work under the launches above)
         (void) hipStreamSynchronize(c->stream);
         dav1d_hip_slab_put(c, reinterpret_cast<uint8_t *>(host), cap);
         if (rc) return rc;
@@ -860,6 +875,7 @@ static int frame_filters_from_pieces(Dav1dHipFrame *f, bool *did_cdef) {
         if (!rc && d_bm) rc = dav1d_hip_launch_cdef_fill_unlisted(&t0, &cur, f->cur.bpc, f->cur.layout, nullptr, 0, d_bm, w8, h8, c->stream);
         if (!rc) rc = dav1d_hip_launch_cdef_groups(&t0, &cur, f->cur.bpc, f->cur.layout, d_tasks, reinterpret_cast<const CdefGroup *>(dev + rb + tb), (int) n_slots,
                                                    f->cdef_damping, nullptr, c->stream);
+        if (!rc) rc = frame_lr_plan(f);          // (host work under the launches above)
         (void) hipStreamSynchronize(c->stream);
         f->cdef_row_units.store(0);              // consumed, like the pieces; the table is wiped before anybody writes to it again
         f->cdef_rows_dirty = true;
@@ -925,14 +941,13 @@ static int frame_filters_from_pieces(Dav1dHipFrame *f, bool *did_cdef) {
         } else if (!rc) {
             rc = dav1d_hip_launch_cdef(&t0, &cur, f->cur.bpc, f->cur.layout, d_tasks, (int) n_cdef, f->cdef_damping, nullptr, 0, c->stream);
         }
+        if (!rc) rc = frame_lr_plan(f);          // (host work under the launches above)
         (void) hipStreamSynchronize(c->stream);
         dav1d_hip_slab_put(c, host, cap);
         if (rc) return rc;
         *did_cdef = true;
     }
-    // restoration units: few; they go through the merged vector and dav1d_hip_lr_batch
     for (Dav1dHipFrame::FilterPiece &p : f->filter_pieces) {
-        f->lr.insert(f->lr.end(), p.lr, p.lr + p.n_lr);
         free(p.lf); free(p.cdef); free(p.lr);
         delete p.groups;
     }
@@ -1005,92 +1020,112 @@ struct FrameTrace {
 
 // Row-granular progress without banding the whole frame (the reference publishes f->sr_cur.progress[1] after the last filter of every
 // superblock row, src/thread_task.c:888-896; post_filters_pipelined() above follows every band through all three stages on three
-// streams and pays 70 % for it).  Here only the LAST stage of a frame tells where it is, and from INSIDE its two launches: the
+// streams and pays 70 % for it).  Here only the LAST stage of a frame tells where it is, and from INSIDE its two launches (frame_lr_run): the
 // restoration tasks are ordered by band of 256 luma rows, every workgroup that has written its pixels bumps its band's counter, and
 // the one that completes a band writes to a word of pinned host memory the ending thread polls (lr.hip band_done).  Cutting the stage
 // into a launch pair per band with an event behind each — the obvious way — was measured at 8K: 34 launches of 43 us each (a band
 // does not fill the device, a launch's time is one workgroup's latency) against 126 us for the two, +58 % on the frame.
 // Rows are final up to where the NEXT band's first stripe begins (restoration stripes start 8 rows above the 64-row grid,
 // src/lr_apply_tmpl.c:176-199).
-static int frame_lr_banded(Dav1dHipFrame *f, const Dav1dHipPicture *out, const Dav1dHipPicture *in, const Dav1dHipPicture *lpf) {
-    Dav1dHipContext *c = f->c;
+// The host half of the restoration stage — tasks validated, Wiener first, self-guided units sorted into rows and waves, for a listener
+// band by band with the bands' wave counts — made as soon as the frame's restoration tasks are known, i.e. while the launches of the
+// stages before are still running (frame_filters_from_pieces calls it ahead of its waits): sorting 10,000 stripes takes 0.14 ms, a
+// tenth of an 8K frame's frame_end when the device sits idle through it.
+static int frame_lr_plan(Dav1dHipFrame *f) {
+    Dav1dHipFrame::LrPlan &pl = f->lrplan;
+    if (pl.valid && pl.sorted.size() == f->lr.size() && pl.banded == (f->progress_cb && !f->sr_w && pl.nb >= 2 && pl.nb <= 64 && !f->lr.empty())) return 0;
     const int H = f->cur.p[0].h, ss_ver = f->cur.layout == DAV1D_HIP_LAYOUT_I420;
-    const int band_h = 256, nb = (H + band_h - 1) / band_h;
+    const int band_h = 256;
     const size_t n = f->lr.size();
-    if (nb < 2 || nb > 64 || !n) return dav1d_hip_lr_batch(c, out, in, lpf, f->lr.data(), n);
-    FrameTrace tr;
-    if (!c->band_cnt) {
-        if (hipMalloc((void **) &c->band_cnt, 128 * sizeof(uint32_t)) != hipSuccess) { c->band_cnt = nullptr; return -ENOMEM; }
-        if (hipHostMalloc((void **) &c->band_flags, 64 * sizeof(uint32_t), 0) != hipSuccess) { c->band_flags = nullptr; return -ENOMEM; }
-        memset(c->band_flags, 0, 64 * sizeof(uint32_t));
-    }
-    // tasks: [Wiener, band by band][self-guided, band by band, each band's units sorted into rows]
-    // (the lists live with the thread: vectors of this size come from mmap and are faulted in page by page on every call — most of
-    // the 0.14 ms this preparation took of a 2 ms frame)
-    static thread_local std::vector<int> band;
-    static thread_local std::vector<size_t> off;
-    static thread_local std::vector<int> first_y;
-    static thread_local std::vector<Dav1dHipLrTask> sorted;
-    static thread_local std::vector<uint32_t> tail, target;
-    static thread_local std::vector<size_t> pos;
+    pl.nb = (H + band_h - 1) / band_h;
+    pl.banded = f->progress_cb && !f->sr_w && pl.nb >= 2 && pl.nb <= 64 && n;
+    const int nb = pl.banded ? pl.nb : 1;
+    std::vector<int> &band = pl.band;
+    std::vector<size_t> &off = pl.off, &pos = pl.pos;
     band.resize(n);
     off.assign(2 * nb + 1, 0);                    // [kind * nb + band]
-    first_y.assign(nb + 1, H);
+    pl.first_y.assign(nb + 1, H);
     for (size_t i = 0; i < n; i++) {
         const Dav1dHipLrTask &t = f->lr[i];
         if (t.plane > 2 || t.edges > 15 || !t.w || t.w > 384 || !t.h || t.h > 64 || t.type > DAV1D_HIP_LR_SGR_MIX) return -EINVAL;
         const int y = (int) t.y << (t.plane ? ss_ver : 0);
-        band[i] = std::min(y / band_h, nb - 1);
-        first_y[band[i]] = std::min(first_y[band[i]], y);
+        band[i] = pl.banded ? std::min(y / band_h, nb - 1) : 0;
+        pl.first_y[band[i]] = std::min(pl.first_y[band[i]], y);
         off[(t.type > DAV1D_HIP_LR_WIENER5) * nb + band[i] + 1]++;
     }
     for (int k = 0; k < 2 * nb; k++) off[k + 1] += off[k];
-    sorted.resize(n);
-    {
-        pos.assign(off.begin(), off.end() - 1);
-        for (size_t i = 0; i < n; i++) {
-            Dav1dHipLrTask &d = sorted[pos[(f->lr[i].type > DAV1D_HIP_LR_WIENER5) * nb + band[i]]++] = f->lr[i];
-            d.pad = (uint8_t) band[i];
-        }
+    // tasks: [Wiener, band by band][self-guided, band by band, each band's units sorted into rows]
+    pl.sorted.resize(n);
+    pos.assign(off.begin(), off.end() - 1);
+    for (size_t i = 0; i < n; i++) {
+        Dav1dHipLrTask &d = pl.sorted[pos[(f->lr[i].type > DAV1D_HIP_LR_WIENER5) * nb + band[i]]++] = f->lr[i];
+        d.pad = (uint8_t) band[i];
     }
-    for (int b = nb - 1; b >= 0; b--) first_y[b] = std::min(first_y[b], first_y[b + 1]);
-    const size_t nw = off[nb];                     // Wiener tasks
-    tail.clear();                                  // the wave descriptors, then the 64 band targets: one upload
-    target.assign(64, 0);
-    int max_w = 0;
-    for (size_t i = 0; i < nw; i++) { max_w = std::max(max_w, (int) sorted[i].w); target[sorted[i].pad] += (uint32_t) ((sorted[i].w + 63) / 64); }
+    for (int b = nb - 1; b >= 0; b--) pl.first_y[b] = std::min(pl.first_y[b], pl.first_y[b + 1]);
+    pl.nw = off[nb];                               // Wiener tasks
+    pl.tail.clear();                               // the wave descriptors, then (banded) the 64 band targets: one upload
+    pl.target.assign(64, 0);
+    pl.max_w = 0;
+    for (size_t i = 0; i < pl.nw; i++) { pl.max_w = std::max(pl.max_w, (int) pl.sorted[i].w); pl.target[pl.sorted[i].pad] += (uint32_t) ((pl.sorted[i].w + 63) / 64); }
     for (int b = 0; b < nb; b++) {
-        const size_t s0 = off[nb + b], s1 = off[nb + b + 1], w0 = tail.size();
-        dav1d_hip_sgr_make_rows(sorted.data() + s0, s1 - s0, tail);
-        for (size_t k = w0; k < tail.size(); k += 4) {          // the band's descriptors count from its first task: from the first self-guided task instead
-            tail[k] += (uint32_t) (s0 - nw); tail[k + 1] += (uint32_t) (s0 - nw); tail[k + 3] = (uint32_t) b;
+        const size_t s0 = off[nb + b], s1 = off[nb + b + 1], w0 = pl.tail.size();
+        dav1d_hip_sgr_make_rows(pl.sorted.data() + s0, s1 - s0, pl.tail);
+        for (size_t k = w0; k < pl.tail.size(); k += 4) {       // the band's descriptors count from its first task: from the first self-guided task instead
+            pl.tail[k] += (uint32_t) (s0 - pl.nw); pl.tail[k + 1] += (uint32_t) (s0 - pl.nw); pl.tail[k + 3] = (uint32_t) b;
         }
-        target[b] += (uint32_t) ((tail.size() - w0) / 4);
+        pl.target[b] += (uint32_t) ((pl.tail.size() - w0) / 4);
     }
-    const size_t n_waves = tail.size() / 4;
-    tail.insert(tail.end(), target.begin(), target.end());
+    pl.n_waves = pl.tail.size() / 4;
+    if (pl.banded) pl.tail.insert(pl.tail.end(), pl.target.begin(), pl.target.end());
+    pl.valid = true;
+    return 0;
+}
+
+static int frame_lr_run(Dav1dHipFrame *f, const Dav1dHipPicture *out, const Dav1dHipPicture *in, const Dav1dHipPicture *lpf) {
+    Dav1dHipContext *c = f->c;
+    FrameTrace tr;
+    int rc = frame_lr_plan(f);
+    if (rc) return rc;
+    Dav1dHipFrame::LrPlan &pl = f->lrplan;
+    const size_t n = pl.sorted.size();
+    if (!n) return 0;
+    if (out->bpc != in->bpc || lpf->bpc != in->bpc) return -EINVAL;
+    const bool banded = pl.banded && f->progress_cb;
+    const int nb = pl.nb;
+    if (banded && !c->band_cnt) {
+        if (hipMalloc((void **) &c->band_cnt, 128 * sizeof(uint32_t)) != hipSuccess) { c->band_cnt = nullptr; return -ENOMEM; }
+        if (hipHostMalloc((void **) &c->band_flags, 64 * sizeof(uint32_t), 0) != hipSuccess) { c->band_flags = nullptr; return -ENOMEM; }
+        memset(c->band_flags, 0, 64 * sizeof(uint32_t));
+    }
     const size_t o_waves = (n * sizeof(Dav1dHipLrTask) + 15) & ~(size_t) 15;
-    TaskBuf devb_buf(c, o_waves + tail.size() * 4 + 16);
+    TaskBuf devb_buf(c, o_waves + pl.tail.size() * 4 + 16);
     uint8_t *const devb = devb_buf.p;
     if (!devb) return -ENOMEM;
     Dav1dHipLrTask *const dev = reinterpret_cast<Dav1dHipLrTask *>(devb);
     tr.mark(0);
-    int rc = dav1d_hip_upload(c, dev, sorted.data(), n * sizeof(*dev));
-    if (!rc) rc = dav1d_hip_upload(c, devb + o_waves, tail.data(), tail.size() * 4);
+    rc = dav1d_hip_upload(c, dev, pl.sorted.data(), n * sizeof(*dev));
+    if (!rc && !pl.tail.empty()) rc = dav1d_hip_upload(c, devb + o_waves, pl.tail.data(), pl.tail.size() * 4);
+    const DevPlanes dp = dev_planes(out), sp = dev_planes(in), lp = dev_planes(lpf);
+    if (!banded) {
+        if (!rc) rc = dav1d_hip_launch_wiener(&dp, &sp, &lp, out->bpc, dev, (int) pl.nw, pl.max_w, c->stream);
+        if (!rc) rc = dav1d_hip_launch_sgr(&dp, &sp, &lp, out->bpc, dev + pl.nw, devb + o_waves, (int) pl.n_waves, c->stream);
+        const int rs = hip_rc(hipStreamSynchronize(c->stream));
+        return rc ? rc : rs;
+    }
     if (!rc) rc = hip_rc(hipMemsetAsync(c->band_cnt, 0, 64 * sizeof(uint32_t), c->stream));
     const uint32_t seq = ++c->band_seq ? c->band_seq : ++c->band_seq;        // never 0: the flags start at 0
-    const BandSignal sig = { c->band_cnt, reinterpret_cast<const uint32_t *>(devb + o_waves + n_waves * 16), c->band_flags, seq };
-    const DevPlanes dp = dev_planes(out), sp = dev_planes(in), lp = dev_planes(lpf);
+    const BandSignal sig = { c->band_cnt, reinterpret_cast<const uint32_t *>(devb + o_waves + pl.n_waves * 16), c->band_flags, seq };
     // "everything before restoration is through" (reconstruction, deblocking, CDEF, the copy of the units that are not listed): what a
     // band WITHOUT restoration tasks has to wait for before its rows count as final
     if (!rc) rc = hip_rc(hipEventRecord(c->ev_fork, c->stream));
-    if (!rc) rc = dav1d_hip_launch_wiener_sig(&dp, &sp, &lp, out->bpc, dev, (int) nw, max_w, &sig, c->stream);
-    if (!rc) rc = dav1d_hip_launch_sgr_sig(&dp, &sp, &lp, out->bpc, dev + nw, devb + o_waves, (int) n_waves, &sig, c->stream);
+    if (!rc) rc = dav1d_hip_launch_wiener_sig(&dp, &sp, &lp, out->bpc, dev, (int) pl.nw, pl.max_w, &sig, c->stream);
+    if (!rc) rc = dav1d_hip_launch_sgr_sig(&dp, &sp, &lp, out->bpc, dev + pl.nw, devb + o_waves, (int) pl.n_waves, &sig, c->stream);
     tr.mark(1);
     // the bands come through (roughly) in order; the last one is published with the frame (frame_run).  A band without tasks has
     // nothing to wait for beyond the bands before it.
     if (!rc) {
         volatile uint32_t *const flags = c->band_flags;
+        const std::vector<uint32_t> &target = pl.target;
         bool all_done = false, waited = false;
         for (int b = 0; b + 1 < nb; b++) {
             for (unsigned spin = 0; target[b] && flags[b] != seq && !all_done; spin++) {
@@ -1103,13 +1138,13 @@ static int frame_lr_banded(Dav1dHipFrame *f, const Dav1dHipPicture *out, const D
             if (target[b]) waited = true;
             else if (!waited) { if (hipEventSynchronize(c->ev_fork) != hipSuccess) break; waited = true; }
             std::atomic_thread_fence(std::memory_order_acquire);
-            f->publish(first_y[b + 1], out);
+            f->publish(pl.first_y[b + 1], out);
         }
     }
     tr.mark(2);
     (void) hipStreamSynchronize(c->stream);
     tr.mark(3);
-    if (tr.on) fprintf(stderr, "frame_lr_banded: host lists %.3f  uploads + launches %.3f  bands published %.3f  tail sync %.3f ms (%zu tasks, %d bands)\n",
+    if (tr.on) fprintf(stderr, "frame_lr_run (banded): upload buffers %.3f  uploads + launches %.3f  bands published %.3f  tail sync %.3f ms (%zu tasks, %d bands)\n",
                        tr.ms[0], tr.ms[1], tr.ms[2], tr.ms[3], n, nb);
     return rc;
 }
@@ -1492,7 +1527,7 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
             if (!rc) rc = copy_unrestored_planes(c, out, last, f->lr);
             // somebody listens for rows (dav1d_hip_frame_set_progress_callback): the LAST stage runs in bands of rows, each followed by
             // an event, and the rows are published band by band while the later bands still run
-            if (!rc) rc = f->progress_cb && !f->sr_w ? frame_lr_banded(f, out, last, lpf) : dav1d_hip_lr_batch(c, out, last, lpf, f->lr.data(), f->lr.size());
+            if (!rc) rc = frame_lr_run(f, out, last, lpf);
             last = out;
         }
     }

@@ -30,6 +30,11 @@
 #ifndef SB_MIN_BLOCKS
 #define SB_MIN_BLOCKS 2
 #endif
+// the next unit's coefficients touched while the current one is worked on: 1 = at the start of the current unit (ahead of its own edge
+// loads), 2 = behind its prediction, 0 = not at all
+#ifndef SB_PREFETCH
+#define SB_PREFETCH 1
+#endif
 
 namespace {
 
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
             if (ni != SB_NONE) {
                 n2 = (uint32_t) __builtin_amdgcn_readfirstlane((int) sb_next<SB_WAVES>(un));
                 if (n2 != SB_NONE) u2 = us[n2];
-                if (un.has & 2) {
+                if (SB_PREFETCH == 1 && (un.has & 2)) {
                     const int nbn = ((int) un.t.rsv[0] | (int) un.t.rsv[1] << 8) * (int) sizeof(coef);
                     keepn = dv::fetch_begin(reinterpret_cast<const char *>(cf + un.t.cf_off) + (lane * 64 < nbn ? lane * 64 : 0));
                 }
@@ -212,6 +217,10 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
             } else {
                 // a residual on its own (the blocks of a palette block, ...): the pixels it is added to come from the picture
                 for (int i = lane; i < w * h; i += 64) tile[i] = dv::ld_coherent(d + (i / w) * stride + (i % w));
+            }
+            if (SB_PREFETCH == 2 && ni != SB_NONE && (un.has & 2)) {
+                const int nbn = ((int) un.t.rsv[0] | (int) un.t.rsv[1] << 8) * (int) sizeof(coef);
+                keepn = dv::fetch_begin(reinterpret_cast<const char *>(cf + un.t.cf_off) + (lane * 64 < nbn ? lane * 64 : 0));
             }
             dv::wave_sync();
             if (has_tx) {
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(NW * 64, SBL2 == 6 ? 2 : 1) void intra_sbl_kernel(c
             if (ni != SB_NONE) {
                 n2 = (uint32_t) __builtin_amdgcn_readfirstlane((int) sb_next<NW>(un));
                 if (n2 != SB_NONE) u2 = us[n2];
-                if (un.has & 2) {
+                if (SB_PREFETCH == 1 && (un.has & 2)) {
                     const int nbn = ((int) un.t.rsv[0] | (int) un.t.rsv[1] << 8) * (int) sizeof(coef);
                     keepn = dv::fetch_begin(reinterpret_cast<const char *>(cf + un.t.cf_off) + (lane * 64 < nbn ? lane * 64 : 0));
                 }

@@ -44,7 +44,8 @@ __device__ __forceinline__ void band_done(const BandSignal &sg, const int band) 
     }
 }
 
-template <typename pixel>
+// SIG: the launch tells the host band by band where it is (frame.hip frame_lr_banded): its pixels leave write-through
+template <typename pixel, bool SIG>
 __global__ __launch_bounds__(64) void wiener_kernel(const DevPlanes dst, const DevPlanes src, const DevPlanes lpf,
                                                     const Dav1dHipLrTask *__restrict__ tasks, const int n, const int bitdepth_max, const BandSignal sig)
 {
@@ -119,10 +120,10 @@ __global__ __launch_bounds__(64) void wiener_kernel(const DevPlanes dst, const D
 #pragma unroll
             for (int k = 0; k < 7; k++) v = dv::mad_i24(win[k], fv[k], v);       // win < 2^16 (clip_limit), 16-bit taps: the full-rate multiplier
             const pixel px_out = (pixel) dv::clamp3((v + rounding_off_v) >> round_bits_v, 0, bitdepth_max);
-            if (active) { if (sig.cnt) dv::st_coherent(d + (r - 3) * dst.stride[pl], px_out); else d[(r - 3) * dst.stride[pl]] = px_out; }
+            if (active) { if (SIG) dv::st_coherent(d + (r - 3) * dst.stride[pl], px_out); else d[(r - 3) * dst.stride[pl]] = px_out; }
         }
     }
-    band_done(sig, t.pad);        // (the library's device copy carries the band in the record's spare byte)
+    if (SIG) band_done(sig, t.pad);        // (the library's device copy carries the band in the record's spare byte)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -163,7 +164,7 @@ __device__ __forceinline__ AB calc_ab(const int sumsq, const int sum, const int 
 // flags, filter type and strengths — is per-lane data; what the waves of a row share is the plane, y and the height.
 struct SgrWave { uint32_t first, end; int32_t v0; uint32_t pad; };      // tasks [first, end) = the row; lane 0 is virtual column v0 of task `first`
 
-template <typename pixel>
+template <typename pixel, bool SIG>
 __global__ __launch_bounds__(64) void sgr_kernel(const DevPlanes dst, const DevPlanes src, const DevPlanes lpf,
                                                  const Dav1dHipLrTask *__restrict__ tasks, const SgrWave *__restrict__ waves, const int n_waves,
                                                  const int bitdepth_max, const BandSignal sig)
@@ -279,11 +280,11 @@ __global__ __launch_bounds__(64) void sgr_kernel(const DevPlanes dst, const DevP
                 acc = dv::mad_i24(w0, t5, acc);
             }
             const pixel px_out = (pixel) dv::clamp3(px + ((acc + (1 << 10)) >> 11), 0, bitdepth_max);
-            if (sig.cnt) dv::st_coherent(d + y * dst.stride[pl], px_out); else d[y * dst.stride[pl]] = px_out;
+            if (SIG) dv::st_coherent(d + y * dst.stride[pl], px_out); else d[y * dst.stride[pl]] = px_out;
         }
         dv::wave_sync();
     }
-    band_done(sig, (int) wv.pad);
+    if (SIG) band_done(sig, (int) wv.pad);
 }
 
 } // namespace
@@ -296,10 +297,10 @@ extern "C" int dav1d_hip_launch_wiener_sig(const DevPlanes *dst, const DevPlanes
     const int bitdepth_max = (1 << bpc) - 1;
     const BandSignal sg = sig ? *sig : BandSignal{ nullptr, nullptr, nullptr, 0 };
     const dim3 grid(((max_w < 1 ? 1 : max_w > 384 ? 384 : max_w) + 63) / 64, n, (64 + LR_SEG - 1) / LR_SEG);   // 64 columns x 64 rows per wave
-    if (bpc == 8)
-        hipLaunchKernelGGL((wiener_kernel<uint8_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks, n, bitdepth_max, sg);
-    else
-        hipLaunchKernelGGL((wiener_kernel<uint16_t>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks, n, bitdepth_max, sg);
+#define WIENER(P, S) hipLaunchKernelGGL((wiener_kernel<P, S>), grid, dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks, n, bitdepth_max, sg)
+    if (bpc == 8) { if (sg.cnt) WIENER(uint8_t, true); else WIENER(uint8_t, false); }
+    else { if (sg.cnt) WIENER(uint16_t, true); else WIENER(uint16_t, false); }
+#undef WIENER
     return hip_rc(hipGetLastError());
 }
 extern "C" int dav1d_hip_launch_wiener(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
@@ -315,12 +316,11 @@ extern "C" int dav1d_hip_launch_sgr_sig(const DevPlanes *dst, const DevPlanes *s
     if (n_waves <= 0) return 0;
     const int bitdepth_max = (1 << bpc) - 1;
     const BandSignal sg = sig ? *sig : BandSignal{ nullptr, nullptr, nullptr, 0 };
-    if (bpc == 8)
-        hipLaunchKernelGGL((sgr_kernel<uint8_t>), dim3(n_waves), dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks,
-                           (const SgrWave *) waves, n_waves, bitdepth_max, sg);
-    else
-        hipLaunchKernelGGL((sgr_kernel<uint16_t>), dim3(n_waves), dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks,
-                           (const SgrWave *) waves, n_waves, bitdepth_max, sg);
+#define SGR(P, S) hipLaunchKernelGGL((sgr_kernel<P, S>), dim3(n_waves), dim3(64), 0, (hipStream_t) stream, *dst, *src, *lpf, tasks, \
+                                     (const SgrWave *) waves, n_waves, bitdepth_max, sg)
+    if (bpc == 8) { if (sg.cnt) SGR(uint8_t, true); else SGR(uint8_t, false); }
+    else { if (sg.cnt) SGR(uint16_t, true); else SGR(uint16_t, false); }
+#undef SGR
     return hip_rc(hipGetLastError());
 }
 extern "C" int dav1d_hip_launch_sgr(const DevPlanes *dst, const DevPlanes *src, const DevPlanes *lpf, int bpc,
