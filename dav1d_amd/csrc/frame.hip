@@ -6,6 +6,7 @@
 // Out-of-place stages land in pictures the frame owns; host code only: every kernel is reached through the batch API.
 #include "capi.h"
 #include <chrono>
+#include <memory>
 #include "cdef_rows.h"
 #include "chunk.h"
 #include <string.h>
@@ -95,6 +96,13 @@ struct Dav1dHipFrame {
         Dav1dHipLrTask *lr; size_t n_lr;
     };
     std::vector<FilterPiece> filter_pieces;
+    // Pinned slabs and device task buffers of launches that are enqueued but not waited for: the post filters of a frame are one
+    // stream of uploads and launches with ONE wait at the end (frame_run), and what they read has to stay until then
+    struct Deferred {
+        std::vector<std::pair<uint8_t *, size_t>> slabs;
+        std::vector<std::unique_ptr<TaskBuf>> bufs;
+        void release(Dav1dHipContext *c) { for (auto &sl : slabs) dav1d_hip_slab_put(c, sl.first, sl.second); slabs.clear(); bufs.clear(); }
+    } deferred;
     // the host half of the restoration stage (frame_lr_plan): made while the earlier stages' launches run
     struct LrPlan {
         bool valid = false, banded = false;
@@ -104,6 +112,8 @@ struct Dav1dHipFrame {
         std::vector<uint32_t> tail, target;
         std::vector<int> first_y, band;
         std::vector<size_t> off, pos;
+        uint8_t *slab = nullptr;       // pinned copy of what the launches read
+        size_t slab_cap = 0, bytes = 0, o_waves = 0;
     } lrplan;
     // CDEF as one record per unit row of a 64-pixel column (cdef_rows.h), written by the filter lister's threads straight into this
     // pinned table and cut into unit records on the device (cdef.hip cdef_expand_kernel); state: 0 not asked yet, 1 in use, -1 refused
@@ -842,15 +852,13 @@ static int frame_filters_from_pieces(Dav1dHipFrame *f, bool *did_cdef) {
             if (p.n_lf > p.n_lf0) memcpy(host + b, p.lf + p.n_lf0, (p.n_lf - p.n_lf0) * sizeof(*host));
             a += p.n_lf0; b += p.n_lf - p.n_lf0;
         }
-        TaskBuf dev_buf(c, n_lf * sizeof(Dav1dHipLfTask));
-        Dav1dHipLfTask *const dev = reinterpret_cast<Dav1dHipLfTask *>(dev_buf.p);
+        f->deferred.slabs.push_back({ reinterpret_cast<uint8_t *>(host), cap });
+        f->deferred.bufs.emplace_back(new TaskBuf(c, n_lf * sizeof(Dav1dHipLfTask)));
+        Dav1dHipLfTask *const dev = reinterpret_cast<Dav1dHipLfTask *>(f->deferred.bufs.back()->p);
         if (!dev) rc = -ENOMEM;
-        if (!rc) rc = dav1d_hip_upload(c, dev, host, n_lf * sizeof(*dev));
+        if (!rc) rc = hip_rc(hipMemcpyAsync(dev, host, n_lf * sizeof(*dev), hipMemcpyHostToDevice, c->stream));
         if (!rc) rc = dav1d_hip_launch_lf(&cur, f->cur.bpc, 0, dev, (int) n_lf0, f->lvl, (int) f->b4_stride, f->lut_e, f->lut_i, c->stream);
         if (!rc) rc = dav1d_hip_launch_lf(&cur, f->cur.bpc, 1, dev + n_lf0, (int) (n_lf - n_lf0), f->lvl, (int) f->b4_stride, f->lut_e, f->lut_i, c->stream);
-        if (!rc) rc = frame_lr_plan(f);          // (host work under the launches above)
-        (void) hipStreamSynchronize(c->stream);
-        dav1d_hip_slab_put(c, reinterpret_cast<uint8_t *>(host), cap);
         if (rc) return rc;
     }
     if (rows) {
@@ -865,19 +873,17 @@ static int frame_filters_from_pieces(Dav1dHipFrame *f, bool *did_cdef) {
         const size_t rb = ((size_t) w64 * h8 * sizeof(Dav1dHipCdefRow) + 255) & ~(size_t) 255, tb = n_slots * 16 * sizeof(Dav1dHipCdefTask);
         const size_t gb = (n_slots * sizeof(CdefGroup) + 255) & ~(size_t) 255;
         const size_t bm_bytes = covered || c->cdef_full_copy ? 0 : (((size_t) w8 * h8 + 31) / 32 * 4 + 255) & ~(size_t) 255;
-        TaskBuf dev_buf(c, rb + tb + gb + bm_bytes + 256);
-        uint8_t *const dev = dev_buf.p;
+        f->deferred.bufs.emplace_back(new TaskBuf(c, rb + tb + gb + bm_bytes + 256));
+        uint8_t *const dev = f->deferred.bufs.back()->p;
         if (!dev) return -ENOMEM;
-        rc = dav1d_hip_upload(c, dev, f->cdef_rows, (size_t) w64 * h8 * sizeof(Dav1dHipCdefRow));
+        rc = hip_rc(hipMemcpyAsync(dev, f->cdef_rows, (size_t) w64 * h8 * sizeof(Dav1dHipCdefRow), hipMemcpyHostToDevice, c->stream));
         Dav1dHipCdefTask *const d_tasks = reinterpret_cast<Dav1dHipCdefTask *>(dev + rb);
         uint32_t *const d_bm = bm_bytes ? reinterpret_cast<uint32_t *>(dev + rb + tb + gb) : nullptr;
         if (!rc) rc = dav1d_hip_launch_cdef_expand(dev, w64, h8, 2 * w8, 2 * h8, w8, d_tasks, dev + rb + tb, d_bm, c->stream);
         if (!rc && d_bm) rc = dav1d_hip_launch_cdef_fill_unlisted(&t0, &cur, f->cur.bpc, f->cur.layout, nullptr, 0, d_bm, w8, h8, c->stream);
         if (!rc) rc = dav1d_hip_launch_cdef_groups(&t0, &cur, f->cur.bpc, f->cur.layout, d_tasks, reinterpret_cast<const CdefGroup *>(dev + rb + tb), (int) n_slots,
                                                    f->cdef_damping, nullptr, c->stream);
-        if (!rc) rc = frame_lr_plan(f);          // (host work under the launches above)
-        (void) hipStreamSynchronize(c->stream);
-        f->cdef_row_units.store(0);              // consumed, like the pieces; the table is wiped before anybody writes to it again
+        f->cdef_row_units.store(0);              // consumed, like the pieces; the table is wiped before anybody writes to it again (after frame_run's wait)
         f->cdef_rows_dirty = true;
         if (rc) return rc;
         *did_cdef = true;
@@ -926,10 +932,11 @@ static int frame_filters_from_pieces(Dav1dHipFrame *f, bool *did_cdef) {
             copy_pieces(0, np / nt);
             for (std::thread &x : th) x.join();
         }
-        TaskBuf dev_buf(c, tb + gb + bm_bytes + 256);
-        uint8_t *const dev = dev_buf.p;
+        f->deferred.slabs.push_back({ host, cap });
+        f->deferred.bufs.emplace_back(new TaskBuf(c, tb + gb + bm_bytes + 256));
+        uint8_t *const dev = f->deferred.bufs.back()->p;
         if (!dev) rc = -ENOMEM;
-        if (!rc) rc = dav1d_hip_upload(c, dev, host, tb + n_groups * sizeof(CdefGroup));
+        if (!rc) rc = hip_rc(hipMemcpyAsync(dev, host, tb + n_groups * sizeof(CdefGroup), hipMemcpyHostToDevice, c->stream));
         const Dav1dHipCdefTask *d_tasks = reinterpret_cast<const Dav1dHipCdefTask *>(dev);
         if (!rc && bm_bytes)
             rc = dav1d_hip_launch_cdef_fill_unlisted(&t0, &cur, f->cur.bpc, f->cur.layout, d_tasks, (int) n_cdef,
@@ -941,12 +948,13 @@ static int frame_filters_from_pieces(Dav1dHipFrame *f, bool *did_cdef) {
         } else if (!rc) {
             rc = dav1d_hip_launch_cdef(&t0, &cur, f->cur.bpc, f->cur.layout, d_tasks, (int) n_cdef, f->cdef_damping, nullptr, 0, c->stream);
         }
-        if (!rc) rc = frame_lr_plan(f);          // (host work under the launches above)
-        (void) hipStreamSynchronize(c->stream);
-        dav1d_hip_slab_put(c, host, cap);
         if (rc) return rc;
         *did_cdef = true;
     }
+    // the pieces' arrays were read by the copies above (host to pinned memory): they can go; the device works on, and the host half of
+    // restoration is made meanwhile
+    rc = frame_lr_plan(f);
+    if (rc) return rc;
     for (Dav1dHipFrame::FilterPiece &p : f->filter_pieces) {
         free(p.lf); free(p.cdef); free(p.lr);
         delete p.groups;
@@ -1077,6 +1085,16 @@ static int frame_lr_plan(Dav1dHipFrame *f) {
     }
     pl.n_waves = pl.tail.size() / 4;
     if (pl.banded) pl.tail.insert(pl.tail.end(), pl.target.begin(), pl.target.end());
+    // what goes to the device, in pinned memory: [tasks][wave descriptors (+ band targets)] — one asynchronous copy at run time
+    pl.o_waves = (n * sizeof(Dav1dHipLrTask) + 15) & ~(size_t) 15;
+    pl.bytes = pl.o_waves + pl.tail.size() * 4;
+    if (pl.slab && pl.slab_cap < pl.bytes + 16) { dav1d_hip_slab_put(f->c, pl.slab, pl.slab_cap); pl.slab = nullptr; }
+    if (!pl.slab && n) pl.slab = dav1d_hip_slab_get(f->c, pl.bytes + 16, &pl.slab_cap);
+    if (n && !pl.slab) return -ENOMEM;
+    if (n) {
+        memcpy(pl.slab, pl.sorted.data(), n * sizeof(Dav1dHipLrTask));
+        if (!pl.tail.empty()) memcpy(pl.slab + pl.o_waves, pl.tail.data(), pl.tail.size() * 4);
+    }
     pl.valid = true;
     return 0;
 }
@@ -1097,20 +1115,19 @@ static int frame_lr_run(Dav1dHipFrame *f, const Dav1dHipPicture *out, const Dav1
         if (hipHostMalloc((void **) &c->band_flags, 64 * sizeof(uint32_t), 0) != hipSuccess) { c->band_flags = nullptr; return -ENOMEM; }
         memset(c->band_flags, 0, 64 * sizeof(uint32_t));
     }
-    const size_t o_waves = (n * sizeof(Dav1dHipLrTask) + 15) & ~(size_t) 15;
-    TaskBuf devb_buf(c, o_waves + pl.tail.size() * 4 + 16);
-    uint8_t *const devb = devb_buf.p;
+    const size_t o_waves = pl.o_waves;
+    f->deferred.bufs.emplace_back(new TaskBuf(c, pl.bytes + 16));
+    uint8_t *const devb = f->deferred.bufs.back()->p;
     if (!devb) return -ENOMEM;
     Dav1dHipLrTask *const dev = reinterpret_cast<Dav1dHipLrTask *>(devb);
     tr.mark(0);
-    rc = dav1d_hip_upload(c, dev, pl.sorted.data(), n * sizeof(*dev));
-    if (!rc && !pl.tail.empty()) rc = dav1d_hip_upload(c, devb + o_waves, pl.tail.data(), pl.tail.size() * 4);
+    rc = hip_rc(hipMemcpyAsync(devb, pl.slab, pl.bytes, hipMemcpyHostToDevice, c->stream));
     const DevPlanes dp = dev_planes(out), sp = dev_planes(in), lp = dev_planes(lpf);
     if (!banded) {
+        // enqueued behind the stages before, not waited for: frame_run waits once, at its end
         if (!rc) rc = dav1d_hip_launch_wiener(&dp, &sp, &lp, out->bpc, dev, (int) pl.nw, pl.max_w, c->stream);
         if (!rc) rc = dav1d_hip_launch_sgr(&dp, &sp, &lp, out->bpc, dev + pl.nw, devb + o_waves, (int) pl.n_waves, c->stream);
-        const int rs = hip_rc(hipStreamSynchronize(c->stream));
-        return rc ? rc : rs;
+        return rc;
     }
     if (!rc) rc = hip_rc(hipMemsetAsync(c->band_cnt, 0, 64 * sizeof(uint32_t), c->stream));
     const uint32_t seq = ++c->band_seq ? c->band_seq : ++c->band_seq;        // never 0: the flags start at 0
@@ -1197,6 +1214,15 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
     Dav1dHipContext *c = f->c;
     int rc = 0;
     FrameTrace tr;
+    // whatever the post filters enqueued without waiting (Dav1dHipFrame::deferred) is through before its buffers go back, on every way out
+    struct DeferredGuard {
+        Dav1dHipFrame *f;
+        ~DeferredGuard() {
+            if (f->deferred.slabs.empty() && f->deferred.bufs.empty()) return;
+            (void) hipStreamSynchronize(f->c->stream);
+            f->deferred.release(f->c);
+        }
+    } deferred_guard{ f };
     // the raster planes of every picture this frame writes change below: whatever tiled twin a recycled picture still carries is
     // stale from here on (*filtered is a copy of one of these descriptors, so it reports twin_ok = 0 unless the frame retiles it)
     f->cur.twin_ok = 0;
@@ -1641,6 +1667,8 @@ void dav1d_hip_frame_destroy(Dav1dHipFrame *f) {
     for (Dav1dHipFrame::StepChunk *sc : f->step_chunks) delete sc;
     for (Dav1dHipFrame::FilterPiece &p : f->filter_pieces) { free(p.lf); free(p.cdef); free(p.lr); delete p.groups; }
     if (f->cdef_rows) dav1d_hip_slab_put(f->c, reinterpret_cast<uint8_t *>(f->cdef_rows), f->cdef_rows_cap);
+    if (f->lrplan.slab) dav1d_hip_slab_put(f->c, f->lrplan.slab, f->lrplan.slab_cap);
+    f->deferred.release(f->c);
     if (f->harena) dav1d_hip_slab_put(f->c, f->harena, f->harena_cap);
     if (f->huarena) dav1d_hip_slab_put(f->c, f->huarena, f->huarena_cap);
     if (f->hcarena) dav1d_hip_slab_put(f->c, f->hcarena, f->hcarena_cap);
