@@ -818,12 +818,21 @@ static int copy_picture(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Da
 static int frame_lr_plan(Dav1dHipFrame *f);
 static int copy_unrestored_planes(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src, const std::vector<Dav1dHipLrTask> &lr);
 
+struct FrameTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    double ms[8];
+    FrameTrace() : on(getenv("DAV1D_HIP_TRACE_FRAME") != nullptr), t(std::chrono::steady_clock::now()) { for (double &v : ms) v = 0; }
+    void mark(int k) { if (!on) return; const auto n = std::chrono::steady_clock::now(); ms[k] += std::chrono::duration<double, std::milli>(n - t).count(); t = n; }
+};
+
 // Deblocking and CDEF of a frame straight from the pieces: the tasks copied piece after piece into pinned memory (the larger
 // arrays on a few threads), one upload each, the launches of dav1d_hip_lf_batch / dav1d_hip_cdef_run_groups.  *did_cdef: the
 // CDEF output is in f->tmp[0].
 static int frame_filters_from_pieces(Dav1dHipFrame *f, bool *did_cdef) {
     Dav1dHipContext *c = f->c;
     *did_cdef = false;
+    FrameTrace tr;
     // CDEF came as unit rows: expanded on the device below — unless unit records were submitted as well (one list then, made here)
     bool rows = f->cdef_rows_state == 1 && f->cdef_row_units.load() > 0;
     if (rows) {
@@ -852,6 +861,7 @@ static int frame_filters_from_pieces(Dav1dHipFrame *f, bool *did_cdef) {
             if (p.n_lf > p.n_lf0) memcpy(host + b, p.lf + p.n_lf0, (p.n_lf - p.n_lf0) * sizeof(*host));
             a += p.n_lf0; b += p.n_lf - p.n_lf0;
         }
+        tr.mark(0);
         f->deferred.slabs.push_back({ reinterpret_cast<uint8_t *>(host), cap });
         f->deferred.bufs.emplace_back(new TaskBuf(c, n_lf * sizeof(Dav1dHipLfTask)));
         Dav1dHipLfTask *const dev = reinterpret_cast<Dav1dHipLfTask *>(f->deferred.bufs.back()->p);
@@ -861,6 +871,7 @@ static int frame_filters_from_pieces(Dav1dHipFrame *f, bool *did_cdef) {
         if (!rc) rc = dav1d_hip_launch_lf(&cur, f->cur.bpc, 1, dev + n_lf0, (int) (n_lf - n_lf0), f->lvl, (int) f->b4_stride, f->lut_e, f->lut_i, c->stream);
         if (rc) return rc;
     }
+    tr.mark(1);
     if (rows) {
         rc = frame_tmp(f, 0);
         if (rc) return rc;
@@ -953,13 +964,18 @@ static int frame_filters_from_pieces(Dav1dHipFrame *f, bool *did_cdef) {
     }
     // the pieces' arrays were read by the copies above (host to pinned memory): they can go; the device works on, and the host half of
     // restoration is made meanwhile
+    tr.mark(2);
     rc = frame_lr_plan(f);
     if (rc) return rc;
+    tr.mark(3);
     for (Dav1dHipFrame::FilterPiece &p : f->filter_pieces) {
         free(p.lf); free(p.cdef); free(p.lr);
         delete p.groups;
     }
     f->filter_pieces.clear();
+    tr.mark(4);
+    if (tr.on) fprintf(stderr, "filters from pieces: deblocking tasks to pinned memory %.3f  enqueue %.3f  CDEF enqueue %.3f  restoration plan %.3f  pieces freed %.3f ms\n",
+                       tr.ms[0], tr.ms[1], tr.ms[2], tr.ms[3], tr.ms[4]);
     return 0;
 }
 
@@ -1018,13 +1034,6 @@ static int copy_picture(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Da
     return 0;
 }
 
-struct FrameTrace {
-    bool on;
-    std::chrono::steady_clock::time_point t;
-    double ms[8];
-    FrameTrace() : on(getenv("DAV1D_HIP_TRACE_FRAME") != nullptr), t(std::chrono::steady_clock::now()) { for (double &v : ms) v = 0; }
-    void mark(int k) { if (!on) return; const auto n = std::chrono::steady_clock::now(); ms[k] += std::chrono::duration<double, std::milli>(n - t).count(); t = n; }
-};
 
 // Row-granular progress without banding the whole frame (the reference publishes f->sr_cur.progress[1] after the last filter of every
 // superblock row, src/thread_task.c:888-896; post_filters_pipelined() above follows every band through all three stages on three
