@@ -165,6 +165,22 @@ def task_loop_rate(hip_lib_path, w, h, bpc, tiles=(4, 1), threads=64, frame_dela
         tail_s, tail_n = run.last_tail, frames - 1 - run.tail_from
         stages = dict(run.last_stats)
         stages["frame_end_ms_by_frame"] = list(run.last_frame_end_ms)
+        # the same chain once more with rows published to dav1d's progress[1] as the backend reports them (C callback: dav1d_hooked_rows_done)
+        fe_plain = list(run.last_frame_end_ms)
+        rp = None
+        try:
+            run.tail_from = min(frame_delay, frames - 2)
+            run(params(w, h, bpc, frames, mode=1, keep_output=False, row_progress=1, **common), hip_lib_path, store, inject=2)
+            fe_rows = list(run.last_frame_end_ms)
+            k0 = min(frame_delay, frames - 2) + 1
+            med = lambda v: float(np.median(v[k0:])) if len(v) > k0 else None
+            a_ms, b_ms = med(fe_plain), med(fe_rows)
+            rp = {"steady_state_fps": round((frames - 1 - run.tail_from) / run.last_tail, 1) if run.last_tail else None,
+                  "frame_end_ms_median": b_ms, "frame_end_ms_median_without": a_ms,
+                  "cost_pct_of_frame_end": round((b_ms / a_ms - 1) * 100, 1) if a_ms and b_ms else None,
+                  "rows_published": int(getattr(run, "last_row_publications", 0))}
+        except Exception as e:          # noqa: BLE001 - the leg reports, the main figure stands
+            rp = {"error": str(e)[:200]}
     finally:
         store.destroy()
     return {"frames": frames, "fps": round(frames / t_s, 1), "ms_per_frame": round(t_s / frames * 1e3, 2),
@@ -173,7 +189,7 @@ def task_loop_rate(hip_lib_path, w, h, bpc, tiles=(4, 1), threads=64, frame_dela
                              "value": round(w * h * tail_n / tail_s / 1e6, 1) if tail_s else None,
                              "what": "the inter frames after the first %d (key frame, first-use allocations and pipeline fill left out): completion of frame %d to "
                                      "completion of the last" % (run.tail_from + 1, run.tail_from)}, "n_fc": n_fc, "worker_threads": threads,
-            "tile_cols": tiles[0], "tile_rows": tiles[1], "ms_per_frame_by_stage_summed_over_threads": stages,
+            "tile_cols": tiles[0], "tile_rows": tiles[1], "ms_per_frame_by_stage_summed_over_threads": stages, "row_progress": rp,
             "peer_fps": round(check_frames / cpu_s, 2), "peer": "the reference's pass 2 + in-loop filters (C, no assembly) under the same task loop, %d worker threads, "
                                                                "%d frames" % (threads, check_frames),
             "parity": "bit-exact vs dav1d's own pass 2 + filters under the same task loop (%d frames)" % check_frames,
