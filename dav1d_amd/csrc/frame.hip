@@ -1268,11 +1268,15 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
         // a chunk that found no room in the twin (the first frames of a size: the arena is sized by what frames have needed) sits in
         // a slab of its own: the arena grows to what was drawn, the twin goes up again if it did, the late chunks follow
         bool regrown = false;
+        FrameTrace t2;
         rc = dav1d_hip_chunks_grow_arena(c, &f->arena, &f->arena_cap, f->arena_used.load(), &regrown);
         if (regrown) f->harena_flushed = 0;
         if (!rc && f->harena) rc = frame_flush_locked(f);       // what dav1d_hip_frame_flush has not sent yet (the gather launch waits for the copy stream)
+        t2.mark(0);
         if (!rc) rc = dav1d_hip_chunks_send_late(c, f->chunks, f->arena, f->arena_cap, regrown);      // after the twin: see chunk.h
         if (!rc) rc = dav1d_hip_chunks_to_recon_list(c, f->chunks, &f->arena, &f->arena_cap, f->refs, f->n_refs, &rl, &il, &ml, &cl, &xl);
+        t2.mark(1);
+        struct T2 { FrameTrace &t; ~T2() { t.mark(2); if (t.on) fprintf(stderr, "recon enqueue: arena + flush %.3f  chunks -> lists (gather) %.3f  launches %.3f ms\n", t.ms[0], t.ms[1], t.ms[2]); } } t2_end{ t2 };
         if (!rc) {
             if (ml.n || cl.n || rl.f_n[0] || rl.f_n[1] || rl.f_n[2] || rl.f_n[3] || rl.f_n[4]) {
                 if (!f->n_refs) rc = -EINVAL;
