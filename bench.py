@@ -1118,6 +1118,18 @@ def run_job(a, rank, local, world):
                     ctx.sync()
                     task_loop_stream = sut.task_loop_rate(_l.DEFAULT_PATH, w, h, bpc, tiles_log2=(2, 0), threads=min(64, os.cpu_count() or 8), frame_delay=8,
                                                           frames=a.stream_frames)
+                    # the same with every segment pinned to a reference frame (random payloads otherwise make three quarters of the blocks
+                    # intra, and the frame waits for the intra wavefront): more of the stream is motion compensation
+                    try:
+                        pinned = sut.task_loop_rate(_l.DEFAULT_PATH, w, h, bpc, tiles_log2=(2, 0), threads=min(64, os.cpu_count() or 8), frame_delay=8,
+                                                    frames=a.stream_frames, seg_pin=1)
+                        task_loop_stream["segments_pinned"] = {k: pinned.get(k) for k in ("steady_state", "peer_steady_state", "fps", "peer_fps", "parity")}
+                        t = pinned.get("tools_in_the_stream") or {}
+                        task_loop_stream["segments_pinned"]["blocks_intra_inter"] = [t.get("b_intra"), t.get("b_inter")]
+                    except AssertionError:
+                        raise
+                    except Exception as e:       # noqa: BLE001
+                        task_loop_stream["segments_pinned"] = {"error": str(e)[:200]}
             except AssertionError as e:
                 raise SystemExit("bench: the dav1d task loop leg behind dav1d's real pass 1 differs from dav1d: %s" % e)
             except Exception as e:       # noqa: BLE001  (a reported extra)
