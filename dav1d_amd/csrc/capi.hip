@@ -2282,8 +2282,10 @@ struct Dav1dHipIntraSb {
     uint32_t *flags;            // n_regions + 1 words for the one-launch form
     std::vector<uint32_t> level_start;
     size_t n_units, n_regions;
-    int sb_log2;
+    int sb_log2, sbw;
     bool needs_aux;
+    bool has_copies;            // intra block copies among the units: the L2 hand-off kernel only, and (one launch) the `where` table
+    uint32_t *where;            // superblock (raster) -> its region, for the copies' waits in the one-launch form
 };
 
 void dav1d_hip_intra_sb_destroy(Dav1dHipContext *c, Dav1dHipIntraSb *l) {
@@ -2292,6 +2294,7 @@ void dav1d_hip_intra_sb_destroy(Dav1dHipContext *c, Dav1dHipIntraSb *l) {
     if (l->units) hipFree(l->units);
     if (l->regions) hipFree(l->regions);
     if (l->flags) hipFree(l->flags);
+    if (l->where) hipFree(l->where);
     delete l;
 }
 size_t dav1d_hip_intra_sb_levels(const Dav1dHipIntraSb *l) { return l && !l->level_start.empty() ? l->level_start.size() - 1 : 0; }
@@ -2327,11 +2330,14 @@ int dav1d_hip_intra_sb_create(Dav1dHipContext *c, Dav1dHipIntraSb **out, const D
     units.swap(sorted);
     const std::vector<SbPart> &parts = st.parts;
     SbPlan plan;
-    rc = dav1d_hip_sbw_plan(tl, { &parts }, { 0 }, nullptr, plan);
+    std::sort(st.copy_deps.begin(), st.copy_deps.end());
+    st.copy_deps.erase(std::unique(st.copy_deps.begin(), st.copy_deps.end()), st.copy_deps.end());
+    rc = dav1d_hip_sbw_plan(tl, { &parts }, { 0 }, nullptr, plan, st.copy_deps.empty() ? nullptr : &st.copy_deps);
     if (rc) return rc;
     Dav1dHipIntraSb *l = new (std::nothrow) Dav1dHipIntraSb();
     if (!l) return -ENOMEM;
-    l->units = nullptr; l->regions = nullptr; l->flags = nullptr;
+    l->units = nullptr; l->regions = nullptr; l->flags = nullptr; l->where = nullptr;
+    l->has_copies = !st.copy_deps.empty(); l->sbw = tl.sbw;
     l->n_units = units.size(); l->n_regions = plan.regions.size();
     l->level_start = plan.level_start;
     l->sb_log2 = tl.sb_log2;
@@ -2342,6 +2348,10 @@ int dav1d_hip_intra_sb_create(Dav1dHipContext *c, Dav1dHipIntraSb **out, const D
         if (!rc && hipMalloc((void **) &l->flags, (l->n_regions + 1) * sizeof(uint32_t)) != hipSuccess) rc = -ENOMEM;
         if (!rc) rc = dav1d_hip_upload(c, l->units, units.data(), l->n_units * sizeof(IntraUnit));
         if (!rc) rc = dav1d_hip_upload(c, l->regions, plan.regions.data(), l->n_regions * sizeof(SbRegion));
+        if (!rc && l->has_copies) {
+            if (hipMalloc((void **) &l->where, plan.where.size() * sizeof(uint32_t)) != hipSuccess) rc = -ENOMEM;
+            if (!rc) rc = dav1d_hip_upload(c, l->where, plan.where.data(), plan.where.size() * sizeof(uint32_t));
+        }
     }
     if (rc) { dav1d_hip_intra_sb_destroy(c, l); return rc; }
     *out = l;
@@ -2354,14 +2364,15 @@ int dav1d_hip_intra_sb_run(Dav1dHipContext *c, const Dav1dHipIntraSb *l, const D
     if (!c || !l || !dst || (l->needs_aux && !aux)) return -EINVAL;
     const DevPlanes dp = dev_planes(dst);
     int rc = 0;
-    if (c->intra_sb_flow && !c->intra_sb_lds && l->level_start.size() > 2) {
+    const int lds = c->intra_sb_lds && !l->has_copies;          // (the LDS-resident form does not copy)
+    if (c->intra_sb_flow && !lds && l->level_start.size() > 2) {
         if (hipMemsetAsync(l->flags, 0, (l->n_regions + 1) * sizeof(uint32_t), c->stream) != hipSuccess) return -EIO;
         return dav1d_hip_launch_intra_sb(&dp, dst->bpc, dst->layout, l->units, l->regions, (int) l->n_regions, aux, nullptr, coef, c->intra_sb_waves, l->sb_log2, 0,
-                                         l->flags, c->stream);
+                                         l->flags, c->stream, l->where, l->sbw);
     }
     for (size_t k = 0; k + 1 < l->level_start.size() && !rc; k++)
         rc = dav1d_hip_launch_intra_sb(&dp, dst->bpc, dst->layout, l->units, l->regions + l->level_start[k],
-                                       (int) (l->level_start[k + 1] - l->level_start[k]), aux, nullptr, coef, c->intra_sb_waves, l->sb_log2, c->intra_sb_lds, nullptr, c->stream);
+                                       (int) (l->level_start[k + 1] - l->level_start[k]), aux, nullptr, coef, c->intra_sb_waves, l->sb_log2, lds, nullptr, c->stream);
     return rc;
 }
 
@@ -2374,7 +2385,7 @@ int dav1d_hip_intra_sb_status(Dav1dHipContext *c, const Dav1dHipIntraSb *l, uint
     if (!l->flags || !l->n_units) return dav1d_hip_sync(c);
     const int rc = dav1d_hip_download(c, &n, l->flags + l->n_regions, sizeof(n));
     if (rc) return rc;
-    if (!(c->intra_sb_flow && !c->intra_sb_lds && l->level_start.size() > 2)) n = 0;      // the flags are only written by the one-launch form
+    if (!(c->intra_sb_flow && !(c->intra_sb_lds && !l->has_copies) && l->level_start.size() > 2)) n = 0;      // the flags are only written by the one-launch form
     if (gave_up) *gave_up = n;
     return n ? -EIO : 0;
 }
