@@ -93,7 +93,6 @@ typedef struct Out {
     VEC(Dav1dHipIpredTask) ipred; VEC(uint16_t) ipred_step;
     VEC(Dav1dHipCompTask) blend;  VEC(uint16_t) blend_step;
     VEC(Dav1dHipItxTask) sitx;    VEC(uint16_t) sitx_step;
-    VEC(Dav1dHipMcTask) smc;      VEC(uint16_t) smc_step;       /* intra block copies: predictions from the frame's own pixels */
     uint8_t *pack; size_t npack, pack_cap;                     /* packing lister: the tile-sbrow's coefficient values (npack of them) */
 } Out;
 
@@ -1250,7 +1249,7 @@ static __thread Out *out_tls;
 static void out_free(void *p) {
     Out *o = (Out *) p;
     if (!o) return;
-    free(o->smc.p); free(o->smc_step.p); free(o->pack);
+    free(o->pack);
     free(o->mc.p); free(o->comp.p); free(o->warp.p); free(o->scaled.p); free(o->itx.p); free(o->itx_dep.p);
     free(o->ipred.p); free(o->ipred_step.p); free(o->blend.p); free(o->blend_step.p); free(o->sitx.p); free(o->sitx_step.p);
     free(o);
@@ -1266,7 +1265,7 @@ static Out *out_get(void) {
         (void) pthread_setspecific(out_key, o);
     }
     o->mc.n = o->comp.n = o->warp.n = o->scaled.n = o->itx.n = o->itx_dep.n = o->ipred.n = o->ipred_step.n = o->blend.n = o->blend_step.n = 0;
-    o->sitx.n = o->sitx_step.n = o->smc.n = o->smc_step.n = 0;
+    o->sitx.n = o->sitx_step.n = 0;
     o->npack = 0;
     return o;
 }
@@ -1320,7 +1319,6 @@ int dav1d_hip_lister_tile_sbrow(Dav1dHipLister *l, const int tile_row, const int
     PROF_ADD(0, t1 - t0); PROF_ADD(1, t2 - t1);
     if (!rc && op->warp.n) rc = dav1d_hip_frame_submit_warp(l->frame, op->warp.p, op->warp.n);
     if (!rc && op->scaled.n) rc = dav1d_hip_frame_submit_scaled(l->frame, op->scaled.p, op->scaled.n);
-    if (!rc && op->smc.n) rc = dav1d_hip_frame_submit_step_copy(l->frame, op->smc.p, op->smc_step.p, op->smc.n);
     if (!rc && (op->ipred.n || op->sitx.n)) {
         /* what this row of superblocks reads of its neighbours (dep_step): a frame without a tiling has no use for it */
         const int sbx0 = w.col_start / l->sb_step, sbx1 = (w.col_end + l->sb_step - 1) / l->sb_step;
@@ -1329,8 +1327,8 @@ int dav1d_hip_lister_tile_sbrow(Dav1dHipLister *l, const int tile_row, const int
     if (!rc) rc = submit_steps(l, op);
     if (!rc) cur->next_sby = sby + 1;
     if (rc && getenv("DAV1D_HIP_TRACE_LISTER"))
-        fprintf(stderr, "lister: tile (%d, %d) sby %d: rc %d (walk err %d, oom %d; %zu mc %zu comp %zu warp %zu scaled %zu itx %zu ipred %zu sitx %zu smc)\n", tile_row, tile_col, sby, rc,
-                w.err, v_oom, op->mc.n, op->comp.n, op->warp.n, op->scaled.n, op->itx.n, op->ipred.n, op->sitx.n, op->smc.n);
+        fprintf(stderr, "lister: tile (%d, %d) sby %d: rc %d (walk err %d, oom %d; %zu mc %zu comp %zu warp %zu scaled %zu itx %zu ipred %zu sitx)\n", tile_row, tile_col, sby, rc,
+                w.err, v_oom, op->mc.n, op->comp.n, op->warp.n, op->scaled.n, op->itx.n, op->ipred.n, op->sitx.n);
     return rc;
 }
 
