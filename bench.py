@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--edge-frac", type=float, default=0.05, help="fraction of blocks pointing outside the picture")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not count roofline.traffic with rocprofv3 children (the committed profile's figure is reported instead)")
     ap.add_argument("--no-inflight", action="store_true", help="skip the frames-in-flight leg of the full table")
     ap.add_argument("--packed", action="store_true", help="feed the residuals in the sparse wire format (DAV1D_HIP_ITX_PACKED)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (hand-off arrays -> lister -> device)")
@@ -134,6 +135,79 @@ def step_traffic(w, h, bpc, a):
     if not files:
         return None
     return json.load(open(files[-1])).get("bytes_per_step")
+
+def _kernel_pattern(name):
+    """bench's kernel label -> regular expression on the HIP kernel's demangled name"""
+    import re
+    m = re.match(r"(mc|itx|recon)_(\d+)x(\d+)", name)
+    if not m:
+        return None
+    if m.group(1) == "recon":
+        return r"recon_fused_kernel<%d," % (int(m.group(2)).bit_length() - 3)
+    if m.group(1) == "mc":
+        return r"mc_(?:twin_)?kernel<%s, %s," % (m.group(2), m.group(3))
+    from dav1d_amd import synth
+    tx = [i for i in range(19) if synth.TX_W[i] == int(m.group(2)) and synth.TX_H[i] == int(m.group(3))][0]
+    return r"itx_add(?:_wide)?_kernel<%d," % tx
+
+
+def counted_traffic(a, timeout=240):
+    """HBM bytes of the step's kernels counted in THIS run on THIS box: two rocprofv3 children (FETCH_SIZE and WRITE_SIZE take a pass
+    each, MI355X_MICROARCH.md "rocprofv3 PMC slots"; kernel trace only, no other trace domain) over `bench.py --step-only` with the
+    same workload arguments.  Returns {"per_kernel": {demangled name: bytes per launch}, "per_step": bytes, "launches": n} or
+    {"error": ...}.  HBM bytes = FETCH_SIZE x 2 (gfx950: 128-byte requests are tallied as 64, calibrated in
+    profiles/r02_calib_fetch_size.txt) + WRITE_SIZE, both reported in KiB."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return {"error": "no rocprofv3 on this host"}
+    steps, warm = 2, 1
+    args = [sys.executable, os.path.abspath(__file__), "--step-only", "--steps", str(steps), "--warmup", str(warm), "--width", str(a.width),
+            "--height", str(a.height), "--bpc", str(a.bpc), "--mix", a.mix, "--mv-range", str(a.mv_range), "--edge-frac", str(a.edge_frac)]
+    if a.packed:
+        args.append("--packed")
+    if a.two_phase:
+        args.append("--two-phase")
+    env = dict(os.environ, DAV1D_BENCH_CHILD="1", TMPDIR="/tmp")
+    tot = {}
+    tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    try:
+        for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, cname)
+            try:
+                r = subprocess.run([exe, "--kernel-trace", "--pmc", cname, "--output-format", "csv", "-d", out, "--"] + args, cwd="/tmp", env=env,
+                                   capture_output=True, text=True, timeout=timeout)
+            except subprocess.TimeoutExpired:
+                return {"error": "rocprofv3 --pmc %s timed out after %d s" % (cname, timeout)}
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode or not files:
+                return {"error": "rocprofv3 --pmc %s: rc %d, %d counter files: %s" % (cname, r.returncode, len(files), (r.stderr or r.stdout)[-200:])}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] != cname:
+                        continue
+                    e = tot.setdefault(row["Kernel_Name"], {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n": 0})
+                    e[cname] += float(row["Counter_Value"]) * 1024
+                    if cname == "FETCH_SIZE":
+                        e["n"] += 1
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    import re
+    step_re = re.compile(r"(mc_kernel|mc_twin_kernel|itx_add_kernel|itx_add_wide_kernel|recon_fused_kernel|comp_kernel|mc_all_kernel|itx_multi_kernel)<")
+    per_kernel, per_step = {}, 0.0
+    for k, e in tot.items():
+        if not e["n"] or not step_re.search(k):        # fills / copies of the harness are not the step
+            continue
+        b = 2 * e["FETCH_SIZE"] + e["WRITE_SIZE"]
+        per_kernel[k] = b / e["n"]
+        per_step += b / (steps + warm)
+    if not per_kernel:
+        return {"error": "no kernel of the step in the counter files"}
+    return {"per_kernel": per_kernel, "per_step": per_step, "launches": steps + warm}
 
 
 def device_probe(torch):
@@ -289,6 +363,114 @@ def respawn_under_launcher(a):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.execv(sys.executable, cmd)
 
+# ---- the line the driver parses.  Everything a run measures goes to bench_legs.json (next to this file, and to gpurun_out/ when that
+# exists) and to stderr; stdout carries ONE line of well under 8 KB (round 4's line had grown to 23 KB and the driver's record of it
+# came back unparsed): the contract fields, flat roofline / cpu_baseline scalars and one number + parity per leg.
+LINE_LIMIT = 8000
+
+
+def _short(v, n=160):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 3] + "..."
+
+
+def _leg_digest(name, leg):
+    """one number + parity per leg"""
+    if not isinstance(leg, dict):
+        return None
+    if "error" in leg:
+        return {"error": _short(leg["error"], 80)}
+    if "status" in leg:
+        return {"status": _short(leg["status"], 80)}
+    d = {}
+    ss = leg.get("steady_state")
+    if isinstance(ss, dict):
+        d["fps"] = ss.get("fps")
+        ps = leg.get("peer_steady_state")
+        if isinstance(ps, dict):
+            d["peer_fps"] = ps.get("fps")
+        if "frame_end_ms" in ss:
+            d["frame_end_ms"] = ss.get("frame_end_ms")
+    for k in ("ms_per_frame", "ms_per_step", "total_ms", "frame_end_ms", "list_ms", "cost_pct", "host_cpu_ms_per_frame", "value", "frac", "save_tmvs_ms"):
+        if k in leg and not isinstance(leg[k], (dict, list)) and k not in d:
+            d[k] = leg[k]
+        if len(d) >= 4:
+            break
+    par = leg.get("parity")
+    if isinstance(par, str):
+        d["parity"] = "bit-exact" if par.startswith(("bit-exact", "every stage bit-exact")) else _short(par, 40)
+    return d or None
+
+
+def compact_line(full, legs=None):
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: full.get(k) for k in keep}
+    cfg = full.get("config") or {}
+    line["config"] = {k: _short(cfg.get(k), 330) for k in ("workload", "parallelism", "parity", "frames_per_step", "coef_format", "step") if k in cfg}
+    roof = full.get("roofline")
+    if isinstance(roof, dict):
+        r = {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_bytes_per_launch",
+                                       "frac_measured_traffic", "traffic_over_algorithmic", "path_frac", "path_achieved", "path_ms", "path_traffic",
+                                       "path_traffic_over_algorithmic", "class_4x4_frac", "class_4x4_ms", "full_table_frac",
+                                       "full_table_ms_per_frame", "full_table_achieved", "kernels_ms", "kernels_frac", "kernels_traffic", "what") if k in roof}
+        r["traffic_source"] = _short(roof.get("traffic_source"), 200)
+        line["roofline"] = r
+    else:
+        line["roofline"] = roof
+    cpu = full.get("cpu_baseline")
+    if isinstance(cpu, dict):
+        line["cpu_baseline"] = {k: _short(cpu.get(k), 200) for k in ("value", "unit", "cores", "kind", "sample", "host_cores_available", "all_cores_value",
+                                                                       "all_cores_cores", "reference_pass2_value", "reference_pass2_cores", "avx2") if k in cpu}
+    else:
+        line["cpu_baseline"] = cpu
+    line["n_ranks_seen"] = full.get("n_ranks_seen")
+    dg = dict(legs or {})
+    for k, v in full.items():
+        if k in keep or k in ("config", "roofline", "cpu_baseline", "n_ranks_seen", "legs", "device", "streams"):
+            continue
+        if k == "end_to_end_frames_in_flight" and isinstance(v, dict):
+            for kk, vv in v.items():
+                e = _leg_digest(kk, vv) if isinstance(vv, dict) else None
+                if e:
+                    dg["in_flight_" + kk] = e
+            continue
+        e = _leg_digest(k, v)
+        if e:
+            dg[k] = e
+    if isinstance(full.get("full_table"), dict) and isinstance(full["full_table"].get("stages_ms"), dict):
+        dg.setdefault("full_table", {})["stages_ms"] = full["full_table"]["stages_ms"]
+    line["legs"] = dg
+    if isinstance(full.get("device"), dict):
+        line["device"] = full["device"]
+    line["legs_file"] = "bench_legs.json (every leg in full; also on stderr)"
+    txt = json.dumps(line)
+    if len(txt) >= LINE_LIMIT:          # never lose the headline to an oversized digest
+        line["legs"] = {k: {kk: vv for kk, vv in v.items() if kk in ("fps", "ms_per_frame", "ms_per_step", "value", "parity", "error")} for k, v in dg.items()}
+        txt = json.dumps(line)
+    if len(txt) >= LINE_LIMIT:
+        line["legs"] = "see legs_file"
+        txt = json.dumps(line)
+    return txt
+
+
+def emit(full, legs=None):
+    if legs:
+        full["legs"] = legs
+    blob = json.dumps(full)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_legs.json"), "w") as f:
+                    f.write(blob + "\n")
+            except OSError:
+                pass
+    print(blob, file=sys.stderr)
+    sys.stderr.flush()
+    if full.get("step_only"):
+        print(blob)
+    else:
+        print(compact_line(full, legs))
+    sys.stdout.flush()
+
 
 def main():
     a = parse()
@@ -329,14 +511,13 @@ def main():
                 return {"metric": line["metric"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"], "scaling": line["scaling"],
                         "parallelism": line["config"].get("parallelism"), "parity": line["config"].get("parity"),
                         "roofline_frac": (line.get("roofline") or {}).get("frac"), "n_ranks_seen": ranks_seen}
-            primary["legs"] = {"replicas": digest(primary), "c3_tile_columns_with_in_loop_filters": digest(c3), "c4_dependent_frames_full_table_film_grain": digest(c4)}
             primary["n_ranks_seen"] = ranks_seen
-            print(json.dumps(primary))
+            emit(primary, {"replicas": digest(primary), "c3_tile_columns_with_in_loop_filters": digest(c3), "c4_dependent_frames_full_table_film_grain": digest(c4)})
     else:
         line = run_job(a, rank, local, world)
         if rank == 0 and line is not None:
             line["n_ranks_seen"] = ranks_seen
-            print(json.dumps(line))
+            emit(line)
     if world > 1:
         dist.barrier()
         dd.close_peers()
@@ -719,6 +900,31 @@ def run_job(a, rank, local, world):
         # where `traffic` comes from: PMC counters cannot be read from inside a run (rocprofv3 wraps the process), so the figure is the
         # committed pass of tools/pmc_profile.sh over this very command — the profile's own directory says which box and build it saw
         roof["traffic_source"] = "profiles/*/traffic.json (rocprofv3 --pmc FETCH_SIZE WRITE_SIZE over `bench.py --step-only`, FETCH_SIZE x 2 as calibrated in profiles/r02_calib_fetch_size.txt); not counted in this run"
+        if world == 1 and not a.emu and not a.no_pmc and not tile_cols and not os.environ.get("DAV1D_BENCH_CHILD"):
+            import re
+            ct = counted_traffic(a)
+            if "error" in ct:
+                roof["traffic_source"] += "; counting it here failed: " + ct["error"]
+            else:
+                pat = _kernel_pattern(dom[0])
+                hit = [v for k, v in ct["per_kernel"].items() if pat and re.search(pat, k)]
+                roof["traffic"] = int(hit[0]) if hit else None
+                roof["path_traffic"] = int(ct["per_step"])
+                roof["path_traffic_over_algorithmic"] = round(ct["per_step"] / path_bytes, 3)
+                if hit:
+                    roof["frac_measured_traffic"] = round(hit[0] / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    roof["traffic_over_algorithmic"] = round(hit[0] / dom[2], 3)
+                roof["path"]["hbm_traffic_bytes_per_frame"] = int(ct["per_step"])
+                roof["path"]["hbm_traffic_achieved"] = round(ct["per_step"] / (ms_per_step * 1e-3) / 1e9, 1)
+                roof["path"]["hbm_traffic_frac"] = round(ct["per_step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                roof["kernels_traffic"] = {}
+                for kn in kernels:
+                    kp = _kernel_pattern(kn[0])
+                    hv = [v for k, v in ct["per_kernel"].items() if kp and re.search(kp, k)]
+                    if hv:
+                        roof["kernels_traffic"][kn[0]] = int(hv[0])
+                roof["traffic_source"] = ("counted in this run on this box: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (one pass each) over "
+                                          "`bench.py --step-only`, %d launches per kernel; HBM bytes = FETCH_SIZE x 2 (gfx950, profiles/r02_calib_fetch_size.txt) + WRITE_SIZE" % ct["launches"])
 
         # ---- parity gate + CPU baseline: the oracle replays the SAME lists on the host
         cpu = None
@@ -1175,7 +1381,7 @@ def run_job(a, rank, local, world):
                                            capture_output=True, text=True, timeout=600)
                     cj = json.loads(child.stdout.strip().splitlines()[-1])
                     out[key] = {"metric": cj["metric"], "value": cj["value"], "unit": cj["unit"], "ms_per_step": cj["ms_per_step"],
-                                "dtype": cj["dtype"], "roofline": {k: cj["roofline"].get(k) for k in ("kernel", "frac", "path")},
+                                "dtype": cj["dtype"], "roofline": {k: cj["roofline"].get(k) for k in ("kernel", "frac", "path_frac", "path_achieved")},
                                 "parity": cj["config"]["parity"], "workload": cj["config"]["workload"]}
                 except Exception as e:
                     out[key] = {"error": str(e)[:200]}

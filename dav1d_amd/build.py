@@ -27,7 +27,22 @@ def _newer(target, deps):
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(not os.path.exists(d) or os.path.getmtime(d) > t for d in deps)
+
+
+def _obj_deps(obj, src, hdrs):
+    """What `obj` was really compiled from: the compiler's own dependency file (-MMD, written next to the object) when there is one —
+    a change to one kernel body then recompiles the translation units that include it, not all twenty — else every header."""
+    d = obj[:-2] + ".d"
+    if not os.path.exists(d) or not os.path.exists(obj):
+        return [src] + hdrs
+    try:
+        txt = open(d).read().replace("\\\n", " ")
+        deps = txt.split(":", 1)[1].split()
+        deps = [x if os.path.isabs(x) else os.path.join(ROOT, x) for x in deps]
+        return [x for x in deps if not x.startswith(("/opt/", "/usr/"))] or [src] + hdrs
+    except (OSError, IndexError):
+        return [src] + hdrs
 
 
 def _deps():
@@ -45,8 +60,8 @@ def _host_jobs(objdir, hdrs, force):
         src = os.path.join(HOST, s)
         obj = os.path.join(objdir, "host_" + s.replace(".c", ".o"))
         objs.append(obj)
-        if force or _newer(obj, [src] + hdrs):
-            jobs.append([CC, "-std=gnu99", "-O2", "-fPIC", "-fvisibility=hidden", "-Wall"] + os.environ.get("DAV1D_HIP_HOST_CFLAGS", "").split() + ["-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
+        if force or _newer(obj, _obj_deps(obj, src, hdrs)):
+            jobs.append([CC, "-std=gnu99", "-O2", "-fPIC", "-fvisibility=hidden", "-Wall", "-MMD"] + os.environ.get("DAV1D_HIP_HOST_CFLAGS", "").split() + ["-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
     return jobs, objs
 
 
@@ -67,8 +82,8 @@ def build_hip(force=False, verbose=False):
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
-        if force or _newer(obj, [src] + hdrs):
-            jobs.append([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+        if force or _newer(obj, _obj_deps(obj, src, hdrs)):
+            jobs.append([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-MMD",
                          "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
     hjobs, hobjs = _host_jobs(objdir, hdrs, force)
     jobs += hjobs
@@ -94,8 +109,8 @@ def build_emu(force=False):
     for src in srcs:
         obj = os.path.join(objdir, os.path.basename(src).rsplit(".", 1)[0] + ".o")
         objs.append(obj)
-        if force or _newer(obj, [src] + hdrs):
-            jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-w"] + os.environ.get("DAV1D_HIP_EMU_CXXFLAGS", "").split() + ["-I" + emu, "-I" + os.path.join(ROOT, "include"),
+        if force or _newer(obj, _obj_deps(obj, src, hdrs)):
+            jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-w", "-MMD"] + os.environ.get("DAV1D_HIP_EMU_CXXFLAGS", "").split() + ["-I" + emu, "-I" + os.path.join(ROOT, "include"),
                          "-x", "c++", "-c", src, "-o", obj])
     hjobs, hobjs = _host_jobs(objdir, hdrs, force)
     jobs += hjobs

@@ -28,8 +28,13 @@ struct Dav1dHipPeer {
     Dav1dHipContext *c;
     int rank, world;
     ncclComm_t comm;
-    uint8_t *send, *recv;          // staging for the strided exchanges, grown on demand
+    uint8_t *send, *recv;          // staging for the strided exchanges on the CONTEXT's stream (gather, halo), grown on demand
     size_t send_cap, recv_cap;
+    // staging of the asynchronous gathers (side stream): buffers of their own, because nothing orders the side stream against the halo
+    // exchange / synchronous gather of the next frame on the context's stream, which would otherwise pack and receive into the bytes an
+    // in-flight gather is still reading.  Gathers on the side stream follow each other in order, so one pair is enough.
+    uint8_t *asend, *arecv;
+    size_t asend_cap, arecv_cap;
 #ifndef DAV1D_HIP_EMU
     void *dl;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
@@ -210,6 +215,7 @@ int dav1d_hip_peer_open(Dav1dHipContext *c, Dav1dHipPeer **out, const uint8_t id
     if (!p) return -ENOMEM;
     p->c = c; p->rank = rank; p->world = world; p->comm = nullptr;
     p->send = p->recv = nullptr; p->send_cap = p->recv_cap = 0;
+    p->asend = p->arecv = nullptr; p->asend_cap = p->arecv_cap = 0;
     p->side = nullptr; p->ev_in = nullptr; p->n_async = 0;
     for (int k = 0; k < 8; k++) p->ev_out[k] = nullptr;
     ncclUniqueId u;
@@ -244,6 +250,8 @@ void dav1d_hip_peer_close(Dav1dHipPeer *p) {
     if (p->comm) (void) NCCL(p, CommDestroy)(p->comm);
     if (p->send) (void) hipFree(p->send);
     if (p->recv) (void) hipFree(p->recv);
+    if (p->asend) (void) hipFree(p->asend);
+    if (p->arecv) (void) hipFree(p->arecv);
     peer_free(p);
 }
 
@@ -272,22 +280,26 @@ int dav1d_hip_peer_broadcast_picture(Dav1dHipPeer *p, Dav1dHipPicture *pic, int 
 // Rank g reconstructed luma columns [x0[g], x1[g]) of `pic` (tile column g; chroma follows the layout): afterwards every rank holds
 // every column.  One message per rank (all planes of its strip, padded to the widest column), ONE all-gather, ONE scatter launch over
 // the strips of all the other ranks.  `st`: the stream it all runs on.
-static int allgather_on(Dav1dHipPeer *p, Dav1dHipPicture *pic, const int *x0, const int *x1, hipStream_t st) {
+static int allgather_on(Dav1dHipPeer *p, Dav1dHipPicture *pic, const int *x0, const int *x1, hipStream_t st, const bool async) {
+    uint8_t **const sendp = async ? &p->asend : &p->send, **const recvp = async ? &p->arecv : &p->recv;
+    size_t *const send_cap = async ? &p->asend_cap : &p->send_cap, *const recv_cap = async ? &p->arecv_cap : &p->recv_cap;
     int wmax = 0;
     for (int g = 0; g < p->world; g++) wmax = x1[g] - x0[g] > wmax ? x1[g] - x0[g] : wmax;
     StripPlan mine, slot;
     plan_strip(pic, x0[p->rank], x1[p->rank], &mine, (size_t) wmax);
     plan_strip(pic, 0, wmax, &slot, (size_t) wmax);
     const size_t per = slot.bytes;
-    int rc = grow(&p->send, &p->send_cap, per);
-    if (!rc) rc = grow(&p->recv, &p->recv_cap, per * (size_t) p->world);
+    // (growing frees the old buffer with hipFree, which waits for the device: an earlier gather still reading it is through by then)
+    int rc = grow(sendp, send_cap, per);
+    if (!rc) rc = grow(recvp, recv_cap, per * (size_t) p->world);
     if (rc) return rc;
+    uint8_t *const send = *sendp, *const recv = *recvp;
     pic->twin_ok = 0;
     // the strip's rows are packed with the strip's own width as row pitch inside a slot laid out for the widest strip
     StripPlan pk = mine;
     for (int pl = 0; pl < 3; pl++) pk.off[pl] = slot.off[pl];
-    launch_strip(true, pic, p->send, pk, st);
-    if (NCCL(p, AllGather)(p->send, p->recv, per, ncclUint8, p->comm, STREAM_ARG(st)) != ncclSuccess) return -EIO;
+    launch_strip(true, pic, send, pk, st);
+    if (NCCL(p, AllGather)(send, recv, per, ncclUint8, p->comm, STREAM_ARG(st)) != ncclSuccess) return -EIO;
     StripSet set;
     memset(&set, 0, sizeof(set));
     for (int g = 0; g < p->world; g++) {
@@ -296,9 +308,9 @@ static int allgather_on(Dav1dHipPeer *p, Dav1dHipPicture *pic, const int *x0, co
         plan_strip(pic, x0[g], x1[g], &up, (size_t) wmax);
         for (int pl = 0; pl < 3; pl++) up.off[pl] = slot.off[pl];
         set.p[set.n] = up; set.slot[set.n] = (size_t) g * per;
-        if (++set.n == MAX_STRIPS) { launch_strips(false, pic, p->recv, set, st); set.n = 0; }       // (more than 9 ranks: a launch per 8 strips)
+        if (++set.n == MAX_STRIPS) { launch_strips(false, pic, recv, set, st); set.n = 0; }       // (more than 9 ranks: a launch per 8 strips)
     }
-    if (set.n) launch_strips(false, pic, p->recv, set, st);
+    if (set.n) launch_strips(false, pic, recv, set, st);
     return hip_rc(hipGetLastError());
 }
 
@@ -307,7 +319,7 @@ int dav1d_hip_peer_allgather_columns(Dav1dHipPeer *p, Dav1dHipPicture *pic, cons
     const int rc = check_columns(pic, x0, x1, p->world, 2);
     if (rc) return rc;
     if (p->world == 1) return 0;
-    return allgather_on(p, pic, x0, x1, p->c->stream);
+    return allgather_on(p, pic, x0, x1, p->c->stream, false);
 }
 
 // The same on the peer's side stream: it starts when what the context's stream holds so far is through (the frame that wrote the
@@ -319,7 +331,7 @@ int dav1d_hip_peer_allgather_columns_async(Dav1dHipPeer *p, Dav1dHipPicture *pic
     if (rc) return rc;
     if (p->world == 1) return 0;
     if (hipEventRecord(p->ev_in, p->c->stream) != hipSuccess || hipStreamWaitEvent(p->side, p->ev_in, 0) != hipSuccess) return -EIO;
-    rc = allgather_on(p, pic, x0, x1, p->side);
+    rc = allgather_on(p, pic, x0, x1, p->side, true);
     if (!rc && hipEventRecord(p->ev_out[p->n_async & 7], p->side) != hipSuccess) rc = -EIO;
     if (!rc) p->n_async++;
     return rc;

@@ -979,6 +979,9 @@ DAV1D_HIP_API int dav1d_hip_peer_exchange_halo(Dav1dHipPeer *p, Dav1dHipPicture 
  * that wrote the columns) and runs next to what the caller enqueues afterwards — the next frame's reconstruction, which predicts from
  * other pictures.  dav1d_hip_peer_wait(p, lag): the context's stream waits for the asynchronous gathers issued so far but the `lag` (0 .. 7) most
  * recent ones — 0 before the first launch that reads `pic`; k for a caller that recycles a picture k + 1 frames later.
+ * The asynchronous gathers stage through buffers of their own: a halo exchange or synchronous gather enqueued on the context's stream
+ * while one is in flight does not touch its data.  The PICTURE is the caller's to keep apart: nothing on the context's stream may
+ * write `pic` before dav1d_hip_peer_wait has covered the gather.
  * Column checks of all three calls (-EINVAL): even, one after the other, inside the plane, at least `halo` wide. */
 DAV1D_HIP_API int dav1d_hip_peer_allgather_columns_async(Dav1dHipPeer *p, Dav1dHipPicture *pic, const int *x0, const int *x1);
 DAV1D_HIP_API int dav1d_hip_peer_wait(Dav1dHipPeer *p, int lag);

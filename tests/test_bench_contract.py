@@ -17,7 +17,16 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
+    # the driver keeps 8 KB of stdout: the line has to fit, and nothing may follow it (round 4's 23 KB line came back unparsed)
+    assert len(lines[0]) < 8000, len(lines[0])
+    assert r.stdout.rstrip("\n").splitlines()[-1] == lines[0]
     d = json.loads(lines[0])
+    full = json.load(open(os.path.join(util.ROOT, "bench_legs.json")))      # every leg in full next to bench.py
+    assert full["value"] == d["value"] and "full_table" in full and "stages_ms" in full["full_table"]
+    # roofline.traffic is counted in the run itself (rocprofv3 children over --step-only) when the profiler is there
+    assert "counted in this run" in d["roofline"]["traffic_source"] or "failed" in d["roofline"]["traffic_source"], d["roofline"]["traffic_source"]
+    if "counted in this run" in d["roofline"]["traffic_source"]:
+        assert d["roofline"]["traffic"] > 0 and d["roofline"]["path_traffic"] > 0
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -33,7 +42,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert k in cpu, k
     assert cpu["kind"] in ("reference", "port") and cpu["cores"] == 1 and cpu["value"] > 0
     assert d["value"] > cpu["value"]
-    assert d["full_table"]["parity"].startswith("every stage bit-exact")
+    assert d["legs"]["full_table"]["parity"] == "bit-exact" and full["full_table"]["parity"].startswith("every stage bit-exact")
 
 
 @pytest.mark.gpu
