@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--edge-frac", type=float, default=0.05, help="fraction of blocks pointing outside the picture")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--layout", choices=["tiled", "raster"], default="tiled",
+                    help="where the step's pictures live: tiled = references read through their tiled twins and the reconstructed picture written as 8x8 "
+                         "tiles ONLY (dav1d_hip_recon_list_run_tiled; raster rows exist at the output only, made by the un-tiling download), "
+                         "raster = the reference's plane layout throughout (rounds 1-4)")
     ap.add_argument("--no-pmc", action="store_true", help="do not count roofline.traffic with rocprofv3 children (the committed profile's figure is reported instead)")
     ap.add_argument("--no-inflight", action="store_true", help="skip the frames-in-flight leg of the full table")
     ap.add_argument("--packed", action="store_true", help="feed the residuals in the sparse wire format (DAV1D_HIP_ITX_PACKED)")
@@ -167,7 +171,8 @@ def counted_traffic(a, timeout=240):
         return {"error": "no rocprofv3 on this host"}
     steps, warm = 2, 1
     args = [sys.executable, os.path.abspath(__file__), "--step-only", "--steps", str(steps), "--warmup", str(warm), "--width", str(a.width),
-            "--height", str(a.height), "--bpc", str(a.bpc), "--mix", a.mix, "--mv-range", str(a.mv_range), "--edge-frac", str(a.edge_frac)]
+            "--height", str(a.height), "--bpc", str(a.bpc), "--mix", a.mix, "--mv-range", str(a.mv_range), "--edge-frac", str(a.edge_frac),
+            "--layout", a.layout]
     if a.packed:
         args.append("--packed")
     if a.two_phase:
@@ -405,7 +410,7 @@ def compact_line(full, legs=None):
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
     line = {k: full.get(k) for k in keep}
     cfg = full.get("config") or {}
-    line["config"] = {k: _short(cfg.get(k), 330) for k in ("workload", "parallelism", "parity", "frames_per_step", "coef_format", "step") if k in cfg}
+    line["config"] = {k: _short(cfg.get(k), 330) for k in ("workload", "parallelism", "parity", "frames_per_step", "coef_format", "step", "picture_layout", "ms_per_step_by_layout") if k in cfg}
     roof = full.get("roofline")
     if isinstance(roof, dict):
         r = {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_bytes_per_launch",
@@ -644,6 +649,10 @@ def run_job(a, rank, local, world):
         for pl in range(3):
             r.upload(pl, rp[pl])
         refs.append(r)
+    tiled = a.layout == "tiled" and not tile_cols and not a.two_phase
+    if tiled:
+        for r in refs:
+            r.retile()          # (a reference of a running chain was left in its twin by the frame that made it)
     NDST = 4
     dsts = []
     cols = dd.tile_columns(w, world) if tile_cols else None
@@ -701,7 +710,9 @@ def run_job(a, rank, local, world):
 
     def step(i):
         d = dsts[i % NDST]
-        if recon_list is not None:
+        if recon_list is not None and tiled:
+            recon_list.run_tiled(d, refs, prep.data_ptr(), arenas[i].data_ptr())
+        elif recon_list is not None:
             recon_list.run(d, refs, prep.data_ptr(), arenas[i].data_ptr())
         else:
             ctx.run_inter_list(inter_list, d, refs, prep.data_ptr())
@@ -759,12 +770,13 @@ def run_job(a, rank, local, world):
         p_tasks, p_coef = synth.pack_frame_coefs(frame)
         p_list = ctx.recon_list(dsts[0], frame.mc, frame.comp, p_tasks)
         p_arena = torch.from_numpy(p_coef).to(dev)
+        p_run = p_list.run_tiled if tiled else p_list.run
         for i in range(a.warmup):
-            p_list.run(dsts[i % NDST], refs, prep.data_ptr(), p_arena.data_ptr())
+            p_run(dsts[i % NDST], refs, prep.data_ptr(), p_arena.data_ptr())
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(a.steps):
-            p_list.run(dsts[i % NDST], refs, prep.data_ptr(), p_arena.data_ptr())
+            p_run(dsts[i % NDST], refs, prep.data_ptr(), p_arena.data_ptr())
         torch.cuda.synchronize()
         dt_p = time.perf_counter() - t0
         p_out = [dsts[(a.steps - 1) % NDST].download(pl) for pl in range(3)]
@@ -772,6 +784,32 @@ def run_job(a, rank, local, world):
                       "unit": "Mpixels/s", "coef_bytes_per_frame": int(p_coef.nbytes), "_pictures": p_out}
         p_list.destroy()
         del p_arena
+
+    # ---- the same step with the pictures laid out the other ways, same box, same run (reported, never `value`): raster planes throughout
+    # (the reference's layout, rounds 1-4) and raster destination + tiled references
+    by_layout = None
+    if rank == 0 and world == 1 and tiled and recon_list is not None and not a.packed and not a.emu and not os.environ.get("DAV1D_BENCH_CHILD"):
+        by_layout = {"tiled": round(ms_per_step, 4)}
+        alt = [ctx.picture(w, h, api.LAYOUT_I420, bpc) for _ in range(2)]
+        for d in alt:
+            for pl in range(3):
+                d.upload(pl, dst_host[pl])
+        for name, ref_twin in (("raster", 0), ("raster_destination_tiled_references", 1)):
+            ctx.set_option("ref_twin", ref_twin)
+            for k in range(a.warmup + a.steps):
+                arenas[k].copy_(pristine)
+            torch.cuda.synchronize()
+            for k in range(a.warmup):
+                recon_list.run(alt[k % 2], refs, prep.data_ptr(), arenas[k].data_ptr())
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(a.warmup, a.warmup + a.steps):
+                recon_list.run(alt[k % 2], refs, prep.data_ptr(), arenas[k].data_ptr())
+            torch.cuda.synchronize()
+            by_layout[name] = round((time.perf_counter() - t0) / a.steps * 1e3, 4)
+        ctx.set_option("ref_twin", 1)
+        for d in alt:
+            d.free()
 
     out = None
     if rank == 0:
@@ -830,9 +868,10 @@ def run_job(a, rank, local, world):
             ms40, cnt40 = (C.c_float * 40)(), (C.c_size_t * 40)()
             best40 = [1e9] * 40
             for rep in range(3):
-                rc = ctx.lib.dav1d_hip_recon_list_run_timed(ctx.h, recon_list.h, C.byref(d.pic), rarr, len(refs), prep.data_ptr(), None,
-                                                            arenas[i + 3 + rep].data_ptr(), ms40, cnt40)
-                assert rc == 0
+                rarr = (api.Picture * len(refs))(*[r.pic for r in refs])
+                fn = ctx.lib.dav1d_hip_recon_list_run_tiled_timed if tiled else ctx.lib.dav1d_hip_recon_list_run_timed
+                rc = fn(ctx.h, recon_list.h, C.byref(d.pic), rarr, len(refs), prep.data_ptr(), None, arenas[i + 3 + rep].data_ptr(), ms40, cnt40)
+                assert rc == 0, rc
                 best40 = [min(x, y) for x, y in zip(best40, ms40)]
             step_kernels = []
             for k in range(5):
@@ -1361,6 +1400,9 @@ def run_job(a, rank, local, world):
                                        "lists resident in HBM") % (w, h, bpc),
                           "step": ("inter list, then itx list" if a.two_phase else
                                    "recon list: residual launches wait only for the prediction launches under their blocks (2 streams)"),
+                          "picture_layout": ("tiled: references read through 8x8-tiled twins, the reconstructed picture written as tiles only (one 128-byte line per 8x8 "
+                                             "block at 10 bits); raster rows are made by the un-tiling download the parity check reads" if tiled else "raster planes (src/picture.c:46-63)"),
+                          "ms_per_step_by_layout": by_layout,
                           "frames_per_step": 1, "parallelism": (("tile-columns x%d, in-loop filters per column after a 16-column halo exchange, one all-gather of the filtered columns per frame"
                                                             if a.tc_filters else "tile-columns x%d + one all-gather per frame") if tile_cols else "frame-parallel x%d") % world,
                           "tasks": {"mc": int(len(frame.mc)), "comp": int(len(frame.comp)), "itx": int(len(frame.itx))},

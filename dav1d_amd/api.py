@@ -59,6 +59,9 @@ class DeviceBuffer:
             self.ptr = None
 
 
+TWIN_ONLY = 2          # Dav1dHipPicture.twin_ok: the picture lives in its tiled twin, the raster planes are stale
+
+
 class DevicePicture:
     def __init__(self, ctx, w, h, layout, bpc):
         self.ctx = ctx
@@ -91,6 +94,10 @@ class DevicePicture:
         self.pic.twin_ok = 0
         if getattr(self.ctx, "auto_retile", False) and plane == self.n_planes - 1:
             self.retile()
+
+    def untile(self):
+        """dav1d_hip_picture_untile: a picture that lives in its twin gets its raster planes back (no-op otherwise)."""
+        _chk(self.ctx.lib.dav1d_hip_picture_untile(self.ctx.h, C.byref(self.pic)), "picture_untile")
 
     def retile(self, overlapped=False):
         """(Re)build the tiled twin from the raster planes: motion compensation then reads this picture through it.  overlapped: on a
@@ -166,11 +173,22 @@ class _ReconList:
                                                  k.ctypes.data, len(k), t.ctypes.data, len(t)), "recon_list_create")
 
     def run(self, dst, refs, prep, coef, mask=None):
+        if getattr(self.ctx, "tiled_native", False):       # (tests: every recon list of the context leaves its picture in the twin only)
+            return self.run_tiled(dst, refs, prep, coef, mask)
         arr = (Picture * len(refs))(*[r.pic for r in refs])
         p = None if prep is None else (prep.ptr if hasattr(prep, "ptr") else prep)
         m = None if mask is None else (mask.ptr if hasattr(mask, "ptr") else mask)
         _chk(self.ctx.lib.dav1d_hip_recon_list_run(self.ctx.h, self.h, C.byref(dst.pic), arr, len(refs), p, m,
                                                    coef.ptr if hasattr(coef, "ptr") else coef), "recon_list_run")
+
+    def run_tiled(self, dst, refs, prep, coef, mask=None):
+        """dav1d_hip_recon_list_run_tiled: the picture lives in its tiled twin only afterwards (dst.pic.twin_ok == TWIN_ONLY when every
+        launch could write tiles; 1 after the raster + retile fallback).  download() / the fetch calls un-tile on the way out."""
+        arr = (Picture * len(refs))(*[r.pic for r in refs])
+        p = None if prep is None else (prep.ptr if hasattr(prep, "ptr") else prep)
+        m = None if mask is None else (mask.ptr if hasattr(mask, "ptr") else mask)
+        _chk(self.ctx.lib.dav1d_hip_recon_list_run_tiled(self.ctx.h, self.h, C.byref(dst.pic), arr, len(refs), p, m,
+                                                         coef.ptr if hasattr(coef, "ptr") else coef), "recon_list_run_tiled")
 
     def run_twin(self, dst, refs, prep, coef, mask=None):
         """dav1d_hip_recon_list_run_twin: the frame's pixels also end up in dst's tiled twin (written by the launches themselves when

@@ -68,6 +68,7 @@ struct Dav1dHipContext {
     size_t pending_slab_cap;
     hipStream_t copy_stream;
     hipEvent_t ev_copy;
+    hipEvent_t ev_untile;       // "the rows of this band are raster rows again" (dav1d_hip_host_picture_fetch of a picture that lives in its twin)
     hipEvent_t ev_retile;       // the end of the most recent overlapped retile (dav1d_hip_picture_retile_overlapped) ...
     bool retile_pending;        // ... which the next launches that read twins have to wait for
     std::mutex run_mtx;         // one multi-stream section (recon list run, banded post filters) at a time per context
@@ -171,7 +172,7 @@ static inline DevPlanes dev_planes(const Dav1dHipPicture *p) {
     return d;
 }
 static inline bool picture_twin_usable(const Dav1dHipPicture *p) {
-    if (!p->twin_ok) return false;
+    if (!p->twin_ok) return false;          // (1: twin and raster planes agree; DAV1D_HIP_TWIN_ONLY: the twin is the picture)
     const int bps = p->bpc > 8 ? 2 : 1;
     for (int i = 0; i < 3; i++)
         if (p->p[i].data && (!p->twin[i] || (p->p[i].stride / bps) % 8)) return false;

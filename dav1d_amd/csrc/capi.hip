@@ -86,7 +86,8 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     c->chunk_hints = (int) env_int("DAV1D_HIP_CHUNK_HINTS", 1);
     c->carena_hint = 0;
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
+        hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_untile, hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
     *out = c;
     return 0;
 }
@@ -99,7 +100,7 @@ void dav1d_hip_close(Dav1dHipContext *c) {
     hipEventDestroy(c->ev_fork);
     for (int i = 0; i < 16; i++) hipEventDestroy(c->ev_bin[i]);
     hipEventDestroy(c->ev_t0); hipEventDestroy(c->ev_t1); hipEventDestroy(c->ev_retile);
-    hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); hipEventDestroy(c->ev_copy);
+    hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); hipEventDestroy(c->ev_copy); hipEventDestroy(c->ev_untile);
     if (c->band_cnt) (void) hipFree(c->band_cnt);
     if (c->band_flags) (void) hipHostFree(c->band_flags);
     for (const Dav1dHipContext::Arena &ar : c->free_arenas) hipFree(ar.dev);
@@ -294,7 +295,24 @@ void dav1d_hip_picture_give(Dav1dHipContext *c, Dav1dHipPicture *pic) {
 
 extern "C" int dav1d_hip_launch_retile(const DevPlanes *src, void *const twin[3], int bpc, void *stream);
 
-// Storage for the tiled twin: per plane stride x (height rounded up to 8 rows) bytes, the planes one after the other.
+// Rows of plane pl that exist in memory: a plane of dav1d_hip_picture_alloc (and of dav1d's own allocator, src/picture.c:46-63) is padded to
+// a multiple of 128 luma rows — blocks on the picture's bottom edge reconstruct into that padding — a caller-wrapped plane only promises its
+// visible rows.
+static inline int picture_plane_rows(const Dav1dHipPicture *pic, int pl, bool padded) {
+    if (!padded) return pic->p[pl].h;
+    const int ss_ver = pic->layout == DAV1D_HIP_LAYOUT_I420;
+    const int ah = (pic->p[0].h + 127) & ~127;
+    return pl ? ah >> ss_ver : ah;
+}
+// the picture's planes for the retile / untile passes: every row the allocation holds when the library made it
+static inline DevPlanes twin_pass_planes(const Dav1dHipPicture *pic) {
+    DevPlanes d = dev_planes(pic);
+    for (int pl = 0; pl < 3; pl++) if (pic->p[pl].data) d.h[pl] = picture_plane_rows(pic, pl, pic->alloc != nullptr);
+    return d;
+}
+
+// Storage for the tiled twin: per plane stride x (rows padded as dav1d's allocator pads them: blocks on the bottom edge write below the
+// visible rows, in the twin as in the raster plane) bytes, the planes one after the other.
 int dav1d_hip_picture_twin_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic) {
     if (!c || !pic || !pic->p[0].data) return -EINVAL;
     if (pic->twin_alloc) return 0;
@@ -304,8 +322,7 @@ int dav1d_hip_picture_twin_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic) {
         if (!pic->p[i].data) continue;
         if (pic->p[i].stride <= 0 || (pic->p[i].stride / bps) % 8 || pic->p[i].stride % 16) return -EINVAL;
         off[i] = total;
-        // a plane of picture_alloc is padded to 128 rows: the twin mirrors what can be addressed (rows up to the next multiple of 8)
-        total += (size_t) pic->p[i].stride * (size_t) ((pic->p[i].h + 7) & ~7);
+        total += (size_t) pic->p[i].stride * (size_t) picture_plane_rows(pic, i, true);
         total = (total + 255) & ~(size_t) 255;
     }
     void *buf = nullptr;
@@ -317,6 +334,7 @@ int dav1d_hip_picture_twin_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic) {
     return 0;
 }
 
+extern "C" int dav1d_hip_launch_untile(const DevPlanes *dst, void *const twin[3], int bpc, const int row0[3], const int row1[3], int plane_mask, void *stream);
 extern "C" int dav1d_hip_launch_retile(const DevPlanes *src, void *const twin[3], int bpc, void *stream);
 
 // The same on a side stream of the context: the copy starts when the work enqueued so far is through and runs NEXT TO whatever the
@@ -332,7 +350,8 @@ int dav1d_hip_picture_retile_overlapped(Dav1dHipContext *c, Dav1dHipPicture *pic
     hipStream_t side = c->side[Dav1dHipContext::N_SIDE - 1];
     HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
     HIP_TRY(hipStreamWaitEvent(side, c->ev_fork, 0));
-    const DevPlanes sp = dev_planes(pic);
+    if (pic->twin_ok == DAV1D_HIP_TWIN_ONLY) return 0;          // the twin IS the picture
+    const DevPlanes sp = twin_pass_planes(pic);
     const int rc = dav1d_hip_launch_retile(&sp, pic->twin, pic->bpc, side);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(c->ev_retile, side));
@@ -347,8 +366,21 @@ int dav1d_hip_picture_retile(Dav1dHipContext *c, Dav1dHipPicture *pic) {
         const int rc = dav1d_hip_picture_twin_alloc(c, pic);
         if (rc) return rc;
     }
-    const DevPlanes sp = dev_planes(pic);
+    if (pic->twin_ok == DAV1D_HIP_TWIN_ONLY) return 0;          // the twin IS the picture
+    const DevPlanes sp = twin_pass_planes(pic);
     const int rc = dav1d_hip_launch_retile(&sp, pic->twin, pic->bpc, c->stream);
+    if (!rc) pic->twin_ok = 1;
+    return rc;
+}
+
+// The other way: a picture that lives in its twin only (twin_ok == DAV1D_HIP_TWIN_ONLY: what dav1d_hip_recon_list_run_tiled leaves) gets
+// its raster planes back, on the context's stream; twin_ok becomes 1 (both valid).  No-op for any other picture.
+int dav1d_hip_picture_untile(Dav1dHipContext *c, Dav1dHipPicture *pic) {
+    if (!c || !pic) return -EINVAL;
+    if (pic->twin_ok != DAV1D_HIP_TWIN_ONLY) return 0;
+    if (!pic->twin[0]) return -EINVAL;
+    const DevPlanes dp = twin_pass_planes(pic);
+    const int rc = dav1d_hip_launch_untile(&dp, pic->twin, pic->bpc, nullptr, nullptr, 7, c->stream);
     if (!rc) pic->twin_ok = 1;
     return rc;
 }
@@ -393,6 +425,21 @@ int dav1d_hip_host_picture_fetch(Dav1dHipContext *c, const Dav1dHipHostPicture *
     if (row1 > src->p[0].h) row1 = src->p[0].h;
     if (row1 <= row0) return 0;
     const int ss_ver = src->layout == DAV1D_HIP_LAYOUT_I420, bps = src->bpc > 8 ? 2 : 1;
+    if (src->twin_ok == DAV1D_HIP_TWIN_ONLY) {
+        // the picture lives in its twin: the rows of this band become raster rows here, on their way out (the raster planes are the
+        // staging; src is const, so the picture stays DAV1D_HIP_TWIN_ONLY and a later band / fetch does its own rows again)
+        if (!src->twin[0]) return -EINVAL;
+        int r0[3], r1[3];
+        for (int pl = 0; pl < 3; pl++) {
+            const int sv = pl ? ss_ver : 0;
+            r0[pl] = row0 >> sv; r1[pl] = row1 >= src->p[0].h ? src->p[pl].h : row1 >> sv;
+        }
+        const DevPlanes dp = dev_planes(src);
+        int rc = dav1d_hip_launch_untile(&dp, src->twin, src->bpc, r0, r1, 7, c->stream);
+        if (!rc) rc = hip_rc(hipEventRecord(c->ev_untile, c->stream));
+        if (!rc) rc = hip_rc(hipStreamWaitEvent(c->copy_stream, c->ev_untile, 0));
+        if (rc) return rc;
+    }
     for (int pl = 0; pl < 3; pl++) {
         if (!src->p[pl].data || !hp->data[pl]) continue;
         const int sv = pl ? ss_ver : 0;
@@ -451,6 +498,13 @@ int dav1d_hip_plane_download(Dav1dHipContext *c, const Dav1dHipPicture *pic, int
     if (!pic || plane < 0 || plane > 2 || !pic->p[plane].data) return -EINVAL;
     size_t rb; int rows;
     plane_extent(pic, plane, padded, &rb, &rows);
+    if (pic->twin_ok == DAV1D_HIP_TWIN_ONLY) {
+        // the picture lives in its twin: this plane's raster rows are made here (pic is const: the flag stays, the next call does it again)
+        if (!pic->twin[plane]) return -EINVAL;
+        const DevPlanes dp = twin_pass_planes(pic);
+        const int rc = dav1d_hip_launch_untile(&dp, pic->twin, pic->bpc, nullptr, nullptr, 1 << plane, c->stream);
+        if (rc) return rc;
+    }
     HIP_TRY(hipMemcpy2DAsync(host, host_stride, pic->p[plane].data, pic->p[plane].stride, rb, rows,
                              hipMemcpyDeviceToHost, c->stream));
     return hip_rc(hipStreamSynchronize(c->stream));
@@ -1792,16 +1846,23 @@ int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipReconList *l, con
 // planes — tiled references, blocks on the 8-pixel grid, no mask / blend tasks (those go through a kernel that only knows raster
 // planes) — it is written by the launches themselves (the paired kernels and the residual kernels through tile_write_out, the
 // prediction kernels strip by strip); otherwise the list runs as always and dav1d_hip_picture_retile follows.  Sets dst->twin_ok.
-int dav1d_hip_recon_list_run_twin(Dav1dHipContext *c, const Dav1dHipReconList *l, Dav1dHipPicture *dst,
-                                  const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask, void *coef) {
-    if (!c || !l || !dst || !refs) return -EINVAL;
-    if (!dst->twin[0] && !dst->twin_alloc) { const int rc = dav1d_hip_picture_twin_alloc(c, dst); if (rc) return rc; }
+// can every launch of the list write dst's twin itself?  (tiled references, blocks on the 8-pixel grid, no mask / blend tasks, aligned planes)
+static bool recon_list_twin_direct(Dav1dHipContext *c, const Dav1dHipReconList *l, const Dav1dHipPicture *dst, const Dav1dHipPicture *refs, int n_refs) {
     bool direct = c->ref_twin != 0 && l->wide_ok && !l->inter->comp->n && mc_fused_min_bin() >= MC_BINS;
     const int bps = dst->bpc > 8 ? 2 : 1;
     for (int p = 0; p < 3 && direct; p++)
         if (dst->p[p].data) direct = dst->twin[p] && !((uintptr_t) dst->p[p].data & 15) && !((uintptr_t) dst->twin[p] & 15) && dst->p[p].stride % 16 == 0 &&
                                      (dst->p[p].stride / bps) % 8 == 0;
     for (int i = 0; i < n_refs && direct; i++) direct = picture_twin_usable(&refs[i]);
+    if (getenv("DAV1D_DEBUG_TILED")) fprintf(stderr, "twin_direct: ref_twin %d wide_ok %d comp %zu min_bin %d -> %d (refs ok: %d %d %d)\n", c->ref_twin, (int) l->wide_ok, (size_t) l->inter->comp->n, mc_fused_min_bin(), (int) direct, n_refs > 0 ? refs[0].twin_ok : -1, n_refs > 1 ? refs[1].twin_ok : -1, n_refs > 2 ? refs[2].twin_ok : -1);
+    return direct;
+}
+
+int dav1d_hip_recon_list_run_twin(Dav1dHipContext *c, const Dav1dHipReconList *l, Dav1dHipPicture *dst,
+                                  const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask, void *coef) {
+    if (!c || !l || !dst || !refs) return -EINVAL;
+    if (!dst->twin[0] && !dst->twin_alloc) { const int rc = dav1d_hip_picture_twin_alloc(c, dst); if (rc) return rc; }
+    const bool direct = recon_list_twin_direct(c, l, dst, refs, n_refs);
     dst->twin_ok = 0;
     if (direct) {
         DevPlanes tw = dev_planes(dst);
@@ -1812,6 +1873,33 @@ int dav1d_hip_recon_list_run_twin(Dav1dHipContext *c, const Dav1dHipReconList *l
     }
     const int rc = recon_list_run_impl(c, l, dst, refs, n_refs, prep, mask, coef, false, nullptr);
     return rc ? rc : dav1d_hip_picture_retile(c, dst);
+}
+
+// The same with the picture living in its twin ONLY: nothing is written to the raster planes (dst->twin_ok = DAV1D_HIP_TWIN_ONLY
+// afterwards) — an 8x8 block leaves as one 128-byte line instead of eight 16-byte row pieces, a 4x4 block as half a line instead of four
+// 8-byte pieces, and the residual launches read the predicted pixels back the same way.  What reads such a picture: motion
+// compensation of later frames (through the twin, as always), dav1d_hip_host_picture_fetch / dav1d_hip_plane_download (they un-tile
+// on the way out: raster rows by the address rules of src/picture.c:46-63 exist at the output only) and dav1d_hip_picture_untile.
+// `dst` on entry: any state; if it holds pixels the list does not overwrite (a partial list), they must be in the twin — a picture
+// whose raster planes alone are valid is retiled first.  Lists that cannot run that way (recon_list_twin_direct) run on the raster
+// planes and retile: twin_ok = 1 then.
+int dav1d_hip_recon_list_run_tiled(Dav1dHipContext *c, const Dav1dHipReconList *l, Dav1dHipPicture *dst,
+                                   const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask, void *coef) {
+    if (!c || !l || !dst || !refs) return -EINVAL;
+    if (!dst->twin[0] && !dst->twin_alloc) { const int rc = dav1d_hip_picture_twin_alloc(c, dst); if (rc) return rc; }
+    if (!recon_list_twin_direct(c, l, dst, refs, n_refs)) {
+        int rc = dav1d_hip_picture_untile(c, dst);
+        if (!rc) rc = recon_list_run_impl(c, l, dst, refs, n_refs, prep, mask, coef, false, nullptr);
+        dst->twin_ok = 0;
+        return rc ? rc : dav1d_hip_picture_retile(c, dst);
+    }
+    if (!dst->twin_ok) { const int rc = dav1d_hip_picture_retile(c, dst); if (rc) return rc; }
+    DevPlanes tw = dev_planes(dst);
+    for (int p = 0; p < 3; p++) tw.data[p] = dst->p[p].data ? dst->twin[p] : nullptr;
+    tw.tiled = 2;
+    const int rc = recon_list_run_impl(c, l, dst, refs, n_refs, prep, mask, coef, true, &tw);
+    dst->twin_ok = rc ? 0 : DAV1D_HIP_TWIN_ONLY;
+    return rc;
 }
 
 static int recon_list_run_impl(Dav1dHipContext *c, const Dav1dHipReconList *l, const Dav1dHipPicture *dst, const Dav1dHipPicture *refs, int n_refs,
@@ -1939,9 +2027,32 @@ static int recon_list_run_impl(Dav1dHipContext *c, const Dav1dHipReconList *l, c
 // Measurement aid: the launches of a recon list one after the other on the context's stream, each bracketed by events.
 // ms / counts: [0..4] the paired launches by size class (blocks), [5..19] the prediction launches by tile shape (tiles), [20] the
 // compound / blend launch (tasks), [21..39] the residual launches by transform size (blocks).
+static int recon_list_run_timed_impl(Dav1dHipContext *c, const Dav1dHipReconList *l, const Dav1dHipPicture *dst,
+                                     const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask, void *coef,
+                                     float *ms, size_t *counts, const DevPlanes *dst_twin);
 int dav1d_hip_recon_list_run_timed(Dav1dHipContext *c, const Dav1dHipReconList *l, const Dav1dHipPicture *dst,
                                    const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask, void *coef,
                                    float *ms, size_t *counts) {
+    return recon_list_run_timed_impl(c, l, dst, refs, n_refs, prep, mask, coef, ms, counts, nullptr);
+}
+// the launches of dav1d_hip_recon_list_run_tiled the same way (-ENOTSUP when the list cannot run with its picture in the twin only)
+int dav1d_hip_recon_list_run_tiled_timed(Dav1dHipContext *c, const Dav1dHipReconList *l, Dav1dHipPicture *dst,
+                                         const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask, void *coef,
+                                         float *ms, size_t *counts) {
+    if (!c || !l || !dst || !refs) return -EINVAL;
+    if (!dst->twin[0] && !dst->twin_alloc) { const int rc = dav1d_hip_picture_twin_alloc(c, dst); if (rc) return rc; }
+    if (!recon_list_twin_direct(c, l, dst, refs, n_refs)) return -ENOTSUP;
+    if (!dst->twin_ok) { const int rc = dav1d_hip_picture_retile(c, dst); if (rc) return rc; }
+    DevPlanes tw = dev_planes(dst);
+    for (int p = 0; p < 3; p++) tw.data[p] = dst->p[p].data ? dst->twin[p] : nullptr;
+    tw.tiled = 2;
+    const int rc = recon_list_run_timed_impl(c, l, dst, refs, n_refs, prep, mask, coef, ms, counts, &tw);
+    dst->twin_ok = rc ? 0 : DAV1D_HIP_TWIN_ONLY;
+    return rc;
+}
+static int recon_list_run_timed_impl(Dav1dHipContext *c, const Dav1dHipReconList *l, const Dav1dHipPicture *dst,
+                                     const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask, void *coef,
+                                     float *ms, size_t *counts, const DevPlanes *dst_twin) {
     if (!c || !l || !dst || !refs || !ms || !counts || n_refs < 1 || n_refs > 8) return -EINVAL;
     const Dav1dHipMcList *ml = l->inter->mc;
     if ((ml->n && ml->max_ref >= n_refs) || l->f_max_ref >= n_refs) return -EINVAL;
@@ -1958,18 +2069,20 @@ int dav1d_hip_recon_list_run_timed(Dav1dHipContext *c, const Dav1dHipReconList *
         size_t cnt = 0;
         if (k < 5) {
             cnt = l->f_n[k];
-            if (cnt) rc = dav1d_hip_launch_recon_fused(&dp, rp, n_refs, dst->bpc, k, l->f_tiles[k], l->f_tasks[k], (int) cnt, prep, coef, c->recon_coop_below, c->stream);
+            if (cnt) rc = dav1d_hip_launch_recon_fused_out(&dp, rp, n_refs, dst->bpc, k, l->f_tiles[k], l->f_tasks[k], (int) cnt, prep, coef, c->recon_coop_below,
+                                                           dst_twin != nullptr, dst_twin, c->stream);
         } else if (k < 20) {
             const int b = k - 5;
             cnt = ml->off[b + 1] - ml->off[b];
-            if (cnt) rc = dav1d_hip_launch_mc_bin(&dp, rp, n_refs, dst->bpc, b, ml->dev + ml->off[b], (int) cnt, prep, c->stream);
+            if (cnt && dst_twin) rc = dav1d_hip_launch_mc_bin_twin(&dp, rp, n_refs, dst->bpc, b, ml->dev + ml->off[b], (int) cnt, prep, dst_twin, c->stream);
+            else if (cnt) rc = dav1d_hip_launch_mc_bin(&dp, rp, n_refs, dst->bpc, b, ml->dev + ml->off[b], (int) cnt, prep, c->stream);
         } else if (k == 20) {
             cnt = l->inter->comp->n;
             if (cnt) rc = dav1d_hip_comp_list_run(c, l->inter->comp, dst, prep, mask);
         } else {
             const int b = k - 21;
             cnt = l->itx->off[b + 1] - l->itx->off[b];
-            if (cnt) rc = dav1d_hip_launch_itx_bin(&dp, dst->bpc, b, l->itx->dev + l->itx->off[b], (int) cnt, coef, c->stream);
+            if (cnt) rc = dav1d_hip_launch_itx_bin_out(&dp, dst->bpc, b, l->itx->dev + l->itx->off[b], (int) cnt, coef, dst_twin != nullptr, dst_twin, c->stream);
         }
         counts[k] = cnt;
         (void) hipEventRecord(ev[k + 1], c->stream);

@@ -16,6 +16,7 @@ struct Dav1dHipChunk {
     size_t cap, used;
     size_t dev_off;                              // where the blob sits in the frame's chunk arena (drawn when the chunk was built)
     bool uploaded;                               // it is in the twin, or has been sent on its own
+    bool wide_ok;                                // its transform blocks may leave in row pieces of up to 8 pixels (Dav1dHipReconList::wide_ok)
     uint64_t order;                              // first destination position: chunks are lined up in picture order
     void release(Dav1dHipContext *c);
 };

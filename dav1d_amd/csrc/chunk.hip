@@ -295,6 +295,7 @@ static int chunk_build_hinted(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav
         ck->dep[t.tx] |= itx_dep[i];
         cnt[CK_ITX + t.tx]++;
     }
+    ck->wide_ok = true;         // the lister's blocks lie on AV1's grid: a transform block starts at a multiple of its width (or of 8)
     ck->order = order;
     ck->max_ref = max_ref;
     // compound / blend tasks that stay tasks: BLEND_V and the MASK tasks that read a mask a W_MASK task of the chunk writes go second
@@ -575,6 +576,9 @@ int dav1d_hip_chunk_build(Dav1dHipContext *c, Dav1dHipChunk **out, const Dav1dHi
     for (const Dav1dHipCompTask &k : rest) { CellMap &m = cm[k.plane]; m.each(k.dst_off, k.w, k.h, [&](size_t q) { m.writers[q] |= 1u << 15; }); }
     std::vector<Dav1dHipItxTask> (&ibins)[19] = scr.ibins;
     for (int b = 0; b < 19; b++) ibins[b].clear();
+    ck->wide_ok = true;
+    for (size_t i = 0; i < n_itx && ck->wide_ok; i++)      // (as dav1d_hip_recon_list_create: may the blocks leave in row pieces of up to 8 pixels?)
+        ck->wide_ok = stride[itx[i].plane] > 0 && (int) (itx[i].dst_off % (uint32_t) stride[itx[i].plane]) % std::min((int) tx_w[itx[i].tx], 8) == 0;
     for (size_t i = 0; i < n_itx; i++) {
         const Dav1dHipItxTask &t = itx[i];
         ck->order = std::min(ck->order, (uint64_t) t.plane << 40 | t.dst_off);
@@ -886,8 +890,10 @@ int dav1d_hip_chunks_to_recon_list(Dav1dHipContext *c, std::vector<Dav1dHipChunk
     for (int p = 0; p < 3; p++) il->cell_stride[p] = il->stride_px[p] = 0;
     l->inter = il; l->itx = xl;
     l->f_max_ref = 0;
+    l->wide_ok = true;
     for (int b = 0; b < 19; b++) l->dep[b] = 0;
     for (Dav1dHipChunk *ck : chunks) {
+        l->wide_ok = l->wide_ok && ck->wide_ok;
         for (int b = 0; b < 19; b++) l->dep[b] |= ck->dep[b];
         ml->max_ref = std::max(ml->max_ref, ck->max_ref);
         l->f_max_ref = std::max(l->f_max_ref, ck->max_ref);

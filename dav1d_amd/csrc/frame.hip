@@ -1256,6 +1256,12 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
     if (!rc && !f->scaled.empty()) rc = dav1d_hip_mc_scaled_batch(c, &f->cur, f->refs, f->n_refs, f->scaled.data(), f->scaled.size(), prep);
     if (rc) return rc;
     tr.mark(1);
+    // Option ref_twin = 3: a frame that is reconstruction and nothing else (no intra wavefront, no in-loop filters, no super-resolution,
+    // no warped / scaled predictions — they write raster planes) leaves its picture in the tiled twin ONLY (dav1d_hip_recon_list_run_tiled);
+    // film grain and the fetch to the host un-tile what they read.  Every other frame runs on the raster planes and is retiled at the end.
+    const bool has_post = !f->filter_pieces.empty() || !f->lf.empty() || !f->cdef.empty() || !f->lr.empty() || (f->cdef_rows_state == 1 && f->cdef_row_units.load() > 0);
+    const bool tiled_native = c->ref_twin >= 3 && f->warp.empty() && f->scaled.empty() && f->step_chunks.empty() && f->step_copy.empty() && !has_post && !f->sr_w;
+    bool wrote_twin = false;
     if (!f->chunks.empty()) {
         // predictions and residuals as one pipelined list (the residual launch of a transform size waits only for the
         // prediction launches under its blocks), assembled from the chunks the submitting threads prepared: one upload per
@@ -1280,6 +1286,12 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
         if (!rc) {
             if (ml.n || cl.n || rl.f_n[0] || rl.f_n[1] || rl.f_n[2] || rl.f_n[3] || rl.f_n[4]) {
                 if (!f->n_refs) rc = -EINVAL;
+                else if (tiled_native) {
+                    // the frame's blocks cover the picture: whatever the recycled twin holds is overwritten, nothing has to be carried along
+                    f->cur.twin_ok = DAV1D_HIP_TWIN_ONLY;
+                    rc = dav1d_hip_recon_list_run_tiled(c, &rl, &f->cur, f->refs, f->n_refs, prep, mask, coef);
+                    wrote_twin = !rc && f->cur.twin_ok != 0;
+                }
                 else rc = dav1d_hip_recon_list_run(c, &rl, &f->cur, f->refs, f->n_refs, prep, mask, coef);
             } else if (xl.n) {
                 rc = dav1d_hip_itx_list_run(c, &xl, &f->cur, coef);
@@ -1571,7 +1583,9 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
         }
     }
     // the picture later frames predict from gets its tiled twin (Dav1dHipPicture.twin: what their motion compensation reads)
-    if (!rc && c->ref_twin >= 2 && last->twin[0]) rc = dav1d_hip_picture_retile(c, const_cast<Dav1dHipPicture *>(last));
+    if (!rc && c->ref_twin >= 2 && last->twin[0] && !(wrote_twin && last == &f->cur)) rc = dav1d_hip_picture_retile(c, const_cast<Dav1dHipPicture *>(last));
+    // film grain reads raster rows: a picture that lives in its twin gets them back first (both valid afterwards)
+    if (!rc && f->have_grain && grain_out && last->twin_ok == DAV1D_HIP_TWIN_ONLY) rc = dav1d_hip_picture_untile(c, const_cast<Dav1dHipPicture *>(last));
     if (!rc && filtered) *filtered = *last;
     if (!rc && f->have_grain && grain_out)
         rc = f->prepared ? dav1d_hip_fg_apply_prepared(c, grain_out, last, f->prepared, f->is_id)

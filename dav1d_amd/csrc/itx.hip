@@ -41,9 +41,14 @@ __global__ __launch_bounds__(64) void itx_add_wide_kernel(const DevPlanes dst, c
     const int group = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x);
     const int block0 = group * BPW;
     if (block0 >= n) return;
-    itx_body<TX, pixel, coef, false, true>(dst, tasks, n, cf, bitdepth_max, group, tmp_s, tile);
+    // twin.tiled == 2: the picture lives in its twin only — the predicted pixels are read from there and the sums go back there
+    // (`twin` carries the strides and sizes of the raster planes next to the twin's data pointers; a DevPlanes put together here from the
+    // two kernel arguments would live in scratch memory)
+    const bool twin_only = twin.tiled == 2;
+    if (twin_only) itx_body<TX, pixel, coef, false, true>(twin, tasks, n, cf, bitdepth_max, group, tmp_s, tile, true);
+    else itx_body<TX, pixel, coef, false, true>(dst, tasks, n, cf, bitdepth_max, group, tmp_s, tile);
     dv::wave_sync();
-    tile_write_out<W, H, BPW, pixel>(tile, tasks + block0, dv::imin(BPW, n - block0), dst, twin, twin.data[0] != nullptr);
+    tile_write_out<W, H, BPW, pixel>(tile, tasks + block0, dv::imin(BPW, n - block0), dst, twin, twin.data[0] != nullptr, !twin_only);
 }
 
 // Every transform size in one launch, for the short lists of an intra wavefront step (a few hundred blocks of up to

@@ -85,10 +85,12 @@ constexpr int itx_lds_ints() {
 // PRED_LDS (fused prediction + residual kernels): the pixels the residual is added to come from pred_s (block `sub` of the
 // wave, W x H, row stride W) instead of the picture; the sum still goes to the picture.
 // COH (with PRED_LDS): the result goes back to the LDS tile instead of the picture; the caller (intra_flow.hip) writes it out.
+// tsrc (with COH, without PRED_LDS): `dst` holds the planes of the picture's tiled twin (8x8 tiles of 64 consecutive pixels, mc_body.h)
+// and the pixels the residual is added to are read from there — a frame whose pictures live in the twin only (DAV1D_HIP_TWIN_ONLY).
 template <int TX, typename pixel, typename coef, bool PRED_LDS = false, bool COH = false>
 __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItxTask *__restrict__ tasks,
                                          const int n, coef *__restrict__ cf, const int bitdepth_max, const int group, int *tmp_s,
-                                         const pixel *pred_s = nullptr)
+                                         const pixel *pred_s = nullptr, const bool tsrc = false)
 {
     constexpr int W = tx_w(TX), H = tx_h(TX);
     constexpr int SW = cmin(W, 32), SH = cmin(H, 32);
@@ -123,6 +125,19 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
     int *const tmp = tmp_s + sub * SH * TS;
     pixel *const d = reinterpret_cast<pixel *>(dst.data[t.plane]) + t.dst_off + l;
     const int stride = dst.stride[t.plane];
+    // tsrc: this lane's column of the block in the tiled plane — pixel (X, Y) lives at (Y & ~7) * stride + (X >> 3) * 64 + (Y & 7) * 8 + (X & 7)
+    int tbx = 0, tby = 0;
+    if (!PRED_LDS && COH && tsrc && live) dv::off_to_xy(t.dst_off, stride, tbx, tby);
+    const pixel *const tcol = reinterpret_cast<const pixel *>(dst.data[t.plane]) + ((((tbx + l) >> 3) << 6) + ((tbx + l) & 7));
+    auto load_dst = [&](pixel (&px)[H]) {
+        if (!PRED_LDS && COH && tsrc) {
+#pragma unroll
+            for (int y = 0; y < H; y++) px[y] = tcol[dv::mul_i24((tby + y) & ~7, stride) + (((tby + y) & 7) << 3)];
+        } else {
+#pragma unroll
+            for (int y = 0; y < H; y++) px[y] = d[y * stride];
+        }
+    };
 
     // ---- issue every global load up front: the row's coefficients (lane r = row r reads
     // coeff[r + x*SH], consecutive lanes -> consecutive addresses) and, for the column pass later,
@@ -155,10 +170,7 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
             v[k] = make_int4(0, 0, 0, 0);
             if (l + k * LPB < nch) v[k] = g4[l + k * LPB];
         }
-        if (!PRED_LDS && l < W) {
-#pragma unroll
-            for (int y = 0; y < H; y++) dpx[y] = d[y * stride];
-        }
+        if (!PRED_LDS && l < W) load_dst(dpx);
 #pragma unroll
         for (int k = 0; k < (NCH + LPB - 1) / LPB; k++) {
             if (l + k * LPB < NCH) s4[l + k * LPB] = v[k];
@@ -166,10 +178,7 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
         }
     } else if (dconly) {
         if (l == 0) { dc = gcf[0]; if (!(t.flags & DAV1D_HIP_ITX_PACKED)) gcf[0] = 0; }            // src/itx_tmpl.c:59-60
-        if (!PRED_LDS && l < W) {
-#pragma unroll
-            for (int y = 0; y < H; y++) dpx[y] = d[y * stride];
-        }
+        if (!PRED_LDS && l < W) load_dst(dpx);
     }
     dc = __shfl(dc, sub * LPB);
     dv::wave_sync();
@@ -283,11 +292,12 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
 // Through the tile (itx_body's COH form: the sums go back to LDS, [block][row][W pixels]) every lane instead takes row pieces of
 // up to 8 pixels — 16 bytes at 10 / 12 bits — and stores each once to the raster plane and, when the picture has a tiled twin
 // (Dav1dHipPicture.twin: 8x8 tiles of 64 consecutive pixels, mc_body.h), once to the twin: a piece is a whole tile row there, an
-// 8x8 block one 128-byte line.
+// 8x8 block one 128-byte line.  raster = false: the twin only (twin.tiled == 2 at the kernels: the picture lives in its twin,
+// DAV1D_HIP_TWIN_ONLY).
 
 template <int W, int H, int BPW, typename pixel>
 __device__ __forceinline__ void tile_write_out(const pixel *tile, const Dav1dHipItxTask *__restrict__ tasks, const int nb,
-                                               const DevPlanes &dst, const DevPlanes &twin, const bool has_twin)
+                                               const DevPlanes &dst, const DevPlanes &twin, const bool has_twin, const bool raster = true)
 {
     constexpr int CP = W < 8 ? W : 8;                   // pixels per piece: inside one row of one 8x8 tile
     constexpr int CPR = W / CP, PER_BLOCK = H * CPR, NCHK = BPW * PER_BLOCK;
@@ -315,7 +325,7 @@ __device__ __forceinline__ void tile_write_out(const pixel *tile, const Dav1dHip
         const int X = x0 + c * CP, Y = y0 + y;
         const int stride = pl == 0 ? dst.stride[0] : pl == 1 ? dst.stride[1] : dst.stride[2];
         pixel *const base = reinterpret_cast<pixel *>(pl == 0 ? dst.data[0] : pl == 1 ? dst.data[1] : dst.data[2]);
-        *reinterpret_cast<piece_t *>(base + (dv::mul_i24(Y, stride) + X)) = v;
+        if (raster) *reinterpret_cast<piece_t *>(base + (dv::mul_i24(Y, stride) + X)) = v;
         if (has_twin) {      // (kernel arguments are never indexed by a run-time value nor have their address taken: either sends them to scratch memory)
             pixel *const tb = reinterpret_cast<pixel *>(pl == 0 ? twin.data[0] : pl == 1 ? twin.data[1] : twin.data[2]);
             *reinterpret_cast<piece_t *>(tb + (dv::mul_i24(Y & ~7, stride) + ((X >> 3) << 6) + ((Y & 7) << 3) + (X & 7))) = v;

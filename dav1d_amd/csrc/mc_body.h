@@ -461,7 +461,10 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
                     ? reinterpret_cast<pixel *>(prep) + t.dst_off + (t.oy + vr) * t.bw + t.ox + 4 * vs
                     : TO_LDS ? pred_s + ((ti - pred_tile0) >> pred_tpb_log2) * (pred_w * pred_h) + (t.oy + vr) * pred_w + t.ox + 4 * vs
                     : reinterpret_cast<pixel *>(dst.data[t.plane]) + t.dst_off + (t.oy + vr) * dst.stride[t.plane] + t.ox + 4 * vs;
-                if (nvalid == 4) {
+                // TWIN with twin.tiled == 2: the picture lives in its twin only (DAV1D_HIP_TWIN_ONLY) — nothing goes to the raster planes
+                const bool to_raster = !(TWIN && !TO_LDS && twin.tiled == 2 && t.kind != MCT_PUT_TMP);
+                if (!to_raster) {
+                } else if (nvalid == 4) {
                     if (HBD) *reinterpret_cast<uint2 *>(d) = make_uint2(dv::pack2(o[0], o[1]), dv::pack2(o[2], o[3]));
                     else *reinterpret_cast<uint32_t *>(d) = (uint32_t) o[0] | ((uint32_t) o[1] << 8) | ((uint32_t) o[2] << 16) | ((uint32_t) o[3] << 24);
                 } else if (nvalid > 0) {

@@ -221,9 +221,10 @@ extern "C" int dav1d_hip_launch_emu_edge(void *dst, ptrdiff_t dst_stride, const 
 // rows x 64 pixels: lane l reads the 8 pixels (r = l >> 3, c = l & 7) of its row segment — the 8 lanes of a row read 128 (64)
 // contiguous bytes — and writes row r of tile c: the wave's stores cover 8 whole tiles, 1 KB (512 bytes) of contiguous memory.
 namespace {
-template <typename pixel>
+// UNTILE: the other way (twin -> raster rows, for the rows [ty0 * 8, ...) the grid covers), same mapping
+template <typename pixel, bool UNTILE>
 __global__ __launch_bounds__(64) void retile_kernel(const pixel *__restrict__ src, pixel *__restrict__ twin, const int stride, const int h,
-                                                    const int n_xg)
+                                                    const int n_xg, const int ty0)
 {
     typedef typename std::conditional<sizeof(pixel) == 2, uint4, uint2>::type piece_t;
     constexpr int ROWS = 8;                   // tile rows (of 8 picture rows) per wave: 8 KB (4 KB) in flight per wave
@@ -234,6 +235,20 @@ __global__ __launch_bounds__(64) void retile_kernel(const pixel *__restrict__ sr
     if (x >= stride) return;
     const int n_ty = (h + 7) >> 3;
     piece_t v[ROWS];
+    if (UNTILE) {
+        // `src` = the twin, `twin` = the raster plane; rows at or below h are not the picture's (a caller-wrapped plane need not have them)
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) {
+            const int ty = dv::imin(ty0 + tyg * ROWS + k, n_ty - 1);
+            v[k] = *reinterpret_cast<const piece_t *>(src + (size_t) ty * 8 * stride + (size_t) (x >> 3) * 64 + r * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) {
+            const int y = (ty0 + tyg * ROWS + k) * 8 + r;
+            if (y < h) *reinterpret_cast<piece_t *>(twin + (size_t) y * stride + x) = v[k];
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < ROWS; k++) {
         const int ty = tyg * ROWS + k;
@@ -256,11 +271,34 @@ extern "C" int dav1d_hip_launch_retile(const DevPlanes *src, void *const twin[3]
         const int n_xg = (src->stride[pl] + 63) / 64, n_ty = ((src->h[pl] + 7) / 8 + 7) / 8;      // 8 tile rows per wave
         const dim3 grid((unsigned) n_xg * (unsigned) n_ty), wave(64);
         if (bpc == 8)
-            hipLaunchKernelGGL((retile_kernel<uint8_t>), grid, wave, 0, (hipStream_t) stream, (const uint8_t *) src->data[pl], (uint8_t *) twin[pl],
-                               src->stride[pl], src->h[pl], n_xg);
+            hipLaunchKernelGGL((retile_kernel<uint8_t, false>), grid, wave, 0, (hipStream_t) stream, (const uint8_t *) src->data[pl], (uint8_t *) twin[pl],
+                               src->stride[pl], src->h[pl], n_xg, 0);
         else
-            hipLaunchKernelGGL((retile_kernel<uint16_t>), grid, wave, 0, (hipStream_t) stream, (const uint16_t *) src->data[pl], (uint16_t *) twin[pl],
-                               src->stride[pl], src->h[pl], n_xg);
+            hipLaunchKernelGGL((retile_kernel<uint16_t, false>), grid, wave, 0, (hipStream_t) stream, (const uint16_t *) src->data[pl], (uint16_t *) twin[pl],
+                               src->stride[pl], src->h[pl], n_xg, 0);
+    }
+    return hip_rc(hipGetLastError());
+}
+
+// Twin -> raster planes (`dst`: the raster planes with their strides and heights), rows [row0[pl], row1[pl]) of each plane widened to
+// whole tile rows; plane_mask: bit pl = untile plane pl.  What a picture that lives in its twin only (DAV1D_HIP_TWIN_ONLY) goes
+// through before anything that reads raster planes — the fetch to the host first of all (src/picture.c:46-63's layout at the output only).
+extern "C" int dav1d_hip_launch_untile(const DevPlanes *dst, void *const twin[3], int bpc, const int row0[3], const int row1[3], int plane_mask, void *stream) {
+    for (int pl = 0; pl < 3; pl++) {
+        if (!dst->data[pl] || !(plane_mask >> pl & 1)) continue;
+        if (!twin[pl] || dst->stride[pl] % 8 || dst->h[pl] <= 0) return -EINVAL;
+        const int h = dst->h[pl];
+        const int r0 = row0 ? (row0[pl] < 0 ? 0 : row0[pl]) : 0, r1 = row1 ? (row1[pl] > h ? h : row1[pl]) : h;
+        if (r1 <= r0) continue;
+        const int ty0 = r0 >> 3, nty = ((r1 + 7) >> 3) - ty0;
+        const int n_xg = (dst->stride[pl] + 63) / 64, n_tyg = (nty + 7) / 8;
+        const dim3 grid((unsigned) n_xg * (unsigned) n_tyg), wave(64);
+        if (bpc == 8)
+            hipLaunchKernelGGL((retile_kernel<uint8_t, true>), grid, wave, 0, (hipStream_t) stream, (const uint8_t *) twin[pl], (uint8_t *) dst->data[pl],
+                               dst->stride[pl], h, n_xg, ty0);
+        else
+            hipLaunchKernelGGL((retile_kernel<uint16_t, true>), grid, wave, 0, (hipStream_t) stream, (const uint16_t *) twin[pl], (uint16_t *) dst->data[pl],
+                               dst->stride[pl], h, n_xg, ty0);
     }
     return hip_rc(hipGetLastError());
 }

@@ -86,7 +86,7 @@ void recon_fused_kernel(const DevPlanes dst, const RefSet refs, const McTile *__
     if constexpr (WIDE) {
         itx_body<TX, pixel, coef, true, true>(dst, tasks, n_blocks, cf, bitdepth_max, group, smem_itx, pred);
         dv::wave_sync();
-        tile_write_out<W, W, BPW, pixel>(pred, tasks + block0, nb, dst, twin, twin.data[0] != nullptr);
+        tile_write_out<W, W, BPW, pixel>(pred, tasks + block0, nb, dst, twin, twin.data[0] != nullptr, twin.tiled != 2);
     } else {
         itx_body<TX, pixel, coef, true>(dst, tasks, n_blocks, cf, bitdepth_max, group, smem_itx, pred);
     }

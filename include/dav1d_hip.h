@@ -117,11 +117,18 @@ typedef struct Dav1dHipPicture {
      * EVERY reference of the call has one that is valid (twin_ok): a prediction window then touches a third to a half of the
      * memory lines it touches in raster order.  dav1d_hip_picture_retile fills it; dav1d_hip_frame_end /
      * dav1d_hip_recon_list_run do so for the picture they produce when it has the storage.  Whoever changes the raster planes by
-     * other means clears twin_ok (or retiles).  twin_alloc: the storage (owned when made by the library). */
+     * other means clears twin_ok (or retiles).  twin_alloc: the storage (owned when made by the library).
+     * twin_ok: 0 = only the raster planes hold the picture; 1 = twin and raster planes agree; DAV1D_HIP_TWIN_ONLY = the picture
+     * lives in its twin and the raster planes are stale (what dav1d_hip_recon_list_run_tiled leaves: the reconstruction wrote whole
+     * tiles — an 8x8 block is one 128-byte line — and nothing else).  Such a picture may be handed to motion compensation as a
+     * reference, to dav1d_hip_host_picture_fetch / dav1d_hip_plane_download (they un-tile the rows they copy: raster rows by the
+     * address rules of the reference's src/picture.c:46-63 exist at the output only), to dav1d_hip_recon_list_run_tiled again and to
+     * dav1d_hip_picture_untile, which gives the raster planes back (twin_ok = 1) for everything else. */
     void *twin[3];
     void *twin_alloc;
     int twin_ok;
 } Dav1dHipPicture;
+#define DAV1D_HIP_TWIN_ONLY 2
 
 /* Allocation with the reference's geometry (src/picture.c:46-78): dimensions padded
  * to 128, stride = aligned_w << hbd, +64 B when a multiple of 1024. */
@@ -131,11 +138,16 @@ DAV1D_HIP_API int dav1d_hip_picture_free(Dav1dHipContext *c, Dav1dHipPicture *pi
 /* The tiled twin of a picture (see Dav1dHipPicture.twin).  Context option "ref_twin" ($DAV1D_HIP_REF_TWIN): 0 = twins are never
  * read; 1 (default) = motion compensation reads references through valid twins, which the caller makes (dav1d_hip_picture_retile
  * once a picture is final); 2 = dav1d_hip_picture_alloc also makes the storage along with the planes and dav1d_hip_frame_end
- * retiles the picture it produces.  _twin_alloc adds the storage to a picture that has none (also to a caller-wrapped one: strides
- * must be multiples of 8 pixels, plane heights are rounded up to 8 rows).  _retile copies the raster planes into the twin on the
+ * retiles the picture it produces; 3 = as 2, and a frame that is reconstruction and nothing else (no intra wavefront, in-loop filters,
+ * super-resolution, warped or scaled predictions) leaves its picture in the twin ONLY (twin_ok = DAV1D_HIP_TWIN_ONLY on the picture
+ * dav1d_hip_frame_end hands back: see Dav1dHipPicture).  _twin_alloc adds the storage to a picture that has none (also to a caller-wrapped one: strides
+ * must be multiples of 8 pixels; the twin has the rows of dav1d's allocator, 128-row padding included).  _retile copies the raster planes into the twin on the
  * context's stream (asynchronous, like every launch) and sets twin_ok. */
 DAV1D_HIP_API int dav1d_hip_picture_twin_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic);
 DAV1D_HIP_API int dav1d_hip_picture_retile(Dav1dHipContext *c, Dav1dHipPicture *pic);
+/* twin -> raster planes for a picture that lives in its twin (twin_ok == DAV1D_HIP_TWIN_ONLY; twin_ok = 1 afterwards); a no-op for any
+ * other picture.  On the context's stream. */
+DAV1D_HIP_API int dav1d_hip_picture_untile(Dav1dHipContext *c, Dav1dHipPicture *pic);
 /* ... on a side stream of the context: starts when what is enqueued so far is through, runs next to what is enqueued afterwards
  * (the copy is bound by bandwidth, a frame's launches by request latency and arithmetic).  Launches of THIS context that read
  * twins, and dav1d_hip_sync, wait for it; other contexts must not read the twin before this context has synchronised. */
@@ -333,6 +345,15 @@ DAV1D_HIP_API int dav1d_hip_recon_list_run(Dav1dHipContext *c, const Dav1dHipRec
  * picture); otherwise the list runs as dav1d_hip_recon_list_run does and dav1d_hip_picture_retile follows. */
 DAV1D_HIP_API int dav1d_hip_recon_list_run_twin(Dav1dHipContext *c, const Dav1dHipReconList *l, Dav1dHipPicture *dst,
                                                 const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask, void *coef);
+/* The same with the picture living in its twin ONLY (the native layout of a reconstructed picture on this backend): nothing is
+ * written to the raster planes, dst->twin_ok = DAV1D_HIP_TWIN_ONLY afterwards (see Dav1dHipPicture).  The paired launches and the
+ * residual launches leave whole tile rows (an 8x8 block = one 128-byte line, where the raster planes take eight 16-byte pieces in
+ * eight lines), the prediction launches store their strips into tiles, the residual launches read the predicted pixels back from
+ * there.  Needs what the direct form of _run_twin needs (tiled references, blocks on AV1's grid, no mask / blend tasks); a list that
+ * cannot run that way runs on the raster planes and is retiled (twin_ok = 1).  If `dst` holds pixels the list does not overwrite
+ * they are carried along: a picture with twin_ok == 0 is retiled first. */
+DAV1D_HIP_API int dav1d_hip_recon_list_run_tiled(Dav1dHipContext *c, const Dav1dHipReconList *l, Dav1dHipPicture *dst,
+                                                 const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask, void *coef);
 DAV1D_HIP_API void dav1d_hip_recon_list_destroy(Dav1dHipContext *c, Dav1dHipReconList *l);
 /* Measurement aid (bench.py): every launch of the list on its own, bracketed by events.  ms / counts hold 40 entries:
  * [0..4] paired launches (prediction + residual in one wave) by square size 4x4 .. 64x64, [5..19] prediction launches by tile
@@ -340,6 +361,10 @@ DAV1D_HIP_API void dav1d_hip_recon_list_destroy(Dav1dHipContext *c, Dav1dHipReco
 DAV1D_HIP_API int dav1d_hip_recon_list_run_timed(Dav1dHipContext *c, const Dav1dHipReconList *l, const Dav1dHipPicture *dst,
                                                  const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask, void *coef,
                                                  float *ms, size_t *counts);
+/* ... of dav1d_hip_recon_list_run_tiled (-ENOTSUP when the list cannot run with its picture in the twin only) */
+DAV1D_HIP_API int dav1d_hip_recon_list_run_tiled_timed(Dav1dHipContext *c, const Dav1dHipReconList *l, Dav1dHipPicture *dst,
+                                                       const Dav1dHipPicture *refs, int n_refs, int16_t *prep, uint8_t *mask, void *coef,
+                                                       float *ms, size_t *counts);
 DAV1D_HIP_API int dav1d_hip_inter_list_run(Dav1dHipContext *c, const Dav1dHipInterList *l,
                                            const Dav1dHipPicture *dst, const Dav1dHipPicture *refs,
                                            int n_refs, int16_t *prep, uint8_t *mask);

@@ -36,11 +36,19 @@ def _default_options(request):
             c.set_option(name, value)
 
 
-@pytest.fixture(params=[False, True], ids=["raster-refs", "tiled-refs"])
+@pytest.fixture(params=[False, True, "native"], ids=["raster-refs", "tiled-refs", "tiled-native"])
 def twin_refs(request, ctx):
-    """Tests that name this fixture run twice: with reference pictures read in raster order, and with every uploaded picture
+    """Tests that name this fixture run three times: with reference pictures read in raster order; with every uploaded picture
     retiled (api.DevicePicture.upload -> dav1d_hip_picture_retile) so that motion compensation reads references through their tiled
-    twins (Dav1dHipPicture.twin, the TILED kernel variants of mc.hip / recon.hip).  Both must give the oracle's pixels."""
-    ctx.auto_retile = request.param
+    twins (Dav1dHipPicture.twin, the TILED kernel variants of mc.hip / recon.hip); and "tiled-native": tiled references AND every
+    reconstruction leaving its picture in the twin ONLY (dav1d_hip_recon_list_run_tiled for recon lists, context option ref_twin = 3
+    for frames: DAV1D_HIP_TWIN_ONLY) — the raster planes the tests compare then come from the un-tiling download / fetch.  All three
+    must give the oracle's pixels."""
+    ctx.auto_retile = bool(request.param)
+    ctx.tiled_native = request.param == "native"
+    if ctx.tiled_native:
+        ctx.set_option("ref_twin", 3)
     yield request.param
     ctx.auto_retile = False
+    ctx.tiled_native = False
+    ctx.set_option("ref_twin", 1)

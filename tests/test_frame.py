@@ -324,3 +324,71 @@ def test_shapes_sharing_one_launch(ctx, mode):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", sel + " and fused", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("size", [(512, 128), (200, 136), (1000, 72)], ids=["512x128", "200x136", "1000x72"])
+@pytest.mark.parametrize("bpc", [8, 10])
+def test_recon_list_with_its_picture_in_the_twin_only(ctx, bpc, size):
+    """dav1d_hip_recon_list_run_tiled: the frame's pixels go to the tiled twin and NOWHERE else (DAV1D_HIP_TWIN_ONLY: the raster planes
+    keep what they held), a chain of two frames predicts the second from the first through that twin, and every way out gives the
+    oracle's raster rows: plane download, dav1d_hip_host_picture_fetch in bands of rows, dav1d_hip_picture_untile.  Sizes that cut blocks
+    reconstruct below the visible rows (the twin has the allocator's padding rows, like the raster planes)."""
+    w, h = size
+    if ctx.backend != "emu" and size == (512, 128):
+        w, h = 1280, 1024
+    oracle = util.default_oracle()
+    frame = synth.make_frame(w, h, bpc, seed=w + 3 * h + bpc, edge_frac=0.1, mv_range_px=40)
+    rng = np.random.default_rng(w + bpc)
+    refs_h = [synth.make_planes(rng, w, h, bpc) for _ in range(frame.n_refs)]
+    dst0 = synth.make_planes(rng, w, h, bpc, smooth=False)
+    want1, _, _ = oracle_frame(oracle, frame, dst0, refs_h)
+    want2, _, _ = oracle_frame(oracle, frame, dst0, [want1] + refs_h[1:])         # the second frame predicts from the first
+    refs = []
+    for rp in refs_h:
+        r = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+        for pl in range(3):
+            r.upload(pl, rp[pl])
+        r.retile()
+        refs.append(r)
+    pics = []
+    for _ in range(2):
+        d = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+        for pl in range(3):
+            d.upload(pl, dst0[pl])
+        pics.append(d)
+    prep = ctx.buffer(frame.prep_elems * 2)
+    prep.zero()
+    rl = ctx.recon_list(pics[0], frame.mc, frame.comp, frame.itx)
+    coef = ctx.buffer_from(frame.coef)
+    rl.run_tiled(pics[0], refs, prep, coef)
+    assert pics[0].pic.twin_ok == api.TWIN_ONLY
+    # nothing reached the raster planes: they still hold what was uploaded
+    raw = np.zeros((pics[0].padded_shape(0)[0], pics[0].stride_px(0)), pics[0].dtype)
+    ctx.sync()
+    assert ctx.lib.dav1d_hip_download(ctx.h, raw.ctypes.data, pics[0].pic.p[0].data, raw.nbytes) == 0
+    assert np.array_equal(raw[:, :dst0[0].shape[1]], dst0[0]), "the raster planes were written"
+    for pl in range(3):
+        assert np.array_equal(pics[0].download(pl), want1[pl]), ("download un-tiles", pl)
+    assert pics[0].pic.twin_ok == api.TWIN_ONLY
+    # rows out to the host in bands (what a row-progress listener does)
+    host = api.HostPictureBuf(ctx, w, h, api.LAYOUT_I420, bpc)
+    edges = sorted({0, min(h, 56), min(h, 120), h})
+    for r0, r1 in zip(edges[:-1], edges[1:]):
+        host.fetch(pics[0].pic, r0, r1)
+    host.wait()
+    for pl in range(3):
+        vh, vw = (h, w) if pl == 0 else ((h + 1) // 2, (w + 1) // 2)
+        assert np.array_equal(host.plane(pl)[:vh, :vw], want1[pl][:vh, :vw]), ("fetch in bands", pl)
+    host.release()
+    # the second frame: reference 0 = the first frame's picture, read through the twin it lives in
+    coef2 = ctx.buffer_from(frame.coef)
+    rl.run_tiled(pics[1], [pics[0]] + refs[1:], prep, coef2)
+    assert pics[1].pic.twin_ok == api.TWIN_ONLY
+    pics[1].untile()
+    assert pics[1].pic.twin_ok == 1
+    ctx.sync()
+    for pl in range(3):
+        assert np.array_equal(pics[1].download(pl), want2[pl]), ("second frame of the chain, after untile", pl)
+    rl.destroy()
+    for o in pics + refs + [prep, coef, coef2]:
+        o.free()

@@ -1,0 +1,128 @@
+"""The recon step of the bench's 8K 10-bit workload with its pictures in the tiled twin only (dav1d_hip_recon_list_run_tiled) under a list
+of context-option sets, next to the raster layout, in ONE process on ONE box (boxes of the pool differ by 10 %): ms per step, per-kernel
+event times, parity of every variant against the raster run.
+    python tools/layout_sweep.py [--sets "recon_fuse=15" "recon_fuse=14,recon_pair_streams=2" ...] [--kernels]"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+NAMES = ["recon_%dx%d" % (4 << k, 4 << k) for k in range(5)] + ["mc_%dx%d" % (4 << (b // 3), 4 << (b % 3)) for b in range(15)] + ["comp"] + ["itx_%d" % b for b in range(19)]
+DEFAULTS = {"recon_fuse": 14, "recon_pair_streams": 1, "recon_lanes": 1, "recon_pipeline": 16384, "recon_coop_below": 4096}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=7680)
+    ap.add_argument("--height", type=int, default=4320)
+    ap.add_argument("--bpc", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--sets", nargs="*", default=[""])
+    ap.add_argument("--kernels", action="store_true")
+    ap.add_argument("--no-raster", action="store_true")
+    a = ap.parse_args()
+    import torch
+    from dav1d_amd import api, synth
+    stream = torch.cuda.current_stream()
+    ctx = api.Context(0, stream=stream.cuda_stream)
+    w, h, bpc = a.width, a.height, a.bpc
+    frame = synth.make_frame(w, h, bpc, seed=0xDA71D002, mv_range_px=64, edge_frac=0.05, n_refs=3)
+    rng = np.random.default_rng(1234)
+    ref_host = [synth.make_planes(rng, w, h, bpc) for _ in range(frame.n_refs)]
+    dst_host = synth.make_planes(rng, w, h, bpc, smooth=False)
+    refs = []
+    for rp in ref_host:
+        r = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+        for pl in range(3):
+            r.upload(pl, rp[pl])
+        r.retile()
+        refs.append(r)
+    dsts = []
+    for _ in range(4):
+        d = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+        for pl in range(3):
+            d.upload(pl, dst_host[pl])
+        dsts.append(d)
+    prep = torch.zeros(frame.prep_elems, dtype=torch.int16, device="cuda")
+    tdt = torch.int16 if bpc == 8 else torch.int32
+    pristine = torch.from_numpy(frame.coef).to("cuda")
+    n_arena = a.steps + 8
+    arenas = torch.empty((n_arena, pristine.numel()), dtype=tdt, device="cuda")
+
+    def fresh():
+        for i in range(n_arena):
+            arenas[i].copy_(pristine)
+        torch.cuda.synchronize()
+
+    def timed(rl, tiled):
+        fresh()
+        run = rl.run_tiled if tiled else rl.run
+        for i in range(3):
+            run(dsts[i % 4], refs, prep.data_ptr(), arenas[i].data_ptr())
+        ctx.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(3, 3 + a.steps):
+            run(dsts[i % 4], refs, prep.data_ptr(), arenas[i].data_ptr())
+        ctx.sync()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.steps * 1e3
+        pics = [dsts[(2 + a.steps) % 4].download(pl) for pl in range(3)]
+        return dt, pics
+
+    def kernels(rl, tiled):
+        fresh()
+        ms = (C.c_float * 40)()
+        cnt = (C.c_size_t * 40)()
+        best = [1e9] * 40
+        for rep in range(3):
+            rarr = (api.Picture * len(refs))(*[r.pic for r in refs])
+            fn = ctx.lib.dav1d_hip_recon_list_run_tiled_timed if tiled else ctx.lib.dav1d_hip_recon_list_run_timed
+            rc = fn(ctx.h, rl.h, C.byref(dsts[0].pic), rarr, len(refs), prep.data_ptr(), None, arenas[rep].data_ptr(), ms, cnt)
+            assert rc == 0, rc
+            best = [min(x, y) for x, y in zip(best, ms)]
+        return {NAMES[k]: round(best[k] * 1e3, 1) for k in range(40) if cnt[k]}
+
+    base = None
+    if not a.no_raster:
+        ctx.set_option("ref_twin", 0)
+        rl = ctx.recon_list(dsts[0], frame.mc, frame.comp, frame.itx)
+        for d in dsts:
+            d.pic.twin_ok = 0
+        dt, base = timed(rl, False)
+        o = {"layout": "raster", "ms_per_step": round(dt, 4)}
+        if a.kernels:
+            o["kernels_us"] = kernels(rl, False)
+        print(json.dumps(o), flush=True)
+        rl.destroy()
+        ctx.set_option("ref_twin", 1)
+    for st in a.sets:
+        opts = dict(DEFAULTS)
+        for kv in [x for x in st.split(",") if x]:
+            k, v = kv.split("=")
+            opts[k] = int(v)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        rl = ctx.recon_list(dsts[0], frame.mc, frame.comp, frame.itx)        # (the pairing is decided at list creation)
+        for d in dsts:
+            d.pic.twin_ok = 0
+            for pl in range(3):
+                d.upload(pl, dst_host[pl])
+        dt, pics = timed(rl, True)
+        o = {"layout": "tiled", "opts": st, "ms_per_step": round(dt, 4), "twin_only": int(dsts[0].pic.twin_ok)}
+        if base is not None:
+            o["equals_raster"] = all(np.array_equal(base[pl], pics[pl]) for pl in range(3))
+        if a.kernels:
+            o["kernels_us"] = kernels(rl, True)
+        print(json.dumps(o), flush=True)
+        rl.destroy()
+
+
+if __name__ == "__main__":
+    main()
