@@ -308,3 +308,37 @@ __device__ __forceinline__ unsigned xcd_chunk_id(unsigned b, unsigned nb) {
 }
 
 } // namespace dv
+
+// ---- where a wave's time goes (variant builds only: -DDV_PHASES, tools/build_variant.py).  DV_PHASE_BEGIN() reads the shader clock,
+// DV_PHASE(slot) adds the cycles since the previous mark to g_phase[slot] (lane 0 of the wave, one atomic) and DV_PHASE_WAVE(slot) the
+// cycles since DV_PHASE_BEGIN.  The marks sit behind the wave_sync that ends a phase (reading the clock also waits for the wave's LDS and
+// scalar-memory operations, not for its vector-memory ones), so a slot holds issue + stall of that phase.  Each translation unit has its own g_phase[] and an accessor (dav1d_hip_debug_phases_<unit>).
+#if defined(DV_PHASES) && !defined(DAV1D_HIP_EMU)
+// (every wave adds into its own word — slot x (workgroup mod DV_PHASE_SPREAD) — : thousands of waves adding into ONE word made the
+// instrumented kernels thirty times slower than the plain ones; the accessor sums the words of a slot)
+#define DV_PHASE_SLOTS 1024
+#define DV_PHASE_SPREAD 8192
+namespace { __device__ unsigned long long g_phase[DV_PHASE_SLOTS * DV_PHASE_SPREAD]; }
+#define DV_PHASE_DEFINE(unit) DV_PHASE_DEFINE_(unit)
+#define DV_PHASE_DEFINE_(unit) \
+    extern "C" __attribute__((visibility("default"))) int dav1d_hip_debug_phases_##unit(unsigned long long *out, int reset) { \
+        if (out) { \
+            unsigned long long *h = new unsigned long long[(size_t) DV_PHASE_SLOTS * DV_PHASE_SPREAD]; \
+            if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(g_phase)) != hipSuccess) { delete[] h; return -5; } \
+            for (int s_ = 0; s_ < DV_PHASE_SLOTS; s_++) { unsigned long long t_ = 0; for (int k_ = 0; k_ < DV_PHASE_SPREAD; k_++) t_ += h[(size_t) s_ * DV_PHASE_SPREAD + k_]; out[s_] = t_; } \
+            delete[] h; \
+        } \
+        if (reset) { void *p_ = nullptr; if (hipGetSymbolAddress(&p_, HIP_SYMBOL(g_phase)) != hipSuccess || hipMemset(p_, 0, sizeof(g_phase)) != hipSuccess) return -5; } \
+        return 0; }
+#define DV_PHASE_AT(slot) g_phase[(size_t) (slot) * DV_PHASE_SPREAD + (blockIdx.x & (DV_PHASE_SPREAD - 1))]
+#define DV_PHASE_BEGIN() unsigned long long dv_t0_ = __builtin_amdgcn_s_memtime(), dv_t_ = dv_t0_
+#define DV_PHASE(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&DV_PHASE_AT(slot), n_ - dv_t_); dv_t_ = n_; } while (0)
+#define DV_PHASE_WAVE(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&DV_PHASE_AT(slot), n_ - dv_t0_); atomicAdd(&DV_PHASE_AT((slot) + 1), 1ull); } } while (0)
+#else
+#define DV_PHASE_DEFINE(unit)
+#define DV_PHASE_BEGIN() do { } while (0)
+#define DV_PHASE(slot) do { } while (0)
+#define DV_PHASE_WAVE(slot) do { } while (0)
+#endif

@@ -13,10 +13,12 @@
 // The slab is fetched with 16-byte loads into LDS (zeroed with 16-byte stores in the same
 // sweep) together with the destination pixels the column pass will need much later; the
 // row pass reads it transposed, and the same LDS region then becomes the transpose buffer.
+#define DV_UNIT itx        // (names this unit's phase accessor in -DDV_PHASES variant builds, common.h)
 #include "itx_body.h"
 #include "capi.h"
 #include <string.h>
 
+DV_PHASE_DEFINE(DV_UNIT)
 namespace {
 
 template <int TX, typename pixel, typename coef>
@@ -41,14 +43,19 @@ __global__ __launch_bounds__(64) void itx_add_wide_kernel(const DevPlanes dst, c
     const int group = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x);
     const int block0 = group * BPW;
     if (block0 >= n) return;
+    DV_PHASE_BEGIN();
     // twin.tiled == 2: the picture lives in its twin only — the predicted pixels are read from there and the sums go back there
     // (`twin` carries the strides and sizes of the raster planes next to the twin's data pointers; a DevPlanes put together here from the
     // two kernel arguments would live in scratch memory)
     const bool twin_only = twin.tiled == 2;
-    if (twin_only) itx_body<TX, pixel, coef, false, true>(twin, tasks, n, cf, bitdepth_max, group, tmp_s, tile, true);
-    else itx_body<TX, pixel, coef, false, true>(dst, tasks, n, cf, bitdepth_max, group, tmp_s, tile);
+    uint32_t toff = 0;
+    int tpl = 0;
+    if (twin_only) itx_body<TX, pixel, coef, false, true>(twin, tasks, n, cf, bitdepth_max, group, tmp_s, tile, true, &toff, &tpl);
+    else itx_body<TX, pixel, coef, false, true>(dst, tasks, n, cf, bitdepth_max, group, tmp_s, tile, false, &toff, &tpl);
     dv::wave_sync();
-    tile_write_out<W, H, BPW, pixel>(tile, tasks + block0, dv::imin(BPW, n - block0), dst, twin, twin.data[0] != nullptr, !twin_only);
+    DV_PHASE(512 + TX * 16 + 6);        // (the body's own marks, then the wait for the sums in the tile)
+    tile_write_out<W, H, BPW, pixel>(tile, tasks + block0, dv::imin(BPW, n - block0), dst, twin, twin.data[0] != nullptr, !twin_only, toff, tpl);
+    DV_PHASE(512 + TX * 16 + 7);        // tile_write_out
 }
 
 // Every transform size in one launch, for the short lists of an intra wavefront step (a few hundred blocks of up to

@@ -85,12 +85,13 @@ constexpr int itx_lds_ints() {
 // PRED_LDS (fused prediction + residual kernels): the pixels the residual is added to come from pred_s (block `sub` of the
 // wave, W x H, row stride W) instead of the picture; the sum still goes to the picture.
 // COH (with PRED_LDS): the result goes back to the LDS tile instead of the picture; the caller (intra_flow.hip) writes it out.
+// task_off / task_plane (optional): this lane's copy of its block's dst_off / plane (lane b * LPB holds block b's), for tile_write_out.
 // tsrc (with COH, without PRED_LDS): `dst` holds the planes of the picture's tiled twin (8x8 tiles of 64 consecutive pixels, mc_body.h)
 // and the pixels the residual is added to are read from there — a frame whose pictures live in the twin only (DAV1D_HIP_TWIN_ONLY).
 template <int TX, typename pixel, typename coef, bool PRED_LDS = false, bool COH = false>
 __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItxTask *__restrict__ tasks,
                                          const int n, coef *__restrict__ cf, const int bitdepth_max, const int group, int *tmp_s,
-                                         const pixel *pred_s = nullptr, const bool tsrc = false)
+                                         const pixel *pred_s = nullptr, const bool tsrc = false, uint32_t *task_off = nullptr, int *task_plane = nullptr)
 {
     constexpr int W = tx_w(TX), H = tx_h(TX);
     constexpr int SW = cmin(W, 32), SH = cmin(H, 32);
@@ -106,6 +107,10 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
     // loads), then, once every lane holds its row in registers, the transposed intermediate
     static_assert(BPW * SH * TS == itx_lds_ints<TX>(), "LDS sizing");
 
+    // phase slots of this transform size (DV_PHASES builds): 0 record + slab and destination loads landed, 1 rows in registers, 2 row pass,
+    // 3 column pass + add + store, 4 whole body, 5 bodies counted
+    constexpr int PH = 512 + TX * 16 + (PRED_LDS ? 8 : 0);
+    DV_PHASE_BEGIN();
     const int lane = threadIdx.x & 63;       // the body belongs to one wave (recon.hip runs several side by side in a workgroup)
     const int sub = BPW == 1 ? 0 : lane / LPB, l = BPW == 1 ? lane : lane % LPB;
     const int ti = group * BPW + sub;
@@ -115,6 +120,9 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
     if (BPW == 1) t = tasks[__builtin_amdgcn_readfirstlane(live ? ti : 0)];   // one block per wave: record in SGPRs
     else t = tasks[live ? ti : 0];
 
+    // (tile_write_out wants the blocks' positions: the lanes that hold a block's record hand them over, no second trip to memory)
+    if (task_off) *task_off = t.dst_off;
+    if (task_plane) *task_plane = t.plane;
     const bool wht = TX == 0 && t.txtp == 16;
     const bool dconly = live && t.txtp == 0 && t.eob < 1;
     const bool full = live && !dconly;
@@ -195,12 +203,14 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
         }
     }
     dv::wave_sync();     // (every lane of the wave passes the two points above and this one: blocks of a wave differ in their paths)
+    DV_PHASE(PH + 0);
     if (row_lane) {
         const coef *slab = reinterpret_cast<const coef *>(tmp);
 #pragma unroll
         for (int x = 0; x < SW; x++) in[x] = slab[x * SH + l];
     }
     dv::wave_sync();     // every row is in registers: the region becomes the transpose buffer
+    DV_PHASE(PH + 1);
 
     int row_min, row_max, col_min, col_max;
     if (HBD) {
@@ -240,6 +250,7 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
         }
     }
     dv::wave_sync();
+    DV_PHASE(PH + 2);
 
     // ---- second pass: lane c = column c, H-point transform along y, add to dst.  COH: the sums go back to the LDS tile the
     // prediction came from (the caller writes it out with wide coherent stores); the tile shares its memory with tmp, so every
@@ -283,6 +294,8 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
             }
         }
     }
+    DV_PHASE(PH + 3);
+    DV_PHASE_WAVE(PH + 4);
 }
 
 
@@ -295,9 +308,13 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
 // 8x8 block one 128-byte line.  raster = false: the twin only (twin.tiled == 2 at the kernels: the picture lives in its twin,
 // DAV1D_HIP_TWIN_ONLY).
 
+// task_off / task_plane: what itx_body handed back (lane b * (64 / BPW) holds block b's record: the positions come from there by wave
+// shuffles — a fresh load of tasks[] here was a whole trip to memory at the end of every wave, 10 % of a paired 8x8 wave's cycles and a
+// quarter of a 4x4 residual wave's: profiles/r05/phases.jsonl); without them (task_plane < 0) the records are read from tasks[].
 template <int W, int H, int BPW, typename pixel>
 __device__ __forceinline__ void tile_write_out(const pixel *tile, const Dav1dHipItxTask *__restrict__ tasks, const int nb,
-                                               const DevPlanes &dst, const DevPlanes &twin, const bool has_twin, const bool raster = true)
+                                               const DevPlanes &dst, const DevPlanes &twin, const bool has_twin, const bool raster = true,
+                                               const uint32_t task_off = 0, const int task_plane = -1)
 {
     constexpr int CP = W < 8 ? W : 8;                   // pixels per piece: inside one row of one 8x8 tile
     constexpr int CPR = W / CP, PER_BLOCK = H * CPR, NCHK = BPW * PER_BLOCK;
@@ -307,7 +324,13 @@ __device__ __forceinline__ void tile_write_out(const pixel *tile, const Dav1dHip
     const int lane = threadIdx.x & 63;
     // lane b knows block b: plane and position, handed to the lanes that store the block's pieces by wave shuffles
     int bx = 0, by = 0, bpl = 0;
-    if (lane < nb) {
+    if (task_plane >= 0) {
+        // every lane of a block's group holds the block's record: lane b takes it from the first lane of group b
+        constexpr int LPB = 64 / BPW;
+        const uint32_t off = BPW == 1 ? task_off : (uint32_t) __shfl((int) task_off, (lane & (BPW - 1)) * LPB);
+        bpl = BPW == 1 ? task_plane : __shfl(task_plane, (lane & (BPW - 1)) * LPB);
+        if (lane < nb) dv::off_to_xy(off, bpl == 0 ? dst.stride[0] : bpl == 1 ? dst.stride[1] : dst.stride[2], bx, by);
+    } else if (lane < nb) {
         const Dav1dHipItxTask t = tasks[lane];
         bpl = t.plane;
         dv::off_to_xy(t.dst_off, bpl == 0 ? dst.stride[0] : bpl == 1 ? dst.stride[1] : dst.stride[2], bx, by);

@@ -28,8 +28,10 @@
 //      mid2, v_dot2 against the taps packed for the row's parity, round/clip, 8-byte store.
 // "No filter" in a direction is the unit tap with zero shift, bilinear is the taps
 // (16-m, m) with 4 instead of 6 bits of precision, so all variants share one code path.
+#define DV_UNIT mc        // (names this unit's phase accessor in -DDV_PHASES variant builds, common.h)
 #include "mc_body.h"
 
+DV_PHASE_DEFINE(DV_UNIT)
 namespace {
 
 // one tile shape per launch: workgroup b of the XCD-chunked order handles tiles [b * G, b * G + G)

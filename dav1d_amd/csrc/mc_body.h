@@ -83,6 +83,11 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
     constexpr int NLD = ((WR - 1) * NCH + LPT - 1) / LPT;   // window loads per lane
     constexpr bool NARROW = TW == 4;                        // window columns start at src_x - 2 instead of src_x - 4, taps 2 .. 5 only
     constexpr bool HBD = sizeof(pixel) == 2;
+    // phase slots of this tile shape (DV_PHASES builds): 0 records, 1 window gather (first reference), 2 horizontal, 3 vertical,
+    // 4 / 5 / 6 the same of the second reference, 7 combine + store, 8 whole body, 9 bodies counted
+    constexpr int PH = ((TW == 4 ? 0 : TW == 8 ? 1 : TW == 16 ? 2 : TW == 32 ? 3 : 4) * 3 + (TH == 4 ? 0 : TH == 8 ? 1 : 2)) * 16 + (TO_LDS ? 256 : 0);
+    DV_PHASE_BEGIN();
+    int dv_second_ = 0;
 
     int16_t *const win_s = reinterpret_cast<int16_t *>(smem);
     uint32_t *const mid_s = reinterpret_cast<uint32_t *>(win_s + G * WR * WS);
@@ -119,6 +124,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
 
     int16_t *const win = win_s + sub * WR * WS;
     uint32_t *const mid = mid_s + sub * NPR * TW;
+    DV_PHASE(PH + 0);
 
     const int ib = HBD ? 14 - (32 - __clz(bitdepth_max)) : 4;   // intermediate_bits
     const int bias = HBD ? 8192 : 0;                            // PREP_BIAS
@@ -281,6 +287,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
             }
         }
         dv::wave_sync();
+        DV_PHASE(PH + 1 + 3 * dv_second_);
 
         // ---- 2. horizontal pass: item = (row pair, strip) -> mid2[pair][4 cols] = (even row, odd row)
         if (act) {
@@ -384,6 +391,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
             }
         }
         dv::wave_sync();
+        DV_PHASE(PH + 2 + 3 * dv_second_);
 
         // ---- 3. vertical pass: item = (output row, strip), R items per lane
         if (act) {
@@ -414,6 +422,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
                 for (int x = 0; x < 4; x++) q[r][x] = (sum[x] >> sh2) - vb;
             }
         }
+        DV_PHASE(PH + 3 + 3 * dv_second_);
     };
 
     predict(t.r[0], live);
@@ -427,6 +436,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
                 for (int x = 0; x < 4; x++) acc0[r][x] = q[r][x];
         }
         dv::wave_sync();                        // the second gather overwrites win / mid
+        dv_second_ = 1;
         predict(t.r[1], compound);
     }
 
@@ -488,6 +498,8 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
             }
         }
     }
+    DV_PHASE(PH + 7);
+    DV_PHASE_WAVE(PH + 8);
 }
 
 

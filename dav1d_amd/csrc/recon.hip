@@ -10,14 +10,19 @@
 //
 // One kernel per square transform size (4x4 .. 64x64): a wave takes as many blocks as the transform body packs into a wave
 // (16, 8, 4, 2, 1) and predicts them tile group by tile group (tiles of <= 64x16, as in mc.hip).
+#define DV_UNIT recon        // (names this unit's phase accessor in -DDV_PHASES variant builds, common.h)
 #include "mc_body.h"
 #include "itx_body.h"
 #include <string.h>
 
+DV_PHASE_DEFINE(DV_UNIT)
 namespace {
 
 #ifndef RECON_WAVES
-#define RECON_WAVES 1
+#define RECON_WAVES 7      // (7 waves per SIMD asked of the register allocator: 72 VGPRs; measured on the 16x16 pairs 74.7 -> 70.1 us, profiles/r05)
+#endif
+#ifndef RECON_WAVES_8
+#define RECON_WAVES_8 7
 #endif
 
 constexpr int rc_log2(int v) { return v <= 1 ? 0 : 1 + rc_log2(v >> 1); }
@@ -39,7 +44,7 @@ template <int CLS> constexpr int recon_waves() {
 // WIDE: the reconstructed blocks leave through the LDS tile in row pieces of up to 16 bytes (tile_write_out, itx_body.h) instead of
 // two bytes per lane and row — and go to the picture's tiled twin as well when `twin` has planes (twin.data[0] != nullptr).
 template <int CLS, typename pixel, typename coef, bool COOP, bool TILED, bool WIDE>
-__global__ __launch_bounds__(COOP ? 64 * recon_waves<CLS>() : 64, COOP ? 1 : CLS == 1 ? 6 : RECON_WAVES)
+__global__ __launch_bounds__(COOP ? 64 * recon_waves<CLS>() : 64, COOP ? 1 : CLS == 1 ? RECON_WAVES_8 : RECON_WAVES)
 void recon_fused_kernel(const DevPlanes dst, const RefSet refs, const McTile *__restrict__ tiles,
                         const Dav1dHipItxTask *__restrict__ tasks, const int n_blocks,
                         int16_t *__restrict__ prep, coef *__restrict__ cf, const int bitdepth_max, const DevPlanes twin)
@@ -67,6 +72,9 @@ void recon_fused_kernel(const DevPlanes dst, const RefSet refs, const McTile *__
     const int group = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x);
     const int block0 = group * BPW;
     if (block0 >= n_blocks) return;
+    // phase slots of the paired kernel of this size (DV_PHASES builds): 0 every prediction of the wave's blocks, 1 the transform body,
+    // 2 tile_write_out, 3 whole wave, 4 waves counted (the bodies' own slots: mc_body.h 256 + ..., itx_body.h 512 + ... + 8)
+    DV_PHASE_BEGIN();
     const int nb = dv::imin(BPW, n_blocks - block0);
     const int tile0 = block0 * TPB, ntile = nb * TPB;
     if constexpr (NW == 1) {
@@ -83,13 +91,20 @@ void recon_fused_kernel(const DevPlanes dst, const RefSet refs, const McTile *__
         __syncthreads();
         if (wave) return;
     }
+    DV_PHASE(768 + CLS * 16 + 0);
     if constexpr (WIDE) {
-        itx_body<TX, pixel, coef, true, true>(dst, tasks, n_blocks, cf, bitdepth_max, group, smem_itx, pred);
+        uint32_t toff = 0;
+        int tpl = 0;
+        itx_body<TX, pixel, coef, true, true>(dst, tasks, n_blocks, cf, bitdepth_max, group, smem_itx, pred, false, &toff, &tpl);
         dv::wave_sync();
-        tile_write_out<W, W, BPW, pixel>(pred, tasks + block0, nb, dst, twin, twin.data[0] != nullptr, twin.tiled != 2);
+        DV_PHASE(768 + CLS * 16 + 1);
+        tile_write_out<W, W, BPW, pixel>(pred, tasks + block0, nb, dst, twin, twin.data[0] != nullptr, twin.tiled != 2, toff, tpl);
+        DV_PHASE(768 + CLS * 16 + 2);
     } else {
         itx_body<TX, pixel, coef, true>(dst, tasks, n_blocks, cf, bitdepth_max, group, smem_itx, pred);
+        DV_PHASE(768 + CLS * 16 + 1);
     }
+    DV_PHASE_WAVE(768 + CLS * 16 + 3);
 }
 
 template <int CLS, typename pixel, typename coef, bool TILED, bool WIDE>

@@ -26,11 +26,13 @@ def main():
     ap.add_argument("--sets", nargs="*", default=[""])
     ap.add_argument("--kernels", action="store_true")
     ap.add_argument("--no-raster", action="store_true")
+    ap.add_argument("--phases", action="store_true", help="with a -DDV_PHASES variant (--lib): shader-clock cycles per wave and phase of every kernel, from one event-bracketed run")
+    ap.add_argument("--lib", default=None, help="a variant build (tools/build_variant.py) instead of dav1d_amd/libdav1d_hip.so")
     a = ap.parse_args()
     import torch
     from dav1d_amd import api, synth
     stream = torch.cuda.current_stream()
-    ctx = api.Context(0, stream=stream.cuda_stream)
+    ctx = api.Context(0, stream=stream.cuda_stream, lib_path=a.lib)
     w, h, bpc = a.width, a.height, a.bpc
     frame = synth.make_frame(w, h, bpc, seed=0xDA71D002, mv_range_px=64, edge_frac=0.05, n_refs=3)
     rng = np.random.default_rng(1234)
@@ -89,6 +91,50 @@ def main():
             best = [min(x, y) for x, y in zip(best, ms)]
         return {NAMES[k]: round(best[k] * 1e3, 1) for k in range(40) if cnt[k]}
 
+    def phases(rl, tiled):
+        """cycles per wave by phase (common.h DV_PHASE): the bodies' slots and the kernels' own"""
+        import ctypes
+        raw = C.CDLL(a.lib)
+        bufs = {}
+        for unit in ("mc", "recon", "itx"):
+            getattr(raw, "dav1d_hip_debug_phases_" + unit)(None, 1)
+        fresh()
+        ms = (C.c_float * 40)()
+        cnt = (C.c_size_t * 40)()
+        rarr = (api.Picture * len(refs))(*[r.pic for r in refs])
+        fn = ctx.lib.dav1d_hip_recon_list_run_tiled_timed if tiled else ctx.lib.dav1d_hip_recon_list_run_timed
+        assert fn(ctx.h, rl.h, C.byref(dsts[0].pic), rarr, len(refs), prep.data_ptr(), None, arenas[0].data_ptr(), ms, cnt) == 0
+        ctx.sync()
+        out = {}
+        for unit in ("mc", "recon", "itx"):
+            buf = (ctypes.c_ulonglong * 1024)()
+            assert getattr(raw, "dav1d_hip_debug_phases_" + unit)(buf, 0) == 0
+            v = list(buf)
+            shapes = [(tw, th) for tw in (4, 8, 16, 32, 64) for th in (4, 8, 16)]
+            for to_lds in (0, 1):
+                for b, (tw, th) in enumerate(shapes):
+                    base_ = b * 16 + 256 * to_lds
+                    n = v[base_ + 9]
+                    if n:
+                        nm = ("pred_in_pair" if to_lds else "mc") + "_%dx%d" % (tw, th)
+                        out["%s.%s" % (unit, nm)] = dict(zip(("records", "gather", "horizontal", "vertical", "gather2", "horizontal2", "vertical2", "combine_store", "body"),
+                                                             [round(v[base_ + k] / n) for k in range(9)]), bodies=n)
+            for tx in range(19):
+                for pl in (0, 8):
+                    base_ = 512 + tx * 16 + pl
+                    n = v[base_ + 5]
+                    if n:
+                        d = dict(zip(("loads_landed", "rows_in_regs", "row_pass", "column_pass_store", "body"), [round(v[base_ + k] / n) for k in range(5)]), bodies=n)
+                        if not pl and v[base_ + 7]:
+                            d["tile_write_out"] = round(v[base_ + 7] / n)
+                        out["%s.itx%s_%d" % (unit, "_in_pair" if pl else "", tx)] = d
+            for cls in range(5):
+                base_ = 768 + cls * 16
+                n = v[base_ + 4]
+                if n:
+                    out["%s.pair_%dx%d" % (unit, 4 << cls, 4 << cls)] = dict(zip(("predictions", "transform", "tile_write_out", "wave"), [round(v[base_ + k] / n) for k in range(4)]), waves=n)
+        return out
+
     base = None
     if not a.no_raster:
         ctx.set_option("ref_twin", 0)
@@ -99,6 +145,8 @@ def main():
         o = {"layout": "raster", "ms_per_step": round(dt, 4)}
         if a.kernels:
             o["kernels_us"] = kernels(rl, False)
+        if a.phases:
+            o["cycles_per_wave"] = phases(rl, False)
         print(json.dumps(o), flush=True)
         rl.destroy()
         ctx.set_option("ref_twin", 1)
@@ -115,11 +163,13 @@ def main():
             for pl in range(3):
                 d.upload(pl, dst_host[pl])
         dt, pics = timed(rl, True)
-        o = {"layout": "tiled", "opts": st, "ms_per_step": round(dt, 4), "twin_only": int(dsts[0].pic.twin_ok)}
+        o = {"layout": "tiled", "lib": os.path.basename(a.lib) if a.lib else None, "opts": st, "ms_per_step": round(dt, 4), "twin_only": int(dsts[0].pic.twin_ok)}
         if base is not None:
             o["equals_raster"] = all(np.array_equal(base[pl], pics[pl]) for pl in range(3))
         if a.kernels:
             o["kernels_us"] = kernels(rl, True)
+        if a.phases:
+            o["cycles_per_wave"] = phases(rl, True)
         print(json.dumps(o), flush=True)
         rl.destroy()
 
