@@ -378,6 +378,7 @@ extern "C" int dav1d_hip_launch_resize(const DevPlanes *dst, const DevPlanes *sr
 extern "C" int dav1d_hip_launch_emu_edge(void *dst, ptrdiff_t dst_stride, const void *ref, ptrdiff_t ref_stride, int bw, int bh,
                                          int iw, int ih, int x, int y, int bpc, void *stream);
 
+extern "C" { extern long long dav1d_hip_live[8]; }      // objects alive by kind (dav1d_hip_live_objects)
 Dav1dHipContext *dav1d_hip_default_context(void);
 // a picture for a frame's own use from the context's pool (zeroed like a fresh one) / back to it
 extern "C" int dav1d_hip_picture_take(Dav1dHipContext *c, Dav1dHipPicture *pic, int w, int h, int layout, int bpc);

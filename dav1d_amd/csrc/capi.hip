@@ -18,6 +18,15 @@ extern "C" {
 
 // ------------------------------------------------------------------ context
 
+// Objects alive right now, by kind (0 contexts, 1 frames, 2 listers, 3 host pictures): what a caller that must not leak — dav1d's frame
+// contexts under error recovery, src/decode.c:3242-3251 — checks after it has closed everything (tests/test_stream_errors.py).
+long long dav1d_hip_live[8];
+int dav1d_hip_live_objects(long long out[4]) {
+    if (!out) return -EINVAL;
+    for (int i = 0; i < 4; i++) out[i] = __atomic_load_n(&dav1d_hip_live[i], __ATOMIC_RELAXED);
+    return 0;
+}
+
 int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     if (!out) return -EINVAL;
     *out = nullptr;
@@ -89,11 +98,13 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
         hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_untile, hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
     *out = c;
+    __atomic_fetch_add(&dav1d_hip_live[0], 1, __ATOMIC_RELAXED);
     return 0;
 }
 
 void dav1d_hip_close(Dav1dHipContext *c) {
     if (!c) return;
+    __atomic_fetch_sub(&dav1d_hip_live[0], 1, __ATOMIC_RELAXED);
     hipStreamSynchronize(c->stream);
     if (c->scratch) hipFree(c->scratch);
     for (int i = 0; i < Dav1dHipContext::N_SIDE; i++) { hipStreamSynchronize(c->side[i]); hipStreamDestroy(c->side[i]); hipEventDestroy(c->ev_join[i]); }
@@ -404,6 +415,7 @@ int dav1d_hip_host_picture_alloc(Dav1dHipContext *c, Dav1dHipHostPicture *hp, in
         hp->data[i] = hp->dev.p[i].data ? (uint8_t *) buf + ((const uint8_t *) hp->dev.p[i].data - (const uint8_t *) hp->dev.alloc) : nullptr;
     hp->stride[0] = hp->dev.p[0].stride;
     hp->stride[1] = hp->dev.p[1].stride;
+    __atomic_fetch_add(&dav1d_hip_live[3], 1, __ATOMIC_RELAXED);
     return 0;
 }
 
@@ -411,7 +423,7 @@ int dav1d_hip_host_picture_release(Dav1dHipContext *c, Dav1dHipHostPicture *hp) 
     if (!c || !hp) return -EINVAL;
     (void) hipStreamSynchronize(c->copy_stream);
     int rc = 0;
-    if (hp->alloc) rc = hip_rc(hipHostFree(hp->alloc));
+    if (hp->alloc) { rc = hip_rc(hipHostFree(hp->alloc)); __atomic_fetch_sub(&dav1d_hip_live[3], 1, __ATOMIC_RELAXED); }
     const int rc2 = dav1d_hip_picture_free(c, &hp->dev);
     memset(hp, 0, sizeof(*hp));
     return rc ? rc : rc2;

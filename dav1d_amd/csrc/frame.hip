@@ -375,6 +375,7 @@ int dav1d_hip_frame_begin(Dav1dHipContext *c, Dav1dHipFrame **out, const Dav1dHi
     for (int i = 0; i < n_refs; i++) if (refs[i].bpc != cur->bpc || refs[i].layout != cur->layout) return -EINVAL;
     Dav1dHipFrame *f = new (std::nothrow) Dav1dHipFrame();
     if (!f) return -ENOMEM;
+    __atomic_fetch_add(&dav1d_hip_live[1], 1, __ATOMIC_RELAXED);       // (every way out from here goes through dav1d_hip_frame_destroy or hands the frame over)
     f->c = c;
     f->cur = *cur;
     for (int i = 0; i < n_refs; i++) f->refs[i] = refs[i];
@@ -1686,6 +1687,7 @@ int dav1d_hip_frame_wait(Dav1dHipFrame *f, Dav1dHipPicture *filtered) {
 
 void dav1d_hip_frame_destroy(Dav1dHipFrame *f) {
     if (!f) return;
+    __atomic_fetch_sub(&dav1d_hip_live[1], 1, __ATOMIC_RELAXED);
     if (f->worker.joinable()) f->worker.join();
     (void) hipStreamSynchronize(f->c->stream);
     if (f->prepared) dav1d_hip_fg_grain_destroy(f->c, f->prepared);

@@ -1100,6 +1100,7 @@ int dav1d_hip_lister_create(Dav1dHipLister **out, const Dav1dHipFrameDesc *d, Da
     if (cur.bpc != d->bpc || cur.layout != d->layout || cur.p[0].w != d->w || cur.p[0].h != d->h) return -EINVAL;
     Dav1dHipLister *l = (Dav1dHipLister *) calloc(1, sizeof(*l));
     if (!l) return -ENOMEM;
+    __atomic_fetch_add(&dav1d_hip_live[2], 1, __ATOMIC_RELAXED);      /* dav1d_hip_live_objects: listers alive */
     l->d = *d;
     if (!d->is_inter) {
         /* key / intra-only frames have no references: whatever the caller's f->svc / refp still hold from the frame context's last
@@ -1153,6 +1154,7 @@ void dav1d_hip_lister_prof(void);
 #endif
 void dav1d_hip_lister_destroy(Dav1dHipLister *l) {
     if (!l) return;
+    __atomic_fetch_sub(&dav1d_hip_live[2], 1, __ATOMIC_RELAXED);
 #ifdef LISTER_PROF
     dav1d_hip_lister_prof();
     { extern void dav1d_hip_chunk_prof(void); dav1d_hip_chunk_prof(); }

@@ -12,6 +12,7 @@ typedef struct ListerGeo {
     const uint16_t *col_start_sb, *row_start_sb;
 } ListerGeo;
 void dav1d_hip_lister_geo(const Dav1dHipLister *l, ListerGeo *out);
+extern long long dav1d_hip_live[8];      /* csrc/capi.hip: objects alive by kind (dav1d_hip_live_objects) */
 /* frame.hip: filter tasks handed over as malloc'ed arrays the frame frees (no copy under the frame's lock) */
 int dav1d_hip_frame_submit_filter_owned(Dav1dHipFrame *f, Dav1dHipLfTask *lf, size_t n_lf, Dav1dHipCdefTask *cdef, size_t n_cdef,
                                         Dav1dHipLrTask *lr, size_t n_lr);

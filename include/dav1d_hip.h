@@ -132,6 +132,10 @@ typedef struct Dav1dHipPicture {
 
 /* Allocation with the reference's geometry (src/picture.c:46-78): dimensions padded
  * to 128, stride = aligned_w << hbd, +64 B when a multiple of 1024. */
+/* Objects of this library alive right now: out[0] contexts, [1] frames (dav1d_hip_frame_begin .. _destroy), [2] listers, [3] host
+ * pictures.  For callers that must prove they do not leak on their error paths (a frame context of dav1d that fails in pass 1 drops its
+ * frame and lister without ever ending the frame: reference src/decode.c:3242-3251). */
+DAV1D_HIP_API int dav1d_hip_live_objects(long long out[4]);
 DAV1D_HIP_API int dav1d_hip_picture_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic,
                                           int w, int h, int layout, int bpc);
 DAV1D_HIP_API int dav1d_hip_picture_free(Dav1dHipContext *c, Dav1dHipPicture *pic);

@@ -1,5 +1,5 @@
 /* The backend inside dav1d's own task loop.  TEST INFRASTRUCTURE ONLY: linked into oracle/_ref_hooked/libdav1d_hooked.so, the
- * reference build with src/thread_task.c patched at the hook points of INTEGRATION.md 2 (oracle/hooked/thread_task.patch).
+ * reference build with src/thread_task.c patched at the hook points of INTEGRATION.md 2 (patches/dav1d-1.5.4-hip.patch).
  *
  * What runs here is dav1d: dav1d_open() creates the context, its frame contexts (n_fc >= 3) and its worker threads
  * (dav1d_worker_task); every frame goes through the reference's dav1d_submit_frame(), dav1d_decode_frame_init(), the task
@@ -9,9 +9,9 @@
  * masks built by the reference's own dav1d_create_lf_mask_*, cdef indices, restoration units) is injected when a frame's
  * arrays exist (Dav1dHooks.after_init), the pass-1 tile tasks return at once.
  *   mode 0: pass 2 and the in-loop filters are the reference's own code on its worker threads — the peer.
- *   mode 1: the glue of INTEGRATION.md: Dav1dPicAllocator on dav1d_hip_host_picture_*, hip_frame_desc(), the pass-2 tile task
- *           calls dav1d_hip_lister_tile_sbrow, the filter tasks dav1d_hip_lister_filter_sbrow, the end of the frame
- *           dav1d_hip_frame_end on a thread of the harness, which then publishes the frame's rows (dav1d_hooked_frame_done).
+ *   mode 1: the PRODUCT's binding (dav1d_amd/host/dav1d_glue.c, linked in: Dav1dPicAllocator on dav1d_hip_host_picture_*, the frame /
+ *           filter descriptors, dav1d_hip_lister_tile_sbrow from the pass-2 tile task, dav1d_hip_lister_filter_sbrow from the filter
+ *           tasks, dav1d_hip_frame_end on its own threads, dav1d_hip_frame_done) behind the harness's own after_init / entropy hooks.
  * Frames form a chain: a key frame, then inter frames that each predict from the three frames before them. */
 #include "config.h"
 #include <dlfcn.h>
@@ -33,7 +33,8 @@
 #include "src/picture.h"
 #include "src/warpmv.h"
 #include "src/thread_task.h"
-#include "hooked/hooks.h"
+#include "dav1d_hooks.h"
+#include "dav1d_glue.h"
 #include "dav1d_hip.h"
 #include "dav1d_synth.h"
 
@@ -70,6 +71,8 @@ typedef struct HookedParams {
     int apply_grain;           /* stream mode: film grain on the output pictures — mode 0: Dav1dSettings.apply_grain (dav1d_apply_grain on the
                                   host); mode 1: apply_grain = 0 and the "application" applies it on the device (dav1d_hip_fg_apply on the picture
                                   dav1d returns, frame_hdr->film_grain.data), as GPU video outputs do */
+    int filters_off;           /* in-loop filters the "application" switches off, both modes: Dav1dSettings.inloop_filters = ALL & ~filters_off
+                                  (bit 0 deblock, 1 CDEF, 2 restoration; include/dav1d/dav1d.h:61-69) */
 } HookedParams;
 
 /* pass 1's output of one frame, as dav1d_decode_frame_init() sizes the arrays */
@@ -84,70 +87,20 @@ typedef struct Store { int n; StoredFrame *fr; } Store;
 /* the entry points of include/dav1d_hip.h, resolved from the library the caller names (libdav1d_hip.so, or the SIMT-emulated
  * build of the same sources on a machine without a GPU) */
 typedef struct Hip {
-    void *dl, *synth_dl;
+    void *synth_dl;
     /* chain mode: the generator of synthetic pass-1 output (tests/synth/libdav1d_synth.so, test infrastructure like this file) */
     int (*synth_frame)(const Dav1dHipFrameDesc *, const Dav1dSynthParams *, void *, size_t, size_t, uint8_t *, size_t);
-    int (*open)(Dav1dHipContext **, int, void *);
-    void (*close)(Dav1dHipContext *);
-    int (*sync)(Dav1dHipContext *);
-    int (*malloc_)(Dav1dHipContext *, void **, size_t);
-    int (*free_)(Dav1dHipContext *, void *);
-    int (*upload)(Dav1dHipContext *, void *, const void *, size_t);
-    int (*memset_)(Dav1dHipContext *, void *, int, size_t);
-    int (*host_picture_alloc)(Dav1dHipContext *, Dav1dHipHostPicture *, int, int, int, int);
-    int (*host_picture_release)(Dav1dHipContext *, Dav1dHipHostPicture *);
-    int (*host_picture_fetch)(Dav1dHipContext *, const Dav1dHipHostPicture *, const Dav1dHipPicture *, int, int);
-    int (*host_picture_wait)(Dav1dHipContext *);
-    int (*frame_begin)(Dav1dHipContext *, Dav1dHipFrame **, const Dav1dHipPicture *, const Dav1dHipPicture *, int);
-    int (*frame_set_refs)(Dav1dHipFrame *, const Dav1dHipPicture *, int);
-    int (*frame_set_filters)(Dav1dHipFrame *, const uint8_t *, ptrdiff_t, const uint8_t *, const uint8_t *, int, const Dav1dHipFilmGrainData *, int);
-    int (*frame_end)(Dav1dHipFrame *, void *, int16_t *, uint8_t *, Dav1dHipPicture *, const Dav1dHipPicture *);
-    void (*frame_destroy)(Dav1dHipFrame *);
-    int (*lister_create)(Dav1dHipLister **, const Dav1dHipFrameDesc *, Dav1dHipFrame *);
-    int (*lister_tile_sbrow)(Dav1dHipLister *, int, int, int);
-    int (*lister_filter_sbrow)(Dav1dHipLister *, const Dav1dHipFilterDesc *, int);
-    size_t (*lister_prep_elems)(const Dav1dHipLister *);
-    size_t (*lister_mask_bytes)(const Dav1dHipLister *);
-    const uint8_t *(*lister_const_masks)(size_t *);
-    void (*lister_destroy)(Dav1dHipLister *);
-    int (*frame_submit_intra_step)(Dav1dHipFrame *, size_t, const Dav1dHipIpredTask *, size_t, const Dav1dHipItxTask *, size_t, uint8_t *);
-    int (*frame_set_super_res)(Dav1dHipFrame *, int);
-    int (*fg_apply)(Dav1dHipContext *, const Dav1dHipPicture *, const Dav1dHipPicture *, const Dav1dHipFilmGrainData *, int);
-    int (*picture_alloc)(Dav1dHipContext *, Dav1dHipPicture *, int, int, int, int);
-    int (*picture_free)(Dav1dHipContext *, Dav1dHipPicture *);
-    int (*plane_download)(Dav1dHipContext *, const Dav1dHipPicture *, int, void *, ptrdiff_t, int);
-    int (*frame_set_progress_callback)(Dav1dHipFrame *, void (*)(void *, int, const Dav1dHipPicture *), void *);
 } Hip;
 
-/* what the allocator hangs on a Dav1dPicture in mode 1 */
-typedef struct HookedPic {
-    Dav1dHipHostPicture hp;
-    Dav1dHipFrame *frame;        /* the frame that produced the picture: owns `ref` when that is not hp.dev */
-    Dav1dHipPicture ref;         /* where the final pixels are: what later frames predict from */
-    atomic_int final;            /* the frame that produced the picture has ended (well or badly): `ref` is settled */
-} HookedPic;
+/* The binding itself — Dav1dPicAllocator on dav1d_hip_host_picture_*, the descriptors, the tile / filter / frame-complete hooks, the three
+ * stage threads, progress and error handling — is PRODUCT code: dav1d_amd/host/dav1d_glue.c, linked in here.  This file keeps what a
+ * test needs around it: injection of pass-1 output, the stream runner, output comparison, statistics. */
 
-/* per frame context */
+/* per frame context: what the harness keeps (the glue has its own state) */
 typedef struct FcState {
-    Dav1dHipFrameDesc desc;
-    Dav1dHipFilterDesc fd;
-    Dav1dHipFrame *frame;
-    Dav1dHipLister *lister;
-    atomic_int *filter_listed;   /* [sby]: the filter tasks of the row are listed */
-    int sbh_cap;
-    void *coef, *lvl, *prep, *mask;
-    size_t coef_cap, lvl_cap, prep_cap, mask_cap;
-    int err;
     /* inject == 2, mode 1: the frame context's own arrays while the stored ones stand in for them */
     void *own_b, *own_cbi, *own_cf;
     int swapped;
-    /* the frame's way through the three stage threads: 0 idle, 1 tasks through, 2 uploaded (or failed), 3 ended */
-    Dav1dFrameContext *q_f;
-    int q_state, q_rc;
-    uint64_t q_arrival;
-    Dav1dHipPicture q_filtered;
-    void *pal_idx;               /* device copy of f->frame_thread.pal_idx (palette frames) */
-    size_t pal_idx_cap;
 } FcState;
 
 typedef struct OutPic { int w, h, layout, bpc, frame_offset, grain; uint8_t *plane[3]; uint64_t hash[3]; double t; } OutPic;
@@ -166,23 +119,13 @@ enum { HIST_FRAMES_KEY, HIST_FRAMES_INTER, HIST_FRAMES_INTRA_ONLY, HIST_FRAMES_S
 typedef struct Hooked {
     HookedParams p;
     Hip hip;
-    Dav1dHipContext *ctx;
+    Dav1dHipGlue *glue;                   /* mode 1: the binding (dav1d_amd/host/dav1d_glue.c) */
     Dav1dContext *c;
     unsigned n_fc;
     Dav1dRef *seq_ref;
     FcState *fcs;
     Store *store;
-    /* Frames whose last task is through go through three threads of the harness (FcState.q_state): coefficients, palette indices and
-     * level cache to the device (any order, a context and stream of its own), dav1d_hip_frame_end (oldest first among the frames
-     * whose references have ended: where a reference's final pixels are is known when that frame ends), the copy of the picture
-     * to the host planes + dav1d_hooked_frame_done. */
-    Dav1dHipContext *ctx_up, *ctx_out;
-    pthread_t up_thread, gpu_thread, out_thread;
-    pthread_mutex_t q_mtx;
-    pthread_cond_t q_cond;
-    uint64_t q_arrivals;
-    double *q_done_t;                     /* chain mode, [frame number]: when dav1d_hooked_frame_done returned */
-    int q_stop;
+    double *q_done_t;                     /* chain mode, [frame number]: when dav1d_hip_frame_done returned */
     /* stream mode */
     struct OutPic *out_pics;              /* what dav1d_get_picture handed out, in that order */
     int n_out_pics, cap_out_pics;
@@ -190,14 +133,9 @@ typedef struct Hooked {
     const size_t *tu_size;
     int n_tu;
     int n_errors;                         /* pictures dav1d reported an error for */
-    atomic_int n_row_publications;
     struct TileError { int tu; size_t off; int overread; } tile_err[64];
     int n_tile_err;
     uint64_t hist[HIST_N];
-    /* pictures between uses (dav1d's default allocator pools them too, src/picture.c:46-82 + src/mem.c) */
-    struct HookedPic *free_pics[32];
-    int n_free_pics, closing;
-    pthread_mutex_t pic_mtx;
     /* outputs */
     uint8_t **out_plane;                  /* [frame * 3 + plane]: tight rows */
     int n_out;
@@ -232,90 +170,6 @@ static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &
 static void stat_add(Hooked *const h, const int i, const double t0) {
     const double dt = now_s() - t0;
     pthread_mutex_lock(&h->stat_mtx); h->stat[i] += dt; pthread_mutex_unlock(&h->stat_mtx);
-}
-
-/* ------------------------------------------------------------------------------------------------ INTEGRATION.md 2, verbatim */
-static void hip_frame_desc(Dav1dHipFrameDesc *d, const Dav1dFrameContext *f) {
-    memset(d, 0, sizeof(*d));
-    d->w = f->cur.p.w; d->h = f->cur.p.h; d->layout = f->cur.p.layout; d->bpc = f->cur.p.bpc;
-    d->sb128 = f->seq_hdr->sb128; d->intra_edge_filter = f->seq_hdr->intra_edge_filter;
-    d->is_inter = IS_INTER_OR_SWITCH(f->frame_hdr);
-    d->n_tile_cols = f->frame_hdr->tiling.cols; d->n_tile_rows = f->frame_hdr->tiling.rows;
-    memcpy(d->col_start_sb, f->frame_hdr->tiling.col_start_sb, sizeof(d->col_start_sb));
-    memcpy(d->row_start_sb, f->frame_hdr->tiling.row_start_sb, sizeof(d->row_start_sb));
-    d->b4_stride = f->b4_stride;
-    d->b = (const Dav1dHipAv1Block *) f->frame_thread.b;           /* same 32-byte layout, pinned by tests/test_lister.py */
-    d->cbi = (const int16_t *) f->frame_thread.cbi;
-    d->tile_start_off = f->frame_thread.tile_start_off;
-    d->pal = f->frame_thread.pal;
-    memcpy(d->svc, f->svc, sizeof(d->svc));
-    for (int i = 0; i < 7; i++) { d->ref_w[i] = f->refp[i].p.p.w; d->ref_h[i] = f->refp[i].p.p.h; }
-    memcpy(d->gmv, f->frame_hdr->gmv, sizeof(d->gmv));             /* Dav1dHipWarpParams == Dav1dWarpedMotionParams */
-    memcpy(d->gmv_warp_allowed, f->gmv_warp_allowed, sizeof(d->gmv_warp_allowed));
-    memcpy(d->jnt_weights, f->jnt_weights, sizeof(d->jnt_weights));
-    d->cf_align64 = ARCH_X86_64;                                   /* the cf cursor realignment of src/decode.c:2209-2218 */
-    memcpy(d->lossless, f->frame_hdr->segmentation.lossless, sizeof(d->lossless));   /* mask builder: src/decode.c:1889-1893 */
-}
-
-static void hip_filter_desc(Dav1dHipFilterDesc *fd, const Dav1dFrameContext *f) {
-    memset(fd, 0, sizeof(*fd));
-    fd->lf_level_y[0] = f->frame_hdr->loopfilter.level_y[0]; fd->lf_level_y[1] = f->frame_hdr->loopfilter.level_y[1];
-    fd->lf_level_u = f->frame_hdr->loopfilter.level_u; fd->lf_level_v = f->frame_hdr->loopfilter.level_v;
-    fd->lf_mask = (const Dav1dHipAv1Filter *) f->lf.mask;
-    fd->tx_lpf_right_edge[0] = f->lf.tx_lpf_right_edge[0]; fd->tx_lpf_right_edge[1] = f->lf.tx_lpf_right_edge[1];
-    fd->a_tx_lpf_y = f->a[0].tx_lpf_y; fd->a_tx_lpf_uv = f->a[0].tx_lpf_uv; fd->a_stride = sizeof(BlockContext);
-    fd->cdef_enabled = f->seq_hdr->cdef; fd->cdef_damping = f->frame_hdr->cdef.damping;
-    for (int i = 0; i < 8; i++) { fd->cdef_y_strength[i] = f->frame_hdr->cdef.y_strength[i]; fd->cdef_uv_strength[i] = f->frame_hdr->cdef.uv_strength[i]; }
-    for (int i = 0; i < 3; i++) fd->lr_type[i] = f->frame_hdr->restoration.type[i];
-    fd->lr_unit_size[0] = f->frame_hdr->restoration.unit_size[0]; fd->lr_unit_size[1] = f->frame_hdr->restoration.unit_size[1];
-    fd->lr_mask = (const Dav1dHipAv1Restoration *) f->lf.lr_mask;
-    fd->sr_w = f->frame_hdr->width[0] != f->frame_hdr->width[1] ? f->sr_cur.p.p.w : 0;      /* restoration works on the upscaled frame */
-}
-
-static int hip_alloc_picture(Dav1dPicture *const p, void *const cookie) {
-    Hooked *const h = cookie;
-    const double t0 = now_s();
-    HookedPic *hp = NULL;
-    pthread_mutex_lock(&h->pic_mtx);
-    for (int i = 0; i < h->n_free_pics; i++) {
-        const Dav1dHipPicture *const d = &h->free_pics[i]->hp.dev;
-        if (d->p[0].w == p->p.w && d->p[0].h == p->p.h && d->layout == (int) p->p.layout && d->bpc == p->p.bpc) {
-            hp = h->free_pics[i];
-            h->free_pics[i] = h->free_pics[--h->n_free_pics];
-            break;
-        }
-    }
-    pthread_mutex_unlock(&h->pic_mtx);
-    int rc = 0;
-    if (hp) rc = h->hip.memset_(h->ctx, hp->hp.dev.alloc, 0, hp->hp.dev.alloc_size);       /* as a fresh one: zero, padding included */
-    if (!hp) {
-        hp = calloc(1, sizeof(*hp));
-        if (!hp) return DAV1D_ERR(ENOMEM);
-        rc = h->hip.host_picture_alloc(h->ctx, &hp->hp, p->p.w, p->p.h, p->p.layout, p->p.bpc);   /* layouts share their values */
-    }
-    stat_add(h, 0, t0);
-    if (rc) { free(hp); return rc; }
-    for (int i = 0; i < 3; i++) p->data[i] = hp->hp.data[i];
-    p->stride[0] = hp->hp.stride[0]; p->stride[1] = hp->hp.stride[1];
-    p->allocator_data = hp;
-    hp->ref = hp->hp.dev;
-    atomic_store(&hp->final, 0);
-    return 0;
-}
-static void hip_release_picture(Dav1dPicture *const p, void *const cookie) {
-    Hooked *const h = cookie;
-    HookedPic *const hp = p->allocator_data;
-    const double t0 = now_s();
-    if (hp->frame) h->hip.frame_destroy(hp->frame);
-    hp->frame = NULL;
-    hp->ref = hp->hp.dev;
-    hp->ref.twin_ok = hp->hp.dev.twin_ok = 0;
-    pthread_mutex_lock(&h->pic_mtx);
-    if (!h->closing && h->n_free_pics < 32) { h->free_pics[h->n_free_pics++] = hp; pthread_mutex_unlock(&h->pic_mtx); stat_add(h, 8, t0); return; }
-    pthread_mutex_unlock(&h->pic_mtx);
-    h->hip.host_picture_release(h->ctx, &hp->hp);
-    free(hp);
-    stat_add(h, 8, t0);
 }
 
 /* ------------------------------------------------------------------------------------------------ pass-1 stand-in: filter inputs
@@ -494,31 +348,6 @@ static int build_filter_inputs(Dav1dFrameContext *const f, const unsigned seed) 
 /* ------------------------------------------------------------------------------------------------ the hooks */
 static FcState *state_of(const Dav1dFrameContext *const f) { return &g_h->fcs[f - f->c->fc]; }
 
-static void note_error(Dav1dFrameContext *const f, const int rc) {
-    if (rc) { atomic_store(&f->task_thread.error, -1); g_h->failed = 1; fprintf(stderr, "hooked: dav1d_hip_lister_filter_sbrow = %d\n", rc); }
-}
-
-static void once_per_row(const Dav1dFrameContext *const f, const int sby) {
-    FcState *const s = state_of(f);
-    if (atomic_exchange(&s->filter_listed[sby], 1)) return;
-    const double t0 = now_s();
-    note_error((Dav1dFrameContext *) f, g_h->hip.lister_filter_sbrow(s->lister, &s->fd, sby));     /* instead of filter_sbrow* */
-    stat_add(g_h, 3, t0);
-}
-static void hk_filter_f(Dav1dFrameContext *const f, const int sby) { once_per_row(f, sby); }
-static void hk_filter_t(Dav1dTaskContext *const tc, const int sby) { once_per_row(tc->f, sby); }
-
-static int grow(Hooked *const h, void **const p, size_t *const cap, const size_t bytes) {
-    if (*cap >= bytes) return 0;
-    if (*p) h->hip.free_(h->ctx, *p);
-    *p = NULL; *cap = 0;
-    size_t want = 1 << 16;
-    while (want < bytes) want <<= 1;
-    const int rc = h->hip.malloc_(h->ctx, p, want);
-    if (!rc) *cap = want;
-    return rc;
-}
-
 static int hk_after_init_(Dav1dFrameContext *const f);
 static int hk_after_init(Dav1dFrameContext *const f) {
     const double t0 = now_s();
@@ -540,16 +369,11 @@ static int hk_after_init_(Dav1dFrameContext *const f) {
     const size_t re_bytes = (size_t) f->lf.re_sz * 32;
     const size_t a_bytes = sizeof(*f->a) * (size_t) f->sb128w * fh->tiling.rows;           /* the pass-1 half */
     int rc = 0;
-    if (h->p.mode == 1 && (s->lister || s->frame)) {        /* a frame that failed after this point left them behind */
-        if (s->lister) h->hip.lister_destroy(s->lister);
-        if (s->frame) h->hip.frame_destroy(s->frame);
-        s->lister = NULL; s->frame = NULL;
-    }
+    Dav1dHipFrameDesc desc;             /* what the generator below is told about the frame (the glue makes its own for the lister) */
     StoredFrame *const sf = !h->p.stream && h->store && fh->frame_offset < h->store->n ? &h->store->fr[fh->frame_offset] : NULL;
     if (h->p.stream) {
         /* ---- nothing to inject: dav1d's own pass 1 fills the arrays from the tile data (dav1d_decode_tile_sbrow in hk_entropy) */
-        if (h->p.mode != 1) return 0;
-        hip_frame_desc(&s->desc, f);
+        return h->p.mode == 1 ? dav1d_hip_glue_frame_init(f) : 0;
     } else if (h->p.inject == 2) {
         for (int j = 0; j < n_tiles; j++) f->ts[j].lflvl = f->lf.lvl;       /* no delta_lf here: the frame's level table, src/decode.c:1018-1021 */
         /* ---- pass 1's output from the store: the three large arrays stand in for the frame context's own where nothing writes them
@@ -569,17 +393,16 @@ static int hk_after_init_(Dav1dFrameContext *const f) {
         if (sf->lr_mask_bytes) memcpy(f->lf.lr_mask, sf->lr_mask, sf->lr_mask_bytes);
         memcpy(f->lf.tx_lpf_right_edge[0], sf->re0, sf->re_bytes); memcpy(f->lf.tx_lpf_right_edge[1], sf->re1, sf->re_bytes);
         memcpy(f->a, sf->a, sf->a_bytes);
-        hip_frame_desc(&s->desc, f);
     } else {
         for (int j = 0; j < n_tiles; j++) f->ts[j].lflvl = f->lf.lvl;
         /* ---- pass 1's output, generated: block records, cbi, coefficients, palettes */
-        hip_frame_desc(&s->desc, f);
+        dav1d_hip_glue_frame_desc(&desc, f);
         memset(f->frame_thread.cf, 0, cf_bytes);
         memset(f->frame_thread.b, 0, b_bytes);
         Dav1dSynthParams sp = h->p.synth;
         sp.seed += 7919u * (uint64_t) fh->frame_offset;
         sp.cf_align64 = ARCH_X86_64;
-        rc = h->hip.synth_frame(&s->desc, &sp, f->frame_thread.cf, cf_bytes, cbi_entries, f->frame_thread.pal_idx, pal_idx_bytes);
+        rc = h->hip.synth_frame(&desc, &sp, f->frame_thread.cf, cf_bytes, cbi_entries, f->frame_thread.pal_idx, pal_idx_bytes);
         if (rc) return DAV1D_ERR(EINVAL);
         /* ---- ... and what pass 1 builds for the in-loop filters */
         if (build_filter_inputs(f, (unsigned) (sp.seed & 0xffffff) + 3)) return DAV1D_ERR(EINVAL);
@@ -614,32 +437,8 @@ static int hk_after_init_(Dav1dFrameContext *const f) {
                     ts->lowest_pixel[r][n][1] = need == INT_MIN ? INT_MIN : need >> (f->cur.p.layout == DAV1D_PIXEL_LAYOUT_I420);
                 }
         }
-    if (h->p.mode != 1) return 0;
-    /* ---- frame + lister, the filter stages pointed at the filter lister */
-    HookedPic *const cur = f->cur.allocator_data;        /* the picture of the CODED size (f->sr_cur's is the upscaled one under super-resolution) */
-    Dav1dHipPicture refs[7];
-    const int n_refs = IS_INTER_OR_SWITCH(fh) ? 7 : 0;
-    for (int i = 0; i < n_refs; i++) refs[i] = ((HookedPic *) f->refp[i].p.allocator_data)->hp.dev;     /* geometry; the final ones at the end */
-    rc = h->hip.frame_begin(h->ctx, &s->frame, &cur->hp.dev, refs, n_refs);
-    if (h->p.pack) s->desc.cf = f->frame_thread.cf;
-    if (!rc) rc = h->hip.lister_create(&s->lister, &s->desc, s->frame);
-    if (!rc && fh->width[0] != fh->width[1]) rc = h->hip.frame_set_super_res(s->frame, f->sr_cur.p.p.w);
-    if (rc) return DAV1D_ERR(ENOMEM);
-    hip_filter_desc(&s->fd, f);
-    if (f->sbh > s->sbh_cap) {
-        free(s->filter_listed);
-        s->filter_listed = calloc((size_t) f->sbh, sizeof(*s->filter_listed));
-        if (!s->filter_listed) return DAV1D_ERR(ENOMEM);
-        s->sbh_cap = f->sbh;
-    }
-    for (int i = 0; i < f->sbh; i++) atomic_store(&s->filter_listed[i], 0);
-    f->bd_fn.filter_sbrow_deblock_cols = hk_filter_f;
-    f->bd_fn.filter_sbrow_deblock_rows = hk_filter_f;
-    f->bd_fn.filter_sbrow_cdef = hk_filter_t;
-    f->bd_fn.filter_sbrow_resize = hk_filter_f;
-    f->bd_fn.filter_sbrow_lr = hk_filter_f;
-    s->err = 0;
-    return 0;
+    /* ---- mode 1: the binding takes it from here (frame + lister, the filter stages pointed at the filter lister) */
+    return h->p.mode == 1 ? dav1d_hip_glue_frame_init(f) : 0;
 }
 
 /* Pass 1.  Chain mode: the hand-off arrays were injected, nothing to do.  Stream mode: dav1d's own entropy decoding of the tile's
@@ -662,34 +461,11 @@ static int hk_entropy(Dav1dTaskContext *const t) {
                 break;
             }
         pthread_mutex_unlock(&h->stat_mtx);
-    } else if (h->p.mode == 1 && h->p.free_listing && IS_INTER_OR_SWITCH(f->frame_hdr)) {
-        const int sby = (t->by - ts->tiling.row_start) >> f->sb_shift;
-        for (int n = 0; n < 7; n++) ts->lowest_pixel[sby][n][0] = ts->lowest_pixel[sby][n][1] = INT_MIN;
+    } else if (h->p.mode == 1) {
+        dav1d_hip_glue_after_entropy(t);
     }
+    (void) f;
     return rc;
-}
-
-static int hk_recon(Dav1dTaskContext *const t) {
-    /* instead of dav1d_decode_tile_sbrow(tc) */
-    const Dav1dFrameContext *const f = t->f;
-    const double t0 = now_s();
-    const int rc = g_h->hip.lister_tile_sbrow(state_of(f)->lister, t->ts->tiling.row, t->ts->tiling.col, t->by >> f->sb_shift);
-    stat_add(g_h, 2, t0);
-    if (rc) { g_h->failed = 1; fprintf(stderr, "hooked: dav1d_hip_lister_tile_sbrow(tile %d, %d, sby %d) = %d\n", t->ts->tiling.row, t->ts->tiling.col, t->by >> f->sb_shift, rc); }
-    return rc ? 1 : 0;
-}
-
-/* the frame's tasks are through (a worker thread, the scheduler's lock held): its turn on the stage threads comes */
-static void hk_frame_complete(Dav1dFrameContext *const f) {
-    Hooked *const h = g_h;
-    FcState *const s = state_of(f);
-    pthread_mutex_lock(&h->q_mtx);
-    s->q_f = f;
-    s->q_rc = 0;
-    s->q_arrival = ++h->q_arrivals;
-    s->q_state = 1;
-    pthread_cond_broadcast(&h->q_cond);
-    pthread_mutex_unlock(&h->q_mtx);
 }
 
 /* ---- which tools the frame's blocks use: the reference's own block walk (decode_sb with pass == 2) over pass 1's output with the two
@@ -834,151 +610,28 @@ static void count_frame(Hooked *const h, Dav1dFrameContext *const f) {
     pthread_mutex_unlock(&h->stat_mtx);
 }
 
-/* stage 1 (any order): what the frame's launches read from the host side */
-static int stage_upload(Hooked *const h, Dav1dFrameContext *const f) {
+/* ---- what the harness wants to know while the binding works (Dav1dHipGlueOptions observers) */
+static void ob_stat(void *const cookie, const int what, const double t0) { stat_add(cookie, what, t0); }
+static void ob_frame_listed(void *const cookie, Dav1dFrameContext *const f) { Hooked *const h = cookie; if (h->p.stream) count_frame(h, f); }
+static void ob_frame_end_seconds(void *const cookie, Dav1dFrameContext *const f, const double sec) {
+    Hooked *const h = cookie;
+    if (!h->p.stream && f->frame_hdr->frame_offset < 64) h->frame_end_s[f->frame_hdr->frame_offset] = sec;
+}
+static void ob_before_frame_done(void *const cookie, Dav1dFrameContext *const f, const int rc) {
+    (void) cookie; (void) rc;
     FcState *const s = state_of(f);
-    const Hip *const hip = &h->hip;
-    const size_t cf_bytes = (size_t) f->frame_thread.cf_sz * 128 * 128 / 2;
-    const size_t lvl_bytes = sizeof(*f->lf.level) * (size_t) f->sb128w * f->sb128h * 32 * 32;
-    const size_t pal_idx_bytes = f->frame_hdr->allow_screen_content_tools ? (size_t) f->frame_thread.pal_idx_sz * 128 * 128 / 8 : 0;
-    size_t n_const = 0;
-    const uint8_t *const blob = hip->lister_const_masks(&n_const);
-    const double t0 = now_s();
-    int rc = h->p.pack ? 0 : grow(h, &s->coef, &s->coef_cap, cf_bytes + 64);
-    if (!rc) rc = grow(h, &s->lvl, &s->lvl_cap, lvl_bytes + 64);
-    if (!rc) rc = grow(h, &s->prep, &s->prep_cap, hip->lister_prep_elems(s->lister) * 2 + 4096);
-    const size_t mask_cap_before = s->mask_cap;
-    if (!rc) rc = grow(h, &s->mask, &s->mask_cap, hip->lister_mask_bytes(s->lister) + 4096);
-    if (!rc && s->mask_cap != mask_cap_before) rc = hip->upload(h->ctx_up, s->mask, blob, n_const);
-    if (!rc && !h->p.pack) {
-        rc = hip->upload(h->ctx_up, s->coef, f->frame_thread.cf, cf_bytes);
-        /* the arena has been consumed: the next frame's pass 1 finds it zero, as after the reference's inverse transforms
-         * (src/itx_tmpl.c:60,108).  (The packing lister does that itself, block by block.) */
-        if (h->p.stream) memset(f->frame_thread.cf, 0, cf_bytes);
-    }
-    if (!rc) rc = hip->upload(h->ctx_up, s->lvl, f->lf.level, lvl_bytes);
-    if (!rc && pal_idx_bytes && f->frame_thread.pal_idx) {
-        /* palette indices (pal_pred's `idx`, src/recon_tmpl.c:1207-1224): the arena PAL tasks point into */
-        rc = grow(h, &s->pal_idx, &s->pal_idx_cap, pal_idx_bytes + 64);
-        if (!rc) rc = hip->upload(h->ctx_up, s->pal_idx, f->frame_thread.pal_idx, pal_idx_bytes);
-        if (!rc) rc = hip->frame_submit_intra_step(s->frame, 0, NULL, 0, NULL, 0, s->pal_idx);
-    }
-    stat_add(h, 5, t0);
-    return rc;
-}
-
-/* have the frames this one predicts from ended?  (-1: one of them failed) */
-static int refs_final(const Dav1dFrameContext *const f) {
-    if (!IS_INTER_OR_SWITCH(f->frame_hdr)) return 1;
-    int all = 1;
-    for (int i = 0; i < 7; i++) {
-        if (atomic_load(&f->refp[i].progress[1]) == FRAME_ERROR) return -1;
-        all &= atomic_load(&((HookedPic *) f->refp[i].p.allocator_data)->final);
-    }
-    return all;
-}
-
-/* INTEGRATION.md 2, progress: rows of the frame's picture have become final on the device */
-static void rows_final(void *const cookie, const int rows, const Dav1dHipPicture *const pic) {
-    (void) pic;
-    Dav1dFrameContext *const f = cookie;
-    g_h->n_row_publications++;
-    dav1d_hooked_rows_done(f, (unsigned) rows);
-}
-
-/* stage 2: INTEGRATION.md 2, "when the last task of the frame is in" */
-static int stage_end(Hooked *const h, Dav1dFrameContext *const f, Dav1dHipPicture *const filtered) {
-    FcState *const s = state_of(f);
-    HookedPic *const out = f->sr_cur.p.allocator_data;     /* the picture dav1d hands on: reference and output */
-    const Hip *const hip = &h->hip;
-    int rc = refs_final(f) < 0 ? -EIO : 0;
-    const double t0 = now_s();
-    if (h->p.stream) count_frame(h, f);
-    if (!rc && IS_INTER_OR_SWITCH(f->frame_hdr)) {
-        Dav1dHipPicture refs[7];
-        for (int i = 0; i < 7; i++) refs[i] = ((HookedPic *) f->refp[i].p.allocator_data)->ref;        /* where those frames' final pixels are */
-        rc = hip->frame_set_refs(s->frame, refs, 7);
-    }
-    if (!rc) rc = hip->frame_set_filters(s->frame, s->lvl, f->b4_stride, f->lf.lim_lut.e, f->lf.lim_lut.i,
-                                         f->frame_hdr->cdef.damping + f->cur.p.bpc - 8, NULL, 0);
-    memset(filtered, 0, sizeof(*filtered));
-    if (!rc && h->p.row_progress) rc = hip->frame_set_progress_callback(s->frame, rows_final, f);
-    if (!rc) rc = hip->frame_end(s->frame, h->p.pack ? NULL : s->coef, s->prep, s->mask, filtered, NULL);
-    if (!h->p.stream && f->frame_hdr->frame_offset < 64) h->frame_end_s[f->frame_hdr->frame_offset] = now_s() - t0;
-    stat_add(h, 6, t0);
-    hip->lister_destroy(s->lister);
-    s->lister = NULL;
-    if (!rc) {
-        out->ref = *filtered;                     /* later frames predict from this; the frame object lives as long as the picture */
-        out->frame = s->frame;
-    } else {
-        hip->frame_destroy(s->frame);
-    }
-    s->frame = NULL;
-    return rc;
-}
-
-/* stage 3: the picture to the host planes the application sees, then the frame is done as far as dav1d is concerned */
-static void stage_out(Hooked *const h, Dav1dFrameContext *const f, int rc, const Dav1dHipPicture *const filtered) {
-    FcState *const s = state_of(f);
-    HookedPic *const out = f->sr_cur.p.allocator_data;
-    const double t0 = now_s();
-    if (!rc) rc = h->hip.host_picture_fetch(h->ctx, &out->hp, filtered, 0, f->sr_cur.p.p.h);
-    if (!rc) rc = h->hip.host_picture_wait(h->ctx);
-    stat_add(h, 7, t0);
     if (s->swapped) {          /* the frame context gets its own arrays back before dav1d sees the frame again */
         f->frame_thread.b = s->own_b; f->frame_thread.cbi = s->own_cbi; f->frame_thread.cf = s->own_cf;
         s->swapped = 0;
     }
-    if (rc) { h->failed = 1; fprintf(stderr, "hooked: frame (order hint %d, type %d, %dx%d) failed in the backend: %d\n", f->frame_hdr->frame_offset, f->frame_hdr->frame_type, f->cur.p.w, f->cur.p.h, rc); }
-    const int k = f->frame_hdr->frame_offset;
-    const int chain = !h->p.stream;
-    dav1d_hooked_frame_done(f, rc ? DAV1D_ERR(EIO) : 0);
-    if (chain && k < h->p.n_frames) h->q_done_t[k] = now_s();
 }
-
-static void *stage_thread(void *const arg) {
-    Hooked *const h = ((void **) arg)[0];
-    const int stage = (int) (intptr_t) ((void **) arg)[1];
-    for (;;) {
-        const double t_wait = now_s();
-        FcState *s = NULL;
-        pthread_mutex_lock(&h->q_mtx);
-        for (;;) {
-            if (h->q_stop) break;
-            s = NULL;
-            for (unsigned i = 0; i < h->n_fc; i++) {
-                FcState *const c = &h->fcs[i];
-                if (c->q_state != stage || (s && s->q_arrival < c->q_arrival)) continue;
-                if (stage == 2 && !refs_final(c->q_f)) continue;        /* its references have not all ended yet */
-                s = c;
-            }
-            if (s) break;
-            pthread_cond_wait(&h->q_cond, &h->q_mtx);
-        }
-        if (h->q_stop) { pthread_mutex_unlock(&h->q_mtx); break; }
-        Dav1dFrameContext *const f = s->q_f;
-        pthread_mutex_unlock(&h->q_mtx);
-        if (stage == 2) stat_add(h, 4, t_wait);
-        if (stage == 1) s->q_rc = stage_upload(h, f);
-        else if (stage == 2) {
-            if (!s->q_rc) s->q_rc = stage_end(h, f, &s->q_filtered);
-            else { h->hip.lister_destroy(s->lister); s->lister = NULL; h->hip.frame_destroy(s->frame); s->frame = NULL; }
-        }
-        pthread_mutex_lock(&h->q_mtx);
-        if (stage == 2) atomic_store(&((HookedPic *) f->sr_cur.p.allocator_data)->final, 1);      /* well or badly: nobody waits for it any longer */
-        s->q_state = stage < 3 ? stage + 1 : 0;        /* (stage 3 first, its work after: dav1d may reuse the frame context from there on) */
-        const int rc = s->q_rc;
-        const Dav1dHipPicture filtered = s->q_filtered;
-        pthread_cond_broadcast(&h->q_cond);
-        pthread_mutex_unlock(&h->q_mtx);
-        if (stage == 3) stage_out(h, f, rc, &filtered);
-    }
-    return NULL;
+static void ob_after_frame_done(void *const cookie, const int k) {
+    Hooked *const h = cookie;
+    if (!h->p.stream && k >= 0 && k < h->p.n_frames) h->q_done_t[k] = now_s();
 }
 
 static const Dav1dHooks hooks_cpu = { hk_after_init, hk_entropy, NULL, NULL };
-static const Dav1dHooks hooks_hip = { hk_after_init, hk_entropy, hk_recon, hk_frame_complete };
+static const Dav1dHooks hooks_hip = { hk_after_init, hk_entropy, dav1d_hip_glue_recon_tile_sbrow, dav1d_hip_glue_frame_complete };
 
 /* ------------------------------------------------------------------------------------------------ headers */
 static void fill_seq(Dav1dSequenceHeader *const seq, const HookedParams *const p) {
@@ -1082,34 +735,29 @@ static void keep_stream_picture(Hooked *const h, const Dav1dPicture *const pic) 
     const int ss_hor = pic->p.layout != DAV1D_PIXEL_LAYOUT_I444, ss_ver = pic->p.layout == DAV1D_PIXEL_LAYOUT_I420;
     const int grain_here = h->p.mode == 1 && h->p.apply_grain && pic_has_grain(pic);
     o->grain = h->p.apply_grain && pic_has_grain(pic);
-    Dav1dHipPicture g;
-    memset(&g, 0, sizeof(g));
     int rc = 0;
-    if (grain_here) {
-        const HookedPic *const hp = pic->allocator_data;
-        rc = h->hip.picture_alloc(h->ctx_out, &g, pic->p.w, pic->p.h, pic->p.layout, pic->p.bpc);
-        if (!rc) rc = h->hip.fg_apply(h->ctx_out, &g, &hp->ref, (const Dav1dHipFilmGrainData *) &pic->frame_hdr->film_grain.data,
-                                      pic->seq_hdr->mtrx == DAV1D_MC_IDENTITY);
-    }
-    for (int pl = 0; pl < n_pl && !rc; pl++) {
+    uint8_t *planes[3] = { NULL, NULL, NULL };
+    for (int pl = 0; pl < n_pl; pl++) {
         const int w = pl ? (pic->p.w + ss_hor) >> ss_hor : pic->p.w, hh = pl ? (pic->p.h + ss_ver) >> ss_ver : pic->p.h;
-        uint8_t *const dst = malloc((size_t) w * hh * bps);
-        if (!dst) { rc = -ENOMEM; break; }
-        if (grain_here) rc = h->hip.plane_download(h->ctx_out, &g, pl, dst, (ptrdiff_t) w * bps, 0);
-        else for (int y = 0; y < hh; y++) memcpy(dst + (size_t) y * w * bps, (const uint8_t *) pic->data[pl] + (ptrdiff_t) y * pic->stride[!!pl], (size_t) w * bps);
+        planes[pl] = malloc((size_t) w * hh * bps);
+        if (!planes[pl]) rc = -ENOMEM;
+    }
+    if (!rc && grain_here) rc = dav1d_hip_glue_output_with_grain(h->glue, pic, planes);
+    for (int pl = 0; pl < n_pl; pl++) {
+        const int w = pl ? (pic->p.w + ss_hor) >> ss_hor : pic->p.w, hh = pl ? (pic->p.h + ss_ver) >> ss_ver : pic->p.h;
+        uint8_t *const dst = planes[pl];
+        if (rc || !dst) { free(dst); continue; }
+        if (!grain_here) for (int y = 0; y < hh; y++) memcpy(dst + (size_t) y * w * bps, (const uint8_t *) pic->data[pl] + (ptrdiff_t) y * pic->stride[!!pl], (size_t) w * bps);
         o->hash[pl] = hash_bytes(0xDA71Dull + (uint64_t) pl, dst, (size_t) w * hh * bps);
         if (h->p.keep_output == 2) free(dst);           /* digests only (long chains of large pictures) */
         else o->plane[pl] = dst;
     }
     o->t = now_s();
-    if (grain_here) { if (!rc) rc = h->hip.sync(h->ctx_out); h->hip.picture_free(h->ctx_out, &g); }
     if (rc) h->failed = 1;
     h->n_out_pics++;
 }
 
 /* ------------------------------------------------------------------------------------------------ entry points */
-#define SYM(field, name) do { *(void **) &h->hip.field = dlsym(h->hip.dl, name); if (!h->hip.field) goto fail; } while (0)
-
 void dav1d_hooked_close(void *handle);
 
 void *dav1d_hooked_store_create(const int n_frames) {
@@ -1139,19 +787,7 @@ void *dav1d_hooked_open(const HookedParams *const p, const char *const hip_lib, 
     h->p = *p;
     h->store = store;
     if (p->inject && !store) { free(h); return NULL; }
-    pthread_mutex_init(&h->q_mtx, NULL);
     pthread_mutex_init(&h->stat_mtx, NULL);
-    pthread_cond_init(&h->q_cond, NULL);
-    h->hip.dl = dlopen(hip_lib, RTLD_NOW | RTLD_LOCAL);
-    if (!h->hip.dl) goto fail;
-    SYM(open, "dav1d_hip_open"); SYM(close, "dav1d_hip_close"); SYM(sync, "dav1d_hip_sync"); SYM(malloc_, "dav1d_hip_malloc"); SYM(free_, "dav1d_hip_free");
-    SYM(upload, "dav1d_hip_upload"); SYM(memset_, "dav1d_hip_memset"); SYM(host_picture_alloc, "dav1d_hip_host_picture_alloc"); SYM(host_picture_release, "dav1d_hip_host_picture_release");
-    SYM(host_picture_fetch, "dav1d_hip_host_picture_fetch"); SYM(host_picture_wait, "dav1d_hip_host_picture_wait");
-    SYM(frame_begin, "dav1d_hip_frame_begin"); SYM(frame_set_refs, "dav1d_hip_frame_set_refs"); SYM(frame_set_filters, "dav1d_hip_frame_set_filters");
-    SYM(frame_end, "dav1d_hip_frame_end"); SYM(frame_destroy, "dav1d_hip_frame_destroy");
-    SYM(lister_create, "dav1d_hip_lister_create"); SYM(lister_tile_sbrow, "dav1d_hip_lister_tile_sbrow"); SYM(lister_filter_sbrow, "dav1d_hip_lister_filter_sbrow");
-    SYM(lister_prep_elems, "dav1d_hip_lister_prep_elems"); SYM(lister_mask_bytes, "dav1d_hip_lister_mask_bytes");
-    SYM(lister_const_masks, "dav1d_hip_lister_const_masks"); SYM(lister_destroy, "dav1d_hip_lister_destroy");
     if (!p->stream) {
         /* ../../tests/synth/libdav1d_synth.so, seen from where this library lies (oracle/_ref_hooked/) */
         Dl_info me;
@@ -1166,20 +802,21 @@ void *dav1d_hooked_open(const HookedParams *const p, const char *const hip_lib, 
         *(void **) &h->hip.synth_frame = dlsym(h->hip.synth_dl, "dav1d_synth_frame");
         if (!h->hip.synth_frame) goto fail;
     }
-    SYM(frame_submit_intra_step, "dav1d_hip_frame_submit_intra_step"); SYM(frame_set_super_res, "dav1d_hip_frame_set_super_res");
-    SYM(fg_apply, "dav1d_hip_fg_apply"); SYM(picture_alloc, "dav1d_hip_picture_alloc"); SYM(picture_free, "dav1d_hip_picture_free");
-    SYM(plane_download, "dav1d_hip_plane_download"); SYM(frame_set_progress_callback, "dav1d_hip_frame_set_progress_callback");
-    pthread_mutex_init(&h->pic_mtx, NULL);
-    if (p->mode == 1 && (h->hip.open(&h->ctx, p->device, NULL) || h->hip.open(&h->ctx_up, p->device, NULL) || h->hip.open(&h->ctx_out, p->device, NULL))) goto fail;
     Dav1dSettings s;
     dav1d_default_settings(&s);
     s.n_threads = p->n_threads;
     s.max_frame_delay = p->frame_delay;
     s.apply_grain = p->stream && p->mode == 0 && p->apply_grain;
+    s.inloop_filters = DAV1D_INLOOPFILTER_ALL & ~p->filters_off;
     if (p->mode == 1) {
-        s.allocator.cookie = h;
-        s.allocator.alloc_picture_callback = hip_alloc_picture;
-        s.allocator.release_picture_callback = hip_release_picture;
+        Dav1dHipGlueOptions o;
+        memset(&o, 0, sizeof(o));
+        o.hip_lib = hip_lib; o.device = p->device; o.pack = p->pack; o.free_listing = p->free_listing; o.row_progress = p->row_progress;
+        o.keep_cf = !p->stream;                      /* chain mode: the generator / the store owns the arena */
+        o.cookie = h; o.stat = ob_stat; o.frame_listed = ob_frame_listed; o.frame_end_seconds = ob_frame_end_seconds;
+        o.before_frame_done = ob_before_frame_done; o.after_frame_done = ob_after_frame_done;
+        if (dav1d_hip_glue_create(&h->glue, &o)) goto fail;
+        dav1d_hip_glue_settings(h->glue, &s);        /* the allocator; apply_grain off: the grain goes on on the device */
     }
     if (dav1d_open(&h->c, &s)) goto fail;
     if (h->c->n_fc < 2) goto fail;                       /* the two-pass hand-off only exists with frame threading */
@@ -1205,7 +842,7 @@ double dav1d_hooked_tail_seconds(void *const handle, const int from) {
     if (from < 0 || from >= h->p.n_frames - 1 || !h->q_done_t[from] || !h->q_done_t[h->p.n_frames - 1]) return 0.;
     return h->q_done_t[h->p.n_frames - 1] - h->q_done_t[from];
 }
-int dav1d_hooked_row_publications(void *const handle) { return handle ? atomic_load(&((Hooked *) handle)->n_row_publications) : 0; }
+int dav1d_hooked_row_publications(void *const handle) { return handle ? dav1d_hip_glue_row_publications(((Hooked *) handle)->glue) : 0; }
 int dav1d_hooked_n_fc(void *const handle) { return handle ? (int) ((Hooked *) handle)->n_fc : 0; }
 
 /* the whole chain: returns 0 and the wall-clock seconds from the first dav1d_submit_frame to the last picture out */
@@ -1215,17 +852,13 @@ int dav1d_hooked_run(void *const handle, double *const seconds) {
     const HookedParams *const p = &h->p;
     const int n_tiles = p->n_tile_cols * p->n_tile_rows;
     g_h = h;
-    dav1d_hooks = p->mode == 1 ? &hooks_hip : &hooks_cpu;
+    dav1d_hooks = &hooks_cpu;
     if (p->stream) return -1;
-    h->q_stop = 0; h->n_out = 0; h->failed = 0;
-    for (unsigned i = 0; i < h->n_fc; i++) h->fcs[i].q_state = 0;
+    h->n_out = 0; h->failed = 0;
     memset(h->stat, 0, sizeof(h->stat));
-    int have_thread = 0;
-    void *targ[3][2] = { { h, (void *) (intptr_t) 1 }, { h, (void *) (intptr_t) 2 }, { h, (void *) (intptr_t) 3 } };
     if (p->mode == 1) {
-        if (pthread_create(&h->up_thread, NULL, stage_thread, targ[0]) || pthread_create(&h->gpu_thread, NULL, stage_thread, targ[1]) ||
-            pthread_create(&h->out_thread, NULL, stage_thread, targ[2])) return -1;
-        have_thread = 1;
+        if (dav1d_hip_glue_attach(h->glue, c)) return -1;           /* per-frame-context state, the three stage threads */
+        dav1d_hooks = &hooks_hip;                                    /* (the harness's after_init / entropy hooks in front of the glue's) */
     }
     int rc = 0;
     const double t0 = now_s();
@@ -1261,16 +894,9 @@ int dav1d_hooked_run(void *const handle, double *const seconds) {
         dav1d_picture_unref(&pic);
     }
     h->seconds = now_s() - t0;
-    if (have_thread) {
-        pthread_mutex_lock(&h->q_mtx);
-        h->q_stop = 1;
-        pthread_cond_broadcast(&h->q_cond);
-        pthread_mutex_unlock(&h->q_mtx);
-        pthread_join(h->up_thread, NULL);
-        pthread_join(h->gpu_thread, NULL);
-        pthread_join(h->out_thread, NULL);
-    }
+    if (p->mode == 1) dav1d_hip_glue_detach(h->glue);
     dav1d_hooks = NULL;
+    if (p->mode == 1 && dav1d_hip_glue_backend_failures(h->glue)) h->failed = 1;
     if (seconds) *seconds = h->seconds;
     if (!rc && (h->failed || h->n_out != p->n_frames)) rc = -2;
     return rc;
@@ -1288,20 +914,16 @@ int dav1d_hooked_stream_run(void *const handle, const uint8_t *const *const tu, 
     const HookedParams *const p = &h->p;
     if (!p->stream) return -1;
     g_h = h;
-    dav1d_hooks = p->mode == 1 ? &hooks_hip : &hooks_cpu;
-    h->q_stop = 0; h->failed = 0; h->n_errors = 0; h->n_tile_err = 0;
+    dav1d_hooks = &hooks_cpu;
+    h->failed = 0; h->n_errors = 0; h->n_tile_err = 0;
     h->tu = tu; h->tu_size = tu_size; h->n_tu = n_tu;
-    for (unsigned i = 0; i < h->n_fc; i++) h->fcs[i].q_state = 0;
     memset(h->stat, 0, sizeof(h->stat));
     memset(h->hist, 0, sizeof(h->hist));
     for (int i = 0; i < h->n_out_pics; i++) for (int pl = 0; pl < 3; pl++) free(h->out_pics[i].plane[pl]);
     h->n_out_pics = 0;
-    int have_thread = 0;
-    void *targ[3][2] = { { h, (void *) (intptr_t) 1 }, { h, (void *) (intptr_t) 2 }, { h, (void *) (intptr_t) 3 } };
     if (p->mode == 1) {
-        if (pthread_create(&h->up_thread, NULL, stage_thread, targ[0]) || pthread_create(&h->gpu_thread, NULL, stage_thread, targ[1]) ||
-            pthread_create(&h->out_thread, NULL, stage_thread, targ[2])) return -1;
-        have_thread = 1;
+        if (dav1d_hip_glue_attach(h->glue, c)) return -1;           /* per-frame-context state, the three stage threads */
+        dav1d_hooks = &hooks_hip;                                    /* (the harness's after_init / entropy hooks in front of the glue's) */
     }
     int rc = 0;
     const double t0 = now_s();
@@ -1329,16 +951,9 @@ int dav1d_hooked_stream_run(void *const handle, const uint8_t *const *const tu, 
         dav1d_picture_unref(&pic);
     }
     h->seconds = now_s() - t0;
-    if (have_thread) {
-        pthread_mutex_lock(&h->q_mtx);
-        h->q_stop = 1;
-        pthread_cond_broadcast(&h->q_cond);
-        pthread_mutex_unlock(&h->q_mtx);
-        pthread_join(h->up_thread, NULL);
-        pthread_join(h->gpu_thread, NULL);
-        pthread_join(h->out_thread, NULL);
-    }
+    if (p->mode == 1) dav1d_hip_glue_detach(h->glue);
     dav1d_hooks = NULL;
+    if (p->mode == 1 && dav1d_hip_glue_backend_failures(h->glue)) h->failed = 1;
     h->tu = NULL; h->tu_size = NULL; h->n_tu = 0;
     if (seconds) *seconds = h->seconds;
     if (!rc && h->failed) rc = -2;           /* the BACKEND failed (a frame dav1d itself rejects is not that: n_errors) */
@@ -1383,40 +998,17 @@ const void *dav1d_hooked_plane(void *const handle, const int frame, const int pl
 void dav1d_hooked_close(void *const handle) {
     Hooked *const h = handle;
     if (!h) return;
-    h->closing = 1;
     if (h->c) {
         /* the references of the last frames still hold pictures: dav1d_close releases them through the allocator */
         dav1d_close(&h->c);
     }
-    for (int i = 0; i < h->n_free_pics; i++) { h->hip.host_picture_release(h->ctx, &h->free_pics[i]->hp); free(h->free_pics[i]); }
-    h->n_free_pics = 0;
-    if (h->fcs) {
-        for (unsigned i = 0; i < h->n_fc; i++) {
-            FcState *const s = &h->fcs[i];
-            if (h->ctx) {
-                if (s->coef) h->hip.free_(h->ctx, s->coef);
-                if (s->lvl) h->hip.free_(h->ctx, s->lvl);
-                if (s->prep) h->hip.free_(h->ctx, s->prep);
-                if (s->mask) h->hip.free_(h->ctx, s->mask);
-                if (s->pal_idx) h->hip.free_(h->ctx, s->pal_idx);
-                if (s->lister) h->hip.lister_destroy(s->lister);
-                if (s->frame) h->hip.frame_destroy(s->frame);
-            }
-            free(s->filter_listed);
-        }
-        free(h->fcs);
-    }
+    free(h->fcs);
     if (h->seq_ref) dav1d_ref_dec(&h->seq_ref);
-    if (h->ctx_out) h->hip.close(h->ctx_out);
-    if (h->ctx_up) h->hip.close(h->ctx_up);
-    if (h->ctx) h->hip.close(h->ctx);
+    dav1d_hip_glue_destroy(h->glue);
     if (h->out_plane) { for (int i = 0; i < h->p.n_frames * 3; i++) free(h->out_plane[i]); free(h->out_plane); }
     for (int i = 0; i < h->n_out_pics; i++) for (int pl = 0; pl < 3; pl++) free(h->out_pics[i].plane[pl]);
     free(h->out_pics);
     free(h->q_done_t);
     if (h->hip.synth_dl) dlclose(h->hip.synth_dl);
-    if (h->hip.dl) dlclose(h->hip.dl);
-    pthread_mutex_destroy(&h->q_mtx);
-    pthread_cond_destroy(&h->q_cond);
     free(h);
 }

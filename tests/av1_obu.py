@@ -889,7 +889,8 @@ class StreamWriter:
         frame_obu_hdr = bytes([OBU_FRAME << 3 | 2]) + leb128(len(payload))
         base = len(pre) + len(frame_obu_hdr) + len(hdr)
         data = bytearray(pre + frame_obu_hdr + payload)
-        self.units.append(dict(data=data, tiles=[(base + o, s) for o, s in tiles], frame=fr))
+        self.units.append(dict(data=data, tiles=[(base + o, s) for o, s in tiles], frame=fr, pre_len=len(pre), obu_hdr_len=len(frame_obu_hdr),
+                               size_bytes=fr.n_bytes))
         # the slots the frame goes to
         for i in range(8):
             if fr.refresh >> i & 1:
@@ -935,6 +936,27 @@ class StreamWriter:
         off, size = u["tiles"][tile]
         from_byte = max(0, min(from_byte, size - 1))
         u["data"][off + from_byte:off + size] = self.rng.bytes(size - from_byte)
+
+
+    def truncate(self, unit, tile, new_size):
+        """Damage on purpose (the error-path tests): the tile's payload is cut to `new_size` bytes and the framing follows — its
+        tile_size_minus_1 field (every tile but the frame's last carries one) and the frame OBU's size — so that dav1d's parser accepts the
+        unit and the symbol decoder of that tile runs out of data (msac.cnt <= -15, reference src/decode.c:2743: the tile task fails)."""
+        u = self.units[unit]
+        off, size = u["tiles"][tile]
+        new_size = max(1, min(new_size, size))
+        data, nb = u["data"], u["size_bytes"]
+        last = tile == len(u["tiles"]) - 1
+        if not last:
+            data[off - nb:off] = (new_size - 1).to_bytes(nb, "little")
+        cut = size - new_size
+        body_start = u["pre_len"] + u["obu_hdr_len"]
+        payload = bytes(data[body_start:off + new_size]) + bytes(data[off + size:])
+        hdr = bytes([OBU_FRAME << 3 | 2]) + leb128(len(payload))
+        shift = len(hdr) - u["obu_hdr_len"]
+        u["data"] = bytearray(bytes(data[:u["pre_len"]]) + hdr + payload)
+        u["obu_hdr_len"] = len(hdr)
+        u["tiles"] = [(o + shift - (cut if i > tile else 0), new_size if i == tile else s) for i, (o, s) in enumerate(u["tiles"])]
 
 
 def make_stream(w, h, layout, bpc, n_frames, seed, sb128=True, knobs=None, **seq_kw):

@@ -21,7 +21,7 @@ class HookedParams(C.Structure):
                 ("cdef_enabled", C.c_int), ("cdef_damping", C.c_int), ("cdef_n_bits", C.c_int), ("cdef_y_strength", C.c_int * 8),
                 ("cdef_uv_strength", C.c_int * 8), ("lr_type", C.c_int * 3), ("lr_unit_size", C.c_int * 2),
                 ("mode", C.c_int), ("free_listing", C.c_int), ("device", C.c_int), ("keep_output", C.c_int), ("inject", C.c_int), ("pack", C.c_int),
-                ("synth", synth_lib.SynthParams), ("stream", C.c_int), ("row_progress", C.c_int), ("apply_grain", C.c_int)]
+                ("synth", synth_lib.SynthParams), ("stream", C.c_int), ("row_progress", C.c_int), ("apply_grain", C.c_int), ("filters_off", C.c_int)]
 
 
 def lib():

@@ -33,7 +33,8 @@ def lib():
     return l
 
 
-def decode(units, mode, hip_lib_path, threads=4, frame_delay=3, free_listing=1, pack=True, apply_grain=True, keep=True, row_progress=0):
+def decode(units, mode, hip_lib_path, threads=4, frame_delay=3, free_listing=1, pack=True, apply_grain=True, keep=True, row_progress=0,
+           filters_off=0, allow_backend_failure=False):
     """units: list of bytes-like temporal units.  Returns dict(pictures=[(info, [planes])], errors=n, tile_errors=[(tu, offset, overread)],
     hist={...} (mode 1), seconds, digests=[(d0, d1, d2)], times=[...]).  keep = 2: digests of the planes only (no pixel copies kept)."""
     l = lib()
@@ -43,6 +44,7 @@ def decode(units, mode, hip_lib_path, threads=4, frame_delay=3, free_listing=1, 
     p.mode, p.free_listing, p.device, p.keep_output = mode, free_listing, 0, int(keep)
     p.pack = int(bool(pack) and mode == 1)
     p.stream, p.apply_grain, p.row_progress = 1, int(apply_grain), int(row_progress)
+    p.filters_off = int(filters_off)         # Dav1dSettings.inloop_filters = ALL & ~filters_off, both modes
     h = l.dav1d_hooked_open(C.byref(p), hip_lib_path.encode(), None)
     assert h, "dav1d_hooked_open failed"
     try:
@@ -51,7 +53,7 @@ def decode(units, mode, hip_lib_path, threads=4, frame_delay=3, free_listing=1, 
         sizes = (C.c_size_t * len(bufs))(*[len(b) for b in bufs])
         sec = C.c_double()
         rc = l.dav1d_hooked_stream_run(h, ptrs, sizes, len(bufs), C.byref(sec))
-        assert rc == 0, "dav1d_hooked_stream_run: %d (the backend failed)" % rc
+        assert rc == 0 or allow_backend_failure, "dav1d_hooked_stream_run: %d (the backend failed)" % rc
         n = l.dav1d_hooked_stream_pictures(h)
         pics, digests, times = [], [], []
         for i in range(n):
@@ -84,7 +86,7 @@ def decode(units, mode, hip_lib_path, threads=4, frame_delay=3, free_listing=1, 
         l.dav1d_hooked_stats(h, st)
         stats = dict(zip(("picture_alloc", "after_init", "listing", "filter_listing", "gpu_thread_idle", "uploads", "frame_end", "fetch", "picture_release"),
                          [round(v * 1e3 / max(1, n), 2) for v in st[:9]]))
-        return dict(row_publications=l.dav1d_hooked_row_publications(h), stats=stats, pictures=pics, errors=l.dav1d_hooked_stream_errors(h), tile_errors=[(te[3 * i], te[3 * i + 1], te[3 * i + 2]) for i in range(nte)],
+        return dict(rc=rc, row_publications=l.dav1d_hooked_row_publications(h), stats=stats, pictures=pics, errors=l.dav1d_hooked_stream_errors(h), tile_errors=[(te[3 * i], te[3 * i + 1], te[3 * i + 2]) for i in range(nte)],
                     hist=dict(zip(HIST, [int(v) for v in hist[:nh]])), seconds=sec.value, digests=digests, times=times)
     finally:
         l.dav1d_hooked_close(h)

@@ -1,6 +1,6 @@
 """The backend inside dav1d's own task loop: dav1d_open / dav1d_submit_frame / dav1d_worker_task threads /
 check_tile dependencies / dav1d_get_picture are the reference's, src/thread_task.c carries the hook points of INTEGRATION.md 2
-(oracle/hooked/thread_task.patch), and a chain of frames — a key frame, then inter frames predicting from the three frames before
+(patches/dav1d-1.5.4-hip.patch), and a chain of frames — a key frame, then inter frames predicting from the three frames before
 them — is decoded twice from the same injected pass-1 output: by the reference's own pass 2 + in-loop filters on its worker
 threads, and by the glue of INTEGRATION.md (allocator on dav1d_hip_host_picture_*, dav1d_hip_lister_tile_sbrow /
 _filter_sbrow from the tile and filter tasks, dav1d_hip_frame_end when the frame's tasks are through).  Every output picture must be
