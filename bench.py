@@ -1201,7 +1201,7 @@ def run_job(a, rank, local, world):
         # pass 2 (dav1d_decode_tile_sbrow on a real Dav1dFrameContext, oracle/ref_frame.c) when the reference build is there
         e2e_leg = key_leg = full_route = e2e_packed = key_packed = None
         if world == 1 and not a.no_e2e:
-            from dav1d_amd import e2e
+            import e2e
 
             def e2e_check(ho, planes, ref_pics, is_inter=True):
                 import lister_util as lu
@@ -1286,7 +1286,7 @@ def run_job(a, rank, local, world):
         # listed top to bottom, so 4 tiles are 4 listing threads), next to the many-tile runs above
         e2e_c2 = full_route_c2 = None
         if world == 1 and not a.no_e2e:
-            from dav1d_amd import e2e
+            import e2e
             e2e_c2 = e2e.run(ctx, w, h, bpc, frames=4, threads=4, tile_cols=4, tile_rows=1, check=None if a.no_check else e2e_check)
             if not a.no_check:
                 import lister_util as lu
@@ -1300,7 +1300,7 @@ def run_job(a, rank, local, world):
         # coefficients that exist instead of the dense arena.  ms_per_frame = sustained over the frames after the warm-up.
         sustained = None
         if world == 1 and not a.no_e2e:
-            from dav1d_amd import e2e
+            import e2e
             sustained = {}
             try:
                 # paced: as many listing threads as the container's CPU quota sustains (e2e.host_threads), 24 frames; burst: 64 threads over 16
@@ -1345,7 +1345,7 @@ def run_job(a, rank, local, world):
                     task_loop = {"status": "skipped: oracle/_ref_hooked is not built (needs /root/reference at build time)"}
                 else:
                     ctx.sync()
-                    task_loop = hk.task_loop_rate(_l.DEFAULT_PATH, w, h, bpc, tiles=(4, 1), threads=min(64, os.cpu_count() or 8), frame_delay=8, frames=24, check_frames=3)
+                    task_loop = hk.task_loop_rate(_l.DEFAULT_PATH, w, h, bpc, tiles=(4, 1), threads=min(64, os.cpu_count() or 8), frame_delay=8, frames=24)
             except AssertionError as e:
                 raise SystemExit("bench: the dav1d task loop leg differs from dav1d's own pass 2 + filters: %s" % e)
             except Exception as e:       # noqa: BLE001  (a reported extra)

@@ -126,6 +126,8 @@ typedef struct Hooked {
     FcState *fcs;
     Store *store;
     double *q_done_t;                     /* chain mode, [frame number]: when dav1d_hip_frame_done returned */
+    double *out_t;                        /* chain mode, [frame number]: when the picture came out of dav1d */
+    uint64_t *out_hash;                   /* chain mode, keep_output == 2: [frame * 3 + plane] digests of the pictures */
     /* stream mode */
     struct OutPic *out_pics;              /* what dav1d_get_picture handed out, in that order */
     int n_out_pics, cap_out_pics;
@@ -692,10 +694,23 @@ static void fill_frame(Dav1dFrameHeader *const fh, const HookedParams *const p, 
 }
 
 /* ------------------------------------------------------------------------------------------------ outputs */
+static uint64_t hash_bytes(uint64_t x, const uint8_t *p, size_t n);
 static void keep_picture(Hooked *const h, const Dav1dPicture *const pic) {
     const int k = pic->frame_hdr->frame_offset;
     if (k < 0 || k >= h->p.n_frames) return;
     h->n_out++;
+    h->out_t[k] = now_s();                /* when dav1d_get_picture / dav1d_submit_frame handed frame k out (either mode) */
+    if (h->p.keep_output == 2) {          /* digests of the visible rows only (long chains of large pictures) */
+        const int bps2 = pic->p.bpc > 8 ? 2 : 1;
+        const int ssh = pic->p.layout != DAV1D_PIXEL_LAYOUT_I444, ssv = pic->p.layout == DAV1D_PIXEL_LAYOUT_I420;
+        for (int pl = 0; pl < (pic->p.layout == DAV1D_PIXEL_LAYOUT_I400 ? 1 : 3); pl++) {
+            const int w = pl ? (pic->p.w + ssh) >> ssh : pic->p.w, hh = pl ? (pic->p.h + ssv) >> ssv : pic->p.h;
+            uint64_t x = 0xDA71Dull + (uint64_t) pl;
+            for (int y = 0; y < hh; y++) x = hash_bytes(x, (const uint8_t *) pic->data[pl] + (ptrdiff_t) y * pic->stride[!!pl], (size_t) w * bps2);
+            h->out_hash[k * 3 + pl] = x;
+        }
+        return;
+    }
     if (!h->p.keep_output) return;
     const int bps = pic->p.bpc > 8 ? 2 : 1;
     const int ss_hor = pic->p.layout != DAV1D_PIXEL_LAYOUT_I444, ss_ver = pic->p.layout == DAV1D_PIXEL_LAYOUT_I420;
@@ -823,8 +838,10 @@ void *dav1d_hooked_open(const HookedParams *const p, const char *const hip_lib, 
     h->n_fc = h->c->n_fc;
     h->fcs = calloc(h->n_fc, sizeof(*h->fcs));
     h->q_done_t = calloc((size_t) p->n_frames + 1, sizeof(*h->q_done_t));
+    h->out_t = calloc((size_t) p->n_frames + 1, sizeof(*h->out_t));
+    h->out_hash = calloc((size_t) p->n_frames * 3 + 3, sizeof(*h->out_hash));
     h->out_plane = calloc((size_t) p->n_frames * 3 + 3, sizeof(*h->out_plane));
-    if (!h->fcs || !h->out_plane || !h->q_done_t) goto fail;
+    if (!h->fcs || !h->out_plane || !h->q_done_t || !h->out_t || !h->out_hash) goto fail;
     h->seq_ref = dav1d_ref_create(ALLOC_OBU_HDR, sizeof(Dav1dSequenceHeader));
     if (!h->seq_ref) goto fail;
     fill_seq(h->seq_ref->data, p);
@@ -841,6 +858,19 @@ double dav1d_hooked_tail_seconds(void *const handle, const int from) {
     Hooked *const h = handle;
     if (from < 0 || from >= h->p.n_frames - 1 || !h->q_done_t[from] || !h->q_done_t[h->p.n_frames - 1]) return 0.;
     return h->q_done_t[h->p.n_frames - 1] - h->q_done_t[from];
+}
+/* chain mode: seconds between the output of frame `from` and of the last frame (either mode: the steady state of the peer too) */
+double dav1d_hooked_output_tail_seconds(void *const handle, const int from) {
+    const Hooked *const h = handle;
+    if (from < 0 || from >= h->p.n_frames - 1) return 0.;
+    return h->out_t[h->p.n_frames - 1] - h->out_t[from];
+}
+/* chain mode, keep_output == 2: the digests of frame k's planes */
+int dav1d_hooked_picture_digest(void *const handle, const int k, uint64_t out[3]) {
+    const Hooked *const h = handle;
+    if (k < 0 || k >= h->p.n_frames) return -1;
+    for (int pl = 0; pl < 3; pl++) out[pl] = h->out_hash[k * 3 + pl];
+    return 0;
 }
 int dav1d_hooked_row_publications(void *const handle) { return handle ? dav1d_hip_glue_row_publications(((Hooked *) handle)->glue) : 0; }
 int dav1d_hooked_n_fc(void *const handle) { return handle ? (int) ((Hooked *) handle)->n_fc : 0; }
@@ -1009,6 +1039,8 @@ void dav1d_hooked_close(void *const handle) {
     for (int i = 0; i < h->n_out_pics; i++) for (int pl = 0; pl < 3; pl++) free(h->out_pics[i].plane[pl]);
     free(h->out_pics);
     free(h->q_done_t);
+    free(h->out_t);
+    free(h->out_hash);
     if (h->hip.synth_dl) dlclose(h->hip.synth_dl);
     free(h);
 }

@@ -1,11 +1,12 @@
-"""End-to-end leg of the benchmark: hand-off arrays -> pass-2 lister (host threads) -> device.
+"""End-to-end leg of the benchmark: hand-off arrays -> pass-2 lister (host threads) -> device.  BENCH / TEST INFRASTRUCTURE (it drives the
+generator of synthetic pass-1 output, tests/synth): lives next to the tests, not in the product package.
 
 What the headline `value` of bench.py leaves out by definition (lists resident in HBM) is measured here: one synthetic 8K
 frame's pass-1 output (Av1Block / cbi / cf, dav1d_synth_frame) is listed by dav1d_hip_lister_tile_sbrow() from a pool of
 host threads (one per tile, as dav1d's pass-2 workers would), every submit prepares its chunk of the device lists on the
 submitting thread, the coefficient arena crosses the host link, and dav1d_hip_frame_end() launches the frame.
 
-    python -m dav1d_amd.e2e [--frames N] [--threads T] [--tile-cols C]
+    python tests/e2e.py [--frames N] [--threads T] [--tile-cols C]
 """
 import argparse
 import ctypes as C
@@ -16,11 +17,11 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
-from . import _lib, api
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dav1d_amd import _lib, api  # noqa: E402
 
 # the generator of synthetic pass-1 output is test infrastructure with a library of its own (tests/synth/libdav1d_synth.so)
-import sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import synth_lib  # noqa: E402
 
 SIZE_MUL = [(4, 4), (6, 5), (8, 6), (12, 8)]      # ss_size_mul, reference src/decode.c:2416-2421

@@ -40,6 +40,9 @@ def lib():
     l.dav1d_hooked_row_publications.argtypes = [C.c_void_p]
     l.dav1d_hooked_tail_seconds.restype = C.c_double
     l.dav1d_hooked_tail_seconds.argtypes = [C.c_void_p, C.c_int]
+    l.dav1d_hooked_output_tail_seconds.restype = C.c_double
+    l.dav1d_hooked_output_tail_seconds.argtypes = [C.c_void_p, C.c_int]
+    l.dav1d_hooked_picture_digest.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
     l.dav1d_hooked_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     l.dav1d_hooked_frame_end_seconds.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     l.dav1d_hooked_close.argtypes = [C.c_void_p]
@@ -112,11 +115,19 @@ def run(p, hip_lib_path, store=None, inject=0):
         run.last_stats = dict(zip(("picture_alloc", "after_init", "listing", "filter_listing", "gpu_thread_idle", "uploads", "frame_end", "fetch", "picture_release"),
                                   [round(v * 1e3 / max(1, p.n_frames), 2) for v in st[:9]]))
         run.last_tail = (lambda frm: l.dav1d_hooked_tail_seconds(h, frm))(getattr(run, "tail_from", 0)) if p.mode == 1 else 0.
+        run.last_out_tail = l.dav1d_hooked_output_tail_seconds(h, getattr(run, "tail_from", 0))
+        run.last_digests = None
+        if p.keep_output == 2:
+            run.last_digests = []
+            for k in range(p.n_frames):
+                dg = (C.c_uint64 * 3)()
+                assert l.dav1d_hooked_picture_digest(h, k, dg) == 0
+                run.last_digests.append(tuple(int(v) for v in dg))
         fe = (C.c_double * 64)()
         l.dav1d_hooked_frame_end_seconds(h, fe)
         run.last_frame_end_ms = [round(v * 1e3, 2) for v in fe[:min(64, p.n_frames)]]
         frames = None
-        if p.keep_output:
+        if p.keep_output == 1:
             dt = np.uint8 if p.bpc == 8 else np.uint16
             ss_hor, ss_ver = int(p.layout != 3), int(p.layout == 1)
             frames = []
@@ -140,27 +151,25 @@ def task_loop_rate(hip_lib_path, w, h, bpc, tiles=(4, 1), threads=64, frame_dela
     its worker threads, check_tile, dav1d_get_picture — with the backend plugged in at the hook points of INTEGRATION.md 2.  First a
     short chain is decoded both ways and compared picture by picture (the peer: the reference's pass 2 + filters on the same worker
     threads, C only); then the chain is timed, first frame submitted to last picture out."""
-    from dav1d_amd import e2e
+    import e2e
     sp = e2e.c2_params(seed)
     sp.intra_pct = intra_pct
     common = dict(tiles=tiles, threads=threads, frame_delay=frame_delay, synth=sp)
     store = Store(frames)
     try:
-        # the peer generates (and keeps) pass 1's output of the first frames; everything after replays the store, so that the generator and
-        # the mask-building walk (one thread per frame in this harness) stay out of the timed chains
-        _, n_fc, want = run(params(w, h, bpc, check_frames, mode=0, **common), hip_lib_path, store, inject=1)
-        _, _, got = run(params(w, h, bpc, check_frames, mode=1, **common), hip_lib_path, store, inject=2)
-        for k in range(check_frames):
-            for pl in range(3):
-                if not np.array_equal(want[k][pl], got[k][pl]):
-                    bad = np.argwhere(want[k][pl] != got[k][pl])
-                    raise AssertionError("dav1d task loop: frame %d plane %d differs from dav1d's own pass 2 + filters: %d pixels, first at (y, x) = %s, "
-                                         "rows %d..%d, columns %d..%d" % (k, pl, len(bad), tuple(bad[0]), bad[:, 0].min(), bad[:, 0].max(), bad[:, 1].min(), bad[:, 1].max()))
-        del want, got
-        run(params(w, h, bpc, frames, mode=0, keep_output=False, **common), hip_lib_path, store, inject=1)      # fills the store for every frame
-        cpu_s, _, _ = run(params(w, h, bpc, check_frames, mode=0, keep_output=False, **common), hip_lib_path, store, inject=2)
-        # last: the packing lister consumes the store's coefficient arrays (as dav1d's pass 2 consumes f->frame_thread.cf)
+        # the peer generates (and keeps) pass 1's output of EVERY frame of the chain and leaves the digests of its pictures; everything after
+        # replays the store, so that the generator and the mask-building walk (one thread per frame in this harness) stay out of the timed chains
         run.tail_from = min(frame_delay, frames - 2)
+        _, n_fc, _ = run(params(w, h, bpc, frames, mode=0, keep_output=2, **common), hip_lib_path, store, inject=1)
+        want = list(run.last_digests)
+        run(params(w, h, bpc, frames, mode=1, keep_output=2, **common), hip_lib_path, store, inject=2)
+        got = list(run.last_digests)
+        bad = [k for k in range(frames) if want[k] != got[k]]
+        assert not bad, "dav1d task loop: frames %s of %d differ from dav1d's own pass 2 + filters (plane digests)" % (bad, frames)
+        # the peer timed over the same chain, steady state over the same frames (replaying the store: copies, its pass 2 consumes cf)
+        cpu_s, _, _ = run(params(w, h, bpc, frames, mode=0, keep_output=False, **common), hip_lib_path, store, inject=2)
+        peer_tail_s = run.last_out_tail
+        # last: the packing lister consumes the store's coefficient arrays (as dav1d's pass 2 consumes f->frame_thread.cf)
         t_s, _, _ = run(params(w, h, bpc, frames, mode=1, keep_output=False, **common), hip_lib_path, store, inject=2)
         tail_s, tail_n = run.last_tail, frames - 1 - run.tail_from
         stages = dict(run.last_stats)
@@ -190,9 +199,12 @@ def task_loop_rate(hip_lib_path, w, h, bpc, tiles=(4, 1), threads=64, frame_dela
                              "what": "the inter frames after the first %d (key frame, first-use allocations and pipeline fill left out): completion of frame %d to "
                                      "completion of the last" % (run.tail_from + 1, run.tail_from)}, "n_fc": n_fc, "worker_threads": threads,
             "tile_cols": tiles[0], "tile_rows": tiles[1], "ms_per_frame_by_stage_summed_over_threads": stages, "row_progress": rp,
-            "peer_fps": round(check_frames / cpu_s, 2), "peer": "the reference's pass 2 + in-loop filters (C, no assembly) under the same task loop, %d worker threads, "
-                                                               "%d frames" % (threads, check_frames),
-            "parity": "bit-exact vs dav1d's own pass 2 + filters under the same task loop (%d frames)" % check_frames,
+            "peer_fps": round(frames / cpu_s, 2),
+            "peer_steady_state": {"frames": tail_n, "fps": round(tail_n / peer_tail_s, 2) if peer_tail_s else None,
+                                  "ms_per_frame": round(peer_tail_s / tail_n * 1e3, 2) if peer_tail_s else None},
+            "peer": "the reference's pass 2 + in-loop filters (C, no assembly) under the same task loop, %d worker threads, the same %d frames, "
+                    "steady state over the same pictures" % (threads, frames),
+            "parity": "bit-exact vs dav1d's own pass 2 + filters under the same task loop on ALL %d pictures (plane digests)" % frames,
             "workload": "%dx%d 4:2:0 %d-bit: key frame + inter frames (C2 mix, 10 %% intra, 3 references = the 3 frames before), deblock + CDEF + switchable "
                         "restoration; pass 1's output injected from memory (no AV1 streams exist here); dav1d_open(n_threads=%d, max_frame_delay=%d), src/thread_task.c with the "
                         "hook points of INTEGRATION.md 2; listing runs ahead, frames end in order on one GPU thread" % (w, h, bpc, threads, frame_delay)}

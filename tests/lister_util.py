@@ -443,7 +443,7 @@ def compare(rf, got):
 
 
 def check_handoff_against_reference(ho, planes, ref_pics, is_inter=True):
-    """The parity gate of the end-to-end route (dav1d_amd/e2e.py): the hand-off arrays `ho` go into a real Dav1dFrameContext,
+    """The parity gate of the end-to-end route (tests/e2e.py): the hand-off arrays `ho` go into a real Dav1dFrameContext,
     the reference's OWN pass 2 (dav1d_decode_tile_sbrow, oracle/ref_frame.c) reconstructs the frame on the CPU, and the
     planes the device produced must equal it.  Returns a description, raises AssertionError on a difference."""
     import time
@@ -479,7 +479,7 @@ def reference_pass2_rate(lib_ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=
     by a pool of workers, one tile each at a time — the split dav1d's frame threading makes in pass 2.  Returns
     {threads: Mpixels/s}.  lib_ctx: anything with .lib = the product library (for the frame generator)."""
     import time
-    from dav1d_amd import e2e
+    import e2e
     if ref_lib() is None:
         return None
     rf = RefFrame(w, h, 1, bpc, is_inter=True, sb128=True, tile_cols=tile_cols, tile_rows=tile_rows)
@@ -508,7 +508,7 @@ def full_route_rate(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=64, frame
     measurement dict, or None without the reference build."""
     import time
     from concurrent.futures import ThreadPoolExecutor
-    from dav1d_amd import e2e
+    import e2e
     if ref_lib() is None:
         return None
     filters = dict(lf=(20, 28, 16, 24, 0, False), cdef=(5, 2, [17, 33, 0, 63], [5, 0, 20, 48]), lr=([1, 1, 1], [6, 6]))
@@ -618,11 +618,11 @@ def row_progress_cost(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=64, fra
 
 
 def full_route_sustained(ctx, w, h, bpc, tile_cols=16, tile_rows=8, threads=None, frames=10, depth=2, warm=2, seed=0xF0E):
-    """full_route_rate with frames in flight (dav1d_amd.e2e.run_pipelined): frame n + 1 is listed — blocks by the packing lister,
+    """full_route_rate with frames in flight (e2e.run_pipelined): frame n + 1 is listed — blocks by the packing lister,
     then the filter tasks — while frame n runs on the device; per frame only the coefficients that exist, the prepared lists and the
     level cache cross the host link.  The last frame's final picture is compared with the reference's dav1d_decode_tile_sbrow +
     dav1d_filter_sbrow.  Returns the measurement dict, or None without the reference build."""
-    from dav1d_amd import e2e
+    import e2e
     if ref_lib() is None:
         return None
     filters = dict(lf=(20, 28, 16, 24, 0, False), cdef=(5, 2, [17, 33, 0, 63], [5, 0, 20, 48]), lr=([1, 1, 1], [6, 6]))

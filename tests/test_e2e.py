@@ -1,10 +1,10 @@
-"""The end-to-end route of bench.py (dav1d_amd/e2e.py): pass-1 hand-off arrays -> pass-2 lister on host threads -> chunks ->
+"""The end-to-end route of bench.py (tests/e2e.py): pass-1 hand-off arrays -> pass-2 lister on host threads -> chunks ->
 device, for an inter frame and for a key frame (every block through the intra wavefront), checked against the reference's
 own pass 2 on a real Dav1dFrameContext."""
 import pytest
 
 import lister_util as lu
-from dav1d_amd import e2e
+import e2e
 
 
 @pytest.mark.parametrize("packed", [False, True], ids=["dense-upload", "packing-lister"])

@@ -321,7 +321,7 @@ def test_reference_pass2_on_worker_threads_equals_one_thread():
         pytest.skip("no reference build (oracle/_ref)")
     import util
     ctx = util.make_context("emu")
-    from dav1d_amd import e2e
+    import e2e
     outs = []
     for threads in (1, 6):
         rf = lu.RefFrame(640, 384, 1, 10, is_inter=True, sb128=True, tile_cols=4, tile_rows=3)

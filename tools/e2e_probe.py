@@ -17,7 +17,8 @@ def main():
     ap.add_argument("--no-full", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     a = ap.parse_args()
-    from dav1d_amd import api, e2e
+    from dav1d_amd import api
+    import e2e
     import lister_util as lu
     ctx = api.Context(0)
     tc, tr = (int(v) for v in a.tiles.split("x"))

@@ -2,7 +2,8 @@
 superblock (0); each checked against the reference's pass 2.  python tools/key_frame_probe.py [--no-check]"""
 import json, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
-from dav1d_amd import api, e2e
+from dav1d_amd import api
+import e2e
 import lister_util as lu
 ctx = api.Context(0, lib_path=os.environ["DAV1D_HIP_LIB"]) if os.environ.get("DAV1D_HIP_LIB") else api.Context(0); ctx.backend = "hip"
 out = {}

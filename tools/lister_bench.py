@@ -7,7 +7,8 @@ import ctypes as C
 from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import util
-from dav1d_amd import api, e2e
+from dav1d_amd import api
+import e2e
 import synth_lib
 
 a = [int(v) for v in sys.argv[1:]]
