@@ -721,13 +721,12 @@ def run_job(a, rank, local, world):
             dd.exchange_halo(d, cols, rank, world)       # enqueued on the context's stream behind the reconstruction (dav1d_hip_peer_exchange_halo)
             pa, cdf, res = tc_post["all"], tc_post["cdf"], tc_post["res"]
             ctx.lf_batch(d.view, tc_post["lf"], tc_post["lvl"], pa.b4_stride, pa.lut_e, pa.lut_i)
-            for pl in range(3):
-                cdf.planes[pl].copy_(d.planes[pl])
+            # no picture copies under CDEF and restoration (round 4's frame path dropped them; this leg still made them with torch): the
+            # column's own units and stripes are all listed — the strip kernel writes every listed unit, restoration every listed stripe —
+            # and what lies outside the column is overwritten by the other ranks' strips when the gather lands
             ctx.cdef_batch(cdf.view, d.view, tc_post["cdef"], pa.cdef_damping)
             dd.wait_gathers(res, rank, world)                 # (one restoration picture: the gather of the frame before has to be through;
                                                               #  it ran next to this frame's reconstruction, deblocking and CDEF)
-            for pl in range(3):
-                res.planes[pl].copy_(cdf.planes[pl])
             ctx.lr_batch(res.view, cdf.view, d.view, tc_post["lr"])
             dd.allgather_tile_columns(res, cols, rank, world, overlap=True)
             final_pic[0] = res

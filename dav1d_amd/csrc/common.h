@@ -336,9 +336,11 @@ namespace { __device__ unsigned long long g_phase[DV_PHASE_SLOTS * DV_PHASE_SPRE
         if ((threadIdx.x & 63) == 0) atomicAdd(&DV_PHASE_AT(slot), n_ - dv_t_); dv_t_ = n_; } while (0)
 #define DV_PHASE_WAVE(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
         if ((threadIdx.x & 63) == 0) { atomicAdd(&DV_PHASE_AT(slot), n_ - dv_t0_); atomicAdd(&DV_PHASE_AT((slot) + 1), 1ull); } } while (0)
+#define DV_PHASE_COUNT(slot, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&DV_PHASE_AT(slot), (unsigned long long) (n)); } while (0)
 #else
 #define DV_PHASE_DEFINE(unit)
 #define DV_PHASE_BEGIN() do { } while (0)
 #define DV_PHASE(slot) do { } while (0)
 #define DV_PHASE_WAVE(slot) do { } while (0)
+#define DV_PHASE_COUNT(slot, n) do { } while (0)
 #endif

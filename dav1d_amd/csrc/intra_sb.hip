@@ -18,6 +18,7 @@
 // flags of the neighbours it reads (release / acquire fences at superblock granularity) — or, on request, as a launch per level.
 // Measured on MI355X: an 8K key frame 27.4 ms as one dataflow launch -> 12.5 ms as 12 level launches -> 10.3 ms as
 // one launch of superblocks.
+#define DV_UNIT intra_sb   // (names this unit's phase accessor in -DDV_PHASES variant builds, common.h)
 #include "ipred_body.h"
 #include "itx_body.h"
 #include "capi.h"
@@ -36,6 +37,7 @@
 #define SB_PREFETCH 1
 #endif
 
+DV_PHASE_DEFINE(DV_UNIT)
 namespace {
 
 constexpr int sb_itx_lds_of(int tx) {
@@ -69,6 +71,11 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
     pixel *const tile = reinterpret_cast<pixel *>(smem_s[wv]);
     int *const smem_itx = reinterpret_cast<int *>(smem_s[wv]);
 
+    // phase slots of a wave of this kernel (DV_PHASES builds, tools/intra_phase_probe.py): 900 start-up (region, records), 901 waiting for
+    // neighbouring superblocks, 902 prediction (edge gather, filter, predict, blend), 903 transform, 904 store, 905 end of a group (own stores
+    // acknowledged + workgroup barrier + publication), 906 whole wave, 907 waves, 908 units, 909 groups, 910 idle turns (groups in which
+    // the wave had no unit)
+    DV_PHASE_BEGIN();
     const SbRegion r = regions[blockIdx.x];
     // FINE (one launch, every prediction stamped by the lister): nobody waits for whole superblocks.  flags[sb] = progress << 2 | state
     // (state 1 finished, 2 gave up; progress P = every unit of a step < P has its pixels out).  A unit whose prediction reads intra pixels
@@ -119,9 +126,12 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
     if (ci != SB_NONE) u = us[ci];
     uint32_t ni = ci != SB_NONE ? (uint32_t) __builtin_amdgcn_readfirstlane((int) sb_next<SB_WAVES>(u)) : SB_NONE;
     if (ni != SB_NONE) un = us[ni];
+    DV_PHASE(900);
     for (uint32_t g = 0; g < n_groups; g++) {
         uint32_t pub = 0;                    // (wave 0 holds the first unit of every group: it knows what to publish behind it)
+        int dv_units_ = 0;
         while (ci != SB_NONE && ((uint32_t) __builtin_amdgcn_readfirstlane((int) u.grp) & 0xffffu) == g) {
+            dv_units_++;
             const IntraUnit *const up = us + ci;
             pub = (uint32_t) __builtin_amdgcn_readfirstlane((int) u.grp) >> 16;
             uint32_t n2 = SB_NONE;
@@ -191,6 +201,7 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
                 skip = bad != 0;
                 dv::fence_acquire_agent();
             }
+            DV_PHASE(901);
             if (skip) {          // never in a sound run: the unit is NOT reconstructed from pixels that are not there
                 dv::fetch_end(keepn);
                 ci = ni; u = un; ni = n2; un = u2;
@@ -223,6 +234,7 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
                 keepn = dv::fetch_begin(reinterpret_cast<const char *>(cf + un.t.cf_off) + (lane * 64 < nbn ? lane * 64 : 0));
             }
             dv::wave_sync();
+            DV_PHASE(902);
             if (has_tx) {
 #define CASE(T) case T: itx_body<T, pixel, coef, true, true>(dst, &up->t, 1, cf, bitdepth_max, 0, smem_itx, tile); break;
                 switch (u.t.tx) {
@@ -232,6 +244,7 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
 #undef CASE
             }
             dv::wave_sync();
+            DV_PHASE(903);
             // the reconstructed tile leaves the LDS four pixels per store (blocks are at least four pixels wide and four-pixel
             // aligned); plain stores: the line stays in this XCD's L2, where the next group of the workgroup reads it
             {
@@ -248,8 +261,12 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
             }
             dv::fetch_end(keepn);
             dv::wave_sync();                 // the LDS is free for the wave's next unit
+            DV_PHASE(904);
             ci = ni; u = un; ni = n2; un = u2;
         }
+        DV_PHASE_COUNT(908, dv_units_);
+        DV_PHASE_COUNT(909, 1);
+        DV_PHASE_COUNT(910, dv_units_ == 0);
         dv::stores_done();                   // this wave's pixels have reached the L2 (the coherent ones: memory) ...
         __syncthreads();                     // ... and so have the other waves': the next group may read them
         if (flags) {
@@ -259,7 +276,9 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
             }
             if (fine && threadIdx.x == 0 && pub) dv::st_coherent(flags + blockIdx.x, pub << 2);
         }
+        DV_PHASE(905);
     }
+    DV_PHASE_WAVE(906);
     if (flags && threadIdx.x == 0) {
         dv::fence_release_agent();           // the XCD's L2 writes the superblock's pixels back: other XCDs may read them
         dv::st_coherent(flags + blockIdx.x, 0xfffffffdu);       // progress: everything; state: finished
