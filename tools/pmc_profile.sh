@@ -9,8 +9,8 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export DAV1D_HIP_SERIAL=1   # per-kernel durations must not overlap: run the shapes back to back
-ARGS="--steps 3 --warmup 1 --no-cpu --no-check --no-full --no-e2e --no-c1 $*"      # the recon step only: clean per-kernel averages
-FULL_ARGS="--steps 3 --warmup 1 --no-cpu --no-check --no-e2e --no-c1 --no-inflight $*"         # + the full-table leg (post filters, intra waves)
+ARGS="--steps 3 --warmup 1 --no-cpu --no-check --no-full --no-e2e --no-c1 --no-pmc $*"      # the recon step only: clean per-kernel averages
+FULL_ARGS="--steps 3 --warmup 1 --no-cpu --no-check --no-e2e --no-c1 --no-inflight --no-pmc $*"         # + the full-table leg (post filters, intra waves)
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python "$ROOT/bench.py" $ARGS > "$OUT/stats.log" 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_full" -- python "$ROOT/bench.py" $FULL_ARGS > "$OUT/stats_full.log" 2>&1
 i=0

@@ -66,7 +66,7 @@ if "--step" in sys.argv:
                 if r["Counter_Name"] != cname:
                     continue
                 k = short(r["Kernel_Name"])
-                if not re.match(r"(mc_kernel|itx_add_kernel|recon_fused_kernel|comp_kernel|mc_all_kernel|itx_multi_kernel)", k):
+                if not re.match(r"(mc_kernel|mc_twin_kernel|itx_add_kernel|itx_add_wide_kernel|recon_fused_kernel|comp_kernel|mc_all_kernel|itx_multi_kernel)", k):
                     continue        # fills / copies of the harness are not the step
                 v = float(r["Counter_Value"]) * 1024
                 tot[cname] += v
