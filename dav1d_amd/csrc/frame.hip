@@ -799,9 +799,10 @@ static int frame_cdef_rows_to_piece(Dav1dHipFrame *f) {
 }
 
 // the pieces -> f->lf / f->cdef / f->lr (once, at frame end; submission order)
-static void frame_merge_filter_pieces(Dav1dHipFrame *f) {
-    (void) frame_cdef_rows_to_piece(f);
-    if (f->filter_pieces.empty()) return;
+static int frame_merge_filter_pieces(Dav1dHipFrame *f) {
+    const int rc_rows = frame_cdef_rows_to_piece(f);       // (-ENOMEM: the frame must not go on without its CDEF units — ADVICE r4)
+    if (rc_rows) return rc_rows;
+    if (f->filter_pieces.empty()) return 0;
     size_t a = f->lf.size(), b = f->cdef.size(), d = f->lr.size();
     for (const Dav1dHipFrame::FilterPiece &p : f->filter_pieces) { a += p.n_lf; b += p.n_cdef; d += p.n_lr; }
     f->lf.reserve(a); f->cdef.reserve(b); f->lr.reserve(d);
@@ -809,10 +810,12 @@ static void frame_merge_filter_pieces(Dav1dHipFrame *f) {
         f->lf.insert(f->lf.end(), p.lf, p.lf + p.n_lf);
         f->cdef.insert(f->cdef.end(), p.cdef, p.cdef + p.n_cdef);
         f->lr.insert(f->lr.end(), p.lr, p.lr + p.n_lr);
+        f->lrplan.valid = false;            // (the plan was made for the list as it was)
         free(p.lf); free(p.cdef); free(p.lr);
         delete p.groups;
     }
     f->filter_pieces.clear();
+    return 0;
 }
 
 static int copy_picture(Dav1dHipContext *c, const Dav1dHipPicture *dst, const Dav1dHipPicture *src);
@@ -843,7 +846,7 @@ static int frame_filters_from_pieces(Dav1dHipFrame *f, bool *did_cdef) {
     }
     // restoration units: few; they go through the merged vector, and their host-side preparation (frame_lr_plan) runs below while the
     // device works on the stages before
-    for (Dav1dHipFrame::FilterPiece &p : f->filter_pieces) { f->lr.insert(f->lr.end(), p.lr, p.lr + p.n_lr); p.n_lr = 0; }
+    for (Dav1dHipFrame::FilterPiece &p : f->filter_pieces) { f->lr.insert(f->lr.end(), p.lr, p.lr + p.n_lr); p.n_lr = 0; f->lrplan.valid = false; }
     size_t n_lf = 0, n_lf0 = 0, n_cdef = 0, n_groups = 0, n_raw = 0;
     for (const Dav1dHipFrame::FilterPiece &p : f->filter_pieces) {
         n_lf += p.n_lf; n_lf0 += p.n_lf0; n_cdef += p.n_cdef; n_raw += p.n_raw;
@@ -1251,7 +1254,7 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
         coef = f->carena;
     }
     tr.mark(0);
-    if (c->post_bands >= 2) frame_merge_filter_pieces(f);          // the banded route works on the merged lists
+    if (c->post_bands >= 2) { rc = frame_merge_filter_pieces(f); if (rc) return rc; }          // the banded route works on the merged lists
     // warped / scaled predictions first: the compound combinations of the list below read their PREP outputs
     if (!f->warp.empty()) rc = dav1d_hip_warp_batch(c, &f->cur, f->refs, f->n_refs, f->warp.data(), f->warp.size(), prep);
     if (!rc && !f->scaled.empty()) rc = dav1d_hip_mc_scaled_batch(c, &f->cur, f->refs, f->n_refs, f->scaled.data(), f->scaled.size(), prep);

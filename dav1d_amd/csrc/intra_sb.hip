@@ -82,9 +82,14 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
     // of other superblocks waits, itself, until those have published a progress above the step it needs; units on a superblock's right /
     // bottom border store coherently and the superblock publishes behind their groups.
     const bool fine = flags && reinterpret_cast<const uint32_t *>(units + r.first)[15] == 1u;
+    // give_up: the whole-superblock form's verdict (set by thread 0 before a barrier: uniform).  give_up2[g & 1]: the per-block form's,
+    // raised by a wave that waits in vain DURING group g and read by every wave behind the barrier that ends group g — a wave that is
+    // already waiting in group g + 1 raises the OTHER word, so all waves of the workgroup take the same way out (with one
+    // word a fast wave could raise it between a slow wave's barrier and its read)
     __shared__ int give_up;
+    __shared__ int give_up2[2];
     if (flags && fine) {
-        if (threadIdx.x == 0) give_up = 0;
+        if (threadIdx.x == 0) { give_up = 0; give_up2[0] = give_up2[1] = 0; }
         __syncthreads();
     } else if (flags) {
         // Every level in one launch: the superblocks this one reads from (r.dep, all earlier in the array) have to be through.
@@ -111,6 +116,7 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
                 dv::st_coherent(flags + blockIdx.x, 2u);
             }
             give_up = !ok;
+            give_up2[0] = give_up2[1] = 0;
             dv::fence_acquire_agent();
         }
         __syncthreads();
@@ -161,11 +167,11 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
                             for (;;) {
                                 const uint32_t v = dv::ld_coherent(flags + r.dep[k]);
                                 if ((v & 3u) == 1u || (v >> 2) > nstep) break;
-                                if ((v & 3u) == 2u || ++spins > (SB_SPIN_LIMIT << 3) || *(volatile int *) &give_up) { bad = 1; break; }
+                                if ((v & 3u) == 2u || ++spins > (SB_SPIN_LIMIT << 3) || ((volatile int *) give_up2)[0] || ((volatile int *) give_up2)[1]) { bad = 1; break; }
                                 dv::nap();
                             }
                         }
-                        if (bad) give_up = 1;
+                        if (bad) ((volatile int *) give_up2)[g & 1] = 1;
                     }
                     bad = __shfl(bad, 0);
                     skip = bad != 0;
@@ -191,11 +197,11 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
                         for (;;) {
                             const uint32_t v = dv::ld_coherent(flags + at);
                             if ((v & 3u) == 1u) break;
-                            if ((v & 3u) == 2u || ++spins > (SB_SPIN_LIMIT << 3) || *(volatile int *) &give_up) { bad = 1; break; }
+                            if ((v & 3u) == 2u || ++spins > (SB_SPIN_LIMIT << 3) || ((volatile int *) give_up2)[0] || ((volatile int *) give_up2)[1]) { bad = 1; break; }
                             dv::nap();
                         }
                     }
-                    if (bad) give_up = 1;
+                    if (bad) ((volatile int *) give_up2)[g & 1] = 1;
                 }
                 bad = __shfl(bad, 0);
                 skip = bad != 0;
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
         dv::stores_done();                   // this wave's pixels have reached the L2 (the coherent ones: memory) ...
         __syncthreads();                     // ... and so have the other waves': the next group may read them
         if (flags) {
-            if (*(volatile int *) &give_up) {
+            if (((volatile int *) give_up2)[g & 1]) {
                 if (threadIdx.x == 0) { atomicAdd(flags + n_regions, 1u); dv::st_coherent(flags + blockIdx.x, 2u); }
                 return;
             }
