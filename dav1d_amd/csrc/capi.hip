@@ -105,6 +105,11 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
 void dav1d_hip_close(Dav1dHipContext *c) {
     if (!c) return;
     __atomic_fetch_sub(&dav1d_hip_live[0], 1, __ATOMIC_RELAXED);
+    (void) hipSetDevice(c->device);
+    // everything this context (or a frame, a grain handle, a peer of it) still has in flight on ANY of its streams is through before the
+    // streams, events and pools go: the per-stream waits below do not cover streams that belong to objects the caller destroyed without
+    // waiting (a GPU test run died once in here, at the session's end, after 249 green tests)
+    (void) hipDeviceSynchronize();
     hipStreamSynchronize(c->stream);
     if (c->scratch) hipFree(c->scratch);
     for (int i = 0; i < Dav1dHipContext::N_SIDE; i++) { hipStreamSynchronize(c->side[i]); hipStreamDestroy(c->side[i]); hipEventDestroy(c->ev_join[i]); }
@@ -474,7 +479,7 @@ int dav1d_hip_host_picture_wait(Dav1dHipContext *c) {
 
 int dav1d_hip_picture_free(Dav1dHipContext *c, Dav1dHipPicture *pic) {
     if (!pic || (!pic->alloc && !pic->twin_alloc)) return 0;
-    hipStreamSynchronize(c->stream);
+    if (c) hipStreamSynchronize(c->stream); else (void) hipDeviceSynchronize();        // (a picture that outlived its context)
     int rc = pic->alloc ? hip_rc(hipFree(pic->alloc)) : 0;
     if (pic->twin_alloc) { const int rc2 = hip_rc(hipFree(pic->twin_alloc)); if (!rc) rc = rc2; }
     memset(pic, 0, sizeof(*pic));

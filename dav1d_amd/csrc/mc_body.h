@@ -47,10 +47,19 @@ constexpr int mc_win_stride(int tw) { return tw == 4 ? 8 : (tw + 8 + 7) & ~7; }
 constexpr int mc_win_stride_tiled(int tw) { return tw == 4 ? 16 : tw + 16; }
 
 // LDS bytes one wave needs for tile shape (TW, TH): window + row-pair intermediate + the tile records
+// Rows of the window a tile of TH rows KEEPS in LDS, and the first of them.  The bodies below index a window of TH + 8 rows (the reach of
+// eight vertical taps).  Tiles of 4 rows only ever meet the 4-tap, bilinear or unit sets vertically (blocks of height <= 4, reference
+// src/mc_tmpl.c GET_V_FILTER): rows 2 .. 8 of that window.  They keep 8 rows (2 .. 9, whole row pairs) and hang their window two rows
+// higher than it is stored: the rows they never store or read with a non-zero tap — 0, 1, 10, 11 — lie in the NEIGHBOURING tiles' rows of
+// the shared buffer.  The 4x4 kernel's LDS per wave 8,896 -> 6,464 bytes: 4.25 -> 6 waves per SIMD.
+constexpr int mc_win_rows(int th) { return th == 4 ? 8 : th + 8; }
+constexpr int mc_win_row0(int th) { return th == 4 ? 2 : 0; }
 template <int TW, int TH, bool TILED = false>
 constexpr int mc_lds_bytes() {
-    constexpr int LPT = mc_cmin(64, TW * TH / 4), G = 64 / LPT, WS = TILED ? mc_win_stride_tiled(TW) : mc_win_stride(TW), WR = TH + 8, NPR = WR / 2;
-    return G * WR * WS * 2 + G * NPR * TW * 4 + (G > 1 ? G * (int) sizeof(McTile) + (int) sizeof(RefSet) : 0);
+    constexpr int LPT = mc_cmin(64, TW * TH / 4), G = 64 / LPT, WS = TILED ? mc_win_stride_tiled(TW) : mc_win_stride(TW);
+    constexpr int WRA = mc_win_rows(TH), WR0 = mc_win_row0(TH), NPRA = WRA / 2;
+    // window rows (+ WR0 rows in front: the first tile's rows 0, 1 are addressable), row pairs of the intermediate (4-row tiles: + a pair at either end)
+    return (WR0 + G * WRA) * WS * 2 + (G * NPRA + (TH == 4 ? 2 : 0)) * TW * 4 + (G > 1 ? G * (int) sizeof(McTile) + (int) sizeof(RefSet) : 0);
 }
 
 // One wave's worth of tiles of shape (TW, TH): tiles[t0 .. t0 + nt), nt <= 64 / LPT.  `smem` = mc_lds_bytes<TW, TH>() of LDS.
@@ -77,10 +86,13 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
     constexpr int G = 64 / LPT;                         // tiles side by side in a wave
     constexpr int R = TW * TH / 4 / LPT;                // output strips per lane (1, 2 or 4)
     constexpr int WS = TILED ? mc_win_stride_tiled(TW) : mc_win_stride(TW);    // window row stride (int16)
-    constexpr int WR = TH + 8;                          // window rows held (TH+7 used, +1 so row pairs are complete)
+    constexpr int WR = TH + 8;                          // window rows ADDRESSED (TH+7 used, +1 so row pairs are complete)
+    constexpr int WRA = mc_win_rows(TH), WR0 = mc_win_row0(TH);   // ... of which rows WR0 .. WR0 + WRA - 1 are this tile's own in LDS (see mc_win_rows)
+    constexpr int WRG = TH == 4 ? WRA : WR - 1;         // rows the raster gathers fetch and store: WR0 .. WR0 + WRG - 1
     constexpr int NCH = (WS + 7) / 8;                   // 8-pixel (16-byte) chunks fetched per window row
-    constexpr int NPR = WR / 2;                         // row pairs of the intermediate
-    constexpr int NLD = ((WR - 1) * NCH + LPT - 1) / LPT;   // window loads per lane
+    constexpr int NPR = WR / 2;                         // row pairs of the intermediate (addressed)
+    constexpr int NPRA = WRA / 2, PR0 = WR0 / 2;        // ... kept per tile, first kept
+    constexpr int NLD = (WRG * NCH + LPT - 1) / LPT;    // window loads per lane
     constexpr bool NARROW = TW == 4;                        // window columns start at src_x - 2 instead of src_x - 4, taps 2 .. 5 only
     constexpr bool HBD = sizeof(pixel) == 2;
     // phase slots of this tile shape (DV_PHASES builds): 0 records, 1 window gather (first reference), 2 horizontal, 3 vertical,
@@ -90,7 +102,8 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
     int dv_second_ = 0;
 
     int16_t *const win_s = reinterpret_cast<int16_t *>(smem);
-    uint32_t *const mid_s = reinterpret_cast<uint32_t *>(win_s + G * WR * WS);
+    constexpr int SL = TH == 4 ? TW : 0;                // 4-row tiles: one pair of slack in front of and behind the intermediates
+    uint32_t *const mid_s = reinterpret_cast<uint32_t *>(win_s + (WR0 + G * WRA) * WS) + SL;
 
     const int lane = threadIdx.x & 63;       // the body belongs to one wave (recon.hip runs several side by side in a workgroup)
     // G == 1: the whole wave works on one tile, so the record, the taps and all the control flow
@@ -105,7 +118,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
     } else {
         // the G records of the wave come in with one coalesced sweep and are handed to their lanes through LDS
         constexpr int RW = sizeof(McTile) / 4;
-        uint32_t *const rec_s = mid_s + G * NPR * TW;
+        uint32_t *const rec_s = mid_s + G * NPRA * TW + SL;
         const uint32_t *recs = reinterpret_cast<const uint32_t *>(tiles + t0);
         const int nw = nt * RW;
         for (int i = lane; i < nw; i += 64) rec_s[i] = recs[i];
@@ -122,8 +135,9 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
         for (int i = 0; i < RW; i++) tw_[i] = rp[i];
     }
 
-    int16_t *const win = win_s + sub * WR * WS;
-    uint32_t *const mid = mid_s + sub * NPR * TW;
+    // row r of the tile's window at win + r * WS, pair j of its intermediate at mid + j * TW: the tile's own rows start WR0 rows in
+    int16_t *const win = win_s + sub * WRA * WS;                       // (= stored row WR0 of tile `sub` minus WR0 rows, WR0 rows of slack in front)
+    uint32_t *const mid = mid_s + sub * NPRA * TW - PR0 * TW;
     DV_PHASE(PH + 0);
 
     const int ib = HBD ? 14 - (32 - __clz(bitdepth_max)) : 4;   // intermediate_bits
@@ -146,7 +160,8 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
         // window rows the vertical taps can reach: the others only ever meet zero taps, so they are neither
         // fetched nor filtered (6-tap regular, 4-tap smooth / small blocks, 2-tap bilinear, 1-tap full-pel)
         const int vspan = rf.vspan;
-        const int row_lo = vspan & 15, row_hi = TH - 1 + (vspan >> 4);
+        // (4-row tiles keep rows 2 .. 9 only, mc_win_rows: their filters reach rows 2 .. 8; the clamp is for a caller that breaks the rule)
+        const int row_lo = TH == 4 ? dv::imax(vspan & 15, 2) : vspan & 15, row_hi = TH == 4 ? dv::imin(TH - 1 + (vspan >> 4), 9) : TH - 1 + (vspan >> 4);
         // TILED: the window starts at the aligned piece that holds its first tap column; `toff` = that column's offset in the piece
         const int tx0 = rf.src_x - (NARROW ? 1 : 3), xa = tx0 & ~7, toff = tx0 & 7;
 
@@ -160,7 +175,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
                 rs = rp.stride[t.plane]; rw = rp.w[t.plane]; rh = rp.h[t.plane];
             } else {
                 constexpr int RW = sizeof(McTile) / 4, DW = sizeof(DevPlanes) / 4;
-                const uint32_t *rt = mid_s + G * NPR * TW + G * RW + rf.ref * DW;      // == ref_s above
+                const uint32_t *rt = mid_s + G * NPRA * TW + SL + G * RW + rf.ref * DW;      // == ref_s above
                 const uint32_t *pd = rt + 2 * t.plane;
                 src = reinterpret_cast<const pixel *>((uint64_t) pd[0] | ((uint64_t) pd[1] << 32));
                 rs = (int) rt[6 + t.plane]; rw = (int) rt[9 + t.plane]; rh = (int) rt[12 + t.plane];
@@ -211,26 +226,26 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
                         }
                 } else {
                     // edge emulation through the tile addressing: per-pixel clamped fetch, 8 independent loads in flight per lane
-                    for (int i0 = l; i0 < (WR - 1) * WS; i0 += 8 * LPT) {
+                    for (int i0 = l; i0 < WRG * WS; i0 += 8 * LPT) {
                         pixel v[8];
 #pragma unroll
                         for (int e = 0; e < 8; e++) {
-                            const int i = dv::imin(i0 + e * LPT, (WR - 1) * WS - 1);
-                            const int wr = dv::div_small<WS>(i);
+                            const int i = dv::imin(i0 + e * LPT, WRG * WS - 1);
+                            const int wq = dv::div_small<WS>(i), wr = WR0 + wq;
                             const int sy = dv::iclip(y0 + wr, 0, rh - 1);
-                            const int sx = dv::iclip(xa + (i - wr * WS), 0, rw - 1);
+                            const int sx = dv::iclip(xa + (i - wq * WS), 0, rw - 1);
                             v[e] = src[dv::mul_i24(sy & ~7, rs) + ((sx >> 3) << 6) + ((sy & 7) << 3) + (sx & 7)];
                         }
 #pragma unroll
                         for (int e = 0; e < 8; e++) {
                             const int i = i0 + e * LPT;
-                            if (i < (WR - 1) * WS) win[i] = (int16_t) v[e];
+                            if (i < WRG * WS) win[WR0 * WS + i] = (int16_t) v[e];
                         }
                     }
                 }
             } else {
             const int x0 = rf.src_x - (NARROW ? 2 : 4), y0 = rf.src_y - 3;
-            const bool interior = x0 >= 0 && y0 >= 0 && x0 + NCH * 8 <= rw && y0 + WR - 1 <= rh;
+            const bool interior = x0 >= 0 && y0 + WR0 >= 0 && x0 + NCH * 8 <= rw && y0 + WR0 + WRG <= rh;
             if (interior) {
                 // 16-byte (8-pixel) loads, rows at arbitrary 2-byte alignment; all of a lane's loads are
                 // issued before the first LDS write
@@ -238,9 +253,9 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
                 uint4 ld[NLD];
 #pragma unroll
                 for (int k = 0; k < NLD; k++) {
-                    const int i = dv::imin(l + k * LPT, (WR - 1) * NCH - 1);
-                    const int wr = dv::div_small<NCH>(i);               // row and 8-pixel piece of the window; the offset stays in 32 bits
-                    const pixel *p = base + (dv::mul_i24(wr, rs) + 8 * (i - wr * NCH));
+                    const int i = dv::imin(l + k * LPT, WRG * NCH - 1);
+                    const int wq = dv::div_small<NCH>(i), wr = WR0 + wq;      // row and 8-pixel piece of the window; the offset stays in 32 bits
+                    const pixel *p = base + (dv::mul_i24(wr, rs) + 8 * (i - wq * NCH));
                     ld[k] = make_uint4(0, 0, 0, 0);
                     if (wr < row_lo || wr >= row_hi) continue;
                     if (HBD) {
@@ -256,31 +271,31 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
 #pragma unroll
                 for (int k = 0; k < NLD; k++) {
                     const int i = l + k * LPT;
-                    if (i >= (WR - 1) * NCH) continue;
-                    const int wr = dv::div_small<NCH>(i);
-                    int16_t *const wp = win + wr * WS + 8 * (i - wr * NCH);
+                    if (i >= WRG * NCH) continue;
+                    const int wq = dv::div_small<NCH>(i), wr = WR0 + wq;
+                    int16_t *const wp = win + wr * WS + 8 * (i - wq * NCH);
                     if (WS % 8 == 0) {
                         *reinterpret_cast<uint4 *>(wp) = ld[k];
                     } else {        // 12-column rows: 8-byte stores, the last chunk keeps only its first half
                         *reinterpret_cast<uint2 *>(wp) = make_uint2(ld[k].x, ld[k].y);
-                        if (8 * (i - wr * NCH) + 8 <= WS) *reinterpret_cast<uint2 *>(wp + 4) = make_uint2(ld[k].z, ld[k].w);
+                        if (8 * (i - wq * NCH) + 8 <= WS) *reinterpret_cast<uint2 *>(wp + 4) = make_uint2(ld[k].z, ld[k].w);
                     }
                 }
             } else {
                 // edge emulation: per-pixel clamped fetch, 8 independent loads in flight per lane
-                for (int i0 = l; i0 < (WR - 1) * WS; i0 += 8 * LPT) {
+                for (int i0 = l; i0 < WRG * WS; i0 += 8 * LPT) {
                     pixel v[8];
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
-                        const int i = dv::imin(i0 + e * LPT, (WR - 1) * WS - 1);
-                        const int sy = dv::iclip(y0 + i / WS, 0, rh - 1);
+                        const int i = dv::imin(i0 + e * LPT, WRG * WS - 1);
+                        const int sy = dv::iclip(y0 + WR0 + i / WS, 0, rh - 1);
                         const int sx = dv::iclip(x0 + i % WS, 0, rw - 1);
                         v[e] = src[sy * rs + sx];
                     }
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
                         const int i = i0 + e * LPT;
-                        if (i < (WR - 1) * WS) win[i] = (int16_t) v[e];
+                        if (i < WRG * WS) win[WR0 * WS + i] = (int16_t) v[e];
                     }
                 }
             }
