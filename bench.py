@@ -1354,6 +1354,18 @@ def run_job(a, rank, local, world):
                 raise SystemExit("bench: the dav1d task loop leg differs from dav1d's own pass 2 + filters: %s" % e)
             except Exception as e:       # noqa: BLE001  (a reported extra)
                 task_loop = {"error": str(e)[:200]}
+        # ---- --gpus N: dav1d is ONE process — the same chain with the binding's frames ending on N devices of one process in turn
+        # (Dav1dHipGlueOptions.n_devices; a reference of another device is copied over first), next to one device, in a child process
+        task_loop_n = None
+        if world > 1 and not a.no_e2e and not a.no_check and not a.emu:
+            import subprocess
+            try:
+                child = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "task_loop_n_devices.py"), str(world),
+                                        "--width", str(w), "--height", str(h), "--bpc", str(bpc), "--frames", "16"], capture_output=True, text=True, timeout=900)
+                last = child.stdout.strip().splitlines()[-1] if child.stdout.strip() else ""
+                task_loop_n = json.loads(last) if child.returncode == 0 and last.startswith("{") else {"error": "rc %d: %s" % (child.returncode, child.stderr[-160:])}
+            except Exception as e:       # noqa: BLE001  (a reported extra)
+                task_loop_n = {"error": str(e)[:200]}
         # ---- ... and behind dav1d's REAL pass 1: an AV1 stream (tests/av1_obu.py: real headers, every tool, random tile payloads) through
         # dav1d_send_data / dav1d_parse_obus / msac / decode_b unmodified; EVERY picture of the chain compared with dav1d's own
         task_loop_stream = None
@@ -1414,7 +1426,7 @@ def run_job(a, rank, local, world):
                           "coef_bytes_per_frame": int(coef_host.nbytes), "coef_h2d_ms_per_frame": h2d_ms,
                           "samples_per_frame": frame.n_samples, "parity": check, "gen_seconds": round(t_gen, 1)},
                "roofline": roof, "cpu_baseline": cpu, "full_table": full, "end_to_end": e2e_leg, "all_intra": key_leg, "end_to_end_packing_lister": e2e_packed, "all_intra_packing_lister": key_packed, "end_to_end_full_table": full_route, "end_to_end_4_tile_columns": e2e_c2, "end_to_end_full_table_4_tile_columns": full_route_c2,
-               "end_to_end_frames_in_flight": sustained, "row_progress": row_progress, "refmvs": refmvs_leg, "dav1d_task_loop": task_loop, "dav1d_task_loop_real_pass1": task_loop_stream, "config_c0_1080p_8bit": c0,
+               "end_to_end_frames_in_flight": sustained, "row_progress": row_progress, "refmvs": refmvs_leg, "dav1d_task_loop": task_loop, "dav1d_task_loop_n_gpus": task_loop_n, "dav1d_task_loop_real_pass1": task_loop_stream, "config_c0_1080p_8bit": c0,
                "device": None if a.no_check else device_probe(torch)}       # (not under the profiler: its copies would sit in the kernel statistics)
         # BASELINE configs[1] (4K 8-bit, the reference's CPU-runnable size) next to the headline: the same bench in a child process,
         # its digest under "config_c1_4k_8bit"

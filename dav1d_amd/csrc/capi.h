@@ -381,6 +381,7 @@ extern "C" int dav1d_hip_launch_emu_edge(void *dst, ptrdiff_t dst_stride, const 
 extern "C" { extern long long dav1d_hip_live[8]; }      // objects alive by kind (dav1d_hip_live_objects)
 Dav1dHipContext *dav1d_hip_default_context(void);
 // a picture for a frame's own use from the context's pool (zeroed like a fresh one) / back to it
+extern "C" int pictures_on_device(const Dav1dHipContext *c, const Dav1dHipPicture *pics, int n);       // capi.hip: 0, or -EXDEV with several devices
 extern "C" int dav1d_hip_picture_take(Dav1dHipContext *c, Dav1dHipPicture *pic, int w, int h, int layout, int bpc);
 extern "C" void dav1d_hip_picture_give(Dav1dHipContext *c, Dav1dHipPicture *pic);
 // the intra wavefront list with the blends of inter-intra blocks (frame driver)

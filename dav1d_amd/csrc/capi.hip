@@ -486,6 +486,72 @@ int dav1d_hip_picture_free(Dav1dHipContext *c, Dav1dHipPicture *pic) {
     return rc;
 }
 
+// ---- more than one device in a process (dav1d is ONE process with n_fc frame contexts: the binding ends frame context k's frames on device
+// k mod N, dav1d_amd/host/dav1d_glue.c).  The current device is a property of the calling THREAD in HIP: a thread that serves contexts of
+// several devices says which one it means before it calls in.
+int dav1d_hip_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : -ENODEV;
+}
+int dav1d_hip_context_device(const Dav1dHipContext *c) { return c ? c->device : -EINVAL; }
+int dav1d_hip_context_use(Dav1dHipContext *c) {
+    if (!c) return -EINVAL;
+    return hipSetDevice(c->device) == hipSuccess ? 0 : -ENODEV;
+}
+// the device a picture's planes live on (-EINVAL: not device memory the runtime knows)
+int dav1d_hip_picture_device(const Dav1dHipPicture *pic) {
+    if (!pic) return -EINVAL;
+    const void *p = pic->twin_ok == DAV1D_HIP_TWIN_ONLY && pic->twin[0] ? pic->twin[0] : pic->p[0].data;
+    hipPointerAttribute_t a;
+    if (!p || hipPointerGetAttributes(&a, p) != hipSuccess || a.type != hipMemoryTypeDevice) { (void) hipGetLastError(); return -EINVAL; }
+    return a.device;
+}
+// with more than one device: are these pictures where context c can launch on them?  (-EXDEV names the first that is not)
+int pictures_on_device(const Dav1dHipContext *c, const Dav1dHipPicture *pics, int n) {
+    static const int n_dev = dav1d_hip_device_count();
+    if (n_dev <= 1) return 0;
+    for (int i = 0; i < n; i++) {
+        if (!pics[i].p[0].data) continue;
+        const int d = dav1d_hip_picture_device(&pics[i]);
+        if (d >= 0 && d != c->device) return -EXDEV;
+    }
+    return 0;
+}
+// `dst` (a picture of dst_c's device with src's geometry: dav1d_hip_picture_alloc under the same ref_twin option) becomes a copy of `src`
+// (src_c's device): the raster planes unless src lives in its twin only, the twin when src has a valid one and dst the storage.  The copy is
+// enqueued on dst_c's stream behind everything src_c's stream holds now (an event across the devices), over xGMI when the devices are peers
+// (hipMemcpyPeerAsync stages through the host when they are not): a launch of dst_c that follows reads the copy.
+int dav1d_hip_picture_copy_peer(Dav1dHipContext *dst_c, Dav1dHipPicture *dst, Dav1dHipContext *src_c, const Dav1dHipPicture *src) {
+    if (!dst_c || !dst || !src_c || !src || !dst->p[0].data || !src->p[0].data) return -EINVAL;
+    if (dst->bpc != src->bpc || dst->layout != src->layout) return -EINVAL;
+    for (int pl = 0; pl < 3; pl++)
+        if (dst->p[pl].w != src->p[pl].w || dst->p[pl].h != src->p[pl].h || dst->p[pl].stride != src->p[pl].stride || !dst->p[pl].data != !src->p[pl].data) return -EINVAL;
+    const bool twin = src->twin_ok && src->twin[0] && dst->twin[0];
+    if (src->twin_ok == DAV1D_HIP_TWIN_ONLY && !twin) return -EINVAL;
+    // behind the source's work
+    // (an event of this call's own: several devices may be copying from one source at a time, and src_c's thread goes on enqueuing.  A twin
+    // made by dav1d_hip_picture_retile_overlapped is on a side stream: its maker waits for it — dav1d_hip_sync — before handing it out.)
+    hipEvent_t ev;
+    if (hipSetDevice(src_c->device) != hipSuccess) return -ENODEV;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, src_c->stream);
+    if (hipSetDevice(dst_c->device) != hipSuccess) { (void) hipEventDestroy(ev); return -ENODEV; }
+    if (e == hipSuccess) e = hipStreamWaitEvent(dst_c->stream, ev, 0);
+    (void) hipEventDestroy(ev);             // (released once the wait has passed it)
+    HIP_TRY(e);
+    const bool padded = src->alloc != nullptr && dst->alloc != nullptr;
+    for (int pl = 0; pl < 3; pl++) {
+        if (!src->p[pl].data) continue;
+        const size_t bytes = (size_t) src->p[pl].stride * (size_t) picture_plane_rows(src, pl, padded);
+        if (src->twin_ok != DAV1D_HIP_TWIN_ONLY)
+            HIP_TRY(hipMemcpyPeerAsync(dst->p[pl].data, dst_c->device, src->p[pl].data, src_c->device, bytes, dst_c->stream));
+        if (twin)
+            HIP_TRY(hipMemcpyPeerAsync(dst->twin[pl], dst_c->device, src->twin[pl], src_c->device, bytes, dst_c->stream));
+    }
+    dst->twin_ok = twin ? src->twin_ok : 0;
+    return 0;
+}
+
 static void plane_extent(const Dav1dHipPicture *pic, int plane, int padded, size_t *row_bytes, int *rows) {
     const int bps = pic->bpc > 8 ? 2 : 1;
     if (padded) {

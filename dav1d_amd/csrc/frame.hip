@@ -373,6 +373,10 @@ int dav1d_hip_frame_begin(Dav1dHipContext *c, Dav1dHipFrame **out, const Dav1dHi
     if (!c || !out || !cur || n_refs < 0 || n_refs > 8 || (n_refs && !refs)) return -EINVAL;
     *out = nullptr;
     for (int i = 0; i < n_refs; i++) if (refs[i].bpc != cur->bpc || refs[i].layout != cur->layout) return -EINVAL;
+    // several devices in the process: the frame's own picture is on the context's device (its references are looked at when the frame ends:
+    // a caller may only know their geometry yet)
+    if (pictures_on_device(c, cur, 1)) return -EXDEV;
+    (void) hipSetDevice(c->device);
     Dav1dHipFrame *f = new (std::nothrow) Dav1dHipFrame();
     if (!f) return -ENOMEM;
     __atomic_fetch_add(&dav1d_hip_live[1], 1, __ATOMIC_RELAXED);       // (every way out from here goes through dav1d_hip_frame_destroy or hands the frame over)
@@ -1194,7 +1198,9 @@ int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *ma
     Dav1dHipContext *c = f->c;
     // the multi-stream sections below use the context's side streams and events: one frame (or list run) at a time per context
     std::lock_guard<std::mutex> run_lk(c->run_mtx);
-    const int rc_run = frame_run(f, coef, prep, mask, filtered, grain_out);
+    (void) hipSetDevice(c->device);
+    // several devices in the process: a reference that lives on another one has to be made resident here first (dav1d_hip_picture_copy_peer)
+    const int rc_run = pictures_on_device(c, f->refs, f->n_refs) ? -EXDEV : frame_run(f, coef, prep, mask, filtered, grain_out);
     // the frame has synchronised (or failed): the pinned chunk blobs go back to the context's pool
     (void) hipStreamSynchronize(c->copy_stream);
     for (Dav1dHipChunk *ck : f->chunks) { ck->release(c); delete ck; }

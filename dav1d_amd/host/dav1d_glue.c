@@ -10,6 +10,11 @@
  *     stage 2 (oldest first among the frames whose references have ENDED: where a reference's final pixels are is known then)
  *                           dav1d_hip_frame_set_refs / _set_filters / dav1d_hip_frame_end; rows go to progress[1] as they become final
  *     stage 3               the picture to the host planes the application sees, then dav1d_hip_frame_done: dav1d_decode_frame_exit
+ * Several devices (option n_devices = N): a picture is allocated on device (allocation number mod N) — dav1d allocates one per frame, in
+ * frame order, so with n_fc a multiple of N frame context k always lands on device k mod N — and its frame ends THERE: every device has its
+ * three contexts and its three stage threads.  A reference that lives on another device is made resident first (a mirror picture on the
+ * reading device, dav1d_hip_picture_copy_peer: xGMI between peers), once per picture and reading device.  Frames that do not predict from
+ * each other (key frames, the layers of a pyramid) end side by side on different devices; a chain of inter frames ends in turn, as on one.
  * The hooks carry no user pointer: one glue per process at a time (g_glue). */
 #include "config.h"
 #include <dlfcn.h>
@@ -62,6 +67,9 @@ typedef struct Hip {
     int (*plane_download)(Dav1dHipContext *, const Dav1dHipPicture *, int, void *, ptrdiff_t, int);
     int (*frame_set_progress_callback)(Dav1dHipFrame *, void (*)(void *, int, const Dav1dHipPicture *), void *);
     int (*live_objects)(long long *);
+    int (*device_count)(void);
+    int (*use)(Dav1dHipContext *);
+    int (*picture_copy_peer)(Dav1dHipContext *, Dav1dHipPicture *, Dav1dHipContext *, const Dav1dHipPicture *);
 } Hip;
 
 /* per frame context */
@@ -72,16 +80,26 @@ typedef struct FcState {
     Dav1dHipLister *lister;
     atomic_int *filter_listed;   /* [sby]: the filter tasks of the row are listed */
     int sbh_cap;
-    void *coef, *lvl, *prep, *mask;
-    size_t coef_cap, lvl_cap, prep_cap, mask_cap;
+    int dev;                     /* the device the frame ends on: its picture's */
+    struct FcBufs {              /* device buffers of the frame context, per device it has had frames on */
+        void *coef, *lvl, *prep, *mask, *pal_idx;
+        size_t coef_cap, lvl_cap, prep_cap, mask_cap, pal_idx_cap;
+    } b[DAV1D_HIP_GLUE_MAX_DEVICES];
     /* the frame's way through the three stage threads: 0 idle, 1 tasks through, 2 uploaded (or failed), 3 ended */
     Dav1dFrameContext *q_f;
     int q_state, q_rc;
     uint64_t q_arrival;
     Dav1dHipPicture q_filtered;
-    void *pal_idx;               /* device copy of f->frame_thread.pal_idx (palette frames) */
-    size_t pal_idx_cap;
 } FcState;
+
+/* a device: the context frames begin, end and are fetched on, one for uploads and one for output work (streams of their own), three stage threads */
+typedef struct Dev {
+    Dav1dHipContext *ctx, *ctx_up, *ctx_out;
+    pthread_t thread[3];
+    int have_threads;
+    void *targ[3][3];
+    atomic_int n_frames, n_peer_copies;
+} Dev;
 
 /* a frame ends badly because a frame it predicts from did: dav1d's error (DAV1D_ERR(EINVAL), as check_tile makes it), not the backend's */
 #define GLUE_REF_FAILED (-1000)
@@ -89,13 +107,12 @@ typedef struct FcState {
 struct Dav1dHipGlue {
     Dav1dHipGlueOptions o;
     Hip hip;
-    Dav1dHipContext *ctx, *ctx_up, *ctx_out;
+    Dev dev[DAV1D_HIP_GLUE_MAX_DEVICES];
+    int n_dev;
+    unsigned alloc_seq;
     Dav1dContext *c;
     unsigned n_fc;
     FcState *fcs;
-    pthread_t up_thread, gpu_thread, out_thread;
-    int have_threads;
-    void *targ[3][2];
     pthread_mutex_t q_mtx;
     pthread_cond_t q_cond;
     uint64_t q_arrivals;
@@ -167,21 +184,24 @@ static int glue_alloc_picture(Dav1dPicture *const p, void *const cookie) {
     const double t0 = now_s();
     Dav1dHipGluePicture *hp = NULL;
     pthread_mutex_lock(&g->pic_mtx);
+    const int dev = (int) (g->alloc_seq++ % (unsigned) g->n_dev);
     for (int i = 0; i < g->n_free_pics; i++) {
         const Dav1dHipPicture *const d = &g->free_pics[i]->hp.dev;
-        if (d->p[0].w == p->p.w && d->p[0].h == p->p.h && d->layout == (int) p->p.layout && d->bpc == p->p.bpc) {
+        if (g->free_pics[i]->dev == dev && d->p[0].w == p->p.w && d->p[0].h == p->p.h && d->layout == (int) p->p.layout && d->bpc == p->p.bpc) {
             hp = g->free_pics[i];
             g->free_pics[i] = g->free_pics[--g->n_free_pics];
             break;
         }
     }
     pthread_mutex_unlock(&g->pic_mtx);
-    int rc = 0;
-    if (hp) rc = g->hip.memset_(g->ctx, hp->hp.dev.alloc, 0, hp->hp.dev.alloc_size);       /* as a fresh one: zero, padding included */
+    Dav1dHipContext *const ctx = g->dev[dev].ctx;
+    int rc = g->hip.use(ctx);
+    if (hp && !rc) rc = g->hip.memset_(ctx, hp->hp.dev.alloc, 0, hp->hp.dev.alloc_size);       /* as a fresh one: zero, padding included */
     if (!hp) {
         hp = calloc(1, sizeof(*hp));
         if (!hp) return DAV1D_ERR(ENOMEM);
-        rc = g->hip.host_picture_alloc(g->ctx, &hp->hp, p->p.w, p->p.h, p->p.layout, p->p.bpc);   /* layouts share their values */
+        hp->dev = dev;
+        if (!rc) rc = g->hip.host_picture_alloc(ctx, &hp->hp, p->p.w, p->p.h, p->p.layout, p->p.bpc);   /* layouts share their values */
     }
     stat_add(g, DAV1D_HIP_GLUE_STAT_PICTURE_ALLOC, t0);
     if (rc) { free(hp); return DAV1D_ERR(ENOMEM); }
@@ -189,27 +209,39 @@ static int glue_alloc_picture(Dav1dPicture *const p, void *const cookie) {
     p->stride[0] = hp->hp.stride[0]; p->stride[1] = hp->hp.stride[1];
     p->allocator_data = hp;
     hp->ref = hp->hp.dev;
+    hp->ref_dev = hp->dev;
+    memset(hp->mirror_ok, 0, sizeof(hp->mirror_ok));
     atomic_store(&hp->final, 0);
     return 0;
+}
+static void free_mirrors(Dav1dHipGlue *const g, Dav1dHipGluePicture *const hp) {
+    for (int d = 0; d < g->n_dev; d++)
+        if (hp->mirror[d].alloc || hp->mirror[d].twin_alloc) { (void) g->hip.use(g->dev[d].ctx); g->hip.picture_free(g->dev[d].ctx, &hp->mirror[d]); }
 }
 static void glue_release_picture(Dav1dPicture *const p, void *const cookie) {
     Dav1dHipGlue *const g = cookie;
     Dav1dHipGluePicture *const hp = p->allocator_data;
     const double t0 = now_s();
+    (void) g->hip.use(g->dev[hp->ref_dev].ctx);
     if (hp->frame) g->hip.frame_destroy(hp->frame);
     hp->frame = NULL;
     hp->ref = hp->hp.dev;
+    hp->ref_dev = hp->dev;
     hp->ref.twin_ok = hp->hp.dev.twin_ok = 0;
+    memset(hp->mirror_ok, 0, sizeof(hp->mirror_ok));          /* (the mirrors' storage stays with the picture while it is pooled) */
     pthread_mutex_lock(&g->pic_mtx);
     if (!g->closing && g->n_free_pics < 32) { g->free_pics[g->n_free_pics++] = hp; pthread_mutex_unlock(&g->pic_mtx); stat_add(g, DAV1D_HIP_GLUE_STAT_PICTURE_RELEASE, t0); return; }
     pthread_mutex_unlock(&g->pic_mtx);
-    g->hip.host_picture_release(g->ctx, &hp->hp);
+    free_mirrors(g, hp);
+    (void) g->hip.use(g->dev[hp->dev].ctx);
+    g->hip.host_picture_release(g->dev[hp->dev].ctx, &hp->hp);
     free(hp);
     stat_add(g, DAV1D_HIP_GLUE_STAT_PICTURE_RELEASE, t0);
 }
 
 /* ------------------------------------------------------------------------------------------------ worker-thread side */
 static void drop_frame_objects(Dav1dHipGlue *const g, FcState *const s) {
+    if (s->lister || s->frame) (void) g->hip.use(g->dev[s->dev].ctx);
     if (s->lister) g->hip.lister_destroy(s->lister);
     if (s->frame) g->hip.frame_destroy(s->frame);
     s->lister = NULL; s->frame = NULL;
@@ -220,6 +252,7 @@ static void once_per_row(const Dav1dFrameContext *const f, const int sby) {
     FcState *const s = state_of(f);
     if (atomic_exchange(&s->filter_listed[sby], 1)) return;
     const double t0 = now_s();
+    (void) g->hip.use(g->dev[s->dev].ctx);
     const int rc = g->hip.lister_filter_sbrow(s->lister, &s->fd, sby);     /* instead of filter_sbrow* */
     if (rc) {
         /* the filter tasks return void (src/recon.h:47-53): the frame is marked the way a failed allocation marks it (src/thread_task.c:459-469) */
@@ -232,13 +265,13 @@ static void once_per_row(const Dav1dFrameContext *const f, const int sby) {
 static void filter_f(Dav1dFrameContext *const f, const int sby) { once_per_row(f, sby); }
 static void filter_t(Dav1dTaskContext *const tc, const int sby) { once_per_row(tc->f, sby); }
 
-static int grow(Dav1dHipGlue *const g, void **const p, size_t *const cap, const size_t bytes) {
+static int grow(Dav1dHipGlue *const g, Dav1dHipContext *const ctx, void **const p, size_t *const cap, const size_t bytes) {
     if (*cap >= bytes) return 0;
-    if (*p) g->hip.free_(g->ctx, *p);
+    if (*p) g->hip.free_(ctx, *p);
     *p = NULL; *cap = 0;
     size_t want = 1 << 16;
     while (want < bytes) want <<= 1;
-    const int rc = g->hip.malloc_(g->ctx, p, want);
+    const int rc = g->hip.malloc_(ctx, p, want);
     if (!rc) *cap = want;
     return rc;
 }
@@ -251,10 +284,13 @@ int dav1d_hip_glue_frame_init(Dav1dFrameContext *const f) {
     drop_frame_objects(g, s);
     dav1d_hip_glue_frame_desc(&s->desc, f);
     Dav1dHipGluePicture *const cur = f->cur.allocator_data;        /* the picture of the CODED size (f->sr_cur's is the upscaled one under super-resolution) */
+    s->dev = cur->dev;                                             /* the frame ends where its picture lives */
+    Dav1dHipContext *const ctx = g->dev[s->dev].ctx;
+    (void) g->hip.use(ctx);
     Dav1dHipPicture refs[7];
     const int n_refs = IS_INTER_OR_SWITCH(fh) ? 7 : 0;
     for (int i = 0; i < n_refs; i++) refs[i] = ((Dav1dHipGluePicture *) f->refp[i].p.allocator_data)->hp.dev;     /* geometry; the final ones at the end */
-    int rc = g->hip.frame_begin(g->ctx, &s->frame, &cur->hp.dev, refs, n_refs);
+    int rc = g->hip.frame_begin(ctx, &s->frame, &cur->hp.dev, refs, n_refs);
     if (g->o.pack) s->desc.cf = f->frame_thread.cf;
     if (!rc) rc = g->hip.lister_create(&s->lister, &s->desc, s->frame);
     if (!rc && fh->width[0] != fh->width[1]) rc = g->hip.frame_set_super_res(s->frame, f->sr_cur.p.p.w);
@@ -297,6 +333,7 @@ int dav1d_hip_glue_recon_tile_sbrow(Dav1dTaskContext *const t) {
     Dav1dHipGlue *const g = g_glue;
     const Dav1dFrameContext *const f = t->f;
     const double t0 = now_s();
+    (void) g->hip.use(g->dev[state_of(f)->dev].ctx);
     const int rc = g->hip.lister_tile_sbrow(state_of(f)->lister, t->ts->tiling.row, t->ts->tiling.col, t->by >> f->sb_shift);
     stat_add(g, DAV1D_HIP_GLUE_STAT_LISTING, t0);
     if (rc) {
@@ -326,30 +363,32 @@ const Dav1dHooks dav1d_hip_glue_hooks = { dav1d_hip_glue_frame_init, glue_entrop
 static int stage_upload(Dav1dHipGlue *const g, Dav1dFrameContext *const f) {
     FcState *const s = state_of(f);
     const Hip *const hip = &g->hip;
+    Dev *const dv = &g->dev[s->dev];
+    struct FcBufs *const b = &s->b[s->dev];
     const size_t cf_bytes = (size_t) f->frame_thread.cf_sz * 128 * 128 / 2;
     const size_t lvl_bytes = sizeof(*f->lf.level) * (size_t) f->sb128w * f->sb128h * 32 * 32;
     const size_t pal_idx_bytes = f->frame_hdr->allow_screen_content_tools ? (size_t) f->frame_thread.pal_idx_sz * 128 * 128 / 8 : 0;
     size_t n_const = 0;
     const uint8_t *const blob = hip->lister_const_masks(&n_const);
     const double t0 = now_s();
-    int rc = g->o.pack ? 0 : grow(g, &s->coef, &s->coef_cap, cf_bytes + 64);
-    if (!rc) rc = grow(g, &s->lvl, &s->lvl_cap, lvl_bytes + 64);
-    if (!rc) rc = grow(g, &s->prep, &s->prep_cap, hip->lister_prep_elems(s->lister) * 2 + 4096);
-    const size_t mask_cap_before = s->mask_cap;
-    if (!rc) rc = grow(g, &s->mask, &s->mask_cap, hip->lister_mask_bytes(s->lister) + 4096);
-    if (!rc && s->mask_cap != mask_cap_before) rc = hip->upload(g->ctx_up, s->mask, blob, n_const);
+    int rc = g->o.pack ? 0 : grow(g, dv->ctx, &b->coef, &b->coef_cap, cf_bytes + 64);
+    if (!rc) rc = grow(g, dv->ctx, &b->lvl, &b->lvl_cap, lvl_bytes + 64);
+    if (!rc) rc = grow(g, dv->ctx, &b->prep, &b->prep_cap, hip->lister_prep_elems(s->lister) * 2 + 4096);
+    const size_t mask_cap_before = b->mask_cap;
+    if (!rc) rc = grow(g, dv->ctx, &b->mask, &b->mask_cap, hip->lister_mask_bytes(s->lister) + 4096);
+    if (!rc && b->mask_cap != mask_cap_before) rc = hip->upload(dv->ctx_up, b->mask, blob, n_const);
     if (!rc && !g->o.pack) {
-        rc = hip->upload(g->ctx_up, s->coef, f->frame_thread.cf, cf_bytes);
+        rc = hip->upload(dv->ctx_up, b->coef, f->frame_thread.cf, cf_bytes);
         /* the arena has been consumed: the next frame's pass 1 finds it zero, as after the reference's inverse transforms
          * (src/itx_tmpl.c:60,108).  (The packing lister does that itself, block by block.) */
         if (!g->o.keep_cf) memset(f->frame_thread.cf, 0, cf_bytes);
     }
-    if (!rc) rc = hip->upload(g->ctx_up, s->lvl, f->lf.level, lvl_bytes);
+    if (!rc) rc = hip->upload(dv->ctx_up, b->lvl, f->lf.level, lvl_bytes);
     if (!rc && pal_idx_bytes && f->frame_thread.pal_idx) {
         /* palette indices (pal_pred's `idx`, src/recon_tmpl.c:1207-1224): the arena PAL tasks point into */
-        rc = grow(g, &s->pal_idx, &s->pal_idx_cap, pal_idx_bytes + 64);
-        if (!rc) rc = hip->upload(g->ctx_up, s->pal_idx, f->frame_thread.pal_idx, pal_idx_bytes);
-        if (!rc) rc = hip->frame_submit_intra_step(s->frame, 0, NULL, 0, NULL, 0, s->pal_idx);
+        rc = grow(g, dv->ctx, &b->pal_idx, &b->pal_idx_cap, pal_idx_bytes + 64);
+        if (!rc) rc = hip->upload(dv->ctx_up, b->pal_idx, f->frame_thread.pal_idx, pal_idx_bytes);
+        if (!rc) rc = hip->frame_submit_intra_step(s->frame, 0, NULL, 0, NULL, 0, b->pal_idx);
     }
     stat_add(g, DAV1D_HIP_GLUE_STAT_UPLOADS, t0);
     return rc;
@@ -374,30 +413,55 @@ static void rows_final(void *const cookie, const int rows, const Dav1dHipPicture
     dav1d_hip_rows_done(f, (unsigned) rows);
 }
 
+/* where frame-ending device `d` reads the final pixels of picture `rp`: the picture itself when it lives there, else its mirror on d, filled
+ * on first use (stage 2 of a device is one thread: nobody else touches mirror[d] while the picture is referenced) */
+static int resident_ref(Dav1dHipGlue *const g, Dav1dHipGluePicture *const rp, const int d, Dav1dHipPicture *const out) {
+    if (rp->ref_dev == d) { *out = rp->ref; return 0; }
+    const Hip *const hip = &g->hip;
+    Dav1dHipPicture *const m = &rp->mirror[d];
+    if (!rp->mirror_ok[d]) {
+        const Dav1dHipPicture *const r = &rp->ref;
+        if (m->alloc && (m->p[0].w != r->p[0].w || m->p[0].h != r->p[0].h || m->layout != r->layout || m->bpc != r->bpc)) hip->picture_free(g->dev[d].ctx, m);
+        int rc = m->alloc ? 0 : hip->picture_alloc(g->dev[d].ctx, m, r->p[0].w, r->p[0].h, r->layout, r->bpc);
+        if (!rc) rc = hip->picture_copy_peer(g->dev[d].ctx, m, g->dev[rp->ref_dev].ctx, r);
+        if (rc) return rc;
+        rp->mirror_ok[d] = 1;
+        atomic_fetch_add(&g->dev[d].n_peer_copies, 1);
+    }
+    *out = *m;
+    return 0;
+}
+
 /* stage 2: "when the last task of the frame is in" */
 static int stage_end(Dav1dHipGlue *const g, Dav1dFrameContext *const f, Dav1dHipPicture *const filtered) {
     FcState *const s = state_of(f);
     Dav1dHipGluePicture *const out = f->sr_cur.p.allocator_data;     /* the picture dav1d hands on: reference and output */
     const Hip *const hip = &g->hip;
+    const struct FcBufs *const b = &s->b[s->dev];
     int rc = refs_final(f) < 0 ? GLUE_REF_FAILED : 0;
     const double t0 = now_s();
     if (g->o.frame_listed) g->o.frame_listed(g->o.cookie, f);
     if (!rc && IS_INTER_OR_SWITCH(f->frame_hdr)) {
         Dav1dHipPicture refs[7];
-        for (int i = 0; i < 7; i++) refs[i] = ((Dav1dHipGluePicture *) f->refp[i].p.allocator_data)->ref;        /* where those frames' final pixels are */
-        rc = hip->frame_set_refs(s->frame, refs, 7);
+        for (int i = 0; i < 7 && !rc; i++) {            /* where those frames' final pixels are (a slot may repeat a picture: its mirror is made once) */
+            rc = resident_ref(g, f->refp[i].p.allocator_data, s->dev, &refs[i]);
+            if (rc) fprintf(stderr, "dav1d_hip_glue: reference %d could not be made resident on device %d: %d\n", i, s->dev, rc);
+        }
+        if (!rc) rc = hip->frame_set_refs(s->frame, refs, 7);
     }
-    if (!rc) rc = hip->frame_set_filters(s->frame, s->lvl, f->b4_stride, f->lf.lim_lut.e, f->lf.lim_lut.i,
+    if (!rc) rc = hip->frame_set_filters(s->frame, b->lvl, f->b4_stride, f->lf.lim_lut.e, f->lf.lim_lut.i,
                                          f->frame_hdr->cdef.damping + f->cur.p.bpc - 8, NULL, 0);
     memset(filtered, 0, sizeof(*filtered));
     if (!rc && g->o.row_progress) rc = hip->frame_set_progress_callback(s->frame, rows_final, f);
-    if (!rc) rc = hip->frame_end(s->frame, g->o.pack ? NULL : s->coef, s->prep, s->mask, filtered, NULL);
+    if (!rc) rc = hip->frame_end(s->frame, g->o.pack ? NULL : b->coef, b->prep, b->mask, filtered, NULL);
+    atomic_fetch_add(&g->dev[s->dev].n_frames, 1);
     if (g->o.frame_end_seconds) g->o.frame_end_seconds(g->o.cookie, f, now_s() - t0);
     stat_add(g, DAV1D_HIP_GLUE_STAT_FRAME_END, t0);
     hip->lister_destroy(s->lister);
     s->lister = NULL;
     if (!rc) {
         out->ref = *filtered;                     /* later frames predict from this; the frame object lives as long as the picture */
+        out->ref_dev = s->dev;                    /* (under super-resolution the upscaled picture dav1d allocated may be another device's: the pixels are the frame's) */
         out->frame = s->frame;
     } else {
         hip->frame_destroy(s->frame);
@@ -409,9 +473,10 @@ static int stage_end(Dav1dHipGlue *const g, Dav1dFrameContext *const f, Dav1dHip
 /* stage 3: the picture to the host planes the application sees, then the frame is done as far as dav1d is concerned */
 static void stage_out(Dav1dHipGlue *const g, Dav1dFrameContext *const f, int rc, const Dav1dHipPicture *const filtered) {
     Dav1dHipGluePicture *const out = f->sr_cur.p.allocator_data;
+    Dav1dHipContext *const ctx = g->dev[state_of(f)->dev].ctx;
     const double t0 = now_s();
-    if (!rc) rc = g->hip.host_picture_fetch(g->ctx, &out->hp, filtered, 0, f->sr_cur.p.p.h);
-    if (!rc) rc = g->hip.host_picture_wait(g->ctx);
+    if (!rc) rc = g->hip.host_picture_fetch(ctx, &out->hp, filtered, 0, f->sr_cur.p.p.h);
+    if (!rc) rc = g->hip.host_picture_wait(ctx);
     stat_add(g, DAV1D_HIP_GLUE_STAT_FETCH, t0);
     if (g->o.before_frame_done) g->o.before_frame_done(g->o.cookie, f, rc);
     if (rc && rc != GLUE_REF_FAILED) {
@@ -423,9 +488,26 @@ static void stage_out(Dav1dHipGlue *const g, Dav1dFrameContext *const f, int rc,
     if (g->o.after_frame_done) g->o.after_frame_done(g->o.cookie, k);
 }
 
+/* Stage 2 of device `dev` has nothing it may end yet: is there a frame queued for this device with a reference that HAS ended, on another
+ * device, and is not resident here?  Copying it now hides the transfer behind the wait for the references that have not ended (q_mtx held). */
+static Dav1dHipGluePicture *ref_to_fetch_ahead(const Dav1dHipGlue *const g, const int dev, const Dav1dHipGluePicture *const skip) {
+    for (unsigned i = 0; i < g->n_fc; i++) {
+        const FcState *const c = &g->fcs[i];
+        if ((c->q_state != 1 && c->q_state != 2) || c->dev != dev || !IS_INTER_OR_SWITCH(c->q_f->frame_hdr)) continue;
+        for (int k = 0; k < 7; k++) {
+            Dav1dHipGluePicture *const rp = c->q_f->refp[k].p.allocator_data;
+            if (rp == skip || !atomic_load(&rp->final) || atomic_load(&c->q_f->refp[k].progress[1]) == FRAME_ERROR) continue;
+            if (rp->ref_dev != dev && !rp->mirror_ok[dev]) return rp;
+        }
+    }
+    return NULL;
+}
+
 static void *stage_thread(void *const arg) {
     Dav1dHipGlue *const g = ((void **) arg)[0];
-    const int stage = (int) (intptr_t) ((void **) arg)[1];
+    const int stage = (int) (intptr_t) ((void **) arg)[1], dev = (int) (intptr_t) ((void **) arg)[2];
+    (void) g->hip.use(g->dev[dev].ctx);          /* this thread's calls all go to one device */
+    Dav1dHipGluePicture *no_luck = NULL;          /* a reference that could not be fetched ahead: left to stage_end, which reports */
     for (;;) {
         const double t_wait = now_s();
         FcState *s = NULL;
@@ -435,11 +517,19 @@ static void *stage_thread(void *const arg) {
             s = NULL;
             for (unsigned i = 0; i < g->n_fc; i++) {
                 FcState *const c = &g->fcs[i];
-                if (c->q_state != stage || (s && s->q_arrival < c->q_arrival)) continue;
+                if (c->q_state != stage || c->dev != dev || (s && s->q_arrival < c->q_arrival)) continue;
                 if (stage == 2 && !refs_final(c->q_f)) continue;        /* its references have not all ended yet */
                 s = c;
             }
             if (s) break;
+            Dav1dHipGluePicture *const ahead = stage == 2 && g->n_dev > 1 ? ref_to_fetch_ahead(g, dev, no_luck) : NULL;
+            if (ahead) {
+                Dav1dHipPicture unused;
+                pthread_mutex_unlock(&g->q_mtx);
+                if (resident_ref(g, ahead, dev, &unused)) no_luck = ahead;
+                pthread_mutex_lock(&g->q_mtx);
+                continue;
+            }
             pthread_cond_wait(&g->q_cond, &g->q_mtx);
         }
         if (g->q_stop) { pthread_mutex_unlock(&g->q_mtx); break; }
@@ -471,21 +561,30 @@ int dav1d_hip_glue_output_with_grain(Dav1dHipGlue *const g, const Dav1dPicture *
     const int ss_hor = pic->p.layout != DAV1D_PIXEL_LAYOUT_I444;
     Dav1dHipPicture grain;
     memset(&grain, 0, sizeof(grain));
-    int rc = g->hip.picture_alloc(g->ctx_out, &grain, pic->p.w, pic->p.h, pic->p.layout, pic->p.bpc);
+    Dav1dHipContext *const ctx_out = g->dev[hp->ref_dev].ctx_out;
+    (void) g->hip.use(ctx_out);
+    int rc = g->hip.picture_alloc(ctx_out, &grain, pic->p.w, pic->p.h, pic->p.layout, pic->p.bpc);
     if (rc) return DAV1D_ERR(ENOMEM);
-    rc = g->hip.fg_apply(g->ctx_out, &grain, &hp->ref, (const Dav1dHipFilmGrainData *) &pic->frame_hdr->film_grain.data,
+    rc = g->hip.fg_apply(ctx_out, &grain, &hp->ref, (const Dav1dHipFilmGrainData *) &pic->frame_hdr->film_grain.data,
                          pic->seq_hdr->mtrx == DAV1D_MC_IDENTITY);
     for (int pl = 0; pl < n_pl && !rc; pl++) {
         const int w = pl ? (pic->p.w + ss_hor) >> ss_hor : pic->p.w;
-        rc = g->hip.plane_download(g->ctx_out, &grain, pl, dst[pl], (ptrdiff_t) w * bps, 0);
+        rc = g->hip.plane_download(ctx_out, &grain, pl, dst[pl], (ptrdiff_t) w * bps, 0);
     }
-    if (!rc) rc = g->hip.sync(g->ctx_out);
-    g->hip.picture_free(g->ctx_out, &grain);
+    if (!rc) rc = g->hip.sync(ctx_out);
+    g->hip.picture_free(ctx_out, &grain);
     return rc ? DAV1D_ERR(EIO) : 0;
 }
 
 int dav1d_hip_glue_backend_failures(const Dav1dHipGlue *const g) { return g ? atomic_load(&g->n_backend_failures) : 0; }
 int dav1d_hip_glue_row_publications(const Dav1dHipGlue *const g) { return g ? atomic_load(&g->n_row_publications) : 0; }
+int dav1d_hip_glue_devices(const Dav1dHipGlue *const g) { return g ? g->n_dev : 0; }
+int dav1d_hip_glue_device_stats(const Dav1dHipGlue *const g, const int d, int *const frames_ended, int *const peer_copies) {
+    if (!g || d < 0 || d >= g->n_dev) return DAV1D_ERR(EINVAL);
+    if (frames_ended) *frames_ended = atomic_load(&g->dev[d].n_frames);
+    if (peer_copies) *peer_copies = atomic_load(&g->dev[d].n_peer_copies);
+    return 0;
+}
 int dav1d_hip_glue_live_objects(const Dav1dHipGlue *const g, long long out[4]) { return g && g->hip.live_objects ? g->hip.live_objects(out) : DAV1D_ERR(EINVAL); }
 
 /* ------------------------------------------------------------------------------------------------ life cycle */
@@ -513,8 +612,14 @@ int dav1d_hip_glue_create(Dav1dHipGlue **const out, const Dav1dHipGlueOptions *c
     SYM(frame_submit_intra_step, "dav1d_hip_frame_submit_intra_step"); SYM(frame_set_super_res, "dav1d_hip_frame_set_super_res");
     SYM(fg_apply, "dav1d_hip_fg_apply"); SYM(picture_alloc, "dav1d_hip_picture_alloc"); SYM(picture_free, "dav1d_hip_picture_free");
     SYM(plane_download, "dav1d_hip_plane_download"); SYM(frame_set_progress_callback, "dav1d_hip_frame_set_progress_callback");
-    SYM(live_objects, "dav1d_hip_live_objects");
-    if (g->hip.open(&g->ctx, o->device, NULL) || g->hip.open(&g->ctx_up, o->device, NULL) || g->hip.open(&g->ctx_out, o->device, NULL)) goto fail;
+    SYM(live_objects, "dav1d_hip_live_objects"); SYM(device_count, "dav1d_hip_device_count"); SYM(use, "dav1d_hip_context_use");
+    SYM(picture_copy_peer, "dav1d_hip_picture_copy_peer");
+    g->n_dev = o->n_devices > 1 ? o->n_devices : 1;
+    if (g->n_dev > DAV1D_HIP_GLUE_MAX_DEVICES || o->device < 0 || o->device + g->n_dev > g->hip.device_count()) { g->n_dev = 0; goto fail; }
+    for (int d = 0; d < g->n_dev; d++) {
+        Dev *const dv = &g->dev[d];
+        if (g->hip.open(&dv->ctx, o->device + d, NULL) || g->hip.open(&dv->ctx_up, o->device + d, NULL) || g->hip.open(&dv->ctx_out, o->device + d, NULL)) goto fail;
+    }
     *out = g;
     return 0;
 fail:
@@ -539,27 +644,28 @@ int dav1d_hip_glue_attach(Dav1dHipGlue *const g, Dav1dContext *const c) {
     }
     for (unsigned i = 0; i < g->n_fc; i++) g->fcs[i].q_state = 0;
     g->q_stop = 0;
-    for (int k = 0; k < 3; k++) { g->targ[k][0] = g; g->targ[k][1] = (void *) (intptr_t) (k + 1); }
     g_glue = g;
-    if (pthread_create(&g->up_thread, NULL, stage_thread, g->targ[0])) return DAV1D_ERR(EAGAIN);
-    if (pthread_create(&g->gpu_thread, NULL, stage_thread, g->targ[1])) { g->have_threads = 1; dav1d_hip_glue_detach(g); return DAV1D_ERR(EAGAIN); }
-    if (pthread_create(&g->out_thread, NULL, stage_thread, g->targ[2])) { g->have_threads = 2; dav1d_hip_glue_detach(g); return DAV1D_ERR(EAGAIN); }
-    g->have_threads = 3;
+    for (int d = 0; d < g->n_dev; d++) {
+        Dev *const dv = &g->dev[d];
+        for (int k = 0; k < 3; k++) {
+            dv->targ[k][0] = g; dv->targ[k][1] = (void *) (intptr_t) (k + 1); dv->targ[k][2] = (void *) (intptr_t) d;
+            if (pthread_create(&dv->thread[k], NULL, stage_thread, dv->targ[k])) { dav1d_hip_glue_detach(g); return DAV1D_ERR(EAGAIN); }
+            dv->have_threads = k + 1;
+        }
+    }
     dav1d_hooks = &dav1d_hip_glue_hooks;
     return 0;
 }
 
 void dav1d_hip_glue_detach(Dav1dHipGlue *const g) {
     if (!g) return;
-    if (g->have_threads) {
-        pthread_mutex_lock(&g->q_mtx);
-        g->q_stop = 1;
-        pthread_cond_broadcast(&g->q_cond);
-        pthread_mutex_unlock(&g->q_mtx);
-        pthread_join(g->up_thread, NULL);
-        if (g->have_threads > 1) pthread_join(g->gpu_thread, NULL);
-        if (g->have_threads > 2) pthread_join(g->out_thread, NULL);
-        g->have_threads = 0;
+    pthread_mutex_lock(&g->q_mtx);
+    g->q_stop = 1;
+    pthread_cond_broadcast(&g->q_cond);
+    pthread_mutex_unlock(&g->q_mtx);
+    for (int d = 0; d < g->n_dev; d++) {
+        for (int k = 0; k < g->dev[d].have_threads; k++) pthread_join(g->dev[d].thread[k], NULL);
+        g->dev[d].have_threads = 0;
     }
     if (dav1d_hooks == &dav1d_hip_glue_hooks) dav1d_hooks = NULL;
 }
@@ -569,26 +675,38 @@ void dav1d_hip_glue_destroy(Dav1dHipGlue *const g) {
     if (!g) return;
     dav1d_hip_glue_detach(g);
     g->closing = 1;
-    for (int i = 0; i < g->n_free_pics; i++) { g->hip.host_picture_release(g->ctx, &g->free_pics[i]->hp); free(g->free_pics[i]); }
+    for (int i = 0; i < g->n_free_pics; i++) {
+        Dav1dHipGluePicture *const hp = g->free_pics[i];
+        free_mirrors(g, hp);
+        (void) g->hip.use(g->dev[hp->dev].ctx);
+        g->hip.host_picture_release(g->dev[hp->dev].ctx, &hp->hp);
+        free(hp);
+    }
     g->n_free_pics = 0;
     if (g->fcs) {
         for (unsigned i = 0; i < g->n_fc; i++) {
             FcState *const s = &g->fcs[i];
-            if (g->ctx) {
-                if (s->coef) g->hip.free_(g->ctx, s->coef);
-                if (s->lvl) g->hip.free_(g->ctx, s->lvl);
-                if (s->prep) g->hip.free_(g->ctx, s->prep);
-                if (s->mask) g->hip.free_(g->ctx, s->mask);
-                if (s->pal_idx) g->hip.free_(g->ctx, s->pal_idx);
-                drop_frame_objects(g, s);          /* frames that failed in pass 1 and were never followed by another frame on their context */
+            for (int d = 0; d < g->n_dev; d++) {
+                struct FcBufs *const b = &s->b[d];
+                Dav1dHipContext *const ctx = g->dev[d].ctx;
+                if (!ctx) continue;
+                (void) g->hip.use(ctx);
+                if (b->coef) g->hip.free_(ctx, b->coef);
+                if (b->lvl) g->hip.free_(ctx, b->lvl);
+                if (b->prep) g->hip.free_(ctx, b->prep);
+                if (b->mask) g->hip.free_(ctx, b->mask);
+                if (b->pal_idx) g->hip.free_(ctx, b->pal_idx);
             }
+            if (g->n_dev && g->dev[s->dev].ctx) drop_frame_objects(g, s);      /* frames that failed in pass 1 and were never followed by another frame on their context */
             free(s->filter_listed);
         }
         free(g->fcs);
     }
-    if (g->ctx_out) g->hip.close(g->ctx_out);
-    if (g->ctx_up) g->hip.close(g->ctx_up);
-    if (g->ctx) g->hip.close(g->ctx);
+    for (int d = 0; d < DAV1D_HIP_GLUE_MAX_DEVICES; d++) {
+        if (g->dev[d].ctx_out) g->hip.close(g->dev[d].ctx_out);
+        if (g->dev[d].ctx_up) g->hip.close(g->dev[d].ctx_up);
+        if (g->dev[d].ctx) g->hip.close(g->dev[d].ctx);
+    }
     if (g->hip.dl) dlclose(g->hip.dl);
     pthread_mutex_destroy(&g->q_mtx);
     pthread_mutex_destroy(&g->pic_mtx);

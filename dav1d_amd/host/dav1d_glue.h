@@ -7,7 +7,7 @@
  * points the hooks here and compares every picture with dav1d's own.
  *
  *   Dav1dSettings s; dav1d_default_settings(&s);
- *   dav1d_hip_glue_create(&g, &opts);            // dlopen("libdav1d_hip.so"), three device contexts
+ *   dav1d_hip_glue_create(&g, &opts);            // dlopen("libdav1d_hip.so"), three device contexts per device (opts.n_devices)
  *   dav1d_hip_glue_settings(g, &s);              // Dav1dPicAllocator on pinned host planes + device pictures
  *   dav1d_open(&c, &s);
  *   dav1d_hip_glue_attach(g, c);                 // per-frame-context state, the three stage threads, dav1d_hooks = the glue's
@@ -33,6 +33,7 @@
 #include "dav1d_hip.h"
 
 typedef struct Dav1dHipGlue Dav1dHipGlue;
+#define DAV1D_HIP_GLUE_MAX_DEVICES 8
 
 /* what the glue hangs on a Dav1dPicture (Dav1dPicture.allocator_data) */
 typedef struct Dav1dHipGluePicture {
@@ -40,11 +41,16 @@ typedef struct Dav1dHipGluePicture {
     Dav1dHipFrame *frame;        /* the frame that produced the picture: owns `ref` when that is not hp.dev */
     Dav1dHipPicture ref;         /* where the final pixels are on the device: what later frames predict from */
     atomic_int final;            /* the frame that produced the picture has ended (well or badly): `ref` is settled */
+    int dev, ref_dev;            /* index (from Dav1dHipGlueOptions.device) of the device hp was made on / the one `ref` lives on */
+    Dav1dHipPicture mirror[DAV1D_HIP_GLUE_MAX_DEVICES];   /* `ref` once more on the other devices that end frames predicting from it */
+    uint8_t mirror_ok[DAV1D_HIP_GLUE_MAX_DEVICES];
 } Dav1dHipGluePicture;
 
 typedef struct Dav1dHipGlueOptions {
     const char *hip_lib;         /* path of libdav1d_hip.so */
-    int device;
+    int device;                  /* the first device */
+    int n_devices;               /* 0 / 1: that device only; N: devices device .. device + N - 1 — frame k's picture is allocated on device k mod N and
+                                    the frame ends there; a reference that lives elsewhere is copied over first (dav1d_hip_picture_copy_peer) */
     int pack;                    /* 1: the lister packs the coefficients (Dav1dHipFrameDesc.cf = f->frame_thread.cf): what exists travels with the
                                     frame's lists, cf is left zero as the reference's inverse transforms leave it; 0: the dense arena is uploaded */
     int free_listing;            /* 1: a frame is listed without waiting for the rows of its references (the pixels are read when the frame ends,
@@ -87,6 +93,9 @@ int dav1d_hip_glue_output_with_grain(Dav1dHipGlue *g, const Dav1dPicture *pic, u
 
 int dav1d_hip_glue_backend_failures(const Dav1dHipGlue *g);    /* frames that failed INSIDE the backend (not: frames dav1d rejects) */
 int dav1d_hip_glue_row_publications(const Dav1dHipGlue *g);
+int dav1d_hip_glue_devices(const Dav1dHipGlue *g);
+/* device d (0 .. devices - 1): frames that ended on it, reference pictures copied TO it from another device */
+int dav1d_hip_glue_device_stats(const Dav1dHipGlue *g, int d, int *frames_ended, int *peer_copies);
 /* objects of libdav1d_hip alive (dav1d_hip_live_objects): contexts, frames, listers, host pictures */
 int dav1d_hip_glue_live_objects(const Dav1dHipGlue *g, long long out[4]);
 #endif

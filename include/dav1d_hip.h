@@ -136,6 +136,20 @@ typedef struct Dav1dHipPicture {
  * pictures.  For callers that must prove they do not leak on their error paths (a frame context of dav1d that fails in pass 1 drops its
  * frame and lister without ever ending the frame: reference src/decode.c:3242-3251). */
 DAV1D_HIP_API int dav1d_hip_live_objects(long long out[4]);
+/* ---- several devices in ONE process.  dav1d is one process with n_fc frame contexts (reference src/internal.h:354-388); its binding
+ * (dav1d_amd/host/dav1d_glue.c, option n_devices) ends the frames of frame context k on device k mod N and makes a reference resident
+ * where it is read.  A context belongs to the device it was opened on.  HIP's current device is a property of the calling thread: a
+ * thread that serves contexts of several devices calls dav1d_hip_context_use before it calls in with one of them (dav1d_hip_open,
+ * dav1d_hip_frame_begin, dav1d_hip_frame_end and dav1d_hip_picture_copy_peer do so themselves).
+ * dav1d_hip_picture_copy_peer: `dst` (dst_c's device; same geometry and strides: dav1d_hip_picture_alloc under the same ref_twin
+ * option) becomes a copy of `src` (src_c's device) — the raster planes unless src lives in its twin only, the twin when src has a valid
+ * one and dst the storage — enqueued on dst_c's stream behind what src_c's stream holds at the call, hipMemcpyPeerAsync (xGMI between
+ * peers).  dav1d_hip_frame_begin / _end answer -EXDEV for a picture that lives on another device than their context. */
+DAV1D_HIP_API int dav1d_hip_device_count(void);
+DAV1D_HIP_API int dav1d_hip_context_device(const Dav1dHipContext *c);
+DAV1D_HIP_API int dav1d_hip_context_use(Dav1dHipContext *c);
+DAV1D_HIP_API int dav1d_hip_picture_device(const Dav1dHipPicture *pic);
+DAV1D_HIP_API int dav1d_hip_picture_copy_peer(Dav1dHipContext *dst_c, Dav1dHipPicture *dst, Dav1dHipContext *src_c, const Dav1dHipPicture *src);
 DAV1D_HIP_API int dav1d_hip_picture_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic,
                                           int w, int h, int layout, int bpc);
 DAV1D_HIP_API int dav1d_hip_picture_free(Dav1dHipContext *c, Dav1dHipPicture *pic);

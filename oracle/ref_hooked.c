@@ -73,6 +73,7 @@ typedef struct HookedParams {
                                   dav1d returns, frame_hdr->film_grain.data), as GPU video outputs do */
     int filters_off;           /* in-loop filters the "application" switches off, both modes: Dav1dSettings.inloop_filters = ALL & ~filters_off
                                   (bit 0 deblock, 1 CDEF, 2 restoration; include/dav1d/dav1d.h:61-69) */
+    int n_devices;             /* mode 1: Dav1dHipGlueOptions.n_devices — frames end on devices device .. device + n_devices - 1 in turn */
 } HookedParams;
 
 /* pass 1's output of one frame, as dav1d_decode_frame_init() sizes the arrays */
@@ -826,7 +827,7 @@ void *dav1d_hooked_open(const HookedParams *const p, const char *const hip_lib, 
     if (p->mode == 1) {
         Dav1dHipGlueOptions o;
         memset(&o, 0, sizeof(o));
-        o.hip_lib = hip_lib; o.device = p->device; o.pack = p->pack; o.free_listing = p->free_listing; o.row_progress = p->row_progress;
+        o.hip_lib = hip_lib; o.device = p->device; o.n_devices = p->n_devices; o.pack = p->pack; o.free_listing = p->free_listing; o.row_progress = p->row_progress;
         o.keep_cf = !p->stream;                      /* chain mode: the generator / the store owns the arena */
         o.cookie = h; o.stat = ob_stat; o.frame_listed = ob_frame_listed; o.frame_end_seconds = ob_frame_end_seconds;
         o.before_frame_done = ob_before_frame_done; o.after_frame_done = ob_after_frame_done;
@@ -871,6 +872,13 @@ int dav1d_hooked_picture_digest(void *const handle, const int k, uint64_t out[3]
     if (k < 0 || k >= h->p.n_frames) return -1;
     for (int pl = 0; pl < 3; pl++) out[pl] = h->out_hash[k * 3 + pl];
     return 0;
+}
+/* device d of the binding: frames that ended on it (out[0]) and reference pictures copied to it from another device (out[1]); returns the number of devices */
+int dav1d_hooked_device_stats(void *const handle, const int d, int out[2]) {
+    if (!handle || !((Hooked *) handle)->glue) return 0;
+    out[0] = out[1] = 0;
+    (void) dav1d_hip_glue_device_stats(((Hooked *) handle)->glue, d, &out[0], &out[1]);
+    return dav1d_hip_glue_devices(((Hooked *) handle)->glue);
 }
 int dav1d_hooked_row_publications(void *const handle) { return handle ? dav1d_hip_glue_row_publications(((Hooked *) handle)->glue) : 0; }
 int dav1d_hooked_n_fc(void *const handle) { return handle ? (int) ((Hooked *) handle)->n_fc : 0; }

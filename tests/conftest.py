@@ -7,6 +7,12 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+# The SIMT emulator shows two devices (tests/emu/emu_rt.cpp): every allocation is tagged with the device it was made on, the library's
+# checks that a frame's pictures live on its context's device have something to check in every emulated test, and the binding's
+# n_devices = 2 path (tests/test_hooked.py, tests/test_stream.py) runs on this box.  Read once, when the emulated library first asks.
+os.environ.setdefault("DAV1D_EMU_DEVICES", "2")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

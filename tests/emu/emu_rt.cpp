@@ -115,3 +115,62 @@ void emu_launch(const std::function<void()> &body, dim3 grid, dim3 block) {
                 run_block(body, block);
             }
 }
+
+// ---- devices and the allocations made on them (see hip_runtime.h)
+#include <map>
+namespace {
+int n_devices() {
+    static const int n = []() { const char *e = getenv("DAV1D_EMU_DEVICES"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > 16 ? 16 : v; }();
+    return n;
+}
+thread_local int cur_device = 0;
+struct Alloc { size_t n; int dev; };
+std::mutex alloc_mtx;
+std::map<uintptr_t, Alloc> allocs;       // only kept with more than one device
+const Alloc *find_alloc(const void *p, uintptr_t *base) {
+    const uintptr_t a = (uintptr_t) p;
+    auto it = allocs.upper_bound(a);
+    if (it == allocs.begin()) return nullptr;
+    --it;
+    if (a >= it->first + it->second.n) return nullptr;
+    if (base) *base = it->first;
+    return &it->second;
+}
+hipError_t alloc_on(void **p, size_t n, int dev) {
+    *p = malloc(n ? n : 1);
+    if (!*p) return hipErrorOutOfMemory;
+    if (n_devices() > 1) { std::lock_guard<std::mutex> lk(alloc_mtx); allocs[(uintptr_t) *p] = Alloc{ n ? n : 1, dev }; }
+    return hipSuccess;
+}
+}
+hipError_t hipSetDevice(int d) { if (d < 0 || d >= n_devices()) return hipErrorInvalidValue; cur_device = d; return hipSuccess; }
+hipError_t hipGetDevice(int *d) { *d = cur_device; return hipSuccess; }
+hipError_t hipGetDeviceCount(int *n) { *n = n_devices(); return hipSuccess; }
+hipError_t hipMalloc(void **p, size_t n) { return alloc_on(p, n, cur_device); }
+hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return alloc_on(p, n, -1); }
+hipError_t hipFree(void *p) {
+    if (p && n_devices() > 1) { std::lock_guard<std::mutex> lk(alloc_mtx); allocs.erase((uintptr_t) p); }
+    free(p);
+    return hipSuccess;
+}
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *p) {
+    a->type = hipMemoryTypeUnregistered; a->device = 0; a->devicePointer = a->hostPointer = nullptr;
+    if (n_devices() == 1) { a->type = hipMemoryTypeDevice; a->devicePointer = const_cast<void *>(p); return hipSuccess; }      // nothing is tracked
+    std::lock_guard<std::mutex> lk(alloc_mtx);
+    const Alloc *al = find_alloc(p, nullptr);
+    if (!al) return hipErrorInvalidValue;
+    if (al->dev < 0) { a->type = hipMemoryTypeHost; a->hostPointer = const_cast<void *>(p); }
+    else { a->type = hipMemoryTypeDevice; a->device = al->dev; a->devicePointer = const_cast<void *>(p); }
+    return hipSuccess;
+}
+hipError_t hipMemcpyPeerAsync(void *d, int d_dev, const void *s, int s_dev, size_t n, hipStream_t) {
+    if (n_devices() > 1) {
+        std::lock_guard<std::mutex> lk(alloc_mtx);
+        uintptr_t bd = 0, bs = 0;
+        const Alloc *ad = find_alloc(d, &bd), *as = find_alloc(s, &bs);
+        if (!ad || !as || ad->dev != d_dev || as->dev != s_dev) return hipErrorInvalidValue;
+        if ((uintptr_t) d + n > bd + ad->n || (uintptr_t) s + n > bs + as->n) return hipErrorInvalidValue;
+    }
+    memcpy(d, s, n);
+    return hipSuccess;
+}

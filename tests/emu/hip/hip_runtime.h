@@ -176,11 +176,24 @@ using std::max;
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     emu_launch([&]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block))
 
-static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
-static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+// Devices: $DAV1D_EMU_DEVICES of them (default 1), the current one a property of the calling thread as in HIP.  With more than one,
+// every allocation remembers the device it was made on (emu_rt.cpp): hipPointerGetAttributes tells, hipMemcpyPeerAsync insists on it,
+// and the library's own checks (a frame's pictures live on the frame's device) have something to check — kernel arguments are opaque,
+// a launch itself checks nothing.
+hipError_t hipMalloc(void **p, size_t n);
+hipError_t hipFree(void *p);
 enum { hipHostMallocDefault = 0 };
-static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+hipError_t hipHostMalloc(void **p, size_t n, unsigned flags = 0);
 static inline hipError_t hipHostFree(void *p) { return hipFree(p); }
+hipError_t hipSetDevice(int d);
+hipError_t hipGetDevice(int *d);
+hipError_t hipGetDeviceCount(int *n);
+enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
+struct hipPointerAttribute_t { hipMemoryType type; int device; void *devicePointer; void *hostPointer; };
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *p);
+hipError_t hipMemcpyPeerAsync(void *d, int d_dev, const void *s, int s_dev, size_t n, hipStream_t = 0);
+static inline hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 1; return hipSuccess; }
+static inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = 0) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t = 0) {
@@ -195,9 +208,6 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; 
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = 0; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
-static inline hipError_t hipSetDevice(int) { return hipSuccess; }
-static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = 0; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }

@@ -21,7 +21,8 @@ class HookedParams(C.Structure):
                 ("cdef_enabled", C.c_int), ("cdef_damping", C.c_int), ("cdef_n_bits", C.c_int), ("cdef_y_strength", C.c_int * 8),
                 ("cdef_uv_strength", C.c_int * 8), ("lr_type", C.c_int * 3), ("lr_unit_size", C.c_int * 2),
                 ("mode", C.c_int), ("free_listing", C.c_int), ("device", C.c_int), ("keep_output", C.c_int), ("inject", C.c_int), ("pack", C.c_int),
-                ("synth", synth_lib.SynthParams), ("stream", C.c_int), ("row_progress", C.c_int), ("apply_grain", C.c_int), ("filters_off", C.c_int)]
+                ("synth", synth_lib.SynthParams), ("stream", C.c_int), ("row_progress", C.c_int), ("apply_grain", C.c_int), ("filters_off", C.c_int),
+                ("n_devices", C.c_int)]
 
 
 def lib():
@@ -38,6 +39,7 @@ def lib():
     l.dav1d_hooked_plane.argtypes = [C.c_void_p, C.c_int, C.c_int]
     l.dav1d_hooked_n_fc.argtypes = [C.c_void_p]
     l.dav1d_hooked_row_publications.argtypes = [C.c_void_p]
+    l.dav1d_hooked_device_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int * 2)]
     l.dav1d_hooked_tail_seconds.restype = C.c_double
     l.dav1d_hooked_tail_seconds.argtypes = [C.c_void_p, C.c_int]
     l.dav1d_hooked_output_tail_seconds.restype = C.c_double
@@ -53,7 +55,7 @@ FILTERS = dict(lf=(20, 28, 16, 24, 0), cdef=(5, 2, [17, 33, 0, 63], [5, 0, 20, 4
 
 
 def params(w, h, bpc, n_frames, mode, layout=1, sb128=True, tiles=(2, 1), threads=4, frame_delay=3, filters=FILTERS, seed=5, free_listing=1,
-           keep_output=True, synth=None, pack=True, row_progress=0):
+           keep_output=True, synth=None, pack=True, row_progress=0, n_devices=0):
     p = HookedParams()
     p.w, p.h, p.layout, p.bpc, p.sb128 = w, h, layout, bpc, int(sb128)
     sb = 128 if sb128 else 64
@@ -78,6 +80,7 @@ def params(w, h, bpc, n_frames, mode, layout=1, sb128=True, tiles=(2, 1), thread
         p.lr_unit_size[0], p.lr_unit_size[1] = filters["lr"][1]
     p.mode, p.free_listing, p.device, p.keep_output = mode, free_listing, 0, int(keep_output)
     p.row_progress = int(row_progress)
+    p.n_devices = int(n_devices)
     p.pack = int(bool(pack) and mode == 1 and os.environ.get("DAV1D_HOOKED_PACK", "1") != "0")
     p.synth = synth if synth is not None else lu.default_synth(seed, n_refs=3, far_mv_pct=2)
     return p
@@ -110,6 +113,12 @@ def run(p, hip_lib_path, store=None, inject=0):
         assert rc == 0, "dav1d_hooked_run: %d" % rc
         n_fc = l.dav1d_hooked_n_fc(h)
         run.last_row_publications = l.dav1d_hooked_row_publications(h)
+        run.last_device_stats = []          # mode 1, per device of the binding: (frames ended there, reference pictures copied there)
+        if p.mode == 1:
+            ds = (C.c_int * 2)()
+            for d in range(max(1, l.dav1d_hooked_device_stats(h, 0, C.byref(ds)))):
+                l.dav1d_hooked_device_stats(h, d, C.byref(ds))
+                run.last_device_stats.append((int(ds[0]), int(ds[1])))
         st = (C.c_double * 16)()
         l.dav1d_hooked_stats(h, st)
         run.last_stats = dict(zip(("picture_alloc", "after_init", "listing", "filter_listing", "gpu_thread_idle", "uploads", "frame_end", "fetch", "picture_release"),
@@ -145,7 +154,7 @@ def run(p, hip_lib_path, store=None, inject=0):
         l.dav1d_hooked_close(h)
 
 
-def task_loop_rate(hip_lib_path, w, h, bpc, tiles=(4, 1), threads=64, frame_delay=8, frames=24, check_frames=4, seed=0x7A5C, intra_pct=10):
+def task_loop_rate(hip_lib_path, w, h, bpc, tiles=(4, 1), threads=64, frame_delay=8, frames=24, check_frames=4, seed=0x7A5C, intra_pct=10, n_devices=0):
     """bench.py's dav1d_task_loop leg: a chain of dependent frames (a key frame, then inter frames of the C2 block mix predicting from
     the three frames before them; deblocking, CDEF and switchable restoration on) through dav1d's OWN task loop — dav1d_submit_frame,
     its worker threads, check_tile, dav1d_get_picture — with the backend plugged in at the hook points of INTEGRATION.md 2.  First a
@@ -154,7 +163,7 @@ def task_loop_rate(hip_lib_path, w, h, bpc, tiles=(4, 1), threads=64, frame_dela
     import e2e
     sp = e2e.c2_params(seed)
     sp.intra_pct = intra_pct
-    common = dict(tiles=tiles, threads=threads, frame_delay=frame_delay, synth=sp)
+    common = dict(tiles=tiles, threads=threads, frame_delay=frame_delay, synth=sp, n_devices=n_devices)      # (n_devices: the binding's, mode 1 only)
     store = Store(frames)
     try:
         # the peer generates (and keeps) pass 1's output of EVERY frame of the chain and leaves the digests of its pictures; everything after
@@ -172,6 +181,7 @@ def task_loop_rate(hip_lib_path, w, h, bpc, tiles=(4, 1), threads=64, frame_dela
         # last: the packing lister consumes the store's coefficient arrays (as dav1d's pass 2 consumes f->frame_thread.cf)
         t_s, _, _ = run(params(w, h, bpc, frames, mode=1, keep_output=False, **common), hip_lib_path, store, inject=2)
         tail_s, tail_n = run.last_tail, frames - 1 - run.tail_from
+        dev_stats = list(run.last_device_stats)
         stages = dict(run.last_stats)
         stages["frame_end_ms_by_frame"] = list(run.last_frame_end_ms)
         # the same chain once more with rows published to dav1d's progress[1] as the backend reports them (C callback: dav1d_hooked_rows_done)
@@ -199,6 +209,7 @@ def task_loop_rate(hip_lib_path, w, h, bpc, tiles=(4, 1), threads=64, frame_dela
                              "what": "the inter frames after the first %d (key frame, first-use allocations and pipeline fill left out): completion of frame %d to "
                                      "completion of the last" % (run.tail_from + 1, run.tail_from)}, "n_fc": n_fc, "worker_threads": threads,
             "tile_cols": tiles[0], "tile_rows": tiles[1], "ms_per_frame_by_stage_summed_over_threads": stages, "row_progress": rp,
+            "devices": {"n": max(1, n_devices), "frames_ended_and_reference_pictures_copied_in_by_device": dev_stats},
             "peer_fps": round(frames / cpu_s, 2),
             "peer_steady_state": {"frames": tail_n, "fps": round(tail_n / peer_tail_s, 2) if peer_tail_s else None,
                                   "ms_per_frame": round(peer_tail_s / tail_n * 1e3, 2) if peer_tail_s else None},
@@ -207,4 +218,5 @@ def task_loop_rate(hip_lib_path, w, h, bpc, tiles=(4, 1), threads=64, frame_dela
             "parity": "bit-exact vs dav1d's own pass 2 + filters under the same task loop on ALL %d pictures (plane digests)" % frames,
             "workload": "%dx%d 4:2:0 %d-bit: key frame + inter frames (C2 mix, 10 %% intra, 3 references = the 3 frames before), deblock + CDEF + switchable "
                         "restoration; pass 1's output injected from memory (no AV1 streams exist here); dav1d_open(n_threads=%d, max_frame_delay=%d), src/thread_task.c with the "
-                        "hook points of INTEGRATION.md 2; listing runs ahead, frames end in order on one GPU thread" % (w, h, bpc, threads, frame_delay)}
+                        "hook points of INTEGRATION.md 2; listing runs ahead, %s" % (w, h, bpc, threads, frame_delay, "frames end in order on one GPU thread" if n_devices < 2 else
+                        "frame k ends on device k mod %d once its references have ended, a reference of another device copied over first (xGMI)" % n_devices)}

@@ -34,7 +34,7 @@ def lib():
 
 
 def decode(units, mode, hip_lib_path, threads=4, frame_delay=3, free_listing=1, pack=True, apply_grain=True, keep=True, row_progress=0,
-           filters_off=0, allow_backend_failure=False):
+           filters_off=0, allow_backend_failure=False, n_devices=0):
     """units: list of bytes-like temporal units.  Returns dict(pictures=[(info, [planes])], errors=n, tile_errors=[(tu, offset, overread)],
     hist={...} (mode 1), seconds, digests=[(d0, d1, d2)], times=[...]).  keep = 2: digests of the planes only (no pixel copies kept)."""
     l = lib()
@@ -45,6 +45,7 @@ def decode(units, mode, hip_lib_path, threads=4, frame_delay=3, free_listing=1, 
     p.pack = int(bool(pack) and mode == 1)
     p.stream, p.apply_grain, p.row_progress = 1, int(apply_grain), int(row_progress)
     p.filters_off = int(filters_off)         # Dav1dSettings.inloop_filters = ALL & ~filters_off, both modes
+    p.n_devices = int(n_devices)             # mode 1: the binding ends frames on that many devices in turn
     h = l.dav1d_hooked_open(C.byref(p), hip_lib_path.encode(), None)
     assert h, "dav1d_hooked_open failed"
     try:
@@ -86,7 +87,13 @@ def decode(units, mode, hip_lib_path, threads=4, frame_delay=3, free_listing=1, 
         l.dav1d_hooked_stats(h, st)
         stats = dict(zip(("picture_alloc", "after_init", "listing", "filter_listing", "gpu_thread_idle", "uploads", "frame_end", "fetch", "picture_release"),
                          [round(v * 1e3 / max(1, n), 2) for v in st[:9]]))
-        return dict(rc=rc, row_publications=l.dav1d_hooked_row_publications(h), stats=stats, pictures=pics, errors=l.dav1d_hooked_stream_errors(h), tile_errors=[(te[3 * i], te[3 * i + 1], te[3 * i + 2]) for i in range(nte)],
+        dev_stats = []
+        if mode == 1:
+            ds = (C.c_int * 2)()
+            for d in range(max(1, hk.lib().dav1d_hooked_device_stats(h, 0, C.byref(ds)))):
+                hk.lib().dav1d_hooked_device_stats(h, d, C.byref(ds))
+                dev_stats.append((int(ds[0]), int(ds[1])))
+        return dict(rc=rc, device_stats=dev_stats, row_publications=l.dav1d_hooked_row_publications(h), stats=stats, pictures=pics, errors=l.dav1d_hooked_stream_errors(h), tile_errors=[(te[3 * i], te[3 * i + 1], te[3 * i + 2]) for i in range(nte)],
                     hist=dict(zip(HIST, [int(v) for v in hist[:nh]])), seconds=sec.value, digests=digests, times=times)
     finally:
         l.dav1d_hooked_close(h)

@@ -1,6 +1,7 @@
 """Driver-level boundary (dav1d_hip_frame_*): tasks submitted tile-sbrow by tile-sbrow from several threads, one
 dav1d_hip_frame_end() for the whole frame -- reconstruction, deblocking, CDEF, loop restoration, film grain -- against the
 oracle running the same stages through oracle/replay.c."""
+import errno
 import threading
 
 import numpy as np
@@ -121,3 +122,58 @@ def test_frame_in_flight_matches_oracle(ctx, bpc, bands, monkeypatch):
     f.destroy()
     for o in [cur, grain, prep, coef, lvl] + refs:
         o.free()
+
+
+def test_two_devices_in_one_process_pictures_belong_to_their_device(ctx):
+    """include/dav1d_hip.h, "several devices in ONE process": a context belongs to its device, a frame's picture has to live there
+    (-EXDEV otherwise), dav1d_hip_picture_copy_peer makes a picture resident on another device — planes and tiled twin.  Here on the two
+    emulated devices (tests/conftest.py): allocations carry their device, a peer copy between the wrong ones fails."""
+    import ctypes as C
+    from dav1d_amd import api
+    lib = ctx.lib
+    if lib.dav1d_hip_device_count() < 2:
+        pytest.skip("one device here")
+    other = api.Context(1, lib_path=ctx.lib_path)
+    try:
+        assert lib.dav1d_hip_context_device(ctx.h) == 0 and lib.dav1d_hip_context_device(other.h) == 1
+        w, h, bpc = 200, 120, 10
+        rng = np.random.default_rng(77)
+        assert lib.dav1d_hip_context_use(ctx.h) == 0
+        a = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+        planes = [rng.integers(0, 1 << bpc, a.padded_shape(pl), dtype=np.uint16) for pl in range(3)]
+        for pl in range(3):
+            a.upload(pl, planes[pl])
+        a.retile()
+        assert lib.dav1d_hip_context_use(other.h) == 0
+        b = other.picture(w, h, api.LAYOUT_I420, bpc)
+        assert lib.dav1d_hip_picture_twin_alloc(other.h, C.byref(b.pic)) == 0
+        assert lib.dav1d_hip_picture_device(C.byref(a.pic)) == 0 and lib.dav1d_hip_picture_device(C.byref(b.pic)) == 1
+        # a frame of device 1 cannot be begun on a picture of device 0, nor ended with such a reference
+        fh = C.c_void_p()
+        assert lib.dav1d_hip_frame_begin(other.h, C.byref(fh), C.byref(a.pic), None, 0) == -errno.EXDEV
+        refs = (api.Picture * 1)(a.pic)
+        assert lib.dav1d_hip_frame_begin(other.h, C.byref(fh), C.byref(b.pic), refs, 1) == 0
+        assert lib.dav1d_hip_frame_end(fh, None, None, None, None, None) == -errno.EXDEV
+        lib.dav1d_hip_frame_destroy(fh)
+        # ... until it has been made resident there
+        assert lib.dav1d_hip_picture_copy_peer(other.h, C.byref(b.pic), ctx.h, C.byref(a.pic)) == 0
+        other.sync()
+        assert b.pic.twin_ok == 1
+        for pl in range(3):
+            assert np.array_equal(b.download(pl), planes[pl])
+        # the twin came along: un-tiling it gives the planes again
+        b.pic.twin_ok = api.TWIN_ONLY
+        for pl in range(3):
+            vis = (h if not pl else (h + 1) // 2), (w if not pl else (w + 1) // 2)
+            assert np.array_equal(b.download(pl)[:vis[0], :vis[1]], planes[pl][:vis[0], :vis[1]])
+        b.pic.twin_ok = 1
+        # geometry has to agree
+        c = other.picture(w + 16, h, api.LAYOUT_I420, bpc)
+        assert lib.dav1d_hip_picture_copy_peer(other.h, C.byref(c.pic), ctx.h, C.byref(a.pic)) == -errno.EINVAL
+        c.free(); b.free()
+        assert lib.dav1d_hip_context_use(ctx.h) == 0
+        a.free()
+    finally:
+        lib.dav1d_hip_context_use(ctx.h)
+        other.close()
+        lib.dav1d_hip_context_use(ctx.h)

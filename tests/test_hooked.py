@@ -44,3 +44,31 @@ def test_chain_through_the_task_loop_equals_dav1d(ctx, name, w, h, bpc, kw):
         assert hk.run.last_row_publications >= n_frames, hk.run.last_row_publications      # bands of 256 rows: several per frame
     # the chain is a chain: frames differ from each other, and an inter frame is not what the key frame was
     assert not np.array_equal(want[0][0], want[1][0]) and not np.array_equal(want[1][0], want[n_frames - 1][0])
+
+
+def n_devices_here(ctx):
+    import ctypes as C
+    l = C.CDLL(hip_lib_path(ctx))
+    return l.dav1d_hip_device_count()
+
+
+@pytest.mark.parametrize("name,w,h,bpc,kw", CASES, ids=[c[0] for c in CASES])
+def test_chain_over_two_devices_in_one_process_equals_dav1d(ctx, name, w, h, bpc, kw):
+    """dav1d is ONE process (n_fc frame contexts, reference src/internal.h:354-388): Dav1dHipGlueOptions.n_devices = 2 ends the frames on two
+    devices in turn, and a frame that predicts from pictures of the other device has them copied over first (dav1d_hip_picture_copy_peer).
+    On this box: two emulated devices ($DAV1D_EMU_DEVICES, tests/conftest.py) whose allocations are tagged — a frame handed a picture of
+    the wrong device ends with -EXDEV, a peer copy between the wrong devices fails."""
+    if n_devices_here(ctx) < 2:
+        pytest.skip("one device here")
+    n_frames = 6 if ctx.backend == "emu" else 9
+    kw = dict(kw)
+    _, _, want = hk.run(hk.params(w, h, bpc, n_frames, mode=0, **kw), hip_lib_path(ctx))
+    _, _, got = hk.run(hk.params(w, h, bpc, n_frames, mode=1, n_devices=2, **kw), hip_lib_path(ctx))
+    for k in range(n_frames):
+        for pl in range(len(want[k])):
+            bad = np.argwhere(want[k][pl] != got[k][pl])
+            assert not len(bad), "frame %d plane %d differs at %s (%d pixels)" % (k, pl, bad[0], len(bad))
+    st = hk.run.last_device_stats
+    assert len(st) == 2 and st[0][0] == (n_frames + 1) // 2 and st[1][0] == n_frames // 2, st       # frames in turn
+    # every inter frame predicts from the three frames before it: at least one of them ended on the other device
+    assert st[0][1] + st[1][1] >= n_frames - 1, st

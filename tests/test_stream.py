@@ -97,6 +97,18 @@ def test_random_streams_through_dav1ds_own_front_end(ctx, seed):
     run_seed(ctx, seed, n_frames=6)
 
 
+@pytest.mark.parametrize("seed", EMU_SEEDS)
+def test_random_streams_over_two_devices_in_one_process(ctx, seed):
+    """the same twelve streams with the binding's frames ending on two devices in turn (Dav1dHipGlueOptions.n_devices = 2): super-resolution
+    (two pictures per frame), scaled references, film grain on the output's device, show-existing frames, and frames dav1d drops"""
+    import ctypes as C
+    if C.CDLL(hip_lib_path(ctx)).dav1d_hip_device_count() < 2:
+        pytest.skip("one device here")
+    got = run_seed(ctx, seed, n_frames=6, n_devices=2)
+    st = got["device_stats"]
+    assert len(st) == 2 and st[0][0] and st[1][0], st
+
+
 def test_screen_content_stream_palette_and_intra_block_copy(ctx):
     """key / intra-only frames with palettes and intra block copies (allow_screen_content_tools on every frame)"""
     k = av1_obu.Knobs(screen_content=1.0, intrabc=1.0, intra_only=0.5, super_res=0.0)
