@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--sets", nargs="*", default=[""])
     ap.add_argument("--kernels", action="store_true")
     ap.add_argument("--no-raster", action="store_true")
+    ap.add_argument("--edge-frac", type=float, default=0.05, help="share of the blocks whose motion vectors point across the picture's edge (bench.py: 0.05)")
     ap.add_argument("--phases", action="store_true", help="with a -DDV_PHASES variant (--lib): shader-clock cycles per wave and phase of every kernel, from one event-bracketed run")
     ap.add_argument("--lib", default=None, help="a variant build (tools/build_variant.py) instead of dav1d_amd/libdav1d_hip.so")
     a = ap.parse_args()
@@ -34,7 +35,7 @@ def main():
     stream = torch.cuda.current_stream()
     ctx = api.Context(0, stream=stream.cuda_stream, lib_path=a.lib)
     w, h, bpc = a.width, a.height, a.bpc
-    frame = synth.make_frame(w, h, bpc, seed=0xDA71D002, mv_range_px=64, edge_frac=0.05, n_refs=3)
+    frame = synth.make_frame(w, h, bpc, seed=0xDA71D002, mv_range_px=64, edge_frac=a.edge_frac, n_refs=3)
     rng = np.random.default_rng(1234)
     ref_host = [synth.make_planes(rng, w, h, bpc) for _ in range(frame.n_refs)]
     dst_host = synth.make_planes(rng, w, h, bpc, smooth=False)
