@@ -498,6 +498,12 @@ int dav1d_hip_context_use(Dav1dHipContext *c) {
     if (!c) return -EINVAL;
     return hipSetDevice(c->device) == hipSuccess ? 0 : -ENODEV;
 }
+// for callers that borrow a thread (an allocator callback on the application's thread): what the thread had, and back to it
+int dav1d_hip_current_device(void) {
+    int d = 0;
+    return hipGetDevice(&d) == hipSuccess ? d : -ENODEV;
+}
+int dav1d_hip_set_device(int device) { return hipSetDevice(device) == hipSuccess ? 0 : -ENODEV; }
 // the device a picture's planes live on (-EINVAL: not device memory the runtime knows)
 int dav1d_hip_picture_device(const Dav1dHipPicture *pic) {
     if (!pic) return -EINVAL;

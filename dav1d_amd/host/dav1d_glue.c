@@ -69,6 +69,8 @@ typedef struct Hip {
     int (*live_objects)(long long *);
     int (*device_count)(void);
     int (*use)(Dav1dHipContext *);
+    int (*current_device)(void);
+    int (*set_device)(int);
     int (*picture_copy_peer)(Dav1dHipContext *, Dav1dHipPicture *, Dav1dHipContext *, const Dav1dHipPicture *);
 } Hip;
 
@@ -178,6 +180,15 @@ void dav1d_hip_glue_filter_desc(Dav1dHipFilterDesc *fd, const Dav1dFrameContext 
     fd->sr_w = f->frame_hdr->width[0] != f->frame_hdr->width[1] ? f->sr_cur.p.p.w : 0;      /* restoration works on the upscaled frame */
 }
 
+/* HIP's current device belongs to the thread.  On a thread that is not the glue's (the allocator callbacks and the life-cycle calls run on the
+ * application's) the glue selects its device and puts back what the thread had. */
+static int borrow_thread(const Dav1dHipGlue *const g, Dav1dHipContext *const ctx) {
+    const int prev = g->hip.current_device();
+    (void) g->hip.use(ctx);
+    return prev;
+}
+static void return_thread(const Dav1dHipGlue *const g, const int prev) { if (prev >= 0) (void) g->hip.set_device(prev); }
+
 /* ------------------------------------------------------------------------------------------------ Dav1dPicAllocator */
 static int glue_alloc_picture(Dav1dPicture *const p, void *const cookie) {
     Dav1dHipGlue *const g = cookie;
@@ -195,14 +206,16 @@ static int glue_alloc_picture(Dav1dPicture *const p, void *const cookie) {
     }
     pthread_mutex_unlock(&g->pic_mtx);
     Dav1dHipContext *const ctx = g->dev[dev].ctx;
-    int rc = g->hip.use(ctx);
-    if (hp && !rc) rc = g->hip.memset_(ctx, hp->hp.dev.alloc, 0, hp->hp.dev.alloc_size);       /* as a fresh one: zero, padding included */
+    const int thread_dev = borrow_thread(g, ctx);
+    int rc = 0;
+    if (hp) rc = g->hip.memset_(ctx, hp->hp.dev.alloc, 0, hp->hp.dev.alloc_size);       /* as a fresh one: zero, padding included */
     if (!hp) {
         hp = calloc(1, sizeof(*hp));
-        if (!hp) return DAV1D_ERR(ENOMEM);
+        if (!hp) { return_thread(g, thread_dev); return DAV1D_ERR(ENOMEM); }
         hp->dev = dev;
-        if (!rc) rc = g->hip.host_picture_alloc(ctx, &hp->hp, p->p.w, p->p.h, p->p.layout, p->p.bpc);   /* layouts share their values */
+        rc = g->hip.host_picture_alloc(ctx, &hp->hp, p->p.w, p->p.h, p->p.layout, p->p.bpc);   /* layouts share their values */
     }
+    return_thread(g, thread_dev);
     stat_add(g, DAV1D_HIP_GLUE_STAT_PICTURE_ALLOC, t0);
     if (rc) { free(hp); return DAV1D_ERR(ENOMEM); }
     for (int i = 0; i < 3; i++) p->data[i] = hp->hp.data[i];
@@ -222,7 +235,7 @@ static void glue_release_picture(Dav1dPicture *const p, void *const cookie) {
     Dav1dHipGlue *const g = cookie;
     Dav1dHipGluePicture *const hp = p->allocator_data;
     const double t0 = now_s();
-    (void) g->hip.use(g->dev[hp->ref_dev].ctx);
+    const int thread_dev = borrow_thread(g, g->dev[hp->ref_dev].ctx);       /* (a stage thread of the glue as often as an application thread) */
     if (hp->frame) g->hip.frame_destroy(hp->frame);
     hp->frame = NULL;
     hp->ref = hp->hp.dev;
@@ -230,12 +243,19 @@ static void glue_release_picture(Dav1dPicture *const p, void *const cookie) {
     hp->ref.twin_ok = hp->hp.dev.twin_ok = 0;
     memset(hp->mirror_ok, 0, sizeof(hp->mirror_ok));          /* (the mirrors' storage stays with the picture while it is pooled) */
     pthread_mutex_lock(&g->pic_mtx);
-    if (!g->closing && g->n_free_pics < 32) { g->free_pics[g->n_free_pics++] = hp; pthread_mutex_unlock(&g->pic_mtx); stat_add(g, DAV1D_HIP_GLUE_STAT_PICTURE_RELEASE, t0); return; }
+    if (!g->closing && g->n_free_pics < 32) {
+        g->free_pics[g->n_free_pics++] = hp;
+        pthread_mutex_unlock(&g->pic_mtx);
+        return_thread(g, thread_dev);
+        stat_add(g, DAV1D_HIP_GLUE_STAT_PICTURE_RELEASE, t0);
+        return;
+    }
     pthread_mutex_unlock(&g->pic_mtx);
     free_mirrors(g, hp);
     (void) g->hip.use(g->dev[hp->dev].ctx);
     g->hip.host_picture_release(g->dev[hp->dev].ctx, &hp->hp);
     free(hp);
+    return_thread(g, thread_dev);
     stat_add(g, DAV1D_HIP_GLUE_STAT_PICTURE_RELEASE, t0);
 }
 
@@ -562,9 +582,9 @@ int dav1d_hip_glue_output_with_grain(Dav1dHipGlue *const g, const Dav1dPicture *
     Dav1dHipPicture grain;
     memset(&grain, 0, sizeof(grain));
     Dav1dHipContext *const ctx_out = g->dev[hp->ref_dev].ctx_out;
-    (void) g->hip.use(ctx_out);
+    const int thread_dev = borrow_thread(g, ctx_out);
     int rc = g->hip.picture_alloc(ctx_out, &grain, pic->p.w, pic->p.h, pic->p.layout, pic->p.bpc);
-    if (rc) return DAV1D_ERR(ENOMEM);
+    if (rc) { return_thread(g, thread_dev); return DAV1D_ERR(ENOMEM); }
     rc = g->hip.fg_apply(ctx_out, &grain, &hp->ref, (const Dav1dHipFilmGrainData *) &pic->frame_hdr->film_grain.data,
                          pic->seq_hdr->mtrx == DAV1D_MC_IDENTITY);
     for (int pl = 0; pl < n_pl && !rc; pl++) {
@@ -573,6 +593,7 @@ int dav1d_hip_glue_output_with_grain(Dav1dHipGlue *const g, const Dav1dPicture *
     }
     if (!rc) rc = g->hip.sync(ctx_out);
     g->hip.picture_free(ctx_out, &grain);
+    return_thread(g, thread_dev);
     return rc ? DAV1D_ERR(EIO) : 0;
 }
 
@@ -613,13 +634,19 @@ int dav1d_hip_glue_create(Dav1dHipGlue **const out, const Dav1dHipGlueOptions *c
     SYM(fg_apply, "dav1d_hip_fg_apply"); SYM(picture_alloc, "dav1d_hip_picture_alloc"); SYM(picture_free, "dav1d_hip_picture_free");
     SYM(plane_download, "dav1d_hip_plane_download"); SYM(frame_set_progress_callback, "dav1d_hip_frame_set_progress_callback");
     SYM(live_objects, "dav1d_hip_live_objects"); SYM(device_count, "dav1d_hip_device_count"); SYM(use, "dav1d_hip_context_use");
+    SYM(current_device, "dav1d_hip_current_device"); SYM(set_device, "dav1d_hip_set_device");
     SYM(picture_copy_peer, "dav1d_hip_picture_copy_peer");
     g->n_dev = o->n_devices > 1 ? o->n_devices : 1;
     if (g->n_dev > DAV1D_HIP_GLUE_MAX_DEVICES || o->device < 0 || o->device + g->n_dev > g->hip.device_count()) { g->n_dev = 0; goto fail; }
+    const int thread_dev = g->hip.current_device();          /* (dav1d_hip_open selects the device it opens on) */
     for (int d = 0; d < g->n_dev; d++) {
         Dev *const dv = &g->dev[d];
-        if (g->hip.open(&dv->ctx, o->device + d, NULL) || g->hip.open(&dv->ctx_up, o->device + d, NULL) || g->hip.open(&dv->ctx_out, o->device + d, NULL)) goto fail;
+        if (g->hip.open(&dv->ctx, o->device + d, NULL) || g->hip.open(&dv->ctx_up, o->device + d, NULL) || g->hip.open(&dv->ctx_out, o->device + d, NULL)) {
+            return_thread(g, thread_dev);
+            goto fail;
+        }
     }
+    return_thread(g, thread_dev);
     *out = g;
     return 0;
 fail:
@@ -675,6 +702,7 @@ void dav1d_hip_glue_destroy(Dav1dHipGlue *const g) {
     if (!g) return;
     dav1d_hip_glue_detach(g);
     g->closing = 1;
+    const int thread_dev = g->hip.current_device ? g->hip.current_device() : -1;
     for (int i = 0; i < g->n_free_pics; i++) {
         Dav1dHipGluePicture *const hp = g->free_pics[i];
         free_mirrors(g, hp);
@@ -707,6 +735,7 @@ void dav1d_hip_glue_destroy(Dav1dHipGlue *const g) {
         if (g->dev[d].ctx_up) g->hip.close(g->dev[d].ctx_up);
         if (g->dev[d].ctx) g->hip.close(g->dev[d].ctx);
     }
+    if (thread_dev >= 0 && g->hip.set_device) (void) g->hip.set_device(thread_dev);
     if (g->hip.dl) dlclose(g->hip.dl);
     pthread_mutex_destroy(&g->q_mtx);
     pthread_mutex_destroy(&g->pic_mtx);

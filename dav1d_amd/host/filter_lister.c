@@ -145,15 +145,13 @@ static void list_cdef(const ListerGeo *g, const Dav1dHipFilterDesc *fd, FOut *o,
     for (int by = start; by < end; by += 2) {
         const Dav1dHipAv1Filter *const row = fd->lf_mask + (size_t) (by >> 5) * sb128w;
         const int by_idx = (by & 30) >> 1;
-        /* The last unit row of a superblock row's own band (dav1d_filter_sbrow_cdef leaves the 8 rows under it to the next
-         * superblock row: src/recon_tmpl.c:2027-2051) reads its two bottom rows from the lines backup_lpf() saved, and backup_lpf
-         * stores the picture's last row twice when it is the first of the two (src/lf_apply_tmpl.c:77-97, n_lines) */
-        int rep = 0;
-        if (!((by + 4) % sbsz) && by + 4 < g->bh) {
-            const int yb = (by + 2) * 4;
-            if (yb + 1 == g->h) rep |= DAV1D_HIP_CDEF_BOT_REP_Y;
-            if (g->layout && (yb >> g->ss_ver) + 1 == (g->h + g->ss_ver) >> g->ss_ver) rep |= DAV1D_HIP_CDEF_BOT_REP_UV;
-        }
+        /* The last unit row of a superblock row's own band (dav1d_filter_sbrow_cdef leaves the 8 rows under it to the next superblock
+         * row: src/recon_tmpl.c:2027-2051) reads its two bottom rows from the lines backup_lpf() saved, and backup_lpf stores the
+         * picture's last row twice when it is the first of the two (src/lf_apply_tmpl.c:77-97, n_lines).  For a unit row of dav1d's own
+         * walk that never coincides: such a row needs by + 4 < bh and h == 4 by + 9 (or + 10 for 4:2:0 chroma), but bh = 2 ceil(h / 8)
+         * = by + 4 then — the row belongs to the picture's last superblock row, which has no rows below it at all.  The unit records
+         * keep the flags (DAV1D_HIP_CDEF_BOT_REP_*, tests/test_cdef.py sets them) for callers with other walks; this lister sets none. */
+        const int rep = 0;
         for (int sbx = 0; sbx * 16 < g->bw; sbx++) {
             const Dav1dHipAv1Filter *const m = &row[sbx >> 1];
             const int cdef_idx = m->cdef_idx[((by & 16) >> 3) + (sbx & 1)];

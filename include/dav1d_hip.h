@@ -148,6 +148,10 @@ DAV1D_HIP_API int dav1d_hip_live_objects(long long out[4]);
 DAV1D_HIP_API int dav1d_hip_device_count(void);
 DAV1D_HIP_API int dav1d_hip_context_device(const Dav1dHipContext *c);
 DAV1D_HIP_API int dav1d_hip_context_use(Dav1dHipContext *c);
+/* for code that borrows somebody else's thread (dav1d's picture allocator runs on the application's): the thread's current device
+ * before dav1d_hip_context_use, and back to it afterwards */
+DAV1D_HIP_API int dav1d_hip_current_device(void);
+DAV1D_HIP_API int dav1d_hip_set_device(int device);
 DAV1D_HIP_API int dav1d_hip_picture_device(const Dav1dHipPicture *pic);
 DAV1D_HIP_API int dav1d_hip_picture_copy_peer(Dav1dHipContext *dst_c, Dav1dHipPicture *dst, Dav1dHipContext *src_c, const Dav1dHipPicture *src);
 DAV1D_HIP_API int dav1d_hip_picture_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic,

@@ -43,6 +43,12 @@ def oracle_cdef_unit(oracle, bpc, src, dst, t, damping, layout=1):
         blk = o[py0:, px0:]
         top = s[max(py0 - 2, 0):, px0:]
         bot = s[min(py0 + h, s.shape[0] - 1):, px0:]
+        if int(t["flags"]) & (8 if pl == 0 else 16):
+            # DAV1D_HIP_CDEF_BOT_REP_*: the two lines handed over as `bottom` are one line twice (what backup_lpf() leaves when the picture's
+            # last row is the first of them, src/lf_apply_tmpl.c:77-97)
+            rep = np.ascontiguousarray(np.repeat(s[py0 + h:py0 + h + 1, :], 2, axis=0))
+            assert rep.strides[0] == s.strides[0]
+            bot = rep[:, px0:]
         # pointers may be offset by -2 columns inside the callee; the planes carry padding columns
         oracle.call(bpc, "cdef_fb", fb_idx, 0, blk.ctypes.data, s.strides[0], left.ctypes.data,
                     top.ctypes.data, bot.ctypes.data, pri, sec, d, damp, edges)
@@ -109,7 +115,9 @@ def test_cdef_units_match_reference(ctx, bpc, layout):
             ysec, uvsec = y_lvl & 3, uv_lvl & 3
             ysec += ysec == 3
             uvsec += uvsec == 3
-            tasks[k] = (bx, by, (y_lvl >> 2) << bd8, ysec << bd8, (uv_lvl >> 2) << bd8, uvsec << bd8, e, 0, 0, 0, (0, 0, 0, 0))
+            # a fifth of the units that have rows below them are told that the second of those rows repeats the first (luma, chroma or both)
+            flags = int(rng.integers(1, 4)) << 3 if (e & 8) and rng.integers(0, 5) == 0 else 0
+            tasks[k] = (bx, by, (y_lvl >> 2) << bd8, ysec << bd8, (uv_lvl >> 2) << bd8, uvsec << bd8, e, flags, 0, 0, (0, 0, 0, 0))
             k += 1
     tasks = tasks[:k]
     want = synth.copy_planes(planes)
