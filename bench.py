@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--e2e-tile-cols", type=int, default=16, help="tile columns of the end-to-end leg (one listing thread per tile)")
     ap.add_argument("--e2e-tile-rows", type=int, default=8, help="tile rows of the end-to-end leg")
     ap.add_argument("--e2e-threads", type=int, default=64, help="listing threads (of the library, dav1d_hip_lister_run) of the one-frame-at-a-time end-to-end legs (0: one per tile).  The MI355X boxes of this pool give the container 16 cores' worth of CPU time per 100 ms (cgroup cpu.max): a burst on 64 threads runs at full speed until that is spent, then every thread stops for the rest of the period — the frames-in-flight legs report both ways")
-    ap.add_argument("--stream-frames", type=int, default=16, help="frames of the AV1 stream of the dav1d_task_loop_real_pass1 leg (every one compared with dav1d's)")
+    ap.add_argument("--stream-frames", type=int, default=25, help="frames of the AV1 stream of the dav1d_task_loop_real_pass1 leg (every one compared with dav1d's)")
     ap.add_argument("--no-c1", action="store_true", help="skip the 4K 8-bit (BASELINE configs[1]) line that the default run appends")
     ap.add_argument("--no-full", action="store_true", help="skip the full-DSP-table leg (deblock, CDEF, restoration, film grain)")
     ap.add_argument("--two-phase", action="store_true",
