@@ -498,6 +498,25 @@ int dav1d_hip_context_use(Dav1dHipContext *c) {
     if (!c) return -EINVAL;
     return hipSetDevice(c->device) == hipSuccess ? 0 : -ENODEV;
 }
+// direct copies between the devices of two contexts (xGMI): without it hipMemcpyPeerAsync goes through host memory.  Both directions; a pair
+// that is enabled already or cannot be peers is not an error (the copy still works, staged).  Leaves the caller's device current.
+int dav1d_hip_enable_peer_access(Dav1dHipContext *a, Dav1dHipContext *b) {
+    if (!a || !b) return -EINVAL;
+    if (a->device == b->device) return 0;
+    int prev = 0, enabled = 0;
+    (void) hipGetDevice(&prev);
+    const int dev[2] = { a->device, b->device };
+    for (int k = 0; k < 2; k++) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dev[k], dev[k ^ 1]) != hipSuccess || !can) continue;
+        if (hipSetDevice(dev[k]) != hipSuccess) continue;
+        const hipError_t e = hipDeviceEnablePeerAccess(dev[k ^ 1], 0);
+        if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) enabled++;
+    }
+    (void) hipGetLastError();
+    (void) hipSetDevice(prev);
+    return enabled;         // 0, 1 or 2 directions
+}
 // for callers that borrow a thread (an allocator callback on the application's thread): what the thread had, and back to it
 int dav1d_hip_current_device(void) {
     int d = 0;

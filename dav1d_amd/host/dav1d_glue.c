@@ -69,6 +69,7 @@ typedef struct Hip {
     int (*live_objects)(long long *);
     int (*device_count)(void);
     int (*use)(Dav1dHipContext *);
+    int (*enable_peer_access)(Dav1dHipContext *, Dav1dHipContext *);
     int (*current_device)(void);
     int (*set_device)(int);
     int (*picture_copy_peer)(Dav1dHipContext *, Dav1dHipPicture *, Dav1dHipContext *, const Dav1dHipPicture *);
@@ -634,7 +635,7 @@ int dav1d_hip_glue_create(Dav1dHipGlue **const out, const Dav1dHipGlueOptions *c
     SYM(fg_apply, "dav1d_hip_fg_apply"); SYM(picture_alloc, "dav1d_hip_picture_alloc"); SYM(picture_free, "dav1d_hip_picture_free");
     SYM(plane_download, "dav1d_hip_plane_download"); SYM(frame_set_progress_callback, "dav1d_hip_frame_set_progress_callback");
     SYM(live_objects, "dav1d_hip_live_objects"); SYM(device_count, "dav1d_hip_device_count"); SYM(use, "dav1d_hip_context_use");
-    SYM(current_device, "dav1d_hip_current_device"); SYM(set_device, "dav1d_hip_set_device");
+    SYM(enable_peer_access, "dav1d_hip_enable_peer_access"); SYM(current_device, "dav1d_hip_current_device"); SYM(set_device, "dav1d_hip_set_device");
     SYM(picture_copy_peer, "dav1d_hip_picture_copy_peer");
     g->n_dev = o->n_devices > 1 ? o->n_devices : 1;
     if (g->n_dev > DAV1D_HIP_GLUE_MAX_DEVICES || o->device < 0 || o->device + g->n_dev > g->hip.device_count()) { g->n_dev = 0; goto fail; }
@@ -646,6 +647,8 @@ int dav1d_hip_glue_create(Dav1dHipGlue **const out, const Dav1dHipGlueOptions *c
             goto fail;
         }
     }
+    for (int d = 0; d < g->n_dev; d++)               /* reference pictures cross between any two of them: direct copies where the devices are peers */
+        for (int e = d + 1; e < g->n_dev; e++) (void) g->hip.enable_peer_access(g->dev[d].ctx, g->dev[e].ctx);
     return_thread(g, thread_dev);
     *out = g;
     return 0;

@@ -153,6 +153,9 @@ DAV1D_HIP_API int dav1d_hip_context_use(Dav1dHipContext *c);
 DAV1D_HIP_API int dav1d_hip_current_device(void);
 DAV1D_HIP_API int dav1d_hip_set_device(int device);
 DAV1D_HIP_API int dav1d_hip_picture_device(const Dav1dHipPicture *pic);
+/* direct (xGMI) copies between the devices of two contexts, both directions: returns how many directions are enabled now (0 - 2; a pair
+ * that cannot be peers still copies, through host memory), < 0 on bad arguments.  The caller's current device is left as it was. */
+DAV1D_HIP_API int dav1d_hip_enable_peer_access(Dav1dHipContext *a, Dav1dHipContext *b);
 DAV1D_HIP_API int dav1d_hip_picture_copy_peer(Dav1dHipContext *dst_c, Dav1dHipPicture *dst, Dav1dHipContext *src_c, const Dav1dHipPicture *src);
 DAV1D_HIP_API int dav1d_hip_picture_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic,
                                           int w, int h, int layout, int bpc);

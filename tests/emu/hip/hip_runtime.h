@@ -51,7 +51,7 @@ extern dim3 blockDim, gridDim;
 typedef int hipError_t;
 typedef struct emu_stream_st *hipStream_t;
 typedef struct emu_event_st *hipEvent_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotSupported = 801, hipErrorUnknown = 999 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorPeerAccessAlreadyEnabled = 704, hipErrorNotSupported = 801, hipErrorUnknown = 999 };
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost,
                      hipMemcpyDeviceToDevice, hipMemcpyDefault };
 

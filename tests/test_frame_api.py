@@ -155,7 +155,9 @@ def test_two_devices_in_one_process_pictures_belong_to_their_device(ctx):
         assert lib.dav1d_hip_frame_begin(other.h, C.byref(fh), C.byref(b.pic), refs, 1) == 0
         assert lib.dav1d_hip_frame_end(fh, None, None, None, None, None) == -errno.EXDEV
         lib.dav1d_hip_frame_destroy(fh)
-        # ... until it has been made resident there
+        # ... until it has been made resident there (direct copies where the devices are peers; the caller's device stays current)
+        assert lib.dav1d_hip_enable_peer_access(other.h, ctx.h) in (0, 1, 2) and lib.dav1d_hip_current_device() == 1
+        assert lib.dav1d_hip_enable_peer_access(ctx.h, ctx.h) == 0
         assert lib.dav1d_hip_picture_copy_peer(other.h, C.byref(b.pic), ctx.h, C.byref(a.pic)) == 0
         other.sync()
         assert b.pic.twin_ok == 1
