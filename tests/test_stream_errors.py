@@ -55,13 +55,14 @@ def damaged_stream(seed, lib):
     return sw, k, ti, ("tiny tile", "cut tile", "re-rolled tile")[how]
 
 
-def check_seed(ctx, seed):
+def check_seed(ctx, seed, n_devices=0):
     lib = hip_lib_path(ctx)
     before = live(lib)
     sw, k, ti, how = damaged_stream(seed, lib)
     units = [u["data"] for u in sw.units]
     want = su.decode(units, 0, lib, threads=2 + seed % 5, frame_delay=2 + seed % 3)
-    got = su.decode(units, 1, lib, threads=2 + seed % 5, frame_delay=2 + seed % 3, free_listing=seed & 1, pack=not seed & 16, row_progress=(seed >> 5) & 1)
+    got = su.decode(units, 1, lib, threads=2 + seed % 5, frame_delay=2 + seed % 3, free_listing=seed & 1, pack=not seed & 16, row_progress=(seed >> 5) & 1,
+                    n_devices=n_devices)
     what = "seed %d (%s in unit %d tile %d)" % (seed, how, k, ti)
     assert got["rc"] == 0, "%s: the BACKEND reported a failure of its own (a frame dav1d rejects is not one)" % what
     assert got["errors"] == want["errors"], "%s: %d errors reported with the backend, %d by dav1d alone" % (what, got["errors"], want["errors"])
@@ -77,6 +78,16 @@ def test_damaged_streams_fail_the_same_way_with_the_backend(ctx, seed):
     if ctx.backend != "emu":
         pytest.skip("the GPU run takes the sweep below")
     check_seed(ctx, seed)
+
+
+@pytest.mark.parametrize("seed", range(1, 9))
+def test_damaged_streams_over_two_devices_in_one_process(ctx, seed):
+    """the same damaged streams with the binding's frames ending on two devices in turn: a frame that failed on one device is the failed
+    reference of a frame on the other (FRAME_ERROR in progress[1], no mirror is made of it), nothing is left behind on either"""
+    import ctypes as C
+    if C.CDLL(hip_lib_path(ctx)).dav1d_hip_device_count() < 2:
+        pytest.skip("one device here")
+    check_seed(ctx, seed, n_devices=2)
 
 
 @pytest.mark.gpu
