@@ -1385,10 +1385,14 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
                 const auto t_b = std::chrono::steady_clock::now();
                 const DevPlanes dp = dev_planes(&f->cur);
                 if (one_launch) {
-                    // every level in one launch: superblocks wait for the flags of the neighbours they read (intra_sb.hip)
+                    // every level in one launch: superblocks wait for the flags of the neighbours they read (intra_sb.hip).  Workgroups of four
+                    // waves unless the option says otherwise: two superblocks per CU are in flight instead of one (256 registers per lane), and
+                    // a superblock's steps rarely have work for more than four waves — 8K key frame 9.3 -> 7.3 ms.  Intra block copies are the
+                    // exception (wide steps of whole-block copies: 11.7 ms with eight waves, 12.9 with four; profiles/r05/intra_sb_waves_ab.jsonl)
+                    const int sb_waves = c->intra_sb_waves ? c->intra_sb_waves : copy_deps.empty() ? 4 : 8;
                     if (!rc) rc = dav1d_hip_launch_intra_sb(&dp, f->cur.bpc, f->cur.layout, reinterpret_cast<const IntraUnit *>(dev),
                                                             reinterpret_cast<const SbRegion *>(dev + ub), (int) plan.regions.size(), f->aux, mask, coef,
-                                                            c->intra_sb_waves, f->tiling.sb_log2, 0, reinterpret_cast<uint32_t *>(dev + o_flags), c->stream,
+                                                            sb_waves, f->tiling.sb_log2, 0, reinterpret_cast<uint32_t *>(dev + o_flags), c->stream,
                                                             reinterpret_cast<const uint32_t *>(dev + o_where), f->tiling.sbw);
                     uint32_t gave_up = 0;
                     if (!rc) rc = dav1d_hip_download(c, &gave_up, dev + o_flags + plan.regions.size() * sizeof(uint32_t), sizeof(gave_up));

@@ -74,3 +74,22 @@ def test_packed_and_dense_residuals_do_not_mix_in_a_frame(ctx):
     frame.destroy()
     dense.free()
     cur.free()
+
+
+@pytest.mark.parametrize("intrabc_pct", [0, 40], ids=["no-copies", "intra-block-copies"])
+@pytest.mark.parametrize("waves", [0, 4, 8], ids=["default", "4-waves", "8-waves"])
+def test_key_frame_with_either_workgroup_size_of_the_superblock_launch(ctx, waves, intrabc_pct):
+    """context option intra_sb_waves: the one-launch superblock form (intra_sb.hip) runs with workgroups of four waves (two superblocks per CU
+    in flight: what a frame without intra block copies gets by default) or of eight (the default with copies); both must give the
+    reference's pixels on both kinds of key frame"""
+    if lu.ref_lib() is None:
+        pytest.skip("no reference build (oracle/_ref)")
+    w, h = (384, 256) if ctx.backend == "emu" else (1920, 1080)
+    ctx.set_option("intra_sb_waves", waves)
+    try:
+        out = e2e.run(ctx, w, h, 10, frames=2, threads=3, tile_cols=2, tile_rows=2, seed=79, key_frame=True, intrabc_pct=intrabc_pct,
+                      check=lambda ho, planes, refs: lu.check_handoff_against_reference(ho, planes, refs, is_inter=False))
+    finally:
+        ctx.set_option("intra_sb_waves", 0)
+    assert out["parity"].startswith("bit-exact"), out["parity"]
+    assert out["wavefront_steps"] >= 2
