@@ -30,7 +30,8 @@ struct Dav1dHipContext {
     int intra_sb_lds;           // 1: the superblock's pixels stay in LDS where that form exists (4:2:0); 0 (default): handed over through the L2 — measured
                                 // equal or a little faster ($DAV1D_HIP_INTRA_SB_LDS / option intra_sb_lds)
     int intra_sb_waves;         // waves per workgroup of that route: 4, 8 or 0 = the kernel form's own choice ($DAV1D_HIP_INTRA_SB_WAVES / option intra_sb_waves;
-                                // the one-launch form chooses 4, or 8 for frames with intra block copies; the per-level launches 8)
+                                // the one-launch form chooses 4 where the levels are wide (>= 128 superblocks on average) and nothing is copied, else 8;
+                                // the per-level launches 8)
     int recon_fuse;             // bit mask of the square block sizes that run paired (DAV1D_HIP_RECON_FUSE)
     long recon_pipeline;        // smallest residual list a recon list pipelines on two streams (DAV1D_HIP_RECON_PIPELINE)
     int recon_lanes;            // side streams of the residual launches (DAV1D_HIP_RECON_LANES)

@@ -2588,9 +2588,10 @@ int dav1d_hip_intra_sb_run(Dav1dHipContext *c, const Dav1dHipIntraSb *l, const D
     const int lds = c->intra_sb_lds && !l->has_copies;          // (the LDS-resident form does not copy)
     if (c->intra_sb_flow && !lds && l->level_start.size() > 2) {
         if (hipMemsetAsync(l->flags, 0, (l->n_regions + 1) * sizeof(uint32_t), c->stream) != hipSuccess) return -EIO;
-        // (four waves per workgroup unless asked otherwise or the list copies blocks: see frame.hip)
+        // (four waves per workgroup where the levels are wide and nothing is copied, unless asked otherwise: see frame.hip)
+        const bool wide_levels = l->n_regions >= 128 * (l->level_start.size() - 1);
         return dav1d_hip_launch_intra_sb(&dp, dst->bpc, dst->layout, l->units, l->regions, (int) l->n_regions, aux, nullptr, coef,
-                                         c->intra_sb_waves ? c->intra_sb_waves : l->has_copies ? 8 : 4, l->sb_log2, 0, l->flags, c->stream, l->where, l->sbw);
+                                         c->intra_sb_waves ? c->intra_sb_waves : !l->has_copies && wide_levels ? 4 : 8, l->sb_log2, 0, l->flags, c->stream, l->where, l->sbw);
     }
     for (size_t k = 0; k + 1 < l->level_start.size() && !rc; k++)
         rc = dav1d_hip_launch_intra_sb(&dp, dst->bpc, dst->layout, l->units, l->regions + l->level_start[k],

@@ -1386,10 +1386,13 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
                 const DevPlanes dp = dev_planes(&f->cur);
                 if (one_launch) {
                     // every level in one launch: superblocks wait for the flags of the neighbours they read (intra_sb.hip).  Workgroups of four
-                    // waves unless the option says otherwise: two superblocks per CU are in flight instead of one (256 registers per lane), and
-                    // a superblock's steps rarely have work for more than four waves — 8K key frame 9.3 -> 7.3 ms.  Intra block copies are the
-                    // exception (wide steps of whole-block copies: 11.7 ms with eight waves, 12.9 with four; profiles/r05/intra_sb_waves_ab.jsonl)
-                    const int sb_waves = c->intra_sb_waves ? c->intra_sb_waves : copy_deps.empty() ? 4 : 8;
+                    // waves where the frame has superblocks to fill the CUs with (>= 128 per level on average: many tiles, or isolated intra
+                    // blocks in an inter frame): two superblocks per CU are in flight instead of one (256 registers per lane) — 8K key frame in
+                    // 15 x 7 tiles 9.7 -> 7.5 ms.  Eight waves where the wavefront is narrow (4 tile columns: 25 superblocks per level; the
+                    // CUs are not all busy and a superblock's own time counts: 30.8 fps against 28.2 on the 8K stream of bench.py) and for
+                    // intra block copies (wide steps of whole-block copies: 12.1 ms against 13.1).  profiles/r05/intra_sb_waves_ab.jsonl
+                    const bool wide_levels = plan.regions.size() >= 128 * (plan.level_start.size() - 1);
+                    const int sb_waves = c->intra_sb_waves ? c->intra_sb_waves : copy_deps.empty() && wide_levels ? 4 : 8;
                     if (!rc) rc = dav1d_hip_launch_intra_sb(&dp, f->cur.bpc, f->cur.layout, reinterpret_cast<const IntraUnit *>(dev),
                                                             reinterpret_cast<const SbRegion *>(dev + ub), (int) plan.regions.size(), f->aux, mask, coef,
                                                             sb_waves, f->tiling.sb_log2, 0, reinterpret_cast<uint32_t *>(dev + o_flags), c->stream,
