@@ -69,7 +69,8 @@ DAV1D_HIP_API void dav1d_hip_graph_destroy(Dav1dHipContext *c, Dav1dHipGraph *g)
  * "serial", "cdef_unit", "flow_groups", "flow_mode", "flow_min_steps", "chunk_arena_min",
  * "intra_sb": the intra blocks of a frame superblock by superblock — 2, the default: every frame whose tiling is known; 1: only
  * wavefronts of at least flow_min_steps steps; 0: never; "intra_sb_lds": 1 = the form of that route that keeps the superblock's
- * pixels in LDS (4:2:0 / 4:0:0), 0 (default) = pixels handed over through the L2; "intra_sb_waves": 4 / 8 waves per superblock, 0 = default;
+ * pixels in LDS (4:2:0 / 4:0:0), 0 (default) = pixels handed over through the L2; "intra_sb_waves": 4 / 8 waves per superblock, 0 (default) = 4 in the
+ * one-launch form where a level holds 128 superblocks or more on average and the frame copies no blocks, else 8;
  * "intra_sb_flow": 1 (default) = all levels of a frame's superblocks as ONE launch, a superblock waiting for the neighbours it reads, 0 = a launch per level,
  * "chunk_order": 1 = the prepared lists of a tile-sbrow are ordered for the device — by code path and reference, a few per cent on the
  * launches for a tenth more host time per frame; 0, the default, leaves decode order); -EINVAL for an unknown name. */
