@@ -511,7 +511,25 @@ def main():
         a4 = copy.copy(a)
         a4.config, a4.dependent, a4.no_cpu = "c4", True, True
         c4 = run_job(a4, rank, local, world)
+        # dav1d's own loop over the N devices, ONE process: rank 0 runs it in a child while the other ranks wait on the CPU (a gloo barrier:
+        # an RCCL one would keep a spinning kernel on the GPUs the child is about to use)
+        n_leg = None
+        if not a.emu and not a.no_e2e and not a.no_check:
+            import datetime
+            try:
+                cpu_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=1500))
+            except Exception as e:       # noqa: BLE001  (the leg is an extra: without a CPU-side group it is left out, on every rank alike)
+                cpu_group = None
+                n_leg = {"status": "skipped: no gloo group next to the RCCL one (%s)" % str(e)[:80]}
+            if cpu_group is not None:
+                if rank == 0:
+                    n_leg = task_loop_n_gpus_leg(a, world)
+                try:
+                    dist.barrier(group=cpu_group)
+                except Exception:        # noqa: BLE001
+                    pass
         if rank == 0:
+            primary["dav1d_task_loop_n_gpus"] = n_leg
             def digest(line):
                 return {"metric": line["metric"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"], "scaling": line["scaling"],
                         "parallelism": line["config"].get("parallelism"), "parity": line["config"].get("parity"),
@@ -527,6 +545,21 @@ def main():
         dist.barrier()
         dd.close_peers()
         dist.destroy_process_group()
+
+
+def task_loop_n_gpus_leg(a, world):
+    """--gpus N: dav1d is ONE process — the chain of the dav1d_task_loop leg with the binding's frames ending on N devices of one process in
+    turn (Dav1dHipGlueOptions.n_devices; a reference of another device is copied over first), next to one device, in a child process
+    (tools/task_loop_n_devices.py) so that whatever happens in there stays out of this line."""
+    import subprocess
+    try:
+        child = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "task_loop_n_devices.py"), str(world),
+                                "--width", str(a.width), "--height", str(a.height), "--bpc", str(a.bpc), "--frames", "16"], capture_output=True, text=True, timeout=900)
+        last = child.stdout.strip().splitlines()[-1] if child.stdout.strip() else ""
+        return json.loads(last) if child.returncode == 0 and last.startswith("{") else {"error": "rc %d: %s" % (child.returncode, child.stderr[-160:])}
+    except Exception as e:       # noqa: BLE001  (a reported extra)
+        return {"error": str(e)[:200]}
+
 
 
 def DEV(a):
@@ -1354,18 +1387,6 @@ def run_job(a, rank, local, world):
                 raise SystemExit("bench: the dav1d task loop leg differs from dav1d's own pass 2 + filters: %s" % e)
             except Exception as e:       # noqa: BLE001  (a reported extra)
                 task_loop = {"error": str(e)[:200]}
-        # ---- --gpus N: dav1d is ONE process — the same chain with the binding's frames ending on N devices of one process in turn
-        # (Dav1dHipGlueOptions.n_devices; a reference of another device is copied over first), next to one device, in a child process
-        task_loop_n = None
-        if world > 1 and not a.no_e2e and not a.no_check and not a.emu:
-            import subprocess
-            try:
-                child = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "task_loop_n_devices.py"), str(world),
-                                        "--width", str(w), "--height", str(h), "--bpc", str(bpc), "--frames", "16"], capture_output=True, text=True, timeout=900)
-                last = child.stdout.strip().splitlines()[-1] if child.stdout.strip() else ""
-                task_loop_n = json.loads(last) if child.returncode == 0 and last.startswith("{") else {"error": "rc %d: %s" % (child.returncode, child.stderr[-160:])}
-            except Exception as e:       # noqa: BLE001  (a reported extra)
-                task_loop_n = {"error": str(e)[:200]}
         # ---- ... and behind dav1d's REAL pass 1: an AV1 stream (tests/av1_obu.py: real headers, every tool, random tile payloads) through
         # dav1d_send_data / dav1d_parse_obus / msac / decode_b unmodified; EVERY picture of the chain compared with dav1d's own
         task_loop_stream = None
@@ -1426,7 +1447,7 @@ def run_job(a, rank, local, world):
                           "coef_bytes_per_frame": int(coef_host.nbytes), "coef_h2d_ms_per_frame": h2d_ms,
                           "samples_per_frame": frame.n_samples, "parity": check, "gen_seconds": round(t_gen, 1)},
                "roofline": roof, "cpu_baseline": cpu, "full_table": full, "end_to_end": e2e_leg, "all_intra": key_leg, "end_to_end_packing_lister": e2e_packed, "all_intra_packing_lister": key_packed, "end_to_end_full_table": full_route, "end_to_end_4_tile_columns": e2e_c2, "end_to_end_full_table_4_tile_columns": full_route_c2,
-               "end_to_end_frames_in_flight": sustained, "row_progress": row_progress, "refmvs": refmvs_leg, "dav1d_task_loop": task_loop, "dav1d_task_loop_n_gpus": task_loop_n, "dav1d_task_loop_real_pass1": task_loop_stream, "config_c0_1080p_8bit": c0,
+               "end_to_end_frames_in_flight": sustained, "row_progress": row_progress, "refmvs": refmvs_leg, "dav1d_task_loop": task_loop, "dav1d_task_loop_real_pass1": task_loop_stream, "config_c0_1080p_8bit": c0,
                "device": None if a.no_check else device_probe(torch)}       # (not under the profiler: its copies would sit in the kernel statistics)
         # BASELINE configs[1] (4K 8-bit, the reference's CPU-runnable size) next to the headline: the same bench in a child process,
         # its digest under "config_c1_4k_8bit"
