@@ -514,7 +514,7 @@ def main():
         # dav1d's own loop over the N devices, ONE process: rank 0 runs it in a child while the other ranks wait on the CPU (a gloo barrier:
         # an RCCL one would keep a spinning kernel on the GPUs the child is about to use)
         n_leg = None
-        if not a.emu and not a.no_e2e and not a.no_check:
+        if (a.emu and os.environ.get("DAV1D_BENCH_N_DEVICES_LEG")) or (not a.emu and not a.no_e2e and not a.no_check):
             import datetime
             try:
                 cpu_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=1500))
@@ -553,8 +553,11 @@ def task_loop_n_gpus_leg(a, world):
     (tools/task_loop_n_devices.py) so that whatever happens in there stays out of this line."""
     import subprocess
     try:
-        child = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "task_loop_n_devices.py"), str(world),
-                                "--width", str(a.width), "--height", str(a.height), "--bpc", str(a.bpc), "--frames", "16"], capture_output=True, text=True, timeout=900)
+        cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "task_loop_n_devices.py"), str(world),
+               "--width", str(a.width), "--height", str(a.height), "--bpc", str(a.bpc), "--frames", "16"]
+        if a.emu:                # ($DAV1D_BENCH_N_DEVICES_LEG: the flow of this leg on emulated devices, tests/test_dist.py)
+            cmd += ["--emu", "--frames", "6", "--threads", "4"]
+        child = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         last = child.stdout.strip().splitlines()[-1] if child.stdout.strip() else ""
         return json.loads(last) if child.returncode == 0 and last.startswith("{") else {"error": "rc %d: %s" % (child.returncode, child.stderr[-160:])}
     except Exception as e:       # noqa: BLE001  (a reported extra)

@@ -434,6 +434,31 @@ def test_bench_py_starts_its_own_launcher_and_reports_three_legs_world2_gloo():
     assert legs["c3_tile_columns_with_in_loop_filters"]["scaling"] == "strong"
 
 
+def test_bench_py_n_gpus_runs_dav1ds_loop_over_the_devices_of_one_process_world2_gloo():
+    """`bench.py --gpus N` also reports dav1d's OWN loop over the N devices of one process (dav1d_task_loop_n_gpus: rank 0 runs
+    tools/task_loop_n_devices.py in a child, the other ranks wait on a gloo barrier).  Here: two ranks over gloo, the child on two emulated
+    devices ($DAV1D_BENCH_N_DEVICES_LEG switches the leg on under --emu)."""
+    import json
+    import hooked_util as hk
+    if hk.lib() is None:
+        pytest.skip("needs oracle/_ref_hooked")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["DAV1D_BENCH_N_DEVICES_LEG"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--emu", "--width", "256", "--height", "128",
+                        "--steps", "2", "--warmup", "2", "--cpu-seconds", "0.1"], capture_output=True, text=True, env=env, timeout=1500, cwd="/tmp")
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 8000, lines
+    leg = json.loads(lines[0])["legs"].get("dav1d_task_loop_n_gpus")
+    assert leg and leg.get("parity", "").startswith("bit-exact") and leg.get("fps"), leg
+    full = json.load(open(os.path.join(util.ROOT, "bench_legs.json")))["dav1d_task_loop_n_gpus"]
+    assert full["devices_2"]["devices"]["n"] == 2 and full["devices_1"]["devices"]["n"] == 1, full
+    st = full["devices_2"]["devices"]["frames_ended_and_reference_pictures_copied_in_by_device"]
+    assert len(st) == 2 and st[0][0] and st[1][0] and st[0][1] + st[1][1] > 0, st
+
+
 def test_peer_calls_check_their_columns():
     """a column narrower than the halo, odd or overlapping columns, columns outside the plane are refused with -EINVAL
     (they made the strip kernels read or write out of bounds) — on one emulated rank, before anything is exchanged."""
