@@ -99,8 +99,12 @@ hipError_t launch_tx_wide(const int tx, const DevPlanes &dst, const Dav1dHipItxT
                            dst, tasks, n, cf, bitdepth_max, twin); \
         break; }
     switch (tx) {
+#ifdef DV_LEAN      // (variant builds that only hold what the 10-bit tiled step launches, see recon.hip)
+        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4)
+#else
         CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9)
         CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18)
+#endif
         default: return hipErrorInvalidValue;
     }
 #undef CASE
@@ -144,6 +148,9 @@ extern "C" int dav1d_hip_launch_itx_all(const DevPlanes *dst, int bpc, const Dav
     seg.off[19] = (int) off[19];
     seg.grp[19] = groups;
     if (!groups) return 0;
+#ifdef DV_LEAN
+    return -ENOTSUP;
+#else
     const int bitdepth_max = (1 << bpc) - 1;
     if (bpc == 8)
         hipLaunchKernelGGL((itx_multi_kernel<uint8_t, int16_t>), dim3(groups), dim3(64), 0, (hipStream_t) stream,
@@ -152,6 +159,7 @@ extern "C" int dav1d_hip_launch_itx_all(const DevPlanes *dst, int bpc, const Dav
         hipLaunchKernelGGL((itx_multi_kernel<uint16_t, int32_t>), dim3(groups), dim3(64), 0, (hipStream_t) stream,
                            *dst, tasks, seg, (int32_t *) coef, bitdepth_max);
     return hipGetLastError() == hipSuccess ? 0 : -5;
+#endif
 }
 
 // tasks[] (device) holds the tasks of ONE tx size; offsets are managed by capi.
@@ -159,11 +167,15 @@ extern "C" int dav1d_hip_launch_itx_bin(const DevPlanes *dst, int bpc, int tx, c
                                         int n, void *coef, void *stream)
 {
     if (n <= 0) return 0;
+#ifdef DV_LEAN
+    return -ENOTSUP;
+#else
     const int bitdepth_max = (1 << bpc) - 1;
     hipError_t e;
     if (bpc == 8) e = launch_tx<uint8_t, int16_t>(tx, *dst, tasks, n, (int16_t *) coef, bitdepth_max, (hipStream_t) stream);
     else          e = launch_tx<uint16_t, int32_t>(tx, *dst, tasks, n, (int32_t *) coef, bitdepth_max, (hipStream_t) stream);
     return e == hipSuccess ? 0 : -5;
+#endif
 }
 
 // the same with wide stores (wide != 0) and, optionally, the tiled twin of dst written along (dst_twin != NULL, needs wide)
@@ -177,7 +189,12 @@ extern "C" int dav1d_hip_launch_itx_bin_out(const DevPlanes *dst, int bpc, int t
     memset(&twin, 0, sizeof(twin));
     if (dst_twin) twin = *dst_twin;
     hipError_t e;
+#ifdef DV_LEAN
+    if (bpc == 8) return -ENOTSUP;
+#else
     if (bpc == 8) e = launch_tx_wide<uint8_t, int16_t>(tx, *dst, tasks, n, (int16_t *) coef, bitdepth_max, twin, (hipStream_t) stream);
-    else          e = launch_tx_wide<uint16_t, int32_t>(tx, *dst, tasks, n, (int32_t *) coef, bitdepth_max, twin, (hipStream_t) stream);
+    else
+#endif
+                  e = launch_tx_wide<uint16_t, int32_t>(tx, *dst, tasks, n, (int32_t *) coef, bitdepth_max, twin, (hipStream_t) stream);
     return e == hipSuccess ? 0 : -5;
 }

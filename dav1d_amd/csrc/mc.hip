@@ -162,8 +162,13 @@ extern "C" int dav1d_hip_launch_mc_bin_twin(const DevPlanes *dst, const DevPlane
     for (int i = 0; i < 8; i++) rs.r[i] = refs[i < n_refs ? i : 0];
     const int bitdepth_max = (1 << bpc) - 1;
     hipError_t e;
+#ifdef DV_LEAN
+    if (bpc == 8) return -ENOTSUP;
+#else
     if (bpc == 8) e = launch_cls_twin<uint8_t>(cls, *dst, rs, tiles, n, prep, bitdepth_max, *dst_twin, (hipStream_t) stream);
-    else          e = launch_cls_twin<uint16_t>(cls, *dst, rs, tiles, n, prep, bitdepth_max, *dst_twin, (hipStream_t) stream);
+    else
+#endif
+                  e = launch_cls_twin<uint16_t>(cls, *dst, rs, tiles, n, prep, bitdepth_max, *dst_twin, (hipStream_t) stream);
     return hip_rc(e);
 }
 
@@ -179,12 +184,16 @@ extern "C" int dav1d_hip_launch_mc_bin(const DevPlanes *dst, const DevPlanes *re
     const int bitdepth_max = (1 << bpc) - 1;
     const int tiled = refs_tiled(refs, n_refs);
     if (tiled < 0) return -EINVAL;
+#ifdef DV_LEAN
+    return -ENOTSUP;
+#else
     hipError_t e;
     if (bpc == 8) e = tiled ? launch_cls<uint8_t, true>(cls, *dst, rs, tiles, n, prep, bitdepth_max, (hipStream_t) stream)
                             : launch_cls<uint8_t, false>(cls, *dst, rs, tiles, n, prep, bitdepth_max, (hipStream_t) stream);
     else          e = tiled ? launch_cls<uint16_t, true>(cls, *dst, rs, tiles, n, prep, bitdepth_max, (hipStream_t) stream)
                             : launch_cls<uint16_t, false>(cls, *dst, rs, tiles, n, prep, bitdepth_max, (hipStream_t) stream);
     return hip_rc(e);
+#endif
 }
 
 // with_small = 0: the group list only holds shapes that are at least 16 wide
@@ -193,6 +202,9 @@ extern "C" int dav1d_hip_launch_mc_all(const DevPlanes *dst, const DevPlanes *re
 {
     if (n_groups <= 0) return 0;
     if (refs_tiled(refs, n_refs) != 0) return -EINVAL;       // the all-shapes launch (an experiment, off by default) reads raster planes
+#ifdef DV_LEAN
+    return -ENOTSUP;
+#else
     RefSet rs;
     for (int i = 0; i < 8; i++) rs.r[i] = refs[i < n_refs ? i : 0];
     const int bitdepth_max = (1 << bpc) - 1;
@@ -203,4 +215,5 @@ extern "C" int dav1d_hip_launch_mc_all(const DevPlanes *dst, const DevPlanes *re
     else if (with_small) hipLaunchKernelGGL((mc_all_kernel<uint16_t, true>), grid, wave, 0, st, *dst, rs, tiles, groups, n_groups, prep, bitdepth_max);
     else hipLaunchKernelGGL((mc_all_kernel<uint16_t, false>), grid, wave, 0, st, *dst, rs, tiles, groups, n_groups, prep, bitdepth_max);
     return hip_rc(hipGetLastError());
+#endif
 }

@@ -28,6 +28,11 @@ __device__ __forceinline__ Taps load_taps(const int set, const int m) {
     // av1_mc_taps_packed[set 0..5 | 6 = bilinear][phase 0..15, 0 = unit tap][ev0..3, od0..4]
     const uint32_t *p = &av1_mc_taps_packed[(set * 16 + m) * 9];
     Taps t;
+#ifdef DV_KO_TAPS
+    for (int k = 0; k < 4; k++) t.ev[k] = (uint32_t) (set + m + k);
+    for (int k = 0; k < 5; k++) t.od[k] = (uint32_t) (set - m + k);
+    if (set != 12345) return t;
+#endif
 #pragma unroll
     for (int k = 0; k < 4; k++) t.ev[k] = p[k];
 #pragma unroll
@@ -142,7 +147,11 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
 
     const int ib = HBD ? 14 - (32 - __clz(bitdepth_max)) : 4;   // intermediate_bits
     const int bias = HBD ? 8192 : 0;                            // PREP_BIAS
+#ifdef DV_KO_SECOND
+    const bool compound = false;
+#else
     const bool compound = live && (t.kind == MCT_AVG || t.kind == MCT_WAVG);
+#endif
     const bool as_prep = t.kind != MCT_PUT && t.kind != MCT_PUT_TMP;   // PREP and both inputs of a compound tile
 
     int acc0[R][4], q[R][4];
@@ -208,7 +217,11 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
                         for (int pi = 0; pi < NPI; pi++) {
                             const int pc = lp + pi * PG, x = xa + 8 * pc;
                             ok[ri][pi] = row_ok && pc < NCH && x + 7 >= c_first && x <= c_last;
+#ifdef DV_KO_GATHER      // (knock-out variant builds, tools/knockout.sh: timing only, the pixels are wrong)
+                            if (ok[ri][pi]) { ld[ri][pi].x = (unsigned) (size_t) prow; ld[ri][pi].y = (unsigned) x; if constexpr (HBD) { ld[ri][pi].z = 0; ld[ri][pi].w = 1; } }
+#else
                             if (ok[ri][pi]) ld[ri][pi] = *reinterpret_cast<const piece_t *>(prow + (x << 3));
+#endif
                         }
                     }
                     // pieces that were not fetched are not stored either: what they would hold only ever meets zero taps
@@ -305,7 +318,11 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
         DV_PHASE(PH + 1 + 3 * dv_second_);
 
         // ---- 2. horizontal pass: item = (row pair, strip) -> mid2[pair][4 cols] = (even row, odd row)
+#ifdef DV_KO_HV
+        if (act && bitdepth_max == 12345) {
+#else
         if (act) {
+#endif
             const int sh1 = has_h ? fbits - ib : 0;
             const int rnd1 = (1 << sh1) >> 1;
 #pragma unroll
@@ -409,7 +426,11 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
         DV_PHASE(PH + 2 + 3 * dv_second_);
 
         // ---- 3. vertical pass: item = (output row, strip), R items per lane
+#ifdef DV_KO_HV
+        if (act && bitdepth_max == 12345) {
+#else
         if (act) {
+#endif
             int sh2, vb;
             if (!has_v) { sh2 = 0; vb = 0; }
             else if (!as_prep) { sh2 = has_h ? fbits + ib : fbits; vb = 0; }          // src/mc_tmpl.c:157-159,176-178

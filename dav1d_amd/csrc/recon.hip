@@ -113,10 +113,12 @@ void launch_cls(const DevPlanes &dst, const RefSet &refs, const McTile *tiles, c
 {
     constexpr int W = 4 << CLS, LPB = cmax(cmin(W, 32), W), BPW = 64 / LPB;
     const int groups = (n + BPW - 1) / BPW;
+#ifndef DV_LEAN      // (DV_LEAN: variant builds of tools/build_variant.py that only hold what the 10-bit tiled step launches — a tenth of the compile time)
     if (recon_waves<CLS>() > 1 && groups < coop_below)
         hipLaunchKernelGGL((recon_fused_kernel<CLS, pixel, coef, true, TILED, WIDE>), dim3(groups), dim3(64 * recon_waves<CLS>()), 0, stream,
                            dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, twin);
     else
+#endif
         hipLaunchKernelGGL((recon_fused_kernel<CLS, pixel, coef, false, TILED, WIDE>), dim3(groups), dim3(64), 0, stream,
                            dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, twin);
 }
@@ -141,10 +143,16 @@ hipError_t launch_variant(const bool tiled, const bool wide, const int cls, cons
                           const Dav1dHipItxTask *tasks, const int n, int16_t *prep, coef *cf, const int bitdepth_max, const int coop_below,
                           const DevPlanes &twin, hipStream_t st)
 {
+#ifdef DV_LEAN
+    if (!tiled || !wide || sizeof(pixel) != 2) return hipErrorInvalidValue;
+    if constexpr (sizeof(pixel) == 2) return launch_any<pixel, coef, true, true>(cls, dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, twin, st);
+    else return hipErrorInvalidValue;
+#else
     if (tiled) return wide ? launch_any<pixel, coef, true, true>(cls, dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, twin, st)
                            : launch_any<pixel, coef, true, false>(cls, dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, twin, st);
     return wide ? launch_any<pixel, coef, false, true>(cls, dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, twin, st)
                 : launch_any<pixel, coef, false, false>(cls, dst, refs, tiles, tasks, n, prep, cf, bitdepth_max, coop_below, twin, st);
+#endif
 }
 
 } // namespace
