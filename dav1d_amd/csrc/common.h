@@ -297,6 +297,28 @@ __device__ __forceinline__ void wave_sync() {
 #endif
 }
 
+// ---- global memory straight into LDS (LDS-DMA, global_load_lds_dwordx4): lane i's 16 bytes land at lds_base + 16 * i, lds_base
+// wave-uniform.  No register holds the data and nothing waits: a wave issues the fetches of everything it is going to need and computes
+// on what has arrived.  The hardware orders a later LDS read behind the transfer ONLY through the issuing wave's own vector-memory
+// counter (MI355X_MICROARCH.md "Co-residence", item 7): glds_wait() before the first read, always.  The instruction is spelled in
+// assembly so that the compiler neither tracks it (it would drain the counter before every LDS read that might alias) nor moves memory
+// operations across it; M0 (the destination base) is saved and restored around it.
+__device__ __forceinline__ void glds16(const void *gsrc, void *lds_base) {
+#ifdef DAV1D_HIP_EMU
+    memcpy(reinterpret_cast<char *>(lds_base) + 16 * emu_lane(), gsrc, 16);
+#else
+    const uint32_t dst = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (uintptr_t) (__attribute__((address_space(3))) char *) lds_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+#endif
+}
+__device__ __forceinline__ void glds_wait() {          // every transfer this wave has issued is in LDS
+#ifndef DAV1D_HIP_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 // Launch-order -> work-order remap.  Workgroup b is observed to land on XCD b % 8
 // (MI355X_MICROARCH.md "Workgroup dispatch"); giving XCD k the k-th contiguous
 // eighth of the (raster-ordered) task list keeps neighbouring blocks of a picture,

@@ -39,14 +39,14 @@ __device__ __forceinline__ void txtp_kinds(const int txtp, int &first, int &seco
     //            FLIPADST_ADST IDTX V_DCT H_DCT V_ADST H_ADST V_FLIPADST H_FLIPADST
     // first        A             I    I     D     I      A      I          F
     // second       F             I    D     I     A      I      F          I
-    constexpr unsigned char tab[16] = {
-        0 | 0 << 2, 0 | 1 << 2, 1 | 0 << 2, 1 | 1 << 2, 0 | 3 << 2, 3 | 0 << 2, 3 | 3 << 2, 3 | 1 << 2,
-        1 | 3 << 2, 2 | 2 << 2, 2 | 0 << 2, 0 | 2 << 2, 2 | 1 << 2, 1 | 2 << 2, 2 | 3 << 2, 3 | 2 << 2,
-    };
-    // spelled as a switch-free lookup on an immediate table (stays in SGPR/const)
-    unsigned v = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) v = (txtp == i) ? tab[i] : v;
+    // one 64-bit constant, four bits per entry: first | second << 2 (a chain of sixteen compares and selects costs a 4x4 wave a sixth of
+    // its vector instructions)
+    constexpr unsigned long long tab =
+        (0ull | 0ull << 2) << 0 | (0ull | 1ull << 2) << 4 | (1ull | 0ull << 2) << 8 | (1ull | 1ull << 2) << 12 |
+        (0ull | 3ull << 2) << 16 | (3ull | 0ull << 2) << 20 | (3ull | 3ull << 2) << 24 | (3ull | 1ull << 2) << 28 |
+        (1ull | 3ull << 2) << 32 | (2ull | 2ull << 2) << 36 | (2ull | 0ull << 2) << 40 | (0ull | 2ull << 2) << 44 |
+        (2ull | 1ull << 2) << 48 | (1ull | 2ull << 2) << 52 | (2ull | 3ull << 2) << 56 | (3ull | 2ull << 2) << 60;
+    const unsigned v = txtp < 16 ? (unsigned) (tab >> (4 * txtp)) & 15u : 0u;
     first = v & 3;
     second = v >> 2;
 }
@@ -84,6 +84,49 @@ constexpr int itx_lds_ints() {
     return (64 / LPB) * SH * (W + 1);
 }
 
+// What a wave can fetch for its transform blocks before it needs them (recon.hip's pipelined form issues these loads at the top of the
+// wave, under the prediction of the same blocks): the task record, then the part of the coefficient slab the scan reached (or coeff[0]
+// of a dc-only block).  itx_body<..., PRE = true> takes them from here instead of loading.
+template <int TX, typename coef>
+struct ItxPre {
+    static constexpr int W = tx_w(TX), H = tx_h(TX), SW = cmin(W, 32), SH = cmin(H, 32), LPB = cmax(SH, W), BPW = 64 / LPB;
+    static constexpr int NCH = SW * SH * (int) sizeof(coef) / 16, NV = (NCH + LPB - 1) / LPB;
+    Dav1dHipItxTask t;
+    int4 v[NV];
+    int dc;
+};
+template <int TX, typename coef>
+__device__ __forceinline__ void itx_prefetch_task(ItxPre<TX, coef> &pre, const Dav1dHipItxTask *__restrict__ tasks, const int n, const int group) {
+    typedef ItxPre<TX, coef> P;
+    const int lane = threadIdx.x & 63;
+    const int sub = P::BPW == 1 ? 0 : lane / P::LPB;
+    const int ti = group * P::BPW + sub;
+    const bool live = ti < n;
+    if (P::BPW == 1) pre.t = tasks[__builtin_amdgcn_readfirstlane(live ? ti : 0)];
+    else pre.t = tasks[live ? ti : 0];
+}
+template <int TX, typename coef>
+__device__ __forceinline__ void itx_prefetch_coefs(ItxPre<TX, coef> &pre, const coef *__restrict__ cf, const int n, const int group) {
+    typedef ItxPre<TX, coef> P;
+    const int lane = threadIdx.x & 63;
+    const int sub = P::BPW == 1 ? 0 : lane / P::LPB, l = P::BPW == 1 ? lane : lane % P::LPB;
+    const bool live = group * P::BPW + sub < n;
+    const Dav1dHipItxTask &t = pre.t;
+    const bool dconly = live && t.txtp == 0 && t.eob < 1;
+    const bool full = live && !dconly;
+    const coef *const gcf = cf + t.cf_off;
+    const bool packed = t.flags & DAV1D_HIP_ITX_PACKED;
+    const int nch = packed ? 0 : (((int) t.rsv[0] | ((int) t.rsv[1] << 8)) * (int) sizeof(coef) + 15) >> 4;
+    const int4 *g4 = reinterpret_cast<const int4 *>(gcf);
+    pre.dc = 0;
+#pragma unroll
+    for (int k = 0; k < P::NV; k++) {
+        pre.v[k] = make_int4(0, 0, 0, 0);
+        if (full && l + k * P::LPB < nch) pre.v[k] = g4[l + k * P::LPB];
+    }
+    if (dconly && l == 0) pre.dc = gcf[0];
+}
+
 // The wave `group` of the blocks of ONE transform size: blocks [group * BPW, group * BPW + BPW) of tasks[0 .. n).
 // PRED_LDS (fused prediction + residual kernels): the pixels the residual is added to come from pred_s (block `sub` of the
 // wave, W x H, row stride W) instead of the picture; the sum still goes to the picture.
@@ -91,10 +134,12 @@ constexpr int itx_lds_ints() {
 // task_off / task_plane (optional): this lane's copy of its block's dst_off / plane (lane b * LPB holds block b's), for tile_write_out.
 // tsrc (with COH, without PRED_LDS): `dst` holds the planes of the picture's tiled twin (8x8 tiles of 64 consecutive pixels, mc_body.h)
 // and the pixels the residual is added to are read from there — a frame whose pictures live in the twin only (DAV1D_HIP_TWIN_ONLY).
-template <int TX, typename pixel, typename coef, bool PRED_LDS = false, bool COH = false>
+// PRE: the record and the coefficients were fetched ahead of time (`pre`, ItxPre above).
+template <int TX, typename pixel, typename coef, bool PRED_LDS = false, bool COH = false, bool PRE = false>
 __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItxTask *__restrict__ tasks,
                                          const int n, coef *__restrict__ cf, const int bitdepth_max, const int group, int *tmp_s,
-                                         const pixel *pred_s = nullptr, const bool tsrc = false, uint32_t *task_off = nullptr, int *task_plane = nullptr)
+                                         const pixel *pred_s = nullptr, const bool tsrc = false, uint32_t *task_off = nullptr, int *task_plane = nullptr,
+                                         const ItxPre<TX, coef> *pre = nullptr)
 {
     constexpr int W = tx_w(TX), H = tx_h(TX);
     constexpr int SW = cmin(W, 32), SH = cmin(H, 32);
@@ -120,7 +165,8 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
     const bool live = ti < n;
 
     Dav1dHipItxTask t;
-    if (BPW == 1) t = tasks[__builtin_amdgcn_readfirstlane(live ? ti : 0)];   // one block per wave: record in SGPRs
+    if (PRE) t = pre->t;
+    else if (BPW == 1) t = tasks[__builtin_amdgcn_readfirstlane(live ? ti : 0)];   // one block per wave: record in SGPRs
     else t = tasks[live ? ti : 0];
 
     // (tile_write_out wants the blocks' positions: the lanes that hold a block's record hand them over, no second trip to memory)
@@ -182,7 +228,8 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
 #ifdef DV_KO_COEF
             if (l + k * LPB < nch) v[k] = make_int4(l, k, 0, 0);
 #else
-            if (l + k * LPB < nch) v[k] = g4[l + k * LPB];
+            if constexpr (PRE) v[k] = pre->v[k];
+            else if (l + k * LPB < nch) v[k] = g4[l + k * LPB];
 #endif
         }
         if (!PRED_LDS && l < W) load_dst(dpx);
@@ -194,7 +241,7 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
 #endif
         }
     } else if (dconly) {
-        if (l == 0) { dc = gcf[0]; if (!(t.flags & DAV1D_HIP_ITX_PACKED)) gcf[0] = 0; }            // src/itx_tmpl.c:59-60
+        if (l == 0) { dc = PRE ? pre->dc : gcf[0]; if (!(t.flags & DAV1D_HIP_ITX_PACKED)) gcf[0] = 0; }            // src/itx_tmpl.c:59-60
         if (!PRED_LDS && l < W) load_dst(dpx);
     }
     dc = __shfl(dc, sub * LPB);

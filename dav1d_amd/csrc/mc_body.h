@@ -67,6 +67,347 @@ constexpr int mc_lds_bytes() {
     return (WR0 + G * WRA) * WS * 2 + (G * NPRA + (TH == 4 ? 2 : 0)) * TW * 4 + (G > 1 ? G * (int) sizeof(McTile) + (int) sizeof(RefSet) : 0);
 }
 
+// ---- the shape of a tile class and what the stages of one prediction share
+template <int TW_, int TH_, typename pixel, bool TILED>
+struct McShape {
+    static constexpr int TW = TW_, TH = TH_;
+    static constexpr int NS = TW / 4;                          // 4-pixel strips per row
+    static constexpr int LPT = mc_cmin(64, TW * TH / 4);       // lanes per tile
+    static constexpr int G = 64 / LPT;                         // tiles side by side in a wave
+    static constexpr int R = TW * TH / 4 / LPT;                // output strips per lane (1, 2 or 4)
+    static constexpr int WS = TILED ? mc_win_stride_tiled(TW) : mc_win_stride(TW);    // window row stride (int16)
+    static constexpr int WR = TH + 8;                          // window rows ADDRESSED (TH+7 used, +1 so row pairs are complete)
+    static constexpr int WRA = mc_win_rows(TH), WR0 = mc_win_row0(TH);   // ... of which rows WR0 .. WR0 + WRA - 1 are this tile's own in LDS (see mc_win_rows)
+    static constexpr int WRG = TH == 4 ? WRA : WR - 1;         // rows the raster gathers fetch and store: WR0 .. WR0 + WRG - 1
+    static constexpr int NCH = (WS + 7) / 8;                   // 8-pixel (16-byte) chunks fetched per window row
+    static constexpr int NPR = WR / 2;                         // row pairs of the intermediate (addressed)
+    static constexpr int NPRA = WRA / 2, PR0 = WR0 / 2;        // ... kept per tile, first kept
+    static constexpr int NLD = (WRG * NCH + LPT - 1) / LPT;    // window loads per lane
+    static constexpr bool NARROW = TW == 4;                    // window columns start at src_x - 2 instead of src_x - 4, taps 2 .. 5 only
+    static constexpr bool HBD = sizeof(pixel) == 2;
+};
+
+// one prediction (one reference of one tile): what its filters are and which part of the window they reach
+struct McPred {
+    int fbits;
+    int row_lo, row_hi;       // window rows the vertical taps can reach: the others only ever meet zero taps, so they are neither
+                              // fetched nor filtered (6-tap regular, 4-tap smooth / small blocks, 2-tap bilinear, 1-tap full-pel)
+    int tx0, xa, toff;        // TILED: the window starts at the aligned piece that holds its first tap column; `toff` = that column's offset in the piece
+};
+template <int TW, int TH>
+__device__ __forceinline__ McPred mc_pred_of(const McRef rf) {
+    constexpr bool NARROW = TW == 4;
+    McPred p;
+    p.fbits = rf.fh == 6 ? 4 : 6;
+    const int vspan = rf.vspan;
+    // (4-row tiles keep rows 2 .. 9 only, mc_win_rows: their filters reach rows 2 .. 8; the clamp is for a caller that breaks the rule)
+    p.row_lo = TH == 4 ? dv::imax(vspan & 15, 2) : vspan & 15;
+    p.row_hi = TH == 4 ? dv::imin(TH - 1 + (vspan >> 4), 9) : TH - 1 + (vspan >> 4);
+    p.tx0 = rf.src_x - (NARROW ? 1 : 3); p.xa = p.tx0 & ~7; p.toff = p.tx0 & 7;
+    return p;
+}
+
+// ---- 1. gather the window of one prediction into `win` (this tile's rows of the wave's LDS window buffer); l = this lane's index in its tile
+template <int TW, int TH, typename pixel, bool TILED>
+__device__ __forceinline__ void mc_gather(const McRef rf, const McPred &pd, const pixel *src, const int rs, const int rw, const int rh,
+                                          int16_t *const win, const int l)
+{
+    typedef McShape<TW, TH, pixel, TILED> S;
+    constexpr int NS = S::NS, LPT = S::LPT, R = S::R, WS = S::WS, WR = S::WR, WR0 = S::WR0, WRG = S::WRG, NCH = S::NCH, NPR = S::NPR, NLD = S::NLD;
+    constexpr bool NARROW = S::NARROW, HBD = S::HBD;
+    (void) NS; (void) LPT; (void) R; (void) WS; (void) WR; (void) WR0; (void) WRG; (void) NCH; (void) NPR; (void) NLD; (void) NARROW; (void) HBD;
+    const int row_lo = pd.row_lo, row_hi = pd.row_hi, xa = pd.xa;
+    if constexpr (TILED) {
+        // columns the horizontal taps reach (the span table again, origin src_x - 3) and rows the vertical ones do: the window
+        // is "inside" when those are — the rest of it is neither fetched nor met by a non-zero tap
+        const int c_first = rf.src_x - 3 + (rf.hspan & 15), c_last = rf.src_x - 3 + TW - 2 + (rf.hspan >> 4);
+        const int y0 = rf.src_y - 3;
+        const bool interior = c_first >= 0 && c_last < rw && y0 + row_lo >= 0 && y0 + row_hi <= rh;
+        if (interior) {
+            // Lanes in a grid of rows x pieces, both powers of two (no division): lane -> (row lr of its row group, piece
+            // column lp), the loops step over row groups and piece columns.  Consecutive lanes walk down the rows of one
+            // tile column: 8 of them share a 128-byte line.  Tiles of 4 rows only ever meet the 4-tap / bilinear / unit
+            // sets vertically (blocks of height <= 4, reference GET_V_FILTER): rows 2 .. TH + 4 of the window.
+            constexpr int R0 = TH == 4 ? 2 : 0, NR = TH == 4 ? TH + 3 : WR - 1;
+            constexpr int RG = NR <= 8 ? 8 : NR <= 16 ? 16 : 32;                 // lanes of a row group
+            constexpr int RPAR = mc_cmin(LPT, RG), NRI = (NR + RPAR - 1) / RPAR;
+            constexpr int PG = LPT >= RG ? LPT / RG : 1, NPI = (NCH + PG - 1) / PG;
+            typedef typename std::conditional<HBD, uint4, uint2>::type piece_t;
+            const int lr = l & (RPAR - 1), lp = PG > 1 ? l / RG : 0;
+            piece_t ld[NRI][NPI];
+            bool ok[NRI][NPI];
+#pragma unroll
+            for (int ri = 0; ri < NRI; ri++) {
+                const int wr = R0 + lr + ri * RPAR, y = y0 + wr;
+                const bool row_ok = lr + ri * RPAR < NR && wr >= row_lo && wr < row_hi;
+                const pixel *prow = src + (dv::mul_i24(y & ~7, rs) + ((y & 7) << 3));
+#pragma unroll
+                for (int pi = 0; pi < NPI; pi++) {
+                    const int pc = lp + pi * PG, x = xa + 8 * pc;
+                    ok[ri][pi] = row_ok && pc < NCH && x + 7 >= c_first && x <= c_last;
+#ifdef DV_KO_GATHER      // (knock-out variant builds, tools/knockout.sh: timing only, the pixels are wrong)
+                    if (ok[ri][pi]) { ld[ri][pi].x = (unsigned) (size_t) prow; ld[ri][pi].y = (unsigned) x; if constexpr (HBD) { ld[ri][pi].z = 0; ld[ri][pi].w = 1; } }
+#else
+                    if (ok[ri][pi]) ld[ri][pi] = *reinterpret_cast<const piece_t *>(prow + (x << 3));
+#endif
+                }
+            }
+            // pieces that were not fetched are not stored either: what they would hold only ever meets zero taps
+#pragma unroll
+            for (int ri = 0; ri < NRI; ri++)
+#pragma unroll
+                for (int pi = 0; pi < NPI; pi++) {
+                    if (!ok[ri][pi]) continue;
+                    const int wr = R0 + lr + ri * RPAR, pc = lp + pi * PG;
+                    uint4 v;
+                    if constexpr (HBD) v = ld[ri][pi];
+                    else v = make_uint4(__builtin_amdgcn_perm(0u, ld[ri][pi].x, 0x0c010c00u), __builtin_amdgcn_perm(0u, ld[ri][pi].x, 0x0c030c02u),
+                                        __builtin_amdgcn_perm(0u, ld[ri][pi].y, 0x0c010c00u), __builtin_amdgcn_perm(0u, ld[ri][pi].y, 0x0c030c02u));
+                    *reinterpret_cast<uint4 *>(win + wr * WS + 8 * pc) = v;
+                }
+        } else {
+            // edge emulation through the tile addressing: per-pixel clamped fetch, 8 independent loads in flight per lane
+            for (int i0 = l; i0 < WRG * WS; i0 += 8 * LPT) {
+                pixel v[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int i = dv::imin(i0 + e * LPT, WRG * WS - 1);
+                    const int wq = dv::div_small<WS>(i), wr = WR0 + wq;
+                    const int sy = dv::iclip(y0 + wr, 0, rh - 1);
+                    const int sx = dv::iclip(xa + (i - wq * WS), 0, rw - 1);
+                    v[e] = src[dv::mul_i24(sy & ~7, rs) + ((sx >> 3) << 6) + ((sy & 7) << 3) + (sx & 7)];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int i = i0 + e * LPT;
+                    if (i < WRG * WS) win[WR0 * WS + i] = (int16_t) v[e];
+                }
+            }
+        }
+    } else {
+    const int x0 = rf.src_x - (NARROW ? 2 : 4), y0 = rf.src_y - 3;
+    const bool interior = x0 >= 0 && y0 + WR0 >= 0 && x0 + NCH * 8 <= rw && y0 + WR0 + WRG <= rh;
+    if (interior) {
+        // 16-byte (8-pixel) loads, rows at arbitrary 2-byte alignment; all of a lane's loads are
+        // issued before the first LDS write
+        const pixel *base = src + y0 * rs + x0;
+        uint4 ld[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int i = dv::imin(l + k * LPT, WRG * NCH - 1);
+            const int wq = dv::div_small<NCH>(i), wr = WR0 + wq;      // row and 8-pixel piece of the window; the offset stays in 32 bits
+            const pixel *p = base + (dv::mul_i24(wr, rs) + 8 * (i - wq * NCH));
+            ld[k] = make_uint4(0, 0, 0, 0);
+            if (wr < row_lo || wr >= row_hi) continue;
+            if (HBD) {
+                const U128u v = *reinterpret_cast<const U128u *>(p);
+                ld[k] = make_uint4(v.a, v.b, v.c, v.d);
+            } else {
+                const U64b v = *reinterpret_cast<const U64b *>(p);
+                // bytes -> 16-bit lanes: one byte permute per pair of pixels (selector 0x0c = a zero byte)
+                ld[k] = make_uint4(__builtin_amdgcn_perm(0u, v.a, 0x0c010c00u), __builtin_amdgcn_perm(0u, v.a, 0x0c030c02u),
+                                   __builtin_amdgcn_perm(0u, v.b, 0x0c010c00u), __builtin_amdgcn_perm(0u, v.b, 0x0c030c02u));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int i = l + k * LPT;
+            if (i >= WRG * NCH) continue;
+            const int wq = dv::div_small<NCH>(i), wr = WR0 + wq;
+            int16_t *const wp = win + wr * WS + 8 * (i - wq * NCH);
+            if (WS % 8 == 0) {
+                *reinterpret_cast<uint4 *>(wp) = ld[k];
+            } else {        // 12-column rows: 8-byte stores, the last chunk keeps only its first half
+                *reinterpret_cast<uint2 *>(wp) = make_uint2(ld[k].x, ld[k].y);
+                if (8 * (i - wq * NCH) + 8 <= WS) *reinterpret_cast<uint2 *>(wp + 4) = make_uint2(ld[k].z, ld[k].w);
+            }
+        }
+    } else {
+        // edge emulation: per-pixel clamped fetch, 8 independent loads in flight per lane
+        for (int i0 = l; i0 < WRG * WS; i0 += 8 * LPT) {
+            pixel v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int i = dv::imin(i0 + e * LPT, WRG * WS - 1);
+                const int sy = dv::iclip(y0 + WR0 + i / WS, 0, rh - 1);
+                const int sx = dv::iclip(x0 + i % WS, 0, rw - 1);
+                v[e] = src[sy * rs + sx];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int i = i0 + e * LPT;
+                if (i < WRG * WS) win[WR0 * WS + i] = (int16_t) v[e];
+            }
+        }
+    }
+    }
+}
+
+// ---- 1'. the same window by LDS-DMA (tiled references at 10 / 12 bits, tile shapes a whole wave works on): nothing is waited for and
+// no register holds a pixel — the caller issues the windows of every tile of its wave, then dv::glds_wait()s once.  The pieces land
+// lane-linear (dv::glds16), so lane i takes piece i of the window in ROW-major order: row i / NCH, piece i % NCH — which is where the
+// row stride of the tiled window (NCH pieces exactly) wants it.  Only windows that are inside the plane (mc_window_inside): the caller
+// runs mc_gather for the others when it gets to them.
+template <int TW, int TH>
+__device__ __forceinline__ bool mc_window_inside(const McRef rf, const McPred &pd, const int rw, const int rh) {
+    const int c_first = rf.src_x - 3 + (rf.hspan & 15), c_last = rf.src_x - 3 + TW - 2 + (rf.hspan >> 4);
+    const int y0 = rf.src_y - 3;
+    return c_first >= 0 && c_last < rw && y0 + pd.row_lo >= 0 && y0 + pd.row_hi <= rh;
+}
+template <int TW, int TH, typename pixel>
+__device__ __forceinline__ void mc_gather_dma(const McRef rf, const McPred &pd, const pixel *src, const int rs, int16_t *const win, const int lane)
+{
+    typedef McShape<TW, TH, pixel, true> S;
+    static_assert(S::HBD && S::G == 1 && TH != 4 && S::WS == 8 * S::NCH, "whole-wave tiles of 16-bit pixels");
+    constexpr int NCH = S::NCH, NP = (S::WR - 1) * NCH, NLD = (NP + 63) / 64;
+    const int c_first = rf.src_x - 3 + (rf.hspan & 15), c_last = rf.src_x - 3 + TW - 2 + (rf.hspan >> 4);
+    const int y0 = rf.src_y - 3;
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+        const int i = lane + 64 * k;
+        const int wr = dv::div_small<NCH>(i), pc = i - wr * NCH;
+        const int y = y0 + wr, x = pd.xa + 8 * pc;
+        // pieces the taps cannot reach are not fetched: what the window holds there only ever meets zero taps
+        const bool ok = i < NP && wr >= pd.row_lo && wr < pd.row_hi && x + 7 >= c_first && x <= c_last;
+#ifndef DV_KO_GATHER
+        if (ok) dv::glds16(src + (dv::mul_i24(y & ~7, rs) + ((y & 7) << 3) + (x << 3)), reinterpret_cast<char *>(win) + 1024 * k);
+#endif
+    }
+}
+
+// ---- 2. horizontal pass: item = (row pair, strip) -> mid2[pair][4 cols] = (even row, odd row)
+template <int TW, int TH, typename pixel, bool TILED>
+__device__ __forceinline__ void mc_hpass(const McPred &pd, const Taps &fh, const int16_t *const win, uint32_t *const mid, const int l,
+                                         const int ib, const int bias, const bool as_prep)
+{
+    typedef McShape<TW, TH, pixel, TILED> S;
+    constexpr int NS = S::NS, LPT = S::LPT, R = S::R, WS = S::WS, WR = S::WR, WR0 = S::WR0, WRG = S::WRG, NCH = S::NCH, NPR = S::NPR, NLD = S::NLD;
+    constexpr bool NARROW = S::NARROW, HBD = S::HBD;
+    (void) NS; (void) LPT; (void) R; (void) WS; (void) WR; (void) WR0; (void) WRG; (void) NCH; (void) NPR; (void) NLD; (void) NARROW; (void) HBD;
+    const int fbits = pd.fbits, row_lo = pd.row_lo, row_hi = pd.row_hi, toff = pd.toff;
+    (void) toff; (void) bias; (void) as_prep;
+    // One formula for the four cases of the reference (src/mc_tmpl.c:129-187 put, :246-305 prep, :434-586 bilinear): the intermediate is
+    // (sum + rnd) >> (fbits - ib) whether there is a horizontal filter or not — without one the tap table holds the unit tap at the
+    // filters' scale (64; bilinear 16), the sum is the pixel times the scale and the shift leaves pixel << ib exactly — and the vertical
+    // pass (mc_vpass) finishes every sample the same way.  The reference's H-only and V-only forms are these with the other direction's
+    // unit tap: ((s + r1) >> (6 - ib) + r2) >> ib == (s + 32 + r1) >> 6, and sums of pixel << ib have no low bits to round.
+    const int sh1 = fbits - ib;
+    const int rnd1 = (1 << sh1) >> 1;
+#pragma unroll
+    for (int it0 = 0; it0 < NPR * NS; it0 += LPT) {
+        const int it = it0 + l;
+        if (it >= NPR * NS) break;
+        const int pr = it / NS, s = it % NS;
+        if (2 * pr + 1 < row_lo || 2 * pr >= row_hi) continue;
+        int o[2][4];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const uint2 *wp = reinterpret_cast<const uint2 *>(win + (2 * pr + e) * WS + 4 * s);
+            int s0 = rnd1, s1 = rnd1, s2 = rnd1, s3 = rnd1;
+            if constexpr (TILED) {
+                // Output x of this strip sums f[k] * p[c + k] from window column c = toff + 4 s + x on.  c even: the pixel
+                // pairs of the row's dwords meet the tap pairs (f0, f1) (f2, f3) .. = ev[]; c odd: (0, f0) (f1, f2) .. = od[]
+                // one dword earlier.  Whether the strip's first column is even is a property of the tile (lists group
+                // tiles by it so that a wave rarely holds both kinds).
+                const uint32_t *dw = reinterpret_cast<const uint32_t *>(win + (2 * pr + e) * WS) + ((toff >> 1) + 2 * s);
+                if constexpr (NARROW) {
+                    // taps 2 .. 5 only: the sums start one tap pair (two columns) into the 8-tap layout
+                    const uint32_t d0 = dw[0], d1 = dw[1], d2 = dw[2], d3 = dw[3];
+                    if (!(toff & 1)) {
+                        s0 = dv::dot2(d0, fh.ev[1], dv::dot2(d1, fh.ev[2], s0));
+                        s1 = dv::dot2(d0, fh.od[1], dv::dot2(d1, fh.od[2], dv::dot2(d2, fh.od[3], s1)));
+                        s2 = dv::dot2(d1, fh.ev[1], dv::dot2(d2, fh.ev[2], s2));
+                        s3 = dv::dot2(d1, fh.od[1], dv::dot2(d2, fh.od[2], dv::dot2(d3, fh.od[3], s3)));
+                    } else {
+                        s0 = dv::dot2(d0, fh.od[1], dv::dot2(d1, fh.od[2], dv::dot2(d2, fh.od[3], s0)));
+                        s1 = dv::dot2(d1, fh.ev[1], dv::dot2(d2, fh.ev[2], s1));
+                        s2 = dv::dot2(d1, fh.od[1], dv::dot2(d2, fh.od[2], dv::dot2(d3, fh.od[3], s2)));
+                        s3 = dv::dot2(d2, fh.ev[1], dv::dot2(d3, fh.ev[2], s3));
+                    }
+                } else {
+                    const uint32_t d[6] = { dw[0], dw[1], dw[2], dw[3], dw[4], dw[5] };
+                    if (!(toff & 1)) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { s0 = dv::dot2(d[k], fh.ev[k], s0); s2 = dv::dot2(d[k + 1], fh.ev[k], s2); }
+#pragma unroll
+                        for (int k = 0; k < 5; k++) { s1 = dv::dot2(d[k], fh.od[k], s1); s3 = dv::dot2(d[k + 1], fh.od[k], s3); }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 5; k++) { s0 = dv::dot2(d[k], fh.od[k], s0); s2 = dv::dot2(d[k + 1], fh.od[k], s2); }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { s1 = dv::dot2(d[k + 1], fh.ev[k], s1); s3 = dv::dot2(d[k + 2], fh.ev[k], s3); }
+                    }
+                }
+            } else if constexpr (NARROW) {
+                // out x sums f[k] * p[x - 1 + k] over k = 2 .. 5, p[] = the 8 pixels of the row: the tap pairs (f1, f2) (f3, f4)
+                // (f5, f6) and (f2, f3) (f4, f5) of the 8-tap layout meet pixel pairs two columns further left
+                const uint2 a = wp[0], b = wp[1];
+                const uint32_t d[4] = { a.x, a.y, b.x, b.y };
+#pragma unroll
+                for (int k = 0; k < 3; k++) { s0 = dv::dot2(d[k], fh.od[k + 1], s0); s2 = dv::dot2(d[k + 1], fh.od[k + 1], s2); }
+#pragma unroll
+                for (int k = 0; k < 2; k++) { s1 = dv::dot2(d[k + 1], fh.ev[k + 1], s1); s3 = dv::dot2(d[k + 2], fh.ev[k + 1], s3); }
+            } else {
+                const uint2 a = wp[0], b = wp[1], c = wp[2];
+                const uint32_t d[6] = { a.x, a.y, b.x, b.y, c.x, c.y };
+                // out x sums f[k] * p[x + 1 + k], p[] = the 12 pixels of d[]; the rounding offset seeds the sum
+#pragma unroll
+                for (int k = 0; k < 5; k++) { s0 = dv::dot2(d[k], fh.od[k], s0); s2 = dv::dot2(d[k + 1], fh.od[k], s2); }
+#pragma unroll
+                for (int k = 0; k < 4; k++) { s1 = dv::dot2(d[k + 1], fh.ev[k], s1); s3 = dv::dot2(d[k + 2], fh.ev[k], s3); }
+            }
+            o[e][0] = s0; o[e][1] = s1; o[e][2] = s2; o[e][3] = s3;
+        }
+        // intermediate rounding, reference src/mc_tmpl.c:150-152 (8-tap) / 462-464 (bilinear)
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) o[e][x] >>= sh1;
+        uint4 m;
+        m.x = dv::pack2(o[0][0], o[1][0]);
+        m.y = dv::pack2(o[0][1], o[1][1]);
+        m.z = dv::pack2(o[0][2], o[1][2]);
+        m.w = dv::pack2(o[0][3], o[1][3]);
+        *reinterpret_cast<uint4 *>(mid + pr * TW + 4 * s) = m;
+    }
+}
+
+// ---- 3. vertical pass: item = (output row, strip), R items per lane -> q[R][4]
+template <int TW, int TH, typename pixel, bool TILED>
+__device__ __forceinline__ void mc_vpass(const McPred &pd, const Taps &fv, const uint32_t *const mid, const int l,
+                                         const int ib, const int bias, const bool as_prep, int (&q)[McShape<TW, TH, pixel, TILED>::R][4])
+{
+    typedef McShape<TW, TH, pixel, TILED> S;
+    constexpr int NS = S::NS, LPT = S::LPT, R = S::R, WS = S::WS, WR = S::WR, WR0 = S::WR0, WRG = S::WRG, NCH = S::NCH, NPR = S::NPR, NLD = S::NLD;
+    constexpr bool NARROW = S::NARROW, HBD = S::HBD;
+    (void) NS; (void) LPT; (void) R; (void) WS; (void) WR; (void) WR0; (void) WRG; (void) NCH; (void) NPR; (void) NLD; (void) NARROW; (void) HBD;
+    const int fbits = pd.fbits;
+    // pixels: (sum + rnd) >> (fbits + ib), src/mc_tmpl.c:157-159, 176-178; intermediates of a compound: (sum + rnd) >> fbits, less the bias, :272-277, 294-299
+    const int sh2 = as_prep ? fbits : fbits + ib, vb = as_prep ? bias : 0;
+    const int rnd2 = (1 << sh2) >> 1;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int it = r * LPT + l;
+        const int vr = it / NS, vs = it % NS;
+        // rows vr .. vr+7 of the window = pairs j0 .. j0+4; odd vr starts in the middle of a pair
+        const int j0 = vr >> 1;
+        const bool odd = vr & 1;
+        int sum[4] = { rnd2, rnd2, rnd2, rnd2 };
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const uint32_t g = odd ? fv.od[k] : (k < 4 ? fv.ev[k] : 0u);
+            const int j = dv::imin(j0 + k, NPR - 1);     // the 5th pair of an even row is weight 0
+            const uint4 m = *reinterpret_cast<const uint4 *>(mid + j * TW + 4 * vs);
+            sum[0] = dv::dot2(m.x, g, sum[0]);
+            sum[1] = dv::dot2(m.y, g, sum[1]);
+            sum[2] = dv::dot2(m.z, g, sum[2]);
+            sum[3] = dv::dot2(m.w, g, sum[3]);
+        }
+#pragma unroll
+        for (int x = 0; x < 4; x++) q[r][x] = (sum[x] >> sh2) - vb;
+    }
+}
+
 // One wave's worth of tiles of shape (TW, TH): tiles[t0 .. t0 + nt), nt <= 64 / LPT.  `smem` = mc_lds_bytes<TW, TH>() of LDS.
 // TO_LDS (fused prediction + residual kernels): pixels of PUT / AVG / WAVG tiles go to pred_s instead of the picture — block
 // (tile index - pred_tile0) >> pred_tpb_log2 of the wave, pred_w x pred_h pixels each, row stride pred_w.
@@ -163,18 +504,8 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
     // one prediction (gather -> h -> v) of this lane's strips into q[]; a lambda invoked once or
     // twice rather than a loop over t.r[] so that the record is never indexed dynamically
     auto predict = [&](const McRef rf, const bool act) {
-        const bool has_h = rf.mx != 0, has_v = rf.my != 0;
-        const int fbits = rf.fh == 6 ? 4 : 6;
+        const McPred pd = mc_pred_of<TW, TH>(rf);
         const Taps fh = load_taps(rf.fh, rf.mx), fv = load_taps(rf.fv, rf.my);
-        // window rows the vertical taps can reach: the others only ever meet zero taps, so they are neither
-        // fetched nor filtered (6-tap regular, 4-tap smooth / small blocks, 2-tap bilinear, 1-tap full-pel)
-        const int vspan = rf.vspan;
-        // (4-row tiles keep rows 2 .. 9 only, mc_win_rows: their filters reach rows 2 .. 8; the clamp is for a caller that breaks the rule)
-        const int row_lo = TH == 4 ? dv::imax(vspan & 15, 2) : vspan & 15, row_hi = TH == 4 ? dv::imin(TH - 1 + (vspan >> 4), 9) : TH - 1 + (vspan >> 4);
-        // TILED: the window starts at the aligned piece that holds its first tap column; `toff` = that column's offset in the piece
-        const int tx0 = rf.src_x - (NARROW ? 1 : 3), xa = tx0 & ~7, toff = tx0 & 7;
-
-        // ---- 1. gather the window
         if (act) {
             const pixel *src;
             int rs, rw, rh;
@@ -185,278 +516,29 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
             } else {
                 constexpr int RW = sizeof(McTile) / 4, DW = sizeof(DevPlanes) / 4;
                 const uint32_t *rt = mid_s + G * NPRA * TW + SL + G * RW + rf.ref * DW;      // == ref_s above
-                const uint32_t *pd = rt + 2 * t.plane;
-                src = reinterpret_cast<const pixel *>((uint64_t) pd[0] | ((uint64_t) pd[1] << 32));
+                const uint32_t *pdat = rt + 2 * t.plane;
+                src = reinterpret_cast<const pixel *>((uint64_t) pdat[0] | ((uint64_t) pdat[1] << 32));
                 rs = (int) rt[6 + t.plane]; rw = (int) rt[9 + t.plane]; rh = (int) rt[12 + t.plane];
             }
-            if constexpr (TILED) {
-                // columns the horizontal taps reach (the span table again, origin src_x - 3) and rows the vertical ones do: the window
-                // is "inside" when those are — the rest of it is neither fetched nor met by a non-zero tap
-                const int c_first = rf.src_x - 3 + (rf.hspan & 15), c_last = rf.src_x - 3 + TW - 2 + (rf.hspan >> 4);
-                const int y0 = rf.src_y - 3;
-                const bool interior = c_first >= 0 && c_last < rw && y0 + row_lo >= 0 && y0 + row_hi <= rh;
-                if (interior) {
-                    // Lanes in a grid of rows x pieces, both powers of two (no division): lane -> (row lr of its row group, piece
-                    // column lp), the loops step over row groups and piece columns.  Consecutive lanes walk down the rows of one
-                    // tile column: 8 of them share a 128-byte line.  Tiles of 4 rows only ever meet the 4-tap / bilinear / unit
-                    // sets vertically (blocks of height <= 4, reference GET_V_FILTER): rows 2 .. TH + 4 of the window.
-                    constexpr int R0 = TH == 4 ? 2 : 0, NR = TH == 4 ? TH + 3 : WR - 1;
-                    constexpr int RG = NR <= 8 ? 8 : NR <= 16 ? 16 : 32;                 // lanes of a row group
-                    constexpr int RPAR = mc_cmin(LPT, RG), NRI = (NR + RPAR - 1) / RPAR;
-                    constexpr int PG = LPT >= RG ? LPT / RG : 1, NPI = (NCH + PG - 1) / PG;
-                    typedef typename std::conditional<HBD, uint4, uint2>::type piece_t;
-                    const int lr = l & (RPAR - 1), lp = PG > 1 ? l / RG : 0;
-                    piece_t ld[NRI][NPI];
-                    bool ok[NRI][NPI];
-#pragma unroll
-                    for (int ri = 0; ri < NRI; ri++) {
-                        const int wr = R0 + lr + ri * RPAR, y = y0 + wr;
-                        const bool row_ok = lr + ri * RPAR < NR && wr >= row_lo && wr < row_hi;
-                        const pixel *prow = src + (dv::mul_i24(y & ~7, rs) + ((y & 7) << 3));
-#pragma unroll
-                        for (int pi = 0; pi < NPI; pi++) {
-                            const int pc = lp + pi * PG, x = xa + 8 * pc;
-                            ok[ri][pi] = row_ok && pc < NCH && x + 7 >= c_first && x <= c_last;
-#ifdef DV_KO_GATHER      // (knock-out variant builds, tools/knockout.sh: timing only, the pixels are wrong)
-                            if (ok[ri][pi]) { ld[ri][pi].x = (unsigned) (size_t) prow; ld[ri][pi].y = (unsigned) x; if constexpr (HBD) { ld[ri][pi].z = 0; ld[ri][pi].w = 1; } }
-#else
-                            if (ok[ri][pi]) ld[ri][pi] = *reinterpret_cast<const piece_t *>(prow + (x << 3));
-#endif
-                        }
-                    }
-                    // pieces that were not fetched are not stored either: what they would hold only ever meets zero taps
-#pragma unroll
-                    for (int ri = 0; ri < NRI; ri++)
-#pragma unroll
-                        for (int pi = 0; pi < NPI; pi++) {
-                            if (!ok[ri][pi]) continue;
-                            const int wr = R0 + lr + ri * RPAR, pc = lp + pi * PG;
-                            uint4 v;
-                            if constexpr (HBD) v = ld[ri][pi];
-                            else v = make_uint4(__builtin_amdgcn_perm(0u, ld[ri][pi].x, 0x0c010c00u), __builtin_amdgcn_perm(0u, ld[ri][pi].x, 0x0c030c02u),
-                                                __builtin_amdgcn_perm(0u, ld[ri][pi].y, 0x0c010c00u), __builtin_amdgcn_perm(0u, ld[ri][pi].y, 0x0c030c02u));
-                            *reinterpret_cast<uint4 *>(win + wr * WS + 8 * pc) = v;
-                        }
-                } else {
-                    // edge emulation through the tile addressing: per-pixel clamped fetch, 8 independent loads in flight per lane
-                    for (int i0 = l; i0 < WRG * WS; i0 += 8 * LPT) {
-                        pixel v[8];
-#pragma unroll
-                        for (int e = 0; e < 8; e++) {
-                            const int i = dv::imin(i0 + e * LPT, WRG * WS - 1);
-                            const int wq = dv::div_small<WS>(i), wr = WR0 + wq;
-                            const int sy = dv::iclip(y0 + wr, 0, rh - 1);
-                            const int sx = dv::iclip(xa + (i - wq * WS), 0, rw - 1);
-                            v[e] = src[dv::mul_i24(sy & ~7, rs) + ((sx >> 3) << 6) + ((sy & 7) << 3) + (sx & 7)];
-                        }
-#pragma unroll
-                        for (int e = 0; e < 8; e++) {
-                            const int i = i0 + e * LPT;
-                            if (i < WRG * WS) win[WR0 * WS + i] = (int16_t) v[e];
-                        }
-                    }
-                }
-            } else {
-            const int x0 = rf.src_x - (NARROW ? 2 : 4), y0 = rf.src_y - 3;
-            const bool interior = x0 >= 0 && y0 + WR0 >= 0 && x0 + NCH * 8 <= rw && y0 + WR0 + WRG <= rh;
-            if (interior) {
-                // 16-byte (8-pixel) loads, rows at arbitrary 2-byte alignment; all of a lane's loads are
-                // issued before the first LDS write
-                const pixel *base = src + y0 * rs + x0;
-                uint4 ld[NLD];
-#pragma unroll
-                for (int k = 0; k < NLD; k++) {
-                    const int i = dv::imin(l + k * LPT, WRG * NCH - 1);
-                    const int wq = dv::div_small<NCH>(i), wr = WR0 + wq;      // row and 8-pixel piece of the window; the offset stays in 32 bits
-                    const pixel *p = base + (dv::mul_i24(wr, rs) + 8 * (i - wq * NCH));
-                    ld[k] = make_uint4(0, 0, 0, 0);
-                    if (wr < row_lo || wr >= row_hi) continue;
-                    if (HBD) {
-                        const U128u v = *reinterpret_cast<const U128u *>(p);
-                        ld[k] = make_uint4(v.a, v.b, v.c, v.d);
-                    } else {
-                        const U64b v = *reinterpret_cast<const U64b *>(p);
-                        // bytes -> 16-bit lanes: one byte permute per pair of pixels (selector 0x0c = a zero byte)
-                        ld[k] = make_uint4(__builtin_amdgcn_perm(0u, v.a, 0x0c010c00u), __builtin_amdgcn_perm(0u, v.a, 0x0c030c02u),
-                                           __builtin_amdgcn_perm(0u, v.b, 0x0c010c00u), __builtin_amdgcn_perm(0u, v.b, 0x0c030c02u));
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < NLD; k++) {
-                    const int i = l + k * LPT;
-                    if (i >= WRG * NCH) continue;
-                    const int wq = dv::div_small<NCH>(i), wr = WR0 + wq;
-                    int16_t *const wp = win + wr * WS + 8 * (i - wq * NCH);
-                    if (WS % 8 == 0) {
-                        *reinterpret_cast<uint4 *>(wp) = ld[k];
-                    } else {        // 12-column rows: 8-byte stores, the last chunk keeps only its first half
-                        *reinterpret_cast<uint2 *>(wp) = make_uint2(ld[k].x, ld[k].y);
-                        if (8 * (i - wq * NCH) + 8 <= WS) *reinterpret_cast<uint2 *>(wp + 4) = make_uint2(ld[k].z, ld[k].w);
-                    }
-                }
-            } else {
-                // edge emulation: per-pixel clamped fetch, 8 independent loads in flight per lane
-                for (int i0 = l; i0 < WRG * WS; i0 += 8 * LPT) {
-                    pixel v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        const int i = dv::imin(i0 + e * LPT, WRG * WS - 1);
-                        const int sy = dv::iclip(y0 + WR0 + i / WS, 0, rh - 1);
-                        const int sx = dv::iclip(x0 + i % WS, 0, rw - 1);
-                        v[e] = src[sy * rs + sx];
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        const int i = i0 + e * LPT;
-                        if (i < WRG * WS) win[WR0 * WS + i] = (int16_t) v[e];
-                    }
-                }
-            }
-            }
+            mc_gather<TW, TH, pixel, TILED>(rf, pd, src, rs, rw, rh, win, l);
         }
         dv::wave_sync();
         DV_PHASE(PH + 1 + 3 * dv_second_);
-
-        // ---- 2. horizontal pass: item = (row pair, strip) -> mid2[pair][4 cols] = (even row, odd row)
 #ifdef DV_KO_HV
         if (act && bitdepth_max == 12345) {
 #else
         if (act) {
 #endif
-            const int sh1 = has_h ? fbits - ib : 0;
-            const int rnd1 = (1 << sh1) >> 1;
-#pragma unroll
-            for (int it0 = 0; it0 < NPR * NS; it0 += LPT) {
-                const int it = it0 + l;
-                if (it >= NPR * NS) break;
-                const int pr = it / NS, s = it % NS;
-                if (2 * pr + 1 < row_lo || 2 * pr >= row_hi) continue;
-                int o[2][4];
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const uint2 *wp = reinterpret_cast<const uint2 *>(win + (2 * pr + e) * WS + 4 * s);
-                    int s0 = rnd1, s1 = rnd1, s2 = rnd1, s3 = rnd1;
-                    if constexpr (TILED) {
-                        // Output x of this strip sums f[k] * p[c + k] from window column c = toff + 4 s + x on.  c even: the pixel
-                        // pairs of the row's dwords meet the tap pairs (f0, f1) (f2, f3) .. = ev[]; c odd: (0, f0) (f1, f2) .. = od[]
-                        // one dword earlier.  Whether the strip's first column is even is a property of the tile (lists group
-                        // tiles by it so that a wave rarely holds both kinds).
-                        const uint32_t *dw = reinterpret_cast<const uint32_t *>(win + (2 * pr + e) * WS) + ((toff >> 1) + 2 * s);
-                        if constexpr (NARROW) {
-                            // taps 2 .. 5 only: the sums start one tap pair (two columns) into the 8-tap layout
-                            const uint32_t d0 = dw[0], d1 = dw[1], d2 = dw[2], d3 = dw[3];
-                            if (!(toff & 1)) {
-                                s0 = dv::dot2(d0, fh.ev[1], dv::dot2(d1, fh.ev[2], s0));
-                                s1 = dv::dot2(d0, fh.od[1], dv::dot2(d1, fh.od[2], dv::dot2(d2, fh.od[3], s1)));
-                                s2 = dv::dot2(d1, fh.ev[1], dv::dot2(d2, fh.ev[2], s2));
-                                s3 = dv::dot2(d1, fh.od[1], dv::dot2(d2, fh.od[2], dv::dot2(d3, fh.od[3], s3)));
-                            } else {
-                                s0 = dv::dot2(d0, fh.od[1], dv::dot2(d1, fh.od[2], dv::dot2(d2, fh.od[3], s0)));
-                                s1 = dv::dot2(d1, fh.ev[1], dv::dot2(d2, fh.ev[2], s1));
-                                s2 = dv::dot2(d1, fh.od[1], dv::dot2(d2, fh.od[2], dv::dot2(d3, fh.od[3], s2)));
-                                s3 = dv::dot2(d2, fh.ev[1], dv::dot2(d3, fh.ev[2], s3));
-                            }
-                        } else {
-                            const uint32_t d[6] = { dw[0], dw[1], dw[2], dw[3], dw[4], dw[5] };
-                            if (!(toff & 1)) {
-#pragma unroll
-                                for (int k = 0; k < 4; k++) { s0 = dv::dot2(d[k], fh.ev[k], s0); s2 = dv::dot2(d[k + 1], fh.ev[k], s2); }
-#pragma unroll
-                                for (int k = 0; k < 5; k++) { s1 = dv::dot2(d[k], fh.od[k], s1); s3 = dv::dot2(d[k + 1], fh.od[k], s3); }
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < 5; k++) { s0 = dv::dot2(d[k], fh.od[k], s0); s2 = dv::dot2(d[k + 1], fh.od[k], s2); }
-#pragma unroll
-                                for (int k = 0; k < 4; k++) { s1 = dv::dot2(d[k + 1], fh.ev[k], s1); s3 = dv::dot2(d[k + 2], fh.ev[k], s3); }
-                            }
-                        }
-                    } else if constexpr (NARROW) {
-                        // out x sums f[k] * p[x - 1 + k] over k = 2 .. 5, p[] = the 8 pixels of the row: the tap pairs (f1, f2) (f3, f4)
-                        // (f5, f6) and (f2, f3) (f4, f5) of the 8-tap layout meet pixel pairs two columns further left
-                        const uint2 a = wp[0], b = wp[1];
-                        const uint32_t d[4] = { a.x, a.y, b.x, b.y };
-#pragma unroll
-                        for (int k = 0; k < 3; k++) { s0 = dv::dot2(d[k], fh.od[k + 1], s0); s2 = dv::dot2(d[k + 1], fh.od[k + 1], s2); }
-#pragma unroll
-                        for (int k = 0; k < 2; k++) { s1 = dv::dot2(d[k + 1], fh.ev[k + 1], s1); s3 = dv::dot2(d[k + 2], fh.ev[k + 1], s3); }
-                    } else {
-                        const uint2 a = wp[0], b = wp[1], c = wp[2];
-                        const uint32_t d[6] = { a.x, a.y, b.x, b.y, c.x, c.y };
-                        // out x sums f[k] * p[x + 1 + k], p[] = the 12 pixels of d[]; the rounding offset seeds the sum
-#pragma unroll
-                        for (int k = 0; k < 5; k++) { s0 = dv::dot2(d[k], fh.od[k], s0); s2 = dv::dot2(d[k + 1], fh.od[k], s2); }
-#pragma unroll
-                        for (int k = 0; k < 4; k++) { s1 = dv::dot2(d[k + 1], fh.ev[k], s1); s3 = dv::dot2(d[k + 2], fh.ev[k], s3); }
-                    }
-                    o[e][0] = s0; o[e][1] = s1; o[e][2] = s2; o[e][3] = s3;
-                }
-                if (has_v) {
-                    // intermediate rounding, reference src/mc_tmpl.c:150-152 (8-tap) / 462-464 (bilinear)
-#pragma unroll
-                    for (int e = 0; e < 2; e++)
-#pragma unroll
-                        for (int x = 0; x < 4; x++) o[e][x] >>= sh1;
-                } else {
-                    // no vertical filter: finish the sample here (the vertical pass is then the unit tap)
-#pragma unroll
-                    for (int e = 0; e < 2; e++)
-#pragma unroll
-                        for (int x = 0; x < 4; x++) {
-                            int v = o[e][x];            // = sum + rnd1
-                            if (!as_prep) {
-                                if (has_h) {
-                                    if (fbits == 4) v = ((v >> sh1) + ((1 << ib) >> 1)) >> ib;   // src/mc_tmpl.c:467-476
-                                    else            v = (v + 32) >> 6;                          // src/mc_tmpl.c:165-171
-                                }
-                            } else {
-                                v = has_h ? (v >> sh1) - bias : (v << ib) - bias;               // :283-291 / :61-72
-                            }
-                            o[e][x] = v;
-                        }
-                }
-                uint4 m;
-                m.x = dv::pack2(o[0][0], o[1][0]);
-                m.y = dv::pack2(o[0][1], o[1][1]);
-                m.z = dv::pack2(o[0][2], o[1][2]);
-                m.w = dv::pack2(o[0][3], o[1][3]);
-                *reinterpret_cast<uint4 *>(mid + pr * TW + 4 * s) = m;
-            }
+            mc_hpass<TW, TH, pixel, TILED>(pd, fh, win, mid, l, ib, bias, as_prep);
         }
         dv::wave_sync();
         DV_PHASE(PH + 2 + 3 * dv_second_);
-
-        // ---- 3. vertical pass: item = (output row, strip), R items per lane
 #ifdef DV_KO_HV
         if (act && bitdepth_max == 12345) {
 #else
         if (act) {
 #endif
-            int sh2, vb;
-            if (!has_v) { sh2 = 0; vb = 0; }
-            else if (!as_prep) { sh2 = has_h ? fbits + ib : fbits; vb = 0; }          // src/mc_tmpl.c:157-159,176-178
-            else { sh2 = has_h ? fbits : fbits - ib; vb = bias; }                     // :272-277, :294-299
-            const int rnd2 = (1 << sh2) >> 1;
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int it = r * LPT + l;
-                const int vr = it / NS, vs = it % NS;
-                // rows vr .. vr+7 of the window = pairs j0 .. j0+4; odd vr starts in the middle of a pair
-                const int j0 = vr >> 1;
-                const bool odd = vr & 1;
-                int sum[4] = { rnd2, rnd2, rnd2, rnd2 };
-#pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    const uint32_t g = odd ? fv.od[k] : (k < 4 ? fv.ev[k] : 0u);
-                    const int j = dv::imin(j0 + k, NPR - 1);     // the 5th pair of an even row is weight 0
-                    const uint4 m = *reinterpret_cast<const uint4 *>(mid + j * TW + 4 * vs);
-                    sum[0] = dv::dot2(m.x, g, sum[0]);
-                    sum[1] = dv::dot2(m.y, g, sum[1]);
-                    sum[2] = dv::dot2(m.z, g, sum[2]);
-                    sum[3] = dv::dot2(m.w, g, sum[3]);
-                }
-#pragma unroll
-                for (int x = 0; x < 4; x++) q[r][x] = (sum[x] >> sh2) - vb;
-            }
+            mc_vpass<TW, TH, pixel, TILED>(pd, fv, mid, l, ib, bias, as_prep, q);
         }
         DV_PHASE(PH + 3 + 3 * dv_second_);
     };

@@ -14,7 +14,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 NAMES = ["recon_%dx%d" % (4 << k, 4 << k) for k in range(5)] + ["mc_%dx%d" % (4 << (b // 3), 4 << (b % 3)) for b in range(15)] + ["comp"] + ["itx_%d" % b for b in range(19)]
-DEFAULTS = {"recon_fuse": 14, "recon_pair_streams": 1, "recon_lanes": 1, "recon_pipeline": 16384, "recon_coop_below": 4096}
+DEFAULTS = {"recon_pipe": 0, "recon_fuse": 14, "recon_pair_streams": 1, "recon_lanes": 1, "recon_pipeline": 16384, "recon_coop_below": 4096}
 
 
 def main():
@@ -166,7 +166,9 @@ def main():
         dt, pics = timed(rl, True)
         o = {"layout": "tiled", "lib": os.path.basename(a.lib) if a.lib else None, "opts": st, "ms_per_step": round(dt, 4), "twin_only": int(dsts[0].pic.twin_ok)}
         if base is not None:
-            o["equals_raster"] = all(np.array_equal(base[pl], pics[pl]) for pl in range(3))
+            o["equals_first" if a.no_raster else "equals_raster"] = all(np.array_equal(base[pl], pics[pl]) for pl in range(3))
+        elif a.no_raster:
+            base = pics         # (without the raster run every set is compared with the first one)
         if a.kernels:
             o["kernels_us"] = kernels(rl, True)
         if a.phases:
