@@ -36,7 +36,6 @@ struct Dav1dHipContext {
     long recon_pipeline;        // smallest residual list a recon list pipelines on two streams (DAV1D_HIP_RECON_PIPELINE)
     int recon_lanes;            // side streams of the residual launches (DAV1D_HIP_RECON_LANES)
     int chunk_upload;           // 0: a frame's chunks go up as one transfer at frame end; 1: each chunk as it is submitted (DAV1D_HIP_CHUNK_UPLOAD)
-    int recon_pipe;             // bit mask of the paired sizes that run in the pipelined form where it exists (recon.hip recon_piped_kernel; DAV1D_HIP_RECON_PIPE)
     int recon_coop_below;       // paired kernels: launches of fewer groups than this take the cooperative form (recon.hip; DAV1D_HIP_RECON_COOP_BELOW)
     int post_bands;             // bands of the pipelined post filters, 0 = stage by stage (DAV1D_HIP_POST_BANDS)
     int recon_pair_streams;     // side streams the paired launches of a recon list are dealt over (DAV1D_HIP_RECON_PAIR_STREAMS, 1 or 2)

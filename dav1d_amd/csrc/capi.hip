@@ -56,7 +56,6 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     c->recon_lanes = (int) env_int("DAV1D_HIP_RECON_LANES", 1);
     c->chunk_upload = (int) env_int("DAV1D_HIP_CHUNK_UPLOAD", 0);
     c->recon_coop_below = (int) env_int("DAV1D_HIP_RECON_COOP_BELOW", 4096);
-    c->recon_pipe = (int) env_int("DAV1D_HIP_RECON_PIPE", 0);
     c->post_bands = (int) env_int("DAV1D_HIP_POST_BANDS", 0);
     c->ref_twin = (int) env_int("DAV1D_HIP_REF_TWIN", 1);
     c->recon_pair_streams = (int) env_int("DAV1D_HIP_RECON_PAIR_STREAMS", 1);
@@ -188,7 +187,6 @@ int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value) {
     else if (!strcmp(name, "recon_lanes")) c->recon_lanes = (int) value;
     else if (!strcmp(name, "chunk_upload")) c->chunk_upload = (int) value;
     else if (!strcmp(name, "recon_coop_below")) c->recon_coop_below = (int) value;
-    else if (!strcmp(name, "recon_pipe")) c->recon_pipe = (int) value;
     else if (!strcmp(name, "post_bands")) c->post_bands = (int) value;
     else if (!strcmp(name, "ref_twin")) c->ref_twin = (int) value;
     else if (!strcmp(name, "recon_pair_streams")) c->recon_pair_streams = (int) value;
@@ -2043,7 +2041,7 @@ static int recon_list_run_impl(Dav1dHipContext *c, const Dav1dHipReconList *l, c
         for (int k = 4; k >= 0 && !rc; k--)
             if (l->f_n[k]) {
                 rc = dav1d_hip_launch_recon_fused_out(&dp, rp, n_refs, dst->bpc, k, l->f_tiles[k], l->f_tasks[k], (int) l->f_n[k], prep, coef, c->recon_coop_below,
-                                                      wide ? 1 | ((c->recon_pipe >> k & 1) << 1) : 0, dst_twin, side ? c->side[ps[lane]] : c->stream);
+                                                      wide, dst_twin, side ? c->side[ps[lane]] : c->stream);
                 lane ^= 1;
             }
         if (side) {
@@ -2180,7 +2178,7 @@ static int recon_list_run_timed_impl(Dav1dHipContext *c, const Dav1dHipReconList
         if (k < 5) {
             cnt = l->f_n[k];
             if (cnt) rc = dav1d_hip_launch_recon_fused_out(&dp, rp, n_refs, dst->bpc, k, l->f_tiles[k], l->f_tasks[k], (int) cnt, prep, coef, c->recon_coop_below,
-                                                           dst_twin != nullptr ? 1 | ((c->recon_pipe >> k & 1) << 1) : 0, dst_twin, c->stream);
+                                                           dst_twin != nullptr, dst_twin, c->stream);
         } else if (k < 20) {
             const int b = k - 5;
             cnt = ml->off[b + 1] - ml->off[b];

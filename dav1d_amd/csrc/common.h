@@ -284,6 +284,9 @@ __device__ __forceinline__ void off_to_xy(const uint32_t off, const int stride, 
     x = r; y = q;
 }
 
+// This lane's index in its wave
+__device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & 63); }
+
 // LDS hand-off between the lanes of ONE wave (no other wave reads the data): order the
 // accesses and let the wave's outstanding LDS operations land; no s_barrier involved, so
 // waves of a workgroup never wait for each other.
@@ -294,28 +297,6 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
-}
-
-// ---- global memory straight into LDS (LDS-DMA, global_load_lds_dwordx4): lane i's 16 bytes land at lds_base + 16 * i, lds_base
-// wave-uniform.  No register holds the data and nothing waits: a wave issues the fetches of everything it is going to need and computes
-// on what has arrived.  The hardware orders a later LDS read behind the transfer ONLY through the issuing wave's own vector-memory
-// counter (MI355X_MICROARCH.md "Co-residence", item 7): glds_wait() before the first read, always.  The instruction is spelled in
-// assembly so that the compiler neither tracks it (it would drain the counter before every LDS read that might alias) nor moves memory
-// operations across it; M0 (the destination base) is saved and restored around it.
-__device__ __forceinline__ void glds16(const void *gsrc, void *lds_base) {
-#ifdef DAV1D_HIP_EMU
-    memcpy(reinterpret_cast<char *>(lds_base) + 16 * emu_lane(), gsrc, 16);
-#else
-    const uint32_t dst = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (uintptr_t) (__attribute__((address_space(3))) char *) lds_base);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
-#endif
-}
-__device__ __forceinline__ void glds_wait() {          // every transfer this wave has issued is in LDS
-#ifndef DAV1D_HIP_EMU
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
 

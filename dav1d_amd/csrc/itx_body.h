@@ -98,7 +98,7 @@ struct ItxPre {
 template <int TX, typename coef>
 __device__ __forceinline__ void itx_prefetch_task(ItxPre<TX, coef> &pre, const Dav1dHipItxTask *__restrict__ tasks, const int n, const int group) {
     typedef ItxPre<TX, coef> P;
-    const int lane = threadIdx.x & 63;
+    const int lane = dv::lane_id();
     const int sub = P::BPW == 1 ? 0 : lane / P::LPB;
     const int ti = group * P::BPW + sub;
     const bool live = ti < n;
@@ -108,7 +108,7 @@ __device__ __forceinline__ void itx_prefetch_task(ItxPre<TX, coef> &pre, const D
 template <int TX, typename coef>
 __device__ __forceinline__ void itx_prefetch_coefs(ItxPre<TX, coef> &pre, const coef *__restrict__ cf, const int n, const int group) {
     typedef ItxPre<TX, coef> P;
-    const int lane = threadIdx.x & 63;
+    const int lane = dv::lane_id();
     const int sub = P::BPW == 1 ? 0 : lane / P::LPB, l = P::BPW == 1 ? lane : lane % P::LPB;
     const bool live = group * P::BPW + sub < n;
     const Dav1dHipItxTask &t = pre.t;
@@ -159,7 +159,7 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
     // 3 column pass + add + store, 4 whole body, 5 bodies counted
     constexpr int PH = 512 + TX * 16 + (PRED_LDS ? 8 : 0);
     DV_PHASE_BEGIN();
-    const int lane = threadIdx.x & 63;       // the body belongs to one wave (recon.hip runs several side by side in a workgroup)
+    const int lane = dv::lane_id();       // the body belongs to one wave (recon.hip runs several side by side in a workgroup)
     const int sub = BPW == 1 ? 0 : lane / LPB, l = BPW == 1 ? lane : lane % LPB;
     const int ti = group * BPW + sub;
     const bool live = ti < n;
@@ -377,7 +377,7 @@ __device__ __forceinline__ void tile_write_out(const pixel *tile, const Dav1dHip
     constexpr int BYTES = CP * (int) sizeof(pixel);
     typedef typename std::conditional<BYTES == 16, uint4, typename std::conditional<BYTES == 8, uint2, uint32_t>::type>::type piece_t;
     static_assert(BYTES == 4 || BYTES == 8 || BYTES == 16, "piece size");
-    const int lane = threadIdx.x & 63;
+    const int lane = dv::lane_id();
     // lane b knows block b: plane and position, handed to the lanes that store the block's pieces by wave shuffles
     int bx = 0, by = 0, bpl = 0;
     if (task_plane >= 0) {

@@ -49,7 +49,12 @@ constexpr int mc_win_stride(int tw) { return tw == 4 ? 8 : (tw + 8 + 7) & ~7; }
 // The same for a reference stored as 8x8 tiles (TILED, see "tiled twin" below): the window is made of whole tile rows — aligned
 // 8-pixel pieces — so it starts at the piece that holds the first column the taps reach (src_x - 3; 4-wide tiles src_x - 1) and
 // holds one piece more than the span needs: TW + 7 (7) columns at any of 8 offsets
-constexpr int mc_win_stride_tiled(int tw) { return tw == 4 ? 16 : tw + 16; }
+// (16-wide tiles: 8 pixels of padding.  A row pair of 2 x 32 pixels is exactly the 32 banks of the LDS, so the twelve row pairs the lanes
+// of a horizontal pass read side by side all sat on the same banks — 56 % of the 16x16 pairs' LDS cycles were bank conflicts,
+// profiles/r06/lds_conflicts.txt; with 40 the pairs step through four bank groups, which is what three times 32 dwords need anyway)
+constexpr int mc_win_stride_tiled(int tw) { return tw == 4 ? 16 : tw == 16 ? 40 : tw + 16; }
+// pieces of 8 pixels a row of the tiled window is fetched in (the stride may hold padding on top)
+constexpr int mc_win_pieces_tiled(int tw) { return tw == 4 ? 2 : (tw + 16) / 8; }
 
 // LDS bytes one wave needs for tile shape (TW, TH): window + row-pair intermediate + the tile records
 // Rows of the window a tile of TH rows KEEPS in LDS, and the first of them.  The bodies below index a window of TH + 8 rows (the reach of
@@ -79,7 +84,7 @@ struct McShape {
     static constexpr int WR = TH + 8;                          // window rows ADDRESSED (TH+7 used, +1 so row pairs are complete)
     static constexpr int WRA = mc_win_rows(TH), WR0 = mc_win_row0(TH);   // ... of which rows WR0 .. WR0 + WRA - 1 are this tile's own in LDS (see mc_win_rows)
     static constexpr int WRG = TH == 4 ? WRA : WR - 1;         // rows the raster gathers fetch and store: WR0 .. WR0 + WRG - 1
-    static constexpr int NCH = (WS + 7) / 8;                   // 8-pixel (16-byte) chunks fetched per window row
+    static constexpr int NCH = TILED ? mc_win_pieces_tiled(TW) : (WS + 7) / 8;   // 8-pixel (16-byte) chunks fetched per window row
     static constexpr int NPR = WR / 2;                         // row pairs of the intermediate (addressed)
     static constexpr int NPRA = WRA / 2, PR0 = WR0 / 2;        // ... kept per tile, first kept
     static constexpr int NLD = (WRG * NCH + LPT - 1) / LPT;    // window loads per lane
@@ -243,38 +248,6 @@ __device__ __forceinline__ void mc_gather(const McRef rf, const McPred &pd, cons
     }
 }
 
-// ---- 1'. the same window by LDS-DMA (tiled references at 10 / 12 bits, tile shapes a whole wave works on): nothing is waited for and
-// no register holds a pixel — the caller issues the windows of every tile of its wave, then dv::glds_wait()s once.  The pieces land
-// lane-linear (dv::glds16), so lane i takes piece i of the window in ROW-major order: row i / NCH, piece i % NCH — which is where the
-// row stride of the tiled window (NCH pieces exactly) wants it.  Only windows that are inside the plane (mc_window_inside): the caller
-// runs mc_gather for the others when it gets to them.
-template <int TW, int TH>
-__device__ __forceinline__ bool mc_window_inside(const McRef rf, const McPred &pd, const int rw, const int rh) {
-    const int c_first = rf.src_x - 3 + (rf.hspan & 15), c_last = rf.src_x - 3 + TW - 2 + (rf.hspan >> 4);
-    const int y0 = rf.src_y - 3;
-    return c_first >= 0 && c_last < rw && y0 + pd.row_lo >= 0 && y0 + pd.row_hi <= rh;
-}
-template <int TW, int TH, typename pixel>
-__device__ __forceinline__ void mc_gather_dma(const McRef rf, const McPred &pd, const pixel *src, const int rs, int16_t *const win, const int lane)
-{
-    typedef McShape<TW, TH, pixel, true> S;
-    static_assert(S::HBD && S::G == 1 && TH != 4 && S::WS == 8 * S::NCH, "whole-wave tiles of 16-bit pixels");
-    constexpr int NCH = S::NCH, NP = (S::WR - 1) * NCH, NLD = (NP + 63) / 64;
-    const int c_first = rf.src_x - 3 + (rf.hspan & 15), c_last = rf.src_x - 3 + TW - 2 + (rf.hspan >> 4);
-    const int y0 = rf.src_y - 3;
-#pragma unroll
-    for (int k = 0; k < NLD; k++) {
-        const int i = lane + 64 * k;
-        const int wr = dv::div_small<NCH>(i), pc = i - wr * NCH;
-        const int y = y0 + wr, x = pd.xa + 8 * pc;
-        // pieces the taps cannot reach are not fetched: what the window holds there only ever meets zero taps
-        const bool ok = i < NP && wr >= pd.row_lo && wr < pd.row_hi && x + 7 >= c_first && x <= c_last;
-#ifndef DV_KO_GATHER
-        if (ok) dv::glds16(src + (dv::mul_i24(y & ~7, rs) + ((y & 7) << 3) + (x << 3)), reinterpret_cast<char *>(win) + 1024 * k);
-#endif
-    }
-}
-
 // ---- 2. horizontal pass: item = (row pair, strip) -> mid2[pair][4 cols] = (even row, odd row)
 template <int TW, int TH, typename pixel, bool TILED>
 __device__ __forceinline__ void mc_hpass(const McPred &pd, const Taps &fh, const int16_t *const win, uint32_t *const mid, const int l,
@@ -435,7 +408,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
     constexpr int WR = TH + 8;                          // window rows ADDRESSED (TH+7 used, +1 so row pairs are complete)
     constexpr int WRA = mc_win_rows(TH), WR0 = mc_win_row0(TH);   // ... of which rows WR0 .. WR0 + WRA - 1 are this tile's own in LDS (see mc_win_rows)
     constexpr int WRG = TH == 4 ? WRA : WR - 1;         // rows the raster gathers fetch and store: WR0 .. WR0 + WRG - 1
-    constexpr int NCH = (WS + 7) / 8;                   // 8-pixel (16-byte) chunks fetched per window row
+    constexpr int NCH = TILED ? mc_win_pieces_tiled(TW) : (WS + 7) / 8;   // 8-pixel (16-byte) chunks fetched per window row
     constexpr int NPR = WR / 2;                         // row pairs of the intermediate (addressed)
     constexpr int NPRA = WRA / 2, PR0 = WR0 / 2;        // ... kept per tile, first kept
     constexpr int NLD = (WRG * NCH + LPT - 1) / LPT;    // window loads per lane
@@ -451,7 +424,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
     constexpr int SL = TH == 4 ? TW : 0;                // 4-row tiles: one pair of slack in front of and behind the intermediates
     uint32_t *const mid_s = reinterpret_cast<uint32_t *>(win_s + (WR0 + G * WRA) * WS) + SL;
 
-    const int lane = threadIdx.x & 63;       // the body belongs to one wave (recon.hip runs several side by side in a workgroup)
+    const int lane = dv::lane_id();       // the body belongs to one wave (recon.hip runs several side by side in a workgroup)
     // G == 1: the whole wave works on one tile, so the record, the taps and all the control flow
     // derived from them are wave-uniform (scalar loads, SGPRs, s_cbranch instead of exec masking)
     const int sub = G == 1 ? 0 : lane / LPT, l = G == 1 ? lane : lane % LPT;

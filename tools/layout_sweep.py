@@ -14,7 +14,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 NAMES = ["recon_%dx%d" % (4 << k, 4 << k) for k in range(5)] + ["mc_%dx%d" % (4 << (b // 3), 4 << (b % 3)) for b in range(15)] + ["comp"] + ["itx_%d" % b for b in range(19)]
-DEFAULTS = {"recon_pipe": 0, "recon_fuse": 14, "recon_pair_streams": 1, "recon_lanes": 1, "recon_pipeline": 16384, "recon_coop_below": 4096}
+DEFAULTS = {"recon_fuse": 14, "recon_pair_streams": 1, "recon_lanes": 1, "recon_pipeline": 16384, "recon_coop_below": 4096}
 
 
 def main():
@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--no-raster", action="store_true")
     ap.add_argument("--edge-frac", type=float, default=0.05, help="share of the blocks whose motion vectors point across the picture's edge (bench.py: 0.05)")
     ap.add_argument("--phases", action="store_true", help="with a -DDV_PHASES variant (--lib): shader-clock cycles per wave and phase of every kernel, from one event-bracketed run")
+    ap.add_argument("--inflight", type=int, default=1, help="frames in flight: N contexts with streams and lists of their own, the steps dealt over them in turn (tiled sets only)")
+    ap.add_argument("--digest", action="store_true", help="a digest of the last picture of every set (to compare runs of different libraries)")
     ap.add_argument("--lib", default=None, help="a variant build (tools/build_variant.py) instead of dav1d_amd/libdav1d_hip.so")
     a = ap.parse_args()
     import torch
@@ -55,7 +57,7 @@ def main():
     prep = torch.zeros(frame.prep_elems, dtype=torch.int16, device="cuda")
     tdt = torch.int16 if bpc == 8 else torch.int32
     pristine = torch.from_numpy(frame.coef).to("cuda")
-    n_arena = a.steps + 8
+    n_arena = a.steps + 10
     arenas = torch.empty((n_arena, pristine.numel()), dtype=tdt, device="cuda")
 
     def fresh():
@@ -63,20 +65,31 @@ def main():
             arenas[i].copy_(pristine)
         torch.cuda.synchronize()
 
-    def timed(rl, tiled):
+    extra = []          # --inflight: further contexts, each on a stream of its own
+    for _ in range(a.inflight - 1):
+        st2 = torch.cuda.Stream()
+        extra.append((api.Context(0, stream=st2.cuda_stream, lib_path=a.lib), st2, torch.zeros(frame.prep_elems, dtype=torch.int16, device="cuda")))
+
+    def timed(rl, tiled, more=()):
         fresh()
-        run = rl.run_tiled if tiled else rl.run
-        for i in range(3):
-            run(dsts[i % 4], refs, prep.data_ptr(), arenas[i].data_ptr())
-        ctx.sync()
-        torch.cuda.synchronize()
+        lanes = [(rl, prep)] + [(r2, p2) for r2, p2 in more]
+        def run(i):
+            l_, p_ = lanes[i % len(lanes)]
+            (l_.run_tiled if tiled else l_.run)(dsts[i % 4], refs, p_.data_ptr(), arenas[i].data_ptr())
+        def sync_all():
+            ctx.sync()
+            for c2, _, _ in extra:
+                c2.sync()
+            torch.cuda.synchronize()
+        for i in range(4):
+            run(i)
+        sync_all()
         t0 = time.perf_counter()
-        for i in range(3, 3 + a.steps):
-            run(dsts[i % 4], refs, prep.data_ptr(), arenas[i].data_ptr())
-        ctx.sync()
-        torch.cuda.synchronize()
+        for i in range(4, 4 + a.steps):
+            run(i)
+        sync_all()
         dt = (time.perf_counter() - t0) / a.steps * 1e3
-        pics = [dsts[(2 + a.steps) % 4].download(pl) for pl in range(3)]
+        pics = [dsts[(3 + a.steps) % 4].download(pl) for pl in range(3)]
         return dt, pics
 
     def kernels(rl, tiled):
@@ -159,16 +172,26 @@ def main():
         for k, v in opts.items():
             ctx.set_option(k, v)
         rl = ctx.recon_list(dsts[0], frame.mc, frame.comp, frame.itx)        # (the pairing is decided at list creation)
+        more = []
+        for c2, _, p2 in extra:
+            for k, v in opts.items():
+                c2.set_option(k, v)
+            more.append((c2.recon_list(dsts[0], frame.mc, frame.comp, frame.itx), p2))
         for d in dsts:
             d.pic.twin_ok = 0
             for pl in range(3):
                 d.upload(pl, dst_host[pl])
-        dt, pics = timed(rl, True)
-        o = {"layout": "tiled", "lib": os.path.basename(a.lib) if a.lib else None, "opts": st, "ms_per_step": round(dt, 4), "twin_only": int(dsts[0].pic.twin_ok)}
+        dt, pics = timed(rl, True, more)
+        for r2, _ in more:
+            r2.destroy()
+        o = {"layout": "tiled", "lib": os.path.basename(a.lib) if a.lib else None, "opts": st, "inflight": a.inflight, "ms_per_step": round(dt, 4), "twin_only": int(dsts[0].pic.twin_ok)}
         if base is not None:
             o["equals_first" if a.no_raster else "equals_raster"] = all(np.array_equal(base[pl], pics[pl]) for pl in range(3))
         elif a.no_raster:
             base = pics         # (without the raster run every set is compared with the first one)
+        if a.digest:
+            import hashlib
+            o["digest"] = hashlib.sha1(b"".join(np.ascontiguousarray(p_).tobytes() for p_ in pics)).hexdigest()[:12]
         if a.kernels:
             o["kernels_us"] = kernels(rl, True)
         if a.phases:

@@ -9,4 +9,4 @@ for f in sys.argv[1:]:
             continue
         k = d.get("kernels_us") or {}
         eq = d.get("equals_raster", d.get("equals_first"))
-        print("%-7s %-28s step %.4f eq %-5s " % (d.get("layout"), d.get("opts"), d["ms_per_step"], eq) + " ".join("%s %.1f" % (a.replace("recon_", "r").split("x")[0] if a.startswith("recon") else a, b) for a, b in k.items()))
+        print("%-22s %-20s step %.4f eq %-5s %s " % (f.split("/")[-1][:22], d.get("opts"), d["ms_per_step"], eq, d.get("digest", "")) + " ".join("%s %.1f" % (a.replace("recon_", "r").split("x")[0] if a.startswith("recon") else a, b) for a, b in k.items()))
