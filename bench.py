@@ -48,6 +48,9 @@ def parse():
                          "tiles ONLY (dav1d_hip_recon_list_run_tiled; raster rows exist at the output only, made by the un-tiling download), "
                          "raster = the reference's plane layout throughout (rounds 1-4)")
     ap.add_argument("--no-pmc", action="store_true", help="do not count roofline.traffic with rocprofv3 children (the committed profile's figure is reported instead)")
+    ap.add_argument("--frame-contexts", type=int, default=2,
+                    help="frame contexts of the headline step (dav1d's n_fc): the steps — one independent frame each — are dealt over that many library "
+                         "contexts with streams of their own, so that a frame's launches run under the tail of the frame before; 1 = one frame at a time")
     ap.add_argument("--no-inflight", action="store_true", help="skip the frames-in-flight leg of the full table")
     ap.add_argument("--packed", action="store_true", help="feed the residuals in the sparse wire format (DAV1D_HIP_ITX_PACKED)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (hand-off arrays -> lister -> device)")
@@ -410,7 +413,7 @@ def compact_line(full, legs=None):
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
     line = {k: full.get(k) for k in keep}
     cfg = full.get("config") or {}
-    line["config"] = {k: _short(cfg.get(k), 330) for k in ("workload", "parallelism", "parity", "frames_per_step", "coef_format", "step", "picture_layout", "ms_per_step_by_layout") if k in cfg}
+    line["config"] = {k: _short(cfg.get(k), 330) for k in ("workload", "parallelism", "parity", "frames_per_step", "frame_contexts", "coef_format", "step", "picture_layout", "ms_per_step_by_layout") if k in cfg}
     roof = full.get("roofline")
     if isinstance(roof, dict):
         r = {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_bytes_per_launch",
@@ -709,6 +712,14 @@ def run_job(a, rank, local, world):
     inter_list, itx_list = ctx.inter_list(frame.mc, frame.comp), ctx.itx_list(itx_tasks)      # also used by the per-kernel timing below
     recon_list = None if a.two_phase else ctx.recon_list(dsts[0], frame.mc, frame.comp, itx_tasks)
     prep = torch.zeros(frame.prep_elems, dtype=torch.int16, device=dev)
+    # frame contexts (dav1d's n_fc, src/lib.c:177-195: the frames a decoder has in flight): context k takes steps k, k + n_fc, ...; each has its
+    # streams, its list and its compound scratch; the pictures and the references are the same memory for all of them
+    n_fc = 1 if (a.emu or a.two_phase or tile_cols or recon_list is None) else max(1, a.frame_contexts)
+    lanes = [(ctx, recon_list, prep, None)]
+    for _ in range(n_fc - 1):
+        st_k = torch.cuda.Stream(device=dev)
+        ctx_k = api.Context(local, stream=st_k.cuda_stream)
+        lanes.append((ctx_k, ctx_k.recon_list(dsts[0], frame.mc, frame.comp, itx_tasks), torch.zeros(frame.prep_elems, dtype=torch.int16, device=dev), st_k))
     tdt = torch.int16 if bpc == 8 else torch.int32
     pristine = torch.from_numpy(coef_host).to(dev)
     n_arena = a.steps + a.warmup + 8
@@ -747,9 +758,11 @@ def run_job(a, rank, local, world):
     def step(i):
         d = dsts[i % NDST]
         if recon_list is not None and tiled:
-            recon_list.run_tiled(d, refs, prep.data_ptr(), arenas[i].data_ptr())
+            _, rl_k, prep_k, _ = lanes[i % n_fc]
+            rl_k.run_tiled(d, refs, prep_k.data_ptr(), arenas[i].data_ptr())
         elif recon_list is not None:
-            recon_list.run(d, refs, prep.data_ptr(), arenas[i].data_ptr())
+            _, rl_k, prep_k, _ = lanes[i % n_fc]
+            rl_k.run(d, refs, prep_k.data_ptr(), arenas[i].data_ptr())
         else:
             ctx.run_inter_list(inter_list, d, refs, prep.data_ptr())
             ctx.run_itx_list(itx_list, d, arenas[i].data_ptr())
@@ -1443,8 +1456,8 @@ def run_job(a, rank, local, world):
                           "picture_layout": ("tiled: references read through 8x8-tiled twins, the reconstructed picture written as tiles only (one 128-byte line per 8x8 "
                                              "block at 10 bits); raster rows are made by the un-tiling download the parity check reads" if tiled else "raster planes (src/picture.c:46-63)"),
                           "ms_per_step_by_layout": by_layout,
-                          "frames_per_step": 1, "parallelism": (("tile-columns x%d, in-loop filters per column after a 16-column halo exchange, one all-gather of the filtered columns per frame"
-                                                            if a.tc_filters else "tile-columns x%d + one all-gather per frame") if tile_cols else "frame-parallel x%d") % world,
+                          "frames_per_step": 1, "frame_contexts": n_fc, "parallelism": (("tile-columns x%d, in-loop filters per column after a 16-column halo exchange, one all-gather of the filtered columns per frame"
+                                                            if a.tc_filters else "tile-columns x%d + one all-gather per frame") if tile_cols else "frame-parallel x%d" + (", %d frame contexts per GPU (independent frames in flight, like dav1d's n_fc)" % n_fc if n_fc > 1 else "")) % world,
                           "tasks": {"mc": int(len(frame.mc)), "comp": int(len(frame.comp)), "itx": int(len(frame.itx))},
                           "coef_format": "packed: eob + 1 scan-order values per block" if a.packed else "dense cf arena (reference layout)",
                           "coef_bytes_per_frame": int(coef_host.nbytes), "coef_h2d_ms_per_frame": h2d_ms,

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64) void itx_add_wide_kernel(const DevPlanes dst, c
                                                           const int n, coef *__restrict__ cf, const int bitdepth_max, const DevPlanes twin)
 {
     constexpr int W = tx_w(TX), H = tx_h(TX), LPB = cmax(cmin(H, 32), W), BPW = 64 / LPB;
-    static_assert(BPW * W * H * (int) sizeof(pixel) <= itx_lds_ints<TX>() * 4, "the tile fits the transpose buffer");
+    static_assert(BPW * itx_tile_stride(W, H) * (int) sizeof(pixel) <= itx_lds_ints<TX>() * 4, "the tile fits the transpose buffer");
     __shared__ __attribute__((aligned(16))) int tmp_s[itx_lds_ints<TX>()];
     pixel *const tile = reinterpret_cast<pixel *>(tmp_s);
     const int group = (int) dv::xcd_chunk_id(blockIdx.x, gridDim.x);

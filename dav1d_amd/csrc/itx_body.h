@@ -77,6 +77,12 @@ __device__ __forceinline__ void tx1d(const int kind, const int *in, const int lo
     }
 }
 
+// Pixels from one block to the next in an LDS tile of W x H blocks ([block][row][W pixels]: the predicted blocks of the paired kernels, the
+// finished ones on their way out): one row more than the block has.  A lane of the transform reads and writes COLUMNS of its block;
+// with the blocks exactly W x H pixels apart — a multiple of the 32 banks for every size — the lanes of the 2 .. 16 blocks of a wave met
+// on the same banks in every one of those accesses.
+__host__ __device__ constexpr int itx_tile_stride(int w, int h) { return w * (h + 1); }
+
 // LDS ints one wave needs for transform size TX (all of its blocks)
 template <int TX>
 constexpr int itx_lds_ints() {
@@ -207,7 +213,7 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
         // the predicted pixels leave the LDS before anything of this body is stored there: recon.hip lets the two regions overlap
         if (live && l < W) {
 #pragma unroll
-            for (int y = 0; y < H; y++) dpx[y] = pred_s[(sub * H + y) * W + l];
+            for (int y = 0; y < H; y++) dpx[y] = pred_s[sub * itx_tile_stride(W, H) + y * W + l];
         }
         dv::wave_sync();
     }
@@ -317,7 +323,7 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
         for (int y = 0; y < H; y++) cin[y] = y < SH ? tmp[y * TS + l] : 0;
     }
     if (COH) dv::wave_sync();
-    pixel *const o = COH ? const_cast<pixel *>(pred_s) + sub * H * W + l : d;
+    pixel *const o = COH ? const_cast<pixel *>(pred_s) + sub * itx_tile_stride(W, H) + l : d;
     const int ostride = COH ? W : stride;
     if (live && l < W) {
         if (dconly) {
@@ -358,7 +364,7 @@ __device__ __forceinline__ void itx_body(const DevPlanes &dst, const Dav1dHipItx
 // ---- reconstructed blocks from an LDS tile to the picture in wide pieces (and, optionally, to the picture's tiled twin)
 //
 // The column pass leaves a lane with a COLUMN of its block: written from there, a W x H block costs H two-byte stores per lane.
-// Through the tile (itx_body's COH form: the sums go back to LDS, [block][row][W pixels]) every lane instead takes row pieces of
+// Through the tile (itx_body's COH form: the sums go back to LDS, [block][row][W pixels], blocks itx_tile_stride apart) every lane instead takes row pieces of
 // up to 8 pixels — 16 bytes at 10 / 12 bits — and stores each once to the raster plane and, when the picture has a tiled twin
 // (Dav1dHipPicture.twin: 8x8 tiles of 64 consecutive pixels, mc_body.h), once to the twin: a piece is a whole tile row there, an
 // 8x8 block one 128-byte line.  raster = false: the twin only (twin.tiled == 2 at the kernels: the picture lives in its twin,
@@ -400,7 +406,7 @@ __device__ __forceinline__ void tile_write_out(const pixel *tile, const Dav1dHip
         const int y0 = BPW == 1 ? __builtin_amdgcn_readfirstlane(by) : __shfl(by, b);
         const int pl = BPW == 1 ? __builtin_amdgcn_readfirstlane(bpl) : __shfl(bpl, b);
         if (i >= NCHK || i / PER_BLOCK >= nb) continue;
-        const piece_t v = *reinterpret_cast<const piece_t *>(tile + (b * H + y) * W + c * CP);
+        const piece_t v = *reinterpret_cast<const piece_t *>(tile + b * itx_tile_stride(W, H) + y * W + c * CP);
 #ifdef DV_KO_WRITE
         if (*reinterpret_cast<const uint32_t *>(&v) != 0xfeedbeefu) continue;
 #endif

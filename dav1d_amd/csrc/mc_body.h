@@ -383,7 +383,8 @@ __device__ __forceinline__ void mc_vpass(const McPred &pd, const Taps &fv, const
 
 // One wave's worth of tiles of shape (TW, TH): tiles[t0 .. t0 + nt), nt <= 64 / LPT.  `smem` = mc_lds_bytes<TW, TH>() of LDS.
 // TO_LDS (fused prediction + residual kernels): pixels of PUT / AVG / WAVG tiles go to pred_s instead of the picture — block
-// (tile index - pred_tile0) >> pred_tpb_log2 of the wave, pred_w x pred_h pixels each, row stride pred_w.
+// (tile index - pred_tile0) >> pred_tpb_log2 of the wave, pred_w x pred_h pixels each, row stride pred_w, pred_w x (pred_h + 1) pixels from
+// one block to the next (itx_tile_stride, itx_body.h).
 //
 // TILED (the "tiled twin" of a reference picture, written by dav1d_hip_picture_retile / the frame's last stage): refs.r[].data
 // point to planes of the same size and stride whose pixels are stored as 8x8 tiles, 64 consecutive pixels each (128 bytes at
@@ -560,7 +561,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
                 // PUT_TMP: pixels into the scratch arena, row stride = block width (the reference's `lap` buffer of obmc())
                 pixel *d = t.kind == MCT_PUT_TMP
                     ? reinterpret_cast<pixel *>(prep) + t.dst_off + (t.oy + vr) * t.bw + t.ox + 4 * vs
-                    : TO_LDS ? pred_s + ((ti - pred_tile0) >> pred_tpb_log2) * (pred_w * pred_h) + (t.oy + vr) * pred_w + t.ox + 4 * vs
+                    : TO_LDS ? pred_s + ((ti - pred_tile0) >> pred_tpb_log2) * (pred_w * (pred_h + 1)) + (t.oy + vr) * pred_w + t.ox + 4 * vs
                     : reinterpret_cast<pixel *>(dst.data[t.plane]) + t.dst_off + (t.oy + vr) * dst.stride[t.plane] + t.ox + 4 * vs;
                 // TWIN with twin.tiled == 2: the picture lives in its twin only (DAV1D_HIP_TWIN_ONLY) — nothing goes to the raster planes
                 const bool to_raster = !(TWIN && !TO_LDS && twin.tiled == 2 && t.kind != MCT_PUT_TMP);

@@ -60,7 +60,7 @@ void recon_fused_kernel(const DevPlanes dst, const RefSet refs, const McTile *__
     // are predicted, then [slabs / transpose buffer of the transform] — the transform body has the predicted pixels in registers
     // before it stores its first slab chunk, so the regions may overlap.  Fewer LDS bytes per wave = more resident waves per CU,
     // which is what these kernels are short of (16x16: 8320 -> 4352 bytes, 5 -> 6 waves per SIMD, 89 -> 76 us per 8K frame).
-    constexpr int MC_B = (mc_lds_bytes<TW, TH, TILED>() + 15) / 16 * 16, PRED_B = BPW * W * W * (int) sizeof(pixel);
+    constexpr int MC_B = (mc_lds_bytes<TW, TH, TILED>() + 15) / 16 * 16, PRED_B = BPW * itx_tile_stride(W, W) * (int) sizeof(pixel);
     constexpr int ITX_B = itx_lds_ints<TX>() * 4;
     constexpr int LDS_B = cmax(NW * MC_B + PRED_B, ITX_B);
     __shared__ uint4 smem[(LDS_B + 15) / 16];
