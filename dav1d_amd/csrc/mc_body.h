@@ -56,7 +56,9 @@ constexpr int mc_win_stride_tiled(int tw) { return tw == 4 ? 16 : tw == 16 ? 40 
 // pieces of 8 pixels a row of the tiled window is fetched in (the stride may hold padding on top)
 constexpr int mc_win_pieces_tiled(int tw) { return tw == 4 ? 2 : (tw + 16) / 8; }
 
-// LDS bytes one wave needs for tile shape (TW, TH): window + row-pair intermediate + the tile records
+// LDS bytes one wave needs for tile shape (TW, TH): window + row-pair intermediate + the reference table (the tile records pass through
+// the window buffer before anything is gathered).  The LDS is handed out in pieces of 1,280 bytes (tools/calib/residency.hip: 5.9 KB hold
+// 25 workgroups on a CU, not 27): the 4x4 launch's 6,432 bytes were six pieces, 21 waves per CU; without the records five, 25
 // Rows of the window a tile of TH rows KEEPS in LDS, and the first of them.  The bodies below index a window of TH + 8 rows (the reach of
 // eight vertical taps).  Tiles of 4 rows only ever meet the 4-tap, bilinear or unit sets vertically (blocks of height <= 4, reference
 // src/mc_tmpl.c GET_V_FILTER): rows 2 .. 8 of that window.  They keep 8 rows (2 .. 9, whole row pairs) and hang their window two rows
@@ -69,7 +71,7 @@ constexpr int mc_lds_bytes() {
     constexpr int LPT = mc_cmin(64, TW * TH / 4), G = 64 / LPT, WS = TILED ? mc_win_stride_tiled(TW) : mc_win_stride(TW);
     constexpr int WRA = mc_win_rows(TH), WR0 = mc_win_row0(TH), NPRA = WRA / 2;
     // window rows (+ WR0 rows in front: the first tile's rows 0, 1 are addressable), row pairs of the intermediate (4-row tiles: + a pair at either end)
-    return (WR0 + G * WRA) * WS * 2 + (G * NPRA + (TH == 4 ? 2 : 0)) * TW * 4 + (G > 1 ? G * (int) sizeof(McTile) + (int) sizeof(RefSet) : 0);
+    return (WR0 + G * WRA) * WS * 2 + (G * NPRA + (TH == 4 ? 2 : 0)) * TW * 4 + (G > 1 ? (int) sizeof(RefSet) : 0);
 }
 
 // ---- the shape of a tile class and what the stages of one prediction share
@@ -438,13 +440,14 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
     } else {
         // the G records of the wave come in with one coalesced sweep and are handed to their lanes through LDS
         constexpr int RW = sizeof(McTile) / 4;
-        uint32_t *const rec_s = mid_s + G * NPRA * TW + SL;
+        static_assert(G * (int) sizeof(McTile) <= G * WRA * WS * 2, "the records fit the window buffer");
+        uint32_t *const rec_s = reinterpret_cast<uint32_t *>(win_s);      // (dead until the gather: every lane has its record in registers first)
         const uint32_t *recs = reinterpret_cast<const uint32_t *>(tiles + t0);
         const int nw = nt * RW;
         for (int i = lane; i < nw; i += 64) rec_s[i] = recs[i];
         // the reference plane table goes to LDS in the same round trip: the lanes index it by their own tile's reference,
         // and a second, dependent trip to the kernel arguments would sit in front of every window fetch
-        uint32_t *const ref_s = rec_s + G * RW;
+        uint32_t *const ref_s = mid_s + G * NPRA * TW + SL;
         const uint32_t *rsrc = reinterpret_cast<const uint32_t *>(&refs);
 #pragma unroll
         for (int i = 0; i < (int) sizeof(RefSet) / 4; i += 64) ref_s[i + lane] = rsrc[i + lane];
@@ -453,6 +456,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
         uint32_t *tw_ = reinterpret_cast<uint32_t *>(&t);
 #pragma unroll
         for (int i = 0; i < RW; i++) tw_[i] = rp[i];
+        dv::wave_sync();                    // (the gather writes where the records lie)
     }
 
     // row r of the tile's window at win + r * WS, pair j of its intermediate at mid + j * TW: the tile's own rows start WR0 rows in
@@ -489,7 +493,7 @@ __device__ __forceinline__ void mc_body(const DevPlanes &dst, const RefSet &refs
                 rs = rp.stride[t.plane]; rw = rp.w[t.plane]; rh = rp.h[t.plane];
             } else {
                 constexpr int RW = sizeof(McTile) / 4, DW = sizeof(DevPlanes) / 4;
-                const uint32_t *rt = mid_s + G * NPRA * TW + SL + G * RW + rf.ref * DW;      // == ref_s above
+                const uint32_t *rt = mid_s + G * NPRA * TW + SL + rf.ref * DW;      // == ref_s above
                 const uint32_t *pdat = rt + 2 * t.plane;
                 src = reinterpret_cast<const pixel *>((uint64_t) pdat[0] | ((uint64_t) pdat[1] << 32));
                 rs = (int) rt[6 + t.plane]; rw = (int) rt[9 + t.plane]; rh = (int) rt[12 + t.plane];
