@@ -26,6 +26,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+# the CPU peers this file times (cpu_baseline, reference_pass2, the peer of the dav1d_task_loop legs) are the reference built the way dav1d
+# ships (oracle/_ref_release, oracle/_ref_hooked_release: -O3 -DNDEBUG -fomit-frame-pointer -ffast-math), when those builds travelled with
+# the repo; the asserts-on build stays the parity checker of tests/ (tests/util.py REF_SO), and tests/test_oracle.py holds the two equal
+if all(os.path.exists(os.path.join(ROOT, "oracle", d_, f_)) for d_, f_ in (("_ref_release", "libdav1d_ref.so"), ("_ref_hooked_release", "libdav1d_hooked.so"))):
+    os.environ.setdefault("DAV1D_REF_BUILD", "release")
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -426,7 +431,7 @@ def compact_line(full, legs=None):
         line["roofline"] = roof
     cpu = full.get("cpu_baseline")
     if isinstance(cpu, dict):
-        line["cpu_baseline"] = {k: _short(cpu.get(k), 200) for k in ("value", "unit", "cores", "kind", "sample", "host_cores_available", "all_cores_value",
+        line["cpu_baseline"] = {k: _short(cpu.get(k), 200) for k in ("value", "unit", "cores", "kind", "flags", "sample", "host_cores_available", "all_cores_value",
                                                                        "all_cores_cores", "reference_pass2_value", "reference_pass2_cores", "avx2") if k in cpu}
     else:
         line["cpu_baseline"] = cpu
@@ -1050,6 +1055,7 @@ def run_job(a, rank, local, world):
                     packed_leg["parity"] = "bit-exact vs %s oracle" % oracle.which
             cpu = {"value": round(frame.luma_pixels * reps / t_cpu / 1e6, 2), "unit": "Mpixels/s", "cores": 1,
                    "kind": "reference" if oracle.which == "ref" else "port",
+                   "flags": util.REF_FLAGS if oracle.which == "ref" else "oracle/port: -O2",
                    "sample": "%d full %dx%d frame(s) of the same task lists through the oracle's C DSP entries, "
                              "1 thread, %.1f s" % (reps, w, h, t_cpu),
                    "host_cores_available": os.cpu_count()}

@@ -10,7 +10,7 @@ import lister_util as lu
 import synth_lib
 from dav1d_amd import _lib
 
-HOOKED_SO = os.path.join(util.ROOT, "oracle", "_ref_hooked", "libdav1d_hooked.so")
+HOOKED_SO = os.path.join(util.ROOT, "oracle", "_ref_hooked_release" if util.REF_RELEASE else "_ref_hooked", "libdav1d_hooked.so")
 
 
 class HookedParams(C.Structure):

@@ -27,3 +27,12 @@ def test_reference_build_matches_golden(name):
     if util.ref_lib() is None:
         pytest.skip("oracle/_ref not available")
     assert CASES[name](util.Oracle("ref")) == GOLD[name]
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_release_build_of_the_reference_matches_golden(name):
+    """oracle/_ref_release (dav1d's own release flags: -O3 -DNDEBUG -fomit-frame-pointer -ffast-math, the CPU peer bench.py times) gives
+    the digests of the asserts-on build that checks parity: the peer that is timed computes what the checker computes."""
+    if util.ref_release_lib() is None:
+        pytest.skip("oracle/_ref_release not available")
+    assert CASES[name](util.Oracle("ref_release")) == GOLD[name]

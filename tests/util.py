@@ -11,7 +11,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-REF_SO = os.path.join(ROOT, "oracle", "_ref", "libdav1d_ref.so")
+# The reference compiled here.  The PARITY checker is oracle/_ref (-O2 -g, asserts live).  $DAV1D_REF_BUILD=release (bench.py sets it for its
+# CPU-peer timings) selects oracle/_ref_release: the same sources with the flags dav1d's own release build uses (oracle/Makefile REL=1);
+# tests/test_oracle.py asserts that the two builds produce identical pictures.
+REF_RELEASE = os.environ.get("DAV1D_REF_BUILD") == "release"
+REF_SO = os.path.join(ROOT, "oracle", "_ref_release" if REF_RELEASE else "_ref", "libdav1d_ref.so")
+REF_FLAGS = "-O3 -DNDEBUG -fomit-frame-pointer -ffast-math (dav1d's release build, meson.build:26-29, 309-312)" if REF_RELEASE else "-O2 -g, asserts live (the parity checker's build)"
+
 PORT_SO = os.path.join(ROOT, "oracle", "libdav1d_port.so")
 EMU_SO = os.path.join(ROOT, "tests", "emu", "libdav1d_hip_emu.so")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
@@ -47,7 +53,7 @@ def ref_lib():
     """The reference's own C path (oracle/_ref, built from /root/reference by oracle/Makefile)."""
     if not os.path.exists(REF_SO):
         if os.path.isdir("/root/reference/src"):
-            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref", "-j8"], check=True,
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref", "-j8"] + (["REL=1"] if REF_RELEASE else []), check=True,
                            stdout=subprocess.DEVNULL)
         else:
             return None
@@ -61,6 +67,20 @@ def ref_lib():
     lib.dav1d_ref_tx1d_fn.restype = C.c_void_p
     lib.dav1d_ref_tx1d_fn.argtypes = [C.c_int, C.c_int]
     lib.dav1d_ref_wht4_1d.restype = C.c_void_p
+    return lib
+
+
+@functools.lru_cache(None)
+def ref_release_lib():
+    """oracle/_ref_release: the reference with dav1d's release flags (oracle/Makefile REL=1), or None."""
+    so = os.path.join(ROOT, "oracle", "_ref_release", "libdav1d_ref.so")
+    if not os.path.exists(so):
+        if not os.path.isdir("/root/reference/src"):
+            return None
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref", "-j8", "REL=1"], check=True, stdout=subprocess.DEVNULL)
+    lib = C.CDLL(so)
+    lib.dav1d_ref_dsp_entry.restype = C.c_void_p
+    lib.dav1d_ref_dsp_entry.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_int]
     return lib
 
 
@@ -115,11 +135,12 @@ class Oracle:
     """Calls DSP entries of an oracle library (`ref` = the reference's C path, `port` = oracle/port)."""
 
     def __init__(self, which="ref"):
-        self.which = which
-        self.lib = ref_lib() if which == "ref" else port_lib()
+        # "ref_release": the release-flag build of the reference whatever $DAV1D_REF_BUILD says (test_oracle.py compares the builds)
+        self.which = "ref" if which == "ref_release" else which
+        self.lib = ref_release_lib() if which == "ref_release" else ref_lib() if which == "ref" else port_lib()
         if self.lib is None:
             raise RuntimeError("oracle library unavailable: " + which)
-        self._entry = self.lib.dav1d_ref_dsp_entry if which == "ref" else self.lib.dav1d_port_dsp_entry
+        self._entry = self.lib.dav1d_ref_dsp_entry if self.which == "ref" else self.lib.dav1d_port_dsp_entry
         self._cache = {}
 
     def fn(self, bpc, family, i=0, j=0):
