@@ -180,11 +180,23 @@ static inline bool picture_twin_usable(const Dav1dHipPicture *p) {
         if (p->p[i].data && (!p->twin[i] || (p->p[i].stride / bps) % 8)) return false;
     return true;
 }
+// Before a launch that reads RASTER planes of pictures: the ones that live in their twin only (DAV1D_HIP_TWIN_ONLY, what a
+// reconstruction in the tiled layout leaves) get their raster planes back first, on the context's stream — a raster reader of such a
+// picture would take stale pixels for the picture without any sign of it.  (The pictures are const for the caller's sake: their pixels do
+// not change; a caller that handed over a copy of the record un-tiles again next time.)
+extern "C" int dav1d_hip_picture_untile(Dav1dHipContext *c, Dav1dHipPicture *pic);
+static inline int raster_planes_valid(Dav1dHipContext *c, const Dav1dHipPicture *pics, int n) {
+    for (int i = 0; i < n; i++)
+        if (pics[i].twin_ok == DAV1D_HIP_TWIN_ONLY)
+            if (const int rc = dav1d_hip_picture_untile(c, const_cast<Dav1dHipPicture *>(&pics[i]))) return rc;
+    return 0;
+}
 // The planes motion compensation reads its references through: the tiled twins when the context uses them and EVERY reference
-// of the call has a valid one (a launch is one kernel variant: all tiled or all raster), the raster planes otherwise.
-static inline void ref_planes(Dav1dHipContext *c, const Dav1dHipPicture *refs, int n_refs, DevPlanes *rp) {
+// of the call has a valid one (a launch is one kernel variant: all tiled or all raster), the raster planes otherwise (made valid first).
+static inline int ref_planes(Dav1dHipContext *c, const Dav1dHipPicture *refs, int n_refs, DevPlanes *rp) {
     bool tiled = c->ref_twin != 0 && n_refs > 0;
     for (int i = 0; i < n_refs && tiled; i++) tiled = picture_twin_usable(&refs[i]);
+    if (!tiled) if (const int rc = raster_planes_valid(c, refs, n_refs)) return rc;
     if (tiled && c->retile_pending) {          // a twin of this context may still be on its way on the side stream
         (void) hipStreamWaitEvent(c->stream, c->ev_retile, 0);
         c->retile_pending = false;
@@ -196,6 +208,7 @@ static inline void ref_planes(Dav1dHipContext *c, const Dav1dHipPicture *refs, i
             rp[i].tiled = 1;
         }
     }
+    return 0;
 }
 
 // kernel launchers (one per family translation unit)

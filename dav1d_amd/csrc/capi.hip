@@ -10,9 +10,11 @@
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
+#include <atomic>
 #include <new>
 #include <algorithm>
 #include <vector>
+extern "C" void dav1d_hip_note_context_device(int device);
 
 extern "C" {
 
@@ -38,6 +40,7 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     if (!c) return -ENOMEM;
     c->device = device;
     c->own_stream = stream == nullptr;
+    dav1d_hip_note_context_device(device);
     c->scratch = nullptr;
     c->scratch_size = 0;
     if (stream) c->stream = (hipStream_t) stream;
@@ -532,9 +535,13 @@ int dav1d_hip_picture_device(const Dav1dHipPicture *pic) {
     return a.device;
 }
 // with more than one device: are these pictures where context c can launch on them?  (-EXDEV names the first that is not)
+// (asked only when this process has opened contexts on more than one device: the question is a trip to the driver per picture, on the
+// frame's critical path, and a process that uses one of a node's eight GPUs cannot have got a picture from another)
+static std::atomic<uint64_t> g_ctx_devices{0};
+void dav1d_hip_note_context_device(int device) { if (device >= 0 && device < 64) g_ctx_devices.fetch_or(1ull << device); }
 int pictures_on_device(const Dav1dHipContext *c, const Dav1dHipPicture *pics, int n) {
-    static const int n_dev = dav1d_hip_device_count();
-    if (n_dev <= 1) return 0;
+    const uint64_t m = g_ctx_devices.load(std::memory_order_relaxed);
+    if (!(m & (m - 1))) return 0;
     for (int i = 0; i < n; i++) {
         if (!pics[i].p[0].data) continue;
         const int d = dav1d_hip_picture_device(&pics[i]);
@@ -1034,8 +1041,10 @@ int dav1d_hip_mc_list_run(Dav1dHipContext *c, const Dav1dHipMcList *l, const Dav
     const DevPlanes dp = dev_planes(dst);
     DevPlanes rp[8];
     for (int i = 0; i < n_refs; i++) if (refs[i].bpc != dst->bpc) return -EINVAL;
-    if (l->n_fused) { for (int i = 0; i < n_refs; i++) rp[i] = dev_planes(&refs[i]); }       // the all-shapes launch reads raster planes
-    else ref_planes(c, refs, n_refs, rp);
+    if (l->n_fused) {       // the all-shapes launch reads raster planes
+        if (const int rv = raster_planes_valid(c, refs, n_refs)) return rv;
+        for (int i = 0; i < n_refs; i++) rp[i] = dev_planes(&refs[i]);
+    } else if (const int rv = ref_planes(c, refs, n_refs, rp)) return rv;
     const int fb = mc_fused_min_bin();
     int rc = mc_regroup(c, const_cast<Dav1dHipMcList *>(l), rp, n_refs);
     if (rc) return rc;
@@ -1055,7 +1064,7 @@ int dav1d_hip_mc_list_run_timed(Dav1dHipContext *c, const Dav1dHipMcList *l, con
     if (!l || !dst || !refs || n_refs < 1 || n_refs > 8 || !ms || (l->n && l->max_ref >= n_refs)) return -EINVAL;
     const DevPlanes dp = dev_planes(dst);
     DevPlanes rp[8];
-    ref_planes(c, refs, n_refs, rp);
+    if (const int rv = ref_planes(c, refs, n_refs, rp)) return rv;
     if (int rg = mc_regroup(c, const_cast<Dav1dHipMcList *>(l), rp, n_refs)) return rg;
     hipEvent_t ev[MC_BINS + 1];
     for (int b = 0; b <= MC_BINS; b++) HIP_TRY(hipEventCreate(&ev[b]));
@@ -1367,6 +1376,7 @@ int dav1d_hip_cdef_run_groups(Dav1dHipContext *c, const Dav1dHipPicture *dst, co
     if (!dev) return -ENOMEM;
     int rc = dav1d_hip_upload(c, dev, tasks, n * sizeof(Dav1dHipCdefTask));
     if (!rc && n_groups) rc = dav1d_hip_upload(c, dev + tb, groups, n_groups * sizeof(CdefGroup));
+    if (const int rv_ = raster_planes_valid(c, src, 1)) return rv_;      // (a source that lives in its tiled twin only: raster planes first)
     const DevPlanes dp = dev_planes(dst), sp = dev_planes(src);
     const Dav1dHipCdefTask *d_tasks = reinterpret_cast<const Dav1dHipCdefTask *>(dev);
     KernelTimer kt(c);
@@ -1386,6 +1396,7 @@ extern "C" int dav1d_hip_cdef_batch(Dav1dHipContext *c, const Dav1dHipPicture *d
     unsigned bad = 0;
     for (size_t i = 0; i < n; i++) bad |= (unsigned) (tasks[i].edges > 15) | (unsigned) (tasks[i].plane > 2) | (unsigned) (tasks[i].dir > 7);
     if (bad) return -EINVAL;
+    if (const int rv_ = raster_planes_valid(c, src, 1)) return rv_;      // (a source that lives in its tiled twin only: raster planes first)
     const DevPlanes dp = dev_planes(dst), sp = dev_planes(src);
     if (dav1d_hip_cdef_strip_ok(&dp, &sp, dst->bpc) && !c->cdef_unit_kernel) {
         // units that sit side by side share a wave (strip kernel); DSP-level RAW tasks keep the one-unit kernel
@@ -1566,6 +1577,7 @@ extern "C" int dav1d_hip_warp_batch(Dav1dHipContext *c, const Dav1dHipPicture *d
         if (t.kind == DAV1D_HIP_MC_PREP && !prep) return -EINVAL;
     }
     DevPlanes rp[8];
+    if (const int rv = raster_planes_valid(c, refs, n_refs)) return rv;          // (the warp kernels read raster planes)
     for (int i = 0; i < n_refs; i++) { if (refs[i].bpc != dst->bpc) return -EINVAL; rp[i] = dev_planes(&refs[i]); }
     const DevPlanes dp = dev_planes(dst);
     return run_task_batch(c, tasks, n, [&](const Dav1dHipWarpTask *dev) {
@@ -1584,6 +1596,7 @@ extern "C" int dav1d_hip_mc_scaled_batch(Dav1dHipContext *c, const Dav1dHipPictu
         if (t.kind != DAV1D_HIP_MC_PUT && !prep) return -EINVAL;
     }
     DevPlanes rp[8];
+    if (const int rv = raster_planes_valid(c, refs, n_refs)) return rv;          // (so do the scaled ones)
     for (int i = 0; i < n_refs; i++) { if (refs[i].bpc != dst->bpc) return -EINVAL; rp[i] = dev_planes(&refs[i]); }
     const DevPlanes dp = dev_planes(dst);
     return run_task_batch(c, tasks, n, [&](const Dav1dHipMcScaledTask *dev) {
@@ -1595,6 +1608,7 @@ extern "C" int dav1d_hip_resize(Dav1dHipContext *c, const Dav1dHipPicture *dst, 
     if (!dst || !src || dst->bpc != src->bpc || plane < 0 || plane > 2 || dst_w < 1 || src_w < 1 || h < 0 || y0 < 0) return -EINVAL;
     if (mx0 < 0 || mx0 > 0x3fff || dx < 0) return -EINVAL;
     if (!h) return 0;
+    if (const int rv_ = raster_planes_valid(c, src, 1)) return rv_;      // (a source that lives in its tiled twin only: raster planes first)
     const DevPlanes dp = dev_planes(dst), sp = dev_planes(src);
     if (y0 + h > dp.h[plane] || y0 + h > sp.h[plane] || dst_w > dp.w[plane]) return -EINVAL;
     const int rc = dav1d_hip_launch_resize(&dp, &sp, dst->bpc, plane, dst_w, y0, h, src_w, dx, mx0, c->stream);
@@ -1638,6 +1652,7 @@ extern "C" int dav1d_hip_lr_batch(Dav1dHipContext *c, const Dav1dHipPicture *dst
     Dav1dHipLrTask *const dev = reinterpret_cast<Dav1dHipLrTask *>(devb);
     int rc = dav1d_hip_upload(c, dev, sorted.data(), n * sizeof(*dev));
     if (!rc && !waves.empty()) rc = dav1d_hip_upload(c, devb + o_waves, waves.data(), waves.size() * 4);
+    if (const int rv_ = raster_planes_valid(c, src, 1)) return rv_;
     const DevPlanes dp = dev_planes(dst), sp = dev_planes(src), lp = dev_planes(lpf);
     KernelTimer kt(c);
     int max_w = 0;
@@ -1758,6 +1773,7 @@ static int fg_apply_core(Dav1dHipContext *c, const Dav1dHipPicture *dst, const D
         rc = hip_rc(hipMemcpy2DAsync(dst->p[pl].data, dst->p[pl].stride, src->p[pl].data, src->p[pl].stride, rb, rows,
                                      hipMemcpyDeviceToDevice, c->stream));
     }
+    if (const int rv_ = raster_planes_valid(c, src, 1)) return rv_;      // (a source that lives in its tiled twin only: raster planes first)
     const DevPlanes dp = dev_planes(dst), sp = dev_planes(src);
     if (!rc) rc = dav1d_hip_launch_fg_apply(&dp, &sp, (const int16_t *) g->dev, g->dev + g->lut_bytes, (int) g->scaling_size, data, bpc, src->layout,
                                             is_id, offs, c->stream);
@@ -1962,7 +1978,8 @@ static bool recon_list_twin_direct(Dav1dHipContext *c, const Dav1dHipReconList *
         if (dst->p[p].data) direct = dst->twin[p] && !((uintptr_t) dst->p[p].data & 15) && !((uintptr_t) dst->twin[p] & 15) && dst->p[p].stride % 16 == 0 &&
                                      (dst->p[p].stride / bps) % 8 == 0;
     for (int i = 0; i < n_refs && direct; i++) direct = picture_twin_usable(&refs[i]);
-    if (getenv("DAV1D_DEBUG_TILED")) fprintf(stderr, "twin_direct: ref_twin %d wide_ok %d comp %zu min_bin %d -> %d (refs ok: %d %d %d)\n", c->ref_twin, (int) l->wide_ok, (size_t) l->inter->comp->n, mc_fused_min_bin(), (int) direct, n_refs > 0 ? refs[0].twin_ok : -1, n_refs > 1 ? refs[1].twin_ok : -1, n_refs > 2 ? refs[2].twin_ok : -1);
+    static const bool debug_tiled = getenv("DAV1D_DEBUG_TILED") != nullptr;      // (asked once: this runs per frame)
+    if (debug_tiled) fprintf(stderr, "twin_direct: ref_twin %d wide_ok %d comp %zu min_bin %d -> %d (refs ok: %d %d %d)\n", c->ref_twin, (int) l->wide_ok, (size_t) l->inter->comp->n, mc_fused_min_bin(), (int) direct, n_refs > 0 ? refs[0].twin_ok : -1, n_refs > 1 ? refs[1].twin_ok : -1, n_refs > 2 ? refs[2].twin_ok : -1);
     return direct;
 }
 
@@ -2001,6 +2018,9 @@ int dav1d_hip_recon_list_run_tiled(Dav1dHipContext *c, const Dav1dHipReconList *
         dst->twin_ok = 0;
         return rc ? rc : dav1d_hip_picture_retile(c, dst);
     }
+    // (a picture whose raster planes alone are valid is retiled first — once per picture: it lives in its twin from then on.  The contract
+    // keeps every pixel the list does not write, the allocator's padding included, so "the list covers the visible picture" is no licence
+    // to skip it)
     if (!dst->twin_ok) { const int rc = dav1d_hip_picture_retile(c, dst); if (rc) return rc; }
     DevPlanes tw = dev_planes(dst);
     for (int p = 0; p < 3; p++) tw.data[p] = dst->p[p].data ? dst->twin[p] : nullptr;
@@ -2025,7 +2045,7 @@ static int recon_list_run_impl(Dav1dHipContext *c, const Dav1dHipReconList *l, c
         const DevPlanes dp = dev_planes(dst);
         DevPlanes rp[8];
         for (int i = 0; i < n_refs; i++) if (refs[i].bpc != dst->bpc) return -EINVAL;
-        ref_planes(c, refs, n_refs, rp);
+        if (const int rv = ref_planes(c, refs, n_refs, rp)) return rv;
         // one after the other on a side stream of their own, next to the pipeline of the unpaired rest below (main stream:
         // predictions, side stream 0: residuals).  Measured: the paired launches on one stream 0.317 ms per frame, on two
         // streams that run side by side 0.334-0.343 — three launches at a time share the memory system better than four.
@@ -2071,7 +2091,7 @@ static int recon_list_run_impl(Dav1dHipContext *c, const Dav1dHipReconList *l, c
     const DevPlanes dp = dev_planes(dst);
     DevPlanes rp[8];
     for (int i = 0; i < n_refs; i++) if (refs[i].bpc != dst->bpc) { join_paired(); return -EINVAL; }
-    ref_planes(c, refs, n_refs, rp);
+    if (const int rv = ref_planes(c, refs, n_refs, rp)) { join_paired(); return rv; }
     int rc = mc_regroup(c, const_cast<Dav1dHipMcList *>(ml), rp, n_refs);
     if (rc) { join_paired(); return rc; }
     // DAV1D_HIP_RECON_LANES: side streams the residual launches are dealt over.  Measured (8K 10-bit): 1 lane 0.379 ms,
@@ -2166,7 +2186,7 @@ static int recon_list_run_timed_impl(Dav1dHipContext *c, const Dav1dHipReconList
     if ((ml->n && ml->max_ref >= n_refs) || l->f_max_ref >= n_refs) return -EINVAL;
     const DevPlanes dp = dev_planes(dst);
     DevPlanes rp[8];
-    ref_planes(c, refs, n_refs, rp);
+    if (const int rv = ref_planes(c, refs, n_refs, rp)) return rv;
     int rc = mc_regroup(c, const_cast<Dav1dHipMcList *>(ml), rp, n_refs);
     if (rc) return rc;
     enum { N = 40 };

@@ -294,6 +294,8 @@ static int allgather_on(Dav1dHipPeer *p, Dav1dHipPicture *pic, const int *x0, co
     if (!rc) rc = grow(recvp, recv_cap, per * (size_t) p->world);
     if (rc) return rc;
     uint8_t *const send = *sendp, *const recv = *recvp;
+    // (the strips are raster rows: a picture that lives in its tiled twin only gets its raster planes back first)
+    if (pic->twin_ok == DAV1D_HIP_TWIN_ONLY) if (const int ru = dav1d_hip_picture_untile(p->c, pic)) return ru;
     pic->twin_ok = 0;
     // the strip's rows are packed with the strip's own width as row pitch inside a slot laid out for the widest strip
     StripPlan pk = mine;
@@ -361,6 +363,7 @@ int dav1d_hip_peer_exchange_halo(Dav1dHipPeer *p, Dav1dHipPicture *pic, const in
     if (!rc) rc = grow(&p->recv, &p->recv_cap, 2 * eb);
     if (rc) return rc;
     hipStream_t st = p->c->stream;
+    if (pic->twin_ok == DAV1D_HIP_TWIN_ONLY) if (const int ru = dav1d_hip_picture_untile(p->c, pic)) return ru;
     pic->twin_ok = 0;
     const bool has_l = r > 0, has_r = r + 1 < p->world;
     // my own left edge [x0, x0 + halo) -> send[0], right edge [x1 - halo, x1) -> send[1]: one pack launch

@@ -191,6 +191,7 @@ static int borrow_thread(const Dav1dHipGlue *const g, Dav1dHipContext *const ctx
 static void return_thread(const Dav1dHipGlue *const g, const int prev) { if (prev >= 0) (void) g->hip.set_device(prev); }
 
 /* ------------------------------------------------------------------------------------------------ Dav1dPicAllocator */
+static void free_mirrors(Dav1dHipGlue *g, Dav1dHipGluePicture *hp);
 static int glue_alloc_picture(Dav1dPicture *const p, void *const cookie) {
     Dav1dHipGlue *const g = cookie;
     const double t0 = now_s();
@@ -209,12 +210,17 @@ static int glue_alloc_picture(Dav1dPicture *const p, void *const cookie) {
     Dav1dHipContext *const ctx = g->dev[dev].ctx;
     const int thread_dev = borrow_thread(g, ctx);
     int rc = 0;
+    const int pooled = hp != NULL;
     if (hp) rc = g->hip.memset_(ctx, hp->hp.dev.alloc, 0, hp->hp.dev.alloc_size);       /* as a fresh one: zero, padding included */
     if (!hp) {
         hp = calloc(1, sizeof(*hp));
         if (!hp) { return_thread(g, thread_dev); return DAV1D_ERR(ENOMEM); }
         hp->dev = dev;
         rc = g->hip.host_picture_alloc(ctx, &hp->hp, p->p.w, p->p.h, p->p.layout, p->p.bpc);   /* layouts share their values */
+    }
+    if (rc && pooled) {        /* a pooled picture owns pinned planes, device planes and mirrors: all of it goes, not just the record */
+        free_mirrors(g, hp);
+        (void) g->hip.host_picture_release(ctx, &hp->hp);
     }
     return_thread(g, thread_dev);
     stat_add(g, DAV1D_HIP_GLUE_STAT_PICTURE_ALLOC, t0);
@@ -225,6 +231,7 @@ static int glue_alloc_picture(Dav1dPicture *const p, void *const cookie) {
     hp->ref = hp->hp.dev;
     hp->ref_dev = hp->dev;
     memset(hp->mirror_ok, 0, sizeof(hp->mirror_ok));
+    atomic_store(&hp->failed, 0);
     atomic_store(&hp->final, 0);
     return 0;
 }
@@ -421,7 +428,10 @@ static int refs_final(const Dav1dFrameContext *const f) {
     int all = 1;
     for (int i = 0; i < 7; i++) {
         if (atomic_load(&f->refp[i].progress[1]) == FRAME_ERROR) return -1;
-        all &= atomic_load(&((Dav1dHipGluePicture *) f->refp[i].p.allocator_data)->final);
+        Dav1dHipGluePicture *const rp = f->refp[i].p.allocator_data;
+        const int fin = atomic_load(&rp->final);
+        if (fin && atomic_load(&rp->failed)) return -1;       /* (ended badly, and dav1d_hip_frame_done has not said so yet) */
+        all &= fin;
     }
     return all;
 }
@@ -517,7 +527,7 @@ static Dav1dHipGluePicture *ref_to_fetch_ahead(const Dav1dHipGlue *const g, cons
         if ((c->q_state != 1 && c->q_state != 2) || c->dev != dev || !IS_INTER_OR_SWITCH(c->q_f->frame_hdr)) continue;
         for (int k = 0; k < 7; k++) {
             Dav1dHipGluePicture *const rp = c->q_f->refp[k].p.allocator_data;
-            if (rp == skip || !atomic_load(&rp->final) || atomic_load(&c->q_f->refp[k].progress[1]) == FRAME_ERROR) continue;
+            if (rp == skip || !atomic_load(&rp->final) || atomic_load(&rp->failed) || atomic_load(&c->q_f->refp[k].progress[1]) == FRAME_ERROR) continue;
             if (rp->ref_dev != dev && !rp->mirror_ok[dev]) return rp;
         }
     }
@@ -563,7 +573,11 @@ static void *stage_thread(void *const arg) {
             else drop_frame_objects(g, s);
         }
         pthread_mutex_lock(&g->q_mtx);
-        if (stage == 2) atomic_store(&((Dav1dHipGluePicture *) f->sr_cur.p.allocator_data)->final, 1);      /* well or badly: nobody waits for it any longer */
+        if (stage == 2) {
+            Dav1dHipGluePicture *const op = f->sr_cur.p.allocator_data;
+            if (s->q_rc) atomic_store(&op->failed, 1);      /* first: see Dav1dHipGluePicture.failed */
+            atomic_store(&op->final, 1);                    /* well or badly: nobody waits for it any longer */
+        }
         s->q_state = stage < 3 ? stage + 1 : 0;        /* (stage 3 first, its work after: dav1d may reuse the frame context from there on) */
         const int rc = s->q_rc;
         const Dav1dHipPicture filtered = s->q_filtered;

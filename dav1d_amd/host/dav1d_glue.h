@@ -41,6 +41,9 @@ typedef struct Dav1dHipGluePicture {
     Dav1dHipFrame *frame;        /* the frame that produced the picture: owns `ref` when that is not hp.dev */
     Dav1dHipPicture ref;         /* where the final pixels are on the device: what later frames predict from */
     atomic_int final;            /* the frame that produced the picture has ended (well or badly): `ref` is settled */
+    atomic_int failed;           /* ... badly: set BEFORE final, so that whoever sees final also sees this — dav1d's own mark, progress[1] =
+                                    FRAME_ERROR, is only stored a stage later (dav1d_hip_frame_done), and a frame that predicts from this picture
+                                    must not end on its unwritten pixels in between */
     int dev, ref_dev;            /* index (from Dav1dHipGlueOptions.device) of the device hp was made on / the one `ref` lives on */
     Dav1dHipPicture mirror[DAV1D_HIP_GLUE_MAX_DEVICES];   /* `ref` once more on the other devices that end frames predicting from it */
     uint8_t mirror_ok[DAV1D_HIP_GLUE_MAX_DEVICES];

@@ -392,3 +392,56 @@ def test_recon_list_with_its_picture_in_the_twin_only(ctx, bpc, size):
     rl.destroy()
     for o in pics + refs + [prep, coef, coef2]:
         o.free()
+
+
+@pytest.mark.parametrize("bpc", [8, 10])
+def test_raster_readers_of_a_picture_that_lives_in_its_twin_only(ctx, bpc):
+    """A frame reconstructed in the tiled layout leaves its picture DAV1D_HIP_TWIN_ONLY: the raster planes are stale.  Launches that read
+    raster planes of their references — warped (global / local motion) and scaled prediction — must see the frame all the same (they
+    un-tile the picture first), not the stale planes: the second frame of a chain whose first frame was plain inter."""
+    if util.ref_lib() is None:
+        pytest.skip("needs the reference build (warp8x8)")
+    oracle = util.Oracle("ref")
+    w, h = 256, 128
+    frame = synth.make_frame(w, h, bpc, seed=77 + bpc, edge_frac=0.0, mv_range_px=24)
+    rng = np.random.default_rng(5 + bpc)
+    refs_h = [synth.make_planes(rng, w, h, bpc) for _ in range(frame.n_refs)]
+    dst0 = synth.make_planes(rng, w, h, bpc, smooth=False)
+    want1, _, _ = oracle_frame(util.default_oracle(), frame, dst0, refs_h)
+    refs = []
+    for rp in refs_h:
+        r = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+        for pl in range(3):
+            r.upload(pl, rp[pl])
+        r.retile()
+        refs.append(r)
+    first = ctx.picture(w, h, api.LAYOUT_I420, bpc)
+    for pl in range(3):
+        first.upload(pl, dst0[pl])          # what the raster planes hold while the picture lives in its twin
+    prep = ctx.buffer(max(frame.prep_elems, 64 * 64) * 2)
+    prep.zero()
+    rl = ctx.recon_list(first, frame.mc, frame.comp, frame.itx)
+    rl.run_tiled(first, refs, prep, ctx.buffer_from(frame.coef))
+    assert first.pic.twin_ok == api.TWIN_ONLY
+    # second frame: 8x8 warped blocks predicted from the first frame's luma
+    pd = util.pix_dtype(bpc)
+    dst = ctx.picture(64, 64, api.LAYOUT_I400, bpc)
+    dplane = rng.integers(0, 1 << bpc, size=dst.padded_shape(0)).astype(pd)
+    dst.upload(0, dplane)
+    want = dplane.copy()
+    sp = dst.stride_px(0)
+    src = np.ascontiguousarray(want1[0])
+    bps = pd().itemsize
+    n = 32
+    tasks = np.zeros(n, api.WARP_TASK)
+    for i in range(n):
+        bx, by = i % 8, i // 8
+        dx, dy = int(rng.integers(4, w - 16)), int(rng.integers(4, h - 16))
+        mx, my = (int(rng.integers(0, 0x2000)) - 0xa00 for _ in range(2))
+        abcd = (rng.integers(0, 0x2000, size=4) - 0xa00).astype(np.int16)
+        blk = want[by * 8:, bx * 8:]
+        oracle.call(bpc, "warp8x8", 0, 0, blk.ctypes.data, want.strides[0], src.ctypes.data + dy * src.strides[0] + dx * bps, src.strides[0], abcd, mx, my)
+        tasks[i] = (by * 8 * sp + bx * 8, dx, dy, mx, my, abcd, 64, 0, 0, 0, (0, 0, 0))
+    ctx.warp_batch(dst, [first], tasks, prep)
+    assert np.array_equal(dst.download(0), want), "the warped prediction did not read the first frame's pixels"
+    rl.destroy()
