@@ -18,6 +18,7 @@ struct Dav1dHipContext {
     enum { N_SIDE = 6 };
     hipStream_t side[N_SIDE];
     hipEvent_t ev_fork, ev_join[N_SIDE];
+    hipEvent_t ev_pair[3];      // ends of the side streams the paired launches of a recon list went to (events of their own: StreamFan re-records ev_join[])
     hipEvent_t ev_bin[16];      // "this tile shape's predictions are in the picture" (recon list pipeline)
     bool concurrent;
     int flow_min_steps;         // wavefronts of at least this many steps run as one dataflow launch ($DAV1D_HIP_FLOW_MIN_STEPS, 0 = never)
@@ -38,7 +39,7 @@ struct Dav1dHipContext {
     int chunk_upload;           // 0: a frame's chunks go up as one transfer at frame end; 1: each chunk as it is submitted (DAV1D_HIP_CHUNK_UPLOAD)
     int recon_coop_below;       // paired kernels: launches of fewer groups than this take the cooperative form (recon.hip; DAV1D_HIP_RECON_COOP_BELOW)
     int post_bands;             // bands of the pipelined post filters, 0 = stage by stage (DAV1D_HIP_POST_BANDS)
-    int recon_pair_streams;     // side streams the paired launches of a recon list are dealt over (DAV1D_HIP_RECON_PAIR_STREAMS, 1 or 2)
+    int recon_pair_streams;     // side streams the paired launches of a recon list are dealt over (DAV1D_HIP_RECON_PAIR_STREAMS, 1 .. 3; default 2)
     int ref_twin;               // tiled twins of reference pictures ($DAV1D_HIP_REF_TWIN): 0 never read, 1 (default) read when a picture has a valid
                                 // one (dav1d_hip_picture_retile), 2 also made for every picture of dav1d_hip_picture_alloc and by dav1d_hip_frame_end
     bool cdef_rows;             // option cdef_rows (default 1) / $DAV1D_HIP_CDEF_ROWS: the filter lister hands over one record per unit row of a 64-pixel column and the device makes the unit records (cdef.hip cdef_expand_kernel)

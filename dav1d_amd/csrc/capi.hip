@@ -3,7 +3,7 @@
 #include "capi.h"
 
 #ifndef RECON_FUSE_DEFAULT
-#define RECON_FUSE_DEFAULT 14       // which square block sizes run paired by default: see recon_fuse_mask() below
+#define RECON_FUSE_DEFAULT 15       // which square block sizes run paired by default: see recon_fuse_mask() below
 #endif
 #include "lists.h"
 #include "av1_scan_prefix.h"
@@ -61,7 +61,7 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     c->recon_coop_below = (int) env_int("DAV1D_HIP_RECON_COOP_BELOW", 4096);
     c->post_bands = (int) env_int("DAV1D_HIP_POST_BANDS", 0);
     c->ref_twin = (int) env_int("DAV1D_HIP_REF_TWIN", 1);
-    c->recon_pair_streams = (int) env_int("DAV1D_HIP_RECON_PAIR_STREAMS", 1);
+    c->recon_pair_streams = (int) env_int("DAV1D_HIP_RECON_PAIR_STREAMS", 2);
     const char *ser = getenv("DAV1D_HIP_SERIAL");
     c->concurrent = !(ser && atoi(ser));
     const char *cu = getenv("DAV1D_HIP_CDEF_UNIT");
@@ -82,6 +82,7 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     for (int i = 0; i < Dav1dHipContext::N_SIDE; i++) {
         if (hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
+        if (i < 3 && hipEventCreateWithFlags(&c->ev_pair[i], hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
     }
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
     for (int i = 0; i < 16; i++)
@@ -115,7 +116,7 @@ void dav1d_hip_close(Dav1dHipContext *c) {
     (void) hipDeviceSynchronize();
     hipStreamSynchronize(c->stream);
     if (c->scratch) hipFree(c->scratch);
-    for (int i = 0; i < Dav1dHipContext::N_SIDE; i++) { hipStreamSynchronize(c->side[i]); hipStreamDestroy(c->side[i]); hipEventDestroy(c->ev_join[i]); }
+    for (int i = 0; i < Dav1dHipContext::N_SIDE; i++) { hipStreamSynchronize(c->side[i]); hipStreamDestroy(c->side[i]); hipEventDestroy(c->ev_join[i]); if (i < 3) hipEventDestroy(c->ev_pair[i]); }
     hipEventDestroy(c->ev_fork);
     for (int i = 0; i < 16; i++) hipEventDestroy(c->ev_bin[i]);
     hipEventDestroy(c->ev_t0); hipEventDestroy(c->ev_t1); hipEventDestroy(c->ev_retile);
@@ -1832,6 +1833,9 @@ extern "C" int dav1d_hip_fg_apply(Dav1dHipContext *c, const Dav1dHipPicture *dst
 // 8x8 + 16x16 + 32x32 (14, the default) 0.317-0.327.  Round 1 (three separate LDS arrays): none 0.362, 6 0.311 (older clock),
 // 4x4 + 8x8 0.318, all 0.411.  What pays is that the paired launches move a quarter less HBM traffic AND run next to the
 // pipelined launches of the other sizes on streams of their own; 4x4 and 64x64 pairs lose to their separate kernels.
+// Round 6: the 4x4 pairs too (15, the default now): their launch fits five LDS pieces since the records pass through the window
+// buffer (48 us against 37 + 23 for the two launches it replaces) and it runs on the MAIN stream, out of the way of the side streams'
+// chains; with two frame contexts and two paired streams 0.2295 against 0.2424 ms per frame (profiles/r06/streams.txt).
 int recon_fuse_mask(const Dav1dHipContext *c) { return c->recon_fuse & 31; }
 
 extern "C" {
@@ -2038,6 +2042,7 @@ static int recon_list_run_impl(Dav1dHipContext *c, const Dav1dHipReconList *l, c
         if (l->stride_px[p] && dst->p[p].stride / bps != l->stride_px[p]) return -EINVAL;    // not the geometry the list was made for
     size_t n_paired = 0;
     bool paired_on_side = false;
+    int n_ps = 0;                                        // side streams the paired launches went to
     for (int k = 0; k < 5; k++) n_paired += l->f_n[k];
     if (n_paired) {
         // the paired blocks: one launch per size, largest first; independent of each other and of everything below
@@ -2051,27 +2056,29 @@ static int recon_list_run_impl(Dav1dHipContext *c, const Dav1dHipReconList *l, c
         // streams that run side by side 0.334-0.343 — three launches at a time share the memory system better than four.
         const bool side = c->concurrent && n_paired >= 16384;
         int rc = 0, lane = 0;
-        // c->recon_pair_streams: 1 = the paired launches one after the other on ONE side stream, 2 = dealt over two
-        const int ps[2] = { 2, c->recon_pair_streams >= 2 ? 3 : 2 };
+        // c->recon_pair_streams: 1 = the paired launches one after the other on ONE side stream, 2 / 3 = dealt over that many (side
+        // streams 2 .. 4; their ends are ev_pair[]).  Measured, round 6 (profiles/r06/streams.txt): with ONE frame in flight the
+        // extra streams change nothing — round 2 measured the same — but with two frame contexts they are worth 11 %: the launches of
+        // two frames on five streams keep every SIMD supplied with waves through the heads and tails of the single launches.
+        n_ps = side ? std::max(1, std::min(3, c->recon_pair_streams)) : 0;
         if (side) {
             (void) hipEventRecord(c->ev_fork, c->stream);
-            (void) hipStreamWaitEvent(c->side[ps[0]], c->ev_fork, 0);
-            (void) hipStreamWaitEvent(c->side[ps[1]], c->ev_fork, 0);
+            for (int j = 0; j < n_ps; j++) (void) hipStreamWaitEvent(c->side[2 + j], c->ev_fork, 0);
         }
         for (int k = 4; k >= 0 && !rc; k--)
             if (l->f_n[k]) {
+                // the 4x4 pairs go to the main stream, in front of the unpaired predictions: the side streams' chains of long launches are
+                // what the step waits for, and the short launches of the main stream end long before them
+                const bool on_main = side && k == 0;
                 rc = dav1d_hip_launch_recon_fused_out(&dp, rp, n_refs, dst->bpc, k, l->f_tiles[k], l->f_tasks[k], (int) l->f_n[k], prep, coef, c->recon_coop_below,
-                                                      wide, dst_twin, side ? c->side[ps[lane]] : c->stream);
-                lane ^= 1;
+                                                      wide, dst_twin, side && !on_main ? c->side[2 + lane] : c->stream);
+                if (!on_main && n_ps) lane = (lane + 1) % n_ps;
             }
-        if (side) {
-            (void) hipEventRecord(c->ev_join[1], c->side[ps[0]]);
-            (void) hipEventRecord(c->ev_join[2], c->side[ps[1]]);
-        }
+        for (int j = 0; j < n_ps; j++) (void) hipEventRecord(c->ev_pair[j], c->side[2 + j]);
         if (rc) return rc;
         paired_on_side = side;
         if (!l->inter->mc->n && !l->inter->comp->n && !l->itx->n) {
-            if (side) { (void) hipStreamWaitEvent(c->stream, c->ev_join[1], 0); (void) hipStreamWaitEvent(c->stream, c->ev_join[2], 0); }
+            for (int j = 0; j < n_ps; j++) (void) hipStreamWaitEvent(c->stream, c->ev_pair[j], 0);
             return 0;
         }
     }
@@ -2079,7 +2086,7 @@ static int recon_list_run_impl(Dav1dHipContext *c, const Dav1dHipReconList *l, c
     // c->recon_pipeline = smallest residual list worth two streams (0: always pipeline, -1: never)
     const long min_tasks = c->recon_pipeline;
     auto join_paired = [&]() {
-        if (paired_on_side) { (void) hipStreamWaitEvent(c->stream, c->ev_join[1], 0); (void) hipStreamWaitEvent(c->stream, c->ev_join[2], 0); }
+        if (paired_on_side) for (int j = 0; j < n_ps; j++) (void) hipStreamWaitEvent(c->stream, c->ev_pair[j], 0);
     };
     if (!dst_twin && (min_tasks < 0 || !c->concurrent || mc_fused_min_bin() < MC_BINS || (long) l->itx->n < min_tasks)) {
         int rc = dav1d_hip_inter_list_run(c, l->inter, dst, refs, n_refs, prep, mask);

@@ -38,7 +38,7 @@ def _default_options(request):
     yield
     if "ctx" in request.fixturenames:
         c = request.getfixturevalue("ctx")
-        for name, value in (("recon_fuse", 14), ("recon_pipeline", 16384), ("recon_lanes", 1), ("recon_coop_below", 4096), ("chunk_upload", 0), ("post_bands", 0), ("chunk_order", 0), ("chunk_hints", 1)):
+        for name, value in (("recon_fuse", 15), ("recon_pair_streams", 2), ("recon_pipeline", 16384), ("recon_lanes", 1), ("recon_coop_below", 4096), ("chunk_upload", 0), ("post_bands", 0), ("chunk_order", 0), ("chunk_hints", 1)):
             c.set_option(name, value)
 
 

@@ -14,7 +14,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 NAMES = ["recon_%dx%d" % (4 << k, 4 << k) for k in range(5)] + ["mc_%dx%d" % (4 << (b // 3), 4 << (b % 3)) for b in range(15)] + ["comp"] + ["itx_%d" % b for b in range(19)]
-DEFAULTS = {"recon_fuse": 14, "recon_pair_streams": 1, "recon_lanes": 1, "recon_pipeline": 16384, "recon_coop_below": 4096}
+DEFAULTS = {"recon_fuse": 15, "recon_pair_streams": 2, "recon_lanes": 1, "recon_pipeline": 16384, "recon_coop_below": 4096}
 
 
 def main():
