@@ -287,6 +287,15 @@ __device__ __forceinline__ void off_to_xy(const uint32_t off, const int stride, 
 // This lane's index in its wave
 __device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & 63); }
 
+// the value lane `lane` (the same for every lane that asks: a loop counter of an unrolled loop, a scalar) holds, as a scalar
+__device__ __forceinline__ int readlane(const int v, const int lane) {
+#ifdef DAV1D_HIP_EMU
+    return __shfl(v, lane);
+#else
+    return __builtin_amdgcn_readlane(v, lane);
+#endif
+}
+
 // LDS hand-off between the lanes of ONE wave (no other wave reads the data): order the
 // accesses and let the wave's outstanding LDS operations land; no s_barrier involved, so
 // waves of a workgroup never wait for each other.

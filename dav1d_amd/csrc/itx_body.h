@@ -384,13 +384,26 @@ __device__ __forceinline__ void tile_write_out(const pixel *tile, const Dav1dHip
     typedef typename std::conditional<BYTES == 16, uint4, typename std::conditional<BYTES == 8, uint2, uint32_t>::type>::type piece_t;
     static_assert(BYTES == 4 || BYTES == 8 || BYTES == 16, "piece size");
     const int lane = dv::lane_id();
-    // lane b knows block b: plane and position, handed to the lanes that store the block's pieces by wave shuffles
+    // Where a lane's pieces go: the position of their block.  With the records handed over by the transform body (task_plane >= 0: every lane
+    // of a block's lane group holds the block's record) no LDS permute is needed where the lanes that store a block are the lanes that
+    // transformed it (OWN: 4x4, 8x8), where a round of 64 pieces belongs to one block (ONE: 32x32) or to two (TWO: 16x16: two scalar reads and
+    // a select) — a wave's last instructions are these stores, and the three permutes per round in front of them were a twentieth of a
+    // 32x32 pair wave's life (profiles/r06: 69.0 -> 65.5 us).  Otherwise lane b works out block b's position and the others ask it.
+    constexpr int LPBX = 64 / BPW;                                       // lanes of a block in the transform body
+    constexpr bool OWN = BPW > 1 && PER_BLOCK == LPBX;                   // (then NCHK == 64: one round)
+    constexpr bool ONE = BPW > 1 && PER_BLOCK % 64 == 0;
+    constexpr bool TWO = BPW > 1 && PER_BLOCK == 32;
+    const bool direct = task_plane >= 0 && (OWN || ONE || TWO);
     int bx = 0, by = 0, bpl = 0;
-    if (task_plane >= 0) {
+    if (direct) {
+        if constexpr (OWN) {
+            bpl = task_plane;
+            dv::off_to_xy(task_off, bpl == 0 ? dst.stride[0] : bpl == 1 ? dst.stride[1] : dst.stride[2], bx, by);
+        }
+    } else if (task_plane >= 0) {
         // every lane of a block's group holds the block's record: lane b takes it from the first lane of group b
-        constexpr int LPB = 64 / BPW;
-        const uint32_t off = BPW == 1 ? task_off : (uint32_t) __shfl((int) task_off, (lane & (BPW - 1)) * LPB);
-        bpl = BPW == 1 ? task_plane : __shfl(task_plane, (lane & (BPW - 1)) * LPB);
+        const uint32_t off = BPW == 1 ? task_off : (uint32_t) __shfl((int) task_off, (lane & (BPW - 1)) * LPBX);
+        bpl = BPW == 1 ? task_plane : __shfl(task_plane, (lane & (BPW - 1)) * LPBX);
         if (lane < nb) dv::off_to_xy(off, bpl == 0 ? dst.stride[0] : bpl == 1 ? dst.stride[1] : dst.stride[2], bx, by);
     } else if (lane < nb) {
         const Dav1dHipItxTask t = tasks[lane];
@@ -402,9 +415,21 @@ __device__ __forceinline__ void tile_write_out(const pixel *tile, const Dav1dHip
         const int i = i0 + lane;
         const int b = BPW == 1 ? 0 : (i / PER_BLOCK) & (BPW - 1), rem = i - (i / PER_BLOCK) * PER_BLOCK;
         const int y = rem / CPR, c = rem - y * CPR;
-        const int x0 = BPW == 1 ? __builtin_amdgcn_readfirstlane(bx) : __shfl(bx, b);
-        const int y0 = BPW == 1 ? __builtin_amdgcn_readfirstlane(by) : __shfl(by, b);
-        const int pl = BPW == 1 ? __builtin_amdgcn_readfirstlane(bpl) : __shfl(bpl, b);
+        int x0, y0, pl;
+        if constexpr (BPW == 1) { x0 = __builtin_amdgcn_readfirstlane(bx); y0 = __builtin_amdgcn_readfirstlane(by); pl = __builtin_amdgcn_readfirstlane(bpl); }
+        else if (direct && OWN) { x0 = bx; y0 = by; pl = bpl; }
+        else if (direct && ONE) {
+            // (the record of the round's block, out of the first lane of its group in the transform body)
+            const int bl = ((i0 / PER_BLOCK) & (BPW - 1)) * LPBX;
+            pl = dv::readlane(task_plane, bl);
+            dv::off_to_xy((uint32_t) dv::readlane((int) task_off, bl), pl == 0 ? dst.stride[0] : pl == 1 ? dst.stride[1] : dst.stride[2], x0, y0);
+        } else if (direct && TWO) {
+            const int bl = ((i0 / PER_BLOCK) & (BPW - 1)) * LPBX;      // the round's first block; lanes 32 .. 63 store the next one
+            const bool hi = lane >= 32;
+            pl = hi ? dv::readlane(task_plane, bl + LPBX) : dv::readlane(task_plane, bl);
+            const uint32_t off = (uint32_t) (hi ? dv::readlane((int) task_off, bl + LPBX) : dv::readlane((int) task_off, bl));
+            dv::off_to_xy(off, pl == 0 ? dst.stride[0] : pl == 1 ? dst.stride[1] : dst.stride[2], x0, y0);
+        } else { x0 = __shfl(bx, b); y0 = __shfl(by, b); pl = __shfl(bpl, b); }
         if (i >= NCHK || i / PER_BLOCK >= nb) continue;
         const piece_t v = *reinterpret_cast<const piece_t *>(tile + b * itx_tile_stride(W, H) + y * W + c * CP);
 #ifdef DV_KO_WRITE

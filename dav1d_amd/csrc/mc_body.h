@@ -268,71 +268,78 @@ __device__ __forceinline__ void mc_hpass(const McPred &pd, const Taps &fh, const
     // unit tap: ((s + r1) >> (6 - ib) + r2) >> ib == (s + 32 + r1) >> 6, and sums of pixel << ib have no low bits to round.
     const int sh1 = fbits - ib;
     const int rnd1 = (1 << sh1) >> 1;
+    // the four sums of one 4-pixel strip of one window row (rounding offset included)
+    auto row_sums = [&](const int row, const int s, int (&o)[4]) {
+        const uint2 *wp = reinterpret_cast<const uint2 *>(win + row * WS + 4 * s);
+        int s0 = rnd1, s1 = rnd1, s2 = rnd1, s3 = rnd1;
+        if constexpr (TILED) {
+            // Output x of this strip sums f[k] * p[c + k] from window column c = toff + 4 s + x on.  c even: the pixel
+            // pairs of the row's dwords meet the tap pairs (f0, f1) (f2, f3) .. = ev[]; c odd: (0, f0) (f1, f2) .. = od[]
+            // one dword earlier.  Whether the strip's first column is even is a property of the tile (lists group
+            // tiles by it so that a wave rarely holds both kinds).
+            const uint32_t *dw = reinterpret_cast<const uint32_t *>(win + row * WS) + ((toff >> 1) + 2 * s);
+            if constexpr (NARROW) {
+                // taps 2 .. 5 only: the sums start one tap pair (two columns) into the 8-tap layout
+                const uint32_t d0 = dw[0], d1 = dw[1], d2 = dw[2], d3 = dw[3];
+                if (!(toff & 1)) {
+                    s0 = dv::dot2(d0, fh.ev[1], dv::dot2(d1, fh.ev[2], s0));
+                    s1 = dv::dot2(d0, fh.od[1], dv::dot2(d1, fh.od[2], dv::dot2(d2, fh.od[3], s1)));
+                    s2 = dv::dot2(d1, fh.ev[1], dv::dot2(d2, fh.ev[2], s2));
+                    s3 = dv::dot2(d1, fh.od[1], dv::dot2(d2, fh.od[2], dv::dot2(d3, fh.od[3], s3)));
+                } else {
+                    s0 = dv::dot2(d0, fh.od[1], dv::dot2(d1, fh.od[2], dv::dot2(d2, fh.od[3], s0)));
+                    s1 = dv::dot2(d1, fh.ev[1], dv::dot2(d2, fh.ev[2], s1));
+                    s2 = dv::dot2(d1, fh.od[1], dv::dot2(d2, fh.od[2], dv::dot2(d3, fh.od[3], s2)));
+                    s3 = dv::dot2(d2, fh.ev[1], dv::dot2(d3, fh.ev[2], s3));
+                }
+            } else {
+                const uint32_t d[6] = { dw[0], dw[1], dw[2], dw[3], dw[4], dw[5] };
+                if (!(toff & 1)) {
 #pragma unroll
-    for (int it0 = 0; it0 < NPR * NS; it0 += LPT) {
+                    for (int k = 0; k < 4; k++) { s0 = dv::dot2(d[k], fh.ev[k], s0); s2 = dv::dot2(d[k + 1], fh.ev[k], s2); }
+#pragma unroll
+                    for (int k = 0; k < 5; k++) { s1 = dv::dot2(d[k], fh.od[k], s1); s3 = dv::dot2(d[k + 1], fh.od[k], s3); }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 5; k++) { s0 = dv::dot2(d[k], fh.od[k], s0); s2 = dv::dot2(d[k + 1], fh.od[k], s2); }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { s1 = dv::dot2(d[k + 1], fh.ev[k], s1); s3 = dv::dot2(d[k + 2], fh.ev[k], s3); }
+                }
+            }
+        } else if constexpr (NARROW) {
+            // out x sums f[k] * p[x - 1 + k] over k = 2 .. 5, p[] = the 8 pixels of the row: the tap pairs (f1, f2) (f3, f4)
+            // (f5, f6) and (f2, f3) (f4, f5) of the 8-tap layout meet pixel pairs two columns further left
+            const uint2 a = wp[0], b = wp[1];
+            const uint32_t d[4] = { a.x, a.y, b.x, b.y };
+#pragma unroll
+            for (int k = 0; k < 3; k++) { s0 = dv::dot2(d[k], fh.od[k + 1], s0); s2 = dv::dot2(d[k + 1], fh.od[k + 1], s2); }
+#pragma unroll
+            for (int k = 0; k < 2; k++) { s1 = dv::dot2(d[k + 1], fh.ev[k + 1], s1); s3 = dv::dot2(d[k + 2], fh.ev[k + 1], s3); }
+        } else {
+            const uint2 a = wp[0], b = wp[1], c = wp[2];
+            const uint32_t d[6] = { a.x, a.y, b.x, b.y, c.x, c.y };
+            // out x sums f[k] * p[x + 1 + k], p[] = the 12 pixels of d[]; the rounding offset seeds the sum
+#pragma unroll
+            for (int k = 0; k < 5; k++) { s0 = dv::dot2(d[k], fh.od[k], s0); s2 = dv::dot2(d[k + 1], fh.od[k], s2); }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { s1 = dv::dot2(d[k + 1], fh.ev[k], s1); s3 = dv::dot2(d[k + 2], fh.ev[k], s3); }
+        }
+        o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
+    };
+    // Items of (row pair, strip) dealt over the tile's lanes.  Where the last round would have items for exactly half of the lanes (32x16
+    // tiles: 96 items, 64 lanes) it is dealt as SINGLE rows over all of them instead — the same rows in half the time; the row's
+    // four values go into their halves of the pair-interleaved intermediate as 16-bit stores.
+    constexpr int NIT = NPR * NS, FULL = NIT / LPT * LPT;
+    constexpr bool SPLIT = (NIT - FULL) * 2 == LPT;
+#pragma unroll
+    for (int it0 = 0; it0 < (SPLIT ? FULL : NIT); it0 += LPT) {
         const int it = it0 + l;
-        if (it >= NPR * NS) break;
+        if (it >= NIT) break;
         const int pr = it / NS, s = it % NS;
         if (2 * pr + 1 < row_lo || 2 * pr >= row_hi) continue;
         int o[2][4];
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-            const uint2 *wp = reinterpret_cast<const uint2 *>(win + (2 * pr + e) * WS + 4 * s);
-            int s0 = rnd1, s1 = rnd1, s2 = rnd1, s3 = rnd1;
-            if constexpr (TILED) {
-                // Output x of this strip sums f[k] * p[c + k] from window column c = toff + 4 s + x on.  c even: the pixel
-                // pairs of the row's dwords meet the tap pairs (f0, f1) (f2, f3) .. = ev[]; c odd: (0, f0) (f1, f2) .. = od[]
-                // one dword earlier.  Whether the strip's first column is even is a property of the tile (lists group
-                // tiles by it so that a wave rarely holds both kinds).
-                const uint32_t *dw = reinterpret_cast<const uint32_t *>(win + (2 * pr + e) * WS) + ((toff >> 1) + 2 * s);
-                if constexpr (NARROW) {
-                    // taps 2 .. 5 only: the sums start one tap pair (two columns) into the 8-tap layout
-                    const uint32_t d0 = dw[0], d1 = dw[1], d2 = dw[2], d3 = dw[3];
-                    if (!(toff & 1)) {
-                        s0 = dv::dot2(d0, fh.ev[1], dv::dot2(d1, fh.ev[2], s0));
-                        s1 = dv::dot2(d0, fh.od[1], dv::dot2(d1, fh.od[2], dv::dot2(d2, fh.od[3], s1)));
-                        s2 = dv::dot2(d1, fh.ev[1], dv::dot2(d2, fh.ev[2], s2));
-                        s3 = dv::dot2(d1, fh.od[1], dv::dot2(d2, fh.od[2], dv::dot2(d3, fh.od[3], s3)));
-                    } else {
-                        s0 = dv::dot2(d0, fh.od[1], dv::dot2(d1, fh.od[2], dv::dot2(d2, fh.od[3], s0)));
-                        s1 = dv::dot2(d1, fh.ev[1], dv::dot2(d2, fh.ev[2], s1));
-                        s2 = dv::dot2(d1, fh.od[1], dv::dot2(d2, fh.od[2], dv::dot2(d3, fh.od[3], s2)));
-                        s3 = dv::dot2(d2, fh.ev[1], dv::dot2(d3, fh.ev[2], s3));
-                    }
-                } else {
-                    const uint32_t d[6] = { dw[0], dw[1], dw[2], dw[3], dw[4], dw[5] };
-                    if (!(toff & 1)) {
-#pragma unroll
-                        for (int k = 0; k < 4; k++) { s0 = dv::dot2(d[k], fh.ev[k], s0); s2 = dv::dot2(d[k + 1], fh.ev[k], s2); }
-#pragma unroll
-                        for (int k = 0; k < 5; k++) { s1 = dv::dot2(d[k], fh.od[k], s1); s3 = dv::dot2(d[k + 1], fh.od[k], s3); }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 5; k++) { s0 = dv::dot2(d[k], fh.od[k], s0); s2 = dv::dot2(d[k + 1], fh.od[k], s2); }
-#pragma unroll
-                        for (int k = 0; k < 4; k++) { s1 = dv::dot2(d[k + 1], fh.ev[k], s1); s3 = dv::dot2(d[k + 2], fh.ev[k], s3); }
-                    }
-                }
-            } else if constexpr (NARROW) {
-                // out x sums f[k] * p[x - 1 + k] over k = 2 .. 5, p[] = the 8 pixels of the row: the tap pairs (f1, f2) (f3, f4)
-                // (f5, f6) and (f2, f3) (f4, f5) of the 8-tap layout meet pixel pairs two columns further left
-                const uint2 a = wp[0], b = wp[1];
-                const uint32_t d[4] = { a.x, a.y, b.x, b.y };
-#pragma unroll
-                for (int k = 0; k < 3; k++) { s0 = dv::dot2(d[k], fh.od[k + 1], s0); s2 = dv::dot2(d[k + 1], fh.od[k + 1], s2); }
-#pragma unroll
-                for (int k = 0; k < 2; k++) { s1 = dv::dot2(d[k + 1], fh.ev[k + 1], s1); s3 = dv::dot2(d[k + 2], fh.ev[k + 1], s3); }
-            } else {
-                const uint2 a = wp[0], b = wp[1], c = wp[2];
-                const uint32_t d[6] = { a.x, a.y, b.x, b.y, c.x, c.y };
-                // out x sums f[k] * p[x + 1 + k], p[] = the 12 pixels of d[]; the rounding offset seeds the sum
-#pragma unroll
-                for (int k = 0; k < 5; k++) { s0 = dv::dot2(d[k], fh.od[k], s0); s2 = dv::dot2(d[k + 1], fh.od[k], s2); }
-#pragma unroll
-                for (int k = 0; k < 4; k++) { s1 = dv::dot2(d[k + 1], fh.ev[k], s1); s3 = dv::dot2(d[k + 2], fh.ev[k], s3); }
-            }
-            o[e][0] = s0; o[e][1] = s1; o[e][2] = s2; o[e][3] = s3;
-        }
+        row_sums(2 * pr, s, o[0]);
+        row_sums(2 * pr + 1, s, o[1]);
         // intermediate rounding, reference src/mc_tmpl.c:150-152 (8-tap) / 462-464 (bilinear)
 #pragma unroll
         for (int e = 0; e < 2; e++)
@@ -344,6 +351,16 @@ __device__ __forceinline__ void mc_hpass(const McPred &pd, const Taps &fh, const
         m.z = dv::pack2(o[0][2], o[1][2]);
         m.w = dv::pack2(o[0][3], o[1][3]);
         *reinterpret_cast<uint4 *>(mid + pr * TW + 4 * s) = m;
+    }
+    if constexpr (SPLIT) {
+        const int it = FULL + (l >> 1), pr = it / NS, s = it % NS, row = 2 * pr + (l & 1);
+        if (row >= row_lo && row < row_hi) {
+            int o[4];
+            row_sums(row, s, o);
+            int16_t *const mp = reinterpret_cast<int16_t *>(mid + pr * TW + 4 * s) + (l & 1);
+#pragma unroll
+            for (int x = 0; x < 4; x++) mp[2 * x] = (int16_t) (o[x] >> sh1);
+        }
     }
 }
 

@@ -24,6 +24,9 @@ namespace {
 #ifndef RECON_WAVES_8
 #define RECON_WAVES_8 7
 #endif
+#ifndef RECON_WAVES_32
+#define RECON_WAVES_32 7   // (the 32x32 pairs: 90 registers whatever is asked, and the LDS holds 4.5 waves per SIMD)
+#endif
 
 constexpr int rc_log2(int v) { return v <= 1 ? 0 : 1 + rc_log2(v >> 1); }
 
@@ -44,7 +47,7 @@ template <int CLS> constexpr int recon_waves() {
 // WIDE: the reconstructed blocks leave through the LDS tile in row pieces of up to 16 bytes (tile_write_out, itx_body.h) instead of
 // two bytes per lane and row — and go to the picture's tiled twin as well when `twin` has planes (twin.data[0] != nullptr).
 template <int CLS, typename pixel, typename coef, bool COOP, bool TILED, bool WIDE>
-__global__ __launch_bounds__(COOP ? 64 * recon_waves<CLS>() : 64, COOP ? 1 : CLS == 1 ? RECON_WAVES_8 : RECON_WAVES)
+__global__ __launch_bounds__(COOP ? 64 * recon_waves<CLS>() : 64, COOP ? 1 : CLS == 1 ? RECON_WAVES_8 : CLS == 3 ? RECON_WAVES_32 : RECON_WAVES)
 void recon_fused_kernel(const DevPlanes dst, const RefSet refs, const McTile *__restrict__ tiles,
                         const Dav1dHipItxTask *__restrict__ tasks, const int n_blocks,
                         int16_t *__restrict__ prep, coef *__restrict__ cf, const int bitdepth_max, const DevPlanes twin)

@@ -72,7 +72,8 @@ def test_device_tables_equal_reference_tables():
 
 
 def test_packed_taps_match_subpel_filters():
-    """av1_mc_taps_packed (v_dot2 operand form) is a pure re-packing of av1_mc_subpel_filters."""
+    """av1_mc_taps_packed (v_dot2 operand form) is a pure re-packing of av1_mc_subpel_filters; phase 0 is the unit tap at the
+    filters' own scale (64, bilinear 16: tools/gen_tables.py)."""
     txt = open(os.path.join(util.ROOT, "dav1d_amd", "csrc", "av1_tables.h")).read()
 
     def table(name):
@@ -83,7 +84,7 @@ def test_packed_taps_match_subpel_filters():
     packed = np.array(table("mc_taps_packed"), dtype=np.uint32).reshape(7, 16, 9)
     for fs in range(7):
         for m in range(16):
-            f = [0, 0, 0, 1, 0, 0, 0, 0] if m == 0 else ([0, 0, 0, 16 - m, m, 0, 0, 0] if fs == 6 else list(filt[fs, m - 1]))
+            f = [0, 0, 0, 16 if fs == 6 else 64, 0, 0, 0, 0] if m == 0 else ([0, 0, 0, 16 - m, m, 0, 0, 0] if fs == 6 else list(filt[fs, m - 1]))
             g = [0] + f + [0]
             want = [(f[2 * k] & 0xffff) | ((f[2 * k + 1] & 0xffff) << 16) for k in range(4)] + \
                    [(g[2 * k] & 0xffff) | ((g[2 * k + 1] & 0xffff) << 16) for k in range(5)]
@@ -91,6 +92,6 @@ def test_packed_taps_match_subpel_filters():
     span = np.array(table("mc_tap_span")).reshape(7, 16)
     for fs in range(7):
         for m in range(16):
-            f = [0, 0, 0, 1, 0, 0, 0, 0] if m == 0 else ([0, 0, 0, 16 - m, m, 0, 0, 0] if fs == 6 else list(filt[fs, m - 1]))
+            f = [0, 0, 0, 16 if fs == 6 else 64, 0, 0, 0, 0] if m == 0 else ([0, 0, 0, 16 - m, m, 0, 0, 0] if fs == 6 else list(filt[fs, m - 1]))
             lo, hi = span[fs, m] & 15, span[fs, m] >> 4
             assert all(v == 0 for v in f[:lo]) and all(v == 0 for v in f[hi:]) and f[lo] and f[hi - 1], (fs, m)
