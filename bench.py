@@ -3,7 +3,7 @@
 8K 4:2:0 10-bit on N MI355X GPUs (BASELINE.json metric), one process per GPU.
 
 A "step" = one pass of the hot path over one synthetic 8K inter frame whose task lists
-(dav1d_amd.synth, SURVEY.md §8d config C2's itx+mc subset) are already resident in HBM:
+(tests/synth_frames.py, SURVEY.md §8d config C2's itx+mc subset) are already resident in HBM:
     mc put/prep (all blocks, 3 planes) -> compound avg (25 % of blocks) -> itxfm_add (all blocks).
 Every step consumes its own pristine copy of the coefficient arena (the kernels zero the
 slabs they consume, as the reference does) and rotates over 4 output pictures, so no step
@@ -126,7 +126,7 @@ def pmc_traffic(kernel, w, h, bpc):
     elif m.group(1) == "mc":
         key = "mc_kernel<%s,%s,u16>" % (m.group(2), m.group(3))
     else:
-        from dav1d_amd import synth
+        import synth_frames as synth
         tx = [i for i in range(19) if synth.TX_W[i] == int(m.group(2)) and synth.TX_H[i] == int(m.group(3))][0]
         key = "itx_add_kernel<%d,u16,int>" % tx
     if key not in d:        # the kernels carry their variants in the name (cooperative / tiled references / wide stores): the plain one has them all off
@@ -158,7 +158,7 @@ def _kernel_pattern(name):
         return r"recon_fused_kernel<%d," % (int(m.group(2)).bit_length() - 3)
     if m.group(1) == "mc":
         return r"mc_(?:twin_)?kernel<%s, %s," % (m.group(2), m.group(3))
-    from dav1d_amd import synth
+    import synth_frames as synth
     tx = [i for i in range(19) if synth.TX_W[i] == int(m.group(2)) and synth.TX_H[i] == int(m.group(3))][0]
     return r"itx_add(?:_wide)?_kernel<%d," % tx
 
@@ -581,7 +581,8 @@ def run_job(a, rank, local, world):
     """One measurement (the mode `a` selects) on the process group main() set up; returns the JSON line on rank 0, None elsewhere."""
     import torch
     from dav1d_amd import dist as dd
-    from dav1d_amd import api, synth
+    from dav1d_amd import api
+    import synth_frames as synth
     dev = DEV(a)
 
     if a.emu:

@@ -223,6 +223,12 @@ class Context:
             self.lib.dav1d_hip_close(self.h)
             self.h = None
 
+    def get_option(self, name):
+        """dav1d_hip_get_option: a counter or knob of this context (see include/dav1d_hip.h)"""
+        v = C.c_long()
+        _chk(self.lib.dav1d_hip_get_option(self.h, name.encode(), C.byref(v)), "get_option(%s)" % name)
+        return v.value
+
     def set_option(self, name, value):
         """dav1d_hip_set_option: a tuning knob of this context (see include/dav1d_hip.h)"""
         _chk(self.lib.dav1d_hip_set_option(self.h, name.encode(), int(value)), "set_option(%s)" % name)

@@ -30,9 +30,11 @@ struct Dav1dHipContext {
                                 // ($DAV1D_HIP_INTRA_SB_FLOW / option intra_sb_flow); 0: a launch per level
     int intra_sb_lds;           // 1: the superblock's pixels stay in LDS where that form exists (4:2:0); 0 (default): handed over through the L2 — measured
                                 // equal or a little faster ($DAV1D_HIP_INTRA_SB_LDS / option intra_sb_lds)
-    int intra_sb_waves;         // waves per workgroup of that route: 4, 8 or 0 = the kernel form's own choice ($DAV1D_HIP_INTRA_SB_WAVES / option intra_sb_waves;
-                                // the one-launch form chooses 4 where the levels are wide (>= 128 superblocks on average) and nothing is copied, else 8;
-                                // the per-level launches 8)
+    int intra_sb_waves;         // waves per workgroup of that route: 1, 4, 8 or 0 = the kernel form's own choice ($DAV1D_HIP_INTRA_SB_WAVES / option intra_sb_waves;
+                                // the one-launch form chooses 1 where the superblocks hold intra_sb_one_below units or fewer on average and nothing is copied,
+                                // 4 where the levels are wide (>= 128 superblocks on average) and nothing is copied, else 8; the per-level launches 8)
+    long intra_sb_fallbacks;    // frames whose one-launch intra pass was finished by launches per level (workgroups gave up waiting: never in a sound run); dav1d_hip_get_stat
+    int intra_sb_one_below;     // see intra_sb_waves ($DAV1D_HIP_INTRA_SB_ONE_BELOW / option intra_sb_one_below; 0: never one wave)
     int recon_fuse;             // bit mask of the square block sizes that run paired (DAV1D_HIP_RECON_FUSE)
     long recon_pipeline;        // smallest residual list a recon list pipelines on two streams (DAV1D_HIP_RECON_PIPELINE)
     int recon_lanes;            // side streams of the residual launches (DAV1D_HIP_RECON_LANES)
@@ -303,6 +305,7 @@ struct SbTiling {                                   // the frame's tiles in supe
     uint16_t col_start[65], row_start[65];
 };
 void dav1d_hip_sbw_set_fine(int on);
+void dav1d_hip_sbw_set_fail_at(int at);
 int dav1d_hip_sb_tiling_make(SbTiling *tl, int w, int h, int sb128, int n_cols, const uint16_t *col_start_sb, int n_rows, const uint16_t *row_start_sb);
 enum : uint32_t { SB_NONE = 0xffffffffu };
 struct SbSort {
@@ -317,10 +320,12 @@ void dav1d_hip_sbw_emit(const std::vector<IntraUnit> &units, const SbSort &st, I
 // extra (or nullptr): further (superblock << 32 | superblock it waits for) pairs, sorted — the sources of intra block copies
 int dav1d_hip_sbw_levels(const SbTiling &tl, const uint32_t *sbs, size_t n, const uint8_t *dep, std::vector<int> &level_of_sb, std::vector<uint32_t> &level,
                          const std::vector<uint64_t> *extra = nullptr);
-// where (with flags; DEVICE, one word per superblock of the frame, raster): the superblock's place in `regions` or SB_NONE; sbw: superblocks per row
+// where (with flags; DEVICE, one word per superblock of the frame, raster): the superblock's place in `regions` or SB_NONE; sbw: superblocks per row;
+// done (DEVICE, a byte per record of `units`, or nullptr): with flags, zeroed by the caller and set behind every unit the launch reconstructs; without flags,
+// the units a launch leaves alone — how launches per level finish a frame whose one-launch pass gave up (frame.hip)
 extern "C" int dav1d_hip_launch_intra_sb(const DevPlanes *dst, int bpc, int layout, const IntraUnit *units, const SbRegion *regions, int n_regions,
                                          uint8_t *aux, const uint8_t *mask, void *coef, int waves, int sb_log2, int lds, uint32_t *flags, void *stream,
-                                         const uint32_t *where = nullptr, int sbw = 0);
+                                         const uint32_t *where = nullptr, int sbw = 0, uint8_t *done = nullptr);
 // regions sorted by level + where each level starts, from the parts of any number of unit arrays laid end to end (base[k] = where
 // array k starts): host-side plan of a frame's launches
 struct SbPlan { std::vector<SbRegion> regions; std::vector<uint32_t> level_start; /* n_levels + 1 */ std::vector<uint32_t> where; /* superblock -> its region */ };

@@ -77,6 +77,8 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     const char *isb = getenv("DAV1D_HIP_INTRA_SB");
     c->intra_sb = isb ? atoi(isb) : 2;
     c->intra_sb_waves = (int) env_int("DAV1D_HIP_INTRA_SB_WAVES", 0);
+    c->intra_sb_one_below = (int) env_int("DAV1D_HIP_INTRA_SB_ONE_BELOW", 0);
+    c->intra_sb_fallbacks = 0;
     c->intra_sb_lds = (int) env_int("DAV1D_HIP_INTRA_SB_LDS", 0);
     c->intra_sb_flow = (int) env_int("DAV1D_HIP_INTRA_SB_FLOW", 1);
     for (int i = 0; i < Dav1dHipContext::N_SIDE; i++) {
@@ -183,6 +185,17 @@ void dav1d_hip_graph_destroy(Dav1dHipContext *c, Dav1dHipGraph *g) {
     hipGraphDestroy(g->graph);
     delete g;
 }
+int dav1d_hip_get_option(Dav1dHipContext *c, const char *name, long *value) {
+    if (!c || !name || !value) return -EINVAL;
+    if (!strcmp(name, "intra_sb_fallbacks")) *value = c->intra_sb_fallbacks;
+    else if (!strcmp(name, "intra_sb_waves")) *value = c->intra_sb_waves;
+    else if (!strcmp(name, "intra_sb_one_below")) *value = c->intra_sb_one_below;
+    else if (!strcmp(name, "recon_fuse")) *value = c->recon_fuse;
+    else if (!strcmp(name, "recon_pair_streams")) *value = c->recon_pair_streams;
+    else if (!strcmp(name, "ref_twin")) *value = c->ref_twin;
+    else return -EINVAL;
+    return 0;
+}
 // knobs by name (the environment variables of DESIGN.md without the DAV1D_HIP_ prefix, lower case); -EINVAL for an unknown name
 int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value) {
     if (!c || !name) return -EINVAL;
@@ -202,10 +215,12 @@ int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value) {
     else if (!strcmp(name, "flow_mode")) c->flow_mode = (int) value;
     else if (!strcmp(name, "flow_min_steps")) c->flow_min_steps = (int) value;
     else if (!strcmp(name, "intra_sb")) c->intra_sb = (int) value;
-    else if (!strcmp(name, "intra_sb_waves")) c->intra_sb_waves = value >= 8 ? 8 : value >= 4 ? 4 : 0;
+    else if (!strcmp(name, "intra_sb_waves")) c->intra_sb_waves = value >= 8 ? 8 : value >= 4 ? 4 : value == 1 ? 1 : 0;
+    else if (!strcmp(name, "intra_sb_one_below")) c->intra_sb_one_below = value > 0 ? (int) value : 0;
     else if (!strcmp(name, "intra_sb_lds")) c->intra_sb_lds = value != 0;
     else if (!strcmp(name, "intra_sb_flow")) c->intra_sb_flow = value != 0;
     else if (!strcmp(name, "intra_sb_fine")) dav1d_hip_sbw_set_fine(value != 0);
+    else if (!strcmp(name, "intra_sb_fail_at")) dav1d_hip_sbw_set_fail_at((int) value);
     else if (!strcmp(name, "chunk_order")) c->chunk_order = value != 0;
     else if (!strcmp(name, "chunk_hints")) c->chunk_hints = value != 0;
     else if (!strcmp(name, "chunk_arena_min")) { if (value < 4096) return -EINVAL; c->arena_min = (size_t) 1 << 12; while (c->arena_min < (size_t) value) c->arena_min <<= 1; c->arena_hint = 0; }

@@ -1375,11 +1375,13 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
                 const bool one_launch = c->intra_sb_flow && !lds && plan.level_start.size() > 2;
                 const size_t fb = (plan.regions.size() + 1) * sizeof(uint32_t), o_flags = (ub + rb + 255) & ~(size_t) 255;
                 const size_t o_where = (o_flags + fb + 255) & ~(size_t) 255, wb = one_launch ? plan.where.size() * sizeof(uint32_t) : 0;
-                TaskBuf dev_buf(c, o_where + wb + 256);
+                const size_t o_done = (o_where + wb + 255) & ~(size_t) 255, db = one_launch ? total : 0;       // a byte per record: reconstructed by the one launch
+                TaskBuf dev_buf(c, o_done + db + 256);
                 uint8_t *const dev = dev_buf.p;
                 if (!dev) rc = -ENOMEM;
                 if (!rc) rc = hip_rc(hipMemcpyAsync(dev, host, ub, hipMemcpyHostToDevice, c->stream));
                 if (!rc && one_launch) rc = hip_rc(hipMemsetAsync(dev + o_flags, 0, fb, c->stream));
+                if (!rc && one_launch) rc = hip_rc(hipMemsetAsync(dev + o_done, 0, db, c->stream));
                 if (!rc) rc = dav1d_hip_upload(c, dev + ub, plan.regions.data(), rb);
                 if (!rc && wb) rc = dav1d_hip_upload(c, dev + o_where, plan.where.data(), wb);
                 const auto t_b = std::chrono::steady_clock::now();
@@ -1392,14 +1394,30 @@ static int frame_run(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask,
                     // CUs are not all busy and a superblock's own time counts: 30.8 fps against 28.2 on the 8K stream of bench.py) and for
                     // intra block copies (wide steps of whole-block copies: 12.1 ms against 13.1).  profiles/r05/intra_sb_waves_ab.jsonl
                     const bool wide_levels = plan.regions.size() >= 128 * (plan.level_start.size() - 1);
-                    const int sb_waves = c->intra_sb_waves ? c->intra_sb_waves : copy_deps.empty() && wide_levels ? 4 : 8;
+                    // ONE wave per superblock (its units one after the other, no barrier, eight superblocks per CU) is there for frames whose
+                    // superblocks hold intra_sb_one_below units or fewer on average; off by default: measured no faster (the inter frame with 10 % intra
+                    // blocks of bench.py's full table 0.435 -> 0.507 ms with it forced: a superblock is as slow as its units in a row, 8 - 10 us each,
+                    // and the launch as slow as its fullest superblock; profiles/r06/intra_one_wave_ab.txt)
+                    const bool few_units = c->intra_sb_one_below > 0 && total - plan.regions.size() <= (size_t) c->intra_sb_one_below * plan.regions.size();
+                    const int sb_waves = c->intra_sb_waves ? c->intra_sb_waves : copy_deps.empty() && few_units ? 1 : copy_deps.empty() && wide_levels ? 4 : 8;
                     if (!rc) rc = dav1d_hip_launch_intra_sb(&dp, f->cur.bpc, f->cur.layout, reinterpret_cast<const IntraUnit *>(dev),
                                                             reinterpret_cast<const SbRegion *>(dev + ub), (int) plan.regions.size(), f->aux, mask, coef,
                                                             sb_waves, f->tiling.sb_log2, 0, reinterpret_cast<uint32_t *>(dev + o_flags), c->stream,
-                                                            reinterpret_cast<const uint32_t *>(dev + o_where), f->tiling.sbw);
+                                                            reinterpret_cast<const uint32_t *>(dev + o_where), f->tiling.sbw, dev + o_done);
                     uint32_t gave_up = 0;
                     if (!rc) rc = dav1d_hip_download(c, &gave_up, dev + o_flags + plan.regions.size() * sizeof(uint32_t), sizeof(gave_up));
-                    if (!rc && gave_up) rc = -EIO;
+                    if (!rc && gave_up) {
+                        // Workgroups gave up waiting for a neighbour (never seen: the form rests on workgroups being dispatched in the order of
+                        // their index and staying resident; a driver that preempts or reorders them would break it).  Nothing is lost: every unit
+                        // the launch reconstructed is marked (`done`, a byte per record), and the launches per level below — no flags, no
+                        // residency assumption — run what is left, level by level.
+                        c->intra_sb_fallbacks++;
+                        for (size_t l = 0; l + 1 < plan.level_start.size() && !rc; l++)
+                            rc = dav1d_hip_launch_intra_sb(&dp, f->cur.bpc, f->cur.layout, reinterpret_cast<const IntraUnit *>(dev),
+                                                           reinterpret_cast<const SbRegion *>(dev + ub) + plan.level_start[l],
+                                                           (int) (plan.level_start[l + 1] - plan.level_start[l]), f->aux, mask, coef, sb_waves, f->tiling.sb_log2,
+                                                           0, nullptr, c->stream, nullptr, 0, dev + o_done);
+                    }
                 } else
                 for (size_t l = 0; l + 1 < plan.level_start.size() && !rc; l++)
                     rc = dav1d_hip_launch_intra_sb(&dp, f->cur.bpc, f->cur.layout, reinterpret_cast<const IntraUnit *>(dev),

@@ -47,7 +47,10 @@ constexpr int sb_itx_lds_max(int tx = 0) { return tx == 19 ? 0 : cmax(sb_itx_lds
 enum { SB_SPIN_LIMIT = 1 << 18 };        // naps of ~3 µs before a waiting workgroup gives up (a bug, never a normal run)
 
 // the unit the same wave works on after `u` (host: dav1d_hip_sbw_emit)
-template <int NW> __device__ __forceinline__ uint32_t sb_next(const IntraUnit &u) { return NW == 4 ? u.pad2 : u.prev_n; }
+// (one wave per superblock: the records in their order — no chain to follow)
+template <int NW> __device__ __forceinline__ uint32_t sb_next(const IntraUnit &u, const uint32_t at, const uint32_t n_units) {
+    return NW == 1 ? (at + 1 < n_units ? at + 1 : SB_NONE) : NW == 4 ? u.pad2 : u.prev_n;
+}
 
 // records [r.first, r.first + r.n): the superblock's header, then its units sorted by (step, predictions first); grp = the unit's
 // group, groups are separated by workgroup barriers.
@@ -58,7 +61,8 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
                                                                      coef *__restrict__ cf, const int layout, const int bitdepth_max,
                                                                      uint32_t *flags /* ONE launch for every level: a word per superblock (+ the error word behind them), or nullptr */,
                                                                      const int n_regions, const uint32_t *__restrict__ where /* superblock (raster) -> its region; with flags */,
-                                                                     const int sbw, const int sb_log2)
+                                                                     const int sbw, const int sb_log2, const int fail_at /* test hook: this workgroup gives up at once; -1 */,
+                                                                     uint8_t *done /* a byte per record, or nullptr: with flags, set behind every reconstructed unit; without, the units to skip */)
 {
     __shared__ int16_t e1_s[SB_WAVES][ESZ], e2_s[SB_WAVES][ESZ];
     __shared__ int16_t blk_s[SB_WAVES][32 * 32];
@@ -77,6 +81,11 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
     // the wave had no unit)
     DV_PHASE_BEGIN();
     const SbRegion r = regions[blockIdx.x];
+    if (flags && (int) blockIdx.x == fail_at) {
+        // (option intra_sb_fail_at: what a workgroup does whose wait ran out — its superblock untouched, its flag telling the others)
+        if (threadIdx.x == 0) { atomicAdd(flags + n_regions, 1u); dv::st_coherent(flags + blockIdx.x, 2u); }
+        return;
+    }
     // FINE (one launch, every prediction stamped by the lister): nobody waits for whole superblocks.  flags[sb] = progress << 2 | state
     // (state 1 finished, 2 gave up; progress P = every unit of a step < P has its pixels out).  A unit whose prediction reads intra pixels
     // of other superblocks waits, itself, until those have published a progress above the step it needs; units on a superblock's right /
@@ -127,10 +136,11 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
     const uint32_t n_groups = (uint32_t) __builtin_amdgcn_readfirstlane((int) hdr[0]);
     // this wave's chain of units (sb_next: the host linked them), two records ahead: while unit `u` is worked on, the record of the
     // next one (un) is in registers — its coefficients set off — and the one after that (u2) is on its way
-    uint32_t ci = (uint32_t) __builtin_amdgcn_readfirstlane((int) hdr[(SB_WAVES == 4 ? 2 : 6) + wv]);
+    const uint32_t n_units = r.n - 1;
+    uint32_t ci = SB_WAVES == 1 ? (n_units ? 0u : SB_NONE) : (uint32_t) __builtin_amdgcn_readfirstlane((int) hdr[(SB_WAVES == 4 ? 2 : 6) + wv]);
     IntraUnit u, un;
     if (ci != SB_NONE) u = us[ci];
-    uint32_t ni = ci != SB_NONE ? (uint32_t) __builtin_amdgcn_readfirstlane((int) sb_next<SB_WAVES>(u)) : SB_NONE;
+    uint32_t ni = ci != SB_NONE ? (uint32_t) __builtin_amdgcn_readfirstlane((int) sb_next<SB_WAVES>(u, ci, n_units)) : SB_NONE;
     if (ni != SB_NONE) un = us[ni];
     DV_PHASE(900);
     for (uint32_t g = 0; g < n_groups; g++) {
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
             IntraUnit u2;
             int keepn = 0;
             if (ni != SB_NONE) {
-                n2 = (uint32_t) __builtin_amdgcn_readfirstlane((int) sb_next<SB_WAVES>(un));
+                n2 = (uint32_t) __builtin_amdgcn_readfirstlane((int) sb_next<SB_WAVES>(un, ni, n_units));
                 if (n2 != SB_NONE) u2 = us[n2];
                 if (SB_PREFETCH == 1 && (un.has & 2)) {
                     const int nbn = ((int) un.t.rsv[0] | (int) un.t.rsv[1] << 8) * (int) sizeof(coef);
@@ -208,6 +218,8 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
                 dv::fence_acquire_agent();
             }
             DV_PHASE(901);
+            // the launches per level that follow a one-launch pass in which workgroups gave up (frame.hip): what that pass finished stays
+            if (!flags && done && done[r.first + 1 + ci]) skip = true;
             if (skip) {          // never in a sound run: the unit is NOT reconstructed from pixels that are not there
                 dv::fetch_end(keepn);
                 ci = ni; u = un; ni = n2; un = u2;
@@ -265,6 +277,9 @@ __global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) v
                     else *reinterpret_cast<quad *>(d + y * stride + x) = v;
                 }
             }
+            // one launch for every level: the unit is marked, so that, should a workgroup of this launch give up waiting, the
+            // launches per level that then finish the frame run exactly the units that are still to do (a residual is added once)
+            if (flags && done && lane == 0) done[r.first + 1 + ci] = 1;
             dv::fetch_end(keepn);
             dv::wave_sync();                 // the LDS is free for the wave's next unit
             DV_PHASE(904);
@@ -373,7 +388,7 @@ __global__ __launch_bounds__(NW * 64, SBL2 == 6 ? 2 : 1) void intra_sbl_kernel(c
     uint32_t ci = (uint32_t) __builtin_amdgcn_readfirstlane((int) hdr[(NW == 4 ? 2 : 6) + wv]);
     IntraUnit u, un;
     if (ci != SB_NONE) u = us[ci];
-    uint32_t ni = ci != SB_NONE ? (uint32_t) __builtin_amdgcn_readfirstlane((int) sb_next<NW>(u)) : SB_NONE;
+    uint32_t ni = ci != SB_NONE ? (uint32_t) __builtin_amdgcn_readfirstlane((int) sb_next<NW>(u, ci, 0u)) : SB_NONE;
     if (ni != SB_NONE) un = us[ni];
     for (uint32_t g = 0; g < n_groups; g++) {
         while (ci != SB_NONE && ((uint32_t) __builtin_amdgcn_readfirstlane((int) u.grp) & 0xffffu) == g) {
@@ -382,7 +397,7 @@ __global__ __launch_bounds__(NW * 64, SBL2 == 6 ? 2 : 1) void intra_sbl_kernel(c
             IntraUnit u2;
             int keepn = 0;
             if (ni != SB_NONE) {
-                n2 = (uint32_t) __builtin_amdgcn_readfirstlane((int) sb_next<NW>(un));
+                n2 = (uint32_t) __builtin_amdgcn_readfirstlane((int) sb_next<NW>(un, ni, 0u));
                 if (n2 != SB_NONE) u2 = us[n2];
                 if (SB_PREFETCH == 1 && (un.has & 2)) {
                     const int nbn = ((int) un.t.rsv[0] | (int) un.t.rsv[1] << 8) * (int) sizeof(coef);
@@ -443,10 +458,15 @@ __global__ __launch_bounds__(NW * 64, SBL2 == 6 ? 2 : 1) void intra_sbl_kernel(c
 
 // flags != nullptr: regions[0 .. n_regions) are EVERY level of the frame in level order and run as one launch (L2 hand-off form only;
 // flags = n_regions + 1 zeroed words, the last one counts workgroups that gave up waiting).
-// waves: workgroup size in waves, 4 or 8 (0: the form's own choice).  lds: the LDS-resident form where it exists (4:2:0 / 4:0:0 pictures).
+// waves: workgroup size in waves: 1 (a superblock's units one after the other by ONE wave: no workgroup barrier, eight superblocks per CU in
+// flight — for superblocks with a handful of units, the isolated intra blocks of an inter frame), 4 or 8 (0: the form's own choice).  lds: the LDS-resident form where it exists (4:2:0 / 4:0:0 pictures).
+// option intra_sb_fail_at (process-wide; tests): the workgroup of this index gives up at once in the one-launch form, as if its wait had run out
+static std::atomic<int> g_sbw_fail_at{-1};
+void dav1d_hip_sbw_set_fail_at(int at) { g_sbw_fail_at.store(at); }
+
 extern "C" int dav1d_hip_launch_intra_sb(const DevPlanes *dst, int bpc, int layout, const IntraUnit *units, const SbRegion *regions, int n_regions,
                                          uint8_t *aux, const uint8_t *mask, void *coef, int waves, int sb_log2, int lds, uint32_t *flags, void *stream,
-                                         const uint32_t *where, int sbw)
+                                         const uint32_t *where, int sbw, uint8_t *done)
 {
     if (n_regions <= 0) return 0;
     const int bitdepth_max = (1 << bpc) - 1;
@@ -469,9 +489,9 @@ extern "C" int dav1d_hip_launch_intra_sb(const DevPlanes *dst, int bpc, int layo
         return hip_rc(hipGetLastError());
     }
 #define SB_LAUNCH(P, Cf, NW) hipLaunchKernelGGL((intra_sb_kernel<P, Cf, NW>), dim3(n_regions), dim3(NW * 64), 0, (hipStream_t) stream, *dst, units, regions, \
-                                                aux, mask, (Cf *) coef, layout, bitdepth_max, flags, n_regions, where, sbw, sb_log2)
-    if (bpc == 8) { if (waves == 4) SB_LAUNCH(uint8_t, int16_t, 4); else SB_LAUNCH(uint8_t, int16_t, 8); }
-    else { if (waves == 4) SB_LAUNCH(uint16_t, int32_t, 4); else SB_LAUNCH(uint16_t, int32_t, 8); }
+                                                aux, mask, (Cf *) coef, layout, bitdepth_max, flags, n_regions, where, sbw, sb_log2, flags ? g_sbw_fail_at.load() : -1, done)
+    if (bpc == 8) { if (waves == 1) SB_LAUNCH(uint8_t, int16_t, 1); else if (waves == 4) SB_LAUNCH(uint8_t, int16_t, 4); else SB_LAUNCH(uint8_t, int16_t, 8); }
+    else { if (waves == 1) SB_LAUNCH(uint16_t, int32_t, 1); else if (waves == 4) SB_LAUNCH(uint16_t, int32_t, 4); else SB_LAUNCH(uint16_t, int32_t, 8); }
 #undef SB_LAUNCH
     return hip_rc(hipGetLastError());
 }

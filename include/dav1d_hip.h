@@ -69,12 +69,18 @@ DAV1D_HIP_API void dav1d_hip_graph_destroy(Dav1dHipContext *c, Dav1dHipGraph *g)
  * "serial", "cdef_unit", "flow_groups", "flow_mode", "flow_min_steps", "chunk_arena_min",
  * "intra_sb": the intra blocks of a frame superblock by superblock — 2, the default: every frame whose tiling is known; 1: only
  * wavefronts of at least flow_min_steps steps; 0: never; "intra_sb_lds": 1 = the form of that route that keeps the superblock's
- * pixels in LDS (4:2:0 / 4:0:0), 0 (default) = pixels handed over through the L2; "intra_sb_waves": 4 / 8 waves per superblock, 0 (default) = 4 in the
- * one-launch form where a level holds 128 superblocks or more on average and the frame copies no blocks, else 8;
+ * pixels in LDS (4:2:0 / 4:0:0), 0 (default) = pixels handed over through the L2; "intra_sb_waves": 1 / 4 / 8 waves per superblock, 0 (default) = in the
+ * one-launch form, for frames that copy no blocks, 1 where the superblocks hold "intra_sb_one_below" units or fewer on average (default 0: never — measured
+ * no faster), 4 where a level holds 128 superblocks or more on average, else 8;
  * "intra_sb_flow": 1 (default) = all levels of a frame's superblocks as ONE launch, a superblock waiting for the neighbours it reads, 0 = a launch per level,
  * "chunk_order": 1 = the prepared lists of a tile-sbrow are ordered for the device — by code path and reference, a few per cent on the
  * launches for a tenth more host time per frame; 0, the default, leaves decode order); -EINVAL for an unknown name. */
 DAV1D_HIP_API int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value);
+/* Reads back what a context counts or was set to: "intra_sb_fallbacks" = frames of this context whose one-launch intra pass had workgroups give
+ * up waiting for a neighbour and was finished by launches per level (0 in a sound run: the one-launch form rests on workgroups being dispatched
+ * in index order and staying resident; the fall-back needs neither); "intra_sb_waves", "intra_sb_one_below", "recon_fuse", "recon_pair_streams",
+ * "ref_twin".  -EINVAL for an unknown name. */
+DAV1D_HIP_API int dav1d_hip_get_option(Dav1dHipContext *c, const char *name, long *value);
 DAV1D_HIP_API const char *dav1d_hip_version(void);
 /* Measurement aid: device time (HIP events on the context's stream) of the kernel launches of the most recent
  * itx_add / cdef / lf / ipred / lr / fg *_batch call on this context -- excludes the task upload the batch calls do. */

@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-from ._lib import ITX_TASK, MC_TASK, COMP_TASK, LF_TASK, CDEF_TASK, LR_TASK, IPRED_TASK, FilmGrainData
+from dav1d_amd._lib import ITX_TASK, MC_TASK, COMP_TASK, LF_TASK, CDEF_TASK, LR_TASK, IPRED_TASK, FilmGrainData
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -23,7 +23,7 @@ _scans = None
 
 def scans():
     """Default scan order per tx size (AV1 spec tables; dumped once from the oracle build by
-    tests/util.py into dav1d_amd/data/scans.npz)."""
+    tests/util.py into tests/data/scans.npz)."""
     global _scans
     if _scans is None:
         z = np.load(os.path.join(HERE, "data", "scans.npz"))

@@ -44,7 +44,8 @@ sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
 import numpy as np
 import torch, torch.distributed as dist
 import util, test_frame
-from dav1d_amd import api, synth, dist as dd
+from dav1d_amd import api, dist as dd
+import synth_frames as synth
 
 rank, local, world = dd.env()
 dist.init_process_group("gloo")
@@ -125,7 +126,8 @@ sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
 import numpy as np
 import torch, torch.distributed as dist
 import util, test_frame, test_postchain
-from dav1d_amd import api, synth, dist as dd
+from dav1d_amd import api, dist as dd
+import synth_frames as synth
 
 rank, local, world = dd.env()
 dist.init_process_group("gloo")
@@ -211,7 +213,8 @@ sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
 import numpy as np
 import torch, torch.distributed as dist
 import util, test_frame
-from dav1d_amd import api, synth, dist as dd
+from dav1d_amd import api, dist as dd
+import synth_frames as synth
 
 rank, local, world = dd.env()
 dist.init_process_group("gloo")
@@ -280,7 +283,8 @@ sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
 import numpy as np
 import torch, torch.distributed as dist
 import util, test_frame, test_postchain
-from dav1d_amd import api, synth, dist as dd
+from dav1d_amd import api, dist as dd
+import synth_frames as synth
 
 rank, local, world = dd.env()
 dist.init_process_group("gloo")
@@ -390,7 +394,8 @@ def test_peer_opens_on_rccl_with_one_rank(tmp_path):
 
 def test_tile_column_split_covers_every_task_once():
     import numpy as np
-    from dav1d_amd import dist as dd, synth
+    from dav1d_amd import dist as dd
+    import synth_frames as synth
     frame = synth.make_frame(1024, 256, 8, seed=3)
     stride_px = [g[0] for g in synth.plane_geometry(1024, 256, 8, 1)]
     for n in (1, 2, 3, 4, 8):

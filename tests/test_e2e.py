@@ -77,11 +77,12 @@ def test_packed_and_dense_residuals_do_not_mix_in_a_frame(ctx):
 
 
 @pytest.mark.parametrize("intrabc_pct", [0, 40], ids=["no-copies", "intra-block-copies"])
-@pytest.mark.parametrize("waves", [0, 4, 8], ids=["default", "4-waves", "8-waves"])
+@pytest.mark.parametrize("waves", [0, 1, 4, 8], ids=["default", "1-wave", "4-waves", "8-waves"])
 def test_key_frame_with_either_workgroup_size_of_the_superblock_launch(ctx, waves, intrabc_pct):
     """context option intra_sb_waves: the one-launch superblock form (intra_sb.hip) runs with workgroups of four waves (two superblocks per CU
-    in flight: what a frame without intra block copies gets by default) or of eight (the default with copies); both must give the
-    reference's pixels on both kinds of key frame"""
+    in flight: what a frame without intra block copies gets by default), of eight (the default with copies), or with ONE wave per superblock
+    (its units one after the other, no barrier: the default where superblocks hold a handful of units); all must give the reference's pixels
+    on both kinds of key frame"""
     if lu.ref_lib() is None:
         pytest.skip("no reference build (oracle/_ref)")
     w, h = (384, 256) if ctx.backend == "emu" else (1920, 1080)
@@ -93,3 +94,26 @@ def test_key_frame_with_either_workgroup_size_of_the_superblock_launch(ctx, wave
         ctx.set_option("intra_sb_waves", 0)
     assert out["parity"].startswith("bit-exact"), out["parity"]
     assert out["wavefront_steps"] >= 2
+
+
+@pytest.mark.parametrize("fail_at", [0, 1, 4], ids=["first-superblock", "second", "fifth"])
+@pytest.mark.parametrize("waves", [4, 8], ids=["4-waves", "8-waves"])
+def test_key_frame_whose_one_launch_pass_gives_up_is_finished_by_the_launches_per_level(ctx, waves, fail_at):
+    """frame.hip: when workgroups of the one-launch superblock form give up waiting for a neighbour (context option intra_sb_fail_at makes the
+    workgroup of that index do what one does whose wait ran out; everything that reads its superblock follows, some of them mid-way), the frame
+    is not lost: the units the launch did reconstruct are marked, the launches per level run the others, and the pictures are the reference's.
+    The context counts such frames (dav1d_hip_get_option "intra_sb_fallbacks")."""
+    if lu.ref_lib() is None:
+        pytest.skip("no reference build (oracle/_ref)")
+    w, h = (384, 256) if ctx.backend == "emu" else (1920, 1080)
+    before = ctx.get_option("intra_sb_fallbacks")
+    ctx.set_option("intra_sb_waves", waves)
+    ctx.set_option("intra_sb_fail_at", fail_at)
+    try:
+        out = e2e.run(ctx, w, h, 10, frames=2, threads=3, tile_cols=2, tile_rows=2, seed=81, key_frame=True,
+                      check=lambda ho, planes, refs: lu.check_handoff_against_reference(ho, planes, refs, is_inter=False))
+    finally:
+        ctx.set_option("intra_sb_fail_at", -1)
+        ctx.set_option("intra_sb_waves", 0)
+    assert out["parity"].startswith("bit-exact"), out["parity"]
+    assert ctx.get_option("intra_sb_fallbacks") >= before + 2

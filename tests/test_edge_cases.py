@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 
 import util
-from dav1d_amd import api, synth
+from dav1d_amd import api
+import synth_frames as synth
 
 
 def test_empty_batches_are_noops(ctx):

@@ -1,5 +1,5 @@
 """Whole-frame parity of the itx+mc reconstruction path: the synthetic pass-2 task lists of
-dav1d_amd.synth run (a) through the HIP backend via the C ABI and (b) through the oracle's
+tests/synth_frames.py run (a) through the HIP backend via the C ABI and (b) through the oracle's
 DSP function pointers via oracle/replay.c; every output plane, the prep arena and the
 coefficient arena must be byte-identical."""
 import ctypes as C
@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 import util
-from dav1d_amd import api, synth
+from dav1d_amd import api
+import synth_frames as synth
 
 
 class RP(C.Structure):

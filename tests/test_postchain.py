@@ -1,5 +1,5 @@
 """The in-loop filter chain of a whole frame -- deblocking, CDEF, loop restoration, film grain -- on the task lists
-dav1d_amd.synth derives from the frame's transform grid: HIP backend through the C ABI vs the oracle's DSP entries
+tests/synth_frames.py derives from the frame's transform grid: HIP backend through the C ABI vs the oracle's DSP entries
 driven by oracle/replay.c the way the reference drivers drive them (src/lf_apply_tmpl.c, src/cdef_apply_tmpl.c,
 src/lr_apply_tmpl.c), stage by stage on identical inputs."""
 import ctypes as C
@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 import util
-from dav1d_amd import api, synth
+from dav1d_amd import api
+import synth_frames as synth
 from test_frame import RP, planes_struct
 
 

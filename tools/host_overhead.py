@@ -3,7 +3,8 @@ import sys, time, os
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np
-from dav1d_amd import api, synth
+from dav1d_amd import api
+import synth_frames as synth
 
 w, h, bpc = 7680, 4320, 10
 ctx = api.Context(0)

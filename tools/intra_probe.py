@@ -9,7 +9,8 @@ import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
-from dav1d_amd import api, synth  # noqa: E402
+from dav1d_amd import api
+import synth_frames as synth  # noqa: E402
 import test_postchain  # noqa: E402
 
 ap = argparse.ArgumentParser()

@@ -31,7 +31,8 @@ def main():
     a = ap.parse_args()
     w, h = (int(v) for v in a.size.split("x"))
     tc, tr = (int(v) for v in a.tiles.split("x"))
-    from dav1d_amd import api, synth
+    from dav1d_amd import api
+    import synth_frames as synth
     import e2e
     import lister_util as lu
     import test_postchain

@@ -12,6 +12,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 
 NAMES = ["recon_%dx%d" % (4 << k, 4 << k) for k in range(5)] + ["mc_%dx%d" % (4 << (b // 3), 4 << (b % 3)) for b in range(15)] + ["comp"] + ["itx_%d" % b for b in range(19)]
 DEFAULTS = {"recon_fuse": 15, "recon_pair_streams": 2, "recon_lanes": 1, "recon_pipeline": 16384, "recon_coop_below": 4096}
@@ -33,7 +34,8 @@ def main():
     ap.add_argument("--lib", default=None, help="a variant build (tools/build_variant.py) instead of dav1d_amd/libdav1d_hip.so")
     a = ap.parse_args()
     import torch
-    from dav1d_amd import api, synth
+    from dav1d_amd import api
+    import synth_frames as synth
     stream = torch.cuda.current_stream()
     ctx = api.Context(0, stream=stream.cuda_stream, lib_path=a.lib)
     w, h, bpc = a.width, a.height, a.bpc

@@ -11,6 +11,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 
 
 def main():
@@ -25,7 +26,8 @@ def main():
     ap.add_argument("--no-kernels", action="store_true")
     a = ap.parse_args()
     import torch
-    from dav1d_amd import api, synth
+    from dav1d_amd import api
+    import synth_frames as synth
     stream = torch.cuda.current_stream()
     ctx = api.Context(0, stream=stream.cuda_stream)
     if a.fuse >= 0:
