@@ -62,7 +62,7 @@ assert ITX_TASK.itemsize == 16 and MC_TASK.itemsize == 24 and COMP_TASK.itemsize
 SYMBOLS = [
     "dav1d_hip_open", "dav1d_hip_set_option", "dav1d_hip_get_option", "dav1d_hip_close", "dav1d_hip_sync", "dav1d_hip_stream", "dav1d_hip_recon_list_create", "dav1d_hip_recon_list_run", "dav1d_hip_recon_list_run_twin", "dav1d_hip_recon_list_run_tiled", "dav1d_hip_recon_list_run_tiled_timed", "dav1d_hip_picture_untile", "dav1d_hip_recon_list_destroy", "dav1d_hip_recon_list_run_timed", "dav1d_hip_fg_prepare", "dav1d_hip_fg_apply_prepared", "dav1d_hip_fg_grain_destroy", "dav1d_hip_intra_list_create", "dav1d_hip_intra_list_run_batch", "dav1d_hip_intra_list_run_all", "dav1d_hip_intra_list_destroy", "dav1d_hip_intra_flow_create", "dav1d_hip_intra_flow_run", "dav1d_hip_intra_flow_destroy", "dav1d_hip_intra_flow_units", "dav1d_hip_intra_flow_status", "dav1d_hip_intra_sb_create", "dav1d_hip_intra_sb_run", "dav1d_hip_intra_sb_status", "dav1d_hip_intra_sb_destroy", "dav1d_hip_intra_sb_levels", "dav1d_hip_intra_sb_superblocks", "dav1d_hip_frame_set_tiling", "dav1d_hip_frame_submit_intra_step", "dav1d_hip_frame_submit_intra_sorted", "dav1d_hip_frame_submit_step_copy", "dav1d_hip_frame_flush", "dav1d_hip_frame_set_refs", "dav1d_hip_frame_set_super_res", "dav1d_hip_frame_end_async", "dav1d_hip_frame_progress", "dav1d_hip_frame_wait", "dav1d_hip_frame_set_progress_callback", "dav1d_hip_host_picture_alloc", "dav1d_hip_host_picture_release", "dav1d_hip_host_picture_fetch", "dav1d_hip_host_picture_wait", "dav1d_hip_lf_rects", "dav1d_hip_lf_rects_sb", "dav1d_hip_lf_rects_free", "dav1d_hip_lf_masks_build", "dav1d_hip_refmvs_splat_batch", "dav1d_hip_refmvs_save_tmvs", "dav1d_hip_frame_post_bands", "dav1d_hip_graph_begin", "dav1d_hip_graph_end", "dav1d_hip_graph_launch", "dav1d_hip_graph_destroy", "dav1d_hip_graph_nodes", "dav1d_hip_version", "dav1d_hip_last_kernel_ms", "dav1d_hip_last_hip_error",
     "dav1d_hip_malloc", "dav1d_hip_free", "dav1d_hip_memset", "dav1d_hip_upload", "dav1d_hip_download",
-    "dav1d_hip_live_objects", "dav1d_hip_device_count", "dav1d_hip_context_device", "dav1d_hip_context_use", "dav1d_hip_current_device", "dav1d_hip_set_device", "dav1d_hip_picture_device", "dav1d_hip_picture_copy_peer", "dav1d_hip_enable_peer_access", "dav1d_hip_picture_alloc", "dav1d_hip_picture_free", "dav1d_hip_picture_twin_alloc", "dav1d_hip_picture_retile", "dav1d_hip_picture_retile_overlapped", "dav1d_hip_peer_unique_id", "dav1d_hip_peer_open", "dav1d_hip_peer_close", "dav1d_hip_peer_rank", "dav1d_hip_peer_world", "dav1d_hip_peer_broadcast_picture", "dav1d_hip_peer_allgather_columns", "dav1d_hip_peer_exchange_halo", "dav1d_hip_peer_allgather_columns_async", "dav1d_hip_peer_wait", "dav1d_hip_plane_upload", "dav1d_hip_plane_download",
+    "dav1d_hip_live_objects", "dav1d_hip_device_count", "dav1d_hip_context_device", "dav1d_hip_context_use", "dav1d_hip_current_device", "dav1d_hip_set_device", "dav1d_hip_picture_device", "dav1d_hip_picture_copy_peer", "dav1d_hip_picture_copy_peer_rows", "dav1d_hip_enable_peer_access", "dav1d_hip_picture_alloc", "dav1d_hip_picture_free", "dav1d_hip_picture_twin_alloc", "dav1d_hip_picture_retile", "dav1d_hip_picture_retile_overlapped", "dav1d_hip_peer_unique_id", "dav1d_hip_peer_open", "dav1d_hip_peer_close", "dav1d_hip_peer_rank", "dav1d_hip_peer_world", "dav1d_hip_peer_broadcast_picture", "dav1d_hip_peer_allgather_columns", "dav1d_hip_peer_exchange_halo", "dav1d_hip_peer_allgather_columns_async", "dav1d_hip_peer_wait", "dav1d_hip_plane_upload", "dav1d_hip_plane_download",
     "dav1d_hip_itx_add_batch", "dav1d_hip_itx_list_create", "dav1d_hip_itx_list_destroy", "dav1d_hip_itx_list_run",
     "dav1d_hip_mc_batch", "dav1d_hip_mc_list_create", "dav1d_hip_mc_list_destroy", "dav1d_hip_mc_list_run",
     "dav1d_hip_comp_batch", "dav1d_hip_comp_list_create", "dav1d_hip_comp_list_destroy", "dav1d_hip_comp_list_run",
@@ -276,6 +276,7 @@ def load(path=None):
         "dav1d_hip_set_device": (i, [i]),
         "dav1d_hip_picture_device": (i, [P(Picture)]),
         "dav1d_hip_picture_copy_peer": (i, [vp, P(Picture), vp, P(Picture)]),
+        "dav1d_hip_picture_copy_peer_rows": (i, [vp, P(Picture), vp, P(Picture), C.c_int, C.c_int]),
         "dav1d_hip_enable_peer_access": (i, [vp, vp]),
         "dav1d_hip_dsp_init_8bpc": (i, [vp]),
         "dav1d_hip_dsp_init_16bpc": (i, [vp, i]),

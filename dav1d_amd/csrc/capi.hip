@@ -600,6 +600,32 @@ int dav1d_hip_picture_copy_peer(Dav1dHipContext *dst_c, Dav1dHipPicture *dst, Da
     return 0;
 }
 
+// Luma rows [y0, y1) of src's RASTER planes (the chroma rows under them) to dst on another device, on dst_c's stream.  The caller says the rows are
+// final on the source device (dav1d_hip_frame_set_progress_callback reported them): nothing of src_c's stream is waited for, so the bands of a
+// picture can cross while the frame that makes it is still ending (dav1d_glue.c).  y0 a multiple of 8; dst's twin is stale afterwards.
+int dav1d_hip_picture_copy_peer_rows(Dav1dHipContext *dst_c, Dav1dHipPicture *dst, Dav1dHipContext *src_c, const Dav1dHipPicture *src, int y0, int y1) {
+    if (!dst_c || !dst || !src_c || !src || !dst->p[0].data || !src->p[0].data) return -EINVAL;
+    if (dst->bpc != src->bpc || dst->layout != src->layout || src->twin_ok == DAV1D_HIP_TWIN_ONLY) return -EINVAL;
+    for (int pl = 0; pl < 3; pl++)
+        if (dst->p[pl].w != src->p[pl].w || dst->p[pl].h != src->p[pl].h || dst->p[pl].stride != src->p[pl].stride || !dst->p[pl].data != !src->p[pl].data) return -EINVAL;
+    if (y0 < 0 || (y0 & 7) || y1 < y0 || y1 > src->p[0].h) return -EINVAL;
+    if (y1 == y0) return 0;
+    if (hipSetDevice(dst_c->device) != hipSuccess) return -ENODEV;
+    const bool padded = src->alloc != nullptr && dst->alloc != nullptr;
+    const bool last = y1 == src->p[0].h;           // (the padding rows below the picture travel with its last band, as dav1d_hip_picture_copy_peer sends them)
+    const int ss_ver = src->layout == DAV1D_HIP_LAYOUT_I420;
+    for (int pl = 0; pl < 3; pl++) {
+        if (!src->p[pl].data) continue;
+        const int sv = pl ? ss_ver : 0;
+        const int r0 = y0 >> sv, r1 = last ? picture_plane_rows(src, pl, padded) : (y1 + sv) >> sv;
+        if (r1 <= r0) continue;
+        const size_t off = (size_t) src->p[pl].stride * (size_t) r0, bytes = (size_t) src->p[pl].stride * (size_t) (r1 - r0);
+        HIP_TRY(hipMemcpyPeerAsync((char *) dst->p[pl].data + off, dst_c->device, (const char *) src->p[pl].data + off, src_c->device, bytes, dst_c->stream));
+    }
+    dst->twin_ok = 0;
+    return 0;
+}
+
 static void plane_extent(const Dav1dHipPicture *pic, int plane, int padded, size_t *row_bytes, int *rows) {
     const int bps = pic->bpc > 8 ? 2 : 1;
     if (padded) {

@@ -73,6 +73,8 @@ typedef struct Hip {
     int (*current_device)(void);
     int (*set_device)(int);
     int (*picture_copy_peer)(Dav1dHipContext *, Dav1dHipPicture *, Dav1dHipContext *, const Dav1dHipPicture *);
+    int (*picture_copy_peer_rows)(Dav1dHipContext *, Dav1dHipPicture *, Dav1dHipContext *, const Dav1dHipPicture *, int, int);
+    int (*picture_retile)(Dav1dHipContext *, Dav1dHipPicture *);
 } Hip;
 
 /* per frame context */
@@ -98,10 +100,11 @@ typedef struct FcState {
 /* a device: the context frames begin, end and are fetched on, one for uploads and one for output work (streams of their own), three stage threads */
 typedef struct Dev {
     Dav1dHipContext *ctx, *ctx_up, *ctx_out;
+    Dav1dHipContext *ctx_peer;   /* (several devices) the stream the bands of other devices' pictures arrive on */
     pthread_t thread[3];
     int have_threads;
     void *targ[3][3];
-    atomic_int n_frames, n_peer_copies;
+    atomic_int n_frames, n_peer_copies, n_band_copies;
 } Dev;
 
 /* a frame ends badly because a frame it predicts from did: dav1d's error (DAV1D_ERR(EINVAL), as check_tile makes it), not the backend's */
@@ -231,6 +234,7 @@ static int glue_alloc_picture(Dav1dPicture *const p, void *const cookie) {
     hp->ref = hp->hp.dev;
     hp->ref_dev = hp->dev;
     memset(hp->mirror_ok, 0, sizeof(hp->mirror_ok));
+    memset(hp->mirror_rows, 0, sizeof(hp->mirror_rows));
     atomic_store(&hp->failed, 0);
     atomic_store(&hp->final, 0);
     return 0;
@@ -250,6 +254,7 @@ static void glue_release_picture(Dav1dPicture *const p, void *const cookie) {
     hp->ref_dev = hp->dev;
     hp->ref.twin_ok = hp->hp.dev.twin_ok = 0;
     memset(hp->mirror_ok, 0, sizeof(hp->mirror_ok));          /* (the mirrors' storage stays with the picture while it is pooled) */
+    memset(hp->mirror_rows, 0, sizeof(hp->mirror_rows));
     pthread_mutex_lock(&g->pic_mtx);
     if (!g->closing && g->n_free_pics < 32) {
         g->free_pics[g->n_free_pics++] = hp;
@@ -436,12 +441,48 @@ static int refs_final(const Dav1dFrameContext *const f) {
     return all;
 }
 
+static int mirror_ready(Dav1dHipGlue *const g, Dav1dHipPicture *const m, const int d, const Dav1dHipPicture *const r) {
+    if (m->alloc && (m->p[0].w != r->p[0].w || m->p[0].h != r->p[0].h || m->layout != r->layout || m->bpc != r->bpc)) g->hip.picture_free(g->dev[d].ctx, m);
+    return m->alloc ? 0 : g->hip.picture_alloc(g->dev[d].ctx, m, r->p[0].w, r->p[0].h, r->layout, r->bpc);
+}
+
+/* Rows [.., rows) of `pic` — the picture frame f leaves, on device `from` — are final: the bands not yet across go to the devices on which a queued
+ * frame predicts from the picture (dav1d starts frame n + 1 on the rows of frame n that progress[1] has published, src/thread_task.c:416-433;
+ * across devices what can start early is the transfer).  Runs on `from`'s stage-2 thread inside dav1d_hip_frame_end, which goes on issuing work
+ * for its own device afterwards: the thread's device is put back.  The consumer's side (resident_ref) only looks at mirror_rows once the
+ * picture is final, i.e. after the last call of this. */
+static void push_rows(Dav1dHipGlue *const g, Dav1dFrameContext *const f, const int rows, const Dav1dHipPicture *const pic) {
+    Dav1dHipGluePicture *const out = f->sr_cur.p.allocator_data;
+    const int from = state_of(f)->dev;
+    if (!pic || pic->twin_ok == DAV1D_HIP_TWIN_ONLY) return;
+    uint8_t want[DAV1D_HIP_GLUE_MAX_DEVICES] = { 0 };
+    int any = 0;
+    pthread_mutex_lock(&g->q_mtx);
+    for (unsigned i = 0; i < g->n_fc; i++) {
+        const FcState *const c = &g->fcs[i];
+        if ((c->q_state != 1 && c->q_state != 2) || c->dev == from || !IS_INTER_OR_SWITCH(c->q_f->frame_hdr)) continue;
+        for (int k = 0; k < 7; k++) if (c->q_f->refp[k].p.allocator_data == out) { want[c->dev] = 1; any = 1; }
+    }
+    pthread_mutex_unlock(&g->q_mtx);
+    if (!any) return;
+    const int h = pic->p[0].h, upto = rows >= h ? h : rows & ~7;
+    for (int d = 0; d < g->n_dev; d++) {
+        if (!want[d] || out->mirror_rows[d] < 0 || out->mirror_rows[d] >= upto) continue;
+        (void) g->hip.use(g->dev[d].ctx);
+        int rc = mirror_ready(g, &out->mirror[d], d, pic);
+        if (!rc) rc = g->hip.picture_copy_peer_rows(g->dev[d].ctx_peer, &out->mirror[d], g->dev[from].ctx, pic, out->mirror_rows[d], upto);
+        out->mirror_rows[d] = rc ? -1 : upto;
+        if (!rc) atomic_fetch_add(&g->dev[d].n_band_copies, 1);
+    }
+    (void) g->hip.use(g->dev[from].ctx);
+}
+
 /* progress: rows of the frame's picture have become final on the device */
 static void rows_final(void *const cookie, const int rows, const Dav1dHipPicture *const pic) {
-    (void) pic;
     Dav1dFrameContext *const f = cookie;
     atomic_fetch_add(&g_glue->n_row_publications, 1);
     dav1d_hip_rows_done(f, (unsigned) rows);
+    if (g_glue->n_dev > 1) push_rows(g_glue, f, rows, pic);
 }
 
 /* where frame-ending device `d` reads the final pixels of picture `rp`: the picture itself when it lives there, else its mirror on d, filled
@@ -452,9 +493,23 @@ static int resident_ref(Dav1dHipGlue *const g, Dav1dHipGluePicture *const rp, co
     Dav1dHipPicture *const m = &rp->mirror[d];
     if (!rp->mirror_ok[d]) {
         const Dav1dHipPicture *const r = &rp->ref;
-        if (m->alloc && (m->p[0].w != r->p[0].w || m->p[0].h != r->p[0].h || m->layout != r->layout || m->bpc != r->bpc)) hip->picture_free(g->dev[d].ctx, m);
-        int rc = m->alloc ? 0 : hip->picture_alloc(g->dev[d].ctx, m, r->p[0].w, r->p[0].h, r->layout, r->bpc);
-        if (!rc) rc = hip->picture_copy_peer(g->dev[d].ctx, m, g->dev[rp->ref_dev].ctx, r);
+        int rc = mirror_ready(g, m, d, r);
+        const int h = r->p[0].h;
+        if (!rc && rp->mirror_rows[d] > 0 && r->twin_ok != DAV1D_HIP_TWIN_ONLY && m->p[0].data) {
+            /* bands crossed while the picture's frame was ending (push_rows): what is missing follows on the same stream, the bands are
+             * waited for, and the mirror's tiled twin is made HERE from its raster planes (a 15 us launch on this device instead of the twin's
+             * 199 MB over the link) */
+            if (rp->mirror_rows[d] < h) {
+                rc = hip->picture_copy_peer_rows(g->dev[d].ctx_peer, m, g->dev[rp->ref_dev].ctx, r, rp->mirror_rows[d], h);
+                if (!rc) atomic_fetch_add(&g->dev[d].n_band_copies, 1);
+            }
+            if (!rc) rc = hip->sync(g->dev[d].ctx_peer);
+            (void) hip->use(g->dev[d].ctx);
+            if (!rc && r->twin_ok && m->twin[0]) rc = hip->picture_retile(g->dev[d].ctx, m);
+            if (!rc) rp->mirror_rows[d] = h;
+        } else if (!rc) {
+            rc = hip->picture_copy_peer(g->dev[d].ctx, m, g->dev[rp->ref_dev].ctx, r);
+        }
         if (rc) return rc;
         rp->mirror_ok[d] = 1;
         atomic_fetch_add(&g->dev[d].n_peer_copies, 1);
@@ -621,6 +676,7 @@ int dav1d_hip_glue_device_stats(const Dav1dHipGlue *const g, const int d, int *c
     if (peer_copies) *peer_copies = atomic_load(&g->dev[d].n_peer_copies);
     return 0;
 }
+int dav1d_hip_glue_band_copies(const Dav1dHipGlue *const g, const int d) { return g && d >= 0 && d < g->n_dev ? atomic_load(&g->dev[d].n_band_copies) : 0; }
 int dav1d_hip_glue_live_objects(const Dav1dHipGlue *const g, long long out[4]) { return g && g->hip.live_objects ? g->hip.live_objects(out) : DAV1D_ERR(EINVAL); }
 
 /* ------------------------------------------------------------------------------------------------ life cycle */
@@ -650,13 +706,14 @@ int dav1d_hip_glue_create(Dav1dHipGlue **const out, const Dav1dHipGlueOptions *c
     SYM(plane_download, "dav1d_hip_plane_download"); SYM(frame_set_progress_callback, "dav1d_hip_frame_set_progress_callback");
     SYM(live_objects, "dav1d_hip_live_objects"); SYM(device_count, "dav1d_hip_device_count"); SYM(use, "dav1d_hip_context_use");
     SYM(enable_peer_access, "dav1d_hip_enable_peer_access"); SYM(current_device, "dav1d_hip_current_device"); SYM(set_device, "dav1d_hip_set_device");
-    SYM(picture_copy_peer, "dav1d_hip_picture_copy_peer");
+    SYM(picture_copy_peer, "dav1d_hip_picture_copy_peer"); SYM(picture_copy_peer_rows, "dav1d_hip_picture_copy_peer_rows"); SYM(picture_retile, "dav1d_hip_picture_retile");
     g->n_dev = o->n_devices > 1 ? o->n_devices : 1;
     if (g->n_dev > DAV1D_HIP_GLUE_MAX_DEVICES || o->device < 0 || o->device + g->n_dev > g->hip.device_count()) { g->n_dev = 0; goto fail; }
     const int thread_dev = g->hip.current_device();          /* (dav1d_hip_open selects the device it opens on) */
     for (int d = 0; d < g->n_dev; d++) {
         Dev *const dv = &g->dev[d];
-        if (g->hip.open(&dv->ctx, o->device + d, NULL) || g->hip.open(&dv->ctx_up, o->device + d, NULL) || g->hip.open(&dv->ctx_out, o->device + d, NULL)) {
+        if (g->hip.open(&dv->ctx, o->device + d, NULL) || g->hip.open(&dv->ctx_up, o->device + d, NULL) || g->hip.open(&dv->ctx_out, o->device + d, NULL) ||
+            (g->n_dev > 1 && g->hip.open(&dv->ctx_peer, o->device + d, NULL))) {
             return_thread(g, thread_dev);
             goto fail;
         }
@@ -748,6 +805,7 @@ void dav1d_hip_glue_destroy(Dav1dHipGlue *const g) {
         free(g->fcs);
     }
     for (int d = 0; d < DAV1D_HIP_GLUE_MAX_DEVICES; d++) {
+        if (g->dev[d].ctx_peer) g->hip.close(g->dev[d].ctx_peer);
         if (g->dev[d].ctx_out) g->hip.close(g->dev[d].ctx_out);
         if (g->dev[d].ctx_up) g->hip.close(g->dev[d].ctx_up);
         if (g->dev[d].ctx) g->hip.close(g->dev[d].ctx);

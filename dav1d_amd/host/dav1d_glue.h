@@ -47,6 +47,8 @@ typedef struct Dav1dHipGluePicture {
     int dev, ref_dev;            /* index (from Dav1dHipGlueOptions.device) of the device hp was made on / the one `ref` lives on */
     Dav1dHipPicture mirror[DAV1D_HIP_GLUE_MAX_DEVICES];   /* `ref` once more on the other devices that end frames predicting from it */
     uint8_t mirror_ok[DAV1D_HIP_GLUE_MAX_DEVICES];
+    int mirror_rows[DAV1D_HIP_GLUE_MAX_DEVICES];          /* luma rows of `ref` that have crossed to mirror[d] band by band while its frame was still ending
+                                                             (rows_final; the rest follows in resident_ref); -1: a band failed, the whole picture goes */
 } Dav1dHipGluePicture;
 
 typedef struct Dav1dHipGlueOptions {
@@ -58,7 +60,9 @@ typedef struct Dav1dHipGlueOptions {
                                     frame's lists, cf is left zero as the reference's inverse transforms leave it; 0: the dense arena is uploaded */
     int free_listing;            /* 1: a frame is listed without waiting for the rows of its references (the pixels are read when the frame ends,
                                     and frames end in order): decode_b's lowest_pixel notes are dropped; 0: dav1d's own rule */
-    int row_progress;            /* 1: rows reach sr_cur.progress[1] band by band while the frame's last stage runs */
+    int row_progress;            /* 1: rows reach sr_cur.progress[1] band by band while the frame's last stage runs — and, with several devices, cross
+                                    to the devices whose queued frames predict from the picture as they are published (dav1d_hip_picture_copy_peer_rows):
+                                    when the frame has ended, its consumers on other devices find the picture (nearly) there */
     int keep_cf;                 /* (pack = 0) 1: f->frame_thread.cf is left as it is after the upload — a caller that lends the frame context
                                     arrays of its own; 0: zeroed, as the reference's inverse transforms leave it (src/itx_tmpl.c:60,108) */
     /* observers, all optional (a test harness keeps its books through them; a plain dav1d leaves them NULL) */
@@ -99,6 +103,8 @@ int dav1d_hip_glue_row_publications(const Dav1dHipGlue *g);
 int dav1d_hip_glue_devices(const Dav1dHipGlue *g);
 /* device d (0 .. devices - 1): frames that ended on it, reference pictures copied TO it from another device */
 int dav1d_hip_glue_device_stats(const Dav1dHipGlue *g, int d, int *frames_ended, int *peer_copies);
+/* bands of other devices' pictures that crossed to device d while their frames were still ending, or as the remainder behind such bands (option row_progress) */
+int dav1d_hip_glue_band_copies(const Dav1dHipGlue *g, int d);
 /* objects of libdav1d_hip alive (dav1d_hip_live_objects): contexts, frames, listers, host pictures */
 int dav1d_hip_glue_live_objects(const Dav1dHipGlue *g, long long out[4]);
 #endif

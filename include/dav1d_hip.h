@@ -164,6 +164,12 @@ DAV1D_HIP_API int dav1d_hip_picture_device(const Dav1dHipPicture *pic);
  * that cannot be peers still copies, through host memory), < 0 on bad arguments.  The caller's current device is left as it was. */
 DAV1D_HIP_API int dav1d_hip_enable_peer_access(Dav1dHipContext *a, Dav1dHipContext *b);
 DAV1D_HIP_API int dav1d_hip_picture_copy_peer(Dav1dHipContext *dst_c, Dav1dHipPicture *dst, Dav1dHipContext *src_c, const Dav1dHipPicture *src);
+/* The same for luma rows [y0, y1) of the RASTER planes only (and the chroma rows under them; y0 a multiple of 8), on dst_c's stream, WITHOUT waiting
+ * for src_c's stream: the caller says these rows are final on the source device — dav1d_hip_frame_set_progress_callback has reported them.  This is
+ * how a picture crosses band by band while the frame that makes it is still ending, the way dav1d's frame threads start on the rows progress[1]
+ * has published (reference src/thread_task.c:416-433, 888-896).  dst's tiled twin is stale afterwards: dav1d_hip_picture_retile on dst_c once the
+ * last band is across.  -EINVAL for a source that lives in its twin only.  Leaves the thread on dst_c's device. */
+DAV1D_HIP_API int dav1d_hip_picture_copy_peer_rows(Dav1dHipContext *dst_c, Dav1dHipPicture *dst, Dav1dHipContext *src_c, const Dav1dHipPicture *src, int y0, int y1);
 DAV1D_HIP_API int dav1d_hip_picture_alloc(Dav1dHipContext *c, Dav1dHipPicture *pic,
                                           int w, int h, int layout, int bpc);
 DAV1D_HIP_API int dav1d_hip_picture_free(Dav1dHipContext *c, Dav1dHipPicture *pic);

@@ -880,6 +880,7 @@ int dav1d_hooked_device_stats(void *const handle, const int d, int out[2]) {
     (void) dav1d_hip_glue_device_stats(((Hooked *) handle)->glue, d, &out[0], &out[1]);
     return dav1d_hip_glue_devices(((Hooked *) handle)->glue);
 }
+int dav1d_hooked_band_copies(void *const handle, const int d) { return handle && ((Hooked *) handle)->glue ? dav1d_hip_glue_band_copies(((Hooked *) handle)->glue, d) : 0; }
 int dav1d_hooked_row_publications(void *const handle) { return handle ? dav1d_hip_glue_row_publications(((Hooked *) handle)->glue) : 0; }
 int dav1d_hooked_n_fc(void *const handle) { return handle ? (int) ((Hooked *) handle)->n_fc : 0; }
 

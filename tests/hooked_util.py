@@ -40,6 +40,8 @@ def lib():
     l.dav1d_hooked_n_fc.argtypes = [C.c_void_p]
     l.dav1d_hooked_row_publications.argtypes = [C.c_void_p]
     l.dav1d_hooked_device_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int * 2)]
+    if hasattr(l, "dav1d_hooked_band_copies"):
+        l.dav1d_hooked_band_copies.argtypes = [C.c_void_p, C.c_int]
     l.dav1d_hooked_tail_seconds.restype = C.c_double
     l.dav1d_hooked_tail_seconds.argtypes = [C.c_void_p, C.c_int]
     l.dav1d_hooked_output_tail_seconds.restype = C.c_double
@@ -119,6 +121,7 @@ def run(p, hip_lib_path, store=None, inject=0):
             for d in range(max(1, l.dav1d_hooked_device_stats(h, 0, C.byref(ds)))):
                 l.dav1d_hooked_device_stats(h, d, C.byref(ds))
                 run.last_device_stats.append((int(ds[0]), int(ds[1])))
+            run.last_band_copies = [int(l.dav1d_hooked_band_copies(h, d)) for d in range(len(run.last_device_stats))] if hasattr(l, "dav1d_hooked_band_copies") else []
         st = (C.c_double * 16)()
         l.dav1d_hooked_stats(h, st)
         run.last_stats = dict(zip(("picture_alloc", "after_init", "listing", "filter_listing", "gpu_thread_idle", "uploads", "frame_end", "fetch", "picture_release"),

@@ -72,3 +72,26 @@ def test_chain_over_two_devices_in_one_process_equals_dav1d(ctx, name, w, h, bpc
     assert len(st) == 2 and st[0][0] == (n_frames + 1) // 2 and st[1][0] == n_frames // 2, st       # frames in turn
     # every inter frame predicts from the three frames before it: at least one of them ended on the other device
     assert st[0][1] + st[1][1] >= n_frames - 1, st
+
+
+def test_rows_cross_to_the_other_device_while_their_frame_is_still_ending(ctx):
+    """Dav1dHipGlueOptions.row_progress with two devices: the rows a frame publishes while its last stage runs (dav1d_hip_frame_set_progress_callback
+    -> progress[1], reference src/thread_task.c:888-896) also cross, band by band, to the device on which a queued frame predicts from the picture
+    (dav1d_hip_picture_copy_peer_rows) — dav1d's frame threads start on published rows (src/thread_task.c:416-433); across devices what starts
+    early is the transfer.  The consumer finds the picture nearly there, sends the remainder and makes the mirror's tiled twin itself.  A chain
+    with restoration (the banded last stage), every picture equal to dav1d's, bands counted."""
+    if n_devices_here(ctx) < 2:
+        pytest.skip("one device here")
+    w, h, bpc = 320, 1100, 10                 # (tall enough for the last stage to run in bands)
+    n_frames = 4 if ctx.backend == "emu" else 9
+    kw = dict(tiles=(1, 1))
+    _, _, want = hk.run(hk.params(w, h, bpc, n_frames, mode=0, **kw), hip_lib_path(ctx))
+    _, _, got = hk.run(hk.params(w, h, bpc, n_frames, mode=1, n_devices=2, row_progress=1, **kw), hip_lib_path(ctx))
+    for k in range(n_frames):
+        for pl in range(len(want[k])):
+            bad = np.argwhere(want[k][pl] != got[k][pl])
+            assert not len(bad), "frame %d plane %d differs at %s (%d pixels)" % (k, pl, bad[0], len(bad))
+    st, bands = hk.run.last_device_stats, hk.run.last_band_copies
+    assert len(st) == 2 and st[0][1] + st[1][1] >= n_frames - 1, st
+    assert hk.run.last_row_publications > n_frames, hk.run.last_row_publications       # rows came band by band
+    assert sum(bands) > 0, (bands, st)            # ... and crossed that way at least once
