@@ -507,6 +507,11 @@ static int resident_ref(Dav1dHipGlue *const g, Dav1dHipGluePicture *const rp, co
             (void) hip->use(g->dev[d].ctx);
             if (!rc && r->twin_ok && m->twin[0]) rc = hip->picture_retile(g->dev[d].ctx, m);
             if (!rc) rp->mirror_rows[d] = h;
+        } else if (!rc && r->twin_ok == 1 && m->twin[0] && m->p[0].data) {
+            /* raster planes and twin both valid: the raster planes cross (the picture is final: nothing of the source's stream to wait for), the
+             * twin is made here — half the bytes over the link */
+            rc = hip->picture_copy_peer_rows(g->dev[d].ctx, m, g->dev[rp->ref_dev].ctx, r, 0, h);
+            if (!rc) rc = hip->picture_retile(g->dev[d].ctx, m);
         } else if (!rc) {
             rc = hip->picture_copy_peer(g->dev[d].ctx, m, g->dev[rp->ref_dev].ctx, r);
         }
