@@ -31,6 +31,9 @@
 #ifndef SB_MIN_BLOCKS
 #define SB_MIN_BLOCKS 2
 #endif
+#ifndef SB_MIN_WAVES_8
+#define SB_MIN_WAVES_8 2      // (waves per SIMD asked of the register allocator for the eight- and one-wave forms; see SB_MIN_BLOCKS)
+#endif
 // the next unit's coefficients touched while the current one is worked on: 1 = at the start of the current unit (ahead of its own edge
 // loads), 2 = behind its prediction, 0 = not at all
 #ifndef SB_PREFETCH
@@ -55,7 +58,7 @@ template <int NW> __device__ __forceinline__ uint32_t sb_next(const IntraUnit &u
 // records [r.first, r.first + r.n): the superblock's header, then its units sorted by (step, predictions first); grp = the unit's
 // group, groups are separated by workgroup barriers.
 template <typename pixel, typename coef, int SB_WAVES>
-__global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : 2) void intra_sb_kernel(const DevPlanes dst, const IntraUnit *__restrict__ units,
+__global__ __launch_bounds__(SB_WAVES * 64, SB_WAVES == 4 ? SB_MIN_BLOCKS : SB_MIN_WAVES_8) void intra_sb_kernel(const DevPlanes dst, const IntraUnit *__restrict__ units,
                                                                      const SbRegion *__restrict__ regions, uint8_t *aux,
                                                                      const uint8_t *__restrict__ mask /* inter-intra masks (may be nullptr without such units) */,
                                                                      coef *__restrict__ cf, const int layout, const int bitdepth_max,
