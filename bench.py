@@ -38,8 +38,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60, help="timed steps (default 60: 15 ms of device time at 8K; with two frames in flight the first and the last step run alone, and a run of 20 shows it — same box 0.246 - 0.254 ms per step at 20, 0.234 at 60, profiles/r06/streams.txt)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--width", type=int, default=7680)
     ap.add_argument("--height", type=int, default=4320)
     ap.add_argument("--bpc", type=int, default=10)
