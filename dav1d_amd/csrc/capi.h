@@ -63,6 +63,8 @@ struct Dav1dHipContext {
     uint32_t *band_cnt = nullptr, *band_flags = nullptr;   // frame_lr_banded (frame.hip): 64 counters + 64 targets on the device, 64 words of pinned host memory
     uint32_t band_seq = 0;
     int chunk_hints;                           // option chunk_hints (default 1): the lister's records are prepared from what the walk wrote into them (chunk.hip chunk_build_hinted); 0 = through the general preparation
+    int prep_async;                            // option prep_async: the chunk preparation of a tile-sbrow on the library's own threads instead of the submitting one — 1 (default)
+                                               // for frames of at most 8 tiles (few listing threads: the walk of a tile's next row runs next to the preparation of the last), 2 always, 0 never
     int chunk_order;                           // option chunk_order: the prepared lists of a tile-sbrow ordered for the device (1) or left in decode order (0)
     size_t arena_min;                          // size of a frame's chunk arena before anything is known (option chunk_arena_min; tests make it tiny)
     size_t uarena_hint = 0;                    // bytes of intra units the largest frame so far carried (sizes a frame's pinned unit arena)

@@ -79,6 +79,7 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     c->intra_sb_waves = (int) env_int("DAV1D_HIP_INTRA_SB_WAVES", 0);
     c->intra_sb_one_below = (int) env_int("DAV1D_HIP_INTRA_SB_ONE_BELOW", 0);
     c->intra_sb_fallbacks = 0;
+    c->prep_async = (int) env_int("DAV1D_HIP_PREP_ASYNC", 1);
     c->intra_sb_lds = (int) env_int("DAV1D_HIP_INTRA_SB_LDS", 0);
     c->intra_sb_flow = (int) env_int("DAV1D_HIP_INTRA_SB_FLOW", 1);
     for (int i = 0; i < Dav1dHipContext::N_SIDE; i++) {
@@ -221,6 +222,7 @@ int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value) {
     else if (!strcmp(name, "intra_sb_flow")) c->intra_sb_flow = value != 0;
     else if (!strcmp(name, "intra_sb_fine")) dav1d_hip_sbw_set_fine(value != 0);
     else if (!strcmp(name, "intra_sb_fail_at")) dav1d_hip_sbw_set_fail_at((int) value);
+    else if (!strcmp(name, "prep_async")) c->prep_async = value < 0 ? 0 : value > 2 ? 2 : (int) value;
     else if (!strcmp(name, "chunk_order")) c->chunk_order = value != 0;
     else if (!strcmp(name, "chunk_hints")) c->chunk_hints = value != 0;
     else if (!strcmp(name, "chunk_arena_min")) { if (value < 4096) return -EINVAL; c->arena_min = (size_t) 1 << 12; while (c->arena_min < (size_t) value) c->arena_min <<= 1; c->arena_hint = 0; }

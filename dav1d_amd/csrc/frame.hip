@@ -12,6 +12,9 @@
 #include <string.h>
 #include <stdlib.h>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <new>
@@ -26,6 +29,11 @@ struct Dav1dHipFrame {
     std::vector<Dav1dHipChunk *> chunks;    // the tile-sbrows' inter predictions + residuals, preprocessed by their submitters (chunk.hip)
     uint8_t *arena;                         // device home of the chunks' blobs
     size_t arena_cap;
+    // chunk preparations handed to the library's threads (option prep_async) and not finished yet; the first error among them
+    std::atomic<int> prep_pending { 0 };
+    std::mutex prep_mtx;
+    std::condition_variable prep_cv;
+    int prep_rc = 0;
     std::atomic<size_t> arena_used;
     // Pinned twin of the arena: a submitter copies its chunk's blob to the offset it drew and is done; the frame goes up as ONE
     // transfer at frame end (30 MB for an 8K frame: half a millisecond).  One hipMemcpyAsync per chunk — 1,800 calls per 8K frame,
@@ -516,12 +524,86 @@ int dav1d_hip_frame_submit_tile_sbrow_own(Dav1dHipFrame *f, const Dav1dHipMcTask
                                           const Dav1dHipItxTask *itx, size_t n_itx, const uint16_t *itx_dep) {
     return submit_tile_sbrow(f, mc, n_mc, comp, n_comp, itx, n_itx, true, itx_dep);
 }
+// ---- the library's preparation threads (option prep_async).  A frame of few tiles has few listing threads — dav1d lists the rows of a tile one
+// after the other (the cursors into cbi / cf are only known behind the row before: src/decode.c:2594-2635) — and each of them used to walk a row,
+// then prepare its chunk, then walk the next: with the preparation (45 % of the two) on a thread of its own, the walk of row k + 1 runs next to
+// the preparation of row k.  Jobs are self-contained (they own copies of the row's records); a frame waits for its jobs before it flushes, ends or dies.
+namespace {
+struct PrepPool {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    int threads = 0;
+    void start_locked() {
+        static const int want = getenv("DAV1D_HIP_PREP_THREADS") ? atoi(getenv("DAV1D_HIP_PREP_THREADS")) : 4;
+        while (threads < (want < 1 ? 1 : want > 32 ? 32 : want)) {
+            std::thread([this]() {
+                for (;;) {
+                    std::function<void()> job;
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        cv.wait(lk, [this]() { return !q.empty(); });
+                        job = std::move(q.front());
+                        q.pop_front();
+                    }
+                    job();
+                }
+            }).detach();
+            threads++;
+        }
+    }
+    void push(std::function<void()> job) {
+        std::lock_guard<std::mutex> lk(m);
+        start_locked();
+        q.push_back(std::move(job));
+        cv.notify_one();
+    }
+};
+PrepPool &prep_pool() { static PrepPool *p = new PrepPool; return *p; }       // (never destroyed: its threads outlive static destruction)
+}
+// every preparation the frame handed out is through; the first error among them (once)
+static int frame_wait_prep(Dav1dHipFrame *f) {
+    std::unique_lock<std::mutex> lk(f->prep_mtx);
+    f->prep_cv.wait(lk, [f]() { return f->prep_pending.load() == 0; });
+    const int rc = f->prep_rc;
+    f->prep_rc = 0;
+    return rc;
+}
+
+static int submit_tile_sbrow_now(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
+                                const Dav1dHipItxTask *itx, size_t n_itx, bool trusted, const uint16_t *itx_dep);
 static int submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
                             const Dav1dHipItxTask *itx, size_t n_itx, bool trusted, const uint16_t *itx_dep) {
     if (!f || (!mc && n_mc) || (!comp && n_comp) || (!itx && n_itx)) return -EINVAL;
     if (!n_mc && !n_comp && !n_itx) return 0;
     if ((n_mc || n_comp) && !f->n_refs) return -EINVAL;
     note_kinds(f, itx, n_itx);
+    const int mode = f->c->prep_async;
+    if (!trusted || !mode || (mode == 1 && !(f->have_tiling && f->tiling.n_cols * f->tiling.n_rows <= 8)))
+        return submit_tile_sbrow_now(f, mc, n_mc, comp, n_comp, itx, n_itx, trusted, itx_dep);
+    struct Job {
+        std::vector<Dav1dHipMcTask> mc; std::vector<Dav1dHipCompTask> comp; std::vector<Dav1dHipItxTask> itx; std::vector<uint16_t> dep;
+    };
+    std::shared_ptr<Job> job;
+    try {
+        job = std::make_shared<Job>();
+        job->mc.assign(mc, mc + n_mc); job->comp.assign(comp, comp + n_comp); job->itx.assign(itx, itx + n_itx);
+        if (itx_dep) job->dep.assign(itx_dep, itx_dep + n_itx);
+    } catch (const std::bad_alloc &) { return -ENOMEM; }
+    f->prep_pending.fetch_add(1);
+    prep_pool().push([f, job]() {
+        (void) hipSetDevice(f->c->device);
+        const int rc = submit_tile_sbrow_now(f, job->mc.data(), job->mc.size(), job->comp.data(), job->comp.size(), job->itx.data(), job->itx.size(), true,
+                                             job->dep.empty() ? nullptr : job->dep.data());
+        std::lock_guard<std::mutex> lk(f->prep_mtx);
+        if (rc && !f->prep_rc) f->prep_rc = rc;
+        f->prep_pending.fetch_sub(1);
+        f->prep_cv.notify_all();
+    });
+    return 0;
+}
+static int submit_tile_sbrow_now(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
+                                const Dav1dHipItxTask *itx, size_t n_itx, bool trusted, const uint16_t *itx_dep) {
     // all the list preparation of this tile-sbrow happens here, on the submitting thread, without the frame's lock
     Dav1dHipChunk *ck = nullptr;
     // the blob's place in the arena is drawn when its size is known; it is written straight into the arena's pinned twin
@@ -1194,13 +1276,14 @@ static int frame_flush_locked(Dav1dHipFrame *f);
 
 int dav1d_hip_frame_end(Dav1dHipFrame *f, void *coef, int16_t *prep, uint8_t *mask, Dav1dHipPicture *filtered, const Dav1dHipPicture *grain_out) {
     if (!f) return -EINVAL;
+    const int rc_prep = frame_wait_prep(f);          // (before the frame's lock: a preparation takes it to hand its chunk in)
     std::lock_guard<std::mutex> lk(f->mtx);
     Dav1dHipContext *c = f->c;
     // the multi-stream sections below use the context's side streams and events: one frame (or list run) at a time per context
     std::lock_guard<std::mutex> run_lk(c->run_mtx);
     (void) hipSetDevice(c->device);
     // several devices in the process: a reference that lives on another one has to be made resident here first (dav1d_hip_picture_copy_peer)
-    const int rc_run = pictures_on_device(c, f->refs, f->n_refs) ? -EXDEV : frame_run(f, coef, prep, mask, filtered, grain_out);
+    const int rc_run = rc_prep ? rc_prep : pictures_on_device(c, f->refs, f->n_refs) ? -EXDEV : frame_run(f, coef, prep, mask, filtered, grain_out);
     // the frame has synchronised (or failed): the pinned chunk blobs go back to the context's pool
     (void) hipStreamSynchronize(c->copy_stream);
     for (Dav1dHipChunk *ck : f->chunks) { ck->release(c); delete ck; }
@@ -1664,6 +1747,10 @@ static int frame_flush_locked(Dav1dHipFrame *f) {
 // against submissions in progress.
 int dav1d_hip_frame_flush(Dav1dHipFrame *f) {
     if (!f) return -EINVAL;
+    {   // (the preparations handed out so far: their blobs are what goes; an error stays for dav1d_hip_frame_end to report)
+        std::unique_lock<std::mutex> lk(f->prep_mtx);
+        f->prep_cv.wait(lk, [f]() { return f->prep_pending.load() == 0; });
+    }
     std::lock_guard<std::mutex> lk(f->mtx);
     return frame_flush_locked(f);
 }
@@ -1723,6 +1810,7 @@ void dav1d_hip_frame_destroy(Dav1dHipFrame *f) {
     if (!f) return;
     __atomic_fetch_sub(&dav1d_hip_live[1], 1, __ATOMIC_RELAXED);
     if (f->worker.joinable()) f->worker.join();
+    (void) frame_wait_prep(f);
     (void) hipStreamSynchronize(f->c->stream);
     if (f->prepared) dav1d_hip_fg_grain_destroy(f->c, f->prepared);
     (void) hipStreamSynchronize(f->c->copy_stream);

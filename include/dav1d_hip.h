@@ -73,6 +73,8 @@ DAV1D_HIP_API void dav1d_hip_graph_destroy(Dav1dHipContext *c, Dav1dHipGraph *g)
  * one-launch form, for frames that copy no blocks, 1 where the superblocks hold "intra_sb_one_below" units or fewer on average (default 0: never — measured
  * no faster), 4 where a level holds 128 superblocks or more on average, else 8;
  * "intra_sb_flow": 1 (default) = all levels of a frame's superblocks as ONE launch, a superblock waiting for the neighbours it reads, 0 = a launch per level,
+ * "prep_async": 1 (default) = the chunk preparation of a tile-sbrow the lister hands in runs on threads of the library for frames of at most 8 tiles (the
+ * listing thread goes on with the tile's next row; errors surface at dav1d_hip_frame_end), 2 = for every frame, 0 = on the submitting thread;
  * "chunk_order": 1 = the prepared lists of a tile-sbrow are ordered for the device — by code path and reference, a few per cent on the
  * launches for a tenth more host time per frame; 0, the default, leaves decode order); -EINVAL for an unknown name. */
 DAV1D_HIP_API int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value);
