@@ -9,6 +9,9 @@
 #include <memory>
 #include "cdef_rows.h"
 #include "chunk.h"
+extern "C" {
+#include "../host/lister_priv.h"       // what the listers (host/*.c) and this file call of each other
+}
 #include <string.h>
 #include <stdlib.h>
 #include <atomic>
@@ -471,8 +474,22 @@ static size_t dense_coef_bytes(const Dav1dHipPicture *p) {
 
 // The values of the caller's PACKED residual tasks (a tile-sbrow's worth): copied into the frame's coefficient arena; *base = what
 // to add to the tasks' cf_off.  The arena travels with the frame (dav1d_hip_frame_flush / dav1d_hip_frame_end with coef = NULL).
+static int frame_coef_room(Dav1dHipFrame *f, size_t n, uint32_t *base, void **dst);
 int dav1d_hip_frame_submit_coefs(Dav1dHipFrame *f, const void *vals, size_t n, uint32_t *base) {
     if (!f || !base || (!vals && n)) return -EINVAL;
+    void *dst = nullptr;
+    const int rc = frame_coef_room(f, n, base, &dst);
+    if (!rc && n) memcpy(dst, vals, n * (f->cur.bpc > 8 ? 4 : 2));
+    return rc;
+}
+// internal (host/lister.c): the room only; the lister's rows are packed straight into it (dav1d_hip_frame_submit_tile_sbrow_packing)
+int dav1d_hip_frame_reserve_coefs(Dav1dHipFrame *f, size_t n, uint32_t *base, void **dst) {
+    if (!f || !base || !dst) return -EINVAL;
+    return frame_coef_room(f, n, base, dst);
+}
+// n values of room in the frame's packed-coefficient arena: in its pinned twin, or (the twin is sized by what frames have needed) in a buffer of
+// its own that goes up at frame end
+static int frame_coef_room(Dav1dHipFrame *f, size_t n, uint32_t *base, void **dst) {
     Dav1dHipContext *c = f->c;
     const size_t csz = f->cur.bpc > 8 ? 4 : 2;
     std::call_once(f->carena_once, [&]() {
@@ -498,11 +515,12 @@ int dav1d_hip_frame_submit_coefs(Dav1dHipFrame *f, const void *vals, size_t n, u
     const size_t bytes = (n * csz + 63) & ~(size_t) 63, off = f->carena_used.fetch_add(bytes);
     if (off + bytes > f->carena_cap || (off + bytes) / csz > 0xffffffffu) return -EINVAL;      // more values than the frame has coefficients
     *base = (uint32_t) (off / csz);
+    *dst = nullptr;
     if (!n) return 0;
-    if (f->hcarena && off + bytes <= f->hcarena_cap) { memcpy(f->hcarena + off, vals, n * csz); return 0; }
+    if (f->hcarena && off + bytes <= f->hcarena_cap) { *dst = f->hcarena + off; return 0; }
     void *copy = malloc(n * csz);
     if (!copy) return -ENOMEM;
-    memcpy(copy, vals, n * csz);
+    *dst = copy;
     std::lock_guard<std::mutex> lk(f->mtx);
     f->late_coefs.push_back({ off, n * csz, copy });
     return 0;
@@ -514,7 +532,8 @@ size_t dav1d_hip_frame_coef_bytes(const Dav1dHipFrame *f) { return f ? f->carena
 // Thread-safe; the order between tile-sbrows is free: inter tasks of a frame write disjoint pixels, and every residual
 // is added after every prediction.
 static int submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
-                            const Dav1dHipItxTask *itx, size_t n_itx, bool trusted, const uint16_t *itx_dep = nullptr);
+                            const Dav1dHipItxTask *itx, size_t n_itx, bool trusted, const uint16_t *itx_dep = nullptr,
+                            const Dav1dHipPackRec *recs = nullptr, size_t n_recs = 0, void *cf = nullptr, void *dst = nullptr);
 int dav1d_hip_frame_submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
                                       const Dav1dHipItxTask *itx, size_t n_itx) {
     return submit_tile_sbrow(f, mc, n_mc, comp, n_comp, itx, n_itx, false);
@@ -523,6 +542,11 @@ int dav1d_hip_frame_submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc
 int dav1d_hip_frame_submit_tile_sbrow_own(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
                                           const Dav1dHipItxTask *itx, size_t n_itx, const uint16_t *itx_dep) {
     return submit_tile_sbrow(f, mc, n_mc, comp, n_comp, itx, n_itx, true, itx_dep);
+}
+int dav1d_hip_frame_submit_tile_sbrow_packing(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
+                                              const Dav1dHipItxTask *itx, size_t n_itx, const uint16_t *itx_dep,
+                                              const Dav1dHipPackRec *recs, size_t n_recs, void *cf, void *dst) {
+    return submit_tile_sbrow(f, mc, n_mc, comp, n_comp, itx, n_itx, true, itx_dep, recs, n_recs, cf, dst);
 }
 // ---- the library's preparation threads (option prep_async).  A frame of few tiles has few listing threads — dav1d lists the rows of a tile one
 // after the other (the cursors into cbi / cf are only known behind the row before: src/decode.c:2594-2635) — and each of them used to walk a row,
@@ -572,28 +596,37 @@ static int frame_wait_prep(Dav1dHipFrame *f) {
 
 static int submit_tile_sbrow_now(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
                                 const Dav1dHipItxTask *itx, size_t n_itx, bool trusted, const uint16_t *itx_dep);
+// recs / cf / dst (the lister's packing rows, or n_recs = 0): the row's coefficient values move from the hand-off's array into the frame's arena
+// before the chunk is prepared — on the same thread as the preparation, whichever that is
 static int submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t n_mc, const Dav1dHipCompTask *comp, size_t n_comp,
-                            const Dav1dHipItxTask *itx, size_t n_itx, bool trusted, const uint16_t *itx_dep) {
-    if (!f || (!mc && n_mc) || (!comp && n_comp) || (!itx && n_itx)) return -EINVAL;
-    if (!n_mc && !n_comp && !n_itx) return 0;
+                            const Dav1dHipItxTask *itx, size_t n_itx, bool trusted, const uint16_t *itx_dep,
+                            const Dav1dHipPackRec *recs, size_t n_recs, void *cf, void *dst) {
+    if (!f || (!mc && n_mc) || (!comp && n_comp) || (!itx && n_itx) || (n_recs && (!recs || !cf || !dst))) return -EINVAL;
+    if (!n_mc && !n_comp && !n_itx && !n_recs) return 0;
     if ((n_mc || n_comp) && !f->n_refs) return -EINVAL;
     note_kinds(f, itx, n_itx);
-    const int mode = f->c->prep_async;
-    if (!trusted || !mode || (mode == 1 && !(f->have_tiling && f->tiling.n_cols * f->tiling.n_rows <= 8)))
-        return submit_tile_sbrow_now(f, mc, n_mc, comp, n_comp, itx, n_itx, trusted, itx_dep);
+    const int mode = f->c->prep_async, csz = f->cur.bpc > 8 ? 4 : 2;
+    if (!trusted || !mode || (mode == 1 && !(f->have_tiling && f->tiling.n_cols * f->tiling.n_rows <= 8))) {
+        if (n_recs) dav1d_hip_pack_run(recs, n_recs, cf, dst, csz);
+        return n_mc || n_comp || n_itx ? submit_tile_sbrow_now(f, mc, n_mc, comp, n_comp, itx, n_itx, trusted, itx_dep) : 0;
+    }
     struct Job {
         std::vector<Dav1dHipMcTask> mc; std::vector<Dav1dHipCompTask> comp; std::vector<Dav1dHipItxTask> itx; std::vector<uint16_t> dep;
+        std::vector<Dav1dHipPackRec> recs;
     };
     std::shared_ptr<Job> job;
     try {
         job = std::make_shared<Job>();
         job->mc.assign(mc, mc + n_mc); job->comp.assign(comp, comp + n_comp); job->itx.assign(itx, itx + n_itx);
         if (itx_dep) job->dep.assign(itx_dep, itx_dep + n_itx);
+        if (n_recs) job->recs.assign(recs, recs + n_recs);
     } catch (const std::bad_alloc &) { return -ENOMEM; }
     f->prep_pending.fetch_add(1);
-    prep_pool().push([f, job]() {
+    prep_pool().push([f, job, cf, dst, csz]() {
         (void) hipSetDevice(f->c->device);
-        const int rc = submit_tile_sbrow_now(f, job->mc.data(), job->mc.size(), job->comp.data(), job->comp.size(), job->itx.data(), job->itx.size(), true,
+        if (!job->recs.empty()) dav1d_hip_pack_run(job->recs.data(), job->recs.size(), cf, dst, csz);
+        const int rc = job->mc.empty() && job->comp.empty() && job->itx.empty() ? 0 :
+                       submit_tile_sbrow_now(f, job->mc.data(), job->mc.size(), job->comp.data(), job->comp.size(), job->itx.data(), job->itx.size(), true,
                                              job->dep.empty() ? nullptr : job->dep.data());
         std::lock_guard<std::mutex> lk(f->prep_mtx);
         if (rc && !f->prep_rc) f->prep_rc = rc;

@@ -93,7 +93,7 @@ typedef struct Out {
     VEC(Dav1dHipIpredTask) ipred; VEC(uint16_t) ipred_step;
     VEC(Dav1dHipCompTask) blend;  VEC(uint16_t) blend_step;
     VEC(Dav1dHipItxTask) sitx;    VEC(uint16_t) sitx_step;
-    uint8_t *pack; size_t npack, pack_cap;                     /* packing lister: the tile-sbrow's coefficient values (npack of them) */
+    VEC(Dav1dHipPackRec) prec; size_t npack;                  /* packing lister: the tile-sbrow's blocks to pack, npack values in all */
 } Out;
 
 typedef struct Walk {
@@ -249,36 +249,41 @@ static uint32_t dst_off(const Dav1dHipLister *l, const int pl, const int x_px, c
 
 /* Packing (Dav1dHipFrameDesc.cf): the eob + 1 values of one block, in the order decode_coefs() produced them — scan position i
  * sits at dav1d_scans[tx][i] for the 2-D transform classes, at i for the horizontal 1-D classes, column-interleaved for the
- * vertical ones (src/recon_tmpl.c:458-520, 548-575) — move to the tile-sbrow's value buffer; where they were becomes zero, as
- * the reference's inverse transform leaves its slab (src/itx_tmpl.c:60,108).  Returns the offset of the first value. */
-static uint32_t pack_block(Walk *w, const int tx, const int txtp, const int eob, const size_t cf_byte) {
-    const Dav1dHipLister *l = w->l;
+ * vertical ones (src/recon_tmpl.c:458-520, 548-575) — move to the frame's value arena; where they were becomes zero, as
+ * the reference's inverse transform leaves its slab (src/itx_tmpl.c:60,108).  The walk only NOTES the block (pack_note: returns the offset of
+ * its first value among the tile-sbrow's); the values move when the row is handed in (dav1d_hip_pack_run: straight into the arena, on the
+ * library's preparation threads where the frame has them — a third of the walk's time, and one copy of every value, used to go here). */
+static uint32_t pack_note(Walk *w, const int tx, const int txtp, const int eob, const size_t cf_byte) {
     Out *o = w->o;
-    const size_t n = (size_t) eob + 1;
-    if (o->npack + n > o->pack_cap) {
-        size_t nc = o->pack_cap ? o->pack_cap * 2 : 1 << 16;
-        while (nc < o->npack + n) nc *= 2;
-        void *q = realloc(o->pack, nc * (size_t) l->csz);
-        if (!q) { v_oom = 1; return 0; }
-        o->pack = (uint8_t *) q; o->pack_cap = nc;
-    }
-    const HostTx *t = &h_tx[tx];
-    const int sw = imin(t->w, 8) * 4, sh = imin(t->h, 8) * 4, lsw = sw == 4 ? 2 : sw == 8 ? 3 : sw == 16 ? 4 : 5;      /* HostTx.w / h: 4-pixel units */
-    /* TxfmType: H_DCT 10, V_DCT 11, H_ADST 12, V_ADST 13, H_FLIPADST 14, V_FLIPADST 15 (src/levels.h:80-100); the transposed storage
-     * of the coefficient slab makes the V_ kinds the row-contiguous ones (src/recon_tmpl.c:458-496) */
-    const int cls = (txtp == 11 || txtp == 13 || txtp == 15) ? 1 : (txtp == 10 || txtp == 12 || txtp == 14) ? 2 : 0;
-    const uint16_t *scan = av1_scans + av1_scan_off[tx];
+    Dav1dHipPackRec *r = VPUSH(o->prec, Dav1dHipPackRec);
+    r->cf_off = (uint32_t) (cf_byte / (size_t) w->l->csz); r->n = (uint16_t) (eob + 1); r->tx = (uint8_t) tx; r->txtp = (uint8_t) txtp;
     const uint32_t at = (uint32_t) o->npack;
+    o->npack += (size_t) eob + 1;
+    return at;
+}
+void dav1d_hip_pack_run(const Dav1dHipPackRec *recs, const size_t n_recs, void *const cf, void *const dstv, const int csz) {
+    h_tables_init();
+    size_t at = 0;
+    for (size_t k = 0; k < n_recs; k++) {
+        const Dav1dHipPackRec *const r = &recs[k];
+        const size_t n = r->n;
+        const HostTx *t = &h_tx[r->tx];
+        const int sw = imin(t->w, 8) * 4, sh = imin(t->h, 8) * 4, lsw = sw == 4 ? 2 : sw == 8 ? 3 : sw == 16 ? 4 : 5;      /* HostTx.w / h: 4-pixel units */
+        /* TxfmType: H_DCT 10, V_DCT 11, H_ADST 12, V_ADST 13, H_FLIPADST 14, V_FLIPADST 15 (src/levels.h:80-100); the transposed storage
+         * of the coefficient slab makes the V_ kinds the row-contiguous ones (src/recon_tmpl.c:458-496) */
+        const int txtp = r->txtp;
+        const int cls = (txtp == 11 || txtp == 13 || txtp == 15) ? 1 : (txtp == 10 || txtp == 12 || txtp == 14) ? 2 : 0;
+        const uint16_t *scan = av1_scans + av1_scan_off[r->tx];
 #define PACK_LOOP(T) do { \
-        T *src = (T *) ((uint8_t *) l->d.cf + cf_byte), *dst = (T *) o->pack + o->npack; \
+        T *src = (T *) cf + r->cf_off, *dst = (T *) dstv + at; \
         if (cls == 0) for (size_t i = 0; i < n; i++) { const int rc = scan[i]; dst[i] = src[rc]; src[rc] = 0; } \
         else if (cls == 1) { memcpy(dst, src, n * sizeof(T)); memset(src, 0, n * sizeof(T)); } \
         else for (size_t i = 0; i < n; i++) { const int rc = ((int) i & (sw - 1)) * sh + ((int) i >> lsw); dst[i] = src[rc]; src[rc] = 0; } \
     } while (0)
-    if (l->hbd) PACK_LOOP(int32_t); else PACK_LOOP(int16_t);
+        if (csz == 4) PACK_LOOP(int32_t); else PACK_LOOP(int16_t);
 #undef PACK_LOOP
-    o->npack += n;
-    return at;
+        at += n;
+    }
 }
 
 /* one transform block: the next cbi entry, its slab, the task (src/recon_tmpl.c:796-816, 1292-1330, 1924-1970) */
@@ -294,7 +299,7 @@ static void emit_tx(Walk *w, const int pl, const int tx, const int x_px, const i
     memset(k, 0, sizeof(*k));
     k->dst_off = dst_off(l, pl, x_px, y_px);
     k->cf_off = (uint32_t) (cf / l->csz);
-    if (l->d.cf) { k->cf_off = pack_block(w, tx, txtp, eob, cf); k->flags = DAV1D_HIP_ITX_PACKED; }
+    if (l->d.cf) { k->cf_off = pack_note(w, tx, txtp, eob, cf); k->flags = DAV1D_HIP_ITX_PACKED; }
     k->eob = (int16_t) eob;
     k->tx = (uint8_t) tx;
     k->txtp = (uint8_t) txtp;
@@ -1251,7 +1256,7 @@ static __thread Out *out_tls;
 static void out_free(void *p) {
     Out *o = (Out *) p;
     if (!o) return;
-    free(o->pack);
+    free(o->prec.p);
     free(o->mc.p); free(o->comp.p); free(o->warp.p); free(o->scaled.p); free(o->itx.p); free(o->itx_dep.p);
     free(o->ipred.p); free(o->ipred_step.p); free(o->blend.p); free(o->blend_step.p); free(o->sitx.p); free(o->sitx_step.p);
     free(o);
@@ -1268,7 +1273,7 @@ static Out *out_get(void) {
     }
     o->mc.n = o->comp.n = o->warp.n = o->scaled.n = o->itx.n = o->itx_dep.n = o->ipred.n = o->ipred_step.n = o->blend.n = o->blend_step.n = 0;
     o->sitx.n = o->sitx_step.n = 0;
-    o->npack = 0;
+    o->npack = 0; o->prec.n = 0;
     return o;
 }
 
@@ -1308,15 +1313,17 @@ int dav1d_hip_lister_tile_sbrow(Dav1dHipLister *l, const int tile_row, const int
     for (int bx = w.col_start; bx < w.col_end && !w.err && !v_oom; bx += l->sb_step)
         walk_sb(&w, l->d.sb128 ? H_BL_128X128 : H_BL_64X64, bx, by, 1, 0);
     int rc = v_oom ? -ENOMEM : w.err;
+    void *pack_dst = NULL;
     if (!rc && l->d.cf && (op->itx.n || op->sitx.n)) {
-        /* the tile-sbrow's values join the frame's coefficient arena; the tasks counted from the start of the buffer */
+        /* the tile-sbrow's values get their place in the frame's coefficient arena; the tasks counted from the start of the row */
         uint32_t base = 0;
-        rc = dav1d_hip_frame_submit_coefs(l->frame, op->pack, op->npack, &base);
+        rc = dav1d_hip_frame_reserve_coefs(l->frame, op->npack, &base, &pack_dst);
         for (size_t i = 0; i < op->itx.n; i++) op->itx.p[i].cf_off += base;
         for (size_t i = 0; i < op->sitx.n; i++) op->sitx.p[i].cf_off += base;
     }
     PROF_T(t1);
-    if (!rc) rc = dav1d_hip_frame_submit_tile_sbrow_own(l->frame, op->mc.p, op->mc.n, op->comp.p, op->comp.n, op->itx.p, op->itx.n, op->itx_dep.n == op->itx.n ? op->itx_dep.p : NULL);
+    if (!rc) rc = dav1d_hip_frame_submit_tile_sbrow_packing(l->frame, op->mc.p, op->mc.n, op->comp.p, op->comp.n, op->itx.p, op->itx.n, op->itx_dep.n == op->itx.n ? op->itx_dep.p : NULL,
+                                                            op->prec.p, pack_dst ? op->prec.n : 0, (void *) l->d.cf, pack_dst);
     PROF_T(t2);
     PROF_ADD(0, t1 - t0); PROF_ADD(1, t2 - t1);
     if (!rc && op->warp.n) rc = dav1d_hip_frame_submit_warp(l->frame, op->warp.p, op->warp.n);

@@ -1,0 +1,16 @@
+#!/bin/bash
+for i in 1 2; do
+  python bench.py --steps 10 --warmup 2 --no-cpu --no-c1 --no-pmc > /tmp/p.json 2> /tmp/p.err
+  python - <<'P'
+import json
+d=json.load(open('bench_legs.json'))
+out={}
+for k in ('end_to_end_packing_lister','all_intra_packing_lister','end_to_end_4_tile_columns','dav1d_task_loop','dav1d_task_loop_real_pass1'):
+    v=d.get(k) or {}
+    out[k]={x:v.get(x) for x in ('total_ms','list_ms','fps') if v.get(x) is not None}
+fl=d.get('end_to_end_frames_in_flight') or {}
+for k,v in fl.items():
+    if isinstance(v,dict): out['in_flight_'+k]={x:v.get(x) for x in ('ms_per_frame','list_ms','host_cpu_ms_per_frame')}
+print(json.dumps(out))
+P
+done
