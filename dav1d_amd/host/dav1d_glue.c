@@ -389,7 +389,12 @@ void dav1d_hip_glue_frame_complete(Dav1dFrameContext *const f) {
     pthread_mutex_unlock(&g->q_mtx);
 }
 
-const Dav1dHooks dav1d_hip_glue_hooks = { dav1d_hip_glue_frame_init, glue_entropy, dav1d_hip_glue_recon_tile_sbrow, dav1d_hip_glue_frame_complete };
+/* Dav1dHooks.before_init: a frame that failed in pass 1 never reached dav1d_hip_glue_frame_complete — the task loop ended it itself — and its objects are
+ * still here, possibly with preparations of its last rows still packing coefficients out of f->frame_thread.cf on the library's threads (option
+ * prep_async).  They are waited for (dav1d_hip_frame_destroy does) BEFORE dav1d_decode_frame_init may reallocate that array for the next frame. */
+void dav1d_hip_glue_before_init(Dav1dFrameContext *const f) { drop_frame_objects(g_glue, state_of(f)); }
+
+const Dav1dHooks dav1d_hip_glue_hooks = { dav1d_hip_glue_before_init, dav1d_hip_glue_frame_init, glue_entropy, dav1d_hip_glue_recon_tile_sbrow, dav1d_hip_glue_frame_complete };
 
 /* ------------------------------------------------------------------------------------------------ the three stage threads */
 /* stage 1 (any order): what the frame's launches read from the host side */

@@ -2,7 +2,7 @@
  *
  * This file and dav1d_glue.c are compiled INTO dav1d (they include dav1d's internal headers, src/internal.h etc.) and talk to
  * libdav1d_hip.so through include/dav1d_hip.h, which they dlopen: no link-time dependency, a dav1d without the library behaves as
- * before.  The patch adds four hook points to src/thread_task.c (dav1d_hooks.h); the functions below are what goes behind them.
+ * before.  The patch adds five hook points to src/thread_task.c (dav1d_hooks.h); the functions below are what goes behind them.
  * INTEGRATION.md 2 walks through it; oracle/ref_hooked.c (test infrastructure) is one user: it opens dav1d with the glue's allocator,
  * points the hooks here and compares every picture with dav1d's own.
  *
@@ -82,9 +82,10 @@ int dav1d_hip_glue_attach(Dav1dHipGlue *g, Dav1dContext *c);
 void dav1d_hip_glue_detach(Dav1dHipGlue *g);
 void dav1d_hip_glue_destroy(Dav1dHipGlue *g);
 
-/* ---- what goes behind the hook points (dav1d_hooks.h).  dav1d_hip_glue_hooks has all four; a caller with hooks of its own (the test
+/* ---- what goes behind the hook points (dav1d_hooks.h).  dav1d_hip_glue_hooks has all five; a caller with hooks of its own (the test
  * harness injects pass 1's output first) calls these from them. */
 extern const Dav1dHooks dav1d_hip_glue_hooks;
+void dav1d_hip_glue_before_init(Dav1dFrameContext *f);        /* Dav1dHooks.before_init: lets go of what a frame that failed in pass 1 left on the context */
 int dav1d_hip_glue_frame_init(Dav1dFrameContext *f);           /* Dav1dHooks.after_init: frame + lister, the filter stages pointed at the filter lister */
 void dav1d_hip_glue_after_entropy(Dav1dTaskContext *t);        /* behind a successful pass-1 tile-sbrow (option free_listing) */
 int dav1d_hip_glue_recon_tile_sbrow(Dav1dTaskContext *t);      /* Dav1dHooks.recon_tile_sbrow: instead of dav1d_decode_tile_sbrow(pass 2) */

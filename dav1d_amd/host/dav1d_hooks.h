@@ -1,6 +1,6 @@
 /* Hook points of patches/dav1d-1.5.4-hip.patch (goes to dav1d's src/ with it).
  *
- * The patch changes ONE file of dav1d, src/thread_task.c, at exactly the places INTEGRATION.md 2 names — the tile task's call of
+ * The patch changes ONE file of dav1d, src/thread_task.c, at exactly the places INTEGRATION.md 2 names — the start of a frame's init task (:700-702), the tile task's call of
  * dav1d_decode_tile_sbrow (reference src/thread_task.c:733-752), the publication of a frame's rows (:888-896) and the places a frame is
  * declared complete (:780-790, :876-885, :899-913) — and adds the two functions a backend that finishes frames on its own thread calls
  * back.  Everything else — dav1d_submit_frame, dav1d_decode_frame_init, the task queues, check_tile's inter-frame dependencies,
@@ -10,6 +10,10 @@
 #include "src/internal.h"
 
 typedef struct Dav1dHooks {
+    /* before dav1d_decode_frame_init, on the worker that is about to run it: the frame context still holds what its last frame left — the moment for
+     * a backend to let go of that frame's objects if the frame never reached frame_complete (it failed in pass 1) and work of its own on the
+     * context's arrays (f->frame_thread.cf ...) may still be running: dav1d_decode_frame_init is free to reallocate them.  NULL: nothing */
+    void (*before_init)(Dav1dFrameContext *f);
     /* after dav1d_decode_frame_init + dav1d_decode_frame_init_cdf, on the worker that ran them, before the frame's tile tasks exist */
     int (*after_init)(Dav1dFrameContext *f);
     /* instead of dav1d_decode_tile_sbrow with pass 1 (entropy decoding); NULL: dav1d's own */

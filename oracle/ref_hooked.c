@@ -633,8 +633,8 @@ static void ob_after_frame_done(void *const cookie, const int k) {
     if (!h->p.stream && k >= 0 && k < h->p.n_frames) h->q_done_t[k] = now_s();
 }
 
-static const Dav1dHooks hooks_cpu = { hk_after_init, hk_entropy, NULL, NULL };
-static const Dav1dHooks hooks_hip = { hk_after_init, hk_entropy, dav1d_hip_glue_recon_tile_sbrow, dav1d_hip_glue_frame_complete };
+static const Dav1dHooks hooks_cpu = { NULL, hk_after_init, hk_entropy, NULL, NULL };
+static const Dav1dHooks hooks_hip = { dav1d_hip_glue_before_init, hk_after_init, hk_entropy, dav1d_hip_glue_recon_tile_sbrow, dav1d_hip_glue_frame_complete };
 
 /* ------------------------------------------------------------------------------------------------ headers */
 static void fill_seq(Dav1dSequenceHeader *const seq, const HookedParams *const p) {
