@@ -894,9 +894,11 @@ typedef struct Dav1dHipFrameDesc {
                                     the lister PACKS: per transform block it gathers the eob + 1 values the entropy decoder
                                     produced (scan order, see DAV1D_HIP_ITX_PACKED) into the frame's own coefficient arena
                                     (dav1d_hip_frame_submit_coefs) and zeroes them where they were — what the reference's
-                                    itxfm_add does to the slab it consumed (src/itx_tmpl.c:60,108): when the last tile-sbrow is
-                                    listed, cf is ready for the next frame's pass 1, and only the values that exist cross the
-                                    host link.  dav1d_hip_frame_end is then called with coef = NULL. */
+                                    itxfm_add does to the slab it consumed (src/itx_tmpl.c:60,108): only the values that exist
+                                    cross the host link.  The values of a tile-sbrow move when the row is handed in — for frames
+                                    of few tiles on threads of the library (option prep_async), so cf has to stay as it is, and
+                                    is only ready for the next frame's pass 1, when dav1d_hip_frame_end (or _flush / _destroy)
+                                    of this frame has returned.  dav1d_hip_frame_end is then called with coef = NULL. */
 } Dav1dHipFrameDesc;
 
 /* Byte offset of a tile's first coefficient in the cf arena, of its first cbi entry and of its first palette index byte, as
