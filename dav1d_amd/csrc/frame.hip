@@ -576,6 +576,12 @@ struct PrepPool {
             threads++;
         }
     }
+    // as many jobs waiting as there are threads to take them: whoever asks does its row itself (frames of few tiles but many of them in flight —
+    // dav1d's n_fc — bring more listing threads than the pool has)
+    bool backed_up() {
+        std::lock_guard<std::mutex> lk(m);
+        return threads > 0 && q.size() >= (size_t) threads;
+    }
     void push(std::function<void()> job) {
         std::lock_guard<std::mutex> lk(m);
         start_locked();
@@ -606,7 +612,7 @@ static int submit_tile_sbrow(Dav1dHipFrame *f, const Dav1dHipMcTask *mc, size_t 
     if ((n_mc || n_comp) && !f->n_refs) return -EINVAL;
     note_kinds(f, itx, n_itx);
     const int mode = f->c->prep_async, csz = f->cur.bpc > 8 ? 4 : 2;
-    if (!trusted || !mode || (mode == 1 && !(f->have_tiling && f->tiling.n_cols * f->tiling.n_rows <= 8))) {
+    if (!trusted || !mode || (mode == 1 && !(f->have_tiling && f->tiling.n_cols * f->tiling.n_rows <= 8)) || prep_pool().backed_up()) {
         if (n_recs) dav1d_hip_pack_run(recs, n_recs, cf, dst, csz);
         return n_mc || n_comp || n_itx ? submit_tile_sbrow_now(f, mc, n_mc, comp, n_comp, itx, n_itx, trusted, itx_dep) : 0;
     }
