@@ -872,8 +872,13 @@ static unsigned src_step(const Walk *w, const int pl, const int x_px, const int 
     const Dav1dHipLister *l = w->l;
     const int sh = pl ? l->ss_hor : 0, sv = pl ? l->ss_ver : 0;
     const int cw = (l->bw + sh) >> sh, ch = (l->bh + sv) >> sv;                     /* cells of the plane */
-    const int x0 = iclip(x_px >> 2, 0, cw - 1), x1 = iclip((x_px + w_px) >> 2, 0, cw - 1);    /* one pixel more: the bilinear taps */
-    const int y0 = iclip(y_px >> 2, 0, ch - 1), y1 = iclip((y_px + h_px) >> 2, 0, ch - 1);
+    /* ... of the TILE: decode_b keeps the source rectangle inside it (src/decode.c:1290-1336), and the cell behind the rectangle's last
+     * column / row (the bilinear taps' pixel more, never read at the integer vectors an intra block copy has) would be the first of the
+     * tile to the right / below when the rectangle ends at the tile's edge — cells another thread lists, or has not cleared yet (the
+     * maps are recycled uncleared): a step drawn from there differs from run to run, and -ERANGE when the stale cell held 0xffff */
+    const int tx_lo = w->col_start >> sh, tx_hi = imin((w->col_end + sh) >> sh, cw), ty_lo = w->row_start >> sv, ty_hi = imin((w->row_end + sv) >> sv, ch);
+    const int x0 = iclip(x_px >> 2, tx_lo, tx_hi - 1), x1 = iclip((x_px + w_px) >> 2, tx_lo, tx_hi - 1);    /* one pixel more: the bilinear taps */
+    const int y0 = iclip(y_px >> 2, ty_lo, ty_hi - 1), y1 = iclip((y_px + h_px) >> 2, ty_lo, ty_hi - 1);
     const uint16_t *m = l->step[pl];
     const int st = l->step_stride[pl];
     unsigned s = 0;
@@ -1134,6 +1139,10 @@ int dav1d_hip_lister_create(Dav1dHipLister **out, const Dav1dHipFrameDesc *d, Da
         l->step_stride[p] = (int) d->b4_stride;
         l->step[p] = (uint16_t *) map_get(l->map_bytes);
     }
+    /* (test hook: the recycled maps arrive full of 0xffff instead of whatever they held — a step drawn from a cell outside the share its
+     * tile has cleared then fails with -ERANGE instead of passing unnoticed, tests/test_lister.py) */
+    if (getenv("DAV1D_HIP_LISTER_POISON"))
+        for (int p = 0; p < 3; p++) if (l->step[p]) memset(l->step[p], 0xff, l->map_bytes);
     const int n_tiles = d->n_tile_cols * d->n_tile_rows;
     l->tiles = (TileCursor *) calloc((size_t) n_tiles, sizeof(TileCursor));
     if (!l->owner || !l->step[0] || !l->step[1] || !l->step[2] || !l->tiles || !l->sb_dep) { dav1d_hip_lister_destroy(l); return -ENOMEM; }

@@ -281,6 +281,20 @@ def test_tile_sbrows_interleaved_across_tile_rows_with_an_odd_row_boundary(ctx):
         run_case(ctx, 448, 320, 1, 10, 77, is_inter=is_inter, tiles=(2, 2), sb128=False, interleave=True, **kw)
 
 
+def test_steps_of_intra_block_copies_come_from_cells_of_their_own_tile(ctx, monkeypatch):
+    """An intra block copy waits for the step of the cells under its source rectangle, which decode_b keeps inside the tile
+    (src/decode.c:1290-1336).  Tile rows one superblock high: a rectangle that ends at the tile's last row has the first cell row of the
+    tile BELOW behind it — cells another thread lists, or has not cleared yet (the maps are recycled uncleared; DAV1D_HIP_LISTER_POISON
+    fills them with 0xffff, so a step drawn from there is refused).  Found by the 2,048-stream sweep of round 6 as a rare -ERANGE; the
+    synthetic generator keeps its rectangles a pixel inside the tile, tests/test_stream.py has the streams that failed."""
+    monkeypatch.setenv("DAV1D_HIP_LISTER_POISON", "1")
+    kw = dict(is_inter=False, sb128=False, intrabc_pct=60)
+    for seed, tiles in ((31, (2, 4)), (33, (4, 2))):
+        a = run_case(ctx, 1024, 256, 1, 8, seed, tiles=tiles, **kw)
+        b = run_case(ctx, 1024, 256, 1, 8, seed, tiles=tiles, interleave=True, **kw)
+        assert a["steps"] == b["steps"], "seed %d: %d steps top-down, %d with the lower tiles first" % (seed, a["steps"], b["steps"])
+
+
 @pytest.mark.gpu
 def test_larger_frame_many_tiles_threads():
     ctx = util.make_context("hip")

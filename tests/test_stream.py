@@ -116,6 +116,21 @@ def test_screen_content_stream_palette_and_intra_block_copy(ctx):
     assert got["hist"]["b_palette_y"] > 0 and got["hist"]["b_intrabc"] > 0, got["hist"]
 
 
+def test_wavefront_steps_come_from_cells_their_tile_has_cleared(ctx, monkeypatch):
+    """The lister's cell maps are recycled from frame to frame uncleared; a tile clears its share when its first superblock row is listed.
+    decode_b lets the source rectangle of an intra block copy end at the tile's last row / column (src/decode.c:1290-1336): the cell
+    behind it belongs to the next tile — listed by another thread, or still holding whatever the map held.  DAV1D_HIP_LISTER_POISON fills
+    the maps with 0xffff at the start of a frame, so a step drawn from such a cell is refused (-ERANGE) instead of differing from run to
+    run: that is how one stream in 3,000 of the GPU sweeps failed (round 6).  Streams 4001, 4002 and 4005 failed here before the fix."""
+    monkeypatch.setenv("DAV1D_HIP_LISTER_POISON", "1")
+    k = av1_obu.Knobs(screen_content=1.0, intrabc=1.0, intra_only=0.5, super_res=0.0)
+    for seed in (4001, 4002, 4005):
+        got = run_seed(ctx, seed, n_frames=5, knobs=k)
+        assert got["hist"]["b_intrabc"] > 0
+    for seed in (2, 7):
+        run_seed(ctx, seed, n_frames=5)
+
+
 def test_filters_over_a_full_copy_give_the_same_pictures(ctx, monkeypatch):
     """CDEF and restoration normally bring over only the units they do not list (cdef.hip cdef_fill_unlisted_kernel, frame.hip
     copy_unrestored_planes); the A/B switch puts the whole-picture copy back underneath: both are dav1d's pictures"""
