@@ -50,11 +50,22 @@ def config_of(seed):
     return layout, bpc, w, h, bool(seed & 8)
 
 
+class Unrepairable(Exception):
+    pass
+
+
 def run_seed(ctx, seed, n_frames=7, knobs=None, **dec):
     layout, bpc, w, h, sb128 = config_of(seed)
     sw = av1_obu.make_stream(w, h, layout, bpc, n_frames, seed, sb128=sb128, knobs=knobs)
     lib = hip_lib_path(ctx)
-    su.repair(sw, lib, max_rounds=8000)
+    try:
+        su.repair(sw, lib, max_rounds=8000)
+    except AssertionError as e:
+        # the WRITER's limit, not the backend's (dav1d alone decodes in repair): a payload whose re-rolls keep running into syntax dav1d
+        # rejects (seed 1763, 4:2:2 12-bit: one in 2,048).  The sweeps count such streams and go on; everything else fails as before
+        if "still rejected" in str(e):
+            raise Unrepairable("seed %d: %s" % (seed, e))
+        raise
     units = [u["data"] for u in sw.units]
     want = su.decode(units, 0, lib)
     assert not want["errors"] and len(want["pictures"]) >= n_frames - 2
@@ -161,7 +172,11 @@ def test_sweep_of_streams_on_the_gpu(seeds):
     ctx.backend = "hip"
     try:
         for seed in seeds:
-            run_seed(ctx, seed, n_frames=7)
+            try:
+                run_seed(ctx, seed, n_frames=7)
+            except Unrepairable as e:
+                SEEN["unrepairable"] += 1
+                print(e)
     finally:
         ctx.close()
 
@@ -173,6 +188,7 @@ def test_sweep_of_streams_on_the_gpu_covered_every_tool():
         pytest.skip("the sweep did not run in this process (or with too few seeds)")
     report("GPU sweep of %d streams" % N_SWEEP)
     assert_covered()
+    assert SEEN["unrepairable"] * 200 <= N_SWEEP, "%d streams of %d the writer could not repair" % (SEEN["unrepairable"], N_SWEEP)
     layouts = {k[0] for k in SEEN if isinstance(k, tuple)}
     assert layouts == {"400", "420", "422", "444"}
     assert {k[1] for k in SEEN if isinstance(k, tuple)} == {8, 10, 12} and {k[2] for k in SEEN if isinstance(k, tuple)} == {64, 128}
