@@ -728,26 +728,6 @@ def run_job(a, rank, local, world):
         lanes.append((ctx_k, ctx_k.recon_list(dsts[0], frame.mc, frame.comp, itx_tasks), torch.zeros(frame.prep_elems, dtype=torch.int16, device=dev), st_k))
     tdt = torch.int16 if bpc == 8 else torch.int32
     pristine = torch.from_numpy(coef_host).to(dev)
-    h2d_first = os.environ.get("BENCH_H2D_FIRST", "1") != "0"
-    def measure_h2d():
-        # what the boundary costs when the residuals arrive from the host every frame (reported next to `value`, never in it)
-        h2d_ms = None
-        if rank == 0 and not a.emu:
-            pinned = torch.from_numpy(coef_host).pin_memory()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            best = 1e9
-            for _ in range(3):
-                e0.record()
-                pristine.copy_(pinned, non_blocking=True)
-                e1.record()
-                torch.cuda.synchronize()
-                best = min(best, e0.elapsed_time(e1))
-            h2d_ms = round(best, 3)
-            del pinned
-
-        return h2d_ms
-    if h2d_first:
-        h2d_ms = measure_h2d()
     n_arena = a.steps + a.warmup + 8
     if a.packed:        # a packed arena is read-only: every step reads the same one
         arenas = [pristine] * n_arena
@@ -756,8 +736,21 @@ def run_job(a, rank, local, world):
         for i in range(n_arena):
             arenas[i].copy_(pristine)
     torch.cuda.synchronize()
-    if not h2d_first:
-        h2d_ms = measure_h2d()
+    # what the boundary costs when the residuals arrive from the host every frame (reported next to `value`, never in it)
+    h2d_ms = None
+    if rank == 0 and not a.emu:
+        pinned = torch.from_numpy(coef_host).pin_memory()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 1e9
+        for _ in range(3):
+            e0.record()
+            pristine.copy_(pinned, non_blocking=True)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        h2d_ms = round(best, 3)
+        del pinned
+
     tc_post = None
     if tile_cols and a.tc_filters:
         # this rank's share of the frame's in-loop filter tasks (margins included) and the two extra pictures of the chain
