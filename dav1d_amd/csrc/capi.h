@@ -42,6 +42,9 @@ struct Dav1dHipContext {
     int recon_coop_below;       // paired kernels: launches of fewer groups than this take the cooperative form (recon.hip; DAV1D_HIP_RECON_COOP_BELOW)
     int post_bands;             // bands of the pipelined post filters, 0 = stage by stage (DAV1D_HIP_POST_BANDS)
     int recon_pair_streams;     // side streams the paired launches of a recon list are dealt over (DAV1D_HIP_RECON_PAIR_STREAMS, 1 .. 3; default 2)
+    int recon_pair_first;       // ... starting at side stream 1 .. 3 (DAV1D_HIP_RECON_PAIR_FIRST; default 2): which HARDWARE queue a stream shares with which other is a matter of the order the
+                                // streams were made in (the runtime deals them over GPU_MAX_HW_QUEUES = 4 queues), profiles/r06/hw_queues.txt
+    hipStream_t pad_streams[8]; int n_pad_streams;      // (DAV1D_HIP_STREAM_PAD: unused streams made in front of the side streams — shifts that dealing; an experiment's knob)
     int ref_twin;               // tiled twins of reference pictures ($DAV1D_HIP_REF_TWIN): 0 never read, 1 (default) read when a picture has a valid
                                 // one (dav1d_hip_picture_retile), 2 also made for every picture of dav1d_hip_picture_alloc and by dav1d_hip_frame_end
     bool cdef_rows;             // option cdef_rows (default 1) / $DAV1D_HIP_CDEF_ROWS: the filter lister hands over one record per unit row of a 64-pixel column and the device makes the unit records (cdef.hip cdef_expand_kernel)

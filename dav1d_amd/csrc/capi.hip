@@ -62,6 +62,32 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     c->post_bands = (int) env_int("DAV1D_HIP_POST_BANDS", 0);
     c->ref_twin = (int) env_int("DAV1D_HIP_REF_TWIN", 1);
     c->recon_pair_streams = (int) env_int("DAV1D_HIP_RECON_PAIR_STREAMS", 2);
+    // (per-context lists "a,b,...": the i-th context opened in the process takes element i mod length)
+    static std::atomic<int> n_opened{0};
+    const int ctx_index = n_opened.fetch_add(1);
+    auto env_list = [&](const char *name, long dflt) {
+        const char *e = getenv(name);
+        if (!e || !*e) return dflt;
+        int n = 1;
+        for (const char *q = e; *q; q++) n += *q == ',';
+        int want = ctx_index % n;
+        const char *q = e;
+        while (want-- > 0) q = strchr(q, ',') + 1;
+        return atol(q);
+    };
+    c->recon_pair_first = (int) std::max(1L, std::min(3L, env_list("DAV1D_HIP_RECON_PAIR_FIRST", 2)));
+    // Which streams share a HARDWARE queue.  The runtime deals a process's streams over GPU_MAX_HW_QUEUES (4) hardware queues in the order they are
+    // made, and a hardware queue runs its packets in order: a stream that waits for an event holds up every stream behind it in the same queue.  A
+    // step's launches run on four streams of the context — main (4x4 pairs, 64-wide predictions, the join), side 0 (64x64 residuals), side 2 and 3 (the
+    // paired launches).  With the side streams made straight behind the main stream, side 2 and 3 of the first context share ONE queue, and a second
+    // context's side 2 joins them there while its side 3 sits behind its own main stream: three of the four streams that carry the long launches in one
+    // queue (rocprofv3's Queue_Id per dispatch, profiles/r06/queue_map.txt).  One unused stream in front of the side streams shifts the dealing so that
+    // each of those four has a queue to itself or shares it with a short stream: measured on the 8K step 0.274 -> 0.260 ms with one frame in flight,
+    // 0.239 -> 0.229 with two, 4K 0.099 -> 0.088 with one (0.0735 -> 0.0765 with two; three 8K contexts 0.243 -> 0.259); more hardware queues (5 .. 16)
+    // or fewer are all slower (profiles/r06/hw_queues.txt).
+    c->n_pad_streams = (int) std::max(0L, std::min(8L, env_list("DAV1D_HIP_STREAM_PAD", 1)));
+    for (int i = 0; i < c->n_pad_streams; i++)
+        if (hipStreamCreateWithFlags(&c->pad_streams[i], hipStreamNonBlocking) != hipSuccess) { c->n_pad_streams = i; break; }
     const char *ser = getenv("DAV1D_HIP_SERIAL");
     c->concurrent = !(ser && atoi(ser));
     const char *cu = getenv("DAV1D_HIP_CDEF_UNIT");
@@ -119,6 +145,7 @@ void dav1d_hip_close(Dav1dHipContext *c) {
     (void) hipDeviceSynchronize();
     hipStreamSynchronize(c->stream);
     if (c->scratch) hipFree(c->scratch);
+    for (int i = 0; i < c->n_pad_streams; i++) hipStreamDestroy(c->pad_streams[i]);
     for (int i = 0; i < Dav1dHipContext::N_SIDE; i++) { hipStreamSynchronize(c->side[i]); hipStreamDestroy(c->side[i]); hipEventDestroy(c->ev_join[i]); if (i < 3) hipEventDestroy(c->ev_pair[i]); }
     hipEventDestroy(c->ev_fork);
     for (int i = 0; i < 16; i++) hipEventDestroy(c->ev_bin[i]);
@@ -193,6 +220,7 @@ int dav1d_hip_get_option(Dav1dHipContext *c, const char *name, long *value) {
     else if (!strcmp(name, "intra_sb_one_below")) *value = c->intra_sb_one_below;
     else if (!strcmp(name, "recon_fuse")) *value = c->recon_fuse;
     else if (!strcmp(name, "recon_pair_streams")) *value = c->recon_pair_streams;
+    else if (!strcmp(name, "recon_pair_first")) *value = c->recon_pair_first;
     else if (!strcmp(name, "ref_twin")) *value = c->ref_twin;
     else return -EINVAL;
     return 0;
@@ -208,6 +236,7 @@ int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, long value) {
     else if (!strcmp(name, "post_bands")) c->post_bands = (int) value;
     else if (!strcmp(name, "ref_twin")) c->ref_twin = (int) value;
     else if (!strcmp(name, "recon_pair_streams")) c->recon_pair_streams = (int) value;
+    else if (!strcmp(name, "recon_pair_first")) c->recon_pair_first = (int) std::max(1L, std::min(3L, (long) value));
     else if (!strcmp(name, "serial")) c->concurrent = !value;
     else if (!strcmp(name, "cdef_unit")) c->cdef_unit_kernel = value != 0;
     else if (!strcmp(name, "filter_full_copy")) c->cdef_full_copy = value != 0;
@@ -2106,7 +2135,7 @@ static int recon_list_run_impl(Dav1dHipContext *c, const Dav1dHipReconList *l, c
         n_ps = side ? std::max(1, std::min(3, c->recon_pair_streams)) : 0;
         if (side) {
             (void) hipEventRecord(c->ev_fork, c->stream);
-            for (int j = 0; j < n_ps; j++) (void) hipStreamWaitEvent(c->side[2 + j], c->ev_fork, 0);
+            for (int j = 0; j < n_ps; j++) (void) hipStreamWaitEvent(c->side[c->recon_pair_first + j], c->ev_fork, 0);
         }
         for (int k = 4; k >= 0 && !rc; k--)
             if (l->f_n[k]) {
@@ -2114,10 +2143,10 @@ static int recon_list_run_impl(Dav1dHipContext *c, const Dav1dHipReconList *l, c
                 // what the step waits for, and the short launches of the main stream end long before them
                 const bool on_main = side && k == 0;
                 rc = dav1d_hip_launch_recon_fused_out(&dp, rp, n_refs, dst->bpc, k, l->f_tiles[k], l->f_tasks[k], (int) l->f_n[k], prep, coef, c->recon_coop_below,
-                                                      wide, dst_twin, side && !on_main ? c->side[2 + lane] : c->stream);
+                                                      wide, dst_twin, side && !on_main ? c->side[c->recon_pair_first + lane] : c->stream);
                 if (!on_main && n_ps) lane = (lane + 1) % n_ps;
             }
-        for (int j = 0; j < n_ps; j++) (void) hipEventRecord(c->ev_pair[j], c->side[2 + j]);
+        for (int j = 0; j < n_ps; j++) (void) hipEventRecord(c->ev_pair[j], c->side[c->recon_pair_first + j]);
         if (rc) return rc;
         paired_on_side = side;
         if (!l->inter->mc->n && !l->inter->comp->n && !l->itx->n) {

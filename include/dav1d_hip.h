@@ -45,7 +45,11 @@ typedef struct Dav1dHipContext Dav1dHipContext;
 /* Opens the backend on HIP device `device`.  `stream` is a hipStream_t owned by the
  * caller (e.g. torch.cuda.current_stream().cuda_stream) or NULL for a private
  * stream.  All batched calls are asynchronous on that stream.
- * Fails with -ENODEV if no gfx950 device is usable: there is no CPU fallback. */
+ * Fails with -ENODEV if no gfx950 device is usable: there is no CPU fallback.
+ * The context makes its side streams here, and the ORDER streams are made in decides which of them share a hardware queue (the runtime
+ * deals them over GPU_MAX_HW_QUEUES = 4 queues, each in order): DAV1D_HIP_STREAM_PAD (default 1; "a,b,..." = per context in the order they
+ * are opened) unused streams are made in front of the side streams, DAV1D_HIP_RECON_PAIR_FIRST (1 .. 3, default 2) is the first side stream
+ * of the paired reconstruction launches — both read at open only; DESIGN.md 9 has the measurements. */
 DAV1D_HIP_API int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream);
 DAV1D_HIP_API void dav1d_hip_close(Dav1dHipContext *c);
 DAV1D_HIP_API int dav1d_hip_sync(Dav1dHipContext *c);
@@ -81,7 +85,7 @@ DAV1D_HIP_API int dav1d_hip_set_option(Dav1dHipContext *c, const char *name, lon
 /* Reads back what a context counts or was set to: "intra_sb_fallbacks" = frames of this context whose one-launch intra pass had workgroups give
  * up waiting for a neighbour and was finished by launches per level (0 in a sound run: the one-launch form rests on workgroups being dispatched
  * in index order and staying resident; the fall-back needs neither); "intra_sb_waves", "intra_sb_one_below", "recon_fuse", "recon_pair_streams",
- * "ref_twin".  -EINVAL for an unknown name. */
+ * "recon_pair_first", "ref_twin".  -EINVAL for an unknown name. */
 DAV1D_HIP_API int dav1d_hip_get_option(Dav1dHipContext *c, const char *name, long *value);
 DAV1D_HIP_API const char *dav1d_hip_version(void);
 /* Measurement aid: device time (HIP events on the context's stream) of the kernel launches of the most recent
