@@ -108,8 +108,23 @@ int dav1d_hip_open(Dav1dHipContext **out, int device, void *stream) {
     c->prep_async = (int) env_int("DAV1D_HIP_PREP_ASYNC", 1);
     c->intra_sb_lds = (int) env_int("DAV1D_HIP_INTRA_SB_LDS", 0);
     c->intra_sb_flow = (int) env_int("DAV1D_HIP_INTRA_SB_FLOW", 1);
+    // (DAV1D_HIP_PAIR_PRIORITY=1, an experiment's knob: the streams of the paired launches are made with the device's highest stream priority — the
+    // runtime keeps a pool of hardware queues per priority, so they are dealt over queues no other stream of the process is in)
+    const long pair_prio = env_list("DAV1D_HIP_PAIR_PRIORITY", 0);
+    int prio_least = 0, prio_greatest = 0;
+#ifndef DAV1D_HIP_EMU
+    if (pair_prio) (void) hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+#endif
+    auto make_side = [&](const int i) {
+#ifndef DAV1D_HIP_EMU
+        if (pair_prio && i >= c->recon_pair_first && i < c->recon_pair_first + 3)
+            return hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking, pair_prio > 0 ? prio_greatest : prio_least);
+#endif
+        return hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking);
+    };
+    (void) prio_least; (void) prio_greatest;
     for (int i = 0; i < Dav1dHipContext::N_SIDE; i++) {
-        if (hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) != hipSuccess ||
+        if (make_side(i) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
         if (i < 3 && hipEventCreateWithFlags(&c->ev_pair[i], hipEventDisableTiming) != hipSuccess) { delete c; return -ENODEV; }
     }
