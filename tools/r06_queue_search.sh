@@ -8,4 +8,11 @@ for ps in 2 1 3; do
     run "ps $ps pad $p" DAV1D_HIP_RECON_PAIR_STREAMS=$ps DAV1D_HIP_STREAM_PAD=$p
   done
 done 2>&1 | tee gpurun_out/r06g/queue_search.txt
+for prio in 1 -1; do
+  for ps in 2 3; do
+    for p in 0 1 2 "0,2"; do
+      run "prio $prio ps $ps pad $p" DAV1D_HIP_PAIR_PRIORITY=$prio DAV1D_HIP_RECON_PAIR_STREAMS=$ps DAV1D_HIP_STREAM_PAD=$p
+    done
+  done
+done 2>&1 | tee -a gpurun_out/r06g/queue_search.txt
 sort -k6 -n gpurun_out/r06g/queue_search.txt | head -12
